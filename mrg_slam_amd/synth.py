@@ -1,0 +1,247 @@
+"""Deterministic synthetic LiDAR scans (measurement inputs).
+
+No KITTI data exists in this container or on the GPU box, so bench.py and the tests ray-cast a procedural
+street scene instead.  The on-the-wire layout follows the reference's KITTI player
+(/root/reference/python_scripts/kitti_singlerobot_processor.py:164-185): N x 4 float32 (x, y, z, intensity),
+16-byte point step.  If ``KITTI_ROOT`` is set, :func:`load_kitti_scan` reads
+``sequences/00/velodyne/%06d.bin`` in that same format instead (optional, never required).
+
+This module is input plumbing only: nothing in the registration / filter path imports it.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+BASE_SEED = 20251003  # seeds are BASE_SEED + scan_index
+
+
+# --------------------------------------------------------------------------------------------------------
+# poses
+# --------------------------------------------------------------------------------------------------------
+def rot_z(a: float) -> np.ndarray:
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float64)
+
+
+def rot_xyz(rx: float, ry: float, rz: float) -> np.ndarray:
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rx @ Ry @ Rz
+
+
+def make_pose(t, R) -> np.ndarray:
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    return T
+
+
+def arc_trajectory(n: int, step: float = 1.0, yaw_rate_deg: float = 1.5) -> list[np.ndarray]:
+    """Sensor poses along a gentle arc: ``step`` metres forward and ``yaw_rate_deg`` of yaw per scan."""
+    poses = []
+    T = np.eye(4)
+    d = make_pose([step, 0, 0], rot_z(np.deg2rad(yaw_rate_deg)))
+    for _ in range(n):
+        poses.append(T.copy())
+        T = T @ d
+    return poses
+
+
+def loop_trajectory(n: int, radius: float = 40.0) -> list[np.ndarray]:
+    """``n`` keyframe poses on a circle of ``radius`` metres, heading tangentially."""
+    poses = []
+    for k in range(n):
+        a = 2 * np.pi * k / n
+        poses.append(make_pose([radius * np.cos(a), radius * np.sin(a), 0.0], rot_z(a + np.pi / 2)))
+    return poses
+
+
+def perturb_pose(T: np.ndarray, rng: np.random.Generator, sigma_t=(0.1, 0.1, 0.05), sigma_r_deg=(0.5, 0.5, 1.0)) -> np.ndarray:
+    """T * exp(xi), xi ~ N(0, diag(sigma)) (warm initial guesses: seed 777 + k)."""
+    dt = rng.normal(0, sigma_t)
+    dr = np.deg2rad(rng.normal(0, sigma_r_deg))
+    return T @ make_pose(dt, rot_xyz(*dr))
+
+
+# --------------------------------------------------------------------------------------------------------
+# scene
+# --------------------------------------------------------------------------------------------------------
+@dataclass
+class Scene:
+    ground_z: float = -1.73
+    boxes: np.ndarray = field(default_factory=lambda: np.zeros((0, 6)))      # xmin,ymin,zmin,xmax,ymax,zmax
+    cylinders: np.ndarray = field(default_factory=lambda: np.zeros((0, 5)))  # cx,cy,r,zmin,zmax
+
+
+def street_scene(seed: int = 1234, x_range=(-120.0, 420.0)) -> Scene:
+    """Ground plane, two rows of buildings (y = +-8..+-20 m, 6-15 m tall, random gaps and setbacks), poles, parked
+    cars, and street furniture (fences / kiosks across the sidewalks) so that motion along the street is observable."""
+    rng = np.random.default_rng(seed)
+    g = -1.73
+    boxes = []
+    for side in (+1, -1):
+        x = x_range[0]
+        while x < x_range[1]:
+            w = rng.uniform(6, 18)
+            gap = rng.uniform(0, 3) if rng.uniform() < 0.5 else rng.uniform(4, 12)
+            y0 = rng.uniform(8, 13)
+            depth = rng.uniform(6, 10)
+            h = rng.uniform(6, 15)
+            ya, yb = sorted((side * y0, side * min(y0 + depth, 22.0)))
+            boxes.append([x, ya, g, x + w, yb, g + h])
+            if rng.uniform() < 0.5:  # porch / bay in front of the facade
+                pw, pd = rng.uniform(1.5, 4.0), rng.uniform(0.8, 2.0)
+                px = rng.uniform(x, x + w - pw)
+                pa, pb = sorted((side * (y0 - pd), side * y0))
+                boxes.append([px, pa, g, px + pw, pb, g + rng.uniform(2.5, 5.0)])
+            x += w + gap
+    length = x_range[1] - x_range[0]
+    cyl = []
+    for _ in range(max(30, int(30 * length / 100.0))):  # poles and tree trunks
+        cx = rng.uniform(*x_range)
+        cy = rng.choice([-1, 1]) * rng.uniform(4.5, 7.8)
+        cyl.append([cx, cy, rng.uniform(0.15, 0.4), g, g + rng.uniform(4, 9)])
+    for _ in range(max(10, int(10 * length / 40.0))):  # parked cars
+        cx = rng.uniform(*x_range)
+        cy = rng.choice([-1, 1]) * rng.uniform(2.8, 4.2)
+        boxes.append([cx - 2.2, cy - 0.9, g, cx + 2.2, cy + 0.9, g + 1.5])
+    for _ in range(int(length / 12.0)):  # fences / kiosks across the sidewalk (faces normal to x)
+        cx = rng.uniform(*x_range)
+        side = rng.choice([-1, 1])
+        ya, yb = sorted((side * rng.uniform(5.0, 6.5), side * rng.uniform(7.0, 8.0)))
+        boxes.append([cx, ya, g, cx + rng.uniform(0.2, 1.5), yb, g + rng.uniform(1.0, 2.6)])
+    return Scene(g, np.asarray(boxes, dtype=np.float64), np.asarray(cyl, dtype=np.float64))
+
+
+def loop_scene(seed: int = 4321, radius: float = 40.0) -> Scene:
+    """Ring road of ``radius`` m: buildings on both sides of the ring, poles and cars along it."""
+    rng = np.random.default_rng(seed)
+    g = -1.73
+    boxes, cyl = [], []
+    for ring_r, n in ((radius - 16.0, 22), (radius + 16.0, 40)):
+        for k in range(n):
+            if rng.uniform() < 0.15:
+                continue
+            a = 2 * np.pi * (k + rng.uniform(-0.2, 0.2)) / n
+            cx, cy = ring_r * np.cos(a), ring_r * np.sin(a)
+            w, d, h = rng.uniform(5, 9), rng.uniform(5, 9), rng.uniform(6, 15)
+            boxes.append([cx - w / 2, cy - d / 2, g, cx + w / 2, cy + d / 2, g + h])
+    for _ in range(40):
+        a = rng.uniform(0, 2 * np.pi)
+        r = radius + rng.choice([-1, 1]) * rng.uniform(4.5, 7.0)
+        cyl.append([r * np.cos(a), r * np.sin(a), rng.uniform(0.15, 0.4), g, g + rng.uniform(4, 9)])
+    for _ in range(14):
+        a = rng.uniform(0, 2 * np.pi)
+        r = radius + rng.choice([-1, 1]) * rng.uniform(2.8, 3.8)
+        cx, cy = r * np.cos(a), r * np.sin(a)
+        boxes.append([cx - 1.6, cy - 1.6, g, cx + 1.6, cy + 1.6, g + 1.5])
+    return Scene(g, np.asarray(boxes, dtype=np.float64), np.asarray(cyl, dtype=np.float64))
+
+
+# --------------------------------------------------------------------------------------------------------
+# sensor models
+# --------------------------------------------------------------------------------------------------------
+def lidar_directions(model: str, azimuth_steps: int | None = None) -> np.ndarray:
+    """Unit ray directions in the sensor frame, beam-major."""
+    if model == "VLP64":
+        elev = np.deg2rad(np.linspace(2.0, -24.8, 64))
+        n_az = azimuth_steps or 2083
+    elif model == "VLP16":
+        elev = np.deg2rad(np.linspace(15.0, -15.0, 16))
+        n_az = azimuth_steps or 1800
+    else:
+        raise ValueError(f"unknown lidar model {model!r}")
+    az = np.linspace(0.0, 2 * np.pi, n_az, endpoint=False)
+    ce, se = np.cos(elev)[:, None], np.sin(elev)[:, None]
+    d = np.stack([ce * np.cos(az)[None, :], ce * np.sin(az)[None, :], np.broadcast_to(se, (elev.size, n_az))], axis=-1)
+    return d.reshape(-1, 3)
+
+
+def raycast(scene: Scene, origin: np.ndarray, dirs: np.ndarray, max_range: float) -> np.ndarray:
+    """Distance along each ray to the first hit (inf when nothing is hit within ``max_range``)."""
+    t_best = np.full(dirs.shape[0], np.inf)
+    # cull objects that cannot be hit within max_range (keeps a 540 m street cheap to ray-cast)
+    ox, oy = origin[0], origin[1]
+    if len(scene.boxes):
+        bx = np.clip(ox, scene.boxes[:, 0], scene.boxes[:, 3]) - ox
+        by = np.clip(oy, scene.boxes[:, 1], scene.boxes[:, 4]) - oy
+        boxes = scene.boxes[bx * bx + by * by <= max_range * max_range]
+    else:
+        boxes = scene.boxes
+    if len(scene.cylinders):
+        cd = np.hypot(scene.cylinders[:, 0] - ox, scene.cylinders[:, 1] - oy) - scene.cylinders[:, 2]
+        cylinders = scene.cylinders[cd <= max_range]
+    else:
+        cylinders = scene.cylinders
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / dirs
+        tg = (scene.ground_z - origin[2]) * inv[:, 2]
+        t_best = np.where((dirs[:, 2] < 0) & (tg > 0), tg, t_best)
+        for b in boxes:
+            t0 = (b[:3] - origin) * inv
+            t1 = (b[3:] - origin) * inv
+            tn = np.nanmax(np.minimum(t0, t1), axis=1)
+            tf = np.nanmin(np.maximum(t0, t1), axis=1)
+            hit = (tf >= tn) & (tf > 0) & (tn > 0)
+            t_best = np.where(hit & (tn < t_best), tn, t_best)
+        for c in cylinders:
+            ox, oy = origin[0] - c[0], origin[1] - c[1]
+            a = dirs[:, 0] ** 2 + dirs[:, 1] ** 2
+            bq = 2 * (ox * dirs[:, 0] + oy * dirs[:, 1])
+            cq = ox * ox + oy * oy - c[2] ** 2
+            disc = bq * bq - 4 * a * cq
+            ok = (disc > 0) & (a > 1e-12)
+            t = (-bq - np.sqrt(np.where(ok, disc, 0.0))) / (2 * np.where(ok, a, 1.0))
+            z = origin[2] + t * dirs[:, 2]
+            hit = ok & (t > 0) & (z >= c[3]) & (z <= c[4])
+            t_best = np.where(hit & (t < t_best), t, t_best)
+    t_best[t_best > max_range] = np.inf
+    return t_best
+
+
+def synth_lidar(scene: Scene, pose: np.ndarray, model: str = "VLP64", seed: int = BASE_SEED, azimuth_steps: int | None = None,
+                max_range: float = 80.0, range_sigma: float = 0.02) -> np.ndarray:
+    """One scan in the SENSOR frame: N x 4 float32 (x, y, z, intensity)."""
+    rng = np.random.default_rng(seed)
+    d_s = lidar_directions(model, azimuth_steps)
+    d_w = d_s @ pose[:3, :3].T
+    t = raycast(scene, pose[:3, 3], d_w, max_range)
+    noise = rng.normal(0.0, range_sigma, size=t.shape)
+    inten = rng.uniform(0.0, 1.0, size=t.shape)
+    ok = np.isfinite(t)
+    r = (t + noise)[ok]
+    pts = d_s[ok] * r[:, None]
+    out = np.empty((pts.shape[0], 4), dtype=np.float32)
+    out[:, :3] = pts.astype(np.float32)
+    out[:, 3] = inten[ok].astype(np.float32)
+    return out
+
+
+def load_kitti_scan(index: int, root: str | None = None) -> np.ndarray:
+    root = root or os.environ["KITTI_ROOT"]
+    path = os.path.join(root, "sequences", "00", "velodyne", f"{index:06d}.bin")
+    return np.fromfile(path, dtype=np.float32).reshape(-1, 4)
+
+
+def scan_pair(k: int, model: str = "VLP64", scene: Scene | None = None, azimuth_steps: int | None = None):
+    """Pair k of the odometry workload: target at pose T_k, source at T_{k+1} (1.0 m / 1.5 deg apart).
+
+    Returns (target, source, true_relative) with ``true_relative`` mapping source-frame points into the target frame
+    (what align() should recover), all in sensor frames.
+    """
+    scene = scene or street_scene()
+    poses = arc_trajectory(k + 2)
+    tgt = synth_lidar(scene, poses[k], model, BASE_SEED + k, azimuth_steps)
+    src = synth_lidar(scene, poses[k + 1], model, BASE_SEED + k + 1, azimuth_steps)
+    rel = np.linalg.inv(poses[k]) @ poses[k + 1]
+    return tgt, src, rel
+
+
+def warm_guess(true_rel: np.ndarray, k: int) -> np.ndarray:
+    """true * exp(xi), xi ~ N(0, diag(0.1 m, 0.1 m, 0.05 m, 0.5 deg, 0.5 deg, 1 deg)), seed 777 + k."""
+    return perturb_pose(true_rel, np.random.default_rng(777 + k))

@@ -1,0 +1,609 @@
+// oracle/ndt.cpp — TEST INFRASTRUCTURE (CPU oracle). Not part of the shipped product path.
+//
+// Restates (PARITY UNPINNED, see quirks.h / SURVEY.md Appendix A.2-A.5):
+//   pclomp::VoxelGridCovariance<PointXYZI>::applyFilter, getNeighborhoodAtPoint{,7,1}, radiusSearch
+//   pclomp::NormalDistributionsTransform::{computeTransformation, computeDerivatives, computeAngleDerivatives,
+//     computePointDerivatives (float 4x6 / 24x6 form and double 3x6 / 18x6 form), updateDerivatives,
+//     computeHessian, updateHessian, computeStepLengthMT, trialValueSelectionMT, updateIntervalMT}
+//   pcl::Registration::align / getFitnessScore
+// behind the reference seam /root/reference/include/mrg_slam/registrations.hpp:20 (NDT_OMP branch
+// src/mrg_slam/registrations.cpp:130-148).
+#include "ndt.h"
+
+#include <omp.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "linalg.h"
+#include "nn.h"
+#include "quirks.h"
+
+namespace orc {
+
+// ------------------------------------------------------------------------------------------------------
+// VoxelGridCovariance
+// ------------------------------------------------------------------------------------------------------
+int VoxelGridCovariance::build(const float* xyzi, int n, float leaf)
+{
+    leaves.clear(); index.clear(); n_valid = 0;
+    leaf_size = leaf;
+    inv_leaf  = 1.0f / leaf;
+    // pcl::getMinMax3D over finite points
+    float min_p[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+    float max_p[3] = {-min_p[0], -min_p[1], -min_p[2]};
+    int   finite   = 0;
+    for (int i = 0; i < n; ++i) {
+        const float* p = xyzi + 4 * i;
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+        ++finite;
+        for (int a = 0; a < 3; ++a) { min_p[a] = std::min(min_p[a], p[a]); max_p[a] = std::max(max_p[a], p[a]); }
+    }
+    if (finite == 0) return -2;
+    int64_t dx = static_cast<int64_t>((max_p[0] - min_p[0]) * inv_leaf) + 1;
+    int64_t dy = static_cast<int64_t>((max_p[1] - min_p[1]) * inv_leaf) + 1;
+    int64_t dz = static_cast<int64_t>((max_p[2] - min_p[2]) * inv_leaf) + 1;
+    if (dx * dy * dz > static_cast<int64_t>(std::numeric_limits<int32_t>::max())) return -1;
+    for (int a = 0; a < 3; ++a) {
+        min_b[a] = static_cast<int>(std::floor(min_p[a] * inv_leaf));
+        max_b[a] = static_cast<int>(std::floor(max_p[a] * inv_leaf));
+        div_b[a] = max_b[a] - min_b[a] + 1;
+    }
+    divb_mul[0] = 1; divb_mul[1] = div_b[0]; divb_mul[2] = div_b[0] * div_b[1];
+
+    // first pass: accumulate in point order
+    struct Acc { int n; double mean[3]; double cov[9]; float centroid[4]; };
+    std::vector<Acc>             acc;
+    std::vector<int>             keys;
+    std::unordered_map<int, int> pos;
+    pos.reserve(static_cast<size_t>(n) / 4 + 16);
+    for (int i = 0; i < n; ++i) {
+        const float* p = xyzi + 4 * i;
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+        int ijk0 = static_cast<int>(std::floor(p[0] * inv_leaf) - static_cast<float>(min_b[0]));
+        int ijk1 = static_cast<int>(std::floor(p[1] * inv_leaf) - static_cast<float>(min_b[1]));
+        int ijk2 = static_cast<int>(std::floor(p[2] * inv_leaf) - static_cast<float>(min_b[2]));
+        int key  = ijk0 * divb_mul[0] + ijk1 * divb_mul[1] + ijk2 * divb_mul[2];
+        auto it  = pos.find(key);
+        int  li;
+        if (it == pos.end()) {
+            li = static_cast<int>(acc.size());
+            pos.emplace(key, li);
+            keys.push_back(key);
+            Acc a; std::memset(&a, 0, sizeof(a));
+            acc.push_back(a);
+        } else {
+            li = it->second;
+        }
+        Acc& a = acc[li];
+        double pt[3] = {p[0], p[1], p[2]};
+        for (int r = 0; r < 3; ++r) a.mean[r] += pt[r];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) a.cov[r * 3 + c] += pt[r] * pt[c];
+        for (int r = 0; r < 4; ++r) a.centroid[r] += p[r];
+        ++a.n;
+    }
+    // second pass in ascending key order (std::map iteration)
+    std::vector<int> ord(keys.size());
+    for (size_t i = 0; i < ord.size(); ++i) ord[i] = static_cast<int>(i);
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return keys[a] < keys[b]; });
+    leaves.resize(keys.size());
+    for (size_t o = 0; o < ord.size(); ++o) {
+        const Acc& a = acc[ord[o]];
+        NdtLeaf&   L = leaves[o];
+        std::memset(&L, 0, sizeof(L));
+        L.key = keys[ord[o]];
+        L.nr_points = a.n;
+        index.emplace(L.key, static_cast<int>(o));
+        for (int r = 0; r < 4; ++r) L.centroid[r] = a.centroid[r] / static_cast<float>(a.n);
+        double pt_sum[3] = {a.mean[0], a.mean[1], a.mean[2]};
+        for (int r = 0; r < 3; ++r) L.mean[r] = a.mean[r] / a.n;
+        if (a.n < quirks::kNdtMinPointsPerVoxel) continue;
+        // single pass covariance, then PCL's (n-1)/n normalisation
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) L.cov[r * 3 + c] = (a.cov[r * 3 + c] - 2 * (pt_sum[r] * L.mean[c])) / a.n + L.mean[r] * L.mean[c];
+        double f = (a.n - 1.0) / a.n;
+        for (int k = 0; k < 9; ++k) L.cov[k] *= f;
+        double ev[3], evec[9];
+        sym_eig3(L.cov, ev, evec);
+        if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) { L.nr_points = -1; continue; }
+        double min_ev = quirks::kNdtMinCovarEigvalMult * ev[2];
+        if (ev[0] < min_ev) {
+            ev[0] = min_ev;
+            if (ev[1] < min_ev) ev[1] = min_ev;
+            double D[9] = {ev[0], 0, 0, 0, ev[1], 0, 0, 0, ev[2]};
+            double ED[9], Einv[9];
+            mul3(evec, D, ED);
+            inv3(evec, Einv);
+            mul3(ED, Einv, L.cov);
+        }
+        inv3(L.cov, L.icov);
+        double mx = L.icov[0], mn = L.icov[0];
+        for (int k = 1; k < 9; ++k) { mx = std::max(mx, L.icov[k]); mn = std::min(mn, L.icov[k]); }
+        if (mx == std::numeric_limits<double>::infinity() || mn == -std::numeric_limits<double>::infinity() || mx != mx || mn != mn) {
+            L.nr_points = -1;
+            continue;
+        }
+        ++n_valid;
+    }
+    return 0;
+}
+
+int VoxelGridCovariance::neighbours(float x, float y, float z, NdtSearch method, int out[27]) const
+{
+    // getNeighborhoodAtPoint: floor(p / leaf_size) (division, unlike the build's multiply by inverse)
+    int ijk[3] = {static_cast<int>(std::floor(x / leaf_size)), static_cast<int>(std::floor(y / leaf_size)), static_cast<int>(std::floor(z / leaf_size))};
+    static const int d7[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+    int cnt = 0;
+    auto probe = [&](int ox, int oy, int oz) -> int {
+        int c[3] = {ijk[0] + ox, ijk[1] + oy, ijk[2] + oz};
+        for (int a = 0; a < 3; ++a) if (c[a] < min_b[a] || c[a] > max_b[a]) return -1;
+        int key = (c[0] - min_b[0]) * divb_mul[0] + (c[1] - min_b[1]) * divb_mul[1] + (c[2] - min_b[2]) * divb_mul[2];
+        auto it = index.find(key);
+        if (it == index.end()) return -1;
+        if (leaves[it->second].nr_points < quirks::kNdtMinPointsPerVoxel) return -1;
+        return it->second;
+    };
+    if (method == NDT_DIRECT7 || method == NDT_DIRECT1) {
+        int m = method == NDT_DIRECT7 ? 7 : 1;
+        for (int k = 0; k < m; ++k) { int l = probe(d7[k][0], d7[k][1], d7[k][2]); if (l >= 0) out[cnt++] = l; }
+        return cnt;
+    }
+    if (method == NDT_DIRECT26) {
+        // pcl::getAllNeighborCellIndices(): 27 offsets, x fastest? -> order only affects f64 summation order
+        for (int ox = -1; ox <= 1; ++ox) for (int oy = -1; oy <= 1; ++oy) for (int oz = -1; oz <= 1; ++oz) {
+            int l = probe(ox, oy, oz); if (l >= 0) out[cnt++] = l;
+        }
+        return cnt;
+    }
+    // KDTREE: radiusSearch(point, resolution) over the centroids of valid leaves (sorted by distance).
+    // A centroid within one leaf size of the point lies in one of the 27 surrounding cells.
+    std::pair<float, int> found[27];
+    int ijk_m[3] = {static_cast<int>(std::floor(x * inv_leaf)), static_cast<int>(std::floor(y * inv_leaf)), static_cast<int>(std::floor(z * inv_leaf))};
+    (void)ijk_m;
+    float r2 = leaf_size * leaf_size;
+    for (int ox = -1; ox <= 1; ++ox) for (int oy = -1; oy <= 1; ++oy) for (int oz = -1; oz <= 1; ++oz) {
+        int l = probe(ox, oy, oz);
+        if (l < 0) continue;
+        const float* c = leaves[l].centroid;
+        float d = sqdist_f(c[0], c[1], c[2], x, y, z);
+        if (d < r2) found[cnt++] = std::make_pair(d, l);  // FLANN RadiusResultSet: dist < radius^2
+    }
+    std::sort(found, found + cnt);
+    for (int k = 0; k < cnt; ++k) out[k] = found[k].second;
+    return cnt;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// NDT
+// ------------------------------------------------------------------------------------------------------
+void Ndt::init_gauss()
+{
+    double gauss_c1 = 10 * (1 - outlier_ratio);
+    double gauss_c2 = outlier_ratio / std::pow(static_cast<double>(resolution), 3);
+    gauss_d3 = -std::log(gauss_c2);
+    gauss_d1 = -std::log(gauss_c1 + gauss_c2) - gauss_d3;
+    gauss_d2 = -2 * std::log((-std::log(gauss_c1 * std::exp(-0.5) + gauss_c2) - gauss_d3) / gauss_d1);
+}
+
+int Ndt::set_target(const float* xyzi, int n)
+{
+    target.assign(xyzi, xyzi + static_cast<size_t>(n) * 4);
+    target_status = cells.build(target.data(), n, resolution);
+    return target_status;
+}
+
+void Ndt::set_source(const float* xyzi, int n) { source.assign(xyzi, xyzi + static_cast<size_t>(n) * 4); }
+
+void Ndt::angle_derivatives(const double p[6], bool compute_hessian)
+{
+    double cx, cy, cz, sx, sy, sz;
+    if (std::fabs(p[3]) < quirks::kNdtSmallAngle) { cx = 1.0; sx = 0.0; } else { cx = std::cos(p[3]); sx = std::sin(p[3]); }
+    if (std::fabs(p[4]) < quirks::kNdtSmallAngle) { cy = 1.0; sy = 0.0; } else { cy = std::cos(p[4]); sy = std::sin(p[4]); }
+    if (std::fabs(p[5]) < quirks::kNdtSmallAngle) { cz = 1.0; sz = 0.0; } else { cz = std::cos(p[5]); sz = std::sin(p[5]); }
+    double j[8][3] = {
+        {(-sx * sz + cx * sy * cz), (-sx * cz - cx * sy * sz), (-cx * cy)},  // a
+        {(cx * sz + sx * sy * cz), (cx * cz - sx * sy * sz), (-sx * cy)},    // b
+        {(-sy * cz), sy * sz, cy},                                           // c
+        {sx * cy * cz, (-sx * cy * sz), sx * sy},                            // d
+        {(-cx * cy * cz), cx * cy * sz, (-cx * sy)},                         // e
+        {(-cy * sz), (-cy * cz), 0},                                         // f
+        {(cx * cz - sx * sy * sz), (-cx * sz - sx * sy * cz), 0},            // g
+        {(sx * cz + cx * sy * sz), (cx * sy * cz - sx * sz), 0}};            // h
+    for (int r = 0; r < 8; ++r) for (int c = 0; c < 3; ++c) { j_ang_d[r][c] = j[r][c]; j_ang_f[r][c] = static_cast<float>(j[r][c]); }
+    if (!compute_hessian) return;
+    double h[15][3] = {
+        {(-cx * sz - sx * sy * cz), (-cx * cz + sx * sy * sz), sx * cy},     // a2
+        {(-sx * sz + cx * sy * cz), (-cx * sy * sz - sx * cz), (-cx * cy)},  // a3
+        {(cx * cy * cz), (-cx * cy * sz), (cx * sy)},                        // b2
+        {(sx * cy * cz), (-sx * cy * sz), (sx * sy)},                        // b3
+        {(-sx * cz - cx * sy * sz), (sx * sz - cx * sy * cz), 0},            // c2
+        {(cx * cz - sx * sy * sz), (-sx * sy * cz - cx * sz), 0},            // c3
+        {(-cy * cz), (cy * sz), (sy)},                                       // d1
+        {(-sx * sy * cz), (sx * sy * sz), (sx * cy)},                        // d2
+        {(cx * sy * cz), (-cx * sy * sz), (-cx * cy)},                       // d3
+        {(sy * sz), (sy * cz), 0},                                           // e1
+        {(-sx * cy * sz), (-sx * cy * cz), 0},                               // e2
+        {(cx * cy * sz), (cx * cy * cz), 0},                                 // e3
+        {(-cy * cz), (cy * sz), 0},                                          // f1
+        {(-cx * sz - sx * sy * cz), (-cx * cz + sx * sy * sz), 0},           // f2
+        {(-sx * sz + cx * sy * cz), (-cx * sy * sz - sx * cz), 0}};          // f3
+    for (int r = 0; r < 15; ++r) for (int c = 0; c < 3; ++c) { h_ang_d[r][c] = h[r][c]; h_ang_f[r][c] = static_cast<float>(h[r][c]); }
+}
+
+void Ndt::transform_cloud(const float T[16])
+{
+    int n = static_cast<int>(source.size() / 4);
+    trans_.resize(static_cast<size_t>(n) * 3);
+    for (int i = 0; i < n; ++i) {
+        const float* p = &source[4 * static_cast<size_t>(i)];
+        transform_point_f(T, p[0], p[1], p[2], trans_[3 * i], trans_[3 * i + 1], trans_[3 * i + 2]);
+    }
+}
+
+static inline float dot3f(float a0, float b0, float a1, float b1, float a2, float b2)
+{
+    float p0 = a0 * b0, p1 = a1 * b1, p2 = a2 * b2;
+    float s = p0 + p1;
+    return s + p2;
+}
+
+double Ndt::compute_derivatives(double grad[6], double hess[36], const double p[6], bool compute_hessian)
+{
+    const int n = static_cast<int>(source.size() / 4);
+    scores_.assign(n, 0.0);
+    grads_.assign(static_cast<size_t>(n) * 6, 0.0);
+    hessians_.assign(static_cast<size_t>(n) * 36, 0.0);
+    angle_derivatives(p, true);
+    ++n_evals;
+    const float  gauss_d2f = static_cast<float>(gauss_d2);
+    const double gd1       = gauss_d1;
+    long long    nb_total  = 0;
+
+#pragma omp parallel for num_threads(num_threads) schedule(guided, 8) reduction(+ : nb_total)
+    for (int idx = 0; idx < n; ++idx) {
+        const float xt[3] = {trans_[3 * idx], trans_[3 * idx + 1], trans_[3 * idx + 2]};
+        int nb[27];
+        int cnt = cells.neighbours(xt[0], xt[1], xt[2], search, nb);
+        if (cnt == 0) continue;
+        nb_total += cnt;
+        const float* xp = &source[4 * static_cast<size_t>(idx)];
+        // Vector3d x(x_pt.x, ..) -> Vector4f x4: float -> double -> float is the identity
+        const float x4[3] = {xp[0], xp[1], xp[2]};
+        // computePointDerivatives (float form): x_j_ang = j_ang * x4 ; x_h_ang = h_ang * x4
+        float xj[8], xh[15];
+        for (int r = 0; r < 8; ++r) xj[r] = dot3f(j_ang_f[r][0], x4[0], j_ang_f[r][1], x4[1], j_ang_f[r][2], x4[2]);
+        for (int r = 0; r < 15; ++r) xh[r] = dot3f(h_ang_f[r][0], x4[0], h_ang_f[r][1], x4[1], h_ang_f[r][2], x4[2]);
+        // point_gradient4 columns 3..5 (rows 0..2); columns 0..2 = identity
+        const float J3[3] = {0.0f, xj[0], xj[1]};
+        const float J4[3] = {xj[2], xj[3], xj[4]};
+        const float J5[3] = {xj[5], xj[6], xj[7]};
+        // point_hessian blocks (3-vectors): a,b,c,d,e,f
+        const float ha[3] = {0.0f, xh[0], xh[1]}, hb[3] = {0.0f, xh[2], xh[3]}, hc[3] = {0.0f, xh[4], xh[5]};
+        const float hd[3] = {xh[6], xh[7], xh[8]}, he[3] = {xh[9], xh[10], xh[11]}, hf[3] = {xh[12], xh[13], xh[14]};
+        // PH[i][j] for i,j in 3..5 : block (i*4, j)
+        const float* PH[3][3] = {{ha, hb, hc}, {hb, hd, he}, {hc, he, hf}};
+
+        double  score_pt = 0;
+        double* g_pt = &grads_[static_cast<size_t>(idx) * 6];
+        double* h_pt = &hessians_[static_cast<size_t>(idx) * 36];
+        for (int k = 0; k < cnt; ++k) {
+            const NdtLeaf& cell = cells.leaves[nb[k]];
+            // x_trans (double) -= mean ; cast to float
+            const float q[3] = {static_cast<float>(static_cast<double>(xt[0]) - cell.mean[0]), static_cast<float>(static_cast<double>(xt[1]) - cell.mean[1]),
+                                static_cast<float>(static_cast<double>(xt[2]) - cell.mean[2])};
+            float C[9];
+            for (int t = 0; t < 9; ++t) C[t] = static_cast<float>(cell.icov[t]);
+            // qC = x_trans4 * c_inv4 (row vector times matrix)
+            float qC[3];
+            for (int c = 0; c < 3; ++c) qC[c] = dot3f(q[0], C[0 * 3 + c], q[1], C[1 * 3 + c], q[2], C[2 * 3 + c]);
+            float qCq = dot3f(q[0], qC[0], q[1], qC[1], q[2], qC[2]);
+            float arg0 = -gauss_d2f * qCq;
+            float arg = arg0 * 0.5f;
+            float e_x_cov_x = static_cast<float>(std::exp(static_cast<double>(arg)));
+            float score_inc = static_cast<float>(-gd1 * static_cast<double>(e_x_cov_x));
+            e_x_cov_x = gauss_d2f * e_x_cov_x;
+            if (e_x_cov_x > 1 || e_x_cov_x < 0 || e_x_cov_x != e_x_cov_x) continue;
+            e_x_cov_x = static_cast<float>(static_cast<double>(e_x_cov_x) * gd1);
+            // CJ = c_inv4 * point_gradient4 : columns 0..2 = C, columns 3..5 = C * J3/J4/J5
+            float CJ[3][6];
+            for (int r = 0; r < 3; ++r) {
+                CJ[r][0] = C[r * 3 + 0]; CJ[r][1] = C[r * 3 + 1]; CJ[r][2] = C[r * 3 + 2];
+                CJ[r][3] = dot3f(C[r * 3 + 0], J3[0], C[r * 3 + 1], J3[1], C[r * 3 + 2], J3[2]);
+                CJ[r][4] = dot3f(C[r * 3 + 0], J4[0], C[r * 3 + 1], J4[1], C[r * 3 + 2], J4[2]);
+                CJ[r][5] = dot3f(C[r * 3 + 0], J5[0], C[r * 3 + 1], J5[1], C[r * 3 + 2], J5[2]);
+            }
+            float qCJ[6];
+            for (int c = 0; c < 6; ++c) qCJ[c] = dot3f(q[0], CJ[0][c], q[1], CJ[1][c], q[2], CJ[2][c]);
+            for (int c = 0; c < 6; ++c) { float t = e_x_cov_x * qCJ[c]; g_pt[c] += static_cast<double>(t); }
+            score_pt += static_cast<double>(score_inc);
+            if (!compute_hessian) continue;
+            // JtCJ(a,b) = J(:,a) . CJ(:,b)
+            const float* Jc[6] = {nullptr, nullptr, nullptr, J3, J4, J5};
+            float JtCJ[6][6];
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b)
+                    JtCJ[a][b] = (a < 3) ? CJ[a][b] : dot3f(Jc[a][0], CJ[0][b], Jc[a][1], CJ[1][b], Jc[a][2], CJ[2][b]);
+            for (int i = 0; i < 6; ++i) {
+                float qCH[6] = {0, 0, 0, 0, 0, 0};
+                if (i >= 3)
+                    for (int j = 3; j < 6; ++j) { const float* v = PH[i - 3][j - 3]; qCH[j] = dot3f(qC[0], v[0], qC[1], v[1], qC[2], v[2]); }
+                for (int j = 0; j < 6; ++j) {
+                    float t0 = -gauss_d2f * qCJ[i];
+                    float t1 = t0 * qCJ[j];
+                    float t2 = t1 + qCH[j];
+                    float t3 = t2 + JtCJ[j][i];
+                    float t4 = e_x_cov_x * t3;
+                    h_pt[i * 6 + j] += static_cast<double>(t4);
+                }
+            }
+        }
+        scores_[idx] = score_pt;
+    }
+    neighbours_sum += n > 0 ? static_cast<double>(nb_total) / n : 0.0;
+    // "Ensure that the result is invariant against the summing up order": sequential sum in index order
+    double score = 0;
+    for (int k = 0; k < 6; ++k) grad[k] = 0;
+    for (int k = 0; k < 36; ++k) hess[k] = 0;
+    for (int i = 0; i < n; ++i) {
+        score += scores_[i];
+        for (int k = 0; k < 6; ++k) grad[k] += grads_[static_cast<size_t>(i) * 6 + k];
+        for (int k = 0; k < 36; ++k) hess[k] += hessians_[static_cast<size_t>(i) * 36 + k];
+    }
+    return score;
+}
+
+// computeHessian: serial, double precision (PCL's original 3x6 / 18x6 point derivative forms)
+void Ndt::compute_hessian(double hess[36], const double p[6])
+{
+    (void)p;  // angular derivative tables are those of the last computeDerivatives call (same pose)
+    const int n = static_cast<int>(source.size() / 4);
+    for (int k = 0; k < 36; ++k) hess[k] = 0;
+    ++n_evals;
+    for (int idx = 0; idx < n; ++idx) {
+        const float xt[3] = {trans_[3 * idx], trans_[3 * idx + 1], trans_[3 * idx + 2]};
+        int nb[27];
+        int cnt = cells.neighbours(xt[0], xt[1], xt[2], search, nb);
+        if (cnt == 0) continue;
+        const float* xp = &source[4 * static_cast<size_t>(idx)];
+        const double x[3] = {xp[0], xp[1], xp[2]};
+        auto dotd = [&](const double* a) { return x[0] * a[0] + x[1] * a[1] + x[2] * a[2]; };
+        double J[3][6] = {{1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}, {0, 0, 1, 0, 0, 0}};
+        J[1][3] = dotd(j_ang_d[0]); J[2][3] = dotd(j_ang_d[1]);
+        J[0][4] = dotd(j_ang_d[2]); J[1][4] = dotd(j_ang_d[3]); J[2][4] = dotd(j_ang_d[4]);
+        J[0][5] = dotd(j_ang_d[5]); J[1][5] = dotd(j_ang_d[6]); J[2][5] = dotd(j_ang_d[7]);
+        double a[3] = {0, dotd(h_ang_d[0]), dotd(h_ang_d[1])}, b[3] = {0, dotd(h_ang_d[2]), dotd(h_ang_d[3])}, c[3] = {0, dotd(h_ang_d[4]), dotd(h_ang_d[5])};
+        double d[3] = {dotd(h_ang_d[6]), dotd(h_ang_d[7]), dotd(h_ang_d[8])}, e[3] = {dotd(h_ang_d[9]), dotd(h_ang_d[10]), dotd(h_ang_d[11])};
+        double f[3] = {dotd(h_ang_d[12]), dotd(h_ang_d[13]), dotd(h_ang_d[14])};
+        const double  zero3[3] = {0, 0, 0};
+        const double* PH[6][6];
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) PH[i][j] = zero3;
+        PH[3][3] = a; PH[4][3] = b; PH[5][3] = c; PH[3][4] = b; PH[4][4] = d; PH[5][4] = e; PH[3][5] = c; PH[4][5] = e; PH[5][5] = f;
+        for (int k = 0; k < cnt; ++k) {
+            const NdtLeaf& cell = cells.leaves[nb[k]];
+            const double q[3] = {static_cast<double>(xt[0]) - cell.mean[0], static_cast<double>(xt[1]) - cell.mean[1], static_cast<double>(xt[2]) - cell.mean[2]};
+            const double* C = cell.icov;
+            auto Cv = [&](const double* v, double out[3]) { for (int r = 0; r < 3; ++r) out[r] = C[r * 3 + 0] * v[0] + C[r * 3 + 1] * v[1] + C[r * 3 + 2] * v[2]; };
+            auto qdot = [&](const double* v) { return q[0] * v[0] + q[1] * v[1] + q[2] * v[2]; };
+            double Cq[3];
+            Cv(q, Cq);
+            double e_x_cov_x = gauss_d2 * std::exp(-gauss_d2 * qdot(Cq) / 2);
+            if (e_x_cov_x > 1 || e_x_cov_x < 0 || e_x_cov_x != e_x_cov_x) continue;
+            e_x_cov_x *= gauss_d1;
+            for (int i = 0; i < 6; ++i) {
+                double Ji[3] = {J[0][i], J[1][i], J[2][i]}, cov_dxd_pi[3];
+                Cv(Ji, cov_dxd_pi);
+                for (int j = 0; j < 6; ++j) {
+                    double Jj[3] = {J[0][j], J[1][j], J[2][j]}, CJj[3], CH[3];
+                    Cv(Jj, CJj);
+                    Cv(PH[i][j], CH);
+                    hess[i * 6 + j] += e_x_cov_x * (-gauss_d2 * qdot(cov_dxd_pi) * qdot(CJj) + qdot(CH) + (Jj[0] * cov_dxd_pi[0] + Jj[1] * cov_dxd_pi[1] + Jj[2] * cov_dxd_pi[2]));
+                }
+            }
+        }
+    }
+}
+
+double Ndt::evaluate(const float T[16], const double p[6], int mode, double grad[6], double hess[36])
+{
+    init_gauss();
+    transform_cloud(T);
+    if (mode == 2) {
+        angle_derivatives(p, true);
+        compute_hessian(hess, p);
+        for (int k = 0; k < 6; ++k) grad[k] = 0;
+        return 0;
+    }
+    return compute_derivatives(grad, hess, p, mode == 0);
+}
+
+// ---- More-Thuente helpers (ndt_omp_impl.hpp) -----------------------------------------------------------
+static inline double psi_mt(double a, double f_a, double f_0, double g_0, double mu) { return f_a - f_0 - mu * g_0 * a; }
+static inline double dpsi_mt(double g_a, double g_0, double mu) { return g_a - mu * g_0; }
+
+static bool update_interval_mt(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t, double g_t)
+{
+    if (f_t > f_l) { a_u = a_t; f_u = f_t; g_u = g_t; return false; }
+    else if (g_t * (a_l - a_t) > 0) { a_l = a_t; f_l = f_t; g_l = g_t; return false; }
+    else if (g_t * (a_l - a_t) < 0) { a_u = a_l; f_u = f_l; g_u = g_l; a_l = a_t; f_l = f_t; g_l = g_t; return false; }
+    return true;
+}
+
+static double trial_value_selection_mt(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t)
+{
+    if (f_t > f_l) {  // case 1
+        double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+        double w = std::sqrt(z * z - g_t * g_l);
+        double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+        double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+        if (std::fabs(a_c - a_l) < std::fabs(a_q - a_l)) return a_c;
+        return 0.5 * (a_q + a_c);
+    } else if (g_t * g_l < 0) {  // case 2
+        double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+        double w = std::sqrt(z * z - g_t * g_l);
+        double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+        double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+        if (std::fabs(a_c - a_t) >= std::fabs(a_s - a_t)) return a_c;
+        return a_s;
+    } else if (std::fabs(g_t) <= std::fabs(g_l)) {  // case 3
+        double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+        double w = std::sqrt(z * z - g_t * g_l);
+        double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+        double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+        double a_t_next = (std::fabs(a_c - a_t) < std::fabs(a_s - a_t)) ? a_c : a_s;
+        if (a_t > a_l) return std::min(a_t + 0.66 * (a_u - a_t), a_t_next);
+        return std::max(a_t + 0.66 * (a_u - a_t), a_t_next);
+    } else {  // case 4
+        double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u;
+        double w = std::sqrt(z * z - g_t * g_u);
+        return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+    }
+}
+
+double Ndt::step_length_mt(const double x[6], double step_dir[6], double step_init, double step_max, double step_min, double& score, double grad[6],
+                           double hess[36])
+{
+    double phi_0 = -score;
+    double d_phi_0 = 0;
+    for (int k = 0; k < 6; ++k) d_phi_0 += grad[k] * step_dir[k];
+    d_phi_0 = -d_phi_0;
+    double x_t[6];
+    if (d_phi_0 >= 0) {
+        if (d_phi_0 == 0) return 0;
+        d_phi_0 *= -1;
+        for (int k = 0; k < 6; ++k) step_dir[k] *= -1;
+    }
+    const int    max_step_iterations = quirks::kMtMaxStepIterations;
+    int          step_iterations = 0;
+    const double mu = quirks::kMtMu, nu = quirks::kMtNu;
+    double a_l = 0, a_u = 0;
+    double f_l = psi_mt(a_l, phi_0, phi_0, d_phi_0, mu);
+    double g_l = dpsi_mt(d_phi_0, d_phi_0, mu);
+    double f_u = psi_mt(a_u, phi_0, phi_0, d_phi_0, mu);
+    double g_u = dpsi_mt(d_phi_0, d_phi_0, mu);
+    bool   interval_converged = (step_max - step_min) < 0, open_interval = true;
+    double a_t = step_init;
+    a_t = std::min(a_t, step_max);
+    a_t = std::max(a_t, step_min);
+    for (int k = 0; k < 6; ++k) x_t[k] = x[k] + step_dir[k] * a_t;
+    pose_to_matrix_f(x_t, final_);
+    transform_cloud(final_);
+    score = compute_derivatives(grad, hess, x_t, true);
+    double phi_t = -score;
+    double d_phi_t = 0;
+    for (int k = 0; k < 6; ++k) d_phi_t += grad[k] * step_dir[k];
+    d_phi_t = -d_phi_t;
+    double psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu);
+    double d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);
+    while (!interval_converged && step_iterations < max_step_iterations && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
+        if (open_interval) a_t = trial_value_selection_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t);
+        else               a_t = trial_value_selection_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
+        a_t = std::min(a_t, step_max);
+        a_t = std::max(a_t, step_min);
+        for (int k = 0; k < 6; ++k) x_t[k] = x[k] + step_dir[k] * a_t;
+        pose_to_matrix_f(x_t, final_);
+        transform_cloud(final_);
+        score = compute_derivatives(grad, hess, x_t, false);
+        phi_t = -score;
+        d_phi_t = 0;
+        for (int k = 0; k < 6; ++k) d_phi_t += grad[k] * step_dir[k];
+        d_phi_t = -d_phi_t;
+        psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu);
+        d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);
+        if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
+            open_interval = false;
+            f_l = f_l + phi_0 - mu * d_phi_0 * a_l;
+            g_l = g_l + mu * d_phi_0;
+            f_u = f_u + phi_0 - mu * d_phi_0 * a_u;
+            g_u = g_u + mu * d_phi_0;
+        }
+        if (open_interval) interval_converged = update_interval_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t);
+        else               interval_converged = update_interval_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
+        step_iterations++;
+    }
+    if (step_iterations) compute_hessian(hess, x_t);
+    return a_t;
+}
+
+void Ndt::align(const float guess[16], float* aligned)
+{
+    const int n = static_cast<int>(source.size() / 4);
+    // pcl::Registration::align
+    converged = false;
+    nr_iterations = 0;
+    n_evals = 0;
+    neighbours_sum = 0;
+    mat4f_identity(final_);
+    float transformation[16], previous[16];
+    mat4f_identity(transformation); mat4f_identity(previous);
+    for (int k = 0; k < 36; ++k) hessian[k] = 0;
+    trans_probability = 0;
+    auto write_output = [&]() {
+        if (!aligned) return;
+        // output == final_transformation_ * input (intensity carried over)
+        for (int i = 0; i < n; ++i) {
+            const float* p = &source[4 * static_cast<size_t>(i)];
+            transform_point_f(final_, p[0], p[1], p[2], aligned[4 * i], aligned[4 * i + 1], aligned[4 * i + 2]);
+            aligned[4 * i + 3] = p[3];
+        }
+    };
+    if (n == 0 || target_status != 0) { write_output(); return; }
+
+    // computeTransformation
+    init_gauss();
+    if (!mat4f_is_identity(guess)) std::memcpy(final_, guess, sizeof(float) * 16);
+    transform_cloud(final_);
+    float eul[3];
+    euler_xyz_f(final_, eul);
+    double p[6] = {final_[3], final_[7], final_[11], eul[0], eul[1], eul[2]};
+    double delta_p[6], grad[6];
+    double score = compute_derivatives(grad, hessian, p, true);
+    while (!converged) {
+        std::memcpy(previous, transformation, sizeof(previous));
+        JacobiSvd6 sv;
+        sv.compute(hessian);
+        double neg_g[6];
+        for (int k = 0; k < 6; ++k) neg_g[k] = -grad[k];
+        sv.solve(neg_g, delta_p);
+        double delta_p_norm = 0;
+        for (int k = 0; k < 6; ++k) delta_p_norm += delta_p[k] * delta_p[k];
+        delta_p_norm = std::sqrt(delta_p_norm);
+        if (delta_p_norm == 0 || delta_p_norm != delta_p_norm) {
+            trans_probability = score / static_cast<double>(n);
+            converged = delta_p_norm == delta_p_norm;
+            write_output();
+            return;
+        }
+        for (int k = 0; k < 6; ++k) delta_p[k] /= delta_p_norm;
+        delta_p_norm = step_length_mt(p, delta_p, delta_p_norm, step_size, trans_eps / 2, score, grad, hessian);
+        for (int k = 0; k < 6; ++k) delta_p[k] *= delta_p_norm;
+        pose_to_matrix_f(delta_p, transformation);
+        for (int k = 0; k < 6; ++k) p[k] = p[k] + delta_p[k];
+        if (nr_iterations > max_iterations || (nr_iterations && (std::fabs(delta_p_norm) < trans_eps))) converged = true;
+        nr_iterations++;
+    }
+    trans_probability = score / static_cast<double>(n);
+    write_output();
+}
+
+double Ndt::fitness(double max_range) const
+{
+    const int n = static_cast<int>(source.size() / 4);
+    const int nt = static_cast<int>(target.size() / 4);
+    if (n == 0 || nt == 0) return std::numeric_limits<double>::max();
+    NnGrid grid;
+    grid.build(target.data(), nt, 1.0f);
+    double sum = 0;
+    int    nr = 0;
+    for (int i = 0; i < n; ++i) {
+        const float* p = &source[4 * static_cast<size_t>(i)];
+        float x, y, z, d;
+        transform_point_f(final_, p[0], p[1], p[2], x, y, z);
+        if (grid.nearest(x, y, z, d) < 0) continue;
+        if (static_cast<double>(d) <= max_range) { sum += d; nr++; }
+    }
+    return nr > 0 ? sum / nr : std::numeric_limits<double>::max();
+}
+
+}  // namespace orc

@@ -1,0 +1,91 @@
+// oracle/ndt.h — TEST INFRASTRUCTURE (CPU oracle). Not part of the shipped product path.
+//
+// CPU restatement of pclomp::VoxelGridCovariance + pclomp::NormalDistributionsTransform (koide3/ndt_omp,
+// un-vendored dependency of the reference: /root/reference/CMakeLists.txt:84, package.xml:18,
+// src/mrg_slam/registrations.cpp:130-148) and of pcl::Registration::align/getFitnessScore as the
+// reference calls them (apps/scan_matching_odometry_component.cpp:203,208,265-276;
+// src/mrg_slam/loop_detector.cpp:104,127,134-144).  PARITY UNPINNED (see quirks.h): follows SURVEY.md
+// Appendix A.2-A.5.
+#pragma once
+#include <cstdint>
+#include <unordered_map>
+#include <vector>
+
+namespace orc {
+
+enum NdtSearch { NDT_KDTREE = 0, NDT_DIRECT26 = 1, NDT_DIRECT7 = 2, NDT_DIRECT1 = 3 };
+
+struct NdtLeaf {
+    int    key;          // linear voxel index (ijk - min_b) . divb_mul
+    int    nr_points;    // >= 6 valid; -1 invalidated by the eigenvalue / inf checks; < 6 unused
+    double mean[3];
+    double cov[9];
+    double icov[9];
+    float  centroid[4];  // float accumulation of x,y,z,intensity (KDTREE search uses xyz)
+};
+
+// pclomp::VoxelGridCovariance<PointXYZI>::applyFilter + getNeighborhoodAtPoint{,7,1}
+struct VoxelGridCovariance {
+    float leaf_size = 1.0f, inv_leaf = 1.0f;
+    int   min_b[3] = {0, 0, 0}, max_b[3] = {0, 0, 0}, div_b[3] = {0, 0, 0}, divb_mul[3] = {0, 0, 0};
+    std::vector<NdtLeaf>         leaves;  // ascending key (std::map iteration order)
+    std::unordered_map<int, int> index;   // key -> leaves[] position (all leaves, also < 6 points)
+    int n_valid = 0;
+
+    // returns 0 ok, -1 index overflow ("Leaf size is too small"), -2 empty input
+    int build(const float* xyzi, int n, float leaf);
+    // neighbours (leaf positions) of an already transformed point; returns count (<= 27)
+    int neighbours(float x, float y, float z, NdtSearch method, int out[27]) const;
+};
+
+struct Ndt {
+    // parameters (defaults = ndt_omp ctor; mrg_slam overrides through registrations.cpp:134-146)
+    float  resolution        = 1.0f;
+    double step_size         = 0.1;
+    double outlier_ratio     = 0.55;
+    double trans_eps         = 0.1;
+    int    max_iterations    = 35;
+    int    num_threads       = 1;
+    NdtSearch search         = NDT_DIRECT7;
+
+    VoxelGridCovariance cells;
+    std::vector<float> target, source;  // xyzi
+    int target_status = -2;
+
+    // results
+    float  final_[16];  // row-major
+    bool   converged   = false;
+    int    nr_iterations = 0;
+    double trans_probability = 0;
+    double hessian[36];
+    int    n_evals = 0;          // derivative evaluations executed (all modes)
+    double neighbours_sum = 0;   // sum over evals of mean valid neighbour voxels per point (k-bar numerator)
+
+    int  set_target(const float* xyzi, int n);
+    void set_source(const float* xyzi, int n);
+    // pcl::Registration::align + computeTransformation. guess row-major. aligned (n*4 floats xyzi) optional.
+    void align(const float guess[16], float* aligned);
+    // pcl::Registration::getFitnessScore(max_range) on the last final transformation
+    double fitness(double max_range) const;
+
+    // one derivative evaluation at pose vector p with the points transformed by T (row-major):
+    // mode 0: score+gradient+hessian (float path), 1: score+gradient only, 2: hessian only (double path,
+    // computeHessian). Exposed for kernel-level parity tests.
+    double evaluate(const float T[16], const double p[6], int mode, double grad[6], double hess[36]);
+
+   private:
+    double gauss_d1 = 0, gauss_d2 = 0, gauss_d3 = 0;
+    double j_ang_d[8][3], h_ang_d[15][3];
+    float  j_ang_f[8][3], h_ang_f[15][3];
+    std::vector<double> scores_, grads_, hessians_;  // per-point results, summed in index order
+    std::vector<float>  trans_;                      // transformed cloud xyz (stride 3)
+    void   init_gauss();
+    void   angle_derivatives(const double p[6], bool compute_hessian = true);
+    void   transform_cloud(const float T[16]);
+    double compute_derivatives(double grad[6], double hess[36], const double p[6], bool compute_hessian);
+    void   compute_hessian(double hess[36], const double p[6]);
+    double step_length_mt(const double x[6], double step_dir[6], double step_init, double step_max, double step_min, double& score,
+                          double grad[6], double hess[36]);
+};
+
+}  // namespace orc

@@ -1,0 +1,351 @@
+"""ctypes bindings of the CPU oracle (oracle/liboracle.so) — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+package (mrg_slam_amd) never does.  PARITY UNPINNED: the oracle restates un-vendored upstream code (see
+oracle/quirks.h).  All 4x4 matrices cross as column-major float32/float64 (numpy: pass ``M.T.copy()`` /
+``order='F'``); helpers here take and return ordinary row-major numpy arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+SEARCH = {"KDTREE": 0, "DIRECT26": 1, "DIRECT7": 2, "DIRECT1": 3}
+ORDER_STABLE, ORDER_STD_SORT = 0, 1
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".h")) or f == "Makefile"]
+    if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs):
+        subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        fp, ip, dp, u8p = C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_ubyte)
+        vp = C.c_void_p
+        sig = {
+            "orc_distance_filter": (C.c_int, [fp, C.c_int, C.c_double, C.c_double, fp]),
+            "orc_voxelgrid": (C.c_int, [fp, C.c_int, C.c_float, C.c_int, C.c_int, fp, ip]),
+            "orc_radius_outlier": (C.c_int, [fp, C.c_int, C.c_double, C.c_int, fp, u8p]),
+            "orc_statistical_outlier": (C.c_int, [fp, C.c_int, C.c_int, C.c_double, fp, u8p]),
+            "orc_knn": (None, [fp, C.c_int, fp, C.c_int, C.c_int, ip, fp]),
+            "orc_nn1_brute": (None, [fp, C.c_int, fp, C.c_int, ip, fp]),
+            "orc_calc_fitness_score": (C.c_double, [fp, C.c_int, fp, C.c_int, dp, C.c_double]),
+            "orc_svd6_solve": (None, [dp, dp, dp, dp]),
+            "orc_sym_eig3": (None, [dp, dp, dp]),
+            "orc_euler_xyz": (None, [fp, fp]),
+            "orc_pose_to_matrix": (None, [dp, fp]),
+            "orc_transform_points": (None, [fp, fp, C.c_int, fp]),
+            "orc_ndt_create": (vp, []),
+            "orc_ndt_destroy": (None, [vp]),
+            "orc_ndt_set_params": (None, [vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]),
+            "orc_ndt_set_target": (C.c_int, [vp, fp, C.c_int]),
+            "orc_ndt_set_source": (None, [vp, fp, C.c_int]),
+            "orc_ndt_align": (None, [vp, fp, fp]),
+            "orc_ndt_converged": (C.c_int, [vp]),
+            "orc_ndt_iterations": (C.c_int, [vp]),
+            "orc_ndt_evals": (C.c_int, [vp]),
+            "orc_ndt_mean_neighbours": (C.c_double, [vp]),
+            "orc_ndt_trans_probability": (C.c_double, [vp]),
+            "orc_ndt_final": (None, [vp, fp]),
+            "orc_ndt_hessian": (None, [vp, dp]),
+            "orc_ndt_fitness": (C.c_double, [vp, C.c_double]),
+            "orc_ndt_evaluate": (C.c_double, [vp, fp, dp, C.c_int, dp, dp]),
+            "orc_ndt_num_leaves": (C.c_int, [vp]),
+            "orc_ndt_grid": (None, [vp, ip, ip, ip]),
+            "orc_ndt_leaves": (None, [vp, ip, ip, dp, dp, dp]),
+            "orc_gicp_create": (vp, []),
+            "orc_gicp_destroy": (None, [vp]),
+            "orc_gicp_set_params": (None, [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]),
+            "orc_gicp_set_target": (None, [vp, fp, C.c_int]),
+            "orc_gicp_set_source": (None, [vp, fp, C.c_int]),
+            "orc_gicp_align": (None, [vp, fp, fp]),
+            "orc_gicp_converged": (C.c_int, [vp]),
+            "orc_gicp_iterations": (C.c_int, [vp]),
+            "orc_gicp_final": (None, [vp, fp]),
+            "orc_gicp_hessian": (None, [vp, dp]),
+            "orc_gicp_fitness": (C.c_double, [vp, C.c_double]),
+            "orc_gicp_covariances": (None, [vp, C.c_int, dp]),
+            "orc_gicp_linearize": (C.c_double, [vp, dp, dp, dp, ip]),
+        }
+        for name, (res, args) in sig.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _pf(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _pd(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _pi(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _cloud(a):
+    a = _f32(a)
+    assert a.ndim == 2 and a.shape[1] == 4, "clouds are N x 4 float32 (x, y, z, intensity)"
+    return a
+
+
+def _colmajor(M, dtype=np.float32):
+    return np.ascontiguousarray(np.asarray(M, dtype=dtype).T)  # row-major of M^T == column-major of M
+
+
+# ---- filters ---------------------------------------------------------------------------------------------
+def distance_filter(cloud, near=0.1, far=35.0):
+    c = _cloud(cloud)
+    out = np.empty_like(c)
+    m = lib().orc_distance_filter(_pf(c), len(c), near, far, _pf(out))
+    return out[:m].copy()
+
+
+def voxelgrid(cloud, leaf=0.1, min_points=1, order=ORDER_STABLE):
+    c = _cloud(cloud)
+    out = np.empty_like(c)
+    m = C.c_int(0)
+    status = lib().orc_voxelgrid(_pf(c), len(c), leaf, min_points, order, _pf(out), C.byref(m))
+    return out[: m.value].copy(), status
+
+
+def radius_outlier(cloud, radius=0.5, min_neighbors=2):
+    c = _cloud(cloud)
+    out = np.empty_like(c)
+    keep = np.zeros(len(c), dtype=np.uint8)
+    m = lib().orc_radius_outlier(_pf(c), len(c), radius, min_neighbors, _pf(out), keep.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return out[:m].copy(), keep.astype(bool)
+
+
+def statistical_outlier(cloud, mean_k=30, stddev_mul=1.2):
+    c = _cloud(cloud)
+    out = np.empty_like(c)
+    keep = np.zeros(len(c), dtype=np.uint8)
+    m = lib().orc_statistical_outlier(_pf(c), len(c), mean_k, stddev_mul, _pf(out), keep.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return out[:m].copy(), keep.astype(bool)
+
+
+def knn(target, query, k):
+    t, q = _cloud(target), _cloud(query)
+    idx = np.empty((len(q), k), dtype=np.int32)
+    sqd = np.empty((len(q), k), dtype=np.float32)
+    lib().orc_knn(_pf(t), len(t), _pf(q), len(q), k, _pi(idx), _pf(sqd))
+    return idx, sqd
+
+
+def nn1_brute(target, query):
+    t, q = _cloud(target), _cloud(query)
+    idx = np.empty(len(q), dtype=np.int32)
+    sqd = np.empty(len(q), dtype=np.float32)
+    lib().orc_nn1_brute(_pf(t), len(t), _pf(q), len(q), _pi(idx), _pf(sqd))
+    return idx, sqd
+
+
+def calc_fitness_score(cloud1, cloud2, relpose, max_range=float("inf")):
+    c1, c2 = _cloud(cloud1), _cloud(cloud2)
+    T = _colmajor(relpose, np.float64)
+    return lib().orc_calc_fitness_score(_pf(c1), len(c1), _pf(c2), len(c2), _pd(T), max_range)
+
+
+# ---- linear algebra --------------------------------------------------------------------------------------
+def svd6_solve(A, b):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x, s = np.empty(6), np.empty(6)
+    lib().orc_svd6_solve(_pd(A), _pd(b), _pd(x), _pd(s))
+    return x, s
+
+
+def sym_eig3(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    w, V = np.empty(3), np.empty((3, 3))
+    lib().orc_sym_eig3(_pd(A), _pd(w), _pd(V))
+    return w, V
+
+
+def euler_xyz(T):
+    Tc = _colmajor(T)
+    out = np.empty(3, dtype=np.float32)
+    lib().orc_euler_xyz(_pf(Tc), _pf(out))
+    return out
+
+
+def pose_to_matrix(p):
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    Tc = np.empty((4, 4), dtype=np.float32)
+    lib().orc_pose_to_matrix(_pd(p), _pf(Tc))
+    return Tc.T.copy()
+
+
+def transform_points(T, cloud):
+    c = _cloud(cloud)
+    out = np.empty_like(c)
+    lib().orc_transform_points(_pf(_colmajor(T)), _pf(c), len(c), _pf(out))
+    return out
+
+
+# ---- NDT ---------------------------------------------------------------------------------------------------
+class Ndt:
+    """pclomp::NormalDistributionsTransform restated (oracle/ndt.cpp) behind the pcl::Registration call surface."""
+
+    def __init__(self, resolution=1.0, step_size=0.1, outlier_ratio=0.55, transformation_epsilon=0.1, maximum_iterations=64, num_threads=1,
+                 search="DIRECT7"):
+        self._h = lib().orc_ndt_create()
+        lib().orc_ndt_set_params(self._h, resolution, step_size, outlier_ratio, transformation_epsilon, maximum_iterations, num_threads, SEARCH[search])
+        self._n_src = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_ndt_destroy(self._h)
+            self._h = None
+
+    def setInputTarget(self, cloud):
+        c = _cloud(cloud)
+        return lib().orc_ndt_set_target(self._h, _pf(c), len(c))
+
+    def setInputSource(self, cloud):
+        c = _cloud(cloud)
+        self._n_src = len(c)
+        lib().orc_ndt_set_source(self._h, _pf(c), len(c))
+
+    def align(self, guess=None, want_aligned=False):
+        g = _colmajor(np.eye(4) if guess is None else guess)
+        out = np.empty((self._n_src, 4), dtype=np.float32) if want_aligned else None
+        lib().orc_ndt_align(self._h, _pf(g), _pf(out) if want_aligned else None)
+        return out
+
+    def hasConverged(self):
+        return bool(lib().orc_ndt_converged(self._h))
+
+    def getFinalTransformation(self):
+        Tc = np.empty((4, 4), dtype=np.float32)
+        lib().orc_ndt_final(self._h, _pf(Tc))
+        return Tc.T.copy()
+
+    def getFitnessScore(self, max_range=float("inf")):
+        return lib().orc_ndt_fitness(self._h, max_range)
+
+    def getFinalNumIteration(self):
+        return lib().orc_ndt_iterations(self._h)
+
+    def getTransformationProbability(self):
+        return lib().orc_ndt_trans_probability(self._h)
+
+    def getHessian(self):
+        H = np.empty((6, 6))
+        lib().orc_ndt_hessian(self._h, _pd(H))
+        return H
+
+    @property
+    def evals(self):
+        return lib().orc_ndt_evals(self._h)
+
+    @property
+    def mean_neighbours(self):
+        return lib().orc_ndt_mean_neighbours(self._h)
+
+    def evaluate(self, T, p, mode=0):
+        """One derivative evaluation: returns (score, grad[6], hess[6,6])."""
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        g, H = np.zeros(6), np.zeros((6, 6))
+        s = lib().orc_ndt_evaluate(self._h, _pf(_colmajor(T)), _pd(p), mode, _pd(g), _pd(H))
+        return s, g, H
+
+    def leaves(self):
+        n = lib().orc_ndt_num_leaves(self._h)
+        keys, npts = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+        mean, cov, icov = np.empty((n, 3)), np.empty((n, 3, 3)), np.empty((n, 3, 3))
+        if n:
+            lib().orc_ndt_leaves(self._h, _pi(keys), _pi(npts), _pd(mean), _pd(cov), _pd(icov))
+        return keys, npts, mean, cov, icov
+
+    def grid(self):
+        a, b, c = (np.empty(3, dtype=np.int32) for _ in range(3))
+        lib().orc_ndt_grid(self._h, _pi(a), _pi(b), _pi(c))
+        return a, b, c
+
+
+# ---- GICP --------------------------------------------------------------------------------------------------
+class FastGicp:
+    """fast_gicp::FastGICP restated (oracle/gicp.cpp)."""
+
+    def __init__(self, correspondence_randomness=20, max_correspondence_distance=2.0, transformation_epsilon=0.1, rotation_epsilon=2e-3,
+                 maximum_iterations=64, num_threads=1):
+        self._h = lib().orc_gicp_create()
+        lib().orc_gicp_set_params(self._h, correspondence_randomness, max_correspondence_distance, transformation_epsilon, rotation_epsilon,
+                                  maximum_iterations, num_threads)
+        self._n_src = self._n_tgt = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_gicp_destroy(self._h)
+            self._h = None
+
+    def setInputTarget(self, cloud):
+        c = _cloud(cloud)
+        self._n_tgt = len(c)
+        lib().orc_gicp_set_target(self._h, _pf(c), len(c))
+
+    def setInputSource(self, cloud):
+        c = _cloud(cloud)
+        self._n_src = len(c)
+        lib().orc_gicp_set_source(self._h, _pf(c), len(c))
+
+    def align(self, guess=None, want_aligned=False):
+        g = _colmajor(np.eye(4) if guess is None else guess)
+        out = np.empty((self._n_src, 4), dtype=np.float32) if want_aligned else None
+        lib().orc_gicp_align(self._h, _pf(g), _pf(out) if want_aligned else None)
+        return out
+
+    def hasConverged(self):
+        return bool(lib().orc_gicp_converged(self._h))
+
+    def getFinalTransformation(self):
+        Tc = np.empty((4, 4), dtype=np.float32)
+        lib().orc_gicp_final(self._h, _pf(Tc))
+        return Tc.T.copy()
+
+    def getFitnessScore(self, max_range=float("inf")):
+        return lib().orc_gicp_fitness(self._h, max_range)
+
+    def getFinalNumIteration(self):
+        return lib().orc_gicp_iterations(self._h)
+
+    def getFinalHessian(self):
+        H = np.empty((6, 6))
+        lib().orc_gicp_hessian(self._h, _pd(H))
+        return H
+
+    def covariances(self, which="source"):
+        n = self._n_src if which == "source" else self._n_tgt
+        out = np.empty((n, 3, 3))
+        lib().orc_gicp_covariances(self._h, 0 if which == "source" else 1, _pd(out))
+        return out
+
+    def linearize(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        H, b, n = np.empty((6, 6)), np.empty(6), C.c_int(0)
+        e = lib().orc_gicp_linearize(self._h, _pd(T), _pd(H), _pd(b), C.byref(n))
+        return e, H, b, n.value

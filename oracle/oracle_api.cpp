@@ -1,0 +1,151 @@
+// oracle/oracle_api.cpp — TEST INFRASTRUCTURE (CPU oracle). Not part of the shipped product path.
+//
+// extern "C" surface of the CPU oracle, bound with ctypes by oracle/oracle.py. Only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+// Matrices cross this boundary column-major (Eigen default), like the product C-ABI in include/mrgfe.h.
+#include <cstring>
+#include <vector>
+
+#include "filters.h"
+#include "gicp.h"
+#include "linalg.h"
+#include "ndt.h"
+#include "nn.h"
+
+using namespace orc;
+
+extern "C" {
+
+// ---- filters -----------------------------------------------------------------------------------------
+int orc_distance_filter(const float* in, int n, double near_thresh, double far_thresh, float* out) { return distance_filter(in, n, near_thresh, far_thresh, out); }
+int orc_voxelgrid(const float* in, int n, float leaf, int min_pts, int order_mode, float* out, int* out_n) { return voxelgrid(in, n, leaf, min_pts, order_mode, out, out_n); }
+int orc_radius_outlier(const float* in, int n, double radius, int min_neighbors, float* out, unsigned char* keep) { return radius_outlier(in, n, radius, min_neighbors, out, keep); }
+int orc_statistical_outlier(const float* in, int n, int mean_k, double stddev_mul, float* out, unsigned char* keep) { return statistical_outlier(in, n, mean_k, stddev_mul, out, keep); }
+
+// ---- nearest neighbour ---------------------------------------------------------------------------------
+// exact k-NN of each query in the target cloud (grid) and brute force (O(n*m)) for cross-checking the grid
+void orc_knn(const float* target, int nt, const float* query, int nq, int k, int* idx, float* sqd)
+{
+    NnGrid g;
+    g.build(target, nt, 1.0f);
+    for (int i = 0; i < nq; ++i) {
+        int got = g.knn(query[4 * i], query[4 * i + 1], query[4 * i + 2], k, idx + static_cast<size_t>(i) * k, sqd + static_cast<size_t>(i) * k);
+        for (int j = got; j < k; ++j) { idx[static_cast<size_t>(i) * k + j] = -1; sqd[static_cast<size_t>(i) * k + j] = -1.0f; }
+    }
+}
+void orc_nn1_brute(const float* target, int nt, const float* query, int nq, int* idx, float* sqd)
+{
+    for (int i = 0; i < nq; ++i) {
+        int best = -1; float bd = 0;
+        for (int j = 0; j < nt; ++j) {
+            float d = sqdist_f(target[4 * j], target[4 * j + 1], target[4 * j + 2], query[4 * i], query[4 * i + 1], query[4 * i + 2]);
+            if (best < 0 || d < bd) { best = j; bd = d; }
+        }
+        idx[i] = best; sqd[i] = bd;
+    }
+}
+// InformationMatrixCalculator::calc_fitness_score (information_matrix_calculator.cpp:46-81):
+// cloud1 = tree, cloud2 transformed by relpose (cast to float), squared NN distance vs un-squared max_range.
+double orc_calc_fitness_score(const float* cloud1, int n1, const float* cloud2, int n2, const double relpose_colmajor[16], double max_range)
+{
+    if (n1 == 0 || n2 == 0) return std::numeric_limits<double>::max();
+    float Tc[16], T[16];
+    for (int i = 0; i < 16; ++i) Tc[i] = static_cast<float>(relpose_colmajor[i]);
+    colmajor_to_rowmajor4(Tc, T);
+    NnGrid g;
+    g.build(cloud1, n1, 1.0f);
+    double sum = 0; int nr = 0;
+    for (int i = 0; i < n2; ++i) {
+        float x, y, z, d;
+        transform_point_f(T, cloud2[4 * i], cloud2[4 * i + 1], cloud2[4 * i + 2], x, y, z);
+        if (g.nearest(x, y, z, d) < 0) continue;
+        if (static_cast<double>(d) <= max_range) { sum += d; ++nr; }
+    }
+    return nr > 0 ? sum / nr : std::numeric_limits<double>::max();
+}
+
+// ---- small linear algebra (exposed so tests can pin it against numpy) --------------------------------
+void orc_svd6_solve(const double A_rowmajor[36], const double b[6], double x[6], double sing[6])
+{
+    JacobiSvd6 sv; sv.compute(A_rowmajor); sv.solve(b, x);
+    for (int i = 0; i < 6; ++i) sing[i] = sv.rank_ >= 0 ? sv.S[i] : 0.0;
+}
+void orc_sym_eig3(const double A[9], double evals[3], double evecs[9]) { sym_eig3(A, evals, evecs); }
+void orc_euler_xyz(const float T_colmajor[16], float out[3]) { float T[16]; colmajor_to_rowmajor4(T_colmajor, T); euler_xyz_f(T, out); }
+void orc_pose_to_matrix(const double p[6], float T_colmajor[16]) { float T[16]; pose_to_matrix_f(p, T); rowmajor_to_colmajor4(T, T_colmajor); }
+void orc_transform_points(const float T_colmajor[16], const float* in, int n, float* out)
+{
+    float T[16]; colmajor_to_rowmajor4(T_colmajor, T);
+    for (int i = 0; i < n; ++i) { transform_point_f(T, in[4 * i], in[4 * i + 1], in[4 * i + 2], out[4 * i], out[4 * i + 1], out[4 * i + 2]); out[4 * i + 3] = in[4 * i + 3]; }
+}
+
+// ---- NDT -------------------------------------------------------------------------------------------------
+void* orc_ndt_create() { return new Ndt(); }
+void  orc_ndt_destroy(void* h) { delete static_cast<Ndt*>(h); }
+void  orc_ndt_set_params(void* h, double resolution, double step_size, double outlier_ratio, double trans_eps, int max_iterations, int num_threads, int search)
+{
+    Ndt* n = static_cast<Ndt*>(h);
+    n->resolution = static_cast<float>(resolution); n->step_size = step_size; n->outlier_ratio = outlier_ratio; n->trans_eps = trans_eps;
+    n->max_iterations = max_iterations; n->num_threads = num_threads > 0 ? num_threads : 1; n->search = static_cast<NdtSearch>(search);
+}
+int  orc_ndt_set_target(void* h, const float* xyzi, int n) { return static_cast<Ndt*>(h)->set_target(xyzi, n); }
+void orc_ndt_set_source(void* h, const float* xyzi, int n) { static_cast<Ndt*>(h)->set_source(xyzi, n); }
+void orc_ndt_align(void* h, const float guess_colmajor[16], float* aligned_or_null)
+{
+    float g[16]; colmajor_to_rowmajor4(guess_colmajor, g);
+    static_cast<Ndt*>(h)->align(g, aligned_or_null);
+}
+int    orc_ndt_converged(void* h) { return static_cast<Ndt*>(h)->converged ? 1 : 0; }
+int    orc_ndt_iterations(void* h) { return static_cast<Ndt*>(h)->nr_iterations; }
+int    orc_ndt_evals(void* h) { return static_cast<Ndt*>(h)->n_evals; }
+double orc_ndt_mean_neighbours(void* h) { Ndt* n = static_cast<Ndt*>(h); return n->n_evals ? n->neighbours_sum / n->n_evals : 0.0; }
+double orc_ndt_trans_probability(void* h) { return static_cast<Ndt*>(h)->trans_probability; }
+void   orc_ndt_final(void* h, float out_colmajor[16]) { rowmajor_to_colmajor4(static_cast<Ndt*>(h)->final_, out_colmajor); }
+void   orc_ndt_hessian(void* h, double out_rowmajor[36]) { std::memcpy(out_rowmajor, static_cast<Ndt*>(h)->hessian, sizeof(double) * 36); }
+double orc_ndt_fitness(void* h, double max_range) { return static_cast<Ndt*>(h)->fitness(max_range); }
+double orc_ndt_evaluate(void* h, const float T_colmajor[16], const double p[6], int mode, double grad[6], double hess_rowmajor[36])
+{
+    float T[16]; colmajor_to_rowmajor4(T_colmajor, T);
+    return static_cast<Ndt*>(h)->evaluate(T, p, mode, grad, hess_rowmajor);
+}
+// target grid inspection: leaves in ascending key order
+int  orc_ndt_num_leaves(void* h) { return static_cast<int>(static_cast<Ndt*>(h)->cells.leaves.size()); }
+void orc_ndt_grid(void* h, int min_b[3], int max_b[3], int div_b[3]) { Ndt* n = static_cast<Ndt*>(h); for (int a = 0; a < 3; ++a) { min_b[a] = n->cells.min_b[a]; max_b[a] = n->cells.max_b[a]; div_b[a] = n->cells.div_b[a]; } }
+void orc_ndt_leaves(void* h, int* keys, int* nr_points, double* mean3, double* cov9, double* icov9)
+{
+    Ndt* n = static_cast<Ndt*>(h);
+    for (size_t i = 0; i < n->cells.leaves.size(); ++i) {
+        const NdtLeaf& L = n->cells.leaves[i];
+        keys[i] = L.key; nr_points[i] = L.nr_points;
+        std::memcpy(mean3 + 3 * i, L.mean, 24); std::memcpy(cov9 + 9 * i, L.cov, 72); std::memcpy(icov9 + 9 * i, L.icov, 72);
+    }
+}
+
+// ---- GICP (fast_gicp::FastGICP formulation) --------------------------------------------------------------
+void* orc_gicp_create() { return new FastGicp(); }
+void  orc_gicp_destroy(void* h) { delete static_cast<FastGicp*>(h); }
+void  orc_gicp_set_params(void* h, int k_correspondences, double max_corr_dist, double trans_eps, double rot_eps, int max_iterations, int num_threads)
+{
+    FastGicp* g = static_cast<FastGicp*>(h);
+    g->k_correspondences = k_correspondences; g->max_corr_dist = max_corr_dist; g->trans_eps = trans_eps; g->rot_eps = rot_eps;
+    g->max_iterations = max_iterations; g->num_threads = num_threads > 0 ? num_threads : 1;
+}
+void orc_gicp_set_target(void* h, const float* xyzi, int n) { static_cast<FastGicp*>(h)->set_target(xyzi, n); }
+void orc_gicp_set_source(void* h, const float* xyzi, int n) { static_cast<FastGicp*>(h)->set_source(xyzi, n); }
+void orc_gicp_align(void* h, const float guess_colmajor[16], float* aligned_or_null)
+{
+    float g[16]; colmajor_to_rowmajor4(guess_colmajor, g);
+    static_cast<FastGicp*>(h)->align(g, aligned_or_null);
+}
+int    orc_gicp_converged(void* h) { return static_cast<FastGicp*>(h)->converged ? 1 : 0; }
+int    orc_gicp_iterations(void* h) { return static_cast<FastGicp*>(h)->nr_iterations; }
+void   orc_gicp_final(void* h, float out_colmajor[16]) { rowmajor_to_colmajor4(static_cast<FastGicp*>(h)->final_, out_colmajor); }
+void   orc_gicp_hessian(void* h, double out_rowmajor[36]) { std::memcpy(out_rowmajor, static_cast<FastGicp*>(h)->final_hessian, sizeof(double) * 36); }
+double orc_gicp_fitness(void* h, double max_range) { return static_cast<FastGicp*>(h)->fitness(max_range); }
+void   orc_gicp_covariances(void* h, int which, double* cov9_per_point) { static_cast<FastGicp*>(h)->get_covariances(which, cov9_per_point); }
+double orc_gicp_linearize(void* h, const double T_rowmajor[16], double H_rowmajor[36], double b[6], int* n_corr)
+{
+    return static_cast<FastGicp*>(h)->linearize(T_rowmajor, H_rowmajor, b, n_corr);
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+// oracle/quirks.h — TEST INFRASTRUCTURE (CPU oracle). Not part of the shipped product path.
+//
+// Every constant and behavioural quirk that the CPU restatement inherits from the un-vendored upstream
+// libraries the reference links against (PCL 1.12, koide3/ndt_omp, SMRT-AIST/fast_gicp; see
+// /root/reference/CMakeLists.txt:26,84-85,91 and src/mrg_slam/registrations.cpp:4-24).
+//
+// PARITY UNPINNED: none of those libraries (nor Eigen/FLANN) exist in this container and the reference
+// ships no tests or golden vectors, so these values are restated from the published upstream sources
+//  and are kept in ONE place so they can be corrected in one edit.
+#pragma once
+
+namespace orc {
+namespace quirks {
+
+// ---- pclomp::VoxelGridCovariance (ndt_omp voxel_grid_covariance_omp.h) ------------------------------
+constexpr int    kNdtMinPointsPerVoxel   = 6;     // min_points_per_voxel_
+constexpr double kNdtMinCovarEigvalMult  = 0.01;  // min_covar_eigvalue_mult_
+
+// ---- pclomp::NormalDistributionsTransform defaults (ndt_omp_impl.hpp ctor) ---------------------------
+constexpr float  kNdtResolution          = 1.0f;
+constexpr double kNdtStepSize            = 0.1;
+constexpr double kNdtOutlierRatio        = 0.55;
+constexpr double kNdtTransformationEps   = 0.1;
+constexpr int    kNdtMaxIterations       = 35;
+// computeAngleDerivatives: angles with |a| < 10e-5 use cos=1, sin=0 exactly.
+constexpr double kNdtSmallAngle          = 10e-5;
+// computeStepLengthMT (More-Thuente) constants.
+constexpr int    kMtMaxStepIterations    = 10;
+constexpr double kMtMu                   = 1.e-4;
+constexpr double kMtNu                   = 0.9;
+
+// ---- mrg_slam overrides (config/mrg_slam.yaml:100-109, registrations.cpp:130-148) -------------------
+constexpr double kMrgTransformationEps   = 0.1;
+constexpr int    kMrgMaxIterations       = 64;
+constexpr double kMrgResolution          = 1.0;
+
+// ---- pcl::VoxelGrid -----------------------------------------------------------------------------------
+// In-voxel accumulation order. PCL sorts (idx, point) pairs with std::sort (unstable introsort): the order
+// inside a voxel is whatever libstdc++ produces. ORDER_STABLE sums in ascending point index instead.
+enum VoxelOrder { ORDER_STABLE = 0, ORDER_STD_SORT = 1 };
+
+// ---- pcl::RadiusOutlierRemoval ------------------------------------------------------------------------
+// Dense-cloud path (VoxelGrid output is_dense=true): nearestKSearch(min_pts+1) and the k-th neighbour is an
+// inlier iff (double)sqdist <= radius*radius  (inclusive). The query point itself is among the neighbours.
+
+// ---- pcl::Registration::getFitnessScore(max_range) ----------------------------------------------------
+// Squared NN distance is compared against the UN-squared max_range (same quirk in
+// /root/reference/src/mrg_slam/information_matrix_calculator.cpp:70).
+
+// ---- fast_gicp::FastGICP defaults ---------------------------------------------------------------------
+constexpr int    kGicpKCorrespondences   = 20;
+constexpr double kGicpRotationEps        = 2e-3;
+constexpr double kGicpLmInitLambdaFactor = 1e-9;
+constexpr int    kGicpLmMaxIterations    = 10;
+constexpr double kGicpPlaneEps           = 1e-3;  // RegularizationMethod::PLANE singular values (1,1,1e-3)
+
+}  // namespace quirks
+}  // namespace orc
