@@ -1,0 +1,187 @@
+/* include/mrgfe.h — C ABI of libmrgfe.so, the MI355X (gfx950) scan-matching front end for mrg_slam.
+ *
+ * Drop-in boundary: everything the reference reaches through
+ *     pcl::Registration<PointXYZI,PointXYZI>::Ptr select_registration_method(rclcpp::Node*)
+ *         /root/reference/include/mrg_slam/registrations.hpp:20, src/mrg_slam/registrations.cpp:28-152
+ * and through the pcl::Filter objects held by the prefiltering component
+ *         /root/reference/apps/prefiltering_component.cpp:158-229
+ * is exported here as plain C: opaque handles, host (or device) pointers and sizes, int status codes.
+ * No exceptions cross this boundary; no torch / PCL / Eigen types appear in it.  The existing precedent for a
+ * GPU registration back end in the reference is the FAST_VGICP_CUDA branch (registrations.cpp:65-75,
+ * CMakeLists.txt:45-49); include/mrgfe_pcl_adapter.hpp wraps this ABI into that same slot.
+ *
+ * Conventions
+ *   - clouds: float x,y,z,intensity per point ("xyzi"); `stride_bytes` between points (16 for packed float4,
+ *     32 for pcl::PointXYZI; 0 means 16).  Inputs are copied to the device inside the call: the caller may
+ *     free or reuse its buffer when the call returns.
+ *   - 4x4 matrices: float[16] / double[16], COLUMN-major (Eigen's default, i.e. Eigen::Matrix4f::data()).
+ *   - 6x6 matrices: double[36], row-major (symmetric in practice).
+ *   - status: 0 = ok, <0 = error; mrgfe_last_error() returns a thread-local message for the last failure.
+ *     Non-convergence is NOT an error (pcl::Registration::align returns void; callers test hasConverged():
+ *     apps/scan_matching_odometry_component.cpp:270, src/mrg_slam/loop_detector.cpp:138).
+ *   - a handle is used from one thread at a time; distinct handles may be used concurrently (each context owns
+ *     its HIP stream; the odometry and loop-closure registrations of the reference live in different threads).
+ */
+#ifndef MRGFE_H
+#define MRGFE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRGFE_OK 0
+#define MRGFE_ERR_INVALID (-1)   /* bad argument / handle */
+#define MRGFE_ERR_HIP (-2)       /* HIP runtime error (no GPU, out of memory, launch failure) */
+#define MRGFE_ERR_OVERFLOW (-3)  /* voxel index would overflow int32 ("Leaf size is too small for the input dataset") */
+#define MRGFE_ERR_EMPTY (-4)     /* operation needs a non-empty cloud */
+#define MRGFE_ERR_STATE (-5)     /* target / source not set */
+
+typedef struct mrgfe_ctx mrgfe_ctx; /* one per (process, GPU): stream + grow-only device workspace */
+typedef struct mrgfe_reg mrgfe_reg; /* one registration object == one pcl::Registration instance */
+
+/* registration_method strings of the reference that this library serves (registrations.cpp:45-151) */
+enum mrgfe_method {
+    MRGFE_NDT_HIP = 0,  /* replaces "NDT_OMP"  : pclomp::NormalDistributionsTransform (registrations.cpp:130-148) */
+    MRGFE_GICP_HIP = 1  /* replaces "FAST_GICP": fast_gicp::FastGICP                  (registrations.cpp:55-63)   */
+};
+/* reg_nn_search_method (registrations.cpp:140-146) */
+enum mrgfe_ndt_search { MRGFE_KDTREE = 0, MRGFE_DIRECT26 = 1, MRGFE_DIRECT7 = 2, MRGFE_DIRECT1 = 3 };
+
+/* Mirrors the ten reg_* ROS parameters read by select_registration_method (registrations.cpp:34-43) plus the
+ * library defaults those classes carry (ndt_omp: step_size 0.1, outlier_ratio 0.55; fast_gicp: rotation_epsilon 2e-3). */
+typedef struct mrgfe_reg_params {
+    int    method;                          /* enum mrgfe_method                        "registration_method"               */
+    int    num_threads;                     /* accepted for parity, unused on the GPU   "reg_num_threads"                   */
+    double transformation_epsilon;          /*                                          "reg_transformation_epsilon"        */
+    int    maximum_iterations;              /*                                          "reg_maximum_iterations"            */
+    double max_correspondence_distance;     /* GICP                                     "reg_max_correspondence_distance"   */
+    int    max_optimizer_iterations;        /* accepted, unused (pcl::GICP BFGS only)   "reg_max_optimizer_iterations"      */
+    int    use_reciprocal_correspondences;  /* accepted, unused (pcl::ICP/GICP only)    "reg_use_reciprocal_correspondences"*/
+    int    correspondence_randomness;       /* GICP k neighbours                        "reg_correspondence_randomness"     */
+    double resolution;                      /* NDT voxel size                           "reg_resolution"                    */
+    int    nn_search_method;                /* enum mrgfe_ndt_search                    "reg_nn_search_method"              */
+    double step_size;                       /* NDT More-Thuente step_max (0.1)    */
+    double outlier_ratio;                   /* NDT (0.55)                         */
+    double rotation_epsilon;                /* GICP (2e-3)                        */
+} mrgfe_reg_params;
+
+/* ---- library / context ------------------------------------------------------------------------------------- */
+const char* mrgfe_last_error(void);
+const char* mrgfe_version(void);
+int  mrgfe_ctx_create(int device_id, mrgfe_ctx** out);
+void mrgfe_ctx_destroy(mrgfe_ctx* ctx);
+int  mrgfe_ctx_synchronize(mrgfe_ctx* ctx);
+/* HIP stream of the context as an opaque pointer (hipStream_t), for callers that order their own work after it */
+void* mrgfe_ctx_stream(mrgfe_ctx* ctx);
+
+/* ---- registration: the pcl::Registration call surface the reference uses (SURVEY.md §8b "Seam") ---------------- */
+/* defaults of select_registration_method's parameters (registrations.cpp:34-43 comments) for `method` */
+void mrgfe_reg_default_params(int method, mrgfe_reg_params* out);
+/* replaces: new pclomp::NormalDistributionsTransform + setters (registrations.cpp:133-146) / new fast_gicp::FastGICP (:57-62) */
+int  mrgfe_reg_create(mrgfe_ctx* ctx, const mrgfe_reg_params* params, mrgfe_reg** out);
+void mrgfe_reg_destroy(mrgfe_reg* reg);
+/* replaces registration_->setInputTarget(cloud): scan_matching_odometry_component.cpp:203,295,333; loop_detector.cpp:104.
+ * NDT: builds the voxel covariance grid (pclomp::VoxelGridCovariance::filter). Returns MRGFE_ERR_OVERFLOW like PCL's
+ * index-overflow abort (the registration then has no target). */
+int  mrgfe_reg_set_target(mrgfe_reg* reg, const float* xyzi, size_t n, size_t stride_bytes);
+/* replaces registration_->setInputSource(cloud): scan_matching_odometry_component.cpp:208; loop_detector.cpp:127,229,272 */
+int  mrgfe_reg_set_source(mrgfe_reg* reg, const float* xyzi, size_t n, size_t stride_bytes);
+/* same, from packed float4 clouds already resident in device memory (zero-copy ingest; bench.py's timed region) */
+int  mrgfe_reg_set_target_device(mrgfe_reg* reg, const void* d_xyzi, size_t n);
+int  mrgfe_reg_set_source_device(mrgfe_reg* reg, const void* d_xyzi, size_t n);
+/* replaces registration_->align(*aligned, guess): scan_matching_odometry_component.cpp:265-266; loop_detector.cpp:134,236,279.
+ * `aligned_xyzi` (n_source packed float4, may be NULL) receives final_transformation * source. */
+int  mrgfe_reg_align(mrgfe_reg* reg, const float guess[16], float* aligned_xyzi);
+/* replaces hasConverged() / getFinalTransformation(): scan_matching_odometry_component.cpp:270,275; loop_detector.cpp:138,144 */
+int  mrgfe_reg_has_converged(const mrgfe_reg* reg);
+int  mrgfe_reg_final_transformation(const mrgfe_reg* reg, float out[16]);
+/* replaces getFitnessScore(max_range): loop_detector.cpp:137; scan_matching_odometry_component.cpp:403.
+ * PCL semantics: mean squared 1-NN distance over source points whose SQUARED distance is <= max_range. */
+int  mrgfe_reg_fitness(mrgfe_reg* reg, double max_range, double* out);
+/* replaces getSearchMethodTarget()->nearestKSearch(pt, 1, ..): scan_matching_odometry_component.cpp:405-417 (batched) */
+int  mrgfe_reg_nn1_target(mrgfe_reg* reg, const float* query_xyzi, size_t n, size_t stride_bytes, int32_t* idx, float* sqdist);
+/* extra read-outs (pcl: getFinalNumIteration / ndt: getTransformationProbability; 6x6 Hessian for the pose gather of §8e) */
+int    mrgfe_reg_iterations(const mrgfe_reg* reg);
+int    mrgfe_reg_evaluations(const mrgfe_reg* reg); /* derivative (NDT) / linearize+error (GICP) passes of the last align */
+double mrgfe_reg_trans_probability(const mrgfe_reg* reg);
+int    mrgfe_reg_hessian(const mrgfe_reg* reg, double out[36]);
+
+/* ---- NDT internals exposed for kernel-level parity tests and the roofline accounting --------------------------- */
+/* one derivative evaluation at pose vector p (tx,ty,tz,rx,ry,rz) with the source transformed by T:
+ * mode 0 = score+gradient+Hessian, 1 = score+gradient, 2 = Hessian only in double (pclomp computeHessian). */
+int mrgfe_ndt_evaluate(mrgfe_reg* reg, const float T[16], const double p[6], int mode, double* score, double grad[6], double hess[36]);
+/* target grid: number of voxels with >= 1 point; per-voxel key (ascending), point count (-1: rejected by the
+ * eigenvalue / inf checks), mean[3], inverse covariance[9] (row-major). Arrays sized by mrgfe_ndt_num_leaves. */
+int mrgfe_ndt_num_leaves(const mrgfe_reg* reg);
+int mrgfe_ndt_grid(const mrgfe_reg* reg, int32_t min_b[3], int32_t max_b[3], int32_t div_b[3]);
+int mrgfe_ndt_leaves(mrgfe_reg* reg, int32_t* keys, int32_t* nr_points, double* mean3, double* icov9);
+/* mean number of valid neighbour voxels per source point over the evaluations of the last align (k-bar of SURVEY §8d) */
+double mrgfe_ndt_mean_neighbours(const mrgfe_reg* reg);
+
+/* ---- prefilter chain (apps/prefiltering_component.cpp:149-151). Outputs: caller-allocated capacity-n packed float4
+ *      buffers + count.  Order-preserving where the reference is. ------------------------------------------------- */
+/* replaces PrefilteringComponent::distance_filter (:206-229): keep iff near < |p| < far */
+int mrgfe_distance_filter(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, double near_thresh, double far_thresh,
+                          float* out_xyzi, size_t* out_n);
+/* replaces pcl::VoxelGrid<PointXYZI>::filter with setLeafSize(l,l,l), setMinimumPointsNumberPerVoxel (:168-171;
+ * scan_matching_odometry_component.cpp:176-179). Returns MRGFE_OK with *overflow=1 and output == input when PCL would
+ * warn "Leaf size is too small" and pass the cloud through. */
+int mrgfe_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, float leaf, int min_points_per_voxel,
+                    float* out_xyzi, size_t* out_n, int* overflow);
+/* replaces pcl::RadiusOutlierRemoval::filter with setRadiusSearch / setMinNeighborsInRadius (:195-198) */
+int mrgfe_radius_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, double radius, int min_neighbors,
+                         float* out_xyzi, size_t* out_n);
+/* replaces pcl::StatisticalOutlierRemoval::filter with setMeanK / setStddevMulThresh (:189-192) */
+int mrgfe_statistical_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, int mean_k, double stddev_mul,
+                              float* out_xyzi, size_t* out_n);
+/* replaces InformationMatrixCalculator::calc_fitness_score (src/mrg_slam/information_matrix_calculator.cpp:46-81) */
+int mrgfe_calc_fitness_score(mrgfe_ctx* ctx, const float* cloud1, size_t n1, const float* cloud2, size_t n2, size_t stride_bytes,
+                             const double relpose[16], double max_range, double* out);
+
+/* ---- batched candidate matching (LoopDetector::matching candidate loop, src/mrg_slam/loop_detector.cpp:126-145) ---- */
+typedef struct mrgfe_pair_result {
+    float   T[16];      /* final transformation, column-major                */
+    double  H[36];      /* 6x6 Hessian of the last iteration, row-major      */
+    double  fitness;    /* getFitnessScore(max_range); DBL_MAX if not computed */
+    double  trans_probability;
+    int32_t converged;
+    int32_t iterations;
+    int32_t evaluations;
+    int32_t pair_id;
+} mrgfe_pair_result; /* 384 bytes: the record the ranks all-gather over RCCL */
+
+typedef struct mrgfe_batch mrgfe_batch;
+/* A batch holds `n_targets` target clouds and `n_pairs` (target index, source cloud, guess) alignments that are advanced
+ * together, one launch per derivative evaluation for all pairs still running. */
+int  mrgfe_batch_create(mrgfe_ctx* ctx, const mrgfe_reg_params* params, mrgfe_batch** out);
+void mrgfe_batch_destroy(mrgfe_batch* b);
+int  mrgfe_batch_clear(mrgfe_batch* b);
+/* returns the target index (>= 0) or an error (< 0) */
+int  mrgfe_batch_add_target(mrgfe_batch* b, const float* xyzi, size_t n, size_t stride_bytes);
+int  mrgfe_batch_add_target_device(mrgfe_batch* b, const void* d_xyzi, size_t n);
+/* returns the pair index (>= 0) or an error (< 0) */
+int  mrgfe_batch_add_pair(mrgfe_batch* b, int target_index, const float* src_xyzi, size_t n, size_t stride_bytes, const float guess[16]);
+int  mrgfe_batch_add_pair_device(mrgfe_batch* b, int target_index, const void* d_src_xyzi, size_t n, const float guess[16]);
+int  mrgfe_batch_set_guess(mrgfe_batch* b, int pair_index, const float guess[16]);
+/* build every target grid (setInputTarget), then align every pair; fitness_max_range < 0 skips getFitnessScore */
+int  mrgfe_batch_build_targets(mrgfe_batch* b);
+int  mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_result* results /* n_pairs */);
+int  mrgfe_batch_num_pairs(const mrgfe_batch* b);
+/* device time (ms, HIP events on the context stream) and launch count of the derivative kernel in the last
+ * mrgfe_batch_align / mrgfe_reg_align; algorithmic bytes it moved per SURVEY.md §8(d): sum over launches of
+ * N_src*(16 + 7*8 + kbar*48) for the pairs active in that launch. */
+int  mrgfe_batch_kernel_stats(const mrgfe_batch* b, double* deriv_ms, int64_t* deriv_launches, double* deriv_alg_bytes);
+int  mrgfe_reg_kernel_stats(const mrgfe_reg* reg, double* deriv_ms, int64_t* deriv_launches, double* deriv_alg_bytes);
+
+/* ---- diagnostic entry points for the primitive tests (tests/test_gpu_primitives.py) --------------------------- */
+int mrgfe_dbg_sort_pairs(mrgfe_ctx* ctx, const uint32_t* keys, const uint32_t* vals, size_t n, int key_bits, uint32_t* out_keys, uint32_t* out_vals);
+int mrgfe_dbg_exclusive_scan(mrgfe_ctx* ctx, const uint32_t* in, size_t n, uint32_t* out, uint32_t* total);
+int mrgfe_dbg_minmax(mrgfe_ctx* ctx, const float* xyzi, size_t n, float min3[3], float max3[3], uint32_t* n_finite);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRGFE_H */

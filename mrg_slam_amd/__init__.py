@@ -1,0 +1,6 @@
+"""mrg_slam_amd — MI355X (gfx950) scan-matching front end for mrg_slam: prefilter chain + NDT/GICP align() as
+hand-written HIP kernels behind a C ABI (include/mrgfe.h), with the host-side mirror of the reference's
+pcl::Registration / pcl::Filter call surface.  See DESIGN.md."""
+from ._lib import Context, MrgfeError, build, default_context  # noqa: F401
+from .filters import RadiusOutlierRemoval, StatisticalOutlierRemoval, VoxelGrid, calc_fitness_score, distance_filter, prefilter  # noqa: F401
+from .registration import BatchMatcher, GicpHip, NdtHip, select_registration_method  # noqa: F401

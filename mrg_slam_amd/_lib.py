@@ -1,0 +1,193 @@
+"""ctypes loader of libmrgfe.so (the C ABI of include/mrgfe.h).
+
+There is NO CPU fallback: if the HIP library is missing it is built with hipcc (cross-compiles without a GPU), and if it
+cannot be loaded, or no GPU is present when a context is created, an exception is raised.  Nothing under ``oracle/`` is
+ever imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_PKG, "csrc")
+LIB_PATH = os.path.join(_PKG, "libmrgfe.so")
+
+MRGFE_OK, ERR_INVALID, ERR_HIP, ERR_OVERFLOW, ERR_EMPTY, ERR_STATE = 0, -1, -2, -3, -4, -5
+NDT_HIP, GICP_HIP = 0, 1
+SEARCH = {"KDTREE": 0, "DIRECT26": 1, "DIRECT7": 2, "DIRECT1": 3}
+
+
+class MrgfeError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libmrgfe error {status}: {message}")
+        self.status = status
+
+
+class RegParams(C.Structure):
+    """struct mrgfe_reg_params (mirrors the reg_* ROS parameters of registrations.cpp:34-43)."""
+
+    _fields_ = [
+        ("method", C.c_int),
+        ("num_threads", C.c_int),
+        ("transformation_epsilon", C.c_double),
+        ("maximum_iterations", C.c_int),
+        ("max_correspondence_distance", C.c_double),
+        ("max_optimizer_iterations", C.c_int),
+        ("use_reciprocal_correspondences", C.c_int),
+        ("correspondence_randomness", C.c_int),
+        ("resolution", C.c_double),
+        ("nn_search_method", C.c_int),
+        ("step_size", C.c_double),
+        ("outlier_ratio", C.c_double),
+        ("rotation_epsilon", C.c_double),
+    ]
+
+
+class PairResult(C.Structure):
+    """struct mrgfe_pair_result: the 384-byte record gathered across ranks."""
+
+    _fields_ = [
+        ("T", C.c_float * 16),
+        ("H", C.c_double * 36),
+        ("fitness", C.c_double),
+        ("trans_probability", C.c_double),
+        ("converged", C.c_int32),
+        ("iterations", C.c_int32),
+        ("evaluations", C.c_int32),
+        ("pair_id", C.c_int32),
+    ]
+
+
+assert C.sizeof(PairResult) == 384
+
+# every symbol include/mrgfe.h declares: name -> (restype, argtypes)
+_vp, _fp, _dp, _ip, _u32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+_szp = C.POINTER(C.c_size_t)
+SIGNATURES = {
+    "mrgfe_last_error": (C.c_char_p, []),
+    "mrgfe_version": (C.c_char_p, []),
+    "mrgfe_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "mrgfe_ctx_destroy": (None, [_vp]),
+    "mrgfe_ctx_synchronize": (C.c_int, [_vp]),
+    "mrgfe_ctx_stream": (_vp, [_vp]),
+    "mrgfe_reg_default_params": (None, [C.c_int, C.POINTER(RegParams)]),
+    "mrgfe_reg_create": (C.c_int, [_vp, C.POINTER(RegParams), C.POINTER(_vp)]),
+    "mrgfe_reg_destroy": (None, [_vp]),
+    "mrgfe_reg_set_target": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t]),
+    "mrgfe_reg_set_source": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t]),
+    "mrgfe_reg_set_target_device": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "mrgfe_reg_set_source_device": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "mrgfe_reg_align": (C.c_int, [_vp, _fp, _fp]),
+    "mrgfe_reg_has_converged": (C.c_int, [_vp]),
+    "mrgfe_reg_final_transformation": (C.c_int, [_vp, _fp]),
+    "mrgfe_reg_fitness": (C.c_int, [_vp, C.c_double, _dp]),
+    "mrgfe_reg_nn1_target": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, _ip, _fp]),
+    "mrgfe_reg_iterations": (C.c_int, [_vp]),
+    "mrgfe_reg_evaluations": (C.c_int, [_vp]),
+    "mrgfe_reg_trans_probability": (C.c_double, [_vp]),
+    "mrgfe_reg_hessian": (C.c_int, [_vp, _dp]),
+    "mrgfe_ndt_evaluate": (C.c_int, [_vp, _fp, _dp, C.c_int, _dp, _dp, _dp]),
+    "mrgfe_ndt_num_leaves": (C.c_int, [_vp]),
+    "mrgfe_ndt_grid": (C.c_int, [_vp, _ip, _ip, _ip]),
+    "mrgfe_ndt_leaves": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),
+    "mrgfe_ndt_mean_neighbours": (C.c_double, [_vp]),
+    "mrgfe_distance_filter": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, C.c_double, C.c_double, _fp, _szp]),
+    "mrgfe_voxelgrid": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, C.c_float, C.c_int, _fp, _szp, C.POINTER(C.c_int)]),
+    "mrgfe_radius_outlier": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, C.c_double, C.c_int, _fp, _szp]),
+    "mrgfe_statistical_outlier": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, C.c_int, C.c_double, _fp, _szp]),
+    "mrgfe_calc_fitness_score": (C.c_int, [_vp, _fp, C.c_size_t, _fp, C.c_size_t, C.c_size_t, _dp, C.c_double, _dp]),
+    "mrgfe_batch_create": (C.c_int, [_vp, C.POINTER(RegParams), C.POINTER(_vp)]),
+    "mrgfe_batch_destroy": (None, [_vp]),
+    "mrgfe_batch_clear": (C.c_int, [_vp]),
+    "mrgfe_batch_add_target": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t]),
+    "mrgfe_batch_add_target_device": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "mrgfe_batch_add_pair": (C.c_int, [_vp, C.c_int, _fp, C.c_size_t, C.c_size_t, _fp]),
+    "mrgfe_batch_add_pair_device": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _fp]),
+    "mrgfe_batch_set_guess": (C.c_int, [_vp, C.c_int, _fp]),
+    "mrgfe_batch_build_targets": (C.c_int, [_vp]),
+    "mrgfe_batch_align": (C.c_int, [_vp, C.c_double, C.POINTER(PairResult)]),
+    "mrgfe_batch_num_pairs": (C.c_int, [_vp]),
+    "mrgfe_batch_kernel_stats": (C.c_int, [_vp, _dp, C.POINTER(C.c_int64), _dp]),
+    "mrgfe_reg_kernel_stats": (C.c_int, [_vp, _dp, C.POINTER(C.c_int64), _dp]),
+    "mrgfe_dbg_sort_pairs": (C.c_int, [_vp, _u32p, _u32p, C.c_size_t, C.c_int, _u32p, _u32p]),
+    "mrgfe_dbg_exclusive_scan": (C.c_int, [_vp, _u32p, C.c_size_t, _u32p, _u32p]),
+    "mrgfe_dbg_minmax": (C.c_int, [_vp, _fp, C.c_size_t, _fp, _fp, _u32p]),
+}
+
+
+def build(force: bool = False) -> str:
+    """Compile libmrgfe.so for gfx950 with hipcc (csrc/Makefile). No-op when it is newer than its sources."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".cpp", ".h")) or f == "Makefile"]
+    srcs.append(os.path.join(os.path.dirname(_PKG), "include", "mrgfe.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.run(["make", "-C", _CSRC, "-j8", "-s"] + (["-B"] if force else []), check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            try:
+                build()
+            except Exception as e:  # noqa: BLE001
+                raise RuntimeError(f"libmrgfe.so is missing and could not be built with hipcc ({e}); there is no CPU fallback") from e
+        # When torch is already in the process its bundled HIP runtime (same soname) must be the one we bind to;
+        # importing it first in a torch-using program keeps a single runtime per process.
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL if "torch" in sys.modules else C.DEFAULT_MODE)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError here == the library does not export a declared symbol
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return lib().mrgfe_last_error().decode("utf-8", "replace")
+
+
+def check(status: int) -> int:
+    if status < 0:
+        raise MrgfeError(status, last_error())
+    return status
+
+
+class Context:
+    """mrgfe_ctx: one per (process, GPU)."""
+
+    def __init__(self, device: int = 0):
+        self._h = _vp()
+        check(lib().mrgfe_ctx_create(device, C.byref(self._h)))
+        self.device = device
+
+    def synchronize(self):
+        check(lib().mrgfe_ctx_synchronize(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mrgfe_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device: int | None = None) -> Context:
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("MRGFE_DEVICE") is None else int(os.environ["MRGFE_DEVICE"])
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

@@ -1,0 +1,566 @@
+// csrc/api.cpp — the extern "C" surface declared in include/mrgfe.h.  Thin: argument checks, column-major <-> row-major
+// conversion, and dispatch into the engines.  Never throws; failures set the thread-local message.
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "cellsort.h"
+#include "common.h"
+#include "filters.h"
+#include "gicp_engine.h"
+#include "ndt_engine.h"
+#include "nn_grid.h"
+
+using namespace mrgfe;
+
+namespace {
+
+void col2row(const float in[16], float out[16]) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[r * 4 + c] = in[c * 4 + r]; }
+void row2col(const float in[16], float out[16]) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[c * 4 + r] = in[r * 4 + c]; }
+
+NdtParams ndt_params_from(const mrgfe_reg_params& p)
+{
+    NdtParams n;
+    n.resolution = static_cast<float>(p.resolution);
+    n.step_size = p.step_size;
+    n.outlier_ratio = p.outlier_ratio;
+    n.trans_eps = p.transformation_epsilon;
+    n.max_iterations = p.maximum_iterations;
+    n.search = p.nn_search_method;
+    return n;
+}
+GicpParams gicp_params_from(const mrgfe_reg_params& p)
+{
+    GicpParams g;
+    g.k_correspondences = p.correspondence_randomness;
+    g.max_corr_dist = p.max_correspondence_distance;
+    g.trans_eps = p.transformation_epsilon;
+    g.rot_eps = p.rotation_epsilon;
+    g.max_iterations = p.maximum_iterations;
+    return g;
+}
+
+int check_params(const mrgfe_reg_params* p)
+{
+    if (!p) { set_error("NULL params"); return MRGFE_ERR_INVALID; }
+    if (p->method != MRGFE_NDT_HIP && p->method != MRGFE_GICP_HIP) { set_error("unknown registration method %d", p->method); return MRGFE_ERR_INVALID; }
+    if (p->method == MRGFE_NDT_HIP) {
+        if (!(p->resolution > 0)) { set_error("resolution must be > 0"); return MRGFE_ERR_INVALID; }
+        if (p->nn_search_method < 0 || p->nn_search_method > 3) { set_error("unknown nn_search_method %d", p->nn_search_method); return MRGFE_ERR_INVALID; }
+    } else {
+        if (p->correspondence_randomness < 4 || p->correspondence_randomness > 64) { set_error("correspondence_randomness must be in [4, 64]"); return MRGFE_ERR_INVALID; }
+    }
+    return MRGFE_OK;
+}
+
+}  // namespace
+
+struct mrgfe_reg {
+    mrgfe_ctx*       ctx = nullptr;
+    mrgfe_reg_params params;
+    NdtEngine*       ndt = nullptr;
+    GicpEngine*      gicp = nullptr;
+    DevBuf           tgt, src;            // owned copies of host-supplied clouds
+    const void*      d_tgt = nullptr;     // current clouds (owned buffer or caller's device memory)
+    const void*      d_src = nullptr;
+    size_t           n_tgt = 0, n_src = 0;
+    bool             has_target = false, has_source = false, aligned_once = false;
+    int              target_status = MRGFE_ERR_STATE;
+    NnGrid           nn;                  // exact 1-NN structure over the target (getFitnessScore / nearestKSearch)
+    bool             nn_valid = false;
+    float            final_rm[16];        // row-major
+    bool             converged = false;
+    int              iterations = 0, evaluations = 0;
+    double           trans_probability = 0;
+    double           hessian[36];
+    double           mean_neighbours = 0;
+};
+
+struct mrgfe_batch {
+    mrgfe_ctx*       ctx = nullptr;
+    mrgfe_reg_params params;
+    NdtEngine*       ndt = nullptr;
+};
+
+extern "C" {
+
+void mrgfe_reg_default_params(int method, mrgfe_reg_params* out)
+{
+    if (!out) return;
+    std::memset(out, 0, sizeof(*out));
+    out->method = method;
+    out->num_threads = 0;                       // registrations.cpp:35
+    out->transformation_epsilon = 0.01;         // :36
+    out->maximum_iterations = 64;               // :37
+    out->max_correspondence_distance = 2.0;     // :38
+    out->max_optimizer_iterations = 20;         // :39
+    out->use_reciprocal_correspondences = 0;    // :40
+    out->correspondence_randomness = 20;        // :41
+    out->resolution = 1.0;                      // :42
+    out->nn_search_method = MRGFE_DIRECT7;      // :43
+    out->step_size = 0.1;
+    out->outlier_ratio = 0.55;
+    out->rotation_epsilon = 2e-3;
+}
+
+int mrgfe_reg_create(mrgfe_ctx* ctx, const mrgfe_reg_params* params, mrgfe_reg** out)
+{
+    if (!ctx || !out) { set_error("mrgfe_reg_create: NULL argument"); return MRGFE_ERR_INVALID; }
+    *out = nullptr;
+    MRGFE_TRY(check_params(params));
+    mrgfe_reg* r = new (std::nothrow) mrgfe_reg();
+    if (!r) { set_error("out of host memory"); return MRGFE_ERR_INVALID; }
+    r->ctx = ctx;
+    r->params = *params;
+    if (params->method == MRGFE_NDT_HIP) {
+        r->ndt = new NdtEngine(ctx, ndt_params_from(*params));
+        if (const char* e = std::getenv("MRGFE_FORCE_HASH")) r->ndt->set_force_hash(e[0] == '1');
+    } else {
+        r->gicp = new GicpEngine(ctx, gicp_params_from(*params));
+    }
+    for (int i = 0; i < 16; ++i) r->final_rm[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    for (int i = 0; i < 36; ++i) r->hessian[i] = 0;
+    *out = r;
+    return MRGFE_OK;
+}
+
+void mrgfe_reg_destroy(mrgfe_reg* reg)
+{
+    if (!reg) return;
+    if (reg->ctx) (void)hipSetDevice(reg->ctx->device);
+    delete reg->ndt;
+    delete reg->gicp;
+    reg->nn.release();
+    reg->tgt.release();
+    reg->src.release();
+    delete reg;
+}
+
+static int reg_target_changed(mrgfe_reg* reg)
+{
+    reg->has_target = true;
+    reg->nn_valid = false;
+    if (reg->ndt) {
+        reg->ndt->clear();
+        int ti = reg->ndt->add_target_device(reg->d_tgt, reg->n_tgt);
+        if (ti < 0) return ti;
+        MRGFE_TRY(reg->ndt->build_targets());
+        reg->target_status = reg->ndt->target(0).status;
+        if (reg->target_status == MRGFE_ERR_OVERFLOW) set_error("[NDT_HIP::setInputTarget] Leaf size is too small for the input dataset. Integer indices would overflow.");
+        if (reg->target_status == MRGFE_ERR_EMPTY) { set_error("setInputTarget: cloud has no finite point"); }
+        return reg->target_status;
+    }
+    MRGFE_TRY(reg->gicp->set_target(reg->d_tgt, reg->n_tgt));
+    reg->target_status = MRGFE_OK;
+    return MRGFE_OK;
+}
+
+int mrgfe_reg_set_target(mrgfe_reg* reg, const float* xyzi, size_t n, size_t stride_bytes)
+{
+    if (!reg || (n && !xyzi)) { set_error("mrgfe_reg_set_target: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(reg->ctx->bind());
+    MRGFE_TRY(reg->tgt.ensure(std::max<size_t>(n, 1) * 16));
+    MRGFE_TRY(upload_cloud(reg->ctx, xyzi, n, stride_bytes, reg->tgt.p));
+    reg->d_tgt = reg->tgt.p;
+    reg->n_tgt = n;
+    return reg_target_changed(reg);
+}
+
+int mrgfe_reg_set_target_device(mrgfe_reg* reg, const void* d_xyzi, size_t n)
+{
+    if (!reg || (n && !d_xyzi)) { set_error("mrgfe_reg_set_target_device: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(reg->ctx->bind());
+    reg->d_tgt = d_xyzi;
+    reg->n_tgt = n;
+    return reg_target_changed(reg);
+}
+
+int mrgfe_reg_set_source(mrgfe_reg* reg, const float* xyzi, size_t n, size_t stride_bytes)
+{
+    if (!reg || (n && !xyzi)) { set_error("mrgfe_reg_set_source: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(reg->ctx->bind());
+    MRGFE_TRY(reg->src.ensure(std::max<size_t>(n, 1) * 16));
+    MRGFE_TRY(upload_cloud(reg->ctx, xyzi, n, stride_bytes, reg->src.p));
+    reg->d_src = reg->src.p;
+    reg->n_src = n;
+    reg->has_source = true;
+    if (reg->gicp) MRGFE_TRY(reg->gicp->set_source(reg->d_src, reg->n_src));
+    return MRGFE_OK;
+}
+
+int mrgfe_reg_set_source_device(mrgfe_reg* reg, const void* d_xyzi, size_t n)
+{
+    if (!reg || (n && !d_xyzi)) { set_error("mrgfe_reg_set_source_device: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(reg->ctx->bind());
+    reg->d_src = d_xyzi;
+    reg->n_src = n;
+    reg->has_source = true;
+    if (reg->gicp) MRGFE_TRY(reg->gicp->set_source(reg->d_src, reg->n_src));
+    return MRGFE_OK;
+}
+
+int mrgfe_reg_align(mrgfe_reg* reg, const float guess[16], float* aligned_xyzi)
+{
+    if (!reg || !guess) { set_error("mrgfe_reg_align: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (!reg->has_target || !reg->has_source) { set_error("align: setInputTarget / setInputSource first"); return MRGFE_ERR_STATE; }
+    MRGFE_TRY(reg->ctx->bind());
+    float g[16];
+    col2row(guess, g);
+    if (reg->ndt) {
+        NdtEngine& e = *reg->ndt;
+        e.clear_pairs();
+        int pi = e.add_pair_device(0, reg->d_src, reg->n_src, g);
+        if (pi < 0) return pi;
+        MRGFE_TRY(e.align_all());
+        const NdtController& c = e.pair(0).ctl;
+        std::memcpy(reg->final_rm, c.final_transformation(), sizeof(reg->final_rm));
+        reg->converged = c.converged();
+        reg->iterations = c.iterations();
+        reg->evaluations = c.evaluations();
+        reg->trans_probability = c.trans_probability();
+        std::memcpy(reg->hessian, c.hessian(), sizeof(reg->hessian));
+        reg->mean_neighbours = c.evaluations() ? c.neighbours_sum() / c.evaluations() : 0.0;
+        if (aligned_xyzi) MRGFE_TRY(e.aligned_cloud(0, aligned_xyzi));
+    } else {
+        GicpEngine& e = *reg->gicp;
+        MRGFE_TRY(e.align(g));
+        std::memcpy(reg->final_rm, e.final_transformation(), sizeof(reg->final_rm));
+        reg->converged = e.converged();
+        reg->iterations = e.iterations();
+        reg->evaluations = e.evaluations();
+        reg->trans_probability = 0;
+        std::memcpy(reg->hessian, e.hessian(), sizeof(reg->hessian));
+        if (aligned_xyzi) MRGFE_TRY(e.aligned_cloud(aligned_xyzi));
+    }
+    reg->aligned_once = true;
+    return MRGFE_OK;
+}
+
+int mrgfe_reg_has_converged(const mrgfe_reg* reg) { return reg && reg->converged ? 1 : 0; }
+
+int mrgfe_reg_final_transformation(const mrgfe_reg* reg, float out[16])
+{
+    if (!reg || !out) { set_error("mrgfe_reg_final_transformation: NULL argument"); return MRGFE_ERR_INVALID; }
+    row2col(reg->final_rm, out);
+    return MRGFE_OK;
+}
+
+static int reg_ensure_nn(mrgfe_reg* reg)
+{
+    if (!reg->has_target) { set_error("no target set"); return MRGFE_ERR_STATE; }
+    if (!reg->nn_valid) {
+        MRGFE_TRY(reg->nn.build(reg->ctx, static_cast<const float4*>(reg->d_tgt), reg->n_tgt, 1.0f));
+        reg->nn_valid = true;
+    }
+    return MRGFE_OK;
+}
+
+int mrgfe_reg_fitness(mrgfe_reg* reg, double max_range, double* out)
+{
+    if (!reg || !out) { set_error("mrgfe_reg_fitness: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (!reg->has_target || !reg->has_source) { set_error("getFitnessScore: target / source not set"); return MRGFE_ERR_STATE; }
+    MRGFE_TRY(reg->ctx->bind());
+    if (reg->n_tgt == 0 || reg->n_src == 0) { *out = DBL_MAX; return MRGFE_OK; }
+    MRGFE_TRY(reg_ensure_nn(reg));
+    return reg->nn.fitness(reg->ctx, static_cast<const float4*>(reg->d_src), reg->n_src, reg->final_rm, max_range, out);
+}
+
+int mrgfe_reg_nn1_target(mrgfe_reg* reg, const float* q, size_t n, size_t stride_bytes, int32_t* idx, float* sqd)
+{
+    if (!reg || (n && (!q || !idx || !sqd))) { set_error("mrgfe_reg_nn1_target: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(reg->ctx->bind());
+    MRGFE_TRY(reg_ensure_nn(reg));
+    return reg->nn.nearest_host(reg->ctx, q, n, stride_bytes, idx, sqd);
+}
+
+int    mrgfe_reg_iterations(const mrgfe_reg* reg) { return reg ? reg->iterations : 0; }
+int    mrgfe_reg_evaluations(const mrgfe_reg* reg) { return reg ? reg->evaluations : 0; }
+double mrgfe_reg_trans_probability(const mrgfe_reg* reg) { return reg ? reg->trans_probability : 0.0; }
+int    mrgfe_reg_hessian(const mrgfe_reg* reg, double out[36])
+{
+    if (!reg || !out) { set_error("mrgfe_reg_hessian: NULL argument"); return MRGFE_ERR_INVALID; }
+    std::memcpy(out, reg->hessian, sizeof(reg->hessian));
+    return MRGFE_OK;
+}
+
+// ---- NDT internals --------------------------------------------------------------------------------------------
+int mrgfe_ndt_evaluate(mrgfe_reg* reg, const float T[16], const double p[6], int mode, double* score, double grad[6], double hess[36])
+{
+    if (!reg || !reg->ndt || !T || !p || !score || !grad || !hess) { set_error("mrgfe_ndt_evaluate: needs an NDT registration and non-NULL arguments"); return MRGFE_ERR_INVALID; }
+    if (!reg->has_target || !reg->has_source) { set_error("evaluate: target / source not set"); return MRGFE_ERR_STATE; }
+    float Tr[16];
+    col2row(T, Tr);
+    NdtEngine& e = *reg->ndt;
+    e.clear_pairs();
+    float ident[16];
+    for (int i = 0; i < 16; ++i) ident[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    int pi = e.add_pair_device(0, reg->d_src, reg->n_src, ident);
+    if (pi < 0) return pi;
+    return e.evaluate(0, Tr, p, mode, score, grad, hess);
+}
+
+int mrgfe_ndt_num_leaves(const mrgfe_reg* reg) { return (reg && reg->ndt && reg->ndt->n_targets() > 0) ? static_cast<int>(reg->ndt->target(0).n_leaves) : 0; }
+
+int mrgfe_ndt_grid(const mrgfe_reg* reg, int32_t min_b[3], int32_t max_b[3], int32_t div_b[3])
+{
+    if (!reg || !reg->ndt || reg->ndt->n_targets() == 0) { set_error("mrgfe_ndt_grid: no NDT target"); return MRGFE_ERR_STATE; }
+    const NdtTargetInfo& t = reg->ndt->target(0);
+    for (int a = 0; a < 3; ++a) { min_b[a] = t.min_b[a]; max_b[a] = t.max_b[a]; div_b[a] = t.div_b[a]; }
+    return MRGFE_OK;
+}
+
+int mrgfe_ndt_leaves(mrgfe_reg* reg, int32_t* keys, int32_t* nr_points, double* mean3, double* icov9)
+{
+    if (!reg || !reg->ndt || reg->ndt->n_targets() == 0) { set_error("mrgfe_ndt_leaves: no NDT target"); return MRGFE_ERR_STATE; }
+    return reg->ndt->read_leaves(0, keys, nr_points, mean3, icov9);
+}
+
+double mrgfe_ndt_mean_neighbours(const mrgfe_reg* reg) { return reg ? reg->mean_neighbours : 0.0; }
+
+int mrgfe_reg_kernel_stats(const mrgfe_reg* reg, double* ms, int64_t* launches, double* bytes)
+{
+    if (!reg) { set_error("NULL registration"); return MRGFE_ERR_INVALID; }
+    double m = 0, b = 0;
+    int64_t l = 0;
+    if (reg->ndt) { m = reg->ndt->deriv_ms; l = reg->ndt->deriv_launches; b = reg->ndt->deriv_alg_bytes; }
+    if (reg->gicp) { m = reg->gicp->kernel_ms; l = reg->gicp->kernel_launches; b = reg->gicp->kernel_alg_bytes; }
+    if (ms) *ms = m;
+    if (launches) *launches = l;
+    if (bytes) *bytes = b;
+    return MRGFE_OK;
+}
+
+// ---- prefilters -----------------------------------------------------------------------------------------------
+int mrgfe_distance_filter(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double near_thresh, double far_thresh, float* out, size_t* out_n)
+{
+    if (!ctx || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_distance_filter: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(ctx->bind());
+    return filter_distance(ctx, xyzi, n, stride, near_thresh, far_thresh, out, out_n);
+}
+int mrgfe_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, float leaf, int min_pts, float* out, size_t* out_n, int* overflow)
+{
+    if (!ctx || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_voxelgrid: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (!(leaf > 0)) { set_error("mrgfe_voxelgrid: leaf size must be > 0"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(ctx->bind());
+    return filter_voxelgrid(ctx, xyzi, n, stride, leaf, min_pts, out, out_n, overflow);
+}
+int mrgfe_radius_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double radius, int min_neighbors, float* out, size_t* out_n)
+{
+    if (!ctx || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_radius_outlier: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (!(radius > 0)) { set_error("mrgfe_radius_outlier: radius must be > 0"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(ctx->bind());
+    return filter_radius_outlier(ctx, xyzi, n, stride, radius, min_neighbors, out, out_n);
+}
+int mrgfe_statistical_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, int mean_k, double stddev_mul, float* out, size_t* out_n)
+{
+    if (!ctx || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_statistical_outlier: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (mean_k < 1 || mean_k > 63) { set_error("mrgfe_statistical_outlier: mean_k must be in [1, 63]"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(ctx->bind());
+    return filter_statistical_outlier(ctx, xyzi, n, stride, mean_k, stddev_mul, out, out_n);
+}
+int mrgfe_calc_fitness_score(mrgfe_ctx* ctx, const float* cloud1, size_t n1, const float* cloud2, size_t n2, size_t stride, const double relpose[16], double max_range, double* out)
+{
+    if (!ctx || !out || !relpose || (n1 && !cloud1) || (n2 && !cloud2)) { set_error("mrgfe_calc_fitness_score: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(ctx->bind());
+    if (n1 == 0 || n2 == 0) { *out = DBL_MAX; return MRGFE_OK; }
+    DevBuf &d1 = ctx->scratch[10], &d2 = ctx->scratch[11];
+    MRGFE_TRY(d1.ensure(n1 * 16));
+    MRGFE_TRY(d2.ensure(n2 * 16));
+    MRGFE_TRY(upload_cloud(ctx, cloud1, n1, stride, d1.p));
+    MRGFE_TRY(upload_cloud(ctx, cloud2, n2, stride, d2.p));
+    NnGrid g;
+    int st = g.build(ctx, d1.as<float4>(), n1, 1.0f);
+    if (st == MRGFE_OK) {
+        float T[16];  // relpose.cast<float>(), row-major
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) T[r * 4 + c] = static_cast<float>(relpose[c * 4 + r]);
+        st = g.fitness(ctx, d2.as<float4>(), n2, T, max_range, out);
+    }
+    g.release();
+    return st;
+}
+
+// ---- batch ------------------------------------------------------------------------------------------------------
+int mrgfe_batch_create(mrgfe_ctx* ctx, const mrgfe_reg_params* params, mrgfe_batch** out)
+{
+    if (!ctx || !out) { set_error("mrgfe_batch_create: NULL argument"); return MRGFE_ERR_INVALID; }
+    *out = nullptr;
+    MRGFE_TRY(check_params(params));
+    if (params->method != MRGFE_NDT_HIP) { set_error("batched matching is available for NDT_HIP"); return MRGFE_ERR_INVALID; }
+    mrgfe_batch* b = new (std::nothrow) mrgfe_batch();
+    if (!b) { set_error("out of host memory"); return MRGFE_ERR_INVALID; }
+    b->ctx = ctx;
+    b->params = *params;
+    b->ndt = new NdtEngine(ctx, ndt_params_from(*params));
+    *out = b;
+    return MRGFE_OK;
+}
+void mrgfe_batch_destroy(mrgfe_batch* b)
+{
+    if (!b) return;
+    delete b->ndt;
+    delete b;
+}
+int mrgfe_batch_clear(mrgfe_batch* b)
+{
+    if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
+    b->ndt->clear();
+    return MRGFE_OK;
+}
+int mrgfe_batch_add_target(mrgfe_batch* b, const float* xyzi, size_t n, size_t stride)
+{
+    if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
+    return b->ndt->add_target_host(xyzi, n, stride);
+}
+int mrgfe_batch_add_target_device(mrgfe_batch* b, const void* d, size_t n)
+{
+    if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
+    return b->ndt->add_target_device(d, n);
+}
+int mrgfe_batch_add_pair(mrgfe_batch* b, int target, const float* xyzi, size_t n, size_t stride, const float guess[16])
+{
+    if (!b || !guess) { set_error("NULL argument"); return MRGFE_ERR_INVALID; }
+    float g[16];
+    col2row(guess, g);
+    return b->ndt->add_pair_host(target, xyzi, n, stride, g);
+}
+int mrgfe_batch_add_pair_device(mrgfe_batch* b, int target, const void* d, size_t n, const float guess[16])
+{
+    if (!b || !guess) { set_error("NULL argument"); return MRGFE_ERR_INVALID; }
+    float g[16];
+    col2row(guess, g);
+    return b->ndt->add_pair_device(target, d, n, g);
+}
+int mrgfe_batch_set_guess(mrgfe_batch* b, int pair, const float guess[16])
+{
+    if (!b || !guess) { set_error("NULL argument"); return MRGFE_ERR_INVALID; }
+    float g[16];
+    col2row(guess, g);
+    return b->ndt->set_guess(pair, g);
+}
+int mrgfe_batch_build_targets(mrgfe_batch* b)
+{
+    if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
+    return b->ndt->build_targets();
+}
+int mrgfe_batch_num_pairs(const mrgfe_batch* b) { return b ? b->ndt->n_pairs() : 0; }
+
+int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_result* results)
+{
+    if (!b || !results) { set_error("mrgfe_batch_align: NULL argument"); return MRGFE_ERR_INVALID; }
+    NdtEngine& e = *b->ndt;
+    MRGFE_TRY(e.align_all());
+    const int P = e.n_pairs();
+    for (int i = 0; i < P; ++i) {
+        const NdtController& c = e.pair(i).ctl;
+        mrgfe_pair_result& r = results[i];
+        row2col(c.final_transformation(), r.T);
+        std::memcpy(r.H, c.hessian(), sizeof(r.H));
+        r.fitness = DBL_MAX;
+        r.trans_probability = c.trans_probability();
+        r.converged = c.converged() ? 1 : 0;
+        r.iterations = c.iterations();
+        r.evaluations = c.evaluations();
+        r.pair_id = i;
+    }
+    if (fitness_max_range >= 0) {
+        // getFitnessScore per pair: one exact-NN grid per distinct target
+        std::vector<NnGrid> grids(e.n_targets());
+        std::vector<char>   built(e.n_targets(), 0);
+        int st = MRGFE_OK;
+        for (int i = 0; i < P && st == MRGFE_OK; ++i) {
+            const NdtPairInfo& p = e.pair(i);
+            const NdtTargetInfo& t = e.target(p.target);
+            if (t.n == 0 || p.n == 0) continue;
+            if (!built[p.target]) { st = grids[p.target].build(b->ctx, t.d_pts, t.n, 1.0f); built[p.target] = 1; }
+            if (st == MRGFE_OK) st = grids[p.target].fitness(b->ctx, p.d_src, p.n, p.ctl.final_transformation(), fitness_max_range, &results[i].fitness);
+        }
+        for (auto& g : grids) g.release();
+        MRGFE_TRY(st);
+    }
+    return MRGFE_OK;
+}
+
+int mrgfe_batch_kernel_stats(const mrgfe_batch* b, double* ms, int64_t* launches, double* bytes)
+{
+    if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
+    if (ms) *ms = b->ndt->deriv_ms;
+    if (launches) *launches = b->ndt->deriv_launches;
+    if (bytes) *bytes = b->ndt->deriv_alg_bytes;
+    return MRGFE_OK;
+}
+
+// ---- diagnostics ----------------------------------------------------------------------------------------------
+int mrgfe_dbg_sort_pairs(mrgfe_ctx* ctx, const uint32_t* keys, const uint32_t* vals, size_t n, int key_bits, uint32_t* out_keys, uint32_t* out_vals)
+{
+    if (!ctx || (n && (!keys || !vals || !out_keys || !out_vals))) { set_error("mrgfe_dbg_sort_pairs: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(ctx->bind());
+    if (n == 0) return MRGFE_OK;
+    uint32_t  nn = static_cast<uint32_t>(n);
+    SliceTable tab;
+    tab.build(&nn, 1);
+    DevBuf &dk = ctx->scratch[2], &dv = ctx->scratch[3], &dkt = ctx->scratch[4], &dvt = ctx->scratch[5], &dh = ctx->scratch[6], &ds = ctx->scratch[0];
+    MRGFE_TRY(dk.ensure(n * 4)); MRGFE_TRY(dv.ensure(n * 4)); MRGFE_TRY(dkt.ensure(n * 4)); MRGFE_TRY(dvt.ensure(n * 4));
+    MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + 1)));
+    MRGFE_TRY(ds.ensure(sizeof(Slice)));
+    MRGFE_HIP_CHECK(hipMemcpy(ds.p, tab.h.data(), sizeof(Slice), hipMemcpyHostToDevice));
+    MRGFE_HIP_CHECK(hipMemcpy(dk.p, keys, n * 4, hipMemcpyHostToDevice));
+    MRGFE_HIP_CHECK(hipMemcpy(dv.p, vals, n * 4, hipMemcpyHostToDevice));
+    uint32_t *sk, *sv;
+    MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), ds.as<Slice>(), tab, key_bits, dh.as<uint32_t>(), &sk, &sv));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MRGFE_HIP_CHECK(hipMemcpy(out_keys, sk, n * 4, hipMemcpyDeviceToHost));
+    MRGFE_HIP_CHECK(hipMemcpy(out_vals, sv, n * 4, hipMemcpyDeviceToHost));
+    return MRGFE_OK;
+}
+
+int mrgfe_dbg_exclusive_scan(mrgfe_ctx* ctx, const uint32_t* in, size_t n, uint32_t* out, uint32_t* total)
+{
+    if (!ctx || !total || (n && (!in || !out))) { set_error("mrgfe_dbg_exclusive_scan: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(ctx->bind());
+    uint32_t  nn = static_cast<uint32_t>(n);
+    SliceTable tab;
+    tab.build(&nn, 1);
+    DevBuf &di = ctx->scratch[2], &dout = ctx->scratch[3], &db = ctx->scratch[8], &ds = ctx->scratch[0];
+    MRGFE_TRY(di.ensure(std::max<size_t>(n, 1) * 4)); MRGFE_TRY(dout.ensure(std::max<size_t>(n, 1) * 4));
+    MRGFE_TRY(db.ensure(sizeof(uint32_t) * (tab.total_blks + 8)));
+    MRGFE_TRY(ds.ensure(sizeof(Slice)));
+    MRGFE_HIP_CHECK(hipMemcpy(ds.p, tab.h.data(), sizeof(Slice), hipMemcpyHostToDevice));
+    if (n) MRGFE_HIP_CHECK(hipMemcpy(di.p, in, n * 4, hipMemcpyHostToDevice));
+    uint32_t* d_tot = db.as<uint32_t>() + tab.total_blks;
+    MRGFE_TRY(exclusive_scan(ctx, di.as<uint32_t>(), dout.as<uint32_t>(), ds.as<Slice>(), tab, db.as<uint32_t>(), d_tot));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (n) MRGFE_HIP_CHECK(hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost));
+    MRGFE_HIP_CHECK(hipMemcpy(total, d_tot, 4, hipMemcpyDeviceToHost));
+    return MRGFE_OK;
+}
+
+int mrgfe_dbg_minmax(mrgfe_ctx* ctx, const float* xyzi, size_t n, float min3[3], float max3[3], uint32_t* n_finite)
+{
+    if (!ctx || !min3 || !max3 || !n_finite || (n && !xyzi)) { set_error("mrgfe_dbg_minmax: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(ctx->bind());
+    uint32_t  nn = static_cast<uint32_t>(n);
+    SliceTable tab;
+    tab.build(&nn, 1);
+    DevBuf &dp = ctx->scratch[10], &dbb = ctx->scratch[1], &ds = ctx->scratch[0];
+    MRGFE_TRY(dp.ensure(std::max<size_t>(n, 1) * 16));
+    MRGFE_TRY(dbb.ensure(sizeof(BBox) * (tab.total_blks + 1)));
+    MRGFE_TRY(ds.ensure(sizeof(Slice) + sizeof(void*)));
+    MRGFE_TRY(upload_cloud(ctx, xyzi, n, 16, dp.p));
+    const void* cp = dp.p;
+    MRGFE_HIP_CHECK(hipMemcpy(ds.p, tab.h.data(), sizeof(Slice), hipMemcpyHostToDevice));
+    MRGFE_HIP_CHECK(hipMemcpy(ds.as<char>() + sizeof(Slice), &cp, sizeof(void*), hipMemcpyHostToDevice));
+    BBox* d_part = dbb.as<BBox>();
+    BBox* d_out = d_part + tab.total_blks;
+    MRGFE_TRY(bounding_boxes(ctx, reinterpret_cast<const float4* const*>(ds.as<char>() + sizeof(Slice)), ds.as<Slice>(), tab, d_part, d_out));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BBox bb;
+    MRGFE_HIP_CHECK(hipMemcpy(&bb, d_out, sizeof(BBox), hipMemcpyDeviceToHost));
+    for (int a = 0; a < 3; ++a) { min3[a] = bb.mn[a]; max3[a] = bb.mx[a]; }
+    *n_finite = bb.n_finite;
+    return MRGFE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+// csrc/cellsort.h — batched device primitives under every grid structure of the front end: bounding box,
+// stable LSD radix sort of (cell key, point index) pairs, exclusive scan, segment (run) detection.
+//
+// "Batched" = several independent problems per launch: blockIdx.y selects the problem, blockIdx.x a 2048-element
+// tile of it.  Problem p owns elements [off, off+n) of every per-element array and tiles [blk_off, blk_off+nblk)
+// of every per-tile array.
+#pragma once
+#include "common.h"
+
+namespace mrgfe {
+
+constexpr int kTile = 2048;  // elements per workgroup tile (256 threads x 8)
+
+struct Slice {
+    uint32_t n;        // elements of this problem
+    uint32_t off;      // first element in the packed per-element arrays
+    uint32_t blk_off;  // first tile in the packed per-tile arrays
+    uint32_t nblk;     // ceil(n / kTile)
+};
+
+// host-side helper: lays problems of sizes n[0..P) out back to back (offsets aligned to 4 elements)
+struct SliceTable {
+    std::vector<Slice> h;
+    uint32_t total_elems = 0, total_blks = 0, max_blks = 0;
+    void build(const uint32_t* n, int nprob);
+    int  nprob() const { return static_cast<int>(h.size()); }
+};
+
+struct BBox {  // result of bounding_boxes, one per problem (32 bytes)
+    float    mn[3];
+    uint32_t n_finite;
+    float    mx[3];
+    uint32_t pad;
+};
+
+// d_slices: device copy of SliceTable::h.  All functions enqueue on ctx->stream and do not synchronise.
+
+// min / max over finite points (pcl::getMinMax3D) of each problem. d_clouds[p] = packed float4 cloud of problem p.
+// d_partial needs total_blks BBox entries; d_out nprob entries.
+int bounding_boxes(mrgfe_ctx* ctx, const float4* const* d_clouds, const Slice* d_slices, const SliceTable& t, BBox* d_partial, BBox* d_out);
+
+// stable LSD radix sort by the low `key_bits` bits. Buffers ping-pong; *out_keys/*out_vals point at the sorted data
+// (either the input or the tmp buffers). d_hist needs (total_blks + nprob) * 256 words.
+int radix_sort_pairs(mrgfe_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, uint32_t* d_keys_tmp, uint32_t* d_vals_tmp, const Slice* d_slices,
+                     const SliceTable& t, int key_bits, uint32_t* d_hist, uint32_t** out_keys, uint32_t** out_vals);
+
+// exclusive prefix sum of uint32 per problem; d_totals[p] = sum. d_blk needs total_blks words. in == out allowed.
+int exclusive_scan(mrgfe_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, const Slice* d_slices, const SliceTable& t, uint32_t* d_blk, uint32_t* d_totals);
+
+// run heads of a sorted key array: d_flags[i] = 1 if i starts a run of equal keys among the first d_n_valid[p]
+// elements of problem p (the invalid keys sort behind them), else 0.
+int mark_run_heads(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, uint32_t* d_flags, const Slice* d_slices, const SliceTable& t, const uint32_t* d_n_valid);
+
+}  // namespace mrgfe

@@ -1,0 +1,329 @@
+// csrc/cellsort.hip — bounding box, stable LSD radix sort, exclusive scan and run-head marking for gfx950.
+//
+// These are HBM-bound integer passes: every kernel streams its slice with coalesced 4-byte or
+// 16-byte accesses, keeps the per-tile state (digit histogram, wave counters) in LDS and never reshapes the work
+// into a GEMM.  Grids are (tiles, problems): a 120k-point cloud is 59 tiles, a 64-pair batch 3.8k workgroups.
+#include "cellsort.h"
+#include "dev_utils.h"
+
+namespace mrgfe {
+
+void SliceTable::build(const uint32_t* n, int nprob)
+{
+    h.resize(nprob);
+    uint32_t off = 0, blk = 0;
+    max_blks = 0;
+    for (int p = 0; p < nprob; ++p) {
+        Slice s;
+        s.n = n[p];
+        s.off = off;
+        s.blk_off = blk;
+        s.nblk = (n[p] + kTile - 1) / kTile;
+        h[p] = s;
+        off += (n[p] + 3u) & ~3u;
+        blk += s.nblk;
+        max_blks = s.nblk > max_blks ? s.nblk : max_blks;
+    }
+    total_elems = off;
+    total_blks = blk;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// bounding boxes
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bbox_partial_kernel(const float4* const* __restrict__ clouds, const Slice* __restrict__ slices, BBox* __restrict__ partial)
+{
+    const Slice s = slices[blockIdx.y];
+    if (blockIdx.x >= s.nblk) return;
+    const uint32_t base = blockIdx.x * kTile;
+    const float4* __restrict__ pts = clouds[blockIdx.y];
+    float    mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kTile / 256; ++k) {
+        uint32_t i = base + k * 256 + threadIdx.x;
+        if (i < s.n) {
+            float4 p = pts[i];
+            if (finite3(p.x, p.y, p.z)) {
+                mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+                mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+                ++cnt;
+            }
+        }
+    }
+    __shared__ float    s_mn[4][3], s_mx[4][3];
+    __shared__ uint32_t s_cnt[4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = wave_min(mn[a]); mx[a] = wave_max(mx[a]); }
+    cnt = wave_sum(cnt);
+    if (lane_id() == 0) {
+        for (int a = 0; a < 3; ++a) { s_mn[wave_id()][a] = mn[a]; s_mx[wave_id()][a] = mx[a]; }
+        s_cnt[wave_id()] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        BBox b;
+        for (int a = 0; a < 3; ++a) {
+            b.mn[a] = fminf(fminf(s_mn[0][a], s_mn[1][a]), fminf(s_mn[2][a], s_mn[3][a]));
+            b.mx[a] = fmaxf(fmaxf(s_mx[0][a], s_mx[1][a]), fmaxf(s_mx[2][a], s_mx[3][a]));
+        }
+        b.n_finite = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        b.pad = 0;
+        partial[s.blk_off + blockIdx.x] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void bbox_final_kernel(const Slice* __restrict__ slices, const BBox* __restrict__ partial, BBox* __restrict__ out)
+{
+    const Slice s = slices[blockIdx.x];
+    float    mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    uint32_t cnt = 0;
+    for (uint32_t b = threadIdx.x; b < s.nblk; b += 256) {
+        BBox q = partial[s.blk_off + b];
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], q.mn[a]); mx[a] = fmaxf(mx[a], q.mx[a]); }
+        cnt += q.n_finite;
+    }
+    __shared__ float    s_mn[4][3], s_mx[4][3];
+    __shared__ uint32_t s_cnt[4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = wave_min(mn[a]); mx[a] = wave_max(mx[a]); }
+    cnt = wave_sum(cnt);
+    if (lane_id() == 0) {
+        for (int a = 0; a < 3; ++a) { s_mn[wave_id()][a] = mn[a]; s_mx[wave_id()][a] = mx[a]; }
+        s_cnt[wave_id()] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        BBox b;
+        for (int a = 0; a < 3; ++a) {
+            b.mn[a] = fminf(fminf(s_mn[0][a], s_mn[1][a]), fminf(s_mn[2][a], s_mn[3][a]));
+            b.mx[a] = fmaxf(fmaxf(s_mx[0][a], s_mx[1][a]), fmaxf(s_mx[2][a], s_mx[3][a]));
+        }
+        b.n_finite = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        b.pad = 0;
+        out[blockIdx.x] = b;
+    }
+}
+
+int bounding_boxes(mrgfe_ctx* ctx, const float4* const* d_clouds, const Slice* d_slices, const SliceTable& t, BBox* d_partial, BBox* d_out)
+{
+    if (t.nprob() == 0) return MRGFE_OK;
+    if (t.max_blks > 0) {
+        dim3 grid(t.max_blks, t.nprob());
+        hipLaunchKernelGGL(bbox_partial_kernel, grid, dim3(256), 0, ctx->stream, d_clouds, d_slices, d_partial);
+    }
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(t.nprob()), dim3(256), 0, ctx->stream, d_slices, d_partial, d_out);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// radix sort (8-bit digits, stable)
+// ------------------------------------------------------------------------------------------------------
+// pass 1: per-tile digit histogram, LDS atomics.  hist layout: [tile][256] so the scan kernel reads coalesced.
+__global__ __launch_bounds__(256) void rs_hist_kernel(const uint32_t* __restrict__ keys, const Slice* __restrict__ slices, uint32_t* __restrict__ hist, int shift)
+{
+    const Slice s = slices[blockIdx.y];
+    if (blockIdx.x >= s.nblk) return;
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kTile;
+#pragma unroll
+    for (int k = 0; k < kTile / 256; ++k) {
+        uint32_t i = base + k * 256 + threadIdx.x;
+        if (i < s.n) atomicAdd(&h[(keys[s.off + i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)(s.blk_off + blockIdx.x) * 256 + threadIdx.x] = h[threadIdx.x];
+}
+
+// pass 2: one workgroup per problem. Thread d turns column d of hist into an exclusive prefix over tiles, then the
+// 256 digit totals are scanned to digit bases (stored in digit_base[problem][256]).
+__global__ __launch_bounds__(256) void rs_scan_kernel(const Slice* __restrict__ slices, uint32_t* __restrict__ hist, uint32_t* __restrict__ digit_base)
+{
+    const Slice s = slices[blockIdx.x];
+    __shared__ uint32_t lds[8];
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < s.nblk; ++b) {
+        size_t   idx = (size_t)(s.blk_off + b) * 256 + threadIdx.x;
+        uint32_t v = hist[idx];
+        hist[idx] = run;
+        run += v;
+    }
+    uint32_t total;
+    uint32_t base = block_exclusive_scan<256>(run, lds, &total);
+    digit_base[(size_t)blockIdx.x * 256 + threadIdx.x] = base;
+}
+
+// pass 3: stable scatter. The tile is consumed in 8 rounds of 256 keys; inside a round the rank of a key among equal
+// digits is (keys of earlier rounds) + (keys of earlier waves) + (lower lanes of its own wave, by ballot matching).
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t* __restrict__ keys_out,
+                                                          uint32_t* __restrict__ vals_out, const Slice* __restrict__ slices, const uint32_t* __restrict__ hist,
+                                                          const uint32_t* __restrict__ digit_base, int shift)
+{
+    const Slice s = slices[blockIdx.y];
+    if (blockIdx.x >= s.nblk) return;
+    __shared__ uint32_t goff[256];        // global offset of this tile's first key of each digit
+    __shared__ uint32_t seen[256];        // keys of each digit consumed in earlier rounds
+    __shared__ uint32_t wcount[4][256];   // per-wave digit counts of the current round
+    goff[threadIdx.x] = digit_base[(size_t)blockIdx.y * 256 + threadIdx.x] + hist[(size_t)(s.blk_off + blockIdx.x) * 256 + threadIdx.x];
+    seen[threadIdx.x] = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wcount[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kTile;
+    const int      lane = lane_id(), w = wave_id();
+    for (int k = 0; k < kTile / 256; ++k) {
+        const uint32_t i = base + k * 256 + threadIdx.x;
+        const bool     valid = i < s.n;
+        uint32_t key = 0, val = 0;
+        if (valid) { key = keys[s.off + i]; val = vals[s.off + i]; }
+        const uint32_t d = (key >> shift) & 255u;
+        const uint64_t active = __ballot(valid);
+        const uint64_t m = wave_match_digit8(d, active);
+        const uint32_t lane_rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (valid && lane_rank == 0) wcount[w][d] = __popcll(m);
+        __syncthreads();
+        if (valid) {
+            uint32_t pre = seen[d];
+            for (int ww = 0; ww < w; ++ww) pre += wcount[ww][d];
+            const uint32_t pos = s.off + goff[d] + pre + lane_rank;
+            keys_out[pos] = key;
+            vals_out[pos] = val;
+        }
+        __syncthreads();
+        {
+            const uint32_t t = threadIdx.x;
+            seen[t] += wcount[0][t] + wcount[1][t] + wcount[2][t] + wcount[3][t];
+            wcount[0][t] = 0; wcount[1][t] = 0; wcount[2][t] = 0; wcount[3][t] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+int radix_sort_pairs(mrgfe_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, uint32_t* d_keys_tmp, uint32_t* d_vals_tmp, const Slice* d_slices, const SliceTable& t,
+                     int key_bits, uint32_t* d_hist, uint32_t** out_keys, uint32_t** out_vals)
+{
+    *out_keys = d_keys;
+    *out_vals = d_vals;
+    if (t.nprob() == 0 || t.max_blks == 0) return MRGFE_OK;
+    if (key_bits < 1) key_bits = 1;
+    if (key_bits > 32) key_bits = 32;
+    const int passes = (key_bits + 7) / 8;
+    uint32_t* digit_base = d_hist + (size_t)t.total_blks * 256;
+    uint32_t *ki = d_keys, *vi = d_vals, *ko = d_keys_tmp, *vo = d_vals_tmp;
+    dim3 grid(t.max_blks, t.nprob());
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * p;
+        hipLaunchKernelGGL(rs_hist_kernel, grid, dim3(256), 0, ctx->stream, ki, d_slices, d_hist, shift);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(t.nprob()), dim3(256), 0, ctx->stream, d_slices, d_hist, digit_base);
+        hipLaunchKernelGGL(rs_scatter_kernel, grid, dim3(256), 0, ctx->stream, ki, vi, ko, vo, d_slices, d_hist, digit_base, shift);
+        uint32_t* tk = ki; ki = ko; ko = tk;
+        uint32_t* tv = vi; vi = vo; vo = tv;
+    }
+    MRGFE_HIP_CHECK(hipGetLastError());
+    *out_keys = ki;
+    *out_vals = vi;
+    return MRGFE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// exclusive scan
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scan_tile_sum_kernel(const uint32_t* __restrict__ in, const Slice* __restrict__ slices, uint32_t* __restrict__ blk)
+{
+    const Slice s = slices[blockIdx.y];
+    if (blockIdx.x >= s.nblk) return;
+    const uint32_t base = blockIdx.x * kTile;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < kTile / 256; ++k) {
+        uint32_t i = base + k * 256 + threadIdx.x;
+        if (i < s.n) acc += in[s.off + i];
+    }
+    __shared__ uint32_t sw[4];
+    acc = wave_sum(acc);
+    if (lane_id() == 0) sw[wave_id()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[s.blk_off + blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
+}
+
+__global__ __launch_bounds__(256) void scan_tiles_kernel(const Slice* __restrict__ slices, uint32_t* __restrict__ blk, uint32_t* __restrict__ totals)
+{
+    const Slice s = slices[blockIdx.x];
+    __shared__ uint32_t lds[8];
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < s.nblk; b0 += 256) {
+        const uint32_t b = b0 + threadIdx.x;
+        uint32_t v = b < s.nblk ? blk[s.blk_off + b] : 0u;
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan<256>(v, lds, &total);
+        if (b < s.nblk) blk[s.blk_off + b] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const Slice* __restrict__ slices,
+                                                          const uint32_t* __restrict__ blk)
+{
+    const Slice s = slices[blockIdx.y];
+    if (blockIdx.x >= s.nblk) return;
+    __shared__ uint32_t lds[8];
+    // blocked arrangement: thread t owns 8 consecutive elements (two 16-byte accesses when fully inside the slice)
+    const uint32_t first = blockIdx.x * kTile + threadIdx.x * 8;
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (first + k < s.n) ? in[s.off + first + k] : 0u;
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { uint32_t t = v[k]; v[k] = tsum; tsum += t; }
+    uint32_t total;
+    const uint32_t pre = block_exclusive_scan<256>(tsum, lds, &total) + blk[s.blk_off + blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (first + k < s.n) out[s.off + first + k] = v[k] + pre;
+}
+
+int exclusive_scan(mrgfe_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, const Slice* d_slices, const SliceTable& t, uint32_t* d_blk, uint32_t* d_totals)
+{
+    if (t.nprob() == 0) return MRGFE_OK;
+    dim3 grid(t.max_blks ? t.max_blks : 1, t.nprob());
+    if (t.max_blks) hipLaunchKernelGGL(scan_tile_sum_kernel, grid, dim3(256), 0, ctx->stream, d_in, d_slices, d_blk);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(t.nprob()), dim3(256), 0, ctx->stream, d_slices, d_blk, d_totals);
+    if (t.max_blks) hipLaunchKernelGGL(scan_apply_kernel, grid, dim3(256), 0, ctx->stream, d_in, d_out, d_slices, d_blk);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// run heads
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void run_heads_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ flags, const Slice* __restrict__ slices, const uint32_t* __restrict__ n_valid)
+{
+    const Slice s = slices[blockIdx.y];
+    if (blockIdx.x >= s.nblk) return;
+    const uint32_t base = blockIdx.x * kTile;
+    const uint32_t nv = n_valid[blockIdx.y];
+#pragma unroll
+    for (int k = 0; k < kTile / 256; ++k) {
+        uint32_t i = base + k * 256 + threadIdx.x;
+        if (i < s.n) {
+            uint32_t f = 0;
+            if (i < nv) f = (i == 0) ? 1u : (keys[s.off + i - 1] != keys[s.off + i] ? 1u : 0u);
+            flags[s.off + i] = f;
+        }
+    }
+}
+
+int mark_run_heads(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, uint32_t* d_flags, const Slice* d_slices, const SliceTable& t, const uint32_t* d_n_valid)
+{
+    if (t.nprob() == 0 || t.max_blks == 0) return MRGFE_OK;
+    dim3 grid(t.max_blks, t.nprob());
+    hipLaunchKernelGGL(run_heads_kernel, grid, dim3(256), 0, ctx->stream, d_sorted_keys, d_flags, d_slices, d_n_valid);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
+}  // namespace mrgfe

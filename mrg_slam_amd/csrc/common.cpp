@@ -1,0 +1,164 @@
+// csrc/common.cpp — error reporting, device / pinned workspaces, context lifetime.
+#include "common.h"
+
+#include <cstdlib>
+
+namespace mrgfe {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+int DevBuf::ensure(size_t bytes)
+{
+    if (bytes <= cap) return MRGFE_OK;
+    size_t want = cap ? cap : 4096;
+    while (want < bytes) want += want / 2 + 4096;
+    want = (want + 255) & ~size_t(255);
+    if (p) { MRGFE_HIP_CHECK(hipFree(p)); p = nullptr; cap = 0; }
+    MRGFE_HIP_CHECK(hipMalloc(&p, want));
+    cap = want;
+    return MRGFE_OK;
+}
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+int PinBuf::ensure(size_t bytes)
+{
+    if (bytes <= cap) return MRGFE_OK;
+    size_t want = cap ? cap : 4096;
+    while (want < bytes) want += want / 2 + 4096;
+    if (p) { MRGFE_HIP_CHECK(hipHostFree(p)); p = nullptr; cap = 0; }
+    MRGFE_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return MRGFE_OK;
+}
+void PinBuf::release()
+{
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+int Arena::alloc(size_t bytes, void** out)
+{
+    bytes = (bytes + 255) & ~size_t(255);
+    if (bytes == 0) bytes = 256;
+    for (auto& c : chunks)
+        if (c.cap - c.used >= bytes) {
+            *out = static_cast<char*>(c.p) + c.used;
+            c.used += bytes;
+            return MRGFE_OK;
+        }
+    Chunk c;
+    c.cap = bytes > chunk_bytes ? bytes : chunk_bytes;
+    c.used = 0;
+    c.p = nullptr;
+    MRGFE_HIP_CHECK(hipMalloc(&c.p, c.cap));
+    *out = c.p;
+    c.used = bytes;
+    chunks.push_back(c);
+    return MRGFE_OK;
+}
+void Arena::reset()
+{
+    for (auto& c : chunks) c.used = 0;
+}
+void Arena::release()
+{
+    for (auto& c : chunks) (void)hipFree(c.p);
+    chunks.clear();
+}
+
+int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, void* d_dst, int pin_slot)
+{
+    if (n == 0) return MRGFE_OK;
+    if (stride_bytes == 0) stride_bytes = 16;
+    if (stride_bytes < 16 || (stride_bytes % 4) != 0) { set_error("point stride must be a multiple of 4 and >= 16 bytes (got %zu)", stride_bytes); return MRGFE_ERR_INVALID; }
+    PinBuf& pb = ctx->pin[pin_slot];
+    MRGFE_TRY(pb.ensure(n * 16));
+    float* dst = pb.as<float>();
+    if (stride_bytes == 16) {
+        std::memcpy(dst, xyzi, n * 16);
+    } else {
+        const char* src = reinterpret_cast<const char*>(xyzi);
+        for (size_t i = 0; i < n; ++i) std::memcpy(dst + 4 * i, src + i * stride_bytes, 16);
+    }
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_dst, dst, n * 16, hipMemcpyHostToDevice, ctx->stream));
+    // the staging buffer is reused by the next upload: wait for the copy engine to drain it
+    MRGFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MRGFE_OK;
+}
+
+}  // namespace mrgfe
+
+int mrgfe_ctx::bind()
+{
+    MRGFE_HIP_CHECK(hipSetDevice(device));
+    return MRGFE_OK;
+}
+
+extern "C" {
+
+const char* mrgfe_last_error(void) { return mrgfe::get_error(); }
+const char* mrgfe_version(void) { return "mrgfe 0.1 (gfx950)"; }
+
+int mrgfe_ctx_create(int device_id, mrgfe_ctx** out)
+{
+    if (!out) { mrgfe::set_error("mrgfe_ctx_create: out is NULL"); return MRGFE_ERR_INVALID; }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        mrgfe::set_error("no HIP device available (%s): libmrgfe has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return MRGFE_ERR_HIP;
+    }
+    if (device_id < 0 || device_id >= count) { mrgfe::set_error("device %d out of range (0..%d)", device_id, count - 1); return MRGFE_ERR_INVALID; }
+    mrgfe_ctx* c = new mrgfe_ctx();
+    c->device = device_id;
+    if (c->bind() != MRGFE_OK) { delete c; return MRGFE_ERR_HIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->cu_count = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        mrgfe::set_error("failed to create HIP stream / events");
+        delete c;
+        return MRGFE_ERR_HIP;
+    }
+    *out = c;
+    return MRGFE_OK;
+}
+
+void mrgfe_ctx_destroy(mrgfe_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& b : ctx->scratch) b.release();
+    for (auto& b : ctx->pin) b.release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int mrgfe_ctx_synchronize(mrgfe_ctx* ctx)
+{
+    if (!ctx) { mrgfe::set_error("NULL context"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(ctx->bind());
+    MRGFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MRGFE_OK;
+}
+
+void* mrgfe_ctx_stream(mrgfe_ctx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
+
+}  // extern "C"

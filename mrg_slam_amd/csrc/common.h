@@ -1,0 +1,77 @@
+// csrc/common.h — host-side plumbing shared by the translation units of libmrgfe.so:
+// error reporting, the per-GPU context (stream + grow-only device/pinned workspaces) and a bump arena.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mrgfe.h"
+
+namespace mrgfe {
+
+void set_error(const char* fmt, ...);
+
+#define MRGFE_HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                        \
+        hipError_t _e = (expr);                                                                                 \
+        if (_e != hipSuccess) {                                                                                 \
+            ::mrgfe::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);      \
+            return MRGFE_ERR_HIP;                                                                               \
+        }                                                                                                       \
+    } while (0)
+
+#define MRGFE_TRY(expr)              \
+    do {                             \
+        int _s = (expr);             \
+        if (_s != MRGFE_OK) return _s; \
+    } while (0)
+
+// grow-only device buffer (avoids a hipMalloc per scan: SURVEY.md §8b "Ownership")
+struct DevBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+    int    ensure(size_t bytes);
+    void   release();
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// grow-only pinned host buffer
+struct PinBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+    int    ensure(size_t bytes);
+    void   release();
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// bump allocator over a few large device chunks; pointers stay valid until reset()
+struct Arena {
+    struct Chunk { void* p; size_t cap; size_t used; };
+    std::vector<Chunk> chunks;
+    size_t chunk_bytes = size_t(64) << 20;
+    int  alloc(size_t bytes, void** out);
+    void reset();    // keep chunks, forget allocations
+    void release();  // free chunks
+};
+
+}  // namespace mrgfe
+
+struct mrgfe_ctx {
+    int          device = 0;
+    hipStream_t  stream = nullptr;
+    hipEvent_t   ev0 = nullptr, ev1 = nullptr;  // timing of the dominant kernel on `stream`
+    mrgfe::DevBuf scratch[12];                  // named by the algorithms that use them
+    mrgfe::PinBuf pin[4];
+    int          cu_count = 256;
+    int          bind();                        // hipSetDevice(device)
+};
+
+namespace mrgfe {
+// copy a strided host cloud into packed float4 device memory via the pinned staging buffer `pin_slot`
+int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, void* d_dst, int pin_slot = 0);
+}  // namespace mrgfe

@@ -1,0 +1,84 @@
+// csrc/dev_utils.h — device helpers for gfx950 (wave64): wave/block reductions and scans.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mrgfe {
+
+constexpr int kWave = 64;  // CDNA4 wavefront width (hard-coded: MI355X_MICROARCH.md "wave = 64 not 32")
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// ---- wave-level reductions through cross-lane shuffles (DPP / ds_bpermute, no LDS traffic) -------------------
+template <class T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;  // valid in lane 0
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v = fminf(v, __shfl_down(v, off, kWave));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, kWave));
+    return v;
+}
+
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        uint32_t t = __shfl_up(v, off, kWave);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// exclusive scan over a block of NT threads (NT multiple of 64, <= 1024). `lds` needs NT/64 + 1 words.
+// Returns the exclusive prefix of `v`; *block_total receives the sum over the block (same value in every thread).
+template <int NT>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t* block_total)
+{
+    constexpr int NW = NT / kWave;
+    const int lane = lane_id(), w = wave_id();
+    uint32_t incl = wave_inclusive_scan(v);
+    if (lane == kWave - 1) lds[w] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { uint32_t t = lds[i]; lds[i] = run; run += t; }
+        lds[NW] = run;
+    }
+    __syncthreads();
+    uint32_t res = incl - v + lds[w];
+    *block_total = lds[NW];
+    __syncthreads();  // lds may be reused by the caller
+    return res;
+}
+
+// lanes of the wave (among `active`) that hold the same 8-bit digit as this lane
+__device__ __forceinline__ uint64_t wave_match_digit8(uint32_t d, uint64_t active)
+{
+    uint64_t m = active;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool     bit = (d >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+    }
+    return m;
+}
+
+__device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
+
+}  // namespace mrgfe

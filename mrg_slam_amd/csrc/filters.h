@@ -1,0 +1,18 @@
+// csrc/filters.h — prefilter chain launchers (filters.hip). Device-pointer forms chain without leaving HBM; the
+// host-pointer forms back the C ABI (include/mrgfe.h).
+#pragma once
+#include "common.h"
+
+namespace mrgfe {
+
+int filter_distance_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, double near_t, double far_t, float4* d_out, size_t* out_n);
+int filter_voxelgrid_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, float leaf, int min_pts, float4* d_out, size_t* out_n, int* overflow);
+int filter_radius_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, double radius, int min_neighbors, float4* d_out, size_t* out_n);
+int filter_statistical_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, int mean_k, double stddev_mul, float4* d_out, size_t* out_n);
+
+int filter_distance(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double near_t, double far_t, float* out, size_t* out_n);
+int filter_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, float leaf, int min_pts, float* out, size_t* out_n, int* overflow);
+int filter_radius_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double radius, int min_neighbors, float* out, size_t* out_n);
+int filter_statistical_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, int mean_k, double stddev_mul, float* out, size_t* out_n);
+
+}  // namespace mrgfe

@@ -1,0 +1,315 @@
+// csrc/filters.hip — the prefilter chain of /root/reference/apps/prefiltering_component.cpp:149-151 on MI355X:
+//   distance_filter (:206-229)            flag + exclusive scan + order-preserving compaction
+//   pcl::VoxelGrid (:158-180)             bounding box -> voxel keys -> stable radix sort -> runs -> f32 centroids
+//   pcl::RadiusOutlierRemoval (:195-198)  neighbour counts on the radix-sorted grid (cell = radius) + compaction
+//   pcl::StatisticalOutlierRemoval (:189-192) k-NN mean distances on the grid, threshold from f64 statistics
+// All passes are streaming / gather kernels bound by HBM and L2; nothing here is GEMM-shaped.
+#include "filters.h"
+
+#include <cmath>
+#include <vector>
+
+#include "cellsort.h"
+#include "dev_float.h"
+#include "dev_utils.h"
+#include "ndt_build.h"
+#include "nn_grid.h"
+
+namespace mrgfe {
+
+// ---- shared: order-preserving compaction -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void compact_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos, uint32_t n,
+                                                       float4* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n && flags[i]) out[pos[i]] = in[i];
+}
+
+// scan flags (one problem) and compact; returns the kept count through *h_total (synchronises)
+static int scan_and_compact(mrgfe_ctx* ctx, const float4* d_in, uint32_t n, uint32_t* d_flags, float4* d_out, uint32_t* h_total)
+{
+    *h_total = 0;
+    if (n == 0) return MRGFE_OK;
+    hipStream_t st = ctx->stream;
+    SliceTable  tab;
+    tab.build(&n, 1);
+    DevBuf &ds = ctx->scratch[0], &dpos = ctx->scratch[4], &dblk = ctx->scratch[8];
+    MRGFE_TRY(ds.ensure(sizeof(Slice)));
+    MRGFE_TRY(dpos.ensure(size_t(n) * 4));
+    MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (tab.total_blks + 8)));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(ds.p, tab.h.data(), sizeof(Slice), hipMemcpyHostToDevice, st));
+    uint32_t* d_tot = dblk.as<uint32_t>() + tab.total_blks;
+    MRGFE_TRY(exclusive_scan(ctx, d_flags, dpos.as<uint32_t>(), ds.as<Slice>(), tab, dblk.as<uint32_t>(), d_tot));
+    hipLaunchKernelGGL(compact_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_in, d_flags, dpos.as<uint32_t>(), n, d_out);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    MRGFE_HIP_CHECK(hipMemcpyAsync(h_total, d_tot, 4, hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    return MRGFE_OK;
+}
+
+static int download(mrgfe_ctx* ctx, const void* d_src, size_t n, float* out)
+{
+    if (n == 0) return MRGFE_OK;
+    MRGFE_HIP_CHECK(hipMemcpyAsync(out, d_src, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MRGFE_OK;
+}
+
+// ---- distance filter -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void distance_flags_kernel(const float4* __restrict__ in, uint32_t n, double near_t, double far_t, uint32_t* __restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    // p.getVector3fMap().norm(): float sqrt((x*x + y*y) + z*z), compared as double with strict inequalities
+    const float  s = dot3f(p.x, p.x, p.y, p.y, p.z, p.z);
+    const double d = static_cast<double>(sqrtf(s));
+    flags[i] = (d > near_t && d < far_t) ? 1u : 0u;
+}
+
+int filter_distance_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, double near_t, double far_t, float4* d_out, size_t* out_n)
+{
+    *out_n = 0;
+    if (n == 0) return MRGFE_OK;
+    const uint32_t nn = static_cast<uint32_t>(n);
+    DevBuf& dfl = ctx->scratch[7];
+    MRGFE_TRY(dfl.ensure(n * 4));
+    hipLaunchKernelGGL(distance_flags_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, d_in, nn, near_t, far_t, dfl.as<uint32_t>());
+    uint32_t kept = 0;
+    MRGFE_TRY(scan_and_compact(ctx, d_in, nn, dfl.as<uint32_t>(), d_out, &kept));
+    *out_n = kept;
+    return MRGFE_OK;
+}
+
+// ---- voxel grid ------------------------------------------------------------------------------------------------
+// one thread per voxel run: float running sums in ascending point index (the stable order), then divide by the count
+__global__ __launch_bounds__(256) void voxel_centroid_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ seg_start,
+                                                              uint32_t n_seg, int min_pts, float4* __restrict__ centroids, uint32_t* __restrict__ keep)
+{
+#pragma clang fp contract(off)
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= n_seg) return;
+    const uint32_t b = seg_start[s], e = seg_start[s + 1];
+    float sx = 0, sy = 0, sz = 0, si = 0;
+    for (uint32_t k = b; k < e; ++k) {
+        const float4 p = pts[sorted_vals[k]];
+        sx += p.x; sy += p.y; sz += p.z; si += p.w;
+    }
+    const float cnt = static_cast<float>(e - b);
+    centroids[s] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+    keep[s] = (e - b) >= static_cast<uint32_t>(min_pts) ? 1u : 0u;
+}
+
+int filter_voxelgrid_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, float leaf, int min_pts, float4* d_out, size_t* out_n, int* overflow)
+{
+    *out_n = 0;
+    if (overflow) *overflow = 0;
+    if (n == 0) return MRGFE_OK;
+    hipStream_t st = ctx->stream;
+    uint32_t    nn = static_cast<uint32_t>(n);
+    SliceTable  tab;
+    tab.build(&nn, 1);
+    // descriptor block: slice | cloud ptr | n_valid | voxel params | leaf slice
+    struct Desc { Slice sl; const float4* cp; uint32_t nv; uint32_t pad; VoxelParams vp; LeafSlice ls; };
+    PinBuf& hp = ctx->pin[1];
+    MRGFE_TRY(hp.ensure(sizeof(Desc) + sizeof(BBox) + 16));
+    Desc* hd = hp.as<Desc>();
+    std::memset(hd, 0, sizeof(Desc));
+    hd->sl = tab.h[0];
+    hd->cp = d_in;
+    DevBuf& dd = ctx->scratch[0];
+    MRGFE_TRY(dd.ensure(sizeof(Desc)));
+    Desc* d_desc = dd.as<Desc>();
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_desc, hd, sizeof(Desc), hipMemcpyHostToDevice, st));
+    DevBuf& dbb = ctx->scratch[1];
+    MRGFE_TRY(dbb.ensure(sizeof(BBox) * (tab.total_blks + 1)));
+    BBox* d_part = dbb.as<BBox>();
+    BBox* d_bbo = d_part + tab.total_blks;
+    MRGFE_TRY(bounding_boxes(ctx, &d_desc->cp, &d_desc->sl, tab, d_part, d_bbo));
+    BBox* h_bb = reinterpret_cast<BBox*>(hp.as<char>() + sizeof(Desc));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(h_bb, d_bbo, sizeof(BBox), hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    if (h_bb->n_finite == 0) return MRGFE_OK;
+    int32_t max_b[3], div_b[3];
+    if (voxel_params_from_bbox(*h_bb, leaf, &hd->vp, max_b, div_b) != MRGFE_OK) {
+        // PCL: warn and pass the input through
+        if (overflow) *overflow = 1;
+        MRGFE_HIP_CHECK(hipMemcpyAsync(d_out, d_in, n * 16, hipMemcpyDeviceToDevice, st));
+        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+        *out_n = n;
+        return MRGFE_OK;
+    }
+    hd->nv = h_bb->n_finite;
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_desc, hd, sizeof(Desc), hipMemcpyHostToDevice, st));
+    int key_bits = 1;
+    while (key_bits < 32 && (uint64_t(1) << key_bits) <= hd->vp.n_cells) ++key_bits;
+    DevBuf &dk = ctx->scratch[2], &dv = ctx->scratch[3], &dkt = ctx->scratch[4], &dvt = ctx->scratch[5], &dh = ctx->scratch[6], &dfl = ctx->scratch[7], &dblk = ctx->scratch[8];
+    MRGFE_TRY(dk.ensure(n * 4)); MRGFE_TRY(dv.ensure(n * 4)); MRGFE_TRY(dkt.ensure(n * 4)); MRGFE_TRY(dvt.ensure(n * 4));
+    MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + 1)));
+    MRGFE_TRY(dfl.ensure(n * 4));
+    MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (tab.total_blks + 8)));
+    MRGFE_TRY(ndt_launch_cellkeys(ctx, &d_desc->cp, &d_desc->sl, tab, &d_desc->vp, dk.as<uint32_t>(), dv.as<uint32_t>()));
+    uint32_t *sk, *sv;
+    MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), &d_desc->sl, tab, key_bits, dh.as<uint32_t>(), &sk, &sv));
+    MRGFE_TRY(mark_run_heads(ctx, sk, dfl.as<uint32_t>(), &d_desc->sl, tab, &d_desc->nv));
+    uint32_t* d_ord = (sk == dk.as<uint32_t>()) ? dkt.as<uint32_t>() : dk.as<uint32_t>();
+    uint32_t* d_tot = dblk.as<uint32_t>() + tab.total_blks;
+    MRGFE_TRY(exclusive_scan(ctx, dfl.as<uint32_t>(), d_ord, &d_desc->sl, tab, dblk.as<uint32_t>(), d_tot));
+    uint32_t* h_tot = reinterpret_cast<uint32_t*>(hp.as<char>() + sizeof(Desc) + sizeof(BBox));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(h_tot, d_tot, 4, hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    const uint32_t V = *h_tot;
+    if (V == 0) return MRGFE_OK;
+    hd->ls.n_leaves = V;
+    hd->ls.leaf_off = 0;
+    hd->ls.seg_off = 0;
+    hd->ls.n_valid = hd->nv;
+    MRGFE_HIP_CHECK(hipMemcpyAsync(&d_desc->ls, &hd->ls, sizeof(LeafSlice), hipMemcpyHostToDevice, st));
+    DevBuf &dseg = ctx->scratch[9], &dcent = ctx->scratch[10], &dkeep = ctx->scratch[11];
+    MRGFE_TRY(dseg.ensure(sizeof(uint32_t) * (size_t(V) + 4) + sizeof(int32_t) * size_t(V)));
+    MRGFE_TRY(dcent.ensure(sizeof(float4) * size_t(V)));
+    MRGFE_TRY(dkeep.ensure(sizeof(uint32_t) * size_t(V)));
+    uint32_t* d_seg = dseg.as<uint32_t>();
+    int32_t*  d_segkey = reinterpret_cast<int32_t*>(d_seg + V + 4);
+    MRGFE_TRY(ndt_launch_segments(ctx, sk, dfl.as<uint32_t>(), d_ord, &d_desc->sl, tab, &d_desc->ls, d_seg, d_segkey));
+    hipLaunchKernelGGL(voxel_centroid_kernel, dim3((V + 255) / 256), dim3(256), 0, st, d_in, sv, d_seg, V, min_pts, dcent.as<float4>(), dkeep.as<uint32_t>());
+    MRGFE_HIP_CHECK(hipGetLastError());
+    uint32_t kept = 0;
+    MRGFE_TRY(scan_and_compact(ctx, dcent.as<float4>(), V, dkeep.as<uint32_t>(), d_out, &kept));
+    *out_n = kept;
+    return MRGFE_OK;
+}
+
+// ---- radius outlier removal ------------------------------------------------------------------------------------
+int filter_radius_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, double radius, int min_neighbors, float4* d_out, size_t* out_n)
+{
+    *out_n = 0;
+    if (n == 0) return MRGFE_OK;
+    NnGrid grid;
+    int st = grid.build(ctx, d_in, n, static_cast<float>(radius));
+    if (st == MRGFE_OK) {
+        DevBuf& dfl = ctx->scratch[7];
+        st = dfl.ensure(n * 4);
+        // inlier iff #{q: (double)sqdist <= radius*radius} >= min_neighbors + 1 (the point itself counts)
+        if (st == MRGFE_OK) st = grid.radius_count_flags(ctx, d_in, n, radius * radius, min_neighbors + 1, dfl.as<uint32_t>());
+        uint32_t kept = 0;
+        if (st == MRGFE_OK) st = scan_and_compact(ctx, d_in, static_cast<uint32_t>(n), dfl.as<uint32_t>(), d_out, &kept);
+        *out_n = kept;
+    }
+    grid.release();
+    return st;
+}
+
+// ---- statistical outlier removal -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sor_mean_dist_kernel(const float* __restrict__ sqd, uint32_t n, int k1, float* __restrict__ dist, uint32_t* __restrict__ valid)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float* row = sqd + size_t(i) * k1;
+    float  d = 0.0f;
+    uint32_t ok = 0;
+    if (row[k1 - 1] >= 0.0f) {  // all mean_k + 1 neighbours found
+        double sum = 0.0;
+        for (int j = 1; j < k1; ++j) sum += static_cast<double>(sqrtf(row[j]));  // k = 0 is the query point
+        d = static_cast<float>(sum / static_cast<double>(k1 - 1));
+        ok = 1;
+    }
+    dist[i] = d;
+    valid[i] = ok;
+}
+
+__global__ __launch_bounds__(256) void sor_flags_kernel(const float* __restrict__ dist, uint32_t n, double thr, uint32_t* __restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) flags[i] = (static_cast<double>(dist[i]) > thr) ? 0u : 1u;
+}
+
+int filter_statistical_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, int mean_k, double stddev_mul, float4* d_out, size_t* out_n)
+{
+    *out_n = 0;
+    if (n == 0) return MRGFE_OK;
+    hipStream_t    st = ctx->stream;
+    const uint32_t nn = static_cast<uint32_t>(n);
+    const int      k1 = mean_k + 1;
+    NnGrid grid;
+    int    rc = grid.build(ctx, d_in, n, 0.5f);
+    if (rc != MRGFE_OK) { grid.release(); return rc; }
+    DevBuf knn_i, knn_d, ddist;
+    auto cleanup = [&]() { grid.release(); knn_i.release(); knn_d.release(); ddist.release(); };
+    rc = knn_i.ensure(n * k1 * 4);
+    if (rc == MRGFE_OK) rc = knn_d.ensure(n * k1 * 4);
+    if (rc == MRGFE_OK) rc = ddist.ensure(n * 8);
+    if (rc == MRGFE_OK) rc = grid.knn_device(ctx, d_in, n, k1, knn_i.as<int32_t>(), knn_d.as<float>());
+    if (rc != MRGFE_OK) { cleanup(); return rc; }
+    float*    d_dist = ddist.as<float>();
+    uint32_t* d_valid = reinterpret_cast<uint32_t*>(d_dist + n);
+    hipLaunchKernelGGL(sor_mean_dist_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, knn_d.as<float>(), nn, k1, d_dist, d_valid);
+    // PCL's mean / variance: sequential f64 sums over the float distances (float square) - done on the host in that order
+    std::vector<float>    h_dist(n);
+    std::vector<uint32_t> h_valid(n);
+    if (hipMemcpyAsync(h_dist.data(), d_dist, n * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(h_valid.data(), d_valid, n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        cleanup();
+        set_error("statistical outlier: device to host copy failed");
+        return MRGFE_ERR_HIP;
+    }
+    double sum = 0, sq_sum = 0;
+    size_t valid = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const float d2 = h_dist[i] * h_dist[i];
+        sum += h_dist[i];
+        sq_sum += d2;
+        valid += h_valid[i];
+    }
+    const double mean = sum / static_cast<double>(valid);
+    const double variance = (sq_sum - sum * sum / static_cast<double>(valid)) / (static_cast<double>(valid) - 1);
+    const double thr = mean + stddev_mul * std::sqrt(variance);
+    DevBuf& dfl = ctx->scratch[7];
+    rc = dfl.ensure(n * 4);
+    if (rc == MRGFE_OK) {
+        hipLaunchKernelGGL(sor_flags_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, d_dist, nn, thr, dfl.as<uint32_t>());
+        uint32_t kept = 0;
+        rc = scan_and_compact(ctx, d_in, nn, dfl.as<uint32_t>(), d_out, &kept);
+        *out_n = kept;
+    }
+    cleanup();
+    return rc;
+}
+
+// ---- host-pointer wrappers (the C ABI) -------------------------------------------------------------------------
+template <class F>
+static int host_wrap(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, float* out, size_t* out_n, F&& f)
+{
+    *out_n = 0;
+    if (n == 0) return MRGFE_OK;
+    DevBuf din, dout;  // per-call buffers: the scratch slots are all in use by the algorithms
+    int rc = din.ensure(n * 16);
+    if (rc == MRGFE_OK) rc = dout.ensure(n * 16);
+    if (rc == MRGFE_OK) rc = upload_cloud(ctx, xyzi, n, stride, din.p);
+    size_t m = 0;
+    if (rc == MRGFE_OK) rc = f(din.as<float4>(), dout.as<float4>(), &m);
+    if (rc == MRGFE_OK) rc = download(ctx, dout.p, m, out);
+    if (rc == MRGFE_OK) *out_n = m;
+    din.release();
+    dout.release();
+    return rc;
+}
+
+int filter_distance(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double near_t, double far_t, float* out, size_t* out_n)
+{
+    return host_wrap(ctx, xyzi, n, stride, out, out_n, [&](const float4* i, float4* o, size_t* m) { return filter_distance_device(ctx, i, n, near_t, far_t, o, m); });
+}
+int filter_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, float leaf, int min_pts, float* out, size_t* out_n, int* overflow)
+{
+    return host_wrap(ctx, xyzi, n, stride, out, out_n, [&](const float4* i, float4* o, size_t* m) { return filter_voxelgrid_device(ctx, i, n, leaf, min_pts, o, m, overflow); });
+}
+int filter_radius_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double radius, int min_neighbors, float* out, size_t* out_n)
+{
+    return host_wrap(ctx, xyzi, n, stride, out, out_n, [&](const float4* i, float4* o, size_t* m) { return filter_radius_outlier_device(ctx, i, n, radius, min_neighbors, o, m); });
+}
+int filter_statistical_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, int mean_k, double stddev_mul, float* out, size_t* out_n)
+{
+    return host_wrap(ctx, xyzi, n, stride, out, out_n, [&](const float4* i, float4* o, size_t* m) { return filter_statistical_outlier_device(ctx, i, n, mean_k, stddev_mul, o, m); });
+}
+
+}  // namespace mrgfe

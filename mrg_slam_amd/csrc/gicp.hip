@@ -1,0 +1,498 @@
+// csrc/gicp.hip — GICP_HIP: fast_gicp::FastGICP<PointXYZI,PointXYZI> + fast_gicp::LsqRegistration (Levenberg-Marquardt)
+// on MI355X, the registration the reference's code default selects (/root/reference/src/mrg_slam/registrations.cpp:55-63;
+// parameter "registration_method" default "FAST_GICP", apps/scan_matching_odometry_component.cpp:122). SURVEY.md A.6.
+//
+// Device side (KNN correspondence path of BASELINE config 3):
+//   covariances : k-NN on the radix-sorted grid -> 3x3 sample covariance -> PLANE regularisation (1, 1, 1e-3)   [per cloud, once]
+//   linearize   : per source point transform -> exact 1-NN within max_correspondence_distance -> Mahalanobis matrix
+//                 (C_B + R C_A R^T)^-1 -> J^T M J (21), J^T M r (6), r^T M r, reduced like the NDT kernel        [per LM outer step]
+//   error       : r^T M r with the stored correspondences / Mahalanobis matrices                                  [per LM trial]
+// Host side: the LM loop (step_lm, is_converged, se3_exp) - a few 6x6 solves per iteration.
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "dev_float.h"
+#include "dev_linalg.h"
+#include "dev_utils.h"
+#include "gicp_engine.h"
+#include "nn_device.h"
+#include "ndt_derivatives.h"  // launch_transform_cloud
+
+namespace mrgfe {
+
+constexpr int kGicpStride = 32;  // partial record: err, b[6], H upper[21], n_corr, pad
+
+__device__ __forceinline__ int gidx(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+
+// ---- covariances -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gicp_cov_kernel(const float4* __restrict__ pts, uint32_t n, const int32_t* __restrict__ knn, int k, double* __restrict__ cov6)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const int32_t* nb = knn + size_t(i) * k;
+    double mean[3] = {0, 0, 0};
+    for (int j = 0; j < k; ++j) {
+        const int32_t id = nb[j];
+        if (id < 0) continue;
+        const float4 p = pts[id];
+        mean[0] += p.x; mean[1] += p.y; mean[2] += p.z;
+    }
+    mean[0] /= k; mean[1] /= k; mean[2] /= k;
+    double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < k; ++j) {
+        const int32_t id = nb[j];
+        if (id < 0) continue;
+        const float4 p = pts[id];
+        const double d[3] = {static_cast<double>(p.x) - mean[0], static_cast<double>(p.y) - mean[1], static_cast<double>(p.z) - mean[2]};
+        for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) c[r * 3 + cc] += d[r] * d[cc];
+    }
+    for (int t = 0; t < 9; ++t) c[t] /= k;
+    double w[3], E[9];
+    dl_sym_eig3(c, w, E);                       // ascending
+    const double vals[3] = {1e-3, 1.0, 1.0};   // RegularizationMethod::PLANE, singular values (1, 1, 1e-3) descending
+    double out[9];
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc) {
+            double s = 0;
+            for (int m = 0; m < 3; ++m) s += E[r * 3 + m] * vals[m] * E[cc * 3 + m];
+            out[r * 3 + cc] = s;
+        }
+    double* o = cov6 + size_t(i) * 6;
+    o[0] = out[0]; o[1] = out[1]; o[2] = out[2]; o[3] = out[4]; o[4] = out[5]; o[5] = out[8];
+}
+
+struct GicpPose {
+    double T[12];   // row-major 3x4, double
+    float  Tf[12];  // trans.cast<float>()
+};
+
+// shared tail: block reduction of 29 doubles into one partial record
+__device__ __forceinline__ void gicp_block_reduce(double (&vals)[29], double* __restrict__ partial_out, int first_used_h)
+{
+    __shared__ double s_red[4][kGicpStride];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) {
+        if (k >= 1 && k < 28 && k >= first_used_h) continue;  // entries not produced by this kernel variant
+        const double r = wave_sum(vals[k]);
+        if (lane_id() == 0) s_red[wave_id()][k] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < kGicpStride) {
+        const int  k = threadIdx.x;
+        const bool skip = k >= 29 || (k >= 1 && k < 28 && k >= first_used_h);
+        double     r = 0.0;
+        if (!skip) r = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
+        partial_out[k] = r;
+    }
+}
+
+// update_correspondences + linearize
+__global__ __launch_bounds__(256) void gicp_linearize_kernel(NnGridDev g, const float4* __restrict__ src, uint32_t n, const float4* __restrict__ tgt,
+                                                              const double* __restrict__ cov_src, const double* __restrict__ cov_tgt, GicpPose pose, double thr2,
+                                                              int32_t* __restrict__ corr, double* __restrict__ mahal, double* __restrict__ partials)
+{
+#pragma clang fp contract(off)
+    double vals[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) vals[k] = 0.0;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) {
+        const float4 a = src[i];
+        // trans_f * Vector4f(x, y, z, 1): accumulated column by column
+        float q[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float s = pose.Tf[r * 4 + 0] * a.x;
+            s = s + pose.Tf[r * 4 + 1] * a.y;
+            s = s + pose.Tf[r * 4 + 2] * a.z;
+            q[r] = s + pose.Tf[r * 4 + 3];
+        }
+        int32_t j = -1;
+        float   sqd = INFINITY;
+        nn_nearest(g, q[0], q[1], q[2], j, sqd);
+        if (j >= 0 && !(static_cast<double>(sqd) < thr2)) j = -1;
+        corr[i] = j;
+        if (j >= 0) {
+            const double* cA = cov_src + size_t(i) * 6;
+            const double* cB = cov_tgt + size_t(j) * 6;
+            const double A[9] = {cA[0], cA[1], cA[2], cA[1], cA[3], cA[4], cA[2], cA[4], cA[5]};
+            const double R[9] = {pose.T[0], pose.T[1], pose.T[2], pose.T[4], pose.T[5], pose.T[6], pose.T[8], pose.T[9], pose.T[10]};
+            double RC[9], Rt[9], RCR[9], M[9];
+            dl_mul3(R, A, RC);
+            for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) Rt[r * 3 + cc] = R[cc * 3 + r];
+            dl_mul3(RC, Rt, RCR);
+            RCR[0] += cB[0]; RCR[1] += cB[1]; RCR[2] += cB[2]; RCR[3] += cB[1]; RCR[4] += cB[3]; RCR[5] += cB[4]; RCR[6] += cB[2]; RCR[7] += cB[4]; RCR[8] += cB[5];
+            dl_inv3(RCR, M);
+            double* mo = mahal + size_t(i) * 9;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) mo[t] = M[t];
+            const float4 b = tgt[j];
+            const double mA[3] = {a.x, a.y, a.z};
+            double tA[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) tA[r] = pose.T[r * 4 + 0] * mA[0] + pose.T[r * 4 + 1] * mA[1] + pose.T[r * 4 + 2] * mA[2] + pose.T[r * 4 + 3];
+            const double err[3] = {static_cast<double>(b.x) - tA[0], static_cast<double>(b.y) - tA[1], static_cast<double>(b.z) - tA[2]};
+            double Me[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) Me[r] = M[r * 3 + 0] * err[0] + M[r * 3 + 1] * err[1] + M[r * 3 + 2] * err[2];
+            vals[0] = err[0] * Me[0] + err[1] * Me[1] + err[2] * Me[2];
+            // J = [ skew(tA) | -I ]
+            const double J[3][6] = {{0, -tA[2], tA[1], -1, 0, 0}, {tA[2], 0, -tA[0], 0, -1, 0}, {-tA[1], tA[0], 0, 0, 0, -1}};
+            double MJ[3][6];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) MJ[r][cc] = M[r * 3 + 0] * J[0][cc] + M[r * 3 + 1] * J[1][cc] + M[r * 3 + 2] * J[2][cc];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                vals[1 + r] = J[0][r] * Me[0] + J[1][r] * Me[1] + J[2][r] * Me[2];
+#pragma unroll
+                for (int cc = r; cc < 6; ++cc) vals[7 + gidx(r, cc)] = J[0][r] * MJ[0][cc] + J[1][r] * MJ[1][cc] + J[2][r] * MJ[2][cc];
+            }
+            vals[28] = 1.0;
+        }
+    }
+    gicp_block_reduce(vals, partials + size_t(blockIdx.x) * kGicpStride, 28);
+}
+
+// compute_error: stored correspondences and Mahalanobis matrices, new pose
+__global__ __launch_bounds__(256) void gicp_error_kernel(const float4* __restrict__ src, uint32_t n, const float4* __restrict__ tgt, GicpPose pose, const int32_t* __restrict__ corr,
+                                                          const double* __restrict__ mahal, double* __restrict__ partials)
+{
+#pragma clang fp contract(off)
+    double vals[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) vals[k] = 0.0;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) {
+        const int32_t j = corr[i];
+        if (j >= 0) {
+            const float4  a = src[i], b = tgt[j];
+            const double* M = mahal + size_t(i) * 9;
+            const double  mA[3] = {a.x, a.y, a.z};
+            double tA[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) tA[r] = pose.T[r * 4 + 0] * mA[0] + pose.T[r * 4 + 1] * mA[1] + pose.T[r * 4 + 2] * mA[2] + pose.T[r * 4 + 3];
+            const double err[3] = {static_cast<double>(b.x) - tA[0], static_cast<double>(b.y) - tA[1], static_cast<double>(b.z) - tA[2]};
+            double Me[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) Me[r] = M[r * 3 + 0] * err[0] + M[r * 3 + 1] * err[1] + M[r * 3 + 2] * err[2];
+            vals[0] = err[0] * Me[0] + err[1] * Me[1] + err[2] * Me[2];
+            vals[28] = 1.0;
+        }
+    }
+    gicp_block_reduce(vals, partials + size_t(blockIdx.x) * kGicpStride, 1);
+}
+
+__global__ __launch_bounds__(256) void gicp_reduce_kernel(const double* __restrict__ partials, uint32_t nblk, double* __restrict__ out)
+{
+    __shared__ double s[8][kGicpStride];
+    const int k = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    double    acc = 0.0;
+    for (uint32_t b = slice; b < nblk; b += 8) acc += partials[size_t(b) * kGicpStride + k];
+    s[slice][k] = acc;
+    __syncthreads();
+    if (threadIdx.x < kGicpStride) {
+        double r = s[0][k];
+#pragma unroll
+        for (int sl = 1; sl < 8; ++sl) r += s[sl][k];
+        out[k] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+void so3_exp_matrix(const double w[3], double R[9])
+{
+    const double theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    double imag, real;
+    if (theta_sq < 1e-10) {
+        const double quad = theta_sq * theta_sq;
+        imag = 0.5 - 1.0 / 48.0 * theta_sq + 1.0 / 3840.0 * quad;
+        real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * quad;
+    } else {
+        const double theta = std::sqrt(theta_sq), half = 0.5 * theta;
+        imag = std::sin(half) / theta;
+        real = std::cos(half);
+    }
+    const double qw = real, qx = imag * w[0], qy = imag * w[1], qz = imag * w[2];
+    const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+void se3_exp(const double a[6], double T[16])
+{
+    const double w[3] = {a[0], a[1], a[2]};
+    const double theta = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    double R[9];
+    so3_exp_matrix(w, R);
+    const double Om[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double Om2[9], V[9];
+    dl_mul3(Om, Om, Om2);
+    if (theta < 1e-10) {
+        std::memcpy(V, R, sizeof(V));
+    } else {
+        const double tsq = theta * theta;
+        const double c1 = (1.0 - std::cos(theta)) / tsq, c2 = (theta - std::sin(theta)) / (tsq * theta);
+        for (int t = 0; t < 9; ++t) V[t] = ((t % 4 == 0) ? 1.0 : 0.0) + c1 * Om[t] + c2 * Om2[t];
+    }
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) T[r * 4 + c] = R[r * 3 + c];
+        T[r * 4 + 3] = V[r * 3 + 0] * a[3] + V[r * 3 + 1] * a[4] + V[r * 3 + 2] * a[5];
+    }
+    T[12] = T[13] = T[14] = 0;
+    T[15] = 1;
+}
+
+void mul4(const double A[16], const double B[16], double o[16])
+{
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) { double s = 0; for (int k = 0; k < 4; ++k) s += A[r * 4 + k] * B[k * 4 + c]; o[r * 4 + c] = s; }
+}
+
+// symmetric positive (semi) definite solve through LDL^T without pivoting, falling back to pivoted elimination
+void solve6(const double A_in[36], const double rhs[6], double x[6])
+{
+    double A[6][7];
+    for (int r = 0; r < 6; ++r) { for (int c = 0; c < 6; ++c) A[r][c] = A_in[r * 6 + c]; A[r][6] = rhs[r]; }
+    for (int k = 0; k < 6; ++k) {
+        int piv = k;
+        for (int r = k + 1; r < 6; ++r) if (std::fabs(A[r][k]) > std::fabs(A[piv][k])) piv = r;
+        if (piv != k) for (int c = 0; c < 7; ++c) std::swap(A[k][c], A[piv][c]);
+        for (int r = k + 1; r < 6; ++r) {
+            const double f = A[r][k] / A[k][k];
+            for (int c = k; c < 7; ++c) A[r][c] -= f * A[k][c];
+        }
+    }
+    for (int r = 5; r >= 0; --r) {
+        double s = A[r][6];
+        for (int c = r + 1; c < 6; ++c) s -= A[r][c] * x[c];
+        x[r] = s / A[r][r];
+    }
+}
+
+bool is_converged(const double d[16], double rot_eps, double trans_eps)
+{
+    double mx = 0;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) mx = std::max(mx, 1.0 / rot_eps * std::fabs(d[r * 4 + c] - (r == c ? 1.0 : 0.0)));
+        mx = std::max(mx, 1.0 / trans_eps * std::fabs(d[r * 4 + 3]));
+    }
+    return mx < 1;
+}
+
+GicpPose make_pose(const double T[16])
+{
+    GicpPose p;
+    for (int i = 0; i < 12; ++i) { p.T[i] = T[i]; p.Tf[i] = static_cast<float>(T[i]); }
+    return p;
+}
+
+}  // namespace
+
+GicpEngine::~GicpEngine()
+{
+    if (ctx_) (void)hipSetDevice(ctx_->device);
+    tgt_grid_.release();
+    d_tgt_cov_.release(); d_src_cov_.release(); d_corr_.release(); d_mahal_.release(); d_partial_.release(); d_T_.release();
+}
+
+int GicpEngine::set_target(const void* d, size_t n)
+{
+    d_tgt_ = static_cast<const float4*>(d);
+    n_tgt_ = n;
+    tgt_grid_valid_ = tgt_cov_valid_ = false;
+    return MRGFE_OK;
+}
+int GicpEngine::set_source(const void* d, size_t n)
+{
+    d_src_ = static_cast<const float4*>(d);
+    n_src_ = n;
+    src_cov_valid_ = false;
+    return MRGFE_OK;
+}
+
+int GicpEngine::compute_covariances(const float4* d_pts, size_t n, DevBuf& out)
+{
+    MRGFE_TRY(out.ensure(std::max<size_t>(n, 1) * 48));
+    if (n == 0) return MRGFE_OK;
+    const int k = prm_.k_correspondences;
+    NnGrid  grid;
+    DevBuf  di, dd;
+    int rc = grid.build(ctx_, d_pts, n, 0.5f);
+    if (rc == MRGFE_OK) rc = di.ensure(n * k * 4);
+    if (rc == MRGFE_OK) rc = dd.ensure(n * k * 4);
+    if (rc == MRGFE_OK) rc = grid.knn_device(ctx_, d_pts, n, k, di.as<int32_t>(), dd.as<float>());
+    if (rc == MRGFE_OK) {
+        const uint32_t nn = static_cast<uint32_t>(n);
+        hipLaunchKernelGGL(gicp_cov_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx_->stream, d_pts, nn, di.as<int32_t>(), k, out.as<double>());
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx_->stream) != hipSuccess) { set_error("gicp covariance kernel failed"); rc = MRGFE_ERR_HIP; }
+    }
+    grid.release(); di.release(); dd.release();
+    return rc;
+}
+
+int GicpEngine::ensure_ready()
+{
+    if (!d_tgt_ && n_tgt_) { set_error("GICP: no target"); return MRGFE_ERR_STATE; }
+    MRGFE_TRY(ctx_->bind());
+    if (!src_cov_valid_) { MRGFE_TRY(compute_covariances(d_src_, n_src_, d_src_cov_)); src_cov_valid_ = true; }
+    if (!tgt_cov_valid_) { MRGFE_TRY(compute_covariances(d_tgt_, n_tgt_, d_tgt_cov_)); tgt_cov_valid_ = true; }
+    if (!tgt_grid_valid_) { MRGFE_TRY(tgt_grid_.build(ctx_, d_tgt_, n_tgt_, 1.0f)); tgt_grid_valid_ = true; }
+    const size_t ns = std::max<size_t>(n_src_, 1);
+    MRGFE_TRY(d_corr_.ensure(ns * 4));
+    MRGFE_TRY(d_mahal_.ensure(ns * 72));
+    MRGFE_TRY(d_partial_.ensure(sizeof(double) * kGicpStride * ((ns + 255) / 256 + 1)));
+    return MRGFE_OK;
+}
+
+int GicpEngine::covariances(int which, double* out9)
+{
+    MRGFE_TRY(ensure_ready());
+    const size_t n = which == 0 ? n_src_ : n_tgt_;
+    std::vector<double> c6(n * 6);
+    if (n) MRGFE_HIP_CHECK(hipMemcpy(c6.data(), (which == 0 ? d_src_cov_ : d_tgt_cov_).p, n * 48, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) {
+        const double* c = &c6[i * 6];
+        double* o = out9 + i * 9;
+        o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[1]; o[4] = c[3]; o[5] = c[4]; o[6] = c[2]; o[7] = c[4]; o[8] = c[5];
+    }
+    return MRGFE_OK;
+}
+
+int GicpEngine::run_linearize(const double T[16], bool, double H[36], double b[6], double* err, int* n_corr)
+{
+    ++n_linearize_;
+    *err = 0;
+    if (n_corr) *n_corr = 0;
+    for (int t = 0; t < 36; ++t) H[t] = 0;
+    for (int t = 0; t < 6; ++t) b[t] = 0;
+    if (n_src_ == 0) return MRGFE_OK;
+    hipStream_t    st = ctx_->stream;
+    const uint32_t n = static_cast<uint32_t>(n_src_), nblk = (n + 255) / 256;
+    double* d_part = d_partial_.as<double>();
+    double* d_res = d_part + size_t(nblk) * kGicpStride;
+    MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev0, st));
+    hipLaunchKernelGGL(gicp_linearize_kernel, dim3(nblk), dim3(256), 0, st, tgt_grid_.dev(), d_src_, n, d_tgt_, d_src_cov_.as<double>(), d_tgt_cov_.as<double>(), make_pose(T),
+                       prm_.max_corr_dist * prm_.max_corr_dist, d_corr_.as<int32_t>(), d_mahal_.as<double>(), d_part);
+    MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev1, st));
+    hipLaunchKernelGGL(gicp_reduce_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, d_res);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    double r[kGicpStride];
+    MRGFE_HIP_CHECK(hipMemcpyAsync(r, d_res, sizeof(r), hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    float ms = 0;
+    MRGFE_HIP_CHECK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
+    kernel_ms += ms;
+    kernel_launches += 1;
+    // SURVEY.md §8(d) GICP byte model with the measured correspondence count: src point + cov + probes + matched target point + cov
+    kernel_alg_bytes += double(n) * (16 + 48 + 27 * 8) + r[28] * (16 + 48);
+    *err = r[0];
+    for (int t = 0; t < 6; ++t) b[t] = r[1 + t];
+    int t = 7;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) { H[i * 6 + j] = r[t]; H[j * 6 + i] = r[t]; ++t; }
+    if (n_corr) *n_corr = static_cast<int>(r[28]);
+    return MRGFE_OK;
+}
+
+int GicpEngine::run_error(const double T[16], double* err)
+{
+    ++n_error_;
+    *err = 0;
+    if (n_src_ == 0) return MRGFE_OK;
+    hipStream_t    st = ctx_->stream;
+    const uint32_t n = static_cast<uint32_t>(n_src_), nblk = (n + 255) / 256;
+    double* d_part = d_partial_.as<double>();
+    double* d_res = d_part + size_t(nblk) * kGicpStride;
+    hipLaunchKernelGGL(gicp_error_kernel, dim3(nblk), dim3(256), 0, st, d_src_, n, d_tgt_, make_pose(T), d_corr_.as<int32_t>(), d_mahal_.as<double>(), d_part);
+    hipLaunchKernelGGL(gicp_reduce_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, d_res);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    double r[kGicpStride];
+    MRGFE_HIP_CHECK(hipMemcpyAsync(r, d_res, sizeof(r), hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    *err = r[0];
+    return MRGFE_OK;
+}
+
+int GicpEngine::linearize(const double T[16], double H[36], double b[6], double* err, int* n_corr)
+{
+    MRGFE_TRY(ensure_ready());
+    return run_linearize(T, true, H, b, err, n_corr);
+}
+
+int GicpEngine::align(const float guess[16])
+{
+    MRGFE_TRY(ensure_ready());
+    kernel_ms = 0; kernel_launches = 0; kernel_alg_bytes = 0;
+    double x0[16];
+    for (int i = 0; i < 16; ++i) x0[i] = static_cast<double>(guess[i]);
+    double lm_lambda = -1.0;
+    converged_ = false;
+    nr_iterations_ = 0;
+    n_linearize_ = n_error_ = 0;
+    for (int t = 0; t < 36; ++t) final_hessian_[t] = (t % 7 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < prm_.max_iterations && !converged_; ++i) {
+        nr_iterations_ = i;
+        double H[36], b[6], delta[16], y0;
+        MRGFE_TRY(run_linearize(x0, true, H, b, &y0, nullptr));
+        if (lm_lambda < 0.0) {
+            double md = 0;
+            for (int d = 0; d < 6; ++d) md = std::max(md, std::fabs(H[d * 6 + d]));
+            lm_lambda = prm_.lm_init_lambda_factor * md;
+        }
+        double nu = 2.0;
+        bool   ok = false;
+        for (int it = 0; it < prm_.lm_max_iterations; ++it) {
+            double A[36], nb[6], d[6], xi[16], yi;
+            for (int t = 0; t < 36; ++t) A[t] = H[t] + ((t % 7 == 0) ? lm_lambda : 0.0);
+            for (int t = 0; t < 6; ++t) nb[t] = -b[t];
+            solve6(A, nb, d);
+            se3_exp(d, delta);
+            mul4(delta, x0, xi);
+            MRGFE_TRY(run_error(xi, &yi));
+            double denom = 0;
+            for (int t = 0; t < 6; ++t) denom += d[t] * (lm_lambda * d[t] - b[t]);
+            const double rho = (y0 - yi) / denom;
+            if (rho < 0) {
+                if (is_converged(delta, prm_.rot_eps, prm_.trans_eps)) { ok = true; break; }
+                lm_lambda = nu * lm_lambda;
+                nu = 2 * nu;
+                continue;
+            }
+            std::memcpy(x0, xi, sizeof(xi));
+            lm_lambda = lm_lambda * std::max(1.0 / 3.0, 1 - std::pow(2 * rho - 1, 3));
+            std::memcpy(final_hessian_, H, sizeof(H));
+            ok = true;
+            break;
+        }
+        if (!ok) break;  // "lm not converged!!"
+        converged_ = is_converged(delta, prm_.rot_eps, prm_.trans_eps);
+    }
+    for (int i = 0; i < 16; ++i) final_[i] = static_cast<float>(x0[i]);
+    return MRGFE_OK;
+}
+
+int GicpEngine::aligned_cloud(float* out)
+{
+    if (n_src_ == 0) return MRGFE_OK;
+    MRGFE_TRY(ctx_->bind());
+    MRGFE_TRY(d_T_.ensure(64 + n_src_ * 16));
+    float*  d_T = d_T_.as<float>();
+    float4* d_out = reinterpret_cast<float4*>(d_T_.as<char>() + 64);
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_T, final_, 48, hipMemcpyHostToDevice, ctx_->stream));
+    MRGFE_TRY(launch_transform_cloud(ctx_, d_src_, d_out, static_cast<uint32_t>(n_src_), d_T));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(out, d_out, n_src_ * 16, hipMemcpyDeviceToHost, ctx_->stream));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(ctx_->stream));
+    return MRGFE_OK;
+}
+
+}  // namespace mrgfe

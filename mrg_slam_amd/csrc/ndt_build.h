@@ -1,0 +1,39 @@
+// csrc/ndt_build.h — launchers of the target voxelisation kernels (ndt_build.hip).
+#pragma once
+#include "cellsort.h"
+#include "ndt_types.h"
+
+namespace mrgfe {
+
+// voxel indexing parameters of one cloud (host computes them from the bounding box exactly as PCL does)
+struct VoxelParams {
+    int32_t  min_b[3];
+    int32_t  divb_mul[3];
+    float    inv_leaf;
+    uint32_t n_cells;  // div_b product; also the sort key given to non-finite points
+};
+
+// where the leaves of one target live in the packed per-leaf arrays
+struct LeafSlice {
+    uint32_t n_leaves;   // V: voxels holding >= 1 point
+    uint32_t leaf_off;   // first leaf in the per-leaf arrays
+    uint32_t seg_off;    // first entry in seg_start (V + 1 entries per target)
+    uint32_t n_valid;    // finite points
+    uint32_t dense;      // lookup kind
+    uint32_t hash_shift, hash_mask;
+    uint32_t pad;
+    uint64_t lookup_byte_off;  // byte offset of this target's lookup table in the lookup arena
+};
+
+int ndt_launch_cellkeys(mrgfe_ctx* ctx, const float4* const* d_clouds, const Slice* d_slices, const SliceTable& t, const VoxelParams* d_vp, uint32_t* d_keys, uint32_t* d_vals);
+int ndt_launch_segments(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, const uint32_t* d_flags, const uint32_t* d_ordinal, const Slice* d_slices, const SliceTable& t,
+                        const LeafSlice* d_leaf_slices, uint32_t* d_seg_start, int32_t* d_seg_key);
+int ndt_launch_leaves(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32_t* d_sorted_vals, const Slice* d_slices, const SliceTable& t, const LeafSlice* d_leaf_slices,
+                      const VoxelParams* d_vp, uint32_t max_leaves, const uint32_t* d_seg_start, const int32_t* d_seg_key, double* d_sums, NdtLeafRec* d_leaves,
+                      double* d_icov64, float4* d_centroid, int32_t* d_nr_points, void* d_lookup_base);
+
+// host: PCL's bounding-box -> (min_b, max_b, div_b, divb_mul) arithmetic. Returns MRGFE_ERR_OVERFLOW when
+// dx*dy*dz > INT32_MAX ("Leaf size is too small for the input dataset").
+int voxel_params_from_bbox(const BBox& bb, float leaf, VoxelParams* vp, int32_t max_b[3], int32_t div_b[3]);
+
+}  // namespace mrgfe

@@ -1,0 +1,342 @@
+// csrc/ndt_derivatives.hip — the correspondence + Jacobian/Hessian kernel of NDT_HIP (the dominant kernel of
+// registration_->align(): /root/reference/apps/scan_matching_odometry_component.cpp:265-266,
+// src/mrg_slam/loop_detector.cpp:134) — MI355X counterpart of pclomp::NormalDistributionsTransform::
+// computeDerivatives / updateDerivatives / computeHessian / updateHessian.
+//
+// One thread owns PPT source points: it loads the packed float4 point (coalesced, 16 B/lane), applies the float
+// rigid transform in pcl::transformPointCloud's operation order, finds its voxel and probes the DIRECT7 (or 1 / 27)
+// neighbours in the target lookup, and for every occupied neighbour accumulates score, gradient (6) and the upper
+// triangle of the Hessian (21) in f64 registers from f32 per-pair terms - exactly the f32/f64 split of the reference.
+// The 6-wide contraction is far too thin for MFMA: the kernel is bound by the dependent
+// point -> lookup -> leaf-record loads, so the transform is fused in (no transformed cloud is ever written) and the
+// 28 partial sums leave the workgroup once: wavefront shuffle reduction, 4-wave LDS combine, one 256-byte record.
+// A second tiny kernel adds the records of each pair in a fixed order (bitwise reproducible results).
+#include "dev_float.h"
+#include "dev_utils.h"
+#include "ndt_derivatives.h"
+
+namespace mrgfe {
+
+__constant__ int8_t kOff7[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+
+__device__ __forceinline__ int hidx(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }  // i <= j, 21 entries
+
+struct Accum {
+    double score;
+    double g[6];
+    double H[21];
+    uint32_t nb;
+};
+
+// float path: updateDerivatives for one (point, voxel) pair
+template <bool HESS>
+__device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, const float xt[3], const float J3[3], const float J4[3], const float J5[3],
+                                           const float (&PH)[6][3], float gauss_d2f, double gauss_d1)
+{
+#pragma clang fp contract(off)
+    const float q[3] = {static_cast<float>(static_cast<double>(xt[0]) - rec.mean[0]), static_cast<float>(static_cast<double>(xt[1]) - rec.mean[1]),
+                        static_cast<float>(static_cast<double>(xt[2]) - rec.mean[2])};
+    // symmetric inverse covariance
+    const float c00 = rec.icov[0], c01 = rec.icov[1], c02 = rec.icov[2], c11 = rec.icov[3], c12 = rec.icov[4], c22 = rec.icov[5];
+    const float C[3][3] = {{c00, c01, c02}, {c01, c11, c12}, {c02, c12, c22}};
+    float qC[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) qC[c] = dot3f(q[0], C[0][c], q[1], C[1][c], q[2], C[2][c]);
+    const float qCq = dot3f(q[0], qC[0], q[1], qC[1], q[2], qC[2]);
+    const float arg0 = -gauss_d2f * qCq;
+    const float arg = arg0 * 0.5f;
+    float e = static_cast<float>(exp(static_cast<double>(arg)));
+    const float score_inc = static_cast<float>(-gauss_d1 * static_cast<double>(e));
+    e = gauss_d2f * e;
+    if (e > 1.0f || e < 0.0f || e != e) return;
+    e = static_cast<float>(static_cast<double>(e) * gauss_d1);
+    // CJ = C * [I | J3 J4 J5]
+    float CJ[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        CJ[r][0] = C[r][0]; CJ[r][1] = C[r][1]; CJ[r][2] = C[r][2];
+        CJ[r][3] = dot3f(C[r][0], J3[0], C[r][1], J3[1], C[r][2], J3[2]);
+        CJ[r][4] = dot3f(C[r][0], J4[0], C[r][1], J4[1], C[r][2], J4[2]);
+        CJ[r][5] = dot3f(C[r][0], J5[0], C[r][1], J5[1], C[r][2], J5[2]);
+    }
+    float qCJ[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) qCJ[c] = dot3f(q[0], CJ[0][c], q[1], CJ[1][c], q[2], CJ[2][c]);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { const float t = e * qCJ[c]; acc.g[c] += static_cast<double>(t); }
+    acc.score += static_cast<double>(score_inc);
+    if (!HESS) return;
+    const float* Jc[6] = {nullptr, nullptr, nullptr, J3, J4, J5};
+    // PH index of the (i,j) second-derivative vector for 3 <= i <= j <= 5: a,b,c,d,e,f = (3,3),(3,4),(3,5),(4,4),(4,5),(5,5)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+            // point_gradient4_colj . c_inv4_x_point_gradient4_col_i  == J(:,j) . CJ(:,i)
+            float jtcj;
+            if (j < 3) jtcj = CJ[j][i];
+            else       jtcj = dot3f(Jc[j][0], CJ[0][i], Jc[j][1], CJ[1][i], Jc[j][2], CJ[2][i]);
+            float qch = 0.0f;
+            if (i >= 3) {
+                const int ph = (i == 3) ? (j - 3) : (i == 4 ? (j - 4 + 3) : 5);
+                qch = dot3f(qC[0], PH[ph][0], qC[1], PH[ph][1], qC[2], PH[ph][2]);
+            }
+            const float t0 = -gauss_d2f * qCJ[i];
+            const float t1 = t0 * qCJ[j];
+            const float t2 = t1 + qch;
+            const float t3 = t2 + jtcj;
+            const float t4 = e * t3;
+            acc.H[hidx(i, j)] += static_cast<double>(t4);
+        }
+    }
+}
+
+// double path: updateHessian for one pair (pclomp computeHessian keeps PCL's f64 3x6 / 18x6 forms)
+__device__ __forceinline__ void pair_double(Accum& acc, const double mean[3], const double* __restrict__ C, const float xt[3], const double (&J)[3][6],
+                                            const double (&PH)[6][3], double gauss_d1, double gauss_d2)
+{
+    const double q[3] = {static_cast<double>(xt[0]) - mean[0], static_cast<double>(xt[1]) - mean[1], static_cast<double>(xt[2]) - mean[2]};
+    double Cq[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) Cq[r] = C[r * 3 + 0] * q[0] + C[r * 3 + 1] * q[1] + C[r * 3 + 2] * q[2];
+    double e = gauss_d2 * exp(-gauss_d2 * (q[0] * Cq[0] + q[1] * Cq[1] + q[2] * Cq[2]) / 2);
+    if (e > 1 || e < 0 || e != e) return;
+    e *= gauss_d1;
+    double CJ[3][6], qCJ[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) CJ[r][c] = C[r * 3 + 0] * J[0][c] + C[r * 3 + 1] * J[1][c] + C[r * 3 + 2] * J[2][c];
+        qCJ[c] = q[0] * CJ[0][c] + q[1] * CJ[1][c] + q[2] * CJ[2][c];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = i; j < 6; ++j) {
+            double qch = 0.0;
+            if (i >= 3) {
+                const int ph = (i == 3) ? (j - 3) : (i == 4 ? (j - 4 + 3) : 5);
+                double CH[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) CH[r] = C[r * 3 + 0] * PH[ph][0] + C[r * 3 + 1] * PH[ph][1] + C[r * 3 + 2] * PH[ph][2];
+                qch = q[0] * CH[0] + q[1] * CH[1] + q[2] * CH[2];
+            }
+            const double jtcj = J[0][j] * CJ[0][i] + J[1][j] * CJ[1][i] + J[2][j] * CJ[2][i];
+            acc.H[hidx(i, j)] += e * (-gauss_d2 * qCJ[i] * qCJ[j] + qch + jtcj);
+        }
+    }
+}
+
+// MODE 0: score+gradient+Hessian, 1: score+gradient, 2: Hessian only (double).  NNB: probed voxels (7, 1 or 27).
+template <int MODE, int NNB>
+__global__ __launch_bounds__(256) void ndt_derivatives_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
+                                                               const NdtEvalDev* __restrict__ evals, double* __restrict__ partials, int ppt)
+{
+    const NdtPairDev pr = pairs[blockIdx.y];
+    if (blockIdx.x >= pr.nblk) return;
+    const NdtEvalDev& ev = evals[blockIdx.y];
+    if (!ev.active || ev.mode != MODE) return;
+    const NdtGridDev& g = grids[pr.grid];
+
+    __shared__ float s_T[12];
+    __shared__ float s_j[8][3], s_h[15][3];
+    __shared__ double s_red[4][kNdtPartialStride];
+    if (threadIdx.x < 12) s_T[threadIdx.x] = ev.T[threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 24) (&s_j[0][0])[threadIdx.x - 64] = (&ev.j_ang[0][0])[threadIdx.x - 64];
+    if (threadIdx.x >= 128 && threadIdx.x < 128 + 45) (&s_h[0][0])[threadIdx.x - 128] = (&ev.h_ang[0][0])[threadIdx.x - 128];
+    __syncthreads();
+
+    const float  gauss_d2f = static_cast<float>(ev.gauss_d2);
+    const double gauss_d1 = ev.gauss_d1, gauss_d2 = ev.gauss_d2;
+    const float  leaf = g.leaf_size;
+    const bool   kdtree = (NNB == 27) && (ev.search == MRGFE_KDTREE);
+
+    Accum acc;
+    acc.score = 0;
+    acc.nb = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc.g[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) acc.H[k] = 0;
+
+    const uint32_t base = blockIdx.x * 256u * ppt;
+    for (int it = 0; it < ppt; ++it) {
+        const uint32_t i = base + it * 256u + threadIdx.x;
+        if (i >= pr.n_src) break;
+        const float4 p = pr.src[i];
+        float xt[3];
+        transform_point(s_T, p.x, p.y, p.z, xt[0], xt[1], xt[2]);
+        // getNeighborhoodAtPoint: floor(p / leaf_size)
+        const int ijk[3] = {static_cast<int>(floorf(xt[0] / leaf)), static_cast<int>(floorf(xt[1] / leaf)), static_cast<int>(floorf(xt[2] / leaf))};
+        int32_t ids[NNB];
+#pragma unroll
+        for (int n = 0; n < NNB; ++n) {
+            int o0, o1, o2;
+            if (NNB == 27) { o0 = n / 9 - 1; o1 = (n / 3) % 3 - 1; o2 = n % 3 - 1; }
+            else           { o0 = kOff7[n][0]; o1 = kOff7[n][1]; o2 = kOff7[n][2]; }
+            const int c0 = ijk[0] + o0, c1 = ijk[1] + o1, c2 = ijk[2] + o2;
+            int32_t id = -1;
+            if (c0 >= g.min_b[0] && c0 <= g.max_b[0] && c1 >= g.min_b[1] && c1 <= g.max_b[1] && c2 >= g.min_b[2] && c2 <= g.max_b[2]) {
+                const uint32_t key = static_cast<uint32_t>((c0 - g.min_b[0]) * g.divb_mul[0] + (c1 - g.min_b[1]) * g.divb_mul[1] + (c2 - g.min_b[2]) * g.divb_mul[2]);
+                id = ndt_lookup(g, key);
+            }
+            ids[n] = id;
+        }
+        if (kdtree) {
+            // radiusSearch(point, resolution) over voxel centroids: FLANN keeps dist^2 < r^2
+            const float r2 = leaf * leaf;
+#pragma unroll
+            for (int n = 0; n < NNB; ++n)
+                if (ids[n] >= 0) {
+                    const float4 c = g.centroid[ids[n]];
+                    const float  dx = c.x - xt[0], dy = c.y - xt[1], dz = c.z - xt[2];
+                    const float  d = dot3f(dx, dx, dy, dy, dz, dz);
+                    if (!(d < r2)) ids[n] = -1;
+                }
+        }
+        bool any = false;
+#pragma unroll
+        for (int n = 0; n < NNB; ++n) any = any || ids[n] >= 0;
+        if (!any) continue;
+
+        if (MODE != 2) {
+            // computePointDerivatives, float form: x_j_ang = j_ang * x, x_h_ang = h_ang * x
+            float xj[8], xh[15];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) xj[r] = dot3f(s_j[r][0], p.x, s_j[r][1], p.y, s_j[r][2], p.z);
+            const float J3[3] = {0.0f, xj[0], xj[1]}, J4[3] = {xj[2], xj[3], xj[4]}, J5[3] = {xj[5], xj[6], xj[7]};
+            float PH[6][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            if (MODE == 0) {
+#pragma unroll
+                for (int r = 0; r < 15; ++r) xh[r] = dot3f(s_h[r][0], p.x, s_h[r][1], p.y, s_h[r][2], p.z);
+                PH[0][1] = xh[0];  PH[0][2] = xh[1];                     // a  (3,3)
+                PH[1][1] = xh[2];  PH[1][2] = xh[3];                     // b  (3,4)
+                PH[2][1] = xh[4];  PH[2][2] = xh[5];                     // c  (3,5)
+                PH[3][0] = xh[6];  PH[3][1] = xh[7];  PH[3][2] = xh[8];  // d  (4,4)
+                PH[4][0] = xh[9];  PH[4][1] = xh[10]; PH[4][2] = xh[11]; // e  (4,5)
+                PH[5][0] = xh[12]; PH[5][1] = xh[13]; PH[5][2] = xh[14]; // f  (5,5)
+            }
+#pragma unroll
+            for (int n = 0; n < NNB; ++n)
+                if (ids[n] >= 0) {
+                    const NdtLeafRec rec = g.leaves[ids[n]];
+                    pair_float<MODE == 0>(acc, rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
+                    ++acc.nb;
+                }
+        } else {
+            const double x[3] = {p.x, p.y, p.z};
+            double J[3][6] = {{1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}, {0, 0, 1, 0, 0, 0}};
+            auto dj = [&](int r) { return x[0] * ev.j_ang_d[r][0] + x[1] * ev.j_ang_d[r][1] + x[2] * ev.j_ang_d[r][2]; };
+            auto dh = [&](int r) { return x[0] * ev.h_ang_d[r][0] + x[1] * ev.h_ang_d[r][1] + x[2] * ev.h_ang_d[r][2]; };
+            J[1][3] = dj(0); J[2][3] = dj(1);
+            J[0][4] = dj(2); J[1][4] = dj(3); J[2][4] = dj(4);
+            J[0][5] = dj(5); J[1][5] = dj(6); J[2][5] = dj(7);
+            const double PH[6][3] = {{0, dh(0), dh(1)}, {0, dh(2), dh(3)}, {0, dh(4), dh(5)}, {dh(6), dh(7), dh(8)}, {dh(9), dh(10), dh(11)}, {dh(12), dh(13), dh(14)}};
+#pragma unroll 1
+            for (int n = 0; n < NNB; ++n)
+                if (ids[n] >= 0) {
+                    const NdtLeafRec rec = g.leaves[ids[n]];
+                    pair_double(acc, rec.mean, g.icov64 + (size_t)ids[n] * 9, xt, J, PH, gauss_d1, gauss_d2);
+                    ++acc.nb;
+                }
+        }
+    }
+
+    // workgroup reduction: shuffle inside each wavefront, 4 wave records through LDS, one 256-byte partial out
+    double vals[kNdtAccum];
+    vals[0] = acc.score;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vals[1 + k] = acc.g[k];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) vals[7 + k] = acc.H[k];
+    vals[28] = static_cast<double>(acc.nb);
+#pragma unroll
+    for (int k = 0; k < kNdtAccum; ++k) {
+        const bool skip = (MODE == 1 && k >= 7 && k < 28) || (MODE == 2 && k < 7);
+        if (skip) continue;
+        const double r = wave_sum(vals[k]);
+        if (lane_id() == 0) s_red[wave_id()][k] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNdtPartialStride) {
+        const int  k = threadIdx.x;
+        const bool skip = k >= kNdtAccum || (MODE == 1 && k >= 7 && k < 28) || (MODE == 2 && k < 7);
+        double     r = 0.0;
+        if (!skip) r = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
+        partials[(size_t)(pr.part_off + blockIdx.x) * kNdtPartialStride + k] = r;
+    }
+}
+
+// fixed-order sum of the block partials of every active pair: 8 interleaved slices, then slice 0..7 in order
+__global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __restrict__ pairs, const NdtEvalDev* __restrict__ evals, const double* __restrict__ partials,
+                                                          double* __restrict__ results)
+{
+    const NdtPairDev pr = pairs[blockIdx.x];
+    if (!evals[blockIdx.x].active) return;
+    __shared__ double s[8][kNdtPartialStride];
+    const int k = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    double    acc = 0.0;
+    for (uint32_t b = slice; b < pr.nblk; b += 8) acc += partials[(size_t)(pr.part_off + b) * kNdtPartialStride + k];
+    s[slice][k] = acc;
+    __syncthreads();
+    if (threadIdx.x < kNdtPartialStride) {
+        double r = s[0][k];
+#pragma unroll
+        for (int sl = 1; sl < 8; ++sl) r += s[sl][k];
+        results[(size_t)blockIdx.x * kNdtPartialStride + k] = r;
+    }
+}
+
+// final_transformation * source -> packed xyzi (the `output` cloud of pcl::Registration::align)
+__global__ __launch_bounds__(256) void transform_cloud_kernel(const float4* __restrict__ src, float4* __restrict__ dst, uint32_t n, const float* __restrict__ T12)
+{
+    __shared__ float s_T[12];
+    if (threadIdx.x < 12) s_T[threadIdx.x] = T12[threadIdx.x];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = src[i];
+    float4 o;
+    transform_point(s_T, p.x, p.y, p.z, o.x, o.y, o.z);
+    o.w = p.w;
+    dst[i] = o;
+}
+
+template <int MODE>
+static void launch_mode(mrgfe_ctx* ctx, int nnb, dim3 grid, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, double* d_partials, int ppt)
+{
+    if (nnb == 7)       hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 7>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_partials, ppt);
+    else if (nnb == 1)  hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 1>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_partials, ppt);
+    else                hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 27>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_partials, ppt);
+}
+
+int ndt_launch_derivatives(mrgfe_ctx* ctx, int mode, int search, uint32_t max_nblk, int npairs, const NdtGridDev* d_grids, const NdtPairDev* d_pairs,
+                           const NdtEvalDev* d_evals, double* d_partials, int ppt)
+{
+    if (npairs == 0 || max_nblk == 0) return MRGFE_OK;
+    const int nnb = (search == MRGFE_DIRECT7) ? 7 : (search == MRGFE_DIRECT1 ? 1 : 27);
+    dim3 grid(max_nblk, npairs);
+    if (mode == 0)      launch_mode<0>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_partials, ppt);
+    else if (mode == 1) launch_mode<1>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_partials, ppt);
+    else                launch_mode<2>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_partials, ppt);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
+int ndt_launch_reduce(mrgfe_ctx* ctx, int npairs, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const double* d_partials, double* d_results)
+{
+    if (npairs == 0) return MRGFE_OK;
+    hipLaunchKernelGGL(ndt_reduce_kernel, dim3(npairs), dim3(256), 0, ctx->stream, d_pairs, d_evals, d_partials, d_results);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
+int launch_transform_cloud(mrgfe_ctx* ctx, const float4* d_src, float4* d_dst, uint32_t n, const float* d_T12)
+{
+    if (n == 0) return MRGFE_OK;
+    hipLaunchKernelGGL(transform_cloud_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_src, d_dst, n, d_T12);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
+}  // namespace mrgfe

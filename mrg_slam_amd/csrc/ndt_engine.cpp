@@ -1,0 +1,482 @@
+// csrc/ndt_engine.cpp — batched NDT_HIP engine (see ndt_engine.h): target voxelisation pipeline and the lock-step
+// alignment rounds.  Replaces, for a whole batch at once, what the reference does per object through
+// setInputTarget / setInputSource / align (/root/reference/src/mrg_slam/loop_detector.cpp:104,126-145).
+#include "ndt_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "ndt_derivatives.h"
+
+namespace mrgfe {
+
+int voxel_params_from_bbox(const BBox& bb, float leaf, VoxelParams* vp, int32_t max_b[3], int32_t div_b[3])
+{
+    const float inv_leaf = 1.0f / leaf;
+    // "Check that the leaf size is not too small, given the size of the data"
+    const int64_t dx = static_cast<int64_t>((bb.mx[0] - bb.mn[0]) * inv_leaf) + 1;
+    const int64_t dy = static_cast<int64_t>((bb.mx[1] - bb.mn[1]) * inv_leaf) + 1;
+    const int64_t dz = static_cast<int64_t>((bb.mx[2] - bb.mn[2]) * inv_leaf) + 1;
+    if (dx * dy * dz > static_cast<int64_t>(INT32_MAX)) return MRGFE_ERR_OVERFLOW;
+    for (int a = 0; a < 3; ++a) {
+        vp->min_b[a] = static_cast<int32_t>(std::floor(bb.mn[a] * inv_leaf));
+        max_b[a] = static_cast<int32_t>(std::floor(bb.mx[a] * inv_leaf));
+        div_b[a] = max_b[a] - vp->min_b[a] + 1;
+    }
+    vp->divb_mul[0] = 1;
+    vp->divb_mul[1] = div_b[0];
+    vp->divb_mul[2] = div_b[0] * div_b[1];
+    vp->inv_leaf = inv_leaf;
+    const int64_t cells = static_cast<int64_t>(div_b[0]) * div_b[1] * div_b[2];
+    if (cells > static_cast<int64_t>(INT32_MAX)) return MRGFE_ERR_OVERFLOW;
+    vp->n_cells = static_cast<uint32_t>(cells);
+    return MRGFE_OK;
+}
+
+NdtEngine::~NdtEngine()
+{
+    if (ctx_) (void)hipSetDevice(ctx_->device);
+    cloud_arena_.release();
+    grid_arena_.release();
+    d_grids_.release(); d_pairs_.release(); d_evals_.release(); d_partials_.release(); d_results_.release(); d_T12_.release(); d_aligned_.release();
+    h_evals_.release(); h_results_.release();
+}
+
+void NdtEngine::clear()
+{
+    targets_.clear();
+    pairs_.clear();
+    h_grids_.clear();
+    leaf_arrays_.clear();
+    cloud_arena_.reset();
+    grid_arena_.reset();
+    pairs_dirty_ = true;
+}
+
+void NdtEngine::clear_pairs()
+{
+    pairs_.clear();
+    pairs_dirty_ = true;
+}
+
+int NdtEngine::add_target_device(const void* d_xyzi, size_t n)
+{
+    if (n > 0 && !d_xyzi) { set_error("add_target: NULL cloud"); return MRGFE_ERR_INVALID; }
+    if (n > 0x7fffffffu) { set_error("add_target: cloud too large"); return MRGFE_ERR_INVALID; }
+    NdtTargetInfo t;
+    t.d_pts = static_cast<const float4*>(d_xyzi);
+    t.n = static_cast<uint32_t>(n);
+    targets_.push_back(t);
+    return static_cast<int>(targets_.size()) - 1;
+}
+
+int NdtEngine::add_target_host(const float* xyzi, size_t n, size_t stride)
+{
+    if (n > 0 && !xyzi) { set_error("add_target: NULL cloud"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(ctx_->bind());
+    void* d = nullptr;
+    MRGFE_TRY(cloud_arena_.alloc(n * 16, &d));
+    MRGFE_TRY(upload_cloud(ctx_, xyzi, n, stride, d));
+    return add_target_device(d, n);
+}
+
+int NdtEngine::add_pair_device(int target, const void* d_xyzi, size_t n, const float guess[16])
+{
+    if (target < 0 || target >= n_targets()) { set_error("add_pair: target index %d out of range", target); return MRGFE_ERR_INVALID; }
+    if (n > 0 && !d_xyzi) { set_error("add_pair: NULL cloud"); return MRGFE_ERR_INVALID; }
+    if (n > 0x7fffffffu) { set_error("add_pair: cloud too large"); return MRGFE_ERR_INVALID; }
+    NdtPairInfo p;
+    p.target = target;
+    p.d_src = static_cast<const float4*>(d_xyzi);
+    p.n = static_cast<uint32_t>(n);
+    std::memcpy(p.guess, guess, sizeof(p.guess));
+    pairs_.push_back(p);
+    pairs_dirty_ = true;
+    return static_cast<int>(pairs_.size()) - 1;
+}
+
+int NdtEngine::add_pair_host(int target, const float* xyzi, size_t n, size_t stride, const float guess[16])
+{
+    if (n > 0 && !xyzi) { set_error("add_pair: NULL cloud"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(ctx_->bind());
+    void* d = nullptr;
+    MRGFE_TRY(cloud_arena_.alloc(n * 16, &d));
+    MRGFE_TRY(upload_cloud(ctx_, xyzi, n, stride, d));
+    return add_pair_device(target, d, n, guess);
+}
+
+int NdtEngine::set_guess(int pair, const float guess[16])
+{
+    if (pair < 0 || pair >= n_pairs()) { set_error("set_guess: pair index %d out of range", pair); return MRGFE_ERR_INVALID; }
+    std::memcpy(pairs_[pair].guess, guess, sizeof(float) * 16);
+    return MRGFE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// target voxelisation
+// ------------------------------------------------------------------------------------------------------
+int NdtEngine::build_targets()
+{
+    MRGFE_TRY(ctx_->bind());
+    std::vector<int> todo;
+    for (int i = 0; i < n_targets(); ++i) if (!targets_[i].built) todo.push_back(i);
+    if (todo.empty()) return MRGFE_OK;
+    const int P = static_cast<int>(todo.size());
+    hipStream_t st = ctx_->stream;
+
+    std::vector<uint32_t> sizes(P);
+    for (int k = 0; k < P; ++k) sizes[k] = targets_[todo[k]].n;
+    SliceTable tab;
+    tab.build(sizes.data(), P);
+
+    // descriptor block in pinned memory: slices | cloud pointers | n_valid | voxel params | leaf slices
+    const size_t o_sl = 0;
+    const size_t o_cp = o_sl + sizeof(Slice) * P;
+    const size_t o_nv = o_cp + sizeof(void*) * P;
+    const size_t o_vp = (o_nv + sizeof(uint32_t) * P + 15) & ~size_t(15);
+    const size_t o_ls = (o_vp + sizeof(VoxelParams) * P + 15) & ~size_t(15);
+    const size_t desc_bytes = o_ls + sizeof(LeafSlice) * P;
+    PinBuf& hdesc = ctx_->pin[1];
+    MRGFE_TRY(hdesc.ensure(desc_bytes + sizeof(BBox) * P + sizeof(uint32_t) * P));
+    char* hd = hdesc.as<char>();
+    Slice*         h_sl = reinterpret_cast<Slice*>(hd + o_sl);
+    const float4** h_cp = reinterpret_cast<const float4**>(hd + o_cp);
+    uint32_t*      h_nv = reinterpret_cast<uint32_t*>(hd + o_nv);
+    VoxelParams*   h_vp = reinterpret_cast<VoxelParams*>(hd + o_vp);
+    LeafSlice*     h_ls = reinterpret_cast<LeafSlice*>(hd + o_ls);
+    BBox*          h_bb = reinterpret_cast<BBox*>(hd + desc_bytes);
+    uint32_t*      h_tot = reinterpret_cast<uint32_t*>(hd + desc_bytes + sizeof(BBox) * P);
+
+    DevBuf& ddesc = ctx_->scratch[0];
+    MRGFE_TRY(ddesc.ensure(desc_bytes));
+    char* dd = ddesc.as<char>();
+    const Slice*         d_sl = reinterpret_cast<const Slice*>(dd + o_sl);
+    const float4* const* d_cp = reinterpret_cast<const float4* const*>(dd + o_cp);
+    const uint32_t*      d_nv = reinterpret_cast<const uint32_t*>(dd + o_nv);
+    const VoxelParams*   d_vp = reinterpret_cast<const VoxelParams*>(dd + o_vp);
+    const LeafSlice*     d_ls = reinterpret_cast<const LeafSlice*>(dd + o_ls);
+
+    for (int k = 0; k < P; ++k) { h_sl[k] = tab.h[k]; h_cp[k] = targets_[todo[k]].d_pts; h_nv[k] = 0; }
+    std::memset(h_vp, 0, sizeof(VoxelParams) * P);
+    std::memset(h_ls, 0, sizeof(LeafSlice) * P);
+    MRGFE_HIP_CHECK(hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, st));
+
+    // 1. bounding boxes
+    DevBuf& dbb = ctx_->scratch[1];
+    MRGFE_TRY(dbb.ensure(sizeof(BBox) * (tab.total_blks + P)));
+    BBox* d_bb_part = dbb.as<BBox>();
+    BBox* d_bb_out = d_bb_part + tab.total_blks;
+    MRGFE_TRY(bounding_boxes(ctx_, d_cp, d_sl, tab, d_bb_part, d_bb_out));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(h_bb, d_bb_out, sizeof(BBox) * P, hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+
+    // 2. voxel parameters (host, PCL arithmetic); failed targets become empty problems
+    uint32_t max_cells = 1;
+    for (int k = 0; k < P; ++k) {
+        NdtTargetInfo& T = targets_[todo[k]];
+        T.built = true;
+        if (h_bb[k].n_finite == 0) { T.status = MRGFE_ERR_EMPTY; h_sl[k].n = 0; h_sl[k].nblk = 0; continue; }
+        int st_vp = voxel_params_from_bbox(h_bb[k], prm_.resolution, &h_vp[k], T.max_b, T.div_b);
+        if (st_vp != MRGFE_OK) { T.status = st_vp; h_sl[k].n = 0; h_sl[k].nblk = 0; std::memset(&h_vp[k], 0, sizeof(VoxelParams)); continue; }
+        for (int a = 0; a < 3; ++a) T.min_b[a] = h_vp[k].min_b[a];
+        T.status = MRGFE_OK;
+        h_nv[k] = h_bb[k].n_finite;
+        max_cells = std::max(max_cells, h_vp[k].n_cells);
+    }
+    // rebuild the tile bookkeeping for the (possibly emptied) problems
+    for (int k = 0; k < P; ++k) sizes[k] = h_sl[k].n;
+    tab.build(sizes.data(), P);
+    for (int k = 0; k < P; ++k) h_sl[k] = tab.h[k];
+    MRGFE_HIP_CHECK(hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, st));
+    int key_bits = 1;
+    while (key_bits < 32 && (uint64_t(1) << key_bits) <= max_cells) ++key_bits;  // key == n_cells marks non-finite points
+
+    // 3. keys, stable sort, run heads, ordinals
+    const size_t ne = std::max<size_t>(tab.total_elems, 4);
+    DevBuf &dk = ctx_->scratch[2], &dv = ctx_->scratch[3], &dkt = ctx_->scratch[4], &dvt = ctx_->scratch[5], &dh = ctx_->scratch[6], &dfl = ctx_->scratch[7], &dblk = ctx_->scratch[8];
+    MRGFE_TRY(dk.ensure(ne * 4)); MRGFE_TRY(dv.ensure(ne * 4)); MRGFE_TRY(dkt.ensure(ne * 4)); MRGFE_TRY(dvt.ensure(ne * 4));
+    MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + P)));
+    MRGFE_TRY(dfl.ensure(ne * 4));
+    MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (tab.total_blks + P + 4)));
+    MRGFE_TRY(ndt_launch_cellkeys(ctx_, d_cp, d_sl, tab, d_vp, dk.as<uint32_t>(), dv.as<uint32_t>()));
+    uint32_t *sk = nullptr, *sv = nullptr;
+    MRGFE_TRY(radix_sort_pairs(ctx_, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), d_sl, tab, key_bits, dh.as<uint32_t>(), &sk, &sv));
+    MRGFE_TRY(mark_run_heads(ctx_, sk, dfl.as<uint32_t>(), d_sl, tab, d_nv));
+    // flags stay in dfl; ordinals go to the unused sort buffer
+    uint32_t* d_flags = dfl.as<uint32_t>();
+    uint32_t* d_ord = (sk == dk.as<uint32_t>()) ? dkt.as<uint32_t>() : dk.as<uint32_t>();
+    uint32_t* d_tot = dblk.as<uint32_t>() + tab.total_blks;
+    MRGFE_TRY(exclusive_scan(ctx_, d_flags, d_ord, d_sl, tab, dblk.as<uint32_t>(), d_tot));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(h_tot, d_tot, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+
+    // 4. leaf storage
+    uint32_t total_leaves = 0, max_leaves = 0;
+    uint64_t lookup_bytes = 0;
+    for (int k = 0; k < P; ++k) {
+        NdtTargetInfo& T = targets_[todo[k]];
+        const uint32_t V = (T.status == MRGFE_OK) ? h_tot[k] : 0;
+        T.n_leaves = V;
+        LeafSlice& ls = h_ls[k];
+        ls.n_leaves = V;
+        ls.leaf_off = total_leaves;
+        ls.seg_off = total_leaves + k;
+        ls.n_valid = h_nv[k];
+        ls.lookup_byte_off = lookup_bytes;
+        if (T.status == MRGFE_OK) {
+            if (h_vp[k].n_cells <= kDenseLookupMaxCells && !force_hash_) {
+                ls.dense = 1;
+                lookup_bytes += (uint64_t(h_vp[k].n_cells) * 4 + 255) & ~uint64_t(255);
+            } else {
+                ls.dense = 0;
+                uint32_t bits = 4;
+                while ((uint64_t(1) << bits) < uint64_t(V) * 2 + 1) ++bits;
+                ls.hash_shift = 32 - bits;
+                ls.hash_mask = (1u << bits) - 1;
+                lookup_bytes += (uint64_t(1) << bits) * 8;
+            }
+        }
+        total_leaves += V;
+        max_leaves = std::max(max_leaves, V);
+    }
+    void *p_keys = nullptr, *p_npts = nullptr, *p_leaves = nullptr, *p_icov = nullptr, *p_cent = nullptr, *p_lookup = nullptr;
+    const size_t nl = std::max<uint32_t>(total_leaves, 1);
+    MRGFE_TRY(grid_arena_.alloc(nl * 4, &p_keys));
+    MRGFE_TRY(grid_arena_.alloc(nl * 4, &p_npts));
+    MRGFE_TRY(grid_arena_.alloc(nl * sizeof(NdtLeafRec), &p_leaves));
+    MRGFE_TRY(grid_arena_.alloc(nl * 72, &p_icov));
+    MRGFE_TRY(grid_arena_.alloc(nl * 16, &p_cent));
+    MRGFE_TRY(grid_arena_.alloc(std::max<uint64_t>(lookup_bytes, 256), &p_lookup));
+    MRGFE_HIP_CHECK(hipMemsetAsync(p_lookup, 0xFF, std::max<uint64_t>(lookup_bytes, 256), st));
+    DevBuf &dseg = ctx_->scratch[9], &dsum = ctx_->scratch[10];
+    MRGFE_TRY(dseg.ensure(sizeof(uint32_t) * (total_leaves + P + 4)));
+    MRGFE_TRY(dsum.ensure(sizeof(double) * 16 * nl));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(dd + o_ls, hd + o_ls, sizeof(LeafSlice) * P, hipMemcpyHostToDevice, st));
+
+    // 5. segments and leaves
+    MRGFE_TRY(ndt_launch_segments(ctx_, sk, d_flags, d_ord, d_sl, tab, d_ls, dseg.as<uint32_t>(), static_cast<int32_t*>(p_keys)));
+    MRGFE_TRY(ndt_launch_leaves(ctx_, d_cp, sv, d_sl, tab, d_ls, d_vp, max_leaves, dseg.as<uint32_t>(), static_cast<const int32_t*>(p_keys), dsum.as<double>(),
+                                static_cast<NdtLeafRec*>(p_leaves), static_cast<double*>(p_icov), static_cast<float4*>(p_cent), static_cast<int32_t*>(p_npts), p_lookup));
+
+    // 6. device grid descriptors
+    if (h_grids_.size() < targets_.size()) { h_grids_.resize(targets_.size()); leaf_arrays_.resize(targets_.size()); }
+    for (int k = 0; k < P; ++k) {
+        const int ti = todo[k];
+        NdtTargetInfo& T = targets_[ti];
+        NdtGridDev g;
+        std::memset(&g, 0, sizeof(g));
+        const LeafSlice& ls = h_ls[k];
+        for (int a = 0; a < 3; ++a) { g.min_b[a] = T.min_b[a]; g.max_b[a] = T.max_b[a]; g.divb_mul[a] = h_vp[k].divb_mul[a]; }
+        g.leaf_size = prm_.resolution;
+        g.inv_leaf = 1.0f / prm_.resolution;
+        g.n_cells = h_vp[k].n_cells;
+        g.dense = ls.dense;
+        g.hash_shift = ls.hash_shift;
+        g.hash_mask = ls.hash_mask;
+        g.n_leaves = ls.n_leaves;
+        g.lookup = static_cast<char*>(p_lookup) + ls.lookup_byte_off;
+        g.leaves = static_cast<NdtLeafRec*>(p_leaves) + ls.leaf_off;
+        g.icov64 = static_cast<double*>(p_icov) + size_t(ls.leaf_off) * 9;
+        g.centroid = static_cast<float4*>(p_cent) + ls.leaf_off;
+        g.nr_points = static_cast<int32_t*>(p_npts) + ls.leaf_off;
+        h_grids_[ti] = g;
+        T.leaf_off = ls.leaf_off;
+        leaf_arrays_[ti] = {static_cast<int32_t*>(p_keys) + ls.leaf_off, static_cast<int32_t*>(p_npts) + ls.leaf_off, static_cast<NdtLeafRec*>(p_leaves) + ls.leaf_off,
+                            static_cast<double*>(p_icov) + size_t(ls.leaf_off) * 9};
+    }
+    MRGFE_TRY(d_grids_.ensure(sizeof(NdtGridDev) * h_grids_.size()));
+    // pageable source: the copy is staged by the runtime before the call returns
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_grids_.p, h_grids_.data(), sizeof(NdtGridDev) * h_grids_.size(), hipMemcpyHostToDevice, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    return MRGFE_OK;
+}
+
+int NdtEngine::read_leaves(int target, int32_t* keys, int32_t* nr_points, double* mean3, double* icov9)
+{
+    if (target < 0 || target >= n_targets() || !targets_[target].built) { set_error("read_leaves: target not built"); return MRGFE_ERR_STATE; }
+    MRGFE_TRY(ctx_->bind());
+    const uint32_t V = targets_[target].n_leaves;
+    if (V == 0) return MRGFE_OK;
+    const LeafArrays& la = leaf_arrays_[target];
+    std::vector<NdtLeafRec> recs(V);
+    MRGFE_HIP_CHECK(hipMemcpy(keys, la.keys, V * 4, hipMemcpyDeviceToHost));
+    MRGFE_HIP_CHECK(hipMemcpy(nr_points, la.nr_points, V * 4, hipMemcpyDeviceToHost));
+    MRGFE_HIP_CHECK(hipMemcpy(recs.data(), la.leaves, V * sizeof(NdtLeafRec), hipMemcpyDeviceToHost));
+    MRGFE_HIP_CHECK(hipMemcpy(icov9, la.icov64, size_t(V) * 72, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < V; ++i) { mean3[3 * i] = recs[i].mean[0]; mean3[3 * i + 1] = recs[i].mean[1]; mean3[3 * i + 2] = recs[i].mean[2]; }
+    return MRGFE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// alignment rounds
+// ------------------------------------------------------------------------------------------------------
+int NdtEngine::upload_pairs()
+{
+    const int P = n_pairs();
+    uint64_t total_pts = 0;
+    for (auto& p : pairs_) total_pts += p.n;
+    // enough workgroups to fill 256 CUs several times over, few enough that the block reduction amortises
+    const uint64_t target_blocks = uint64_t(ctx_->cu_count) * 16;
+    int ppt = static_cast<int>(total_pts / (256 * target_blocks));
+    ppt = std::max(1, std::min(ppt, 8));
+    ppt_ = ppt;
+    h_pairs_.resize(P);
+    uint32_t part = 0;
+    max_nblk_ = 0;
+    for (int i = 0; i < P; ++i) {
+        NdtPairDev d;
+        d.src = pairs_[i].d_src;
+        d.n_src = pairs_[i].n;
+        d.grid = static_cast<uint32_t>(pairs_[i].target);
+        d.nblk = (pairs_[i].n + 256u * ppt - 1) / (256u * ppt);
+        d.part_off = part;
+        part += d.nblk;
+        max_nblk_ = std::max(max_nblk_, d.nblk);
+        h_pairs_[i] = d;
+    }
+    MRGFE_TRY(d_pairs_.ensure(sizeof(NdtPairDev) * std::max(P, 1)));
+    MRGFE_TRY(d_evals_.ensure(sizeof(NdtEvalDev) * std::max(P, 1)));
+    MRGFE_TRY(d_partials_.ensure(sizeof(double) * kNdtPartialStride * std::max<uint32_t>(part, 1)));
+    MRGFE_TRY(d_results_.ensure(sizeof(double) * kNdtPartialStride * std::max(P, 1)));
+    MRGFE_TRY(h_evals_.ensure(sizeof(NdtEvalDev) * std::max(P, 1)));
+    MRGFE_TRY(h_results_.ensure(sizeof(double) * kNdtPartialStride * std::max(P, 1)));
+    if (P) MRGFE_HIP_CHECK(hipMemcpyAsync(d_pairs_.p, h_pairs_.data(), sizeof(NdtPairDev) * P, hipMemcpyHostToDevice, ctx_->stream));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(ctx_->stream));
+    pairs_dirty_ = false;
+    return MRGFE_OK;
+}
+
+static void fill_eval(NdtEvalDev& e, const NdtRequest& r, const NdtController& c, int search, bool active)
+{
+    for (int row = 0; row < 3; ++row) for (int col = 0; col < 4; ++col) e.T[row * 4 + col] = r.T[row * 4 + col];
+    for (int a = 0; a < 8; ++a) for (int b = 0; b < 3; ++b) { e.j_ang_d[a][b] = r.j_ang[a][b]; e.j_ang[a][b] = static_cast<float>(r.j_ang[a][b]); }
+    for (int a = 0; a < 15; ++a) for (int b = 0; b < 3; ++b) { e.h_ang_d[a][b] = r.h_ang[a][b]; e.h_ang[a][b] = static_cast<float>(r.h_ang[a][b]); }
+    e.gauss_d1 = c.gauss_d1();
+    e.gauss_d2 = c.gauss_d2();
+    e.mode = r.mode;
+    e.active = active ? 1 : 0;
+    e.search = search;
+    e.pad = 0;
+}
+
+int NdtEngine::run_round(int* n_active)
+{
+    const int P = n_pairs();
+    NdtEvalDev* he = h_evals_.as<NdtEvalDev>();
+    bool modes[3] = {false, false, false};
+    int  active = 0;
+    for (int i = 0; i < P; ++i) {
+        NdtController& c = pairs_[i].ctl;
+        if (c.done()) { he[i].active = 0; continue; }
+        fill_eval(he[i], c.request(), c, prm_.search, true);
+        modes[c.request().mode] = true;
+        ++active;
+    }
+    *n_active = active;
+    if (!active) return MRGFE_OK;
+    hipStream_t st = ctx_->stream;
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));
+    MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev0, st));
+    int launches = 0;
+    for (int m = 0; m < 3; ++m)
+        if (modes[m]) {
+            MRGFE_TRY(ndt_launch_derivatives(ctx_, m, prm_.search, max_nblk_, P, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(),
+                                             d_partials_.as<double>(), ppt_));
+            ++launches;
+        }
+    MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev1, st));
+    MRGFE_TRY(ndt_launch_reduce(ctx_, P, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_partials_.as<double>(), d_results_.as<double>()));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(h_results_.p, d_results_.p, sizeof(double) * kNdtPartialStride * P, hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    float ms = 0;
+    MRGFE_HIP_CHECK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
+    deriv_ms += ms;
+    deriv_launches += launches;
+    const double* hr = h_results_.as<double>();
+    const int probes = prm_.search == MRGFE_DIRECT7 ? 7 : (prm_.search == MRGFE_DIRECT1 ? 1 : 27);
+    for (int i = 0; i < P; ++i) {
+        NdtController& c = pairs_[i].ctl;
+        if (c.done()) continue;
+        const double* r = hr + size_t(i) * kNdtPartialStride;
+        // SURVEY.md §8(d) byte model: point (16) + probes (8 each) + 48 per valid neighbour voxel
+        deriv_alg_bytes += double(pairs_[i].n) * (16.0 + 8.0 * probes) + r[28] * 48.0;
+        c.on_result(r);
+    }
+    return MRGFE_OK;
+}
+
+int NdtEngine::align_all()
+{
+    MRGFE_TRY(ctx_->bind());
+    MRGFE_TRY(build_targets());
+    if (pairs_dirty_) MRGFE_TRY(upload_pairs());
+    deriv_ms = 0;
+    deriv_launches = 0;
+    deriv_alg_bytes = 0;
+    for (auto& p : pairs_) {
+        p.ctl.start(prm_, p.guess, p.n);
+        if (targets_[p.target].status != MRGFE_OK && !p.ctl.done()) p.ctl.abort_no_target();
+    }
+    // every controller needs at most (max_iterations + 2) * (max line-search trials + 2) evaluations
+    const int round_cap = (prm_.max_iterations + 3) * 13 + 8;
+    for (int round = 0; round < round_cap; ++round) {
+        int active = 0;
+        MRGFE_TRY(run_round(&active));
+        if (!active) return MRGFE_OK;
+    }
+    set_error("NDT alignment did not terminate within %d rounds", round_cap);
+    return MRGFE_ERR_STATE;
+}
+
+int NdtEngine::evaluate(int pair, const float T[16], const double p[6], int mode, double* score, double grad[6], double hess[36])
+{
+    if (pair < 0 || pair >= n_pairs()) { set_error("evaluate: pair index out of range"); return MRGFE_ERR_INVALID; }
+    if (mode < 0 || mode > 2) { set_error("evaluate: mode must be 0, 1 or 2"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(ctx_->bind());
+    MRGFE_TRY(build_targets());
+    if (targets_[pairs_[pair].target].status != MRGFE_OK) { set_error("evaluate: target has no grid"); return MRGFE_ERR_STATE; }
+    if (pairs_dirty_) MRGFE_TRY(upload_pairs());
+    const int P = n_pairs();
+    NdtController tmp;
+    tmp.start(prm_, T, pairs_[pair].n);  // gauss constants
+    NdtRequest r;
+    r.mode = mode;
+    std::memcpy(r.T, T, sizeof(r.T));
+    std::memcpy(r.p, p, sizeof(r.p));
+    NdtController::angle_tables(p, r.j_ang, r.h_ang);
+    NdtEvalDev* he = h_evals_.as<NdtEvalDev>();
+    for (int i = 0; i < P; ++i) he[i].active = 0;
+    fill_eval(he[pair], r, tmp, prm_.search, true);
+    hipStream_t st = ctx_->stream;
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));
+    MRGFE_TRY(ndt_launch_derivatives(ctx_, mode, prm_.search, max_nblk_, P, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(),
+                                     d_partials_.as<double>(), ppt_));
+    MRGFE_TRY(ndt_launch_reduce(ctx_, P, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_partials_.as<double>(), d_results_.as<double>()));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(h_results_.p, d_results_.p, sizeof(double) * kNdtPartialStride * P, hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    const double* res = h_results_.as<double>() + size_t(pair) * kNdtPartialStride;
+    *score = res[0];
+    for (int k = 0; k < 6; ++k) grad[k] = res[1 + k];
+    int t = 7;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) { hess[i * 6 + j] = res[t]; hess[j * 6 + i] = res[t]; ++t; }
+    return MRGFE_OK;
+}
+
+int NdtEngine::aligned_cloud(int pair, float* out)
+{
+    if (pair < 0 || pair >= n_pairs()) { set_error("aligned_cloud: pair index out of range"); return MRGFE_ERR_INVALID; }
+    const NdtPairInfo& p = pairs_[pair];
+    if (p.n == 0) return MRGFE_OK;
+    MRGFE_TRY(ctx_->bind());
+    MRGFE_TRY(d_T12_.ensure(64));
+    MRGFE_TRY(d_aligned_.ensure(size_t(p.n) * 16));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_T12_.p, p.ctl.final_transformation(), 48, hipMemcpyHostToDevice, ctx_->stream));
+    MRGFE_TRY(launch_transform_cloud(ctx_, p.d_src, d_aligned_.as<float4>(), p.n, d_T12_.as<float>()));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(out, d_aligned_.p, size_t(p.n) * 16, hipMemcpyDeviceToHost, ctx_->stream));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(ctx_->stream));
+    return MRGFE_OK;
+}
+
+}  // namespace mrgfe

@@ -1,0 +1,92 @@
+// csrc/ndt_engine.h — batched NDT_HIP engine: owns the device-resident clouds and target grids of a batch of
+// (target, source, guess) alignments and advances all of them together, one derivative launch per round.
+// A single pcl::Registration-style object (mrgfe_reg) is a batch with one target and one pair.
+#pragma once
+#include <vector>
+
+#include "cellsort.h"
+#include "common.h"
+#include "ndt_build.h"
+#include "ndt_controller.h"
+#include "ndt_types.h"
+
+namespace mrgfe {
+
+struct NdtTargetInfo {
+    const float4* d_pts = nullptr;
+    uint32_t      n = 0;
+    int           status = MRGFE_ERR_STATE;  // MRGFE_OK once the grid is built
+    int32_t       min_b[3] = {0, 0, 0}, max_b[3] = {0, 0, 0}, div_b[3] = {0, 0, 0};
+    uint32_t      n_leaves = 0;
+    uint32_t      leaf_off = 0;
+    bool          built = false;
+};
+
+struct NdtPairInfo {
+    int           target = -1;
+    const float4* d_src = nullptr;
+    uint32_t      n = 0;
+    float         guess[16];  // row-major
+    NdtController ctl;
+};
+
+class NdtEngine {
+   public:
+    NdtEngine(mrgfe_ctx* ctx, const NdtParams& prm) : ctx_(ctx), prm_(prm) {}
+    ~NdtEngine();
+
+    void clear();                 // forget targets and pairs (device memory is kept for reuse)
+    void clear_pairs();
+    // clouds: host (strided) or device (packed float4). device clouds are referenced, not copied.
+    int add_target_host(const float* xyzi, size_t n, size_t stride);
+    int add_target_device(const void* d_xyzi, size_t n);
+    int add_pair_host(int target, const float* xyzi, size_t n, size_t stride, const float guess_rowmajor[16]);
+    int add_pair_device(int target, const void* d_xyzi, size_t n, const float guess_rowmajor[16]);
+    int set_guess(int pair, const float guess_rowmajor[16]);
+
+    int build_targets();          // voxelise every target not yet built
+    int align_all();              // run every pair to completion
+    // one derivative evaluation of pair `pair` (tests): mode 0/1/2
+    int evaluate(int pair, const float T_rowmajor[16], const double p[6], int mode, double* score, double grad[6], double hess[36]);
+    int aligned_cloud(int pair, float* out_xyzi_host);  // final_transformation * source
+
+    int n_targets() const { return static_cast<int>(targets_.size()); }
+    int n_pairs() const { return static_cast<int>(pairs_.size()); }
+    const NdtTargetInfo& target(int i) const { return targets_[i]; }
+    const NdtPairInfo&   pair(int i) const { return pairs_[i]; }
+    int read_leaves(int target, int32_t* keys, int32_t* nr_points, double* mean3, double* icov9);
+
+    // derivative-kernel accounting of the last align_all()
+    double  deriv_ms = 0;
+    int64_t deriv_launches = 0;
+    double  deriv_alg_bytes = 0;
+
+    const NdtParams& params() const { return prm_; }
+    void set_force_hash(bool f) { force_hash_ = f; }  // tests: exercise the hashed lookup on small grids
+    mrgfe_ctx* ctx() const { return ctx_; }
+
+   private:
+    mrgfe_ctx* ctx_;
+    NdtParams  prm_;
+    std::vector<NdtTargetInfo> targets_;
+    std::vector<NdtPairInfo>   pairs_;
+    Arena cloud_arena_;  // host-supplied clouds copied to the device
+    Arena grid_arena_;   // leaves, lookups, ...
+    // packed per-leaf arrays of the built targets (grid_arena_)
+    std::vector<NdtGridDev> h_grids_;
+    DevBuf d_grids_, d_pairs_, d_evals_, d_partials_, d_results_, d_T12_, d_aligned_;
+    PinBuf h_evals_, h_results_;
+    bool   pairs_dirty_ = true;
+    bool   force_hash_ = false;
+    int    ppt_ = 1;
+    uint32_t max_nblk_ = 0;
+    std::vector<NdtPairDev> h_pairs_;
+    // per-target arrays kept for read_leaves
+    struct LeafArrays { int32_t* keys; int32_t* nr_points; NdtLeafRec* leaves; double* icov64; };
+    std::vector<LeafArrays> leaf_arrays_;
+
+    int upload_pairs();
+    int run_round(int* n_active);
+};
+
+}  // namespace mrgfe

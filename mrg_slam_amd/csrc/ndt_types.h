@@ -1,0 +1,90 @@
+// csrc/ndt_types.h — device-visible data layout of the NDT target grid and of one derivative evaluation.
+//
+// HBM layout: a target grid is
+//   leaves   : NdtLeafRec[V]   48 B each: mean as 3 x f64 (the reference subtracts the f64 mean from the f32 point,
+//                              pclomp computeDerivatives), inverse covariance as 6 x f32 upper triangle (it is cast
+//                              to float in updateDerivatives anyway)
+//   icov64   : double[V][9]    only read by the rare double-precision Hessian pass (pclomp computeHessian)
+//   lookup   : dense  int32[D]          voxel key -> leaf id (-1 = no usable voxel) when D = div_b product <= 2^22
+//              hashed uint2[capacity]   (key, leaf id) open addressing, linear probing, when the box is larger
+//   nr_points, keys : int32[V] bookkeeping (ascending key = std::map iteration order of the reference)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mrgfe {
+
+constexpr int      kNdtMinPointsPerVoxel = 6;      // pclomp::VoxelGridCovariance::min_points_per_voxel_
+constexpr double   kNdtMinCovarEigMult   = 0.01;   // min_covar_eigvalue_mult_
+constexpr uint32_t kHashEmpty            = 0xFFFFFFFFu;
+constexpr uint32_t kDenseLookupMaxCells  = 1u << 22;
+
+struct __attribute__((aligned(16))) NdtLeafRec {
+    double mean[3];
+    float  icov[6];  // xx, xy, xz, yy, yz, zz
+};
+static_assert(sizeof(NdtLeafRec) == 48, "leaf record is 48 bytes (SURVEY.md §8d byte model)");
+
+struct NdtGridDev {
+    int32_t  min_b[3];
+    int32_t  max_b[3];
+    int32_t  divb_mul[3];
+    float    leaf_size;
+    float    inv_leaf;
+    uint32_t n_cells;      // D = div_b product
+    uint32_t dense;        // 1: lookup is int32[D]; 0: uint2 hash slots
+    uint32_t hash_shift;   // 32 - log2(capacity)
+    uint32_t hash_mask;    // capacity - 1
+    uint32_t n_leaves;     // V
+    const void*       lookup;
+    const NdtLeafRec* leaves;
+    const double*     icov64;
+    const float4*     centroid;  // float centroid of every leaf (KDTREE search)
+    const int32_t*    nr_points;
+};
+
+__device__ __forceinline__ uint32_t ndt_hash(uint32_t key, uint32_t shift) { return (key * 0x9E3779B1u) >> shift; }
+
+// leaf id of voxel `key`, or -1
+__device__ __forceinline__ int32_t ndt_lookup(const NdtGridDev& g, uint32_t key)
+{
+    if (g.dense) return static_cast<const int32_t*>(g.lookup)[key];
+    const uint2* slots = static_cast<const uint2*>(g.lookup);
+    uint32_t h = ndt_hash(key, g.hash_shift);
+    for (uint32_t probe = 0; probe <= g.hash_mask; ++probe) {
+        uint2 s = slots[h];
+        if (s.x == key) return static_cast<int32_t>(s.y);
+        if (s.x == kHashEmpty) return -1;
+        h = (h + 1) & g.hash_mask;
+    }
+    return -1;
+}
+
+// one alignment in flight: static part
+struct NdtPairDev {
+    const float4* src;     // packed xyzi
+    uint32_t      n_src;
+    uint32_t      grid;    // index into the NdtGridDev array
+    uint32_t      part_off;  // first block-partial record of this pair
+    uint32_t      nblk;      // workgroups of this pair per evaluation
+};
+
+// per-evaluation part, rewritten by the host controller before every launch
+struct NdtEvalDev {
+    float    T[12];        // row-major 3x4 of final_transformation_ (pcl::transformPointCloud operand)
+    float    j_ang[8][3];  // computeAngleDerivatives rows a..h (double products cast to float)
+    float    h_ang[15][3]; // rows a2,a3,b2,b3,c2,c3,d1,d2,d3,e1,e2,e3,f1,f2,f3
+    double   j_ang_d[8][3];
+    double   h_ang_d[15][3];
+    double   gauss_d1, gauss_d2;
+    int32_t  mode;         // 0: score+grad+hess (float path), 1: score+grad, 2: hessian only (double path)
+    int32_t  active;       // 0: this pair is finished or waiting, its workgroups exit immediately
+    int32_t  search;       // mrgfe_ndt_search
+    int32_t  pad;
+};
+
+// block partial / final result of one evaluation: score, gradient(6), upper-triangular Hessian(21), neighbour count
+constexpr int kNdtAccum = 29;  // 1 + 6 + 21 + 1
+constexpr int kNdtPartialStride = 32;
+
+}  // namespace mrgfe

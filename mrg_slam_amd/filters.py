@@ -1,0 +1,153 @@
+"""Host-side mirror of the prefilter objects the reference's PrefilteringComponent holds
+(/root/reference/apps/prefiltering_component.cpp:158-229): pcl::VoxelGrid, pcl::RadiusOutlierRemoval,
+pcl::StatisticalOutlierRemoval plus its in-tree distance_filter, bound to libmrgfe.so.  The pcl::Filter call surface
+(setters, setInputCloud, filter) is kept."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import Context, check, default_context, lib
+
+_fp = C.POINTER(C.c_float)
+
+
+def _cloud(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != 4:
+        raise ValueError("clouds are N x 4 float32 arrays (x, y, z, intensity)")
+    return a
+
+
+class _Filter:
+    def __init__(self, ctx: Context | None = None):
+        self._ctx = ctx or default_context()
+        self._input = np.zeros((0, 4), dtype=np.float32)
+
+    def setInputCloud(self, cloud):
+        self._input = _cloud(cloud)
+
+    def filter(self) -> np.ndarray:
+        raise NotImplementedError
+
+
+class VoxelGrid(_Filter):
+    """pcl::VoxelGrid<PointXYZI> (prefiltering_component.cpp:168-171; scan_matching_odometry_component.cpp:176-179)."""
+
+    def __init__(self, ctx=None):
+        super().__init__(ctx)
+        self._leaf, self._min_pts = 0.1, 1
+        self.overflow = False
+
+    def setLeafSize(self, lx, ly=None, lz=None):
+        if (ly is not None and ly != lx) or (lz is not None and lz != lx):
+            raise ValueError("the reference only uses cubic leaves (setLeafSize(r, r, r))")
+        self._leaf = float(lx)
+
+    def setMinimumPointsNumberPerVoxel(self, n):
+        self._min_pts = int(n)
+
+    def filter(self):
+        c = self._input
+        out = np.empty_like(c)
+        m, ov = C.c_size_t(0), C.c_int(0)
+        check(lib().mrgfe_voxelgrid(self._ctx._h, c.ctypes.data_as(_fp), len(c), 16, self._leaf, self._min_pts, out.ctypes.data_as(_fp), C.byref(m), C.byref(ov)))
+        self.overflow = bool(ov.value)
+        return out[: m.value].copy()
+
+
+class RadiusOutlierRemoval(_Filter):
+    """pcl::RadiusOutlierRemoval<PointXYZI> (prefiltering_component.cpp:195-198)."""
+
+    def __init__(self, ctx=None):
+        super().__init__(ctx)
+        self._radius, self._min_neighbors = 0.5, 2
+
+    def setRadiusSearch(self, r):
+        self._radius = float(r)
+
+    def setMinNeighborsInRadius(self, n):
+        self._min_neighbors = int(n)
+
+    def filter(self):
+        c = self._input
+        out = np.empty_like(c)
+        m = C.c_size_t(0)
+        check(lib().mrgfe_radius_outlier(self._ctx._h, c.ctypes.data_as(_fp), len(c), 16, self._radius, self._min_neighbors, out.ctypes.data_as(_fp), C.byref(m)))
+        return out[: m.value].copy()
+
+
+class StatisticalOutlierRemoval(_Filter):
+    """pcl::StatisticalOutlierRemoval<PointXYZI> (prefiltering_component.cpp:189-192)."""
+
+    def __init__(self, ctx=None):
+        super().__init__(ctx)
+        self._mean_k, self._stddev = 30, 1.2
+
+    def setMeanK(self, k):
+        self._mean_k = int(k)
+
+    def setStddevMulThresh(self, s):
+        self._stddev = float(s)
+
+    def filter(self):
+        c = self._input
+        out = np.empty_like(c)
+        m = C.c_size_t(0)
+        check(lib().mrgfe_statistical_outlier(self._ctx._h, c.ctypes.data_as(_fp), len(c), 16, self._mean_k, self._stddev, out.ctypes.data_as(_fp), C.byref(m)))
+        return out[: m.value].copy()
+
+
+def distance_filter(cloud, near_thresh=0.1, far_thresh=35.0, ctx: Context | None = None) -> np.ndarray:
+    """PrefilteringComponent::distance_filter (prefiltering_component.cpp:206-229)."""
+    ctx = ctx or default_context()
+    c = _cloud(cloud)
+    out = np.empty_like(c)
+    m = C.c_size_t(0)
+    check(lib().mrgfe_distance_filter(ctx._h, c.ctypes.data_as(_fp), len(c), 16, near_thresh, far_thresh, out.ctypes.data_as(_fp), C.byref(m)))
+    return out[: m.value].copy()
+
+
+def calc_fitness_score(cloud1, cloud2, relpose, max_range=float("inf"), ctx: Context | None = None) -> float:
+    """InformationMatrixCalculator::calc_fitness_score (src/mrg_slam/information_matrix_calculator.cpp:46-81)."""
+    ctx = ctx or default_context()
+    c1, c2 = _cloud(cloud1), _cloud(cloud2)
+    T = np.ascontiguousarray(np.asarray(relpose, dtype=np.float64).T)
+    out = C.c_double(0)
+    check(lib().mrgfe_calc_fitness_score(ctx._h, c1.ctypes.data_as(_fp), len(c1), c2.ctypes.data_as(_fp), len(c2), 16, T.ctypes.data_as(C.POINTER(C.c_double)), max_range,
+                                         C.byref(out)))
+    return out.value
+
+
+def prefilter(cloud, params: dict | None = None, ctx: Context | None = None) -> np.ndarray:
+    """The chain of PrefilteringComponent::cloud_callback (:149-151) with the reference's parameter names and YAML
+    defaults (config/mrg_slam.yaml:41-64): distance_filter -> downsample -> outlier_removal."""
+    p = {"enable_distance_filter": True, "distance_near_thresh": 0.1, "distance_far_thresh": 35.0, "downsample_method": "VOXELGRID", "downsample_resolution": 0.1,
+         "downsample_min_points_per_voxel": 1, "outlier_removal_method": "RADIUS", "radius_radius": 0.5, "radius_min_neighbors": 2, "statistical_mean_k": 30,
+         "statistical_stddev": 1.2}
+    p.update(params or {})
+    c = _cloud(cloud)
+    if p["enable_distance_filter"]:
+        c = distance_filter(c, p["distance_near_thresh"], p["distance_far_thresh"], ctx)
+    if p["downsample_method"] == "VOXELGRID":
+        vg = VoxelGrid(ctx)
+        vg.setLeafSize(p["downsample_resolution"])
+        vg.setMinimumPointsNumberPerVoxel(p["downsample_min_points_per_voxel"])
+        vg.setInputCloud(c)
+        c = vg.filter()
+    elif p["downsample_method"] != "NONE":
+        raise ValueError("APPROX_VOXELGRID is order dependent and stays on the CPU in the reference (SURVEY.md A.1)")
+    if p["outlier_removal_method"] == "RADIUS":
+        ro = RadiusOutlierRemoval(ctx)
+        ro.setRadiusSearch(p["radius_radius"])
+        ro.setMinNeighborsInRadius(p["radius_min_neighbors"])
+        ro.setInputCloud(c)
+        c = ro.filter()
+    elif p["outlier_removal_method"] == "STATISTICAL":
+        so = StatisticalOutlierRemoval(ctx)
+        so.setMeanK(p["statistical_mean_k"])
+        so.setStddevMulThresh(p["statistical_stddev"])
+        so.setInputCloud(c)
+        c = so.filter()
+    return c

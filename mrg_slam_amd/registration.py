@@ -1,0 +1,289 @@
+"""Host-side mirror of the reference's registration seam, bound to libmrgfe.so through ctypes.
+
+The reference hands out ``pcl::Registration<PointXYZI,PointXYZI>::Ptr`` objects from
+``select_registration_method(rclcpp::Node*)`` (/root/reference/include/mrg_slam/registrations.hpp:20,
+src/mrg_slam/registrations.cpp:28-152) and its callers use exactly: setInputTarget, setInputSource, align(out, guess),
+hasConverged, getFinalTransformation, getFitnessScore(max_range) and getSearchMethodTarget()->nearestKSearch
+(SURVEY.md §8b).  The classes below keep those names, argument meanings and the "non-convergence is not an error"
+behaviour, so the parity tests read like code written against the reference.
+
+Clouds are N x 4 float32 arrays (x, y, z, intensity); matrices are ordinary row-major 4 x 4 numpy arrays (converted to
+the C ABI's column-major layout here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import GICP_HIP, NDT_HIP, SEARCH, Context, PairResult, RegParams, check, default_context, lib
+
+_fp = C.POINTER(C.c_float)
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+def _cloud(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != 4:
+        raise ValueError("clouds are N x 4 float32 arrays (x, y, z, intensity)")
+    return a
+
+
+def _colmajor(M) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(M, dtype=np.float32).T)
+
+
+def default_params(method: int) -> RegParams:
+    p = RegParams()
+    lib().mrgfe_reg_default_params(method, C.byref(p))
+    return p
+
+
+class HipRegistration:
+    """Common pcl::Registration call surface over one ``mrgfe_reg`` handle."""
+
+    METHOD = None
+
+    def __init__(self, params: RegParams, ctx: Context | None = None):
+        self._ctx = ctx or default_context()
+        self._params = params
+        self._h = C.c_void_p()
+        check(lib().mrgfe_reg_create(self._ctx._h, C.byref(params), C.byref(self._h)))
+        self._n_src = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().mrgfe_reg_destroy(self._h)
+                self._h = None
+        except Exception:  # noqa: BLE001
+            pass
+
+    # -- pcl::Registration ------------------------------------------------------------------------------------
+    def setInputTarget(self, cloud) -> int:
+        """registration_->setInputTarget(cloud). Returns the library status (0 ok, ERR_OVERFLOW / ERR_EMPTY when PCL
+        would abort the voxelisation): like PCL this does not raise for those, the registration simply has no target."""
+        c = _cloud(cloud)
+        st = lib().mrgfe_reg_set_target(self._h, c.ctypes.data_as(_fp), len(c), 16)
+        if st < 0 and st not in (_lib.ERR_OVERFLOW, _lib.ERR_EMPTY):
+            check(st)
+        return st
+
+    def setInputSource(self, cloud) -> None:
+        c = _cloud(cloud)
+        self._n_src = len(c)
+        check(lib().mrgfe_reg_set_source(self._h, c.ctypes.data_as(_fp), len(c), 16))
+
+    def setInputTargetDevice(self, dev_ptr: int, n: int) -> int:
+        st = lib().mrgfe_reg_set_target_device(self._h, C.c_void_p(dev_ptr), n)
+        if st < 0 and st not in (_lib.ERR_OVERFLOW, _lib.ERR_EMPTY):
+            check(st)
+        return st
+
+    def setInputSourceDevice(self, dev_ptr: int, n: int) -> None:
+        self._n_src = n
+        check(lib().mrgfe_reg_set_source_device(self._h, C.c_void_p(dev_ptr), n))
+
+    def align(self, guess=None, want_aligned: bool = False):
+        """registration_->align(*aligned, guess); returns the aligned cloud when ``want_aligned``."""
+        g = _colmajor(np.eye(4) if guess is None else guess)
+        out = np.empty((self._n_src, 4), dtype=np.float32) if want_aligned else None
+        check(lib().mrgfe_reg_align(self._h, g.ctypes.data_as(_fp), out.ctypes.data_as(_fp) if want_aligned else None))
+        return out
+
+    def hasConverged(self) -> bool:
+        return bool(lib().mrgfe_reg_has_converged(self._h))
+
+    def getFinalTransformation(self) -> np.ndarray:
+        Tc = np.empty((4, 4), dtype=np.float32)
+        check(lib().mrgfe_reg_final_transformation(self._h, Tc.ctypes.data_as(_fp)))
+        return Tc.T.copy()
+
+    def getFitnessScore(self, max_range: float = float("inf")) -> float:
+        out = C.c_double(0)
+        check(lib().mrgfe_reg_fitness(self._h, max_range, C.byref(out)))
+        return out.value
+
+    def nearestKSearch1(self, queries):
+        """getSearchMethodTarget()->nearestKSearch(pt, 1, ...) for a whole cloud of queries: (indices, sq. distances)."""
+        q = _cloud(queries)
+        idx = np.empty(len(q), dtype=np.int32)
+        sqd = np.empty(len(q), dtype=np.float32)
+        check(lib().mrgfe_reg_nn1_target(self._h, q.ctypes.data_as(_fp), len(q), 16, idx.ctypes.data_as(_ip), sqd.ctypes.data_as(_fp)))
+        return idx, sqd
+
+    def getFinalNumIteration(self) -> int:
+        return lib().mrgfe_reg_iterations(self._h)
+
+    def getHessian(self) -> np.ndarray:
+        H = np.empty((6, 6))
+        check(lib().mrgfe_reg_hessian(self._h, H.ctypes.data_as(_dp)))
+        return H
+
+    @property
+    def evals(self) -> int:
+        return lib().mrgfe_reg_evaluations(self._h)
+
+    def kernel_stats(self):
+        ms, n, b = C.c_double(0), C.c_int64(0), C.c_double(0)
+        check(lib().mrgfe_reg_kernel_stats(self._h, C.byref(ms), C.byref(n), C.byref(b)))
+        return ms.value, n.value, b.value
+
+
+class NdtHip(HipRegistration):
+    """registration_method "NDT_HIP": drop-in for the NDT_OMP branch (registrations.cpp:130-148)."""
+
+    METHOD = NDT_HIP
+
+    def __init__(self, resolution=1.0, transformation_epsilon=0.01, maximum_iterations=64, search="DIRECT7", step_size=0.1, outlier_ratio=0.55,
+                 num_threads=0, ctx: Context | None = None):
+        p = default_params(NDT_HIP)
+        p.resolution = resolution
+        p.transformation_epsilon = transformation_epsilon
+        p.maximum_iterations = maximum_iterations
+        p.nn_search_method = SEARCH[search] if isinstance(search, str) else int(search)
+        p.step_size = step_size
+        p.outlier_ratio = outlier_ratio
+        p.num_threads = num_threads
+        super().__init__(p, ctx)
+
+    def getTransformationProbability(self) -> float:
+        return lib().mrgfe_reg_trans_probability(self._h)
+
+    @property
+    def mean_neighbours(self) -> float:
+        return lib().mrgfe_ndt_mean_neighbours(self._h)
+
+    def evaluate(self, T, p, mode=0):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        s, g, H = C.c_double(0), np.zeros(6), np.zeros((6, 6))
+        check(lib().mrgfe_ndt_evaluate(self._h, _colmajor(T).ctypes.data_as(_fp), p.ctypes.data_as(_dp), mode, C.byref(s), g.ctypes.data_as(_dp), H.ctypes.data_as(_dp)))
+        return s.value, g, H
+
+    def leaves(self):
+        n = lib().mrgfe_ndt_num_leaves(self._h)
+        keys, npts = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+        mean, icov = np.empty((n, 3)), np.empty((n, 3, 3))
+        if n:
+            check(lib().mrgfe_ndt_leaves(self._h, keys.ctypes.data_as(_ip), npts.ctypes.data_as(_ip), mean.ctypes.data_as(_dp), icov.ctypes.data_as(_dp)))
+        return keys, npts, mean, icov
+
+    def grid(self):
+        a, b, c = (np.empty(3, dtype=np.int32) for _ in range(3))
+        check(lib().mrgfe_ndt_grid(self._h, a.ctypes.data_as(_ip), b.ctypes.data_as(_ip), c.ctypes.data_as(_ip)))
+        return a, b, c
+
+
+class GicpHip(HipRegistration):
+    """registration_method "GICP_HIP": drop-in for the FAST_GICP branch (registrations.cpp:55-63)."""
+
+    METHOD = GICP_HIP
+
+    def __init__(self, correspondence_randomness=20, max_correspondence_distance=2.0, transformation_epsilon=0.01, rotation_epsilon=2e-3,
+                 maximum_iterations=64, num_threads=0, ctx: Context | None = None):
+        p = default_params(GICP_HIP)
+        p.correspondence_randomness = correspondence_randomness
+        p.max_correspondence_distance = max_correspondence_distance
+        p.transformation_epsilon = transformation_epsilon
+        p.rotation_epsilon = rotation_epsilon
+        p.maximum_iterations = maximum_iterations
+        p.num_threads = num_threads
+        super().__init__(p, ctx)
+
+
+def select_registration_method(params: dict, ctx: Context | None = None) -> HipRegistration:
+    """Python mirror of mrg_slam::select_registration_method (registrations.cpp:28-152) for the HIP back ends.
+
+    ``params`` carries the reference's ROS parameter names (registration_method, reg_num_threads,
+    reg_transformation_epsilon, reg_maximum_iterations, reg_max_correspondence_distance, reg_correspondence_randomness,
+    reg_resolution, reg_nn_search_method).  "NDT_HIP" (and, to stay drop-in, "NDT_OMP"/"NDT") select :class:`NdtHip`;
+    "GICP_HIP" / "FAST_GICP" select :class:`GicpHip`.  Like the reference, an unknown name falls through to NDT.
+    """
+    method = str(params.get("registration_method", "FAST_GICP"))
+    eps = float(params.get("reg_transformation_epsilon", 0.01))
+    iters = int(params.get("reg_maximum_iterations", 64))
+    threads = int(params.get("reg_num_threads", 0))
+    if method in ("GICP_HIP", "FAST_GICP"):
+        return GicpHip(int(params.get("reg_correspondence_randomness", 20)), float(params.get("reg_max_correspondence_distance", 2.0)), eps,
+                       maximum_iterations=iters, num_threads=threads, ctx=ctx)
+    search = str(params.get("reg_nn_search_method", "DIRECT7"))
+    if search not in ("KDTREE", "DIRECT1"):
+        search = "DIRECT7"  # registrations.cpp:140-146: anything else means DIRECT7
+    return NdtHip(float(params.get("reg_resolution", 1.0)), eps, iters, search, num_threads=threads, ctx=ctx)
+
+
+class BatchMatcher:
+    """Batched candidate matching: the candidate loop of LoopDetector::matching (src/mrg_slam/loop_detector.cpp:126-145)
+    advanced for all candidates at once on one GPU (mrgfe_batch_*)."""
+
+    def __init__(self, params: RegParams | None = None, ctx: Context | None = None, **ndt_kwargs):
+        self._ctx = ctx or default_context()
+        if params is None:
+            params = default_params(NDT_HIP)
+            params.transformation_epsilon = ndt_kwargs.get("transformation_epsilon", 0.01)
+            params.maximum_iterations = ndt_kwargs.get("maximum_iterations", 64)
+            params.resolution = ndt_kwargs.get("resolution", 1.0)
+            params.nn_search_method = SEARCH[ndt_kwargs.get("search", "DIRECT7")]
+        self._h = C.c_void_p()
+        check(lib().mrgfe_batch_create(self._ctx._h, C.byref(params), C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().mrgfe_batch_destroy(self._h)
+                self._h = None
+        except Exception:  # noqa: BLE001
+            pass
+
+    def clear(self):
+        check(lib().mrgfe_batch_clear(self._h))
+
+    def add_target(self, cloud) -> int:
+        c = _cloud(cloud)
+        return check(lib().mrgfe_batch_add_target(self._h, c.ctypes.data_as(_fp), len(c), 16))
+
+    def add_target_device(self, dev_ptr: int, n: int) -> int:
+        return check(lib().mrgfe_batch_add_target_device(self._h, C.c_void_p(dev_ptr), n))
+
+    def add_pair(self, target: int, source, guess=None) -> int:
+        c = _cloud(source)
+        g = _colmajor(np.eye(4) if guess is None else guess)
+        return check(lib().mrgfe_batch_add_pair(self._h, target, c.ctypes.data_as(_fp), len(c), 16, g.ctypes.data_as(_fp)))
+
+    def add_pair_device(self, target: int, dev_ptr: int, n: int, guess=None) -> int:
+        g = _colmajor(np.eye(4) if guess is None else guess)
+        return check(lib().mrgfe_batch_add_pair_device(self._h, target, C.c_void_p(dev_ptr), n, g.ctypes.data_as(_fp)))
+
+    def set_guess(self, pair: int, guess) -> None:
+        check(lib().mrgfe_batch_set_guess(self._h, pair, _colmajor(guess).ctypes.data_as(_fp)))
+
+    def build_targets(self) -> None:
+        check(lib().mrgfe_batch_build_targets(self._h))
+
+    def align(self, fitness_max_range: float = -1.0):
+        """Returns a structured numpy array of mrgfe_pair_result records (one per pair)."""
+        n = lib().mrgfe_batch_num_pairs(self._h)
+        res = (PairResult * max(n, 1))()
+        check(lib().mrgfe_batch_align(self._h, fitness_max_range, res))
+        return results_to_numpy(res, n)
+
+    def kernel_stats(self):
+        ms, n, b = C.c_double(0), C.c_int64(0), C.c_double(0)
+        check(lib().mrgfe_batch_kernel_stats(self._h, C.byref(ms), C.byref(n), C.byref(b)))
+        return ms.value, n.value, b.value
+
+
+RESULT_DTYPE = np.dtype([("T", np.float32, (16,)), ("H", np.float64, (36,)), ("fitness", np.float64), ("trans_probability", np.float64),
+                         ("converged", np.int32), ("iterations", np.int32), ("evaluations", np.int32), ("pair_id", np.int32)])
+assert RESULT_DTYPE.itemsize == 384
+
+
+def results_to_numpy(res, n: int) -> np.ndarray:
+    return np.frombuffer(bytes(res), dtype=RESULT_DTYPE, count=n).copy()
+
+
+def result_matrix(rec) -> np.ndarray:
+    """Row-major 4 x 4 transformation of one result record (stored column-major)."""
+    return np.asarray(rec["T"], dtype=np.float32).reshape(4, 4).T.copy()

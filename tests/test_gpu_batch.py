@@ -1,0 +1,58 @@
+"""GPU: batched candidate matching (LoopDetector::matching candidate loop) equals one-by-one registration."""
+import numpy as np
+import pytest
+
+from conftest import small_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batch_equals_sequential_registrations():
+    from mrg_slam_amd import BatchMatcher, NdtHip, synth
+    from mrg_slam_amd.registration import result_matrix
+    from oracle import oracle as orc
+
+    targets = [small_cloud(5000, 100), small_cloud(3000, 101)]
+    rng = np.random.default_rng(5)
+    pairs = []
+    for k in range(7):
+        ti = k % 2
+        rel = synth.make_pose(rng.normal(0, 0.2, 3), synth.rot_xyz(*rng.normal(0, 0.02, 3)))
+        src = orc.transform_points(np.linalg.inv(rel), targets[ti][: 2500 + 300 * k])  # ragged sizes
+        guess = synth.perturb_pose(np.eye(4), rng)
+        pairs.append((ti, src, guess))
+    bm = BatchMatcher(transformation_epsilon=0.01, maximum_iterations=64)
+    tids = [bm.add_target(t) for t in targets]
+    for ti, src, guess in pairs:
+        bm.add_pair(tids[ti], src, guess)
+    res = bm.align(fitness_max_range=float("inf"))
+    assert len(res) == len(pairs)
+    for k, (ti, src, guess) in enumerate(pairs):
+        reg = NdtHip(transformation_epsilon=0.01, maximum_iterations=64)
+        reg.setInputTarget(targets[ti])
+        reg.setInputSource(src)
+        reg.align(guess)
+        np.testing.assert_array_equal(result_matrix(res[k]), reg.getFinalTransformation())
+        assert res[k]["converged"] == int(reg.hasConverged())
+        assert res[k]["iterations"] == reg.getFinalNumIteration()
+        assert res[k]["evaluations"] == reg.evals
+        assert res[k]["pair_id"] == k
+        np.testing.assert_array_equal(res[k]["H"].reshape(6, 6), reg.getHessian())
+        assert res[k]["fitness"] == pytest.approx(reg.getFitnessScore(), rel=1e-12)
+    ms, launches, nbytes = bm.kernel_stats()
+    assert ms > 0 and launches > 0 and nbytes > 0
+
+
+def test_batch_edge_cases():
+    from mrg_slam_amd import BatchMatcher
+
+    bm = BatchMatcher()
+    assert len(bm.align()) == 0  # empty batch
+    t = bm.add_target(small_cloud(2000, 1))
+    e = bm.add_target(np.zeros((0, 4), np.float32))  # empty target: its pairs do not converge
+    bm.add_pair(t, small_cloud(2000, 1))
+    bm.add_pair(e, small_cloud(100, 2))
+    bm.add_pair(t, np.zeros((0, 4), np.float32))  # empty source
+    res = bm.align()
+    assert res[0]["converged"] == 1
+    assert res[1]["converged"] == 0 and res[2]["converged"] == 0

@@ -1,0 +1,131 @@
+"""GPU: prefilter chain and exact nearest-neighbour queries against the CPU oracle (bit-exact: these are index /
+membership computations plus float sums in a defined order)."""
+import numpy as np
+import pytest
+
+from conftest import small_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def test_distance_filter_exact():
+    from mrg_slam_amd import distance_filter
+    from oracle import oracle as orc
+
+    c = small_cloud(20000, 3, extent=(45, 45, 3))
+    c[:5, :3] = 0.01
+    np.testing.assert_array_equal(distance_filter(c, 0.1, 35.0), orc.distance_filter(c, 0.1, 35.0))
+    assert len(distance_filter(np.zeros((0, 4), np.float32))) == 0
+    assert len(distance_filter(c, 100.0, 200.0)) == 0
+
+
+@pytest.mark.parametrize("leaf,min_pts,n", [(0.1, 1, 30000), (0.5, 1, 30000), (0.5, 3, 8000), (2.0, 1, 8000), (0.05, 1, 3000)])
+def test_voxelgrid_exact(leaf, min_pts, n):
+    from mrg_slam_amd import VoxelGrid
+    from oracle import oracle as orc
+
+    c = small_cloud(n, 5)
+    vg = VoxelGrid()
+    vg.setLeafSize(leaf, leaf, leaf)
+    vg.setMinimumPointsNumberPerVoxel(min_pts)
+    vg.setInputCloud(c)
+    out = vg.filter()
+    exp, status = orc.voxelgrid(c, leaf, min_pts, orc.ORDER_STABLE)
+    assert status == 0 and not vg.overflow
+    np.testing.assert_array_equal(out, exp)
+    # PCL's own (std::sort) in-voxel order gives the same voxels and centroids to float rounding
+    exp2, _ = orc.voxelgrid(c, leaf, min_pts, orc.ORDER_STD_SORT)
+    assert exp2.shape == out.shape
+    np.testing.assert_allclose(out, exp2, rtol=0, atol=2e-5)
+
+
+def test_voxelgrid_edge_cases():
+    from mrg_slam_amd import VoxelGrid
+    from oracle import oracle as orc
+
+    vg = VoxelGrid()
+    vg.setLeafSize(0.1)
+    vg.setInputCloud(np.zeros((0, 4), np.float32))
+    assert len(vg.filter()) == 0
+    c = small_cloud(500)
+    c[0, :3] = [3e5, -3e5, 3e5]  # index overflow: PCL warns and passes the cloud through
+    vg.setInputCloud(c)
+    out = vg.filter()
+    assert vg.overflow
+    np.testing.assert_array_equal(out, c)
+    c = small_cloud(500)
+    c[7, 1] = np.nan  # non-finite points are dropped
+    vg.setInputCloud(c)
+    exp, _ = orc.voxelgrid(c, 0.1, 1)
+    np.testing.assert_array_equal(vg.filter(), exp)
+
+
+@pytest.mark.parametrize("radius,min_nb", [(0.5, 2), (0.3, 1), (1.0, 8)])
+def test_radius_outlier_exact(radius, min_nb):
+    from mrg_slam_amd import RadiusOutlierRemoval
+    from oracle import oracle as orc
+
+    c = small_cloud(20000, 7)
+    c[:20, :3] += 100.0
+    ro = RadiusOutlierRemoval()
+    ro.setRadiusSearch(radius)
+    ro.setMinNeighborsInRadius(min_nb)
+    ro.setInputCloud(c)
+    out = ro.filter()
+    exp, keep = orc.radius_outlier(c, radius, min_nb)
+    assert 0 < len(exp) < len(c)
+    np.testing.assert_array_equal(out, exp)
+    # lattice with spacing exactly r: the compare is inclusive (sqdist <= r*r)
+    g = np.zeros((27, 4), np.float32)
+    g[:, :3] = np.stack(np.meshgrid(*[np.arange(3) * 0.5] * 3, indexing="ij"), -1).reshape(-1, 3)
+    ro2 = RadiusOutlierRemoval()
+    ro2.setRadiusSearch(0.5)
+    ro2.setMinNeighborsInRadius(3)
+    ro2.setInputCloud(g)
+    np.testing.assert_array_equal(ro2.filter(), g)
+
+
+def test_statistical_outlier_exact():
+    from mrg_slam_amd import StatisticalOutlierRemoval
+    from oracle import oracle as orc
+
+    c = small_cloud(6000, 13)
+    c[:10, :3] += 60.0
+    for k, s in ((30, 1.2), (10, 0.5)):
+        so = StatisticalOutlierRemoval()
+        so.setMeanK(k)
+        so.setStddevMulThresh(s)
+        so.setInputCloud(c)
+        exp, _ = orc.statistical_outlier(c, k, s)
+        np.testing.assert_array_equal(so.filter(), exp)
+
+
+def test_prefilter_chain_on_street_scan(street_pair_vlp16):
+    from mrg_slam_amd import prefilter
+    from oracle import oracle as orc
+
+    tgt, _, _ = street_pair_vlp16
+    exp = orc.distance_filter(tgt, 0.1, 35.0)
+    exp, _ = orc.voxelgrid(exp, 0.1, 1)
+    exp, _ = orc.radius_outlier(exp, 0.5, 2)
+    np.testing.assert_array_equal(prefilter(tgt), exp)
+
+
+def test_nearest_neighbour_and_fitness_exact():
+    from mrg_slam_amd import NdtHip, calc_fitness_score, synth
+    from oracle import oracle as orc
+
+    t, q = small_cloud(20000, 11), small_cloud(3000, 12, extent=(30, 20, 5))
+    q[:3, :3] += 500.0  # far outside the target's bounding box
+    reg = NdtHip()
+    reg.setInputTarget(t)
+    idx, sqd = reg.nearestKSearch1(q)
+    bi, bd = orc.nn1_brute(t, q)
+    np.testing.assert_array_equal(sqd, bd)
+    np.testing.assert_array_equal(idx, bi)
+    rel = synth.make_pose([0.05, -0.02, 0.01], synth.rot_xyz(0.001, 0.002, -0.003))
+    for max_range in (float("inf"), 0.01, 1e-9):
+        got = calc_fitness_score(t, q, rel, max_range)
+        exp = orc.calc_fitness_score(t, q, rel, max_range)
+        assert got == pytest.approx(exp, rel=1e-12)
+    assert calc_fitness_score(t, np.zeros((0, 4), np.float32), rel) == np.finfo(np.float64).max

@@ -1,0 +1,180 @@
+"""GPU: NDT_HIP against the CPU oracle (restated pclomp NDT) through the C ABI, on identical inputs.
+
+Bars (BASELINE.json north_star): final transformation within 1e-4 m / 1e-4 rad of the oracle; per-evaluation sums
+to float-rounding level (the per-pair terms are f32 in both, accumulated in f64)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import small_cloud
+
+pytestmark = pytest.mark.gpu
+
+TOL_T, TOL_R = 1e-4, 1e-4  # metres / radians (north_star)
+
+
+def _rot_angle(Ra, Rb):
+    dR = Ra.astype(np.float64).T @ Rb.astype(np.float64)
+    return float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)))
+
+
+def _pair(n=4000, seed=0, noise=0.01):
+    from mrg_slam_amd import synth
+    from oracle import oracle as orc
+
+    tgt = small_cloud(n, seed)
+    rel = synth.make_pose([0.25, -0.1, 0.03], synth.rot_xyz(0.01, -0.008, 0.03))
+    src = orc.transform_points(np.linalg.inv(rel), tgt)
+    src[:, :3] += np.random.default_rng(seed + 1).normal(0, noise, (len(src), 3)).astype(np.float32)
+    return tgt, src, rel
+
+
+def _both(tgt, src, **kw):
+    from mrg_slam_amd import NdtHip
+    from oracle import oracle as orc
+
+    search = kw.pop("search", "DIRECT7")
+    g = NdtHip(search=search, **kw)
+    o = orc.Ndt(search=search, num_threads=4, **kw)
+    assert g.setInputTarget(tgt) == 0 and o.setInputTarget(tgt) == 0
+    g.setInputSource(src)
+    o.setInputSource(src)
+    return g, o
+
+
+@pytest.mark.parametrize("force_hash", ["0", "1"])
+def test_target_grid_matches_oracle(force_hash, monkeypatch):
+    monkeypatch.setenv("MRGFE_FORCE_HASH", force_hash)
+    tgt, src, _ = _pair(6000)
+    tgt[5, 0] = np.nan  # non-finite points are skipped by both
+    g, o = _both(tgt, src)
+    gk, gn, gm, gi = g.leaves()
+    ok, on, om, oc, oi = o.leaves()
+    np.testing.assert_array_equal(gk, ok)
+    np.testing.assert_array_equal(gn, on)
+    for a, b in zip(g.grid(), o.grid()):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_allclose(gm, om, rtol=0, atol=1e-12)
+    valid = on >= 6
+    assert valid.sum() > 50
+    scale = np.abs(oi[valid]).max(axis=(1, 2), keepdims=True)
+    # f64 sums are reduced in a different order (wavefront tree vs sequential): agreement to ~1e-8 of the matrix scale
+    assert (np.abs(gi[valid] - oi[valid]) <= 1e-7 * scale).all()
+    assert (gi[~valid] == 0).all()
+
+
+@pytest.mark.parametrize("search", ["DIRECT7", "DIRECT1", "DIRECT26", "KDTREE"])
+@pytest.mark.parametrize("force_hash", ["0", "1"])
+def test_single_evaluation_matches_oracle(search, force_hash, monkeypatch):
+    from oracle import oracle as orc
+
+    monkeypatch.setenv("MRGFE_FORCE_HASH", force_hash)
+    tgt, src, _ = _pair(5000, seed=3)
+    g, o = _both(tgt, src, search=search)
+    p = np.array([0.2, -0.05, 0.01, 0.012, -0.006, 0.025])
+    T = orc.pose_to_matrix(p)
+    for mode in (0, 1, 2):
+        gs, gg, gH = g.evaluate(T, p, mode)
+        os_, og, oH = o.evaluate(T, p, mode)
+        if mode != 2:
+            assert gs == pytest.approx(os_, rel=1e-9)
+            np.testing.assert_allclose(gg, og, rtol=0, atol=1e-8 * np.abs(og).max())
+        if mode != 1:
+            # the GPU accumulates the upper triangle and mirrors it; the reference fills all 36 entries in float
+            np.testing.assert_allclose(gH, oH, rtol=0, atol=2e-6 * np.abs(oH).max())
+            np.testing.assert_array_equal(gH, gH.T)
+
+
+@pytest.mark.parametrize("eps", [0.1, 0.01, 0.001])
+@pytest.mark.parametrize("guess_kind", ["identity", "warm", "far"])
+def test_align_matches_oracle(eps, guess_kind):
+    from mrg_slam_amd import synth
+
+    tgt, src, rel = _pair(6000, seed=5)
+    g, o = _both(tgt, src, transformation_epsilon=eps, maximum_iterations=64)
+    guess = {"identity": np.eye(4), "warm": synth.warm_guess(rel, 3), "far": synth.make_pose([0.8, 0.5, 0.1], synth.rot_xyz(0.02, 0.01, -0.08)) @ rel}[guess_kind]
+    aligned = g.align(guess, want_aligned=True)
+    o.align(guess)
+    Tg, To = g.getFinalTransformation(), o.getFinalTransformation()
+    assert g.hasConverged() == o.hasConverged()
+    assert g.getFinalNumIteration() == o.getFinalNumIteration()
+    assert g.evals == o.evals
+    assert np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3]) <= TOL_T
+    assert _rot_angle(Tg[:3, :3], To[:3, :3]) <= TOL_R
+    assert g.getTransformationProbability() == pytest.approx(o.getTransformationProbability(), rel=1e-6)
+    np.testing.assert_allclose(g.getHessian(), o.getHessian(), rtol=0, atol=1e-4 * np.abs(o.getHessian()).max())
+    assert g.mean_neighbours == pytest.approx(o.mean_neighbours, rel=1e-3)
+    # output cloud == final_transformation * source, in pcl::transformPointCloud's float operation order
+    from oracle import oracle as orc
+
+    np.testing.assert_array_equal(aligned, orc.transform_points(Tg, src))
+    assert g.getFitnessScore() == pytest.approx(o.getFitnessScore(), rel=1e-3)
+
+
+def test_align_on_street_scan_pair(street_pair_vlp16):
+    from mrg_slam_amd import prefilter, synth
+    from oracle import oracle as orc
+
+    tgt, src, rel = street_pair_vlp16
+    # GPU prefilter chain == oracle prefilter chain (checked in test_gpu_filters); use it to feed both
+    ft, fs = prefilter(tgt), prefilter(src)
+    g, o = _both(ft, fs, transformation_epsilon=0.01)
+    guess = synth.warm_guess(rel, 0)
+    g.align(guess)
+    o.align(guess)
+    Tg, To = g.getFinalTransformation(), o.getFinalTransformation()
+    assert np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3]) <= TOL_T
+    assert _rot_angle(Tg[:3, :3], To[:3, :3]) <= TOL_R
+    assert (g.hasConverged(), g.getFinalNumIteration(), g.evals) == (o.hasConverged(), o.getFinalNumIteration(), o.evals)
+    assert np.linalg.norm(Tg[:3, 3] - rel[:3, 3]) < 0.05  # and both are near the true motion
+
+
+def test_degenerate_inputs_behave_like_the_reference():
+    from mrg_slam_amd import NdtHip, _lib, synth
+
+    g = NdtHip()
+    assert g.setInputTarget(np.zeros((0, 4), np.float32)) == _lib.ERR_EMPTY
+    g.setInputSource(small_cloud(100))
+    g.align(np.eye(4))
+    assert not g.hasConverged()
+    np.testing.assert_array_equal(g.getFinalTransformation(), np.eye(4, dtype=np.float32))
+    # no voxel reaches 6 points: zero score, zero step -> converged at the guess with 0 iterations
+    sparse = small_cloud(40, extent=(200, 200, 50))
+    g2 = NdtHip()
+    assert g2.setInputTarget(sparse) == 0
+    g2.setInputSource(sparse)
+    guess = synth.make_pose([0.3, 0, 0], np.eye(3))
+    g2.align(guess)
+    assert g2.hasConverged() and g2.getFinalNumIteration() == 0
+    np.testing.assert_array_equal(g2.getFinalTransformation(), guess.astype(np.float32))
+    # index overflow is reported, the registration has no target
+    far = small_cloud(100)
+    far[0, 0] = 1e6
+    g3 = NdtHip(resolution=0.01)
+    assert g3.setInputTarget(far) == _lib.ERR_OVERFLOW
+    # empty source: nothing to do
+    g4 = NdtHip()
+    assert g4.setInputTarget(small_cloud(500)) == 0
+    g4.setInputSource(np.zeros((0, 4), np.float32))
+    g4.align(np.eye(4))
+    assert not g4.hasConverged()
+    # align before any input is a state error
+    with pytest.raises(_lib.MrgfeError):
+        NdtHip().align(np.eye(4))
+
+
+def test_target_can_be_replaced_and_source_kept():
+    # keyframe switch of the odometry component (scan_matching_odometry_component.cpp:326-339)
+    tgt, src, _ = _pair(3000, seed=9)
+    g, o = _both(tgt, src, transformation_epsilon=0.01)
+    g.align(np.eye(4))
+    first = g.getFinalTransformation()
+    tgt2 = small_cloud(3000, 10)
+    assert g.setInputTarget(tgt2) == 0 and o.setInputTarget(tgt2) == 0
+    g.align(np.eye(4))
+    o.align(np.eye(4))
+    assert np.linalg.norm(g.getFinalTransformation()[:3, 3].astype(np.float64) - o.getFinalTransformation()[:3, 3]) <= TOL_T
+    assert g.setInputTarget(tgt) == 0
+    g.align(np.eye(4))
+    np.testing.assert_array_equal(g.getFinalTransformation(), first)  # bitwise reproducible
