@@ -34,6 +34,15 @@ def rot_xyz(rx: float, ry: float, rz: float) -> np.ndarray:
     return Rx @ Ry @ Rz
 
 
+def rotation_angle(Ra, Rb) -> float:
+    """Angle (rad) of Ra^T Rb, accurate for tiny angles: uses the skew part (sin) instead of arccos of the trace,
+    which loses everything below ~5e-4 rad for float32 matrices."""
+    dR = np.asarray(Ra, dtype=np.float64)[:3, :3].T @ np.asarray(Rb, dtype=np.float64)[:3, :3]
+    v = 0.5 * np.array([dR[2, 1] - dR[1, 2], dR[0, 2] - dR[2, 0], dR[1, 0] - dR[0, 1]])
+    s, c = float(np.linalg.norm(v)), 0.5 * (float(np.trace(dR)) - 1.0)
+    return float(np.arctan2(s, c))
+
+
 def make_pose(t, R) -> np.ndarray:
     T = np.eye(4)
     T[:3, :3] = R

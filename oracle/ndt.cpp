@@ -361,11 +361,13 @@ void Ndt::compute_hessian(double hess[36], const double p[6])
     const int n = static_cast<int>(source.size() / 4);
     for (int k = 0; k < 36; ++k) hess[k] = 0;
     ++n_evals;
+    long long nb_total = 0;
     for (int idx = 0; idx < n; ++idx) {
         const float xt[3] = {trans_[3 * idx], trans_[3 * idx + 1], trans_[3 * idx + 2]};
         int nb[27];
         int cnt = cells.neighbours(xt[0], xt[1], xt[2], search, nb);
         if (cnt == 0) continue;
+        nb_total += cnt;
         const float* xp = &source[4 * static_cast<size_t>(idx)];
         const double x[3] = {xp[0], xp[1], xp[2]};
         auto dotd = [&](const double* a) { return x[0] * a[0] + x[1] * a[1] + x[2] * a[2]; };
@@ -403,6 +405,7 @@ void Ndt::compute_hessian(double hess[36], const double p[6])
             }
         }
     }
+    neighbours_sum += n > 0 ? static_cast<double>(nb_total) / n : 0.0;
 }
 
 double Ndt::evaluate(const float T[16], const double p[6], int mode, double grad[6], double hess[36])

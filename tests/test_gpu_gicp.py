@@ -18,8 +18,9 @@ def _pair(n=3000, seed=0):
 
 
 def _rot_angle(Ra, Rb):
-    dR = Ra.astype(np.float64).T @ Rb.astype(np.float64)
-    return float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)))
+    from mrg_slam_amd import synth
+
+    return synth.rotation_angle(Ra, Rb)
 
 
 @pytest.mark.parametrize("eps", [0.1, 0.01])

@@ -15,8 +15,9 @@ TOL_T, TOL_R = 1e-4, 1e-4  # metres / radians (north_star)
 
 
 def _rot_angle(Ra, Rb):
-    dR = Ra.astype(np.float64).T @ Rb.astype(np.float64)
-    return float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)))
+    from mrg_slam_amd import synth
+
+    return synth.rotation_angle(Ra, Rb)
 
 
 def _pair(n=4000, seed=0, noise=0.01):

@@ -92,8 +92,7 @@ def test_align_recovers_known_transform():
     T = ndt.getFinalTransformation().astype(np.float64)
     assert ndt.hasConverged()
     assert np.linalg.norm(T[:3, 3] - rel[:3, 3]) < 0.02
-    dR = T[:3, :3].T @ rel[:3, :3]
-    assert np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)) < 2e-3
+    assert synth.rotation_angle(T, rel) < 2e-3
     assert ndt.getFitnessScore() < 0.01
     aligned = ndt.align(np.eye(4), want_aligned=True)
     np.testing.assert_array_equal(aligned, orc.transform_points(ndt.getFinalTransformation(), src))
