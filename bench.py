@@ -124,15 +124,13 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    k_ms = k_launch = k_bytes = 0.0
+    per_mode = np.zeros((3, 3))  # [mode] -> (device ms, launches, algorithmic bytes), HIP events around every launch
     evals = iters = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
-        ms, nl, nb = bm.kernel_stats()
-        k_ms += ms
-        k_launch += nl
-        k_bytes += nb
+        for m in range(3):
+            per_mode[m] += bm.kernel_stats(m)
         evals += int(res["evaluations"].sum())
         iters += int(res["iterations"].sum())
     sync()
@@ -201,7 +199,12 @@ def main():
             same = same and bool(res[k]["converged"]) == conv and int(res[k]["iterations"]) == it
         parity = {"pairs": ncpu, "max_dt_m": max(dts), "max_dr_rad": max(drs), "same_iterations_and_convergence": same, "bar": "1e-4 m / 1e-4 rad"}
 
+    # dominant kernel = ndt_derivatives_kernel<0,7> (score + gradient + Hessian); the other two variants are listed beside it
+    k_ms, k_launch, k_bytes = per_mode[0]
     achieved = (k_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
+    variants = {name: {"launches": int(per_mode[m][1]), "avg_launch_ms": (per_mode[m][0] / per_mode[m][1]) if per_mode[m][1] else None,
+                       "achieved_GBps": (per_mode[m][2] / 1e9) / (per_mode[m][0] / 1e3) if per_mode[m][0] > 0 else None}
+                for m, name in enumerate(("ndt_derivatives_kernel<0,7>", "ndt_derivatives_kernel<1,7>", "ndt_derivatives_kernel<2,7>"))}
     true_err = float(np.mean([np.linalg.norm(result_matrix(res[b])[:3, 3] - pairs[b][3][:3, 3]) for b in range(args.batch)]))
     out = {
         "metric": "scan-pair alignments/sec (NDT, ~120k pts, 1.0 m voxel)",
@@ -226,9 +229,10 @@ def main():
             "parallelism": f"{world} x 1 GPU, pairs sharded per rank, RCCL all-gather of 384-byte result records" if world > 1 else "1 GPU",
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel": "ndt_derivatives_kernel", "avg_launch_ms": (k_ms / k_launch) if k_launch else None, "launches": int(k_launch),
+                     "kernel": "ndt_derivatives_kernel<0,7>", "avg_launch_ms": (k_ms / k_launch) if k_launch else None, "launches": int(k_launch),
                      "alg_bytes_per_launch": (k_bytes / k_launch) if k_launch else None,
-                     "byte_model": "sum over active pairs of N_src*(16 + 7*8) + valid_neighbours*48 (SURVEY.md §8d)"},
+                     "byte_model": "per launch: sum over active pairs of N_src*(16 + 7*8) + valid_neighbours*48 (SURVEY.md §8d)",
+                     "variants": variants},
         "cpu_baseline": cpu,
         "parity_vs_oracle": parity,
         "evaluations_per_alignment": evals / (args.batch * args.steps),

@@ -170,11 +170,13 @@ int  mrgfe_batch_set_guess(mrgfe_batch* b, int pair_index, const float guess[16]
 int  mrgfe_batch_build_targets(mrgfe_batch* b);
 int  mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_result* results /* n_pairs */);
 int  mrgfe_batch_num_pairs(const mrgfe_batch* b);
-/* device time (ms, HIP events on the context stream) and launch count of the derivative kernel in the last
- * mrgfe_batch_align / mrgfe_reg_align; algorithmic bytes it moved per SURVEY.md §8(d): sum over launches of
- * N_src*(16 + 7*8 + kbar*48) for the pairs active in that launch. */
-int  mrgfe_batch_kernel_stats(const mrgfe_batch* b, double* deriv_ms, int64_t* deriv_launches, double* deriv_alg_bytes);
-int  mrgfe_reg_kernel_stats(const mrgfe_reg* reg, double* deriv_ms, int64_t* deriv_launches, double* deriv_alg_bytes);
+/* Accounting of the NDT derivative kernel in the last mrgfe_batch_align / mrgfe_reg_align, per kernel variant
+ * `mode` (0: score+gradient+Hessian ndt_derivatives_kernel<0,*>, 1: score+gradient <1,*>, 2: f64 Hessian <2,*>; -1: all):
+ * device time in ms from HIP events recorded around each launch on the context stream, launch count, and the
+ * algorithmic bytes of SURVEY.md §8(d): sum over launches and active pairs of N_src*(16 + probes*8) + valid_neighbours*48.
+ * For GICP_HIP registrations `mode` is ignored and the linearize kernel is reported. */
+int  mrgfe_batch_kernel_stats(const mrgfe_batch* b, int mode, double* deriv_ms, int64_t* deriv_launches, double* deriv_alg_bytes);
+int  mrgfe_reg_kernel_stats(const mrgfe_reg* reg, int mode, double* deriv_ms, int64_t* deriv_launches, double* deriv_alg_bytes);
 
 /* ---- diagnostic entry points for the primitive tests (tests/test_gpu_primitives.py) --------------------------- */
 int mrgfe_dbg_sort_pairs(mrgfe_ctx* ctx, const uint32_t* keys, const uint32_t* vals, size_t n, int key_bits, uint32_t* out_keys, uint32_t* out_vals);

@@ -320,12 +320,12 @@ int mrgfe_ndt_leaves(mrgfe_reg* reg, int32_t* keys, int32_t* nr_points, double* 
 
 double mrgfe_ndt_mean_neighbours(const mrgfe_reg* reg) { return reg ? reg->mean_neighbours : 0.0; }
 
-int mrgfe_reg_kernel_stats(const mrgfe_reg* reg, double* ms, int64_t* launches, double* bytes)
+int mrgfe_reg_kernel_stats(const mrgfe_reg* reg, int mode, double* ms, int64_t* launches, double* bytes)
 {
     if (!reg) { set_error("NULL registration"); return MRGFE_ERR_INVALID; }
     double m = 0, b = 0;
     int64_t l = 0;
-    if (reg->ndt) { m = reg->ndt->deriv_ms; l = reg->ndt->deriv_launches; b = reg->ndt->deriv_alg_bytes; }
+    if (reg->ndt) reg->ndt->kernel_stats(mode, &m, &l, &b);
     if (reg->gicp) { m = reg->gicp->kernel_ms; l = reg->gicp->kernel_launches; b = reg->gicp->kernel_alg_bytes; }
     if (ms) *ms = m;
     if (launches) *launches = l;
@@ -483,12 +483,10 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
     return MRGFE_OK;
 }
 
-int mrgfe_batch_kernel_stats(const mrgfe_batch* b, double* ms, int64_t* launches, double* bytes)
+int mrgfe_batch_kernel_stats(const mrgfe_batch* b, int mode, double* ms, int64_t* launches, double* bytes)
 {
     if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
-    if (ms) *ms = b->ndt->deriv_ms;
-    if (launches) *launches = b->ndt->deriv_launches;
-    if (bytes) *bytes = b->ndt->deriv_alg_bytes;
+    b->ndt->kernel_stats(mode, ms, launches, bytes);
     return MRGFE_OK;
 }
 

@@ -134,6 +134,9 @@ int mrgfe_ctx_create(int device_id, mrgfe_ctx** out)
         delete c;
         return MRGFE_ERR_HIP;
     }
+    for (int m = 0; m < 3; ++m)
+        for (int k = 0; k < 2; ++k)
+            if (hipEventCreate(&c->ev_mode[m][k]) != hipSuccess) { mrgfe::set_error("failed to create HIP events"); delete c; return MRGFE_ERR_HIP; }
     *out = c;
     return MRGFE_OK;
 }
@@ -147,6 +150,7 @@ void mrgfe_ctx_destroy(mrgfe_ctx* ctx)
     for (auto& b : ctx->pin) b.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (auto& pr : ctx->ev_mode) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

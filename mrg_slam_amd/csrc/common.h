@@ -65,6 +65,7 @@ struct mrgfe_ctx {
     int          device = 0;
     hipStream_t  stream = nullptr;
     hipEvent_t   ev0 = nullptr, ev1 = nullptr;  // timing of the dominant kernel on `stream`
+    hipEvent_t   ev_mode[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // per NDT kernel variant
     mrgfe::DevBuf scratch[12];                  // named by the algorithms that use them
     mrgfe::PinBuf pin[4];
     int          cu_count = 256;

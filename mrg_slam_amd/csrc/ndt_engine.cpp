@@ -377,22 +377,24 @@ int NdtEngine::run_round(int* n_active)
     if (!active) return MRGFE_OK;
     hipStream_t st = ctx_->stream;
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));
-    MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev0, st));
-    int launches = 0;
+    // every kernel variant (mode) is bracketed by its own HIP events on the launch stream
     for (int m = 0; m < 3; ++m)
         if (modes[m]) {
+            MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev_mode[m][0], st));
             MRGFE_TRY(ndt_launch_derivatives(ctx_, m, prm_.search, max_nblk_, P, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(),
                                              d_partials_.as<double>(), ppt_));
-            ++launches;
+            MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev_mode[m][1], st));
         }
-    MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev1, st));
     MRGFE_TRY(ndt_launch_reduce(ctx_, P, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_partials_.as<double>(), d_results_.as<double>()));
     MRGFE_HIP_CHECK(hipMemcpyAsync(h_results_.p, d_results_.p, sizeof(double) * kNdtPartialStride * P, hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
-    float ms = 0;
-    MRGFE_HIP_CHECK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
-    deriv_ms += ms;
-    deriv_launches += launches;
+    for (int m = 0; m < 3; ++m)
+        if (modes[m]) {
+            float ms = 0;
+            MRGFE_HIP_CHECK(hipEventElapsedTime(&ms, ctx_->ev_mode[m][0], ctx_->ev_mode[m][1]));
+            mode_ms[m] += ms;
+            mode_launches[m] += 1;
+        }
     const double* hr = h_results_.as<double>();
     const int probes = prm_.search == MRGFE_DIRECT7 ? 7 : (prm_.search == MRGFE_DIRECT1 ? 1 : 27);
     for (int i = 0; i < P; ++i) {
@@ -400,7 +402,7 @@ int NdtEngine::run_round(int* n_active)
         if (c.done()) continue;
         const double* r = hr + size_t(i) * kNdtPartialStride;
         // SURVEY.md §8(d) byte model: point (16) + probes (8 each) + 48 per valid neighbour voxel
-        deriv_alg_bytes += double(pairs_[i].n) * (16.0 + 8.0 * probes) + r[28] * 48.0;
+        mode_alg_bytes[c.request().mode] += double(pairs_[i].n) * (16.0 + 8.0 * probes) + r[28] * 48.0;
         c.on_result(r);
     }
     return MRGFE_OK;
@@ -411,9 +413,7 @@ int NdtEngine::align_all()
     MRGFE_TRY(ctx_->bind());
     MRGFE_TRY(build_targets());
     if (pairs_dirty_) MRGFE_TRY(upload_pairs());
-    deriv_ms = 0;
-    deriv_launches = 0;
-    deriv_alg_bytes = 0;
+    for (int m = 0; m < 3; ++m) { mode_ms[m] = 0; mode_launches[m] = 0; mode_alg_bytes[m] = 0; }
     for (auto& p : pairs_) {
         p.ctl.start(prm_, p.guess, p.n);
         if (targets_[p.target].status != MRGFE_OK && !p.ctl.done()) p.ctl.abort_no_target();

@@ -56,10 +56,21 @@ class NdtEngine {
     const NdtPairInfo&   pair(int i) const { return pairs_[i]; }
     int read_leaves(int target, int32_t* keys, int32_t* nr_points, double* mean3, double* icov9);
 
-    // derivative-kernel accounting of the last align_all()
-    double  deriv_ms = 0;
-    int64_t deriv_launches = 0;
-    double  deriv_alg_bytes = 0;
+    // derivative-kernel accounting of the last align_all(), per kernel variant (mode 0 / 1 / 2): device time from HIP
+    // events around each launch, launch count, algorithmic bytes (SURVEY.md §8d model)
+    double  mode_ms[3] = {0, 0, 0};
+    int64_t mode_launches[3] = {0, 0, 0};
+    double  mode_alg_bytes[3] = {0, 0, 0};
+    void kernel_stats(int mode, double* ms, int64_t* launches, double* bytes) const
+    {
+        double m = 0, b = 0;
+        int64_t l = 0;
+        for (int k = 0; k < 3; ++k)
+            if (mode < 0 || mode == k) { m += mode_ms[k]; l += mode_launches[k]; b += mode_alg_bytes[k]; }
+        if (ms) *ms = m;
+        if (launches) *launches = l;
+        if (bytes) *bytes = b;
+    }
 
     const NdtParams& params() const { return prm_; }
     void set_force_hash(bool f) { force_hash_ = f; }  // tests: exercise the hashed lookup on small grids

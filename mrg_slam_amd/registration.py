@@ -126,9 +126,10 @@ class HipRegistration:
     def evals(self) -> int:
         return lib().mrgfe_reg_evaluations(self._h)
 
-    def kernel_stats(self):
+    def kernel_stats(self, mode: int = -1):
+        """(device ms, launches, algorithmic bytes) of the dominant kernel in the last align(); NDT: per variant `mode`."""
         ms, n, b = C.c_double(0), C.c_int64(0), C.c_double(0)
-        check(lib().mrgfe_reg_kernel_stats(self._h, C.byref(ms), C.byref(n), C.byref(b)))
+        check(lib().mrgfe_reg_kernel_stats(self._h, mode, C.byref(ms), C.byref(n), C.byref(b)))
         return ms.value, n.value, b.value
 
 
@@ -269,9 +270,10 @@ class BatchMatcher:
         check(lib().mrgfe_batch_align(self._h, fitness_max_range, res))
         return results_to_numpy(res, n)
 
-    def kernel_stats(self):
+    def kernel_stats(self, mode: int = -1):
+        """(device ms, launches, algorithmic bytes) of the derivative kernel variant `mode` (-1: all) in the last align()."""
         ms, n, b = C.c_double(0), C.c_int64(0), C.c_double(0)
-        check(lib().mrgfe_batch_kernel_stats(self._h, C.byref(ms), C.byref(n), C.byref(b)))
+        check(lib().mrgfe_batch_kernel_stats(self._h, mode, C.byref(ms), C.byref(n), C.byref(b)))
         return ms.value, n.value, b.value
 
 

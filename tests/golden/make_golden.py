@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/frontend_small.npz: small seeded inputs and the CPU oracle's outputs for them.
+
+The reference (aserbremen/mrg_slam) ships no tests, fixtures or golden vectors for this path and its arithmetic lives in
+un-vendored PCL / ndt_omp / fast_gicp, so these vectors are produced by this repo's own CPU restatement
+(oracle/) - they freeze ITS numbers: the CPU suite checks that the oracle still reproduces them, the GPU suite checks
+the HIP path against them on the GPU box.  Re-run only when the oracle is deliberately changed:
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from conftest import small_cloud  # noqa: E402
+from mrg_slam_amd import synth  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def main():
+    out = {}
+    tgt = small_cloud(2500, 2024)
+    rel = synth.make_pose([0.22, -0.08, 0.02], synth.rot_xyz(0.008, -0.006, 0.025))
+    src = orc.transform_points(np.linalg.inv(rel), tgt)
+    src[:, :3] += np.random.default_rng(99).normal(0, 0.01, (len(src), 3)).astype(np.float32)
+    guess = synth.warm_guess(rel, 5)
+    out.update(tgt=tgt, src=src, rel=rel, guess=guess)
+    # prefilters
+    raw = small_cloud(3000, 77, extent=(40, 30, 4))
+    out["raw"] = raw
+    out["distance_out"] = orc.distance_filter(raw, 0.1, 35.0)
+    out["voxel_out_0p1"], _ = orc.voxelgrid(out["distance_out"], 0.1, 1)
+    out["voxel_out_0p5_min2"], _ = orc.voxelgrid(out["distance_out"], 0.5, 2)
+    out["radius_out"], out["radius_keep"] = orc.radius_outlier(out["voxel_out_0p1"], 0.5, 2)
+    out["sor_out"], out["sor_keep"] = orc.statistical_outlier(out["voxel_out_0p1"], 30, 1.2)
+    # NDT
+    for eps, tag in ((0.1, "eps0p1"), (0.01, "eps0p01")):
+        ndt = orc.Ndt(resolution=1.0, transformation_epsilon=eps, maximum_iterations=64, num_threads=2)
+        assert ndt.setInputTarget(tgt) == 0
+        ndt.setInputSource(src)
+        ndt.align(guess)
+        out[f"ndt_{tag}_T"] = ndt.getFinalTransformation()
+        out[f"ndt_{tag}_H"] = ndt.getHessian()
+        out[f"ndt_{tag}_meta"] = np.array([ndt.hasConverged(), ndt.getFinalNumIteration(), ndt.evals], dtype=np.int64)
+        out[f"ndt_{tag}_fitness"] = np.array([ndt.getFitnessScore(), ndt.getTransformationProbability()])
+    keys, npts, mean, cov, icov = ndt.leaves()
+    out.update(ndt_leaf_keys=keys, ndt_leaf_npts=npts, ndt_leaf_mean=mean, ndt_leaf_icov=icov)
+    p = np.array([0.2, -0.05, 0.01, 0.012, -0.006, 0.025])
+    out["eval_p"] = p
+    out["eval_T"] = orc.pose_to_matrix(p)
+    for mode in (0, 1, 2):
+        s, g, H = ndt.evaluate(out["eval_T"], p, mode)
+        out[f"eval{mode}_score"], out[f"eval{mode}_g"], out[f"eval{mode}_H"] = np.array([s]), g, H
+    # GICP
+    gicp = orc.FastGicp(transformation_epsilon=0.01, num_threads=2)
+    gicp.setInputTarget(tgt)
+    gicp.setInputSource(src)
+    gicp.align(guess)
+    out["gicp_T"] = gicp.getFinalTransformation()
+    out["gicp_H"] = gicp.getFinalHessian()
+    out["gicp_meta"] = np.array([gicp.hasConverged(), gicp.getFinalNumIteration()], dtype=np.int64)
+    out["gicp_src_cov"] = gicp.covariances("source")[:64]
+    e, H, b, n = gicp.linearize(np.asarray(guess, dtype=np.float64))
+    out["gicp_lin_err"], out["gicp_lin_H"], out["gicp_lin_b"], out["gicp_lin_n"] = np.array([e]), H, b, np.array([n])
+    # fitness / NN
+    out["fitness_inf"] = np.array([orc.calc_fitness_score(tgt, src, rel)])
+    idx, sqd = orc.nn1_brute(tgt, src[:200])
+    out.update(nn_idx=idx, nn_sqd=sqd)
+    path = os.path.join(ROOT, "tests", "golden", "frontend_small.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+"""CPU, world_size 2 over gloo: the multi-GPU sharding / record gather / sequential best-candidate replay of
+mrg_slam_amd/loop_closure.py gives the same answer as the single-process sequential loop
+(/root/reference/src/mrg_slam/loop_detector.cpp:126-145)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+
+def _fake_records(n, seed=0):
+    from mrg_slam_amd.registration import RESULT_DTYPE
+
+    rng = np.random.default_rng(seed)
+    r = np.zeros(n, dtype=RESULT_DTYPE)
+    r["T"] = rng.normal(size=(n, 16)).astype(np.float32)
+    r["H"] = rng.normal(size=(n, 36))
+    r["fitness"] = np.round(rng.uniform(0.1, 2.0, n), 1)  # coarse values: equal scores do occur
+    r["converged"] = rng.uniform(size=n) > 0.25
+    r["iterations"] = rng.integers(1, 30, n)
+    r["evaluations"] = r["iterations"] * 3
+    r["pair_id"] = np.arange(n)
+    return r
+
+
+class _FakeMatcher:
+    """Stands in for BatchMatcher on the CPU: returns the precomputed record of every pair it was given."""
+
+    def __init__(self, table):
+        self.table, self.ids = table, []
+
+    def add_target(self, cloud):
+        return 0
+
+    def add_pair(self, t, cloud, guess):
+        self.ids.append(int(cloud[0, 0]))  # the fake "cloud" carries its candidate id
+
+    def align(self, fitness_max_range):
+        return self.table[self.ids].copy()
+
+
+def _worker(rank, world, port, n, q):
+    import torch.distributed as dist
+
+    from mrg_slam_amd import loop_closure as lc
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    table = _fake_records(n, seed=7)
+    clouds = [np.full((1, 4), i, dtype=np.float32) for i in range(n)]
+    rec, best, score = lc.match_candidates(lambda: _FakeMatcher(table), np.zeros((1, 4), np.float32), clouds, [np.eye(4)] * n)
+    q.put((rank, rec.tobytes(), best, score, lc.shard_indices(n, world, rank).tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 256])
+def test_two_rank_gather_equals_sequential_loop(n):
+    from mrg_slam_amd import loop_closure as lc
+    from mrg_slam_amd.registration import RESULT_DTYPE
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    table = _fake_records(n, seed=7)
+    exp_best, exp_score = lc.select_best(table)
+    shards = set()
+    for rank, blob, best, score, mine in outs:
+        rec = np.frombuffer(blob, dtype=RESULT_DTYPE)
+        assert rec.tobytes() == table.tobytes()  # every rank holds every record, in candidate order
+        assert (best, score) == (exp_best, exp_score)
+        assert all(i % 2 == rank for i in mine)
+        shards |= set(mine)
+    assert shards == set(range(n))
+
+
+def test_select_best_replays_reference_semantics():
+    from mrg_slam_amd import loop_closure as lc
+    from mrg_slam_amd.registration import RESULT_DTYPE
+
+    r = np.zeros(5, dtype=RESULT_DTYPE)
+    r["fitness"] = [0.5, 0.3, 0.3, 0.1, 0.3]
+    r["converged"] = [1, 1, 1, 0, 1]
+    assert lc.select_best(r) == (4, 0.3)  # "score > best_score" skips: the LAST of equal scores wins; non-converged never match
+    r["converged"] = 0
+    assert lc.select_best(r) == (None, np.finfo(np.float64).max)
+    assert lc.select_best(r[:0]) == (None, np.finfo(np.float64).max)
+    # single process (no process group): gather is the identity
+    t = _fake_records(9)
+    np.testing.assert_array_equal(lc.gather_records(t[::-1].copy(), 9), t)

@@ -1,0 +1,124 @@
+"""Frozen vectors (tests/golden/frontend_small.npz, made by tests/golden/make_golden.py from the CPU oracle).
+CPU: the oracle still reproduces them bit for bit (float results: to 1e-12, they are thread-count independent).
+GPU: the HIP path matches them through the C ABI on the GPU box, where /root/reference and its data do not exist."""
+import os
+
+import numpy as np
+import pytest
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frontend_small.npz"))
+
+
+# ---- CPU: oracle vs its frozen outputs --------------------------------------------------------------------------
+def test_oracle_prefilters_reproduce_golden():
+    from oracle import oracle as orc
+
+    d = orc.distance_filter(G["raw"], 0.1, 35.0)
+    np.testing.assert_array_equal(d, G["distance_out"])
+    v, _ = orc.voxelgrid(d, 0.1, 1)
+    np.testing.assert_array_equal(v, G["voxel_out_0p1"])
+    np.testing.assert_array_equal(orc.voxelgrid(d, 0.5, 2)[0], G["voxel_out_0p5_min2"])
+    r, keep = orc.radius_outlier(v, 0.5, 2)
+    np.testing.assert_array_equal(r, G["radius_out"])
+    np.testing.assert_array_equal(keep, G["radius_keep"])
+    s, keep = orc.statistical_outlier(v, 30, 1.2)
+    np.testing.assert_array_equal(s, G["sor_out"])
+
+
+@pytest.mark.parametrize("eps,tag", [(0.1, "eps0p1"), (0.01, "eps0p01")])
+def test_oracle_ndt_reproduces_golden(eps, tag):
+    from oracle import oracle as orc
+
+    ndt = orc.Ndt(resolution=1.0, transformation_epsilon=eps, maximum_iterations=64, num_threads=4)
+    assert ndt.setInputTarget(G["tgt"]) == 0
+    ndt.setInputSource(G["src"])
+    ndt.align(G["guess"])
+    np.testing.assert_array_equal(ndt.getFinalTransformation(), G[f"ndt_{tag}_T"])
+    np.testing.assert_array_equal(ndt.getHessian(), G[f"ndt_{tag}_H"])
+    assert [int(ndt.hasConverged()), ndt.getFinalNumIteration(), ndt.evals] == G[f"ndt_{tag}_meta"].tolist()
+    np.testing.assert_allclose([ndt.getFitnessScore(), ndt.getTransformationProbability()], G[f"ndt_{tag}_fitness"], rtol=1e-13)
+    s, g, H = ndt.evaluate(G["eval_T"], G["eval_p"], 0)
+    assert s == G["eval0_score"][0]
+    np.testing.assert_array_equal(g, G["eval0_g"])
+    np.testing.assert_array_equal(H, G["eval0_H"])
+
+
+def test_oracle_gicp_reproduces_golden():
+    from oracle import oracle as orc
+
+    g = orc.FastGicp(transformation_epsilon=0.01, num_threads=2)
+    g.setInputTarget(G["tgt"])
+    g.setInputSource(G["src"])
+    g.align(G["guess"])
+    np.testing.assert_allclose(g.getFinalTransformation(), G["gicp_T"], rtol=0, atol=1e-6)  # per-thread partial sums: order varies
+    assert [int(g.hasConverged()), g.getFinalNumIteration()] == G["gicp_meta"].tolist()
+    np.testing.assert_array_equal(g.covariances("source")[:64], G["gicp_src_cov"])
+
+
+# ---- GPU: HIP path vs the frozen outputs ------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_hip_prefilters_match_golden():
+    from mrg_slam_amd import RadiusOutlierRemoval, StatisticalOutlierRemoval, VoxelGrid, calc_fitness_score, distance_filter
+
+    d = distance_filter(G["raw"], 0.1, 35.0)
+    np.testing.assert_array_equal(d, G["distance_out"])
+    vg = VoxelGrid()
+    vg.setLeafSize(0.1)
+    vg.setInputCloud(d)
+    v = vg.filter()
+    np.testing.assert_array_equal(v, G["voxel_out_0p1"])
+    vg.setLeafSize(0.5)
+    vg.setMinimumPointsNumberPerVoxel(2)
+    np.testing.assert_array_equal(vg.filter(), G["voxel_out_0p5_min2"])
+    ro = RadiusOutlierRemoval()
+    ro.setInputCloud(v)
+    np.testing.assert_array_equal(ro.filter(), G["radius_out"])
+    so = StatisticalOutlierRemoval()
+    so.setInputCloud(v)
+    np.testing.assert_array_equal(so.filter(), G["sor_out"])
+    assert calc_fitness_score(G["tgt"], G["src"], G["rel"]) == pytest.approx(G["fitness_inf"][0], rel=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eps,tag", [(0.1, "eps0p1"), (0.01, "eps0p01")])
+def test_hip_ndt_matches_golden(eps, tag):
+    from mrg_slam_amd import NdtHip, synth
+
+    g = NdtHip(resolution=1.0, transformation_epsilon=eps, maximum_iterations=64)
+    assert g.setInputTarget(G["tgt"]) == 0
+    g.setInputSource(G["src"])
+    g.align(G["guess"])
+    T, To = g.getFinalTransformation(), G[f"ndt_{tag}_T"]
+    assert np.linalg.norm(T[:3, 3].astype(np.float64) - To[:3, 3]) <= 1e-4  # north_star bar
+    assert synth.rotation_angle(T, To) <= 1e-4
+    assert [int(g.hasConverged()), g.getFinalNumIteration(), g.evals] == G[f"ndt_{tag}_meta"].tolist()
+    np.testing.assert_allclose(g.getHessian(), G[f"ndt_{tag}_H"], rtol=0, atol=1e-4 * np.abs(G[f"ndt_{tag}_H"]).max())
+    assert g.getFitnessScore() == pytest.approx(G[f"ndt_{tag}_fitness"][0], rel=1e-3)
+    keys, npts, mean, icov = g.leaves()
+    np.testing.assert_array_equal(keys, G["ndt_leaf_keys"])
+    np.testing.assert_array_equal(npts, G["ndt_leaf_npts"])
+    np.testing.assert_allclose(mean, G["ndt_leaf_mean"], rtol=0, atol=1e-12)
+    for mode in (0, 1, 2):
+        s, gr, H = g.evaluate(G["eval_T"], G["eval_p"], mode)
+        if mode != 2:
+            assert s == pytest.approx(G[f"eval{mode}_score"][0], rel=1e-9)
+            np.testing.assert_allclose(gr, G[f"eval{mode}_g"], rtol=0, atol=1e-8 * np.abs(G[f"eval{mode}_g"]).max())
+        if mode != 1:
+            np.testing.assert_allclose(H, G[f"eval{mode}_H"], rtol=0, atol=2e-6 * np.abs(G[f"eval{mode}_H"]).max())
+    idx, sqd = g.nearestKSearch1(G["src"][:200])
+    np.testing.assert_array_equal(idx, G["nn_idx"])
+    np.testing.assert_array_equal(sqd, G["nn_sqd"])
+
+
+@pytest.mark.gpu
+def test_hip_gicp_matches_golden():
+    from mrg_slam_amd import GicpHip, synth
+
+    g = GicpHip(transformation_epsilon=0.01)
+    g.setInputTarget(G["tgt"])
+    g.setInputSource(G["src"])
+    g.align(G["guess"])
+    T = g.getFinalTransformation()
+    assert np.linalg.norm(T[:3, 3].astype(np.float64) - G["gicp_T"][:3, 3]) <= 1e-4
+    assert synth.rotation_angle(T, G["gicp_T"]) <= 1e-4
+    assert [int(g.hasConverged()), g.getFinalNumIteration()] == G["gicp_meta"].tolist()

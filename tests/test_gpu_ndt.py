@@ -103,7 +103,7 @@ def test_align_matches_oracle(eps, guess_kind):
     assert g.evals == o.evals
     assert np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3]) <= TOL_T
     assert _rot_angle(Tg[:3, :3], To[:3, :3]) <= TOL_R
-    assert g.getTransformationProbability() == pytest.approx(o.getTransformationProbability(), rel=1e-6)
+    assert g.getTransformationProbability() == pytest.approx(o.getTransformationProbability(), rel=1e-3)  # a point on a voxel face may hop (1 of 6000 = 1.7e-4)
     np.testing.assert_allclose(g.getHessian(), o.getHessian(), rtol=0, atol=1e-4 * np.abs(o.getHessian()).max())
     assert g.mean_neighbours == pytest.approx(o.mean_neighbours, rel=1e-3)
     # output cloud == final_transformation * source, in pcl::transformPointCloud's float operation order
