@@ -7,54 +7,59 @@
 namespace mrgfe {
 
 // Cyclic Jacobi on a symmetric 3x3 (lower triangle read). w ascending, V columns = eigenvectors (row-major V[r*3+c]).
+// The operation sequence (rotation formulas, two-sided updates, sweep test, stable ascending order) is fixed: with FMA
+// contraction off every f64 operation rounds once, so a CPU running the same sequence produces the same bits.
 __host__ __device__ inline void dl_sym_eig3(const double A[9], double w[3], double V[9])
 {
-    double a00 = A[0], a11 = A[4], a22 = A[8], a01 = A[3], a02 = A[6], a12 = A[7];
-    double v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    for (int sweep = 0; sweep < 32; ++sweep) {
-        const double off = fabs(a01) + fabs(a02) + fabs(a12);
-        const double dia = fabs(a00) + fabs(a11) + fabs(a22);
-        if (off <= 1e-300 || off <= 2.2e-19 * dia) break;
-        // rotation (0,1)
-        if (a01 != 0.0) {
-            double th = (a11 - a00) / (2.0 * a01);
-            double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-            double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-            double n00 = a00 - t * a01, n11 = a11 + t * a01;
-            double n02 = c * a02 - s * a12, n12 = s * a02 + c * a12;
-            a00 = n00; a11 = n11; a01 = 0.0; a02 = n02; a12 = n12;
-            for (int k = 0; k < 3; ++k) { double p = v[k * 3 + 0], q = v[k * 3 + 1]; v[k * 3 + 0] = c * p - s * q; v[k * 3 + 1] = s * p + c * q; }
-        }
-        // rotation (0,2)
-        if (a02 != 0.0) {
-            double th = (a22 - a00) / (2.0 * a02);
-            double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-            double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-            double n00 = a00 - t * a02, n22 = a22 + t * a02;
-            double n01 = c * a01 - s * a12, n12 = s * a01 + c * a12;
-            a00 = n00; a22 = n22; a02 = 0.0; a01 = n01; a12 = n12;
-            for (int k = 0; k < 3; ++k) { double p = v[k * 3 + 0], q = v[k * 3 + 2]; v[k * 3 + 0] = c * p - s * q; v[k * 3 + 2] = s * p + c * q; }
-        }
-        // rotation (1,2)
-        if (a12 != 0.0) {
-            double th = (a22 - a11) / (2.0 * a12);
-            double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-            double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-            double n11 = a11 - t * a12, n22 = a22 + t * a12;
-            double n01 = c * a01 - s * a02, n02 = s * a01 + c * a02;
-            a11 = n11; a22 = n22; a12 = 0.0; a01 = n01; a02 = n02;
-            for (int k = 0; k < 3; ++k) { double p = v[k * 3 + 1], q = v[k * 3 + 2]; v[k * 3 + 1] = c * p - s * q; v[k * 3 + 2] = s * p + c * q; }
-        }
+    double a[3][3];
+    a[0][0] = A[0]; a[1][1] = A[4]; a[2][2] = A[8];
+    a[1][0] = a[0][1] = A[3];
+    a[2][0] = a[0][2] = A[6];
+    a[2][1] = a[1][2] = A[7];
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+        const double diag = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
+        if (off <= 1e-300 || off <= 2.220446049250313e-16 * 1e-3 * diag) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                if (a[p][q] == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {  // A <- A * J
+                    const double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = c * akp - s * akq;
+                    a[k][q] = s * akp + c * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {  // A <- J^T * A
+                    const double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = c * apk - s * aqk;
+                    a[q][k] = s * apk + c * aqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = v[k][p], vkq = v[k][q];
+                    v[k][p] = c * vkp - s * vkq;
+                    v[k][q] = s * vkp + c * vkq;
+                }
+            }
     }
-    double d[3] = {a00, a11, a22};
-    int i0 = 0, i1 = 1, i2 = 2;
-    if (d[i0] > d[i1]) { int t = i0; i0 = i1; i1 = t; }
-    if (d[i1] > d[i2]) { int t = i1; i1 = i2; i2 = t; }
-    if (d[i0] > d[i1]) { int t = i0; i0 = i1; i1 = t; }
+    const double d[3] = {a[0][0], a[1][1], a[2][2]};
+    int i0 = 0, i1 = 1, i2 = 2;  // stable ascending order of three values
+    if (d[i1] < d[i0]) { const int t = i0; i0 = i1; i1 = t; }
+    if (d[i2] < d[i1]) { const int t = i1; i1 = i2; i2 = t; }
+    if (d[i1] < d[i0]) { const int t = i0; i0 = i1; i1 = t; }
     const int idx[3] = {i0, i1, i2};
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
         w[c] = d[idx[c]];
-        for (int r = 0; r < 3; ++r) V[r * 3 + c] = v[r * 3 + idx[c]];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) V[r * 3 + c] = v[r][idx[c]];
     }
 }
 

@@ -66,38 +66,50 @@ __global__ __launch_bounds__(256) void ndt_segments_kernel(const uint32_t* __res
     }
 }
 
-// one wavefront per leaf: f64 sums of x, y, z and of the six distinct products, f32 sums of x,y,z,intensity.
-// sums layout per leaf (16 doubles): [0..2] sum p, [3..8] sum xx,xy,xz,yy,yz,zz, [9] n, [10..13] float centroid sums.
+// one wavefront per leaf. The reference accumulates each voxel's sums point by point in index order
+// (pclomp::VoxelGridCovariance first pass); to reproduce those f64 sums BIT FOR BIT the additions of one accumulator stay
+// sequential, and the parallelism is across the 13 accumulators instead: the wave stages 64 points at a time into LDS
+// with one coalesced index read + one 16-byte gather per lane, then lane k (k < 13) walks the staged points in order and
+// adds its own term: k 0..2 sum p, 3..8 sum xx,xy,xz,yy,yz,zz (f64), 9..12 the f32 centroid sums of x,y,z,intensity.
+// sums layout per leaf (16 doubles): [0..2] sum p, [3..8] products, [9] n, [10..13] float centroid sums.
 __global__ __launch_bounds__(256) void ndt_leaf_sums_kernel(const float4* const* __restrict__ clouds, const uint32_t* __restrict__ sorted_vals, const Slice* __restrict__ slices,
                                                              const LeafSlice* __restrict__ leaf_slices, const uint32_t* __restrict__ seg_start,
                                                              double* __restrict__ sums)
 {
+    __shared__ float4 stage[4][kWave];
     const LeafSlice ls = leaf_slices[blockIdx.y];
     const uint32_t  leaf = blockIdx.x * 4 + wave_id();
-    if (leaf >= ls.n_leaves) return;
+    if (leaf >= ls.n_leaves) return;  // wave-uniform
     const Slice    s = slices[blockIdx.y];
     const float4* __restrict__ pts = clouds[blockIdx.y];
     const uint32_t b = seg_start[ls.seg_off + leaf], e = seg_start[ls.seg_off + leaf + 1];
-    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    float  c[4] = {0, 0, 0, 0};
-    for (uint32_t i = b + lane_id(); i < e; i += kWave) {
-        const float4 p = pts[sorted_vals[s.off + i]];
-        const double x = p.x, y = p.y, z = p.z;
-        a[0] += x; a[1] += y; a[2] += z;
-        a[3] += x * x; a[4] += x * y; a[5] += x * z; a[6] += y * y; a[7] += y * z; a[8] += z * z;
-        c[0] += p.x; c[1] += p.y; c[2] += p.z; c[3] += p.w;
+    const int      lane = lane_id();
+    // which coordinates lane k multiplies: (ia, ib); ib == 3 selects the constant 1.0
+    const int ia = lane < 3 ? lane : (lane < 6 ? 0 : (lane < 8 ? 1 : 2));
+    const int ib = lane < 3 ? 3 : (lane == 3 ? 0 : lane == 4 ? 1 : lane == 5 ? 2 : lane == 6 ? 1 : lane == 7 ? 2 : 2);
+    double acc = 0.0;
+    float  facc = 0.0f;
+    float4* st = stage[wave_id()];
+    for (uint32_t base = b; base < e; base += kWave) {
+        const uint32_t i = base + lane;
+        if (i < e) st[lane] = pts[sorted_vals[s.off + i]];
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const uint32_t cnt = min(static_cast<uint32_t>(kWave), e - base);
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const float4 p = st[j];
+            const float  pf[4] = {p.x, p.y, p.z, p.w};
+            const double pd[4] = {static_cast<double>(p.x), static_cast<double>(p.y), static_cast<double>(p.z), 1.0};
+            acc += pd[ia] * pd[ib];
+            facc += pf[lane >= 9 && lane < 13 ? lane - 9 : 0];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
     }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) a[k] = wave_sum(a[k]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) c[k] = wave_sum(c[k]);
-    if (lane_id() == 0) {
-        double* o = sums + (size_t)(ls.leaf_off + leaf) * 16;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) o[k] = a[k];
-        o[9] = static_cast<double>(e - b);
-        o[10] = c[0]; o[11] = c[1]; o[12] = c[2]; o[13] = c[3];
-    }
+    double* o = sums + (size_t)(ls.leaf_off + leaf) * 16;
+    if (lane < 9) o[lane] = acc;
+    else if (lane == 9) o[9] = static_cast<double>(e - b);
+    if (lane >= 9 && lane < 13) o[lane + 1] = static_cast<double>(facc);
 }
 
 // one thread per leaf: pclomp::VoxelGridCovariance second pass + lookup insertion

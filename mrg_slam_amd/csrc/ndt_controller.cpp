@@ -247,21 +247,18 @@ void NdtController::abort_no_target()
     phase_ = DONE;
 }
 
-void NdtController::store_result(const double r[29], bool with_score_grad, bool with_hessian)
+void NdtController::store_result(const double r[44], bool with_score_grad, bool with_hessian)
 {
     if (with_score_grad) {
         score_ = r[0];
         for (int k = 0; k < 6; ++k) g_[k] = r[1 + k];
     }
-    if (with_hessian) {
-        int t = 7;
-        for (int i = 0; i < 6; ++i)
-            for (int j = i; j < 6; ++j) { H_[i * 6 + j] = r[t]; H_[j * 6 + i] = r[t]; ++t; }
-    }
-    nb_sum_ += n_src_ ? r[28] / static_cast<double>(n_src_) : 0.0;
+    if (with_hessian)
+        for (int k = 0; k < 36; ++k) H_[k] = r[7 + k];
+    nb_sum_ += n_src_ ? r[43] / static_cast<double>(n_src_) : 0.0;
 }
 
-void NdtController::on_result(const double r[29])
+void NdtController::on_result(const double r[44])
 {
     switch (phase_) {
         case INIT:

@@ -35,8 +35,8 @@ class NdtController {
     void start(const NdtParams& prm, const float guess_rowmajor[16], uint32_t n_src);
     bool done() const { return phase_ == DONE || phase_ == IDLE; }
     const NdtRequest& request() const { return req_; }
-    // reduced sums of the requested evaluation: r[0] score, r[1..6] gradient, r[7..27] upper Hessian, r[28] neighbours
-    void on_result(const double r[29]);
+    // reduced sums of the requested evaluation: r[0] score, r[1..6] gradient, r[7..42] Hessian (row-major), r[43] neighbours
+    void on_result(const double r[44]);
     // finish immediately without target (no usable grid): align() leaves final = guess semantics of an empty run
     void abort_no_target();
 
@@ -75,7 +75,7 @@ class NdtController {
     int    step_iterations_;
 
     void make_request(int mode, const double p[6]);
-    void store_result(const double r[29], bool with_score_grad, bool with_hessian);
+    void store_result(const double r[44], bool with_score_grad, bool with_hessian);
     void newton_step();
     void ls_after_eval();
     void ls_continue_or_finish();

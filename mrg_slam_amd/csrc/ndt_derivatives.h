@@ -8,7 +8,7 @@ namespace mrgfe {
 // one derivative evaluation for every active pair whose NdtEvalDev::mode == mode (grid = max_nblk x npairs)
 int ndt_launch_derivatives(mrgfe_ctx* ctx, int mode, int search, uint32_t max_nblk, int npairs, const NdtGridDev* d_grids, const NdtPairDev* d_pairs,
                            const NdtEvalDev* d_evals, double* d_partials, int ppt);
-// fixed-order sum of the block partials -> results[pair][32] = {score, g[6], H upper[21], neighbours, pad}
+// fixed-order sum of the block partials -> results[pair][48] = {score, g[6], H[36] row-major, neighbours, pad}
 int ndt_launch_reduce(mrgfe_ctx* ctx, int npairs, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const double* d_partials, double* d_results);
 // dst = T * src (row-major 3x4 float T in device memory)
 int launch_transform_cloud(mrgfe_ctx* ctx, const float4* d_src, float4* d_dst, uint32_t n, const float* d_T12);

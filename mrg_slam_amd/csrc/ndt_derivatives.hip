@@ -19,12 +19,11 @@ namespace mrgfe {
 
 __constant__ int8_t kOff7[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
 
-__device__ __forceinline__ int hidx(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }  // i <= j, 21 entries
 
 struct Accum {
     double score;
     double g[6];
-    double H[21];
+    double H[36];  // row-major, every entry (see ndt_types.h)
     uint32_t nb;
 };
 
@@ -67,18 +66,19 @@ __device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, co
     acc.score += static_cast<double>(score_inc);
     if (!HESS) return;
     const float* Jc[6] = {nullptr, nullptr, nullptr, J3, J4, J5};
-    // PH index of the (i,j) second-derivative vector for 3 <= i <= j <= 5: a,b,c,d,e,f = (3,3),(3,4),(3,5),(4,4),(4,5),(5,5)
+    // PH index of the second-derivative vector of (i,j), 3 <= i,j <= 5: a,b,c,d,e,f = (3,3),(3,4),(3,5),(4,4),(4,5),(5,5)
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
 #pragma unroll
-        for (int j = i; j < 6; ++j) {
+        for (int j = 0; j < 6; ++j) {
             // point_gradient4_colj . c_inv4_x_point_gradient4_col_i  == J(:,j) . CJ(:,i)
             float jtcj;
             if (j < 3) jtcj = CJ[j][i];
             else       jtcj = dot3f(Jc[j][0], CJ[0][i], Jc[j][1], CJ[1][i], Jc[j][2], CJ[2][i]);
             float qch = 0.0f;
-            if (i >= 3) {
-                const int ph = (i == 3) ? (j - 3) : (i == 4 ? (j - 4 + 3) : 5);
+            if (i >= 3 && j >= 3) {
+                const int lo = i < j ? i : j, hi = i < j ? j : i;
+                const int ph = (lo == 3) ? (hi - 3) : (lo == 4 ? (hi - 4 + 3) : 5);
                 qch = dot3f(qC[0], PH[ph][0], qC[1], PH[ph][1], qC[2], PH[ph][2]);
             }
             const float t0 = -gauss_d2f * qCJ[i];
@@ -86,7 +86,7 @@ __device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, co
             const float t2 = t1 + qch;
             const float t3 = t2 + jtcj;
             const float t4 = e * t3;
-            acc.H[hidx(i, j)] += static_cast<double>(t4);
+            acc.H[i * 6 + j] += static_cast<double>(t4);
         }
     }
 }
@@ -112,17 +112,18 @@ __device__ __forceinline__ void pair_double(Accum& acc, const double mean[3], co
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
 #pragma unroll
-        for (int j = i; j < 6; ++j) {
+        for (int j = 0; j < 6; ++j) {
             double qch = 0.0;
-            if (i >= 3) {
-                const int ph = (i == 3) ? (j - 3) : (i == 4 ? (j - 4 + 3) : 5);
+            if (i >= 3 && j >= 3) {
+                const int lo = i < j ? i : j, hi = i < j ? j : i;
+                const int ph = (lo == 3) ? (hi - 3) : (lo == 4 ? (hi - 4 + 3) : 5);
                 double CH[3];
 #pragma unroll
                 for (int r = 0; r < 3; ++r) CH[r] = C[r * 3 + 0] * PH[ph][0] + C[r * 3 + 1] * PH[ph][1] + C[r * 3 + 2] * PH[ph][2];
                 qch = q[0] * CH[0] + q[1] * CH[1] + q[2] * CH[2];
             }
             const double jtcj = J[0][j] * CJ[0][i] + J[1][j] * CJ[1][i] + J[2][j] * CJ[2][i];
-            acc.H[hidx(i, j)] += e * (-gauss_d2 * qCJ[i] * qCJ[j] + qch + jtcj);
+            acc.H[i * 6 + j] += e * (-gauss_d2 * qCJ[i] * qCJ[j] + qch + jtcj);
         }
     }
 }
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void ndt_derivatives_kernel(const NdtGridDev* 
 #pragma unroll
     for (int k = 0; k < 6; ++k) acc.g[k] = 0;
 #pragma unroll
-    for (int k = 0; k < 21; ++k) acc.H[k] = 0;
+    for (int k = 0; k < 36; ++k) acc.H[k] = 0;
 
     const uint32_t base = blockIdx.x * 256u * ppt;
     for (int it = 0; it < ppt; ++it) {
@@ -242,17 +243,17 @@ __global__ __launch_bounds__(256) void ndt_derivatives_kernel(const NdtGridDev* 
         }
     }
 
-    // workgroup reduction: shuffle inside each wavefront, 4 wave records through LDS, one 256-byte partial out
+    // workgroup reduction: shuffle inside each wavefront, 4 wave records through LDS, one 384-byte partial out
     double vals[kNdtAccum];
     vals[0] = acc.score;
 #pragma unroll
     for (int k = 0; k < 6; ++k) vals[1 + k] = acc.g[k];
 #pragma unroll
-    for (int k = 0; k < 21; ++k) vals[7 + k] = acc.H[k];
-    vals[28] = static_cast<double>(acc.nb);
+    for (int k = 0; k < 36; ++k) vals[7 + k] = acc.H[k];
+    vals[kNdtNbIndex] = static_cast<double>(acc.nb);
 #pragma unroll
     for (int k = 0; k < kNdtAccum; ++k) {
-        const bool skip = (MODE == 1 && k >= 7 && k < 28) || (MODE == 2 && k < 7);
+        const bool skip = (MODE == 1 && k >= 7 && k < kNdtNbIndex) || (MODE == 2 && k < 7);
         if (skip) continue;
         const double r = wave_sum(vals[k]);
         if (lane_id() == 0) s_red[wave_id()][k] = r;
@@ -260,30 +261,30 @@ __global__ __launch_bounds__(256) void ndt_derivatives_kernel(const NdtGridDev* 
     __syncthreads();
     if (threadIdx.x < kNdtPartialStride) {
         const int  k = threadIdx.x;
-        const bool skip = k >= kNdtAccum || (MODE == 1 && k >= 7 && k < 28) || (MODE == 2 && k < 7);
+        const bool skip = k >= kNdtAccum || (MODE == 1 && k >= 7 && k < kNdtNbIndex) || (MODE == 2 && k < 7);
         double     r = 0.0;
         if (!skip) r = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
         partials[(size_t)(pr.part_off + blockIdx.x) * kNdtPartialStride + k] = r;
     }
 }
 
-// fixed-order sum of the block partials of every active pair: 8 interleaved slices, then slice 0..7 in order
+// fixed-order sum of the block partials of every active pair: 4 interleaved slices, then slice 0..3 in order
 __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __restrict__ pairs, const NdtEvalDev* __restrict__ evals, const double* __restrict__ partials,
                                                           double* __restrict__ results)
 {
     const NdtPairDev pr = pairs[blockIdx.x];
     if (!evals[blockIdx.x].active) return;
-    __shared__ double s[8][kNdtPartialStride];
-    const int k = threadIdx.x & 31, slice = threadIdx.x >> 5;
-    double    acc = 0.0;
-    for (uint32_t b = slice; b < pr.nblk; b += 8) acc += partials[(size_t)(pr.part_off + b) * kNdtPartialStride + k];
-    s[slice][k] = acc;
+    __shared__ double s[4][kNdtPartialStride];
+    const int k = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    if (k < kNdtPartialStride) {
+        double acc = 0.0;
+        for (uint32_t b = slice; b < pr.nblk; b += 4) acc += partials[(size_t)(pr.part_off + b) * kNdtPartialStride + k];
+        s[slice][k] = acc;
+    }
     __syncthreads();
     if (threadIdx.x < kNdtPartialStride) {
-        double r = s[0][k];
-#pragma unroll
-        for (int sl = 1; sl < 8; ++sl) r += s[sl][k];
-        results[(size_t)blockIdx.x * kNdtPartialStride + k] = r;
+        const double r = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
+        results[(size_t)blockIdx.x * kNdtPartialStride + threadIdx.x] = r;
     }
 }
 

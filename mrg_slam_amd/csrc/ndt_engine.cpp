@@ -402,7 +402,7 @@ int NdtEngine::run_round(int* n_active)
         if (c.done()) continue;
         const double* r = hr + size_t(i) * kNdtPartialStride;
         // SURVEY.md §8(d) byte model: point (16) + probes (8 each) + 48 per valid neighbour voxel
-        mode_alg_bytes[c.request().mode] += double(pairs_[i].n) * (16.0 + 8.0 * probes) + r[28] * 48.0;
+        mode_alg_bytes[c.request().mode] += double(pairs_[i].n) * (16.0 + 8.0 * probes) + r[kNdtNbIndex] * 48.0;
         c.on_result(r);
     }
     return MRGFE_OK;
@@ -458,9 +458,7 @@ int NdtEngine::evaluate(int pair, const float T[16], const double p[6], int mode
     const double* res = h_results_.as<double>() + size_t(pair) * kNdtPartialStride;
     *score = res[0];
     for (int k = 0; k < 6; ++k) grad[k] = res[1 + k];
-    int t = 7;
-    for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 6; ++j) { hess[i * 6 + j] = res[t]; hess[j * 6 + i] = res[t]; ++t; }
+    for (int k = 0; k < 36; ++k) hess[k] = res[7 + k];
     return MRGFE_OK;
 }
 

@@ -83,8 +83,11 @@ struct NdtEvalDev {
     int32_t  pad;
 };
 
-// block partial / final result of one evaluation: score, gradient(6), upper-triangular Hessian(21), neighbour count
-constexpr int kNdtAccum = 29;  // 1 + 6 + 21 + 1
-constexpr int kNdtPartialStride = 32;
+// block partial / final result of one evaluation: score, gradient(6), full 6x6 Hessian(36, row-major), neighbour count.
+// All 36 Hessian entries are kept: the reference fills H(i,j) and H(j,i) with differently rounded float terms, and an
+// ill-conditioned Newton solve amplifies that 1e-7 asymmetry far above the 1e-4 parity bar if it is mirrored away.
+constexpr int kNdtAccum = 44;  // 1 + 6 + 36 + 1
+constexpr int kNdtNbIndex = 43;
+constexpr int kNdtPartialStride = 48;
 
 }  // namespace mrgfe

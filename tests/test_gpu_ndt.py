@@ -56,12 +56,12 @@ def test_target_grid_matches_oracle(force_hash, monkeypatch):
     np.testing.assert_array_equal(gn, on)
     for a, b in zip(g.grid(), o.grid()):
         np.testing.assert_array_equal(a, b)
-    np.testing.assert_allclose(gm, om, rtol=0, atol=1e-12)
+    # voxel sums are accumulated in the reference's order (point index) and the eigen clamp / inverse run the same f64
+    # operation sequence without FMA contraction: means and inverse covariances agree bit for bit
+    np.testing.assert_array_equal(gm, om)
     valid = on >= 6
     assert valid.sum() > 50
-    scale = np.abs(oi[valid]).max(axis=(1, 2), keepdims=True)
-    # f64 sums are reduced in a different order (wavefront tree vs sequential): agreement to ~1e-8 of the matrix scale
-    assert (np.abs(gi[valid] - oi[valid]) <= 1e-7 * scale).all()
+    np.testing.assert_array_equal(gi[valid], oi[valid])
     assert (gi[~valid] == 0).all()
 
 
@@ -82,9 +82,9 @@ def test_single_evaluation_matches_oracle(search, force_hash, monkeypatch):
             assert gs == pytest.approx(os_, rel=1e-9)
             np.testing.assert_allclose(gg, og, rtol=0, atol=1e-8 * np.abs(og).max())
         if mode != 1:
-            # the GPU accumulates the upper triangle and mirrors it; the reference fills all 36 entries in float
-            np.testing.assert_allclose(gH, oH, rtol=0, atol=2e-6 * np.abs(oH).max())
-            np.testing.assert_array_equal(gH, gH.T)
+            # all 36 entries are accumulated like the reference does (H(i,j) and H(j,i) round differently in float);
+            # only the order of the f64 additions differs
+            np.testing.assert_allclose(gH, oH, rtol=0, atol=1e-11 * np.abs(oH).max())
 
 
 @pytest.mark.parametrize("eps", [0.1, 0.01, 0.001])
