@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--eps", type=float, default=0.1, help="reg_transformation_epsilon (config/mrg_slam.yaml:102)")
     ap.add_argument("--cpu-pairs", type=int, default=4, help="pairs of the bounded CPU-oracle sample (0 disables)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--latency", action="store_true", help="also time single-pair setInputTarget+align latency (extra, differently sized launches of the "
+                                                            "same kernels: off by default so rocprof averages of the default run describe the timed workload)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,12 +128,15 @@ def main():
     sync()
     per_mode = np.zeros((3, 3))  # [mode] -> (device ms, launches, algorithmic bytes), HIP events around every launch
     evals = iters = 0
+    pts_evals = 0.0
+    src_sizes = np.array([len(scans[p[1]]) for p in pairs], dtype=np.float64)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
         for m in range(3):
             per_mode[m] += bm.kernel_stats(m)
         evals += int(res["evaluations"].sum())
+        pts_evals += float(np.dot(res["evaluations"].astype(np.float64), src_sizes))
         iters += int(res["iterations"].sum())
     sync()
     elapsed = time.perf_counter() - t0
@@ -148,20 +153,23 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- single-pair latency (one pcl::Registration-style object, host loop per evaluation) ------------------------
-    reg = NdtHip(resolution=1.0, transformation_epsilon=args.eps, maximum_iterations=64, ctx=ctx)
-    ti, si, guess, truth = pairs[0]
-    lat = []
-    for _ in range(5):
-        ctx.synchronize()
-        t1 = time.perf_counter()
-        reg.setInputTargetDevice(dev[ti].data_ptr(), len(scans[ti]))
-        reg.setInputSourceDevice(dev[si].data_ptr(), len(scans[si]))
-        reg.align(guess)
-        lat.append(time.perf_counter() - t1)
-    single_ms = 1e3 * float(np.median(lat[1:]))
-    kbar = reg.mean_neighbours
-
+    # ---- single-pair latency (one pcl::Registration-style object, host loop per evaluation), opt-in ------------------
+    single_ms = None
+    if args.latency:
+        reg = NdtHip(resolution=1.0, transformation_epsilon=args.eps, maximum_iterations=64, ctx=ctx)
+        ti, si, guess, truth = pairs[0]
+        lat = []
+        for _ in range(6):
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            reg.setInputTargetDevice(dev[ti].data_ptr(), len(scans[ti]))
+            reg.setInputSourceDevice(dev[si].data_ptr(), len(scans[si]))
+            reg.align(guess)
+            lat.append(time.perf_counter() - t1)
+        single_ms = 1e3 * float(np.median(lat[1:]))
+    # mean valid neighbour voxels per point and evaluation (k-bar of SURVEY.md §8d), from the byte accounting:
+    # bytes = 72 * point_evaluations + 48 * valid_neighbours
+    kbar = (float(per_mode[:, 2].sum()) - 72.0 * pts_evals) / 48.0 / pts_evals if pts_evals else 0.0
     # ---- CPU baseline + parity on a bounded sample of the same pairs ---------------------------------------------------
     cpu = None
     parity = None

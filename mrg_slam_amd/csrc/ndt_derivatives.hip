@@ -3,14 +3,21 @@
 // src/mrg_slam/loop_detector.cpp:134) — MI355X counterpart of pclomp::NormalDistributionsTransform::
 // computeDerivatives / updateDerivatives / computeHessian / updateHessian.
 //
-// One thread owns PPT source points: it loads the packed float4 point (coalesced, 16 B/lane), applies the float
-// rigid transform in pcl::transformPointCloud's operation order, finds its voxel and probes the DIRECT7 (or 1 / 27)
-// neighbours in the target lookup, and for every occupied neighbour accumulates score, gradient (6) and the upper
-// triangle of the Hessian (21) in f64 registers from f32 per-pair terms - exactly the f32/f64 split of the reference.
-// The 6-wide contraction is far too thin for MFMA: the kernel is bound by the dependent
-// point -> lookup -> leaf-record loads, so the transform is fused in (no transformed cloud is ever written) and the
-// 28 partial sums leave the workgroup once: wavefront shuffle reduction, 4-wave LDS combine, one 256-byte record.
-// A second tiny kernel adds the records of each pair in a fixed order (bitwise reproducible results).
+// Work distribution (a workgroup owns tiles of 256 source points):
+//   phase 1, one lane per POINT: coalesced 16-byte point load, float rigid transform in pcl::transformPointCloud's
+//            operation order (fused in: no transformed cloud is ever written), voxel coordinate, DIRECT7 (or 1 / 27)
+//            lookups in the target grid, the point's angular Jacobian / second-derivative terms.  The per-point terms
+//            are staged in LDS ([field][slot], conflict-free) and every occupied (point, voxel) pair is appended to an
+//            LDS work queue at the offset given by a workgroup prefix sum (deterministic order, no atomics).
+//   phase 2, one lane per PAIR: the queue is consumed 256 pairs at a time, so lanes stay busy although points have
+//            between 0 and 7 occupied neighbours (a point-per-lane loop leaves ~1/3 of the lanes masked off).
+//            Each lane gathers its point terms from LDS and the 48-byte voxel record from L2/HBM, evaluates the f32
+//            per-pair terms in the reference's order and accumulates score, gradient (6) and all 36 Hessian entries in
+//            f64 registers — the f32/f64 split of the reference.
+//   phase 3: wavefront shuffle reduction, 4-wave LDS combine, one 384-byte partial record per workgroup; a second
+//            tiny kernel adds the records of each pair in a fixed order (bitwise reproducible results).
+// The contraction is 6 wide: far too thin for MFMA; the kernel is bound by VALU issue and by the
+// dependent point -> lookup -> record loads, which is what the byte-model roofline in bench.py is held against.
 #include "dev_float.h"
 #include "dev_utils.h"
 #include "ndt_derivatives.h"
@@ -19,12 +26,12 @@ namespace mrgfe {
 
 __constant__ int8_t kOff7[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
 
+constexpr int kTilePts = 256;  // points per tile == threads per workgroup
 
 struct Accum {
     double score;
     double g[6];
     double H[36];  // row-major, every entry (see ndt_types.h)
-    uint32_t nb;
 };
 
 // float path: updateDerivatives for one (point, voxel) pair
@@ -139,12 +146,19 @@ __global__ __launch_bounds__(256) void ndt_derivatives_kernel(const NdtGridDev* 
     if (!ev.active || ev.mode != MODE) return;
     const NdtGridDev& g = grids[pr.grid];
 
-    __shared__ float s_T[12];
-    __shared__ float s_j[8][3], s_h[15][3];
-    __shared__ double s_red[4][kNdtPartialStride];
+    using StageT = typename std::conditional<MODE == 2, double, float>::type;  // precision of the staged point terms
+    constexpr int kHRows = (MODE == 1) ? 1 : 15;
+    __shared__ float    s_T[12];
+    __shared__ float    s_ja[8][3], s_ha[15][3];
+    __shared__ float    s_xt[3][kTilePts];
+    __shared__ StageT   s_xj[8][kTilePts];
+    __shared__ StageT   s_xh[kHRows][kTilePts];
+    __shared__ uint32_t s_queue[kTilePts * NNB];  // (slot << 24) | leaf id
+    __shared__ uint32_t s_scan[8];
+    __shared__ double   s_red[4][kNdtPartialStride];
     if (threadIdx.x < 12) s_T[threadIdx.x] = ev.T[threadIdx.x];
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + 24) (&s_j[0][0])[threadIdx.x - 64] = (&ev.j_ang[0][0])[threadIdx.x - 64];
-    if (threadIdx.x >= 128 && threadIdx.x < 128 + 45) (&s_h[0][0])[threadIdx.x - 128] = (&ev.h_ang[0][0])[threadIdx.x - 128];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 24) (&s_ja[0][0])[threadIdx.x - 64] = (&ev.j_ang[0][0])[threadIdx.x - 64];
+    if (threadIdx.x >= 128 && threadIdx.x < 128 + 45) (&s_ha[0][0])[threadIdx.x - 128] = (&ev.h_ang[0][0])[threadIdx.x - 128];
     __syncthreads();
 
     const float  gauss_d2f = static_cast<float>(ev.gauss_d2);
@@ -154,103 +168,133 @@ __global__ __launch_bounds__(256) void ndt_derivatives_kernel(const NdtGridDev* 
 
     Accum acc;
     acc.score = 0;
-    acc.nb = 0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) acc.g[k] = 0;
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc.H[k] = 0;
+    uint32_t nb_total = 0;
 
-    const uint32_t base = blockIdx.x * 256u * ppt;
+    const uint32_t base = blockIdx.x * static_cast<uint32_t>(kTilePts) * ppt;
     for (int it = 0; it < ppt; ++it) {
-        const uint32_t i = base + it * 256u + threadIdx.x;
-        if (i >= pr.n_src) break;
-        const float4 p = pr.src[i];
-        float xt[3];
-        transform_point(s_T, p.x, p.y, p.z, xt[0], xt[1], xt[2]);
-        // getNeighborhoodAtPoint: floor(p / leaf_size)
-        const int ijk[3] = {static_cast<int>(floorf(xt[0] / leaf)), static_cast<int>(floorf(xt[1] / leaf)), static_cast<int>(floorf(xt[2] / leaf))};
-        int32_t ids[NNB];
+        const uint32_t tile0 = base + it * kTilePts;
+        if (tile0 >= pr.n_src) break;  // uniform
+        // ---- phase 1: one lane per point -------------------------------------------------------------------------
+        const uint32_t i = tile0 + threadIdx.x;
+        int32_t  ids[NNB];
+        uint32_t cnt = 0;
 #pragma unroll
-        for (int n = 0; n < NNB; ++n) {
-            int o0, o1, o2;
-            if (NNB == 27) { o0 = n / 9 - 1; o1 = (n / 3) % 3 - 1; o2 = n % 3 - 1; }
-            else           { o0 = kOff7[n][0]; o1 = kOff7[n][1]; o2 = kOff7[n][2]; }
-            const int c0 = ijk[0] + o0, c1 = ijk[1] + o1, c2 = ijk[2] + o2;
-            int32_t id = -1;
-            if (c0 >= g.min_b[0] && c0 <= g.max_b[0] && c1 >= g.min_b[1] && c1 <= g.max_b[1] && c2 >= g.min_b[2] && c2 <= g.max_b[2]) {
-                const uint32_t key = static_cast<uint32_t>((c0 - g.min_b[0]) * g.divb_mul[0] + (c1 - g.min_b[1]) * g.divb_mul[1] + (c2 - g.min_b[2]) * g.divb_mul[2]);
-                id = ndt_lookup(g, key);
-            }
-            ids[n] = id;
-        }
-        if (kdtree) {
-            // radiusSearch(point, resolution) over voxel centroids: FLANN keeps dist^2 < r^2
-            const float r2 = leaf * leaf;
+        for (int n = 0; n < NNB; ++n) ids[n] = -1;
+        if (i < pr.n_src) {
+            const float4 p = pr.src[i];
+            float xt[3];
+            transform_point(s_T, p.x, p.y, p.z, xt[0], xt[1], xt[2]);
+            // getNeighborhoodAtPoint: floor(p / leaf_size)
+            const int ijk[3] = {static_cast<int>(floorf(xt[0] / leaf)), static_cast<int>(floorf(xt[1] / leaf)), static_cast<int>(floorf(xt[2] / leaf))};
 #pragma unroll
-            for (int n = 0; n < NNB; ++n)
-                if (ids[n] >= 0) {
-                    const float4 c = g.centroid[ids[n]];
-                    const float  dx = c.x - xt[0], dy = c.y - xt[1], dz = c.z - xt[2];
-                    const float  d = dot3f(dx, dx, dy, dy, dz, dz);
-                    if (!(d < r2)) ids[n] = -1;
+            for (int n = 0; n < NNB; ++n) {
+                int o0, o1, o2;
+                if (NNB == 27) { o0 = n / 9 - 1; o1 = (n / 3) % 3 - 1; o2 = n % 3 - 1; }
+                else           { o0 = kOff7[n][0]; o1 = kOff7[n][1]; o2 = kOff7[n][2]; }
+                const int c0 = ijk[0] + o0, c1 = ijk[1] + o1, c2 = ijk[2] + o2;
+                int32_t id = -1;
+                if (c0 >= g.min_b[0] && c0 <= g.max_b[0] && c1 >= g.min_b[1] && c1 <= g.max_b[1] && c2 >= g.min_b[2] && c2 <= g.max_b[2]) {
+                    const uint32_t key = static_cast<uint32_t>((c0 - g.min_b[0]) * g.divb_mul[0] + (c1 - g.min_b[1]) * g.divb_mul[1] + (c2 - g.min_b[2]) * g.divb_mul[2]);
+                    id = ndt_lookup(g, key);
                 }
-        }
-        bool any = false;
+                ids[n] = id;
+            }
+            if (kdtree) {
+                // radiusSearch(point, resolution) over voxel centroids: FLANN keeps dist^2 < r^2
+                const float r2 = leaf * leaf;
 #pragma unroll
-        for (int n = 0; n < NNB; ++n) any = any || ids[n] >= 0;
-        if (!any) continue;
+                for (int n = 0; n < NNB; ++n)
+                    if (ids[n] >= 0) {
+                        const float4 c = g.centroid[ids[n]];
+                        const float  dx = c.x - xt[0], dy = c.y - xt[1], dz = c.z - xt[2];
+                        const float  d = dot3f(dx, dx, dy, dy, dz, dz);
+                        if (!(d < r2)) ids[n] = -1;
+                    }
+            }
+#pragma unroll
+            for (int n = 0; n < NNB; ++n) cnt += ids[n] >= 0 ? 1u : 0u;
+            if (cnt) {
+                s_xt[0][threadIdx.x] = xt[0]; s_xt[1][threadIdx.x] = xt[1]; s_xt[2][threadIdx.x] = xt[2];
+                if (MODE != 2) {
+                    // computePointDerivatives, float form: x_j_ang = j_ang * x, x_h_ang = h_ang * x
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) s_xj[r][threadIdx.x] = dot3f(s_ja[r][0], p.x, s_ja[r][1], p.y, s_ja[r][2], p.z);
+                    if (MODE == 0) {
+#pragma unroll
+                        for (int r = 0; r < 15; ++r) s_xh[r][threadIdx.x] = dot3f(s_ha[r][0], p.x, s_ha[r][1], p.y, s_ha[r][2], p.z);
+                    }
+                } else {
+                    // computePointDerivatives, double form
+                    const double x[3] = {p.x, p.y, p.z};
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) s_xj[r][threadIdx.x] = x[0] * ev.j_ang_d[r][0] + x[1] * ev.j_ang_d[r][1] + x[2] * ev.j_ang_d[r][2];
+#pragma unroll
+                    for (int r = 0; r < 15; ++r) s_xh[r][threadIdx.x] = x[0] * ev.h_ang_d[r][0] + x[1] * ev.h_ang_d[r][1] + x[2] * ev.h_ang_d[r][2];
+                }
+            }
+        }
+        uint32_t total;
+        uint32_t off = block_exclusive_scan<256>(cnt, s_scan, &total);
+#pragma unroll
+        for (int n = 0; n < NNB; ++n)
+            if (ids[n] >= 0) s_queue[off++] = (threadIdx.x << 24) | static_cast<uint32_t>(ids[n]);
+        __syncthreads();
+        nb_total += (threadIdx.x == 0) ? total : 0u;
 
-        if (MODE != 2) {
-            // computePointDerivatives, float form: x_j_ang = j_ang * x, x_h_ang = h_ang * x
-            float xj[8], xh[15];
+        // ---- phase 2: one lane per (point, voxel) pair -----------------------------------------------------------
+        for (uint32_t qi = threadIdx.x; qi < total; qi += kTilePts) {
+            const uint32_t entry = s_queue[qi];
+            const uint32_t slot = entry >> 24, lid = entry & 0x00FFFFFFu;
+            if (lid >= g.n_leaves) continue;  // cannot happen; keeps a corrupted queue entry from faulting the GPU
+            const float xt[3] = {s_xt[0][slot], s_xt[1][slot], s_xt[2][slot]};
+            const NdtLeafRec rec = g.leaves[lid];
+            if (MODE != 2) {
+                float xj[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) xj[r] = dot3f(s_j[r][0], p.x, s_j[r][1], p.y, s_j[r][2], p.z);
-            const float J3[3] = {0.0f, xj[0], xj[1]}, J4[3] = {xj[2], xj[3], xj[4]}, J5[3] = {xj[5], xj[6], xj[7]};
-            float PH[6][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-            if (MODE == 0) {
+                for (int r = 0; r < 8; ++r) xj[r] = static_cast<float>(s_xj[r][slot]);
+                const float J3[3] = {0.0f, xj[0], xj[1]}, J4[3] = {xj[2], xj[3], xj[4]}, J5[3] = {xj[5], xj[6], xj[7]};
+                float PH[6][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+                if (MODE == 0) {
+                    float xh[15];
 #pragma unroll
-                for (int r = 0; r < 15; ++r) xh[r] = dot3f(s_h[r][0], p.x, s_h[r][1], p.y, s_h[r][2], p.z);
-                PH[0][1] = xh[0];  PH[0][2] = xh[1];                     // a  (3,3)
-                PH[1][1] = xh[2];  PH[1][2] = xh[3];                     // b  (3,4)
-                PH[2][1] = xh[4];  PH[2][2] = xh[5];                     // c  (3,5)
-                PH[3][0] = xh[6];  PH[3][1] = xh[7];  PH[3][2] = xh[8];  // d  (4,4)
-                PH[4][0] = xh[9];  PH[4][1] = xh[10]; PH[4][2] = xh[11]; // e  (4,5)
-                PH[5][0] = xh[12]; PH[5][1] = xh[13]; PH[5][2] = xh[14]; // f  (5,5)
+                    for (int r = 0; r < 15; ++r) xh[r] = static_cast<float>(s_xh[r][slot]);
+                    PH[0][1] = xh[0];  PH[0][2] = xh[1];                     // a  (3,3)
+                    PH[1][1] = xh[2];  PH[1][2] = xh[3];                     // b  (3,4)
+                    PH[2][1] = xh[4];  PH[2][2] = xh[5];                     // c  (3,5)
+                    PH[3][0] = xh[6];  PH[3][1] = xh[7];  PH[3][2] = xh[8];  // d  (4,4)
+                    PH[4][0] = xh[9];  PH[4][1] = xh[10]; PH[4][2] = xh[11]; // e  (4,5)
+                    PH[5][0] = xh[12]; PH[5][1] = xh[13]; PH[5][2] = xh[14]; // f  (5,5)
+                }
+                pair_float<MODE == 0>(acc, rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
+            } else {
+                double J[3][6] = {{1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}, {0, 0, 1, 0, 0, 0}};
+                J[1][3] = s_xj[0][slot]; J[2][3] = s_xj[1][slot];
+                J[0][4] = s_xj[2][slot]; J[1][4] = s_xj[3][slot]; J[2][4] = s_xj[4][slot];
+                J[0][5] = s_xj[5][slot]; J[1][5] = s_xj[6][slot]; J[2][5] = s_xj[7][slot];
+                const double PH[6][3] = {{0, s_xh[0][slot], s_xh[1][slot]},
+                                         {0, s_xh[2][slot], s_xh[3][slot]},
+                                         {0, s_xh[4][slot], s_xh[5][slot]},
+                                         {s_xh[6][slot], s_xh[7][slot], s_xh[8][slot]},
+                                         {s_xh[9][slot], s_xh[10][slot], s_xh[11][slot]},
+                                         {s_xh[12][slot], s_xh[13][slot], s_xh[14][slot]}};
+                pair_double(acc, rec.mean, g.icov64 + (size_t)lid * 9, xt, J, PH, gauss_d1, gauss_d2);
             }
-#pragma unroll
-            for (int n = 0; n < NNB; ++n)
-                if (ids[n] >= 0) {
-                    const NdtLeafRec rec = g.leaves[ids[n]];
-                    pair_float<MODE == 0>(acc, rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
-                    ++acc.nb;
-                }
-        } else {
-            const double x[3] = {p.x, p.y, p.z};
-            double J[3][6] = {{1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}, {0, 0, 1, 0, 0, 0}};
-            auto dj = [&](int r) { return x[0] * ev.j_ang_d[r][0] + x[1] * ev.j_ang_d[r][1] + x[2] * ev.j_ang_d[r][2]; };
-            auto dh = [&](int r) { return x[0] * ev.h_ang_d[r][0] + x[1] * ev.h_ang_d[r][1] + x[2] * ev.h_ang_d[r][2]; };
-            J[1][3] = dj(0); J[2][3] = dj(1);
-            J[0][4] = dj(2); J[1][4] = dj(3); J[2][4] = dj(4);
-            J[0][5] = dj(5); J[1][5] = dj(6); J[2][5] = dj(7);
-            const double PH[6][3] = {{0, dh(0), dh(1)}, {0, dh(2), dh(3)}, {0, dh(4), dh(5)}, {dh(6), dh(7), dh(8)}, {dh(9), dh(10), dh(11)}, {dh(12), dh(13), dh(14)}};
-#pragma unroll 1
-            for (int n = 0; n < NNB; ++n)
-                if (ids[n] >= 0) {
-                    const NdtLeafRec rec = g.leaves[ids[n]];
-                    pair_double(acc, rec.mean, g.icov64 + (size_t)ids[n] * 9, xt, J, PH, gauss_d1, gauss_d2);
-                    ++acc.nb;
-                }
         }
+        __syncthreads();  // the next tile overwrites the staged terms and the queue
     }
 
-    // workgroup reduction: shuffle inside each wavefront, 4 wave records through LDS, one 384-byte partial out
+    // ---- phase 3: workgroup reduction -----------------------------------------------------------------------------
     double vals[kNdtAccum];
     vals[0] = acc.score;
 #pragma unroll
     for (int k = 0; k < 6; ++k) vals[1 + k] = acc.g[k];
 #pragma unroll
     for (int k = 0; k < 36; ++k) vals[7 + k] = acc.H[k];
-    vals[kNdtNbIndex] = static_cast<double>(acc.nb);
+    vals[kNdtNbIndex] = static_cast<double>(nb_total);
 #pragma unroll
     for (int k = 0; k < kNdtAccum; ++k) {
         const bool skip = (MODE == 1 && k >= 7 && k < kNdtNbIndex) || (MODE == 2 && k < 7);

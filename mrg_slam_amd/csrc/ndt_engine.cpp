@@ -216,7 +216,12 @@ int NdtEngine::build_targets()
     uint64_t lookup_bytes = 0;
     for (int k = 0; k < P; ++k) {
         NdtTargetInfo& T = targets_[todo[k]];
-        const uint32_t V = (T.status == MRGFE_OK) ? h_tot[k] : 0;
+        uint32_t V = (T.status == MRGFE_OK) ? h_tot[k] : 0;
+        if (V >= (1u << 24)) {  // the derivative kernel packs (tile slot, leaf id) into 8 + 24 bits
+            set_error("target has %u occupied voxels; NDT_HIP supports fewer than 2^24 per target", V);
+            T.status = MRGFE_ERR_INVALID;
+            V = 0;
+        }
         T.n_leaves = V;
         LeafSlice& ls = h_ls[k];
         ls.n_leaves = V;
