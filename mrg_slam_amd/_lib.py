@@ -13,7 +13,7 @@ import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
-LIB_PATH = os.path.join(_PKG, "libmrgfe.so")
+LIB_PATH = os.environ.get("MRGFE_LIB") or os.path.join(_PKG, "libmrgfe.so")  # MRGFE_LIB: kernel-variant experiments only
 
 MRGFE_OK, ERR_INVALID, ERR_HIP, ERR_OVERFLOW, ERR_EMPTY, ERR_STATE = 0, -1, -2, -3, -4, -5
 NDT_HIP, GICP_HIP = 0, 1

@@ -68,40 +68,49 @@ __global__ __launch_bounds__(256) void ndt_segments_kernel(const uint32_t* __res
 
 // one wavefront per leaf. The reference accumulates each voxel's sums point by point in index order
 // (pclomp::VoxelGridCovariance first pass); to reproduce those f64 sums BIT FOR BIT the additions of one accumulator stay
-// sequential, and the parallelism is across the 13 accumulators instead: the wave stages 64 points at a time into LDS
-// with one coalesced index read + one 16-byte gather per lane, then lane k (k < 13) walks the staged points in order and
-// adds its own term: k 0..2 sum p, 3..8 sum xx,xy,xz,yy,yz,zz (f64), 9..12 the f32 centroid sums of x,y,z,intensity.
-// sums layout per leaf (16 doubles): [0..2] sum p, [3..8] products, [9] n, [10..13] float centroid sums.
+// sequential and the parallelism is moved elsewhere:
+//   step A  64 lanes fetch 64 points of the leaf (coalesced index read + 16-byte gather) and each lane computes the 13
+//           terms of ITS point (x,y,z, the six products in f64, x,y,z,intensity in f32) into LDS, [term][point];
+//   step B  lane k (k < 13) walks row k of the staged terms in point order and adds them to its accumulator: 13
+//           independent dependent-add chains, fed by pipelined conflict-free LDS reads.
+// sums layout per leaf (16 doubles): [0..2] sum p, [3..8] sum xx,xy,xz,yy,yz,zz, [9] n, [10..13] float centroid sums.
 __global__ __launch_bounds__(256) void ndt_leaf_sums_kernel(const float4* const* __restrict__ clouds, const uint32_t* __restrict__ sorted_vals, const Slice* __restrict__ slices,
                                                              const LeafSlice* __restrict__ leaf_slices, const uint32_t* __restrict__ seg_start,
                                                              double* __restrict__ sums)
 {
-    __shared__ float4 stage[4][kWave];
+    __shared__ double s_term[4][9][kWave + 1];   // +1: the 13 row readers hit different banks
+    __shared__ float  s_fterm[4][4][kWave + 1];
     const LeafSlice ls = leaf_slices[blockIdx.y];
     const uint32_t  leaf = blockIdx.x * 4 + wave_id();
     if (leaf >= ls.n_leaves) return;  // wave-uniform
     const Slice    s = slices[blockIdx.y];
     const float4* __restrict__ pts = clouds[blockIdx.y];
     const uint32_t b = seg_start[ls.seg_off + leaf], e = seg_start[ls.seg_off + leaf + 1];
-    const int      lane = lane_id();
-    // which coordinates lane k multiplies: (ia, ib); ib == 3 selects the constant 1.0
-    const int ia = lane < 3 ? lane : (lane < 6 ? 0 : (lane < 8 ? 1 : 2));
-    const int ib = lane < 3 ? 3 : (lane == 3 ? 0 : lane == 4 ? 1 : lane == 5 ? 2 : lane == 6 ? 1 : lane == 7 ? 2 : 2);
+    const int      lane = lane_id(), w = wave_id();
+    const int      row = lane < 9 ? lane : 0, frow = (lane >= 9 && lane < 13) ? lane - 9 : 0;
     double acc = 0.0;
     float  facc = 0.0f;
-    float4* st = stage[wave_id()];
     for (uint32_t base = b; base < e; base += kWave) {
         const uint32_t i = base + lane;
-        if (i < e) st[lane] = pts[sorted_vals[s.off + i]];
+        if (i < e) {
+            const float4 p = pts[sorted_vals[s.off + i]];
+            const double x = p.x, y = p.y, z = p.z;
+            s_term[w][0][lane] = x; s_term[w][1][lane] = y; s_term[w][2][lane] = z;
+            s_term[w][3][lane] = x * x; s_term[w][4][lane] = x * y; s_term[w][5][lane] = x * z;
+            s_term[w][6][lane] = y * y; s_term[w][7][lane] = y * z; s_term[w][8][lane] = z * z;
+            s_fterm[w][0][lane] = p.x; s_fterm[w][1][lane] = p.y; s_fterm[w][2][lane] = p.z; s_fterm[w][3][lane] = p.w;
+        }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
         const uint32_t cnt = min(static_cast<uint32_t>(kWave), e - base);
-        for (uint32_t j = 0; j < cnt; ++j) {
-            const float4 p = st[j];
-            const float  pf[4] = {p.x, p.y, p.z, p.w};
-            const double pd[4] = {static_cast<double>(p.x), static_cast<double>(p.y), static_cast<double>(p.z), 1.0};
-            acc += pd[ia] * pd[ib];
-            facc += pf[lane >= 9 && lane < 13 ? lane - 9 : 0];
+        if (lane < 9) {
+            const double* t = s_term[w][row];
+#pragma unroll 8
+            for (uint32_t j = 0; j < cnt; ++j) acc += t[j];
+        } else if (lane < 13) {
+            const float* t = s_fterm[w][frow];
+#pragma unroll 8
+            for (uint32_t j = 0; j < cnt; ++j) facc += t[j];
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();

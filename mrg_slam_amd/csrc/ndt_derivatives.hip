@@ -136,8 +136,10 @@ __device__ __forceinline__ void pair_double(Accum& acc, const double mean[3], co
 }
 
 // MODE 0: score+gradient+Hessian, 1: score+gradient, 2: Hessian only (double).  NNB: probed voxels (7, 1 or 27).
+// Register budget: the full variant (43 f64 accumulators) is latency-bound at 2 waves/SIMD; capping it at 168 VGPRs
+// (3 waves/SIMD, ~44 B/lane of spill) is 12 % faster on MI355X, 128 VGPRs (4 waves) spills too much (measured).
 template <int MODE, int NNB>
-__global__ __launch_bounds__(256) void ndt_derivatives_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
+__global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? 3 : 2)) void ndt_derivatives_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
                                                                const NdtEvalDev* __restrict__ evals, double* __restrict__ partials, int ppt)
 {
     const NdtPairDev pr = pairs[blockIdx.y];
