@@ -213,6 +213,15 @@ def main():
     variants = {name: {"launches": int(per_mode[m][1]), "avg_launch_ms": (per_mode[m][0] / per_mode[m][1]) if per_mode[m][1] else None,
                        "achieved_GBps": (per_mode[m][2] / 1e9) / (per_mode[m][0] / 1e3) if per_mode[m][0] > 0 else None}
                 for m, name in enumerate(("ndt_derivatives_kernel<0,7>", "ndt_derivatives_kernel<1,7>", "ndt_derivatives_kernel<2,7>"))}
+    # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately with
+    # rocprofv3 --pmc and corrected as MI355X_MICROARCH.md prescribes; profiles/summarize.py) - null until a profile exists
+    traffic = None
+    try:
+        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_summary.json"))
+        if prof:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", prof[-1]))).get("traffic_bytes_per_full_launch")
+    except OSError:
+        pass
     true_err = float(np.mean([np.linalg.norm(result_matrix(res[b])[:3, 3] - pairs[b][3][:3, 3]) for b in range(args.batch)]))
     out = {
         "metric": "scan-pair alignments/sec (NDT, ~120k pts, 1.0 m voxel)",
@@ -236,7 +245,7 @@ def main():
             "points_per_scan": n_pts,
             "parallelism": f"{world} x 1 GPU, pairs sharded per rank, RCCL all-gather of 384-byte result records" if world > 1 else "1 GPU",
         },
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel": "ndt_derivatives_kernel<0,7>", "avg_launch_ms": (k_ms / k_launch) if k_launch else None, "launches": int(k_launch),
                      "alg_bytes_per_launch": (k_bytes / k_launch) if k_launch else None,
                      "byte_model": "per launch: sum over active pairs of N_src*(16 + 7*8) + valid_neighbours*48 (SURVEY.md §8d)",

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 CSVs that a profiling `gpurun` call merged into gpurun_out/ into the small, tracked summaries
+under profiles/ (gpurun_out/ is scratch and ignored by git).
+
+    python profiles/summarize.py r01            # reads gpurun_out/{prof,pmc_fetch,pmc_write,pmc_sq}_*, writes profiles/r01_*
+
+Commands that produced the inputs (run on the GPU box from /tmp with TMPDIR=/tmp, program directly after `--`):
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r01 -o r01 -- python3 bench.py --no-cpu
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --no-cpu --steps 1 --warmup 0
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py --no-cpu --steps 1 --warmup 0
+    rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace \
+              --output-format csv -d gpurun_out/pmc_sq -o s -- python3 bench.py --no-cpu --steps 1 --warmup 0
+HBM traffic follows MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB, collected in separate passes; on gfx950
+FETCH_SIZE reports half of the bytes of wide coalesced reads, so it is doubled (an upper estimate for this kernel, whose
+reads are a mix of 16-byte streams and scattered 48-byte records).
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+DOMINANT = "ndt_derivatives_kernel<0, 7>"
+
+
+def short(name):
+    name = name.replace("void mrgfe::", "").replace("mrgfe::", "")
+    return name.split("(")[0]
+
+
+def counters(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not os.path.exists(path):
+        return agg
+    for r in csv.DictReader(open(path)):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    lines = [f"# rocprofv3 summary {tag} (MI355X, gfx950) — `python3 bench.py --no-cpu`", ""]
+    stats = list(csv.DictReader(open(os.path.join(OUT, f"prof_{tag}", f"{tag}_kernel_stats.csv"))))
+    lines += ["## --kernel-trace --stats (all kernels of the run: 2 warm-up + 5 timed steps)", "",
+              "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---:|---:|---:|---:|---:|---:|"]
+    for r in stats:
+        lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.2f} | "
+                     f"{float(r['MinNs']) / 1e3:.2f} | {float(r['MaxNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} |")
+    dom = next((r for r in stats if short(r["Name"]) == DOMINANT), None)
+    summary = {"tag": tag, "dominant_kernel": DOMINANT}
+    if dom:
+        summary["avg_launch_ms_rocprof"] = float(dom["AverageNs"]) / 1e6
+        summary["calls"] = int(dom["Calls"])
+    # PMC passes (steps 1, warm-up 0): per-launch values; the full-batch launches are the largest ones
+    fetch = counters(os.path.join(OUT, "pmc_fetch", "f_counter_collection.csv"))
+    write = counters(os.path.join(OUT, "pmc_write", "w_counter_collection.csv"))
+    sq = counters(os.path.join(OUT, "pmc_sq", "s_counter_collection.csv"))
+    lines += ["", "## --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB per launch; `bench.py --no-cpu --steps 1 --warmup 0`)", "",
+              "| kernel | launches | FETCH_SIZE max | FETCH_SIZE mean | WRITE_SIZE max | WRITE_SIZE mean | HBM bytes per full launch = (2*FETCH + WRITE)*1024 |",
+              "|---|---:|---:|---:|---:|---:|---:|"]
+    for k in sorted(set(fetch) | set(write)):
+        f = fetch.get(k, {}).get("FETCH_SIZE", [])
+        w = write.get(k, {}).get("WRITE_SIZE", [])
+        if not f and not w:
+            continue
+        fm, wm = (max(f) if f else 0.0), (max(w) if w else 0.0)
+        lines.append(f"| `{k}` | {max(len(f), len(w))} | {fm:.1f} | {sum(f) / max(len(f), 1):.1f} | {wm:.1f} | {sum(w) / max(len(w), 1):.1f} | {(2 * fm + wm) * 1024 / 1e6:.2f} MB |")
+        if k == DOMINANT:
+            summary["traffic_bytes_per_full_launch"] = (2 * fm + wm) * 1024
+            summary["fetch_size_kib_max"] = fm
+            summary["write_size_kib_max"] = wm
+    if sq:
+        lines += ["", "## --pmc SQ counters (largest launch of each derivative kernel)", "",
+                  "| kernel | SQ_WAVES | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU | SQ_WAVE_CYCLES | SQ_BUSY_CYCLES | GRBM_GUI_ACTIVE | VALU instr / wave | VALU busy = ACTIVE_INST_VALU*4 / (1024 SIMD * GUI_ACTIVE/8) |",
+                  "|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
+        for k in sorted(sq):
+            if "ndt_derivatives" not in k:
+                continue
+            v = {c: max(x) for c, x in sq[k].items()}
+            waves = v.get("SQ_WAVES", 0) or 1
+            gui = v.get("GRBM_GUI_ACTIVE", 0) / 8.0 or 1
+            busy = v.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (1024 * gui)
+            lines.append(f"| `{k}` | {v.get('SQ_WAVES', 0):.0f} | {v.get('SQ_INSTS_VALU', 0):.0f} | {v.get('SQ_ACTIVE_INST_VALU', 0):.0f} | {v.get('SQ_WAVE_CYCLES', 0):.0f} | "
+                         f"{v.get('SQ_BUSY_CYCLES', 0):.0f} | {v.get('GRBM_GUI_ACTIVE', 0):.0f} | {v.get('SQ_INSTS_VALU', 0) / waves:.0f} | {busy:.2f} |")
+            if k == DOMINANT:
+                summary["valu_instr_per_wave"] = v.get("SQ_INSTS_VALU", 0) / waves
+                summary["valu_busy_estimate"] = busy
+    bench = os.path.join(OUT, f"bench_{tag}.json")
+    if os.path.exists(bench):
+        b = json.load(open(bench))
+        summary["bench"] = {k: b[k] for k in ("value", "unit", "ms_per_step", "roofline", "cpu_baseline", "parity_vs_oracle", "evaluations_per_alignment", "mean_valid_neighbours")}
+        lines += ["", "## bench.py line of the same build (`python bench.py`)", "", "```json", json.dumps(b, indent=1), "```"]
+        if dom:
+            ev = b["roofline"]["avg_launch_ms"]
+            lines += ["", f"Agreement check: HIP-event average of `{DOMINANT}` inside bench.py = {ev * 1e3:.2f} us over {b['roofline']['launches']} timed launches; "
+                          f"rocprofv3 average = {float(dom['AverageNs']) / 1e3:.2f} us over {dom['Calls']} launches (warm-up included)."]
+    lat = os.path.join(OUT, f"bench_{tag}_latency.json")
+    if os.path.exists(lat):
+        summary["single_pair_latency_ms"] = json.load(open(lat)).get("single_pair_latency_ms")
+    open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
+    json.dump(summary, open(os.path.join(ROOT, "profiles", f"{tag}_summary.json"), "w"), indent=1)
+    # the raw per-kernel stats travel too (small)
+    import shutil
+
+    shutil.copy(os.path.join(OUT, f"prof_{tag}", f"{tag}_kernel_stats.csv"), os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
+    print(json.dumps(summary, indent=1)[:1500])
+
+
+if __name__ == "__main__":
+    main()
