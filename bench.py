@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="scan pairs per step and per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="scan pairs per step and per GPU (more pairs in flight keep the GPU full in the late rounds)")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic scan pairs generated per rank (reused with different guesses)")
     ap.add_argument("--prefilter", choices=["distance", "full"], default="distance")
     ap.add_argument("--eps", type=float, default=0.1, help="reg_transformation_epsilon (config/mrg_slam.yaml:102)")

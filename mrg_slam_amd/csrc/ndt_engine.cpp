@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "ndt_derivatives.h"
@@ -39,6 +40,10 @@ NdtEngine::~NdtEngine()
     if (ctx_) (void)hipSetDevice(ctx_->device);
     cloud_arena_.release();
     grid_arena_.release();
+    for (auto& g : groups_) {
+        if (g.done) (void)hipEventDestroy(g.done);
+        for (auto& pr : g.ev) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
+    }
     d_grids_.release(); d_pairs_.release(); d_evals_.release(); d_partials_.release(); d_results_.release(); d_T12_.release(); d_aligned_.release();
     h_evals_.release(); h_results_.release();
 }
@@ -325,6 +330,7 @@ int NdtEngine::upload_pairs()
     const uint64_t target_blocks = uint64_t(ctx_->cu_count) * 16;
     int ppt = static_cast<int>(total_pts / (256 * target_blocks));
     ppt = std::max(1, std::min(ppt, 8));
+    if (const char* e = std::getenv("MRGFE_PPT")) ppt = std::max(1, std::min(std::atoi(e), 64));  // tuning experiments
     ppt_ = ppt;
     h_pairs_.resize(P);
     uint32_t part = 0;
@@ -365,44 +371,61 @@ static void fill_eval(NdtEvalDev& e, const NdtRequest& r, const NdtController& c
     e.pad = 0;
 }
 
-int NdtEngine::run_round(int* n_active)
+// ---- rounds --------------------------------------------------------------------------------------------------------
+// The pairs of a batch are split into (up to) two contiguous groups that take turns on the context stream: while the
+// host steps the controllers of one group (6x6 solves, line-search logic) and uploads its next requests, the other
+// group's derivative kernels are already queued, so the GPU does not idle during host turnarounds.  Both groups use
+// the same stream: kernels never overlap each other and the per-launch HIP-event timings stay clean.
+// batches at least this large are split into two alternating groups (each half still fills the GPU)
+static int pipeline_min_pairs() { const char* e = std::getenv("MRGFE_PIPELINE_MIN_PAIRS"); return e ? std::atoi(e) : 1 << 30; }  // measured on MI355X: alternating half-batches lose more to smaller launches than they hide
+
+int NdtEngine::launch_group(RoundGroup& g)
 {
-    const int P = n_pairs();
     NdtEvalDev* he = h_evals_.as<NdtEvalDev>();
-    bool modes[3] = {false, false, false};
-    int  active = 0;
-    for (int i = 0; i < P; ++i) {
+    g.modes[0] = g.modes[1] = g.modes[2] = false;
+    int active = 0;
+    for (int i = g.first; i < g.first + g.count; ++i) {
         NdtController& c = pairs_[i].ctl;
         if (c.done()) { he[i].active = 0; continue; }
         fill_eval(he[i], c.request(), c, prm_.search, true);
-        modes[c.request().mode] = true;
+        g.modes[c.request().mode] = true;
         ++active;
     }
-    *n_active = active;
+    g.inflight = false;
     if (!active) return MRGFE_OK;
     hipStream_t st = ctx_->stream;
-    MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));
+    NdtEvalDev*       d_ev = d_evals_.as<NdtEvalDev>() + g.first;
+    const NdtPairDev* d_pr = d_pairs_.as<NdtPairDev>() + g.first;
+    double*           d_res = d_results_.as<double>() + size_t(g.first) * kNdtPartialStride;
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_ev, he + g.first, sizeof(NdtEvalDev) * g.count, hipMemcpyHostToDevice, st));
     // every kernel variant (mode) is bracketed by its own HIP events on the launch stream
     for (int m = 0; m < 3; ++m)
-        if (modes[m]) {
-            MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev_mode[m][0], st));
-            MRGFE_TRY(ndt_launch_derivatives(ctx_, m, prm_.search, max_nblk_, P, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(),
-                                             d_partials_.as<double>(), ppt_));
-            MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev_mode[m][1], st));
+        if (g.modes[m]) {
+            MRGFE_HIP_CHECK(hipEventRecord(g.ev[m][0], st));
+            MRGFE_TRY(ndt_launch_derivatives(ctx_, m, prm_.search, g.max_nblk, g.count, d_grids_.as<NdtGridDev>(), d_pr, d_ev, d_partials_.as<double>(), ppt_));
+            MRGFE_HIP_CHECK(hipEventRecord(g.ev[m][1], st));
         }
-    MRGFE_TRY(ndt_launch_reduce(ctx_, P, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_partials_.as<double>(), d_results_.as<double>()));
-    MRGFE_HIP_CHECK(hipMemcpyAsync(h_results_.p, d_results_.p, sizeof(double) * kNdtPartialStride * P, hipMemcpyDeviceToHost, st));
-    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    MRGFE_TRY(ndt_launch_reduce(ctx_, g.count, d_pr, d_ev, d_partials_.as<double>(), d_res));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(h_results_.as<double>() + size_t(g.first) * kNdtPartialStride, d_res, sizeof(double) * kNdtPartialStride * g.count, hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipEventRecord(g.done, st));
+    g.inflight = true;
+    return MRGFE_OK;
+}
+
+int NdtEngine::finish_group(RoundGroup& g)
+{
+    MRGFE_HIP_CHECK(hipEventSynchronize(g.done));
+    g.inflight = false;
     for (int m = 0; m < 3; ++m)
-        if (modes[m]) {
+        if (g.modes[m]) {
             float ms = 0;
-            MRGFE_HIP_CHECK(hipEventElapsedTime(&ms, ctx_->ev_mode[m][0], ctx_->ev_mode[m][1]));
+            MRGFE_HIP_CHECK(hipEventElapsedTime(&ms, g.ev[m][0], g.ev[m][1]));
             mode_ms[m] += ms;
             mode_launches[m] += 1;
         }
     const double* hr = h_results_.as<double>();
     const int probes = prm_.search == MRGFE_DIRECT7 ? 7 : (prm_.search == MRGFE_DIRECT1 ? 1 : 27);
-    for (int i = 0; i < P; ++i) {
+    for (int i = g.first; i < g.first + g.count; ++i) {
         NdtController& c = pairs_[i].ctl;
         if (c.done()) continue;
         const double* r = hr + size_t(i) * kNdtPartialStride;
@@ -423,13 +446,48 @@ int NdtEngine::align_all()
         p.ctl.start(prm_, p.guess, p.n);
         if (targets_[p.target].status != MRGFE_OK && !p.ctl.done()) p.ctl.abort_no_target();
     }
+    const int P = n_pairs();
+    if (P == 0) return MRGFE_OK;
+    // groups: two halves of (roughly) equal point count once the batch is large enough to keep the GPU busy with one
+    const int n_groups = P >= pipeline_min_pairs() ? 2 : 1;
+    if (groups_.size() < 2) {
+        groups_.resize(2);
+        for (auto& g : groups_) {
+            MRGFE_HIP_CHECK(hipEventCreate(&g.done));
+            for (int m = 0; m < 3; ++m) for (int k = 0; k < 2; ++k) MRGFE_HIP_CHECK(hipEventCreate(&g.ev[m][k]));
+        }
+    }
+    int split = P;
+    if (n_groups == 2) {
+        uint64_t total = 0, run = 0;
+        for (auto& p : pairs_) total += p.n;
+        split = 0;
+        while (split < P - 1 && (run + pairs_[split].n) * 2 <= total + pairs_[split].n) run += pairs_[split++].n;
+        split = std::max(1, std::min(split, P - 1));
+    }
+    for (int k = 0; k < 2; ++k) {
+        RoundGroup& g = groups_[k];
+        g.first = k == 0 ? 0 : split;
+        g.count = k == 0 ? split : P - split;
+        g.inflight = false;
+        g.max_nblk = 0;
+        for (int i = g.first; i < g.first + g.count; ++i) g.max_nblk = std::max(g.max_nblk, h_pairs_[i].nblk);
+    }
     // every controller needs at most (max_iterations + 2) * (max line-search trials + 2) evaluations
     const int round_cap = (prm_.max_iterations + 3) * 13 + 8;
+    for (int k = 0; k < n_groups; ++k) MRGFE_TRY(launch_group(groups_[k]));
     for (int round = 0; round < round_cap; ++round) {
-        int active = 0;
-        MRGFE_TRY(run_round(&active));
-        if (!active) return MRGFE_OK;
+        bool any = false;
+        for (int k = 0; k < n_groups; ++k) {
+            RoundGroup& g = groups_[k];
+            if (!g.inflight) continue;
+            any = true;
+            MRGFE_TRY(finish_group(g));
+            MRGFE_TRY(launch_group(g));  // no-op when every pair of the group is done
+        }
+        if (!any) return MRGFE_OK;
     }
+    MRGFE_HIP_CHECK(hipStreamSynchronize(ctx_->stream));
     set_error("NDT alignment did not terminate within %d rounds", round_cap);
     return MRGFE_ERR_STATE;
 }

@@ -96,8 +96,19 @@ class NdtEngine {
     struct LeafArrays { int32_t* keys; int32_t* nr_points; NdtLeafRec* leaves; double* icov64; };
     std::vector<LeafArrays> leaf_arrays_;
 
+    // a contiguous range of pairs whose rounds are launched and collected together (see align_all)
+    struct RoundGroup {
+        int        first = 0, count = 0;
+        uint32_t   max_nblk = 0;
+        bool       inflight = false;
+        bool       modes[3] = {false, false, false};
+        hipEvent_t done = nullptr;
+        hipEvent_t ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    };
+    std::vector<RoundGroup> groups_;
     int upload_pairs();
-    int run_round(int* n_active);
+    int launch_group(RoundGroup& g);
+    int finish_group(RoundGroup& g);
 };
 
 }  // namespace mrgfe
