@@ -43,7 +43,9 @@ def make_workload(n_distinct: int, batch: int, rank: int, prefilter_mode: str):
     from mrg_slam_amd import synth
 
     scene = synth.street_scene()
-    poses = synth.arc_trajectory(n_distinct + 1 + 40 * rank)[40 * rank:]  # every rank drives its own stretch of the street
+    # every rank drives its own stretch of the street (40 m further along x), same gentle arc
+    start = synth.make_pose([40.0 * rank, 0.0, 0.0], np.eye(3))
+    poses = [start @ T for T in synth.arc_trajectory(n_distinct + 1)]
     scans = [synth.synth_lidar(scene, poses[k], "VLP64", synth.BASE_SEED + 40 * rank + k) for k in range(n_distinct + 1)]
     return scene, poses, scans
 

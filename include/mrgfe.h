@@ -19,8 +19,9 @@
  *   - status: 0 = ok, <0 = error; mrgfe_last_error() returns a thread-local message for the last failure.
  *     Non-convergence is NOT an error (pcl::Registration::align returns void; callers test hasConverged():
  *     apps/scan_matching_odometry_component.cpp:270, src/mrg_slam/loop_detector.cpp:138).
- *   - a handle is used from one thread at a time; distinct handles may be used concurrently (each context owns
- *     its HIP stream; the odometry and loop-closure registrations of the reference live in different threads).
+ *   - a handle is used from one thread at a time; distinct handles may be used from different threads (the odometry
+ *     and loop-closure registrations of the reference live in different threads): calls that share a context are
+ *     serialised by a per-context lock, calls on different contexts (e.g. one per GPU) run concurrently.
  */
 #ifndef MRGFE_H
 #define MRGFE_H

@@ -130,7 +130,8 @@ int mrgfe_reg_create(mrgfe_ctx* ctx, const mrgfe_reg_params* params, mrgfe_reg**
 void mrgfe_reg_destroy(mrgfe_reg* reg)
 {
     if (!reg) return;
-    if (reg->ctx) (void)hipSetDevice(reg->ctx->device);
+    MRGFE_LOCK(reg->ctx);
+    (void)hipSetDevice(reg->ctx->device);
     delete reg->ndt;
     delete reg->gicp;
     reg->nn.release();
@@ -161,6 +162,7 @@ static int reg_target_changed(mrgfe_reg* reg)
 int mrgfe_reg_set_target(mrgfe_reg* reg, const float* xyzi, size_t n, size_t stride_bytes)
 {
     if (!reg || (n && !xyzi)) { set_error("mrgfe_reg_set_target: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(reg->ctx);
     MRGFE_TRY(reg->ctx->bind());
     MRGFE_TRY(reg->tgt.ensure(std::max<size_t>(n, 1) * 16));
     MRGFE_TRY(upload_cloud(reg->ctx, xyzi, n, stride_bytes, reg->tgt.p));
@@ -172,6 +174,7 @@ int mrgfe_reg_set_target(mrgfe_reg* reg, const float* xyzi, size_t n, size_t str
 int mrgfe_reg_set_target_device(mrgfe_reg* reg, const void* d_xyzi, size_t n)
 {
     if (!reg || (n && !d_xyzi)) { set_error("mrgfe_reg_set_target_device: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(reg->ctx);
     MRGFE_TRY(reg->ctx->bind());
     reg->d_tgt = d_xyzi;
     reg->n_tgt = n;
@@ -181,6 +184,7 @@ int mrgfe_reg_set_target_device(mrgfe_reg* reg, const void* d_xyzi, size_t n)
 int mrgfe_reg_set_source(mrgfe_reg* reg, const float* xyzi, size_t n, size_t stride_bytes)
 {
     if (!reg || (n && !xyzi)) { set_error("mrgfe_reg_set_source: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(reg->ctx);
     MRGFE_TRY(reg->ctx->bind());
     MRGFE_TRY(reg->src.ensure(std::max<size_t>(n, 1) * 16));
     MRGFE_TRY(upload_cloud(reg->ctx, xyzi, n, stride_bytes, reg->src.p));
@@ -194,6 +198,7 @@ int mrgfe_reg_set_source(mrgfe_reg* reg, const float* xyzi, size_t n, size_t str
 int mrgfe_reg_set_source_device(mrgfe_reg* reg, const void* d_xyzi, size_t n)
 {
     if (!reg || (n && !d_xyzi)) { set_error("mrgfe_reg_set_source_device: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(reg->ctx);
     MRGFE_TRY(reg->ctx->bind());
     reg->d_src = d_xyzi;
     reg->n_src = n;
@@ -206,6 +211,7 @@ int mrgfe_reg_align(mrgfe_reg* reg, const float guess[16], float* aligned_xyzi)
 {
     if (!reg || !guess) { set_error("mrgfe_reg_align: NULL argument"); return MRGFE_ERR_INVALID; }
     if (!reg->has_target || !reg->has_source) { set_error("align: setInputTarget / setInputSource first"); return MRGFE_ERR_STATE; }
+    MRGFE_LOCK(reg->ctx);
     MRGFE_TRY(reg->ctx->bind());
     float g[16];
     col2row(guess, g);
@@ -262,6 +268,7 @@ int mrgfe_reg_fitness(mrgfe_reg* reg, double max_range, double* out)
 {
     if (!reg || !out) { set_error("mrgfe_reg_fitness: NULL argument"); return MRGFE_ERR_INVALID; }
     if (!reg->has_target || !reg->has_source) { set_error("getFitnessScore: target / source not set"); return MRGFE_ERR_STATE; }
+    MRGFE_LOCK(reg->ctx);
     MRGFE_TRY(reg->ctx->bind());
     if (reg->n_tgt == 0 || reg->n_src == 0) { *out = DBL_MAX; return MRGFE_OK; }
     MRGFE_TRY(reg_ensure_nn(reg));
@@ -271,6 +278,7 @@ int mrgfe_reg_fitness(mrgfe_reg* reg, double max_range, double* out)
 int mrgfe_reg_nn1_target(mrgfe_reg* reg, const float* q, size_t n, size_t stride_bytes, int32_t* idx, float* sqd)
 {
     if (!reg || (n && (!q || !idx || !sqd))) { set_error("mrgfe_reg_nn1_target: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(reg->ctx);
     MRGFE_TRY(reg->ctx->bind());
     MRGFE_TRY(reg_ensure_nn(reg));
     return reg->nn.nearest_host(reg->ctx, q, n, stride_bytes, idx, sqd);
@@ -291,6 +299,7 @@ int mrgfe_ndt_evaluate(mrgfe_reg* reg, const float T[16], const double p[6], int
 {
     if (!reg || !reg->ndt || !T || !p || !score || !grad || !hess) { set_error("mrgfe_ndt_evaluate: needs an NDT registration and non-NULL arguments"); return MRGFE_ERR_INVALID; }
     if (!reg->has_target || !reg->has_source) { set_error("evaluate: target / source not set"); return MRGFE_ERR_STATE; }
+    MRGFE_LOCK(reg->ctx);
     float Tr[16];
     col2row(T, Tr);
     NdtEngine& e = *reg->ndt;
@@ -315,6 +324,7 @@ int mrgfe_ndt_grid(const mrgfe_reg* reg, int32_t min_b[3], int32_t max_b[3], int
 int mrgfe_ndt_leaves(mrgfe_reg* reg, int32_t* keys, int32_t* nr_points, double* mean3, double* icov9)
 {
     if (!reg || !reg->ndt || reg->ndt->n_targets() == 0) { set_error("mrgfe_ndt_leaves: no NDT target"); return MRGFE_ERR_STATE; }
+    MRGFE_LOCK(reg->ctx);
     return reg->ndt->read_leaves(0, keys, nr_points, mean3, icov9);
 }
 
@@ -337,6 +347,7 @@ int mrgfe_reg_kernel_stats(const mrgfe_reg* reg, int mode, double* ms, int64_t* 
 int mrgfe_distance_filter(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double near_thresh, double far_thresh, float* out, size_t* out_n)
 {
     if (!ctx || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_distance_filter: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);
     MRGFE_TRY(ctx->bind());
     return filter_distance(ctx, xyzi, n, stride, near_thresh, far_thresh, out, out_n);
 }
@@ -344,6 +355,7 @@ int mrgfe_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, 
 {
     if (!ctx || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_voxelgrid: NULL argument"); return MRGFE_ERR_INVALID; }
     if (!(leaf > 0)) { set_error("mrgfe_voxelgrid: leaf size must be > 0"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);
     MRGFE_TRY(ctx->bind());
     return filter_voxelgrid(ctx, xyzi, n, stride, leaf, min_pts, out, out_n, overflow);
 }
@@ -351,6 +363,7 @@ int mrgfe_radius_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t str
 {
     if (!ctx || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_radius_outlier: NULL argument"); return MRGFE_ERR_INVALID; }
     if (!(radius > 0)) { set_error("mrgfe_radius_outlier: radius must be > 0"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);
     MRGFE_TRY(ctx->bind());
     return filter_radius_outlier(ctx, xyzi, n, stride, radius, min_neighbors, out, out_n);
 }
@@ -358,12 +371,14 @@ int mrgfe_statistical_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_
 {
     if (!ctx || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_statistical_outlier: NULL argument"); return MRGFE_ERR_INVALID; }
     if (mean_k < 1 || mean_k > 63) { set_error("mrgfe_statistical_outlier: mean_k must be in [1, 63]"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);
     MRGFE_TRY(ctx->bind());
     return filter_statistical_outlier(ctx, xyzi, n, stride, mean_k, stddev_mul, out, out_n);
 }
 int mrgfe_calc_fitness_score(mrgfe_ctx* ctx, const float* cloud1, size_t n1, const float* cloud2, size_t n2, size_t stride, const double relpose[16], double max_range, double* out)
 {
     if (!ctx || !out || !relpose || (n1 && !cloud1) || (n2 && !cloud2)) { set_error("mrgfe_calc_fitness_score: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);
     MRGFE_TRY(ctx->bind());
     if (n1 == 0 || n2 == 0) { *out = DBL_MAX; return MRGFE_OK; }
     DevBuf &d1 = ctx->scratch[10], &d2 = ctx->scratch[11];
@@ -400,28 +415,35 @@ int mrgfe_batch_create(mrgfe_ctx* ctx, const mrgfe_reg_params* params, mrgfe_bat
 void mrgfe_batch_destroy(mrgfe_batch* b)
 {
     if (!b) return;
-    delete b->ndt;
+    {
+        MRGFE_LOCK(b->ctx);
+        delete b->ndt;
+    }
     delete b;
 }
 int mrgfe_batch_clear(mrgfe_batch* b)
 {
     if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(b->ctx);
     b->ndt->clear();
     return MRGFE_OK;
 }
 int mrgfe_batch_add_target(mrgfe_batch* b, const float* xyzi, size_t n, size_t stride)
 {
     if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(b->ctx);
     return b->ndt->add_target_host(xyzi, n, stride);
 }
 int mrgfe_batch_add_target_device(mrgfe_batch* b, const void* d, size_t n)
 {
     if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(b->ctx);
     return b->ndt->add_target_device(d, n);
 }
 int mrgfe_batch_add_pair(mrgfe_batch* b, int target, const float* xyzi, size_t n, size_t stride, const float guess[16])
 {
     if (!b || !guess) { set_error("NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(b->ctx);
     float g[16];
     col2row(guess, g);
     return b->ndt->add_pair_host(target, xyzi, n, stride, g);
@@ -429,6 +451,7 @@ int mrgfe_batch_add_pair(mrgfe_batch* b, int target, const float* xyzi, size_t n
 int mrgfe_batch_add_pair_device(mrgfe_batch* b, int target, const void* d, size_t n, const float guess[16])
 {
     if (!b || !guess) { set_error("NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(b->ctx);
     float g[16];
     col2row(guess, g);
     return b->ndt->add_pair_device(target, d, n, g);
@@ -436,6 +459,7 @@ int mrgfe_batch_add_pair_device(mrgfe_batch* b, int target, const void* d, size_
 int mrgfe_batch_set_guess(mrgfe_batch* b, int pair, const float guess[16])
 {
     if (!b || !guess) { set_error("NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(b->ctx);
     float g[16];
     col2row(guess, g);
     return b->ndt->set_guess(pair, g);
@@ -443,6 +467,7 @@ int mrgfe_batch_set_guess(mrgfe_batch* b, int pair, const float guess[16])
 int mrgfe_batch_build_targets(mrgfe_batch* b)
 {
     if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(b->ctx);
     return b->ndt->build_targets();
 }
 int mrgfe_batch_num_pairs(const mrgfe_batch* b) { return b ? b->ndt->n_pairs() : 0; }
@@ -450,6 +475,7 @@ int mrgfe_batch_num_pairs(const mrgfe_batch* b) { return b ? b->ndt->n_pairs() :
 int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_result* results)
 {
     if (!b || !results) { set_error("mrgfe_batch_align: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(b->ctx);
     NdtEngine& e = *b->ndt;
     MRGFE_TRY(e.align_all());
     const int P = e.n_pairs();
@@ -494,6 +520,7 @@ int mrgfe_batch_kernel_stats(const mrgfe_batch* b, int mode, double* ms, int64_t
 int mrgfe_dbg_sort_pairs(mrgfe_ctx* ctx, const uint32_t* keys, const uint32_t* vals, size_t n, int key_bits, uint32_t* out_keys, uint32_t* out_vals)
 {
     if (!ctx || (n && (!keys || !vals || !out_keys || !out_vals))) { set_error("mrgfe_dbg_sort_pairs: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);
     MRGFE_TRY(ctx->bind());
     if (n == 0) return MRGFE_OK;
     uint32_t  nn = static_cast<uint32_t>(n);
@@ -517,6 +544,7 @@ int mrgfe_dbg_sort_pairs(mrgfe_ctx* ctx, const uint32_t* keys, const uint32_t* v
 int mrgfe_dbg_exclusive_scan(mrgfe_ctx* ctx, const uint32_t* in, size_t n, uint32_t* out, uint32_t* total)
 {
     if (!ctx || !total || (n && (!in || !out))) { set_error("mrgfe_dbg_exclusive_scan: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);
     MRGFE_TRY(ctx->bind());
     uint32_t  nn = static_cast<uint32_t>(n);
     SliceTable tab;
@@ -538,6 +566,7 @@ int mrgfe_dbg_exclusive_scan(mrgfe_ctx* ctx, const uint32_t* in, size_t n, uint3
 int mrgfe_dbg_minmax(mrgfe_ctx* ctx, const float* xyzi, size_t n, float min3[3], float max3[3], uint32_t* n_finite)
 {
     if (!ctx || !min3 || !max3 || !n_finite || (n && !xyzi)) { set_error("mrgfe_dbg_minmax: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);
     MRGFE_TRY(ctx->bind());
     uint32_t  nn = static_cast<uint32_t>(n);
     SliceTable tab;

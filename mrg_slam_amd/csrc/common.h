@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -61,6 +62,10 @@ struct Arena {
 
 }  // namespace mrgfe
 
+// every extern "C" entry point that touches the GPU takes the context lock: handles of one context may be used from
+// several threads (the reference's odometry and loop-closure registrations live in different threads of one process)
+#define MRGFE_LOCK(ctxptr) std::lock_guard<std::recursive_mutex> _mrgfe_lock((ctxptr)->mu)
+
 struct mrgfe_ctx {
     int          device = 0;
     hipStream_t  stream = nullptr;
@@ -69,6 +74,7 @@ struct mrgfe_ctx {
     mrgfe::DevBuf scratch[12];                  // named by the algorithms that use them
     mrgfe::PinBuf pin[4];
     int          cu_count = 256;
+    std::recursive_mutex mu;                    // serialises API calls that share this context's stream / workspaces
     int          bind();                        // hipSetDevice(device)
 };
 

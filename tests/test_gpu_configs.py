@@ -1,0 +1,144 @@
+"""GPU: parity on workloads shaped like BASELINE.json's configs (synthetic scans, sizes the CPU oracle finishes in
+seconds): [0] VLP-16 NDT pair is test_gpu_ndt.test_align_on_street_scan_pair, [2] GICP scan-to-keyframe,
+[3] batched loop-closure candidates, [4] two robots: concurrent odometry streams + an inter-robot candidate batch."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # metres / radians (north_star)
+
+
+def _close(Ta, Tb):
+    from mrg_slam_amd import synth
+
+    return np.linalg.norm(Ta[:3, 3].astype(np.float64) - Tb[:3, 3]) <= TOL and synth.rotation_angle(Ta, Tb) <= TOL
+
+
+@pytest.fixture(scope="module")
+def street_scans():
+    from mrg_slam_amd import prefilter, synth
+
+    scene = synth.street_scene()
+    poses = synth.arc_trajectory(5)
+    scans = [prefilter(synth.synth_lidar(scene, poses[k], "VLP16", synth.BASE_SEED + k)) for k in range(5)]
+    return poses, scans
+
+
+def test_config3_gicp_scan_to_keyframe(street_scans):
+    """GICP_HIP == restated FAST_GICP on a keyframe + following scans, warm-started like the odometry component
+    (align(aligned, prev_trans), apps/scan_matching_odometry_component.cpp:265-266)."""
+    from mrg_slam_amd import GicpHip
+    from oracle import oracle as orc
+
+    poses, scans = street_scans
+    g = GicpHip(transformation_epsilon=0.1)
+    o = orc.FastGicp(transformation_epsilon=0.1, num_threads=8)
+    g.setInputTarget(scans[0])
+    o.setInputTarget(scans[0])
+    prev_g = prev_o = np.eye(4)
+    for k in (1, 2, 3):
+        g.setInputSource(scans[k])
+        o.setInputSource(scans[k])
+        g.align(prev_g)
+        o.align(prev_o)
+        Tg, To = g.getFinalTransformation(), o.getFinalTransformation()
+        assert _close(Tg, To), (k, Tg, To)
+        assert g.hasConverged() == o.hasConverged() and g.getFinalNumIteration() == o.getFinalNumIteration()
+        truth = np.linalg.inv(poses[0]) @ poses[k]
+        assert np.linalg.norm(Tg[:3, 3] - truth[:3, 3]) < 0.15
+        prev_g, prev_o = Tg, To
+
+
+def test_config4_batched_loop_closure_candidates():
+    """One new keyframe against many candidates (LoopDetector::matching, loop_detector.cpp:104,126-145): the batched engine
+    must give every candidate the oracle's transform / convergence / fitness and pick the oracle's best candidate."""
+    from mrg_slam_amd import BatchMatcher, loop_closure, prefilter, synth
+    from mrg_slam_amd.registration import result_matrix
+    from oracle import oracle as orc
+
+    scene = synth.loop_scene()
+    kf_poses = synth.loop_trajectory(64, 40.0)
+    new_id = 0
+    cand_ids = [k for k in range(1, 64) if np.linalg.norm(kf_poses[k][:2, 3] - kf_poses[new_id][:2, 3]) <= 15.0]
+    assert len(cand_ids) >= 6
+    clouds = {k: prefilter(synth.synth_lidar(scene, kf_poses[k], "VLP16", 4242 + k)) for k in [new_id] + cand_ids}
+    rng = np.random.default_rng(4242)
+    guesses = [synth.perturb_pose(np.linalg.inv(kf_poses[new_id]) @ kf_poses[k], rng, (0.5, 0.5, 0.1), (2.0, 2.0, 2.0)) for k in cand_ids]
+    bm = BatchMatcher(transformation_epsilon=0.1, maximum_iterations=64)
+    t = bm.add_target(clouds[new_id])
+    for k, g in zip(cand_ids, guesses):
+        bm.add_pair(t, clouds[k], g)
+    res = bm.align(fitness_max_range=float("inf"))
+    # sequential oracle loop, exactly as the reference runs it
+    o = orc.Ndt(transformation_epsilon=0.1, maximum_iterations=64, num_threads=8)
+    o.setInputTarget(clouds[new_id])
+    best_score, best = np.finfo(np.float64).max, None
+    for i, (k, g) in enumerate(zip(cand_ids, guesses)):
+        o.setInputSource(clouds[k])
+        o.align(g)
+        score = o.getFitnessScore(float("inf"))
+        assert _close(result_matrix(res[i]), o.getFinalTransformation()), i
+        assert bool(res[i]["converged"]) == o.hasConverged() and res[i]["iterations"] == o.getFinalNumIteration()
+        assert res[i]["fitness"] == pytest.approx(score, rel=1e-6)
+        if not o.hasConverged() or score > best_score:
+            continue
+        best_score, best = score, i
+    gbest, gscore = loop_closure.select_best(res)
+    assert gbest == best and gscore == pytest.approx(best_score, rel=1e-6)
+
+
+def test_config5_two_robots_concurrent_streams_and_inter_robot_batch(street_scans):
+    """Two odometry streams run concurrently from two threads on their own registration handles (one process per robot
+    in the reference, kitti_multirobot_processor.py:164-172; here two threads sharing one context), then an inter-robot
+    candidate batch. Results must equal the single-threaded oracle."""
+    from mrg_slam_amd import BatchMatcher, NdtHip, synth
+    from mrg_slam_amd.registration import result_matrix
+    from oracle import oracle as orc
+
+    poses, scans = street_scans
+    streams = {"robot_a": [0, 1, 2], "robot_b": [4, 3, 2]}  # b drives the street the other way
+    out, errs = {}, []
+
+    def run(name, ids):
+        try:
+            reg = NdtHip(transformation_epsilon=0.1)
+            reg.setInputTarget(scans[ids[0]])
+            prev, res = np.eye(4), []
+            for k in ids[1:]:
+                reg.setInputSource(scans[k])
+                reg.align(prev)
+                prev = reg.getFinalTransformation()
+                res.append(prev)
+            out[name] = res
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=run, args=kv) for kv in streams.items()]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for name, ids in streams.items():
+        o = orc.Ndt(transformation_epsilon=0.1, num_threads=4)
+        o.setInputTarget(scans[ids[0]])
+        prev = np.eye(4)
+        for j, k in enumerate(ids[1:]):
+            o.setInputSource(scans[k])
+            o.align(prev)
+            prev = o.getFinalTransformation()
+            assert _close(out[name][j], prev), (name, k)
+    # inter-robot loop closure batch: robot a's keyframe against robot b's scans
+    bm = BatchMatcher(transformation_epsilon=0.1)
+    t = bm.add_target(scans[0])
+    guesses = [np.linalg.inv(poses[0]) @ poses[k] for k in (2, 3, 4)]
+    for k, g in zip((2, 3, 4), guesses):
+        bm.add_pair(t, scans[k], synth.warm_guess(g, k))
+    res = bm.align(fitness_max_range=float("inf"))
+    o = orc.Ndt(transformation_epsilon=0.1, num_threads=4)
+    o.setInputTarget(scans[0])
+    for i, (k, g) in enumerate(zip((2, 3, 4), guesses)):
+        o.setInputSource(scans[k])
+        o.align(synth.warm_guess(g, k))
+        assert _close(result_matrix(res[i]), o.getFinalTransformation()), k
