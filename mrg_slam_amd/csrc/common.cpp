@@ -1,7 +1,10 @@
 // csrc/common.cpp — error reporting, device / pinned workspaces, context lifetime.
 #include "common.h"
 
+#include <algorithm>
+#include <condition_variable>
 #include <cstdlib>
+#include <thread>
 
 namespace mrgfe {
 
@@ -78,6 +81,86 @@ void Arena::release()
 {
     for (auto& c : chunks) (void)hipFree(c.p);
     chunks.clear();
+}
+
+namespace {
+class HostPool {
+   public:
+    HostPool()
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        int n = 0;  // off unless MRGFE_HOST_THREADS asks: on a 256-thread host the wake-ups cost more than they save (measured)
+        (void)hw;
+        if (const char* e = std::getenv("MRGFE_HOST_THREADS")) n = std::atoi(e) - 1;
+        n = n < 0 ? 0 : (n > 7 ? 7 : n);
+        for (int i = 0; i < n; ++i) workers_.emplace_back([this, i] { loop(i); });
+    }
+    ~HostPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+            ++epoch_;
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void run(int n, const std::function<void(int, int)>& body)
+    {
+        const int parts = static_cast<int>(workers_.size()) + 1;
+        const int chunk = (n + parts - 1) / parts;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            body_ = &body;
+            n_ = n;
+            chunk_ = chunk;
+            pending_ = static_cast<int>(workers_.size());
+            ++epoch_;
+        }
+        cv_.notify_all();
+        body(0, chunk < n ? chunk : n);  // the caller takes the first chunk
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [this] { return pending_ == 0; });
+        body_ = nullptr;
+    }
+    int size() const { return static_cast<int>(workers_.size()) + 1; }
+
+   private:
+    void loop(int id)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return epoch_ != seen; });
+            seen = epoch_;
+            if (stop_) return;
+            const std::function<void(int, int)>* body = body_;
+            const int b = (id + 1) * chunk_, e = std::min(n_, (id + 2) * chunk_);
+            lk.unlock();
+            if (body && b < e) (*body)(b, e);
+            lk.lock();
+            if (--pending_ == 0) done_cv_.notify_one();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(int, int)>* body_ = nullptr;
+    int n_ = 0, chunk_ = 0, pending_ = 0;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+};
+std::mutex g_pool_mu;  // one parallel region at a time (contexts on different GPUs share the pool)
+}  // namespace
+
+void host_parallel_for(int n, int min_serial, const std::function<void(int, int)>& body)
+{
+    if (n <= 0) return;
+    if (n < min_serial) { body(0, n); return; }
+    static HostPool pool;
+    if (pool.size() == 1) { body(0, n); return; }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    pool.run(n, body);
 }
 
 int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, void* d_dst, int pin_slot)

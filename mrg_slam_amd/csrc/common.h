@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -49,6 +50,10 @@ struct PinBuf {
     void   release();
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
+
+// persistent host worker threads for the per-pair controller steps of large batches (a 6x6 SVD solve and the line-search
+// bookkeeping per pair and round: ~3 us each, which adds up to the kernel time of a round once a batch has >100 pairs)
+void host_parallel_for(int n, int min_serial, const std::function<void(int, int)>& body);
 
 // bump allocator over a few large device chunks; pointers stay valid until reset()
 struct Arena {

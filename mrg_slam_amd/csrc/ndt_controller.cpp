@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -138,6 +139,20 @@ void matmul3f(const float a[9], const float b[9], float o[9])
 
 }  // namespace
 
+static bool spec_enabled()
+{
+    // Off by default: measured on MI355X, only ~40 % of the first trials end in computeHessian at the same pose, so the
+    // speculative f64 pass costs more GPU time than the host round trips it saves (7.4k -> 5.3k alignments/s at 32 pairs).
+    static const bool on = [] { const char* e = std::getenv("MRGFE_SPEC"); return e && e[0] == '1'; }();
+    return on;
+}
+
+static bool reuse_enabled()
+{
+    static const bool on = [] { const char* e = std::getenv("MRGFE_NO_REUSE"); return !(e && e[0] == '1'); }();
+    return on;
+}
+
 void NdtController::pose_to_matrix(const double p[6], float M[16])
 {
     float Rx[9], Ry[9], Rz[9], Rxy[9], R[9];
@@ -204,6 +219,7 @@ void NdtController::angle_tables(const double p[6], double j[8][3], double h[15]
 void NdtController::make_request(int mode, const double p[6])
 {
     req_.mode = mode;
+    req_.spec_hessian = false;
     std::memcpy(req_.T, final_, sizeof(final_));
     std::memcpy(req_.p, p, sizeof(double) * 6);
     angle_tables(p, req_.j_ang, req_.h_ang);
@@ -218,6 +234,10 @@ void NdtController::start(const NdtParams& prm, const float guess[16], uint32_t 
     converged_ = false;
     nr_iterations_ = 0;
     n_evals_ = 0;
+    n_reused_ = 0;
+    n_spec_used_ = 0;
+    cache_valid_ = false;
+    spec_valid_ = false;
     nb_sum_ = 0;
     trans_probability_ = 0;
     identity16(final_); identity16(transformation_); identity16(previous_);
@@ -255,10 +275,17 @@ void NdtController::store_result(const double r[44], bool with_score_grad, bool 
     }
     if (with_hessian)
         for (int k = 0; k < 36; ++k) H_[k] = r[7 + k];
-    nb_sum_ += n_src_ ? r[43] / static_cast<double>(n_src_) : 0.0;
+    const double nb = n_src_ ? r[43] / static_cast<double>(n_src_) : 0.0;
+    nb_sum_ += nb;
+    // remember the pose of evaluations whose transform was built from the pose vector (line-search trials)
+    if (with_score_grad && phase_ != INIT) {
+        std::memcpy(cache_p_, req_.p, sizeof(cache_p_));
+        cache_nb_ = nb;
+        cache_valid_ = true;
+    }
 }
 
-void NdtController::on_result(const double r[44])
+void NdtController::on_result(const double r[44], const double* r_spec)
 {
     switch (phase_) {
         case INIT:
@@ -267,23 +294,19 @@ void NdtController::on_result(const double r[44])
             break;
         case LS_FIRST:
             store_result(r, true, true);
+            spec_valid_ = false;
+            if (r_spec && req_.spec_hessian) {
+                for (int k = 0; k < 36; ++k) H_spec_[k] = r_spec[7 + k];
+                std::memcpy(spec_p_, req_.p, sizeof(spec_p_));
+                spec_nb_ = n_src_ ? r_spec[43] / static_cast<double>(n_src_) : 0.0;
+                spec_valid_ = true;
+            }
             ls_after_eval();
             ls_continue_or_finish();
             break;
         case LS_ITER:
             store_result(r, true, false);
-            ls_after_eval();
-            if (open_interval_ && (psi_t_ <= 0 && d_psi_t_ >= 0)) {
-                open_interval_ = false;
-                f_l_ = f_l_ + phi_0_ - kMu * d_phi_0_ * a_l_;
-                g_l_ = g_l_ + kMu * d_phi_0_;
-                f_u_ = f_u_ + phi_0_ - kMu * d_phi_0_ * a_u_;
-                g_u_ = g_u_ + kMu * d_phi_0_;
-            }
-            if (open_interval_) interval_converged_ = update_interval(a_l_, f_l_, g_l_, a_u_, f_u_, g_u_, a_t_, psi_t_, d_psi_t_);
-            else                interval_converged_ = update_interval(a_l_, f_l_, g_l_, a_u_, f_u_, g_u_, a_t_, phi_t_, d_phi_t_);
-            step_iterations_++;
-            ls_continue_or_finish();
+            ls_iter_update();
             break;
         case LS_HESS:
             store_result(r, false, true);
@@ -340,6 +363,9 @@ void NdtController::newton_step()
     for (int k = 0; k < 6; ++k) x_t_[k] = x_[k] + dir_[k] * a_t_;
     pose_to_matrix(x_t_, final_);
     make_request(0, x_t_);
+    // When the first trial is rejected the search almost always ends on a repeated (clamped) step and the reference then
+    // calls computeHessian at that same pose: ask for that f64 Hessian in the same round (dropped if it is not needed).
+    req_.spec_hessian = spec_enabled();
     phase_ = LS_FIRST;
 }
 
@@ -353,6 +379,23 @@ void NdtController::ls_after_eval()
     d_psi_t_ = dpsi_mt(d_phi_t_, d_phi_0_, kMu);
 }
 
+// bookkeeping of one line-search trial after its score / gradient are known (body of the while loop of computeStepLengthMT)
+void NdtController::ls_iter_update()
+{
+    ls_after_eval();
+    if (open_interval_ && (psi_t_ <= 0 && d_psi_t_ >= 0)) {
+        open_interval_ = false;
+        f_l_ = f_l_ + phi_0_ - kMu * d_phi_0_ * a_l_;
+        g_l_ = g_l_ + kMu * d_phi_0_;
+        f_u_ = f_u_ + phi_0_ - kMu * d_phi_0_ * a_u_;
+        g_u_ = g_u_ + kMu * d_phi_0_;
+    }
+    if (open_interval_) interval_converged_ = update_interval(a_l_, f_l_, g_l_, a_u_, f_u_, g_u_, a_t_, psi_t_, d_psi_t_);
+    else                interval_converged_ = update_interval(a_l_, f_l_, g_l_, a_u_, f_u_, g_u_, a_t_, phi_t_, d_phi_t_);
+    step_iterations_++;
+    ls_continue_or_finish();
+}
+
 void NdtController::ls_continue_or_finish()
 {
     if (!interval_converged_ && step_iterations_ < kMaxStepIterations && !(psi_t_ <= 0 && d_phi_t_ <= -kNu * d_phi_0_)) {
@@ -362,11 +405,30 @@ void NdtController::ls_continue_or_finish()
         a_t_ = std::max(a_t_, prm_.trans_eps / 2);
         for (int k = 0; k < 6; ++k) x_t_[k] = x_[k] + dir_[k] * a_t_;
         pose_to_matrix(x_t_, final_);
+        if (reuse_enabled() && cache_valid_ && std::memcmp(x_t_, cache_p_, sizeof(cache_p_)) == 0) {
+            // The clamped trial step often repeats the previous one (a_t pinned at step_min / step_max): same pose vector
+            // -> same float transform -> the evaluation would reproduce score_ / g_ bit for bit.  The reference
+            // recomputes it; here the held values are reused and no GPU round is spent (the evaluation is still counted).
+            ++n_evals_;
+            ++n_reused_;
+            nb_sum_ += cache_nb_;
+            ls_iter_update();
+            return;
+        }
         make_request(1, x_t_);
         phase_ = LS_ITER;
         return;
     }
     if (step_iterations_) {
+        if (spec_valid_ && std::memcmp(x_t_, spec_p_, sizeof(spec_p_)) == 0) {
+            // computeHessian at the pose whose f64 Hessian was evaluated speculatively with the first trial
+            for (int k = 0; k < 36; ++k) H_[k] = H_spec_[k];
+            ++n_evals_;
+            ++n_spec_used_;
+            nb_sum_ += spec_nb_;
+            finish_line_search(a_t_);
+            return;
+        }
         make_request(2, x_t_);  // computeHessian at x_t (final_ already holds its matrix)
         phase_ = LS_HESS;
         return;

@@ -22,6 +22,7 @@ struct NdtParams {
 // request for one derivative evaluation (what NdtEvalDev carries to the device)
 struct NdtRequest {
     int    mode;          // 0 score+grad+hess, 1 score+grad, 2 hessian only (double)
+    bool   spec_hessian;  // with mode 0: also evaluate the f64 Hessian (computeHessian) at the same pose in this round
     float  T[16];         // row-major final_transformation_
     double p[6];          // pose vector the angular derivative tables are built for
     double j_ang[8][3];
@@ -36,7 +37,8 @@ class NdtController {
     bool done() const { return phase_ == DONE || phase_ == IDLE; }
     const NdtRequest& request() const { return req_; }
     // reduced sums of the requested evaluation: r[0] score, r[1..6] gradient, r[7..42] Hessian (row-major), r[43] neighbours
-    void on_result(const double r[44]);
+    // r_spec: the f64 Hessian record when the request asked for it (spec_hessian), else nullptr
+    void on_result(const double r[44], const double* r_spec = nullptr);
     // finish immediately without target (no usable grid): align() leaves final = guess semantics of an empty run
     void abort_no_target();
 
@@ -44,7 +46,9 @@ class NdtController {
     const float* final_transformation() const { return final_; }  // row-major
     bool   converged() const { return converged_; }
     int    iterations() const { return nr_iterations_; }
-    int    evaluations() const { return n_evals_; }
+    int    evaluations() const { return n_evals_; }          // derivative evaluations of the reference's control flow
+    int    reused_evaluations() const { return n_reused_; }
+    int    speculative_hessians_used() const { return n_spec_used_; }  // of those, served from the previous identical trial
     double trans_probability() const { return trans_probability_; }
     const double* hessian() const { return H_; }  // 6x6 row-major, symmetric
     double neighbours_sum() const { return nb_sum_; }
@@ -64,7 +68,12 @@ class NdtController {
     float  final_[16];
     float  transformation_[16], previous_[16];
     bool   converged_ = false;
-    int    nr_iterations_ = 0, n_evals_ = 0;
+    int    nr_iterations_ = 0, n_evals_ = 0, n_reused_ = 0;
+    double cache_p_[6], cache_nb_ = 0;
+    bool   cache_valid_ = false;
+    double H_spec_[36], spec_p_[6], spec_nb_ = 0;  // speculative f64 Hessian of the last first trial and its pose
+    bool   spec_valid_ = false;
+    int    n_spec_used_ = 0;
     double trans_probability_ = 0, nb_sum_ = 0;
     double gauss_d1_ = 0, gauss_d2_ = 0, gauss_d3_ = 0;
     double p_[6], score_ = 0, g_[6], H_[36];
@@ -78,6 +87,7 @@ class NdtController {
     void store_result(const double r[44], bool with_score_grad, bool with_hessian);
     void newton_step();
     void ls_after_eval();
+    void ls_iter_update();
     void ls_continue_or_finish();
     void finish_line_search(double a_t);
 };

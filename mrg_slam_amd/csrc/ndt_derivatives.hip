@@ -140,12 +140,17 @@ __device__ __forceinline__ void pair_double(Accum& acc, const double mean[3], co
 // (3 waves/SIMD, ~44 B/lane of spill) is 12 % faster on MI355X, 128 VGPRs (4 waves) spills too much (measured).
 template <int MODE, int NNB>
 __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? 3 : 2)) void ndt_derivatives_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
-                                                               const NdtEvalDev* __restrict__ evals, double* __restrict__ partials, int ppt)
+                                                               const NdtEvalDev* __restrict__ evals, double* __restrict__ partials, int ppt,
+                                                               uint32_t spec_part_base)
 {
     const NdtPairDev pr = pairs[blockIdx.y];
     if (blockIdx.x >= pr.nblk) return;
     const NdtEvalDev& ev = evals[blockIdx.y];
-    if (!ev.active || ev.mode != MODE) return;
+    // the f64 Hessian variant also serves the speculative requests attached to mode-0 evaluations; their partial records
+    // go to the second half of the partial buffer
+    const bool spec = (MODE == 2) && ev.mode == 0 && ev.spec != 0;
+    if (!ev.active || (ev.mode != MODE && !spec)) return;
+    const uint32_t part_off = pr.part_off + (spec ? spec_part_base : 0u);
     const NdtGridDev& g = grids[pr.grid];
 
     using StageT = typename std::conditional<MODE == 2, double, float>::type;  // precision of the staged point terms
@@ -310,16 +315,20 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? 3 : 2)) void ndt_de
         const bool skip = k >= kNdtAccum || (MODE == 1 && k >= 7 && k < kNdtNbIndex) || (MODE == 2 && k < 7);
         double     r = 0.0;
         if (!skip) r = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
-        partials[(size_t)(pr.part_off + blockIdx.x) * kNdtPartialStride + k] = r;
+        partials[(size_t)(part_off + blockIdx.x) * kNdtPartialStride + k] = r;
     }
 }
 
 // fixed-order sum of the block partials of every active pair: 4 interleaved slices, then slice 0..3 in order
 __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __restrict__ pairs, const NdtEvalDev* __restrict__ evals, const double* __restrict__ partials,
-                                                          double* __restrict__ results)
+                                                          double* __restrict__ results, uint32_t spec_part_base, uint32_t spec_result_base)
 {
-    const NdtPairDev pr = pairs[blockIdx.x];
-    if (!evals[blockIdx.x].active) return;
+    // blockIdx.y == 1: the speculative f64 Hessian records of the pairs that asked for them
+    const bool spec = blockIdx.y == 1;
+    NdtPairDev pr = pairs[blockIdx.x];
+    const NdtEvalDev& ev = evals[blockIdx.x];
+    if (!ev.active || (spec && !(ev.mode == 0 && ev.spec != 0))) return;
+    if (spec) { pr.part_off += spec_part_base; results += (size_t)spec_result_base * kNdtPartialStride; }
     __shared__ double s[4][kNdtPartialStride];
     const int k = threadIdx.x & 63, slice = threadIdx.x >> 6;
     if (k < kNdtPartialStride) {
@@ -350,30 +359,32 @@ __global__ __launch_bounds__(256) void transform_cloud_kernel(const float4* __re
 }
 
 template <int MODE>
-static void launch_mode(mrgfe_ctx* ctx, int nnb, dim3 grid, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, double* d_partials, int ppt)
+static void launch_mode(mrgfe_ctx* ctx, int nnb, dim3 grid, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, double* d_partials, int ppt,
+                        uint32_t spec_part_base)
 {
-    if (nnb == 7)       hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 7>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_partials, ppt);
-    else if (nnb == 1)  hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 1>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_partials, ppt);
-    else                hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 27>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_partials, ppt);
+    if (nnb == 7)       hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 7>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_partials, ppt, spec_part_base);
+    else if (nnb == 1)  hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 1>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_partials, ppt, spec_part_base);
+    else                hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 27>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_partials, ppt, spec_part_base);
 }
 
 int ndt_launch_derivatives(mrgfe_ctx* ctx, int mode, int search, uint32_t max_nblk, int npairs, const NdtGridDev* d_grids, const NdtPairDev* d_pairs,
-                           const NdtEvalDev* d_evals, double* d_partials, int ppt)
+                           const NdtEvalDev* d_evals, double* d_partials, int ppt, uint32_t spec_part_base)
 {
     if (npairs == 0 || max_nblk == 0) return MRGFE_OK;
     const int nnb = (search == MRGFE_DIRECT7) ? 7 : (search == MRGFE_DIRECT1 ? 1 : 27);
     dim3 grid(max_nblk, npairs);
-    if (mode == 0)      launch_mode<0>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_partials, ppt);
-    else if (mode == 1) launch_mode<1>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_partials, ppt);
-    else                launch_mode<2>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_partials, ppt);
+    if (mode == 0)      launch_mode<0>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_partials, ppt, spec_part_base);
+    else if (mode == 1) launch_mode<1>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_partials, ppt, spec_part_base);
+    else                launch_mode<2>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_partials, ppt, spec_part_base);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }
 
-int ndt_launch_reduce(mrgfe_ctx* ctx, int npairs, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const double* d_partials, double* d_results)
+int ndt_launch_reduce(mrgfe_ctx* ctx, int npairs, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const double* d_partials, double* d_results, bool with_spec,
+                      uint32_t spec_part_base, uint32_t spec_result_base)
 {
     if (npairs == 0) return MRGFE_OK;
-    hipLaunchKernelGGL(ndt_reduce_kernel, dim3(npairs), dim3(256), 0, ctx->stream, d_pairs, d_evals, d_partials, d_results);
+    hipLaunchKernelGGL(ndt_reduce_kernel, dim3(npairs, with_spec ? 2 : 1), dim3(256), 0, ctx->stream, d_pairs, d_evals, d_partials, d_results, spec_part_base, spec_result_base);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }

@@ -348,10 +348,11 @@ int NdtEngine::upload_pairs()
     }
     MRGFE_TRY(d_pairs_.ensure(sizeof(NdtPairDev) * std::max(P, 1)));
     MRGFE_TRY(d_evals_.ensure(sizeof(NdtEvalDev) * std::max(P, 1)));
-    MRGFE_TRY(d_partials_.ensure(sizeof(double) * kNdtPartialStride * std::max<uint32_t>(part, 1)));
-    MRGFE_TRY(d_results_.ensure(sizeof(double) * kNdtPartialStride * std::max(P, 1)));
+    total_part_blocks_ = part;
+    MRGFE_TRY(d_partials_.ensure(sizeof(double) * kNdtPartialStride * 2 * std::max<uint32_t>(part, 1)));  // second half: speculative Hessians
+    MRGFE_TRY(d_results_.ensure(sizeof(double) * kNdtPartialStride * 2 * std::max(P, 1)));
     MRGFE_TRY(h_evals_.ensure(sizeof(NdtEvalDev) * std::max(P, 1)));
-    MRGFE_TRY(h_results_.ensure(sizeof(double) * kNdtPartialStride * std::max(P, 1)));
+    MRGFE_TRY(h_results_.ensure(sizeof(double) * kNdtPartialStride * 2 * std::max(P, 1)));
     if (P) MRGFE_HIP_CHECK(hipMemcpyAsync(d_pairs_.p, h_pairs_.data(), sizeof(NdtPairDev) * P, hipMemcpyHostToDevice, ctx_->stream));
     MRGFE_HIP_CHECK(hipStreamSynchronize(ctx_->stream));
     pairs_dirty_ = false;
@@ -368,7 +369,7 @@ static void fill_eval(NdtEvalDev& e, const NdtRequest& r, const NdtController& c
     e.mode = r.mode;
     e.active = active ? 1 : 0;
     e.search = search;
-    e.pad = 0;
+    e.spec = r.spec_hessian ? 1 : 0;
 }
 
 // ---- rounds --------------------------------------------------------------------------------------------------------
@@ -384,11 +385,19 @@ int NdtEngine::launch_group(RoundGroup& g)
     NdtEvalDev* he = h_evals_.as<NdtEvalDev>();
     g.modes[0] = g.modes[1] = g.modes[2] = false;
     int active = 0;
+    host_parallel_for(g.count, 48, [&](int b, int e) {
+        for (int i = g.first + b; i < g.first + e; ++i) {
+            NdtController& c = pairs_[i].ctl;
+            if (c.done()) he[i].active = 0;
+            else          fill_eval(he[i], c.request(), c, prm_.search, true);
+        }
+    });
+    g.any_spec = false;
     for (int i = g.first; i < g.first + g.count; ++i) {
-        NdtController& c = pairs_[i].ctl;
-        if (c.done()) { he[i].active = 0; continue; }
-        fill_eval(he[i], c.request(), c, prm_.search, true);
+        const NdtController& c = pairs_[i].ctl;
+        if (c.done()) continue;
         g.modes[c.request().mode] = true;
+        if (c.request().mode == 0 && c.request().spec_hessian) { g.modes[2] = true; g.any_spec = true; }
         ++active;
     }
     g.inflight = false;
@@ -402,11 +411,15 @@ int NdtEngine::launch_group(RoundGroup& g)
     for (int m = 0; m < 3; ++m)
         if (g.modes[m]) {
             MRGFE_HIP_CHECK(hipEventRecord(g.ev[m][0], st));
-            MRGFE_TRY(ndt_launch_derivatives(ctx_, m, prm_.search, g.max_nblk, g.count, d_grids_.as<NdtGridDev>(), d_pr, d_ev, d_partials_.as<double>(), ppt_));
+            MRGFE_TRY(ndt_launch_derivatives(ctx_, m, prm_.search, g.max_nblk, g.count, d_grids_.as<NdtGridDev>(), d_pr, d_ev, d_partials_.as<double>(), ppt_, total_part_blocks_));
             MRGFE_HIP_CHECK(hipEventRecord(g.ev[m][1], st));
         }
-    MRGFE_TRY(ndt_launch_reduce(ctx_, g.count, d_pr, d_ev, d_partials_.as<double>(), d_res));
+    const uint32_t P = static_cast<uint32_t>(n_pairs());
+    MRGFE_TRY(ndt_launch_reduce(ctx_, g.count, d_pr, d_ev, d_partials_.as<double>(), d_res, g.any_spec, total_part_blocks_, P));
     MRGFE_HIP_CHECK(hipMemcpyAsync(h_results_.as<double>() + size_t(g.first) * kNdtPartialStride, d_res, sizeof(double) * kNdtPartialStride * g.count, hipMemcpyDeviceToHost, st));
+    if (g.any_spec)
+        MRGFE_HIP_CHECK(hipMemcpyAsync(h_results_.as<double>() + size_t(P + g.first) * kNdtPartialStride, d_res + size_t(P) * kNdtPartialStride,
+                                       sizeof(double) * kNdtPartialStride * g.count, hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipEventRecord(g.done, st));
     g.inflight = true;
     return MRGFE_OK;
@@ -426,13 +439,24 @@ int NdtEngine::finish_group(RoundGroup& g)
     const double* hr = h_results_.as<double>();
     const int probes = prm_.search == MRGFE_DIRECT7 ? 7 : (prm_.search == MRGFE_DIRECT1 ? 1 : 27);
     for (int i = g.first; i < g.first + g.count; ++i) {
-        NdtController& c = pairs_[i].ctl;
+        const NdtController& c = pairs_[i].ctl;
         if (c.done()) continue;
         const double* r = hr + size_t(i) * kNdtPartialStride;
         // SURVEY.md §8(d) byte model: point (16) + probes (8 each) + 48 per valid neighbour voxel
-        mode_alg_bytes[c.request().mode] += double(pairs_[i].n) * (16.0 + 8.0 * probes) + r[kNdtNbIndex] * 48.0;
-        c.on_result(r);
+        const double bytes = double(pairs_[i].n) * (16.0 + 8.0 * probes) + r[kNdtNbIndex] * 48.0;
+        mode_alg_bytes[c.request().mode] += bytes;
+        if (c.request().mode == 0 && c.request().spec_hessian) mode_alg_bytes[2] += bytes;  // the speculative f64 pass reads the same data
     }
+    const size_t spec_base = size_t(n_pairs()) * kNdtPartialStride;
+    // controller steps are independent per pair: spread them over the host worker threads for large batches
+    host_parallel_for(g.count, 48, [&](int b, int e) {
+        for (int i = g.first + b; i < g.first + e; ++i) {
+            NdtController& c = pairs_[i].ctl;
+            if (c.done()) continue;
+            const bool spec = c.request().mode == 0 && c.request().spec_hessian;
+            c.on_result(hr + size_t(i) * kNdtPartialStride, spec ? hr + spec_base + size_t(i) * kNdtPartialStride : nullptr);
+        }
+    });
     return MRGFE_OK;
 }
 
@@ -514,8 +538,8 @@ int NdtEngine::evaluate(int pair, const float T[16], const double p[6], int mode
     hipStream_t st = ctx_->stream;
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));
     MRGFE_TRY(ndt_launch_derivatives(ctx_, mode, prm_.search, max_nblk_, P, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(),
-                                     d_partials_.as<double>(), ppt_));
-    MRGFE_TRY(ndt_launch_reduce(ctx_, P, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_partials_.as<double>(), d_results_.as<double>()));
+                                     d_partials_.as<double>(), ppt_, total_part_blocks_));
+    MRGFE_TRY(ndt_launch_reduce(ctx_, P, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_partials_.as<double>(), d_results_.as<double>(), false, 0, 0));
     MRGFE_HIP_CHECK(hipMemcpyAsync(h_results_.p, d_results_.p, sizeof(double) * kNdtPartialStride * P, hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
     const double* res = h_results_.as<double>() + size_t(pair) * kNdtPartialStride;

@@ -91,6 +91,7 @@ class NdtEngine {
     bool   force_hash_ = false;
     int    ppt_ = 1;
     uint32_t max_nblk_ = 0;
+    uint32_t total_part_blocks_ = 0;
     std::vector<NdtPairDev> h_pairs_;
     // per-target arrays kept for read_leaves
     struct LeafArrays { int32_t* keys; int32_t* nr_points; NdtLeafRec* leaves; double* icov64; };
@@ -102,6 +103,7 @@ class NdtEngine {
         uint32_t   max_nblk = 0;
         bool       inflight = false;
         bool       modes[3] = {false, false, false};
+        bool       any_spec = false;
         hipEvent_t done = nullptr;
         hipEvent_t ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     };

@@ -80,7 +80,7 @@ struct NdtEvalDev {
     int32_t  mode;         // 0: score+grad+hess (float path), 1: score+grad, 2: hessian only (double path)
     int32_t  active;       // 0: this pair is finished or waiting, its workgroups exit immediately
     int32_t  search;       // mrgfe_ndt_search
-    int32_t  pad;
+    int32_t  spec;         // 1 with mode 0: also run the f64 Hessian pass at this pose (speculative computeHessian)
 };
 
 // block partial / final result of one evaluation: score, gradient(6), full 6x6 Hessian(36, row-major), neighbour count.
