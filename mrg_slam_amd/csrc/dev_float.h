@@ -14,6 +14,21 @@ __device__ __forceinline__ float dot3f(float a0, float b0, float a1, float b1, f
     return s + p2;
 }
 
+// NDT three-term products, accumulated left to right with fused multiply-adds: s = a0*b0; s = fma(a1,b1,s); s = fma(a2,b2,s).
+// The CPU oracle runs the same sequence (oracle/ndt.cpp dot3f<true>): results are bit-identical.
+__device__ __forceinline__ float fdot3f(float a0, float b0, float a1, float b1, float a2, float b2)
+{
+#pragma clang fp contract(off)
+    const float s0 = a0 * b0;
+    return __builtin_fmaf(a2, b2, __builtin_fmaf(a1, b1, s0));
+}
+__device__ __forceinline__ double fdot3d(double a0, double b0, double a1, double b1, double a2, double b2)
+{
+#pragma clang fp contract(off)
+    const double s0 = a0 * b0;
+    return __builtin_fma(a2, b2, __builtin_fma(a1, b1, s0));
+}
+
 // pcl::transformPointCloud float path (pcl::detail::Transformer<float>::se3): x' = m0*x + (m1*y + (m2*z + m3)).
 // T: row-major 3x4.
 __device__ __forceinline__ void transform_point(const float* __restrict__ T, float x, float y, float z, float& ox, float& oy, float& oz)

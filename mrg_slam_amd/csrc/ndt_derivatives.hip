@@ -47,8 +47,8 @@ __device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, co
     const float C[3][3] = {{c00, c01, c02}, {c01, c11, c12}, {c02, c12, c22}};
     float qC[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) qC[c] = dot3f(q[0], C[0][c], q[1], C[1][c], q[2], C[2][c]);
-    const float qCq = dot3f(q[0], qC[0], q[1], qC[1], q[2], qC[2]);
+    for (int c = 0; c < 3; ++c) qC[c] = fdot3f(q[0], C[0][c], q[1], C[1][c], q[2], C[2][c]);
+    const float qCq = fdot3f(q[0], qC[0], q[1], qC[1], q[2], qC[2]);
     const float arg0 = -gauss_d2f * qCq;
     const float arg = arg0 * 0.5f;
     float e = static_cast<float>(exp(static_cast<double>(arg)));
@@ -61,13 +61,13 @@ __device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, co
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         CJ[r][0] = C[r][0]; CJ[r][1] = C[r][1]; CJ[r][2] = C[r][2];
-        CJ[r][3] = dot3f(C[r][0], J3[0], C[r][1], J3[1], C[r][2], J3[2]);
-        CJ[r][4] = dot3f(C[r][0], J4[0], C[r][1], J4[1], C[r][2], J4[2]);
-        CJ[r][5] = dot3f(C[r][0], J5[0], C[r][1], J5[1], C[r][2], J5[2]);
+        CJ[r][3] = fdot3f(C[r][0], J3[0], C[r][1], J3[1], C[r][2], J3[2]);
+        CJ[r][4] = fdot3f(C[r][0], J4[0], C[r][1], J4[1], C[r][2], J4[2]);
+        CJ[r][5] = fdot3f(C[r][0], J5[0], C[r][1], J5[1], C[r][2], J5[2]);
     }
     float qCJ[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) qCJ[c] = dot3f(q[0], CJ[0][c], q[1], CJ[1][c], q[2], CJ[2][c]);
+    for (int c = 0; c < 6; ++c) qCJ[c] = fdot3f(q[0], CJ[0][c], q[1], CJ[1][c], q[2], CJ[2][c]);
 #pragma unroll
     for (int c = 0; c < 6; ++c) { const float t = e * qCJ[c]; acc.g[c] += static_cast<double>(t); }
     acc.score += static_cast<double>(score_inc);
@@ -81,16 +81,15 @@ __device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, co
             // point_gradient4_colj . c_inv4_x_point_gradient4_col_i  == J(:,j) . CJ(:,i)
             float jtcj;
             if (j < 3) jtcj = CJ[j][i];
-            else       jtcj = dot3f(Jc[j][0], CJ[0][i], Jc[j][1], CJ[1][i], Jc[j][2], CJ[2][i]);
+            else       jtcj = fdot3f(Jc[j][0], CJ[0][i], Jc[j][1], CJ[1][i], Jc[j][2], CJ[2][i]);
             float qch = 0.0f;
             if (i >= 3 && j >= 3) {
                 const int lo = i < j ? i : j, hi = i < j ? j : i;
                 const int ph = (lo == 3) ? (hi - 3) : (lo == 4 ? (hi - 4 + 3) : 5);
-                qch = dot3f(qC[0], PH[ph][0], qC[1], PH[ph][1], qC[2], PH[ph][2]);
+                qch = fdot3f(qC[0], PH[ph][0], qC[1], PH[ph][1], qC[2], PH[ph][2]);
             }
             const float t0 = -gauss_d2f * qCJ[i];
-            const float t1 = t0 * qCJ[j];
-            const float t2 = t1 + qch;
+            const float t2 = __builtin_fmaf(t0, qCJ[j], qch);
             const float t3 = t2 + jtcj;
             const float t4 = e * t3;
             acc.H[i * 6 + j] += static_cast<double>(t4);
@@ -102,19 +101,20 @@ __device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, co
 __device__ __forceinline__ void pair_double(Accum& acc, const double mean[3], const double* __restrict__ C, const float xt[3], const double (&J)[3][6],
                                             const double (&PH)[6][3], double gauss_d1, double gauss_d2)
 {
+#pragma clang fp contract(off)
     const double q[3] = {static_cast<double>(xt[0]) - mean[0], static_cast<double>(xt[1]) - mean[1], static_cast<double>(xt[2]) - mean[2]};
     double Cq[3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) Cq[r] = C[r * 3 + 0] * q[0] + C[r * 3 + 1] * q[1] + C[r * 3 + 2] * q[2];
-    double e = gauss_d2 * exp(-gauss_d2 * (q[0] * Cq[0] + q[1] * Cq[1] + q[2] * Cq[2]) / 2);
+    for (int r = 0; r < 3; ++r) Cq[r] = fdot3d(C[r * 3 + 0], q[0], C[r * 3 + 1], q[1], C[r * 3 + 2], q[2]);
+    double e = gauss_d2 * exp(-gauss_d2 * fdot3d(q[0], Cq[0], q[1], Cq[1], q[2], Cq[2]) / 2);
     if (e > 1 || e < 0 || e != e) return;
     e *= gauss_d1;
     double CJ[3][6], qCJ[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) CJ[r][c] = C[r * 3 + 0] * J[0][c] + C[r * 3 + 1] * J[1][c] + C[r * 3 + 2] * J[2][c];
-        qCJ[c] = q[0] * CJ[0][c] + q[1] * CJ[1][c] + q[2] * CJ[2][c];
+        for (int r = 0; r < 3; ++r) CJ[r][c] = fdot3d(C[r * 3 + 0], J[0][c], C[r * 3 + 1], J[1][c], C[r * 3 + 2], J[2][c]);
+        qCJ[c] = fdot3d(q[0], CJ[0][c], q[1], CJ[1][c], q[2], CJ[2][c]);
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -126,11 +126,12 @@ __device__ __forceinline__ void pair_double(Accum& acc, const double mean[3], co
                 const int ph = (lo == 3) ? (hi - 3) : (lo == 4 ? (hi - 4 + 3) : 5);
                 double CH[3];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) CH[r] = C[r * 3 + 0] * PH[ph][0] + C[r * 3 + 1] * PH[ph][1] + C[r * 3 + 2] * PH[ph][2];
-                qch = q[0] * CH[0] + q[1] * CH[1] + q[2] * CH[2];
+                for (int r = 0; r < 3; ++r) CH[r] = fdot3d(C[r * 3 + 0], PH[ph][0], C[r * 3 + 1], PH[ph][1], C[r * 3 + 2], PH[ph][2]);
+                qch = fdot3d(q[0], CH[0], q[1], CH[1], q[2], CH[2]);
             }
-            const double jtcj = J[0][j] * CJ[0][i] + J[1][j] * CJ[1][i] + J[2][j] * CJ[2][i];
-            acc.H[i * 6 + j] += e * (-gauss_d2 * qCJ[i] * qCJ[j] + qch + jtcj);
+            const double jtcj = fdot3d(J[0][j], CJ[0][i], J[1][j], CJ[1][i], J[2][j], CJ[2][i]);
+            const double t0 = -gauss_d2 * qCJ[i];
+            acc.H[i * 6 + j] = __builtin_fma(e, __builtin_fma(t0, qCJ[j], qch) + jtcj, acc.H[i * 6 + j]);
         }
     }
 }
@@ -229,18 +230,18 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? 3 : 2)) void ndt_de
                 if (MODE != 2) {
                     // computePointDerivatives, float form: x_j_ang = j_ang * x, x_h_ang = h_ang * x
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) s_xj[r][threadIdx.x] = dot3f(s_ja[r][0], p.x, s_ja[r][1], p.y, s_ja[r][2], p.z);
+                    for (int r = 0; r < 8; ++r) s_xj[r][threadIdx.x] = fdot3f(s_ja[r][0], p.x, s_ja[r][1], p.y, s_ja[r][2], p.z);
                     if (MODE == 0) {
 #pragma unroll
-                        for (int r = 0; r < 15; ++r) s_xh[r][threadIdx.x] = dot3f(s_ha[r][0], p.x, s_ha[r][1], p.y, s_ha[r][2], p.z);
+                        for (int r = 0; r < 15; ++r) s_xh[r][threadIdx.x] = fdot3f(s_ha[r][0], p.x, s_ha[r][1], p.y, s_ha[r][2], p.z);
                     }
                 } else {
                     // computePointDerivatives, double form
                     const double x[3] = {p.x, p.y, p.z};
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) s_xj[r][threadIdx.x] = x[0] * ev.j_ang_d[r][0] + x[1] * ev.j_ang_d[r][1] + x[2] * ev.j_ang_d[r][2];
+                    for (int r = 0; r < 8; ++r) s_xj[r][threadIdx.x] = fdot3d(x[0], ev.j_ang_d[r][0], x[1], ev.j_ang_d[r][1], x[2], ev.j_ang_d[r][2]);
 #pragma unroll
-                    for (int r = 0; r < 15; ++r) s_xh[r][threadIdx.x] = x[0] * ev.h_ang_d[r][0] + x[1] * ev.h_ang_d[r][1] + x[2] * ev.h_ang_d[r][2];
+                    for (int r = 0; r < 15; ++r) s_xh[r][threadIdx.x] = fdot3d(x[0], ev.h_ang_d[r][0], x[1], ev.h_ang_d[r][1], x[2], ev.h_ang_d[r][2]);
                 }
             }
         }

@@ -242,14 +242,38 @@ void Ndt::transform_cloud(const float T[16])
     }
 }
 
+// Three-term products accumulated left to right.  FUSED: s = a0*b0; s = fma(a1,b1,s); s = fma(a2,b2,s) - the sequence a build
+// of the reference with hardware FMA produces (its aarch64 flags, /root/reference/CMakeLists.txt:19); otherwise the SSE-only
+// x86 sequence (CMakeLists.txt:15): every product and sum rounded separately.  The reference's float order is not part of
+// its contract (quirks.h); the HIP kernels execute the FUSED sequence bit for bit.
+template <bool FUSED>
 static inline float dot3f(float a0, float b0, float a1, float b1, float a2, float b2)
 {
+    if (FUSED) return std::fmaf(a2, b2, std::fmaf(a1, b1, a0 * b0));
     float p0 = a0 * b0, p1 = a1 * b1, p2 = a2 * b2;
     float s = p0 + p1;
     return s + p2;
 }
+template <bool FUSED>
+static inline double dot3d(double a0, double b0, double a1, double b1, double a2, double b2)
+{
+    if (FUSED) return std::fma(a2, b2, std::fma(a1, b1, a0 * b0));
+    return a0 * b0 + a1 * b1 + a2 * b2;
+}
 
 double Ndt::compute_derivatives(double grad[6], double hess[36], const double p[6], bool compute_hessian)
+{
+    return fused ? compute_derivatives_impl<true>(grad, hess, p, compute_hessian) : compute_derivatives_impl<false>(grad, hess, p, compute_hessian);
+}
+
+void Ndt::compute_hessian(double hess[36], const double p[6])
+{
+    if (fused) compute_hessian_impl<true>(hess, p);
+    else       compute_hessian_impl<false>(hess, p);
+}
+
+template <bool FUSED>
+double Ndt::compute_derivatives_impl(double grad[6], double hess[36], const double p[6], bool compute_hessian)
 {
     const int n = static_cast<int>(source.size() / 4);
     scores_.assign(n, 0.0);
@@ -273,8 +297,8 @@ double Ndt::compute_derivatives(double grad[6], double hess[36], const double p[
         const float x4[3] = {xp[0], xp[1], xp[2]};
         // computePointDerivatives (float form): x_j_ang = j_ang * x4 ; x_h_ang = h_ang * x4
         float xj[8], xh[15];
-        for (int r = 0; r < 8; ++r) xj[r] = dot3f(j_ang_f[r][0], x4[0], j_ang_f[r][1], x4[1], j_ang_f[r][2], x4[2]);
-        for (int r = 0; r < 15; ++r) xh[r] = dot3f(h_ang_f[r][0], x4[0], h_ang_f[r][1], x4[1], h_ang_f[r][2], x4[2]);
+        for (int r = 0; r < 8; ++r) xj[r] = dot3f<FUSED>(j_ang_f[r][0], x4[0], j_ang_f[r][1], x4[1], j_ang_f[r][2], x4[2]);
+        for (int r = 0; r < 15; ++r) xh[r] = dot3f<FUSED>(h_ang_f[r][0], x4[0], h_ang_f[r][1], x4[1], h_ang_f[r][2], x4[2]);
         // point_gradient4 columns 3..5 (rows 0..2); columns 0..2 = identity
         const float J3[3] = {0.0f, xj[0], xj[1]};
         const float J4[3] = {xj[2], xj[3], xj[4]};
@@ -297,8 +321,8 @@ double Ndt::compute_derivatives(double grad[6], double hess[36], const double p[
             for (int t = 0; t < 9; ++t) C[t] = static_cast<float>(cell.icov[t]);
             // qC = x_trans4 * c_inv4 (row vector times matrix)
             float qC[3];
-            for (int c = 0; c < 3; ++c) qC[c] = dot3f(q[0], C[0 * 3 + c], q[1], C[1 * 3 + c], q[2], C[2 * 3 + c]);
-            float qCq = dot3f(q[0], qC[0], q[1], qC[1], q[2], qC[2]);
+            for (int c = 0; c < 3; ++c) qC[c] = dot3f<FUSED>(q[0], C[0 * 3 + c], q[1], C[1 * 3 + c], q[2], C[2 * 3 + c]);
+            float qCq = dot3f<FUSED>(q[0], qC[0], q[1], qC[1], q[2], qC[2]);
             float arg0 = -gauss_d2f * qCq;
             float arg = arg0 * 0.5f;
             float e_x_cov_x = static_cast<float>(std::exp(static_cast<double>(arg)));
@@ -310,12 +334,12 @@ double Ndt::compute_derivatives(double grad[6], double hess[36], const double p[
             float CJ[3][6];
             for (int r = 0; r < 3; ++r) {
                 CJ[r][0] = C[r * 3 + 0]; CJ[r][1] = C[r * 3 + 1]; CJ[r][2] = C[r * 3 + 2];
-                CJ[r][3] = dot3f(C[r * 3 + 0], J3[0], C[r * 3 + 1], J3[1], C[r * 3 + 2], J3[2]);
-                CJ[r][4] = dot3f(C[r * 3 + 0], J4[0], C[r * 3 + 1], J4[1], C[r * 3 + 2], J4[2]);
-                CJ[r][5] = dot3f(C[r * 3 + 0], J5[0], C[r * 3 + 1], J5[1], C[r * 3 + 2], J5[2]);
+                CJ[r][3] = dot3f<FUSED>(C[r * 3 + 0], J3[0], C[r * 3 + 1], J3[1], C[r * 3 + 2], J3[2]);
+                CJ[r][4] = dot3f<FUSED>(C[r * 3 + 0], J4[0], C[r * 3 + 1], J4[1], C[r * 3 + 2], J4[2]);
+                CJ[r][5] = dot3f<FUSED>(C[r * 3 + 0], J5[0], C[r * 3 + 1], J5[1], C[r * 3 + 2], J5[2]);
             }
             float qCJ[6];
-            for (int c = 0; c < 6; ++c) qCJ[c] = dot3f(q[0], CJ[0][c], q[1], CJ[1][c], q[2], CJ[2][c]);
+            for (int c = 0; c < 6; ++c) qCJ[c] = dot3f<FUSED>(q[0], CJ[0][c], q[1], CJ[1][c], q[2], CJ[2][c]);
             for (int c = 0; c < 6; ++c) { float t = e_x_cov_x * qCJ[c]; g_pt[c] += static_cast<double>(t); }
             score_pt += static_cast<double>(score_inc);
             if (!compute_hessian) continue;
@@ -324,15 +348,16 @@ double Ndt::compute_derivatives(double grad[6], double hess[36], const double p[
             float JtCJ[6][6];
             for (int a = 0; a < 6; ++a)
                 for (int b = 0; b < 6; ++b)
-                    JtCJ[a][b] = (a < 3) ? CJ[a][b] : dot3f(Jc[a][0], CJ[0][b], Jc[a][1], CJ[1][b], Jc[a][2], CJ[2][b]);
+                    JtCJ[a][b] = (a < 3) ? CJ[a][b] : dot3f<FUSED>(Jc[a][0], CJ[0][b], Jc[a][1], CJ[1][b], Jc[a][2], CJ[2][b]);
             for (int i = 0; i < 6; ++i) {
                 float qCH[6] = {0, 0, 0, 0, 0, 0};
                 if (i >= 3)
-                    for (int j = 3; j < 6; ++j) { const float* v = PH[i - 3][j - 3]; qCH[j] = dot3f(qC[0], v[0], qC[1], v[1], qC[2], v[2]); }
+                    for (int j = 3; j < 6; ++j) { const float* v = PH[i - 3][j - 3]; qCH[j] = dot3f<FUSED>(qC[0], v[0], qC[1], v[1], qC[2], v[2]); }
                 for (int j = 0; j < 6; ++j) {
                     float t0 = -gauss_d2f * qCJ[i];
-                    float t1 = t0 * qCJ[j];
-                    float t2 = t1 + qCH[j];
+                    float t2;
+                    if (FUSED) { t2 = std::fmaf(t0, qCJ[j], qCH[j]); }
+                    else       { float t1 = t0 * qCJ[j]; t2 = t1 + qCH[j]; }
                     float t3 = t2 + JtCJ[j][i];
                     float t4 = e_x_cov_x * t3;
                     h_pt[i * 6 + j] += static_cast<double>(t4);
@@ -355,7 +380,8 @@ double Ndt::compute_derivatives(double grad[6], double hess[36], const double p[
 }
 
 // computeHessian: serial, double precision (PCL's original 3x6 / 18x6 point derivative forms)
-void Ndt::compute_hessian(double hess[36], const double p[6])
+template <bool FUSED>
+void Ndt::compute_hessian_impl(double hess[36], const double p[6])
 {
     (void)p;  // angular derivative tables are those of the last computeDerivatives call (same pose)
     const int n = static_cast<int>(source.size() / 4);
@@ -370,7 +396,7 @@ void Ndt::compute_hessian(double hess[36], const double p[6])
         nb_total += cnt;
         const float* xp = &source[4 * static_cast<size_t>(idx)];
         const double x[3] = {xp[0], xp[1], xp[2]};
-        auto dotd = [&](const double* a) { return x[0] * a[0] + x[1] * a[1] + x[2] * a[2]; };
+        auto dotd = [&](const double* a) { return dot3d<FUSED>(x[0], a[0], x[1], a[1], x[2], a[2]); };
         double J[3][6] = {{1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}, {0, 0, 1, 0, 0, 0}};
         J[1][3] = dotd(j_ang_d[0]); J[2][3] = dotd(j_ang_d[1]);
         J[0][4] = dotd(j_ang_d[2]); J[1][4] = dotd(j_ang_d[3]); J[2][4] = dotd(j_ang_d[4]);
@@ -386,8 +412,8 @@ void Ndt::compute_hessian(double hess[36], const double p[6])
             const NdtLeaf& cell = cells.leaves[nb[k]];
             const double q[3] = {static_cast<double>(xt[0]) - cell.mean[0], static_cast<double>(xt[1]) - cell.mean[1], static_cast<double>(xt[2]) - cell.mean[2]};
             const double* C = cell.icov;
-            auto Cv = [&](const double* v, double out[3]) { for (int r = 0; r < 3; ++r) out[r] = C[r * 3 + 0] * v[0] + C[r * 3 + 1] * v[1] + C[r * 3 + 2] * v[2]; };
-            auto qdot = [&](const double* v) { return q[0] * v[0] + q[1] * v[1] + q[2] * v[2]; };
+            auto Cv = [&](const double* v, double out[3]) { for (int r = 0; r < 3; ++r) out[r] = dot3d<FUSED>(C[r * 3 + 0], v[0], C[r * 3 + 1], v[1], C[r * 3 + 2], v[2]); };
+            auto qdot = [&](const double* v) { return dot3d<FUSED>(q[0], v[0], q[1], v[1], q[2], v[2]); };
             double Cq[3];
             Cv(q, Cq);
             double e_x_cov_x = gauss_d2 * std::exp(-gauss_d2 * qdot(Cq) / 2);
@@ -400,7 +426,10 @@ void Ndt::compute_hessian(double hess[36], const double p[6])
                     double Jj[3] = {J[0][j], J[1][j], J[2][j]}, CJj[3], CH[3];
                     Cv(Jj, CJj);
                     Cv(PH[i][j], CH);
-                    hess[i * 6 + j] += e_x_cov_x * (-gauss_d2 * qdot(cov_dxd_pi) * qdot(CJj) + qdot(CH) + (Jj[0] * cov_dxd_pi[0] + Jj[1] * cov_dxd_pi[1] + Jj[2] * cov_dxd_pi[2]));
+                    const double jtcj = dot3d<FUSED>(Jj[0], cov_dxd_pi[0], Jj[1], cov_dxd_pi[1], Jj[2], cov_dxd_pi[2]);
+                    const double t0 = -gauss_d2 * qdot(cov_dxd_pi);
+                    if (FUSED) hess[i * 6 + j] = std::fma(e_x_cov_x, std::fma(t0, qdot(CJj), qdot(CH)) + jtcj, hess[i * 6 + j]);
+                    else       hess[i * 6 + j] += e_x_cov_x * (t0 * qdot(CJj) + qdot(CH) + jtcj);
                 }
             }
         }

@@ -47,6 +47,7 @@ struct Ndt {
     int    max_iterations    = 35;
     int    num_threads       = 1;
     NdtSearch search         = NDT_DIRECT7;
+    bool   fused             = true;   // float/double three-term products accumulated with FMA (see ndt.cpp dot3f)
 
     VoxelGridCovariance cells;
     std::vector<float> target, source;  // xyzi
@@ -84,6 +85,8 @@ struct Ndt {
     void   transform_cloud(const float T[16]);
     double compute_derivatives(double grad[6], double hess[36], const double p[6], bool compute_hessian);
     void   compute_hessian(double hess[36], const double p[6]);
+    template <bool FUSED> double compute_derivatives_impl(double grad[6], double hess[36], const double p[6], bool compute_hessian);
+    template <bool FUSED> void   compute_hessian_impl(double hess[36], const double p[6]);
     double step_length_mt(const double x[6], double step_dir[6], double step_init, double step_max, double step_min, double& score,
                           double grad[6], double hess[36]);
 };

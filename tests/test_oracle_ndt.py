@@ -141,3 +141,18 @@ def test_empty_and_degenerate_inputs():
     far[0, 0] = 1e6
     ndt3 = orc.Ndt(resolution=0.01)
     assert ndt3.setInputTarget(far) == -1
+
+
+@pytest.mark.parametrize("eps", [0.1, 0.01])
+def test_fused_and_unfused_float_sequences_agree(eps):
+    """The reference's float rounding sequence is build dependent (x86: SSE only, CMakeLists.txt:15; aarch64: FMA,
+    :19). The oracle's default sequence fuses the NDT three-term products; the unfused one must give the same
+    alignment far inside the 1e-4 bar on a well-conditioned pair."""
+    res = []
+    for fused in (True, False):
+        ndt, _, _, rel = _make(n=6000, transformation_epsilon=eps, num_threads=4, fused=fused)
+        ndt.align(synth.warm_guess(rel, 2))
+        res.append((ndt.getFinalTransformation().astype(np.float64), ndt.hasConverged(), ndt.getFinalNumIteration(), ndt.evals))
+    (Ta, ca, ia, ea), (Tb, cb, ib, eb) = res
+    assert (ca, ia, ea) == (cb, ib, eb)
+    assert np.linalg.norm(Ta[:3, 3] - Tb[:3, 3]) < 1e-5 and synth.rotation_angle(Ta, Tb) < 1e-5
