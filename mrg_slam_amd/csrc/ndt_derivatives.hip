@@ -139,8 +139,11 @@ __device__ __forceinline__ void pair_double(Accum& acc, const double mean[3], co
 // MODE 0: score+gradient+Hessian, 1: score+gradient, 2: Hessian only (double).  NNB: probed voxels (7, 1 or 27).
 // Register budget: the full variant (43 f64 accumulators) is latency-bound at 2 waves/SIMD; capping it at 168 VGPRs
 // (3 waves/SIMD, ~44 B/lane of spill) is 12 % faster on MI355X, 128 VGPRs (4 waves) spills too much (measured).
+#ifndef NDT_MODE0_WAVES
+#define NDT_MODE0_WAVES 3
+#endif
 template <int MODE, int NNB>
-__global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? 3 : 2)) void ndt_derivatives_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
+__global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2)) void ndt_derivatives_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
                                                                const NdtEvalDev* __restrict__ evals, double* __restrict__ partials, int ppt,
                                                                uint32_t spec_part_base)
 {
@@ -254,12 +257,13 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? 3 : 2)) void ndt_de
         nb_total += (threadIdx.x == 0) ? total : 0u;
 
         // ---- phase 2: one lane per (point, voxel) pair -----------------------------------------------------------
+        // (a register-double-buffered prefetch of the next pair's record was measured slower: it costs the occupancy it saves)
         for (uint32_t qi = threadIdx.x; qi < total; qi += kTilePts) {
             const uint32_t entry = s_queue[qi];
             const uint32_t slot = entry >> 24, lid = entry & 0x00FFFFFFu;
             if (lid >= g.n_leaves) continue;  // cannot happen; keeps a corrupted queue entry from faulting the GPU
-            const float xt[3] = {s_xt[0][slot], s_xt[1][slot], s_xt[2][slot]};
             const NdtLeafRec rec = g.leaves[lid];
+            const float xt[3] = {s_xt[0][slot], s_xt[1][slot], s_xt[2][slot]};
             if (MODE != 2) {
                 float xj[8];
 #pragma unroll

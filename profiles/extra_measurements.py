@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Side measurements quoted in DESIGN.md §6 (not the headline metric): run on the GPU box, prints one JSON object.
+
+* host-pointer (PCIe-inclusive) batched NDT throughput: clouds handed over as host buffers every step
+* single-pair NDT latency through one pcl::Registration-style handle
+* GICP_HIP vs the CPU oracle (restated fast_gicp) on one VLP-64 pair
+* prefilter chain (distance + 0.1 m voxel + radius outlier) per raw VLP-64 scan, GPU vs CPU oracle
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from mrg_slam_amd import BatchMatcher, Context, GicpHip, NdtHip, distance_filter, prefilter, synth
+    from mrg_slam_amd._lib import NDT_HIP, SEARCH
+    from mrg_slam_amd.registration import default_params
+    from oracle import oracle as orc
+
+    ctx = Context(0)
+    scene = synth.street_scene()
+    poses = synth.arc_trajectory(5)
+    raw = [synth.synth_lidar(scene, poses[k], "VLP64", synth.BASE_SEED + k) for k in range(5)]
+    scans = [distance_filter(s, 0.1, 35.0, ctx=ctx) for s in raw]
+    rels = [np.linalg.inv(poses[k]) @ poses[k + 1] for k in range(4)]
+    out = {"points_per_scan": float(np.mean([len(s) for s in scans]))}
+
+    # ---- host-pointer batched NDT -------------------------------------------------------------------------------
+    prm = default_params(NDT_HIP)
+    prm.transformation_epsilon, prm.maximum_iterations, prm.resolution, prm.nn_search_method = 0.1, 64, 1.0, SEARCH["DIRECT7"]
+    bm = BatchMatcher(prm, ctx)
+    B = 64
+    pairs = [(b % 4, b % 4 + 1, synth.warm_guess(rels[b % 4], b)) for b in range(B)]
+
+    def step_host():
+        bm.clear()
+        for ti, si, g in pairs:
+            t = bm.add_target(scans[ti])
+            bm.add_pair(t, scans[si], g)
+        return bm.align()
+
+    step_host()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        step_host()
+    ctx.synchronize()
+    out["ndt_host_pointer_alignments_per_s"] = 3 * B / (time.perf_counter() - t0)
+    out["ndt_host_pointer_note"] = f"{B} pairs per step, both clouds of every pair copied host->device (pinned staging) inside the timed region"
+
+    # ---- single pair latency ----------------------------------------------------------------------------------------
+    reg = NdtHip(resolution=1.0, transformation_epsilon=0.1, maximum_iterations=64, ctx=ctx)
+    lat = []
+    for _ in range(8):
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        reg.setInputTarget(scans[0])
+        reg.setInputSource(scans[1])
+        reg.align(pairs[0][2])
+        lat.append(time.perf_counter() - t1)
+    out["ndt_single_pair_latency_ms_host_pointers"] = 1e3 * float(np.median(lat[2:]))
+    out["ndt_single_pair_evaluations"] = reg.evals
+
+    # ---- GICP ---------------------------------------------------------------------------------------------------------
+    ft, fs = prefilter(raw[0], ctx=ctx), prefilter(raw[1], ctx=ctx)
+    g = GicpHip(transformation_epsilon=0.1, ctx=ctx)
+    guess = synth.warm_guess(rels[0], 0)
+    tg = []
+    for _ in range(4):
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        g.setInputTarget(ft)
+        g.setInputSource(fs)
+        g.align(guess)
+        tg.append(time.perf_counter() - t1)
+    cores = min(32, os.cpu_count() or 1)
+    o = orc.FastGicp(transformation_epsilon=0.1, num_threads=cores)
+    t1 = time.perf_counter()
+    o.setInputTarget(ft)
+    o.setInputSource(fs)
+    o.align(guess)
+    tcpu = time.perf_counter() - t1
+    Tg, To = g.getFinalTransformation(), o.getFinalTransformation()
+    out["gicp"] = {"points": [len(ft), len(fs)], "gpu_ms": 1e3 * float(np.median(tg[1:])), "cpu_oracle_ms": 1e3 * tcpu, "cpu_threads": cores,
+                   "dt_m": float(np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3])), "dr_rad": synth.rotation_angle(Tg, To),
+                   "iterations": [g.getFinalNumIteration(), o.getFinalNumIteration()]}
+
+    # ---- prefilter chain --------------------------------------------------------------------------------------------
+    tp = []
+    for _ in range(5):
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        f = prefilter(raw[2], ctx=ctx)
+        tp.append(time.perf_counter() - t1)
+    t1 = time.perf_counter()
+    e = orc.distance_filter(raw[2], 0.1, 35.0)
+    e, _ = orc.voxelgrid(e, 0.1, 1)
+    e, _ = orc.radius_outlier(e, 0.5, 2)
+    tcpu = time.perf_counter() - t1
+    out["prefilter"] = {"raw_points": len(raw[2]), "out_points": len(f), "gpu_ms_host_pointers": 1e3 * float(np.median(tp[1:])), "cpu_oracle_ms_1_thread": 1e3 * tcpu,
+                        "exact": bool(f.shape == e.shape and (f == e).all())}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
