@@ -83,6 +83,7 @@ struct mrgfe_batch {
     mrgfe_ctx*       ctx = nullptr;
     mrgfe_reg_params params;
     NdtEngine*       ndt = nullptr;
+    std::vector<NnGrid> fit_grids;  // getFitnessScore grids, one per target; device buffers kept between align calls
 };
 
 extern "C" {
@@ -386,14 +387,13 @@ int mrgfe_calc_fitness_score(mrgfe_ctx* ctx, const float* cloud1, size_t n1, con
     MRGFE_TRY(d2.ensure(n2 * 16));
     MRGFE_TRY(upload_cloud(ctx, cloud1, n1, stride, d1.p));
     MRGFE_TRY(upload_cloud(ctx, cloud2, n2, stride, d2.p));
-    NnGrid g;
+    NnGrid& g = ctx_tmp_grid(ctx);
     int st = g.build(ctx, d1.as<float4>(), n1, 1.0f);
     if (st == MRGFE_OK) {
         float T[16];  // relpose.cast<float>(), row-major
         for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) T[r * 4 + c] = static_cast<float>(relpose[c * 4 + r]);
         st = g.fitness(ctx, d2.as<float4>(), n2, T, max_range, out);
     }
-    g.release();
     return st;
 }
 
@@ -417,6 +417,8 @@ void mrgfe_batch_destroy(mrgfe_batch* b)
     if (!b) return;
     {
         MRGFE_LOCK(b->ctx);
+        (void)b->ctx->bind();
+        for (auto& g : b->fit_grids) g.release();
         delete b->ndt;
     }
     delete b;
@@ -492,18 +494,25 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
         r.pair_id = i;
     }
     if (fitness_max_range >= 0) {
-        // getFitnessScore per pair: one exact-NN grid per distinct target
-        std::vector<NnGrid> grids(e.n_targets());
+        // getFitnessScore of every pair in one launch: one exact-NN grid per distinct target
+        std::vector<NnGrid>& grids = b->fit_grids;
+        if (grids.size() < static_cast<size_t>(e.n_targets())) grids.resize(e.n_targets());
         std::vector<char>   built(e.n_targets(), 0);
+        std::vector<NnFitnessJob> jobs;
+        std::vector<int>          job_pair;
         int st = MRGFE_OK;
         for (int i = 0; i < P && st == MRGFE_OK; ++i) {
             const NdtPairInfo& p = e.pair(i);
             const NdtTargetInfo& t = e.target(p.target);
             if (t.n == 0 || p.n == 0) continue;
             if (!built[p.target]) { st = grids[p.target].build(b->ctx, t.d_pts, t.n, 1.0f); built[p.target] = 1; }
-            if (st == MRGFE_OK) st = grids[p.target].fitness(b->ctx, p.d_src, p.n, p.ctl.final_transformation(), fitness_max_range, &results[i].fitness);
+            if (st == MRGFE_OK) { jobs.push_back(grids[p.target].make_fitness_job(p.d_src, p.n, p.ctl.final_transformation())); job_pair.push_back(i); }
         }
-        for (auto& g : grids) g.release();
+        if (st == MRGFE_OK && !jobs.empty()) {
+            std::vector<double> fit(jobs.size());
+            st = nn_fitness_batch(b->ctx, jobs.data(), jobs.size(), fitness_max_range, fit.data());
+            if (st == MRGFE_OK) for (size_t j = 0; j < jobs.size(); ++j) results[job_pair[j]].fitness = fit[j];
+        }
         MRGFE_TRY(st);
     }
     return MRGFE_OK;

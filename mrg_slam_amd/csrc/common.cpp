@@ -229,6 +229,7 @@ void mrgfe_ctx_destroy(mrgfe_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    mrgfe::ctx_tmp_grid_free(ctx);
     for (auto& b : ctx->scratch) b.release();
     for (auto& b : ctx->pin) b.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

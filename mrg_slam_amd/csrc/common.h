@@ -71,6 +71,12 @@ struct Arena {
 // several threads (the reference's odometry and loop-closure registrations live in different threads of one process)
 #define MRGFE_LOCK(ctxptr) std::lock_guard<std::recursive_mutex> _mrgfe_lock((ctxptr)->mu)
 
+struct mrgfe_ctx;
+namespace mrgfe {
+class NnGrid;
+void ctx_tmp_grid_free(mrgfe_ctx* ctx);  // nn_grid.hip
+}
+
 struct mrgfe_ctx {
     int          device = 0;
     hipStream_t  stream = nullptr;
@@ -79,6 +85,7 @@ struct mrgfe_ctx {
     mrgfe::DevBuf scratch[12];                  // named by the algorithms that use them
     mrgfe::PinBuf pin[4];
     int          cu_count = 256;
+    mrgfe::NnGrid* tmp_grid = nullptr;          // reusable exact-NN grid of the stateless filter / fitness calls (nn_grid.hip)
     std::recursive_mutex mu;                    // serialises API calls that share this context's stream / workspaces
     int          bind();                        // hipSetDevice(device)
 };

@@ -185,8 +185,8 @@ int filter_radius_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, d
 {
     *out_n = 0;
     if (n == 0) return MRGFE_OK;
-    NnGrid grid;
-    int st = grid.build(ctx, d_in, n, static_cast<float>(radius));
+    NnGrid& grid = ctx_tmp_grid(ctx);
+    int st = grid.build(ctx, d_in, n, static_cast<float>(radius), NnGrid::kCrowding1nn, false);
     if (st == MRGFE_OK) {
         DevBuf& dfl = ctx->scratch[7];
         st = dfl.ensure(n * 4);
@@ -196,7 +196,6 @@ int filter_radius_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, d
         if (st == MRGFE_OK) st = scan_and_compact(ctx, d_in, static_cast<uint32_t>(n), dfl.as<uint32_t>(), d_out, &kept);
         *out_n = kept;
     }
-    grid.release();
     return st;
 }
 
@@ -231,11 +230,11 @@ int filter_statistical_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t
     hipStream_t    st = ctx->stream;
     const uint32_t nn = static_cast<uint32_t>(n);
     const int      k1 = mean_k + 1;
-    NnGrid grid;
-    int    rc = grid.build(ctx, d_in, n, 0.5f);
-    if (rc != MRGFE_OK) { grid.release(); return rc; }
+    NnGrid& grid = ctx_tmp_grid(ctx);
+    int     rc = grid.build(ctx, d_in, n, 1.0f, NnGrid::kCrowdingKnn, false);
+    if (rc != MRGFE_OK) return rc;
     DevBuf knn_i, knn_d, ddist;
-    auto cleanup = [&]() { grid.release(); knn_i.release(); knn_d.release(); ddist.release(); };
+    auto cleanup = [&]() { knn_i.release(); knn_d.release(); ddist.release(); };
     rc = knn_i.ensure(n * k1 * 4);
     if (rc == MRGFE_OK) rc = knn_d.ensure(n * k1 * 4);
     if (rc == MRGFE_OK) rc = ddist.ensure(n * 8);

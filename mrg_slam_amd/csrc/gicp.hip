@@ -88,10 +88,34 @@ __device__ __forceinline__ void gicp_block_reduce(double (&vals)[29], double* __
     }
 }
 
-// update_correspondences + linearize
-__global__ __launch_bounds__(256) void gicp_linearize_kernel(NnGridDev g, const float4* __restrict__ src, uint32_t n, const float4* __restrict__ tgt,
-                                                              const double* __restrict__ cov_src, const double* __restrict__ cov_tgt, GicpPose pose, double thr2,
-                                                              int32_t* __restrict__ corr, double* __restrict__ mahal, double* __restrict__ partials)
+// update_correspondences: exact 1-NN of trans_f * source point in the target, kGicpGroup lanes per query
+constexpr int kGicpGroup = 8;
+__global__ __launch_bounds__(256) void gicp_corr_kernel(NnGrid2Dev g, const float4* __restrict__ src, uint32_t n, GicpPose pose, double thr2, int32_t* __restrict__ corr)
+{
+#pragma clang fp contract(off)
+    const uint32_t i = blockIdx.x * (256u / kGicpGroup) + threadIdx.x / kGicpGroup;
+    if (i >= n) return;
+    const float4 a = src[i];
+    // trans_f * Vector4f(x, y, z, 1): accumulated column by column
+    float q[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float s = pose.Tf[r * 4 + 0] * a.x;
+        s = s + pose.Tf[r * 4 + 1] * a.y;
+        s = s + pose.Tf[r * 4 + 2] * a.z;
+        q[r] = s + pose.Tf[r * 4 + 3];
+    }
+    int32_t j = -1;
+    float   sqd = INFINITY;
+    nn_nearest_group<kGicpGroup>(g, q[0], q[1], q[2], static_cast<int>(threadIdx.x % kGicpGroup), thr2, j, sqd);
+    if (j >= 0 && !(static_cast<double>(sqd) < thr2)) j = -1;
+    if (threadIdx.x % kGicpGroup == 0) corr[i] = j;
+}
+
+// linearize over the correspondences of gicp_corr_kernel
+__global__ __launch_bounds__(256) void gicp_linearize_kernel(const float4* __restrict__ src, uint32_t n, const float4* __restrict__ tgt, const double* __restrict__ cov_src,
+                                                              const double* __restrict__ cov_tgt, GicpPose pose, const int32_t* __restrict__ corr, double* __restrict__ mahal,
+                                                              double* __restrict__ partials)
 {
 #pragma clang fp contract(off)
     double vals[29];
@@ -99,21 +123,8 @@ __global__ __launch_bounds__(256) void gicp_linearize_kernel(NnGridDev g, const 
     for (int k = 0; k < 29; ++k) vals[k] = 0.0;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) {
-        const float4 a = src[i];
-        // trans_f * Vector4f(x, y, z, 1): accumulated column by column
-        float q[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            float s = pose.Tf[r * 4 + 0] * a.x;
-            s = s + pose.Tf[r * 4 + 1] * a.y;
-            s = s + pose.Tf[r * 4 + 2] * a.z;
-            q[r] = s + pose.Tf[r * 4 + 3];
-        }
-        int32_t j = -1;
-        float   sqd = INFINITY;
-        nn_nearest(g, q[0], q[1], q[2], j, sqd);
-        if (j >= 0 && !(static_cast<double>(sqd) < thr2)) j = -1;
-        corr[i] = j;
+        const float4  a = src[i];
+        const int32_t j = corr[i];
         if (j >= 0) {
             const double* cA = cov_src + size_t(i) * 6;
             const double* cB = cov_tgt + size_t(j) * 6;
@@ -302,6 +313,8 @@ GicpEngine::~GicpEngine()
 {
     if (ctx_) (void)hipSetDevice(ctx_->device);
     tgt_grid_.release();
+    cov_grid_.release();
+    d_knn_i_.release(); d_knn_d_.release();
     d_tgt_cov_.release(); d_src_cov_.release(); d_corr_.release(); d_mahal_.release(); d_partial_.release(); d_T_.release();
 }
 
@@ -325,19 +338,14 @@ int GicpEngine::compute_covariances(const float4* d_pts, size_t n, DevBuf& out)
     MRGFE_TRY(out.ensure(std::max<size_t>(n, 1) * 48));
     if (n == 0) return MRGFE_OK;
     const int k = prm_.k_correspondences;
-    NnGrid  grid;
-    DevBuf  di, dd;
-    int rc = grid.build(ctx_, d_pts, n, 0.5f);
-    if (rc == MRGFE_OK) rc = di.ensure(n * k * 4);
-    if (rc == MRGFE_OK) rc = dd.ensure(n * k * 4);
-    if (rc == MRGFE_OK) rc = grid.knn_device(ctx_, d_pts, n, k, di.as<int32_t>(), dd.as<float>());
-    if (rc == MRGFE_OK) {
-        const uint32_t nn = static_cast<uint32_t>(n);
-        hipLaunchKernelGGL(gicp_cov_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx_->stream, d_pts, nn, di.as<int32_t>(), k, out.as<double>());
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx_->stream) != hipSuccess) { set_error("gicp covariance kernel failed"); rc = MRGFE_ERR_HIP; }
-    }
-    grid.release(); di.release(); dd.release();
-    return rc;
+    MRGFE_TRY(cov_grid_.build(ctx_, d_pts, n, 1.0f, NnGrid::kCrowdingKnn, false));
+    MRGFE_TRY(d_knn_i_.ensure(n * k * 4));
+    MRGFE_TRY(d_knn_d_.ensure(n * k * 4));
+    MRGFE_TRY(cov_grid_.knn_device(ctx_, d_pts, n, k, d_knn_i_.as<int32_t>(), d_knn_d_.as<float>()));
+    const uint32_t nn = static_cast<uint32_t>(n);
+    hipLaunchKernelGGL(gicp_cov_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx_->stream, d_pts, nn, d_knn_i_.as<int32_t>(), k, out.as<double>());
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
 }
 
 int GicpEngine::ensure_ready()
@@ -381,8 +389,11 @@ int GicpEngine::run_linearize(const double T[16], bool, double H[36], double b[6
     double* d_part = d_partial_.as<double>();
     double* d_res = d_part + size_t(nblk) * kGicpStride;
     MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev0, st));
-    hipLaunchKernelGGL(gicp_linearize_kernel, dim3(nblk), dim3(256), 0, st, tgt_grid_.dev(), d_src_, n, d_tgt_, d_src_cov_.as<double>(), d_tgt_cov_.as<double>(), make_pose(T),
-                       prm_.max_corr_dist * prm_.max_corr_dist, d_corr_.as<int32_t>(), d_mahal_.as<double>(), d_part);
+    const GicpPose pose = make_pose(T);
+    constexpr uint32_t per_blk = 256u / kGicpGroup;
+    hipLaunchKernelGGL(gicp_corr_kernel, dim3((n + per_blk - 1) / per_blk), dim3(256), 0, st, tgt_grid_.dev2(), d_src_, n, pose, prm_.max_corr_dist * prm_.max_corr_dist, d_corr_.as<int32_t>());
+    hipLaunchKernelGGL(gicp_linearize_kernel, dim3(nblk), dim3(256), 0, st, d_src_, n, d_tgt_, d_src_cov_.as<double>(), d_tgt_cov_.as<double>(), pose, d_corr_.as<int32_t>(),
+                       d_mahal_.as<double>(), d_part);
     MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev1, st));
     hipLaunchKernelGGL(gicp_reduce_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, d_res);
     MRGFE_HIP_CHECK(hipGetLastError());

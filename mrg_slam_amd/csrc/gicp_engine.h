@@ -44,6 +44,8 @@ class GicpEngine {
     const float4* d_src_ = nullptr;
     size_t n_tgt_ = 0, n_src_ = 0;
     NnGrid tgt_grid_;
+    NnGrid cov_grid_;        // k-NN grid of the cloud whose covariances are being computed (buffers reused)
+    DevBuf d_knn_i_, d_knn_d_;
     bool   tgt_grid_valid_ = false, tgt_cov_valid_ = false, src_cov_valid_ = false;
     DevBuf d_tgt_cov_, d_src_cov_, d_corr_, d_mahal_, d_partial_, d_T_;
     float  final_[16];

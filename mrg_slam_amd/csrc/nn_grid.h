@@ -13,26 +13,53 @@
 
 namespace mrgfe {
 
-struct NnGridDev {
+struct NnGridDev {  // one resolution level
     float           origin[3];
     float           cell;
+    float           slack;       // absolute bound on the binning error of floorf((p - origin) / cell) * cell, metres
     int32_t         dim[3];
     uint32_t        n;           // points in `sorted`
+    uint32_t        pad;
     const uint32_t* cell_start;  // dim product + 1
     const float4*   sorted;      // xyz + original index (bit pattern) in w
 };
 
+// Two levels over the same points: 1-NN queries look at the 3x3x3 fine cells around the query and, when that is not
+// conclusive (sparse surroundings), continue on the coarse level, whose ring walk reaches far neighbours in few rings.
+struct NnGrid2Dev {
+    NnGridDev fine, coarse;
+    int32_t   has_coarse;  // 0: coarse == fine (small grids)
+    int32_t   fine_rings;  // rings walked on the fine level before a query moves to the coarse one
+};
+
+// one getFitnessScore evaluation: source cloud `src` (device) moved by the row-major 3x4 float transform, matched
+// against `grid`
+struct NnFitnessJob {
+    NnGrid2Dev    grid;
+    const float4* src;
+    uint32_t      n;
+    uint32_t      pad;
+    float         T12[12];
+};
+
 class NnGrid {
    public:
-    // (re)build over a packed float4 device cloud
-    int build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size);
+    // (re)build over a packed float4 device cloud. `cell_size` is the largest cell edge; with `crowding_target` > 0 the
+    // edge is halved (at most four times) while the population of the cell an average point sits in exceeds the target,
+    // so a walk over the 27 cells around a query touches tens, not thousands, of candidates on dense clouds.
+    static constexpr double kCrowding1nn = 12.0;  // lane-group 1-NN / radius walks: short cell runs
+    static constexpr double kCrowdingKnn = 32.0;  // wave-per-query k-NN: cell rows of about one wavefront
+    static constexpr float  kCoarseRatio = 4.0f;
+    int build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size, double crowding_target = kCrowding1nn, bool with_coarse = true);
     void release();
     bool valid() const { return built_; }
-    const NnGridDev& dev() const { return h_; }
+    const NnGridDev&  dev() const { return h_.fine; }  // k-NN and radius queries walk the fine level only
+    const NnGrid2Dev& dev2() const { return h_; }
     size_t size() const { return n_; }
 
     // mean squared 1-NN distance of T*src over points whose squared distance <= max_range (PCL getFitnessScore)
     int fitness(mrgfe_ctx* ctx, const float4* d_src, size_t n_src, const float T_rowmajor[16], double max_range, double* out);
+    NnFitnessJob make_fitness_job(const float4* d_src, size_t n_src, const float T_rowmajor[16]) const;
     // 1-NN of host queries
     int nearest_host(mrgfe_ctx* ctx, const float* q, size_t n, size_t stride, int32_t* idx, float* sqd);
     // 1-NN of device queries, optionally transformed by a row-major 3x4 float matrix in device memory (may be null)
@@ -45,8 +72,16 @@ class NnGrid {
    private:
     bool      built_ = false;
     size_t    n_ = 0;
-    NnGridDev h_;
-    DevBuf    d_cell_start_, d_sorted_;
+    NnGrid2Dev h_;
+    DevBuf     d_cell_start_, d_sorted_, d_cell_start2_, d_sorted2_;
+    int build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, float cell, const SliceTable& tab, NnGridDev& lv, DevBuf& d_cells, DevBuf& d_sorted,
+                    bool counts_only, double* crowding);
 };
+
+// the context's reusable grid (created on first use; buffers grow only) and its disposal in mrgfe_ctx_destroy
+NnGrid& ctx_tmp_grid(mrgfe_ctx* ctx);
+
+// all jobs in one launch (blockIdx.y = job); out[j] = mean squared distance or DBL_MAX when nothing is in range
+int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, double max_range, double* out);
 
 }  // namespace mrgfe

@@ -5,7 +5,9 @@
 // which hold spatially neighbouring queries for a LiDAR scan — hit the same cache lines.  HBM/L2 bound, no MFMA.
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "dev_float.h"
 #include "dev_utils.h"
@@ -16,19 +18,23 @@ namespace mrgfe {
 
 // ---- build ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nn_cellkey_kernel(const float4* __restrict__ pts, uint32_t n, NnGridDev g, uint32_t n_cells, uint32_t* __restrict__ keys,
-                                                          uint32_t* __restrict__ vals, uint32_t* __restrict__ counts)
+                                                          uint32_t* __restrict__ vals, uint32_t* __restrict__ counts, unsigned long long* __restrict__ crowd)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = pts[i];
-    int          c[3];
-    uint32_t     key = n_cells;
-    if (nn_cell_of(g, p.x, p.y, p.z, c)) {
-        key = (static_cast<uint32_t>(c[2]) * g.dim[1] + c[1]) * g.dim[0] + c[0];
-        atomicAdd(&counts[key], 1u);
+    uint32_t       before = 0;  // points that reached this point's cell before it: summed over the cloud, sum_c n_c (n_c - 1) / 2
+    if (i < n) {
+        const float4 p = pts[i];
+        int          c[3];
+        uint32_t     key = n_cells;
+        if (nn_cell_of(g, p.x, p.y, p.z, c)) {
+            key = (static_cast<uint32_t>(c[2]) * g.dim[1] + c[1]) * g.dim[0] + c[0];
+            before = atomicAdd(&counts[key], 1u);
+        }
+        keys[i] = key;
+        vals[i] = i;
     }
-    keys[i] = key;
-    vals[i] = i;
+    const uint32_t w = wave_sum(before);
+    if (lane_id() == 0 && w) atomicAdd(crowd, static_cast<unsigned long long>(w));
 }
 
 __global__ __launch_bounds__(256) void nn_gather_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ sorted_vals, uint32_t n_valid, float4* __restrict__ sorted)
@@ -41,13 +47,61 @@ __global__ __launch_bounds__(256) void nn_gather_kernel(const float4* __restrict
     sorted[i] = p;
 }
 
-int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size)
+// bins, sorts and gathers one level; `counts_only` stops after the binning kernel (adaptive cell search)
+int NnGrid::build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, float cell, const SliceTable& tab, NnGridDev& lv, DevBuf& d_cells, DevBuf& d_sorted,
+                        bool counts_only, double* crowding)
+{
+    hipStream_t st = ctx->stream;
+    DevBuf &ds = ctx->scratch[0], &dk = ctx->scratch[2], &dv = ctx->scratch[3], &dkt = ctx->scratch[4], &dvt = ctx->scratch[5], &dh = ctx->scratch[6], &dblk = ctx->scratch[8];
+    float extent = 0.0f;
+    for (int a = 0; a < 3; ++a) { lv.origin[a] = bb.mn[a]; extent = std::max(extent, bb.mx[a] - bb.mn[a]); }
+    lv.cell = cell;
+    lv.slack = 1e-6f * (extent + cell);
+    lv.n = bb.n_finite;
+    for (int a = 0; a < 3; ++a) lv.dim[a] = static_cast<int>(std::floor((bb.mx[a] - bb.mn[a]) / cell)) + 1;
+    const uint32_t n_cells = static_cast<uint32_t>(lv.dim[0]) * lv.dim[1] * lv.dim[2];
+    MRGFE_TRY(d_cells.ensure(sizeof(uint32_t) * (size_t(n_cells) + 6)));
+    MRGFE_HIP_CHECK(hipMemsetAsync(d_cells.p, 0, sizeof(uint32_t) * (size_t(n_cells) + 6), st));
+    lv.cell_start = d_cells.as<uint32_t>();
+    // the crowd counter lives behind the (n_cells + 1)-entry count table, 8-byte aligned
+    unsigned long long* d_crowd = reinterpret_cast<unsigned long long*>(d_cells.as<uint32_t>() + ((size_t(n_cells) + 2) & ~size_t(1)));
+    hipLaunchKernelGGL(nn_cellkey_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, d_pts, nn, lv, n_cells, dk.as<uint32_t>(), dv.as<uint32_t>(), d_cells.as<uint32_t>(), d_crowd);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    if (crowding) {
+        unsigned long long crowd = 0;
+        MRGFE_HIP_CHECK(hipMemcpyAsync(&crowd, d_crowd, 8, hipMemcpyDeviceToHost, st));
+        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+        // population of the cell an average POINT sits in (queries are distributed like the points, not like the cells)
+        *crowding = 1.0 + 2.0 * double(crowd) / double(bb.n_finite);
+    }
+    if (counts_only) return MRGFE_OK;
+    int key_bits = 1;
+    while (key_bits < 32 && (uint64_t(1) << key_bits) <= n_cells) ++key_bits;
+    uint32_t *sk, *sv;
+    MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), ds.as<Slice>(), tab, key_bits, dh.as<uint32_t>(), &sk, &sv));
+    // counts -> cell_start (exclusive scan over n_cells + 1 entries, in place)
+    uint32_t   nc1 = n_cells + 1;
+    SliceTable ctab;
+    ctab.build(&nc1, 1);
+    MRGFE_HIP_CHECK(hipMemcpyAsync(ds.as<char>() + sizeof(Slice), ctab.h.data(), sizeof(Slice), hipMemcpyHostToDevice, st));
+    MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (ctab.total_blks + 8)));
+    MRGFE_TRY(exclusive_scan(ctx, d_cells.as<uint32_t>(), d_cells.as<uint32_t>(), ds.as<Slice>() + 1, ctab, dblk.as<uint32_t>(), dblk.as<uint32_t>() + ctab.total_blks));
+    MRGFE_TRY(d_sorted.ensure(sizeof(float4) * std::max<size_t>(nn, 1)));
+    lv.sorted = d_sorted.as<float4>();
+    hipLaunchKernelGGL(nn_gather_kernel, dim3((lv.n + 255) / 256), dim3(256), 0, st, d_pts, sv, lv.n, d_sorted.as<float4>());
+    MRGFE_HIP_CHECK(hipGetLastError());
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));  // ctab's host table was the source of an async copy
+    return MRGFE_OK;
+}
+
+int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size, double crowding_target, bool with_coarse)
 {
     built_ = false;
     n_ = n;
+    if (const char* e = std::getenv("MRGFE_NN_CELL")) { cell_size = static_cast<float>(std::atof(e)); crowding_target = 0; }  // tuning hook
     std::memset(&h_, 0, sizeof(h_));
-    h_.cell = cell_size;
-    h_.dim[0] = h_.dim[1] = h_.dim[2] = 1;
+    h_.fine.cell = h_.coarse.cell = cell_size;
+    for (int a = 0; a < 3; ++a) h_.fine.dim[a] = h_.coarse.dim[a] = 1;
     if (n > 0x7fffffffu) { set_error("NnGrid: cloud too large"); return MRGFE_ERR_INVALID; }
     hipStream_t st = ctx->stream;
     uint32_t    nn = static_cast<uint32_t>(n);
@@ -68,148 +122,201 @@ int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size
     MRGFE_HIP_CHECK(hipMemcpyAsync(&bb, d_out, sizeof(BBox), hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
     if (bb.n_finite == 0) {  // empty grid: one cell, no points
-        for (int a = 0; a < 3; ++a) h_.origin[a] = 0;
         MRGFE_TRY(d_cell_start_.ensure(8));
         MRGFE_HIP_CHECK(hipMemsetAsync(d_cell_start_.p, 0, 8, st));
         MRGFE_TRY(d_sorted_.ensure(16));
-        h_.n = 0;
-        h_.cell_start = d_cell_start_.as<uint32_t>();
-        h_.sorted = d_sorted_.as<float4>();
+        h_.fine.cell_start = d_cell_start_.as<uint32_t>();
+        h_.fine.sorted = d_sorted_.as<float4>();
+        h_.coarse = h_.fine;
         built_ = true;
         return MRGFE_OK;
     }
-    float cell = cell_size;
-    for (;;) {
-        double prod = 1;
-        for (int a = 0; a < 3; ++a) { h_.dim[a] = static_cast<int>(std::floor((bb.mx[a] - bb.mn[a]) / cell)) + 1; prod *= h_.dim[a]; }
-        if (prod <= double(1u << 24)) break;
-        cell *= 2.0f;
-    }
-    h_.cell = cell;
-    for (int a = 0; a < 3; ++a) h_.origin[a] = bb.mn[a];
-    const uint32_t n_cells = static_cast<uint32_t>(h_.dim[0]) * h_.dim[1] * h_.dim[2];
-    MRGFE_TRY(d_cell_start_.ensure(sizeof(uint32_t) * (size_t(n_cells) + 4)));
-    MRGFE_TRY(d_sorted_.ensure(sizeof(float4) * std::max<size_t>(n, 1)));
-    MRGFE_HIP_CHECK(hipMemsetAsync(d_cell_start_.p, 0, sizeof(uint32_t) * (size_t(n_cells) + 1), st));
-    h_.cell_start = d_cell_start_.as<uint32_t>();
-    h_.sorted = d_sorted_.as<float4>();
-    h_.n = bb.n_finite;
-    DevBuf &dk = ctx->scratch[2], &dv = ctx->scratch[3], &dkt = ctx->scratch[4], &dvt = ctx->scratch[5], &dh = ctx->scratch[6], &dblk = ctx->scratch[8];
+    DevBuf &dk = ctx->scratch[2], &dv = ctx->scratch[3], &dkt = ctx->scratch[4], &dvt = ctx->scratch[5], &dh = ctx->scratch[6];
     MRGFE_TRY(dk.ensure(n * 4)); MRGFE_TRY(dv.ensure(n * 4)); MRGFE_TRY(dkt.ensure(n * 4)); MRGFE_TRY(dvt.ensure(n * 4));
     MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + 1)));
-    hipLaunchKernelGGL(nn_cellkey_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, d_pts, nn, h_, n_cells, dk.as<uint32_t>(), dv.as<uint32_t>(), d_cell_start_.as<uint32_t>());
-    int key_bits = 1;
-    while (key_bits < 32 && (uint64_t(1) << key_bits) <= n_cells) ++key_bits;
-    uint32_t *sk, *sv;
-    MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), ds.as<Slice>(), tab, key_bits, dh.as<uint32_t>(), &sk, &sv));
-    // counts -> cell_start (exclusive scan over n_cells + 1 entries, in place)
-    uint32_t   nc1 = n_cells + 1;
-    SliceTable ctab;
-    ctab.build(&nc1, 1);
-    MRGFE_HIP_CHECK(hipMemcpyAsync(ds.as<char>() + sizeof(Slice), ctab.h.data(), sizeof(Slice), hipMemcpyHostToDevice, st));
-    MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (ctab.total_blks + 8)));
-    MRGFE_TRY(exclusive_scan(ctx, d_cell_start_.as<uint32_t>(), d_cell_start_.as<uint32_t>(), ds.as<Slice>() + 1, ctab, dblk.as<uint32_t>(), dblk.as<uint32_t>() + ctab.total_blks));
-    hipLaunchKernelGGL(nn_gather_kernel, dim3((h_.n + 255) / 256), dim3(256), 0, st, d_pts, sv, h_.n, d_sorted_.as<float4>());
-    MRGFE_HIP_CHECK(hipGetLastError());
-    MRGFE_HIP_CHECK(hipStreamSynchronize(st));  // ctab / tab host tables were sources of async copies
+    auto cells_at = [&](float c) {
+        double prod = 1;
+        for (int a = 0; a < 3; ++a) prod *= std::floor((bb.mx[a] - bb.mn[a]) / c) + 1;
+        return prod;
+    };
+    float cell = cell_size;
+    while (cells_at(cell) > double(1u << 24)) cell *= 2.0f;
+    if (crowding_target > 0) {
+        // halve the edge while the cell an average point sits in is more crowded than the target (at most four times)
+        for (int pass = 0; pass < 4 && cells_at(cell * 0.5f) <= double(1u << 24); ++pass) {
+            double crowding = 0;
+            MRGFE_TRY(build_level(ctx, d_pts, nn, bb, cell, tab, h_.fine, d_cell_start_, d_sorted_, true, &crowding));
+            if (crowding <= crowding_target) break;
+            cell *= 0.5f;
+        }
+    }
+    MRGFE_TRY(build_level(ctx, d_pts, nn, bb, cell, tab, h_.fine, d_cell_start_, d_sorted_, false, nullptr));
+    // coarse level for queries whose neighbourhood is empty at the fine scale: kCoarseRatio x the edge, same origin
+    if (with_coarse && std::max(h_.fine.dim[0], std::max(h_.fine.dim[1], h_.fine.dim[2])) > 4) {
+        float ratio = kCoarseRatio;
+        if (const char* e = std::getenv("MRGFE_NN_COARSE_RATIO")) ratio = std::max(2.0f, static_cast<float>(std::atof(e)));  // tuning hook
+        MRGFE_TRY(build_level(ctx, d_pts, nn, bb, cell * ratio, tab, h_.coarse, d_cell_start2_, d_sorted2_, false, nullptr));
+        h_.has_coarse = 1;
+        h_.fine_rings = 8;
+        if (const char* e = std::getenv("MRGFE_NN_FINE_RINGS")) h_.fine_rings = std::max(1, std::atoi(e));  // tuning hook
+    } else {
+        h_.coarse = h_.fine;
+        h_.has_coarse = 0;
+    }
     built_ = true;
     return MRGFE_OK;
+}
+
+NnGrid& ctx_tmp_grid(mrgfe_ctx* ctx)
+{
+    if (!ctx->tmp_grid) ctx->tmp_grid = new NnGrid();
+    return *ctx->tmp_grid;
+}
+void ctx_tmp_grid_free(mrgfe_ctx* ctx)
+{
+    if (!ctx->tmp_grid) return;
+    ctx->tmp_grid->release();
+    delete ctx->tmp_grid;
+    ctx->tmp_grid = nullptr;
 }
 
 void NnGrid::release()
 {
     d_cell_start_.release();
     d_sorted_.release();
+    d_cell_start2_.release();
+    d_sorted2_.release();
     built_ = false;
 }
 
 // ---- queries ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nn_nearest_kernel(NnGridDev g, const float4* __restrict__ q, uint32_t n, const float* __restrict__ T12, int32_t* __restrict__ idx,
+constexpr int kNnGroup = 8;  // lanes that share one 1-NN query (nn_nearest_group)
+
+__global__ __launch_bounds__(256) void nn_nearest_kernel(NnGrid2Dev g, const float4* __restrict__ q, uint32_t n, const float* __restrict__ T12, int32_t* __restrict__ idx,
                                                           float* __restrict__ sqd)
 {
     __shared__ float s_T[12];
     const bool       use_T = T12 != nullptr;
     if (use_T && threadIdx.x < 12) s_T[threadIdx.x] = T12[threadIdx.x];
     __syncthreads();
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i = blockIdx.x * (256u / kNnGroup) + threadIdx.x / kNnGroup;
+    const int      sub = threadIdx.x % kNnGroup;
     if (i >= n) return;
     const float4 p = q[i];
     float x = p.x, y = p.y, z = p.z;
     if (use_T) transform_point(s_T, p.x, p.y, p.z, x, y, z);
     int32_t bi;
     float   bd;
-    nn_nearest(g, x, y, z, bi, bd);
-    idx[i] = bi;
-    sqd[i] = bi >= 0 ? bd : -1.0f;
+    nn_nearest_group<kNnGroup>(g, x, y, z, sub, static_cast<double>(INFINITY), bi, bd);
+    if (sub == 0) {
+        idx[i] = bi;
+        sqd[i] = bi >= 0 ? bd : -1.0f;
+    }
 }
 
-// getFitnessScore: block partial = (sum of squared distances, count)
-__global__ __launch_bounds__(256) void nn_fitness_kernel(NnGridDev g, const float4* __restrict__ src, uint32_t n, const float* __restrict__ T12, double max_range,
-                                                          double* __restrict__ partial)
+// getFitnessScore for a batch of (grid, source cloud, transform) jobs: blockIdx.y = job, block partial = (sum of
+// squared 1-NN distances <= max_range, count)
+__global__ __launch_bounds__(256) void nn_fitness_kernel(const NnFitnessJob* __restrict__ jobs, double max_range, double* __restrict__ partial)
 {
-    __shared__ float  s_T[12];
-    __shared__ double s_sum[4];
-    __shared__ uint32_t s_cnt[4];
-    if (threadIdx.x < 12) s_T[threadIdx.x] = T12[threadIdx.x];
+    __shared__ NnFitnessJob s_job;
+    __shared__ double       s_sum[4];
+    __shared__ uint32_t     s_cnt[4];
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(jobs + blockIdx.y);
+        uint32_t*       dst = reinterpret_cast<uint32_t*>(&s_job);
+        for (uint32_t w = threadIdx.x; w < sizeof(NnFitnessJob) / 4; w += 256) dst[w] = src[w];
+    }
     __syncthreads();
+    const NnGrid2Dev& g = s_job.grid;
+    const uint32_t   n = s_job.n;
+    const int        sub = threadIdx.x % kNnGroup;
     double   sum = 0.0;
     uint32_t cnt = 0;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const float4 p = src[i];
+    for (uint32_t i = blockIdx.x * (256u / kNnGroup) + threadIdx.x / kNnGroup; i < n; i += gridDim.x * (256u / kNnGroup)) {
+        const float4 p = s_job.src[i];
         float x, y, z;
-        transform_point(s_T, p.x, p.y, p.z, x, y, z);
+        transform_point(s_job.T12, p.x, p.y, p.z, x, y, z);
         int32_t bi;
         float   bd;
-        nn_nearest(g, x, y, z, bi, bd);
-        if (bi >= 0 && static_cast<double>(bd) <= max_range) { sum += static_cast<double>(bd); ++cnt; }
+        nn_nearest_group<kNnGroup>(g, x, y, z, sub, max_range, bi, bd);
+        if (sub == 0 && bi >= 0 && static_cast<double>(bd) <= max_range) { sum += static_cast<double>(bd); ++cnt; }
     }
     sum = wave_sum(sum);
     cnt = wave_sum(cnt);
     if (lane_id() == 0) { s_sum[wave_id()] = sum; s_cnt[wave_id()] = cnt; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        partial[2 * blockIdx.x] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
-        partial[2 * blockIdx.x + 1] = static_cast<double>(s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+        double* o = partial + 2 * (size_t(blockIdx.y) * gridDim.x + blockIdx.x);
+        o[0] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
+        o[1] = static_cast<double>(s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
     }
 }
 
 __global__ __launch_bounds__(256) void nn_fitness_final_kernel(const double* __restrict__ partial, uint32_t nblk, double* __restrict__ out)
 {
     __shared__ double s_a[4], s_b[4];
+    const double* part = partial + 2 * size_t(blockIdx.x) * nblk;
     double a = 0, b = 0;
-    for (uint32_t i = threadIdx.x; i < nblk; i += 256) { a += partial[2 * i]; b += partial[2 * i + 1]; }
+    for (uint32_t i = threadIdx.x; i < nblk; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
     a = wave_sum(a);
     b = wave_sum(b);
     if (lane_id() == 0) { s_a[wave_id()] = a; s_b[wave_id()] = b; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[0] = ((s_a[0] + s_a[1]) + s_a[2]) + s_a[3];
-        out[1] = ((s_b[0] + s_b[1]) + s_b[2]) + s_b[3];
+        out[2 * blockIdx.x] = ((s_a[0] + s_a[1]) + s_a[2]) + s_a[3];
+        out[2 * blockIdx.x + 1] = ((s_b[0] + s_b[1]) + s_b[2]) + s_b[3];
     }
+}
+
+int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, double max_range, double* out)
+{
+    for (size_t j = 0; j < count; ++j) out[j] = DBL_MAX;
+    if (count == 0) return MRGFE_OK;
+    if (count > 65535) { set_error("nn_fitness_batch: too many jobs"); return MRGFE_ERR_INVALID; }
+    hipStream_t st = ctx->stream;
+    uint32_t    max_n = 0;
+    for (size_t j = 0; j < count; ++j) max_n = std::max(max_n, jobs[j].n);
+    if (max_n == 0) return MRGFE_OK;
+    constexpr uint32_t per_blk = 256u / kNnGroup;
+    // enough blocks to fill the chip a few times over, few enough that the partial table stays small
+    const uint32_t want = static_cast<uint32_t>(std::max<size_t>(1, (size_t(ctx->cu_count) * 16 + count - 1) / count));
+    const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((max_n + per_blk - 1) / per_blk, want));
+    DevBuf& dw = ctx->scratch[9];
+    const size_t jobs_bytes = (sizeof(NnFitnessJob) * count + 255) & ~size_t(255);
+    MRGFE_TRY(dw.ensure(jobs_bytes + sizeof(double) * 2 * (size_t(nblk) + 1) * count));
+    NnFitnessJob* d_jobs = dw.as<NnFitnessJob>();
+    double*       d_part = reinterpret_cast<double*>(dw.as<char>() + jobs_bytes);
+    double*       d_res = d_part + 2 * size_t(nblk) * count;
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_jobs, jobs, sizeof(NnFitnessJob) * count, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(nn_fitness_kernel, dim3(nblk, static_cast<uint32_t>(count)), dim3(256), 0, st, d_jobs, max_range, d_part);
+    hipLaunchKernelGGL(nn_fitness_final_kernel, dim3(static_cast<uint32_t>(count)), dim3(256), 0, st, d_part, nblk, d_res);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    std::vector<double> res(2 * count);
+    MRGFE_HIP_CHECK(hipMemcpyAsync(res.data(), d_res, sizeof(double) * 2 * count, hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    for (size_t j = 0; j < count; ++j)
+        if (res[2 * j + 1] > 0) out[j] = res[2 * j] / res[2 * j + 1];
+    return MRGFE_OK;
 }
 
 int NnGrid::fitness(mrgfe_ctx* ctx, const float4* d_src, size_t n_src, const float T[16], double max_range, double* out)
 {
     *out = DBL_MAX;
     if (!built_) { set_error("NnGrid::fitness before build"); return MRGFE_ERR_STATE; }
-    if (n_src == 0 || h_.n == 0) return MRGFE_OK;
-    hipStream_t st = ctx->stream;
-    const uint32_t n = static_cast<uint32_t>(n_src);
-    const uint32_t nblk = std::min<uint32_t>((n + 255) / 256, 4096);
-    DevBuf& dw = ctx->scratch[9];
-    MRGFE_TRY(dw.ensure(64 + sizeof(double) * 2 * (nblk + 1)));
-    float*  d_T = dw.as<float>();
-    double* d_part = reinterpret_cast<double*>(dw.as<char>() + 64);
-    double* d_res = d_part + 2 * nblk;
-    MRGFE_HIP_CHECK(hipMemcpyAsync(d_T, T, 48, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(nn_fitness_kernel, dim3(nblk), dim3(256), 0, st, h_, d_src, n, d_T, max_range, d_part);
-    hipLaunchKernelGGL(nn_fitness_final_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, d_res);
-    MRGFE_HIP_CHECK(hipGetLastError());
-    double res[2];
-    MRGFE_HIP_CHECK(hipMemcpyAsync(res, d_res, sizeof(res), hipMemcpyDeviceToHost, st));
-    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
-    if (res[1] > 0) *out = res[0] / res[1];
-    return MRGFE_OK;
+    if (n_src == 0 || h_.fine.n == 0) return MRGFE_OK;
+    NnFitnessJob job = make_fitness_job(d_src, n_src, T);
+    return nn_fitness_batch(ctx, &job, 1, max_range, out);
+}
+
+NnFitnessJob NnGrid::make_fitness_job(const float4* d_src, size_t n_src, const float T[16]) const
+{
+    NnFitnessJob job;
+    job.grid = h_;
+    job.src = d_src;
+    job.n = static_cast<uint32_t>(n_src);
+    job.pad = 0;
+    std::memcpy(job.T12, T, 48);
+    return job;
 }
 
 int NnGrid::nearest_device(mrgfe_ctx* ctx, const float4* d_q, size_t n, const float* d_T12, int32_t* d_idx, float* d_sqd)
@@ -217,7 +324,8 @@ int NnGrid::nearest_device(mrgfe_ctx* ctx, const float4* d_q, size_t n, const fl
     if (!built_) { set_error("NnGrid::nearest before build"); return MRGFE_ERR_STATE; }
     if (n == 0) return MRGFE_OK;
     const uint32_t nn = static_cast<uint32_t>(n);
-    hipLaunchKernelGGL(nn_nearest_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, h_, d_q, nn, d_T12, d_idx, d_sqd);
+    constexpr uint32_t per_blk = 256u / kNnGroup;
+    hipLaunchKernelGGL(nn_nearest_kernel, dim3((nn + per_blk - 1) / per_blk), dim3(256), 0, ctx->stream, h_, d_q, nn, d_T12, d_idx, d_sqd);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }
@@ -248,7 +356,7 @@ __global__ __launch_bounds__(256) void nn_radius_flags_kernel(NnGridDev g, const
     int          count = 0;
     if (g.n > 0 && nn_cell_of(g, p.x, p.y, p.z, c)) {
         nn_walk(
-            g, c, rings,
+            g, c, 0.0, rings,
             [&](const float4& t) {
                 if (static_cast<double>(sqdist3f(t.x, t.y, t.z, p.x, p.y, p.z)) <= r2) ++count;
             },
@@ -263,57 +371,66 @@ int NnGrid::radius_count_flags(mrgfe_ctx* ctx, const float4* d_q, size_t n, doub
     if (n == 0) return MRGFE_OK;
     const uint32_t nn = static_cast<uint32_t>(n);
     // every point within r of the query lies within ceil(r / cell) + 1 rings of its cell
-    const int rings = static_cast<int>(std::ceil(std::sqrt(r2) / h_.cell)) + 1;
-    hipLaunchKernelGGL(nn_radius_flags_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, h_, d_q, nn, r2, need, rings, d_flags);
+    const int rings = static_cast<int>(std::ceil(std::sqrt(r2) / h_.fine.cell)) + 1;
+    hipLaunchKernelGGL(nn_radius_flags_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, h_.fine, d_q, nn, r2, need, rings, d_flags);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }
 
-// k nearest neighbours. Per-thread sorted candidate lists live in LDS, laid out [slot][thread] (conflict-free).
-constexpr int kKnnThreads = 128;
-__global__ __launch_bounds__(kKnnThreads) void nn_knn_kernel(NnGridDev g, const float4* __restrict__ q, uint32_t n, int k, int32_t* __restrict__ idx, float* __restrict__ sqd)
+// k nearest neighbours, one wavefront per query.  The running top-k list lives in registers, entry j in lane j, kept
+// sorted by (squared distance, index); the wave reads 64 candidates of a cell run per step (coalesced), ballots the ones
+// that beat the current k-th entry and inserts them one at a time with a popcount for the slot and one lane shift.
+// (distance, index) is a total order, so the result does not depend on the visiting order.
+__global__ __launch_bounds__(256) void nn_knn_kernel(NnGridDev g, const float4* __restrict__ q, uint32_t n, int k, int32_t* __restrict__ idx, float* __restrict__ sqd)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char knn_lds[];
-    float*   ld = reinterpret_cast<float*>(knn_lds);                       // [k][kKnnThreads]
-    int32_t* li = reinterpret_cast<int32_t*>(knn_lds) + k * kKnnThreads;   // [k][kKnnThreads]
-    const uint32_t i = blockIdx.x * kKnnThreads + threadIdx.x;
-    if (i >= n) return;
-    const int t = threadIdx.x;
-    int       cnt = 0;
+    const uint32_t i = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    if (i >= n) return;  // uniform per wave
+    const int    lane = lane_id();
     const float4 p = q[i];
+    float        td = INFINITY;     // list entry of this lane
+    int32_t      ti = 0x7fffffff;
+    float        kth_d = INFINITY;  // current k-th entry (uniform); (inf, max) while the list is not full
+    int32_t      kth_i = 0x7fffffff;
+    int          cnt = 0;
     int          c[3];
     if (g.n > 0 && nn_cell_of(g, p.x, p.y, p.z, c)) {
-        nn_walk(
-            g, c, -1,
-            [&](const float4& cand) {
-                const float   d = sqdist3f(cand.x, cand.y, cand.z, p.x, p.y, p.z);
-                const int32_t ci = __float_as_int(cand.w);
-                if (cnt == k) {
-                    const float   wd = ld[(k - 1) * kKnnThreads + t];
-                    const int32_t wi = li[(k - 1) * kKnnThreads + t];
-                    if (!(d < wd || (d == wd && ci < wi))) return;
-                }
-                int pos = cnt < k ? cnt : k - 1;  // slot that is free / dropped
-                while (pos > 0) {
-                    const float   pd = ld[(pos - 1) * kKnnThreads + t];
-                    const int32_t pi = li[(pos - 1) * kKnnThreads + t];
-                    if (d < pd || (d == pd && ci < pi)) {
-                        ld[pos * kKnnThreads + t] = pd;
-                        li[pos * kKnnThreads + t] = pi;
-                        --pos;
-                    } else {
-                        break;
+        nn_walk_ranges(
+            g, c, nn_face_margin(g, c, p.x, p.y, p.z), -1,
+            [&](uint32_t b, uint32_t e) {
+                for (uint32_t base = b; base < e; base += 64u) {
+                    const uint32_t kk = base + lane;
+                    const bool     valid = kk < e;
+                    float          d = INFINITY;
+                    int32_t        ci = 0x7fffffff;
+                    if (valid) {
+                        const float4 cand = g.sorted[kk];
+                        d = sqdist3f(cand.x, cand.y, cand.z, p.x, p.y, p.z);
+                        ci = __float_as_int(cand.w);
+                    }
+                    uint64_t m = __ballot(valid && (d < kth_d || (d == kth_d && ci < kth_i)));
+                    while (m) {
+                        const int src = __ffsll(static_cast<unsigned long long>(m)) - 1;
+                        m &= m - 1;
+                        const float   cd = __shfl(d, src);
+                        const int32_t cci = __shfl(ci, src);
+                        if (!(cd < kth_d || (cd == kth_d && cci < kth_i))) continue;  // the k-th entry moved since the ballot
+                        const bool     mine_less = td < cd || (td == cd && ti < cci);
+                        const int      pos = __popcll(__ballot(mine_less));  // sorted list: the lanes below pos hold the smaller entries
+                        const float    up_d = __shfl_up(td, 1);
+                        const int32_t  up_i = __shfl_up(ti, 1);
+                        if (lane == pos) { td = cd; ti = cci; }
+                        else if (lane > pos) { td = up_d; ti = up_i; }
+                        if (lane >= k) { td = INFINITY; ti = 0x7fffffff; }
+                        if (cnt < k) ++cnt;
+                        if (cnt == k) { kth_d = __shfl(td, k - 1); kth_i = __shfl(ti, k - 1); }
                     }
                 }
-                ld[pos * kKnnThreads + t] = d;
-                li[pos * kKnnThreads + t] = ci;
-                if (cnt < k) ++cnt;
             },
-            [&](double bound_sq) { return cnt == k && static_cast<double>(ld[(k - 1) * kKnnThreads + t]) < bound_sq; });
+            [&](double bound_sq) { return cnt == k && static_cast<double>(kth_d) < bound_sq; });
     }
-    for (int s = 0; s < k; ++s) {
-        idx[size_t(i) * k + s] = s < cnt ? li[s * kKnnThreads + t] : -1;
-        sqd[size_t(i) * k + s] = s < cnt ? ld[s * kKnnThreads + t] : -1.0f;
+    if (lane < k) {
+        idx[size_t(i) * k + lane] = lane < cnt ? ti : -1;
+        sqd[size_t(i) * k + lane] = lane < cnt ? td : -1.0f;
     }
 }
 
@@ -322,9 +439,9 @@ int NnGrid::knn_device(mrgfe_ctx* ctx, const float4* d_q, size_t n, int k, int32
     if (!built_) { set_error("NnGrid::knn before build"); return MRGFE_ERR_STATE; }
     if (k < 1 || k > 64) { set_error("NnGrid::knn: k must be in [1, 64]"); return MRGFE_ERR_INVALID; }
     if (n == 0) return MRGFE_OK;
+    if (n > (0xffffffffu >> 6)) { set_error("NnGrid::knn: too many queries"); return MRGFE_ERR_INVALID; }
     const uint32_t nn = static_cast<uint32_t>(n);
-    const size_t   lds = size_t(k) * kKnnThreads * 8;
-    hipLaunchKernelGGL(nn_knn_kernel, dim3((nn + kKnnThreads - 1) / kKnnThreads), dim3(kKnnThreads), lds, ctx->stream, h_, d_q, nn, k, d_idx, d_sqd);
+    hipLaunchKernelGGL(nn_knn_kernel, dim3((nn + 3) / 4), dim3(256), 0, ctx->stream, h_.fine, d_q, nn, k, d_idx, d_sqd);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }

@@ -54,6 +54,24 @@ def main():
     out["ndt_host_pointer_alignments_per_s"] = 3 * B / (time.perf_counter() - t0)
     out["ndt_host_pointer_note"] = f"{B} pairs per step, both clouds of every pair copied host->device (pinned staging) inside the timed region"
 
+    # ---- loop-closure style batch: one new keyframe (target) against B candidate clouds, getFitnessScore(inf) per pair --------
+    bm.clear()
+    t = bm.add_target(scans[0])
+    for b in range(B):
+        bm.add_pair(t, scans[1 + b % 4], synth.warm_guess(np.linalg.inv(poses[0]) @ poses[1 + b % 4], b))
+    lc = {}
+    for name, rng in (("align_only_ms", -1.0), ("align_plus_fitness_inf_ms", float("inf")), ("align_plus_fitness_2m2_ms", 2.0)):
+        bm.align(rng)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            res = bm.align(rng)
+        ctx.synchronize()
+        lc[name] = 1e3 * (time.perf_counter() - t0) / 3
+    lc["pairs"] = B
+    lc["fitness_sample"] = [float(res["fitness"][0]), float(res["fitness"][1])]
+    out["loop_closure_batch"] = lc
+
     # ---- single pair latency ----------------------------------------------------------------------------------------
     reg = NdtHip(resolution=1.0, transformation_epsilon=0.1, maximum_iterations=64, ctx=ctx)
     lat = []

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Small fixed workload for kernel traces of the non-headline paths: rocprofv3 --kernel-trace --stats -- python3 profiles/side_workloads.py
+GICP_HIP (3 full set-target/set-source/align cycles on one prefiltered VLP-64 pair), the prefilter chain (3 raw scans)
+and calc_fitness_score (3 calls)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from mrg_slam_amd import Context, GicpHip, calc_fitness_score, prefilter, synth
+
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    ctx = Context(0)
+    scene = synth.street_scene()
+    poses = synth.arc_trajectory(3)
+    raw = [synth.synth_lidar(scene, poses[k], "VLP64", synth.BASE_SEED + k) for k in range(3)]
+    rel = np.linalg.inv(poses[0]) @ poses[1]
+    ft, fs = prefilter(raw[0], ctx=ctx), prefilter(raw[1], ctx=ctx)
+    if which in ("all", "prefilter"):
+        for k in range(3):
+            prefilter(raw[k], ctx=ctx)
+    if which in ("all", "gicp"):
+        g = GicpHip(transformation_epsilon=0.01, ctx=ctx)
+        for k in range(3):
+            g.setInputTarget(ft)
+            g.setInputSource(fs)
+            g.align(rel @ synth.make_pose([0.3, -0.2, 0.05], synth.rot_z(0.03)))
+        print("gicp iterations", g.getFinalNumIteration())
+    if which in ("all", "fitness"):
+        for k in range(3):
+            print("fitness", calc_fitness_score(ft, fs, rel, 2.0, ctx=ctx))
+    ctx.synchronize()
+
+
+if __name__ == "__main__":
+    main()
