@@ -146,6 +146,9 @@ __device__ __forceinline__ bool nn_level_search(const NnGridDev& g, float x, flo
         const double b2 = b * b * (1.0 - 1e-5);
         return (best_i >= 0 && static_cast<double>(best_d) < b2) || b2 > max_sq;
     };
+    // squared distance beyond which a cell cannot matter to this lane any more: its best so far (any candidate bounds
+    // the answer from above) or the caller's cut-off
+    auto cur_lim = [&]() { return fmin(best_i >= 0 ? static_cast<double>(best_d) : 1e300, max_sq); };
     int rmax = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) rmax = max(rmax, max(c[a], g.dim[a] - 1 - c[a]));
@@ -158,9 +161,9 @@ __device__ __forceinline__ bool nn_level_search(const NnGridDev& g, float x, flo
     }
     if (rmax == 0) return true;
     if (!finished(1)) {  // 2. rest of the 3x3x3 block
-        const double lim = fmin(best_i >= 0 ? static_cast<double>(best_d) : 1e300, max_sq);  // uniform within the group
         const double fx0 = flo[0] * flo[0], fx1 = fhi[0] * fhi[0];
         for (int j = sub; j < 9; j += G) {
+            const double lim = cur_lim();
             const int dz = j / 3 - 1, dy = j % 3 - 1;
             const int zz = c[2] + dz, yy = c[1] + dy;
             if (zz < 0 || zz >= g.dim[2] || yy < 0 || yy >= g.dim[1]) continue;
@@ -182,32 +185,41 @@ __device__ __forceinline__ bool nn_level_search(const NnGridDev& g, float x, flo
     const int rlast = min(rmax, max_ring);
     for (int r = 2; r <= rlast; ++r) {  // 3. rings
         if (finished(r)) return true;
-        const double lim = fmin(best_i >= 0 ? static_cast<double>(best_d) : 1e300, max_sq);
-        const int    w = 2 * r + 1;
-        // each x-row of the ring is one run (rows on a y/z face) or two single cells (x faces); the run bounds of
-        // kRows rows are fetched together so their latencies overlap — far rings are mostly empty rows
+        const int w = 2 * r + 1;
+        // each x-row of the ring is one run (rows on a y/z face) or two single cells (x faces), cut down to the chord of
+        // the sphere of the best distance so far; the run bounds of kRows rows are fetched together so their latencies
+        // overlap (far rings are mostly empty rows) and the group shares its best after every such batch
         constexpr int kRows = 4;
-        for (int j0 = sub; j0 < w * w; j0 += kRows * G) {
+        for (int j0 = 0; j0 < w * w; j0 += kRows * G) {
             uint32_t rb[kRows][2], re[kRows][2];
+            const double lim = cur_lim();
 #pragma unroll
             for (int u = 0; u < kRows; ++u) {
                 rb[u][0] = re[u][0] = rb[u][1] = re[u][1] = 0u;
-                const int j = j0 + u * G;
+                const int j = j0 + sub + u * G;
                 if (j >= w * w) continue;
                 const int dz = j / w - r, dy = j % w - r;
                 const int zz = c[2] + dz, yy = c[1] + dy;
                 if (zz < 0 || zz >= g.dim[2] || yy < 0 || yy >= g.dim[1]) continue;
                 const double ly = axis_lb(1, dy), lz = axis_lb(2, dz);
-                if ((ly * ly + lz * lz) * (1.0 - 1e-5) > lim) continue;
+                const double lyz = (ly * ly + lz * lz) * (1.0 - 1e-5);
+                if (lyz > lim) continue;
+                // cells k >= 1 to the left / right can matter while face + (k - 1) * cell <= hx
+                int kl = r, kr = r;
+                if (lim < 1e299) {
+                    const double hx = sqrt(lim - lyz) * (1.0 + 1e-5);
+                    kl = hx >= flo[0] ? static_cast<int>(fmin((hx - flo[0]) / static_cast<double>(g.cell), 1e9)) + 1 : 0;
+                    kr = hx >= fhi[0] ? static_cast<int>(fmin((hx - fhi[0]) / static_cast<double>(g.cell), 1e9)) + 1 : 0;
+                }
                 const uint32_t row = (static_cast<uint32_t>(zz) * g.dim[1] + yy) * g.dim[0];
                 if (dz == r || dz == -r || dy == r || dy == -r) {
-                    const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.dim[0] - 1);
+                    const int x0 = max(c[0] - min(r, kl), 0), x1 = min(c[0] + min(r, kr), g.dim[0] - 1);
                     rb[u][0] = g.cell_start[row + x0];
                     re[u][0] = g.cell_start[row + x1 + 1];
                 } else {
                     const int xa = c[0] - r, xb = c[0] + r;
-                    if (xa >= 0) { rb[u][0] = g.cell_start[row + xa]; re[u][0] = g.cell_start[row + xa + 1]; }
-                    if (xb < g.dim[0]) { rb[u][1] = g.cell_start[row + xb]; re[u][1] = g.cell_start[row + xb + 1]; }
+                    if (xa >= 0 && kl >= r) { rb[u][0] = g.cell_start[row + xa]; re[u][0] = g.cell_start[row + xa + 1]; }
+                    if (xb < g.dim[0] && kr >= r) { rb[u][1] = g.cell_start[row + xb]; re[u][1] = g.cell_start[row + xb + 1]; }
                 }
             }
 #pragma unroll
@@ -215,8 +227,8 @@ __device__ __forceinline__ bool nn_level_search(const NnGridDev& g, float x, flo
                 scan(rb[u][0], re[u][0]);
                 scan(rb[u][1], re[u][1]);
             }
+            nn_group_min<G>(best_d, best_i);
         }
-        nn_group_min<G>(best_d, best_i);
     }
     return rlast == rmax || finished(rlast + 1);
 }

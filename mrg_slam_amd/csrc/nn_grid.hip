@@ -279,7 +279,7 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     if (max_n == 0) return MRGFE_OK;
     constexpr uint32_t per_blk = 256u / kNnGroup;
     // enough blocks to fill the chip a few times over, few enough that the partial table stays small
-    const uint32_t want = static_cast<uint32_t>(std::max<size_t>(1, (size_t(ctx->cu_count) * 16 + count - 1) / count));
+    const uint32_t want = static_cast<uint32_t>(std::max<size_t>(1, (size_t(ctx->cu_count) * 128 + count - 1) / count));
     const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((max_n + per_blk - 1) / per_blk, want));
     DevBuf& dw = ctx->scratch[9];
     const size_t jobs_bytes = (sizeof(NnFitnessJob) * count + 255) & ~size_t(255);
