@@ -18,6 +18,7 @@ Output    = ONE JSON line (rank 0) with `roofline` (derivative kernel: algorithm
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -128,13 +129,20 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    # a full (generation 2) collection walks every object `import torch` created: ~40 ms, once, at an arbitrary step.
+    # Collect now and move the survivors to the permanent generation so the timed steps are not interrupted by it.
+    gc.collect()
+    gc.freeze()
     per_mode = np.zeros((3, 3))  # [mode] -> (device ms, launches, algorithmic bytes), HIP events around every launch
     evals = iters = 0
     pts_evals = 0.0
     src_sizes = np.array([len(scans[p[1]]) for p in pairs], dtype=np.float64)
     t0 = time.perf_counter()
+    step_ms = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         res = step()
+        step_ms.append(1e3 * (time.perf_counter() - ts))
         for m in range(3):
             per_mode[m] += bm.kernel_stats(m)
         evals += int(res["evaluations"].sum())
@@ -142,6 +150,7 @@ def main():
         iters += int(res["iterations"].sum())
     sync()
     elapsed = time.perf_counter() - t0
+    print(f"[bench rank {rank}] per-step ms: " + " ".join(f"{v:.2f}" for v in step_ms), file=sys.stderr)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
