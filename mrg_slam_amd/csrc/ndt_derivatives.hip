@@ -147,9 +147,10 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2
                                                                const NdtEvalDev* __restrict__ evals, double* __restrict__ partials, int ppt,
                                                                uint32_t spec_part_base)
 {
-    const NdtPairDev pr = pairs[blockIdx.y];
-    if (blockIdx.x >= pr.nblk) return;
-    const NdtEvalDev& ev = evals[blockIdx.y];
+    const uint32_t   pi = evals[blockIdx.y].order[MODE];  // the blockIdx.y-th pair this variant has work for
+    const NdtPairDev pr = pairs[pi];
+    if (blockIdx.x * static_cast<uint32_t>(kTilePts) * ppt >= pr.n_src) return;  // this launch gives every workgroup ppt tiles
+    const NdtEvalDev& ev = evals[pi];
     // the f64 Hessian variant also serves the speculative requests attached to mode-0 evaluations; their partial records
     // go to the second half of the partial buffer
     const bool spec = (MODE == 2) && ev.mode == 0 && ev.spec != 0;
@@ -257,7 +258,8 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2
         nb_total += (threadIdx.x == 0) ? total : 0u;
 
         // ---- phase 2: one lane per (point, voxel) pair -----------------------------------------------------------
-        // (a register-double-buffered prefetch of the next pair's record was measured slower: it costs the occupancy it saves)
+        // (prefetching the next pair's record was measured slower both as a register double buffer — it costs the occupancy it
+        // saves — and as an LDS-DMA into per-lane slots, -6 % / -13 % for the two float variants)
         for (uint32_t qi = threadIdx.x; qi < total; qi += kTilePts) {
             const uint32_t entry = s_queue[qi];
             const uint32_t slot = entry >> 24, lid = entry & 0x00FFFFFFu;
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2
 
 // fixed-order sum of the block partials of every active pair: 4 interleaved slices, then slice 0..3 in order
 __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __restrict__ pairs, const NdtEvalDev* __restrict__ evals, const double* __restrict__ partials,
-                                                          double* __restrict__ results, uint32_t spec_part_base, uint32_t spec_result_base)
+                                                          double* __restrict__ results, uint32_t spec_part_base, uint32_t spec_result_base, int ppt0, int ppt1, int ppt2)
 {
     // blockIdx.y == 1: the speculative f64 Hessian records of the pairs that asked for them
     const bool spec = blockIdx.y == 1;
@@ -334,11 +336,14 @@ __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __res
     const NdtEvalDev& ev = evals[blockIdx.x];
     if (!ev.active || (spec && !(ev.mode == 0 && ev.spec != 0))) return;
     if (spec) { pr.part_off += spec_part_base; results += (size_t)spec_result_base * kNdtPartialStride; }
+    // workgroups (= partial records) the derivative launch of this pair's kernel variant used
+    const uint32_t per_wg = 256u * static_cast<uint32_t>(spec || ev.mode == 2 ? ppt2 : (ev.mode == 1 ? ppt1 : ppt0));
+    const uint32_t nblk = (pr.n_src + per_wg - 1) / per_wg;
     __shared__ double s[4][kNdtPartialStride];
     const int k = threadIdx.x & 63, slice = threadIdx.x >> 6;
     if (k < kNdtPartialStride) {
         double acc = 0.0;
-        for (uint32_t b = slice; b < pr.nblk; b += 4) acc += partials[(size_t)(pr.part_off + b) * kNdtPartialStride + k];
+        for (uint32_t b = slice; b < nblk; b += 4) acc += partials[(size_t)(pr.part_off + b) * kNdtPartialStride + k];
         s[slice][k] = acc;
     }
     __syncthreads();
@@ -386,10 +391,11 @@ int ndt_launch_derivatives(mrgfe_ctx* ctx, int mode, int search, uint32_t max_nb
 }
 
 int ndt_launch_reduce(mrgfe_ctx* ctx, int npairs, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const double* d_partials, double* d_results, bool with_spec,
-                      uint32_t spec_part_base, uint32_t spec_result_base)
+                      uint32_t spec_part_base, uint32_t spec_result_base, const int ppt[3])
 {
     if (npairs == 0) return MRGFE_OK;
-    hipLaunchKernelGGL(ndt_reduce_kernel, dim3(npairs, with_spec ? 2 : 1), dim3(256), 0, ctx->stream, d_pairs, d_evals, d_partials, d_results, spec_part_base, spec_result_base);
+    hipLaunchKernelGGL(ndt_reduce_kernel, dim3(npairs, with_spec ? 2 : 1), dim3(256), 0, ctx->stream, d_pairs, d_evals, d_partials, d_results, spec_part_base, spec_result_base,
+                       ppt[0], ppt[1], ppt[2]);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }

@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 
 #include "ndt_derivatives.h"
@@ -324,14 +326,7 @@ int NdtEngine::read_leaves(int target, int32_t* keys, int32_t* nr_points, double
 int NdtEngine::upload_pairs()
 {
     const int P = n_pairs();
-    uint64_t total_pts = 0;
-    for (auto& p : pairs_) total_pts += p.n;
-    // enough workgroups to fill 256 CUs several times over, few enough that the block reduction amortises
-    const uint64_t target_blocks = uint64_t(ctx_->cu_count) * 16;
-    int ppt = static_cast<int>(total_pts / (256 * target_blocks));
-    ppt = std::max(1, std::min(ppt, 8));
-    if (const char* e = std::getenv("MRGFE_PPT")) ppt = std::max(1, std::min(std::atoi(e), 64));  // tuning experiments
-    ppt_ = ppt;
+    if (const char* e = std::getenv("MRGFE_PPT")) forced_ppt_ = std::max(1, std::min(std::atoi(e), 64));  // tuning experiments
     h_pairs_.resize(P);
     uint32_t part = 0;
     max_nblk_ = 0;
@@ -340,7 +335,7 @@ int NdtEngine::upload_pairs()
         d.src = pairs_[i].d_src;
         d.n_src = pairs_[i].n;
         d.grid = static_cast<uint32_t>(pairs_[i].target);
-        d.nblk = (pairs_[i].n + 256u * ppt - 1) / (256u * ppt);
+        d.nblk = (pairs_[i].n + 255u) / 256u;
         d.part_off = part;
         part += d.nblk;
         max_nblk_ = std::max(max_nblk_, d.nblk);
@@ -380,6 +375,18 @@ static void fill_eval(NdtEvalDev& e, const NdtRequest& r, const NdtController& c
 // batches at least this large are split into two alternating groups (each half still fills the GPU)
 static int pipeline_min_pairs() { const char* e = std::getenv("MRGFE_PIPELINE_MIN_PAIRS"); return e ? std::atoi(e) : 1 << 30; }  // measured on MI355X: alternating half-batches lose more to smaller launches than they hide
 
+// Tiles of 256 points per workgroup for a launch over `pts` source points: enough workgroups to fill the CUs several
+// times over, few enough that the 384-byte block reduction amortises.  Chosen per launch: the late rounds of a batch
+// have a few stragglers left, and those want one tile per workgroup to spread over the whole chip.
+int NdtEngine::tiles_per_workgroup(uint64_t pts) const
+{
+    if (forced_ppt_ > 0) return forced_ppt_;
+    static const int per_cu = [] { const char* e = std::getenv("MRGFE_WG_PER_CU"); return e ? std::max(1, std::atoi(e)) : 4; }();
+    static const int max_ppt = [] { const char* e = std::getenv("MRGFE_MAX_PPT"); return e ? std::max(1, std::atoi(e)) : 8; }();
+    const uint64_t target_blocks = uint64_t(ctx_->cu_count) * per_cu;
+    return static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(pts / (256 * target_blocks), max_ppt)));
+}
+
 int NdtEngine::launch_group(RoundGroup& g)
 {
     NdtEvalDev* he = h_evals_.as<NdtEvalDev>();
@@ -393,12 +400,29 @@ int NdtEngine::launch_group(RoundGroup& g)
         }
     });
     g.any_spec = false;
+    g.n_mode[0] = g.n_mode[1] = g.n_mode[2] = 0;
+    uint64_t mode_pts[3] = {0, 0, 0};
+    uint32_t mode_max_n[3] = {0, 0, 0};
     for (int i = g.first; i < g.first + g.count; ++i) {
         const NdtController& c = pairs_[i].ctl;
         if (c.done()) continue;
-        g.modes[c.request().mode] = true;
-        if (c.request().mode == 0 && c.request().spec_hessian) { g.modes[2] = true; g.any_spec = true; }
+        const int  m = c.request().mode;
+        const bool spec = m == 0 && c.request().spec_hessian;
+        he[g.first + g.n_mode[m]++].order[m] = static_cast<uint32_t>(i - g.first);
+        mode_pts[m] += pairs_[i].n;
+        mode_max_n[m] = std::max(mode_max_n[m], pairs_[i].n);
+        if (spec) {
+            he[g.first + g.n_mode[2]++].order[2] = static_cast<uint32_t>(i - g.first);
+            mode_pts[2] += pairs_[i].n;
+            mode_max_n[2] = std::max(mode_max_n[2], pairs_[i].n);
+            g.any_spec = true;
+        }
         ++active;
+    }
+    for (int m = 0; m < 3; ++m) {
+        g.modes[m] = g.n_mode[m] > 0;
+        g.ppt[m] = tiles_per_workgroup(mode_pts[m]);
+        g.nblk[m] = (mode_max_n[m] + 256u * g.ppt[m] - 1) / (256u * g.ppt[m]);
     }
     g.inflight = false;
     if (!active) return MRGFE_OK;
@@ -411,11 +435,11 @@ int NdtEngine::launch_group(RoundGroup& g)
     for (int m = 0; m < 3; ++m)
         if (g.modes[m]) {
             MRGFE_HIP_CHECK(hipEventRecord(g.ev[m][0], st));
-            MRGFE_TRY(ndt_launch_derivatives(ctx_, m, prm_.search, g.max_nblk, g.count, d_grids_.as<NdtGridDev>(), d_pr, d_ev, d_partials_.as<double>(), ppt_, total_part_blocks_));
+            MRGFE_TRY(ndt_launch_derivatives(ctx_, m, prm_.search, g.nblk[m], g.n_mode[m], d_grids_.as<NdtGridDev>(), d_pr, d_ev, d_partials_.as<double>(), g.ppt[m], total_part_blocks_));
             MRGFE_HIP_CHECK(hipEventRecord(g.ev[m][1], st));
         }
     const uint32_t P = static_cast<uint32_t>(n_pairs());
-    MRGFE_TRY(ndt_launch_reduce(ctx_, g.count, d_pr, d_ev, d_partials_.as<double>(), d_res, g.any_spec, total_part_blocks_, P));
+    MRGFE_TRY(ndt_launch_reduce(ctx_, g.count, d_pr, d_ev, d_partials_.as<double>(), d_res, g.any_spec, total_part_blocks_, P, g.ppt));
     MRGFE_HIP_CHECK(hipMemcpyAsync(h_results_.as<double>() + size_t(g.first) * kNdtPartialStride, d_res, sizeof(double) * kNdtPartialStride * g.count, hipMemcpyDeviceToHost, st));
     if (g.any_spec)
         MRGFE_HIP_CHECK(hipMemcpyAsync(h_results_.as<double>() + size_t(P + g.first) * kNdtPartialStride, d_res + size_t(P) * kNdtPartialStride,
@@ -494,11 +518,10 @@ int NdtEngine::align_all()
         g.first = k == 0 ? 0 : split;
         g.count = k == 0 ? split : P - split;
         g.inflight = false;
-        g.max_nblk = 0;
-        for (int i = g.first; i < g.first + g.count; ++i) g.max_nblk = std::max(g.max_nblk, h_pairs_[i].nblk);
     }
     // every controller needs at most (max_iterations + 2) * (max line-search trials + 2) evaluations
     const int round_cap = (prm_.max_iterations + 3) * 13 + 8;
+    static const bool trace = std::getenv("MRGFE_TRACE") != nullptr;  // per-round host timings on stderr
     for (int k = 0; k < n_groups; ++k) MRGFE_TRY(launch_group(groups_[k]));
     for (int round = 0; round < round_cap; ++round) {
         bool any = false;
@@ -506,8 +529,16 @@ int NdtEngine::align_all()
             RoundGroup& g = groups_[k];
             if (!g.inflight) continue;
             any = true;
+            const auto t0 = std::chrono::steady_clock::now();
+            MRGFE_HIP_CHECK(hipEventSynchronize(g.done));
+            const auto t1 = std::chrono::steady_clock::now();
             MRGFE_TRY(finish_group(g));
+            const auto t2 = std::chrono::steady_clock::now();
             MRGFE_TRY(launch_group(g));  // no-op when every pair of the group is done
+            const auto t3 = std::chrono::steady_clock::now();
+            if (trace) std::fprintf(stderr, "[mrgfe round %d] wait %.0f us, finish %.0f us, launch %.0f us, busy pairs %d/%d/%d\n", round,
+                                    std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(),
+                                    std::chrono::duration<double, std::micro>(t3 - t2).count(), g.n_mode[0], g.n_mode[1], g.n_mode[2]);
         }
         if (!any) return MRGFE_OK;
     }
@@ -535,11 +566,13 @@ int NdtEngine::evaluate(int pair, const float T[16], const double p[6], int mode
     NdtEvalDev* he = h_evals_.as<NdtEvalDev>();
     for (int i = 0; i < P; ++i) he[i].active = 0;
     fill_eval(he[pair], r, tmp, prm_.search, true);
+    he[0].order[mode] = static_cast<uint32_t>(pair);
     hipStream_t st = ctx_->stream;
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));
-    MRGFE_TRY(ndt_launch_derivatives(ctx_, mode, prm_.search, max_nblk_, P, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(),
-                                     d_partials_.as<double>(), ppt_, total_part_blocks_));
-    MRGFE_TRY(ndt_launch_reduce(ctx_, P, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_partials_.as<double>(), d_results_.as<double>(), false, 0, 0));
+    const int ppt1[3] = {1, 1, 1};
+    MRGFE_TRY(ndt_launch_derivatives(ctx_, mode, prm_.search, h_pairs_[pair].nblk, 1, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(),
+                                     d_partials_.as<double>(), 1, total_part_blocks_));
+    MRGFE_TRY(ndt_launch_reduce(ctx_, P, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_partials_.as<double>(), d_results_.as<double>(), false, 0, 0, ppt1));
     MRGFE_HIP_CHECK(hipMemcpyAsync(h_results_.p, d_results_.p, sizeof(double) * kNdtPartialStride * P, hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
     const double* res = h_results_.as<double>() + size_t(pair) * kNdtPartialStride;

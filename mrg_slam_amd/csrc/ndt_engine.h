@@ -89,7 +89,8 @@ class NdtEngine {
     PinBuf h_evals_, h_results_;
     bool   pairs_dirty_ = true;
     bool   force_hash_ = false;
-    int    ppt_ = 1;
+    int    forced_ppt_ = 0;  // MRGFE_PPT tuning hook (0: chosen per launch)
+    int    tiles_per_workgroup(uint64_t pts) const;
     uint32_t max_nblk_ = 0;
     uint32_t total_part_blocks_ = 0;
     std::vector<NdtPairDev> h_pairs_;
@@ -100,9 +101,11 @@ class NdtEngine {
     // a contiguous range of pairs whose rounds are launched and collected together (see align_all)
     struct RoundGroup {
         int        first = 0, count = 0;
-        uint32_t   max_nblk = 0;
+        int        ppt[3] = {1, 1, 1};   // tiles per workgroup of this round's launch of each variant
+        uint32_t   nblk[3] = {0, 0, 0};  // grid.x of each launch
         bool       inflight = false;
         bool       modes[3] = {false, false, false};
+        int        n_mode[3] = {0, 0, 0};  // pairs each kernel variant has work for this round
         bool       any_spec = false;
         hipEvent_t done = nullptr;
         hipEvent_t ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};

@@ -66,7 +66,7 @@ struct NdtPairDev {
     uint32_t      n_src;
     uint32_t      grid;    // index into the NdtGridDev array
     uint32_t      part_off;  // first block-partial record of this pair
-    uint32_t      nblk;      // workgroups of this pair per evaluation
+    uint32_t      nblk;      // block-partial records reserved for this pair: ceil(n_src / 256), the workgroups of a launch with one tile per workgroup
 };
 
 // per-evaluation part, rewritten by the host controller before every launch
@@ -81,6 +81,11 @@ struct NdtEvalDev {
     int32_t  active;       // 0: this pair is finished or waiting, its workgroups exit immediately
     int32_t  search;       // mrgfe_ndt_search
     int32_t  spec;         // 1 with mode 0: also run the f64 Hessian pass at this pose (speculative computeHessian)
+    // launch compaction: entry k of the array names the k-th pair (index into the same array) that kernel variant m has
+    // work for this round, so a variant's grid has one y-slice per busy pair instead of one per pair of the batch
+    // (dispatching tens of thousands of workgroups that exit at once costs ~100 us per launch on MI355X)
+    uint32_t order[3];
+    uint32_t pad;
 };
 
 // block partial / final result of one evaluation: score, gradient(6), full 6x6 Hessian(36, row-major), neighbour count.
