@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstdlib>
+#include <atomic>
 #include <thread>
 
 namespace mrgfe {
@@ -84,84 +85,113 @@ void Arena::release()
 }
 
 namespace {
+// A handful of persistent workers.  Between the rounds of an alignment batch they SPIN on the epoch counter (a round
+// comes every millisecond or so and a condition-variable wake-up costs 30-60 us on a large host, as much as the work
+// it hands out); outside host_parallel_hot(true) .. (false) they sleep on the condition variable.
 class HostPool {
    public:
     HostPool()
     {
-        unsigned hw = std::thread::hardware_concurrency();
-        int n = 0;  // off unless MRGFE_HOST_THREADS asks: on a 256-thread host the wake-ups cost more than they save (measured)
-        (void)hw;
-        if (const char* e = std::getenv("MRGFE_HOST_THREADS")) n = std::atoi(e) - 1;
-        n = n < 0 ? 0 : (n > 7 ? 7 : n);
-        for (int i = 0; i < n; ++i) workers_.emplace_back([this, i] { loop(i); });
+        int n = 8;  // total threads, the caller included
+        if (const char* e = std::getenv("MRGFE_HOST_THREADS")) n = std::atoi(e);
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw && static_cast<unsigned>(n) > hw) n = static_cast<int>(hw);
+        n = n < 1 ? 1 : (n > 8 ? 8 : n);
+        for (int i = 0; i < n - 1; ++i) workers_.emplace_back([this, i] { loop(i); });
     }
     ~HostPool()
     {
         {
             std::lock_guard<std::mutex> lk(mu_);
-            stop_ = true;
-            ++epoch_;
+            stop_.store(true);
+            epoch_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
         for (auto& t : workers_) t.join();
+    }
+    void set_hot(bool hot)  // counted: several contexts may be inside a batch at once
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            hot_.fetch_add(hot ? 1 : -1, std::memory_order_release);
+        }
+        if (hot) cv_.notify_all();
     }
     void run(int n, const std::function<void(int, int)>& body)
     {
         const int parts = static_cast<int>(workers_.size()) + 1;
         const int chunk = (n + parts - 1) / parts;
+        body_ = &body;
+        n_ = n;
+        chunk_ = chunk;
+        pending_.store(static_cast<int>(workers_.size()), std::memory_order_relaxed);
         {
-            std::lock_guard<std::mutex> lk(mu_);
-            body_ = &body;
-            n_ = n;
-            chunk_ = chunk;
-            pending_ = static_cast<int>(workers_.size());
-            ++epoch_;
+            std::lock_guard<std::mutex> lk(mu_);  // pairs with the predicate check of a sleeping worker
+            epoch_.fetch_add(1, std::memory_order_release);
         }
-        cv_.notify_all();
+        if (hot_.load(std::memory_order_relaxed) <= 0) cv_.notify_all();
         body(0, chunk < n ? chunk : n);  // the caller takes the first chunk
-        std::unique_lock<std::mutex> lk(mu_);
-        done_cv_.wait(lk, [this] { return pending_ == 0; });
+        while (pending_.load(std::memory_order_acquire) != 0) cpu_relax();
         body_ = nullptr;
     }
     int size() const { return static_cast<int>(workers_.size()) + 1; }
 
    private:
+    static void cpu_relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
     void loop(int id)
     {
         uint64_t seen = 0;
         for (;;) {
-            std::unique_lock<std::mutex> lk(mu_);
-            cv_.wait(lk, [&] { return epoch_ != seen; });
-            seen = epoch_;
-            if (stop_) return;
+            while (epoch_.load(std::memory_order_acquire) == seen) {
+                if (hot_.load(std::memory_order_relaxed) > 0) { cpu_relax(); continue; }
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return epoch_.load(std::memory_order_acquire) != seen || hot_.load(std::memory_order_relaxed) > 0; });
+            }
+            seen = epoch_.load(std::memory_order_acquire);
+            if (stop_.load()) return;
             const std::function<void(int, int)>* body = body_;
             const int b = (id + 1) * chunk_, e = std::min(n_, (id + 2) * chunk_);
-            lk.unlock();
             if (body && b < e) (*body)(b, e);
-            lk.lock();
-            if (--pending_ == 0) done_cv_.notify_one();
+            pending_.fetch_sub(1, std::memory_order_release);
         }
     }
     std::vector<std::thread> workers_;
     std::mutex mu_;
-    std::condition_variable cv_, done_cv_;
+    std::condition_variable cv_;
     const std::function<void(int, int)>* body_ = nullptr;
-    int n_ = 0, chunk_ = 0, pending_ = 0;
-    uint64_t epoch_ = 0;
-    bool stop_ = false;
+    int n_ = 0, chunk_ = 0;
+    std::atomic<int>      pending_{0};
+    std::atomic<uint64_t> epoch_{0};
+    std::atomic<bool>     stop_{false};
+    std::atomic<int>      hot_{0};
 };
 std::mutex g_pool_mu;  // one parallel region at a time (contexts on different GPUs share the pool)
+HostPool& host_pool()
+{
+    static HostPool pool;
+    return pool;
+}
 }  // namespace
 
 void host_parallel_for(int n, int min_serial, const std::function<void(int, int)>& body)
 {
     if (n <= 0) return;
     if (n < min_serial) { body(0, n); return; }
-    static HostPool pool;
+    HostPool& pool = host_pool();
     if (pool.size() == 1) { body(0, n); return; }
-    std::lock_guard<std::mutex> lk(g_pool_mu);
+    std::unique_lock<std::mutex> lk(g_pool_mu, std::try_to_lock);
+    if (!lk.owns_lock()) { body(0, n); return; }  // another context is inside a parallel region: do not wait for it
     pool.run(n, body);
 }
+
+void host_parallel_hot(bool hot) { host_pool().set_hot(hot); }
 
 int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, void* d_dst, int pin_slot)
 {

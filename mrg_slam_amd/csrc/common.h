@@ -54,6 +54,8 @@ struct PinBuf {
 // persistent host worker threads for the per-pair controller steps of large batches (a 6x6 SVD solve and the line-search
 // bookkeeping per pair and round: ~3 us each, which adds up to the kernel time of a round once a batch has >100 pairs)
 void host_parallel_for(int n, int min_serial, const std::function<void(int, int)>& body);
+// workers spin between host_parallel_for calls while hot (set around the rounds of a large alignment batch), sleep otherwise
+void host_parallel_hot(bool hot);
 
 // bump allocator over a few large device chunks; pointers stay valid until reset()
 struct Arena {

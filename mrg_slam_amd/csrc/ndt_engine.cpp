@@ -373,6 +373,8 @@ static void fill_eval(NdtEvalDev& e, const NdtRequest& r, const NdtController& c
 // group's derivative kernels are already queued, so the GPU does not idle during host turnarounds.  Both groups use
 // the same stream: kernels never overlap each other and the per-launch HIP-event timings stay clean.
 // batches at least this large are split into two alternating groups (each half still fills the GPU)
+constexpr int kHostParallelMinPairs = 48;  // below this the controller steps of a round run on the calling thread
+
 static int pipeline_min_pairs() { const char* e = std::getenv("MRGFE_PIPELINE_MIN_PAIRS"); return e ? std::atoi(e) : 1 << 30; }  // measured on MI355X: alternating half-batches lose more to smaller launches than they hide
 
 // Tiles of 256 points per workgroup for a launch over `pts` source points: enough workgroups to fill the CUs several
@@ -392,7 +394,7 @@ int NdtEngine::launch_group(RoundGroup& g)
     NdtEvalDev* he = h_evals_.as<NdtEvalDev>();
     g.modes[0] = g.modes[1] = g.modes[2] = false;
     int active = 0;
-    host_parallel_for(g.count, 48, [&](int b, int e) {
+    host_parallel_for(g.count, kHostParallelMinPairs, [&](int b, int e) {
         for (int i = g.first + b; i < g.first + e; ++i) {
             NdtController& c = pairs_[i].ctl;
             if (c.done()) he[i].active = 0;
@@ -473,7 +475,7 @@ int NdtEngine::finish_group(RoundGroup& g)
     }
     const size_t spec_base = size_t(n_pairs()) * kNdtPartialStride;
     // controller steps are independent per pair: spread them over the host worker threads for large batches
-    host_parallel_for(g.count, 48, [&](int b, int e) {
+    host_parallel_for(g.count, kHostParallelMinPairs, [&](int b, int e) {
         for (int i = g.first + b; i < g.first + e; ++i) {
             NdtController& c = pairs_[i].ctl;
             if (c.done()) continue;
@@ -496,6 +498,12 @@ int NdtEngine::align_all()
     }
     const int P = n_pairs();
     if (P == 0) return MRGFE_OK;
+    // large batches: keep the host workers spinning between rounds (see host_parallel_for)
+    struct HotGuard {
+        bool on;
+        explicit HotGuard(bool o) : on(o) { if (on) host_parallel_hot(true); }
+        ~HotGuard() { if (on) host_parallel_hot(false); }
+    } hot_guard(P >= kHostParallelMinPairs);
     // groups: two halves of (roughly) equal point count once the batch is large enough to keep the GPU busy with one
     const int n_groups = P >= pipeline_min_pairs() ? 2 : 1;
     if (groups_.size() < 2) {
