@@ -142,6 +142,27 @@ int mrgfe_statistical_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_
 int mrgfe_calc_fitness_score(mrgfe_ctx* ctx, const float* cloud1, size_t n1, const float* cloud2, size_t n2, size_t stride_bytes,
                              const double relpose[16], double max_range, double* out);
 
+/* ---- per-point passes around the path ------------------------------------------------ */
+/* replaces MapCloudGenerator::generate (src/mrg_slam/map_cloud_generator.cpp:14-86) including its
+ * pcl::ApproximateMeanVoxelGrid pass (include/pcl/filters/ApproximateMeanVoxelGrid.hpp:63-126): every keyframe cloud is
+ * moved by its pose (poses: n_keyframes column-major 4x4 doubles, Eigen::Isometry3d::matrix()), points farther than
+ * distance_far_thresh (if > 0) from their sensor are dropped, the union is voxel-filtered (true mean of x, y, z,
+ * intensity per voxel of edge `resolution`, voxels with fewer than min_points_per_voxel points dropped; resolution <= 0
+ * returns the unfiltered union).  first_keyframe (may be NULL) marks the clouds skip_first_cloud leaves out.
+ * Output order: ascending voxel index (z, y, x) — the reference emits boost::unordered_map order, which is unspecified.
+ * Returns MRGFE_ERR_EMPTY where the reference returns nullptr (no keyframes; or nothing left although n_keyframes > 1),
+ * MRGFE_ERR_INVALID with *out_n = needed points when capacity is too small. */
+int mrgfe_map_cloud_generate(mrgfe_ctx* ctx, int n_keyframes, const float* const* clouds_xyzi, const size_t* n_points, size_t stride_bytes, const double* poses,
+                             const uint8_t* first_keyframe, float resolution, int min_points_per_voxel, float distance_far_thresh, int skip_first_cloud,
+                             float* out_xyzi, size_t capacity, size_t* out_n);
+/* replaces the other-robot point removal of apps/mrg_slam_component.cpp:396-429: drops every point whose squared float
+ * distance to one of the centres (sensor frame, <= 64) is < radius_sqr; kept / removed (may be NULL) keep the input order */
+int mrgfe_remove_points_near(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, const float* centres_xyz, int n_centres, float radius_sqr,
+                             float* kept_xyzi, size_t* n_kept, float* removed_xyzi, size_t* n_removed);
+/* replaces PrefilteringComponent::deskewing (apps/prefiltering_component.cpp:231-292): point i is rotated by the inverse of
+ * Quaternionf(1, dt/2 * -w) with dt = scan_period * i / n and w the IMU angular velocity */
+int mrgfe_deskew(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, const float ang_v_xyz[3], double scan_period, float* out_xyzi);
+
 /* ---- batched candidate matching (LoopDetector::matching candidate loop, src/mrg_slam/loop_detector.cpp:126-145) ---- */
 typedef struct mrgfe_pair_result {
     float   T[16];      /* final transformation, column-major                */

@@ -99,6 +99,10 @@ SIGNATURES = {
     "mrgfe_radius_outlier": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, C.c_double, C.c_int, _fp, _szp]),
     "mrgfe_statistical_outlier": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, C.c_int, C.c_double, _fp, _szp]),
     "mrgfe_calc_fitness_score": (C.c_int, [_vp, _fp, C.c_size_t, _fp, C.c_size_t, C.c_size_t, _dp, C.c_double, _dp]),
+    "mrgfe_map_cloud_generate": (C.c_int, [_vp, C.c_int, C.POINTER(_fp), _szp, C.c_size_t, _dp, C.POINTER(C.c_uint8), C.c_float, C.c_int, C.c_float, C.c_int, _fp,
+                                           C.c_size_t, _szp]),
+    "mrgfe_remove_points_near": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, _fp, C.c_int, C.c_float, _fp, _szp, _fp, _szp]),
+    "mrgfe_deskew": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, _fp, C.c_double, _fp]),
     "mrgfe_batch_create": (C.c_int, [_vp, C.POINTER(RegParams), C.POINTER(_vp)]),
     "mrgfe_batch_destroy": (None, [_vp]),
     "mrgfe_batch_clear": (C.c_int, [_vp]),

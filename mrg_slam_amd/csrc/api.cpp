@@ -10,6 +10,7 @@
 #include "cellsort.h"
 #include "common.h"
 #include "filters.h"
+#include "mapcloud.h"
 #include "gicp_engine.h"
 #include "ndt_engine.h"
 #include "nn_grid.h"
@@ -395,6 +396,100 @@ int mrgfe_calc_fitness_score(mrgfe_ctx* ctx, const float* cloud1, size_t n1, con
         st = g.fitness(ctx, d2.as<float4>(), n2, T, max_range, out);
     }
     return st;
+}
+
+// ---- map cloud, other-robot removal, deskewing --------------------------------------------------------------------
+int mrgfe_map_cloud_generate(mrgfe_ctx* ctx, int K, const float* const* clouds, const size_t* n_points, size_t stride, const double* poses, const uint8_t* first_keyframe,
+                             float resolution, int min_points_per_voxel, float distance_far_thresh, int skip_first_cloud, float* out, size_t capacity, size_t* out_n)
+{
+    if (!ctx || !out_n || (K > 0 && (!clouds || !n_points || !poses))) { set_error("mrgfe_map_cloud_generate: NULL argument"); return MRGFE_ERR_INVALID; }
+    *out_n = 0;
+    if (K <= 0) { set_error("keyframes are empty, cannot generate map cloud"); return MRGFE_ERR_EMPTY; }  // map_cloud_generator.cpp:19-22
+    MRGFE_LOCK(ctx);
+    MRGFE_TRY(ctx->bind());
+    std::vector<uint32_t> off(1, 0u);
+    std::vector<float>    pose_f;
+    std::vector<int>      used;
+    uint64_t total = 0;
+    for (int k = 0; k < K; ++k) {
+        if (first_keyframe && first_keyframe[k] && skip_first_cloud) continue;  // :32-34
+        if (n_points[k] && !clouds[k]) { set_error("mrgfe_map_cloud_generate: NULL cloud %d", k); return MRGFE_ERR_INVALID; }
+        total += n_points[k];
+        if (total > 0x7fffffffu) { set_error("mrgfe_map_cloud_generate: more than 2^31 points"); return MRGFE_ERR_INVALID; }
+        used.push_back(k);
+        off.push_back(static_cast<uint32_t>(total));
+        for (int t = 0; t < 16; ++t) pose_f.push_back(static_cast<float>(poses[16 * k + t]));  // pose.matrix().cast<float>()
+    }
+    size_t m = 0, unfiltered = 0;
+    int    rc = MRGFE_OK;
+    DevBuf dcat, dout;
+    if (total) {
+        rc = dcat.ensure(total * 16);
+        if (rc == MRGFE_OK) rc = dout.ensure(total * 16);
+        for (size_t u = 0; u < used.size() && rc == MRGFE_OK; ++u)
+            if (n_points[used[u]]) rc = upload_cloud(ctx, clouds[used[u]], n_points[used[u]], stride, dcat.as<char>() + size_t(off[u]) * 16);
+        if (rc == MRGFE_OK)
+            rc = map_cloud_device(ctx, dcat.as<float4>(), off.data(), pose_f.data(), static_cast<int>(used.size()), resolution, min_points_per_voxel, distance_far_thresh,
+                                  dout.as<float4>(), &m, &unfiltered);
+    }
+    // :57-60: the cloud BEFORE the voxel filter decides
+    if (rc == MRGFE_OK && unfiltered == 0 && K > 1) { set_error("cloud is empty after processing keyframes"); rc = MRGFE_ERR_EMPTY; }
+    if (rc == MRGFE_OK && m > capacity) { *out_n = m; set_error("mrgfe_map_cloud_generate: output needs %zu points, capacity is %zu", m, capacity); rc = MRGFE_ERR_INVALID; }
+    if (rc == MRGFE_OK && m) {
+        if (!out) { set_error("mrgfe_map_cloud_generate: NULL output"); rc = MRGFE_ERR_INVALID; }
+        else if (hipMemcpyAsync(out, dout.p, m * 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            set_error("mrgfe_map_cloud_generate: device to host copy failed");
+            rc = MRGFE_ERR_HIP;
+        }
+    }
+    if (rc == MRGFE_OK) *out_n = m;
+    dcat.release();
+    dout.release();
+    return rc;
+}
+
+int mrgfe_remove_points_near(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, const float* centres, int n_centres, float radius_sqr, float* kept, size_t* n_kept,
+                             float* removed, size_t* n_removed)
+{
+    if (!ctx || !n_kept || (n && (!xyzi || !kept)) || (n_centres > 0 && !centres) || n_centres < 0) { set_error("mrgfe_remove_points_near: bad argument"); return MRGFE_ERR_INVALID; }
+    *n_kept = 0;
+    if (n_removed) *n_removed = 0;
+    if (n == 0) return MRGFE_OK;
+    MRGFE_LOCK(ctx);
+    MRGFE_TRY(ctx->bind());
+    DevBuf din, dk, dr;
+    int rc = din.ensure(n * 16);
+    if (rc == MRGFE_OK) rc = dk.ensure(n * 16);
+    if (rc == MRGFE_OK && removed) rc = dr.ensure(n * 16);
+    if (rc == MRGFE_OK) rc = upload_cloud(ctx, xyzi, n, stride, din.p);
+    size_t nk = 0, nr = 0;
+    if (rc == MRGFE_OK) rc = remove_points_near_device(ctx, din.as<float4>(), n, centres, n_centres, radius_sqr, dk.as<float4>(), &nk, removed ? dr.as<float4>() : nullptr, &nr);
+    if (rc == MRGFE_OK && nk && hipMemcpyAsync(kept, dk.p, nk * 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = MRGFE_ERR_HIP;
+    if (rc == MRGFE_OK && removed && nr && hipMemcpyAsync(removed, dr.p, nr * 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = MRGFE_ERR_HIP;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == MRGFE_OK) rc = MRGFE_ERR_HIP;
+    if (rc == MRGFE_ERR_HIP) set_error("mrgfe_remove_points_near: device to host copy failed");
+    if (rc == MRGFE_OK) { *n_kept = nk; if (n_removed) *n_removed = nr; }
+    din.release(); dk.release(); dr.release();
+    return rc;
+}
+
+int mrgfe_deskew(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, const float ang_v[3], double scan_period, float* out)
+{
+    if (!ctx || !ang_v || (n && (!xyzi || !out))) { set_error("mrgfe_deskew: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (n == 0) return MRGFE_OK;
+    MRGFE_LOCK(ctx);
+    MRGFE_TRY(ctx->bind());
+    DevBuf din, dout;
+    int rc = din.ensure(n * 16);
+    if (rc == MRGFE_OK) rc = dout.ensure(n * 16);
+    if (rc == MRGFE_OK) rc = upload_cloud(ctx, xyzi, n, stride, din.p);
+    if (rc == MRGFE_OK) rc = deskew_device(ctx, din.as<float4>(), n, ang_v, scan_period, dout.as<float4>());
+    if (rc == MRGFE_OK && (hipMemcpyAsync(out, dout.p, n * 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+        set_error("mrgfe_deskew: device to host copy failed");
+        rc = MRGFE_ERR_HIP;
+    }
+    din.release(); dout.release();
+    return rc;
 }
 
 // ---- batch ------------------------------------------------------------------------------------------------------

@@ -10,6 +10,10 @@ int filter_voxelgrid_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, float 
 int filter_radius_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, double radius, int min_neighbors, float4* d_out, size_t* out_n);
 int filter_statistical_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, int mean_k, double stddev_mul, float4* d_out, size_t* out_n);
 
+// order-preserving compaction of the points whose flag is 1 (exclusive scan of the flags + scatter); synchronises and
+// returns the kept count.  Uses ctx scratch slots 0, 4 and 8.
+int compact_by_flags(mrgfe_ctx* ctx, const float4* d_in, uint32_t n, uint32_t* d_flags, float4* d_out, uint32_t* h_total);
+
 int filter_distance(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double near_t, double far_t, float* out, size_t* out_n);
 int filter_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, float leaf, int min_pts, float* out, size_t* out_n, int* overflow);
 int filter_radius_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double radius, int min_neighbors, float* out, size_t* out_n);

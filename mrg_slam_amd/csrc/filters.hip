@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const float4* __restrict__
 }
 
 // scan flags (one problem) and compact; returns the kept count through *h_total (synchronises)
-static int scan_and_compact(mrgfe_ctx* ctx, const float4* d_in, uint32_t n, uint32_t* d_flags, float4* d_out, uint32_t* h_total)
+int compact_by_flags(mrgfe_ctx* ctx, const float4* d_in, uint32_t n, uint32_t* d_flags, float4* d_out, uint32_t* h_total)
 {
     *h_total = 0;
     if (n == 0) return MRGFE_OK;
@@ -76,7 +76,7 @@ int filter_distance_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, double 
     MRGFE_TRY(dfl.ensure(n * 4));
     hipLaunchKernelGGL(distance_flags_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, d_in, nn, near_t, far_t, dfl.as<uint32_t>());
     uint32_t kept = 0;
-    MRGFE_TRY(scan_and_compact(ctx, d_in, nn, dfl.as<uint32_t>(), d_out, &kept));
+    MRGFE_TRY(compact_by_flags(ctx, d_in, nn, dfl.as<uint32_t>(), d_out, &kept));
     *out_n = kept;
     return MRGFE_OK;
 }
@@ -175,7 +175,7 @@ int filter_voxelgrid_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, float 
     hipLaunchKernelGGL(voxel_centroid_kernel, dim3((V + 255) / 256), dim3(256), 0, st, d_in, sv, d_seg, V, min_pts, dcent.as<float4>(), dkeep.as<uint32_t>());
     MRGFE_HIP_CHECK(hipGetLastError());
     uint32_t kept = 0;
-    MRGFE_TRY(scan_and_compact(ctx, dcent.as<float4>(), V, dkeep.as<uint32_t>(), d_out, &kept));
+    MRGFE_TRY(compact_by_flags(ctx, dcent.as<float4>(), V, dkeep.as<uint32_t>(), d_out, &kept));
     *out_n = kept;
     return MRGFE_OK;
 }
@@ -193,7 +193,7 @@ int filter_radius_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, d
         // inlier iff #{q: (double)sqdist <= radius*radius} >= min_neighbors + 1 (the point itself counts)
         if (st == MRGFE_OK) st = grid.radius_count_flags(ctx, d_in, n, radius * radius, min_neighbors + 1, dfl.as<uint32_t>());
         uint32_t kept = 0;
-        if (st == MRGFE_OK) st = scan_and_compact(ctx, d_in, static_cast<uint32_t>(n), dfl.as<uint32_t>(), d_out, &kept);
+        if (st == MRGFE_OK) st = compact_by_flags(ctx, d_in, static_cast<uint32_t>(n), dfl.as<uint32_t>(), d_out, &kept);
         *out_n = kept;
     }
     return st;
@@ -268,7 +268,7 @@ int filter_statistical_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t
     if (rc == MRGFE_OK) {
         hipLaunchKernelGGL(sor_flags_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, d_dist, nn, thr, dfl.as<uint32_t>());
         uint32_t kept = 0;
-        rc = scan_and_compact(ctx, d_in, nn, dfl.as<uint32_t>(), d_out, &kept);
+        rc = compact_by_flags(ctx, d_in, nn, dfl.as<uint32_t>(), d_out, &kept);
         *out_n = kept;
     }
     cleanup();

@@ -42,6 +42,9 @@ def lib():
             "orc_voxelgrid": (C.c_int, [fp, C.c_int, C.c_float, C.c_int, C.c_int, fp, ip]),
             "orc_radius_outlier": (C.c_int, [fp, C.c_int, C.c_double, C.c_int, fp, u8p]),
             "orc_statistical_outlier": (C.c_int, [fp, C.c_int, C.c_int, C.c_double, fp, u8p]),
+            "orc_map_cloud_generate": (C.c_int, [C.c_int, C.POINTER(fp), ip, dp, u8p, C.c_float, C.c_int, C.c_float, C.c_int, fp, ip]),
+            "orc_remove_points_near": (C.c_int, [fp, C.c_int, fp, C.c_int, C.c_float, fp, fp, ip]),
+            "orc_deskew": (None, [fp, C.c_int, fp, C.c_double, fp]),
             "orc_knn": (None, [fp, C.c_int, fp, C.c_int, C.c_int, ip, fp]),
             "orc_nn1_brute": (None, [fp, C.c_int, fp, C.c_int, ip, fp]),
             "orc_calc_fitness_score": (C.c_double, [fp, C.c_int, fp, C.c_int, dp, C.c_double]),
@@ -146,6 +149,40 @@ def statistical_outlier(cloud, mean_k=30, stddev_mul=1.2):
     keep = np.zeros(len(c), dtype=np.uint8)
     m = lib().orc_statistical_outlier(_pf(c), len(c), mean_k, stddev_mul, _pf(out), keep.ctypes.data_as(C.POINTER(C.c_ubyte)))
     return out[:m].copy(), keep.astype(bool)
+
+
+def map_cloud_generate(clouds, poses, first_keyframe=None, resolution=0.1, min_points_per_voxel=1, distance_far_thresh=10000.0, skip_first_cloud=False):
+    """MapCloudGenerator::generate; returns (cloud, status): status 0 ok, -1 no keyframes, -2 empty after processing."""
+    cs = [_cloud(c) for c in clouds]
+    K = len(cs)
+    ptrs = (C.POINTER(C.c_float) * max(K, 1))(*[_pf(c) for c in cs])
+    ns = np.array([len(c) for c in cs], dtype=np.int32)
+    P = np.ascontiguousarray(np.stack([np.asarray(T, dtype=np.float64).T.reshape(16) for T in poses]) if K else np.zeros((0, 16)))
+    fk = None if first_keyframe is None else np.ascontiguousarray(np.asarray(first_keyframe, dtype=np.uint8))
+    out = np.empty((max(int(ns.sum()), 1), 4), dtype=np.float32)
+    m = C.c_int(0)
+    status = lib().orc_map_cloud_generate(K, ptrs, _pi(ns), _pd(P), None if fk is None else fk.ctypes.data_as(C.POINTER(C.c_ubyte)), resolution, min_points_per_voxel,
+                                          distance_far_thresh, int(skip_first_cloud), _pf(out), C.byref(m))
+    return out[: m.value].copy(), status
+
+
+def remove_points_near(cloud, centres, radius):
+    """other-robot point removal (mrg_slam_component.cpp:396-429); radius_sqr = float(radius * radius) like the reference.
+    Returns (kept, removed)."""
+    c = _cloud(cloud)
+    ctr = np.ascontiguousarray(np.asarray(centres, dtype=np.float32).reshape(-1, 3))
+    out, rem = np.empty_like(c), np.empty_like(c)
+    nr = C.c_int(0)
+    kept = lib().orc_remove_points_near(_pf(c), len(c), _pf(ctr), len(ctr), float(np.float32(float(radius) * float(radius))), _pf(out), _pf(rem), C.byref(nr))
+    return out[:kept].copy(), rem[: nr.value].copy()
+
+
+def deskew(cloud, ang_v, scan_period=0.1):
+    c = _cloud(cloud)
+    out = np.empty_like(c)
+    av = np.ascontiguousarray(np.asarray(ang_v, dtype=np.float32))
+    lib().orc_deskew(_pf(c), len(c), _pf(av), float(scan_period), _pf(out))
+    return out
 
 
 def knn(target, query, k):

@@ -9,6 +9,7 @@
 #include "filters.h"
 #include "gicp.h"
 #include "linalg.h"
+#include "mapcloud.h"
 #include "ndt.h"
 #include "nn.h"
 
@@ -21,6 +22,18 @@ int orc_distance_filter(const float* in, int n, double near_thresh, double far_t
 int orc_voxelgrid(const float* in, int n, float leaf, int min_pts, int order_mode, float* out, int* out_n) { return voxelgrid(in, n, leaf, min_pts, order_mode, out, out_n); }
 int orc_radius_outlier(const float* in, int n, double radius, int min_neighbors, float* out, unsigned char* keep) { return radius_outlier(in, n, radius, min_neighbors, out, keep); }
 int orc_statistical_outlier(const float* in, int n, int mean_k, double stddev_mul, float* out, unsigned char* keep) { return statistical_outlier(in, n, mean_k, stddev_mul, out, keep); }
+
+// ---- map cloud, other-robot removal, deskewing ------------------------------------------------
+int orc_map_cloud_generate(int K, const float* const* clouds, const int* n, const double* poses, const unsigned char* first_keyframe, float resolution,
+                           int min_points_per_voxel, float distance_far_thresh, int skip_first_cloud, float* out, int* out_n)
+{
+    return map_cloud_generate(K, clouds, n, poses, first_keyframe, resolution, min_points_per_voxel, distance_far_thresh, skip_first_cloud, out, out_n);
+}
+int orc_remove_points_near(const float* in, int n, const float* centres_xyz, int K, float radius_sqr, float* out, float* removed, int* n_removed)
+{
+    return remove_points_near(in, n, centres_xyz, K, radius_sqr, out, removed, n_removed);
+}
+void orc_deskew(const float* in, int n, const float ang_v_xyz[3], double scan_period, float* out) { deskew(in, n, ang_v_xyz, scan_period, out); }
 
 // ---- nearest neighbour ---------------------------------------------------------------------------------
 // exact k-NN of each query in the target cloud (grid) and brute force (O(n*m)) for cross-checking the grid

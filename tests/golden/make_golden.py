@@ -74,6 +74,26 @@ def main():
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes")
 
+    # ---- map cloud, other-robot removal, deskewing (tests/golden/perpoint_small.npz) -----
+    pp = {}
+    rng = np.random.default_rng(31)
+    for k in range(3):
+        c = rng.normal(0, 5, (900 + 50 * k, 4)).astype(np.float32)
+        c[:, 3] = rng.uniform(0, 1, len(c)).astype(np.float32)
+        pp[f"kf{k}_cloud"] = c
+        pp[f"kf{k}_pose"] = synth.make_pose([2.0 * k, -1.0 * k, 0.05 * k], synth.rot_xyz(0.01 * k, -0.02 * k, 0.3 * k))
+    clouds, poses = [pp[f"kf{k}_cloud"] for k in range(3)], [pp[f"kf{k}_pose"] for k in range(3)]
+    pp["map_0p5"], _ = orc.map_cloud_generate(clouds, poses, [1, 0, 0], 0.5, 1, 10000.0, False)
+    pp["map_0p25_min2_far8_skip"], _ = orc.map_cloud_generate(clouds, poses, [1, 0, 0], 0.25, 2, 8.0, True)
+    pp["map_full_far6"], _ = orc.map_cloud_generate(clouds, poses, [1, 0, 0], 0.0, 1, 6.0, False)
+    pp["centres"] = np.array([[1.0, 0.5, 0.0], [-2.0, 2.0, 0.3]], dtype=np.float32)
+    pp["near_kept"], pp["near_removed"] = orc.remove_points_near(clouds[0], pp["centres"], 1.5)
+    pp["ang_v"] = np.array([0.31, -0.22, 0.77], dtype=np.float32)
+    pp["deskewed"] = orc.deskew(clouds[1], pp["ang_v"], 0.1)
+    path = os.path.join(ROOT, "tests", "golden", "perpoint_small.npz")
+    np.savez_compressed(path, **pp)
+    print(path, os.path.getsize(path), "bytes")
+
 
 if __name__ == "__main__":
     main()

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frontend_small.npz"))
+PP = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "perpoint_small.npz"))
 
 
 # ---- CPU: oracle vs its frozen outputs --------------------------------------------------------------------------
@@ -55,7 +56,35 @@ def test_oracle_gicp_reproduces_golden():
     np.testing.assert_array_equal(g.covariances("source")[:64], G["gicp_src_cov"])
 
 
+def test_oracle_perpoint_passes_reproduce_golden():
+    from oracle import oracle as orc
+
+    clouds, poses = [PP[f"kf{k}_cloud"] for k in range(3)], [PP[f"kf{k}_pose"] for k in range(3)]
+    np.testing.assert_array_equal(orc.map_cloud_generate(clouds, poses, [1, 0, 0], 0.5, 1, 10000.0, False)[0], PP["map_0p5"])
+    np.testing.assert_array_equal(orc.map_cloud_generate(clouds, poses, [1, 0, 0], 0.25, 2, 8.0, True)[0], PP["map_0p25_min2_far8_skip"])
+    np.testing.assert_array_equal(orc.map_cloud_generate(clouds, poses, [1, 0, 0], 0.0, 1, 6.0, False)[0], PP["map_full_far6"])
+    kept, removed = orc.remove_points_near(clouds[0], PP["centres"], 1.5)
+    np.testing.assert_array_equal(kept, PP["near_kept"])
+    np.testing.assert_array_equal(removed, PP["near_removed"])
+    np.testing.assert_array_equal(orc.deskew(clouds[1], PP["ang_v"], 0.1), PP["deskewed"])
+
+
 # ---- GPU: HIP path vs the frozen outputs ------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_hip_perpoint_passes_match_golden():
+    from mrg_slam_amd import KeyFrameSnapshot, MapCloudGenerator, deskew, remove_points_near
+
+    kfs = [KeyFrameSnapshot(PP[f"kf{k}_pose"], PP[f"kf{k}_cloud"], k == 0) for k in range(3)]
+    gen = MapCloudGenerator()
+    np.testing.assert_array_equal(gen.generate(kfs, 0.5, 1, 10000.0, False), PP["map_0p5"])
+    np.testing.assert_array_equal(gen.generate(kfs, 0.25, 2, 8.0, True), PP["map_0p25_min2_far8_skip"])
+    np.testing.assert_array_equal(gen.generate(kfs, 0.0, 1, 6.0, False), PP["map_full_far6"])
+    kept, removed = remove_points_near(kfs[0].cloud, PP["centres"], 1.5)
+    np.testing.assert_array_equal(kept, PP["near_kept"])
+    np.testing.assert_array_equal(removed, PP["near_removed"])
+    np.testing.assert_array_equal(deskew(kfs[1].cloud, PP["ang_v"], 0.1), PP["deskewed"])
+
+
 @pytest.mark.gpu
 def test_hip_prefilters_match_golden():
     from mrg_slam_amd import RadiusOutlierRemoval, StatisticalOutlierRemoval, VoxelGrid, calc_fitness_score, distance_filter
