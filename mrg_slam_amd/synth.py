@@ -234,7 +234,9 @@ def synth_lidar(scene: Scene, pose: np.ndarray, model: str = "VLP64", seed: int 
 def load_kitti_scan(index: int, root: str | None = None) -> np.ndarray:
     root = root or os.environ["KITTI_ROOT"]
     path = os.path.join(root, "sequences", "00", "velodyne", f"{index:06d}.bin")
-    return np.fromfile(path, dtype=np.float32).reshape(-1, 4)
+    from .io import read_kitti_bin
+
+    return read_kitti_bin(path)
 
 
 def scan_pair(k: int, model: str = "VLP64", scene: Scene | None = None, azimuth_steps: int | None = None):
