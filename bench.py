@@ -43,6 +43,22 @@ def make_workload(n_distinct: int, batch: int, rank: int, prefilter_mode: str):
     """Returns (targets, sources, guesses, truths): `batch` pairs built from `n_distinct` consecutive synthetic scans."""
     from mrg_slam_amd import synth
 
+    kitti = os.environ.get("KITTI_ROOT")
+    if kitti and os.path.exists(os.path.join(kitti, "sequences", "00", "velodyne", "000000.bin")):
+        # optional (SURVEY.md §8d): KITTI odometry sequence 00, rank r starts at scan 500 r; lidar-frame ground truth
+        # inv(Tr) * pose * Tr when poses/00.txt and calib.txt are there, else a 1 m/scan forward guess as "truth"
+        first = 500 * rank
+        scans = [synth.load_kitti_scan(first + k, kitti) for k in range(n_distinct + 1)]
+        poses = None
+        pf, cf = os.path.join(kitti, "poses", "00.txt"), os.path.join(kitti, "sequences", "00", "calib.txt")
+        if os.path.exists(pf) and os.path.exists(cf):
+            cam = np.loadtxt(pf)[first:first + n_distinct + 1].reshape(-1, 3, 4)
+            tr = next(np.array(line.split()[1:], dtype=np.float64).reshape(3, 4) for line in open(cf) if line.startswith("Tr"))
+            Tr = np.vstack([tr, [0, 0, 0, 1]])
+            poses = [np.linalg.inv(Tr) @ np.vstack([c, [0, 0, 0, 1]]) @ Tr for c in cam]
+        if poses is None:
+            poses = [synth.make_pose([1.0 * k, 0.0, 0.0], np.eye(3)) for k in range(n_distinct + 1)]
+        return None, poses, scans
     scene = synth.street_scene()
     # every rank drives its own stretch of the street (40 m further along x), same gentle arc
     start = synth.make_pose([40.0 * rank, 0.0, 0.0], np.eye(3))
@@ -230,7 +246,7 @@ def main():
     try:
         prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_summary.json"))
         if prof:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", prof[-1]))).get("traffic_bytes_per_full_launch")
+            traffic = json.load(open(os.path.join(ROOT, "profiles", prof[-1]))).get("traffic_bytes_per_mean_launch")
     except OSError:
         pass
     true_err = float(np.mean([np.linalg.norm(result_matrix(res[b])[:3, 3] - pairs[b][3][:3, 3]) for b in range(args.batch)]))
@@ -246,7 +262,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32 per-pair terms, f64 accumulation",
-        "data": "synthetic",
+        "data": "synthetic" if scene is not None else "KITTI odometry sequence 00 (KITTI_ROOT)",
         "config": {
             "workload": f"BASELINE config[1] shape: synthetic VLP-64 scan-to-scan NDT_HIP (DIRECT7, resolution 1.0 m, eps {args.eps}, max_iter 64), "
                         f"{args.batch} pairs per GPU per step ({args.distinct} distinct pairs x warm guesses), mean {n_pts:.0f} pts/scan "

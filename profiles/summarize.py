@@ -69,6 +69,9 @@ def main():
         lines.append(f"| `{k}` | {max(len(f), len(w))} | {fm:.1f} | {sum(f) / max(len(f), 1):.1f} | {wm:.1f} | {sum(w) / max(len(w), 1):.1f} | {(2 * fm + wm) * 1024 / 1e6:.2f} MB |")
         if k == DOMINANT:
             summary["traffic_bytes_per_full_launch"] = (2 * fm + wm) * 1024
+            # same basis as bench.py's roofline.achieved (algorithmic bytes of the AVERAGE launch of a step): every step
+            # issues the same launches, so the mean over the launches of the one profiled step is the per-launch traffic
+            summary["traffic_bytes_per_mean_launch"] = (2 * sum(f) / max(len(f), 1) + sum(w) / max(len(w), 1)) * 1024
             summary["fetch_size_kib_max"] = fm
             summary["write_size_kib_max"] = wm
     if sq:
@@ -96,9 +99,19 @@ def main():
             ev = b["roofline"]["avg_launch_ms"]
             lines += ["", f"Agreement check: HIP-event average of `{DOMINANT}` inside bench.py = {ev * 1e3:.2f} us over {b['roofline']['launches']} timed launches; "
                           f"rocprofv3 average = {float(dom['AverageNs']) / 1e3:.2f} us over {dom['Calls']} launches (warm-up included)."]
-    lat = os.path.join(OUT, f"bench_{tag}_latency.json")
-    if os.path.exists(lat):
-        summary["single_pair_latency_ms"] = json.load(open(lat)).get("single_pair_latency_ms")
+    extra = os.path.join(OUT, f"extra_{tag}.json")
+    if os.path.exists(extra):
+        json.dump(json.load(open(extra)), open(os.path.join(ROOT, "profiles", f"{tag}_extra_measurements.json"), "w"), indent=1)
+    # kernel stats of the non-headline paths (profiles/side_workloads.py): GICP, prefilter chain, calc_fitness_score
+    for w in ("gicp", "prefilter", "fitness"):
+        side = os.path.join(OUT, f"prof_side_{w}", "s_kernel_stats.csv")
+        if not os.path.exists(side):
+            continue
+        rows = list(csv.DictReader(open(side)))
+        lines += ["", f"## side workload `{w}` (`rocprofv3 --kernel-trace --stats -- python3 profiles/side_workloads.py {w}`), top kernels", "",
+                  "| kernel | calls | total us | avg us | % |", "|---|---:|---:|---:|---:|"]
+        for r in rows[:8]:
+            lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e3:.1f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |")
     open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
     json.dump(summary, open(os.path.join(ROOT, "profiles", f"{tag}_summary.json"), "w"), indent=1)
     # the raw per-kernel stats travel too (small)
