@@ -29,6 +29,15 @@ __device__ __forceinline__ double fdot3d(double a0, double b0, double a1, double
     return __builtin_fma(a2, b2, __builtin_fma(a1, b1, s0));
 }
 
+// the same sum when the first product is a structural zero (0 * finite = +-0, and fma(a, b, +-0) = round(a * b)): equal
+// to fdot3d(x, 0, a1, b1, a2, b2) for finite x except for the sign of an exact zero result
+__device__ __forceinline__ double fdot3d_z(double a1, double b1, double a2, double b2)
+{
+#pragma clang fp contract(off)
+    const double s1 = a1 * b1;
+    return __builtin_fma(a2, b2, s1);
+}
+
 // pcl::transformPointCloud float path (pcl::detail::Transformer<float>::se3): x' = m0*x + (m1*y + (m2*z + m3)).
 // T: row-major 3x4.
 __device__ __forceinline__ void transform_point(const float* __restrict__ T, float x, float y, float z, float& ox, float& oy, float& oz)

@@ -86,6 +86,7 @@ __device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, co
             if (i >= 3 && j >= 3) {
                 const int lo = i < j ? i : j, hi = i < j ? j : i;
                 const int ph = (lo == 3) ? (hi - 3) : (lo == 4 ? (hi - 4 + 3) : 5);
+                // (skipping the structural zeros J3[0] and PH[a..c][0] here was measured 8 % SLOWER: it breaks the packed-f32 pairing)
                 qch = fdot3f(qC[0], PH[ph][0], qC[1], PH[ph][1], qC[2], PH[ph][2]);
             }
             const float t0 = -gauss_d2f * qCJ[i];
@@ -112,8 +113,10 @@ __device__ __forceinline__ void pair_double(Accum& acc, const double mean[3], co
     double CJ[3][6], qCJ[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
+        // the translation columns of J are unit vectors and J(0,3) is a structural zero: x*1 = x, fma(x, 0, s) = s
 #pragma unroll
-        for (int r = 0; r < 3; ++r) CJ[r][c] = fdot3d(C[r * 3 + 0], J[0][c], C[r * 3 + 1], J[1][c], C[r * 3 + 2], J[2][c]);
+        for (int r = 0; r < 3; ++r)
+            CJ[r][c] = c < 3 ? C[r * 3 + c] : (c == 3 ? fdot3d_z(C[r * 3 + 1], J[1][c], C[r * 3 + 2], J[2][c]) : fdot3d(C[r * 3 + 0], J[0][c], C[r * 3 + 1], J[1][c], C[r * 3 + 2], J[2][c]));
         qCJ[c] = fdot3d(q[0], CJ[0][c], q[1], CJ[1][c], q[2], CJ[2][c]);
     }
 #pragma unroll
@@ -126,10 +129,11 @@ __device__ __forceinline__ void pair_double(Accum& acc, const double mean[3], co
                 const int ph = (lo == 3) ? (hi - 3) : (lo == 4 ? (hi - 4 + 3) : 5);
                 double CH[3];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) CH[r] = fdot3d(C[r * 3 + 0], PH[ph][0], C[r * 3 + 1], PH[ph][1], C[r * 3 + 2], PH[ph][2]);
+                for (int r = 0; r < 3; ++r)
+                    CH[r] = ph < 3 ? fdot3d_z(C[r * 3 + 1], PH[ph][1], C[r * 3 + 2], PH[ph][2]) : fdot3d(C[r * 3 + 0], PH[ph][0], C[r * 3 + 1], PH[ph][1], C[r * 3 + 2], PH[ph][2]);
                 qch = fdot3d(q[0], CH[0], q[1], CH[1], q[2], CH[2]);
             }
-            const double jtcj = fdot3d(J[0][j], CJ[0][i], J[1][j], CJ[1][i], J[2][j], CJ[2][i]);
+            const double jtcj = j < 3 ? CJ[j][i] : (j == 3 ? fdot3d_z(J[1][3], CJ[1][i], J[2][3], CJ[2][i]) : fdot3d(J[0][j], CJ[0][i], J[1][j], CJ[1][i], J[2][j], CJ[2][i]));
             const double t0 = -gauss_d2 * qCJ[i];
             acc.H[i * 6 + j] = __builtin_fma(e, __builtin_fma(t0, qCJ[j], qch) + jtcj, acc.H[i * 6 + j]);
         }
