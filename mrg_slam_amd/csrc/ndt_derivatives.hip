@@ -86,7 +86,7 @@ __device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, co
             if (i >= 3 && j >= 3) {
                 const int lo = i < j ? i : j, hi = i < j ? j : i;
                 const int ph = (lo == 3) ? (hi - 3) : (lo == 4 ? (hi - 4 + 3) : 5);
-                // (skipping the structural zeros J3[0] and PH[a..c][0] here was measured 8 % SLOWER: it breaks the packed-f32 pairing)
+                // (skipping the structural zeros J3[0] and PH[a..c][0] here was measured: no gain without packed f32, 8 % slower with it)
                 qch = fdot3f(qC[0], PH[ph][0], qC[1], PH[ph][1], qC[2], PH[ph][2]);
             }
             const float t0 = -gauss_d2f * qCJ[i];
