@@ -46,7 +46,7 @@ NdtEngine::~NdtEngine()
         if (g.done) (void)hipEventDestroy(g.done);
         for (auto& pr : g.ev) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
     }
-    d_grids_.release(); d_pairs_.release(); d_evals_.release(); d_partials_.release(); d_results_.release(); d_T12_.release(); d_aligned_.release();
+    d_grids_.release(); d_pairs_.release(); d_evals_.release(); d_partials_.release(); d_T12_.release(); d_aligned_.release();
     h_evals_.release(); h_results_.release();
 }
 
@@ -345,7 +345,6 @@ int NdtEngine::upload_pairs()
     MRGFE_TRY(d_evals_.ensure(sizeof(NdtEvalDev) * std::max(P, 1)));
     total_part_blocks_ = part;
     MRGFE_TRY(d_partials_.ensure(sizeof(double) * kNdtPartialStride * 2 * std::max<uint32_t>(part, 1)));  // second half: speculative Hessians
-    MRGFE_TRY(d_results_.ensure(sizeof(double) * kNdtPartialStride * 2 * std::max(P, 1)));
     MRGFE_TRY(h_evals_.ensure(sizeof(NdtEvalDev) * std::max(P, 1)));
     MRGFE_TRY(h_results_.ensure(sizeof(double) * kNdtPartialStride * 2 * std::max(P, 1)));
     if (P) MRGFE_HIP_CHECK(hipMemcpyAsync(d_pairs_.p, h_pairs_.data(), sizeof(NdtPairDev) * P, hipMemcpyHostToDevice, ctx_->stream));
@@ -431,7 +430,9 @@ int NdtEngine::launch_group(RoundGroup& g)
     hipStream_t st = ctx_->stream;
     NdtEvalDev*       d_ev = d_evals_.as<NdtEvalDev>() + g.first;
     const NdtPairDev* d_pr = d_pairs_.as<NdtPairDev>() + g.first;
-    double*           d_res = d_results_.as<double>() + size_t(g.first) * kNdtPartialStride;
+    // the reduction kernel writes the 384-byte result records straight into pinned host memory (device-visible): no
+    // device-to-host copy command, and its queue gap, in any of the ~20 rounds of a batch
+    double*           d_res = h_results_.as<double>() + size_t(g.first) * kNdtPartialStride;
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_ev, he + g.first, sizeof(NdtEvalDev) * g.count, hipMemcpyHostToDevice, st));
     // every kernel variant (mode) is bracketed by its own HIP events on the launch stream
     for (int m = 0; m < 3; ++m)
@@ -442,10 +443,6 @@ int NdtEngine::launch_group(RoundGroup& g)
         }
     const uint32_t P = static_cast<uint32_t>(n_pairs());
     MRGFE_TRY(ndt_launch_reduce(ctx_, g.count, d_pr, d_ev, d_partials_.as<double>(), d_res, g.any_spec, total_part_blocks_, P, g.ppt));
-    MRGFE_HIP_CHECK(hipMemcpyAsync(h_results_.as<double>() + size_t(g.first) * kNdtPartialStride, d_res, sizeof(double) * kNdtPartialStride * g.count, hipMemcpyDeviceToHost, st));
-    if (g.any_spec)
-        MRGFE_HIP_CHECK(hipMemcpyAsync(h_results_.as<double>() + size_t(P + g.first) * kNdtPartialStride, d_res + size_t(P) * kNdtPartialStride,
-                                       sizeof(double) * kNdtPartialStride * g.count, hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipEventRecord(g.done, st));
     g.inflight = true;
     return MRGFE_OK;
@@ -580,8 +577,7 @@ int NdtEngine::evaluate(int pair, const float T[16], const double p[6], int mode
     const int ppt1[3] = {1, 1, 1};
     MRGFE_TRY(ndt_launch_derivatives(ctx_, mode, prm_.search, h_pairs_[pair].nblk, 1, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(),
                                      d_partials_.as<double>(), 1, total_part_blocks_));
-    MRGFE_TRY(ndt_launch_reduce(ctx_, P, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_partials_.as<double>(), d_results_.as<double>(), false, 0, 0, ppt1));
-    MRGFE_HIP_CHECK(hipMemcpyAsync(h_results_.p, d_results_.p, sizeof(double) * kNdtPartialStride * P, hipMemcpyDeviceToHost, st));
+    MRGFE_TRY(ndt_launch_reduce(ctx_, P, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_partials_.as<double>(), h_results_.as<double>(), false, 0, 0, ppt1));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
     const double* res = h_results_.as<double>() + size_t(pair) * kNdtPartialStride;
     *score = res[0];

@@ -85,7 +85,7 @@ class NdtEngine {
     Arena grid_arena_;   // leaves, lookups, ...
     // packed per-leaf arrays of the built targets (grid_arena_)
     std::vector<NdtGridDev> h_grids_;
-    DevBuf d_grids_, d_pairs_, d_evals_, d_partials_, d_results_, d_T12_, d_aligned_;
+    DevBuf d_grids_, d_pairs_, d_evals_, d_partials_, d_T12_, d_aligned_;
     PinBuf h_evals_, h_results_;
     bool   pairs_dirty_ = true;
     bool   force_hash_ = false;
