@@ -372,6 +372,10 @@ static void fill_eval(NdtEvalDev& e, const NdtRequest& r, const NdtController& c
 // group's derivative kernels are already queued, so the GPU does not idle during host turnarounds.  Both groups use
 // the same stream: kernels never overlap each other and the per-launch HIP-event timings stay clean.
 // batches at least this large are split into two alternating groups (each half still fills the GPU)
+// HIP events around the derivative launches (what mrgfe_*_kernel_stats reports): 2 = every variant (default), 1 = only the
+// dominant score+gradient+Hessian variant, 0 = none.  MRGFE_KERNEL_TIMING overrides.
+static int timing_level() { static const int v = [] { const char* e = std::getenv("MRGFE_KERNEL_TIMING"); return e ? std::atoi(e) : 2; }(); return v; }
+
 constexpr int kHostParallelMinPairs = 48;  // below this the controller steps of a round run on the calling thread
 
 static int pipeline_min_pairs() { const char* e = std::getenv("MRGFE_PIPELINE_MIN_PAIRS"); return e ? std::atoi(e) : 1 << 30; }  // measured on MI355X: alternating half-batches lose more to smaller launches than they hide
@@ -437,9 +441,9 @@ int NdtEngine::launch_group(RoundGroup& g)
     // every kernel variant (mode) is bracketed by its own HIP events on the launch stream
     for (int m = 0; m < 3; ++m)
         if (g.modes[m]) {
-            MRGFE_HIP_CHECK(hipEventRecord(g.ev[m][0], st));
+            if (timing_level() > (m == 0 ? 0 : 1)) MRGFE_HIP_CHECK(hipEventRecord(g.ev[m][0], st));
             MRGFE_TRY(ndt_launch_derivatives(ctx_, m, prm_.search, g.nblk[m], g.n_mode[m], d_grids_.as<NdtGridDev>(), d_pr, d_ev, d_partials_.as<double>(), g.ppt[m], total_part_blocks_));
-            MRGFE_HIP_CHECK(hipEventRecord(g.ev[m][1], st));
+            if (timing_level() > (m == 0 ? 0 : 1)) MRGFE_HIP_CHECK(hipEventRecord(g.ev[m][1], st));
         }
     const uint32_t P = static_cast<uint32_t>(n_pairs());
     MRGFE_TRY(ndt_launch_reduce(ctx_, g.count, d_pr, d_ev, d_partials_.as<double>(), d_res, g.any_spec, total_part_blocks_, P, g.ppt));
@@ -453,7 +457,7 @@ int NdtEngine::finish_group(RoundGroup& g)
     MRGFE_HIP_CHECK(hipEventSynchronize(g.done));
     g.inflight = false;
     for (int m = 0; m < 3; ++m)
-        if (g.modes[m]) {
+        if (g.modes[m] && timing_level() > (m == 0 ? 0 : 1)) {
             float ms = 0;
             MRGFE_HIP_CHECK(hipEventElapsedTime(&ms, g.ev[m][0], g.ev[m][1]));
             mode_ms[m] += ms;
