@@ -176,8 +176,10 @@ typedef struct mrgfe_pair_result {
 } mrgfe_pair_result; /* 384 bytes: the record the ranks all-gather over RCCL */
 
 typedef struct mrgfe_batch mrgfe_batch;
-/* A batch holds `n_targets` target clouds and `n_pairs` (target index, source cloud, guess) alignments that are advanced
- * together, one launch per derivative evaluation for all pairs still running. */
+/* A batch holds `n_targets` target clouds and `n_pairs` (target index, source cloud, guess) alignments.  NDT_HIP: they are
+ * advanced together, one launch per derivative evaluation for all pairs still running.  GICP_HIP: the candidates of a target
+ * share its covariances and correspondence grid (computed once, like the single setInputTarget of loop_detector.cpp:104)
+ * and are aligned one after the other. */
 int  mrgfe_batch_create(mrgfe_ctx* ctx, const mrgfe_reg_params* params, mrgfe_batch** out);
 void mrgfe_batch_destroy(mrgfe_batch* b);
 int  mrgfe_batch_clear(mrgfe_batch* b);

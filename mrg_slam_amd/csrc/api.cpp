@@ -83,7 +83,9 @@ struct mrgfe_reg {
 struct mrgfe_batch {
     mrgfe_ctx*       ctx = nullptr;
     mrgfe_reg_params params;
-    NdtEngine*       ndt = nullptr;
+    NdtEngine*       ndt = nullptr;   // holds the clouds, targets and pairs of the batch for both methods; aligns them for NDT_HIP
+    std::vector<GicpEngine*> gicp;    // GICP_HIP: one engine per target (its covariances and correspondence grid are computed once)
+    std::vector<float>  gicp_final;   // GICP_HIP: row-major final transformation of every pair
     std::vector<NnGrid> fit_grids;  // getFitnessScore grids, one per target; device buffers kept between align calls
 };
 
@@ -498,7 +500,6 @@ int mrgfe_batch_create(mrgfe_ctx* ctx, const mrgfe_reg_params* params, mrgfe_bat
     if (!ctx || !out) { set_error("mrgfe_batch_create: NULL argument"); return MRGFE_ERR_INVALID; }
     *out = nullptr;
     MRGFE_TRY(check_params(params));
-    if (params->method != MRGFE_NDT_HIP) { set_error("batched matching is available for NDT_HIP"); return MRGFE_ERR_INVALID; }
     mrgfe_batch* b = new (std::nothrow) mrgfe_batch();
     if (!b) { set_error("out of host memory"); return MRGFE_ERR_INVALID; }
     b->ctx = ctx;
@@ -514,6 +515,7 @@ void mrgfe_batch_destroy(mrgfe_batch* b)
         MRGFE_LOCK(b->ctx);
         (void)b->ctx->bind();
         for (auto& g : b->fit_grids) g.release();
+        for (auto* g : b->gicp) delete g;
         delete b->ndt;
     }
     delete b;
@@ -523,6 +525,8 @@ int mrgfe_batch_clear(mrgfe_batch* b)
     if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(b->ctx);
     b->ndt->clear();
+    for (auto* g : b->gicp) delete g;  // their cached target state belongs to the clouds just forgotten
+    b->gicp.clear();
     return MRGFE_OK;
 }
 int mrgfe_batch_add_target(mrgfe_batch* b, const float* xyzi, size_t n, size_t stride)
@@ -565,6 +569,7 @@ int mrgfe_batch_build_targets(mrgfe_batch* b)
 {
     if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(b->ctx);
+    if (b->params.method == MRGFE_GICP_HIP) return MRGFE_OK;  // target covariances and grids are built by the first align
     return b->ndt->build_targets();
 }
 int mrgfe_batch_num_pairs(const mrgfe_batch* b) { return b ? b->ndt->n_pairs() : 0; }
@@ -574,19 +579,49 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
     if (!b || !results) { set_error("mrgfe_batch_align: NULL argument"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(b->ctx);
     NdtEngine& e = *b->ndt;
-    MRGFE_TRY(e.align_all());
     const int P = e.n_pairs();
-    for (int i = 0; i < P; ++i) {
-        const NdtController& c = e.pair(i).ctl;
-        mrgfe_pair_result& r = results[i];
-        row2col(c.final_transformation(), r.T);
-        std::memcpy(r.H, c.hessian(), sizeof(r.H));
-        r.fitness = DBL_MAX;
-        r.trans_probability = c.trans_probability();
-        r.converged = c.converged() ? 1 : 0;
-        r.iterations = c.iterations();
-        r.evaluations = c.evaluations();
-        r.pair_id = i;
+    const bool gicp = b->params.method == MRGFE_GICP_HIP;
+    if (gicp) {
+        // GICP_HIP: the candidates of a target share its covariances and correspondence grid; the LM loops run one pair
+        // after the other (not yet advanced together like the NDT rounds)
+        MRGFE_TRY(b->ctx->bind());
+        if (b->gicp.size() < static_cast<size_t>(e.n_targets())) b->gicp.resize(e.n_targets(), nullptr);
+        b->gicp_final.assign(size_t(P) * 16, 0.0f);
+        for (int i = 0; i < P; ++i) {
+            const NdtPairInfo& p = e.pair(i);
+            const NdtTargetInfo& t = e.target(p.target);
+            GicpEngine*& g = b->gicp[p.target];
+            if (!g) {
+                g = new GicpEngine(b->ctx, gicp_params_from(b->params));
+                MRGFE_TRY(g->set_target(t.d_pts, t.n));
+            }
+            MRGFE_TRY(g->set_source(p.d_src, p.n));
+            MRGFE_TRY(g->align(p.guess));
+            mrgfe_pair_result& r = results[i];
+            std::memcpy(&b->gicp_final[size_t(i) * 16], g->final_transformation(), 64);
+            row2col(g->final_transformation(), r.T);
+            std::memcpy(r.H, g->hessian(), sizeof(r.H));
+            r.fitness = DBL_MAX;
+            r.trans_probability = 0.0;
+            r.converged = g->converged() ? 1 : 0;
+            r.iterations = g->iterations();
+            r.evaluations = g->evaluations();
+            r.pair_id = i;
+        }
+    } else {
+        MRGFE_TRY(e.align_all());
+        for (int i = 0; i < P; ++i) {
+            const NdtController& c = e.pair(i).ctl;
+            mrgfe_pair_result& r = results[i];
+            row2col(c.final_transformation(), r.T);
+            std::memcpy(r.H, c.hessian(), sizeof(r.H));
+            r.fitness = DBL_MAX;
+            r.trans_probability = c.trans_probability();
+            r.converged = c.converged() ? 1 : 0;
+            r.iterations = c.iterations();
+            r.evaluations = c.evaluations();
+            r.pair_id = i;
+        }
     }
     if (fitness_max_range >= 0) {
         // getFitnessScore of every pair in one launch: one exact-NN grid per distinct target
@@ -601,7 +636,7 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
             const NdtTargetInfo& t = e.target(p.target);
             if (t.n == 0 || p.n == 0) continue;
             if (!built[p.target]) { st = grids[p.target].build(b->ctx, t.d_pts, t.n, 1.0f); built[p.target] = 1; }
-            if (st == MRGFE_OK) { jobs.push_back(grids[p.target].make_fitness_job(p.d_src, p.n, p.ctl.final_transformation())); job_pair.push_back(i); }
+            if (st == MRGFE_OK) { jobs.push_back(grids[p.target].make_fitness_job(p.d_src, p.n, gicp ? &b->gicp_final[size_t(i) * 16] : p.ctl.final_transformation())); job_pair.push_back(i); }
         }
         if (st == MRGFE_OK && !jobs.empty()) {
             std::vector<double> fit(jobs.size());

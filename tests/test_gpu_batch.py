@@ -43,6 +43,49 @@ def test_batch_equals_sequential_registrations():
     assert ms > 0 and launches > 0 and nbytes > 0
 
 
+def test_gicp_batch_equals_sequential_registrations_and_oracle():
+    """GICP_HIP through the batch API (the loop-closure configuration of config/mrg_slam.yaml:181 uses a GICP back end):
+    same results as one GicpHip object per pair and as the CPU oracle."""
+    from mrg_slam_amd import BatchMatcher, GicpHip, synth
+    from mrg_slam_amd._lib import GICP_HIP
+    from mrg_slam_amd.registration import default_params, result_matrix
+    from oracle import oracle as orc
+
+    targets = [small_cloud(4000, 200), small_cloud(3000, 201)]
+    rng = np.random.default_rng(9)
+    pairs = []
+    for k in range(5):
+        ti = k % 2
+        rel = synth.make_pose(rng.normal(0, 0.15, 3), synth.rot_xyz(*rng.normal(0, 0.015, 3)))
+        src = orc.transform_points(np.linalg.inv(rel), targets[ti][: 2000 + 250 * k])
+        pairs.append((ti, src, synth.perturb_pose(np.eye(4), rng)))
+    prm = default_params(GICP_HIP)
+    prm.transformation_epsilon = 0.01
+    bm = BatchMatcher(prm)
+    tids = [bm.add_target(t) for t in targets]
+    for ti, src, guess in pairs:
+        bm.add_pair(tids[ti], src, guess)
+    res = bm.align(fitness_max_range=float("inf"))
+    again = bm.align(fitness_max_range=float("inf"))  # cached target state: same answer
+    for k, (ti, src, guess) in enumerate(pairs):
+        reg = GicpHip(transformation_epsilon=0.01)
+        reg.setInputTarget(targets[ti])
+        reg.setInputSource(src)
+        reg.align(guess)
+        np.testing.assert_array_equal(result_matrix(res[k]), reg.getFinalTransformation())
+        np.testing.assert_array_equal(result_matrix(again[k]), reg.getFinalTransformation())
+        assert res[k]["converged"] == int(reg.hasConverged()) and res[k]["iterations"] == reg.getFinalNumIteration()
+        assert res[k]["fitness"] == pytest.approx(reg.getFitnessScore(), rel=1e-12)
+        o = orc.FastGicp(transformation_epsilon=0.01, num_threads=2)
+        o.setInputTarget(targets[ti])
+        o.setInputSource(src)
+        o.align(guess)
+        To = o.getFinalTransformation().astype(np.float64)
+        Tg = result_matrix(res[k]).astype(np.float64)
+        assert np.linalg.norm(Tg[:3, 3] - To[:3, 3]) < 1e-4 and synth.rotation_angle(Tg, To) < 1e-4
+        assert res[k]["converged"] == int(o.hasConverged())
+
+
 def test_batch_edge_cases():
     from mrg_slam_amd import BatchMatcher
 
