@@ -186,7 +186,7 @@ int filter_radius_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, d
     *out_n = 0;
     if (n == 0) return MRGFE_OK;
     NnGrid& grid = ctx_tmp_grid(ctx);
-    int st = grid.build(ctx, d_in, n, static_cast<float>(radius), NnGrid::kCrowding1nn, false);
+    int st = grid.build(ctx, d_in, n, static_cast<float>(radius), NnGrid::kCrowding1nn, 1);
     if (st == MRGFE_OK) {
         DevBuf& dfl = ctx->scratch[7];
         st = dfl.ensure(n * 4);
@@ -231,7 +231,7 @@ int filter_statistical_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t
     const uint32_t nn = static_cast<uint32_t>(n);
     const int      k1 = mean_k + 1;
     NnGrid& grid = ctx_tmp_grid(ctx);
-    int     rc = grid.build(ctx, d_in, n, 1.0f, NnGrid::kCrowdingKnn, false);
+    int     rc = grid.build(ctx, d_in, n, 1.0f, NnGrid::kCrowdingKnn);
     if (rc != MRGFE_OK) return rc;
     DevBuf knn_i, knn_d, ddist;
     auto cleanup = [&]() { knn_i.release(); knn_d.release(); ddist.release(); };

@@ -333,15 +333,15 @@ int GicpEngine::set_source(const void* d, size_t n)
     return MRGFE_OK;
 }
 
-int GicpEngine::compute_covariances(const float4* d_pts, size_t n, DevBuf& out)
+int GicpEngine::compute_covariances(const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid)
 {
     MRGFE_TRY(out.ensure(std::max<size_t>(n, 1) * 48));
     if (n == 0) return MRGFE_OK;
     const int k = prm_.k_correspondences;
-    MRGFE_TRY(cov_grid_.build(ctx_, d_pts, n, 1.0f, NnGrid::kCrowdingKnn, false));
+    MRGFE_TRY(grid.build(ctx_, d_pts, n, 1.0f, NnGrid::kCrowdingKnn));
     MRGFE_TRY(d_knn_i_.ensure(n * k * 4));
     MRGFE_TRY(d_knn_d_.ensure(n * k * 4));
-    MRGFE_TRY(cov_grid_.knn_device(ctx_, d_pts, n, k, d_knn_i_.as<int32_t>(), d_knn_d_.as<float>()));
+    MRGFE_TRY(grid.knn_device(ctx_, d_pts, n, k, d_knn_i_.as<int32_t>(), d_knn_d_.as<float>()));
     const uint32_t nn = static_cast<uint32_t>(n);
     hipLaunchKernelGGL(gicp_cov_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx_->stream, d_pts, nn, d_knn_i_.as<int32_t>(), k, out.as<double>());
     MRGFE_HIP_CHECK(hipGetLastError());
@@ -352,9 +352,13 @@ int GicpEngine::ensure_ready()
 {
     if (!d_tgt_ && n_tgt_) { set_error("GICP: no target"); return MRGFE_ERR_STATE; }
     MRGFE_TRY(ctx_->bind());
-    if (!src_cov_valid_) { MRGFE_TRY(compute_covariances(d_src_, n_src_, d_src_cov_)); src_cov_valid_ = true; }
-    if (!tgt_cov_valid_) { MRGFE_TRY(compute_covariances(d_tgt_, n_tgt_, d_tgt_cov_)); tgt_cov_valid_ = true; }
-    if (!tgt_grid_valid_) { MRGFE_TRY(tgt_grid_.build(ctx_, d_tgt_, n_tgt_, 1.0f)); tgt_grid_valid_ = true; }
+    if (!src_cov_valid_) { MRGFE_TRY(compute_covariances(d_src_, n_src_, d_src_cov_, cov_grid_)); src_cov_valid_ = true; }
+    // the target's k-NN grid also serves the per-iteration correspondence search (one build per setInputTarget)
+    if (!tgt_cov_valid_ || !tgt_grid_valid_) {
+        MRGFE_TRY(compute_covariances(d_tgt_, n_tgt_, d_tgt_cov_, tgt_grid_));
+        if (n_tgt_ == 0) MRGFE_TRY(tgt_grid_.build(ctx_, d_tgt_, 0, 1.0f));
+        tgt_cov_valid_ = tgt_grid_valid_ = true;
+    }
     const size_t ns = std::max<size_t>(n_src_, 1);
     MRGFE_TRY(d_corr_.ensure(ns * 4));
     MRGFE_TRY(d_mahal_.ensure(ns * 72));

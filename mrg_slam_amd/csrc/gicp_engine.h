@@ -44,7 +44,7 @@ class GicpEngine {
     const float4* d_src_ = nullptr;
     size_t n_tgt_ = 0, n_src_ = 0;
     NnGrid tgt_grid_;
-    NnGrid cov_grid_;        // k-NN grid of the cloud whose covariances are being computed (buffers reused)
+    NnGrid cov_grid_;        // k-NN grid of the source cloud (covariances only; buffers reused)
     DevBuf d_knn_i_, d_knn_d_;
     bool   tgt_grid_valid_ = false, tgt_cov_valid_ = false, src_cov_valid_ = false;
     DevBuf d_tgt_cov_, d_src_cov_, d_corr_, d_mahal_, d_partial_, d_T_;
@@ -53,7 +53,7 @@ class GicpEngine {
     bool   converged_ = false;
     int    nr_iterations_ = 0, n_linearize_ = 0, n_error_ = 0;
     int ensure_ready();
-    int compute_covariances(const float4* d_pts, size_t n, DevBuf& out);
+    int compute_covariances(const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid);
     int run_linearize(const double T[16], bool with_jacobian, double H[36], double b[6], double* err, int* n_corr);
     int run_error(const double T[16], double* err);
 };

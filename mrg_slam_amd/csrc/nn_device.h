@@ -240,9 +240,9 @@ __device__ __forceinline__ void nn_nearest_group(const NnGrid2Dev& g, float x, f
 {
     best_i = -1;
     best_d = INFINITY;
-    if (g.fine.n == 0 || !finite3(x, y, z)) return;  // uniform within the group
-    if (nn_level_search<G>(g.fine, x, y, z, sub, g.has_coarse ? g.fine_rings : 0x7fffffff, max_sq, best_i, best_d)) return;
-    nn_level_search<G>(g.coarse, x, y, z, sub, 0x7fffffff, max_sq, best_i, best_d);
+    if (g.level[0].n == 0 || !finite3(x, y, z)) return;  // uniform within the group
+    for (int l = 0; l < g.n_levels; ++l)
+        if (nn_level_search<G>(g.level[l], x, y, z, sub, l + 1 < g.n_levels ? g.fine_rings : 0x7fffffff, max_sq, best_i, best_d)) return;
 }
 
 }  // namespace mrgfe

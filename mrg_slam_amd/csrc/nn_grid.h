@@ -24,12 +24,14 @@ struct NnGridDev {  // one resolution level
     const float4*   sorted;      // xyz + original index (bit pattern) in w
 };
 
-// Two levels over the same points: 1-NN queries look at the 3x3x3 fine cells around the query and, when that is not
-// conclusive (sparse surroundings), continue on the coarse level, whose ring walk reaches far neighbours in few rings.
+// Up to three levels over the same points (cell edge x kLevelRatio per level): a query looks at the cells around it on
+// the finest level and, when that is not conclusive (sparse surroundings), continues on the next coarser one, whose ring
+// walk reaches far neighbours in few rings.
+constexpr int kNnMaxLevels = 3;
 struct NnGrid2Dev {
-    NnGridDev fine, coarse;
-    int32_t   has_coarse;  // 0: coarse == fine (small grids)
-    int32_t   fine_rings;  // rings walked on the fine level before a query moves to the coarse one
+    NnGridDev level[kNnMaxLevels];
+    int32_t   n_levels;    // >= 1
+    int32_t   fine_rings;  // rings walked on a level before a 1-NN query moves to the next coarser one
 };
 
 // one getFitnessScore evaluation: source cloud `src` (device) moved by the row-major 3x4 float transform, matched
@@ -49,11 +51,11 @@ class NnGrid {
     // so a walk over the 27 cells around a query touches tens, not thousands, of candidates on dense clouds.
     static constexpr double kCrowding1nn = 12.0;  // lane-group 1-NN / radius walks: short cell runs
     static constexpr double kCrowdingKnn = 32.0;  // wave-per-query k-NN: cell rows of about one wavefront
-    static constexpr float  kCoarseRatio = 4.0f;
-    int build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size, double crowding_target = kCrowding1nn, bool with_coarse = true);
+    static constexpr float  kLevelRatio = 4.0f;
+    int build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size, double crowding_target = kCrowding1nn, int max_levels = kNnMaxLevels);
     void release();
     bool valid() const { return built_; }
-    const NnGridDev&  dev() const { return h_.fine; }  // k-NN and radius queries walk the fine level only
+    const NnGridDev&  dev() const { return h_.level[0]; }  // radius queries walk the finest level only
     const NnGrid2Dev& dev2() const { return h_; }
     size_t size() const { return n_; }
 
@@ -73,7 +75,7 @@ class NnGrid {
     bool      built_ = false;
     size_t    n_ = 0;
     NnGrid2Dev h_;
-    DevBuf     d_cell_start_, d_sorted_, d_cell_start2_, d_sorted2_;
+    DevBuf     d_cell_start_[kNnMaxLevels], d_sorted_[kNnMaxLevels];
     int build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, float cell, const SliceTable& tab, NnGridDev& lv, DevBuf& d_cells, DevBuf& d_sorted,
                     bool counts_only, double* crowding);
 };

@@ -17,24 +17,52 @@
 namespace mrgfe {
 
 // ---- build ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kCrowdSlots = 32;
 __global__ __launch_bounds__(256) void nn_cellkey_kernel(const float4* __restrict__ pts, uint32_t n, NnGridDev g, uint32_t n_cells, uint32_t* __restrict__ keys,
                                                           uint32_t* __restrict__ vals, uint32_t* __restrict__ counts, unsigned long long* __restrict__ crowd)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    uint32_t       before = 0;  // points that reached this point's cell before it: summed over the cloud, sum_c n_c (n_c - 1) / 2
+    uint32_t       key = n_cells;  // non-finite points: behind every cell
     if (i < n) {
         const float4 p = pts[i];
         int          c[3];
-        uint32_t     key = n_cells;
-        if (nn_cell_of(g, p.x, p.y, p.z, c)) {
-            key = (static_cast<uint32_t>(c[2]) * g.dim[1] + c[1]) * g.dim[0] + c[0];
-            before = atomicAdd(&counts[key], 1u);
-        }
+        if (nn_cell_of(g, p.x, p.y, p.z, c)) key = (static_cast<uint32_t>(c[2]) * g.dim[1] + c[1]) * g.dim[0] + c[0];
         keys[i] = key;
         vals[i] = i;
     }
+    // count per cell, one atomic per distinct cell of the wavefront (consecutive points of a scan crowd into few cells);
+    // `before` = points counted into this point's cell ahead of it: summed over the cloud it is sum_c n_c (n_c - 1) / 2
+    uint32_t before = 0;
+    bool     todo = i < n && key < n_cells;
+    // ... when at least half of the lanes share their cell with the lane before them; otherwise plain per-lane atomics
+    if (__popcll(__ballot(todo && key == __shfl_up(key, 1) && lane_id() > 0)) < 32) {
+        if (todo) before = atomicAdd(&counts[key], 1u);
+        todo = false;
+    }
+    while (__ballot(todo)) {
+        const uint64_t pending = __ballot(todo);
+        const int      leader = __ffsll(static_cast<unsigned long long>(pending)) - 1;
+        const uint32_t lkey = __shfl(key, leader);
+        const bool     mine = todo && key == lkey;
+        const uint64_t grp = __ballot(mine);
+        if (mine) {
+            uint32_t old = 0;
+            if (lane_id() == leader) old = atomicAdd(&counts[lkey], static_cast<uint32_t>(__popcll(grp)));
+            old = __shfl(old, leader);
+            before = old + static_cast<uint32_t>(__popcll(grp & ((1ull << lane_id()) - 1ull)));
+            todo = false;
+        }
+    }
+    if (crowd == nullptr) return;  // uniform: only the adaptive passes ask for the crowding figure
+    __shared__ uint32_t s_w[4];
     const uint32_t w = wave_sum(before);
-    if (lane_id() == 0 && w) atomicAdd(crowd, static_cast<unsigned long long>(w));
+    if (lane_id() == 0) s_w[wave_id()] = w;
+    __syncthreads();
+    // one atomic per workgroup, spread over kCrowdSlots addresses (two thousand wavefronts adding to ONE address took 20+ us)
+    if (threadIdx.x == 0) {
+        const uint32_t t = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (t) atomicAdd(&crowd[blockIdx.x % kCrowdSlots], static_cast<unsigned long long>(t));
+    }
 }
 
 __global__ __launch_bounds__(256) void nn_gather_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ sorted_vals, uint32_t n_valid, float4* __restrict__ sorted)
@@ -60,17 +88,19 @@ int NnGrid::build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const 
     lv.n = bb.n_finite;
     for (int a = 0; a < 3; ++a) lv.dim[a] = static_cast<int>(std::floor((bb.mx[a] - bb.mn[a]) / cell)) + 1;
     const uint32_t n_cells = static_cast<uint32_t>(lv.dim[0]) * lv.dim[1] * lv.dim[2];
-    MRGFE_TRY(d_cells.ensure(sizeof(uint32_t) * (size_t(n_cells) + 6)));
-    MRGFE_HIP_CHECK(hipMemsetAsync(d_cells.p, 0, sizeof(uint32_t) * (size_t(n_cells) + 6), st));
+    MRGFE_TRY(d_cells.ensure(sizeof(uint32_t) * (size_t(n_cells) + 4 + 2 * kCrowdSlots)));
+    MRGFE_HIP_CHECK(hipMemsetAsync(d_cells.p, 0, sizeof(uint32_t) * (size_t(n_cells) + 4 + 2 * kCrowdSlots), st));
     lv.cell_start = d_cells.as<uint32_t>();
-    // the crowd counter lives behind the (n_cells + 1)-entry count table, 8-byte aligned
+    // the crowd counters live behind the (n_cells + 1)-entry count table, 8-byte aligned
     unsigned long long* d_crowd = reinterpret_cast<unsigned long long*>(d_cells.as<uint32_t>() + ((size_t(n_cells) + 2) & ~size_t(1)));
-    hipLaunchKernelGGL(nn_cellkey_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, d_pts, nn, lv, n_cells, dk.as<uint32_t>(), dv.as<uint32_t>(), d_cells.as<uint32_t>(), d_crowd);
+    hipLaunchKernelGGL(nn_cellkey_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, d_pts, nn, lv, n_cells, dk.as<uint32_t>(), dv.as<uint32_t>(), d_cells.as<uint32_t>(),
+                       crowding ? d_crowd : nullptr);
     MRGFE_HIP_CHECK(hipGetLastError());
     if (crowding) {
-        unsigned long long crowd = 0;
-        MRGFE_HIP_CHECK(hipMemcpyAsync(&crowd, d_crowd, 8, hipMemcpyDeviceToHost, st));
+        unsigned long long slots[kCrowdSlots], crowd = 0;
+        MRGFE_HIP_CHECK(hipMemcpyAsync(slots, d_crowd, sizeof(slots), hipMemcpyDeviceToHost, st));
         MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+        for (unsigned long long v : slots) crowd += v;
         // population of the cell an average POINT sits in (queries are distributed like the points, not like the cells)
         *crowding = 1.0 + 2.0 * double(crowd) / double(bb.n_finite);
     }
@@ -94,14 +124,15 @@ int NnGrid::build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const 
     return MRGFE_OK;
 }
 
-int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size, double crowding_target, bool with_coarse)
+int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size, double crowding_target, int max_levels)
 {
     built_ = false;
     n_ = n;
     if (const char* e = std::getenv("MRGFE_NN_CELL")) { cell_size = static_cast<float>(std::atof(e)); crowding_target = 0; }  // tuning hook
     std::memset(&h_, 0, sizeof(h_));
-    h_.fine.cell = h_.coarse.cell = cell_size;
-    for (int a = 0; a < 3; ++a) h_.fine.dim[a] = h_.coarse.dim[a] = 1;
+    h_.n_levels = 1;
+    h_.fine_rings = 8;
+    for (auto& lv : h_.level) { lv.cell = cell_size; lv.dim[0] = lv.dim[1] = lv.dim[2] = 1; }
     if (n > 0x7fffffffu) { set_error("NnGrid: cloud too large"); return MRGFE_ERR_INVALID; }
     hipStream_t st = ctx->stream;
     uint32_t    nn = static_cast<uint32_t>(n);
@@ -122,12 +153,11 @@ int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size
     MRGFE_HIP_CHECK(hipMemcpyAsync(&bb, d_out, sizeof(BBox), hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
     if (bb.n_finite == 0) {  // empty grid: one cell, no points
-        MRGFE_TRY(d_cell_start_.ensure(8));
-        MRGFE_HIP_CHECK(hipMemsetAsync(d_cell_start_.p, 0, 8, st));
-        MRGFE_TRY(d_sorted_.ensure(16));
-        h_.fine.cell_start = d_cell_start_.as<uint32_t>();
-        h_.fine.sorted = d_sorted_.as<float4>();
-        h_.coarse = h_.fine;
+        MRGFE_TRY(d_cell_start_[0].ensure(8));
+        MRGFE_HIP_CHECK(hipMemsetAsync(d_cell_start_[0].p, 0, 8, st));
+        MRGFE_TRY(d_sorted_[0].ensure(16));
+        h_.level[0].cell_start = d_cell_start_[0].as<uint32_t>();
+        h_.level[0].sorted = d_sorted_[0].as<float4>();
         built_ = true;
         return MRGFE_OK;
     }
@@ -142,26 +172,32 @@ int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size
     float cell = cell_size;
     while (cells_at(cell) > double(1u << 24)) cell *= 2.0f;
     if (crowding_target > 0) {
-        // halve the edge while the cell an average point sits in is more crowded than the target (at most four times)
-        for (int pass = 0; pass < 4 && cells_at(cell * 0.5f) <= double(1u << 24); ++pass) {
+        // halve the edge while the cell an average point sits in is more crowded than the target (at most four times).
+        // LiDAR returns lie on surfaces, so the crowding falls about 4x per halving: jump by the predicted number of
+        // halvings, then correct by single steps.
+        int halvings = 0;
+        for (int pass = 0; pass < 3 && halvings < 4 && cells_at(cell * 0.5f) <= double(1u << 24); ++pass) {
             double crowding = 0;
-            MRGFE_TRY(build_level(ctx, d_pts, nn, bb, cell, tab, h_.fine, d_cell_start_, d_sorted_, true, &crowding));
+            MRGFE_TRY(build_level(ctx, d_pts, nn, bb, cell, tab, h_.level[0], d_cell_start_[0], d_sorted_[0], true, &crowding));
             if (crowding <= crowding_target) break;
-            cell *= 0.5f;
+            int step = std::max(1, static_cast<int>(std::ceil(std::log(crowding / crowding_target) / std::log(4.0))));
+            step = std::min(step, 4 - halvings);
+            while (step > 1 && cells_at(cell * std::ldexp(1.0f, -step)) > double(1u << 24)) --step;
+            cell *= std::ldexp(1.0f, -step);
+            halvings += step;
         }
     }
-    MRGFE_TRY(build_level(ctx, d_pts, nn, bb, cell, tab, h_.fine, d_cell_start_, d_sorted_, false, nullptr));
-    // coarse level for queries whose neighbourhood is empty at the fine scale: kCoarseRatio x the edge, same origin
-    if (with_coarse && std::max(h_.fine.dim[0], std::max(h_.fine.dim[1], h_.fine.dim[2])) > 4) {
-        float ratio = kCoarseRatio;
-        if (const char* e = std::getenv("MRGFE_NN_COARSE_RATIO")) ratio = std::max(2.0f, static_cast<float>(std::atof(e)));  // tuning hook
-        MRGFE_TRY(build_level(ctx, d_pts, nn, bb, cell * ratio, tab, h_.coarse, d_cell_start2_, d_sorted2_, false, nullptr));
-        h_.has_coarse = 1;
-        h_.fine_rings = 8;
-        if (const char* e = std::getenv("MRGFE_NN_FINE_RINGS")) h_.fine_rings = std::max(1, std::atoi(e));  // tuning hook
-    } else {
-        h_.coarse = h_.fine;
-        h_.has_coarse = 0;
+    MRGFE_TRY(build_level(ctx, d_pts, nn, bb, cell, tab, h_.level[0], d_cell_start_[0], d_sorted_[0], false, nullptr));
+    // coarser levels for queries whose neighbourhood is empty at the finer scale: kLevelRatio x the edge each, same origin,
+    // as long as the level above still has more than a handful of cells per axis
+    float ratio = kLevelRatio;
+    if (const char* e = std::getenv("MRGFE_NN_COARSE_RATIO")) ratio = std::max(2.0f, static_cast<float>(std::atof(e)));  // tuning hooks
+    if (const char* e = std::getenv("MRGFE_NN_FINE_RINGS")) h_.fine_rings = std::max(1, std::atoi(e));
+    while (h_.n_levels < std::min(max_levels, kNnMaxLevels)) {
+        const NnGridDev& below = h_.level[h_.n_levels - 1];
+        if (std::max(below.dim[0], std::max(below.dim[1], below.dim[2])) <= 4) break;
+        MRGFE_TRY(build_level(ctx, d_pts, nn, bb, below.cell * ratio, tab, h_.level[h_.n_levels], d_cell_start_[h_.n_levels], d_sorted_[h_.n_levels], false, nullptr));
+        ++h_.n_levels;
     }
     built_ = true;
     return MRGFE_OK;
@@ -182,10 +218,8 @@ void ctx_tmp_grid_free(mrgfe_ctx* ctx)
 
 void NnGrid::release()
 {
-    d_cell_start_.release();
-    d_sorted_.release();
-    d_cell_start2_.release();
-    d_sorted2_.release();
+    for (auto& b : d_cell_start_) b.release();
+    for (auto& b : d_sorted_) b.release();
     built_ = false;
 }
 
@@ -303,7 +337,7 @@ int NnGrid::fitness(mrgfe_ctx* ctx, const float4* d_src, size_t n_src, const flo
 {
     *out = DBL_MAX;
     if (!built_) { set_error("NnGrid::fitness before build"); return MRGFE_ERR_STATE; }
-    if (n_src == 0 || h_.fine.n == 0) return MRGFE_OK;
+    if (n_src == 0 || h_.level[0].n == 0) return MRGFE_OK;
     NnFitnessJob job = make_fitness_job(d_src, n_src, T);
     return nn_fitness_batch(ctx, &job, 1, max_range, out);
 }
@@ -371,8 +405,8 @@ int NnGrid::radius_count_flags(mrgfe_ctx* ctx, const float4* d_q, size_t n, doub
     if (n == 0) return MRGFE_OK;
     const uint32_t nn = static_cast<uint32_t>(n);
     // every point within r of the query lies within ceil(r / cell) + 1 rings of its cell
-    const int rings = static_cast<int>(std::ceil(std::sqrt(r2) / h_.fine.cell)) + 1;
-    hipLaunchKernelGGL(nn_radius_flags_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, h_.fine, d_q, nn, r2, need, rings, d_flags);
+    const int rings = static_cast<int>(std::ceil(std::sqrt(r2) / h_.level[0].cell)) + 1;
+    hipLaunchKernelGGL(nn_radius_flags_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, h_.level[0], d_q, nn, r2, need, rings, d_flags);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }
@@ -380,8 +414,11 @@ int NnGrid::radius_count_flags(mrgfe_ctx* ctx, const float4* d_q, size_t n, doub
 // k nearest neighbours, one wavefront per query.  The running top-k list lives in registers, entry j in lane j, kept
 // sorted by (squared distance, index); the wave reads 64 candidates of a cell run per step (coalesced), ballots the ones
 // that beat the current k-th entry and inserts them one at a time with a popcount for the slot and one lane shift.
-// (distance, index) is a total order, so the result does not depend on the visiting order.
-__global__ __launch_bounds__(256) void nn_knn_kernel(NnGridDev g, const float4* __restrict__ q, uint32_t n, int k, int32_t* __restrict__ idx, float* __restrict__ sqd)
+// (distance, index) is a total order, so the result does not depend on the visiting order.  A query walks kKnnRings rings
+// of a level and then starts over on the next coarser one (sparse surroundings: the k-th neighbour is many fine cells
+// away); candidates it meets again there are recognised in the list by their (distance, index) and skipped.
+constexpr int kKnnRings = 2;
+__global__ __launch_bounds__(256) void nn_knn_kernel(NnGrid2Dev g, const float4* __restrict__ q, uint32_t n, int k, int32_t* __restrict__ idx, float* __restrict__ sqd)
 {
     const uint32_t i = (blockIdx.x * 256u + threadIdx.x) >> 6;
     if (i >= n) return;  // uniform per wave
@@ -392,41 +429,58 @@ __global__ __launch_bounds__(256) void nn_knn_kernel(NnGridDev g, const float4* 
     float        kth_d = INFINITY;  // current k-th entry (uniform); (inf, max) while the list is not full
     int32_t      kth_i = 0x7fffffff;
     int          cnt = 0;
-    int          c[3];
-    if (g.n > 0 && nn_cell_of(g, p.x, p.y, p.z, c)) {
-        nn_walk_ranges(
-            g, c, nn_face_margin(g, c, p.x, p.y, p.z), -1,
-            [&](uint32_t b, uint32_t e) {
-                for (uint32_t base = b; base < e; base += 64u) {
-                    const uint32_t kk = base + lane;
-                    const bool     valid = kk < e;
-                    float          d = INFINITY;
-                    int32_t        ci = 0x7fffffff;
-                    if (valid) {
-                        const float4 cand = g.sorted[kk];
-                        d = sqdist3f(cand.x, cand.y, cand.z, p.x, p.y, p.z);
-                        ci = __float_as_int(cand.w);
+    if (g.level[0].n > 0 && finite3(p.x, p.y, p.z)) {
+        bool done = false;
+        for (int l = 0; l < g.n_levels && !done; ++l) {
+            const NnGridDev& lv = g.level[l];
+            const bool       again = l > 0;  // candidates may already be in the list
+            int              c[3];
+            nn_cell_of(lv, p.x, p.y, p.z, c);
+            int rmax = 0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) rmax = max(rmax, max(c[a], lv.dim[a] - 1 - c[a]));
+            const int last_ring = l + 1 < g.n_levels ? min(rmax, kKnnRings) : rmax;
+            done = true;  // unless the walk below runs out of rings on this level
+            nn_walk_ranges(
+                lv, c, nn_face_margin(lv, c, p.x, p.y, p.z), last_ring,
+                [&](uint32_t b, uint32_t e) {
+                    for (uint32_t base = b; base < e; base += 64u) {
+                        const uint32_t kk = base + lane;
+                        const bool     valid = kk < e;
+                        float          d = INFINITY;
+                        int32_t        ci = 0x7fffffff;
+                        if (valid) {
+                            const float4 cand = lv.sorted[kk];
+                            d = sqdist3f(cand.x, cand.y, cand.z, p.x, p.y, p.z);
+                            ci = __float_as_int(cand.w);
+                        }
+                        uint64_t m = __ballot(valid && (d < kth_d || (d == kth_d && ci < kth_i)));
+                        while (m) {
+                            const int src = __ffsll(static_cast<unsigned long long>(m)) - 1;
+                            m &= m - 1;
+                            const float   cd = __shfl(d, src);
+                            const int32_t cci = __shfl(ci, src);
+                            if (!(cd < kth_d || (cd == kth_d && cci < kth_i))) continue;  // the k-th entry moved since the ballot
+                            if (again && __ballot(td == cd && ti == cci)) continue;       // met on a finer level already
+                            const bool    mine_less = td < cd || (td == cd && ti < cci);
+                            const int     pos = __popcll(__ballot(mine_less));  // sorted list: the lanes below pos hold the smaller entries
+                            const float   up_d = __shfl_up(td, 1);
+                            const int32_t up_i = __shfl_up(ti, 1);
+                            if (lane == pos) { td = cd; ti = cci; }
+                            else if (lane > pos) { td = up_d; ti = up_i; }
+                            if (lane >= k) { td = INFINITY; ti = 0x7fffffff; }
+                            if (cnt < k) ++cnt;
+                            if (cnt == k) { kth_d = __shfl(td, k - 1); kth_i = __shfl(ti, k - 1); }
+                        }
                     }
-                    uint64_t m = __ballot(valid && (d < kth_d || (d == kth_d && ci < kth_i)));
-                    while (m) {
-                        const int src = __ffsll(static_cast<unsigned long long>(m)) - 1;
-                        m &= m - 1;
-                        const float   cd = __shfl(d, src);
-                        const int32_t cci = __shfl(ci, src);
-                        if (!(cd < kth_d || (cd == kth_d && cci < kth_i))) continue;  // the k-th entry moved since the ballot
-                        const bool     mine_less = td < cd || (td == cd && ti < cci);
-                        const int      pos = __popcll(__ballot(mine_less));  // sorted list: the lanes below pos hold the smaller entries
-                        const float    up_d = __shfl_up(td, 1);
-                        const int32_t  up_i = __shfl_up(ti, 1);
-                        if (lane == pos) { td = cd; ti = cci; }
-                        else if (lane > pos) { td = up_d; ti = up_i; }
-                        if (lane >= k) { td = INFINITY; ti = 0x7fffffff; }
-                        if (cnt < k) ++cnt;
-                        if (cnt == k) { kth_d = __shfl(td, k - 1); kth_i = __shfl(ti, k - 1); }
-                    }
-                }
-            },
-            [&](double bound_sq) { return cnt == k && static_cast<double>(kth_d) < bound_sq; });
+                },
+                [&](double bound_sq) { return cnt == k && static_cast<double>(kth_d) < bound_sq; });
+            // conclusive iff everything beyond the walked rings is farther than the k-th entry (or the level is exhausted)
+            if (last_ring < rmax) {
+                const double bnd = static_cast<double>(last_ring) * static_cast<double>(lv.cell) + nn_face_margin(lv, c, p.x, p.y, p.z);
+                done = cnt == k && static_cast<double>(kth_d) < bnd * bnd * (1.0 - 1e-5);
+            }
+        }
     }
     if (lane < k) {
         idx[size_t(i) * k + lane] = lane < cnt ? ti : -1;
@@ -441,7 +495,7 @@ int NnGrid::knn_device(mrgfe_ctx* ctx, const float4* d_q, size_t n, int k, int32
     if (n == 0) return MRGFE_OK;
     if (n > (0xffffffffu >> 6)) { set_error("NnGrid::knn: too many queries"); return MRGFE_ERR_INVALID; }
     const uint32_t nn = static_cast<uint32_t>(n);
-    hipLaunchKernelGGL(nn_knn_kernel, dim3((nn + 3) / 4), dim3(256), 0, ctx->stream, h_.fine, d_q, nn, k, d_idx, d_sqd);
+    hipLaunchKernelGGL(nn_knn_kernel, dim3((nn + 3) / 4), dim3(256), 0, ctx->stream, h_, d_q, nn, k, d_idx, d_sqd);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }

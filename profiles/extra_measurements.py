@@ -109,6 +109,27 @@ def main():
                    "dt_m": float(np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3])), "dr_rad": synth.rotation_angle(Tg, To),
                    "iterations": [g.getFinalNumIteration(), o.getFinalNumIteration()]}
 
+    # ---- GICP on the full-size (distance-filtered, ~130k point) scans: BASELINE config[2] shape -------------------------
+    g2 = GicpHip(transformation_epsilon=0.1, ctx=ctx)
+    tg = []
+    for _ in range(3):
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        g2.setInputTarget(scans[0])
+        g2.setInputSource(scans[1])
+        g2.align(guess)
+        tg.append(time.perf_counter() - t1)
+    o2 = orc.FastGicp(transformation_epsilon=0.1, num_threads=cores)
+    t1 = time.perf_counter()
+    o2.setInputTarget(scans[0])
+    o2.setInputSource(scans[1])
+    o2.align(guess)
+    tcpu = time.perf_counter() - t1
+    Tg, To = g2.getFinalTransformation(), o2.getFinalTransformation()
+    out["gicp_full_size"] = {"points": [len(scans[0]), len(scans[1])], "gpu_ms": 1e3 * float(np.median(tg[1:])), "cpu_oracle_ms": 1e3 * tcpu, "cpu_threads": cores,
+                             "dt_m": float(np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3])), "dr_rad": synth.rotation_angle(Tg, To),
+                             "iterations": [g2.getFinalNumIteration(), o2.getFinalNumIteration()]}
+
     # ---- prefilter chain --------------------------------------------------------------------------------------------
     tp = []
     for _ in range(5):

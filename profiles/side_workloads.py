@@ -31,6 +31,16 @@ def main():
             g.setInputSource(fs)
             g.align(rel @ synth.make_pose([0.3, -0.2, 0.05], synth.rot_z(0.03)))
         print("gicp iterations", g.getFinalNumIteration())
+    if which == "gicp_full":  # ~130k-point clouds (distance filter only): BASELINE config[2] shape
+        from mrg_slam_amd import distance_filter
+
+        a, b = distance_filter(raw[0], 0.1, 35.0, ctx=ctx), distance_filter(raw[1], 0.1, 35.0, ctx=ctx)
+        g = GicpHip(transformation_epsilon=0.1, ctx=ctx)
+        for k in range(3):
+            g.setInputTarget(a)
+            g.setInputSource(b)
+            g.align(rel @ synth.make_pose([0.3, -0.2, 0.05], synth.rot_z(0.03)))
+        print("gicp iterations", g.getFinalNumIteration())
     if which in ("all", "fitness"):
         for k in range(3):
             print("fitness", calc_fitness_score(ft, fs, rel, 2.0, ctx=ctx))
