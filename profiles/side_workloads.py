@@ -41,6 +41,18 @@ def main():
             g.setInputSource(b)
             g.align(rel @ synth.make_pose([0.3, -0.2, 0.05], synth.rot_z(0.03)))
         print("gicp iterations", g.getFinalNumIteration())
+    if which == "lc":  # loop-closure batch: one 130k-point keyframe against 64 candidates, getFitnessScore(inf) of each
+        from mrg_slam_amd import BatchMatcher, distance_filter
+
+        more = synth.arc_trajectory(5)
+        sc = [distance_filter(synth.synth_lidar(scene, more[k], "VLP64", synth.BASE_SEED + k), 0.1, 35.0, ctx=ctx) for k in range(5)]
+        bm = BatchMatcher(ctx=ctx, transformation_epsilon=0.1)
+        t = bm.add_target(sc[0])
+        for b in range(64):
+            bm.add_pair(t, sc[1 + b % 4], synth.warm_guess(np.linalg.inv(more[0]) @ more[1 + b % 4], b))
+        for k in range(2):
+            res = bm.align(float("inf"))
+        print("fitness", res["fitness"][:4])
     if which in ("all", "fitness"):
         for k in range(3):
             print("fitness", calc_fitness_score(ft, fs, rel, 2.0, ctx=ctx))

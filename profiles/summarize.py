@@ -102,8 +102,9 @@ def main():
     extra = os.path.join(OUT, f"extra_{tag}.json")
     if os.path.exists(extra):
         json.dump(json.load(open(extra)), open(os.path.join(ROOT, "profiles", f"{tag}_extra_measurements.json"), "w"), indent=1)
-    # kernel stats of the non-headline paths (profiles/side_workloads.py): GICP, prefilter chain, calc_fitness_score
-    for w in ("gicp", "prefilter", "fitness"):
+    # kernel stats of the non-headline paths (profiles/side_workloads.py): GICP (33k / 130k points), prefilter chain,
+    # calc_fitness_score, loop-closure batch with getFitnessScore
+    for w in ("gicp", "gicp_full", "prefilter", "fitness", "lc"):
         side = os.path.join(OUT, f"prof_side_{w}", "s_kernel_stats.csv")
         if not os.path.exists(side):
             continue
