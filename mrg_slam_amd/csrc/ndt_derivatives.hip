@@ -119,19 +119,18 @@ __device__ __forceinline__ void pair_double(Accum& acc, const double mean[3], co
             CJ[r][c] = c < 3 ? C[r * 3 + c] : (c == 3 ? fdot3d_z(C[r * 3 + 1], J[1][c], C[r * 3 + 2], J[2][c]) : fdot3d(C[r * 3 + 0], J[0][c], C[r * 3 + 1], J[1][c], C[r * 3 + 2], J[2][c]));
         qCJ[c] = fdot3d(q[0], CJ[0][c], q[1], CJ[1][c], q[2], CJ[2][c]);
     }
+    // Everything here is f64, so the reference's H(i,j) and H(j,i) differ by rounding at the 1e-16 level — far below the
+    // noise of the summation order — and so does q.(C PH) against (C q).PH for the numerically symmetric inverse
+    // covariance: only the upper triangle is evaluated (mirrored in the epilogue) and the second-derivative term reuses
+    // C q.  (The float path keeps all 36 entries: there the two roundings differ by 1e-7 and it matters.)
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
+        for (int j = i; j < 6; ++j) {
             double qch = 0.0;
-            if (i >= 3 && j >= 3) {
-                const int lo = i < j ? i : j, hi = i < j ? j : i;
-                const int ph = (lo == 3) ? (hi - 3) : (lo == 4 ? (hi - 4 + 3) : 5);
-                double CH[3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-                    CH[r] = ph < 3 ? fdot3d_z(C[r * 3 + 1], PH[ph][1], C[r * 3 + 2], PH[ph][2]) : fdot3d(C[r * 3 + 0], PH[ph][0], C[r * 3 + 1], PH[ph][1], C[r * 3 + 2], PH[ph][2]);
-                qch = fdot3d(q[0], CH[0], q[1], CH[1], q[2], CH[2]);
+            if (i >= 3) {
+                const int ph = (i == 3) ? (j - 3) : (i == 4 ? (j - 4 + 3) : 5);
+                qch = ph < 3 ? fdot3d_z(Cq[1], PH[ph][1], Cq[2], PH[ph][2]) : fdot3d(Cq[0], PH[ph][0], Cq[1], PH[ph][1], Cq[2], PH[ph][2]);
             }
             const double jtcj = j < 3 ? CJ[j][i] : (j == 3 ? fdot3d_z(J[1][3], CJ[1][i], J[2][3], CJ[2][i]) : fdot3d(J[0][j], CJ[0][i], J[1][j], CJ[1][i], J[2][j], CJ[2][i]));
             const double t0 = -gauss_d2 * qCJ[i];
@@ -166,10 +165,13 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2
     constexpr int kHRows = (MODE == 1) ? 1 : 15;
     __shared__ float    s_T[12];
     __shared__ float    s_ja[8][3], s_ha[15][3];
-    __shared__ float    s_xt[3][kTilePts];
-    __shared__ StageT   s_xj[8][kTilePts];
-    __shared__ StageT   s_xh[kHRows][kTilePts];
-    __shared__ uint32_t s_queue[kTilePts * NNB];  // (slot << 24) | leaf id
+    // (the f64 variant stages 23 doubles per point: 59 KB of LDS, two workgroups per CU; staging 128 points at a time to fit
+    // three was measured slower, 0.28 vs 0.26 ms)
+    constexpr int kTile = kTilePts;
+    __shared__ float    s_xt[3][kTile];
+    __shared__ StageT   s_xj[8][kTile];
+    __shared__ StageT   s_xh[kHRows][kTile];
+    __shared__ uint32_t s_queue[kTile * NNB];  // (slot << 24) | leaf id
     __shared__ uint32_t s_scan[8];
     __shared__ double   s_red[4][kNdtPartialStride];
     if (threadIdx.x < 12) s_T[threadIdx.x] = ev.T[threadIdx.x];
@@ -191,16 +193,15 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2
     uint32_t nb_total = 0;
 
     const uint32_t base = blockIdx.x * static_cast<uint32_t>(kTilePts) * ppt;
-    for (int it = 0; it < ppt; ++it) {
-        const uint32_t tile0 = base + it * kTilePts;
-        if (tile0 >= pr.n_src) break;  // uniform
+    const uint32_t last = min(pr.n_src, base + static_cast<uint32_t>(kTilePts) * ppt);  // end of this workgroup's points
+    for (uint32_t tile0 = base; tile0 < last; tile0 += kTile) {
         // ---- phase 1: one lane per point -------------------------------------------------------------------------
         const uint32_t i = tile0 + threadIdx.x;
         int32_t  ids[NNB];
         uint32_t cnt = 0;
 #pragma unroll
         for (int n = 0; n < NNB; ++n) ids[n] = -1;
-        if (i < pr.n_src) {
+        if (threadIdx.x < kTile && i < last) {
             const float4 p = pr.src[i];
             float xt[3];
             transform_point(s_T, p.x, p.y, p.z, xt[0], xt[1], xt[2]);
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2
 #pragma unroll
     for (int k = 0; k < 6; ++k) vals[1 + k] = acc.g[k];
 #pragma unroll
-    for (int k = 0; k < 36; ++k) vals[7 + k] = acc.H[k];
+    for (int k = 0; k < 36; ++k) vals[7 + k] = (MODE == 2 && k / 6 > k % 6) ? acc.H[(k % 6) * 6 + k / 6] : acc.H[k];  // the f64 pass fills the upper triangle
     vals[kNdtNbIndex] = static_cast<double>(nb_total);
 #pragma unroll
     for (int k = 0; k < kNdtAccum; ++k) {
