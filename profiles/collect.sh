@@ -14,5 +14,5 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES 
 for w in gicp gicp_full prefilter fitness lc; do
     rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_side_$w -o s -- python3 profiles/side_workloads.py $w > gpurun_out/side_$w.log 2>&1
 done
-python3 profiles/extra_measurements.py > gpurun_out/extra_$tag.json 2> gpurun_out/extra_$tag.err
+python3 tests/extra_measurements.py > gpurun_out/extra_$tag.json 2> gpurun_out/extra_$tag.err
 tail -1 gpurun_out/bench_$tag.json | cut -c1-400

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Side measurements quoted in DESIGN.md §6 (not the headline metric): run on the GPU box, prints one JSON object.
+Lives under tests/ because it times the CPU oracle beside the GPU path (only tests/, smoke() and bench.py may use oracle/).
 
 * host-pointer (PCIe-inclusive) batched NDT throughput: clouds handed over as host buffers every step
 * single-pair NDT latency through one pcl::Registration-style handle

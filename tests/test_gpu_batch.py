@@ -99,3 +99,48 @@ def test_batch_edge_cases():
     res = bm.align()
     assert res[0]["converged"] == 1
     assert res[1]["converged"] == 0 and res[2]["converged"] == 0
+
+
+def test_two_contexts_from_two_threads_give_the_sequential_results():
+    """Handles on distinct contexts (= HIP streams) are independent (SURVEY.md §8b threading row: the odometry and the
+    loop-closure handles live in different threads of one process)."""
+    import threading
+
+    from mrg_slam_amd import BatchMatcher, Context, synth
+    from mrg_slam_amd.registration import result_matrix
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(12)
+    jobs = []
+    for w in range(2):
+        tgt = small_cloud(6000, 300 + w)
+        pairs = []
+        for k in range(6):
+            rel = synth.make_pose(rng.normal(0, 0.2, 3), synth.rot_xyz(*rng.normal(0, 0.02, 3)))
+            pairs.append((orc.transform_points(np.linalg.inv(rel), tgt[: 3000 + 400 * k]), synth.perturb_pose(np.eye(4), rng)))
+        jobs.append((tgt, pairs))
+
+    def run(ctx, job, out, slot, repeats):
+        tgt, pairs = job
+        bm = BatchMatcher(ctx=ctx, transformation_epsilon=0.01)
+        t = bm.add_target(tgt)
+        for src, guess in pairs:
+            bm.add_pair(t, src, guess)
+        for _ in range(repeats):
+            res = bm.align(fitness_max_range=float("inf"))
+        out[slot] = res
+
+    seq, par = [None, None], [None, None]
+    ctxs = [Context(0), Context(0)]
+    for w in range(2):
+        run(ctxs[w], jobs[w], seq, w, 1)
+    threads = [threading.Thread(target=run, args=(ctxs[w], jobs[w], par, w, 5)) for w in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for w in range(2):
+        assert len(par[w]) == len(seq[w]) == 6
+        for k in range(6):
+            np.testing.assert_array_equal(result_matrix(par[w][k]), result_matrix(seq[w][k]))
+            assert par[w][k]["fitness"] == seq[w][k]["fitness"] and par[w][k]["iterations"] == seq[w][k]["iterations"]
