@@ -24,7 +24,7 @@
 
 namespace mrgfe {
 
-__constant__ int8_t kOff7[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+// DIRECT7 probes: the voxel of the point, then +x, -x, +y, -y, +z, -z (pclomp getNeighborhoodAtPoint7)
 
 constexpr int kTilePts = 256;  // points per tile == threads per workgroup
 
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2
     const bool spec = (MODE == 2) && ev.mode == 0 && ev.spec != 0;
     if (!ev.active || (ev.mode != MODE && !spec)) return;
     const uint32_t part_off = pr.part_off + (spec ? spec_part_base : 0u);
-    const NdtGridDev& g = grids[pr.grid];
+    const NdtGridDev g = grids[pr.grid];  // by value: the grid parameters live in scalar registers for the whole kernel
 
     using StageT = typename std::conditional<MODE == 2, double, float>::type;  // precision of the staged point terms
     constexpr int kHRows = (MODE == 1) ? 1 : 15;
@@ -206,19 +206,44 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2
             float xt[3];
             transform_point(s_T, p.x, p.y, p.z, xt[0], xt[1], xt[2]);
             // getNeighborhoodAtPoint: floor(p / leaf_size)
-            const int ijk[3] = {static_cast<int>(floorf(xt[0] / leaf)), static_cast<int>(floorf(xt[1] / leaf)), static_cast<int>(floorf(xt[2] / leaf))};
+            int ijk[3];
+            if (leaf == 1.0f) {  // uniform; x / 1.0f == x exactly, and the IEEE division sequence is ~10 instructions per axis
+                ijk[0] = static_cast<int>(floorf(xt[0])); ijk[1] = static_cast<int>(floorf(xt[1])); ijk[2] = static_cast<int>(floorf(xt[2]));
+            } else {
+                ijk[0] = static_cast<int>(floorf(xt[0] / leaf)); ijk[1] = static_cast<int>(floorf(xt[1] / leaf)); ijk[2] = static_cast<int>(floorf(xt[2] / leaf));
+            }
+            // per axis: is cell (ijk - 1, ijk, ijk + 1) inside the grid box?  key of a neighbour = key of the centre cell +
+            // offset . divb_mul (two's-complement arithmetic: the centre itself may lie outside while a neighbour is inside)
+            bool in_box[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int o = -1; o <= 1; ++o) in_box[a][o + 1] = ijk[a] + o >= g.min_b[a] && ijk[a] + o <= g.max_b[a];
+            const uint32_t mul[3] = {static_cast<uint32_t>(g.divb_mul[0]), static_cast<uint32_t>(g.divb_mul[1]), static_cast<uint32_t>(g.divb_mul[2])};
+            const uint32_t key0 = (static_cast<uint32_t>(ijk[0]) - static_cast<uint32_t>(g.min_b[0])) * mul[0] + (static_cast<uint32_t>(ijk[1]) - static_cast<uint32_t>(g.min_b[1])) * mul[1] +
+                                  (static_cast<uint32_t>(ijk[2]) - static_cast<uint32_t>(g.min_b[2])) * mul[2];
+            uint32_t keys[NNB];
+            bool     ok[NNB];
 #pragma unroll
             for (int n = 0; n < NNB; ++n) {
                 int o0, o1, o2;
                 if (NNB == 27) { o0 = n / 9 - 1; o1 = (n / 3) % 3 - 1; o2 = n % 3 - 1; }
-                else           { o0 = kOff7[n][0]; o1 = kOff7[n][1]; o2 = kOff7[n][2]; }
-                const int c0 = ijk[0] + o0, c1 = ijk[1] + o1, c2 = ijk[2] + o2;
-                int32_t id = -1;
-                if (c0 >= g.min_b[0] && c0 <= g.max_b[0] && c1 >= g.min_b[1] && c1 <= g.max_b[1] && c2 >= g.min_b[2] && c2 <= g.max_b[2]) {
-                    const uint32_t key = static_cast<uint32_t>((c0 - g.min_b[0]) * g.divb_mul[0] + (c1 - g.min_b[1]) * g.divb_mul[1] + (c2 - g.min_b[2]) * g.divb_mul[2]);
-                    id = ndt_lookup(g, key);
-                }
-                ids[n] = id;
+                else if (NNB == 7) { o0 = (n == 1) - (n == 2); o1 = (n == 3) - (n == 4); o2 = (n == 5) - (n == 6); }  // kOff7, folded at compile time
+                else           { o0 = o1 = o2 = 0; }
+                ok[n] = in_box[0][o0 + 1] && in_box[1][o1 + 1] && in_box[2][o2 + 1];
+                keys[n] = key0 + static_cast<uint32_t>(o0) * mul[0] + static_cast<uint32_t>(o1) * mul[1] + static_cast<uint32_t>(o2) * mul[2];
+            }
+            if (g.dense) {
+                // all probes of the point in flight together (a probe-by-probe loop waits for each load in turn)
+                const int32_t* __restrict__ table = static_cast<const int32_t*>(g.lookup);
+                int32_t v[NNB];
+#pragma unroll
+                for (int n = 0; n < NNB; ++n) v[n] = table[ok[n] ? keys[n] : 0u];
+#pragma unroll
+                for (int n = 0; n < NNB; ++n) ids[n] = ok[n] ? v[n] : -1;
+            } else {
+#pragma unroll
+                for (int n = 0; n < NNB; ++n) ids[n] = ok[n] ? ndt_lookup(g, keys[n]) : -1;
             }
             if (kdtree) {
                 // radiusSearch(point, resolution) over voxel centroids: FLANN keeps dist^2 < r^2
