@@ -372,8 +372,19 @@ __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __res
     __shared__ double s[4][kNdtPartialStride];
     const int k = threadIdx.x & 63, slice = threadIdx.x >> 6;
     if (k < kNdtPartialStride) {
-        double acc = 0.0;
-        for (uint32_t b = slice; b < nblk; b += 4) acc += partials[(size_t)(pr.part_off + b) * kNdtPartialStride + k];
+        // the additions stay in order; eight loads are in flight ahead of them (a straggler round has one pair with 500
+        // records, and a load-add-load-add chain over them took longer than the derivative kernel it follows)
+        const double* col = partials + (size_t)pr.part_off * kNdtPartialStride + k;
+        double   acc = 0.0;
+        uint32_t b = slice;
+        for (; b + 28 < nblk; b += 32) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(b + 4 * u) * kNdtPartialStride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; b < nblk; b += 4) acc += col[(size_t)b * kNdtPartialStride];
         s[slice][k] = acc;
     }
     __syncthreads();
