@@ -150,9 +150,8 @@ def main():
     gc.collect()
     gc.freeze()
     per_mode = np.zeros((3, 3))  # [mode] -> (device ms, launches, algorithmic bytes), HIP events around every launch
+    launched = np.zeros(2)       # (source points, valid point-voxel pairs) of the evaluations actually launched
     evals = iters = 0
-    pts_evals = 0.0
-    src_sizes = np.array([len(scans[p[1]]) for p in pairs], dtype=np.float64)
     t0 = time.perf_counter()
     step_ms = []
     for _ in range(args.steps):
@@ -161,8 +160,8 @@ def main():
         step_ms.append(1e3 * (time.perf_counter() - ts))
         for m in range(3):
             per_mode[m] += bm.kernel_stats(m)
+        launched += np.array(bm.pair_counts())
         evals += int(res["evaluations"].sum())
-        pts_evals += float(np.dot(res["evaluations"].astype(np.float64), src_sizes))
         iters += int(res["iterations"].sum())
     sync()
     elapsed = time.perf_counter() - t0
@@ -194,9 +193,9 @@ def main():
             reg.align(guess)
             lat.append(time.perf_counter() - t1)
         single_ms = 1e3 * float(np.median(lat[1:]))
-    # mean valid neighbour voxels per point and evaluation (k-bar of SURVEY.md §8d), from the byte accounting:
-    # bytes = 72 * point_evaluations + 48 * valid_neighbours
-    kbar = (float(per_mode[:, 2].sum()) - 72.0 * pts_evals) / 48.0 / pts_evals if pts_evals else 0.0
+    # mean valid neighbour voxels per point of the evaluations actually launched (k-bar of SURVEY.md §8d); evaluations a
+    # controller answers from its cache (repeated line-search trials) are neither launched nor counted
+    kbar = float(launched[1] / launched[0]) if launched[0] else 0.0
     # ---- CPU baseline + parity on a bounded sample of the same pairs ---------------------------------------------------
     cpu = None
     parity = None

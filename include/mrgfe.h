@@ -201,6 +201,9 @@ int  mrgfe_batch_num_pairs(const mrgfe_batch* b);
  * For GICP_HIP registrations `mode` is ignored and the linearize kernel is reported. */
 int  mrgfe_batch_kernel_stats(const mrgfe_batch* b, int mode, double* deriv_ms, int64_t* deriv_launches, double* deriv_alg_bytes);
 int  mrgfe_reg_kernel_stats(const mrgfe_reg* reg, int mode, double* deriv_ms, int64_t* deriv_launches, double* deriv_alg_bytes);
+/* source points and valid (point, voxel) pairs of the derivative evaluations the last mrgfe_batch_align launched: their ratio
+ * is the k-bar of SURVEY.md §8(d) (evaluations answered from a controller's cache are not launched and not counted) */
+int  mrgfe_batch_pair_counts(const mrgfe_batch* b, int mode, double* points, double* neighbours);
 
 /* ---- diagnostic entry points for the primitive tests (tests/test_gpu_primitives.py) --------------------------- */
 int mrgfe_dbg_sort_pairs(mrgfe_ctx* ctx, const uint32_t* keys, const uint32_t* vals, size_t n, int key_bits, uint32_t* out_keys, uint32_t* out_vals);

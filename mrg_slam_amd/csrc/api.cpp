@@ -655,6 +655,17 @@ int mrgfe_batch_kernel_stats(const mrgfe_batch* b, int mode, double* ms, int64_t
     return MRGFE_OK;
 }
 
+int mrgfe_batch_pair_counts(const mrgfe_batch* b, int mode, double* points, double* neighbours)
+{
+    if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
+    double p = 0, n = 0;
+    for (int m = 0; m < 3; ++m)
+        if (mode < 0 || mode == m) { p += b->ndt->mode_points[m]; n += b->ndt->mode_neighbours[m]; }
+    if (points) *points = p;
+    if (neighbours) *neighbours = n;
+    return MRGFE_OK;
+}
+
 // ---- diagnostics ----------------------------------------------------------------------------------------------
 int mrgfe_dbg_sort_pairs(mrgfe_ctx* ctx, const uint32_t* keys, const uint32_t* vals, size_t n, int key_bits, uint32_t* out_keys, uint32_t* out_vals)
 {

@@ -472,6 +472,8 @@ int NdtEngine::finish_group(RoundGroup& g)
         // SURVEY.md §8(d) byte model: point (16) + probes (8 each) + 48 per valid neighbour voxel
         const double bytes = double(pairs_[i].n) * (16.0 + 8.0 * probes) + r[kNdtNbIndex] * 48.0;
         mode_alg_bytes[c.request().mode] += bytes;
+        mode_points[c.request().mode] += double(pairs_[i].n);
+        mode_neighbours[c.request().mode] += r[kNdtNbIndex];
         if (c.request().mode == 0 && c.request().spec_hessian) mode_alg_bytes[2] += bytes;  // the speculative f64 pass reads the same data
     }
     const size_t spec_base = size_t(n_pairs()) * kNdtPartialStride;
@@ -492,7 +494,7 @@ int NdtEngine::align_all()
     MRGFE_TRY(ctx_->bind());
     MRGFE_TRY(build_targets());
     if (pairs_dirty_) MRGFE_TRY(upload_pairs());
-    for (int m = 0; m < 3; ++m) { mode_ms[m] = 0; mode_launches[m] = 0; mode_alg_bytes[m] = 0; }
+    for (int m = 0; m < 3; ++m) { mode_ms[m] = 0; mode_launches[m] = 0; mode_alg_bytes[m] = 0; mode_points[m] = 0; mode_neighbours[m] = 0; }
     for (auto& p : pairs_) {
         p.ctl.start(prm_, p.guess, p.n);
         if (targets_[p.target].status != MRGFE_OK && !p.ctl.done()) p.ctl.abort_no_target();

@@ -61,6 +61,8 @@ class NdtEngine {
     double  mode_ms[3] = {0, 0, 0};
     int64_t mode_launches[3] = {0, 0, 0};
     double  mode_alg_bytes[3] = {0, 0, 0};
+    double  mode_points[3] = {0, 0, 0};      // source points of the evaluations actually launched (reused trials are not)
+    double  mode_neighbours[3] = {0, 0, 0};  // valid (point, voxel) pairs they found
     void kernel_stats(int mode, double* ms, int64_t* launches, double* bytes) const
     {
         double m = 0, b = 0;

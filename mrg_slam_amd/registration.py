@@ -270,6 +270,12 @@ class BatchMatcher:
         check(lib().mrgfe_batch_align(self._h, fitness_max_range, res))
         return results_to_numpy(res, n)
 
+    def pair_counts(self, mode: int = -1):
+        """(source points, valid point-voxel pairs) of the derivative evaluations the last align launched."""
+        p, n = C.c_double(0), C.c_double(0)
+        check(lib().mrgfe_batch_pair_counts(self._h, mode, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
     def kernel_stats(self, mode: int = -1):
         """(device ms, launches, algorithmic bytes) of the derivative kernel variant `mode` (-1: all) in the last align()."""
         ms, n, b = C.c_double(0), C.c_int64(0), C.c_double(0)
