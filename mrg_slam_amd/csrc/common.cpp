@@ -198,7 +198,13 @@ int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_byte
     if (n == 0) return MRGFE_OK;
     if (stride_bytes == 0) stride_bytes = 16;
     if (stride_bytes < 16 || (stride_bytes % 4) != 0) { set_error("point stride must be a multiple of 4 and >= 16 bytes (got %zu)", stride_bytes); return MRGFE_ERR_INVALID; }
-    PinBuf& pb = ctx->pin[pin_slot];
+    (void)pin_slot;
+    const int slot = ctx->up_next;
+    ctx->up_next ^= 1;
+    if (!ctx->up_ev[slot]) MRGFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->up_ev[slot], hipEventDisableTiming));
+    // this staging buffer may still be the source of the copy issued two uploads ago
+    if (ctx->up_busy[slot]) { MRGFE_HIP_CHECK(hipEventSynchronize(ctx->up_ev[slot])); ctx->up_busy[slot] = false; }
+    PinBuf& pb = ctx->up_pin[slot];
     MRGFE_TRY(pb.ensure(n * 16));
     float* dst = pb.as<float>();
     if (stride_bytes == 16) {
@@ -208,9 +214,9 @@ int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_byte
         for (size_t i = 0; i < n; ++i) std::memcpy(dst + 4 * i, src + i * stride_bytes, 16);
     }
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_dst, dst, n * 16, hipMemcpyHostToDevice, ctx->stream));
-    // the staging buffer is reused by the next upload: wait for the copy engine to drain it
-    MRGFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    return MRGFE_OK;
+    MRGFE_HIP_CHECK(hipEventRecord(ctx->up_ev[slot], ctx->stream));
+    ctx->up_busy[slot] = true;
+    return MRGFE_OK;  // stream-ordered: later work on ctx->stream sees the cloud; the caller's buffer is already free
 }
 
 }  // namespace mrgfe
@@ -262,6 +268,8 @@ void mrgfe_ctx_destroy(mrgfe_ctx* ctx)
     mrgfe::ctx_tmp_grid_free(ctx);
     for (auto& b : ctx->scratch) b.release();
     for (auto& b : ctx->pin) b.release();
+    for (auto& b : ctx->up_pin) b.release();
+    for (auto& e : ctx->up_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (auto& pr : ctx->ev_mode) for (auto& e : pr) if (e) (void)hipEventDestroy(e);

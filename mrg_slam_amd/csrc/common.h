@@ -86,6 +86,10 @@ struct mrgfe_ctx {
     hipEvent_t   ev_mode[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // per NDT kernel variant
     mrgfe::DevBuf scratch[12];                  // named by the algorithms that use them
     mrgfe::PinBuf pin[4];
+    mrgfe::PinBuf up_pin[2];                    // upload_cloud staging ring: the host packs cloud k + 1 while cloud k is on the wire
+    hipEvent_t   up_ev[2] = {nullptr, nullptr};
+    bool         up_busy[2] = {false, false};
+    int          up_next = 0;
     int          cu_count = 256;
     mrgfe::NnGrid* tmp_grid = nullptr;          // reusable exact-NN grid of the stateless filter / fitness calls (nn_grid.hip)
     std::recursive_mutex mu;                    // serialises API calls that share this context's stream / workspaces
