@@ -92,3 +92,35 @@ def test_tum_round_trip_and_formatting(tmp_path):
     assert mio.read_tum(str(tmp_path / "traj_cpp.txt"))[1][3][1, 3] == -2.5
     q = mio.quat_from_rot(poses[3][:3, :3])
     assert abs(np.linalg.norm(q) - 1) < 1e-12 and np.allclose(mio.rot_from_quat(q), poses[3][:3, :3], atol=1e-12)
+
+
+def test_bench_kitti_root_hook(tmp_path, monkeypatch):
+    """bench.py's optional KITTI_ROOT input: velodyne .bin scans plus lidar-frame ground truth
+    inv(Tr) * pose * Tr from poses/00.txt and calib.txt (kitti_singlerobot_processor.py:95-98)."""
+    import importlib
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    seq = tmp_path / "sequences" / "00"
+    (seq / "velodyne").mkdir(parents=True)
+    (tmp_path / "poses").mkdir()
+    clouds = [_cloud(300 + k, 50 + k) for k in range(3)]
+    for k, c in enumerate(clouds):
+        mio.write_kitti_bin(str(seq / "velodyne" / f"{k:06d}.bin"), c)
+    Tr = synth.make_pose([0.27, -0.08, -0.05], synth.rot_xyz(-1.57, 0.02, -1.55))
+    lidar = [synth.make_pose([1.0 * k, 0.1 * k, 0.0], synth.rot_z(0.02 * k)) for k in range(3)]
+    cam = [Tr @ L @ np.linalg.inv(Tr) for L in lidar]
+    np.savetxt(tmp_path / "poses" / "00.txt", np.array([c[:3, :].reshape(12) for c in cam]))
+    (seq / "calib.txt").write_text("P0: " + " ".join(["0"] * 12) + "\nTr: " + " ".join(repr(float(v)) for v in Tr[:3, :].reshape(12)) + "\n")
+    monkeypatch.setenv("KITTI_ROOT", str(tmp_path))
+    scene, poses, scans = bench.make_workload(2, 4, 0, "distance")
+    assert scene is None and len(scans) == 3 and len(poses) == 3
+    for k in range(3):
+        assert np.array_equal(scans[k], clouds[k])
+        assert np.allclose(poses[k], lidar[k], atol=1e-9)
+    monkeypatch.delenv("KITTI_ROOT")
+    scene, poses, scans = bench.make_workload(1, 2, 0, "distance")
+    assert scene is not None and len(scans) == 2 and scans[0].shape[1] == 4
