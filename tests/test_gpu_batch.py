@@ -41,6 +41,10 @@ def test_batch_equals_sequential_registrations():
         assert res[k]["fitness"] == pytest.approx(reg.getFitnessScore(), rel=1e-12)
     ms, launches, nbytes = bm.kernel_stats()
     assert ms > 0 and launches > 0 and nbytes > 0
+    # launched evaluations only: points x (16 + 7 x 8) + valid neighbours x 48 is the byte model of SURVEY.md §8(d)
+    pts, nbrs = bm.pair_counts()
+    assert pts > 0 and 0 < nbrs / pts <= 7
+    assert nbytes == pytest.approx(pts * 72 + nbrs * 48, rel=1e-12)
 
 
 def test_gicp_batch_equals_sequential_registrations_and_oracle():
