@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — scan-pair NDT alignments per second on MI355X (BASELINE.json metric), one rank per GPU.
 
-Step      = one pass of the hot path over one batch of B synthetic VLP-64 scan pairs already resident in HBM:
+Step      = one pass of the hot path over one batch of B (default 256: the candidate-batch size of BASELINE config[3])
+            synthetic VLP-64 scan pairs already resident in HBM:
             for every pair  setInputTarget (voxel covariance grid build)  +  setInputSource  +  align(guess)
             (reference call sites: apps/scan_matching_odometry_component.cpp:203,208,265-266; loop_detector.cpp:104,127,134),
             advanced together by the batched engine (one derivative launch per round for all pairs still running).
@@ -72,7 +73,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128, help="scan pairs per step and per GPU (more pairs in flight keep the GPU full in the late rounds)")
+    ap.add_argument("--batch", type=int, default=256, help="scan pairs per step and per GPU (more pairs in flight keep the GPU full in the late rounds)")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic scan pairs generated per rank (reused with different guesses)")
     ap.add_argument("--prefilter", choices=["distance", "full"], default="distance")
     ap.add_argument("--eps", type=float, default=0.1, help="reg_transformation_epsilon (config/mrg_slam.yaml:102)")
