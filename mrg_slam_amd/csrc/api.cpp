@@ -86,6 +86,8 @@ struct mrgfe_batch {
     NdtEngine*       ndt = nullptr;   // holds the clouds, targets and pairs of the batch for both methods; aligns them for NDT_HIP
     std::vector<GicpEngine*> gicp;    // GICP_HIP: one engine per target (its covariances and correspondence grid are computed once)
     std::vector<float>  gicp_final;   // GICP_HIP: row-major final transformation of every pair
+    GicpBatch*          gicp_batch = nullptr;
+    std::vector<GicpBatchPair> gicp_pairs;  // per-pair device buffers, kept between align calls
     std::vector<NnGrid> fit_grids;  // getFitnessScore grids, one per target; device buffers kept between align calls
 };
 
@@ -515,6 +517,8 @@ void mrgfe_batch_destroy(mrgfe_batch* b)
         MRGFE_LOCK(b->ctx);
         (void)b->ctx->bind();
         for (auto& g : b->fit_grids) g.release();
+        for (auto& gp : b->gicp_pairs) { gp.cov.release(); gp.corr.release(); gp.mahal.release(); }
+        delete b->gicp_batch;
         for (auto* g : b->gicp) delete g;
         delete b->ndt;
     }
@@ -582,11 +586,13 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
     const int P = e.n_pairs();
     const bool gicp = b->params.method == MRGFE_GICP_HIP;
     if (gicp) {
-        // GICP_HIP: the candidates of a target share its covariances and correspondence grid; the LM loops run one pair
-        // after the other (not yet advanced together like the NDT rounds)
+        // GICP_HIP: the candidates of a target share its covariances and correspondence grid, and all LM loops advance
+        // together (GicpBatch: one launch per kernel and round for the pairs still running)
         MRGFE_TRY(b->ctx->bind());
         if (b->gicp.size() < static_cast<size_t>(e.n_targets())) b->gicp.resize(e.n_targets(), nullptr);
-        b->gicp_final.assign(size_t(P) * 16, 0.0f);
+        if (!b->gicp_batch) b->gicp_batch = new GicpBatch(b->ctx);
+        for (size_t i = P; i < b->gicp_pairs.size(); ++i) { b->gicp_pairs[i].cov.release(); b->gicp_pairs[i].corr.release(); b->gicp_pairs[i].mahal.release(); }
+        b->gicp_pairs.resize(P);
         for (int i = 0; i < P; ++i) {
             const NdtPairInfo& p = e.pair(i);
             const NdtTargetInfo& t = e.target(p.target);
@@ -595,17 +601,25 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
                 g = new GicpEngine(b->ctx, gicp_params_from(b->params));
                 MRGFE_TRY(g->set_target(t.d_pts, t.n));
             }
-            MRGFE_TRY(g->set_source(p.d_src, p.n));
-            MRGFE_TRY(g->align(p.guess));
+            GicpBatchPair& bp = b->gicp_pairs[i];
+            bp.target = p.target;
+            bp.d_src = p.d_src;
+            bp.n = p.n;
+            std::memcpy(bp.guess, p.guess, sizeof(bp.guess));
+        }
+        MRGFE_TRY(b->gicp_batch->align_all(b->gicp, b->gicp_pairs));
+        b->gicp_final.assign(size_t(P) * 16, 0.0f);
+        for (int i = 0; i < P; ++i) {
+            const GicpLmController& c = b->gicp_pairs[i].ctl;
             mrgfe_pair_result& r = results[i];
-            std::memcpy(&b->gicp_final[size_t(i) * 16], g->final_transformation(), 64);
-            row2col(g->final_transformation(), r.T);
-            std::memcpy(r.H, g->hessian(), sizeof(r.H));
+            c.final_transformation(&b->gicp_final[size_t(i) * 16]);
+            row2col(&b->gicp_final[size_t(i) * 16], r.T);
+            std::memcpy(r.H, c.hessian(), sizeof(r.H));
             r.fitness = DBL_MAX;
             r.trans_probability = 0.0;
-            r.converged = g->converged() ? 1 : 0;
-            r.iterations = g->iterations();
-            r.evaluations = g->evaluations();
+            r.converged = c.converged() ? 1 : 0;
+            r.iterations = c.iterations();
+            r.evaluations = c.evaluations();
             r.pair_id = i;
         }
     } else {

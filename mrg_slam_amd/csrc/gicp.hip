@@ -90,10 +90,11 @@ __device__ __forceinline__ void gicp_block_reduce(double (&vals)[29], double* __
 
 // update_correspondences: exact 1-NN of trans_f * source point in the target, kGicpGroup lanes per query
 constexpr int kGicpGroup = 8;
-__global__ __launch_bounds__(256) void gicp_corr_kernel(NnGrid2Dev g, const float4* __restrict__ src, uint32_t n, GicpPose pose, double thr2, int32_t* __restrict__ corr)
+__device__ __forceinline__ void gicp_corr_query(const NnGrid2Dev& g, const float4* __restrict__ src, uint32_t n, const GicpPose& pose, double thr2, int32_t* __restrict__ corr,
+                                                uint32_t blk)
 {
 #pragma clang fp contract(off)
-    const uint32_t i = blockIdx.x * (256u / kGicpGroup) + threadIdx.x / kGicpGroup;
+    const uint32_t i = blk * (256u / kGicpGroup) + threadIdx.x / kGicpGroup;
     if (i >= n) return;
     const float4 a = src[i];
     // trans_f * Vector4f(x, y, z, 1): accumulated column by column
@@ -112,16 +113,21 @@ __global__ __launch_bounds__(256) void gicp_corr_kernel(NnGrid2Dev g, const floa
     if (threadIdx.x % kGicpGroup == 0) corr[i] = j;
 }
 
+__global__ __launch_bounds__(256) void gicp_corr_kernel(NnGrid2Dev g, const float4* __restrict__ src, uint32_t n, GicpPose pose, double thr2, int32_t* __restrict__ corr)
+{
+    gicp_corr_query(g, src, n, pose, thr2, corr, blockIdx.x);
+}
+
 // linearize over the correspondences of gicp_corr_kernel
-__global__ __launch_bounds__(256) void gicp_linearize_kernel(const float4* __restrict__ src, uint32_t n, const float4* __restrict__ tgt, const double* __restrict__ cov_src,
-                                                              const double* __restrict__ cov_tgt, GicpPose pose, const int32_t* __restrict__ corr, double* __restrict__ mahal,
-                                                              double* __restrict__ partials)
+__device__ __forceinline__ void gicp_linearize_block(const float4* __restrict__ src, uint32_t n, const float4* __restrict__ tgt, const double* __restrict__ cov_src,
+                                                     const double* __restrict__ cov_tgt, const GicpPose& pose, const int32_t* __restrict__ corr, double* __restrict__ mahal,
+                                                     double* __restrict__ partials, uint32_t blk)
 {
 #pragma clang fp contract(off)
     double vals[29];
 #pragma unroll
     for (int k = 0; k < 29; ++k) vals[k] = 0.0;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i = blk * 256u + threadIdx.x;
     if (i < n) {
         const float4  a = src[i];
         const int32_t j = corr[i];
@@ -165,18 +171,25 @@ __global__ __launch_bounds__(256) void gicp_linearize_kernel(const float4* __res
             vals[28] = 1.0;
         }
     }
-    gicp_block_reduce(vals, partials + size_t(blockIdx.x) * kGicpStride, 28);
+    gicp_block_reduce(vals, partials + size_t(blk) * kGicpStride, 28);
+}
+
+__global__ __launch_bounds__(256) void gicp_linearize_kernel(const float4* __restrict__ src, uint32_t n, const float4* __restrict__ tgt, const double* __restrict__ cov_src,
+                                                              const double* __restrict__ cov_tgt, GicpPose pose, const int32_t* __restrict__ corr, double* __restrict__ mahal,
+                                                              double* __restrict__ partials)
+{
+    gicp_linearize_block(src, n, tgt, cov_src, cov_tgt, pose, corr, mahal, partials, blockIdx.x);
 }
 
 // compute_error: stored correspondences and Mahalanobis matrices, new pose
-__global__ __launch_bounds__(256) void gicp_error_kernel(const float4* __restrict__ src, uint32_t n, const float4* __restrict__ tgt, GicpPose pose, const int32_t* __restrict__ corr,
-                                                          const double* __restrict__ mahal, double* __restrict__ partials)
+__device__ __forceinline__ void gicp_error_block(const float4* __restrict__ src, uint32_t n, const float4* __restrict__ tgt, const GicpPose& pose, const int32_t* __restrict__ corr,
+                                                 const double* __restrict__ mahal, double* __restrict__ partials, uint32_t blk)
 {
 #pragma clang fp contract(off)
     double vals[29];
 #pragma unroll
     for (int k = 0; k < 29; ++k) vals[k] = 0.0;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i = blk * 256u + threadIdx.x;
     if (i < n) {
         const int32_t j = corr[i];
         if (j >= 0) {
@@ -194,10 +207,16 @@ __global__ __launch_bounds__(256) void gicp_error_kernel(const float4* __restric
             vals[28] = 1.0;
         }
     }
-    gicp_block_reduce(vals, partials + size_t(blockIdx.x) * kGicpStride, 1);
+    gicp_block_reduce(vals, partials + size_t(blk) * kGicpStride, 1);
 }
 
-__global__ __launch_bounds__(256) void gicp_reduce_kernel(const double* __restrict__ partials, uint32_t nblk, double* __restrict__ out)
+__global__ __launch_bounds__(256) void gicp_error_kernel(const float4* __restrict__ src, uint32_t n, const float4* __restrict__ tgt, GicpPose pose, const int32_t* __restrict__ corr,
+                                                          const double* __restrict__ mahal, double* __restrict__ partials)
+{
+    gicp_error_block(src, n, tgt, pose, corr, mahal, partials, blockIdx.x);
+}
+
+__device__ __forceinline__ void gicp_reduce_record(const double* __restrict__ partials, uint32_t nblk, double* __restrict__ out)
 {
     __shared__ double s[8][kGicpStride];
     const int k = threadIdx.x & 31, slice = threadIdx.x >> 5;
@@ -211,6 +230,70 @@ __global__ __launch_bounds__(256) void gicp_reduce_kernel(const double* __restri
         for (int sl = 1; sl < 8; ++sl) r += s[sl][k];
         out[k] = r;
     }
+}
+
+__global__ __launch_bounds__(256) void gicp_reduce_kernel(const double* __restrict__ partials, uint32_t nblk, double* __restrict__ out) { gicp_reduce_record(partials, nblk, out); }
+
+// ---- batched variants: blockIdx.y = the y-th busy pair of this kernel in the round --------------------------------------
+struct GicpPairDev {  // static per pair
+    const float4* src;
+    const float4* tgt;
+    const double* cov_src;
+    const double* cov_tgt;
+    int32_t*      corr;
+    double*       mahal;
+    uint32_t      n;
+    uint32_t      part_off;  // first block-partial record of this pair
+    uint32_t      target;    // index into the grid array
+    uint32_t      pad;
+};
+struct GicpEvalDev {  // per round
+    GicpPose pose;
+    double   thr2;
+    uint32_t order[2];  // entry k: the k-th pair with a linearize / an error request this round
+    int32_t  type;      // 0 linearize, 1 error, -1 idle
+    int32_t  pad;
+};
+
+__global__ __launch_bounds__(256) void gicp_corr_batch_kernel(const GicpPairDev* __restrict__ pairs, const GicpEvalDev* __restrict__ evals, const NnGrid2Dev* __restrict__ grids)
+{
+    __shared__ NnGrid2Dev s_grid;
+    const uint32_t     pi = evals[blockIdx.y].order[0];
+    const GicpPairDev  pr = pairs[pi];
+    if (blockIdx.x * (256u / kGicpGroup) >= pr.n) return;  // uniform
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(grids + pr.target);
+        uint32_t*       dst = reinterpret_cast<uint32_t*>(&s_grid);
+        for (uint32_t w = threadIdx.x; w < sizeof(NnGrid2Dev) / 4; w += 256) dst[w] = src[w];
+    }
+    __syncthreads();
+    const GicpEvalDev& ev = evals[pi];
+    gicp_corr_query(s_grid, pr.src, pr.n, ev.pose, ev.thr2, pr.corr, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void gicp_linearize_batch_kernel(const GicpPairDev* __restrict__ pairs, const GicpEvalDev* __restrict__ evals, double* __restrict__ partials)
+{
+    const uint32_t    pi = evals[blockIdx.y].order[0];
+    const GicpPairDev pr = pairs[pi];
+    if (blockIdx.x * 256u >= pr.n) return;
+    gicp_linearize_block(pr.src, pr.n, pr.tgt, pr.cov_src, pr.cov_tgt, evals[pi].pose, pr.corr, pr.mahal, partials + size_t(pr.part_off) * kGicpStride, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void gicp_error_batch_kernel(const GicpPairDev* __restrict__ pairs, const GicpEvalDev* __restrict__ evals, double* __restrict__ partials)
+{
+    const uint32_t    pi = evals[blockIdx.y].order[1];
+    const GicpPairDev pr = pairs[pi];
+    if (blockIdx.x * 256u >= pr.n) return;
+    gicp_error_block(pr.src, pr.n, pr.tgt, evals[pi].pose, pr.corr, pr.mahal, partials + size_t(pr.part_off) * kGicpStride, blockIdx.x);
+}
+
+// one workgroup per pair: the same fixed-order sum as gicp_reduce_kernel, written to (pinned host) results[pair][32]
+__global__ __launch_bounds__(256) void gicp_reduce_batch_kernel(const GicpPairDev* __restrict__ pairs, const GicpEvalDev* __restrict__ evals, const double* __restrict__ partials,
+                                                                 double* __restrict__ results)
+{
+    if (evals[blockIdx.x].type < 0) return;
+    const GicpPairDev pr = pairs[blockIdx.x];
+    gicp_reduce_record(partials + size_t(pr.part_off) * kGicpStride, (pr.n + 255u) / 256u, results + size_t(blockIdx.x) * kGicpStride);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -348,17 +431,25 @@ int GicpEngine::compute_covariances(const float4* d_pts, size_t n, DevBuf& out, 
     return MRGFE_OK;
 }
 
-int GicpEngine::ensure_ready()
+int GicpEngine::prepare_target()
 {
     if (!d_tgt_ && n_tgt_) { set_error("GICP: no target"); return MRGFE_ERR_STATE; }
     MRGFE_TRY(ctx_->bind());
-    if (!src_cov_valid_) { MRGFE_TRY(compute_covariances(d_src_, n_src_, d_src_cov_, cov_grid_)); src_cov_valid_ = true; }
     // the target's k-NN grid also serves the per-iteration correspondence search (one build per setInputTarget)
     if (!tgt_cov_valid_ || !tgt_grid_valid_) {
         MRGFE_TRY(compute_covariances(d_tgt_, n_tgt_, d_tgt_cov_, tgt_grid_));
         if (n_tgt_ == 0) MRGFE_TRY(tgt_grid_.build(ctx_, d_tgt_, 0, 1.0f));
         tgt_cov_valid_ = tgt_grid_valid_ = true;
     }
+    return MRGFE_OK;
+}
+
+int GicpEngine::ensure_ready()
+{
+    if (!d_tgt_ && n_tgt_) { set_error("GICP: no target"); return MRGFE_ERR_STATE; }
+    MRGFE_TRY(ctx_->bind());
+    if (!src_cov_valid_) { MRGFE_TRY(compute_covariances(d_src_, n_src_, d_src_cov_, cov_grid_)); src_cov_valid_ = true; }
+    MRGFE_TRY(prepare_target());
     const size_t ns = std::max<size_t>(n_src_, 1);
     MRGFE_TRY(d_corr_.ensure(ns * 4));
     MRGFE_TRY(d_mahal_.ensure(ns * 72));
@@ -448,52 +539,108 @@ int GicpEngine::align(const float guess[16])
 {
     MRGFE_TRY(ensure_ready());
     kernel_ms = 0; kernel_launches = 0; kernel_alg_bytes = 0;
-    double x0[16];
-    for (int i = 0; i < 16; ++i) x0[i] = static_cast<double>(guess[i]);
-    double lm_lambda = -1.0;
+    n_linearize_ = n_error_ = 0;
+    GicpLmController ctl;
+    ctl.start(prm_, guess, static_cast<uint32_t>(n_src_));
+    while (!ctl.done()) {
+        const GicpRequest& rq = ctl.request();
+        double r[kGicpStride] = {0};
+        if (rq.type == 0) {
+            double H[36], b[6], err;
+            int    nc = 0;
+            MRGFE_TRY(run_linearize(rq.T, true, H, b, &err, &nc));
+            r[0] = err;
+            for (int t = 0; t < 6; ++t) r[1 + t] = b[t];
+            int t = 7;
+            for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) r[t++] = H[i * 6 + j];
+            r[28] = nc;
+        } else {
+            MRGFE_TRY(run_error(rq.T, &r[0]));
+        }
+        ctl.on_result(r);
+    }
+    converged_ = ctl.converged();
+    nr_iterations_ = ctl.iterations();
+    std::memcpy(final_hessian_, ctl.hessian(), sizeof(final_hessian_));
+    ctl.final_transformation(final_);
+    return MRGFE_OK;
+}
+
+// ---- the LM loop of fast_gicp::LsqRegistration, one request at a time ------------------------------------------------
+void GicpLmController::start(const GicpParams& prm, const float guess[16], uint32_t)
+{
+    prm_ = prm;
+    for (int i = 0; i < 16; ++i) x0_[i] = static_cast<double>(guess[i]);
+    lambda_ = -1.0;
     converged_ = false;
     nr_iterations_ = 0;
     n_linearize_ = n_error_ = 0;
+    outer_ = 0;
     for (int t = 0; t < 36; ++t) final_hessian_[t] = (t % 7 == 0) ? 1.0 : 0.0;
-    for (int i = 0; i < prm_.max_iterations && !converged_; ++i) {
-        nr_iterations_ = i;
-        double H[36], b[6], delta[16], y0;
-        MRGFE_TRY(run_linearize(x0, true, H, b, &y0, nullptr));
-        if (lm_lambda < 0.0) {
+    done_ = prm_.max_iterations <= 0;
+    if (!done_) { req_.type = 0; std::memcpy(req_.T, x0_, sizeof(x0_)); }
+}
+
+void GicpLmController::propose()
+{
+    double A[36], nb[6];
+    for (int t = 0; t < 36; ++t) A[t] = H_[t] + ((t % 7 == 0) ? lambda_ : 0.0);
+    for (int t = 0; t < 6; ++t) nb[t] = -b_[t];
+    solve6(A, nb, d_);
+    se3_exp(d_, delta_);
+    mul4(delta_, x0_, xi_);
+    req_.type = 1;
+    std::memcpy(req_.T, xi_, sizeof(xi_));
+}
+
+void GicpLmController::end_outer(bool ok)
+{
+    if (!ok) { done_ = true; return; }  // "lm not converged!!"
+    converged_ = is_converged(delta_, prm_.rot_eps, prm_.trans_eps);
+    ++outer_;
+    if (converged_ || outer_ >= prm_.max_iterations) { done_ = true; return; }
+    req_.type = 0;
+    std::memcpy(req_.T, x0_, sizeof(x0_));
+}
+
+void GicpLmController::on_result(const double r[32])
+{
+    if (req_.type == 0) {
+        ++n_linearize_;
+        nr_iterations_ = outer_;
+        y0_ = r[0];
+        for (int t = 0; t < 6; ++t) b_[t] = r[1 + t];
+        int t = 7;
+        for (int i = 0; i < 6; ++i)
+            for (int j = i; j < 6; ++j) { H_[i * 6 + j] = r[t]; H_[j * 6 + i] = r[t]; ++t; }
+        if (lambda_ < 0.0) {
             double md = 0;
-            for (int d = 0; d < 6; ++d) md = std::max(md, std::fabs(H[d * 6 + d]));
-            lm_lambda = prm_.lm_init_lambda_factor * md;
+            for (int d = 0; d < 6; ++d) md = std::max(md, std::fabs(H_[d * 6 + d]));
+            lambda_ = prm_.lm_init_lambda_factor * md;
         }
-        double nu = 2.0;
-        bool   ok = false;
-        for (int it = 0; it < prm_.lm_max_iterations; ++it) {
-            double A[36], nb[6], d[6], xi[16], yi;
-            for (int t = 0; t < 36; ++t) A[t] = H[t] + ((t % 7 == 0) ? lm_lambda : 0.0);
-            for (int t = 0; t < 6; ++t) nb[t] = -b[t];
-            solve6(A, nb, d);
-            se3_exp(d, delta);
-            mul4(delta, x0, xi);
-            MRGFE_TRY(run_error(xi, &yi));
-            double denom = 0;
-            for (int t = 0; t < 6; ++t) denom += d[t] * (lm_lambda * d[t] - b[t]);
-            const double rho = (y0 - yi) / denom;
-            if (rho < 0) {
-                if (is_converged(delta, prm_.rot_eps, prm_.trans_eps)) { ok = true; break; }
-                lm_lambda = nu * lm_lambda;
-                nu = 2 * nu;
-                continue;
-            }
-            std::memcpy(x0, xi, sizeof(xi));
-            lm_lambda = lm_lambda * std::max(1.0 / 3.0, 1 - std::pow(2 * rho - 1, 3));
-            std::memcpy(final_hessian_, H, sizeof(H));
-            ok = true;
-            break;
-        }
-        if (!ok) break;  // "lm not converged!!"
-        converged_ = is_converged(delta, prm_.rot_eps, prm_.trans_eps);
+        nu_ = 2.0;
+        inner_ = 0;
+        if (prm_.lm_max_iterations <= 0) { end_outer(false); return; }
+        propose();
+        return;
     }
-    for (int i = 0; i < 16; ++i) final_[i] = static_cast<float>(x0[i]);
-    return MRGFE_OK;
+    ++n_error_;
+    const double yi = r[0];
+    double denom = 0;
+    for (int t = 0; t < 6; ++t) denom += d_[t] * (lambda_ * d_[t] - b_[t]);
+    const double rho = (y0_ - yi) / denom;
+    if (rho < 0) {
+        if (is_converged(delta_, prm_.rot_eps, prm_.trans_eps)) { end_outer(true); return; }
+        lambda_ = nu_ * lambda_;
+        nu_ = 2 * nu_;
+        if (++inner_ >= prm_.lm_max_iterations) { end_outer(false); return; }
+        propose();
+        return;
+    }
+    std::memcpy(x0_, xi_, sizeof(xi_));
+    lambda_ = lambda_ * std::max(1.0 / 3.0, 1 - std::pow(2 * rho - 1, 3));
+    std::memcpy(final_hessian_, H_, sizeof(H_));
+    end_outer(true);
 }
 
 int GicpEngine::aligned_cloud(float* out)
@@ -508,6 +655,101 @@ int GicpEngine::aligned_cloud(float* out)
     MRGFE_HIP_CHECK(hipMemcpyAsync(out, d_out, n_src_ * 16, hipMemcpyDeviceToHost, ctx_->stream));
     MRGFE_HIP_CHECK(hipStreamSynchronize(ctx_->stream));
     return MRGFE_OK;
+}
+
+// ---- batched LM rounds -------------------------------------------------------------------------------------------------
+GicpBatch::~GicpBatch()
+{
+    if (ctx_) (void)hipSetDevice(ctx_->device);
+    d_pairs_.release(); d_evals_.release(); d_grids_.release(); d_partials_.release();
+    h_evals_.release(); h_results_.release();
+    if (done_) (void)hipEventDestroy(done_);
+}
+
+int GicpBatch::align_all(std::vector<GicpEngine*>& engines, std::vector<GicpBatchPair>& pairs)
+{
+    MRGFE_TRY(ctx_->bind());
+    const int P = static_cast<int>(pairs.size());
+    if (P == 0) return MRGFE_OK;
+    hipStream_t st = ctx_->stream;
+    if (!done_) MRGFE_HIP_CHECK(hipEventCreateWithFlags(&done_, hipEventDisableTiming));
+    // targets: covariances + correspondence grid once each; sources: covariances cloud by cloud
+    std::vector<NnGrid2Dev> h_grids(engines.size());
+    for (size_t t = 0; t < engines.size(); ++t) {
+        if (!engines[t]) continue;
+        MRGFE_TRY(engines[t]->prepare_target());
+        h_grids[t] = engines[t]->target_grid();
+    }
+    std::vector<GicpPairDev> h_pairs(P);
+    uint32_t part = 0, max_n = 0;
+    for (int i = 0; i < P; ++i) {
+        GicpBatchPair& p = pairs[i];
+        GicpEngine*    e = engines[p.target];
+        MRGFE_TRY(e->compute_covariances(p.d_src, p.n, p.cov, e->scratch_grid()));
+        MRGFE_TRY(p.corr.ensure(std::max<size_t>(p.n, 1) * 4));
+        MRGFE_TRY(p.mahal.ensure(std::max<size_t>(p.n, 1) * 72));
+        GicpPairDev d;
+        d.src = p.d_src; d.tgt = e->target_points(); d.cov_src = p.cov.as<double>(); d.cov_tgt = e->target_covariances();
+        d.corr = p.corr.as<int32_t>(); d.mahal = p.mahal.as<double>();
+        d.n = p.n; d.part_off = part; d.target = static_cast<uint32_t>(p.target); d.pad = 0;
+        part += (p.n + 255u) / 256u;
+        max_n = std::max(max_n, p.n);
+        h_pairs[i] = d;
+        p.ctl.start(e->params(), p.guess, p.n);
+    }
+    MRGFE_TRY(d_pairs_.ensure(sizeof(GicpPairDev) * P));
+    MRGFE_TRY(d_grids_.ensure(sizeof(NnGrid2Dev) * std::max<size_t>(engines.size(), 1)));
+    MRGFE_TRY(d_evals_.ensure(sizeof(GicpEvalDev) * P));
+    MRGFE_TRY(d_partials_.ensure(sizeof(double) * kGicpStride * std::max<uint32_t>(part, 1)));
+    MRGFE_TRY(h_evals_.ensure(sizeof(GicpEvalDev) * P));
+    MRGFE_TRY(h_results_.ensure(sizeof(double) * kGicpStride * P));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_pairs_.p, h_pairs.data(), sizeof(GicpPairDev) * P, hipMemcpyHostToDevice, st));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_grids_.p, h_grids.data(), sizeof(NnGrid2Dev) * h_grids.size(), hipMemcpyHostToDevice, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));  // h_pairs / h_grids are locals
+    GicpEvalDev* he = h_evals_.as<GicpEvalDev>();
+    double*      hr = h_results_.as<double>();
+    const double thr = engines[pairs[0].target]->params().max_corr_dist;
+    const int    round_cap = (engines[pairs[0].target]->params().max_iterations + 1) * (engines[pairs[0].target]->params().lm_max_iterations + 2) + 4;
+    for (int round = 0; round < round_cap; ++round) {
+        uint32_t n_lin = 0, n_err = 0;
+        for (int i = 0; i < P; ++i) {
+            GicpLmController& c = pairs[i].ctl;
+            if (c.done() || pairs[i].n == 0) { he[i].type = -1; continue; }
+            he[i].pose = make_pose(c.request().T);
+            he[i].thr2 = thr * thr;
+            he[i].type = c.request().type;
+            if (he[i].type == 0) he[n_lin++].order[0] = static_cast<uint32_t>(i);
+            else                 he[n_err++].order[1] = static_cast<uint32_t>(i);
+        }
+        // an empty source still walks its LM loop on all-zero records (like the single engine does)
+        bool any_empty = false;
+        for (int i = 0; i < P; ++i)
+            if (!pairs[i].ctl.done() && pairs[i].n == 0) any_empty = true;
+        if (n_lin + n_err == 0 && !any_empty) return MRGFE_OK;
+        if (n_lin + n_err) {
+            MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(GicpEvalDev) * P, hipMemcpyHostToDevice, st));
+            const GicpPairDev* dp = d_pairs_.as<GicpPairDev>();
+            const GicpEvalDev* de = d_evals_.as<GicpEvalDev>();
+            if (n_lin) {
+                constexpr uint32_t per_blk = 256u / kGicpGroup;
+                hipLaunchKernelGGL(gicp_corr_batch_kernel, dim3((max_n + per_blk - 1) / per_blk, n_lin), dim3(256), 0, st, dp, de, d_grids_.as<NnGrid2Dev>());
+                hipLaunchKernelGGL(gicp_linearize_batch_kernel, dim3((max_n + 255) / 256, n_lin), dim3(256), 0, st, dp, de, d_partials_.as<double>());
+            }
+            if (n_err) hipLaunchKernelGGL(gicp_error_batch_kernel, dim3((max_n + 255) / 256, n_err), dim3(256), 0, st, dp, de, d_partials_.as<double>());
+            hipLaunchKernelGGL(gicp_reduce_batch_kernel, dim3(P), dim3(256), 0, st, dp, de, d_partials_.as<double>(), hr);
+            MRGFE_HIP_CHECK(hipGetLastError());
+            MRGFE_HIP_CHECK(hipEventRecord(done_, st));
+            MRGFE_HIP_CHECK(hipEventSynchronize(done_));
+        }
+        const double zeros[kGicpStride] = {0};
+        for (int i = 0; i < P; ++i) {
+            GicpLmController& c = pairs[i].ctl;
+            if (c.done()) continue;
+            c.on_result(pairs[i].n ? hr + size_t(i) * kGicpStride : zeros);
+        }
+    }
+    set_error("GICP batch did not terminate within %d rounds", round_cap);
+    return MRGFE_ERR_STATE;
 }
 
 }  // namespace mrgfe

@@ -1,6 +1,8 @@
 // csrc/gicp_engine.h — GICP_HIP engine: fast_gicp::FastGICP (registrations.cpp:55-63) on MI355X.
 #pragma once
 #include "common.h"
+#include <vector>
+
 #include "nn_grid.h"
 
 namespace mrgfe {
@@ -26,6 +28,17 @@ class GicpEngine {
     // update_correspondences + linearize at T (row-major double 4x4): tests
     int linearize(const double T[16], double H[36], double b[6], double* err, int* n_corr);
     int covariances(int which, double* out9);  // 0 source, 1 target
+
+    // k-NN covariances of a packed device cloud into `out` (6 doubles per point), through `grid` (rebuilt over the cloud)
+    int compute_covariances(const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid);
+    // batch access (GicpBatch): the target's covariances and correspondence grid, built on demand
+    int prepare_target();
+    const float4*     target_points() const { return d_tgt_; }
+    size_t            target_size() const { return n_tgt_; }
+    const double*     target_covariances() const { return d_tgt_cov_.as<double>(); }
+    const NnGrid2Dev& target_grid() const { return tgt_grid_.dev2(); }
+    NnGrid&           scratch_grid() { return cov_grid_; }
+    const GicpParams& params() const { return prm_; }
 
     const float* final_transformation() const { return final_; }
     bool converged() const { return converged_; }
@@ -53,9 +66,63 @@ class GicpEngine {
     bool   converged_ = false;
     int    nr_iterations_ = 0, n_linearize_ = 0, n_error_ = 0;
     int ensure_ready();
-    int compute_covariances(const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid);
+
     int run_linearize(const double T[16], bool with_jacobian, double H[36], double b[6], double* err, int* n_corr);
     int run_error(const double T[16], double* err);
+};
+
+// One Levenberg-Marquardt loop of fast_gicp::LsqRegistration as a resumable state machine: the same decisions, in the
+// same order, as GicpEngine::align — which is this controller driven one request at a time.
+struct GicpRequest {
+    int    type;   // 0: update_correspondences + linearize at T, 1: compute_error at T
+    double T[16];  // row-major
+};
+class GicpLmController {
+   public:
+    void start(const GicpParams& prm, const float guess_rowmajor[16], uint32_t n_src);
+    bool done() const { return done_; }
+    const GicpRequest& request() const { return req_; }
+    void on_result(const double r[32]);  // record of gicp_reduce: err, b[6], H upper[21], n_corr
+    bool converged() const { return converged_; }
+    int  iterations() const { return nr_iterations_; }
+    int  evaluations() const { return n_linearize_ + n_error_; }
+    const double* hessian() const { return final_hessian_; }
+    void final_transformation(float out_rowmajor[16]) const { for (int i = 0; i < 16; ++i) out_rowmajor[i] = static_cast<float>(x0_[i]); }
+
+   private:
+    GicpParams  prm_;
+    GicpRequest req_;
+    bool   done_ = true, converged_ = false;
+    int    nr_iterations_ = 0, n_linearize_ = 0, n_error_ = 0;
+    int    outer_ = 0, inner_ = 0;
+    double x0_[16], xi_[16], delta_[16], H_[36], b_[6], d_[6], y0_ = 0, lambda_ = -1, nu_ = 2;
+    double final_hessian_[36];
+    void propose();       // next LM trial from (H_, b_, lambda_): request compute_error at xi_
+    void end_outer(bool ok);
+};
+
+// Batched GICP_HIP: the candidates of a batch advance through their LM loops together, one launch per kernel per round
+// (blockIdx.y = busy pair), like the NDT rounds.  Source covariances are computed cloud by cloud beforehand.
+struct GicpBatchPair {
+    int           target = -1;
+    const float4* d_src = nullptr;
+    uint32_t      n = 0;
+    float         guess[16];
+    DevBuf        cov, corr, mahal;
+    GicpLmController ctl;
+};
+class GicpBatch {
+   public:
+    explicit GicpBatch(mrgfe_ctx* ctx) : ctx_(ctx) {}
+    ~GicpBatch();
+    // engines[t] holds target t (set_target done); pairs: target index, device source cloud, guess (row-major)
+    int align_all(std::vector<GicpEngine*>& engines, std::vector<GicpBatchPair>& pairs);
+
+   private:
+    mrgfe_ctx* ctx_;
+    DevBuf d_pairs_, d_evals_, d_grids_, d_partials_;
+    PinBuf h_evals_, h_results_;
+    hipEvent_t done_ = nullptr;
 };
 
 }  // namespace mrgfe
