@@ -179,3 +179,34 @@ def test_target_can_be_replaced_and_source_kept():
     assert g.setInputTarget(tgt) == 0
     g.align(np.eye(4))
     np.testing.assert_array_equal(g.getFinalTransformation(), first)  # bitwise reproducible
+
+
+def test_non_finite_and_degenerate_inputs_match_oracle():
+    """NaN / inf points in both clouds, duplicated points, a source entirely outside the target grid: same behaviour as
+    the oracle (non-finite target points are skipped by the voxel build; a non-finite or far-away source point has no
+    neighbours and contributes nothing)."""
+    from mrg_slam_amd import synth
+
+    tgt, src, rel = _pair(5000, seed=21)
+    tgt, src = tgt.copy(), src.copy()
+    tgt[::97, 0] = np.nan
+    tgt[5::131, 2] = np.inf
+    src[::53, 1] = np.nan
+    src[7::211, 0] = -np.inf
+    src[1000:1100] = src[1000]            # 100 copies of one point
+    tgt[2000:2050] = tgt[2000]
+    g, o = _both(tgt, src, transformation_epsilon=0.01, maximum_iterations=64)
+    guess = synth.warm_guess(rel, 4)
+    g.align(guess)
+    o.align(guess)
+    np.testing.assert_array_equal(g.getFinalTransformation(), o.getFinalTransformation())
+    assert g.hasConverged() == o.hasConverged() and g.getFinalNumIteration() == o.getFinalNumIteration()
+    # a source that never touches the target grid: no neighbours at all, both sides give the guess back
+    far = src.copy()
+    far[:, :3] += 500.0
+    g.setInputSource(far)
+    o.setInputSource(far)
+    g.align(np.eye(4))
+    o.align(np.eye(4))
+    np.testing.assert_array_equal(g.getFinalTransformation(), o.getFinalTransformation())
+    assert g.hasConverged() == o.hasConverged()
