@@ -95,7 +95,13 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL over xGMI; BENCH_DIST_BACKEND=gloo lets two ranks share one GPU to exercise this path on a 1-GPU box (RCCL
+        # refuses duplicate devices)
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from mrg_slam_amd import BatchMatcher, Context, NdtHip, distance_filter, prefilter, synth
     from mrg_slam_amd._lib import NDT_HIP, SEARCH
