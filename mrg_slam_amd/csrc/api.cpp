@@ -264,7 +264,7 @@ static int reg_ensure_nn(mrgfe_reg* reg)
 {
     if (!reg->has_target) { set_error("no target set"); return MRGFE_ERR_STATE; }
     if (!reg->nn_valid) {
-        MRGFE_TRY(reg->nn.build(reg->ctx, static_cast<const float4*>(reg->d_tgt), reg->n_tgt, 1.0f));
+        MRGFE_TRY(reg->nn.build(reg->ctx, static_cast<const float4*>(reg->d_tgt), reg->n_tgt, 1.0f, NnGrid::kCrowding1nn, 1));
         reg->nn_valid = true;
     }
     return MRGFE_OK;
@@ -393,7 +393,7 @@ int mrgfe_calc_fitness_score(mrgfe_ctx* ctx, const float* cloud1, size_t n1, con
     MRGFE_TRY(upload_cloud(ctx, cloud1, n1, stride, d1.p));
     MRGFE_TRY(upload_cloud(ctx, cloud2, n2, stride, d2.p));
     NnGrid& g = ctx_tmp_grid(ctx);
-    int st = g.build(ctx, d1.as<float4>(), n1, 1.0f);
+    int st = g.build(ctx, d1.as<float4>(), n1, 1.0f, NnGrid::kCrowding1nn, 1);
     if (st == MRGFE_OK) {
         float T[16];  // relpose.cast<float>(), row-major
         for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) T[r * 4 + c] = static_cast<float>(relpose[c * 4 + r]);
@@ -649,7 +649,7 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
             const NdtPairInfo& p = e.pair(i);
             const NdtTargetInfo& t = e.target(p.target);
             if (t.n == 0 || p.n == 0) continue;
-            if (!built[p.target]) { st = grids[p.target].build(b->ctx, t.d_pts, t.n, 1.0f); built[p.target] = 1; }
+            if (!built[p.target]) { st = grids[p.target].build(b->ctx, t.d_pts, t.n, 1.0f, NnGrid::kCrowding1nn, 1); built[p.target] = 1; }
             if (st == MRGFE_OK) { jobs.push_back(grids[p.target].make_fitness_job(p.d_src, p.n, gicp ? &b->gicp_final[size_t(i) * 16] : p.ctl.final_transformation())); job_pair.push_back(i); }
         }
         if (st == MRGFE_OK && !jobs.empty()) {

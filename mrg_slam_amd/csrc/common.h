@@ -84,7 +84,7 @@ struct mrgfe_ctx {
     hipStream_t  stream = nullptr;
     hipEvent_t   ev0 = nullptr, ev1 = nullptr;  // timing of the dominant kernel on `stream`
     hipEvent_t   ev_mode[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // per NDT kernel variant
-    mrgfe::DevBuf scratch[12];                  // named by the algorithms that use them
+    mrgfe::DevBuf scratch[14];                  // named by the algorithms that use them
     mrgfe::PinBuf pin[4];
     mrgfe::PinBuf up_pin[2];                    // upload_cloud staging ring: the host packs cloud k + 1 while cloud k is on the wire
     hipEvent_t   up_ev[2] = {nullptr, nullptr};

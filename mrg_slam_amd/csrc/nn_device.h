@@ -100,13 +100,279 @@ __device__ __forceinline__ void nn_group_min(float& d, int32_t& i)
     }
 }
 
+// ---- occupancy pyramid ------------------------------------------------------------------------------------------------
+// Nodes: bricks (4^3 cells), super-bricks (4^3 bricks), blocks (4^3 super-bricks); one 64-bit word each, bit x + 4 y + 16 z
+// set iff the child holds a point.  An occupied node bounds the answer from BOTH sides without touching a point: nothing
+// in it is nearer than its box (lb) and something in it is no farther than the far corner of its box (ub).  A query with
+// an empty neighbourhood therefore first narrows `lim` — the squared radius that can still matter — from the words alone,
+// and opens only cells with lb <= lim.  (Walking rings of cells instead cost ~400 dependent row probes per such query,
+// and walking coarser point grids meant scanning 200-point cells.)
+// Bounds are float with a margin of four binning slacks; comparisons carry another 2e-5 relative.
+struct NnPyramidQuery {
+    float t[3];  // query - origin
+    float m;     // margin, metres
+    __device__ __forceinline__ void box(float E, int nx, int ny, int nz, float& lb2, float& ub2) const
+    {
+        const int n[3] = {nx, ny, nz};
+        lb2 = 0.0f;
+        ub2 = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float lo = static_cast<float>(n[a]) * E, hi = lo + E;
+            const float l = fmaxf(fmaxf(lo - t[a], t[a] - hi) - m, 0.0f);
+            const float u = fmaxf(t[a] - lo, hi - t[a]) + m;
+            lb2 += l * l;
+            ub2 += u * u;
+        }
+    }
+};
+constexpr float kNnPrune = 1.0f + 2e-5f;
+
+template <int G>
+__device__ __forceinline__ float nn_group_fmin(float v)
+{
+#pragma unroll
+    for (int k = 1; k < G; k <<= 1) v = fminf(v, __shfl_xor(v, k));
+    return v;
+}
+
+// offsets (dx + 2) | (dy + 2) << 3 | (dz + 2) << 6 of the 5 x 5 x 5 nodes around a centre, shell 0 first, then the 26 of
+// shell 1, then the 98 of shell 2 (the order nn_shell_walk's general enumeration produces)
+__device__ __forceinline__ void nn_small_shell_pos(int idx, int d[3])
+{
+    static constexpr uint16_t kTab[125] = {146, 73, 74, 75, 81, 82, 83, 89, 90, 91, 201, 202, 203, 209, 210, 211, 217, 218, 219, 137, 138, 139, 153, 154, 155, 145, 147, 0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 16, 17, 18, 19, 20, 24, 25, 26, 27, 28, 32, 33, 34, 35, 36, 256, 257, 258, 259, 260, 264, 265, 266, 267, 268, 272, 273, 274, 275, 276, 280, 281, 282, 283, 284, 288, 289, 290, 291, 292, 64, 65, 66, 67, 68, 96, 97, 98, 99, 100, 72, 76, 80, 84, 88, 92, 128, 129, 130, 131, 132, 160, 161, 162, 163, 164, 136, 140, 144, 148, 152, 156, 192, 193, 194, 195, 196, 224, 225, 226, 227, 228, 200, 204, 208, 212, 216, 220};
+    const int v = kTab[idx];
+    d[0] = (v & 7) - 2;
+    d[1] = ((v >> 3) & 7) - 2;
+    d[2] = (v >> 6) - 2;
+}
+
+// Shells s_first .. s_last of the nodes around `ctr` on one pyramid level.  Each lane fetches the words of two nodes of
+// the shell (those whose box can still matter); the group then calls proc(word, nx, ny, nz) for every non-empty one, all
+// lanes together, and proc leaves `lim` agreed within the group.  Returns true when the search is over: the next shell
+// lies beyond lim, or the level has no more nodes.
+template <int G, bool kSmall, class Proc>
+__device__ __forceinline__ bool nn_shell_walk(const unsigned long long* __restrict__ words, const int dims[3], const int ctr[3], float E, const NnPyramidQuery& pq, int s_first,
+                                              int s_last, int sub, float& lim, Proc&& proc)
+{
+    constexpr int U = 2;  // the nearest-first selection below is written for two
+    int   smax = 0;
+    float nm = INFINITY;  // distance to the nearest face of the centre node, >= 0
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        smax = max(smax, max(ctr[a], dims[a] - 1 - ctr[a]));
+        const float lo = static_cast<float>(ctr[a]) * E;
+        nm = fminf(nm, fminf(pq.t[a] - lo, lo + E - pq.t[a]));
+    }
+    nm = fmaxf(nm - pq.m, 0.0f);
+    const int base = static_cast<int>(lane_id()) & ~(G - 1);
+    const int send = min(s_last, smax);
+    for (int s = s_first; s <= send; ++s) {
+        if (s >= 1) {  // everything outside the Chebyshev ball of s - 1 nodes
+            const float b = static_cast<float>(s - 1) * E + nm;
+            if (b * b > lim * kNnPrune) return true;
+        }
+        const int  w = 2 * s + 1, per_z = 4 * w - 4;
+        const bool merged = kSmall && s == 0 && send >= 1;  // the centre node and shell 1 in one go: one round trip less
+        const int  total = merged ? 27 : s == 0 ? 1 : 2 * w * w + (w - 2) * per_z;
+        const int  first = s == 0 ? 0 : s == 1 ? 1 : 27;  // kSmall: where the shell starts in the table
+        auto shell_pos = [&](int tt, int d[3]) {  // tt-th node of the shell: the two z faces, then per middle z the y faces and the x ends
+            if (kSmall) { nn_small_shell_pos(first + tt, d); return; }
+            if (s == 0) { d[0] = d[1] = d[2] = 0; return; }
+            if (tt < 2 * w * w) {
+                const int u = tt < w * w ? tt : tt - w * w;
+                const int qy = u / w;
+                d[2] = tt < w * w ? -s : s;
+                d[1] = qy - s;
+                d[0] = u - qy * w - s;
+                return;
+            }
+            const int u = tt - 2 * w * w, qz = u / per_z, v = u - qz * per_z;
+            d[2] = qz - s + 1;
+            if (v < 2 * w) {
+                d[1] = v < w ? -s : s;
+                d[0] = (v < w ? v : v - w) - s;
+            } else {
+                const int k = v - 2 * w;
+                d[1] = (k >> 1) - s + 1;
+                d[0] = (k & 1) ? s : -s;
+            }
+        };
+        for (int t0 = 0; t0 < total; t0 += U * G) {
+            unsigned long long word[U];
+            float              wlb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                word[u] = 0ull;
+                wlb[u] = INFINITY;
+                const int tt = t0 + u * G + sub;
+                if (tt >= total) continue;
+                int d[3];
+                shell_pos(tt, d);
+                const int nx = ctr[0] + d[0], ny = ctr[1] + d[1], nz = ctr[2] + d[2];
+                if (nx < 0 || nx >= dims[0] || ny < 0 || ny >= dims[1] || nz < 0 || nz >= dims[2]) continue;
+                float lb2, ub2;
+                pq.box(E, nx, ny, nz, lb2, ub2);
+                if (lb2 <= lim * kNnPrune) {
+                    word[u] = words[(static_cast<uint32_t>(nz) * dims[1] + ny) * dims[0] + nx];
+                    wlb[u] = word[u] != 0ull ? lb2 : INFINITY;
+                }
+            }
+            // non-empty nodes nearest first: the first ones usually pull lim in far enough to drop the rest unopened
+            for (;;) {
+                float nb = fminf(wlb[0], wlb[1]);
+                int   code = (wlb[1] < wlb[0] ? G : 0) + sub;  // u * G + lane of the group
+#pragma unroll
+                for (int k = 1; k < G; k <<= 1) {
+                    const float ob = __shfl_xor(nb, k);
+                    const int   oc = __shfl_xor(code, k);
+                    if (ob < nb || (ob == nb && oc < code)) { nb = ob; code = oc; }
+                }
+                if (nb == INFINITY || !(nb <= lim * kNnPrune)) break;  // nothing left / nothing near enough (uniform within the group)
+                const int u = code >= G ? 1 : 0, b = code - u * G;
+                if (b == sub) wlb[u] = INFINITY;
+                {
+                    const unsigned long long wsel = u ? word[1] : word[0];
+                    const uint32_t wlo = __shfl(static_cast<uint32_t>(wsel), base + b), whi = __shfl(static_cast<uint32_t>(wsel >> 32), base + b);
+                    const unsigned long long wb = (static_cast<unsigned long long>(whi) << 32) | wlo;
+                    int d[3];
+                    shell_pos(t0 + u * G + b, d);
+                    proc(wb, ctr[0] + d[0], ctr[1] + d[1], ctr[2] + d[2]);
+                }
+            }
+        }
+        if (merged) ++s;
+    }
+    if (send == smax) return true;
+    const float b = static_cast<float>(send) * E + nm;
+    return b * b > lim * kNnPrune;
+}
+
+// every `G`-th set bit of w, starting with the sub-th
+__device__ __forceinline__ unsigned long long nn_deal_bits(unsigned long long w, int G, int sub)
+{
+    unsigned long long mine = 0ull;
+    for (int i = 0; w != 0ull; ++i) {
+        const unsigned long long low = w & (0ull - w);
+        if (i % G == sub) mine |= low;
+        w ^= low;
+    }
+    return mine;
+}
+
+// Exhaustive remainder of a 1-NN search after the query's 3x3x3 block of cells: bricks within two shells of the query's
+// brick, then super-bricks within two shells (descending through their bricks), then all blocks.
+// kByPos: (best_i, best_d) name the candidate by its position in g.sorted instead of its original index (ties then go to
+// the lowest position; callers that only want the distance, or the point itself, save the index indirection).
+// `bound`: a squared distance already known to be attained by some point (INFINITY: none) that has no (best_i, best_d).
+template <int G, bool kByPos = false>
+__device__ __forceinline__ void nn_pyramid_walk(const NnGridDev& g, float x, float y, float z, const int c[3], int sub, double max_sq, int32_t& best_i, float& best_d,
+                                                float bound = INFINITY)
+{
+    NnPyramidQuery pq;
+    pq.t[0] = x - g.origin[0];
+    pq.t[1] = y - g.origin[1];
+    pq.t[2] = z - g.origin[2];
+    pq.m = 4.0f * g.slack;
+    const float E0 = g.cell, E1 = 4.0f * g.cell, E2 = 16.0f * g.cell, E3 = 64.0f * g.cell;
+    float lim = max_sq >= 3.0e38 ? INFINITY : static_cast<float>(max_sq) * (1.0f + 1e-6f);
+    lim = fminf(lim, bound);
+    if (best_i >= 0) lim = fminf(lim, best_d);
+    constexpr int kShells = 2;  // shells walked on a level before the next coarser one takes over
+    const int b1[3] = {c[0] >> 2, c[1] >> 2, c[2] >> 2}, b2[3] = {c[0] >> 4, c[1] >> 4, c[2] >> 4}, b3[3] = {c[0] >> 6, c[1] >> 6, c[2] >> 6};
+    const int d1[3] = {g.bdim[0], g.bdim[1], g.bdim[2]};
+    const int d2[3] = {(d1[0] + 3) >> 2, (d1[1] + 3) >> 2, (d1[2] + 3) >> 2};
+    const int d3[3] = {(d2[0] + 3) >> 2, (d2[1] + 3) >> 2, (d2[2] + 3) >> 2};
+
+    // the lane's share `mine` of the cells of brick (bx, by, bz): narrow lim from the occupancy alone ...
+    auto cells_bound = [&](unsigned long long mine, int bx, int by, int bz) {
+        for (unsigned long long w = mine; w != 0ull; w &= w - 1ull) {
+            const int bit = __ffsll(w) - 1;
+            float     lb2, ub2;
+            pq.box(E0, bx * 4 + (bit & 3), by * 4 + ((bit >> 2) & 3), bz * 4 + (bit >> 4), lb2, ub2);
+            lim = fminf(lim, ub2 * kNnPrune);
+        }
+    };
+    // ... and open the cells that are left
+    auto cells_open = [&](unsigned long long mine, int bx, int by, int bz) {
+        for (unsigned long long w = mine; w != 0ull; w &= w - 1ull) {
+            const int bit = __ffsll(w) - 1;
+            const int cx = bx * 4 + (bit & 3), cy = by * 4 + ((bit >> 2) & 3), cz = bz * 4 + (bit >> 4);
+            if (cx - c[0] >= -1 && cx - c[0] <= 1 && cy - c[1] >= -1 && cy - c[1] <= 1 && cz - c[2] >= -1 && cz - c[2] <= 1) continue;  // the block is done
+            float lb2, ub2;
+            pq.box(E0, cx, cy, cz, lb2, ub2);
+            if (lb2 > lim * kNnPrune) continue;
+            const uint32_t at = (static_cast<uint32_t>(cz) * g.dim[1] + cy) * g.dim[0] + cx;
+            const uint32_t kb = g.cell_start[at], ke = g.cell_start[at + 1];
+            for (uint32_t k = kb; k < ke; ++k) {
+                const float4  p = g.sorted[k];
+                const float   d = sqdist3f(p.x, p.y, p.z, x, y, z);
+                const int32_t i = kByPos ? static_cast<int32_t>(k) : __float_as_int(p.w);
+                if (best_i < 0 || d < best_d || (d == best_d && i < best_i)) { best_d = d; best_i = i; }
+            }
+            if (best_i >= 0) lim = fminf(lim, best_d);
+        }
+    };
+    auto agree = [&]() {
+        nn_group_min<G>(best_d, best_i);
+        lim = nn_group_fmin<G>(lim);
+        if (best_i >= 0) lim = fminf(lim, best_d);
+    };
+    // the lane's share of the bricks of super-brick (sx, sy, sz), except those within `done` bricks of the query's
+    auto bricks = [&](unsigned long long mine, int sx, int sy, int sz, int done) {
+        for (unsigned long long w = mine; w != 0ull; w &= w - 1ull) {
+            const int bit = __ffsll(w) - 1;
+            const int bx = sx * 4 + (bit & 3), by = sy * 4 + ((bit >> 2) & 3), bz = sz * 4 + (bit >> 4);
+            float     lb2, ub2;
+            pq.box(E1, bx, by, bz, lb2, ub2);
+            lim = fminf(lim, ub2 * kNnPrune);
+            if (lb2 > lim * kNnPrune) continue;
+            if (bx - b1[0] >= -done && bx - b1[0] <= done && by - b1[1] >= -done && by - b1[1] <= done && bz - b1[2] >= -done && bz - b1[2] <= done) continue;
+            const unsigned long long w0 = g.occ[(static_cast<uint32_t>(bz) * d1[1] + by) * d1[0] + bx];
+            cells_bound(w0, bx, by, bz);
+            cells_open(w0, bx, by, bz);
+        }
+    };
+
+    // A. bricks
+    if (nn_shell_walk<G, true>(g.occ, d1, b1, E1, pq, 0, kShells, sub, lim, [&](unsigned long long wb, int bx, int by, int bz) {
+            const unsigned long long mine = nn_deal_bits(wb, G, sub);
+            cells_bound(mine, bx, by, bz);
+            lim = nn_group_fmin<G>(lim);
+            cells_open(mine, bx, by, bz);
+            agree();
+        }))
+        return;
+    // B. super-bricks
+    if (nn_shell_walk<G, true>(g.occ1, d2, b2, E2, pq, 0, kShells, sub, lim, [&](unsigned long long wb, int sx, int sy, int sz) {
+            bricks(nn_deal_bits(wb, G, sub), sx, sy, sz, kShells);
+            agree();
+        }))
+        return;
+    // C. blocks, to the end of the grid
+    nn_shell_walk<G, false>(g.occ2, d3, b3, E3, pq, 0, 0x3fffffff, sub, lim, [&](unsigned long long wb, int kx, int ky, int kz) {
+        const unsigned long long mine = nn_deal_bits(wb, G, sub);
+        for (unsigned long long w = mine; w != 0ull; w &= w - 1ull) {
+            const int bit = __ffsll(w) - 1;
+            const int sx = kx * 4 + (bit & 3), sy = ky * 4 + ((bit >> 2) & 3), sz = kz * 4 + (bit >> 4);
+            float     lb2, ub2;
+            pq.box(E2, sx, sy, sz, lb2, ub2);
+            lim = fminf(lim, ub2 * kNnPrune);
+            if (lb2 > lim * kNnPrune) continue;
+            if (sx - b2[0] >= -kShells && sx - b2[0] <= kShells && sy - b2[1] >= -kShells && sy - b2[1] <= kShells && sz - b2[2] >= -kShells && sz - b2[2] <= kShells) continue;
+            bricks(g.occ1[(static_cast<uint32_t>(sz) * d2[1] + sy) * d2[0] + sx], sx, sy, sz, -1);
+        }
+        agree();
+    });
+}
+
 // One level of the group search.  Order of work, each step followed by a (distance, index) min over the group:
 //   1. the query's own cell, candidates strided over the G lanes (coalesced);
 //   2. the other 26 cells of the 3x3x3 block as x-rows, one row per lane, skipping rows and end cells whose box is
 //      farther than the best so far — on dense clouds the nearest neighbour is centimetres away and almost all go;
-//   3. rings 2 .. max_ring, rows pruned the same way.
-// Returns true when the search is finished: everything not visited is farther than the best candidate, or farther
-// than sqrt(max_sq), or the level is exhausted.  (best_d, best_i) carry over from an earlier level.
+//   3. (max_ring > 1) the rest of the grid through the occupancy pyramid, see nn_pyramid_walk.
+// Returns true when the search is finished: everything not visited is farther than the best candidate or farther
+// than sqrt(max_sq); false only for max_ring <= 1 when the block was not conclusive.
 template <int G>
 __device__ __forceinline__ bool nn_level_search(const NnGridDev& g, float x, float y, float z, int sub, int max_ring, double max_sq, int32_t& best_i, float& best_d)
 {
@@ -182,55 +448,10 @@ __device__ __forceinline__ bool nn_level_search(const NnGridDev& g, float x, flo
         }
         nn_group_min<G>(best_d, best_i);
     }
-    const int rlast = min(rmax, max_ring);
-    for (int r = 2; r <= rlast; ++r) {  // 3. rings
-        if (finished(r)) return true;
-        const int w = 2 * r + 1;
-        // each x-row of the ring is one run (rows on a y/z face) or two single cells (x faces), cut down to the chord of
-        // the sphere of the best distance so far; the run bounds of kRows rows are fetched together so their latencies
-        // overlap (far rings are mostly empty rows) and the group shares its best after every such batch
-        constexpr int kRows = 4;
-        for (int j0 = 0; j0 < w * w; j0 += kRows * G) {
-            uint32_t rb[kRows][2], re[kRows][2];
-            const double lim = cur_lim();
-#pragma unroll
-            for (int u = 0; u < kRows; ++u) {
-                rb[u][0] = re[u][0] = rb[u][1] = re[u][1] = 0u;
-                const int j = j0 + sub + u * G;
-                if (j >= w * w) continue;
-                const int dz = j / w - r, dy = j % w - r;
-                const int zz = c[2] + dz, yy = c[1] + dy;
-                if (zz < 0 || zz >= g.dim[2] || yy < 0 || yy >= g.dim[1]) continue;
-                const double ly = axis_lb(1, dy), lz = axis_lb(2, dz);
-                const double lyz = (ly * ly + lz * lz) * (1.0 - 1e-5);
-                if (lyz > lim) continue;
-                // cells k >= 1 to the left / right can matter while face + (k - 1) * cell <= hx
-                int kl = r, kr = r;
-                if (lim < 1e299) {
-                    const double hx = sqrt(lim - lyz) * (1.0 + 1e-5);
-                    kl = hx >= flo[0] ? static_cast<int>(fmin((hx - flo[0]) / static_cast<double>(g.cell), 1e9)) + 1 : 0;
-                    kr = hx >= fhi[0] ? static_cast<int>(fmin((hx - fhi[0]) / static_cast<double>(g.cell), 1e9)) + 1 : 0;
-                }
-                const uint32_t row = (static_cast<uint32_t>(zz) * g.dim[1] + yy) * g.dim[0];
-                if (dz == r || dz == -r || dy == r || dy == -r) {
-                    const int x0 = max(c[0] - min(r, kl), 0), x1 = min(c[0] + min(r, kr), g.dim[0] - 1);
-                    rb[u][0] = g.cell_start[row + x0];
-                    re[u][0] = g.cell_start[row + x1 + 1];
-                } else {
-                    const int xa = c[0] - r, xb = c[0] + r;
-                    if (xa >= 0 && kl >= r) { rb[u][0] = g.cell_start[row + xa]; re[u][0] = g.cell_start[row + xa + 1]; }
-                    if (xb < g.dim[0] && kr >= r) { rb[u][1] = g.cell_start[row + xb]; re[u][1] = g.cell_start[row + xb + 1]; }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < kRows; ++u) {
-                scan(rb[u][0], re[u][0]);
-                scan(rb[u][1], re[u][1]);
-            }
-            nn_group_min<G>(best_d, best_i);
-        }
-    }
-    return rlast == rmax || finished(rlast + 1);
+    if (finished(2) || rmax <= 1) return true;
+    if (max_ring <= 1) return false;  // block-only pass (nn_fit_block_kernel)
+    nn_pyramid_walk<G>(g, x, y, z, c, sub, max_sq, best_i, best_d);  // 3. everything else
+    return true;
 }
 
 // Exact nearest neighbour among the points within sqrt(max_sq) of the query (max_sq = +inf: of all points); a best
@@ -241,8 +462,22 @@ __device__ __forceinline__ void nn_nearest_group(const NnGrid2Dev& g, float x, f
     best_i = -1;
     best_d = INFINITY;
     if (g.level[0].n == 0 || !finite3(x, y, z)) return;  // uniform within the group
-    for (int l = 0; l < g.n_levels; ++l)
-        if (nn_level_search<G>(g.level[l], x, y, z, sub, l + 1 < g.n_levels ? g.fine_rings : 0x7fffffff, max_sq, best_i, best_d)) return;
+    nn_level_search<G>(g.level[0], x, y, z, sub, 0x7fffffff, max_sq, best_i, best_d);
+}
+
+// The part of a 1-NN search that follows an inconclusive look at the query's 3x3x3 block (nn_level_search with
+// max_ring <= 1), for callers that want the nearest POINT rather than its index: `bound` is the best squared distance the
+// block gave (INFINITY: none) or any other distance known to be attained; on return best_pos >= 0 names the position in
+// level[0].sorted of the nearest point found outside the block with its squared distance best_d, if one is within the
+// bound; the answer is the smaller of bound and best_d.
+template <int G>
+__device__ __forceinline__ void nn_far_search(const NnGrid2Dev& g, float x, float y, float z, int sub, double max_sq, float bound, int32_t& best_pos, float& best_d)
+{
+    best_pos = -1;
+    best_d = INFINITY;
+    int c[3];
+    nn_cell_of(g.level[0], x, y, z, c);
+    nn_pyramid_walk<G, true>(g.level[0], x, y, z, c, sub, max_sq, best_pos, best_d, bound);
 }
 
 }  // namespace mrgfe

@@ -19,19 +19,25 @@ struct NnGridDev {  // one resolution level
     float           slack;       // absolute bound on the binning error of floorf((p - origin) / cell) * cell, metres
     int32_t         dim[3];
     uint32_t        n;           // points in `sorted`
-    uint32_t        pad;
+    int32_t         bdim[3];     // bricks of 4 x 4 x 4 cells per axis
     const uint32_t* cell_start;  // dim product + 1
     const float4*   sorted;      // xyz + original index (bit pattern) in w
+    // occupancy: one 64-bit word per brick, bit x + 4 y + 16 z (cell offsets inside the brick) set iff the cell holds a
+    // point.  A query whose 3x3x3 block is empty finds the occupied cells around it from a few of these words instead
+    // of probing cell_start row by row.
+    const unsigned long long* occ;
+    const unsigned long long* occ1;  // per super-brick (4^3 bricks): which bricks are occupied
+    const unsigned long long* occ2;  // per block (4^3 super-bricks)
 };
 
-// Up to three levels over the same points (cell edge x kLevelRatio per level): a query looks at the cells around it on
-// the finest level and, when that is not conclusive (sparse surroundings), continues on the next coarser one, whose ring
-// walk reaches far neighbours in few rings.
+// Up to three levels over the same points (cell edge x kLevelRatio per level).  k-NN queries whose neighbourhood is
+// sparse at the finest scale climb to the coarser ones (nn_knn_kernel); 1-NN queries stay on the finest level and reach
+// far neighbours through its occupancy pyramid (nn_device.h), so grids that only serve 1-NN are built with one level.
 constexpr int kNnMaxLevels = 3;
 struct NnGrid2Dev {
     NnGridDev level[kNnMaxLevels];
-    int32_t   n_levels;    // >= 1
-    int32_t   fine_rings;  // rings walked on a level before a 1-NN query moves to the next coarser one
+    int32_t   n_levels;  // >= 1
+    int32_t   pad;
 };
 
 // one getFitnessScore evaluation: source cloud `src` (device) moved by the row-major 3x4 float transform, matched

@@ -65,6 +65,25 @@ __global__ __launch_bounds__(256) void nn_cellkey_kernel(const float4* __restric
     }
 }
 
+// occupancy words of the bricks (after cell_start is final): one thread per cell, an atomic only for occupied cells
+__global__ __launch_bounds__(256) void nn_occupancy_kernel(NnGridDev g, uint32_t n_cells, unsigned long long* __restrict__ occ)
+{
+    const uint32_t at = blockIdx.x * 256u + threadIdx.x;
+    if (at >= n_cells || g.cell_start[at + 1] == g.cell_start[at]) return;
+    const uint32_t x = at % g.dim[0], y = (at / g.dim[0]) % g.dim[1], z = at / (static_cast<uint32_t>(g.dim[0]) * g.dim[1]);
+    const uint32_t brick = ((z >> 2) * g.bdim[1] + (y >> 2)) * g.bdim[0] + (x >> 2);
+    atomicOr(&occ[brick], 1ull << ((x & 3u) | ((y & 3u) << 2) | ((z & 3u) << 4)));
+}
+
+// next pyramid level: bit of a child node set iff its word is non-zero (dims = child grid, pdim = parent grid)
+__global__ __launch_bounds__(256) void nn_occupancy_up_kernel(const unsigned long long* __restrict__ child, int dx, int dy, int dz, int px, int py, unsigned long long* __restrict__ parent)
+{
+    const uint32_t at = blockIdx.x * 256u + threadIdx.x;
+    if (at >= static_cast<uint32_t>(dx) * dy * dz || child[at] == 0ull) return;
+    const uint32_t x = at % dx, y = (at / dx) % dy, z = at / (static_cast<uint32_t>(dx) * dy);
+    atomicOr(&parent[((z >> 2) * py + (y >> 2)) * px + (x >> 2)], 1ull << ((x & 3u) | ((y & 3u) << 2) | ((z & 3u) << 4)));
+}
+
 __global__ __launch_bounds__(256) void nn_gather_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ sorted_vals, uint32_t n_valid, float4* __restrict__ sorted)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -88,9 +107,23 @@ int NnGrid::build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const 
     lv.n = bb.n_finite;
     for (int a = 0; a < 3; ++a) lv.dim[a] = static_cast<int>(std::floor((bb.mx[a] - bb.mn[a]) / cell)) + 1;
     const uint32_t n_cells = static_cast<uint32_t>(lv.dim[0]) * lv.dim[1] * lv.dim[2];
-    MRGFE_TRY(d_cells.ensure(sizeof(uint32_t) * (size_t(n_cells) + 4 + 2 * kCrowdSlots)));
-    MRGFE_HIP_CHECK(hipMemsetAsync(d_cells.p, 0, sizeof(uint32_t) * (size_t(n_cells) + 4 + 2 * kCrowdSlots), st));
+    int    pd[3][3];  // node grids of the occupancy pyramid: bricks, super-bricks, blocks
+    size_t pn[3] = {1, 1, 1};
+    for (int a = 0; a < 3; ++a) {
+        lv.bdim[a] = pd[0][a] = (lv.dim[a] + 3) / 4;
+        pd[1][a] = (pd[0][a] + 3) / 4;
+        pd[2][a] = (pd[1][a] + 3) / 4;
+        for (int k = 0; k < 3; ++k) pn[k] *= static_cast<size_t>(pd[k][a]);
+    }
+    // [counts / cell_start: n_cells + 1][crowd counters][occupancy words of the three pyramid levels], zeroed together
+    const size_t head_words = size_t(n_cells) + 4 + 2 * kCrowdSlots, occ_at = (head_words + 1) & ~size_t(1);
+    const size_t all_words = occ_at + 2 * (pn[0] + pn[1] + pn[2]);
+    MRGFE_TRY(d_cells.ensure(sizeof(uint32_t) * all_words));
+    MRGFE_HIP_CHECK(hipMemsetAsync(d_cells.p, 0, sizeof(uint32_t) * all_words, st));
     lv.cell_start = d_cells.as<uint32_t>();
+    lv.occ = reinterpret_cast<const unsigned long long*>(d_cells.as<uint32_t>() + occ_at);
+    lv.occ1 = lv.occ + pn[0];
+    lv.occ2 = lv.occ1 + pn[1];
     // the crowd counters live behind the (n_cells + 1)-entry count table, 8-byte aligned
     unsigned long long* d_crowd = reinterpret_cast<unsigned long long*>(d_cells.as<uint32_t>() + ((size_t(n_cells) + 2) & ~size_t(1)));
     hipLaunchKernelGGL(nn_cellkey_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, d_pts, nn, lv, n_cells, dk.as<uint32_t>(), dv.as<uint32_t>(), d_cells.as<uint32_t>(),
@@ -116,6 +149,13 @@ int NnGrid::build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const 
     MRGFE_HIP_CHECK(hipMemcpyAsync(ds.as<char>() + sizeof(Slice), ctab.h.data(), sizeof(Slice), hipMemcpyHostToDevice, st));
     MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (ctab.total_blks + 8)));
     MRGFE_TRY(exclusive_scan(ctx, d_cells.as<uint32_t>(), d_cells.as<uint32_t>(), ds.as<Slice>() + 1, ctab, dblk.as<uint32_t>(), dblk.as<uint32_t>() + ctab.total_blks));
+    if (&lv == &h_.level[0]) {  // only the finest level is searched through the pyramid (the coarser ones serve the k-NN climb)
+        hipLaunchKernelGGL(nn_occupancy_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, st, lv, n_cells, const_cast<unsigned long long*>(lv.occ));
+        hipLaunchKernelGGL(nn_occupancy_up_kernel, dim3(static_cast<uint32_t>((pn[0] + 255) / 256)), dim3(256), 0, st, lv.occ, pd[0][0], pd[0][1], pd[0][2], pd[1][0], pd[1][1],
+                           const_cast<unsigned long long*>(lv.occ1));
+        hipLaunchKernelGGL(nn_occupancy_up_kernel, dim3(static_cast<uint32_t>((pn[1] + 255) / 256)), dim3(256), 0, st, lv.occ1, pd[1][0], pd[1][1], pd[1][2], pd[2][0], pd[2][1],
+                           const_cast<unsigned long long*>(lv.occ2));
+    }
     MRGFE_TRY(d_sorted.ensure(sizeof(float4) * std::max<size_t>(nn, 1)));
     lv.sorted = d_sorted.as<float4>();
     hipLaunchKernelGGL(nn_gather_kernel, dim3((lv.n + 255) / 256), dim3(256), 0, st, d_pts, sv, lv.n, d_sorted.as<float4>());
@@ -131,8 +171,7 @@ int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size
     if (const char* e = std::getenv("MRGFE_NN_CELL")) { cell_size = static_cast<float>(std::atof(e)); crowding_target = 0; }  // tuning hook
     std::memset(&h_, 0, sizeof(h_));
     h_.n_levels = 1;
-    h_.fine_rings = 8;
-    for (auto& lv : h_.level) { lv.cell = cell_size; lv.dim[0] = lv.dim[1] = lv.dim[2] = 1; }
+    for (auto& lv : h_.level) { lv.cell = cell_size; lv.dim[0] = lv.dim[1] = lv.dim[2] = 1; lv.bdim[0] = lv.bdim[1] = lv.bdim[2] = 1; }
     if (n > 0x7fffffffu) { set_error("NnGrid: cloud too large"); return MRGFE_ERR_INVALID; }
     hipStream_t st = ctx->stream;
     uint32_t    nn = static_cast<uint32_t>(n);
@@ -153,8 +192,11 @@ int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size
     MRGFE_HIP_CHECK(hipMemcpyAsync(&bb, d_out, sizeof(BBox), hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
     if (bb.n_finite == 0) {  // empty grid: one cell, no points
-        MRGFE_TRY(d_cell_start_[0].ensure(8));
-        MRGFE_HIP_CHECK(hipMemsetAsync(d_cell_start_[0].p, 0, 8, st));
+        MRGFE_TRY(d_cell_start_[0].ensure(32));
+        MRGFE_HIP_CHECK(hipMemsetAsync(d_cell_start_[0].p, 0, 32, st));
+        h_.level[0].occ = reinterpret_cast<const unsigned long long*>(d_cell_start_[0].as<uint32_t>() + 2);
+        h_.level[0].occ1 = h_.level[0].occ + 1;
+        h_.level[0].occ2 = h_.level[0].occ + 2;
         MRGFE_TRY(d_sorted_[0].ensure(16));
         h_.level[0].cell_start = d_cell_start_[0].as<uint32_t>();
         h_.level[0].sorted = d_sorted_[0].as<float4>();
@@ -191,8 +233,7 @@ int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size
     // coarser levels for queries whose neighbourhood is empty at the finer scale: kLevelRatio x the edge each, same origin,
     // as long as the level above still has more than a handful of cells per axis
     float ratio = kLevelRatio;
-    if (const char* e = std::getenv("MRGFE_NN_COARSE_RATIO")) ratio = std::max(2.0f, static_cast<float>(std::atof(e)));  // tuning hooks
-    if (const char* e = std::getenv("MRGFE_NN_FINE_RINGS")) h_.fine_rings = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("MRGFE_NN_COARSE_RATIO")) ratio = std::max(2.0f, static_cast<float>(std::atof(e)));  // tuning hook
     while (h_.n_levels < std::min(max_levels, kNnMaxLevels)) {
         const NnGridDev& below = h_.level[h_.n_levels - 1];
         if (std::max(below.dim[0], std::max(below.dim[1], below.dim[2])) <= 4) break;
@@ -248,32 +289,122 @@ __global__ __launch_bounds__(256) void nn_nearest_kernel(NnGrid2Dev g, const flo
     }
 }
 
-// getFitnessScore for a batch of (grid, source cloud, transform) jobs: blockIdx.y = job, block partial = (sum of
-// squared 1-NN distances <= max_range, count)
-__global__ __launch_bounds__(256) void nn_fitness_kernel(const NnFitnessJob* __restrict__ jobs, double max_range, double* __restrict__ partial)
+// getFitnessScore for a batch of (grid, source cloud, transform) jobs (blockIdx.y = job) in three passes over one float
+// per query.  A wavefront holds eight queries and runs as long as its slowest one, and on a loop-closure candidate about a
+// third of the queries have nothing in the 3x3x3 block around them, so in a single pass nearly every wavefront pays for a
+// far search.  Hence:
+//   block : own cell + 3x3x3 block of the finest level; writes the squared distance, -1 (nothing within max_range), or
+//           queues the query (per-job list, appended through LDS: one global atomic per workgroup flush);
+//   far   : the queued queries only, densely packed eight to a wavefront: full search (brick walk, coarser levels);
+//   sum   : per job, fixed-order f64 sum and count of the distances — the far pass fills slots, so the order in which
+//           queries were queued does not enter and the result is bitwise reproducible.
+constexpr float    kFitNone = -1.0f;
+constexpr uint32_t kFitPendCap = 1024;
+
+__device__ __forceinline__ void nn_load_job(NnFitnessJob& s_job, const NnFitnessJob* job)
+{
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(job);
+    uint32_t*       dst = reinterpret_cast<uint32_t*>(&s_job);
+    for (uint32_t w = threadIdx.x; w < sizeof(NnFitnessJob) / 4; w += 256) dst[w] = src[w];
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void nn_fit_block_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range, float* __restrict__ sqd,
+                                                            uint32_t* __restrict__ pend, uint32_t* __restrict__ pend_cnt)
 {
     __shared__ NnFitnessJob s_job;
-    __shared__ double       s_sum[4];
-    __shared__ uint32_t     s_cnt[4];
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(jobs + blockIdx.y);
-        uint32_t*       dst = reinterpret_cast<uint32_t*>(&s_job);
-        for (uint32_t w = threadIdx.x; w < sizeof(NnFitnessJob) / 4; w += 256) dst[w] = src[w];
-    }
+    __shared__ uint32_t     s_pend[kFitPendCap], s_np, s_base;
+    nn_load_job(s_job, jobs + blockIdx.y);
+    if (threadIdx.x == 0) s_np = 0;
     __syncthreads();
     const NnGrid2Dev& g = s_job.grid;
-    const uint32_t   n = s_job.n;
-    const int        sub = threadIdx.x % kNnGroup;
-    double   sum = 0.0;
-    uint32_t cnt = 0;
-    for (uint32_t i = blockIdx.x * (256u / kNnGroup) + threadIdx.x / kNnGroup; i < n; i += gridDim.x * (256u / kNnGroup)) {
-        const float4 p = s_job.src[i];
+    const uint32_t    n = s_job.n, off = job_off[blockIdx.y];
+    const int         sub = threadIdx.x % kNnGroup;
+    constexpr uint32_t per_blk = 256u / kNnGroup;
+    auto flush = [&]() {  // called by the whole workgroup
+        __syncthreads();
+        const uint32_t np = s_np;
+        if (np) {
+            if (threadIdx.x == 0) s_base = atomicAdd(&pend_cnt[blockIdx.y], np);
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < np; k += 256) pend[off + s_base + k] = s_pend[k];
+            __syncthreads();
+            if (threadIdx.x == 0) s_np = 0;
+        }
+        __syncthreads();
+    };
+    // each workgroup takes a contiguous chunk of the queries and queues in query order, so neighbours in the queue are
+    // neighbours in the scan (the far pass hands each group a run of consecutive entries)
+    __shared__ uint32_t s_w[4];
+    const uint32_t chunk = ((n + gridDim.x - 1) / gridDim.x + per_blk - 1) / per_blk * per_blk;
+    const uint32_t i_end = min(n, (blockIdx.x + 1) * chunk);
+    for (uint32_t i0 = blockIdx.x * chunk; i0 < i_end; i0 += per_blk) {  // uniform trip count
+        if (s_np > kFitPendCap - per_blk) flush();  // s_np is stable here: the appends of the last trip are behind a barrier
+        const uint32_t i = i0 + threadIdx.x / kNnGroup;
+        bool           queue = false;
+        if (i < i_end) {
+            const float4 p = s_job.src[i];
+            float x, y, z;
+            transform_point(s_job.T12, p.x, p.y, p.z, x, y, z);
+            int32_t bi = -1;
+            float   bd = INFINITY;
+            bool    done = true;
+            if (g.level[0].n != 0 && finite3(x, y, z)) done = nn_level_search<kNnGroup>(g.level[0], x, y, z, sub, 1, max_range, bi, bd);
+            // queued queries leave what the block gave (INFINITY: nothing) as the far pass's starting bound
+            if (sub == 0) sqd[off + i] = done ? ((bi >= 0 && static_cast<double>(bd) <= max_range) ? bd : kFitNone) : (bi >= 0 ? bd : INFINITY);
+            queue = sub == 0 && !done;
+        }
+        const uint64_t m = __ballot(queue);
+        if (lane_id() == 0) s_w[wave_id()] = static_cast<uint32_t>(__popcll(m));
+        __syncthreads();
+        if (queue) {
+            uint32_t at = s_np + static_cast<uint32_t>(__popcll(m & ((1ull << lane_id()) - 1ull)));
+            for (uint32_t w = 0; w < wave_id(); ++w) at += s_w[w];
+            s_pend[at] = i;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_np += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    flush();
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void nn_fit_far_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range, const uint32_t* __restrict__ pend,
+                                                          const uint32_t* __restrict__ pend_cnt, float* __restrict__ sqd)
+{
+    const uint32_t np = pend_cnt[blockIdx.y];
+    constexpr uint32_t per_blk = 256u / kNnGroup;
+    if (blockIdx.x * per_blk >= np) return;
+    __shared__ NnFitnessJob s_job;
+    nn_load_job(s_job, jobs + blockIdx.y);
+    __syncthreads();
+    const uint32_t off = job_off[blockIdx.y];
+    const int      sub = threadIdx.x % kNnGroup;
+    for (uint32_t k = blockIdx.x * per_blk + threadIdx.x / kNnGroup; k < np; k += gridDim.x * per_blk) {
+        const uint32_t i = pend[off + k];
+        const float4   p = s_job.src[i];
         float x, y, z;
         transform_point(s_job.T12, p.x, p.y, p.z, x, y, z);
-        int32_t bi;
+        const float bound = sqd[off + i];  // what the block gave
+        int32_t bpos;
         float   bd;
-        nn_nearest_group<kNnGroup>(g, x, y, z, sub, max_range, bi, bd);
-        if (sub == 0 && bi >= 0 && static_cast<double>(bd) <= max_range) { sum += static_cast<double>(bd); ++cnt; }
+        nn_far_search<kNnGroup>(s_job.grid, x, y, z, sub, max_range, bound, bpos, bd);
+        bd = fminf(bd, bound);
+        if (sub == 0) sqd[off + i] = static_cast<double>(bd) <= max_range ? bd : kFitNone;
+    }
+}
+
+// block partial = (sum, count) over a fixed slice of the job's queries
+__global__ __launch_bounds__(256) void nn_fit_sum_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, const float* __restrict__ sqd,
+                                                          double* __restrict__ partial)
+{
+    __shared__ double   s_sum[4];
+    __shared__ uint32_t s_cnt[4];
+    const uint32_t n = jobs[blockIdx.y].n, off = job_off[blockIdx.y];
+    double   sum = 0.0;
+    uint32_t cnt = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const float d = sqd[off + i];
+        if (d >= 0.0f) { sum += static_cast<double>(d); ++cnt; }
     }
     sum = wave_sum(sum);
     cnt = wave_sum(cnt);
@@ -308,22 +439,41 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     if (count == 0) return MRGFE_OK;
     if (count > 65535) { set_error("nn_fitness_batch: too many jobs"); return MRGFE_ERR_INVALID; }
     hipStream_t st = ctx->stream;
-    uint32_t    max_n = 0;
-    for (size_t j = 0; j < count; ++j) max_n = std::max(max_n, jobs[j].n);
+    std::vector<uint32_t> off(count + 1, 0u);
+    uint32_t max_n = 0;
+    for (size_t j = 0; j < count; ++j) {
+        if (uint64_t(off[j]) + jobs[j].n > 0xfffffff0ull) { set_error("nn_fitness_batch: more than 2^32 queries"); return MRGFE_ERR_INVALID; }
+        off[j + 1] = off[j] + jobs[j].n;
+        max_n = std::max(max_n, jobs[j].n);
+    }
+    const size_t total = off[count];
     if (max_n == 0) return MRGFE_OK;
     constexpr uint32_t per_blk = 256u / kNnGroup;
-    // enough blocks to fill the chip a few times over, few enough that the partial table stays small
+    // enough blocks to fill the chip many times over (the far pass is ragged), few enough that each has a few trips
     const uint32_t want = static_cast<uint32_t>(std::max<size_t>(1, (size_t(ctx->cu_count) * 128 + count - 1) / count));
     const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((max_n + per_blk - 1) / per_blk, want));
-    DevBuf& dw = ctx->scratch[9];
+    const uint32_t nblk_sum = std::max<uint32_t>(1, std::min<uint32_t>((max_n + 1023) / 1024, 256));
+    // scratch 9: jobs, offsets, queue lengths, partial sums; 12: one float per query; 13: the queues (10 and 11 may hold
+    // the caller's clouds, see mrgfe_calc_fitness_score)
+    DevBuf &dw = ctx->scratch[9], &dq = ctx->scratch[12], &dp = ctx->scratch[13];
     const size_t jobs_bytes = (sizeof(NnFitnessJob) * count + 255) & ~size_t(255);
-    MRGFE_TRY(dw.ensure(jobs_bytes + sizeof(double) * 2 * (size_t(nblk) + 1) * count));
+    const size_t off_bytes = (sizeof(uint32_t) * 2 * (count + 1) + 255) & ~size_t(255);
+    MRGFE_TRY(dw.ensure(jobs_bytes + off_bytes + sizeof(double) * 2 * (size_t(nblk_sum) + 1) * count));
+    MRGFE_TRY(dq.ensure(sizeof(float) * total));
+    MRGFE_TRY(dp.ensure(sizeof(uint32_t) * total));
     NnFitnessJob* d_jobs = dw.as<NnFitnessJob>();
-    double*       d_part = reinterpret_cast<double*>(dw.as<char>() + jobs_bytes);
-    double*       d_res = d_part + 2 * size_t(nblk) * count;
+    uint32_t*     d_off = reinterpret_cast<uint32_t*>(dw.as<char>() + jobs_bytes);
+    uint32_t*     d_cnt = d_off + count + 1;
+    double*       d_part = reinterpret_cast<double*>(dw.as<char>() + jobs_bytes + off_bytes);
+    double*       d_res = d_part + 2 * size_t(nblk_sum) * count;
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_jobs, jobs, sizeof(NnFitnessJob) * count, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(nn_fitness_kernel, dim3(nblk, static_cast<uint32_t>(count)), dim3(256), 0, st, d_jobs, max_range, d_part);
-    hipLaunchKernelGGL(nn_fitness_final_kernel, dim3(static_cast<uint32_t>(count)), dim3(256), 0, st, d_part, nblk, d_res);
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_off, off.data(), sizeof(uint32_t) * (count + 1), hipMemcpyHostToDevice, st));
+    MRGFE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * count, st));
+    const dim3 grid(nblk, static_cast<uint32_t>(count));
+    hipLaunchKernelGGL(nn_fit_block_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, dq.as<float>(), dp.as<uint32_t>(), d_cnt);
+    hipLaunchKernelGGL(nn_fit_far_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, dp.as<uint32_t>(), d_cnt, dq.as<float>());
+    hipLaunchKernelGGL(nn_fit_sum_kernel, dim3(nblk_sum, static_cast<uint32_t>(count)), dim3(256), 0, st, d_jobs, d_off, dq.as<float>(), d_part);
+    hipLaunchKernelGGL(nn_fitness_final_kernel, dim3(static_cast<uint32_t>(count)), dim3(256), 0, st, d_part, nblk_sum, d_res);
     MRGFE_HIP_CHECK(hipGetLastError());
     std::vector<double> res(2 * count);
     MRGFE_HIP_CHECK(hipMemcpyAsync(res.data(), d_res, sizeof(double) * 2 * count, hipMemcpyDeviceToHost, st));

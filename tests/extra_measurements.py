@@ -72,6 +72,9 @@ def main():
     lc["pairs"] = B
     lc["fitness_sample"] = [float(res["fitness"][0]), float(res["fitness"][1])]
     out["loop_closure_batch"] = lc
+    if "--lc-only" in sys.argv:
+        print(json.dumps(out))
+        return
 
     # ---- single pair latency ----------------------------------------------------------------------------------------
     reg = NdtHip(resolution=1.0, transformation_epsilon=0.1, maximum_iterations=64, ctx=ctx)
