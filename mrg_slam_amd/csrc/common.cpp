@@ -94,7 +94,12 @@ class HostPool {
     {
         int n = 8;  // total threads, the caller included
         if (const char* e = std::getenv("MRGFE_HOST_THREADS")) n = std::atoi(e);
-        const unsigned hw = std::thread::hardware_concurrency();
+        unsigned hw = std::thread::hardware_concurrency();
+        // one process per GPU (torchrun sets LOCAL_WORLD_SIZE): the ranks of a node share its cores, and these threads spin
+        if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) {
+            const int ranks = std::atoi(e);
+            if (hw && ranks > 1) hw = std::max(1u, hw / static_cast<unsigned>(ranks));
+        }
         if (hw && static_cast<unsigned>(n) > hw) n = static_cast<int>(hw);
         n = n < 1 ? 1 : (n > 8 ? 8 : n);
         for (int i = 0; i < n - 1; ++i) workers_.emplace_back([this, i] { loop(i); });

@@ -378,16 +378,19 @@ __device__ __forceinline__ bool nn_level_search(const NnGridDev& g, float x, flo
 {
     int c[3];
     nn_cell_of(g, x, y, z, c);  // the caller checked that the query is finite
-    // distance from the query to the low / high face of its cell per axis, never negative (clamped queries), less the
-    // binning slack: a point in a cell k > 0 cells away along an axis is at least face + (k - 1) * cell away along it
-    const float q[3] = {x, y, z};
-    double      flo[3], fhi[3], margin = 1e300;
+    // distance from the query to the low / high face of its cell per axis, never negative (clamped queries), less a
+    // margin of four binning slacks (float bounds, see NnPyramidQuery): a point in a cell k > 0 cells away along an axis is
+    // at least face + (k - 1) * cell away along it
+    const float m = 4.0f * g.slack;
+    const float t[3] = {x - g.origin[0], y - g.origin[1], z - g.origin[2]};
+    const float max_sq_f = max_sq >= 3.0e38 ? INFINITY : static_cast<float>(max_sq) * (1.0f + 1e-6f);
+    float       flo[3], fhi[3], margin = INFINITY;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const double lo = static_cast<double>(g.origin[a]) + static_cast<double>(c[a]) * static_cast<double>(g.cell);
-        flo[a] = fmax(static_cast<double>(q[a]) - lo - static_cast<double>(g.slack), 0.0);
-        fhi[a] = fmax(lo + static_cast<double>(g.cell) - static_cast<double>(q[a]) - static_cast<double>(g.slack), 0.0);
-        margin = fmin(margin, fmin(flo[a], fhi[a]));
+        const float lo = static_cast<float>(c[a]) * g.cell;
+        flo[a] = fmaxf(t[a] - lo - m, 0.0f);
+        fhi[a] = fmaxf(lo + g.cell - t[a] - m, 0.0f);
+        margin = fminf(margin, fminf(flo[a], fhi[a]));
     }
     auto consider = [&](const float4& p) {
         const float   d = sqdist3f(p.x, p.y, p.z, x, y, z);
@@ -404,17 +407,17 @@ __device__ __forceinline__ bool nn_level_search(const NnGridDev& g, float x, flo
         if (k < e) consider(g.sorted[k]);
     };
     auto axis_lb = [&](int a, int d) {  // lower bound on the distance along axis a to a cell d cells away
-        if (d == 0) return 0.0;
-        return (d < 0 ? flo[a] : fhi[a]) + static_cast<double>((d < 0 ? -d : d) - 1) * static_cast<double>(g.cell);
+        if (d == 0) return 0.0f;
+        return (d < 0 ? flo[a] : fhi[a]) + static_cast<float>((d < 0 ? -d : d) - 1) * g.cell;
     };
     auto finished = [&](int r) {  // before ring r: lower bound on everything outside the Chebyshev ball of r - 1 cells
-        const double b = static_cast<double>(r - 1) * static_cast<double>(g.cell) + margin;
-        const double b2 = b * b * (1.0 - 1e-5);
-        return (best_i >= 0 && static_cast<double>(best_d) < b2) || b2 > max_sq;
+        const float b = static_cast<float>(r - 1) * g.cell + margin;
+        const float b2 = b * b;
+        return (best_i >= 0 && best_d * kNnPrune < b2) || b2 > max_sq_f * kNnPrune;
     };
     // squared distance beyond which a cell cannot matter to this lane any more: its best so far (any candidate bounds
-    // the answer from above) or the caller's cut-off
-    auto cur_lim = [&]() { return fmin(best_i >= 0 ? static_cast<double>(best_d) : 1e300, max_sq); };
+    // the answer from above) or the caller's cut-off, with the comparison slack
+    auto cur_lim = [&]() { return fminf(best_i >= 0 ? best_d : INFINITY, max_sq_f) * kNnPrune; };
     int rmax = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) rmax = max(rmax, max(c[a], g.dim[a] - 1 - c[a]));
@@ -427,17 +430,17 @@ __device__ __forceinline__ bool nn_level_search(const NnGridDev& g, float x, flo
     }
     if (rmax == 0) return true;
     if (!finished(1)) {  // 2. rest of the 3x3x3 block
-        const double fx0 = flo[0] * flo[0], fx1 = fhi[0] * fhi[0];
+        const float fx0 = flo[0] * flo[0], fx1 = fhi[0] * fhi[0];
         for (int j = sub; j < 9; j += G) {
-            const double lim = cur_lim();
+            const float lim = cur_lim();
             const int dz = j / 3 - 1, dy = j % 3 - 1;
             const int zz = c[2] + dz, yy = c[1] + dy;
             if (zz < 0 || zz >= g.dim[2] || yy < 0 || yy >= g.dim[1]) continue;
-            const double ly = axis_lb(1, dy), lz = axis_lb(2, dz);
-            const double lyz = ly * ly + lz * lz;
-            if (lyz * (1.0 - 1e-5) > lim) continue;
-            const bool     left = c[0] > 0 && (lyz + fx0) * (1.0 - 1e-5) <= lim;
-            const bool     right = c[0] + 1 < g.dim[0] && (lyz + fx1) * (1.0 - 1e-5) <= lim;
+            const float ly = axis_lb(1, dy), lz = axis_lb(2, dz);
+            const float lyz = ly * ly + lz * lz;
+            if (lyz > lim) continue;
+            const bool left = c[0] > 0 && lyz + fx0 <= lim;
+            const bool right = c[0] + 1 < g.dim[0] && lyz + fx1 <= lim;
             const uint32_t row = (static_cast<uint32_t>(zz) * g.dim[1] + yy) * g.dim[0];
             if (j == 4) {  // own row: the own cell is done
                 if (left) scan(g.cell_start[row + c[0] - 1], g.cell_start[row + c[0]]);
