@@ -46,7 +46,9 @@ typedef struct mrgfe_reg mrgfe_reg; /* one registration object == one pcl::Regis
 /* registration_method strings of the reference that this library serves (registrations.cpp:45-151) */
 enum mrgfe_method {
     MRGFE_NDT_HIP = 0,  /* replaces "NDT_OMP"  : pclomp::NormalDistributionsTransform (registrations.cpp:130-148) */
-    MRGFE_GICP_HIP = 1  /* replaces "FAST_GICP": fast_gicp::FastGICP                  (registrations.cpp:55-63)   */
+    MRGFE_GICP_HIP = 1, /* replaces "FAST_GICP": fast_gicp::FastGICP                  (registrations.cpp:55-63)   */
+    MRGFE_SMALL_GICP_HIP = 2 /* replaces "SMALL_GICP" (the YAML default, config/mrg_slam.yaml:100): small_gicp::RegistrationPCL
+                                (registrations.cpp:46-54): the same GICP factor perturbed on the right, small_gicp's LM schedule */
 };
 /* reg_nn_search_method (registrations.cpp:140-146) */
 enum mrgfe_ndt_search { MRGFE_KDTREE = 0, MRGFE_DIRECT26 = 1, MRGFE_DIRECT7 = 2, MRGFE_DIRECT1 = 3 };
@@ -121,6 +123,14 @@ int mrgfe_ndt_grid(const mrgfe_reg* reg, int32_t min_b[3], int32_t max_b[3], int
 int mrgfe_ndt_leaves(mrgfe_reg* reg, int32_t* keys, int32_t* nr_points, double* mean3, double* icov9);
 /* mean number of valid neighbour voxels per source point over the evaluations of the last align (k-bar of SURVEY §8d) */
 double mrgfe_ndt_mean_neighbours(const mrgfe_reg* reg);
+
+/* ---- GICP internals exposed for kernel-level parity tests ------------------------------------------------------------ */
+/* update_correspondences + linearize at the pose T (column-major double 4x4, T_target_source): H (row-major 6x6,
+ * rotation block first), b, the sum of r^T M r over the correspondences (the variants scale it themselves) and their
+ * number.  The Jacobian is the one of the registration's method (fast_gicp: left, small_gicp: right perturbation). */
+int mrgfe_gicp_linearize(mrgfe_reg* reg, const double T[16], double H[36], double b[6], double* sum_errors, int* n_correspondences);
+/* regularised k-NN covariances (row-major 3x3 per point) of the source (which = 0) or target (1) cloud */
+int mrgfe_gicp_covariances(mrgfe_reg* reg, int which, double* cov9_per_point);
 
 /* ---- prefilter chain (apps/prefiltering_component.cpp:149-151). Outputs: caller-allocated capacity-n packed float4
  *      buffers + count.  Order-preserving where the reference is. ------------------------------------------------- */

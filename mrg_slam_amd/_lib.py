@@ -16,7 +16,7 @@ _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.environ.get("MRGFE_LIB") or os.path.join(_PKG, "libmrgfe.so")  # MRGFE_LIB: kernel-variant experiments only
 
 MRGFE_OK, ERR_INVALID, ERR_HIP, ERR_OVERFLOW, ERR_EMPTY, ERR_STATE = 0, -1, -2, -3, -4, -5
-NDT_HIP, GICP_HIP = 0, 1
+NDT_HIP, GICP_HIP, SMALL_GICP_HIP = 0, 1, 2
 SEARCH = {"KDTREE": 0, "DIRECT26": 1, "DIRECT7": 2, "DIRECT1": 3}
 
 
@@ -90,6 +90,8 @@ SIGNATURES = {
     "mrgfe_reg_trans_probability": (C.c_double, [_vp]),
     "mrgfe_reg_hessian": (C.c_int, [_vp, _dp]),
     "mrgfe_ndt_evaluate": (C.c_int, [_vp, _fp, _dp, C.c_int, _dp, _dp, _dp]),
+    "mrgfe_gicp_linearize": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _ip]),
+    "mrgfe_gicp_covariances": (C.c_int, [_vp, C.c_int, _dp]),
     "mrgfe_ndt_num_leaves": (C.c_int, [_vp]),
     "mrgfe_ndt_grid": (C.c_int, [_vp, _ip, _ip, _ip]),
     "mrgfe_ndt_leaves": (C.c_int, [_vp, _ip, _ip, _dp, _dp]),

@@ -41,13 +41,14 @@ GicpParams gicp_params_from(const mrgfe_reg_params& p)
     g.trans_eps = p.transformation_epsilon;
     g.rot_eps = p.rotation_epsilon;
     g.max_iterations = p.maximum_iterations;
+    g.variant = p.method == MRGFE_SMALL_GICP_HIP ? 1 : 0;
     return g;
 }
 
 int check_params(const mrgfe_reg_params* p)
 {
     if (!p) { set_error("NULL params"); return MRGFE_ERR_INVALID; }
-    if (p->method != MRGFE_NDT_HIP && p->method != MRGFE_GICP_HIP) { set_error("unknown registration method %d", p->method); return MRGFE_ERR_INVALID; }
+    if (p->method != MRGFE_NDT_HIP && p->method != MRGFE_GICP_HIP && p->method != MRGFE_SMALL_GICP_HIP) { set_error("unknown registration method %d", p->method); return MRGFE_ERR_INVALID; }
     if (p->method == MRGFE_NDT_HIP) {
         if (!(p->resolution > 0)) { set_error("resolution must be > 0"); return MRGFE_ERR_INVALID; }
         if (p->nn_search_method < 0 || p->nn_search_method > 3) { set_error("unknown nn_search_method %d", p->nn_search_method); return MRGFE_ERR_INVALID; }
@@ -317,6 +318,26 @@ int mrgfe_ndt_evaluate(mrgfe_reg* reg, const float T[16], const double p[6], int
     return e.evaluate(0, Tr, p, mode, score, grad, hess);
 }
 
+int mrgfe_gicp_linearize(mrgfe_reg* reg, const double T[16], double H[36], double b[6], double* sum_errors, int* n_correspondences)
+{
+    if (!reg || !reg->gicp || !T || !H || !b || !sum_errors || !n_correspondences) { set_error("mrgfe_gicp_linearize: needs a GICP registration and non-NULL arguments"); return MRGFE_ERR_INVALID; }
+    if (!reg->has_target || !reg->has_source) { set_error("linearize: target / source not set"); return MRGFE_ERR_STATE; }
+    MRGFE_LOCK(reg->ctx);
+    MRGFE_TRY(reg->ctx->bind());
+    double Tr[16];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) Tr[r * 4 + c] = T[c * 4 + r];
+    return reg->gicp->linearize(Tr, H, b, sum_errors, n_correspondences);
+}
+
+int mrgfe_gicp_covariances(mrgfe_reg* reg, int which, double* cov9_per_point)
+{
+    if (!reg || !reg->gicp || !cov9_per_point || which < 0 || which > 1) { set_error("mrgfe_gicp_covariances: needs a GICP registration, which in {0, 1} and an output buffer"); return MRGFE_ERR_INVALID; }
+    if ((which == 0 && !reg->has_source) || (which == 1 && !reg->has_target)) { set_error("covariances: cloud not set"); return MRGFE_ERR_STATE; }
+    MRGFE_LOCK(reg->ctx);
+    MRGFE_TRY(reg->ctx->bind());
+    return reg->gicp->covariances(which, cov9_per_point);
+}
+
 int mrgfe_ndt_num_leaves(const mrgfe_reg* reg) { return (reg && reg->ndt && reg->ndt->n_targets() > 0) ? static_cast<int>(reg->ndt->target(0).n_leaves) : 0; }
 
 int mrgfe_ndt_grid(const mrgfe_reg* reg, int32_t min_b[3], int32_t max_b[3], int32_t div_b[3])
@@ -573,7 +594,7 @@ int mrgfe_batch_build_targets(mrgfe_batch* b)
 {
     if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(b->ctx);
-    if (b->params.method == MRGFE_GICP_HIP) return MRGFE_OK;  // target covariances and grids are built by the first align
+    if (b->params.method != MRGFE_NDT_HIP) return MRGFE_OK;  // GICP variants: target covariances and grids are built by the first align
     return b->ndt->build_targets();
 }
 int mrgfe_batch_num_pairs(const mrgfe_batch* b) { return b ? b->ndt->n_pairs() : 0; }
@@ -584,7 +605,7 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
     MRGFE_LOCK(b->ctx);
     NdtEngine& e = *b->ndt;
     const int P = e.n_pairs();
-    const bool gicp = b->params.method == MRGFE_GICP_HIP;
+    const bool gicp = b->params.method != MRGFE_NDT_HIP;
     if (gicp) {
         // GICP_HIP: the candidates of a target share its covariances and correspondence grid, and all LM loops advance
         // together (GicpBatch: one launch per kernel and round for the pairs still running)

@@ -66,6 +66,8 @@ __global__ __launch_bounds__(256) void gicp_cov_kernel(const float4* __restrict_
 struct GicpPose {
     double T[12];   // row-major 3x4, double
     float  Tf[12];  // trans.cast<float>()
+    int    right;   // 1: linearise for T <- T exp(d) (small_gicp), 0: for T <- exp(d) T (fast_gicp)
+    int    pad;
 };
 
 // shared tail: block reduction of 29 doubles into one partial record
@@ -155,8 +157,20 @@ __device__ __forceinline__ void gicp_linearize_block(const float4* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 3; ++r) Me[r] = M[r * 3 + 0] * err[0] + M[r * 3 + 1] * err[1] + M[r * 3 + 2] * err[2];
             vals[0] = err[0] * Me[0] + err[1] * Me[1] + err[2] * Me[2];
-            // J = [ skew(tA) | -I ]
-            const double J[3][6] = {{0, -tA[2], tA[1], -1, 0, 0}, {tA[2], 0, -tA[0], 0, -1, 0}, {-tA[1], tA[0], 0, 0, 0, -1}};
+            // J = [ skew(tA) | -I ], or for a right perturbation [ R skew(a) | -R ]
+            double J[3][6] = {{0, -tA[2], tA[1], -1, 0, 0}, {tA[2], 0, -tA[0], 0, -1, 0}, {-tA[1], tA[0], 0, 0, 0, -1}};
+            if (pose.right) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const double r0 = pose.T[r * 4 + 0], r1 = pose.T[r * 4 + 1], r2 = pose.T[r * 4 + 2];
+                    J[r][0] = r1 * mA[2] - r2 * mA[1];
+                    J[r][1] = r2 * mA[0] - r0 * mA[2];
+                    J[r][2] = r0 * mA[1] - r1 * mA[0];
+                    J[r][3] = -r0;
+                    J[r][4] = -r1;
+                    J[r][5] = -r2;
+                }
+            }
             double MJ[3][6];
 #pragma unroll
             for (int r = 0; r < 3; ++r)
@@ -383,10 +397,12 @@ bool is_converged(const double d[16], double rot_eps, double trans_eps)
     return mx < 1;
 }
 
-GicpPose make_pose(const double T[16])
+GicpPose make_pose(const double T[16], int variant)
 {
     GicpPose p;
     for (int i = 0; i < 12; ++i) { p.T[i] = T[i]; p.Tf[i] = static_cast<float>(T[i]); }
+    p.right = variant == 1 ? 1 : 0;
+    p.pad = 0;
     return p;
 }
 
@@ -484,7 +500,7 @@ int GicpEngine::run_linearize(const double T[16], bool, double H[36], double b[6
     double* d_part = d_partial_.as<double>();
     double* d_res = d_part + size_t(nblk) * kGicpStride;
     MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev0, st));
-    const GicpPose pose = make_pose(T);
+    const GicpPose pose = make_pose(T, prm_.variant);
     constexpr uint32_t per_blk = 256u / kGicpGroup;
     hipLaunchKernelGGL(gicp_corr_kernel, dim3((n + per_blk - 1) / per_blk), dim3(256), 0, st, tgt_grid_.dev2(), d_src_, n, pose, prm_.max_corr_dist * prm_.max_corr_dist, d_corr_.as<int32_t>());
     hipLaunchKernelGGL(gicp_linearize_kernel, dim3(nblk), dim3(256), 0, st, d_src_, n, d_tgt_, d_src_cov_.as<double>(), d_tgt_cov_.as<double>(), pose, d_corr_.as<int32_t>(),
@@ -519,7 +535,7 @@ int GicpEngine::run_error(const double T[16], double* err)
     const uint32_t n = static_cast<uint32_t>(n_src_), nblk = (n + 255) / 256;
     double* d_part = d_partial_.as<double>();
     double* d_res = d_part + size_t(nblk) * kGicpStride;
-    hipLaunchKernelGGL(gicp_error_kernel, dim3(nblk), dim3(256), 0, st, d_src_, n, d_tgt_, make_pose(T), d_corr_.as<int32_t>(), d_mahal_.as<double>(), d_part);
+    hipLaunchKernelGGL(gicp_error_kernel, dim3(nblk), dim3(256), 0, st, d_src_, n, d_tgt_, make_pose(T, prm_.variant), d_corr_.as<int32_t>(), d_mahal_.as<double>(), d_part);
     hipLaunchKernelGGL(gicp_reduce_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, d_res);
     MRGFE_HIP_CHECK(hipGetLastError());
     double r[kGicpStride];
@@ -571,7 +587,7 @@ void GicpLmController::start(const GicpParams& prm, const float guess[16], uint3
 {
     prm_ = prm;
     for (int i = 0; i < 16; ++i) x0_[i] = static_cast<double>(guess[i]);
-    lambda_ = -1.0;
+    lambda_ = prm_.variant == 1 ? prm_.sg_init_lambda : -1.0;
     converged_ = false;
     nr_iterations_ = 0;
     n_linearize_ = n_error_ = 0;
@@ -588,7 +604,8 @@ void GicpLmController::propose()
     for (int t = 0; t < 6; ++t) nb[t] = -b_[t];
     solve6(A, nb, d_);
     se3_exp(d_, delta_);
-    mul4(delta_, x0_, xi_);
+    if (prm_.variant == 1) mul4(x0_, delta_, xi_);  // small_gicp perturbs on the right
+    else                   mul4(delta_, x0_, xi_);
     req_.type = 1;
     std::memcpy(req_.T, xi_, sizeof(xi_));
 }
@@ -603,8 +620,43 @@ void GicpLmController::end_outer(bool ok)
     std::memcpy(req_.T, x0_, sizeof(x0_));
 }
 
+// small_gicp::LevenbergMarquardtOptimizer::optimize, one request at a time (gicp_engine.h, variant 1)
+void GicpLmController::on_result_small(const double r[32])
+{
+    if (req_.type == 0) {
+        ++n_linearize_;
+        nr_iterations_ = outer_;
+        y0_ = 0.5 * r[0];
+        for (int t = 0; t < 6; ++t) b_[t] = r[1 + t];
+        int t = 7;
+        for (int i = 0; i < 6; ++i)
+            for (int j = i; j < 6; ++j) { H_[i * 6 + j] = r[t]; H_[j * 6 + i] = r[t]; ++t; }
+        std::memcpy(final_hessian_, H_, sizeof(H_));
+        inner_ = 0;
+        if (prm_.sg_max_inner_iterations <= 0) { done_ = true; return; }
+        propose();
+        return;
+    }
+    ++n_error_;
+    const double new_e = 0.5 * r[0];
+    if (new_e <= y0_) {
+        converged_ = std::sqrt(d_[0] * d_[0] + d_[1] * d_[1] + d_[2] * d_[2]) <= prm_.rot_eps && std::sqrt(d_[3] * d_[3] + d_[4] * d_[4] + d_[5] * d_[5]) <= prm_.trans_eps;
+        std::memcpy(x0_, xi_, sizeof(xi_));
+        lambda_ /= prm_.sg_lambda_factor;
+        ++outer_;
+        if (converged_ || outer_ >= prm_.max_iterations) { done_ = true; return; }
+        req_.type = 0;
+        std::memcpy(req_.T, x0_, sizeof(x0_));
+        return;
+    }
+    lambda_ *= prm_.sg_lambda_factor;
+    if (++inner_ >= prm_.sg_max_inner_iterations) { done_ = true; return; }  // no trial was accepted: give up, not converged
+    propose();
+}
+
 void GicpLmController::on_result(const double r[32])
 {
+    if (prm_.variant == 1) { on_result_small(r); return; }
     if (req_.type == 0) {
         ++n_linearize_;
         nr_iterations_ = outer_;
@@ -709,13 +761,14 @@ int GicpBatch::align_all(std::vector<GicpEngine*>& engines, std::vector<GicpBatc
     GicpEvalDev* he = h_evals_.as<GicpEvalDev>();
     double*      hr = h_results_.as<double>();
     const double thr = engines[pairs[0].target]->params().max_corr_dist;
-    const int    round_cap = (engines[pairs[0].target]->params().max_iterations + 1) * (engines[pairs[0].target]->params().lm_max_iterations + 2) + 4;
+    const GicpParams& prm0 = engines[pairs[0].target]->params();
+    const int    round_cap = (prm0.max_iterations + 1) * (std::max(prm0.lm_max_iterations, prm0.sg_max_inner_iterations) + 2) + 4;
     for (int round = 0; round < round_cap; ++round) {
         uint32_t n_lin = 0, n_err = 0;
         for (int i = 0; i < P; ++i) {
             GicpLmController& c = pairs[i].ctl;
             if (c.done() || pairs[i].n == 0) { he[i].type = -1; continue; }
-            he[i].pose = make_pose(c.request().T);
+            he[i].pose = make_pose(c.request().T, engines[pairs[i].target]->params().variant);
             he[i].thr2 = thr * thr;
             he[i].type = c.request().type;
             if (he[i].type == 0) he[n_lin++].order[0] = static_cast<uint32_t>(i);

@@ -1,4 +1,7 @@
-// csrc/gicp_engine.h — GICP_HIP engine: fast_gicp::FastGICP (registrations.cpp:55-63) on MI355X.
+// csrc/gicp_engine.h — GICP engines on MI355X: GICP_HIP = fast_gicp::FastGICP (registrations.cpp:55-63) and
+// SMALL_GICP_HIP = small_gicp::RegistrationPCL (registrations.cpp:46-54, the YAML default).  Both share the k-NN
+// covariances, the 1-NN correspondence search and the Mahalanobis weights; they differ in the side the pose is
+// perturbed on (Jacobian) and in the Levenberg-Marquardt schedule, which is the `variant` of GicpParams.
 #pragma once
 #include "common.h"
 #include <vector>
@@ -15,6 +18,12 @@ struct GicpParams {
     int    max_iterations = 64;
     int    lm_max_iterations = 10;
     double lm_init_lambda_factor = 1e-9;
+    // variant 1, small_gicp: T <- T exp(d), J = [R skew(a) | -R], error 0.5 r^T M r; LevenbergMarquardtOptimizer with
+    // lambda 1e-3, factor 10, at most 10 inner trials, a trial accepted iff its error does not exceed the current one;
+    // converged iff |d_rot| <= rot_eps and |d_trans| <= trans_eps
+    int    variant = 0;
+    double sg_init_lambda = 1e-3, sg_lambda_factor = 10.0;
+    int    sg_max_inner_iterations = 10;
 };
 
 class GicpEngine {
@@ -99,6 +108,7 @@ class GicpLmController {
     double final_hessian_[36];
     void propose();       // next LM trial from (H_, b_, lambda_): request compute_error at xi_
     void end_outer(bool ok);
+    void on_result_small(const double r[32]);  // variant 1
 };
 
 // Batched GICP_HIP: the candidates of a batch advance through their LM loops together, one launch per kernel per round

@@ -17,7 +17,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import GICP_HIP, NDT_HIP, SEARCH, Context, PairResult, RegParams, check, default_context, lib
+from ._lib import GICP_HIP, NDT_HIP, SEARCH, SMALL_GICP_HIP, Context, PairResult, RegParams, check, default_context, lib
 
 _fp = C.POINTER(C.c_float)
 _dp = C.POINTER(C.c_double)
@@ -51,7 +51,7 @@ class HipRegistration:
         self._params = params
         self._h = C.c_void_p()
         check(lib().mrgfe_reg_create(self._ctx._h, C.byref(params), C.byref(self._h)))
-        self._n_src = 0
+        self._n_src = self._n_tgt = 0
 
     def __del__(self):
         try:
@@ -66,6 +66,7 @@ class HipRegistration:
         """registration_->setInputTarget(cloud). Returns the library status (0 ok, ERR_OVERFLOW / ERR_EMPTY when PCL
         would abort the voxelisation): like PCL this does not raise for those, the registration simply has no target."""
         c = _cloud(cloud)
+        self._n_tgt = len(c)
         st = lib().mrgfe_reg_set_target(self._h, c.ctypes.data_as(_fp), len(c), 16)
         if st < 0 and st not in (_lib.ERR_OVERFLOW, _lib.ERR_EMPTY):
             check(st)
@@ -77,6 +78,7 @@ class HipRegistration:
         check(lib().mrgfe_reg_set_source(self._h, c.ctypes.data_as(_fp), len(c), 16))
 
     def setInputTargetDevice(self, dev_ptr: int, n: int) -> int:
+        self._n_tgt = n
         st = lib().mrgfe_reg_set_target_device(self._h, C.c_void_p(dev_ptr), n)
         if st < 0 and st not in (_lib.ERR_OVERFLOW, _lib.ERR_EMPTY):
             check(st)
@@ -193,6 +195,37 @@ class GicpHip(HipRegistration):
         p.num_threads = num_threads
         super().__init__(p, ctx)
 
+    def linearize(self, T):
+        """update_correspondences + linearize at T (4x4, T_target_source): (H, b, sum of r^T M r, correspondences)."""
+        Tc = np.ascontiguousarray(np.asarray(T, dtype=np.float64).T)
+        H, b, e, n = np.zeros((6, 6)), np.zeros(6), C.c_double(0), C.c_int(0)
+        check(lib().mrgfe_gicp_linearize(self._h, Tc.ctypes.data_as(_dp), H.ctypes.data_as(_dp), b.ctypes.data_as(_dp), C.byref(e), C.byref(n)))
+        return H, b, e.value, n.value
+
+    def covariances(self, which="source"):
+        n = self._n_src if which == "source" else self._n_tgt
+        out = np.empty((n, 3, 3))
+        check(lib().mrgfe_gicp_covariances(self._h, 0 if which == "source" else 1, out.ctypes.data_as(_dp)))
+        return out
+
+
+class SmallGicpHip(GicpHip):
+    """registration_method "SMALL_GICP_HIP": drop-in for the SMALL_GICP branch (registrations.cpp:46-54), the default of
+    config/mrg_slam.yaml: small_gicp's GICP factor (right perturbation) and Levenberg-Marquardt schedule."""
+
+    METHOD = SMALL_GICP_HIP
+
+    def __init__(self, correspondence_randomness=20, max_correspondence_distance=2.0, transformation_epsilon=0.01, rotation_epsilon=2e-3,
+                 maximum_iterations=64, num_threads=0, ctx: Context | None = None):
+        p = default_params(SMALL_GICP_HIP)
+        p.correspondence_randomness = correspondence_randomness
+        p.max_correspondence_distance = max_correspondence_distance
+        p.transformation_epsilon = transformation_epsilon
+        p.rotation_epsilon = rotation_epsilon
+        p.maximum_iterations = maximum_iterations
+        p.num_threads = num_threads
+        HipRegistration.__init__(self, p, ctx)
+
 
 def select_registration_method(params: dict, ctx: Context | None = None) -> HipRegistration:
     """Python mirror of mrg_slam::select_registration_method (registrations.cpp:28-152) for the HIP back ends.
@@ -200,12 +233,16 @@ def select_registration_method(params: dict, ctx: Context | None = None) -> HipR
     ``params`` carries the reference's ROS parameter names (registration_method, reg_num_threads,
     reg_transformation_epsilon, reg_maximum_iterations, reg_max_correspondence_distance, reg_correspondence_randomness,
     reg_resolution, reg_nn_search_method).  "NDT_HIP" (and, to stay drop-in, "NDT_OMP"/"NDT") select :class:`NdtHip`;
-    "GICP_HIP" / "FAST_GICP" select :class:`GicpHip`.  Like the reference, an unknown name falls through to NDT.
+    "GICP_HIP" / "FAST_GICP" select :class:`GicpHip`, "SMALL_GICP_HIP" / "SMALL_GICP" :class:`SmallGicpHip`.  Like the
+    reference, an unknown name falls through to NDT.
     """
     method = str(params.get("registration_method", "FAST_GICP"))
     eps = float(params.get("reg_transformation_epsilon", 0.01))
     iters = int(params.get("reg_maximum_iterations", 64))
     threads = int(params.get("reg_num_threads", 0))
+    if method in ("SMALL_GICP_HIP", "SMALL_GICP"):
+        return SmallGicpHip(int(params.get("reg_correspondence_randomness", 20)), float(params.get("reg_max_correspondence_distance", 2.0)), eps,
+                            maximum_iterations=iters, num_threads=threads, ctx=ctx)
     if method in ("GICP_HIP", "FAST_GICP"):
         return GicpHip(int(params.get("reg_correspondence_randomness", 20)), float(params.get("reg_max_correspondence_distance", 2.0)), eps,
                        maximum_iterations=iters, num_threads=threads, ctx=ctx)

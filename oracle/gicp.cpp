@@ -141,6 +141,17 @@ double FastGicp::linearize(const double T[16], double H[36], double b[6], int* n
         if (!H || !b) continue;
         // J = [ skew(tA) | -I ]  (3 x 6)
         double J[3][6] = {{0, -tA[2], tA[1], -1, 0, 0}, {tA[2], 0, -tA[0], 0, -1, 0}, {-tA[1], tA[0], 0, 0, 0, -1}};
+        if (variant == 1) {  // small_gicp: J = [ R skew(a) | -R ]
+            for (int r = 0; r < 3; ++r) {
+                const double r0 = T[r * 4 + 0], r1 = T[r * 4 + 1], r2 = T[r * 4 + 2];
+                J[r][0] = r1 * mean_A[2] - r2 * mean_A[1];
+                J[r][1] = r2 * mean_A[0] - r0 * mean_A[2];
+                J[r][2] = r0 * mean_A[1] - r1 * mean_A[0];
+                J[r][3] = -r0;
+                J[r][4] = -r1;
+                J[r][5] = -r2;
+            }
+        }
         double MJ[3][6];
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 6; ++c) MJ[r][c] = M[r * 3 + 0] * J[0][c] + M[r * 3 + 1] * J[1][c] + M[r * 3 + 2] * J[2][c];
         double* Ht = &Hs[static_cast<size_t>(omp_get_thread_num()) * 36];
@@ -268,10 +279,60 @@ static bool is_converged(const double delta[16], double rot_eps, double trans_ep
     return mx < 1;
 }
 
+// small_gicp::LevenbergMarquardtOptimizer::optimize over the GICP factors (header of gicp.h)
+void FastGicp::align_small_gicp(const float guess[16])
+{
+    double T[16];
+    for (int i = 0; i < 16; ++i) T[i] = static_cast<double>(guess[i]);
+    double lambda = sg_init_lambda;
+    converged = false;
+    nr_iterations = 0;
+    n_linearize = n_error_evals = 0;
+    for (int t = 0; t < 36; ++t) final_hessian[t] = (t % 7 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < max_iterations && !converged; ++i) {
+        double H[36], b[6];
+        double e = 0.5 * linearize(T, H, b, nullptr);
+        bool   success = false;
+        for (int j = 0; j < sg_max_inner_iterations; ++j) {
+            double A[36], nb[6], d[6], delta[16], new_T[16];
+            for (int t = 0; t < 36; ++t) A[t] = H[t] + ((t % 7 == 0) ? lambda : 0.0);
+            for (int t = 0; t < 6; ++t) nb[t] = -b[t];
+            solve6(A, nb, d);
+            se3_exp(d, delta);
+            mul4d(T, delta, new_T);
+            const double new_e = 0.5 * compute_error(new_T);
+            ++n_error_evals;
+            if (new_e <= e) {
+                converged = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) <= rot_eps && std::sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]) <= trans_eps;
+                std::memcpy(T, new_T, sizeof(new_T));
+                lambda /= sg_lambda_factor;
+                success = true;
+                e = new_e;
+                break;
+            }
+            lambda *= sg_lambda_factor;
+        }
+        nr_iterations = i;
+        std::memcpy(final_hessian, H, sizeof(H));
+        if (!success) break;
+    }
+    for (int i = 0; i < 16; ++i) final_[i] = static_cast<float>(T[i]);
+}
+
 void FastGicp::align(const float guess[16], float* aligned)
 {
     const int n = static_cast<int>(source.size() / 4);
     ensure_covs();
+    if (variant == 1) {
+        align_small_gicp(guess);
+        if (aligned)
+            for (int i = 0; i < n; ++i) {
+                const float* p = &source[4 * static_cast<size_t>(i)];
+                transform_point_f(final_, p[0], p[1], p[2], aligned[4 * i], aligned[4 * i + 1], aligned[4 * i + 2]);
+                aligned[4 * i + 3] = p[3];
+            }
+        return;
+    }
     double x0[16];
     for (int i = 0; i < 16; ++i) x0[i] = static_cast<double>(guess[i]);
     double lm_lambda = -1.0;

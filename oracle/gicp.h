@@ -5,6 +5,16 @@
 // src/mrg_slam/registrations.cpp:55-63 with num_threads / transformation_epsilon / maximum_iterations /
 // max_correspondence_distance / correspondence_randomness) on top of fast_gicp::LsqRegistration
 // (Levenberg-Marquardt) — SURVEY.md Appendix A.6.  PARITY UNPINNED (see quirks.h).
+//
+// `variant = 1` restates small_gicp::RegistrationPCL<PointXYZI,PointXYZI> (koide3/small_gicp, un-vendored, no version
+// pinned: CMakeLists.txt:91, package.xml:21; the YAML default "SMALL_GICP", registrations.cpp:46-54) as published:
+// the same GICP factor (k-NN covariances regularised to eigenvalues (1e-3, 1, 1), 1-NN correspondences rejected beyond
+// max_correspondence_distance, Mahalanobis (C_B + T C_A T^T)^-1) linearised for a RIGHT perturbation T <- T exp(d),
+// J = [ R skew(a) | -R ], error 0.5 r^T M r, and its LevenbergMarquardtOptimizer (lambda 1e-3, factor 10, at most 10
+// inner trials, a trial is accepted iff its error does not exceed the current one; converged iff |d_rot| <= rotation_eps
+// and |d_trans| <= translation_eps, RegistrationPCL sets rotation_eps 2e-3 and translation_eps = transformation_epsilon).
+// Deviation kept from the fast_gicp path: correspondences are searched with the float-cast transform (small_gicp's own
+// kd-tree works on the double coordinates).
 #pragma once
 #include <vector>
 
@@ -21,6 +31,9 @@ struct FastGicp {
     int    num_threads       = 1;
     int    lm_max_iterations = 10;
     double lm_init_lambda_factor = 1e-9;
+    int    variant = 0;                 // 0: fast_gicp::FastGICP, 1: small_gicp::RegistrationPCL (GICP)
+    double sg_init_lambda = 1e-3, sg_lambda_factor = 10.0;  // small_gicp::LevenbergMarquardtOptimizer defaults
+    int    sg_max_inner_iterations = 10;
 
     std::vector<float>  target, source;        // xyzi
     std::vector<double> target_covs, source_covs;  // 9 doubles (3x3 block of the 4x4) per point
@@ -35,6 +48,7 @@ struct FastGicp {
     void   set_target(const float* xyzi, int n);
     void   set_source(const float* xyzi, int n);
     void   align(const float guess_rowmajor[16], float* aligned);
+    void   align_small_gicp(const float guess_rowmajor[16]);  // variant 1: leaves the result in final_
     double fitness(double max_range) const;
     void   get_covariances(int which, double* out) const;  // 0 = source, 1 = target (computes if needed)
     // update_correspondences + linearize at T (row-major 4x4 double). returns sum of errors.

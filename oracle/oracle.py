@@ -75,6 +75,7 @@ def lib():
             "orc_gicp_create": (vp, []),
             "orc_gicp_destroy": (None, [vp]),
             "orc_gicp_set_params": (None, [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]),
+            "orc_gicp_set_variant": (None, [vp, C.c_int]),
             "orc_gicp_set_target": (None, [vp, fp, C.c_int]),
             "orc_gicp_set_source": (None, [vp, fp, C.c_int]),
             "orc_gicp_align": (None, [vp, fp, fp]),
@@ -330,11 +331,14 @@ class Ndt:
 class FastGicp:
     """fast_gicp::FastGICP restated (oracle/gicp.cpp)."""
 
+    VARIANT = 0
+
     def __init__(self, correspondence_randomness=20, max_correspondence_distance=2.0, transformation_epsilon=0.1, rotation_epsilon=2e-3,
                  maximum_iterations=64, num_threads=1):
         self._h = lib().orc_gicp_create()
         lib().orc_gicp_set_params(self._h, correspondence_randomness, max_correspondence_distance, transformation_epsilon, rotation_epsilon,
                                   maximum_iterations, num_threads)
+        lib().orc_gicp_set_variant(self._h, self.VARIANT)
         self._n_src = self._n_tgt = 0
 
     def __del__(self):
@@ -388,3 +392,9 @@ class FastGicp:
         H, b, n = np.empty((6, 6)), np.empty(6), C.c_int(0)
         e = lib().orc_gicp_linearize(self._h, _pd(T), _pd(H), _pd(b), C.byref(n))
         return e, H, b, n.value
+
+
+class SmallGicp(FastGicp):
+    """small_gicp::RegistrationPCL (GICP) restated: the reference's YAML default "SMALL_GICP" (oracle/gicp.h, variant 1)."""
+
+    VARIANT = 1

@@ -5,7 +5,8 @@ The reference (aserbremen/mrg_slam) ships no tests, fixtures or golden vectors f
 un-vendored PCL / ndt_omp / fast_gicp, so these vectors are produced by this repo's own CPU restatement
 (oracle/) - they freeze ITS numbers: the CPU suite checks that the oracle still reproduces them, the GPU suite checks
 the HIP path against them on the GPU box.  Re-run only when the oracle is deliberately changed:
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py                      # all three files
+    python tests/golden/make_golden.py --small-gicp-only    # tests/golden/small_gicp.npz only
 """
 import os
 import sys
@@ -95,5 +96,29 @@ def main():
     print(path, os.path.getsize(path), "bytes")
 
 
+def small_gicp():
+    """tests/golden/small_gicp.npz: the restated small_gicp (oracle variant 1) on the inputs of frontend_small.npz
+    (loaded from the committed file, which is left untouched)."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "frontend_small.npz"))
+    out = {}
+    g = orc.SmallGicp(transformation_epsilon=0.01, num_threads=1)
+    g.setInputTarget(G["tgt"])
+    g.setInputSource(G["src"])
+    for tag, guess in (("warm", G["guess"]), ("identity", np.eye(4))):
+        g.align(guess)
+        out[f"{tag}_T"] = g.getFinalTransformation()
+        out[f"{tag}_H"] = g.getFinalHessian()
+        out[f"{tag}_meta"] = np.array([g.hasConverged(), g.getFinalNumIteration()], dtype=np.int64)
+    e, H, b, n = g.linearize(np.asarray(G["guess"], dtype=np.float64))
+    out["lin_err"], out["lin_H"], out["lin_b"], out["lin_n"] = np.array([e]), H, b, np.array([n])
+    path = os.path.join(ROOT, "tests", "golden", "small_gicp.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if "--small-gicp-only" in sys.argv:
+        small_gicp()
+    else:
+        main()
+        small_gicp()

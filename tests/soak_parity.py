@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     from conftest import small_cloud
-    from mrg_slam_amd import GicpHip, NdtHip, synth
+    from mrg_slam_amd import GicpHip, NdtHip, SmallGicpHip, synth
     from oracle import oracle as orc
 
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -35,10 +35,14 @@ def main():
             g = NdtHip(resolution=res, transformation_epsilon=eps, maximum_iterations=64, search=search)
             o = orc.Ndt(resolution=res, transformation_epsilon=eps, maximum_iterations=64, num_threads=8, search=search)
             tag = f"NDT res={res} {search} eps={eps}"
-        else:
+        elif rng.random() < 0.5:
             g = GicpHip(transformation_epsilon=eps)
             o = orc.FastGicp(transformation_epsilon=eps, num_threads=8)
             tag = f"GICP eps={eps}"
+        else:
+            g = SmallGicpHip(transformation_epsilon=eps)
+            o = orc.SmallGicp(transformation_epsilon=eps, num_threads=8)
+            tag = f"SMALL_GICP eps={eps}"
         ok = g.setInputTarget(tgt)
         ook = o.setInputTarget(tgt)
         g.setInputSource(src)

@@ -56,6 +56,27 @@ def test_oracle_gicp_reproduces_golden():
     np.testing.assert_array_equal(g.covariances("source")[:64], G["gicp_src_cov"])
 
 
+def test_oracle_small_gicp_reproduces_golden():
+    from oracle import oracle as orc
+
+    S = np.load(os.path.join(os.path.dirname(__file__), "golden", "small_gicp.npz"))
+    g = orc.SmallGicp(transformation_epsilon=0.01, num_threads=1)  # one thread: sequential sums, exact reproduction
+    g.setInputTarget(G["tgt"])
+    g.setInputSource(G["src"])
+    for tag, guess in (("warm", G["guess"]), ("identity", np.eye(4))):
+        g.align(guess)
+        np.testing.assert_array_equal(g.getFinalTransformation(), S[f"{tag}_T"])
+        np.testing.assert_array_equal(g.getFinalHessian(), S[f"{tag}_H"])
+        assert [int(g.hasConverged()), g.getFinalNumIteration()] == S[f"{tag}_meta"].tolist()
+    e, H, b, n = g.linearize(np.asarray(G["guess"], dtype=np.float64))
+    assert e == S["lin_err"][0] and n == S["lin_n"][0]
+    np.testing.assert_array_equal(H, S["lin_H"])
+    np.testing.assert_array_equal(b, S["lin_b"])
+    # the solution is the one the fast_gicp formulation finds (same cost, different parametrisation of the step)
+    assert np.linalg.norm(S["warm_T"][:3, 3] - G["gicp_T"][:3, 3]) < 2e-3
+    assert np.linalg.norm(S["warm_T"][:3, 3] - G["rel"][:3, 3]) < 0.02
+
+
 def test_oracle_perpoint_passes_reproduce_golden():
     from oracle import oracle as orc
 
@@ -137,6 +158,25 @@ def test_hip_ndt_matches_golden(eps, tag):
     idx, sqd = g.nearestKSearch1(G["src"][:200])
     np.testing.assert_array_equal(idx, G["nn_idx"])
     np.testing.assert_array_equal(sqd, G["nn_sqd"])
+
+
+@pytest.mark.gpu
+def test_hip_small_gicp_matches_golden():
+    from mrg_slam_amd import SmallGicpHip, synth
+
+    S = np.load(os.path.join(os.path.dirname(__file__), "golden", "small_gicp.npz"))
+    g = SmallGicpHip(transformation_epsilon=0.01)
+    g.setInputTarget(G["tgt"])
+    g.setInputSource(G["src"])
+    for tag, guess in (("warm", G["guess"]), ("identity", np.eye(4))):
+        g.align(guess)
+        T = g.getFinalTransformation()
+        assert np.linalg.norm(T[:3, 3].astype(np.float64) - S[f"{tag}_T"][:3, 3]) <= 1e-4
+        assert synth.rotation_angle(T, S[f"{tag}_T"]) <= 1e-4
+        assert [int(g.hasConverged()), g.getFinalNumIteration()] == S[f"{tag}_meta"].tolist()
+    H, b, e, n = g.linearize(np.asarray(G["guess"], dtype=np.float64))
+    assert n == S["lin_n"][0] and e == pytest.approx(S["lin_err"][0], rel=1e-12)
+    np.testing.assert_allclose(H, S["lin_H"], rtol=0, atol=1e-12 * np.abs(S["lin_H"]).max())
 
 
 @pytest.mark.gpu

@@ -1,4 +1,5 @@
-"""GPU: GICP_HIP against the CPU oracle (restated fast_gicp::FastGICP) through the C ABI."""
+"""GPU: GICP_HIP / SMALL_GICP_HIP against the CPU oracle (restated fast_gicp::FastGICP / small_gicp::RegistrationPCL) through
+the C ABI."""
 import numpy as np
 import pytest
 
@@ -46,3 +47,106 @@ def test_gicp_align_matches_oracle(eps):
     np.testing.assert_array_equal(aligned, orc.transform_points(Tg, src))
     assert g.getFitnessScore() == pytest.approx(o.getFitnessScore(), rel=1e-3)
     assert np.linalg.norm(Tg[:3, 3] - rel[:3, 3]) < 0.1
+
+
+@pytest.mark.parametrize("eps", [0.1, 0.01, 1e-4])
+@pytest.mark.parametrize("guess_seed", [None, 3])
+def test_small_gicp_align_matches_oracle(eps, guess_seed):
+    """SMALL_GICP_HIP (the reference's YAML default, registrations.cpp:46-54): same decisions and result as the restated
+    small_gicp optimiser; bar 1e-4 m / 1e-4 rad."""
+    from mrg_slam_amd import SmallGicpHip, synth
+    from oracle import oracle as orc
+
+    tgt, src, rel = _pair()
+    guess = np.eye(4) if guess_seed is None else synth.perturb_pose(rel, np.random.default_rng(guess_seed))
+    g = SmallGicpHip(transformation_epsilon=eps)
+    o = orc.SmallGicp(transformation_epsilon=eps, num_threads=1)
+    g.setInputTarget(tgt)
+    o.setInputTarget(tgt)
+    g.setInputSource(src)
+    o.setInputSource(src)
+    aligned = g.align(guess, want_aligned=True)
+    o.align(guess)
+    Tg, To = g.getFinalTransformation(), o.getFinalTransformation()
+    assert g.hasConverged() == o.hasConverged()
+    assert g.getFinalNumIteration() == o.getFinalNumIteration()
+    assert np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3]) <= 1e-4
+    assert _rot_angle(Tg[:3, :3], To[:3, :3]) <= 1e-4
+    np.testing.assert_allclose(g.getHessian(), o.getFinalHessian(), rtol=0, atol=1e-6 * np.abs(o.getFinalHessian()).max())
+    np.testing.assert_array_equal(aligned, orc.transform_points(Tg, src))
+    assert np.linalg.norm(Tg[:3, 3] - rel[:3, 3]) < 0.1
+
+
+@pytest.mark.parametrize("variant", ["fast", "small"])
+def test_gicp_covariances_and_linearize_match_oracle(variant):
+    """Kernel-level parity: regularised k-NN covariances and one update_correspondences + linearize pass."""
+    from mrg_slam_amd import GicpHip, SmallGicpHip, synth
+    from oracle import oracle as orc
+
+    tgt, src, rel = _pair(2500, 7)
+    g = (GicpHip if variant == "fast" else SmallGicpHip)(transformation_epsilon=0.01)
+    o = (orc.FastGicp if variant == "fast" else orc.SmallGicp)(transformation_epsilon=0.01, num_threads=1)
+    for r in (g, o):
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+    T = synth.perturb_pose(rel, np.random.default_rng(2)).astype(np.float64)
+    H, b, e, n = g.linearize(T)
+    eo, Ho, bo, no = o.linearize(T)
+    assert n == no and n > 0.5 * len(src)
+    assert e == pytest.approx(eo, rel=1e-12)
+    np.testing.assert_allclose(H, Ho, rtol=0, atol=1e-12 * np.abs(Ho).max())
+    np.testing.assert_allclose(b, bo, rtol=0, atol=1e-12 * np.abs(bo).max() + 1e-9)
+    for which in ("source", "target"):
+        np.testing.assert_allclose(g.covariances(which), o.covariances(which), rtol=0, atol=1e-12)
+
+
+def test_small_gicp_linearize_is_the_right_perturbation_of_the_left_one():
+    """The two variants linearise the same cost: H_right = Ad^T H_left Ad, b_right = Ad^T b_left with the adjoint of T
+    (rotation block first), and the error is the same number."""
+    from mrg_slam_amd import GicpHip, SmallGicpHip, synth
+
+    tgt, src, rel = _pair(2000, 4)
+    T = synth.perturb_pose(rel, np.random.default_rng(1)).astype(np.float64)
+    out = []
+    for cls in (GicpHip, SmallGicpHip):
+        g = cls(transformation_epsilon=0.01)
+        g.setInputTarget(tgt)
+        g.setInputSource(src)
+        out.append(g.linearize(T))
+    (Hl, bl, el, nl), (Hr, br, er, nr) = out
+    R, t = T[:3, :3], T[:3, 3]
+    skew = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Ad = np.block([[R, np.zeros((3, 3))], [skew @ R, R]])
+    assert nl == nr and el == er
+    np.testing.assert_allclose(Hr, Ad.T @ Hl @ Ad, rtol=0, atol=1e-9 * np.abs(Hl).max())
+    np.testing.assert_allclose(br, Ad.T @ bl, rtol=0, atol=1e-9 * np.abs(bl).max())
+
+
+def test_small_gicp_batch_equals_single_registrations():
+    from mrg_slam_amd import BatchMatcher, SmallGicpHip, synth
+    from mrg_slam_amd._lib import SMALL_GICP_HIP
+    from mrg_slam_amd.registration import default_params, result_matrix
+    from oracle import oracle as orc
+
+    tgt = small_cloud(4000, 210)
+    rng = np.random.default_rng(10)
+    prm = default_params(SMALL_GICP_HIP)
+    prm.transformation_epsilon = 0.01
+    bm = BatchMatcher(prm)
+    t = bm.add_target(tgt)
+    pairs = []
+    for k in range(4):
+        rel = synth.make_pose(rng.normal(0, 0.15, 3), synth.rot_xyz(*rng.normal(0, 0.015, 3)))
+        src = orc.transform_points(np.linalg.inv(rel), tgt[: 2500 + 300 * k])
+        guess = synth.perturb_pose(np.eye(4), rng)
+        pairs.append((src, guess))
+        bm.add_pair(t, src, guess)
+    res = bm.align(fitness_max_range=float("inf"))
+    for k, (src, guess) in enumerate(pairs):
+        reg = SmallGicpHip(transformation_epsilon=0.01)
+        reg.setInputTarget(tgt)
+        reg.setInputSource(src)
+        reg.align(guess)
+        np.testing.assert_array_equal(result_matrix(res[k]), reg.getFinalTransformation())
+        assert res[k]["converged"] == int(reg.hasConverged()) and res[k]["iterations"] == reg.getFinalNumIteration()
+        assert res[k]["fitness"] == pytest.approx(reg.getFitnessScore(), rel=1e-12)

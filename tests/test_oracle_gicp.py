@@ -1,0 +1,80 @@
+"""CPU: the oracle's two GICP formulations (oracle/gicp.h): restated fast_gicp::FastGICP (registrations.cpp:55-63) and
+restated small_gicp::RegistrationPCL (registrations.cpp:46-54, the YAML default).  No reference vectors exist for either
+(parity unpinned), so these check the properties the published algorithms imply."""
+import numpy as np
+import pytest
+
+from conftest import small_cloud
+
+
+def _pair(n=1500, seed=11):
+    from mrg_slam_amd import synth
+    from oracle import oracle as orc
+
+    tgt = small_cloud(n, seed)
+    rel = synth.make_pose([0.18, -0.12, 0.04], synth.rot_xyz(0.012, -0.007, 0.03))
+    src = orc.transform_points(np.linalg.inv(rel), tgt)
+    return tgt, src, rel
+
+
+@pytest.mark.parametrize("cls", ["FastGicp", "SmallGicp"])
+def test_recovers_the_known_motion(cls):
+    from mrg_slam_amd import synth
+    from oracle import oracle as orc
+
+    tgt, src, rel = _pair()
+    g = getattr(orc, cls)(transformation_epsilon=1e-4, num_threads=1)
+    g.setInputTarget(tgt)
+    g.setInputSource(src)
+    g.align(np.eye(4))
+    T = g.getFinalTransformation().astype(np.float64)
+    assert g.hasConverged()
+    assert np.linalg.norm(T[:3, 3] - rel[:3, 3]) < 1e-3 and synth.rotation_angle(T, rel) < 1e-3
+    # a source that is an exact rigid copy of the target: the optimum has (numerically) zero cost
+    assert g.getFitnessScore() < 1e-6
+
+
+def test_left_and_right_linearisations_are_adjoint_related():
+    """Same cost, two parametrisations of the step: H_right = Ad^T H_left Ad and b_right = Ad^T b_left with the adjoint
+    of T (rotation block first); small_gicp's error carries the factor 1/2 in the optimiser, not in the sum."""
+    from mrg_slam_amd import synth
+    from oracle import oracle as orc
+
+    tgt, src, rel = _pair()
+    T = synth.perturb_pose(rel, np.random.default_rng(5)).astype(np.float64)
+    out = []
+    for cls in (orc.FastGicp, orc.SmallGicp):
+        g = cls(transformation_epsilon=0.01, num_threads=1)
+        g.setInputTarget(tgt)
+        g.setInputSource(src)
+        out.append(g.linearize(T))
+    (el, Hl, bl, nl), (er, Hr, br, nr) = out
+    R, t = T[:3, :3], T[:3, 3]
+    skew = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Ad = np.block([[R, np.zeros((3, 3))], [skew @ R, R]])
+    assert nl == nr and el == er
+    np.testing.assert_allclose(Hr, Ad.T @ Hl @ Ad, rtol=0, atol=1e-9 * np.abs(Hl).max())
+    np.testing.assert_allclose(br, Ad.T @ bl, rtol=0, atol=1e-9 * np.abs(bl).max())
+
+
+def test_small_gicp_termination_rules():
+    """translation_eps = transformation_epsilon, rotation_eps = 2e-3: a loose epsilon stops after the first accepted
+    step, max_iterations = 1 stops unconverged, and an empty target never converges."""
+    from oracle import oracle as orc
+
+    tgt, src, _ = _pair()
+    loose = orc.SmallGicp(transformation_epsilon=10.0, rotation_epsilon=10.0, num_threads=1)
+    loose.setInputTarget(tgt)
+    loose.setInputSource(src)
+    loose.align(np.eye(4))
+    assert loose.hasConverged() and loose.getFinalNumIteration() == 0
+    one = orc.SmallGicp(transformation_epsilon=1e-9, rotation_epsilon=1e-9, maximum_iterations=1, num_threads=1)
+    one.setInputTarget(tgt)
+    one.setInputSource(src)
+    one.align(np.eye(4))
+    assert not one.hasConverged() and one.getFinalNumIteration() == 0
+    far = orc.SmallGicp(transformation_epsilon=0.01, max_correspondence_distance=1e-3, num_threads=1)
+    far.setInputTarget(tgt)
+    far.setInputSource(src + np.float32([50, 0, 0, 0]))
+    far.align(np.eye(4))  # no correspondences: H = 0, b = 0, the zero step is accepted at equal (zero) error
+    np.testing.assert_allclose(far.getFinalTransformation(), np.eye(4), atol=1e-7)
