@@ -11,6 +11,9 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "dev_float.h"
@@ -432,19 +435,24 @@ int GicpEngine::set_source(const void* d, size_t n)
     return MRGFE_OK;
 }
 
-int GicpEngine::compute_covariances(const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid)
+// k-NN covariances of one cloud on ctx's stream, through the caller's grid and neighbour buffers
+int gicp_compute_covariances(mrgfe_ctx* ctx, int k, const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid, DevBuf& knn_i, DevBuf& knn_d)
 {
     MRGFE_TRY(out.ensure(std::max<size_t>(n, 1) * 48));
     if (n == 0) return MRGFE_OK;
-    const int k = prm_.k_correspondences;
-    MRGFE_TRY(grid.build(ctx_, d_pts, n, 1.0f, NnGrid::kCrowdingKnn));
-    MRGFE_TRY(d_knn_i_.ensure(n * k * 4));
-    MRGFE_TRY(d_knn_d_.ensure(n * k * 4));
-    MRGFE_TRY(grid.knn_device(ctx_, d_pts, n, k, d_knn_i_.as<int32_t>(), d_knn_d_.as<float>()));
+    MRGFE_TRY(grid.build(ctx, d_pts, n, 1.0f, NnGrid::kCrowdingKnn));
+    MRGFE_TRY(knn_i.ensure(n * k * 4));
+    MRGFE_TRY(knn_d.ensure(n * k * 4));
+    MRGFE_TRY(grid.knn_device(ctx, d_pts, n, k, knn_i.as<int32_t>(), knn_d.as<float>()));
     const uint32_t nn = static_cast<uint32_t>(n);
-    hipLaunchKernelGGL(gicp_cov_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx_->stream, d_pts, nn, d_knn_i_.as<int32_t>(), k, out.as<double>());
+    hipLaunchKernelGGL(gicp_cov_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, d_pts, nn, knn_i.as<int32_t>(), k, out.as<double>());
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
+}
+
+int GicpEngine::compute_covariances(const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid)
+{
+    return gicp_compute_covariances(ctx_, prm_.k_correspondences, d_pts, n, out, grid, d_knn_i_, d_knn_d_);
 }
 
 int GicpEngine::prepare_target()
@@ -713,6 +721,11 @@ int GicpEngine::aligned_cloud(float* out)
 GicpBatch::~GicpBatch()
 {
     if (ctx_) (void)hipSetDevice(ctx_->device);
+    for (Lane* l : lanes_) {
+        l->grid.release(); l->knn_i.release(); l->knn_d.release();
+        mrgfe_ctx_destroy(l->ctx);
+        delete l;
+    }
     d_pairs_.release(); d_evals_.release(); d_grids_.release(); d_partials_.release();
     h_evals_.release(); h_results_.release();
     if (done_) (void)hipEventDestroy(done_);
@@ -732,12 +745,47 @@ int GicpBatch::align_all(std::vector<GicpEngine*>& engines, std::vector<GicpBatc
         MRGFE_TRY(engines[t]->prepare_target());
         h_grids[t] = engines[t]->target_grid();
     }
+    // Source covariances: one cloud is a chain of small launches and a few host round trips (bounding box, cell-size
+    // passes, sorts, k-NN, covariance) that leaves most of the chip idle, so `lanes` host threads work through the clouds
+    // side by side, each on its own stream and workspace.
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));  // the clouds were uploaded on this stream
+    {
+        int want = 4;
+        if (const char* e = std::getenv("MRGFE_GICP_LANES")) want = std::atoi(e);
+        const int n_lanes = std::max(1, std::min(std::min(want, 8), P));
+        while (static_cast<int>(lanes_.size()) < n_lanes) {
+            Lane* l = new Lane();
+            if (mrgfe_ctx_create(ctx_->device, &l->ctx) != MRGFE_OK) { delete l; return MRGFE_ERR_HIP; }
+            lanes_.push_back(l);
+        }
+        std::vector<int> status(n_lanes, MRGFE_OK);
+        std::vector<std::string> message(n_lanes);
+        std::atomic<int> next{0};
+        auto work = [&](int li) {
+            Lane& l = *lanes_[li];
+            if (l.ctx->bind() != MRGFE_OK) { status[li] = MRGFE_ERR_HIP; return; }
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= P) break;
+                GicpBatchPair& p = pairs[i];
+                const int rc = gicp_compute_covariances(l.ctx, engines[p.target]->params().k_correspondences, p.d_src, p.n, p.cov, l.grid, l.knn_i, l.knn_d);
+                if (rc != MRGFE_OK) { status[li] = rc; message[li] = mrgfe_last_error(); break; }
+            }
+            if (hipStreamSynchronize(l.ctx->stream) != hipSuccess && status[li] == MRGFE_OK) status[li] = MRGFE_ERR_HIP;
+        };
+        std::vector<std::thread> th;
+        for (int li = 1; li < n_lanes; ++li) th.emplace_back(work, li);
+        work(0);
+        for (auto& t : th) t.join();
+        MRGFE_TRY(ctx_->bind());
+        for (int li = 0; li < n_lanes; ++li)
+            if (status[li] != MRGFE_OK) { set_error("GICP batch: source covariances failed: %s", message[li].c_str()); return status[li]; }
+    }
     std::vector<GicpPairDev> h_pairs(P);
     uint32_t part = 0, max_n = 0;
     for (int i = 0; i < P; ++i) {
         GicpBatchPair& p = pairs[i];
         GicpEngine*    e = engines[p.target];
-        MRGFE_TRY(e->compute_covariances(p.d_src, p.n, p.cov, e->scratch_grid()));
         MRGFE_TRY(p.corr.ensure(std::max<size_t>(p.n, 1) * 4));
         MRGFE_TRY(p.mahal.ensure(std::max<size_t>(p.n, 1) * 72));
         GicpPairDev d;

@@ -76,6 +76,30 @@ def main():
         print(json.dumps(out))
         return
 
+    # ---- GICP loop-closure batch: 32 candidate clouds against one 130k-point keyframe -------------------------------
+    def gicp_batch(method):
+        gp = default_params(method)
+        gp.transformation_epsilon = 0.1
+        gb = BatchMatcher(gp, ctx)
+        gt = gb.add_target(scans[0])
+        for b in range(32):
+            gb.add_pair(gt, scans[1 + b % 4], synth.warm_guess(np.linalg.inv(poses[0]) @ poses[1 + b % 4], b))
+        gb.align(-1.0)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            r = gb.align(-1.0)
+        ctx.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / 2, int(np.sum(r["converged"]))
+
+    from mrg_slam_amd._lib import GICP_HIP, SMALL_GICP_HIP
+    ms_f, conv_f = gicp_batch(GICP_HIP)
+    ms_s, conv_s = gicp_batch(SMALL_GICP_HIP)
+    out["gicp_batch_32x130k"] = {"gicp_hip_ms": ms_f, "small_gicp_hip_ms": ms_s, "converged": [conv_f, conv_s]}
+    if "--gicp-batch-only" in sys.argv:
+        print(json.dumps(out))
+        return
+
     # ---- single pair latency ----------------------------------------------------------------------------------------
     reg = NdtHip(resolution=1.0, transformation_epsilon=0.1, maximum_iterations=64, ctx=ctx)
     lat = []
