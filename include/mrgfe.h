@@ -199,6 +199,19 @@ int  mrgfe_batch_add_target_device(mrgfe_batch* b, const void* d_xyzi, size_t n)
 /* returns the pair index (>= 0) or an error (< 0) */
 int  mrgfe_batch_add_pair(mrgfe_batch* b, int target_index, const float* src_xyzi, size_t n, size_t stride_bytes, const float guess[16]);
 int  mrgfe_batch_add_pair_device(mrgfe_batch* b, int target_index, const void* d_src_xyzi, size_t n, const float guess[16]);
+/* Keyframe store.  The candidates of LoopDetector::matching are old keyframes that come back call after call
+ * (loop_detector.cpp:66-100 selects them from the same pool for every new keyframe), while the reference hands their
+ * clouds to setInputSource from host memory each time (:128).  A pair added with a non-zero `cloud_key` (the keyframe id)
+ * keeps its packed cloud — and, for the GICP methods, its k-NN covariances — resident in HBM inside the batch object,
+ * across mrgfe_batch_clear: the next pair with the same key and point count uses them and `src_xyzi` may be NULL.
+ * The store is bounded (MRGFE_KEYFRAME_STORE_MB, default 16384; least recently used keyframes not referenced by the
+ * current batch are dropped first); mrgfe_batch_forget drops one key (0: all).  Results are identical to the unkeyed call. */
+int  mrgfe_batch_add_pair_keyed(mrgfe_batch* b, int target_index, uint64_t cloud_key, const float* src_xyzi, size_t n, size_t stride_bytes,
+                                const float guess[16]);
+/* 1 if the store holds that key (a keyed add with the same point count may then pass NULL), else 0; *n = its point count */
+int  mrgfe_batch_has_cloud(const mrgfe_batch* b, uint64_t cloud_key, size_t* n);
+size_t mrgfe_batch_store_bytes(const mrgfe_batch* b);
+int  mrgfe_batch_forget(mrgfe_batch* b, uint64_t cloud_key);
 int  mrgfe_batch_set_guess(mrgfe_batch* b, int pair_index, const float guess[16]);
 /* build every target grid (setInputTarget), then align every pair; fitness_max_range < 0 skips getFitnessScore */
 int  mrgfe_batch_build_targets(mrgfe_batch* b);

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
 #include "cellsort.h"
@@ -90,7 +91,41 @@ struct mrgfe_batch {
     GicpBatch*          gicp_batch = nullptr;
     std::vector<GicpBatchPair> gicp_pairs;  // per-pair device buffers, kept between align calls
     std::vector<NnGrid> fit_grids;  // getFitnessScore grids, one per target; device buffers kept between align calls
+    // keyframe store (mrgfe_batch_add_pair_keyed): packed clouds and GICP covariances by caller-chosen key, resident across clears
+    struct Keyframe {
+        DevBuf   cloud, cov;
+        uint32_t n = 0;
+        int      cov_k = 0;       // k_correspondences the covariances were computed with; 0: none yet
+        uint64_t last_epoch = 0;  // batch epoch (number of clears) of the last use
+        uint64_t last_tick = 0;
+        size_t   bytes() const { return cloud.cap + cov.cap; }
+    };
+    std::unordered_map<uint64_t, Keyframe*> store;
+    std::vector<uint64_t> pair_key;  // per pair; 0: not from the store
+    uint64_t epoch = 1, tick = 0;
+    size_t   store_cap = size_t(16384) << 20;
 };
+
+// drop least recently used keyframes that the current batch does not reference until `need` more bytes fit
+void store_make_room(mrgfe_batch* b, size_t need)
+{
+    size_t total = 0;
+    for (auto& kv : b->store) total += kv.second->bytes();
+    while (total + need > b->store_cap) {
+        uint64_t victim = 0, best = ~uint64_t(0);
+        for (auto& kv : b->store)
+            if (kv.second->last_epoch < b->epoch && kv.second->last_tick < best) { best = kv.second->last_tick; victim = kv.first; }
+        if (!victim) return;  // everything left is in use: the store grows past its cap for this batch
+        {
+            auto it = b->store.find(victim);
+            total -= it->second->bytes();
+            it->second->cloud.release();
+            it->second->cov.release();
+            delete it->second;
+            b->store.erase(it);
+        }
+    }
+}
 
 extern "C" {
 
@@ -528,6 +563,7 @@ int mrgfe_batch_create(mrgfe_ctx* ctx, const mrgfe_reg_params* params, mrgfe_bat
     b->ctx = ctx;
     b->params = *params;
     b->ndt = new NdtEngine(ctx, ndt_params_from(*params));
+    if (const char* e = std::getenv("MRGFE_KEYFRAME_STORE_MB")) b->store_cap = static_cast<size_t>(std::max(0.0, std::atof(e))) << 20;
     *out = b;
     return MRGFE_OK;
 }
@@ -542,6 +578,7 @@ void mrgfe_batch_destroy(mrgfe_batch* b)
         delete b->gicp_batch;
         for (auto* g : b->gicp) delete g;
         delete b->ndt;
+        for (auto& kv : b->store) { kv.second->cloud.release(); kv.second->cov.release(); delete kv.second; }
     }
     delete b;
 }
@@ -552,6 +589,8 @@ int mrgfe_batch_clear(mrgfe_batch* b)
     b->ndt->clear();
     for (auto* g : b->gicp) delete g;  // their cached target state belongs to the clouds just forgotten
     b->gicp.clear();
+    b->pair_key.clear();
+    ++b->epoch;  // stored keyframes stay; none is referenced by the (now empty) batch
     return MRGFE_OK;
 }
 int mrgfe_batch_add_target(mrgfe_batch* b, const float* xyzi, size_t n, size_t stride)
@@ -581,6 +620,78 @@ int mrgfe_batch_add_pair_device(mrgfe_batch* b, int target, const void* d, size_
     float g[16];
     col2row(guess, g);
     return b->ndt->add_pair_device(target, d, n, g);
+}
+int mrgfe_batch_add_pair_keyed(mrgfe_batch* b, int target, uint64_t key, const float* xyzi, size_t n, size_t stride, const float guess[16])
+{
+    if (!b || !guess) { set_error("NULL argument"); return MRGFE_ERR_INVALID; }
+    if (key == 0) return mrgfe_batch_add_pair(b, target, xyzi, n, stride, guess);
+    MRGFE_LOCK(b->ctx);
+    MRGFE_TRY(b->ctx->bind());
+    if (n > 0x7fffffffu) { set_error("cloud too large"); return MRGFE_ERR_INVALID; }
+    mrgfe_batch::Keyframe* kf = nullptr;
+    auto it = b->store.find(key);
+    if (it != b->store.end() && it->second->n == n) {
+        kf = it->second;
+    } else {
+        if (n && !xyzi) { set_error("mrgfe_batch_add_pair_keyed: key %llu is not in the store (or has another size) and no cloud was given", static_cast<unsigned long long>(key)); return MRGFE_ERR_INVALID; }
+        if (it != b->store.end()) {  // same key, different cloud: replace — unless this batch already uses the old one
+            if (it->second->last_epoch == b->epoch) { set_error("mrgfe_batch_add_pair_keyed: key %llu is already used in this batch with %u points", static_cast<unsigned long long>(key), it->second->n); return MRGFE_ERR_INVALID; }
+            it->second->cloud.release();
+            it->second->cov.release();
+            delete it->second;
+            b->store.erase(it);
+        }
+        store_make_room(b, n * 16 + (b->params.method != MRGFE_NDT_HIP ? n * 48 : 0));
+        kf = new (std::nothrow) mrgfe_batch::Keyframe();
+        if (!kf) { set_error("out of host memory"); return MRGFE_ERR_INVALID; }
+        int rc = kf->cloud.ensure(std::max<size_t>(n, 1) * 16);
+        if (rc == MRGFE_OK && n) rc = upload_cloud(b->ctx, xyzi, n, stride, kf->cloud.p);
+        if (rc != MRGFE_OK) { kf->cloud.release(); delete kf; return rc; }
+        kf->n = static_cast<uint32_t>(n);
+        b->store[key] = kf;
+    }
+    kf->last_epoch = b->epoch;
+    kf->last_tick = ++b->tick;
+    float g[16];
+    col2row(guess, g);
+    const int pair = b->ndt->add_pair_device(target, kf->cloud.p, n, g);
+    if (pair >= 0) {
+        if (b->pair_key.size() <= static_cast<size_t>(pair)) b->pair_key.resize(pair + 1, 0);
+        b->pair_key[pair] = key;
+    }
+    return pair;
+}
+int mrgfe_batch_has_cloud(const mrgfe_batch* b, uint64_t key, size_t* n)
+{
+    if (!b || key == 0) return 0;
+    MRGFE_LOCK(b->ctx);
+    auto it = b->store.find(key);
+    if (it == b->store.end()) return 0;
+    if (n) *n = it->second->n;
+    return 1;
+}
+size_t mrgfe_batch_store_bytes(const mrgfe_batch* b)
+{
+    if (!b) return 0;
+    MRGFE_LOCK(b->ctx);
+    size_t total = 0;
+    for (auto& kv : b->store) total += kv.second->bytes();
+    return total;
+}
+int mrgfe_batch_forget(mrgfe_batch* b, uint64_t key)
+{
+    if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(b->ctx);
+    MRGFE_TRY(b->ctx->bind());
+    for (auto it = b->store.begin(); it != b->store.end();) {
+        if (key != 0 && it->first != key) { ++it; continue; }
+        if (it->second->last_epoch == b->epoch && !b->pair_key.empty()) { set_error("mrgfe_batch_forget: key %llu is used by the current batch (clear it first)", static_cast<unsigned long long>(it->first)); return MRGFE_ERR_STATE; }
+        it->second->cloud.release();
+        it->second->cov.release();
+        delete it->second;
+        it = b->store.erase(it);
+    }
+    return MRGFE_OK;
 }
 int mrgfe_batch_set_guess(mrgfe_batch* b, int pair, const float guess[16])
 {
@@ -626,6 +737,13 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
             bp.target = p.target;
             bp.d_src = p.d_src;
             bp.n = p.n;
+            bp.ext_cov = nullptr;
+            bp.ext_cov_k = nullptr;
+            if (static_cast<size_t>(i) < b->pair_key.size() && b->pair_key[i]) {
+                mrgfe_batch::Keyframe* kf = b->store.at(b->pair_key[i]);
+                bp.ext_cov = &kf->cov;
+                bp.ext_cov_k = &kf->cov_k;
+            }
             std::memcpy(bp.guess, p.guess, sizeof(bp.guess));
         }
         MRGFE_TRY(b->gicp_batch->align_all(b->gicp, b->gicp_pairs));

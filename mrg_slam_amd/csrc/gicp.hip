@@ -760,16 +760,31 @@ int GicpBatch::align_all(std::vector<GicpEngine*>& engines, std::vector<GicpBatc
         }
         std::vector<int> status(n_lanes, MRGFE_OK);
         std::vector<std::string> message(n_lanes);
-        std::atomic<int> next{0};
+        // clouds to do: every pair without stored covariances; a stored cloud shared by several pairs once
+        std::vector<int> todo;
+        for (int i = 0; i < P; ++i) {
+            GicpBatchPair& p = pairs[i];
+            const int k = engines[p.target]->params().k_correspondences;
+            if (p.ext_cov) {
+                if (*p.ext_cov_k == k) continue;
+                bool dup = false;
+                for (int j : todo) dup = dup || pairs[j].ext_cov == p.ext_cov;
+                if (dup) continue;
+            }
+            todo.push_back(i);
+        }
+        std::atomic<size_t> next{0};
         auto work = [&](int li) {
             Lane& l = *lanes_[li];
             if (l.ctx->bind() != MRGFE_OK) { status[li] = MRGFE_ERR_HIP; return; }
             for (;;) {
-                const int i = next.fetch_add(1);
-                if (i >= P) break;
-                GicpBatchPair& p = pairs[i];
-                const int rc = gicp_compute_covariances(l.ctx, engines[p.target]->params().k_correspondences, p.d_src, p.n, p.cov, l.grid, l.knn_i, l.knn_d);
+                const size_t w = next.fetch_add(1);
+                if (w >= todo.size()) break;
+                GicpBatchPair& p = pairs[todo[w]];
+                const int k = engines[p.target]->params().k_correspondences;
+                const int rc = gicp_compute_covariances(l.ctx, k, p.d_src, p.n, p.ext_cov ? *p.ext_cov : p.cov, l.grid, l.knn_i, l.knn_d);
                 if (rc != MRGFE_OK) { status[li] = rc; message[li] = mrgfe_last_error(); break; }
+                if (p.ext_cov) *p.ext_cov_k = k;
             }
             if (hipStreamSynchronize(l.ctx->stream) != hipSuccess && status[li] == MRGFE_OK) status[li] = MRGFE_ERR_HIP;
         };
@@ -789,7 +804,7 @@ int GicpBatch::align_all(std::vector<GicpEngine*>& engines, std::vector<GicpBatc
         MRGFE_TRY(p.corr.ensure(std::max<size_t>(p.n, 1) * 4));
         MRGFE_TRY(p.mahal.ensure(std::max<size_t>(p.n, 1) * 72));
         GicpPairDev d;
-        d.src = p.d_src; d.tgt = e->target_points(); d.cov_src = p.cov.as<double>(); d.cov_tgt = e->target_covariances();
+        d.src = p.d_src; d.tgt = e->target_points(); d.cov_src = (p.ext_cov ? *p.ext_cov : p.cov).as<double>(); d.cov_tgt = e->target_covariances();
         d.corr = p.corr.as<int32_t>(); d.mahal = p.mahal.as<double>();
         d.n = p.n; d.part_off = part; d.target = static_cast<uint32_t>(p.target); d.pad = 0;
         part += (p.n + 255u) / 256u;

@@ -119,6 +119,9 @@ struct GicpBatchPair {
     uint32_t      n = 0;
     float         guess[16];
     DevBuf        cov, corr, mahal;
+    // keyframe store (api.cpp): covariances kept with the cloud; *ext_cov_k == k_correspondences means they are valid
+    DevBuf*       ext_cov = nullptr;
+    int*          ext_cov_k = nullptr;
     GicpLmController ctl;
 };
 class GicpBatch {

@@ -75,12 +75,14 @@ def select_best(records: np.ndarray):
     return best, best_score
 
 
-def match_candidates(matcher_factory, target_cloud, candidate_clouds, guesses, fitness_max_range=float("inf"), group=None):
+def match_candidates(matcher_factory, target_cloud, candidate_clouds, guesses, fitness_max_range=float("inf"), group=None, candidate_keys=None):
     """Distributed candidate matching for one new keyframe.
 
-    ``matcher_factory()`` returns a fresh ``BatchMatcher`` bound to this rank's GPU; ``target_cloud`` is the new keyframe's
-    cloud (registration_->setInputTarget(new_keyframe->cloud), :104), ``candidate_clouds[i]`` / ``guesses[i]`` the
-    candidates and their initial guesses (:127-133).  Returns (records ordered by candidate, best index, best score)."""
+    ``matcher_factory()`` returns a ``BatchMatcher`` bound to this rank's GPU (a fresh one, or — to profit from the keyframe
+    store — the same cleared one every call); ``target_cloud`` is the new keyframe's cloud
+    (registration_->setInputTarget(new_keyframe->cloud), :104), ``candidate_clouds[i]`` / ``guesses[i]`` the candidates and
+    their initial guesses (:127-133).  ``candidate_keys[i]`` (optional, non-zero keyframe ids) keep the candidates' clouds
+    and GICP covariances resident on the rank that matched them.  Returns (records ordered by candidate, best index, best score)."""
     import torch.distributed as dist
 
     n = len(candidate_clouds)
@@ -94,7 +96,10 @@ def match_candidates(matcher_factory, target_cloud, candidate_clouds, guesses, f
         bm = matcher_factory()
         t = bm.add_target(target_cloud)
         for i in mine:
-            bm.add_pair(t, candidate_clouds[i], guesses[i])
+            if candidate_keys is None:
+                bm.add_pair(t, candidate_clouds[i], guesses[i])
+            else:
+                bm.add_pair(t, candidate_clouds[i], guesses[i], key=int(candidate_keys[i]))
         local = bm.align(fitness_max_range)
         local["pair_id"] = mine.astype(np.int32)
     records = gather_records(local, n, group)

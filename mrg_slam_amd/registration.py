@@ -285,10 +285,31 @@ class BatchMatcher:
     def add_target_device(self, dev_ptr: int, n: int) -> int:
         return check(lib().mrgfe_batch_add_target_device(self._h, C.c_void_p(dev_ptr), n))
 
-    def add_pair(self, target: int, source, guess=None) -> int:
-        c = _cloud(source)
+    def add_pair(self, target: int, source, guess=None, key: int = 0) -> int:
+        """``key`` != 0 (the candidate's keyframe id): the cloud — and for the GICP methods its covariances — stay in the
+        batch's HBM keyframe store across ``clear()``; once ``has_cloud(key)`` a later call may pass ``source=None``."""
         g = _colmajor(np.eye(4) if guess is None else guess)
+        if key:
+            if source is None:
+                n = self.has_cloud(key)
+                if n is None:
+                    raise KeyError(f"keyframe {key} is not in the store")
+                return check(lib().mrgfe_batch_add_pair_keyed(self._h, target, key, None, n, 16, g.ctypes.data_as(_fp)))
+            c = _cloud(source)
+            return check(lib().mrgfe_batch_add_pair_keyed(self._h, target, key, c.ctypes.data_as(_fp), len(c), 16, g.ctypes.data_as(_fp)))
+        c = _cloud(source)
         return check(lib().mrgfe_batch_add_pair(self._h, target, c.ctypes.data_as(_fp), len(c), 16, g.ctypes.data_as(_fp)))
+
+    def has_cloud(self, key: int):
+        """Point count of the stored keyframe ``key``, or None."""
+        n = C.c_size_t(0)
+        return n.value if lib().mrgfe_batch_has_cloud(self._h, key, C.byref(n)) else None
+
+    def store_bytes(self) -> int:
+        return int(lib().mrgfe_batch_store_bytes(self._h))
+
+    def forget(self, key: int = 0) -> None:
+        check(lib().mrgfe_batch_forget(self._h, key))
 
     def add_pair_device(self, target: int, dev_ptr: int, n: int, guess=None) -> int:
         g = _colmajor(np.eye(4) if guess is None else guess)

@@ -96,6 +96,35 @@ def main():
     ms_f, conv_f = gicp_batch(GICP_HIP)
     ms_s, conv_s = gicp_batch(SMALL_GICP_HIP)
     out["gicp_batch_32x130k"] = {"gicp_hip_ms": ms_f, "small_gicp_hip_ms": ms_s, "converged": [conv_f, conv_s]}
+
+    # ---- one loop-detection call end to end, host clouds in: new keyframe + 32 recurring candidates -------------------
+    # (clear, add_target, add_pair x 32, align): candidates handed over as host clouds every call vs named by keyframe id
+    def lc_call(method, keyed, calls=3):
+        lp = default_params(method)
+        lp.transformation_epsilon, lp.maximum_iterations, lp.resolution, lp.nn_search_method = 0.1, 64, 1.0, SEARCH["DIRECT7"]
+        lb = BatchMatcher(lp, ctx)
+        times = []
+        for c in range(calls + 1):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            lb.clear()
+            lt = lb.add_target(scans[0])
+            for b in range(32):
+                k = 1 + b % 4
+                guess = synth.warm_guess(np.linalg.inv(poses[0]) @ poses[k], b)
+                if keyed:
+                    lb.add_pair(lt, scans[k] if lb.has_cloud(100 + b) is None else None, guess, key=100 + b)
+                else:
+                    lb.add_pair(lt, scans[k], guess)
+            lb.align(-1.0)
+            ctx.synchronize()
+            times.append(1e3 * (time.perf_counter() - t0))
+        return float(np.median(times[1:]))
+
+    out["loop_detection_call_32_candidates_ms"] = {
+        "ndt_host_clouds": lc_call(NDT_HIP, False), "ndt_keyframe_store": lc_call(NDT_HIP, True),
+        "gicp_host_clouds": lc_call(GICP_HIP, False), "gicp_keyframe_store": lc_call(GICP_HIP, True),
+        "small_gicp_host_clouds": lc_call(SMALL_GICP_HIP, False), "small_gicp_keyframe_store": lc_call(SMALL_GICP_HIP, True)}
     if "--gicp-batch-only" in sys.argv:
         print(json.dumps(out))
         return

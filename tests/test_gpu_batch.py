@@ -148,3 +148,68 @@ def test_two_contexts_from_two_threads_give_the_sequential_results():
         for k in range(6):
             np.testing.assert_array_equal(result_matrix(par[w][k]), result_matrix(seq[w][k]))
             assert par[w][k]["fitness"] == seq[w][k]["fitness"] and par[w][k]["iterations"] == seq[w][k]["iterations"]
+
+
+@pytest.mark.parametrize("method", ["NDT_HIP", "GICP_HIP", "SMALL_GICP_HIP"])
+def test_keyframe_store_gives_the_unkeyed_results(method):
+    """Candidates added by keyframe id stay resident (cloud, GICP covariances) across clear(); a later batch that names
+    them without handing the cloud over again gives exactly the results of plain add_pair calls."""
+    from mrg_slam_amd import BatchMatcher, synth
+    from mrg_slam_amd import _lib
+    from mrg_slam_amd.registration import default_params, result_matrix
+    from oracle import oracle as orc
+
+    prm = default_params(getattr(_lib, method))
+    prm.transformation_epsilon = 0.01
+    rng = np.random.default_rng(21)
+    keyframes = {k: small_cloud(2500 + 200 * k, 300 + k) for k in (1, 2, 3)}
+    plain, keyed = BatchMatcher(prm), BatchMatcher(prm)
+    assert keyed.store_bytes() == 0 and keyed.has_cloud(1) is None
+    for call in range(3):  # three "new keyframes", the same candidate pool every time
+        tgt = small_cloud(3000, 400 + call)
+        guesses = {k: synth.perturb_pose(np.eye(4), rng) for k in keyframes}
+        plain.clear()
+        keyed.clear()
+        tp, tk = plain.add_target(tgt), keyed.add_target(tgt)
+        for k, cloud in keyframes.items():
+            plain.add_pair(tp, cloud, guesses[k])
+            keyed.add_pair(tk, cloud if call == 0 else None, guesses[k], key=k)  # later calls: by id only
+        if call == 2:  # the same keyframe against the target twice in one batch
+            plain.add_pair(tp, keyframes[2], np.eye(4))
+            keyed.add_pair(tk, None, np.eye(4), key=2)
+        a, b = plain.align(float("inf")), keyed.align(float("inf"))
+        for i in range(len(a)):
+            np.testing.assert_array_equal(result_matrix(a[i]), result_matrix(b[i]))
+            assert a[i]["converged"] == b[i]["converged"] and a[i]["iterations"] == b[i]["iterations"]
+            assert a[i]["fitness"] == b[i]["fitness"]
+    per_point = 16 if method == "NDT_HIP" else 64
+    assert keyed.store_bytes() >= per_point * sum(len(c) for c in keyframes.values())
+    assert keyed.has_cloud(2) == len(keyframes[2])
+    with pytest.raises(KeyError):
+        keyed.add_pair(0, None, np.eye(4), key=99)
+    # a key can be re-bound to another cloud once no batch uses it; forgetting frees the memory
+    keyed.clear()
+    t = keyed.add_target(small_cloud(2000, 1))
+    keyed.add_pair(t, small_cloud(1000, 2), np.eye(4), key=2)
+    assert keyed.has_cloud(2) == 1000
+    with pytest.raises(RuntimeError):
+        keyed.forget(2)  # in use
+    keyed.clear()
+    keyed.forget()
+    assert keyed.store_bytes() == 0
+
+
+def test_keyframe_store_evicts_least_recently_used(monkeypatch):
+    from mrg_slam_amd import BatchMatcher
+
+    monkeypatch.setenv("MRGFE_KEYFRAME_STORE_MB", "1")  # 1 MiB: room for about three 20k-point clouds of 320 KB
+    bm = BatchMatcher()
+    for call, key in enumerate((1, 2, 3, 4, 5)):
+        bm.clear()
+        t = bm.add_target(small_cloud(1000, 5))
+        bm.add_pair(t, small_cloud(20000, 50 + key), np.eye(4), key=key)
+        if call >= 1:
+            bm.add_pair(t, None, np.eye(4), key=1)  # keyframe 1 is used every time: it must survive
+    assert bm.has_cloud(1) == 20000 and bm.has_cloud(5) == 20000
+    assert bm.has_cloud(2) is None  # oldest unused one went first
+    assert bm.store_bytes() <= (1 << 20) + 20000 * 16
