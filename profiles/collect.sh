@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o 
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --no-cpu --steps 1 --warmup 0 > gpurun_out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py --no-cpu --steps 1 --warmup 0 > gpurun_out/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_sq -o s -- python3 bench.py --no-cpu --steps 1 --warmup 0 > gpurun_out/pmc_sq.log 2>&1
-for w in gicp gicp_full prefilter fitness lc; do
+for w in gicp gicp_full prefilter fitness lc gicp_lc; do
     rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_side_$w -o s -- python3 profiles/side_workloads.py $w > gpurun_out/side_$w.log 2>&1
 done
 python3 tests/extra_measurements.py > gpurun_out/extra_$tag.json 2> gpurun_out/extra_$tag.err

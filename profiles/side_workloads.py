@@ -53,6 +53,23 @@ def main():
         for k in range(2):
             res = bm.align(float("inf"))
         print("fitness", res["fitness"][:4])
+    if which == "gicp_lc":  # loop-detection calls with GICP_HIP: one 130k-point keyframe, 32 candidates named by keyframe id
+        from mrg_slam_amd import BatchMatcher, distance_filter
+        from mrg_slam_amd._lib import GICP_HIP
+        from mrg_slam_amd.registration import default_params
+
+        more = synth.arc_trajectory(5)
+        sc = [distance_filter(synth.synth_lidar(scene, more[k], "VLP64", synth.BASE_SEED + k), 0.1, 35.0, ctx=ctx) for k in range(5)]
+        prm = default_params(GICP_HIP)
+        prm.transformation_epsilon = 0.1
+        bm = BatchMatcher(prm, ctx)
+        for call in range(3):  # the first call fills the keyframe store, the others find the candidates (and covariances) resident
+            bm.clear()
+            t = bm.add_target(sc[0])
+            for b in range(32):
+                bm.add_pair(t, sc[1 + b % 4] if bm.has_cloud(100 + b) is None else None, synth.warm_guess(np.linalg.inv(more[0]) @ more[1 + b % 4], b), key=100 + b)
+            res = bm.align(-1.0)
+        print("converged", int(res["converged"].sum()), "store MB", bm.store_bytes() >> 20)
     if which in ("all", "fitness"):
         for k in range(3):
             print("fitness", calc_fitness_score(ft, fs, rel, 2.0, ctx=ctx))

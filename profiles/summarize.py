@@ -104,7 +104,7 @@ def main():
         json.dump(json.load(open(extra)), open(os.path.join(ROOT, "profiles", f"{tag}_extra_measurements.json"), "w"), indent=1)
     # kernel stats of the non-headline paths (profiles/side_workloads.py): GICP (33k / 130k points), prefilter chain,
     # calc_fitness_score, loop-closure batch with getFitnessScore
-    for w in ("gicp", "gicp_full", "prefilter", "fitness", "lc"):
+    for w in ("gicp", "gicp_full", "prefilter", "fitness", "lc", "gicp_lc"):
         side = os.path.join(OUT, f"prof_side_{w}", "s_kernel_stats.csv")
         if not os.path.exists(side):
             continue
