@@ -129,3 +129,52 @@ def test_nearest_neighbour_and_fitness_exact():
         exp = orc.calc_fitness_score(t, q, rel, max_range)
         assert got == pytest.approx(exp, rel=1e-12)
     assert calc_fitness_score(t, np.zeros((0, 4), np.float32), rel) == np.finfo(np.float64).max
+
+
+def _adversarial_target(rng, kind):
+    if kind == "clusters":  # dense blobs metres apart: most of the bounding box is empty, far queries cross many empty bricks
+        centres = rng.uniform(-40, 40, (12, 3)) * [1, 1, 0.1]
+        pts = np.concatenate([c + rng.normal(0, 0.15, (3000, 3)) for c in centres])
+    elif kind == "plane_and_specks":  # one dense sheet plus isolated points far above it
+        sheet = np.c_[rng.uniform(-30, 30, (40000, 2)), rng.normal(0, 0.01, 40000)]
+        specks = rng.uniform(-30, 30, (40, 3)) + [0, 0, 45]
+        pts = np.concatenate([sheet, specks])
+    elif kind == "line":  # degenerate extent along two axes
+        pts = np.c_[rng.uniform(-50, 50, 20000), np.zeros(20000), np.zeros(20000)]
+    elif kind == "duplicates":  # every point four times: ties must resolve to the lowest index
+        base = rng.uniform(-10, 10, (2500, 3))
+        pts = np.concatenate([base, base, base, base])
+    else:  # "tiny"
+        pts = rng.uniform(-1, 1, (3, 3))
+    out = np.zeros((len(pts), 4), np.float32)
+    out[:, :3] = pts
+    return out
+
+
+@pytest.mark.parametrize("kind", ["clusters", "plane_and_specks", "line", "duplicates", "tiny"])
+def test_nearest_neighbour_exact_on_adversarial_clouds(kind):
+    """The occupancy-pyramid search is exhaustive: indices and squared distances equal the brute-force scan (ties to the
+    lowest index) for queries next to, between, far from and outside the points, and the bounded fitness sums agree."""
+    from mrg_slam_amd import NdtHip, calc_fitness_score
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng({"clusters": 1, "plane_and_specks": 2, "line": 3, "duplicates": 4, "tiny": 5}[kind])
+    t = _adversarial_target(rng, kind)
+    lo, hi = t[:, :3].min(0), t[:, :3].max(0)
+    q = np.zeros((4000, 4), np.float32)
+    q[:1000, :3] = t[rng.integers(0, len(t), 1000), :3] + rng.normal(0, 0.02, (1000, 3))      # next to points
+    q[1000:2500, :3] = rng.uniform(lo - 1, hi + 1, (1500, 3))                                  # anywhere in the box
+    q[2500:3500, :3] = rng.uniform(lo - 60, hi + 60, (1000, 3))                                # mostly outside
+    q[3500:3990, :3] = t[rng.integers(0, len(t), 490), :3]                                     # exactly on points
+    q[3990:, :3] = [[1e4, 0, 0], [0, -1e4, 0], [0, 0, 1e4], [1e4, 1e4, 1e4], [-3e3, 2e3, 5e2], [np.nan, 0, 0], [0, np.inf, 0], [7, 7, 7], [0, 0, 0], [-0.0, 0.0, -0.0]]
+    reg = NdtHip()
+    reg.setInputTarget(t)
+    idx, sqd = reg.nearestKSearch1(q)
+    bi, bd = orc.nn1_brute(t, q)
+    finite = np.isfinite(q[:, :3]).all(1)
+    np.testing.assert_array_equal(sqd[finite], bd[finite])
+    np.testing.assert_array_equal(idx[finite], bi[finite])
+    assert (idx[~finite] == -1).all()
+    qf = q[finite]
+    for max_range in (float("inf"), 25.0, 1.0, 0.01):
+        assert calc_fitness_score(t, qf, np.eye(4), max_range) == pytest.approx(orc.calc_fitness_score(t, qf, np.eye(4), max_range), rel=1e-12)
