@@ -124,6 +124,11 @@ int mrgfe_ndt_leaves(mrgfe_reg* reg, int32_t* keys, int32_t* nr_points, double* 
 /* mean number of valid neighbour voxels per source point over the evaluations of the last align (k-bar of SURVEY §8d) */
 double mrgfe_ndt_mean_neighbours(const mrgfe_reg* reg);
 
+/* k nearest neighbours of every query among the points of `cloud` (pcl::search::KdTree::nearestKSearch(pt, k, ...), the
+ * search behind fast_gicp's covariances and StatisticalOutlierRemoval): idx / sqd are [nq][k], ascending by (squared
+ * distance, index); entries beyond the cloud's size are -1 / -1.  1 <= k <= 64.  Non-finite queries get no neighbours. */
+int mrgfe_knn(mrgfe_ctx* ctx, const float* cloud_xyzi, size_t n, const float* query_xyzi, size_t nq, size_t stride_bytes, int k, int32_t* idx, float* sqd);
+
 /* ---- GICP internals exposed for kernel-level parity tests ------------------------------------------------------------ */
 /* update_correspondences + linearize at the pose T (column-major double 4x4, T_target_source): H (row-major 6x6,
  * rotation block first), b, the sum of r^T M r over the correspondences (the variants scale it themselves) and their

@@ -90,6 +90,7 @@ SIGNATURES = {
     "mrgfe_reg_trans_probability": (C.c_double, [_vp]),
     "mrgfe_reg_hessian": (C.c_int, [_vp, _dp]),
     "mrgfe_ndt_evaluate": (C.c_int, [_vp, _fp, _dp, C.c_int, _dp, _dp, _dp]),
+    "mrgfe_knn": (C.c_int, [_vp, _fp, C.c_size_t, _fp, C.c_size_t, C.c_size_t, C.c_int, _ip, _fp]),
     "mrgfe_gicp_linearize": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _ip]),
     "mrgfe_gicp_covariances": (C.c_int, [_vp, C.c_int, _dp]),
     "mrgfe_ndt_num_leaves": (C.c_int, [_vp]),

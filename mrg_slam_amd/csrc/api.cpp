@@ -353,6 +353,33 @@ int mrgfe_ndt_evaluate(mrgfe_reg* reg, const float T[16], const double p[6], int
     return e.evaluate(0, Tr, p, mode, score, grad, hess);
 }
 
+int mrgfe_knn(mrgfe_ctx* ctx, const float* cloud, size_t n, const float* query, size_t nq, size_t stride, int k, int32_t* idx, float* sqd)
+{
+    if (!ctx || (n && !cloud) || (nq && (!query || !idx || !sqd))) { set_error("mrgfe_knn: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (k < 1 || k > 64) { set_error("mrgfe_knn: k must be in [1, 64]"); return MRGFE_ERR_INVALID; }
+    if (nq == 0) return MRGFE_OK;
+    MRGFE_LOCK(ctx);
+    MRGFE_TRY(ctx->bind());
+    DevBuf dc, dq, di, dd;
+    NnGrid grid;
+    int rc = dc.ensure(std::max<size_t>(n, 1) * 16);
+    if (rc == MRGFE_OK) rc = dq.ensure(nq * 16);
+    if (rc == MRGFE_OK) rc = di.ensure(nq * k * 4);
+    if (rc == MRGFE_OK) rc = dd.ensure(nq * k * 4);
+    if (rc == MRGFE_OK && n) rc = upload_cloud(ctx, cloud, n, stride, dc.p);
+    if (rc == MRGFE_OK) rc = upload_cloud(ctx, query, nq, stride, dq.p);
+    if (rc == MRGFE_OK) rc = grid.build(ctx, dc.as<float4>(), n, 1.0f, NnGrid::kCrowdingKnn);
+    if (rc == MRGFE_OK) rc = grid.knn_device(ctx, dq.as<float4>(), nq, k, di.as<int32_t>(), dd.as<float>());
+    if (rc == MRGFE_OK && (hipMemcpyAsync(idx, di.p, nq * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                           hipMemcpyAsync(sqd, dd.p, nq * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+        set_error("mrgfe_knn: device to host copy failed");
+        rc = MRGFE_ERR_HIP;
+    }
+    grid.release();
+    dc.release(); dq.release(); di.release(); dd.release();
+    return rc;
+}
+
 int mrgfe_gicp_linearize(mrgfe_reg* reg, const double T[16], double H[36], double b[6], double* sum_errors, int* n_correspondences)
 {
     if (!reg || !reg->gicp || !T || !H || !b || !sum_errors || !n_correspondences) { set_error("mrgfe_gicp_linearize: needs a GICP registration and non-NULL arguments"); return MRGFE_ERR_INVALID; }

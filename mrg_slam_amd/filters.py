@@ -120,6 +120,16 @@ def calc_fitness_score(cloud1, cloud2, relpose, max_range=float("inf"), ctx: Con
     return out.value
 
 
+def knn(cloud, queries, k: int, ctx: Context | None = None):
+    """pcl::search::KdTree::nearestKSearch(pt, k) for a cloud of queries: (indices [nq, k], squared distances [nq, k]),
+    ascending by (distance, index), -1 where the cloud has fewer than k points."""
+    ctx = ctx or default_context()
+    c, q = _cloud(cloud), _cloud(queries)
+    idx, sqd = np.empty((len(q), k), dtype=np.int32), np.empty((len(q), k), dtype=np.float32)
+    check(lib().mrgfe_knn(ctx._h, c.ctypes.data_as(_fp), len(c), q.ctypes.data_as(_fp), len(q), 16, k, idx.ctypes.data_as(C.POINTER(C.c_int32)), sqd.ctypes.data_as(_fp)))
+    return idx, sqd
+
+
 def prefilter(cloud, params: dict | None = None, ctx: Context | None = None) -> np.ndarray:
     """The chain of PrefilteringComponent::cloud_callback (:149-151) with the reference's parameter names and YAML
     defaults (config/mrg_slam.yaml:41-64): distance_filter -> downsample -> outlier_removal."""

@@ -178,3 +178,29 @@ def test_nearest_neighbour_exact_on_adversarial_clouds(kind):
     qf = q[finite]
     for max_range in (float("inf"), 25.0, 1.0, 0.01):
         assert calc_fitness_score(t, qf, np.eye(4), max_range) == pytest.approx(orc.calc_fitness_score(t, qf, np.eye(4), max_range), rel=1e-12)
+
+
+@pytest.mark.parametrize("kind,k", [("clusters", 20), ("plane_and_specks", 20), ("line", 7), ("duplicates", 30), ("tiny", 5)])
+def test_knn_exact_on_adversarial_clouds(kind, k):
+    """nearestKSearch(k) (GICP covariances, StatisticalOutlierRemoval): equal to a full sort of all squared distances by
+    (distance, index), also for queries in empty regions (level climbing) and for clouds smaller than k."""
+    from mrg_slam_amd import knn
+
+    rng = np.random.default_rng({"clusters": 11, "plane_and_specks": 12, "line": 13, "duplicates": 14, "tiny": 15}[kind])
+    t = _adversarial_target(rng, kind)
+    lo, hi = t[:, :3].min(0), t[:, :3].max(0)
+    q = np.zeros((600, 4), np.float32)
+    q[:300, :3] = t[rng.integers(0, len(t), 300), :3]                # the cloud's own points (self k-NN)
+    q[300:500, :3] = rng.uniform(lo - 1, hi + 1, (200, 3))
+    q[500:, :3] = rng.uniform(lo - 40, hi + 40, (100, 3))
+    idx, sqd = knn(t, q, k)
+    tx, ty, tz = (t[:, a].astype(np.float32) for a in range(3))
+    for i in range(len(q)):
+        # the library's float expression: ((dx*dx + dy*dy) + dz*dz) in float32
+        dx, dy, dz = tx - q[i, 0], ty - q[i, 1], tz - q[i, 2]
+        d = (dx * dx + dy * dy) + dz * dz
+        order = np.lexsort((np.arange(len(t)), d))[:k]
+        m = len(order)
+        np.testing.assert_array_equal(idx[i, :m], order.astype(np.int32), err_msg=f"query {i}")
+        np.testing.assert_array_equal(sqd[i, :m], d[order])
+        assert (idx[i, m:] == -1).all()
