@@ -92,6 +92,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if os.environ.get("BENCH_DIST_BACKEND", "nccl") != "nccl":
+        local_rank %= torch.cuda.device_count()  # test hook only: gloo ranks may share a GPU (one rank per GPU otherwise)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
