@@ -42,13 +42,13 @@ __device__ __forceinline__ double nn_face_margin(const NnGridDev& g, const int c
 // belongs to the ring; `stop(lower_bound_sq)` is asked before each ring r >= 1 with a lower bound on the squared
 // distance of everything not yet visited, ((r-1)*cell + margin)^2 shrunk by 1e-5 against float rounding.
 template <class Range, class Stop>
-__device__ __forceinline__ void nn_walk_ranges(const NnGridDev& g, const int c[3], double margin, int max_rings, Range&& range, Stop&& stop)
+__device__ __forceinline__ void nn_walk_ranges(const NnGridDev& g, const int c[3], double margin, int max_rings, Range&& range, Stop&& stop, int first_ring = 0)
 {
     int rmax = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) rmax = max(rmax, max(c[a], g.dim[a] - 1 - c[a]));
     if (max_rings >= 0) rmax = min(rmax, max_rings);
-    for (int r = 0; r <= rmax; ++r) {
+    for (int r = first_ring; r <= rmax; ++r) {
         if (r >= 1) {
             const double b = static_cast<double>(r - 1) * static_cast<double>(g.cell) + margin;
             if (stop(b * b * (1.0 - 1e-5))) break;

@@ -568,6 +568,42 @@ int NnGrid::radius_count_flags(mrgfe_ctx* ctx, const float4* d_q, size_t n, doub
 // of a level and then starts over on the next coarser one (sparse surroundings: the k-th neighbour is many fine cells
 // away); candidates it meets again there are recognised in the list by their (distance, index) and skipped.
 constexpr int kKnnRings = 2;
+constexpr int kKnnSortMin = 12;  // candidates of one 64-wide step that beat the k-th entry: from here on sort + merge beats one-by-one insertion
+
+// (distance, index) order of the neighbour lists
+__device__ __forceinline__ bool knn_less(float ad, int32_t ai, float bd, int32_t bi) { return ad < bd || (ad == bd && ai < bi); }
+
+// compare-exchange with the lane `stride` away; `up`: this pair ends ascending from the lower lane
+__device__ __forceinline__ void knn_cmpx(float& d, int32_t& i, int stride, bool up)
+{
+    const float   od = __shfl_xor(d, stride);
+    const int32_t oi = __shfl_xor(i, stride);
+    const bool    lower = (lane_id() & stride) == 0;
+    const bool    mine_less = knn_less(d, i, od, oi);
+    // the lower lane of an ascending pair keeps the smaller element, its partner the larger; reversed when descending
+    const bool keep = (lower == up) ? mine_less : !mine_less;
+    if (!keep) { d = od; i = oi; }
+}
+
+// The k smallest of (sorted list in td/ti, lanes >= its length hold (inf, max)) and (64 unsorted candidates in d/ci, the
+// ones that do not count set to (inf, max)), sorted ascending over the lanes again.  Bitonic sort of the candidates
+// (21 compare-exchange stages), elementwise minimum with the reversed list (a bitonic sequence holding the 64 smallest),
+// bitonic merge (6 stages).
+__device__ __forceinline__ void knn_sort_merge(float& td, int32_t& ti, float d, int32_t ci)
+{
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+        const bool up = (lane_id() & size) == 0 || size == 64;
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) knn_cmpx(d, ci, stride, up);
+    }
+    const float   rd = __shfl(d, 63 - lane_id());
+    const int32_t ri = __shfl(ci, 63 - lane_id());
+    if (knn_less(rd, ri, td, ti)) { td = rd; ti = ri; }
+#pragma unroll
+    for (int stride = 32; stride > 0; stride >>= 1) knn_cmpx(td, ti, stride, true);
+}
+
 __global__ __launch_bounds__(256) void nn_knn_kernel(NnGrid2Dev g, const float4* __restrict__ q, uint32_t n, int k, int32_t* __restrict__ idx, float* __restrict__ sqd)
 {
     const uint32_t i = (blockIdx.x * 256u + threadIdx.x) >> 6;
@@ -591,43 +627,83 @@ __global__ __launch_bounds__(256) void nn_knn_kernel(NnGrid2Dev g, const float4*
             for (int a = 0; a < 3; ++a) rmax = max(rmax, max(c[a], lv.dim[a] - 1 - c[a]));
             const int last_ring = l + 1 < g.n_levels ? min(rmax, kKnnRings) : rmax;
             done = true;  // unless the walk below runs out of rings on this level
-            nn_walk_ranges(
-                lv, c, nn_face_margin(lv, c, p.x, p.y, p.z), last_ring,
-                [&](uint32_t b, uint32_t e) {
-                    for (uint32_t base = b; base < e; base += 64u) {
-                        const uint32_t kk = base + lane;
-                        const bool     valid = kk < e;
-                        float          d = INFINITY;
-                        int32_t        ci = 0x7fffffff;
-                        if (valid) {
-                            const float4 cand = lv.sorted[kk];
-                            d = sqdist3f(cand.x, cand.y, cand.z, p.x, p.y, p.z);
-                            ci = __float_as_int(cand.w);
-                        }
-                        uint64_t m = __ballot(valid && (d < kth_d || (d == kth_d && ci < kth_i)));
-                        while (m) {
-                            const int src = __ffsll(static_cast<unsigned long long>(m)) - 1;
-                            m &= m - 1;
-                            const float   cd = __shfl(d, src);
-                            const int32_t cci = __shfl(ci, src);
-                            if (!(cd < kth_d || (cd == kth_d && cci < kth_i))) continue;  // the k-th entry moved since the ballot
-                            if (again && __ballot(td == cd && ti == cci)) continue;       // met on a finer level already
-                            const bool    mine_less = td < cd || (td == cd && ti < cci);
-                            const int     pos = __popcll(__ballot(mine_less));  // sorted list: the lanes below pos hold the smaller entries
-                            const float   up_d = __shfl_up(td, 1);
-                            const int32_t up_i = __shfl_up(ti, 1);
-                            if (lane == pos) { td = cd; ti = cci; }
-                            else if (lane > pos) { td = up_d; ti = up_i; }
-                            if (lane >= k) { td = INFINITY; ti = 0x7fffffff; }
-                            if (cnt < k) ++cnt;
-                            if (cnt == k) { kth_d = __shfl(td, k - 1); kth_i = __shfl(ti, k - 1); }
-                        }
+            // one 64-wide step: lane candidates (valid, position kk in lv.sorted) against the list
+            auto step = [&](bool valid, const float4& cand) {
+                float   d = INFINITY;
+                int32_t ci = 0x7fffffff;
+                if (valid) {
+                    d = sqdist3f(cand.x, cand.y, cand.z, p.x, p.y, p.z);
+                    ci = __float_as_int(cand.w);
+                }
+                const bool beats = valid && (d < kth_d || (d == kth_d && ci < kth_i));
+                uint64_t   m = __ballot(beats);
+                if (!again && __popcll(m) >= kKnnSortMin) {  // many at once (the first steps of a query): sort + merge
+                    knn_sort_merge(td, ti, beats ? d : INFINITY, beats ? ci : 0x7fffffff);
+                    if (lane >= k) { td = INFINITY; ti = 0x7fffffff; }
+                    cnt = min(k, cnt + static_cast<int>(__popcll(m)));
+                    if (cnt == k) { kth_d = __shfl(td, k - 1); kth_i = __shfl(ti, k - 1); }
+                    m = 0;
+                }
+                while (m) {
+                    const int src = __ffsll(static_cast<unsigned long long>(m)) - 1;
+                    m &= m - 1;
+                    const float   cd = __shfl(d, src);
+                    const int32_t cci = __shfl(ci, src);
+                    if (!(cd < kth_d || (cd == kth_d && cci < kth_i))) continue;  // the k-th entry moved since the ballot
+                    if (again && __ballot(td == cd && ti == cci)) continue;       // met on a finer level already
+                    const bool    mine_less = td < cd || (td == cd && ti < cci);
+                    const int     pos = __popcll(__ballot(mine_less));  // sorted list: the lanes below pos hold the smaller entries
+                    const float   up_d = __shfl_up(td, 1);
+                    const int32_t up_i = __shfl_up(ti, 1);
+                    if (lane == pos) { td = cd; ti = cci; }
+                    else if (lane > pos) { td = up_d; ti = up_i; }
+                    if (lane >= k) { td = INFINITY; ti = 0x7fffffff; }
+                    if (cnt < k) ++cnt;
+                    if (cnt == k) { kth_d = __shfl(td, k - 1); kth_i = __shfl(ti, k - 1); }
+                }
+            };
+            const double margin = nn_face_margin(lv, c, p.x, p.y, p.z);
+            int          first_ring = 0;
+            if (last_ring >= 1) {
+                // rings 0 and 1 together: the nine x-rows of the 3x3x3 block.  Lanes 0..8 fetch the bounds of one row each
+                // (one round trip instead of nine dependent ones), the rows are then consumed as ONE list, 64 candidates
+                // per step whatever the row lengths, nearest rows first.
+                const int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};  // row j: dz = j / 3 - 1, dy = j % 3 - 1
+                uint32_t  rb = 0, rl = 0;
+                if (lane < 9) {
+                    const int j = order[lane], zz = c[2] + j / 3 - 1, yy = c[1] + j % 3 - 1;
+                    if (zz >= 0 && zz < lv.dim[2] && yy >= 0 && yy < lv.dim[1]) {
+                        const uint32_t row = (static_cast<uint32_t>(zz) * lv.dim[1] + yy) * lv.dim[0];
+                        rb = lv.cell_start[row + max(c[0] - 1, 0)];
+                        rl = lv.cell_start[row + min(c[0] + 1, lv.dim[0] - 1) + 1] - rb;
                     }
+                }
+                uint32_t off[10], beg[9];
+                off[0] = 0;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    beg[j] = __shfl(rb, j);
+                    off[j + 1] = off[j] + __shfl(rl, j);
+                }
+                for (uint32_t base = 0; base < off[9]; base += 64u) {
+                    const uint32_t v = base + lane;
+                    uint32_t       kk = 0;
+#pragma unroll
+                    for (int j = 0; j < 9; ++j)
+                        if (v >= off[j] && v < off[j + 1]) kk = beg[j] + (v - off[j]);
+                    step(v < off[9], v < off[9] ? lv.sorted[kk] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                }
+                first_ring = 2;
+            }
+            nn_walk_ranges(
+                lv, c, margin, last_ring,
+                [&](uint32_t b, uint32_t e) {
+                    for (uint32_t base = b; base < e; base += 64u) step(base + lane < e, base + lane < e ? lv.sorted[base + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                 },
-                [&](double bound_sq) { return cnt == k && static_cast<double>(kth_d) < bound_sq; });
+                [&](double bound_sq) { return cnt == k && static_cast<double>(kth_d) < bound_sq; }, first_ring);
             // conclusive iff everything beyond the walked rings is farther than the k-th entry (or the level is exhausted)
             if (last_ring < rmax) {
-                const double bnd = static_cast<double>(last_ring) * static_cast<double>(lv.cell) + nn_face_margin(lv, c, p.x, p.y, p.z);
+                const double bnd = static_cast<double>(last_ring) * static_cast<double>(lv.cell) + margin;
                 done = cnt == k && static_cast<double>(kth_d) < bnd * bnd * (1.0 - 1e-5);
             }
         }
