@@ -139,6 +139,26 @@ int mrgfe_gicp_covariances(mrgfe_reg* reg, int which, double* cov9_per_point);
 
 /* ---- prefilter chain (apps/prefiltering_component.cpp:149-151). Outputs: caller-allocated capacity-n packed float4
  *      buffers + count.  Order-preserving where the reference is. ------------------------------------------------- */
+/* The whole chain of PrefilteringComponent::cloud_callback (:149-151: distance_filter -> downsample -> outlier_removal) in
+ * one call: the cloud goes up once, stays in HBM between the three passes, and comes down once.  Same output as the three
+ * calls below one after the other.  Parameter names / YAML defaults: config/mrg_slam.yaml:41-64
+ * (prefiltering_component.cpp:92-112 declares them). */
+typedef struct mrgfe_prefilter_params {
+    int    enable_distance_filter;            /* 1                                     */
+    double distance_near_thresh;              /* 0.1                                   */
+    double distance_far_thresh;               /* 35.0                                  */
+    int    downsample_method;                 /* 0 NONE, 1 VOXELGRID (APPROX_VOXELGRID is order dependent and not offered) */
+    double downsample_resolution;             /* 0.1                                   */
+    int    downsample_min_points_per_voxel;   /* 1                                     */
+    int    outlier_removal_method;            /* 0 NONE, 1 RADIUS, 2 STATISTICAL       */
+    double radius_radius;                     /* 0.5                                   */
+    int    radius_min_neighbors;              /* 2                                     */
+    int    statistical_mean_k;                /* 30                                    */
+    double statistical_stddev;                /* 1.2                                   */
+} mrgfe_prefilter_params;
+void mrgfe_prefilter_default_params(mrgfe_prefilter_params* out);
+int  mrgfe_prefilter(mrgfe_ctx* ctx, const mrgfe_prefilter_params* params, const float* xyzi, size_t n, size_t stride_bytes, float* out_xyzi, size_t* out_n);
+
 /* replaces PrefilteringComponent::distance_filter (:206-229): keep iff near < |p| < far */
 int mrgfe_distance_filter(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, double near_thresh, double far_thresh,
                           float* out_xyzi, size_t* out_n);

@@ -26,6 +26,14 @@ class MrgfeError(RuntimeError):
         self.status = status
 
 
+class PrefilterParams(C.Structure):
+    """struct mrgfe_prefilter_params (the prefiltering_component ROS parameters, config/mrg_slam.yaml:41-64)."""
+
+    _fields_ = [("enable_distance_filter", C.c_int), ("distance_near_thresh", C.c_double), ("distance_far_thresh", C.c_double), ("downsample_method", C.c_int),
+                ("downsample_resolution", C.c_double), ("downsample_min_points_per_voxel", C.c_int), ("outlier_removal_method", C.c_int), ("radius_radius", C.c_double),
+                ("radius_min_neighbors", C.c_int), ("statistical_mean_k", C.c_int), ("statistical_stddev", C.c_double)]
+
+
 class RegParams(C.Structure):
     """struct mrgfe_reg_params (mirrors the reg_* ROS parameters of registrations.cpp:34-43)."""
 
@@ -90,6 +98,8 @@ SIGNATURES = {
     "mrgfe_reg_trans_probability": (C.c_double, [_vp]),
     "mrgfe_reg_hessian": (C.c_int, [_vp, _dp]),
     "mrgfe_ndt_evaluate": (C.c_int, [_vp, _fp, _dp, C.c_int, _dp, _dp, _dp]),
+    "mrgfe_prefilter_default_params": (None, [C.POINTER(PrefilterParams)]),
+    "mrgfe_prefilter": (C.c_int, [_vp, C.POINTER(PrefilterParams), _fp, C.c_size_t, C.c_size_t, _fp, C.POINTER(C.c_size_t)]),
     "mrgfe_knn": (C.c_int, [_vp, _fp, C.c_size_t, _fp, C.c_size_t, C.c_size_t, C.c_int, _ip, _fp]),
     "mrgfe_gicp_linearize": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _ip]),
     "mrgfe_gicp_covariances": (C.c_int, [_vp, C.c_int, _dp]),

@@ -464,6 +464,43 @@ int mrgfe_statistical_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_
     MRGFE_TRY(ctx->bind());
     return filter_statistical_outlier(ctx, xyzi, n, stride, mean_k, stddev_mul, out, out_n);
 }
+void mrgfe_prefilter_default_params(mrgfe_prefilter_params* p)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->enable_distance_filter = 1;           // config/mrg_slam.yaml:62-64
+    p->distance_near_thresh = 0.1;
+    p->distance_far_thresh = 35.0;
+    p->downsample_method = 1;                // :48-50
+    p->downsample_resolution = 0.1;
+    p->downsample_min_points_per_voxel = 1;
+    p->outlier_removal_method = 1;           // :53-59
+    p->radius_radius = 0.5;
+    p->radius_min_neighbors = 2;
+    p->statistical_mean_k = 30;
+    p->statistical_stddev = 1.2;
+}
+int mrgfe_prefilter(mrgfe_ctx* ctx, const mrgfe_prefilter_params* p, const float* xyzi, size_t n, size_t stride, float* out, size_t* out_n)
+{
+    if (!ctx || !p || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_prefilter: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (p->downsample_method < 0 || p->downsample_method > 1 || p->outlier_removal_method < 0 || p->outlier_removal_method > 2) { set_error("mrgfe_prefilter: unknown method"); return MRGFE_ERR_INVALID; }
+    if (p->downsample_method == 1 && !(p->downsample_resolution > 0)) { set_error("mrgfe_prefilter: downsample_resolution must be > 0"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);
+    MRGFE_TRY(ctx->bind());
+    PrefilterChain ch;
+    ch.distance = p->enable_distance_filter != 0;
+    ch.near_t = p->distance_near_thresh;
+    ch.far_t = p->distance_far_thresh;
+    ch.voxelgrid = p->downsample_method == 1;
+    ch.leaf = static_cast<float>(p->downsample_resolution);
+    ch.min_pts = p->downsample_min_points_per_voxel;
+    ch.outlier = p->outlier_removal_method;
+    ch.radius = p->radius_radius;
+    ch.radius_min_neighbors = p->radius_min_neighbors;
+    ch.mean_k = p->statistical_mean_k;
+    ch.stddev_mul = p->statistical_stddev;
+    return filter_chain(ctx, ch, xyzi, n, stride, out, out_n);
+}
 int mrgfe_calc_fitness_score(mrgfe_ctx* ctx, const float* cloud1, size_t n1, const float* cloud2, size_t n2, size_t stride, const double relpose[16], double max_range, double* out)
 {
     if (!ctx || !out || !relpose || (n1 && !cloud1) || (n2 && !cloud2)) { set_error("mrgfe_calc_fitness_score: NULL argument"); return MRGFE_ERR_INVALID; }

@@ -14,6 +14,21 @@ int filter_statistical_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t
 // returns the kept count.  Uses ctx scratch slots 0, 4 and 8.
 int compact_by_flags(mrgfe_ctx* ctx, const float4* d_in, uint32_t n, uint32_t* d_flags, float4* d_out, uint32_t* h_total);
 
+struct PrefilterChain {
+    bool   distance = true;
+    double near_t = 0.1, far_t = 35.0;
+    bool   voxelgrid = true;
+    float  leaf = 0.1f;
+    int    min_pts = 1;
+    int    outlier = 1;  // 0 none, 1 radius, 2 statistical
+    double radius = 0.5;
+    int    radius_min_neighbors = 2;
+    int    mean_k = 30;
+    double stddev_mul = 1.2;
+};
+// the three passes back to back on the device (one upload, one download)
+int filter_chain(mrgfe_ctx* ctx, const PrefilterChain& chain, const float* xyzi, size_t n, size_t stride, float* out, size_t* out_n);
+
 int filter_distance(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double near_t, double far_t, float* out, size_t* out_n);
 int filter_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, float leaf, int min_pts, float* out, size_t* out_n, int* overflow);
 int filter_radius_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double radius, int min_neighbors, float* out, size_t* out_n);

@@ -294,6 +294,33 @@ static int host_wrap(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride,
     return rc;
 }
 
+int filter_chain(mrgfe_ctx* ctx, const PrefilterChain& ch, const float* xyzi, size_t n, size_t stride, float* out, size_t* out_n)
+{
+    *out_n = 0;
+    if (n == 0) return MRGFE_OK;
+    DevBuf a, b;  // ping-pong
+    int rc = a.ensure(n * 16);
+    if (rc == MRGFE_OK) rc = b.ensure(n * 16);
+    if (rc == MRGFE_OK) rc = upload_cloud(ctx, xyzi, n, stride, a.p);
+    float4 *cur = a.as<float4>(), *nxt = b.as<float4>();
+    size_t  m = n;
+    auto pass = [&](auto&& f) {
+        if (rc != MRGFE_OK || m == 0) return;
+        size_t k = 0;
+        rc = f(cur, m, nxt, &k);
+        if (rc == MRGFE_OK) { std::swap(cur, nxt); m = k; }
+    };
+    if (ch.distance) pass([&](const float4* i, size_t ni, float4* o, size_t* k) { return filter_distance_device(ctx, i, ni, ch.near_t, ch.far_t, o, k); });
+    if (ch.voxelgrid) pass([&](const float4* i, size_t ni, float4* o, size_t* k) { int overflow = 0; return filter_voxelgrid_device(ctx, i, ni, ch.leaf, ch.min_pts, o, k, &overflow); });
+    if (ch.outlier == 1) pass([&](const float4* i, size_t ni, float4* o, size_t* k) { return filter_radius_outlier_device(ctx, i, ni, ch.radius, ch.radius_min_neighbors, o, k); });
+    if (ch.outlier == 2) pass([&](const float4* i, size_t ni, float4* o, size_t* k) { return filter_statistical_outlier_device(ctx, i, ni, ch.mean_k, ch.stddev_mul, o, k); });
+    if (rc == MRGFE_OK) rc = download(ctx, cur, m, out);
+    if (rc == MRGFE_OK) *out_n = m;
+    a.release();
+    b.release();
+    return rc;
+}
+
 int filter_distance(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double near_t, double far_t, float* out, size_t* out_n)
 {
     return host_wrap(ctx, xyzi, n, stride, out, out_n, [&](const float4* i, float4* o, size_t* m) { return filter_distance_device(ctx, i, n, near_t, far_t, o, m); });

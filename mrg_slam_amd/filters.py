@@ -8,6 +8,7 @@ import ctypes as C
 
 import numpy as np
 
+from . import _lib
 from ._lib import Context, check, default_context, lib
 
 _fp = C.POINTER(C.c_float)
@@ -138,6 +139,21 @@ def prefilter(cloud, params: dict | None = None, ctx: Context | None = None) -> 
          "statistical_stddev": 1.2}
     p.update(params or {})
     c = _cloud(cloud)
+    if p["downsample_method"] in ("VOXELGRID", "NONE") and p["outlier_removal_method"] in ("RADIUS", "STATISTICAL", "NONE"):
+        # one call: the cloud stays in HBM between the passes (mrgfe_prefilter)
+        ctx = ctx or default_context()
+        q = _lib.PrefilterParams()
+        lib().mrgfe_prefilter_default_params(C.byref(q))
+        q.enable_distance_filter = int(bool(p["enable_distance_filter"]))
+        q.distance_near_thresh, q.distance_far_thresh = p["distance_near_thresh"], p["distance_far_thresh"]
+        q.downsample_method = 1 if p["downsample_method"] == "VOXELGRID" else 0
+        q.downsample_resolution, q.downsample_min_points_per_voxel = p["downsample_resolution"], p["downsample_min_points_per_voxel"]
+        q.outlier_removal_method = {"NONE": 0, "RADIUS": 1, "STATISTICAL": 2}[p["outlier_removal_method"]]
+        q.radius_radius, q.radius_min_neighbors = p["radius_radius"], p["radius_min_neighbors"]
+        q.statistical_mean_k, q.statistical_stddev = p["statistical_mean_k"], p["statistical_stddev"]
+        out, m = np.empty((max(len(c), 1), 4), dtype=np.float32), C.c_size_t(0)
+        check(lib().mrgfe_prefilter(ctx._h, C.byref(q), c.ctypes.data_as(_fp), len(c), 16, out.ctypes.data_as(_fp), C.byref(m)))
+        return out[: m.value].copy()
     if p["enable_distance_filter"]:
         c = distance_filter(c, p["distance_near_thresh"], p["distance_far_thresh"], ctx)
     if p["downsample_method"] == "VOXELGRID":

@@ -204,3 +204,41 @@ def test_knn_exact_on_adversarial_clouds(kind, k):
         np.testing.assert_array_equal(idx[i, :m], order.astype(np.int32), err_msg=f"query {i}")
         np.testing.assert_array_equal(sqd[i, :m], d[order])
         assert (idx[i, m:] == -1).all()
+
+
+@pytest.mark.parametrize("outlier", ["RADIUS", "STATISTICAL", "NONE"])
+@pytest.mark.parametrize("downsample", ["VOXELGRID", "NONE"])
+def test_fused_prefilter_equals_the_three_calls(street_pair_vlp16, outlier, downsample):
+    """mrgfe_prefilter (one upload, the passes back to back in HBM, one download) == distance_filter -> VoxelGrid ->
+    outlier removal called one after the other == the oracle chain."""
+    from mrg_slam_amd import RadiusOutlierRemoval, StatisticalOutlierRemoval, VoxelGrid, distance_filter, prefilter
+    from oracle import oracle as orc
+
+    raw = street_pair_vlp16[0]
+    params = {"downsample_method": downsample, "outlier_removal_method": outlier, "downsample_resolution": 0.2, "distance_far_thresh": 30.0}
+    got = prefilter(raw, params)
+    c = distance_filter(raw, 0.1, 30.0)
+    e = orc.distance_filter(raw, 0.1, 30.0)
+    if downsample == "VOXELGRID":
+        vg = VoxelGrid()
+        vg.setLeafSize(0.2)
+        vg.setInputCloud(c)
+        c = vg.filter()
+        e, _ = orc.voxelgrid(e, 0.2, 1)
+    if outlier == "RADIUS":
+        ro = RadiusOutlierRemoval()
+        ro.setRadiusSearch(0.5)
+        ro.setMinNeighborsInRadius(2)
+        ro.setInputCloud(c)
+        c = ro.filter()
+        e, _ = orc.radius_outlier(e, 0.5, 2)
+    elif outlier == "STATISTICAL":
+        so = StatisticalOutlierRemoval()
+        so.setMeanK(30)
+        so.setStddevMulThresh(1.2)
+        so.setInputCloud(c)
+        c = so.filter()
+        e, _ = orc.statistical_outlier(e, 30, 1.2)
+    np.testing.assert_array_equal(got, c)
+    np.testing.assert_array_equal(got, e)
+    assert len(prefilter(np.zeros((0, 4), np.float32), params)) == 0
