@@ -158,6 +158,9 @@ typedef struct mrgfe_prefilter_params {
 } mrgfe_prefilter_params;
 void mrgfe_prefilter_default_params(mrgfe_prefilter_params* out);
 int  mrgfe_prefilter(mrgfe_ctx* ctx, const mrgfe_prefilter_params* params, const float* xyzi, size_t n, size_t stride_bytes, float* out_xyzi, size_t* out_n);
+/* the same with the result left in device memory (packed float4, capacity >= n points) for mrgfe_reg_set_source_device /
+ * mrgfe_batch_add_*_device: the filtered scan goes from the prefiltering callback to the scan matcher without leaving HBM */
+int  mrgfe_prefilter_device(mrgfe_ctx* ctx, const mrgfe_prefilter_params* params, const float* xyzi, size_t n, size_t stride_bytes, void* d_out_xyzi, size_t* out_n);
 
 /* replaces PrefilteringComponent::distance_filter (:206-229): keep iff near < |p| < far */
 int mrgfe_distance_filter(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, double near_thresh, double far_thresh,

@@ -100,6 +100,7 @@ SIGNATURES = {
     "mrgfe_ndt_evaluate": (C.c_int, [_vp, _fp, _dp, C.c_int, _dp, _dp, _dp]),
     "mrgfe_prefilter_default_params": (None, [C.POINTER(PrefilterParams)]),
     "mrgfe_prefilter": (C.c_int, [_vp, C.POINTER(PrefilterParams), _fp, C.c_size_t, C.c_size_t, _fp, C.POINTER(C.c_size_t)]),
+    "mrgfe_prefilter_device": (C.c_int, [_vp, C.POINTER(PrefilterParams), _fp, C.c_size_t, C.c_size_t, _vp, C.POINTER(C.c_size_t)]),
     "mrgfe_knn": (C.c_int, [_vp, _fp, C.c_size_t, _fp, C.c_size_t, C.c_size_t, C.c_int, _ip, _fp]),
     "mrgfe_gicp_linearize": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _ip]),
     "mrgfe_gicp_covariances": (C.c_int, [_vp, C.c_int, _dp]),
@@ -161,8 +162,14 @@ def lib() -> C.CDLL:
                 build()
             except Exception as e:  # noqa: BLE001
                 raise RuntimeError(f"libmrgfe.so is missing and could not be built with hipcc ({e}); there is no CPU fallback") from e
-        # When torch is already in the process its bundled HIP runtime (same soname) must be the one we bind to;
-        # importing it first in a torch-using program keeps a single runtime per process.
+        # A process that uses both this library and PyTorch must bind them to ONE HIP runtime, and that only works out
+        # when torch's bundled runtime (same soname) is loaded first: loaded after libmrgfe, torch reports "No HIP GPUs are
+        # available".  So import torch here if it is installed (MRGFE_NO_TORCH=1 skips this for torch-free programs).
+        if "torch" not in sys.modules and os.environ.get("MRGFE_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:  # noqa: BLE001
+                pass
         L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL if "torch" in sys.modules else C.DEFAULT_MODE)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)  # AttributeError here == the library does not export a declared symbol

@@ -480,7 +480,16 @@ void mrgfe_prefilter_default_params(mrgfe_prefilter_params* p)
     p->statistical_mean_k = 30;
     p->statistical_stddev = 1.2;
 }
+static int prefilter_impl(mrgfe_ctx* ctx, const mrgfe_prefilter_params* p, const float* xyzi, size_t n, size_t stride, void* out, size_t* out_n, bool on_device);
 int mrgfe_prefilter(mrgfe_ctx* ctx, const mrgfe_prefilter_params* p, const float* xyzi, size_t n, size_t stride, float* out, size_t* out_n)
+{
+    return prefilter_impl(ctx, p, xyzi, n, stride, out, out_n, false);
+}
+int mrgfe_prefilter_device(mrgfe_ctx* ctx, const mrgfe_prefilter_params* p, const float* xyzi, size_t n, size_t stride, void* d_out, size_t* out_n)
+{
+    return prefilter_impl(ctx, p, xyzi, n, stride, d_out, out_n, true);
+}
+static int prefilter_impl(mrgfe_ctx* ctx, const mrgfe_prefilter_params* p, const float* xyzi, size_t n, size_t stride, void* out, size_t* out_n, bool on_device)
 {
     if (!ctx || !p || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_prefilter: NULL argument"); return MRGFE_ERR_INVALID; }
     if (p->downsample_method < 0 || p->downsample_method > 1 || p->outlier_removal_method < 0 || p->outlier_removal_method > 2) { set_error("mrgfe_prefilter: unknown method"); return MRGFE_ERR_INVALID; }
@@ -499,7 +508,7 @@ int mrgfe_prefilter(mrgfe_ctx* ctx, const mrgfe_prefilter_params* p, const float
     ch.radius_min_neighbors = p->radius_min_neighbors;
     ch.mean_k = p->statistical_mean_k;
     ch.stddev_mul = p->statistical_stddev;
-    return filter_chain(ctx, ch, xyzi, n, stride, out, out_n);
+    return filter_chain(ctx, ch, xyzi, n, stride, out, out_n, on_device);
 }
 int mrgfe_calc_fitness_score(mrgfe_ctx* ctx, const float* cloud1, size_t n1, const float* cloud2, size_t n2, size_t stride, const double relpose[16], double max_range, double* out)
 {

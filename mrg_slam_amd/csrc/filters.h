@@ -27,7 +27,7 @@ struct PrefilterChain {
     double stddev_mul = 1.2;
 };
 // the three passes back to back on the device (one upload, one download)
-int filter_chain(mrgfe_ctx* ctx, const PrefilterChain& chain, const float* xyzi, size_t n, size_t stride, float* out, size_t* out_n);
+int filter_chain(mrgfe_ctx* ctx, const PrefilterChain& chain, const float* xyzi, size_t n, size_t stride, void* out, size_t* out_n, bool out_on_device = false);
 
 int filter_distance(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double near_t, double far_t, float* out, size_t* out_n);
 int filter_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, float leaf, int min_pts, float* out, size_t* out_n, int* overflow);

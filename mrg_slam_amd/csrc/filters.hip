@@ -294,7 +294,7 @@ static int host_wrap(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride,
     return rc;
 }
 
-int filter_chain(mrgfe_ctx* ctx, const PrefilterChain& ch, const float* xyzi, size_t n, size_t stride, float* out, size_t* out_n)
+int filter_chain(mrgfe_ctx* ctx, const PrefilterChain& ch, const float* xyzi, size_t n, size_t stride, void* out, size_t* out_n, bool out_on_device)
 {
     *out_n = 0;
     if (n == 0) return MRGFE_OK;
@@ -314,7 +314,14 @@ int filter_chain(mrgfe_ctx* ctx, const PrefilterChain& ch, const float* xyzi, si
     if (ch.voxelgrid) pass([&](const float4* i, size_t ni, float4* o, size_t* k) { int overflow = 0; return filter_voxelgrid_device(ctx, i, ni, ch.leaf, ch.min_pts, o, k, &overflow); });
     if (ch.outlier == 1) pass([&](const float4* i, size_t ni, float4* o, size_t* k) { return filter_radius_outlier_device(ctx, i, ni, ch.radius, ch.radius_min_neighbors, o, k); });
     if (ch.outlier == 2) pass([&](const float4* i, size_t ni, float4* o, size_t* k) { return filter_statistical_outlier_device(ctx, i, ni, ch.mean_k, ch.stddev_mul, o, k); });
-    if (rc == MRGFE_OK) rc = download(ctx, cur, m, out);
+    if (rc == MRGFE_OK) {
+        if (!out_on_device) {
+            rc = download(ctx, cur, m, static_cast<float*>(out));
+        } else if (m && (hipMemcpyAsync(out, cur, m * 16, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+            set_error("prefilter: device copy failed");
+            rc = MRGFE_ERR_HIP;
+        }
+    }
     if (rc == MRGFE_OK) *out_n = m;
     a.release();
     b.release();

@@ -131,6 +131,38 @@ def knn(cloud, queries, k: int, ctx: Context | None = None):
     return idx, sqd
 
 
+def _prefilter_params(p: dict) -> "_lib.PrefilterParams":
+    q = _lib.PrefilterParams()
+    lib().mrgfe_prefilter_default_params(C.byref(q))
+    q.enable_distance_filter = int(bool(p["enable_distance_filter"]))
+    q.distance_near_thresh, q.distance_far_thresh = p["distance_near_thresh"], p["distance_far_thresh"]
+    q.downsample_method = 1 if p["downsample_method"] == "VOXELGRID" else 0
+    q.downsample_resolution, q.downsample_min_points_per_voxel = p["downsample_resolution"], p["downsample_min_points_per_voxel"]
+    q.outlier_removal_method = {"NONE": 0, "RADIUS": 1, "STATISTICAL": 2}[p["outlier_removal_method"]]
+    q.radius_radius, q.radius_min_neighbors = p["radius_radius"], p["radius_min_neighbors"]
+    q.statistical_mean_k, q.statistical_stddev = p["statistical_mean_k"], p["statistical_stddev"]
+    return q
+
+
+_PREFILTER_DEFAULTS = {"enable_distance_filter": True, "distance_near_thresh": 0.1, "distance_far_thresh": 35.0, "downsample_method": "VOXELGRID",
+                       "downsample_resolution": 0.1, "downsample_min_points_per_voxel": 1, "outlier_removal_method": "RADIUS", "radius_radius": 0.5,
+                       "radius_min_neighbors": 2, "statistical_mean_k": 30, "statistical_stddev": 1.2}
+
+
+def prefilter_to_device(cloud, dev_ptr: int, capacity: int, params: dict | None = None, ctx: Context | None = None) -> int:
+    """The prefiltering chain with the filtered scan left in device memory at ``dev_ptr`` (packed float4, room for
+    ``capacity`` >= len(cloud) points), ready for setInputSourceDevice / add_pair_device.  Returns the point count."""
+    p = dict(_PREFILTER_DEFAULTS)
+    p.update(params or {})
+    c = _cloud(cloud)
+    if capacity < len(c):
+        raise ValueError("device buffer too small")
+    ctx = ctx or default_context()
+    q, m = _prefilter_params(p), C.c_size_t(0)
+    check(lib().mrgfe_prefilter_device(ctx._h, C.byref(q), c.ctypes.data_as(_fp), len(c), 16, C.c_void_p(dev_ptr), C.byref(m)))
+    return m.value
+
+
 def prefilter(cloud, params: dict | None = None, ctx: Context | None = None) -> np.ndarray:
     """The chain of PrefilteringComponent::cloud_callback (:149-151) with the reference's parameter names and YAML
     defaults (config/mrg_slam.yaml:41-64): distance_filter -> downsample -> outlier_removal."""
@@ -142,15 +174,7 @@ def prefilter(cloud, params: dict | None = None, ctx: Context | None = None) -> 
     if p["downsample_method"] in ("VOXELGRID", "NONE") and p["outlier_removal_method"] in ("RADIUS", "STATISTICAL", "NONE"):
         # one call: the cloud stays in HBM between the passes (mrgfe_prefilter)
         ctx = ctx or default_context()
-        q = _lib.PrefilterParams()
-        lib().mrgfe_prefilter_default_params(C.byref(q))
-        q.enable_distance_filter = int(bool(p["enable_distance_filter"]))
-        q.distance_near_thresh, q.distance_far_thresh = p["distance_near_thresh"], p["distance_far_thresh"]
-        q.downsample_method = 1 if p["downsample_method"] == "VOXELGRID" else 0
-        q.downsample_resolution, q.downsample_min_points_per_voxel = p["downsample_resolution"], p["downsample_min_points_per_voxel"]
-        q.outlier_removal_method = {"NONE": 0, "RADIUS": 1, "STATISTICAL": 2}[p["outlier_removal_method"]]
-        q.radius_radius, q.radius_min_neighbors = p["radius_radius"], p["radius_min_neighbors"]
-        q.statistical_mean_k, q.statistical_stddev = p["statistical_mean_k"], p["statistical_stddev"]
+        q = _prefilter_params(p)
         out, m = np.empty((max(len(c), 1), 4), dtype=np.float32), C.c_size_t(0)
         check(lib().mrgfe_prefilter(ctx._h, C.byref(q), c.ctypes.data_as(_fp), len(c), 16, out.ctypes.data_as(_fp), C.byref(m)))
         return out[: m.value].copy()

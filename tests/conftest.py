@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # before anything loads libmrgfe: a process that also uses PyTorch must bind both to ONE HIP runtime, torch's (see _lib.lib)
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

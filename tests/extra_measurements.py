@@ -187,6 +187,26 @@ def main():
                              "dt_m": float(np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3])), "dr_rad": synth.rotation_angle(Tg, To),
                              "iterations": [g2.getFinalNumIteration(), o2.getFinalNumIteration()]}
 
+    # ---- one odometry frame: raw scan in host memory -> prefilter -> scan-to-keyframe NDT against a resident keyframe ----
+    import torch
+
+    from mrg_slam_amd import prefilter_to_device
+
+    kf = prefilter(raw[0], ctx=ctx)
+    odo = NdtHip(resolution=1.0, transformation_epsilon=0.1, maximum_iterations=64, ctx=ctx)
+    odo.setInputTarget(kf)
+    dbuf = torch.empty((len(raw[1]), 4), dtype=torch.float32, device="cuda:0")
+    prev = np.eye(4)
+    tf = []
+    for k in (1, 2, 3, 4, 1, 2, 3, 4):
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        m = prefilter_to_device(raw[k], dbuf.data_ptr(), len(raw[k]), ctx=ctx)
+        odo.setInputSourceDevice(dbuf.data_ptr(), m)
+        odo.align(synth.warm_guess(np.linalg.inv(poses[0]) @ poses[k], k))
+        tf.append(time.perf_counter() - t1)
+    out["odometry_frame_ms"] = {"raw_points": len(raw[1]), "filtered_points": int(m), "prefilter_plus_scan_to_keyframe_ndt_ms": 1e3 * float(np.median(tf[2:]))}
+
     # ---- prefilter chain --------------------------------------------------------------------------------------------
     tp = []
     for _ in range(5):

@@ -242,3 +242,28 @@ def test_fused_prefilter_equals_the_three_calls(street_pair_vlp16, outlier, down
     np.testing.assert_array_equal(got, c)
     np.testing.assert_array_equal(got, e)
     assert len(prefilter(np.zeros((0, 4), np.float32), params)) == 0
+
+
+def test_prefilter_to_device_feeds_the_scan_matcher_without_leaving_hbm(street_pair_vlp16):
+    """mrgfe_prefilter_device leaves the filtered scan in device memory; registering from there gives the result of the
+    host round trip (prefiltering_component -> scan_matching_odometry_component as two ROS nodes)."""
+    import torch
+
+    from mrg_slam_amd import NdtHip, prefilter, prefilter_to_device
+
+    tgt_raw, src_raw, _ = street_pair_vlp16
+    tgt, src = prefilter(tgt_raw), prefilter(src_raw)
+    buf = torch.empty((len(src_raw), 4), dtype=torch.float32, device="cuda:0")
+    m = prefilter_to_device(src_raw, buf.data_ptr(), len(src_raw))
+    assert m == len(src)
+    np.testing.assert_array_equal(buf[:m].cpu().numpy(), src)
+    a, b = NdtHip(transformation_epsilon=0.01), NdtHip(transformation_epsilon=0.01)
+    for r in (a, b):
+        r.setInputTarget(tgt)
+    a.setInputSource(src)
+    b.setInputSourceDevice(buf.data_ptr(), m)
+    a.align(np.eye(4))
+    b.align(np.eye(4))
+    np.testing.assert_array_equal(a.getFinalTransformation(), b.getFinalTransformation())
+    with pytest.raises(ValueError):
+        prefilter_to_device(src_raw, buf.data_ptr(), 10)
