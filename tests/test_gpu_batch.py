@@ -213,3 +213,38 @@ def test_keyframe_store_evicts_least_recently_used(monkeypatch):
     assert bm.has_cloud(1) == 20000 and bm.has_cloud(5) == 20000
     assert bm.has_cloud(2) is None  # oldest unused one went first
     assert bm.store_bytes() <= (1 << 20) + 20000 * 16
+
+
+def test_device_resident_clouds_give_the_host_pointer_results():
+    """The *_device entry points reference clouds already in HBM (packed float4, e.g. torch tensors): same results as
+    handing the same clouds over as host pointers, for the batch and for a single registration."""
+    import torch
+
+    from mrg_slam_amd import BatchMatcher, NdtHip, synth
+    from mrg_slam_amd.registration import result_matrix
+
+    rng = np.random.default_rng(33)
+    tgt = small_cloud(4000, 500)
+    srcs = [small_cloud(2500 + 100 * k, 510 + k) for k in range(3)]
+    guesses = [synth.perturb_pose(np.eye(4), rng) for _ in srcs]
+    d_tgt = torch.from_numpy(tgt).cuda(0)
+    d_srcs = [torch.from_numpy(s).cuda(0) for s in srcs]
+    torch.cuda.synchronize()
+    host, dev = BatchMatcher(transformation_epsilon=0.01), BatchMatcher(transformation_epsilon=0.01)
+    th, td = host.add_target(tgt), dev.add_target_device(d_tgt.data_ptr(), len(tgt))
+    for s, ds, g in zip(srcs, d_srcs, guesses):
+        host.add_pair(th, s, g)
+        dev.add_pair_device(td, ds.data_ptr(), len(s), g)
+    a, b = host.align(float("inf")), dev.align(float("inf"))
+    for i in range(len(srcs)):
+        np.testing.assert_array_equal(result_matrix(a[i]), result_matrix(b[i]))
+        assert a[i]["fitness"] == b[i]["fitness"] and a[i]["iterations"] == b[i]["iterations"]
+    r1, r2 = NdtHip(transformation_epsilon=0.01), NdtHip(transformation_epsilon=0.01)
+    r1.setInputTarget(tgt)
+    r1.setInputSource(srcs[0])
+    r2.setInputTargetDevice(d_tgt.data_ptr(), len(tgt))
+    r2.setInputSourceDevice(d_srcs[0].data_ptr(), len(srcs[0]))
+    r1.align(guesses[0])
+    r2.align(guesses[0])
+    np.testing.assert_array_equal(r1.getFinalTransformation(), r2.getFinalTransformation())
+    assert r1.getFitnessScore() == r2.getFitnessScore()
