@@ -206,6 +206,19 @@ def main():
         odo.align(synth.warm_guess(np.linalg.inv(poses[0]) @ poses[k], k))
         tf.append(time.perf_counter() - t1)
     out["odometry_frame_ms"] = {"raw_points": len(raw[1]), "filtered_points": int(m), "prefilter_plus_scan_to_keyframe_ndt_ms": 1e3 * float(np.median(tf[2:]))}
+    from mrg_slam_amd import SmallGicpHip
+
+    odo_g = SmallGicpHip(transformation_epsilon=0.1, ctx=ctx)  # the YAML default registration (config/mrg_slam.yaml:100)
+    odo_g.setInputTarget(kf)
+    tf = []
+    for k in (1, 2, 3, 4, 1, 2, 3, 4):
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        m = prefilter_to_device(raw[k], dbuf.data_ptr(), len(raw[k]), ctx=ctx)
+        odo_g.setInputSourceDevice(dbuf.data_ptr(), m)
+        odo_g.align(synth.warm_guess(np.linalg.inv(poses[0]) @ poses[k], k))
+        tf.append(time.perf_counter() - t1)
+    out["odometry_frame_ms"]["prefilter_plus_scan_to_keyframe_small_gicp_ms"] = 1e3 * float(np.median(tf[2:]))
 
     # ---- prefilter chain --------------------------------------------------------------------------------------------
     tp = []
