@@ -193,6 +193,21 @@ int mrgfe_calc_fitness_score(mrgfe_ctx* ctx, const float* cloud1, size_t n1, con
 int mrgfe_map_cloud_generate(mrgfe_ctx* ctx, int n_keyframes, const float* const* clouds_xyzi, const size_t* n_points, size_t stride_bytes, const double* poses,
                              const uint8_t* first_keyframe, float resolution, int min_points_per_voxel, float distance_far_thresh, int skip_first_cloud,
                              float* out_xyzi, size_t capacity, size_t* out_n);
+/* The same over keyframe clouds that stay in HBM.  The map is regenerated from ALL keyframes whenever it is published or
+ * saved (apps/mrg_slam_component.cpp:727,781,1097) and only their poses change between calls (graph optimisation), while
+ * the reference walks the host clouds every time.  A map store keeps each keyframe's packed cloud resident (append-only,
+ * 16 B/point, no cap: the keyframes of a session fit 288 GB many times over); generate() then moves K poses instead of
+ * the clouds.  Same output as mrgfe_map_cloud_generate for the same keyframes in the same order. */
+typedef struct mrgfe_map_store mrgfe_map_store;
+int    mrgfe_map_store_create(mrgfe_ctx* ctx, mrgfe_map_store** out);
+void   mrgfe_map_store_destroy(mrgfe_map_store* store);
+/* adds keyframe `key` (non-zero); adding a key again with the same point count is a no-op, with another count an error */
+int    mrgfe_map_store_add(mrgfe_map_store* store, uint64_t key, const float* xyzi, size_t n, size_t stride_bytes);
+int    mrgfe_map_store_has(const mrgfe_map_store* store, uint64_t key, size_t* n);
+size_t mrgfe_map_store_bytes(const mrgfe_map_store* store);
+int    mrgfe_map_store_generate(mrgfe_map_store* store, int n_keyframes, const uint64_t* keys, const double* poses, const uint8_t* first_keyframe, float resolution,
+                                int min_points_per_voxel, float distance_far_thresh, int skip_first_cloud, float* out_xyzi, size_t capacity, size_t* out_n);
+
 /* replaces the other-robot point removal of apps/mrg_slam_component.cpp:396-429: drops every point whose squared float
  * distance to one of the centres (sensor frame, <= 64) is < radius_sqr; kept / removed (may be NULL) keep the input order */
 int mrgfe_remove_points_near(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, const float* centres_xyz, int n_centres, float radius_sqr,

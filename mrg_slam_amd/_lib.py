@@ -98,6 +98,13 @@ SIGNATURES = {
     "mrgfe_reg_trans_probability": (C.c_double, [_vp]),
     "mrgfe_reg_hessian": (C.c_int, [_vp, _dp]),
     "mrgfe_ndt_evaluate": (C.c_int, [_vp, _fp, _dp, C.c_int, _dp, _dp, _dp]),
+    "mrgfe_map_store_create": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
+    "mrgfe_map_store_destroy": (None, [_vp]),
+    "mrgfe_map_store_add": (C.c_int, [_vp, C.c_uint64, _fp, C.c_size_t, C.c_size_t]),
+    "mrgfe_map_store_has": (C.c_int, [_vp, C.c_uint64, C.POINTER(C.c_size_t)]),
+    "mrgfe_map_store_bytes": (C.c_size_t, [_vp]),
+    "mrgfe_map_store_generate": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint64), _dp, C.POINTER(C.c_uint8), C.c_float, C.c_int, C.c_float, C.c_int, _fp, C.c_size_t,
+                                           C.POINTER(C.c_size_t)]),
     "mrgfe_prefilter_default_params": (None, [C.POINTER(PrefilterParams)]),
     "mrgfe_prefilter": (C.c_int, [_vp, C.POINTER(PrefilterParams), _fp, C.c_size_t, C.c_size_t, _fp, C.POINTER(C.c_size_t)]),
     "mrgfe_prefilter_device": (C.c_int, [_vp, C.POINTER(PrefilterParams), _fp, C.c_size_t, C.c_size_t, _vp, C.POINTER(C.c_size_t)]),

@@ -532,6 +532,36 @@ int mrgfe_calc_fitness_score(mrgfe_ctx* ctx, const float* cloud1, size_t n1, con
 }
 
 // ---- map cloud, other-robot removal, deskewing --------------------------------------------------------------------
+// shared tail of the two map-cloud entry points: run the device pass over `total` points (d_cat, or the per-keyframe
+// pointers kf_ptrs), apply the reference's emptiness / capacity rules and bring the result down
+static int map_cloud_finish(mrgfe_ctx* ctx, int K_all, const float4* d_cat, const float4* const* kf_ptrs, const std::vector<uint32_t>& off, const std::vector<float>& pose_f,
+                            float resolution, int min_points_per_voxel, float distance_far_thresh, float* out, size_t capacity, size_t* out_n)
+{
+    const uint64_t total = off.back();
+    size_t m = 0, unfiltered = 0;
+    int    rc = MRGFE_OK;
+    DevBuf dout;
+    if (total) {
+        rc = dout.ensure(total * 16);
+        if (rc == MRGFE_OK)
+            rc = map_cloud_device(ctx, d_cat, off.data(), pose_f.data(), static_cast<int>(off.size()) - 1, resolution, min_points_per_voxel, distance_far_thresh, dout.as<float4>(), &m,
+                                  &unfiltered, kf_ptrs);
+    }
+    // :57-60: the cloud BEFORE the voxel filter decides
+    if (rc == MRGFE_OK && unfiltered == 0 && K_all > 1) { set_error("cloud is empty after processing keyframes"); rc = MRGFE_ERR_EMPTY; }
+    if (rc == MRGFE_OK && m > capacity) { *out_n = m; set_error("map cloud: output needs %zu points, capacity is %zu", m, capacity); rc = MRGFE_ERR_INVALID; }
+    if (rc == MRGFE_OK && m) {
+        if (!out) { set_error("map cloud: NULL output"); rc = MRGFE_ERR_INVALID; }
+        else if (hipMemcpyAsync(out, dout.p, m * 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            set_error("map cloud: device to host copy failed");
+            rc = MRGFE_ERR_HIP;
+        }
+    }
+    if (rc == MRGFE_OK) *out_n = m;
+    dout.release();
+    return rc;
+}
+
 int mrgfe_map_cloud_generate(mrgfe_ctx* ctx, int K, const float* const* clouds, const size_t* n_points, size_t stride, const double* poses, const uint8_t* first_keyframe,
                              float resolution, int min_points_per_voxel, float distance_far_thresh, int skip_first_cloud, float* out, size_t capacity, size_t* out_n)
 {
@@ -553,32 +583,106 @@ int mrgfe_map_cloud_generate(mrgfe_ctx* ctx, int K, const float* const* clouds, 
         off.push_back(static_cast<uint32_t>(total));
         for (int t = 0; t < 16; ++t) pose_f.push_back(static_cast<float>(poses[16 * k + t]));  // pose.matrix().cast<float>()
     }
-    size_t m = 0, unfiltered = 0;
     int    rc = MRGFE_OK;
-    DevBuf dcat, dout;
+    DevBuf dcat;
     if (total) {
         rc = dcat.ensure(total * 16);
-        if (rc == MRGFE_OK) rc = dout.ensure(total * 16);
         for (size_t u = 0; u < used.size() && rc == MRGFE_OK; ++u)
             if (n_points[used[u]]) rc = upload_cloud(ctx, clouds[used[u]], n_points[used[u]], stride, dcat.as<char>() + size_t(off[u]) * 16);
-        if (rc == MRGFE_OK)
-            rc = map_cloud_device(ctx, dcat.as<float4>(), off.data(), pose_f.data(), static_cast<int>(used.size()), resolution, min_points_per_voxel, distance_far_thresh,
-                                  dout.as<float4>(), &m, &unfiltered);
     }
-    // :57-60: the cloud BEFORE the voxel filter decides
-    if (rc == MRGFE_OK && unfiltered == 0 && K > 1) { set_error("cloud is empty after processing keyframes"); rc = MRGFE_ERR_EMPTY; }
-    if (rc == MRGFE_OK && m > capacity) { *out_n = m; set_error("mrgfe_map_cloud_generate: output needs %zu points, capacity is %zu", m, capacity); rc = MRGFE_ERR_INVALID; }
-    if (rc == MRGFE_OK && m) {
-        if (!out) { set_error("mrgfe_map_cloud_generate: NULL output"); rc = MRGFE_ERR_INVALID; }
-        else if (hipMemcpyAsync(out, dout.p, m * 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
-            set_error("mrgfe_map_cloud_generate: device to host copy failed");
-            rc = MRGFE_ERR_HIP;
-        }
-    }
-    if (rc == MRGFE_OK) *out_n = m;
+    if (rc == MRGFE_OK) rc = map_cloud_finish(ctx, K, dcat.as<float4>(), nullptr, off, pose_f, resolution, min_points_per_voxel, distance_far_thresh, out, capacity, out_n);
     dcat.release();
-    dout.release();
     return rc;
+}
+
+// ---- map store: keyframe clouds resident in HBM (include/mrgfe.h) --------------------------------------------------------
+struct mrgfe_map_store {
+    mrgfe_ctx* ctx = nullptr;
+    Arena      arena;  // append-only
+    struct Entry { const float4* p; uint32_t n; };
+    std::unordered_map<uint64_t, Entry> clouds;
+    size_t bytes = 0;
+};
+
+int mrgfe_map_store_create(mrgfe_ctx* ctx, mrgfe_map_store** out)
+{
+    if (!ctx || !out) { set_error("mrgfe_map_store_create: NULL argument"); return MRGFE_ERR_INVALID; }
+    mrgfe_map_store* s = new (std::nothrow) mrgfe_map_store();
+    if (!s) { set_error("out of host memory"); return MRGFE_ERR_INVALID; }
+    s->ctx = ctx;
+    *out = s;
+    return MRGFE_OK;
+}
+void mrgfe_map_store_destroy(mrgfe_map_store* s)
+{
+    if (!s) return;
+    {
+        MRGFE_LOCK(s->ctx);
+        (void)s->ctx->bind();
+        s->arena.release();
+    }
+    delete s;
+}
+int mrgfe_map_store_add(mrgfe_map_store* s, uint64_t key, const float* xyzi, size_t n, size_t stride)
+{
+    if (!s || key == 0 || (n && !xyzi)) { set_error("mrgfe_map_store_add: NULL store / cloud or key 0"); return MRGFE_ERR_INVALID; }
+    if (n > 0x7fffffffu) { set_error("cloud too large"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(s->ctx);
+    MRGFE_TRY(s->ctx->bind());
+    auto it = s->clouds.find(key);
+    if (it != s->clouds.end()) {
+        if (it->second.n == n) return MRGFE_OK;
+        set_error("mrgfe_map_store_add: keyframe %llu is stored with %u points, not %zu", static_cast<unsigned long long>(key), it->second.n, n);
+        return MRGFE_ERR_INVALID;
+    }
+    void* p = nullptr;
+    if (n) {
+        MRGFE_TRY(s->arena.alloc(n * 16, &p));
+        MRGFE_TRY(upload_cloud(s->ctx, xyzi, n, stride, p));
+    }
+    s->clouds[key] = {static_cast<const float4*>(p), static_cast<uint32_t>(n)};
+    s->bytes += n * 16;
+    return MRGFE_OK;
+}
+int mrgfe_map_store_has(const mrgfe_map_store* s, uint64_t key, size_t* n)
+{
+    if (!s) return 0;
+    MRGFE_LOCK(s->ctx);
+    auto it = s->clouds.find(key);
+    if (it == s->clouds.end()) return 0;
+    if (n) *n = it->second.n;
+    return 1;
+}
+size_t mrgfe_map_store_bytes(const mrgfe_map_store* s)
+{
+    if (!s) return 0;
+    MRGFE_LOCK(s->ctx);
+    return s->bytes;
+}
+int mrgfe_map_store_generate(mrgfe_map_store* s, int K, const uint64_t* keys, const double* poses, const uint8_t* first_keyframe, float resolution, int min_points_per_voxel,
+                             float distance_far_thresh, int skip_first_cloud, float* out, size_t capacity, size_t* out_n)
+{
+    if (!s || !out_n || (K > 0 && (!keys || !poses))) { set_error("mrgfe_map_store_generate: NULL argument"); return MRGFE_ERR_INVALID; }
+    *out_n = 0;
+    if (K <= 0) { set_error("keyframes are empty, cannot generate map cloud"); return MRGFE_ERR_EMPTY; }  // map_cloud_generator.cpp:19-22
+    MRGFE_LOCK(s->ctx);
+    MRGFE_TRY(s->ctx->bind());
+    std::vector<uint32_t>      off(1, 0u);
+    std::vector<float>         pose_f;
+    std::vector<const float4*> ptrs;
+    uint64_t total = 0;
+    for (int k = 0; k < K; ++k) {
+        if (first_keyframe && first_keyframe[k] && skip_first_cloud) continue;  // :32-34
+        auto it = s->clouds.find(keys[k]);
+        if (it == s->clouds.end()) { set_error("mrgfe_map_store_generate: keyframe %llu is not in the store", static_cast<unsigned long long>(keys[k])); return MRGFE_ERR_INVALID; }
+        total += it->second.n;
+        if (total > 0x7fffffffu) { set_error("mrgfe_map_store_generate: more than 2^31 points"); return MRGFE_ERR_INVALID; }
+        ptrs.push_back(it->second.p);
+        off.push_back(static_cast<uint32_t>(total));
+        for (int t = 0; t < 16; ++t) pose_f.push_back(static_cast<float>(poses[16 * k + t]));
+    }
+    MRGFE_HIP_CHECK(hipStreamSynchronize(s->ctx->stream));  // clouds added just before are still on their way up
+    return map_cloud_finish(s->ctx, K, nullptr, ptrs.data(), off, pose_f, resolution, min_points_per_voxel, distance_far_thresh, out, capacity, out_n);
 }
 
 int mrgfe_remove_points_near(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, const float* centres, int n_centres, float radius_sqr, float* kept, size_t* n_kept,

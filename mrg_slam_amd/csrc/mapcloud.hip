@@ -15,8 +15,10 @@
 namespace mrgfe {
 
 // one lane per point of the concatenated keyframe clouds; the keyframe of a point is found by bisection of kf_off
-__global__ __launch_bounds__(256) void map_transform_kernel(const float4* __restrict__ cat, uint32_t n, const uint32_t* __restrict__ kf_off, const float* __restrict__ poses, int K,
-                                                             int use_far, float far_sq, float4* __restrict__ out, uint32_t* __restrict__ flags)
+// cat: the keyframe clouds back to back, or nullptr when every keyframe is read through its own pointer srcs[k]
+__global__ __launch_bounds__(256) void map_transform_kernel(const float4* __restrict__ cat, const float4* const* __restrict__ srcs, uint32_t n, const uint32_t* __restrict__ kf_off,
+                                                             const float* __restrict__ poses, int K, int use_far, float far_sq, float4* __restrict__ out,
+                                                             uint32_t* __restrict__ flags)
 {
 #pragma clang fp contract(off)
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -26,7 +28,7 @@ __global__ __launch_bounds__(256) void map_transform_kernel(const float4* __rest
         const int mid = (lo + hi) >> 1;
         if (kf_off[mid] <= i) lo = mid; else hi = mid;
     }
-    const float4 p = cat[i];
+    const float4 p = cat ? cat[i] : srcs[lo][i - kf_off[lo]];
     uint32_t keep = 1u;
     if (use_far) {
         float s = p.x * p.x + p.y * p.y;  // getVector3fMap().squaredNorm()
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void map_transform_kernel(const float4* __rest
 }
 
 int map_cloud_device(mrgfe_ctx* ctx, const float4* d_cat, const uint32_t* kf_off, const float* poses_f, int K, float resolution, int min_pts, float far_thresh, float4* d_out,
-                     size_t* out_n, size_t* n_unfiltered)
+                     size_t* out_n, size_t* n_unfiltered, const float4* const* kf_ptrs)
 {
     *out_n = 0;
     *n_unfiltered = 0;
@@ -56,20 +58,23 @@ int map_cloud_device(mrgfe_ctx* ctx, const float4* d_cat, const uint32_t* kf_off
     hipStream_t st = ctx->stream;
     DevBuf dtab, dtrans, dfl;  // per-call buffers: the scratch slots are in use by the voxel-grid pass below
     auto cleanup = [&]() { dtab.release(); dtrans.release(); dfl.release(); };
-    int rc = dtab.ensure(sizeof(uint32_t) * (K + 1) + sizeof(float) * 16 * K);
+    const size_t ptr_at = (sizeof(uint32_t) * (K + 1) + sizeof(float) * 16 * K + 15) & ~size_t(15);
+    int rc = dtab.ensure(ptr_at + sizeof(void*) * K);
     if (rc == MRGFE_OK) rc = dtrans.ensure(size_t(n) * 16);
     if (rc == MRGFE_OK) rc = dfl.ensure(size_t(n) * 4);
     if (rc != MRGFE_OK) { cleanup(); return rc; }
     uint32_t* d_off = dtab.as<uint32_t>();
     float*    d_pose = reinterpret_cast<float*>(d_off + (K + 1));
+    const float4* const* d_ptrs = kf_ptrs ? reinterpret_cast<const float4* const*>(dtab.as<char>() + ptr_at) : nullptr;
     const bool use_far = far_thresh > 0;  // map_cloud_generator.cpp:27-28
-    if (hipMemcpyAsync(d_off, kf_off, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice, st) != hipSuccess ||
+    if ((kf_ptrs && hipMemcpyAsync(dtab.as<char>() + ptr_at, kf_ptrs, sizeof(void*) * K, hipMemcpyHostToDevice, st) != hipSuccess) ||
+        hipMemcpyAsync(d_off, kf_off, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(d_pose, poses_f, sizeof(float) * 16 * K, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
         cleanup();
         set_error("map cloud: table upload failed");
         return MRGFE_ERR_HIP;
     }
-    hipLaunchKernelGGL(map_transform_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_cat, n, d_off, d_pose, K, use_far ? 1 : 0, far_thresh * far_thresh, dtrans.as<float4>(),
+    hipLaunchKernelGGL(map_transform_kernel, dim3((n + 255) / 256), dim3(256), 0, st, kf_ptrs ? nullptr : d_cat, d_ptrs, n, d_off, d_pose, K, use_far ? 1 : 0, far_thresh * far_thresh, dtrans.as<float4>(),
                        dfl.as<uint32_t>());
     if (hipGetLastError() != hipSuccess) { cleanup(); set_error("map cloud: transform kernel launch failed"); return MRGFE_ERR_HIP; }
     const float4* d_cloud = dtrans.as<float4>();

@@ -29,6 +29,55 @@ class KeyFrameSnapshot:
     first_keyframe: bool = False
 
 
+class MapCloudStore:
+    """Keyframe clouds resident in HBM (mrgfe_map_store): the map is regenerated from all keyframes every time it is
+    published, and between two calls only the poses change."""
+
+    def __init__(self, ctx: Context | None = None):
+        self._ctx = ctx or default_context()
+        self._h = C.c_void_p()
+        check(lib().mrgfe_map_store_create(self._ctx._h, C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().mrgfe_map_store_destroy(self._h)
+                self._h = None
+        except Exception:  # noqa: BLE001
+            pass
+
+    def add(self, key: int, cloud) -> None:
+        c = _cloud(cloud)
+        check(lib().mrgfe_map_store_add(self._h, key, c.ctypes.data_as(_fp), len(c), 16))
+
+    def has(self, key: int):
+        n = C.c_size_t(0)
+        return n.value if lib().mrgfe_map_store_has(self._h, key, C.byref(n)) else None
+
+    def bytes(self) -> int:
+        return int(lib().mrgfe_map_store_bytes(self._h))
+
+    def generate(self, keys, poses, first_keyframe=None, resolution: float = 0.1, min_points_per_voxel: int = 1, distance_far_thresh: float = 10000.0,
+                 skip_first_cloud: bool = False):
+        """MapCloudGenerator.generate over the stored keyframes ``keys`` with their current ``poses`` (4 x 4 each)."""
+        K = len(keys)
+        ks = np.ascontiguousarray(np.asarray(keys, dtype=np.uint64))
+        P = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.float64).T.reshape(16) for p in poses])) if K else np.zeros((0, 16))
+        first = np.ascontiguousarray(np.asarray(first_keyframe if first_keyframe is not None else np.zeros(K), dtype=np.uint8))
+        cap = max(sum(self.has(int(k)) or 0 for k in keys), 1)
+        out = np.empty((cap, 4), dtype=np.float32)
+        m = C.c_size_t(0)
+        try:
+            check(lib().mrgfe_map_store_generate(self._h, K, ks.ctypes.data_as(C.POINTER(C.c_uint64)), P.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 first.ctypes.data_as(C.POINTER(C.c_uint8)), float(resolution), int(min_points_per_voxel), float(distance_far_thresh),
+                                                 int(bool(skip_first_cloud)), out.ctypes.data_as(_fp), cap, C.byref(m)))
+        except MrgfeError as e:
+            if e.status == ERR_EMPTY:
+                return None
+            raise
+        return out[: m.value].copy()
+
+
 class MapCloudGenerator:
     def __init__(self, ctx: Context | None = None):
         self._ctx = ctx or default_context()

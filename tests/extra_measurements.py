@@ -220,6 +220,29 @@ def main():
         tf.append(time.perf_counter() - t1)
     out["odometry_frame_ms"]["prefilter_plus_scan_to_keyframe_small_gicp_ms"] = 1e3 * float(np.median(tf[2:]))
 
+    # ---- map cloud of 200 prefiltered keyframes (6.5 M points): host clouds every call vs the HBM map store -------------
+    from mrg_slam_amd import KeyFrameSnapshot, MapCloudGenerator, MapCloudStore
+
+    kf_clouds = [prefilter(raw[k % 5], ctx=ctx) for k in range(5)]
+    K = 200
+    kposes = [synth.make_pose([1.0 * k, 0.3 * k, 0.0], synth.rot_z(0.01 * k)) for k in range(K)]
+    gen, mstore = MapCloudGenerator(ctx), MapCloudStore(ctx)
+    for k in range(K):
+        mstore.add(k + 1, kf_clouds[k % 5])
+    snaps = [KeyFrameSnapshot(kposes[k], kf_clouds[k % 5], k == 0) for k in range(K)]
+    tm = {}
+    for name, fn in (("host_clouds_ms", lambda: gen.generate(snaps, 0.1)), ("map_store_ms", lambda: mstore.generate(list(range(1, K + 1)), kposes, None, 0.1))):
+        fn()
+        ts = []
+        for _ in range(3):
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            res_map = fn()
+            ts.append(time.perf_counter() - t1)
+        tm[name] = 1e3 * float(np.median(ts))
+    tm.update(keyframes=K, points_in=int(sum(len(kf_clouds[k % 5]) for k in range(K))), points_out=int(len(res_map)))
+    out["map_cloud_200_keyframes"] = tm
+
     # ---- prefilter chain --------------------------------------------------------------------------------------------
     tp = []
     for _ in range(5):

@@ -95,3 +95,37 @@ def test_deskew_matches_oracle(n, w, period):
 
     c = np.random.default_rng(n).normal(0, 15, (n, 4)).astype(np.float32)
     np.testing.assert_array_equal(deskew(c, w, period), orc.deskew(c, w, period))
+
+
+def test_map_store_equals_the_host_cloud_generator():
+    """Keyframe clouds resident in HBM (mrgfe_map_store): same map as MapCloudGenerator.generate over host clouds for the same
+    keyframes in the same order, for changing poses, subsets, reordering, the far cut and skip_first_cloud."""
+    from mrg_slam_amd import KeyFrameSnapshot, MapCloudGenerator, MapCloudStore, synth
+
+    rng = np.random.default_rng(71)
+    clouds = {k: np.c_[rng.normal(0, 6, (1500 + 100 * k, 3)), rng.uniform(0, 1, 1500 + 100 * k)].astype(np.float32) for k in range(1, 7)}
+    clouds[7] = np.zeros((0, 4), np.float32)  # an empty keyframe
+    store, gen = MapCloudStore(), MapCloudGenerator()
+    assert store.bytes() == 0 and store.has(1) is None
+    for k, c in clouds.items():
+        store.add(k, c)
+        store.add(k, c)  # again: no-op
+    assert store.bytes() == 16 * sum(len(c) for c in clouds.values()) and store.has(3) == len(clouds[3])
+    with pytest.raises(RuntimeError):
+        store.add(3, clouds[4])  # same key, other size
+
+    def poses_for(keys, seed):
+        r = np.random.default_rng(seed)
+        return [synth.make_pose(r.normal(0, 4, 3), synth.rot_xyz(*r.normal(0, 0.3, 3))) for _ in keys]
+
+    cases = [([1, 2, 3, 4, 5, 6, 7], 0.5, 1, 10000.0, False), ([6, 2, 4], 0.25, 2, 9.0, False), ([1, 2, 3], 0.0, 1, 7.0, False), ([3, 1, 2, 5], 0.5, 1, 10000.0, True)]
+    for it, (keys, res, minp, far, skip) in enumerate(cases * 2):  # second round: same keyframes, new poses (after optimisation)
+        poses = poses_for(keys, 100 + it)
+        first = [k == keys[0] for k in keys]
+        got = store.generate(keys, poses, first, res, minp, far, skip)
+        exp = gen.generate([KeyFrameSnapshot(p, clouds[k], f) for k, p, f in zip(keys, poses, first)], res, minp, far, skip)
+        np.testing.assert_array_equal(got, exp)
+    assert store.generate([], [], None) is None                                      # no keyframes: nullptr in the reference
+    assert store.generate([7, 7], poses_for([7, 7], 1), None) is None                # nothing left from more than one keyframe
+    with pytest.raises(RuntimeError):
+        store.generate([1, 99], poses_for([1, 99], 2))                               # unknown keyframe
