@@ -107,7 +107,7 @@ struct mrgfe_batch {
 };
 
 // drop least recently used keyframes that the current batch does not reference until `need` more bytes fit
-void store_make_room(mrgfe_batch* b, size_t need)
+static void store_make_room(mrgfe_batch* b, size_t need)
 {
     size_t total = 0;
     for (auto& kv : b->store) total += kv.second->bytes();
@@ -116,14 +116,12 @@ void store_make_room(mrgfe_batch* b, size_t need)
         for (auto& kv : b->store)
             if (kv.second->last_epoch < b->epoch && kv.second->last_tick < best) { best = kv.second->last_tick; victim = kv.first; }
         if (!victim) return;  // everything left is in use: the store grows past its cap for this batch
-        {
-            auto it = b->store.find(victim);
-            total -= it->second->bytes();
-            it->second->cloud.release();
-            it->second->cov.release();
-            delete it->second;
-            b->store.erase(it);
-        }
+        auto it = b->store.find(victim);
+        total -= it->second->bytes();
+        it->second->cloud.release();
+        it->second->cov.release();
+        delete it->second;
+        b->store.erase(it);
     }
 }
 
