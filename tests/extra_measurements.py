@@ -220,6 +220,51 @@ def main():
         tf.append(time.perf_counter() - t1)
     out["odometry_frame_ms"]["prefilter_plus_scan_to_keyframe_small_gicp_ms"] = 1e3 * float(np.median(tf[2:]))
 
+    # ---- BASELINE config[4] shape on one GPU: two robots' odometry streams (threads / contexts A, B) while a loop-closure
+    #      batch stream (context C: 64 NDT candidates per call, keyframe store) keeps the GPU busy ---------------------------
+    import threading
+
+    def odo_stream(cx, frames, lat):
+        o = NdtHip(resolution=1.0, transformation_epsilon=0.1, maximum_iterations=64, ctx=cx)
+        o.setInputTarget(kf)
+        buf = torch.empty((len(raw[1]), 4), dtype=torch.float32, device="cuda:0")
+        for f in range(frames):
+            k = 1 + f % 4
+            t1 = time.perf_counter()
+            mm = prefilter_to_device(raw[k], buf.data_ptr(), len(raw[k]), ctx=cx)
+            o.setInputSourceDevice(buf.data_ptr(), mm)
+            o.align(synth.warm_guess(np.linalg.inv(poses[0]) @ poses[k], k))
+            lat.append(time.perf_counter() - t1)
+
+    def lc_stream(cx, stop, count):
+        lb = BatchMatcher(prm, cx)
+        while not stop.is_set():
+            lb.clear()
+            lt = lb.add_target(scans[0])
+            for b in range(64):
+                k = 1 + b % 4
+                lb.add_pair(lt, scans[k] if lb.has_cloud(500 + b) is None else None, synth.warm_guess(np.linalg.inv(poses[0]) @ poses[k], b), key=500 + b)
+            lb.align(-1.0)
+            count.append(1)
+
+    cA, cB, cC = Context(0), Context(0), Context(0)
+    alone = []
+    odo_stream(cA, 24, alone)
+    latA, latB, calls, stop = [], [], [], threading.Event()
+    tl = threading.Thread(target=lc_stream, args=(cC, stop, calls))
+    tl.start()
+    time.sleep(0.05)
+    t_begin = time.perf_counter()
+    ta, tb = threading.Thread(target=odo_stream, args=(cA, 60, latA)), threading.Thread(target=odo_stream, args=(cB, 60, latB))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    span = time.perf_counter() - t_begin
+    stop.set()
+    tl.join()
+    both = np.array(latA[4:] + latB[4:])
+    out["two_odometry_streams_plus_loop_closure_stream"] = {
+        "odometry_frame_alone_ms": 1e3 * float(np.median(alone[4:])), "odometry_frame_median_ms": 1e3 * float(np.median(both)), "odometry_frame_p95_ms": 1e3 * float(np.percentile(both, 95)),
+        "odometry_frames_per_s_both_robots": 120 / span, "loop_closure_calls_per_s_64_candidates": len(calls) / span}
+
     # ---- map cloud of 200 prefiltered keyframes (6.5 M points): host clouds every call vs the HBM map store -------------
     from mrg_slam_amd import KeyFrameSnapshot, MapCloudGenerator, MapCloudStore
 
