@@ -47,8 +47,10 @@ typedef struct mrgfe_reg mrgfe_reg; /* one registration object == one pcl::Regis
 enum mrgfe_method {
     MRGFE_NDT_HIP = 0,  /* replaces "NDT_OMP"  : pclomp::NormalDistributionsTransform (registrations.cpp:130-148) */
     MRGFE_GICP_HIP = 1, /* replaces "FAST_GICP": fast_gicp::FastGICP                  (registrations.cpp:55-63)   */
-    MRGFE_SMALL_GICP_HIP = 2 /* replaces "SMALL_GICP" (the YAML default, config/mrg_slam.yaml:100): small_gicp::RegistrationPCL
-                                (registrations.cpp:46-54): the same GICP factor perturbed on the right, small_gicp's LM schedule */
+    MRGFE_SMALL_GICP_HIP = 2, /* replaces "SMALL_GICP" (the YAML default, config/mrg_slam.yaml:100): small_gicp::RegistrationPCL
+                                 (registrations.cpp:46-54): the same GICP factor perturbed on the right, small_gicp's LM schedule */
+    MRGFE_VGICP_HIP = 3 /* replaces "FAST_VGICP" (fast_gicp::FastVGICP, registrations.cpp:76-84) and the reference's own GPU slot
+                           "FAST_VGICP_CUDA" (:65-75): voxelised GICP, target as a Gaussian voxel map of edge `resolution` */
 };
 /* reg_nn_search_method (registrations.cpp:140-146) */
 enum mrgfe_ndt_search { MRGFE_KDTREE = 0, MRGFE_DIRECT26 = 1, MRGFE_DIRECT7 = 2, MRGFE_DIRECT1 = 3 };
@@ -64,7 +66,7 @@ typedef struct mrgfe_reg_params {
     int    max_optimizer_iterations;        /* accepted, unused (pcl::GICP BFGS only)   "reg_max_optimizer_iterations"      */
     int    use_reciprocal_correspondences;  /* accepted, unused (pcl::ICP/GICP only)    "reg_use_reciprocal_correspondences"*/
     int    correspondence_randomness;       /* GICP k neighbours                        "reg_correspondence_randomness"     */
-    double resolution;                      /* NDT voxel size                           "reg_resolution"                    */
+    double resolution;                      /* NDT / VGICP voxel size                   "reg_resolution"                    */
     int    nn_search_method;                /* enum mrgfe_ndt_search                    "reg_nn_search_method"              */
     double step_size;                       /* NDT More-Thuente step_max (0.1)    */
     double outlier_ratio;                   /* NDT (0.55)                         */

@@ -42,19 +42,21 @@ GicpParams gicp_params_from(const mrgfe_reg_params& p)
     g.trans_eps = p.transformation_epsilon;
     g.rot_eps = p.rotation_epsilon;
     g.max_iterations = p.maximum_iterations;
-    g.variant = p.method == MRGFE_SMALL_GICP_HIP ? 1 : 0;
+    g.variant = p.method == MRGFE_SMALL_GICP_HIP ? 1 : p.method == MRGFE_VGICP_HIP ? 2 : 0;
+    g.voxel_resolution = p.resolution;
     return g;
 }
 
 int check_params(const mrgfe_reg_params* p)
 {
     if (!p) { set_error("NULL params"); return MRGFE_ERR_INVALID; }
-    if (p->method != MRGFE_NDT_HIP && p->method != MRGFE_GICP_HIP && p->method != MRGFE_SMALL_GICP_HIP) { set_error("unknown registration method %d", p->method); return MRGFE_ERR_INVALID; }
+    if (p->method != MRGFE_NDT_HIP && p->method != MRGFE_GICP_HIP && p->method != MRGFE_SMALL_GICP_HIP && p->method != MRGFE_VGICP_HIP) { set_error("unknown registration method %d", p->method); return MRGFE_ERR_INVALID; }
     if (p->method == MRGFE_NDT_HIP) {
         if (!(p->resolution > 0)) { set_error("resolution must be > 0"); return MRGFE_ERR_INVALID; }
         if (p->nn_search_method < 0 || p->nn_search_method > 3) { set_error("unknown nn_search_method %d", p->nn_search_method); return MRGFE_ERR_INVALID; }
     } else {
         if (p->correspondence_randomness < 4 || p->correspondence_randomness > 64) { set_error("correspondence_randomness must be in [4, 64]"); return MRGFE_ERR_INVALID; }
+        if (p->method == MRGFE_VGICP_HIP && !(p->resolution > 0)) { set_error("resolution must be > 0"); return MRGFE_ERR_INVALID; }
     }
     return MRGFE_OK;
 }

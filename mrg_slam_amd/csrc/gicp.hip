@@ -66,6 +66,84 @@ __global__ __launch_bounds__(256) void gicp_cov_kernel(const float4* __restrict_
     o[0] = out[0]; o[1] = out[1]; o[2] = out[2]; o[3] = out[4]; o[4] = out[5]; o[5] = out[8];
 }
 
+// ---- VGICP: GaussianVoxelMap of the target (fast_gicp::GaussianVoxelMap, ADDITIVE accumulation) -------------------------
+constexpr int kVoxRec = 10;  // per voxel: mean[3], covariance xx xy xz yy yz zz, number of points
+struct VoxGridDev {
+    double        res;
+    int32_t       cmin[3], dim[3];
+    uint32_t      n_cells;
+    const double* vox;  // n_cells records, dense in (z, y, x) of the voxel coordinates; points == 0: empty
+};
+// voxel_coord: floor(x / resolution - 0.5)
+__device__ __forceinline__ int vox_coord(double x, double res) { return static_cast<int>(floor(x / res - 0.5)); }
+__device__ __forceinline__ uint32_t vox_cell(const VoxGridDev& g, double x, double y, double z)
+{
+    if (!(isfinite(x) && isfinite(y) && isfinite(z))) return g.n_cells;
+    const int c[3] = {vox_coord(x, g.res) - g.cmin[0], vox_coord(y, g.res) - g.cmin[1], vox_coord(z, g.res) - g.cmin[2]};
+    if (c[0] < 0 || c[0] >= g.dim[0] || c[1] < 0 || c[1] >= g.dim[1] || c[2] < 0 || c[2] >= g.dim[2]) return g.n_cells;
+    return (static_cast<uint32_t>(c[2]) * g.dim[1] + c[1]) * g.dim[0] + c[0];
+}
+__global__ __launch_bounds__(256) void vox_key_kernel(const float4* __restrict__ pts, uint32_t n, VoxGridDev g, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    keys[i] = vox_cell(g, p.x, p.y, p.z);  // n_cells: non-finite, sorts behind every voxel
+    vals[i] = i;
+}
+// first / one-past-last position of every voxel's run in the sorted keys (first == 0xffffffff: empty voxel)
+__global__ __launch_bounds__(256) void vox_runs_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t n_cells, uint32_t* __restrict__ first, uint32_t* __restrict__ last)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = keys[i];
+    if (k >= n_cells) return;
+    if (i == 0 || keys[i - 1] != k) first[k] = i;
+    if (i + 1 == n || keys[i + 1] != k) last[k] = i + 1;
+}
+// one thread per voxel: sums in point order (the radix sort is stable), then the means
+__global__ __launch_bounds__(256) void vox_sums_kernel(const float4* __restrict__ pts, const double* __restrict__ cov6, const uint32_t* __restrict__ sorted_vals,
+                                                        const uint32_t* __restrict__ first, const uint32_t* __restrict__ last, uint32_t n_cells, double* __restrict__ vox)
+{
+#pragma clang fp contract(off)
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= n_cells) return;
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t cnt = 0;
+    if (first[c] != 0xffffffffu) {
+        for (uint32_t k = first[c]; k < last[c]; ++k) {
+            const uint32_t i = sorted_vals[k];
+            const float4   p = pts[i];
+            acc[0] += static_cast<double>(p.x); acc[1] += static_cast<double>(p.y); acc[2] += static_cast<double>(p.z);
+            const double* cv = cov6 + size_t(i) * 6;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) acc[3 + t] += cv[t];
+            ++cnt;
+        }
+        const double dn = static_cast<double>(cnt);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = acc[t] / dn;
+    }
+    double* o = vox + size_t(c) * kVoxRec;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) o[t] = acc[t];
+    o[9] = static_cast<double>(cnt);
+}
+// FastVGICP::update_correspondences, DIRECT1: the voxel trans * mean_A falls in (double), -1 if it is empty
+__global__ __launch_bounds__(256) void vox_corr_kernel(const float4* __restrict__ src, uint32_t n, VoxGridDev g, const double* __restrict__ T12, int32_t* __restrict__ corr)
+{
+#pragma clang fp contract(off)
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = src[i];
+    const double mA[3] = {a.x, a.y, a.z};
+    double tA[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) tA[r] = T12[r * 4 + 0] * mA[0] + T12[r * 4 + 1] * mA[1] + T12[r * 4 + 2] * mA[2] + T12[r * 4 + 3];
+    const uint32_t c = vox_cell(g, tA[0], tA[1], tA[2]);
+    corr[i] = (c < g.n_cells && g.vox[size_t(c) * kVoxRec + 9] > 0.0) ? static_cast<int32_t>(c) : -1;
+}
+
 struct GicpPose {
     double T[12];   // row-major 3x4, double
     float  Tf[12];  // trans.cast<float>()
@@ -137,8 +215,9 @@ __device__ __forceinline__ void gicp_linearize_block(const float4* __restrict__ 
         const float4  a = src[i];
         const int32_t j = corr[i];
         if (j >= 0) {
+            const bool    voxel = tgt == nullptr;  // VGICP: cov_tgt holds the voxel records (mean 3, covariance 6, points 1) and j names a voxel
             const double* cA = cov_src + size_t(i) * 6;
-            const double* cB = cov_tgt + size_t(j) * 6;
+            const double* cB = voxel ? cov_tgt + size_t(j) * kVoxRec + 3 : cov_tgt + size_t(j) * 6;
             const double A[9] = {cA[0], cA[1], cA[2], cA[1], cA[3], cA[4], cA[2], cA[4], cA[5]};
             const double R[9] = {pose.T[0], pose.T[1], pose.T[2], pose.T[4], pose.T[5], pose.T[6], pose.T[8], pose.T[9], pose.T[10]};
             double RC[9], Rt[9], RCR[9], M[9];
@@ -150,16 +229,29 @@ __device__ __forceinline__ void gicp_linearize_block(const float4* __restrict__ 
             double* mo = mahal + size_t(i) * 9;
 #pragma unroll
             for (int t = 0; t < 9; ++t) mo[t] = M[t];
-            const float4 b = tgt[j];
+            double mB[3], w = 1.0;
+            if (voxel) {
+                const double* v = cov_tgt + size_t(j) * kVoxRec;
+                mB[0] = v[0]; mB[1] = v[1]; mB[2] = v[2];
+                w = sqrt(v[9]);
+            } else {
+                const float4 b = tgt[j];
+                mB[0] = b.x; mB[1] = b.y; mB[2] = b.z;
+            }
             const double mA[3] = {a.x, a.y, a.z};
             double tA[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) tA[r] = pose.T[r * 4 + 0] * mA[0] + pose.T[r * 4 + 1] * mA[1] + pose.T[r * 4 + 2] * mA[2] + pose.T[r * 4 + 3];
-            const double err[3] = {static_cast<double>(b.x) - tA[0], static_cast<double>(b.y) - tA[1], static_cast<double>(b.z) - tA[2]};
+            const double err[3] = {mB[0] - tA[0], mB[1] - tA[1], mB[2] - tA[2]};
             double Me[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) Me[r] = M[r * 3 + 0] * err[0] + M[r * 3 + 1] * err[1] + M[r * 3 + 2] * err[2];
             vals[0] = err[0] * Me[0] + err[1] * Me[1] + err[2] * Me[2];
+            if (voxel) {  // every term of the voxelised cost carries w = sqrt(points in the voxel)
+                vals[0] = w * vals[0];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) Me[r] = w * Me[r];
+            }
             // J = [ skew(tA) | -I ], or for a right perturbation [ R skew(a) | -R ]
             double J[3][6] = {{0, -tA[2], tA[1], -1, 0, 0}, {tA[2], 0, -tA[0], 0, -1, 0}, {-tA[1], tA[0], 0, 0, 0, -1}};
             if (pose.right) {
@@ -179,6 +271,12 @@ __device__ __forceinline__ void gicp_linearize_block(const float4* __restrict__ 
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int cc = 0; cc < 6; ++cc) MJ[r][cc] = M[r * 3 + 0] * J[0][cc] + M[r * 3 + 1] * J[1][cc] + M[r * 3 + 2] * J[2][cc];
+            if (voxel) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < 6; ++cc) MJ[r][cc] = w * MJ[r][cc];
+            }
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
                 vals[1 + r] = J[0][r] * Me[0] + J[1][r] * Me[1] + J[2][r] * Me[2];
@@ -200,7 +298,7 @@ __global__ __launch_bounds__(256) void gicp_linearize_kernel(const float4* __res
 
 // compute_error: stored correspondences and Mahalanobis matrices, new pose
 __device__ __forceinline__ void gicp_error_block(const float4* __restrict__ src, uint32_t n, const float4* __restrict__ tgt, const GicpPose& pose, const int32_t* __restrict__ corr,
-                                                 const double* __restrict__ mahal, double* __restrict__ partials, uint32_t blk)
+                                                 const double* __restrict__ mahal, double* __restrict__ partials, uint32_t blk, const double* __restrict__ vox = nullptr)
 {
 #pragma clang fp contract(off)
     double vals[29];
@@ -210,17 +308,27 @@ __device__ __forceinline__ void gicp_error_block(const float4* __restrict__ src,
     if (i < n) {
         const int32_t j = corr[i];
         if (j >= 0) {
-            const float4  a = src[i], b = tgt[j];
+            const float4  a = src[i];
+            double mB[3], w = 1.0;
+            if (vox) {
+                const double* v = vox + size_t(j) * kVoxRec;
+                mB[0] = v[0]; mB[1] = v[1]; mB[2] = v[2];
+                w = sqrt(v[9]);
+            } else {
+                const float4 b = tgt[j];
+                mB[0] = b.x; mB[1] = b.y; mB[2] = b.z;
+            }
             const double* M = mahal + size_t(i) * 9;
             const double  mA[3] = {a.x, a.y, a.z};
             double tA[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) tA[r] = pose.T[r * 4 + 0] * mA[0] + pose.T[r * 4 + 1] * mA[1] + pose.T[r * 4 + 2] * mA[2] + pose.T[r * 4 + 3];
-            const double err[3] = {static_cast<double>(b.x) - tA[0], static_cast<double>(b.y) - tA[1], static_cast<double>(b.z) - tA[2]};
+            const double err[3] = {mB[0] - tA[0], mB[1] - tA[1], mB[2] - tA[2]};
             double Me[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) Me[r] = M[r * 3 + 0] * err[0] + M[r * 3 + 1] * err[1] + M[r * 3 + 2] * err[2];
             vals[0] = err[0] * Me[0] + err[1] * Me[1] + err[2] * Me[2];
+            if (vox) vals[0] = w * vals[0];
             vals[28] = 1.0;
         }
     }
@@ -228,9 +336,9 @@ __device__ __forceinline__ void gicp_error_block(const float4* __restrict__ src,
 }
 
 __global__ __launch_bounds__(256) void gicp_error_kernel(const float4* __restrict__ src, uint32_t n, const float4* __restrict__ tgt, GicpPose pose, const int32_t* __restrict__ corr,
-                                                          const double* __restrict__ mahal, double* __restrict__ partials)
+                                                          const double* __restrict__ mahal, double* __restrict__ partials, const double* __restrict__ vox)
 {
-    gicp_error_block(src, n, tgt, pose, corr, mahal, partials, blockIdx.x);
+    gicp_error_block(src, n, tgt, pose, corr, mahal, partials, blockIdx.x, vox);
 }
 
 __device__ __forceinline__ void gicp_reduce_record(const double* __restrict__ partials, uint32_t nblk, double* __restrict__ out)
@@ -288,6 +396,24 @@ __global__ __launch_bounds__(256) void gicp_corr_batch_kernel(const GicpPairDev*
     gicp_corr_query(s_grid, pr.src, pr.n, ev.pose, ev.thr2, pr.corr, blockIdx.x);
 }
 
+__global__ __launch_bounds__(256) void vox_corr_batch_kernel(const GicpPairDev* __restrict__ pairs, const GicpEvalDev* __restrict__ evals, const VoxGridDev* __restrict__ vgrids)
+{
+#pragma clang fp contract(off)
+    const uint32_t    pi = evals[blockIdx.y].order[0];
+    const GicpPairDev pr = pairs[pi];
+    const uint32_t    i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= pr.n) return;
+    const VoxGridDev g = vgrids[pr.target];
+    const double*    T = evals[pi].pose.T;
+    const float4     a = pr.src[i];
+    const double     mA[3] = {a.x, a.y, a.z};
+    double tA[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) tA[r] = T[r * 4 + 0] * mA[0] + T[r * 4 + 1] * mA[1] + T[r * 4 + 2] * mA[2] + T[r * 4 + 3];
+    const uint32_t c = vox_cell(g, tA[0], tA[1], tA[2]);
+    pr.corr[i] = (c < g.n_cells && g.vox[size_t(c) * kVoxRec + 9] > 0.0) ? static_cast<int32_t>(c) : -1;
+}
+
 __global__ __launch_bounds__(256) void gicp_linearize_batch_kernel(const GicpPairDev* __restrict__ pairs, const GicpEvalDev* __restrict__ evals, double* __restrict__ partials)
 {
     const uint32_t    pi = evals[blockIdx.y].order[0];
@@ -301,7 +427,7 @@ __global__ __launch_bounds__(256) void gicp_error_batch_kernel(const GicpPairDev
     const uint32_t    pi = evals[blockIdx.y].order[1];
     const GicpPairDev pr = pairs[pi];
     if (blockIdx.x * 256u >= pr.n) return;
-    gicp_error_block(pr.src, pr.n, pr.tgt, evals[pi].pose, pr.corr, pr.mahal, partials + size_t(pr.part_off) * kGicpStride, blockIdx.x);
+    gicp_error_block(pr.src, pr.n, pr.tgt, evals[pi].pose, pr.corr, pr.mahal, partials + size_t(pr.part_off) * kGicpStride, blockIdx.x, pr.tgt ? nullptr : pr.cov_tgt);
 }
 
 // one workgroup per pair: the same fixed-order sum as gicp_reduce_kernel, written to (pinned host) results[pair][32]
@@ -418,6 +544,7 @@ GicpEngine::~GicpEngine()
     cov_grid_.release();
     d_knn_i_.release(); d_knn_d_.release();
     d_tgt_cov_.release(); d_src_cov_.release(); d_corr_.release(); d_mahal_.release(); d_partial_.release(); d_T_.release();
+    d_vox_.release(); d_vox_runs_.release();
 }
 
 int GicpEngine::set_target(const void* d, size_t n)
@@ -455,6 +582,86 @@ int GicpEngine::compute_covariances(const float4* d_pts, size_t n, DevBuf& out, 
     return gicp_compute_covariances(ctx_, prm_.k_correspondences, d_pts, n, out, grid, d_knn_i_, d_knn_d_);
 }
 
+void GicpEngine::voxel_grid(double* res, int32_t cmin[3], int32_t dim[3], uint32_t* n_cells) const
+{
+    *res = vox_res_;
+    for (int a = 0; a < 3; ++a) { cmin[a] = vox_cmin_[a]; dim[a] = vox_dim_[a]; }
+    *n_cells = vox_cells_;
+}
+
+// fast_gicp::GaussianVoxelMap::create_voxelmap over the target and its covariances
+int GicpEngine::build_voxelmap()
+{
+    vox_valid_ = false;
+    vox_res_ = prm_.voxel_resolution;
+    vox_cells_ = vox_occupied_ = 0;
+    for (int a = 0; a < 3; ++a) { vox_cmin_[a] = 0; vox_dim_[a] = 1; }
+    if (!(vox_res_ > 0)) { set_error("VGICP: resolution must be > 0"); return MRGFE_ERR_INVALID; }
+    hipStream_t st = ctx_->stream;
+    if (n_tgt_ == 0) {
+        MRGFE_TRY(d_vox_.ensure(sizeof(double) * kVoxRec));
+        MRGFE_HIP_CHECK(hipMemsetAsync(d_vox_.p, 0, sizeof(double) * kVoxRec, st));
+        vox_cells_ = 1;
+        vox_valid_ = true;
+        return MRGFE_OK;
+    }
+    if (n_tgt_ > 0x7fffffffu) { set_error("VGICP: cloud too large"); return MRGFE_ERR_INVALID; }
+    const uint32_t nn = static_cast<uint32_t>(n_tgt_);
+    SliceTable tab;
+    tab.build(&nn, 1);
+    DevBuf &ds = ctx_->scratch[0], &dbb = ctx_->scratch[1], &dk = ctx_->scratch[2], &dv = ctx_->scratch[3], &dkt = ctx_->scratch[4], &dvt = ctx_->scratch[5], &dh = ctx_->scratch[6];
+    MRGFE_TRY(ds.ensure(sizeof(Slice) * 2 + sizeof(void*)));
+    const void* cp = d_tgt_;
+    MRGFE_HIP_CHECK(hipMemcpyAsync(ds.p, tab.h.data(), sizeof(Slice), hipMemcpyHostToDevice, st));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(ds.as<char>() + 2 * sizeof(Slice), &cp, sizeof(void*), hipMemcpyHostToDevice, st));
+    MRGFE_TRY(dbb.ensure(sizeof(BBox) * (tab.total_blks + 1)));
+    BBox* d_part = dbb.as<BBox>();
+    BBox* d_out = d_part + tab.total_blks;
+    MRGFE_TRY(bounding_boxes(ctx_, reinterpret_cast<const float4* const*>(ds.as<char>() + 2 * sizeof(Slice)), ds.as<Slice>(), tab, d_part, d_out));
+    BBox bb;
+    MRGFE_HIP_CHECK(hipMemcpyAsync(&bb, d_out, sizeof(BBox), hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    if (bb.n_finite == 0) {
+        MRGFE_TRY(d_vox_.ensure(sizeof(double) * kVoxRec));
+        MRGFE_HIP_CHECK(hipMemsetAsync(d_vox_.p, 0, sizeof(double) * kVoxRec, st));
+        vox_cells_ = 1;
+        vox_valid_ = true;
+        return MRGFE_OK;
+    }
+    double cells = 1;
+    for (int a = 0; a < 3; ++a) {  // the voxel coordinate is monotonic in x: the corner voxels come from the bounding box
+        const int lo = static_cast<int>(std::floor(static_cast<double>(bb.mn[a]) / vox_res_ - 0.5)), hi = static_cast<int>(std::floor(static_cast<double>(bb.mx[a]) / vox_res_ - 0.5));
+        vox_cmin_[a] = lo;
+        vox_dim_[a] = hi - lo + 1;
+        cells *= static_cast<double>(vox_dim_[a]);
+    }
+    if (cells > double(1u << 24)) { set_error("VGICP: the target needs %.0f voxels of %.3f m (more than 2^24)", cells, vox_res_); return MRGFE_ERR_OVERFLOW; }
+    vox_cells_ = static_cast<uint32_t>(cells);
+    MRGFE_TRY(dk.ensure(n_tgt_ * 4)); MRGFE_TRY(dv.ensure(n_tgt_ * 4)); MRGFE_TRY(dkt.ensure(n_tgt_ * 4)); MRGFE_TRY(dvt.ensure(n_tgt_ * 4));
+    MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + 1)));
+    MRGFE_TRY(d_vox_.ensure(sizeof(double) * kVoxRec * size_t(vox_cells_)));
+    MRGFE_TRY(d_vox_runs_.ensure(sizeof(uint32_t) * 2 * size_t(vox_cells_)));
+    VoxGridDev g;
+    g.res = vox_res_;
+    for (int a = 0; a < 3; ++a) { g.cmin[a] = vox_cmin_[a]; g.dim[a] = vox_dim_[a]; }
+    g.n_cells = vox_cells_;
+    g.vox = d_vox_.as<double>();
+    hipLaunchKernelGGL(vox_key_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, d_tgt_, nn, g, dk.as<uint32_t>(), dv.as<uint32_t>());
+    int key_bits = 1;
+    while (key_bits < 32 && (uint64_t(1) << key_bits) <= vox_cells_) ++key_bits;
+    uint32_t *sk, *sv;
+    MRGFE_TRY(radix_sort_pairs(ctx_, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), ds.as<Slice>(), tab, key_bits, dh.as<uint32_t>(), &sk, &sv));
+    uint32_t* d_first = d_vox_runs_.as<uint32_t>();
+    uint32_t* d_last = d_first + vox_cells_;
+    MRGFE_HIP_CHECK(hipMemsetAsync(d_first, 0xff, sizeof(uint32_t) * size_t(vox_cells_), st));
+    hipLaunchKernelGGL(vox_runs_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, sk, nn, vox_cells_, d_first, d_last);
+    hipLaunchKernelGGL(vox_sums_kernel, dim3((vox_cells_ + 255) / 256), dim3(256), 0, st, d_tgt_, d_tgt_cov_.as<double>(), sv, d_first, d_last, vox_cells_, d_vox_.as<double>());
+    MRGFE_HIP_CHECK(hipGetLastError());
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));  // tab's host table was the source of an async copy
+    vox_valid_ = true;
+    return MRGFE_OK;
+}
+
 int GicpEngine::prepare_target()
 {
     if (!d_tgt_ && n_tgt_) { set_error("GICP: no target"); return MRGFE_ERR_STATE; }
@@ -464,7 +671,9 @@ int GicpEngine::prepare_target()
         MRGFE_TRY(compute_covariances(d_tgt_, n_tgt_, d_tgt_cov_, tgt_grid_));
         if (n_tgt_ == 0) MRGFE_TRY(tgt_grid_.build(ctx_, d_tgt_, 0, 1.0f));
         tgt_cov_valid_ = tgt_grid_valid_ = true;
+        vox_valid_ = false;
     }
+    if (prm_.variant == 2 && !vox_valid_) MRGFE_TRY(build_voxelmap());
     return MRGFE_OK;
 }
 
@@ -510,9 +719,22 @@ int GicpEngine::run_linearize(const double T[16], bool, double H[36], double b[6
     MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev0, st));
     const GicpPose pose = make_pose(T, prm_.variant);
     constexpr uint32_t per_blk = 256u / kGicpGroup;
-    hipLaunchKernelGGL(gicp_corr_kernel, dim3((n + per_blk - 1) / per_blk), dim3(256), 0, st, tgt_grid_.dev2(), d_src_, n, pose, prm_.max_corr_dist * prm_.max_corr_dist, d_corr_.as<int32_t>());
-    hipLaunchKernelGGL(gicp_linearize_kernel, dim3(nblk), dim3(256), 0, st, d_src_, n, d_tgt_, d_src_cov_.as<double>(), d_tgt_cov_.as<double>(), pose, d_corr_.as<int32_t>(),
-                       d_mahal_.as<double>(), d_part);
+    if (prm_.variant == 2) {
+        VoxGridDev g;
+        g.res = vox_res_;
+        for (int a = 0; a < 3; ++a) { g.cmin[a] = vox_cmin_[a]; g.dim[a] = vox_dim_[a]; }
+        g.n_cells = vox_cells_;
+        g.vox = d_vox_.as<double>();
+        MRGFE_TRY(d_T_.ensure(sizeof(double) * 12));
+        MRGFE_HIP_CHECK(hipMemcpyAsync(d_T_.p, pose.T, sizeof(double) * 12, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(vox_corr_kernel, dim3(nblk), dim3(256), 0, st, d_src_, n, g, d_T_.as<double>(), d_corr_.as<int32_t>());
+        hipLaunchKernelGGL(gicp_linearize_kernel, dim3(nblk), dim3(256), 0, st, d_src_, n, static_cast<const float4*>(nullptr), d_src_cov_.as<double>(), d_vox_.as<double>(), pose,
+                           d_corr_.as<int32_t>(), d_mahal_.as<double>(), d_part);
+    } else {
+        hipLaunchKernelGGL(gicp_corr_kernel, dim3((n + per_blk - 1) / per_blk), dim3(256), 0, st, tgt_grid_.dev2(), d_src_, n, pose, prm_.max_corr_dist * prm_.max_corr_dist, d_corr_.as<int32_t>());
+        hipLaunchKernelGGL(gicp_linearize_kernel, dim3(nblk), dim3(256), 0, st, d_src_, n, d_tgt_, d_src_cov_.as<double>(), d_tgt_cov_.as<double>(), pose, d_corr_.as<int32_t>(),
+                           d_mahal_.as<double>(), d_part);
+    }
     MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev1, st));
     hipLaunchKernelGGL(gicp_reduce_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, d_res);
     MRGFE_HIP_CHECK(hipGetLastError());
@@ -543,7 +765,8 @@ int GicpEngine::run_error(const double T[16], double* err)
     const uint32_t n = static_cast<uint32_t>(n_src_), nblk = (n + 255) / 256;
     double* d_part = d_partial_.as<double>();
     double* d_res = d_part + size_t(nblk) * kGicpStride;
-    hipLaunchKernelGGL(gicp_error_kernel, dim3(nblk), dim3(256), 0, st, d_src_, n, d_tgt_, make_pose(T, prm_.variant), d_corr_.as<int32_t>(), d_mahal_.as<double>(), d_part);
+    hipLaunchKernelGGL(gicp_error_kernel, dim3(nblk), dim3(256), 0, st, d_src_, n, d_tgt_, make_pose(T, prm_.variant), d_corr_.as<int32_t>(), d_mahal_.as<double>(), d_part,
+                       prm_.variant == 2 ? d_vox_.as<const double>() : static_cast<const double*>(nullptr));
     hipLaunchKernelGGL(gicp_reduce_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, d_res);
     MRGFE_HIP_CHECK(hipGetLastError());
     double r[kGicpStride];
@@ -740,10 +963,18 @@ int GicpBatch::align_all(std::vector<GicpEngine*>& engines, std::vector<GicpBatc
     if (!done_) MRGFE_HIP_CHECK(hipEventCreateWithFlags(&done_, hipEventDisableTiming));
     // targets: covariances + correspondence grid once each; sources: covariances cloud by cloud
     std::vector<NnGrid2Dev> h_grids(engines.size());
+    std::vector<VoxGridDev> h_vgrids(engines.size());
+    bool voxel = false;  // VGICP: the targets are voxel maps, the correspondence search is a table lookup
     for (size_t t = 0; t < engines.size(); ++t) {
         if (!engines[t]) continue;
         MRGFE_TRY(engines[t]->prepare_target());
         h_grids[t] = engines[t]->target_grid();
+        voxel = engines[t]->params().variant == 2;
+        if (voxel) {
+            VoxGridDev& g = h_vgrids[t];
+            engines[t]->voxel_grid(&g.res, g.cmin, g.dim, &g.n_cells);
+            g.vox = engines[t]->voxel_records();
+        }
     }
     // Source covariances: one cloud is a chain of small launches and a few host round trips (bounding box, cell-size
     // passes, sorts, k-NN, covariance) that leaves most of the chip idle, so `lanes` host threads work through the clouds
@@ -804,7 +1035,9 @@ int GicpBatch::align_all(std::vector<GicpEngine*>& engines, std::vector<GicpBatc
         MRGFE_TRY(p.corr.ensure(std::max<size_t>(p.n, 1) * 4));
         MRGFE_TRY(p.mahal.ensure(std::max<size_t>(p.n, 1) * 72));
         GicpPairDev d;
-        d.src = p.d_src; d.tgt = e->target_points(); d.cov_src = (p.ext_cov ? *p.ext_cov : p.cov).as<double>(); d.cov_tgt = e->target_covariances();
+        d.src = p.d_src; d.cov_src = (p.ext_cov ? *p.ext_cov : p.cov).as<double>();
+        d.tgt = voxel ? nullptr : e->target_points();  // tgt == nullptr tells the linearize / error kernels that cov_tgt holds voxel records
+        d.cov_tgt = voxel ? e->voxel_records() : e->target_covariances();
         d.corr = p.corr.as<int32_t>(); d.mahal = p.mahal.as<double>();
         d.n = p.n; d.part_off = part; d.target = static_cast<uint32_t>(p.target); d.pad = 0;
         part += (p.n + 255u) / 256u;
@@ -813,13 +1046,14 @@ int GicpBatch::align_all(std::vector<GicpEngine*>& engines, std::vector<GicpBatc
         p.ctl.start(e->params(), p.guess, p.n);
     }
     MRGFE_TRY(d_pairs_.ensure(sizeof(GicpPairDev) * P));
-    MRGFE_TRY(d_grids_.ensure(sizeof(NnGrid2Dev) * std::max<size_t>(engines.size(), 1)));
+    MRGFE_TRY(d_grids_.ensure((voxel ? sizeof(VoxGridDev) : sizeof(NnGrid2Dev)) * std::max<size_t>(engines.size(), 1)));
     MRGFE_TRY(d_evals_.ensure(sizeof(GicpEvalDev) * P));
     MRGFE_TRY(d_partials_.ensure(sizeof(double) * kGicpStride * std::max<uint32_t>(part, 1)));
     MRGFE_TRY(h_evals_.ensure(sizeof(GicpEvalDev) * P));
     MRGFE_TRY(h_results_.ensure(sizeof(double) * kGicpStride * P));
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_pairs_.p, h_pairs.data(), sizeof(GicpPairDev) * P, hipMemcpyHostToDevice, st));
-    MRGFE_HIP_CHECK(hipMemcpyAsync(d_grids_.p, h_grids.data(), sizeof(NnGrid2Dev) * h_grids.size(), hipMemcpyHostToDevice, st));
+    if (voxel) MRGFE_HIP_CHECK(hipMemcpyAsync(d_grids_.p, h_vgrids.data(), sizeof(VoxGridDev) * h_vgrids.size(), hipMemcpyHostToDevice, st));
+    else       MRGFE_HIP_CHECK(hipMemcpyAsync(d_grids_.p, h_grids.data(), sizeof(NnGrid2Dev) * h_grids.size(), hipMemcpyHostToDevice, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));  // h_pairs / h_grids are locals
     GicpEvalDev* he = h_evals_.as<GicpEvalDev>();
     double*      hr = h_results_.as<double>();
@@ -848,7 +1082,8 @@ int GicpBatch::align_all(std::vector<GicpEngine*>& engines, std::vector<GicpBatc
             const GicpEvalDev* de = d_evals_.as<GicpEvalDev>();
             if (n_lin) {
                 constexpr uint32_t per_blk = 256u / kGicpGroup;
-                hipLaunchKernelGGL(gicp_corr_batch_kernel, dim3((max_n + per_blk - 1) / per_blk, n_lin), dim3(256), 0, st, dp, de, d_grids_.as<NnGrid2Dev>());
+                if (voxel) hipLaunchKernelGGL(vox_corr_batch_kernel, dim3((max_n + 255) / 256, n_lin), dim3(256), 0, st, dp, de, d_grids_.as<VoxGridDev>());
+                else       hipLaunchKernelGGL(gicp_corr_batch_kernel, dim3((max_n + per_blk - 1) / per_blk, n_lin), dim3(256), 0, st, dp, de, d_grids_.as<NnGrid2Dev>());
                 hipLaunchKernelGGL(gicp_linearize_batch_kernel, dim3((max_n + 255) / 256, n_lin), dim3(256), 0, st, dp, de, d_partials_.as<double>());
             }
             if (n_err) hipLaunchKernelGGL(gicp_error_batch_kernel, dim3((max_n + 255) / 256, n_err), dim3(256), 0, st, dp, de, d_partials_.as<double>());

@@ -22,6 +22,10 @@ struct GicpParams {
     // lambda 1e-3, factor 10, at most 10 inner trials, a trial accepted iff its error does not exceed the current one;
     // converged iff |d_rot| <= rot_eps and |d_trans| <= trans_eps
     int    variant = 0;
+    // variant 2, fast_gicp::FastVGICP (registrations.cpp:76-84; the algorithm of the FAST_VGICP_CUDA slot :65-75): the target is
+    // a GaussianVoxelMap of edge voxel_resolution (mean of the points and of their covariances per voxel), a source point
+    // corresponds to the voxel its transformed position falls in, terms weighted by sqrt(points in the voxel); fast_gicp's LM
+    double voxel_resolution = 1.0;
     double sg_init_lambda = 1e-3, sg_lambda_factor = 10.0;
     int    sg_max_inner_iterations = 10;
 };
@@ -46,6 +50,10 @@ class GicpEngine {
     size_t            target_size() const { return n_tgt_; }
     const double*     target_covariances() const { return d_tgt_cov_.as<double>(); }
     const NnGrid2Dev& target_grid() const { return tgt_grid_.dev2(); }
+    // VGICP: the voxel records (10 doubles per voxel) and the voxel grid geometry, valid after prepare_target()
+    const double*     voxel_records() const { return d_vox_.as<double>(); }
+    void              voxel_grid(double* res, int32_t cmin[3], int32_t dim[3], uint32_t* n_cells) const;
+    uint32_t          voxels_occupied() const { return vox_occupied_; }
     NnGrid&           scratch_grid() { return cov_grid_; }
     const GicpParams& params() const { return prm_; }
 
@@ -70,6 +78,12 @@ class GicpEngine {
     DevBuf d_knn_i_, d_knn_d_;
     bool   tgt_grid_valid_ = false, tgt_cov_valid_ = false, src_cov_valid_ = false;
     DevBuf d_tgt_cov_, d_src_cov_, d_corr_, d_mahal_, d_partial_, d_T_;
+    DevBuf d_vox_, d_vox_runs_;  // VGICP voxel records; first / last run positions (build scratch)
+    bool     vox_valid_ = false;
+    double   vox_res_ = 1.0;
+    int32_t  vox_cmin_[3] = {0, 0, 0}, vox_dim_[3] = {1, 1, 1};
+    uint32_t vox_cells_ = 0, vox_occupied_ = 0;
+    int build_voxelmap();
     float  final_[16];
     double final_hessian_[36];
     bool   converged_ = false;

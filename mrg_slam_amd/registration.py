@@ -17,7 +17,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import GICP_HIP, NDT_HIP, SEARCH, SMALL_GICP_HIP, Context, PairResult, RegParams, check, default_context, lib
+from ._lib import GICP_HIP, NDT_HIP, SEARCH, SMALL_GICP_HIP, VGICP_HIP, Context, PairResult, RegParams, check, default_context, lib
 
 _fp = C.POINTER(C.c_float)
 _dp = C.POINTER(C.c_double)
@@ -227,19 +227,40 @@ class SmallGicpHip(GicpHip):
         HipRegistration.__init__(self, p, ctx)
 
 
+class VgicpHip(GicpHip):
+    """registration_method "VGICP_HIP": drop-in for the FAST_VGICP branch (registrations.cpp:76-84) and for the reference's own
+    GPU slot FAST_VGICP_CUDA (:65-75): fast_gicp's voxelised GICP, the target as a Gaussian voxel map of edge ``resolution``."""
+
+    METHOD = VGICP_HIP
+
+    def __init__(self, resolution=1.0, correspondence_randomness=20, transformation_epsilon=0.01, rotation_epsilon=2e-3, maximum_iterations=64, num_threads=0,
+                 ctx: Context | None = None):
+        p = default_params(VGICP_HIP)
+        p.resolution = resolution
+        p.correspondence_randomness = correspondence_randomness
+        p.transformation_epsilon = transformation_epsilon
+        p.rotation_epsilon = rotation_epsilon
+        p.maximum_iterations = maximum_iterations
+        p.num_threads = num_threads
+        HipRegistration.__init__(self, p, ctx)
+
+
 def select_registration_method(params: dict, ctx: Context | None = None) -> HipRegistration:
     """Python mirror of mrg_slam::select_registration_method (registrations.cpp:28-152) for the HIP back ends.
 
     ``params`` carries the reference's ROS parameter names (registration_method, reg_num_threads,
     reg_transformation_epsilon, reg_maximum_iterations, reg_max_correspondence_distance, reg_correspondence_randomness,
     reg_resolution, reg_nn_search_method).  "NDT_HIP" (and, to stay drop-in, "NDT_OMP"/"NDT") select :class:`NdtHip`;
-    "GICP_HIP" / "FAST_GICP" select :class:`GicpHip`, "SMALL_GICP_HIP" / "SMALL_GICP" :class:`SmallGicpHip`.  Like the
-    reference, an unknown name falls through to NDT.
+    "GICP_HIP" / "FAST_GICP" select :class:`GicpHip`, "SMALL_GICP_HIP" / "SMALL_GICP" :class:`SmallGicpHip`, "VGICP_HIP" /
+    "FAST_VGICP" / "FAST_VGICP_CUDA" :class:`VgicpHip`.  Like the reference, an unknown name falls through to NDT.
     """
     method = str(params.get("registration_method", "FAST_GICP"))
     eps = float(params.get("reg_transformation_epsilon", 0.01))
     iters = int(params.get("reg_maximum_iterations", 64))
     threads = int(params.get("reg_num_threads", 0))
+    if method in ("VGICP_HIP", "FAST_VGICP", "FAST_VGICP_CUDA"):
+        return VgicpHip(float(params.get("reg_resolution", 1.0)), int(params.get("reg_correspondence_randomness", 20)), eps, maximum_iterations=iters,
+                        num_threads=threads, ctx=ctx)
     if method in ("SMALL_GICP_HIP", "SMALL_GICP"):
         return SmallGicpHip(int(params.get("reg_correspondence_randomness", 20)), float(params.get("reg_max_correspondence_distance", 2.0)), eps,
                             maximum_iterations=iters, num_threads=threads, ctx=ctx)

@@ -24,6 +24,7 @@ void FastGicp::set_target(const float* xyzi, int n)
     target.assign(xyzi, xyzi + static_cast<size_t>(n) * 4);
     target_covs_valid = false;
     target_grid_valid_ = false;
+    voxelmap_valid_ = false;
 }
 void FastGicp::set_source(const float* xyzi, int n)
 {
@@ -70,11 +71,42 @@ void FastGicp::calculate_covariances(const std::vector<float>& cloud, std::vecto
     }
 }
 
+// fast_gicp::GaussianVoxelMap: voxel_coord, create_voxelmap with VoxelAccumulationMode::ADDITIVE
+FastGicp::Coord FastGicp::voxel_coord(const double x[3]) const
+{
+    Coord c;
+    for (int a = 0; a < 3; ++a) c.c[a] = static_cast<int>(std::floor(x[a] / voxel_resolution - 0.5));
+    return c;
+}
+void FastGicp::build_voxelmap()
+{
+    voxel_index_.clear();
+    voxels_.clear();
+    const int n = static_cast<int>(target.size() / 4);
+    for (int i = 0; i < n; ++i) {  // point order: the sums of a voxel are sequential in the point index
+        const double x[3] = {target[4 * static_cast<size_t>(i)], target[4 * static_cast<size_t>(i) + 1], target[4 * static_cast<size_t>(i) + 2]};
+        if (!std::isfinite(x[0]) || !std::isfinite(x[1]) || !std::isfinite(x[2])) continue;
+        const Coord c = voxel_coord(x);
+        auto it = voxel_index_.find(c);
+        if (it == voxel_index_.end()) { it = voxel_index_.emplace(c, static_cast<int>(voxels_.size())).first; voxels_.emplace_back(); }
+        Voxel& v = voxels_[it->second];
+        v.num_points += 1;
+        for (int a = 0; a < 3; ++a) v.mean[a] += x[a];
+        for (int t = 0; t < 9; ++t) v.cov[t] += target_covs[static_cast<size_t>(i) * 9 + t];
+    }
+    for (Voxel& v : voxels_) {
+        for (int a = 0; a < 3; ++a) v.mean[a] /= v.num_points;
+        for (int t = 0; t < 9; ++t) v.cov[t] /= v.num_points;
+    }
+    voxelmap_valid_ = true;
+}
+
 void FastGicp::ensure_covs()
 {
     if (!source_covs_valid) { calculate_covariances(source, source_covs); source_covs_valid = true; }
     if (!target_covs_valid) { calculate_covariances(target, target_covs); target_covs_valid = true; }
     if (!target_grid_valid_) { target_grid_.build(target.data(), static_cast<int>(target.size() / 4), 1.0f); target_grid_valid_ = true; }
+    if (variant == 2 && !voxelmap_valid_) build_voxelmap();
 }
 
 void FastGicp::get_covariances(int which, double* out) const
@@ -107,12 +139,23 @@ double FastGicp::linearize(const double T[16], double H[36], double b[6], int* n
         // trans_f * Vector4f(x,y,z,1): Eigen 4x4 * 4x1 float product, accumulated left to right
         float q[3];
         for (int r = 0; r < 3; ++r) { float s = Tf[r * 4 + 0] * a[0]; s = s + Tf[r * 4 + 1] * a[1]; s = s + Tf[r * 4 + 2] * a[2]; q[r] = s + Tf[r * 4 + 3]; }
-        float sqd;
-        int j = target_grid_.nearest(q[0], q[1], q[2], sqd);
-        if (j < 0 || !(static_cast<double>(sqd) < thr2)) continue;
+        int j;
+        if (variant == 2) {  // FastVGICP::update_correspondences, DIRECT1: the voxel of trans * mean_A (double)
+            const double mA[3] = {a[0], a[1], a[2]};
+            double tA[3];
+            for (int r = 0; r < 3; ++r) tA[r] = T[r * 4 + 0] * mA[0] + T[r * 4 + 1] * mA[1] + T[r * 4 + 2] * mA[2] + T[r * 4 + 3];
+            if (!std::isfinite(tA[0]) || !std::isfinite(tA[1]) || !std::isfinite(tA[2])) continue;
+            auto it = voxel_index_.find(voxel_coord(tA));
+            if (it == voxel_index_.end()) continue;
+            j = it->second;
+        } else {
+            float sqd;
+            j = target_grid_.nearest(q[0], q[1], q[2], sqd);
+            if (j < 0 || !(static_cast<double>(sqd) < thr2)) continue;
+        }
         correspondences_[i] = j;
         const double* cA = &source_covs[static_cast<size_t>(i) * 9];
-        const double* cB = &target_covs[static_cast<size_t>(j) * 9];
+        const double* cB = variant == 2 ? voxels_[j].cov : &target_covs[static_cast<size_t>(j) * 9];
         double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
         double RC[9], Rt[9], RCR[9];
         mul3(R, cA, RC);
@@ -130,14 +173,25 @@ double FastGicp::linearize(const double T[16], double H[36], double b[6], int* n
         if (j < 0) continue;
         ++corr;
         const double mean_A[3] = {source[4 * static_cast<size_t>(i)], source[4 * static_cast<size_t>(i) + 1], source[4 * static_cast<size_t>(i) + 2]};
-        const double mean_B[3] = {target[4 * static_cast<size_t>(j)], target[4 * static_cast<size_t>(j) + 1], target[4 * static_cast<size_t>(j) + 2]};
+        double mean_B[3] = {0, 0, 0}, w = 1.0;
+        if (variant == 2) {
+            for (int a = 0; a < 3; ++a) mean_B[a] = voxels_[j].mean[a];
+            w = std::sqrt(static_cast<double>(voxels_[j].num_points));
+        } else {
+            for (int a = 0; a < 3; ++a) mean_B[a] = target[4 * static_cast<size_t>(j) + a];
+        }
         double tA[3];
         isometry_apply_d(T, mean_A, tA);
         const double  err[3] = {mean_B[0] - tA[0], mean_B[1] - tA[1], mean_B[2] - tA[2]};
         const double* M = &mahalanobis_[static_cast<size_t>(i) * 9];
         double Me[3];
         for (int r = 0; r < 3; ++r) Me[r] = M[r * 3 + 0] * err[0] + M[r * 3 + 1] * err[1] + M[r * 3 + 2] * err[2];
-        sum_errors += err[0] * Me[0] + err[1] * Me[1] + err[2] * Me[2];
+        if (variant == 2) {  // every term of the voxelised cost carries w = sqrt(points in the voxel)
+            sum_errors += w * (err[0] * Me[0] + err[1] * Me[1] + err[2] * Me[2]);
+            for (int r = 0; r < 3; ++r) Me[r] = w * Me[r];
+        } else {
+            sum_errors += err[0] * Me[0] + err[1] * Me[1] + err[2] * Me[2];
+        }
         if (!H || !b) continue;
         // J = [ skew(tA) | -I ]  (3 x 6)
         double J[3][6] = {{0, -tA[2], tA[1], -1, 0, 0}, {tA[2], 0, -tA[0], 0, -1, 0}, {-tA[1], tA[0], 0, 0, 0, -1}};
@@ -154,6 +208,8 @@ double FastGicp::linearize(const double T[16], double H[36], double b[6], int* n
         }
         double MJ[3][6];
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 6; ++c) MJ[r][c] = M[r * 3 + 0] * J[0][c] + M[r * 3 + 1] * J[1][c] + M[r * 3 + 2] * J[2][c];
+        if (variant == 2)
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 6; ++c) MJ[r][c] = w * MJ[r][c];
         double* Ht = &Hs[static_cast<size_t>(omp_get_thread_num()) * 36];
         double* bt = &bs[static_cast<size_t>(omp_get_thread_num()) * 6];
         for (int r = 0; r < 6; ++r) {
@@ -182,14 +238,21 @@ double FastGicp::compute_error(const double T[16]) const
         int j = correspondences_[i];
         if (j < 0) continue;
         const double mean_A[3] = {source[4 * static_cast<size_t>(i)], source[4 * static_cast<size_t>(i) + 1], source[4 * static_cast<size_t>(i) + 2]};
-        const double mean_B[3] = {target[4 * static_cast<size_t>(j)], target[4 * static_cast<size_t>(j) + 1], target[4 * static_cast<size_t>(j) + 2]};
+        double mean_B[3] = {0, 0, 0}, w = 1.0;
+        if (variant == 2) {
+            for (int a = 0; a < 3; ++a) mean_B[a] = voxels_[j].mean[a];
+            w = std::sqrt(static_cast<double>(voxels_[j].num_points));
+        } else {
+            for (int a = 0; a < 3; ++a) mean_B[a] = target[4 * static_cast<size_t>(j) + a];
+        }
         double tA[3];
         isometry_apply_d(T, mean_A, tA);
         const double  err[3] = {mean_B[0] - tA[0], mean_B[1] - tA[1], mean_B[2] - tA[2]};
         const double* M = &mahalanobis_[static_cast<size_t>(i) * 9];
         double Me[3];
         for (int r = 0; r < 3; ++r) Me[r] = M[r * 3 + 0] * err[0] + M[r * 3 + 1] * err[1] + M[r * 3 + 2] * err[2];
-        sum_errors += err[0] * Me[0] + err[1] * Me[1] + err[2] * Me[2];
+        const double e = err[0] * Me[0] + err[1] * Me[1] + err[2] * Me[2];
+        sum_errors += variant == 2 ? w * e : e;
     }
     return sum_errors;
 }

@@ -15,7 +15,14 @@
 // and |d_trans| <= translation_eps, RegistrationPCL sets rotation_eps 2e-3 and translation_eps = transformation_epsilon).
 // Deviation kept from the fast_gicp path: correspondences are searched with the float-cast transform (small_gicp's own
 // kd-tree works on the double coordinates).
+//
+// `variant = 2` restates fast_gicp::FastVGICP<PointXYZI,PointXYZI> (registrations.cpp:76-84, and the algorithm its CUDA
+// sibling FAST_VGICP_CUDA :65-75 runs): the target becomes a GaussianVoxelMap (resolution = reg_resolution, ADDITIVE
+// accumulation: per voxel the mean of its points and the mean of their regularised covariances; voxel of x =
+// floor(x / resolution - 0.5)), a source point corresponds to the voxel its transformed position falls in (DIRECT1),
+// every term carries the weight sqrt(points in the voxel); optimiser, Jacobian and convergence test are fast_gicp's.
 #pragma once
+#include <map>
 #include <vector>
 
 #include "nn.h"
@@ -31,7 +38,8 @@ struct FastGicp {
     int    num_threads       = 1;
     int    lm_max_iterations = 10;
     double lm_init_lambda_factor = 1e-9;
-    int    variant = 0;                 // 0: fast_gicp::FastGICP, 1: small_gicp::RegistrationPCL (GICP)
+    int    variant = 0;                 // 0: fast_gicp::FastGICP, 1: small_gicp::RegistrationPCL (GICP), 2: fast_gicp::FastVGICP
+    double voxel_resolution = 1.0;      // variant 2: setResolution(reg_resolution)
     double sg_init_lambda = 1e-3, sg_lambda_factor = 10.0;  // small_gicp::LevenbergMarquardtOptimizer defaults
     int    sg_max_inner_iterations = 10;
 
@@ -54,6 +62,7 @@ struct FastGicp {
     // update_correspondences + linearize at T (row-major 4x4 double). returns sum of errors.
     double linearize(const double T[16], double H[36], double b[6], int* n_corr);
     double compute_error(const double T[16]) const;
+    int    num_voxels() const { return static_cast<int>(voxels_.size()); }
 
    private:
     std::vector<int>    correspondences_;
@@ -62,6 +71,14 @@ struct FastGicp {
     void ensure_covs();
     NnGrid target_grid_;
     bool   target_grid_valid_ = false;
+    // variant 2: GaussianVoxelMap of the target
+    struct Voxel { int num_points = 0; double mean[3] = {0, 0, 0}; double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; };
+    struct Coord { int c[3]; bool operator<(const Coord& o) const { return c[0] != o.c[0] ? c[0] < o.c[0] : c[1] != o.c[1] ? c[1] < o.c[1] : c[2] < o.c[2]; } };
+    std::map<Coord, int> voxel_index_;
+    std::vector<Voxel>   voxels_;
+    bool voxelmap_valid_ = false;
+    void build_voxelmap();
+    Coord voxel_coord(const double x[3]) const;
 };
 
 }  // namespace orc

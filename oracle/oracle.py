@@ -76,6 +76,8 @@ def lib():
             "orc_gicp_destroy": (None, [vp]),
             "orc_gicp_set_params": (None, [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]),
             "orc_gicp_set_variant": (None, [vp, C.c_int]),
+            "orc_gicp_set_resolution": (None, [vp, C.c_double]),
+            "orc_gicp_num_voxels": (C.c_int, [vp]),
             "orc_gicp_set_target": (None, [vp, fp, C.c_int]),
             "orc_gicp_set_source": (None, [vp, fp, C.c_int]),
             "orc_gicp_align": (None, [vp, fp, fp]),
@@ -398,3 +400,16 @@ class SmallGicp(FastGicp):
     """small_gicp::RegistrationPCL (GICP) restated: the reference's YAML default "SMALL_GICP" (oracle/gicp.h, variant 1)."""
 
     VARIANT = 1
+
+
+class FastVgicp(FastGicp):
+    """fast_gicp::FastVGICP restated (the FAST_VGICP / FAST_VGICP_CUDA algorithm, oracle/gicp.h, variant 2)."""
+
+    VARIANT = 2
+
+    def __init__(self, resolution=1.0, correspondence_randomness=20, transformation_epsilon=0.1, rotation_epsilon=2e-3, maximum_iterations=64, num_threads=1):
+        super().__init__(correspondence_randomness, 2.0, transformation_epsilon, rotation_epsilon, maximum_iterations, num_threads)
+        lib().orc_gicp_set_resolution(self._h, resolution)
+
+    def numVoxels(self):
+        return lib().orc_gicp_num_voxels(self._h)

@@ -144,7 +144,9 @@ void  orc_gicp_set_params(void* h, int k_correspondences, double max_corr_dist, 
     g->k_correspondences = k_correspondences; g->max_corr_dist = max_corr_dist; g->trans_eps = trans_eps; g->rot_eps = rot_eps;
     g->max_iterations = max_iterations; g->num_threads = num_threads > 0 ? num_threads : 1;
 }
-void orc_gicp_set_variant(void* h, int variant) { static_cast<FastGicp*>(h)->variant = variant; }  // 1: small_gicp formulation
+void orc_gicp_set_variant(void* h, int variant) { static_cast<FastGicp*>(h)->variant = variant; }  // 1: small_gicp formulation, 2: fast_gicp::FastVGICP
+void orc_gicp_set_resolution(void* h, double resolution) { static_cast<FastGicp*>(h)->voxel_resolution = resolution; }
+int  orc_gicp_num_voxels(void* h) { FastGicp* g = static_cast<FastGicp*>(h); double H[36], b[6], I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; g->linearize(I, H, b, nullptr); return g->num_voxels(); }
 void orc_gicp_set_target(void* h, const float* xyzi, int n) { static_cast<FastGicp*>(h)->set_target(xyzi, n); }
 void orc_gicp_set_source(void* h, const float* xyzi, int n) { static_cast<FastGicp*>(h)->set_source(xyzi, n); }
 void orc_gicp_align(void* h, const float guess_colmajor[16], float* aligned_or_null)

@@ -92,7 +92,7 @@ def main():
         ctx.synchronize()
         return 1e3 * (time.perf_counter() - t0) / 2, int(np.sum(r["converged"]))
 
-    from mrg_slam_amd._lib import GICP_HIP, SMALL_GICP_HIP
+    from mrg_slam_amd._lib import GICP_HIP, SMALL_GICP_HIP, VGICP_HIP
     ms_f, conv_f = gicp_batch(GICP_HIP)
     ms_s, conv_s = gicp_batch(SMALL_GICP_HIP)
     out["gicp_batch_32x130k"] = {"gicp_hip_ms": ms_f, "small_gicp_hip_ms": ms_s, "converged": [conv_f, conv_s]}
@@ -219,6 +219,22 @@ def main():
         odo_g.align(synth.warm_guess(np.linalg.inv(poses[0]) @ poses[k], k))
         tf.append(time.perf_counter() - t1)
     out["odometry_frame_ms"]["prefilter_plus_scan_to_keyframe_small_gicp_ms"] = 1e3 * float(np.median(tf[2:]))
+    from mrg_slam_amd import VgicpHip
+
+    odo_v = VgicpHip(resolution=1.0, transformation_epsilon=0.1, ctx=ctx)  # FAST_VGICP / the reference's FAST_VGICP_CUDA slot
+    odo_v.setInputTarget(kf)
+    tf = []
+    for k in (1, 2, 3, 4, 1, 2, 3, 4):
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        m = prefilter_to_device(raw[k], dbuf.data_ptr(), len(raw[k]), ctx=ctx)
+        odo_v.setInputSourceDevice(dbuf.data_ptr(), m)
+        odo_v.align(synth.warm_guess(np.linalg.inv(poses[0]) @ poses[k], k))
+        tf.append(time.perf_counter() - t1)
+    out["odometry_frame_ms"]["prefilter_plus_scan_to_keyframe_vgicp_ms"] = 1e3 * float(np.median(tf[2:]))
+    ms_v, conv_v = gicp_batch(VGICP_HIP)
+    out["gicp_batch_32x130k"]["vgicp_hip_ms"] = ms_v
+    out["gicp_batch_32x130k"]["converged"].append(conv_v)
 
     # ---- BASELINE config[4] shape on one GPU: two robots' odometry streams (threads / contexts A, B) while a loop-closure
     #      batch stream (context C: 64 NDT candidates per call, keyframe store) keeps the GPU busy ---------------------------

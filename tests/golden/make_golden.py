@@ -7,6 +7,7 @@ un-vendored PCL / ndt_omp / fast_gicp, so these vectors are pro
 the HIP path against them on the GPU box.  Re-run only when the oracle is deliberately changed:
     python tests/golden/make_golden.py                      # all three files
     python tests/golden/make_golden.py --small-gicp-only    # tests/golden/small_gicp.npz only
+    python tests/golden/make_golden.py --vgicp-only         # tests/golden/vgicp.npz only
 """
 import os
 import sys
@@ -116,9 +117,32 @@ def small_gicp():
     print(path, os.path.getsize(path), "bytes")
 
 
+def vgicp():
+    """tests/golden/vgicp.npz: the restated fast_gicp::FastVGICP (oracle variant 2) on the inputs of frontend_small.npz."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "frontend_small.npz"))
+    out = {}
+    g = orc.FastVgicp(resolution=1.0, transformation_epsilon=0.01, num_threads=1)
+    g.setInputTarget(G["tgt"])
+    g.setInputSource(G["src"])
+    for tag, guess in (("warm", G["guess"]), ("identity", np.eye(4))):
+        g.align(guess)
+        out[f"{tag}_T"] = g.getFinalTransformation()
+        out[f"{tag}_H"] = g.getFinalHessian()
+        out[f"{tag}_meta"] = np.array([g.hasConverged(), g.getFinalNumIteration()], dtype=np.int64)
+    e, H, b, n = g.linearize(np.asarray(G["guess"], dtype=np.float64))
+    out["lin_err"], out["lin_H"], out["lin_b"], out["lin_n"] = np.array([e]), H, b, np.array([n])
+    out["num_voxels"] = np.array([g.numVoxels()])
+    path = os.path.join(ROOT, "tests", "golden", "vgicp.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
     if "--small-gicp-only" in sys.argv:
         small_gicp()
+    elif "--vgicp-only" in sys.argv:
+        vgicp()
     else:
         main()
         small_gicp()
+        vgicp()

@@ -77,6 +77,24 @@ def test_oracle_small_gicp_reproduces_golden():
     assert np.linalg.norm(S["warm_T"][:3, 3] - G["rel"][:3, 3]) < 0.02
 
 
+def test_oracle_vgicp_reproduces_golden():
+    from oracle import oracle as orc
+
+    V = np.load(os.path.join(os.path.dirname(__file__), "golden", "vgicp.npz"))
+    g = orc.FastVgicp(resolution=1.0, transformation_epsilon=0.01, num_threads=1)
+    g.setInputTarget(G["tgt"])
+    g.setInputSource(G["src"])
+    for tag, guess in (("warm", G["guess"]), ("identity", np.eye(4))):
+        g.align(guess)
+        np.testing.assert_array_equal(g.getFinalTransformation(), V[f"{tag}_T"])
+        np.testing.assert_array_equal(g.getFinalHessian(), V[f"{tag}_H"])
+        assert [int(g.hasConverged()), g.getFinalNumIteration()] == V[f"{tag}_meta"].tolist()
+    e, H, b, n = g.linearize(np.asarray(G["guess"], dtype=np.float64))
+    assert e == V["lin_err"][0] and n == V["lin_n"][0] and g.numVoxels() == V["num_voxels"][0]
+    np.testing.assert_array_equal(H, V["lin_H"])
+    assert np.linalg.norm(V["warm_T"][:3, 3] - G["rel"][:3, 3]) < 0.05
+
+
 def test_oracle_perpoint_passes_reproduce_golden():
     from oracle import oracle as orc
 
@@ -177,6 +195,25 @@ def test_hip_small_gicp_matches_golden():
     H, b, e, n = g.linearize(np.asarray(G["guess"], dtype=np.float64))
     assert n == S["lin_n"][0] and e == pytest.approx(S["lin_err"][0], rel=1e-12)
     np.testing.assert_allclose(H, S["lin_H"], rtol=0, atol=1e-12 * np.abs(S["lin_H"]).max())
+
+
+@pytest.mark.gpu
+def test_hip_vgicp_matches_golden():
+    from mrg_slam_amd import VgicpHip, synth
+
+    V = np.load(os.path.join(os.path.dirname(__file__), "golden", "vgicp.npz"))
+    g = VgicpHip(resolution=1.0, transformation_epsilon=0.01)
+    g.setInputTarget(G["tgt"])
+    g.setInputSource(G["src"])
+    for tag, guess in (("warm", G["guess"]), ("identity", np.eye(4))):
+        g.align(guess)
+        T = g.getFinalTransformation()
+        assert np.linalg.norm(T[:3, 3].astype(np.float64) - V[f"{tag}_T"][:3, 3]) <= 1e-4
+        assert synth.rotation_angle(T, V[f"{tag}_T"]) <= 1e-4
+        assert [int(g.hasConverged()), g.getFinalNumIteration()] == V[f"{tag}_meta"].tolist()
+    H, b, e, n = g.linearize(np.asarray(G["guess"], dtype=np.float64))
+    assert n == V["lin_n"][0] and e == pytest.approx(V["lin_err"][0], rel=1e-12)
+    np.testing.assert_allclose(H, V["lin_H"], rtol=0, atol=1e-12 * np.abs(V["lin_H"]).max())
 
 
 @pytest.mark.gpu

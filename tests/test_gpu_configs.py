@@ -27,18 +27,18 @@ def street_scans():
     return poses, scans
 
 
-@pytest.mark.parametrize("method", ["FAST_GICP", "SMALL_GICP"])
+@pytest.mark.parametrize("method", ["FAST_GICP", "SMALL_GICP", "FAST_VGICP"])
 def test_config3_gicp_scan_to_keyframe(street_scans, method):
     """GICP_HIP == restated FAST_GICP and SMALL_GICP_HIP == restated SMALL_GICP (the YAML default) on a keyframe +
     following scans, warm-started like the odometry component (align(aligned, prev_trans),
     apps/scan_matching_odometry_component.cpp:265-266); the registration objects come out of the factory mirror."""
-    from mrg_slam_amd import GicpHip, SmallGicpHip, select_registration_method
+    from mrg_slam_amd import GicpHip, SmallGicpHip, VgicpHip, select_registration_method
     from oracle import oracle as orc
 
     poses, scans = street_scans
     g = select_registration_method({"registration_method": method, "reg_transformation_epsilon": 0.1})
-    assert type(g) is (SmallGicpHip if method == "SMALL_GICP" else GicpHip)
-    o = (orc.SmallGicp if method == "SMALL_GICP" else orc.FastGicp)(transformation_epsilon=0.1, num_threads=8)
+    assert type(g) is {"SMALL_GICP": SmallGicpHip, "FAST_GICP": GicpHip, "FAST_VGICP": VgicpHip}[method]
+    o = {"SMALL_GICP": orc.SmallGicp, "FAST_GICP": orc.FastGicp, "FAST_VGICP": orc.FastVgicp}[method](transformation_epsilon=0.1, num_threads=1 if method == "FAST_VGICP" else 8)
     g.setInputTarget(scans[0])
     o.setInputTarget(scans[0])
     prev_g = prev_o = np.eye(4)

@@ -150,3 +150,89 @@ def test_small_gicp_batch_equals_single_registrations():
         np.testing.assert_array_equal(result_matrix(res[k]), reg.getFinalTransformation())
         assert res[k]["converged"] == int(reg.hasConverged()) and res[k]["iterations"] == reg.getFinalNumIteration()
         assert res[k]["fitness"] == pytest.approx(reg.getFitnessScore(), rel=1e-12)
+
+
+@pytest.mark.parametrize("eps,res", [(0.1, 1.0), (0.01, 1.0), (0.01, 0.5), (1e-4, 2.0)])
+@pytest.mark.parametrize("guess_seed", [None, 5])
+def test_vgicp_align_matches_oracle(eps, res, guess_seed):
+    """VGICP_HIP (FAST_VGICP, registrations.cpp:76-84, and the reference's GPU slot FAST_VGICP_CUDA :65-75): same decisions and
+    result as the restated fast_gicp::FastVGICP; bar 1e-4 m / 1e-4 rad."""
+    from mrg_slam_amd import VgicpHip, synth
+    from oracle import oracle as orc
+
+    tgt, src, rel = _pair()
+    guess = np.eye(4) if guess_seed is None else synth.perturb_pose(rel, np.random.default_rng(guess_seed))
+    g = VgicpHip(resolution=res, transformation_epsilon=eps)
+    o = orc.FastVgicp(resolution=res, transformation_epsilon=eps, num_threads=1)
+    for r in (g, o):
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+    aligned = g.align(guess, want_aligned=True)
+    o.align(guess)
+    Tg, To = g.getFinalTransformation(), o.getFinalTransformation()
+    assert g.hasConverged() == o.hasConverged()
+    assert g.getFinalNumIteration() == o.getFinalNumIteration()
+    assert np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3]) <= 1e-4
+    assert _rot_angle(Tg[:3, :3], To[:3, :3]) <= 1e-4
+    np.testing.assert_allclose(g.getHessian(), o.getFinalHessian(), rtol=0, atol=1e-6 * np.abs(o.getFinalHessian()).max())
+    np.testing.assert_array_equal(aligned, orc.transform_points(Tg, src))
+    # 3000 random points in 1 m voxels are a coarse target: only the easy start with a tight epsilon must also reach the truth
+    if eps <= 0.01 and guess_seed is None and res <= 1.0:
+        assert np.linalg.norm(Tg[:3, 3] - rel[:3, 3]) < 0.15
+
+
+def test_vgicp_linearize_matches_oracle():
+    """One update_correspondences + linearize pass of the voxelised cost: same correspondences (voxel of the transformed point,
+    floor(x / res - 0.5)), weights sqrt(points per voxel), H / b / error to f64 rounding."""
+    from mrg_slam_amd import VgicpHip, synth
+    from oracle import oracle as orc
+
+    tgt, src, rel = _pair(2500, 9)
+    src = np.concatenate([src, np.float32([[500, 0, 0, 0], [np.nan, 0, 0, 0]])])  # a point without a voxel, a non-finite one
+    for res in (1.0, 0.37):
+        g = VgicpHip(resolution=res, transformation_epsilon=0.01)
+        o = orc.FastVgicp(resolution=res, transformation_epsilon=0.01, num_threads=1)
+        for r in (g, o):
+            r.setInputTarget(tgt)
+            r.setInputSource(src)
+        T = synth.perturb_pose(rel, np.random.default_rng(3)).astype(np.float64)
+        H, b, e, n = g.linearize(T)
+        eo, Ho, bo, no = o.linearize(T)
+        assert n == no and 0 < n < len(src)
+        assert e == pytest.approx(eo, rel=1e-12)
+        np.testing.assert_allclose(H, Ho, rtol=0, atol=1e-12 * np.abs(Ho).max())
+        np.testing.assert_allclose(b, bo, rtol=0, atol=1e-12 * np.abs(bo).max() + 1e-9)
+
+
+def test_vgicp_batch_equals_single_registrations():
+    from mrg_slam_amd import BatchMatcher, VgicpHip, synth
+    from mrg_slam_amd._lib import VGICP_HIP
+    from mrg_slam_amd.registration import default_params, result_matrix
+    from oracle import oracle as orc
+
+    targets = [small_cloud(4000, 220), small_cloud(3500, 221)]
+    rng = np.random.default_rng(12)
+    prm = default_params(VGICP_HIP)
+    prm.transformation_epsilon = 0.01
+    prm.resolution = 1.0
+    bm = BatchMatcher(prm)
+    tids = [bm.add_target(t) for t in targets]
+    pairs = []
+    for k in range(5):
+        ti = k % 2
+        rel = synth.make_pose(rng.normal(0, 0.1, 3), synth.rot_xyz(*rng.normal(0, 0.01, 3)))
+        src = orc.transform_points(np.linalg.inv(rel), targets[ti][: 2500 + 300 * k])
+        guess = synth.perturb_pose(np.eye(4), rng)
+        pairs.append((ti, src, guess))
+        bm.add_pair(tids[ti], src, guess, key=900 + k)  # through the keyframe store as well
+    res = bm.align(fitness_max_range=float("inf"))
+    again = bm.align(fitness_max_range=float("inf"))
+    for k, (ti, src, guess) in enumerate(pairs):
+        reg = VgicpHip(resolution=1.0, transformation_epsilon=0.01)
+        reg.setInputTarget(targets[ti])
+        reg.setInputSource(src)
+        reg.align(guess)
+        np.testing.assert_array_equal(result_matrix(res[k]), reg.getFinalTransformation())
+        np.testing.assert_array_equal(result_matrix(again[k]), reg.getFinalTransformation())
+        assert res[k]["converged"] == int(reg.hasConverged()) and res[k]["iterations"] == reg.getFinalNumIteration()
+        assert res[k]["fitness"] == pytest.approx(reg.getFitnessScore(), rel=1e-12)

@@ -17,7 +17,7 @@ def _pair(n=1500, seed=11):
     return tgt, src, rel
 
 
-@pytest.mark.parametrize("cls", ["FastGicp", "SmallGicp"])
+@pytest.mark.parametrize("cls", ["FastGicp", "SmallGicp", "FastVgicp"])
 def test_recovers_the_known_motion(cls):
     from mrg_slam_amd import synth
     from oracle import oracle as orc
@@ -78,3 +78,28 @@ def test_small_gicp_termination_rules():
     far.setInputSource(src + np.float32([50, 0, 0, 0]))
     far.align(np.eye(4))  # no correspondences: H = 0, b = 0, the zero step is accepted at equal (zero) error
     np.testing.assert_allclose(far.getFinalTransformation(), np.eye(4), atol=1e-7)
+
+
+def test_vgicp_voxel_map_and_weights():
+    """GaussianVoxelMap restated: voxel of x = floor(x / res - 0.5); a correspondence exists iff the transformed point falls
+    in an occupied voxel; with the identity the number of correspondences is the number of source points whose own voxel is
+    occupied, and halving the resolution cannot reduce the number of voxels."""
+    from oracle import oracle as orc
+
+    tgt, src, _ = _pair(2000, 3)
+    counts = []
+    for res in (2.0, 1.0, 0.5):
+        g = orc.FastVgicp(resolution=res, transformation_epsilon=0.01, num_threads=1)
+        g.setInputTarget(tgt)
+        g.setInputSource(tgt)  # the target against itself
+        e, H, b, n = g.linearize(np.eye(4))
+        assert n == len(tgt)  # every point lies in its own (occupied) voxel
+        coords = np.floor(tgt[:, :3].astype(np.float64) / res - 0.5).astype(np.int64)
+        assert g.numVoxels() == len(np.unique(coords, axis=0))
+        counts.append(g.numVoxels())
+        assert np.isfinite(e) and np.all(np.isfinite(H)) and np.allclose(H, H.T)
+    assert counts[0] <= counts[1] <= counts[2]
+    far = orc.FastVgicp(resolution=1.0, num_threads=1)
+    far.setInputTarget(tgt)
+    far.setInputSource(src + np.float32([500, 0, 0, 0]))
+    assert far.linearize(np.eye(4))[3] == 0  # nothing falls in an occupied voxel
