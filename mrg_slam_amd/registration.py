@@ -252,7 +252,9 @@ def select_registration_method(params: dict, ctx: Context | None = None) -> HipR
     reg_transformation_epsilon, reg_maximum_iterations, reg_max_correspondence_distance, reg_correspondence_randomness,
     reg_resolution, reg_nn_search_method).  "NDT_HIP" (and, to stay drop-in, "NDT_OMP"/"NDT") select :class:`NdtHip`;
     "GICP_HIP" / "FAST_GICP" select :class:`GicpHip`, "SMALL_GICP_HIP" / "SMALL_GICP" :class:`SmallGicpHip`, "VGICP_HIP" /
-    "FAST_VGICP" / "FAST_VGICP_CUDA" :class:`VgicpHip`.  Like the reference, an unknown name falls through to NDT.
+    "FAST_VGICP" / "FAST_VGICP_CUDA" :class:`VgicpHip`.  Like the reference, an unknown name falls through to NDT; "NDT"
+    (pcl's single-threaded class) gets the KDTREE neighbourhood, its only one, on the pclomp float formulation; "ICP", "GICP"
+    and "GICP_OMP" raise NotImplementedError.
     """
     method = str(params.get("registration_method", "FAST_GICP"))
     eps = float(params.get("reg_transformation_epsilon", 0.01))
@@ -267,9 +269,16 @@ def select_registration_method(params: dict, ctx: Context | None = None) -> HipR
     if method in ("GICP_HIP", "FAST_GICP"):
         return GicpHip(int(params.get("reg_correspondence_randomness", 20)), float(params.get("reg_max_correspondence_distance", 2.0)), eps,
                        maximum_iterations=iters, num_threads=threads, ctx=ctx)
+    if method == "ICP" or ("GICP" in method):
+        # registrations.cpp:85-114: pcl::IterativeClosestPoint, pcl::GeneralizedIterativeClosestPoint and pclomp::GICP (BFGS
+        # inner optimiser) have no HIP counterpart here; running something else in their name would be wrong
+        raise NotImplementedError(f'registration_method "{method}" is not offered by libmrgfe (available: NDT_OMP/NDT_HIP, FAST_GICP/GICP_HIP, '
+                                  f'SMALL_GICP/SMALL_GICP_HIP, FAST_VGICP/FAST_VGICP_CUDA/VGICP_HIP)')
     search = str(params.get("reg_nn_search_method", "DIRECT7"))
     if search not in ("KDTREE", "DIRECT1"):
         search = "DIRECT7"  # registrations.cpp:140-146: anything else means DIRECT7
+    if "NDT" in method and "OMP" not in method and method != "NDT_HIP":
+        search = "KDTREE"  # :123-129 pcl::NormalDistributionsTransform: radius search over the voxel centroids is its only neighbourhood
     return NdtHip(float(params.get("reg_resolution", 1.0)), eps, iters, search, num_threads=threads, ctx=ctx)
 
 

@@ -145,3 +145,21 @@ def test_config5_two_robots_concurrent_streams_and_inter_robot_batch(street_scan
         o.setInputSource(scans[k])
         o.align(synth.warm_guess(g, k))
         assert _close(result_matrix(res[i]), o.getFinalTransformation()), k
+
+
+def test_factory_mirror_dispatch():
+    """select_registration_method: the reference's names and the HIP ones (registrations.cpp:45-151)."""
+    from mrg_slam_amd import GicpHip, NdtHip, SmallGicpHip, VgicpHip, select_registration_method
+    from mrg_slam_amd._lib import SEARCH
+
+    expect = {"NDT_OMP": NdtHip, "NDT_HIP": NdtHip, "NDT": NdtHip, "no such method": NdtHip, "FAST_GICP": GicpHip, "GICP_HIP": GicpHip, "SMALL_GICP": SmallGicpHip,
+              "SMALL_GICP_HIP": SmallGicpHip, "FAST_VGICP": VgicpHip, "FAST_VGICP_CUDA": VgicpHip, "VGICP_HIP": VgicpHip}
+    for name, cls in expect.items():
+        assert type(select_registration_method({"registration_method": name})) is cls, name
+    assert select_registration_method({"registration_method": "NDT_OMP", "reg_nn_search_method": "whatever"})._params.nn_search_method == SEARCH["DIRECT7"]
+    assert select_registration_method({"registration_method": "NDT_OMP", "reg_nn_search_method": "DIRECT1"})._params.nn_search_method == SEARCH["DIRECT1"]
+    assert select_registration_method({"registration_method": "NDT"})._params.nn_search_method == SEARCH["KDTREE"]
+    assert select_registration_method({"registration_method": "FAST_VGICP", "reg_resolution": 0.5})._params.resolution == 0.5
+    for name in ("ICP", "GICP", "GICP_OMP"):
+        with pytest.raises(NotImplementedError):
+            select_registration_method({"registration_method": name})
