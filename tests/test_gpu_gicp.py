@@ -236,3 +236,44 @@ def test_vgicp_batch_equals_single_registrations():
         np.testing.assert_array_equal(result_matrix(again[k]), reg.getFinalTransformation())
         assert res[k]["converged"] == int(reg.hasConverged()) and res[k]["iterations"] == reg.getFinalNumIteration()
         assert res[k]["fitness"] == pytest.approx(reg.getFitnessScore(), rel=1e-12)
+
+
+@pytest.mark.parametrize("cls_name", ["GicpHip", "SmallGicpHip", "VgicpHip"])
+def test_gicp_family_degenerate_inputs(cls_name):
+    """Empty and non-finite clouds must not fault the GPU; results mirror the oracle's decisions."""
+    import mrg_slam_amd
+    from oracle import oracle as orc
+
+    cls = getattr(mrg_slam_amd, cls_name)
+    ocls = {"GicpHip": orc.FastGicp, "SmallGicpHip": orc.SmallGicp, "VgicpHip": orc.FastVgicp}[cls_name]
+    tgt, src, _ = _pair(1500, 21)
+    empty = np.zeros((0, 4), np.float32)
+    nan_src = src.copy()
+    nan_src[::3, 0] = np.nan
+    far_src = src + np.float32([1000, 0, 0, 0])  # no correspondences at all
+    for t, s_ in ((tgt, empty), (empty, src), (tgt, nan_src), (tgt, far_src), (tgt[:3], src[:5])):
+        g, o = cls(transformation_epsilon=0.01), ocls(transformation_epsilon=0.01, num_threads=1)
+        for r in (g, o):
+            r.setInputTarget(t)
+            r.setInputSource(s_)
+            r.align(np.eye(4))
+        Tg, To = g.getFinalTransformation().astype(np.float64), o.getFinalTransformation().astype(np.float64)
+        assert g.hasConverged() == o.hasConverged(), (cls_name, len(t), len(s_))
+        if np.all(np.isfinite(To)):
+            assert np.linalg.norm(Tg[:3, 3] - To[:3, 3]) <= 1e-4 and _rot_angle(Tg[:3, :3], To[:3, :3]) <= 1e-4
+        else:
+            assert not np.all(np.isfinite(Tg))
+
+
+def test_vgicp_rejects_a_voxel_map_that_does_not_fit():
+    from mrg_slam_amd import VgicpHip
+    from mrg_slam_amd._lib import MrgfeError
+
+    tgt, src, _ = _pair(1500, 22)
+    g = VgicpHip(resolution=1e-3)  # 20 m / 1 mm per axis: far more than 2^24 voxels
+    g.setInputTarget(tgt)
+    g.setInputSource(src)
+    with pytest.raises(MrgfeError):
+        g.align(np.eye(4))
+    with pytest.raises(MrgfeError):
+        VgicpHip(resolution=0.0)
