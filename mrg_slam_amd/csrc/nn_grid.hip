@@ -694,6 +694,43 @@ __global__ __launch_bounds__(256) void nn_knn_kernel(NnGrid2Dev g, const float4*
                     step(v < off[9], v < off[9] ? lv.sorted[kk] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                 }
                 first_ring = 2;
+                // ring 2 the same way when it is needed: its 16 face rows and 18 end cells are 34 ranges, their bounds fetched by
+                // lanes 0..33 in one round trip instead of 34 dependent probes
+                const double b2 = static_cast<double>(lv.cell) + margin;  // everything outside the block is at least this far
+                if (last_ring >= 2 && !(cnt == k && static_cast<double>(kth_d) < b2 * b2 * (1.0 - 1e-5))) {
+                    uint32_t qb = 0, ql = 0;
+                    if (lane < 34) {
+                        int dz, dy, x0, x1;
+                        if (lane < 16) {  // rows on a y / z face: the full x extent of the ring
+                            const int f = lane;  // 0..4: dz = -2; 5..9: dz = +2; 10..12: dy = -2, dz = -1..1; 13..15: dy = +2
+                            if (f < 5) { dz = -2; dy = f - 2; }
+                            else if (f < 10) { dz = 2; dy = f - 7; }
+                            else if (f < 13) { dy = -2; dz = f - 11; }
+                            else { dy = 2; dz = f - 14; }
+                            x0 = c[0] - 2;
+                            x1 = c[0] + 2;
+                        } else {  // inner rows: the two end cells
+                            const int e = lane - 16;  // 0..17: row e / 2 of the 3x3 inner rows, side e & 1
+                            dz = (e >> 1) / 3 - 1;
+                            dy = (e >> 1) % 3 - 1;
+                            x0 = x1 = (e & 1) ? c[0] + 2 : c[0] - 2;
+                        }
+                        const int zz = c[2] + dz, yy = c[1] + dy;
+                        x0 = max(x0, 0);
+                        x1 = min(x1, lv.dim[0] - 1);
+                        if (zz >= 0 && zz < lv.dim[2] && yy >= 0 && yy < lv.dim[1] && x0 <= x1) {
+                            const uint32_t row = (static_cast<uint32_t>(zz) * lv.dim[1] + yy) * lv.dim[0];
+                            qb = lv.cell_start[row + x0];
+                            ql = lv.cell_start[row + x1 + 1] - qb;
+                        }
+                    }
+                    for (int r = 0; r < 34; ++r) {
+                        const uint32_t rb2 = __shfl(qb, r), rl2 = __shfl(ql, r);
+                        for (uint32_t base = 0; base < rl2; base += 64u)
+                            step(base + lane < rl2, base + lane < rl2 ? lv.sorted[rb2 + base + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                    }
+                    first_ring = 3;
+                }
             }
             nn_walk_ranges(
                 lv, c, margin, last_ring,
