@@ -105,3 +105,22 @@ def test_select_best_replays_reference_semantics():
     # single process (no process group): gather is the identity
     t = _fake_records(9)
     np.testing.assert_array_equal(lc.gather_records(t[::-1].copy(), 9), t)
+
+
+def test_candidate_keys_reach_the_matcher_single_process():
+    """match_candidates passes keyframe ids through to add_pair(key=...) (the keyframe store of the rank that owns the pair)."""
+    from mrg_slam_amd import loop_closure as lc
+
+    table = _fake_records(5, seed=3)
+    seen = []
+
+    class _KeyedMatcher(_FakeMatcher):
+        def add_pair(self, t, cloud, guess, key=0):
+            seen.append(key)
+            super().add_pair(t, cloud, guess)
+
+    clouds = [np.full((1, 4), i, dtype=np.float32) for i in range(5)]
+    rec, best, score = lc.match_candidates(lambda: _KeyedMatcher(table), np.zeros((1, 4), np.float32), clouds, [np.eye(4)] * 5, candidate_keys=[11, 12, 13, 14, 15])
+    assert seen == [11, 12, 13, 14, 15]
+    rec2, best2, score2 = lc.match_candidates(lambda: _FakeMatcher(table), np.zeros((1, 4), np.float32), clouds, [np.eye(4)] * 5)
+    assert rec.tobytes() == rec2.tobytes() and best == best2 and score == score2
