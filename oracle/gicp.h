@@ -16,8 +16,8 @@
 // Deviation kept from the fast_gicp path: correspondences are searched with the float-cast transform (small_gicp's own
 // kd-tree works on the double coordinates).
 //
-// `variant = 2` restates fast_gicp::FastVGICP<PointXYZI,PointXYZI> (registrations.cpp:76-84, and the algorithm its CUDA
-// sibling FAST_VGICP_CUDA :65-75 runs): the target becomes a GaussianVoxelMap (resolution = reg_resolution, ADDITIVE
+// `variant = 2` restates fast_gicp::FastVGICP<PointXYZI,PointXYZI> (registrations.cpp:76-84; its CUDA sibling
+// FAST_VGICP_CUDA, :65-75, minimises the same voxelised cost on the device and is not restated separately): the target becomes a GaussianVoxelMap (resolution = reg_resolution, ADDITIVE
 // accumulation: per voxel the mean of its points and the mean of their regularised covariances; voxel of x =
 // floor(x / resolution - 0.5)), a source point corresponds to the voxel its transformed position falls in (DIRECT1),
 // every term carries the weight sqrt(points in the voxel); optimiser, Jacobian and convergence test are fast_gicp's.
