@@ -232,9 +232,10 @@ typedef struct mrgfe_pair_result {
 
 typedef struct mrgfe_batch mrgfe_batch;
 /* A batch holds `n_targets` target clouds and `n_pairs` (target index, source cloud, guess) alignments.  NDT_HIP: they are
- * advanced together, one launch per derivative evaluation for all pairs still running.  GICP_HIP: the candidates of a target
- * share its covariances and correspondence grid (computed once, like the single setInputTarget of loop_detector.cpp:104),
- * source covariances are computed cloud by cloud, and the Levenberg-Marquardt loops of all pairs advance together. */
+ * advanced together, one launch per derivative evaluation for all pairs still running.  GICP_HIP / SMALL_GICP_HIP / VGICP_HIP:
+ * the candidates of a target share its covariances and correspondence grid or voxel map (computed once, like the single
+ * setInputTarget of loop_detector.cpp:104), the source covariances are computed on a few parallel streams (or taken from the
+ * keyframe store below), and the Levenberg-Marquardt loops of all pairs advance together. */
 int  mrgfe_batch_create(mrgfe_ctx* ctx, const mrgfe_reg_params* params, mrgfe_batch** out);
 void mrgfe_batch_destroy(mrgfe_batch* b);
 int  mrgfe_batch_clear(mrgfe_batch* b);
