@@ -49,8 +49,10 @@ enum mrgfe_method {
     MRGFE_GICP_HIP = 1, /* replaces "FAST_GICP": fast_gicp::FastGICP                  (registrations.cpp:55-63)   */
     MRGFE_SMALL_GICP_HIP = 2, /* replaces "SMALL_GICP" (the YAML default, config/mrg_slam.yaml:100): small_gicp::RegistrationPCL
                                  (registrations.cpp:46-54): the same GICP factor perturbed on the right, small_gicp's LM schedule */
-    MRGFE_VGICP_HIP = 3 /* replaces "FAST_VGICP" (fast_gicp::FastVGICP, registrations.cpp:76-84) and the reference's own GPU slot
-                           "FAST_VGICP_CUDA" (:65-75): voxelised GICP, target as a Gaussian voxel map of edge `resolution` */
+    MRGFE_VGICP_HIP = 3, /* replaces "FAST_VGICP" (fast_gicp::FastVGICP, registrations.cpp:76-84) and the reference's own GPU slot
+                            "FAST_VGICP_CUDA" (:65-75): voxelised GICP, target as a Gaussian voxel map of edge `resolution` */
+    MRGFE_ICP_HIP = 4 /* replaces "ICP": pcl::IterativeClosestPoint (registrations.cpp:85-92), reciprocal correspondences off;
+                         single registrations only (not in mrgfe_batch_*) */
 };
 /* reg_nn_search_method (registrations.cpp:140-146) */
 enum mrgfe_ndt_search { MRGFE_KDTREE = 0, MRGFE_DIRECT26 = 1, MRGFE_DIRECT7 = 2, MRGFE_DIRECT1 = 3 };

@@ -39,7 +39,7 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
 
     explicit HipRegistration(const mrgfe_reg_params& params, int device = 0)
     {
-        this->reg_name_ = params.method == MRGFE_NDT_HIP ? "NDT_HIP" : params.method == MRGFE_GICP_HIP ? "GICP_HIP" : params.method == MRGFE_VGICP_HIP ? "VGICP_HIP" : "SMALL_GICP_HIP";
+        this->reg_name_ = params.method == MRGFE_NDT_HIP ? "NDT_HIP" : params.method == MRGFE_GICP_HIP ? "GICP_HIP" : params.method == MRGFE_VGICP_HIP ? "VGICP_HIP" : params.method == MRGFE_ICP_HIP ? "ICP_HIP" : "SMALL_GICP_HIP";
         if (mrgfe_reg_create(shared_context(device), &params, &reg_) != MRGFE_OK) throw std::runtime_error(std::string("mrgfe: ") + mrgfe_last_error());
         this->max_iterations_ = params.maximum_iterations;
         this->transformation_epsilon_ = params.transformation_epsilon;

@@ -4,4 +4,4 @@ pcl::Registration / pcl::Filter call surface.  See DESIGN.md."""
 from ._lib import Context, MrgfeError, build, default_context  # noqa: F401
 from .filters import RadiusOutlierRemoval, StatisticalOutlierRemoval, VoxelGrid, calc_fitness_score, distance_filter, knn, prefilter, prefilter_to_device  # noqa: F401
 from .map_cloud import KeyFrameSnapshot, MapCloudGenerator, MapCloudStore, deskew, remove_points_near  # noqa: F401
-from .registration import BatchMatcher, GicpHip, NdtHip, SmallGicpHip, VgicpHip, select_registration_method  # noqa: F401
+from .registration import BatchMatcher, GicpHip, IcpHip, NdtHip, SmallGicpHip, VgicpHip, select_registration_method  # noqa: F401

@@ -42,7 +42,7 @@ GicpParams gicp_params_from(const mrgfe_reg_params& p)
     g.trans_eps = p.transformation_epsilon;
     g.rot_eps = p.rotation_epsilon;
     g.max_iterations = p.maximum_iterations;
-    g.variant = p.method == MRGFE_SMALL_GICP_HIP ? 1 : p.method == MRGFE_VGICP_HIP ? 2 : 0;
+    g.variant = p.method == MRGFE_SMALL_GICP_HIP ? 1 : p.method == MRGFE_VGICP_HIP ? 2 : p.method == MRGFE_ICP_HIP ? 3 : 0;
     g.voxel_resolution = p.resolution;
     return g;
 }
@@ -50,12 +50,13 @@ GicpParams gicp_params_from(const mrgfe_reg_params& p)
 int check_params(const mrgfe_reg_params* p)
 {
     if (!p) { set_error("NULL params"); return MRGFE_ERR_INVALID; }
-    if (p->method != MRGFE_NDT_HIP && p->method != MRGFE_GICP_HIP && p->method != MRGFE_SMALL_GICP_HIP && p->method != MRGFE_VGICP_HIP) { set_error("unknown registration method %d", p->method); return MRGFE_ERR_INVALID; }
+    if (p->method < MRGFE_NDT_HIP || p->method > MRGFE_ICP_HIP) { set_error("unknown registration method %d", p->method); return MRGFE_ERR_INVALID; }
     if (p->method == MRGFE_NDT_HIP) {
         if (!(p->resolution > 0)) { set_error("resolution must be > 0"); return MRGFE_ERR_INVALID; }
         if (p->nn_search_method < 0 || p->nn_search_method > 3) { set_error("unknown nn_search_method %d", p->nn_search_method); return MRGFE_ERR_INVALID; }
     } else {
-        if (p->correspondence_randomness < 4 || p->correspondence_randomness > 64) { set_error("correspondence_randomness must be in [4, 64]"); return MRGFE_ERR_INVALID; }
+        if (p->method != MRGFE_ICP_HIP && (p->correspondence_randomness < 4 || p->correspondence_randomness > 64)) { set_error("correspondence_randomness must be in [4, 64]"); return MRGFE_ERR_INVALID; }
+        if (p->method == MRGFE_ICP_HIP && p->use_reciprocal_correspondences) { set_error("ICP_HIP: reciprocal correspondences are not offered"); return MRGFE_ERR_INVALID; }
         if (p->method == MRGFE_VGICP_HIP && !(p->resolution > 0)) { set_error("resolution must be > 0"); return MRGFE_ERR_INVALID; }
     }
     return MRGFE_OK;
@@ -383,6 +384,7 @@ int mrgfe_knn(mrgfe_ctx* ctx, const float* cloud, size_t n, const float* query, 
 int mrgfe_gicp_linearize(mrgfe_reg* reg, const double T[16], double H[36], double b[6], double* sum_errors, int* n_correspondences)
 {
     if (!reg || !reg->gicp || !T || !H || !b || !sum_errors || !n_correspondences) { set_error("mrgfe_gicp_linearize: needs a GICP registration and non-NULL arguments"); return MRGFE_ERR_INVALID; }
+    if (reg->params.method == MRGFE_ICP_HIP) { set_error("mrgfe_gicp_linearize: ICP_HIP has no linearised cost"); return MRGFE_ERR_INVALID; }
     if (!reg->has_target || !reg->has_source) { set_error("linearize: target / source not set"); return MRGFE_ERR_STATE; }
     MRGFE_LOCK(reg->ctx);
     MRGFE_TRY(reg->ctx->bind());
@@ -394,6 +396,7 @@ int mrgfe_gicp_linearize(mrgfe_reg* reg, const double T[16], double H[36], doubl
 int mrgfe_gicp_covariances(mrgfe_reg* reg, int which, double* cov9_per_point)
 {
     if (!reg || !reg->gicp || !cov9_per_point || which < 0 || which > 1) { set_error("mrgfe_gicp_covariances: needs a GICP registration, which in {0, 1} and an output buffer"); return MRGFE_ERR_INVALID; }
+    if (reg->params.method == MRGFE_ICP_HIP) { set_error("mrgfe_gicp_covariances: ICP_HIP has no covariances"); return MRGFE_ERR_INVALID; }
     if ((which == 0 && !reg->has_source) || (which == 1 && !reg->has_target)) { set_error("covariances: cloud not set"); return MRGFE_ERR_STATE; }
     MRGFE_LOCK(reg->ctx);
     MRGFE_TRY(reg->ctx->bind());
@@ -735,6 +738,7 @@ int mrgfe_batch_create(mrgfe_ctx* ctx, const mrgfe_reg_params* params, mrgfe_bat
     if (!ctx || !out) { set_error("mrgfe_batch_create: NULL argument"); return MRGFE_ERR_INVALID; }
     *out = nullptr;
     MRGFE_TRY(check_params(params));
+    if (params->method == MRGFE_ICP_HIP) { set_error("mrgfe_batch_create: ICP_HIP is offered for single registrations only"); return MRGFE_ERR_INVALID; }
     mrgfe_batch* b = new (std::nothrow) mrgfe_batch();
     if (!b) { set_error("out of host memory"); return MRGFE_ERR_INVALID; }
     b->ctx = ctx;

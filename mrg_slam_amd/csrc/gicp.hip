@@ -144,6 +144,20 @@ __global__ __launch_bounds__(256) void vox_corr_kernel(const float4* __restrict_
     corr[i] = (c < g.n_cells && g.vox[size_t(c) * kVoxRec + 9] > 0.0) ? static_cast<int32_t>(c) : -1;
 }
 
+// ---- ICP (pcl::IterativeClosestPoint): correspondences + the moment sums of TransformationEstimationSVD ------------------
+// record: [0] correspondences, [1..3] sum src, [4..6] sum dst, [7..15] sum dst * src^T (row-major), [16] sum of squared distances
+__global__ __launch_bounds__(256) void icp_corr_sums_kernel(NnGrid2Dev g, const float4* __restrict__ cur, const float4* __restrict__ tgt, uint32_t n, double max_sq,
+                                                             double* __restrict__ partials);
+__global__ __launch_bounds__(256) void icp_transform_kernel(float4* __restrict__ cur, uint32_t n, const float* __restrict__ T12)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float4 p = cur[i];
+    float  x, y, z;
+    transform_point(T12, p.x, p.y, p.z, x, y, z);  // pcl::transformPointCloud
+    cur[i] = make_float4(x, y, z, p.w);
+}
+
 struct GicpPose {
     double T[12];   // row-major 3x4, double
     float  Tf[12];  // trans.cast<float>()
@@ -199,6 +213,37 @@ __device__ __forceinline__ void gicp_corr_query(const NnGrid2Dev& g, const float
 __global__ __launch_bounds__(256) void gicp_corr_kernel(NnGrid2Dev g, const float4* __restrict__ src, uint32_t n, GicpPose pose, double thr2, int32_t* __restrict__ corr)
 {
     gicp_corr_query(g, src, n, pose, thr2, corr, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void icp_corr_sums_kernel(NnGrid2Dev g, const float4* __restrict__ cur, const float4* __restrict__ tgt, uint32_t n, double max_sq,
+                                                             double* __restrict__ partials)
+{
+#pragma clang fp contract(off)
+    double vals[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) vals[k] = 0.0;
+    // eight lanes search one query; lane 0 of the group carries its contribution into the block sum
+    constexpr uint32_t per_blk = 256u / kGicpGroup;
+    const uint32_t i = blockIdx.x * per_blk + threadIdx.x / kGicpGroup;
+    if (i < n) {
+        const float4 p = cur[i];
+        int32_t j = -1;
+        float   sqd = INFINITY;
+        nn_nearest_group<kGicpGroup>(g, p.x, p.y, p.z, static_cast<int>(threadIdx.x % kGicpGroup), max_sq, j, sqd);
+        if (threadIdx.x % kGicpGroup == 0 && j >= 0 && !(static_cast<double>(sqd) > max_sq)) {  // determineCorrespondences: skipped iff distance > max_dist^2
+            const float4 q = tgt[j];
+            vals[0] = 1.0;
+            vals[1] = p.x; vals[2] = p.y; vals[3] = p.z;
+            vals[4] = q.x; vals[5] = q.y; vals[6] = q.z;
+            const double s[3] = {p.x, p.y, p.z}, d[3] = {q.x, q.y, q.z};
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) vals[7 + r * 3 + c] = d[r] * s[c];
+            vals[16] = sqd;
+        }
+    }
+    gicp_block_reduce(vals, partials + size_t(blockIdx.x) * kGicpStride, 17);
 }
 
 // linearize over the correspondences of gicp_corr_kernel
@@ -544,7 +589,7 @@ GicpEngine::~GicpEngine()
     cov_grid_.release();
     d_knn_i_.release(); d_knn_d_.release();
     d_tgt_cov_.release(); d_src_cov_.release(); d_corr_.release(); d_mahal_.release(); d_partial_.release(); d_T_.release();
-    d_vox_.release(); d_vox_runs_.release();
+    d_vox_.release(); d_vox_runs_.release(); d_cur_.release();
 }
 
 int GicpEngine::set_target(const void* d, size_t n)
@@ -782,8 +827,151 @@ int GicpEngine::linearize(const double T[16], double H[36], double b[6], double*
     return run_linearize(T, true, H, b, err, n_corr);
 }
 
+namespace {
+// Rotation of the Umeyama / Kabsch problem, R = U diag(1, 1, det(U) det(V)) V^T for sigma = U S V^T: one-sided (Hestenes)
+// Jacobi SVD in f64; a vanishing singular direction is completed by the cross product of the other two.
+void umeyama_rotation(const double sigma[9], double R[9])
+{
+    double W[3][3], V[3][3];  // W = sigma V converges to U S
+    double scale = 0;
+    for (int i = 0; i < 9; ++i) scale = std::max(scale, std::fabs(sigma[i]));
+    if (!(scale > 0) || !std::isfinite(scale)) { for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0; return; }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { W[r][c] = sigma[r * 3 + c] / scale; V[r][c] = r == c ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int k = 0; k < 3; ++k) { alpha += W[k][p] * W[k][p]; beta += W[k][q] * W[k][q]; gamma += W[k][p] * W[k][q]; }
+                if (gamma == 0.0 || std::fabs(gamma) <= 1e-15 * std::sqrt(alpha * beta)) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
+                for (int k = 0; k < 3; ++k) {
+                    const double wp = W[k][p], wq = W[k][q];
+                    W[k][p] = c * wp - s * wq; W[k][q] = s * wp + c * wq;
+                    const double vp = V[k][p], vq = V[k][q];
+                    V[k][p] = c * vp - s * vq; V[k][q] = s * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    double sig[3], U[3][3];
+    int    order[3] = {0, 1, 2};
+    for (int j = 0; j < 3; ++j) sig[j] = std::sqrt(W[0][j] * W[0][j] + W[1][j] * W[1][j] + W[2][j] * W[2][j]);
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2 - a; ++b) if (sig[order[b]] < sig[order[b + 1]]) std::swap(order[b], order[b + 1]);  // descending
+    const double tiny = 1e-12 * sig[order[0]];
+    for (int jj = 0; jj < 3; ++jj) {
+        const int j = order[jj];
+        if (sig[j] > tiny) { for (int k = 0; k < 3; ++k) U[k][j] = W[k][j] / sig[j]; }
+        else if (jj == 2) {  // rank 2: complete the basis
+            const int a = order[0], b = order[1];
+            U[0][j] = U[1][a] * U[2][b] - U[2][a] * U[1][b];
+            U[1][j] = U[2][a] * U[0][b] - U[0][a] * U[2][b];
+            U[2][j] = U[0][a] * U[1][b] - U[1][a] * U[0][b];
+        } else { for (int k = 0; k < 3; ++k) U[k][j] = V[k][j]; }  // rank <= 1: no unique answer; stay finite
+    }
+    auto det3 = [](const double M[3][3]) { return M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) + M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]); };
+    double S[3] = {1, 1, 1};
+    if (det3(U) * det3(V) < 0) S[order[2]] = -1;  // the smallest singular direction flips
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double s = 0;
+            for (int j = 0; j < 3; ++j) s += U[r][j] * S[j] * V[c][j];
+            R[r * 3 + c] = s;
+        }
+}
+}  // namespace
+
+// pcl::IterativeClosestPoint::computeTransformation with TransformationEstimationSVD and DefaultConvergenceCriteria
+// (gicp_engine.h, variant 3).  Per iteration: one correspondence + moment kernel, a 17-double record to the host, a 3x3 SVD,
+// one in-place transform of the working copy of the source.
+int GicpEngine::align_icp(const float guess[16])
+{
+    if (!d_tgt_ && n_tgt_) { set_error("ICP: no target"); return MRGFE_ERR_STATE; }
+    MRGFE_TRY(ctx_->bind());
+    hipStream_t st = ctx_->stream;
+    kernel_ms = 0; kernel_launches = 0; kernel_alg_bytes = 0;
+    n_linearize_ = n_error_ = 0;
+    converged_ = false;
+    nr_iterations_ = 0;
+    for (int t = 0; t < 36; ++t) final_hessian_[t] = 0.0;
+    std::memcpy(final_, guess, sizeof(final_));
+    if (!tgt_grid_valid_) {
+        MRGFE_TRY(tgt_grid_.build(ctx_, d_tgt_, n_tgt_, 1.0f, NnGrid::kCrowding1nn, 1));
+        tgt_grid_valid_ = true;
+    }
+    const uint32_t n = static_cast<uint32_t>(n_src_);
+    constexpr uint32_t per_blk = 256u / kGicpGroup;
+    const uint32_t nblk_t = (n + 255) / 256, nblk_c = (n + per_blk - 1) / per_blk;
+    MRGFE_TRY(d_cur_.ensure(std::max<size_t>(n_src_, 1) * 16));
+    MRGFE_TRY(d_partial_.ensure(sizeof(double) * kGicpStride * (size_t(nblk_c) + 2)));
+    MRGFE_TRY(d_T_.ensure(64));
+    float4* d_cur = d_cur_.as<float4>();
+    double* d_part = d_partial_.as<double>();
+    double* d_res = d_part + size_t(nblk_c) * kGicpStride;
+    if (n) MRGFE_HIP_CHECK(hipMemcpyAsync(d_cur, d_src_, size_t(n) * 16, hipMemcpyDeviceToDevice, st));
+    bool identity = true;
+    for (int i = 0; i < 16; ++i) identity = identity && guess[i] == ((i % 5 == 0) ? 1.0f : 0.0f);
+    if (!identity && n) {
+        MRGFE_HIP_CHECK(hipMemcpyAsync(d_T_.p, guess, 48, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(icp_transform_kernel, dim3(nblk_t), dim3(256), 0, st, d_cur, n, d_T_.as<float>());
+        MRGFE_HIP_CHECK(hipStreamSynchronize(st));  // d_T_ is rewritten below
+    }
+    const double max_sq = prm_.max_corr_dist * prm_.max_corr_dist;
+    const double rot_thr = 1.0 - prm_.trans_eps, trans_thr = prm_.trans_eps;
+    double prev_mse = std::numeric_limits<double>::max();
+    for (;;) {
+        ++n_linearize_;
+        double r[kGicpStride] = {0};
+        if (n && n_tgt_) {
+            hipLaunchKernelGGL(icp_corr_sums_kernel, dim3(nblk_c), dim3(256), 0, st, tgt_grid_.dev2(), d_cur, d_tgt_, n, max_sq, d_part);
+            hipLaunchKernelGGL(gicp_reduce_kernel, dim3(1), dim3(256), 0, st, d_part, nblk_c, d_res);
+            MRGFE_HIP_CHECK(hipGetLastError());
+            MRGFE_HIP_CHECK(hipMemcpyAsync(r, d_res, sizeof(r), hipMemcpyDeviceToHost, st));
+            MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+            kernel_launches += 1;
+        }
+        const double cnt = r[0];
+        if (cnt < 3) { converged_ = false; break; }  // "Not enough correspondences found"
+        double mu_s[3], mu_d[3], sigma[9], R[9];
+        for (int a = 0; a < 3; ++a) { mu_s[a] = r[1 + a] / cnt; mu_d[a] = r[4 + a] / cnt; }
+        for (int rr = 0; rr < 3; ++rr) for (int c = 0; c < 3; ++c) sigma[rr * 3 + c] = r[7 + rr * 3 + c] / cnt - mu_d[rr] * mu_s[c];
+        umeyama_rotation(sigma, R);
+        float Tm[16];
+        for (int i = 0; i < 16; ++i) Tm[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+        const float ms[3] = {static_cast<float>(mu_s[0]), static_cast<float>(mu_s[1]), static_cast<float>(mu_s[2])};
+        for (int rr = 0; rr < 3; ++rr) {
+            for (int c = 0; c < 3; ++c) Tm[rr * 4 + c] = static_cast<float>(R[rr * 3 + c]);
+            float s = Tm[rr * 4 + 0] * ms[0];  // Rt.col(3).head(3) = dst_mean - R * src_mean, in float
+            s = s + Tm[rr * 4 + 1] * ms[1];
+            s = s + Tm[rr * 4 + 2] * ms[2];
+            Tm[rr * 4 + 3] = static_cast<float>(mu_d[rr]) - s;
+        }
+        MRGFE_HIP_CHECK(hipMemcpyAsync(d_T_.p, Tm, 48, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(icp_transform_kernel, dim3(nblk_t), dim3(256), 0, st, d_cur, n, d_T_.as<float>());
+        MRGFE_HIP_CHECK(hipGetLastError());
+        MRGFE_HIP_CHECK(hipStreamSynchronize(st));  // Tm is a local
+        float nf[16];
+        for (int rr = 0; rr < 4; ++rr)
+            for (int c = 0; c < 4; ++c) { float s = 0; for (int k = 0; k < 4; ++k) s += Tm[rr * 4 + k] * final_[k * 4 + c]; nf[rr * 4 + c] = s; }
+        std::memcpy(final_, nf, sizeof(nf));
+        ++nr_iterations_;
+        if (nr_iterations_ >= prm_.max_iterations) { converged_ = true; break; }
+        const double cos_angle = 0.5 * (static_cast<double>(Tm[0]) + static_cast<double>(Tm[5]) + static_cast<double>(Tm[10]) - 1.0);
+        const double tsq = static_cast<double>(Tm[3]) * Tm[3] + static_cast<double>(Tm[7]) * Tm[7] + static_cast<double>(Tm[11]) * Tm[11];
+        if (cos_angle >= rot_thr && tsq <= trans_thr) { converged_ = true; break; }
+        const double mse = r[16] / cnt;
+        if (std::fabs(mse - prev_mse) < 1e-12) { converged_ = true; break; }
+        prev_mse = mse;
+    }
+    return MRGFE_OK;
+}
+
 int GicpEngine::align(const float guess[16])
 {
+    if (prm_.variant == 3) return align_icp(guess);
     MRGFE_TRY(ensure_ready());
     kernel_ms = 0; kernel_launches = 0; kernel_alg_bytes = 0;
     n_linearize_ = n_error_ = 0;

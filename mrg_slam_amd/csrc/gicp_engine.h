@@ -26,6 +26,9 @@ struct GicpParams {
     // a GaussianVoxelMap of edge voxel_resolution (mean of the points and of their covariances per voxel), a source point
     // corresponds to the voxel its transformed position falls in, terms weighted by sqrt(points in the voxel); fast_gicp's LM
     double voxel_resolution = 1.0;
+    // variant 3, pcl::IterativeClosestPoint (registrations.cpp:85-92): nearest target point within max_corr_dist of the cumulatively
+    // transformed source, TransformationEstimationSVD (Umeyama, no scaling) per iteration, DefaultConvergenceCriteria with
+    // translation threshold trans_eps (on the squared translation) and rotation threshold 1 - trans_eps; no covariances
     double sg_init_lambda = 1e-3, sg_lambda_factor = 10.0;
     int    sg_max_inner_iterations = 10;
 };
@@ -84,6 +87,8 @@ class GicpEngine {
     int32_t  vox_cmin_[3] = {0, 0, 0}, vox_dim_[3] = {1, 1, 1};
     uint32_t vox_cells_ = 0, vox_occupied_ = 0;
     int build_voxelmap();
+    int align_icp(const float guess_rowmajor[16]);
+    DevBuf d_cur_;  // ICP: the source as transformed so far
     float  final_[16];
     double final_hessian_[36];
     bool   converged_ = false;

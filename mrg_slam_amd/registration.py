@@ -17,7 +17,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import GICP_HIP, NDT_HIP, SEARCH, SMALL_GICP_HIP, VGICP_HIP, Context, PairResult, RegParams, check, default_context, lib
+from ._lib import GICP_HIP, ICP_HIP, NDT_HIP, SEARCH, SMALL_GICP_HIP, VGICP_HIP, Context, PairResult, RegParams, check, default_context, lib
 
 _fp = C.POINTER(C.c_float)
 _dp = C.POINTER(C.c_double)
@@ -245,6 +245,20 @@ class VgicpHip(GicpHip):
         HipRegistration.__init__(self, p, ctx)
 
 
+class IcpHip(HipRegistration):
+    """registration_method "ICP_HIP": drop-in for the ICP branch (registrations.cpp:85-92), pcl::IterativeClosestPoint with
+    TransformationEstimationSVD and the default convergence criteria; reciprocal correspondences are not offered."""
+
+    METHOD = ICP_HIP
+
+    def __init__(self, max_correspondence_distance=2.0, transformation_epsilon=0.01, maximum_iterations=64, ctx: Context | None = None):
+        p = default_params(ICP_HIP)
+        p.max_correspondence_distance = max_correspondence_distance
+        p.transformation_epsilon = transformation_epsilon
+        p.maximum_iterations = maximum_iterations
+        super().__init__(p, ctx)
+
+
 def select_registration_method(params: dict, ctx: Context | None = None) -> HipRegistration:
     """Python mirror of mrg_slam::select_registration_method (registrations.cpp:28-152) for the HIP back ends.
 
@@ -253,8 +267,8 @@ def select_registration_method(params: dict, ctx: Context | None = None) -> HipR
     reg_resolution, reg_nn_search_method).  "NDT_HIP" (and, to stay drop-in, "NDT_OMP"/"NDT") select :class:`NdtHip`;
     "GICP_HIP" / "FAST_GICP" select :class:`GicpHip`, "SMALL_GICP_HIP" / "SMALL_GICP" :class:`SmallGicpHip`, "VGICP_HIP" /
     "FAST_VGICP" / "FAST_VGICP_CUDA" :class:`VgicpHip`.  Like the reference, an unknown name falls through to NDT; "NDT"
-    (pcl's single-threaded class) gets the KDTREE neighbourhood, its only one, on the pclomp float formulation; "ICP", "GICP"
-    and "GICP_OMP" raise NotImplementedError.
+    (pcl's single-threaded class) gets the KDTREE neighbourhood, its only one, on the pclomp float formulation; "ICP" / "ICP_HIP"
+    select :class:`IcpHip`; "GICP" and "GICP_OMP" raise NotImplementedError.
     """
     method = str(params.get("registration_method", "FAST_GICP"))
     eps = float(params.get("reg_transformation_epsilon", 0.01))
@@ -269,11 +283,15 @@ def select_registration_method(params: dict, ctx: Context | None = None) -> HipR
     if method in ("GICP_HIP", "FAST_GICP"):
         return GicpHip(int(params.get("reg_correspondence_randomness", 20)), float(params.get("reg_max_correspondence_distance", 2.0)), eps,
                        maximum_iterations=iters, num_threads=threads, ctx=ctx)
-    if method == "ICP" or ("GICP" in method):
-        # registrations.cpp:85-114: pcl::IterativeClosestPoint, pcl::GeneralizedIterativeClosestPoint and pclomp::GICP (BFGS
-        # inner optimiser) have no HIP counterpart here; running something else in their name would be wrong
+    if method in ("ICP", "ICP_HIP"):
+        if bool(params.get("reg_use_reciprocal_correspondences", False)):
+            raise NotImplementedError("ICP_HIP: reciprocal correspondences are not offered")
+        return IcpHip(float(params.get("reg_max_correspondence_distance", 2.0)), eps, iters, ctx=ctx)
+    if "GICP" in method:
+        # registrations.cpp:93-114: pcl::GeneralizedIterativeClosestPoint and pclomp::GICP (BFGS inner optimiser) have no HIP
+        # counterpart here; running something else in their name would be wrong
         raise NotImplementedError(f'registration_method "{method}" is not offered by libmrgfe (available: NDT_OMP/NDT_HIP, FAST_GICP/GICP_HIP, '
-                                  f'SMALL_GICP/SMALL_GICP_HIP, FAST_VGICP/FAST_VGICP_CUDA/VGICP_HIP)')
+                                  f'SMALL_GICP/SMALL_GICP_HIP, FAST_VGICP/FAST_VGICP_CUDA/VGICP_HIP, ICP/ICP_HIP)')
     search = str(params.get("reg_nn_search_method", "DIRECT7"))
     if search not in ("KDTREE", "DIRECT1"):
         search = "DIRECT7"  # registrations.cpp:140-146: anything else means DIRECT7

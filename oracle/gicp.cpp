@@ -382,9 +382,92 @@ void FastGicp::align_small_gicp(const float guess[16])
     for (int i = 0; i < 16; ++i) final_[i] = static_cast<float>(T[i]);
 }
 
+// pcl::IterativeClosestPoint::computeTransformation + DefaultConvergenceCriteria::hasConverged +
+// TransformationEstimationSVD (header of gicp.h)
+void FastGicp::align_icp(const float guess[16])
+{
+    const int n = static_cast<int>(source.size() / 4), nt = static_cast<int>(target.size() / 4);
+    if (!target_grid_valid_) { target_grid_.build(target.data(), nt, 1.0f); target_grid_valid_ = true; }
+    std::vector<float> cur(source);
+    bool guess_is_identity = true;
+    for (int i = 0; i < 16; ++i) guess_is_identity = guess_is_identity && guess[i] == ((i % 5 == 0) ? 1.0f : 0.0f);
+    if (!guess_is_identity)
+        for (int i = 0; i < n; ++i) transform_point_f(guess, source[4 * static_cast<size_t>(i)], source[4 * static_cast<size_t>(i) + 1], source[4 * static_cast<size_t>(i) + 2],
+                                                      cur[4 * static_cast<size_t>(i)], cur[4 * static_cast<size_t>(i) + 1], cur[4 * static_cast<size_t>(i) + 2]);
+    float fin[16];
+    std::memcpy(fin, guess, sizeof(fin));
+    converged = false;
+    nr_iterations = 0;
+    n_linearize = n_error_evals = 0;
+    for (int t = 0; t < 36; ++t) final_hessian[t] = 0.0;
+    const double max_sq = max_corr_dist * max_corr_dist;
+    const double rot_thr = 1.0 - trans_eps, trans_thr = trans_eps;  // setRotationThreshold(1 - eps), setTranslationThreshold(eps)
+    double prev_mse = std::numeric_limits<double>::max();
+    for (;;) {
+        ++n_linearize;
+        double cnt = 0, Ss[3] = {0, 0, 0}, Sd[3] = {0, 0, 0}, Sds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Smse = 0;
+        for (int i = 0; i < n; ++i) {
+            const float* p = &cur[4 * static_cast<size_t>(i)];
+            float sqd;
+            const int j = nt ? target_grid_.nearest(p[0], p[1], p[2], sqd) : -1;
+            if (j < 0 || static_cast<double>(sqd) > max_sq) continue;
+            const float* q = &target[4 * static_cast<size_t>(j)];
+            cnt += 1;
+            for (int a = 0; a < 3; ++a) { Ss[a] += p[a]; Sd[a] += q[a]; }
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Sds[r * 3 + c] += static_cast<double>(q[r]) * static_cast<double>(p[c]);
+            Smse += sqd;
+        }
+        if (cnt < 3) { converged = false; break; }  // "Not enough correspondences found"
+        double mu_s[3], mu_d[3], sigma[9], R[9];
+        for (int a = 0; a < 3; ++a) { mu_s[a] = Ss[a] / cnt; mu_d[a] = Sd[a] / cnt; }
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) sigma[r * 3 + c] = Sds[r * 3 + c] / cnt - mu_d[r] * mu_s[c];
+        umeyama_rotation(sigma, R);
+        float Tm[16];
+        mat4f_identity(Tm);
+        const float ms[3] = {static_cast<float>(mu_s[0]), static_cast<float>(mu_s[1]), static_cast<float>(mu_s[2])};
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) Tm[r * 4 + c] = static_cast<float>(R[r * 3 + c]);
+            float s = Tm[r * 4 + 0] * ms[0];  // Rt.col(3).head(3) = dst_mean - R * src_mean, in float
+            s = s + Tm[r * 4 + 1] * ms[1];
+            s = s + Tm[r * 4 + 2] * ms[2];
+            Tm[r * 4 + 3] = static_cast<float>(mu_d[r]) - s;
+        }
+        for (int i = 0; i < n; ++i) {
+            float* p = &cur[4 * static_cast<size_t>(i)];
+            float x, y, z;
+            transform_point_f(Tm, p[0], p[1], p[2], x, y, z);
+            p[0] = x; p[1] = y; p[2] = z;
+        }
+        float nf[16];
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) { float s = 0; for (int k = 0; k < 4; ++k) s += Tm[r * 4 + k] * fin[k * 4 + c]; nf[r * 4 + c] = s; }
+        std::memcpy(fin, nf, sizeof(fin));
+        ++nr_iterations;
+        // DefaultConvergenceCriteria::hasConverged
+        if (nr_iterations >= max_iterations) { converged = true; break; }
+        const double cos_angle = 0.5 * (static_cast<double>(Tm[0]) + static_cast<double>(Tm[5]) + static_cast<double>(Tm[10]) - 1.0);
+        const double tsq = static_cast<double>(Tm[3]) * Tm[3] + static_cast<double>(Tm[7]) * Tm[7] + static_cast<double>(Tm[11]) * Tm[11];
+        if (cos_angle >= rot_thr && tsq <= trans_thr) { converged = true; break; }
+        const double mse = Smse / cnt;
+        if (std::fabs(mse - prev_mse) < 1e-12) { converged = true; break; }
+        prev_mse = mse;
+    }
+    std::memcpy(final_, fin, sizeof(fin));
+}
+
 void FastGicp::align(const float guess[16], float* aligned)
 {
     const int n = static_cast<int>(source.size() / 4);
+    if (variant == 3) {
+        align_icp(guess);
+        if (aligned)
+            for (int i = 0; i < n; ++i) {
+                const float* p = &source[4 * static_cast<size_t>(i)];
+                transform_point_f(final_, p[0], p[1], p[2], aligned[4 * i], aligned[4 * i + 1], aligned[4 * i + 2]);
+                aligned[4 * i + 3] = p[3];
+            }
+        return;
+    }
     ensure_covs();
     if (variant == 1) {
         align_small_gicp(guess);

@@ -21,6 +21,14 @@
 // accumulation: per voxel the mean of its points and the mean of their regularised covariances; voxel of x =
 // floor(x / resolution - 0.5)), a source point corresponds to the voxel its transformed position falls in (DIRECT1),
 // every term carries the weight sqrt(points in the voxel); optimiser, Jacobian and convergence test are fast_gicp's.
+//
+// `variant = 3` restates pcl::IterativeClosestPoint<PointXYZI,PointXYZI> (PCL 1.12, registrations.cpp:85-92: setTransformationEpsilon,
+// setMaximumIterations, setMaxCorrespondenceDistance, reciprocal correspondences off): per iteration the cumulatively
+// transformed source is matched to its nearest target points within the distance limit, TransformationEstimationSVD
+// (Umeyama without scaling) gives the increment, DefaultConvergenceCriteria decides (iterations >= max; or rotation cosine >=
+// 1 - epsilon and squared translation <= epsilon; or |mse - previous mse| < 1e-12).  Documented deviations: Eigen's float
+// reductions have no fixed order, so the moment sums are f64 and the 3x3 SVD is a one-sided Jacobi in f64 before the result
+// is cast to the float matrices PCL works with.
 #pragma once
 #include <map>
 #include <vector>
@@ -38,7 +46,7 @@ struct FastGicp {
     int    num_threads       = 1;
     int    lm_max_iterations = 10;
     double lm_init_lambda_factor = 1e-9;
-    int    variant = 0;                 // 0: fast_gicp::FastGICP, 1: small_gicp::RegistrationPCL (GICP), 2: fast_gicp::FastVGICP
+    int    variant = 0;                 // 0: fast_gicp::FastGICP, 1: small_gicp::RegistrationPCL (GICP), 2: fast_gicp::FastVGICP, 3: pcl::IterativeClosestPoint
     double voxel_resolution = 1.0;      // variant 2: setResolution(reg_resolution)
     double sg_init_lambda = 1e-3, sg_lambda_factor = 10.0;  // small_gicp::LevenbergMarquardtOptimizer defaults
     int    sg_max_inner_iterations = 10;
@@ -57,6 +65,7 @@ struct FastGicp {
     void   set_source(const float* xyzi, int n);
     void   align(const float guess_rowmajor[16], float* aligned);
     void   align_small_gicp(const float guess_rowmajor[16]);  // variant 1: leaves the result in final_
+    void   align_icp(const float guess_rowmajor[16]);         // variant 3
     double fitness(double max_range) const;
     void   get_covariances(int which, double* out) const;  // 0 = source, 1 = target (computes if needed)
     // update_correspondences + linearize at T (row-major 4x4 double). returns sum of errors.

@@ -213,6 +213,61 @@ struct JacobiSvd6 {
 
 // ------------------------------------------------------------------------------------------------------
 // float 4x4 helpers, row-major M[r*4+c].
+// Rotation of the Umeyama / Kabsch problem: R = U diag(1, 1, det(U) det(V)) V^T for sigma = U S V^T, through a one-sided
+// (Hestenes) Jacobi SVD in f64.  A vanishing singular direction is completed by the cross product of the other two.
+inline void umeyama_rotation(const double sigma[9], double R[9])
+{
+    double W[3][3], V[3][3];  // W = sigma V converges to U S
+    double scale = 0;
+    for (int i = 0; i < 9; ++i) scale = std::max(scale, std::fabs(sigma[i]));
+    if (!(scale > 0) || !std::isfinite(scale)) { for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0; return; }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { W[r][c] = sigma[r * 3 + c] / scale; V[r][c] = r == c ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int k = 0; k < 3; ++k) { alpha += W[k][p] * W[k][p]; beta += W[k][q] * W[k][q]; gamma += W[k][p] * W[k][q]; }
+                if (gamma == 0.0 || std::fabs(gamma) <= 1e-15 * std::sqrt(alpha * beta)) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
+                for (int k = 0; k < 3; ++k) {
+                    const double wp = W[k][p], wq = W[k][q];
+                    W[k][p] = c * wp - s * wq; W[k][q] = s * wp + c * wq;
+                    const double vp = V[k][p], vq = V[k][q];
+                    V[k][p] = c * vp - s * vq; V[k][q] = s * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    double sig[3], U[3][3];
+    int    order[3] = {0, 1, 2};
+    for (int j = 0; j < 3; ++j) sig[j] = std::sqrt(W[0][j] * W[0][j] + W[1][j] * W[1][j] + W[2][j] * W[2][j]);
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2 - a; ++b) if (sig[order[b]] < sig[order[b + 1]]) std::swap(order[b], order[b + 1]);  // descending
+    const double tiny = 1e-12 * sig[order[0]];
+    for (int jj = 0; jj < 3; ++jj) {
+        const int j = order[jj];
+        if (sig[j] > tiny) { for (int k = 0; k < 3; ++k) U[k][j] = W[k][j] / sig[j]; }
+        else if (jj == 2) {  // rank 2: complete the basis
+            const int a = order[0], b = order[1];
+            U[0][j] = U[1][a] * U[2][b] - U[2][a] * U[1][b];
+            U[1][j] = U[2][a] * U[0][b] - U[0][a] * U[2][b];
+            U[2][j] = U[0][a] * U[1][b] - U[1][a] * U[0][b];
+        } else { for (int k = 0; k < 3; ++k) U[k][j] = V[k][j]; }  // rank <= 1: no unique answer; stay finite
+    }
+    auto det3 = [](const double M[3][3]) { return M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) + M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]); };
+    double S[3] = {1, 1, 1};
+    if (det3(U) * det3(V) < 0) S[order[2]] = -1;  // the smallest singular direction flips
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double s = 0;
+            for (int j = 0; j < 3; ++j) s += U[r][j] * S[j] * V[c][j];
+            R[r * 3 + c] = s;
+        }
+}
+
 inline void mat4f_identity(float M[16]) { for (int i = 0; i < 16; ++i) M[i] = (i % 5 == 0) ? 1.0f : 0.0f; }
 inline bool mat4f_is_identity(const float M[16])
 {

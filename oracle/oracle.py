@@ -413,3 +413,12 @@ class FastVgicp(FastGicp):
 
     def numVoxels(self):
         return lib().orc_gicp_num_voxels(self._h)
+
+
+class Icp(FastGicp):
+    """pcl::IterativeClosestPoint restated (oracle/gicp.h, variant 3)."""
+
+    VARIANT = 3
+
+    def __init__(self, max_correspondence_distance=2.0, transformation_epsilon=0.01, maximum_iterations=64):
+        super().__init__(20, max_correspondence_distance, transformation_epsilon, 2e-3, maximum_iterations, 1)

@@ -8,6 +8,7 @@ the HIP path against them on the GPU box.  Re-run only when the oracle is delibe
     python tests/golden/make_golden.py                      # all three files
     python tests/golden/make_golden.py --small-gicp-only    # tests/golden/small_gicp.npz only
     python tests/golden/make_golden.py --vgicp-only         # tests/golden/vgicp.npz only
+    python tests/golden/make_golden.py --icp-only           # tests/golden/icp.npz only
 """
 import os
 import sys
@@ -137,8 +138,26 @@ def vgicp():
     print(path, os.path.getsize(path), "bytes")
 
 
+def icp():
+    """tests/golden/icp.npz: the restated pcl::IterativeClosestPoint (oracle variant 3) on the inputs of frontend_small.npz."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "frontend_small.npz"))
+    out = {}
+    for tag, guess, eps in (("warm", G["guess"], 0.01), ("identity", np.eye(4), 1e-6)):
+        g = orc.Icp(transformation_epsilon=eps)
+        g.setInputTarget(G["tgt"])
+        g.setInputSource(G["src"])
+        g.align(guess)
+        out[f"{tag}_T"] = g.getFinalTransformation()
+        out[f"{tag}_meta"] = np.array([g.hasConverged(), g.getFinalNumIteration()], dtype=np.int64)
+    path = os.path.join(ROOT, "tests", "golden", "icp.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    if "--small-gicp-only" in sys.argv:
+    if "--icp-only" in sys.argv:
+        icp()
+    elif "--small-gicp-only" in sys.argv:
         small_gicp()
     elif "--vgicp-only" in sys.argv:
         vgicp()
@@ -146,3 +165,4 @@ if __name__ == "__main__":
         main()
         small_gicp()
         vgicp()
+        icp()

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     from conftest import small_cloud
-    from mrg_slam_amd import GicpHip, NdtHip, SmallGicpHip, VgicpHip, synth
+    from mrg_slam_amd import GicpHip, IcpHip, NdtHip, SmallGicpHip, VgicpHip, synth
     from oracle import oracle as orc
 
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -35,6 +35,10 @@ def main():
             g = NdtHip(resolution=res, transformation_epsilon=eps, maximum_iterations=64, search=search)
             o = orc.Ndt(resolution=res, transformation_epsilon=eps, maximum_iterations=64, num_threads=8, search=search)
             tag = f"NDT res={res} {search} eps={eps}"
+        elif rng.random() < 0.2:
+            g = IcpHip(transformation_epsilon=eps * 1e-3)
+            o = orc.Icp(transformation_epsilon=eps * 1e-3)
+            tag = f"ICP eps={eps * 1e-3}"
         elif rng.random() < 0.3:
             vres = float(rng.choice([0.5, 1.0, 2.0]))
             g = VgicpHip(resolution=vres, transformation_epsilon=eps)

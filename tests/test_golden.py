@@ -95,6 +95,20 @@ def test_oracle_vgicp_reproduces_golden():
     assert np.linalg.norm(V["warm_T"][:3, 3] - G["rel"][:3, 3]) < 0.05
 
 
+def test_oracle_icp_reproduces_golden():
+    from oracle import oracle as orc
+
+    I = np.load(os.path.join(os.path.dirname(__file__), "golden", "icp.npz"))
+    for tag, guess, eps in (("warm", G["guess"], 0.01), ("identity", np.eye(4), 1e-6)):
+        g = orc.Icp(transformation_epsilon=eps)
+        g.setInputTarget(G["tgt"])
+        g.setInputSource(G["src"])
+        g.align(guess)
+        np.testing.assert_array_equal(g.getFinalTransformation(), I[f"{tag}_T"])
+        assert [int(g.hasConverged()), g.getFinalNumIteration()] == I[f"{tag}_meta"].tolist()
+    assert np.linalg.norm(I["identity_T"][:3, 3] - G["rel"][:3, 3]) < 0.02
+
+
 def test_oracle_perpoint_passes_reproduce_golden():
     from oracle import oracle as orc
 
@@ -195,6 +209,22 @@ def test_hip_small_gicp_matches_golden():
     H, b, e, n = g.linearize(np.asarray(G["guess"], dtype=np.float64))
     assert n == S["lin_n"][0] and e == pytest.approx(S["lin_err"][0], rel=1e-12)
     np.testing.assert_allclose(H, S["lin_H"], rtol=0, atol=1e-12 * np.abs(S["lin_H"]).max())
+
+
+@pytest.mark.gpu
+def test_hip_icp_matches_golden():
+    from mrg_slam_amd import IcpHip, synth
+
+    I = np.load(os.path.join(os.path.dirname(__file__), "golden", "icp.npz"))
+    for tag, guess, eps in (("warm", G["guess"], 0.01), ("identity", np.eye(4), 1e-6)):
+        g = IcpHip(transformation_epsilon=eps)
+        g.setInputTarget(G["tgt"])
+        g.setInputSource(G["src"])
+        g.align(guess)
+        T = g.getFinalTransformation()
+        assert np.linalg.norm(T[:3, 3].astype(np.float64) - I[f"{tag}_T"][:3, 3]) <= 1e-4
+        assert synth.rotation_angle(T, I[f"{tag}_T"]) <= 1e-4
+        assert [int(g.hasConverged()), g.getFinalNumIteration()] == I[f"{tag}_meta"].tolist()
 
 
 @pytest.mark.gpu

@@ -160,6 +160,9 @@ def test_factory_mirror_dispatch():
     assert select_registration_method({"registration_method": "NDT_OMP", "reg_nn_search_method": "DIRECT1"})._params.nn_search_method == SEARCH["DIRECT1"]
     assert select_registration_method({"registration_method": "NDT"})._params.nn_search_method == SEARCH["KDTREE"]
     assert select_registration_method({"registration_method": "FAST_VGICP", "reg_resolution": 0.5})._params.resolution == 0.5
-    for name in ("ICP", "GICP", "GICP_OMP"):
+    from mrg_slam_amd import IcpHip
+
+    assert type(select_registration_method({"registration_method": "ICP"})) is IcpHip
+    for kw in ({"registration_method": "GICP"}, {"registration_method": "GICP_OMP"}, {"registration_method": "ICP", "reg_use_reciprocal_correspondences": True}):
         with pytest.raises(NotImplementedError):
-            select_registration_method({"registration_method": name})
+            select_registration_method(kw)

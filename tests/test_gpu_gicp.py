@@ -277,3 +277,56 @@ def test_vgicp_rejects_a_voxel_map_that_does_not_fit():
         g.align(np.eye(4))
     with pytest.raises(MrgfeError):
         VgicpHip(resolution=0.0)
+
+
+@pytest.mark.parametrize("eps", [0.01, 1e-4, 1e-8])
+@pytest.mark.parametrize("guess_seed", [None, 7])
+def test_icp_align_matches_oracle(eps, guess_seed):
+    """ICP_HIP (pcl::IterativeClosestPoint, registrations.cpp:85-92): same iteration count, convergence decision and result
+    as the restated algorithm; bar 1e-4 m / 1e-4 rad."""
+    from mrg_slam_amd import IcpHip, synth
+    from oracle import oracle as orc
+
+    tgt, src, rel = _pair()
+    guess = np.eye(4) if guess_seed is None else synth.perturb_pose(rel, np.random.default_rng(guess_seed))
+    g, o = IcpHip(transformation_epsilon=eps), orc.Icp(transformation_epsilon=eps)
+    for r in (g, o):
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+    aligned = g.align(guess, want_aligned=True)
+    o.align(guess)
+    Tg, To = g.getFinalTransformation(), o.getFinalTransformation()
+    assert g.hasConverged() == o.hasConverged()
+    assert g.getFinalNumIteration() == o.getFinalNumIteration()
+    assert np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3]) <= 1e-4
+    assert _rot_angle(Tg[:3, :3], To[:3, :3]) <= 1e-4
+    np.testing.assert_array_equal(aligned, orc.transform_points(Tg, src))
+    assert g.getFitnessScore() == pytest.approx(o.getFitnessScore(), rel=1e-3, abs=1e-9)
+
+
+def test_icp_exact_copy_limits_and_degenerate_inputs():
+    from mrg_slam_amd import IcpHip, synth
+    from oracle import oracle as orc
+
+    tgt = small_cloud(3000, 31)
+    rel = synth.make_pose([0.15, -0.1, 0.02], synth.rot_xyz(0.01, -0.005, 0.02))
+    src = orc.transform_points(np.linalg.inv(rel), tgt)  # an exact rigid copy: ICP must land on the motion
+    g = IcpHip(transformation_epsilon=1e-8)
+    g.setInputTarget(tgt)
+    g.setInputSource(src)
+    g.align(np.eye(4))
+    T = g.getFinalTransformation().astype(np.float64)
+    assert g.hasConverged() and np.linalg.norm(T[:3, 3] - rel[:3, 3]) < 1e-5 and synth.rotation_angle(T, rel) < 1e-5
+    one = IcpHip(transformation_epsilon=1e-12, maximum_iterations=1)  # the iteration limit counts as converged (failure_after_max_iter_ = false)
+    one.setInputTarget(tgt)
+    one.setInputSource(src)
+    one.align(np.eye(4))
+    assert one.hasConverged() and one.getFinalNumIteration() == 1
+    for t, s_ in ((tgt, np.zeros((0, 4), np.float32)), (np.zeros((0, 4), np.float32), src), (tgt, src + np.float32([1000, 0, 0, 0]))):
+        r, o = IcpHip(), orc.Icp()
+        for x in (r, o):
+            x.setInputTarget(t)
+            x.setInputSource(s_)
+            x.align(np.eye(4))
+        assert r.hasConverged() == o.hasConverged() and r.getFinalNumIteration() == o.getFinalNumIteration()
+        np.testing.assert_allclose(r.getFinalTransformation(), o.getFinalTransformation(), atol=1e-5)

@@ -103,3 +103,36 @@ def test_vgicp_voxel_map_and_weights():
     far.setInputTarget(tgt)
     far.setInputSource(src + np.float32([500, 0, 0, 0]))
     assert far.linearize(np.eye(4))[3] == 0  # nothing falls in an occupied voxel
+
+
+def test_icp_restatement_properties():
+    """pcl::IterativeClosestPoint restated: an exact rigid copy is recovered; the iteration limit counts as converged
+    (failure_after_max_iter_ is false); fewer than three correspondences end the loop unconverged; the Umeyama rotation of a
+    reflected correlation is still a proper rotation."""
+    from mrg_slam_amd import synth
+    from oracle import oracle as orc
+
+    tgt, src, rel = _pair(2000, 17)
+    g = orc.Icp(transformation_epsilon=1e-8)
+    g.setInputTarget(tgt)
+    g.setInputSource(src)
+    g.align(np.eye(4))
+    T = g.getFinalTransformation().astype(np.float64)
+    assert g.hasConverged() and np.linalg.norm(T[:3, 3] - rel[:3, 3]) < 1e-5 and synth.rotation_angle(T, rel) < 1e-5
+    assert abs(np.linalg.det(T[:3, :3]) - 1.0) < 1e-5
+    one = orc.Icp(transformation_epsilon=1e-12, maximum_iterations=1)
+    one.setInputTarget(tgt)
+    one.setInputSource(src)
+    one.align(np.eye(4))
+    assert one.hasConverged() and one.getFinalNumIteration() == 1
+    far = orc.Icp(max_correspondence_distance=0.5)
+    far.setInputTarget(tgt)
+    far.setInputSource(src + np.float32([100, 0, 0, 0]))
+    far.align(np.eye(4))
+    assert not far.hasConverged() and far.getFinalNumIteration() == 0
+    np.testing.assert_array_equal(far.getFinalTransformation(), np.eye(4, dtype=np.float32))
+    loose = orc.Icp(transformation_epsilon=0.5)  # cos >= 0.5 and |t|^2 <= 0.5 after the first increment
+    loose.setInputTarget(tgt)
+    loose.setInputSource(src)
+    loose.align(np.eye(4))
+    assert loose.hasConverged() and loose.getFinalNumIteration() == 1
