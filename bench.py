@@ -2,17 +2,26 @@
 """bench.py — scan-pair NDT alignments per second on MI355X (BASELINE.json metric), one rank per GPU.
 
 Step      = one pass of the hot path over one batch of B (default 256: the candidate-batch size of BASELINE config[3])
-            synthetic VLP-64 scan pairs already resident in HBM:
+            DISTINCT synthetic VLP-64 scan pairs already resident in HBM (2 x 257 scans ~ 1 GB per rank: past the 256 MiB
+            Infinity Cache, so the source stream of every derivative launch really comes from HBM):
             for every pair  setInputTarget (voxel covariance grid build)  +  setInputSource  +  align(guess)
             (reference call sites: apps/scan_matching_odometry_component.cpp:203,208,265-266; loop_detector.cpp:104,127,134),
             advanced together by the batched engine (one derivative launch per round for all pairs still running).
 Workload  = BASELINE config[1] shape: ~120k points per scan, NDT resolution 1.0 m, DIRECT7, reg_transformation_epsilon 0.1,
-            reg_maximum_iterations 64 (config/mrg_slam.yaml:100-109), warm initial guesses (perturbed truth, seed 777+k).
+            reg_maximum_iterations 64 (config/mrg_slam.yaml:100-109); initial guesses as SURVEY.md §8(d) specifies them: warm
+            (perturbed truth, seed 777+k) for three pairs in four, cold (identity) for every fourth (--cold-every).
             No KITTI data exists here: scans are ray-cast by mrg_slam_amd/synth.py; the 0.1 m voxel
             prefilter saturates this synthetic street at ~35k points, so the ~120k-point clouds the metric is quoted
             on are the distance-filtered (0.1..35 m) scans (--prefilter full selects the whole chain instead).
-N > 1     = weak scaling: every rank aligns its own B pairs (independent units, no data-path collective), then the ranks
-            all-gather the 384-byte result records over RCCL (the pose/Hessian gather of the north star).
+N > 1     = `python bench.py --gpus N` starts the N ranks itself (child processes, before anything touches the GPU) unless a
+            launcher (torchrun) already did (WORLD_SIZE set).
+            --mode weak (default): every rank aligns its own B pairs (independent units, no data-path collective), then the
+            ranks all-gather the 384-byte result records over RCCL (the pose/Hessian gather of the north star).
+            --mode shard: BASELINE config[3] as stated — 256 loop-closure candidate pairs in total (64 keyframes on a 40 m
+            ring, seed 4242), pair i -> rank i mod G, every rank builds only the target grids its pairs need, fitness score
+            with max_range = inf, RCCL all-gather of the records, replay of the reference's best-candidate rule
+            (loop_detector.cpp:126-145) per new keyframe.  Strong scaling.  The default run also measures a few steps of it
+            and reports them under "config3_shard" (never as `value`).
 Output    = ONE JSON line (rank 0) with `roofline` (derivative kernel: algorithmic bytes / HIP-event time on the launch
             stream) and `cpu_baseline` (the CPU oracle, kind "port", timed on a bounded sample of the same pairs).
 """
@@ -22,6 +31,8 @@ import argparse
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +43,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+METRIC = "scan-pair alignments/sec (NDT, ~120k pts, 1.0 m voxel)"
 
 
 def rot_angle(Ra, Rb):
@@ -40,8 +52,37 @@ def rot_angle(Ra, Rb):
     return synth.rotation_angle(Ra, Rb)
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# N ranks from one command line
+# ------------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N copies of this command line as child processes, one per GPU
+    (RANK = LOCAL_RANK = i), wait for them and pass rank 0's JSON line through.  Runs before this process imports torch or
+    touches HIP — it never does either.  Returns the exit code (non-zero if any rank failed)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"[bench] ranks failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# workloads (host side, before the process touches the GPU: the scans are ray-cast on a pool of forked workers)
+# ------------------------------------------------------------------------------------------------------------------------
 def make_workload(n_distinct: int, batch: int, rank: int, prefilter_mode: str):
-    """Returns (targets, sources, guesses, truths): `batch` pairs built from `n_distinct` consecutive synthetic scans."""
+    """BASELINE config[1] shape. Returns (scene, poses, raw scans): n_distinct + 1 consecutive scans; pair k = (scan k, scan k + 1)."""
     from mrg_slam_amd import synth
 
     kitti = os.environ.get("KITTI_ROOT")
@@ -60,12 +101,35 @@ def make_workload(n_distinct: int, batch: int, rank: int, prefilter_mode: str):
         if poses is None:
             poses = [synth.make_pose([1.0 * k, 0.0, 0.0], np.eye(3)) for k in range(n_distinct + 1)]
         return None, poses, scans
-    scene = synth.street_scene()
-    # every rank drives its own stretch of the street (40 m further along x), same gentle arc
-    start = synth.make_pose([40.0 * rank, 0.0, 0.0], np.eye(3))
-    poses = [start @ T for T in synth.arc_trajectory(n_distinct + 1)]
-    scans = [synth.synth_lidar(scene, poses[k], "VLP64", synth.BASE_SEED + 40 * rank + k) for k in range(n_distinct + 1)]
+    # every rank drives its own street (scene seed 1234 + rank), 1 m and +-1.5 deg of yaw per scan, weaving between the building rows
+    scene = synth.street_scene(seed=1234 + rank, x_range=(-120.0, float(max(420, n_distinct + 140))))
+    poses = synth.weave_trajectory(n_distinct + 1)
+    seeds = [synth.BASE_SEED + 100000 * rank + k for k in range(n_distinct + 1)]
+    scans = synth.synth_lidar_many(scene, poses, "VLP64", seeds, cache_tag=f"street_r{rank}_n{n_distinct + 1}")
     return scene, poses, scans
+
+
+def make_loop_workload(n_keyframes: int = 64, n_pairs: int = 256, radius: float = 40.0, seed: int = 4242):
+    """BASELINE config[3] (SURVEY.md §8d "C4"): keyframes on a ring road, (new keyframe, candidate) pairs with xy distance
+    <= candidate_max_xy_distance = 15 m (config/mrg_slam.yaml:169), drawn with `seed`, guesses = relative pose of the graph
+    estimates = truth perturbed by N(0, 0.5 m / 2 deg).  Same on every rank.  Returns (scans, pairs) with pairs sorted by new
+    keyframe: (new keyframe index, candidate index, guess 4x4, true relative pose)."""
+    from mrg_slam_amd import synth
+
+    scene = synth.loop_scene(radius=radius)
+    poses = synth.loop_trajectory(n_keyframes, radius)
+    scans = synth.synth_lidar_many(scene, poses, "VLP64", [synth.BASE_SEED + 5000 + k for k in range(n_keyframes)], cache_tag=f"loop_k{n_keyframes}_r{int(radius)}")
+    rng = np.random.default_rng(seed)
+    cand = [(a, b) for a in range(n_keyframes) for b in range(n_keyframes)
+            if a != b and np.hypot(*(poses[a][:2, 3] - poses[b][:2, 3])) <= 15.0]
+    pick = sorted(rng.choice(len(cand), size=min(n_pairs, len(cand)), replace=False).tolist())
+    pairs = []
+    for i in pick:
+        a, b = cand[i]
+        rel = np.linalg.inv(poses[a]) @ poses[b]  # candidate -> new keyframe frame (loop_detector.cpp:130)
+        guess = synth.perturb_pose(rel, rng, sigma_t=(0.5, 0.5, 0.1), sigma_r_deg=(0.5, 0.5, 2.0))
+        pairs.append((a, b, guess, rel))
+    return scans, pairs
 
 
 def main():
@@ -73,57 +137,76 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=["weak", "shard"], default="weak", help="weak: B own pairs per rank (config[1] shape); shard: config[3], 256 pairs over all ranks")
     ap.add_argument("--batch", type=int, default=256, help="scan pairs per step and per GPU (more pairs in flight keep the GPU full in the late rounds)")
-    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic scan pairs generated per rank (reused with different guesses)")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic scan pairs generated per rank (0: = --batch, every pair its own two scans)")
+    ap.add_argument("--cold-every", type=int, default=4, help="every n-th pair starts from the identity guess (0: warm guesses only)")
     ap.add_argument("--prefilter", choices=["distance", "full"], default="distance")
     ap.add_argument("--eps", type=float, default=0.1, help="reg_transformation_epsilon (config/mrg_slam.yaml:102)")
-    ap.add_argument("--cpu-pairs", type=int, default=96, help="pairs of the bounded CPU-oracle sample, ~10-15 s of CPU work (0 disables)")
+    ap.add_argument("--cpu-pairs", type=int, default=64, help="pairs of the bounded CPU-oracle sample, ~10-20 s of CPU work (0 disables)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--shard-steps", type=int, default=3, help="steps of the config[3] side measurement of a --mode weak run (0 disables)")
+    ap.add_argument("--prepare-only", action="store_true", help="generate (and cache) the synthetic scans, then exit without touching the GPU")
     ap.add_argument("--latency", action="store_true", help="also time single-pair setInputTarget+align latency (extra, differently sized launches of the "
                                                             "same kernels: off by default so rocprof averages of the default run describe the timed workload)")
     args = ap.parse_args()
+    if args.distinct <= 0:
+        args.distinct = args.batch
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("BENCH_SPAWN_TEST"):  # CPU test hook of the launcher above: report the rank environment and stop before any GPU work
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "rank": rank, "local_rank": local_rank, "master": os.environ.get("MASTER_ADDR"), "port": os.environ.get("MASTER_PORT")}))
+        sys.exit(int(os.environ.get("BENCH_SPAWN_TEST_FAIL_RANK", "-1")) == rank)
 
-    import torch  # first: libmrgfe then binds to the HIP runtime already in the process
+    # ---- inputs, host part (untimed; forks worker processes, so it runs before the GPU is initialised) ------------------
+    from mrg_slam_amd import synth
+
+    t_gen = time.time()
+    scene = poses = raw = None
+    if args.mode == "weak":
+        scene, poses, raw = make_workload(args.distinct, args.batch, rank, args.prefilter)
+    loop_raw = loop_pairs = None
+    if args.mode == "shard" or args.shard_steps > 0:
+        loop_raw, loop_pairs = make_loop_workload()
+    if args.prepare_only:
+        print(f"[bench rank {rank}] synthetic scans ready in {time.time() - t_gen:.1f} s", file=sys.stderr)
+        return
+
+    import torch  # before libmrgfe: it then binds to the HIP runtime already in the process
     import torch.distributed as dist
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    if os.environ.get("BENCH_DIST_BACKEND", "nccl") != "nccl":
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if backend != "nccl":
         local_rank %= torch.cuda.device_count()  # test hook only: gloo ranks may share a GPU (one rank per GPU otherwise)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL over xGMI; BENCH_DIST_BACKEND=gloo lets two ranks share one GPU to exercise this path on a 1-GPU box (RCCL
         # refuses duplicate devices)
-        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+    gdev = torch.device("cuda", local_rank)
 
-    from mrg_slam_amd import BatchMatcher, Context, NdtHip, distance_filter, prefilter, synth
+    from mrg_slam_amd import BatchMatcher, Context, NdtHip, distance_filter, prefilter
+    from mrg_slam_amd import loop_closure as lc
     from mrg_slam_amd._lib import NDT_HIP, SEARCH
     from mrg_slam_amd.registration import RESULT_DTYPE, default_params, result_matrix
 
     ctx = Context(local_rank)
 
-    # ---- inputs (untimed): synthetic scans -> prefilter on the GPU -> resident in HBM -------------------------------
-    t_gen = time.time()
-    scene, poses, raw = make_workload(args.distinct, args.batch, rank, args.prefilter)
-    scans = [prefilter(s, ctx=ctx) if args.prefilter == "full" else distance_filter(s, 0.1, 35.0, ctx=ctx) for s in raw]
-    rels = [np.linalg.inv(poses[k]) @ poses[k + 1] for k in range(args.distinct)]
-    dev = [torch.from_numpy(s).cuda(local_rank) for s in scans]
-    pairs = []  # (target scan index, source scan index, guess, truth)
-    for b in range(args.batch):
-        k = b % args.distinct
-        guess = synth.warm_guess(rels[k], 1000 * rank + b)
-        pairs.append((k, k + 1, guess, rels[k]))
-    n_pts = float(np.mean([len(scans[p[1]]) for p in pairs]))
-    t_gen = time.time() - t_gen
+    def to_hbm(raw_scans):
+        host = [prefilter(s, ctx=ctx) if args.prefilter == "full" else distance_filter(s, 0.1, 35.0, ctx=ctx) for s in raw_scans]
+        return host, [torch.from_numpy(s).to(gdev) for s in host]
 
     prm = default_params(NDT_HIP)
     prm.transformation_epsilon = args.eps
@@ -132,18 +215,21 @@ def main():
     prm.nn_search_method = SEARCH["DIRECT7"]
     prm.num_threads = 8
     bm = BatchMatcher(prm, ctx)
-    gathered = torch.empty((world * args.batch, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=f"cuda:{local_rank}") if world > 1 else None
 
-    def step():
-        bm.clear()
-        for (ti, si, guess, _) in pairs:
-            t = bm.add_target_device(dev[ti].data_ptr(), len(scans[ti]))  # one setInputTarget per alignment
-            bm.add_pair_device(t, dev[si].data_ptr(), len(scans[si]), guess)
-        res = bm.align()
-        if world > 1:  # pose / Hessian record gather over RCCL
-            mine = torch.from_numpy(res.view(np.uint8).reshape(args.batch, -1)).cuda(local_rank)
-            dist.all_gather_into_tensor(gathered, mine)
-        return res
+    def all_gather_records(local: np.ndarray, per: int):
+        """the pose / Hessian record gather of the north star: `per` 384-byte records per rank over RCCL (gloo in the test hook)"""
+        pad = np.zeros(per, dtype=RESULT_DTYPE)
+        pad["pair_id"] = -1
+        pad[: len(local)] = local
+        mine = torch.from_numpy(pad.view(np.uint8).reshape(per, -1))
+        if backend == "nccl":
+            mine = mine.to(gdev)
+            out = torch.empty((world * per, RESULT_DTYPE.itemsize), dtype=torch.uint8, device=gdev)
+        else:
+            out = torch.empty((world * per, RESULT_DTYPE.itemsize), dtype=torch.uint8)
+        dist.all_gather_into_tensor(out, mine)
+        rec = np.frombuffer(out.cpu().numpy().tobytes(), dtype=RESULT_DTYPE)
+        return rec[rec["pair_id"] >= 0]
 
     def sync():
         ctx.synchronize()
@@ -151,36 +237,127 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    # a full (generation 2) collection walks every object `import torch` created: ~40 ms, once, at an arbitrary step.
-    # Collect now and move the survivors to the permanent generation so the timed steps are not interrupted by it.
-    gc.collect()
-    gc.freeze()
+    def timed(step_fn, steps, warmup):
+        for _ in range(warmup):
+            step_fn()
+        sync()
+        # a full (generation 2) collection walks every object `import torch` created: ~40 ms, once, at an arbitrary step.
+        # Collect now and move the survivors to the permanent generation so the timed steps are not interrupted by it.
+        gc.collect()
+        gc.freeze()
+        t0 = time.perf_counter()
+        step_ms, last = [], None
+        for _ in range(steps):
+            ts = time.perf_counter()
+            last = step_fn()
+            step_ms.append(1e3 * (time.perf_counter() - ts))
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=gdev if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, step_ms, last
+
+    # ---- config[3]: 256 loop-closure candidate pairs sharded over the ranks ------------------------------------------------
+    def run_shard(steps, warmup):
+        l_host, l_dev = to_hbm(loop_raw)
+        n_pairs = len(loop_pairs)
+        mine = lc.shard_indices(n_pairs, world, rank)
+        per = -(-n_pairs // world)
+        my_targets = sorted({loop_pairs[i][0] for i in mine})  # the new keyframes this rank needs a grid for (loop_detector.cpp:104)
+        groups = {}
+        for i, (a, _, _, _) in enumerate(loop_pairs):
+            groups.setdefault(a, []).append(i)
+
+        def step():
+            bm.clear()
+            tix = {a: bm.add_target_device(l_dev[a].data_ptr(), len(l_host[a])) for a in my_targets}
+            for i in mine:
+                a, b, guess, _ = loop_pairs[i]
+                bm.add_pair_device(tix[a], l_dev[b].data_ptr(), len(l_host[b]), guess)
+            local = bm.align(float("inf"))  # getFitnessScore(fitness_score_max_range = .inf), config/mrg_slam.yaml:172
+            local["pair_id"] = mine.astype(np.int32)
+            rec = all_gather_records(local, per) if world > 1 else local
+            full = np.zeros(n_pairs, dtype=RESULT_DTYPE)
+            full[rec["pair_id"]] = rec
+            # every rank replays the sequential best-candidate rule per new keyframe (loop_detector.cpp:126-145)
+            best = {a: lc.select_best(full[ids]) for a, ids in groups.items()}
+            return full, best
+
+        elapsed, step_ms, (full, best) = timed(step, steps, warmup)
+        err = [float(np.linalg.norm(result_matrix(full[i])[:3, 3] - loop_pairs[i][3][:3, 3])) for i in range(n_pairs)]
+        digest = __import__("hashlib").sha256(full["T"].tobytes() + full["fitness"].tobytes() + full["converged"].tobytes()).hexdigest()[:16]
+        return {"pairs_total": n_pairs, "new_keyframes": len(groups), "pairs_per_gpu": int(len(mine)), "targets_built_per_gpu": len(my_targets),
+                "steps": steps, "ms_per_step": 1e3 * elapsed / steps, "alignments_per_s": n_pairs * steps / elapsed, "scaling": "strong",
+                "fitness_max_range": "inf", "converged": int(full["converged"].sum()), "matched_keyframes": int(sum(b[0] is not None for b in best.values())),
+                "median_translation_error_vs_truth_m": float(np.median(err)), "mean_iterations": float(full["iterations"].mean()),
+                "mean_points_per_scan": float(np.mean([len(s) for s in l_host])), "records_sha256_16": digest, "per_step_ms": [round(v, 2) for v in step_ms]}
+
+    if args.mode == "shard":
+        r = run_shard(args.steps, args.warmup)
+        if rank == 0:
+            out = {"metric": METRIC, "value": r["alignments_per_s"], "unit": "alignments/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 per-pair terms, f64 accumulation",
+                   "data": "synthetic",
+                   "config": {"workload": f"BASELINE config[3]: {r['pairs_total']} loop-closure candidate pairs ({r['new_keyframes']} new keyframes on a 40 m ring, VLP-64, "
+                                          f"mean {r['mean_points_per_scan']:.0f} pts/scan), NDT_HIP DIRECT7 res 1.0 eps {args.eps}, pair i -> rank i mod G, one target grid per "
+                                          f"new keyframe and rank, getFitnessScore(inf), record all-gather, best-candidate replay; inputs resident in HBM",
+                              "parallelism": f"{world} x 1 GPU" if world > 1 else "1 GPU"},
+                   "roofline": None, "cpu_baseline": None, "config3_shard": r}
+            print(json.dumps(out))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- config[1] shape, weak scaling --------------------------------------------------------------------------------------
+    scans, dev = to_hbm(raw)
+    rels = [np.linalg.inv(poses[k]) @ poses[k + 1] for k in range(args.distinct)]
+    pairs = []  # (target scan index, source scan index, guess, truth, cold)
+    for b in range(args.batch):
+        k = b % args.distinct
+        cold = args.cold_every > 0 and b % args.cold_every == args.cold_every - 1
+        guess = np.eye(4) if cold else synth.warm_guess(rels[k], 1000 * rank + b)
+        pairs.append((k, k + 1, guess, rels[k], cold))
+    n_pts = float(np.mean([len(scans[p[1]]) for p in pairs]))
+    hbm_input_bytes = 16.0 * sum(len(scans[p[0]]) + len(scans[p[1]]) for p in pairs)
+    t_gen = time.time() - t_gen
+
     per_mode = np.zeros((3, 3))  # [mode] -> (device ms, launches, algorithmic bytes), HIP events around every launch
     launched = np.zeros(2)       # (source points, valid point-voxel pairs) of the evaluations actually launched
-    evals = iters = 0
-    t0 = time.perf_counter()
-    step_ms = []
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        res = step()
-        step_ms.append(1e3 * (time.perf_counter() - ts))
-        for m in range(3):
-            per_mode[m] += bm.kernel_stats(m)
-        launched += np.array(bm.pair_counts())
-        evals += int(res["evaluations"].sum())
-        iters += int(res["iterations"].sum())
-    sync()
-    elapsed = time.perf_counter() - t0
+    counters = {"evals": 0, "iters": 0, "on": False}
+
+    def step():
+        bm.clear()
+        for (ti, si, guess, _, _) in pairs:
+            t = bm.add_target_device(dev[ti].data_ptr(), len(scans[ti]))  # one setInputTarget per alignment
+            bm.add_pair_device(t, dev[si].data_ptr(), len(scans[si]), guess)
+        res = bm.align()
+        if world > 1:  # pose / Hessian record gather over RCCL
+            res["pair_id"] = np.arange(args.batch, dtype=np.int32)
+            all_gather_records(res, args.batch)
+        if counters["on"]:
+            for m in range(3):
+                per_mode[m] += bm.kernel_stats(m)
+            launched[:] += np.array(bm.pair_counts())
+            counters["evals"] += int(res["evaluations"].sum())
+            counters["iters"] += int(res["iterations"].sum())
+        return res
+
+    for _ in range(args.warmup):
+        step()
+    counters["on"] = True
+    elapsed, step_ms, res = timed(step, args.steps, 0)
+    counters["on"] = False
+    evals, iters = counters["evals"], counters["iters"]
     print(f"[bench rank {rank}] per-step ms: " + " ".join(f"{v:.2f}" for v in step_ms), file=sys.stderr)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
     total_pairs = world * args.batch * args.steps
     value = total_pairs / elapsed
+
+    shard = None
+    if args.shard_steps > 0:
+        shard = run_shard(args.shard_steps, 1)
 
     if rank != 0:
         if world > 1:
@@ -188,20 +365,20 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- single-pair latency (one pcl::Registration-style object, host loop per evaluation), opt-in ------------------
+    # ---- single-pair latency (one pcl::Registration-style object), opt-in ------------------------------------------------------
     single_ms = None
     if args.latency:
         reg = NdtHip(resolution=1.0, transformation_epsilon=args.eps, maximum_iterations=64, ctx=ctx)
-        ti, si, guess, truth = pairs[0]
+        ti, si, guess, truth, _ = pairs[0]
         lat = []
-        for _ in range(6):
+        for _ in range(12):
             ctx.synchronize()
             t1 = time.perf_counter()
             reg.setInputTargetDevice(dev[ti].data_ptr(), len(scans[ti]))
             reg.setInputSourceDevice(dev[si].data_ptr(), len(scans[si]))
             reg.align(guess)
             lat.append(time.perf_counter() - t1)
-        single_ms = 1e3 * float(np.median(lat[1:]))
+        single_ms = 1e3 * float(np.median(lat[2:]))
     # mean valid neighbour voxels per point of the evaluations actually launched (k-bar of SURVEY.md §8d); evaluations a
     # controller answers from its cache (repeated line-search trials) are neither launched nor counted
     kbar = float(launched[1] / launched[0]) if launched[0] else 0.0
@@ -214,25 +391,30 @@ def main():
         host_cores = os.cpu_count() or 1
         ncpu = min(args.cpu_pairs, len(pairs))
         # thread count: the reference default (reg_num_threads: 8, config/mrg_slam.yaml:101) and wider settings up to the
-        # host's cores; the fastest one is reported (the per-point OpenMP loop stops scaling well before 256 threads)
+        # host's cores; the fastest one is reported (the per-point OpenMP loop stops scaling well before 256 threads), the
+        # reference default beside it
         sweep = sorted({t for t in (8, 16, 32, 64, host_cores) if t <= host_cores})
 
         def run_cpu(nt, sample):
             o = orc.Ndt(resolution=1.0, transformation_epsilon=args.eps, maximum_iterations=64, num_threads=nt)
             tc, out = time.perf_counter(), []
-            for (ti, si, guess, _) in sample:
+            for (ti, si, guess, _, _) in sample:
                 o.setInputTarget(scans[ti])
                 o.setInputSource(scans[si])
                 o.align(guess)
                 out.append((o.getFinalTransformation(), o.hasConverged(), o.getFinalNumIteration(), o.evals))
             return time.perf_counter() - tc, out
 
-        probe = pairs[:min(4, ncpu)]  # thread-count probe on a few pairs, then the whole sample with the fastest setting
-        cores = min(sweep, key=lambda nt: run_cpu(nt, probe)[0])
+        probe = pairs[:min(8, ncpu)]  # thread-count probe on a few pairs, then the whole sample with the fastest setting
+        probe_s = {nt: run_cpu(nt, probe)[0] for nt in sweep}
+        cores = min(sweep, key=lambda nt: probe_s[nt])
         tc, o_res = run_cpu(cores, pairs[:ncpu])
         cpu = {"value": ncpu / tc, "unit": "alignments/s", "cores": cores, "kind": "port",
-               "sample": f"{ncpu} of the {args.batch} pairs of one step (setInputTarget+align each), CPU oracle = restated pclomp NDT_OMP, "
-                         f"-O3 -fopenmp, fastest of OpenMP thread counts {sweep} on a {host_cores}-thread host = {cores} threads, {tc:.2f} s"}
+               "sample": f"{ncpu} of the {args.batch} pairs of one step (setInputTarget+align each, same warm/cold guesses), CPU oracle = restated pclomp NDT_OMP "
+                         f"(not the upstream library: parity unpinned, DESIGN.md §2), -O3 -fopenmp, fastest of OpenMP thread counts {sweep} on a {host_cores}-thread "
+                         f"host = {cores} threads, {tc:.2f} s",
+               "reference_default_8_threads": {"value": len(probe) / probe_s[8], "pairs": len(probe), "note": "reg_num_threads: 8 (config/mrg_slam.yaml:101)"} if 8 in probe_s else None,
+               "host_cpu": next((ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")), "unknown")}
         dts, drs, same = [], [], True
         for k in range(ncpu):
             Tg = result_matrix(res[k])
@@ -248,18 +430,28 @@ def main():
     variants = {name: {"launches": int(per_mode[m][1]), "avg_launch_ms": (per_mode[m][0] / per_mode[m][1]) if per_mode[m][1] else None,
                        "achieved_GBps": (per_mode[m][2] / 1e9) / (per_mode[m][0] / 1e3) if per_mode[m][0] > 0 else None}
                 for m, name in enumerate(("ndt_derivatives_kernel<0,7>", "ndt_derivatives_kernel<1,7>", "ndt_derivatives_kernel<2,7>"))}
-    # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately with
+    # HBM bytes per launch of the dominant kernel and its VALU utilisation from the PMC passes (collected separately with
     # rocprofv3 --pmc and corrected as MI355X_MICROARCH.md prescribes; profiles/summarize.py) - null until a profile exists
-    traffic = None
+    traffic = valu_busy = None
+    prof_name = None
     try:
         prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_summary.json"))
         if prof:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", prof[-1]))).get("traffic_bytes_per_mean_launch")
-    except OSError:
+            prof_name = prof[-1]
+            pj = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
+            traffic = pj.get("traffic_bytes_per_mean_launch")
+            valu_busy = pj.get("valu_busy_dominant")
+    except (OSError, ValueError):
         pass
-    true_err = float(np.mean([np.linalg.norm(result_matrix(res[b])[:3, 3] - pairs[b][3][:3, 3]) for b in range(args.batch)]))
+    alg_per_launch = (k_bytes / k_launch) if k_launch else None
+    ratio = (traffic / alg_per_launch) if (traffic and alg_per_launch) else None
+    # what the counters say limits the kernel: HBM only if the bytes it really moves are a large share of the byte model
+    limiter = "hbm" if (ratio is None or ratio >= 0.5) else "valu"
+    true_err = [float(np.linalg.norm(result_matrix(res[b])[:3, 3] - pairs[b][3][:3, 3])) for b in range(args.batch)]
+    cold_ix = [b for b in range(args.batch) if pairs[b][4]]
+    warm_ix = [b for b in range(args.batch) if not pairs[b][4]]
     out = {
-        "metric": "scan-pair alignments/sec (NDT, ~120k pts, 1.0 m voxel)",
+        "metric": METRIC,
         "value": value,
         "unit": "alignments/s",
         "n_gpus": world,
@@ -273,26 +465,33 @@ def main():
         "data": "synthetic" if scene is not None else "KITTI odometry sequence 00 (KITTI_ROOT)",
         "config": {
             "workload": f"BASELINE config[1] shape: synthetic VLP-64 scan-to-scan NDT_HIP (DIRECT7, resolution 1.0 m, eps {args.eps}, max_iter 64), "
-                        f"{args.batch} pairs per GPU per step ({args.distinct} distinct pairs x warm guesses), mean {n_pts:.0f} pts/scan "
+                        f"{args.batch} pairs per GPU per step = {min(args.distinct, args.batch)} distinct scan pairs ({hbm_input_bytes / 1e6:.0f} MB of clouds per step), "
+                        f"{len(warm_ix)} warm + {len(cold_ix)} cold (identity) guesses, mean {n_pts:.0f} pts/scan "
                         f"({'distance filter 0.1-35 m' if args.prefilter == 'distance' else 'distance + 0.1 m voxel + radius outlier prefilter'}), "
                         f"setInputTarget + setInputSource + align per pair, inputs resident in HBM",
             "pairs_per_gpu_per_step": args.batch,
+            "distinct_pairs": min(args.distinct, args.batch),
             "points_per_scan": n_pts,
-            "parallelism": f"{world} x 1 GPU, pairs sharded per rank, RCCL all-gather of 384-byte result records" if world > 1 else "1 GPU",
+            "parallelism": f"{world} x 1 GPU, own pairs per rank, RCCL all-gather of 384-byte result records" if world > 1 else "1 GPU",
         },
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+        "roofline": {"bound": limiter, "byte_model_bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": traffic, "traffic_over_algorithmic": ratio, "valu_busy": valu_busy, "pmc_profile": prof_name,
                      "kernel": "ndt_derivatives_kernel<0,7>", "avg_launch_ms": (k_ms / k_launch) if k_launch else None, "launches": int(k_launch),
-                     "alg_bytes_per_launch": (k_bytes / k_launch) if k_launch else None,
-                     "byte_model": "per launch: sum over active pairs of N_src*(16 + 7*8) + valid_neighbours*48 (SURVEY.md §8d)",
+                     "alg_bytes_per_launch": alg_per_launch,
+                     "byte_model": "per launch: sum over active pairs of N_src*(16 + 7*8) + valid_neighbours*48 (SURVEY.md §8d); `frac` prices these ALGORITHMIC "
+                                   "bytes against the HBM peak as the contract asks; `bound` is what the PMC counters say limits the kernel",
                      "variants": variants},
         "cpu_baseline": cpu,
         "parity_vs_oracle": parity,
         "evaluations_per_alignment": evals / (args.batch * args.steps),
         "iterations_per_alignment": iters / (args.batch * args.steps),
+        "iterations_warm_cold": [float(np.mean(res["iterations"][warm_ix])) if warm_ix else None, float(np.mean(res["iterations"][cold_ix])) if cold_ix else None],
+        "converged": int(res["converged"].sum()),
         "mean_valid_neighbours": kbar,
         "single_pair_latency_ms": single_ms,
-        "mean_translation_error_vs_truth_m": true_err,
+        "median_translation_error_vs_truth_m": float(np.median(true_err)),
         "input_generation_s": t_gen,
+        "config3_shard": shard,
     }
     print(json.dumps(out))
     if world > 1:

@@ -11,9 +11,13 @@
  * CMakeLists.txt:45-49); include/mrgfe_pcl_adapter.hpp wraps this ABI into that same slot.
  *
  * Conventions
- *   - clouds: float x,y,z,intensity per point ("xyzi"); `stride_bytes` between points (16 for packed float4,
- *     32 for pcl::PointXYZI; 0 means 16).  Inputs are copied to the device inside the call: the caller may
- *     free or reuse its buffer when the call returns.
+ *   - clouds: float x,y,z,intensity per point ("xyzi").  Every `stride_bytes` argument is a point-layout descriptor:
+ *     16 (or 0) = packed x,y,z,intensity records (KITTI .bin, the replay scripts' PointCloud2, every output of this
+ *     library); any other record layout is named with MRGFE_LAYOUT(stride, xyz_offset, intensity_offset) —
+ *     MRGFE_LAYOUT_PCL_XYZI for the reference's in-memory pcl::PointXYZI (32 bytes: x,y,z at 0, a 1.0f padding word at 12,
+ *     intensity at byte 16).  A bare stride other than 16 is refused (MRGFE_ERR_INVALID): it cannot say where the
+ *     intensity lives.  Strided records go to the device as they are and are gathered there.  Inputs are copied to the
+ *     device inside the call: the caller may free or reuse its buffer when the call returns.
  *   - 4x4 matrices: float[16] / double[16], COLUMN-major (Eigen's default, i.e. Eigen::Matrix4f::data()).
  *   - 6x6 matrices: double[36], row-major (symmetric in practice).
  *   - status: 0 = ok, <0 = error; mrgfe_last_error() returns a thread-local message for the last failure.
@@ -32,6 +36,13 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* point-layout descriptor for the `stride_bytes` arguments: stride (<= 65532) | (intensity byte offset + 1) << 16 | (byte offset of
+ * x; y and z follow it) << 24; offsets < 252, multiples of 4 */
+#define MRGFE_LAYOUT(stride, xyz_offset, intensity_offset) \
+    ((size_t)(stride) | ((size_t)((intensity_offset) + 1) << 16) | ((size_t)(xyz_offset) << 24))
+#define MRGFE_LAYOUT_PACKED ((size_t)16)
+#define MRGFE_LAYOUT_PCL_XYZI MRGFE_LAYOUT(32, 0, 16) /* sizeof(pcl::PointXYZI) == 32, intensity behind the padded xyz quad */
 
 #define MRGFE_OK 0
 #define MRGFE_ERR_INVALID (-1)   /* bad argument / handle */
@@ -83,6 +94,17 @@ void mrgfe_ctx_destroy(mrgfe_ctx* ctx);
 int  mrgfe_ctx_synchronize(mrgfe_ctx* ctx);
 /* HIP stream of the context as an opaque pointer (hipStream_t), for callers that order their own work after it */
 void* mrgfe_ctx_stream(mrgfe_ctx* ctx);
+
+/* ---- cloud ingest --------------------------------------------------------------------------------- */
+/* replaces pcl::fromROSMsg(*cloud_msg, *cloud) (apps/prefiltering_component.cpp:119-120, scan_matching_odometry_component.cpp:144-145):
+ * the byte payload of a sensor_msgs/PointCloud2 (little-endian FLOAT32 fields at the given byte offsets; row_step 0 means
+ * width * point_step; off_intensity < 0: no such field, intensity 0 like PointXYZI's default) becomes a packed x,y,z,intensity
+ * cloud in host memory (out_xyzi, width*height*16 bytes, may be NULL) and / or device memory (d_out_xyzi, may be NULL) — the
+ * latter feeds mrgfe_reg_set_*_device / mrgfe_batch_add_*_device / mrgfe_prefilter_device without the cloud leaving HBM.
+ * The replay scripts' layout (point_step 16, offsets 0/4/8/12: python_scripts/kitti_singlerobot_processor.py:164-185) is a plain
+ * copy; anything else is gathered on the device. */
+int mrgfe_ingest_pointcloud2(mrgfe_ctx* ctx, const uint8_t* data, uint32_t width, uint32_t height, uint32_t point_step, uint32_t row_step, uint32_t off_x, uint32_t off_y,
+                             uint32_t off_z, int32_t off_intensity, float* out_xyzi, void* d_out_xyzi);
 
 /* ---- registration: the pcl::Registration call surface the reference uses (SURVEY.md §8b "Seam") ---------------- */
 /* defaults of select_registration_method's parameters (registrations.cpp:34-43 comments) for `method` */

@@ -4,28 +4,188 @@
 // It occupies the slot the reference already has for a GPU back end (FAST_VGICP_CUDA:
 // /root/reference/src/mrg_slam/registrations.cpp:19-21,65-75; CMakeLists.txt:45-49).  PCL is not installed in the
 // build container, so this file ships as source and is compiled only where <pcl/registration/registration.h> exists
-// (INTEGRATION.md shows the ten-line factory patch).  It uses nothing but the C ABI of include/mrgfe.h.
+// (INTEGRATION.md shows the factory patch).  It uses nothing but the C ABI of include/mrgfe.h.
+//
+// What the reference calls through the BASE pointer, and how each call reaches the GPU:
+//   setInputTarget / setInputSource   virtual in pcl::Registration -> overridden here (clouds go up in their 32-byte
+//                                     pcl::PointXYZI layout, gathered on the device: no host repacking)
+//   align(output, guess)              non-virtual; calls initCompute() and the virtual computeTransformation() -> overridden
+//   hasConverged / getFinalTransformation   read converged_ / final_transformation_, which computeTransformation fills
+//   getFitnessScore(max_range)        NON-virtual in PCL (loop_detector.cpp:137, scan_matching_odometry_component.cpp:403):
+//                                     it transforms the source by final_transformation_ and asks tree_ for the 1-NN of every
+//                                     point in turn.  tree_ is replaced (setSearchMethodTarget(tree, force_no_recompute =
+//                                     true)) by GpuTargetSearch below, whose nearestKSearch answers those N sequential queries
+//                                     from ONE batched GPU pass (mrgfe_reg_nn1_target over final_transformation_ * source), so
+//                                     PCL's own loop sums GPU-computed distances — and initCompute() never builds a FLANN
+//                                     kd-tree over the target.
+//   getSearchMethodTarget()->nearestKSearch(pt, 1, ..)   the status loop (scan_matching_odometry_component.cpp:405-417)
+//                                     walks the aligned cloud in order: served by the same batch.
+// Callers that hold the derived pointer can use getFitnessScore() of this class (it hides the base method): one GPU call, no
+// per-point host loop at all.
 #pragma once
 #if __has_include(<pcl/registration/registration.h>)
 
 #include <pcl/point_types.h>
 #include <pcl/registration/registration.h>
+#include <pcl/search/kdtree.h>
 
+#include <array>
+#include <cmath>
+#include <cstddef>
+#include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "mrgfe.h"
 
 namespace mrgfe_pcl {
 
-// One context per process and GPU (stream + workspaces), shared by every registration object of that process.
+// One context per process and GPU (stream + workspaces), shared by every registration object on that GPU.
 inline mrgfe_ctx* shared_context(int device = 0)
 {
-    static mrgfe_ctx* ctx = nullptr;
-    if (!ctx && mrgfe_ctx_create(device, &ctx) != MRGFE_OK) throw std::runtime_error(std::string("mrgfe: ") + mrgfe_last_error());
+    static std::mutex               mu;
+    static std::map<int, mrgfe_ctx*> ctxs;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = ctxs.find(device);
+    if (it != ctxs.end()) return it->second;
+    mrgfe_ctx* ctx = nullptr;
+    if (mrgfe_ctx_create(device, &ctx) != MRGFE_OK) throw std::runtime_error(std::string("mrgfe: ") + mrgfe_last_error());
+    ctxs[device] = ctx;
     return ctx;
 }
+
+// stride_bytes descriptor of a PCL point type with x, y, z and intensity members (pcl::PointXYZI: 32 bytes, intensity at 16)
+template <typename PointT>
+inline size_t point_layout()
+{
+    return MRGFE_LAYOUT(sizeof(PointT), offsetof(PointT, x), offsetof(PointT, intensity));
+}
+
+// The target "kd-tree" of a HipRegistration: a pcl::search::KdTree whose FLANN index is never built.  1-NN queries that walk
+// final_transformation * source in order (pcl::Registration::getFitnessScore, the scan-matching status loop) are answered from
+// one batched GPU pass; any other use (k > 1, radius search, 1-NN queries of unrelated points) falls back to a single GPU query
+// or — for the searches the ABI does not offer — to the real FLANN tree, built lazily on first use.
+template <typename PointT>
+class GpuTargetSearch : public pcl::search::KdTree<PointT> {
+   public:
+    using Base = pcl::search::KdTree<PointT>;
+    using PointCloudConstPtr = typename Base::PointCloudConstPtr;
+    using IndicesConstPtr = typename Base::IndicesConstPtr;
+
+    explicit GpuTargetSearch(mrgfe_reg* reg) : reg_(reg) {}
+
+    // initCompute() / setInputTarget never reach FLANN: remember the cloud for the lazy fallback only
+    void setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) override
+    {
+        cloud_ = cloud;
+        indices_ = indices;
+        flann_built_ = false;
+    }
+    PointCloudConstPtr getInputCloud() const override { return cloud_; }
+
+    // the registration hands over final_transformation * source (packed xyzi, n points) after every align()
+    void expect_queries(const float* xyzi, std::size_t n)
+    {
+        if (n) expected_.assign(xyzi, xyzi + 4 * n);
+        else   expected_.clear();
+        answered_ = false;
+        cursor_ = 0;
+    }
+    std::size_t batched_answers() const { return n_batched_; }
+    std::size_t single_queries() const { return n_single_; }
+    bool        flann_built() const { return flann_built_; }
+
+    int nearestKSearch(const PointT& point, int k, pcl::Indices& k_indices, std::vector<float>& k_sqr_distances) const override
+    {
+        if (k != 1) return fallback().nearestKSearch(point, k, k_indices, k_sqr_distances);
+        k_indices.resize(1);
+        k_sqr_distances.resize(1);
+        const std::size_t n = expected_.size() / 4;
+        // sequential walk over the expected queries: position `cursor_`, else the start (a second pass over the same cloud)
+        for (int attempt = 0; attempt < 2 && n; ++attempt) {
+            const std::size_t c = attempt == 0 ? cursor_ : 0;
+            if (c < n && std::memcmp(&expected_[4 * c], &point.x, 12) == 0) {
+                if (!answered_) answer_batch();
+                cursor_ = c + 1;
+                ++n_batched_;
+                k_indices[0] = idx_[c];
+                k_sqr_distances[0] = sqd_[c];
+                return idx_[c] >= 0 ? 1 : 0;
+            }
+        }
+        // Not bit-equal to the point we predicted.  PCL's getFitnessScore transforms the source on the host
+        // (pcl::transformPointCloud: SSE, AVX or scalar code depending on how PCL was built), so its queries may differ from
+        // the GPU's transform in the last bits.  Such a query keeps the batched neighbour; only its distance is recomputed
+        // here against the actual query point, in FLANN's L2_Simple order (x, y, z; float).
+        if (cursor_ < n && cloud_) {
+            const float* e = &expected_[4 * cursor_];
+            const float  tol = 2e-6f * (std::fabs(e[0]) + std::fabs(e[1]) + std::fabs(e[2]) + 1.0f);
+            if (std::fabs(point.x - e[0]) <= tol && std::fabs(point.y - e[1]) <= tol && std::fabs(point.z - e[2]) <= tol) {
+                if (!answered_) answer_batch();
+                const std::size_t c = cursor_++;
+                ++n_batched_;
+                k_indices[0] = idx_[c];
+                if (idx_[c] < 0) { k_sqr_distances[0] = std::numeric_limits<float>::quiet_NaN(); return 0; }
+                const PointT& t = (*cloud_)[static_cast<std::size_t>(idx_[c])];
+                const float   dx = t.x - point.x, dy = t.y - point.y, dz = t.z - point.z;
+                float         d = dx * dx;
+                d += dy * dy;
+                d += dz * dz;
+                k_sqr_distances[0] = d;
+                return 1;
+            }
+        }
+        // an unrelated point: one GPU query (exact, but a round trip per point)
+        const float q[4] = {point.x, point.y, point.z, 0.0f};
+        int32_t     i = -1;
+        float       d = std::numeric_limits<float>::quiet_NaN();
+        ++n_single_;
+        if (mrgfe_reg_nn1_target(reg_, q, 1, 16, &i, &d) != MRGFE_OK) i = -1;
+        k_indices[0] = i;
+        k_sqr_distances[0] = i >= 0 ? d : std::numeric_limits<float>::quiet_NaN();
+        return i >= 0 ? 1 : 0;
+    }
+
+    int radiusSearch(const PointT& point, double radius, pcl::Indices& k_indices, std::vector<float>& k_sqr_distances, unsigned int max_nn = 0) const override
+    {
+        return fallback().radiusSearch(point, radius, k_indices, k_sqr_distances, max_nn);
+    }
+
+   private:
+    void answer_batch() const
+    {
+        const std::size_t n = expected_.size() / 4;
+        idx_.assign(n, -1);
+        sqd_.assign(n, std::numeric_limits<float>::quiet_NaN());
+        if (n && mrgfe_reg_nn1_target(reg_, expected_.data(), n, 16, idx_.data(), sqd_.data()) != MRGFE_OK)
+            PCL_ERROR("[mrgfe_pcl::GpuTargetSearch] %s\n", mrgfe_last_error());
+        for (std::size_t i = 0; i < n; ++i)
+            if (idx_[i] < 0) sqd_[i] = std::numeric_limits<float>::quiet_NaN();  // non-finite query: compares false against any max_range
+        answered_ = true;
+    }
+    // searches the C ABI has no entry point for: the real pcl::search::KdTree over the same cloud, built on first use
+    const Base& fallback() const
+    {
+        if (!flann_built_) {
+            const_cast<GpuTargetSearch*>(this)->Base::setInputCloud(cloud_, indices_);
+            flann_built_ = true;
+        }
+        return *this;
+    }
+
+    mrgfe_reg*         reg_;
+    PointCloudConstPtr cloud_;
+    IndicesConstPtr    indices_;
+    std::vector<float> expected_;
+    mutable std::vector<int32_t> idx_;
+    mutable std::vector<float>   sqd_;
+    mutable bool        answered_ = false, flann_built_ = false;
+    mutable std::size_t cursor_ = 0, n_batched_ = 0, n_single_ = 0;
+};
 
 template <typename PointSource = pcl::PointXYZI, typename PointTarget = pcl::PointXYZI>
 class HipRegistration : public pcl::Registration<PointSource, PointTarget, float> {
@@ -36,6 +196,7 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
     using PointCloudSourceConstPtr = typename Base::PointCloudSourceConstPtr;
     using PointCloudTargetConstPtr = typename Base::PointCloudTargetConstPtr;
     using Matrix4 = typename Base::Matrix4;
+    using Search = GpuTargetSearch<PointTarget>;
 
     explicit HipRegistration(const mrgfe_reg_params& params, int device = 0)
     {
@@ -43,25 +204,33 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
         if (mrgfe_reg_create(shared_context(device), &params, &reg_) != MRGFE_OK) throw std::runtime_error(std::string("mrgfe: ") + mrgfe_last_error());
         this->max_iterations_ = params.maximum_iterations;
         this->transformation_epsilon_ = params.transformation_epsilon;
+        // tree_ = our search object; force_no_recompute: initCompute() must not call tree_->setInputCloud(target_) (a FLANN build
+        // over the whole target on the CPU at every target change) — setInputTarget below keeps the search object current itself
+        search_.reset(new Search(reg_));
+        Base::setSearchMethodTarget(search_, true);
     }
     ~HipRegistration() override { mrgfe_reg_destroy(reg_); }
 
-    // registration_->setInputTarget(cloud): pcl::PointXYZI is x,y,z,pad,intensity,pad...: 32-byte stride; the intensity sits
-    // at float offset 4, so the cloud is repacked to xyzi once per call on the host.
+    // registration_->setInputTarget(cloud): the 32-byte pcl::PointXYZI records go to the device as they are and x, y, z,
+    // intensity are gathered there (MRGFE_LAYOUT)
     void setInputTarget(const PointCloudTargetConstPtr& cloud) override
     {
         Base::setInputTarget(cloud);
-        pack(*cloud);
-        mrgfe_reg_set_target(reg_, packed_.data(), cloud->size(), 16);  // overflow -> no target, like PCL's warning
+        search_->setInputCloud(cloud);
+        search_->expect_queries(nullptr, 0);
+        // overflow -> no target, like PCL's "Leaf size is too small" warning
+        mrgfe_reg_set_target(reg_, cloud->empty() ? nullptr : &cloud->points[0].x, cloud->size(), point_layout<PointTarget>());
     }
     void setInputSource(const PointCloudSourceConstPtr& cloud) override
     {
         Base::setInputSource(cloud);
-        pack(*cloud);
-        if (mrgfe_reg_set_source(reg_, packed_.data(), cloud->size(), 16) != MRGFE_OK) PCL_ERROR("[%s::setInputSource] %s\n", this->reg_name_.c_str(), mrgfe_last_error());
+        search_->expect_queries(nullptr, 0);
+        if (mrgfe_reg_set_source(reg_, cloud->empty() ? nullptr : &cloud->points[0].x, cloud->size(), point_layout<PointSource>()) != MRGFE_OK)
+            PCL_ERROR("[%s::setInputSource] %s\n", this->reg_name_.c_str(), mrgfe_last_error());
     }
 
-    // getFitnessScore(max_range): same semantics as the PCL base (squared distance against max_range)
+    // Fast path for holders of the DERIVED pointer (this hides the non-virtual base method): one GPU call, no per-point host
+    // loop.  Through the base pointer PCL's own getFitnessScore runs and gets the same distances from GpuTargetSearch.
     double getFitnessScore(double max_range = std::numeric_limits<double>::max())
     {
         double out = std::numeric_limits<double>::max();
@@ -69,12 +238,14 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
         return out;
     }
     int getFinalNumIteration() const { return mrgfe_reg_iterations(reg_); }
-    Eigen::Matrix<double, 6, 6> getFinalHessian() const
+    std::array<double, 36> getFinalHessian() const  // 6x6, row-major
     {
-        double h[36];
-        mrgfe_reg_hessian(reg_, h);
-        return Eigen::Map<Eigen::Matrix<double, 6, 6, Eigen::RowMajor>>(h);
+        std::array<double, 36> h{};
+        mrgfe_reg_hessian(reg_, h.data());
+        return h;
     }
+    const Search& gpuSearch() const { return *search_; }
+    mrgfe_reg*    handle() const { return reg_; }
 
    protected:
     // called by pcl::Registration::align(output, guess) after it copied the source into `output`
@@ -84,6 +255,7 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
         if (mrgfe_reg_align(reg_, guess.data() /* column-major */, aligned_.data()) != MRGFE_OK) {
             PCL_ERROR("[%s::computeTransformation] %s\n", this->reg_name_.c_str(), mrgfe_last_error());
             this->converged_ = false;
+            search_->expect_queries(nullptr, 0);
             return;
         }
         for (std::size_t i = 0; i < output.size(); ++i) {
@@ -94,22 +266,14 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
         mrgfe_reg_final_transformation(reg_, this->final_transformation_.data());
         this->converged_ = mrgfe_reg_has_converged(reg_) != 0;
         this->nr_iterations_ = mrgfe_reg_iterations(reg_);
+        // what getFitnessScore / the status loop will ask next: final_transformation * source, point by point
+        search_->expect_queries(aligned_.data(), output.size());
     }
 
    private:
-    template <class Cloud>
-    void pack(const Cloud& c)
-    {
-        packed_.resize(c.size() * 4);
-        for (std::size_t i = 0; i < c.size(); ++i) {
-            packed_[4 * i] = c[i].x;
-            packed_[4 * i + 1] = c[i].y;
-            packed_[4 * i + 2] = c[i].z;
-            packed_[4 * i + 3] = c[i].intensity;
-        }
-    }
-    mrgfe_reg*         reg_ = nullptr;
-    std::vector<float> packed_, aligned_;
+    mrgfe_reg*                 reg_ = nullptr;
+    pcl::shared_ptr<Search>    search_;
+    std::vector<float>         aligned_;
 };
 
 }  // namespace mrgfe_pcl

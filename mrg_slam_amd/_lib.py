@@ -20,6 +20,15 @@ NDT_HIP, GICP_HIP, SMALL_GICP_HIP, VGICP_HIP, ICP_HIP = 0, 1, 2, 3, 4
 SEARCH = {"KDTREE": 0, "DIRECT26": 1, "DIRECT7": 2, "DIRECT1": 3}
 
 
+def layout(stride: int, xyz_offset: int = 0, intensity_offset: int = 12) -> int:
+    """MRGFE_LAYOUT(stride, xyz_offset, intensity_offset) of include/mrgfe.h: the point-layout descriptor passed as ``stride_bytes``."""
+    return int(stride) | ((int(intensity_offset) + 1) << 16) | (int(xyz_offset) << 24)
+
+
+LAYOUT_PACKED = 16
+LAYOUT_PCL_XYZI = layout(32, 0, 16)  # in-memory pcl::PointXYZI
+
+
 class MrgfeError(RuntimeError):
     def __init__(self, status: int, message: str):
         super().__init__(f"libmrgfe error {status}: {message}")
@@ -81,6 +90,7 @@ SIGNATURES = {
     "mrgfe_ctx_destroy": (None, [_vp]),
     "mrgfe_ctx_synchronize": (C.c_int, [_vp]),
     "mrgfe_ctx_stream": (_vp, [_vp]),
+    "mrgfe_ingest_pointcloud2": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, _fp, _vp]),
     "mrgfe_reg_default_params": (None, [C.c_int, C.POINTER(RegParams)]),
     "mrgfe_reg_create": (C.c_int, [_vp, C.POINTER(RegParams), C.POINTER(_vp)]),
     "mrgfe_reg_destroy": (None, [_vp]),

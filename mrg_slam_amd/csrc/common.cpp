@@ -1,5 +1,6 @@
 // csrc/common.cpp — error reporting, device / pinned workspaces, context lifetime.
 #include "common.h"
+#include "ingest.h"
 
 #include <algorithm>
 #include <condition_variable>
@@ -198,12 +199,39 @@ void host_parallel_for(int n, int min_serial, const std::function<void(int, int)
 
 void host_parallel_hot(bool hot) { host_pool().set_hot(hot); }
 
-int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, void* d_dst, int pin_slot)
+int decode_layout(size_t layout, uint32_t* stride, uint32_t* xyz_off, int32_t* intensity_off)
+{
+    if (layout == 0) layout = 16;
+    const uint32_t st = static_cast<uint32_t>(layout & 0xFFFFu), io1 = static_cast<uint32_t>((layout >> 16) & 0xFFu), xo = static_cast<uint32_t>((layout >> 24) & 0xFFu);
+    if ((layout >> 32) != 0 || st < 16 || (st % 4) != 0) { set_error("point stride must be a multiple of 4 and >= 16 bytes (got layout 0x%zx)", layout); return MRGFE_ERR_INVALID; }
+    if (io1 == 0) {
+        // a bare stride says nothing about where the intensity lives.  16 is the packed x,y,z,intensity record; anything wider
+        // must name its layout (a bare 32 used to read pcl::PointXYZI's 1.0f padding word as the intensity)
+        if (st != 16 || xo != 0) {
+            set_error("stride_bytes %u without a layout: pass MRGFE_LAYOUT(stride, xyz_offset, intensity_offset), e.g. MRGFE_LAYOUT_PCL_XYZI for pcl::PointXYZI", st);
+            return MRGFE_ERR_INVALID;
+        }
+        *stride = 16; *xyz_off = 0; *intensity_off = 12;
+        return MRGFE_OK;
+    }
+    const uint32_t io = io1 - 1;
+    if ((io % 4) != 0 || (xo % 4) != 0 || io + 4 > st || xo + 12 > st || (io + 4 > xo && io < xo + 12)) {
+        set_error("layout 0x%zx: xyz offset %u / intensity offset %u do not fit a %u-byte point", layout, xo, io, st);
+        return MRGFE_ERR_INVALID;
+    }
+    *stride = st; *xyz_off = xo; *intensity_off = static_cast<int32_t>(io);
+    return MRGFE_OK;
+}
+
+int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t layout, void* d_dst, int pin_slot)
 {
     if (n == 0) return MRGFE_OK;
-    if (stride_bytes == 0) stride_bytes = 16;
-    if (stride_bytes < 16 || (stride_bytes % 4) != 0) { set_error("point stride must be a multiple of 4 and >= 16 bytes (got %zu)", stride_bytes); return MRGFE_ERR_INVALID; }
+    uint32_t stride = 16, xo = 0;
+    int32_t  io = 12;
+    MRGFE_TRY(decode_layout(layout, &stride, &xo, &io));
     (void)pin_slot;
+    if (!(stride == 16 && xo == 0 && io == 12))  // strided records: raw bytes up in one copy, x/y/z/intensity gathered on the device (ingest.hip)
+        return upload_gathered(ctx, xyzi, n * size_t(stride), n, static_cast<uint32_t>(n), static_cast<uint32_t>(n) * stride, stride, xo, xo + 4, xo + 8, io, d_dst);
     const int slot = ctx->up_next;
     ctx->up_next ^= 1;
     if (!ctx->up_ev[slot]) MRGFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->up_ev[slot], hipEventDisableTiming));
@@ -212,12 +240,7 @@ int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_byte
     PinBuf& pb = ctx->up_pin[slot];
     MRGFE_TRY(pb.ensure(n * 16));
     float* dst = pb.as<float>();
-    if (stride_bytes == 16) {
-        std::memcpy(dst, xyzi, n * 16);
-    } else {
-        const char* src = reinterpret_cast<const char*>(xyzi);
-        for (size_t i = 0; i < n; ++i) std::memcpy(dst + 4 * i, src + i * stride_bytes, 16);
-    }
+    std::memcpy(dst, xyzi, n * 16);
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_dst, dst, n * 16, hipMemcpyHostToDevice, ctx->stream));
     MRGFE_HIP_CHECK(hipEventRecord(ctx->up_ev[slot], ctx->stream));
     ctx->up_busy[slot] = true;
@@ -274,6 +297,8 @@ void mrgfe_ctx_destroy(mrgfe_ctx* ctx)
     for (auto& b : ctx->scratch) b.release();
     for (auto& b : ctx->pin) b.release();
     for (auto& b : ctx->up_pin) b.release();
+    ctx->up_raw.release();
+    ctx->up_out.release();
     for (auto& e : ctx->up_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

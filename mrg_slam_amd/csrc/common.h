@@ -87,6 +87,7 @@ struct mrgfe_ctx {
     mrgfe::DevBuf scratch[14];                  // named by the algorithms that use them
     mrgfe::PinBuf pin[4];
     mrgfe::PinBuf up_pin[2];                    // upload_cloud staging ring: the host packs cloud k + 1 while cloud k is on the wire
+    mrgfe::DevBuf up_raw, up_out;               // raw strided records waiting for the device gather / packed result of mrgfe_ingest_pointcloud2
     hipEvent_t   up_ev[2] = {nullptr, nullptr};
     bool         up_busy[2] = {false, false};
     int          up_next = 0;
@@ -97,6 +98,8 @@ struct mrgfe_ctx {
 };
 
 namespace mrgfe {
-// copy a strided host cloud into packed float4 device memory via the pinned staging buffer `pin_slot`
-int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, void* d_dst, int pin_slot = 0);
+// copy a host cloud into packed float4 device memory via the pinned staging ring; `layout` is the stride_bytes argument of the C
+// ABI (16, or MRGFE_LAYOUT(stride, xyz offset, intensity offset): such records are gathered on the device)
+int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t layout, void* d_dst, int pin_slot = 0);
+int decode_layout(size_t layout, uint32_t* stride, uint32_t* xyz_off, int32_t* intensity_off);
 }  // namespace mrgfe

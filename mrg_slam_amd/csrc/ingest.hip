@@ -1,0 +1,91 @@
+// csrc/ingest.hip — point-layout ingest: gathers x, y, z, intensity out of strided point records into the packed float4
+// layout every kernel of libmrgfe works on.  What it replaces in the reference:
+//   * pcl::fromROSMsg(*cloud_msg, *cloud) — sensor_msgs/PointCloud2 (any point_step / field offsets) -> pcl::PointXYZI:
+//     /root/reference/apps/prefiltering_component.cpp:119-120, apps/scan_matching_odometry_component.cpp:144-145;
+//     the replay scripts publish point_step 16, offsets 0/4/8/12 (python_scripts/kitti_singlerobot_processor.py:164-185);
+//   * the 32-byte in-memory pcl::PointXYZI (x, y, z, 1.0f padding; intensity at byte 16; 12 bytes of padding) that the
+//     reference's clouds live in (include/mrg_slam/keyframe.hpp, PointT = pcl::PointXYZI) and that keyframe .pcd files are
+//     read into (src/mrg_slam/keyframe.cpp:196).
+// The raw records are copied to the device as they are (one contiguous H2D copy through the pinned staging ring, no host
+// repacking loop) and gathered there: one lane per point, four 4-byte loads, one 16-byte store.
+#include "common.h"
+#include "ingest.h"
+
+namespace mrgfe {
+
+__global__ __launch_bounds__(256) void gather_points_kernel(const uint8_t* __restrict__ raw, float4* __restrict__ dst, uint32_t n, uint32_t width, uint32_t row_step, uint32_t point_step,
+                                                            uint32_t ox, uint32_t oy, uint32_t oz, int32_t oi)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t row = i / width, col = i - row * width;
+    const uint8_t* p = raw + size_t(row) * row_step + size_t(col) * point_step;
+    float4 o;
+    o.x = *reinterpret_cast<const float*>(p + ox);
+    o.y = *reinterpret_cast<const float*>(p + oy);
+    o.z = *reinterpret_cast<const float*>(p + oz);
+    o.w = oi >= 0 ? *reinterpret_cast<const float*>(p + oi) : 0.0f;  // pcl::fromROSMsg leaves a missing field at PointXYZI's default (0)
+    dst[i] = o;
+}
+
+int launch_gather_points(mrgfe_ctx* ctx, const void* d_raw, float4* d_dst, size_t n, uint32_t width, uint32_t row_step, uint32_t point_step, uint32_t ox, uint32_t oy, uint32_t oz,
+                         int32_t oi)
+{
+    if (n == 0) return MRGFE_OK;
+    hipLaunchKernelGGL(gather_points_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, ctx->stream, static_cast<const uint8_t*>(d_raw), d_dst,
+                       static_cast<uint32_t>(n), width, row_step, point_step, ox, oy, oz, oi);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
+// raw host bytes -> device scratch (contiguous copy through the staging ring) -> gather into d_dst
+int upload_gathered(mrgfe_ctx* ctx, const void* raw, size_t raw_bytes, size_t n, uint32_t width, uint32_t row_step, uint32_t point_step, uint32_t ox, uint32_t oy, uint32_t oz,
+                    int32_t oi, void* d_dst)
+{
+    if (n == 0) return MRGFE_OK;
+    const int slot = ctx->up_next;
+    ctx->up_next ^= 1;
+    if (!ctx->up_ev[slot]) MRGFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->up_ev[slot], hipEventDisableTiming));
+    if (ctx->up_busy[slot]) { MRGFE_HIP_CHECK(hipEventSynchronize(ctx->up_ev[slot])); ctx->up_busy[slot] = false; }
+    PinBuf& pb = ctx->up_pin[slot];
+    MRGFE_TRY(pb.ensure(raw_bytes));
+    std::memcpy(pb.p, raw, raw_bytes);
+    // the raw device buffer is reused by the next gathered upload: stream order (copy k+1 after gather k) keeps that safe
+    MRGFE_TRY(ctx->up_raw.ensure(raw_bytes));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(ctx->up_raw.p, pb.p, raw_bytes, hipMemcpyHostToDevice, ctx->stream));
+    MRGFE_HIP_CHECK(hipEventRecord(ctx->up_ev[slot], ctx->stream));
+    ctx->up_busy[slot] = true;
+    return launch_gather_points(ctx, ctx->up_raw.p, static_cast<float4*>(d_dst), n, width, row_step, point_step, ox, oy, oz, oi);
+}
+
+}  // namespace mrgfe
+
+using namespace mrgfe;
+
+extern "C" int mrgfe_ingest_pointcloud2(mrgfe_ctx* ctx, const uint8_t* data, uint32_t width, uint32_t height, uint32_t point_step, uint32_t row_step, uint32_t off_x,
+                                        uint32_t off_y, uint32_t off_z, int32_t off_intensity, float* out_xyzi, void* d_out_xyzi)
+{
+    if (!ctx) { set_error("mrgfe_ingest_pointcloud2: NULL context"); return MRGFE_ERR_INVALID; }
+    const size_t n = size_t(width) * height;
+    if (n == 0) return MRGFE_OK;
+    if (!data || (!out_xyzi && !d_out_xyzi)) { set_error("mrgfe_ingest_pointcloud2: NULL data / no output"); return MRGFE_ERR_INVALID; }
+    if (row_step == 0) row_step = width * point_step;
+    const uint32_t offs[4] = {off_x, off_y, off_z, off_intensity >= 0 ? static_cast<uint32_t>(off_intensity) : 0u};
+    for (uint32_t o : offs)
+        if ((o % 4) != 0 || o + 4 > point_step) { set_error("mrgfe_ingest_pointcloud2: FLOAT32 field offset %u does not fit point_step %u (offsets must be multiples of 4)", o, point_step); return MRGFE_ERR_INVALID; }
+    if ((point_step % 4) != 0 || (row_step % 4) != 0 || uint64_t(width) * point_step > row_step) { set_error("mrgfe_ingest_pointcloud2: bad point_step %u / row_step %u", point_step, row_step); return MRGFE_ERR_INVALID; }
+    if (n > 0x7fffffffu) { set_error("mrgfe_ingest_pointcloud2: cloud too large"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);
+    MRGFE_TRY(ctx->bind());
+    void* d_dst = d_out_xyzi;
+    if (!d_dst) { MRGFE_TRY(ctx->up_out.ensure(n * 16)); d_dst = ctx->up_out.p; }
+    const size_t raw_bytes = size_t(height - 1) * row_step + size_t(width) * point_step;
+    if (point_step == 16 && off_x == 0 && off_y == 4 && off_z == 8 && off_intensity == 12 && row_step == width * 16u) {
+        MRGFE_TRY(upload_cloud(ctx, reinterpret_cast<const float*>(data), n, 16, d_dst));  // the replay layout is the device layout: plain copy
+    } else {
+        MRGFE_TRY(upload_gathered(ctx, data, raw_bytes, n, width, row_step, point_step, off_x, off_y, off_z, off_intensity, d_dst));
+    }
+    if (out_xyzi) MRGFE_HIP_CHECK(hipMemcpyAsync(out_xyzi, d_dst, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MRGFE_OK;
+}

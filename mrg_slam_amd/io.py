@@ -184,3 +184,34 @@ def read_tum(path: str):
             T[:3, 3] = v[:3]
             poses.append(T)
     return stamps, poses
+
+
+# ---- device ingest (the C ABI's mrgfe_ingest_pointcloud2) ---------------------------------------------------------
+def ingest_pointcloud2(data, width: int, height: int, point_step: int, fields: dict[str, int], row_step: int = 0, ctx=None, dev_ptr: int = 0) -> np.ndarray | None:
+    """pcl::fromROSMsg on the GPU: the PointCloud2 payload goes to the device as it is and x, y, z, intensity are gathered
+    there (``mrgfe_ingest_pointcloud2``).  Returns the packed N x 4 float32 cloud, or — with ``dev_ptr`` (room for N packed
+    points in device memory) — leaves it there and returns None.  Same result as :func:`xyzi_from_pointcloud2`."""
+    import ctypes as C
+
+    from ._lib import check, default_context, lib
+
+    ctx = ctx or default_context()
+    n = int(width) * int(height)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    out = None if dev_ptr else np.empty((n, 4), dtype=np.float32)
+    oi = fields.get("intensity")
+    check(lib().mrgfe_ingest_pointcloud2(ctx._h, buf.ctypes.data_as(C.POINTER(C.c_uint8)), int(width), int(height), int(point_step), int(row_step), int(fields["x"]), int(fields["y"]),
+                                         int(fields["z"]), -1 if oi is None else int(oi),
+                                         out.ctypes.data_as(C.POINTER(C.c_float)) if out is not None else None, C.c_void_p(dev_ptr) if dev_ptr else None))
+    return out
+
+
+def pcl_xyzi_records(cloud) -> np.ndarray:
+    """The reference's in-memory layout of a cloud: N 32-byte pcl::PointXYZI records (x, y, z, 1.0f; intensity, 3 padding words),
+    as uint8 [N, 32] — what ``stride_bytes = MRGFE_LAYOUT_PCL_XYZI`` ingests."""
+    c = np.ascontiguousarray(cloud, dtype=_F32).reshape(-1, 4)
+    rec = np.zeros((len(c), 8), dtype=_F32)
+    rec[:, :3] = c[:, :3]
+    rec[:, 3] = 1.0
+    rec[:, 4] = c[:, 3]
+    return rec.view(np.uint8).reshape(len(c), 32)

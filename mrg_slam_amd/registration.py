@@ -266,8 +266,9 @@ def select_registration_method(params: dict, ctx: Context | None = None) -> HipR
     reg_transformation_epsilon, reg_maximum_iterations, reg_max_correspondence_distance, reg_correspondence_randomness,
     reg_resolution, reg_nn_search_method).  "NDT_HIP" (and, to stay drop-in, "NDT_OMP"/"NDT") select :class:`NdtHip`;
     "GICP_HIP" / "FAST_GICP" select :class:`GicpHip`, "SMALL_GICP_HIP" / "SMALL_GICP" :class:`SmallGicpHip`, "VGICP_HIP" /
-    "FAST_VGICP" / "FAST_VGICP_CUDA" :class:`VgicpHip`.  Like the reference, an unknown name falls through to NDT; "NDT"
-    (pcl's single-threaded class) gets the KDTREE neighbourhood, its only one, on the pclomp float formulation; "ICP" / "ICP_HIP"
+    "FAST_VGICP" / "FAST_VGICP_CUDA" :class:`VgicpHip`.  Like the reference, an unknown name falls through to NDT: names
+    without "OMP" in them ("NDT", or any unknown string) reach pcl's single-threaded class there (:115-129) and get the KDTREE
+    neighbourhood, its only one, on the pclomp float formulation; "ICP" / "ICP_HIP"
     select :class:`IcpHip`; "GICP" and "GICP_OMP" raise NotImplementedError.
     """
     method = str(params.get("registration_method", "FAST_GICP"))
@@ -295,8 +296,10 @@ def select_registration_method(params: dict, ctx: Context | None = None) -> HipR
     search = str(params.get("reg_nn_search_method", "DIRECT7"))
     if search not in ("KDTREE", "DIRECT1"):
         search = "DIRECT7"  # registrations.cpp:140-146: anything else means DIRECT7
-    if "NDT" in method and "OMP" not in method and method != "NDT_HIP":
-        search = "KDTREE"  # :123-129 pcl::NormalDistributionsTransform: radius search over the voxel centroids is its only neighbourhood
+    if "OMP" not in method and method != "NDT_HIP":
+        # :115-129: every name without "OMP" in it — "NDT" and any unknown string alike — ends in pcl::NormalDistributionsTransform,
+        # whose only neighbourhood is the radius search over the voxel centroids
+        search = "KDTREE"
     return NdtHip(float(params.get("reg_resolution", 1.0)), eps, iters, search, num_threads=threads, ctx=ctx)
 
 

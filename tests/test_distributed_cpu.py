@@ -124,3 +124,55 @@ def test_candidate_keys_reach_the_matcher_single_process():
     assert seen == [11, 12, 13, 14, 15]
     rec2, best2, score2 = lc.match_candidates(lambda: _FakeMatcher(table), np.zeros((1, 4), np.float32), clouds, [np.eye(4)] * 5)
     assert rec.tobytes() == rec2.tobytes() and best == best2 and score == score2
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus N` without a launcher starts N ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) before touching
+    the GPU, forwards rank 0's JSON line and fails when a rank fails (the flag used to be parsed and ignored)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_SPAWN_TEST="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 3 and line["rank"] == 0 and line["master"] == "127.0.0.1" and int(line["port"]) > 0
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, BENCH_SPAWN_TEST_FAIL_RANK="1"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    # under a launcher (WORLD_SIZE set) it does not spawn again
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 2
+
+
+def test_loop_workload_is_config3_shaped_and_rank_independent():
+    """bench.py --mode shard: 256 (new keyframe, candidate) pairs within 15 m on a 64-keyframe ring, seed 4242 (SURVEY.md §8d C4);
+    the shards of G = 1, 2, 8 partition the same pair list and every target a rank builds is one its pairs use."""
+    import importlib
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    from mrg_slam_amd import loop_closure as lc
+    from mrg_slam_amd import synth
+
+    real = synth.synth_lidar_many
+    synth.synth_lidar_many = lambda scene, poses, model, seeds, **kw: [np.zeros((1, 4), np.float32) for _ in poses]  # the scans themselves are not needed here
+    try:
+        scans, pairs = bench.make_loop_workload()
+        scans2, pairs2 = bench.make_loop_workload()
+    finally:
+        synth.synth_lidar_many = real
+    assert len(scans) == 64 and len(pairs) == 256
+    assert all(a != b for a, b, _, _ in pairs) and [p[0] for p in pairs] == sorted(p[0] for p in pairs)
+    for (a, b, g, rel), (a2, b2, g2, rel2) in zip(pairs, pairs2):
+        assert (a, b) == (a2, b2) and np.array_equal(g, g2)
+        assert np.linalg.norm(rel[:2, 3]) <= 15.0 + 1e-9 and np.linalg.norm(g[:3, 3] - rel[:3, 3]) < 3.0
+    for world in (1, 2, 8):
+        seen = np.concatenate([lc.shard_indices(256, world, r) for r in range(world)])
+        assert sorted(seen.tolist()) == list(range(256))
+        assert max(len(lc.shard_indices(256, world, r)) for r in range(world)) == 256 // world

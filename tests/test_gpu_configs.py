@@ -159,6 +159,10 @@ def test_factory_mirror_dispatch():
     assert select_registration_method({"registration_method": "NDT_OMP", "reg_nn_search_method": "whatever"})._params.nn_search_method == SEARCH["DIRECT7"]
     assert select_registration_method({"registration_method": "NDT_OMP", "reg_nn_search_method": "DIRECT1"})._params.nn_search_method == SEARCH["DIRECT1"]
     assert select_registration_method({"registration_method": "NDT"})._params.nn_search_method == SEARCH["KDTREE"]
+    # registrations.cpp:115-129: an unknown name without "OMP" in it ends in pcl::NormalDistributionsTransform (KDTREE only),
+    # one with "OMP" in the pclomp branch with the requested neighbourhood
+    assert select_registration_method({"registration_method": "FOO", "reg_nn_search_method": "DIRECT1"})._params.nn_search_method == SEARCH["KDTREE"]
+    assert select_registration_method({"registration_method": "FOO_OMP", "reg_nn_search_method": "DIRECT1"})._params.nn_search_method == SEARCH["DIRECT1"]
     assert select_registration_method({"registration_method": "FAST_VGICP", "reg_resolution": 0.5})._params.resolution == 0.5
     from mrg_slam_amd import IcpHip
 
