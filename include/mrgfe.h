@@ -303,6 +303,33 @@ int mrgfe_dbg_sort_pairs(mrgfe_ctx* ctx, const uint32_t* keys, const uint32_t* v
 int mrgfe_dbg_exclusive_scan(mrgfe_ctx* ctx, const uint32_t* in, size_t n, uint32_t* out, uint32_t* total);
 int mrgfe_dbg_minmax(mrgfe_ctx* ctx, const float* xyzi, size_t n, float min3[3], float max3[3], uint32_t* n_finite);
 
+/* The NDT optimiser (Newton + More-Thuente state machine: pclomp computeTransformation / computeStepLengthMT, the same source
+ * the device steps in ndt_reduce_kernel) driven by hand, no GPU involved: create() runs align()'s prologue for `guess`;
+ * request() returns 1 and the pending derivative evaluation (mode 0 score+gradient+Hessian, 1 score+gradient, 2 f64 Hessian
+ * only; T = the transform to evaluate at, column-major; p = its pose vector) or 0 when the alignment is finished; result() hands
+ * that evaluation's sums over and advances to the next request.  tests/test_controller_cpu.py feeds it the CPU oracle's
+ * evaluations. */
+/* Who steps that optimiser during the following alignments of this process: 0 = the device (the batch advances round after round
+ * without the host), 1 = the host (one synchronisation per round), -1 = automatic (default: single registrations on the host,
+ * batches on the device; the environment variable MRGFE_HOST_CONTROL sets the initial value).  Results are the same either way;
+ * tests/test_gpu_control.py holds the two against each other. */
+int mrgfe_dbg_set_host_control(int mode);
+/* The optimiser's scalar routines (pose vector -> float matrix, angle derivative tables, 6x6 SVD solve) on n cases of 48 doubles
+ * (p[6], A[36] row-major, b[6]), on the host (on_device = 0, ctx may be NULL) or on the device: M16 [n][16] row-major, tables69
+ * [n][8*3 + 15*3], x6 [n][6].  One source (csrc/ndt_ctl.h) compiled twice; the test compares the two bit for bit. */
+/* the float sine / cosine the optimiser builds its pose matrices with (host build of csrc/ndt_ctl.h: glibc's sinf / cosf algorithm
+ * restated, because the reference's Eigen::AngleAxisf calls exactly those and they are not correctly rounded) */
+void mrgfe_dbg_sincosf(const float* x, size_t n, float* sin_out, float* cos_out);
+int mrgfe_dbg_ctl_math(mrgfe_ctx* ctx, const double* cases48, int n, int on_device, float* M16, double* tables69, double* x6);
+/* rounds (plan -> derivative launches -> reduce / controller step) of the last mrgfe_batch_align of an NDT_HIP batch */
+int mrgfe_batch_rounds(const mrgfe_batch* b);
+typedef struct mrgfe_dbg_ctl mrgfe_dbg_ctl;
+int  mrgfe_dbg_ctl_create(const mrgfe_reg_params* params, const float guess[16], uint32_t n_src, mrgfe_dbg_ctl** out);
+void mrgfe_dbg_ctl_destroy(mrgfe_dbg_ctl* h);
+int  mrgfe_dbg_ctl_request(const mrgfe_dbg_ctl* h, int* mode, float T[16], double p[6]);
+int  mrgfe_dbg_ctl_result(mrgfe_dbg_ctl* h, double score, const double grad[6], const double hess[36], double neighbours);
+int  mrgfe_dbg_ctl_final(const mrgfe_dbg_ctl* h, float T[16], int* converged, int* iterations, int* evaluations);
+
 #ifdef __cplusplus
 }
 #endif

@@ -155,6 +155,15 @@ SIGNATURES = {
     "mrgfe_dbg_sort_pairs": (C.c_int, [_vp, _u32p, _u32p, C.c_size_t, C.c_int, _u32p, _u32p]),
     "mrgfe_dbg_exclusive_scan": (C.c_int, [_vp, _u32p, C.c_size_t, _u32p, _u32p]),
     "mrgfe_dbg_minmax": (C.c_int, [_vp, _fp, C.c_size_t, _fp, _fp, _u32p]),
+    "mrgfe_dbg_set_host_control": (C.c_int, [C.c_int]),
+    "mrgfe_batch_rounds": (C.c_int, [_vp]),
+    "mrgfe_dbg_sincosf": (None, [_fp, C.c_size_t, _fp, _fp]),
+    "mrgfe_dbg_ctl_math": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _fp, _dp, _dp]),
+    "mrgfe_dbg_ctl_create": (C.c_int, [C.POINTER(RegParams), _fp, C.c_uint32, C.POINTER(_vp)]),
+    "mrgfe_dbg_ctl_destroy": (None, [_vp]),
+    "mrgfe_dbg_ctl_request": (C.c_int, [_vp, C.POINTER(C.c_int), _fp, _dp]),
+    "mrgfe_dbg_ctl_result": (C.c_int, [_vp, C.c_double, _dp, _dp, C.c_double]),
+    "mrgfe_dbg_ctl_final": (C.c_int, [_vp, _fp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 
 

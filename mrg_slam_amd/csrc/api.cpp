@@ -13,6 +13,7 @@
 #include "filters.h"
 #include "mapcloud.h"
 #include "gicp_engine.h"
+#include "ndt_derivatives.h"
 #include "ndt_engine.h"
 #include "nn_grid.h"
 
@@ -1071,6 +1072,95 @@ int mrgfe_dbg_minmax(mrgfe_ctx* ctx, const float* xyzi, size_t n, float min3[3],
     MRGFE_HIP_CHECK(hipMemcpy(&bb, d_out, sizeof(BBox), hipMemcpyDeviceToHost));
     for (int a = 0; a < 3; ++a) { min3[a] = bb.mn[a]; max3[a] = bb.mx[a]; }
     *n_finite = bb.n_finite;
+    return MRGFE_OK;
+}
+
+// ---- the NDT optimiser state machine stepped by hand (no GPU involved): tests/test_controller_cpu.py feeds it the CPU oracle's
+// derivative evaluations and must end where the oracle's own computeTransformation ends -------------------------------------
+struct mrgfe_dbg_ctl { NdtController c; };
+
+int mrgfe_dbg_set_host_control(int mode)
+{
+    ndt_set_host_control(mode);
+    return MRGFE_OK;
+}
+void mrgfe_dbg_sincosf(const float* x, size_t n, float* sin_out, float* cos_out)
+{
+    for (size_t i = 0; i < n; ++i) { sin_out[i] = ctl::sin_f(x[i]); cos_out[i] = ctl::cos_f(x[i]); }
+}
+int mrgfe_dbg_ctl_math(mrgfe_ctx* ctx, const double* cases48, int n, int on_device, float* M16, double* tables69, double* x6)
+{
+    if (!cases48 || !M16 || !tables69 || !x6 || n < 0) { set_error("mrgfe_dbg_ctl_math: bad argument"); return MRGFE_ERR_INVALID; }
+    if (!on_device) {
+        for (int i = 0; i < n; ++i) {
+            const double* c = cases48 + size_t(i) * 48;
+            ctl::pose_to_matrix(c, M16 + size_t(i) * 16);
+            double j[8][3], h[15][3];
+            ctl::angle_tables(c, j, h);
+            std::memcpy(tables69 + size_t(i) * 69, j, sizeof(j));
+            std::memcpy(tables69 + size_t(i) * 69 + 24, h, sizeof(h));
+            ctl::svd_solve6(c + 6, c + 42, x6 + size_t(i) * 6);
+        }
+        return MRGFE_OK;
+    }
+    if (!ctx) { set_error("mrgfe_dbg_ctl_math: NULL context"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);
+    MRGFE_TRY(ctx->bind());
+    DevBuf &din = ctx->scratch[0], &dM = ctx->scratch[1], &dt = ctx->scratch[2], &dx = ctx->scratch[3];
+    const size_t nn = std::max(n, 1);
+    MRGFE_TRY(din.ensure(nn * 48 * 8)); MRGFE_TRY(dM.ensure(nn * 64)); MRGFE_TRY(dt.ensure(nn * 69 * 8)); MRGFE_TRY(dx.ensure(nn * 48));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(din.p, cases48, size_t(n) * 48 * 8, hipMemcpyHostToDevice, ctx->stream));
+    MRGFE_TRY(ndt_ctl_math_device(ctx, din.as<double>(), n, dM.as<float>(), dt.as<double>(), dx.as<double>()));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(M16, dM.p, size_t(n) * 64, hipMemcpyDeviceToHost, ctx->stream));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(tables69, dt.p, size_t(n) * 69 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(x6, dx.p, size_t(n) * 48, hipMemcpyDeviceToHost, ctx->stream));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MRGFE_OK;
+}
+int mrgfe_batch_rounds(const mrgfe_batch* b) { return b && b->ndt ? b->ndt->rounds() : 0; }
+
+
+int mrgfe_dbg_ctl_create(const mrgfe_reg_params* params, const float guess[16], uint32_t n_src, mrgfe_dbg_ctl** out)
+{
+    if (!params || !guess || !out) { set_error("mrgfe_dbg_ctl_create: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (params->method != MRGFE_NDT_HIP) { set_error("mrgfe_dbg_ctl_create: NDT_HIP only"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(check_params(params));
+    mrgfe_dbg_ctl* h = new mrgfe_dbg_ctl();
+    float g[16];
+    col2row(guess, g);
+    h->c.start(ndt_params_from(*params), g, n_src);
+    *out = h;
+    return MRGFE_OK;
+}
+void mrgfe_dbg_ctl_destroy(mrgfe_dbg_ctl* h) { delete h; }
+int mrgfe_dbg_ctl_request(const mrgfe_dbg_ctl* h, int* mode, float T[16], double p[6])
+{
+    if (!h || h->c.done()) return 0;
+    const NdtCtlState& s = h->c.state();
+    if (mode) *mode = s.req_mode;
+    if (T) row2col(s.final_, T);
+    if (p) std::memcpy(p, s.req_p, sizeof(double) * 6);
+    return 1;
+}
+int mrgfe_dbg_ctl_result(mrgfe_dbg_ctl* h, double score, const double grad[6], const double hess[36], double neighbours)
+{
+    if (!h || !grad || !hess) { set_error("mrgfe_dbg_ctl_result: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (h->c.done()) { set_error("mrgfe_dbg_ctl_result: no request pending"); return MRGFE_ERR_STATE; }
+    double r[kNdtPartialStride] = {0};
+    r[0] = score;
+    std::memcpy(r + 1, grad, sizeof(double) * 6);
+    std::memcpy(r + 7, hess, sizeof(double) * 36);
+    r[kNdtNbIndex] = neighbours;
+    h->c.on_result(r);
+    return MRGFE_OK;
+}
+int mrgfe_dbg_ctl_final(const mrgfe_dbg_ctl* h, float T[16], int* converged, int* iterations, int* evaluations)
+{
+    if (!h || !T) { set_error("mrgfe_dbg_ctl_final: NULL argument"); return MRGFE_ERR_INVALID; }
+    row2col(h->c.final_transformation(), T);
+    if (converged) *converged = h->c.converged() ? 1 : 0;
+    if (iterations) *iterations = h->c.iterations();
+    if (evaluations) *evaluations = h->c.evaluations();
     return MRGFE_OK;
 }
 

@@ -1,0 +1,493 @@
+// csrc/ndt_ctl.h — the optimiser of NDT_HIP as ONE piece of host/device code: pclomp::NormalDistributionsTransform::
+// computeTransformation + computeStepLengthMT + trialValueSelectionMT + updateIntervalMT + computeAngleDerivatives
+// (reached through registration_->align(): /root/reference/apps/scan_matching_odometry_component.cpp:
+// 265-266, src/mrg_slam/loop_detector.cpp:134) unrolled into a resumable state machine over a plain struct.
+//
+// Every computeDerivatives / computeHessian call of the reference is one REQUEST (an NdtEvalDev record read by the derivative
+// kernels); the machine resumes when the 44 reduced sums of that evaluation are known (ctl::on_result).  The same source runs
+//   * on the DEVICE inside ndt_reduce_control_kernel (ndt_derivatives.hip): a batch advances round after round without the
+//     host — reduce -> controller step -> next request, all in HBM;
+//   * on the HOST behind class NdtController (ndt_controller.cpp), the host-stepped path kept for single registrations and as
+//     the A/B check of the device path (MRGFE_HOST_CONTROL).
+// All arithmetic is f64 (or the reference's f32 where it uses f32) in the written order: compiled with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ndt_types.h"
+
+#define MRGFE_HD __host__ __device__ inline
+
+namespace mrgfe {
+
+enum NdtPhase : int32_t { NDT_IDLE = 0, NDT_INIT = 1, NDT_LS_FIRST = 2, NDT_LS_ITER = 3, NDT_LS_HESS = 4, NDT_DONE = 5 };
+
+// Complete state of one alignment (device-resident during a batch; ~1.4 KB)
+struct NdtCtlState {
+    // parameters
+    double   step_size, trans_eps, outlier_ratio;
+    float    resolution;
+    int32_t  max_iterations, search, reuse;
+    // status
+    int32_t  phase;
+    uint32_t n_src;
+    int32_t  converged, nr_iterations, n_evals, n_reused, cache_valid, pad0;
+    float    final_[16], transformation_[16], previous_[16];  // row-major
+    double   cache_p[6], cache_nb;
+    double   trans_probability, nb_sum;
+    double   gauss_d1, gauss_d2, gauss_d3;
+    double   p[6], score, g[6], H[36];
+    // More-Thuente
+    double   x[6], x_t[6], dir[6];
+    double   phi_0, d_phi_0, a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t, psi_t, d_psi_t;
+    int32_t  interval_converged, open_interval, step_iterations;
+    // pending request
+    int32_t  req_mode;
+    double   req_p[6];
+    // accounting of the evaluations that were launched for this pair, per kernel variant (SURVEY.md §8d byte model)
+    double   acct_points[3], acct_nb[3];
+};
+
+namespace ctl {
+
+constexpr double kMu = 1.e-4, kNu = 0.9;
+constexpr int    kMaxStepIterations = 10;
+
+// std::min / std::max exactly — (b < a) ? b : a and (a < b) ? b : a — because a NaN trial step (the cubic of
+// trialValueSelectionMT takes the square root of a negative number now and then) must propagate the way it does in the reference
+MRGFE_HD double dmin(double a, double b) { return (b < a) ? b : a; }
+MRGFE_HD double dmax(double a, double b) { return (a < b) ? b : a; }
+MRGFE_HD bool   finite_d(double v) { return (v - v) == 0.0; }
+
+// ---- float sine / cosine of Eigen::AngleAxisf ------------------------------------------------------------------------
+// The reference calls std::sin / std::cos on floats, i.e. the C library's sinf / cosf, and those are NOT correctly rounded
+// (glibc >= 2.28 documents 0.56 ULP): rounding a double-precision sine to float differs from glibc in ~1 % of the arguments,
+// which moved 6 % of the pose matrices by an ulp when the device did that.  So both builds of this file evaluate glibc's own
+// algorithm (the ARM optimized-routines sincosf: double-precision minimax polynomials on [-pi/4, pi/4] after a reduction by
+// multiples of pi/2, written here from its published description): tests/test_controller_cpu.py compares it with the C
+// library's sinf / cosf on every float with 2^-31 <= |x| < 120 of a strided sweep (identical on glibc 2.35 / x86-64 with FMA:
+// the reduction x - n * (pi/2) is fused there).  |x| >= 120, NaN and infinities take the plain double routine.
+struct SinCosPoly { double c0, c1, c2, c3, c4, s1, s2, s3; };
+MRGFE_HD uint32_t f_abstop12(float x) { return (__builtin_bit_cast(uint32_t, x) >> 20) & 0x7ffu; }
+MRGFE_HD float sincosf_poly(double x, double x2, bool negate_cos, int n)
+{
+    const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    const double sg = negate_cos ? -1.0 : 1.0;
+    const double C0 = sg * 0x1p0, C1 = sg * -0x1.ffffffd0c621cp-2, C2 = sg * 0x1.55553e1068f19p-5, C3 = sg * -0x1.6c087e89a359dp-10, C4 = sg * 0x1.99343027bf8c3p-16;
+    if ((n & 1) == 0) {
+        const double x3 = x * x2;
+        const double s1 = S2 + x2 * S3;
+        const double x7 = x3 * x2;
+        const double s = x + x3 * S1;
+        return static_cast<float>(s + x7 * s1);
+    }
+    const double x4 = x2 * x2;
+    const double c2 = C3 + x2 * C4;
+    const double c1 = C0 + x2 * C1;
+    const double x6 = x4 * x2;
+    const double c = c1 + x4 * C2;
+    return static_cast<float>(c + x6 * c2);
+}
+MRGFE_HD double sincosf_reduce(double x, int* np)
+{
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    const double r = x * hpi_inv;
+    const int    n = (static_cast<int32_t>(r) + 0x800000) >> 24;
+    *np = n;
+    return __builtin_fma(-static_cast<double>(n), hpi, x);
+}
+MRGFE_HD float sin_f(float y)
+{
+    double x = y;
+    if (f_abstop12(y) < f_abstop12(0x1.921FB6p-1f)) {
+        if (f_abstop12(y) < f_abstop12(0x1p-12f)) return y;
+        return sincosf_poly(x, x * x, false, 0);
+    }
+    if (f_abstop12(y) < f_abstop12(120.0f)) {
+        int n;
+        x = sincosf_reduce(x, &n);
+        const double sign = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;  // {1, -1, -1, 1}[n & 3]
+        return sincosf_poly(x * sign, x * x, (n & 2) != 0, n);
+    }
+    return static_cast<float>(sin(x));
+}
+MRGFE_HD float cos_f(float y)
+{
+    double x = y;
+    if (f_abstop12(y) < f_abstop12(0x1.921FB6p-1f)) {
+        if (f_abstop12(y) < f_abstop12(0x1p-12f)) return 1.0f;
+        return sincosf_poly(x, x * x, false, 1);
+    }
+    if (f_abstop12(y) < f_abstop12(120.0f)) {
+        int n;
+        x = sincosf_reduce(x, &n);
+        const int m = n + 1;
+        const double sign = ((m & 3) == 1 || (m & 3) == 2) ? -1.0 : 1.0;
+        return sincosf_poly(x * sign, x * x, (m & 2) != 0, n ^ 1);
+    }
+    return static_cast<float>(cos(x));
+}
+
+// ---- 6x6 solve through a one-sided (Hestenes) Jacobi SVD: x = V diag(1/s) U^T b over singular values above
+// 6*eps*s_max, i.e. the minimum-norm solution Eigen::JacobiSVD<Matrix6d>::solve returns (no PD fix-up). -----------
+MRGFE_HD void svd_solve6(const double A[36], const double b[6], double x[6])
+{
+    const double kNaN = __builtin_nan("");
+    for (int i = 0; i < 36; ++i)
+        if (!finite_d(A[i])) { for (int k = 0; k < 6; ++k) x[k] = kNaN; return; }
+    double U[6][6], V[6][6];
+    double scale = 0;
+    for (int i = 0; i < 36; ++i) scale = dmax(scale, fabs(A[i]));
+    if (scale == 0) { for (int k = 0; k < 6; ++k) x[k] = 0; return; }
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { U[r][c] = A[r * 6 + c] / scale; V[r][c] = r == c ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 5; ++p)
+            for (int q = p + 1; q < 6; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int k = 0; k < 6; ++k) { alpha += U[k][p] * U[k][p]; beta += U[k][q] * U[k][q]; gamma += U[k][p] * U[k][q]; }
+                if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta)) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int k = 0; k < 6; ++k) {
+                    const double up = U[k][p], uq = U[k][q];
+                    U[k][p] = c * up - s * uq; U[k][q] = s * up + c * uq;
+                    const double vp = V[k][p], vq = V[k][q];
+                    V[k][p] = c * vp - s * vq; V[k][q] = s * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    double sig[6], smax = 0;
+    for (int j = 0; j < 6; ++j) {
+        double n2 = 0;
+        for (int k = 0; k < 6; ++k) n2 += U[k][j] * U[k][j];
+        sig[j] = sqrt(n2);
+        smax = dmax(smax, sig[j]);
+    }
+    const double thr = dmax(smax * 6.0 * 2.2204460492503131e-16, 2.2250738585072014e-308 / scale);
+    for (int k = 0; k < 6; ++k) x[k] = 0;
+    for (int j = 0; j < 6; ++j) {
+        if (!(sig[j] > thr)) continue;
+        double ub = 0;
+        for (int k = 0; k < 6; ++k) ub += U[k][j] * b[k];
+        const double coef = ub / (sig[j] * sig[j] * scale);  // U[:,j] is sig_j * u_j
+        for (int k = 0; k < 6; ++k) x[k] += V[k][j] * coef;
+    }
+}
+
+MRGFE_HD double psi_mt(double a, double f_a, double f_0, double g_0, double mu) { return f_a - f_0 - mu * g_0 * a; }
+MRGFE_HD double dpsi_mt(double g_a, double g_0, double mu) { return g_a - mu * g_0; }
+
+MRGFE_HD bool update_interval(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t, double g_t)
+{
+    if (f_t > f_l) { a_u = a_t; f_u = f_t; g_u = g_t; return false; }
+    if (g_t * (a_l - a_t) > 0) { a_l = a_t; f_l = f_t; g_l = g_t; return false; }
+    if (g_t * (a_l - a_t) < 0) { a_u = a_l; f_u = f_l; g_u = g_l; a_l = a_t; f_l = f_t; g_l = g_t; return false; }
+    return true;
+}
+
+// minimiser of the cubic through (a0,f0,g0) and (a1,f1,g1), Sun & Yuan eq. 2.4.52/2.4.56
+MRGFE_HD double cubic_min(double a0, double f0, double g0, double a1, double f1, double g1)
+{
+    const double z = 3 * (f1 - f0) / (a1 - a0) - g1 - g0;
+    const double w = sqrt(z * z - g1 * g0);
+    return a0 + (a1 - a0) * (w - g0 - z) / (g1 - g0 + 2 * w);
+}
+
+MRGFE_HD double trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t)
+{
+    if (f_t > f_l) {
+        const double a_c = cubic_min(a_l, f_l, g_l, a_t, f_t, g_t);
+        const double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+        return (fabs(a_c - a_l) < fabs(a_q - a_l)) ? a_c : 0.5 * (a_q + a_c);
+    }
+    if (g_t * g_l < 0) {
+        const double a_c = cubic_min(a_l, f_l, g_l, a_t, f_t, g_t);
+        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+        return (fabs(a_c - a_t) >= fabs(a_s - a_t)) ? a_c : a_s;
+    }
+    if (fabs(g_t) <= fabs(g_l)) {
+        const double a_c = cubic_min(a_l, f_l, g_l, a_t, f_t, g_t);
+        const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+        const double a_next = (fabs(a_c - a_t) < fabs(a_s - a_t)) ? a_c : a_s;
+        return (a_t > a_l) ? dmin(a_t + 0.66 * (a_u - a_t), a_next) : dmax(a_t + 0.66 * (a_u - a_t), a_next);
+    }
+    return cubic_min(a_u, f_u, g_u, a_t, f_t, g_t);
+}
+
+MRGFE_HD void identity16(float M[16]) { for (int i = 0; i < 16; ++i) M[i] = (i % 5 == 0) ? 1.0f : 0.0f; }
+MRGFE_HD bool is_identity16(const float M[16])
+{
+    for (int i = 0; i < 16; ++i) if (M[i] != ((i % 5 == 0) ? 1.0f : 0.0f)) return false;
+    return true;
+}
+
+// Eigen::AngleAxisf(angle, e_axis).toRotationMatrix()
+MRGFE_HD void axis_rotation(float angle, int axis, float R[9])
+{
+    float ax[3] = {0, 0, 0};
+    ax[axis] = 1.0f;
+    const float sn = sin_f(angle), c = cos_f(angle);
+    const float sa[3] = {sn * ax[0], sn * ax[1], sn * ax[2]};
+    const float ca[3] = {(1.0f - c) * ax[0], (1.0f - c) * ax[1], (1.0f - c) * ax[2]};
+    float tmp;
+    tmp = ca[0] * ax[1]; R[1] = tmp - sa[2]; R[3] = tmp + sa[2];
+    tmp = ca[0] * ax[2]; R[2] = tmp + sa[1]; R[6] = tmp - sa[1];
+    tmp = ca[1] * ax[2]; R[5] = tmp - sa[0]; R[7] = tmp + sa[0];
+    R[0] = ca[0] * ax[0] + c; R[4] = ca[1] * ax[1] + c; R[8] = ca[2] * ax[2] + c;
+}
+MRGFE_HD void matmul3f(const float a[9], const float b[9], float o[9])
+{
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            const float p0 = a[r * 3] * b[c], p1 = a[r * 3 + 1] * b[3 + c], p2 = a[r * 3 + 2] * b[6 + c];
+            const float s = p0 + p1;
+            o[r * 3 + c] = s + p2;
+        }
+}
+
+// Translation(p0..2) * AngleAxis(p3, X) * AngleAxis(p4, Y) * AngleAxis(p5, Z) as a float matrix (row-major)
+MRGFE_HD void pose_to_matrix(const double p[6], float M[16])
+{
+    float Rx[9], Ry[9], Rz[9], Rxy[9], R[9];
+    axis_rotation(static_cast<float>(p[3]), 0, Rx);
+    axis_rotation(static_cast<float>(p[4]), 1, Ry);
+    axis_rotation(static_cast<float>(p[5]), 2, Rz);
+    matmul3f(Rx, Ry, Rxy);
+    matmul3f(Rxy, Rz, R);
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) M[r * 4 + c] = R[r * 3 + c];
+        M[r * 4 + 3] = static_cast<float>(p[r]);
+    }
+    M[12] = M[13] = M[14] = 0.0f;
+    M[15] = 1.0f;
+}
+
+// computeAngleDerivatives: rows a..h of j_ang and a2..f3 of h_ang
+MRGFE_HD void angle_tables(const double p[6], double j[8][3], double h[15][3])
+{
+    double cx, cy, cz, sx, sy, sz;
+    if (fabs(p[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = cos(p[3]); sx = sin(p[3]); }
+    if (fabs(p[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = cos(p[4]); sy = sin(p[4]); }
+    if (fabs(p[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = cos(p[5]); sz = sin(p[5]); }
+    j[0][0] = (-sx * sz + cx * sy * cz); j[0][1] = (-sx * cz - cx * sy * sz); j[0][2] = (-cx * cy);
+    j[1][0] = (cx * sz + sx * sy * cz);  j[1][1] = (cx * cz - sx * sy * sz);  j[1][2] = (-sx * cy);
+    j[2][0] = (-sy * cz);                j[2][1] = sy * sz;                   j[2][2] = cy;
+    j[3][0] = sx * cy * cz;              j[3][1] = (-sx * cy * sz);           j[3][2] = sx * sy;
+    j[4][0] = (-cx * cy * cz);           j[4][1] = cx * cy * sz;              j[4][2] = (-cx * sy);
+    j[5][0] = (-cy * sz);                j[5][1] = (-cy * cz);                j[5][2] = 0;
+    j[6][0] = (cx * cz - sx * sy * sz);  j[6][1] = (-cx * sz - sx * sy * cz); j[6][2] = 0;
+    j[7][0] = (sx * cz + cx * sy * sz);  j[7][1] = (cx * sy * cz - sx * sz);  j[7][2] = 0;
+    h[0][0] = (-cx * sz - sx * sy * cz);  h[0][1] = (-cx * cz + sx * sy * sz);  h[0][2] = sx * cy;
+    h[1][0] = (-sx * sz + cx * sy * cz);  h[1][1] = (-cx * sy * sz - sx * cz);  h[1][2] = (-cx * cy);
+    h[2][0] = (cx * cy * cz);             h[2][1] = (-cx * cy * sz);            h[2][2] = (cx * sy);
+    h[3][0] = (sx * cy * cz);             h[3][1] = (-sx * cy * sz);            h[3][2] = (sx * sy);
+    h[4][0] = (-sx * cz - cx * sy * sz);  h[4][1] = (sx * sz - cx * sy * cz);   h[4][2] = 0;
+    h[5][0] = (cx * cz - sx * sy * sz);   h[5][1] = (-sx * sy * cz - cx * sz);  h[5][2] = 0;
+    h[6][0] = (-cy * cz);                 h[6][1] = (cy * sz);                  h[6][2] = (sy);
+    h[7][0] = (-sx * sy * cz);            h[7][1] = (sx * sy * sz);             h[7][2] = (sx * cy);
+    h[8][0] = (cx * sy * cz);             h[8][1] = (-cx * sy * sz);            h[8][2] = (-cx * cy);
+    h[9][0] = (sy * sz);                  h[9][1] = (sy * cz);                  h[9][2] = 0;
+    h[10][0] = (-sx * cy * sz);           h[10][1] = (-sx * cy * cz);           h[10][2] = 0;
+    h[11][0] = (cx * cy * sz);            h[11][1] = (cx * cy * cz);            h[11][2] = 0;
+    h[12][0] = (-cy * cz);                h[12][1] = (cy * sz);                 h[12][2] = 0;
+    h[13][0] = (-cx * sz - sx * sy * cz); h[13][1] = (-cx * cz + sx * sy * sz); h[13][2] = 0;
+    h[14][0] = (-sx * sz + cx * sy * cz); h[14][1] = (-cx * sy * sz - sx * cz); h[14][2] = 0;
+}
+
+MRGFE_HD bool done(const NdtCtlState& s) { return s.phase == NDT_DONE || s.phase == NDT_IDLE; }
+
+MRGFE_HD void make_request(NdtCtlState& s, int mode, const double p[6])
+{
+    s.req_mode = mode;
+    for (int k = 0; k < 6; ++k) s.req_p[k] = p[k];
+    ++s.n_evals;
+}
+
+// the record the derivative kernels read for the pending request of `s` (its transform is final_ as of the request)
+MRGFE_HD void fill_eval(const NdtCtlState& s, NdtEvalDev& e)
+{
+    if (done(s)) { e.active = 0; return; }
+    for (int k = 0; k < 12; ++k) e.T[k] = s.final_[k];
+    double j[8][3], h[15][3];
+    angle_tables(s.req_p, j, h);
+    for (int a = 0; a < 8; ++a) for (int b = 0; b < 3; ++b) { e.j_ang_d[a][b] = j[a][b]; e.j_ang[a][b] = static_cast<float>(j[a][b]); }
+    for (int a = 0; a < 15; ++a) for (int b = 0; b < 3; ++b) { e.h_ang_d[a][b] = h[a][b]; e.h_ang[a][b] = static_cast<float>(h[a][b]); }
+    e.gauss_d1 = s.gauss_d1;
+    e.gauss_d2 = s.gauss_d2;
+    e.mode = s.req_mode;
+    e.active = 1;
+    e.search = s.search;
+}
+
+MRGFE_HD void store_result(NdtCtlState& s, const double r[44], bool with_score_grad, bool with_hessian)
+{
+    if (with_score_grad) {
+        s.score = r[0];
+        for (int k = 0; k < 6; ++k) s.g[k] = r[1 + k];
+    }
+    if (with_hessian)
+        for (int k = 0; k < 36; ++k) s.H[k] = r[7 + k];
+    const double nb = s.n_src ? r[kNdtNbIndex] / static_cast<double>(s.n_src) : 0.0;
+    s.nb_sum += nb;
+    s.acct_points[s.req_mode] += static_cast<double>(s.n_src);
+    s.acct_nb[s.req_mode] += r[kNdtNbIndex];
+    // remember the pose of evaluations whose transform was built from the pose vector (line-search trials)
+    if (with_score_grad && s.phase != NDT_INIT) {
+        for (int k = 0; k < 6; ++k) s.cache_p[k] = s.req_p[k];
+        s.cache_nb = nb;
+        s.cache_valid = 1;
+    }
+}
+
+MRGFE_HD void ls_after_eval(NdtCtlState& s)
+{
+    s.phi_t = -s.score;
+    double d = 0;
+    for (int k = 0; k < 6; ++k) d += s.g[k] * s.dir[k];
+    s.d_phi_t = -d;
+    s.psi_t = psi_mt(s.a_t, s.phi_t, s.phi_0, s.d_phi_0, kMu);
+    s.d_psi_t = dpsi_mt(s.d_phi_t, s.d_phi_0, kMu);
+}
+
+// resume after the reduced sums r[0..43] (score, gradient, 6x6 Hessian row-major, neighbour count) of the pending request.
+// On return either done(s) or a new request is pending (s.req_mode / s.req_p / s.final_).
+MRGFE_HD void on_result(NdtCtlState& s, const double r[44])
+{
+    enum Next { NEWTON, LS_UPDATE, LS_DECIDE, FINISH_LS, RETURN };
+    Next   next = RETURN;
+    double a_fin = 0.0;  // step length handed to FINISH_LS
+    switch (s.phase) {
+        case NDT_INIT:     store_result(s, r, true, true);  next = NEWTON; break;
+        case NDT_LS_FIRST: store_result(s, r, true, true);  ls_after_eval(s); next = LS_DECIDE; break;
+        case NDT_LS_ITER:  store_result(s, r, true, false); next = LS_UPDATE; break;
+        case NDT_LS_HESS:  store_result(s, r, false, true); a_fin = s.a_t; next = FINISH_LS; break;
+        default: return;
+    }
+    for (;;) {
+        switch (next) {
+            case NEWTON: {
+                // computeTransformation loop body: delta_p = JacobiSVD(H).solve(-g), then computeStepLengthMT
+                for (int k = 0; k < 16; ++k) s.previous_[k] = s.transformation_[k];
+                double neg_g[6], delta[6];
+                for (int k = 0; k < 6; ++k) neg_g[k] = -s.g[k];
+                svd_solve6(s.H, neg_g, delta);
+                double n2 = 0;
+                for (int k = 0; k < 6; ++k) n2 += delta[k] * delta[k];
+                const double norm = sqrt(n2);
+                if (norm == 0 || norm != norm) {
+                    s.trans_probability = s.score / static_cast<double>(s.n_src);
+                    s.converged = (norm == norm) ? 1 : 0;
+                    s.phase = NDT_DONE;
+                    return;
+                }
+                for (int k = 0; k < 6; ++k) s.dir[k] = delta[k] / norm;
+                // computeStepLengthMT prologue
+                for (int k = 0; k < 6; ++k) s.x[k] = s.p[k];
+                s.phi_0 = -s.score;
+                double d = 0;
+                for (int k = 0; k < 6; ++k) d += s.g[k] * s.dir[k];
+                s.d_phi_0 = -d;
+                if (s.d_phi_0 >= 0) {
+                    if (s.d_phi_0 == 0) {
+                        // "return 0": a zero-length step; the outer loop then converges on its second pass (|0| < eps)
+                        a_fin = 0.0;
+                        next = FINISH_LS;
+                        break;
+                    }
+                    s.d_phi_0 *= -1;
+                    for (int k = 0; k < 6; ++k) s.dir[k] *= -1;
+                }
+                s.step_iterations = 0;
+                s.a_l = 0; s.a_u = 0;
+                s.f_l = psi_mt(s.a_l, s.phi_0, s.phi_0, s.d_phi_0, kMu);
+                s.g_l = dpsi_mt(s.d_phi_0, s.d_phi_0, kMu);
+                s.f_u = psi_mt(s.a_u, s.phi_0, s.phi_0, s.d_phi_0, kMu);
+                s.g_u = dpsi_mt(s.d_phi_0, s.d_phi_0, kMu);
+                const double step_max = s.step_size, step_min = s.trans_eps / 2;
+                s.interval_converged = (step_max - step_min) < 0 ? 1 : 0;
+                s.open_interval = 1;
+                s.a_t = norm;
+                s.a_t = dmin(s.a_t, step_max);
+                s.a_t = dmax(s.a_t, step_min);
+                for (int k = 0; k < 6; ++k) s.x_t[k] = s.x[k] + s.dir[k] * s.a_t;
+                pose_to_matrix(s.x_t, s.final_);
+                make_request(s, 0, s.x_t);
+                s.phase = NDT_LS_FIRST;
+                return;
+            }
+            case LS_UPDATE: {
+                // bookkeeping of one line-search trial once its score / gradient are known (body of the while loop of computeStepLengthMT)
+                ls_after_eval(s);
+                if (s.open_interval && (s.psi_t <= 0 && s.d_psi_t >= 0)) {
+                    s.open_interval = 0;
+                    s.f_l = s.f_l + s.phi_0 - kMu * s.d_phi_0 * s.a_l;
+                    s.g_l = s.g_l + kMu * s.d_phi_0;
+                    s.f_u = s.f_u + s.phi_0 - kMu * s.d_phi_0 * s.a_u;
+                    s.g_u = s.g_u + kMu * s.d_phi_0;
+                }
+                if (s.open_interval) s.interval_converged = update_interval(s.a_l, s.f_l, s.g_l, s.a_u, s.f_u, s.g_u, s.a_t, s.psi_t, s.d_psi_t) ? 1 : 0;
+                else                 s.interval_converged = update_interval(s.a_l, s.f_l, s.g_l, s.a_u, s.f_u, s.g_u, s.a_t, s.phi_t, s.d_phi_t) ? 1 : 0;
+                s.step_iterations++;
+                next = LS_DECIDE;
+                break;
+            }
+            case LS_DECIDE: {
+                if (!s.interval_converged && s.step_iterations < kMaxStepIterations && !(s.psi_t <= 0 && s.d_phi_t <= -kNu * s.d_phi_0)) {
+                    if (s.open_interval) s.a_t = trial_value(s.a_l, s.f_l, s.g_l, s.a_u, s.f_u, s.g_u, s.a_t, s.psi_t, s.d_psi_t);
+                    else                 s.a_t = trial_value(s.a_l, s.f_l, s.g_l, s.a_u, s.f_u, s.g_u, s.a_t, s.phi_t, s.d_phi_t);
+                    s.a_t = dmin(s.a_t, s.step_size);
+                    s.a_t = dmax(s.a_t, s.trans_eps / 2);
+                    for (int k = 0; k < 6; ++k) s.x_t[k] = s.x[k] + s.dir[k] * s.a_t;
+                    pose_to_matrix(s.x_t, s.final_);
+                    bool same = s.reuse && s.cache_valid;  // bitwise: the same doubles give the same float transform
+                    for (int k = 0; k < 6 && same; ++k) same = __builtin_bit_cast(uint64_t, s.x_t[k]) == __builtin_bit_cast(uint64_t, s.cache_p[k]);
+                    if (same) {
+                        // The clamped trial step often repeats the previous one (a_t pinned at step_min / step_max): same pose vector
+                        // -> same float transform -> the evaluation would reproduce score / g bit for bit.  The reference
+                        // recomputes it; here the held values are reused and no GPU round is spent (the evaluation is still counted).
+                        ++s.n_evals;
+                        ++s.n_reused;
+                        s.nb_sum += s.cache_nb;
+                        next = LS_UPDATE;
+                        break;
+                    }
+                    make_request(s, 1, s.x_t);
+                    s.phase = NDT_LS_ITER;
+                    return;
+                }
+                if (s.step_iterations) {
+                    make_request(s, 2, s.x_t);  // computeHessian at x_t (final_ already holds its matrix)
+                    s.phase = NDT_LS_HESS;
+                    return;
+                }
+                a_fin = s.a_t;
+                next = FINISH_LS;
+                break;
+            }
+            case FINISH_LS: {
+                // back in computeTransformation's loop body
+                double delta_p[6];
+                for (int k = 0; k < 6; ++k) delta_p[k] = s.dir[k] * a_fin;
+                pose_to_matrix(delta_p, s.transformation_);
+                for (int k = 0; k < 6; ++k) s.p[k] = s.p[k] + delta_p[k];
+                if (s.nr_iterations > s.max_iterations || (s.nr_iterations && (fabs(a_fin) < s.trans_eps))) s.converged = 1;
+                s.nr_iterations++;
+                if (s.converged) {
+                    s.trans_probability = s.score / static_cast<double>(s.n_src);
+                    s.phase = NDT_DONE;
+                    return;
+                }
+                next = NEWTON;  // next Newton iteration from the derivatives already held for p == x_t
+                break;
+            }
+            default: return;
+        }
+    }
+}
+
+}  // namespace ctl
+}  // namespace mrgfe

@@ -1,19 +1,24 @@
-// csrc/ndt_derivatives.h — launchers of the NDT derivative / reduction kernels (ndt_derivatives.hip).
+// csrc/ndt_derivatives.h — launchers of the NDT plan / derivative / reduce(+control) kernels (ndt_derivatives.hip).
 #pragma once
 #include "common.h"
+#include "ndt_ctl.h"
 #include "ndt_types.h"
 
 namespace mrgfe {
 
-// one derivative evaluation for the `npairs` pairs listed in NdtEvalDev::order[mode]; every workgroup takes `ppt` tiles of
-// 256 points, grid = (max_nblk x npairs) with max_nblk = ceil(largest source cloud / (256 * ppt))
-int ndt_launch_derivatives(mrgfe_ctx* ctx, int mode, int search, uint32_t max_nblk, int npairs, const NdtGridDev* d_grids, const NdtPairDev* d_pairs,
-                           const NdtEvalDev* d_evals, double* d_partials, int ppt, uint32_t spec_part_base);
-// fixed-order sum of the block partials -> results[pair][48] = {score, g[6], H[36] row-major, neighbours, pad}
-// with_spec: also reduce the speculative f64 Hessian records (second half of the partial buffer) into
-// results[spec_result_base + pair]
-int ndt_launch_reduce(mrgfe_ctx* ctx, int npairs, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const double* d_partials, double* d_results, bool with_spec,
-                      uint32_t spec_part_base, uint32_t spec_result_base, const int ppt[3] /* tiles per workgroup of the three variants' launches */);
+// the round's plan from the pending requests of the P pairs (ndt_types.h: NdtPlanHead); h_info[round] (pinned, may be NULL)
+// receives the number of pairs still running
+int ndt_launch_plan(mrgfe_ctx* ctx, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, uint32_t P, uint32_t* d_plan, uint32_t wg_target, uint32_t max_ppt, uint32_t forced_ppt,
+                    uint32_t round, NdtRoundInfo* h_info);
+// one derivative evaluation for the pairs the plan lists under `mode`: `grid` workgroups walk the plan's items
+int ndt_launch_derivatives(mrgfe_ctx* ctx, int mode, int search, uint32_t grid, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals,
+                           const uint32_t* d_plan, uint32_t P, double* d_partials);
+// fixed-order sum of the item partials of every pending evaluation.  d_states != NULL: followed by the controller step on the
+// device (next request written to d_evals).  d_states == NULL: results[pair][48] = {score, g[6], H[36] row-major, neighbours, pad}
+int ndt_launch_reduce(mrgfe_ctx* ctx, uint32_t P, const NdtPairDev* d_pairs, NdtEvalDev* d_evals, const double* d_partials, const uint32_t* d_plan, double* d_results,
+                      NdtCtlState* d_states);
+// diagnostic: ctl::pose_to_matrix / angle_tables / svd_solve6 for n cases of 48 doubles (p[6], A[36], b[6]) on the device
+int ndt_ctl_math_device(mrgfe_ctx* ctx, const double* d_in, int n, float* d_M, double* d_tables, double* d_x);
 // dst = T * src (row-major 3x4 float T in device memory)
 int launch_transform_cloud(mrgfe_ctx* ctx, const float4* d_src, float4* d_dst, uint32_t n, const float* d_T12);
 

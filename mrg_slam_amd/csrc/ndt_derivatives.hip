@@ -20,6 +20,7 @@
 // dependent point -> lookup -> record loads, which is what the byte-model roofline in bench.py is held against.
 #include "dev_float.h"
 #include "dev_utils.h"
+#include "ndt_ctl.h"
 #include "ndt_derivatives.h"
 
 namespace mrgfe {
@@ -147,19 +148,16 @@ __device__ __forceinline__ void pair_double(Accum& acc, const double mean[3], co
 #endif
 template <int MODE, int NNB>
 __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2)) void ndt_derivatives_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
-                                                               const NdtEvalDev* __restrict__ evals, double* __restrict__ partials, int ppt,
-                                                               uint32_t spec_part_base)
+                                                               const NdtEvalDev* __restrict__ evals, const uint32_t* __restrict__ plan, uint32_t n_all_pairs,
+                                                               double* __restrict__ partials)
 {
-    const uint32_t   pi = evals[blockIdx.y].order[MODE];  // the blockIdx.y-th pair this variant has work for
-    const NdtPairDev pr = pairs[pi];
-    if (blockIdx.x * static_cast<uint32_t>(kTilePts) * ppt >= pr.n_src) return;  // this launch gives every workgroup ppt tiles
-    const NdtEvalDev& ev = evals[pi];
-    // the f64 Hessian variant also serves the speculative requests attached to mode-0 evaluations; their partial records
-    // go to the second half of the partial buffer
-    const bool spec = (MODE == 2) && ev.mode == 0 && ev.spec != 0;
-    if (!ev.active || (ev.mode != MODE && !spec)) return;
-    const uint32_t part_off = pr.part_off + (spec ? spec_part_base : 0u);
-    const NdtGridDev g = grids[pr.grid];  // by value: the grid parameters live in scalar registers for the whole kernel
+    // the round's plan (ndt_plan_kernel): this variant's busy pairs and the prefix of their work items
+    const NdtPlanHead& head = *reinterpret_cast<const NdtPlanHead*>(plan);
+    const uint32_t n_items = head.n_items[MODE];
+    if (blockIdx.x >= n_items) return;
+    const uint32_t ppt = head.ppt[MODE], n_busy = head.n_pairs[MODE];
+    const uint32_t* __restrict__ pair_of = plan + ndt_plan_pair_off(n_all_pairs, MODE);
+    const uint32_t* __restrict__ item_start = plan + ndt_plan_start_off(n_all_pairs, MODE);
 
     using StageT = typename std::conditional<MODE == 2, double, float>::type;  // precision of the staged point terms
     constexpr int kHRows = (MODE == 1) ? 1 : 15;
@@ -174,6 +172,20 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2
     __shared__ uint32_t s_queue[kTile * NNB];  // (slot << 24) | leaf id
     __shared__ uint32_t s_scan[8];
     __shared__ double   s_red[4][kNdtPartialStride];
+  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {  // (body indented as before the item loop existed)
+    // pair of this item: the last busy pair whose first item is <= item (uniform over the workgroup: scalar loads)
+    uint32_t lo = 0, hi = n_busy;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (item_start[mid] <= item) lo = mid; else hi = mid;
+    }
+    const uint32_t   pi = pair_of[lo];
+    const uint32_t   item_in_pair = item - item_start[lo];
+    const NdtPairDev pr = pairs[pi];
+    const NdtEvalDev& ev = evals[pi];
+    const uint32_t part_off = pr.part_off;
+    const NdtGridDev g = grids[pr.grid];  // by value: the grid parameters live in scalar registers for the whole item
+    __syncthreads();  // the previous item's epilogue has read s_red / the staged tables
     if (threadIdx.x < 12) s_T[threadIdx.x] = ev.T[threadIdx.x];
     if (threadIdx.x >= 64 && threadIdx.x < 64 + 24) (&s_ja[0][0])[threadIdx.x - 64] = (&ev.j_ang[0][0])[threadIdx.x - 64];
     if (threadIdx.x >= 128 && threadIdx.x < 128 + 45) (&s_ha[0][0])[threadIdx.x - 128] = (&ev.h_ang[0][0])[threadIdx.x - 128];
@@ -192,8 +204,8 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2
     for (int k = 0; k < 36; ++k) acc.H[k] = 0;
     uint32_t nb_total = 0;
 
-    const uint32_t base = blockIdx.x * static_cast<uint32_t>(kTilePts) * ppt;
-    const uint32_t last = min(pr.n_src, base + static_cast<uint32_t>(kTilePts) * ppt);  // end of this workgroup's points
+    const uint32_t base = item_in_pair * static_cast<uint32_t>(kTilePts) * ppt;
+    const uint32_t last = min(pr.n_src, base + static_cast<uint32_t>(kTilePts) * ppt);  // end of this item's points
     for (uint32_t tile0 = base; tile0 < last; tile0 += kTile) {
         // ---- phase 1: one lane per point -------------------------------------------------------------------------
         const uint32_t i = tile0 + threadIdx.x;
@@ -352,24 +364,105 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2
         const bool skip = k >= kNdtAccum || (MODE == 1 && k >= 7 && k < kNdtNbIndex) || (MODE == 2 && k < 7);
         double     r = 0.0;
         if (!skip) r = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
-        partials[(size_t)(part_off + blockIdx.x) * kNdtPartialStride + k] = r;
+        partials[(size_t)(part_off + item_in_pair) * kNdtPartialStride + k] = r;
+    }
+  }  // items
+}
+
+// ---- the round's plan -------------------------------------------------------------------------------------------------
+// One workgroup scans the pending requests of all P pairs: per kernel variant the busy pairs (compacted, in pair order), the
+// tiles-per-item of the launch and the exclusive prefix of the pairs' item counts.  Also tells the host how many pairs are
+// still running (pinned memory; the host only uses it to stop enqueueing rounds).
+__global__ __launch_bounds__(256) void ndt_plan_kernel(const NdtPairDev* __restrict__ pairs, const NdtEvalDev* __restrict__ evals, uint32_t P, uint32_t* __restrict__ plan,
+                                                        uint32_t wg_target, uint32_t max_ppt, uint32_t forced_ppt, uint32_t round, NdtRoundInfo* __restrict__ host_info)
+{
+    __shared__ uint32_t s_scan[8];
+    __shared__ uint32_t s_tiles[3], s_ppt[3];
+    if (threadIdx.x < 3) s_tiles[threadIdx.x] = 0;
+    __syncthreads();
+    // pass 1: tiles of 256 points per variant
+    uint32_t my_tiles[3] = {0, 0, 0};
+    for (uint32_t i = threadIdx.x; i < P; i += 256) {
+        const NdtEvalDev& ev = evals[i];
+        if (ev.active) my_tiles[ev.mode] += (pairs[i].n_src + 255u) / 256u;
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const uint32_t t = wave_sum(my_tiles[m]);
+        if (lane_id() == 0 && t) atomicAdd(&s_tiles[m], t);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t ppt = s_tiles[threadIdx.x] / wg_target;
+        ppt = ppt < 1u ? 1u : (ppt > max_ppt ? max_ppt : ppt);
+        s_ppt[threadIdx.x] = forced_ppt ? forced_ppt : ppt;
+    }
+    __syncthreads();
+    // pass 2: compaction and item prefix per variant, 256 pairs at a time
+    uint32_t run_pairs[3] = {0, 0, 0}, run_items[3] = {0, 0, 0}, n_active = 0;
+    for (uint32_t c0 = 0; c0 < P; c0 += 256) {
+        const uint32_t i = c0 + threadIdx.x;
+        int      mode = -1;
+        uint32_t tiles = 0;
+        if (i < P) {
+            const NdtEvalDev& ev = evals[i];
+            if (ev.active) { mode = ev.mode; tiles = (pairs[i].n_src + 255u) / 256u; }
+        }
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const bool     mine = mode == m;
+            const uint32_t items = mine ? (tiles + s_ppt[m] - 1) / s_ppt[m] : 0u;
+            uint32_t tot_pairs, tot_items;
+            const uint32_t k = block_exclusive_scan<256>(mine ? 1u : 0u, s_scan, &tot_pairs);
+            const uint32_t st = block_exclusive_scan<256>(items, s_scan, &tot_items);
+            if (mine) {
+                plan[ndt_plan_pair_off(P, m) + run_pairs[m] + k] = i;
+                plan[ndt_plan_start_off(P, m) + run_pairs[m] + k] = run_items[m] + st;
+            }
+            run_pairs[m] += tot_pairs;
+            run_items[m] += tot_items;
+        }
+    }
+    if (threadIdx.x == 0) {
+        NdtPlanHead h;
+        for (int m = 0; m < 3; ++m) {
+            h.n_pairs[m] = run_pairs[m]; h.n_items[m] = run_items[m]; h.ppt[m] = s_ppt[m];
+            plan[ndt_plan_start_off(P, m) + run_pairs[m]] = run_items[m];
+            n_active += run_pairs[m];
+        }
+        h.n_active = n_active;
+        h.round = round;
+        for (int k = 0; k < 5; ++k) h.pad[k] = 0;
+        *reinterpret_cast<NdtPlanHead*>(plan) = h;
+        if (host_info) {
+            NdtRoundInfo& o = host_info[round];
+            o.n_active = n_active;
+            for (int m = 0; m < 3; ++m) { o.n_pairs[m] = run_pairs[m]; o.n_items[m] = run_items[m]; }
+            __threadfence_system();
+            __hip_atomic_store(&o.tag, round + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
-// fixed-order sum of the block partials of every active pair: 4 interleaved slices, then slice 0..3 in order
-__global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __restrict__ pairs, const NdtEvalDev* __restrict__ evals, const double* __restrict__ partials,
-                                                          double* __restrict__ results, uint32_t spec_part_base, uint32_t spec_result_base, int ppt0, int ppt1, int ppt2)
+// ---- reduce (+ controller step) -----------------------------------------------------------------------------------------
+// One workgroup per pair with a pending request: fixed-order sum of the item partials of its evaluation (4 interleaved
+// slices, then slice 0..3 in order: bitwise reproducible), then
+//   CONTROL = true : the pair's optimiser state (HBM) is staged in LDS, lane 0 resumes the state machine of ndt_ctl.h with the
+//                    44 sums and writes the next request — the batch advances without the host;
+//   CONTROL = false: the sums go to `results` (pinned host memory) for the host-stepped controller.
+template <bool CONTROL>
+__global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __restrict__ pairs, NdtEvalDev* __restrict__ evals, const double* __restrict__ partials,
+                                                          const uint32_t* __restrict__ plan, double* __restrict__ results, NdtCtlState* __restrict__ states)
 {
-    // blockIdx.y == 1: the speculative f64 Hessian records of the pairs that asked for them
-    const bool spec = blockIdx.y == 1;
-    NdtPairDev pr = pairs[blockIdx.x];
+    const NdtPairDev pr = pairs[blockIdx.x];
     const NdtEvalDev& ev = evals[blockIdx.x];
-    if (!ev.active || (spec && !(ev.mode == 0 && ev.spec != 0))) return;
-    if (spec) { pr.part_off += spec_part_base; results += (size_t)spec_result_base * kNdtPartialStride; }
-    // workgroups (= partial records) the derivative launch of this pair's kernel variant used
-    const uint32_t per_wg = 256u * static_cast<uint32_t>(spec || ev.mode == 2 ? ppt2 : (ev.mode == 1 ? ppt1 : ppt0));
-    const uint32_t nblk = (pr.n_src + per_wg - 1) / per_wg;
+    if (!ev.active) return;
+    const NdtPlanHead& head = *reinterpret_cast<const NdtPlanHead*>(plan);
+    // items (= partial records) the derivative launch of this pair's kernel variant used
+    const uint32_t per_item = 256u * head.ppt[ev.mode];
+    const uint32_t nblk = (pr.n_src + per_item - 1) / per_item;
     __shared__ double s[4][kNdtPartialStride];
+    __shared__ double s_r[kNdtPartialStride];
     const int k = threadIdx.x & 63, slice = threadIdx.x >> 6;
     if (k < kNdtPartialStride) {
         // the additions stay in order; eight loads are in flight ahead of them (a straggler round has one pair with 500
@@ -390,8 +483,56 @@ __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __res
     __syncthreads();
     if (threadIdx.x < kNdtPartialStride) {
         const double r = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
-        results[(size_t)blockIdx.x * kNdtPartialStride + threadIdx.x] = r;
+        if (CONTROL) s_r[threadIdx.x] = r;
+        else         results[(size_t)blockIdx.x * kNdtPartialStride + threadIdx.x] = r;
     }
+    if (!CONTROL) return;
+    // stage the state in LDS (coalesced), step it on one lane, write it and the next request back
+    constexpr int kWords = sizeof(NdtCtlState) / 8;
+    static_assert(sizeof(NdtCtlState) % 8 == 0, "state is copied as 8-byte words");
+    __shared__ double s_state[kWords];
+    __shared__ NdtEvalDev s_eval;
+    const double* gs = reinterpret_cast<const double*>(states + blockIdx.x);
+    for (int w = threadIdx.x; w < kWords; w += 256) s_state[w] = gs[w];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        NdtCtlState& st = *reinterpret_cast<NdtCtlState*>(s_state);
+        ctl::on_result(st, s_r);
+        s_eval.active = 0;
+        ctl::fill_eval(st, s_eval);
+    }
+    __syncthreads();
+    double* gd = reinterpret_cast<double*>(states + blockIdx.x);
+    for (int w = threadIdx.x; w < kWords; w += 256) gd[w] = s_state[w];
+    constexpr int kEvalWords = sizeof(NdtEvalDev) / 8;
+    static_assert(sizeof(NdtEvalDev) % 8 == 0, "request record is copied as 8-byte words");
+    const double* se = reinterpret_cast<const double*>(&s_eval);
+    double*       ge = reinterpret_cast<double*>(evals + blockIdx.x);
+    if (s_eval.active) { for (int w = threadIdx.x; w < kEvalWords; w += 256) ge[w] = se[w]; }
+    else if (threadIdx.x == 0) evals[blockIdx.x].active = 0;
+}
+
+// ---- diagnostic: the controller's scalar routines on the device (tests/test_gpu_control.py holds them against the host build
+// of the same source): per case p[6], A[36], b[6] -> pose matrix (16 floats), angle tables (8*3 + 15*3 doubles), solve x[6]
+__global__ __launch_bounds__(64) void ndt_ctl_math_kernel(const double* __restrict__ in, int n, float* __restrict__ M, double* __restrict__ tables, double* __restrict__ x)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const double* c = in + size_t(i) * 48;
+    ctl::pose_to_matrix(c, M + size_t(i) * 16);
+    double j[8][3], h[15][3];
+    ctl::angle_tables(c, j, h);
+    for (int a = 0; a < 8; ++a) for (int b = 0; b < 3; ++b) tables[size_t(i) * 69 + a * 3 + b] = j[a][b];
+    for (int a = 0; a < 15; ++a) for (int b = 0; b < 3; ++b) tables[size_t(i) * 69 + 24 + a * 3 + b] = h[a][b];
+    ctl::svd_solve6(c + 6, c + 42, x + size_t(i) * 6);
+}
+
+int ndt_ctl_math_device(mrgfe_ctx* ctx, const double* d_in, int n, float* d_M, double* d_tables, double* d_x)
+{
+    if (n <= 0) return MRGFE_OK;
+    hipLaunchKernelGGL(ndt_ctl_math_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_in, n, d_M, d_tables, d_x);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
 }
 
 // final_transformation * source -> packed xyzi (the `output` cloud of pcl::Registration::align)
@@ -410,33 +551,40 @@ __global__ __launch_bounds__(256) void transform_cloud_kernel(const float4* __re
 }
 
 template <int MODE>
-static void launch_mode(mrgfe_ctx* ctx, int nnb, dim3 grid, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, double* d_partials, int ppt,
-                        uint32_t spec_part_base)
+static void launch_mode(mrgfe_ctx* ctx, int nnb, uint32_t grid, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const uint32_t* d_plan, uint32_t P,
+                        double* d_partials)
 {
-    if (nnb == 7)       hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 7>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_partials, ppt, spec_part_base);
-    else if (nnb == 1)  hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 1>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_partials, ppt, spec_part_base);
-    else                hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 27>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_partials, ppt, spec_part_base);
+    if (nnb == 7)       hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 7>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
+    else if (nnb == 1)  hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 1>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
+    else                hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 27>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
 }
 
-int ndt_launch_derivatives(mrgfe_ctx* ctx, int mode, int search, uint32_t max_nblk, int npairs, const NdtGridDev* d_grids, const NdtPairDev* d_pairs,
-                           const NdtEvalDev* d_evals, double* d_partials, int ppt, uint32_t spec_part_base)
+int ndt_launch_plan(mrgfe_ctx* ctx, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, uint32_t P, uint32_t* d_plan, uint32_t wg_target, uint32_t max_ppt, uint32_t forced_ppt,
+                    uint32_t round, NdtRoundInfo* h_info)
 {
-    if (npairs == 0 || max_nblk == 0) return MRGFE_OK;
-    const int nnb = (search == MRGFE_DIRECT7) ? 7 : (search == MRGFE_DIRECT1 ? 1 : 27);
-    dim3 grid(max_nblk, npairs);
-    if (mode == 0)      launch_mode<0>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_partials, ppt, spec_part_base);
-    else if (mode == 1) launch_mode<1>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_partials, ppt, spec_part_base);
-    else                launch_mode<2>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_partials, ppt, spec_part_base);
+    hipLaunchKernelGGL(ndt_plan_kernel, dim3(1), dim3(256), 0, ctx->stream, d_pairs, d_evals, P, d_plan, wg_target, max_ppt, forced_ppt, round, h_info);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }
 
-int ndt_launch_reduce(mrgfe_ctx* ctx, int npairs, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const double* d_partials, double* d_results, bool with_spec,
-                      uint32_t spec_part_base, uint32_t spec_result_base, const int ppt[3])
+int ndt_launch_derivatives(mrgfe_ctx* ctx, int mode, int search, uint32_t grid, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals,
+                           const uint32_t* d_plan, uint32_t P, double* d_partials)
 {
-    if (npairs == 0) return MRGFE_OK;
-    hipLaunchKernelGGL(ndt_reduce_kernel, dim3(npairs, with_spec ? 2 : 1), dim3(256), 0, ctx->stream, d_pairs, d_evals, d_partials, d_results, spec_part_base, spec_result_base,
-                       ppt[0], ppt[1], ppt[2]);
+    if (grid == 0 || P == 0) return MRGFE_OK;
+    const int nnb = (search == MRGFE_DIRECT7) ? 7 : (search == MRGFE_DIRECT1 ? 1 : 27);
+    if (mode == 0)      launch_mode<0>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
+    else if (mode == 1) launch_mode<1>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
+    else                launch_mode<2>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
+int ndt_launch_reduce(mrgfe_ctx* ctx, uint32_t P, const NdtPairDev* d_pairs, NdtEvalDev* d_evals, const double* d_partials, const uint32_t* d_plan, double* d_results,
+                      NdtCtlState* d_states)
+{
+    if (P == 0) return MRGFE_OK;
+    if (d_states) hipLaunchKernelGGL((ndt_reduce_kernel<true>), dim3(P), dim3(256), 0, ctx->stream, d_pairs, d_evals, d_partials, d_plan, d_results, d_states);
+    else          hipLaunchKernelGGL((ndt_reduce_kernel<false>), dim3(P), dim3(256), 0, ctx->stream, d_pairs, d_evals, d_partials, d_plan, d_results, d_states);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }

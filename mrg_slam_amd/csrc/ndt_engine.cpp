@@ -4,6 +4,7 @@
 #include "ndt_engine.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <chrono>
@@ -42,12 +43,9 @@ NdtEngine::~NdtEngine()
     if (ctx_) (void)hipSetDevice(ctx_->device);
     cloud_arena_.release();
     grid_arena_.release();
-    for (auto& g : groups_) {
-        if (g.done) (void)hipEventDestroy(g.done);
-        for (auto& pr : g.ev) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
-    }
-    d_grids_.release(); d_pairs_.release(); d_evals_.release(); d_partials_.release(); d_T12_.release(); d_aligned_.release();
-    h_evals_.release(); h_results_.release();
+    for (auto& e : ev_pool_) if (e) (void)hipEventDestroy(e);
+    d_grids_.release(); d_pairs_.release(); d_evals_.release(); d_partials_.release(); d_T12_.release(); d_aligned_.release(); d_states_.release(); d_plan_.release();
+    h_evals_.release(); h_results_.release(); h_states_.release(); h_info_.release();
 }
 
 void NdtEngine::clear()
@@ -341,152 +339,106 @@ int NdtEngine::upload_pairs()
         max_nblk_ = std::max(max_nblk_, d.nblk);
         h_pairs_[i] = d;
     }
-    MRGFE_TRY(d_pairs_.ensure(sizeof(NdtPairDev) * std::max(P, 1)));
-    MRGFE_TRY(d_evals_.ensure(sizeof(NdtEvalDev) * std::max(P, 1)));
+    const size_t P1 = static_cast<size_t>(std::max(P, 1));
+    MRGFE_TRY(d_pairs_.ensure(sizeof(NdtPairDev) * P1));
+    MRGFE_TRY(d_evals_.ensure(sizeof(NdtEvalDev) * P1));
+    MRGFE_TRY(d_states_.ensure(sizeof(NdtCtlState) * P1));
+    MRGFE_TRY(d_plan_.ensure(sizeof(uint32_t) * ndt_plan_words(static_cast<uint32_t>(P1))));
     total_part_blocks_ = part;
-    MRGFE_TRY(d_partials_.ensure(sizeof(double) * kNdtPartialStride * 2 * std::max<uint32_t>(part, 1)));  // second half: speculative Hessians
-    MRGFE_TRY(h_evals_.ensure(sizeof(NdtEvalDev) * std::max(P, 1)));
-    MRGFE_TRY(h_results_.ensure(sizeof(double) * kNdtPartialStride * 2 * std::max(P, 1)));
+    MRGFE_TRY(d_partials_.ensure(sizeof(double) * kNdtPartialStride * std::max<uint32_t>(part, 1)));  // one record per tile: enough for any tiles-per-item
+    MRGFE_TRY(h_evals_.ensure(sizeof(NdtEvalDev) * P1));
+    MRGFE_TRY(h_states_.ensure(sizeof(NdtCtlState) * P1));
+    MRGFE_TRY(h_results_.ensure(sizeof(double) * kNdtPartialStride * P1));
     if (P) MRGFE_HIP_CHECK(hipMemcpyAsync(d_pairs_.p, h_pairs_.data(), sizeof(NdtPairDev) * P, hipMemcpyHostToDevice, ctx_->stream));
     MRGFE_HIP_CHECK(hipStreamSynchronize(ctx_->stream));
     pairs_dirty_ = false;
     return MRGFE_OK;
 }
 
-static void fill_eval(NdtEvalDev& e, const NdtRequest& r, const NdtController& c, int search, bool active)
-{
-    for (int row = 0; row < 3; ++row) for (int col = 0; col < 4; ++col) e.T[row * 4 + col] = r.T[row * 4 + col];
-    for (int a = 0; a < 8; ++a) for (int b = 0; b < 3; ++b) { e.j_ang_d[a][b] = r.j_ang[a][b]; e.j_ang[a][b] = static_cast<float>(r.j_ang[a][b]); }
-    for (int a = 0; a < 15; ++a) for (int b = 0; b < 3; ++b) { e.h_ang_d[a][b] = r.h_ang[a][b]; e.h_ang[a][b] = static_cast<float>(r.h_ang[a][b]); }
-    e.gauss_d1 = c.gauss_d1();
-    e.gauss_d2 = c.gauss_d2();
-    e.mode = r.mode;
-    e.active = active ? 1 : 0;
-    e.search = search;
-    e.spec = r.spec_hessian ? 1 : 0;
-}
-
 // ---- rounds --------------------------------------------------------------------------------------------------------
-// The pairs of a batch are split into (up to) two contiguous groups that take turns on the context stream: while the
-// host steps the controllers of one group (6x6 solves, line-search logic) and uploads its next requests, the other
-// group's derivative kernels are already queued, so the GPU does not idle during host turnarounds.  Both groups use
-// the same stream: kernels never overlap each other and the per-launch HIP-event timings stay clean.
-// batches at least this large are split into two alternating groups (each half still fills the GPU)
+// A round = plan -> one derivative launch per kernel variant -> reduce (+ controller step).  Two ways to drive it:
+//   device control (default for batches): the optimiser state of every pair lives in HBM and ndt_reduce_kernel<true> steps it,
+//       so the host only ENQUEUES rounds — a few ahead of the GPU — and watches the count of running pairs the plan kernel
+//       publishes in pinned memory to know when to stop.  No host round trip inside a batch.
+//   host control (single registrations, MRGFE_HOST_CONTROL=1): the reduced sums come back through pinned memory and the host
+//       steps the same state machine (ndt_ctl.h), one synchronisation per round.
 // HIP events around the derivative launches (what mrgfe_*_kernel_stats reports): 2 = every variant (default), 1 = only the
 // dominant score+gradient+Hessian variant, 0 = none.  MRGFE_KERNEL_TIMING overrides.
 static int timing_level() { static const int v = [] { const char* e = std::getenv("MRGFE_KERNEL_TIMING"); return e ? std::atoi(e) : 2; }(); return v; }
 
 constexpr int kHostParallelMinPairs = 48;  // below this the controller steps of a round run on the calling thread
 
-static int pipeline_min_pairs() { const char* e = std::getenv("MRGFE_PIPELINE_MIN_PAIRS"); return e ? std::atoi(e) : 1 << 30; }  // measured on MI355X: alternating half-batches lose more to smaller launches than they hide
-
-// Tiles of 256 points per workgroup for a launch over `pts` source points: enough workgroups to fill the CUs several
-// times over, few enough that the 384-byte block reduction amortises.  Chosen per launch: the late rounds of a batch
-// have a few stragglers left, and those want one tile per workgroup to spread over the whole chip.
-int NdtEngine::tiles_per_workgroup(uint64_t pts) const
+// -1: automatic (single registrations are stepped by the host, batches on the device); 0 / 1 force device / host control
+static std::atomic<int> g_host_control{-2};  // -2: not read yet
+static int host_control_mode()
 {
-    if (forced_ppt_ > 0) return forced_ppt_;
-    static const int per_cu = [] { const char* e = std::getenv("MRGFE_WG_PER_CU"); return e ? std::max(1, std::atoi(e)) : 4; }();
-    static const int max_ppt = [] { const char* e = std::getenv("MRGFE_MAX_PPT"); return e ? std::max(1, std::atoi(e)) : 8; }();
-    const uint64_t target_blocks = uint64_t(ctx_->cu_count) * per_cu;
-    return static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(pts / (256 * target_blocks), max_ppt)));
+    int v = g_host_control.load(std::memory_order_relaxed);
+    if (v == -2) { const char* e = std::getenv("MRGFE_HOST_CONTROL"); v = e ? std::atoi(e) : -1; g_host_control.store(v, std::memory_order_relaxed); }
+    return v;
+}
+void ndt_set_host_control(int mode) { g_host_control.store(mode < -1 || mode > 1 ? -1 : mode, std::memory_order_relaxed); }
+static int env_int(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; }
+
+// grid of a derivative launch: a few workgroups per resident slot; they walk the plan's items (item += gridDim.x)
+uint32_t NdtEngine::derivative_grid(int mode) const
+{
+    static const int per_slot = std::max(1, env_int("MRGFE_GRID_PER_SLOT", 4));
+    const int slots_per_cu = (mode == 0 && prm_.search != MRGFE_KDTREE && prm_.search != MRGFE_DIRECT26) ? 3 : 2;  // __launch_bounds__ of the variants
+    return static_cast<uint32_t>(ctx_->cu_count * slots_per_cu * per_slot);
 }
 
-int NdtEngine::launch_group(RoundGroup& g)
+int NdtEngine::ensure_events(size_t rounds)
 {
-    NdtEvalDev* he = h_evals_.as<NdtEvalDev>();
-    g.modes[0] = g.modes[1] = g.modes[2] = false;
-    int active = 0;
-    host_parallel_for(g.count, kHostParallelMinPairs, [&](int b, int e) {
-        for (int i = g.first + b; i < g.first + e; ++i) {
-            NdtController& c = pairs_[i].ctl;
-            if (c.done()) he[i].active = 0;
-            else          fill_eval(he[i], c.request(), c, prm_.search, true);
-        }
-    });
-    g.any_spec = false;
-    g.n_mode[0] = g.n_mode[1] = g.n_mode[2] = 0;
-    uint64_t mode_pts[3] = {0, 0, 0};
-    uint32_t mode_max_n[3] = {0, 0, 0};
-    for (int i = g.first; i < g.first + g.count; ++i) {
-        const NdtController& c = pairs_[i].ctl;
-        if (c.done()) continue;
-        const int  m = c.request().mode;
-        const bool spec = m == 0 && c.request().spec_hessian;
-        he[g.first + g.n_mode[m]++].order[m] = static_cast<uint32_t>(i - g.first);
-        mode_pts[m] += pairs_[i].n;
-        mode_max_n[m] = std::max(mode_max_n[m], pairs_[i].n);
-        if (spec) {
-            he[g.first + g.n_mode[2]++].order[2] = static_cast<uint32_t>(i - g.first);
-            mode_pts[2] += pairs_[i].n;
-            mode_max_n[2] = std::max(mode_max_n[2], pairs_[i].n);
-            g.any_spec = true;
-        }
-        ++active;
+    while (ev_pool_.size() < rounds * 6) {
+        hipEvent_t e = nullptr;
+        MRGFE_HIP_CHECK(hipEventCreate(&e));
+        ev_pool_.push_back(e);
     }
-    for (int m = 0; m < 3; ++m) {
-        g.modes[m] = g.n_mode[m] > 0;
-        g.ppt[m] = tiles_per_workgroup(mode_pts[m]);
-        g.nblk[m] = (mode_max_n[m] + 256u * g.ppt[m] - 1) / (256u * g.ppt[m]);
-    }
-    g.inflight = false;
-    if (!active) return MRGFE_OK;
-    hipStream_t st = ctx_->stream;
-    NdtEvalDev*       d_ev = d_evals_.as<NdtEvalDev>() + g.first;
-    const NdtPairDev* d_pr = d_pairs_.as<NdtPairDev>() + g.first;
-    // the reduction kernel writes the 384-byte result records straight into pinned host memory (device-visible): no
-    // device-to-host copy command, and its queue gap, in any of the ~20 rounds of a batch
-    double*           d_res = h_results_.as<double>() + size_t(g.first) * kNdtPartialStride;
-    MRGFE_HIP_CHECK(hipMemcpyAsync(d_ev, he + g.first, sizeof(NdtEvalDev) * g.count, hipMemcpyHostToDevice, st));
-    // every kernel variant (mode) is bracketed by its own HIP events on the launch stream
-    for (int m = 0; m < 3; ++m)
-        if (g.modes[m]) {
-            if (timing_level() > (m == 0 ? 0 : 1)) MRGFE_HIP_CHECK(hipEventRecord(g.ev[m][0], st));
-            MRGFE_TRY(ndt_launch_derivatives(ctx_, m, prm_.search, g.nblk[m], g.n_mode[m], d_grids_.as<NdtGridDev>(), d_pr, d_ev, d_partials_.as<double>(), g.ppt[m], total_part_blocks_));
-            if (timing_level() > (m == 0 ? 0 : 1)) MRGFE_HIP_CHECK(hipEventRecord(g.ev[m][1], st));
-        }
-    const uint32_t P = static_cast<uint32_t>(n_pairs());
-    MRGFE_TRY(ndt_launch_reduce(ctx_, g.count, d_pr, d_ev, d_partials_.as<double>(), d_res, g.any_spec, total_part_blocks_, P, g.ppt));
-    MRGFE_HIP_CHECK(hipEventRecord(g.done, st));
-    g.inflight = true;
     return MRGFE_OK;
 }
 
-int NdtEngine::finish_group(RoundGroup& g)
+int NdtEngine::enqueue_round(uint32_t round, bool device_control, const bool want_mode[3], NdtRoundInfo* h_info)
 {
-    MRGFE_HIP_CHECK(hipEventSynchronize(g.done));
-    g.inflight = false;
-    for (int m = 0; m < 3; ++m)
-        if (g.modes[m] && timing_level() > (m == 0 ? 0 : 1)) {
+    hipStream_t st = ctx_->stream;
+    const uint32_t P = static_cast<uint32_t>(n_pairs());
+    static const uint32_t per_cu = static_cast<uint32_t>(std::max(1, env_int("MRGFE_WG_PER_CU", 4)));
+    static const uint32_t max_ppt = static_cast<uint32_t>(std::max(1, env_int("MRGFE_MAX_PPT", 8)));
+    MRGFE_TRY(ndt_launch_plan(ctx_, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), P, d_plan_.as<uint32_t>(), static_cast<uint32_t>(ctx_->cu_count) * per_cu, max_ppt,
+                              static_cast<uint32_t>(forced_ppt_), round, h_info));
+    for (int m = 0; m < 3; ++m) {
+        if (!want_mode[m]) continue;
+        const bool timed = timing_level() > (m == 0 ? 0 : 1);
+        if (timed) MRGFE_HIP_CHECK(hipEventRecord(ev_pool_[size_t(round) * 6 + m * 2], st));
+        MRGFE_TRY(ndt_launch_derivatives(ctx_, m, prm_.search, derivative_grid(m), d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(),
+                                         d_plan_.as<uint32_t>(), P, d_partials_.as<double>()));
+        if (timed) MRGFE_HIP_CHECK(hipEventRecord(ev_pool_[size_t(round) * 6 + m * 2 + 1], st));
+    }
+    // host control: the 384-byte result records go straight into pinned host memory (no device-to-host copy command)
+    MRGFE_TRY(ndt_launch_reduce(ctx_, P, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_partials_.as<double>(), d_plan_.as<uint32_t>(), h_results_.as<double>(),
+                                device_control ? d_states_.as<NdtCtlState>() : nullptr));
+    return MRGFE_OK;
+}
+
+void NdtEngine::account(const std::vector<NdtRoundInfo>& info, size_t rounds)
+{
+    for (size_t r = 0; r < rounds; ++r)
+        for (int m = 0; m < 3; ++m) {
+            if (info[r].n_pairs[m] == 0 || timing_level() <= (m == 0 ? 0 : 1)) continue;
             float ms = 0;
-            MRGFE_HIP_CHECK(hipEventElapsedTime(&ms, g.ev[m][0], g.ev[m][1]));
+            if (hipEventElapsedTime(&ms, ev_pool_[r * 6 + m * 2], ev_pool_[r * 6 + m * 2 + 1]) != hipSuccess) continue;
             mode_ms[m] += ms;
             mode_launches[m] += 1;
         }
-    const double* hr = h_results_.as<double>();
     const int probes = prm_.search == MRGFE_DIRECT7 ? 7 : (prm_.search == MRGFE_DIRECT1 ? 1 : 27);
-    for (int i = g.first; i < g.first + g.count; ++i) {
-        const NdtController& c = pairs_[i].ctl;
-        if (c.done()) continue;
-        const double* r = hr + size_t(i) * kNdtPartialStride;
-        // SURVEY.md §8(d) byte model: point (16) + probes (8 each) + 48 per valid neighbour voxel
-        const double bytes = double(pairs_[i].n) * (16.0 + 8.0 * probes) + r[kNdtNbIndex] * 48.0;
-        mode_alg_bytes[c.request().mode] += bytes;
-        mode_points[c.request().mode] += double(pairs_[i].n);
-        mode_neighbours[c.request().mode] += r[kNdtNbIndex];
-        if (c.request().mode == 0 && c.request().spec_hessian) mode_alg_bytes[2] += bytes;  // the speculative f64 pass reads the same data
-    }
-    const size_t spec_base = size_t(n_pairs()) * kNdtPartialStride;
-    // controller steps are independent per pair: spread them over the host worker threads for large batches
-    host_parallel_for(g.count, kHostParallelMinPairs, [&](int b, int e) {
-        for (int i = g.first + b; i < g.first + e; ++i) {
-            NdtController& c = pairs_[i].ctl;
-            if (c.done()) continue;
-            const bool spec = c.request().mode == 0 && c.request().spec_hessian;
-            c.on_result(hr + size_t(i) * kNdtPartialStride, spec ? hr + spec_base + size_t(i) * kNdtPartialStride : nullptr);
+    for (const auto& p : pairs_) {
+        const NdtCtlState& s = p.ctl.state();
+        for (int m = 0; m < 3; ++m) {
+            // SURVEY.md §8(d) byte model: point (16) + probes (8 each) + 48 per valid neighbour voxel
+            mode_alg_bytes[m] += s.acct_points[m] * (16.0 + 8.0 * probes) + s.acct_nb[m] * 48.0;
+            mode_points[m] += s.acct_points[m];
+            mode_neighbours[m] += s.acct_nb[m];
         }
-    });
-    return MRGFE_OK;
+    }
 }
 
 int NdtEngine::align_all()
@@ -495,66 +447,114 @@ int NdtEngine::align_all()
     MRGFE_TRY(build_targets());
     if (pairs_dirty_) MRGFE_TRY(upload_pairs());
     for (int m = 0; m < 3; ++m) { mode_ms[m] = 0; mode_launches[m] = 0; mode_alg_bytes[m] = 0; mode_points[m] = 0; mode_neighbours[m] = 0; }
-    for (auto& p : pairs_) {
-        p.ctl.start(prm_, p.guess, p.n);
-        if (targets_[p.target].status != MRGFE_OK && !p.ctl.done()) p.ctl.abort_no_target();
-    }
+    rounds_ = 0;
     const int P = n_pairs();
     if (P == 0) return MRGFE_OK;
-    // large batches: keep the host workers spinning between rounds (see host_parallel_for)
+    NdtEvalDev*  he = h_evals_.as<NdtEvalDev>();
+    NdtCtlState* hs = h_states_.as<NdtCtlState>();
+    int running = 0;
+    for (int i = 0; i < P; ++i) {
+        NdtPairInfo& p = pairs_[i];
+        p.ctl.start(prm_, p.guess, p.n);
+        if (targets_[p.target].status != MRGFE_OK && !p.ctl.done()) p.ctl.abort_no_target();
+        he[i].active = 0;
+        p.ctl.fill_eval(he[i]);
+        running += p.ctl.done() ? 0 : 1;
+    }
+    if (!running) return MRGFE_OK;
+    // every controller needs at most (max_iterations + 2) * (max line-search trials + 2) evaluations
+    const size_t round_cap = size_t(prm_.max_iterations + 3) * 13 + 8;
+    const int    hc = host_control_mode();
+    const bool   device_control = hc == 0 || (hc < 0 && P > 1);
+    hipStream_t  st = ctx_->stream;
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));
+    static const bool trace = std::getenv("MRGFE_TRACE") != nullptr;  // per-round host timings on stderr
+    std::vector<NdtRoundInfo> info;
+
+    if (device_control) {
+        static const size_t lookahead = static_cast<size_t>(std::max(1, env_int("MRGFE_LOOKAHEAD", 3)));
+        for (int i = 0; i < P; ++i) hs[i] = pairs_[i].ctl.state();
+        MRGFE_HIP_CHECK(hipMemcpyAsync(d_states_.p, hs, sizeof(NdtCtlState) * P, hipMemcpyHostToDevice, st));
+        MRGFE_TRY(h_info_.ensure(sizeof(NdtRoundInfo) * (round_cap + lookahead + 2)));
+        volatile NdtRoundInfo* hi = h_info_.as<NdtRoundInfo>();
+        const bool all_modes[3] = {true, true, true};
+        size_t enq = 0, seen = 0;  // rounds enqueued / rounds whose plan the host has seen
+        bool   finished = false;
+        while (!finished) {
+            // keep a few rounds queued ahead of the GPU; beyond that wait for the oldest unseen plan
+            if (enq - seen >= lookahead || enq >= round_cap) {
+                while (__atomic_load_n(&hi[seen].tag, __ATOMIC_ACQUIRE) != static_cast<uint32_t>(seen + 1)) {
+                    if (hipStreamQuery(st) != hipErrorNotReady && __atomic_load_n(&hi[seen].tag, __ATOMIC_ACQUIRE) != static_cast<uint32_t>(seen + 1)) {
+                        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+                        if (hi[seen].tag != static_cast<uint32_t>(seen + 1)) { set_error("NDT round %zu never reported", seen); return MRGFE_ERR_HIP; }
+                    }
+                }
+                if (hi[seen].n_active == 0) finished = true;
+                ++seen;
+                if (seen >= round_cap && !finished) break;
+                continue;
+            }
+            MRGFE_TRY(ensure_events(enq + 1));
+            const_cast<NdtRoundInfo*>(hi)[enq].tag = 0;
+            MRGFE_TRY(enqueue_round(static_cast<uint32_t>(enq), true, all_modes, const_cast<NdtRoundInfo*>(hi)));
+            ++enq;
+        }
+        MRGFE_HIP_CHECK(hipMemcpyAsync(hs, d_states_.p, sizeof(NdtCtlState) * P, hipMemcpyDeviceToHost, st));
+        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+        if (!finished) { set_error("NDT alignment did not terminate within %zu rounds", round_cap); return MRGFE_ERR_STATE; }
+        for (int i = 0; i < P; ++i) pairs_[i].ctl.adopt(hs[i]);
+        const size_t rounds = seen - 1;  // the last plan seen found nothing left to do
+        info.resize(rounds);
+        for (size_t r = 0; r < rounds; ++r) info[r] = const_cast<NdtRoundInfo*>(hi)[r];
+        rounds_ = static_cast<int>(rounds);
+        if (trace) std::fprintf(stderr, "[mrgfe] device control: %zu rounds, %zu enqueued\n", rounds, enq);
+        account(info, rounds);
+        return MRGFE_OK;
+    }
+
+    // ---- host control --------------------------------------------------------------------------------------------------------
     struct HotGuard {
         bool on;
         explicit HotGuard(bool o) : on(o) { if (on) host_parallel_hot(true); }
         ~HotGuard() { if (on) host_parallel_hot(false); }
-    } hot_guard(P >= kHostParallelMinPairs);
-    // groups: two halves of (roughly) equal point count once the batch is large enough to keep the GPU busy with one
-    const int n_groups = P >= pipeline_min_pairs() ? 2 : 1;
-    if (groups_.size() < 2) {
-        groups_.resize(2);
-        for (auto& g : groups_) {
-            MRGFE_HIP_CHECK(hipEventCreate(&g.done));
-            for (int m = 0; m < 3; ++m) for (int k = 0; k < 2; ++k) MRGFE_HIP_CHECK(hipEventCreate(&g.ev[m][k]));
+    } hot_guard(P >= kHostParallelMinPairs);  // large batches: keep the host workers spinning between rounds (see host_parallel_for)
+    const double* hr = h_results_.as<double>();
+    for (size_t round = 0; round < round_cap; ++round) {
+        bool want[3] = {false, false, false};
+        NdtRoundInfo ri{};
+        for (int i = 0; i < P; ++i) {
+            const NdtController& c = pairs_[i].ctl;
+            if (c.done()) continue;
+            want[c.request_mode()] = true;
+            ri.n_pairs[c.request_mode()]++;
+            ri.n_active++;
         }
-    }
-    int split = P;
-    if (n_groups == 2) {
-        uint64_t total = 0, run = 0;
-        for (auto& p : pairs_) total += p.n;
-        split = 0;
-        while (split < P - 1 && (run + pairs_[split].n) * 2 <= total + pairs_[split].n) run += pairs_[split++].n;
-        split = std::max(1, std::min(split, P - 1));
-    }
-    for (int k = 0; k < 2; ++k) {
-        RoundGroup& g = groups_[k];
-        g.first = k == 0 ? 0 : split;
-        g.count = k == 0 ? split : P - split;
-        g.inflight = false;
-    }
-    // every controller needs at most (max_iterations + 2) * (max line-search trials + 2) evaluations
-    const int round_cap = (prm_.max_iterations + 3) * 13 + 8;
-    static const bool trace = std::getenv("MRGFE_TRACE") != nullptr;  // per-round host timings on stderr
-    for (int k = 0; k < n_groups; ++k) MRGFE_TRY(launch_group(groups_[k]));
-    for (int round = 0; round < round_cap; ++round) {
-        bool any = false;
-        for (int k = 0; k < n_groups; ++k) {
-            RoundGroup& g = groups_[k];
-            if (!g.inflight) continue;
-            any = true;
-            const auto t0 = std::chrono::steady_clock::now();
-            MRGFE_HIP_CHECK(hipEventSynchronize(g.done));
-            const auto t1 = std::chrono::steady_clock::now();
-            MRGFE_TRY(finish_group(g));
-            const auto t2 = std::chrono::steady_clock::now();
-            MRGFE_TRY(launch_group(g));  // no-op when every pair of the group is done
-            const auto t3 = std::chrono::steady_clock::now();
-            if (trace) std::fprintf(stderr, "[mrgfe round %d] wait %.0f us, finish %.0f us, launch %.0f us, busy pairs %d/%d/%d\n", round,
-                                    std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(),
-                                    std::chrono::duration<double, std::micro>(t3 - t2).count(), g.n_mode[0], g.n_mode[1], g.n_mode[2]);
+        if (!ri.n_active) {
+            rounds_ = static_cast<int>(round);
+            account(info, info.size());
+            return MRGFE_OK;
         }
-        if (!any) return MRGFE_OK;
+        info.push_back(ri);
+        const auto t0 = std::chrono::steady_clock::now();
+        MRGFE_TRY(ensure_events(round + 1));
+        if (round) MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));
+        MRGFE_TRY(enqueue_round(static_cast<uint32_t>(round), false, want, nullptr));
+        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+        const auto t1 = std::chrono::steady_clock::now();
+        // controller steps are independent per pair: spread them over the host worker threads for large batches
+        host_parallel_for(P, kHostParallelMinPairs, [&](int b, int e) {
+            for (int i = b; i < e; ++i) {
+                NdtController& c = pairs_[i].ctl;
+                if (c.done()) continue;
+                c.on_result(hr + size_t(i) * kNdtPartialStride);
+                he[i].active = 0;
+                c.fill_eval(he[i]);
+            }
+        });
+        if (trace) std::fprintf(stderr, "[mrgfe round %zu] gpu %.0f us, host %.0f us, busy pairs %u/%u/%u\n", round, std::chrono::duration<double, std::micro>(t1 - t0).count(),
+                                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count(), ri.n_pairs[0], ri.n_pairs[1], ri.n_pairs[2]);
     }
-    MRGFE_HIP_CHECK(hipStreamSynchronize(ctx_->stream));
-    set_error("NDT alignment did not terminate within %d rounds", round_cap);
+    set_error("NDT alignment did not terminate within %zu rounds", round_cap);
     return MRGFE_ERR_STATE;
 }
 
@@ -569,21 +569,23 @@ int NdtEngine::evaluate(int pair, const float T[16], const double p[6], int mode
     const int P = n_pairs();
     NdtController tmp;
     tmp.start(prm_, T, pairs_[pair].n);  // gauss constants
-    NdtRequest r;
-    r.mode = mode;
-    std::memcpy(r.T, T, sizeof(r.T));
-    std::memcpy(r.p, p, sizeof(r.p));
-    NdtController::angle_tables(p, r.j_ang, r.h_ang);
+    NdtCtlState s = tmp.state();
+    std::memcpy(s.final_, T, sizeof(s.final_));
+    s.phase = NDT_INIT;
+    s.req_mode = mode;
+    std::memcpy(s.req_p, p, sizeof(s.req_p));
     NdtEvalDev* he = h_evals_.as<NdtEvalDev>();
     for (int i = 0; i < P; ++i) he[i].active = 0;
-    fill_eval(he[pair], r, tmp, prm_.search, true);
-    he[0].order[mode] = static_cast<uint32_t>(pair);
+    ctl::fill_eval(s, he[pair]);
     hipStream_t st = ctx_->stream;
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));
-    const int ppt1[3] = {1, 1, 1};
-    MRGFE_TRY(ndt_launch_derivatives(ctx_, mode, prm_.search, h_pairs_[pair].nblk, 1, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(),
-                                     d_partials_.as<double>(), 1, total_part_blocks_));
-    MRGFE_TRY(ndt_launch_reduce(ctx_, P, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_partials_.as<double>(), h_results_.as<double>(), false, 0, 0, ppt1));
+    MRGFE_TRY(ensure_events(1));
+    bool want[3] = {mode == 0, mode == 1, mode == 2};
+    const int keep = forced_ppt_;
+    forced_ppt_ = 1;
+    const int rc = enqueue_round(0, false, want, nullptr);
+    forced_ppt_ = keep;
+    MRGFE_TRY(rc);
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
     const double* res = h_results_.as<double>() + size_t(pair) * kNdtPartialStride;
     *score = res[0];

@@ -30,6 +30,9 @@ struct NdtPairInfo {
     NdtController ctl;
 };
 
+// who steps the optimiser of the following alignments: -1 automatic (default; MRGFE_HOST_CONTROL overrides), 0 device, 1 host
+void ndt_set_host_control(int mode);
+
 class NdtEngine {
    public:
     NdtEngine(mrgfe_ctx* ctx, const NdtParams& prm) : ctx_(ctx), prm_(prm) {}
@@ -77,6 +80,7 @@ class NdtEngine {
     const NdtParams& params() const { return prm_; }
     void set_force_hash(bool f) { force_hash_ = f; }  // tests: exercise the hashed lookup on small grids
     mrgfe_ctx* ctx() const { return ctx_; }
+    int rounds() const { return rounds_; }  // rounds of the last align_all()
 
    private:
     mrgfe_ctx* ctx_;
@@ -92,7 +96,6 @@ class NdtEngine {
     bool   pairs_dirty_ = true;
     bool   force_hash_ = false;
     int    forced_ppt_ = 0;  // MRGFE_PPT tuning hook (0: chosen per launch)
-    int    tiles_per_workgroup(uint64_t pts) const;
     uint32_t max_nblk_ = 0;
     uint32_t total_part_blocks_ = 0;
     std::vector<NdtPairDev> h_pairs_;
@@ -100,22 +103,16 @@ class NdtEngine {
     struct LeafArrays { int32_t* keys; int32_t* nr_points; NdtLeafRec* leaves; double* icov64; };
     std::vector<LeafArrays> leaf_arrays_;
 
-    // a contiguous range of pairs whose rounds are launched and collected together (see align_all)
-    struct RoundGroup {
-        int        first = 0, count = 0;
-        int        ppt[3] = {1, 1, 1};   // tiles per workgroup of this round's launch of each variant
-        uint32_t   nblk[3] = {0, 0, 0};  // grid.x of each launch
-        bool       inflight = false;
-        bool       modes[3] = {false, false, false};
-        int        n_mode[3] = {0, 0, 0};  // pairs each kernel variant has work for this round
-        bool       any_spec = false;
-        hipEvent_t done = nullptr;
-        hipEvent_t ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-    };
-    std::vector<RoundGroup> groups_;
+    // rounds (see align_all)
+    DevBuf d_states_, d_plan_;            // NdtCtlState[P] (device control), the round's plan
+    PinBuf h_states_, h_info_;            // staging of the states, NdtRoundInfo per round (written by the plan kernel)
+    std::vector<hipEvent_t> ev_pool_;     // [round][variant][begin, end]
+    int    rounds_ = 0;
     int upload_pairs();
-    int launch_group(RoundGroup& g);
-    int finish_group(RoundGroup& g);
+    int ensure_events(size_t rounds);
+    uint32_t derivative_grid(int mode) const;
+    int enqueue_round(uint32_t round, bool device_control, const bool want_mode[3], NdtRoundInfo* h_info);
+    void account(const std::vector<NdtRoundInfo>& info, size_t rounds);
 };
 
 }  // namespace mrgfe

@@ -69,7 +69,8 @@ struct NdtPairDev {
     uint32_t      nblk;      // block-partial records reserved for this pair: ceil(n_src / 256), the workgroups of a launch with one tile per workgroup
 };
 
-// per-evaluation part, rewritten by the host controller before every launch
+// per-evaluation part: the pending request of one alignment, written by its controller step (ctl::fill_eval in ndt_ctl.h —
+// on the device by ndt_reduce_control_kernel, or by the host in the host-stepped path) and read by the derivative kernels
 struct NdtEvalDev {
     float    T[12];        // row-major 3x4 of final_transformation_ (pcl::transformPointCloud operand)
     float    j_ang[8][3];  // computeAngleDerivatives rows a..h (double products cast to float)
@@ -78,14 +79,38 @@ struct NdtEvalDev {
     double   h_ang_d[15][3];
     double   gauss_d1, gauss_d2;
     int32_t  mode;         // 0: score+grad+hess (float path), 1: score+grad, 2: hessian only (double path)
-    int32_t  active;       // 0: this pair is finished or waiting, its workgroups exit immediately
+    int32_t  active;       // 0: this pair is finished, no kernel touches it
     int32_t  search;       // mrgfe_ndt_search
-    int32_t  spec;         // 1 with mode 0: also run the f64 Hessian pass at this pose (speculative computeHessian)
-    // launch compaction: entry k of the array names the k-th pair (index into the same array) that kernel variant m has
-    // work for this round, so a variant's grid has one y-slice per busy pair instead of one per pair of the batch
-    // (dispatching tens of thousands of workgroups that exit at once costs ~100 us per launch on MI355X)
-    uint32_t order[3];
-    uint32_t pad;
+    int32_t  pad;
+};
+
+// Plan of one round, built on the device by ndt_plan_kernel from the pending requests: which pairs each kernel variant has
+// work for and how that work is cut into items of `ppt` tiles (256 points each).  A derivative launch has a FIXED grid; its
+// workgroups walk the items of their variant (item = blockIdx.x, += gridDim.x), so the host needs to know neither how many
+// pairs are still running nor which variant they want: dispatching one y-slice per pair of the batch instead would cost
+// ~100 us per launch in workgroups that exit at once (measured on MI355X), and asking the host would cost a round trip.
+// Layout (uint32 words): NdtPlanHead (16 words), then for m = 0..2: pair_of[m][P] | item_start[m][P + 1].
+struct NdtPlanHead {
+    uint32_t n_pairs[3];   // busy pairs per variant
+    uint32_t n_items[3];   // work items per variant
+    uint32_t ppt[3];       // tiles per item: clamp(tiles of the variant / (4 * CUs), 1, 8) — full batches amortise the 44 wave
+                           // reductions of an item's epilogue over 8 tiles, a lone straggler spreads over the whole chip
+    uint32_t n_active;     // pairs still running
+    uint32_t round;
+    uint32_t pad[5];
+};
+constexpr uint32_t kNdtPlanHeadWords = 16;
+static_assert(sizeof(NdtPlanHead) == 4 * kNdtPlanHeadWords, "plan head is 16 words");
+__host__ __device__ inline size_t   ndt_plan_words(uint32_t P) { return kNdtPlanHeadWords + 3 * (2 * size_t(P) + 1); }
+__host__ __device__ inline uint32_t ndt_plan_pair_off(uint32_t P, int m) { return kNdtPlanHeadWords + uint32_t(m) * (2 * P + 1); }
+__host__ __device__ inline uint32_t ndt_plan_start_off(uint32_t P, int m) { return ndt_plan_pair_off(P, m) + P; }
+
+// what the plan kernel tells the host about a round (pinned host memory, polled: the host only decides when to stop enqueueing)
+struct NdtRoundInfo {
+    uint32_t tag;          // round number + 1, written last
+    uint32_t n_active;
+    uint32_t n_pairs[3];
+    uint32_t n_items[3];
 };
 
 // block partial / final result of one evaluation: score, gradient(6), full 6x6 Hessian(36, row-major), neighbour count.
