@@ -270,12 +270,15 @@ def main():
         for i, (a, _, _, _) in enumerate(loop_pairs):
             groups.setdefault(a, []).append(i)
 
+        tpos = {a: k for k, a in enumerate(my_targets)}
+        shard_args = ([l_dev[a].data_ptr() for a in my_targets], [len(l_host[a]) for a in my_targets], np.array([tpos[loop_pairs[i][0]] for i in mine], dtype=np.int32),
+                      [l_dev[loop_pairs[i][1]].data_ptr() for i in mine], [len(l_host[loop_pairs[i][1]]) for i in mine],
+                      np.stack([loop_pairs[i][2] for i in mine]) if len(mine) else np.zeros((0, 4, 4)))
+
         def step():
             bm.clear()
-            tix = {a: bm.add_target_device(l_dev[a].data_ptr(), len(l_host[a])) for a in my_targets}
-            for i in mine:
-                a, b, guess, _ = loop_pairs[i]
-                bm.add_pair_device(tix[a], l_dev[b].data_ptr(), len(l_host[b]), guess)
+            if len(mine):
+                bm.add_device(*shard_args)
             local = bm.align(float("inf"))  # getFitnessScore(fitness_score_max_range = .inf), config/mrg_slam.yaml:172
             local["pair_id"] = mine.astype(np.int32)
             rec = all_gather_records(local, per) if world > 1 else local
@@ -328,11 +331,13 @@ def main():
     launched = np.zeros(2)       # (source points, valid point-voxel pairs) of the evaluations actually launched
     counters = {"evals": 0, "iters": 0, "on": False}
 
+    # one setInputTarget per alignment: every pair has its own target entry
+    add_args = ([dev[p[0]].data_ptr() for p in pairs], [len(scans[p[0]]) for p in pairs], np.arange(args.batch, dtype=np.int32),
+                [dev[p[1]].data_ptr() for p in pairs], [len(scans[p[1]]) for p in pairs], np.stack([p[2] for p in pairs]))
+
     def step():
         bm.clear()
-        for (ti, si, guess, _, _) in pairs:
-            t = bm.add_target_device(dev[ti].data_ptr(), len(scans[ti]))  # one setInputTarget per alignment
-            bm.add_pair_device(t, dev[si].data_ptr(), len(scans[si]), guess)
+        bm.add_device(*add_args)
         res = bm.align()
         if world > 1:  # pose / Hessian record gather over RCCL
             res["pair_id"] = np.arange(args.batch, dtype=np.int32)

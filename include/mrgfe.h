@@ -269,6 +269,11 @@ int  mrgfe_batch_add_target_device(mrgfe_batch* b, const void* d_xyzi, size_t n)
 /* returns the pair index (>= 0) or an error (< 0) */
 int  mrgfe_batch_add_pair(mrgfe_batch* b, int target_index, const float* src_xyzi, size_t n, size_t stride_bytes, const float guess[16]);
 int  mrgfe_batch_add_pair_device(mrgfe_batch* b, int target_index, const void* d_src_xyzi, size_t n, const float guess[16]);
+/* n_targets device clouds and n_pairs alignments against them in one call — what a loop over mrgfe_batch_add_target_device /
+ * mrgfe_batch_add_pair_device does (pair_target[i] indexes the targets of THIS call; guesses: n_pairs column-major 4x4).
+ * Returns the index of the first pair added (the others follow in order) or an error (< 0). */
+int  mrgfe_batch_add_device(mrgfe_batch* b, int n_targets, const void* const* d_targets, const size_t* target_points, int n_pairs, const int32_t* pair_target,
+                            const void* const* d_sources, const size_t* source_points, const float* guesses);
 /* Keyframe store.  The candidates of LoopDetector::matching are old keyframes that come back call after call
  * (loop_detector.cpp:66-100 selects them from the same pool for every new keyframe), while the reference hands their
  * clouds to setInputSource from host memory each time (:128).  A pair added with a non-zero `cloud_key` (the keyframe id)
@@ -316,7 +321,8 @@ int mrgfe_dbg_minmax(mrgfe_ctx* ctx, const float* xyzi, size_t n, float min3[3],
 int mrgfe_dbg_set_host_control(int mode);
 /* The optimiser's scalar routines (pose vector -> float matrix, angle derivative tables, 6x6 SVD solve) on n cases of 48 doubles
  * (p[6], A[36] row-major, b[6]), on the host (on_device = 0, ctx may be NULL) or on the device: M16 [n][16] row-major, tables69
- * [n][8*3 + 15*3], x6 [n][6].  One source (csrc/ndt_ctl.h) compiled twice; the test compares the two bit for bit. */
+ * [n][8*3 + 15*3], x6 [n][6]; on_device = 2: x6 from the wavefront form of the solve (three lanes rotate, 36 apply) that the
+ * device controller uses.  One source (csrc/ndt_ctl.h) compiled twice; the test compares the builds bit for bit. */
 /* the float sine / cosine the optimiser builds its pose matrices with (host build of csrc/ndt_ctl.h: glibc's sinf / cosf algorithm
  * restated, because the reference's Eigen::AngleAxisf calls exactly those and they are not correctly rounded) */
 void mrgfe_dbg_sincosf(const float* x, size_t n, float* sin_out, float* cos_out);

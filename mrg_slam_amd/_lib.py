@@ -141,6 +141,7 @@ SIGNATURES = {
     "mrgfe_batch_add_target_device": (C.c_int, [_vp, _vp, C.c_size_t]),
     "mrgfe_batch_add_pair": (C.c_int, [_vp, C.c_int, _fp, C.c_size_t, C.c_size_t, _fp]),
     "mrgfe_batch_add_pair_device": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _fp]),
+    "mrgfe_batch_add_device": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_void_p), _szp, C.c_int, _ip, C.POINTER(C.c_void_p), _szp, _fp]),
     "mrgfe_batch_add_pair_keyed": (C.c_int, [_vp, C.c_int, C.c_uint64, _fp, C.c_size_t, C.c_size_t, _fp]),
     "mrgfe_batch_has_cloud": (C.c_int, [_vp, C.c_uint64, C.POINTER(C.c_size_t)]),
     "mrgfe_batch_store_bytes": (C.c_size_t, [_vp]),

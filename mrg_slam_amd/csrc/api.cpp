@@ -803,6 +803,29 @@ int mrgfe_batch_add_pair_device(mrgfe_batch* b, int target, const void* d, size_
     col2row(guess, g);
     return b->ndt->add_pair_device(target, d, n, g);
 }
+int mrgfe_batch_add_device(mrgfe_batch* b, int n_targets, const void* const* d_targets, const size_t* target_points, int n_pairs, const int32_t* pair_target,
+                           const void* const* d_sources, const size_t* source_points, const float* guesses)
+{
+    if (!b || n_targets < 0 || n_pairs < 0 || (n_targets && (!d_targets || !target_points)) || (n_pairs && (!pair_target || !d_sources || !source_points || !guesses))) {
+        set_error("mrgfe_batch_add_device: bad argument");
+        return MRGFE_ERR_INVALID;
+    }
+    MRGFE_LOCK(b->ctx);
+    const int t0 = b->ndt->n_targets(), p0 = b->ndt->n_pairs();
+    for (int i = 0; i < n_pairs; ++i)
+        if (pair_target[i] < 0 || pair_target[i] >= n_targets) { set_error("mrgfe_batch_add_device: pair %d names target %d of %d", i, pair_target[i], n_targets); return MRGFE_ERR_INVALID; }
+    for (int i = 0; i < n_targets; ++i) {
+        const int t = b->ndt->add_target_device(d_targets[i], target_points[i]);
+        if (t < 0) return t;
+    }
+    for (int i = 0; i < n_pairs; ++i) {
+        float g[16];
+        col2row(guesses + size_t(i) * 16, g);
+        const int pi = b->ndt->add_pair_device(t0 + pair_target[i], d_sources[i], source_points[i], g);
+        if (pi < 0) return pi;
+    }
+    return p0;
+}
 int mrgfe_batch_add_pair_keyed(mrgfe_batch* b, int target, uint64_t key, const float* xyzi, size_t n, size_t stride, const float guess[16])
 {
     if (!b || !guess) { set_error("NULL argument"); return MRGFE_ERR_INVALID; }
@@ -1111,6 +1134,7 @@ int mrgfe_dbg_ctl_math(mrgfe_ctx* ctx, const double* cases48, int n, int on_devi
     MRGFE_TRY(din.ensure(nn * 48 * 8)); MRGFE_TRY(dM.ensure(nn * 64)); MRGFE_TRY(dt.ensure(nn * 69 * 8)); MRGFE_TRY(dx.ensure(nn * 48));
     MRGFE_HIP_CHECK(hipMemcpyAsync(din.p, cases48, size_t(n) * 48 * 8, hipMemcpyHostToDevice, ctx->stream));
     MRGFE_TRY(ndt_ctl_math_device(ctx, din.as<double>(), n, dM.as<float>(), dt.as<double>(), dx.as<double>()));
+    if (on_device == 2) MRGFE_TRY(ndt_ctl_svd_wave_device(ctx, din.as<double>(), n, dx.as<double>()));  // x from the wavefront form of the solve
     MRGFE_HIP_CHECK(hipMemcpyAsync(M16, dM.p, size_t(n) * 64, hipMemcpyDeviceToHost, ctx->stream));
     MRGFE_HIP_CHECK(hipMemcpyAsync(tables69, dt.p, size_t(n) * 69 * 8, hipMemcpyDeviceToHost, ctx->stream));
     MRGFE_HIP_CHECK(hipMemcpyAsync(x6, dx.p, size_t(n) * 48, hipMemcpyDeviceToHost, ctx->stream));

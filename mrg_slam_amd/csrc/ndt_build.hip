@@ -66,6 +66,11 @@ __global__ __launch_bounds__(256) void ndt_segments_kernel(const uint32_t* __res
     }
 }
 
+// (Measured and dropped in round 2: a wavefront that owns the leaves starting in a 256-point segment of the sorted stream,
+// fetches 64 points per step whatever the leaf boundaries and spreads the (leaf, term) chains over all 64 lanes — every lane
+// busy, bit-identical sums — took 1.04 ms per 256 targets of 130k points against 0.82 ms for the kernel below, software
+// pipelined and with the leaf extents kept in LDS: the kernel is bound by the random 16-byte point gather through the sorted
+// index, which a wavefront per leaf overlaps better — 5.6 M short independent wavefronts — than 130 k long ones.)
 // one wavefront per leaf. The reference accumulates each voxel's sums point by point in index order
 // (pclomp::VoxelGridCovariance first pass); to reproduce those f64 sums BIT FOR BIT the additions of one accumulator stay
 // sequential and the parallelism is moved elsewhere:

@@ -130,6 +130,28 @@ MRGFE_HD float cos_f(float y)
 
 // ---- 6x6 solve through a one-sided (Hestenes) Jacobi SVD: x = V diag(1/s) U^T b over singular values above
 // 6*eps*s_max, i.e. the minimum-norm solution Eigen::JacobiSVD<Matrix6d>::solve returns (no PD fix-up). -----------
+// Column pairs are visited in round-robin order: five steps of three DISJOINT pairs per sweep.  The rotations of a step touch
+// different columns, so executing them one after the other (this function: host, single lane) or side by side (svd_solve6_wave:
+// three lanes compute the rotations, 36 lanes apply them) gives the same doubles; both are held against each other in
+// tests/test_gpu_control.py.
+struct SvdPair { int p, q; };
+MRGFE_HD SvdPair svd_schedule(int step, int m)
+{
+    // (0,5)(1,4)(2,3) | (0,4)(3,5)(1,2) | (0,3)(2,4)(1,5) | (0,2)(1,3)(4,5) | (0,1)(2,5)(3,4): every pair once per sweep
+    const int P[5][3] = {{0, 1, 2}, {0, 3, 1}, {0, 2, 1}, {0, 1, 4}, {0, 2, 3}};
+    const int Q[5][3] = {{5, 4, 3}, {4, 5, 2}, {3, 4, 5}, {2, 3, 5}, {1, 5, 4}};
+    return SvdPair{P[step][m], Q[step][m]};
+}
+// rotation that orthogonalises two columns with squared norms alpha, beta and inner product gamma; false: leave them
+MRGFE_HD bool svd_rotation(double alpha, double beta, double gamma, double* c, double* sn)
+{
+    if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta)) return false;
+    const double zeta = (beta - alpha) / (2.0 * gamma);
+    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    *c = 1.0 / sqrt(1.0 + t * t);
+    *sn = *c * t;
+    return true;
+}
 MRGFE_HD void svd_solve6(const double A[36], const double b[6], double x[6])
 {
     const double kNaN = __builtin_nan("");
@@ -142,20 +164,20 @@ MRGFE_HD void svd_solve6(const double A[36], const double b[6], double x[6])
     for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { U[r][c] = A[r * 6 + c] / scale; V[r][c] = r == c ? 1.0 : 0.0; }
     for (int sweep = 0; sweep < 60; ++sweep) {
         bool rotated = false;
-        for (int p = 0; p < 5; ++p)
-            for (int q = p + 1; q < 6; ++q) {
+        for (int step = 0; step < 5; ++step)
+            for (int m = 0; m < 3; ++m) {
+                const SvdPair pq = svd_schedule(step, m);
+                const int p = pq.p, q = pq.q;
                 double alpha = 0, beta = 0, gamma = 0;
                 for (int k = 0; k < 6; ++k) { alpha += U[k][p] * U[k][p]; beta += U[k][q] * U[k][q]; gamma += U[k][p] * U[k][q]; }
-                if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta)) continue;
+                double c, sn;
+                if (!svd_rotation(alpha, beta, gamma, &c, &sn)) continue;
                 rotated = true;
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
                 for (int k = 0; k < 6; ++k) {
                     const double up = U[k][p], uq = U[k][q];
-                    U[k][p] = c * up - s * uq; U[k][q] = s * up + c * uq;
+                    U[k][p] = c * up - sn * uq; U[k][q] = sn * up + c * uq;
                     const double vp = V[k][p], vq = V[k][q];
-                    V[k][p] = c * vp - s * vq; V[k][q] = s * vp + c * vq;
+                    V[k][p] = c * vp - sn * vq; V[k][q] = sn * vp + c * vq;
                 }
             }
         if (!rotated) break;
@@ -177,6 +199,83 @@ MRGFE_HD void svd_solve6(const double A[36], const double b[6], double x[6])
         for (int k = 0; k < 6; ++k) x[k] += V[k][j] * coef;
     }
 }
+
+#if defined(__HIPCC__)
+// The same solve by the 64 lanes of one wavefront (all of them must call it; A, b, x may be LDS or global; `w` is LDS scratch).
+struct SvdWaveScratch { double U[6][6], V[6][6], c[3], s[3], sig[6], coef[6]; int rot[3], bad; };
+__device__ inline void svd_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ inline void svd_solve6_wave(const double* A, const double* b, double* x, SvdWaveScratch& w)
+{
+    const int lane = threadIdx.x & 63;
+    const double kNaN = __builtin_nan("");
+    double a = 0;
+    bool   fin = true;
+    if (lane < 36) { a = A[lane]; fin = finite_d(a); }
+    const bool all_finite = __ballot(!fin) == 0;
+    double scale = fabs(a);  // max over the 36 entries (lanes >= 36 hold 0): exact, whatever the order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) scale = dmax(scale, __shfl_xor(scale, off, 64));
+    if (!all_finite) { if (lane < 6) x[lane] = kNaN; svd_wave_sync(); return; }
+    if (scale == 0) { if (lane < 6) x[lane] = 0; svd_wave_sync(); return; }
+    if (lane < 36) { w.U[lane / 6][lane % 6] = a / scale; w.V[lane / 6][lane % 6] = (lane / 6 == lane % 6) ? 1.0 : 0.0; }
+    svd_wave_sync();
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int step = 0; step < 5; ++step) {
+            if (lane < 3) {
+                const SvdPair pq = svd_schedule(step, lane);
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int k = 0; k < 6; ++k) { const double up = w.U[k][pq.p], uq = w.U[k][pq.q]; alpha += up * up; beta += uq * uq; gamma += up * uq; }
+                double c = 1, sn = 0;
+                w.rot[lane] = svd_rotation(alpha, beta, gamma, &c, &sn) ? 1 : 0;
+                w.c[lane] = c; w.s[lane] = sn;
+            }
+            svd_wave_sync();
+            if (lane < 36) {
+                const int m = lane / 12, rem = lane % 12, k = rem % 6;
+                if (w.rot[m]) {
+                    const SvdPair pq = svd_schedule(step, m);
+                    double (*M)[6] = rem < 6 ? w.U : w.V;
+                    const double c = w.c[m], sn = w.s[m], up = M[k][pq.p], uq = M[k][pq.q];
+                    M[k][pq.p] = c * up - sn * uq; M[k][pq.q] = sn * up + c * uq;
+                }
+            }
+            rotated = rotated || (w.rot[0] | w.rot[1] | w.rot[2]);
+            svd_wave_sync();
+        }
+        if (!rotated) break;
+    }
+    double my_sig = 0;
+    if (lane < 6) {
+        double n2 = 0;
+        for (int k = 0; k < 6; ++k) n2 += w.U[k][lane] * w.U[k][lane];
+        my_sig = sqrt(n2);
+        w.sig[lane] = my_sig;
+    }
+    double smax = my_sig;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) smax = dmax(smax, __shfl_xor(smax, off, 64));
+    const double thr = dmax(smax * 6.0 * 2.2204460492503131e-16, 2.2250738585072014e-308 / scale);
+    if (lane < 6) {
+        double ub = 0;
+        for (int k = 0; k < 6; ++k) ub += w.U[k][lane] * b[k];
+        w.coef[lane] = ub / (my_sig * my_sig * scale);
+    }
+    svd_wave_sync();
+    if (lane < 6) {
+        double acc = 0;
+        for (int j = 0; j < 6; ++j)
+            if (w.sig[j] > thr) acc += w.V[lane][j] * w.coef[j];
+        x[lane] = acc;
+    }
+    svd_wave_sync();
+}
+#endif
 
 MRGFE_HD double psi_mt(double a, double f_a, double f_0, double g_0, double mu) { return f_a - f_0 - mu * g_0 * a; }
 MRGFE_HD double dpsi_mt(double g_a, double g_0, double mu) { return g_a - mu * g_0; }
@@ -353,73 +452,20 @@ MRGFE_HD void ls_after_eval(NdtCtlState& s)
     s.d_psi_t = dpsi_mt(s.d_phi_t, s.d_phi_0, kMu);
 }
 
-// resume after the reduced sums r[0..43] (score, gradient, 6x6 Hessian row-major, neighbour count) of the pending request.
-// On return either done(s) or a new request is pending (s.req_mode / s.req_p / s.final_).
-MRGFE_HD void on_result(NdtCtlState& s, const double r[44])
+// The state machine, resumable around the 6x6 solve so that the device can run that solve on a whole wavefront:
+//   resume(s, r)        takes the reduced sums r[0..43] (score, gradient, 6x6 Hessian row-major, neighbour count) of the pending
+//                       request and runs until a new request is pending / the alignment is done (CTL_RETURN) or the next
+//                       Newton step needs  delta = JacobiSVD(H).solve(-g)  (CTL_NEED_SOLVE: solve s.H * delta = -s.g);
+//   after_solve(s, d)   continues with that delta; may again ask for a solve (a zero-length step ends an iteration at once).
+enum { CTL_RETURN = 0, CTL_NEED_SOLVE = 1 };
+enum CtlNext { CTL_LS_UPDATE, CTL_LS_DECIDE, CTL_FINISH_LS };
+
+// line-search flow from `next` on (FINISH_LS uses a_fin); returns CTL_RETURN or CTL_NEED_SOLVE
+MRGFE_HD int ls_flow(NdtCtlState& s, CtlNext next, double a_fin)
 {
-    enum Next { NEWTON, LS_UPDATE, LS_DECIDE, FINISH_LS, RETURN };
-    Next   next = RETURN;
-    double a_fin = 0.0;  // step length handed to FINISH_LS
-    switch (s.phase) {
-        case NDT_INIT:     store_result(s, r, true, true);  next = NEWTON; break;
-        case NDT_LS_FIRST: store_result(s, r, true, true);  ls_after_eval(s); next = LS_DECIDE; break;
-        case NDT_LS_ITER:  store_result(s, r, true, false); next = LS_UPDATE; break;
-        case NDT_LS_HESS:  store_result(s, r, false, true); a_fin = s.a_t; next = FINISH_LS; break;
-        default: return;
-    }
     for (;;) {
         switch (next) {
-            case NEWTON: {
-                // computeTransformation loop body: delta_p = JacobiSVD(H).solve(-g), then computeStepLengthMT
-                for (int k = 0; k < 16; ++k) s.previous_[k] = s.transformation_[k];
-                double neg_g[6], delta[6];
-                for (int k = 0; k < 6; ++k) neg_g[k] = -s.g[k];
-                svd_solve6(s.H, neg_g, delta);
-                double n2 = 0;
-                for (int k = 0; k < 6; ++k) n2 += delta[k] * delta[k];
-                const double norm = sqrt(n2);
-                if (norm == 0 || norm != norm) {
-                    s.trans_probability = s.score / static_cast<double>(s.n_src);
-                    s.converged = (norm == norm) ? 1 : 0;
-                    s.phase = NDT_DONE;
-                    return;
-                }
-                for (int k = 0; k < 6; ++k) s.dir[k] = delta[k] / norm;
-                // computeStepLengthMT prologue
-                for (int k = 0; k < 6; ++k) s.x[k] = s.p[k];
-                s.phi_0 = -s.score;
-                double d = 0;
-                for (int k = 0; k < 6; ++k) d += s.g[k] * s.dir[k];
-                s.d_phi_0 = -d;
-                if (s.d_phi_0 >= 0) {
-                    if (s.d_phi_0 == 0) {
-                        // "return 0": a zero-length step; the outer loop then converges on its second pass (|0| < eps)
-                        a_fin = 0.0;
-                        next = FINISH_LS;
-                        break;
-                    }
-                    s.d_phi_0 *= -1;
-                    for (int k = 0; k < 6; ++k) s.dir[k] *= -1;
-                }
-                s.step_iterations = 0;
-                s.a_l = 0; s.a_u = 0;
-                s.f_l = psi_mt(s.a_l, s.phi_0, s.phi_0, s.d_phi_0, kMu);
-                s.g_l = dpsi_mt(s.d_phi_0, s.d_phi_0, kMu);
-                s.f_u = psi_mt(s.a_u, s.phi_0, s.phi_0, s.d_phi_0, kMu);
-                s.g_u = dpsi_mt(s.d_phi_0, s.d_phi_0, kMu);
-                const double step_max = s.step_size, step_min = s.trans_eps / 2;
-                s.interval_converged = (step_max - step_min) < 0 ? 1 : 0;
-                s.open_interval = 1;
-                s.a_t = norm;
-                s.a_t = dmin(s.a_t, step_max);
-                s.a_t = dmax(s.a_t, step_min);
-                for (int k = 0; k < 6; ++k) s.x_t[k] = s.x[k] + s.dir[k] * s.a_t;
-                pose_to_matrix(s.x_t, s.final_);
-                make_request(s, 0, s.x_t);
-                s.phase = NDT_LS_FIRST;
-                return;
-            }
-            case LS_UPDATE: {
+            case CTL_LS_UPDATE: {
                 // bookkeeping of one line-search trial once its score / gradient are known (body of the while loop of computeStepLengthMT)
                 ls_after_eval(s);
                 if (s.open_interval && (s.psi_t <= 0 && s.d_psi_t >= 0)) {
@@ -432,10 +478,10 @@ MRGFE_HD void on_result(NdtCtlState& s, const double r[44])
                 if (s.open_interval) s.interval_converged = update_interval(s.a_l, s.f_l, s.g_l, s.a_u, s.f_u, s.g_u, s.a_t, s.psi_t, s.d_psi_t) ? 1 : 0;
                 else                 s.interval_converged = update_interval(s.a_l, s.f_l, s.g_l, s.a_u, s.f_u, s.g_u, s.a_t, s.phi_t, s.d_phi_t) ? 1 : 0;
                 s.step_iterations++;
-                next = LS_DECIDE;
+                next = CTL_LS_DECIDE;
                 break;
             }
-            case LS_DECIDE: {
+            case CTL_LS_DECIDE: {
                 if (!s.interval_converged && s.step_iterations < kMaxStepIterations && !(s.psi_t <= 0 && s.d_phi_t <= -kNu * s.d_phi_0)) {
                     if (s.open_interval) s.a_t = trial_value(s.a_l, s.f_l, s.g_l, s.a_u, s.f_u, s.g_u, s.a_t, s.psi_t, s.d_psi_t);
                     else                 s.a_t = trial_value(s.a_l, s.f_l, s.g_l, s.a_u, s.f_u, s.g_u, s.a_t, s.phi_t, s.d_phi_t);
@@ -452,23 +498,23 @@ MRGFE_HD void on_result(NdtCtlState& s, const double r[44])
                         ++s.n_evals;
                         ++s.n_reused;
                         s.nb_sum += s.cache_nb;
-                        next = LS_UPDATE;
+                        next = CTL_LS_UPDATE;
                         break;
                     }
                     make_request(s, 1, s.x_t);
                     s.phase = NDT_LS_ITER;
-                    return;
+                    return CTL_RETURN;
                 }
                 if (s.step_iterations) {
                     make_request(s, 2, s.x_t);  // computeHessian at x_t (final_ already holds its matrix)
                     s.phase = NDT_LS_HESS;
-                    return;
+                    return CTL_RETURN;
                 }
                 a_fin = s.a_t;
-                next = FINISH_LS;
+                next = CTL_FINISH_LS;
                 break;
             }
-            case FINISH_LS: {
+            case CTL_FINISH_LS: {
                 // back in computeTransformation's loop body
                 double delta_p[6];
                 for (int k = 0; k < 6; ++k) delta_p[k] = s.dir[k] * a_fin;
@@ -479,13 +525,77 @@ MRGFE_HD void on_result(NdtCtlState& s, const double r[44])
                 if (s.converged) {
                     s.trans_probability = s.score / static_cast<double>(s.n_src);
                     s.phase = NDT_DONE;
-                    return;
+                    return CTL_RETURN;
                 }
-                next = NEWTON;  // next Newton iteration from the derivatives already held for p == x_t
-                break;
+                return CTL_NEED_SOLVE;  // next Newton iteration from the derivatives already held for p == x_t
             }
-            default: return;
         }
+    }
+}
+
+MRGFE_HD int resume(NdtCtlState& s, const double r[44])
+{
+    switch (s.phase) {
+        case NDT_INIT:     store_result(s, r, true, true);  return CTL_NEED_SOLVE;
+        case NDT_LS_FIRST: store_result(s, r, true, true);  ls_after_eval(s); return ls_flow(s, CTL_LS_DECIDE, 0.0);
+        case NDT_LS_ITER:  store_result(s, r, true, false); return ls_flow(s, CTL_LS_UPDATE, 0.0);
+        case NDT_LS_HESS:  store_result(s, r, false, true); return ls_flow(s, CTL_FINISH_LS, s.a_t);
+        default: return CTL_RETURN;
+    }
+}
+
+// computeTransformation loop body after  delta = JacobiSVD(H).solve(-g):  computeStepLengthMT's prologue and first trial
+MRGFE_HD int after_solve(NdtCtlState& s, const double delta[6])
+{
+    for (int k = 0; k < 16; ++k) s.previous_[k] = s.transformation_[k];
+    double n2 = 0;
+    for (int k = 0; k < 6; ++k) n2 += delta[k] * delta[k];
+    const double norm = sqrt(n2);
+    if (norm == 0 || norm != norm) {
+        s.trans_probability = s.score / static_cast<double>(s.n_src);
+        s.converged = (norm == norm) ? 1 : 0;
+        s.phase = NDT_DONE;
+        return CTL_RETURN;
+    }
+    for (int k = 0; k < 6; ++k) s.dir[k] = delta[k] / norm;
+    for (int k = 0; k < 6; ++k) s.x[k] = s.p[k];
+    s.phi_0 = -s.score;
+    double d = 0;
+    for (int k = 0; k < 6; ++k) d += s.g[k] * s.dir[k];
+    s.d_phi_0 = -d;
+    if (s.d_phi_0 >= 0) {
+        if (s.d_phi_0 == 0) return ls_flow(s, CTL_FINISH_LS, 0.0);  // "return 0": a zero-length step; the outer loop converges on its second pass (|0| < eps)
+        s.d_phi_0 *= -1;
+        for (int k = 0; k < 6; ++k) s.dir[k] *= -1;
+    }
+    s.step_iterations = 0;
+    s.a_l = 0; s.a_u = 0;
+    s.f_l = psi_mt(s.a_l, s.phi_0, s.phi_0, s.d_phi_0, kMu);
+    s.g_l = dpsi_mt(s.d_phi_0, s.d_phi_0, kMu);
+    s.f_u = psi_mt(s.a_u, s.phi_0, s.phi_0, s.d_phi_0, kMu);
+    s.g_u = dpsi_mt(s.d_phi_0, s.d_phi_0, kMu);
+    const double step_max = s.step_size, step_min = s.trans_eps / 2;
+    s.interval_converged = (step_max - step_min) < 0 ? 1 : 0;
+    s.open_interval = 1;
+    s.a_t = norm;
+    s.a_t = dmin(s.a_t, step_max);
+    s.a_t = dmax(s.a_t, step_min);
+    for (int k = 0; k < 6; ++k) s.x_t[k] = s.x[k] + s.dir[k] * s.a_t;
+    pose_to_matrix(s.x_t, s.final_);
+    make_request(s, 0, s.x_t);
+    s.phase = NDT_LS_FIRST;
+    return CTL_RETURN;
+}
+
+// single-lane / host form: on return either done(s) or a new request is pending (s.req_mode / s.req_p / s.final_)
+MRGFE_HD void on_result(NdtCtlState& s, const double r[44])
+{
+    int next = resume(s, r);
+    while (next == CTL_NEED_SOLVE) {
+        double neg_g[6], delta[6];
+        for (int k = 0; k < 6; ++k) neg_g[k] = -s.g[k];
+        svd_solve6(s.H, neg_g, delta);
+        next = after_solve(s, delta);
     }
 }
 

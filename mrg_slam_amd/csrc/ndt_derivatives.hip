@@ -146,8 +146,11 @@ __device__ __forceinline__ void pair_double(Accum& acc, const double mean[3], co
 #ifndef NDT_MODE0_WAVES
 #define NDT_MODE0_WAVES 3
 #endif
+#ifndef NDT_MODE2_WAVES
+#define NDT_MODE2_WAVES 3  // the per-point f64 Hessian pass holds 21 + 15 f64 accumulators and no LDS staging
+#endif
 template <int MODE, int NNB>
-__global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2)) void ndt_derivatives_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
+__global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : ((MODE == 2 && NNB <= 7) ? NDT_MODE2_WAVES : 2))) void ndt_derivatives_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
                                                                const NdtEvalDev* __restrict__ evals, const uint32_t* __restrict__ plan, uint32_t n_all_pairs,
                                                                double* __restrict__ partials)
 {
@@ -163,13 +166,12 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2
     constexpr int kHRows = (MODE == 1) ? 1 : 15;
     __shared__ float    s_T[12];
     __shared__ float    s_ja[8][3], s_ha[15][3];
-    // (the f64 variant stages 23 doubles per point: 59 KB of LDS, two workgroups per CU; staging 128 points at a time to fit
-    // three was measured slower, 0.28 vs 0.26 ms)
     constexpr int kTile = kTilePts;
-    __shared__ float    s_xt[3][kTile];
-    __shared__ StageT   s_xj[8][kTile];
-    __shared__ StageT   s_xh[kHRows][kTile];
-    __shared__ uint32_t s_queue[kTile * NNB];  // (slot << 24) | leaf id
+    constexpr int kStage = (MODE == 2) ? 1 : kTile;  // the f64 Hessian variant keeps a point's terms in registers (see below)
+    __shared__ float    s_xt[3][kStage];
+    __shared__ StageT   s_xj[8][kStage];
+    __shared__ StageT   s_xh[kHRows][kStage];
+    __shared__ uint32_t s_queue[kStage * NNB];  // (slot << 24) | leaf id
     __shared__ uint32_t s_scan[8];
     __shared__ double   s_red[4][kNdtPartialStride];
   for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {  // (body indented as before the item loop existed)
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2
     for (int k = 0; k < 6; ++k) acc.g[k] = 0;
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc.H[k] = 0;
-    uint32_t nb_total = 0;
+    uint32_t nb_total = 0, nb_mine = 0;
 
     const uint32_t base = item_in_pair * static_cast<uint32_t>(kTilePts) * ppt;
     const uint32_t last = min(pr.n_src, base + static_cast<uint32_t>(kTilePts) * ppt);  // end of this item's points
@@ -271,26 +273,94 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2
             }
 #pragma unroll
             for (int n = 0; n < NNB; ++n) cnt += ids[n] >= 0 ? 1u : 0u;
-            if (cnt) {
-                s_xt[0][threadIdx.x] = xt[0]; s_xt[1][threadIdx.x] = xt[1]; s_xt[2][threadIdx.x] = xt[2];
-                if (MODE != 2) {
-                    // computePointDerivatives, float form: x_j_ang = j_ang * x, x_h_ang = h_ang * x
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) s_xj[r][threadIdx.x] = fdot3f(s_ja[r][0], p.x, s_ja[r][1], p.y, s_ja[r][2], p.z);
-                    if (MODE == 0) {
-#pragma unroll
-                        for (int r = 0; r < 15; ++r) s_xh[r][threadIdx.x] = fdot3f(s_ha[r][0], p.x, s_ha[r][1], p.y, s_ha[r][2], p.z);
-                    }
-                } else {
-                    // computePointDerivatives, double form
+            if (MODE == 2) {
+                // ---- computeHessian (pclomp: f64, PCL's 3x6 / 18x6 forms), one lane per POINT ------------------------------
+                // Per pair the reference evaluates  e * ( -d2 (q.C J_i)(q.C J_j) + q.C PH_ij + J_j.C J_i ).  J and PH belong to the
+                // point, so with v = C q the sum over the point's voxels factors into
+                //     J_i^T [ sum e C  -  d2 sum e v v^T ] J_j  +  (sum e v) . PH_ij
+                // ~30 fused multiply-adds per voxel and ~90 per point instead of ~160 per pair: 3x fewer f64 operations.  Everything is
+                // f64, so this differs from the reference's association by rounding at the 1e-16 level, like the order of the sums
+                // (the float path above keeps the reference's per-pair sequence, where the rounding is 1e-7 and matters).
+                nb_mine += cnt;
+                if (cnt) {
                     const double x[3] = {p.x, p.y, p.z};
+                    double M1[6] = {0, 0, 0, 0, 0, 0}, M2[6] = {0, 0, 0, 0, 0, 0}, w[3] = {0, 0, 0};
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) s_xj[r][threadIdx.x] = fdot3d(x[0], ev.j_ang_d[r][0], x[1], ev.j_ang_d[r][1], x[2], ev.j_ang_d[r][2]);
+                    for (int n = 0; n < NNB; ++n) {
+                        if (ids[n] < 0) continue;
+                        const uint32_t lid = static_cast<uint32_t>(ids[n]);
+                        if (lid >= g.n_leaves) continue;  // cannot happen; keeps a corrupted table entry from faulting the GPU
+                        const double* __restrict__ C = g.icov64 + (size_t)lid * 9;
+                        const double* __restrict__ mean = g.leaves[lid].mean;
+                        const double q[3] = {static_cast<double>(xt[0]) - mean[0], static_cast<double>(xt[1]) - mean[1], static_cast<double>(xt[2]) - mean[2]};
+                        double v[3];
 #pragma unroll
-                    for (int r = 0; r < 15; ++r) s_xh[r][threadIdx.x] = fdot3d(x[0], ev.h_ang_d[r][0], x[1], ev.h_ang_d[r][1], x[2], ev.h_ang_d[r][2]);
+                        for (int r = 0; r < 3; ++r) v[r] = fdot3d(C[r * 3 + 0], q[0], C[r * 3 + 1], q[1], C[r * 3 + 2], q[2]);
+                        double e = gauss_d2 * exp(-gauss_d2 * fdot3d(q[0], v[0], q[1], v[1], q[2], v[2]) / 2);
+                        if (e > 1 || e < 0 || e != e) continue;
+                        e *= gauss_d1;
+                        const double ev3[3] = {e * v[0], e * v[1], e * v[2]};
+                        M1[0] = __builtin_fma(e, C[0], M1[0]); M1[1] = __builtin_fma(e, C[1], M1[1]); M1[2] = __builtin_fma(e, C[2], M1[2]);
+                        M1[3] = __builtin_fma(e, C[4], M1[3]); M1[4] = __builtin_fma(e, C[5], M1[4]); M1[5] = __builtin_fma(e, C[8], M1[5]);
+                        M2[0] = __builtin_fma(ev3[0], v[0], M2[0]); M2[1] = __builtin_fma(ev3[0], v[1], M2[1]); M2[2] = __builtin_fma(ev3[0], v[2], M2[2]);
+                        M2[3] = __builtin_fma(ev3[1], v[1], M2[3]); M2[4] = __builtin_fma(ev3[1], v[2], M2[4]); M2[5] = __builtin_fma(ev3[2], v[2], M2[5]);
+                        w[0] += ev3[0]; w[1] += ev3[1]; w[2] += ev3[2];
+                    }
+                    // A = sum e C - d2 sum e v v^T (symmetric: xx, xy, xz, yy, yz, zz)
+                    double A[3][3];
+                    {
+                        double a[6];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) a[k] = __builtin_fma(-gauss_d2, M2[k], M1[k]);
+                        A[0][0] = a[0]; A[0][1] = A[1][0] = a[1]; A[0][2] = A[2][0] = a[2]; A[1][1] = a[3]; A[1][2] = A[2][1] = a[4]; A[2][2] = a[5];
+                    }
+                    // computePointDerivatives, double form: rotational columns of J and the second-derivative vectors
+                    double xj[8], xh[15];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) xj[r] = fdot3d(x[0], ev.j_ang_d[r][0], x[1], ev.j_ang_d[r][1], x[2], ev.j_ang_d[r][2]);
+#pragma unroll
+                    for (int r = 0; r < 15; ++r) xh[r] = fdot3d(x[0], ev.h_ang_d[r][0], x[1], ev.h_ang_d[r][1], x[2], ev.h_ang_d[r][2]);
+                    const double Jr[3][3] = {{0.0, xj[2], xj[5]}, {xj[0], xj[3], xj[6]}, {xj[1], xj[4], xj[7]}};  // Jr[row][c]: columns 3, 4, 5 of J
+                    double AJ[3][3];  // A * Jr
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        AJ[r][0] = fdot3d_z(A[r][1], Jr[1][0], A[r][2], Jr[2][0]);  // J(0,3) is a structural zero
+                        AJ[r][1] = fdot3d(A[r][0], Jr[0][1], A[r][1], Jr[1][1], A[r][2], Jr[2][1]);
+                        AJ[r][2] = fdot3d(A[r][0], Jr[0][2], A[r][1], Jr[1][2], A[r][2], Jr[2][2]);
+                    }
+                    // translation block and translation x rotation block (upper triangle: i <= j)
+                    acc.H[0 * 6 + 0] += A[0][0]; acc.H[0 * 6 + 1] += A[0][1]; acc.H[0 * 6 + 2] += A[0][2]; acc.H[1 * 6 + 1] += A[1][1]; acc.H[1 * 6 + 2] += A[1][2]; acc.H[2 * 6 + 2] += A[2][2];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) acc.H[i * 6 + 3 + c] += AJ[i][c];
+                    // rotation block: J_i^T (A J_j) + w . PH_ij;  PH index a,b,c,d,e,f = (3,3),(3,4),(3,5),(4,4),(4,5),(5,5)
+                    const double PH[6][3] = {{0, xh[0], xh[1]}, {0, xh[2], xh[3]}, {0, xh[4], xh[5]}, {xh[6], xh[7], xh[8]}, {xh[9], xh[10], xh[11]}, {xh[12], xh[13], xh[14]}};
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = i; j < 3; ++j) {
+                            const int ph = (i == 0) ? j : (i == 1 ? j + 2 : 5);
+                            const double jaj = (i == 0) ? fdot3d_z(Jr[1][0], AJ[1][j], Jr[2][0], AJ[2][j]) : fdot3d(Jr[0][i], AJ[0][j], Jr[1][i], AJ[1][j], Jr[2][i], AJ[2][j]);
+                            const double wph = (ph < 3) ? fdot3d_z(w[1], PH[ph][1], w[2], PH[ph][2]) : fdot3d(w[0], PH[ph][0], w[1], PH[ph][1], w[2], PH[ph][2]);
+                            acc.H[(3 + i) * 6 + 3 + j] += jaj + wph;
+                        }
+                }
+                cnt = 0;  // nothing queued: the pair phase below is the float path's
+#pragma unroll
+                for (int n = 0; n < NNB; ++n) ids[n] = -1;
+            } else if (cnt) {
+                s_xt[0][threadIdx.x] = xt[0]; s_xt[1][threadIdx.x] = xt[1]; s_xt[2][threadIdx.x] = xt[2];
+                // computePointDerivatives, float form: x_j_ang = j_ang * x, x_h_ang = h_ang * x
+#pragma unroll
+                for (int r = 0; r < 8; ++r) s_xj[r][threadIdx.x] = fdot3f(s_ja[r][0], p.x, s_ja[r][1], p.y, s_ja[r][2], p.z);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int r = 0; r < 15; ++r) s_xh[r][threadIdx.x] = fdot3f(s_ha[r][0], p.x, s_ha[r][1], p.y, s_ha[r][2], p.z);
                 }
             }
         }
+        if (MODE == 2) continue;  // next tile: no LDS staging, no pair queue
         uint32_t total;
         uint32_t off = block_exclusive_scan<256>(cnt, s_scan, &total);
 #pragma unroll
@@ -350,7 +420,7 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : 2
     for (int k = 0; k < 6; ++k) vals[1 + k] = acc.g[k];
 #pragma unroll
     for (int k = 0; k < 36; ++k) vals[7 + k] = (MODE == 2 && k / 6 > k % 6) ? acc.H[(k % 6) * 6 + k / 6] : acc.H[k];  // the f64 pass fills the upper triangle
-    vals[kNdtNbIndex] = static_cast<double>(nb_total);
+    vals[kNdtNbIndex] = static_cast<double>(MODE == 2 ? nb_mine : nb_total);
 #pragma unroll
     for (int k = 0; k < kNdtAccum; ++k) {
         const bool skip = (MODE == 1 && k >= 7 && k < kNdtNbIndex) || (MODE == 2 && k < 7);
@@ -492,14 +562,28 @@ __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __res
     static_assert(sizeof(NdtCtlState) % 8 == 0, "state is copied as 8-byte words");
     __shared__ double s_state[kWords];
     __shared__ NdtEvalDev s_eval;
+    __shared__ ctl::SvdWaveScratch s_svd;
+    __shared__ double s_negg[6], s_delta[6];
     const double* gs = reinterpret_cast<const double*>(states + blockIdx.x);
     for (int w = threadIdx.x; w < kWords; w += 256) s_state[w] = gs[w];
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (wave_id() == 0) {
+        // lane 0 runs the state machine; the 6x6 SVD solves of its Newton steps run on the whole wavefront
         NdtCtlState& st = *reinterpret_cast<NdtCtlState*>(s_state);
-        ctl::on_result(st, s_r);
-        s_eval.active = 0;
-        ctl::fill_eval(st, s_eval);
+        int next = 0;
+        if (threadIdx.x == 0) next = ctl::resume(st, s_r);
+        next = __shfl(next, 0, kWave);
+        while (next == ctl::CTL_NEED_SOLVE) {
+            if (threadIdx.x < 6) s_negg[threadIdx.x] = -st.g[threadIdx.x];
+            ctl::svd_wave_sync();
+            ctl::svd_solve6_wave(st.H, s_negg, s_delta, s_svd);
+            if (threadIdx.x == 0) next = ctl::after_solve(st, s_delta);
+            next = __shfl(next, 0, kWave);
+        }
+        if (threadIdx.x == 0) {
+            s_eval.active = 0;
+            ctl::fill_eval(st, s_eval);
+        }
     }
     __syncthreads();
     double* gd = reinterpret_cast<double*>(states + blockIdx.x);
@@ -526,11 +610,30 @@ __global__ __launch_bounds__(64) void ndt_ctl_math_kernel(const double* __restri
     for (int a = 0; a < 15; ++a) for (int b = 0; b < 3; ++b) tables[size_t(i) * 69 + 24 + a * 3 + b] = h[a][b];
     ctl::svd_solve6(c + 6, c + 42, x + size_t(i) * 6);
 }
+// the wavefront form of the solve, one case per workgroup of 64 lanes
+__global__ __launch_bounds__(64) void ndt_ctl_svd_wave_kernel(const double* __restrict__ in, int n, double* __restrict__ x)
+{
+    __shared__ ctl::SvdWaveScratch s_svd;
+    __shared__ double s_A[36], s_b[6], s_x[6];
+    const double* c = in + size_t(blockIdx.x) * 48;
+    if (threadIdx.x < 36) s_A[threadIdx.x] = c[6 + threadIdx.x];
+    if (threadIdx.x < 6) s_b[threadIdx.x] = c[42 + threadIdx.x];
+    ctl::svd_wave_sync();
+    ctl::svd_solve6_wave(s_A, s_b, s_x, s_svd);
+    if (threadIdx.x < 6) x[size_t(blockIdx.x) * 6 + threadIdx.x] = s_x[threadIdx.x];
+}
 
 int ndt_ctl_math_device(mrgfe_ctx* ctx, const double* d_in, int n, float* d_M, double* d_tables, double* d_x)
 {
     if (n <= 0) return MRGFE_OK;
     hipLaunchKernelGGL(ndt_ctl_math_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_in, n, d_M, d_tables, d_x);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+int ndt_ctl_svd_wave_device(mrgfe_ctx* ctx, const double* d_in, int n, double* d_x)
+{
+    if (n <= 0) return MRGFE_OK;
+    hipLaunchKernelGGL(ndt_ctl_svd_wave_kernel, dim3(n), dim3(64), 0, ctx->stream, d_in, n, d_x);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }

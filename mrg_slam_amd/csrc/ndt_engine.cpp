@@ -383,7 +383,7 @@ static int env_int(const char* name, int dflt) { const char* e = std::getenv(nam
 uint32_t NdtEngine::derivative_grid(int mode) const
 {
     static const int per_slot = std::max(1, env_int("MRGFE_GRID_PER_SLOT", 4));
-    const int slots_per_cu = (mode == 0 && prm_.search != MRGFE_KDTREE && prm_.search != MRGFE_DIRECT26) ? 3 : 2;  // __launch_bounds__ of the variants
+    const int slots_per_cu = (mode != 1 && prm_.search != MRGFE_KDTREE && prm_.search != MRGFE_DIRECT26) ? 3 : 2;  // __launch_bounds__ of the variants
     return static_cast<uint32_t>(ctx_->cu_count * slots_per_cu * per_slot);
 }
 

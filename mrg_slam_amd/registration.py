@@ -366,6 +366,22 @@ class BatchMatcher:
         g = _colmajor(np.eye(4) if guess is None else guess)
         return check(lib().mrgfe_batch_add_pair_device(self._h, target, C.c_void_p(dev_ptr), n, g.ctypes.data_as(_fp)))
 
+    def add_device(self, target_ptrs, target_points, pair_target, source_ptrs, source_points, guesses) -> int:
+        """Many device-resident targets and pairs in one call (``mrgfe_batch_add_device``): ``pair_target[i]`` indexes
+        ``target_ptrs``; ``guesses`` is [n_pairs, 4, 4] row-major.  Returns the index of the first pair added."""
+        nt, npair = len(target_ptrs), len(source_ptrs)
+        tp = (C.c_void_p * max(nt, 1))(*[int(p) for p in target_ptrs])
+        tn = (C.c_size_t * max(nt, 1))(*[int(n) for n in target_points])
+        sp = (C.c_void_p * max(npair, 1))(*[int(p) for p in source_ptrs])
+        sn = (C.c_size_t * max(npair, 1))(*[int(n) for n in source_points])
+        pt = np.ascontiguousarray(pair_target, dtype=np.int32)
+        g = np.ascontiguousarray(np.asarray(guesses, dtype=np.float32).reshape(npair, 4, 4).transpose(0, 2, 1))  # column-major per pair
+        return check(lib().mrgfe_batch_add_device(self._h, nt, tp, tn, npair, pt.ctypes.data_as(_ip), sp, sn, g.ctypes.data_as(_fp)))
+
+    def rounds(self) -> int:
+        """Rounds (plan -> derivative launches -> reduce / controller step) of the last NDT align()."""
+        return int(lib().mrgfe_batch_rounds(self._h))
+
     def set_guess(self, pair: int, guess) -> None:
         check(lib().mrgfe_batch_set_guess(self._h, pair, _colmajor(guess).ctypes.data_as(_fp)))
 

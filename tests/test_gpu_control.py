@@ -134,7 +134,7 @@ def test_controller_math_device_equals_host():
     cases[:, 42:] = rng.normal(0, 10, (n, 6))
     out = {}
     _dp, _fp = C.POINTER(C.c_double), C.POINTER(C.c_float)
-    for dev in (0, 1):
+    for dev in (0, 1, 2):
         M, tab, x = np.empty((n, 16), np.float32), np.empty((n, 69)), np.empty((n, 6))
         check(lib().mrgfe_dbg_ctl_math(default_context()._h, cases.ctypes.data_as(_dp), n, dev, M.ctypes.data_as(_fp), tab.ctypes.data_as(_dp), x.ctypes.data_as(_dp)))
         out[dev] = (M, tab, x)
@@ -149,3 +149,7 @@ def test_controller_math_device_equals_host():
     scale = np.abs(xh[ok]).max(axis=1, keepdims=True) + 1e-300
     assert (np.abs(xd[ok] - xh[ok]) / scale).max() <= 1e-6  # ill-conditioned systems amplify the last-bit differences of sqrt / division
     assert ((xd[ok] == xh[ok]).all(axis=1)).mean() >= 0.5
+    # the wavefront form of the solve (what the device controller runs) against the single-lane form, both on the device
+    xw = out[2][2]
+    assert (np.isfinite(xw).all(axis=1) == ok).all()
+    assert (xw[ok] == xd[ok]).all()
