@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -95,6 +97,8 @@ struct mrgfe_batch {
     GicpBatch*          gicp_batch = nullptr;
     std::vector<GicpBatchPair> gicp_pairs;  // per-pair device buffers, kept between align calls
     std::vector<NnGrid> fit_grids;  // getFitnessScore grids, one per target; device buffers kept between align calls
+    mrgfe_ctx*          fit_ctx = nullptr;  // helper context (own stream and workspaces): the grids are built on it by a second host
+                                            // thread while the alignment rounds run on the batch's context
     // keyframe store (mrgfe_batch_add_pair_keyed): packed clouds and GICP covariances by caller-chosen key, resident across clears
     struct Keyframe {
         DevBuf   cloud, cov;
@@ -756,6 +760,7 @@ void mrgfe_batch_destroy(mrgfe_batch* b)
         MRGFE_LOCK(b->ctx);
         (void)b->ctx->bind();
         for (auto& g : b->fit_grids) g.release();
+        if (b->fit_ctx) mrgfe_ctx_destroy(b->fit_ctx);
         for (auto& gp : b->gicp_pairs) { gp.cov.release(); gp.corr.release(); gp.mahal.release(); }
         delete b->gicp_batch;
         for (auto* g : b->gicp) delete g;
@@ -922,6 +927,7 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
     NdtEngine& e = *b->ndt;
     const int P = e.n_pairs();
     const bool gicp = b->params.method != MRGFE_NDT_HIP;
+    std::vector<char> fit_built;  // targets whose fitness grid is built in this call
     if (gicp) {
         // GICP_HIP: the candidates of a target share its covariances and correspondence grid, and all LM loops advance
         // together (GicpBatch: one launch per kernel and round for the pairs still running)
@@ -967,7 +973,40 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
             r.pair_id = i;
         }
     } else {
-        MRGFE_TRY(e.align_all());
+        // getFitnessScore needs an exact-NN grid per distinct target, and those depend on the target clouds only: they are built
+        // on a helper context by a second host thread WHILE the alignment rounds run (their small launches fill the tails of the
+        // derivative kernels), instead of one after the other behind the alignment (64 targets: ~10 ms of a 65 ms step)
+        std::thread  builder;
+        int          build_status = MRGFE_OK;
+        std::string  build_error;
+        const bool   overlap = fitness_max_range >= 0 && P >= 2 && std::getenv("MRGFE_NO_FIT_OVERLAP") == nullptr;
+        if (overlap) {
+            if (!b->fit_ctx && mrgfe_ctx_create(b->ctx->device, &b->fit_ctx) != MRGFE_OK) return MRGFE_ERR_HIP;
+            if (fit_built.size() < static_cast<size_t>(e.n_targets())) fit_built.resize(e.n_targets(), 0);
+            if (b->fit_grids.size() < static_cast<size_t>(e.n_targets())) b->fit_grids.resize(e.n_targets());
+            std::vector<int> todo;
+            for (int i = 0; i < P; ++i) {
+                const NdtPairInfo& p = e.pair(i);
+                if (e.target(p.target).n == 0 || p.n == 0 || fit_built[p.target]) continue;
+                fit_built[p.target] = 1;
+                todo.push_back(p.target);
+            }
+            builder = std::thread([b, &e, todo, &build_status, &build_error] {
+                mrgfe_ctx* fc = b->fit_ctx;
+                std::lock_guard<std::recursive_mutex> lock(fc->mu);
+                if (fc->bind() != MRGFE_OK) { build_status = MRGFE_ERR_HIP; build_error = mrgfe_last_error(); return; }
+                for (int t : todo) {
+                    const NdtTargetInfo& T = e.target(t);
+                    const int st = b->fit_grids[t].build(fc, T.d_pts, T.n, 1.0f, NnGrid::kCrowding1nn, 1);
+                    if (st != MRGFE_OK) { build_status = st; build_error = mrgfe_last_error(); return; }
+                }
+                if (hipStreamSynchronize(fc->stream) != hipSuccess) { build_status = MRGFE_ERR_HIP; build_error = "helper stream synchronisation failed"; }
+            });
+        }
+        const int align_status = e.align_all();
+        if (builder.joinable()) builder.join();
+        MRGFE_TRY(align_status);
+        if (build_status != MRGFE_OK) { set_error("%s", build_error.c_str()); return build_status; }
         for (int i = 0; i < P; ++i) {
             const NdtController& c = e.pair(i).ctl;
             mrgfe_pair_result& r = results[i];
@@ -985,7 +1024,8 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
         // getFitnessScore of every pair in one launch: one exact-NN grid per distinct target
         std::vector<NnGrid>& grids = b->fit_grids;
         if (grids.size() < static_cast<size_t>(e.n_targets())) grids.resize(e.n_targets());
-        std::vector<char>   built(e.n_targets(), 0);
+        if (fit_built.size() < static_cast<size_t>(e.n_targets())) fit_built.resize(e.n_targets(), 0);
+        std::vector<char>&  built = fit_built;
         std::vector<NnFitnessJob> jobs;
         std::vector<int>          job_pair;
         int st = MRGFE_OK;
@@ -1152,7 +1192,7 @@ int mrgfe_dbg_ctl_create(const mrgfe_reg_params* params, const float guess[16], 
     mrgfe_dbg_ctl* h = new mrgfe_dbg_ctl();
     float g[16];
     col2row(guess, g);
-    h->c.start(ndt_params_from(*params), g, n_src);
+    h->c.start(ndt_params_from(*params), g, n_src, std::getenv("MRGFE_DBG_CTL_SPLIT") != nullptr);
     *out = h;
     return MRGFE_OK;
 }

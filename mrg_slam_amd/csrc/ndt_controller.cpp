@@ -30,7 +30,7 @@ void NdtController::euler_xyz(const float M[16], float out[3])
     out[0] = -r0; out[1] = -r1; out[2] = -r2;
 }
 
-void NdtController::start(const NdtParams& prm, const float guess[16], uint32_t n_src)
+void NdtController::start(const NdtParams& prm, const float guess[16], uint32_t n_src, bool split_first)
 {
     std::memset(&s_, 0, sizeof(s_));
     s_.step_size = prm.step_size;
@@ -40,6 +40,7 @@ void NdtController::start(const NdtParams& prm, const float guess[16], uint32_t 
     s_.max_iterations = prm.max_iterations;
     s_.search = prm.search;
     s_.reuse = reuse_enabled() ? 1 : 0;
+    s_.split_first = split_first ? 1 : 0;
     s_.n_src = n_src;
     // pcl::Registration::align
     ctl::identity16(s_.final_); ctl::identity16(s_.transformation_); ctl::identity16(s_.previous_);

@@ -22,7 +22,8 @@ struct NdtParams {
 
 class NdtController {
    public:
-    void start(const NdtParams& prm, const float guess_rowmajor[16], uint32_t n_src);
+    // split_first: evaluate the first trial of every line search without its Hessian and fetch that only when it is used (ndt_ctl.h)
+    void start(const NdtParams& prm, const float guess_rowmajor[16], uint32_t n_src, bool split_first = false);
     bool done() const { return ctl::done(s_); }
     // pending request: kernel variant (0 score+grad+hess, 1 score+grad, 2 f64 hessian) and the record the kernels read
     int  request_mode() const { return s_.req_mode; }

@@ -20,7 +20,7 @@
 
 namespace mrgfe {
 
-enum NdtPhase : int32_t { NDT_IDLE = 0, NDT_INIT = 1, NDT_LS_FIRST = 2, NDT_LS_ITER = 3, NDT_LS_HESS = 4, NDT_DONE = 5 };
+enum NdtPhase : int32_t { NDT_IDLE = 0, NDT_INIT = 1, NDT_LS_FIRST = 2, NDT_LS_ITER = 3, NDT_LS_HESS = 4, NDT_DONE = 5, NDT_LS_FIRST_HESS = 6 };
 
 // Complete state of one alignment (device-resident during a batch; ~1.4 KB)
 struct NdtCtlState {
@@ -31,7 +31,8 @@ struct NdtCtlState {
     // status
     int32_t  phase;
     uint32_t n_src;
-    int32_t  converged, nr_iterations, n_evals, n_reused, cache_valid, pad0;
+    int32_t  converged, nr_iterations, n_evals, n_reused, cache_valid;
+    int32_t  split_first;  // 1: the first trial of a line search is evaluated without its Hessian, which is fetched afterwards if used (below)
     float    final_[16], transformation_[16], previous_[16];  // row-major
     double   cache_p[6], cache_nb;
     double   trans_probability, nb_sum;
@@ -422,7 +423,7 @@ MRGFE_HD void fill_eval(const NdtCtlState& s, NdtEvalDev& e)
     e.search = s.search;
 }
 
-MRGFE_HD void store_result(NdtCtlState& s, const double r[44], bool with_score_grad, bool with_hessian)
+MRGFE_HD void store_result(NdtCtlState& s, const double r[44], bool with_score_grad, bool with_hessian, bool counted = true)
 {
     if (with_score_grad) {
         s.score = r[0];
@@ -431,8 +432,8 @@ MRGFE_HD void store_result(NdtCtlState& s, const double r[44], bool with_score_g
     if (with_hessian)
         for (int k = 0; k < 36; ++k) s.H[k] = r[7 + k];
     const double nb = s.n_src ? r[kNdtNbIndex] / static_cast<double>(s.n_src) : 0.0;
-    s.nb_sum += nb;
-    s.acct_points[s.req_mode] += static_cast<double>(s.n_src);
+    if (counted) s.nb_sum += nb;  // mean neighbours per evaluation of the reference's control flow
+    s.acct_points[s.req_mode] += static_cast<double>(s.n_src);  // what was launched (byte model)
     s.acct_nb[s.req_mode] += r[kNdtNbIndex];
     // remember the pose of evaluations whose transform was built from the pose vector (line-search trials)
     if (with_score_grad && s.phase != NDT_INIT) {
@@ -510,6 +511,18 @@ MRGFE_HD int ls_flow(NdtCtlState& s, CtlNext next, double a_fin)
                     s.phase = NDT_LS_HESS;
                     return CTL_RETURN;
                 }
+                if (s.split_first) {
+                    // The first trial was accepted, so the Hessian of ITS evaluation drives the next Newton step — and in split mode
+                    // that evaluation ran without it.  The reference computes score, gradient and Hessian of the first trial in one
+                    // pass (computeDerivatives(.., true)) and throws the Hessian away whenever the search goes on (computeHessian then
+                    // recomputes it at the final step): 46 % of the iterations on the bench workload.  Here the trial costs a
+                    // score+gradient pass (1/5 of the full one) and the full pass runs at the same pose only when its Hessian is used:
+                    // same per-pair float terms, same sums up to the order of the f64 additions.  Not counted as an evaluation.
+                    s.req_mode = 0;
+                    for (int k = 0; k < 6; ++k) s.req_p[k] = s.x_t[k];
+                    s.phase = NDT_LS_FIRST_HESS;
+                    return CTL_RETURN;
+                }
                 a_fin = s.a_t;
                 next = CTL_FINISH_LS;
                 break;
@@ -537,7 +550,8 @@ MRGFE_HD int resume(NdtCtlState& s, const double r[44])
 {
     switch (s.phase) {
         case NDT_INIT:     store_result(s, r, true, true);  return CTL_NEED_SOLVE;
-        case NDT_LS_FIRST: store_result(s, r, true, true);  ls_after_eval(s); return ls_flow(s, CTL_LS_DECIDE, 0.0);
+        case NDT_LS_FIRST: store_result(s, r, true, !s.split_first); ls_after_eval(s); return ls_flow(s, CTL_LS_DECIDE, 0.0);
+        case NDT_LS_FIRST_HESS: store_result(s, r, false, true, false); return ls_flow(s, CTL_FINISH_LS, s.a_t);
         case NDT_LS_ITER:  store_result(s, r, true, false); return ls_flow(s, CTL_LS_UPDATE, 0.0);
         case NDT_LS_HESS:  store_result(s, r, false, true); return ls_flow(s, CTL_FINISH_LS, s.a_t);
         default: return CTL_RETURN;
@@ -582,7 +596,7 @@ MRGFE_HD int after_solve(NdtCtlState& s, const double delta[6])
     s.a_t = dmax(s.a_t, step_min);
     for (int k = 0; k < 6; ++k) s.x_t[k] = s.x[k] + s.dir[k] * s.a_t;
     pose_to_matrix(s.x_t, s.final_);
-    make_request(s, 0, s.x_t);
+    make_request(s, s.split_first ? 1 : 0, s.x_t);
     s.phase = NDT_LS_FIRST;
     return CTL_RETURN;
 }

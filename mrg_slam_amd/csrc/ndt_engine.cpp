@@ -362,9 +362,9 @@ int NdtEngine::upload_pairs()
 //       publishes in pinned memory to know when to stop.  No host round trip inside a batch.
 //   host control (single registrations, MRGFE_HOST_CONTROL=1): the reduced sums come back through pinned memory and the host
 //       steps the same state machine (ndt_ctl.h), one synchronisation per round.
-// HIP events around the derivative launches (what mrgfe_*_kernel_stats reports): 2 = every variant (default), 1 = only the
-// dominant score+gradient+Hessian variant, 0 = none.  MRGFE_KERNEL_TIMING overrides.
-static int timing_level() { static const int v = [] { const char* e = std::getenv("MRGFE_KERNEL_TIMING"); return e ? std::atoi(e) : 2; }(); return v; }
+// HIP events around the derivative launches (what mrgfe_*_kernel_stats reports): 2 = every variant, 1 = only the dominant
+// score+gradient+Hessian variant (default: each event pair costs ~4 us of queue gap per round), 0 = none.  MRGFE_KERNEL_TIMING.
+static int timing_level() { static const int v = [] { const char* e = std::getenv("MRGFE_KERNEL_TIMING"); return e ? std::atoi(e) : 1; }(); return v; }
 
 constexpr int kHostParallelMinPairs = 48;  // below this the controller steps of a round run on the calling thread
 
@@ -382,7 +382,7 @@ static int env_int(const char* name, int dflt) { const char* e = std::getenv(nam
 // grid of a derivative launch: a few workgroups per resident slot; they walk the plan's items (item += gridDim.x)
 uint32_t NdtEngine::derivative_grid(int mode) const
 {
-    static const int per_slot = std::max(1, env_int("MRGFE_GRID_PER_SLOT", 4));
+    static const int per_slot = std::max(1, env_int("MRGFE_GRID_PER_SLOT", 8));
     const int slots_per_cu = (mode != 1 && prm_.search != MRGFE_KDTREE && prm_.search != MRGFE_DIRECT26) ? 3 : 2;  // __launch_bounds__ of the variants
     return static_cast<uint32_t>(ctx_->cu_count * slots_per_cu * per_slot);
 }
@@ -452,10 +452,14 @@ int NdtEngine::align_all()
     if (P == 0) return MRGFE_OK;
     NdtEvalDev*  he = h_evals_.as<NdtEvalDev>();
     NdtCtlState* hs = h_states_.as<NdtCtlState>();
+    // MRGFE_SPLIT_FIRST=1: evaluate the first trial of a line search without its Hessian and fetch that by a second pass only when
+    // the trial is accepted (ndt_ctl.h).  Same results, 25 % less derivative work on the bench workload — and measured SLOWER
+    // (13.6 vs 13.0 ms per 256-pair step): the fetches add rounds, and in lock-step rounds every extra launch pays its own tail.
+    static const bool split_first = env_int("MRGFE_SPLIT_FIRST", 0) != 0;
     int running = 0;
     for (int i = 0; i < P; ++i) {
         NdtPairInfo& p = pairs_[i];
-        p.ctl.start(prm_, p.guess, p.n);
+        p.ctl.start(prm_, p.guess, p.n, split_first);
         if (targets_[p.target].status != MRGFE_OK && !p.ctl.done()) p.ctl.abort_no_target();
         he[i].active = 0;
         p.ctl.fill_eval(he[i]);
@@ -472,7 +476,7 @@ int NdtEngine::align_all()
     std::vector<NdtRoundInfo> info;
 
     if (device_control) {
-        static const size_t lookahead = static_cast<size_t>(std::max(1, env_int("MRGFE_LOOKAHEAD", 3)));
+        static const size_t lookahead = static_cast<size_t>(std::max(1, env_int("MRGFE_LOOKAHEAD", 2)));
         for (int i = 0; i < P; ++i) hs[i] = pairs_[i].ctl.state();
         MRGFE_HIP_CHECK(hipMemcpyAsync(d_states_.p, hs, sizeof(NdtCtlState) * P, hipMemcpyHostToDevice, st));
         MRGFE_TRY(h_info_.ensure(sizeof(NdtRoundInfo) * (round_cap + lookahead + 2)));

@@ -34,10 +34,18 @@ def _drive(orc_ndt, params, guess, n_src):
         lib().mrgfe_dbg_ctl_destroy(h)
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("seed,eps,search,res", [(1, 0.1, "DIRECT7", 1.0), (2, 0.01, "DIRECT7", 1.0), (3, 0.001, "DIRECT7", 2.0), (4, 0.01, "DIRECT1", 1.0),
                                                  (5, 0.1, "KDTREE", 1.5), (6, 0.01, "DIRECT7", 0.5), (7, 0.1, "DIRECT7", 1.0), (8, 0.01, "DIRECT26", 1.0)])
-def test_state_machine_follows_the_oracle(seed, eps, search, res):
+def test_state_machine_follows_the_oracle(seed, eps, search, res, split, monkeypatch):
+    """split: the batch engine's variant — first trial of a line search without its Hessian, fetched by a second pass at the same
+    pose only when the trial is accepted (csrc/ndt_ctl.h); must end exactly where the single-pass flow ends"""
     from mrg_slam_amd import synth
+
+    if split:
+        monkeypatch.setenv("MRGFE_DBG_CTL_SPLIT", "1")
+    else:
+        monkeypatch.delenv("MRGFE_DBG_CTL_SPLIT", raising=False)
     from mrg_slam_amd._lib import NDT_HIP, SEARCH
     from mrg_slam_amd.registration import default_params
     from oracle import oracle as orc
@@ -62,6 +70,8 @@ def test_state_machine_follows_the_oracle(seed, eps, search, res):
     assert ev == o.evals  # the cached repeats of a clamped trial are counted like the reference's recomputations
     assert np.linalg.norm(T[:3, 3].astype(np.float64) - To[:3, 3]) <= 1e-6 and synth.rotation_angle(T, To) <= 1e-6
     assert modes[0] == 0 and set(modes) <= {0, 1, 2}
+    if split:  # every full pass after the first is a Hessian fetch right behind the score+gradient pass of an accepted first trial
+        assert all(modes[k - 1] == 1 for k in range(1, len(modes)) if modes[k] == 0)
 
 
 def test_degenerate_starts():
