@@ -261,13 +261,103 @@ static inline double dot3d(double a0, double b0, double a1, double b1, double a2
     return a0 * b0 + a1 * b1 + a2 * b2;
 }
 
+// updateDerivatives for one (point, voxel) pair, float form: score increment, gradient terms t_g[6] and (compute_hessian) the 36
+// Hessian terms t_h, each the rounded float the reference widens to double and adds.  false: the pair fails the e_x_cov_x range check
+// and contributes nothing.
+namespace {
+struct PointTermsF {
+    float xt[3];
+    float J3[3], J4[3], J5[3];
+    float ha[3], hb[3], hc[3], hd[3], he[3], hf[3];
+};
+template <bool FUSED>
+inline void point_terms_f(const float xt[3], const float x4[3], const float j_ang_f[8][3], const float h_ang_f[15][3], PointTermsF& P)
+{
+    // computePointDerivatives (float form): x_j_ang = j_ang * x4 ; x_h_ang = h_ang * x4
+    float xj[8], xh[15];
+    for (int r = 0; r < 8; ++r) xj[r] = dot3f<FUSED>(j_ang_f[r][0], x4[0], j_ang_f[r][1], x4[1], j_ang_f[r][2], x4[2]);
+    for (int r = 0; r < 15; ++r) xh[r] = dot3f<FUSED>(h_ang_f[r][0], x4[0], h_ang_f[r][1], x4[1], h_ang_f[r][2], x4[2]);
+    for (int a = 0; a < 3; ++a) P.xt[a] = xt[a];
+    // point_gradient4 columns 3..5 (rows 0..2); columns 0..2 = identity
+    P.J3[0] = 0.0f; P.J3[1] = xj[0]; P.J3[2] = xj[1];
+    P.J4[0] = xj[2]; P.J4[1] = xj[3]; P.J4[2] = xj[4];
+    P.J5[0] = xj[5]; P.J5[1] = xj[6]; P.J5[2] = xj[7];
+    // point_hessian blocks (3-vectors): a,b,c,d,e,f
+    P.ha[0] = 0.0f; P.ha[1] = xh[0]; P.ha[2] = xh[1];
+    P.hb[0] = 0.0f; P.hb[1] = xh[2]; P.hb[2] = xh[3];
+    P.hc[0] = 0.0f; P.hc[1] = xh[4]; P.hc[2] = xh[5];
+    P.hd[0] = xh[6]; P.hd[1] = xh[7]; P.hd[2] = xh[8];
+    P.he[0] = xh[9]; P.he[1] = xh[10]; P.he[2] = xh[11];
+    P.hf[0] = xh[12]; P.hf[1] = xh[13]; P.hf[2] = xh[14];
+}
+template <bool FUSED>
+inline bool pair_terms_f(const PointTermsF& P, const NdtLeaf& cell, float gauss_d2f, double gd1, bool compute_hessian, float* score_inc_out, float t_g[6], float t_h[36])
+{
+    const float* xt = P.xt;
+    const float *J3 = P.J3, *J4 = P.J4, *J5 = P.J5;
+    // PH[i][j] for i,j in 3..5 : block (i*4, j)
+    const float* PH[3][3] = {{P.ha, P.hb, P.hc}, {P.hb, P.hd, P.he}, {P.hc, P.he, P.hf}};
+    // x_trans (double) -= mean ; cast to float
+    const float q[3] = {static_cast<float>(static_cast<double>(xt[0]) - cell.mean[0]), static_cast<float>(static_cast<double>(xt[1]) - cell.mean[1]),
+                        static_cast<float>(static_cast<double>(xt[2]) - cell.mean[2])};
+    float C[9];
+    for (int t = 0; t < 9; ++t) C[t] = static_cast<float>(cell.icov[t]);
+    // qC = x_trans4 * c_inv4 (row vector times matrix)
+    float qC[3];
+    for (int c = 0; c < 3; ++c) qC[c] = dot3f<FUSED>(q[0], C[0 * 3 + c], q[1], C[1 * 3 + c], q[2], C[2 * 3 + c]);
+    float qCq = dot3f<FUSED>(q[0], qC[0], q[1], qC[1], q[2], qC[2]);
+    float arg0 = -gauss_d2f * qCq;
+    float arg = arg0 * 0.5f;
+    float e_x_cov_x = static_cast<float>(std::exp(static_cast<double>(arg)));
+    float score_inc = static_cast<float>(-gd1 * static_cast<double>(e_x_cov_x));
+    e_x_cov_x = gauss_d2f * e_x_cov_x;
+    if (e_x_cov_x > 1 || e_x_cov_x < 0 || e_x_cov_x != e_x_cov_x) return false;
+    e_x_cov_x = static_cast<float>(static_cast<double>(e_x_cov_x) * gd1);
+    // CJ = c_inv4 * point_gradient4 : columns 0..2 = C, columns 3..5 = C * J3/J4/J5
+    float CJ[3][6];
+    for (int r = 0; r < 3; ++r) {
+        CJ[r][0] = C[r * 3 + 0]; CJ[r][1] = C[r * 3 + 1]; CJ[r][2] = C[r * 3 + 2];
+        CJ[r][3] = dot3f<FUSED>(C[r * 3 + 0], J3[0], C[r * 3 + 1], J3[1], C[r * 3 + 2], J3[2]);
+        CJ[r][4] = dot3f<FUSED>(C[r * 3 + 0], J4[0], C[r * 3 + 1], J4[1], C[r * 3 + 2], J4[2]);
+        CJ[r][5] = dot3f<FUSED>(C[r * 3 + 0], J5[0], C[r * 3 + 1], J5[1], C[r * 3 + 2], J5[2]);
+    }
+    float qCJ[6];
+    for (int c = 0; c < 6; ++c) qCJ[c] = dot3f<FUSED>(q[0], CJ[0][c], q[1], CJ[1][c], q[2], CJ[2][c]);
+    for (int c = 0; c < 6; ++c) t_g[c] = e_x_cov_x * qCJ[c];
+    *score_inc_out = score_inc;
+    if (!compute_hessian) return true;
+    // JtCJ(a,b) = J(:,a) . CJ(:,b)
+    const float* Jc[6] = {nullptr, nullptr, nullptr, J3, J4, J5};
+    float JtCJ[6][6];
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b)
+            JtCJ[a][b] = (a < 3) ? CJ[a][b] : dot3f<FUSED>(Jc[a][0], CJ[0][b], Jc[a][1], CJ[1][b], Jc[a][2], CJ[2][b]);
+    for (int i = 0; i < 6; ++i) {
+        float qCH[6] = {0, 0, 0, 0, 0, 0};
+        if (i >= 3)
+            for (int j = 3; j < 6; ++j) { const float* v = PH[i - 3][j - 3]; qCH[j] = dot3f<FUSED>(qC[0], v[0], qC[1], v[1], qC[2], v[2]); }
+        for (int j = 0; j < 6; ++j) {
+            float t0 = -gauss_d2f * qCJ[i];
+            float t2;
+            if (FUSED) { t2 = std::fmaf(t0, qCJ[j], qCH[j]); }
+            else       { float t1 = t0 * qCJ[j]; t2 = t1 + qCH[j]; }
+            float t3 = t2 + JtCJ[j][i];
+            t_h[i * 6 + j] = e_x_cov_x * t3;
+        }
+    }
+    return true;
+}
+}  // namespace
+
 double Ndt::compute_derivatives(double grad[6], double hess[36], const double p[6], bool compute_hessian)
 {
+    if (gpu_order_ppt > 0) return compute_derivatives_gpu_order(grad, hess, p, compute_hessian);
     return fused ? compute_derivatives_impl<true>(grad, hess, p, compute_hessian) : compute_derivatives_impl<false>(grad, hess, p, compute_hessian);
 }
 
 void Ndt::compute_hessian(double hess[36], const double p[6])
 {
+    if (gpu_order_ppt > 0) { compute_hessian_gpu_order(hess, p); return; }
     if (fused) compute_hessian_impl<true>(hess, p);
     else       compute_hessian_impl<false>(hess, p);
 }
@@ -295,74 +385,19 @@ double Ndt::compute_derivatives_impl(double grad[6], double hess[36], const doub
         const float* xp = &source[4 * static_cast<size_t>(idx)];
         // Vector3d x(x_pt.x, ..) -> Vector4f x4: float -> double -> float is the identity
         const float x4[3] = {xp[0], xp[1], xp[2]};
-        // computePointDerivatives (float form): x_j_ang = j_ang * x4 ; x_h_ang = h_ang * x4
-        float xj[8], xh[15];
-        for (int r = 0; r < 8; ++r) xj[r] = dot3f<FUSED>(j_ang_f[r][0], x4[0], j_ang_f[r][1], x4[1], j_ang_f[r][2], x4[2]);
-        for (int r = 0; r < 15; ++r) xh[r] = dot3f<FUSED>(h_ang_f[r][0], x4[0], h_ang_f[r][1], x4[1], h_ang_f[r][2], x4[2]);
-        // point_gradient4 columns 3..5 (rows 0..2); columns 0..2 = identity
-        const float J3[3] = {0.0f, xj[0], xj[1]};
-        const float J4[3] = {xj[2], xj[3], xj[4]};
-        const float J5[3] = {xj[5], xj[6], xj[7]};
-        // point_hessian blocks (3-vectors): a,b,c,d,e,f
-        const float ha[3] = {0.0f, xh[0], xh[1]}, hb[3] = {0.0f, xh[2], xh[3]}, hc[3] = {0.0f, xh[4], xh[5]};
-        const float hd[3] = {xh[6], xh[7], xh[8]}, he[3] = {xh[9], xh[10], xh[11]}, hf[3] = {xh[12], xh[13], xh[14]};
-        // PH[i][j] for i,j in 3..5 : block (i*4, j)
-        const float* PH[3][3] = {{ha, hb, hc}, {hb, hd, he}, {hc, he, hf}};
+        PointTermsF P;
+        point_terms_f<FUSED>(xt, x4, j_ang_f, h_ang_f, P);
 
         double  score_pt = 0;
         double* g_pt = &grads_[static_cast<size_t>(idx) * 6];
         double* h_pt = &hessians_[static_cast<size_t>(idx) * 36];
         for (int k = 0; k < cnt; ++k) {
-            const NdtLeaf& cell = cells.leaves[nb[k]];
-            // x_trans (double) -= mean ; cast to float
-            const float q[3] = {static_cast<float>(static_cast<double>(xt[0]) - cell.mean[0]), static_cast<float>(static_cast<double>(xt[1]) - cell.mean[1]),
-                                static_cast<float>(static_cast<double>(xt[2]) - cell.mean[2])};
-            float C[9];
-            for (int t = 0; t < 9; ++t) C[t] = static_cast<float>(cell.icov[t]);
-            // qC = x_trans4 * c_inv4 (row vector times matrix)
-            float qC[3];
-            for (int c = 0; c < 3; ++c) qC[c] = dot3f<FUSED>(q[0], C[0 * 3 + c], q[1], C[1 * 3 + c], q[2], C[2 * 3 + c]);
-            float qCq = dot3f<FUSED>(q[0], qC[0], q[1], qC[1], q[2], qC[2]);
-            float arg0 = -gauss_d2f * qCq;
-            float arg = arg0 * 0.5f;
-            float e_x_cov_x = static_cast<float>(std::exp(static_cast<double>(arg)));
-            float score_inc = static_cast<float>(-gd1 * static_cast<double>(e_x_cov_x));
-            e_x_cov_x = gauss_d2f * e_x_cov_x;
-            if (e_x_cov_x > 1 || e_x_cov_x < 0 || e_x_cov_x != e_x_cov_x) continue;
-            e_x_cov_x = static_cast<float>(static_cast<double>(e_x_cov_x) * gd1);
-            // CJ = c_inv4 * point_gradient4 : columns 0..2 = C, columns 3..5 = C * J3/J4/J5
-            float CJ[3][6];
-            for (int r = 0; r < 3; ++r) {
-                CJ[r][0] = C[r * 3 + 0]; CJ[r][1] = C[r * 3 + 1]; CJ[r][2] = C[r * 3 + 2];
-                CJ[r][3] = dot3f<FUSED>(C[r * 3 + 0], J3[0], C[r * 3 + 1], J3[1], C[r * 3 + 2], J3[2]);
-                CJ[r][4] = dot3f<FUSED>(C[r * 3 + 0], J4[0], C[r * 3 + 1], J4[1], C[r * 3 + 2], J4[2]);
-                CJ[r][5] = dot3f<FUSED>(C[r * 3 + 0], J5[0], C[r * 3 + 1], J5[1], C[r * 3 + 2], J5[2]);
-            }
-            float qCJ[6];
-            for (int c = 0; c < 6; ++c) qCJ[c] = dot3f<FUSED>(q[0], CJ[0][c], q[1], CJ[1][c], q[2], CJ[2][c]);
-            for (int c = 0; c < 6; ++c) { float t = e_x_cov_x * qCJ[c]; g_pt[c] += static_cast<double>(t); }
+            float score_inc, t_g[6], t_h[36];
+            if (!pair_terms_f<FUSED>(P, cells.leaves[nb[k]], gauss_d2f, gd1, compute_hessian, &score_inc, t_g, t_h)) continue;
+            for (int c = 0; c < 6; ++c) g_pt[c] += static_cast<double>(t_g[c]);
             score_pt += static_cast<double>(score_inc);
             if (!compute_hessian) continue;
-            // JtCJ(a,b) = J(:,a) . CJ(:,b)
-            const float* Jc[6] = {nullptr, nullptr, nullptr, J3, J4, J5};
-            float JtCJ[6][6];
-            for (int a = 0; a < 6; ++a)
-                for (int b = 0; b < 6; ++b)
-                    JtCJ[a][b] = (a < 3) ? CJ[a][b] : dot3f<FUSED>(Jc[a][0], CJ[0][b], Jc[a][1], CJ[1][b], Jc[a][2], CJ[2][b]);
-            for (int i = 0; i < 6; ++i) {
-                float qCH[6] = {0, 0, 0, 0, 0, 0};
-                if (i >= 3)
-                    for (int j = 3; j < 6; ++j) { const float* v = PH[i - 3][j - 3]; qCH[j] = dot3f<FUSED>(qC[0], v[0], qC[1], v[1], qC[2], v[2]); }
-                for (int j = 0; j < 6; ++j) {
-                    float t0 = -gauss_d2f * qCJ[i];
-                    float t2;
-                    if (FUSED) { t2 = std::fmaf(t0, qCJ[j], qCH[j]); }
-                    else       { float t1 = t0 * qCJ[j]; t2 = t1 + qCH[j]; }
-                    float t3 = t2 + JtCJ[j][i];
-                    float t4 = e_x_cov_x * t3;
-                    h_pt[i * 6 + j] += static_cast<double>(t4);
-                }
-            }
+            for (int c = 0; c < 36; ++c) h_pt[c] += static_cast<double>(t_h[c]);
         }
         scores_[idx] = score_pt;
     }
@@ -435,6 +470,186 @@ void Ndt::compute_hessian_impl(double hess[36], const double p[6])
         }
     }
     neighbours_sum += n > 0 ? static_cast<double>(nb_total) / n : 0.0;
+}
+
+// ---- diagnostic: the HIP kernels' operation ORDER on the CPU ------------------------------------------------------------------
+// gpu_order_ppt > 0 makes compute_derivatives / compute_hessian add their terms in the order ndt_derivatives_kernel and
+// ndt_reduce_kernel do (mrg_slam_amd/csrc/ndt_derivatives.hip): items of gpu_order_ppt tiles of 256 points; per tile the occupied
+// (point, voxel) pairs queued point by point in probe order and dealt round-robin to 256 lanes, every lane adding its pairs' float
+// terms to f64 accumulators; a 64-lane shuffle tree (offsets 32..1), the four waves as ((w0 + w1) + w2) + w3; the item partials of an
+// evaluation in four interleaved slices, combined the same way.  The f64 Hessian pass is the kernel's per-point factorisation (one lane
+// per point).  With the same per-pair float terms this reproduces the GPU's sums bit for bit (float path; the f64 pass differs where
+// the two C libraries' exp differ in the last bit), so a test can tell summation-order noise from an arithmetic difference.
+namespace {
+inline void gpu_tree_reduce(std::vector<double>& acc /* [256][48] */, double out[48])
+{
+    double waves[4][48];
+    for (int w = 0; w < 4; ++w)
+        for (int k = 0; k < 48; ++k) {
+            double v[64];
+            for (int l = 0; l < 64; ++l) v[l] = acc[static_cast<size_t>(w * 64 + l) * 48 + k];
+            for (int off = 32; off > 0; off >>= 1)
+                for (int l = 0; l < off; ++l) v[l] = v[l] + v[l + off];
+            waves[w][k] = v[0];
+        }
+    for (int k = 0; k < 48; ++k) out[k] = ((waves[0][k] + waves[1][k]) + waves[2][k]) + waves[3][k];
+}
+inline void gpu_slice_reduce(const std::vector<double>& partials /* [nblk][48] */, size_t nblk, double out[48])
+{
+    for (int k = 0; k < 48; ++k) {
+        double s[4] = {0, 0, 0, 0};
+        for (int sl = 0; sl < 4; ++sl)
+            for (size_t b = sl; b < nblk; b += 4) s[sl] += partials[b * 48 + k];
+        out[k] = ((s[0] + s[1]) + s[2]) + s[3];
+    }
+}
+}  // namespace
+
+int Ndt::neighbours_probe_order(float x, float y, float z, int out[27]) const
+{
+    if (search != NDT_KDTREE) return cells.neighbours(x, y, z, search, out);
+    // the kernel keeps the 27 probes in probe order and drops the centroids outside the radius; the reference sorts by distance
+    int all[27];
+    const int m = cells.neighbours(x, y, z, NDT_DIRECT26, all);
+    int cnt = 0;
+    const float r2 = cells.leaf_size * cells.leaf_size;
+    for (int k = 0; k < m; ++k) {
+        const float* c = cells.leaves[all[k]].centroid;
+        const float dx = c[0] - x, dy = c[1] - y, dz = c[2] - z;
+        float d = dx * dx;
+        d += dy * dy;
+        d += dz * dz;
+        if (d < r2) out[cnt++] = all[k];
+    }
+    return cnt;
+}
+
+double Ndt::compute_derivatives_gpu_order(double grad[6], double hess[36], const double p[6], bool compute_hessian)
+{
+    const int n = static_cast<int>(source.size() / 4);
+    angle_derivatives(p, true);
+    ++n_evals;
+    const float  gauss_d2f = static_cast<float>(gauss_d2);
+    const double gd1 = gauss_d1;
+    const int    per_item = 256 * gpu_order_ppt;
+    const size_t nblk = static_cast<size_t>((n + per_item - 1) / per_item);
+    std::vector<double> partials(std::max<size_t>(nblk, 1) * 48, 0.0);
+    long long nb_total = 0;
+    for (size_t item = 0; item < nblk; ++item) {
+        std::vector<double> acc(256 * 48, 0.0);
+        const int base = static_cast<int>(item) * per_item, last = std::min(n, base + per_item);
+        for (int tile0 = base; tile0 < last; tile0 += 256) {
+            std::vector<PointTermsF> pts(256);
+            std::vector<std::pair<int, int>> queue;  // (slot, leaf)
+            for (int t = 0; t < 256 && tile0 + t < last; ++t) {
+                const int idx = tile0 + t;
+                const float xt[3] = {trans_[3 * idx], trans_[3 * idx + 1], trans_[3 * idx + 2]};
+                int nb[27];
+                const int cnt = neighbours_probe_order(xt[0], xt[1], xt[2], nb);
+                if (!cnt) continue;
+                const float* xp = &source[4 * static_cast<size_t>(idx)];
+                const float x4[3] = {xp[0], xp[1], xp[2]};
+                point_terms_f<true>(xt, x4, j_ang_f, h_ang_f, pts[t]);
+                for (int k = 0; k < cnt; ++k) queue.emplace_back(t, nb[k]);
+            }
+            nb_total += static_cast<long long>(queue.size());
+            for (size_t qi = 0; qi < queue.size(); ++qi) {
+                double* a = &acc[(qi % 256) * 48];
+                float score_inc, t_g[6], t_h[36];
+                if (!pair_terms_f<true>(pts[queue[qi].first], cells.leaves[queue[qi].second], gauss_d2f, gd1, compute_hessian, &score_inc, t_g, t_h)) continue;
+                for (int c = 0; c < 6; ++c) a[1 + c] += static_cast<double>(t_g[c]);
+                a[0] += static_cast<double>(score_inc);
+                if (compute_hessian)
+                    for (int c = 0; c < 36; ++c) a[7 + c] += static_cast<double>(t_h[c]);
+            }
+        }
+        gpu_tree_reduce(acc, &partials[item * 48]);
+    }
+    double r[48];
+    gpu_slice_reduce(partials, nblk, r);
+    neighbours_sum += n > 0 ? static_cast<double>(nb_total) / n : 0.0;
+    for (int k = 0; k < 6; ++k) grad[k] = r[1 + k];
+    for (int k = 0; k < 36; ++k) hess[k] = compute_hessian ? r[7 + k] : 0.0;
+    return r[0];
+}
+
+void Ndt::compute_hessian_gpu_order(double hess[36], const double p[6])
+{
+    (void)p;
+    const int n = static_cast<int>(source.size() / 4);
+    ++n_evals;
+    const int    per_item = 256 * gpu_order_ppt;
+    const size_t nblk = static_cast<size_t>((n + per_item - 1) / per_item);
+    std::vector<double> partials(std::max<size_t>(nblk, 1) * 48, 0.0);
+    long long nb_total = 0;
+    auto fd3 = [](double a0, double b0, double a1, double b1, double a2, double b2) { return std::fma(a2, b2, std::fma(a1, b1, a0 * b0)); };
+    auto fd3z = [](double a1, double b1, double a2, double b2) { return std::fma(a2, b2, a1 * b1); };
+    for (size_t item = 0; item < nblk; ++item) {
+        std::vector<double> acc(256 * 48, 0.0);
+        const int base = static_cast<int>(item) * per_item, last = std::min(n, base + per_item);
+        for (int idx = base; idx < last; ++idx) {
+            double* H = &acc[static_cast<size_t>((idx - base) % 256) * 48] + 7;  // this lane's 36 Hessian slots (upper triangle used)
+            const float xt[3] = {trans_[3 * idx], trans_[3 * idx + 1], trans_[3 * idx + 2]};
+            int nb[27];
+            const int cnt = neighbours_probe_order(xt[0], xt[1], xt[2], nb);
+            nb_total += cnt;
+            if (!cnt) continue;
+            const float* xp = &source[4 * static_cast<size_t>(idx)];
+            const double x[3] = {xp[0], xp[1], xp[2]};
+            double M1[6] = {0, 0, 0, 0, 0, 0}, M2[6] = {0, 0, 0, 0, 0, 0}, w[3] = {0, 0, 0};
+            for (int k = 0; k < cnt; ++k) {
+                const NdtLeaf& cell = cells.leaves[nb[k]];
+                const double*  C = cell.icov;
+                const double   q[3] = {static_cast<double>(xt[0]) - cell.mean[0], static_cast<double>(xt[1]) - cell.mean[1], static_cast<double>(xt[2]) - cell.mean[2]};
+                double v[3];
+                for (int r = 0; r < 3; ++r) v[r] = fd3(C[r * 3 + 0], q[0], C[r * 3 + 1], q[1], C[r * 3 + 2], q[2]);
+                double e = gauss_d2 * std::exp(-gauss_d2 * fd3(q[0], v[0], q[1], v[1], q[2], v[2]) / 2);
+                if (e > 1 || e < 0 || e != e) continue;
+                e *= gauss_d1;
+                const double ev3[3] = {e * v[0], e * v[1], e * v[2]};
+                M1[0] = std::fma(e, C[0], M1[0]); M1[1] = std::fma(e, C[1], M1[1]); M1[2] = std::fma(e, C[2], M1[2]);
+                M1[3] = std::fma(e, C[4], M1[3]); M1[4] = std::fma(e, C[5], M1[4]); M1[5] = std::fma(e, C[8], M1[5]);
+                M2[0] = std::fma(ev3[0], v[0], M2[0]); M2[1] = std::fma(ev3[0], v[1], M2[1]); M2[2] = std::fma(ev3[0], v[2], M2[2]);
+                M2[3] = std::fma(ev3[1], v[1], M2[3]); M2[4] = std::fma(ev3[1], v[2], M2[4]); M2[5] = std::fma(ev3[2], v[2], M2[5]);
+                w[0] += ev3[0]; w[1] += ev3[1]; w[2] += ev3[2];
+            }
+            double a[6];
+            for (int k = 0; k < 6; ++k) a[k] = std::fma(-gauss_d2, M2[k], M1[k]);
+            const double A[3][3] = {{a[0], a[1], a[2]}, {a[1], a[3], a[4]}, {a[2], a[4], a[5]}};
+            double xj[8], xh[15];
+            for (int r = 0; r < 8; ++r) xj[r] = fd3(x[0], j_ang_d[r][0], x[1], j_ang_d[r][1], x[2], j_ang_d[r][2]);
+            for (int r = 0; r < 15; ++r) xh[r] = fd3(x[0], h_ang_d[r][0], x[1], h_ang_d[r][1], x[2], h_ang_d[r][2]);
+            const double Jr[3][3] = {{0.0, xj[2], xj[5]}, {xj[0], xj[3], xj[6]}, {xj[1], xj[4], xj[7]}};
+            double AJ[3][3];
+            for (int r = 0; r < 3; ++r) {
+                AJ[r][0] = fd3z(A[r][1], Jr[1][0], A[r][2], Jr[2][0]);
+                AJ[r][1] = fd3(A[r][0], Jr[0][1], A[r][1], Jr[1][1], A[r][2], Jr[2][1]);
+                AJ[r][2] = fd3(A[r][0], Jr[0][2], A[r][1], Jr[1][2], A[r][2], Jr[2][2]);
+            }
+            H[0 * 6 + 0] += A[0][0]; H[0 * 6 + 1] += A[0][1]; H[0 * 6 + 2] += A[0][2]; H[1 * 6 + 1] += A[1][1]; H[1 * 6 + 2] += A[1][2]; H[2 * 6 + 2] += A[2][2];
+            for (int i = 0; i < 3; ++i)
+                for (int c = 0; c < 3; ++c) H[i * 6 + 3 + c] += AJ[i][c];
+            const double PH[6][3] = {{0, xh[0], xh[1]}, {0, xh[2], xh[3]}, {0, xh[4], xh[5]}, {xh[6], xh[7], xh[8]}, {xh[9], xh[10], xh[11]}, {xh[12], xh[13], xh[14]}};
+            for (int i = 0; i < 3; ++i)
+                for (int j = i; j < 3; ++j) {
+                    const int ph = (i == 0) ? j : (i == 1 ? j + 2 : 5);
+                    const double jaj = (i == 0) ? fd3z(Jr[1][0], AJ[1][j], Jr[2][0], AJ[2][j]) : fd3(Jr[0][i], AJ[0][j], Jr[1][i], AJ[1][j], Jr[2][i], AJ[2][j]);
+                    const double wph = (ph < 3) ? fd3z(w[1], PH[ph][1], w[2], PH[ph][2]) : fd3(w[0], PH[ph][0], w[1], PH[ph][1], w[2], PH[ph][2]);
+                    H[(3 + i) * 6 + 3 + j] += jaj + wph;
+                }
+        }
+        // the kernel mirrors the upper triangle of every lane before the tree
+        for (int l = 0; l < 256; ++l) {
+            double* H = &acc[static_cast<size_t>(l) * 48] + 7;
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < i; ++j) H[i * 6 + j] = H[j * 6 + i];
+        }
+        gpu_tree_reduce(acc, &partials[item * 48]);
+    }
+    double r[48];
+    gpu_slice_reduce(partials, nblk, r);
+    neighbours_sum += n > 0 ? static_cast<double>(nb_total) / n : 0.0;
+    for (int k = 0; k < 36; ++k) hess[k] = r[7 + k];
 }
 
 double Ndt::evaluate(const float T[16], const double p[6], int mode, double grad[6], double hess[36])

@@ -48,6 +48,7 @@ struct Ndt {
     int    num_threads       = 1;
     NdtSearch search         = NDT_DIRECT7;
     bool   fused             = true;   // float/double three-term products accumulated with FMA (see ndt.cpp dot3f)
+    int    gpu_order_ppt     = 0;      // > 0: diagnostic — add the terms in the HIP kernels' order, items of this many 256-point tiles (ndt.cpp)
 
     VoxelGridCovariance cells;
     std::vector<float> target, source;  // xyzi
@@ -85,6 +86,9 @@ struct Ndt {
     void   transform_cloud(const float T[16]);
     double compute_derivatives(double grad[6], double hess[36], const double p[6], bool compute_hessian);
     void   compute_hessian(double hess[36], const double p[6]);
+    double compute_derivatives_gpu_order(double grad[6], double hess[36], const double p[6], bool compute_hessian);
+    void   compute_hessian_gpu_order(double hess[36], const double p[6]);
+    int    neighbours_probe_order(float x, float y, float z, int out[27]) const;
     template <bool FUSED> double compute_derivatives_impl(double grad[6], double hess[36], const double p[6], bool compute_hessian);
     template <bool FUSED> void   compute_hessian_impl(double hess[36], const double p[6]);
     double step_length_mt(const double x[6], double step_dir[6], double step_init, double step_max, double step_min, double& score,

@@ -101,6 +101,7 @@ void  orc_ndt_set_params(void* h, double resolution, double step_size, double ou
     n->resolution = static_cast<float>(resolution); n->step_size = step_size; n->outlier_ratio = outlier_ratio; n->trans_eps = trans_eps;
     n->max_iterations = max_iterations; n->num_threads = num_threads > 0 ? num_threads : 1; n->search = static_cast<NdtSearch>(search);
 }
+void orc_ndt_set_gpu_order(void* h, int ppt) { static_cast<Ndt*>(h)->gpu_order_ppt = ppt; }
 void orc_ndt_set_fused(void* h, int fused) { static_cast<Ndt*>(h)->fused = fused != 0; }
 int  orc_ndt_set_target(void* h, const float* xyzi, int n) { return static_cast<Ndt*>(h)->set_target(xyzi, n); }
 void orc_ndt_set_source(void* h, const float* xyzi, int n) { static_cast<Ndt*>(h)->set_source(xyzi, n); }

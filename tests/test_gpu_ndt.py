@@ -210,3 +210,32 @@ def test_non_finite_and_degenerate_inputs_match_oracle():
     o.align(np.eye(4))
     np.testing.assert_array_equal(g.getFinalTransformation(), o.getFinalTransformation())
     assert g.hasConverged() == o.hasConverged()
+
+
+@pytest.mark.parametrize("search", ["DIRECT7", "DIRECT1", "DIRECT26", "KDTREE"])
+def test_evaluation_is_bit_identical_to_the_oracle_in_gpu_order(search):
+    """The oracle adding the same per-pair float terms in the kernels' summation order (gpu_order_ppt, oracle/ndt.cpp) must
+    reproduce a GPU evaluation BIT FOR BIT — score, gradient, Hessian — for the float path (modes 0, 1).  The f64 Hessian pass
+    (mode 2, per-point factorisation) agrees to the last bits of the two C libraries' exp."""
+    from mrg_slam_amd import NdtHip, synth
+    from oracle import oracle as orc
+
+    tgt, src, rel = _pair(7000, seed=9)
+    g = NdtHip(transformation_epsilon=0.01, search=search)
+    o = orc.Ndt(transformation_epsilon=0.01, num_threads=1, search=search, gpu_order_ppt=1)  # mrgfe_ndt_evaluate launches one tile per item
+    assert g.setInputTarget(tgt) == 0 and o.setInputTarget(tgt) == 0
+    g.setInputSource(src)
+    o.setInputSource(src)
+    rng = np.random.default_rng(4)
+    for trial in range(6):
+        T = synth.perturb_pose(rel, rng)
+        p = np.concatenate([T[:3, 3], rng.normal(0, 0.05, 3)])
+        for mode in (0, 1):
+            sg, gg, Hg = g.evaluate(T, p, mode)
+            so, go, Ho = o.evaluate(T, p, mode)
+            assert sg == so and np.array_equal(gg, go), (search, trial, mode)
+            if mode == 0:
+                assert np.array_equal(Hg, Ho), (search, trial)
+        _, _, Hg = g.evaluate(T, p, 2)
+        _, _, Ho = o.evaluate(T, p, 2)
+        np.testing.assert_allclose(Hg, Ho, rtol=0, atol=1e-14 * np.abs(Ho).max())

@@ -156,3 +156,30 @@ def test_fused_and_unfused_float_sequences_agree(eps):
     (Ta, ca, ia, ea), (Tb, cb, ib, eb) = res
     assert (ca, ia, ea) == (cb, ib, eb)
     assert np.linalg.norm(Ta[:3, 3] - Tb[:3, 3]) < 1e-5 and synth.rotation_angle(Ta, Tb) < 1e-5
+
+
+@pytest.mark.parametrize("search", ["DIRECT7", "DIRECT1", "DIRECT26", "KDTREE"])
+def test_gpu_order_mode_only_reorders_the_sums(search):
+    """oracle.Ndt(gpu_order_ppt=k) adds the same per-pair terms in the HIP kernels' order (diagnostic mode): score, gradient and
+    Hessian equal the reference-order values to summation-order rounding, for every tile count per item."""
+    from conftest import small_cloud
+    from mrg_slam_amd import synth
+
+    tgt = small_cloud(5000, 21)
+    rel = synth.make_pose([0.2, -0.1, 0.05], synth.rot_xyz(0.01, -0.02, 0.03))
+    src = orc.transform_points(np.linalg.inv(rel), tgt[:3700])
+    T = synth.perturb_pose(rel, np.random.default_rng(2))
+    p = np.array([T[0, 3], T[1, 3], T[2, 3], 0.011, -0.019, 0.031])
+    ref = orc.Ndt(search=search, num_threads=2)
+    ref.setInputTarget(tgt)
+    ref.setInputSource(src)
+    for ppt in (1, 3, 8):
+        g = orc.Ndt(search=search, num_threads=1, gpu_order_ppt=ppt)
+        g.setInputTarget(tgt)
+        g.setInputSource(src)
+        for mode in (0, 1, 2):
+            s0, g0, H0 = ref.evaluate(T, p, mode)
+            s1, g1, H1 = g.evaluate(T, p, mode)
+            assert abs(s1 - s0) <= 1e-12 * max(1.0, abs(s0))
+            np.testing.assert_allclose(g1, g0, rtol=0, atol=1e-12 * max(1.0, np.abs(g0).max()))
+            np.testing.assert_allclose(H1, H0, rtol=0, atol=(1e-12 if mode != 2 else 1e-11) * max(1.0, np.abs(H0).max()))
