@@ -244,6 +244,19 @@ def synth_lidar(scene: Scene, pose: np.ndarray, model: str = "VLP64", seed: int 
     return out
 
 
+def _gpu_in_use() -> bool:
+    import sys
+
+    t = sys.modules.get("torch")
+    try:
+        if t is not None and t.cuda.is_initialized():
+            return True
+    except Exception:  # noqa: BLE001
+        pass
+    lib_mod = sys.modules.get("mrg_slam_amd._lib")
+    return bool(lib_mod is not None and getattr(lib_mod, "_lib", None) is not None)
+
+
 def _synth_job(job):
     scene, pose, model, seed = job
     return synth_lidar(scene, pose, model, seed)
@@ -271,6 +284,13 @@ def synth_lidar_many(scene: Scene, poses, model: str, seeds, workers: int | None
         workers = min(len(jobs), max(1, (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))), 64)
     if workers <= 1 or len(jobs) < 4:
         scans = [_synth_job(j) for j in jobs]
+    elif _gpu_in_use():
+        # a process that has touched the GPU must not fork (the HIP runtime's threads and queues do not survive it) nor exec:
+        # threads instead — numpy releases the interpreter lock in the ray-casting loops, a few of them overlap
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(min(workers, 16)) as pool:
+            scans = list(pool.map(_synth_job, jobs))
     else:
         import multiprocessing as mp
 

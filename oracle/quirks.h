@@ -24,6 +24,18 @@ constexpr double kNdtTransformationEps   = 0.1;
 constexpr int    kNdtMaxIterations       = 35;
 // computeAngleDerivatives: angles with |a| < 10e-5 use cos=1, sin=0 exactly.
 constexpr double kNdtSmallAngle          = 10e-5;
+// computeAngleDerivatives, second-derivative row d1 (the x row of d^2 R / d ry^2 for R = Rx Ry Rz): upstream (PCL ndt.hpp, copied by
+// ndt_omp) has  h_ang_d1 = (-cy cz, cy sz, +sy);  the true second derivative ends in -sy (tests/ndt_analytic.py builds it from
+// rotation-matrix derivative products).  The restatement KEEPS upstream's +sy: the Hessian entry (ry, ry) of every registration of
+// the reference carries it, and parity is with the reference, not with the thesis.  tests/test_oracle_ndt.py::
+// test_derivatives_match_the_first_principles_model pins it: first principles + this one sign = the oracle.
+constexpr double kNdtHAngD1ZSign         = +1.0;
+// updateDerivatives evaluates the exponent in FLOAT with a float copy of gauss_d2 ("float gauss_d2 = gauss_d2_;" at the top of
+// ndt_omp's updateDerivatives): e_x_cov_x = exp(-gauss_d2f * x_trans4.dot(x_trans4 * c_inv4) * 0.5f) with the unqualified ::exp, i.e.
+// the float argument widened to double, exp in double, the result narrowed to float.  Audited in round 2: the
+// HIP kernel (ndt_derivatives.hip pair_float: arg0 = -gauss_d2f * qCq; arg = arg0 * 0.5f; e = float(exp(double(arg)))) and
+// oracle/ndt.cpp pair_terms_f execute exactly that sequence; computeHessian (updateHessian) keeps the double gauss_d2_.
+// This is recalled upstream text, like everything in this file: no copy of ndt_omp exists here to confirm it.
 // computeStepLengthMT (More-Thuente) constants.
 constexpr int    kMtMaxStepIterations    = 10;
 constexpr double kMtMu                   = 1.e-4;

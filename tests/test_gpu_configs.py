@@ -1,6 +1,7 @@
 """GPU: parity on workloads shaped like BASELINE.json's configs (synthetic scans, sizes the CPU oracle finishes in
 seconds): [0] VLP-16 NDT pair is test_gpu_ndt.test_align_on_street_scan_pair, [2] GICP scan-to-keyframe,
 [3] batched loop-closure candidates, [4] two robots: concurrent odometry streams + an inter-robot candidate batch."""
+import os
 import threading
 
 import numpy as np
@@ -91,6 +92,73 @@ def test_config4_batched_loop_closure_candidates():
         best_score, best = score, i
     gbest, gscore = loop_closure.select_best(res)
     assert gbest == best and gscore == pytest.approx(best_score, rel=1e-6)
+
+
+def test_config4_256_candidate_pairs_as_bench_shards_them():
+    """BASELINE config[3] at its stated size: bench.py's 256 (new keyframe, candidate) pairs over 64 ring keyframes, VLP-64 clouds,
+    getFitnessScore(inf), one batch.  A sample of the pairs is held against the oracle's sequential loop (align + fitness), the
+    best-candidate replay of every new keyframe in the sample against the reference's rule, and sharding the same pairs over 2 or
+    8 'ranks' (pair i -> rank i mod G, run one after the other on this GPU) must reproduce the one-GPU transforms, fitness scores,
+    convergence flags and iteration counts bit for bit."""
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from mrg_slam_amd import BatchMatcher, distance_filter, loop_closure, synth
+    from mrg_slam_amd.registration import RESULT_DTYPE, result_matrix
+    from oracle import oracle as orc
+
+    raw, pairs = bench.make_loop_workload()
+    assert len(pairs) == 256
+    scans = [distance_filter(s, 0.1, 35.0) for s in raw]
+    dev = [torch.from_numpy(s).cuda() for s in scans]
+
+    def run(ids):
+        bm = BatchMatcher(transformation_epsilon=0.1, maximum_iterations=64)
+        targets = sorted({pairs[i][0] for i in ids})
+        tpos = {a: k for k, a in enumerate(targets)}
+        bm.add_device([dev[a].data_ptr() for a in targets], [len(scans[a]) for a in targets], np.array([tpos[pairs[i][0]] for i in ids], dtype=np.int32),
+                      [dev[pairs[i][1]].data_ptr() for i in ids], [len(scans[pairs[i][1]]) for i in ids], np.stack([pairs[i][2] for i in ids]))
+        r = bm.align(float("inf"))
+        r["pair_id"] = np.asarray(ids, dtype=np.int32)
+        return r
+
+    full = run(list(range(256)))
+    assert int(full["converged"].sum()) >= 250
+    for world in (2, 8):
+        merged = np.zeros(256, dtype=RESULT_DTYPE)
+        for rank in range(world):
+            part = run(loop_closure.shard_indices(256, world, rank).tolist())
+            merged[part["pair_id"]] = part
+        for f in ("T", "fitness", "converged", "iterations", "evaluations"):
+            assert np.array_equal(merged[f], full[f]), (world, f)
+        # the f64 Hessians carry the order of their sums: a round with fewer busy pairs cuts a cloud into smaller work items
+        # (ndt_plan_kernel), which regroups additions — 1e-15 relative, and the float transforms above come out the same
+        np.testing.assert_allclose(merged["H"], full["H"], rtol=0, atol=1e-12 * np.abs(full["H"]).max())
+    # oracle: the sequential loop of the reference for the first three new keyframes of the list
+    groups = {}
+    for i, (a, _, _, _) in enumerate(pairs):
+        groups.setdefault(a, []).append(i)
+    for a in sorted(groups)[:3]:
+        o = orc.Ndt(transformation_epsilon=0.1, maximum_iterations=64, num_threads=32)
+        o.setInputTarget(scans[a])
+        best_score, best = np.finfo(np.float64).max, None
+        for k, i in enumerate(groups[a]):
+            o.setInputSource(scans[pairs[i][1]])
+            o.align(pairs[i][2])
+            score = o.getFitnessScore(float("inf"))
+            settled = o.hasConverged() and o.getFinalNumIteration() <= 30
+            if settled:
+                assert _close(result_matrix(full[i]), o.getFinalTransformation()), i
+                assert bool(full[i]["converged"]) and full[i]["iterations"] == o.getFinalNumIteration()
+                assert full[i]["fitness"] == pytest.approx(score, rel=1e-6)
+            if not o.hasConverged() or score > best_score:
+                continue
+            best_score, best = score, k
+        gbest, gscore = loop_closure.select_best(full[groups[a]])
+        assert gbest == best and gscore == pytest.approx(best_score, rel=1e-6)
 
 
 def test_config5_two_robots_concurrent_streams_and_inter_robot_batch(street_scans):

@@ -90,3 +90,30 @@ def test_radix_sort_properties_at_batch_scale():
     same = ok[1:] == ok[:-1]
     assert (ov[1:][same] > ov[:-1][same]).all()  # stable
     assert np.bincount(ov, minlength=n).max() == 1
+
+
+@pytest.mark.parametrize("method", ["GICP", "SMALL_GICP", "VGICP"])
+def test_gicp_family_full_size_matches_oracle(vlp64, method):
+    """BASELINE config[2] at its stated size: scan-to-keyframe GICP on ~130k-point clouds (k = 20 covariances over both clouds, 1-NN
+    correspondences within 2 m).  The final transform must be the oracle's (bar 1e-4 m / 1e-4 rad; it is bit-identical on this
+    pair), with the same convergence flag and iteration count."""
+    from mrg_slam_amd import GicpHip, SmallGicpHip, VgicpHip, distance_filter, synth
+    from oracle import oracle as orc
+
+    tgt, src, rel = vlp64
+    ft, fs = distance_filter(tgt), distance_filter(src)
+    assert len(ft) > 120000 and len(fs) > 120000
+    guess = synth.warm_guess(rel, 1)
+    g, o = {"GICP": (GicpHip(transformation_epsilon=0.01), orc.FastGicp(transformation_epsilon=0.01, num_threads=32)),
+            "SMALL_GICP": (SmallGicpHip(transformation_epsilon=0.01), orc.SmallGicp(transformation_epsilon=0.01, num_threads=32)),
+            "VGICP": (VgicpHip(resolution=1.0, transformation_epsilon=0.01), orc.FastVgicp(resolution=1.0, transformation_epsilon=0.01, num_threads=32))}[method]
+    g.setInputTarget(ft)
+    o.setInputTarget(ft)
+    g.setInputSource(fs)
+    o.setInputSource(fs)
+    g.align(guess)
+    o.align(guess)
+    Tg, To = g.getFinalTransformation(), o.getFinalTransformation()
+    assert np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3]) <= 1e-4 and synth.rotation_angle(Tg, To) <= 1e-4
+    assert g.hasConverged() == o.hasConverged() and g.getFinalNumIteration() == o.getFinalNumIteration()
+    assert np.linalg.norm(Tg[:3, 3] - rel[:3, 3]) < 0.1  # and it found the motion

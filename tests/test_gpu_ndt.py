@@ -239,3 +239,33 @@ def test_evaluation_is_bit_identical_to_the_oracle_in_gpu_order(search):
         _, _, Hg = g.evaluate(T, p, 2)
         _, _, Ho = o.evaluate(T, p, 2)
         np.testing.assert_allclose(Hg, Ho, rtol=0, atol=1e-14 * np.abs(Ho).max())
+
+
+@pytest.mark.parametrize("search", ["DIRECT7", "DIRECT1", "DIRECT26"])
+def test_kernels_match_the_first_principles_model(search):
+    """tests/ndt_analytic.py (the Gaussian NDT model from rotation-matrix derivative products, float64, written independently of
+    the oracle's line-by-line restatement) against the HIP kernels, with the kernels' own target grid: float path at the f32 level,
+    the per-point f64 Hessian pass to f64 rounding — up to the one sign upstream's second-derivative table carries."""
+    import ndt_analytic
+    from mrg_slam_amd import NdtHip, synth
+    from oracle import oracle as orc
+
+    tgt = small_cloud(3000, 31)
+    rel = synth.make_pose([0.3, -0.2, 0.05], synth.rot_xyz(0.02, -0.03, 0.06))
+    src = orc.transform_points(np.linalg.inv(rel), tgt[:700])
+    g = NdtHip(search=search)
+    assert g.setInputTarget(tgt) == 0
+    g.setInputSource(src)
+    keys, npts, mean, icov = g.leaves()
+    rng = np.random.default_rng(5)
+    for trial in range(3):
+        p = np.concatenate([rel[:3, 3] + rng.normal(0, 0.1, 3), np.array([0.02, -0.03, 0.06]) + rng.normal(0, 0.02, 3)])
+        T = orc.pose_to_matrix(p)
+        xt = orc.transform_points(T, src)[:, :3]
+        s0, g0, H0 = g.evaluate(T, p, 0)
+        _, _, H2 = g.evaluate(T, p, 2)
+        sa, ga, Ha = ndt_analytic.evaluate(src[:, :3], p, search, 1.0, g.grid(), (keys, npts, mean, icov), transformed=xt, upstream_d1_sign=True)
+        assert abs(s0 - sa) <= 2e-6 * abs(sa)
+        np.testing.assert_allclose(g0, ga, rtol=0, atol=1e-4 * np.abs(ga).max())
+        np.testing.assert_allclose(H0, Ha, rtol=0, atol=1e-4 * np.abs(Ha).max())
+        np.testing.assert_allclose(H2, Ha, rtol=0, atol=1e-11 * np.abs(Ha).max())

@@ -183,3 +183,39 @@ def test_gpu_order_mode_only_reorders_the_sums(search):
             assert abs(s1 - s0) <= 1e-12 * max(1.0, abs(s0))
             np.testing.assert_allclose(g1, g0, rtol=0, atol=1e-12 * max(1.0, np.abs(g0).max()))
             np.testing.assert_allclose(H1, H0, rtol=0, atol=(1e-12 if mode != 2 else 1e-11) * max(1.0, np.abs(H0).max()))
+
+
+@pytest.mark.parametrize("search", ["DIRECT7", "DIRECT1", "DIRECT26"])
+def test_derivatives_match_the_first_principles_model(search):
+    """tests/ndt_analytic.py: score, gradient and Hessian of the Gaussian NDT model from rotation-matrix derivative products in
+    float64 — independent of pclomp's expanded angle tables and float layouts.  The oracle's float path (modes 0 / 1) must agree at
+    the float32 level, its f64 computeHessian (mode 2) at the f64 level."""
+    import ndt_analytic
+    from conftest import small_cloud
+    from mrg_slam_amd import synth
+
+    tgt = small_cloud(3000, 31)
+    rel = synth.make_pose([0.3, -0.2, 0.05], synth.rot_xyz(0.02, -0.03, 0.06))
+    src = orc.transform_points(np.linalg.inv(rel), tgt[:700])
+    o = orc.Ndt(search=search, num_threads=2)
+    o.setInputTarget(tgt)
+    o.setInputSource(src)
+    keys, npts, mean, cov, icov = o.leaves()
+    rng = np.random.default_rng(5)
+    for trial in range(3):
+        p = np.concatenate([rel[:3, 3] + rng.normal(0, 0.1, 3), np.array([0.02, -0.03, 0.06]) + rng.normal(0, 0.02, 3)])
+        T = orc.pose_to_matrix(p)
+        s0, g0, H0 = o.evaluate(T, p, 0)
+        _, _, H2 = o.evaluate(T, p, 2)
+        xt = orc.transform_points(T, src)[:, :3]  # the reference's float-transformed cloud
+        sa, ga, Ha = ndt_analytic.evaluate(src[:, :3], p, search, 1.0, o.grid(), (keys, npts, mean, icov), transformed=xt, upstream_d1_sign=True)
+        assert abs(s0 - sa) <= 2e-6 * abs(sa)
+        np.testing.assert_allclose(g0, ga, rtol=0, atol=1e-4 * np.abs(ga).max())
+        np.testing.assert_allclose(H0, Ha, rtol=0, atol=1e-4 * np.abs(Ha).max())   # float path: f32 rounding, amplified by thin voxels
+        np.testing.assert_allclose(H2, Ha, rtol=0, atol=1e-11 * np.abs(Ha).max())  # f64 computeHessian: the same model to rounding
+        # the one place where upstream leaves first principles: the sign of sin(ry) in the (ry, ry) second derivative
+        _, _, Htrue = ndt_analytic.evaluate(src[:, :3], p, search, 1.0, o.grid(), (keys, npts, mean, icov), transformed=xt)
+        diff = H2 - Htrue
+        assert abs(diff[4, 4]) > 1e-9 * np.abs(Htrue).max()
+        diff[4, 4] = 0
+        assert np.abs(diff).max() <= 1e-11 * np.abs(Htrue).max()
