@@ -206,6 +206,26 @@ int mrgfe_statistical_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_
 int mrgfe_calc_fitness_score(mrgfe_ctx* ctx, const float* cloud1, size_t n1, const float* cloud2, size_t n2, size_t stride_bytes,
                              const double relpose[16], double max_range, double* out);
 
+/* InformationMatrixCalculator's parameters (apps/mrg_slam_component.cpp:313-322 declares them; defaults: config/mrg_slam.yaml:216-223,173) */
+typedef struct mrgfe_inf_params {
+    int    use_const_inf_matrix;          /* 0    */
+    double const_stddev_x, const_stddev_q; /* 0.5, 0.1 */
+    double var_gain_a;                    /* 2.0  */
+    double min_stddev_x, max_stddev_x;    /* 0.1, 0.75 */
+    double min_stddev_q, max_stddev_q;    /* 0.05, 0.2 */
+    double fitness_score_thresh;          /* 1.25 */
+} mrgfe_inf_params;
+void   mrgfe_inf_default_params(mrgfe_inf_params* out);
+/* replaces InformationMatrixCalculator::weight (information_matrix_calculator.cpp:83-88) */
+double mrgfe_inf_weight(double a, double max_x, double min_y, double max_y, double x);
+/* the 6x6 information matrix (row-major) of a graph edge from its fitness score: :19-24 (constant) / :30-43 (weights) */
+int    mrgfe_inf_matrix_from_fitness(const mrgfe_inf_params* params, double fitness_score, double inf[36]);
+/* replaces InformationMatrixCalculator::calc_information_matrix(cloud1, cloud2, relpose) (:14-44; call sites
+ * src/mrg_slam/graph_database.cpp:139-142 for every odometry edge, :579-581 for every loop edge): fitness score with the header's
+ * default max_range (DBL_MAX), then the weights.  fitness_out (may be NULL) receives the score. */
+int    mrgfe_calc_information_matrix(mrgfe_ctx* ctx, const mrgfe_inf_params* params, const float* cloud1, size_t n1, const float* cloud2, size_t n2, size_t stride_bytes,
+                                     const double relpose[16], double inf[36], double* fitness_out);
+
 /* ---- per-point passes around the path ------------------------------------------------ */
 /* replaces MapCloudGenerator::generate (src/mrg_slam/map_cloud_generator.cpp:14-86) including its
  * pcl::ApproximateMeanVoxelGrid pass (include/pcl/filters/ApproximateMeanVoxelGrid.hpp:63-126): every keyframe cloud is
@@ -233,6 +253,13 @@ int    mrgfe_map_store_has(const mrgfe_map_store* store, uint64_t key, size_t* n
 size_t mrgfe_map_store_bytes(const mrgfe_map_store* store);
 int    mrgfe_map_store_generate(mrgfe_map_store* store, int n_keyframes, const uint64_t* keys, const double* poses, const uint8_t* first_keyframe, float resolution,
                                 int min_points_per_voxel, float distance_far_thresh, int skip_first_cloud, float* out_xyzi, size_t capacity, size_t* out_n);
+
+/* The same two calls for keyframes that already sit in a map store: a graph edge names its two keyframes, so
+ * neither cloud is uploaded again, and the exact-NN grid of key1's cloud is kept for the next edges of that keyframe (the
+ * reference builds a fresh kd-tree over cloud1 for every edge: information_matrix_calculator.cpp:51-52). */
+int mrgfe_map_store_fitness(mrgfe_map_store* store, uint64_t key1, uint64_t key2, const double relpose[16], double max_range, double* out);
+int mrgfe_map_store_information_matrix(mrgfe_map_store* store, const mrgfe_inf_params* params, uint64_t key1, uint64_t key2, const double relpose[16], double inf[36],
+                                       double* fitness_out);
 
 /* replaces the other-robot point removal of apps/mrg_slam_component.cpp:396-429: drops every point whose squared float
  * distance to one of the centres (sensor frame, <= 64) is < radius_sqr; kept / removed (may be NULL) keep the input order */

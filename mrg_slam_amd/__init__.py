@@ -2,6 +2,6 @@
 hand-written HIP kernels behind a C ABI (include/mrgfe.h), with the host-side mirror of the reference's
 pcl::Registration / pcl::Filter call surface.  See DESIGN.md."""
 from ._lib import Context, MrgfeError, build, default_context  # noqa: F401
-from .filters import RadiusOutlierRemoval, StatisticalOutlierRemoval, VoxelGrid, calc_fitness_score, distance_filter, knn, prefilter, prefilter_to_device  # noqa: F401
+from .filters import InformationMatrixCalculator, RadiusOutlierRemoval, StatisticalOutlierRemoval, VoxelGrid, calc_fitness_score, distance_filter, knn, prefilter, prefilter_to_device  # noqa: F401
 from .map_cloud import KeyFrameSnapshot, MapCloudGenerator, MapCloudStore, deskew, remove_points_near  # noqa: F401
 from .registration import BatchMatcher, GicpHip, IcpHip, NdtHip, SmallGicpHip, VgicpHip, select_registration_method  # noqa: F401

@@ -43,6 +43,13 @@ class PrefilterParams(C.Structure):
                 ("radius_min_neighbors", C.c_int), ("statistical_mean_k", C.c_int), ("statistical_stddev", C.c_double)]
 
 
+class InfParams(C.Structure):
+    """struct mrgfe_inf_params (InformationMatrixCalculator's ROS parameters, config/mrg_slam.yaml:216-223,173)."""
+
+    _fields_ = [("use_const_inf_matrix", C.c_int), ("const_stddev_x", C.c_double), ("const_stddev_q", C.c_double), ("var_gain_a", C.c_double), ("min_stddev_x", C.c_double),
+                ("max_stddev_x", C.c_double), ("min_stddev_q", C.c_double), ("max_stddev_q", C.c_double), ("fitness_score_thresh", C.c_double)]
+
+
 class RegParams(C.Structure):
     """struct mrgfe_reg_params (mirrors the reg_* ROS parameters of registrations.cpp:34-43)."""
 
@@ -130,6 +137,12 @@ SIGNATURES = {
     "mrgfe_radius_outlier": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, C.c_double, C.c_int, _fp, _szp]),
     "mrgfe_statistical_outlier": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, C.c_int, C.c_double, _fp, _szp]),
     "mrgfe_calc_fitness_score": (C.c_int, [_vp, _fp, C.c_size_t, _fp, C.c_size_t, C.c_size_t, _dp, C.c_double, _dp]),
+    "mrgfe_inf_default_params": (None, [C.POINTER(InfParams)]),
+    "mrgfe_inf_weight": (C.c_double, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "mrgfe_inf_matrix_from_fitness": (C.c_int, [C.POINTER(InfParams), C.c_double, _dp]),
+    "mrgfe_calc_information_matrix": (C.c_int, [_vp, C.POINTER(InfParams), _fp, C.c_size_t, _fp, C.c_size_t, C.c_size_t, _dp, _dp, _dp]),
+    "mrgfe_map_store_fitness": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _dp, C.c_double, _dp]),
+    "mrgfe_map_store_information_matrix": (C.c_int, [_vp, C.POINTER(InfParams), C.c_uint64, C.c_uint64, _dp, _dp, _dp]),
     "mrgfe_map_cloud_generate": (C.c_int, [_vp, C.c_int, C.POINTER(_fp), _szp, C.c_size_t, _dp, C.POINTER(C.c_uint8), C.c_float, C.c_int, C.c_float, C.c_int, _fp,
                                            C.c_size_t, _szp]),
     "mrgfe_remove_points_near": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, _fp, C.c_int, C.c_float, _fp, _szp, _fp, _szp]),

@@ -539,6 +539,52 @@ int mrgfe_calc_fitness_score(mrgfe_ctx* ctx, const float* cloud1, size_t n1, con
     return st;
 }
 
+// ---- InformationMatrixCalculator (src/mrg_slam/information_matrix_calculator.cpp) ------------------------------------------
+void mrgfe_inf_default_params(mrgfe_inf_params* p)
+{
+    if (!p) return;
+    p->use_const_inf_matrix = 0;   // config/mrg_slam.yaml:216
+    p->const_stddev_x = 0.5;       // :217
+    p->const_stddev_q = 0.1;       // :218
+    p->var_gain_a = 2.0;           // :219
+    p->min_stddev_x = 0.1;         // :220
+    p->max_stddev_x = 0.75;        // :221
+    p->min_stddev_q = 0.05;        // :222
+    p->max_stddev_q = 0.2;         // :223
+    p->fitness_score_thresh = 1.25;  // :173
+}
+double mrgfe_inf_weight(double a, double max_x, double min_y, double max_y, double x)
+{
+    const double y = (1.0 - std::exp(-a * x)) / (1.0 - std::exp(-a * max_x));  // information_matrix_calculator.cpp:86
+    return min_y + (max_y - min_y) * y;
+}
+int mrgfe_inf_matrix_from_fitness(const mrgfe_inf_params* p, double fitness_score, double inf[36])
+{
+    if (!p || !inf) { set_error("mrgfe_inf_matrix_from_fitness: NULL argument"); return MRGFE_ERR_INVALID; }
+    double dx, dq;  // divisors of the two diagonal blocks
+    if (p->use_const_inf_matrix) {  // :19-24 (divides by the standard deviation itself, as the reference does)
+        dx = p->const_stddev_x;
+        dq = p->const_stddev_q;
+    } else {                        // :30-43
+        const double min_var_x = std::pow(p->min_stddev_x, 2), max_var_x = std::pow(p->max_stddev_x, 2);
+        const double min_var_q = std::pow(p->min_stddev_q, 2), max_var_q = std::pow(p->max_stddev_q, 2);
+        dx = mrgfe_inf_weight(p->var_gain_a, p->fitness_score_thresh, min_var_x, max_var_x, fitness_score);
+        dq = mrgfe_inf_weight(p->var_gain_a, p->fitness_score_thresh, min_var_q, max_var_q, fitness_score);
+    }
+    for (int k = 0; k < 36; ++k) inf[k] = 0.0;
+    for (int k = 0; k < 3; ++k) { inf[k * 7] = 1.0 / dx; inf[(k + 3) * 7] = 1.0 / dq; }
+    return MRGFE_OK;
+}
+int mrgfe_calc_information_matrix(mrgfe_ctx* ctx, const mrgfe_inf_params* p, const float* cloud1, size_t n1, const float* cloud2, size_t n2, size_t stride,
+                                  const double relpose[16], double inf[36], double* fitness_out)
+{
+    if (!p || !inf) { set_error("mrgfe_calc_information_matrix: NULL argument"); return MRGFE_ERR_INVALID; }
+    double fit = 0.0;
+    if (!p->use_const_inf_matrix) MRGFE_TRY(mrgfe_calc_fitness_score(ctx, cloud1, n1, cloud2, n2, stride, relpose, DBL_MAX, &fit));  // the header's default max_range
+    if (fitness_out) *fitness_out = fit;
+    return mrgfe_inf_matrix_from_fitness(p, fit, inf);
+}
+
 // ---- map cloud, other-robot removal, deskewing --------------------------------------------------------------------
 // shared tail of the two map-cloud entry points: run the device pass over `total` points (d_cat, or the per-keyframe
 // pointers kf_ptrs), apply the reference's emptiness / capacity rules and bring the result down
@@ -610,6 +656,12 @@ struct mrgfe_map_store {
     struct Entry { const float4* p; uint32_t n; };
     std::unordered_map<uint64_t, Entry> clouds;
     size_t bytes = 0;
+    // exact-NN grids of the keyframes that were `cloud1` of a fitness score lately (graph edges of one keyframe come in bursts:
+    // its odometry edge, then the loop edges of the same optimisation cycle), least recently used first out
+    struct CachedGrid { uint64_t key = 0; uint64_t tick = 0; NnGrid grid; };
+    std::vector<CachedGrid*> grids;
+    uint64_t tick = 0;
+    size_t   max_grids = 8;
 };
 
 int mrgfe_map_store_create(mrgfe_ctx* ctx, mrgfe_map_store** out)
@@ -627,6 +679,7 @@ void mrgfe_map_store_destroy(mrgfe_map_store* s)
     {
         MRGFE_LOCK(s->ctx);
         (void)s->ctx->bind();
+        for (auto* g : s->grids) { g->grid.release(); delete g; }
         s->arena.release();
     }
     delete s;
@@ -691,6 +744,40 @@ int mrgfe_map_store_generate(mrgfe_map_store* s, int K, const uint64_t* keys, co
     }
     MRGFE_HIP_CHECK(hipStreamSynchronize(s->ctx->stream));  // clouds added just before are still on their way up
     return map_cloud_finish(s->ctx, K, nullptr, ptrs.data(), off, pose_f, resolution, min_points_per_voxel, distance_far_thresh, out, capacity, out_n);
+}
+
+int mrgfe_map_store_fitness(mrgfe_map_store* s, uint64_t key1, uint64_t key2, const double relpose[16], double max_range, double* out)
+{
+    if (!s || !relpose || !out) { set_error("mrgfe_map_store_fitness: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(s->ctx);
+    MRGFE_TRY(s->ctx->bind());
+    auto i1 = s->clouds.find(key1), i2 = s->clouds.find(key2);
+    if (i1 == s->clouds.end() || i2 == s->clouds.end()) {
+        set_error("mrgfe_map_store_fitness: keyframe %llu is not in the store", static_cast<unsigned long long>(i1 == s->clouds.end() ? key1 : key2));
+        return MRGFE_ERR_INVALID;
+    }
+    if (i1->second.n == 0 || i2->second.n == 0) { *out = DBL_MAX; return MRGFE_OK; }
+    mrgfe_map_store::CachedGrid* g = nullptr;
+    for (auto* c : s->grids) if (c->key == key1) g = c;
+    if (!g) {
+        if (s->grids.size() < s->max_grids) { g = new mrgfe_map_store::CachedGrid(); s->grids.push_back(g); }
+        else { g = s->grids[0]; for (auto* c : s->grids) if (c->tick < g->tick) g = c; }
+        g->key = 0;
+        MRGFE_TRY(g->grid.build(s->ctx, i1->second.p, i1->second.n, 1.0f, NnGrid::kCrowding1nn, 1));
+        g->key = key1;
+    }
+    g->tick = ++s->tick;
+    float T[16];  // relpose.cast<float>(), row-major
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) T[r * 4 + c] = static_cast<float>(relpose[c * 4 + r]);
+    return g->grid.fitness(s->ctx, i2->second.p, i2->second.n, T, max_range, out);
+}
+int mrgfe_map_store_information_matrix(mrgfe_map_store* s, const mrgfe_inf_params* p, uint64_t key1, uint64_t key2, const double relpose[16], double inf[36], double* fitness_out)
+{
+    if (!p || !inf) { set_error("mrgfe_map_store_information_matrix: NULL argument"); return MRGFE_ERR_INVALID; }
+    double fit = 0.0;
+    if (!p->use_const_inf_matrix) MRGFE_TRY(mrgfe_map_store_fitness(s, key1, key2, relpose, DBL_MAX, &fit));
+    if (fitness_out) *fitness_out = fit;
+    return mrgfe_inf_matrix_from_fitness(p, fit, inf);
 }
 
 int mrgfe_remove_points_near(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, const float* centres, int n_centres, float radius_sqr, float* kept, size_t* n_kept,

@@ -121,6 +121,52 @@ def calc_fitness_score(cloud1, cloud2, relpose, max_range=float("inf"), ctx: Con
     return out.value
 
 
+class InformationMatrixCalculator:
+    """mrg_slam::InformationMatrixCalculator (src/mrg_slam/information_matrix_calculator.cpp): the 6x6 information matrix of a
+    graph edge from the fitness score of its two keyframe clouds.  ``params`` carries the reference's ROS parameter names
+    (use_const_inf_matrix, const_stddev_x/q, var_gain_a, min/max_stddev_x/q, fitness_score_thresh; YAML defaults otherwise)."""
+
+    def __init__(self, params: dict | None = None, ctx: Context | None = None):
+        self._ctx = ctx or default_context()
+        self._p = _lib.InfParams()
+        lib().mrgfe_inf_default_params(C.byref(self._p))
+        for k, v in (params or {}).items():
+            if not hasattr(self._p, k):
+                raise KeyError(k)
+            setattr(self._p, k, int(bool(v)) if k == "use_const_inf_matrix" else float(v))
+        self.last_fitness_score = None
+
+    calc_fitness_score = staticmethod(calc_fitness_score)
+
+    @staticmethod
+    def weight(a, max_x, min_y, max_y, x) -> float:
+        return lib().mrgfe_inf_weight(a, max_x, min_y, max_y, x)
+
+    def from_fitness(self, fitness_score: float) -> np.ndarray:
+        inf = np.empty((6, 6))
+        check(lib().mrgfe_inf_matrix_from_fitness(C.byref(self._p), fitness_score, inf.ctypes.data_as(C.POINTER(C.c_double))))
+        return inf
+
+    def calc_information_matrix(self, cloud1, cloud2, relpose) -> np.ndarray:
+        c1, c2 = _cloud(cloud1), _cloud(cloud2)
+        T = np.ascontiguousarray(np.asarray(relpose, dtype=np.float64).T)
+        inf, fit = np.empty((6, 6)), C.c_double(0)
+        dp = C.POINTER(C.c_double)
+        check(lib().mrgfe_calc_information_matrix(self._ctx._h, C.byref(self._p), c1.ctypes.data_as(_fp), len(c1), c2.ctypes.data_as(_fp), len(c2), 16, T.ctypes.data_as(dp),
+                                                  inf.ctypes.data_as(dp), C.byref(fit)))
+        self.last_fitness_score = fit.value
+        return inf
+
+    def calc_information_matrix_keyed(self, store, key1: int, key2: int, relpose) -> np.ndarray:
+        """The same for two keyframes of a :class:`MapCloudStore`: nothing is uploaded, key1's search grid is kept for its next edges."""
+        T = np.ascontiguousarray(np.asarray(relpose, dtype=np.float64).T)
+        inf, fit = np.empty((6, 6)), C.c_double(0)
+        dp = C.POINTER(C.c_double)
+        check(lib().mrgfe_map_store_information_matrix(store._h, C.byref(self._p), int(key1), int(key2), T.ctypes.data_as(dp), inf.ctypes.data_as(dp), C.byref(fit)))
+        self.last_fitness_score = fit.value
+        return inf
+
+
 def knn(cloud, queries, k: int, ctx: Context | None = None):
     """pcl::search::KdTree::nearestKSearch(pt, k) for a cloud of queries: (indices [nq, k], squared distances [nq, k]),
     ascending by (distance, index), -1 where the cloud has fewer than k points."""

@@ -57,6 +57,13 @@ class MapCloudStore:
     def bytes(self) -> int:
         return int(lib().mrgfe_map_store_bytes(self._h))
 
+    def fitness(self, key1: int, key2: int, relpose, max_range: float = float("inf")) -> float:
+        """InformationMatrixCalculator::calc_fitness_score(cloud1 = keyframe key1, cloud2 = keyframe key2, relpose) on the resident clouds."""
+        T = np.ascontiguousarray(np.asarray(relpose, dtype=np.float64).T)
+        out = C.c_double(0)
+        check(lib().mrgfe_map_store_fitness(self._h, int(key1), int(key2), T.ctypes.data_as(C.POINTER(C.c_double)), max_range, C.byref(out)))
+        return out.value
+
     def generate(self, keys, poses, first_keyframe=None, resolution: float = 0.1, min_points_per_voxel: int = 1, distance_far_thresh: float = 10000.0,
                  skip_first_cloud: bool = False):
         """MapCloudGenerator.generate over the stored keyframes ``keys`` with their current ``poses`` (4 x 4 each)."""

@@ -56,6 +56,8 @@ def lib():
             "orc_ndt_create": (vp, []),
             "orc_ndt_destroy": (None, [vp]),
             "orc_ndt_set_params": (None, [vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]),
+            "orc_inf_weight": (C.c_double, [C.c_double] * 5),
+            "orc_inf_matrix": (None, [dp, C.c_double, dp]),
             "orc_ndt_set_fused": (None, [vp, C.c_int]),
             "orc_ndt_set_gpu_order": (None, [vp, C.c_int]),
             "orc_ndt_set_target": (C.c_int, [vp, fp, C.c_int]),
@@ -209,6 +211,26 @@ def calc_fitness_score(cloud1, cloud2, relpose, max_range=float("inf")):
     c1, c2 = _cloud(cloud1), _cloud(cloud2)
     T = _colmajor(relpose, np.float64)
     return lib().orc_calc_fitness_score(_pf(c1), len(c1), _pf(c2), len(c2), _pd(T), max_range)
+
+
+INF_DEFAULTS = {"use_const_inf_matrix": False, "const_stddev_x": 0.5, "const_stddev_q": 0.1, "var_gain_a": 2.0, "min_stddev_x": 0.1, "max_stddev_x": 0.75,
+                "min_stddev_q": 0.05, "max_stddev_q": 0.2, "fitness_score_thresh": 1.25}  # config/mrg_slam.yaml:216-223,173
+
+
+def inf_weight(a, max_x, min_y, max_y, x):
+    return lib().orc_inf_weight(a, max_x, min_y, max_y, x)
+
+
+def calc_information_matrix(cloud1, cloud2, relpose, params=None):
+    """InformationMatrixCalculator::calc_information_matrix (information_matrix_calculator.cpp:14-44): (6x6 matrix, fitness score)."""
+    p = dict(INF_DEFAULTS)
+    p.update(params or {})
+    fit = 0.0 if p["use_const_inf_matrix"] else calc_fitness_score(cloud1, cloud2, relpose, np.finfo(np.float64).max)
+    v = np.array([float(bool(p["use_const_inf_matrix"])), p["const_stddev_x"], p["const_stddev_q"], p["var_gain_a"], p["min_stddev_x"], p["max_stddev_x"], p["min_stddev_q"],
+                  p["max_stddev_q"], p["fitness_score_thresh"]], dtype=np.float64)
+    inf = np.empty((6, 6))
+    lib().orc_inf_matrix(_pd(v), fit, _pd(inf))
+    return inf, fit
 
 
 # ---- linear algebra --------------------------------------------------------------------------------------

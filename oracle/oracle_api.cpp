@@ -78,6 +78,30 @@ double orc_calc_fitness_score(const float* cloud1, int n1, const float* cloud2, 
 }
 
 // ---- small linear algebra (exposed so tests can pin it against numpy) --------------------------------
+// InformationMatrixCalculator::weight (/root/reference/src/mrg_slam/information_matrix_calculator.cpp:83-88)
+double orc_inf_weight(double a, double max_x, double min_y, double max_y, double x)
+{
+    double y = (1.0 - std::exp(-a * x)) / (1.0 - std::exp(-a * max_x));
+    return min_y + (max_y - min_y) * y;
+}
+// InformationMatrixCalculator::calc_information_matrix after its fitness score (:19-43): params = {use_const, const_stddev_x, const_stddev_q,
+// var_gain_a, min_stddev_x, max_stddev_x, min_stddev_q, max_stddev_q, fitness_score_thresh}; inf row-major 6x6
+void orc_inf_matrix(const double params[9], double fitness_score, double inf[36])
+{
+    for (int k = 0; k < 36; ++k) inf[k] = 0.0;
+    for (int k = 0; k < 6; ++k) inf[k * 7] = 1.0;
+    double w_x, w_q;
+    if (params[0] != 0.0) {
+        w_x = params[1];
+        w_q = params[2];
+    } else {
+        double min_var_x = std::pow(params[4], 2), max_var_x = std::pow(params[5], 2), min_var_q = std::pow(params[6], 2), max_var_q = std::pow(params[7], 2);
+        w_x = orc_inf_weight(params[3], params[8], min_var_x, max_var_x, fitness_score);
+        w_q = orc_inf_weight(params[3], params[8], min_var_q, max_var_q, fitness_score);
+    }
+    for (int k = 0; k < 3; ++k) { inf[k * 7] /= w_x; inf[(k + 3) * 7] /= w_q; }
+}
+
 void orc_svd6_solve(const double A_rowmajor[36], const double b[6], double x[6], double sing[6])
 {
     JacobiSvd6 sv; sv.compute(A_rowmajor); sv.solve(b, x);

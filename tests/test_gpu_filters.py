@@ -267,3 +267,34 @@ def test_prefilter_to_device_feeds_the_scan_matcher_without_leaving_hbm(street_p
     np.testing.assert_array_equal(a.getFinalTransformation(), b.getFinalTransformation())
     with pytest.raises(ValueError):
         prefilter_to_device(src_raw, buf.data_ptr(), 10)
+
+
+def test_information_matrix_of_graph_edges_host_clouds_and_store():
+    """calc_information_matrix for an odometry edge and a loop edge (graph_database.cpp:139-142, 579-581): host clouds and the
+    store-resident keyed variant give the oracle's fitness score (f64 rounding) and therefore its 6x6 matrix; the keyed variant
+    reuses key1's search grid across edges."""
+    from mrg_slam_amd import InformationMatrixCalculator, MapCloudStore, prefilter, synth
+    from oracle import oracle as orc
+
+    scene = synth.street_scene()
+    poses = synth.arc_trajectory(4)
+    clouds = [prefilter(synth.synth_lidar(scene, poses[k], "VLP16", 900 + k)) for k in range(4)]
+    calc = InformationMatrixCalculator()
+    store = MapCloudStore()
+    for k, c in enumerate(clouds):
+        store.add(k + 1, c)
+    rng = np.random.default_rng(1)
+    for (a, b) in [(1, 0), (2, 1), (3, 2), (3, 0), (3, 1), (0, 3)]:
+        rel = synth.perturb_pose(np.linalg.inv(poses[a]) @ poses[b], rng, (0.05, 0.05, 0.02), (0.2, 0.2, 0.5))
+        o_inf, o_fit = orc.calc_information_matrix(clouds[a], clouds[b], rel)
+        inf = calc.calc_information_matrix(clouds[a], clouds[b], rel)
+        assert calc.last_fitness_score == pytest.approx(o_fit, rel=1e-9)
+        np.testing.assert_allclose(inf, o_inf, rtol=1e-9, atol=0)
+        inf_k = calc.calc_information_matrix_keyed(store, a + 1, b + 1, rel)
+        assert calc.last_fitness_score == pytest.approx(o_fit, rel=1e-9)
+        np.testing.assert_array_equal(inf_k, inf)
+        assert store.fitness(a + 1, b + 1, rel, 0.04) == pytest.approx(orc.calc_fitness_score(clouds[a], clouds[b], rel, 0.04), rel=1e-9)
+    const = InformationMatrixCalculator({"use_const_inf_matrix": True, "const_stddev_x": 0.25})
+    np.testing.assert_array_equal(const.calc_information_matrix(clouds[0], clouds[1], np.eye(4)), np.diag([4.0] * 3 + [10.0] * 3))
+    with pytest.raises(Exception):
+        store.fitness(1, 99, np.eye(4))

@@ -113,3 +113,43 @@ def test_fitness_score_semantics():
     sel = d.astype(np.float64) <= 0.001
     assert s2 == pytest.approx(d[sel].astype(np.float64).mean(), rel=1e-12)
     assert orc.calc_fitness_score(t, t, np.diag([1, 1, 1, 1.0]) + np.eye(4, k=3) * 500, max_range=1.0) == np.finfo(np.float64).max
+
+
+def test_information_matrix_weights_against_numpy():
+    """InformationMatrixCalculator::weight / calc_information_matrix (information_matrix_calculator.cpp:14-44,83-88): the oracle's
+    restatement and the product's host arithmetic (mrgfe_inf_weight / mrgfe_inf_matrix_from_fitness, no GPU involved) against the
+    formula written out in numpy."""
+    import ctypes as C
+
+    from mrg_slam_amd import _lib
+    from mrg_slam_amd._lib import lib
+
+    rng = np.random.default_rng(0)
+    p = _lib.InfParams()
+    lib().mrgfe_inf_default_params(C.byref(p))
+    assert (p.use_const_inf_matrix, p.const_stddev_x, p.const_stddev_q, p.var_gain_a, p.min_stddev_x, p.max_stddev_x, p.min_stddev_q, p.max_stddev_q,
+            p.fitness_score_thresh) == (0, 0.5, 0.1, 2.0, 0.1, 0.75, 0.05, 0.2, 1.25)
+    for fit in [0.0, 1e-3, 0.2, 1.25, 3.0, np.finfo(np.float64).max] + list(rng.uniform(0, 2, 20)):
+        w = {}
+        for tag, (lo, hi) in {"x": (0.1, 0.75), "q": (0.05, 0.2)}.items():
+            y = (1.0 - np.exp(-2.0 * fit)) / (1.0 - np.exp(-2.0 * 1.25))
+            w[tag] = lo ** 2 + (hi ** 2 - lo ** 2) * y
+            wo = orc.inf_weight(2.0, 1.25, lo ** 2, hi ** 2, fit)
+            assert wo == pytest.approx(w[tag], rel=1e-14)  # numpy's exp and the C library's differ in the last bit
+            assert lib().mrgfe_inf_weight(2.0, 1.25, lo ** 2, hi ** 2, fit) == wo  # oracle and product: the same C library
+            w[tag] = wo
+        exp = np.diag([1 / w["x"]] * 3 + [1 / w["q"]] * 3)
+        inf = np.empty((6, 6))
+        assert lib().mrgfe_inf_matrix_from_fitness(C.byref(p), fit, inf.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        np.testing.assert_array_equal(inf, exp)
+        v = np.array([0, 0.5, 0.1, 2.0, 0.1, 0.75, 0.05, 0.2, 1.25])
+        o_inf = np.empty((6, 6))
+        orc.lib().orc_inf_matrix(v.ctypes.data_as(C.POINTER(C.c_double)), float(fit), o_inf.ctypes.data_as(C.POINTER(C.c_double)))
+        np.testing.assert_array_equal(o_inf, inf)
+    # constant matrix: the reference divides by the standard deviation itself (:21-22)
+    p.use_const_inf_matrix = 1
+    inf = np.empty((6, 6))
+    lib().mrgfe_inf_matrix_from_fitness(C.byref(p), 123.0, inf.ctypes.data_as(C.POINTER(C.c_double)))
+    np.testing.assert_array_equal(inf, np.diag([2.0] * 3 + [10.0] * 3))
+    o_inf, o_fit = orc.calc_information_matrix(np.zeros((1, 4), np.float32), np.zeros((1, 4), np.float32), np.eye(4), {"use_const_inf_matrix": True})
+    np.testing.assert_array_equal(o_inf, inf)
