@@ -12,6 +12,9 @@ int filter_statistical_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t
 
 // order-preserving compaction of the points whose flag is 1 (exclusive scan of the flags + scatter); synchronises and
 // returns the kept count.  Uses ctx scratch slots 0, 4 and 8.
+// per-run float centroids (sums in ascending sorted position) and the count-threshold flags: the tail of the voxel-grid passes
+int launch_voxel_centroids(mrgfe_ctx* ctx, const float4* d_pts, const uint32_t* d_sorted_vals, const uint32_t* d_seg_start, uint32_t n_seg, int min_pts, float4* d_centroids,
+                           uint32_t* d_keep);
 int compact_by_flags(mrgfe_ctx* ctx, const float4* d_in, uint32_t n, uint32_t* d_flags, float4* d_out, uint32_t* h_total);
 
 struct PrefilterChain {

@@ -100,6 +100,15 @@ __global__ __launch_bounds__(256) void voxel_centroid_kernel(const float4* __res
     keep[s] = (e - b) >= static_cast<uint32_t>(min_pts) ? 1u : 0u;
 }
 
+int launch_voxel_centroids(mrgfe_ctx* ctx, const float4* d_pts, const uint32_t* d_sorted_vals, const uint32_t* d_seg_start, uint32_t n_seg, int min_pts, float4* d_centroids,
+                           uint32_t* d_keep)
+{
+    if (n_seg == 0) return MRGFE_OK;
+    hipLaunchKernelGGL(voxel_centroid_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, ctx->stream, d_pts, d_sorted_vals, d_seg_start, n_seg, min_pts, d_centroids, d_keep);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
 int filter_voxelgrid_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, float leaf, int min_pts, float4* d_out, size_t* out_n, int* overflow)
 {
     *out_n = 0;

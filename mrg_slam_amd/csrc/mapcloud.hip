@@ -7,7 +7,11 @@
 // Float expressions run in the order documented in oracle/mapcloud.cpp (left to right, no FMA).
 #include "mapcloud.h"
 
+#include <algorithm>
+#include <cmath>
 #include <vector>
+
+#include "cellsort.h"
 
 #include "dev_utils.h"
 #include "filters.h"
@@ -46,6 +50,154 @@ __global__ __launch_bounds__(256) void map_transform_kernel(const float4* __rest
     }
     out[i] = make_float4(q[0], q[1], q[2], p.w);
     flags[i] = keep;
+}
+
+// ---- pcl::ApproximateMeanVoxelGrid on occupied cells ------------------------------------------------------------------------
+// The reference keys a hash map on the integer cell (floor(p * inverse_leaf) per axis, ApproximateMeanVoxelGrid.hpp:85-91): no limit
+// on the extent of the map.  A dense linear voxel index over the bounding box (what pcl::VoxelGrid uses, and the prefilter with it)
+// overflows int32 at 200 m x 200 m x 30 m / 0.1 m — smaller than a KITTI map (round 1 returned MRGFE_ERR_OVERFLOW there).  Here the key
+// is the cell itself, bit-packed: (iz - min) | (iy - min) | (ix - min) with just the bits each axis needs (up to 21 per axis), one
+// more bit on top marking non-finite points so that they sort behind every cell.  Up to 32 key bits are one stable radix sort of
+// (key, index) pairs as before; longer keys are sorted low word first, then — stably — by the gathered high word.  Runs of equal
+// keys, float sums in input order, division by float(count) and the count threshold are the voxel-grid pass of filters.hip.
+// Output order: ascending (z, y, x) cell — the same order the dense index gave.
+struct CellKeyParams { float inv_leaf; int32_t min_c[3]; uint32_t shift_y, shift_z, total_bits; };
+
+__global__ __launch_bounds__(256) void mapvox_keys_kernel(const float4* __restrict__ pts, uint32_t n, CellKeyParams kp, uint32_t* __restrict__ key_lo, uint32_t* __restrict__ key_hi,
+                                                           uint32_t* __restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    uint64_t key = uint64_t(1) << kp.total_bits;  // non-finite: behind every cell
+    if (finite3(p.x, p.y, p.z)) {
+        const uint64_t cx = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int>(floorf(p.x * kp.inv_leaf))) - kp.min_c[0]);
+        const uint64_t cy = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int>(floorf(p.y * kp.inv_leaf))) - kp.min_c[1]);
+        const uint64_t cz = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int>(floorf(p.z * kp.inv_leaf))) - kp.min_c[2]);
+        key = cx | (cy << kp.shift_y) | (cz << kp.shift_z);
+    }
+    key_lo[i] = static_cast<uint32_t>(key);
+    key_hi[i] = static_cast<uint32_t>(key >> 32);
+    vals[i] = i;
+}
+__global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t n, uint32_t* __restrict__ dst)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+// run heads of the sorted 64-bit keys among the first n_valid positions (the non-finite points sit behind them)
+__global__ __launch_bounds__(256) void heads64_kernel(const uint32_t* __restrict__ key_lo, const uint32_t* __restrict__ key_hi, const uint32_t* __restrict__ sorted_vals, uint32_t n,
+                                                       uint32_t n_valid, uint32_t* __restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t f = 0;
+    if (i < n_valid) {
+        if (i == 0) f = 1;
+        else {
+            const uint32_t a = sorted_vals[i], b = sorted_vals[i - 1];
+            f = (key_lo[a] != key_lo[b] || key_hi[a] != key_hi[b]) ? 1u : 0u;
+        }
+    }
+    flags[i] = f;
+}
+__global__ __launch_bounds__(256) void seg_from_heads_kernel(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ ordinal, uint32_t n, uint32_t n_valid, uint32_t n_seg,
+                                                              uint32_t* __restrict__ seg_start)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    if (flags[i]) seg_start[ordinal[i]] = i;
+    if (i + 1 == n_valid) seg_start[n_seg] = n_valid;
+}
+
+int mean_voxelgrid_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, float leaf, int min_pts, float4* d_out, size_t* out_n)
+{
+    *out_n = 0;
+    if (n == 0) return MRGFE_OK;
+    hipStream_t st = ctx->stream;
+    uint32_t    nn = static_cast<uint32_t>(n);
+    SliceTable  tab;
+    tab.build(&nn, 1);
+    struct Desc { Slice sl; const float4* cp; };
+    PinBuf& hp = ctx->pin[1];
+    MRGFE_TRY(hp.ensure(sizeof(Desc) + sizeof(BBox) + 16));
+    Desc* hd = hp.as<Desc>();
+    hd->sl = tab.h[0];
+    hd->cp = d_in;
+    DevBuf& dd = ctx->scratch[0];
+    MRGFE_TRY(dd.ensure(sizeof(Desc)));
+    Desc* d_desc = dd.as<Desc>();
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_desc, hd, sizeof(Desc), hipMemcpyHostToDevice, st));
+    DevBuf& dbb = ctx->scratch[1];
+    MRGFE_TRY(dbb.ensure(sizeof(BBox) * (tab.total_blks + 1)));
+    BBox* d_part = dbb.as<BBox>();
+    BBox* d_bbo = d_part + tab.total_blks;
+    MRGFE_TRY(bounding_boxes(ctx, &d_desc->cp, &d_desc->sl, tab, d_part, d_bbo));
+    BBox* h_bb = reinterpret_cast<BBox*>(hp.as<char>() + sizeof(Desc));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(h_bb, d_bbo, sizeof(BBox), hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    const uint32_t n_valid = h_bb->n_finite;
+    if (n_valid == 0) return MRGFE_OK;
+    // cells of the extreme points (float multiply and floor are monotonic, so these are the extreme cells)
+    CellKeyParams kp;
+    kp.inv_leaf = 1.0f / leaf;  // ApproximateMeanVoxelGrid::setLeafSize: inverse_leaf_size_ = 1 / leaf_size_ (float)
+    uint32_t bits[3];
+    for (int a = 0; a < 3; ++a) {
+        const double lo = std::floor(static_cast<double>(h_bb->mn[a] * kp.inv_leaf)), hi = std::floor(static_cast<double>(h_bb->mx[a] * kp.inv_leaf));
+        if (!(lo > -2147483000.0 && hi < 2147483000.0)) { set_error("map cloud: cell index beyond int32 (the reference's int cast overflows there too)"); return MRGFE_ERR_OVERFLOW; }
+        kp.min_c[a] = static_cast<int32_t>(lo);
+        const uint64_t span = static_cast<uint64_t>(hi - lo);
+        bits[a] = 1;
+        while ((uint64_t(1) << bits[a]) <= span) ++bits[a];
+    }
+    kp.shift_y = bits[0];
+    kp.shift_z = bits[0] + bits[1];
+    kp.total_bits = bits[0] + bits[1] + bits[2];
+    if (kp.total_bits > 62) { set_error("map cloud: %u key bits needed (extent / resolution)", kp.total_bits); return MRGFE_ERR_OVERFLOW; }
+    DevBuf &dk = ctx->scratch[2], &dv = ctx->scratch[3], &dkt = ctx->scratch[4], &dvt = ctx->scratch[5], &dh = ctx->scratch[6], &dfl = ctx->scratch[7], &dblk = ctx->scratch[8],
+           &dkh = ctx->scratch[12], &dlo = ctx->scratch[13];
+    MRGFE_TRY(dk.ensure(n * 4)); MRGFE_TRY(dv.ensure(n * 4)); MRGFE_TRY(dkt.ensure(n * 4)); MRGFE_TRY(dvt.ensure(n * 4)); MRGFE_TRY(dkh.ensure(n * 4)); MRGFE_TRY(dlo.ensure(n * 4));
+    MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + 1)));
+    MRGFE_TRY(dfl.ensure(n * 4));
+    MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (tab.total_blks + 8)));
+    const dim3 grid((nn + 255) / 256);
+    // dlo / dkh keep the keys by POINT index; dk is the sort's working copy
+    hipLaunchKernelGGL(mapvox_keys_kernel, grid, dim3(256), 0, st, d_in, nn, kp, dlo.as<uint32_t>(), dkh.as<uint32_t>(), dv.as<uint32_t>());
+    MRGFE_HIP_CHECK(hipGetLastError());
+    MRGFE_HIP_CHECK(hipMemcpyAsync(dk.p, dlo.p, n * 4, hipMemcpyDeviceToDevice, st));
+    const int key_bits = static_cast<int>(kp.total_bits) + 1;
+    uint32_t *sk, *sv;
+    MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), &d_desc->sl, tab, std::min(key_bits, 32), dh.as<uint32_t>(), &sk, &sv));
+    if (key_bits > 32) {
+        // second, stable pass over the high word, gathered into the order the first pass produced
+        uint32_t* k2 = (sk == dk.as<uint32_t>()) ? dk.as<uint32_t>() : dkt.as<uint32_t>();       // the buffer holding the sorted low words: no longer needed
+        uint32_t* k2t = (sk == dk.as<uint32_t>()) ? dkt.as<uint32_t>() : dk.as<uint32_t>();
+        uint32_t* v2t = (sv == dv.as<uint32_t>()) ? dvt.as<uint32_t>() : dv.as<uint32_t>();
+        hipLaunchKernelGGL(gather_u32_kernel, grid, dim3(256), 0, st, dkh.as<uint32_t>(), sv, nn, k2);
+        MRGFE_HIP_CHECK(hipGetLastError());
+        MRGFE_TRY(radix_sort_pairs(ctx, k2, sv, k2t, v2t, &d_desc->sl, tab, key_bits - 32, dh.as<uint32_t>(), &sk, &sv));
+    }
+    hipLaunchKernelGGL(heads64_kernel, grid, dim3(256), 0, st, dlo.as<uint32_t>(), dkh.as<uint32_t>(), sv, nn, n_valid, dfl.as<uint32_t>());
+    MRGFE_HIP_CHECK(hipGetLastError());
+    uint32_t* d_ord = (sk == dk.as<uint32_t>()) ? dkt.as<uint32_t>() : dk.as<uint32_t>();  // the sort buffer that does not hold the result
+    uint32_t* d_tot = dblk.as<uint32_t>() + tab.total_blks;
+    MRGFE_TRY(exclusive_scan(ctx, dfl.as<uint32_t>(), d_ord, &d_desc->sl, tab, dblk.as<uint32_t>(), d_tot));
+    uint32_t* h_tot = reinterpret_cast<uint32_t*>(hp.as<char>() + sizeof(Desc) + sizeof(BBox));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(h_tot, d_tot, 4, hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    const uint32_t V = *h_tot;
+    if (V == 0) return MRGFE_OK;
+    DevBuf &dseg = ctx->scratch[9], &dcent = ctx->scratch[10], &dkeep = ctx->scratch[11];
+    MRGFE_TRY(dseg.ensure(sizeof(uint32_t) * (size_t(V) + 4)));
+    MRGFE_TRY(dcent.ensure(sizeof(float4) * size_t(V)));
+    MRGFE_TRY(dkeep.ensure(sizeof(uint32_t) * size_t(V)));
+    hipLaunchKernelGGL(seg_from_heads_kernel, grid, dim3(256), 0, st, dfl.as<uint32_t>(), d_ord, nn, n_valid, V, dseg.as<uint32_t>());
+    MRGFE_HIP_CHECK(hipGetLastError());
+    MRGFE_TRY(launch_voxel_centroids(ctx, d_in, sv, dseg.as<uint32_t>(), V, min_pts, dcent.as<float4>(), dkeep.as<uint32_t>()));
+    uint32_t kept = 0;
+    MRGFE_TRY(compact_by_flags(ctx, dcent.as<float4>(), V, dkeep.as<uint32_t>(), d_out, &kept));
+    *out_n = kept;
+    return MRGFE_OK;
 }
 
 int map_cloud_device(mrgfe_ctx* ctx, const float4* d_cat, const uint32_t* kf_off, const float* poses_f, int K, float resolution, int min_pts, float far_thresh, float4* d_out,
@@ -94,16 +246,9 @@ int map_cloud_device(mrgfe_ctx* ctx, const float4* d_cat, const uint32_t* kf_off
         if (hipStreamSynchronize(st) != hipSuccess) rc = MRGFE_ERR_HIP;
         *out_n = total;
     } else if (total) {
-        // ApproximateMeanVoxelGrid == the voxel-grid pass: same cells (floor(p * inverse_leaf)), f32 sums in input order
-        // (the radix sort is stable), division by float(count), count threshold; only the output order differs
-        // (ascending voxel index instead of the reference's hash-map order)
-        int overflow = 0;
-        rc = filter_voxelgrid_device(ctx, d_cloud, total, resolution, min_pts, d_out, out_n, &overflow);
-        if (rc == MRGFE_OK && overflow) {
-            *out_n = 0;
-            set_error("map cloud: extent / resolution needs more than 2^31 voxel indices");
-            rc = MRGFE_ERR_OVERFLOW;
-        }
+        // ApproximateMeanVoxelGrid: cells floor(p * inverse_leaf), f32 sums in input order (the radix sort is stable), division by
+        // float(count), count threshold; only the output order differs (ascending cell instead of the reference's hash-map order)
+        rc = mean_voxelgrid_device(ctx, d_cloud, total, resolution, min_pts, d_out, out_n);
     }
     cleanup();
     dcomp.release();

@@ -129,3 +129,31 @@ def test_map_store_equals_the_host_cloud_generator():
     assert store.generate([7, 7], poses_for([7, 7], 1), None) is None                # nothing left from more than one keyframe
     with pytest.raises(RuntimeError):
         store.generate([1, 99], poses_for([1, 99], 2))                               # unknown keyframe
+
+
+@pytest.mark.parametrize("extent_xy,extent_z,resolution", [(400.0, 40.0, 0.1), (3000.0, 60.0, 0.1), (60000.0, 300.0, 0.05), (5.0, 2.0, 0.001)])
+def test_map_cloud_of_any_extent(extent_xy, extent_z, resolution):
+    """The reference's ApproximateMeanVoxelGrid keys a hash map on the integer cell and has no extent limit
+    (ApproximateMeanVoxelGrid.hpp:85-91); a KITTI-sized map at the default 0.1 m has far more than 2^31 cells in its bounding box
+    (round 1 returned MRGFE_ERR_OVERFLOW from 200 x 200 x 30 m on).  Keys are the cells themselves, bit-packed: 32 bits or fewer
+    are one radix sort, more are two (3 km at 0.1 m: 15 + 15 + 10 bits; 60 km at 0.05 m: 21 + 21 + 13).  Bit-exact against the oracle."""
+    from mrg_slam_amd import KeyFrameSnapshot, MapCloudGenerator, synth
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(int(extent_xy))
+    kfs = []
+    for k in range(6):
+        c = rng.normal(0, 4.0, (6000, 4)).astype(np.float32)
+        c[:, 2] *= 0.3
+        c[:, 3] = rng.uniform(0, 1, len(c)).astype(np.float32)
+        centre = [rng.uniform(-extent_xy / 2, extent_xy / 2), rng.uniform(-extent_xy / 2, extent_xy / 2), rng.uniform(-extent_z / 2, extent_z / 2)]
+        kfs.append(KeyFrameSnapshot(synth.make_pose(centre, synth.rot_z(rng.uniform(0, 6.28))), c, first_keyframe=(k == 0)))
+    kfs[1] = KeyFrameSnapshot(kfs[0].pose, kfs[1].cloud, False)  # two keyframes overlap: shared voxels
+    got = MapCloudGenerator().generate(kfs, resolution, 1, 10000.0, False)
+    want, status = orc.map_cloud_generate([k.cloud for k in kfs], [k.pose for k in kfs], [k.first_keyframe for k in kfs], resolution, 1, 10000.0, False)
+    assert status == 0 and got is not None
+    np.testing.assert_array_equal(got, want)
+    got2 = MapCloudGenerator().generate(kfs, resolution, 2, 10000.0, False)
+    want2, _ = orc.map_cloud_generate([k.cloud for k in kfs], [k.pose for k in kfs], [k.first_keyframe for k in kfs], resolution, 2, 10000.0, False)
+    np.testing.assert_array_equal(got2, want2)
+    assert len(got2) < len(got)
