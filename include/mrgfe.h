@@ -90,6 +90,10 @@ typedef struct mrgfe_reg_params {
 const char* mrgfe_last_error(void);
 const char* mrgfe_version(void);
 int  mrgfe_ctx_create(int device_id, mrgfe_ctx** out);
+/* the same with the context's stream at the device's highest stream priority (high_priority != 0): workgroups of its kernels are
+ * dispatched ahead of those of normal contexts as slots free up — for the latency-critical odometry registration of a process that
+ * also runs loop-closure batches (scan_matching_odometry_component next to mrg_slam_component's LoopDetector) */
+int  mrgfe_ctx_create_priority(int device_id, int high_priority, mrgfe_ctx** out);
 void mrgfe_ctx_destroy(mrgfe_ctx* ctx);
 int  mrgfe_ctx_synchronize(mrgfe_ctx* ctx);
 /* HIP stream of the context as an opaque pointer (hipStream_t), for callers that order their own work after it */

@@ -94,6 +94,7 @@ SIGNATURES = {
     "mrgfe_last_error": (C.c_char_p, []),
     "mrgfe_version": (C.c_char_p, []),
     "mrgfe_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "mrgfe_ctx_create_priority": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
     "mrgfe_ctx_destroy": (None, [_vp]),
     "mrgfe_ctx_synchronize": (C.c_int, [_vp]),
     "mrgfe_ctx_stream": (_vp, [_vp]),
@@ -231,9 +232,10 @@ def check(status: int) -> int:
 class Context:
     """mrgfe_ctx: one per (process, GPU)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, high_priority: bool = False):
+        """``high_priority``: the context's stream gets the device's highest stream priority (odometry next to loop-closure batches)."""
         self._h = _vp()
-        check(lib().mrgfe_ctx_create(device, C.byref(self._h)))
+        check(lib().mrgfe_ctx_create_priority(device, int(bool(high_priority)), C.byref(self._h)))
         self.device = device
 
     def synchronize(self):

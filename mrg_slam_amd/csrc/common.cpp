@@ -260,7 +260,15 @@ extern "C" {
 const char* mrgfe_last_error(void) { return mrgfe::get_error(); }
 const char* mrgfe_version(void) { return "mrgfe 0.1 (gfx950)"; }
 
-int mrgfe_ctx_create(int device_id, mrgfe_ctx** out)
+static hipError_t create_stream(hipStream_t* st, bool high_priority)
+{
+    if (!high_priority) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    int least = 0, greatest = 0;  // numerically lower = higher priority
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest);
+}
+
+int mrgfe_ctx_create_priority(int device_id, int high_priority, mrgfe_ctx** out)
 {
     if (!out) { mrgfe::set_error("mrgfe_ctx_create: out is NULL"); return MRGFE_ERR_INVALID; }
     *out = nullptr;
@@ -276,7 +284,7 @@ int mrgfe_ctx_create(int device_id, mrgfe_ctx** out)
     if (c->bind() != MRGFE_OK) { delete c; return MRGFE_ERR_HIP; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->cu_count = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    if (create_stream(&c->stream, high_priority != 0) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         mrgfe::set_error("failed to create HIP stream / events");
         delete c;
         return MRGFE_ERR_HIP;
@@ -287,6 +295,8 @@ int mrgfe_ctx_create(int device_id, mrgfe_ctx** out)
     *out = c;
     return MRGFE_OK;
 }
+
+int mrgfe_ctx_create(int device_id, mrgfe_ctx** out) { return mrgfe_ctx_create_priority(device_id, 0, out); }
 
 void mrgfe_ctx_destroy(mrgfe_ctx* ctx)
 {

@@ -105,7 +105,9 @@ class NdtEngine {
 
     // rounds (see align_all)
     DevBuf d_states_, d_plan_;            // NdtCtlState[P] (device control), the round's plan
-    PinBuf h_states_, h_info_;            // staging of the states, NdtRoundInfo per round (written by the plan kernel)
+    PinBuf h_states_, h_info_, h_plan_;   // staging of the states, NdtRoundInfo per round (written by the plan kernel), host-built plan
+    std::vector<uint32_t> plan_scratch_;
+    void host_plan(std::vector<uint32_t>& plan, uint32_t wg_target, uint32_t max_ppt) const;
     std::vector<hipEvent_t> ev_pool_;     // [round][variant][begin, end]
     int    rounds_ = 0;
     int upload_pairs();

@@ -40,10 +40,10 @@ def counters(path):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     lines = [f"# rocprofv3 summary {tag} (MI355X, gfx950) — `python3 bench.py --no-cpu`", ""]
     stats = list(csv.DictReader(open(os.path.join(OUT, f"prof_{tag}", f"{tag}_kernel_stats.csv"))))
-    lines += ["## --kernel-trace --stats (all kernels of the run: 2 warm-up + 5 timed steps)", "",
+    lines += ["## --kernel-trace --stats (all kernels of the run: 2 warm-up + 5 timed steps; the device-controlled rounds launch all three", "derivative variants every round, so the per-kernel averages include launches that find no busy pair and exit in ~4 us)", "",
               "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---:|---:|---:|---:|---:|---:|"]
     for r in stats:
         lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.2f} | "
@@ -90,10 +90,23 @@ def main():
             if k == DOMINANT:
                 summary["valu_instr_per_wave"] = v.get("SQ_INSTS_VALU", 0) / waves
                 summary["valu_busy_estimate"] = busy
+                summary["valu_busy_dominant"] = busy
     bench = os.path.join(OUT, f"bench_{tag}.json")
     if os.path.exists(bench):
         b = json.load(open(bench))
-        summary["bench"] = {k: b[k] for k in ("value", "unit", "ms_per_step", "roofline", "cpu_baseline", "parity_vs_oracle", "evaluations_per_alignment", "mean_valid_neighbours")}
+        summary["bench"] = {k: b.get(k) for k in ("value", "unit", "ms_per_step", "roofline", "cpu_baseline", "parity_vs_oracle", "evaluations_per_alignment", "mean_valid_neighbours",
+                                                   "single_pair_latency_ms", "config3_shard")}
+        small = {}
+        for bsz in (32, 64, 128):
+            f = os.path.join(OUT, f"bench_{tag}_b{bsz}.json")
+            if os.path.exists(f) and os.path.getsize(f):
+                j = json.load(open(f))
+                small[str(bsz)] = {"value": j["value"], "ms_per_step": j["ms_per_step"]}
+        if small:
+            summary["batch_size_sweep"] = small
+            lines += ["", "## batch-size sweep (`bench.py --no-cpu --shard-steps 0 --batch B --steps 10`)", "", "| pairs per step | alignments/s | ms per step |", "|---:|---:|---:|"]
+            lines += [f"| {k} | {v['value']:.0f} | {v['ms_per_step']:.3f} |" for k, v in small.items()]
+            lines.append(f"| 256 | {b['value']:.0f} | {b['ms_per_step']:.3f} |")
         lines += ["", "## bench.py line of the same build (`python bench.py`)", "", "```json", json.dumps(b, indent=1), "```"]
         if dom:
             ev = b["roofline"]["avg_launch_ms"]
@@ -104,6 +117,13 @@ def main():
         json.dump(json.load(open(extra)), open(os.path.join(ROOT, "profiles", f"{tag}_extra_measurements.json"), "w"), indent=1)
     # kernel stats of the non-headline paths (profiles/side_workloads.py): GICP (33k / 130k points), prefilter chain,
     # calc_fitness_score, loop-closure batch with getFitnessScore
+    shard = os.path.join(OUT, f"prof_shard_{tag}", "s_kernel_stats.csv")
+    if os.path.exists(shard):
+        rows = list(csv.DictReader(open(shard)))
+        lines += ["", "## BASELINE config[3] on one GPU (`rocprofv3 --kernel-trace --stats -- python3 bench.py --mode shard --steps 3 --warmup 1`), top kernels", "",
+                  "| kernel | calls | total ms | avg us | % |", "|---|---:|---:|---:|---:|"]
+        for r in rows[:12]:
+            lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |")
     for w in ("gicp", "gicp_full", "prefilter", "fitness", "lc", "gicp_lc"):
         side = os.path.join(OUT, f"prof_side_{w}", "s_kernel_stats.csv")
         if not os.path.exists(side):

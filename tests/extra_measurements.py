@@ -263,23 +263,27 @@ def main():
             lb.align(-1.0)
             count.append(1)
 
-    cA, cB, cC = Context(0), Context(0), Context(0)
-    alone = []
-    odo_stream(cA, 24, alone)
-    latA, latB, calls, stop = [], [], [], threading.Event()
-    tl = threading.Thread(target=lc_stream, args=(cC, stop, calls))
-    tl.start()
-    time.sleep(0.05)
-    t_begin = time.perf_counter()
-    ta, tb = threading.Thread(target=odo_stream, args=(cA, 60, latA)), threading.Thread(target=odo_stream, args=(cB, 60, latB))
-    ta.start(); tb.start(); ta.join(); tb.join()
-    span = time.perf_counter() - t_begin
-    stop.set()
-    tl.join()
-    both = np.array(latA[4:] + latB[4:])
-    out["two_odometry_streams_plus_loop_closure_stream"] = {
-        "odometry_frame_alone_ms": 1e3 * float(np.median(alone[4:])), "odometry_frame_median_ms": 1e3 * float(np.median(both)), "odometry_frame_p95_ms": 1e3 * float(np.percentile(both, 95)),
-        "odometry_frames_per_s_both_robots": 120 / span, "loop_closure_calls_per_s_64_candidates": len(calls) / span}
+    def concurrent(high_priority):
+        cA, cB, cC = Context(0, high_priority), Context(0, high_priority), Context(0)
+        alone = []
+        odo_stream(cA, 24, alone)
+        latA, latB, calls, stop = [], [], [], threading.Event()
+        tl = threading.Thread(target=lc_stream, args=(cC, stop, calls))
+        tl.start()
+        time.sleep(0.05)
+        t_begin = time.perf_counter()
+        ta, tb = threading.Thread(target=odo_stream, args=(cA, 60, latA)), threading.Thread(target=odo_stream, args=(cB, 60, latB))
+        ta.start(); tb.start(); ta.join(); tb.join()
+        span = time.perf_counter() - t_begin
+        stop.set()
+        tl.join()
+        both = np.array(latA[4:] + latB[4:])
+        return {"odometry_frame_alone_ms": 1e3 * float(np.median(alone[4:])), "odometry_frame_median_ms": 1e3 * float(np.median(both)),
+                "odometry_frame_p95_ms": 1e3 * float(np.percentile(both, 95)), "odometry_frames_per_s_both_robots": 120 / span,
+                "loop_closure_calls_per_s_64_candidates": len(calls) / span}
+
+    out["two_odometry_streams_plus_loop_closure_stream"] = concurrent(False)
+    out["two_high_priority_odometry_streams_plus_loop_closure_stream"] = concurrent(True)
 
     # ---- map cloud of 200 prefiltered keyframes (6.5 M points): host clouds every call vs the HBM map store -------------
     from mrg_slam_amd import KeyFrameSnapshot, MapCloudGenerator, MapCloudStore
