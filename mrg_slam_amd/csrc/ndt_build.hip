@@ -95,30 +95,70 @@ __global__ __launch_bounds__(256) void ndt_leaf_sums_kernel(const float4* const*
     const int      row = lane < 9 ? lane : 0, frow = (lane >= 9 && lane < 13) ? lane - 9 : 0;
     double acc = 0.0;
     float  facc = 0.0f;
-    for (uint32_t base = b; base < e; base += kWave) {
-        const uint32_t i = base + lane;
-        if (i < e) {
-            const float4 p = pts[sorted_vals[s.off + i]];
-            const double x = p.x, y = p.y, z = p.z;
-            s_term[w][0][lane] = x; s_term[w][1][lane] = y; s_term[w][2][lane] = z;
-            s_term[w][3][lane] = x * x; s_term[w][4][lane] = x * y; s_term[w][5][lane] = x * z;
-            s_term[w][6][lane] = y * y; s_term[w][7][lane] = y * z; s_term[w][8][lane] = z * z;
-            s_fterm[w][0][lane] = p.x; s_fterm[w][1][lane] = p.y; s_fterm[w][2][lane] = p.z; s_fterm[w][3][lane] = p.w;
+    // A voxel next to the sensor holds over a thousand points (the inner rings of a VLP-64 put ~90 points per metre on the ground),
+    // and its one wavefront walks them 64 at a time: with one dependent index -> point gather per step that leaf alone took 150 us,
+    // which is what a single registration's setInputTarget waited for.  The gathers of four steps are issued together.
+    constexpr int kAhead = 4;
+    for (uint32_t base4 = b; base4 < e; base4 += kAhead * kWave) {
+        float4 pre[kAhead];
+#pragma unroll
+        for (int d = 0; d < kAhead; ++d) {
+            const uint32_t i = base4 + d * kWave + lane;
+            if (i < e) pre[d] = pts[sorted_vals[s.off + i]];
         }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        const uint32_t cnt = min(static_cast<uint32_t>(kWave), e - base);
-        if (lane < 9) {
-            const double* t = s_term[w][row];
+#pragma unroll
+        for (int d = 0; d < kAhead; ++d) {
+            const uint32_t base = base4 + d * kWave;
+            if (base >= e) break;  // wave-uniform
+            const uint32_t i = base + lane;
+            if (i < e) {
+                const float4 p = pre[d];
+                const double x = p.x, y = p.y, z = p.z;
+                s_term[w][0][lane] = x; s_term[w][1][lane] = y; s_term[w][2][lane] = z;
+                s_term[w][3][lane] = x * x; s_term[w][4][lane] = x * y; s_term[w][5][lane] = x * z;
+                s_term[w][6][lane] = y * y; s_term[w][7][lane] = y * z; s_term[w][8][lane] = z * z;
+                s_fterm[w][0][lane] = p.x; s_fterm[w][1][lane] = p.y; s_fterm[w][2][lane] = p.z; s_fterm[w][3][lane] = p.w;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            const uint32_t cnt = min(static_cast<uint32_t>(kWave), e - base);
+            if (cnt == kWave) {
+                // full step: all 64 staged terms of the row into registers first, then the 64 dependent additions back to back
+                // (the additions of a row cannot be reordered; their operands can be fetched ahead)
+                // (in two halves of 32: 64 values at once cost the kernel its occupancy and the 256-target build 5 %)
+                if (lane < 9) {
+                    const double* t = s_term[w][row];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        double v[32];
+#pragma unroll
+                        for (int j = 0; j < 32; ++j) v[j] = t[h * 32 + j];
+#pragma unroll
+                        for (int j = 0; j < 32; ++j) acc += v[j];
+                    }
+                } else if (lane < 13) {
+                    const float* t = s_fterm[w][frow];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float v[32];
+#pragma unroll
+                        for (int j = 0; j < 32; ++j) v[j] = t[h * 32 + j];
+#pragma unroll
+                        for (int j = 0; j < 32; ++j) facc += v[j];
+                    }
+                }
+            } else if (lane < 9) {
+                const double* t = s_term[w][row];
 #pragma unroll 8
-            for (uint32_t j = 0; j < cnt; ++j) acc += t[j];
-        } else if (lane < 13) {
-            const float* t = s_fterm[w][frow];
+                for (uint32_t j = 0; j < cnt; ++j) acc += t[j];
+            } else if (lane < 13) {
+                const float* t = s_fterm[w][frow];
 #pragma unroll 8
-            for (uint32_t j = 0; j < cnt; ++j) facc += t[j];
+                for (uint32_t j = 0; j < cnt; ++j) facc += t[j];
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
         }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
     }
     double* o = sums + (size_t)(ls.leaf_off + leaf) * 16;
     if (lane < 9) o[lane] = acc;
