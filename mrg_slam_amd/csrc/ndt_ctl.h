@@ -367,12 +367,23 @@ MRGFE_HD void pose_to_matrix(const double p[6], float M[16])
 }
 
 // computeAngleDerivatives: rows a..h of j_ang and a2..f3 of h_ang
+// cs = {cx, sx, cy, sy, cz, sz}: cosine / sine of the three angles with upstream's small-angle rule (|a| < 10e-5: cos 1, sin 0)
+MRGFE_HD double angle_trig(const double p[6], int which)
+{
+    const double a = p[3 + which / 2];
+    if (fabs(a) < 10e-5) return (which & 1) ? 0.0 : 1.0;
+    return (which & 1) ? sin(a) : cos(a);
+}
+MRGFE_HD void angle_tables_from(const double cs[6], double j[8][3], double h[15][3]);
 MRGFE_HD void angle_tables(const double p[6], double j[8][3], double h[15][3])
 {
-    double cx, cy, cz, sx, sy, sz;
-    if (fabs(p[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = cos(p[3]); sx = sin(p[3]); }
-    if (fabs(p[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = cos(p[4]); sy = sin(p[4]); }
-    if (fabs(p[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = cos(p[5]); sz = sin(p[5]); }
+    double cs[6];
+    for (int k = 0; k < 6; ++k) cs[k] = angle_trig(p, k);
+    angle_tables_from(cs, j, h);
+}
+MRGFE_HD void angle_tables_from(const double cs[6], double j[8][3], double h[15][3])
+{
+    const double cx = cs[0], sx = cs[1], cy = cs[2], sy = cs[3], cz = cs[4], sz = cs[5];
     j[0][0] = (-sx * sz + cx * sy * cz); j[0][1] = (-sx * cz - cx * sy * sz); j[0][2] = (-cx * cy);
     j[1][0] = (cx * sz + sx * sy * cz);  j[1][1] = (cx * cz - sx * sy * sz);  j[1][2] = (-sx * cy);
     j[2][0] = (-sy * cz);                j[2][1] = sy * sz;                   j[2][2] = cy;
@@ -408,12 +419,12 @@ MRGFE_HD void make_request(NdtCtlState& s, int mode, const double p[6])
 }
 
 // the record the derivative kernels read for the pending request of `s` (its transform is final_ as of the request)
-MRGFE_HD void fill_eval(const NdtCtlState& s, NdtEvalDev& e)
+MRGFE_HD void fill_eval_from(const NdtCtlState& s, const double cs[6], NdtEvalDev& e)
 {
     if (done(s)) { e.active = 0; return; }
     for (int k = 0; k < 12; ++k) e.T[k] = s.final_[k];
     double j[8][3], h[15][3];
-    angle_tables(s.req_p, j, h);
+    angle_tables_from(cs, j, h);
     for (int a = 0; a < 8; ++a) for (int b = 0; b < 3; ++b) { e.j_ang_d[a][b] = j[a][b]; e.j_ang[a][b] = static_cast<float>(j[a][b]); }
     for (int a = 0; a < 15; ++a) for (int b = 0; b < 3; ++b) { e.h_ang_d[a][b] = h[a][b]; e.h_ang[a][b] = static_cast<float>(h[a][b]); }
     e.gauss_d1 = s.gauss_d1;
@@ -421,6 +432,13 @@ MRGFE_HD void fill_eval(const NdtCtlState& s, NdtEvalDev& e)
     e.mode = s.req_mode;
     e.active = 1;
     e.search = s.search;
+}
+MRGFE_HD void fill_eval(const NdtCtlState& s, NdtEvalDev& e)
+{
+    if (done(s)) { e.active = 0; return; }
+    double cs[6];
+    for (int k = 0; k < 6; ++k) cs[k] = angle_trig(s.req_p, k);
+    fill_eval_from(s, cs, e);
 }
 
 MRGFE_HD void store_result(NdtCtlState& s, const double r[44], bool with_score_grad, bool with_hessian, bool counted = true)

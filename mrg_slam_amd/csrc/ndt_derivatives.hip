@@ -580,9 +580,13 @@ __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __res
             if (threadIdx.x == 0) next = ctl::after_solve(st, s_delta);
             next = __shfl(next, 0, kWave);
         }
+        // the six double-precision sines / cosines of the next request's angle tables: one lane each instead of six in a row
+        __shared__ double s_cs[6];
+        if (threadIdx.x < 6 && !ctl::done(st)) s_cs[threadIdx.x] = ctl::angle_trig(st.req_p, threadIdx.x);
+        ctl::svd_wave_sync();
         if (threadIdx.x == 0) {
             s_eval.active = 0;
-            ctl::fill_eval(st, s_eval);
+            ctl::fill_eval_from(st, s_cs, s_eval);
         }
     }
     __syncthreads();
