@@ -393,7 +393,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
     }
 }
 
-// block partial = (sum, count) over a fixed slice of the job's queries
+constexpr uint32_t kFitSumSlice = 1024;
+// block partial = (sum, count) over queries [1024 b, 1024 (b + 1)) of the job: the slices and the order of the additions depend on
+// the job alone, not on the other jobs of the batch (a block past the job's end writes zeros, which add exactly), so a pair's
+// fitness score is the same whichever batch or rank it is matched in
 __global__ __launch_bounds__(256) void nn_fit_sum_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, const float* __restrict__ sqd,
                                                           double* __restrict__ partial)
 {
@@ -402,9 +405,12 @@ __global__ __launch_bounds__(256) void nn_fit_sum_kernel(const NnFitnessJob* __r
     const uint32_t n = jobs[blockIdx.y].n, off = job_off[blockIdx.y];
     double   sum = 0.0;
     uint32_t cnt = 0;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const float d = sqd[off + i];
-        if (d >= 0.0f) { sum += static_cast<double>(d); ++cnt; }
+    for (uint32_t k = 0; k < kFitSumSlice / 256u; ++k) {
+        const uint32_t i = blockIdx.x * kFitSumSlice + k * 256u + threadIdx.x;
+        if (i < n) {
+            const float d = sqd[off + i];
+            if (d >= 0.0f) { sum += static_cast<double>(d); ++cnt; }
+        }
     }
     sum = wave_sum(sum);
     cnt = wave_sum(cnt);
@@ -452,7 +458,7 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     // enough blocks to fill the chip many times over (the far pass is ragged), few enough that each has a few trips
     const uint32_t want = static_cast<uint32_t>(std::max<size_t>(1, (size_t(ctx->cu_count) * 128 + count - 1) / count));
     const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((max_n + per_blk - 1) / per_blk, want));
-    const uint32_t nblk_sum = std::max<uint32_t>(1, std::min<uint32_t>((max_n + 1023) / 1024, 256));
+    const uint32_t nblk_sum = (max_n + kFitSumSlice - 1) / kFitSumSlice;
     // scratch 9: jobs, offsets, queue lengths, partial sums; 12: one float per query; 13: the queues (10 and 11 may hold
     // the caller's clouds, see mrgfe_calc_fitness_score)
     DevBuf &dw = ctx->scratch[9], &dq = ctx->scratch[12], &dp = ctx->scratch[13];

@@ -5,7 +5,10 @@ The reference aligns every candidate keyframe against the new keyframe sequentia
 (:126-145) and keeps the candidate with the lowest fitness score among the converged ones.  The alignments are
 independent (they share only the read-only target), so here
 
-* the pairs are sharded round-robin over the ranks (one process per GPU): pair i -> rank i mod G   (SURVEY.md §8e),
+* the pairs are sharded over the ranks (one process per GPU) in contiguous blocks of the candidate list, sizes differing by at
+  most one.  The list is ordered by new keyframe (the reference matches keyframe after keyframe,
+  loop_detector.cpp:21-31), so a rank's block touches few distinct targets and builds only those voxel grids — with round-robin
+  (pair i -> rank i mod G) every rank built nearly every target of a many-keyframe batch (64 / 64 / 53 / 32 of 64 at G = 1 / 2 / 4 / 8);
 * each rank advances its shard on its GPU with the batched engine (``BatchMatcher``), no data-path collective,
 * the ranks all-gather the fixed-size 384-byte result records (pose, 6x6 Hessian, fitness, flags) — RCCL over xGMI
   on GPUs (``backend="nccl"``), gloo in the CPU tests,
@@ -21,9 +24,14 @@ import numpy as np
 from .registration import RESULT_DTYPE
 
 
-def shard_indices(n_pairs: int, world_size: int, rank: int) -> np.ndarray:
-    """Pairs owned by ``rank``: i with i mod world_size == rank (round-robin keeps ragged batches balanced)."""
-    return np.arange(rank, n_pairs, world_size, dtype=np.int64)
+def shard_indices(n_pairs: int, world_size: int, rank: int, policy: str = "block") -> np.ndarray:
+    """Pairs owned by ``rank``.  "block" (default): the rank-th of world_size contiguous blocks whose sizes differ by at most one
+    (the first n_pairs mod world_size blocks are the longer ones); "round_robin": i with i mod world_size == rank."""
+    if policy == "round_robin":
+        return np.arange(rank, n_pairs, world_size, dtype=np.int64)
+    base, extra = divmod(n_pairs, world_size)
+    lo = rank * base + min(rank, extra)
+    return np.arange(lo, lo + base + (1 if rank < extra else 0), dtype=np.int64)
 
 
 def gather_records(local: np.ndarray, n_pairs: int, group=None) -> np.ndarray:

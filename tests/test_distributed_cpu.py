@@ -86,7 +86,7 @@ def test_two_rank_gather_equals_sequential_loop(n):
         rec = np.frombuffer(blob, dtype=RESULT_DTYPE)
         assert rec.tobytes() == table.tobytes()  # every rank holds every record, in candidate order
         assert (best, score) == (exp_best, exp_score)
-        assert all(i % 2 == rank for i in mine)
+        assert mine == list(range(min(mine), max(mine) + 1)) if mine else True  # a contiguous block of the candidate list
         shards |= set(mine)
     assert shards == set(range(n))
 
@@ -176,3 +176,9 @@ def test_loop_workload_is_config3_shaped_and_rank_independent():
         seen = np.concatenate([lc.shard_indices(256, world, r) for r in range(world)])
         assert sorted(seen.tolist()) == list(range(256))
         assert max(len(lc.shard_indices(256, world, r)) for r in range(world)) == 256 // world
+        # contiguous blocks of the keyframe-ordered list: a rank builds about 64 / world (+1) target grids, not all of them
+        assert max(len({pairs[i][0] for i in lc.shard_indices(256, world, r)}) for r in range(world)) <= 64 // world + 2
+    for n, world in ((7, 3), (5, 8), (0, 2)):
+        parts = [lc.shard_indices(n, world, r) for r in range(world)]
+        assert np.concatenate(parts).tolist() == list(range(n)) and max(map(len, parts)) - min(map(len, parts)) <= 1
+        assert sorted(np.concatenate([lc.shard_indices(n, world, r, "round_robin") for r in range(world)]).tolist()) == list(range(n))

@@ -98,7 +98,7 @@ def test_config4_256_candidate_pairs_as_bench_shards_them():
     """BASELINE config[3] at its stated size: bench.py's 256 (new keyframe, candidate) pairs over 64 ring keyframes, VLP-64 clouds,
     getFitnessScore(inf), one batch.  A sample of the pairs is held against the oracle's sequential loop (align + fitness), the
     best-candidate replay of every new keyframe in the sample against the reference's rule, and sharding the same pairs over 2 or
-    8 'ranks' (pair i -> rank i mod G, run one after the other on this GPU) must reproduce the one-GPU transforms, fitness scores,
+    8 'ranks' (contiguous blocks of the list, and the round-robin split pair i -> rank i mod G; run one after the other on this GPU) must reproduce the one-GPU transforms, fitness scores,
     convergence flags and iteration counts bit for bit."""
     import sys
 
@@ -127,13 +127,13 @@ def test_config4_256_candidate_pairs_as_bench_shards_them():
 
     full = run(list(range(256)))
     assert int(full["converged"].sum()) >= 250
-    for world in (2, 8):
+    for world, policy in ((2, "block"), (8, "block"), (8, "round_robin")):
         merged = np.zeros(256, dtype=RESULT_DTYPE)
         for rank in range(world):
-            part = run(loop_closure.shard_indices(256, world, rank).tolist())
+            part = run(loop_closure.shard_indices(256, world, rank, policy).tolist())
             merged[part["pair_id"]] = part
         for f in ("T", "fitness", "converged", "iterations", "evaluations"):
-            assert np.array_equal(merged[f], full[f]), (world, f)
+            assert np.array_equal(merged[f], full[f]), (world, policy, f)
         # the f64 Hessians carry the order of their sums: a round with fewer busy pairs cuts a cloud into smaller work items
         # (ndt_plan_kernel), which regroups additions — 1e-15 relative, and the float transforms above come out the same
         np.testing.assert_allclose(merged["H"], full["H"], rtol=0, atol=1e-12 * np.abs(full["H"]).max())
