@@ -88,6 +88,10 @@ __device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, co
                 const int lo = i < j ? i : j, hi = i < j ? j : i;
                 const int ph = (lo == 3) ? (hi - 3) : (lo == 4 ? (hi - 4 + 3) : 5);
                 // (skipping the structural zeros J3[0] and PH[a..c][0] here was measured: no gain without packed f32, 8 % slower with it)
+                // (a hand-laid packed-f32 form of this function — R^3 vectors as (xy pair, z), Hessian columns (0,1) and (4,5) as pairs,
+                // scalars broadcast through op_sel — brings the pair loop from 358 to 334 VALU instructions (208 -> 83 scalar + 76 packed
+                // f32 operations, 27 moves) but wants 205 VGPRs; under the 168 of three waves per SIMD the allocator rotates the f64
+                // accumulators through 99 extra v_mov_b64 per pair.  Not kept.)
                 qch = fdot3f(qC[0], PH[ph][0], qC[1], PH[ph][1], qC[2], PH[ph][2]);
             }
             const float t0 = -gauss_d2f * qCJ[i];
