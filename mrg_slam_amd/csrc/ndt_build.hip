@@ -66,104 +66,221 @@ __global__ __launch_bounds__(256) void ndt_segments_kernel(const uint32_t* __res
     }
 }
 
-// (Measured and dropped in round 2: a wavefront that owns the leaves starting in a 256-point segment of the sorted stream,
-// fetches 64 points per step whatever the leaf boundaries and spreads the (leaf, term) chains over all 64 lanes — every lane
-// busy, bit-identical sums — took 1.04 ms per 256 targets of 130k points against 0.82 ms for the kernel below, software
-// pipelined and with the leaf extents kept in LDS: the kernel is bound by the random 16-byte point gather through the sorted
-// index, which a wavefront per leaf overlaps better — 5.6 M short independent wavefronts — than 130 k long ones.)
-// one wavefront per leaf. The reference accumulates each voxel's sums point by point in index order
-// (pclomp::VoxelGridCovariance first pass); to reproduce those f64 sums BIT FOR BIT the additions of one accumulator stay
-// sequential and the parallelism is moved elsewhere:
-//   step A  64 lanes fetch 64 points of the leaf (coalesced index read + 16-byte gather) and each lane computes the 13
-//           terms of ITS point (x,y,z, the six products in f64, x,y,z,intensity in f32) into LDS, [term][point];
-//   step B  lane k (k < 13) walks row k of the staged terms in point order and adds them to its accumulator: 13
-//           independent dependent-add chains, fed by pipelined conflict-free LDS reads.
+// The reference accumulates each voxel's sums point by point in index order (pclomp::VoxelGridCovariance first pass); to
+// reproduce those f64 sums BIT FOR BIT the additions of one accumulator stay sequential — a voxel is 13 dependent-add chains (x, y,
+// z, the six products in f64; x, y, z, intensity in f32) — and the parallelism is moved elsewhere.  What the kernel waits for is
+// then the LONGEST chain: a voxel next to the sensor holds thousands of points (the inner rings of a VLP-64 put ~90 points per
+// metre on the ground; 5145 in the benchmark scans), and with one wavefront per voxel in launch order the 256-target build ran at 1.4
+// resident wavefronts per SIMD (SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE) behind the big voxels of the last targets.  So:
+//   * voxels of more than kLeafBig points are listed per target (ndt_big_leaves_kernel) and taken by the FIRST workgroups of the
+//     launch, one wavefront each, built for a short chain: the gathers of four 64-point steps in flight, every point's 13 terms
+//     computed by its lane into LDS, then three instructions per point on the chain (8-byte LDS read, f64 add, f32 add);
+//   * the rest go four at a time per wavefront, one per group of 13 lanes (group g takes the voxels g, g + 4, ... of a span of
+//     kLeafSpan and moves on when one is finished, so unequal voxels even out): per round and group 64 lanes fetch the next 64
+//     points (coalesced index read + 16-byte gather, the gathers of the NEXT round in flight while this round is summed) into
+//     LDS as rows x, y, z, intensity; lanes past the voxel's end store zeros — the accumulators start at +0 and are never -0,
+//     so adding a zero term is exact — and lane k of group g walks row(ia) * row(ib) (a row of ones standing for the factor of
+//     the plain sums: x * 1.0 == x) or row(k - 9) of ITS group's rows in point order; the products are not on the chain;
+//   * the target index is the fast grid dimension: the big voxels of ALL targets start at once.
+// (Dropped earlier in round 2: owning the voxels that start in a 256-point window of the sorted stream and fetching 64 points
+// per step across voxel boundaries, without the look-ahead: 1.04 ms against 0.87 ms for one wavefront per voxel.)
 // sums layout per leaf (16 doubles): [0..2] sum p, [3..8] sum xx,xy,xz,yy,yz,zz, [9] n, [10..13] float centroid sums.
-__global__ __launch_bounds__(256) void ndt_leaf_sums_kernel(const float4* const* __restrict__ clouds, const uint32_t* __restrict__ sorted_vals, const Slice* __restrict__ slices,
-                                                             const LeafSlice* __restrict__ leaf_slices, const uint32_t* __restrict__ seg_start,
-                                                             double* __restrict__ sums)
+constexpr int      kLeafGroups = 4;     // voxels in flight per wavefront (small voxels)
+constexpr int      kLeafSpan = 16;      // voxels per wavefront
+constexpr uint32_t kLeafBig = 256;      // points above which a voxel gets a wavefront of its own
+constexpr uint32_t kLeafBigBlocks = 64; // workgroups per target that walk the list of big voxels
+
+// one thread per voxel: the big ones into the target's list (the order of the list does not enter any result)
+__global__ __launch_bounds__(256) void ndt_big_leaves_kernel(const LeafSlice* __restrict__ leaf_slices, const uint32_t* __restrict__ seg_start, uint32_t* __restrict__ big_cnt,
+                                                              uint32_t* __restrict__ big_list)
 {
-    __shared__ double s_term[4][9][kWave + 1];   // +1: the 13 row readers hit different banks
-    __shared__ float  s_fterm[4][4][kWave + 1];
     const LeafSlice ls = leaf_slices[blockIdx.y];
-    const uint32_t  leaf = blockIdx.x * 4 + wave_id();
-    if (leaf >= ls.n_leaves) return;  // wave-uniform
-    const Slice    s = slices[blockIdx.y];
-    const float4* __restrict__ pts = clouds[blockIdx.y];
-    const uint32_t b = seg_start[ls.seg_off + leaf], e = seg_start[ls.seg_off + leaf + 1];
-    const int      lane = lane_id(), w = wave_id();
-    const int      row = lane < 9 ? lane : 0, frow = (lane >= 9 && lane < 13) ? lane - 9 : 0;
+    const uint32_t  leaf = blockIdx.x * 256u + threadIdx.x;
+    if (leaf >= ls.n_leaves) return;
+    if (seg_start[ls.seg_off + leaf + 1] - seg_start[ls.seg_off + leaf] > kLeafBig) big_list[ls.leaf_off + atomicAdd(&big_cnt[blockIdx.y], 1u)] = leaf;
+}
+
+__device__ __forceinline__ void leaf_store(double* __restrict__ o, int k, double acc, float facc, uint32_t n)
+{
+    if (k < 9) o[k] = acc;
+    else if (k < 13) o[k + 1] = static_cast<double>(facc);
+    if (k == 9) o[9] = static_cast<double>(n);
+}
+
+__global__ __launch_bounds__(64, 6) void ndt_leaf_sums_kernel(const float4* const* __restrict__ clouds, const uint32_t* __restrict__ sorted_vals, const Slice* __restrict__ slices,
+                                                               const LeafSlice* __restrict__ leaf_slices, const uint32_t* __restrict__ seg_start,
+                                                               const uint32_t* __restrict__ big_cnt, const uint32_t* __restrict__ big_list, double* __restrict__ sums)
+{
+    // small voxels: rows x, y, z, intensity, ones per group (+1: the rows lie in different banks); big voxels: 13 rows of 8-byte slots
+    __shared__ double s_mem[13 * (kWave + 1)];
+    static_assert(sizeof(double) * 13 * (kWave + 1) >= sizeof(float) * kLeafGroups * 5 * (kWave + 1), "LDS union");
+    const LeafSlice ls = leaf_slices[blockIdx.x];
+    const Slice     s = slices[blockIdx.x];
+    const float4* __restrict__ pts = clouds[blockIdx.x];
+    const uint32_t* __restrict__ order = sorted_vals + s.off;
+    const int lane = lane_id();
+
+    if (blockIdx.y < kLeafBigBlocks) {
+        // ---- big voxels: one at a time --------------------------------------------------------------------------------------
+        double (*s_t)[kWave + 1] = reinterpret_cast<double (*)[kWave + 1]>(s_mem);
+        const uint32_t n_big = big_cnt[blockIdx.x];
+        const int      k = lane < 13 ? lane : 12;
+        const double* __restrict__ row = s_t[k];
+        for (uint32_t bi = blockIdx.y; bi < n_big; bi += kLeafBigBlocks) {
+            const uint32_t leaf = big_list[ls.leaf_off + bi];
+            const uint32_t b = seg_start[ls.seg_off + leaf], e = seg_start[ls.seg_off + leaf + 1];
+            double acc = 0.0;
+            float  facc = 0.0f;
+            constexpr int kAhead = 4;
+            float4 pre[kAhead];
+            auto fetch4 = [&](uint32_t base4) {  // unconditional loads of positions that exist: all index reads, one wait, all gathers
+                uint32_t id[kAhead];
+#pragma unroll
+                for (int d = 0; d < kAhead; ++d) id[d] = order[min(base4 + d * kWave + lane, e - 1)];
+#pragma unroll
+                for (int d = 0; d < kAhead; ++d) pre[d] = pts[id[d]];
+            };
+            fetch4(b);
+            for (uint32_t base4 = b; base4 < e; base4 += kAhead * kWave) {
+                float4 cur4[kAhead];
+#pragma unroll
+                for (int d = 0; d < kAhead; ++d) cur4[d] = pre[d];
+                if (base4 + kAhead * kWave < e) fetch4(base4 + kAhead * kWave);  // wave-uniform
+#pragma unroll
+                for (int d = 0; d < kAhead; ++d) {
+                    const uint32_t base = base4 + d * kWave;
+                    if (base >= e) break;  // wave-uniform
+                    {
+                        const bool   in = base + lane < e;
+                        const float4 p = cur4[d];
+                        const double x = p.x, y = p.y, z = p.z;
+                        // a lane past the end stores zeros (exact to add, see above)
+                        s_t[0][lane] = in ? x : 0.0; s_t[1][lane] = in ? y : 0.0; s_t[2][lane] = in ? z : 0.0;
+                        s_t[3][lane] = in ? x * x : 0.0; s_t[4][lane] = in ? x * y : 0.0; s_t[5][lane] = in ? x * z : 0.0;
+                        s_t[6][lane] = in ? y * y : 0.0; s_t[7][lane] = in ? y * z : 0.0; s_t[8][lane] = in ? z * z : 0.0;
+                        // the f32 sums travel in the low half of an 8-byte slot: one read serves both kinds of chain
+                        reinterpret_cast<float*>(&s_t[9][lane])[0] = in ? p.x : 0.0f; reinterpret_cast<float*>(&s_t[10][lane])[0] = in ? p.y : 0.0f;
+                        reinterpret_cast<float*>(&s_t[11][lane])[0] = in ? p.z : 0.0f; reinterpret_cast<float*>(&s_t[12][lane])[0] = in ? p.w : 0.0f;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    __threadfence_block();
+                    const uint32_t cnt = min(static_cast<uint32_t>(kWave), e - base);
+                    for (uint32_t h = 0; h < (cnt + 15) / 16; ++h) {
+                        double v[16];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) v[j] = row[h * 16 + j];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            acc += v[j];
+                            facc += __builtin_bit_cast(float, static_cast<uint32_t>(__builtin_bit_cast(unsigned long long, v[j])));
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    __threadfence_block();
+                }
+            }
+            if (lane < 13) leaf_store(sums + (size_t)(ls.leaf_off + leaf) * 16, lane, acc, facc, e - b);
+        }
+        return;
+    }
+
+    // ---- small voxels: four at a time ---------------------------------------------------------------------------------------
+    float (*s_c)[5][kWave + 1] = reinterpret_cast<float (*)[5][kWave + 1]>(s_mem);
+  for (uint32_t first = (blockIdx.y - kLeafBigBlocks) * kLeafSpan; first < ls.n_leaves; first += (gridDim.y - kLeafBigBlocks) * kLeafSpan) {  // (one trip unless the grid was capped)
+    const uint32_t span = min(static_cast<uint32_t>(kLeafSpan), ls.n_leaves - first);
+    // extents of the span's voxels: lane l holds the start of voxel first + l (l <= span)
+    const uint32_t seg_v = seg_start[ls.seg_off + first + min(static_cast<uint32_t>(lane), span)];
+    auto seg_at = [&](uint32_t l) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(seg_v), static_cast<int>(l))); };
+    const int g = min(lane / 13, kLeafGroups - 1), k = lane < 52 ? lane % 13 : 13;  // k == 13: spare lanes, never stored
+    //   k:  0 1 2 | 3  4  5  6  7  8         (x y z | xx xy xz yy yz zz)
+    const int ia = k < 3 ? k : (k < 6 ? 0 : (k < 8 ? 1 : 2));
+    const int ib = k < 3 ? 4 : (k < 6 ? k - 3 : (k < 8 ? k - 5 : 2));
+    const float* __restrict__ ra = s_c[g][ia];
+    const float* __restrict__ rb = s_c[g][ib];
+    const float* __restrict__ rf = s_c[g][(k - 9) & 3];
+#pragma unroll
+    for (int q = 0; q < kLeafGroups; ++q) s_c[q][4][lane] = 1.0f;
+    // per group (wave-uniform): the voxel of the span it is on, the next position in it, its end
+    uint32_t cur[kLeafGroups], pos[kLeafGroups], end[kLeafGroups];
+    auto enter = [&](int q) {  // group q on to its next small voxel
+        pos[q] = end[q] = 0;
+        while (cur[q] < span) {
+            pos[q] = seg_at(cur[q]);
+            end[q] = seg_at(cur[q] + 1);
+            if (end[q] - pos[q] <= kLeafBig) break;
+            cur[q] += kLeafGroups;  // a big one: not ours
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < kLeafGroups; ++q) { cur[q] = q; enter(q); }
     double acc = 0.0;
     float  facc = 0.0f;
-    // A voxel next to the sensor holds over a thousand points (the inner rings of a VLP-64 put ~90 points per metre on the ground),
-    // and its one wavefront walks them 64 at a time: with one dependent index -> point gather per step that leaf alone took 150 us,
-    // which is what a single registration's setInputTarget waited for.  The gathers of four steps are issued together.
-    constexpr int kAhead = 4;
-    for (uint32_t base4 = b; base4 < e; base4 += kAhead * kWave) {
-        float4 pre[kAhead];
+    float4   pre[kLeafGroups];
+    uint32_t cnt[kLeafGroups];
+    auto fetch = [&]() {  // the next 64 points of every group's voxel
+        // unconditional loads from positions that exist (a lane past the end re-reads a point and drops it): no branch between
+        // them, so the four index reads go out together and the four gathers after ONE wait
+        uint32_t id[kLeafGroups];
 #pragma unroll
-        for (int d = 0; d < kAhead; ++d) {
-            const uint32_t i = base4 + d * kWave + lane;
-            if (i < e) pre[d] = pts[sorted_vals[s.off + i]];
+        for (int q = 0; q < kLeafGroups; ++q) {
+            cnt[q] = cur[q] < span ? min(static_cast<uint32_t>(kWave), end[q] - pos[q]) : 0u;
+            const uint32_t at = cur[q] < span ? pos[q] : seg_at(0);
+            id[q] = order[at + (static_cast<uint32_t>(lane) < cnt[q] ? lane : 0)];
         }
 #pragma unroll
-        for (int d = 0; d < kAhead; ++d) {
-            const uint32_t base = base4 + d * kWave;
-            if (base >= e) break;  // wave-uniform
-            const uint32_t i = base + lane;
-            if (i < e) {
-                const float4 p = pre[d];
-                const double x = p.x, y = p.y, z = p.z;
-                s_term[w][0][lane] = x; s_term[w][1][lane] = y; s_term[w][2][lane] = z;
-                s_term[w][3][lane] = x * x; s_term[w][4][lane] = x * y; s_term[w][5][lane] = x * z;
-                s_term[w][6][lane] = y * y; s_term[w][7][lane] = y * z; s_term[w][8][lane] = z * z;
-                s_fterm[w][0][lane] = p.x; s_fterm[w][1][lane] = p.y; s_fterm[w][2][lane] = p.z; s_fterm[w][3][lane] = p.w;
+        for (int q = 0; q < kLeafGroups; ++q) pre[q] = pts[id[q]];
+#pragma unroll
+        for (int q = 0; q < kLeafGroups; ++q)
+            if (static_cast<uint32_t>(lane) >= cnt[q]) pre[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    };
+    fetch();
+    for (;;) {
+        uint32_t now_leaf[kLeafGroups], now_n[kLeafGroups];
+        bool     now_done[kLeafGroups];
+        uint32_t maxcnt = 0;
+#pragma unroll
+        for (int q = 0; q < kLeafGroups; ++q) {
+            s_c[q][0][lane] = pre[q].x; s_c[q][1][lane] = pre[q].y; s_c[q][2][lane] = pre[q].z; s_c[q][3][lane] = pre[q].w;
+            now_leaf[q] = cur[q];
+            maxcnt = max(maxcnt, cnt[q]);
+            pos[q] += cnt[q];
+            now_done[q] = cur[q] < span && pos[q] == end[q];
+            now_n[q] = 0;
+            if (now_done[q]) {  // on to the group's next voxel
+                now_n[q] = end[q] - seg_at(cur[q]);
+                cur[q] += kLeafGroups;
+                enter(q);
             }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
-            const uint32_t cnt = min(static_cast<uint32_t>(kWave), e - base);
-            if (cnt == kWave) {
-                // full step: all 64 staged terms of the row into registers first, then the 64 dependent additions back to back
-                // (the additions of a row cannot be reordered; their operands can be fetched ahead)
-                // (in two halves of 32: 64 values at once cost the kernel its occupancy and the 256-target build 5 %)
-                if (lane < 9) {
-                    const double* t = s_term[w][row];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        double v[32];
-#pragma unroll
-                        for (int j = 0; j < 32; ++j) v[j] = t[h * 32 + j];
-#pragma unroll
-                        for (int j = 0; j < 32; ++j) acc += v[j];
-                    }
-                } else if (lane < 13) {
-                    const float* t = s_fterm[w][frow];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        float v[32];
-#pragma unroll
-                        for (int j = 0; j < 32; ++j) v[j] = t[h * 32 + j];
-#pragma unroll
-                        for (int j = 0; j < 32; ++j) facc += v[j];
-                    }
-                }
-            } else if (lane < 9) {
-                const double* t = s_term[w][row];
-#pragma unroll 8
-                for (uint32_t j = 0; j < cnt; ++j) acc += t[j];
-            } else if (lane < 13) {
-                const float* t = s_fterm[w][frow];
-#pragma unroll 8
-                for (uint32_t j = 0; j < cnt; ++j) facc += t[j];
-            }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
         }
+        if (maxcnt == 0) break;  // wave-uniform: every group is through its voxels
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        fetch();  // the gathers of the next round fly while this one is summed
+        // the staged values into registers eight at a time, then their additions back to back (the additions of an accumulator
+        // cannot be reordered; their operands can be fetched and multiplied ahead).  Rows are zero past a voxel's end, so the last
+        // eight may run over it.
+        for (uint32_t h = 0; h < (maxcnt + 7) / 8; ++h) {
+            double t[8];
+            float  f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { t[j] = static_cast<double>(ra[h * 8 + j]) * static_cast<double>(rb[h * 8 + j]); f[j] = rf[h * 8 + j]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { acc += t[j]; facc += f[j]; }
+        }
+        // voxels that ended in this round: out with their sums, and the group's accumulators start over
+#pragma unroll
+        for (int q = 0; q < kLeafGroups; ++q) {
+            if (!now_done[q]) continue;  // wave-uniform
+            if (g == q && k < 13) {
+                leaf_store(sums + (size_t)(ls.leaf_off + first + now_leaf[q]) * 16, k, acc, facc, now_n[q]);
+                acc = 0.0;
+                facc = 0.0f;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
     }
-    double* o = sums + (size_t)(ls.leaf_off + leaf) * 16;
-    if (lane < 9) o[lane] = acc;
-    else if (lane == 9) o[9] = static_cast<double>(e - b);
-    if (lane >= 9 && lane < 13) o[lane + 1] = static_cast<double>(facc);
+  }
 }
 
 // one thread per leaf: pclomp::VoxelGridCovariance second pass + lookup insertion
@@ -259,12 +376,15 @@ int ndt_launch_segments(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, const uin
 }
 
 int ndt_launch_leaves(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32_t* d_sorted_vals, const Slice* d_slices, const SliceTable& t, const LeafSlice* d_leaf_slices,
-                      const VoxelParams* d_vp, uint32_t max_leaves, const uint32_t* d_seg_start, const int32_t* d_seg_key, double* d_sums, NdtLeafRec* d_leaves,
-                      double* d_icov64, float4* d_centroid, int32_t* d_nr_points, void* d_lookup_base)
+                      const VoxelParams* d_vp, uint32_t max_leaves, const uint32_t* d_seg_start, uint32_t* d_big_cnt, uint32_t* d_big_list, const int32_t* d_seg_key, double* d_sums,
+                      NdtLeafRec* d_leaves, double* d_icov64, float4* d_centroid, int32_t* d_nr_points, void* d_lookup_base)
 {
     if (t.nprob() == 0 || max_leaves == 0) return MRGFE_OK;
-    hipLaunchKernelGGL(ndt_leaf_sums_kernel, dim3((max_leaves + 3) / 4, t.nprob()), dim3(256), 0, ctx->stream, d_clouds, d_sorted_vals, d_slices, d_leaf_slices,
-                       d_seg_start, d_sums);
+    MRGFE_HIP_CHECK(hipMemsetAsync(d_big_cnt, 0, sizeof(uint32_t) * t.nprob(), ctx->stream));
+    hipLaunchKernelGGL(ndt_big_leaves_kernel, dim3((max_leaves + 255) / 256, t.nprob()), dim3(256), 0, ctx->stream, d_leaf_slices, d_seg_start, d_big_cnt, d_big_list);
+    // x = target (fast: the big voxels of all targets are dispatched first), y = the big-voxel workgroups, then the spans
+    hipLaunchKernelGGL(ndt_leaf_sums_kernel, dim3(t.nprob(), kLeafBigBlocks + std::min<uint32_t>((max_leaves + kLeafSpan - 1) / kLeafSpan, 65535u - kLeafBigBlocks)), dim3(64), 0, ctx->stream, d_clouds, d_sorted_vals, d_slices,
+                       d_leaf_slices, d_seg_start, d_big_cnt, d_big_list, d_sums);
     hipLaunchKernelGGL(ndt_leaf_finalize_kernel, dim3((max_leaves + 255) / 256, t.nprob()), dim3(256), 0, ctx->stream, d_leaf_slices, d_vp, d_sums, d_seg_key,
                        d_leaves, d_icov64, d_centroid, d_nr_points, d_lookup_base);
     MRGFE_HIP_CHECK(hipGetLastError());

@@ -260,13 +260,16 @@ int NdtEngine::build_targets()
     MRGFE_TRY(grid_arena_.alloc(std::max<uint64_t>(lookup_bytes, 256), &p_lookup));
     MRGFE_HIP_CHECK(hipMemsetAsync(p_lookup, 0xFF, std::max<uint64_t>(lookup_bytes, 256), st));
     DevBuf &dseg = ctx_->scratch[9], &dsum = ctx_->scratch[10];
-    MRGFE_TRY(dseg.ensure(sizeof(uint32_t) * (total_leaves + P + 4)));
+    // seg_start (V + 1 per target), then the per-target counts and lists of big voxels (ndt_big_leaves_kernel)
+    const size_t seg_words = size_t(total_leaves) + P + 4;
+    MRGFE_TRY(dseg.ensure(sizeof(uint32_t) * (seg_words + P + nl)));
     MRGFE_TRY(dsum.ensure(sizeof(double) * 16 * nl));
     MRGFE_HIP_CHECK(hipMemcpyAsync(dd + o_ls, hd + o_ls, sizeof(LeafSlice) * P, hipMemcpyHostToDevice, st));
 
     // 5. segments and leaves
     MRGFE_TRY(ndt_launch_segments(ctx_, sk, d_flags, d_ord, d_sl, tab, d_ls, dseg.as<uint32_t>(), static_cast<int32_t*>(p_keys)));
-    MRGFE_TRY(ndt_launch_leaves(ctx_, d_cp, sv, d_sl, tab, d_ls, d_vp, max_leaves, dseg.as<uint32_t>(), static_cast<const int32_t*>(p_keys), dsum.as<double>(),
+    MRGFE_TRY(ndt_launch_leaves(ctx_, d_cp, sv, d_sl, tab, d_ls, d_vp, max_leaves, dseg.as<uint32_t>(), dseg.as<uint32_t>() + seg_words, dseg.as<uint32_t>() + seg_words + P,
+                                static_cast<const int32_t*>(p_keys), dsum.as<double>(),
                                 static_cast<NdtLeafRec*>(p_leaves), static_cast<double*>(p_icov), static_cast<float4*>(p_cent), static_cast<int32_t*>(p_npts), p_lookup));
 
     // 6. device grid descriptors
