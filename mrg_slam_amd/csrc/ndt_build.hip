@@ -83,11 +83,12 @@ __global__ __launch_bounds__(256) void ndt_segments_kernel(const uint32_t* __res
 //     the plain sums: x * 1.0 == x) or row(k - 9) of ITS group's rows in point order; the products are not on the chain;
 //   * the target index is the fast grid dimension: the big voxels of ALL targets start at once.
 // (Dropped earlier in round 2: owning the voxels that start in a 256-point window of the sorted stream and fetching 64 points
-// per step across voxel boundaries, without the look-ahead: 1.04 ms against 0.87 ms for one wavefront per voxel.)
+// per step across voxel boundaries, without the look-ahead: 1.04 ms against 0.87 ms for one wavefront per voxel.  This kernel:
+// 0.32 ms per 256 targets of 130k points; kLeafBig 128 / 256 / 512 / 1024: 0.41 / 0.37 / 0.32 / 0.32 ms.)
 // sums layout per leaf (16 doubles): [0..2] sum p, [3..8] sum xx,xy,xz,yy,yz,zz, [9] n, [10..13] float centroid sums.
 constexpr int      kLeafGroups = 4;     // voxels in flight per wavefront (small voxels)
 constexpr int      kLeafSpan = 16;      // voxels per wavefront
-constexpr uint32_t kLeafBig = 256;      // points above which a voxel gets a wavefront of its own
+constexpr uint32_t kLeafBig = 512;      // points above which a voxel gets a wavefront of its own
 constexpr uint32_t kLeafBigBlocks = 64; // workgroups per target that walk the list of big voxels
 
 // one thread per voxel: the big ones into the target's list (the order of the list does not enter any result)
