@@ -137,10 +137,12 @@ __device__ __forceinline__ float nn_group_fmin(float v)
 }
 
 // offsets (dx + 2) | (dy + 2) << 3 | (dz + 2) << 6 of the 5 x 5 x 5 nodes around a centre, shell 0 first, then the 26 of
-// shell 1, then the 98 of shell 2 (the order nn_shell_walk's general enumeration produces)
+// shell 1 (the order nn_shell_walk's general enumeration produces), then the 98 of shell 2 by the number of their coordinates that
+// are +-2 — 54 face nodes, 36 edge nodes, 8 corners: a node with k such coordinates is at least sqrt(k) (E + nm) away, so the walk
+// of the shell can stop at a class boundary (24.4 -> 23.9 ms)
 __device__ __forceinline__ void nn_small_shell_pos(int idx, int d[3])
 {
-    static constexpr uint16_t kTab[125] = {146, 73, 74, 75, 81, 82, 83, 89, 90, 91, 201, 202, 203, 209, 210, 211, 217, 218, 219, 137, 138, 139, 153, 154, 155, 145, 147, 0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 16, 17, 18, 19, 20, 24, 25, 26, 27, 28, 32, 33, 34, 35, 36, 256, 257, 258, 259, 260, 264, 265, 266, 267, 268, 272, 273, 274, 275, 276, 280, 281, 282, 283, 284, 288, 289, 290, 291, 292, 64, 65, 66, 67, 68, 96, 97, 98, 99, 100, 72, 76, 80, 84, 88, 92, 128, 129, 130, 131, 132, 160, 161, 162, 163, 164, 136, 140, 144, 148, 152, 156, 192, 193, 194, 195, 196, 224, 225, 226, 227, 228, 200, 204, 208, 212, 216, 220};
+    static constexpr uint16_t kTab[125] = {146, 73, 74, 75, 81, 82, 83, 89, 90, 91, 201, 202, 203, 209, 210, 211, 217, 218, 219, 137, 138, 139, 153, 154, 155, 145, 147, 18, 274, 130, 162, 144, 148, 10, 17, 19, 26, 266, 273, 275, 282, 66, 98, 80, 84, 129, 131, 161, 163, 136, 140, 152, 156, 194, 226, 208, 212, 9, 11, 25, 27, 265, 267, 281, 283, 65, 67, 97, 99, 72, 76, 88, 92, 193, 195, 225, 227, 200, 204, 216, 220, 2, 16, 20, 34, 258, 272, 276, 290, 128, 132, 160, 164, 1, 3, 8, 12, 24, 28, 33, 35, 257, 259, 264, 268, 280, 284, 289, 291, 64, 68, 96, 100, 192, 196, 224, 228, 0, 4, 32, 36, 256, 260, 288, 292};
     const int v = kTab[idx];
     d[0] = (v & 7) - 2;
     d[1] = ((v >> 3) & 7) - 2;
@@ -199,6 +201,10 @@ __device__ __forceinline__ bool nn_shell_walk(const unsigned long long* __restri
             }
         };
         for (int t0 = 0; t0 < total; t0 += U * G) {
+            if (kSmall && s == 2) {  // the table lists shell 2 nearest class first: faces [0, 54), edges [54, 90), corners [90, 98)
+                const float kmin = t0 >= 90 ? 3.0f : (t0 >= 54 ? 2.0f : 1.0f), b = E + nm;
+                if (kmin * b * b > lim * kNnPrune) break;
+            }
             unsigned long long word[U];
             float              wlb[U];
 #pragma unroll
@@ -248,16 +254,19 @@ __device__ __forceinline__ bool nn_shell_walk(const unsigned long long* __restri
     return b * b > lim * kNnPrune;
 }
 
-// every `G`-th set bit of w, starting with the sub-th
-__device__ __forceinline__ unsigned long long nn_deal_bits(unsigned long long w, int G, int sub)
+// The lane's share of the set bits of a node's word: the bit POSITIONS dealt to it (one AND), not every G-th set bit (a loop over
+// the word's population; the far pass is bound by VALU issue, 0.76 busy: 25.5 -> 25.0 ms for config[3]'s 256 pairs).  For groups of eight, position p = x + 4 y + 16 z (two bits per
+// axis) goes to lane (x0 ^ y1) | (x1 ^ z0) << 1 | (y0 ^ z1) << 2: every axis-aligned plane of the 4 x 4 x 4 node — a wall, the
+// ground — spreads over all eight lanes, two cells each.  (The plain pattern p % 8 hands a wall to one lane: 26.6 ms.)
+__device__ __forceinline__ unsigned long long nn_deal_mask(int G, int sub)
 {
-    unsigned long long mine = 0ull;
-    for (int i = 0; w != 0ull; ++i) {
-        const unsigned long long low = w & (0ull - w);
-        if (i % G == sub) mine |= low;
-        w ^= low;
+    if (G == 8) {
+        static constexpr unsigned long long kDeal8[8] = {0x8040201008040201ull, 0x4080102004080102ull, 0x2010804002010804ull, 0x1020408001020408ull,
+                                                        0x0804020180402010ull, 0x0408010240801020ull, 0x0201080420108040ull, 0x0102040810204080ull};
+        return kDeal8[sub & 7];
     }
-    return mine;
+    const unsigned long long every = G == 2 ? 0x5555555555555555ull : (G == 4 ? 0x1111111111111111ull : 0x0001000100010001ull);
+    return every << sub;
 }
 
 // Exhaustive remainder of a 1-NN search after the query's 3x3x3 block of cells: bricks within two shells of the query's
@@ -279,28 +288,22 @@ __device__ __forceinline__ void nn_pyramid_walk(const NnGridDev& g, float x, flo
     lim = fminf(lim, bound);
     if (best_i >= 0) lim = fminf(lim, best_d);
     constexpr int kShells = 2;  // shells walked on a level before the next coarser one takes over
+    const unsigned long long deal = nn_deal_mask(G, sub);
     const int b1[3] = {c[0] >> 2, c[1] >> 2, c[2] >> 2}, b2[3] = {c[0] >> 4, c[1] >> 4, c[2] >> 4}, b3[3] = {c[0] >> 6, c[1] >> 6, c[2] >> 6};
     const int d1[3] = {g.bdim[0], g.bdim[1], g.bdim[2]};
     const int d2[3] = {(d1[0] + 3) >> 2, (d1[1] + 3) >> 2, (d1[2] + 3) >> 2};
     const int d3[3] = {(d2[0] + 3) >> 2, (d2[1] + 3) >> 2, (d2[2] + 3) >> 2};
 
-    // the lane's share `mine` of the cells of brick (bx, by, bz): narrow lim from the occupancy alone ...
-    auto cells_bound = [&](unsigned long long mine, int bx, int by, int bz) {
-        for (unsigned long long w = mine; w != 0ull; w &= w - 1ull) {
-            const int bit = __ffsll(w) - 1;
-            float     lb2, ub2;
-            pq.box(E0, bx * 4 + (bit & 3), by * 4 + ((bit >> 2) & 3), bz * 4 + (bit >> 4), lb2, ub2);
-            lim = fminf(lim, ub2 * kNnPrune);
-        }
-    };
-    // ... and open the cells that are left
+    // the lane's share `mine` of the cells of brick (bx, by, bz): narrow lim from the occupancy alone and open the cells that can still matter,
+    // in one pass (bounding all of the brick's cells before opening any cost a second box evaluation per cell: far pass 25.0 -> 24.4 ms)
     auto cells_open = [&](unsigned long long mine, int bx, int by, int bz) {
         for (unsigned long long w = mine; w != 0ull; w &= w - 1ull) {
             const int bit = __ffsll(w) - 1;
             const int cx = bx * 4 + (bit & 3), cy = by * 4 + ((bit >> 2) & 3), cz = bz * 4 + (bit >> 4);
-            if (cx - c[0] >= -1 && cx - c[0] <= 1 && cy - c[1] >= -1 && cy - c[1] <= 1 && cz - c[2] >= -1 && cz - c[2] <= 1) continue;  // the block is done
             float lb2, ub2;
             pq.box(E0, cx, cy, cz, lb2, ub2);
+            lim = fminf(lim, ub2 * kNnPrune);  // an occupied cell: something is no farther than its far corner
+            if (cx - c[0] >= -1 && cx - c[0] <= 1 && cy - c[1] >= -1 && cy - c[1] <= 1 && cz - c[2] >= -1 && cz - c[2] <= 1) continue;  // the block is done
             if (lb2 > lim * kNnPrune) continue;
             const uint32_t at = (static_cast<uint32_t>(cz) * g.dim[1] + cy) * g.dim[0] + cx;
             const uint32_t kb = g.cell_start[at], ke = g.cell_start[at + 1];
@@ -329,29 +332,25 @@ __device__ __forceinline__ void nn_pyramid_walk(const NnGridDev& g, float x, flo
             if (lb2 > lim * kNnPrune) continue;
             if (bx - b1[0] >= -done && bx - b1[0] <= done && by - b1[1] >= -done && by - b1[1] <= done && bz - b1[2] >= -done && bz - b1[2] <= done) continue;
             const unsigned long long w0 = g.occ[(static_cast<uint32_t>(bz) * d1[1] + by) * d1[0] + bx];
-            cells_bound(w0, bx, by, bz);
             cells_open(w0, bx, by, bz);
         }
     };
 
     // A. bricks
     if (nn_shell_walk<G, true>(g.occ, d1, b1, E1, pq, 0, kShells, sub, lim, [&](unsigned long long wb, int bx, int by, int bz) {
-            const unsigned long long mine = nn_deal_bits(wb, G, sub);
-            cells_bound(mine, bx, by, bz);
-            lim = nn_group_fmin<G>(lim);
-            cells_open(mine, bx, by, bz);
+            cells_open(wb & deal, bx, by, bz);
             agree();
         }))
         return;
     // B. super-bricks
     if (nn_shell_walk<G, true>(g.occ1, d2, b2, E2, pq, 0, kShells, sub, lim, [&](unsigned long long wb, int sx, int sy, int sz) {
-            bricks(nn_deal_bits(wb, G, sub), sx, sy, sz, kShells);
+            bricks(wb & deal, sx, sy, sz, kShells);
             agree();
         }))
         return;
     // C. blocks, to the end of the grid
     nn_shell_walk<G, false>(g.occ2, d3, b3, E3, pq, 0, 0x3fffffff, sub, lim, [&](unsigned long long wb, int kx, int ky, int kz) {
-        const unsigned long long mine = nn_deal_bits(wb, G, sub);
+        const unsigned long long mine = wb & deal;
         for (unsigned long long w = mine; w != 0ull; w &= w - 1ull) {
             const int bit = __ffsll(w) - 1;
             const int sx = kx * 4 + (bit & 3), sy = ky * 4 + ((bit >> 2) & 3), sz = kz * 4 + (bit >> 4);
