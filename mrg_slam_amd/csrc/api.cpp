@@ -6,6 +6,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -97,7 +98,7 @@ struct mrgfe_batch {
     GicpBatch*          gicp_batch = nullptr;
     std::vector<GicpBatchPair> gicp_pairs;  // per-pair device buffers, kept between align calls
     std::vector<NnGrid> fit_grids;  // getFitnessScore grids, one per target; device buffers kept between align calls
-    mrgfe_ctx*          fit_ctx = nullptr;  // helper context (own stream and workspaces): the grids are built on it by a second host
+    std::vector<mrgfe_ctx*> fit_ctxs;       // helper contexts (own stream and workspaces each): the grids are built on them by extra host
                                             // thread while the alignment rounds run on the batch's context
     // keyframe store (mrgfe_batch_add_pair_keyed): packed clouds and GICP covariances by caller-chosen key, resident across clears
     struct Keyframe {
@@ -847,7 +848,7 @@ void mrgfe_batch_destroy(mrgfe_batch* b)
         MRGFE_LOCK(b->ctx);
         (void)b->ctx->bind();
         for (auto& g : b->fit_grids) g.release();
-        if (b->fit_ctx) mrgfe_ctx_destroy(b->fit_ctx);
+        for (mrgfe_ctx* fc : b->fit_ctxs) mrgfe_ctx_destroy(fc);
         for (auto& gp : b->gicp_pairs) { gp.cov.release(); gp.corr.release(); gp.mahal.release(); }
         delete b->gicp_batch;
         for (auto* g : b->gicp) delete g;
@@ -1063,35 +1064,49 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
         // getFitnessScore needs an exact-NN grid per distinct target, and those depend on the target clouds only: they are built
         // on a helper context by a second host thread WHILE the alignment rounds run (their small launches fill the tails of the
         // derivative kernels), instead of one after the other behind the alignment (64 targets: ~10 ms of a 65 ms step)
-        std::thread  builder;
+        // One grid is a dozen small launches and half a dozen host waits (bounding box, the adaptive cell size, the scan table): 64
+        // of them in a row took 30 ms of wall time for 4 ms of kernels and outlasted the 17 ms of alignment they were meant to
+        // hide behind.  The targets are dealt to up to four builder threads, each with its own context.
+        std::vector<std::thread> builders;
         int          build_status = MRGFE_OK;
         std::string  build_error;
+        std::mutex   build_mu;
+        std::vector<int> todo;  // (outlives the threads: they are joined below)
         const bool   overlap = fitness_max_range >= 0 && P >= 2 && std::getenv("MRGFE_NO_FIT_OVERLAP") == nullptr;
         if (overlap) {
-            if (!b->fit_ctx && mrgfe_ctx_create(b->ctx->device, &b->fit_ctx) != MRGFE_OK) return MRGFE_ERR_HIP;
             if (fit_built.size() < static_cast<size_t>(e.n_targets())) fit_built.resize(e.n_targets(), 0);
             if (b->fit_grids.size() < static_cast<size_t>(e.n_targets())) b->fit_grids.resize(e.n_targets());
-            std::vector<int> todo;
             for (int i = 0; i < P; ++i) {
                 const NdtPairInfo& p = e.pair(i);
                 if (e.target(p.target).n == 0 || p.n == 0 || fit_built[p.target]) continue;
                 fit_built[p.target] = 1;
                 todo.push_back(p.target);
             }
-            builder = std::thread([b, &e, todo, &build_status, &build_error] {
-                mrgfe_ctx* fc = b->fit_ctx;
-                std::lock_guard<std::recursive_mutex> lock(fc->mu);
-                if (fc->bind() != MRGFE_OK) { build_status = MRGFE_ERR_HIP; build_error = mrgfe_last_error(); return; }
-                for (int t : todo) {
-                    const NdtTargetInfo& T = e.target(t);
-                    const int st = b->fit_grids[t].build(fc, T.d_pts, T.n, 1.0f, NnGrid::kCrowding1nn, 1);
-                    if (st != MRGFE_OK) { build_status = st; build_error = mrgfe_last_error(); return; }
-                }
-                if (hipStreamSynchronize(fc->stream) != hipSuccess) { build_status = MRGFE_ERR_HIP; build_error = "helper stream synchronisation failed"; }
-            });
+            size_t n_builders = 4;
+            if (const char* env = std::getenv("MRGFE_FIT_BUILDERS")) n_builders = static_cast<size_t>(std::max(1, std::atoi(env)));
+            n_builders = std::min(n_builders, todo.size());
+            while (b->fit_ctxs.size() < n_builders) {
+                mrgfe_ctx* fc = nullptr;
+                if (mrgfe_ctx_create(b->ctx->device, &fc) != MRGFE_OK) return MRGFE_ERR_HIP;
+                b->fit_ctxs.push_back(fc);
+            }
+            for (size_t w = 0; w < n_builders; ++w)
+                builders.emplace_back([b, &e, &todo, w, n_builders, &build_status, &build_error, &build_mu] {
+                    mrgfe_ctx* fc = b->fit_ctxs[w];
+                    auto fail = [&](int st, const std::string& why) { std::lock_guard<std::mutex> g(build_mu); if (build_status == MRGFE_OK) { build_status = st; build_error = why; } };
+                    std::lock_guard<std::recursive_mutex> lock(fc->mu);
+                    if (fc->bind() != MRGFE_OK) { fail(MRGFE_ERR_HIP, mrgfe_last_error()); return; }
+                    for (size_t k = w; k < todo.size(); k += n_builders) {
+                        const int t = todo[k];
+                        const NdtTargetInfo& T = e.target(t);
+                        const int st = b->fit_grids[t].build(fc, T.d_pts, T.n, 1.0f, NnGrid::kCrowding1nn, 1);
+                        if (st != MRGFE_OK) { fail(st, mrgfe_last_error()); return; }
+                    }
+                    if (hipStreamSynchronize(fc->stream) != hipSuccess) fail(MRGFE_ERR_HIP, "helper stream synchronisation failed");
+                });
         }
         const int align_status = e.align_all();
-        if (builder.joinable()) builder.join();
+        for (std::thread& t : builders) t.join();
         MRGFE_TRY(align_status);
         if (build_status != MRGFE_OK) { set_error("%s", build_error.c_str()); return build_status; }
         for (int i = 0; i < P; ++i) {
