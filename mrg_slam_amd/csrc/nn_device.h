@@ -157,7 +157,7 @@ template <int G, bool kSmall, class Proc>
 __device__ __forceinline__ bool nn_shell_walk(const unsigned long long* __restrict__ words, const int dims[3], const int ctr[3], float E, const NnPyramidQuery& pq, int s_first,
                                               int s_last, int sub, float& lim, Proc&& proc)
 {
-    constexpr int U = 2;  // the nearest-first selection below is written for two
+    constexpr int U = G >= 8 ? 2 : (G == 4 ? 4 : 8);  // words a lane fetches per trip: sixteen to the group (eight for one or two lanes: registers)
     int   smax = 0;
     float nm = INFINITY;  // distance to the nearest face of the centre node, >= 0
 #pragma unroll
@@ -226,8 +226,12 @@ __device__ __forceinline__ bool nn_shell_walk(const unsigned long long* __restri
             }
             // non-empty nodes nearest first: the first ones usually pull lim in far enough to drop the rest unopened
             for (;;) {
-                float nb = fminf(wlb[0], wlb[1]);
-                int   code = (wlb[1] < wlb[0] ? G : 0) + sub;  // u * G + lane of the group
+                float nb = wlb[0];
+                int   ub = 0;
+#pragma unroll
+                for (int u = 1; u < U; ++u)
+                    if (wlb[u] < nb) { nb = wlb[u]; ub = u; }
+                int code = ub * G + sub;  // u * G + lane of the group
 #pragma unroll
                 for (int k = 1; k < G; k <<= 1) {
                     const float ob = __shfl_xor(nb, k);
@@ -235,12 +239,20 @@ __device__ __forceinline__ bool nn_shell_walk(const unsigned long long* __restri
                     if (ob < nb || (ob == nb && oc < code)) { nb = ob; code = oc; }
                 }
                 if (nb == INFINITY || !(nb <= lim * kNnPrune)) break;  // nothing left / nothing near enough (uniform within the group)
-                const int u = code >= G ? 1 : 0, b = code - u * G;
-                if (b == sub) wlb[u] = INFINITY;
+                const int u = code / G, b = code - u * G;
+                unsigned long long wsel = word[0];
+#pragma unroll
+                for (int v = 1; v < U; ++v)
+                    if (u == v) wsel = word[v];
+#pragma unroll
+                for (int v = 0; v < U; ++v)
+                    if (b == sub && u == v) wlb[v] = INFINITY;
                 {
-                    const unsigned long long wsel = u ? word[1] : word[0];
-                    const uint32_t wlo = __shfl(static_cast<uint32_t>(wsel), base + b), whi = __shfl(static_cast<uint32_t>(wsel >> 32), base + b);
-                    const unsigned long long wb = (static_cast<unsigned long long>(whi) << 32) | wlo;
+                    unsigned long long wb = wsel;
+                    if (G > 1) {
+                        const uint32_t wlo = __shfl(static_cast<uint32_t>(wsel), base + b), whi = __shfl(static_cast<uint32_t>(wsel >> 32), base + b);
+                        wb = (static_cast<unsigned long long>(whi) << 32) | wlo;
+                    }
                     int d[3];
                     shell_pos(t0 + u * G + b, d);
                     proc(wb, ctr[0] + d[0], ctr[1] + d[1], ctr[2] + d[2]);
@@ -265,8 +277,14 @@ __device__ __forceinline__ unsigned long long nn_deal_mask(int G, int sub)
                                                         0x0804020180402010ull, 0x0408010240801020ull, 0x0201080420108040ull, 0x0102040810204080ull};
         return kDeal8[sub & 7];
     }
-    const unsigned long long every = G == 2 ? 0x5555555555555555ull : (G == 4 ? 0x1111111111111111ull : 0x0001000100010001ull);
-    return every << sub;
+    if (G == 4) {  // the same mixing, two of the eight shares per lane
+        static constexpr unsigned long long kDeal4[4] = {0x8040201008040201ull | 0x0804020180402010ull, 0x4080102004080102ull | 0x0408010240801020ull,
+                                                        0x2010804002010804ull | 0x0201080420108040ull, 0x1020408001020408ull | 0x0102040810204080ull};
+        return kDeal4[sub & 3];
+    }
+    if (G == 1) return ~0ull;
+    if (G == 2) return (sub & 1) ? 0x55aa55aa55aa55aaull : 0xaa55aa55aa55aa55ull;  // by the parity of x0 ^ y1
+    return 0x0001000100010001ull << sub;
 }
 
 // Exhaustive remainder of a 1-NN search after the query's 3x3x3 block of cells: bricks within two shells of the query's

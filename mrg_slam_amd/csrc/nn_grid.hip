@@ -308,6 +308,10 @@ __device__ __forceinline__ void nn_load_job(NnFitnessJob& s_job, const NnFitness
     for (uint32_t w = threadIdx.x; w < sizeof(NnFitnessJob) / 4; w += 256) dst[w] = src[w];
 }
 
+#ifndef MRGFE_BLOCK_GROUP
+#define MRGFE_BLOCK_GROUP 1
+#endif
+constexpr int kBlockGroup = MRGFE_BLOCK_GROUP;  // lanes per query in the block pass
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void nn_fit_block_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range, float* __restrict__ sqd,
                                                             uint32_t* __restrict__ pend, uint32_t* __restrict__ pend_cnt)
 {
@@ -318,8 +322,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void n
     __syncthreads();
     const NnGrid2Dev& g = s_job.grid;
     const uint32_t    n = s_job.n, off = job_off[blockIdx.y];
-    const int         sub = threadIdx.x % kNnGroup;
-    constexpr uint32_t per_blk = 256u / kNnGroup;
+    const int         sub = threadIdx.x % kBlockGroup;
+    constexpr uint32_t per_blk = 256u / kBlockGroup;
     auto flush = [&]() {  // called by the whole workgroup
         __syncthreads();
         const uint32_t np = s_np;
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void n
     const uint32_t i_end = min(n, (blockIdx.x + 1) * chunk);
     for (uint32_t i0 = blockIdx.x * chunk; i0 < i_end; i0 += per_blk) {  // uniform trip count
         if (s_np > kFitPendCap - per_blk) flush();  // s_np is stable here: the appends of the last trip are behind a barrier
-        const uint32_t i = i0 + threadIdx.x / kNnGroup;
+        const uint32_t i = i0 + threadIdx.x / kBlockGroup;
         bool           queue = false;
         if (i < i_end) {
             const float4 p = s_job.src[i];
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void n
             int32_t bi = -1;
             float   bd = INFINITY;
             bool    done = true;
-            if (g.level[0].n != 0 && finite3(x, y, z)) done = nn_level_search<kNnGroup>(g.level[0], x, y, z, sub, 1, max_range, bi, bd);
+            if (g.level[0].n != 0 && finite3(x, y, z)) done = nn_level_search<kBlockGroup>(g.level[0], x, y, z, sub, 1, max_range, bi, bd);
             // queued queries leave what the block gave (INFINITY: nothing) as the far pass's starting bound
             if (sub == 0) sqd[off + i] = done ? ((bi >= 0 && static_cast<double>(bd) <= max_range) ? bd : kFitNone) : (bi >= 0 ? bd : INFINITY);
             queue = sub == 0 && !done;
@@ -368,18 +372,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void n
     flush();
 }
 
+#ifndef MRGFE_FAR_GROUP
+#define MRGFE_FAR_GROUP 2
+#endif
+constexpr int kFarGroup = MRGFE_FAR_GROUP;  // lanes per query in the far pass
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void nn_fit_far_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range, const uint32_t* __restrict__ pend,
                                                           const uint32_t* __restrict__ pend_cnt, float* __restrict__ sqd)
 {
     const uint32_t np = pend_cnt[blockIdx.y];
-    constexpr uint32_t per_blk = 256u / kNnGroup;
+    constexpr uint32_t per_blk = 256u / kFarGroup;
     if (blockIdx.x * per_blk >= np) return;
     __shared__ NnFitnessJob s_job;
     nn_load_job(s_job, jobs + blockIdx.y);
     __syncthreads();
     const uint32_t off = job_off[blockIdx.y];
-    const int      sub = threadIdx.x % kNnGroup;
-    for (uint32_t k = blockIdx.x * per_blk + threadIdx.x / kNnGroup; k < np; k += gridDim.x * per_blk) {
+    const int      sub = threadIdx.x % kFarGroup;
+    for (uint32_t k = blockIdx.x * per_blk + threadIdx.x / kFarGroup; k < np; k += gridDim.x * per_blk) {
         const uint32_t i = pend[off + k];
         const float4   p = s_job.src[i];
         float x, y, z;
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
         const float bound = sqd[off + i];  // what the block gave
         int32_t bpos;
         float   bd;
-        nn_far_search<kNnGroup>(s_job.grid, x, y, z, sub, max_range, bound, bpos, bd);
+        nn_far_search<kFarGroup>(s_job.grid, x, y, z, sub, max_range, bound, bpos, bd);
         bd = fminf(bd, bound);
         if (sub == 0) sqd[off + i] = static_cast<double>(bd) <= max_range ? bd : kFitNone;
     }
@@ -454,7 +462,7 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     }
     const size_t total = off[count];
     if (max_n == 0) return MRGFE_OK;
-    constexpr uint32_t per_blk = 256u / kNnGroup;
+    constexpr uint32_t per_blk = 256u / kBlockGroup;
     // enough blocks to fill the chip many times over (the far pass is ragged), few enough that each has a few trips
     const uint32_t want = static_cast<uint32_t>(std::max<size_t>(1, (size_t(ctx->cu_count) * 128 + count - 1) / count));
     const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((max_n + per_blk - 1) / per_blk, want));
