@@ -185,13 +185,17 @@ __device__ __forceinline__ void gicp_block_reduce(double (&vals)[29], double* __
     }
 }
 
-// update_correspondences: exact 1-NN of trans_f * source point in the target, kGicpGroup lanes per query
-constexpr int kGicpGroup = 8;
+// update_correspondences: exact 1-NN of trans_f * source point in the target, G lanes per query.  A single registration has 130k
+// queries and wants eight lanes on each to fill the chip (two: 1.05 -> 1.49 ms over six rounds); a batch of candidates fills it
+// anyway, and there the lanes of a group mostly repeat each other's bookkeeping (eight -> two: 22.9 -> 16.7 ms for 64 pairs).
+constexpr int kGicpGroup = 8;       // single registration, and the ICP moment kernel
+constexpr int kGicpBatchGroup = 2;  // batched candidates
+template <int G>
 __device__ __forceinline__ void gicp_corr_query(const NnGrid2Dev& g, const float4* __restrict__ src, uint32_t n, const GicpPose& pose, double thr2, int32_t* __restrict__ corr,
                                                 uint32_t blk)
 {
 #pragma clang fp contract(off)
-    const uint32_t i = blk * (256u / kGicpGroup) + threadIdx.x / kGicpGroup;
+    const uint32_t i = blk * (256u / G) + threadIdx.x / G;
     if (i >= n) return;
     const float4 a = src[i];
     // trans_f * Vector4f(x, y, z, 1): accumulated column by column
@@ -205,14 +209,14 @@ __device__ __forceinline__ void gicp_corr_query(const NnGrid2Dev& g, const float
     }
     int32_t j = -1;
     float   sqd = INFINITY;
-    nn_nearest_group<kGicpGroup>(g, q[0], q[1], q[2], static_cast<int>(threadIdx.x % kGicpGroup), thr2, j, sqd);
+    nn_nearest_group<G>(g, q[0], q[1], q[2], static_cast<int>(threadIdx.x % G), thr2, j, sqd);
     if (j >= 0 && !(static_cast<double>(sqd) < thr2)) j = -1;
-    if (threadIdx.x % kGicpGroup == 0) corr[i] = j;
+    if (threadIdx.x % G == 0) corr[i] = j;
 }
 
 __global__ __launch_bounds__(256) void gicp_corr_kernel(NnGrid2Dev g, const float4* __restrict__ src, uint32_t n, GicpPose pose, double thr2, int32_t* __restrict__ corr)
 {
-    gicp_corr_query(g, src, n, pose, thr2, corr, blockIdx.x);
+    gicp_corr_query<kGicpGroup>(g, src, n, pose, thr2, corr, blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void icp_corr_sums_kernel(NnGrid2Dev g, const float4* __restrict__ cur, const float4* __restrict__ tgt, uint32_t n, double max_sq,
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(256) void gicp_corr_batch_kernel(const GicpPairDev*
     __shared__ NnGrid2Dev s_grid;
     const uint32_t     pi = evals[blockIdx.y].order[0];
     const GicpPairDev  pr = pairs[pi];
-    if (blockIdx.x * (256u / kGicpGroup) >= pr.n) return;  // uniform
+    if (blockIdx.x * (256u / kGicpBatchGroup) >= pr.n) return;  // uniform
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(grids + pr.target);
         uint32_t*       dst = reinterpret_cast<uint32_t*>(&s_grid);
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(256) void gicp_corr_batch_kernel(const GicpPairDev*
     }
     __syncthreads();
     const GicpEvalDev& ev = evals[pi];
-    gicp_corr_query(s_grid, pr.src, pr.n, ev.pose, ev.thr2, pr.corr, blockIdx.x);
+    gicp_corr_query<kGicpBatchGroup>(s_grid, pr.src, pr.n, ev.pose, ev.thr2, pr.corr, blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void vox_corr_batch_kernel(const GicpPairDev* __restrict__ pairs, const GicpEvalDev* __restrict__ evals, const VoxGridDev* __restrict__ vgrids)
@@ -1269,7 +1273,7 @@ int GicpBatch::align_all(std::vector<GicpEngine*>& engines, std::vector<GicpBatc
             const GicpPairDev* dp = d_pairs_.as<GicpPairDev>();
             const GicpEvalDev* de = d_evals_.as<GicpEvalDev>();
             if (n_lin) {
-                constexpr uint32_t per_blk = 256u / kGicpGroup;
+                constexpr uint32_t per_blk = 256u / kGicpBatchGroup;
                 if (voxel) hipLaunchKernelGGL(vox_corr_batch_kernel, dim3((max_n + 255) / 256, n_lin), dim3(256), 0, st, dp, de, d_grids_.as<VoxGridDev>());
                 else       hipLaunchKernelGGL(gicp_corr_batch_kernel, dim3((max_n + per_blk - 1) / per_blk, n_lin), dim3(256), 0, st, dp, de, d_grids_.as<NnGrid2Dev>());
                 hipLaunchKernelGGL(gicp_linearize_batch_kernel, dim3((max_n + 255) / 256, n_lin), dim3(256), 0, st, dp, de, d_partials_.as<double>());
