@@ -376,6 +376,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void n
 #define MRGFE_FAR_GROUP 2
 #endif
 constexpr int kFarGroup = MRGFE_FAR_GROUP;  // lanes per query in the far pass
+// (Measured and dropped: two queues per job — queries the block gave a first distance from the front, queries with nothing around
+// them from the back — so that a wavefront of the far pass holds walks of one kind: far 19.5 -> 19.3 ms, block 2.7 -> 2.9 ms.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void nn_fit_far_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range, const uint32_t* __restrict__ pend,
                                                           const uint32_t* __restrict__ pend_cnt, float* __restrict__ sqd)
 {
