@@ -440,7 +440,8 @@ def main():
     achieved = (k_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
     variants = {name: {"launches": int(per_mode[m][1]), "avg_launch_ms": (per_mode[m][0] / per_mode[m][1]) if per_mode[m][1] else None,
                        "achieved_GBps": (per_mode[m][2] / 1e9) / (per_mode[m][0] / 1e3) if per_mode[m][0] > 0 else None}
-                for m, name in enumerate(("ndt_derivatives_kernel<0,7>", "ndt_derivatives_kernel<1,7>", "ndt_derivatives_kernel<2,7>"))}
+                for m, name in enumerate(("ndt_derivatives_kernel<0,7>", "ndt_derivatives_kernel<1,7>", "ndt_derivatives_kernel<2,7>"))
+                if per_mode[m][1]}  # (the line-search and f64-Hessian variants are timed only with MRGFE_KERNEL_TIMING=2: their events cost the round a little)
     # HBM bytes per launch of the dominant kernel and its VALU utilisation from the PMC passes (collected separately with
     # rocprofv3 --pmc and corrected as MI355X_MICROARCH.md prescribes; profiles/summarize.py) - null until a profile exists
     traffic = valu_busy = None
