@@ -290,14 +290,16 @@ __global__ __launch_bounds__(256) void nn_nearest_kernel(NnGrid2Dev g, const flo
 }
 
 // getFitnessScore for a batch of (grid, source cloud, transform) jobs (blockIdx.y = job) in three passes over one float
-// per query.  A wavefront holds eight queries and runs as long as its slowest one, and on a loop-closure candidate about a
-// third of the queries have nothing in the 3x3x3 block around them, so in a single pass nearly every wavefront pays for a
-// far search.  Hence:
+// per query.  A wavefront runs as long as its slowest query, and on a loop-closure candidate half of the queries are not settled
+// by the 3x3x3 block around them, so in a single pass nearly every wavefront pays for a far search.  Hence:
 //   block : own cell + 3x3x3 block of the finest level; writes the squared distance, -1 (nothing within max_range), or
 //           queues the query (per-job list, appended through LDS: one global atomic per workgroup flush);
-//   far   : the queued queries only, densely packed eight to a wavefront: full search (brick walk, coarser levels);
+//   far   : the queued queries only, densely packed: full search (brick walk, coarser levels);
 //   sum   : per job, fixed-order f64 sum and count of the distances — the far pass fills slots, so the order in which
 //           queries were queued does not enter and the result is bitwise reproducible.
+// Lanes per query: a batch fills the chip whatever the group size, and the lanes of a group mostly repeat each other's
+// bookkeeping (both passes are bound by VALU issue), so ONE lane per query in the block pass and TWO in the far pass
+// (config[3], 256 pairs: block 5.3 / 4.0 / 3.2 / 2.7 ms for 8 / 4 / 2 / 1 lanes, far 23.9 / 21.3 / 19.5 / 19.6 ms).
 constexpr float    kFitNone = -1.0f;
 constexpr uint32_t kFitPendCap = 1024;
 
