@@ -65,6 +65,32 @@ def test_target_grid_matches_oracle(force_hash, monkeypatch):
     assert (gi[~valid] == 0).all()
 
 
+def test_voxel_sums_at_every_population_boundary():
+    """ndt_leaf_sums_kernel takes voxels of up to 512 points four at a time per wavefront, 64 points a round, spans of 16 voxels per
+    wavefront, and gives bigger voxels a wavefront of their own with four 64-point steps in flight: voxels of 1 ... 3000 points,
+    on both sides of 64, 128, 256 (the look-ahead), 512 (the threshold) and their multiples, in a shuffled cloud — the sums are
+    added in the reference's point order, so means and inverse covariances must equal the oracle's bit for bit."""
+    rng = np.random.default_rng(77)
+    sizes = [1, 2, 5, 6, 7, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 300, 511, 512, 513, 575, 576, 577, 767, 768, 769, 1023, 1024, 1025, 1500, 3000]
+    sizes += [int(v) for v in rng.integers(1, 90, size=70)]  # several spans of small voxels around the big ones
+    pts = []
+    for k, n in enumerate(sizes):
+        cx, cy, cz = (k % 12) * 2 - 11, (k // 12) * 2 - 8, (k % 3) - 1  # voxels two cells apart: no shared cells
+        pts.append(np.column_stack([cx + 0.05 + 0.9 * rng.random(n), cy + 0.05 + 0.9 * rng.random(n), cz + 0.05 + 0.9 * rng.random(n), rng.random(n)]))
+    tgt = np.concatenate(pts).astype(np.float32)
+    tgt = tgt[rng.permutation(len(tgt))]
+    src = tgt[:500].copy()
+    g, o = _both(tgt, src)
+    gk, gn, gm, gi = g.leaves()
+    ok, on, om, oc, oi = o.leaves()
+    np.testing.assert_array_equal(gk, ok)
+    np.testing.assert_array_equal(gn, on)
+    assert sorted(on.tolist()) == sorted(sizes)
+    np.testing.assert_array_equal(gm, om)
+    valid = on >= 6
+    np.testing.assert_array_equal(gi[valid], oi[valid])
+
+
 @pytest.mark.parametrize("search", ["DIRECT7", "DIRECT1", "DIRECT26", "KDTREE"])
 @pytest.mark.parametrize("force_hash", ["0", "1"])
 def test_single_evaluation_matches_oracle(search, force_hash, monkeypatch):
