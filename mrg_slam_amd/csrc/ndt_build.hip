@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void ndt_segments_kernel(const uint32_t* __res
 // metre on the ground; 5145 in the benchmark scans), and with one wavefront per voxel in launch order the 256-target build ran at 1.4
 // resident wavefronts per SIMD (SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE) behind the big voxels of the last targets.  So:
 //   * voxels of more than kLeafBig points are listed per target (ndt_big_leaves_kernel) and taken by the FIRST workgroups of the
-//     launch, built for a short chain: a wavefront for the nine f64 sums and another for the four f32 sums, the gathers of four
-//     64-point steps in flight, every point's terms computed by its lane into LDS, two instructions per point on the chain;
+//     launch, one wavefront each, built for a short chain: the gathers of four 64-point steps in flight, every point's 13 terms
+//     computed by its lane into LDS, then three instructions per point on the chain (8-byte LDS read, f64 add, f32 add);
 //   * the rest go four at a time per wavefront, one per group of 13 lanes (group g takes the voxels g, g + 4, ... of a span of
 //     kLeafSpan and moves on when one is finished, so unequal voxels even out): per round and group 64 lanes fetch the next 64
 //     points (coalesced index read + 16-byte gather, the gathers of the NEXT round in flight while this round is summed) into
@@ -87,8 +87,8 @@ __global__ __launch_bounds__(256) void ndt_segments_kernel(const uint32_t* __res
 // 0.32 ms per 256 targets of 130k points; kLeafBig 128 / 256 / 512 / 1024: 0.41 / 0.37 / 0.32 / 0.32 ms.)
 // sums layout per leaf (16 doubles): [0..2] sum p, [3..8] sum xx,xy,xz,yy,yz,zz, [9] n, [10..13] float centroid sums.
 constexpr int      kLeafGroups = 4;     // voxels in flight per wavefront (small voxels)
-constexpr int      kLeafSpan = 16;      // voxels per wavefront (most; a build of a few targets takes 4 and a threshold of 128: more, shorter wavefronts)
-constexpr uint32_t kLeafBig = 512;      // points above which a voxel gets wavefronts of its own
+constexpr int      kLeafSpan = 16;      // voxels per wavefront (a build of a few targets takes 4: more, shorter wavefronts)
+constexpr uint32_t kLeafBig = 512;      // points above which a voxel gets a wavefront of its own (256 for a build of a few targets)
 constexpr uint32_t kLeafBigBlocks = 64; // workgroups per target that walk the list of big voxels
 
 // one thread per voxel: the big ones into the target's list (the order of the list does not enter any result)
@@ -113,9 +113,9 @@ __global__ __launch_bounds__(64, 6) void ndt_leaf_sums_kernel(const float4* cons
                                                                const uint32_t* __restrict__ big_cnt, const uint32_t* __restrict__ big_list, uint32_t big_thr,
                                                                uint32_t span_max, uint32_t big_blocks, double* __restrict__ sums)
 {
-    // small voxels: rows x, y, z, intensity, ones per group (+1: the rows lie in different banks); big voxels: 9 rows of f64 terms or 4 of floats
-    __shared__ double s_mem[10 * (kWave + 1)];
-    static_assert(sizeof(double) * 10 * (kWave + 1) >= sizeof(float) * kLeafGroups * 5 * (kWave + 1), "LDS union");
+    // small voxels: rows x, y, z, intensity, ones per group (+1: the rows lie in different banks); big voxels: 13 rows of 8-byte slots
+    __shared__ double s_mem[13 * (kWave + 1)];
+    static_assert(sizeof(double) * 13 * (kWave + 1) >= sizeof(float) * kLeafGroups * 5 * (kWave + 1), "LDS union");
     const LeafSlice ls = leaf_slices[blockIdx.x];
     const Slice     s = slices[blockIdx.x];
     const float4* __restrict__ pts = clouds[blockIdx.x];
@@ -126,13 +126,10 @@ __global__ __launch_bounds__(64, 6) void ndt_leaf_sums_kernel(const float4* cons
         // ---- big voxels: one at a time --------------------------------------------------------------------------------------
         double (*s_t)[kWave + 1] = reinterpret_cast<double (*)[kWave + 1]>(s_mem);
         const uint32_t n_big = big_cnt[blockIdx.x];
-        const double* __restrict__ row = s_t[lane < 9 ? lane : 8];
-        // every big voxel is taken twice, by different wavefronts: once for its nine f64 sums, once for its four f32 sums — the
-        // chain is what a single registration's setInputTarget waits for (5145 points: 70 us with all 13 chains in one wavefront,
-        // three instructions per point), and each kind alone needs two instructions per point
-        for (uint32_t bi = blockIdx.y; bi < 2u * n_big; bi += big_blocks) {
-            const uint32_t leaf = big_list[ls.leaf_off + (bi >> 1)];
-            const bool     f32_kind = (bi & 1u) != 0;  // wave-uniform
+        const int      k = lane < 13 ? lane : 12;
+        const double* __restrict__ row = s_t[k];
+        for (uint32_t bi = blockIdx.y; bi < n_big; bi += big_blocks) {
+            const uint32_t leaf = big_list[ls.leaf_off + bi];
             const uint32_t b = seg_start[ls.seg_off + leaf], e = seg_start[ls.seg_off + leaf + 1];
             double acc = 0.0;
             float  facc = 0.0f;
@@ -146,8 +143,6 @@ __global__ __launch_bounds__(64, 6) void ndt_leaf_sums_kernel(const float4* cons
                 for (int d = 0; d < kAhead; ++d) pre[d] = pts[id[d]];
             };
             fetch4(b);
-            float (*s_f)[kWave + 1] = reinterpret_cast<float (*)[kWave + 1]>(s_mem);
-            const float* __restrict__ frow = s_f[lane < 4 ? lane : 3];
             for (uint32_t base4 = b; base4 < e; base4 += kAhead * kWave) {
                 float4 cur4[kAhead];
 #pragma unroll
@@ -157,48 +152,36 @@ __global__ __launch_bounds__(64, 6) void ndt_leaf_sums_kernel(const float4* cons
                 for (int d = 0; d < kAhead; ++d) {
                     const uint32_t base = base4 + d * kWave;
                     if (base >= e) break;  // wave-uniform
-                    const bool   in = base + lane < e;
-                    const float4 p = cur4[d];
-                    // a lane past the end stores zeros (exact to add, see above)
-                    if (f32_kind) {
-                        s_f[0][lane] = in ? p.x : 0.0f; s_f[1][lane] = in ? p.y : 0.0f; s_f[2][lane] = in ? p.z : 0.0f; s_f[3][lane] = in ? p.w : 0.0f;
-                    } else {
+                    {
+                        const bool   in = base + lane < e;
+                        const float4 p = cur4[d];
                         const double x = p.x, y = p.y, z = p.z;
+                        // a lane past the end stores zeros (exact to add, see above)
                         s_t[0][lane] = in ? x : 0.0; s_t[1][lane] = in ? y : 0.0; s_t[2][lane] = in ? z : 0.0;
                         s_t[3][lane] = in ? x * x : 0.0; s_t[4][lane] = in ? x * y : 0.0; s_t[5][lane] = in ? x * z : 0.0;
                         s_t[6][lane] = in ? y * y : 0.0; s_t[7][lane] = in ? y * z : 0.0; s_t[8][lane] = in ? z * z : 0.0;
+                        // the f32 sums travel in the low half of an 8-byte slot: one read serves both kinds of chain
+                        reinterpret_cast<float*>(&s_t[9][lane])[0] = in ? p.x : 0.0f; reinterpret_cast<float*>(&s_t[10][lane])[0] = in ? p.y : 0.0f;
+                        reinterpret_cast<float*>(&s_t[11][lane])[0] = in ? p.z : 0.0f; reinterpret_cast<float*>(&s_t[12][lane])[0] = in ? p.w : 0.0f;
                     }
                     __builtin_amdgcn_wave_barrier();
                     __threadfence_block();
                     const uint32_t cnt = min(static_cast<uint32_t>(kWave), e - base);
-                    if (f32_kind) {
-                        for (uint32_t h = 0; h < (cnt + 15) / 16; ++h) {
-                            float v[16];
+                    for (uint32_t h = 0; h < (cnt + 15) / 16; ++h) {
+                        double v[16];
 #pragma unroll
-                            for (int j = 0; j < 16; ++j) v[j] = frow[h * 16 + j];
+                        for (int j = 0; j < 16; ++j) v[j] = row[h * 16 + j];
 #pragma unroll
-                            for (int j = 0; j < 16; ++j) facc += v[j];
-                        }
-                    } else {
-                        for (uint32_t h = 0; h < (cnt + 15) / 16; ++h) {
-                            double v[16];
-#pragma unroll
-                            for (int j = 0; j < 16; ++j) v[j] = row[h * 16 + j];
-#pragma unroll
-                            for (int j = 0; j < 16; ++j) acc += v[j];
+                        for (int j = 0; j < 16; ++j) {
+                            acc += v[j];
+                            facc += __builtin_bit_cast(float, static_cast<uint32_t>(__builtin_bit_cast(unsigned long long, v[j])));
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
                     __threadfence_block();
                 }
             }
-            double* o = sums + (size_t)(ls.leaf_off + leaf) * 16;
-            if (f32_kind) {
-                if (lane < 4) o[10 + lane] = static_cast<double>(facc);
-            } else {
-                if (lane < 9) o[lane] = acc;
-                if (lane == 9) o[9] = static_cast<double>(e - b);
-            }
+            if (lane < 13) leaf_store(sums + (size_t)(ls.leaf_off + leaf) * 16, lane, acc, facc, e - b);
         }
         return;
     }
@@ -400,7 +383,10 @@ int ndt_launch_leaves(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint3
 {
     if (t.nprob() == 0 || max_leaves == 0) return MRGFE_OK;
     MRGFE_HIP_CHECK(hipMemsetAsync(d_big_cnt, 0, sizeof(uint32_t) * t.nprob(), ctx->stream));
-    // a build of a few targets does not fill the chip: more and shorter wavefronts, and more workgroups on the list of big voxels (single registration: sums 72 -> 64 us)
+    // a build of a few targets does not fill the chip: more and shorter wavefronts, and more workgroups on the list of big voxels
+    // (single registration: sums 72 -> 70 us; what is left is the 5145-point chain of the biggest voxel).  Measured and dropped: a big
+    // voxel's nine f64 and four f32 sums on two wavefronts, two instead of three instructions per point on the chain — 64 us for one
+    // target, but 335 -> 386 us for 256 (the points are gathered twice).
     const bool     few = t.nprob() <= 8;
     const uint32_t big_thr = few ? 256u : kLeafBig, span = few ? 4u : static_cast<uint32_t>(kLeafSpan), big_blocks = few ? 512u : kLeafBigBlocks;
     hipLaunchKernelGGL(ndt_big_leaves_kernel, dim3((max_leaves + 255) / 256, t.nprob()), dim3(256), 0, ctx->stream, d_leaf_slices, d_seg_start, big_thr, d_big_cnt, d_big_list);
