@@ -435,13 +435,22 @@ def main():
             same = same and bool(res[k]["converged"]) == conv and int(res[k]["iterations"]) == it
         parity = {"pairs": ncpu, "max_dt_m": max(dts), "max_dr_rad": max(drs), "same_iterations_and_convergence": same, "bar": "1e-4 m / 1e-4 rad"}
 
-    # dominant kernel = ndt_derivatives_kernel<0,7> (score + gradient + Hessian); the other two variants are listed beside it
+    # dominant kernel.  Fused launches (default): ndt_derivatives_all_kernel<7>, ONE launch per round that runs the work items of all
+    # three evaluation kinds (score + gradient + Hessian, score + gradient, f64 Hessian): its time and launch count are reported
+    # under variant 0 by the library, its algorithmic bytes are those of all three kinds.  MRGFE_FUSED=0: ndt_derivatives_kernel<0,7>
+    # (score + gradient + Hessian), the other two variants listed beside it.
+    from mrg_slam_amd._lib import lib
+
+    fused = bool(lib().mrgfe_dbg_set_fused_launch(-1))
     k_ms, k_launch, k_bytes = per_mode[0]
+    if fused:
+        k_bytes = float(per_mode[:, 2].sum())
+    kernel_name = "ndt_derivatives_all_kernel<7>" if fused else "ndt_derivatives_kernel<0,7>"
     achieved = (k_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
     variants = {name: {"launches": int(per_mode[m][1]), "avg_launch_ms": (per_mode[m][0] / per_mode[m][1]) if per_mode[m][1] else None,
                        "achieved_GBps": (per_mode[m][2] / 1e9) / (per_mode[m][0] / 1e3) if per_mode[m][0] > 0 else None}
                 for m, name in enumerate(("ndt_derivatives_kernel<0,7>", "ndt_derivatives_kernel<1,7>", "ndt_derivatives_kernel<2,7>"))
-                if per_mode[m][1]}  # (the line-search and f64-Hessian variants are timed only with MRGFE_KERNEL_TIMING=2: their events cost the round a little)
+                if per_mode[m][1] and not fused}  # (the line-search and f64-Hessian variants are timed only with MRGFE_KERNEL_TIMING=2: their events cost the round a little)
     # HBM bytes per launch of the dominant kernel and its VALU utilisation from the PMC passes (collected separately with
     # rocprofv3 --pmc and corrected as MI355X_MICROARCH.md prescribes; profiles/summarize.py) - null until a profile exists
     traffic = valu_busy = None
@@ -488,10 +497,12 @@ def main():
         },
         "roofline": {"bound": limiter, "byte_model_bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": traffic, "traffic_over_algorithmic": ratio, "valu_busy": valu_busy, "pmc_profile": prof_name,
-                     "kernel": "ndt_derivatives_kernel<0,7>", "avg_launch_ms": (k_ms / k_launch) if k_launch else None, "launches": int(k_launch),
+                     "kernel": kernel_name, "avg_launch_ms": (k_ms / k_launch) if k_launch else None, "launches": int(k_launch),
                      "alg_bytes_per_launch": alg_per_launch,
                      "byte_model": "per launch: sum over active pairs of N_src*(16 + 7*8) + valid_neighbours*48 (SURVEY.md §8d); `frac` prices these ALGORITHMIC "
                                    "bytes against the HBM peak as the contract asks; `bound` is what the PMC counters say limits the kernel",
+                     "alg_bytes_by_evaluation_kind": {"score+gradient+hessian": per_mode[0][2] / max(k_launch, 1), "score+gradient": per_mode[1][2] / max(k_launch, 1),
+                                                      "f64_hessian": per_mode[2][2] / max(k_launch, 1)},
                      "variants": variants},
         "cpu_baseline": cpu,
         "parity_vs_oracle": parity,

@@ -350,6 +350,11 @@ int mrgfe_dbg_minmax(mrgfe_ctx* ctx, const float* xyzi, size_t n, float min3[3],
  * batches on the device; the environment variable MRGFE_HOST_CONTROL sets the initial value).  Results are the same either way;
  * tests/test_gpu_control.py holds the two against each other. */
 int mrgfe_dbg_set_host_control(int mode);
+/* How the derivative evaluations of a round are launched during the following alignments of this process: 1 = ONE launch for all
+ * three kernel variants, their work items interleaved (default; the environment variable MRGFE_FUSED sets the initial value),
+ * 0 = one launch per variant.  Any other value only asks.  Returns the setting in effect.  Same sums either way: an item's partial
+ * record does not depend on the launch it is computed in (tests/test_gpu_control.py). */
+int mrgfe_dbg_set_fused_launch(int mode);
 /* The optimiser's scalar routines (pose vector -> float matrix, angle derivative tables, 6x6 SVD solve) on n cases of 48 doubles
  * (p[6], A[36] row-major, b[6]), on the host (on_device = 0, ctx may be NULL) or on the device: M16 [n][16] row-major, tables69
  * [n][8*3 + 15*3], x6 [n][6]; on_device = 2: x6 from the wavefront form of the solve (three lanes rotate, 36 apply) that the

@@ -171,6 +171,7 @@ SIGNATURES = {
     "mrgfe_dbg_exclusive_scan": (C.c_int, [_vp, _u32p, C.c_size_t, _u32p, _u32p]),
     "mrgfe_dbg_minmax": (C.c_int, [_vp, _fp, C.c_size_t, _fp, _fp, _u32p]),
     "mrgfe_dbg_set_host_control": (C.c_int, [C.c_int]),
+    "mrgfe_dbg_set_fused_launch": (C.c_int, [C.c_int]),
     "mrgfe_batch_rounds": (C.c_int, [_vp]),
     "mrgfe_dbg_sincosf": (None, [_fp, C.c_size_t, _fp, _fp]),
     "mrgfe_dbg_ctl_math": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _fp, _dp, _dp]),

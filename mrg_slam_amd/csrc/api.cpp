@@ -1249,6 +1249,7 @@ int mrgfe_dbg_set_host_control(int mode)
     ndt_set_host_control(mode);
     return MRGFE_OK;
 }
+int mrgfe_dbg_set_fused_launch(int mode) { return ndt_set_fused_launch(mode); }
 void mrgfe_dbg_sincosf(const float* x, size_t n, float* sin_out, float* cos_out)
 {
     for (size_t i = 0; i < n; ++i) { sin_out[i] = ctl::sin_f(x[i]); cos_out[i] = ctl::cos_f(x[i]); }

@@ -103,47 +103,6 @@ __device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, co
     }
 }
 
-// double path: updateHessian for one pair (pclomp computeHessian keeps PCL's f64 3x6 / 18x6 forms)
-__device__ __forceinline__ void pair_double(Accum& acc, const double mean[3], const double* __restrict__ C, const float xt[3], const double (&J)[3][6],
-                                            const double (&PH)[6][3], double gauss_d1, double gauss_d2)
-{
-#pragma clang fp contract(off)
-    const double q[3] = {static_cast<double>(xt[0]) - mean[0], static_cast<double>(xt[1]) - mean[1], static_cast<double>(xt[2]) - mean[2]};
-    double Cq[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) Cq[r] = fdot3d(C[r * 3 + 0], q[0], C[r * 3 + 1], q[1], C[r * 3 + 2], q[2]);
-    double e = gauss_d2 * exp(-gauss_d2 * fdot3d(q[0], Cq[0], q[1], Cq[1], q[2], Cq[2]) / 2);
-    if (e > 1 || e < 0 || e != e) return;
-    e *= gauss_d1;
-    double CJ[3][6], qCJ[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        // the translation columns of J are unit vectors and J(0,3) is a structural zero: x*1 = x, fma(x, 0, s) = s
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-            CJ[r][c] = c < 3 ? C[r * 3 + c] : (c == 3 ? fdot3d_z(C[r * 3 + 1], J[1][c], C[r * 3 + 2], J[2][c]) : fdot3d(C[r * 3 + 0], J[0][c], C[r * 3 + 1], J[1][c], C[r * 3 + 2], J[2][c]));
-        qCJ[c] = fdot3d(q[0], CJ[0][c], q[1], CJ[1][c], q[2], CJ[2][c]);
-    }
-    // Everything here is f64, so the reference's H(i,j) and H(j,i) differ by rounding at the 1e-16 level — far below the
-    // noise of the summation order — and so does q.(C PH) against (C q).PH for the numerically symmetric inverse
-    // covariance: only the upper triangle is evaluated (mirrored in the epilogue) and the second-derivative term reuses
-    // C q.  (The float path keeps all 36 entries: there the two roundings differ by 1e-7 and it matters.)
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-#pragma unroll
-        for (int j = i; j < 6; ++j) {
-            double qch = 0.0;
-            if (i >= 3) {
-                const int ph = (i == 3) ? (j - 3) : (i == 4 ? (j - 4 + 3) : 5);
-                qch = ph < 3 ? fdot3d_z(Cq[1], PH[ph][1], Cq[2], PH[ph][2]) : fdot3d(Cq[0], PH[ph][0], Cq[1], PH[ph][1], Cq[2], PH[ph][2]);
-            }
-            const double jtcj = j < 3 ? CJ[j][i] : (j == 3 ? fdot3d_z(J[1][3], CJ[1][i], J[2][3], CJ[2][i]) : fdot3d(J[0][j], CJ[0][i], J[1][j], CJ[1][i], J[2][j], CJ[2][i]));
-            const double t0 = -gauss_d2 * qCJ[i];
-            acc.H[i * 6 + j] = __builtin_fma(e, __builtin_fma(t0, qCJ[j], qch) + jtcj, acc.H[i * 6 + j]);
-        }
-    }
-}
-
 // MODE 0: score+gradient+Hessian, 1: score+gradient, 2: Hessian only (double).  NNB: probed voxels (7, 1 or 27).
 // Register budget: the full variant (43 f64 accumulators) is latency-bound at 2 waves/SIMD; capping it at 168 VGPRs
 // (3 waves/SIMD, ~44 B/lane of spill) is 12 % faster on MI355X, 128 VGPRs (4 waves) spills too much (measured).
@@ -153,48 +112,45 @@ __device__ __forceinline__ void pair_double(Accum& acc, const double mean[3], co
 #ifndef NDT_MODE2_WAVES
 #define NDT_MODE2_WAVES 3  // the per-point f64 Hessian pass holds 21 + 15 f64 accumulators and no LDS staging
 #endif
-template <int MODE, int NNB>
-__global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : ((MODE == 2 && NNB <= 7) ? NDT_MODE2_WAVES : 2))) void ndt_derivatives_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
-                                                               const NdtEvalDev* __restrict__ evals, const uint32_t* __restrict__ plan, uint32_t n_all_pairs,
-                                                               double* __restrict__ partials)
-{
-    // the round's plan (ndt_plan_kernel): this variant's busy pairs and the prefix of their work items
-    const NdtPlanHead& head = *reinterpret_cast<const NdtPlanHead*>(plan);
-    const uint32_t n_items = head.n_items[MODE];
-    if (blockIdx.x >= n_items) return;
-    const uint32_t ppt = head.ppt[MODE], n_busy = head.n_pairs[MODE];
-    const uint32_t* __restrict__ pair_of = plan + ndt_plan_pair_off(n_all_pairs, MODE);
-    const uint32_t* __restrict__ item_start = plan + ndt_plan_start_off(n_all_pairs, MODE);
+// LDS of one workgroup (all variants share it: a fused launch runs items of every variant)
+template <int NNB>
+struct NdtDerivShared {
+    float    T[12];
+    float    ja[8][3], ha[15][3];
+    float    xt[3][kTilePts];
+    float    xj[8][kTilePts];
+    float    xh[15][kTilePts];
+    uint32_t queue[kTilePts * NNB];  // (slot << 24) | leaf id
+    uint32_t scan[8];
+    double   red[4][kNdtPartialStride];
+};
 
-    using StageT = typename std::conditional<MODE == 2, double, float>::type;  // precision of the staged point terms
-    constexpr int kHRows = (MODE == 1) ? 1 : 15;
-    __shared__ float    s_T[12];
-    __shared__ float    s_ja[8][3], s_ha[15][3];
+// One work item: `ppt` consecutive tiles of pair `pi`, starting at tile item_in_pair * ppt; one 384-byte partial record.
+template <int MODE, int NNB>
+__device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
+                                                     const NdtEvalDev* __restrict__ evals, uint32_t pi, uint32_t item_in_pair, uint32_t ppt, double* __restrict__ partials)
+{
     constexpr int kTile = kTilePts;
-    constexpr int kStage = (MODE == 2) ? 1 : kTile;  // the f64 Hessian variant keeps a point's terms in registers (see below)
-    __shared__ float    s_xt[3][kStage];
-    __shared__ StageT   s_xj[8][kStage];
-    __shared__ StageT   s_xh[kHRows][kStage];
-    __shared__ uint32_t s_queue[kStage * NNB];  // (slot << 24) | leaf id
-    __shared__ uint32_t s_scan[8];
-    __shared__ double   s_red[4][kNdtPartialStride];
-  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {  // (body indented as before the item loop existed)
-    // pair of this item: the last busy pair whose first item is <= item (uniform over the workgroup: scalar loads)
-    uint32_t lo = 0, hi = n_busy;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (item_start[mid] <= item) lo = mid; else hi = mid;
-    }
-    const uint32_t   pi = pair_of[lo];
-    const uint32_t   item_in_pair = item - item_start[lo];
+    float (&s_T)[12] = sh.T;
+    float (&s_ja)[8][3] = sh.ja;
+    float (&s_ha)[15][3] = sh.ha;
+    float (&s_xt)[3][kTilePts] = sh.xt;
+    float (&s_xj)[8][kTilePts] = sh.xj;
+    float (&s_xh)[15][kTilePts] = sh.xh;
+    uint32_t (&s_queue)[kTilePts * NNB] = sh.queue;
+    uint32_t (&s_scan)[8] = sh.scan;
+    double (&s_red)[4][kNdtPartialStride] = sh.red;
+    {
     const NdtPairDev pr = pairs[pi];
     const NdtEvalDev& ev = evals[pi];
     const uint32_t part_off = pr.part_off;
     const NdtGridDev g = grids[pr.grid];  // by value: the grid parameters live in scalar registers for the whole item
     __syncthreads();  // the previous item's epilogue has read s_red / the staged tables
     if (threadIdx.x < 12) s_T[threadIdx.x] = ev.T[threadIdx.x];
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + 24) (&s_ja[0][0])[threadIdx.x - 64] = (&ev.j_ang[0][0])[threadIdx.x - 64];
-    if (threadIdx.x >= 128 && threadIdx.x < 128 + 45) (&s_ha[0][0])[threadIdx.x - 128] = (&ev.h_ang[0][0])[threadIdx.x - 128];
+    if (MODE != 2) {
+        if (threadIdx.x >= 64 && threadIdx.x < 64 + 24) (&s_ja[0][0])[threadIdx.x - 64] = (&ev.j_ang[0][0])[threadIdx.x - 64];
+        if (MODE == 0 && threadIdx.x >= 128 && threadIdx.x < 128 + 45) (&s_ha[0][0])[threadIdx.x - 128] = (&ev.h_ang[0][0])[threadIdx.x - 128];
+    }
     __syncthreads();
 
     const float  gauss_d2f = static_cast<float>(ev.gauss_d2);
@@ -382,37 +338,23 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : (
             if (lid >= g.n_leaves) continue;  // cannot happen; keeps a corrupted queue entry from faulting the GPU
             const NdtLeafRec rec = g.leaves[lid];
             const float xt[3] = {s_xt[0][slot], s_xt[1][slot], s_xt[2][slot]};
-            if (MODE != 2) {
-                float xj[8];
+            float xj[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) xj[r] = static_cast<float>(s_xj[r][slot]);
-                const float J3[3] = {0.0f, xj[0], xj[1]}, J4[3] = {xj[2], xj[3], xj[4]}, J5[3] = {xj[5], xj[6], xj[7]};
-                float PH[6][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-                if (MODE == 0) {
-                    float xh[15];
+            for (int r = 0; r < 8; ++r) xj[r] = s_xj[r][slot];
+            const float J3[3] = {0.0f, xj[0], xj[1]}, J4[3] = {xj[2], xj[3], xj[4]}, J5[3] = {xj[5], xj[6], xj[7]};
+            float PH[6][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            if (MODE == 0) {
+                float xh[15];
 #pragma unroll
-                    for (int r = 0; r < 15; ++r) xh[r] = static_cast<float>(s_xh[r][slot]);
-                    PH[0][1] = xh[0];  PH[0][2] = xh[1];                     // a  (3,3)
-                    PH[1][1] = xh[2];  PH[1][2] = xh[3];                     // b  (3,4)
-                    PH[2][1] = xh[4];  PH[2][2] = xh[5];                     // c  (3,5)
-                    PH[3][0] = xh[6];  PH[3][1] = xh[7];  PH[3][2] = xh[8];  // d  (4,4)
-                    PH[4][0] = xh[9];  PH[4][1] = xh[10]; PH[4][2] = xh[11]; // e  (4,5)
-                    PH[5][0] = xh[12]; PH[5][1] = xh[13]; PH[5][2] = xh[14]; // f  (5,5)
-                }
-                pair_float<MODE == 0>(acc, rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
-            } else {
-                double J[3][6] = {{1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}, {0, 0, 1, 0, 0, 0}};
-                J[1][3] = s_xj[0][slot]; J[2][3] = s_xj[1][slot];
-                J[0][4] = s_xj[2][slot]; J[1][4] = s_xj[3][slot]; J[2][4] = s_xj[4][slot];
-                J[0][5] = s_xj[5][slot]; J[1][5] = s_xj[6][slot]; J[2][5] = s_xj[7][slot];
-                const double PH[6][3] = {{0, s_xh[0][slot], s_xh[1][slot]},
-                                         {0, s_xh[2][slot], s_xh[3][slot]},
-                                         {0, s_xh[4][slot], s_xh[5][slot]},
-                                         {s_xh[6][slot], s_xh[7][slot], s_xh[8][slot]},
-                                         {s_xh[9][slot], s_xh[10][slot], s_xh[11][slot]},
-                                         {s_xh[12][slot], s_xh[13][slot], s_xh[14][slot]}};
-                pair_double(acc, rec.mean, g.icov64 + (size_t)lid * 9, xt, J, PH, gauss_d1, gauss_d2);
+                for (int r = 0; r < 15; ++r) xh[r] = s_xh[r][slot];
+                PH[0][1] = xh[0];  PH[0][2] = xh[1];                     // a  (3,3)
+                PH[1][1] = xh[2];  PH[1][2] = xh[3];                     // b  (3,4)
+                PH[2][1] = xh[4];  PH[2][2] = xh[5];                     // c  (3,5)
+                PH[3][0] = xh[6];  PH[3][1] = xh[7];  PH[3][2] = xh[8];  // d  (4,4)
+                PH[4][0] = xh[9];  PH[4][1] = xh[10]; PH[4][2] = xh[11]; // e  (4,5)
+                PH[5][0] = xh[12]; PH[5][1] = xh[13]; PH[5][2] = xh[14]; // f  (5,5)
             }
+            pair_float<MODE == 0>(acc, rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
         }
         __syncthreads();  // the next tile overwrites the staged terms and the queue
     }
@@ -440,7 +382,81 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : (
         if (!skip) r = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
         partials[(size_t)(part_off + item_in_pair) * kNdtPartialStride + k] = r;
     }
-  }  // items
+    }
+}
+
+// pair and position within the pair of item `item` of variant `mode`: the last busy pair whose first item is <= item
+// (uniform over the workgroup: scalar loads)
+__device__ __forceinline__ void ndt_plan_find(const uint32_t* __restrict__ plan, uint32_t n_all_pairs, int mode, uint32_t n_busy, uint32_t item, uint32_t& pi, uint32_t& item_in_pair)
+{
+    const uint32_t* __restrict__ pair_of = plan + ndt_plan_pair_off(n_all_pairs, mode);
+    const uint32_t* __restrict__ item_start = plan + ndt_plan_start_off(n_all_pairs, mode);
+    uint32_t lo = 0, hi = n_busy;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (item_start[mid] <= item) lo = mid; else hi = mid;
+    }
+    pi = pair_of[lo];
+    item_in_pair = item - item_start[lo];
+}
+
+// One variant per launch (MRGFE_FUSED=0; kept to hold the fused launch against).
+template <int MODE, int NNB>
+__global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : ((MODE == 2 && NNB <= 7) ? NDT_MODE2_WAVES : 2))) void ndt_derivatives_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
+                                                               const NdtEvalDev* __restrict__ evals, const uint32_t* __restrict__ plan, uint32_t n_all_pairs,
+                                                               double* __restrict__ partials)
+{
+    // the round's plan (ndt_plan_kernel): this variant's busy pairs and the prefix of their work items
+    const NdtPlanHead& head = *reinterpret_cast<const NdtPlanHead*>(plan);
+    const uint32_t n_items = head.n_items[MODE];
+    if (blockIdx.x >= n_items) return;
+    const uint32_t ppt = head.ppt[MODE], n_busy = head.n_pairs[MODE];
+    __shared__ NdtDerivShared<NNB> sh;
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        uint32_t pi, item_in_pair;
+        ndt_plan_find(plan, n_all_pairs, MODE, n_busy, item, pi, item_in_pair);
+        ndt_derivatives_item<MODE, NNB>(sh, grids, pairs, evals, pi, item_in_pair, ppt, partials);
+    }
+}
+
+// All three variants in ONE launch per round.  The items of the variants are interleaved in proportion to their counts
+// (two nested Bresenham splits: variant 0 against the rest, then 2 against 1), so that the f64 Hessian items — latency-bound,
+// VALU busy 0.41 on their own — and the cheap score+gradient items share the CUs with the VALU-bound items of variant 0
+// instead of each variant paying its own launch, its own tail and a queue gap.
+// All three variants in ONE launch per round: the workgroups walk the items of variant 0, then those of variant 2, then those of
+// variant 1 (heaviest first), one loop per variant — a variant's tail is filled by the next variant's items instead of idling
+// until its own launch has drained, and a round costs one queue gap instead of three.
+template <int MODE, int NNB>
+__device__ __forceinline__ void ndt_derivatives_walk(NdtDerivShared<NNB>& sh, uint32_t first, const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
+                                                     const NdtEvalDev* __restrict__ evals, const uint32_t* __restrict__ plan, uint32_t n_all_pairs, double* __restrict__ partials)
+{
+    const NdtPlanHead& head = *reinterpret_cast<const NdtPlanHead*>(plan);
+    const uint32_t n_items = head.n_items[MODE], ppt = head.ppt[MODE], n_busy = head.n_pairs[MODE];
+    for (uint32_t item = first; item < n_items; item += gridDim.x) {
+        uint32_t pi, item_in_pair;
+        ndt_plan_find(plan, n_all_pairs, MODE, n_busy, item, pi, item_in_pair);
+        ndt_derivatives_item<MODE, NNB>(sh, grids, pairs, evals, pi, item_in_pair, ppt, partials);
+    }
+}
+
+template <int NNB>
+__global__ __launch_bounds__(256, NNB <= 7 ? NDT_MODE0_WAVES : 2) void ndt_derivatives_all_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
+                                                               const NdtEvalDev* __restrict__ evals, const uint32_t* __restrict__ plan, uint32_t n_all_pairs,
+                                                               double* __restrict__ partials)
+{
+    __shared__ NdtDerivShared<NNB> sh;
+    const NdtPlanHead& head = *reinterpret_cast<const NdtPlanHead*>(plan);
+    // position of this workgroup in the concatenated item list 0 | 2 | 1; a workgroup past the end of a variant's items starts in
+    // the next variant at the position the stride leaves it
+    const uint32_t n0 = head.n_items[0], n2 = head.n_items[2], g = gridDim.x;
+    uint32_t at = blockIdx.x;
+    ndt_derivatives_walk<0, NNB>(sh, at, grids, pairs, evals, plan, n_all_pairs, partials);
+    if (at < n0) at += (n0 - at + g - 1) / g * g;  // first position >= n0 on this workgroup's stride
+    at -= n0;
+    ndt_derivatives_walk<2, NNB>(sh, at, grids, pairs, evals, plan, n_all_pairs, partials);
+    if (at < n2) at += (n2 - at + g - 1) / g * g;
+    at -= n2;
+    ndt_derivatives_walk<1, NNB>(sh, at, grids, pairs, evals, plan, n_all_pairs, partials);
 }
 
 // ---- the round's plan -------------------------------------------------------------------------------------------------
@@ -539,11 +555,18 @@ __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __res
     __shared__ double s_r[kNdtPartialStride];
     const int k = threadIdx.x & 63, slice = threadIdx.x >> 6;
     if (k < kNdtPartialStride) {
-        // the additions stay in order; eight loads are in flight ahead of them (a straggler round has one pair with 500
+        // the additions stay in order; 32 (then eight) loads are in flight ahead of them (a straggler round has one pair with 500
         // records, and a load-add-load-add chain over them took longer than the derivative kernel it follows)
         const double* col = partials + (size_t)pr.part_off * kNdtPartialStride + k;
         double   acc = 0.0;
         uint32_t b = slice;
+        for (; b + 124 < nblk; b += 128) {
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = col[(size_t)(b + 4 * u) * kNdtPartialStride];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc += v[u];
+        }
         for (; b + 28 < nblk; b += 32) {
             double v[8];
 #pragma unroll
@@ -668,6 +691,17 @@ static void launch_mode(mrgfe_ctx* ctx, int nnb, uint32_t grid, const NdtGridDev
     if (nnb == 7)       hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 7>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
     else if (nnb == 1)  hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 1>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
     else                hipLaunchKernelGGL((ndt_derivatives_kernel<MODE, 27>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
+}
+
+int ndt_launch_derivatives_all(mrgfe_ctx* ctx, int search, uint32_t grid, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const uint32_t* d_plan,
+                               uint32_t P, double* d_partials)
+{
+    if (grid == 0 || P == 0) return MRGFE_OK;
+    if (search == MRGFE_DIRECT7)      hipLaunchKernelGGL((ndt_derivatives_all_kernel<7>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
+    else if (search == MRGFE_DIRECT1) hipLaunchKernelGGL((ndt_derivatives_all_kernel<1>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
+    else                              hipLaunchKernelGGL((ndt_derivatives_all_kernel<27>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
 }
 
 int ndt_launch_plan(mrgfe_ctx* ctx, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, uint32_t P, uint32_t* d_plan, uint32_t wg_target, uint32_t max_ppt, uint32_t forced_ppt,

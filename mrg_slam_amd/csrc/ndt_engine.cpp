@@ -369,6 +369,20 @@ int NdtEngine::upload_pairs()
 // score+gradient+Hessian variant (default: each event pair costs ~4 us of queue gap per round), 0 = none.  MRGFE_KERNEL_TIMING.
 static int timing_level() { static const int v = [] { const char* e = std::getenv("MRGFE_KERNEL_TIMING"); return e ? std::atoi(e) : 1; }(); return v; }
 
+// MRGFE_FUSED=0: one derivative launch per kernel variant and round (the layout before the fused launch; kept to hold it against)
+static std::atomic<int> g_fused{-1};  // -1: not read yet
+static bool fused_launch()
+{
+    int v = g_fused.load(std::memory_order_relaxed);
+    if (v < 0) { const char* e = std::getenv("MRGFE_FUSED"); v = e ? (std::atoi(e) != 0 ? 1 : 0) : 1; g_fused.store(v, std::memory_order_relaxed); }
+    return v != 0;
+}
+int ndt_set_fused_launch(int mode)
+{
+    if (mode == 0 || mode == 1) g_fused.store(mode, std::memory_order_relaxed);
+    return fused_launch() ? 1 : 0;
+}
+
 constexpr int kHostParallelMinPairs = 48;  // below this the controller steps of a round run on the calling thread
 
 // -1: automatic (single registrations are stepped by the host, batches on the device); 0 / 1 force device / host control
@@ -386,7 +400,8 @@ static int env_int(const char* name, int dflt) { const char* e = std::getenv(nam
 uint32_t NdtEngine::derivative_grid(int mode) const
 {
     static const int per_slot = std::max(1, env_int("MRGFE_GRID_PER_SLOT", 8));
-    const int slots_per_cu = (mode != 1 && prm_.search != MRGFE_KDTREE && prm_.search != MRGFE_DIRECT26) ? 3 : 2;  // __launch_bounds__ of the variants
+    const bool narrow = prm_.search != MRGFE_KDTREE && prm_.search != MRGFE_DIRECT26;
+    const int slots_per_cu = fused_launch() ? (narrow ? 3 : 2) : ((mode != 1 && narrow) ? 3 : 2);  // __launch_bounds__ of the kernels
     return static_cast<uint32_t>(ctx_->cu_count * slots_per_cu * per_slot);
 }
 
@@ -447,6 +462,21 @@ int NdtEngine::enqueue_round(uint32_t round, bool device_control, const bool wan
         std::memcpy(h_plan_.p, plan_scratch_.data(), words * 4);
         MRGFE_HIP_CHECK(hipMemcpyAsync(d_plan_.p, h_plan_.p, words * 4, hipMemcpyHostToDevice, st));
     }
+    if (fused_launch()) {
+        // every variant's items in one launch (ndt_derivatives_all_kernel); its events sit in the slots of variant 0
+        if (want_mode[0] || want_mode[1] || want_mode[2]) {
+            const bool timed = timing_level() > 0;
+            if (timed) MRGFE_HIP_CHECK(hipEventRecord(ev_pool_[size_t(round) * 6], st));
+            uint32_t grid = derivative_grid(0);
+            if (!device_control) {
+                const NdtPlanHead* h = reinterpret_cast<const NdtPlanHead*>(plan_scratch_.data());
+                grid = std::min(grid, h->n_items[0] + h->n_items[1] + h->n_items[2]);  // the host knows the item count
+            }
+            MRGFE_TRY(ndt_launch_derivatives_all(ctx_, prm_.search, grid, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_plan_.as<uint32_t>(), P,
+                                                 d_partials_.as<double>()));
+            if (timed) MRGFE_HIP_CHECK(hipEventRecord(ev_pool_[size_t(round) * 6 + 1], st));
+        }
+    } else
     for (int m = 0; m < 3; ++m) {
         if (!want_mode[m]) continue;
         const bool timed = timing_level() > (m == 0 ? 0 : 1);
@@ -469,6 +499,16 @@ void NdtEngine::account(const std::vector<NdtRoundInfo>& info, size_t rounds)
     // ~4 us): the device-controlled path launches all three variants every round, and rocprofv3's per-kernel average — which
     // bench.py's HIP-event average is held against — is over all of them too
     // (the host-stepped path launches only the variants with work: `info` lists them and the other event slots are stale)
+    if (fused_launch()) {
+        // one launch per round; its time and count go under variant 0, the byte model below stays per variant
+        for (size_t r = 0; r < rounds && timing_level() > 0; ++r) {
+            if (!info.empty() && (r >= info.size() || info[r].n_active == 0)) continue;
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev_pool_[r * 6], ev_pool_[r * 6 + 1]) != hipSuccess) continue;
+            mode_ms[0] += ms;
+            mode_launches[0] += 1;
+        }
+    } else
     for (size_t r = 0; r < rounds; ++r)
         for (int m = 0; m < 3; ++m) {
             if (timing_level() <= (m == 0 ? 0 : 1)) continue;

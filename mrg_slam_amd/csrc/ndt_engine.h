@@ -32,6 +32,9 @@ struct NdtPairInfo {
 
 // who steps the optimiser of the following alignments: -1 automatic (default; MRGFE_HOST_CONTROL overrides), 0 device, 1 host
 void ndt_set_host_control(int mode);
+// derivative launches of the following alignments: 1 = one launch per round for all kernel variants (default; MRGFE_FUSED
+// overrides), 0 = one launch per variant; any other value only asks.  Returns the setting in effect.
+int ndt_set_fused_launch(int mode);
 
 class NdtEngine {
    public:

@@ -20,6 +20,15 @@ def control():
     lib().mrgfe_dbg_set_host_control(-1)
 
 
+@pytest.fixture()
+def fused():
+    from mrg_slam_amd._lib import lib
+
+    before = lib().mrgfe_dbg_set_fused_launch(-1)
+    yield lambda m: lib().mrgfe_dbg_set_fused_launch(m)
+    lib().mrgfe_dbg_set_fused_launch(before)
+
+
 def _scenes(n_pairs, seed):
     from mrg_slam_amd import synth
     from oracle import oracle as orc
@@ -153,3 +162,26 @@ def test_controller_math_device_equals_host():
     xw = out[2][2]
     assert (np.isfinite(xw).all(axis=1) == ok).all()
     assert (xw[ok] == xd[ok]).all()
+
+
+@pytest.mark.parametrize("search", ["DIRECT7", "DIRECT1", "KDTREE"])
+@pytest.mark.parametrize("host", [0, 1])
+def test_fused_launch_equals_one_launch_per_variant(control, fused, search, host):
+    """All three kernel variants of a round in ONE launch (items interleaved) against one launch per variant: an item's partial
+    record does not depend on the launch it is computed in, so every result is the same bit for bit (device- and host-stepped)."""
+    from mrg_slam_amd import BatchMatcher
+
+    scenes = _scenes(40, 23)
+    control(host)
+    res = {}
+    for f in (0, 1):
+        assert fused(f) == f
+        bm = BatchMatcher(transformation_epsilon=0.01, search=search)
+        for tgt, src, guess in scenes:
+            bm.add_pair(bm.add_target(tgt), src, guess)
+        res[f] = bm.align(float("inf"))
+        ms, launches, nbytes = bm.kernel_stats(-1)
+        assert launches > 0 and nbytes > 0
+    a, b = res[0], res[1]
+    for field in ("T", "H", "fitness", "converged", "iterations", "evaluations", "trans_probability"):
+        assert np.array_equal(a[field], b[field]), field
