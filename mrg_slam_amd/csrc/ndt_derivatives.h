@@ -23,6 +23,8 @@ int ndt_launch_reduce(mrgfe_ctx* ctx, uint32_t P, const NdtPairDev* d_pairs, Ndt
 // diagnostic: ctl::pose_to_matrix / angle_tables / svd_solve6 for n cases of 48 doubles (p[6], A[36], b[6]) on the device
 int ndt_ctl_math_device(mrgfe_ctx* ctx, const double* d_in, int n, float* d_M, double* d_tables, double* d_x);
 int ndt_ctl_svd_wave_device(mrgfe_ctx* ctx, const double* d_in, int n, double* d_x);  // the wavefront form of the solve, one case per workgroup
+// diagnostic builds (-DNDT_PHASE_CLOCK): prints the phase clocks of the derivative kernel to stderr; a no-op otherwise
+void ndt_phase_dump();
 // dst = T * src (row-major 3x4 float T in device memory)
 int launch_transform_cloud(mrgfe_ctx* ctx, const float4* d_src, float4* d_dst, uint32_t n, const float* d_T12);
 

@@ -18,12 +18,28 @@
 //            tiny kernel adds the records of each pair in a fixed order (bitwise reproducible results).
 // The contraction is 6 wide: far too thin for MFMA; the kernel is bound by VALU issue and by the
 // dependent point -> lookup -> record loads, which is what the byte-model roofline in bench.py is held against.
+#include <cstdio>
+
 #include "dev_float.h"
 #include "dev_utils.h"
 #include "ndt_ctl.h"
 #include "ndt_derivatives.h"
 
 namespace mrgfe {
+
+// -DNDT_PHASE_CLOCK (diagnostic build, see profiles/README in README.md): wall-clock ticks (100 MHz) wavefront 0 of a workgroup of the
+// score+gradient+Hessian variant spends in the stages of a tile — point loaded, table probes back, point terms staged, queue built
+// (end of the point phase), pair phase — and in the item's epilogue, summed over all workgroups; MRGFE_PHASE=1 prints them after an alignment
+#ifdef NDT_PHASE_CLOCK
+__device__ unsigned long long g_phase[8];
+#define NDT_CLOCK(var) long long var = 0; if (MODE == 0 && threadIdx.x == 0) var = wall_clock64()
+#define NDT_CLOCK_WAIT(var) if (MODE == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); NDT_CLOCK(var)
+#define NDT_CLOCK_ADD(slot, ticks) if (MODE == 0 && threadIdx.x == 0) atomicAdd(&g_phase[slot], static_cast<unsigned long long>(ticks))
+#else
+#define NDT_CLOCK(var)
+#define NDT_CLOCK_WAIT(var)
+#define NDT_CLOCK_ADD(slot, ticks)
+#endif
 
 // DIRECT7 probes: the voxel of the point, then +x, -x, +y, -y, +z, -z (pclomp getNeighborhoodAtPoint7)
 
@@ -165,11 +181,16 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc.H[k] = 0;
     uint32_t nb_total = 0, nb_mine = 0;
+#ifdef NDT_PHASE_CLOCK
+    long long clk[6] = {0, 0, 0, 0, 0, 0};
+#endif
 
     const uint32_t base = item_in_pair * static_cast<uint32_t>(kTilePts) * ppt;
     const uint32_t last = min(pr.n_src, base + static_cast<uint32_t>(kTilePts) * ppt);  // end of this item's points
     for (uint32_t tile0 = base; tile0 < last; tile0 += kTile) {
         // ---- phase 1: one lane per point -------------------------------------------------------------------------
+        NDT_CLOCK(tc0);
+        NDT_CLOCK(tc_p); NDT_CLOCK(tc_l); NDT_CLOCK(tc_s);
         const uint32_t i = tile0 + threadIdx.x;
         int32_t  ids[NNB];
         uint32_t cnt = 0;
@@ -178,6 +199,9 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
         if (threadIdx.x < kTile && i < last) {
             const float4 p = pr.src[i];
             float xt[3];
+#ifdef NDT_PHASE_CLOCK
+            if (MODE == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (threadIdx.x == 0) tc_p = wall_clock64(); }
+#endif
             transform_point(s_T, p.x, p.y, p.z, xt[0], xt[1], xt[2]);
             // getNeighborhoodAtPoint: floor(p / leaf_size)
             int ijk[3];
@@ -233,6 +257,9 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
             }
 #pragma unroll
             for (int n = 0; n < NNB; ++n) cnt += ids[n] >= 0 ? 1u : 0u;
+#ifdef NDT_PHASE_CLOCK
+            if (MODE == 0 && threadIdx.x == 0) tc_l = wall_clock64();  // (cnt depends on every probe)
+#endif
             if (MODE == 2) {
                 // ---- computeHessian (pclomp: f64, PCL's 3x6 / 18x6 forms), one lane per POINT ------------------------------
                 // Per pair the reference evaluates  e * ( -d2 (q.C J_i)(q.C J_j) + q.C PH_ij + J_j.C J_i ).  J and PH belong to the
@@ -321,6 +348,9 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
             }
         }
         if (MODE == 2) continue;  // next tile: no LDS staging, no pair queue
+#ifdef NDT_PHASE_CLOCK
+        if (MODE == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0) tc_s = wall_clock64(); }
+#endif
         uint32_t total;
         uint32_t off = block_exclusive_scan<256>(cnt, s_scan, &total);
 #pragma unroll
@@ -330,6 +360,7 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
         nb_total += (threadIdx.x == 0) ? total : 0u;
 
         // ---- phase 2: one lane per (point, voxel) pair -----------------------------------------------------------
+        NDT_CLOCK(tc1);
         // (prefetching the next pair's record was measured slower both as a register double buffer — it costs the occupancy it
         // saves — and as an LDS-DMA into per-lane slots, -6 % / -13 % for the two float variants)
         for (uint32_t qi = threadIdx.x; qi < total; qi += kTilePts) {
@@ -357,23 +388,32 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
             pair_float<MODE == 0>(acc, rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
         }
         __syncthreads();  // the next tile overwrites the staged terms and the queue
+#ifdef NDT_PHASE_CLOCK
+        NDT_CLOCK(tc2);
+        if (MODE == 0 && threadIdx.x == 0) { clk[0] += tc_p - tc0; clk[1] += tc_l - tc_p; clk[2] += tc_s - tc_l; clk[3] += tc1 - tc_s; clk[4] += tc2 - tc1; clk[5] += 1; }  // (one atomic per item, below: per tile they held the next tile's loads back)
+#endif
     }
 
     // ---- phase 3: workgroup reduction -----------------------------------------------------------------------------
-    double vals[kNdtAccum];
-    vals[0] = acc.score;
+    NDT_CLOCK(tc3);
+    // the sums this variant delivers: MODE 0 all 44 (score, gradient, Hessian, neighbour count), MODE 1 score + gradient + count,
+    // MODE 2 Hessian + count; folded wave reduction (dev_utils.h): the same tree as 44 separate wave_sum calls, a sixth of the traffic
+    constexpr int kVals = MODE == 0 ? kNdtAccum : (MODE == 1 ? 8 : 37);
+    double vals[kVals];
+    int    keys[kVals];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) vals[1 + k] = acc.g[k];
-#pragma unroll
-    for (int k = 0; k < 36; ++k) vals[7 + k] = (MODE == 2 && k / 6 > k % 6) ? acc.H[(k % 6) * 6 + k / 6] : acc.H[k];  // the f64 pass fills the upper triangle
-    vals[kNdtNbIndex] = static_cast<double>(MODE == 2 ? nb_mine : nb_total);
-#pragma unroll
-    for (int k = 0; k < kNdtAccum; ++k) {
-        const bool skip = (MODE == 1 && k >= 7 && k < kNdtNbIndex) || (MODE == 2 && k < 7);
-        if (skip) continue;
-        const double r = wave_sum(vals[k]);
-        if (lane_id() == 0) s_red[wave_id()][k] = r;
+    for (int n = 0; n < kVals; ++n) {
+        const int k = (MODE == 1 && n == 7) ? kNdtNbIndex : (MODE == 2 ? 7 + n : n);  // slot of the partial record
+        keys[n] = k;
+        if (k == 0)                vals[n] = acc.score;
+        else if (k < 7)            vals[n] = acc.g[k - 1];
+        else if (k < kNdtNbIndex)  vals[n] = (MODE == 2 && (k - 7) / 6 > (k - 7) % 6) ? acc.H[((k - 7) % 6) * 6 + (k - 7) / 6] : acc.H[k - 7];  // the f64 pass fills the upper triangle
+        else                       vals[n] = static_cast<double>(MODE == 2 ? nb_mine : nb_total);
     }
+    double total_v;
+    int    total_k;
+    wave_sum_fold<kVals, 32>(vals, keys, total_v, total_k);
+    s_red[wave_id()][total_k] = total_v;  // (lanes that hold the same sum write the same double)
     __syncthreads();
     if (threadIdx.x < kNdtPartialStride) {
         const int  k = threadIdx.x;
@@ -382,6 +422,11 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
         if (!skip) r = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
         partials[(size_t)(part_off + item_in_pair) * kNdtPartialStride + k] = r;
     }
+#ifdef NDT_PHASE_CLOCK
+    NDT_CLOCK(tc4);
+    for (int c = 0; c < 6; ++c) NDT_CLOCK_ADD(c, clk[c]);
+    NDT_CLOCK_ADD(6, tc4 - tc3); NDT_CLOCK_ADD(7, 1);
+#endif
     }
 }
 
@@ -702,6 +747,17 @@ int ndt_launch_derivatives_all(mrgfe_ctx* ctx, int search, uint32_t grid, const 
     else                              hipLaunchKernelGGL((ndt_derivatives_all_kernel<27>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
+}
+
+void ndt_phase_dump()
+{
+#ifdef NDT_PHASE_CLOCK
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)) != hipSuccess) return;
+    const double t = 100.0 * (h[5] ? h[5] : 1);
+    std::fprintf(stderr, "[mrgfe phase clocks] %llu tiles, us per tile: point loaded %.2f, probes back %.2f, terms staged %.2f, queue built %.2f | pair phase %.2f; %llu items: epilogue %.2f us per item\n",
+                 h[5], h[0] / t, h[1] / t, h[2] / t, h[3] / t, h[4] / t, h[7], h[6] / 100.0 / (h[7] ? h[7] : 1));
+#endif
 }
 
 int ndt_launch_plan(mrgfe_ctx* ctx, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, uint32_t P, uint32_t* d_plan, uint32_t wg_target, uint32_t max_ppt, uint32_t forced_ppt,

@@ -532,6 +532,7 @@ void NdtEngine::account(const std::vector<NdtRoundInfo>& info, size_t rounds)
 
 int NdtEngine::align_all()
 {
+    struct PhaseDump { ~PhaseDump() { static const bool on = std::getenv("MRGFE_PHASE") != nullptr; if (on) ndt_phase_dump(); } } phase_dump;  // diagnostic builds only
     MRGFE_TRY(ctx_->bind());
     MRGFE_TRY(build_targets());
     if (pairs_dirty_) MRGFE_TRY(upload_pairs());
