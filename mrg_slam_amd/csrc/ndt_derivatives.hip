@@ -351,8 +351,29 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
 #ifdef NDT_PHASE_CLOCK
         if (MODE == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0) tc_s = wall_clock64(); }
 #endif
-        uint32_t total;
-        uint32_t off = block_exclusive_scan<256>(cnt, s_scan, &total);
+        // queue offsets: exclusive scan of cnt over the workgroup.  ONE barrier: every lane adds up the totals of the wavefronts before
+        // its own, and the four totals alternate between two LDS slots by tile parity (block_exclusive_scan costs three barriers, and
+        // each is a rendezvous of four wavefronts on four SIMDs that serve two other workgroups)
+        uint32_t total, off;
+        {
+            // within the wavefront: cnt <= NNB is a few bits wide — one ballot per bit and a count of the set bits below the lane
+            // (no cross-lane round trips; a shuffle scan is six dependent ones)
+            constexpr int kBits = NNB <= 1 ? 1 : (NNB <= 7 ? 3 : 5);
+            uint32_t excl = 0, wave_total = 0;
+#pragma unroll
+            for (int b = 0; b < kBits; ++b) {
+                const unsigned long long m = __ballot((cnt >> b) & 1u);
+                excl += __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)) << b;
+                wave_total += static_cast<uint32_t>(__popcll(m)) << b;
+            }
+            uint32_t* tot = s_scan + (((tile0 - base) / kTile) & 1u) * 4u;
+            if (lane_id() == 0) tot[wave_id()] = wave_total;
+            __syncthreads();
+            const uint32_t t0 = tot[0], t1 = tot[1], t2 = tot[2], t3 = tot[3];
+            const int w = wave_id();
+            off = excl + (w > 0 ? t0 : 0u) + (w > 1 ? t1 : 0u) + (w > 2 ? t2 : 0u);
+            total = t0 + t1 + t2 + t3;
+        }
 #pragma unroll
         for (int n = 0; n < NNB; ++n)
             if (ids[n] >= 0) s_queue[off++] = (threadIdx.x << 24) | static_cast<uint32_t>(ids[n]);
