@@ -163,9 +163,9 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
     const NdtGridDev g = grids[pr.grid];  // by value: the grid parameters live in scalar registers for the whole item
     __syncthreads();  // the previous item's epilogue has read s_red / the staged tables
     if (threadIdx.x < 12) s_T[threadIdx.x] = ev.T[threadIdx.x];
-    if (MODE != 2) {
+    if (MODE == 0) {
         if (threadIdx.x >= 64 && threadIdx.x < 64 + 24) (&s_ja[0][0])[threadIdx.x - 64] = (&ev.j_ang[0][0])[threadIdx.x - 64];
-        if (MODE == 0 && threadIdx.x >= 128 && threadIdx.x < 128 + 45) (&s_ha[0][0])[threadIdx.x - 128] = (&ev.h_ang[0][0])[threadIdx.x - 128];
+        if (threadIdx.x >= 128 && threadIdx.x < 128 + 45) (&s_ha[0][0])[threadIdx.x - 128] = (&ev.h_ang[0][0])[threadIdx.x - 128];
     }
     __syncthreads();
 
@@ -336,6 +336,31 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
                 cnt = 0;  // nothing queued: the pair phase below is the float path's
 #pragma unroll
                 for (int n = 0; n < NNB; ++n) ids[n] = -1;
+            } else if (MODE == 1) {
+                // ---- score + gradient (line-search trials), one lane per POINT ---------------------------------------------------
+                // ~110 instructions per pair: less than the queue machinery around them costs (staging through LDS, the offsets, three
+                // barriers per tile — this variant spent two thirds of a tile there), so the lane walks its own voxels in probe order
+                // although a third of the lanes idle in every step (0 - 7 occupied neighbours, 4.4 on average).  Same per-pair float
+                // terms; the f64 sums run per point instead of per queue slot (the oracle's GPU-order mode follows).
+                nb_mine += cnt;
+                if (cnt) {
+                    float xj[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) xj[r] = fdot3f(ev.j_ang[r][0], p.x, ev.j_ang[r][1], p.y, ev.j_ang[r][2], p.z);
+                    const float J3[3] = {0.0f, xj[0], xj[1]}, J4[3] = {xj[2], xj[3], xj[4]}, J5[3] = {xj[5], xj[6], xj[7]};
+                    const float PH[6][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+                    // (requesting the records of four probes together — two waits per point instead of one per occupied voxel — changed
+                    // nothing: 156 registers, three waves per SIMD, same time)
+#pragma unroll
+                    for (int n = 0; n < NNB; ++n) {
+                        if (ids[n] < 0) continue;
+                        const uint32_t lid = static_cast<uint32_t>(ids[n]);
+                        if (lid >= g.n_leaves) continue;  // cannot happen; keeps a corrupted table entry from faulting the GPU
+                        const NdtLeafRec rec = g.leaves[lid];
+                        pair_float<false>(acc, rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
+                    }
+                }
+                cnt = 0;
             } else if (cnt) {
                 s_xt[0][threadIdx.x] = xt[0]; s_xt[1][threadIdx.x] = xt[1]; s_xt[2][threadIdx.x] = xt[2];
                 // computePointDerivatives, float form: x_j_ang = j_ang * x, x_h_ang = h_ang * x
@@ -347,7 +372,7 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
                 }
             }
         }
-        if (MODE == 2) continue;  // next tile: no LDS staging, no pair queue
+        if (MODE != 0) continue;  // next tile: no LDS staging, no pair queue
 #ifdef NDT_PHASE_CLOCK
         if (MODE == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0) tc_s = wall_clock64(); }
 #endif
@@ -429,7 +454,7 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
         if (k == 0)                vals[n] = acc.score;
         else if (k < 7)            vals[n] = acc.g[k - 1];
         else if (k < kNdtNbIndex)  vals[n] = (MODE == 2 && (k - 7) / 6 > (k - 7) % 6) ? acc.H[((k - 7) % 6) * 6 + (k - 7) / 6] : acc.H[k - 7];  // the f64 pass fills the upper triangle
-        else                       vals[n] = static_cast<double>(MODE == 2 ? nb_mine : nb_total);
+        else                       vals[n] = static_cast<double>(MODE != 0 ? nb_mine : nb_total);
     }
     double total_v;
     int    total_k;

@@ -475,8 +475,8 @@ void Ndt::compute_hessian_impl(double hess[36], const double p[6])
 // ---- diagnostic: the HIP kernels' operation ORDER on the CPU ------------------------------------------------------------------
 // gpu_order_ppt > 0 makes compute_derivatives / compute_hessian add their terms in the order ndt_derivatives_kernel and
 // ndt_reduce_kernel do (mrg_slam_amd/csrc/ndt_derivatives.hip): items of gpu_order_ppt tiles of 256 points; per tile the occupied
-// (point, voxel) pairs queued point by point in probe order and dealt round-robin to 256 lanes, every lane adding its pairs' float
-// terms to f64 accumulators; a 64-lane shuffle tree (offsets 32..1), the four waves as ((w0 + w1) + w2) + w3; the item partials of an
+// (point, voxel) pairs queued point by point in probe order and dealt round-robin to 256 lanes (score + gradient + Hessian) or kept
+// on the lane of their point (score + gradient only), every lane adding its pairs' float terms to f64 accumulators; a 64-lane shuffle tree (offsets 32..1), the four waves as ((w0 + w1) + w2) + w3; the item partials of an
 // evaluation in four interleaved slices, combined the same way.  The f64 Hessian pass is the kernel's per-point factorisation (one lane
 // per point).  With the same per-pair float terms this reproduces the GPU's sums bit for bit (float path; the f64 pass differs where
 // the two C libraries' exp differ in the last bit), so a test can tell summation-order noise from an arithmetic difference.
@@ -554,7 +554,9 @@ double Ndt::compute_derivatives_gpu_order(double grad[6], double hess[36], const
             }
             nb_total += static_cast<long long>(queue.size());
             for (size_t qi = 0; qi < queue.size(); ++qi) {
-                double* a = &acc[(qi % 256) * 48];
+                // score + gradient + Hessian: queue slots dealt round-robin to the 256 lanes; score + gradient only (line-search trials):
+                // the kernel keeps one lane per POINT, which walks its voxels in probe order
+                double* a = &acc[static_cast<size_t>(compute_hessian ? qi % 256 : static_cast<size_t>(queue[qi].first)) * 48];
                 float score_inc, t_g[6], t_h[36];
                 if (!pair_terms_f<true>(pts[queue[qi].first], cells.leaves[queue[qi].second], gauss_d2f, gd1, compute_hessian, &score_inc, t_g, t_h)) continue;
                 for (int c = 0; c < 6; ++c) a[1 + c] += static_cast<double>(t_g[c]);
