@@ -201,7 +201,7 @@ def main():
 
     from mrg_slam_amd import BatchMatcher, Context, NdtHip, distance_filter, prefilter
     from mrg_slam_amd import loop_closure as lc
-    from mrg_slam_amd._lib import NDT_HIP, SEARCH
+    from mrg_slam_amd._lib import NDT_HIP, SEARCH, lib
     from mrg_slam_amd.registration import RESULT_DTYPE, default_params, result_matrix
 
     ctx = Context(local_rank)
@@ -366,6 +366,22 @@ def main():
     total_pairs = world * args.batch * args.steps
     value = total_pairs / elapsed
 
+    # the score + gradient + Hessian variant on its own (round 1 / 2 reported it as the dominant kernel): two extra, UNTIMED steps with one
+    # launch per variant, so that its launches can be told from the others' — listed beside the fused kernel's figures, never `value`
+    alone = None
+    if lib().mrgfe_dbg_set_fused_launch(-1) == 1:
+        lib().mrgfe_dbg_set_fused_launch(0)
+        m0 = np.zeros(3)
+        step()
+        for _ in range(2):
+            step()
+            m0 += bm.kernel_stats(0)
+        lib().mrgfe_dbg_set_fused_launch(1)
+        if m0[1] and m0[0] > 0:
+            alone = {"kernel": "ndt_derivatives_kernel<0,7>", "launches": int(m0[1]), "avg_launch_ms": m0[0] / m0[1], "alg_bytes_per_launch": m0[2] / m0[1],
+                     "achieved_GBps": (m0[2] / 1e9) / (m0[0] / 1e3), "frac": (m0[2] / 1e9) / (m0[0] / 1e3) / HBM_PEAK_GBPS,
+                     "note": "MRGFE_FUSED=0 (one launch per variant), 2 steps outside the timed region"}
+
     shard = None
     if args.shard_steps > 0:
         shard = run_shard(args.shard_steps, 1)
@@ -439,8 +455,6 @@ def main():
     # three evaluation kinds (score + gradient + Hessian, score + gradient, f64 Hessian): its time and launch count are reported
     # under variant 0 by the library, its algorithmic bytes are those of all three kinds.  MRGFE_FUSED=0: ndt_derivatives_kernel<0,7>
     # (score + gradient + Hessian), the other two variants listed beside it.
-    from mrg_slam_amd._lib import lib
-
     fused = bool(lib().mrgfe_dbg_set_fused_launch(-1))
     k_ms, k_launch, k_bytes = per_mode[0]
     if fused:
@@ -499,10 +513,12 @@ def main():
                      "traffic": traffic, "traffic_over_algorithmic": ratio, "valu_busy": valu_busy, "pmc_profile": prof_name,
                      "kernel": kernel_name, "avg_launch_ms": (k_ms / k_launch) if k_launch else None, "launches": int(k_launch),
                      "alg_bytes_per_launch": alg_per_launch,
-                     "byte_model": "per launch: sum over active pairs of N_src*(16 + 7*8) + valid_neighbours*48 (SURVEY.md §8d); `frac` prices these ALGORITHMIC "
-                                   "bytes against the HBM peak as the contract asks; `bound` is what the PMC counters say limits the kernel",
+                     "byte_model": "per launch: sum over the evaluations of all active pairs (every kind: score+gradient+Hessian, score+gradient, f64 Hessian) of "
+                                   "N_src*(16 + 7*8) + valid_neighbours*48 (SURVEY.md §8d); `frac` prices these ALGORITHMIC bytes against the HBM peak as the contract "
+                                   "asks; `bound` is what the PMC counters say limits the kernel (most of these bytes are served by L2 / Infinity Cache: `traffic`)",
                      "alg_bytes_by_evaluation_kind": {"score+gradient+hessian": per_mode[0][2] / max(k_launch, 1), "score+gradient": per_mode[1][2] / max(k_launch, 1),
                                                       "f64_hessian": per_mode[2][2] / max(k_launch, 1)},
+                     "score_gradient_hessian_variant_alone": alone,
                      "variants": variants},
         "cpu_baseline": cpu,
         "parity_vs_oracle": parity,

@@ -22,7 +22,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
-DOMINANT = "ndt_derivatives_kernel<0, 7>"
+DOMINANT = "ndt_derivatives_all_kernel<7>"  # one launch per round: the work items of all three evaluation kinds
 
 
 def short(name):
@@ -43,7 +43,7 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     lines = [f"# rocprofv3 summary {tag} (MI355X, gfx950) — `python3 bench.py --no-cpu`", ""]
     stats = list(csv.DictReader(open(os.path.join(OUT, f"prof_{tag}", f"{tag}_kernel_stats.csv"))))
-    lines += ["## --kernel-trace --stats (all kernels of the run: 2 warm-up + 5 timed steps; the device-controlled rounds launch all three", "derivative variants every round, so the per-kernel averages include launches that find no busy pair and exit in ~4 us)", "",
+    lines += ["## --kernel-trace --stats (all kernels of the run: 2 warm-up + 5 timed steps + 3 untimed steps with one launch per variant, MRGFE_FUSED=0, for the", "per-variant figures; the per-kernel averages include the launches of the last one or two rounds, which find no busy pair and exit in ~4 us)", "",
               "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---:|---:|---:|---:|---:|---:|"]
     for r in stats:
         lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.2f} | "
