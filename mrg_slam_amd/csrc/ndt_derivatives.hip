@@ -51,6 +51,27 @@ struct Accum {
     double H[36];  // row-major, every entry (see ndt_types.h)
 };
 
+// Pointers that come out of a descriptor in memory (NdtPairDev::src, NdtGridDev::lookup / leaves / icov64 / centroid) are generic to the
+// compiler: it emitted FLAT loads for every point, table probe and voxel record — issued to the LDS and the memory pipeline both,
+// counted in lgkmcnt as well as vmcnt.  These helpers name the address space (global), so the loads are global_load_*.
+#define MRGFE_GLOBAL __attribute__((address_space(1)))
+typedef float  gvec4f __attribute__((ext_vector_type(4)));
+typedef double gvec2d __attribute__((ext_vector_type(2)));
+template <class T>
+__device__ __forceinline__ const MRGFE_GLOBAL T* as_global(const T* p) { return (const MRGFE_GLOBAL T*)p; }
+__device__ __forceinline__ float4 load_point(const float4* p)
+{
+    const gvec4f v = *(const MRGFE_GLOBAL gvec4f*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ NdtLeafRec load_leaf(const NdtLeafRec* p)
+{
+    const MRGFE_GLOBAL gvec4f* q = (const MRGFE_GLOBAL gvec4f*)p;  // 48 bytes, 16-byte aligned
+    union { gvec4f v[3]; NdtLeafRec r; } u;
+    u.v[0] = q[0]; u.v[1] = q[1]; u.v[2] = q[2];
+    return u.r;
+}
+
 // float path: updateDerivatives for one (point, voxel) pair
 template <bool HESS>
 __device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, const float xt[3], const float J3[3], const float J4[3], const float J5[3],
@@ -197,7 +218,7 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
 #pragma unroll
         for (int n = 0; n < NNB; ++n) ids[n] = -1;
         if (threadIdx.x < kTile && i < last) {
-            const float4 p = pr.src[i];
+            const float4 p = load_point(pr.src + i);
             float xt[3];
 #ifdef NDT_PHASE_CLOCK
             if (MODE == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (threadIdx.x == 0) tc_p = wall_clock64(); }
@@ -233,7 +254,7 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
             }
             if (g.dense) {
                 // all probes of the point in flight together (a probe-by-probe loop waits for each load in turn)
-                const int32_t* __restrict__ table = static_cast<const int32_t*>(g.lookup);
+                const MRGFE_GLOBAL int32_t* __restrict__ table = as_global(static_cast<const int32_t*>(g.lookup));
                 int32_t v[NNB];
 #pragma unroll
                 for (int n = 0; n < NNB; ++n) v[n] = table[ok[n] ? keys[n] : 0u];
@@ -249,7 +270,7 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
 #pragma unroll
                 for (int n = 0; n < NNB; ++n)
                     if (ids[n] >= 0) {
-                        const float4 c = g.centroid[ids[n]];
+                        const float4 c = load_point(g.centroid + ids[n]);
                         const float  dx = c.x - xt[0], dy = c.y - xt[1], dz = c.z - xt[2];
                         const float  d = dot3f(dx, dx, dy, dy, dz, dz);
                         if (!(d < r2)) ids[n] = -1;
@@ -277,8 +298,8 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
                         if (ids[n] < 0) continue;
                         const uint32_t lid = static_cast<uint32_t>(ids[n]);
                         if (lid >= g.n_leaves) continue;  // cannot happen; keeps a corrupted table entry from faulting the GPU
-                        const double* __restrict__ C = g.icov64 + (size_t)lid * 9;
-                        const double* __restrict__ mean = g.leaves[lid].mean;
+                        const MRGFE_GLOBAL double* __restrict__ C = as_global(g.icov64 + (size_t)lid * 9);
+                        const MRGFE_GLOBAL double* __restrict__ mean = as_global(g.leaves[lid].mean);
                         const double q[3] = {static_cast<double>(xt[0]) - mean[0], static_cast<double>(xt[1]) - mean[1], static_cast<double>(xt[2]) - mean[2]};
                         double v[3];
 #pragma unroll
@@ -356,7 +377,7 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
                         if (ids[n] < 0) continue;
                         const uint32_t lid = static_cast<uint32_t>(ids[n]);
                         if (lid >= g.n_leaves) continue;  // cannot happen; keeps a corrupted table entry from faulting the GPU
-                        const NdtLeafRec rec = g.leaves[lid];
+                        const NdtLeafRec rec = load_leaf(g.leaves + lid);
                         pair_float<false>(acc, rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
                     }
                 }
@@ -413,7 +434,7 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
             const uint32_t entry = s_queue[qi];
             const uint32_t slot = entry >> 24, lid = entry & 0x00FFFFFFu;
             if (lid >= g.n_leaves) continue;  // cannot happen; keeps a corrupted queue entry from faulting the GPU
-            const NdtLeafRec rec = g.leaves[lid];
+            const NdtLeafRec rec = load_leaf(g.leaves + lid);
             const float xt[3] = {s_xt[0][slot], s_xt[1][slot], s_xt[2][slot]};
             float xj[8];
 #pragma unroll
