@@ -7,6 +7,19 @@ namespace mrgfe {
 
 constexpr int kWave = 64;  // CDNA4 wavefront width (hard-coded: MI355X_MICROARCH.md "wave = 64 not 32")
 
+// Pointers that come out of a descriptor in memory or LDS (NdtPairDev::src, NdtGridDev / NnGridDev members, job records) are generic to
+// the compiler, which emits FLAT loads for them — issued to the LDS and the memory pipeline both, counted in lgkmcnt as well as vmcnt.
+// These helpers name the address space (global), so the loads are global_load_*.
+#define MRGFE_GLOBAL __attribute__((address_space(1)))
+typedef float gvec4f __attribute__((ext_vector_type(4)));
+template <class T>
+__device__ __forceinline__ const MRGFE_GLOBAL T* as_global(const T* p) { return (const MRGFE_GLOBAL T*)p; }
+__device__ __forceinline__ float4 load_point(const float4* p)
+{
+    const gvec4f v = *(const MRGFE_GLOBAL gvec4f*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 

@@ -51,19 +51,7 @@ struct Accum {
     double H[36];  // row-major, every entry (see ndt_types.h)
 };
 
-// Pointers that come out of a descriptor in memory (NdtPairDev::src, NdtGridDev::lookup / leaves / icov64 / centroid) are generic to the
-// compiler: it emitted FLAT loads for every point, table probe and voxel record — issued to the LDS and the memory pipeline both,
-// counted in lgkmcnt as well as vmcnt.  These helpers name the address space (global), so the loads are global_load_*.
-#define MRGFE_GLOBAL __attribute__((address_space(1)))
-typedef float  gvec4f __attribute__((ext_vector_type(4)));
-typedef double gvec2d __attribute__((ext_vector_type(2)));
-template <class T>
-__device__ __forceinline__ const MRGFE_GLOBAL T* as_global(const T* p) { return (const MRGFE_GLOBAL T*)p; }
-__device__ __forceinline__ float4 load_point(const float4* p)
-{
-    const gvec4f v = *(const MRGFE_GLOBAL gvec4f*)p;
-    return make_float4(v.x, v.y, v.z, v.w);
-}
+// a voxel record through a global load (dev_utils.h: pointers out of descriptors are generic to the compiler)
 __device__ __forceinline__ NdtLeafRec load_leaf(const NdtLeafRec* p)
 {
     const MRGFE_GLOBAL gvec4f* q = (const MRGFE_GLOBAL gvec4f*)p;  // 48 bytes, 16-byte aligned

@@ -62,11 +62,11 @@ __device__ __forceinline__ void nn_walk_ranges(const NnGridDev& g, const int c[3
                 const uint32_t row = (static_cast<uint32_t>(z) * g.dim[1] + y) * g.dim[0];
                 if (face) {
                     const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.dim[0] - 1);
-                    range(g.cell_start[row + x0], g.cell_start[row + x1 + 1]);
+                    range(as_global(g.cell_start)[row + x0], as_global(g.cell_start)[row + x1 + 1]);
                 } else {
                     const int xa = c[0] - r, xb = c[0] + r;
-                    if (xa >= 0) range(g.cell_start[row + xa], g.cell_start[row + xa + 1]);
-                    if (xb < g.dim[0]) range(g.cell_start[row + xb], g.cell_start[row + xb + 1]);
+                    if (xa >= 0) range(as_global(g.cell_start)[row + xa], as_global(g.cell_start)[row + xa + 1]);
+                    if (xb < g.dim[0]) range(as_global(g.cell_start)[row + xb], as_global(g.cell_start)[row + xb + 1]);
                 }
             }
         }
@@ -80,7 +80,7 @@ __device__ __forceinline__ void nn_walk(const NnGridDev& g, const int c[3], doub
     nn_walk_ranges(
         g, c, margin, max_rings,
         [&](uint32_t b, uint32_t e) {
-            for (uint32_t k = b; k < e; ++k) visit(g.sorted[k]);
+            for (uint32_t k = b; k < e; ++k) visit(load_point(g.sorted + k));
         },
         stop);
 }
@@ -220,7 +220,7 @@ __device__ __forceinline__ bool nn_shell_walk(const unsigned long long* __restri
                 float lb2, ub2;
                 pq.box(E, nx, ny, nz, lb2, ub2);
                 if (lb2 <= lim * kNnPrune) {
-                    word[u] = words[(static_cast<uint32_t>(nz) * dims[1] + ny) * dims[0] + nx];
+                    word[u] = as_global(words)[(static_cast<uint32_t>(nz) * dims[1] + ny) * dims[0] + nx];
                     wlb[u] = word[u] != 0ull ? lb2 : INFINITY;
                 }
             }
@@ -324,9 +324,9 @@ __device__ __forceinline__ void nn_pyramid_walk(const NnGridDev& g, float x, flo
             if (cx - c[0] >= -1 && cx - c[0] <= 1 && cy - c[1] >= -1 && cy - c[1] <= 1 && cz - c[2] >= -1 && cz - c[2] <= 1) continue;  // the block is done
             if (lb2 > lim * kNnPrune) continue;
             const uint32_t at = (static_cast<uint32_t>(cz) * g.dim[1] + cy) * g.dim[0] + cx;
-            const uint32_t kb = g.cell_start[at], ke = g.cell_start[at + 1];
+            const uint32_t kb = as_global(g.cell_start)[at], ke = as_global(g.cell_start)[at + 1];
             for (uint32_t k = kb; k < ke; ++k) {
-                const float4  p = g.sorted[k];
+                const float4  p = load_point(g.sorted + k);
                 const float   d = sqdist3f(p.x, p.y, p.z, x, y, z);
                 const int32_t i = kByPos ? static_cast<int32_t>(k) : __float_as_int(p.w);
                 if (best_i < 0 || d < best_d || (d == best_d && i < best_i)) { best_d = d; best_i = i; }
@@ -349,7 +349,7 @@ __device__ __forceinline__ void nn_pyramid_walk(const NnGridDev& g, float x, flo
             lim = fminf(lim, ub2 * kNnPrune);
             if (lb2 > lim * kNnPrune) continue;
             if (bx - b1[0] >= -done && bx - b1[0] <= done && by - b1[1] >= -done && by - b1[1] <= done && bz - b1[2] >= -done && bz - b1[2] <= done) continue;
-            const unsigned long long w0 = g.occ[(static_cast<uint32_t>(bz) * d1[1] + by) * d1[0] + bx];
+            const unsigned long long w0 = as_global(g.occ)[(static_cast<uint32_t>(bz) * d1[1] + by) * d1[0] + bx];
             cells_open(w0, bx, by, bz);
         }
     };
@@ -377,7 +377,7 @@ __device__ __forceinline__ void nn_pyramid_walk(const NnGridDev& g, float x, flo
             lim = fminf(lim, ub2 * kNnPrune);
             if (lb2 > lim * kNnPrune) continue;
             if (sx - b2[0] >= -kShells && sx - b2[0] <= kShells && sy - b2[1] >= -kShells && sy - b2[1] <= kShells && sz - b2[2] >= -kShells && sz - b2[2] <= kShells) continue;
-            bricks(g.occ1[(static_cast<uint32_t>(sz) * d2[1] + sy) * d2[0] + sx], sx, sy, sz, -1);
+            bricks(as_global(g.occ1)[(static_cast<uint32_t>(sz) * d2[1] + sy) * d2[0] + sx], sx, sy, sz, -1);
         }
         agree();
     });
@@ -417,11 +417,11 @@ __device__ __forceinline__ bool nn_level_search(const NnGridDev& g, float x, flo
     auto scan = [&](uint32_t b, uint32_t e) {
         uint32_t k = b;
         for (; k + 2 <= e; k += 2) {  // two independent loads in flight
-            const float4 p0 = g.sorted[k], p1 = g.sorted[k + 1];
+            const float4 p0 = load_point(g.sorted + k), p1 = load_point(g.sorted + k + 1);
             consider(p0);
             consider(p1);
         }
-        if (k < e) consider(g.sorted[k]);
+        if (k < e) consider(load_point(g.sorted + k));
     };
     auto axis_lb = [&](int a, int d) {  // lower bound on the distance along axis a to a cell d cells away
         if (d == 0) return 0.0f;
@@ -441,8 +441,8 @@ __device__ __forceinline__ bool nn_level_search(const NnGridDev& g, float x, flo
 
     {  // 1. own cell
         const uint32_t at = (static_cast<uint32_t>(c[2]) * g.dim[1] + c[1]) * g.dim[0] + c[0];
-        const uint32_t b = g.cell_start[at], e = g.cell_start[at + 1];
-        for (uint32_t k = b + sub; k < e; k += G) consider(g.sorted[k]);
+        const uint32_t b = as_global(g.cell_start)[at], e = as_global(g.cell_start)[at + 1];
+        for (uint32_t k = b + sub; k < e; k += G) consider(load_point(g.sorted + k));
         nn_group_min<G>(best_d, best_i);
     }
     if (rmax == 0) return true;
@@ -460,10 +460,10 @@ __device__ __forceinline__ bool nn_level_search(const NnGridDev& g, float x, flo
             const bool right = c[0] + 1 < g.dim[0] && lyz + fx1 <= lim;
             const uint32_t row = (static_cast<uint32_t>(zz) * g.dim[1] + yy) * g.dim[0];
             if (j == 4) {  // own row: the own cell is done
-                if (left) scan(g.cell_start[row + c[0] - 1], g.cell_start[row + c[0]]);
-                if (right) scan(g.cell_start[row + c[0] + 1], g.cell_start[row + c[0] + 2]);
+                if (left) scan(as_global(g.cell_start)[row + c[0] - 1], as_global(g.cell_start)[row + c[0]]);
+                if (right) scan(as_global(g.cell_start)[row + c[0] + 1], as_global(g.cell_start)[row + c[0] + 2]);
             } else {
-                scan(g.cell_start[row + (left ? c[0] - 1 : c[0])], g.cell_start[row + (right ? c[0] + 1 : c[0]) + 1]);
+                scan(as_global(g.cell_start)[row + (left ? c[0] - 1 : c[0])], as_global(g.cell_start)[row + (right ? c[0] + 1 : c[0]) + 1]);
             }
         }
         nn_group_min<G>(best_d, best_i);

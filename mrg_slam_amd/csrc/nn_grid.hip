@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void n
         const uint32_t i = i0 + threadIdx.x / kBlockGroup;
         bool           queue = false;
         if (i < i_end) {
-            const float4 p = s_job.src[i];
+            const float4 p = load_point(s_job.src + i);
             float x, y, z;
             transform_point(s_job.T12, p.x, p.y, p.z, x, y, z);
             int32_t bi = -1;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
     const int      sub = threadIdx.x % kFarGroup;
     for (uint32_t k = blockIdx.x * per_blk + threadIdx.x / kFarGroup; k < np; k += gridDim.x * per_blk) {
         const uint32_t i = pend[off + k];
-        const float4   p = s_job.src[i];
+        const float4   p = load_point(s_job.src + i);
         float x, y, z;
         transform_point(s_job.T12, p.x, p.y, p.z, x, y, z);
         const float bound = sqd[off + i];  // what the block gave
