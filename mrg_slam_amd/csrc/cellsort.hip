@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float4* const* 
     for (int k = 0; k < kTile / 256; ++k) {
         uint32_t i = base + k * 256 + threadIdx.x;
         if (i < s.n) {
-            float4 p = pts[i];
+            float4 p = load_point(pts + i);
             if (finite3(p.x, p.y, p.z)) {
                 mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
                 mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);

@@ -261,12 +261,12 @@ __device__ __forceinline__ void gicp_linearize_block(const float4* __restrict__ 
     for (int k = 0; k < 29; ++k) vals[k] = 0.0;
     const uint32_t i = blk * 256u + threadIdx.x;
     if (i < n) {
-        const float4  a = src[i];
-        const int32_t j = corr[i];
+        const float4  a = load_point(src + i);
+        const int32_t j = as_global(corr)[i];
         if (j >= 0) {
             const bool    voxel = tgt == nullptr;  // VGICP: cov_tgt holds the voxel records (mean 3, covariance 6, points 1) and j names a voxel
-            const double* cA = cov_src + size_t(i) * 6;
-            const double* cB = voxel ? cov_tgt + size_t(j) * kVoxRec + 3 : cov_tgt + size_t(j) * 6;
+            const MRGFE_GLOBAL double* cA = as_global(cov_src) + size_t(i) * 6;
+            const MRGFE_GLOBAL double* cB = voxel ? as_global(cov_tgt) + size_t(j) * kVoxRec + 3 : as_global(cov_tgt) + size_t(j) * 6;
             const double A[9] = {cA[0], cA[1], cA[2], cA[1], cA[3], cA[4], cA[2], cA[4], cA[5]};
             const double R[9] = {pose.T[0], pose.T[1], pose.T[2], pose.T[4], pose.T[5], pose.T[6], pose.T[8], pose.T[9], pose.T[10]};
             double RC[9], Rt[9], RCR[9], M[9];
@@ -275,16 +275,16 @@ __device__ __forceinline__ void gicp_linearize_block(const float4* __restrict__ 
             dl_mul3(RC, Rt, RCR);
             RCR[0] += cB[0]; RCR[1] += cB[1]; RCR[2] += cB[2]; RCR[3] += cB[1]; RCR[4] += cB[3]; RCR[5] += cB[4]; RCR[6] += cB[2]; RCR[7] += cB[4]; RCR[8] += cB[5];
             dl_inv3(RCR, M);
-            double* mo = mahal + size_t(i) * 9;
+            MRGFE_GLOBAL double* mo = (MRGFE_GLOBAL double*)(mahal + size_t(i) * 9);
 #pragma unroll
             for (int t = 0; t < 9; ++t) mo[t] = M[t];
             double mB[3], w = 1.0;
             if (voxel) {
-                const double* v = cov_tgt + size_t(j) * kVoxRec;
+                const MRGFE_GLOBAL double* v = as_global(cov_tgt) + size_t(j) * kVoxRec;
                 mB[0] = v[0]; mB[1] = v[1]; mB[2] = v[2];
                 w = sqrt(v[9]);
             } else {
-                const float4 b = tgt[j];
+                const float4 b = load_point(tgt + j);
                 mB[0] = b.x; mB[1] = b.y; mB[2] = b.z;
             }
             const double mA[3] = {a.x, a.y, a.z};
@@ -355,19 +355,19 @@ __device__ __forceinline__ void gicp_error_block(const float4* __restrict__ src,
     for (int k = 0; k < 29; ++k) vals[k] = 0.0;
     const uint32_t i = blk * 256u + threadIdx.x;
     if (i < n) {
-        const int32_t j = corr[i];
+        const int32_t j = as_global(corr)[i];
         if (j >= 0) {
-            const float4  a = src[i];
+            const float4  a = load_point(src + i);
             double mB[3], w = 1.0;
             if (vox) {
-                const double* v = vox + size_t(j) * kVoxRec;
+                const MRGFE_GLOBAL double* v = as_global(vox) + size_t(j) * kVoxRec;
                 mB[0] = v[0]; mB[1] = v[1]; mB[2] = v[2];
                 w = sqrt(v[9]);
             } else {
-                const float4 b = tgt[j];
+                const float4 b = load_point(tgt + j);
                 mB[0] = b.x; mB[1] = b.y; mB[2] = b.z;
             }
-            const double* M = mahal + size_t(i) * 9;
+            const MRGFE_GLOBAL double* M = as_global(mahal) + size_t(i) * 9;
             const double  mA[3] = {a.x, a.y, a.z};
             double tA[3];
 #pragma unroll
@@ -454,13 +454,13 @@ __global__ __launch_bounds__(256) void vox_corr_batch_kernel(const GicpPairDev* 
     if (i >= pr.n) return;
     const VoxGridDev g = vgrids[pr.target];
     const double*    T = evals[pi].pose.T;
-    const float4     a = pr.src[i];
+    const float4     a = load_point(pr.src + i);
     const double     mA[3] = {a.x, a.y, a.z};
     double tA[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) tA[r] = T[r * 4 + 0] * mA[0] + T[r * 4 + 1] * mA[1] + T[r * 4 + 2] * mA[2] + T[r * 4 + 3];
     const uint32_t c = vox_cell(g, tA[0], tA[1], tA[2]);
-    pr.corr[i] = (c < g.n_cells && g.vox[size_t(c) * kVoxRec + 9] > 0.0) ? static_cast<int32_t>(c) : -1;
+    ((MRGFE_GLOBAL int32_t*)pr.corr)[i] = (c < g.n_cells && as_global(g.vox)[size_t(c) * kVoxRec + 9] > 0.0) ? static_cast<int32_t>(c) : -1;
 }
 
 __global__ __launch_bounds__(256) void gicp_linearize_batch_kernel(const GicpPairDev* __restrict__ pairs, const GicpEvalDev* __restrict__ evals, double* __restrict__ partials)

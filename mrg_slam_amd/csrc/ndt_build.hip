@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void ndt_cellkey_kernel(const float4* const* _
     for (int k = 0; k < kTile / 256; ++k) {
         const uint32_t i = base + k * 256 + threadIdx.x;
         if (i < s.n) {
-            const float4 p = pts[i];
+            const float4 p = load_point(pts + i);
             uint32_t key = g.n_cells;  // non-finite points sort behind every voxel
             if (finite3(p.x, p.y, p.z)) {
                 const int ijk0 = static_cast<int>(floorf(p.x * g.inv_leaf) - static_cast<float>(g.min_b[0]));
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64, 6) void ndt_leaf_sums_kernel(const float4* cons
 #pragma unroll
                 for (int d = 0; d < kAhead; ++d) id[d] = order[min(base4 + d * kWave + lane, e - 1)];
 #pragma unroll
-                for (int d = 0; d < kAhead; ++d) pre[d] = pts[id[d]];
+                for (int d = 0; d < kAhead; ++d) pre[d] = load_point(pts + id[d]);
             };
             fetch4(b);
             for (uint32_t base4 = b; base4 < e; base4 += kAhead * kWave) {
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64, 6) void ndt_leaf_sums_kernel(const float4* cons
             id[q] = order[at + (static_cast<uint32_t>(lane) < cnt[q] ? lane : 0)];
         }
 #pragma unroll
-        for (int q = 0; q < kLeafGroups; ++q) pre[q] = pts[id[q]];
+        for (int q = 0; q < kLeafGroups; ++q) pre[q] = load_point(pts + id[q]);
 #pragma unroll
         for (int q = 0; q < kLeafGroups; ++q)
             if (static_cast<uint32_t>(lane) >= cnt[q]) pre[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
