@@ -323,10 +323,12 @@ int  mrgfe_batch_set_guess(mrgfe_batch* b, int pair_index, const float guess[16]
 int  mrgfe_batch_build_targets(mrgfe_batch* b);
 int  mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_result* results /* n_pairs */);
 int  mrgfe_batch_num_pairs(const mrgfe_batch* b);
-/* Accounting of the NDT derivative kernel in the last mrgfe_batch_align / mrgfe_reg_align, per kernel variant
- * `mode` (0: score+gradient+Hessian ndt_derivatives_kernel<0,*>, 1: score+gradient <1,*>, 2: f64 Hessian <2,*>; -1: all):
- * device time in ms from HIP events recorded around each launch on the context stream, launch count, and the
- * algorithmic bytes of SURVEY.md §8(d): sum over launches and active pairs of N_src*(16 + probes*8) + valid_neighbours*48.
+/* Accounting of the NDT derivative kernel in the last mrgfe_batch_align / mrgfe_reg_align, per kind of evaluation
+ * `mode` (0: score+gradient+Hessian, 1: score+gradient, 2: f64 Hessian; -1: all): device time in ms from HIP events recorded
+ * around each launch on the context stream, launch count, and the algorithmic bytes of SURVEY.md §8(d): sum over launches and
+ * active pairs of N_src*(16 + probes*8) + valid_neighbours*48.  With the default ONE launch per round for all kinds
+ * (ndt_derivatives_all_kernel, see mrgfe_dbg_set_fused_launch) time and launch count are reported under mode 0 (and -1), the bytes
+ * still per kind; with one launch per kind (ndt_derivatives_kernel<0|1|2,*>) everything is per kind.
  * For GICP_HIP registrations `mode` is ignored and the linearize kernel is reported. */
 int  mrgfe_batch_kernel_stats(const mrgfe_batch* b, int mode, double* deriv_ms, int64_t* deriv_launches, double* deriv_alg_bytes);
 int  mrgfe_reg_kernel_stats(const mrgfe_reg* reg, int mode, double* deriv_ms, int64_t* deriv_launches, double* deriv_alg_bytes);
@@ -351,7 +353,7 @@ int mrgfe_dbg_minmax(mrgfe_ctx* ctx, const float* xyzi, size_t n, float min3[3],
  * tests/test_gpu_control.py holds the two against each other. */
 int mrgfe_dbg_set_host_control(int mode);
 /* How the derivative evaluations of a round are launched during the following alignments of this process: 1 = ONE launch for all
- * three kernel variants, their work items interleaved (default; the environment variable MRGFE_FUSED sets the initial value),
+ * three kernel variants, their work items walked kind after kind (default; the environment variable MRGFE_FUSED sets the initial value),
  * 0 = one launch per variant.  Any other value only asks.  Returns the setting in effect.  Same sums either way: an item's partial
  * record does not depend on the launch it is computed in (tests/test_gpu_control.py). */
 int mrgfe_dbg_set_fused_launch(int mode);
