@@ -129,10 +129,22 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const uint32_t* __restrict
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * kTile;
+    // neighbours in a scan fall into the same voxel: a wavefront's keys share a handful of digits, and 64 LDS atomics on one
+    // counter are served one after the other.  The lanes of a wavefront that hold the same digit are matched by ballots (as in the
+    // scatter kernel) and the first of them adds their number: one atomic per distinct digit.  All eight loads of the tile first.
+    uint32_t key[kTile / 256];
 #pragma unroll
     for (int k = 0; k < kTile / 256; ++k) {
-        uint32_t i = base + k * 256 + threadIdx.x;
-        if (i < s.n) atomicAdd(&h[(keys[s.off + i] >> shift) & 255u], 1u);
+        const uint32_t i = base + k * 256 + threadIdx.x;
+        key[k] = i < s.n ? keys[s.off + i] : 0u;
+    }
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 0; k < kTile / 256; ++k) {
+        const bool     valid = base + k * 256 + threadIdx.x < s.n;
+        const uint32_t d = (key[k] >> shift) & 255u;
+        const uint64_t m = wave_match_digit8(d, __ballot(valid));
+        if (valid && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&h[d], static_cast<uint32_t>(__popcll(m)));
     }
     __syncthreads();
     hist[(size_t)(s.blk_off + blockIdx.x) * 256 + threadIdx.x] = h[threadIdx.x];
