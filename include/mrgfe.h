@@ -338,6 +338,10 @@ int  mrgfe_batch_pair_counts(const mrgfe_batch* b, int mode, double* points, dou
 
 /* ---- diagnostic entry points for the primitive tests (tests/test_gpu_primitives.py) --------------------------- */
 int mrgfe_dbg_sort_pairs(mrgfe_ctx* ctx, const uint32_t* keys, const uint32_t* vals, size_t n, int key_bits, uint32_t* out_keys, uint32_t* out_vals);
+/* The wave reduction of the derivative kernels' epilogue (csrc/dev_utils.h): in = cases x 64 lanes x n_vals doubles (n_vals 44, 37 or 1);
+ * out_fold[cases][n_vals] from wave_sum_fold (n_vals values per lane folded in six steps), out_plain from n_vals separate wave_sum
+ * calls.  Same summation tree, so the two must agree bit for bit (tests/test_gpu_primitives.py). */
+int mrgfe_dbg_wave_sums(mrgfe_ctx* ctx, int n_vals, const double* in, int cases, double* out_fold, double* out_plain);
 int mrgfe_dbg_exclusive_scan(mrgfe_ctx* ctx, const uint32_t* in, size_t n, uint32_t* out, uint32_t* total);
 int mrgfe_dbg_minmax(mrgfe_ctx* ctx, const float* xyzi, size_t n, float min3[3], float max3[3], uint32_t* n_finite);
 

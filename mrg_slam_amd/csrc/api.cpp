@@ -1191,6 +1191,22 @@ int mrgfe_dbg_sort_pairs(mrgfe_ctx* ctx, const uint32_t* keys, const uint32_t* v
     return MRGFE_OK;
 }
 
+int mrgfe_dbg_wave_sums(mrgfe_ctx* ctx, int n_vals, const double* in, int cases, double* out_fold, double* out_plain)
+{
+    if (!ctx || !in || !out_fold || !out_plain || cases < 0) { set_error("mrgfe_dbg_wave_sums: bad argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);
+    MRGFE_TRY(ctx->bind());
+    const size_t n_in = size_t(cases) * 64 * n_vals, n_out = size_t(cases) * n_vals;
+    DevBuf &di = ctx->scratch[0], &df = ctx->scratch[1], &dp = ctx->scratch[2];
+    MRGFE_TRY(di.ensure(std::max<size_t>(n_in, 1) * 8)); MRGFE_TRY(df.ensure(std::max<size_t>(n_out, 1) * 8)); MRGFE_TRY(dp.ensure(std::max<size_t>(n_out, 1) * 8));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(di.p, in, n_in * 8, hipMemcpyHostToDevice, ctx->stream));
+    MRGFE_TRY(wave_fold_check_device(ctx, n_vals, di.as<double>(), cases, df.as<double>(), dp.as<double>()));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(out_fold, df.p, n_out * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(out_plain, dp.p, n_out * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MRGFE_OK;
+}
+
 int mrgfe_dbg_exclusive_scan(mrgfe_ctx* ctx, const uint32_t* in, size_t n, uint32_t* out, uint32_t* total)
 {
     if (!ctx || !total || (n && (!in || !out))) { set_error("mrgfe_dbg_exclusive_scan: NULL argument"); return MRGFE_ERR_INVALID; }

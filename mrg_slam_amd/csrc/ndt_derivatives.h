@@ -22,6 +22,8 @@ int ndt_launch_reduce(mrgfe_ctx* ctx, uint32_t P, const NdtPairDev* d_pairs, Ndt
                       NdtCtlState* d_states);
 // diagnostic: ctl::pose_to_matrix / angle_tables / svd_solve6 for n cases of 48 doubles (p[6], A[36], b[6]) on the device
 int ndt_ctl_math_device(mrgfe_ctx* ctx, const double* d_in, int n, float* d_M, double* d_tables, double* d_x);
+// diagnostic: n_vals (44, 37 or 1) doubles per lane and wavefront, summed by wave_sum_fold and by wave_sum (dev_utils.h)
+int wave_fold_check_device(mrgfe_ctx* ctx, int n_vals, const double* d_in, int cases, double* d_fold, double* d_plain);
 int ndt_ctl_svd_wave_device(mrgfe_ctx* ctx, const double* d_in, int n, double* d_x);  // the wavefront form of the solve, one case per workgroup
 // diagnostic builds (-DNDT_PHASE_CLOCK): prints the phase clocks of the derivative kernel to stderr; a no-op otherwise
 void ndt_phase_dump();

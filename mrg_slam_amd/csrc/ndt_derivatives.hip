@@ -754,6 +754,37 @@ __global__ __launch_bounds__(64) void ndt_ctl_svd_wave_kernel(const double* __re
     if (threadIdx.x < 6) x[size_t(blockIdx.x) * 6 + threadIdx.x] = s_x[threadIdx.x];
 }
 
+// ---- diagnostic: the folded wave reduction against the plain one (tests/test_gpu_primitives.py) -----------------------------------
+// in: cases x 64 lanes x N doubles; out_fold / out_plain: cases x N sums (wave_sum_fold hands every lane one total; wave_sum lane 0 all)
+template <int N>
+__global__ __launch_bounds__(64) void wave_fold_check_kernel(const double* __restrict__ in, double* __restrict__ out_fold, double* __restrict__ out_plain)
+{
+    double v[N];
+    int    key[N];
+    const double* mine = in + (size_t(blockIdx.x) * 64 + threadIdx.x) * N;
+#pragma unroll
+    for (int n = 0; n < N; ++n) { v[n] = mine[n]; key[n] = n; }
+    double tv;
+    int    tk;
+    wave_sum_fold<N, 32>(v, key, tv, tk);
+    out_fold[size_t(blockIdx.x) * N + tk] = tv;  // lanes that hold the same sum write the same double
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const double r = wave_sum(v[n]);
+        if (threadIdx.x == 0) out_plain[size_t(blockIdx.x) * N + n] = r;
+    }
+}
+int wave_fold_check_device(mrgfe_ctx* ctx, int n_vals, const double* d_in, int cases, double* d_fold, double* d_plain)
+{
+    if (cases <= 0) return MRGFE_OK;
+    if (n_vals == 44)      hipLaunchKernelGGL((wave_fold_check_kernel<44>), dim3(cases), dim3(64), 0, ctx->stream, d_in, d_fold, d_plain);
+    else if (n_vals == 37) hipLaunchKernelGGL((wave_fold_check_kernel<37>), dim3(cases), dim3(64), 0, ctx->stream, d_in, d_fold, d_plain);
+    else if (n_vals == 1)  hipLaunchKernelGGL((wave_fold_check_kernel<1>), dim3(cases), dim3(64), 0, ctx->stream, d_in, d_fold, d_plain);
+    else { set_error("wave_fold_check: 44, 37 or 1 values per lane"); return MRGFE_ERR_INVALID; }
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
 int ndt_ctl_math_device(mrgfe_ctx* ctx, const double* d_in, int n, float* d_M, double* d_tables, double* d_x)
 {
     if (n <= 0) return MRGFE_OK;

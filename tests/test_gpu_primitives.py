@@ -66,3 +66,30 @@ def test_bounding_box_skips_non_finite_points(ctx, n):
     assert cnt.value == fin.sum()
     np.testing.assert_array_equal(mn, c[fin, :3].min(0))
     np.testing.assert_array_equal(mx, c[fin, :3].max(0))
+
+
+@pytest.mark.parametrize("n_vals", [44, 37, 1])
+def test_folded_wave_reduction_equals_the_plain_one(n_vals):
+    """wave_sum_fold (the derivative kernels' epilogue: N values per lane folded in six shuffle steps, N / 2 values moved per step)
+    adds every value in wave_sum's tree — (lane i) + (lane i + 32), + 16, ... — so its totals are the same doubles as N separate
+    wave_sum calls, whatever the magnitudes; and both equal that tree evaluated in numpy."""
+    from mrg_slam_amd import Context
+    from mrg_slam_amd._lib import check, lib
+
+    ctx = Context(0)
+    rng = np.random.default_rng(5)
+    cases = 64
+    x = rng.normal(0, 1, (cases, 64, n_vals)) * 10.0 ** rng.integers(-12, 12, (cases, 64, n_vals))
+    x[0] = 0.0
+    x[1, ::2] *= -1.0
+    x = np.ascontiguousarray(x)
+    fold, plain = np.empty((cases, n_vals)), np.empty((cases, n_vals))
+    dp = C.POINTER(C.c_double)
+    check(lib().mrgfe_dbg_wave_sums(ctx._h, n_vals, x.ctypes.data_as(dp), cases, fold.ctypes.data_as(dp), plain.ctypes.data_as(dp)))
+    assert np.array_equal(fold, plain)
+    v = x.copy()
+    off = 32
+    while off:
+        v[:, :off] = v[:, :off] + v[:, off:2 * off]
+        off //= 2
+    assert np.array_equal(plain, v[:, 0])
