@@ -116,7 +116,10 @@ __device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, co
                 // (a hand-laid packed-f32 form of this function — R^3 vectors as (xy pair, z), Hessian columns (0,1) and (4,5) as pairs,
                 // scalars broadcast through op_sel — brings the pair loop from 358 to 334 VALU instructions (208 -> 83 scalar + 76 packed
                 // f32 operations, 27 moves) but wants 205 VGPRs; under the 168 of three waves per SIMD the allocator rotates the f64
-                // accumulators through 99 extra v_mov_b64 per pair.  Not kept.)
+                // accumulators through 99 extra v_mov_b64 per pair.  Not kept.  Nor was, at 0.95 VALU busy in the second half of round 2,
+                // packing only the last three operations of an entry — fma, + jtcj, * e — on column pairs (v_pk_fma / add / mul_f32, the rest
+                // scalar, -fno-slp-vectorize): 54 packed for 108 scalar operations, bit-identical, but 21 more moves and 16 more spill
+                // accesses; 10.5 -> 11.25 ms per 256-pair step.)
                 qch = fdot3f(qC[0], PH[ph][0], qC[1], PH[ph][1], qC[2], PH[ph][2]);
             }
             const float t0 = -gauss_d2f * qCJ[i];
