@@ -301,7 +301,8 @@ def main():
                 "projected_for_gpus": fake_world or None,
                 "fitness_max_range": "inf", "converged": int(full["converged"].sum()), "matched_keyframes": int(sum(b[0] is not None for b in best.values())),
                 "median_translation_error_vs_truth_m": float(np.median(err)), "mean_iterations": float(full["iterations"][have].mean()),
-                "mean_points_per_scan": float(np.mean([len(s) for s in l_host])), "records_sha256_16": digest, "per_step_ms": [round(v, 2) for v in step_ms]}
+                "mean_points_per_scan": float(np.mean([len(s) for s in l_host])), "records_sha256_16": digest, "per_step_ms": [round(v, 2) for v in step_ms],
+                "fitness_passes_last_step": ctx.fitness_stats()}
 
     if args.mode == "shard":
         r = run_shard(args.steps, args.warmup)

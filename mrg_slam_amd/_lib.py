@@ -98,6 +98,7 @@ SIGNATURES = {
     "mrgfe_ctx_destroy": (None, [_vp]),
     "mrgfe_ctx_synchronize": (C.c_int, [_vp]),
     "mrgfe_ctx_stream": (_vp, [_vp]),
+    "mrgfe_ctx_fitness_stats": (C.c_int, [_vp, _dp]),
     "mrgfe_ingest_pointcloud2": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, _fp, _vp]),
     "mrgfe_reg_default_params": (None, [C.c_int, C.POINTER(RegParams)]),
     "mrgfe_reg_create": (C.c_int, [_vp, C.POINTER(RegParams), C.POINTER(_vp)]),
@@ -173,6 +174,7 @@ SIGNATURES = {
     "mrgfe_dbg_minmax": (C.c_int, [_vp, _fp, C.c_size_t, _fp, _fp, _u32p]),
     "mrgfe_dbg_set_host_control": (C.c_int, [C.c_int]),
     "mrgfe_dbg_set_fused_launch": (C.c_int, [C.c_int]),
+    "mrgfe_dbg_set_fit_shell": (C.c_int, [C.c_int]),
     "mrgfe_batch_rounds": (C.c_int, [_vp]),
     "mrgfe_dbg_sincosf": (None, [_fp, C.c_size_t, _fp, _fp]),
     "mrgfe_dbg_ctl_math": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _fp, _dp, _dp]),
@@ -242,6 +244,13 @@ class Context:
 
     def synchronize(self):
         check(lib().mrgfe_ctx_synchronize(self._h))
+
+    def fitness_stats(self) -> dict:
+        """What the last getFitnessScore pass on this context did (``mrgfe_ctx_fitness_stats``)."""
+        v = (C.c_double * 10)()
+        check(lib().mrgfe_ctx_fitness_stats(self._h, v))
+        keys = ("ms_block", "ms_shell", "ms_far", "queries", "queued", "queued_far", "words", "cells", "points", "calls")
+        return dict(zip(keys, [float(x) for x in v]))
 
     def close(self):
         if getattr(self, "_h", None):

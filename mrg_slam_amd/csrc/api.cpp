@@ -111,6 +111,7 @@ struct mrgfe_batch {
     };
     std::unordered_map<uint64_t, Keyframe*> store;
     std::vector<uint64_t> pair_key;  // per pair; 0: not from the store
+    hipEvent_t uploads_done = nullptr;  // recorded on ctx->stream before helper streams read the batch's clouds (upload_cloud is stream-ordered only)
     uint64_t epoch = 1, tick = 0;
     size_t   store_cap = size_t(16384) << 20;
 };
@@ -849,6 +850,7 @@ void mrgfe_batch_destroy(mrgfe_batch* b)
         (void)b->ctx->bind();
         for (auto& g : b->fit_grids) g.release();
         for (mrgfe_ctx* fc : b->fit_ctxs) mrgfe_ctx_destroy(fc);
+        if (b->uploads_done) (void)hipEventDestroy(b->uploads_done);
         for (auto& gp : b->gicp_pairs) { gp.cov.release(); gp.corr.release(); gp.mahal.release(); }
         delete b->gicp_batch;
         for (auto* g : b->gicp) delete g;
@@ -1090,12 +1092,18 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
                 if (mrgfe_ctx_create(b->ctx->device, &fc) != MRGFE_OK) return MRGFE_ERR_HIP;
                 b->fit_ctxs.push_back(fc);
             }
+            // the target clouds reach the device by asynchronous copies (and gathers) on the batch's stream: the helper streams
+            // must not read them before those have finished
+            MRGFE_TRY(b->ctx->bind());
+            if (!b->uploads_done) MRGFE_HIP_CHECK(hipEventCreateWithFlags(&b->uploads_done, hipEventDisableTiming));
+            MRGFE_HIP_CHECK(hipEventRecord(b->uploads_done, b->ctx->stream));
             for (size_t w = 0; w < n_builders; ++w)
                 builders.emplace_back([b, &e, &todo, w, n_builders, &build_status, &build_error, &build_mu] {
                     mrgfe_ctx* fc = b->fit_ctxs[w];
                     auto fail = [&](int st, const std::string& why) { std::lock_guard<std::mutex> g(build_mu); if (build_status == MRGFE_OK) { build_status = st; build_error = why; } };
                     std::lock_guard<std::recursive_mutex> lock(fc->mu);
                     if (fc->bind() != MRGFE_OK) { fail(MRGFE_ERR_HIP, mrgfe_last_error()); return; }
+                    if (hipStreamWaitEvent(fc->stream, b->uploads_done, 0) != hipSuccess) { fail(MRGFE_ERR_HIP, "helper stream could not wait for the uploads"); return; }
                     for (size_t k = w; k < todo.size(); k += n_builders) {
                         const int t = todo[k];
                         const NdtTargetInfo& T = e.target(t);
@@ -1266,6 +1274,7 @@ int mrgfe_dbg_set_host_control(int mode)
     return MRGFE_OK;
 }
 int mrgfe_dbg_set_fused_launch(int mode) { return ndt_set_fused_launch(mode); }
+int mrgfe_dbg_set_fit_shell(int mode) { return nn_set_fit_shell(mode); }
 void mrgfe_dbg_sincosf(const float* x, size_t n, float* sin_out, float* cos_out)
 {
     for (size_t i = 0; i < n; ++i) { sin_out[i] = ctl::sin_f(x[i]); cos_out[i] = ctl::cos_f(x[i]); }

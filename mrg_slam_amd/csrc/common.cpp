@@ -313,6 +313,7 @@ void mrgfe_ctx_destroy(mrgfe_ctx* ctx)
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (auto& pr : ctx->ev_mode) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->ev_fit) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -326,5 +327,15 @@ int mrgfe_ctx_synchronize(mrgfe_ctx* ctx)
 }
 
 void* mrgfe_ctx_stream(mrgfe_ctx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
+
+int mrgfe_ctx_fitness_stats(mrgfe_ctx* ctx, double out[10])
+{
+    if (!ctx || !out) { mrgfe::set_error("mrgfe_ctx_fitness_stats: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);
+    const mrgfe::FitStats& f = ctx->fit_stats;
+    const double v[10] = {f.ms_block, f.ms_shell, f.ms_far, double(f.queries), double(f.queued), double(f.queued_far), double(f.words), double(f.cells), double(f.points), double(f.calls)};
+    std::memcpy(out, v, sizeof(v));
+    return MRGFE_OK;
+}
 
 }  // extern "C"

@@ -79,6 +79,16 @@ class NnGrid;
 void ctx_tmp_grid_free(mrgfe_ctx* ctx);  // nn_grid.hip
 }
 
+namespace mrgfe {
+// what the last nn_fitness_batch on a context did (getFitnessScore passes): HIP-event times of its passes and the walk's counters
+struct FitStats {
+    double   ms_block = 0, ms_shell = 0, ms_far = 0;  // block pass / brick-shell pass / remaining far walk
+    uint64_t queries = 0, queued = 0, queued_far = 0; // all queries / not settled by the 3x3x3 block / not settled within two brick shells
+    uint64_t words = 0, cells = 0, points = 0;        // brick-shell pass: occupancy words fetched, cells opened, candidate points measured (MRGFE_FIT_STATS=1)
+    uint64_t calls = 0;
+};
+}  // namespace mrgfe
+
 struct mrgfe_ctx {
     int          device = 0;
     hipStream_t  stream = nullptr;
@@ -91,6 +101,8 @@ struct mrgfe_ctx {
     hipEvent_t   up_ev[2] = {nullptr, nullptr};
     bool         up_busy[2] = {false, false};
     int          up_next = 0;
+    hipEvent_t   ev_fit[4] = {nullptr, nullptr, nullptr, nullptr};  // around the passes of nn_fitness_batch
+    mrgfe::FitStats fit_stats;                  // of the last nn_fitness_batch on this context
     int          cu_count = 256;
     mrgfe::NnGrid* tmp_grid = nullptr;          // reusable exact-NN grid of the stateless filter / fitness calls (nn_grid.hip)
     std::recursive_mutex mu;                    // serialises API calls that share this context's stream / workspaces

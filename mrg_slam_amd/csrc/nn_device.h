@@ -127,6 +127,7 @@ struct NnPyramidQuery {
     }
 };
 constexpr float kNnPrune = 1.0f + 2e-5f;
+constexpr int   kNnBrickShells = 2;  // shells of nodes walked on a pyramid level before the next coarser one takes over
 
 template <int G>
 __device__ __forceinline__ float nn_group_fmin(float v)
@@ -292,7 +293,8 @@ __device__ __forceinline__ unsigned long long nn_deal_mask(int G, int sub)
 // kByPos: (best_i, best_d) name the candidate by its position in g.sorted instead of its original index (ties then go to
 // the lowest position; callers that only want the distance, or the point itself, save the index indirection).
 // `bound`: a squared distance already known to be attained by some point (INFINITY: none) that has no (best_i, best_d).
-template <int G, bool kByPos = false>
+// kSkipBricks: the caller has already searched the bricks within kShells of the query's (nn_fit_shell_kernel): start at the super-bricks.
+template <int G, bool kByPos = false, bool kSkipBricks = false>
 __device__ __forceinline__ void nn_pyramid_walk(const NnGridDev& g, float x, float y, float z, const int c[3], int sub, double max_sq, int32_t& best_i, float& best_d,
                                                 float bound = INFINITY)
 {
@@ -305,7 +307,7 @@ __device__ __forceinline__ void nn_pyramid_walk(const NnGridDev& g, float x, flo
     float lim = max_sq >= 3.0e38 ? INFINITY : static_cast<float>(max_sq) * (1.0f + 1e-6f);
     lim = fminf(lim, bound);
     if (best_i >= 0) lim = fminf(lim, best_d);
-    constexpr int kShells = 2;  // shells walked on a level before the next coarser one takes over
+    constexpr int kShells = kNnBrickShells;
     const unsigned long long deal = nn_deal_mask(G, sub);
     const int b1[3] = {c[0] >> 2, c[1] >> 2, c[2] >> 2}, b2[3] = {c[0] >> 4, c[1] >> 4, c[2] >> 4}, b3[3] = {c[0] >> 6, c[1] >> 6, c[2] >> 6};
     const int d1[3] = {g.bdim[0], g.bdim[1], g.bdim[2]};
@@ -355,7 +357,7 @@ __device__ __forceinline__ void nn_pyramid_walk(const NnGridDev& g, float x, flo
     };
 
     // A. bricks
-    if (nn_shell_walk<G, true>(g.occ, d1, b1, E1, pq, 0, kShells, sub, lim, [&](unsigned long long wb, int bx, int by, int bz) {
+    if (!kSkipBricks && nn_shell_walk<G, true>(g.occ, d1, b1, E1, pq, 0, kShells, sub, lim, [&](unsigned long long wb, int bx, int by, int bz) {
             cells_open(wb & deal, bx, by, bz);
             agree();
         }))
@@ -490,14 +492,14 @@ __device__ __forceinline__ void nn_nearest_group(const NnGrid2Dev& g, float x, f
 // block gave (INFINITY: none) or any other distance known to be attained; on return best_pos >= 0 names the position in
 // level[0].sorted of the nearest point found outside the block with its squared distance best_d, if one is within the
 // bound; the answer is the smaller of bound and best_d.
-template <int G>
+template <int G, bool kSkipBricks = false>
 __device__ __forceinline__ void nn_far_search(const NnGrid2Dev& g, float x, float y, float z, int sub, double max_sq, float bound, int32_t& best_pos, float& best_d)
 {
     best_pos = -1;
     best_d = INFINITY;
     int c[3];
     nn_cell_of(g.level[0], x, y, z, c);
-    nn_pyramid_walk<G, true>(g.level[0], x, y, z, c, sub, max_sq, best_pos, best_d, bound);
+    nn_pyramid_walk<G, true, kSkipBricks>(g.level[0], x, y, z, c, sub, max_sq, best_pos, best_d, bound);
 }
 
 }  // namespace mrgfe

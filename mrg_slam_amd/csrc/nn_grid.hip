@@ -3,6 +3,7 @@
 // Memory behaviour: the query kernels read one query (16 B, coalesced) and then a handful of contiguous candidate
 // ranges (16 B per candidate) out of a cloud that was reordered cell-major at build time, so neighbouring lanes —
 // which hold spatially neighbouring queries for a LiDAR scan — hit the same cache lines.  HBM/L2 bound, no MFMA.
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -374,12 +375,271 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void n
     flush();
 }
 
+// ---- far pass, first part: the bricks within two shells of the query's, as flat work items ----------------------------
+// A queued query's walk over the 5 x 5 x 5 bricks around it is a nest of data-dependent loops (which words are non-empty, which of
+// their cells are occupied, how many points those hold): run one query per lane (or lane pair) a wavefront executes the union of
+// 32 different walks — ~15 000 VALU instructions per wavefront in round 2's nn_fit_far_kernel, of which the distance evaluations
+// themselves are a few per cent.  Here a workgroup takes a tile of 64 queued queries and turns every level of the nest into a list
+// of equal work items in LDS:
+//   phase 1  item = (query, brick node): lane = query, the node is uniform over the wavefront (its offset is scalar); lower bound of
+//            the node's box against the query's `lim`, occupancy word fetched; non-empty ones appended to the brick list;
+//   phase 2  item = brick list entry: the lane walks the set bits of the word: an occupied cell pulls `lim` in through its far corner
+//            (LDS atomic min, shared by all lanes working for that query) and is appended to the cell list if its near corner is
+//            inside `lim`;
+//   phase 3  item = cell list entry: two table reads, the cell's points measured, minimum into the query's best distance / `lim`.
+// `lim` (squared radius that can still matter) only ever shrinks and is always an upper bound of the answer, so the order in which
+// the items run changes how much is pruned, never the result: the exact nearest distance, as before.  Pass 0 covers the query's
+// brick and shell 1 (27 nodes); queries whose `lim` still reaches beyond them take shell 2 in four more passes (its 98 nodes nearest
+// class first: faces, edges, corners, as nn_small_shell_pos lists them); what is still open then (nothing within ~1 m: a fifth of the
+// queued queries of a loop-closure candidate) goes to a second queue for nn_fit_far_kernel, which starts at the super-bricks.
+constexpr uint32_t kShellQ = 64;  // queries per tile = lanes per wavefront
+constexpr uint32_t kShellNodes = 27;
+constexpr uint32_t kShellBrickCap = kShellQ * kShellNodes;
+constexpr uint32_t kShellCellCap = 1024;
+
+__global__ __launch_bounds__(256) void nn_fit_shell_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range,
+                                                            const uint32_t* __restrict__ pend, const uint32_t* __restrict__ pend_cnt, float* __restrict__ sqd,
+                                                            uint32_t* __restrict__ pend2, uint32_t* __restrict__ pend2_cnt, unsigned long long* __restrict__ stats)
+{
+    const uint32_t np = pend_cnt[blockIdx.y];
+    if (blockIdx.x * kShellQ >= np) return;
+    __shared__ float    s_t[3][kShellQ], s_q[3][kShellQ], s_nm[kShellQ];
+    __shared__ int      s_c[3][kShellQ], s_smax[kShellQ], s_state[kShellQ];  // state 0: searching, 1: settled, 2: no query in this slot
+    __shared__ uint32_t s_lim[kShellQ], s_best[kShellQ], s_i[kShellQ];       // float bit patterns (>= 0: ordered like unsigned integers)
+    __shared__ uint16_t s_bmeta[kShellBrickCap];                             // query | node << 8
+    __shared__ unsigned long long s_bword[kShellBrickCap];
+    __shared__ uint32_t s_cmeta[kShellCellCap];                              // query << 24 | cell
+    __shared__ float    s_clb[kShellCellCap];
+    __shared__ uint32_t s_nb, s_nc;
+    const NnFitnessJob& J = jobs[blockIdx.y];  // uniform: scalar loads
+    const NnGridDev&    g = J.grid.level[0];
+    const uint32_t      off = job_off[blockIdx.y];
+    const float         E0 = g.cell, E1 = 4.0f * g.cell, mg = 4.0f * g.slack;
+    const int           d1[3] = {g.bdim[0], g.bdim[1], g.bdim[2]};
+    const int           gd0 = g.dim[0], gd1 = g.dim[1];
+    const float         max_sq_f = max_range >= 3.0e38 ? INFINITY : static_cast<float>(max_range) * (1.0f + 1e-6f);
+    const int           lane = lane_id();
+    const int           w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const uint64_t      below = (1ull << lane) - 1ull;
+    uint32_t            n_words = 0, n_cells = 0, n_points = 0;  // diagnostics (stats != nullptr)
+    NnPyramidQuery      pq;
+    pq.m = mg;
+    // settle(s): shells 0..s are done; a query is finished when everything beyond them is farther than lim, or there is nothing beyond
+    auto settle = [&](int s) {
+        if (threadIdx.x < kShellQ && s_state[threadIdx.x] == 0) {
+            const float b = static_cast<float>(s) * E1 + s_nm[threadIdx.x];
+            if (s_smax[threadIdx.x] <= s || b * b > __uint_as_float(s_lim[threadIdx.x]) * kNnPrune) s_state[threadIdx.x] = 1;
+        }
+    };
+    for (uint32_t k0 = blockIdx.x * kShellQ; k0 < np; k0 += gridDim.x * kShellQ) {
+        // ---- phase 0: the tile's queries
+        if (threadIdx.x < kShellQ) {
+            const uint32_t k = k0 + threadIdx.x;
+            int state = 2;
+            if (k < np) {
+                const uint32_t i = as_global(pend)[off + k];
+                const float4   p = load_point(J.src + i);
+                float x, y, z;
+                transform_point(J.T12, p.x, p.y, p.z, x, y, z);
+                const float bound = sqd[off + i];  // what the block gave (INFINITY: nothing)
+                int c[3];
+                nn_cell_of(g, x, y, z, c);  // queued queries are finite
+                const float t[3] = {x - g.origin[0], y - g.origin[1], z - g.origin[2]};
+                float nm = INFINITY;
+                int   smax = 0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const int   b = c[a] >> 2;
+                    const float lo = static_cast<float>(b) * E1;
+                    nm = fminf(nm, fminf(t[a] - lo, lo + E1 - t[a]));
+                    smax = max(smax, max(b, d1[a] - 1 - b));
+                    s_t[a][threadIdx.x] = t[a];
+                    s_c[a][threadIdx.x] = c[a];
+                }
+                s_q[0][threadIdx.x] = x;
+                s_q[1][threadIdx.x] = y;
+                s_q[2][threadIdx.x] = z;
+                s_nm[threadIdx.x] = fmaxf(nm - mg, 0.0f);
+                s_smax[threadIdx.x] = smax;
+                s_lim[threadIdx.x] = __float_as_uint(fminf(max_sq_f, bound));
+                s_best[threadIdx.x] = __float_as_uint(bound);
+                s_i[threadIdx.x] = i;
+                state = 0;
+            }
+            s_state[threadIdx.x] = state;
+        }
+        if (threadIdx.x == 0) { s_nb = 0; s_nc = 0; }
+        __syncthreads();
+        for (int pass = 0; pass < 5; ++pass) {
+            if (pass == 1) settle(1);
+            if (pass >= 1 && !__syncthreads_or(threadIdx.x < kShellQ && s_state[threadIdx.x] == 0)) break;
+            const int first = pass * static_cast<int>(kShellNodes), last = min(first + static_cast<int>(kShellNodes), 125);
+            // ---- phase 1: lane = query, node uniform per wavefront
+            {
+                const bool act = s_state[lane] == 0;
+                const int  b[3] = {s_c[0][lane] >> 2, s_c[1][lane] >> 2, s_c[2][lane] >> 2};
+                pq.t[0] = s_t[0][lane];
+                pq.t[1] = s_t[1][lane];
+                pq.t[2] = s_t[2][lane];
+                const float lim = __uint_as_float(s_lim[lane]) * kNnPrune;
+                const float e1 = E1 + s_nm[lane], cls = e1 * e1;  // a shell-2 node with k coordinates at +-2 is at least sqrt(k) e1 away
+                constexpr int U = (kShellNodes + 3) / 4;
+                unsigned long long wd[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    wd[u] = 0ull;
+                    const int node = first + w + 4 * u;
+                    if (node >= last) continue;  // uniform
+                    int d[3];
+                    nn_small_shell_pos(node, d);
+                    const float kmin = node < 27 ? 0.0f : (node < 27 + 54 ? 1.0f : (node < 27 + 90 ? 2.0f : 3.0f));
+                    const int   nx = b[0] + d[0], ny = b[1] + d[1], nz = b[2] + d[2];
+                    if (!act || kmin * cls > lim || nx < 0 || nx >= d1[0] || ny < 0 || ny >= d1[1] || nz < 0 || nz >= d1[2]) continue;
+                    float lb2, ub2;
+                    pq.box(E1, nx, ny, nz, lb2, ub2);
+                    if (lb2 <= lim) {
+                        wd[u] = as_global(g.occ)[(static_cast<uint32_t>(nz) * d1[1] + ny) * d1[0] + nx];
+                        ++n_words;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool     push = wd[u] != 0ull;
+                    const uint64_t m = __ballot(push);
+                    if (m == 0) continue;  // uniform
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&s_nb, static_cast<uint32_t>(__popcll(m)));
+                    base = __shfl(base, 0);
+                    if (push) {
+                        const uint32_t slot = base + static_cast<uint32_t>(__popcll(m & below));
+                        s_bmeta[slot] = static_cast<uint16_t>(static_cast<uint32_t>(lane) | static_cast<uint32_t>(first + w + 4 * u) << 8);
+                        s_bword[slot] = wd[u];
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- phases 2 and 3, alternating while the cell list fills up
+            const uint32_t nb = s_nb;
+            uint32_t       e = threadIdx.x;
+            bool           have = e < nb;
+            uint32_t       meta = 0;
+            unsigned long long bits = 0ull;
+            if (have) { meta = s_bmeta[e]; bits = s_bword[e]; }
+            for (;;) {
+                bool full = false;
+                while (!full && __ballot(have)) {  // uniform: every lane of the wavefront stays in the loop
+                    bool     push = false;
+                    uint32_t cm = 0;
+                    float    clb = 0.0f;
+                    if (have) {
+                        const int q = static_cast<int>(meta & 0xffu);
+                        int d[3];
+                        nn_small_shell_pos(static_cast<int>(meta >> 8), d);
+                        const int bit = __ffsll(bits) - 1;
+                        const int c0 = s_c[0][q], c1 = s_c[1][q], c2 = s_c[2][q];
+                        const int cx = ((c0 >> 2) + d[0]) * 4 + (bit & 3), cy = ((c1 >> 2) + d[1]) * 4 + ((bit >> 2) & 3), cz = ((c2 >> 2) + d[2]) * 4 + (bit >> 4);
+                        pq.t[0] = s_t[0][q];
+                        pq.t[1] = s_t[1][q];
+                        pq.t[2] = s_t[2][q];
+                        float lb2, ub2;
+                        pq.box(E0, cx, cy, cz, lb2, ub2);
+                        float lim = __uint_as_float(s_lim[q]);
+                        const float ub = ub2 * kNnPrune;  // an occupied cell: something is no farther than its far corner
+                        if (ub < lim) { atomicMin(&s_lim[q], __float_as_uint(ub)); lim = ub; }
+                        const bool in_block = cx - c0 >= -1 && cx - c0 <= 1 && cy - c1 >= -1 && cy - c1 <= 1 && cz - c2 >= -1 && cz - c2 <= 1;  // the block pass did these
+                        push = !in_block && lb2 <= lim * kNnPrune;
+                        cm = static_cast<uint32_t>(q) << 24 | ((static_cast<uint32_t>(cz) * gd1 + cy) * gd0 + cx);
+                        clb = lb2;
+                    }
+                    const uint64_t m = __ballot(push);
+                    bool           stalled = false;
+                    if (m != 0) {  // uniform
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&s_nc, static_cast<uint32_t>(__popcll(m)));
+                        base = __shfl(base, 0);
+                        if (push) {
+                            const uint32_t slot = base + static_cast<uint32_t>(__popcll(m & below));
+                            if (slot < kShellCellCap) { s_cmeta[slot] = cm; s_clb[slot] = clb; }
+                            else stalled = true;  // list full: this cell again after phase 3 has emptied it
+                        }
+                        full = base + static_cast<uint32_t>(__popcll(m)) >= kShellCellCap;
+                    }
+                    if (have && !stalled) {
+                        bits &= bits - 1ull;
+                        if (bits == 0ull) {
+                            e += 256u;
+                            have = e < nb;
+                            if (have) { meta = s_bmeta[e]; bits = s_bword[e]; }
+                        }
+                    }
+                }
+                __syncthreads();
+                const uint32_t nc = min(s_nc, kShellCellCap);
+                for (uint32_t j = threadIdx.x; j < nc; j += 256u) {
+                    const uint32_t cmj = s_cmeta[j];
+                    const int      q = static_cast<int>(cmj >> 24);
+                    const float    lim = __uint_as_float(s_lim[q]);
+                    if (s_clb[j] > lim * kNnPrune) continue;  // lim has moved since the cell was listed
+                    const uint32_t at = cmj & 0xffffffu;
+                    const uint32_t kb = as_global(g.cell_start)[at], ke = as_global(g.cell_start)[at + 1];
+                    const float    x = s_q[0][q], y = s_q[1][q], z = s_q[2][q];
+                    float          dm = INFINITY;
+                    for (uint32_t k = kb; k < ke; ++k) {
+                        const float4 p = load_point(g.sorted + k);
+                        dm = fminf(dm, sqdist3f(p.x, p.y, p.z, x, y, z));
+                    }
+                    ++n_cells;
+                    n_points += ke - kb;
+                    if (dm < lim) {
+                        atomicMin(&s_best[q], __float_as_uint(dm));
+                        atomicMin(&s_lim[q], __float_as_uint(dm));
+                    }
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) s_nc = 0;
+                if (!__syncthreads_or(have)) break;
+            }
+            if (threadIdx.x == 0) s_nb = 0;
+            // (the barrier at the head of the next pass, or the one below, orders this reset and the lists' reuse)
+        }
+        __syncthreads();
+        settle(2);
+        // ---- results: settled queries get their distance, the others go on to the super-brick walk with what is known so far
+        if (threadIdx.x < kShellQ) {  // wavefront 0
+            const int   state = s_state[threadIdx.x];
+            const float best = __uint_as_float(s_best[threadIdx.x]);
+            const bool  on = state == 0;
+            if (state == 1) sqd[off + s_i[threadIdx.x]] = static_cast<double>(best) <= max_range ? best : kFitNone;
+            if (on) sqd[off + s_i[threadIdx.x]] = best;
+            const uint64_t m = __ballot(on);
+            if (m != 0) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&pend2_cnt[blockIdx.y], static_cast<uint32_t>(__popcll(m)));
+                base = __shfl(base, 0);
+                if (on) pend2[off + base + static_cast<uint32_t>(__popcll(m & below))] = s_i[threadIdx.x];
+            }
+        }
+        __syncthreads();
+    }
+    if (stats != nullptr) {
+        __shared__ uint32_t s_st[3][4];
+        const uint32_t a = wave_sum(n_words), b = wave_sum(n_cells), c = wave_sum(n_points);
+        if (lane == 0) { s_st[0][w] = a; s_st[1][w] = b; s_st[2][w] = c; }
+        __syncthreads();
+        if (threadIdx.x < 3) atomicAdd(&stats[threadIdx.x], static_cast<unsigned long long>(s_st[threadIdx.x][0]) + s_st[threadIdx.x][1] + s_st[threadIdx.x][2] + s_st[threadIdx.x][3]);
+    }
+}
+
 #ifndef MRGFE_FAR_GROUP
 #define MRGFE_FAR_GROUP 2
 #endif
 constexpr int kFarGroup = MRGFE_FAR_GROUP;  // lanes per query in the far pass
+// The rest of the far pass: one lane group per queued query, the occupancy pyramid walked as nn_pyramid_walk describes.  kSkipBricks:
+// the queue is nn_fit_shell_kernel's — the bricks within two shells are done, the walk starts at the super-bricks (false: round 2's
+// single far pass, kept for MRGFE_FIT_SHELL=0 and as the reference the shell pass is tested against).
 // (Measured and dropped: two queues per job — queries the block gave a first distance from the front, queries with nothing around
 // them from the back — so that a wavefront of the far pass holds walks of one kind: far 19.5 -> 19.3 ms, block 2.7 -> 2.9 ms.)
+template <bool kSkipBricks>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void nn_fit_far_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range, const uint32_t* __restrict__ pend,
                                                           const uint32_t* __restrict__ pend_cnt, float* __restrict__ sqd)
 {
@@ -396,10 +656,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
         const float4   p = load_point(s_job.src + i);
         float x, y, z;
         transform_point(s_job.T12, p.x, p.y, p.z, x, y, z);
-        const float bound = sqd[off + i];  // what the block gave
+        const float bound = sqd[off + i];  // what the earlier passes gave
         int32_t bpos;
         float   bd;
-        nn_far_search<kFarGroup>(s_job.grid, x, y, z, sub, max_range, bound, bpos, bd);
+        nn_far_search<kFarGroup, kSkipBricks>(s_job.grid, x, y, z, sub, max_range, bound, bpos, bd);
         bd = fminf(bd, bound);
         if (sub == 0) sqd[off + i] = static_cast<double>(bd) <= max_range ? bd : kFitNone;
     }
@@ -451,6 +711,20 @@ __global__ __launch_bounds__(256) void nn_fitness_final_kernel(const double* __r
     }
 }
 
+static std::atomic<int> g_fit_shell{-1};  // -1: not read yet
+static int fit_shell_mode()
+{
+    int v = g_fit_shell.load(std::memory_order_relaxed);
+    if (v < 0) { const char* e = std::getenv("MRGFE_FIT_SHELL"); v = e ? (std::atoi(e) != 0 ? 1 : 0) : 1; g_fit_shell.store(v, std::memory_order_relaxed); }
+    return v;
+}
+int nn_set_fit_shell(int mode)
+{
+    if (mode == 0 || mode == 1) g_fit_shell.store(mode, std::memory_order_relaxed);
+    return fit_shell_mode();
+}
+static int fit_stats_mode() { static const int v = [] { const char* e = std::getenv("MRGFE_FIT_STATS"); return e ? std::atoi(e) : 0; }(); return v; }
+
 int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, double max_range, double* out)
 {
     for (size_t j = 0; j < count; ++j) out[j] = DBL_MAX;
@@ -471,33 +745,68 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     const uint32_t want = static_cast<uint32_t>(std::max<size_t>(1, (size_t(ctx->cu_count) * 128 + count - 1) / count));
     const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((max_n + per_blk - 1) / per_blk, want));
     const uint32_t nblk_sum = (max_n + kFitSumSlice - 1) / kFitSumSlice;
-    // scratch 9: jobs, offsets, queue lengths, partial sums; 12: one float per query; 13: the queues (10 and 11 may hold
-    // the caller's clouds, see mrgfe_calc_fitness_score)
+    // scratch 9: jobs, offsets, queue lengths, counters, partial sums; 12: one float per query; 13: the two queues (10 and 11 may
+    // hold the caller's clouds, see mrgfe_calc_fitness_score)
     DevBuf &dw = ctx->scratch[9], &dq = ctx->scratch[12], &dp = ctx->scratch[13];
     const size_t jobs_bytes = (sizeof(NnFitnessJob) * count + 255) & ~size_t(255);
-    const size_t off_bytes = (sizeof(uint32_t) * 2 * (count + 1) + 255) & ~size_t(255);
+    const size_t off_bytes = (sizeof(uint32_t) * 3 * (count + 1) + 64 + 255) & ~size_t(255);
     MRGFE_TRY(dw.ensure(jobs_bytes + off_bytes + sizeof(double) * 2 * (size_t(nblk_sum) + 1) * count));
     MRGFE_TRY(dq.ensure(sizeof(float) * total));
-    MRGFE_TRY(dp.ensure(sizeof(uint32_t) * total));
+    MRGFE_TRY(dp.ensure(sizeof(uint32_t) * 2 * total));
     NnFitnessJob* d_jobs = dw.as<NnFitnessJob>();
     uint32_t*     d_off = reinterpret_cast<uint32_t*>(dw.as<char>() + jobs_bytes);
-    uint32_t*     d_cnt = d_off + count + 1;
+    uint32_t*     d_cnt = d_off + count + 1;   // queue lengths: after the block pass
+    uint32_t*     d_cnt2 = d_cnt + count + 1;  // ... after the brick-shell pass
+    unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(dw.as<char>() + jobs_bytes + off_bytes - 64);  // 4 counters, 8-byte aligned
     double*       d_part = reinterpret_cast<double*>(dw.as<char>() + jobs_bytes + off_bytes);
     double*       d_res = d_part + 2 * size_t(nblk_sum) * count;
+    uint32_t*     d_pend = dp.as<uint32_t>();
+    uint32_t*     d_pend2 = d_pend + total;
+    const bool    shell = fit_shell_mode() != 0, counters = fit_stats_mode() != 0;
+    for (auto& e : ctx->ev_fit)
+        if (!e) MRGFE_HIP_CHECK(hipEventCreate(&e));
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_jobs, jobs, sizeof(NnFitnessJob) * count, hipMemcpyHostToDevice, st));
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_off, off.data(), sizeof(uint32_t) * (count + 1), hipMemcpyHostToDevice, st));
-    MRGFE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * count, st));
+    MRGFE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, off_bytes - sizeof(uint32_t) * (count + 1), st));  // both queue lengths and the counters behind them
     const dim3 grid(nblk, static_cast<uint32_t>(count));
-    hipLaunchKernelGGL(nn_fit_block_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, dq.as<float>(), dp.as<uint32_t>(), d_cnt);
-    hipLaunchKernelGGL(nn_fit_far_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, dp.as<uint32_t>(), d_cnt, dq.as<float>());
+    MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[0], st));
+    hipLaunchKernelGGL(nn_fit_block_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, dq.as<float>(), d_pend, d_cnt);
+    MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[1], st));
+    if (shell) {
+        // 64 queries per tile: as many workgroups as the block pass has, walking the queue on their stride
+        hipLaunchKernelGGL(nn_fit_shell_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend, d_cnt, dq.as<float>(), d_pend2, d_cnt2, counters ? d_stats : nullptr);
+        MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[2], st));
+        hipLaunchKernelGGL(nn_fit_far_kernel<true>, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend2, d_cnt2, dq.as<float>());
+    } else {
+        MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[2], st));
+        hipLaunchKernelGGL(nn_fit_far_kernel<false>, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend, d_cnt, dq.as<float>());
+    }
+    MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[3], st));
     hipLaunchKernelGGL(nn_fit_sum_kernel, dim3(nblk_sum, static_cast<uint32_t>(count)), dim3(256), 0, st, d_jobs, d_off, dq.as<float>(), d_part);
     hipLaunchKernelGGL(nn_fitness_final_kernel, dim3(static_cast<uint32_t>(count)), dim3(256), 0, st, d_part, nblk_sum, d_res);
     MRGFE_HIP_CHECK(hipGetLastError());
-    std::vector<double> res(2 * count);
+    std::vector<double>   res(2 * count);
+    std::vector<uint32_t> cnts(2 * (count + 1));
+    unsigned long long    h_stats[4] = {0, 0, 0, 0};
     MRGFE_HIP_CHECK(hipMemcpyAsync(res.data(), d_res, sizeof(double) * 2 * count, hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(cnts.data(), d_cnt, sizeof(uint32_t) * 2 * (count + 1), hipMemcpyDeviceToHost, st));
+    if (counters) MRGFE_HIP_CHECK(hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
     for (size_t j = 0; j < count; ++j)
         if (res[2 * j + 1] > 0) out[j] = res[2 * j] / res[2 * j + 1];
+    FitStats& fs = ctx->fit_stats;
+    float ms[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) (void)hipEventElapsedTime(&ms[k], ctx->ev_fit[k], ctx->ev_fit[k + 1]);
+    fs.ms_block = ms[0];
+    fs.ms_shell = ms[1];
+    fs.ms_far = ms[2];
+    fs.queries = total;
+    fs.queued = fs.queued_far = 0;
+    for (size_t j = 0; j < count; ++j) { fs.queued += cnts[j]; fs.queued_far += shell ? cnts[count + 1 + j] : cnts[j]; }
+    fs.words = h_stats[0];
+    fs.cells = h_stats[1];
+    fs.points = h_stats[2];
+    ++fs.calls;
     return MRGFE_OK;
 }
 

@@ -333,6 +333,12 @@ class BatchMatcher:
         c = _cloud(cloud)
         return check(lib().mrgfe_batch_add_target(self._h, c.ctypes.data_as(_fp), len(c), 16))
 
+    def add_target_records(self, records, n: int, layout: int) -> int:
+        """A target held as strided point records (``layout`` = ``_lib.layout(...)``, e.g. ``LAYOUT_PCL_XYZI`` for the reference's
+        in-memory pcl::PointXYZI): uploaded raw and gathered on the device."""
+        buf = np.ascontiguousarray(records)
+        return check(lib().mrgfe_batch_add_target(self._h, buf.ctypes.data_as(_fp), n, layout))
+
     def add_target_device(self, dev_ptr: int, n: int) -> int:
         return check(lib().mrgfe_batch_add_target_device(self._h, C.c_void_p(dev_ptr), n))
 

@@ -248,3 +248,40 @@ def test_device_resident_clouds_give_the_host_pointer_results():
     r2.align(guesses[0])
     np.testing.assert_array_equal(r1.getFinalTransformation(), r2.getFinalTransformation())
     assert r1.getFitnessScore() == r2.getFitnessScore()
+
+
+def test_fitness_grids_wait_for_the_target_upload(monkeypatch):
+    """The steady state of INTEGRATION.md: ONE new keyframe handed over as host records (asynchronous copy + device gather on the
+    batch's stream), every candidate resident in the keyframe store, then align.  The fitness grids are built on helper streams
+    beside the alignment: they must see the finished upload (round-2 advisor finding) — same scores as building them afterwards
+    on the batch's own stream, call after call."""
+    from mrg_slam_amd import BatchMatcher
+    from mrg_slam_amd._lib import LAYOUT_PCL_XYZI
+
+    rng = np.random.default_rng(77)
+    cands = {k: small_cloud(20000, 900 + k) for k in (1, 2, 3, 4)}
+    bm = BatchMatcher(transformation_epsilon=0.1)
+    t0 = bm.add_target(small_cloud(1000, 1))
+    for k, c in cands.items():
+        bm.add_pair(t0, c, np.eye(4), key=k)  # fills the store
+    bm.align(float("inf"))
+    for call in range(6):
+        tgt = small_cloud(200000, 950 + call)  # large: the copy and the gather are still in flight when the builders start
+        rec = np.zeros((len(tgt), 8), np.float32)
+        rec[:, :3] = tgt[:, :3]
+        rec[:, 3] = 1.0
+        rec[:, 4] = tgt[:, 3]
+        got = []
+        for no_overlap in (False, True):
+            if no_overlap:
+                monkeypatch.setenv("MRGFE_NO_FIT_OVERLAP", "1")
+            else:
+                monkeypatch.delenv("MRGFE_NO_FIT_OVERLAP", raising=False)
+            bm.clear()
+            t = bm.add_target_records(rec, len(tgt), LAYOUT_PCL_XYZI)
+            for k in cands:
+                bm.add_pair(t, None, np.eye(4), key=k)
+            got.append(bm.align(float("inf")))
+        for a, b in zip(*got):
+            assert a["fitness"] == b["fitness"] and np.isfinite(a["fitness"])
+            np.testing.assert_array_equal(a["T"], b["T"])
