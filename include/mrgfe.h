@@ -100,11 +100,11 @@ int  mrgfe_ctx_synchronize(mrgfe_ctx* ctx);
 void* mrgfe_ctx_stream(mrgfe_ctx* ctx);
 /* Measurement hook ("1-NN fitness on hash grid: N (16 + 27*8 + m*16)"): what the last getFitnessScore pass on this context
  * did — mrgfe_reg_fitness, mrgfe_batch_align(fitness_max_range >= 0), mrgfe_calc_fitness_score, mrgfe_map_store_fitness.
- * out[0..2] = HIP-event milliseconds of the block pass / the brick-shell pass / the remaining far walk (events on the context's stream),
- * out[3] = queries, out[4] = queries the 3x3x3 block did not settle, out[5] = queries two brick shells did not settle,
- * out[6..8] = occupancy words fetched / cells opened / candidate points measured by the brick-shell pass (0 unless MRGFE_FIT_STATS=1),
- * out[9] = number of passes run on this context so far. */
-int mrgfe_ctx_fitness_stats(mrgfe_ctx* ctx, double out[10]);
+ * out[0..2] = HIP-event milliseconds of the block pass / the seed + sweep pass / the pyramid walk of what could not be seeded (events on
+ * the context's stream), out[3] = queries, out[4] = queries their 3x3x3 block did not settle, out[5] = queries without a seed within three
+ * blocks, out[6..9] = occupancy words fetched / boxes tested against the sphere / cells opened / candidate points measured by the seed +
+ * sweep pass (0 unless MRGFE_FIT_STATS=1), out[10] = number of passes run on this context so far. */
+int mrgfe_ctx_fitness_stats(mrgfe_ctx* ctx, double out[11]);
 
 /* ---- cloud ingest --------------------------------------------------------------------------------- */
 /* replaces pcl::fromROSMsg(*cloud_msg, *cloud) (apps/prefiltering_component.cpp:119-120, scan_matching_odometry_component.cpp:144-145):
@@ -368,11 +368,11 @@ int mrgfe_dbg_set_host_control(int mode);
  * 0 = one launch per variant.  Any other value only asks.  Returns the setting in effect.  Same sums either way: an item's partial
  * record does not depend on the launch it is computed in (tests/test_gpu_control.py). */
 int mrgfe_dbg_set_fused_launch(int mode);
-/* How getFitnessScore's far pass runs during the following calls of this process: 1 = the bricks within two shells of a queued query as
- * flat work items (nn_fit_shell_kernel), the rest by the pyramid walk from the super-bricks on (default; MRGFE_FIT_SHELL sets the
- * initial value), 0 = round 2's single far pass.  Any other value only asks.  Returns the setting in effect.  Both give the exact nearest
- * distances (tests/test_gpu_fitness_passes.py). */
-int mrgfe_dbg_set_fit_shell(int mode);
+/* How getFitnessScore's far pass runs during the following calls of this process: 1 = seed + sweep (nn_fit_sweep_kernel: a near occupied
+ * cell found through the occupancy words gives a radius, the occupied cells inside it are enumerated top-down with bit masks; default,
+ * MRGFE_FIT_SWEEP sets the initial value), 0 = round 2's pyramid walk for every queued query.  Any other value only asks.  Returns the
+ * setting in effect.  Both give the exact nearest distances (tests/test_gpu_fitness_passes.py). */
+int mrgfe_dbg_set_fit_sweep(int mode);
 /* The optimiser's scalar routines (pose vector -> float matrix, angle derivative tables, 6x6 SVD solve) on n cases of 48 doubles
  * (p[6], A[36] row-major, b[6]), on the host (on_device = 0, ctx may be NULL) or on the device: M16 [n][16] row-major, tables69
  * [n][8*3 + 15*3], x6 [n][6]; on_device = 2: x6 from the wavefront form of the solve (three lanes rotate, 36 apply) that the

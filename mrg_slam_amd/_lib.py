@@ -174,7 +174,7 @@ SIGNATURES = {
     "mrgfe_dbg_minmax": (C.c_int, [_vp, _fp, C.c_size_t, _fp, _fp, _u32p]),
     "mrgfe_dbg_set_host_control": (C.c_int, [C.c_int]),
     "mrgfe_dbg_set_fused_launch": (C.c_int, [C.c_int]),
-    "mrgfe_dbg_set_fit_shell": (C.c_int, [C.c_int]),
+    "mrgfe_dbg_set_fit_sweep": (C.c_int, [C.c_int]),
     "mrgfe_batch_rounds": (C.c_int, [_vp]),
     "mrgfe_dbg_sincosf": (None, [_fp, C.c_size_t, _fp, _fp]),
     "mrgfe_dbg_ctl_math": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _fp, _dp, _dp]),
@@ -247,9 +247,9 @@ class Context:
 
     def fitness_stats(self) -> dict:
         """What the last getFitnessScore pass on this context did (``mrgfe_ctx_fitness_stats``)."""
-        v = (C.c_double * 10)()
+        v = (C.c_double * 11)()
         check(lib().mrgfe_ctx_fitness_stats(self._h, v))
-        keys = ("ms_block", "ms_shell", "ms_far", "queries", "queued", "queued_far", "words", "cells", "points", "calls")
+        keys = ("ms_block", "ms_sweep", "ms_far", "queries", "queued", "queued_far", "words", "boxes_tested", "cells", "points", "calls")
         return dict(zip(keys, [float(x) for x in v]))
 
     def close(self):

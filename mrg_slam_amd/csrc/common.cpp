@@ -328,12 +328,12 @@ int mrgfe_ctx_synchronize(mrgfe_ctx* ctx)
 
 void* mrgfe_ctx_stream(mrgfe_ctx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
 
-int mrgfe_ctx_fitness_stats(mrgfe_ctx* ctx, double out[10])
+int mrgfe_ctx_fitness_stats(mrgfe_ctx* ctx, double out[11])
 {
     if (!ctx || !out) { mrgfe::set_error("mrgfe_ctx_fitness_stats: NULL argument"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(ctx);
     const mrgfe::FitStats& f = ctx->fit_stats;
-    const double v[10] = {f.ms_block, f.ms_shell, f.ms_far, double(f.queries), double(f.queued), double(f.queued_far), double(f.words), double(f.cells), double(f.points), double(f.calls)};
+    const double v[11] = {f.ms_block, f.ms_sweep, f.ms_far, double(f.queries), double(f.queued), double(f.queued_far), double(f.words), double(f.tested), double(f.cells), double(f.points), double(f.calls)};
     std::memcpy(out, v, sizeof(v));
     return MRGFE_OK;
 }

@@ -82,9 +82,9 @@ void ctx_tmp_grid_free(mrgfe_ctx* ctx);  // nn_grid.hip
 namespace mrgfe {
 // what the last nn_fitness_batch on a context did (getFitnessScore passes): HIP-event times of its passes and the walk's counters
 struct FitStats {
-    double   ms_block = 0, ms_shell = 0, ms_far = 0;  // block pass / brick-shell pass / remaining far walk
-    uint64_t queries = 0, queued = 0, queued_far = 0; // all queries / not settled by the 3x3x3 block / not settled within two brick shells
-    uint64_t words = 0, cells = 0, points = 0;        // brick-shell pass: occupancy words fetched, cells opened, candidate points measured (MRGFE_FIT_STATS=1)
+    double   ms_block = 0, ms_sweep = 0, ms_far = 0;   // block pass / seed + sweep / pyramid walk of the unseeded rest
+    uint64_t queries = 0, queued = 0, queued_far = 0;  // all queries / not settled by their 3x3x3 block / not seeded within three blocks
+    uint64_t words = 0, tested = 0, cells = 0, points = 0;  // seed + sweep: occupancy words fetched, boxes tested against the sphere, cells opened, points measured (MRGFE_FIT_STATS=1)
     uint64_t calls = 0;
 };
 }  // namespace mrgfe

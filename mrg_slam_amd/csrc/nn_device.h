@@ -138,12 +138,13 @@ __device__ __forceinline__ float nn_group_fmin(float v)
 }
 
 // offsets (dx + 2) | (dy + 2) << 3 | (dz + 2) << 6 of the 5 x 5 x 5 nodes around a centre, shell 0 first, then the 26 of
-// shell 1 (the order nn_shell_walk's general enumeration produces), then the 98 of shell 2 by the number of their coordinates that
+// shell 1 (the six that share a face with the centre, the twelve that share an edge, the eight corners: nearest kind first, round 3),
+// then the 98 of shell 2 by the number of their coordinates that
 // are +-2 — 54 face nodes, 36 edge nodes, 8 corners: a node with k such coordinates is at least sqrt(k) (E + nm) away, so the walk
 // of the shell can stop at a class boundary (24.4 -> 23.9 ms)
 __device__ __forceinline__ void nn_small_shell_pos(int idx, int d[3])
 {
-    static constexpr uint16_t kTab[125] = {146, 73, 74, 75, 81, 82, 83, 89, 90, 91, 201, 202, 203, 209, 210, 211, 217, 218, 219, 137, 138, 139, 153, 154, 155, 145, 147, 18, 274, 130, 162, 144, 148, 10, 17, 19, 26, 266, 273, 275, 282, 66, 98, 80, 84, 129, 131, 161, 163, 136, 140, 152, 156, 194, 226, 208, 212, 9, 11, 25, 27, 265, 267, 281, 283, 65, 67, 97, 99, 72, 76, 88, 92, 193, 195, 225, 227, 200, 204, 216, 220, 2, 16, 20, 34, 258, 272, 276, 290, 128, 132, 160, 164, 1, 3, 8, 12, 24, 28, 33, 35, 257, 259, 264, 268, 280, 284, 289, 291, 64, 68, 96, 100, 192, 196, 224, 228, 0, 4, 32, 36, 256, 260, 288, 292};
+    static constexpr uint16_t kTab[125] = {146, 82, 210, 138, 154, 145, 147, 74, 81, 83, 90, 202, 209, 211, 218, 137, 139, 153, 155, 73, 75, 89, 91, 201, 203, 217, 219, 18, 274, 130, 162, 144, 148, 10, 17, 19, 26, 266, 273, 275, 282, 66, 98, 80, 84, 129, 131, 161, 163, 136, 140, 152, 156, 194, 226, 208, 212, 9, 11, 25, 27, 265, 267, 281, 283, 65, 67, 97, 99, 72, 76, 88, 92, 193, 195, 225, 227, 200, 204, 216, 220, 2, 16, 20, 34, 258, 272, 276, 290, 128, 132, 160, 164, 1, 3, 8, 12, 24, 28, 33, 35, 257, 259, 264, 268, 280, 284, 289, 291, 64, 68, 96, 100, 192, 196, 224, 228, 0, 4, 32, 36, 256, 260, 288, 292};
     const int v = kTab[idx];
     d[0] = (v & 7) - 2;
     d[1] = ((v >> 3) & 7) - 2;
@@ -293,8 +294,7 @@ __device__ __forceinline__ unsigned long long nn_deal_mask(int G, int sub)
 // kByPos: (best_i, best_d) name the candidate by its position in g.sorted instead of its original index (ties then go to
 // the lowest position; callers that only want the distance, or the point itself, save the index indirection).
 // `bound`: a squared distance already known to be attained by some point (INFINITY: none) that has no (best_i, best_d).
-// kSkipBricks: the caller has already searched the bricks within kShells of the query's (nn_fit_shell_kernel): start at the super-bricks.
-template <int G, bool kByPos = false, bool kSkipBricks = false>
+template <int G, bool kByPos = false>
 __device__ __forceinline__ void nn_pyramid_walk(const NnGridDev& g, float x, float y, float z, const int c[3], int sub, double max_sq, int32_t& best_i, float& best_d,
                                                 float bound = INFINITY)
 {
@@ -357,7 +357,7 @@ __device__ __forceinline__ void nn_pyramid_walk(const NnGridDev& g, float x, flo
     };
 
     // A. bricks
-    if (!kSkipBricks && nn_shell_walk<G, true>(g.occ, d1, b1, E1, pq, 0, kShells, sub, lim, [&](unsigned long long wb, int bx, int by, int bz) {
+    if (nn_shell_walk<G, true>(g.occ, d1, b1, E1, pq, 0, kShells, sub, lim, [&](unsigned long long wb, int bx, int by, int bz) {
             cells_open(wb & deal, bx, by, bz);
             agree();
         }))
@@ -492,14 +492,14 @@ __device__ __forceinline__ void nn_nearest_group(const NnGrid2Dev& g, float x, f
 // block gave (INFINITY: none) or any other distance known to be attained; on return best_pos >= 0 names the position in
 // level[0].sorted of the nearest point found outside the block with its squared distance best_d, if one is within the
 // bound; the answer is the smaller of bound and best_d.
-template <int G, bool kSkipBricks = false>
+template <int G>
 __device__ __forceinline__ void nn_far_search(const NnGrid2Dev& g, float x, float y, float z, int sub, double max_sq, float bound, int32_t& best_pos, float& best_d)
 {
     best_pos = -1;
     best_d = INFINITY;
     int c[3];
     nn_cell_of(g.level[0], x, y, z, c);
-    nn_pyramid_walk<G, true, kSkipBricks>(g.level[0], x, y, z, c, sub, max_sq, best_pos, best_d, bound);
+    nn_pyramid_walk<G, true>(g.level[0], x, y, z, c, sub, max_sq, best_pos, best_d, bound);
 }
 
 }  // namespace mrgfe

@@ -92,7 +92,7 @@ NnGrid& ctx_tmp_grid(mrgfe_ctx* ctx);
 // all jobs in one launch (blockIdx.y = job); out[j] = mean squared distance or DBL_MAX when nothing is in range
 int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, double max_range, double* out);
 
-// far pass of the fitness score: 1 = brick shells as flat work items + pyramid walk from the super-bricks, 0 = single pyramid walk
-int nn_set_fit_shell(int mode);
+// far pass of the fitness score: 1 = seed + sweep (nn_fit_sweep_kernel), 0 = the pyramid walk for every queued query
+int nn_set_fit_sweep(int mode);
 
 }  // namespace mrgfe

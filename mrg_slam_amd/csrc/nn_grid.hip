@@ -375,258 +375,458 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void n
     flush();
 }
 
-// ---- far pass, first part: the bricks within two shells of the query's, as flat work items ----------------------------
-// A queued query's walk over the 5 x 5 x 5 bricks around it is a nest of data-dependent loops (which words are non-empty, which of
-// their cells are occupied, how many points those hold): run one query per lane (or lane pair) a wavefront executes the union of
-// 32 different walks — ~15 000 VALU instructions per wavefront in round 2's nn_fit_far_kernel, of which the distance evaluations
-// themselves are a few per cent.  Here a workgroup takes a tile of 64 queued queries and turns every level of the nest into a list
-// of equal work items in LDS:
-//   phase 1  item = (query, brick node): lane = query, the node is uniform over the wavefront (its offset is scalar); lower bound of
-//            the node's box against the query's `lim`, occupancy word fetched; non-empty ones appended to the brick list;
-//   phase 2  item = brick list entry: the lane walks the set bits of the word: an occupied cell pulls `lim` in through its far corner
-//            (LDS atomic min, shared by all lanes working for that query) and is appended to the cell list if its near corner is
-//            inside `lim`;
-//   phase 3  item = cell list entry: two table reads, the cell's points measured, minimum into the query's best distance / `lim`.
-// `lim` (squared radius that can still matter) only ever shrinks and is always an upper bound of the answer, so the order in which
-// the items run changes how much is pruned, never the result: the exact nearest distance, as before.  Pass 0 covers the query's
-// brick and shell 1 (27 nodes); queries whose `lim` still reaches beyond them take shell 2 in four more passes (its 98 nodes nearest
-// class first: faces, edges, corners, as nn_small_shell_pos lists them); what is still open then (nothing within ~1 m: a fifth of the
-// queued queries of a loop-closure candidate) goes to a second queue for nn_fit_far_kernel, which starts at the super-bricks.
-constexpr uint32_t kShellQ = 64;  // queries per tile = lanes per wavefront
-constexpr uint32_t kShellNodes = 27;
-constexpr uint32_t kShellBrickCap = kShellQ * kShellNodes;
-constexpr uint32_t kShellCellCap = 1024;
+// ---- far pass: seed, then sweep -------------------------------------------------------------------------------------------
+// Three quarters of the queued queries of a loop-closure candidate arrive without any bound (their 3 x 3 x 3 block is empty), and
+// nothing can be pruned before SOME distance is known: round 2's walk spent its time bounding occupied cells that a known radius
+// would have excluded wholesale.  And a walk per lane is a nest of data-dependent loops: a wavefront executes the union of its
+// lanes' walks (round 2: ~15 000 VALU instructions per wavefront of 32 queries, the distance evaluations a few per cent of them).
+// So a workgroup takes a tile of 256 queued queries, one per lane, and works in phases whose items are equal:
+//   seed   (lane = query) the nearest non-empty brick among the 27 around the query's, read off the (at most eight) super-brick
+//          words that cover them; failing that the nearest non-empty super-brick among 27 (block words), then the nearest non-empty
+//          block among 27; descend to the nearest occupied cell of what was found (nearest = smallest box distance; any occupied
+//          cell would do) and measure its points.  `lim` is now a distance that IS attained, usually close to the answer.
+//          Everything that could beat it lies in the cube of half edge sqrt(lim) around the query: per axis a range of cells, hence
+//          of bricks, super-bricks and blocks.
+//   bricks (lane = query) top-down over that cube: a block's word ANDed with the mask of its super-bricks inside the cube (three
+//          4-bit ranges spread to 64 bits: ~20 instructions for up to 64 children), a surviving super-brick's word with the mask
+//          of its bricks; bricks whose box reaches into the sphere are appended to the brick list in LDS;
+//   cells  (lane = brick list entry) the brick's word ANDed with the mask of its cells inside the cube and outside the query's
+//          own 3 x 3 x 3 block; cells whose box reaches into the sphere are appended to the cell list;
+//   points (lane = cell list entry) two table reads, the cell's points measured, minimum into the query's best distance and lim
+//          (LDS atomics on the float bit patterns).
+// The lists are bounded: a lane that finds one full keeps its place, the list is worked off, and the phase resumes.  `lim` only ever
+// shrinks and is always attained, so the order in which items run changes how much is pruned, never the result: every point within
+// sqrt(lim) of the query is in a cell that gets opened (or in the query's own block, which the block pass measured and which is
+// where lim starts) — the exact nearest distance, as before.  Queries with nothing within three blocks (8 m and more) keep their bound
+// and go to nn_fit_far_kernel's pyramid walk.
+__device__ __forceinline__ unsigned long long nn_range_mask(const int L[3], const int H[3], int ox, int oy, int oz)
+{
+    // children (x + 4 y + 16 z) of the node with first child (ox, oy, oz) whose coordinates lie in [L, H] per axis; 0 if none
+    const int xl = max(L[0] - ox, 0), xh = min(H[0] - ox, 3), yl = max(L[1] - oy, 0), yh = min(H[1] - oy, 3), zl = max(L[2] - oz, 0), zh = min(H[2] - oz, 3);
+    if (xl > xh || yl > yh || zl > zh) return 0ull;
+    const uint32_t mx = (0xfu >> (3 - xh)) & (0xfu << xl) & 0xfu, my = (0xfu >> (3 - yh)) & (0xfu << yl) & 0xfu, mz = (0xfu >> (3 - zh)) & (0xfu << zl) & 0xfu;
+    const uint32_t rows = mx * ((my & 1u) | (my & 2u) << 3 | (my & 4u) << 6 | (my & 8u) << 9);  // mx at every y of the range: one z layer
+    const uint32_t lo = rows * ((mz & 1u) | (mz & 2u) << 15), hi = rows * (((mz >> 2) & 1u) | ((mz >> 2) & 2u) << 15);
+    return static_cast<unsigned long long>(hi) << 32 | lo;
+}
 
-__global__ __launch_bounds__(256) void nn_fit_shell_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range,
-                                                            const uint32_t* __restrict__ pend, const uint32_t* __restrict__ pend_cnt, float* __restrict__ sqd,
-                                                            uint32_t* __restrict__ pend2, uint32_t* __restrict__ pend2_cnt, unsigned long long* __restrict__ stats)
+constexpr uint32_t kSweepQ = 256;          // queries per tile = lanes per workgroup
+constexpr uint32_t kSweepBrickCap = 1024;  // brick list entries
+constexpr uint32_t kSweepCellCap = 2048;   // cell list entries
+constexpr int      kSweepStats = 16;       // diagnostic counters (MRGFE_FIT_STATS)
+constexpr uint32_t kNoSeed = 0x80000000u;  // flag on a queue entry: no seed, the query takes the pyramid walk
+
+// squared distance from a query to the box with centre offset |centre - query| = (ax, ay, az) and half edge + margin h
+__device__ __forceinline__ float nn_lower2(float ax, float ay, float az, float h)
+{
+    const float lx = fmaxf(ax - h, 0.0f), ly = fmaxf(ay - h, 0.0f), lz = fmaxf(az - h, 0.0f);
+    return lx * lx + ly * ly + lz * lz;
+}
+// ... to child (cx, cy, cz) of edge E on a pyramid level, t = query - grid origin
+__device__ __forceinline__ float nn_child_lb(const float t[3], int cx, int cy, int cz, float E, float h)
+{
+    return nn_lower2(fabsf((static_cast<float>(cx) + 0.5f) * E - t[0]), fabsf((static_cast<float>(cy) + 0.5f) * E - t[1]), fabsf((static_cast<float>(cz) + 0.5f) * E - t[2]), h);
+}
+
+// seed: one lane per queued query; sqd[query] becomes min(what the block gave, the nearest point of the seed cell) — attained —, or the
+// queue entry is flagged kNoSeed and appended to the second queue
+__global__ __launch_bounds__(256) void nn_fit_seed_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range, uint32_t* __restrict__ pend,
+                                                           const uint32_t* __restrict__ pend_cnt, float* __restrict__ sqd, uint32_t* __restrict__ pend2, uint32_t* __restrict__ pend2_cnt,
+                                                           unsigned long long* __restrict__ stats)
 {
     const uint32_t np = pend_cnt[blockIdx.y];
-    if (blockIdx.x * kShellQ >= np) return;
-    __shared__ float    s_t[3][kShellQ], s_q[3][kShellQ], s_nm[kShellQ];
-    __shared__ int      s_c[3][kShellQ], s_smax[kShellQ], s_state[kShellQ];  // state 0: searching, 1: settled, 2: no query in this slot
-    __shared__ uint32_t s_lim[kShellQ], s_best[kShellQ], s_i[kShellQ];       // float bit patterns (>= 0: ordered like unsigned integers)
-    __shared__ uint16_t s_bmeta[kShellBrickCap];                             // query | node << 8
-    __shared__ unsigned long long s_bword[kShellBrickCap];
-    __shared__ uint32_t s_cmeta[kShellCellCap];                              // query << 24 | cell
-    __shared__ float    s_clb[kShellCellCap];
+    if (blockIdx.x * 256u >= np) return;
+    const NnFitnessJob& J = jobs[blockIdx.y];  // uniform: scalar loads
+    const NnGridDev&    g = J.grid.level[0];
+    const uint32_t      off = job_off[blockIdx.y];
+    const float         E0 = g.cell, E1 = 4.0f * E0, E2 = 16.0f * E0, E3 = 64.0f * E0, mg = 4.0f * g.slack;
+    const float         h0 = 0.5f * E0 + mg, h1 = 0.5f * E1 + mg, h2 = 0.5f * E2 + mg, h3 = 0.5f * E3 + mg;  // half edge plus the margin
+    const int           d0[3] = {g.dim[0], g.dim[1], g.dim[2]};
+    const int           d1[3] = {g.bdim[0], g.bdim[1], g.bdim[2]};
+    const int           d2[3] = {(d1[0] + 3) >> 2, (d1[1] + 3) >> 2, (d1[2] + 3) >> 2};
+    const int           d3[3] = {(d2[0] + 3) >> 2, (d2[1] + 3) >> 2, (d2[2] + 3) >> 2};
+    const float         max_sq_f = max_range >= 3.0e38 ? INFINITY : static_cast<float>(max_range) * (1.0f + 1e-6f);
+    const int           lane = lane_id();
+    const uint64_t      below = (1ull << lane) - 1ull;
+    uint32_t            n_words = 0, n_points = 0, n_seed2 = 0, n_seed3 = 0, n_noseed = 0;  // diagnostics
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < ((np + 63u) & ~63u); k += gridDim.x * 256u) {  // whole wavefronts: the queue append ballots
+        bool     noseed = false;
+        uint32_t qi = 0;
+        if (k < np) {
+            qi = pend[off + k];
+            const float4 p = load_point(J.src + qi);
+            float x, y, z;
+            transform_point(J.T12, p.x, p.y, p.z, x, y, z);
+            int c[3];
+            nn_cell_of(g, x, y, z, c);  // queued queries are finite
+            const float t[3] = {x - g.origin[0], y - g.origin[1], z - g.origin[2]};
+            // the child of a node (first child at 4 n) with the smallest box distance among those set in `word`
+            auto nearest_child = [&](unsigned long long word, int nx, int ny, int nz, float E, float h, int out[3]) {
+                float best = INFINITY;
+                for (unsigned long long m = word; m != 0ull; m &= m - 1ull) {
+                    const int   bit = __ffsll(m) - 1;
+                    const int   cx = 4 * nx + (bit & 3), cy = 4 * ny + ((bit >> 2) & 3), cz = 4 * nz + (bit >> 4);
+                    const float lb = nn_child_lb(t, cx, cy, cz, E, h);
+                    if (lb < best) { best = lb; out[0] = cx; out[1] = cy; out[2] = cz; }
+                }
+            };
+            // candidates of one level: the non-empty children, within one node of the query's, of the parents that cover them; the nearest
+            auto seed_level = [&](const unsigned long long* __restrict__ words, const int pdim[3], int shift, const int cdim[3], float E, float h, int out[3]) {
+                int Ls[3], Hs[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { Ls[a] = max((c[a] >> shift) - 1, 0); Hs[a] = min((c[a] >> shift) + 1, cdim[a] - 1); }
+                float best = INFINITY;
+                for (int pz = Ls[2] >> 2; pz <= Hs[2] >> 2; ++pz)
+                    for (int py = Ls[1] >> 2; py <= Hs[1] >> 2; ++py)
+                        for (int px = Ls[0] >> 2; px <= Hs[0] >> 2; ++px) {
+                            const unsigned long long wd = as_global(words)[(static_cast<uint32_t>(pz) * pdim[1] + py) * pdim[0] + px] & nn_range_mask(Ls, Hs, 4 * px, 4 * py, 4 * pz);
+                            ++n_words;
+                            for (unsigned long long m = wd; m != 0ull; m &= m - 1ull) {
+                                const int   bit = __ffsll(m) - 1;
+                                const int   cx = 4 * px + (bit & 3), cy = 4 * py + ((bit >> 2) & 3), cz = 4 * pz + (bit >> 4);
+                                const float lb = nn_child_lb(t, cx, cy, cz, E, h);
+                                if (lb < best) { best = lb; out[0] = cx; out[1] = cy; out[2] = cz; }
+                            }
+                        }
+                return best < INFINITY;
+            };
+            int  br[3] = {0, 0, 0};  // the brick the seed cell is taken from
+            bool seeded = seed_level(g.occ1, d2, 2, d1, E1, h1, br);
+            if (!seeded) {
+                int  sb[3] = {0, 0, 0};
+                bool found = seed_level(g.occ2, d3, 4, d2, E2, h2, sb);
+                ++n_seed2;
+                if (!found) {  // blocks: no word above them, so the 27 around the query's one by one
+                    ++n_seed3;
+                    float best = INFINITY;
+                    int   bk[3] = {0, 0, 0};
+                    for (int kz = max((c[2] >> 6) - 1, 0); kz <= min((c[2] >> 6) + 1, d3[2] - 1); ++kz)
+                        for (int ky = max((c[1] >> 6) - 1, 0); ky <= min((c[1] >> 6) + 1, d3[1] - 1); ++ky)
+                            for (int kx = max((c[0] >> 6) - 1, 0); kx <= min((c[0] >> 6) + 1, d3[0] - 1); ++kx) {
+                                if (as_global(g.occ2)[(static_cast<uint32_t>(kz) * d3[1] + ky) * d3[0] + kx] == 0ull) continue;
+                                const float lb = nn_child_lb(t, kx, ky, kz, E3, h3);
+                                if (lb < best) { best = lb; bk[0] = kx; bk[1] = ky; bk[2] = kz; }
+                            }
+                    if (best < INFINITY) {
+                        nearest_child(as_global(g.occ2)[(static_cast<uint32_t>(bk[2]) * d3[1] + bk[1]) * d3[0] + bk[0]], bk[0], bk[1], bk[2], E2, h2, sb);
+                        found = true;
+                    }
+                }
+                if (found) {
+                    nearest_child(as_global(g.occ1)[(static_cast<uint32_t>(sb[2]) * d2[1] + sb[1]) * d2[0] + sb[0]], sb[0], sb[1], sb[2], E1, h1, br);
+                    seeded = true;
+                }
+            }
+            if (seeded) {
+                int sc[3] = {0, 0, 0};
+                nearest_child(as_global(g.occ)[(static_cast<uint32_t>(br[2]) * d1[1] + br[1]) * d1[0] + br[0]], br[0], br[1], br[2], E0, h0, sc);
+                const uint32_t at = (static_cast<uint32_t>(sc[2]) * d0[1] + sc[1]) * d0[0] + sc[0];
+                const uint32_t kb = as_global(g.cell_start)[at], ke = as_global(g.cell_start)[at + 1];
+                float          best = sqd[off + qi];  // what the block gave (INFINITY: nothing)
+                for (uint32_t kk = kb; kk < ke; ++kk) {
+                    const float4 q = load_point(g.sorted + kk);
+                    best = fminf(best, sqdist3f(q.x, q.y, q.z, x, y, z));
+                }
+                n_points += ke - kb;
+                sqd[off + qi] = best;
+                // the sweep names a brick by its offset from the query's in eight bits per axis: a radius beyond that (60 m at 0.125 m cells: a query
+                // far outside the scene) is left to the pyramid walk, with the seed's distance as its bound
+                if (sqrtf(fminf(best, max_sq_f)) > 118.0f * E1) seeded = false;
+            }
+            if (!seeded) {
+                noseed = true;
+                ++n_noseed;
+                pend[off + k] = qi | kNoSeed;
+            }
+        }
+        const uint64_t m = __ballot(noseed);
+        if (m != 0) {
+            const int leader = __ffsll(static_cast<unsigned long long>(m)) - 1;
+            uint32_t  base = 0;
+            if (lane == leader) base = atomicAdd(&pend2_cnt[blockIdx.y], static_cast<uint32_t>(__popcll(m)));
+            base = __shfl(base, leader);
+            if (noseed) pend2[off + base + static_cast<uint32_t>(__popcll(m & below))] = qi;
+        }
+    }
+    if (stats != nullptr) {
+        const uint32_t v[5] = {wave_sum(n_words), wave_sum(n_points), wave_sum(n_seed2), wave_sum(n_seed3), wave_sum(n_noseed)};
+        if (lane == 0) {
+            const int at[5] = {0, 3, 4, 5, 6};
+            for (int kk = 0; kk < 5; ++kk)
+                if (v[kk]) atomicAdd(&stats[at[kk]], static_cast<unsigned long long>(v[kk]));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void nn_fit_sweep_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range,
+                                                            const uint32_t* __restrict__ pend, const uint32_t* __restrict__ pend_cnt, float* __restrict__ sqd,
+                                                            unsigned long long* __restrict__ stats)
+{
+    const uint32_t np = pend_cnt[blockIdx.y];
+    if (blockIdx.x * kSweepQ >= np) return;
+    __shared__ float    s_q[3][kSweepQ];                    // the transformed queries
+    __shared__ int      s_c[3][kSweepQ];                    // their cells
+    __shared__ int      s_L[3][kSweepQ], s_H[3][kSweepQ];   // the cube of half edge sqrt(lim at seed time), in cells
+    __shared__ uint32_t s_lim[kSweepQ], s_best[kSweepQ];    // float bit patterns (>= 0: ordered like unsigned integers)
+    __shared__ uint32_t s_bl[kSweepBrickCap];               // query | (brick - query's brick + 128) per axis << 8, 16, 24
+    __shared__ uint32_t s_cl[kSweepCellCap];                // query << 24 | cell
+    __shared__ float    s_clb[kSweepCellCap];               // the cell's box distance
     __shared__ uint32_t s_nb, s_nc;
     const NnFitnessJob& J = jobs[blockIdx.y];  // uniform: scalar loads
     const NnGridDev&    g = J.grid.level[0];
     const uint32_t      off = job_off[blockIdx.y];
-    const float         E0 = g.cell, E1 = 4.0f * g.cell, mg = 4.0f * g.slack;
+    const float         E0 = g.cell, E1 = 4.0f * E0, E2 = 16.0f * E0, mg = 4.0f * g.slack;
+    const float         h0 = 0.5f * E0 + mg, h1 = 0.5f * E1 + mg, h2 = 0.5f * E2 + mg;  // half edge plus the margin
+    const float         org[3] = {g.origin[0], g.origin[1], g.origin[2]};
+    const int           d0[3] = {g.dim[0], g.dim[1], g.dim[2]};
     const int           d1[3] = {g.bdim[0], g.bdim[1], g.bdim[2]};
-    const int           gd0 = g.dim[0], gd1 = g.dim[1];
+    const int           d2[3] = {(d1[0] + 3) >> 2, (d1[1] + 3) >> 2, (d1[2] + 3) >> 2};
+    const int           d3[3] = {(d2[0] + 3) >> 2, (d2[1] + 3) >> 2, (d2[2] + 3) >> 2};
     const float         max_sq_f = max_range >= 3.0e38 ? INFINITY : static_cast<float>(max_range) * (1.0f + 1e-6f);
     const int           lane = lane_id();
-    const int           w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-    const uint64_t      below = (1ull << lane) - 1ull;
-    uint32_t            n_words = 0, n_cells = 0, n_points = 0;  // diagnostics (stats != nullptr)
-    NnPyramidQuery      pq;
-    pq.m = mg;
-    // settle(s): shells 0..s are done; a query is finished when everything beyond them is farther than lim, or there is nothing beyond
-    auto settle = [&](int s) {
-        if (threadIdx.x < kShellQ && s_state[threadIdx.x] == 0) {
-            const float b = static_cast<float>(s) * E1 + s_nm[threadIdx.x];
-            if (s_smax[threadIdx.x] <= s || b * b > __uint_as_float(s_lim[threadIdx.x]) * kNnPrune) s_state[threadIdx.x] = 1;
+    const int           tid = static_cast<int>(threadIdx.x);
+    uint32_t            n_words = 0, n_tested = 0, n_cells = 0, n_points = 0, n_bricks = 0, n_listed = 0;  // diagnostics
+    long long           clk[4] = {0, 0, 0, 0}, tick = 0;  // thread 0: shader clocks spent in the four phases
+    auto stamp = [&](int ph) { if (stats != nullptr && threadIdx.x == 0) { const long long now = clock64(); clk[ph] += now - tick; tick = now; } };
+    // every lane of the wavefront asks for `cnt` consecutive slots of a bounded LDS list: returns the lane's first slot; `full` when the list has filled up
+    auto reserve = [&](uint32_t cnt, uint32_t* counter, uint32_t cap, bool& full) -> uint32_t {
+        const uint32_t incl = wave_inclusive_scan(cnt);
+        const uint32_t total = __shfl(incl, kWave - 1);
+        uint32_t       base = 0;
+        if (total != 0) {  // uniform
+            if (lane == kWave - 1) base = atomicAdd(counter, total);
+            base = __shfl(base, kWave - 1);
+            full = full || base + total >= cap;
         }
+        return base + incl - cnt;
     };
-    for (uint32_t k0 = blockIdx.x * kShellQ; k0 < np; k0 += gridDim.x * kShellQ) {
-        // ---- phase 0: the tile's queries
-        if (threadIdx.x < kShellQ) {
-            const uint32_t k = k0 + threadIdx.x;
-            int state = 2;
-            if (k < np) {
-                const uint32_t i = as_global(pend)[off + k];
-                const float4   p = load_point(J.src + i);
-                float x, y, z;
-                transform_point(J.T12, p.x, p.y, p.z, x, y, z);
-                const float bound = sqd[off + i];  // what the block gave (INFINITY: nothing)
-                int c[3];
-                nn_cell_of(g, x, y, z, c);  // queued queries are finite
-                const float t[3] = {x - g.origin[0], y - g.origin[1], z - g.origin[2]};
-                float nm = INFINITY;
-                int   smax = 0;
+    if (stats != nullptr && threadIdx.x == 0) tick = clock64();
+    for (uint32_t k0 = blockIdx.x * kSweepQ; k0 < np; k0 += gridDim.x * kSweepQ) {
+        // ================= the tile's queries (lane = query): lim as the seed left it, the cube it spans =================
+        const uint32_t k = k0 + threadIdx.x;
+        uint32_t qi = 0;
+        bool     mine = false;
+        float    t[3] = {0, 0, 0};
+        int      c[3] = {0, 0, 0}, L[3] = {0, 0, 0}, H[3] = {-1, -1, -1};
+        if (k < np) {
+            qi = as_global(pend)[off + k];
+            mine = (qi & kNoSeed) == 0;
+        }
+        if (mine) {
+            const float4 p = load_point(J.src + qi);
+            float x, y, z;
+            transform_point(J.T12, p.x, p.y, p.z, x, y, z);
+            const float best = sqd[off + qi];  // attained (seed)
+            nn_cell_of(g, x, y, z, c);
+            t[0] = x - org[0];
+            t[1] = y - org[1];
+            t[2] = z - org[2];
+            const float lim = fminf(best, max_sq_f);
+            const float r = sqrtf(lim * kNnPrune) * (1.0f + 1e-6f) + mg;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const int   b = c[a] >> 2;
-                    const float lo = static_cast<float>(b) * E1;
-                    nm = fminf(nm, fminf(t[a] - lo, lo + E1 - t[a]));
-                    smax = max(smax, max(b, d1[a] - 1 - b));
-                    s_t[a][threadIdx.x] = t[a];
-                    s_c[a][threadIdx.x] = c[a];
-                }
-                s_q[0][threadIdx.x] = x;
-                s_q[1][threadIdx.x] = y;
-                s_q[2][threadIdx.x] = z;
-                s_nm[threadIdx.x] = fmaxf(nm - mg, 0.0f);
-                s_smax[threadIdx.x] = smax;
-                s_lim[threadIdx.x] = __float_as_uint(fminf(max_sq_f, bound));
-                s_best[threadIdx.x] = __float_as_uint(bound);
-                s_i[threadIdx.x] = i;
-                state = 0;
+            for (int a = 0; a < 3; ++a) {
+                L[a] = static_cast<int>(fminf(fmaxf(floorf((t[a] - r) / E0), 0.0f), static_cast<float>(d0[a] - 1)));
+                H[a] = static_cast<int>(fminf(fmaxf(floorf((t[a] + r) / E0), 0.0f), static_cast<float>(d0[a] - 1)));
+                s_c[a][tid] = c[a];
+                s_L[a][tid] = L[a];
+                s_H[a][tid] = H[a];
             }
-            s_state[threadIdx.x] = state;
+            s_lim[tid] = __float_as_uint(lim);
+            s_best[tid] = __float_as_uint(best);
+            s_q[0][tid] = x;
+            s_q[1][tid] = y;
+            s_q[2][tid] = z;
         }
         if (threadIdx.x == 0) { s_nb = 0; s_nc = 0; }
         __syncthreads();
-        for (int pass = 0; pass < 5; ++pass) {
-            if (pass == 1) settle(1);
-            if (pass >= 1 && !__syncthreads_or(threadIdx.x < kShellQ && s_state[threadIdx.x] == 0)) break;
-            const int first = pass * static_cast<int>(kShellNodes), last = min(first + static_cast<int>(kShellNodes), 125);
-            // ---- phase 1: lane = query, node uniform per wavefront
-            {
-                const bool act = s_state[lane] == 0;
-                const int  b[3] = {s_c[0][lane] >> 2, s_c[1][lane] >> 2, s_c[2][lane] >> 2};
-                pq.t[0] = s_t[0][lane];
-                pq.t[1] = s_t[1][lane];
-                pq.t[2] = s_t[2][lane];
-                const float lim = __uint_as_float(s_lim[lane]) * kNnPrune;
-                const float e1 = E1 + s_nm[lane], cls = e1 * e1;  // a shell-2 node with k coordinates at +-2 is at least sqrt(k) e1 away
-                constexpr int U = (kShellNodes + 3) / 4;
-                unsigned long long wd[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    wd[u] = 0ull;
-                    const int node = first + w + 4 * u;
-                    if (node >= last) continue;  // uniform
-                    int d[3];
-                    nn_small_shell_pos(node, d);
-                    const float kmin = node < 27 ? 0.0f : (node < 27 + 54 ? 1.0f : (node < 27 + 90 ? 2.0f : 3.0f));
-                    const int   nx = b[0] + d[0], ny = b[1] + d[1], nz = b[2] + d[2];
-                    if (!act || kmin * cls > lim || nx < 0 || nx >= d1[0] || ny < 0 || ny >= d1[1] || nz < 0 || nz >= d1[2]) continue;
-                    float lb2, ub2;
-                    pq.box(E1, nx, ny, nz, lb2, ub2);
-                    if (lb2 <= lim) {
-                        wd[u] = as_global(g.occ)[(static_cast<uint32_t>(nz) * d1[1] + ny) * d1[0] + nx];
+        stamp(0);
+        // ================= bricks (lane = query): blocks -> super-bricks -> bricks of the cube =================
+        const int L1[3] = {L[0] >> 2, L[1] >> 2, L[2] >> 2}, H1[3] = {H[0] >> 2, H[1] >> 2, H[2] >> 2};
+        const int L2[3] = {L[0] >> 4, L[1] >> 4, L[2] >> 4}, H2[3] = {H[0] >> 4, H[1] >> 4, H[2] >> 4};
+        int  kx = L[0] >> 6, ky = L[1] >> 6, kz = L[2] >> 6;  // next block to load
+        bool blocks_left = mine;
+        bool act = mine;
+        unsigned long long m2 = 0ull, m1p = 0ull;  // super-bricks of the current block still to visit / bricks of the current super-brick still to list
+        int  s2[3] = {0, 0, 0}, s1[3] = {0, 0, 0};  // first super-brick of the block m2 belongs to / first brick of the super-brick m1p belongs to
+        for (;;) {
+            bool full = false;
+            while (!full && __ballot(act)) {  // uniform: every lane of the wavefront stays in the loop
+                if (act && m1p == 0ull) {  // next super-brick of the cube that reaches into the sphere: its bricks that do
+                    const float lim = __uint_as_float(s_lim[tid]) * kNnPrune;
+                    while (m2 == 0ull && blocks_left) {
+                        s2[0] = 4 * kx;
+                        s2[1] = 4 * ky;
+                        s2[2] = 4 * kz;
+                        m2 = as_global(g.occ2)[(static_cast<uint32_t>(kz) * d3[1] + ky) * d3[0] + kx] & nn_range_mask(L2, H2, s2[0], s2[1], s2[2]);
                         ++n_words;
+                        if (++kx > (H[0] >> 6)) {
+                            kx = L[0] >> 6;
+                            if (++ky > (H[1] >> 6)) {
+                                ky = L[1] >> 6;
+                                if (++kz > (H[2] >> 6)) blocks_left = false;
+                            }
+                        }
+                    }
+                    if (m2 == 0ull) {
+                        act = false;
+                    } else {
+                        const int bit = __ffsll(m2) - 1;
+                        m2 &= m2 - 1ull;
+                        const int sx = s2[0] + (bit & 3), sy = s2[1] + ((bit >> 2) & 3), sz = s2[2] + (bit >> 4);
+                        ++n_tested;
+                        if (nn_child_lb(t, sx, sy, sz, E2, h2) <= lim) {
+                            s1[0] = 4 * sx;
+                            s1[1] = 4 * sy;
+                            s1[2] = 4 * sz;
+                            ++n_words;
+                            for (unsigned long long m1 = as_global(g.occ1)[(static_cast<uint32_t>(sz) * d2[1] + sy) * d2[0] + sx] & nn_range_mask(L1, H1, s1[0], s1[1], s1[2]); m1 != 0ull; m1 &= m1 - 1ull) {
+                                const int b1 = __ffsll(m1) - 1;
+                                ++n_tested;
+                                if (nn_child_lb(t, s1[0] + (b1 & 3), s1[1] + ((b1 >> 2) & 3), s1[2] + (b1 >> 4), E1, h1) <= lim) m1p |= 1ull << b1;
+                            }
+                        }
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const bool     push = wd[u] != 0ull;
-                    const uint64_t m = __ballot(push);
-                    if (m == 0) continue;  // uniform
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&s_nb, static_cast<uint32_t>(__popcll(m)));
-                    base = __shfl(base, 0);
-                    if (push) {
-                        const uint32_t slot = base + static_cast<uint32_t>(__popcll(m & below));
-                        s_bmeta[slot] = static_cast<uint16_t>(static_cast<uint32_t>(lane) | static_cast<uint32_t>(first + w + 4 * u) << 8);
-                        s_bword[slot] = wd[u];
-                    }
+                uint32_t slot = reserve(static_cast<uint32_t>(__popcll(m1p)), &s_nb, kSweepBrickCap, full);
+                for (; m1p != 0ull && slot < kSweepBrickCap; ++slot) {  // what does not fit stays in m1p for the next round
+                    const int b1 = __ffsll(m1p) - 1;
+                    m1p &= m1p - 1ull;
+                    const int bx = s1[0] + (b1 & 3), by = s1[1] + ((b1 >> 2) & 3), bz = s1[2] + (b1 >> 4);
+                    s_bl[slot] = static_cast<uint32_t>(tid) | static_cast<uint32_t>(bx - (c[0] >> 2) + 128) << 8 | static_cast<uint32_t>(by - (c[1] >> 2) + 128) << 16 |
+                                 static_cast<uint32_t>(bz - (c[2] >> 2) + 128) << 24;  // offsets fit: the seed kernel kept wider cubes out
                 }
             }
             __syncthreads();
-            // ---- phases 2 and 3, alternating while the cell list fills up
-            const uint32_t nb = s_nb;
-            uint32_t       e = threadIdx.x;
-            bool           have = e < nb;
-            uint32_t       meta = 0;
-            unsigned long long bits = 0ull;
-            if (have) { meta = s_bmeta[e]; bits = s_bword[e]; }
+            stamp(1);
+            // ================= cells (lane = brick list entry) and points (lane = cell list entry) =================
+            const uint32_t nb = min(s_nb, kSweepBrickCap);
+            if (threadIdx.x == 0) n_bricks += nb;
+            // a lane's entries (its stride of the list: at most four) are independent: their occupancy words are requested together
+            constexpr int kEnt = kSweepBrickCap / 256;
+            uint32_t           ent[kEnt];
+            unsigned long long wrd[kEnt];
+            int                n_ent = 0, u_ent = 0;
+#pragma unroll
+            for (int u = 0; u < kEnt; ++u) {
+                const uint32_t e = threadIdx.x + 256u * u;
+                ent[u] = 0;
+                wrd[u] = 0ull;
+                if (e >= nb) continue;
+                n_ent = u + 1;
+                const uint32_t it = s_bl[e];
+                const int      qq = static_cast<int>(it & 0xffu);
+                ent[u] = it;
+                wrd[u] = as_global(g.occ)[(static_cast<uint32_t>((s_c[2][qq] >> 2) + static_cast<int>(it >> 24) - 128) * d1[1] + ((s_c[1][qq] >> 2) + static_cast<int>((it >> 16) & 0xffu) - 128)) * d1[0] +
+                                          ((s_c[0][qq] >> 2) + static_cast<int>((it >> 8) & 0xffu) - 128)];
+                ++n_words;
+            }
+            unsigned long long m0p = 0ull;  // cells of the current entry still to list
+            int                q = 0, o0[3] = {0, 0, 0};  // the entry's query and the brick's first cell
+            float              tq[3] = {0, 0, 0};
             for (;;) {
-                bool full = false;
-                while (!full && __ballot(have)) {  // uniform: every lane of the wavefront stays in the loop
-                    bool     push = false;
-                    uint32_t cm = 0;
-                    float    clb = 0.0f;
-                    if (have) {
-                        const int q = static_cast<int>(meta & 0xffu);
-                        int d[3];
-                        nn_small_shell_pos(static_cast<int>(meta >> 8), d);
-                        const int bit = __ffsll(bits) - 1;
-                        const int c0 = s_c[0][q], c1 = s_c[1][q], c2 = s_c[2][q];
-                        const int cx = ((c0 >> 2) + d[0]) * 4 + (bit & 3), cy = ((c1 >> 2) + d[1]) * 4 + ((bit >> 2) & 3), cz = ((c2 >> 2) + d[2]) * 4 + (bit >> 4);
-                        pq.t[0] = s_t[0][q];
-                        pq.t[1] = s_t[1][q];
-                        pq.t[2] = s_t[2][q];
-                        float lb2, ub2;
-                        pq.box(E0, cx, cy, cz, lb2, ub2);
-                        float lim = __uint_as_float(s_lim[q]);
-                        const float ub = ub2 * kNnPrune;  // an occupied cell: something is no farther than its far corner
-                        if (ub < lim) { atomicMin(&s_lim[q], __float_as_uint(ub)); lim = ub; }
-                        const bool in_block = cx - c0 >= -1 && cx - c0 <= 1 && cy - c1 >= -1 && cy - c1 <= 1 && cz - c2 >= -1 && cz - c2 <= 1;  // the block pass did these
-                        push = !in_block && lb2 <= lim * kNnPrune;
-                        cm = static_cast<uint32_t>(q) << 24 | ((static_cast<uint32_t>(cz) * gd1 + cy) * gd0 + cx);
-                        clb = lb2;
-                    }
-                    const uint64_t m = __ballot(push);
-                    bool           stalled = false;
-                    if (m != 0) {  // uniform
-                        uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(&s_nc, static_cast<uint32_t>(__popcll(m)));
-                        base = __shfl(base, 0);
-                        if (push) {
-                            const uint32_t slot = base + static_cast<uint32_t>(__popcll(m & below));
-                            if (slot < kShellCellCap) { s_cmeta[slot] = cm; s_clb[slot] = clb; }
-                            else stalled = true;  // list full: this cell again after phase 3 has emptied it
+                bool cfull = false;
+                while (!cfull && __ballot(m0p != 0ull || u_ent < n_ent)) {  // uniform
+                    if (m0p == 0ull && u_ent < n_ent) {  // next entry: the brick's cells inside the cube, outside the query's own block, reaching into the sphere
+                        uint32_t           it = ent[0];
+                        unsigned long long w0 = wrd[0];
+#pragma unroll
+                        for (int u = 1; u < kEnt; ++u)
+                            if (u == u_ent) { it = ent[u]; w0 = wrd[u]; }
+                        ++u_ent;
+                        q = static_cast<int>(it & 0xffu);
+                        const int cq[3] = {s_c[0][q], s_c[1][q], s_c[2][q]};
+                        o0[0] = 4 * ((cq[0] >> 2) + static_cast<int>((it >> 8) & 0xffu) - 128);
+                        o0[1] = 4 * ((cq[1] >> 2) + static_cast<int>((it >> 16) & 0xffu) - 128);
+                        o0[2] = 4 * ((cq[2] >> 2) + static_cast<int>(it >> 24) - 128);
+                        const int Lq[3] = {s_L[0][q], s_L[1][q], s_L[2][q]}, Hq[3] = {s_H[0][q], s_H[1][q], s_H[2][q]};
+                        const int bl[3] = {cq[0] - 1, cq[1] - 1, cq[2] - 1}, bh[3] = {cq[0] + 1, cq[1] + 1, cq[2] + 1};  // the query's own block: done
+                        tq[0] = s_q[0][q] - org[0];
+                        tq[1] = s_q[1][q] - org[1];
+                        tq[2] = s_q[2][q] - org[2];
+                        const float lim = __uint_as_float(s_lim[q]) * kNnPrune;
+                        for (unsigned long long m0 = w0 & nn_range_mask(Lq, Hq, o0[0], o0[1], o0[2]) & ~nn_range_mask(bl, bh, o0[0], o0[1], o0[2]); m0 != 0ull; m0 &= m0 - 1ull) {
+                            const int b0 = __ffsll(m0) - 1;
+                            ++n_tested;
+                            if (nn_child_lb(tq, o0[0] + (b0 & 3), o0[1] + ((b0 >> 2) & 3), o0[2] + (b0 >> 4), E0, h0) <= lim) m0p |= 1ull << b0;
                         }
-                        full = base + static_cast<uint32_t>(__popcll(m)) >= kShellCellCap;
                     }
-                    if (have && !stalled) {
-                        bits &= bits - 1ull;
-                        if (bits == 0ull) {
-                            e += 256u;
-                            have = e < nb;
-                            if (have) { meta = s_bmeta[e]; bits = s_bword[e]; }
+                    uint32_t slot = reserve(static_cast<uint32_t>(__popcll(m0p)), &s_nc, kSweepCellCap, cfull);
+                    for (; m0p != 0ull && slot < kSweepCellCap; ++slot) {  // what does not fit stays in m0p until the points phase has emptied the list
+                        const int b0 = __ffsll(m0p) - 1;
+                        m0p &= m0p - 1ull;
+                        const int cx = o0[0] + (b0 & 3), cy = o0[1] + ((b0 >> 2) & 3), cz = o0[2] + (b0 >> 4);
+                        s_cl[slot] = static_cast<uint32_t>(q) << 24 | ((static_cast<uint32_t>(cz) * d0[1] + cy) * d0[0] + cx);
+                        s_clb[slot] = nn_child_lb(tq, cx, cy, cz, E0, h0);
+                    }
+                }
+                __syncthreads();
+                stamp(2);
+                const uint32_t nc = min(s_nc, kSweepCellCap);
+                if (threadIdx.x == 0) n_listed += nc;
+                {
+                    // a lane's entries are independent: the table reads of all of them go out together, then their points (the phase is a chain of
+                    // two memory round trips per entry otherwise, eight entries deep)
+                    constexpr int U = kSweepCellCap / 256;
+                    uint32_t kb[U], ke[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t j = threadIdx.x + 256u * u;
+                        kb[u] = ke[u] = 0;
+                        if (j >= nc) continue;
+                        const uint32_t cj = s_cl[j];
+                        if (s_clb[j] > __uint_as_float(s_lim[cj >> 24]) * kNnPrune) continue;  // lim has moved since the cell was listed
+                        const uint32_t at = cj & 0xffffffu;
+                        kb[u] = as_global(g.cell_start)[at];
+                        ke[u] = as_global(g.cell_start)[at + 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (kb[u] == ke[u]) continue;
+                        const int   qj = static_cast<int>(s_cl[threadIdx.x + 256u * u] >> 24);
+                        const float x = s_q[0][qj], y = s_q[1][qj], z = s_q[2][qj];
+                        float       dm = INFINITY;
+                        uint32_t    kk = kb[u];
+                        for (; kk + 4 <= ke[u]; kk += 4) {  // four loads in flight
+                            const float4 p0 = load_point(g.sorted + kk), p1 = load_point(g.sorted + kk + 1), p2 = load_point(g.sorted + kk + 2), p3 = load_point(g.sorted + kk + 3);
+                            dm = fminf(fminf(dm, sqdist3f(p0.x, p0.y, p0.z, x, y, z)), sqdist3f(p1.x, p1.y, p1.z, x, y, z));
+                            dm = fminf(fminf(dm, sqdist3f(p2.x, p2.y, p2.z, x, y, z)), sqdist3f(p3.x, p3.y, p3.z, x, y, z));
+                        }
+                        for (; kk < ke[u]; ++kk) {
+                            const float4 pt = load_point(g.sorted + kk);
+                            dm = fminf(dm, sqdist3f(pt.x, pt.y, pt.z, x, y, z));
+                        }
+                        ++n_cells;
+                        n_points += ke[u] - kb[u];
+                        if (dm < __uint_as_float(s_lim[qj])) {
+                            atomicMin(&s_best[qj], __float_as_uint(dm));
+                            atomicMin(&s_lim[qj], __float_as_uint(dm));
                         }
                     }
                 }
                 __syncthreads();
-                const uint32_t nc = min(s_nc, kShellCellCap);
-                for (uint32_t j = threadIdx.x; j < nc; j += 256u) {
-                    const uint32_t cmj = s_cmeta[j];
-                    const int      q = static_cast<int>(cmj >> 24);
-                    const float    lim = __uint_as_float(s_lim[q]);
-                    if (s_clb[j] > lim * kNnPrune) continue;  // lim has moved since the cell was listed
-                    const uint32_t at = cmj & 0xffffffu;
-                    const uint32_t kb = as_global(g.cell_start)[at], ke = as_global(g.cell_start)[at + 1];
-                    const float    x = s_q[0][q], y = s_q[1][q], z = s_q[2][q];
-                    float          dm = INFINITY;
-                    for (uint32_t k = kb; k < ke; ++k) {
-                        const float4 p = load_point(g.sorted + k);
-                        dm = fminf(dm, sqdist3f(p.x, p.y, p.z, x, y, z));
-                    }
-                    ++n_cells;
-                    n_points += ke - kb;
-                    if (dm < lim) {
-                        atomicMin(&s_best[q], __float_as_uint(dm));
-                        atomicMin(&s_lim[q], __float_as_uint(dm));
-                    }
-                }
-                __syncthreads();
+                stamp(3);
                 if (threadIdx.x == 0) s_nc = 0;
-                if (!__syncthreads_or(have)) break;
+                if (!__syncthreads_or(m0p != 0ull || u_ent < n_ent)) break;
             }
             if (threadIdx.x == 0) s_nb = 0;
-            // (the barrier at the head of the next pass, or the one below, orders this reset and the lists' reuse)
+            if (!__syncthreads_or(act)) break;
         }
-        __syncthreads();
-        settle(2);
-        // ---- results: settled queries get their distance, the others go on to the super-brick walk with what is known so far
-        if (threadIdx.x < kShellQ) {  // wavefront 0
-            const int   state = s_state[threadIdx.x];
-            const float best = __uint_as_float(s_best[threadIdx.x]);
-            const bool  on = state == 0;
-            if (state == 1) sqd[off + s_i[threadIdx.x]] = static_cast<double>(best) <= max_range ? best : kFitNone;
-            if (on) sqd[off + s_i[threadIdx.x]] = best;
-            const uint64_t m = __ballot(on);
-            if (m != 0) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&pend2_cnt[blockIdx.y], static_cast<uint32_t>(__popcll(m)));
-                base = __shfl(base, 0);
-                if (on) pend2[off + base + static_cast<uint32_t>(__popcll(m & below))] = s_i[threadIdx.x];
-            }
+        // ================= results =================
+        if (mine) {
+            const float best = __uint_as_float(s_best[tid]);
+            sqd[off + qi] = static_cast<double>(best) <= max_range ? best : kFitNone;
         }
         __syncthreads();
     }
     if (stats != nullptr) {
-        __shared__ uint32_t s_st[3][4];
-        const uint32_t a = wave_sum(n_words), b = wave_sum(n_cells), c = wave_sum(n_points);
-        if (lane == 0) { s_st[0][w] = a; s_st[1][w] = b; s_st[2][w] = c; }
-        __syncthreads();
-        if (threadIdx.x < 3) atomicAdd(&stats[threadIdx.x], static_cast<unsigned long long>(s_st[threadIdx.x][0]) + s_st[threadIdx.x][1] + s_st[threadIdx.x][2] + s_st[threadIdx.x][3]);
+        const uint32_t v[6] = {wave_sum(n_words), wave_sum(n_tested), wave_sum(n_cells), wave_sum(n_points), wave_sum(n_bricks), wave_sum(n_listed)};
+        if (lane == 0) {
+            const int at[6] = {0, 1, 2, 3, 7, 8};
+            for (int kk = 0; kk < 6; ++kk)
+                if (v[kk]) atomicAdd(&stats[at[kk]], static_cast<unsigned long long>(v[kk]));
+        }
+        if (threadIdx.x == 0)
+            for (int kk = 0; kk < 4; ++kk) atomicAdd(&stats[9 + kk], static_cast<unsigned long long>(clk[kk]));
     }
 }
 
@@ -634,12 +834,10 @@ __global__ __launch_bounds__(256) void nn_fit_shell_kernel(const NnFitnessJob* _
 #define MRGFE_FAR_GROUP 2
 #endif
 constexpr int kFarGroup = MRGFE_FAR_GROUP;  // lanes per query in the far pass
-// The rest of the far pass: one lane group per queued query, the occupancy pyramid walked as nn_pyramid_walk describes.  kSkipBricks:
-// the queue is nn_fit_shell_kernel's — the bricks within two shells are done, the walk starts at the super-bricks (false: round 2's
-// single far pass, kept for MRGFE_FIT_SHELL=0 and as the reference the shell pass is tested against).
+// The pyramid walk of nn_device.h, one lane group per queued query: round 2's far pass.  It takes what nn_fit_sweep_kernel could not
+// seed (nothing within three blocks), or the whole queue with MRGFE_FIT_SWEEP=0 (the reference the sweep is tested against).
 // (Measured and dropped: two queues per job — queries the block gave a first distance from the front, queries with nothing around
 // them from the back — so that a wavefront of the far pass holds walks of one kind: far 19.5 -> 19.3 ms, block 2.7 -> 2.9 ms.)
-template <bool kSkipBricks>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void nn_fit_far_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range, const uint32_t* __restrict__ pend,
                                                           const uint32_t* __restrict__ pend_cnt, float* __restrict__ sqd)
 {
@@ -659,7 +857,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
         const float bound = sqd[off + i];  // what the earlier passes gave
         int32_t bpos;
         float   bd;
-        nn_far_search<kFarGroup, kSkipBricks>(s_job.grid, x, y, z, sub, max_range, bound, bpos, bd);
+        nn_far_search<kFarGroup>(s_job.grid, x, y, z, sub, max_range, bound, bpos, bd);
         bd = fminf(bd, bound);
         if (sub == 0) sqd[off + i] = static_cast<double>(bd) <= max_range ? bd : kFitNone;
     }
@@ -711,17 +909,17 @@ __global__ __launch_bounds__(256) void nn_fitness_final_kernel(const double* __r
     }
 }
 
-static std::atomic<int> g_fit_shell{-1};  // -1: not read yet
-static int fit_shell_mode()
+static std::atomic<int> g_fit_sweep{-1};  // -1: not read yet
+static int fit_sweep_mode()
 {
-    int v = g_fit_shell.load(std::memory_order_relaxed);
-    if (v < 0) { const char* e = std::getenv("MRGFE_FIT_SHELL"); v = e ? (std::atoi(e) != 0 ? 1 : 0) : 1; g_fit_shell.store(v, std::memory_order_relaxed); }
+    int v = g_fit_sweep.load(std::memory_order_relaxed);
+    if (v < 0) { const char* e = std::getenv("MRGFE_FIT_SWEEP"); v = e ? (std::atoi(e) != 0 ? 1 : 0) : 1; g_fit_sweep.store(v, std::memory_order_relaxed); }
     return v;
 }
-int nn_set_fit_shell(int mode)
+int nn_set_fit_sweep(int mode)
 {
-    if (mode == 0 || mode == 1) g_fit_shell.store(mode, std::memory_order_relaxed);
-    return fit_shell_mode();
+    if (mode == 0 || mode == 1) g_fit_sweep.store(mode, std::memory_order_relaxed);
+    return fit_sweep_mode();
 }
 static int fit_stats_mode() { static const int v = [] { const char* e = std::getenv("MRGFE_FIT_STATS"); return e ? std::atoi(e) : 0; }(); return v; }
 
@@ -748,38 +946,38 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     // scratch 9: jobs, offsets, queue lengths, counters, partial sums; 12: one float per query; 13: the two queues (10 and 11 may
     // hold the caller's clouds, see mrgfe_calc_fitness_score)
     DevBuf &dw = ctx->scratch[9], &dq = ctx->scratch[12], &dp = ctx->scratch[13];
+    constexpr size_t kStatBytes = sizeof(unsigned long long) * kSweepStats;
     const size_t jobs_bytes = (sizeof(NnFitnessJob) * count + 255) & ~size_t(255);
-    const size_t off_bytes = (sizeof(uint32_t) * 3 * (count + 1) + 64 + 255) & ~size_t(255);
+    const size_t off_bytes = (sizeof(uint32_t) * 3 * (count + 1) + 8 + kStatBytes + 255) & ~size_t(255);
     MRGFE_TRY(dw.ensure(jobs_bytes + off_bytes + sizeof(double) * 2 * (size_t(nblk_sum) + 1) * count));
     MRGFE_TRY(dq.ensure(sizeof(float) * total));
     MRGFE_TRY(dp.ensure(sizeof(uint32_t) * 2 * total));
     NnFitnessJob* d_jobs = dw.as<NnFitnessJob>();
     uint32_t*     d_off = reinterpret_cast<uint32_t*>(dw.as<char>() + jobs_bytes);
-    uint32_t*     d_cnt = d_off + count + 1;   // queue lengths: after the block pass
-    uint32_t*     d_cnt2 = d_cnt + count + 1;  // ... after the brick-shell pass
-    unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(dw.as<char>() + jobs_bytes + off_bytes - 64);  // 4 counters, 8-byte aligned
+    uint32_t*     d_cnt = d_off + count + 1;  // queue lengths after the block pass and after the sweep: [2][count + 1]
+    unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(dw.as<char>() + jobs_bytes + off_bytes - kStatBytes);  // 8-byte aligned
     double*       d_part = reinterpret_cast<double*>(dw.as<char>() + jobs_bytes + off_bytes);
     double*       d_res = d_part + 2 * size_t(nblk_sum) * count;
-    uint32_t*     d_pend = dp.as<uint32_t>();
-    uint32_t*     d_pend2 = d_pend + total;
-    const bool    shell = fit_shell_mode() != 0, counters = fit_stats_mode() != 0;
+    uint32_t*     d_pend[2] = {dp.as<uint32_t>(), dp.as<uint32_t>() + total};
+    uint32_t*     d_cnts[2] = {d_cnt, d_cnt + (count + 1)};
+    const bool    sweep = fit_sweep_mode() != 0, counters = fit_stats_mode() != 0;
     for (auto& e : ctx->ev_fit)
         if (!e) MRGFE_HIP_CHECK(hipEventCreate(&e));
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_jobs, jobs, sizeof(NnFitnessJob) * count, hipMemcpyHostToDevice, st));
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_off, off.data(), sizeof(uint32_t) * (count + 1), hipMemcpyHostToDevice, st));
-    MRGFE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, off_bytes - sizeof(uint32_t) * (count + 1), st));  // both queue lengths and the counters behind them
+    MRGFE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, off_bytes - sizeof(uint32_t) * (count + 1), st));  // the queue lengths and the counters behind them
     const dim3 grid(nblk, static_cast<uint32_t>(count));
     MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[0], st));
-    hipLaunchKernelGGL(nn_fit_block_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, dq.as<float>(), d_pend, d_cnt);
+    hipLaunchKernelGGL(nn_fit_block_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, dq.as<float>(), d_pend[0], d_cnts[0]);
     MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[1], st));
-    if (shell) {
-        // 64 queries per tile: as many workgroups as the block pass has, walking the queue on their stride
-        hipLaunchKernelGGL(nn_fit_shell_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend, d_cnt, dq.as<float>(), d_pend2, d_cnt2, counters ? d_stats : nullptr);
+    if (sweep) {
+        hipLaunchKernelGGL(nn_fit_seed_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), d_pend[1], d_cnts[1], counters ? d_stats : nullptr);
+        hipLaunchKernelGGL(nn_fit_sweep_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), counters ? d_stats : nullptr);
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[2], st));
-        hipLaunchKernelGGL(nn_fit_far_kernel<true>, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend2, d_cnt2, dq.as<float>());
+        hipLaunchKernelGGL(nn_fit_far_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[1], d_cnts[1], dq.as<float>());
     } else {
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[2], st));
-        hipLaunchKernelGGL(nn_fit_far_kernel<false>, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend, d_cnt, dq.as<float>());
+        hipLaunchKernelGGL(nn_fit_far_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>());
     }
     MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[3], st));
     hipLaunchKernelGGL(nn_fit_sum_kernel, dim3(nblk_sum, static_cast<uint32_t>(count)), dim3(256), 0, st, d_jobs, d_off, dq.as<float>(), d_part);
@@ -787,7 +985,7 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     MRGFE_HIP_CHECK(hipGetLastError());
     std::vector<double>   res(2 * count);
     std::vector<uint32_t> cnts(2 * (count + 1));
-    unsigned long long    h_stats[4] = {0, 0, 0, 0};
+    unsigned long long    h_stats[kSweepStats] = {0};
     MRGFE_HIP_CHECK(hipMemcpyAsync(res.data(), d_res, sizeof(double) * 2 * count, hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipMemcpyAsync(cnts.data(), d_cnt, sizeof(uint32_t) * 2 * (count + 1), hipMemcpyDeviceToHost, st));
     if (counters) MRGFE_HIP_CHECK(hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, st));
@@ -798,15 +996,21 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     float ms[3] = {0, 0, 0};
     for (int k = 0; k < 3; ++k) (void)hipEventElapsedTime(&ms[k], ctx->ev_fit[k], ctx->ev_fit[k + 1]);
     fs.ms_block = ms[0];
-    fs.ms_shell = ms[1];
+    fs.ms_sweep = ms[1];
     fs.ms_far = ms[2];
     fs.queries = total;
     fs.queued = fs.queued_far = 0;
-    for (size_t j = 0; j < count; ++j) { fs.queued += cnts[j]; fs.queued_far += shell ? cnts[count + 1 + j] : cnts[j]; }
+    for (size_t j = 0; j < count; ++j) { fs.queued += cnts[j]; fs.queued_far += sweep ? cnts[count + 1 + j] : cnts[j]; }
     fs.words = h_stats[0];
-    fs.cells = h_stats[1];
-    fs.points = h_stats[2];
+    fs.tested = h_stats[1];
+    fs.cells = h_stats[2];
+    fs.points = h_stats[3];
     ++fs.calls;
+    if (counters && fit_stats_mode() > 1)
+        std::fprintf(stderr, "[mrgfe] fitness sweep: %llu queued, %llu words, %llu boxes tested, %llu brick entries, %llu cells listed, %llu opened, %llu points; seeds from super-bricks %llu, "
+                             "from blocks %llu, none %llu; clocks (thread 0 of every workgroup) seed / bricks / cells / points: %llu %llu %llu %llu\n",
+                     static_cast<unsigned long long>(fs.queued), h_stats[0], h_stats[1], h_stats[7], h_stats[8], h_stats[2], h_stats[3], h_stats[4], h_stats[5], h_stats[6], h_stats[9], h_stats[10],
+                     h_stats[11], h_stats[12]);
     return MRGFE_OK;
 }
 

@@ -1,5 +1,5 @@
-"""GPU: getFitnessScore's passes (block -> brick shells as flat work items -> pyramid walk from the super-bricks) give the exact
-nearest distances: equal to round 2's single far pass, to the brute-force oracle, and independent of where a query is settled.
+"""GPU: getFitnessScore's passes (block -> seed + sweep -> pyramid walk of the unseeded rest) give the exact nearest distances: equal
+to round 2's pyramid walk for every queued query, to the brute-force oracle, and independent of where a query is settled.
 Reference: pcl::Registration::getFitnessScore as called at src/mrg_slam/loop_detector.cpp:137 (max_range = inf there)."""
 import numpy as np
 import pytest
@@ -9,17 +9,17 @@ from conftest import small_cloud
 pytestmark = pytest.mark.gpu
 
 
-def _set_shell(mode):
+def _set_sweep(mode):
     from mrg_slam_amd._lib import lib
 
-    return lib().mrgfe_dbg_set_fit_shell(mode)
+    return lib().mrgfe_dbg_set_fit_sweep(mode)
 
 
 @pytest.fixture()
-def shell_mode():
-    before = _set_shell(-1)
+def sweep_mode():
+    before = _set_sweep(-1)
     yield
-    _set_shell(before)
+    _set_sweep(before)
 
 
 def _clouds(seed):
@@ -42,7 +42,7 @@ def _clouds(seed):
 
 
 @pytest.mark.parametrize("max_range", [float("inf"), 4.0, 0.04])
-def test_shell_pass_equals_single_far_pass_and_oracle(shell_mode, max_range):
+def test_sweep_equals_pyramid_walk_and_oracle(sweep_mode, max_range):
     from mrg_slam_amd import default_context
     from mrg_slam_amd.filters import calc_fitness_score
     from oracle import oracle as orc
@@ -51,7 +51,7 @@ def test_shell_pass_equals_single_far_pass_and_oracle(shell_mode, max_range):
     ctx_stats = []
     got = {}
     for mode in (1, 0):
-        assert _set_shell(mode) == mode
+        assert _set_sweep(mode) == mode
         vals = []
         for s in srcs:
             vals.append(calc_fitness_score(tgt, s, np.eye(4), max_range))
@@ -64,9 +64,9 @@ def test_shell_pass_equals_single_far_pass_and_oracle(shell_mode, max_range):
     assert ctx_stats[0]["queued"] >= ctx_stats[0]["queued_far"]
 
 
-def test_batched_jobs_and_sparse_targets(shell_mode):
-    """Many jobs in one launch (ragged sizes, one empty source), a target so sparse that nearly every query leaves the brick shells,
-    and a tiny target: every score equals the other mode's and the oracle's."""
+def test_batched_jobs_and_sparse_targets(sweep_mode):
+    """Many jobs in one launch (ragged sizes), a target so sparse that most seeds come from the super-brick and block levels (some
+    queries find none and take the pyramid walk), and a tiny target: every score equals the other mode's and the oracle's."""
     from mrg_slam_amd import BatchMatcher
     from oracle import oracle as orc
 
@@ -80,7 +80,7 @@ def test_batched_jobs_and_sparse_targets(shell_mode):
     srcs = [small_cloud(3000 + 777 * k, 40 + k, extent=(30.0, 30.0, 3.0)) for k in range(7)]
     res = {}
     for mode in (1, 0):
-        assert _set_shell(mode) == mode
+        assert _set_sweep(mode) == mode
         bm = BatchMatcher(transformation_epsilon=0.1, maximum_iterations=1)
         tids = [bm.add_target(t) for t in targets]
         for k, s in enumerate(srcs):
