@@ -296,13 +296,16 @@ def main():
         have = [i for i in range(n_pairs) if not fake_world or i in set(mine.tolist())]
         err = [float(np.linalg.norm(result_matrix(full[i])[:3, 3] - loop_pairs[i][3][:3, 3])) for i in have]
         digest = __import__("hashlib").sha256(full["T"].tobytes() + full["fitness"].tobytes() + full["converged"].tobytes()).hexdigest()[:16]
+        # the records are a function of the inputs: the synthetic scans are ray-cast with numpy on the host (its SIMD paths differ from CPU to CPU
+        # in the last bit), so the digest of the inputs goes with the digest of the records
+        in_digest = __import__("hashlib").sha256(b"".join(np.ascontiguousarray(c).tobytes() for c in l_host)).hexdigest()[:16]
         return {"pairs_total": n_pairs, "new_keyframes": len(groups), "pairs_per_gpu": int(len(mine)), "targets_built_per_gpu": len(my_targets),
                 "steps": steps, "ms_per_step": 1e3 * elapsed / steps, "alignments_per_s": n_pairs * steps / elapsed, "scaling": "strong",
                 "projected_for_gpus": fake_world or None,
                 "fitness_max_range": "inf", "converged": int(full["converged"].sum()), "matched_keyframes": int(sum(b[0] is not None for b in best.values())),
                 "median_translation_error_vs_truth_m": float(np.median(err)), "mean_iterations": float(full["iterations"][have].mean()),
-                "mean_points_per_scan": float(np.mean([len(s) for s in l_host])), "records_sha256_16": digest, "per_step_ms": [round(v, 2) for v in step_ms],
-                "fitness_passes_last_step": ctx.fitness_stats()}
+                "mean_points_per_scan": float(np.mean([len(s) for s in l_host])), "records_sha256_16": digest, "inputs_sha256_16": in_digest, "per_step_ms": [round(v, 2) for v in step_ms],
+                "fitness_passes_last_step": bm.fitness_stats()}
 
     if args.mode == "shard":
         r = run_shard(args.steps, args.warmup)

@@ -342,6 +342,9 @@ int  mrgfe_reg_kernel_stats(const mrgfe_reg* reg, int mode, double* deriv_ms, in
 /* source points and valid (point, voxel) pairs of the derivative evaluations the last mrgfe_batch_align launched: their ratio
  * is the k-bar of SURVEY.md §8(d) (evaluations answered from a controller's cache are not launched and not counted) */
 int  mrgfe_batch_pair_counts(const mrgfe_batch* b, int mode, double* points, double* neighbours);
+/* getFitnessScore passes of the last mrgfe_batch_align(fitness_max_range >= 0) of this batch, all launches added up (finished pairs are
+ * scored in waves beside the remaining alignment rounds, the rest afterwards): the layout of mrgfe_ctx_fitness_stats, out[10] = launches. */
+int  mrgfe_batch_fitness_stats(const mrgfe_batch* b, double out[11]);
 
 /* ---- diagnostic entry points for the primitive tests (tests/test_gpu_primitives.py) --------------------------- */
 int mrgfe_dbg_sort_pairs(mrgfe_ctx* ctx, const uint32_t* keys, const uint32_t* vals, size_t n, int key_bits, uint32_t* out_keys, uint32_t* out_vals);

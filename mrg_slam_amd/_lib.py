@@ -165,6 +165,7 @@ SIGNATURES = {
     "mrgfe_batch_build_targets": (C.c_int, [_vp]),
     "mrgfe_batch_align": (C.c_int, [_vp, C.c_double, C.POINTER(PairResult)]),
     "mrgfe_batch_num_pairs": (C.c_int, [_vp]),
+    "mrgfe_batch_fitness_stats": (C.c_int, [_vp, _dp]),
     "mrgfe_batch_kernel_stats": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_int64), _dp]),
     "mrgfe_reg_kernel_stats": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_int64), _dp]),
     "mrgfe_batch_pair_counts": (C.c_int, [_vp, C.c_int, _dp, _dp]),

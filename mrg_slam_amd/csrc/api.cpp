@@ -1,6 +1,9 @@
 // csrc/api.cpp — the extern "C" surface declared in include/mrgfe.h.  Thin: argument checks, column-major <-> row-major
 // conversion, and dispatch into the engines.  Never throws; failures set the thread-local message.
+#include <atomic>
 #include <cfloat>
+#include <chrono>
+#include <memory>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -111,6 +114,8 @@ struct mrgfe_batch {
     };
     std::unordered_map<uint64_t, Keyframe*> store;
     std::vector<uint64_t> pair_key;  // per pair; 0: not from the store
+    FitStats   fit_total;             // getFitnessScore passes of the last align(), all waves added up
+    std::unique_ptr<NdtSnapshotPort> port;  // early fitness passes (mrgfe_batch_align)
     hipEvent_t uploads_done = nullptr;  // recorded on ctx->stream before helper streams read the batch's clouds (upload_cloud is stream-ordered only)
     uint64_t epoch = 1, tick = 0;
     size_t   store_cap = size_t(16384) << 20;
@@ -851,6 +856,7 @@ void mrgfe_batch_destroy(mrgfe_batch* b)
         for (auto& g : b->fit_grids) g.release();
         for (mrgfe_ctx* fc : b->fit_ctxs) mrgfe_ctx_destroy(fc);
         if (b->uploads_done) (void)hipEventDestroy(b->uploads_done);
+        if (b->port) b->port->buf.release();
         for (auto& gp : b->gicp_pairs) { gp.cov.release(); gp.corr.release(); gp.mahal.release(); }
         delete b->gicp_batch;
         for (auto* g : b->gicp) delete g;
@@ -1017,7 +1023,8 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
     NdtEngine& e = *b->ndt;
     const int P = e.n_pairs();
     const bool gicp = b->params.method != MRGFE_NDT_HIP;
-    std::vector<char> fit_built;  // targets whose fitness grid is built in this call
+    std::vector<char> fit_built;   // targets whose fitness grid is built in this call
+    std::vector<char> early_skip;  // pairs whose fitness score was computed beside the alignment rounds
     if (gicp) {
         // GICP_HIP: the candidates of a target share its covariances and correspondence grid, and all LM loops advance
         // together (GicpBatch: one launch per kernel and round for the pairs still running)
@@ -1075,9 +1082,13 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
         std::mutex   build_mu;
         std::vector<int> todo;  // (outlives the threads: they are joined below)
         const bool   overlap = fitness_max_range >= 0 && P >= 2 && std::getenv("MRGFE_NO_FIT_OVERLAP") == nullptr;
+        std::unique_ptr<std::atomic<char>[]> grid_ready;  // per target: its fitness grid is complete (set by the builder that made it)
+        auto fail = [&](int st, const std::string& why) { std::lock_guard<std::mutex> g(build_mu); if (build_status == MRGFE_OK) { build_status = st; build_error = why; } };
         if (overlap) {
             if (fit_built.size() < static_cast<size_t>(e.n_targets())) fit_built.resize(e.n_targets(), 0);
             if (b->fit_grids.size() < static_cast<size_t>(e.n_targets())) b->fit_grids.resize(e.n_targets());
+            grid_ready.reset(new std::atomic<char>[std::max(1, e.n_targets())]);
+            for (int t = 0; t < e.n_targets(); ++t) grid_ready[t].store(0, std::memory_order_relaxed);
             for (int i = 0; i < P; ++i) {
                 const NdtPairInfo& p = e.pair(i);
                 if (e.target(p.target).n == 0 || p.n == 0 || fit_built[p.target]) continue;
@@ -1087,7 +1098,7 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
             size_t n_builders = 4;
             if (const char* env = std::getenv("MRGFE_FIT_BUILDERS")) n_builders = static_cast<size_t>(std::max(1, std::atoi(env)));
             n_builders = std::min(n_builders, todo.size());
-            while (b->fit_ctxs.size() < n_builders) {
+            while (b->fit_ctxs.size() < n_builders + 1) {  // the last one belongs to the early fitness passes below
                 mrgfe_ctx* fc = nullptr;
                 if (mrgfe_ctx_create(b->ctx->device, &fc) != MRGFE_OK) return MRGFE_ERR_HIP;
                 b->fit_ctxs.push_back(fc);
@@ -1098,22 +1109,91 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
             if (!b->uploads_done) MRGFE_HIP_CHECK(hipEventCreateWithFlags(&b->uploads_done, hipEventDisableTiming));
             MRGFE_HIP_CHECK(hipEventRecord(b->uploads_done, b->ctx->stream));
             for (size_t w = 0; w < n_builders; ++w)
-                builders.emplace_back([b, &e, &todo, w, n_builders, &build_status, &build_error, &build_mu] {
+                builders.emplace_back([b, &e, &todo, w, n_builders, &fail, &grid_ready] {
                     mrgfe_ctx* fc = b->fit_ctxs[w];
-                    auto fail = [&](int st, const std::string& why) { std::lock_guard<std::mutex> g(build_mu); if (build_status == MRGFE_OK) { build_status = st; build_error = why; } };
                     std::lock_guard<std::recursive_mutex> lock(fc->mu);
                     if (fc->bind() != MRGFE_OK) { fail(MRGFE_ERR_HIP, mrgfe_last_error()); return; }
                     if (hipStreamWaitEvent(fc->stream, b->uploads_done, 0) != hipSuccess) { fail(MRGFE_ERR_HIP, "helper stream could not wait for the uploads"); return; }
                     for (size_t k = w; k < todo.size(); k += n_builders) {
                         const int t = todo[k];
                         const NdtTargetInfo& T = e.target(t);
-                        const int st = b->fit_grids[t].build(fc, T.d_pts, T.n, 1.0f, NnGrid::kCrowding1nn, 1);
+                        const int st = b->fit_grids[t].build(fc, T.d_pts, T.n, 1.0f, NnGrid::kCrowding1nn, 1);  // returns with the grid complete (synchronised)
                         if (st != MRGFE_OK) { fail(st, mrgfe_last_error()); return; }
+                        grid_ready[t].store(1, std::memory_order_release);
                     }
                     if (hipStreamSynchronize(fc->stream) != hipSuccess) fail(MRGFE_ERR_HIP, "helper stream synchronisation failed");
                 });
         }
-        const int align_status = e.align_all();
+        // Early fitness passes.  The rounds of a batch end in a long tail — a few stragglers line-searching while most alignments have
+        // finished and the chip idles between their small launches — and getFitnessScore of a finished pair needs nothing but its final
+        // transformation.  A second host thread asks the aligning thread for snapshots (NdtSnapshotPort), and whenever enough finished
+        // pairs with a complete grid have accumulated it runs their passes on a helper context beside the remaining rounds.  A pair's
+        // score does not depend on the launch it is computed in (nn_fit_sum_kernel's fixed slices), so the records are the same.
+        if (!b->port) b->port.reset(new NdtSnapshotPort());
+        NdtSnapshotPort& port = *b->port;  // (its pinned buffer is kept between calls)
+        port.want.store(0);
+        port.issued.store(0);
+        port.finished.store(0);
+        std::vector<char> early_done(P, 0);
+        std::thread early;
+        // (measured on config[3]: 256 pairs 30.8 -> 29.7 ms per step, 128 pairs no change, 64 and 32 pairs slower — small waves pay the fixed
+        // costs of a fitness launch several times and take the chip from rounds that are not idle yet: on for large batches only)
+        int early_min_pairs = 128;
+        if (const char* env = std::getenv("MRGFE_EARLY_FIT_MIN_PAIRS")) early_min_pairs = std::max(8, std::atoi(env));
+        const bool early_on = overlap && P >= early_min_pairs && std::getenv("MRGFE_NO_EARLY_FIT") == nullptr;
+        b->fit_total = FitStats();
+        if (early_on) {
+            if (port.buf.ensure(sizeof(NdtSnapshotHead) + sizeof(NdtSnapshotRec) * size_t(P)) != MRGFE_OK) return MRGFE_ERR_HIP;
+            port.head()->tag = 0;
+            early = std::thread([&, P] {
+                mrgfe_ctx* fc = b->fit_ctxs.back();
+                std::lock_guard<std::recursive_mutex> lock(fc->mu);
+                if (fc->bind() != MRGFE_OK) { fail(MRGFE_ERR_HIP, mrgfe_last_error()); return; }
+                const int min_wave = std::max(4, P / 6);
+                std::vector<NnFitnessJob> jobs;
+                std::vector<int>          job_pair;
+                std::vector<double>       fit;
+                uint32_t seen_tag = 0;
+                while (!port.finished.load(std::memory_order_acquire)) {
+                    port.want.store(1, std::memory_order_release);
+                    // wait for the snapshot (or the end of the alignment)
+                    while (port.issued.load(std::memory_order_acquire) == seen_tag && !port.finished.load(std::memory_order_acquire)) std::this_thread::yield();
+                    const uint32_t tag = port.issued.load(std::memory_order_acquire);
+                    if (tag == seen_tag) break;  // finished without another snapshot
+                    volatile NdtSnapshotHead* hd = port.head();
+                    bool alive = true;
+                    while (__atomic_load_n(&hd->tag, __ATOMIC_ACQUIRE) != tag) {
+                        if (port.finished.load(std::memory_order_acquire) && __atomic_load_n(&hd->tag, __ATOMIC_ACQUIRE) != tag) { alive = false; break; }  // align_all failed before the kernel ran
+                        std::this_thread::yield();
+                    }
+                    if (!alive) break;
+                    seen_tag = tag;
+                    jobs.clear();
+                    job_pair.clear();
+                    const NdtSnapshotRec* recs = port.recs();
+                    for (int i = 0; i < P; ++i) {
+                        if (early_done[i] || !recs[i].done) continue;
+                        const NdtPairInfo& p = e.pair(i);
+                        if (e.target(p.target).n == 0 || p.n == 0 || !grid_ready[p.target].load(std::memory_order_acquire)) continue;
+                        float T[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
+                        std::memcpy(T, recs[i].T12, sizeof(recs[i].T12));
+                        jobs.push_back(b->fit_grids[p.target].make_fitness_job(p.d_src, p.n, T));
+                        job_pair.push_back(i);
+                    }
+                    if (static_cast<int>(jobs.size()) < min_wave) {  // not worth a launch yet
+                        std::this_thread::sleep_for(std::chrono::microseconds(150));
+                        continue;
+                    }
+                    fit.assign(jobs.size(), 0.0);
+                    const int st = nn_fitness_batch(fc, jobs.data(), jobs.size(), fitness_max_range, fit.data());
+                    if (st != MRGFE_OK) { fail(st, mrgfe_last_error()); return; }
+                    b->fit_total.add(fc->fit_stats);
+                    for (size_t j = 0; j < jobs.size(); ++j) { results[job_pair[j]].fitness = fit[j]; early_done[job_pair[j]] = 1; }
+                }
+            });
+        }
+        const int align_status = e.align_all(early_on ? &port : nullptr);
+        if (early.joinable()) early.join();
         for (std::thread& t : builders) t.join();
         MRGFE_TRY(align_status);
         if (build_status != MRGFE_OK) { set_error("%s", build_error.c_str()); return build_status; }
@@ -1122,13 +1202,14 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
             mrgfe_pair_result& r = results[i];
             row2col(c.final_transformation(), r.T);
             std::memcpy(r.H, c.hessian(), sizeof(r.H));
-            r.fitness = DBL_MAX;
+            if (!early_done[i]) r.fitness = DBL_MAX;
             r.trans_probability = c.trans_probability();
             r.converged = c.converged() ? 1 : 0;
             r.iterations = c.iterations();
             r.evaluations = c.evaluations();
             r.pair_id = i;
         }
+        early_skip.swap(early_done);
     }
     if (fitness_max_range >= 0) {
         // getFitnessScore of every pair in one launch: one exact-NN grid per distinct target
@@ -1142,17 +1223,30 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
         for (int i = 0; i < P && st == MRGFE_OK; ++i) {
             const NdtPairInfo& p = e.pair(i);
             const NdtTargetInfo& t = e.target(p.target);
-            if (t.n == 0 || p.n == 0) continue;
+            if (t.n == 0 || p.n == 0 || (static_cast<size_t>(i) < early_skip.size() && early_skip[i])) continue;
             if (!built[p.target]) { st = grids[p.target].build(b->ctx, t.d_pts, t.n, 1.0f, NnGrid::kCrowding1nn, 1); built[p.target] = 1; }
             if (st == MRGFE_OK) { jobs.push_back(grids[p.target].make_fitness_job(p.d_src, p.n, gicp ? &b->gicp_final[size_t(i) * 16] : p.ctl.final_transformation())); job_pair.push_back(i); }
         }
         if (st == MRGFE_OK && !jobs.empty()) {
             std::vector<double> fit(jobs.size());
             st = nn_fitness_batch(b->ctx, jobs.data(), jobs.size(), fitness_max_range, fit.data());
-            if (st == MRGFE_OK) for (size_t j = 0; j < jobs.size(); ++j) results[job_pair[j]].fitness = fit[j];
+            if (st == MRGFE_OK) {
+                b->fit_total.add(b->ctx->fit_stats);
+                for (size_t j = 0; j < jobs.size(); ++j) results[job_pair[j]].fitness = fit[j];
+            }
         }
         MRGFE_TRY(st);
     }
+    return MRGFE_OK;
+}
+
+int mrgfe_batch_fitness_stats(const mrgfe_batch* b, double out[11])
+{
+    if (!b || !out) { set_error("mrgfe_batch_fitness_stats: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(b->ctx);
+    const FitStats& f = b->fit_total;
+    const double v[11] = {f.ms_block, f.ms_sweep, f.ms_far, double(f.queries), double(f.queued), double(f.queued_far), double(f.words), double(f.tested), double(f.cells), double(f.points), double(f.calls)};
+    std::memcpy(out, v, sizeof(v));
     return MRGFE_OK;
 }
 

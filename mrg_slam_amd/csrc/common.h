@@ -86,6 +86,13 @@ struct FitStats {
     uint64_t queries = 0, queued = 0, queued_far = 0;  // all queries / not settled by their 3x3x3 block / not seeded within three blocks
     uint64_t words = 0, tested = 0, cells = 0, points = 0;  // seed + sweep: occupancy words fetched, boxes tested against the sphere, cells opened, points measured (MRGFE_FIT_STATS=1)
     uint64_t calls = 0;
+    void add(const FitStats& o)
+    {
+        ms_block += o.ms_block; ms_sweep += o.ms_sweep; ms_far += o.ms_far;
+        queries += o.queries; queued += o.queued; queued_far += o.queued_far;
+        words += o.words; tested += o.tested; cells += o.cells; points += o.points;
+        calls += 1;
+    }
 };
 }  // namespace mrgfe
 

@@ -10,6 +10,8 @@ namespace mrgfe {
 // receives the number of pairs still running
 int ndt_launch_plan(mrgfe_ctx* ctx, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, uint32_t P, uint32_t* d_plan, uint32_t wg_target, uint32_t max_ppt, uint32_t forced_ppt,
                     uint32_t round, NdtRoundInfo* h_info);
+// between two rounds: which pairs have finished and their final transformations, into pinned host memory (h_head->tag = tag, written last)
+int ndt_launch_snapshot(mrgfe_ctx* ctx, const NdtCtlState* d_states, uint32_t P, uint32_t tag, NdtSnapshotHead* h_head, NdtSnapshotRec* h_recs);
 // one derivative evaluation for the pairs the plan lists under `mode`: `grid` workgroups walk the plan's items
 int ndt_launch_derivatives(mrgfe_ctx* ctx, int mode, int search, uint32_t grid, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals,
                            const uint32_t* d_plan, uint32_t P, double* d_partials);

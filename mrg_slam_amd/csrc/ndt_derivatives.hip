@@ -849,6 +849,38 @@ void ndt_phase_dump()
 #endif
 }
 
+// which pairs have finished, and where: one workgroup, records first, the request's tag last (system scope: the host polls it)
+__global__ __launch_bounds__(256) void ndt_snapshot_kernel(const NdtCtlState* __restrict__ states, uint32_t P, uint32_t tag, NdtSnapshotHead* __restrict__ head, NdtSnapshotRec* __restrict__ recs)
+{
+    __shared__ uint32_t s_done[4];
+    uint32_t mine = 0;
+    for (uint32_t i = threadIdx.x; i < P; i += 256) {
+        const NdtCtlState& st = states[i];
+        const bool fin = ctl::done(st);
+        recs[i].done = fin ? 1u : 0u;
+        if (fin) {
+            for (int k = 0; k < 12; ++k) recs[i].T12[k] = st.final_[k];
+            ++mine;
+        }
+    }
+    mine = wave_sum(mine);
+    if (lane_id() == 0) s_done[wave_id()] = mine;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        head->n_done = s_done[0] + s_done[1] + s_done[2] + s_done[3];
+        __threadfence_system();
+        __hip_atomic_store(&head->tag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+int ndt_launch_snapshot(mrgfe_ctx* ctx, const NdtCtlState* d_states, uint32_t P, uint32_t tag, NdtSnapshotHead* h_head, NdtSnapshotRec* h_recs)
+{
+    hipLaunchKernelGGL(ndt_snapshot_kernel, dim3(1), dim3(256), 0, ctx->stream, d_states, P, tag, h_head, h_recs);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
 int ndt_launch_plan(mrgfe_ctx* ctx, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, uint32_t P, uint32_t* d_plan, uint32_t wg_target, uint32_t max_ppt, uint32_t forced_ppt,
                     uint32_t round, NdtRoundInfo* h_info)
 {

@@ -530,8 +530,12 @@ void NdtEngine::account(const std::vector<NdtRoundInfo>& info, size_t rounds)
     }
 }
 
-int NdtEngine::align_all()
+int NdtEngine::align_all(NdtSnapshotPort* port)
 {
+    struct PortGuard {  // whatever way this returns: no more snapshots
+        NdtSnapshotPort* p;
+        ~PortGuard() { if (p) p->finished.store(1, std::memory_order_release); }
+    } port_guard{port};
     struct PhaseDump { ~PhaseDump() { static const bool on = std::getenv("MRGFE_PHASE") != nullptr; if (on) ndt_phase_dump(); } } phase_dump;  // diagnostic builds only
     MRGFE_TRY(ctx_->bind());
     MRGFE_TRY(build_targets());
@@ -574,10 +578,19 @@ int NdtEngine::align_all()
         const bool all_modes[3] = {true, true, true};
         size_t enq = 0, seen = 0;  // rounds enqueued / rounds whose plan the host has seen
         bool   finished = false;
+        auto serve_port = [&]() -> int {  // a snapshot between two rounds, when the other thread has asked for one
+            if (port && port->want.exchange(0, std::memory_order_acq_rel)) {
+                const uint32_t tag = port->issued.load(std::memory_order_relaxed) + 1;
+                MRGFE_TRY(ndt_launch_snapshot(ctx_, d_states_.as<NdtCtlState>(), static_cast<uint32_t>(P), tag, port->head(), port->recs()));
+                port->issued.store(tag, std::memory_order_release);
+            }
+            return MRGFE_OK;
+        };
         while (!finished) {
             // keep a few rounds queued ahead of the GPU; beyond that wait for the oldest unseen plan
             if (enq - seen >= lookahead || enq >= round_cap) {
                 while (__atomic_load_n(&hi[seen].tag, __ATOMIC_ACQUIRE) != static_cast<uint32_t>(seen + 1)) {
+                    MRGFE_TRY(serve_port());
                     if (hipStreamQuery(st) != hipErrorNotReady && __atomic_load_n(&hi[seen].tag, __ATOMIC_ACQUIRE) != static_cast<uint32_t>(seen + 1)) {
                         MRGFE_HIP_CHECK(hipStreamSynchronize(st));
                         if (hi[seen].tag != static_cast<uint32_t>(seen + 1)) { set_error("NDT round %zu never reported", seen); return MRGFE_ERR_HIP; }
@@ -590,6 +603,7 @@ int NdtEngine::align_all()
             }
             MRGFE_TRY(ensure_events(enq + 1));
             const_cast<NdtRoundInfo*>(hi)[enq].tag = 0;
+            MRGFE_TRY(serve_port());
             MRGFE_TRY(enqueue_round(static_cast<uint32_t>(enq), true, all_modes, const_cast<NdtRoundInfo*>(hi)));
             ++enq;
         }

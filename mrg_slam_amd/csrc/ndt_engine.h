@@ -2,6 +2,7 @@
 // (target, source, guess) alignments and advances all of them together, one derivative launch per round.
 // A single pcl::Registration-style object (mrgfe_reg) is a batch with one target and one pair.
 #pragma once
+#include <atomic>
 #include <vector>
 
 #include "cellsort.h"
@@ -36,6 +37,18 @@ void ndt_set_host_control(int mode);
 // overrides), 0 = one launch per variant; any other value only asks.  Returns the setting in effect.
 int ndt_set_fused_launch(int mode);
 
+// A second host thread may ask a running device-controlled align_all() for snapshots (which pairs have finished, their final
+// transformations): it raises `want`; the aligning thread enqueues ndt_snapshot_kernel between two rounds and counts `issued` up; the
+// kernel writes the records and then head->tag = issued.  `finished` is set when align_all() returns (no more snapshots).
+struct NdtSnapshotPort {
+    std::atomic<int>      want{0};
+    std::atomic<uint32_t> issued{0};
+    std::atomic<int>      finished{0};
+    PinBuf                buf;  // NdtSnapshotHead, then NdtSnapshotRec[P]
+    NdtSnapshotHead*      head() const { return buf.as<NdtSnapshotHead>(); }
+    NdtSnapshotRec*       recs() const { return reinterpret_cast<NdtSnapshotRec*>(buf.as<char>() + sizeof(NdtSnapshotHead)); }
+};
+
 class NdtEngine {
    public:
     NdtEngine(mrgfe_ctx* ctx, const NdtParams& prm) : ctx_(ctx), prm_(prm) {}
@@ -51,7 +64,7 @@ class NdtEngine {
     int set_guess(int pair, const float guess_rowmajor[16]);
 
     int build_targets();          // voxelise every target not yet built
-    int align_all();              // run every pair to completion
+    int align_all(NdtSnapshotPort* port = nullptr);  // run every pair to completion (port: see NdtSnapshotPort; batches under device control only)
     // one derivative evaluation of pair `pair` (tests): mode 0/1/2
     int evaluate(int pair, const float T_rowmajor[16], const double p[6], int mode, double* score, double grad[6], double hess[36]);
     int aligned_cloud(int pair, float* out_xyzi_host);  // final_transformation * source

@@ -113,6 +113,18 @@ struct NdtRoundInfo {
     uint32_t n_items[3];
 };
 
+// Snapshot of a batch between two rounds (ndt_snapshot_kernel, pinned host memory): which alignments have finished, and their final
+// transformations — what the fitness passes of finished pairs need while the stragglers still iterate (mrgfe_batch_align).
+struct NdtSnapshotRec {
+    uint32_t done;     // 1: the optimiser has finished, T12 is final
+    float    T12[12];  // row-major 3 x 4
+};
+struct NdtSnapshotHead {
+    uint32_t tag;  // request number, written last
+    uint32_t n_done;
+    uint32_t pad[2];
+};
+
 // block partial / final result of one evaluation: score, gradient(6), full 6x6 Hessian(36, row-major), neighbour count.
 // All 36 Hessian entries are kept: the reference fills H(i,j) and H(j,i) with differently rounded float terms, and an
 // ill-conditioned Newton solve amplifies that 1e-7 asymmetry far above the 1e-4 parity bar if it is mirrored away.

@@ -399,6 +399,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void n
 // sqrt(lim) of the query is in a cell that gets opened (or in the query's own block, which the block pass measured and which is
 // where lim starts) — the exact nearest distance, as before.  Queries with nothing within three blocks (8 m and more) keep their bound
 // and go to nn_fit_far_kernel's pyramid walk.
+// The queue keeps the order of the scan: neighbours in the queue are neighbours in space, and a tile's table and point reads hit the
+// caches.  (Measured and dropped: a second queue for the queries whose cube covers more than eight super-bricks — a tenth of them, and a
+// tile runs as long as its widest cube — filled by atomic appends: the scrambled order cost more than the even tiles gained, sweep 9.2 ->
+// 11.4 ms for config[3].  Also dropped: a batch as two to eight sub-batches on as many contexts and host threads: 28.8 -> 33 / 36 / 44 ms
+// per config[3] step.)
 __device__ __forceinline__ unsigned long long nn_range_mask(const int L[3], const int H[3], int ox, int oy, int oz)
 {
     // children (x + 4 y + 16 z) of the node with first child (ox, oy, oz) whose coordinates lie in [L, H] per axis; 0 if none

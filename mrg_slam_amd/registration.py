@@ -407,6 +407,13 @@ class BatchMatcher:
         check(lib().mrgfe_batch_pair_counts(self._h, mode, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def fitness_stats(self) -> dict:
+        """getFitnessScore passes of the last align(), all launches added up (``mrgfe_batch_fitness_stats``)."""
+        v = (C.c_double * 11)()
+        check(lib().mrgfe_batch_fitness_stats(self._h, v))
+        keys = ("ms_block", "ms_sweep", "ms_far", "queries", "queued", "queued_far", "words", "boxes_tested", "cells", "points", "launches")
+        return dict(zip(keys, [float(x) for x in v]))
+
     def kernel_stats(self, mode: int = -1):
         """(device ms, launches, algorithmic bytes) of the derivative kernel variant `mode` (-1: all) in the last align()."""
         ms, n, b = C.c_double(0), C.c_int64(0), C.c_double(0)
