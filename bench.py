@@ -292,20 +292,67 @@ def main():
             best = {a: lc.select_best(full[ids]) for a, ids in groups.items()}  # (with --shard-of the other ranks' records are missing: unconverged zeros)
             return full, best
 
+        deriv = np.zeros(3)   # (device ms, launches, algorithmic bytes) of the derivative launches, HIP events around every launch
+        fit_acc = {"ms_block": 0.0, "ms_sweep": 0.0, "ms_far": 0.0, "queued": 0.0, "queries": 0.0, "queued_far": 0.0, "launches": 0.0}
+        acc_on = {"on": False}
+        inner_step = step
+
+        def step():  # noqa: F811 - the timed step plus the library's own accounting of it (read back after the step: host-side only)
+            out = inner_step()
+            if acc_on["on"]:
+                deriv[:] += np.array(bm.kernel_stats(-1))
+                fs = bm.fitness_stats()
+                for k in fit_acc:
+                    fit_acc[k] += fs[k]
+            return out
+
         elapsed, step_ms, (full, best) = timed(step, steps, warmup)
+        # kernel times for the roofline records: two more, untimed, steps WITHOUT the early fitness waves (beside the alignment rounds the
+        # kernels of both share the chip and their HIP-event times say little about either), then one with the sweep's counters on:
+        # candidate points measured per queued query (the m-bar of SURVEY.md §8d)
+        acc_steps = 2
+        os.environ["MRGFE_NO_EARLY_FIT"] = "1"
+        step()
+        acc_on["on"] = True
+        for _ in range(acc_steps):
+            step()
+        acc_on["on"] = False
+        lib().mrgfe_dbg_set_fit_stats(1)
+        inner_step()
+        cs = bm.fitness_stats()
+        lib().mrgfe_dbg_set_fit_stats(0)
+        del os.environ["MRGFE_NO_EARLY_FIT"]
+        mbar = cs["points"] / cs["queued"] if cs["queued"] else 0.0
         have = [i for i in range(n_pairs) if not fake_world or i in set(mine.tolist())]
         err = [float(np.linalg.norm(result_matrix(full[i])[:3, 3] - loop_pairs[i][3][:3, 3])) for i in have]
         digest = __import__("hashlib").sha256(full["T"].tobytes() + full["fitness"].tobytes() + full["converged"].tobytes()).hexdigest()[:16]
         # the records are a function of the inputs: the synthetic scans are ray-cast with numpy on the host (its SIMD paths differ from CPU to CPU
         # in the last bit), so the digest of the inputs goes with the digest of the records
         in_digest = __import__("hashlib").sha256(b"".join(np.ascontiguousarray(c).tobytes() for c in l_host)).hexdigest()[:16]
+        d_gbps = (deriv[2] / 1e9) / (deriv[0] / 1e3) if deriv[0] > 0 else 0.0
+        # getFitnessScore's seed + sweep pass (nn_fit_seed_kernel + nn_fit_sweep_kernel, HIP events around the two): SURVEY.md §8(d) prices a 1-NN
+        # query on the hash grid at 16 + 27 * 8 + m-bar * 16 bytes; N = the queries the 3x3x3 block did not settle
+        f_bytes = fit_acc["queued"] * (16.0 + 27.0 * 8.0 + mbar * 16.0)
+        f_gbps = (f_bytes / 1e9) / (fit_acc["ms_sweep"] / 1e3) if fit_acc["ms_sweep"] > 0 else 0.0
+        roof = {"bound": "valu", "byte_model_bound": "hbm", "kernel": "ndt_derivatives_all_kernel<7>", "achieved": d_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": d_gbps / HBM_PEAK_GBPS, "traffic": None, "launches": int(deriv[1]), "avg_launch_ms": deriv[0] / deriv[1] if deriv[1] else None,
+                "alg_bytes_per_launch": deriv[2] / deriv[1] if deriv[1] else None, "ms_per_step": deriv[0] / acc_steps,
+                "byte_model": "per launch: sum over the evaluations of all active pairs of N_src*(16 + 7*8) + valid_neighbours*48 (SURVEY.md §8d); PMC traffic of this "
+                              "kernel: profiles/r03_rocprof_summary.md"}
+        roof_fit = {"bound": "valu", "byte_model_bound": "hbm", "kernel": "nn_fit_seed_kernel + nn_fit_sweep_kernel (getFitnessScore(inf), the queries their 3x3x3 block does not settle)",
+                    "achieved": f_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": f_gbps / HBM_PEAK_GBPS, "traffic": None,
+                    "queued_queries_per_step": fit_acc["queued"] / acc_steps, "queries_per_step": fit_acc["queries"] / acc_steps, "unseeded_queries_per_step": fit_acc["queued_far"] / acc_steps,
+                    "candidate_points_per_queued_query": mbar, "alg_bytes_per_step": f_bytes / acc_steps, "ms_per_step": fit_acc["ms_sweep"] / acc_steps,
+                    "block_pass_ms_per_step": fit_acc["ms_block"] / acc_steps, "pyramid_walk_ms_per_step": fit_acc["ms_far"] / acc_steps,
+                    "byte_model": "N_queued * (16 + 27*8 + m*16), m = candidate points measured per queued query (counted in one extra untimed step); kernel times from "
+                                  f"{acc_steps} untimed steps without the early fitness waves (MRGFE_NO_EARLY_FIT=1: one fitness launch per step, behind the alignment)"}
         return {"pairs_total": n_pairs, "new_keyframes": len(groups), "pairs_per_gpu": int(len(mine)), "targets_built_per_gpu": len(my_targets),
                 "steps": steps, "ms_per_step": 1e3 * elapsed / steps, "alignments_per_s": n_pairs * steps / elapsed, "scaling": "strong",
                 "projected_for_gpus": fake_world or None,
                 "fitness_max_range": "inf", "converged": int(full["converged"].sum()), "matched_keyframes": int(sum(b[0] is not None for b in best.values())),
                 "median_translation_error_vs_truth_m": float(np.median(err)), "mean_iterations": float(full["iterations"][have].mean()),
-                "mean_points_per_scan": float(np.mean([len(s) for s in l_host])), "records_sha256_16": digest, "inputs_sha256_16": in_digest, "per_step_ms": [round(v, 2) for v in step_ms],
-                "fitness_passes_last_step": bm.fitness_stats()}
+                "mean_points_per_scan": float(np.mean([len(s) for s in l_host])), "records_sha256_16": digest, "inputs_sha256_16": in_digest,
+                "per_step_ms": [round(v, 2) for v in step_ms], "roofline": roof, "roofline_fitness": roof_fit}
 
     if args.mode == "shard":
         r = run_shard(args.steps, args.warmup)
@@ -317,7 +364,7 @@ def main():
                                           f"mean {r['mean_points_per_scan']:.0f} pts/scan), NDT_HIP DIRECT7 res 1.0 eps {args.eps}, contiguous blocks of the keyframe-ordered pair list per rank, one target grid per "
                                           f"new keyframe and rank, getFitnessScore(inf), record all-gather, best-candidate replay; inputs resident in HBM",
                               "parallelism": f"{world} x 1 GPU" if world > 1 else "1 GPU"},
-                   "roofline": None, "cpu_baseline": None, "config3_shard": r}
+                   "roofline": r["roofline"], "roofline_fitness": r["roofline_fitness"], "cpu_baseline": None, "config3_shard": r}
             print(json.dumps(out))
         if world > 1:
             dist.barrier()

@@ -376,6 +376,10 @@ int mrgfe_dbg_set_fused_launch(int mode);
  * MRGFE_FIT_SWEEP sets the initial value), 0 = round 2's pyramid walk for every queued query.  Any other value only asks.  Returns the
  * setting in effect.  Both give the exact nearest distances (tests/test_gpu_fitness_passes.py). */
 int mrgfe_dbg_set_fit_sweep(int mode);
+/* Counters of the seed + sweep pass (mrgfe_ctx_fitness_stats out[6..9], mrgfe_batch_fitness_stats) during the following calls of this process:
+ * 0 = off (default; MRGFE_FIT_STATS sets the initial value), 1 = counted, 2 = also the kernel's phase clocks and a line on stderr (slows
+ * the kernel: a clock read waits for the memory operations in flight).  Any other value only asks.  Returns the setting in effect. */
+int mrgfe_dbg_set_fit_stats(int mode);
 /* The optimiser's scalar routines (pose vector -> float matrix, angle derivative tables, 6x6 SVD solve) on n cases of 48 doubles
  * (p[6], A[36] row-major, b[6]), on the host (on_device = 0, ctx may be NULL) or on the device: M16 [n][16] row-major, tables69
  * [n][8*3 + 15*3], x6 [n][6]; on_device = 2: x6 from the wavefront form of the solve (three lanes rotate, 36 apply) that the

@@ -1369,6 +1369,7 @@ int mrgfe_dbg_set_host_control(int mode)
 }
 int mrgfe_dbg_set_fused_launch(int mode) { return ndt_set_fused_launch(mode); }
 int mrgfe_dbg_set_fit_sweep(int mode) { return nn_set_fit_sweep(mode); }
+int mrgfe_dbg_set_fit_stats(int mode) { return nn_set_fit_stats(mode); }
 void mrgfe_dbg_sincosf(const float* x, size_t n, float* sin_out, float* cos_out)
 {
     for (size_t i = 0; i < n; ++i) { sin_out[i] = ctl::sin_f(x[i]); cos_out[i] = ctl::cos_f(x[i]); }

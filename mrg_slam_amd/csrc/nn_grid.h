@@ -94,5 +94,7 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
 
 // far pass of the fitness score: 1 = seed + sweep (nn_fit_sweep_kernel), 0 = the pyramid walk for every queued query
 int nn_set_fit_sweep(int mode);
+// diagnostic counters of the seed + sweep pass: 0 off, 1 counters (FitStats::words ...), 2 also phase clocks and a line on stderr
+int nn_set_fit_stats(int mode);
 
 }  // namespace mrgfe

@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void nn_fit_seed_kernel(const NnFitnessJob* __
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void nn_fit_sweep_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range,
                                                             const uint32_t* __restrict__ pend, const uint32_t* __restrict__ pend_cnt, float* __restrict__ sqd,
-                                                            unsigned long long* __restrict__ stats)
+                                                            unsigned long long* __restrict__ stats, int clocks)
 {
     const uint32_t np = pend_cnt[blockIdx.y];
     if (blockIdx.x * kSweepQ >= np) return;
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
     const int           tid = static_cast<int>(threadIdx.x);
     uint32_t            n_words = 0, n_tested = 0, n_cells = 0, n_points = 0, n_bricks = 0, n_listed = 0;  // diagnostics
     long long           clk[4] = {0, 0, 0, 0}, tick = 0;  // thread 0: shader clocks spent in the four phases
-    auto stamp = [&](int ph) { if (stats != nullptr && threadIdx.x == 0) { const long long now = clock64(); clk[ph] += now - tick; tick = now; } };
+    auto stamp = [&](int ph) { if (clocks && threadIdx.x == 0) { const long long now = clock64(); clk[ph] += now - tick; tick = now; } };  // (a clock read waits for the memory operations in flight)
     // every lane of the wavefront asks for `cnt` consecutive slots of a bounded LDS list: returns the lane's first slot; `full` when the list has filled up
     auto reserve = [&](uint32_t cnt, uint32_t* counter, uint32_t cap, bool& full) -> uint32_t {
         const uint32_t incl = wave_inclusive_scan(cnt);
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
         }
         return base + incl - cnt;
     };
-    if (stats != nullptr && threadIdx.x == 0) tick = clock64();
+    if (clocks && threadIdx.x == 0) tick = clock64();
     for (uint32_t k0 = blockIdx.x * kSweepQ; k0 < np; k0 += gridDim.x * kSweepQ) {
         // ================= the tile's queries (lane = query): lim as the seed left it, the cube it spans =================
         const uint32_t k = k0 + threadIdx.x;
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
             for (int kk = 0; kk < 6; ++kk)
                 if (v[kk]) atomicAdd(&stats[at[kk]], static_cast<unsigned long long>(v[kk]));
         }
-        if (threadIdx.x == 0)
+        if (clocks && threadIdx.x == 0)
             for (int kk = 0; kk < 4; ++kk) atomicAdd(&stats[9 + kk], static_cast<unsigned long long>(clk[kk]));
     }
 }
@@ -926,7 +926,18 @@ int nn_set_fit_sweep(int mode)
     if (mode == 0 || mode == 1) g_fit_sweep.store(mode, std::memory_order_relaxed);
     return fit_sweep_mode();
 }
-static int fit_stats_mode() { static const int v = [] { const char* e = std::getenv("MRGFE_FIT_STATS"); return e ? std::atoi(e) : 0; }(); return v; }
+static std::atomic<int> g_fit_stats{-1};  // -1: not read yet; 0 off, 1 counters, 2 counters + phase clocks and a line on stderr
+static int fit_stats_mode()
+{
+    int v = g_fit_stats.load(std::memory_order_relaxed);
+    if (v < 0) { const char* e = std::getenv("MRGFE_FIT_STATS"); v = e ? std::max(0, std::min(2, std::atoi(e))) : 0; g_fit_stats.store(v, std::memory_order_relaxed); }
+    return v;
+}
+int nn_set_fit_stats(int mode)
+{
+    if (mode >= 0 && mode <= 2) g_fit_stats.store(mode, std::memory_order_relaxed);
+    return fit_stats_mode();
+}
 
 int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, double max_range, double* out)
 {
@@ -977,7 +988,7 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[1], st));
     if (sweep) {
         hipLaunchKernelGGL(nn_fit_seed_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), d_pend[1], d_cnts[1], counters ? d_stats : nullptr);
-        hipLaunchKernelGGL(nn_fit_sweep_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), counters ? d_stats : nullptr);
+        hipLaunchKernelGGL(nn_fit_sweep_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), counters ? d_stats : nullptr, fit_stats_mode() > 1 ? 1 : 0);
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[2], st));
         hipLaunchKernelGGL(nn_fit_far_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[1], d_cnts[1], dq.as<float>());
     } else {
