@@ -132,6 +132,77 @@ def make_loop_workload(n_keyframes: int = 64, n_pairs: int = 256, radius: float 
     return scans, pairs
 
 
+def run_config2(ctx, scans, dev, poses, lib, args):
+    """BASELINE config[2]: scan-to-keyframe GICP on the ~130k-point scans (registrations.cpp:46-63: SMALL_GICP is the YAML default, FAST_GICP the
+    code default), per frame setInputSource (k = 20 covariances) + align against a keyframe set once; kernel times from the library's HIP events."""
+    from mrg_slam_amd import GicpHip, SmallGicpHip, synth
+    from oracle import oracle as orc
+
+    out = {"workload": f"keyframe = scan 0 ({len(scans[0])} points), frames = scans 1..6, guess = perturbed true motion (seed 777+k), max_correspondence_distance 2.0, "
+                       f"k = 20, eps {args.eps}, clouds resident in HBM"}
+    frames = list(range(1, min(7, len(scans))))
+    rels = {k: np.linalg.inv(poses[0]) @ poses[k] for k in frames}
+    guesses = {k: synth.warm_guess(rels[k], 5000 + k) for k in frames}
+    for name, cls, ocls in (("SMALL_GICP_HIP", SmallGicpHip, orc.SmallGicp), ("GICP_HIP", GicpHip, orc.FastGicp)):
+        reg = cls(transformation_epsilon=args.eps, ctx=ctx)
+        t_set, t_frame, lin, its, finals = [], [], np.zeros(3), [], {}
+        knn = None
+        for rep in range(3):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            reg.setInputTargetDevice(dev[0].data_ptr(), len(scans[0]))
+            reg.setInputSourceDevice(dev[frames[0]].data_ptr(), len(scans[frames[0]]))
+            reg.align(guesses[frames[0]])  # the target's covariances and grid are built by the first align
+            ctx.synchronize()
+            t_set.append(1e3 * (time.perf_counter() - t0))
+            for k in frames:
+                t0 = time.perf_counter()
+                reg.setInputSourceDevice(dev[k].data_ptr(), len(scans[k]))
+                reg.align(guesses[k])
+                if rep:
+                    t_frame.append(1e3 * (time.perf_counter() - t0))
+                    lin += np.array(reg.kernel_stats())
+                    its.append(reg.getFinalNumIteration())
+                finals[k] = reg.getFinalTransformation()
+            knn = ctx.knn_stats()
+        # candidates the k-NN measures per query: one more frame with the diagnostic counters on
+        lib().mrgfe_dbg_set_fit_stats(1)
+        reg.setInputSourceDevice(dev[frames[0]].data_ptr(), len(scans[frames[0]]))
+        reg.align(guesses[frames[0]])
+        kc = ctx.knn_stats()
+        lib().mrgfe_dbg_set_fit_stats(0)
+        mbar = kc["candidates"] / kc["queries"] if kc["queries"] else 0.0
+        knn_bytes = knn["queries"] * (16.0 + 27.0 * 8.0 + mbar * 16.0)
+        knn_gbps = (knn_bytes / 1e9) / (knn["ms"] / 1e3) if knn["ms"] > 0 else 0.0
+        lin_gbps = (lin[2] / 1e9) / (lin[0] / 1e3) if lin[0] > 0 else 0.0
+        err = [float(np.linalg.norm(finals[k][:3, 3] - rels[k][:3, 3])) for k in frames]
+        rec = {"first_frame_incl_setInputTarget_ms": float(np.median(t_set)), "frame_ms": float(np.median(t_frame)), "frames_timed": len(t_frame),
+               "outer_iterations_per_frame": float(np.mean(its)), "median_translation_error_vs_truth_m": float(np.median(err)),
+               "roofline_knn": {"bound": "latency", "byte_model_bound": "hbm", "kernel": "nn_knn_kernel (k = 20, one wavefront per query)", "achieved": knn_gbps, "peak": HBM_PEAK_GBPS,
+                                "unit": "GB/s", "frac": knn_gbps / HBM_PEAK_GBPS, "traffic": None, "launch_ms": knn["ms"], "queries": knn["queries"],
+                                "candidate_points_per_query": mbar, "byte_model": "N * (16 + 27*8 + m*16), m = candidates measured per query (counted)"},
+               "roofline_linearize": {"bound": "latency", "byte_model_bound": "hbm", "kernel": "gicp_corr_kernel + gicp_linearize_kernel (one HIP-event pair around both)",
+                                      "achieved": lin_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": lin_gbps / HBM_PEAK_GBPS, "traffic": None, "launches": int(lin[1]),
+                                      "avg_launch_ms": lin[0] / lin[1] if lin[1] else None,
+                                      "byte_model": "N_src * (16 + 48 + 27*8) + correspondences * (16 + 48) per linearisation (SURVEY.md §8d)"}}
+        if not args.no_cpu:
+            host_cores = os.cpu_count() or 1
+            nt = min(32, host_cores)
+            o = ocls(transformation_epsilon=args.eps, num_threads=nt)
+            k = frames[0]
+            tc = time.perf_counter()
+            o.setInputTarget(scans[0])
+            o.setInputSource(scans[k])
+            o.align(guesses[k])
+            tc = time.perf_counter() - tc
+            To = o.getFinalTransformation()
+            rec["cpu_oracle"] = {"ms": 1e3 * tc, "threads": nt, "sample": "one frame incl. setInputTarget (both clouds' k-NN covariances)", "kind": "port",
+                                 "max_dt_m": float(np.linalg.norm(finals[k][:3, 3].astype(np.float64) - To[:3, 3])), "max_dr_rad": rot_angle(finals[k][:3, :3], To[:3, :3]),
+                                 "same_iterations": int(o.getFinalNumIteration()) == int(its[0]) if its else None}
+        out[name] = rec
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,6 +220,8 @@ def main():
     ap.add_argument("--shard-of", type=int, default=0, help="--mode shard on ONE GPU: run only rank 0's shard of an N-rank job (no process group): what each GPU of an "
                                                            "N-GPU node would do per step, for projecting the strong scaling where N GPUs are not at hand")
     ap.add_argument("--prepare-only", action="store_true", help="generate (and cache) the synthetic scans, then exit without touching the GPU")
+    ap.add_argument("--parity-pairs", type=int, default=0, help="pairs of the step checked against the CPU oracle (0: all of them; the CPU TIMING uses --cpu-pairs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs behind the main line (setInputTarget / align split, host-pointer rate, pipeline shape, config[2] GICP)")
     ap.add_argument("--latency", action="store_true", help="also time single-pair setInputTarget+align latency (extra, differently sized launches of the "
                                                             "same kernels: off by default so rocprof averages of the default run describe the timed workload)")
     args = ap.parse_args()
@@ -381,6 +454,7 @@ def main():
         guess = np.eye(4) if cold else synth.warm_guess(rels[k], 1000 * rank + b)
         pairs.append((k, k + 1, guess, rels[k], cold))
     n_pts = float(np.mean([len(scans[p[1]]) for p in pairs]))
+    n_src_per_step = float(sum(len(scans[p[1]]) for p in pairs)) / args.batch  # mean source points per alignment
     hbm_input_bytes = 16.0 * sum(len(scans[p[0]]) + len(scans[p[1]]) for p in pairs)
     t_gen = time.time() - t_gen
 
@@ -433,6 +507,72 @@ def main():
                      "achieved_GBps": (m0[2] / 1e9) / (m0[0] / 1e3), "frac": (m0[2] / 1e9) / (m0[0] / 1e3) / HBM_PEAK_GBPS,
                      "note": "MRGFE_FUSED=0 (one launch per variant), 2 steps outside the timed region"}
 
+    # ---- the rest of SURVEY.md §8(d), all outside the timed region above (never `value`) ------------------------------------------
+    extras = {}
+    if not args.no_extras and rank == 0:
+        # (1) setInputTarget and align apart (a synchronisation between them; the timed steps run them back to back)
+        split = []
+        for _ in range(3):
+            bm.clear()
+            bm.add_device(*add_args)
+            ctx.synchronize()
+            ta = time.perf_counter()
+            bm.build_targets()
+            ctx.synchronize()
+            tb = time.perf_counter()
+            bm.align()
+            split.append((1e3 * (tb - ta), 1e3 * (time.perf_counter() - tb)))
+        extras["gpu_split_ms_per_step"] = {"set_target_ms": float(np.median([a for a, _ in split])), "align_ms": float(np.median([b for _, b in split])),
+                                           "pairs_per_step": args.batch, "note": "mrgfe_batch_build_targets then mrgfe_batch_align, device-resident clouds, median of 3 steps"}
+        # (2) PCIe-inclusive rate: both clouds of every pair handed over as HOST pointers inside the timed region
+        def host_step():
+            bm.clear()
+            for (ti, si, guess, _, _) in pairs:
+                t = bm.add_target(scans[ti])
+                bm.add_pair(t, scans[si], guess)
+            return bm.align()
+
+        host_step()
+        ctx.synchronize()
+        th = time.perf_counter()
+        n_host = 3
+        for _ in range(n_host):
+            host_res = host_step()
+        ctx.synchronize()
+        th = time.perf_counter() - th
+        extras["value_host_pointers"] = {"value": args.batch * n_host / th, "unit": "alignments/s", "ms_per_step": 1e3 * th / n_host, "steps": n_host,
+                                         "same_results_as_device_pointers": bool(np.array_equal(host_res["T"], res["T"])),
+                                         "note": f"mrgfe_batch_add_target + mrgfe_batch_add_pair with host clouds ({hbm_input_bytes / 1e6:.0f} MB over PCIe per step through the pinned staging ring) + align"}
+        # (3) pipeline shape: what prefiltering_component -> scan_matching_odometry really feeds NDT (distance + 0.1 m voxel + radius outlier filter)
+        if args.prefilter != "full" and raw is not None:
+            f_host = [prefilter(sc, ctx=ctx) for sc in raw]
+            f_dev = [torch.from_numpy(sc).to(gdev) for sc in f_host]
+            f_args = ([f_dev[p[0]].data_ptr() for p in pairs], [len(f_host[p[0]]) for p in pairs], np.arange(args.batch, dtype=np.int32),
+                      [f_dev[p[1]].data_ptr() for p in pairs], [len(f_host[p[1]]) for p in pairs], np.stack([p[2] for p in pairs]))
+
+            def f_step():
+                bm.clear()
+                bm.add_device(*f_args)
+                return bm.align()
+
+            f_step()
+            ctx.synchronize()
+            tf = time.perf_counter()
+            n_f = 5
+            for _ in range(n_f):
+                f_res = f_step()
+            ctx.synchronize()
+            tf = time.perf_counter() - tf
+            f_err = [float(np.linalg.norm(result_matrix(f_res[b])[:3, 3] - pairs[b][3][:3, 3])) for b in range(args.batch)]
+            extras["pipeline_shape"] = {"value": args.batch * n_f / tf, "unit": "alignments/s", "ms_per_step": 1e3 * tf / n_f, "steps": n_f,
+                                        "mean_points_per_scan": float(np.mean([len(c) for c in f_host])), "iterations_per_alignment": float(f_res["iterations"].mean()),
+                                        "median_translation_error_vs_truth_m": float(np.median(f_err)),
+                                        "note": "the same pairs after mrgfe_prefilter (distance 0.1-35 m, VoxelGrid 0.1 m, RadiusOutlierRemoval 0.5 m / 2): the synthetic street saturates "
+                                                "that voxel grid at a quarter of the points"}
+            del f_dev
+        # (4) BASELINE config[2]: GICP scan-to-keyframe (the k-NN correspondence path), keyframe = scan 0, frames = scans 1..6
+        extras["config2_gicp"] = run_config2(ctx, scans, dev, poses, lib, args)
+
     shard = None
     if args.shard_steps > 0:
         shard = run_shard(args.shard_steps, 1)
@@ -473,34 +613,54 @@ def main():
         # reference default beside it
         sweep = sorted({t for t in (8, 16, 32, 64, host_cores) if t <= host_cores})
 
-        def run_cpu(nt, sample):
-            o = orc.Ndt(resolution=1.0, transformation_epsilon=args.eps, maximum_iterations=64, num_threads=nt)
-            tc, out = time.perf_counter(), []
+        def run_cpu(nt, sample, thread_sums=True):
+            # thread_sums: ndt_omp's own accumulation (one accumulator per OpenMP thread) — what is TIMED; the checker's per-point records
+            # added in point order (thread-count invariant, but 45 MB written and summed serially per evaluation) would not scale at all
+            o = orc.Ndt(resolution=1.0, transformation_epsilon=args.eps, maximum_iterations=64, num_threads=nt, thread_sums=thread_sums)
+            t_set = t_align = 0.0
+            out = []
             for (ti, si, guess, _, _) in sample:
+                t0 = time.perf_counter()
                 o.setInputTarget(scans[ti])
+                t1 = time.perf_counter()
                 o.setInputSource(scans[si])
                 o.align(guess)
+                t2 = time.perf_counter()
+                t_set += t1 - t0
+                t_align += t2 - t1
                 out.append((o.getFinalTransformation(), o.hasConverged(), o.getFinalNumIteration(), o.evals))
-            return time.perf_counter() - tc, out
+            return t_set + t_align, t_set, t_align, out
 
         probe = pairs[:min(8, ncpu)]  # thread-count probe on a few pairs, then the whole sample with the fastest setting
-        probe_s = {nt: run_cpu(nt, probe)[0] for nt in sweep}
-        cores = min(sweep, key=lambda nt: probe_s[nt])
-        tc, o_res = run_cpu(cores, pairs[:ncpu])
+        probe_r = {nt: run_cpu(nt, probe) for nt in sweep}
+        cores = min(sweep, key=lambda nt: probe_r[nt][0])
+        tc, tc_set, tc_align, o_res = run_cpu(cores, pairs[:ncpu])
         cpu = {"value": ncpu / tc, "unit": "alignments/s", "cores": cores, "kind": "port",
                "sample": f"{ncpu} of the {args.batch} pairs of one step (setInputTarget+align each, same warm/cold guesses), CPU oracle = restated pclomp NDT_OMP "
                          f"(not the upstream library: parity unpinned, DESIGN.md §2), -O3 -fopenmp, fastest of OpenMP thread counts {sweep} on a {host_cores}-thread "
                          f"host = {cores} threads, {tc:.2f} s",
-               "reference_default_8_threads": {"value": len(probe) / probe_s[8], "pairs": len(probe), "note": "reg_num_threads: 8 (config/mrg_slam.yaml:101)"} if 8 in probe_s else None,
+               "set_target_ms_per_pair": 1e3 * tc_set / ncpu, "align_ms_per_pair": 1e3 * tc_align / ncpu,
+               "reference_default_8_threads": {"value": len(probe) / probe_r[8][0], "pairs": len(probe), "set_target_ms_per_pair": 1e3 * probe_r[8][1] / len(probe),
+                                               "align_ms_per_pair": 1e3 * probe_r[8][2] / len(probe), "note": "reg_num_threads: 8 (config/mrg_slam.yaml:101)"} if 8 in probe_r else None,
+               "split_note": "timed with ndt_omp's accumulation (one score / gradient / Hessian accumulator per OpenMP thread, static chunks); setInputTarget "
+                             "(VoxelGridCovariance::filter) and computeHessian are serial in ndt_omp and in the restatement",
                "host_cpu": next((ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")), "unknown")}
-        dts, drs, same = [], [], True
-        for k in range(ncpu):
+        # parity on ALL pairs of the step (the timing above is the sample; the check is not): the remaining pairs at the same thread count, untimed
+        n_par = len(pairs) if args.parity_pairs <= 0 else min(args.parity_pairs, len(pairs))
+        if n_par > ncpu:
+            o_res = o_res + run_cpu(cores, pairs[ncpu:n_par], thread_sums=False)[3]
+        n_par = len(o_res)
+        dts, drs, over, mism, capped = [], [], 0, 0, 0
+        for k in range(n_par):
             Tg = result_matrix(res[k])
             To, conv, it, ev = o_res[k]
             dts.append(float(np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3])))
             drs.append(rot_angle(Tg[:3, :3], To[:3, :3]))
-            same = same and bool(res[k]["converged"]) == conv and int(res[k]["iterations"]) == it
-        parity = {"pairs": ncpu, "max_dt_m": max(dts), "max_dr_rad": max(drs), "same_iterations_and_convergence": same, "bar": "1e-4 m / 1e-4 rad"}
+            over += int(dts[-1] > 1e-4 or drs[-1] > 1e-4)
+            mism += int(bool(res[k]["converged"]) != conv or int(res[k]["iterations"]) != it)
+            capped += int(it > 64)
+        parity = {"pairs": n_par, "max_dt_m": max(dts), "max_dr_rad": max(drs), "pairs_over_bar": over, "pairs_with_other_iterations_or_convergence": mism,
+                  "pairs_at_the_iteration_limit": capped, "same_iterations_and_convergence": mism == 0, "bar": "1e-4 m / 1e-4 rad"}
 
     # dominant kernel.  Fused launches (default): ndt_derivatives_all_kernel<7>, ONE launch per round that runs the work items of all
     # three evaluation kinds (score + gradient + Hessian, score + gradient, f64 Hessian): its time and launch count are reported
@@ -574,6 +734,7 @@ def main():
         "cpu_baseline": cpu,
         "parity_vs_oracle": parity,
         "evaluations_per_alignment": evals / (args.batch * args.steps),
+        "evaluations_launched_per_alignment": float(launched[0] / (n_src_per_step * args.batch * args.steps)) if n_src_per_step else None,
         "iterations_per_alignment": iters / (args.batch * args.steps),
         "iterations_warm_cold": [float(np.mean(res["iterations"][warm_ix])) if warm_ix else None, float(np.mean(res["iterations"][cold_ix])) if cold_ix else None],
         "converged": int(res["converged"].sum()),
@@ -581,6 +742,10 @@ def main():
         "single_pair_latency_ms": single_ms,
         "median_translation_error_vs_truth_m": float(np.median(true_err)),
         "input_generation_s": t_gen,
+        "value_host_pointers": extras.get("value_host_pointers"),
+        "gpu_split_ms_per_step": extras.get("gpu_split_ms_per_step"),
+        "pipeline_shape": extras.get("pipeline_shape"),
+        "config2_gicp": extras.get("config2_gicp"),
         "config3_shard": shard,
     }
     print(json.dumps(out))

@@ -105,6 +105,11 @@ void* mrgfe_ctx_stream(mrgfe_ctx* ctx);
  * blocks, out[6..9] = occupancy words fetched / boxes tested against the sphere / cells opened / candidate points measured by the seed +
  * sweep pass (0 unless MRGFE_FIT_STATS=1), out[10] = number of passes run on this context so far. */
 int mrgfe_ctx_fitness_stats(mrgfe_ctx* ctx, double out[11]);
+/* The same for the last exact k-NN launch on this context (nn_knn_kernel: the k = 20 neighbourhoods behind the GICP covariances of
+ * setInputSource / setInputTarget, registrations.cpp:46-63; StatisticalOutlierRemoval; mrgfe_knn): out[0] = HIP-event milliseconds of the
+ * launch, out[1] = queries, out[2] = k, out[3] = candidate points measured (0 unless the diagnostic counters are on,
+ * mrgfe_dbg_set_fit_stats), out[4] = k-NN launches on this context so far.  Waits for that launch to finish. */
+int mrgfe_ctx_knn_stats(mrgfe_ctx* ctx, double out[5]);
 
 /* ---- cloud ingest --------------------------------------------------------------------------------- */
 /* replaces pcl::fromROSMsg(*cloud_msg, *cloud) (apps/prefiltering_component.cpp:119-120, scan_matching_odometry_component.cpp:144-145):

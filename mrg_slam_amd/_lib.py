@@ -99,6 +99,7 @@ SIGNATURES = {
     "mrgfe_ctx_synchronize": (C.c_int, [_vp]),
     "mrgfe_ctx_stream": (_vp, [_vp]),
     "mrgfe_ctx_fitness_stats": (C.c_int, [_vp, _dp]),
+    "mrgfe_ctx_knn_stats": (C.c_int, [_vp, _dp]),
     "mrgfe_ingest_pointcloud2": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, _fp, _vp]),
     "mrgfe_reg_default_params": (None, [C.c_int, C.POINTER(RegParams)]),
     "mrgfe_reg_create": (C.c_int, [_vp, C.POINTER(RegParams), C.POINTER(_vp)]),
@@ -253,6 +254,12 @@ class Context:
         check(lib().mrgfe_ctx_fitness_stats(self._h, v))
         keys = ("ms_block", "ms_sweep", "ms_far", "queries", "queued", "queued_far", "words", "boxes_tested", "cells", "points", "calls")
         return dict(zip(keys, [float(x) for x in v]))
+
+    def knn_stats(self) -> dict:
+        """The last exact k-NN launch on this context (``mrgfe_ctx_knn_stats``)."""
+        v = (C.c_double * 5)()
+        check(lib().mrgfe_ctx_knn_stats(self._h, v))
+        return dict(zip(("ms", "queries", "k", "candidates", "launches"), [float(x) for x in v]))
 
     def close(self):
         if getattr(self, "_h", None):

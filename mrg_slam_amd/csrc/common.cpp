@@ -314,6 +314,8 @@ void mrgfe_ctx_destroy(mrgfe_ctx* ctx)
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (auto& pr : ctx->ev_mode) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->ev_fit) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->knn_stats.ev) if (e) (void)hipEventDestroy(e);
+    ctx->knn_stats.counter.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -327,6 +329,27 @@ int mrgfe_ctx_synchronize(mrgfe_ctx* ctx)
 }
 
 void* mrgfe_ctx_stream(mrgfe_ctx* ctx) { return ctx ? static_cast<void*>(ctx->stream) : nullptr; }
+
+int mrgfe_ctx_knn_stats(mrgfe_ctx* ctx, double out[5])
+{
+    if (!ctx || !out) { mrgfe::set_error("mrgfe_ctx_knn_stats: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);
+    MRGFE_TRY(ctx->bind());
+    mrgfe::KnnStats& ks = ctx->knn_stats;
+    for (int k = 0; k < 5; ++k) out[k] = 0.0;
+    if (!ks.launches || !ks.ev[1]) return MRGFE_OK;
+    MRGFE_HIP_CHECK(hipEventSynchronize(ks.ev[1]));
+    float ms = 0;
+    MRGFE_HIP_CHECK(hipEventElapsedTime(&ms, ks.ev[0], ks.ev[1]));
+    unsigned long long cand = 0;
+    if (ks.counted) MRGFE_HIP_CHECK(hipMemcpy(&cand, ks.counter.p, 8, hipMemcpyDeviceToHost));
+    out[0] = ms;
+    out[1] = double(ks.queries);
+    out[2] = double(ks.k);
+    out[3] = double(cand);
+    out[4] = double(ks.launches);
+    return MRGFE_OK;
+}
 
 int mrgfe_ctx_fitness_stats(mrgfe_ctx* ctx, double out[11])
 {

@@ -94,6 +94,14 @@ struct FitStats {
         calls += 1;
     }
 };
+// the last k-NN launch on a context (NnGrid::knn_device: GICP covariances, StatisticalOutlierRemoval, mrgfe_knn)
+struct KnnStats {
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    DevBuf     counter;      // candidates measured (diagnostic counters on)
+    uint64_t   queries = 0, launches = 0;
+    int        k = 0;
+    bool       counted = false;
+};
 }  // namespace mrgfe
 
 struct mrgfe_ctx {
@@ -110,6 +118,7 @@ struct mrgfe_ctx {
     int          up_next = 0;
     hipEvent_t   ev_fit[4] = {nullptr, nullptr, nullptr, nullptr};  // around the passes of nn_fitness_batch
     mrgfe::FitStats fit_stats;                  // of the last nn_fitness_batch on this context
+    mrgfe::KnnStats knn_stats;                  // of the last k-NN launch on this context
     int          cu_count = 256;
     mrgfe::NnGrid* tmp_grid = nullptr;          // reusable exact-NN grid of the stateless filter / fitness calls (nn_grid.hip)
     std::recursive_mutex mu;                    // serialises API calls that share this context's stream / workspaces

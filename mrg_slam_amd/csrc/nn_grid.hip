@@ -1151,7 +1151,8 @@ __device__ __forceinline__ void knn_sort_merge(float& td, int32_t& ti, float d, 
     for (int stride = 32; stride > 0; stride >>= 1) knn_cmpx(td, ti, stride, true);
 }
 
-__global__ __launch_bounds__(256) void nn_knn_kernel(NnGrid2Dev g, const float4* __restrict__ q, uint32_t n, int k, int32_t* __restrict__ idx, float* __restrict__ sqd)
+__global__ __launch_bounds__(256) void nn_knn_kernel(NnGrid2Dev g, const float4* __restrict__ q, uint32_t n, int k, int32_t* __restrict__ idx, float* __restrict__ sqd,
+                                                      unsigned long long* __restrict__ stats)
 {
     const uint32_t i = (blockIdx.x * 256u + threadIdx.x) >> 6;
     if (i >= n) return;  // uniform per wave
@@ -1162,6 +1163,7 @@ __global__ __launch_bounds__(256) void nn_knn_kernel(NnGrid2Dev g, const float4*
     float        kth_d = INFINITY;  // current k-th entry (uniform); (inf, max) while the list is not full
     int32_t      kth_i = 0x7fffffff;
     int          cnt = 0;
+    uint32_t     n_cand = 0;  // candidates measured (uniform; diagnostics)
     if (g.level[0].n > 0 && finite3(p.x, p.y, p.z)) {
         bool done = false;
         for (int l = 0; l < g.n_levels && !done; ++l) {
@@ -1183,6 +1185,7 @@ __global__ __launch_bounds__(256) void nn_knn_kernel(NnGrid2Dev g, const float4*
                     ci = __float_as_int(cand.w);
                 }
                 const bool beats = valid && (d < kth_d || (d == kth_d && ci < kth_i));
+                n_cand += static_cast<uint32_t>(__popcll(__ballot(valid)));
                 uint64_t   m = __ballot(beats);
                 if (!again && __popcll(m) >= kKnnSortMin) {  // many at once (the first steps of a query): sort + merge
                     knn_sort_merge(td, ti, beats ? d : INFINITY, beats ? ci : 0x7fffffff);
@@ -1296,6 +1299,7 @@ __global__ __launch_bounds__(256) void nn_knn_kernel(NnGrid2Dev g, const float4*
         idx[size_t(i) * k + lane] = lane < cnt ? ti : -1;
         sqd[size_t(i) * k + lane] = lane < cnt ? td : -1.0f;
     }
+    if (stats != nullptr && lane == 0 && n_cand) atomicAdd(stats, static_cast<unsigned long long>(n_cand));
 }
 
 int NnGrid::knn_device(mrgfe_ctx* ctx, const float4* d_q, size_t n, int k, int32_t* d_idx, float* d_sqd)
@@ -1305,8 +1309,24 @@ int NnGrid::knn_device(mrgfe_ctx* ctx, const float4* d_q, size_t n, int k, int32
     if (n == 0) return MRGFE_OK;
     if (n > (0xffffffffu >> 6)) { set_error("NnGrid::knn: too many queries"); return MRGFE_ERR_INVALID; }
     const uint32_t nn = static_cast<uint32_t>(n);
-    hipLaunchKernelGGL(nn_knn_kernel, dim3((nn + 3) / 4), dim3(256), 0, ctx->stream, h_, d_q, nn, k, d_idx, d_sqd);
+    // measurement hook (mrgfe_ctx_knn_stats): HIP events around the launch; with the diagnostic counters on, the candidates it measures
+    KnnStats& ks = ctx->knn_stats;
+    for (auto& e : ks.ev)
+        if (!e) MRGFE_HIP_CHECK(hipEventCreate(&e));
+    unsigned long long* d_cand = nullptr;
+    if (fit_stats_mode() != 0) {
+        MRGFE_TRY(ks.counter.ensure(8));
+        d_cand = ks.counter.as<unsigned long long>();
+        MRGFE_HIP_CHECK(hipMemsetAsync(d_cand, 0, 8, ctx->stream));
+    }
+    MRGFE_HIP_CHECK(hipEventRecord(ks.ev[0], ctx->stream));
+    hipLaunchKernelGGL(nn_knn_kernel, dim3((nn + 3) / 4), dim3(256), 0, ctx->stream, h_, d_q, nn, k, d_idx, d_sqd, d_cand);
     MRGFE_HIP_CHECK(hipGetLastError());
+    MRGFE_HIP_CHECK(hipEventRecord(ks.ev[1], ctx->stream));
+    ks.queries = n;
+    ks.k = k;
+    ks.counted = d_cand != nullptr;
+    ks.launches += 1;
     return MRGFE_OK;
 }
 

@@ -366,14 +366,56 @@ template <bool FUSED>
 double Ndt::compute_derivatives_impl(double grad[6], double hess[36], const double p[6], bool compute_hessian)
 {
     const int n = static_cast<int>(source.size() / 4);
-    scores_.assign(n, 0.0);
-    grads_.assign(static_cast<size_t>(n) * 6, 0.0);
-    hessians_.assign(static_cast<size_t>(n) * 36, 0.0);
     angle_derivatives(p, true);
     ++n_evals;
     const float  gauss_d2f = static_cast<float>(gauss_d2);
     const double gd1       = gauss_d1;
     long long    nb_total  = 0;
+    if (thread_sums) {
+        // ndt_omp's own shape: scores / score_gradients / hessians per thread (`thread_n = omp_get_thread_num()`), summed over the threads afterwards.
+        // schedule(static) where upstream has schedule(guided, 8): with a dynamic schedule the sums of two evaluations AT THE SAME POSE differ in the
+        // last bits, and More-Thuente with mrg_slam's parameters (every step clamped to [eps / 2, 0.1]) re-evaluates the pose it has just been at —
+        // the interval update then divides a rounding difference by zero and the search ends in a NaN step now and then (seen in a quarter of the
+        // runs of one bench pair with 4 threads).  Static chunks keep re-evaluations bitwise repeatable; the thread-order sums remain.
+        const int nt = std::max(1, num_threads);
+        std::vector<double> acc(static_cast<size_t>(nt) * 48, 0.0);
+#pragma omp parallel for num_threads(num_threads) schedule(static) reduction(+ : nb_total)
+        for (int idx = 0; idx < n; ++idx) {
+            const float xt[3] = {trans_[3 * idx], trans_[3 * idx + 1], trans_[3 * idx + 2]};
+            int nb[27];
+            int cnt = cells.neighbours(xt[0], xt[1], xt[2], search, nb);
+            if (cnt == 0) continue;
+            nb_total += cnt;
+            const float* xp = &source[4 * static_cast<size_t>(idx)];
+            const float x4[3] = {xp[0], xp[1], xp[2]};
+            PointTermsF P;
+            point_terms_f<FUSED>(xt, x4, j_ang_f, h_ang_f, P);
+            double pt[43] = {0};
+            for (int k = 0; k < cnt; ++k) {
+                float score_inc, t_g[6], t_h[36];
+                if (!pair_terms_f<FUSED>(P, cells.leaves[nb[k]], gauss_d2f, gd1, compute_hessian, &score_inc, t_g, t_h)) continue;
+                pt[0] += static_cast<double>(score_inc);
+                for (int c = 0; c < 6; ++c) pt[1 + c] += static_cast<double>(t_g[c]);
+                if (!compute_hessian) continue;
+                for (int c = 0; c < 36; ++c) pt[7 + c] += static_cast<double>(t_h[c]);
+            }
+            double* a = &acc[static_cast<size_t>(omp_get_thread_num()) * 48];
+            for (int c = 0; c < 43; ++c) a[c] += pt[c];
+        }
+        neighbours_sum += n > 0 ? static_cast<double>(nb_total) / n : 0.0;
+        double score = 0;
+        for (int k = 0; k < 6; ++k) grad[k] = 0;
+        for (int k = 0; k < 36; ++k) hess[k] = 0;
+        for (int t = 0; t < nt; ++t) {
+            score += acc[static_cast<size_t>(t) * 48];
+            for (int k = 0; k < 6; ++k) grad[k] += acc[static_cast<size_t>(t) * 48 + 1 + k];
+            for (int k = 0; k < 36; ++k) hess[k] += acc[static_cast<size_t>(t) * 48 + 7 + k];
+        }
+        return score;
+    }
+    scores_.assign(n, 0.0);
+    grads_.assign(static_cast<size_t>(n) * 6, 0.0);
+    hessians_.assign(static_cast<size_t>(n) * 36, 0.0);
 
 #pragma omp parallel for num_threads(num_threads) schedule(guided, 8) reduction(+ : nb_total)
     for (int idx = 0; idx < n; ++idx) {

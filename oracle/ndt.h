@@ -49,6 +49,9 @@ struct Ndt {
     NdtSearch search         = NDT_DIRECT7;
     bool   fused             = true;   // float/double three-term products accumulated with FMA (see ndt.cpp dot3f)
     int    gpu_order_ppt     = 0;      // > 0: diagnostic — add the terms in the HIP kernels' order, items of this many 256-point tiles (ndt.cpp)
+    bool   thread_sums       = false;  // true: upstream's accumulation — one score / gradient / Hessian accumulator per OpenMP thread, added up in
+                                       // thread order (ndt_omp computeDerivatives): the sums depend on the schedule in the last bits, which is why the
+                                       // checker keeps per-point records and adds them in point order; this mode is what bench.py TIMES (cpu_baseline)
 
     VoxelGridCovariance cells;
     std::vector<float> target, source;  // xyzi

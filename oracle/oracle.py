@@ -59,6 +59,7 @@ def lib():
             "orc_inf_weight": (C.c_double, [C.c_double] * 5),
             "orc_inf_matrix": (None, [dp, C.c_double, dp]),
             "orc_ndt_set_fused": (None, [vp, C.c_int]),
+            "orc_ndt_set_thread_sums": (None, [vp, C.c_int]),
             "orc_ndt_set_gpu_order": (None, [vp, C.c_int]),
             "orc_ndt_set_target": (C.c_int, [vp, fp, C.c_int]),
             "orc_ndt_set_source": (None, [vp, fp, C.c_int]),
@@ -275,7 +276,7 @@ class Ndt:
     """pclomp::NormalDistributionsTransform restated (oracle/ndt.cpp) behind the pcl::Registration call surface."""
 
     def __init__(self, resolution=1.0, step_size=0.1, outlier_ratio=0.55, transformation_epsilon=0.1, maximum_iterations=64, num_threads=1,
-                 search="DIRECT7", fused=True, gpu_order_ppt=0):
+                 search="DIRECT7", fused=True, gpu_order_ppt=0, thread_sums=False):
         """gpu_order_ppt > 0 (diagnostic): the derivative sums are added in the HIP kernels' order (items of that many 256-point
         tiles, lane round-robin, shuffle tree, slice reduce) instead of the reference's point order, so that a GPU result can be
         reproduced bit for bit and summation-order noise told from an arithmetic difference (oracle/ndt.cpp)."""
@@ -283,6 +284,9 @@ class Ndt:
         lib().orc_ndt_set_params(self._h, resolution, step_size, outlier_ratio, transformation_epsilon, maximum_iterations, num_threads, SEARCH[search])
         lib().orc_ndt_set_fused(self._h, int(fused))
         lib().orc_ndt_set_gpu_order(self._h, int(gpu_order_ppt))
+        # thread_sums: ndt_omp's own accumulation (one accumulator per OpenMP thread, added in thread order: schedule-dependent in the last
+        # bits) instead of the checker's per-point records added in point order — the mode bench.py times as cpu_baseline
+        lib().orc_ndt_set_thread_sums(self._h, int(thread_sums))
         self._n_src = 0
 
     def __del__(self):

@@ -127,6 +127,7 @@ void  orc_ndt_set_params(void* h, double resolution, double step_size, double ou
 }
 void orc_ndt_set_gpu_order(void* h, int ppt) { static_cast<Ndt*>(h)->gpu_order_ppt = ppt; }
 void orc_ndt_set_fused(void* h, int fused) { static_cast<Ndt*>(h)->fused = fused != 0; }
+void orc_ndt_set_thread_sums(void* h, int on) { static_cast<Ndt*>(h)->thread_sums = on != 0; }
 int  orc_ndt_set_target(void* h, const float* xyzi, int n) { return static_cast<Ndt*>(h)->set_target(xyzi, n); }
 void orc_ndt_set_source(void* h, const float* xyzi, int n) { static_cast<Ndt*>(h)->set_source(xyzi, n); }
 void orc_ndt_align(void* h, const float guess_colmajor[16], float* aligned_or_null)

@@ -219,3 +219,30 @@ def test_derivatives_match_the_first_principles_model(search):
         assert abs(diff[4, 4]) > 1e-9 * np.abs(Htrue).max()
         diff[4, 4] = 0
         assert np.abs(diff).max() <= 1e-11 * np.abs(Htrue).max()
+
+
+def test_thread_sums_mode_agrees_with_point_order_sums(street_pair_vlp16):
+    """The accumulation bench.py TIMES as cpu_baseline (ndt_omp's: one accumulator per OpenMP thread, added in thread order) against the
+    checker's (per-point records added in point order): the same sums to rounding, the same alignment."""
+    from mrg_slam_amd import synth
+
+    tgt, src, rel = street_pair_vlp16
+    guess = synth.warm_guess(rel, 3)
+    p = np.concatenate([guess[:3, 3], orc.euler_xyz(guess)])
+    ref = orc.Ndt(num_threads=2)
+    ref.setInputTarget(tgt)
+    ref.setInputSource(src)
+    for nt in (1, 3, 4):
+        o = orc.Ndt(num_threads=nt, thread_sums=True)
+        o.setInputTarget(tgt)
+        o.setInputSource(src)
+        for mode in (0, 1):
+            s0, g0, h0 = ref.evaluate(guess, p, mode)
+            s1, g1, h1 = o.evaluate(guess, p, mode)
+            assert s1 == pytest.approx(s0, rel=1e-12)
+            np.testing.assert_allclose(g1, g0, rtol=0, atol=1e-11 * np.abs(g0).max())
+            np.testing.assert_allclose(h1, h0, rtol=0, atol=1e-11 * max(np.abs(h0).max(), 1e-300))
+        ref.align(guess)
+        o.align(guess)
+        np.testing.assert_allclose(o.getFinalTransformation(), ref.getFinalTransformation(), atol=1e-6)
+        assert o.getFinalNumIteration() == ref.getFinalNumIteration()
