@@ -1,0 +1,75 @@
+"""GPU, several PROCESSES on one card: BASELINE config[4] (two robots, one process each, concurrent odometry streams on VLP-64 scans and
+an inter-robot 64-candidate loop-closure batch, everything held against the CPU oracle run sequentially) and the two-rank record gather with
+the real BatchMatcher.  The children are started as ordinary child processes (never an exec of this process)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_all(cmds, timeout):
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    procs = [subprocess.Popen(c, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for c in cmds]
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    return outs
+
+
+def test_config4_two_robot_processes_at_stated_size(tmp_path):
+    """BASELINE config[4]: 2 robots = 2 processes on the GPU at once (kitti_multirobot_processor.py:164-172), VLP-64 scans through the
+    prefilter chain, 12 frames each with keyframe switches (scan_matching_odometry_component.cpp:326-339), then 64 inter-robot candidates
+    per robot with getFitnessScore(inf).  Each process compares itself with the oracle's sequential run of the same loops."""
+    frames = 12
+    outs = _run_all([[sys.executable, os.path.join(ROOT, "tests", "workers", "robot_worker.py"), str(r), str(frames), str(tmp_path / f"robot{r}.json")] for r in (0, 1)], timeout=900)
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0, (r, e[-3000:])
+        d = json.load(open(tmp_path / f"robot{r}.json"))
+        assert d["points_per_filtered_scan"] > 20000  # VLP-64 scans after the 0.1 m voxel prefilter
+        assert d["keyframes_gpu"] == d["keyframes_cpu"] and d["keyframes_gpu"] >= 4  # 1 m per scan against keyframe_delta_translation 1.0: several switches
+        assert d["odometry_max_dt_m"] <= 1e-4 and d["odometry_max_dr_rad"] <= 1e-4, d
+        assert d["odometry_same_iterations"], d
+        assert d["batch_max_dt_m"] <= 1e-4 and d["batch_max_dr_rad"] <= 1e-4 and d["batch_mismatches"] == 0, d
+        assert d["batch_max_rel_fitness_diff"] <= 1e-6, d
+        assert d["batch_best_gpu"] == d["batch_best_cpu"], d
+        assert d["final_odom_error_vs_truth_m"] < 0.5, d
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_gloo_ranks_with_the_real_matcher_equal_one_rank(tmp_path):
+    """Two ranks share the card (gloo: RCCL refuses duplicate devices), each aligns its block of the candidate list with the real BatchMatcher,
+    the records are all-gathered and the best candidate replayed: bit for bit the records and the answer of ONE rank matching all candidates."""
+    n = 23
+    worker = os.path.join(ROOT, "tests", "workers", "gloo_matcher_worker.py")
+    one = _run_all([[sys.executable, worker, "0", "1", "0", str(n), str(tmp_path / "one.npy")]], timeout=600)
+    assert one[0][0] == 0, one[0][2][-3000:]
+    port = _free_port()
+    two = _run_all([[sys.executable, worker, str(r), "2", str(port), str(n), str(tmp_path / "two.npy")] for r in (0, 1)], timeout=600)
+    for rc, o, e in two:
+        assert rc == 0, e[-3000:]
+    a, b = np.load(tmp_path / "one.npy"), np.load(tmp_path / "two.npy")
+    assert len(a) == len(b) == n
+    for f in ("T", "fitness", "converged", "iterations", "evaluations", "pair_id"):
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+    np.testing.assert_allclose(a["H"], b["H"], rtol=1e-12)  # f64 sums carry the order of a round's items (1e-15 relative)
+    assert one[0][1].strip().splitlines()[-1].split() == two[0][1].strip().splitlines()[-1].split()  # same best candidate and score (gloo chats on stdout before it)
