@@ -44,7 +44,9 @@
 
 namespace mrgfe_pcl {
 
-// One context per process and GPU (stream + workspaces), shared by every registration object on that GPU.
+#ifndef MRGFE_PCL_SHARED_CONTEXT
+#define MRGFE_PCL_SHARED_CONTEXT
+// One context per process and GPU (stream + workspaces), shared by every adapter object on that GPU.
 inline mrgfe_ctx* shared_context(int device = 0)
 {
     static std::mutex               mu;
@@ -57,13 +59,16 @@ inline mrgfe_ctx* shared_context(int device = 0)
     ctxs[device] = ctx;
     return ctx;
 }
-
-// stride_bytes descriptor of a PCL point type with x, y, z and intensity members (pcl::PointXYZI: 32 bytes, intensity at 16)
+// stride_bytes descriptor of a PCL point type with x, y, z and intensity members (pcl::PointXYZI: 32 bytes, intensity at 16);
+// member addresses of an object instead of offsetof: PCL's point types are not standard-layout (-Winvalid-offsetof)
 template <typename PointT>
-inline size_t point_layout()
+inline std::size_t point_layout()
 {
-    return MRGFE_LAYOUT(sizeof(PointT), offsetof(PointT, x), offsetof(PointT, intensity));
+    static const PointT p{};
+    const char* base = reinterpret_cast<const char*>(&p);
+    return MRGFE_LAYOUT(sizeof(PointT), static_cast<std::size_t>(reinterpret_cast<const char*>(&p.x) - base), static_cast<std::size_t>(reinterpret_cast<const char*>(&p.intensity) - base));
 }
+#endif
 
 // The target "kd-tree" of a HipRegistration: a pcl::search::KdTree whose FLANN index is never built.  1-NN queries that walk
 // final_transformation * source in order (pcl::Registration::getFitnessScore, the scan-matching status loop) are answered from
@@ -78,13 +83,29 @@ class GpuTargetSearch : public pcl::search::KdTree<PointT> {
 
     explicit GpuTargetSearch(mrgfe_reg* reg) : reg_(reg) {}
 
-    // initCompute() / setInputTarget never reach FLANN: remember the cloud for the lazy fallback only
+    // initCompute() / setInputTarget never reach FLANN: remember the cloud for the lazy fallback only.
+    // (pcl::search::KdTree::setInputCloud returns void up to PCL 1.12 — ROS 2 Humble — and bool from 1.13 on — Jazzy.)
+#if defined(PCL_VERSION_COMPARE)
+#if PCL_VERSION_COMPARE(>=, 1, 13, 0)
+#define MRGFE_PCL_SET_INPUT_RETURNS_BOOL 1
+#endif
+#endif
+#ifdef MRGFE_PCL_SET_INPUT_RETURNS_BOOL
+    bool setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) override
+    {
+        cloud_ = cloud;
+        indices_ = indices;
+        flann_built_ = false;
+        return true;
+    }
+#else
     void setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) override
     {
         cloud_ = cloud;
         indices_ = indices;
         flann_built_ = false;
     }
+#endif
     PointCloudConstPtr getInputCloud() const override { return cloud_; }
 
     // the registration hands over final_transformation * source (packed xyzi, n points) after every align()
@@ -105,9 +126,16 @@ class GpuTargetSearch : public pcl::search::KdTree<PointT> {
         k_indices.resize(1);
         k_sqr_distances.resize(1);
         const std::size_t n = expected_.size() / 4;
+        // pcl::Registration::getFitnessScore skips the non-finite points of a source that is not dense (`if (!input_->is_dense &&
+        // !pcl::isXYZFinite(point)) continue;`): it never asks about them, so neither do we wait for them
+        auto finite_at = [&](std::size_t c) { return std::isfinite(expected_[4 * c]) && std::isfinite(expected_[4 * c + 1]) && std::isfinite(expected_[4 * c + 2]); };
+        if (std::isfinite(point.x) && std::isfinite(point.y) && std::isfinite(point.z))
+            while (cursor_ < n && !finite_at(cursor_)) ++cursor_;
         // sequential walk over the expected queries: position `cursor_`, else the start (a second pass over the same cloud)
         for (int attempt = 0; attempt < 2 && n; ++attempt) {
-            const std::size_t c = attempt == 0 ? cursor_ : 0;
+            std::size_t c = attempt == 0 ? cursor_ : 0;
+            if (attempt == 1)
+                while (c < n && !finite_at(c) && std::isfinite(point.x)) ++c;  // a second pass starts at the first point PCL asks about
             if (c < n && std::memcmp(&expected_[4 * c], &point.x, 12) == 0) {
                 if (!answered_) answer_batch();
                 cursor_ = c + 1;

@@ -2,13 +2,20 @@
 // mrgfe_pcl::HipRegistration (built against the stand-in headers of this directory, linked with libmrgfe.so, run on the GPU):
 //   LoopDetector::matching            /root/reference/src/mrg_slam/loop_detector.cpp:104,127-144
 //   publish_scan_matching_status      /root/reference/apps/scan_matching_odometry_component.cpp:403-417
+//   PrefilteringComponent::downsample / outlier_removal   /root/reference/apps/prefiltering_component.cpp:37,54-55,168-171,189-199
+//   (mrgfe_pcl::HipVoxelGrid / HipRadiusOutlierRemoval / HipStatisticalOutlierRemoval held in the reference's own member types)
 // Prints one line per check; exit code 0 iff all hold.  Clouds: two perturbed copies of a seeded random "room".
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <vector>
 #include <random>
 
 #include <mrgfe_pcl_adapter.hpp>
+#include <mrgfe_pcl_filters.hpp>
 
 using PointT = pcl::PointXYZI;
 using Cloud = pcl::PointCloud<PointT>;
@@ -110,6 +117,87 @@ int main(int argc, char** argv)
     registration->align(*aligned, Eigen::Matrix4f::Identity());
     const double self = registration->getFitnessScore();
     check(self < 1e-6, "source aligned onto itself after setInputTarget(source): fitness ~ 0");
+    // a source that is not dense: PCL's getFitnessScore skips its non-finite points and never asks the search object about them
+    {
+        Cloud::Ptr holes(new Cloud(*make_room(2, n, 0.3f)));
+        holes->is_dense = false;
+        for (int i : {0, 7, 8, n / 2, n - 1}) (*holes)[i].x = std::numeric_limits<float>::quiet_NaN();
+        registration->setInputTarget(target);
+        registration->setInputSource(holes);
+        registration->align(*aligned, Eigen::Matrix4f::Identity());
+        const std::size_t b0 = hip->gpuSearch().batched_answers(), s0 = hip->gpuSearch().single_queries();
+        const double sc = registration->getFitnessScore();
+        double       dir = -1;
+        mrgfe_reg_fitness(hip->handle(), std::numeric_limits<double>::max(), &dir);
+        check(sc == dir, "non-dense source: base-class getFitnessScore == mrgfe_reg_fitness");
+        check(hip->gpuSearch().batched_answers() == b0 + std::size_t(n - 5) && hip->gpuSearch().single_queries() == s0, "non-dense source: the skipped points cost no single-point round trips");
+    }
+
+    // ---- prefiltering_component.cpp: the filters, held in the reference's member types and driven by its call sequences ----
+    {
+        using Filter = pcl::Filter<PointT>;
+        std::shared_ptr<pcl::VoxelGrid<PointT>>                 voxelgrid_filter_ = std::make_shared<mrgfe_pcl::HipVoxelGrid<PointT>>();                                   // :37
+        std::shared_ptr<pcl::StatisticalOutlierRemoval<PointT>> statistical_outlier_removal_filter_ = std::make_shared<mrgfe_pcl::HipStatisticalOutlierRemoval<PointT>>();  // :54
+        std::shared_ptr<pcl::RadiusOutlierRemoval<PointT>>      radius_outlier_removal_filter_ = std::make_shared<mrgfe_pcl::HipRadiusOutlierRemoval<PointT>>();            // :55
+        const int  cpu0 = Filter::cpu_calls();
+        Cloud::ConstPtr cloud = make_room(5, n, 0.0f);
+        auto packed = [](const Cloud& c) {
+            std::vector<float> v(4 * c.size());
+            for (std::size_t i = 0; i < c.size(); ++i) { v[4 * i] = c[i].x; v[4 * i + 1] = c[i].y; v[4 * i + 2] = c[i].z; v[4 * i + 3] = c[i].intensity; }
+            return v;
+        };
+        auto same_as = [&](const Cloud& got, const std::vector<float>& exp, std::size_t m) {
+            if (got.size() != m || got.width != m || got.height != 1) return false;
+            const std::vector<float> g = packed(got);
+            return std::memcmp(g.data(), exp.data(), 16 * m) == 0;
+        };
+        mrgfe_ctx* ctx = mrgfe_pcl::shared_context();
+        const std::vector<float> in = packed(*cloud);
+        std::vector<float> exp(in.size());
+        std::size_t m = 0;
+        int         overflow = 0;
+        // downsample(), :168-171
+        Cloud::Ptr filtered(new Cloud());
+        const double downsample_resolution = 0.25;
+        voxelgrid_filter_->setLeafSize(downsample_resolution, downsample_resolution, downsample_resolution);
+        voxelgrid_filter_->setMinimumPointsNumberPerVoxel(2);
+        voxelgrid_filter_->setInputCloud(cloud);
+        voxelgrid_filter_->filter(*filtered);
+        mrgfe_voxelgrid(ctx, in.data(), cloud->size(), 16, 0.25f, 2, exp.data(), &m, &overflow);
+        check(m > 0 && m < cloud->size() && same_as(*filtered, exp, m), "pcl::VoxelGrid::filter through HipVoxelGrid == mrgfe_voxelgrid on the packed cloud");
+        check((*filtered)[0].data3 == 1.0f && filtered->is_dense, "voxel grid output: PCL's padding word and is_dense");
+        // outlier_removal(), RADIUS :195-198
+        Cloud::Ptr kept(new Cloud());
+        radius_outlier_removal_filter_->setRadiusSearch(0.4);
+        radius_outlier_removal_filter_->setMinNeighborsInRadius(3);
+        radius_outlier_removal_filter_->setInputCloud(filtered);
+        radius_outlier_removal_filter_->filter(*kept);
+        const std::vector<float> fin = packed(*filtered);
+        std::size_t mr = 0;
+        mrgfe_radius_outlier(ctx, fin.data(), filtered->size(), 16, 0.4, 3, exp.data(), &mr);
+        check(mr > 0 && same_as(*kept, exp, mr), "pcl::RadiusOutlierRemoval::filter through HipRadiusOutlierRemoval == mrgfe_radius_outlier");
+        // outlier_removal(), STATISTICAL :189-192
+        Cloud::Ptr kept2(new Cloud());
+        statistical_outlier_removal_filter_->setMeanK(12);
+        statistical_outlier_removal_filter_->setStddevMulThresh(1.0);
+        statistical_outlier_removal_filter_->setInputCloud(filtered);
+        statistical_outlier_removal_filter_->filter(*kept2);
+        std::size_t ms = 0;
+        mrgfe_statistical_outlier(ctx, fin.data(), filtered->size(), 16, 12, 1.0, exp.data(), &ms);
+        check(ms > 0 && ms < filtered->size() && same_as(*kept2, exp, ms), "pcl::StatisticalOutlierRemoval::filter through HipStatisticalOutlierRemoval == mrgfe_statistical_outlier");
+        check(Filter::cpu_calls() == cpu0, "none of the three filter() calls ran PCL's CPU code");
+        // filtering in place (output is the input) and through the pcl::Filter base pointer
+        std::shared_ptr<Filter> base = voxelgrid_filter_;
+        Cloud::Ptr inplace(new Cloud(*cloud));
+        base->setInputCloud(inplace);
+        base->filter(*inplace);
+        check(same_as(*inplace, packed(*filtered), filtered->size()), "pcl::Filter base pointer, in place: same voxel grid output");
+        // what the GPU path does not offer stays PCL's: unequal leaf sizes
+        voxelgrid_filter_->setLeafSize(0.25f, 0.5f, 0.25f);
+        voxelgrid_filter_->setInputCloud(cloud);
+        voxelgrid_filter_->filter(*filtered);
+        check(Filter::cpu_calls() == cpu0 + 1, "unequal leaf sizes fall back to PCL's own applyFilter");
+    }
     std::printf("%s\n", failures ? "ADAPTER CHECK FAILED" : "adapter check passed");
     return failures ? 1 : 0;
 }

@@ -25,6 +25,11 @@ struct Matrix {
 using Matrix4f = Matrix<float, 4, 4>;
 }  // namespace Eigen
 
+// pcl_config.h: the version macros the adapter keys the pcl::search::KdTree::setInputCloud signature on (this stand-in restates 1.12.1)
+#define PCL_VERSION_CALC(MAJ, MIN, PATCH) (MAJ * 100000 + MIN * 100 + PATCH)
+#define PCL_VERSION PCL_VERSION_CALC(1, 12, 1)
+#define PCL_VERSION_COMPARE(OP, MAJ, MIN, PATCH) (PCL_VERSION OP PCL_VERSION_CALC(MAJ, MIN, PATCH))
+
 namespace pcl {
 template <typename T> using shared_ptr = std::shared_ptr<T>;
 using Indices = std::vector<int>;
@@ -36,4 +41,6 @@ struct alignas(16) PointXYZI {
     float intensity = 0.f, pad_[3] = {0.f, 0.f, 0.f};
 };
 static_assert(sizeof(PointXYZI) == 32, "pcl::PointXYZI is 32 bytes");
+template <typename PointT>
+inline bool isXYZFinite(const PointT& p) { return p.x - p.x == 0.f && p.y - p.y == 0.f && p.z - p.z == 0.f; }
 }  // namespace pcl

@@ -73,6 +73,7 @@ class Registration : public PCLBase<PointSource> {
         std::vector<float> nn_dists(1);
         int                nr = 0;
         for (const auto& point : input_transformed) {
+            if (!this->input_->is_dense && !pcl::isXYZFinite(point)) continue;  // (PCL 1.12: non-finite points of a non-dense source are skipped)
             tree_->nearestKSearch(point, 1, nn_indices, nn_dists);
             if (nn_dists[0] <= max_range) {
                 fitness_score += nn_dists[0];

@@ -28,9 +28,9 @@ def test_adapter_is_valid_cxx_against_the_stub_interface():
 
 
 def test_adapter_is_inert_without_pcl(tmp_path):
-    """without <pcl/registration/registration.h> on the include path the header compiles to nothing (it ships as source)"""
+    """without PCL's headers on the include path the adapter headers compile to nothing (they ship as source)"""
     src = tmp_path / "t.cpp"
-    src.write_text('#include "mrgfe_pcl_adapter.hpp"\n#ifdef MRGFE_H\n#error "the adapter must not pull in anything without PCL"\n#endif\nint main() { return 0; }\n')
+    src.write_text('#include "mrgfe_pcl_adapter.hpp"\n#include "mrgfe_pcl_filters.hpp"\n#ifdef MRGFE_H\n#error "the adapters must not pull in anything without PCL"\n#endif\nint main() { return 0; }\n')
     r = subprocess.run([_gxx(), "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
 
@@ -45,6 +45,28 @@ def _build(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return exe
+
+
+def test_adapter_compiles_for_the_pcl_113_signature(tmp_path):
+    """pcl::search::KdTree::setInputCloud returns bool from PCL 1.13 on (ROS 2 Jazzy): the override follows PCL_VERSION_COMPARE.  The stand-in
+    restates 1.12; with its version macro raised and its own base signature changed accordingly the adapter must still compile."""
+    import re
+
+    stub = tmp_path / "stub"
+    shutil.copytree(STUB, stub)
+    pt = stub / "pcl" / "point_types.h"
+    pt.write_text(pt.read_text().replace("PCL_VERSION_CALC(1, 12, 1)", "PCL_VERSION_CALC(1, 13, 0)"))
+    kd = stub / "pcl" / "search" / "kdtree.h"
+    txt = kd.read_text()
+    txt = txt.replace("virtual void setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) = 0;",
+                      "virtual bool setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& indices = IndicesConstPtr()) = 0;")
+    txt = re.sub(r"void setInputCloud\(const PointCloudConstPtr& cloud, const IndicesConstPtr& = IndicesConstPtr\(\)\) override\s*\{\s*input_ = cloud;\s*\+\+builds\(\);\s*\}",
+                 "bool setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& = IndicesConstPtr()) override { input_ = cloud; ++builds(); return true; }", txt)
+    assert "bool setInputCloud(const PointCloudConstPtr& cloud, const IndicesConstPtr& = IndicesConstPtr()) override" in txt
+    kd.write_text(txt)
+    r = subprocess.run([_gxx(), "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I" + str(stub), "-I" + os.path.join(ROOT, "include"), os.path.join(STUB, "adapter_main.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
 
 
 def test_adapter_links_with_the_library(tmp_path):
