@@ -34,6 +34,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -59,23 +60,61 @@ def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N copies of this command line as child processes, one per GPU
     (RANK = LOCAL_RANK = i), wait for them and pass rank 0's JSON line through.  Runs before this process imports torch or
     touches HIP — it never does either.  Returns the exit code (non-zero if any rank failed)."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode("utf-8", "replace"))
-    sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        print(f"[bench] ranks failed: {bad}", file=sys.stderr)
-        return 1
-    return 0
+    def launch(port):
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                          stderr=subprocess.PIPE if r == 0 else None))
+        return procs
+
+    for attempt in range(3):  # the port is probed, released and reused: another process may take it in between
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs = launch(port)
+        # rank 0's output is drained by threads (its pipes must not fill up) while ALL children are polled: when one dies — before or at the
+        # rendezvous, say — the others are ended instead of waiting for the process group's timeout
+        chunks = {"out": [], "err": []}
+        readers = [threading.Thread(target=lambda f, k: chunks[k].append(f.read()), args=(procs[0].stdout, "out"), daemon=True),
+                   threading.Thread(target=lambda f, k: chunks[k].append(f.read()), args=(procs[0].stderr, "err"), daemon=True)]
+        for t in readers:
+            t.start()
+        codes = [None] * n
+        while any(c is None for c in codes):
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    codes[r] = p.poll()
+            if any(c not in (None, 0) for c in codes):
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        p.terminate()
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        try:
+                            codes[r] = p.wait(timeout=20)
+                        except subprocess.TimeoutExpired:
+                            p.kill()
+                            codes[r] = p.wait()
+                break
+            time.sleep(0.05)
+        for t in readers:
+            t.join(timeout=10)
+        out0 = b"".join(chunks["out"]).decode("utf-8", "replace")
+        err0 = b"".join(chunks["err"]).decode("utf-8", "replace")
+        if any(c != 0 for c in codes) and ("EADDRINUSE" in err0 or "Address already in use" in err0 or "address already in use" in err0) and attempt < 2:
+            print(f"[bench] rendezvous port {port} was taken, trying another", file=sys.stderr)
+            continue
+        sys.stderr.write(err0)
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+        bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+        if bad:
+            print(f"[bench] ranks failed: {bad}", file=sys.stderr)
+            return 1
+        return 0
+    return 1
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -237,6 +276,8 @@ def main():
     if os.environ.get("BENCH_SPAWN_TEST"):  # CPU test hook of the launcher above: report the rank environment and stop before any GPU work
         if rank == 0:
             print(json.dumps({"n_gpus": world, "rank": rank, "local_rank": local_rank, "master": os.environ.get("MASTER_ADDR"), "port": os.environ.get("MASTER_PORT")}))
+        if int(os.environ.get("BENCH_SPAWN_TEST_HANG_RANK", "-1")) == rank:
+            time.sleep(120)  # stands for a rank waiting at a rendezvous that will never complete
         sys.exit(int(os.environ.get("BENCH_SPAWN_TEST_FAIL_RANK", "-1")) == rank)
 
     # ---- inputs, host part (untimed; forks worker processes, so it runs before the GPU is initialised) ------------------

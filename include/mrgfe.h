@@ -118,7 +118,8 @@ int mrgfe_ctx_knn_stats(mrgfe_ctx* ctx, double out[5]);
  * cloud in host memory (out_xyzi, width*height*16 bytes, may be NULL) and / or device memory (d_out_xyzi, may be NULL) — the
  * latter feeds mrgfe_reg_set_*_device / mrgfe_batch_add_*_device / mrgfe_prefilter_device without the cloud leaving HBM.
  * The replay scripts' layout (point_step 16, offsets 0/4/8/12: python_scripts/kitti_singlerobot_processor.py:164-185) is a plain
- * copy; anything else is gathered on the device. */
+ * copy; anything else is gathered on the device.  `data` must hold (height - 1) * row_step + width * point_step bytes: there is no
+ * length argument (a sensor_msgs/PointCloud2 guarantees it; the Python wrapper checks it). */
 int mrgfe_ingest_pointcloud2(mrgfe_ctx* ctx, const uint8_t* data, uint32_t width, uint32_t height, uint32_t point_step, uint32_t row_step, uint32_t off_x, uint32_t off_y,
                              uint32_t off_z, int32_t off_intensity, float* out_xyzi, void* d_out_xyzi);
 

@@ -69,6 +69,7 @@ extern "C" int mrgfe_ingest_pointcloud2(mrgfe_ctx* ctx, const uint8_t* data, uin
     const size_t n = size_t(width) * height;
     if (n == 0) return MRGFE_OK;
     if (!data || (!out_xyzi && !d_out_xyzi)) { set_error("mrgfe_ingest_pointcloud2: NULL data / no output"); return MRGFE_ERR_INVALID; }
+    if (uint64_t(width) * point_step > 0xffffffffull) { set_error("mrgfe_ingest_pointcloud2: width %u x point_step %u does not fit a row", width, point_step); return MRGFE_ERR_INVALID; }
     if (row_step == 0) row_step = width * point_step;
     const uint32_t offs[4] = {off_x, off_y, off_z, off_intensity >= 0 ? static_cast<uint32_t>(off_intensity) : 0u};
     for (uint32_t o : offs)
@@ -80,7 +81,7 @@ extern "C" int mrgfe_ingest_pointcloud2(mrgfe_ctx* ctx, const uint8_t* data, uin
     void* d_dst = d_out_xyzi;
     if (!d_dst) { MRGFE_TRY(ctx->up_out.ensure(n * 16)); d_dst = ctx->up_out.p; }
     const size_t raw_bytes = size_t(height - 1) * row_step + size_t(width) * point_step;
-    if (point_step == 16 && off_x == 0 && off_y == 4 && off_z == 8 && off_intensity == 12 && row_step == width * 16u) {
+    if (point_step == 16 && off_x == 0 && off_y == 4 && off_z == 8 && off_intensity == 12 && uint64_t(row_step) == uint64_t(width) * 16u) {
         MRGFE_TRY(upload_cloud(ctx, reinterpret_cast<const float*>(data), n, 16, d_dst));  // the replay layout is the device layout: plain copy
     } else {
         MRGFE_TRY(upload_gathered(ctx, data, raw_bytes, n, width, row_step, point_step, off_x, off_y, off_z, off_intensity, d_dst));

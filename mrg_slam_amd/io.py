@@ -198,6 +198,11 @@ def ingest_pointcloud2(data, width: int, height: int, point_step: int, fields: d
     ctx = ctx or default_context()
     n = int(width) * int(height)
     buf = np.frombuffer(data, dtype=np.uint8)
+    # the C entry point has no length argument (it copies (height - 1) * row_step + width * point_step bytes): a short or malformed payload
+    # must fail here, like xyzi_from_pointcloud2 does, not as an out-of-bounds host read
+    need = (int(height) - 1) * (int(row_step) or int(width) * int(point_step)) + int(width) * int(point_step) if n else 0
+    if len(buf) < need:
+        raise ValueError(f"PointCloud2 payload has {len(buf)} bytes, {need} are needed for {width} x {height} points of {point_step} bytes (row_step {row_step})")
     out = None if dev_ptr else np.empty((n, 4), dtype=np.float32)
     oi = fields.get("intensity")
     check(lib().mrgfe_ingest_pointcloud2(ctx._h, buf.ctypes.data_as(C.POINTER(C.c_uint8)), int(width), int(height), int(point_step), int(row_step), int(fields["x"]), int(fields["y"]),

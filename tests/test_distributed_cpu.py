@@ -143,6 +143,13 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert line["n_gpus"] == 3 and line["rank"] == 0 and line["master"] == "127.0.0.1" and int(line["port"]) > 0
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, BENCH_SPAWN_TEST_FAIL_RANK="1"), capture_output=True, text=True, timeout=120)
     assert r.returncode != 0
+    # a rank that dies while another one waits (at the rendezvous, say): the launcher ends the waiting one instead of sitting out its timeout
+    import time
+
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, BENCH_SPAWN_TEST_FAIL_RANK="1", BENCH_SPAWN_TEST_HANG_RANK="0"),
+                       capture_output=True, text=True, timeout=100)
+    assert r.returncode != 0 and time.time() - t0 < 60
     # under a launcher (WORLD_SIZE set) it does not spawn again
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 2

@@ -124,3 +124,15 @@ def test_bench_kitti_root_hook(tmp_path, monkeypatch):
     monkeypatch.delenv("KITTI_ROOT")
     scene, poses, scans = bench.make_workload(1, 2, 0, "distance")
     assert scene is not None and len(scans) == 2 and scans[0].shape[1] == 4
+
+
+def test_ingest_pointcloud2_refuses_a_short_payload():
+    """The C entry point has no length argument: the wrapper must refuse a payload that is shorter than its header says (an exception, not
+    an out-of-bounds host read) before it reaches the library — no GPU needed to get that far."""
+    from mrg_slam_amd import io
+
+    data = np.zeros(10 * 16 - 1, dtype=np.uint8).tobytes()
+    with pytest.raises(ValueError, match="payload"):
+        io.ingest_pointcloud2(data, 10, 1, 16, {"x": 0, "y": 4, "z": 8, "intensity": 12}, ctx=object())
+    with pytest.raises(ValueError, match="payload"):
+        io.ingest_pointcloud2(np.zeros(3 * 64, np.uint8).tobytes(), 2, 4, 16, {"x": 0, "y": 4, "z": 8}, row_step=64, ctx=object())
