@@ -1,0 +1,268 @@
+"""Host mirror of ``mrg_slam::LoopDetector`` (/root/reference/src/mrg_slam/loop_detector.cpp, include/mrg_slam/loop_detector.hpp): the
+caller of the hot path in the back end — ``find_candidates`` (:41-95), the candidate loop of ``matching`` (:97-180) with the planar
+guess (:129-133), the best-score rule (:137-144), the ``fitness_score_thresh`` gate (:156-160), the consistency check against the best
+match's previous / next keyframe (:190-303) and the ``LoopManager`` bookkeeping.
+
+Two ways to run ``matching`` on the same decisions:
+
+* ``registration=`` anything with the ``pcl::Registration`` call surface (a HIP registration or the CPU oracle's classes): the
+  reference's loop as it stands, one ``align`` at a time;
+* ``matcher=`` a ``BatchMatcher``: all candidates of a new keyframe advance together on the GPU (``mrgfe_batch_*``, candidates named by
+  keyframe id so that their clouds stay in the HBM keyframe store), then a second batch of at most two pairs — the best match's previous and
+  next keyframe against the same target — supplies the consistency check; the next keyframe's result is used only where the reference
+  would have computed it (the previous one failed).  The alignments are independent, so the Loop list is the reference's.
+
+Poses are ``numpy`` 4 x 4 matrices: keyframe estimates in double (``Eigen::Isometry3d``), registration results in float
+(``Eigen::Matrix4f``), products and inverses in the type the reference forms them in."""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+from . import loop_closure
+
+DEFAULTS = {  # config/mrg_slam.yaml:169-179
+    "candidate_max_xy_distance": 15.0,
+    "accum_distance_thresh_same_robot": 15.0,
+    "accum_distance_thresh_other_robot": 5.0,
+    "fitness_score_max_range": float("inf"),
+    "fitness_score_thresh": 1.25,
+    "use_planar_registration_guess": False,
+    "enable_loop_closure_consistency_check": True,
+    "loop_closure_consistency_max_delta_trans": 0.3,
+    "loop_closure_consistency_max_delta_angle": 0.0523599,
+}
+
+
+@dataclasses.dataclass(eq=False)
+class Edge:
+    """The slice of mrg_slam::Edge the loop detector reads: ``from_keyframe`` --relative_pose--> ``to_keyframe``."""
+    from_keyframe: "KeyFrame"
+    to_keyframe: "KeyFrame"
+    relative_pose: np.ndarray  # 4 x 4 double
+
+
+@dataclasses.dataclass(eq=False)
+class KeyFrame:
+    """The slice of mrg_slam::KeyFrame the loop detector reads (include/mrg_slam/keyframe.hpp)."""
+    id: int                      # non-zero: names the cloud in the GPU keyframe store
+    cloud: np.ndarray            # N x 4 float32
+    estimate: np.ndarray         # node->estimate(): 4 x 4 double
+    accum_distance: float
+    slam_uuid: str = "robot"
+    first_keyframe: bool = False
+    static_keyframe: bool = False
+    prev_edge: Edge | None = None  # this keyframe -> the one before it (prev_edge->to_keyframe, loop_detector.cpp:213)
+    next_edge: Edge | None = None  # the one after it -> this keyframe (next_edge->from_keyframe, :256)
+    connected: set = dataclasses.field(default_factory=set)  # ids of keyframes this one shares a graph edge with (KeyFrame::edge_exists)
+
+    def edge_exists(self, other: "KeyFrame") -> bool:
+        return other.id in self.connected
+
+
+@dataclasses.dataclass(eq=False)
+class Loop:
+    key1: KeyFrame             # new keyframe testing for loop closure
+    key2: KeyFrame             # best matched candidate keyframe
+    relative_pose: np.ndarray  # float 4 x 4, key1 -> key2
+
+
+class LoopManager:
+    """loop_detector.hpp:39-115: the most recent loop per (new keyframe's SLAM instance, candidate's SLAM instance)."""
+
+    def __init__(self):
+        self.loop_map: dict = {}
+
+    def get_loop(self, new_uuid, cand_uuid):
+        return self.loop_map.get(new_uuid, {}).get(cand_uuid)
+
+    def add_loop(self, loop: Loop):
+        self.loop_map.setdefault(loop.key1.slam_uuid, {})[loop.key2.slam_uuid] = loop
+
+
+def _quat_from_matrix(R, dtype):
+    """Eigen's matrix -> quaternion conversion (w, x, y, z) in ``dtype``."""
+    R = np.asarray(R, dtype=dtype)
+    one, half = dtype(1), dtype(0.5)
+    t = R[0, 0] + R[1, 1] + R[2, 2]
+    q = np.zeros(4, dtype=dtype)
+    if t > 0:
+        t = np.sqrt(t + one)
+        q[0] = half * t
+        t = half / t
+        q[1], q[2], q[3] = (R[2, 1] - R[1, 2]) * t, (R[0, 2] - R[2, 0]) * t, (R[1, 0] - R[0, 1]) * t
+    else:
+        i = 0
+        if R[1, 1] > R[0, 0]:
+            i = 1
+        if R[2, 2] > R[i, i]:
+            i = 2
+        j, k = (i + 1) % 3, (i + 2) % 3
+        t = np.sqrt(R[i, i] - R[j, j] - R[k, k] + one)
+        q[1 + i] = half * t
+        t = half / t
+        q[0] = (R[k, j] - R[j, k]) * t
+        q[1 + j] = (R[j, i] + R[i, j]) * t
+        q[1 + k] = (R[k, i] + R[i, k]) * t
+    return q
+
+
+def _quat_to_matrix(q):
+    w, x, y, z = q
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    return np.array([[1 - (tyy + tzz), txy - twz, txz + twy], [txy + twz, 1 - (txx + tzz), tyz - twx], [txz - twy, tyz + twx, 1 - (txx + tyy)]], dtype=q.dtype)
+
+
+def normalize_estimate(estimate) -> np.ndarray:
+    """LoopDetector::normalize_estimate (:183-188): linear() = Quaterniond(linear()).normalized().toRotationMatrix()."""
+    out = np.array(estimate, dtype=np.float64)
+    q = _quat_from_matrix(out[:3, :3], np.float64)
+    out[:3, :3] = _quat_to_matrix(q / np.linalg.norm(q))
+    return out
+
+
+def angular_distance_to_identity(R) -> float:
+    """Eigen::Quaternionf(R).angularDistance(Quaternionf::Identity()) = 2 atan2(|vec|, |w|), in float."""
+    q = _quat_from_matrix(R, np.float32)
+    return float(np.float32(2.0) * np.arctan2(np.linalg.norm(q[1:]).astype(np.float32), np.abs(q[0])))
+
+
+class LoopDetector:
+    def __init__(self, params: dict | None = None, registration=None, matcher=None):
+        if (registration is None) == (matcher is None):
+            raise ValueError("give either a registration object (the reference's sequential loop) or a BatchMatcher (all candidates at once)")
+        self.p = dict(DEFAULTS)
+        self.p.update(params or {})
+        self.registration, self.matcher = registration, matcher
+        self.loop_manager = LoopManager()
+        self.alignments = 0  # registrations run so far (candidates + consistency checks)
+
+    # ---- detect (:14-38)
+    def detect(self, keyframes, new_keyframes):
+        detected = []
+        for new_keyframe in new_keyframes:
+            candidates = self.find_candidates(new_keyframe, keyframes)
+            loop = self.matching(candidates, new_keyframe)
+            if loop is not None:
+                detected.append(loop)
+        return detected
+
+    # ---- find_candidates (:41-95)
+    def find_candidates(self, new_keyframe: KeyFrame, keyframes):
+        p = self.p
+        max_sq = p["candidate_max_xy_distance"] * p["candidate_max_xy_distance"]
+        out = []
+        for candidate in keyframes:
+            if new_keyframe.edge_exists(candidate):  # there is already an edge
+                continue
+            if candidate.first_keyframe:  # first keyframes don't filter out points that hit other rovers
+                continue
+            d = candidate.estimate[:2, 3] - new_keyframe.estimate[:2, 3]
+            if float(d @ d) > max_sq:
+                continue
+            if new_keyframe.slam_uuid == candidate.slam_uuid and new_keyframe.accum_distance - candidate.accum_distance < p["accum_distance_thresh_same_robot"]:
+                continue
+            last_loop = self.loop_manager.get_loop(new_keyframe.slam_uuid, candidate.slam_uuid)
+            if last_loop and new_keyframe.slam_uuid == candidate.slam_uuid and new_keyframe.accum_distance - last_loop.key1.accum_distance < p["accum_distance_thresh_same_robot"]:
+                continue
+            if last_loop and new_keyframe.slam_uuid != candidate.slam_uuid and new_keyframe.accum_distance - last_loop.key1.accum_distance < p["accum_distance_thresh_other_robot"]:
+                continue
+            out.append(candidate)
+        return out
+
+    def _guess(self, new_estimate, kf: KeyFrame) -> np.ndarray:
+        g = (np.linalg.inv(new_estimate) @ normalize_estimate(kf.estimate)).astype(np.float32)  # :130-133
+        if self.p["use_planar_registration_guess"]:
+            g[2, 3] = 0.0
+        return g
+
+    # ---- the alignments: (final transformation, converged, fitness) per source against the new keyframe's cloud
+    def _align_all(self, new_keyframe: KeyFrame, sources, guesses, want_fitness: bool):
+        self.alignments += len(sources)
+        max_range = self.p["fitness_score_max_range"]
+        if self.registration is not None:
+            out = []
+            for kf, g in zip(sources, guesses):
+                self.registration.setInputSource(kf.cloud)
+                self.registration.align(g)
+                score = self.registration.getFitnessScore(max_range) if want_fitness else None
+                out.append((np.asarray(self.registration.getFinalTransformation(), dtype=np.float32), bool(self.registration.hasConverged()), score))
+            return out
+        from .registration import result_matrix
+
+        bm = self.matcher
+        bm.clear()
+        t = bm.add_target(new_keyframe.cloud)
+        for kf, g in zip(sources, guesses):
+            have = bm.has_cloud(kf.id) == len(kf.cloud)
+            bm.add_pair(t, None if have else kf.cloud, g, key=kf.id)
+        res = bm.align(max_range if want_fitness else -1.0)
+        return [(result_matrix(r), bool(r["converged"]), float(r["fitness"]) if want_fitness else None) for r in res]
+
+    # ---- matching (:97-180)
+    def matching(self, candidate_keyframes, new_keyframe: KeyFrame):
+        if not candidate_keyframes:
+            return None
+        if self.registration is not None:
+            self.registration.setInputTarget(new_keyframe.cloud)  # :104
+        new_estimate = normalize_estimate(new_keyframe.estimate)
+        guesses = [self._guess(new_estimate, c) for c in candidate_keyframes]
+        results = self._align_all(new_keyframe, candidate_keyframes, guesses, True)
+        best_score, best_matched, rel_pose = np.finfo(np.float64).max, None, None
+        for candidate, (T, converged, score) in zip(candidate_keyframes, results):  # :137-144
+            if not converged or score > best_score:
+                continue
+            best_score, best_matched, rel_pose = score, candidate, T
+        consistent = self._consistency_check(new_keyframe, new_estimate, rel_pose, best_matched, best_score)
+        if best_score > self.p["fitness_score_thresh"]:  # :156-160
+            return None
+        if self.p["enable_loop_closure_consistency_check"] and best_matched is not None and not best_matched.first_keyframe and not consistent:  # :162-166
+            return None
+        loop = Loop(new_keyframe, best_matched, rel_pose)
+        self.loop_manager.add_loop(loop)
+        return loop
+
+    # ---- perform_loop_closure_consistency_check (:190-210) with :212-303
+    def _consistency_check(self, new_keyframe, new_estimate, rel_pose_new_to_best, best_matched, best_score) -> bool:
+        p = self.p
+        if best_matched is not None and (best_matched.first_keyframe or best_matched.static_keyframe):
+            return True
+        if best_matched is None or not p["enable_loop_closure_consistency_check"] or best_score > p["fitness_score_thresh"]:
+            return False
+        prev_kf = best_matched.prev_edge.to_keyframe if best_matched.prev_edge is not None else None
+        next_kf = best_matched.next_edge.from_keyframe if best_matched.next_edge is not None else None
+        if self.registration is not None:  # the reference's order: the next keyframe only if the previous one failed
+            if prev_kf is not None and self._consistent_prev(best_matched, rel_pose_new_to_best, self._align_all(new_keyframe, [prev_kf], [self._guess(new_estimate, prev_kf)], False)[0][0]):
+                return True
+            return next_kf is not None and self._consistent_next(best_matched, rel_pose_new_to_best, self._align_all(new_keyframe, [next_kf], [self._guess(new_estimate, next_kf)], False)[0][0])
+        # batched: both neighbours in one launch; the decisions are evaluated in the reference's order
+        srcs = [kf for kf in (prev_kf, next_kf) if kf is not None]
+        if not srcs:
+            return False
+        res = self._align_all(new_keyframe, srcs, [self._guess(new_estimate, kf) for kf in srcs], False)
+        T = {id(kf): r[0] for kf, r in zip(srcs, res)}
+        if prev_kf is not None and self._consistent_prev(best_matched, rel_pose_new_to_best, T[id(prev_kf)]):
+            return True
+        return next_kf is not None and self._consistent_next(best_matched, rel_pose_new_to_best, T[id(next_kf)])
+
+    def _within(self, M) -> bool:
+        delta_trans = float(np.linalg.norm(M[:3, 3].astype(np.float32)))
+        delta_angle = angular_distance_to_identity(M[:3, :3])
+        return not (delta_trans > self.p["loop_closure_consistency_max_delta_trans"] or delta_angle > self.p["loop_closure_consistency_max_delta_angle"])
+
+    def _consistent_prev(self, best_matched, rel_pose_new_to_best, rel_pose_new_to_prev) -> bool:
+        cand_to_prev = best_matched.prev_edge.relative_pose.astype(np.float32)  # :218
+        M = (np.linalg.inv(rel_pose_new_to_prev.astype(np.float32)).astype(np.float32) @ rel_pose_new_to_best.astype(np.float32) @ cand_to_prev).astype(np.float32)  # :233
+        return self._within(M)
+
+    def _consistent_next(self, best_matched, rel_pose_new_to_best, rel_pose_new_to_next) -> bool:
+        next_to_cand = best_matched.next_edge.relative_pose.astype(np.float32)  # :261
+        M = (np.linalg.inv(rel_pose_new_to_best.astype(np.float32)).astype(np.float32) @ rel_pose_new_to_next.astype(np.float32) @ next_to_cand).astype(np.float32)  # :276
+        return self._within(M)
+
+
+__all__ = ["DEFAULTS", "Edge", "KeyFrame", "Loop", "LoopManager", "LoopDetector", "normalize_estimate", "angular_distance_to_identity", "loop_closure"]

@@ -1,0 +1,42 @@
+"""GPU: a scripted 64-keyframe ring session through the LoopDetector mirror — the batched GPU path (BatchMatcher: all candidates of a new
+keyframe at once, candidates named by keyframe id, a second batch for the consistency check) against the reference's sequential loop run on
+the CPU oracle (/root/reference/src/mrg_slam/loop_detector.cpp:97-303): the same list of loops, the same relative poses."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("planar", [False, True])
+def test_ring_session_gpu_batched_equals_sequential_oracle(planar):
+    from loop_session import make_ring_session, run_session
+    from mrg_slam_amd import BatchMatcher, NdtHip, prefilter, synth
+    from mrg_slam_amd.loop_detector import LoopDetector
+    from oracle import oracle as orc
+
+    prm = {"use_planar_registration_guess": planar}
+    reg_kw = dict(resolution=1.0, transformation_epsilon=0.01, maximum_iterations=64)
+    sessions = {}
+    for name in ("gpu_batched", "gpu_sequential", "oracle"):
+        kfs, order = make_ring_session(64, "VLP64", prefilter=lambda c: prefilter(c, {"downsample_resolution": 0.2}))
+        if name == "gpu_batched":
+            det = LoopDetector(prm, matcher=BatchMatcher(**reg_kw))
+        elif name == "gpu_sequential":
+            det = LoopDetector(prm, registration=NdtHip(**reg_kw))
+        else:
+            det = LoopDetector(prm, registration=orc.Ndt(num_threads=8, **reg_kw))
+        sessions[name] = (run_session(det, kfs, order), det, kfs)
+    ref, det_o, kfs = sessions["oracle"]
+    assert len(ref) >= 4 and any(lp.key1.slam_uuid != lp.key2.slam_uuid for lp in ref)  # loops on the second lap and between the robots
+    assert np.mean([len(k.cloud) for k in kfs]) > 15000
+    for name in ("gpu_batched", "gpu_sequential"):
+        got, det, _ = sessions[name]
+        assert [(lp.key1.id, lp.key2.id) for lp in got] == [(lp.key1.id, lp.key2.id) for lp in ref], name
+        for a, b in zip(got, ref):
+            assert np.linalg.norm(a.relative_pose[:3, 3].astype(np.float64) - b.relative_pose[:3, 3]) <= 1e-4, name
+            assert synth.rotation_angle(a.relative_pose.astype(np.float64), b.relative_pose.astype(np.float64)) <= 1e-4, name
+    # the batched path ran at most one alignment more per consistency check (the next keyframe beside the previous one)
+    assert sessions["gpu_sequential"][1].alignments == det_o.alignments
+    assert 0 <= sessions["gpu_batched"][1].alignments - det_o.alignments <= len(ref) + 8
+    # the candidates' clouds stayed in the HBM keyframe store between calls
+    assert sessions["gpu_batched"][1].matcher.store_bytes() > 0
