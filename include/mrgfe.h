@@ -62,8 +62,12 @@ enum mrgfe_method {
                                  (registrations.cpp:46-54): the same GICP factor perturbed on the right, small_gicp's LM schedule */
     MRGFE_VGICP_HIP = 3, /* replaces "FAST_VGICP" (fast_gicp::FastVGICP, registrations.cpp:76-84) and the reference's own GPU slot
                             "FAST_VGICP_CUDA" (:65-75): voxelised GICP, target as a Gaussian voxel map of edge `resolution` */
-    MRGFE_ICP_HIP = 4 /* replaces "ICP": pcl::IterativeClosestPoint (registrations.cpp:85-92), reciprocal correspondences off;
-                         single registrations only (not in mrgfe_batch_*) */
+    MRGFE_ICP_HIP = 4, /* replaces "ICP": pcl::IterativeClosestPoint (registrations.cpp:85-92), use_reciprocal_correspondences as in :91;
+                          single registrations only (not in mrgfe_batch_*) */
+    MRGFE_PCL_GICP_HIP = 5, /* replaces "GICP": pcl::GeneralizedIterativeClosestPoint (registrations.cpp:93-103): PCL's covariances, nearest-point
+                               correspondences, inner BFGS with max_optimizer_iterations steps; single registrations only */
+    MRGFE_PCL_GICP_OMP_HIP = 6 /* replaces "GICP_OMP": pclomp::GeneralizedIterativeClosestPoint (registrations.cpp:104-114): the same algorithm with
+                                  the older stopping rule of the inner BFGS (norm of the whole gradient < 1e-2) */
 };
 /* reg_nn_search_method (registrations.cpp:140-146) */
 enum mrgfe_ndt_search { MRGFE_KDTREE = 0, MRGFE_DIRECT26 = 1, MRGFE_DIRECT7 = 2, MRGFE_DIRECT1 = 3 };
@@ -76,8 +80,8 @@ typedef struct mrgfe_reg_params {
     double transformation_epsilon;          /*                                          "reg_transformation_epsilon"        */
     int    maximum_iterations;              /*                                          "reg_maximum_iterations"            */
     double max_correspondence_distance;     /* GICP                                     "reg_max_correspondence_distance"   */
-    int    max_optimizer_iterations;        /* accepted, unused (pcl::GICP BFGS only)   "reg_max_optimizer_iterations"      */
-    int    use_reciprocal_correspondences;  /* accepted, unused (pcl::ICP/GICP only)    "reg_use_reciprocal_correspondences"*/
+    int    max_optimizer_iterations;        /* PCL_GICP_HIP: steps of the inner BFGS    "reg_max_optimizer_iterations"      */
+    int    use_reciprocal_correspondences;  /* ICP_HIP (pcl::GICP ignores it upstream)  "reg_use_reciprocal_correspondences"*/
     int    correspondence_randomness;       /* GICP k neighbours                        "reg_correspondence_randomness"     */
     double resolution;                      /* NDT / VGICP voxel size                   "reg_resolution"                    */
     int    nn_search_method;                /* enum mrgfe_ndt_search                    "reg_nn_search_method"              */
@@ -178,6 +182,9 @@ int mrgfe_knn(mrgfe_ctx* ctx, const float* cloud_xyzi, size_t n, const float* qu
  * number.  The Jacobian is the one of the registration's method (fast_gicp: left, small_gicp: right perturbation). */
 int mrgfe_gicp_linearize(mrgfe_reg* reg, const double T[16], double H[36], double b[6], double* sum_errors, int* n_correspondences);
 /* regularised k-NN covariances (row-major 3x3 per point) of the source (which = 0) or target (1) cloud */
+/* PCL_GICP_HIP (tests): the correspondences and Mahalanobis matrices pcl::GICP's search loop finds at transformation_ = T (column-major, guess
+ * = identity), and the cost estimateRigidTransformationBFGS minimises at x = (t, euler ZYX) over them: *f, grad[6], number of correspondences */
+int mrgfe_pclgicp_evaluate(mrgfe_reg* reg, const float T[16], const double x[6], double* f, double grad[6], int* n_correspondences);
 int mrgfe_gicp_covariances(mrgfe_reg* reg, int which, double* cov9_per_point);
 
 /* ---- prefilter chain (apps/prefiltering_component.cpp:149-151). Outputs: caller-allocated capacity-n packed float4

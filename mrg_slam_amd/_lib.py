@@ -16,7 +16,7 @@ _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.environ.get("MRGFE_LIB") or os.path.join(_PKG, "libmrgfe.so")  # MRGFE_LIB: kernel-variant experiments only
 
 MRGFE_OK, ERR_INVALID, ERR_HIP, ERR_OVERFLOW, ERR_EMPTY, ERR_STATE = 0, -1, -2, -3, -4, -5
-NDT_HIP, GICP_HIP, SMALL_GICP_HIP, VGICP_HIP, ICP_HIP = 0, 1, 2, 3, 4
+NDT_HIP, GICP_HIP, SMALL_GICP_HIP, VGICP_HIP, ICP_HIP, PCL_GICP_HIP, PCL_GICP_OMP_HIP = 0, 1, 2, 3, 4, 5, 6
 SEARCH = {"KDTREE": 0, "DIRECT26": 1, "DIRECT7": 2, "DIRECT1": 3}
 
 
@@ -129,6 +129,7 @@ SIGNATURES = {
     "mrgfe_prefilter": (C.c_int, [_vp, C.POINTER(PrefilterParams), _fp, C.c_size_t, C.c_size_t, _fp, C.POINTER(C.c_size_t)]),
     "mrgfe_prefilter_device": (C.c_int, [_vp, C.POINTER(PrefilterParams), _fp, C.c_size_t, C.c_size_t, _vp, C.POINTER(C.c_size_t)]),
     "mrgfe_knn": (C.c_int, [_vp, _fp, C.c_size_t, _fp, C.c_size_t, C.c_size_t, C.c_int, _ip, _fp]),
+    "mrgfe_pclgicp_evaluate": (C.c_int, [_vp, _fp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
     "mrgfe_gicp_linearize": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _ip]),
     "mrgfe_gicp_covariances": (C.c_int, [_vp, C.c_int, _dp]),
     "mrgfe_ndt_num_leaves": (C.c_int, [_vp]),

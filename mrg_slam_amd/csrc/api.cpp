@@ -49,7 +49,10 @@ GicpParams gicp_params_from(const mrgfe_reg_params& p)
     g.trans_eps = p.transformation_epsilon;
     g.rot_eps = p.rotation_epsilon;
     g.max_iterations = p.maximum_iterations;
-    g.variant = p.method == MRGFE_SMALL_GICP_HIP ? 1 : p.method == MRGFE_VGICP_HIP ? 2 : p.method == MRGFE_ICP_HIP ? 3 : 0;
+    g.variant = p.method == MRGFE_SMALL_GICP_HIP ? 1 : p.method == MRGFE_VGICP_HIP ? 2 : p.method == MRGFE_ICP_HIP ? 3 : (p.method == MRGFE_PCL_GICP_HIP || p.method == MRGFE_PCL_GICP_OMP_HIP) ? 4 : 0;
+    g.max_inner_iterations = p.max_optimizer_iterations;
+    g.pcl_whole_gradient_norm = p.method == MRGFE_PCL_GICP_OMP_HIP;
+    g.use_reciprocal = p.method == MRGFE_ICP_HIP && p.use_reciprocal_correspondences != 0;
     g.voxel_resolution = p.resolution;
     return g;
 }
@@ -57,13 +60,13 @@ GicpParams gicp_params_from(const mrgfe_reg_params& p)
 int check_params(const mrgfe_reg_params* p)
 {
     if (!p) { set_error("NULL params"); return MRGFE_ERR_INVALID; }
-    if (p->method < MRGFE_NDT_HIP || p->method > MRGFE_ICP_HIP) { set_error("unknown registration method %d", p->method); return MRGFE_ERR_INVALID; }
+    if (p->method < MRGFE_NDT_HIP || p->method > MRGFE_PCL_GICP_OMP_HIP) { set_error("unknown registration method %d", p->method); return MRGFE_ERR_INVALID; }
+    if ((p->method == MRGFE_PCL_GICP_HIP || p->method == MRGFE_PCL_GICP_OMP_HIP) && p->max_optimizer_iterations < 1) { set_error("max_optimizer_iterations must be >= 1"); return MRGFE_ERR_INVALID; }
     if (p->method == MRGFE_NDT_HIP) {
         if (!(p->resolution > 0)) { set_error("resolution must be > 0"); return MRGFE_ERR_INVALID; }
         if (p->nn_search_method < 0 || p->nn_search_method > 3) { set_error("unknown nn_search_method %d", p->nn_search_method); return MRGFE_ERR_INVALID; }
     } else {
         if (p->method != MRGFE_ICP_HIP && (p->correspondence_randomness < 4 || p->correspondence_randomness > 64)) { set_error("correspondence_randomness must be in [4, 64]"); return MRGFE_ERR_INVALID; }
-        if (p->method == MRGFE_ICP_HIP && p->use_reciprocal_correspondences) { set_error("ICP_HIP: reciprocal correspondences are not offered"); return MRGFE_ERR_INVALID; }
         if (p->method == MRGFE_VGICP_HIP && !(p->resolution > 0)) { set_error("resolution must be > 0"); return MRGFE_ERR_INVALID; }
     }
     return MRGFE_OK;
@@ -397,12 +400,27 @@ int mrgfe_gicp_linearize(mrgfe_reg* reg, const double T[16], double H[36], doubl
 {
     if (!reg || !reg->gicp || !T || !H || !b || !sum_errors || !n_correspondences) { set_error("mrgfe_gicp_linearize: needs a GICP registration and non-NULL arguments"); return MRGFE_ERR_INVALID; }
     if (reg->params.method == MRGFE_ICP_HIP) { set_error("mrgfe_gicp_linearize: ICP_HIP has no linearised cost"); return MRGFE_ERR_INVALID; }
+    if (reg->params.method == MRGFE_PCL_GICP_HIP || reg->params.method == MRGFE_PCL_GICP_OMP_HIP) { set_error("mrgfe_gicp_linearize: PCL_GICP_HIP minimises with BFGS (mrgfe_pclgicp_evaluate)"); return MRGFE_ERR_INVALID; }
     if (!reg->has_target || !reg->has_source) { set_error("linearize: target / source not set"); return MRGFE_ERR_STATE; }
     MRGFE_LOCK(reg->ctx);
     MRGFE_TRY(reg->ctx->bind());
     double Tr[16];
     for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) Tr[r * 4 + c] = T[c * 4 + r];
     return reg->gicp->linearize(Tr, H, b, sum_errors, n_correspondences);
+}
+
+int mrgfe_pclgicp_evaluate(mrgfe_reg* reg, const float T[16], const double x[6], double* f, double grad[6], int* n_correspondences)
+{
+    if (!reg || !reg->gicp || !T || !x || !f || !grad || !n_correspondences) { set_error("mrgfe_pclgicp_evaluate: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (reg->params.method != MRGFE_PCL_GICP_HIP && reg->params.method != MRGFE_PCL_GICP_OMP_HIP) { set_error("mrgfe_pclgicp_evaluate: needs a PCL_GICP_HIP registration"); return MRGFE_ERR_INVALID; }
+    if (!reg->has_target || !reg->has_source) { set_error("evaluate: target / source not set"); return MRGFE_ERR_STATE; }
+    MRGFE_LOCK(reg->ctx);
+    MRGFE_TRY(reg->ctx->bind());
+    float Tr[16], eye[16];
+    col2row(T, Tr);
+    for (int i = 0; i < 16; ++i) eye[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    MRGFE_TRY(reg->gicp->covariances(0, nullptr));  // covariances, target grid and work buffers in place
+    return reg->gicp->pcl_evaluate(Tr, eye, reg->gicp->source_points(), true, x, f, grad, n_correspondences);
 }
 
 int mrgfe_gicp_covariances(mrgfe_reg* reg, int which, double* cov9_per_point)
@@ -837,7 +855,10 @@ int mrgfe_batch_create(mrgfe_ctx* ctx, const mrgfe_reg_params* params, mrgfe_bat
     if (!ctx || !out) { set_error("mrgfe_batch_create: NULL argument"); return MRGFE_ERR_INVALID; }
     *out = nullptr;
     MRGFE_TRY(check_params(params));
-    if (params->method == MRGFE_ICP_HIP) { set_error("mrgfe_batch_create: ICP_HIP is offered for single registrations only"); return MRGFE_ERR_INVALID; }
+    if (params->method == MRGFE_ICP_HIP || params->method == MRGFE_PCL_GICP_HIP || params->method == MRGFE_PCL_GICP_OMP_HIP) {
+        set_error("mrgfe_batch_create: ICP_HIP and PCL_GICP_HIP are offered for single registrations only");
+        return MRGFE_ERR_INVALID;
+    }
     mrgfe_batch* b = new (std::nothrow) mrgfe_batch();
     if (!b) { set_error("out of host memory"); return MRGFE_ERR_INVALID; }
     b->ctx = ctx;

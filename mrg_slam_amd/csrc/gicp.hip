@@ -11,6 +11,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <atomic>
 #include <string>
 #include <thread>
@@ -19,6 +20,7 @@
 #include "dev_float.h"
 #include "dev_linalg.h"
 #include "dev_utils.h"
+#include "bfgs.h"
 #include "gicp_engine.h"
 #include "nn_device.h"
 #include "ndt_derivatives.h"  // launch_transform_cloud
@@ -146,7 +148,8 @@ __global__ __launch_bounds__(256) void vox_corr_kernel(const float4* __restrict_
 
 // ---- ICP (pcl::IterativeClosestPoint): correspondences + the moment sums of TransformationEstimationSVD ------------------
 // record: [0] correspondences, [1..3] sum src, [4..6] sum dst, [7..15] sum dst * src^T (row-major), [16] sum of squared distances
-__global__ __launch_bounds__(256) void icp_corr_sums_kernel(NnGrid2Dev g, const float4* __restrict__ cur, const float4* __restrict__ tgt, uint32_t n, double max_sq,
+template <bool kReciprocal>
+__global__ __launch_bounds__(256) void icp_corr_sums_kernel(NnGrid2Dev g, NnGrid2Dev g_cur, const float4* __restrict__ cur, const float4* __restrict__ tgt, uint32_t n, double max_sq,
                                                              double* __restrict__ partials);
 __global__ __launch_bounds__(256) void icp_transform_kernel(float4* __restrict__ cur, uint32_t n, const float* __restrict__ T12)
 {
@@ -219,7 +222,8 @@ __global__ __launch_bounds__(256) void gicp_corr_kernel(NnGrid2Dev g, const floa
     gicp_corr_query<kGicpGroup>(g, src, n, pose, thr2, corr, blockIdx.x);
 }
 
-__global__ __launch_bounds__(256) void icp_corr_sums_kernel(NnGrid2Dev g, const float4* __restrict__ cur, const float4* __restrict__ tgt, uint32_t n, double max_sq,
+template <bool kReciprocal>
+__global__ __launch_bounds__(256) void icp_corr_sums_kernel(NnGrid2Dev g, NnGrid2Dev g_cur, const float4* __restrict__ cur, const float4* __restrict__ tgt, uint32_t n, double max_sq,
                                                              double* __restrict__ partials)
 {
 #pragma clang fp contract(off)
@@ -234,7 +238,15 @@ __global__ __launch_bounds__(256) void icp_corr_sums_kernel(NnGrid2Dev g, const 
         int32_t j = -1;
         float   sqd = INFINITY;
         nn_nearest_group<kGicpGroup>(g, p.x, p.y, p.z, static_cast<int>(threadIdx.x % kGicpGroup), max_sq, j, sqd);
-        if (threadIdx.x % kGicpGroup == 0 && j >= 0 && !(static_cast<double>(sqd) > max_sq)) {  // determineCorrespondences: skipped iff distance > max_dist^2
+        bool keep = j >= 0 && !(static_cast<double>(sqd) > max_sq);  // determineCorrespondences: skipped iff distance > max_dist^2 (uniform within the group)
+        if (kReciprocal && keep) {  // determineReciprocalCorrespondences: the target point's nearest source point must be this one, within the limit
+            const float4 q = tgt[j];
+            int32_t ri = -1;
+            float   rd = INFINITY;
+            nn_nearest_group<kGicpGroup>(g_cur, q.x, q.y, q.z, static_cast<int>(threadIdx.x % kGicpGroup), max_sq, ri, rd);
+            keep = ri == static_cast<int32_t>(i) && !(static_cast<double>(rd) > max_sq);
+        }
+        if (threadIdx.x % kGicpGroup == 0 && keep) {
             const float4 q = tgt[j];
             vals[0] = 1.0;
             vals[1] = p.x; vals[2] = p.y; vals[3] = p.z;
@@ -248,6 +260,130 @@ __global__ __launch_bounds__(256) void icp_corr_sums_kernel(NnGrid2Dev g, const 
         }
     }
     gicp_block_reduce(vals, partials + size_t(blockIdx.x) * kGicpStride, 17);
+}
+
+// ---- PCL_GICP_HIP: pcl::GeneralizedIterativeClosestPoint (registrations.cpp:93-103) / pclomp::GICP (:104-114) -----------------------
+// computeCovariances: raw second moments of the FLOAT coordinates (float products) summed in double, / k, minus mean mean^T; the SVD of the
+// symmetric result = its eigenvectors ordered by |eigenvalue|; singular values replaced by (1, 1, gicp_epsilon)
+__global__ __launch_bounds__(256) void pclgicp_cov_kernel(const float4* __restrict__ pts, uint32_t n, const int32_t* __restrict__ knn, int k, double gicp_epsilon, double* __restrict__ cov6)
+{
+#pragma clang fp contract(off)
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const int32_t* nb = knn + size_t(i) * k;
+    double mean[3] = {0, 0, 0}, c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < k; ++j) {
+        const int32_t id = nb[j];
+        if (id < 0) continue;
+        const float4 p = pts[id];
+        mean[0] += p.x; mean[1] += p.y; mean[2] += p.z;
+        const float xx = p.x * p.x, yx = p.y * p.x, yy = p.y * p.y, zx = p.z * p.x, zy = p.z * p.y, zz = p.z * p.z;
+        c[0] += xx; c[3] += yx; c[4] += yy; c[6] += zx; c[7] += zy; c[8] += zz;
+    }
+    for (int a = 0; a < 3; ++a) mean[a] /= static_cast<double>(k);
+    for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc <= r; ++cc) {
+            c[r * 3 + cc] /= static_cast<double>(k);
+            c[r * 3 + cc] -= mean[r] * mean[cc];
+            c[cc * 3 + r] = c[r * 3 + cc];
+        }
+    double w[3], E[9];
+    dl_sym_eig3(c, w, E);  // ascending eigenvalues; singular values are their magnitudes
+    int order[3] = {0, 1, 2};
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2 - a; ++b)
+            if (fabs(w[order[b]]) < fabs(w[order[b + 1]])) { const int t = order[b]; order[b] = order[b + 1]; order[b + 1] = t; }  // descending, stable
+    double out[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int kk = 0; kk < 3; ++kk) {
+        const double v = kk == 2 ? gicp_epsilon : 1.0;
+        const int    col = order[kk];
+        for (int r = 0; r < 3; ++r)
+            for (int cc = 0; cc < 3; ++cc) out[r * 3 + cc] += v * E[r * 3 + col] * E[cc * 3 + col];
+    }
+    double* o = cov6 + size_t(i) * 6;
+    o[0] = out[0]; o[1] = out[1]; o[2] = out[2]; o[3] = out[4]; o[4] = out[5]; o[5] = out[8];
+}
+
+// one outer iteration's search loop (gicp.hpp computeTransformation): query = transformation_ * point in float, nearest target point, kept iff
+// squared distance < max_correspondence_distance^2; its Mahalanobis matrix (R C1 R^T + C2)^-1, R = rotation of transformation_ * guess (double)
+struct PclGicpIter {
+    float  Tf[12];
+    double R[9];
+    double thr2;
+};
+__global__ __launch_bounds__(256) void pclgicp_corr_kernel(NnGrid2Dev g, const float4* __restrict__ src, uint32_t n, PclGicpIter it, const double* __restrict__ cov_src,
+                                                            const double* __restrict__ cov_tgt, int32_t* __restrict__ corr, double* __restrict__ mahal)
+{
+#pragma clang fp contract(off)
+    const uint32_t i = blockIdx.x * (256u / kGicpGroup) + threadIdx.x / kGicpGroup;
+    if (i >= n) return;
+    const float4 a = src[i];
+    float q[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float s = it.Tf[r * 4 + 0] * a.x;
+        s = s + it.Tf[r * 4 + 1] * a.y;
+        s = s + it.Tf[r * 4 + 2] * a.z;
+        q[r] = s + it.Tf[r * 4 + 3];
+    }
+    int32_t j = -1;
+    float   sqd = INFINITY;
+    nn_nearest_group<kGicpGroup>(g, q[0], q[1], q[2], static_cast<int>(threadIdx.x % kGicpGroup), it.thr2, j, sqd);
+    if (threadIdx.x % kGicpGroup != 0) return;
+    if (j >= 0 && !(static_cast<double>(sqd) < it.thr2)) j = -1;
+    corr[i] = j;
+    if (j < 0) return;
+    const double* c1 = cov_src + size_t(i) * 6;
+    const double* c2 = cov_tgt + size_t(j) * 6;
+    const double C1[9] = {c1[0], c1[1], c1[2], c1[1], c1[3], c1[4], c1[2], c1[4], c1[5]};
+    const double C2[9] = {c2[0], c2[1], c2[2], c2[1], c2[3], c2[4], c2[2], c2[4], c2[5]};
+    double RC[9], Rt[9], tmp[9], M[9];
+    dl_mul3(it.R, C1, RC);
+    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) Rt[r * 3 + cc] = it.R[cc * 3 + r];
+    dl_mul3(RC, Rt, tmp);
+    for (int t = 0; t < 9; ++t) tmp[t] += C2[t];
+    dl_inv3(tmp, M);
+    double* o = mahal + size_t(i) * 9;
+    for (int t = 0; t < 9; ++t) o[t] = M[t];
+}
+
+// OptimizationFunctorWithIndices::fdf over the correspondences: d = T(x) p_src - p_tgt (float), Md = M d, f += d^T Md, g_t += Md,
+// dCost_dR_T += p_base_src Md^T (base_transformation_ is the identity in computeTransformation: p_base_src = p_src)
+__global__ __launch_bounds__(256) void pclgicp_fdf_kernel(const float4* __restrict__ src, uint32_t n, const float4* __restrict__ tgt, const int32_t* __restrict__ corr,
+                                                           const double* __restrict__ mahal, PclGicpIter it, double* __restrict__ partials)
+{
+#pragma clang fp contract(off)
+    double vals[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) vals[k] = 0.0;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) {
+        const int32_t j = corr[i];
+        if (j >= 0) {
+            const float4 a = src[i], b = tgt[j];
+            float q[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float s = it.Tf[r * 4 + 0] * a.x;
+                s = s + it.Tf[r * 4 + 1] * a.y;
+                s = s + it.Tf[r * 4 + 2] * a.z;
+                q[r] = s + it.Tf[r * 4 + 3];
+            }
+            const float  df[3] = {q[0] - b.x, q[1] - b.y, q[2] - b.z};
+            const double d[3] = {df[0], df[1], df[2]};
+            const double* M = mahal + size_t(i) * 9;
+            const double Md[3] = {M[0] * d[0] + M[1] * d[1] + M[2] * d[2], M[3] * d[0] + M[4] * d[1] + M[5] * d[2], M[6] * d[0] + M[7] * d[1] + M[8] * d[2]};
+            vals[0] = d[0] * Md[0] + d[1] * Md[1] + d[2] * Md[2];
+            vals[1] = Md[0]; vals[2] = Md[1]; vals[3] = Md[2];
+            const double pb[3] = {a.x, a.y, a.z};
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) vals[4 + r * 3 + cc] = pb[r] * Md[cc];
+            vals[28] = 1.0;
+        }
+    }
+    gicp_block_reduce(vals, partials + size_t(blockIdx.x) * kGicpStride, 13);
 }
 
 // linearize over the correspondences of gicp_corr_kernel
@@ -591,6 +727,7 @@ GicpEngine::~GicpEngine()
     if (ctx_) (void)hipSetDevice(ctx_->device);
     tgt_grid_.release();
     cov_grid_.release();
+    cur_grid_.release();
     d_knn_i_.release(); d_knn_d_.release();
     d_tgt_cov_.release(); d_src_cov_.release(); d_corr_.release(); d_mahal_.release(); d_partial_.release(); d_T_.release();
     d_vox_.release(); d_vox_runs_.release(); d_cur_.release();
@@ -612,7 +749,7 @@ int GicpEngine::set_source(const void* d, size_t n)
 }
 
 // k-NN covariances of one cloud on ctx's stream, through the caller's grid and neighbour buffers
-int gicp_compute_covariances(mrgfe_ctx* ctx, int k, const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid, DevBuf& knn_i, DevBuf& knn_d)
+int gicp_compute_covariances(mrgfe_ctx* ctx, int k, const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid, DevBuf& knn_i, DevBuf& knn_d, bool pcl_moments)
 {
     MRGFE_TRY(out.ensure(std::max<size_t>(n, 1) * 48));
     if (n == 0) return MRGFE_OK;
@@ -621,14 +758,15 @@ int gicp_compute_covariances(mrgfe_ctx* ctx, int k, const float4* d_pts, size_t 
     MRGFE_TRY(knn_d.ensure(n * k * 4));
     MRGFE_TRY(grid.knn_device(ctx, d_pts, n, k, knn_i.as<int32_t>(), knn_d.as<float>()));
     const uint32_t nn = static_cast<uint32_t>(n);
-    hipLaunchKernelGGL(gicp_cov_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, d_pts, nn, knn_i.as<int32_t>(), k, out.as<double>());
+    if (pcl_moments) hipLaunchKernelGGL(pclgicp_cov_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, d_pts, nn, knn_i.as<int32_t>(), k, 1e-3 /* gicp_epsilon_ */, out.as<double>());
+    else             hipLaunchKernelGGL(gicp_cov_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, d_pts, nn, knn_i.as<int32_t>(), k, out.as<double>());
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }
 
 int GicpEngine::compute_covariances(const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid)
 {
-    return gicp_compute_covariances(ctx_, prm_.k_correspondences, d_pts, n, out, grid, d_knn_i_, d_knn_d_);
+    return gicp_compute_covariances(ctx_, prm_.k_correspondences, d_pts, n, out, grid, d_knn_i_, d_knn_d_, prm_.variant == 4);
 }
 
 void GicpEngine::voxel_grid(double* res, int32_t cmin[3], int32_t dim[3], uint32_t* n_cells) const
@@ -742,6 +880,7 @@ int GicpEngine::ensure_ready()
 int GicpEngine::covariances(int which, double* out9)
 {
     MRGFE_TRY(ensure_ready());
+    if (!out9) return MRGFE_OK;  // (callers that only want the covariances, grid and buffers in place)
     const size_t n = which == 0 ? n_src_ : n_tgt_;
     std::vector<double> c6(n * 6);
     if (n) MRGFE_HIP_CHECK(hipMemcpy(c6.data(), (which == 0 ? d_src_cov_ : d_tgt_cov_).p, n * 48, hipMemcpyDeviceToHost));
@@ -930,7 +1069,12 @@ int GicpEngine::align_icp(const float guess[16])
         ++n_linearize_;
         double r[kGicpStride] = {0};
         if (n && n_tgt_) {
-            hipLaunchKernelGGL(icp_corr_sums_kernel, dim3(nblk_c), dim3(256), 0, st, tgt_grid_.dev2(), d_cur, d_tgt_, n, max_sq, d_part);
+            if (prm_.use_reciprocal) {
+                MRGFE_TRY(cur_grid_.build(ctx_, d_cur, n, 1.0f, NnGrid::kCrowding1nn, 1));
+                hipLaunchKernelGGL(icp_corr_sums_kernel<true>, dim3(nblk_c), dim3(256), 0, st, tgt_grid_.dev2(), cur_grid_.dev2(), d_cur, d_tgt_, n, max_sq, d_part);
+            } else {
+                hipLaunchKernelGGL(icp_corr_sums_kernel<false>, dim3(nblk_c), dim3(256), 0, st, tgt_grid_.dev2(), tgt_grid_.dev2(), d_cur, d_tgt_, n, max_sq, d_part);
+            }
             hipLaunchKernelGGL(gicp_reduce_kernel, dim3(1), dim3(256), 0, st, d_part, nblk_c, d_res);
             MRGFE_HIP_CHECK(hipGetLastError());
             MRGFE_HIP_CHECK(hipMemcpyAsync(r, d_res, sizeof(r), hipMemcpyDeviceToHost, st));
@@ -973,9 +1117,224 @@ int GicpEngine::align_icp(const float guess[16])
     return MRGFE_OK;
 }
 
+// pcl::GeneralizedIterativeClosestPoint::computeTransformation + estimateRigidTransformationBFGS (gicp_engine.h, variant 4).  Per outer
+// iteration one correspondence + Mahalanobis kernel; per functor evaluation of the inner BFGS one 14-sum kernel and a small record to the host.
+namespace {
+struct PclGicpFunctor {
+    GicpEngine* eng;
+    std::function<int(const double x[6], double* f, double g[6])> eval;  // 0 on success
+    int  status = MRGFE_OK, evaluations = 0;
+    double operator()(const double x[6]) { double f = 0, g[6]; run(x, &f, g); return f; }
+    void   df(const double x[6], double g[6]) { double f = 0; run(x, &f, g); }
+    void   fdf(const double x[6], double& f, double g[6]) { run(x, &f, g); }
+    void   run(const double x[6], double* f, double g[6])
+    {
+        ++evaluations;
+        const int rc = eval(x, f, g);
+        if (rc != MRGFE_OK && status == MRGFE_OK) status = rc;
+    }
+};
+// GeneralizedIterativeClosestPoint::applyState: t.topLeftCorner<3,3>() = Rz(x5) Ry(x4) Rx(x3) t.topLeftCorner<3,3>(); t.col(3) += (x0, x1, x2, 0); all float,
+// the rotations as Eigen::AngleAxisf::toRotationMatrix() builds them
+void angle_axis_unit_f(float angle, int axis, float R[9])
+{
+    float ax[3] = {0, 0, 0};
+    ax[axis] = 1.0f;
+    const float sn = std::sin(angle), c = std::cos(angle);
+    const float sin_axis[3] = {sn * ax[0], sn * ax[1], sn * ax[2]};
+    const float cos1_axis[3] = {(1.0f - c) * ax[0], (1.0f - c) * ax[1], (1.0f - c) * ax[2]};
+    float tmp;
+    tmp = cos1_axis[0] * ax[1]; R[1] = tmp - sin_axis[2]; R[3] = tmp + sin_axis[2];
+    tmp = cos1_axis[0] * ax[2]; R[2] = tmp + sin_axis[1]; R[6] = tmp - sin_axis[1];
+    tmp = cos1_axis[1] * ax[2]; R[5] = tmp - sin_axis[0]; R[7] = tmp + sin_axis[0];
+    R[0] = cos1_axis[0] * ax[0] + c; R[4] = cos1_axis[1] * ax[1] + c; R[8] = cos1_axis[2] * ax[2] + c;
+}
+void mul3f(const float a[9], const float b[9], float out[9])
+{
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            const float p0 = a[r * 3 + 0] * b[0 * 3 + c], p1 = a[r * 3 + 1] * b[1 * 3 + c], p2 = a[r * 3 + 2] * b[2 * 3 + c];
+            const float s = p0 + p1;
+            out[r * 3 + c] = s + p2;
+        }
+}
+void pclgicp_apply_state(float t[16], const double x[6])
+{
+    float Rx[9], Ry[9], Rz[9], Rzy[9], R[9], old[9], nw[9];
+    angle_axis_unit_f(static_cast<float>(x[5]), 2, Rz);
+    angle_axis_unit_f(static_cast<float>(x[4]), 1, Ry);
+    angle_axis_unit_f(static_cast<float>(x[3]), 0, Rx);
+    mul3f(Rz, Ry, Rzy);
+    mul3f(Rzy, Rx, R);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) old[r * 3 + c] = t[r * 4 + c];
+    mul3f(R, old, nw);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) t[r * 4 + c] = nw[r * 3 + c];
+    for (int r = 0; r < 3; ++r) t[r * 4 + 3] += static_cast<float>(x[r]);
+}
+// computeRDerivative: g[3..5] = tr(dR/dphi dCost_dR_T), ... for R = Rz(psi) Ry(theta) Rx(phi)
+void pclgicp_r_derivative(const double x[6], const double dC[9], double g[6])
+{
+    const double phi = x[3], theta = x[4], psi = x[5];
+    const double cphi = std::cos(phi), sphi = std::sin(phi), ctheta = std::cos(theta), stheta = std::sin(theta), cpsi = std::cos(psi), spsi = std::sin(psi);
+    const double dPhi[9] = {0, sphi * spsi + cphi * cpsi * stheta, cphi * spsi - cpsi * sphi * stheta, 0, -cpsi * sphi + cphi * spsi * stheta, -cphi * cpsi - sphi * spsi * stheta,
+                            0, cphi * ctheta, -ctheta * sphi};
+    const double dTheta[9] = {-cpsi * stheta, cpsi * ctheta * sphi, cphi * cpsi * ctheta, -spsi * stheta, ctheta * sphi * spsi, cphi * ctheta * spsi, -ctheta, -sphi * stheta, -cphi * stheta};
+    const double dPsi[9] = {-ctheta * spsi, -cphi * cpsi - sphi * spsi * stheta, cpsi * sphi - cphi * spsi * stheta, cpsi * ctheta, -cphi * spsi + cpsi * sphi * stheta,
+                            sphi * spsi + cphi * cpsi * stheta, 0, 0, 0};
+    auto inner = [&](const double A[9]) {  // matricesInnerProd(A, dCost_dR_T) = sum_ij A(j, i) dC(i, j)
+        double r = 0;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r += A[j * 3 + i] * dC[i * 3 + j];
+        return r;
+    };
+    g[3] = inner(dPhi);
+    g[4] = inner(dTheta);
+    g[5] = inner(dPsi);
+}
+}  // namespace
+
+int GicpEngine::pcl_evaluate(const float T_rowmajor[16], const float guess_rowmajor[16], const float4* d_pts, bool search, const double x[6], double* f, double g[6], int* n_corr)
+{
+    hipStream_t    st = ctx_->stream;
+    const uint32_t n = static_cast<uint32_t>(n_src_), nblk = (n + 255) / 256;
+    *f = 0;
+    for (int k = 0; k < 6; ++k) g[k] = 0;
+    if (n_corr) *n_corr = 0;
+    if (n == 0 || n_tgt_ == 0) return MRGFE_OK;
+    PclGicpIter it;
+    if (search) {  // the outer iteration's correspondences and Mahalanobis matrices at transformation_ = T
+        for (int k = 0; k < 12; ++k) it.Tf[k] = T_rowmajor[k];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+                for (int k = 0; k < 4; ++k) s += static_cast<double>(T_rowmajor[i * 4 + k]) * static_cast<double>(guess_rowmajor[k * 4 + j]);
+                it.R[i * 3 + j] = s;
+            }
+        it.thr2 = prm_.max_corr_dist * prm_.max_corr_dist;
+        constexpr uint32_t per_blk = 256u / kGicpGroup;
+        hipLaunchKernelGGL(pclgicp_corr_kernel, dim3((n + per_blk - 1) / per_blk), dim3(256), 0, st, tgt_grid_.dev2(), d_pts, n, it, d_src_cov_.as<double>(), d_tgt_cov_.as<double>(),
+                           d_corr_.as<int32_t>(), d_mahal_.as<double>());
+        MRGFE_HIP_CHECK(hipGetLastError());
+        if (!x) return MRGFE_OK;
+    }
+    float Tx[16];
+    for (int i = 0; i < 16; ++i) Tx[i] = (i % 5 == 0) ? 1.0f : 0.0f;  // base_transformation_ = Identity
+    pclgicp_apply_state(Tx, x);
+    for (int k = 0; k < 12; ++k) it.Tf[k] = Tx[k];
+    for (int k = 0; k < 9; ++k) it.R[k] = 0;
+    it.thr2 = 0;
+    double* d_part = d_partial_.as<double>();
+    double* d_res = d_part + size_t(nblk) * kGicpStride;
+    MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev0, st));
+    hipLaunchKernelGGL(pclgicp_fdf_kernel, dim3(nblk), dim3(256), 0, st, d_pts, n, d_tgt_, d_corr_.as<int32_t>(), d_mahal_.as<double>(), it, d_part);
+    MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev1, st));
+    hipLaunchKernelGGL(gicp_reduce_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, d_res);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    double r[kGicpStride];
+    MRGFE_HIP_CHECK(hipMemcpyAsync(r, d_res, sizeof(r), hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    float ms = 0;
+    MRGFE_HIP_CHECK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
+    kernel_ms += ms;
+    kernel_launches += 1;
+    kernel_alg_bytes += double(n) * (16 + 4) + r[28] * (16 + 72);
+    const double m = r[28];
+    if (n_corr) *n_corr = static_cast<int>(m);
+    if (m <= 0) return MRGFE_OK;
+    *f = r[0] / m;
+    for (int k = 0; k < 3; ++k) g[k] = r[1 + k] * (2.0 / m);
+    double dC[9];
+    for (int k = 0; k < 9; ++k) dC[k] = r[4 + k] * (2.0 / m);
+    pclgicp_r_derivative(x, dC, g);
+    return MRGFE_OK;
+}
+
+int GicpEngine::align_pcl_gicp(const float guess[16])
+{
+    MRGFE_TRY(ensure_ready());
+    hipStream_t st = ctx_->stream;
+    kernel_ms = 0; kernel_launches = 0; kernel_alg_bytes = 0;
+    n_linearize_ = n_error_ = 0;
+    converged_ = false;
+    nr_iterations_ = 0;
+    for (int t = 0; t < 36; ++t) final_hessian_[t] = 0.0;
+    float transformation[16], previous[16];
+    for (int i = 0; i < 16; ++i) transformation[i] = previous[i] = final_[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    const uint32_t n = static_cast<uint32_t>(n_src_);
+    // pcl::Registration::align copies the source into `output`; computeTransformation moves it by the guess (pcl::transformPointCloud)
+    MRGFE_TRY(d_cur_.ensure(std::max<size_t>(n_src_, 1) * 16));
+    MRGFE_TRY(d_T_.ensure(64));
+    float4* d_out = d_cur_.as<float4>();
+    if (n) {
+        MRGFE_HIP_CHECK(hipMemcpyAsync(d_out, d_src_, size_t(n) * 16, hipMemcpyDeviceToDevice, st));
+        MRGFE_HIP_CHECK(hipMemcpyAsync(d_T_.p, guess, 48, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(icp_transform_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_out, n, d_T_.as<float>());
+        MRGFE_HIP_CHECK(hipGetLastError());
+        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    while (!converged_ && n > 0) {
+        double f0 = 0, g0[6];
+        int    m = 0;
+        MRGFE_TRY(pcl_evaluate(transformation, guess, d_out, true, nullptr, &f0, g0, nullptr));  // the search loop of this iteration
+        std::memcpy(previous, transformation, sizeof(previous));
+        // ---- estimateRigidTransformationBFGS
+        // x[3] = std::atan2(T(2,1), T(2,2)) and x[5] = std::atan2(T(1,0), T(0,0)) on floats, x[4] = asin(-T(2,0)) through the C function (double)
+        double x[6] = {transformation[3], transformation[7], transformation[11], static_cast<double>(std::atan2(transformation[9], transformation[10])),
+                       std::asin(static_cast<double>(-transformation[8])), static_cast<double>(std::atan2(transformation[4], transformation[0]))};
+        PclGicpFunctor fn;
+        fn.eng = this;
+        fn.eval = [&](const double xx[6], double* f, double g[6]) { return pcl_evaluate(nullptr, nullptr, d_out, false, xx, f, g, &m); };
+        // NotEnoughPointsException when fewer than four correspondences: known after the first evaluation (the count comes back with every record)
+        BFGS<PclGicpFunctor> bfgs(fn);
+        int inner = 0;
+        BFGSSpace::Status result = bfgs.minimizeInit(x);
+        MRGFE_TRY(fn.status);
+        if (m < 4) break;
+        result = BFGSSpace::Running;
+        do {
+            ++inner;
+            result = bfgs.minimizeOneStep(x);
+            MRGFE_TRY(fn.status);
+            if (result) break;
+            // testGradient -> OptimizationFunctorWithIndices::checkGradient (PCL >= 1.11: translation and rotation parts apart; pclomp: the whole norm)
+            const double* gr = bfgs.gradient;
+            const double gt = std::sqrt(gr[0] * gr[0] + gr[1] * gr[1] + gr[2] * gr[2]), grn = std::sqrt(gr[3] * gr[3] + gr[4] * gr[4] + gr[5] * gr[5]);
+            const bool ok = prm_.pcl_whole_gradient_norm ? std::sqrt(gt * gt + grn * grn) < 1e-2 : (gt < 1e-2 && grn < 1e-2);
+            result = ok ? BFGSSpace::Success : BFGSSpace::Running;
+        } while (result == BFGSSpace::Running && inner < prm_.max_inner_iterations);
+        n_error_ += fn.evaluations;
+        n_linearize_ += 1;
+        if (result == BFGSSpace::NoProgress || result == BFGSSpace::Success || inner == prm_.max_inner_iterations) {
+            for (int i = 0; i < 16; ++i) transformation[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+            pclgicp_apply_state(transformation, x);
+        } else {
+            break;  // SolverDidntConvergeException
+        }
+        double delta = 0;
+        for (int k = 0; k < 4; ++k)
+            for (int l = 0; l < 4; ++l) {
+                const double ratio = (k < 3 && l < 3) ? 1.0 / prm_.rot_eps : 1.0 / prm_.trans_eps;
+                const double c_delta = ratio * std::fabs(static_cast<double>(previous[k * 4 + l] - transformation[k * 4 + l]));
+                if (c_delta > delta) delta = c_delta;
+            }
+        ++nr_iterations_;
+        if (nr_iterations_ >= prm_.max_iterations || delta < 1) {
+            converged_ = true;
+            std::memcpy(previous, transformation, sizeof(previous));
+        }
+    }
+    for (int r = 0; r < 4; ++r)  // final_transformation_ = previous_transformation_ * guess (float)
+        for (int c = 0; c < 4; ++c) {
+            float s = 0;
+            for (int k = 0; k < 4; ++k) s += previous[r * 4 + k] * guess[k * 4 + c];
+            final_[r * 4 + c] = s;
+        }
+    return MRGFE_OK;
+}
+
 int GicpEngine::align(const float guess[16])
 {
     if (prm_.variant == 3) return align_icp(guess);
+    if (prm_.variant == 4) return align_pcl_gicp(guess);
     MRGFE_TRY(ensure_ready());
     kernel_ms = 0; kernel_launches = 0; kernel_alg_bytes = 0;
     n_linearize_ = n_error_ = 0;
@@ -1205,7 +1564,7 @@ int GicpBatch::align_all(std::vector<GicpEngine*>& engines, std::vector<GicpBatc
                 if (w >= todo.size()) break;
                 GicpBatchPair& p = pairs[todo[w]];
                 const int k = engines[p.target]->params().k_correspondences;
-                const int rc = gicp_compute_covariances(l.ctx, k, p.d_src, p.n, p.ext_cov ? *p.ext_cov : p.cov, l.grid, l.knn_i, l.knn_d);
+                const int rc = gicp_compute_covariances(l.ctx, k, p.d_src, p.n, p.ext_cov ? *p.ext_cov : p.cov, l.grid, l.knn_i, l.knn_d, false);
                 if (rc != MRGFE_OK) { status[li] = rc; message[li] = mrgfe_last_error(); break; }
                 if (p.ext_cov) *p.ext_cov_k = k;
             }

@@ -29,6 +29,16 @@ struct GicpParams {
     // variant 3, pcl::IterativeClosestPoint (registrations.cpp:85-92): nearest target point within max_corr_dist of the cumulatively
     // transformed source, TransformationEstimationSVD (Umeyama, no scaling) per iteration, DefaultConvergenceCriteria with
     // translation threshold trans_eps (on the squared translation) and rotation threshold 1 - trans_eps; no covariances
+    // ... with use_reciprocal (setUseReciprocalCorrespondences, registrations.cpp:91): a pair (i, j) counts only if the nearest point of
+    // target j among the source points AS TRANSFORMED SO FAR is i again, within max_corr_dist (determineReciprocalCorrespondences):
+    // a second exact-NN grid, over the working copy of the source, rebuilt every iteration
+    bool   use_reciprocal = false;
+    // variant 4, pcl::GeneralizedIterativeClosestPoint (registrations.cpp:93-103; pclomp::GICP :104-114 with pcl_whole_gradient_norm): PCL's own
+    // covariances (raw float moments, singular values (1, 1, 1e-3)), per outer iteration nearest target points within max_corr_dist and
+    // Mahalanobis matrices (R C1 R^T + C2)^-1, inner BFGS (csrc/bfgs.h) over (t, euler ZYX) for at most max_inner_iterations steps,
+    // converged iff max entry change / (rot_eps | trans_eps) < 1 or the iteration limit is reached
+    int    max_inner_iterations = 20;
+    bool   pcl_whole_gradient_norm = false;
     double sg_init_lambda = 1e-3, sg_lambda_factor = 10.0;
     int    sg_max_inner_iterations = 10;
 };
@@ -88,7 +98,15 @@ class GicpEngine {
     uint32_t vox_cells_ = 0, vox_occupied_ = 0;
     int build_voxelmap();
     int align_icp(const float guess_rowmajor[16]);
+    int align_pcl_gicp(const float guess_rowmajor[16]);
+   public:
+    // PCL_GICP_HIP: (search) the correspondences + Mahalanobis matrices at transformation_ = T with `guess`, and / or (x != NULL) the functor of
+    // estimateRigidTransformationBFGS at x over the stored correspondences of the points d_pts: f, g[6], number of correspondences
+    int pcl_evaluate(const float T_rowmajor[16], const float guess_rowmajor[16], const float4* d_pts, bool search, const double x[6], double* f, double g[6], int* n_corr);
+    const float4* source_points() const { return d_src_; }
+   private:
     DevBuf d_cur_;  // ICP: the source as transformed so far
+    NnGrid cur_grid_;  // ICP with reciprocal correspondences: exact-NN grid over d_cur_
     float  final_[16];
     double final_hessian_[36];
     bool   converged_ = false;

@@ -17,7 +17,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import GICP_HIP, ICP_HIP, NDT_HIP, SEARCH, SMALL_GICP_HIP, VGICP_HIP, Context, PairResult, RegParams, check, default_context, lib
+from ._lib import GICP_HIP, ICP_HIP, NDT_HIP, PCL_GICP_HIP, PCL_GICP_OMP_HIP, SEARCH, SMALL_GICP_HIP, VGICP_HIP, Context, PairResult, RegParams, check, default_context, lib
 
 _fp = C.POINTER(C.c_float)
 _dp = C.POINTER(C.c_double)
@@ -247,16 +247,53 @@ class VgicpHip(GicpHip):
 
 class IcpHip(HipRegistration):
     """registration_method "ICP_HIP": drop-in for the ICP branch (registrations.cpp:85-92), pcl::IterativeClosestPoint with
-    TransformationEstimationSVD and the default convergence criteria; reciprocal correspondences are not offered."""
+    TransformationEstimationSVD and the default convergence criteria; ``use_reciprocal_correspondences`` as in :91."""
 
     METHOD = ICP_HIP
 
-    def __init__(self, max_correspondence_distance=2.0, transformation_epsilon=0.01, maximum_iterations=64, ctx: Context | None = None):
+    def __init__(self, max_correspondence_distance=2.0, transformation_epsilon=0.01, maximum_iterations=64, use_reciprocal_correspondences=False, ctx: Context | None = None):
         p = default_params(ICP_HIP)
         p.max_correspondence_distance = max_correspondence_distance
         p.transformation_epsilon = transformation_epsilon
         p.maximum_iterations = maximum_iterations
+        p.use_reciprocal_correspondences = int(bool(use_reciprocal_correspondences))
         super().__init__(p, ctx)
+
+
+class PclGicpHip(HipRegistration):
+    """registration_method "GICP" / "PCL_GICP_HIP" (pcl::GeneralizedIterativeClosestPoint, registrations.cpp:93-103) and, with ``omp=True``,
+    "GICP_OMP" / "PCL_GICP_OMP_HIP" (pclomp::GeneralizedIterativeClosestPoint, :104-114): PCL's covariances and nearest-point correspondences on
+    the GPU, the inner BFGS (``max_optimizer_iterations`` steps) on the host over 13 GPU sums per evaluation.  ``use_reciprocal_correspondences``
+    is accepted and has no effect, as upstream: pcl::GICP's computeTransformation runs its own search loop."""
+
+    METHOD = PCL_GICP_HIP
+
+    def __init__(self, correspondence_randomness=20, max_correspondence_distance=2.0, transformation_epsilon=0.01, rotation_epsilon=2e-3, maximum_iterations=64,
+                 max_optimizer_iterations=20, use_reciprocal_correspondences=False, omp=False, ctx: Context | None = None):
+        p = default_params(PCL_GICP_OMP_HIP if omp else PCL_GICP_HIP)
+        p.correspondence_randomness = correspondence_randomness
+        p.max_correspondence_distance = max_correspondence_distance
+        p.transformation_epsilon = transformation_epsilon
+        p.rotation_epsilon = rotation_epsilon
+        p.maximum_iterations = maximum_iterations
+        p.max_optimizer_iterations = max_optimizer_iterations
+        p.use_reciprocal_correspondences = int(bool(use_reciprocal_correspondences))
+        super().__init__(p, ctx)
+
+    def covariances(self, which="source"):
+        n = self._n_src if which == "source" else self._n_tgt
+        out = np.empty((n, 3, 3))
+        check(lib().mrgfe_gicp_covariances(self._h, 0 if which == "source" else 1, out.ctypes.data_as(_dp)))
+        return out
+
+    def evaluate(self, T, x):
+        """The correspondences pcl::GICP finds at transformation T (guess identity) and the cost estimateRigidTransformationBFGS minimises at x
+        over them: (f, g[6], correspondences)."""
+        Tc = _colmajor(T)
+        xx = np.ascontiguousarray(x, dtype=np.float64)
+        f, g, n = C.c_double(0), np.zeros(6), C.c_int(0)
+        check(lib().mrgfe_pclgicp_evaluate(self._h, Tc.ctypes.data_as(_fp), xx.ctypes.data_as(_dp), C.byref(f), g.ctypes.data_as(_dp), C.byref(n)))
+        return f.value, g, n.value
 
 
 def select_registration_method(params: dict, ctx: Context | None = None) -> HipRegistration:
@@ -285,14 +322,12 @@ def select_registration_method(params: dict, ctx: Context | None = None) -> HipR
         return GicpHip(int(params.get("reg_correspondence_randomness", 20)), float(params.get("reg_max_correspondence_distance", 2.0)), eps,
                        maximum_iterations=iters, num_threads=threads, ctx=ctx)
     if method in ("ICP", "ICP_HIP"):
-        if bool(params.get("reg_use_reciprocal_correspondences", False)):
-            raise NotImplementedError("ICP_HIP: reciprocal correspondences are not offered")
-        return IcpHip(float(params.get("reg_max_correspondence_distance", 2.0)), eps, iters, ctx=ctx)
+        return IcpHip(float(params.get("reg_max_correspondence_distance", 2.0)), eps, iters, bool(params.get("reg_use_reciprocal_correspondences", False)), ctx=ctx)
     if "GICP" in method:
-        # registrations.cpp:93-114: pcl::GeneralizedIterativeClosestPoint and pclomp::GICP (BFGS inner optimiser) have no HIP
-        # counterpart here; running something else in their name would be wrong
-        raise NotImplementedError(f'registration_method "{method}" is not offered by libmrgfe (available: NDT_OMP/NDT_HIP, FAST_GICP/GICP_HIP, '
-                                  f'SMALL_GICP/SMALL_GICP_HIP, FAST_VGICP/FAST_VGICP_CUDA/VGICP_HIP, ICP/ICP_HIP)')
+        # registrations.cpp:93-114: any other name with "GICP" in it is pcl::GeneralizedIterativeClosestPoint, with "OMP" in it as well pclomp's
+        return PclGicpHip(int(params.get("reg_correspondence_randomness", 20)), float(params.get("reg_max_correspondence_distance", 2.0)), eps, maximum_iterations=iters,
+                          max_optimizer_iterations=int(params.get("reg_max_optimizer_iterations", 20)),
+                          use_reciprocal_correspondences=bool(params.get("reg_use_reciprocal_correspondences", False)), omp="OMP" in method, ctx=ctx)
     search = str(params.get("reg_nn_search_method", "DIRECT7"))
     if search not in ("KDTREE", "DIRECT1"):
         search = "DIRECT7"  # registrations.cpp:140-146: anything else means DIRECT7

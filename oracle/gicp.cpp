@@ -406,12 +406,19 @@ void FastGicp::align_icp(const float guess[16])
     for (;;) {
         ++n_linearize;
         double cnt = 0, Ss[3] = {0, 0, 0}, Sd[3] = {0, 0, 0}, Sds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Smse = 0;
+        NnGrid cur_grid;  // determineReciprocalCorrespondences: a search structure over the source as transformed so far, rebuilt every iteration
+        if (use_reciprocal && n) cur_grid.build(cur.data(), n, 1.0f);
         for (int i = 0; i < n; ++i) {
             const float* p = &cur[4 * static_cast<size_t>(i)];
             float sqd;
             const int j = nt ? target_grid_.nearest(p[0], p[1], p[2], sqd) : -1;
             if (j < 0 || static_cast<double>(sqd) > max_sq) continue;
             const float* q = &target[4 * static_cast<size_t>(j)];
+            if (use_reciprocal) {
+                float     rsqd;
+                const int ri = cur_grid.nearest(q[0], q[1], q[2], rsqd);
+                if (ri < 0 || static_cast<double>(rsqd) > max_sq || ri != i) continue;
+            }
             cnt += 1;
             for (int a = 0; a < 3; ++a) { Ss[a] += p[a]; Sd[a] += q[a]; }
             for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Sds[r * 3 + c] += static_cast<double>(q[r]) * static_cast<double>(p[c]);

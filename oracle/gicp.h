@@ -23,10 +23,12 @@
 // every term carries the weight sqrt(points in the voxel); optimiser, Jacobian and convergence test are fast_gicp's.
 //
 // `variant = 3` restates pcl::IterativeClosestPoint<PointXYZI,PointXYZI> (PCL 1.12, registrations.cpp:85-92: setTransformationEpsilon,
-// setMaximumIterations, setMaxCorrespondenceDistance, reciprocal correspondences off): per iteration the cumulatively
+// setMaximumIterations, setMaxCorrespondenceDistance, setUseReciprocalCorrespondences): per iteration the cumulatively
 // transformed source is matched to its nearest target points within the distance limit, TransformationEstimationSVD
 // (Umeyama without scaling) gives the increment, DefaultConvergenceCriteria decides (iterations >= max; or rotation cosine >=
-// 1 - epsilon and squared translation <= epsilon; or |mse - previous mse| < 1e-12).  Documented deviations: Eigen's float
+// 1 - epsilon and squared translation <= epsilon; or |mse - previous mse| < 1e-12).  With reciprocal correspondences a pair (i, j) counts
+// only if the nearest point of target j among the TRANSFORMED source points is i again, within the distance limit
+// (CorrespondenceEstimation::determineReciprocalCorrespondences; ties at equal distance go to the lowest index here).  Documented deviations: Eigen's float
 // reductions have no fixed order, so the moment sums are f64 and the 3x3 SVD is a one-sided Jacobi in f64 before the result
 // is cast to the float matrices PCL works with.
 #pragma once
@@ -48,6 +50,7 @@ struct FastGicp {
     double lm_init_lambda_factor = 1e-9;
     int    variant = 0;                 // 0: fast_gicp::FastGICP, 1: small_gicp::RegistrationPCL (GICP), 2: fast_gicp::FastVGICP, 3: pcl::IterativeClosestPoint
     double voxel_resolution = 1.0;      // variant 2: setResolution(reg_resolution)
+    bool   use_reciprocal = false;      // variant 3: setUseReciprocalCorrespondences (registrations.cpp:91): CorrespondenceEstimation::determineReciprocalCorrespondences
     double sg_init_lambda = 1e-3, sg_lambda_factor = 10.0;  // small_gicp::LevenbergMarquardtOptimizer defaults
     int    sg_max_inner_iterations = 10;
 

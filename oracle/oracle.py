@@ -76,10 +76,25 @@ def lib():
             "orc_ndt_num_leaves": (C.c_int, [vp]),
             "orc_ndt_grid": (None, [vp, ip, ip, ip]),
             "orc_ndt_leaves": (None, [vp, ip, ip, dp, dp, dp]),
+            "orc_pclgicp_create": (vp, []),
+            "orc_pclgicp_destroy": (None, [vp]),
+            "orc_pclgicp_set_params": (None, [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]),
+            "orc_pclgicp_set_target": (None, [vp, fp, C.c_int]),
+            "orc_pclgicp_set_source": (None, [vp, fp, C.c_int]),
+            "orc_pclgicp_align": (None, [vp, fp, fp]),
+            "orc_pclgicp_converged": (C.c_int, [vp]),
+            "orc_pclgicp_iterations": (C.c_int, [vp]),
+            "orc_pclgicp_evaluations": (C.c_int, [vp]),
+            "orc_pclgicp_inner_steps": (C.c_int, [vp]),
+            "orc_pclgicp_final": (None, [vp, fp]),
+            "orc_pclgicp_fitness": (C.c_double, [vp, C.c_double]),
+            "orc_pclgicp_covariances": (None, [vp, C.c_int, dp]),
+            "orc_pclgicp_evaluate": (C.c_double, [vp, fp, dp, dp, C.POINTER(C.c_int)]),
             "orc_gicp_create": (vp, []),
             "orc_gicp_destroy": (None, [vp]),
             "orc_gicp_set_params": (None, [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]),
             "orc_gicp_set_variant": (None, [vp, C.c_int]),
+            "orc_gicp_set_reciprocal": (None, [vp, C.c_int]),
             "orc_gicp_set_resolution": (None, [vp, C.c_double]),
             "orc_gicp_num_voxels": (C.c_int, [vp]),
             "orc_gicp_set_target": (None, [vp, fp, C.c_int]),
@@ -451,5 +466,76 @@ class Icp(FastGicp):
 
     VARIANT = 3
 
-    def __init__(self, max_correspondence_distance=2.0, transformation_epsilon=0.01, maximum_iterations=64):
+    def __init__(self, max_correspondence_distance=2.0, transformation_epsilon=0.01, maximum_iterations=64, use_reciprocal_correspondences=False):
         super().__init__(20, max_correspondence_distance, transformation_epsilon, 2e-3, maximum_iterations, 1)
+        lib().orc_gicp_set_reciprocal(self._h, int(bool(use_reciprocal_correspondences)))
+
+
+class PclGicp:
+    """pcl::GeneralizedIterativeClosestPoint ("GICP") and pclomp::GeneralizedIterativeClosestPoint ("GICP_OMP", ``omp=True``: the older
+    whole-gradient-norm stopping rule of the inner BFGS) restated (oracle/pcl_gicp.h), registrations.cpp:93-114."""
+
+    def __init__(self, correspondence_randomness=20, max_correspondence_distance=2.0, transformation_epsilon=0.01, rotation_epsilon=2e-3, maximum_iterations=64,
+                 max_optimizer_iterations=20, omp=False, num_threads=1):
+        self._h = lib().orc_pclgicp_create()
+        lib().orc_pclgicp_set_params(self._h, correspondence_randomness, max_correspondence_distance, transformation_epsilon, rotation_epsilon, maximum_iterations,
+                                     max_optimizer_iterations, int(bool(omp)), num_threads)
+        self._n_src = self._n_tgt = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().orc_pclgicp_destroy(self._h)
+                self._h = None
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def setInputTarget(self, cloud):
+        c = _cloud(cloud)
+        self._n_tgt = len(c)
+        lib().orc_pclgicp_set_target(self._h, _pf(c), len(c))
+
+    def setInputSource(self, cloud):
+        c = _cloud(cloud)
+        self._n_src = len(c)
+        lib().orc_pclgicp_set_source(self._h, _pf(c), len(c))
+
+    def align(self, guess=None, want_aligned=False):
+        g = _colmajor(np.eye(4) if guess is None else guess)
+        out = np.empty((self._n_src, 4), dtype=np.float32) if want_aligned else None
+        lib().orc_pclgicp_align(self._h, _pf(g), _pf(out) if want_aligned else None)
+        return out
+
+    def hasConverged(self):
+        return bool(lib().orc_pclgicp_converged(self._h))
+
+    def getFinalTransformation(self):
+        T = np.empty((4, 4), dtype=np.float32)
+        lib().orc_pclgicp_final(self._h, _pf(T))
+        return T.T.copy()
+
+    def getFitnessScore(self, max_range=float("inf")):
+        return lib().orc_pclgicp_fitness(self._h, max_range)
+
+    def getFinalNumIteration(self):
+        return lib().orc_pclgicp_iterations(self._h)
+
+    @property
+    def evals(self):
+        return lib().orc_pclgicp_evaluations(self._h)
+
+    @property
+    def inner_steps(self):
+        return lib().orc_pclgicp_inner_steps(self._h)
+
+    def covariances(self, which="source"):
+        n = self._n_src if which == "source" else self._n_tgt
+        out = np.empty((n, 3, 3))
+        lib().orc_pclgicp_covariances(self._h, 0 if which == "source" else 1, _pd(out))
+        return out
+
+    def evaluate(self, T, x):
+        """Cost of estimateRigidTransformationBFGS at x for the correspondences found at transformation T (guess identity): (f, g[6], correspondences)."""
+        g, n = np.zeros(6), C.c_int(0)
+        f = lib().orc_pclgicp_evaluate(self._h, _pf(_colmajor(T)), _pd(np.ascontiguousarray(x, dtype=np.float64)), _pd(g), C.byref(n))
+        return f, g, n.value

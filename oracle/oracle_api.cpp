@@ -8,6 +8,7 @@
 
 #include "filters.h"
 #include "gicp.h"
+#include "pcl_gicp.h"
 #include "linalg.h"
 #include "mapcloud.h"
 #include "ndt.h"
@@ -170,6 +171,7 @@ void  orc_gicp_set_params(void* h, int k_correspondences, double max_corr_dist, 
     g->k_correspondences = k_correspondences; g->max_corr_dist = max_corr_dist; g->trans_eps = trans_eps; g->rot_eps = rot_eps;
     g->max_iterations = max_iterations; g->num_threads = num_threads > 0 ? num_threads : 1;
 }
+void orc_gicp_set_reciprocal(void* h, int on) { static_cast<FastGicp*>(h)->use_reciprocal = on != 0; }
 void orc_gicp_set_variant(void* h, int variant) { static_cast<FastGicp*>(h)->variant = variant; }  // 1: small_gicp formulation, 2: fast_gicp::FastVGICP
 void orc_gicp_set_resolution(void* h, double resolution) { static_cast<FastGicp*>(h)->voxel_resolution = resolution; }
 int  orc_gicp_num_voxels(void* h) { FastGicp* g = static_cast<FastGicp*>(h); double H[36], b[6], I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; g->linearize(I, H, b, nullptr); return g->num_voxels(); }
@@ -192,3 +194,36 @@ double orc_gicp_linearize(void* h, const double T_rowmajor[16], double H_rowmajo
 }
 
 }  // extern "C"
+
+// ---- pcl::GeneralizedIterativeClosestPoint / pclomp::GICP (pcl_gicp.h) --------------------------------------------------------------
+extern "C" {
+void* orc_pclgicp_create() { return new orc::PclGicp(); }
+void  orc_pclgicp_destroy(void* h) { delete static_cast<orc::PclGicp*>(h); }
+void  orc_pclgicp_set_params(void* h, int k, double max_corr_dist, double trans_eps, double rot_eps, int max_iterations, int max_inner_iterations, int whole_gradient_norm, int num_threads)
+{
+    orc::PclGicp* g = static_cast<orc::PclGicp*>(h);
+    g->k_correspondences = k; g->max_corr_dist = max_corr_dist; g->trans_eps = trans_eps; g->rot_eps = rot_eps; g->max_iterations = max_iterations;
+    g->max_inner_iterations = max_inner_iterations; g->whole_gradient_norm = whole_gradient_norm; g->num_threads = num_threads;
+}
+void orc_pclgicp_set_target(void* h, const float* xyzi, int n) { static_cast<orc::PclGicp*>(h)->set_target(xyzi, n); }
+void orc_pclgicp_set_source(void* h, const float* xyzi, int n) { static_cast<orc::PclGicp*>(h)->set_source(xyzi, n); }
+void orc_pclgicp_align(void* h, const float guess_colmajor[16], float* aligned_or_null)
+{
+    float g[16];
+    orc::colmajor_to_rowmajor4(guess_colmajor, g);
+    static_cast<orc::PclGicp*>(h)->align(g, aligned_or_null);
+}
+int    orc_pclgicp_converged(void* h) { return static_cast<orc::PclGicp*>(h)->converged ? 1 : 0; }
+int    orc_pclgicp_iterations(void* h) { return static_cast<orc::PclGicp*>(h)->nr_iterations; }
+int    orc_pclgicp_evaluations(void* h) { return static_cast<orc::PclGicp*>(h)->n_evaluations; }
+int    orc_pclgicp_inner_steps(void* h) { return static_cast<orc::PclGicp*>(h)->n_inner_steps; }
+void   orc_pclgicp_final(void* h, float out_colmajor[16]) { orc::rowmajor_to_colmajor4(static_cast<orc::PclGicp*>(h)->final_, out_colmajor); }
+double orc_pclgicp_fitness(void* h, double max_range) { return static_cast<orc::PclGicp*>(h)->fitness(max_range); }
+void   orc_pclgicp_covariances(void* h, int which, double* out9) { static_cast<orc::PclGicp*>(h)->get_covariances(which, out9); }
+double orc_pclgicp_evaluate(void* h, const float T_colmajor[16], const double x[6], double g[6], int* n_corr)
+{
+    float T[16];
+    orc::colmajor_to_rowmajor4(T_colmajor, T);
+    return static_cast<orc::PclGicp*>(h)->evaluate(T, x, g, n_corr);
+}
+}

@@ -66,5 +66,14 @@ constexpr double kGicpLmInitLambdaFactor = 1e-9;
 constexpr int    kGicpLmMaxIterations    = 10;
 constexpr double kGicpPlaneEps           = 1e-3;  // RegularizationMethod::PLANE singular values (1,1,1e-3)
 
+// ---- pcl::GeneralizedIterativeClosestPoint / pclomp::GeneralizedIterativeClosestPoint (pcl_gicp.cpp, bfgs.h) ----------------------------
+// Recalled upstream text like everything here: gicp_epsilon_ = 0.001, k_correspondences_ = 20, rotation_epsilon_ = 2e-3, max_inner_iterations_ = 20,
+// min_number_correspondences_ = 4; the BFGS parameters estimateRigidTransformationBFGS sets (sigma = rho = 0.01, tau1 = 9, tau2 = 0.05, tau3 = 0.5,
+// order = 3) and the class defaults it leaves (step_size = 0.01, bracket / section iteration caps of 100); the inner loop's stopping rule:
+// PCL >= 1.11 checks the translation and the rotation part of the gradient apart (each norm < 1e-2), PCL <= 1.10 and pclomp the whole norm < 1e-2.
+// The initial Euler angles mix float and double library calls: x[3] and x[5] through std::atan2 on floats, x[4] through the C asin on a double.
+constexpr double kPclGicpEpsilon         = 1e-3;
+constexpr double kPclGicpGradientTol     = 1e-2;
+
 }  // namespace quirks
 }  // namespace orc

@@ -235,6 +235,12 @@ def test_factory_mirror_dispatch():
     from mrg_slam_amd import IcpHip
 
     assert type(select_registration_method({"registration_method": "ICP"})) is IcpHip
-    for kw in ({"registration_method": "GICP"}, {"registration_method": "GICP_OMP"}, {"registration_method": "ICP", "reg_use_reciprocal_correspondences": True}):
-        with pytest.raises(NotImplementedError):
-            select_registration_method(kw)
+    assert select_registration_method({"registration_method": "ICP", "reg_use_reciprocal_correspondences": True})._params.use_reciprocal_correspondences == 1
+    # registrations.cpp:93-114: "GICP" is pcl::GeneralizedIterativeClosestPoint, a name with "GICP" and "OMP" in it pclomp's; nothing the reference
+    # accepts is refused
+    from mrg_slam_amd import PclGicpHip
+    from mrg_slam_amd._lib import PCL_GICP_HIP, PCL_GICP_OMP_HIP
+
+    for name, method in (("GICP", PCL_GICP_HIP), ("GICP_OMP", PCL_GICP_OMP_HIP), ("MY_GICP_VARIANT", PCL_GICP_HIP)):
+        r = select_registration_method({"registration_method": name, "reg_max_optimizer_iterations": 7})
+        assert type(r) is PclGicpHip and r._params.method == method and r._params.max_optimizer_iterations == 7

@@ -92,12 +92,12 @@ def test_radix_sort_properties_at_batch_scale():
     assert np.bincount(ov, minlength=n).max() == 1
 
 
-@pytest.mark.parametrize("method", ["GICP", "SMALL_GICP", "VGICP"])
+@pytest.mark.parametrize("method", ["GICP", "SMALL_GICP", "VGICP", "PCL_GICP", "ICP_RECIPROCAL"])
 def test_gicp_family_full_size_matches_oracle(vlp64, method):
     """BASELINE config[2] at its stated size: scan-to-keyframe GICP on ~130k-point clouds (k = 20 covariances over both clouds, 1-NN
     correspondences within 2 m).  The final transform must be the oracle's (bar 1e-4 m / 1e-4 rad; it is bit-identical on this
     pair), with the same convergence flag and iteration count."""
-    from mrg_slam_amd import GicpHip, SmallGicpHip, VgicpHip, distance_filter, synth
+    from mrg_slam_amd import GicpHip, IcpHip, PclGicpHip, SmallGicpHip, VgicpHip, distance_filter, synth
     from oracle import oracle as orc
 
     tgt, src, rel = vlp64
@@ -106,7 +106,10 @@ def test_gicp_family_full_size_matches_oracle(vlp64, method):
     guess = synth.warm_guess(rel, 1)
     g, o = {"GICP": (GicpHip(transformation_epsilon=0.01), orc.FastGicp(transformation_epsilon=0.01, num_threads=32)),
             "SMALL_GICP": (SmallGicpHip(transformation_epsilon=0.01), orc.SmallGicp(transformation_epsilon=0.01, num_threads=32)),
-            "VGICP": (VgicpHip(resolution=1.0, transformation_epsilon=0.01), orc.FastVgicp(resolution=1.0, transformation_epsilon=0.01, num_threads=32))}[method]
+            "VGICP": (VgicpHip(resolution=1.0, transformation_epsilon=0.01), orc.FastVgicp(resolution=1.0, transformation_epsilon=0.01, num_threads=32)),
+            "PCL_GICP": (PclGicpHip(transformation_epsilon=0.01), orc.PclGicp(transformation_epsilon=0.01, num_threads=32)),
+            "ICP_RECIPROCAL": (IcpHip(transformation_epsilon=0.01, use_reciprocal_correspondences=True),
+                               orc.Icp(transformation_epsilon=0.01, use_reciprocal_correspondences=True))}[method]
     g.setInputTarget(ft)
     o.setInputTarget(ft)
     g.setInputSource(fs)

@@ -304,6 +304,29 @@ def test_icp_align_matches_oracle(eps, guess_seed):
     assert g.getFitnessScore() == pytest.approx(o.getFitnessScore(), rel=1e-3, abs=1e-9)
 
 
+@pytest.mark.parametrize("guess_seed", [None, 7])
+def test_icp_with_reciprocal_correspondences_matches_oracle(guess_seed):
+    """setUseReciprocalCorrespondences(true) (registrations.cpp:91): a pair counts only if the target point's nearest (transformed) source
+    point is the query again — fewer correspondences, another trajectory; the same as the restated algorithm, and not the one-way result."""
+    from mrg_slam_amd import IcpHip, select_registration_method, synth
+    from oracle import oracle as orc
+
+    tgt, src, rel = _pair()
+    src = src[: len(src) * 2 // 3]  # different sizes: the reciprocal test prunes
+    guess = np.eye(4) if guess_seed is None else synth.perturb_pose(rel, np.random.default_rng(guess_seed))
+    g = select_registration_method({"registration_method": "ICP", "reg_use_reciprocal_correspondences": True, "reg_transformation_epsilon": 1e-4})
+    assert type(g) is IcpHip
+    o, plain = orc.Icp(transformation_epsilon=1e-4, use_reciprocal_correspondences=True), IcpHip(transformation_epsilon=1e-4)
+    for r in (g, o, plain):
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+        r.align(guess)
+    Tg, To = g.getFinalTransformation(), o.getFinalTransformation()
+    assert g.hasConverged() == o.hasConverged() and g.getFinalNumIteration() == o.getFinalNumIteration()
+    assert np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3]) <= 1e-4 and _rot_angle(Tg[:3, :3], To[:3, :3]) <= 1e-4
+    assert not np.array_equal(Tg, plain.getFinalTransformation())
+
+
 def test_icp_exact_copy_limits_and_degenerate_inputs():
     from mrg_slam_amd import IcpHip, synth
     from oracle import oracle as orc

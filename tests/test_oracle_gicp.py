@@ -136,3 +136,17 @@ def test_icp_restatement_properties():
     loose.setInputSource(src)
     loose.align(np.eye(4))
     assert loose.hasConverged() and loose.getFinalNumIteration() == 1
+    # reciprocal correspondences (determineReciprocalCorrespondences): on an exact rigid copy every pair is mutual once the clouds meet, so the
+    # motion is still recovered; on a target with extra points the mutual test prunes pairs and the trajectory differs from the one-way one
+    rec = orc.Icp(transformation_epsilon=1e-8, use_reciprocal_correspondences=True)
+    rec.setInputTarget(tgt)
+    rec.setInputSource(src)
+    rec.align(np.eye(4))
+    Tr = rec.getFinalTransformation().astype(np.float64)
+    assert rec.hasConverged() and np.linalg.norm(Tr[:3, 3] - rel[:3, 3]) < 1e-4 and synth.rotation_angle(Tr, rel) < 1e-4
+    a, b = orc.Icp(transformation_epsilon=1e-6), orc.Icp(transformation_epsilon=1e-6, use_reciprocal_correspondences=True)
+    for r in (a, b):
+        r.setInputTarget(tgt)
+        r.setInputSource(src[:1200])
+        r.align(np.eye(4), )
+    assert not np.array_equal(a.getFinalTransformation(), b.getFinalTransformation())
