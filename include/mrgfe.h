@@ -360,6 +360,10 @@ int  mrgfe_batch_pair_counts(const mrgfe_batch* b, int mode, double* points, dou
 int  mrgfe_batch_fitness_stats(const mrgfe_batch* b, double out[11]);
 
 /* ---- diagnostic entry points for the primitive tests (tests/test_gpu_primitives.py) --------------------------- */
+/* Grids over `count` host clouds (packed xyzw floats) built TOGETHER (csrc NnGridSet, the batched form of the search grid under
+ * getFitnessScore and the GICP covariances), then the `nq` queries answered against each: k == 1 the exact nearest neighbour, k > 1 the k
+ * nearest, as mrgfe_knn.  idx / sqd: [count][nq][k].  `rounds` > 1 rebuilds the set that often (later builds reuse the cell edges). */
+int mrgfe_dbg_grid_set_query(mrgfe_ctx* ctx, const float* const* clouds, const size_t* n, int count, const float* query, size_t nq, int k, int rounds, int32_t* idx, float* sqd);
 int mrgfe_dbg_sort_pairs(mrgfe_ctx* ctx, const uint32_t* keys, const uint32_t* vals, size_t n, int key_bits, uint32_t* out_keys, uint32_t* out_vals);
 /* The wave reduction of the derivative kernels' epilogue (csrc/dev_utils.h): in = cases x 64 lanes x n_vals doubles (n_vals 44, 37 or 1);
  * out_fold[cases][n_vals] from wave_sum_fold (n_vals values per lane folded in six steps), out_plain from n_vals separate wave_sum

@@ -104,6 +104,7 @@ struct mrgfe_batch {
     GicpBatch*          gicp_batch = nullptr;
     std::vector<GicpBatchPair> gicp_pairs;  // per-pair device buffers, kept between align calls
     std::vector<NnGrid> fit_grids;  // getFitnessScore grids, one per target; device buffers kept between align calls
+    std::vector<std::unique_ptr<NnGridSet>> fit_sets;  // ... which are views into these when the grids were built a chunk of targets at a time
     std::vector<mrgfe_ctx*> fit_ctxs;       // helper contexts (own stream and workspaces each): the grids are built on them by extra host
                                             // thread while the alignment rounds run on the batch's context
     // keyframe store (mrgfe_batch_add_pair_keyed): packed clouds and GICP covariances by caller-chosen key, resident across clears
@@ -393,6 +394,48 @@ int mrgfe_knn(mrgfe_ctx* ctx, const float* cloud, size_t n, const float* query, 
     }
     grid.release();
     dc.release(); dq.release(); di.release(); dd.release();
+    return rc;
+}
+
+int mrgfe_dbg_grid_set_query(mrgfe_ctx* ctx, const float* const* clouds, const size_t* n, int count, const float* query, size_t nq, int k, int rounds, int32_t* idx, float* sqd)
+{
+    if (!ctx || count < 1 || !clouds || !n || !query || !idx || !sqd || nq == 0) { set_error("mrgfe_dbg_grid_set_query: bad argument"); return MRGFE_ERR_INVALID; }
+    if (k < 1 || k > 64) { set_error("mrgfe_dbg_grid_set_query: k must be in [1, 64]"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);
+    MRGFE_TRY(ctx->bind());
+    std::vector<DevBuf>        dc(count);
+    std::vector<NnGrid>        grids(count);
+    std::vector<NnGrid*>       gp(count);
+    std::vector<const float4*> cp(count);
+    std::vector<uint32_t>      nn(count);
+    DevBuf     dq, di, dd;
+    NnGridSet  set;
+    int rc = dq.ensure(nq * 16);
+    if (rc == MRGFE_OK) rc = di.ensure(nq * k * 4);
+    if (rc == MRGFE_OK) rc = dd.ensure(nq * k * 4);
+    if (rc == MRGFE_OK) rc = upload_cloud(ctx, query, nq, 16, dq.p);
+    for (int m = 0; m < count && rc == MRGFE_OK; ++m) {
+        rc = dc[m].ensure(std::max<size_t>(n[m], 1) * 16);
+        if (rc == MRGFE_OK && n[m]) rc = upload_cloud(ctx, clouds[m], n[m], 16, dc[m].p);
+        cp[m] = dc[m].as<float4>();
+        nn[m] = static_cast<uint32_t>(n[m]);
+        gp[m] = &grids[m];
+    }
+    // (built `rounds` times: the second and later builds start from the first one's cell edges)
+    for (int r = 0; r < std::max(1, rounds) && rc == MRGFE_OK; ++r)
+        rc = k == 1 ? set.build(ctx, cp.data(), nn.data(), count, 1.0f, NnGrid::kCrowding1nn, 1, gp.data()) : set.build(ctx, cp.data(), nn.data(), count, 1.0f, NnGrid::kCrowdingKnn, kNnMaxLevels, gp.data());
+    for (int m = 0; m < count && rc == MRGFE_OK; ++m) {
+        rc = k == 1 ? grids[m].nearest_device(ctx, dq.as<float4>(), nq, nullptr, di.as<int32_t>(), dd.as<float>()) : grids[m].knn_device(ctx, dq.as<float4>(), nq, k, di.as<int32_t>(), dd.as<float>());
+        if (rc == MRGFE_OK && (hipMemcpyAsync(idx + size_t(m) * nq * k, di.p, nq * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                               hipMemcpyAsync(sqd + size_t(m) * nq * k, dd.p, nq * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+            set_error("mrgfe_dbg_grid_set_query: device to host copy failed");
+            rc = MRGFE_ERR_HIP;
+        }
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == MRGFE_OK) rc = MRGFE_ERR_HIP;
+    set.release();
+    for (auto& b : dc) b.release();
+    dq.release(); di.release(); dd.release();
     return rc;
 }
 
@@ -875,6 +918,7 @@ void mrgfe_batch_destroy(mrgfe_batch* b)
         MRGFE_LOCK(b->ctx);
         (void)b->ctx->bind();
         for (auto& g : b->fit_grids) g.release();
+        for (auto& gs : b->fit_sets) gs->release();
         for (mrgfe_ctx* fc : b->fit_ctxs) mrgfe_ctx_destroy(fc);
         if (b->uploads_done) (void)hipEventDestroy(b->uploads_done);
         if (b->port) b->port->buf.release();
@@ -1116,9 +1160,13 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
                 fit_built[p.target] = 1;
                 todo.push_back(p.target);
             }
-            size_t n_builders = 4;
+            // ... and each thread builds its targets a chunk at a time, every step of the build one launch over the chunk (NnGridSet)
+            size_t n_builders = 2, chunk = 16;
             if (const char* env = std::getenv("MRGFE_FIT_BUILDERS")) n_builders = static_cast<size_t>(std::max(1, std::atoi(env)));
-            n_builders = std::min(n_builders, todo.size());
+            if (const char* env = std::getenv("MRGFE_FIT_CHUNK")) chunk = static_cast<size_t>(std::max(1, std::atoi(env)));
+            const size_t n_chunks = (todo.size() + chunk - 1) / chunk;
+            n_builders = std::min(n_builders, n_chunks);
+            while (b->fit_sets.size() < n_chunks) b->fit_sets.emplace_back(new NnGridSet());
             while (b->fit_ctxs.size() < n_builders + 1) {  // the last one belongs to the early fitness passes below
                 mrgfe_ctx* fc = nullptr;
                 if (mrgfe_ctx_create(b->ctx->device, &fc) != MRGFE_OK) return MRGFE_ERR_HIP;
@@ -1130,17 +1178,26 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
             if (!b->uploads_done) MRGFE_HIP_CHECK(hipEventCreateWithFlags(&b->uploads_done, hipEventDisableTiming));
             MRGFE_HIP_CHECK(hipEventRecord(b->uploads_done, b->ctx->stream));
             for (size_t w = 0; w < n_builders; ++w)
-                builders.emplace_back([b, &e, &todo, w, n_builders, &fail, &grid_ready] {
+                builders.emplace_back([b, &e, &todo, w, n_builders, n_chunks, chunk, &fail, &grid_ready] {
                     mrgfe_ctx* fc = b->fit_ctxs[w];
                     std::lock_guard<std::recursive_mutex> lock(fc->mu);
                     if (fc->bind() != MRGFE_OK) { fail(MRGFE_ERR_HIP, mrgfe_last_error()); return; }
                     if (hipStreamWaitEvent(fc->stream, b->uploads_done, 0) != hipSuccess) { fail(MRGFE_ERR_HIP, "helper stream could not wait for the uploads"); return; }
-                    for (size_t k = w; k < todo.size(); k += n_builders) {
-                        const int t = todo[k];
-                        const NdtTargetInfo& T = e.target(t);
-                        const int st = b->fit_grids[t].build(fc, T.d_pts, T.n, 1.0f, NnGrid::kCrowding1nn, 1);  // returns with the grid complete (synchronised)
+                    std::vector<const float4*> clouds;
+                    std::vector<uint32_t>      sizes;
+                    std::vector<NnGrid*>       views;
+                    for (size_t c = w; c < n_chunks; c += n_builders) {
+                        const size_t k0 = c * chunk, k1 = std::min(todo.size(), k0 + chunk);
+                        clouds.clear(); sizes.clear(); views.clear();
+                        for (size_t k = k0; k < k1; ++k) {
+                            const NdtTargetInfo& T = e.target(todo[k]);
+                            clouds.push_back(T.d_pts);
+                            sizes.push_back(static_cast<uint32_t>(T.n));
+                            views.push_back(&b->fit_grids[todo[k]]);
+                        }
+                        const int st = b->fit_sets[c]->build(fc, clouds.data(), sizes.data(), static_cast<int>(k1 - k0), 1.0f, NnGrid::kCrowding1nn, 1, views.data());  // returns with the grids complete (synchronised)
                         if (st != MRGFE_OK) { fail(st, mrgfe_last_error()); return; }
-                        grid_ready[t].store(1, std::memory_order_release);
+                        for (size_t k = k0; k < k1; ++k) grid_ready[todo[k]].store(1, std::memory_order_release);
                     }
                     if (hipStreamSynchronize(fc->stream) != hipSuccess) fail(MRGFE_ERR_HIP, "helper stream synchronisation failed");
                 });
@@ -1157,9 +1214,11 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
         port.finished.store(0);
         std::vector<char> early_done(P, 0);
         std::thread early;
-        // (measured on config[3]: 256 pairs 30.8 -> 29.7 ms per step, 128 pairs no change, 64 and 32 pairs slower — small waves pay the fixed
-        // costs of a fitness launch several times and take the chip from rounds that are not idle yet: on for large batches only)
-        int early_min_pairs = 128;
+        // (measured on config[3] while the grids were built one by one and outlasted the rounds: 256 pairs 30.8 -> 29.7 ms per step, 128 pairs
+        // no change, 64 and 32 pairs slower.  With the grids built a chunk at a time (NnGridSet) they are complete a few ms into the rounds,
+        // a step is the sum of its kernel times, and the waves only add their fixed costs: 27.8 ms without them, 28.7 ms with.  Off unless
+        // MRGFE_EARLY_FIT_MIN_PAIRS asks for them.)
+        int early_min_pairs = 1 << 30;
         if (const char* env = std::getenv("MRGFE_EARLY_FIT_MIN_PAIRS")) early_min_pairs = std::max(8, std::atoi(env));
         const bool early_on = overlap && P >= early_min_pairs && std::getenv("MRGFE_NO_EARLY_FIT") == nullptr;
         b->fit_total = FitStats();

@@ -749,11 +749,20 @@ int GicpEngine::set_source(const void* d, size_t n)
 }
 
 // k-NN covariances of one cloud on ctx's stream, through the caller's grid and neighbour buffers
+int gicp_covariances_on_grid(mrgfe_ctx* ctx, int k, const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid, DevBuf& knn_i, DevBuf& knn_d, bool pcl_moments);
 int gicp_compute_covariances(mrgfe_ctx* ctx, int k, const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid, DevBuf& knn_i, DevBuf& knn_d, bool pcl_moments)
 {
     MRGFE_TRY(out.ensure(std::max<size_t>(n, 1) * 48));
     if (n == 0) return MRGFE_OK;
     MRGFE_TRY(grid.build(ctx, d_pts, n, 1.0f, NnGrid::kCrowdingKnn));
+    return gicp_covariances_on_grid(ctx, k, d_pts, n, out, grid, knn_i, knn_d, pcl_moments);
+}
+
+// the k-NN search and the covariance kernel on a grid that is already built over d_pts
+int gicp_covariances_on_grid(mrgfe_ctx* ctx, int k, const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid, DevBuf& knn_i, DevBuf& knn_d, bool pcl_moments)
+{
+    MRGFE_TRY(out.ensure(std::max<size_t>(n, 1) * 48));
+    if (n == 0) return MRGFE_OK;
     MRGFE_TRY(knn_i.ensure(n * k * 4));
     MRGFE_TRY(knn_d.ensure(n * k * 4));
     MRGFE_TRY(grid.knn_device(ctx, d_pts, n, k, knn_i.as<int32_t>(), knn_d.as<float>()));
@@ -1496,7 +1505,7 @@ GicpBatch::~GicpBatch()
 {
     if (ctx_) (void)hipSetDevice(ctx_->device);
     for (Lane* l : lanes_) {
-        l->grid.release(); l->knn_i.release(); l->knn_d.release();
+        l->set.release(); l->views.clear(); l->knn_i.release(); l->knn_d.release();
         mrgfe_ctx_destroy(l->ctx);
         delete l;
     }
@@ -1555,18 +1564,37 @@ int GicpBatch::align_all(std::vector<GicpEngine*>& engines, std::vector<GicpBatc
             }
             todo.push_back(i);
         }
+        // ... a chunk of clouds at a time: their k-NN grids are built together (NnGridSet: one launch per build step for the chunk, three
+        // host waits per chunk instead of per cloud), then each cloud's k-NN search and covariance kernel follow on the lane's stream
+        size_t chunk = 8;
+        if (const char* e = std::getenv("MRGFE_GICP_CHUNK")) chunk = static_cast<size_t>(std::max(1, std::atoi(e)));
+        const size_t n_chunks = (todo.size() + chunk - 1) / chunk;
         std::atomic<size_t> next{0};
         auto work = [&](int li) {
             Lane& l = *lanes_[li];
             if (l.ctx->bind() != MRGFE_OK) { status[li] = MRGFE_ERR_HIP; return; }
+            std::vector<const float4*> clouds;
+            std::vector<uint32_t>      sizes;
+            std::vector<NnGrid*>       views;
+            if (l.views.size() < chunk) l.views.resize(chunk);
             for (;;) {
-                const size_t w = next.fetch_add(1);
-                if (w >= todo.size()) break;
-                GicpBatchPair& p = pairs[todo[w]];
-                const int k = engines[p.target]->params().k_correspondences;
-                const int rc = gicp_compute_covariances(l.ctx, k, p.d_src, p.n, p.ext_cov ? *p.ext_cov : p.cov, l.grid, l.knn_i, l.knn_d, false);
+                const size_t c = next.fetch_add(1);
+                if (c >= n_chunks) break;
+                const size_t w0 = c * chunk, w1 = std::min(todo.size(), w0 + chunk);
+                clouds.clear(); sizes.clear(); views.clear();
+                for (size_t w = w0; w < w1; ++w) {
+                    clouds.push_back(pairs[todo[w]].d_src);
+                    sizes.push_back(pairs[todo[w]].n);
+                    views.push_back(&l.views[w - w0]);
+                }
+                int rc = l.set.build(l.ctx, clouds.data(), sizes.data(), static_cast<int>(w1 - w0), 1.0f, NnGrid::kCrowdingKnn, kNnMaxLevels, views.data());
+                for (size_t w = w0; w < w1 && rc == MRGFE_OK; ++w) {
+                    GicpBatchPair& p = pairs[todo[w]];
+                    const int k = engines[p.target]->params().k_correspondences;
+                    rc = gicp_covariances_on_grid(l.ctx, k, p.d_src, p.n, p.ext_cov ? *p.ext_cov : p.cov, l.views[w - w0], l.knn_i, l.knn_d, false);
+                    if (rc == MRGFE_OK && p.ext_cov) *p.ext_cov_k = k;
+                }
                 if (rc != MRGFE_OK) { status[li] = rc; message[li] = mrgfe_last_error(); break; }
-                if (p.ext_cov) *p.ext_cov_k = k;
             }
             if (hipStreamSynchronize(l.ctx->stream) != hipSuccess && status[li] == MRGFE_OK) status[li] = MRGFE_ERR_HIP;
         };

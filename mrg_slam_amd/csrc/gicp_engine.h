@@ -171,7 +171,7 @@ class GicpBatch {
    private:
     mrgfe_ctx* ctx_;
     // helper streams + workspaces for the source covariances (created on first use, kept)
-    struct Lane { mrgfe_ctx* ctx = nullptr; NnGrid grid; DevBuf knn_i, knn_d; };
+    struct Lane { mrgfe_ctx* ctx = nullptr; NnGridSet set; std::vector<NnGrid> views; DevBuf knn_i, knn_d; };
     std::vector<Lane*> lanes_;
     DevBuf d_pairs_, d_evals_, d_grids_, d_partials_;
     PinBuf h_evals_, h_results_;

@@ -8,6 +8,8 @@
 // Points are sorted by cell (stable radix sort, so ascending index inside a cell); cell rows along x are contiguous,
 // so a query walks a few contiguous ranges per ring.  Ties at equal distance resolve to the lowest index.
 #pragma once
+#include <vector>
+
 #include "cellsort.h"
 #include "common.h"
 
@@ -76,14 +78,36 @@ class NnGrid {
     int radius_count_flags(mrgfe_ctx* ctx, const float4* d_q, size_t n, double r2, int need, uint32_t* d_flags);
     // k nearest neighbours (ascending by (sqdist, index)) of every query: d_idx / d_sqd are [n][k]; missing -> -1
     int knn_device(mrgfe_ctx* ctx, const float4* d_q, size_t n, int k, int32_t* d_idx, float* d_sqd);
+    // become a view of a grid whose device arrays another object owns (NnGridSet); release() then only forgets it
+    void adopt(const NnGrid2Dev& h, size_t n) { release(); h_ = h; n_ = n; built_ = true; }
 
    private:
     bool      built_ = false;
     size_t    n_ = 0;
+    float     hint_cell_ = 0, hint_cell_size_ = 0;  // the finest edge the adaptive passes chose last time, for which (cell_size, crowding target)
+    double    hint_target_ = 0;
     NnGrid2Dev h_;
     DevBuf     d_cell_start_[kNnMaxLevels], d_sorted_[kNnMaxLevels];
     int build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, float cell, const SliceTable& tab, NnGridDev& lv, DevBuf& d_cells, DevBuf& d_sorted,
                     bool counts_only, double* crowding);
+};
+
+// Grids over several clouds built TOGETHER: every step of the build (bounding boxes, binning, the radix sort, the scan of the cell
+// counts, the occupancy pyramid, the gather) is one launch over all members instead of one per cloud, and the host waits three times
+// per set instead of three times per cloud.  One grid over a 130k-point scan is ~20 launches of 5-10 us each and was bound by their
+// issue, not by their work: 64 of them (the targets of a loop-closure batch) took 17 ms of wall time on four streams.
+// The members' device arrays live packed in the set's buffers; `out[m]` become views (NnGrid::adopt) that stay valid until the set is
+// built again or released.  Search results do not depend on how a grid was built.
+class NnGridSet {
+   public:
+    int  build(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32_t* n, int count, float cell_size, double crowding_target, int max_levels, NnGrid* const* out);
+    void release();
+
+   private:
+    DevBuf d_cells_[kNnMaxLevels], d_sorted_[kNnMaxLevels];
+    std::vector<float> hint_cell_;  // per member: the edge the adaptive passes settled on last time
+    float  hint_cell_size_ = 0;
+    double hint_target_ = 0;
 };
 
 // the context's reusable grid (created on first use; buffers grow only) and its disposal in mrgfe_ctx_destroy

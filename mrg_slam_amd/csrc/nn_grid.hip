@@ -19,8 +19,8 @@ namespace mrgfe {
 
 // ---- build ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kCrowdSlots = 32;
-__global__ __launch_bounds__(256) void nn_cellkey_kernel(const float4* __restrict__ pts, uint32_t n, NnGridDev g, uint32_t n_cells, uint32_t* __restrict__ keys,
-                                                          uint32_t* __restrict__ vals, uint32_t* __restrict__ counts, unsigned long long* __restrict__ crowd)
+__device__ __forceinline__ void nn_cellkey_body(const float4* __restrict__ pts, uint32_t n, const NnGridDev& g, uint32_t n_cells, uint32_t* __restrict__ keys,
+                                                uint32_t* __restrict__ vals, uint32_t* __restrict__ counts, unsigned long long* __restrict__ crowd)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     uint32_t       key = n_cells;  // non-finite points: behind every cell
@@ -66,8 +66,14 @@ __global__ __launch_bounds__(256) void nn_cellkey_kernel(const float4* __restric
     }
 }
 
+__global__ __launch_bounds__(256) void nn_cellkey_kernel(const float4* __restrict__ pts, uint32_t n, NnGridDev g, uint32_t n_cells, uint32_t* __restrict__ keys,
+                                                          uint32_t* __restrict__ vals, uint32_t* __restrict__ counts, unsigned long long* __restrict__ crowd)
+{
+    nn_cellkey_body(pts, n, g, n_cells, keys, vals, counts, crowd);
+}
+
 // occupancy words of the bricks (after cell_start is final): one thread per cell, an atomic only for occupied cells
-__global__ __launch_bounds__(256) void nn_occupancy_kernel(NnGridDev g, uint32_t n_cells, unsigned long long* __restrict__ occ)
+__device__ __forceinline__ void nn_occupancy_body(const NnGridDev& g, uint32_t n_cells, unsigned long long* __restrict__ occ)
 {
     const uint32_t at = blockIdx.x * 256u + threadIdx.x;
     if (at >= n_cells || g.cell_start[at + 1] == g.cell_start[at]) return;
@@ -75,14 +81,19 @@ __global__ __launch_bounds__(256) void nn_occupancy_kernel(NnGridDev g, uint32_t
     const uint32_t brick = ((z >> 2) * g.bdim[1] + (y >> 2)) * g.bdim[0] + (x >> 2);
     atomicOr(&occ[brick], 1ull << ((x & 3u) | ((y & 3u) << 2) | ((z & 3u) << 4)));
 }
+__global__ __launch_bounds__(256) void nn_occupancy_kernel(NnGridDev g, uint32_t n_cells, unsigned long long* __restrict__ occ) { nn_occupancy_body(g, n_cells, occ); }
 
 // next pyramid level: bit of a child node set iff its word is non-zero (dims = child grid, pdim = parent grid)
-__global__ __launch_bounds__(256) void nn_occupancy_up_kernel(const unsigned long long* __restrict__ child, int dx, int dy, int dz, int px, int py, unsigned long long* __restrict__ parent)
+__device__ __forceinline__ void nn_occupancy_up_body(const unsigned long long* __restrict__ child, int dx, int dy, int dz, int px, int py, unsigned long long* __restrict__ parent)
 {
     const uint32_t at = blockIdx.x * 256u + threadIdx.x;
     if (at >= static_cast<uint32_t>(dx) * dy * dz || child[at] == 0ull) return;
     const uint32_t x = at % dx, y = (at / dx) % dy, z = at / (static_cast<uint32_t>(dx) * dy);
     atomicOr(&parent[((z >> 2) * py + (y >> 2)) * px + (x >> 2)], 1ull << ((x & 3u) | ((y & 3u) << 2) | ((z & 3u) << 4)));
+}
+__global__ __launch_bounds__(256) void nn_occupancy_up_kernel(const unsigned long long* __restrict__ child, int dx, int dy, int dz, int px, int py, unsigned long long* __restrict__ parent)
+{
+    nn_occupancy_up_body(child, dx, dy, dz, px, py, parent);
 }
 
 __global__ __launch_bounds__(256) void nn_gather_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ sorted_vals, uint32_t n_valid, float4* __restrict__ sorted)
@@ -93,6 +104,50 @@ __global__ __launch_bounds__(256) void nn_gather_kernel(const float4* __restrict
     float4 p = pts[v];
     p.w = __int_as_float(static_cast<int>(v));
     sorted[i] = p;
+}
+
+// ---- the same steps for the members of an NnGridSet: blockIdx.y = member --------------------------------------
+struct NnBuildDev {
+    NnGridDev           lv;       // geometry and device arrays of the level being built
+    const float4*       pts;
+    uint32_t*           counts;   // == lv.cell_start, writable
+    unsigned long long* crowd;    // kCrowdSlots counters, or null
+    unsigned long long* occ[3];   // == lv.occ, occ1, occ2, writable
+    float4*             sorted;   // == lv.sorted, writable
+    uint32_t            n;        // points of the cloud
+    uint32_t            off;      // first element of the member in the packed key / value arrays
+    uint32_t            n_cells;
+    uint32_t            active;   // 0: the launch skips this member
+    int32_t             pd[3][3]; // node grids of the pyramid: bricks, super-bricks, blocks
+};
+
+__global__ __launch_bounds__(256) void nn_cellkey_many_kernel(const NnBuildDev* __restrict__ d, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const NnBuildDev& b = d[blockIdx.y];
+    if (!b.active || blockIdx.x * 256u >= b.n) return;  // uniform per workgroup
+    nn_cellkey_body(b.pts, b.n, b.lv, b.n_cells, keys + b.off, vals + b.off, b.counts, b.crowd);
+}
+__global__ __launch_bounds__(256) void nn_occupancy_many_kernel(const NnBuildDev* __restrict__ d)
+{
+    const NnBuildDev& b = d[blockIdx.y];
+    if (!b.active || blockIdx.x * 256u >= b.n_cells) return;
+    nn_occupancy_body(b.lv, b.n_cells, b.occ[0]);
+}
+__global__ __launch_bounds__(256) void nn_occupancy_up_many_kernel(const NnBuildDev* __restrict__ d, int from)
+{
+    const NnBuildDev& b = d[blockIdx.y];
+    if (!b.active) return;
+    nn_occupancy_up_body(b.occ[from], b.pd[from][0], b.pd[from][1], b.pd[from][2], b.pd[from + 1][0], b.pd[from + 1][1], b.occ[from + 1]);
+}
+__global__ __launch_bounds__(256) void nn_gather_many_kernel(const NnBuildDev* __restrict__ d, const uint32_t* __restrict__ sorted_vals)
+{
+    const NnBuildDev& b = d[blockIdx.y];
+    const uint32_t    i = blockIdx.x * 256u + threadIdx.x;
+    if (!b.active || i >= b.lv.n) return;
+    const uint32_t v = sorted_vals[b.off + i];
+    float4 p = b.pts[v];
+    p.w = __int_as_float(static_cast<int>(v));
+    b.sorted[i] = p;
 }
 
 // bins, sorts and gathers one level; `counts_only` stops after the binning kernel (adaptive cell search)
@@ -130,13 +185,17 @@ int NnGrid::build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const 
     hipLaunchKernelGGL(nn_cellkey_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, d_pts, nn, lv, n_cells, dk.as<uint32_t>(), dv.as<uint32_t>(), d_cells.as<uint32_t>(),
                        crowding ? d_crowd : nullptr);
     MRGFE_HIP_CHECK(hipGetLastError());
-    if (crowding) {
-        unsigned long long slots[kCrowdSlots], crowd = 0;
-        MRGFE_HIP_CHECK(hipMemcpyAsync(slots, d_crowd, sizeof(slots), hipMemcpyDeviceToHost, st));
-        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    unsigned long long slots[kCrowdSlots];
+    auto crowding_from_slots = [&]() {
+        unsigned long long crowd = 0;
         for (unsigned long long v : slots) crowd += v;
         // population of the cell an average POINT sits in (queries are distributed like the points, not like the cells)
         *crowding = 1.0 + 2.0 * double(crowd) / double(bb.n_finite);
+    };
+    if (crowding && counts_only) {
+        MRGFE_HIP_CHECK(hipMemcpyAsync(slots, d_crowd, sizeof(slots), hipMemcpyDeviceToHost, st));
+        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+        crowding_from_slots();
     }
     if (counts_only) return MRGFE_OK;
     int key_bits = 1;
@@ -161,7 +220,10 @@ int NnGrid::build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const 
     lv.sorted = d_sorted.as<float4>();
     hipLaunchKernelGGL(nn_gather_kernel, dim3((lv.n + 255) / 256), dim3(256), 0, st, d_pts, sv, lv.n, d_sorted.as<float4>());
     MRGFE_HIP_CHECK(hipGetLastError());
+    // a full build that also measures: the counters (behind the count table, untouched by the scan) ride on the build's own synchronisation
+    if (crowding) MRGFE_HIP_CHECK(hipMemcpyAsync(slots, d_crowd, sizeof(slots), hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));  // ctab's host table was the source of an async copy
+    if (crowding) crowding_from_slots();
     return MRGFE_OK;
 }
 
@@ -214,6 +276,22 @@ int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size
     };
     float cell = cell_size;
     while (cells_at(cell) > double(1u << 24)) cell *= 2.0f;
+    // The edge the adaptive passes below chose for the previous cloud of this grid object (a registration's source cloud frame after frame, the
+    // k-th target of a batch call after call: clouds of one sensor) is tried first, as a FULL build that measures its own crowding: when the
+    // figure is still in range the build is done — no counting pass, no extra host round trip (each is a launch, a read-back and a wait: a third
+    // of a 130k-point build).  The search results do not depend on the edge, only the time does.
+    if (crowding_target > 0 && hint_cell_ > 0 && hint_target_ == crowding_target && hint_cell_size_ == cell_size && hint_cell_ <= cell && cells_at(hint_cell_) <= double(1u << 24)) {
+        double crowding = 0;
+        MRGFE_TRY(build_level(ctx, d_pts, nn, bb, hint_cell_, tab, h_.level[0], d_cell_start_[0], d_sorted_[0], false, &crowding));
+        const bool too_crowded = crowding > 1.5 * crowding_target && cells_at(hint_cell_ * 0.5f) <= double(1u << 24) && hint_cell_ * 16.0f > cell_size * 0.999f;
+        const bool too_fine = crowding * 6.0 < crowding_target && hint_cell_ < cell;
+        if (!too_crowded) {
+            if (too_fine) hint_cell_ = 0;  // this build stands; the next one adapts from the top again
+            cell = h_.level[0].cell;
+            goto coarser_levels;
+        }
+        hint_cell_ = 0;
+    }
     if (crowding_target > 0) {
         // halve the edge while the cell an average point sits in is more crowded than the target (at most four times).
         // LiDAR returns lie on surfaces, so the crowding falls about 4x per halving: jump by the predicted number of
@@ -231,6 +309,8 @@ int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size
         }
     }
     MRGFE_TRY(build_level(ctx, d_pts, nn, bb, cell, tab, h_.level[0], d_cell_start_[0], d_sorted_[0], false, nullptr));
+    if (crowding_target > 0) { hint_cell_ = cell; hint_target_ = crowding_target; hint_cell_size_ = cell_size; }
+coarser_levels:
     // coarser levels for queries whose neighbourhood is empty at the finer scale: kLevelRatio x the edge each, same origin,
     // as long as the level above still has more than a handful of cells per axis
     float ratio = kLevelRatio;
@@ -263,6 +343,246 @@ void NnGrid::release()
     for (auto& b : d_cell_start_) b.release();
     for (auto& b : d_sorted_) b.release();
     built_ = false;
+}
+
+// ---- NnGridSet ---------------------------------------------------------------------------------------------------
+void NnGridSet::release()
+{
+    for (auto& b : d_cells_) b.release();
+    for (auto& b : d_sorted_) b.release();
+    hint_cell_.clear();
+}
+
+int NnGridSet::build(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32_t* n, int count, float cell_size, double crowding_target, int max_levels, NnGrid* const* out)
+{
+    if (count <= 0) return MRGFE_OK;
+    if (const char* e = std::getenv("MRGFE_NN_CELL")) { cell_size = static_cast<float>(std::atof(e)); crowding_target = 0; }  // tuning hook (as NnGrid::build)
+    hipStream_t st = ctx->stream;
+    const size_t M = static_cast<size_t>(count);
+    uint64_t total = 0;
+    for (size_t m = 0; m < M; ++m) total += (uint64_t(n[m]) + 3u) & ~uint64_t(3);
+    if (total > 0x7fffffffu) { set_error("NnGridSet: %llu points in one set", static_cast<unsigned long long>(total)); return MRGFE_ERR_INVALID; }
+    SliceTable tab;
+    tab.build(n, count);
+    // descriptors: [point slices][cell slices][cloud pointers][NnBuildDev]
+    DevBuf& ds = ctx->scratch[0];
+    const size_t at_cs = sizeof(Slice) * M, at_ptr = 2 * sizeof(Slice) * M, at_dev = (at_ptr + sizeof(void*) * M + 15) & ~size_t(15);
+    MRGFE_TRY(ds.ensure(at_dev + sizeof(NnBuildDev) * M));
+    const Slice*      d_slices = ds.as<Slice>();
+    const Slice*      d_cslices = reinterpret_cast<const Slice*>(ds.as<char>() + at_cs);
+    const NnBuildDev* d_dev = reinterpret_cast<const NnBuildDev*>(ds.as<char>() + at_dev);
+    MRGFE_HIP_CHECK(hipMemcpyAsync(ds.p, tab.h.data(), sizeof(Slice) * M, hipMemcpyHostToDevice, st));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(ds.as<char>() + at_ptr, d_clouds, sizeof(void*) * M, hipMemcpyHostToDevice, st));
+    DevBuf& dbb = ctx->scratch[1];
+    MRGFE_TRY(dbb.ensure(sizeof(BBox) * (tab.total_blks + M)));
+    BBox* d_part = dbb.as<BBox>();
+    BBox* d_out = d_part + tab.total_blks;
+    MRGFE_TRY(bounding_boxes(ctx, reinterpret_cast<const float4* const*>(ds.as<char>() + at_ptr), d_slices, tab, d_part, d_out));
+    std::vector<BBox> bb(M);
+    MRGFE_HIP_CHECK(hipMemcpyAsync(bb.data(), d_out, sizeof(BBox) * M, hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    DevBuf &dk = ctx->scratch[2], &dv = ctx->scratch[3], &dkt = ctx->scratch[4], &dvt = ctx->scratch[5], &dh = ctx->scratch[6], &dblk = ctx->scratch[8];
+    const size_t ne = std::max<size_t>(tab.total_elems, 4);
+    MRGFE_TRY(dk.ensure(ne * 4)); MRGFE_TRY(dv.ensure(ne * 4)); MRGFE_TRY(dkt.ensure(ne * 4)); MRGFE_TRY(dvt.ensure(ne * 4));
+    MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + M)));
+
+    auto cells_at = [&](size_t m, float c) {
+        double prod = 1;
+        for (int a = 0; a < 3; ++a) prod *= std::floor((bb[m].mx[a] - bb[m].mn[a]) / c) + 1;
+        return prod;
+    };
+    std::vector<NnGrid2Dev> h(M);
+    for (auto& g : h) {
+        std::memset(&g, 0, sizeof(g));
+        g.n_levels = 1;
+        for (auto& lv : g.level) { lv.cell = cell_size; lv.dim[0] = lv.dim[1] = lv.dim[2] = 1; lv.bdim[0] = lv.bdim[1] = lv.bdim[2] = 1; }
+    }
+    std::vector<NnBuildDev> dev(M);
+    // one level of every active member at its own edge: counting passes stop after the binning, full passes leave the level complete
+    auto build_level = [&](int level, const std::vector<float>& cell, const std::vector<char>& active, bool counts_only, std::vector<double>* crowding) -> int {
+        std::vector<uint32_t> nc1(M);
+        std::vector<size_t>   pn(M * 3, 1);
+        for (size_t m = 0; m < M; ++m) {
+            NnBuildDev& b = dev[m];
+            std::memset(&b, 0, sizeof(b));
+            b.active = active[m] && bb[m].n_finite > 0 ? 1u : 0u;
+            nc1[m] = 8;  // members left out of this launch: eight zero words (an empty cloud's whole grid, see below)
+            if (!b.active) continue;
+            NnGridDev& lv = b.lv;
+            float extent = 0.0f;
+            for (int a = 0; a < 3; ++a) { lv.origin[a] = bb[m].mn[a]; extent = std::max(extent, bb[m].mx[a] - bb[m].mn[a]); }
+            lv.cell = cell[m];
+            lv.slack = 1e-6f * (extent + cell[m]);
+            lv.n = bb[m].n_finite;
+            for (int a = 0; a < 3; ++a) lv.dim[a] = static_cast<int>(std::floor((bb[m].mx[a] - bb[m].mn[a]) / cell[m])) + 1;
+            b.n_cells = static_cast<uint32_t>(lv.dim[0]) * lv.dim[1] * lv.dim[2];
+            for (int a = 0; a < 3; ++a) {
+                lv.bdim[a] = b.pd[0][a] = (lv.dim[a] + 3) / 4;
+                b.pd[1][a] = (b.pd[0][a] + 3) / 4;
+                b.pd[2][a] = (b.pd[1][a] + 3) / 4;
+                for (int k = 0; k < 3; ++k) pn[m * 3 + k] *= static_cast<size_t>(b.pd[k][a]);
+            }
+            b.pts = d_clouds[m];
+            b.n = n[m];
+            b.off = tab.h[m].off;
+            nc1[m] = b.n_cells + 1;
+        }
+        // [cell counts / starts of every member, laid out by the scan's slice table][crowd counters][pyramid words], zeroed together
+        SliceTable ctab;
+        ctab.build(nc1.data(), count);
+        uint64_t words = (uint64_t(ctab.total_elems) + 1) & ~uint64_t(1);
+        const uint64_t crowd_at = words;
+        words += 2ull * kCrowdSlots * M;
+        std::vector<uint64_t> occ_at(M);
+        for (size_t m = 0; m < M; ++m) { occ_at[m] = words; if (dev[m].active) words += 2ull * (pn[m * 3] + pn[m * 3 + 1] + pn[m * 3 + 2]); }
+        if (words > 0xffffffffull) { set_error("NnGridSet: cell tables of %llu words", static_cast<unsigned long long>(words)); return MRGFE_ERR_INVALID; }
+        DevBuf& dc = d_cells_[level];
+        MRGFE_TRY(dc.ensure(sizeof(uint32_t) * words));
+        MRGFE_HIP_CHECK(hipMemsetAsync(dc.p, 0, sizeof(uint32_t) * words, st));
+        if (!counts_only) MRGFE_TRY(d_sorted_[level].ensure(sizeof(float4) * std::max<size_t>(tab.total_elems, 1)));
+        uint32_t max_cells = 1, max_bricks = 1, max_super = 1;
+        for (size_t m = 0; m < M; ++m) {
+            NnBuildDev& b = dev[m];
+            if (!b.active) continue;
+            b.counts = dc.as<uint32_t>() + ctab.h[m].off;
+            b.crowd = crowding ? reinterpret_cast<unsigned long long*>(dc.as<uint32_t>() + crowd_at) + kCrowdSlots * m : nullptr;
+            b.occ[0] = reinterpret_cast<unsigned long long*>(dc.as<uint32_t>() + occ_at[m]);
+            b.occ[1] = b.occ[0] + pn[m * 3];
+            b.occ[2] = b.occ[1] + pn[m * 3 + 1];
+            b.sorted = counts_only ? nullptr : d_sorted_[level].as<float4>() + tab.h[m].off;
+            b.lv.cell_start = b.counts;
+            b.lv.sorted = b.sorted;
+            b.lv.occ = b.occ[0];
+            b.lv.occ1 = b.occ[1];
+            b.lv.occ2 = b.occ[2];
+            max_cells = std::max(max_cells, b.n_cells);
+            max_bricks = std::max<uint32_t>(max_bricks, static_cast<uint32_t>(pn[m * 3]));
+            max_super = std::max<uint32_t>(max_super, static_cast<uint32_t>(pn[m * 3 + 1]));
+        }
+        MRGFE_HIP_CHECK(hipMemcpyAsync(ds.as<char>() + at_dev, dev.data(), sizeof(NnBuildDev) * M, hipMemcpyHostToDevice, st));
+        if (tab.max_blks) hipLaunchKernelGGL(nn_cellkey_many_kernel, dim3(tab.max_blks * (kTile / 256), count), dim3(256), 0, st, d_dev, dk.as<uint32_t>(), dv.as<uint32_t>());
+        MRGFE_HIP_CHECK(hipGetLastError());
+        std::vector<unsigned long long> slots;
+        auto read_crowding = [&]() {
+            for (size_t m = 0; m < M; ++m) {
+                unsigned long long crowd = 0;
+                for (uint32_t k = 0; k < kCrowdSlots; ++k) crowd += slots[m * kCrowdSlots + k];
+                (*crowding)[m] = dev[m].active ? 1.0 + 2.0 * double(crowd) / double(bb[m].n_finite) : 0.0;
+            }
+        };
+        if (crowding) slots.resize(M * kCrowdSlots);
+        if (counts_only) {
+            MRGFE_HIP_CHECK(hipMemcpyAsync(slots.data(), dc.as<uint32_t>() + crowd_at, 8 * slots.size(), hipMemcpyDeviceToHost, st));
+            MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+            read_crowding();
+            return MRGFE_OK;
+        }
+        int key_bits = 1;
+        while (key_bits < 32 && (uint64_t(1) << key_bits) <= max_cells) ++key_bits;
+        uint32_t *sk = nullptr, *sv = nullptr;
+        if (tab.max_blks) MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), d_slices, tab, key_bits, dh.as<uint32_t>(), &sk, &sv));
+        MRGFE_HIP_CHECK(hipMemcpyAsync(ds.as<char>() + at_cs, ctab.h.data(), sizeof(Slice) * M, hipMemcpyHostToDevice, st));
+        MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (ctab.total_blks + M + 8)));
+        MRGFE_TRY(exclusive_scan(ctx, dc.as<uint32_t>(), dc.as<uint32_t>(), d_cslices, ctab, dblk.as<uint32_t>(), dblk.as<uint32_t>() + ctab.total_blks));
+        if (level == 0) {  // only the finest level is searched through the pyramid
+            hipLaunchKernelGGL(nn_occupancy_many_kernel, dim3((max_cells + 255) / 256, count), dim3(256), 0, st, d_dev);
+            hipLaunchKernelGGL(nn_occupancy_up_many_kernel, dim3((max_bricks + 255) / 256, count), dim3(256), 0, st, d_dev, 0);
+            hipLaunchKernelGGL(nn_occupancy_up_many_kernel, dim3((max_super + 255) / 256, count), dim3(256), 0, st, d_dev, 1);
+        }
+        if (tab.max_blks) hipLaunchKernelGGL(nn_gather_many_kernel, dim3(tab.max_blks * (kTile / 256), count), dim3(256), 0, st, d_dev, sv);
+        MRGFE_HIP_CHECK(hipGetLastError());
+        if (crowding) MRGFE_HIP_CHECK(hipMemcpyAsync(slots.data(), dc.as<uint32_t>() + crowd_at, 8 * slots.size(), hipMemcpyDeviceToHost, st));
+        MRGFE_HIP_CHECK(hipStreamSynchronize(st));  // the descriptor tables above were sources of asynchronous copies
+        if (crowding) read_crowding();
+        for (size_t m = 0; m < M; ++m) {
+            if (dev[m].active) h[m].level[level] = dev[m].lv;
+            else if (level == 0 && bb[m].n_finite == 0) {  // empty member: one cell, no points, an empty pyramid (as NnGrid::build's empty grid)
+                NnGridDev& lv = h[m].level[0];
+                lv.cell_start = dc.as<uint32_t>() + ctab.h[m].off;
+                lv.occ = reinterpret_cast<const unsigned long long*>(lv.cell_start + 2);
+                lv.occ1 = lv.occ + 1;
+                lv.occ2 = lv.occ + 2;
+                lv.sorted = d_sorted_[0].as<float4>();
+            }
+        }
+        return MRGFE_OK;
+    };
+
+    // the finest edge of every member: last time's choice when there is one (verified by the full build's own crowding figure), else the
+    // adaptive counting passes of NnGrid::build, all undecided members per launch
+    const bool hints = crowding_target > 0 && hint_cell_.size() == M && hint_cell_size_ == cell_size && hint_target_ == crowding_target;
+    std::vector<float> cell(M), top(M);
+    std::vector<char>  hinted(M, 0), all(M, 1);
+    for (size_t m = 0; m < M; ++m) {
+        float c = cell_size;
+        if (bb[m].n_finite) while (cells_at(m, c) > double(1u << 24)) c *= 2.0f;
+        top[m] = cell[m] = c;
+        if (hints && bb[m].n_finite && hint_cell_[m] > 0 && hint_cell_[m] <= c && cells_at(m, hint_cell_[m]) <= double(1u << 24)) { cell[m] = hint_cell_[m]; hinted[m] = 1; }
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (crowding_target > 0) {
+            std::vector<int>  halvings(M, 0);
+            std::vector<char> open(M);
+            for (size_t m = 0; m < M; ++m) open[m] = !hinted[m] && bb[m].n_finite > 0 && cells_at(m, cell[m] * 0.5f) <= double(1u << 24);
+            for (int pass = 0; pass < 3; ++pass) {
+                bool any = false;
+                for (char o : open) any = any || o;
+                if (!any) break;
+                std::vector<double> crowding(M, 0.0);
+                MRGFE_TRY(build_level(0, cell, open, true, &crowding));
+                for (size_t m = 0; m < M; ++m) {
+                    if (!open[m]) continue;
+                    if (crowding[m] <= crowding_target) { open[m] = 0; continue; }
+                    int step = std::max(1, static_cast<int>(std::ceil(std::log(crowding[m] / crowding_target) / std::log(4.0))));
+                    step = std::min(step, 4 - halvings[m]);
+                    while (step > 1 && cells_at(m, cell[m] * std::ldexp(1.0f, -step)) > double(1u << 24)) --step;
+                    cell[m] *= std::ldexp(1.0f, -step);
+                    halvings[m] += step;
+                    if (halvings[m] >= 4 || cells_at(m, cell[m] * 0.5f) > double(1u << 24)) open[m] = 0;
+                }
+            }
+        }
+        std::vector<double> crowding(M, 0.0);
+        MRGFE_TRY(build_level(0, cell, all, false, crowding_target > 0 ? &crowding : nullptr));
+        bool redo = false;
+        for (size_t m = 0; m < M && crowding_target > 0; ++m) {
+            if (!hinted[m]) continue;
+            const bool too_crowded = crowding[m] > 1.5 * crowding_target && cells_at(m, cell[m] * 0.5f) <= double(1u << 24) && cell[m] * 16.0f > cell_size * 0.999f;
+            if (too_crowded) { hinted[m] = 0; cell[m] = top[m]; redo = true; }
+        }
+        if (!redo) {
+            if (crowding_target > 0) {
+                hint_cell_.assign(M, 0.0f);
+                for (size_t m = 0; m < M; ++m)
+                    if (bb[m].n_finite && !(hinted[m] && crowding[m] * 6.0 < crowding_target && cell[m] < top[m])) hint_cell_[m] = cell[m];  // (a hint that has become too fine is dropped: the next build adapts from the top)
+                hint_cell_size_ = cell_size;
+                hint_target_ = crowding_target;
+            }
+            break;
+        }
+    }
+    // coarser levels for the k-NN climb: kLevelRatio x the edge each, while the level below has more than a handful of cells per axis
+    float ratio = NnGrid::kLevelRatio;
+    if (const char* e = std::getenv("MRGFE_NN_COARSE_RATIO")) ratio = std::max(2.0f, static_cast<float>(std::atof(e)));
+    for (int level = 1; level < std::min(max_levels, kNnMaxLevels); ++level) {
+        std::vector<char>  act(M, 0);
+        std::vector<float> c(M, cell_size);
+        bool any = false;
+        for (size_t m = 0; m < M; ++m) {
+            if (!bb[m].n_finite || h[m].n_levels != level) continue;
+            const NnGridDev& below = h[m].level[level - 1];
+            if (std::max(below.dim[0], std::max(below.dim[1], below.dim[2])) <= 4) continue;
+            act[m] = 1;
+            c[m] = below.cell * ratio;
+            any = true;
+        }
+        if (!any) break;
+        MRGFE_TRY(build_level(level, c, act, false, nullptr));
+        for (size_t m = 0; m < M; ++m)
+            if (act[m]) ++h[m].n_levels;
+    }
+    for (size_t m = 0; m < M; ++m) out[m]->adopt(h[m], n[m]);
+    return MRGFE_OK;
 }
 
 // ---- queries ---------------------------------------------------------------------------------------------------
@@ -1151,13 +1471,10 @@ __device__ __forceinline__ void knn_sort_merge(float& td, int32_t& ti, float d, 
     for (int stride = 32; stride > 0; stride >>= 1) knn_cmpx(td, ti, stride, true);
 }
 
-__global__ __launch_bounds__(256) void nn_knn_kernel(NnGrid2Dev g, const float4* __restrict__ q, uint32_t n, int k, int32_t* __restrict__ idx, float* __restrict__ sqd,
-                                                      unsigned long long* __restrict__ stats)
+// one query per wavefront: the k nearest of p, written to row i of idx / sqd; returns the candidates measured
+__device__ __forceinline__ uint32_t nn_knn_query(const NnGrid2Dev& g, const float4 p, uint32_t i, int k, int32_t* __restrict__ idx, float* __restrict__ sqd)
 {
-    const uint32_t i = (blockIdx.x * 256u + threadIdx.x) >> 6;
-    if (i >= n) return;  // uniform per wave
     const int    lane = lane_id();
-    const float4 p = q[i];
     float        td = INFINITY;     // list entry of this lane
     int32_t      ti = 0x7fffffff;
     float        kth_d = INFINITY;  // current k-th entry (uniform); (inf, max) while the list is not full
@@ -1218,10 +1535,10 @@ __global__ __launch_bounds__(256) void nn_knn_kernel(NnGrid2Dev g, const float4*
                 // rings 0 and 1 together: the nine x-rows of the 3x3x3 block.  Lanes 0..8 fetch the bounds of one row each
                 // (one round trip instead of nine dependent ones), the rows are then consumed as ONE list, 64 candidates
                 // per step whatever the row lengths, nearest rows first.
-                const int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};  // row j: dz = j / 3 - 1, dy = j % 3 - 1
+                constexpr unsigned long long order = 0x862075314ull;  // row j: dz = j / 3 - 1, dy = j % 3 - 1; 4, 1, 3, 5, 7, 0, 2, 6, 8 (a nibble each)
                 uint32_t  rb = 0, rl = 0;
                 if (lane < 9) {
-                    const int j = order[lane], zz = c[2] + j / 3 - 1, yy = c[1] + j % 3 - 1;
+                    const int j = static_cast<int>((order >> (4 * lane)) & 15ull), zz = c[2] + j / 3 - 1, yy = c[1] + j % 3 - 1;
                     if (zz >= 0 && zz < lv.dim[2] && yy >= 0 && yy < lv.dim[1]) {
                         const uint32_t row = (static_cast<uint32_t>(zz) * lv.dim[1] + yy) * lv.dim[0];
                         rb = lv.cell_start[row + max(c[0] - 1, 0)];
@@ -1282,12 +1599,48 @@ __global__ __launch_bounds__(256) void nn_knn_kernel(NnGrid2Dev g, const float4*
                     first_ring = 3;
                 }
             }
-            nn_walk_ranges(
-                lv, c, margin, last_ring,
-                [&](uint32_t b, uint32_t e) {
-                    for (uint32_t base = b; base < e; base += 64u) step(base + lane < e, base + lane < e ? lv.sorted[base + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-                },
-                [&](double bound_sq) { return cnt == k && static_cast<double>(kth_d) < bound_sq; }, first_ring);
+            // The remaining rings.  Ring r is (2r+1)^2 x-rows: the rows on a y / z face contribute their full x extent, the inner ones their
+            // two end cells — 2 (2r+1)^2 ranges, most of them empty where a query has to look this far.  Their bounds are fetched 64 at a
+            // time, one lane each (probing them one after the other made a handful of isolated points — hundreds of dependent round trips
+            // each — the tail that set the duration of the whole launch); the non-empty ones are then consumed 64 candidates a step.
+            for (int r = first_ring; r <= last_ring; ++r) {
+                if (r >= 1) {
+                    const double b = static_cast<double>(r - 1) * static_cast<double>(lv.cell) + margin;
+                    if (cnt == k && static_cast<double>(kth_d) < b * b * (1.0 - 1e-5)) break;
+                }
+                const int      w = 2 * r + 1;
+                const uint32_t total = 2u * static_cast<uint32_t>(w) * static_cast<uint32_t>(w);
+                for (uint32_t t0 = 0; t0 < total; t0 += 64u) {
+                    const uint32_t t = t0 + lane;
+                    uint32_t       qb = 0, qe = 0;
+                    if (t < total) {
+                        const int rowi = static_cast<int>(t >> 1), side = static_cast<int>(t & 1u);
+                        const int dz = rowi / w - r, dy = rowi % w - r, zz = c[2] + dz, yy = c[1] + dy;
+                        if (zz >= 0 && zz < lv.dim[2] && yy >= 0 && yy < lv.dim[1]) {
+                            const uint32_t row = (static_cast<uint32_t>(zz) * lv.dim[1] + yy) * lv.dim[0];
+                            const bool     face = dz == r || dz == -r || dy == r || dy == -r;
+                            int            x0 = 1, x1 = 0;
+                            if (face) {
+                                if (side == 0) { x0 = max(c[0] - r, 0); x1 = min(c[0] + r, lv.dim[0] - 1); }
+                            } else {
+                                x0 = x1 = side ? c[0] + r : c[0] - r;
+                                if (x0 < 0 || x0 >= lv.dim[0]) { x0 = 1; x1 = 0; }
+                            }
+                            if (x0 <= x1) {
+                                qb = lv.cell_start[row + x0];
+                                qe = lv.cell_start[row + x1 + 1];
+                            }
+                        }
+                    }
+                    uint64_t some = __ballot(qe > qb);
+                    while (some) {
+                        const int src = __ffsll(static_cast<unsigned long long>(some)) - 1;
+                        some &= some - 1;
+                        const uint32_t b = __shfl(qb, src), e = __shfl(qe, src);
+                        for (uint32_t base = b; base < e; base += 64u) step(base + lane < e, base + lane < e ? lv.sorted[base + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                    }
+                }
+            }
             // conclusive iff everything beyond the walked rings is farther than the k-th entry (or the level is exhausted)
             if (last_ring < rmax) {
                 const double bnd = static_cast<double>(last_ring) * static_cast<double>(lv.cell) + margin;
@@ -1299,7 +1652,16 @@ __global__ __launch_bounds__(256) void nn_knn_kernel(NnGrid2Dev g, const float4*
         idx[size_t(i) * k + lane] = lane < cnt ? ti : -1;
         sqd[size_t(i) * k + lane] = lane < cnt ? td : -1.0f;
     }
-    if (stats != nullptr && lane == 0 && n_cand) atomicAdd(stats, static_cast<unsigned long long>(n_cand));
+    return n_cand;
+}
+
+__global__ __launch_bounds__(256) void nn_knn_kernel(NnGrid2Dev g, const float4* __restrict__ q, uint32_t n, int k, int32_t* __restrict__ idx, float* __restrict__ sqd,
+                                                      unsigned long long* __restrict__ stats)
+{
+    const uint32_t i = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    if (i >= n) return;  // uniform per wave
+    const uint32_t n_cand = nn_knn_query(g, q[i], i, k, idx, sqd);
+    if (stats != nullptr && lane_id() == 0 && n_cand) atomicAdd(stats, static_cast<unsigned long long>(n_cand));
 }
 
 int NnGrid::knn_device(mrgfe_ctx* ctx, const float4* d_q, size_t n, int k, int32_t* d_idx, float* d_sqd)

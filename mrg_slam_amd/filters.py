@@ -177,6 +177,19 @@ def knn(cloud, queries, k: int, ctx: Context | None = None):
     return idx, sqd
 
 
+def grid_set_query(clouds, queries, k: int, rounds: int = 1, ctx: Context | None = None):
+    """Diagnostic (``mrgfe_dbg_grid_set_query``): search grids over several clouds built together, the queries answered against each.
+    Returns (indices [len(clouds), nq, k], squared distances likewise); k == 1 is the exact 1-NN search, k > 1 the k-NN search."""
+    ctx = ctx or default_context()
+    cs = [_cloud(c) for c in clouds]
+    q = _cloud(queries)
+    ptrs = (_fp * len(cs))(*[c.ctypes.data_as(_fp) for c in cs])
+    ns = (C.c_size_t * len(cs))(*[len(c) for c in cs])
+    idx, sqd = np.empty((len(cs), len(q), k), dtype=np.int32), np.empty((len(cs), len(q), k), dtype=np.float32)
+    check(lib().mrgfe_dbg_grid_set_query(ctx._h, ptrs, ns, len(cs), q.ctypes.data_as(_fp), len(q), k, rounds, idx.ctypes.data_as(C.POINTER(C.c_int32)), sqd.ctypes.data_as(_fp)))
+    return idx, sqd
+
+
 def _prefilter_params(p: dict) -> "_lib.PrefilterParams":
     q = _lib.PrefilterParams()
     lib().mrgfe_prefilter_default_params(C.byref(q))

@@ -206,6 +206,37 @@ def test_knn_exact_on_adversarial_clouds(kind, k):
         assert (idx[i, m:] == -1).all()
 
 
+@pytest.mark.parametrize("kind,k", [("clusters", 20), ("plane_and_specks", 20), ("line", 7), ("duplicates", 30), ("tiny", 5), ("scan", 20), ("scan", 31), ("scan_nan", 10)])
+def test_knn_of_a_clouds_own_points(street_pair_vlp16, kind, k):
+    """The cloud's own points as queries (GICP covariances, StatisticalOutlierRemoval), isolated points included (they climb rings and levels):
+    a sample of rows equals the full sort by (distance, index); non-finite points get empty rows."""
+    from mrg_slam_amd import knn
+
+    rng = np.random.default_rng(21 + k)
+    if kind.startswith("scan"):
+        t = street_pair_vlp16[0].copy()
+        t[:40, :3] += rng.uniform(-300, 300, (40, 3)).astype(np.float32)  # specks far from everything
+        if kind == "scan_nan":
+            t[::13, 2] = np.nan
+            t[7::101, 0] = np.inf
+    else:
+        t = _adversarial_target(rng, kind)
+    idx, sqd = knn(t, t, k)
+    fin = np.isfinite(t[:, :3]).all(1)
+    assert (idx[~fin] == -1).all() and (sqd[~fin] == -1.0).all()
+    ids = np.nonzero(fin)[0]
+    tx, ty, tz = (t[ids, a].astype(np.float32) for a in range(3))
+    sample = np.unique(np.concatenate([rng.choice(ids, min(300, len(ids)), replace=False), ids[ids < 40]]))
+    for i in sample:
+        dx, dy, dz = tx - t[i, 0], ty - t[i, 1], tz - t[i, 2]
+        d = (dx * dx + dy * dy) + dz * dz
+        order = np.lexsort((ids, d))[:k]
+        m = len(order)
+        np.testing.assert_array_equal(idx[i, :m], ids[order].astype(np.int32), err_msg=f"query {i}")
+        np.testing.assert_array_equal(sqd[i, :m], d[order])
+        assert (idx[i, m:] == -1).all()
+
+
 @pytest.mark.parametrize("outlier", ["RADIUS", "STATISTICAL", "NONE"])
 @pytest.mark.parametrize("downsample", ["VOXELGRID", "NONE"])
 def test_fused_prefilter_equals_the_three_calls(street_pair_vlp16, outlier, downsample):

@@ -93,3 +93,60 @@ def test_folded_wave_reduction_equals_the_plain_one(n_vals):
         v[:, :off] = v[:, :off] + v[:, off:2 * off]
         off //= 2
     assert np.array_equal(plain, v[:, 0])
+
+
+def _brute_knn(cloud, q, k):
+    """(index, squared distance) of the k nearest points, ascending by (distance, index), float32 arithmetic in the kernel's order"""
+    c, qq = cloud[:, :3].astype(np.float32), q[:, :3].astype(np.float32)
+    idx = np.full((len(qq), k), -1, dtype=np.int32)
+    sqd = np.full((len(qq), k), -1.0, dtype=np.float32)
+    fin = np.isfinite(c).all(axis=1)
+    ids = np.nonzero(fin)[0]
+    for i, p in enumerate(qq):
+        if not np.isfinite(p).all() or len(ids) == 0:
+            continue
+        d = c[ids] - p
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        o = np.lexsort((ids, d2))[:k]
+        idx[i, : len(o)] = ids[o]
+        sqd[i, : len(o)] = d2[o]
+    return idx, sqd
+
+
+@pytest.mark.parametrize("k", [1, 5, 20])
+def test_grid_set_members_answer_like_single_grids(ctx, k):
+    """NnGridSet (all members per launch, csrc/nn_grid.hip) against the single-cloud build and against brute force: clouds of very different
+    size, extent and density in one set, an empty one, one with non-finite points; the rebuilt set (cell edges reused) answers the same."""
+    from mrg_slam_amd import synth
+    from mrg_slam_amd.filters import grid_set_query, knn
+
+    rng = np.random.default_rng(100 + k)
+    scene = synth.street_scene()
+    poses = synth.arc_trajectory(3)
+    scan = synth.synth_lidar(scene, poses[0], "VLP16", synth.BASE_SEED)
+    scan2 = synth.synth_lidar(scene, poses[2], "VLP16", synth.BASE_SEED + 2)[::3]
+    blob = np.zeros((3000, 4), dtype=np.float32)
+    blob[:, :3] = rng.normal(0, 0.05, (3000, 3))  # everything inside one coarse cell: the adaptive edge halves four times
+    few = np.zeros((7, 4), dtype=np.float32)
+    few[:, :3] = rng.uniform(-30, 30, (7, 3))
+    holes = scan2.copy()
+    holes[::17, 1] = np.nan
+    holes[5::29, 0] = np.inf
+    line = np.zeros((500, 4), dtype=np.float32)
+    line[:, 0] = np.linspace(-100, 100, 500)  # a degenerate extent
+    clouds = [scan, blob, np.zeros((0, 4), dtype=np.float32), few, holes, line, scan2]
+    q = np.concatenate([scan[::40], blob[::300], few, (rng.uniform(-60, 60, (200, 4))).astype(np.float32)])
+    q[3, 2] = np.nan
+    for rounds in (1, 3):
+        idx, sqd = grid_set_query(clouds, q, k, rounds=rounds, ctx=ctx)
+        for m, c in enumerate(clouds):
+            bi, bd = _brute_knn(c, q, k)
+            if k == 1:
+                bi[~np.isfinite(q[:, :3]).all(axis=1)] = -1
+            np.testing.assert_array_equal(idx[m], bi, err_msg=f"member {m} rounds {rounds}")
+            ok = bi >= 0
+            np.testing.assert_array_equal(sqd[m][ok], bd[ok], err_msg=f"member {m} rounds {rounds}")
+            if k > 1 and len(c):
+                si, sd = knn(c, q, k, ctx=ctx)
+                np.testing.assert_array_equal(idx[m], si)
+                np.testing.assert_array_equal(sqd[m], sd)
