@@ -392,11 +392,16 @@ def main():
                       [l_dev[loop_pairs[i][1]].data_ptr() for i in mine], [len(l_host[loop_pairs[i][1]]) for i in mine],
                       np.stack([loop_pairs[i][2] for i in mine]) if len(mine) else np.zeros((0, 4, 4)))
 
+        phases = [] if os.environ.get("BENCH_STEP_PHASES") else None  # diagnostic: host-side split of a step (queue the batch / align / records)
+
         def step():
+            t0 = time.perf_counter()
             bm.clear()
             if len(mine):
                 bm.add_device(*shard_args)
+            t1 = time.perf_counter()
             local = bm.align(float("inf"))  # getFitnessScore(fitness_score_max_range = .inf), config/mrg_slam.yaml:172
+            t2 = time.perf_counter()
             local["pair_id"] = mine.astype(np.int32)
             rec = all_gather_records(local, per) if world > 1 else local
             full = np.zeros(n_pairs, dtype=RESULT_DTYPE)
@@ -404,6 +409,8 @@ def main():
             full[rec["pair_id"]] = rec
             # every rank replays the sequential best-candidate rule per new keyframe (loop_detector.cpp:126-145)
             best = {a: lc.select_best(full[ids]) for a, ids in groups.items()}  # (with --shard-of the other ranks' records are missing: unconverged zeros)
+            if phases is not None:
+                phases.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
             return full, best
 
         deriv = np.zeros(3)   # (device ms, launches, algorithmic bytes) of the derivative launches, HIP events around every launch
@@ -421,6 +428,8 @@ def main():
             return out
 
         elapsed, step_ms, (full, best) = timed(step, steps, warmup)
+        if phases:
+            print("[bench] step phases, median ms: queue the batch %.3f, align %.3f, records + best candidate %.3f" % tuple(1e3 * np.median(np.array(phases[-steps:]), axis=0)), file=sys.stderr)
         # kernel times for the roofline records: two more, untimed, steps WITHOUT the early fitness waves (beside the alignment rounds the
         # kernels of both share the chip and their HIP-event times say little about either), then one with the sweep's counters on:
         # candidate points measured per queued query (the m-bar of SURVEY.md §8d)

@@ -314,6 +314,8 @@ void mrgfe_ctx_destroy(mrgfe_ctx* ctx)
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (auto& pr : ctx->ev_mode) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->ev_fit) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->ev_side) if (e) (void)hipEventDestroy(e);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     for (auto& e : ctx->knn_stats.ev) if (e) (void)hipEventDestroy(e);
     ctx->knn_stats.counter.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

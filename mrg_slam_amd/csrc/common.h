@@ -117,6 +117,8 @@ struct mrgfe_ctx {
     bool         up_busy[2] = {false, false};
     int          up_next = 0;
     hipEvent_t   ev_fit[4] = {nullptr, nullptr, nullptr, nullptr};  // around the passes of nn_fitness_batch
+    hipStream_t  side = nullptr;                // second stream of nn_fitness_batch: the pyramid walk of the unseeded queries beside the sweep
+    hipEvent_t   ev_side[4] = {nullptr, nullptr, nullptr, nullptr};  // fork, start and end of the side work, join
     mrgfe::FitStats fit_stats;                  // of the last nn_fitness_batch on this context
     mrgfe::KnnStats knn_stats;                  // of the last k-NN launch on this context
     int          cu_count = 256;

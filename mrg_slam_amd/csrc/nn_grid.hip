@@ -1303,14 +1303,28 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_off, off.data(), sizeof(uint32_t) * (count + 1), hipMemcpyHostToDevice, st));
     MRGFE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, off_bytes - sizeof(uint32_t) * (count + 1), st));  // the queue lengths and the counters behind them
     const dim3 grid(nblk, static_cast<uint32_t>(count));
+    bool       side_far = false;
     MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[0], st));
     hipLaunchKernelGGL(nn_fit_block_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, dq.as<float>(), d_pend[0], d_cnts[0]);
     MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[1], st));
     if (sweep) {
         hipLaunchKernelGGL(nn_fit_seed_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), d_pend[1], d_cnts[1], counters ? d_stats : nullptr);
+        // The unseeded queries (a few hundred of millions: nothing within three blocks) walk the pyramid, a handful of long dependent walks
+        // that occupy a few wavefronts for ~0.25 ms: on a second stream beside the sweep, which leaves them alone (their queue entries are
+        // flagged), instead of behind it.
+        if (!ctx->side) MRGFE_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        for (int e = 0; e < 4; ++e)
+            if (!ctx->ev_side[e]) MRGFE_HIP_CHECK((e == 1 || e == 2) ? hipEventCreate(&ctx->ev_side[e]) : hipEventCreateWithFlags(&ctx->ev_side[e], hipEventDisableTiming));
+        MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[0], st));
+        MRGFE_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev_side[0], 0));
+        MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[1], ctx->side));
+        hipLaunchKernelGGL(nn_fit_far_kernel, grid, dim3(256), 0, ctx->side, d_jobs, d_off, max_range, d_pend[1], d_cnts[1], dq.as<float>());
+        MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[2], ctx->side));
+        MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[3], ctx->side));
         hipLaunchKernelGGL(nn_fit_sweep_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), counters ? d_stats : nullptr, fit_stats_mode() > 1 ? 1 : 0);
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[2], st));
-        hipLaunchKernelGGL(nn_fit_far_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[1], d_cnts[1], dq.as<float>());
+        MRGFE_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_side[3], 0));
+        side_far = true;
     } else {
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[2], st));
         hipLaunchKernelGGL(nn_fit_far_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>());
@@ -1331,6 +1345,7 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     FitStats& fs = ctx->fit_stats;
     float ms[3] = {0, 0, 0};
     for (int k = 0; k < 3; ++k) (void)hipEventElapsedTime(&ms[k], ctx->ev_fit[k], ctx->ev_fit[k + 1]);
+    if (side_far) (void)hipEventElapsedTime(&ms[2], ctx->ev_side[1], ctx->ev_side[2]);  // the walk ran beside the sweep: its own duration
     fs.ms_block = ms[0];
     fs.ms_sweep = ms[1];
     fs.ms_far = ms[2];
