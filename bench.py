@@ -171,6 +171,18 @@ def make_loop_workload(n_keyframes: int = 64, n_pairs: int = 256, radius: float 
     return scans, pairs
 
 
+def latest_pmc_summary():
+    """(name, dict) of the newest profiles/*_summary.json: the HBM traffic and VALU utilisation of the named kernels from separate rocprofv3 --pmc
+    passes (profiles/collect*.sh, profiles/summarize.py), or (None, {}) when there is none."""
+    try:
+        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_summary.json"))
+        if prof:
+            return prof[-1], json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
+    except (OSError, ValueError):
+        pass
+    return None, {}
+
+
 def run_config2(ctx, scans, dev, poses, lib, args):
     """BASELINE config[2]: scan-to-keyframe GICP on the ~130k-point scans (registrations.cpp:46-63: SMALL_GICP is the YAML default, FAST_GICP the
     code default), per frame setInputSource (k = 20 covariances) + align against a keyframe set once; kernel times from the library's HIP events."""
@@ -215,10 +227,12 @@ def run_config2(ctx, scans, dev, poses, lib, args):
         knn_gbps = (knn_bytes / 1e9) / (knn["ms"] / 1e3) if knn["ms"] > 0 else 0.0
         lin_gbps = (lin[2] / 1e9) / (lin[0] / 1e3) if lin[0] > 0 else 0.0
         err = [float(np.linalg.norm(finals[k][:3, 3] - rels[k][:3, 3])) for k in frames]
+        pmc_name, pmc = latest_pmc_summary()
         rec = {"first_frame_incl_setInputTarget_ms": float(np.median(t_set)), "frame_ms": float(np.median(t_frame)), "frames_timed": len(t_frame),
                "outer_iterations_per_frame": float(np.mean(its)), "median_translation_error_vs_truth_m": float(np.median(err)),
                "roofline_knn": {"bound": "latency", "byte_model_bound": "hbm", "kernel": "nn_knn_kernel (k = 20, one wavefront per query)", "achieved": knn_gbps, "peak": HBM_PEAK_GBPS,
-                                "unit": "GB/s", "frac": knn_gbps / HBM_PEAK_GBPS, "traffic": None, "launch_ms": knn["ms"], "queries": knn["queries"],
+                                "unit": "GB/s", "frac": knn_gbps / HBM_PEAK_GBPS, "traffic": pmc.get("knn_traffic_bytes_per_launch"), "traffic_note": "PMC bytes per launch on a ~130k-point cloud "
+                                "(profiles/gicp_profile.py batch), not on this frame's cloud", "valu_busy": pmc.get("knn_valu_busy"), "pmc_profile": pmc_name, "launch_ms": knn["ms"], "queries": knn["queries"],
                                 "candidate_points_per_query": mbar, "byte_model": "N * (16 + 27*8 + m*16), m = candidates measured per query (counted)"},
                "roofline_linearize": {"bound": "latency", "byte_model_bound": "hbm", "kernel": "gicp_corr_kernel + gicp_linearize_kernel (one HIP-event pair around both)",
                                       "achieved": lin_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": lin_gbps / HBM_PEAK_GBPS, "traffic": None, "launches": int(lin[1]),
@@ -457,13 +471,21 @@ def main():
         # query on the hash grid at 16 + 27 * 8 + m-bar * 16 bytes; N = the queries the 3x3x3 block did not settle
         f_bytes = fit_acc["queued"] * (16.0 + 27.0 * 8.0 + mbar * 16.0)
         f_gbps = (f_bytes / 1e9) / (fit_acc["ms_sweep"] / 1e3) if fit_acc["ms_sweep"] > 0 else 0.0
+        pmc_name, pmc = latest_pmc_summary()
+        sh_pmc = pmc.get("shard_pmc", {})
+        d_pmc = sh_pmc.get("kernels", {}).get("ndt_derivatives_all_kernel<7>")
+        # (the counter passes profile the whole 256-pair step on one GPU: per-launch / per-step traffic is quoted for that shape only)
+        full_shape = len(mine) == n_pairs
         roof = {"bound": "valu", "byte_model_bound": "hbm", "kernel": "ndt_derivatives_all_kernel<7>", "achieved": d_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": d_gbps / HBM_PEAK_GBPS, "traffic": None, "launches": int(deriv[1]), "avg_launch_ms": deriv[0] / deriv[1] if deriv[1] else None,
+                "frac": d_gbps / HBM_PEAK_GBPS, "traffic": (d_pmc["hbm_bytes"] / d_pmc["launches"]) if (d_pmc and full_shape) else None,
+                "valu_busy": d_pmc["valu_busy"] if d_pmc else None, "pmc_profile": pmc_name, "launches": int(deriv[1]), "avg_launch_ms": deriv[0] / deriv[1] if deriv[1] else None,
                 "alg_bytes_per_launch": deriv[2] / deriv[1] if deriv[1] else None, "ms_per_step": deriv[0] / acc_steps,
                 "byte_model": "per launch: sum over the evaluations of all active pairs of N_src*(16 + 7*8) + valid_neighbours*48 (SURVEY.md §8d); PMC traffic of this "
                               "kernel: profiles/r03_rocprof_summary.md"}
         roof_fit = {"bound": "valu", "byte_model_bound": "hbm", "kernel": "nn_fit_seed_kernel + nn_fit_sweep_kernel (getFitnessScore(inf), the queries their 3x3x3 block does not settle)",
-                    "achieved": f_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": f_gbps / HBM_PEAK_GBPS, "traffic": None,
+                    "achieved": f_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": f_gbps / HBM_PEAK_GBPS,
+                    "traffic": pmc.get("fitness_sweep_traffic_bytes_per_step") if full_shape else None, "traffic_unit": "HBM bytes per step (compare alg_bytes_per_step)",
+                    "valu_busy": pmc.get("fitness_sweep_valu_busy"), "pmc_profile": pmc_name,
                     "queued_queries_per_step": fit_acc["queued"] / acc_steps, "queries_per_step": fit_acc["queries"] / acc_steps, "unseeded_queries_per_step": fit_acc["queued_far"] / acc_steps,
                     "candidate_points_per_queued_query": mbar, "alg_bytes_per_step": f_bytes / acc_steps, "ms_per_step": fit_acc["ms_sweep"] / acc_steps,
                     "block_pass_ms_per_step": fit_acc["ms_block"] / acc_steps, "pyramid_walk_ms_per_step": fit_acc["ms_far"] / acc_steps,
@@ -730,15 +752,9 @@ def main():
     # rocprofv3 --pmc and corrected as MI355X_MICROARCH.md prescribes; profiles/summarize.py) - null until a profile exists
     traffic = valu_busy = None
     prof_name = None
-    try:
-        prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_summary.json"))
-        if prof:
-            prof_name = prof[-1]
-            pj = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
-            traffic = pj.get("traffic_bytes_per_mean_launch")
-            valu_busy = pj.get("valu_busy_dominant")
-    except (OSError, ValueError):
-        pass
+    prof_name, pj = latest_pmc_summary()
+    traffic = pj.get("traffic_bytes_per_mean_launch")
+    valu_busy = pj.get("valu_busy_dominant")
     alg_per_launch = (k_bytes / k_launch) if k_launch else None
     ratio = (traffic / alg_per_launch) if (traffic and alg_per_launch) else None
     # what the counters say limits the kernel: HBM only if the bytes it really moves are a large share of the byte model

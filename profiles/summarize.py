@@ -124,6 +124,68 @@ def main():
                   "| kernel | calls | total ms | avg us | % |", "|---|---:|---:|---:|---:|"]
         for r in rows[:12]:
             lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |")
+    # round 3: counter passes of one config[3] step (profiles/collect_r03.sh) — getFitnessScore kernels and the derivative kernel in shard mode
+    def pmc_table(title, suffix, keep, per, per_name):
+        fe = counters(os.path.join(OUT, f"pmc_fetch_{suffix}", "f_counter_collection.csv"))
+        wr = counters(os.path.join(OUT, f"pmc_write_{suffix}", "w_counter_collection.csv"))
+        sqc = counters(os.path.join(OUT, f"pmc_sq_{suffix}", "s_counter_collection.csv"))
+        if not fe and not wr:
+            return {}
+        out = {}
+        rows = ["", title, "", f"| kernel | launches | sum FETCH_SIZE KiB | sum WRITE_SIZE KiB | HBM bytes per {per_name} = (2*FETCH + WRITE)*1024 / {per} | VALU instr / wave | VALU busy |", "|---|---:|---:|---:|---:|---:|---:|"]
+        for k in sorted(set(fe) | set(wr)):
+            if not any(w in k for w in keep):
+                continue
+            f, w = fe.get(k, {}).get("FETCH_SIZE", []), wr.get(k, {}).get("WRITE_SIZE", [])
+            v = {c: sum(x) for c, x in sqc.get(k, {}).items()}
+            waves = v.get("SQ_WAVES", 0) or 1
+            gui = v.get("GRBM_GUI_ACTIVE", 0) / 8.0 or 1
+            busy = v.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (1024 * gui)
+            hbm = (2 * sum(f) + sum(w)) * 1024 / per
+            out[k] = {"launches": max(len(f), len(w)), "hbm_bytes": hbm, "valu_instr_per_wave": v.get("SQ_INSTS_VALU", 0) / waves, "valu_busy": busy}
+            rows.append(f"| `{k}` | {max(len(f), len(w))} | {sum(f):.0f} | {sum(w):.0f} | {hbm / 1e6:.1f} MB | {v.get('SQ_INSTS_VALU', 0) / waves:.0f} | {busy:.2f} |")
+        lines.extend(rows)
+        return out
+
+    sh = pmc_table("## config[3] step, counter passes (`rocprofv3 --pmc ... -- python3 bench.py --mode shard --no-cpu --no-extras --steps 1 --warmup 1`: two steps per run; the rest of the run — "
+                   "the untimed accounting steps bench.py adds — is included, see `steps_in_run`)", "shard", ("nn_fit", "ndt_derivatives", "nn_cellkey", "nn_gather", "nn_occupancy", "rs_", "ndt_leaf", "ndt_cellkey", "bbox"), 1, "run")
+    if sh:
+        # steps in the profiled run = launches of nn_fit_block_kernel (one fitness launch per step)
+        steps_in_run = max(1, sh.get("nn_fit_block_kernel", {}).get("launches", 1))
+        summary["shard_pmc"] = {"steps_in_run": steps_in_run, "kernels": sh}
+        fit = sum(v["hbm_bytes"] for k, v in sh.items() if k in ("nn_fit_seed_kernel", "nn_fit_sweep_kernel")) / steps_in_run
+        summary["fitness_sweep_traffic_bytes_per_step"] = fit
+        summary["fitness_sweep_valu_busy"] = sh.get("nn_fit_sweep_kernel", {}).get("valu_busy")
+        lines += ["", f"Per step ({steps_in_run} steps in the run): `nn_fit_seed_kernel` + `nn_fit_sweep_kernel` move {fit / 1e9:.2f} GB of HBM traffic; "
+                      f"`nn_fit_block_kernel` {sh.get('nn_fit_block_kernel', {}).get('hbm_bytes', 0) / steps_in_run / 1e9:.2f} GB."]
+    gi = pmc_table("## GICP batch, counter passes (`rocprofv3 --pmc ... -- python3 profiles/gicp_profile.py batch`: 4 aligns of 32 x ~130k-point clouds, covariances recomputed each)", "gicp",
+                   ("nn_knn", "gicp_", "nn_cellkey", "nn_gather", "rs_"), 4, "align call")
+    if gi:
+        summary["gicp_pmc_per_align"] = gi
+        if "nn_knn_kernel" in gi:
+            summary["knn_traffic_bytes_per_launch"] = gi["nn_knn_kernel"]["hbm_bytes"] * 4 / max(1, gi["nn_knn_kernel"]["launches"])
+            summary["knn_valu_busy"] = gi["nn_knn_kernel"]["valu_busy"]
+    for name, d in (("config[3] shard of 8 (`bench.py --mode shard --shard-of 8`)", f"prof_shard8_{tag}"), ("GICP batch (`profiles/gicp_profile.py batch`)", "prof_gicp_batch"),
+                    ("GICP odometry frame (`profiles/gicp_profile.py frame`)", "prof_gicp_frame")):
+        f = os.path.join(OUT, d, "s_kernel_stats.csv")
+        if not os.path.exists(f):
+            continue
+        rows = list(csv.DictReader(open(f)))
+        lines += ["", f"## {name}: `rocprofv3 --kernel-trace --stats`, top kernels", "", "| kernel | calls | total ms | avg us | % |", "|---|---:|---:|---:|---:|"]
+        for r in rows[:12]:
+            lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |")
+    for nm in ("shard", "shard8"):
+        f = os.path.join(OUT, f"bench_{nm}_{tag}.json")
+        if os.path.exists(f) and os.path.getsize(f):
+            j = json.load(open(f))
+            summary[f"bench_{nm}"] = {"ms_per_step": j["ms_per_step"], "value": j["value"], "records_sha256_16": j["config3_shard"]["records_sha256_16"], "roofline": j["roofline"],
+                                      "roofline_fitness": j["roofline_fitness"]}
+            lines += ["", f"`bench.py --mode shard{' --shard-of 8' if nm == 'shard8' else ''} --no-cpu --no-extras`: {j['ms_per_step']:.2f} ms per step, records digest {j['config3_shard']['records_sha256_16']}"]
+    for w in ("batch", "frame"):
+        f = os.path.join(OUT, f"gicp_{w}.txt")
+        if os.path.exists(f):
+            summary[f"gicp_{w}"] = open(f).read().strip()
+            lines += ["", f"`profiles/gicp_profile.py {w}`: {summary[f'gicp_{w}']}"]
     for w in ("gicp", "gicp_full", "prefilter", "fitness", "lc", "gicp_lc"):
         side = os.path.join(OUT, f"prof_side_{w}", "s_kernel_stats.csv")
         if not os.path.exists(side):
