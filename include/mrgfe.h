@@ -360,6 +360,10 @@ int  mrgfe_batch_pair_counts(const mrgfe_batch* b, int mode, double* points, dou
 int  mrgfe_batch_fitness_stats(const mrgfe_batch* b, double out[11]);
 
 /* ---- diagnostic entry points for the primitive tests (tests/test_gpu_primitives.py) --------------------------- */
+/* correspondence search of GICP_HIP / SMALL_GICP_HIP (fast_gicp / small_gicp update_correspondences): the batched passes of getFitnessScore
+ * carrying the index of the nearest point (csrc nn_nearest_batch) or one lane group per query until its answer is final.  1 = the passes for
+ * batches of >= 400k queries (default: that is where they are faster), 0 = never, 2 = always.  Same correspondences either way; tests compare. */
+int mrgfe_dbg_set_gicp_corr_passes(int mode);
 /* Grids over `count` host clouds (packed xyzw floats) built TOGETHER (csrc NnGridSet, the batched form of the search grid under
  * getFitnessScore and the GICP covariances), then the `nq` queries answered against each: k == 1 the exact nearest neighbour, k > 1 the k
  * nearest, as mrgfe_knn.  idx / sqd: [count][nq][k].  `rounds` > 1 rebuilds the set that often (later builds reuse the cell edges). */

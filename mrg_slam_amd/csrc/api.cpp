@@ -397,6 +397,8 @@ int mrgfe_knn(mrgfe_ctx* ctx, const float* cloud, size_t n, const float* query, 
     return rc;
 }
 
+int mrgfe_dbg_set_gicp_corr_passes(int mode) { return gicp_set_corr_passes(mode); }
+
 int mrgfe_dbg_grid_set_query(mrgfe_ctx* ctx, const float* const* clouds, const size_t* n, int count, const float* query, size_t nq, int k, int rounds, int32_t* idx, float* sqd)
 {
     if (!ctx || count < 1 || !clouds || !n || !query || !idx || !sqd || nq == 0) { set_error("mrgfe_dbg_grid_set_query: bad argument"); return MRGFE_ERR_INVALID; }

@@ -749,6 +749,31 @@ int GicpEngine::set_source(const void* d, size_t n)
 }
 
 // k-NN covariances of one cloud on ctx's stream, through the caller's grid and neighbour buffers
+// Correspondence search of GICP_HIP / SMALL_GICP_HIP: one lane group per query that walks until its answer is final (gicp_corr_kernel), or the
+// passes of getFitnessScore carrying the index (nn_nearest_batch: block / seed / sweep / pyramid walk), which sort the queries by the work they
+// still need.  Measured: a batch of 32 x 130k queries 5.6 -> 3.8 ms per call (three rounds), but ONE cloud is slower through the passes
+// (130k queries: frame 1.68 -> 1.85 ms, 33k: 1.86 -> 2.13 ms — four launches, two small copies and a stream fork against one launch that
+// already fills the chip with eight lanes per query).  Mode 1 (default): the passes for batches of at least kCorrPassMinQueries queries;
+// 0: never; 2: always (tests).
+static std::atomic<int> g_corr_passes{-1};
+constexpr size_t kCorrPassMinQueries = 400000;
+static int gicp_corr_mode()
+{
+    int m = g_corr_passes.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = std::getenv("MRGFE_GICP_CORR_PASSES");
+        m = e ? std::max(0, std::min(2, std::atoi(e))) : 1;
+        g_corr_passes.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+static bool gicp_corr_passes(size_t queries) { return gicp_corr_mode() == 2 || (gicp_corr_mode() == 1 && queries >= kCorrPassMinQueries); }
+int gicp_set_corr_passes(int mode)
+{
+    g_corr_passes.store(std::max(0, std::min(2, mode)), std::memory_order_relaxed);
+    return MRGFE_OK;
+}
+
 int gicp_covariances_on_grid(mrgfe_ctx* ctx, int k, const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid, DevBuf& knn_i, DevBuf& knn_d, bool pcl_moments);
 int gicp_compute_covariances(mrgfe_ctx* ctx, int k, const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid, DevBuf& knn_i, DevBuf& knn_d, bool pcl_moments)
 {
@@ -928,7 +953,15 @@ int GicpEngine::run_linearize(const double T[16], bool, double H[36], double b[6
         hipLaunchKernelGGL(gicp_linearize_kernel, dim3(nblk), dim3(256), 0, st, d_src_, n, static_cast<const float4*>(nullptr), d_src_cov_.as<double>(), d_vox_.as<double>(), pose,
                            d_corr_.as<int32_t>(), d_mahal_.as<double>(), d_part);
     } else {
-        hipLaunchKernelGGL(gicp_corr_kernel, dim3((n + per_blk - 1) / per_blk), dim3(256), 0, st, tgt_grid_.dev2(), d_src_, n, pose, prm_.max_corr_dist * prm_.max_corr_dist, d_corr_.as<int32_t>());
+        if (gicp_corr_passes(n)) {  // (a single cloud: only when forced, see gicp_corr_mode)
+            NnFitnessJob job = tgt_grid_.make_fitness_job(d_src_, n, pose.Tf);
+            std::memcpy(job.T12, pose.Tf, sizeof(job.T12));
+            job.gicp_order = 1;
+            job.idx_out = d_corr_.as<int32_t>();
+            MRGFE_TRY(nn_nearest_batch(ctx_, &job, 1, prm_.max_corr_dist * prm_.max_corr_dist));
+        } else {
+            hipLaunchKernelGGL(gicp_corr_kernel, dim3((n + per_blk - 1) / per_blk), dim3(256), 0, st, tgt_grid_.dev2(), d_src_, n, pose, prm_.max_corr_dist * prm_.max_corr_dist, d_corr_.as<int32_t>());
+        }
         hipLaunchKernelGGL(gicp_linearize_kernel, dim3(nblk), dim3(256), 0, st, d_src_, n, d_tgt_, d_src_cov_.as<double>(), d_tgt_cov_.as<double>(), pose, d_corr_.as<int32_t>(),
                            d_mahal_.as<double>(), d_part);
     }
@@ -1639,15 +1672,17 @@ int GicpBatch::align_all(std::vector<GicpEngine*>& engines, std::vector<GicpBatc
     const double thr = engines[pairs[0].target]->params().max_corr_dist;
     const GicpParams& prm0 = engines[pairs[0].target]->params();
     const int    round_cap = (prm0.max_iterations + 1) * (std::max(prm0.lm_max_iterations, prm0.sg_max_inner_iterations) + 2) + 4;
+    std::vector<NnFitnessJob> corr_jobs;
     for (int round = 0; round < round_cap; ++round) {
         uint32_t n_lin = 0, n_err = 0;
+        size_t   lin_queries = 0;
         for (int i = 0; i < P; ++i) {
             GicpLmController& c = pairs[i].ctl;
             if (c.done() || pairs[i].n == 0) { he[i].type = -1; continue; }
             he[i].pose = make_pose(c.request().T, engines[pairs[i].target]->params().variant);
             he[i].thr2 = thr * thr;
             he[i].type = c.request().type;
-            if (he[i].type == 0) he[n_lin++].order[0] = static_cast<uint32_t>(i);
+            if (he[i].type == 0) { he[n_lin++].order[0] = static_cast<uint32_t>(i); lin_queries += pairs[i].n; }
             else                 he[n_err++].order[1] = static_cast<uint32_t>(i);
         }
         // an empty source still walks its LM loop on all-zero records (like the single engine does)
@@ -1661,8 +1696,25 @@ int GicpBatch::align_all(std::vector<GicpEngine*>& engines, std::vector<GicpBatc
             const GicpEvalDev* de = d_evals_.as<GicpEvalDev>();
             if (n_lin) {
                 constexpr uint32_t per_blk = 256u / kGicpBatchGroup;
-                if (voxel) hipLaunchKernelGGL(vox_corr_batch_kernel, dim3((max_n + 255) / 256, n_lin), dim3(256), 0, st, dp, de, d_grids_.as<VoxGridDev>());
-                else       hipLaunchKernelGGL(gicp_corr_batch_kernel, dim3((max_n + per_blk - 1) / per_blk, n_lin), dim3(256), 0, st, dp, de, d_grids_.as<NnGrid2Dev>());
+                if (voxel) {
+                    hipLaunchKernelGGL(vox_corr_batch_kernel, dim3((max_n + 255) / 256, n_lin), dim3(256), 0, st, dp, de, d_grids_.as<VoxGridDev>());
+                } else if (gicp_corr_passes(lin_queries)) {
+                    corr_jobs.clear();
+                    for (uint32_t w = 0; w < n_lin; ++w) {
+                        const uint32_t i = he[w].order[0];
+                        NnFitnessJob job;
+                        job.grid = h_grids[pairs[i].target];
+                        job.src = pairs[i].d_src;
+                        job.n = pairs[i].n;
+                        job.gicp_order = 1;
+                        std::memcpy(job.T12, he[i].pose.Tf, sizeof(job.T12));
+                        job.idx_out = pairs[i].corr.as<int32_t>();
+                        corr_jobs.push_back(job);
+                    }
+                    MRGFE_TRY(nn_nearest_batch(ctx_, corr_jobs.data(), corr_jobs.size(), thr * thr));
+                } else {
+                    hipLaunchKernelGGL(gicp_corr_batch_kernel, dim3((max_n + per_blk - 1) / per_blk, n_lin), dim3(256), 0, st, dp, de, d_grids_.as<NnGrid2Dev>());
+                }
                 hipLaunchKernelGGL(gicp_linearize_batch_kernel, dim3((max_n + 255) / 256, n_lin), dim3(256), 0, st, dp, de, d_partials_.as<double>());
             }
             if (n_err) hipLaunchKernelGGL(gicp_error_batch_kernel, dim3((max_n + 255) / 256, n_err), dim3(256), 0, st, dp, de, d_partials_.as<double>());

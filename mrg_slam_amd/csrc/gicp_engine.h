@@ -178,4 +178,7 @@ class GicpBatch {
     hipEvent_t done_ = nullptr;
 };
 
+// correspondence search of GICP_HIP / SMALL_GICP_HIP: 1 the passes of nn_nearest_batch for large batches (default), 0 one lane group per query always, 2 the passes always
+int gicp_set_corr_passes(int mode);
+
 }  // namespace mrgfe

@@ -48,8 +48,9 @@ struct NnFitnessJob {
     NnGrid2Dev    grid;
     const float4* src;
     uint32_t      n;
-    uint32_t      pad;
+    uint32_t      gicp_order;  // how T12 is applied: 0 pcl::transformPointCloud's order (getFitnessScore), 1 fast_gicp's trans_f * Vector4f (correspondence search)
     float         T12[12];
+    int32_t*      idx_out;     // nn_nearest_batch: the index of the nearest target point per query (-1: none within the range); null in fitness jobs
 };
 
 class NnGrid {
@@ -115,6 +116,10 @@ NnGrid& ctx_tmp_grid(mrgfe_ctx* ctx);
 
 // all jobs in one launch (blockIdx.y = job); out[j] = mean squared distance or DBL_MAX when nothing is in range
 int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, double max_range, double* out);
+
+// The same passes as a correspondence search (fast_gicp / small_gicp update_correspondences): jobs[j].idx_out[i] = index of the target point
+// nearest to T * src[i] (ties: the lowest index) if its squared distance is < max_sq, else -1.  Enqueued on ctx->stream, no host wait.
+int nn_nearest_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, double max_sq);
 
 // far pass of the fitness score: 1 = seed + sweep (nn_fit_sweep_kernel), 0 = the pyramid walk for every queued query
 int nn_set_fit_sweep(int mode);

@@ -631,10 +631,29 @@ __device__ __forceinline__ void nn_load_job(NnFitnessJob& s_job, const NnFitness
     for (uint32_t w = threadIdx.x; w < sizeof(NnFitnessJob) / 4; w += 256) dst[w] = src[w];
 }
 
+// the query of a job: its transform applied in the order of the code the job stands in for
+__device__ __forceinline__ void nn_job_transform(const float* __restrict__ T, uint32_t gicp_order, float px, float py, float pz, float& x, float& y, float& z)
+{
+#pragma clang fp contract(off)
+    if (gicp_order) {  // (uniform) trans_f * Vector4f(x, y, z, 1): accumulated column by column, as gicp_corr_query does
+        float s;
+        s = T[0] * px; s = s + T[1] * py; s = s + T[2] * pz; x = s + T[3];
+        s = T[4] * px; s = s + T[5] * py; s = s + T[6] * pz; y = s + T[7];
+        s = T[8] * px; s = s + T[9] * py; s = s + T[10] * pz; z = s + T[11];
+    } else {
+        transform_point(T, px, py, pz, x, y, z);
+    }
+}
+// kIdx passes: is the candidate (d, i) better than (best_d, best_i)?  Ties go to the lower index.
+__device__ __forceinline__ unsigned long long nn_key(float d, int32_t i) { return static_cast<unsigned long long>(__float_as_uint(d)) << 32 | static_cast<uint32_t>(i); }
+
 #ifndef MRGFE_BLOCK_GROUP
 #define MRGFE_BLOCK_GROUP 1
 #endif
 constexpr int kBlockGroup = MRGFE_BLOCK_GROUP;  // lanes per query in the block pass
+// kIdx (all four passes): the correspondence search of nn_nearest_batch — the index of the nearest point is carried beside its distance
+// (ties: the lowest index) in the job's idx_out, a query counts when its squared distance is < max_range (fast_gicp's test) instead of <=.
+template <bool kIdx>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void nn_fit_block_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range, float* __restrict__ sqd,
                                                             uint32_t* __restrict__ pend, uint32_t* __restrict__ pend_cnt)
 {
@@ -671,13 +690,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void n
         if (i < i_end) {
             const float4 p = load_point(s_job.src + i);
             float x, y, z;
-            transform_point(s_job.T12, p.x, p.y, p.z, x, y, z);
+            nn_job_transform(s_job.T12, s_job.gicp_order, p.x, p.y, p.z, x, y, z);
             int32_t bi = -1;
             float   bd = INFINITY;
             bool    done = true;
             if (g.level[0].n != 0 && finite3(x, y, z)) done = nn_level_search<kBlockGroup>(g.level[0], x, y, z, sub, 1, max_range, bi, bd);
             // queued queries leave what the block gave (INFINITY: nothing) as the far pass's starting bound
-            if (sub == 0) sqd[off + i] = done ? ((bi >= 0 && static_cast<double>(bd) <= max_range) ? bd : kFitNone) : (bi >= 0 ? bd : INFINITY);
+            if (sub == 0) {
+                if (kIdx) {
+                    const bool hit = bi >= 0 && static_cast<double>(bd) < max_range;
+                    sqd[off + i] = done ? (hit ? bd : kFitNone) : (bi >= 0 ? bd : INFINITY);
+                    s_job.idx_out[i] = done ? (hit ? bi : -1) : bi;
+                } else {
+                    sqd[off + i] = done ? ((bi >= 0 && static_cast<double>(bd) <= max_range) ? bd : kFitNone) : (bi >= 0 ? bd : INFINITY);
+                }
+            }
             queue = sub == 0 && !done;
         }
         const uint64_t m = __ballot(queue);
@@ -755,6 +782,7 @@ __device__ __forceinline__ float nn_child_lb(const float t[3], int cx, int cy, i
 
 // seed: one lane per queued query; sqd[query] becomes min(what the block gave, the nearest point of the seed cell) — attained —, or the
 // queue entry is flagged kNoSeed and appended to the second queue
+template <bool kIdx>
 __global__ __launch_bounds__(256) void nn_fit_seed_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range, uint32_t* __restrict__ pend,
                                                            const uint32_t* __restrict__ pend_cnt, float* __restrict__ sqd, uint32_t* __restrict__ pend2, uint32_t* __restrict__ pend2_cnt,
                                                            unsigned long long* __restrict__ stats)
@@ -781,7 +809,7 @@ __global__ __launch_bounds__(256) void nn_fit_seed_kernel(const NnFitnessJob* __
             qi = pend[off + k];
             const float4 p = load_point(J.src + qi);
             float x, y, z;
-            transform_point(J.T12, p.x, p.y, p.z, x, y, z);
+            nn_job_transform(J.T12, J.gicp_order, p.x, p.y, p.z, x, y, z);
             int c[3];
             nn_cell_of(g, x, y, z, c);  // queued queries are finite
             const float t[3] = {x - g.origin[0], y - g.origin[1], z - g.origin[2]};
@@ -848,9 +876,20 @@ __global__ __launch_bounds__(256) void nn_fit_seed_kernel(const NnFitnessJob* __
                 const uint32_t at = (static_cast<uint32_t>(sc[2]) * d0[1] + sc[1]) * d0[0] + sc[0];
                 const uint32_t kb = as_global(g.cell_start)[at], ke = as_global(g.cell_start)[at + 1];
                 float          best = sqd[off + qi];  // what the block gave (INFINITY: nothing)
-                for (uint32_t kk = kb; kk < ke; ++kk) {
-                    const float4 q = load_point(g.sorted + kk);
-                    best = fminf(best, sqdist3f(q.x, q.y, q.z, x, y, z));
+                if (kIdx) {
+                    int32_t bidx = J.idx_out[qi];
+                    for (uint32_t kk = kb; kk < ke; ++kk) {
+                        const float4  q = load_point(g.sorted + kk);
+                        const float   d = sqdist3f(q.x, q.y, q.z, x, y, z);
+                        const int32_t i = __float_as_int(q.w);
+                        if (bidx < 0 || d < best || (d == best && i < bidx)) { best = d; bidx = i; }
+                    }
+                    J.idx_out[qi] = bidx;
+                } else {
+                    for (uint32_t kk = kb; kk < ke; ++kk) {
+                        const float4 q = load_point(g.sorted + kk);
+                        best = fminf(best, sqdist3f(q.x, q.y, q.z, x, y, z));
+                    }
                 }
                 n_points += ke - kb;
                 sqd[off + qi] = best;
@@ -883,6 +922,7 @@ __global__ __launch_bounds__(256) void nn_fit_seed_kernel(const NnFitnessJob* __
     }
 }
 
+template <bool kIdx>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void nn_fit_sweep_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range,
                                                             const uint32_t* __restrict__ pend, const uint32_t* __restrict__ pend_cnt, float* __restrict__ sqd,
                                                             unsigned long long* __restrict__ stats, int clocks)
@@ -893,6 +933,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
     __shared__ int      s_c[3][kSweepQ];                    // their cells
     __shared__ int      s_L[3][kSweepQ], s_H[3][kSweepQ];   // the cube of half edge sqrt(lim at seed time), in cells
     __shared__ uint32_t s_lim[kSweepQ], s_best[kSweepQ];    // float bit patterns (>= 0: ordered like unsigned integers)
+    __shared__ unsigned long long s_key[kIdx ? kSweepQ : 1];  // kIdx: (distance bits, index) of the best point so far, instead of s_best
     __shared__ uint32_t s_bl[kSweepBrickCap];               // query | (brick - query's brick + 128) per axis << 8, 16, 24
     __shared__ uint32_t s_cl[kSweepCellCap];                // query << 24 | cell
     __shared__ float    s_clb[kSweepCellCap];               // the cell's box distance
@@ -940,7 +981,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
         if (mine) {
             const float4 p = load_point(J.src + qi);
             float x, y, z;
-            transform_point(J.T12, p.x, p.y, p.z, x, y, z);
+            nn_job_transform(J.T12, J.gicp_order, p.x, p.y, p.z, x, y, z);
             const float best = sqd[off + qi];  // attained (seed)
             nn_cell_of(g, x, y, z, c);
             t[0] = x - org[0];
@@ -958,6 +999,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
             }
             s_lim[tid] = __float_as_uint(lim);
             s_best[tid] = __float_as_uint(best);
+            if (kIdx) s_key[tid] = nn_key(best, J.idx_out[qi]);
             s_q[0][tid] = x;
             s_q[1][tid] = y;
             s_q[2][tid] = z;
@@ -1111,6 +1153,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
                         const float x = s_q[0][qj], y = s_q[1][qj], z = s_q[2][qj];
                         float       dm = INFINITY;
                         uint32_t    kk = kb[u];
+                        if (kIdx) {
+                            unsigned long long km = ~0ull;
+                            for (; kk + 4 <= ke[u]; kk += 4) {  // four loads in flight
+                                const float4 p0 = load_point(g.sorted + kk), p1 = load_point(g.sorted + kk + 1), p2 = load_point(g.sorted + kk + 2), p3 = load_point(g.sorted + kk + 3);
+                                const unsigned long long k0 = nn_key(sqdist3f(p0.x, p0.y, p0.z, x, y, z), __float_as_int(p0.w)), k1 = nn_key(sqdist3f(p1.x, p1.y, p1.z, x, y, z), __float_as_int(p1.w));
+                                const unsigned long long k2 = nn_key(sqdist3f(p2.x, p2.y, p2.z, x, y, z), __float_as_int(p2.w)), k3 = nn_key(sqdist3f(p3.x, p3.y, p3.z, x, y, z), __float_as_int(p3.w));
+                                const unsigned long long ka = k0 < k1 ? k0 : k1, kb2 = k2 < k3 ? k2 : k3, kc = ka < kb2 ? ka : kb2;
+                                km = kc < km ? kc : km;
+                            }
+                            for (; kk < ke[u]; ++kk) {
+                                const float4             pt = load_point(g.sorted + kk);
+                                const unsigned long long k1 = nn_key(sqdist3f(pt.x, pt.y, pt.z, x, y, z), __float_as_int(pt.w));
+                                km = k1 < km ? k1 : km;
+                            }
+                            ++n_cells;
+                            n_points += ke[u] - kb[u];
+                            const uint32_t db = static_cast<uint32_t>(km >> 32);  // a point AT the current radius may still win by its index
+                            if (db <= s_lim[qj]) {
+                                atomicMin(&s_key[qj], km);
+                                atomicMin(&s_lim[qj], db);
+                            }
+                            continue;
+                        }
                         for (; kk + 4 <= ke[u]; kk += 4) {  // four loads in flight
                             const float4 p0 = load_point(g.sorted + kk), p1 = load_point(g.sorted + kk + 1), p2 = load_point(g.sorted + kk + 2), p3 = load_point(g.sorted + kk + 3);
                             dm = fminf(fminf(dm, sqdist3f(p0.x, p0.y, p0.z, x, y, z)), sqdist3f(p1.x, p1.y, p1.z, x, y, z));
@@ -1138,8 +1203,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
         }
         // ================= results =================
         if (mine) {
-            const float best = __uint_as_float(s_best[tid]);
-            sqd[off + qi] = static_cast<double>(best) <= max_range ? best : kFitNone;
+            if (kIdx) {
+                const unsigned long long key = s_key[tid];
+                const float best = __uint_as_float(static_cast<uint32_t>(key >> 32));
+                const bool  hit = static_cast<double>(best) < max_range;
+                sqd[off + qi] = hit ? best : kFitNone;
+                J.idx_out[qi] = hit ? static_cast<int32_t>(static_cast<uint32_t>(key)) : -1;
+            } else {
+                const float best = __uint_as_float(s_best[tid]);
+                sqd[off + qi] = static_cast<double>(best) <= max_range ? best : kFitNone;
+            }
         }
         __syncthreads();
     }
@@ -1163,6 +1236,7 @@ constexpr int kFarGroup = MRGFE_FAR_GROUP;  // lanes per query in the far pass
 // seed (nothing within three blocks), or the whole queue with MRGFE_FIT_SWEEP=0 (the reference the sweep is tested against).
 // (Measured and dropped: two queues per job — queries the block gave a first distance from the front, queries with nothing around
 // them from the back — so that a wavefront of the far pass holds walks of one kind: far 19.5 -> 19.3 ms, block 2.7 -> 2.9 ms.)
+template <bool kIdx>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void nn_fit_far_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range, const uint32_t* __restrict__ pend,
                                                           const uint32_t* __restrict__ pend_cnt, float* __restrict__ sqd)
 {
@@ -1178,8 +1252,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
         const uint32_t i = pend[off + k];
         const float4   p = load_point(s_job.src + i);
         float x, y, z;
-        transform_point(s_job.T12, p.x, p.y, p.z, x, y, z);
+        nn_job_transform(s_job.T12, s_job.gicp_order, p.x, p.y, p.z, x, y, z);
         const float bound = sqd[off + i];  // what the earlier passes gave
+        if (kIdx) {  // the walk continues from the (index, distance) the earlier passes found, if any
+            int32_t bi = s_job.idx_out[i];
+            float   bd = bi >= 0 ? bound : INFINITY;
+            int     c[3];
+            nn_cell_of(s_job.grid.level[0], x, y, z, c);
+            nn_pyramid_walk<kFarGroup, false>(s_job.grid.level[0], x, y, z, c, sub, max_range, bi, bd);
+            if (sub == 0) {
+                const bool hit = bi >= 0 && static_cast<double>(bd) < max_range;
+                sqd[off + i] = hit ? bd : kFitNone;
+                s_job.idx_out[i] = hit ? bi : -1;
+            }
+            continue;
+        }
         int32_t bpos;
         float   bd;
         nn_far_search<kFarGroup>(s_job.grid, x, y, z, sub, max_range, bound, bpos, bd);
@@ -1259,6 +1346,56 @@ int nn_set_fit_stats(int mode)
     return fit_stats_mode();
 }
 
+int nn_nearest_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, double max_sq)
+{
+    if (count == 0) return MRGFE_OK;
+    if (count > 65535) { set_error("nn_nearest_batch: too many jobs"); return MRGFE_ERR_INVALID; }
+    hipStream_t st = ctx->stream;
+    std::vector<uint32_t> off(count + 1, 0u);
+    uint32_t max_n = 0;
+    for (size_t j = 0; j < count; ++j) {
+        if (uint64_t(off[j]) + jobs[j].n > 0xfffffff0ull) { set_error("nn_nearest_batch: more than 2^32 queries"); return MRGFE_ERR_INVALID; }
+        if (jobs[j].n && !jobs[j].idx_out) { set_error("nn_nearest_batch: job without an index array"); return MRGFE_ERR_INVALID; }
+        off[j + 1] = off[j] + jobs[j].n;
+        max_n = std::max(max_n, jobs[j].n);
+    }
+    const size_t total = off[count];
+    if (max_n == 0) return MRGFE_OK;
+    constexpr uint32_t per_blk = 256u / kBlockGroup;
+    const uint32_t want = static_cast<uint32_t>(std::max<size_t>(1, (size_t(ctx->cu_count) * 128 + count - 1) / count));
+    const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((max_n + per_blk - 1) / per_blk, want));
+    // the workspaces of nn_fitness_batch (scratch 9: jobs, offsets, queue lengths; 12: one float per query; 13: the two queues)
+    DevBuf &dw = ctx->scratch[9], &dq = ctx->scratch[12], &dp = ctx->scratch[13];
+    const size_t jobs_bytes = (sizeof(NnFitnessJob) * count + 255) & ~size_t(255);
+    const size_t off_bytes = (sizeof(uint32_t) * 3 * (count + 1) + 255) & ~size_t(255);
+    MRGFE_TRY(dw.ensure(jobs_bytes + off_bytes));
+    MRGFE_TRY(dq.ensure(sizeof(float) * total));
+    MRGFE_TRY(dp.ensure(sizeof(uint32_t) * 2 * total));
+    NnFitnessJob* d_jobs = dw.as<NnFitnessJob>();
+    uint32_t*     d_off = reinterpret_cast<uint32_t*>(dw.as<char>() + jobs_bytes);
+    uint32_t*     d_cnt = d_off + count + 1;
+    uint32_t*     d_pend[2] = {dp.as<uint32_t>(), dp.as<uint32_t>() + total};
+    uint32_t*     d_cnts[2] = {d_cnt, d_cnt + (count + 1)};
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_jobs, jobs, sizeof(NnFitnessJob) * count, hipMemcpyHostToDevice, st));
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_off, off.data(), sizeof(uint32_t) * (count + 1), hipMemcpyHostToDevice, st));
+    MRGFE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * 2 * (count + 1), st));
+    const dim3 grid(nblk, static_cast<uint32_t>(count));
+    hipLaunchKernelGGL(nn_fit_block_kernel<true>, grid, dim3(256), 0, st, d_jobs, d_off, max_sq, dq.as<float>(), d_pend[0], d_cnts[0]);
+    hipLaunchKernelGGL(nn_fit_seed_kernel<true>, grid, dim3(256), 0, st, d_jobs, d_off, max_sq, d_pend[0], d_cnts[0], dq.as<float>(), d_pend[1], d_cnts[1], static_cast<unsigned long long*>(nullptr));
+    // the unseeded queries' pyramid walk beside the sweep, as in nn_fitness_batch
+    if (!ctx->side) MRGFE_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    for (int e = 0; e < 4; ++e)
+        if (!ctx->ev_side[e]) MRGFE_HIP_CHECK((e == 1 || e == 2) ? hipEventCreate(&ctx->ev_side[e]) : hipEventCreateWithFlags(&ctx->ev_side[e], hipEventDisableTiming));
+    MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[0], st));
+    MRGFE_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev_side[0], 0));
+    hipLaunchKernelGGL(nn_fit_far_kernel<true>, grid, dim3(256), 0, ctx->side, d_jobs, d_off, max_sq, d_pend[1], d_cnts[1], dq.as<float>());
+    MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[3], ctx->side));
+    hipLaunchKernelGGL(nn_fit_sweep_kernel<true>, grid, dim3(256), 0, st, d_jobs, d_off, max_sq, d_pend[0], d_cnts[0], dq.as<float>(), static_cast<unsigned long long*>(nullptr), 0);
+    MRGFE_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_side[3], 0));
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
 int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, double max_range, double* out)
 {
     for (size_t j = 0; j < count; ++j) out[j] = DBL_MAX;
@@ -1305,10 +1442,10 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     const dim3 grid(nblk, static_cast<uint32_t>(count));
     bool       side_far = false;
     MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[0], st));
-    hipLaunchKernelGGL(nn_fit_block_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, dq.as<float>(), d_pend[0], d_cnts[0]);
+    hipLaunchKernelGGL(nn_fit_block_kernel<false>, grid, dim3(256), 0, st, d_jobs, d_off, max_range, dq.as<float>(), d_pend[0], d_cnts[0]);
     MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[1], st));
     if (sweep) {
-        hipLaunchKernelGGL(nn_fit_seed_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), d_pend[1], d_cnts[1], counters ? d_stats : nullptr);
+        hipLaunchKernelGGL(nn_fit_seed_kernel<false>, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), d_pend[1], d_cnts[1], counters ? d_stats : nullptr);
         // The unseeded queries (a few hundred of millions: nothing within three blocks) walk the pyramid, a handful of long dependent walks
         // that occupy a few wavefronts for ~0.25 ms: on a second stream beside the sweep, which leaves them alone (their queue entries are
         // flagged), instead of behind it.
@@ -1318,16 +1455,16 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[0], st));
         MRGFE_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev_side[0], 0));
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[1], ctx->side));
-        hipLaunchKernelGGL(nn_fit_far_kernel, grid, dim3(256), 0, ctx->side, d_jobs, d_off, max_range, d_pend[1], d_cnts[1], dq.as<float>());
+        hipLaunchKernelGGL(nn_fit_far_kernel<false>, grid, dim3(256), 0, ctx->side, d_jobs, d_off, max_range, d_pend[1], d_cnts[1], dq.as<float>());
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[2], ctx->side));
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[3], ctx->side));
-        hipLaunchKernelGGL(nn_fit_sweep_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), counters ? d_stats : nullptr, fit_stats_mode() > 1 ? 1 : 0);
+        hipLaunchKernelGGL(nn_fit_sweep_kernel<false>, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), counters ? d_stats : nullptr, fit_stats_mode() > 1 ? 1 : 0);
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[2], st));
         MRGFE_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_side[3], 0));
         side_far = true;
     } else {
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[2], st));
-        hipLaunchKernelGGL(nn_fit_far_kernel, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>());
+        hipLaunchKernelGGL(nn_fit_far_kernel<false>, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>());
     }
     MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[3], st));
     hipLaunchKernelGGL(nn_fit_sum_kernel, dim3(nblk_sum, static_cast<uint32_t>(count)), dim3(256), 0, st, d_jobs, d_off, dq.as<float>(), d_part);
@@ -1380,7 +1517,8 @@ NnFitnessJob NnGrid::make_fitness_job(const float4* d_src, size_t n_src, const f
     job.grid = h_;
     job.src = d_src;
     job.n = static_cast<uint32_t>(n_src);
-    job.pad = 0;
+    job.gicp_order = 0;
+    job.idx_out = nullptr;
     std::memcpy(job.T12, T, 48);
     return job;
 }

@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+timeout -k 10 600 python3 -m pytest tests/test_gpu_gicp.py -q -x -m gpu 2>&1 | tail -6 || exit 1
+for m in 0 1; do echo passes $m; MRGFE_GICP_CORR_PASSES=$m python3 profiles/gicp_profile.py batch 2>/dev/null | tail -1; MRGFE_GICP_CORR_PASSES=$m python3 profiles/gicp_profile.py frame 2>/dev/null | tail -1; done

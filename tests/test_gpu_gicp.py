@@ -353,3 +353,81 @@ def test_icp_exact_copy_limits_and_degenerate_inputs():
             x.align(np.eye(4))
         assert r.hasConverged() == o.hasConverged() and r.getFinalNumIteration() == o.getFinalNumIteration()
         np.testing.assert_allclose(r.getFinalTransformation(), o.getFinalTransformation(), atol=1e-5)
+
+
+@pytest.mark.parametrize("variant", ["fast", "small"])
+@pytest.mark.parametrize("max_corr", [0.3, 2.0, 1e3])
+def test_correspondence_passes_equal_the_lane_group_search(street_pair_vlp16, variant, max_corr):
+    """update_correspondences as the batched passes of getFitnessScore carrying the index (nn_nearest_batch: block / seed / sweep / pyramid walk)
+    against one lane group per query (gicp_corr_kernel) and against the oracle: the same correspondences, so the same linearisation to the
+    last bit, at poses near the truth and far from it (most queries then leave the block pass open), with a tight, the default and a huge
+    max_correspondence_distance; ties at equal distance go to the lowest index either way (a cloud matched against itself with duplicates)."""
+    from mrg_slam_amd import GicpHip, SmallGicpHip, synth
+    from mrg_slam_amd._lib import lib
+    from oracle import oracle as orc
+
+    tgt, src, rel = street_pair_vlp16
+    tgt = np.concatenate([tgt, tgt[::7]])  # duplicates: equal distances, different indices
+    cls, ocls = (GicpHip, orc.FastGicp) if variant == "fast" else (SmallGicpHip, orc.SmallGicp)
+    g = cls(transformation_epsilon=0.01, max_correspondence_distance=max_corr)
+    o = ocls(transformation_epsilon=0.01, num_threads=8, max_correspondence_distance=max_corr)
+    for r in (g, o):
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+    rng = np.random.default_rng(5)
+    poses = [rel, synth.perturb_pose(rel, rng), np.eye(4), synth.make_pose([6.0, -4.0, 0.5], synth.rot_xyz(0.02, 0.01, 0.4)), synth.make_pose([40.0, 25.0, 3.0], synth.rot_xyz(0, 0, 1.0))]
+    try:
+        for T in poses:
+            T = np.asarray(T, dtype=np.float64)
+            lib().mrgfe_dbg_set_gicp_corr_passes(0)
+            H0, b0, e0, n0 = g.linearize(T)
+            lib().mrgfe_dbg_set_gicp_corr_passes(2)
+            H1, b1, e1, n1 = g.linearize(T)
+            assert n1 == n0 and e1 == e0
+            np.testing.assert_array_equal(H1, H0)
+            np.testing.assert_array_equal(b1, b0)
+            eo, Ho, bo, no = o.linearize(T)
+            assert n1 == no
+            assert e1 == pytest.approx(eo, rel=1e-12)
+    finally:
+        lib().mrgfe_dbg_set_gicp_corr_passes(1)
+    # and a registration from start to end
+    lib().mrgfe_dbg_set_gicp_corr_passes(0)
+    try:
+        g.align(synth.perturb_pose(rel, np.random.default_rng(9)))
+        Ta, ia = g.getFinalTransformation().copy(), g.getFinalNumIteration()
+    finally:
+        lib().mrgfe_dbg_set_gicp_corr_passes(2)
+    try:
+        g.align(synth.perturb_pose(rel, np.random.default_rng(9)))
+    finally:
+        lib().mrgfe_dbg_set_gicp_corr_passes(1)
+    np.testing.assert_array_equal(g.getFinalTransformation(), Ta)
+    assert g.getFinalNumIteration() == ia
+
+
+def test_batch_correspondence_passes_equal_the_lane_group_search(street_pair_vlp16):
+    """The batched LM rounds with the correspondence passes forced on (mode 2; by default batches of >= 400k queries take them) and off: the same
+    records, bit for bit, for candidates near their answer and one far from it."""
+    from mrg_slam_amd import BatchMatcher, synth
+    from mrg_slam_amd._lib import SMALL_GICP_HIP, lib
+    from mrg_slam_amd.registration import default_params
+
+    tgt, src, rel = street_pair_vlp16
+    prm = default_params(SMALL_GICP_HIP)
+    prm.transformation_epsilon = 0.01
+    rng = np.random.default_rng(3)
+    guesses = [synth.perturb_pose(rel, rng) for _ in range(5)] + [np.eye(4), synth.make_pose([5.0, 3.0, 0.2], synth.rot_xyz(0, 0, 0.3))]
+    out = []
+    try:
+        for mode in (0, 2):
+            lib().mrgfe_dbg_set_gicp_corr_passes(mode)
+            bm = BatchMatcher(prm)
+            t = bm.add_target(tgt)
+            for k, gss in enumerate(guesses):
+                bm.add_pair(t, src[: len(src) - 100 * k], gss)
+            out.append(bm.align(fitness_max_range=float("inf")).copy())
+    finally:
+        lib().mrgfe_dbg_set_gicp_corr_passes(1)
+    for f in ("T", "H", "fitness", "converged", "iterations"):
+        np.testing.assert_array_equal(out[0][f], out[1][f], err_msg=f)
