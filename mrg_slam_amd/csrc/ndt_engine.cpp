@@ -121,7 +121,7 @@ int NdtEngine::set_guess(int pair, const float guess[16])
 // ------------------------------------------------------------------------------------------------------
 // target voxelisation
 // ------------------------------------------------------------------------------------------------------
-int NdtEngine::build_targets()
+int NdtEngine::build_targets(bool wait)
 {
     MRGFE_TRY(ctx_->bind());
     std::vector<int> todo;
@@ -301,7 +301,9 @@ int NdtEngine::build_targets()
     MRGFE_TRY(d_grids_.ensure(sizeof(NdtGridDev) * h_grids_.size()));
     // pageable source: the copy is staged by the runtime before the call returns
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_grids_.p, h_grids_.data(), sizeof(NdtGridDev) * h_grids_.size(), hipMemcpyHostToDevice, st));
-    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    // align_all goes on enqueueing behind the build on the same stream (its first host wait comes with the first round's plan); the pinned
+    // descriptor block is next written by the next build, which is behind that wait
+    if (wait) MRGFE_HIP_CHECK(hipStreamSynchronize(st));
     return MRGFE_OK;
 }
 
@@ -352,8 +354,8 @@ int NdtEngine::upload_pairs()
     MRGFE_TRY(h_evals_.ensure(sizeof(NdtEvalDev) * P1));
     MRGFE_TRY(h_states_.ensure(sizeof(NdtCtlState) * P1));
     MRGFE_TRY(h_results_.ensure(sizeof(double) * kNdtPartialStride * P1));
+    // (pageable source: staged by the runtime before the call returns — no wait, the rounds are enqueued behind the build and this copy)
     if (P) MRGFE_HIP_CHECK(hipMemcpyAsync(d_pairs_.p, h_pairs_.data(), sizeof(NdtPairDev) * P, hipMemcpyHostToDevice, ctx_->stream));
-    MRGFE_HIP_CHECK(hipStreamSynchronize(ctx_->stream));
     pairs_dirty_ = false;
     return MRGFE_OK;
 }
@@ -538,7 +540,7 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
     } port_guard{port};
     struct PhaseDump { ~PhaseDump() { static const bool on = std::getenv("MRGFE_PHASE") != nullptr; if (on) ndt_phase_dump(); } } phase_dump;  // diagnostic builds only
     MRGFE_TRY(ctx_->bind());
-    MRGFE_TRY(build_targets());
+    MRGFE_TRY(build_targets(false));
     if (pairs_dirty_) MRGFE_TRY(upload_pairs());
     for (int m = 0; m < 3; ++m) { mode_ms[m] = 0; mode_launches[m] = 0; mode_alg_bytes[m] = 0; mode_points[m] = 0; mode_neighbours[m] = 0; }
     rounds_ = 0;

@@ -63,7 +63,7 @@ class NdtEngine {
     int add_pair_device(int target, const void* d_xyzi, size_t n, const float guess_rowmajor[16]);
     int set_guess(int pair, const float guess_rowmajor[16]);
 
-    int build_targets();          // voxelise every target not yet built
+    int build_targets(bool wait = true);  // voxelise every target not yet built; `wait`: return with the stream drained
     int align_all(NdtSnapshotPort* port = nullptr);  // run every pair to completion (port: see NdtSnapshotPort; batches under device control only)
     // one derivative evaluation of pair `pair` (tests): mode 0/1/2
     int evaluate(int pair, const float T_rowmajor[16], const double p[6], int mode, double* score, double grad[6], double hess[36]);

@@ -653,7 +653,7 @@ __device__ __forceinline__ unsigned long long nn_key(float d, int32_t i) { retur
 constexpr int kBlockGroup = MRGFE_BLOCK_GROUP;  // lanes per query in the block pass
 // kIdx (all four passes): the correspondence search of nn_nearest_batch — the index of the nearest point is carried beside its distance
 // (ties: the lowest index) in the job's idx_out, a query counts when its squared distance is < max_range (fast_gicp's test) instead of <=.
-template <bool kIdx>
+template <bool kIdx, int G>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void nn_fit_block_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range, float* __restrict__ sqd,
                                                             uint32_t* __restrict__ pend, uint32_t* __restrict__ pend_cnt)
 {
@@ -664,8 +664,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void n
     __syncthreads();
     const NnGrid2Dev& g = s_job.grid;
     const uint32_t    n = s_job.n, off = job_off[blockIdx.y];
-    const int         sub = threadIdx.x % kBlockGroup;
-    constexpr uint32_t per_blk = 256u / kBlockGroup;
+    const int         sub = threadIdx.x % G;
+    constexpr uint32_t per_blk = 256u / G;
     auto flush = [&]() {  // called by the whole workgroup
         __syncthreads();
         const uint32_t np = s_np;
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void n
     const uint32_t i_end = min(n, (blockIdx.x + 1) * chunk);
     for (uint32_t i0 = blockIdx.x * chunk; i0 < i_end; i0 += per_blk) {  // uniform trip count
         if (s_np > kFitPendCap - per_blk) flush();  // s_np is stable here: the appends of the last trip are behind a barrier
-        const uint32_t i = i0 + threadIdx.x / kBlockGroup;
+        const uint32_t i = i0 + threadIdx.x / G;
         bool           queue = false;
         if (i < i_end) {
             const float4 p = load_point(s_job.src + i);
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void n
             int32_t bi = -1;
             float   bd = INFINITY;
             bool    done = true;
-            if (g.level[0].n != 0 && finite3(x, y, z)) done = nn_level_search<kBlockGroup>(g.level[0], x, y, z, sub, 1, max_range, bi, bd);
+            if (g.level[0].n != 0 && finite3(x, y, z)) done = nn_level_search<G>(g.level[0], x, y, z, sub, 1, max_range, bi, bd);
             // queued queries leave what the block gave (INFINITY: nothing) as the far pass's starting bound
             if (sub == 0) {
                 if (kIdx) {
@@ -762,7 +762,6 @@ __device__ __forceinline__ unsigned long long nn_range_mask(const int L[3], cons
     return static_cast<unsigned long long>(hi) << 32 | lo;
 }
 
-constexpr uint32_t kSweepQ = 256;          // queries per tile = lanes per workgroup
 constexpr uint32_t kSweepBrickCap = 1024;  // brick list entries
 constexpr uint32_t kSweepCellCap = 2048;   // cell list entries
 constexpr int      kSweepStats = 16;       // diagnostic counters (MRGFE_FIT_STATS)
@@ -922,21 +921,22 @@ __global__ __launch_bounds__(256) void nn_fit_seed_kernel(const NnFitnessJob* __
     }
 }
 
-template <bool kIdx>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void nn_fit_sweep_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range,
+template <bool kIdx, int kT>
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4))) void nn_fit_sweep_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range,
                                                             const uint32_t* __restrict__ pend, const uint32_t* __restrict__ pend_cnt, float* __restrict__ sqd,
                                                             unsigned long long* __restrict__ stats, int clocks)
 {
+    constexpr uint32_t kBrickCap = kSweepBrickCap * kT / 256, kCellCap = kSweepCellCap * kT / 256;  // list entries per tile of kT queries
     const uint32_t np = pend_cnt[blockIdx.y];
-    if (blockIdx.x * kSweepQ >= np) return;
-    __shared__ float    s_q[3][kSweepQ];                    // the transformed queries
-    __shared__ int      s_c[3][kSweepQ];                    // their cells
-    __shared__ int      s_L[3][kSweepQ], s_H[3][kSweepQ];   // the cube of half edge sqrt(lim at seed time), in cells
-    __shared__ uint32_t s_lim[kSweepQ], s_best[kSweepQ];    // float bit patterns (>= 0: ordered like unsigned integers)
-    __shared__ unsigned long long s_key[kIdx ? kSweepQ : 1];  // kIdx: (distance bits, index) of the best point so far, instead of s_best
-    __shared__ uint32_t s_bl[kSweepBrickCap];               // query | (brick - query's brick + 128) per axis << 8, 16, 24
-    __shared__ uint32_t s_cl[kSweepCellCap];                // query << 24 | cell
-    __shared__ float    s_clb[kSweepCellCap];               // the cell's box distance
+    if (blockIdx.x * static_cast<uint32_t>(kT) >= np) return;
+    __shared__ float    s_q[3][static_cast<uint32_t>(kT)];                    // the transformed queries
+    __shared__ int      s_c[3][static_cast<uint32_t>(kT)];                    // their cells
+    __shared__ int      s_L[3][static_cast<uint32_t>(kT)], s_H[3][static_cast<uint32_t>(kT)];   // the cube of half edge sqrt(lim at seed time), in cells
+    __shared__ uint32_t s_lim[static_cast<uint32_t>(kT)], s_best[static_cast<uint32_t>(kT)];    // float bit patterns (>= 0: ordered like unsigned integers)
+    __shared__ unsigned long long s_key[kIdx ? static_cast<uint32_t>(kT) : 1];  // kIdx: (distance bits, index) of the best point so far, instead of s_best
+    __shared__ uint32_t s_bl[kBrickCap];               // query | (brick - query's brick + 128) per axis << 8, 16, 24
+    __shared__ uint32_t s_cl[kCellCap];                // query << 24 | cell
+    __shared__ float    s_clb[kCellCap];               // the cell's box distance
     __shared__ uint32_t s_nb, s_nc;
     const NnFitnessJob& J = jobs[blockIdx.y];  // uniform: scalar loads
     const NnGridDev&    g = J.grid.level[0];
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
         return base + incl - cnt;
     };
     if (clocks && threadIdx.x == 0) tick = clock64();
-    for (uint32_t k0 = blockIdx.x * kSweepQ; k0 < np; k0 += gridDim.x * kSweepQ) {
+    for (uint32_t k0 = blockIdx.x * static_cast<uint32_t>(kT); k0 < np; k0 += gridDim.x * static_cast<uint32_t>(kT)) {
         // ================= the tile's queries (lane = query): lim as the seed left it, the cube it spans =================
         const uint32_t k = k0 + threadIdx.x;
         uint32_t qi = 0;
@@ -1054,8 +1054,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
                         }
                     }
                 }
-                uint32_t slot = reserve(static_cast<uint32_t>(__popcll(m1p)), &s_nb, kSweepBrickCap, full);
-                for (; m1p != 0ull && slot < kSweepBrickCap; ++slot) {  // what does not fit stays in m1p for the next round
+                uint32_t slot = reserve(static_cast<uint32_t>(__popcll(m1p)), &s_nb, kBrickCap, full);
+                for (; m1p != 0ull && slot < kBrickCap; ++slot) {  // what does not fit stays in m1p for the next round
                     const int b1 = __ffsll(m1p) - 1;
                     m1p &= m1p - 1ull;
                     const int bx = s1[0] + (b1 & 3), by = s1[1] + ((b1 >> 2) & 3), bz = s1[2] + (b1 >> 4);
@@ -1066,16 +1066,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
             __syncthreads();
             stamp(1);
             // ================= cells (lane = brick list entry) and points (lane = cell list entry) =================
-            const uint32_t nb = min(s_nb, kSweepBrickCap);
+            const uint32_t nb = min(s_nb, kBrickCap);
             if (threadIdx.x == 0) n_bricks += nb;
             // a lane's entries (its stride of the list: at most four) are independent: their occupancy words are requested together
-            constexpr int kEnt = kSweepBrickCap / 256;
+            constexpr int kEnt = kBrickCap / kT;
             uint32_t           ent[kEnt];
             unsigned long long wrd[kEnt];
             int                n_ent = 0, u_ent = 0;
 #pragma unroll
             for (int u = 0; u < kEnt; ++u) {
-                const uint32_t e = threadIdx.x + 256u * u;
+                const uint32_t e = threadIdx.x + static_cast<uint32_t>(kT) * u;
                 ent[u] = 0;
                 wrd[u] = 0ull;
                 if (e >= nb) continue;
@@ -1117,8 +1117,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
                             if (nn_child_lb(tq, o0[0] + (b0 & 3), o0[1] + ((b0 >> 2) & 3), o0[2] + (b0 >> 4), E0, h0) <= lim) m0p |= 1ull << b0;
                         }
                     }
-                    uint32_t slot = reserve(static_cast<uint32_t>(__popcll(m0p)), &s_nc, kSweepCellCap, cfull);
-                    for (; m0p != 0ull && slot < kSweepCellCap; ++slot) {  // what does not fit stays in m0p until the points phase has emptied the list
+                    uint32_t slot = reserve(static_cast<uint32_t>(__popcll(m0p)), &s_nc, kCellCap, cfull);
+                    for (; m0p != 0ull && slot < kCellCap; ++slot) {  // what does not fit stays in m0p until the points phase has emptied the list
                         const int b0 = __ffsll(m0p) - 1;
                         m0p &= m0p - 1ull;
                         const int cx = o0[0] + (b0 & 3), cy = o0[1] + ((b0 >> 2) & 3), cz = o0[2] + (b0 >> 4);
@@ -1128,16 +1128,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
                 }
                 __syncthreads();
                 stamp(2);
-                const uint32_t nc = min(s_nc, kSweepCellCap);
+                const uint32_t nc = min(s_nc, kCellCap);
                 if (threadIdx.x == 0) n_listed += nc;
                 {
                     // a lane's entries are independent: the table reads of all of them go out together, then their points (the phase is a chain of
                     // two memory round trips per entry otherwise, eight entries deep)
-                    constexpr int U = kSweepCellCap / 256;
+                    constexpr int U = kCellCap / kT;
                     uint32_t kb[U], ke[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
-                        const uint32_t j = threadIdx.x + 256u * u;
+                        const uint32_t j = threadIdx.x + static_cast<uint32_t>(kT) * u;
                         kb[u] = ke[u] = 0;
                         if (j >= nc) continue;
                         const uint32_t cj = s_cl[j];
@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         if (kb[u] == ke[u]) continue;
-                        const int   qj = static_cast<int>(s_cl[threadIdx.x + 256u * u] >> 24);
+                        const int   qj = static_cast<int>(s_cl[threadIdx.x + static_cast<uint32_t>(kT) * u] >> 24);
                         const float x = s_q[0][qj], y = s_q[1][qj], z = s_q[2][qj];
                         float       dm = INFINITY;
                         uint32_t    kk = kb[u];
@@ -1276,6 +1276,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
 }
 
 constexpr uint32_t kFitSumSlice = 1024;
+constexpr size_t   kFitSmallTotal = size_t(1) << 20;  // queries of a launch below which the passes run in their many-small-workgroups form
 // block partial = (sum, count) over queries [1024 b, 1024 (b + 1)) of the job: the slices and the order of the additions depend on
 // the job alone, not on the other jobs of the batch (a block past the job's end writes zeros, which add exactly), so a pair's
 // fitness score is the same whichever batch or rank it is matched in
@@ -1361,7 +1362,11 @@ int nn_nearest_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     }
     const size_t total = off[count];
     if (max_n == 0) return MRGFE_OK;
-    constexpr uint32_t per_blk = 256u / kBlockGroup;
+    // One or a few clouds do not fill the chip with a lane per query (130k queries: 507 workgroups in the block pass, two wavefronts per SIMD
+    // working through dependent loads): eight lanes per query then (161 -> 85 us).  (The sweep stays as it is: 64-query tiles made it slower,
+    // 244 -> 312 us per 130k-query cloud — a launch lasts as long as its widest tile either way.)
+    const bool     small = total < kFitSmallTotal;
+    const uint32_t per_blk = small ? 256u / 8u : 256u / kBlockGroup;
     const uint32_t want = static_cast<uint32_t>(std::max<size_t>(1, (size_t(ctx->cu_count) * 128 + count - 1) / count));
     const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((max_n + per_blk - 1) / per_blk, want));
     // the workspaces of nn_fitness_batch (scratch 9: jobs, offsets, queue lengths; 12: one float per query; 13: the two queues)
@@ -1380,7 +1385,8 @@ int nn_nearest_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_off, off.data(), sizeof(uint32_t) * (count + 1), hipMemcpyHostToDevice, st));
     MRGFE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * 2 * (count + 1), st));
     const dim3 grid(nblk, static_cast<uint32_t>(count));
-    hipLaunchKernelGGL(nn_fit_block_kernel<true>, grid, dim3(256), 0, st, d_jobs, d_off, max_sq, dq.as<float>(), d_pend[0], d_cnts[0]);
+    if (small) hipLaunchKernelGGL((nn_fit_block_kernel<true, 8>), grid, dim3(256), 0, st, d_jobs, d_off, max_sq, dq.as<float>(), d_pend[0], d_cnts[0]);
+    else       hipLaunchKernelGGL((nn_fit_block_kernel<true, kBlockGroup>), grid, dim3(256), 0, st, d_jobs, d_off, max_sq, dq.as<float>(), d_pend[0], d_cnts[0]);
     hipLaunchKernelGGL(nn_fit_seed_kernel<true>, grid, dim3(256), 0, st, d_jobs, d_off, max_sq, d_pend[0], d_cnts[0], dq.as<float>(), d_pend[1], d_cnts[1], static_cast<unsigned long long*>(nullptr));
     // the unseeded queries' pyramid walk beside the sweep, as in nn_fitness_batch
     if (!ctx->side) MRGFE_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
@@ -1390,7 +1396,7 @@ int nn_nearest_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     MRGFE_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev_side[0], 0));
     hipLaunchKernelGGL(nn_fit_far_kernel<true>, grid, dim3(256), 0, ctx->side, d_jobs, d_off, max_sq, d_pend[1], d_cnts[1], dq.as<float>());
     MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[3], ctx->side));
-    hipLaunchKernelGGL(nn_fit_sweep_kernel<true>, grid, dim3(256), 0, st, d_jobs, d_off, max_sq, d_pend[0], d_cnts[0], dq.as<float>(), static_cast<unsigned long long*>(nullptr), 0);
+    hipLaunchKernelGGL((nn_fit_sweep_kernel<true, 256>), grid, dim3(256), 0, st, d_jobs, d_off, max_sq, d_pend[0], d_cnts[0], dq.as<float>(), static_cast<unsigned long long*>(nullptr), 0);
     MRGFE_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_side[3], 0));
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
@@ -1411,7 +1417,11 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     }
     const size_t total = off[count];
     if (max_n == 0) return MRGFE_OK;
-    constexpr uint32_t per_blk = 256u / kBlockGroup;
+    // One or a few clouds do not fill the chip with a lane per query (130k queries: 507 workgroups in the block pass, two wavefronts per SIMD
+    // working through dependent loads): eight lanes per query then (161 -> 85 us).  (The sweep stays as it is: 64-query tiles made it slower,
+    // 244 -> 312 us per 130k-query cloud — a launch lasts as long as its widest tile either way.)
+    const bool     small = total < kFitSmallTotal;
+    const uint32_t per_blk = small ? 256u / 8u : 256u / kBlockGroup;
     // enough blocks to fill the chip many times over (the far pass is ragged), few enough that each has a few trips
     const uint32_t want = static_cast<uint32_t>(std::max<size_t>(1, (size_t(ctx->cu_count) * 128 + count - 1) / count));
     const uint32_t nblk = std::max<uint32_t>(1, std::min<uint32_t>((max_n + per_blk - 1) / per_blk, want));
@@ -1442,7 +1452,8 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     const dim3 grid(nblk, static_cast<uint32_t>(count));
     bool       side_far = false;
     MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[0], st));
-    hipLaunchKernelGGL(nn_fit_block_kernel<false>, grid, dim3(256), 0, st, d_jobs, d_off, max_range, dq.as<float>(), d_pend[0], d_cnts[0]);
+    if (small) hipLaunchKernelGGL((nn_fit_block_kernel<false, 8>), grid, dim3(256), 0, st, d_jobs, d_off, max_range, dq.as<float>(), d_pend[0], d_cnts[0]);
+    else       hipLaunchKernelGGL((nn_fit_block_kernel<false, kBlockGroup>), grid, dim3(256), 0, st, d_jobs, d_off, max_range, dq.as<float>(), d_pend[0], d_cnts[0]);
     MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[1], st));
     if (sweep) {
         hipLaunchKernelGGL(nn_fit_seed_kernel<false>, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), d_pend[1], d_cnts[1], counters ? d_stats : nullptr);
@@ -1458,7 +1469,7 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
         hipLaunchKernelGGL(nn_fit_far_kernel<false>, grid, dim3(256), 0, ctx->side, d_jobs, d_off, max_range, d_pend[1], d_cnts[1], dq.as<float>());
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[2], ctx->side));
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[3], ctx->side));
-        hipLaunchKernelGGL(nn_fit_sweep_kernel<false>, grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), counters ? d_stats : nullptr, fit_stats_mode() > 1 ? 1 : 0);
+        hipLaunchKernelGGL((nn_fit_sweep_kernel<false, 256>), grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), counters ? d_stats : nullptr, fit_stats_mode() > 1 ? 1 : 0);
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[2], st));
         MRGFE_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_side[3], 0));
         side_far = true;
