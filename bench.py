@@ -401,6 +401,7 @@ def main():
         for i, (a, _, _, _) in enumerate(loop_pairs):
             groups.setdefault(a, []).append(i)
 
+        group_keys, group_ids = list(groups.keys()), list(groups.values())
         tpos = {a: k for k, a in enumerate(my_targets)}
         shard_args = ([l_dev[a].data_ptr() for a in my_targets], [len(l_host[a]) for a in my_targets], np.array([tpos[loop_pairs[i][0]] for i in mine], dtype=np.int32),
                       [l_dev[loop_pairs[i][1]].data_ptr() for i in mine], [len(l_host[loop_pairs[i][1]]) for i in mine],
@@ -422,7 +423,7 @@ def main():
             full["pair_id"] = -1
             full[rec["pair_id"]] = rec
             # every rank replays the sequential best-candidate rule per new keyframe (loop_detector.cpp:126-145)
-            best = {a: lc.select_best(full[ids]) for a, ids in groups.items()}  # (with --shard-of the other ranks' records are missing: unconverged zeros)
+            best = dict(zip(group_keys, lc.select_best_groups(full, group_ids)))  # (with --shard-of the other ranks' records are missing: unconverged zeros)
             if phases is not None:
                 phases.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
             return full, best

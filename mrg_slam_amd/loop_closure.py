@@ -83,6 +83,41 @@ def select_best(records: np.ndarray):
     return best, best_score
 
 
+def select_best_groups(records: np.ndarray, groups):
+    """:func:`select_best` for many new keyframes at once: ``groups[g]`` = indices into ``records`` of keyframe g's candidates in candidate order.
+    Returns a list of (best position within the group or None, best score), the same values the sequential rule gives group by group — one
+    vectorised pass when no score is NaN (the rule's `score > best_score` lets a NaN through and then accepts everything after it: that case
+    is replayed group by group)."""
+    n_g = len(groups)
+    if n_g == 0:
+        return []
+    width = max(len(g) for g in groups)
+    if width == 0:
+        return [(None, np.finfo(np.float64).max)] * n_g
+    idx = np.zeros((n_g, width), dtype=np.int64)
+    valid = np.zeros((n_g, width), dtype=bool)
+    for k, g in enumerate(groups):
+        idx[k, : len(g)] = g
+        valid[k, : len(g)] = True
+    return _select_best_table(records, idx, valid, groups)
+
+
+def _select_best_table(records, idx, valid, groups):
+    fit = records["fitness"][idx].astype(np.float64)
+    ok = valid & (records["converged"][idx] != 0)
+    if np.isnan(fit[ok]).any():
+        return [select_best(records[np.asarray(g, dtype=np.int64)]) for g in groups]
+    big = np.finfo(np.float64).max
+    # candidates the rule can accept at all: converged and score <= the initial best_score (DBL_MAX): +inf never matches
+    ok &= fit <= big
+    score = np.where(ok, fit, np.inf)
+    best = score.min(axis=1)
+    hit = ok & (score == best[:, None])
+    last = idx.shape[1] - 1 - np.argmax(hit[:, ::-1], axis=1)  # among equal scores the LAST candidate wins
+    some = hit.any(axis=1)
+    return [(int(last[k]), float(best[k])) if some[k] else (None, big) for k in range(len(groups))]
+
+
 def match_candidates(matcher_factory, target_cloud, candidate_clouds, guesses, fitness_max_range=float("inf"), group=None, candidate_keys=None):
     """Distributed candidate matching for one new keyframe.
 

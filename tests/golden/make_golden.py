@@ -9,6 +9,7 @@ the HIP path against them on the GPU box.  Re-run only when the oracle is delibe
     python tests/golden/make_golden.py --small-gicp-only    # tests/golden/small_gicp.npz only
     python tests/golden/make_golden.py --vgicp-only         # tests/golden/vgicp.npz only
     python tests/golden/make_golden.py --icp-only           # tests/golden/icp.npz only
+    python tests/golden/make_golden.py --round3-only        # tests/golden/round3.npz only (pcl::GICP, pclomp::GICP, reciprocal ICP)
 """
 import os
 import sys
@@ -154,8 +155,34 @@ def icp():
     print(path, os.path.getsize(path), "bytes")
 
 
+def round3():
+    """tests/golden/round3.npz: the restated pcl::GeneralizedIterativeClosestPoint ("GICP") and pclomp::GICP ("GICP_OMP", the older stopping rule
+    of the inner BFGS), and pcl::IterativeClosestPoint with reciprocal correspondences, on the inputs of frontend_small.npz."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "frontend_small.npz"))
+    out = {}
+    for tag, omp in (("gicp", False), ("gicp_omp", True)):
+        g = orc.PclGicp(transformation_epsilon=0.01, omp=omp, num_threads=1)
+        g.setInputTarget(G["tgt"])
+        g.setInputSource(G["src"])
+        g.align(G["guess"])
+        out[f"{tag}_T"] = g.getFinalTransformation()
+        out[f"{tag}_meta"] = np.array([g.hasConverged(), g.getFinalNumIteration()], dtype=np.int64)
+        out[f"{tag}_src_cov"] = g.covariances("source")[:64]
+    g = orc.Icp(transformation_epsilon=0.01, use_reciprocal_correspondences=True)
+    g.setInputTarget(G["tgt"])
+    g.setInputSource(G["src"])
+    g.align(G["guess"])
+    out["icp_reciprocal_T"] = g.getFinalTransformation()
+    out["icp_reciprocal_meta"] = np.array([g.hasConverged(), g.getFinalNumIteration()], dtype=np.int64)
+    path = os.path.join(ROOT, "tests", "golden", "round3.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    if "--icp-only" in sys.argv:
+    if "--round3-only" in sys.argv:
+        round3()
+    elif "--icp-only" in sys.argv:
         icp()
     elif "--small-gicp-only" in sys.argv:
         small_gicp()
@@ -166,3 +193,4 @@ if __name__ == "__main__":
         small_gicp()
         vgicp()
         icp()
+        round3()

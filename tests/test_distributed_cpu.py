@@ -102,6 +102,30 @@ def test_select_best_replays_reference_semantics():
     r["converged"] = 0
     assert lc.select_best(r) == (None, np.finfo(np.float64).max)
     assert lc.select_best(r[:0]) == (None, np.finfo(np.float64).max)
+
+
+def test_select_best_groups_equals_the_sequential_rule_per_group():
+    """The vectorised pass over many new keyframes gives what select_best gives group by group: ragged and empty groups, equal scores, nothing
+    converged, DBL_MAX and +inf scores, and NaN scores (which the reference's comparison lets through: replayed sequentially)."""
+    from mrg_slam_amd import loop_closure as lc
+    from mrg_slam_amd.registration import RESULT_DTYPE
+
+    rng = np.random.default_rng(8)
+    for trial in range(40):
+        n = 60
+        r = np.zeros(n, dtype=RESULT_DTYPE)
+        r["fitness"] = rng.choice([0.1, 0.2, 0.2, 0.5, np.finfo(np.float64).max, np.inf], n)
+        r["converged"] = rng.random(n) < 0.7
+        if trial % 4 == 3:
+            r["fitness"][rng.integers(0, n, 3)] = np.nan
+        perm = rng.permutation(n)
+        cuts = np.sort(rng.choice(np.arange(n + 1), 9, replace=True))
+        groups = [list(perm[a:b]) for a, b in zip(np.concatenate([[0], cuts]), np.concatenate([cuts, [n]]))]
+        got = lc.select_best_groups(r, groups)
+        exp = [lc.select_best(r[np.asarray(g, dtype=np.int64)]) for g in groups]
+        assert len(got) == len(exp)
+        for (gi, gs), (ei, es) in zip(got, exp):
+            assert gi == ei and (gs == es or (np.isnan(gs) and np.isnan(es)))
     # single process (no process group): gather is the identity
     t = _fake_records(9)
     np.testing.assert_array_equal(lc.gather_records(t[::-1].copy(), 9), t)

@@ -109,6 +109,28 @@ def test_oracle_icp_reproduces_golden():
     assert np.linalg.norm(I["identity_T"][:3, 3] - G["rel"][:3, 3]) < 0.02
 
 
+def test_oracle_round3_methods_reproduce_golden():
+    """pcl::GICP, pclomp::GICP and reciprocal ICP (tests/golden/round3.npz)."""
+    from oracle import oracle as orc
+
+    R = np.load(os.path.join(os.path.dirname(__file__), "golden", "round3.npz"))
+    for tag, omp in (("gicp", False), ("gicp_omp", True)):
+        g = orc.PclGicp(transformation_epsilon=0.01, omp=omp, num_threads=1)
+        g.setInputTarget(G["tgt"])
+        g.setInputSource(G["src"])
+        g.align(G["guess"])
+        np.testing.assert_array_equal(g.getFinalTransformation(), R[f"{tag}_T"])
+        assert [int(g.hasConverged()), g.getFinalNumIteration()] == R[f"{tag}_meta"].tolist()
+        np.testing.assert_array_equal(g.covariances("source")[:64], R[f"{tag}_src_cov"])
+    g = orc.Icp(transformation_epsilon=0.01, use_reciprocal_correspondences=True)
+    g.setInputTarget(G["tgt"])
+    g.setInputSource(G["src"])
+    g.align(G["guess"])
+    np.testing.assert_array_equal(g.getFinalTransformation(), R["icp_reciprocal_T"])
+    assert [int(g.hasConverged()), g.getFinalNumIteration()] == R["icp_reciprocal_meta"].tolist()
+    assert np.linalg.norm(R["gicp_T"][:3, 3] - G["rel"][:3, 3]) < 2e-3
+
+
 def test_oracle_perpoint_passes_reproduce_golden():
     from oracle import oracle as orc
 
@@ -225,6 +247,31 @@ def test_hip_icp_matches_golden():
         assert np.linalg.norm(T[:3, 3].astype(np.float64) - I[f"{tag}_T"][:3, 3]) <= 1e-4
         assert synth.rotation_angle(T, I[f"{tag}_T"]) <= 1e-4
         assert [int(g.hasConverged()), g.getFinalNumIteration()] == I[f"{tag}_meta"].tolist()
+
+
+@pytest.mark.gpu
+def test_hip_round3_methods_match_golden():
+    from mrg_slam_amd import IcpHip, PclGicpHip, synth
+
+    R = np.load(os.path.join(os.path.dirname(__file__), "golden", "round3.npz"))
+    for tag, omp in (("gicp", False), ("gicp_omp", True)):
+        g = PclGicpHip(transformation_epsilon=0.01, omp=omp)
+        g.setInputTarget(G["tgt"])
+        g.setInputSource(G["src"])
+        g.align(G["guess"])
+        T = g.getFinalTransformation()
+        assert np.linalg.norm(T[:3, 3].astype(np.float64) - R[f"{tag}_T"][:3, 3]) <= 1e-4
+        assert synth.rotation_angle(T, R[f"{tag}_T"]) <= 1e-4
+        assert [int(g.hasConverged()), g.getFinalNumIteration()] == R[f"{tag}_meta"].tolist()
+        np.testing.assert_allclose(g.covariances("source")[:64], R[f"{tag}_src_cov"], rtol=0, atol=1e-12)
+    g = IcpHip(transformation_epsilon=0.01, use_reciprocal_correspondences=True)
+    g.setInputTarget(G["tgt"])
+    g.setInputSource(G["src"])
+    g.align(G["guess"])
+    T = g.getFinalTransformation()
+    assert np.linalg.norm(T[:3, 3].astype(np.float64) - R["icp_reciprocal_T"][:3, 3]) <= 1e-4
+    assert synth.rotation_angle(T, R["icp_reciprocal_T"]) <= 1e-4
+    assert [int(g.hasConverged()), g.getFinalNumIteration()] == R["icp_reciprocal_meta"].tolist()
 
 
 @pytest.mark.gpu
