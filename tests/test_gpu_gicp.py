@@ -431,3 +431,29 @@ def test_batch_correspondence_passes_equal_the_lane_group_search(street_pair_vlp
         lib().mrgfe_dbg_set_gicp_corr_passes(1)
     for f in ("T", "H", "fitness", "converged", "iterations"):
         np.testing.assert_array_equal(out[0][f], out[1][f], err_msg=f)
+
+
+def test_batch_correspondence_passes_with_empty_clouds():
+    """Empty source clouds and an empty target go through the correspondence passes like through the lane-group search: the same records."""
+    from mrg_slam_amd import BatchMatcher, synth
+    from mrg_slam_amd._lib import SMALL_GICP_HIP, lib
+    from mrg_slam_amd.registration import default_params
+
+    tgt, src, rel = _pair(1500, 31)
+    empty = np.zeros((0, 4), dtype=np.float32)
+    prm = default_params(SMALL_GICP_HIP)
+    out = []
+    try:
+        for mode in (0, 2):
+            lib().mrgfe_dbg_set_gicp_corr_passes(mode)
+            bm = BatchMatcher(prm)
+            t0, t1 = bm.add_target(tgt), bm.add_target(empty)
+            bm.add_pair(t0, src, rel)
+            bm.add_pair(t0, empty, np.eye(4))
+            bm.add_pair(t1, src, np.eye(4))
+            bm.add_pair(t0, src[:700], synth.perturb_pose(rel, np.random.default_rng(1)))
+            out.append(bm.align(fitness_max_range=-1.0).copy())
+    finally:
+        lib().mrgfe_dbg_set_gicp_corr_passes(1)
+    for f in ("T", "H", "converged", "iterations"):
+        np.testing.assert_array_equal(out[0][f], out[1][f], err_msg=f)

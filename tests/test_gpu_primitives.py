@@ -150,3 +150,24 @@ def test_grid_set_members_answer_like_single_grids(ctx, k):
                 si, sd = knn(c, q, k, ctx=ctx)
                 np.testing.assert_array_equal(idx[m], si)
                 np.testing.assert_array_equal(sqd[m], sd)
+
+
+@pytest.mark.parametrize("k", [1, 4])
+def test_grid_set_degenerate_sets(ctx, k):
+    """A set of one cloud, a set of empty clouds only, a set whose clouds hold nothing but non-finite points, one point per cloud."""
+    from mrg_slam_amd.filters import grid_set_query
+
+    rng = np.random.default_rng(7)
+    q = rng.uniform(-5, 5, (50, 4)).astype(np.float32)
+    one = np.zeros((300, 4), dtype=np.float32)
+    one[:, :3] = rng.uniform(-4, 4, (300, 3))
+    nan_only = np.full((5, 4), np.nan, dtype=np.float32)
+    single = np.zeros((1, 4), dtype=np.float32)
+    single[0, :3] = [1.0, 2.0, 3.0]
+    for clouds in ([one], [np.zeros((0, 4), dtype=np.float32)] * 3, [nan_only, nan_only], [single, single + 1.0], [one, nan_only, single]):
+        idx, sqd = grid_set_query(clouds, q, k, rounds=2, ctx=ctx)
+        for m, c in enumerate(clouds):
+            bi, bd = _brute_knn(c, q, k)
+            np.testing.assert_array_equal(idx[m], bi)
+            ok = bi >= 0
+            np.testing.assert_array_equal(sqd[m][ok], bd[ok])
