@@ -47,8 +47,9 @@ int radix_sort_pairs(mrgfe_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, uint32_
 // exclusive prefix sum of uint32 per problem; d_totals[p] = sum. d_blk needs total_blks words. in == out allowed.
 int exclusive_scan(mrgfe_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, const Slice* d_slices, const SliceTable& t, uint32_t* d_blk, uint32_t* d_totals);
 
-// run heads of a sorted key array: d_flags[i] = 1 if i starts a run of equal keys among the first d_n_valid[p]
-// elements of problem p (the invalid keys sort behind them), else 0.
-int mark_run_heads(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, uint32_t* d_flags, const Slice* d_slices, const SliceTable& t, const uint32_t* d_n_valid);
+// run heads of a sorted key array: element i starts a run of equal keys among the first d_n_valid[p] elements of problem p (the invalid
+// keys sort behind them).  d_out[i] = number of run heads before element i (the ordinal of i's run when i is a head), d_totals[p] = runs.
+int exclusive_scan_run_heads(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, uint32_t* d_out, const Slice* d_slices, const SliceTable& t, const uint32_t* d_n_valid, uint32_t* d_blk,
+                             uint32_t* d_totals);
 
 }  // namespace mrgfe

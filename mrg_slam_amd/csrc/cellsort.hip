@@ -322,28 +322,64 @@ int exclusive_scan(mrgfe_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, const 
 // ------------------------------------------------------------------------------------------------------
 // run heads
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void run_heads_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ flags, const Slice* __restrict__ slices, const uint32_t* __restrict__ n_valid)
+// Exclusive scan of the run-head flags of a sorted key array (flag i = 1 iff i starts a run of equal keys among the first n_valid elements; the
+// invalid keys sort behind them) without a flag array: both scan kernels read the keys and compare neighbours.  (Round 2 marked the heads
+// in a kernel of their own and scanned the flags: one launch and 4 bytes per element more.)
+__device__ __forceinline__ uint32_t run_head(const uint32_t* __restrict__ keys, uint32_t i, uint32_t nv) { return i < nv && (i == 0 || keys[i - 1] != keys[i]) ? 1u : 0u; }
+
+__global__ __launch_bounds__(256) void scan_heads_tile_sum_kernel(const uint32_t* __restrict__ keys, const Slice* __restrict__ slices, const uint32_t* __restrict__ n_valid, uint32_t* __restrict__ blk)
 {
     const Slice s = slices[blockIdx.y];
     if (blockIdx.x >= s.nblk) return;
-    const uint32_t base = blockIdx.x * kTile;
-    const uint32_t nv = n_valid[blockIdx.y];
+    const uint32_t base = blockIdx.x * kTile, nv = n_valid[blockIdx.y];
+    const uint32_t* __restrict__ k0 = keys + s.off;
+    uint32_t acc = 0;
 #pragma unroll
     for (int k = 0; k < kTile / 256; ++k) {
-        uint32_t i = base + k * 256 + threadIdx.x;
-        if (i < s.n) {
-            uint32_t f = 0;
-            if (i < nv) f = (i == 0) ? 1u : (keys[s.off + i - 1] != keys[s.off + i] ? 1u : 0u);
-            flags[s.off + i] = f;
-        }
+        const uint32_t i = base + k * 256 + threadIdx.x;
+        if (i < s.n) acc += run_head(k0, i, nv);
     }
+    __shared__ uint32_t sw[4];
+    acc = wave_sum(acc);
+    if (lane_id() == 0) sw[wave_id()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[s.blk_off + blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
 }
 
-int mark_run_heads(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, uint32_t* d_flags, const Slice* d_slices, const SliceTable& t, const uint32_t* d_n_valid)
+__global__ __launch_bounds__(256) void scan_heads_apply_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ out, const Slice* __restrict__ slices, const uint32_t* __restrict__ n_valid,
+                                                                const uint32_t* __restrict__ blk)
 {
-    if (t.nprob() == 0 || t.max_blks == 0) return MRGFE_OK;
-    dim3 grid(t.max_blks, t.nprob());
-    hipLaunchKernelGGL(run_heads_kernel, grid, dim3(256), 0, ctx->stream, d_sorted_keys, d_flags, d_slices, d_n_valid);
+    const Slice s = slices[blockIdx.y];
+    if (blockIdx.x >= s.nblk) return;
+    __shared__ uint32_t lds[8];
+    const uint32_t nv = n_valid[blockIdx.y];
+    const uint32_t* __restrict__ k0 = keys + s.off;
+    const uint32_t first = blockIdx.x * kTile + threadIdx.x * 8;
+    uint32_t kk[9];  // the thread's eight keys and the one before them
+    kk[0] = (first > 0 && first - 1 < s.n) ? k0[first - 1] : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) kk[k + 1] = (first + k < s.n) ? k0[first + k] : 0u;
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (first + k < nv && (first + k == 0 || kk[k] != kk[k + 1])) ? 1u : 0u;
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { uint32_t t = v[k]; v[k] = tsum; tsum += t; }
+    uint32_t total;
+    const uint32_t pre = block_exclusive_scan<256>(tsum, lds, &total) + blk[s.blk_off + blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (first + k < s.n) out[s.off + first + k] = v[k] + pre;
+}
+
+int exclusive_scan_run_heads(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, uint32_t* d_out, const Slice* d_slices, const SliceTable& t, const uint32_t* d_n_valid, uint32_t* d_blk,
+                             uint32_t* d_totals)
+{
+    if (t.nprob() == 0) return MRGFE_OK;
+    dim3 grid(t.max_blks ? t.max_blks : 1, t.nprob());
+    if (t.max_blks) hipLaunchKernelGGL(scan_heads_tile_sum_kernel, grid, dim3(256), 0, ctx->stream, d_sorted_keys, d_slices, d_n_valid, d_blk);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(t.nprob()), dim3(256), 0, ctx->stream, d_slices, d_blk, d_totals);
+    if (t.max_blks) hipLaunchKernelGGL(scan_heads_apply_kernel, grid, dim3(256), 0, ctx->stream, d_sorted_keys, d_out, d_slices, d_n_valid, d_blk);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }

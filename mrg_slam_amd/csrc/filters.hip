@@ -152,18 +152,16 @@ int filter_voxelgrid_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, float 
     MRGFE_HIP_CHECK(hipMemcpyAsync(d_desc, hd, sizeof(Desc), hipMemcpyHostToDevice, st));
     int key_bits = 1;
     while (key_bits < 32 && (uint64_t(1) << key_bits) <= hd->vp.n_cells) ++key_bits;
-    DevBuf &dk = ctx->scratch[2], &dv = ctx->scratch[3], &dkt = ctx->scratch[4], &dvt = ctx->scratch[5], &dh = ctx->scratch[6], &dfl = ctx->scratch[7], &dblk = ctx->scratch[8];
+    DevBuf &dk = ctx->scratch[2], &dv = ctx->scratch[3], &dkt = ctx->scratch[4], &dvt = ctx->scratch[5], &dh = ctx->scratch[6], &dblk = ctx->scratch[8];
     MRGFE_TRY(dk.ensure(n * 4)); MRGFE_TRY(dv.ensure(n * 4)); MRGFE_TRY(dkt.ensure(n * 4)); MRGFE_TRY(dvt.ensure(n * 4));
     MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + 1)));
-    MRGFE_TRY(dfl.ensure(n * 4));
     MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (tab.total_blks + 8)));
     MRGFE_TRY(ndt_launch_cellkeys(ctx, &d_desc->cp, &d_desc->sl, tab, &d_desc->vp, dk.as<uint32_t>(), dv.as<uint32_t>()));
     uint32_t *sk, *sv;
     MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), &d_desc->sl, tab, key_bits, dh.as<uint32_t>(), &sk, &sv));
-    MRGFE_TRY(mark_run_heads(ctx, sk, dfl.as<uint32_t>(), &d_desc->sl, tab, &d_desc->nv));
     uint32_t* d_ord = (sk == dk.as<uint32_t>()) ? dkt.as<uint32_t>() : dk.as<uint32_t>();
     uint32_t* d_tot = dblk.as<uint32_t>() + tab.total_blks;
-    MRGFE_TRY(exclusive_scan(ctx, dfl.as<uint32_t>(), d_ord, &d_desc->sl, tab, dblk.as<uint32_t>(), d_tot));
+    MRGFE_TRY(exclusive_scan_run_heads(ctx, sk, d_ord, &d_desc->sl, tab, &d_desc->nv, dblk.as<uint32_t>(), d_tot));
     uint32_t* h_tot = reinterpret_cast<uint32_t*>(hp.as<char>() + sizeof(Desc) + sizeof(BBox));
     MRGFE_HIP_CHECK(hipMemcpyAsync(h_tot, d_tot, 4, hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
@@ -180,7 +178,7 @@ int filter_voxelgrid_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, float 
     MRGFE_TRY(dkeep.ensure(sizeof(uint32_t) * size_t(V)));
     uint32_t* d_seg = dseg.as<uint32_t>();
     int32_t*  d_segkey = reinterpret_cast<int32_t*>(d_seg + V + 4);
-    MRGFE_TRY(ndt_launch_segments(ctx, sk, dfl.as<uint32_t>(), d_ord, &d_desc->sl, tab, &d_desc->ls, d_seg, d_segkey));
+    MRGFE_TRY(ndt_launch_segments(ctx, sk, d_ord, &d_desc->sl, tab, &d_desc->ls, d_seg, d_segkey));
     hipLaunchKernelGGL(voxel_centroid_kernel, dim3((V + 255) / 256), dim3(256), 0, st, d_in, sv, d_seg, V, min_pts, dcent.as<float4>(), dkeep.as<uint32_t>());
     MRGFE_HIP_CHECK(hipGetLastError());
     uint32_t kept = 0;

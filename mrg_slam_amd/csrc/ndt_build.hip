@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void ndt_cellkey_kernel(const float4* const* _
 
 // run heads -> seg_start[leaf] (position in the sorted arrays) and seg_key[leaf]; the thread that sees the last valid
 // element also writes the sentinel seg_start[V] = n_valid.
-__global__ __launch_bounds__(256) void ndt_segments_kernel(const uint32_t* __restrict__ sorted_keys, const uint32_t* __restrict__ flags,
+__global__ __launch_bounds__(256) void ndt_segments_kernel(const uint32_t* __restrict__ sorted_keys,
                                                             const uint32_t* __restrict__ ordinal, const Slice* __restrict__ slices,
                                                             const LeafSlice* __restrict__ leaf_slices, uint32_t* __restrict__ seg_start, int32_t* __restrict__ seg_key)
 {
@@ -56,10 +56,11 @@ __global__ __launch_bounds__(256) void ndt_segments_kernel(const uint32_t* __res
     for (int k = 0; k < kTile / 256; ++k) {
         const uint32_t i = base + k * 256 + threadIdx.x;
         if (i < s.n) {
-            if (flags[s.off + i]) {
+            const uint32_t key = sorted_keys[s.off + i];
+            if (i < ls.n_valid && (i == 0 || sorted_keys[s.off + i - 1] != key)) {  // a run head
                 const uint32_t o = ordinal[s.off + i];
                 seg_start[ls.seg_off + o] = i;
-                seg_key[ls.leaf_off + o] = static_cast<int32_t>(sorted_keys[s.off + i]);
+                seg_key[ls.leaf_off + o] = static_cast<int32_t>(key);
             }
             if (i + 1 == ls.n_valid) seg_start[ls.seg_off + ls.n_leaves] = ls.n_valid;
         }
@@ -367,11 +368,11 @@ int ndt_launch_cellkeys(mrgfe_ctx* ctx, const float4* const* d_clouds, const Sli
     return MRGFE_OK;
 }
 
-int ndt_launch_segments(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, const uint32_t* d_flags, const uint32_t* d_ordinal, const Slice* d_slices, const SliceTable& t,
+int ndt_launch_segments(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, const uint32_t* d_ordinal, const Slice* d_slices, const SliceTable& t,
                         const LeafSlice* d_leaf_slices, uint32_t* d_seg_start, int32_t* d_seg_key)
 {
     if (t.nprob() == 0 || t.max_blks == 0) return MRGFE_OK;
-    hipLaunchKernelGGL(ndt_segments_kernel, dim3(t.max_blks, t.nprob()), dim3(256), 0, ctx->stream, d_sorted_keys, d_flags, d_ordinal, d_slices, d_leaf_slices,
+    hipLaunchKernelGGL(ndt_segments_kernel, dim3(t.max_blks, t.nprob()), dim3(256), 0, ctx->stream, d_sorted_keys, d_ordinal, d_slices, d_leaf_slices,
                        d_seg_start, d_seg_key);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;

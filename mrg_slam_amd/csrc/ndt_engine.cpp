@@ -199,20 +199,17 @@ int NdtEngine::build_targets(bool wait)
 
     // 3. keys, stable sort, run heads, ordinals
     const size_t ne = std::max<size_t>(tab.total_elems, 4);
-    DevBuf &dk = ctx_->scratch[2], &dv = ctx_->scratch[3], &dkt = ctx_->scratch[4], &dvt = ctx_->scratch[5], &dh = ctx_->scratch[6], &dfl = ctx_->scratch[7], &dblk = ctx_->scratch[8];
+    DevBuf &dk = ctx_->scratch[2], &dv = ctx_->scratch[3], &dkt = ctx_->scratch[4], &dvt = ctx_->scratch[5], &dh = ctx_->scratch[6], &dblk = ctx_->scratch[8];
     MRGFE_TRY(dk.ensure(ne * 4)); MRGFE_TRY(dv.ensure(ne * 4)); MRGFE_TRY(dkt.ensure(ne * 4)); MRGFE_TRY(dvt.ensure(ne * 4));
     MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + P)));
-    MRGFE_TRY(dfl.ensure(ne * 4));
     MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (tab.total_blks + P + 4)));
     MRGFE_TRY(ndt_launch_cellkeys(ctx_, d_cp, d_sl, tab, d_vp, dk.as<uint32_t>(), dv.as<uint32_t>()));
     uint32_t *sk = nullptr, *sv = nullptr;
     MRGFE_TRY(radix_sort_pairs(ctx_, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), d_sl, tab, key_bits, dh.as<uint32_t>(), &sk, &sv));
-    MRGFE_TRY(mark_run_heads(ctx_, sk, dfl.as<uint32_t>(), d_sl, tab, d_nv));
-    // flags stay in dfl; ordinals go to the unused sort buffer
-    uint32_t* d_flags = dfl.as<uint32_t>();
+    // run heads of the sorted keys -> ordinals (the voxel's leaf index at its first point), into the unused sort buffer
     uint32_t* d_ord = (sk == dk.as<uint32_t>()) ? dkt.as<uint32_t>() : dk.as<uint32_t>();
     uint32_t* d_tot = dblk.as<uint32_t>() + tab.total_blks;
-    MRGFE_TRY(exclusive_scan(ctx_, d_flags, d_ord, d_sl, tab, dblk.as<uint32_t>(), d_tot));
+    MRGFE_TRY(exclusive_scan_run_heads(ctx_, sk, d_ord, d_sl, tab, d_nv, dblk.as<uint32_t>(), d_tot));
     MRGFE_HIP_CHECK(hipMemcpyAsync(h_tot, d_tot, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
 
@@ -267,7 +264,7 @@ int NdtEngine::build_targets(bool wait)
     MRGFE_HIP_CHECK(hipMemcpyAsync(dd + o_ls, hd + o_ls, sizeof(LeafSlice) * P, hipMemcpyHostToDevice, st));
 
     // 5. segments and leaves
-    MRGFE_TRY(ndt_launch_segments(ctx_, sk, d_flags, d_ord, d_sl, tab, d_ls, dseg.as<uint32_t>(), static_cast<int32_t*>(p_keys)));
+    MRGFE_TRY(ndt_launch_segments(ctx_, sk, d_ord, d_sl, tab, d_ls, dseg.as<uint32_t>(), static_cast<int32_t*>(p_keys)));
     MRGFE_TRY(ndt_launch_leaves(ctx_, d_cp, sv, d_sl, tab, d_ls, d_vp, max_leaves, dseg.as<uint32_t>(), dseg.as<uint32_t>() + seg_words, dseg.as<uint32_t>() + seg_words + P,
                                 static_cast<const int32_t*>(p_keys), dsum.as<double>(),
                                 static_cast<NdtLeafRec*>(p_leaves), static_cast<double*>(p_icov), static_cast<float4*>(p_cent), static_cast<int32_t*>(p_npts), p_lookup));
