@@ -41,8 +41,11 @@ int bounding_boxes(mrgfe_ctx* ctx, const float4* const* d_clouds, const Slice* d
 
 // stable LSD radix sort by the low `key_bits` bits. Buffers ping-pong; *out_keys/*out_vals point at the sorted data
 // (either the input or the tmp buffers). d_hist needs (total_blks + nprob) * 256 words.
+// `iota_vals`: the values are the element indices 0 .. n-1 of each problem and d_vals need not be filled (the first pass makes them up);
+// `first_hist_ready`: d_hist already holds the per-tile histograms of the lowest digit in rs_hist_kernel's layout, [tile][256] (the kernel
+// that made the keys counted them while it had them in registers).
 int radix_sort_pairs(mrgfe_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, uint32_t* d_keys_tmp, uint32_t* d_vals_tmp, const Slice* d_slices,
-                     const SliceTable& t, int key_bits, uint32_t* d_hist, uint32_t** out_keys, uint32_t** out_vals);
+                     const SliceTable& t, int key_bits, uint32_t* d_hist, uint32_t** out_keys, uint32_t** out_vals, bool iota_vals = false, bool first_hist_ready = false);
 
 // exclusive prefix sum of uint32 per problem; d_totals[p] = sum. d_blk needs total_blks words. in == out allowed.
 int exclusive_scan(mrgfe_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, const Slice* d_slices, const SliceTable& t, uint32_t* d_blk, uint32_t* d_totals);

@@ -180,6 +180,8 @@ __global__ __launch_bounds__(256) void rs_scan_kernel(const Slice* __restrict__ 
 
 // pass 3: stable scatter. The tile is consumed in 8 rounds of 256 keys; inside a round the rank of a key among equal
 // digits is (keys of earlier rounds) + (keys of earlier waves) + (lower lanes of its own wave, by ballot matching).
+// kIota: the values are the element indices 0 .. n-1 of the problem (first pass of a sort of (key, index) pairs: nobody has to write or read them)
+template <bool kIota>
 __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t* __restrict__ keys_out,
                                                           uint32_t* __restrict__ vals_out, const Slice* __restrict__ slices, const uint32_t* __restrict__ hist,
                                                           const uint32_t* __restrict__ digit_base, int shift)
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint32_t* __restr
         const uint32_t i = base + k * 256 + threadIdx.x;
         const bool     valid = i < s.n;
         uint32_t key = 0, val = 0;
-        if (valid) { key = keys[s.off + i]; val = vals[s.off + i]; }
+        if (valid) { key = keys[s.off + i]; val = kIota ? i : vals[s.off + i]; }
         const uint32_t d = (key >> shift) & 255u;
         const uint64_t active = __ballot(valid);
         const uint64_t m = wave_match_digit8(d, active);
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint32_t* __restr
 }
 
 int radix_sort_pairs(mrgfe_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, uint32_t* d_keys_tmp, uint32_t* d_vals_tmp, const Slice* d_slices, const SliceTable& t,
-                     int key_bits, uint32_t* d_hist, uint32_t** out_keys, uint32_t** out_vals)
+                     int key_bits, uint32_t* d_hist, uint32_t** out_keys, uint32_t** out_vals, bool iota_vals, bool first_hist_ready)
 {
     *out_keys = d_keys;
     *out_vals = d_vals;
@@ -238,9 +240,10 @@ int radix_sort_pairs(mrgfe_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, uint32_
     dim3 grid(t.max_blks, t.nprob());
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
-        hipLaunchKernelGGL(rs_hist_kernel, grid, dim3(256), 0, ctx->stream, ki, d_slices, d_hist, shift);
+        if (!(p == 0 && first_hist_ready)) hipLaunchKernelGGL(rs_hist_kernel, grid, dim3(256), 0, ctx->stream, ki, d_slices, d_hist, shift);
         hipLaunchKernelGGL(rs_scan_kernel, dim3(t.nprob()), dim3(256), 0, ctx->stream, d_slices, d_hist, digit_base);
-        hipLaunchKernelGGL(rs_scatter_kernel, grid, dim3(256), 0, ctx->stream, ki, vi, ko, vo, d_slices, d_hist, digit_base, shift);
+        if (p == 0 && iota_vals) hipLaunchKernelGGL(rs_scatter_kernel<true>, grid, dim3(256), 0, ctx->stream, ki, vi, ko, vo, d_slices, d_hist, digit_base, shift);
+        else                     hipLaunchKernelGGL(rs_scatter_kernel<false>, grid, dim3(256), 0, ctx->stream, ki, vi, ko, vo, d_slices, d_hist, digit_base, shift);
         uint32_t* tk = ki; ki = ko; ko = tk;
         uint32_t* tv = vi; vi = vo; vo = tv;
     }

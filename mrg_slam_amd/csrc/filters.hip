@@ -156,9 +156,9 @@ int filter_voxelgrid_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, float 
     MRGFE_TRY(dk.ensure(n * 4)); MRGFE_TRY(dv.ensure(n * 4)); MRGFE_TRY(dkt.ensure(n * 4)); MRGFE_TRY(dvt.ensure(n * 4));
     MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + 1)));
     MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (tab.total_blks + 8)));
-    MRGFE_TRY(ndt_launch_cellkeys(ctx, &d_desc->cp, &d_desc->sl, tab, &d_desc->vp, dk.as<uint32_t>(), dv.as<uint32_t>()));
+    MRGFE_TRY(ndt_launch_cellkeys(ctx, &d_desc->cp, &d_desc->sl, tab, &d_desc->vp, dk.as<uint32_t>(), dh.as<uint32_t>()));
     uint32_t *sk, *sv;
-    MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), &d_desc->sl, tab, key_bits, dh.as<uint32_t>(), &sk, &sv));
+    MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), &d_desc->sl, tab, key_bits, dh.as<uint32_t>(), &sk, &sv, true, true));
     uint32_t* d_ord = (sk == dk.as<uint32_t>()) ? dkt.as<uint32_t>() : dk.as<uint32_t>();
     uint32_t* d_tot = dblk.as<uint32_t>() + tab.total_blks;
     MRGFE_TRY(exclusive_scan_run_heads(ctx, sk, d_ord, &d_desc->sl, tab, &d_desc->nv, dblk.as<uint32_t>(), d_tot));

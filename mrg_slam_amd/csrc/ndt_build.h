@@ -25,7 +25,8 @@ struct LeafSlice {
     uint64_t lookup_byte_off;  // byte offset of this target's lookup table in the lookup arena
 };
 
-int ndt_launch_cellkeys(mrgfe_ctx* ctx, const float4* const* d_clouds, const Slice* d_slices, const SliceTable& t, const VoxelParams* d_vp, uint32_t* d_keys, uint32_t* d_vals);
+// voxel keys of every point and, in d_hist, the radix sort's first per-tile digit histograms (radix_sort_pairs(..., iota_vals, first_hist_ready))
+int ndt_launch_cellkeys(mrgfe_ctx* ctx, const float4* const* d_clouds, const Slice* d_slices, const SliceTable& t, const VoxelParams* d_vp, uint32_t* d_keys, uint32_t* d_hist);
 int ndt_launch_segments(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, const uint32_t* d_ordinal, const Slice* d_slices, const SliceTable& t,
                         const LeafSlice* d_leaf_slices, uint32_t* d_seg_start, int32_t* d_seg_key);
 int ndt_launch_leaves(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32_t* d_sorted_vals, const Slice* d_slices, const SliceTable& t, const LeafSlice* d_leaf_slices,

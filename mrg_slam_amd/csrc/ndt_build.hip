@@ -17,29 +17,45 @@ namespace mrgfe {
 
 // voxel key of every point (pcl VoxelGrid indexing: floor(p * inverse_leaf_size) - min_b, dotted with divb_mul)
 __global__ __launch_bounds__(256) void ndt_cellkey_kernel(const float4* const* __restrict__ clouds, const Slice* __restrict__ slices, const VoxelParams* __restrict__ vp,
-                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ hist)
 {
     const Slice       s = slices[blockIdx.y];
     if (blockIdx.x >= s.nblk) return;
     const VoxelParams g = vp[blockIdx.y];
     const float4* __restrict__ pts = clouds[blockIdx.y];
     const uint32_t    base = blockIdx.x * kTile;
+    // the radix sort's first per-tile digit histogram on the way (rs_hist_kernel's layout and method: the keys are in registers here, a pass
+    // of its own would read them back), and no index array: the sort's first scatter makes the indices up
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t key[kTile / 256];
 #pragma unroll
     for (int k = 0; k < kTile / 256; ++k) {
         const uint32_t i = base + k * 256 + threadIdx.x;
+        key[k] = 0u;
         if (i < s.n) {
             const float4 p = load_point(pts + i);
-            uint32_t key = g.n_cells;  // non-finite points sort behind every voxel
+            key[k] = g.n_cells;  // non-finite points sort behind every voxel
             if (finite3(p.x, p.y, p.z)) {
                 const int ijk0 = static_cast<int>(floorf(p.x * g.inv_leaf) - static_cast<float>(g.min_b[0]));
                 const int ijk1 = static_cast<int>(floorf(p.y * g.inv_leaf) - static_cast<float>(g.min_b[1]));
                 const int ijk2 = static_cast<int>(floorf(p.z * g.inv_leaf) - static_cast<float>(g.min_b[2]));
-                key = static_cast<uint32_t>(ijk0 * g.divb_mul[0] + ijk1 * g.divb_mul[1] + ijk2 * g.divb_mul[2]);
+                key[k] = static_cast<uint32_t>(ijk0 * g.divb_mul[0] + ijk1 * g.divb_mul[1] + ijk2 * g.divb_mul[2]);
             }
-            keys[s.off + i] = key;
-            vals[s.off + i] = i;
+            keys[s.off + i] = key[k];
         }
     }
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 0; k < kTile / 256; ++k) {
+        const bool     valid = base + k * 256 + threadIdx.x < s.n;
+        const uint32_t d = key[k] & 255u;
+        const uint64_t m = wave_match_digit8(d, __ballot(valid));
+        if (valid && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&h[d], static_cast<uint32_t>(__popcll(m)));
+    }
+    __syncthreads();
+    hist[(size_t)(s.blk_off + blockIdx.x) * 256 + threadIdx.x] = h[threadIdx.x];
 }
 
 // run heads -> seg_start[leaf] (position in the sorted arrays) and seg_key[leaf]; the thread that sees the last valid
@@ -360,10 +376,10 @@ __global__ __launch_bounds__(256) void ndt_leaf_finalize_kernel(const LeafSlice*
     (void)g;
 }
 
-int ndt_launch_cellkeys(mrgfe_ctx* ctx, const float4* const* d_clouds, const Slice* d_slices, const SliceTable& t, const VoxelParams* d_vp, uint32_t* d_keys, uint32_t* d_vals)
+int ndt_launch_cellkeys(mrgfe_ctx* ctx, const float4* const* d_clouds, const Slice* d_slices, const SliceTable& t, const VoxelParams* d_vp, uint32_t* d_keys, uint32_t* d_hist)
 {
     if (t.nprob() == 0 || t.max_blks == 0) return MRGFE_OK;
-    hipLaunchKernelGGL(ndt_cellkey_kernel, dim3(t.max_blks, t.nprob()), dim3(256), 0, ctx->stream, d_clouds, d_slices, d_vp, d_keys, d_vals);
+    hipLaunchKernelGGL(ndt_cellkey_kernel, dim3(t.max_blks, t.nprob()), dim3(256), 0, ctx->stream, d_clouds, d_slices, d_vp, d_keys, d_hist);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }

@@ -28,8 +28,7 @@ __device__ __forceinline__ void nn_cellkey_body(const float4* __restrict__ pts, 
         const float4 p = pts[i];
         int          c[3];
         if (nn_cell_of(g, p.x, p.y, p.z, c)) key = (static_cast<uint32_t>(c[2]) * g.dim[1] + c[1]) * g.dim[0] + c[0];
-        keys[i] = key;
-        vals[i] = i;
+        keys[i] = key;  // (no index array: the sort's first scatter makes the indices up)
     }
     // count per cell, one atomic per distinct cell of the wavefront (consecutive points of a scan crowd into few cells);
     // `before` = points counted into this point's cell ahead of it: summed over the cloud it is sum_c n_c (n_c - 1) / 2
@@ -201,7 +200,7 @@ int NnGrid::build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const 
     int key_bits = 1;
     while (key_bits < 32 && (uint64_t(1) << key_bits) <= n_cells) ++key_bits;
     uint32_t *sk, *sv;
-    MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), ds.as<Slice>(), tab, key_bits, dh.as<uint32_t>(), &sk, &sv));
+    MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), ds.as<Slice>(), tab, key_bits, dh.as<uint32_t>(), &sk, &sv, true));
     // counts -> cell_start (exclusive scan over n_cells + 1 entries, in place)
     uint32_t   nc1 = n_cells + 1;
     SliceTable ctab;
@@ -480,7 +479,7 @@ int NnGridSet::build(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32
         int key_bits = 1;
         while (key_bits < 32 && (uint64_t(1) << key_bits) <= max_cells) ++key_bits;
         uint32_t *sk = nullptr, *sv = nullptr;
-        if (tab.max_blks) MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), d_slices, tab, key_bits, dh.as<uint32_t>(), &sk, &sv));
+        if (tab.max_blks) MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), d_slices, tab, key_bits, dh.as<uint32_t>(), &sk, &sv, true));
         MRGFE_HIP_CHECK(hipMemcpyAsync(ds.as<char>() + at_cs, ctab.h.data(), sizeof(Slice) * M, hipMemcpyHostToDevice, st));
         MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (ctab.total_blks + M + 8)));
         MRGFE_TRY(exclusive_scan(ctx, dc.as<uint32_t>(), dc.as<uint32_t>(), d_cslices, ctab, dblk.as<uint32_t>(), dblk.as<uint32_t>() + ctab.total_blks));
