@@ -151,13 +151,15 @@ def main():
                    "the untimed accounting steps bench.py adds — is included, see `steps_in_run`)", "shard", ("nn_fit", "ndt_derivatives", "nn_cellkey", "nn_gather", "nn_occupancy", "rs_", "ndt_leaf", "ndt_cellkey", "bbox"), 1, "run")
     if sh:
         # steps in the profiled run = launches of nn_fit_block_kernel (one fitness launch per step)
-        steps_in_run = max(1, sh.get("nn_fit_block_kernel", {}).get("launches", 1))
+        def named(prefix):  # (the fitness kernels are templates: "nn_fit_sweep_kernel<false, 256>")
+            return [v for k, v in sh.items() if k.startswith(prefix)]
+        steps_in_run = max(1, sum(v["launches"] for v in named("nn_fit_block_kernel")))
         summary["shard_pmc"] = {"steps_in_run": steps_in_run, "kernels": sh}
-        fit = sum(v["hbm_bytes"] for k, v in sh.items() if k in ("nn_fit_seed_kernel", "nn_fit_sweep_kernel")) / steps_in_run
+        fit = sum(v["hbm_bytes"] for v in named("nn_fit_seed_kernel") + named("nn_fit_sweep_kernel")) / steps_in_run
         summary["fitness_sweep_traffic_bytes_per_step"] = fit
-        summary["fitness_sweep_valu_busy"] = sh.get("nn_fit_sweep_kernel", {}).get("valu_busy")
+        summary["fitness_sweep_valu_busy"] = max([v["valu_busy"] for v in named("nn_fit_sweep_kernel")], default=None)
         lines += ["", f"Per step ({steps_in_run} steps in the run): `nn_fit_seed_kernel` + `nn_fit_sweep_kernel` move {fit / 1e9:.2f} GB of HBM traffic; "
-                      f"`nn_fit_block_kernel` {sh.get('nn_fit_block_kernel', {}).get('hbm_bytes', 0) / steps_in_run / 1e9:.2f} GB."]
+                      f"`nn_fit_block_kernel` {sum(v['hbm_bytes'] for v in named('nn_fit_block_kernel')) / steps_in_run / 1e9:.2f} GB."]
     gi = pmc_table("## GICP batch, counter passes (`rocprofv3 --pmc ... -- python3 profiles/gicp_profile.py batch`: 4 aligns of 32 x ~130k-point clouds, covariances recomputed each)", "gicp",
                    ("nn_knn", "gicp_", "nn_cellkey", "nn_gather", "rs_"), 4, "align call")
     if gi:
