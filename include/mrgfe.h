@@ -292,6 +292,10 @@ int mrgfe_remove_points_near(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t
 /* replaces PrefilteringComponent::deskewing (apps/prefiltering_component.cpp:231-292): point i is rotated by the inverse of
  * Quaternionf(1, dt/2 * -w) with dt = scan_period * i / n and w the IMU angular velocity */
 int mrgfe_deskew(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, const float ang_v_xyz[3], double scan_period, float* out_xyzi);
+/* replaces pcl_ros::transformPointCloud(*src_cloud, *transformed, transform) of PrefilteringComponent::cloud_callback
+ * (apps/prefiltering_component.cpp:141: the scan into base_link_frame) = pcl::transformPointCloud with the Matrix4f of the transform:
+ * T column-major 4x4 float; non-finite points pass through unchanged, intensity is copied */
+int mrgfe_transform_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, const float T[16], float* out_xyzi);
 
 /* ---- batched candidate matching (LoopDetector::matching candidate loop, src/mrg_slam/loop_detector.cpp:126-145) ---- */
 typedef struct mrgfe_pair_result {

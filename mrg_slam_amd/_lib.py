@@ -151,6 +151,7 @@ SIGNATURES = {
                                            C.c_size_t, _szp]),
     "mrgfe_remove_points_near": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, _fp, C.c_int, C.c_float, _fp, _szp, _fp, _szp]),
     "mrgfe_deskew": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, _fp, C.c_double, _fp]),
+    "mrgfe_transform_cloud": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, _fp, _fp]),
     "mrgfe_batch_create": (C.c_int, [_vp, C.POINTER(RegParams), C.POINTER(_vp)]),
     "mrgfe_batch_destroy": (None, [_vp]),
     "mrgfe_batch_clear": (C.c_int, [_vp]),

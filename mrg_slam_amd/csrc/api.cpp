@@ -894,6 +894,27 @@ int mrgfe_deskew(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, con
     return rc;
 }
 
+int mrgfe_transform_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, const float T[16], float* out)
+{
+    if (!ctx || !T || (n && (!xyzi || !out))) { set_error("mrgfe_transform_cloud: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (n == 0) return MRGFE_OK;
+    MRGFE_LOCK(ctx);
+    MRGFE_TRY(ctx->bind());
+    float Tr[16];
+    col2row(T, Tr);
+    DevBuf din, dout;
+    int rc = din.ensure(n * 16);
+    if (rc == MRGFE_OK) rc = dout.ensure(n * 16);
+    if (rc == MRGFE_OK) rc = upload_cloud(ctx, xyzi, n, stride, din.p);
+    if (rc == MRGFE_OK) rc = transform_cloud_device(ctx, din.as<float4>(), n, Tr, dout.as<float4>());
+    if (rc == MRGFE_OK && (hipMemcpyAsync(out, dout.p, n * 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+        set_error("mrgfe_transform_cloud: device to host copy failed");
+        rc = MRGFE_ERR_HIP;
+    }
+    din.release(); dout.release();
+    return rc;
+}
+
 // ---- batch ------------------------------------------------------------------------------------------------------
 int mrgfe_batch_create(mrgfe_ctx* ctx, const mrgfe_reg_params* params, mrgfe_batch** out)
 {

@@ -19,5 +19,7 @@ int remove_points_near_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, cons
 
 // PrefilteringComponent::deskewing (apps/prefiltering_component.cpp:231-292)
 int deskew_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, const float ang_v[3], double scan_period, float4* d_out);
+// pcl::transformPointCloud(in, out, Matrix4f): the float arithmetic of dev_float.h's transform_point, intensity copied
+int transform_cloud_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, const float T_rowmajor[16], float4* d_out);
 
 }  // namespace mrgfe

@@ -9,10 +9,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "cellsort.h"
-
+#include "dev_float.h"
 #include "dev_utils.h"
 #include "filters.h"
 
@@ -332,6 +333,32 @@ int deskew_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, const float ang_
     const uint32_t nn = static_cast<uint32_t>(n);
     // ang_v *= -1 (:275)
     hipLaunchKernelGGL(deskew_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, d_in, nn, ang_v[0] * -1.0f, ang_v[1] * -1.0f, ang_v[2] * -1.0f, scan_period, d_out);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
+// ---- rigid transform of a cloud ------------------------------------------------------------------------------------
+struct Transform12 { float m[12]; };
+__global__ __launch_bounds__(256) void transform_cloud_kernel(const float4* __restrict__ in, uint32_t n, Transform12 T, float4* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float4 p = in[i];
+    if (finite3(p.x, p.y, p.z)) {  // pcl::transformPointCloud leaves the non-finite points of a non-dense cloud as they are
+        float x, y, z;
+        transform_point(T.m, p.x, p.y, p.z, x, y, z);
+        p.x = x; p.y = y; p.z = z;
+    }
+    out[i] = p;
+}
+
+int transform_cloud_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, const float T_rowmajor[16], float4* d_out)
+{
+    if (n == 0) return MRGFE_OK;
+    Transform12 T;
+    std::memcpy(T.m, T_rowmajor, sizeof(T.m));
+    const uint32_t nn = static_cast<uint32_t>(n);
+    hipLaunchKernelGGL(transform_cloud_kernel, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, d_in, nn, T, d_out);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }

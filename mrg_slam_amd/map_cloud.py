@@ -133,3 +133,14 @@ def deskew(cloud, angular_velocity, scan_period: float = 0.1, ctx: Context | Non
     av = np.ascontiguousarray(np.asarray(angular_velocity, dtype=np.float32).reshape(3))
     check(lib().mrgfe_deskew(ctx._h, c.ctypes.data_as(_fp), len(c), 16, av.ctypes.data_as(_fp), float(scan_period), out.ctypes.data_as(_fp)))
     return out
+
+
+def transform_cloud(cloud, T, ctx: Context | None = None) -> np.ndarray:
+    """pcl::transformPointCloud(cloud, out, Matrix4f(T)) (the base_link transform of PrefilteringComponent::cloud_callback,
+    apps/prefiltering_component.cpp:141): float arithmetic, non-finite points unchanged, intensity copied."""
+    ctx = ctx or default_context()
+    c = _cloud(cloud)
+    out = np.empty_like(c)
+    Tc = np.ascontiguousarray(np.asarray(T, dtype=np.float32).T)
+    check(lib().mrgfe_transform_cloud(ctx._h, c.ctypes.data_as(_fp), len(c), 16, Tc.ctypes.data_as(_fp), out.ctypes.data_as(_fp)))
+    return out
