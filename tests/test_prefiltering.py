@@ -107,3 +107,47 @@ def test_transform_cloud_matches_oracle():
     np.testing.assert_array_equal(out[fin], orc.transform_points(T, scan[fin]))
     np.testing.assert_array_equal(out[~fin], scan[~fin])
     assert transform_cloud(scan[:0], T).shape == (0, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["NDT", "SMALL_GICP"])
+def test_prefiltering_into_odometry_hip_chain_equals_oracle_chain(method):
+    """The two components composed as the reference composes them (the prefiltering component's output feeds
+    ScanMatchingOdometryComponent::matching): a short VLP-16 drive with IMU messages and a base_link offset, the HIP chain against the
+    oracle chain — identical filtered clouds, odometry poses within the bar, the same keyframe switches."""
+    from mrg_slam_amd import NdtHip, PrefilteringComponent, ScanMatchingOdometry, SmallGicpHip, synth
+    from mrg_slam_amd.prefiltering import HipOps, OracleOps
+    from oracle import oracle as orc
+
+    scene = synth.street_scene()
+    frames = 7
+    poses = [synth.make_pose([0.8 * k, 0.05 * k, 0.0], synth.rot_xyz(0.0, 0.0, np.deg2rad(2.0 * k))) for k in range(frames)]
+    T_bl = synth.make_pose([0.2, 0.0, 0.3], synth.rot_xyz(0.0, 0.0, 0.0)).astype(np.float32)  # lidar -> base_link
+    raw = [synth.synth_lidar(scene, poses[k], "VLP16", seed=4000 + k) for k in range(frames)]
+    deltas = [np.eye(4)] + [synth.warm_guess(np.linalg.inv(poses[k - 1]) @ poses[k], 50 + k) for k in range(1, frames)]
+    params = {"enable_deskewing": True, "scan_period": 0.1}
+    odo_params = {"keyframe_delta_translation": 1.5}
+
+    def run(ops, reg):
+        pre = PrefilteringComponent(params, ops=ops, lookup_transform=lambda a, b: T_bl)
+        odo = ScanMatchingOdometry(reg, odo_params)
+        clouds, odoms, kfs = [], [], []
+        for k in range(frames):
+            pre.imu_callback(0.1 * k + 0.05, [0.0, 0.0, 0.02])  # a slow yaw rate
+            f = pre.cloud_callback(raw[k], stamp=0.1 * k, frame_id="velodyne")
+            clouds.append(f)
+            odoms.append(np.array(odo.matching(0.1 * k, f, deltas[k]), dtype=np.float64))
+            kfs.append(float(odo.keyframe_stamp))
+        return clouds, odoms, kfs
+
+    if method == "NDT":
+        g, o = NdtHip(resolution=1.0, transformation_epsilon=0.1), orc.Ndt(resolution=1.0, transformation_epsilon=0.1, num_threads=8)
+    else:
+        g, o = SmallGicpHip(transformation_epsilon=0.1), orc.SmallGicp(transformation_epsilon=0.1, num_threads=8)
+    gc, go, gk = run(HipOps(), g)
+    oc, oo, ok = run(OracleOps(orc), o)
+    for a, b in zip(gc, oc):
+        np.testing.assert_array_equal(a, b)
+    assert gk == ok and len(set(gk)) >= 2  # the keyframe was switched at least once, at the same frames
+    for a, b in zip(go, oo):
+        assert np.linalg.norm(a[:3, 3] - b[:3, 3]) <= 1e-4 and synth.rotation_angle(a, b) <= 1e-4
