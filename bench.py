@@ -582,7 +582,7 @@ def main():
 
     # ---- the rest of SURVEY.md §8(d), all outside the timed region above (never `value`) ------------------------------------------
     extras = {}
-    if not args.no_extras and rank == 0:
+    if not args.no_extras and rank == 0 and world == 1:  # (single-GPU side measurements: not while the other ranks of an N-GPU run wait)
         # (1) setInputTarget and align apart (a synchronisation between them; the timed steps run them back to back)
         split = []
         for _ in range(3):
@@ -676,7 +676,7 @@ def main():
     # ---- CPU baseline + parity on a bounded sample of the same pairs ---------------------------------------------------
     cpu = None
     parity = None
-    if not args.no_cpu and args.cpu_pairs > 0:
+    if not args.no_cpu and args.cpu_pairs > 0 and rank == 0 and world == 1:  # the CPU baseline and the parity check: rank 0 of the 1-GPU run only
         from oracle import oracle as orc
 
         host_cores = os.cpu_count() or 1
