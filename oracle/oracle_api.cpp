@@ -205,6 +205,7 @@ void  orc_pclgicp_set_params(void* h, int k, double max_corr_dist, double trans_
     g->k_correspondences = k; g->max_corr_dist = max_corr_dist; g->trans_eps = trans_eps; g->rot_eps = rot_eps; g->max_iterations = max_iterations;
     g->max_inner_iterations = max_inner_iterations; g->whole_gradient_norm = whole_gradient_norm; g->num_threads = num_threads;
 }
+void orc_pclgicp_set_gpu_order(void* h, int on) { static_cast<orc::PclGicp*>(h)->gpu_order = on; }
 void orc_pclgicp_set_target(void* h, const float* xyzi, int n) { static_cast<orc::PclGicp*>(h)->set_target(xyzi, n); }
 void orc_pclgicp_set_source(void* h, const float* xyzi, int n) { static_cast<orc::PclGicp*>(h)->set_source(xyzi, n); }
 void orc_pclgicp_align(void* h, const float guess_colmajor[16], float* aligned_or_null)

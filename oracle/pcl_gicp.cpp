@@ -56,9 +56,68 @@ struct Functor {  // OptimizationFunctorWithIndices
     const std::vector<int>*    idx_tgt;
     const std::vector<double>* mahal;  // 9 per source point
     float base[16];                    // base_transformation_ (identity in computeTransformation)
+    int   gpu_order = 0;               // diagnostic: add the per-point terms in the order the HIP kernels do (see terms_gpu_order)
+
+    // The same per-point terms as terms(), added in the order of mrg_slam_amd/csrc/gicp.hip (pclgicp_fdf_kernel + gicp_reduce_record): one
+    // lane per SOURCE point (points without a correspondence contribute exact zeros), workgroups of 256 points, per wavefront of 64 a
+    // shuffle-down tree (offsets 32 ... 1), the four wavefronts as ((w0 + w1) + w2) + w3, the workgroup partials in eight interleaved slices
+    // (slice s takes workgroups s, s + 8, ...), the slices in order.  A diagnostic mode: it shows that what separates a HIP result from the
+    // reference-order result is the order of these f64 additions and nothing else.
+    static double sum_gpu_order(const std::vector<double>& v)
+    {
+        const size_t n = v.size(), nblk = (n + 255) / 256;
+        double slice[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t b = 0; b < nblk; ++b) {
+            double w[4];
+            for (int wv = 0; wv < 4; ++wv) {
+                double a[64];
+                for (int l = 0; l < 64; ++l) {
+                    const size_t i = b * 256 + static_cast<size_t>(wv) * 64 + l;
+                    a[l] = i < n ? v[i] : 0.0;
+                }
+                for (int off = 32; off > 0; off >>= 1)
+                    for (int l = 0; l < off; ++l) a[l] = a[l] + a[l + off];
+                w[wv] = a[0];
+            }
+            slice[b & 7] += ((w[0] + w[1]) + w[2]) + w[3];
+        }
+        double r = slice[0];
+        for (int sl = 1; sl < 8; ++sl) r += slice[sl];
+        return r;
+    }
+    void terms_gpu_order(const double x[6], double* fsum, double g_t[3], double dC[9]) const
+    {
+        float T[16];
+        std::memcpy(T, base, sizeof(T));
+        apply_state(T, x);
+        const size_t n = src->size() / 4;
+        std::vector<std::vector<double>> col(13, std::vector<double>(n, 0.0));
+        const int m = static_cast<int>(idx_src->size());
+        for (int i = 0; i < m; ++i) {
+            const int    is = (*idx_src)[i], it = (*idx_tgt)[i];
+            const float* ps = &(*src)[4 * static_cast<size_t>(is)];
+            const float* pt = &(*tgt)[4 * static_cast<size_t>(it)];
+            float q[3];
+            mat4f_point(T, ps, q);
+            const double d[3] = {static_cast<double>(q[0] - pt[0]), static_cast<double>(q[1] - pt[1]), static_cast<double>(q[2] - pt[2])};
+            const double* M = &(*mahal)[9 * static_cast<size_t>(is)];
+            const double Md[3] = {M[0] * d[0] + M[1] * d[1] + M[2] * d[2], M[3] * d[0] + M[4] * d[1] + M[5] * d[2], M[6] * d[0] + M[7] * d[1] + M[8] * d[2]};
+            col[0][is] = d[0] * Md[0] + d[1] * Md[1] + d[2] * Md[2];
+            float pb[3];
+            mat4f_point(base, ps, pb);
+            for (int k = 0; k < 3; ++k) col[1 + k][is] = Md[k];
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) col[4 + r * 3 + c][is] = static_cast<double>(pb[r]) * Md[c];
+        }
+        *fsum = sum_gpu_order(col[0]);
+        if (g_t) {
+            for (int k = 0; k < 3; ++k) g_t[k] = sum_gpu_order(col[1 + k]);
+            for (int k = 0; k < 9; ++k) dC[k] = sum_gpu_order(col[4 + k]);
+        }
+    }
 
     void terms(const double x[6], double* fsum, double g_t[3], double dC[9]) const
     {
+        if (gpu_order) { terms_gpu_order(x, fsum, g_t, dC); return; }
         float T[16];
         std::memcpy(T, base, sizeof(T));
         apply_state(T, x);
@@ -252,7 +311,7 @@ double PclGicp::evaluate(const float T[16], const double x[6], double g[6], int*
     std::vector<double> mahal;
     correspondences(*this, target_grid_, source, T, eye, is, it, mahal);
     if (n_corr) *n_corr = static_cast<int>(is.size());
-    Functor fn{&source, &target, &is, &it, &mahal, {}};
+    Functor fn{&source, &target, &is, &it, &mahal, {}, gpu_order};
     mat4f_identity(fn.base);
     double f = 0;
     if (is.empty()) { for (int k = 0; k < 6; ++k) g[k] = 0; return 0.0; }
@@ -291,7 +350,7 @@ void PclGicp::align(const float guess[16], float* aligned)
         // the unqualified C function, i.e. in double
         double x[6] = {transformation[3], transformation[7], transformation[11], static_cast<double>(std::atan2(transformation[9], transformation[10])),
                        std::asin(static_cast<double>(-transformation[8])), static_cast<double>(std::atan2(transformation[4], transformation[0]))};
-        Functor fn{&output, &target, &idx_src, &idx_tgt, &mahal, {}};
+        Functor fn{&output, &target, &idx_src, &idx_tgt, &mahal, {}, gpu_order};
         mat4f_identity(fn.base);
         Bfgs<Functor> bfgs(fn);
         int inner = 0;

@@ -35,6 +35,7 @@ struct PclGicp {
     double translation_gradient_tolerance = 1e-2, rotation_gradient_tolerance = 1e-2;  // PCL >= 1.11
     int    whole_gradient_norm = 0;      // 1: pclomp / PCL <= 1.10: |g| < 1e-2 over all six components
     int    num_threads = 1;
+    int    gpu_order = 0;                // diagnostic: the cost sums in the HIP kernels' order of additions (pcl_gicp.cpp Functor::terms_gpu_order)
 
     std::vector<float>  target, source;  // xyzi
     std::vector<double> target_covs, source_covs;  // 9 per point

@@ -65,6 +65,25 @@ def test_gradient_matches_finite_differences_and_motion_is_recovered():
         assert o.getFitnessScore() < 1e-5
 
 
+def test_gpu_order_mode_adds_the_same_terms():
+    """PclGicp(gpu_order=True) — the diagnostic mode the GPU soak replays against — changes the order of the f64 additions of the cost sums and
+    nothing else: f and the gradient agree with the reference-order evaluation to rounding, registrations to the bar."""
+    tgt, src, rel = _pair()
+    a, b = orc.PclGicp(transformation_epsilon=1e-3, num_threads=1), orc.PclGicp(transformation_epsilon=1e-3, num_threads=1, gpu_order=True)
+    for g in (a, b):
+        g.setInputTarget(tgt)
+        g.setInputSource(src)
+    x0 = np.array([0.05, -0.02, 0.01, 0.004, -0.01, 0.02])
+    fa, ga, na = a.evaluate(np.eye(4), x0)
+    fb, gb, nb = b.evaluate(np.eye(4), x0)
+    assert na == nb and fa == pytest.approx(fb, rel=1e-13)
+    np.testing.assert_allclose(ga, gb, rtol=0, atol=1e-12 * np.abs(ga).max())
+    for g in (a, b):
+        g.align(np.eye(4))
+    Ta, Tb = a.getFinalTransformation().astype(np.float64), b.getFinalTransformation().astype(np.float64)
+    assert np.linalg.norm(Ta[:3, 3] - Tb[:3, 3]) < 5e-3 and synth.rotation_angle(Ta, Tb) < 5e-3
+
+
 def test_termination_rules():
     tgt, src, rel = _pair(2500, 9, 2000)
     one = orc.PclGicp(transformation_epsilon=1e-12, maximum_iterations=1)  # nr_iterations_ >= max_iterations_ counts as converged
