@@ -120,3 +120,41 @@ def test_gicp_family_full_size_matches_oracle(vlp64, method):
     assert np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3]) <= 1e-4 and synth.rotation_angle(Tg, To) <= 1e-4
     assert g.hasConverged() == o.hasConverged() and g.getFinalNumIteration() == o.getFinalNumIteration()
     assert np.linalg.norm(Tg[:3, 3] - rel[:3, 3]) < 0.1  # and it found the motion
+
+
+def test_small_gicp_batch_full_size_takes_the_correspondence_passes_and_equals_single_registrations(vlp64):
+    """Five 130k-point candidates against one 130k-point keyframe (650k queries a round: the batch takes nn_nearest_batch's passes by default,
+    single registrations the lane-group search): every record equals the single registration's bit for bit, one is held against the oracle,
+    and the fitness grids of the batch (built together) give the single registration's score."""
+    from mrg_slam_amd import BatchMatcher, SmallGicpHip, synth
+    from mrg_slam_amd._lib import SMALL_GICP_HIP
+    from mrg_slam_amd.registration import default_params, result_matrix
+    from oracle import oracle as orc
+
+    tgt, src, rel = vlp64
+    prm = default_params(SMALL_GICP_HIP)
+    prm.transformation_epsilon = 0.01
+    rng = np.random.default_rng(17)
+    guesses = [synth.perturb_pose(rel, rng) for _ in range(4)] + [np.eye(4)]
+    sources = [src, src[:-999], src[::2], src[3000:], src]
+    bm = BatchMatcher(prm)
+    t = bm.add_target(tgt)
+    for s_, g_ in zip(sources, guesses):
+        bm.add_pair(t, s_, g_)
+    res = bm.align(fitness_max_range=float("inf"))
+    for k, (s_, g_) in enumerate(zip(sources, guesses)):
+        reg = SmallGicpHip(transformation_epsilon=0.01)
+        reg.setInputTarget(tgt)
+        reg.setInputSource(s_)
+        reg.align(g_)
+        np.testing.assert_array_equal(result_matrix(res[k]), reg.getFinalTransformation(), err_msg=f"pair {k}")
+        assert res[k]["converged"] == int(reg.hasConverged()) and res[k]["iterations"] == reg.getFinalNumIteration()
+        assert res[k]["fitness"] == pytest.approx(reg.getFitnessScore(), rel=1e-12)
+    o = orc.SmallGicp(transformation_epsilon=0.01, num_threads=16)
+    o.setInputTarget(tgt)
+    o.setInputSource(sources[2])
+    o.align(guesses[2])
+    To = o.getFinalTransformation()
+    Tg = result_matrix(res[2])
+    assert np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3]) <= 1e-4 and synth.rotation_angle(Tg, To) <= 1e-4
+    assert res[2]["iterations"] == o.getFinalNumIteration()
