@@ -921,7 +921,11 @@ __global__ __launch_bounds__(256) void nn_fit_seed_kernel(const NnFitnessJob* __
 }
 
 template <bool kIdx, int kT>
-__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4))) void nn_fit_sweep_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range,
+#ifndef MRGFE_SWEEP_WAVES
+#define MRGFE_SWEEP_WAVES 4  // wavefronts per SIMD the register allocation aims for (tuning builds: -DMRGFE_SWEEP_WAVES=...).  The kernel wants ~165
+                             // VGPRs: at 4 (128 VGPRs, 84 bytes of scratch per lane) the sweep of a config[3] step takes 9.2 - 9.5 ms, at 3 (no scratch) 9.8 - 9.9 ms
+#endif
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(MRGFE_SWEEP_WAVES))) void nn_fit_sweep_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range,
                                                             const uint32_t* __restrict__ pend, const uint32_t* __restrict__ pend_cnt, float* __restrict__ sqd,
                                                             unsigned long long* __restrict__ stats, int clocks)
 {
