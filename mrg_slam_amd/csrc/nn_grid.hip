@@ -920,11 +920,19 @@ __global__ __launch_bounds__(256) void nn_fit_seed_kernel(const NnFitnessJob* __
     }
 }
 
-template <bool kIdx, int kT>
 #ifndef MRGFE_SWEEP_WAVES
 #define MRGFE_SWEEP_WAVES 4  // wavefronts per SIMD the register allocation aims for (tuning builds: -DMRGFE_SWEEP_WAVES=...).  The kernel wants ~165
                              // VGPRs: at 4 (128 VGPRs, 84 bytes of scratch per lane) the sweep of a config[3] step takes 9.2 - 9.5 ms, at 3 (no scratch) 9.8 - 9.9 ms
 #endif
+// a diagnostic counter that costs no register when the diagnostics are compiled out
+template <bool kOn>
+struct DiagCount {
+    uint32_t v = 0;
+    __device__ __forceinline__ void operator++() { if (kOn) ++v; }
+    __device__ __forceinline__ void operator+=(uint32_t x) { if (kOn) v += x; }
+};
+
+template <bool kIdx, int kT, bool kStats>
 __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(MRGFE_SWEEP_WAVES))) void nn_fit_sweep_kernel(const NnFitnessJob* __restrict__ jobs, const uint32_t* __restrict__ job_off, double max_range,
                                                             const uint32_t* __restrict__ pend, const uint32_t* __restrict__ pend_cnt, float* __restrict__ sqd,
                                                             unsigned long long* __restrict__ stats, int clocks)
@@ -954,9 +962,10 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(MRGFE_SWEEP_
     const float         max_sq_f = max_range >= 3.0e38 ? INFINITY : static_cast<float>(max_range) * (1.0f + 1e-6f);
     const int           lane = lane_id();
     const int           tid = static_cast<int>(threadIdx.x);
-    uint32_t            n_words = 0, n_tested = 0, n_cells = 0, n_points = 0, n_bricks = 0, n_listed = 0;  // diagnostics
+    // diagnostics (kStats builds only: six counters and the phase clocks would otherwise hold 16 registers of a kernel that spills)
+    DiagCount<kStats>   n_words, n_tested, n_cells, n_points, n_bricks, n_listed;
     long long           clk[4] = {0, 0, 0, 0}, tick = 0;  // thread 0: shader clocks spent in the four phases
-    auto stamp = [&](int ph) { if (clocks && threadIdx.x == 0) { const long long now = clock64(); clk[ph] += now - tick; tick = now; } };  // (a clock read waits for the memory operations in flight)
+    auto stamp = [&](int ph) { if (kStats && clocks && threadIdx.x == 0) { const long long now = clock64(); clk[ph] += now - tick; tick = now; } };  // (a clock read waits for the memory operations in flight)
     // every lane of the wavefront asks for `cnt` consecutive slots of a bounded LDS list: returns the lane's first slot; `full` when the list has filled up
     auto reserve = [&](uint32_t cnt, uint32_t* counter, uint32_t cap, bool& full) -> uint32_t {
         const uint32_t incl = wave_inclusive_scan(cnt);
@@ -969,19 +978,22 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(MRGFE_SWEEP_
         }
         return base + incl - cnt;
     };
-    if (clocks && threadIdx.x == 0) tick = clock64();
+    if (kStats && clocks && threadIdx.x == 0) tick = clock64();
     for (uint32_t k0 = blockIdx.x * static_cast<uint32_t>(kT); k0 < np; k0 += gridDim.x * static_cast<uint32_t>(kT)) {
         // ================= the tile's queries (lane = query): lim as the seed left it, the cube it spans =================
         const uint32_t k = k0 + threadIdx.x;
         uint32_t qi = 0;
         bool     mine = false;
-        float    t[3] = {0, 0, 0};
-        int      c[3] = {0, 0, 0}, L[3] = {0, 0, 0}, H[3] = {-1, -1, -1};
+        int      kx = 0, ky = 0, kz = 0;  // next block to load (bricks phase)
         if (k < np) {
             qi = as_global(pend)[off + k];
             mine = (qi & kNoSeed) == 0;
         }
         if (mine) {
+            // (the query's cell, cube and offset from the grid origin live in LDS from here on: the bricks phase reloads them every time it
+            // resumes, so that they do not hold a dozen registers through the cells and points phases of a kernel that spills)
+            float t[3];
+            int   c[3], L[3], H[3];
             const float4 p = load_point(J.src + qi);
             float x, y, z;
             nn_job_transform(J.T12, J.gicp_order, p.x, p.y, p.z, x, y, z);
@@ -1006,20 +1018,25 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(MRGFE_SWEEP_
             s_q[0][tid] = x;
             s_q[1][tid] = y;
             s_q[2][tid] = z;
+            kx = L[0] >> 6;
+            ky = L[1] >> 6;
+            kz = L[2] >> 6;
         }
         if (threadIdx.x == 0) { s_nb = 0; s_nc = 0; }
         __syncthreads();
         stamp(0);
         // ================= bricks (lane = query): blocks -> super-bricks -> bricks of the cube =================
-        const int L1[3] = {L[0] >> 2, L[1] >> 2, L[2] >> 2}, H1[3] = {H[0] >> 2, H[1] >> 2, H[2] >> 2};
-        const int L2[3] = {L[0] >> 4, L[1] >> 4, L[2] >> 4}, H2[3] = {H[0] >> 4, H[1] >> 4, H[2] >> 4};
-        int  kx = L[0] >> 6, ky = L[1] >> 6, kz = L[2] >> 6;  // next block to load
         bool blocks_left = mine;
         bool act = mine;
         unsigned long long m2 = 0ull, m1p = 0ull;  // super-bricks of the current block still to visit / bricks of the current super-brick still to list
         int  s2[3] = {0, 0, 0}, s1[3] = {0, 0, 0};  // first super-brick of the block m2 belongs to / first brick of the super-brick m1p belongs to
         for (;;) {
             bool full = false;
+            // (an inactive lane's entries may be stale or unset: it does not use them)
+            const int   L[3] = {s_L[0][tid], s_L[1][tid], s_L[2][tid]}, H[3] = {s_H[0][tid], s_H[1][tid], s_H[2][tid]}, c[3] = {s_c[0][tid], s_c[1][tid], s_c[2][tid]};
+            const float t[3] = {s_q[0][tid] - org[0], s_q[1][tid] - org[1], s_q[2][tid] - org[2]};
+            const int   L1[3] = {L[0] >> 2, L[1] >> 2, L[2] >> 2}, H1[3] = {H[0] >> 2, H[1] >> 2, H[2] >> 2};
+            const int   L2[3] = {L[0] >> 4, L[1] >> 4, L[2] >> 4}, H2[3] = {H[0] >> 4, H[1] >> 4, H[2] >> 4};
             while (!full && __ballot(act)) {  // uniform: every lane of the wavefront stays in the loop
                 if (act && m1p == 0ull) {  // next super-brick of the cube that reaches into the sphere: its bricks that do
                     const float lim = __uint_as_float(s_lim[tid]) * kNnPrune;
@@ -1219,8 +1236,8 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(MRGFE_SWEEP_
         }
         __syncthreads();
     }
-    if (stats != nullptr) {
-        const uint32_t v[6] = {wave_sum(n_words), wave_sum(n_tested), wave_sum(n_cells), wave_sum(n_points), wave_sum(n_bricks), wave_sum(n_listed)};
+    if (kStats && stats != nullptr) {
+        const uint32_t v[6] = {wave_sum(n_words.v), wave_sum(n_tested.v), wave_sum(n_cells.v), wave_sum(n_points.v), wave_sum(n_bricks.v), wave_sum(n_listed.v)};
         if (lane == 0) {
             const int at[6] = {0, 1, 2, 3, 7, 8};
             for (int kk = 0; kk < 6; ++kk)
@@ -1399,7 +1416,7 @@ int nn_nearest_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     MRGFE_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev_side[0], 0));
     hipLaunchKernelGGL(nn_fit_far_kernel<true>, grid, dim3(256), 0, ctx->side, d_jobs, d_off, max_sq, d_pend[1], d_cnts[1], dq.as<float>());
     MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[3], ctx->side));
-    hipLaunchKernelGGL((nn_fit_sweep_kernel<true, 256>), grid, dim3(256), 0, st, d_jobs, d_off, max_sq, d_pend[0], d_cnts[0], dq.as<float>(), static_cast<unsigned long long*>(nullptr), 0);
+    hipLaunchKernelGGL((nn_fit_sweep_kernel<true, 256, false>), grid, dim3(256), 0, st, d_jobs, d_off, max_sq, d_pend[0], d_cnts[0], dq.as<float>(), static_cast<unsigned long long*>(nullptr), 0);
     MRGFE_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_side[3], 0));
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
@@ -1472,7 +1489,8 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
         hipLaunchKernelGGL(nn_fit_far_kernel<false>, grid, dim3(256), 0, ctx->side, d_jobs, d_off, max_range, d_pend[1], d_cnts[1], dq.as<float>());
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[2], ctx->side));
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[3], ctx->side));
-        hipLaunchKernelGGL((nn_fit_sweep_kernel<false, 256>), grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), counters ? d_stats : nullptr, fit_stats_mode() > 1 ? 1 : 0);
+        if (counters) hipLaunchKernelGGL((nn_fit_sweep_kernel<false, 256, true>), grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), d_stats, fit_stats_mode() > 1 ? 1 : 0);
+        else          hipLaunchKernelGGL((nn_fit_sweep_kernel<false, 256, false>), grid, dim3(256), 0, st, d_jobs, d_off, max_range, d_pend[0], d_cnts[0], dq.as<float>(), static_cast<unsigned long long*>(nullptr), 0);
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_fit[2], st));
         MRGFE_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_side[3], 0));
         side_far = true;
