@@ -24,6 +24,12 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
 // ---- wave-level reductions through cross-lane shuffles (DPP / ds_bpermute, no LDS traffic) -------------------
+// the value lane `lane` holds, as a wave-uniform (scalar) value; `lane` must be the same in every lane.  Unlike __shfl with a uniform index
+// this is a v_readlane (no LDS round trip) and the result lives in a scalar register.
+__device__ __forceinline__ int      wave_read(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ uint32_t wave_read(uint32_t v, int lane) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), lane)); }
+__device__ __forceinline__ float    wave_read(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
 template <class T>
 __device__ __forceinline__ T wave_sum(T v)
 {

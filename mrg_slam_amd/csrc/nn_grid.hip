@@ -1693,14 +1693,14 @@ __device__ __forceinline__ uint32_t nn_knn_query(const NnGrid2Dev& g, const floa
                     knn_sort_merge(td, ti, beats ? d : INFINITY, beats ? ci : 0x7fffffff);
                     if (lane >= k) { td = INFINITY; ti = 0x7fffffff; }
                     cnt = min(k, cnt + static_cast<int>(__popcll(m)));
-                    if (cnt == k) { kth_d = __shfl(td, k - 1); kth_i = __shfl(ti, k - 1); }
+                    if (cnt == k) { kth_d = wave_read(td, k - 1); kth_i = wave_read(ti, k - 1); }
                     m = 0;
                 }
                 while (m) {
                     const int src = __ffsll(static_cast<unsigned long long>(m)) - 1;
                     m &= m - 1;
-                    const float   cd = __shfl(d, src);
-                    const int32_t cci = __shfl(ci, src);
+                    const float   cd = wave_read(d, src);  // (scalar: the candidate is the same for every lane)
+                    const int32_t cci = wave_read(ci, src);
                     if (!(cd < kth_d || (cd == kth_d && cci < kth_i))) continue;  // the k-th entry moved since the ballot
                     if (again && __ballot(td == cd && ti == cci)) continue;       // met on a finer level already
                     const bool    mine_less = td < cd || (td == cd && ti < cci);
@@ -1711,7 +1711,7 @@ __device__ __forceinline__ uint32_t nn_knn_query(const NnGrid2Dev& g, const floa
                     else if (lane > pos) { td = up_d; ti = up_i; }
                     if (lane >= k) { td = INFINITY; ti = 0x7fffffff; }
                     if (cnt < k) ++cnt;
-                    if (cnt == k) { kth_d = __shfl(td, k - 1); kth_i = __shfl(ti, k - 1); }
+                    if (cnt == k) { kth_d = wave_read(td, k - 1); kth_i = wave_read(ti, k - 1); }
                 }
             };
             const double margin = nn_face_margin(lv, c, p.x, p.y, p.z);
@@ -1734,8 +1734,8 @@ __device__ __forceinline__ uint32_t nn_knn_query(const NnGrid2Dev& g, const floa
                 off[0] = 0;
 #pragma unroll
                 for (int j = 0; j < 9; ++j) {
-                    beg[j] = __shfl(rb, j);
-                    off[j + 1] = off[j] + __shfl(rl, j);
+                    beg[j] = wave_read(rb, j);  // (scalars: nineteen registers of the wavefront, not of every lane)
+                    off[j + 1] = off[j] + wave_read(rl, j);
                 }
                 for (uint32_t base = 0; base < off[9]; base += 64u) {
                     const uint32_t v = base + lane;
@@ -1777,7 +1777,7 @@ __device__ __forceinline__ uint32_t nn_knn_query(const NnGrid2Dev& g, const floa
                         }
                     }
                     for (int r = 0; r < 34; ++r) {
-                        const uint32_t rb2 = __shfl(qb, r), rl2 = __shfl(ql, r);
+                        const uint32_t rb2 = wave_read(qb, r), rl2 = wave_read(ql, r);
                         for (uint32_t base = 0; base < rl2; base += 64u)
                             step(base + lane < rl2, base + lane < rl2 ? lv.sorted[rb2 + base + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                     }
@@ -1821,7 +1821,7 @@ __device__ __forceinline__ uint32_t nn_knn_query(const NnGrid2Dev& g, const floa
                     while (some) {
                         const int src = __ffsll(static_cast<unsigned long long>(some)) - 1;
                         some &= some - 1;
-                        const uint32_t b = __shfl(qb, src), e = __shfl(qe, src);
+                        const uint32_t b = wave_read(qb, src), e = wave_read(qe, src);
                         for (uint32_t base = b; base < e; base += 64u) step(base + lane < e, base + lane < e ? lv.sorted[base + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                     }
                 }
@@ -1840,6 +1840,11 @@ __device__ __forceinline__ uint32_t nn_knn_query(const NnGrid2Dev& g, const floa
     return n_cand;
 }
 
+#ifndef MRGFE_KNN_WAVES
+#define MRGFE_KNN_WAVES 8  // the kernel is bound by instruction issue (VALU busy 0.7) with long dependent chains: eight wavefronts per SIMD on 64 VGPRs and
+                           // 40 bytes of scratch run 4 % faster than seven on 65 without (0.283 against 0.295 ms per 130k queries, k = 20; six on 76: 0.304)
+#endif
+__attribute__((amdgpu_waves_per_eu(MRGFE_KNN_WAVES)))
 __global__ __launch_bounds__(256) void nn_knn_kernel(NnGrid2Dev g, const float4* __restrict__ q, uint32_t n, int k, int32_t* __restrict__ idx, float* __restrict__ sqd,
                                                       unsigned long long* __restrict__ stats)
 {
