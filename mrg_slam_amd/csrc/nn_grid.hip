@@ -42,13 +42,13 @@ __device__ __forceinline__ void nn_cellkey_body(const float4* __restrict__ pts, 
     while (__ballot(todo)) {
         const uint64_t pending = __ballot(todo);
         const int      leader = __ffsll(static_cast<unsigned long long>(pending)) - 1;
-        const uint32_t lkey = __shfl(key, leader);
+        const uint32_t lkey = wave_read(key, leader);
         const bool     mine = todo && key == lkey;
         const uint64_t grp = __ballot(mine);
         if (mine) {
             uint32_t old = 0;
             if (lane_id() == leader) old = atomicAdd(&counts[lkey], static_cast<uint32_t>(__popcll(grp)));
-            old = __shfl(old, leader);
+            old = wave_read(old, leader);
             before = old + static_cast<uint32_t>(__popcll(grp & ((1ull << lane_id()) - 1ull)));
             todo = false;
         }
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(256) void nn_fit_seed_kernel(const NnFitnessJob* __
             const int leader = __ffsll(static_cast<unsigned long long>(m)) - 1;
             uint32_t  base = 0;
             if (lane == leader) base = atomicAdd(&pend2_cnt[blockIdx.y], static_cast<uint32_t>(__popcll(m)));
-            base = __shfl(base, leader);
+            base = wave_read(base, leader);
             if (noseed) pend2[off + base + static_cast<uint32_t>(__popcll(m & below))] = qi;
         }
     }
@@ -969,11 +969,11 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(MRGFE_SWEEP_
     // every lane of the wavefront asks for `cnt` consecutive slots of a bounded LDS list: returns the lane's first slot; `full` when the list has filled up
     auto reserve = [&](uint32_t cnt, uint32_t* counter, uint32_t cap, bool& full) -> uint32_t {
         const uint32_t incl = wave_inclusive_scan(cnt);
-        const uint32_t total = __shfl(incl, kWave - 1);
+        const uint32_t total = wave_read(incl, kWave - 1);
         uint32_t       base = 0;
         if (total != 0) {  // uniform
             if (lane == kWave - 1) base = atomicAdd(counter, total);
-            base = __shfl(base, kWave - 1);
+            base = wave_read(base, kWave - 1);
             full = full || base + total >= cap;
         }
         return base + incl - cnt;
