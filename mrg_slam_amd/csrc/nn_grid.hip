@@ -1623,7 +1623,12 @@ constexpr int kKnnRings = 2;
 constexpr int kKnnSortMin = 12;  // candidates of one 64-wide step that beat the k-th entry: from here on sort + merge beats one-by-one insertion
 
 // (distance, index) order of the neighbour lists
-__device__ __forceinline__ bool knn_less(float ad, int32_t ai, float bd, int32_t bi) { return ad < bd || (ad == bd && ai < bi); }
+// (squared distances are >= +0 or +inf and indices >= 0: their bit patterns order like the values, so the pair compares as ONE unsigned
+// 64-bit number — one v_cmp instead of three compares and two logic operations, in a kernel bound by instruction issue)
+__device__ __forceinline__ bool knn_less(float ad, int32_t ai, float bd, int32_t bi)
+{
+    return (static_cast<unsigned long long>(__float_as_uint(ad)) << 32 | static_cast<uint32_t>(ai)) < (static_cast<unsigned long long>(__float_as_uint(bd)) << 32 | static_cast<uint32_t>(bi));
+}
 
 // compare-exchange with the lane `stride` away; `up`: this pair ends ascending from the lower lane
 __device__ __forceinline__ void knn_cmpx(float& d, int32_t& i, int stride, bool up)
@@ -1686,7 +1691,7 @@ __device__ __forceinline__ uint32_t nn_knn_query(const NnGrid2Dev& g, const floa
                     d = sqdist3f(cand.x, cand.y, cand.z, p.x, p.y, p.z);
                     ci = __float_as_int(cand.w);
                 }
-                const bool beats = valid && (d < kth_d || (d == kth_d && ci < kth_i));
+                const bool beats = valid && knn_less(d, ci, kth_d, kth_i);
                 n_cand += static_cast<uint32_t>(__popcll(__ballot(valid)));
                 uint64_t   m = __ballot(beats);
                 if (!again && __popcll(m) >= kKnnSortMin) {  // many at once (the first steps of a query): sort + merge
@@ -1701,9 +1706,9 @@ __device__ __forceinline__ uint32_t nn_knn_query(const NnGrid2Dev& g, const floa
                     m &= m - 1;
                     const float   cd = wave_read(d, src);  // (scalar: the candidate is the same for every lane)
                     const int32_t cci = wave_read(ci, src);
-                    if (!(cd < kth_d || (cd == kth_d && cci < kth_i))) continue;  // the k-th entry moved since the ballot
+                    if (!knn_less(cd, cci, kth_d, kth_i)) continue;  // the k-th entry moved since the ballot
                     if (again && __ballot(td == cd && ti == cci)) continue;       // met on a finer level already
-                    const bool    mine_less = td < cd || (td == cd && ti < cci);
+                    const bool    mine_less = knn_less(td, ti, cd, cci);
                     const int     pos = __popcll(__ballot(mine_less));  // sorted list: the lanes below pos hold the smaller entries
                     const float   up_d = __shfl_up(td, 1);
                     const int32_t up_i = __shfl_up(ti, 1);
@@ -1737,13 +1742,18 @@ __device__ __forceinline__ uint32_t nn_knn_query(const NnGrid2Dev& g, const floa
                     beg[j] = wave_read(rb, j);  // (scalars: nineteen registers of the wavefront, not of every lane)
                     off[j + 1] = off[j] + wave_read(rl, j);
                 }
+                // position of candidate v in lv.sorted: v + (beg[j] - off[j]) for the row j it falls into, i.e. the LAST j with off[j] <= v (off
+                // ascends): one compare and one select per row on scalar operands
+                uint32_t dlt[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) dlt[j] = beg[j] - off[j];
                 for (uint32_t base = 0; base < off[9]; base += 64u) {
                     const uint32_t v = base + lane;
-                    uint32_t       kk = 0;
+                    uint32_t       dv = dlt[0];
 #pragma unroll
-                    for (int j = 0; j < 9; ++j)
-                        if (v >= off[j] && v < off[j + 1]) kk = beg[j] + (v - off[j]);
-                    step(v < off[9], v < off[9] ? lv.sorted[kk] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                    for (int j = 1; j < 9; ++j)
+                        if (v >= off[j]) dv = dlt[j];
+                    step(v < off[9], v < off[9] ? lv.sorted[v + dv] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                 }
                 first_ring = 2;
                 // ring 2 the same way when it is needed: its 16 face rows and 18 end cells are 34 ranges, their bounds fetched by
