@@ -1620,7 +1620,10 @@ int NnGrid::radius_count_flags(mrgfe_ctx* ctx, const float4* d_q, size_t n, doub
 // of a level and then starts over on the next coarser one (sparse surroundings: the k-th neighbour is many fine cells
 // away); candidates it meets again there are recognised in the list by their (distance, index) and skipped.
 constexpr int kKnnRings = 2;
-constexpr int kKnnSortMin = 12;  // candidates of one 64-wide step that beat the k-th entry: from here on sort + merge beats one-by-one insertion
+#ifndef MRGFE_KNN_SORT_MIN
+#define MRGFE_KNN_SORT_MIN 9
+#endif
+constexpr int kKnnSortMin = MRGFE_KNN_SORT_MIN;  // candidates of one 64-wide step that beat the k-th entry: from here on sort + merge beats one-by-one insertion
 
 // (distance, index) order of the neighbour lists
 // (squared distances are >= +0 or +inf and indices >= 0: their bit patterns order like the values, so the pair compares as ONE unsigned
