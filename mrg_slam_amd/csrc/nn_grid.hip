@@ -1649,13 +1649,19 @@ __device__ __forceinline__ void knn_cmpx(float& d, int32_t& i, int stride, bool 
 // ones that do not count set to (inf, max)), sorted ascending over the lanes again.  Bitonic sort of the candidates
 // (21 compare-exchange stages), elementwise minimum with the reversed list (a bitonic sequence holding the 64 smallest),
 // bitonic merge (6 stages).
-__device__ __forceinline__ void knn_sort_merge(float& td, int32_t& ti, float d, int32_t ci)
+// `empty`: the list holds nothing yet (uniform) — the sorted candidates ARE the new list, no merge
+__device__ __forceinline__ void knn_sort_merge(float& td, int32_t& ti, float d, int32_t ci, bool empty)
 {
 #pragma unroll
     for (int size = 2; size <= 64; size <<= 1) {
         const bool up = (lane_id() & size) == 0 || size == 64;
 #pragma unroll
         for (int stride = size >> 1; stride > 0; stride >>= 1) knn_cmpx(d, ci, stride, up);
+    }
+    if (empty) {
+        td = d;
+        ti = ci;
+        return;
     }
     const float   rd = __shfl(d, 63 - lane_id());
     const int32_t ri = __shfl(ci, 63 - lane_id());
@@ -1698,7 +1704,7 @@ __device__ __forceinline__ uint32_t nn_knn_query(const NnGrid2Dev& g, const floa
                 n_cand += static_cast<uint32_t>(__popcll(__ballot(valid)));
                 uint64_t   m = __ballot(beats);
                 if (!again && __popcll(m) >= kKnnSortMin) {  // many at once (the first steps of a query): sort + merge
-                    knn_sort_merge(td, ti, beats ? d : INFINITY, beats ? ci : 0x7fffffff);
+                    knn_sort_merge(td, ti, beats ? d : INFINITY, beats ? ci : 0x7fffffff, cnt == 0);
                     if (lane >= k) { td = INFINITY; ti = 0x7fffffff; }
                     cnt = min(k, cnt + static_cast<int>(__popcll(m)));
                     if (cnt == k) { kth_d = wave_read(td, k - 1); kth_i = wave_read(ti, k - 1); }
