@@ -883,10 +883,13 @@ __global__ __launch_bounds__(256) void nn_fit_seed_kernel(const NnFitnessJob* __
                         if (bidx < 0 || d < best || (d == best && i < bidx)) { best = d; bidx = i; }
                     }
                     J.idx_out[qi] = bidx;
-                } else {
-                    for (uint32_t kk = kb; kk < ke; ++kk) {
-                        const float4 q = load_point(g.sorted + kk);
-                        best = fminf(best, sqdist3f(q.x, q.y, q.z, x, y, z));
+                } else if (ke > kb) {
+                    const uint32_t last = ke - 1u;
+                    for (uint32_t kk = kb; kk < ke; kk += 4) {  // four loads in flight; past the end the last point again
+                        const float4 q0 = load_point(g.sorted + kk), q1 = load_point(g.sorted + min(kk + 1, last)), q2 = load_point(g.sorted + min(kk + 2, last)),
+                                     q3 = load_point(g.sorted + min(kk + 3, last));
+                        best = fminf(fminf(best, sqdist3f(q0.x, q0.y, q0.z, x, y, z)), sqdist3f(q1.x, q1.y, q1.z, x, y, z));
+                        best = fminf(fminf(best, sqdist3f(q2.x, q2.y, q2.z, x, y, z)), sqdist3f(q3.x, q3.y, q3.z, x, y, z));
                     }
                 }
                 n_points += ke - kb;
@@ -1175,17 +1178,14 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(MRGFE_SWEEP_
                         uint32_t    kk = kb[u];
                         if (kIdx) {
                             unsigned long long km = ~0ull;
-                            for (; kk + 4 <= ke[u]; kk += 4) {  // four loads in flight
-                                const float4 p0 = load_point(g.sorted + kk), p1 = load_point(g.sorted + kk + 1), p2 = load_point(g.sorted + kk + 2), p3 = load_point(g.sorted + kk + 3);
+                            const uint32_t last = ke[u] - 1u;
+                            for (; kk < ke[u]; kk += 4) {  // four loads in flight (past the end: the last point again, see below)
+                                const float4 p0 = load_point(g.sorted + kk), p1 = load_point(g.sorted + min(kk + 1, last)), p2 = load_point(g.sorted + min(kk + 2, last)),
+                                             p3 = load_point(g.sorted + min(kk + 3, last));
                                 const unsigned long long k0 = nn_key(sqdist3f(p0.x, p0.y, p0.z, x, y, z), __float_as_int(p0.w)), k1 = nn_key(sqdist3f(p1.x, p1.y, p1.z, x, y, z), __float_as_int(p1.w));
                                 const unsigned long long k2 = nn_key(sqdist3f(p2.x, p2.y, p2.z, x, y, z), __float_as_int(p2.w)), k3 = nn_key(sqdist3f(p3.x, p3.y, p3.z, x, y, z), __float_as_int(p3.w));
                                 const unsigned long long ka = k0 < k1 ? k0 : k1, kb2 = k2 < k3 ? k2 : k3, kc = ka < kb2 ? ka : kb2;
                                 km = kc < km ? kc : km;
-                            }
-                            for (; kk < ke[u]; ++kk) {
-                                const float4             pt = load_point(g.sorted + kk);
-                                const unsigned long long k1 = nn_key(sqdist3f(pt.x, pt.y, pt.z, x, y, z), __float_as_int(pt.w));
-                                km = k1 < km ? k1 : km;
                             }
                             ++n_cells;
                             n_points += ke[u] - kb[u];
@@ -1196,14 +1196,14 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(MRGFE_SWEEP_
                             }
                             continue;
                         }
-                        for (; kk + 4 <= ke[u]; kk += 4) {  // four loads in flight
-                            const float4 p0 = load_point(g.sorted + kk), p1 = load_point(g.sorted + kk + 1), p2 = load_point(g.sorted + kk + 2), p3 = load_point(g.sorted + kk + 3);
+                        // four loads in flight per round trip, the cell's last one to three points included: past the end the LAST point is
+                        // read again (a minimum does not mind) instead of one dependent load per leftover point — cells hold 6.4 points on average
+                        const uint32_t last = ke[u] - 1u;
+                        for (; kk < ke[u]; kk += 4) {
+                            const float4 p0 = load_point(g.sorted + kk), p1 = load_point(g.sorted + min(kk + 1, last)), p2 = load_point(g.sorted + min(kk + 2, last)),
+                                         p3 = load_point(g.sorted + min(kk + 3, last));
                             dm = fminf(fminf(dm, sqdist3f(p0.x, p0.y, p0.z, x, y, z)), sqdist3f(p1.x, p1.y, p1.z, x, y, z));
                             dm = fminf(fminf(dm, sqdist3f(p2.x, p2.y, p2.z, x, y, z)), sqdist3f(p3.x, p3.y, p3.z, x, y, z));
-                        }
-                        for (; kk < ke[u]; ++kk) {
-                            const float4 pt = load_point(g.sorted + kk);
-                            dm = fminf(dm, sqdist3f(pt.x, pt.y, pt.z, x, y, z));
                         }
                         ++n_cells;
                         n_points += ke[u] - kb[u];
