@@ -1172,6 +1172,18 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
         const bool   overlap = fitness_max_range >= 0 && P >= 2 && std::getenv("MRGFE_NO_FIT_OVERLAP") == nullptr;
         std::unique_ptr<std::atomic<char>[]> grid_ready;  // per target: its fitness grid is complete (set by the builder that made it)
         auto fail = [&](int st, const std::string& why) { std::lock_guard<std::mutex> g(build_mu); if (build_status == MRGFE_OK) { build_status = st; build_error = why; } };
+        // Everything that can fail with an early return happens BEFORE the first helper thread exists: a joinable std::thread
+        // destroyed by a return would end the process (the SLAM node) instead of reporting the error.
+        // (early fitness waves, measured on config[3] while the grids were built one by one and outlasted the rounds: 256 pairs 30.8 -> 29.7 ms
+        // per step, 128 pairs no change, 64 and 32 pairs slower.  With the grids built a chunk at a time (NnGridSet) they are complete a few ms
+        // into the rounds, a step is the sum of its kernel times, and the waves only add their fixed costs: 27.8 ms without them, 28.7 ms with.
+        // Off unless MRGFE_EARLY_FIT_MIN_PAIRS asks for them.)
+        int early_min_pairs = 1 << 30;
+        if (const char* env = std::getenv("MRGFE_EARLY_FIT_MIN_PAIRS")) early_min_pairs = std::max(8, std::atoi(env));
+        const bool early_on = overlap && P >= early_min_pairs && std::getenv("MRGFE_NO_EARLY_FIT") == nullptr;
+        if (!b->port) b->port.reset(new NdtSnapshotPort());
+        NdtSnapshotPort& port = *b->port;  // (its pinned buffer is kept between calls)
+        if (early_on) MRGFE_TRY(port.buf.ensure(sizeof(NdtSnapshotHead) + sizeof(NdtSnapshotRec) * size_t(P)));
         if (overlap) {
             if (fit_built.size() < static_cast<size_t>(e.n_targets())) fit_built.resize(e.n_targets(), 0);
             if (b->fit_grids.size() < static_cast<size_t>(e.n_targets())) b->fit_grids.resize(e.n_targets());
@@ -1190,7 +1202,7 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
             const size_t n_chunks = (todo.size() + chunk - 1) / chunk;
             n_builders = std::min(n_builders, n_chunks);
             while (b->fit_sets.size() < n_chunks) b->fit_sets.emplace_back(new NnGridSet());
-            while (b->fit_ctxs.size() < n_builders + 1) {  // the last one belongs to the early fitness passes below
+            while (b->fit_ctxs.size() < n_builders + (early_on ? 1 : 0)) {  // with early passes on, one more context for them (the last)
                 mrgfe_ctx* fc = nullptr;
                 if (mrgfe_ctx_create(b->ctx->device, &fc) != MRGFE_OK) return MRGFE_ERR_HIP;
                 b->fit_ctxs.push_back(fc);
@@ -1230,23 +1242,13 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
         // transformation.  A second host thread asks the aligning thread for snapshots (NdtSnapshotPort), and whenever enough finished
         // pairs with a complete grid have accumulated it runs their passes on a helper context beside the remaining rounds.  A pair's
         // score does not depend on the launch it is computed in (nn_fit_sum_kernel's fixed slices), so the records are the same.
-        if (!b->port) b->port.reset(new NdtSnapshotPort());
-        NdtSnapshotPort& port = *b->port;  // (its pinned buffer is kept between calls)
         port.want.store(0);
         port.issued.store(0);
         port.finished.store(0);
         std::vector<char> early_done(P, 0);
         std::thread early;
-        // (measured on config[3] while the grids were built one by one and outlasted the rounds: 256 pairs 30.8 -> 29.7 ms per step, 128 pairs
-        // no change, 64 and 32 pairs slower.  With the grids built a chunk at a time (NnGridSet) they are complete a few ms into the rounds,
-        // a step is the sum of its kernel times, and the waves only add their fixed costs: 27.8 ms without them, 28.7 ms with.  Off unless
-        // MRGFE_EARLY_FIT_MIN_PAIRS asks for them.)
-        int early_min_pairs = 1 << 30;
-        if (const char* env = std::getenv("MRGFE_EARLY_FIT_MIN_PAIRS")) early_min_pairs = std::max(8, std::atoi(env));
-        const bool early_on = overlap && P >= early_min_pairs && std::getenv("MRGFE_NO_EARLY_FIT") == nullptr;
         b->fit_total = FitStats();
         if (early_on) {
-            if (port.buf.ensure(sizeof(NdtSnapshotHead) + sizeof(NdtSnapshotRec) * size_t(P)) != MRGFE_OK) return MRGFE_ERR_HIP;
             port.head()->tag = 0;
             early = std::thread([&, P] {
                 mrgfe_ctx* fc = b->fit_ctxs.back();

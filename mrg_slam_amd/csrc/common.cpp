@@ -255,6 +255,21 @@ int mrgfe_ctx::bind()
     return MRGFE_OK;
 }
 
+int mrgfe_ctx::stage_h2d(void* d_dst, const void* src, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return MRGFE_OK;
+    const int slot = stage_next;
+    stage_next = (stage_next + 1) % kStageSlots;
+    if (!stage_ev[slot]) MRGFE_HIP_CHECK(hipEventCreateWithFlags(&stage_ev[slot], hipEventDisableTiming));
+    if (stage_busy[slot]) { MRGFE_HIP_CHECK(hipEventSynchronize(stage_ev[slot])); stage_busy[slot] = false; }
+    MRGFE_TRY(stage_pin[slot].ensure(bytes));
+    std::memcpy(stage_pin[slot].p, src, bytes);
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_dst, stage_pin[slot].p, bytes, hipMemcpyHostToDevice, st));
+    MRGFE_HIP_CHECK(hipEventRecord(stage_ev[slot], st));
+    stage_busy[slot] = true;
+    return MRGFE_OK;
+}
+
 extern "C" {
 
 const char* mrgfe_last_error(void) { return mrgfe::get_error(); }
@@ -310,6 +325,8 @@ void mrgfe_ctx_destroy(mrgfe_ctx* ctx)
     ctx->up_raw.release();
     ctx->up_out.release();
     for (auto& e : ctx->up_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& b : ctx->stage_pin) b.release();
+    for (auto& e : ctx->stage_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (auto& pr : ctx->ev_mode) for (auto& e : pr) if (e) (void)hipEventDestroy(e);

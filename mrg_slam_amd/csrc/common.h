@@ -121,6 +121,14 @@ struct mrgfe_ctx {
     hipEvent_t   ev_side[4] = {nullptr, nullptr, nullptr, nullptr};  // fork, start and end of the side work, join
     mrgfe::FitStats fit_stats;                  // of the last nn_fitness_batch on this context
     mrgfe::KnnStats knn_stats;                  // of the last k-NN launch on this context
+    // descriptor staging ring: small host tables (job records, offsets, slice tables) whose owner does not outlive the call that
+    // enqueues their copy go through one of these pinned slots; a slot is reused only after the event behind its copy has passed
+    static constexpr int kStageSlots = 8;
+    mrgfe::PinBuf stage_pin[kStageSlots];
+    hipEvent_t   stage_ev[kStageSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool         stage_busy[kStageSlots] = {false, false, false, false, false, false, false, false};
+    int          stage_next = 0;
+    int          stage_h2d(void* d_dst, const void* src, size_t bytes, hipStream_t st);  // stream-ordered copy; `src` is free on return
     int          cu_count = 256;
     mrgfe::NnGrid* tmp_grid = nullptr;          // reusable exact-NN grid of the stateless filter / fitness calls (nn_grid.hip)
     std::recursive_mutex mu;                    // serialises API calls that share this context's stream / workspaces

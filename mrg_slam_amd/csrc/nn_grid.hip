@@ -1401,8 +1401,10 @@ int nn_nearest_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     uint32_t*     d_cnt = d_off + count + 1;
     uint32_t*     d_pend[2] = {dp.as<uint32_t>(), dp.as<uint32_t>() + total};
     uint32_t*     d_cnts[2] = {d_cnt, d_cnt + (count + 1)};
-    MRGFE_HIP_CHECK(hipMemcpyAsync(d_jobs, jobs, sizeof(NnFitnessJob) * count, hipMemcpyHostToDevice, st));
-    MRGFE_HIP_CHECK(hipMemcpyAsync(d_off, off.data(), sizeof(uint32_t) * (count + 1), hipMemcpyHostToDevice, st));
+    // this function does not wait on the host: the job records (the caller refills its array every round) and the local offset table
+    // go through the context's pinned staging ring, not straight from pageable memory that may be gone when the copy runs
+    MRGFE_TRY(ctx->stage_h2d(d_jobs, jobs, sizeof(NnFitnessJob) * count, st));
+    MRGFE_TRY(ctx->stage_h2d(d_off, off.data(), sizeof(uint32_t) * (count + 1), st));
     MRGFE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * 2 * (count + 1), st));
     const dim3 grid(nblk, static_cast<uint32_t>(count));
     if (small) hipLaunchKernelGGL((nn_fit_block_kernel<true, 8>), grid, dim3(256), 0, st, d_jobs, d_off, max_sq, dq.as<float>(), d_pend[0], d_cnts[0]);

@@ -17,6 +17,7 @@ Poses are ``numpy`` 4 x 4 matrices: keyframe estimates in double (``Eigen::Isome
 from __future__ import annotations
 
 import dataclasses
+import hashlib
 
 import numpy as np
 
@@ -59,6 +60,22 @@ class KeyFrame:
 
     def edge_exists(self, other: "KeyFrame") -> bool:
         return other.id in self.connected
+
+    def store_key(self) -> int:
+        """Name of this keyframe's cloud in the GPU keyframe store: a non-zero 63-bit hash of (slam_uuid, id, cloud content).
+
+        The reference re-reads ``candidate->cloud`` on every ``matching`` call (loop_detector.cpp:128), so a keyframe whose cloud was
+        replaced — or two robots reusing an id — must not meet a stale resident copy: the content is part of the name.  The digest is
+        computed once per cloud OBJECT (keyframe clouds are ``ConstPtr`` in the reference: replaced, never edited in place)."""
+        tok = getattr(self, "_store_token", None)
+        if tok is None or tok[0] is not self.cloud:
+            c = np.ascontiguousarray(self.cloud, dtype=np.float32)
+            h = hashlib.blake2b(digest_size=8)
+            h.update(f"{self.slam_uuid}/{self.id}/{c.shape[0]}/".encode())
+            h.update(c.tobytes())
+            tok = (self.cloud, (int.from_bytes(h.digest(), "little") & ((1 << 63) - 1)) | 1)
+            self._store_token = tok
+        return tok[1]
 
 
 @dataclasses.dataclass(eq=False)
@@ -198,8 +215,9 @@ class LoopDetector:
         bm.clear()
         t = bm.add_target(new_keyframe.cloud)
         for kf, g in zip(sources, guesses):
-            have = bm.has_cloud(kf.id) == len(kf.cloud)
-            bm.add_pair(t, None if have else kf.cloud, g, key=kf.id)
+            key = kf.store_key()  # (slam_uuid, id, content): an equal-length replacement or another robot's same id is another entry
+            have = bm.has_cloud(key) == len(kf.cloud)
+            bm.add_pair(t, None if have else kf.cloud, g, key=key)
         res = bm.align(max_range if want_fitness else -1.0)
         return [(result_matrix(r), bool(r["converged"]), float(r["fitness"]) if want_fitness else None) for r in res]
 

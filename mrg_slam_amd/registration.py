@@ -306,7 +306,8 @@ def select_registration_method(params: dict, ctx: Context | None = None) -> HipR
     "FAST_VGICP" / "FAST_VGICP_CUDA" :class:`VgicpHip`.  Like the reference, an unknown name falls through to NDT: names
     without "OMP" in them ("NDT", or any unknown string) reach pcl's single-threaded class there (:115-129) and get the KDTREE
     neighbourhood, its only one, on the pclomp float formulation; "ICP" / "ICP_HIP"
-    select :class:`IcpHip`; "GICP" and "GICP_OMP" raise NotImplementedError.
+    select :class:`IcpHip`; "GICP" / "GICP_OMP" (:93-114) select :class:`PclGicpHip` (pcl::GeneralizedIterativeClosestPoint / pclomp::GICP with
+    the BFGS inner optimiser).
     """
     method = str(params.get("registration_method", "FAST_GICP"))
     eps = float(params.get("reg_transformation_epsilon", 0.01))

@@ -47,7 +47,7 @@ class ScriptedMatcher:
     """BatchMatcher call surface over the same table."""
 
     def __init__(self, table):
-        self.table, self.store, self.calls = table, {}, []
+        self.table, self.store, self.ids, self.calls = table, {}, {}, []
 
     def clear(self):
         self.pairs = []
@@ -64,7 +64,8 @@ class ScriptedMatcher:
             assert key in self.store
         else:
             self.store[key] = len(cloud)
-        self.pairs.append((key, np.asarray(guess)))
+            self.ids[key] = int(cloud[0, 0])  # the store key names (slam_uuid, id, content); the table is keyed by keyframe id
+        self.pairs.append((self.ids[key], np.asarray(guess)))
 
     def align(self, fitness_max_range):
         from mrg_slam_amd.registration import RESULT_DTYPE
@@ -146,7 +147,7 @@ def test_keyframe_store_is_used_by_the_batched_path():
     m = ScriptedMatcher(table)
     det = LoopDetector({"enable_loop_closure_consistency_check": False}, matcher=m)
     det.matching(kfs[1:], _kf(50, 1.0, 0.0, 400.0))
-    assert m.store == {2: 1, 3: 1, 4: 1}
+    assert m.store == {kf.store_key(): 1 for kf in kfs[1:]} and sorted(m.ids.values()) == [2, 3, 4]
     det.matching(kfs[1:], _kf(51, 1.0, 0.0, 500.0))  # the second new keyframe names the candidates by id only (add_pair asserts it)
 
 
@@ -173,3 +174,17 @@ def test_scripted_ring_session_on_the_oracle():
     assert len(loops) >= 2
     for lp in loops:
         assert lp.key1.accum_distance - lp.key2.accum_distance >= 15.0 or lp.key1.slam_uuid != lp.key2.slam_uuid
+
+
+def test_store_key_names_the_cloud_content_not_just_the_id():
+    """A keyframe whose cloud is replaced by one of EQUAL length, or another robot's keyframe with the same id, must not meet a stale
+    resident copy in the GPU keyframe store (the reference re-reads candidate->cloud every call, loop_detector.cpp:128)."""
+    a = _kf(7, 0, 0, 0.0)
+    k0 = a.store_key()
+    assert k0 == a.store_key() and 0 < k0 < (1 << 63)
+    a.cloud = a.cloud.copy()
+    assert a.store_key() == k0  # same content under the same name
+    a.cloud = np.full((1, 4), 8, dtype=np.float32)  # equal length, other content
+    assert a.store_key() != k0
+    b = _kf(7, 0, 0, 0.0, uuid="b")
+    assert b.store_key() != k0
