@@ -165,7 +165,7 @@ def make_loop_workload(n_keyframes: int = 64, n_pairs: int = 256, radius: float 
     pairs = []
     for i in pick:
         a, b = cand[i]
-        rel = np.linalg.inv(poses[a]) @ poses[b]  # candidate -> new keyframe frame (loop_detector.cpp:130)
+        rel = synth.rel_pose(poses[a], poses[b])  # candidate -> new keyframe frame (loop_detector.cpp:130)
         guess = synth.perturb_pose(rel, rng, sigma_t=(0.5, 0.5, 0.1), sigma_r_deg=(0.5, 0.5, 2.0))
         pairs.append((a, b, guess, rel))
     return scans, pairs
@@ -192,7 +192,7 @@ def run_config2(ctx, scans, dev, poses, lib, args):
     out = {"workload": f"keyframe = scan 0 ({len(scans[0])} points), frames = scans 1..6, guess = perturbed true motion (seed 777+k), max_correspondence_distance 2.0, "
                        f"k = 20, eps {args.eps}, clouds resident in HBM"}
     frames = list(range(1, min(7, len(scans))))
-    rels = {k: np.linalg.inv(poses[0]) @ poses[k] for k in frames}
+    rels = {k: synth.rel_pose(poses[0], poses[k]) for k in frames}
     guesses = {k: synth.warm_guess(rels[k], 5000 + k) for k in frames}
     for name, cls, ocls in (("SMALL_GICP_HIP", SmallGicpHip, orc.SmallGicp), ("GICP_HIP", GicpHip, orc.FastGicp)):
         reg = cls(transformation_epsilon=args.eps, ctx=ctx)
@@ -519,7 +519,7 @@ def main():
 
     # ---- config[1] shape, weak scaling --------------------------------------------------------------------------------------
     scans, dev = to_hbm(raw)
-    rels = [np.linalg.inv(poses[k]) @ poses[k + 1] for k in range(args.distinct)]
+    rels = [synth.rel_pose(poses[k], poses[k + 1]) for k in range(args.distinct)]
     pairs = []  # (target scan index, source scan index, guess, truth, cold)
     for b in range(args.batch):
         k = b % args.distinct

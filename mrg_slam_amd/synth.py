@@ -19,19 +19,109 @@ BASE_SEED = 20251003  # seeds are BASE_SEED + scan_index
 
 
 # --------------------------------------------------------------------------------------------------------
+# host-independent arithmetic
+#
+# The scans are inputs of parity checks whose record digests are compared across machines, so they must be the same BITS on every
+# host.  numpy's sin / cos / hypot (SIMD libraries chosen by CPU), BLAS matrix products (kernels and FMA orders chosen by CPU), LAPACK's
+# inverse and the ziggurat normal generator (libm calls in its tails) are not; IEEE +, -, *, /, sqrt, floor and frexp on float64 arrays
+# are (numpy never fuses a multiply with an add across ufunc calls).  Everything below is built from those alone.
+# --------------------------------------------------------------------------------------------------------
+_PIO2_HI = 1.5707963267341256e+00   # pi/2, leading 33 bits
+_PIO2_LO = 6.0771005065061922e-11   # pi/2 - _PIO2_HI
+_S = (-1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04, 2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10)
+_C = (4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05, -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11)
+
+
+def _sincos(x):
+    """(sin x, cos x) elementwise for |x| up to a few thousand: Cody-Waite reduction by multiples of pi/2, degree-13 / 14 polynomials
+    (the fdlibm kernels' coefficients), + - * only: ~1e-16 absolute, and the same doubles on every host."""
+    x = np.asarray(x, dtype=np.float64)
+    k = np.floor(x * 0.63661977236758138 + 0.5)
+    r = (x - k * _PIO2_HI) - k * _PIO2_LO
+    z = r * r
+    ps = _S[5]
+    for c in _S[4::-1]:
+        ps = ps * z + c
+    sin_r = r + r * (z * ps)
+    pc = _C[5]
+    for c in _C[4::-1]:
+        pc = pc * z + c
+    cos_r = (1.0 - 0.5 * z) + z * (z * pc)
+    q = np.mod(k, 4.0)
+    s = np.where(q == 0, sin_r, np.where(q == 1, cos_r, np.where(q == 2, -sin_r, -cos_r)))
+    c = np.where(q == 0, cos_r, np.where(q == 1, -sin_r, np.where(q == 2, -cos_r, sin_r)))
+    return s, c
+
+
+def dsin(x):
+    return _sincos(x)[0]
+
+
+def dcos(x):
+    return _sincos(x)[1]
+
+
+def dlog(x):
+    """Natural logarithm of positive doubles: frexp, then 2 atanh((m - 1) / (m + 1)) as an odd series on [1/sqrt 2, sqrt 2)."""
+    x = np.asarray(x, dtype=np.float64)
+    m, e = np.frexp(x)
+    small = m < 0.70710678118654752
+    m = np.where(small, m * 2.0, m)
+    e = np.where(small, e - 1, e).astype(np.float64)
+    t = (m - 1.0) / (m + 1.0)
+    z = t * t
+    p = 1.0 / 23.0
+    for n in (21.0, 19.0, 17.0, 15.0, 13.0, 11.0, 9.0, 7.0, 5.0, 3.0, 1.0):
+        p = p * z + 1.0 / n
+    return 2.0 * t * p + e * 0.69314718055994531
+
+
+def dnormal(rng: np.random.Generator, sigma, size=None) -> np.ndarray:
+    """N(0, sigma) samples by Box-Muller from two exact uniform streams of ``rng`` (PCG64: integers scaled by 2^-53)."""
+    shape = np.shape(sigma) if size is None else size
+    u1 = 1.0 - rng.random(shape)  # (0, 1]
+    u2 = rng.random(shape)
+    return np.sqrt(-2.0 * dlog(u1)) * dcos(6.283185307179586 * u2) * sigma
+
+
+def mat_mul(A, B) -> np.ndarray:
+    """A @ B for small matrices with the sum over k taken left to right (no BLAS: its kernels and FMA orders vary with the CPU)."""
+    A, B = np.asarray(A, dtype=np.float64), np.asarray(B, dtype=np.float64)
+    out = A[:, 0:1] * B[0:1, :]
+    for k in range(1, A.shape[1]):
+        out = out + A[:, k:k + 1] * B[k:k + 1, :]
+    return out
+
+
+def inv_pose(T) -> np.ndarray:
+    """Inverse of a rigid 4x4 pose: (R^T, -R^T t)."""
+    T = np.asarray(T, dtype=np.float64)
+    out = np.eye(4)
+    Rt = T[:3, :3].T
+    out[:3, :3] = Rt
+    out[:3, 3] = -(Rt[:, 0] * T[0, 3] + Rt[:, 1] * T[1, 3] + Rt[:, 2] * T[2, 3])
+    return out
+
+
+def rel_pose(Ta, Tb) -> np.ndarray:
+    """inv(Ta) * Tb: frame b expressed in frame a."""
+    return mat_mul(inv_pose(Ta), Tb)
+
+
+# --------------------------------------------------------------------------------------------------------
 # poses
 # --------------------------------------------------------------------------------------------------------
 def rot_z(a: float) -> np.ndarray:
-    c, s = np.cos(a), np.sin(a)
+    s, c = (float(v) for v in _sincos(a))
     return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float64)
 
 
 def rot_xyz(rx: float, ry: float, rz: float) -> np.ndarray:
-    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    (sx, sy, sz), (cx, cy, cz) = (v.tolist() for v in _sincos([rx, ry, rz]))
     Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
     Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
     Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
-    return Rx @ Ry @ Rz
+    return mat_mul(mat_mul(Rx, Ry), Rz)
 
 
 def rotation_angle(Ra, Rb) -> float:
@@ -57,7 +147,7 @@ def arc_trajectory(n: int, step: float = 1.0, yaw_rate_deg: float = 1.5) -> list
     d = make_pose([step, 0, 0], rot_z(np.deg2rad(yaw_rate_deg)))
     for _ in range(n):
         poses.append(T.copy())
-        T = T @ d
+        T = mat_mul(T, d)
     return poses
 
 
@@ -70,7 +160,7 @@ def weave_trajectory(n: int, step: float = 1.0, yaw_rate_deg: float = 1.5, half_
     for k in range(n):
         poses.append(T.copy())
         sign = 1.0 if ((k + half_period // 2) // half_period) % 2 == 0 else -1.0
-        T = T @ make_pose([step, 0, 0], rot_z(np.deg2rad(sign * yaw_rate_deg)))
+        T = mat_mul(T, make_pose([step, 0, 0], rot_z(np.deg2rad(sign * yaw_rate_deg))))
     return poses
 
 
@@ -79,15 +169,15 @@ def loop_trajectory(n: int, radius: float = 40.0) -> list[np.ndarray]:
     poses = []
     for k in range(n):
         a = 2 * np.pi * k / n
-        poses.append(make_pose([radius * np.cos(a), radius * np.sin(a), 0.0], rot_z(a + np.pi / 2)))
+        poses.append(make_pose([radius * float(dcos(a)), radius * float(dsin(a)), 0.0], rot_z(a + np.pi / 2)))
     return poses
 
 
 def perturb_pose(T: np.ndarray, rng: np.random.Generator, sigma_t=(0.1, 0.1, 0.05), sigma_r_deg=(0.5, 0.5, 1.0)) -> np.ndarray:
     """T * exp(xi), xi ~ N(0, diag(sigma)) (warm initial guesses: seed 777 + k)."""
-    dt = rng.normal(0, sigma_t)
-    dr = np.deg2rad(rng.normal(0, sigma_r_deg))
-    return T @ make_pose(dt, rot_xyz(*dr))
+    dt = dnormal(rng, np.asarray(sigma_t, dtype=np.float64))
+    dr = np.deg2rad(dnormal(rng, np.asarray(sigma_r_deg, dtype=np.float64)))
+    return mat_mul(T, make_pose(dt, rot_xyz(*dr)))
 
 
 # --------------------------------------------------------------------------------------------------------
@@ -150,17 +240,17 @@ def loop_scene(seed: int = 4321, radius: float = 40.0) -> Scene:
             if rng.uniform() < 0.15:
                 continue
             a = 2 * np.pi * (k + rng.uniform(-0.2, 0.2)) / n
-            cx, cy = ring_r * np.cos(a), ring_r * np.sin(a)
+            cx, cy = ring_r * float(dcos(a)), ring_r * float(dsin(a))
             w, d, h = rng.uniform(5, 9), rng.uniform(5, 9), rng.uniform(6, 15)
             boxes.append([cx - w / 2, cy - d / 2, g, cx + w / 2, cy + d / 2, g + h])
     for _ in range(40):
         a = rng.uniform(0, 2 * np.pi)
         r = radius + rng.choice([-1, 1]) * rng.uniform(4.5, 7.0)
-        cyl.append([r * np.cos(a), r * np.sin(a), rng.uniform(0.15, 0.4), g, g + rng.uniform(4, 9)])
+        cyl.append([r * float(dcos(a)), r * float(dsin(a)), rng.uniform(0.15, 0.4), g, g + rng.uniform(4, 9)])
     for _ in range(14):
         a = rng.uniform(0, 2 * np.pi)
         r = radius + rng.choice([-1, 1]) * rng.uniform(2.8, 3.8)
-        cx, cy = r * np.cos(a), r * np.sin(a)
+        cx, cy = r * float(dcos(a)), r * float(dsin(a))
         boxes.append([cx - 1.6, cy - 1.6, g, cx + 1.6, cy + 1.6, g + 1.5])
     return Scene(g, np.asarray(boxes, dtype=np.float64), np.asarray(cyl, dtype=np.float64))
 
@@ -179,8 +269,9 @@ def lidar_directions(model: str, azimuth_steps: int | None = None) -> np.ndarray
     else:
         raise ValueError(f"unknown lidar model {model!r}")
     az = np.linspace(0.0, 2 * np.pi, n_az, endpoint=False)
-    ce, se = np.cos(elev)[:, None], np.sin(elev)[:, None]
-    d = np.stack([ce * np.cos(az)[None, :], ce * np.sin(az)[None, :], np.broadcast_to(se, (elev.size, n_az))], axis=-1)
+    (se, ce), (sa, ca) = _sincos(elev), _sincos(az)
+    ce, se = ce[:, None], se[:, None]
+    d = np.stack([ce * ca[None, :], ce * sa[None, :], np.broadcast_to(se, (elev.size, n_az))], axis=-1)
     return d.reshape(-1, 3)
 
 
@@ -196,7 +287,8 @@ def raycast(scene: Scene, origin: np.ndarray, dirs: np.ndarray, max_range: float
     else:
         boxes = scene.boxes
     if len(scene.cylinders):
-        cd = np.hypot(scene.cylinders[:, 0] - ox, scene.cylinders[:, 1] - oy) - scene.cylinders[:, 2]
+        cdx, cdy = scene.cylinders[:, 0] - ox, scene.cylinders[:, 1] - oy
+        cd = np.sqrt(cdx * cdx + cdy * cdy) - scene.cylinders[:, 2]
         cylinders = scene.cylinders[cd <= max_range]
     else:
         cylinders = scene.cylinders
@@ -213,9 +305,9 @@ def raycast(scene: Scene, origin: np.ndarray, dirs: np.ndarray, max_range: float
             t_best = np.where(hit & (tn < t_best), tn, t_best)
         for c in cylinders:
             ox, oy = origin[0] - c[0], origin[1] - c[1]
-            a = dirs[:, 0] ** 2 + dirs[:, 1] ** 2
+            a = dirs[:, 0] * dirs[:, 0] + dirs[:, 1] * dirs[:, 1]
             bq = 2 * (ox * dirs[:, 0] + oy * dirs[:, 1])
-            cq = ox * ox + oy * oy - c[2] ** 2
+            cq = ox * ox + oy * oy - c[2] * c[2]
             disc = bq * bq - 4 * a * cq
             ok = (disc > 0) & (a > 1e-12)
             t = (-bq - np.sqrt(np.where(ok, disc, 0.0))) / (2 * np.where(ok, a, 1.0))
@@ -231,9 +323,9 @@ def synth_lidar(scene: Scene, pose: np.ndarray, model: str = "VLP64", seed: int 
     """One scan in the SENSOR frame: N x 4 float32 (x, y, z, intensity)."""
     rng = np.random.default_rng(seed)
     d_s = lidar_directions(model, azimuth_steps)
-    d_w = d_s @ pose[:3, :3].T
+    d_w = mat_mul(d_s, pose[:3, :3].T)
     t = raycast(scene, pose[:3, 3], d_w, max_range)
-    noise = rng.normal(0.0, range_sigma, size=t.shape)
+    noise = dnormal(rng, range_sigma, size=t.shape)
     inten = rng.uniform(0.0, 1.0, size=t.shape)
     ok = np.isfinite(t)
     r = (t + noise)[ok]
@@ -326,7 +418,7 @@ def scan_pair(k: int, model: str = "VLP64", scene: Scene | None = None, azimuth_
     poses = arc_trajectory(k + 2)
     tgt = synth_lidar(scene, poses[k], model, BASE_SEED + k, azimuth_steps)
     src = synth_lidar(scene, poses[k + 1], model, BASE_SEED + k + 1, azimuth_steps)
-    rel = np.linalg.inv(poses[k]) @ poses[k + 1]
+    rel = rel_pose(poses[k], poses[k + 1])
     return tgt, src, rel
 
 
