@@ -183,6 +183,29 @@ def latest_pmc_summary():
     return None, {}
 
 
+def pmc_reference(name, pj):
+    """Where the cached counter figures printed beside the live measurements come from (they are from another run and build)."""
+    if not name:
+        return None
+    return {"profile": f"profiles/{name}", "git_rev": pj.get("git_rev"), "collected": pj.get("collected"),
+            "note": "`traffic` / `valu_busy` are rocprofv3 --pmc figures of that profile's run (separate passes, collected at that revision), not of this run; "
+                    "everything else in the record is measured live"}
+
+
+def sha16(arrays) -> str:
+    import hashlib
+
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()[:16]
+
+
+# digests of the RAW synthetic scans of the default workloads as generated in the build container (mrg_slam_amd/synth.py is built from IEEE
+# + - * / sqrt alone, tests/test_synth_reproducible.py): the same value must come out on every host
+EXPECTED_RAW_INPUTS = {"config1_rank0_257_scans": "656edc98f6ac7ec3", "config3_64_keyframes": "dc76f90d0d1b35a7"}
+
+
 def run_config2(ctx, scans, dev, poses, lib, args):
     """BASELINE config[2]: scan-to-keyframe GICP on the ~130k-point scans (registrations.cpp:46-63: SMALL_GICP is the YAML default, FAST_GICP the
     code default), per frame setInputSource (k = 20 covariances) + align against a keyframe set once; kernel times from the library's HIP events."""
@@ -194,6 +217,9 @@ def run_config2(ctx, scans, dev, poses, lib, args):
     frames = list(range(1, min(7, len(scans))))
     rels = {k: synth.rel_pose(poses[0], poses[k]) for k in frames}
     guesses = {k: synth.warm_guess(rels[k], 5000 + k) for k in frames}
+    # loop-closure-sized perturbations of the same frames (0.5 m / 2 deg, seed 4242 + k: SURVEY.md §8d "C4"): alignments that need several outer iterations
+    far_rng = {k: np.random.default_rng(4242 + k) for k in frames}
+    far_guesses = {k: synth.perturb_pose(rels[k], far_rng[k], sigma_t=(0.5, 0.5, 0.1), sigma_r_deg=(0.5, 0.5, 2.0)) for k in frames}
     for name, cls, ocls in (("SMALL_GICP_HIP", SmallGicpHip, orc.SmallGicp), ("GICP_HIP", GicpHip, orc.FastGicp)):
         reg = cls(transformation_epsilon=args.eps, ctx=ctx)
         t_set, t_frame, lin, its, finals = [], [], np.zeros(3), [], {}
@@ -228,6 +254,7 @@ def run_config2(ctx, scans, dev, poses, lib, args):
         lin_gbps = (lin[2] / 1e9) / (lin[0] / 1e3) if lin[0] > 0 else 0.0
         err = [float(np.linalg.norm(finals[k][:3, 3] - rels[k][:3, 3])) for k in frames]
         pmc_name, pmc = latest_pmc_summary()
+        out["pmc_reference"] = pmc_reference(pmc_name, pmc)
         rec = {"first_frame_incl_setInputTarget_ms": float(np.median(t_set)), "frame_ms": float(np.median(t_frame)), "frames_timed": len(t_frame),
                "outer_iterations_per_frame": float(np.mean(its)), "median_translation_error_vs_truth_m": float(np.median(err)),
                "roofline_knn": {"bound": "latency", "byte_model_bound": "hbm", "kernel": "nn_knn_kernel (k = 20, one wavefront per query)", "achieved": knn_gbps, "peak": HBM_PEAK_GBPS,
@@ -238,20 +265,44 @@ def run_config2(ctx, scans, dev, poses, lib, args):
                                       "achieved": lin_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": lin_gbps / HBM_PEAK_GBPS, "traffic": None, "launches": int(lin[1]),
                                       "avg_launch_ms": lin[0] / lin[1] if lin[1] else None,
                                       "byte_model": "N_src * (16 + 48 + 27*8) + correspondences * (16 + 48) per linearisation (SURVEY.md §8d)"}}
+        # the same frames from loop-closure-sized guesses: several outer iterations per alignment (the warm frames above converge in one)
+        far = {}
+        t_far = []
+        for k in frames:
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            reg.setInputSourceDevice(dev[k].data_ptr(), len(scans[k]))
+            reg.align(far_guesses[k])
+            t_far.append(1e3 * (time.perf_counter() - t0))
+            far[k] = (reg.getFinalTransformation(), bool(reg.hasConverged()), int(reg.getFinalNumIteration()))
+        rec["far_guess_frames"] = {"frame_ms": float(np.median(t_far)), "outer_iterations_per_frame": float(np.mean([v[2] for v in far.values()])),
+                                   "guess": "true motion perturbed by N(0, 0.5 m / 2 deg), seed 4242 + k"}
         if not args.no_cpu:
             host_cores = os.cpu_count() or 1
             nt = min(32, host_cores)
             o = ocls(transformation_epsilon=args.eps, num_threads=nt)
-            k = frames[0]
             tc = time.perf_counter()
             o.setInputTarget(scans[0])
-            o.setInputSource(scans[k])
-            o.align(guesses[k])
+            o.setInputSource(scans[frames[0]])
+            o.align(guesses[frames[0]])
             tc = time.perf_counter() - tc
-            To = o.getFinalTransformation()
-            rec["cpu_oracle"] = {"ms": 1e3 * tc, "threads": nt, "sample": "one frame incl. setInputTarget (both clouds' k-NN covariances)", "kind": "port",
-                                 "max_dt_m": float(np.linalg.norm(finals[k][:3, 3].astype(np.float64) - To[:3, 3])), "max_dr_rad": rot_angle(finals[k][:3, :3], To[:3, :3]),
-                                 "same_iterations": int(o.getFinalNumIteration()) == int(its[0]) if its else None}
+            # parity: every warm frame and every far-guess frame against the oracle (the timing above is the one-frame sample)
+            dts, drs, mism, its_o = [], [], 0, []
+            for kind, gs, got in (("warm", guesses, {k: (finals[k], True, None) for k in frames}), ("far", far_guesses, far)):
+                for k in frames:
+                    o.setInputSource(scans[k])
+                    o.align(gs[k])
+                    To = o.getFinalTransformation()
+                    Tg = got[k][0]
+                    dts.append(float(np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3])))
+                    drs.append(rot_angle(Tg[:3, :3], To[:3, :3]))
+                    if kind == "far":
+                        mism += int(got[k][1] != bool(o.hasConverged()) or got[k][2] != int(o.getFinalNumIteration()))
+                        its_o.append(int(o.getFinalNumIteration()))
+            rec["cpu_oracle"] = {"ms": 1e3 * tc, "threads": nt, "sample": "one frame incl. setInputTarget (both clouds' k-NN covariances)", "kind": "port"}
+            rec["parity_vs_oracle"] = {"frames": len(dts), "warm_frames": len(frames), "far_guess_frames": len(frames), "max_dt_m": max(dts), "max_dr_rad": max(drs),
+                                       "frames_over_bar": int(sum(a > 1e-4 or b > 1e-4 for a, b in zip(dts, drs))), "frames_bit_identical": int(sum(a == 0.0 and b == 0.0 for a, b in zip(dts, drs))),
+                                       "far_frames_with_other_iterations_or_convergence": mism, "far_frames_oracle_outer_iterations": its_o, "bar": "1e-4 m / 1e-4 rad"}
         out[name] = rec
     return out
 
@@ -274,6 +325,8 @@ def main():
                                                            "N-GPU node would do per step, for projecting the strong scaling where N GPUs are not at hand")
     ap.add_argument("--prepare-only", action="store_true", help="generate (and cache) the synthetic scans, then exit without touching the GPU")
     ap.add_argument("--parity-pairs", type=int, default=0, help="pairs of the step checked against the CPU oracle (0: all of them; the CPU TIMING uses --cpu-pairs)")
+    ap.add_argument("--no-shard-parity", action="store_true", help="skip the 256-pair oracle loop of the config[3] leg (parity_vs_oracle of config3_shard)")
+    ap.add_argument("--soak-cases", type=int, default=120, help="random small scenes of the parity soak printed as soak_over_bar (0 disables; pcl::GICP / reciprocal ICP get a third as many)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs behind the main line (setInputTarget / align split, host-pointer rate, pipeline shape, config[2] GICP)")
     ap.add_argument("--latency", action="store_true", help="also time single-pair setInputTarget+align latency (extra, differently sized launches of the "
                                                             "same kernels: off by default so rocprof averages of the default run describe the timed workload)")
@@ -492,7 +545,29 @@ def main():
                     "block_pass_ms_per_step": fit_acc["ms_block"] / acc_steps, "pyramid_walk_ms_per_step": fit_acc["ms_far"] / acc_steps,
                     "byte_model": "N_queued * (16 + 27*8 + m*16), m = candidate points measured per queued query (counted in one extra untimed step); kernel times from "
                                   f"{acc_steps} untimed steps without the early fitness waves (MRGFE_NO_EARLY_FIT=1: one fitness launch per step, behind the alignment)"}
+        # parity at the stated size: every pair of the step against the oracle running the reference's sequential loop per new keyframe
+        # (loop_detector.cpp:104,126-145: transform, convergence, iterations, getFitnessScore(inf), best candidate); over-the-bar pairs are replayed in
+        # the kernels' summation order (oracle/replay.py) — rank 0 of the 1-GPU run only, outside every timed region
+        parity = None
+        if not args.no_cpu and rank == 0 and world == 1 and full_shape and not args.no_shard_parity:
+            from oracle.replay import loop_parity
+
+            def single(i):
+                reg = NdtHip(resolution=1.0, transformation_epsilon=args.eps, maximum_iterations=64, ctx=ctx)
+                a, b = loop_pairs[i][0], loop_pairs[i][1]
+                reg.setInputTargetDevice(l_dev[a].data_ptr(), len(l_host[a]))
+                reg.setInputSourceDevice(l_dev[b].data_ptr(), len(l_host[b]))
+                reg.align(loop_pairs[i][2])
+                return reg.getFinalTransformation(), reg.hasConverged(), reg.getFinalNumIteration()
+
+            tp = time.perf_counter()
+            parity = loop_parity(l_host, loop_pairs, full, args.eps, single_runner=single)
+            parity["seconds"] = time.perf_counter() - tp
+        raw_digest = sha16(loop_raw)
         return {"pairs_total": n_pairs, "new_keyframes": len(groups), "pairs_per_gpu": int(len(mine)), "targets_built_per_gpu": len(my_targets),
+                "parity_vs_oracle": parity, "raw_inputs_sha256_16": raw_digest,
+                "raw_inputs_as_in_the_build_container": (raw_digest == EXPECTED_RAW_INPUTS["config3_64_keyframes"]) if EXPECTED_RAW_INPUTS["config3_64_keyframes"] else None,
+                "pmc_reference": pmc_reference(pmc_name, pmc),
                 "steps": steps, "ms_per_step": 1e3 * elapsed / steps, "alignments_per_s": n_pairs * steps / elapsed, "scaling": "strong",
                 "projected_for_gpus": fake_world or None,
                 "fitness_max_range": "inf", "converged": int(full["converged"].sum()), "matched_keyframes": int(sum(b[0] is not None for b in best.values())),
@@ -526,6 +601,7 @@ def main():
         cold = args.cold_every > 0 and b % args.cold_every == args.cold_every - 1
         guess = np.eye(4) if cold else synth.warm_guess(rels[k], 1000 * rank + b)
         pairs.append((k, k + 1, guess, rels[k], cold))
+    raw_digest = sha16(raw)
     n_pts = float(np.mean([len(scans[p[1]]) for p in pairs]))
     n_src_per_step = float(sum(len(scans[p[1]]) for p in pairs)) / args.batch  # mean source points per alignment
     hbm_input_bytes = 16.0 * sum(len(scans[p[0]]) + len(scans[p[1]]) for p in pairs)
@@ -735,6 +811,29 @@ def main():
         parity = {"pairs": n_par, "max_dt_m": max(dts), "max_dr_rad": max(drs), "pairs_over_bar": over, "pairs_with_other_iterations_or_convergence": mism,
                   "pairs_at_the_iteration_limit": capped, "same_iterations_and_convergence": mism == 0, "bar": "1e-4 m / 1e-4 rad"}
 
+    # ---- every tolerated over-the-bar case as a number: the randomised soak of the GPU suite, a bounded sample of it per run
+    soak = None
+    if not args.no_cpu and args.soak_cases > 0 and rank == 0 and world == 1:
+        from oracle.replay import ndt_soak, round3_soak
+
+        ts = time.perf_counter()
+        a = ndt_soak(args.soak_cases, 20260411)
+        b = round3_soak(max(1, args.soak_cases // 3), 20260412)
+        soak = {"ndt": f"{a['ndt_over_bar']}/{a['ndt']}", "ndt_settled": f"{a['ndt_settled_over_bar']}/{a['ndt_settled']}",
+                "ndt_over_bar_equal_to_gpu_order_replay": f"{a['ndt_over_bar_equal_to_gpu_order_replay']}/{a['ndt_over_bar']}",
+                "ndt_bit_identical_to_reference_order_oracle": f"{a['ndt_exact_ref']}/{a['ndt']}", "ndt_bit_identical_to_gpu_order_replay": f"{a['ndt_exact_gpu_order']}/{a['ndt']}",
+                "ndt_worst_settled_m_or_rad": a["ndt_worst_settled"], "ndt_worst_m_or_rad": a["ndt_worst"],
+                "icp_gicp_vgicp_small_gicp": f"{a['other_over_bar']}/{a['other']}", "icp_gicp_vgicp_small_gicp_bit_identical": f"{a['other_exact']}/{a['other']}",
+                "pcl_gicp": f"{b['gicp_over_bar']}/{b['gicp']}", "pcl_gicp_over_bar_equal_to_gpu_order_replay": f"{b['gicp_over_bar_equal_to_gpu_order_replay']}/{b['gicp_over_bar']}",
+                "pcl_gicp_bit_identical_to_gpu_order_replay": f"{b['gicp_exact_gpu_order']}/{b['gicp']}", "pcl_gicp_bit_identical_to_reference_order_oracle": f"{b['gicp_exact_ref']}/{b['gicp']}",
+                "pcl_gicp_worst_m_or_rad": b["gicp_worst"], "icp_reciprocal": f"{b['icp_over_bar']}/{b['icp']}",
+                "worst_m": max(a["ndt_worst"], a["other_worst"], b["gicp_worst"], b["icp_worst"]),
+                "flag_or_iteration_mismatches": a["ndt_flag_or_iteration_mismatch"] + a["other_flag_mismatch"] + b["gicp_flag_or_iteration_mismatch"] + b["icp_flag_or_iteration_mismatch"],
+                "over_bar_cases": a["over_bar"] + b["over_bar"], "seconds": time.perf_counter() - ts,
+                "what": f"{args.soak_cases} + {max(1, args.soak_cases // 3)} random 1.5k-9k-point scenes (oracle/replay.py, seeds 20260411 / 20260412: every method, resolution 0.5-2 m, four NDT "
+                        "neighbourhoods, eps 0.1-0.001, warm and identity guesses), k/N = scenes over the 1e-4 m / 1e-4 rad bar against the reference-order oracle; "
+                        "'settled' = converged within 30 iterations on both sides; a larger run of the same soak is kept under profiles/"}
+
     # dominant kernel.  Fused launches (default): ndt_derivatives_all_kernel<7>, ONE launch per round that runs the work items of all
     # three evaluation kinds (score + gradient + Hessian, score + gradient, f64 Hessian): its time and launch count are reported
     # under variant 0 by the library, its algorithmic bytes are those of all three kinds.  MRGFE_FUSED=0: ndt_derivatives_kernel<0,7>
@@ -798,8 +897,12 @@ def main():
                                                       "f64_hessian": per_mode[2][2] / max(k_launch, 1)},
                      "score_gradient_hessian_variant_alone": alone,
                      "variants": variants},
+        "pmc_reference": pmc_reference(prof_name, pj),
         "cpu_baseline": cpu,
         "parity_vs_oracle": parity,
+        "soak_over_bar": soak,
+        "raw_inputs_sha256_16": raw_digest,
+        "raw_inputs_as_in_the_build_container": (raw_digest == EXPECTED_RAW_INPUTS["config1_rank0_257_scans"]) if (EXPECTED_RAW_INPUTS["config1_rank0_257_scans"] and rank == 0 and args.distinct == 256 and scene is not None) else None,
         "evaluations_per_alignment": evals / (args.batch * args.steps),
         "evaluations_launched_per_alignment": float(launched[0] / (n_src_per_step * args.batch * args.steps)) if n_src_per_step else None,
         "iterations_per_alignment": iters / (args.batch * args.steps),

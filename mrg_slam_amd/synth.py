@@ -16,6 +16,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 BASE_SEED = 20251003  # seeds are BASE_SEED + scan_index
+GENERATOR_VERSION = 2  # part of the scan cache's file names: 2 = host-independent arithmetic (round 4)
 
 
 # --------------------------------------------------------------------------------------------------------
@@ -362,7 +363,7 @@ def synth_lidar_many(scene: Scene, poses, model: str, seeds, workers: int | None
     cache = None
     if cache_tag:
         root = os.environ.get("BENCH_CACHE", "/tmp/mrgfe_synth_cache")
-        cache = os.path.join(root, cache_tag + ".npz")
+        cache = os.path.join(root, f"{cache_tag}_v{GENERATOR_VERSION}.npz")
         if os.path.exists(cache):
             try:
                 z = np.load(cache)

@@ -577,6 +577,8 @@ double Ndt::compute_derivatives_gpu_order(double grad[6], double hess[36], const
     const size_t nblk = static_cast<size_t>((n + per_item - 1) / per_item);
     std::vector<double> partials(std::max<size_t>(nblk, 1) * 48, 0.0);
     long long nb_total = 0;
+    // (items are independent and every item owns its partial record: the loop may run on any number of threads without touching the order of a sum)
+#pragma omp parallel for num_threads(std::max(1, num_threads)) schedule(dynamic, 1) reduction(+ : nb_total)
     for (size_t item = 0; item < nblk; ++item) {
         std::vector<double> acc(256 * 48, 0.0);
         const int base = static_cast<int>(item) * per_item, last = std::min(n, base + per_item);
@@ -628,6 +630,8 @@ void Ndt::compute_hessian_gpu_order(double hess[36], const double p[6])
     long long nb_total = 0;
     auto fd3 = [](double a0, double b0, double a1, double b1, double a2, double b2) { return std::fma(a2, b2, std::fma(a1, b1, a0 * b0)); };
     auto fd3z = [](double a1, double b1, double a2, double b2) { return std::fma(a2, b2, a1 * b1); };
+    // (items are independent and every item owns its partial record: the loop may run on any number of threads without touching the order of a sum)
+#pragma omp parallel for num_threads(std::max(1, num_threads)) schedule(dynamic, 1) reduction(+ : nb_total)
     for (size_t item = 0; item < nblk; ++item) {
         std::vector<double> acc(256 * 48, 0.0);
         const int base = static_cast<int>(item) * per_item, last = std::min(n, base + per_item);

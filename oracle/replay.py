@@ -1,0 +1,307 @@
+"""Checker utilities shared by tests/ and bench.py's parity legs (TEST INFRASTRUCTURE, like everything under oracle/: the product
+never imports this; this module drives the product through its C ABI to hold it against the CPU restatement).
+
+* :func:`drive` — the product's NDT optimiser state machine (csrc/ndt_ctl.h behind ``mrgfe_dbg_ctl_*``) stepped on the CPU with an
+  oracle object supplying every derivative evaluation it asks for.  With ``orc.Ndt(gpu_order_ppt=k)`` as the evaluator this is the
+  *GPU-order replay*: same per-pair float terms as the HIP kernels, added in the kernels' order => the same doubles, so a HIP
+  trajectory must repeat bit for bit.
+* :func:`soak_scene`, :func:`ndt_soak`, :func:`round3_soak` — the randomised parity soak (small scenes, every method, resolutions,
+  neighbourhoods, epsilons, guesses).  The GPU suite asserts on the returned counts; bench.py prints them (``soak_over_bar``), so a
+  tolerated over-the-bar case is a NUMBER in the driver-run line and not an allowance inside a test.
+* :func:`loop_parity` — BASELINE config[3] held against the reference's sequential loop (loop_detector.cpp:104,126-145) pair by pair.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+_fp, _dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+BAR = 1e-4  # north_star: <= 1e-4 m translation / <= 1e-4 rad rotation
+
+
+def small_cloud(n=2000, seed=0, extent=(20.0, 12.0, 3.0)):
+    """Structured random cloud: a ground plane, two walls and scattered clutter (N x 4 float32)."""
+    rng = np.random.default_rng(seed)
+    n_g, n_w = int(n * 0.45), int(n * 0.2)
+    n_c = n - n_g - 2 * n_w
+    g = np.stack([rng.uniform(-extent[0], extent[0], n_g), rng.uniform(-extent[1], extent[1], n_g), -1.73 + rng.normal(0, 0.02, n_g)], 1)
+    w1 = np.stack([rng.uniform(-extent[0], extent[0], n_w), extent[1] * 0.9637 + rng.normal(0, 0.02, n_w), rng.uniform(-1.7, extent[2], n_w)], 1)
+    w2 = np.stack([extent[0] * 0.5817 + rng.normal(0, 0.02, n_w), rng.uniform(-extent[1], extent[1], n_w), rng.uniform(-1.7, extent[2], n_w)], 1)
+    c = np.stack([rng.uniform(-extent[0], extent[0], n_c), rng.uniform(-extent[1], extent[1], n_c), rng.uniform(-1.7, extent[2], n_c)], 1)
+    xyz = np.concatenate([g, w1, w2, c]).astype(np.float32)
+    xyz = xyz[rng.permutation(len(xyz))]
+    out = np.empty((len(xyz), 4), dtype=np.float32)
+    out[:, :3] = xyz
+    out[:, 3] = rng.uniform(0, 1, len(xyz)).astype(np.float32)
+    return out
+
+
+def drive(orc_ndt, params, guess, n_src):
+    """Step the product's optimiser on the CPU; ``orc_ndt.evaluate`` answers its requests.  Returns (T 4x4 float32, converged,
+    iterations, evaluations, list of requested evaluation kinds)."""
+    from mrg_slam_amd._lib import check, lib
+
+    h = C.c_void_p()
+    g = np.ascontiguousarray(np.asarray(guess, dtype=np.float32).T)
+    check(lib().mrgfe_dbg_ctl_create(C.byref(params), g.ctypes.data_as(_fp), n_src, C.byref(h)))
+    modes = []
+    try:
+        mode, Tc, p = C.c_int(0), np.empty((4, 4), dtype=np.float32), np.empty(6)
+        while lib().mrgfe_dbg_ctl_request(h, C.byref(mode), Tc.ctypes.data_as(_fp), p.ctypes.data_as(_dp)):
+            assert len(modes) < 2000
+            s, grad, H = orc_ndt.evaluate(Tc.T.copy(), p, mode.value)
+            modes.append(mode.value)
+            check(lib().mrgfe_dbg_ctl_result(h, s, np.ascontiguousarray(grad).ctypes.data_as(_dp), np.ascontiguousarray(H).ctypes.data_as(_dp), 0.0))
+        conv, it, ev = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().mrgfe_dbg_ctl_final(h, Tc.ctypes.data_as(_fp), C.byref(conv), C.byref(it), C.byref(ev)))
+        return Tc.T.copy(), bool(conv.value), it.value, ev.value, modes
+    finally:
+        lib().mrgfe_dbg_ctl_destroy(h)
+
+
+def _diff(Tg, To):
+    from mrg_slam_amd import synth
+
+    return float(np.linalg.norm(np.asarray(Tg, dtype=np.float64)[:3, 3] - np.asarray(To, dtype=np.float64)[:3, 3])), float(synth.rotation_angle(Tg, To))
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# randomised soak
+# ------------------------------------------------------------------------------------------------------------------------
+def soak_scene(rng):
+    from mrg_slam_amd import synth
+
+    from . import oracle as orc
+
+    n = int(rng.integers(1500, 9000))
+    tgt = small_cloud(n, int(rng.integers(1 << 30)), extent=(float(rng.uniform(15, 45)), float(rng.uniform(10, 40)), float(rng.uniform(2, 6))))
+    rel = synth.make_pose(rng.normal(0, 0.3, 3), synth.rot_xyz(*rng.normal(0, 0.03, 3)))
+    src = orc.transform_points(np.linalg.inv(rel), tgt[: int(n * rng.uniform(0.5, 1.0))])
+    src[:, :3] += rng.normal(0, 0.01, (len(src), 3)).astype(np.float32)
+    guess = synth.perturb_pose(rel if rng.random() < 0.7 else np.eye(4), rng)
+    return tgt, src, guess, float(rng.choice([0.1, 0.01, 0.001]))
+
+
+def ndt_soak(cases: int, seed: int, ndt_share: float = 0.75):
+    """Random scenes over NDT (all neighbourhoods / resolutions) and ICP / VGICP / GICP / SMALL_GICP, HIP against the oracle.  Every NDT
+    alignment is held against the reference-order oracle AND the GPU-order replay.  Returns the counts (no assertion here)."""
+    from mrg_slam_amd import GicpHip, IcpHip, NdtHip, SmallGicpHip, VgicpHip
+    from mrg_slam_amd._lib import NDT_HIP, SEARCH, lib
+    from mrg_slam_amd.registration import default_params
+
+    from . import oracle as orc
+
+    lib().mrgfe_dbg_set_host_control(-1)
+    rng = np.random.default_rng(seed)
+    st = {"cases": cases, "seed": seed, "ndt": 0, "ndt_exact_ref": 0, "ndt_exact_gpu_order": 0, "ndt_settled": 0, "ndt_over_bar": 0, "ndt_settled_over_bar": 0,
+          "ndt_over_bar_equal_to_gpu_order_replay": 0, "ndt_worst_settled": 0.0, "ndt_worst": 0.0, "ndt_flag_or_iteration_mismatch": 0,
+          "other": 0, "other_exact": 0, "other_over_bar": 0, "other_worst": 0.0, "other_flag_mismatch": 0,
+          "over_bar": [], "unexplained": []}
+    for c in range(cases):
+        tgt, src, guess, eps = soak_scene(rng)
+        kind = rng.random()
+        if kind < ndt_share:
+            res = float(rng.choice([0.5, 1.0, 1.5, 2.0]))
+            search = str(rng.choice(["DIRECT7", "DIRECT1", "DIRECT26", "KDTREE"]))
+            g = NdtHip(resolution=res, transformation_epsilon=eps, maximum_iterations=64, search=search)
+            o = orc.Ndt(resolution=res, transformation_epsilon=eps, maximum_iterations=64, num_threads=8, search=search)
+            tag = f"case {c}: NDT res={res} {search} eps={eps}"
+        else:
+            sub = rng.random()
+            if sub < 0.2:
+                g, o, tag = IcpHip(transformation_epsilon=eps * 1e-3), orc.Icp(transformation_epsilon=eps * 1e-3), f"case {c}: ICP"
+            elif sub < 0.45:
+                vres = float(rng.choice([0.5, 1.0, 2.0]))
+                g, o, tag = VgicpHip(resolution=vres, transformation_epsilon=eps), orc.FastVgicp(resolution=vres, transformation_epsilon=eps, num_threads=1), f"case {c}: VGICP"
+            elif sub < 0.72:
+                g, o, tag = GicpHip(transformation_epsilon=eps), orc.FastGicp(transformation_epsilon=eps, num_threads=8), f"case {c}: GICP"
+            else:
+                g, o, tag = SmallGicpHip(transformation_epsilon=eps), orc.SmallGicp(transformation_epsilon=eps, num_threads=8), f"case {c}: SMALL_GICP"
+        for r in (g, o):
+            r.setInputTarget(tgt)
+            r.setInputSource(src)
+            r.align(guess)
+        Tg, To = g.getFinalTransformation(), o.getFinalTransformation()
+        dt, dr = _diff(Tg, To)
+        exact = bool(np.array_equal(Tg, To))
+        if not isinstance(g, NdtHip):
+            st["other"] += 1
+            st["other_exact"] += exact
+            st["other_flag_mismatch"] += int(bool(g.hasConverged()) != bool(o.hasConverged()))
+            st["other_over_bar"] += int(dt > BAR or dr > BAR)
+            st["other_worst"] = max(st["other_worst"], dt, dr)
+            continue
+        st["ndt"] += 1
+        st["ndt_exact_ref"] += exact
+        st["ndt_worst"] = max(st["ndt_worst"], dt, dr)
+        st["ndt_flag_or_iteration_mismatch"] += int(bool(g.hasConverged()) != bool(o.hasConverged()) or g.getFinalNumIteration() != o.getFinalNumIteration())
+        # the same alignment replayed on the CPU in the GPU's summation order
+        p = default_params(NDT_HIP)
+        p.resolution, p.transformation_epsilon, p.maximum_iterations, p.nn_search_method = res, eps, 64, SEARCH[search]
+        d = orc.Ndt(resolution=res, transformation_epsilon=eps, maximum_iterations=64, num_threads=1, search=search, gpu_order_ppt=1)
+        d.setInputTarget(tgt)
+        d.setInputSource(src)
+        Tr, conv_r, it_r, ev_r, _ = drive(d, p, guess, len(src))
+        same = bool(np.array_equal(Tg, Tr) and bool(g.hasConverged()) == conv_r and g.getFinalNumIteration() == it_r and g.evals == ev_r)
+        st["ndt_exact_gpu_order"] += same
+        settled = bool(o.hasConverged() and g.hasConverged() and o.getFinalNumIteration() <= 30 and g.getFinalNumIteration() <= 30)
+        over = dt > BAR or dr > BAR
+        st["ndt_settled"] += settled
+        if settled:
+            st["ndt_worst_settled"] = max(st["ndt_worst_settled"], dt, dr)
+        if over:
+            st["ndt_over_bar"] += 1
+            st["ndt_settled_over_bar"] += settled
+            st["ndt_over_bar_equal_to_gpu_order_replay"] += same
+            st["over_bar"].append({"case": tag, "dt_m": dt, "dr_rad": dr, "iterations_hip": int(g.getFinalNumIteration()), "iterations_oracle": int(o.getFinalNumIteration()),
+                                   "settled": settled, "equal_to_gpu_order_replay": same})
+        if not exact and not same:
+            st["unexplained"].append({"case": tag, "dt_m": dt, "dt_vs_replay_m": _diff(Tg, Tr)[0], "iterations_hip": int(g.getFinalNumIteration()), "iterations_replay": int(it_r)})
+    return st
+
+
+def round3_soak(cases: int, seed: int):
+    """pcl::GICP (both stopping rules of its BFGS) and ICP with reciprocal correspondences: HIP against the reference-order oracle and — pcl::GICP
+    — against the oracle run with its cost sums in the kernels' order."""
+    from mrg_slam_amd import IcpHip, PclGicpHip
+
+    from . import oracle as orc
+
+    rng = np.random.default_rng(seed)
+    st = {"cases": cases, "seed": seed, "gicp": 0, "gicp_exact_ref": 0, "gicp_exact_gpu_order": 0, "gicp_over_bar": 0, "gicp_over_bar_equal_to_gpu_order_replay": 0,
+          "gicp_worst": 0.0, "gicp_flag_or_iteration_mismatch": 0, "icp": 0, "icp_exact": 0, "icp_over_bar": 0, "icp_worst": 0.0, "icp_flag_or_iteration_mismatch": 0, "over_bar": []}
+    for c in range(cases):
+        tgt, src, guess, eps = soak_scene(rng)
+        kind = rng.random()
+        replay = None
+        if kind < 0.7:
+            omp = kind >= 0.4
+            g, o, tag = PclGicpHip(transformation_epsilon=eps, omp=omp), orc.PclGicp(transformation_epsilon=eps, omp=omp, num_threads=8), f"case {c}: PCL GICP{'_OMP' if omp else ''} eps={eps}"
+            replay = orc.PclGicp(transformation_epsilon=eps, omp=omp, num_threads=1, gpu_order=True)
+        else:
+            g, o, tag = (IcpHip(transformation_epsilon=eps * 1e-3, use_reciprocal_correspondences=True),
+                         orc.Icp(transformation_epsilon=eps * 1e-3, use_reciprocal_correspondences=True), f"case {c}: ICP reciprocal")
+        for r in (g, o) + ((replay,) if replay else ()):
+            r.setInputTarget(tgt)
+            r.setInputSource(src)
+            r.align(guess)
+        Tg, To = g.getFinalTransformation(), o.getFinalTransformation()
+        dt, dr = _diff(Tg, To)
+        mism = int(bool(g.hasConverged()) != bool(o.hasConverged()) or g.getFinalNumIteration() != o.getFinalNumIteration())
+        if replay is None:
+            st["icp"] += 1
+            st["icp_exact"] += bool(np.array_equal(Tg, To))
+            st["icp_over_bar"] += int(dt > BAR or dr > BAR)
+            st["icp_worst"] = max(st["icp_worst"], dt, dr)
+            st["icp_flag_or_iteration_mismatch"] += mism
+            continue
+        st["gicp"] += 1
+        st["gicp_exact_ref"] += bool(np.array_equal(Tg, To))
+        same = bool(np.array_equal(Tg, replay.getFinalTransformation()) and g.getFinalNumIteration() == replay.getFinalNumIteration())
+        st["gicp_exact_gpu_order"] += same
+        st["gicp_worst"] = max(st["gicp_worst"], dt, dr)
+        st["gicp_flag_or_iteration_mismatch"] += mism
+        if dt > BAR or dr > BAR:
+            st["gicp_over_bar"] += 1
+            st["gicp_over_bar_equal_to_gpu_order_replay"] += same
+            st["over_bar"].append({"case": tag, "dt_m": dt, "dr_rad": dr, "equal_to_gpu_order_replay": same})
+    return st
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# BASELINE config[3] against the reference's sequential loop
+# ------------------------------------------------------------------------------------------------------------------------
+def loop_parity(scans, pairs, records, eps: float, workers: int | None = None, threads_per_worker: int = 2, replay_limit: int = 6, single_runner=None):
+    """Hold the records of a loop-closure batch against the oracle running the reference's loop keyframe by keyframe:
+    ``setInputTarget(new keyframe)`` once (loop_detector.cpp:104), then per candidate ``setInputSource`` / ``align(guess)`` /
+    ``getFitnessScore(inf)`` and the best-score rule (:126-145).
+
+    ``scans[i]``: host clouds; ``pairs[k] = (new keyframe, candidate, guess, ...)`` sorted by new keyframe; ``records``: the HIP
+    batch's ``mrgfe_pair_result`` array in pair order.  Keyframe groups are dealt to ``workers`` host threads (an oracle object each;
+    the ctypes calls release the interpreter lock).  Every pair over the 1e-4 m / 1e-4 rad bar is then *explained* (up to
+    ``replay_limit`` of them, the rest counted): replayed on the CPU through the product's optimiser with the oracle evaluating in the
+    kernels' summation order (tiles per work item 8 / 4 / 2 / 1 — a batch round picks it from the number of busy pairs); a pair whose HIP
+    record equals one of these replays bit for bit differs from the reference-order run by the ORDER of the f64 additions alone.
+    ``single_runner(pair index) -> (T, converged, iterations)`` (optional): the same pair as a single HIP registration (one tile per item),
+    compared with the ppt = 1 replay when the batch record matched none."""
+    from mrg_slam_amd import loop_closure
+    from mrg_slam_amd._lib import NDT_HIP, SEARCH
+    from mrg_slam_amd.registration import default_params, result_matrix
+
+    from . import oracle as orc
+
+    groups: dict = {}
+    for i, pr in enumerate(pairs):
+        groups.setdefault(pr[0], []).append(i)
+    n = len(pairs)
+    workers = workers or max(1, min(16, (os.cpu_count() or 1) // max(1, threads_per_worker), len(groups)))
+    o_T = np.zeros((n, 4, 4), dtype=np.float32)
+    o_conv, o_it, o_fit = np.zeros(n, dtype=bool), np.zeros(n, dtype=np.int64), np.zeros(n)
+    o_best = {}
+
+    def run_group(a):
+        o = orc.Ndt(resolution=1.0, transformation_epsilon=eps, maximum_iterations=64, num_threads=threads_per_worker)
+        o.setInputTarget(scans[a])
+        best_score, best = np.finfo(np.float64).max, None
+        for k, i in enumerate(groups[a]):
+            o.setInputSource(scans[pairs[i][1]])
+            o.align(pairs[i][2])
+            score = o.getFitnessScore(float("inf"))
+            o_T[i], o_conv[i], o_it[i], o_fit[i] = o.getFinalTransformation(), o.hasConverged(), o.getFinalNumIteration(), score
+            if not o.hasConverged() or score > best_score:  # loop_detector.cpp:138-144
+                continue
+            best_score, best = score, k
+        o_best[a] = (best, best_score)
+
+    with ThreadPoolExecutor(workers) as pool:
+        list(pool.map(run_group, sorted(groups)))
+
+    dts, drs = np.zeros(n), np.zeros(n)
+    for i in range(n):
+        dts[i], drs[i] = _diff(result_matrix(records[i]), o_T[i])
+    over = [i for i in range(n) if dts[i] > BAR or drs[i] > BAR]
+    mism = [i for i in range(n) if bool(records[i]["converged"]) != bool(o_conv[i]) or int(records[i]["iterations"]) != int(o_it[i])]
+    exact = int(sum(np.array_equal(result_matrix(records[i]), o_T[i]) for i in range(n)))
+    settled = lambda i: bool(o_conv[i] and records[i]["converged"] and o_it[i] <= 30 and records[i]["iterations"] <= 30)  # noqa: E731
+    within = [i for i in range(n) if i not in set(over)]
+    fit_rel = [abs(float(records[i]["fitness"]) - o_fit[i]) / max(abs(o_fit[i]), 1e-300) for i in within if np.isfinite(o_fit[i]) and o_fit[i] < 1e300]
+    best_mism = 0
+    for a, ids in groups.items():
+        gbest, _ = loop_closure.select_best(records[ids])
+        best_mism += int(gbest != o_best[a][0])
+    # ---- explain the pairs over the bar
+    explained, details = 0, []
+    p = default_params(NDT_HIP)
+    p.resolution, p.transformation_epsilon, p.maximum_iterations, p.nn_search_method = 1.0, eps, 64, SEARCH["DIRECT7"]
+    for i in over[:replay_limit]:
+        a, b, guess = pairs[i][0], pairs[i][1], pairs[i][2]
+        Tg = result_matrix(records[i])
+        how = None
+        replay_1 = None
+        for ppt in (8, 4, 2, 1):
+            d = orc.Ndt(resolution=1.0, transformation_epsilon=eps, maximum_iterations=64, num_threads=8, gpu_order_ppt=ppt)  # (items in parallel: the sums keep their order)
+            d.setInputTarget(scans[a])
+            d.setInputSource(scans[b])
+            Tr, conv_r, it_r, _, _ = drive(d, p, guess, len(scans[b]))
+            if ppt == 1:
+                replay_1 = (Tr, conv_r, it_r)
+            if np.array_equal(Tg, Tr) and bool(records[i]["converged"]) == conv_r and int(records[i]["iterations"]) == it_r:
+                how = f"batch record == GPU-order replay (tiles per item {ppt})"
+                break
+        if how is None and single_runner is not None:
+            Ts, conv_s, it_s = single_runner(i)
+            if np.array_equal(Ts, replay_1[0]) and bool(conv_s) == replay_1[1] and int(it_s) == replay_1[2]:
+                ds = _diff(Ts, o_T[i])
+                how = f"the pair as a single HIP registration == GPU-order replay (1 tile per item) and is itself {ds[0]:.2e} m / {ds[1]:.2e} rad from the reference-order oracle"
+        explained += how is not None
+        details.append({"pair": int(i), "dt_m": float(dts[i]), "dr_rad": float(drs[i]), "iterations_hip": int(records[i]["iterations"]), "iterations_oracle": int(o_it[i]),
+                        "settled": settled(i), "explained_by": how})
+    return {"pairs": n, "new_keyframes": len(groups), "bar": "1e-4 m / 1e-4 rad", "oracle": "sequential loop per new keyframe (loop_detector.cpp:104,126-145), reference-order sums",
+            "max_dt_m": float(dts.max()) if n else 0.0, "max_dr_rad": float(drs.max()) if n else 0.0, "pairs_bit_identical": exact, "pairs_over_bar": len(over),
+            "pairs_over_bar_settled": int(sum(settled(i) for i in over)), "pairs_over_bar_replayed": len(details), "pairs_over_bar_equal_to_gpu_order_replay": int(explained),
+            "pairs_with_other_iterations_or_convergence": len(mism), "pairs_at_the_iteration_limit": int((o_it > 64).sum()),
+            "fitness_max_rel_diff_pairs_within_bar": float(max(fit_rel)) if fit_rel else 0.0, "best_candidate_mismatches": best_mism,
+            "median_dt_m": float(np.median(dts)) if n else 0.0, "over_bar": details, "host_threads": [workers, threads_per_worker]}

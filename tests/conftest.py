@@ -18,21 +18,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with `pytest -m gpu`)")
 
 
-def small_cloud(n=2000, seed=0, extent=(20.0, 12.0, 3.0)):
-    """Structured random cloud: a ground plane, two walls and scattered clutter (N x 4 float32)."""
-    rng = np.random.default_rng(seed)
-    n_g, n_w = int(n * 0.45), int(n * 0.2)
-    n_c = n - n_g - 2 * n_w
-    g = np.stack([rng.uniform(-extent[0], extent[0], n_g), rng.uniform(-extent[1], extent[1], n_g), -1.73 + rng.normal(0, 0.02, n_g)], 1)
-    w1 = np.stack([rng.uniform(-extent[0], extent[0], n_w), extent[1] * 0.9637 + rng.normal(0, 0.02, n_w), rng.uniform(-1.7, extent[2], n_w)], 1)
-    w2 = np.stack([extent[0] * 0.5817 + rng.normal(0, 0.02, n_w), rng.uniform(-extent[1], extent[1], n_w), rng.uniform(-1.7, extent[2], n_w)], 1)
-    c = np.stack([rng.uniform(-extent[0], extent[0], n_c), rng.uniform(-extent[1], extent[1], n_c), rng.uniform(-1.7, extent[2], n_c)], 1)
-    xyz = np.concatenate([g, w1, w2, c]).astype(np.float32)
-    xyz = xyz[rng.permutation(len(xyz))]
-    out = np.empty((len(xyz), 4), dtype=np.float32)
-    out[:, :3] = xyz
-    out[:, 3] = rng.uniform(0, 1, len(xyz)).astype(np.float32)
-    return out
+from oracle.replay import small_cloud  # noqa: E402,F401  (one definition: the soak of oracle/replay.py and bench.py use it too)
 
 
 @pytest.fixture(scope="session")

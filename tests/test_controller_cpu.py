@@ -13,25 +13,7 @@ from conftest import small_cloud
 _fp, _dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
 
 
-def _drive(orc_ndt, params, guess, n_src):
-    from mrg_slam_amd._lib import check, lib
-
-    h = C.c_void_p()
-    g = np.ascontiguousarray(np.asarray(guess, dtype=np.float32).T)
-    check(lib().mrgfe_dbg_ctl_create(C.byref(params), g.ctypes.data_as(_fp), n_src, C.byref(h)))
-    modes = []
-    try:
-        mode, Tc, p = C.c_int(0), np.empty((4, 4), dtype=np.float32), np.empty(6)
-        while lib().mrgfe_dbg_ctl_request(h, C.byref(mode), Tc.ctypes.data_as(_fp), p.ctypes.data_as(_dp)):
-            assert len(modes) < 2000
-            s, grad, H = orc_ndt.evaluate(Tc.T.copy(), p, mode.value)
-            modes.append(mode.value)
-            check(lib().mrgfe_dbg_ctl_result(h, s, np.ascontiguousarray(grad).ctypes.data_as(_dp), np.ascontiguousarray(H).ctypes.data_as(_dp), 0.0))
-        conv, it, ev = C.c_int(0), C.c_int(0), C.c_int(0)
-        check(lib().mrgfe_dbg_ctl_final(h, Tc.ctypes.data_as(_fp), C.byref(conv), C.byref(it), C.byref(ev)))
-        return Tc.T.copy(), bool(conv.value), it.value, ev.value, modes
-    finally:
-        lib().mrgfe_dbg_ctl_destroy(h)
+from oracle.replay import drive as _drive  # noqa: E402  (shared with the soak and bench.py's parity legs)
 
 
 @pytest.mark.parametrize("split", [False, True])
