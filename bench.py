@@ -514,6 +514,49 @@ def main():
         lib().mrgfe_dbg_set_fit_stats(0)
         del os.environ["MRGFE_NO_EARLY_FIT"]
         mbar = cs["points"] / cs["queued"] if cs["queued"] else 0.0
+        # per-rank phase times (host clock, a synchronisation between the phases: NOT how the timed step runs — there the phases follow each other
+        # without a host wait — but what each rank spends where, so that a measured scaling curve explains its own efficiency)
+        NPH = 7
+        ph = np.zeros((3, NPH))
+        for rep in range(ph.shape[0]):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            bm.clear()
+            if len(mine):
+                bm.add_device(*shard_args)
+            t1 = time.perf_counter()
+            bm.build_targets()
+            ctx.synchronize()
+            t2 = time.perf_counter()
+            bm.align(-1.0)  # the alignment rounds alone (no getFitnessScore)
+            t3 = time.perf_counter()
+            bm.clear()
+            if len(mine):
+                bm.add_device(*shard_args)
+            ctx.synchronize()
+            t4 = time.perf_counter()
+            local = bm.align(float("inf"))
+            t5 = time.perf_counter()
+            local["pair_id"] = mine.astype(np.int32)
+            rec = all_gather_records(local, per) if world > 1 else local
+            t6 = time.perf_counter()
+            fl = np.zeros(n_pairs, dtype=RESULT_DTYPE)
+            fl["pair_id"] = -1
+            fl[rec["pair_id"]] = rec
+            lc.select_best_groups(fl, group_ids)
+            t7 = time.perf_counter()
+            ph[rep] = [t1 - t0, t2 - t1, t3 - t2, (t5 - t4) - (t3 - t1), t6 - t5, t7 - t6, t5 - t4]
+        ph_med = 1e3 * np.median(ph, axis=0)
+        if world > 1:
+            tt = torch.from_numpy(ph_med.copy())
+            tt = tt.to(gdev) if backend == "nccl" else tt
+            allp = torch.empty(world * NPH, dtype=torch.float64, device=tt.device)
+            dist.all_gather_into_tensor(allp, tt)
+            allp = allp.cpu().numpy().reshape(world, NPH)
+        else:
+            allp = ph_med.reshape(1, NPH)
+        phase_names = ("queue_the_batch", "build_targets", "alignment_rounds", "fitness_passes", "record_gather", "best_candidate_replay", "align_call_with_fitness")
+        per_rank_phases = [dict({"rank": r}, **{k: round(float(v), 3) for k, v in zip(phase_names, allp[r])}) for r in range(world)]
         have = [i for i in range(n_pairs) if not fake_world or i in set(mine.tolist())]
         err = [float(np.linalg.norm(result_matrix(full[i])[:3, 3] - loop_pairs[i][3][:3, 3])) for i in have]
         digest = __import__("hashlib").sha256(full["T"].tobytes() + full["fitness"].tobytes() + full["converged"].tobytes()).hexdigest()[:16]
@@ -566,6 +609,9 @@ def main():
         raw_digest = sha16(loop_raw)
         return {"pairs_total": n_pairs, "new_keyframes": len(groups), "pairs_per_gpu": int(len(mine)), "targets_built_per_gpu": len(my_targets),
                 "parity_vs_oracle": parity, "raw_inputs_sha256_16": raw_digest,
+                "per_rank_phases_ms": per_rank_phases,
+                "per_rank_phases_note": "median of 3 untimed steps with a host synchronisation between the phases (build_targets | align without fitness | the full align call again, "
+                                        "fitness_passes = that call minus build and rounds | all-gather of the 384-byte records | best-candidate replay); the timed step runs them back to back",
                 "raw_inputs_as_in_the_build_container": (raw_digest == EXPECTED_RAW_INPUTS["config3_64_keyframes"]) if EXPECTED_RAW_INPUTS["config3_64_keyframes"] else None,
                 "pmc_reference": pmc_reference(pmc_name, pmc),
                 "steps": steps, "ms_per_step": 1e3 * elapsed / steps, "alignments_per_s": n_pairs * steps / elapsed, "scaling": "strong",

@@ -73,3 +73,43 @@ def test_two_gloo_ranks_with_the_real_matcher_equal_one_rank(tmp_path):
         np.testing.assert_array_equal(a[f], b[f], err_msg=f)
     np.testing.assert_allclose(a["H"], b["H"], rtol=1e-12)  # f64 sums carry the order of a round's items (1e-15 relative)
     assert one[0][1].strip().splitlines()[-1].split() == two[0][1].strip().splitlines()[-1].split()  # same best candidate and score (gloo chats on stdout before it)
+
+
+def test_four_gloo_ranks_uneven_shards_equal_one_rank(tmp_path):
+    """23 candidates over FOUR ranks sharing the card (blocks of 6 / 6 / 6 / 5): the all-gathered records and the replayed best candidate are
+    those of one rank matching all 23 (padding records of the short shard never reach the replay)."""
+    n = 23
+    worker = os.path.join(ROOT, "tests", "workers", "gloo_matcher_worker.py")
+    one = _run_all([[sys.executable, worker, "0", "1", "0", str(n), str(tmp_path / "one.npy")]], timeout=600)
+    assert one[0][0] == 0, one[0][2][-3000:]
+    port = _free_port()
+    four = _run_all([[sys.executable, worker, str(r), "4", str(port), str(n), str(tmp_path / "four.npy")] for r in range(4)], timeout=600)
+    for rc, o, e in four:
+        assert rc == 0, e[-3000:]
+    a, b = np.load(tmp_path / "one.npy"), np.load(tmp_path / "four.npy")
+    assert len(a) == len(b) == n
+    for f in ("T", "fitness", "converged", "iterations", "evaluations", "pair_id"):
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+    np.testing.assert_allclose(a["H"], b["H"], rtol=1e-12)
+    assert one[0][1].strip().splitlines()[-1].split() == four[0][1].strip().splitlines()[-1].split()
+
+
+def test_bench_shard_mode_two_gloo_ranks_print_the_one_rank_digest(tmp_path):
+    """`bench.py --mode shard` (BASELINE config[3], 256 pairs) as the driver's launcher would run it on two GPUs — here two gloo ranks on the one
+    card (BENCH_DIST_BACKEND=gloo), started by bench.py's own launcher as child processes: the printed line says n_gpus 2, carries both ranks'
+    phase times and the SAME record digest as the one-rank line."""
+    env = dict(os.environ, BENCH_CACHE=str(tmp_path / "cache"), OMP_NUM_THREADS="8")
+    env.pop("WORLD_SIZE", None)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "shard", "--no-cpu", "--no-extras", "--steps", "1", "--warmup", "1"]
+    one = subprocess.run(base, env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run(base + ["--gpus", "2"], env=dict(env, BENCH_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    l1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    l2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert l1["n_gpus"] == 1 and l2["n_gpus"] == 2 and l2["scaling"] == "strong"
+    s1, s2 = l1["config3_shard"], l2["config3_shard"]
+    assert s1["pairs_total"] == s2["pairs_total"] == 256 and s2["pairs_per_gpu"] == 128
+    assert s1["inputs_sha256_16"] == s2["inputs_sha256_16"] and s1["raw_inputs_as_in_the_build_container"] is True
+    assert s1["records_sha256_16"] == s2["records_sha256_16"]
+    assert [p["rank"] for p in s2["per_rank_phases_ms"]] == [0, 1] and all(p["alignment_rounds"] > 0 for p in s2["per_rank_phases_ms"])
