@@ -484,12 +484,19 @@ def main():
         deriv = np.zeros(3)   # (device ms, launches, algorithmic bytes) of the derivative launches, HIP events around every launch
         fit_acc = {"ms_block": 0.0, "ms_sweep": 0.0, "ms_far": 0.0, "queued": 0.0, "queries": 0.0, "queued_far": 0.0, "launches": 0.0}
         acc_on = {"on": False}
+        kind_bytes, kind_points, s_largest = np.zeros(3), np.zeros(3), {"ms": 0.0, "pairs": [0, 0, 0]}
         inner_step = step
 
         def step():  # noqa: F811 - the timed step plus the library's own accounting of it (read back after the step: host-side only)
             out = inner_step()
             if acc_on["on"]:
                 deriv[:] += np.array(bm.kernel_stats(-1))
+                for m in range(3):
+                    kind_bytes[m] += bm.kernel_stats(m)[2]
+                    kind_points[m] += bm.pair_counts(m)[0]
+                lm, lp = bm.largest_launch()
+                if lm > s_largest["ms"]:
+                    s_largest["ms"], s_largest["pairs"] = lm, lp
                 fs = bm.fitness_stats()
                 for k in fit_acc:
                     fit_acc[k] += fs[k]
@@ -579,6 +586,12 @@ def main():
                 "alg_bytes_per_launch": deriv[2] / deriv[1] if deriv[1] else None, "ms_per_step": deriv[0] / acc_steps,
                 "byte_model": "per launch: sum over the evaluations of all active pairs of N_src*(16 + 7*8) + valid_neighbours*48 (SURVEY.md §8d); PMC traffic of this "
                               "kernel: profiles/r03_rocprof_summary.md"}
+        n_src_mean = float(np.mean([len(l_host[loop_pairs[i][1]]) for i in mine])) if len(mine) else 0.0
+        if s_largest["ms"] > 0 and n_src_mean > 0:
+            per_eval = [kind_bytes[m] / (kind_points[m] / n_src_mean) if kind_points[m] > 0 else 0.0 for m in range(3)]
+            lb = float(sum(n * b for n, b in zip(s_largest["pairs"], per_eval)))
+            roof["largest_launch"] = {"ms": s_largest["ms"], "busy_pairs_by_kind": s_largest["pairs"], "alg_bytes": lb, "achieved_GBps": lb / 1e9 / (s_largest["ms"] / 1e3),
+                                      "frac": lb / 1e9 / (s_largest["ms"] / 1e3) / HBM_PEAK_GBPS}
         roof_fit = {"bound": "valu", "byte_model_bound": "hbm", "kernel": "nn_fit_seed_kernel + nn_fit_sweep_kernel (getFitnessScore(inf), the queries their 3x3x3 block does not settle)",
                     "achieved": f_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": f_gbps / HBM_PEAK_GBPS,
                     "traffic": pmc.get("fitness_sweep_traffic_bytes_per_step") if full_shape else None, "traffic_unit": "HBM bytes per step (compare alg_bytes_per_step)",
@@ -656,6 +669,8 @@ def main():
     per_mode = np.zeros((3, 3))  # [mode] -> (device ms, launches, algorithmic bytes), HIP events around every launch
     launched = np.zeros(2)       # (source points, valid point-voxel pairs) of the evaluations actually launched
     counters = {"evals": 0, "iters": 0, "on": False}
+    points_by_kind = np.zeros(3)   # source points of the launched evaluations, per evaluation kind
+    largest = {"ms": 0.0, "pairs": [0, 0, 0]}
 
     # one setInputTarget per alignment: every pair has its own target entry
     add_args = ([dev[p[0]].data_ptr() for p in pairs], [len(scans[p[0]]) for p in pairs], np.arange(args.batch, dtype=np.int32),
@@ -672,6 +687,11 @@ def main():
             for m in range(3):
                 per_mode[m] += bm.kernel_stats(m)
             launched[:] += np.array(bm.pair_counts())
+            for m in range(3):
+                points_by_kind[m] += bm.pair_counts(m)[0]
+            lm, lp = bm.largest_launch()
+            if lm > largest["ms"]:
+                largest["ms"], largest["pairs"] = lm, lp
             counters["evals"] += int(res["evaluations"].sum())
             counters["iters"] += int(res["iterations"].sum())
         return res
@@ -902,6 +922,14 @@ def main():
     traffic = pj.get("traffic_bytes_per_mean_launch")
     valu_busy = pj.get("valu_busy_dominant")
     alg_per_launch = (k_bytes / k_launch) if k_launch else None
+    # the largest launch of the timed steps (a trace shows it as the kernel's maximum): its round's busy pairs per kind x the mean algorithmic
+    # bytes of one evaluation of that kind
+    largest_rec = None
+    if largest["ms"] > 0 and n_src_per_step > 0:
+        per_eval = [per_mode[m][2] / (points_by_kind[m] / n_src_per_step) if points_by_kind[m] > 0 else 0.0 for m in range(3)]
+        lb = float(sum(n * b for n, b in zip(largest["pairs"], per_eval)))
+        largest_rec = {"ms": largest["ms"], "busy_pairs_by_kind": largest["pairs"], "alg_bytes": lb, "achieved_GBps": lb / 1e9 / (largest["ms"] / 1e3),
+                       "frac": lb / 1e9 / (largest["ms"] / 1e3) / HBM_PEAK_GBPS}
     ratio = (traffic / alg_per_launch) if (traffic and alg_per_launch) else None
     # what the counters say limits the kernel: HBM only if the bytes it really moves are a large share of the byte model
     limiter = "hbm" if (ratio is None or ratio >= 0.5) else "valu"
@@ -941,6 +969,7 @@ def main():
                                    "asks; `bound` is what the PMC counters say limits the kernel (most of these bytes are served by L2 / Infinity Cache: `traffic`)",
                      "alg_bytes_by_evaluation_kind": {"score+gradient+hessian": per_mode[0][2] / max(k_launch, 1), "score+gradient": per_mode[1][2] / max(k_launch, 1),
                                                       "f64_hessian": per_mode[2][2] / max(k_launch, 1)},
+                     "largest_launch": largest_rec,
                      "score_gradient_hessian_variant_alone": alone,
                      "variants": variants},
         "pmc_reference": pmc_reference(prof_name, pj),

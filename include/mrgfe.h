@@ -359,6 +359,10 @@ int  mrgfe_reg_kernel_stats(const mrgfe_reg* reg, int mode, double* deriv_ms, in
 /* source points and valid (point, voxel) pairs of the derivative evaluations the last mrgfe_batch_align launched: their ratio
  * is the k-bar of SURVEY.md §8(d) (evaluations answered from a controller's cache are not launched and not counted) */
 int  mrgfe_batch_pair_counts(const mrgfe_batch* b, int mode, double* points, double* neighbours);
+/* the longest timed derivative launch of the last mrgfe_batch_align: out[0] = device ms (HIP events), out[1..3] = pairs of each evaluation kind
+ * (score+gradient+Hessian, score+gradient, f64 Hessian) busy in its round — the launch a rocprofv3 trace shows as the kernel's maximum
+ * (diagnostic, like the two calls above: no reference counterpart) */
+int  mrgfe_batch_largest_launch(const mrgfe_batch* b, double out[4]);
 /* getFitnessScore passes of the last mrgfe_batch_align(fitness_max_range >= 0) of this batch, all launches added up (finished pairs are
  * scored in waves beside the remaining alignment rounds, the rest afterwards): the layout of mrgfe_ctx_fitness_stats, out[10] = launches. */
 int  mrgfe_batch_fitness_stats(const mrgfe_batch* b, double out[11]);

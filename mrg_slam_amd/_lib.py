@@ -172,6 +172,7 @@ SIGNATURES = {
     "mrgfe_batch_kernel_stats": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_int64), _dp]),
     "mrgfe_reg_kernel_stats": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_int64), _dp]),
     "mrgfe_batch_pair_counts": (C.c_int, [_vp, C.c_int, _dp, _dp]),
+    "mrgfe_batch_largest_launch": (C.c_int, [_vp, _dp]),
     "mrgfe_dbg_set_gicp_corr_passes": (C.c_int, [C.c_int]),
     "mrgfe_dbg_grid_set_query": (C.c_int, [_vp, C.POINTER(_fp), C.POINTER(C.c_size_t), C.c_int, _fp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int32), _fp]),
     "mrgfe_dbg_sort_pairs": (C.c_int, [_vp, _u32p, _u32p, C.c_size_t, C.c_int, _u32p, _u32p]),

@@ -1362,6 +1362,14 @@ int mrgfe_batch_kernel_stats(const mrgfe_batch* b, int mode, double* ms, int64_t
     return MRGFE_OK;
 }
 
+int mrgfe_batch_largest_launch(const mrgfe_batch* b, double out[4])
+{
+    if (!b || !out) { set_error("mrgfe_batch_largest_launch: NULL argument"); return MRGFE_ERR_INVALID; }
+    out[0] = b->ndt->largest_ms;
+    for (int m = 0; m < 3; ++m) out[1 + m] = double(b->ndt->largest_pairs[m]);
+    return MRGFE_OK;
+}
+
 int mrgfe_batch_pair_counts(const mrgfe_batch* b, int mode, double* points, double* neighbours)
 {
     if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }

@@ -506,6 +506,10 @@ void NdtEngine::account(const std::vector<NdtRoundInfo>& info, size_t rounds)
             if (hipEventElapsedTime(&ms, ev_pool_[r * 6], ev_pool_[r * 6 + 1]) != hipSuccess) continue;
             mode_ms[0] += ms;
             mode_launches[0] += 1;
+            if (ms > largest_ms && r < round_info_.size()) {
+                largest_ms = ms;
+                for (int m = 0; m < 3; ++m) largest_pairs[m] = round_info_[r].n_pairs[m];
+            }
         }
     } else
     for (size_t r = 0; r < rounds; ++r)
@@ -539,7 +543,9 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
     MRGFE_TRY(ctx_->bind());
     MRGFE_TRY(build_targets(false));
     if (pairs_dirty_) MRGFE_TRY(upload_pairs());
-    for (int m = 0; m < 3; ++m) { mode_ms[m] = 0; mode_launches[m] = 0; mode_alg_bytes[m] = 0; mode_points[m] = 0; mode_neighbours[m] = 0; }
+    for (int m = 0; m < 3; ++m) { mode_ms[m] = 0; mode_launches[m] = 0; mode_alg_bytes[m] = 0; mode_points[m] = 0; mode_neighbours[m] = 0; largest_pairs[m] = 0; }
+    largest_ms = 0;
+    round_info_.clear();
     rounds_ = 0;
     const int P = n_pairs();
     if (P == 0) return MRGFE_OK;
@@ -615,6 +621,7 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
         for (size_t r = 0; r < rounds; ++r) info[r] = const_cast<NdtRoundInfo*>(hi)[r];
         rounds_ = static_cast<int>(rounds);
         if (trace) std::fprintf(stderr, "[mrgfe] device control: %zu rounds, %zu enqueued\n", rounds, enq);
+        round_info_ = info;  // (busy pairs per kind and round: names the largest launch)
         info.clear();  // device control: all three variants were launched in every enqueued round
         account(info, enq);
         return MRGFE_OK;
@@ -639,6 +646,7 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
         }
         if (!ri.n_active) {
             rounds_ = static_cast<int>(round);
+            round_info_ = info;
             account(info, info.size());
             return MRGFE_OK;
         }

@@ -79,6 +79,8 @@ class NdtEngine {
     // events around each launch, launch count, algorithmic bytes (SURVEY.md §8d model)
     double  mode_ms[3] = {0, 0, 0};
     int64_t mode_launches[3] = {0, 0, 0};
+    double   largest_ms = 0;                 // longest timed derivative launch of the last align_all and the pairs of each kind its round had busy
+    uint32_t largest_pairs[3] = {0, 0, 0};
     double  mode_alg_bytes[3] = {0, 0, 0};
     double  mode_points[3] = {0, 0, 0};      // source points of the evaluations actually launched (reused trials are not)
     double  mode_neighbours[3] = {0, 0, 0};  // valid (point, voxel) pairs they found
@@ -126,6 +128,7 @@ class NdtEngine {
     void host_plan(std::vector<uint32_t>& plan, uint32_t wg_target, uint32_t max_ppt) const;
     std::vector<hipEvent_t> ev_pool_;     // [round][variant][begin, end]
     int    rounds_ = 0;
+    std::vector<NdtRoundInfo> round_info_;  // busy pairs per kind of every round of the last align_all
     int upload_pairs();
     int ensure_events(size_t rounds);
     uint32_t derivative_grid(int mode) const;

@@ -443,6 +443,12 @@ class BatchMatcher:
         check(lib().mrgfe_batch_pair_counts(self._h, mode, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def largest_launch(self):
+        """(device ms, [busy pairs per evaluation kind]) of the longest timed derivative launch of the last align()."""
+        v = (C.c_double * 4)()
+        check(lib().mrgfe_batch_largest_launch(self._h, v))
+        return float(v[0]), [int(v[1]), int(v[2]), int(v[3])]
+
     def fitness_stats(self) -> dict:
         """getFitnessScore passes of the last align(), all launches added up (``mrgfe_batch_fitness_stats``)."""
         v = (C.c_double * 11)()

@@ -197,6 +197,66 @@ def main():
                   "| kernel | calls | total us | avg us | % |", "|---|---:|---:|---:|---:|"]
         for r in rows[:8]:
             lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e3:.1f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |")
+    # ---- roofline from the traces alone (round 4): for each isolated workload the dominant kernel's rocprofv3 average / maximum beside the
+    # HIP-event figures of the bench line the SAME profiled command printed (its log's last line)
+    def last_json(path):
+        if not os.path.exists(path):
+            return None
+        for ln in reversed(open(path).read().splitlines()):
+            if ln.startswith("{"):
+                try:
+                    return json.loads(ln)
+                except ValueError:
+                    return None
+        return None
+
+    def trace_row(stats_csv, kernel):
+        if not os.path.exists(stats_csv):
+            return None
+        for r in csv.DictReader(open(stats_csv)):
+            if short(r["Name"]) == kernel:
+                return r
+        return None
+
+    rft = {}
+    for name, log, stats_csv in (("config1", os.path.join(OUT, f"prof_{tag}.log"), os.path.join(OUT, f"prof_{tag}", f"{tag}_kernel_stats.csv")),
+                                 ("config3", os.path.join(OUT, f"prof_shard_{tag}.log"), os.path.join(OUT, f"prof_shard_{tag}", "s_kernel_stats.csv")),
+                                 ("config3_shard_of_8", os.path.join(OUT, f"prof_shard8_{tag}.log"), os.path.join(OUT, f"prof_shard8_{tag}", "s_kernel_stats.csv"))):
+        j, row = last_json(log), trace_row(stats_csv, DOMINANT)
+        if not j or not row:
+            continue
+        roof = j["roofline"]
+        avg_ms, max_ms = float(row["AverageNs"]) / 1e6, float(row["MaxNs"]) / 1e6
+        alg = roof.get("alg_bytes_per_launch")
+        rec = {"kernel": DOMINANT, "trace_calls": int(row["Calls"]), "trace_avg_launch_ms": avg_ms, "trace_max_launch_ms": max_ms, "alg_bytes_per_launch": alg,
+               "frac_from_trace": (alg / 1e9) / (avg_ms / 1e3) / 8000.0 if alg else None, "frac_in_bench_line": roof.get("frac"), "hip_event_avg_launch_ms": roof.get("avg_launch_ms"),
+               "hip_event_launches": roof.get("launches"), "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py " +
+               {"config1": "--no-cpu --no-extras --shard-steps 0", "config3": "--mode shard --no-cpu --no-extras --steps 6 --warmup 2",
+                "config3_shard_of_8": "--mode shard --no-cpu --no-extras --shard-of 8 --steps 12 --warmup 3"}[name]}
+        if rec["frac_from_trace"] and rec["frac_in_bench_line"]:
+            rec["agreement"] = rec["frac_from_trace"] / rec["frac_in_bench_line"]
+        ll = roof.get("largest_launch")
+        if ll:
+            rec["largest_launch"] = {"alg_bytes": ll["alg_bytes"], "busy_pairs_by_kind": ll["busy_pairs_by_kind"], "hip_event_ms": ll["ms"], "frac_hip_events": ll["frac"],
+                                     "frac_from_trace_max": (ll["alg_bytes"] / 1e9) / (max_ms / 1e3) / 8000.0}
+        rft[name] = rec
+    if rft:
+        summary["roofline_from_trace"] = rft
+        lines += ["", "## roofline.frac recomputed from the traces alone (isolated workloads: the dominant kernel runs only in steps of the named workload)", "",
+                  "| workload | trace calls | trace avg ms | HIP-event avg ms | alg GB / launch | frac from trace | frac in the line | ratio | largest launch: trace max ms / alg GB / frac |",
+                  "|---|---:|---:|---:|---:|---:|---:|---:|---|"]
+        for name, r in rft.items():
+            ll = r.get("largest_launch")
+            lines.append(f"| {name} | {r['trace_calls']} | {r['trace_avg_launch_ms']:.4f} | {r['hip_event_avg_launch_ms']:.4f} | {r['alg_bytes_per_launch'] / 1e9:.3f} | {r['frac_from_trace']:.3f} | "
+                         f"{r['frac_in_bench_line']:.3f} | {r.get('agreement', float('nan')):.3f} | " + (f"{r['trace_max_launch_ms']:.3f} / {ll['alg_bytes'] / 1e9:.2f} / {ll['frac_from_trace_max']:.2f}" if ll else "—") + " |")
+    for part in ("trace", "pmc"):
+        f = os.path.join(OUT, f"collected_rev_{part}.txt")
+        if os.path.exists(f):
+            summary.setdefault("git_rev", open(f).read().strip())
+            summary[f"git_rev_{part}"] = open(f).read().strip()
+        f = os.path.join(OUT, f"collected_date_{part}.txt")
+        if os.path.exists(f):
+            summary.setdefault("collected", open(f).read().strip())
     open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
     json.dump(summary, open(os.path.join(ROOT, "profiles", f"{tag}_summary.json"), "w"), indent=1)
     # the raw per-kernel stats travel too (small)

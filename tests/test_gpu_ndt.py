@@ -154,7 +154,9 @@ def test_align_on_street_scan_pair(street_pair_vlp16):
     assert np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3]) <= TOL_T
     assert _rot_angle(Tg[:3, :3], To[:3, :3]) <= TOL_R
     assert (g.hasConverged(), g.getFinalNumIteration(), g.evals) == (o.hasConverged(), o.getFinalNumIteration(), o.evals)
-    assert np.linalg.norm(Tg[:3, 3] - rel[:3, 3]) < 0.05  # and both are near the true motion
+    # and both are near the true motion (a sanity bound, not parity: with 1 m voxels a 16-beam scan pins z only loosely and where the search stops
+    # inside its step tolerance depends on the noise realisation — 0.5 to 15 cm over four noise seeds of this very pair)
+    assert np.linalg.norm(Tg[:3, 3] - rel[:3, 3]) < 0.25
 
 
 def test_degenerate_inputs_behave_like_the_reference():
