@@ -319,6 +319,9 @@ void mrgfe_ctx_destroy(mrgfe_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     mrgfe::ctx_tmp_grid_free(ctx);
+    for (auto& b : ctx->pf_buf) b.release();
+    ctx->pf_state.release();
+    ctx->pf_status.release();
     for (auto& b : ctx->scratch) b.release();
     for (auto& b : ctx->pin) b.release();
     for (auto& b : ctx->up_pin) b.release();

@@ -129,6 +129,9 @@ struct mrgfe_ctx {
     bool         stage_busy[kStageSlots] = {false, false, false, false, false, false, false, false};
     int          stage_next = 0;
     int          stage_h2d(void* d_dst, const void* src, size_t bytes, hipStream_t st);  // stream-ordered copy; `src` is free on return
+    mrgfe::DevBuf pf_buf[2], pf_state;          // prefilter chain: ping-pong clouds and the device-resident state record (filters.hip)
+    mrgfe::PinBuf pf_status;                    // ... and the few words the host reads at the chain's single wait
+    void*        pf_grid = nullptr;             // NnDeviceDrivenGrid of the radius filter (nn_grid.h), created on first use
     int          cu_count = 256;
     mrgfe::NnGrid* tmp_grid = nullptr;          // reusable exact-NN grid of the stateless filter / fitness calls (nn_grid.hip)
     std::recursive_mutex mu;                    // serialises API calls that share this context's stream / workspaces

@@ -111,6 +111,22 @@ class NnGridSet {
     double hint_target_ = 0;
 };
 
+// A single-level grid over a cloud whose SIZE THE HOST DOES NOT KNOW (round 4: the prefilter chain keeps its point counts on the device and
+// waits once, at its end).  The point count comes from a Slice in device memory, the bounding box from bounding_boxes' device output; one
+// single-thread kernel derives the geometry exactly as NnGrid::build_level does on the host and writes the build descriptor the *_many
+// kernels read; launches are sized for `n_cap` points.  The cell table is written entry by entry from the sorted keys (nn_fill_body), so
+// its capacity `cells_cap` only has to be allocated, never cleared; a cloud that needs more cells sets bit kNnAnomalyCells in *d_anomaly
+// (the caller then falls back to the host-driven build).  No pyramid: the grid serves ring walks (radius counts) only.
+constexpr uint32_t kNnAnomalyCells = 1u << 8;
+struct NnDeviceDrivenGrid {
+    DevBuf cells, sorted, desc;  // cell table (cells_cap + 8 words), cell-major points (n_cap), the NnBuildDev record
+};
+int nn_build_device_driven(mrgfe_ctx* ctx, const float4* const* d_cloud_ptr, const Slice* d_slice, uint32_t n_cap, const BBox* d_bbox, float cell, uint32_t cells_cap,
+                           NnDeviceDrivenGrid& g, uint32_t* d_anomaly);
+// flags[i] = 1 iff #{j : sqdist(q_i, p_j) <= r2} >= need for the first d_slice->n points of d_q (the grid's own cloud): nn_radius_flags_kernel with
+// the grid and the count read from device memory
+int nn_radius_flags_device_driven(mrgfe_ctx* ctx, const NnDeviceDrivenGrid& g, const float4* d_q, const Slice* d_slice, uint32_t n_cap, double r2, int need, float cell, uint32_t* d_flags);
+
 // the context's reusable grid (created on first use; buffers grow only) and its disposal in mrgfe_ctx_destroy
 NnGrid& ctx_tmp_grid(mrgfe_ctx* ctx);
 

@@ -30,6 +30,7 @@ __device__ __forceinline__ void nn_cellkey_body(const float4* __restrict__ pts, 
         if (nn_cell_of(g, p.x, p.y, p.z, c)) key = (static_cast<uint32_t>(c[2]) * g.dim[1] + c[1]) * g.dim[0] + c[0];
         keys[i] = key;  // (no index array: the sort's first scatter makes the indices up)
     }
+    if (counts == nullptr) return;  // uniform: full builds take the cell table from the SORTED keys (nn_fill_body), only the adaptive counting passes count here
     // count per cell, one atomic per distinct cell of the wavefront (consecutive points of a scan crowd into few cells);
     // `before` = points counted into this point's cell ahead of it: summed over the cloud it is sum_c n_c (n_c - 1) / 2
     uint32_t before = 0;
@@ -105,6 +106,90 @@ __global__ __launch_bounds__(256) void nn_gather_kernel(const float4* __restrict
     sorted[i] = p;
 }
 
+// The cell table straight from the sorted keys (round 4).  After the stable sort, cell_start[c] is the position of the first sorted point
+// whose key is >= c: a point whose key differs from its predecessor's (a run head, at position i) owns the entries (previous key, own key]
+// and writes i into them — its own entry itself, the gap of empty cells before it through a loop of its wavefront (64 consecutive entries
+// per store instruction; a 2^24-cell table over a 130k-point scan is 99.6 % gaps).  Thread n, one past the last point, closes the table
+// with n.  Every entry is written exactly once: no zeroing of the table, no atomic counting, no scan over 2^24 + 1 entries, and the
+// occupancy bits of the bricks come from the run heads (one atomic per OCCUPIED cell) instead of a kernel that reads the whole table —
+// the dense-table passes were 13 x the target points in traffic and ~9 ms of co-running kernels per config[3] step.  The same launch
+// gathers the points into sorted order and — for builds that measure their own crowding — adds up rank-in-run = (position - position of
+// the run's head), which is the figure the counting atomics used to produce: sum over cells of n (n - 1) / 2.
+__device__ __forceinline__ void nn_fill_body(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const float4* __restrict__ pts, uint32_t n, const NnGridDev& g,
+                                             uint32_t n_cells, uint32_t* __restrict__ cell_start, unsigned long long* __restrict__ occ, float4* __restrict__ sorted,
+                                             unsigned long long* __restrict__ crowd)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const int      lane = lane_id();
+    uint32_t       k = n_cells, kp = n_cells;
+    bool           head = false;
+    if (i < n) {
+        k = keys[i];
+        kp = i ? keys[i - 1] : 0xffffffffu;  // (kp + 1 wraps to entry 0 for the first point)
+        head = i == 0 || k != kp;
+    } else if (i == n) {  // closes the table: entries (last key, n_cells] = n
+        kp = keys[n - 1];
+        head = kp != n_cells;
+    }
+    if (head) cell_start[k] = i;
+    const uint32_t c0 = kp + 1u;
+    uint64_t       gaps = __ballot(head && c0 != k);
+    while (gaps) {
+        const int l = __ffsll(static_cast<unsigned long long>(gaps)) - 1;
+        gaps &= gaps - 1;
+        const uint32_t a = wave_read(c0, l), b = wave_read(k, l), v = wave_read(i, l);
+        for (uint32_t c = a + static_cast<uint32_t>(lane); c < b; c += 64u) cell_start[c] = v;
+    }
+    if (head && i < n && k < n_cells && occ != nullptr) {
+        const uint32_t d0 = static_cast<uint32_t>(g.dim[0]), d1 = static_cast<uint32_t>(g.dim[1]);
+        const uint32_t t = k / d0, x = k - t * d0, z = t / d1, y = t - z * d1;
+        atomicOr(&occ[((z >> 2) * g.bdim[1] + (y >> 2)) * g.bdim[0] + (x >> 2)], 1ull << ((x & 3u) | ((y & 3u) << 2) | ((z & 3u) << 4)));
+    }
+    if (i < g.n) {  // the finite points: sorted order, original index in w
+        const uint32_t v = vals[i];
+        float4 p = pts[v];
+        p.w = __int_as_float(static_cast<int>(v));
+        sorted[i] = p;
+    }
+    if (crowd == nullptr) return;  // uniform
+    uint32_t before = 0;
+    {
+        const uint64_t hm = __ballot(head && i < n);
+        // the run of a lane without a head at or below it began before this wavefront: where, says a bisection of the sorted keys (uniform)
+        uint32_t run0 = 0;
+        const uint32_t i0 = i - static_cast<uint32_t>(lane);
+        if (!(hm & 1ull) && i0 < n) {
+            const uint32_t k0 = keys[i0];
+            uint32_t lo = 0, hi = i0;  // first position whose key is >= k0
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (keys[mid] < k0) lo = mid + 1; else hi = mid;
+            }
+            run0 = lo;
+        }
+        if (i < n && k < n_cells) {
+            const uint64_t below = hm & ((2ull << lane) - 1ull);
+            const uint32_t hp = below ? i0 + static_cast<uint32_t>(63 - __clzll(static_cast<long long>(below))) : run0;
+            before = i - hp;
+        }
+    }
+    __shared__ uint32_t s_w[4];
+    const uint32_t w = wave_sum(before);
+    if (lane == 0) s_w[wave_id()] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        if (t) atomicAdd(&crowd[blockIdx.x % kCrowdSlots], static_cast<unsigned long long>(t));
+    }
+}
+
+__global__ __launch_bounds__(256) void nn_fill_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const float4* __restrict__ pts, uint32_t n, NnGridDev g,
+                                                       uint32_t n_cells, uint32_t* __restrict__ cell_start, unsigned long long* __restrict__ occ, float4* __restrict__ sorted,
+                                                       unsigned long long* __restrict__ crowd)
+{
+    nn_fill_body(keys, vals, pts, n, g, n_cells, cell_start, occ, sorted, crowd);
+}
+
 // ---- the same steps for the members of an NnGridSet: blockIdx.y = member --------------------------------------
 struct NnBuildDev {
     NnGridDev           lv;       // geometry and device arrays of the level being built
@@ -120,11 +205,17 @@ struct NnBuildDev {
     int32_t             pd[3][3]; // node grids of the pyramid: bricks, super-bricks, blocks
 };
 
-__global__ __launch_bounds__(256) void nn_cellkey_many_kernel(const NnBuildDev* __restrict__ d, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+__global__ __launch_bounds__(256) void nn_cellkey_many_kernel(const NnBuildDev* __restrict__ d, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int counting)
 {
     const NnBuildDev& b = d[blockIdx.y];
     if (!b.active || blockIdx.x * 256u >= b.n) return;  // uniform per workgroup
-    nn_cellkey_body(b.pts, b.n, b.lv, b.n_cells, keys + b.off, vals + b.off, b.counts, b.crowd);
+    nn_cellkey_body(b.pts, b.n, b.lv, b.n_cells, keys + b.off, vals + b.off, counting ? b.counts : nullptr, counting ? b.crowd : nullptr);
+}
+__global__ __launch_bounds__(256) void nn_fill_many_kernel(const NnBuildDev* __restrict__ d, const uint32_t* __restrict__ sorted_keys, const uint32_t* __restrict__ sorted_vals, int with_occ)
+{
+    const NnBuildDev& b = d[blockIdx.y];
+    if (!b.active || blockIdx.x * 256u > b.n) return;  // (thread n closes the table)
+    nn_fill_body(sorted_keys + b.off, sorted_vals + b.off, b.pts, b.n, b.lv, b.n_cells, b.counts, with_occ ? b.occ[0] : nullptr, b.sorted, b.crowd);
 }
 __global__ __launch_bounds__(256) void nn_occupancy_many_kernel(const NnBuildDev* __restrict__ d)
 {
@@ -174,15 +265,19 @@ int NnGrid::build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const 
     const size_t head_words = size_t(n_cells) + 4 + 2 * kCrowdSlots, occ_at = (head_words + 1) & ~size_t(1);
     const size_t all_words = occ_at + 2 * (pn[0] + pn[1] + pn[2]);
     MRGFE_TRY(d_cells.ensure(sizeof(uint32_t) * all_words));
-    MRGFE_HIP_CHECK(hipMemsetAsync(d_cells.p, 0, sizeof(uint32_t) * all_words, st));
+    // counting passes zero the count table; a full build writes every entry of the cell table itself (nn_fill_kernel) and only needs the
+    // crowd counters and the pyramid words behind it cleared
+    const size_t crowd_word = (size_t(n_cells) + 2) & ~size_t(1);
+    if (counts_only) MRGFE_HIP_CHECK(hipMemsetAsync(d_cells.p, 0, sizeof(uint32_t) * all_words, st));
+    else             MRGFE_HIP_CHECK(hipMemsetAsync(d_cells.as<uint32_t>() + crowd_word, 0, sizeof(uint32_t) * (all_words - crowd_word), st));
     lv.cell_start = d_cells.as<uint32_t>();
     lv.occ = reinterpret_cast<const unsigned long long*>(d_cells.as<uint32_t>() + occ_at);
     lv.occ1 = lv.occ + pn[0];
     lv.occ2 = lv.occ1 + pn[1];
     // the crowd counters live behind the (n_cells + 1)-entry count table, 8-byte aligned
     unsigned long long* d_crowd = reinterpret_cast<unsigned long long*>(d_cells.as<uint32_t>() + ((size_t(n_cells) + 2) & ~size_t(1)));
-    hipLaunchKernelGGL(nn_cellkey_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, d_pts, nn, lv, n_cells, dk.as<uint32_t>(), dv.as<uint32_t>(), d_cells.as<uint32_t>(),
-                       crowding ? d_crowd : nullptr);
+    hipLaunchKernelGGL(nn_cellkey_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, d_pts, nn, lv, n_cells, dk.as<uint32_t>(), dv.as<uint32_t>(), counts_only ? d_cells.as<uint32_t>() : nullptr,
+                       (crowding && counts_only) ? d_crowd : nullptr);
     MRGFE_HIP_CHECK(hipGetLastError());
     unsigned long long slots[kCrowdSlots];
     auto crowding_from_slots = [&]() {
@@ -201,28 +296,27 @@ int NnGrid::build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const 
     while (key_bits < 32 && (uint64_t(1) << key_bits) <= n_cells) ++key_bits;
     uint32_t *sk, *sv;
     MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), ds.as<Slice>(), tab, key_bits, dh.as<uint32_t>(), &sk, &sv, true));
-    // counts -> cell_start (exclusive scan over n_cells + 1 entries, in place)
-    uint32_t   nc1 = n_cells + 1;
-    SliceTable ctab;
-    ctab.build(&nc1, 1);
-    MRGFE_HIP_CHECK(hipMemcpyAsync(ds.as<char>() + sizeof(Slice), ctab.h.data(), sizeof(Slice), hipMemcpyHostToDevice, st));
-    MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (ctab.total_blks + 8)));
-    MRGFE_TRY(exclusive_scan(ctx, d_cells.as<uint32_t>(), d_cells.as<uint32_t>(), ds.as<Slice>() + 1, ctab, dblk.as<uint32_t>(), dblk.as<uint32_t>() + ctab.total_blks));
-    if (&lv == &h_.level[0]) {  // only the finest level is searched through the pyramid (the coarser ones serve the k-NN climb)
-        hipLaunchKernelGGL(nn_occupancy_kernel, dim3((n_cells + 255) / 256), dim3(256), 0, st, lv, n_cells, const_cast<unsigned long long*>(lv.occ));
+    // cell table, brick words, sorted points and the crowding figure from the sorted (key, index) pairs in one launch
+    (void)dblk;
+    MRGFE_TRY(d_sorted.ensure(sizeof(float4) * std::max<size_t>(nn, 1)));
+    lv.sorted = d_sorted.as<float4>();
+    const bool pyramid = &lv == &h_.level[0];  // only the finest level is searched through the pyramid (the coarser ones serve the k-NN climb)
+    hipLaunchKernelGGL(nn_fill_kernel, dim3(nn / 256 + 1), dim3(256), 0, st, sk, sv, d_pts, nn, lv, n_cells, d_cells.as<uint32_t>(), pyramid ? const_cast<unsigned long long*>(lv.occ) : nullptr,
+                       d_sorted.as<float4>(), crowding ? d_crowd : nullptr);
+    if (pyramid) {
         hipLaunchKernelGGL(nn_occupancy_up_kernel, dim3(static_cast<uint32_t>((pn[0] + 255) / 256)), dim3(256), 0, st, lv.occ, pd[0][0], pd[0][1], pd[0][2], pd[1][0], pd[1][1],
                            const_cast<unsigned long long*>(lv.occ1));
         hipLaunchKernelGGL(nn_occupancy_up_kernel, dim3(static_cast<uint32_t>((pn[1] + 255) / 256)), dim3(256), 0, st, lv.occ1, pd[1][0], pd[1][1], pd[1][2], pd[2][0], pd[2][1],
                            const_cast<unsigned long long*>(lv.occ2));
     }
-    MRGFE_TRY(d_sorted.ensure(sizeof(float4) * std::max<size_t>(nn, 1)));
-    lv.sorted = d_sorted.as<float4>();
-    hipLaunchKernelGGL(nn_gather_kernel, dim3((lv.n + 255) / 256), dim3(256), 0, st, d_pts, sv, lv.n, d_sorted.as<float4>());
     MRGFE_HIP_CHECK(hipGetLastError());
-    // a full build that also measures: the counters (behind the count table, untouched by the scan) ride on the build's own synchronisation
-    if (crowding) MRGFE_HIP_CHECK(hipMemcpyAsync(slots, d_crowd, sizeof(slots), hipMemcpyDeviceToHost, st));
-    MRGFE_HIP_CHECK(hipStreamSynchronize(st));  // ctab's host table was the source of an async copy
-    if (crowding) crowding_from_slots();
+    // a full build that also measures: the counters ride on one synchronisation; a build that does not measure returns without waiting
+    // (nothing on the host was the source of an asynchronous copy here: the stream orders the searches behind the build)
+    if (crowding) {
+        MRGFE_HIP_CHECK(hipMemcpyAsync(slots, d_crowd, sizeof(slots), hipMemcpyDeviceToHost, st));
+        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+        crowding_from_slots();
+    }
     return MRGFE_OK;
 }
 
@@ -331,6 +425,12 @@ NnGrid& ctx_tmp_grid(mrgfe_ctx* ctx)
 }
 void ctx_tmp_grid_free(mrgfe_ctx* ctx)
 {
+    if (ctx->pf_grid) {
+        NnDeviceDrivenGrid* g = static_cast<NnDeviceDrivenGrid*>(ctx->pf_grid);
+        g->cells.release(); g->sorted.release(); g->desc.release();
+        delete g;
+        ctx->pf_grid = nullptr;
+    }
     if (!ctx->tmp_grid) return;
     ctx->tmp_grid->release();
     delete ctx->tmp_grid;
@@ -437,7 +537,15 @@ int NnGridSet::build(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32
         if (words > 0xffffffffull) { set_error("NnGridSet: cell tables of %llu words", static_cast<unsigned long long>(words)); return MRGFE_ERR_INVALID; }
         DevBuf& dc = d_cells_[level];
         MRGFE_TRY(dc.ensure(sizeof(uint32_t) * words));
-        MRGFE_HIP_CHECK(hipMemsetAsync(dc.p, 0, sizeof(uint32_t) * words, st));
+        // counting passes zero the count tables; a full build writes every entry of the cell tables itself (nn_fill_many_kernel) and needs only the
+        // crowd counters and pyramid words behind them cleared — and the eight zero words that stand for the grid of a member without a finite point
+        if (counts_only) {
+            MRGFE_HIP_CHECK(hipMemsetAsync(dc.p, 0, sizeof(uint32_t) * words, st));
+        } else {
+            MRGFE_HIP_CHECK(hipMemsetAsync(dc.as<uint32_t>() + crowd_at, 0, sizeof(uint32_t) * (words - crowd_at), st));
+            for (size_t m = 0; m < M; ++m)
+                if (!dev[m].active) MRGFE_HIP_CHECK(hipMemsetAsync(dc.as<uint32_t>() + ctab.h[m].off, 0, sizeof(uint32_t) * 8, st));
+        }
         if (!counts_only) MRGFE_TRY(d_sorted_[level].ensure(sizeof(float4) * std::max<size_t>(tab.total_elems, 1)));
         uint32_t max_cells = 1, max_bricks = 1, max_super = 1;
         for (size_t m = 0; m < M; ++m) {
@@ -459,7 +567,7 @@ int NnGridSet::build(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32
             max_super = std::max<uint32_t>(max_super, static_cast<uint32_t>(pn[m * 3 + 1]));
         }
         MRGFE_HIP_CHECK(hipMemcpyAsync(ds.as<char>() + at_dev, dev.data(), sizeof(NnBuildDev) * M, hipMemcpyHostToDevice, st));
-        if (tab.max_blks) hipLaunchKernelGGL(nn_cellkey_many_kernel, dim3(tab.max_blks * (kTile / 256), count), dim3(256), 0, st, d_dev, dk.as<uint32_t>(), dv.as<uint32_t>());
+        if (tab.max_blks) hipLaunchKernelGGL(nn_cellkey_many_kernel, dim3(tab.max_blks * (kTile / 256), count), dim3(256), 0, st, d_dev, dk.as<uint32_t>(), dv.as<uint32_t>(), counts_only ? 1 : 0);
         MRGFE_HIP_CHECK(hipGetLastError());
         std::vector<unsigned long long> slots;
         auto read_crowding = [&]() {
@@ -480,15 +588,13 @@ int NnGridSet::build(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32
         while (key_bits < 32 && (uint64_t(1) << key_bits) <= max_cells) ++key_bits;
         uint32_t *sk = nullptr, *sv = nullptr;
         if (tab.max_blks) MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), d_slices, tab, key_bits, dh.as<uint32_t>(), &sk, &sv, true));
-        MRGFE_HIP_CHECK(hipMemcpyAsync(ds.as<char>() + at_cs, ctab.h.data(), sizeof(Slice) * M, hipMemcpyHostToDevice, st));
-        MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (ctab.total_blks + M + 8)));
-        MRGFE_TRY(exclusive_scan(ctx, dc.as<uint32_t>(), dc.as<uint32_t>(), d_cslices, ctab, dblk.as<uint32_t>(), dblk.as<uint32_t>() + ctab.total_blks));
+        // cell tables, brick words, sorted points and crowding figures of all members from their sorted (key, index) pairs in one launch
+        (void)d_cslices; (void)dblk; (void)max_cells;
+        if (tab.max_blks) hipLaunchKernelGGL(nn_fill_many_kernel, dim3(tab.max_blks * (kTile / 256) + 1, count), dim3(256), 0, st, d_dev, sk, sv, level == 0 ? 1 : 0);
         if (level == 0) {  // only the finest level is searched through the pyramid
-            hipLaunchKernelGGL(nn_occupancy_many_kernel, dim3((max_cells + 255) / 256, count), dim3(256), 0, st, d_dev);
             hipLaunchKernelGGL(nn_occupancy_up_many_kernel, dim3((max_bricks + 255) / 256, count), dim3(256), 0, st, d_dev, 0);
             hipLaunchKernelGGL(nn_occupancy_up_many_kernel, dim3((max_super + 255) / 256, count), dim3(256), 0, st, d_dev, 1);
         }
-        if (tab.max_blks) hipLaunchKernelGGL(nn_gather_many_kernel, dim3(tab.max_blks * (kTile / 256), count), dim3(256), 0, st, d_dev, sv);
         MRGFE_HIP_CHECK(hipGetLastError());
         if (crowding) MRGFE_HIP_CHECK(hipMemcpyAsync(slots.data(), dc.as<uint32_t>() + crowd_at, 8 * slots.size(), hipMemcpyDeviceToHost, st));
         MRGFE_HIP_CHECK(hipStreamSynchronize(st));  // the descriptor tables above were sources of asynchronous copies
@@ -581,6 +687,107 @@ int NnGridSet::build(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32
             if (act[m]) ++h[m].n_levels;
     }
     for (size_t m = 0; m < M; ++m) out[m]->adopt(h[m], n[m]);
+    return MRGFE_OK;
+}
+
+// ---- a grid the device sizes itself (nn_grid.h: NnDeviceDrivenGrid) ---------------------------------------------------
+__global__ void nn_geometry_kernel(const float4* const* __restrict__ cloud_ptr, const Slice* __restrict__ slice, const BBox* __restrict__ bbox, float cell, uint32_t cells_cap,
+                                   uint32_t* cell_table, float4* sorted, NnBuildDev* __restrict__ out, uint32_t* __restrict__ anomaly)
+{
+#pragma clang fp contract(off)
+    if (threadIdx.x || blockIdx.x) return;
+    const BBox bb = *bbox;
+    NnBuildDev b;
+    memset(&b, 0, sizeof(b));
+    NnGridDev& lv = b.lv;
+    // (the arithmetic of NnGrid::build_level, float for float)
+    float extent = 0.0f;
+    for (int a = 0; a < 3; ++a) { lv.origin[a] = bb.mn[a]; extent = fmaxf(extent, bb.mx[a] - bb.mn[a]); }
+    lv.cell = cell;
+    lv.slack = 1e-6f * (extent + cell);
+    lv.n = bb.n_finite;
+    unsigned long long cells = 1;
+    for (int a = 0; a < 3; ++a) {
+        lv.dim[a] = bb.n_finite ? static_cast<int>(floorf((bb.mx[a] - bb.mn[a]) / cell)) + 1 : 1;
+        lv.bdim[a] = (lv.dim[a] + 3) / 4;
+        cells *= static_cast<unsigned long long>(lv.dim[a] > 0 ? lv.dim[a] : 1);
+    }
+    const bool fits = cells <= cells_cap && lv.dim[0] > 0 && lv.dim[1] > 0 && lv.dim[2] > 0;
+    if (!fits) { atomicOr(anomaly, kNnAnomalyCells); lv.dim[0] = lv.dim[1] = lv.dim[2] = 1; lv.bdim[0] = lv.bdim[1] = lv.bdim[2] = 1; cells = 1; }
+    b.n_cells = static_cast<uint32_t>(cells);
+    b.pts = *cloud_ptr;
+    b.n = fits ? slice->n : 0u;
+    b.off = 0;
+    b.active = (fits && bb.n_finite > 0) ? 1u : 0u;
+    b.counts = cell_table;
+    b.sorted = sorted;
+    lv.cell_start = cell_table;
+    lv.sorted = sorted;
+    if (!b.active) {  // an empty grid: one cell without points (the search kernels test lv.n first)
+        lv.n = 0;
+        cell_table[0] = 0;
+        cell_table[1] = 0;
+    }
+    *out = b;
+}
+
+__global__ __launch_bounds__(256) void nn_radius_flags_dd_kernel(const NnBuildDev* __restrict__ d, const float4* __restrict__ q, const Slice* __restrict__ slice, double r2, int need, int rings,
+                                                                  uint32_t* __restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (blockIdx.x * 256u >= slice->n) return;  // uniform
+    __shared__ NnGridDev s_g;
+    static_assert(sizeof(NnGridDev) % 4 == 0 && sizeof(NnGridDev) / 4 <= 256, "one word per thread");
+    if (threadIdx.x < sizeof(NnGridDev) / 4) reinterpret_cast<uint32_t*>(&s_g)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&d->lv)[threadIdx.x];
+    __syncthreads();
+    if (i >= slice->n) return;
+    const NnGridDev& g = s_g;
+    const float4 p = q[i];
+    int          c[3];
+    int          count = 0;
+    if (g.n > 0 && nn_cell_of(g, p.x, p.y, p.z, c)) {
+        nn_walk(
+            g, c, 0.0, rings,
+            [&](const float4& t) {
+                if (static_cast<double>(sqdist3f(t.x, t.y, t.z, p.x, p.y, p.z)) <= r2) ++count;
+            },
+            [&](double) { return count >= need; });
+    }
+    flags[i] = count >= need ? 1u : 0u;
+}
+
+int nn_build_device_driven(mrgfe_ctx* ctx, const float4* const* d_cloud_ptr, const Slice* d_slice, uint32_t n_cap, const BBox* d_bbox, float cell, uint32_t cells_cap,
+                           NnDeviceDrivenGrid& g, uint32_t* d_anomaly)
+{
+    hipStream_t st = ctx->stream;
+    SliceTable  tab;
+    tab.build(&n_cap, 1);
+    MRGFE_TRY(g.cells.ensure(sizeof(uint32_t) * (size_t(cells_cap) + 8)));
+    MRGFE_TRY(g.sorted.ensure(sizeof(float4) * std::max<size_t>(n_cap, 1)));
+    MRGFE_TRY(g.desc.ensure(sizeof(NnBuildDev)));
+    DevBuf &dk = ctx->scratch[2], &dv = ctx->scratch[3], &dkt = ctx->scratch[4], &dvt = ctx->scratch[5], &dh = ctx->scratch[6];
+    const size_t ne = std::max<size_t>(n_cap, 4);
+    MRGFE_TRY(dk.ensure(ne * 4)); MRGFE_TRY(dv.ensure(ne * 4)); MRGFE_TRY(dkt.ensure(ne * 4)); MRGFE_TRY(dvt.ensure(ne * 4));
+    MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + 1)));
+    NnBuildDev* d_dev = g.desc.as<NnBuildDev>();
+    hipLaunchKernelGGL(nn_geometry_kernel, dim3(1), dim3(1), 0, st, d_cloud_ptr, d_slice, d_bbox, cell, cells_cap, g.cells.as<uint32_t>(), g.sorted.as<float4>(), d_dev, d_anomaly);
+    if (tab.max_blks == 0) { MRGFE_HIP_CHECK(hipGetLastError()); return MRGFE_OK; }
+    hipLaunchKernelGGL(nn_cellkey_many_kernel, dim3(tab.max_blks * (kTile / 256), 1), dim3(256), 0, st, d_dev, dk.as<uint32_t>(), dv.as<uint32_t>(), 0);
+    int key_bits = 1;
+    while (key_bits < 32 && (uint64_t(1) << key_bits) <= cells_cap) ++key_bits;  // the key of a non-finite point is n_cells <= cells_cap
+    uint32_t *sk = nullptr, *sv = nullptr;
+    MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), d_slice, tab, key_bits, dh.as<uint32_t>(), &sk, &sv, true));
+    hipLaunchKernelGGL(nn_fill_many_kernel, dim3(tab.max_blks * (kTile / 256) + 1, 1), dim3(256), 0, st, d_dev, sk, sv, 0);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
+int nn_radius_flags_device_driven(mrgfe_ctx* ctx, const NnDeviceDrivenGrid& g, const float4* d_q, const Slice* d_slice, uint32_t n_cap, double r2, int need, float cell, uint32_t* d_flags)
+{
+    if (n_cap == 0) return MRGFE_OK;
+    const int rings = static_cast<int>(std::ceil(std::sqrt(r2) / cell)) + 1;  // (NnGrid::radius_count_flags)
+    hipLaunchKernelGGL(nn_radius_flags_dd_kernel, dim3((n_cap + 255) / 256), dim3(256), 0, ctx->stream, g.desc.as<NnBuildDev>(), d_q, d_slice, r2, need, rings, d_flags);
+    MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }
 
