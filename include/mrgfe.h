@@ -405,6 +405,10 @@ int mrgfe_dbg_set_fused_launch(int mode);
  * MRGFE_FIT_SWEEP sets the initial value), 0 = round 2's pyramid walk for every queued query.  Any other value only asks.  Returns the
  * setting in effect.  Both give the exact nearest distances (tests/test_gpu_fitness_passes.py). */
 int mrgfe_dbg_set_fit_sweep(int mode);
+/* mrgfe_prefilter / mrgfe_prefilter_device with VoxelGrid + RadiusOutlierRemoval: 1 (default) the stages' point counts stay on the device and the
+ * call waits once at its end, 0 every stage reports its count to the host (round 3; also what an unusual scan falls back to); other values
+ * query.  Same outputs either way. */
+int mrgfe_dbg_set_prefilter_device_driven(int mode);
 /* Counters of the seed + sweep pass (mrgfe_ctx_fitness_stats out[6..9], mrgfe_batch_fitness_stats) during the following calls of this process:
  * 0 = off (default; MRGFE_FIT_STATS sets the initial value), 1 = counted, 2 = also the kernel's phase clocks and a line on stderr (slows
  * the kernel: a clock read waits for the memory operations in flight).  Any other value only asks.  Returns the setting in effect. */

@@ -1362,6 +1362,8 @@ int mrgfe_batch_kernel_stats(const mrgfe_batch* b, int mode, double* ms, int64_t
     return MRGFE_OK;
 }
 
+int mrgfe_dbg_set_prefilter_device_driven(int mode) { return prefilter_set_device_driven(mode); }
+
 int mrgfe_batch_largest_launch(const mrgfe_batch* b, double out[4])
 {
     if (!b || !out) { set_error("mrgfe_batch_largest_launch: NULL argument"); return MRGFE_ERR_INVALID; }

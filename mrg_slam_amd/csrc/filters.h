@@ -29,6 +29,8 @@ struct PrefilterChain {
     int    mean_k = 30;
     double stddev_mul = 1.2;
 };
+// 1: the usual chain (voxel grid + radius filter) keeps its point counts on the device and waits once (default); 0: host-driven stages; < 0: query
+int prefilter_set_device_driven(int mode);
 // the three passes back to back on the device (one upload, one download)
 int filter_chain(mrgfe_ctx* ctx, const PrefilterChain& chain, const float* xyzi, size_t n, size_t stride, void* out, size_t* out_n, bool out_on_device = false);
 

@@ -6,7 +6,9 @@
 // All passes are streaming / gather kernels bound by HBM and L2; nothing here is GEMM-shaped.
 #include "filters.h"
 
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "cellsort.h"
@@ -427,6 +429,20 @@ __global__ __launch_bounds__(256) void compact_dd_kernel(const float4* __restric
     if (i < sl->n && flags[i]) out[pos[i]] = in[i];
 }
 
+// 1 (default): the usual chain keeps its counts on the device; 0: always the host-driven chain of round 3 (MRGFE_PREFILTER_HOST_DRIVEN=1, tests)
+static std::atomic<int> g_pf_device_driven{-1};
+static int prefilter_device_driven_mode()
+{
+    int v = g_pf_device_driven.load(std::memory_order_relaxed);
+    if (v < 0) { v = std::getenv("MRGFE_PREFILTER_HOST_DRIVEN") ? 0 : 1; g_pf_device_driven.store(v, std::memory_order_relaxed); }
+    return v;
+}
+int prefilter_set_device_driven(int mode)
+{
+    if (mode == 0 || mode == 1) g_pf_device_driven.store(mode, std::memory_order_relaxed);
+    return prefilter_device_driven_mode();
+}
+
 static NnDeviceDrivenGrid& pf_grid(mrgfe_ctx* ctx)
 {
     if (!ctx->pf_grid) ctx->pf_grid = new NnDeviceDrivenGrid();
@@ -437,8 +453,7 @@ static NnDeviceDrivenGrid& pf_grid(mrgfe_ctx* ctx)
 static int filter_chain_device_driven(mrgfe_ctx* ctx, const PrefilterChain& ch, const float4* d_in, uint32_t n, float4* d_work, float4* d_final, size_t* out_n, bool* used)
 {
     *used = false;
-    static const bool off = std::getenv("MRGFE_PREFILTER_HOST_DRIVEN") != nullptr;  // (A/B hook: the round-3 chain)
-    if (off || !ch.voxelgrid || ch.outlier != 1 || n == 0 || !(ch.leaf > 0)) return MRGFE_OK;
+    if (!prefilter_device_driven_mode() || !ch.voxelgrid || ch.outlier != 1 || n == 0 || !(ch.leaf > 0)) return MRGFE_OK;
     hipStream_t st = ctx->stream;
     SliceTable  tab;
     tab.build(&n, 1);

@@ -329,3 +329,41 @@ def test_information_matrix_of_graph_edges_host_clouds_and_store():
     np.testing.assert_array_equal(const.calc_information_matrix(clouds[0], clouds[1], np.eye(4)), np.diag([4.0] * 3 + [10.0] * 3))
     with pytest.raises(Exception):
         store.fitness(1, 99, np.eye(4))
+
+
+def test_device_driven_prefilter_chain_equals_the_host_driven_one_and_the_oracle():
+    """Round 4: mrgfe_prefilter keeps the stages' point counts on the device and waits once (csrc/filters.hip: PfState).  Same bits as the host-driven
+    stages of round 3 and as the oracle chain — on ordinary scans and on the ones the device-driven chain hands back: nothing survives the distance
+    filter, non-finite points, PCL's 'leaf size is too small' pass-through, a radius grid beyond its table."""
+    from mrg_slam_amd import prefilter, synth
+    from mrg_slam_amd._lib import lib
+    from oracle import oracle as orc
+
+    def oracle_chain(c, p):
+        c = orc.distance_filter(c, p.get("distance_near_thresh", 0.1), p.get("distance_far_thresh", 35.0))
+        c, _ = orc.voxelgrid(c, p.get("downsample_resolution", 0.1), p.get("downsample_min_points_per_voxel", 1))
+        c, _ = orc.radius_outlier(c, p.get("radius_radius", 0.5), p.get("radius_min_neighbors", 2))
+        return c
+
+    sc = synth.street_scene()
+    scan = synth.synth_lidar(sc, np.eye(4), "VLP16", 4711)
+    rng = np.random.default_rng(5)
+    with_nan = scan.copy()
+    with_nan[rng.choice(len(scan), 200, replace=False), rng.integers(0, 3, 200)] = np.nan
+    with_nan[7, 0] = np.inf
+    spread = small_cloud(3000, 3, extent=(30000.0, 30000.0, 30000.0))  # 0.01 m leaves over 60 km: PCL passes the cloud through
+    cases = [("street scan", scan, {}), ("coarser leaf, more neighbours", scan, {"downsample_resolution": 0.3, "radius_min_neighbors": 4, "radius_radius": 0.8}),
+             ("min points per voxel 2", scan, {"downsample_min_points_per_voxel": 2}), ("nothing survives the distance filter", scan, {"distance_near_thresh": 500.0, "distance_far_thresh": 600.0}),
+             ("non-finite points", with_nan, {}), ("leaf size too small", spread, {"downsample_resolution": 0.01, "distance_far_thresh": 1e9}),
+             ("radius grid beyond its table", small_cloud(4000, 9, extent=(400.0, 400.0, 40.0)), {"distance_far_thresh": 1e9, "radius_radius": 0.4}),
+             ("three points", scan[:3], {}), ("all non-finite", np.full((50, 4), np.nan, dtype=np.float32), {})]
+    try:
+        for name, cloud, p in cases:
+            assert lib().mrgfe_dbg_set_prefilter_device_driven(1) == 1
+            fast = prefilter(cloud, p)
+            assert lib().mrgfe_dbg_set_prefilter_device_driven(0) == 0
+            slow = prefilter(cloud, p)
+            np.testing.assert_array_equal(fast, slow, err_msg=name)
+            np.testing.assert_array_equal(fast, oracle_chain(cloud, p), err_msg=name)
+    finally:
+        lib().mrgfe_dbg_set_prefilter_device_driven(1)
