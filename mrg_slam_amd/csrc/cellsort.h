@@ -52,6 +52,7 @@ int exclusive_scan(mrgfe_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, const 
 
 // run heads of a sorted key array: element i starts a run of equal keys among the first d_n_valid[p] elements of problem p (the invalid
 // keys sort behind them).  d_out[i] = number of run heads before element i (the ordinal of i's run when i is a head), d_totals[p] = runs.
+// d_out == nullptr: only d_totals and the exclusive prefix of the tiles' head counts in d_blk are produced (what ndt_launch_segments needs).
 int exclusive_scan_run_heads(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, uint32_t* d_out, const Slice* d_slices, const SliceTable& t, const uint32_t* d_n_valid, uint32_t* d_blk,
                              uint32_t* d_totals);
 

@@ -382,7 +382,9 @@ int exclusive_scan_run_heads(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, uint
     dim3 grid(t.max_blks ? t.max_blks : 1, t.nprob());
     if (t.max_blks) hipLaunchKernelGGL(scan_heads_tile_sum_kernel, grid, dim3(256), 0, ctx->stream, d_sorted_keys, d_slices, d_n_valid, d_blk);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(t.nprob()), dim3(256), 0, ctx->stream, d_slices, d_blk, d_totals);
-    if (t.max_blks) hipLaunchKernelGGL(scan_heads_apply_kernel, grid, dim3(256), 0, ctx->stream, d_sorted_keys, d_out, d_slices, d_n_valid, d_blk);
+    // d_out == nullptr: the caller wants the run count and the tiles' prefixes in d_blk only (ndt_launch_segments derives each head's ordinal from
+    // them on the fly: no per-element ordinal array is written or read)
+    if (t.max_blks && d_out) hipLaunchKernelGGL(scan_heads_apply_kernel, grid, dim3(256), 0, ctx->stream, d_sorted_keys, d_out, d_slices, d_n_valid, d_blk);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }

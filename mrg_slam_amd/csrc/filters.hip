@@ -161,9 +161,8 @@ int filter_voxelgrid_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, float 
     MRGFE_TRY(ndt_launch_cellkeys(ctx, &d_desc->cp, &d_desc->sl, tab, &d_desc->vp, dk.as<uint32_t>(), dh.as<uint32_t>()));
     uint32_t *sk, *sv;
     MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), &d_desc->sl, tab, key_bits, dh.as<uint32_t>(), &sk, &sv, true, true));
-    uint32_t* d_ord = (sk == dk.as<uint32_t>()) ? dkt.as<uint32_t>() : dk.as<uint32_t>();
     uint32_t* d_tot = dblk.as<uint32_t>() + tab.total_blks;
-    MRGFE_TRY(exclusive_scan_run_heads(ctx, sk, d_ord, &d_desc->sl, tab, &d_desc->nv, dblk.as<uint32_t>(), d_tot));
+    MRGFE_TRY(exclusive_scan_run_heads(ctx, sk, nullptr, &d_desc->sl, tab, &d_desc->nv, dblk.as<uint32_t>(), d_tot));
     uint32_t* h_tot = reinterpret_cast<uint32_t*>(hp.as<char>() + sizeof(Desc) + sizeof(BBox));
     MRGFE_HIP_CHECK(hipMemcpyAsync(h_tot, d_tot, 4, hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
@@ -180,7 +179,7 @@ int filter_voxelgrid_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, float 
     MRGFE_TRY(dkeep.ensure(sizeof(uint32_t) * size_t(V)));
     uint32_t* d_seg = dseg.as<uint32_t>();
     int32_t*  d_segkey = reinterpret_cast<int32_t*>(d_seg + V + 4);
-    MRGFE_TRY(ndt_launch_segments(ctx, sk, d_ord, &d_desc->sl, tab, &d_desc->ls, d_seg, d_segkey));
+    MRGFE_TRY(ndt_launch_segments(ctx, sk, &d_desc->sl, tab, &d_desc->nv, dblk.as<uint32_t>(), &d_desc->ls, d_seg, d_segkey));
     hipLaunchKernelGGL(voxel_centroid_kernel, dim3((V + 255) / 256), dim3(256), 0, st, d_in, sv, d_seg, V, min_pts, dcent.as<float4>(), dkeep.as<uint32_t>());
     MRGFE_HIP_CHECK(hipGetLastError());
     uint32_t kept = 0;
@@ -492,12 +491,11 @@ static int filter_chain_device_driven(mrgfe_ctx* ctx, const PrefilterChain& ch, 
     MRGFE_TRY(ndt_launch_cellkeys(ctx, &d_st->cp[0], &d_st->sl_in, tab, &d_st->vp, dk.as<uint32_t>(), dh.as<uint32_t>()));
     uint32_t *sk, *sv;
     MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), &d_st->sl_in, tab, 32, dh.as<uint32_t>(), &sk, &sv, true, true));
-    uint32_t* d_ord = (sk == dk.as<uint32_t>()) ? dkt.as<uint32_t>() : dk.as<uint32_t>();
-    MRGFE_TRY(exclusive_scan_run_heads(ctx, sk, d_ord, &d_st->sl_in, tab, &d_st->nv, dblk.as<uint32_t>(), d_tot));
+    MRGFE_TRY(exclusive_scan_run_heads(ctx, sk, nullptr, &d_st->sl_in, tab, &d_st->nv, dblk.as<uint32_t>(), d_tot));
     hipLaunchKernelGGL(pf_leaves_kernel, dim3(1), dim3(1), 0, st, d_st, d_tot);
     uint32_t* d_seg = dseg.as<uint32_t>();
     int32_t*  d_segkey = reinterpret_cast<int32_t*>(d_seg + size_t(n) + 4);
-    MRGFE_TRY(ndt_launch_segments(ctx, sk, d_ord, &d_st->sl_in, tab, &d_st->ls, d_seg, d_segkey));
+    MRGFE_TRY(ndt_launch_segments(ctx, sk, &d_st->sl_in, tab, &d_st->nv, dblk.as<uint32_t>(), &d_st->ls, d_seg, d_segkey));
     hipLaunchKernelGGL(voxel_centroid_dd_kernel, g256, b256, 0, st, vox_in, sv, d_seg, &d_st->sl_vox, ch.min_pts, dcent.as<float4>(), dkeep.as<uint32_t>());
     MRGFE_TRY(exclusive_scan(ctx, dkeep.as<uint32_t>(), dpos.as<uint32_t>(), &d_st->sl_vox, tab, dblk.as<uint32_t>(), d_tot));
     // (the voxel grid's output goes to d_final for now: the radius filter reads it there and compacts into the work buffer ...)

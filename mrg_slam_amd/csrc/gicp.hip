@@ -531,7 +531,17 @@ __device__ __forceinline__ void gicp_reduce_record(const double* __restrict__ pa
     __shared__ double s[8][kGicpStride];
     const int k = threadIdx.x & 31, slice = threadIdx.x >> 5;
     double    acc = 0.0;
-    for (uint32_t b = slice; b < nblk; b += 8) acc += partials[size_t(b) * kGicpStride + k];
+    // eight of the slice's records in flight, then added in the same order as one after the other (the loop used to wait for every load in
+    // turn: 64 round trips = 17 us per reduction, four of them in a 130k-point frame)
+    uint32_t b = slice;
+    for (; b + 56 < nblk; b += 64) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partials[size_t(b + 8 * u) * kGicpStride + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; b < nblk; b += 8) acc += partials[size_t(b) * kGicpStride + k];
     s[slice][k] = acc;
     __syncthreads();
     if (threadIdx.x < kGicpStride) {

@@ -27,7 +27,8 @@ struct LeafSlice {
 
 // voxel keys of every point and, in d_hist, the radix sort's first per-tile digit histograms (radix_sort_pairs(..., iota_vals, first_hist_ready))
 int ndt_launch_cellkeys(mrgfe_ctx* ctx, const float4* const* d_clouds, const Slice* d_slices, const SliceTable& t, const VoxelParams* d_vp, uint32_t* d_keys, uint32_t* d_hist);
-int ndt_launch_segments(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, const uint32_t* d_ordinal, const Slice* d_slices, const SliceTable& t,
+// seg_start / seg_key of every run head of the sorted keys; d_blk = the tiles' head-count prefixes that exclusive_scan_run_heads(..., d_out = nullptr, ...) left
+int ndt_launch_segments(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, const Slice* d_slices, const SliceTable& t, const uint32_t* d_n_valid, const uint32_t* d_blk,
                         const LeafSlice* d_leaf_slices, uint32_t* d_seg_start, int32_t* d_seg_key);
 int ndt_launch_leaves(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32_t* d_sorted_vals, const Slice* d_slices, const SliceTable& t, const LeafSlice* d_leaf_slices,
                       const VoxelParams* d_vp, uint32_t max_leaves, const uint32_t* d_seg_start, uint32_t* d_big_cnt, uint32_t* d_big_list, const int32_t* d_seg_key, double* d_sums, NdtLeafRec* d_leaves,

@@ -59,27 +59,38 @@ __global__ __launch_bounds__(256) void ndt_cellkey_kernel(const float4* const* _
 }
 
 // run heads -> seg_start[leaf] (position in the sorted arrays) and seg_key[leaf]; the thread that sees the last valid
-// element also writes the sentinel seg_start[V] = n_valid.
-__global__ __launch_bounds__(256) void ndt_segments_kernel(const uint32_t* __restrict__ sorted_keys,
-                                                            const uint32_t* __restrict__ ordinal, const Slice* __restrict__ slices,
-                                                            const LeafSlice* __restrict__ leaf_slices, uint32_t* __restrict__ seg_start, int32_t* __restrict__ seg_key)
+// element also writes the sentinel seg_start[V] = n_valid.  A head's leaf index is its ordinal among the run heads: the exclusive prefix of the
+// tile (blk, from exclusive_scan_run_heads) + the scan of the head flags inside the tile, computed here — round 3 wrote an ordinal for EVERY
+// point in one launch and read it back for the heads in the next (8 bytes per point and a launch more: 138 + 54 us per 256 targets).
+__global__ __launch_bounds__(256) void ndt_segments_kernel(const uint32_t* __restrict__ sorted_keys, const Slice* __restrict__ slices, const uint32_t* __restrict__ n_valid,
+                                                            const uint32_t* __restrict__ blk, const LeafSlice* __restrict__ leaf_slices, uint32_t* __restrict__ seg_start,
+                                                            int32_t* __restrict__ seg_key)
 {
     const Slice s = slices[blockIdx.y];
     if (blockIdx.x >= s.nblk) return;
+    __shared__ uint32_t lds[8];
     const LeafSlice ls = leaf_slices[blockIdx.y];
-    const uint32_t  base = blockIdx.x * kTile;
+    const uint32_t  nv = n_valid[blockIdx.y];
+    const uint32_t* __restrict__ k0 = sorted_keys + s.off;
+    const uint32_t first = blockIdx.x * kTile + threadIdx.x * 8;
+    uint32_t kk[9];  // the thread's eight keys and the one before them
+    kk[0] = (first > 0 && first - 1 < s.n) ? k0[first - 1] : 0u;
 #pragma unroll
-    for (int k = 0; k < kTile / 256; ++k) {
-        const uint32_t i = base + k * 256 + threadIdx.x;
-        if (i < s.n) {
-            const uint32_t key = sorted_keys[s.off + i];
-            if (i < ls.n_valid && (i == 0 || sorted_keys[s.off + i - 1] != key)) {  // a run head
-                const uint32_t o = ordinal[s.off + i];
-                seg_start[ls.seg_off + o] = i;
-                seg_key[ls.leaf_off + o] = static_cast<int32_t>(key);
-            }
-            if (i + 1 == ls.n_valid) seg_start[ls.seg_off + ls.n_leaves] = ls.n_valid;
+    for (int k = 0; k < 8; ++k) kk[k + 1] = (first + k < s.n) ? k0[first + k] : 0u;
+    uint32_t head[8], tsum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { head[k] = (first + k < nv && (first + k == 0 || kk[k] != kk[k + 1])) ? 1u : 0u; tsum += head[k]; }
+    uint32_t total;
+    uint32_t ord = block_exclusive_scan<256>(tsum, lds, &total) + blk[s.blk_off + blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t i = first + k;
+        if (head[k] && ord < ls.n_leaves) {  // (n_leaves = 0 for a target the host has disabled)
+            seg_start[ls.seg_off + ord] = i;
+            seg_key[ls.leaf_off + ord] = static_cast<int32_t>(kk[k + 1]);
         }
+        ord += head[k];
+        if (i < s.n && i + 1 == ls.n_valid) seg_start[ls.seg_off + ls.n_leaves] = ls.n_valid;
     }
 }
 
@@ -384,12 +395,11 @@ int ndt_launch_cellkeys(mrgfe_ctx* ctx, const float4* const* d_clouds, const Sli
     return MRGFE_OK;
 }
 
-int ndt_launch_segments(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, const uint32_t* d_ordinal, const Slice* d_slices, const SliceTable& t,
+int ndt_launch_segments(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, const Slice* d_slices, const SliceTable& t, const uint32_t* d_n_valid, const uint32_t* d_blk,
                         const LeafSlice* d_leaf_slices, uint32_t* d_seg_start, int32_t* d_seg_key)
 {
     if (t.nprob() == 0 || t.max_blks == 0) return MRGFE_OK;
-    hipLaunchKernelGGL(ndt_segments_kernel, dim3(t.max_blks, t.nprob()), dim3(256), 0, ctx->stream, d_sorted_keys, d_ordinal, d_slices, d_leaf_slices,
-                       d_seg_start, d_seg_key);
+    hipLaunchKernelGGL(ndt_segments_kernel, dim3(t.max_blks, t.nprob()), dim3(256), 0, ctx->stream, d_sorted_keys, d_slices, d_n_valid, d_blk, d_leaf_slices, d_seg_start, d_seg_key);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }

@@ -206,10 +206,9 @@ int NdtEngine::build_targets(bool wait)
     MRGFE_TRY(ndt_launch_cellkeys(ctx_, d_cp, d_sl, tab, d_vp, dk.as<uint32_t>(), dh.as<uint32_t>()));
     uint32_t *sk = nullptr, *sv = nullptr;
     MRGFE_TRY(radix_sort_pairs(ctx_, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), d_sl, tab, key_bits, dh.as<uint32_t>(), &sk, &sv, true, true));
-    // run heads of the sorted keys -> ordinals (the voxel's leaf index at its first point), into the unused sort buffer
-    uint32_t* d_ord = (sk == dk.as<uint32_t>()) ? dkt.as<uint32_t>() : dk.as<uint32_t>();
+    // run heads of the sorted keys: their number per target and the tiles' prefixes (a head's ordinal = its voxel's leaf index, made up by the segments kernel)
     uint32_t* d_tot = dblk.as<uint32_t>() + tab.total_blks;
-    MRGFE_TRY(exclusive_scan_run_heads(ctx_, sk, d_ord, d_sl, tab, d_nv, dblk.as<uint32_t>(), d_tot));
+    MRGFE_TRY(exclusive_scan_run_heads(ctx_, sk, nullptr, d_sl, tab, d_nv, dblk.as<uint32_t>(), d_tot));
     MRGFE_HIP_CHECK(hipMemcpyAsync(h_tot, d_tot, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
 
@@ -264,7 +263,7 @@ int NdtEngine::build_targets(bool wait)
     MRGFE_HIP_CHECK(hipMemcpyAsync(dd + o_ls, hd + o_ls, sizeof(LeafSlice) * P, hipMemcpyHostToDevice, st));
 
     // 5. segments and leaves
-    MRGFE_TRY(ndt_launch_segments(ctx_, sk, d_ord, d_sl, tab, d_ls, dseg.as<uint32_t>(), static_cast<int32_t*>(p_keys)));
+    MRGFE_TRY(ndt_launch_segments(ctx_, sk, d_sl, tab, d_nv, dblk.as<uint32_t>(), d_ls, dseg.as<uint32_t>(), static_cast<int32_t*>(p_keys)));
     MRGFE_TRY(ndt_launch_leaves(ctx_, d_cp, sv, d_sl, tab, d_ls, d_vp, max_leaves, dseg.as<uint32_t>(), dseg.as<uint32_t>() + seg_words, dseg.as<uint32_t>() + seg_words + P,
                                 static_cast<const int32_t*>(p_keys), dsum.as<double>(),
                                 static_cast<NdtLeafRec*>(p_leaves), static_cast<double*>(p_icov), static_cast<float4*>(p_cent), static_cast<int32_t*>(p_npts), p_lookup));

@@ -115,9 +115,19 @@ __global__ __launch_bounds__(256) void nn_gather_kernel(const float4* __restrict
 // the dense-table passes were 13 x the target points in traffic and ~9 ms of co-running kernels per config[3] step.  The same launch
 // gathers the points into sorted order and — for builds that measure their own crowding — adds up rank-in-run = (position - position of
 // the run's head), which is the figure the counting atomics used to produce: sum over cells of n (n - 1) / 2.
+// Long gaps.  A scan's cells are x-fastest, so the gap in front of the first occupied cell of a row is a few cells, of a plane a few rows — and
+// of the first occupied plane, or behind the last one, MILLIONS of entries: one wavefront writing such a gap alone (a 256-byte store at a
+// time) was the whole kernel's tail (63 us for a 2^24-entry table whose 64 MB go out in 20 us at the chip's rate).  Gaps of kLongGap entries
+// or more are therefore cut into chunks of kGapChunk entries and queued; nn_fill_long_kernel writes the chunks, a workgroup each.
+constexpr uint32_t kLongGap = 4096, kGapChunk = 16384, kGapCap = 8192;
+struct NnGapQueue {  // zeroed with the pyramid words before every build
+    uint32_t count, pad[3];
+    uint4    e[kGapCap];  // first entry, one past the last, value, -
+};
+
 __device__ __forceinline__ void nn_fill_body(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const float4* __restrict__ pts, uint32_t n, const NnGridDev& g,
                                              uint32_t n_cells, uint32_t* __restrict__ cell_start, unsigned long long* __restrict__ occ, float4* __restrict__ sorted,
-                                             unsigned long long* __restrict__ crowd)
+                                             unsigned long long* __restrict__ crowd, NnGapQueue* __restrict__ gapq)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const int      lane = lane_id();
@@ -138,6 +148,19 @@ __device__ __forceinline__ void nn_fill_body(const uint32_t* __restrict__ keys, 
         const int l = __ffsll(static_cast<unsigned long long>(gaps)) - 1;
         gaps &= gaps - 1;
         const uint32_t a = wave_read(c0, l), b = wave_read(k, l), v = wave_read(i, l);
+        if (gapq != nullptr && b - a >= kLongGap) {  // uniform
+            const uint32_t nch = (b - a + kGapChunk - 1) / kGapChunk;
+            uint32_t       base = 0;
+            if (lane == 0) base = atomicAdd(&gapq->count, nch);
+            base = wave_read(base, 0);
+            if (base + nch <= kGapCap) {
+                for (uint32_t c = static_cast<uint32_t>(lane); c < nch; c += 64u) {
+                    const uint32_t lo = a + c * kGapChunk, hi = (c + 1 == nch) ? b : lo + kGapChunk;
+                    gapq->e[base + c] = make_uint4(lo, hi, v, 0u);
+                }
+                continue;
+            }  // (a full queue: the wavefront writes the gap itself; the reserved slots stay zero = empty chunks)
+        }
         for (uint32_t c = a + static_cast<uint32_t>(lane); c < b; c += 64u) cell_start[c] = v;
     }
     if (head && i < n && k < n_cells && occ != nullptr) {
@@ -185,10 +208,20 @@ __device__ __forceinline__ void nn_fill_body(const uint32_t* __restrict__ keys, 
 
 __global__ __launch_bounds__(256) void nn_fill_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const float4* __restrict__ pts, uint32_t n, NnGridDev g,
                                                        uint32_t n_cells, uint32_t* __restrict__ cell_start, unsigned long long* __restrict__ occ, float4* __restrict__ sorted,
-                                                       unsigned long long* __restrict__ crowd)
+                                                       unsigned long long* __restrict__ crowd, NnGapQueue* __restrict__ gapq)
 {
-    nn_fill_body(keys, vals, pts, n, g, n_cells, cell_start, occ, sorted, crowd);
+    nn_fill_body(keys, vals, pts, n, g, n_cells, cell_start, occ, sorted, crowd, gapq);
 }
+__device__ __forceinline__ void nn_fill_long_body(const NnGapQueue* __restrict__ q, uint32_t* __restrict__ cell_start)
+{
+    const uint32_t cnt = min(q->count, kGapCap);
+    for (uint32_t e = blockIdx.x; e < cnt; e += gridDim.x) {
+        const uint4 r = q->e[e];
+        for (uint32_t c = r.x + threadIdx.x; c < r.y; c += 256u) cell_start[c] = r.z;
+    }
+}
+__global__ __launch_bounds__(256) void nn_fill_long_kernel(const NnGapQueue* __restrict__ q, uint32_t* __restrict__ cell_start) { nn_fill_long_body(q, cell_start); }
+constexpr uint32_t kFillLongBlocks = 1024;
 
 // ---- the same steps for the members of an NnGridSet: blockIdx.y = member --------------------------------------
 struct NnBuildDev {
@@ -196,6 +229,7 @@ struct NnBuildDev {
     const float4*       pts;
     uint32_t*           counts;   // == lv.cell_start, writable
     unsigned long long* crowd;    // kCrowdSlots counters, or null
+    NnGapQueue*         gapq;     // long gaps of the cell table (nn_fill_body), or null
     unsigned long long* occ[3];   // == lv.occ, occ1, occ2, writable
     float4*             sorted;   // == lv.sorted, writable
     uint32_t            n;        // points of the cloud
@@ -215,7 +249,13 @@ __global__ __launch_bounds__(256) void nn_fill_many_kernel(const NnBuildDev* __r
 {
     const NnBuildDev& b = d[blockIdx.y];
     if (!b.active || blockIdx.x * 256u > b.n) return;  // (thread n closes the table)
-    nn_fill_body(sorted_keys + b.off, sorted_vals + b.off, b.pts, b.n, b.lv, b.n_cells, b.counts, with_occ ? b.occ[0] : nullptr, b.sorted, b.crowd);
+    nn_fill_body(sorted_keys + b.off, sorted_vals + b.off, b.pts, b.n, b.lv, b.n_cells, b.counts, with_occ ? b.occ[0] : nullptr, b.sorted, b.crowd, b.gapq);
+}
+__global__ __launch_bounds__(256) void nn_fill_long_many_kernel(const NnBuildDev* __restrict__ d)
+{
+    const NnBuildDev& b = d[blockIdx.y];
+    if (!b.active || b.gapq == nullptr) return;
+    nn_fill_long_body(b.gapq, b.counts);
 }
 __global__ __launch_bounds__(256) void nn_occupancy_many_kernel(const NnBuildDev* __restrict__ d)
 {
@@ -263,7 +303,9 @@ int NnGrid::build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const 
     }
     // [counts / cell_start: n_cells + 1][crowd counters][occupancy words of the three pyramid levels], zeroed together
     const size_t head_words = size_t(n_cells) + 4 + 2 * kCrowdSlots, occ_at = (head_words + 1) & ~size_t(1);
-    const size_t all_words = occ_at + 2 * (pn[0] + pn[1] + pn[2]);
+    const bool   long_gaps = !counts_only && n_cells >= 64u * kLongGap;  // tables in which long gaps are worth a second launch
+    const size_t gapq_at = (occ_at + 2 * (pn[0] + pn[1] + pn[2]) + 3) & ~size_t(3);  // 16-byte aligned
+    const size_t all_words = gapq_at + (long_gaps ? sizeof(NnGapQueue) / 4 : 0);
     MRGFE_TRY(d_cells.ensure(sizeof(uint32_t) * all_words));
     // counting passes zero the count table; a full build writes every entry of the cell table itself (nn_fill_kernel) and only needs the
     // crowd counters and the pyramid words behind it cleared
@@ -301,8 +343,10 @@ int NnGrid::build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const 
     MRGFE_TRY(d_sorted.ensure(sizeof(float4) * std::max<size_t>(nn, 1)));
     lv.sorted = d_sorted.as<float4>();
     const bool pyramid = &lv == &h_.level[0];  // only the finest level is searched through the pyramid (the coarser ones serve the k-NN climb)
+    NnGapQueue* d_gapq = long_gaps ? reinterpret_cast<NnGapQueue*>(d_cells.as<uint32_t>() + gapq_at) : nullptr;
     hipLaunchKernelGGL(nn_fill_kernel, dim3(nn / 256 + 1), dim3(256), 0, st, sk, sv, d_pts, nn, lv, n_cells, d_cells.as<uint32_t>(), pyramid ? const_cast<unsigned long long*>(lv.occ) : nullptr,
-                       d_sorted.as<float4>(), crowding ? d_crowd : nullptr);
+                       d_sorted.as<float4>(), crowding ? d_crowd : nullptr, d_gapq);
+    if (long_gaps) hipLaunchKernelGGL(nn_fill_long_kernel, dim3(kFillLongBlocks), dim3(256), 0, st, d_gapq, d_cells.as<uint32_t>());
     if (pyramid) {
         hipLaunchKernelGGL(nn_occupancy_up_kernel, dim3(static_cast<uint32_t>((pn[0] + 255) / 256)), dim3(256), 0, st, lv.occ, pd[0][0], pd[0][1], pd[0][2], pd[1][0], pd[1][1],
                            const_cast<unsigned long long*>(lv.occ1));
@@ -534,6 +578,16 @@ int NnGridSet::build(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32
         words += 2ull * kCrowdSlots * M;
         std::vector<uint64_t> occ_at(M);
         for (size_t m = 0; m < M; ++m) { occ_at[m] = words; if (dev[m].active) words += 2ull * (pn[m * 3] + pn[m * 3 + 1] + pn[m * 3 + 2]); }
+        // queues of long gaps (nn_fill_body) for the members whose tables are large enough to have any worth a second launch
+        std::vector<uint64_t> gapq_at(M, 0);
+        bool any_long = false;
+        for (size_t m = 0; m < M && !counts_only; ++m) {
+            if (!dev[m].active || dev[m].n_cells < 64u * kLongGap) continue;
+            words = (words + 3) & ~uint64_t(3);
+            gapq_at[m] = words;
+            words += sizeof(NnGapQueue) / 4;
+            any_long = true;
+        }
         if (words > 0xffffffffull) { set_error("NnGridSet: cell tables of %llu words", static_cast<unsigned long long>(words)); return MRGFE_ERR_INVALID; }
         DevBuf& dc = d_cells_[level];
         MRGFE_TRY(dc.ensure(sizeof(uint32_t) * words));
@@ -553,6 +607,7 @@ int NnGridSet::build(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32
             if (!b.active) continue;
             b.counts = dc.as<uint32_t>() + ctab.h[m].off;
             b.crowd = crowding ? reinterpret_cast<unsigned long long*>(dc.as<uint32_t>() + crowd_at) + kCrowdSlots * m : nullptr;
+            b.gapq = gapq_at[m] ? reinterpret_cast<NnGapQueue*>(dc.as<uint32_t>() + gapq_at[m]) : nullptr;
             b.occ[0] = reinterpret_cast<unsigned long long*>(dc.as<uint32_t>() + occ_at[m]);
             b.occ[1] = b.occ[0] + pn[m * 3];
             b.occ[2] = b.occ[1] + pn[m * 3 + 1];
@@ -591,6 +646,7 @@ int NnGridSet::build(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32
         // cell tables, brick words, sorted points and crowding figures of all members from their sorted (key, index) pairs in one launch
         (void)d_cslices; (void)dblk; (void)max_cells;
         if (tab.max_blks) hipLaunchKernelGGL(nn_fill_many_kernel, dim3(tab.max_blks * (kTile / 256) + 1, count), dim3(256), 0, st, d_dev, sk, sv, level == 0 ? 1 : 0);
+        if (tab.max_blks && any_long) hipLaunchKernelGGL(nn_fill_long_many_kernel, dim3(kFillLongBlocks / 4, count), dim3(256), 0, st, d_dev);
         if (level == 0) {  // only the finest level is searched through the pyramid
             hipLaunchKernelGGL(nn_occupancy_up_many_kernel, dim3((max_bricks + 255) / 256, count), dim3(256), 0, st, d_dev, 0);
             hipLaunchKernelGGL(nn_occupancy_up_many_kernel, dim3((max_super + 255) / 256, count), dim3(256), 0, st, d_dev, 1);
