@@ -364,6 +364,108 @@ int NnGrid::build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const 
     return MRGFE_OK;
 }
 
+// All levels of one grid in ONE pass of launches (round 4).  The levels of a k-NN grid (cell edges c, 4 c, 16 c over the same points) used to be
+// built one after the other — bin, sort, fill: a dozen launches each — and a 130k-point GICP frame spent 0.38 ms in them for 0.2 ms of kernels.
+// Here every level is a member of the batched kernels (blockIdx.y = level: its own geometry, cell table and sorted copy, the same points), so
+// the three levels cost the launches of one; only level 0 carries the pyramid and the crowding counters.
+int NnGrid::build_levels_together(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, const float* cell, int L, double* crowding)
+{
+    hipStream_t st = ctx->stream;
+    std::vector<uint32_t> sizes(L, nn);
+    SliceTable tab;
+    tab.build(sizes.data(), L);
+    DevBuf &ds = ctx->scratch[0], &dk = ctx->scratch[2], &dv = ctx->scratch[3], &dkt = ctx->scratch[4], &dvt = ctx->scratch[5], &dh = ctx->scratch[6];
+    const size_t ne = std::max<size_t>(tab.total_elems, 4);
+    MRGFE_TRY(dk.ensure(ne * 4)); MRGFE_TRY(dv.ensure(ne * 4)); MRGFE_TRY(dkt.ensure(ne * 4)); MRGFE_TRY(dvt.ensure(ne * 4));
+    MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + L)));
+    const size_t at_dev = (sizeof(Slice) * L + 15) & ~size_t(15);
+    MRGFE_TRY(ds.ensure(at_dev + sizeof(NnBuildDev) * L));
+    std::vector<NnBuildDev> dev(L);
+    unsigned long long* d_crowd = nullptr;
+    uint32_t max_cells = 1, max_bricks = 1, max_super = 1;
+    bool any_long = false;
+    for (int l = 0; l < L; ++l) {
+        NnBuildDev& b = dev[l];
+        std::memset(&b, 0, sizeof(b));
+        NnGridDev& lv = b.lv;
+        float extent = 0.0f;
+        for (int a = 0; a < 3; ++a) { lv.origin[a] = bb.mn[a]; extent = std::max(extent, bb.mx[a] - bb.mn[a]); }
+        lv.cell = cell[l];
+        lv.slack = 1e-6f * (extent + cell[l]);
+        lv.n = bb.n_finite;
+        for (int a = 0; a < 3; ++a) lv.dim[a] = static_cast<int>(std::floor((bb.mx[a] - bb.mn[a]) / cell[l])) + 1;
+        const uint32_t n_cells = static_cast<uint32_t>(lv.dim[0]) * lv.dim[1] * lv.dim[2];
+        size_t pn[3] = {1, 1, 1};
+        for (int a = 0; a < 3; ++a) {
+            lv.bdim[a] = b.pd[0][a] = (lv.dim[a] + 3) / 4;
+            b.pd[1][a] = (b.pd[0][a] + 3) / 4;
+            b.pd[2][a] = (b.pd[1][a] + 3) / 4;
+            for (int k = 0; k < 3; ++k) pn[k] *= static_cast<size_t>(b.pd[k][a]);
+        }
+        // [cell table: n_cells + 1][crowd counters][occupancy words of the three pyramid levels][queue of long gaps]; the table is written entry by
+        // entry (nn_fill_body), the rest is cleared
+        const size_t crowd_word = (size_t(n_cells) + 2) & ~size_t(1);
+        const size_t head_words = size_t(n_cells) + 4 + 2 * kCrowdSlots, occ_at = (head_words + 1) & ~size_t(1);
+        const bool   long_gaps = n_cells >= 64u * kLongGap;
+        const size_t gapq_at = (occ_at + 2 * (pn[0] + pn[1] + pn[2]) + 3) & ~size_t(3);
+        const size_t all_words = gapq_at + (long_gaps ? sizeof(NnGapQueue) / 4 : 0);
+        DevBuf& d_cells = d_cell_start_[l];
+        MRGFE_TRY(d_cells.ensure(sizeof(uint32_t) * all_words));
+        MRGFE_HIP_CHECK(hipMemsetAsync(d_cells.as<uint32_t>() + crowd_word, 0, sizeof(uint32_t) * (all_words - crowd_word), st));
+        MRGFE_TRY(d_sorted_[l].ensure(sizeof(float4) * std::max<size_t>(nn, 1)));
+        lv.cell_start = d_cells.as<uint32_t>();
+        lv.sorted = d_sorted_[l].as<float4>();
+        lv.occ = reinterpret_cast<const unsigned long long*>(d_cells.as<uint32_t>() + occ_at);
+        lv.occ1 = lv.occ + pn[0];
+        lv.occ2 = lv.occ1 + pn[1];
+        b.pts = d_pts;
+        b.counts = d_cells.as<uint32_t>();
+        b.sorted = d_sorted_[l].as<float4>();
+        b.n = nn;
+        b.off = tab.h[l].off;
+        b.n_cells = n_cells;
+        b.active = 1;
+        b.gapq = long_gaps ? reinterpret_cast<NnGapQueue*>(d_cells.as<uint32_t>() + gapq_at) : nullptr;
+        any_long = any_long || long_gaps;
+        if (l == 0) {  // only the finest level is searched through the pyramid and measures its crowding
+            b.occ[0] = const_cast<unsigned long long*>(lv.occ);
+            b.occ[1] = const_cast<unsigned long long*>(lv.occ1);
+            b.occ[2] = const_cast<unsigned long long*>(lv.occ2);
+            d_crowd = reinterpret_cast<unsigned long long*>(d_cells.as<uint32_t>() + crowd_word);
+            b.crowd = crowding ? d_crowd : nullptr;
+            max_bricks = static_cast<uint32_t>(pn[0]);
+            max_super = static_cast<uint32_t>(pn[1]);
+        }
+        max_cells = std::max(max_cells, n_cells);
+        h_.level[l] = lv;
+    }
+    h_.n_levels = L;
+    const Slice*      d_slices = ds.as<Slice>();
+    const NnBuildDev* d_dev = reinterpret_cast<const NnBuildDev*>(ds.as<char>() + at_dev);
+    MRGFE_TRY(ctx->stage_h2d(ds.p, tab.h.data(), sizeof(Slice) * L, st));
+    MRGFE_TRY(ctx->stage_h2d(ds.as<char>() + at_dev, dev.data(), sizeof(NnBuildDev) * L, st));
+    const dim3 grid(tab.max_blks * (kTile / 256), L);
+    hipLaunchKernelGGL(nn_cellkey_many_kernel, grid, dim3(256), 0, st, d_dev, dk.as<uint32_t>(), dv.as<uint32_t>(), 0);
+    int key_bits = 1;
+    while (key_bits < 32 && (uint64_t(1) << key_bits) <= max_cells) ++key_bits;
+    uint32_t *sk = nullptr, *sv = nullptr;
+    MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), d_slices, tab, key_bits, dh.as<uint32_t>(), &sk, &sv, true));
+    hipLaunchKernelGGL(nn_fill_many_kernel, dim3(tab.max_blks * (kTile / 256) + 1, L), dim3(256), 0, st, d_dev, sk, sv, 1);
+    if (any_long) hipLaunchKernelGGL(nn_fill_long_many_kernel, dim3(kFillLongBlocks, L), dim3(256), 0, st, d_dev);
+    hipLaunchKernelGGL(nn_occupancy_up_many_kernel, dim3((max_bricks + 255) / 256, 1), dim3(256), 0, st, d_dev, 0);  // (member 0 = the finest level)
+    hipLaunchKernelGGL(nn_occupancy_up_many_kernel, dim3((max_super + 255) / 256, 1), dim3(256), 0, st, d_dev, 1);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    if (crowding) {
+        unsigned long long slots[kCrowdSlots];
+        MRGFE_HIP_CHECK(hipMemcpyAsync(slots, d_crowd, sizeof(slots), hipMemcpyDeviceToHost, st));
+        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+        unsigned long long crowd = 0;
+        for (unsigned long long v : slots) crowd += v;
+        *crowding = 1.0 + 2.0 * double(crowd) / double(bb.n_finite);
+    }
+    return MRGFE_OK;
+}
+
 int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size, double crowding_target, int max_levels)
 {
     built_ = false;
@@ -417,15 +519,33 @@ int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size
     // k-th target of a batch call after call: clouds of one sensor) is tried first, as a FULL build that measures its own crowding: when the
     // figure is still in range the build is done — no counting pass, no extra host round trip (each is a launch, a read-back and a wait: a third
     // of a 130k-point build).  The search results do not depend on the edge, only the time does.
+    // the edges of all levels once the finest is known: kLevelRatio x the edge each, same origin, as long as the level below has more than a
+    // handful of cells per axis
+    float ratio = kLevelRatio;
+    if (const char* e = std::getenv("MRGFE_NN_COARSE_RATIO")) ratio = std::max(2.0f, static_cast<float>(std::atof(e)));  // tuning hook
+    auto level_edges = [&](float c0, float* edges) {
+        int L = 1;
+        edges[0] = c0;
+        while (L < std::min(max_levels, kNnMaxLevels)) {
+            int dmax = 0;
+            for (int a = 0; a < 3; ++a) dmax = std::max(dmax, static_cast<int>(std::floor((bb.mx[a] - bb.mn[a]) / edges[L - 1])) + 1);
+            if (dmax <= 4) break;
+            edges[L] = edges[L - 1] * ratio;
+            ++L;
+        }
+        return L;
+    };
+    float edges[kNnMaxLevels];
     if (crowding_target > 0 && hint_cell_ > 0 && hint_target_ == crowding_target && hint_cell_size_ == cell_size && hint_cell_ <= cell && cells_at(hint_cell_) <= double(1u << 24)) {
         double crowding = 0;
-        MRGFE_TRY(build_level(ctx, d_pts, nn, bb, hint_cell_, tab, h_.level[0], d_cell_start_[0], d_sorted_[0], false, &crowding));
+        const int L = level_edges(hint_cell_, edges);
+        MRGFE_TRY(build_levels_together(ctx, d_pts, nn, bb, edges, L, &crowding));
         const bool too_crowded = crowding > 1.5 * crowding_target && cells_at(hint_cell_ * 0.5f) <= double(1u << 24) && hint_cell_ * 16.0f > cell_size * 0.999f;
         const bool too_fine = crowding * 6.0 < crowding_target && hint_cell_ < cell;
         if (!too_crowded) {
             if (too_fine) hint_cell_ = 0;  // this build stands; the next one adapts from the top again
-            cell = h_.level[0].cell;
-            goto coarser_levels;
+            built_ = true;
+            return MRGFE_OK;
         }
         hint_cell_ = 0;
     }
@@ -445,19 +565,11 @@ int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size
             halvings += step;
         }
     }
-    MRGFE_TRY(build_level(ctx, d_pts, nn, bb, cell, tab, h_.level[0], d_cell_start_[0], d_sorted_[0], false, nullptr));
-    if (crowding_target > 0) { hint_cell_ = cell; hint_target_ = crowding_target; hint_cell_size_ = cell_size; }
-coarser_levels:
-    // coarser levels for queries whose neighbourhood is empty at the finer scale: kLevelRatio x the edge each, same origin,
-    // as long as the level above still has more than a handful of cells per axis
-    float ratio = kLevelRatio;
-    if (const char* e = std::getenv("MRGFE_NN_COARSE_RATIO")) ratio = std::max(2.0f, static_cast<float>(std::atof(e)));  // tuning hook
-    while (h_.n_levels < std::min(max_levels, kNnMaxLevels)) {
-        const NnGridDev& below = h_.level[h_.n_levels - 1];
-        if (std::max(below.dim[0], std::max(below.dim[1], below.dim[2])) <= 4) break;
-        MRGFE_TRY(build_level(ctx, d_pts, nn, bb, below.cell * ratio, tab, h_.level[h_.n_levels], d_cell_start_[h_.n_levels], d_sorted_[h_.n_levels], false, nullptr));
-        ++h_.n_levels;
+    {
+        const int L = level_edges(cell, edges);
+        MRGFE_TRY(build_levels_together(ctx, d_pts, nn, bb, edges, L, nullptr));
     }
+    if (crowding_target > 0) { hint_cell_ = cell; hint_target_ = crowding_target; hint_cell_size_ = cell_size; }
     built_ = true;
     return MRGFE_OK;
 }
