@@ -834,25 +834,100 @@ int NnGridSet::build(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32
             break;
         }
     }
-    // coarser levels for the k-NN climb: kLevelRatio x the edge each, while the level below has more than a handful of cells per axis
+    // coarser levels for the k-NN climb: kLevelRatio x the edge each, while the level below has more than a handful of cells per axis — the coarser
+    // levels of ALL members in one pass of launches (an entry per (member, level): its own geometry, cell table and sorted copy; round 3 ran a
+    // pass per level)
     float ratio = NnGrid::kLevelRatio;
     if (const char* e = std::getenv("MRGFE_NN_COARSE_RATIO")) ratio = std::max(2.0f, static_cast<float>(std::atof(e)));
-    for (int level = 1; level < std::min(max_levels, kNnMaxLevels); ++level) {
-        std::vector<char>  act(M, 0);
-        std::vector<float> c(M, cell_size);
-        bool any = false;
-        for (size_t m = 0; m < M; ++m) {
-            if (!bb[m].n_finite || h[m].n_levels != level) continue;
-            const NnGridDev& below = h[m].level[level - 1];
-            if (std::max(below.dim[0], std::max(below.dim[1], below.dim[2])) <= 4) continue;
-            act[m] = 1;
-            c[m] = below.cell * ratio;
-            any = true;
+    struct Entry { size_t m; int level; float cell; };
+    std::vector<Entry> entries;
+    for (size_t m = 0; m < M; ++m) {
+        if (!bb[m].n_finite) continue;
+        float c = h[m].level[0].cell;
+        for (int level = 1; level < std::min(max_levels, kNnMaxLevels); ++level) {
+            int dmax = 0;
+            for (int a = 0; a < 3; ++a) dmax = std::max(dmax, static_cast<int>(std::floor((bb[m].mx[a] - bb[m].mn[a]) / c)) + 1);
+            if (dmax <= 4) break;
+            c *= ratio;
+            entries.push_back({m, level, c});
         }
-        if (!any) break;
-        MRGFE_TRY(build_level(level, c, act, false, nullptr));
-        for (size_t m = 0; m < M; ++m)
-            if (act[m]) ++h[m].n_levels;
+    }
+    if (!entries.empty()) {
+        const size_t E = entries.size();
+        std::vector<uint32_t> sizes(E);
+        for (size_t e = 0; e < E; ++e) sizes[e] = n[entries[e].m];
+        SliceTable etab;
+        etab.build(sizes.data(), static_cast<int>(E));
+        if (etab.total_elems > 0x7fffffffu) { set_error("NnGridSet: %u points in the coarser levels of one set", etab.total_elems); return MRGFE_ERR_INVALID; }
+        const size_t ee = std::max<size_t>(etab.total_elems, 4);
+        MRGFE_TRY(dk.ensure(ee * 4)); MRGFE_TRY(dv.ensure(ee * 4)); MRGFE_TRY(dkt.ensure(ee * 4)); MRGFE_TRY(dvt.ensure(ee * 4));
+        MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (etab.total_blks + E)));
+        std::vector<NnBuildDev> edev(E);
+        std::vector<uint64_t>   cell_at(E), gq_at(E, 0);
+        uint64_t words = 0;
+        uint32_t max_cells = 1;
+        bool     any_long = false;
+        for (size_t e = 0; e < E; ++e) {
+            const size_t m = entries[e].m;
+            NnBuildDev&  b = edev[e];
+            std::memset(&b, 0, sizeof(b));
+            NnGridDev& lv = b.lv;
+            float extent = 0.0f;
+            for (int a = 0; a < 3; ++a) { lv.origin[a] = bb[m].mn[a]; extent = std::max(extent, bb[m].mx[a] - bb[m].mn[a]); }
+            lv.cell = entries[e].cell;
+            lv.slack = 1e-6f * (extent + lv.cell);
+            lv.n = bb[m].n_finite;
+            for (int a = 0; a < 3; ++a) { lv.dim[a] = static_cast<int>(std::floor((bb[m].mx[a] - bb[m].mn[a]) / lv.cell)) + 1; lv.bdim[a] = (lv.dim[a] + 3) / 4; }
+            b.n_cells = static_cast<uint32_t>(lv.dim[0]) * lv.dim[1] * lv.dim[2];
+            b.pts = d_clouds[m];
+            b.n = n[m];
+            b.off = etab.h[e].off;
+            b.active = 1;
+            cell_at[e] = words;
+            words += (uint64_t(b.n_cells) + 1 + 3) & ~uint64_t(3);
+            if (b.n_cells >= 64u * kLongGap) { gq_at[e] = 1; any_long = true; }
+            max_cells = std::max(max_cells, b.n_cells);
+        }
+        const uint64_t gq_base = words;  // the queues of long gaps behind all tables: the only part that has to be cleared (no pyramid, no counters here)
+        for (size_t e = 0; e < E; ++e)
+            if (gq_at[e]) { gq_at[e] = words; words += sizeof(NnGapQueue) / 4; }
+        if (words > 0xffffffffull) { set_error("NnGridSet: coarse cell tables of %llu words", static_cast<unsigned long long>(words)); return MRGFE_ERR_INVALID; }
+        DevBuf &dc = d_cells_[1], &dso = d_sorted_[1];
+        MRGFE_TRY(dc.ensure(sizeof(uint32_t) * std::max<uint64_t>(words, 4)));
+        MRGFE_TRY(dso.ensure(sizeof(float4) * std::max<size_t>(etab.total_elems, 1)));
+        if (words > gq_base) MRGFE_HIP_CHECK(hipMemsetAsync(dc.as<uint32_t>() + gq_base, 0, sizeof(uint32_t) * (words - gq_base), st));
+        for (size_t e = 0; e < E; ++e) {
+            NnBuildDev& b = edev[e];
+            b.counts = dc.as<uint32_t>() + cell_at[e];
+            b.sorted = dso.as<float4>() + etab.h[e].off;
+            b.gapq = gq_at[e] ? reinterpret_cast<NnGapQueue*>(dc.as<uint32_t>() + gq_at[e]) : nullptr;
+            b.lv.cell_start = b.counts;
+            b.lv.sorted = b.sorted;
+            b.lv.occ = b.lv.occ1 = b.lv.occ2 = nullptr;  // (only the finest level is searched through the pyramid)
+        }
+        // the entries' slices and descriptors: in the bounding boxes' scratch (free since their read-back), through the pinned staging ring
+        const size_t at_edev = (sizeof(Slice) * E + 15) & ~size_t(15);
+        MRGFE_TRY(dbb.ensure(at_edev + sizeof(NnBuildDev) * E));
+        MRGFE_TRY(ctx->stage_h2d(dbb.p, etab.h.data(), sizeof(Slice) * E, st));
+        MRGFE_TRY(ctx->stage_h2d(dbb.as<char>() + at_edev, edev.data(), sizeof(NnBuildDev) * E, st));
+        const Slice*      d_eslices = dbb.as<Slice>();
+        const NnBuildDev* d_edev = reinterpret_cast<const NnBuildDev*>(dbb.as<char>() + at_edev);
+        if (etab.max_blks) {
+            hipLaunchKernelGGL(nn_cellkey_many_kernel, dim3(etab.max_blks * (kTile / 256), static_cast<uint32_t>(E)), dim3(256), 0, st, d_edev, dk.as<uint32_t>(), dv.as<uint32_t>(), 0);
+            int key_bits = 1;
+            while (key_bits < 32 && (uint64_t(1) << key_bits) <= max_cells) ++key_bits;
+            uint32_t *sk = nullptr, *sv = nullptr;
+            MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), d_eslices, etab, key_bits, dh.as<uint32_t>(), &sk, &sv, true));
+            hipLaunchKernelGGL(nn_fill_many_kernel, dim3(etab.max_blks * (kTile / 256) + 1, static_cast<uint32_t>(E)), dim3(256), 0, st, d_edev, sk, sv, 0);
+            if (any_long) hipLaunchKernelGGL(nn_fill_long_many_kernel, dim3(kFillLongBlocks / 4, static_cast<uint32_t>(E)), dim3(256), 0, st, d_edev);
+            MRGFE_HIP_CHECK(hipGetLastError());
+        }
+        MRGFE_HIP_CHECK(hipStreamSynchronize(st));  // the set returns with its grids complete
+        for (size_t e = 0; e < E; ++e) {
+            NnGrid2Dev& g = h[entries[e].m];
+            g.level[entries[e].level] = edev[e].lv;
+            g.n_levels = std::max(g.n_levels, entries[e].level + 1);
+        }
     }
     for (size_t m = 0; m < M; ++m) out[m]->adopt(h[m], n[m]);
     return MRGFE_OK;
