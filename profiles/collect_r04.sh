@@ -34,6 +34,9 @@ if [ "$part" = trace ]; then
         rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_side_$w -o s -- python3 profiles/side_workloads.py $w > gpurun_out/side_$w.log 2>&1 || exit 1
     done
     python3 tests/extra_measurements.py > gpurun_out/extra_$tag.json 2> gpurun_out/extra_$tag.err
+    echo "extra measurements done"
+    python3 profiles/soak.py 2000 600 > gpurun_out/soak_$tag.json 2> gpurun_out/soak_$tag.err
+    echo "soak done"
     $C3 2>/dev/null | tail -1 > gpurun_out/bench_shard_$tag.json
     $C38 2>/dev/null | tail -1 > gpurun_out/bench_shard8_$tag.json
     for b in 32 64 128; do python3 bench.py --no-cpu --no-extras --shard-steps 0 --batch $b --steps 10 2>/dev/null | tail -1 > gpurun_out/bench_${tag}_b$b.json; done

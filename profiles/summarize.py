@@ -249,6 +249,19 @@ def main():
             ll = r.get("largest_launch")
             lines.append(f"| {name} | {r['trace_calls']} | {r['trace_avg_launch_ms']:.4f} | {r['hip_event_avg_launch_ms']:.4f} | {r['alg_bytes_per_launch'] / 1e9:.3f} | {r['frac_from_trace']:.3f} | "
                          f"{r['frac_in_bench_line']:.3f} | {r.get('agreement', float('nan')):.3f} | " + (f"{r['trace_max_launch_ms']:.3f} / {ll['alg_bytes'] / 1e9:.2f} / {ll['frac_from_trace_max']:.2f}" if ll else "—") + " |")
+    soak = os.path.join(OUT, f"soak_{tag}.json")
+    if os.path.exists(soak) and os.path.getsize(soak):
+        sj = json.load(open(soak))
+        json.dump(sj, open(os.path.join(ROOT, "profiles", f"{tag}_soak.json"), "w"), indent=1)
+        a, b = sj["all_methods"], sj["pcl_gicp_and_reciprocal_icp"]
+        summary["soak"] = {"ndt_over_bar": f"{a['ndt_over_bar']}/{a['ndt']}", "ndt_settled_over_bar": f"{a['ndt_settled_over_bar']}/{a['ndt_settled']}",
+                           "ndt_over_bar_equal_to_gpu_order_replay": f"{a['ndt_over_bar_equal_to_gpu_order_replay']}/{a['ndt_over_bar']}",
+                           "ndt_bit_identical_to_reference_order_oracle": f"{a['ndt_exact_ref']}/{a['ndt']}", "ndt_bit_identical_to_gpu_order_replay": f"{a['ndt_exact_gpu_order']}/{a['ndt']}",
+                           "ndt_worst_settled": a["ndt_worst_settled"], "other_methods_over_bar": f"{a['other_over_bar']}/{a['other']}", "other_methods_bit_identical": f"{a['other_exact']}/{a['other']}",
+                           "pcl_gicp_over_bar": f"{b['gicp_over_bar']}/{b['gicp']}", "pcl_gicp_over_bar_equal_to_gpu_order_replay": f"{b['gicp_over_bar_equal_to_gpu_order_replay']}/{b['gicp_over_bar']}",
+                           "pcl_gicp_bit_identical_to_gpu_order_replay": f"{b['gicp_exact_gpu_order']}/{b['gicp']}", "pcl_gicp_worst": b["gicp_worst"],
+                           "icp_reciprocal_over_bar": f"{b['icp_over_bar']}/{b['icp']}", "seconds": sj["seconds"]}
+        lines += ["", f"## parity soak (`python3 profiles/soak.py 2000 600`, profiles/{tag}_soak.json)", "", "```json", json.dumps(summary["soak"], indent=1), "```"]
     for part in ("trace", "pmc"):
         f = os.path.join(OUT, f"collected_rev_{part}.txt")
         if os.path.exists(f):
