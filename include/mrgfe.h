@@ -197,7 +197,7 @@ typedef struct mrgfe_prefilter_params {
     int    enable_distance_filter;            /* 1                                     */
     double distance_near_thresh;              /* 0.1                                   */
     double distance_far_thresh;               /* 35.0                                  */
-    int    downsample_method;                 /* 0 NONE, 1 VOXELGRID (APPROX_VOXELGRID is order dependent and not offered) */
+    int    downsample_method;                 /* 0 NONE, 1 VOXELGRID, 2 APPROX_VOXELGRID */
     double downsample_resolution;             /* 0.1                                   */
     int    downsample_min_points_per_voxel;   /* 1                                     */
     int    outlier_removal_method;            /* 0 NONE, 1 RADIUS, 2 STATISTICAL       */
@@ -220,6 +220,13 @@ int mrgfe_distance_filter(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t st
  * warn "Leaf size is too small" and pass the cloud through. */
 int mrgfe_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, float leaf, int min_points_per_voxel,
                     float* out_xyzi, size_t* out_n, int* overflow);
+/* replaces pcl::ApproximateVoxelGrid<PointXYZI>::filter (downsample_method APPROX_VOXELGRID: prefiltering_component.cpp:172-175,
+ * scan_matching_odometry_component.cpp:180-183): the 512-entry direct-mapped history of cells (hash (ix*7171 + iy*3079 + iz*4231) & 511), an entry
+ * flushed — its float centroid of x, y, z, intensity emitted — whenever a point of another cell arrives at it, the rest flushed in entry order at
+ * the end.  The output depends on the order of the input, a cell can be emitted several times, and there is no minimum point count: all of
+ * that is reproduced point for point (csrc/filters.hip decomposes the sequential loop into the 512 independent per-entry sequences).
+ * out_xyzi: capacity n points. */
+int mrgfe_approx_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, float leaf, float* out_xyzi, size_t* out_n);
 /* replaces pcl::RadiusOutlierRemoval::filter with setRadiusSearch / setMinNeighborsInRadius (:195-198) */
 int mrgfe_radius_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride_bytes, double radius, int min_neighbors,
                          float* out_xyzi, size_t* out_n);

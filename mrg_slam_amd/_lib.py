@@ -138,6 +138,7 @@ SIGNATURES = {
     "mrgfe_ndt_mean_neighbours": (C.c_double, [_vp]),
     "mrgfe_distance_filter": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, C.c_double, C.c_double, _fp, _szp]),
     "mrgfe_voxelgrid": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, C.c_float, C.c_int, _fp, _szp, C.POINTER(C.c_int)]),
+    "mrgfe_approx_voxelgrid": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, C.c_float, _fp, _szp]),
     "mrgfe_radius_outlier": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, C.c_double, C.c_int, _fp, _szp]),
     "mrgfe_statistical_outlier": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t, C.c_int, C.c_double, _fp, _szp]),
     "mrgfe_calc_fitness_score": (C.c_int, [_vp, _fp, C.c_size_t, _fp, C.c_size_t, C.c_size_t, _dp, C.c_double, _dp]),

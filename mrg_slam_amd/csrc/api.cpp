@@ -518,6 +518,14 @@ int mrgfe_distance_filter(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t st
     MRGFE_TRY(ctx->bind());
     return filter_distance(ctx, xyzi, n, stride, near_thresh, far_thresh, out, out_n);
 }
+int mrgfe_approx_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, float leaf, float* out, size_t* out_n)
+{
+    if (!ctx || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_approx_voxelgrid: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (!(leaf > 0)) { set_error("mrgfe_approx_voxelgrid: leaf size must be > 0"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);
+    MRGFE_TRY(ctx->bind());
+    return filter_approx_voxelgrid(ctx, xyzi, n, stride, leaf, out, out_n);
+}
 int mrgfe_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, float leaf, int min_pts, float* out, size_t* out_n, int* overflow)
 {
     if (!ctx || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_voxelgrid: NULL argument"); return MRGFE_ERR_INVALID; }
@@ -570,8 +578,8 @@ int mrgfe_prefilter_device(mrgfe_ctx* ctx, const mrgfe_prefilter_params* p, cons
 static int prefilter_impl(mrgfe_ctx* ctx, const mrgfe_prefilter_params* p, const float* xyzi, size_t n, size_t stride, void* out, size_t* out_n, bool on_device)
 {
     if (!ctx || !p || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_prefilter: NULL argument"); return MRGFE_ERR_INVALID; }
-    if (p->downsample_method < 0 || p->downsample_method > 1 || p->outlier_removal_method < 0 || p->outlier_removal_method > 2) { set_error("mrgfe_prefilter: unknown method"); return MRGFE_ERR_INVALID; }
-    if (p->downsample_method == 1 && !(p->downsample_resolution > 0)) { set_error("mrgfe_prefilter: downsample_resolution must be > 0"); return MRGFE_ERR_INVALID; }
+    if (p->downsample_method < 0 || p->downsample_method > 2 || p->outlier_removal_method < 0 || p->outlier_removal_method > 2) { set_error("mrgfe_prefilter: unknown method"); return MRGFE_ERR_INVALID; }
+    if (p->downsample_method >= 1 && !(p->downsample_resolution > 0)) { set_error("mrgfe_prefilter: downsample_resolution must be > 0"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(ctx);
     MRGFE_TRY(ctx->bind());
     PrefilterChain ch;
@@ -579,6 +587,7 @@ static int prefilter_impl(mrgfe_ctx* ctx, const mrgfe_prefilter_params* p, const
     ch.near_t = p->distance_near_thresh;
     ch.far_t = p->distance_far_thresh;
     ch.voxelgrid = p->downsample_method == 1;
+    ch.approx_voxelgrid = p->downsample_method == 2;
     ch.leaf = static_cast<float>(p->downsample_resolution);
     ch.min_pts = p->downsample_min_points_per_voxel;
     ch.outlier = p->outlier_removal_method;

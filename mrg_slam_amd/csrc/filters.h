@@ -8,6 +8,8 @@ namespace mrgfe {
 int filter_distance_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, double near_t, double far_t, float4* d_out, size_t* out_n);
 int filter_voxelgrid_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, float leaf, int min_pts, float4* d_out, size_t* out_n, int* overflow);
 int filter_radius_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, double radius, int min_neighbors, float4* d_out, size_t* out_n);
+// pcl::ApproximateVoxelGrid: the sequential 512-entry history loop decomposed into independent per-entry sequences (filters.hip)
+int filter_approx_voxelgrid_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, float leaf, float4* d_out, size_t* out_n);
 int filter_statistical_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, int mean_k, double stddev_mul, float4* d_out, size_t* out_n);
 
 // order-preserving compaction of the points whose flag is 1 (exclusive scan of the flags + scatter); synchronises and
@@ -21,6 +23,7 @@ struct PrefilterChain {
     bool   distance = true;
     double near_t = 0.1, far_t = 35.0;
     bool   voxelgrid = true;
+    bool   approx_voxelgrid = false;  // downsample_method APPROX_VOXELGRID (instead of voxelgrid; same leaf)
     float  leaf = 0.1f;
     int    min_pts = 1;
     int    outlier = 1;  // 0 none, 1 radius, 2 statistical
@@ -36,6 +39,7 @@ int filter_chain(mrgfe_ctx* ctx, const PrefilterChain& chain, const float* xyzi,
 
 int filter_distance(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double near_t, double far_t, float* out, size_t* out_n);
 int filter_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, float leaf, int min_pts, float* out, size_t* out_n, int* overflow);
+int filter_approx_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, float leaf, float* out, size_t* out_n);
 int filter_radius_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double radius, int min_neighbors, float* out, size_t* out_n);
 int filter_statistical_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, int mean_k, double stddev_mul, float* out, size_t* out_n);
 

@@ -188,6 +188,136 @@ int filter_voxelgrid_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, float 
     return MRGFE_OK;
 }
 
+// ---- approximate voxel grid -----------------------------------------------------------------------------------------------------------
+// pcl::ApproximateVoxelGrid (downsample_method APPROX_VOXELGRID: prefiltering_component.cpp:172-175, scan_matching_odometry_component.cpp:180-183)
+// is a sequential algorithm on the CPU — every point looks up a 512-entry direct-mapped history keyed by a hash of its cell, flushes the entry
+// (emits its centroid) when another cell holds it, and takes it over; the occupied entries are flushed at the end — and SURVEY.md left it there
+// ("order dependent, effectively unparallelisable").  It decomposes exactly:
+//   * an entry only ever sees the points that hash to it, in arrival order, so the 512 entries are independent sequences — a stable sort of
+//     (hash, index) pairs lays them out; inside a sequence a maximal stretch of points of ONE cell is one emitted centroid (float sums in
+//     arrival order / float count: one thread per stretch, like the voxel grid's runs);
+//   * a stretch is emitted when the first point of the NEXT stretch of its entry arrives, so its place in the output is the number of such
+//     "flushing" points with a smaller index — an exclusive scan over the cloud in its original order — and the last stretch of every entry
+//     follows behind all of those, in entry order.
+// Same output, point for point and bit for bit, as the sequential loop (oracle/filters.cpp approx_voxelgrid): no sequential pass anywhere.
+__device__ __forceinline__ int avg_cell(float v)
+{
+    const float f = floorf(v);
+    if (!(f >= -2147483648.0f && f < 2147483648.0f)) return INT_MIN;  // the x86 conversion's answer out of range and for NaN (the GPU's saturates)
+    return static_cast<int>(f);
+}
+__device__ __forceinline__ void avg_cell3(const float4& p, float inv, int c[3])
+{
+#pragma clang fp contract(off)
+    c[0] = avg_cell(p.x * inv); c[1] = avg_cell(p.y * inv); c[2] = avg_cell(p.z * inv);
+}
+__global__ __launch_bounds__(256) void avg_keys_kernel(const float4* __restrict__ in, uint32_t n, float inv, uint32_t* __restrict__ keys)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    int c[3];
+    avg_cell3(in[i], inv, c);
+    keys[i] = (static_cast<uint32_t>(c[0]) * 7171u + static_cast<uint32_t>(c[1]) * 3079u + static_cast<uint32_t>(c[2]) * 4231u) & 511u;
+}
+// sorted position j starts a stretch iff its entry or its cell differs from position j - 1's; the first point of a stretch that is not its entry's first flushes
+__global__ __launch_bounds__(256) void avg_heads_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ sk, const uint32_t* __restrict__ sv, uint32_t n, float inv,
+                                                         uint32_t* __restrict__ head, uint32_t* __restrict__ flusher)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= n) return;
+    uint32_t h = 1;
+    if (j > 0) {
+        const bool same_entry = sk[j] == sk[j - 1];
+        int a[3], b[3];
+        avg_cell3(in[sv[j]], inv, a);
+        avg_cell3(in[sv[j - 1]], inv, b);
+        const bool same_cell = a[0] == b[0] && a[1] == b[1] && a[2] == b[2];
+        h = (same_entry && same_cell) ? 0u : 1u;
+        if (h && same_entry) flusher[sv[j]] = 1u;
+    }
+    head[j] = h;
+}
+__global__ __launch_bounds__(256) void avg_segments_kernel(const uint32_t* __restrict__ head, const uint32_t* __restrict__ ord, uint32_t n, const uint32_t* __restrict__ n_runs,
+                                                            uint32_t* __restrict__ seg_start)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= n) return;
+    if (head[j]) seg_start[ord[j]] = j;
+    if (j + 1 == n) seg_start[*n_runs] = n;
+}
+// rank of every entry among the occupied ones (their last stretches close the output in entry order)
+__global__ __launch_bounds__(512) void avg_entry_ranks_kernel(const uint32_t* __restrict__ sk, uint32_t n, uint32_t* __restrict__ rank)
+{
+    __shared__ uint32_t lds[16];
+    const uint32_t b = threadIdx.x;
+    auto lower = [&](uint32_t key) {
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sk[mid] < key) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    const uint32_t occupied = lower(b + 1) > lower(b) ? 1u : 0u;
+    uint32_t total;
+    rank[b] = block_exclusive_scan<512>(occupied, lds, &total);
+}
+__global__ __launch_bounds__(256) void avg_emit_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ sk, const uint32_t* __restrict__ sv, uint32_t n,
+                                                        const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ totals /* runs, flushing points */,
+                                                        const uint32_t* __restrict__ fpos, const uint32_t* __restrict__ entry_rank, float4* __restrict__ out)
+{
+#pragma clang fp contract(off)
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= totals[0]) return;
+    const uint32_t b = seg_start[r], e = seg_start[r + 1];
+    float sx = 0, sy = 0, sz = 0, si = 0;
+    for (uint32_t k = b; k < e; ++k) {
+        const float4 p = in[sv[k]];
+        sx += p.x; sy += p.y; sz += p.z; si += p.w;
+    }
+    const float cnt = static_cast<float>(e - b);
+    const uint32_t entry = sk[b];
+    const uint32_t op = (e < n && sk[e] == entry) ? fpos[sv[e]] : totals[1] + entry_rank[entry];
+    out[op] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+}
+
+int filter_approx_voxelgrid_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, float leaf, float4* d_out, size_t* out_n)
+{
+    *out_n = 0;
+    if (n == 0) return MRGFE_OK;
+    if (n > 0x7fffffffu) { set_error("approximate voxel grid: cloud too large"); return MRGFE_ERR_INVALID; }
+    hipStream_t st = ctx->stream;
+    uint32_t    nn = static_cast<uint32_t>(n);
+    SliceTable  tab;
+    tab.build(&nn, 1);
+    DevBuf &ds = ctx->scratch[0], &drank = ctx->scratch[1], &dk = ctx->scratch[2], &dv = ctx->scratch[3], &dkt = ctx->scratch[4], &dvt = ctx->scratch[5], &dh = ctx->scratch[6],
+           &dhead = ctx->scratch[7], &dblk = ctx->scratch[8], &dseg = ctx->scratch[9], &dfpos = ctx->scratch[10], &dflush = ctx->scratch[11], &dord = ctx->scratch[12];
+    MRGFE_TRY(ds.ensure(sizeof(Slice)));
+    MRGFE_TRY(drank.ensure(sizeof(uint32_t) * 512));
+    MRGFE_TRY(dk.ensure(n * 4)); MRGFE_TRY(dv.ensure(n * 4)); MRGFE_TRY(dkt.ensure(n * 4)); MRGFE_TRY(dvt.ensure(n * 4));
+    MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + 1)));
+    MRGFE_TRY(dhead.ensure(n * 4)); MRGFE_TRY(dord.ensure(n * 4)); MRGFE_TRY(dflush.ensure(n * 4)); MRGFE_TRY(dfpos.ensure(n * 4));
+    MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (tab.total_blks + 8)));
+    MRGFE_TRY(dseg.ensure(sizeof(uint32_t) * (n + 4)));
+    MRGFE_TRY(ctx->stage_h2d(ds.p, tab.h.data(), sizeof(Slice), st));
+    const float inv = 1.0f / leaf;  // inverse_leaf_size_ = Array3f::Ones() / leaf_size_
+    const dim3  g256((nn + 255) / 256), b256(256);
+    uint32_t*   d_tot = dblk.as<uint32_t>() + tab.total_blks;  // [0] stretches, [1] flushing points
+    hipLaunchKernelGGL(avg_keys_kernel, g256, b256, 0, st, d_in, nn, inv, dk.as<uint32_t>());
+    uint32_t *sk, *sv;
+    MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), ds.as<Slice>(), tab, 9, dh.as<uint32_t>(), &sk, &sv, true));
+    MRGFE_HIP_CHECK(hipMemsetAsync(dflush.p, 0, n * 4, st));
+    hipLaunchKernelGGL(avg_heads_kernel, g256, b256, 0, st, d_in, sk, sv, nn, inv, dhead.as<uint32_t>(), dflush.as<uint32_t>());
+    MRGFE_TRY(exclusive_scan(ctx, dhead.as<uint32_t>(), dord.as<uint32_t>(), ds.as<Slice>(), tab, dblk.as<uint32_t>(), d_tot));
+    hipLaunchKernelGGL(avg_segments_kernel, g256, b256, 0, st, dhead.as<uint32_t>(), dord.as<uint32_t>(), nn, d_tot, dseg.as<uint32_t>());
+    MRGFE_TRY(exclusive_scan(ctx, dflush.as<uint32_t>(), dfpos.as<uint32_t>(), ds.as<Slice>(), tab, dblk.as<uint32_t>(), d_tot + 1));
+    hipLaunchKernelGGL(avg_entry_ranks_kernel, dim3(1), dim3(512), 0, st, sk, nn, drank.as<uint32_t>());
+    hipLaunchKernelGGL(avg_emit_kernel, g256, b256, 0, st, d_in, sk, sv, nn, dseg.as<uint32_t>(), d_tot, dfpos.as<uint32_t>(), drank.as<uint32_t>(), d_out);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    uint32_t runs = 0;
+    MRGFE_HIP_CHECK(hipMemcpyAsync(&runs, d_tot, 4, hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    *out_n = runs;
+    return MRGFE_OK;
+}
+
 // ---- radius outlier removal ------------------------------------------------------------------------------------
 int filter_radius_outlier_device(mrgfe_ctx* ctx, const float4* d_in, size_t n, double radius, int min_neighbors, float4* d_out, size_t* out_n)
 {
@@ -452,7 +582,7 @@ static NnDeviceDrivenGrid& pf_grid(mrgfe_ctx* ctx)
 static int filter_chain_device_driven(mrgfe_ctx* ctx, const PrefilterChain& ch, const float4* d_in, uint32_t n, float4* d_work, float4* d_final, size_t* out_n, bool* used)
 {
     *used = false;
-    if (!prefilter_device_driven_mode() || !ch.voxelgrid || ch.outlier != 1 || n == 0 || !(ch.leaf > 0)) return MRGFE_OK;
+    if (!prefilter_device_driven_mode() || ch.approx_voxelgrid || !ch.voxelgrid || ch.outlier != 1 || n == 0 || !(ch.leaf > 0)) return MRGFE_OK;
     hipStream_t st = ctx->stream;
     SliceTable  tab;
     tab.build(&n, 1);
@@ -554,7 +684,8 @@ int filter_chain(mrgfe_ctx* ctx, const PrefilterChain& ch, const float* xyzi, si
         if (rc == MRGFE_OK) { std::swap(cur, nxt); m = k; }
     };
     if (ch.distance) pass([&](const float4* i, size_t ni, float4* o, size_t* k) { return filter_distance_device(ctx, i, ni, ch.near_t, ch.far_t, o, k); });
-    if (ch.voxelgrid) pass([&](const float4* i, size_t ni, float4* o, size_t* k) { int overflow = 0; return filter_voxelgrid_device(ctx, i, ni, ch.leaf, ch.min_pts, o, k, &overflow); });
+    if (ch.approx_voxelgrid) pass([&](const float4* i, size_t ni, float4* o, size_t* k) { return filter_approx_voxelgrid_device(ctx, i, ni, ch.leaf, o, k); });
+    else if (ch.voxelgrid) pass([&](const float4* i, size_t ni, float4* o, size_t* k) { int overflow = 0; return filter_voxelgrid_device(ctx, i, ni, ch.leaf, ch.min_pts, o, k, &overflow); });
     if (ch.outlier == 1) pass([&](const float4* i, size_t ni, float4* o, size_t* k) { return filter_radius_outlier_device(ctx, i, ni, ch.radius, ch.radius_min_neighbors, o, k); });
     if (ch.outlier == 2) pass([&](const float4* i, size_t ni, float4* o, size_t* k) { return filter_statistical_outlier_device(ctx, i, ni, ch.mean_k, ch.stddev_mul, o, k); });
     if (rc == MRGFE_OK) {
@@ -576,6 +707,10 @@ int filter_distance(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, 
 int filter_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, float leaf, int min_pts, float* out, size_t* out_n, int* overflow)
 {
     return host_wrap(ctx, xyzi, n, stride, out, out_n, [&](const float4* i, float4* o, size_t* m) { return filter_voxelgrid_device(ctx, i, n, leaf, min_pts, o, m, overflow); });
+}
+int filter_approx_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, float leaf, float* out, size_t* out_n)
+{
+    return host_wrap(ctx, xyzi, n, stride, out, out_n, [&](const float4* i, float4* o, size_t* m) { return filter_approx_voxelgrid_device(ctx, i, n, leaf, o, m); });
 }
 int filter_radius_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double radius, int min_neighbors, float* out, size_t* out_n)
 {

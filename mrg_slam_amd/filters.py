@@ -58,6 +58,27 @@ class VoxelGrid(_Filter):
         return out[: m.value].copy()
 
 
+class ApproximateVoxelGrid(_Filter):
+    """pcl::ApproximateVoxelGrid<PointXYZI> (downsample_method APPROX_VOXELGRID: prefiltering_component.cpp:172-175;
+    scan_matching_odometry_component.cpp:180-183): order dependent, a cell may be emitted more than once, no minimum point count."""
+
+    def __init__(self, ctx=None):
+        super().__init__(ctx)
+        self._leaf = 0.1
+
+    def setLeafSize(self, lx, ly=None, lz=None):
+        if (ly is not None and ly != lx) or (lz is not None and lz != lx):
+            raise ValueError("the reference only uses cubic leaves (setLeafSize(r, r, r))")
+        self._leaf = float(lx)
+
+    def filter(self):
+        c = self._input
+        out = np.empty((max(len(c), 1), 4), dtype=np.float32)
+        m = C.c_size_t(0)
+        check(lib().mrgfe_approx_voxelgrid(self._ctx._h, c.ctypes.data_as(_fp), len(c), 16, self._leaf, out.ctypes.data_as(_fp), C.byref(m)))
+        return out[: m.value].copy()
+
+
 class RadiusOutlierRemoval(_Filter):
     """pcl::RadiusOutlierRemoval<PointXYZI> (prefiltering_component.cpp:195-198)."""
 
@@ -195,7 +216,7 @@ def _prefilter_params(p: dict) -> "_lib.PrefilterParams":
     lib().mrgfe_prefilter_default_params(C.byref(q))
     q.enable_distance_filter = int(bool(p["enable_distance_filter"]))
     q.distance_near_thresh, q.distance_far_thresh = p["distance_near_thresh"], p["distance_far_thresh"]
-    q.downsample_method = 1 if p["downsample_method"] == "VOXELGRID" else 0
+    q.downsample_method = {"NONE": 0, "VOXELGRID": 1, "APPROX_VOXELGRID": 2}[p["downsample_method"]]
     q.downsample_resolution, q.downsample_min_points_per_voxel = p["downsample_resolution"], p["downsample_min_points_per_voxel"]
     q.outlier_removal_method = {"NONE": 0, "RADIUS": 1, "STATISTICAL": 2}[p["outlier_removal_method"]]
     q.radius_radius, q.radius_min_neighbors = p["radius_radius"], p["radius_min_neighbors"]
@@ -230,7 +251,7 @@ def prefilter(cloud, params: dict | None = None, ctx: Context | None = None) -> 
          "statistical_stddev": 1.2}
     p.update(params or {})
     c = _cloud(cloud)
-    if p["downsample_method"] in ("VOXELGRID", "NONE") and p["outlier_removal_method"] in ("RADIUS", "STATISTICAL", "NONE"):
+    if p["downsample_method"] in ("VOXELGRID", "APPROX_VOXELGRID", "NONE") and p["outlier_removal_method"] in ("RADIUS", "STATISTICAL", "NONE"):
         # one call: the cloud stays in HBM between the passes (mrgfe_prefilter)
         ctx = ctx or default_context()
         q = _prefilter_params(p)
@@ -245,8 +266,13 @@ def prefilter(cloud, params: dict | None = None, ctx: Context | None = None) -> 
         vg.setMinimumPointsNumberPerVoxel(p["downsample_min_points_per_voxel"])
         vg.setInputCloud(c)
         c = vg.filter()
+    elif p["downsample_method"] == "APPROX_VOXELGRID":
+        av = ApproximateVoxelGrid(ctx)
+        av.setLeafSize(p["downsample_resolution"])
+        av.setInputCloud(c)
+        c = av.filter()
     elif p["downsample_method"] != "NONE":
-        raise ValueError("APPROX_VOXELGRID is order dependent and stays on the CPU in the reference (SURVEY.md A.1)")
+        raise ValueError(f"unknown downsample_method {p['downsample_method']!r}")
     if p["outlier_removal_method"] == "RADIUS":
         ro = RadiusOutlierRemoval(ctx)
         ro.setRadiusSearch(p["radius_radius"])

@@ -69,6 +69,8 @@ class OracleOps:
             c = self.orc.distance_filter(c, p["distance_near_thresh"], p["distance_far_thresh"])
         if p["downsample_method"] == "VOXELGRID":
             c = self.orc.voxelgrid(c, p["downsample_resolution"], p["downsample_min_points_per_voxel"])[0]
+        elif p["downsample_method"] == "APPROX_VOXELGRID":
+            c = self.orc.approx_voxelgrid(c, p["downsample_resolution"])
         if p["outlier_removal_method"] == "RADIUS":
             c = self.orc.radius_outlier(c, p["radius_radius"], p["radius_min_neighbors"])[0]
         elif p["outlier_removal_method"] == "STATISTICAL":
@@ -80,9 +82,8 @@ class PrefilteringComponent:
     def __init__(self, params: dict | None = None, ops=None, lookup_transform=None):
         self.p = dict(DEFAULTS)
         self.p.update(params or {})
-        if self.p["downsample_method"] not in ("VOXELGRID", "NONE"):
-            # APPROX_VOXELGRID (:168-171) is order-dependent (a 512-entry history of the last voxels) and stays with PCL: DESIGN.md §8
-            raise ValueError(f"downsample_method {self.p['downsample_method']!r} is not offered on the GPU path")
+        if self.p["downsample_method"] not in ("VOXELGRID", "APPROX_VOXELGRID", "NONE"):
+            raise ValueError(f"unknown downsample_method {self.p['downsample_method']!r}")
         if self.p["outlier_removal_method"] not in ("RADIUS", "STATISTICAL", "NONE"):
             raise ValueError(f"unknown outlier_removal_method {self.p['outlier_removal_method']!r}")
         self.ops = ops or HipOps()

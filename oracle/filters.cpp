@@ -34,6 +34,48 @@ int distance_filter(const float* in, int n, double near_thresh, double far_thres
     return m;
 }
 
+// pcl::ApproximateVoxelGrid<PointXYZI>::applyFilter (PCL 1.12 filters/impl/approximate_voxel_grid.hpp; [UPSTREAM-RECALL]):
+// a direct-mapped history of histsize_ = 512 entries keyed by (ix * 7171 + iy * 3079 + iz * 4231) & 511 with ijk = floor(p * inverse_leaf_size)
+// (float, inverse_leaf_size = 1 / leaf as float).  A point whose entry holds ANOTHER cell flushes that entry — its centroid (float sums of
+// x, y, z, intensity in arrival order, divided by the float count) becomes the next output point — and takes it over; at the end the
+// occupied entries are flushed in entry order.  Order dependent; a cell may be emitted several times.  There is no min-points threshold and
+// no bounding box (a non-finite coordinate goes through floor and the int cast like any other: x86's cvttss2si gives INT_MIN for it).
+int approx_voxelgrid(const float* in, int n, float leaf, float* out)
+{
+    constexpr int kHist = 512;
+    struct He { int ix, iy, iz, count; float c[4]; };
+    std::vector<He> hist(kHist);
+    for (auto& h : hist) { h.ix = h.iy = h.iz = 0; h.count = 0; h.c[0] = h.c[1] = h.c[2] = h.c[3] = 0.0f; }
+    const float inv = 1.0f / leaf;
+    auto cell = [](float v) {
+        const float f = std::floor(v);
+        if (!(f >= -2147483648.0f && f < 2147483648.0f)) return std::numeric_limits<int>::min();  // what the x86 conversion returns out of range / for NaN
+        return static_cast<int>(f);
+    };
+    auto flush = [&](He& h, int op) {
+        const float cnt = static_cast<float>(h.count);
+        for (int k = 0; k < 4; ++k) out[4 * op + k] = h.c[k] / cnt;
+    };
+    int op = 0;
+    for (int i = 0; i < n; ++i) {
+        const float* p = in + 4 * i;
+        const int ix = cell(p[0] * inv), iy = cell(p[1] * inv), iz = cell(p[2] * inv);
+        const unsigned hash = (static_cast<unsigned>(ix) * 7171u + static_cast<unsigned>(iy) * 3079u + static_cast<unsigned>(iz) * 4231u) & (kHist - 1);
+        He& h = hist[hash];
+        if (h.count && (ix != h.ix || iy != h.iy || iz != h.iz)) {
+            flush(h, op++);
+            h.count = 0;
+            h.c[0] = h.c[1] = h.c[2] = h.c[3] = 0.0f;
+        }
+        h.ix = ix; h.iy = iy; h.iz = iz;
+        h.count++;
+        for (int k = 0; k < 4; ++k) h.c[k] += p[k];
+    }
+    for (auto& h : hist)
+        if (h.count) flush(h, op++);
+    return op;
+}
+
 int voxelgrid(const float* in, int n, float leaf, int min_points_per_voxel, int order_mode, float* out, int* out_n)
 {
     *out_n = 0;

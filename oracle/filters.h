@@ -8,6 +8,9 @@ namespace orc {
 int distance_filter(const float* in, int n, double near_thresh, double far_thresh, float* out);
 // returns 0 ok, 1 = index overflow (output == input, PCL behaviour)
 int voxelgrid(const float* in, int n, float leaf, int min_points_per_voxel, int order_mode, float* out, int* out_n);
+// pcl::ApproximateVoxelGrid<PointXYZI>::applyFilter (downsample_method APPROX_VOXELGRID, prefiltering_component.cpp:172-175,
+// scan_matching_odometry_component.cpp:180-183); returns the number of output points (capacity n)
+int approx_voxelgrid(const float* in, int n, float leaf, float* out);
 int radius_outlier(const float* in, int n, double radius, int min_neighbors, float* out, unsigned char* keep_mask);
 int statistical_outlier(const float* in, int n, int mean_k, double stddev_mul, float* out, unsigned char* keep_mask);
 

@@ -40,6 +40,7 @@ def lib():
         sig = {
             "orc_distance_filter": (C.c_int, [fp, C.c_int, C.c_double, C.c_double, fp]),
             "orc_voxelgrid": (C.c_int, [fp, C.c_int, C.c_float, C.c_int, C.c_int, fp, ip]),
+            "orc_approx_voxelgrid": (C.c_int, [fp, C.c_int, C.c_float, fp]),
             "orc_radius_outlier": (C.c_int, [fp, C.c_int, C.c_double, C.c_int, fp, u8p]),
             "orc_statistical_outlier": (C.c_int, [fp, C.c_int, C.c_int, C.c_double, fp, u8p]),
             "orc_map_cloud_generate": (C.c_int, [C.c_int, C.POINTER(fp), ip, dp, u8p, C.c_float, C.c_int, C.c_float, C.c_int, fp, ip]),
@@ -147,6 +148,14 @@ def distance_filter(cloud, near=0.1, far=35.0):
     c = _cloud(cloud)
     out = np.empty_like(c)
     m = lib().orc_distance_filter(_pf(c), len(c), near, far, _pf(out))
+    return out[:m].copy()
+
+
+def approx_voxelgrid(cloud, leaf=0.1):
+    """pcl::ApproximateVoxelGrid (downsample_method APPROX_VOXELGRID): N x 4 float32 in arrival order -> flushed centroids in flush order."""
+    c = _cloud(cloud)
+    out = np.empty((max(len(c), 1), 4), dtype=np.float32)
+    m = lib().orc_approx_voxelgrid(_pf(c), len(c), leaf, _pf(out))
     return out[:m].copy()
 
 

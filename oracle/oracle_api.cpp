@@ -20,6 +20,7 @@ extern "C" {
 
 // ---- filters -----------------------------------------------------------------------------------------
 int orc_distance_filter(const float* in, int n, double near_thresh, double far_thresh, float* out) { return distance_filter(in, n, near_thresh, far_thresh, out); }
+int orc_approx_voxelgrid(const float* in, int n, float leaf, float* out) { return approx_voxelgrid(in, n, leaf, out); }
 int orc_voxelgrid(const float* in, int n, float leaf, int min_pts, int order_mode, float* out, int* out_n) { return voxelgrid(in, n, leaf, min_pts, order_mode, out, out_n); }
 int orc_radius_outlier(const float* in, int n, double radius, int min_neighbors, float* out, unsigned char* keep) { return radius_outlier(in, n, radius, min_neighbors, out, keep); }
 int orc_statistical_outlier(const float* in, int n, int mean_k, double stddev_mul, float* out, unsigned char* keep) { return statistical_outlier(in, n, mean_k, stddev_mul, out, keep); }

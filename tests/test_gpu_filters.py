@@ -367,3 +367,50 @@ def test_device_driven_prefilter_chain_equals_the_host_driven_one_and_the_oracle
             np.testing.assert_array_equal(fast, oracle_chain(cloud, p), err_msg=name)
     finally:
         lib().mrgfe_dbg_set_prefilter_device_driven(1)
+
+
+@pytest.mark.parametrize("leaf", [0.05, 0.1, 0.5, 5.0, 80.0])
+def test_approx_voxelgrid_exact(street_pair_vlp16, leaf):
+    """pcl::ApproximateVoxelGrid (downsample_method APPROX_VOXELGRID) — a sequential loop over a 512-entry history in the reference, 512 independent
+    sequences on the GPU (csrc/filters.hip): the same points in the same ORDER as the oracle's loop, bit for bit — scans, shuffled clouds, clouds of one
+    cell, duplicates, non-finite and out-of-int-range coordinates, one and zero points."""
+    from mrg_slam_amd import ApproximateVoxelGrid
+    from oracle import oracle as orc
+
+    def hip(c):
+        f = ApproximateVoxelGrid()
+        f.setLeafSize(leaf, leaf, leaf)
+        f.setInputCloud(c)
+        return f.filter()
+
+    rng = np.random.default_rng(17)
+    scan = street_pair_vlp16[0]
+    odd = small_cloud(6000, 5, extent=(40.0, 40.0, 5.0))
+    odd[rng.choice(6000, 60, replace=False), rng.integers(0, 3, 60)] = np.nan
+    odd[11, 1] = np.inf
+    odd[12, 2] = -np.inf
+    odd[13, 0] = 3e12   # beyond the int range after the division by the leaf
+    odd[14, 0] = -3e12
+    odd[100:140] = odd[100]  # duplicates
+    for name, c in (("scan", scan), ("shuffled scan", scan[rng.permutation(len(scan))]), ("odd values", odd), ("one point", scan[:1]), ("two points", scan[:2]),
+                    ("empty", np.zeros((0, 4), np.float32)), ("one cell", (small_cloud(500, 2) * np.float32(1e-3)).astype(np.float32))):
+        got, exp = hip(c), orc.approx_voxelgrid(c, leaf)
+        assert got.shape == exp.shape, (name, got.shape, exp.shape)
+        np.testing.assert_array_equal(got, exp, err_msg=name)  # (NaN centroids of cells with a non-finite coordinate compare equal)
+
+
+def test_prefilter_chain_with_approx_voxelgrid(street_pair_vlp16):
+    from mrg_slam_amd import prefilter
+    from mrg_slam_amd.prefiltering import HipOps, OracleOps, PrefilteringComponent
+    from oracle import oracle as orc
+
+    raw = street_pair_vlp16[1]
+    p = {"downsample_method": "APPROX_VOXELGRID", "downsample_resolution": 0.2}
+    e = orc.distance_filter(raw, 0.1, 35.0)
+    e = orc.approx_voxelgrid(e, 0.2)
+    e, _ = orc.radius_outlier(e, 0.5, 2)
+    np.testing.assert_array_equal(prefilter(raw, p), e)
+    a = PrefilteringComponent(p, ops=HipOps()).cloud_callback(raw, 0.0, "base_link")
+    b = PrefilteringComponent(p, ops=OracleOps(orc)).cloud_callback(raw, 0.0, "base_link")
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, e)

@@ -153,3 +153,40 @@ def test_information_matrix_weights_against_numpy():
     np.testing.assert_array_equal(inf, np.diag([2.0] * 3 + [10.0] * 3))
     o_inf, o_fit = orc.calc_information_matrix(np.zeros((1, 4), np.float32), np.zeros((1, 4), np.float32), np.eye(4), {"use_const_inf_matrix": True})
     np.testing.assert_array_equal(o_inf, inf)
+
+
+def _approx_voxelgrid_py(c, leaf):
+    """pcl::ApproximateVoxelGrid as a plain Python loop over a dict-backed 512-entry history (independent restatement of SURVEY.md A.1)."""
+    inv = np.float32(1.0) / np.float32(leaf)
+    hist, out = {}, []
+    for p in c:
+        ijk = tuple(int(np.floor(np.float32(p[k]) * inv)) for k in range(3))
+        h = (ijk[0] * 7171 + ijk[1] * 3079 + ijk[2] * 4231) & 511
+        e = hist.get(h)
+        if e is not None and e[0] != ijk:
+            out.append(e[1] / np.float32(e[2]))
+            e = None
+        if e is None:
+            e = [ijk, np.zeros(4, np.float32), 0]
+        e[1] = e[1] + p
+        e[2] += 1
+        hist[h] = e
+    for h in sorted(hist):
+        out.append(hist[h][1] / np.float32(hist[h][2]))
+    return np.array(out, dtype=np.float32).reshape(-1, 4)
+
+
+@pytest.mark.parametrize("leaf", [0.05, 0.3, 2.0, 50.0])
+def test_approx_voxelgrid_oracle_matches_the_plain_loop(leaf):
+    from oracle import oracle as orc
+
+    c = small_cloud(3000, 21, extent=(25.0, 15.0, 4.0))
+    np.testing.assert_array_equal(orc.approx_voxelgrid(c, leaf), _approx_voxelgrid_py(c, leaf))
+    # order dependent: another arrival order gives another cloud (as many or more points: a cell can be flushed more than once)
+    shuffled = c[np.random.default_rng(3).permutation(len(c))]
+    a, b = orc.approx_voxelgrid(c, leaf), orc.approx_voxelgrid(shuffled, leaf)
+    np.testing.assert_array_equal(b, _approx_voxelgrid_py(shuffled, leaf))
+    assert leaf >= 50.0 or not np.array_equal(a, b)
+    assert len(orc.approx_voxelgrid(np.zeros((0, 4), np.float32), leaf)) == 0
+    one = orc.approx_voxelgrid(c[:1], leaf)
+    np.testing.assert_array_equal(one, c[:1])
