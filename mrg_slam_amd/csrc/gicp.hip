@@ -553,6 +553,17 @@ __device__ __forceinline__ void gicp_reduce_record(const double* __restrict__ pa
 }
 
 __global__ __launch_bounds__(256) void gicp_reduce_kernel(const double* __restrict__ partials, uint32_t nblk, double* __restrict__ out) { gicp_reduce_record(partials, nblk, out); }
+// the same record written straight into pinned HOST memory, its last slot = `tag` once the rest is visible: the single registration's LM loop
+// polls that slot instead of queueing a device-to-host copy and waiting for the stream (a copy command and a wake-up less per trial)
+__global__ __launch_bounds__(256) void gicp_reduce_host_kernel(const double* __restrict__ partials, uint32_t nblk, double* __restrict__ h_out, double tag)
+{
+    gicp_reduce_record(partials, nblk, h_out);  // writes slots 0 .. 31 (29 .. 31 are zero padding)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(&h_out[kGicpStride], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 // ---- batched variants: blockIdx.y = the y-th busy pair of this kernel in the round --------------------------------------
 struct GicpPairDev {  // static per pair
@@ -741,6 +752,7 @@ GicpEngine::~GicpEngine()
     d_knn_i_.release(); d_knn_d_.release();
     d_tgt_cov_.release(); d_src_cov_.release(); d_corr_.release(); d_mahal_.release(); d_partial_.release(); d_T_.release();
     d_vox_.release(); d_vox_runs_.release(); d_cur_.release();
+    h_rec_.release();
 }
 
 int GicpEngine::set_target(const void* d, size_t n)
@@ -936,6 +948,23 @@ int GicpEngine::covariances(int which, double* out9)
     return MRGFE_OK;
 }
 
+// wait for gicp_reduce_host_kernel's record: poll the tag in pinned memory; the stream is asked now and then so that a failed launch cannot hang the caller
+static int gicp_wait_record(hipStream_t st, const volatile double* h_rec, double tag)
+{
+    for (uint32_t spin = 0;; ++spin) {
+        if (__atomic_load_n(reinterpret_cast<const volatile uint64_t*>(&h_rec[kGicpStride]), __ATOMIC_ACQUIRE) == *reinterpret_cast<const uint64_t*>(&tag)) return MRGFE_OK;
+        if ((spin & 0x3ff) == 0x3ff) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) {  // everything queued has run: the record is there, or never will be
+                if (__atomic_load_n(reinterpret_cast<const volatile uint64_t*>(&h_rec[kGicpStride]), __ATOMIC_ACQUIRE) == *reinterpret_cast<const uint64_t*>(&tag)) return MRGFE_OK;
+                set_error("GICP: the reduction did not report");
+                return MRGFE_ERR_HIP;
+            }
+            if (q != hipErrorNotReady) { set_error("GICP: %s", hipGetErrorString(q)); return MRGFE_ERR_HIP; }
+        }
+    }
+}
+
 int GicpEngine::run_linearize(const double T[16], bool, double H[36], double b[6], double* err, int* n_corr)
 {
     ++n_linearize_;
@@ -976,11 +1005,16 @@ int GicpEngine::run_linearize(const double T[16], bool, double H[36], double b[6
                            d_mahal_.as<double>(), d_part);
     }
     MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev1, st));
-    hipLaunchKernelGGL(gicp_reduce_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, d_res);
+    (void)d_res;
+    MRGFE_TRY(h_rec_.ensure(sizeof(double) * (kGicpStride + 1)));
+    const double tag = static_cast<double>(++rec_tag_);
+    h_rec_.as<double>()[kGicpStride] = 0.0;  // (nothing is in flight: the previous record was waited for)
+    hipLaunchKernelGGL(gicp_reduce_host_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, h_rec_.as<double>(), tag);
     MRGFE_HIP_CHECK(hipGetLastError());
+    MRGFE_TRY(gicp_wait_record(st, h_rec_.as<double>(), tag));
     double r[kGicpStride];
-    MRGFE_HIP_CHECK(hipMemcpyAsync(r, d_res, sizeof(r), hipMemcpyDeviceToHost, st));
-    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    std::memcpy(r, h_rec_.p, sizeof(r));
+    MRGFE_HIP_CHECK(hipEventSynchronize(ctx_->ev1));  // (long passed: the reduction ran behind it)
     float ms = 0;
     MRGFE_HIP_CHECK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
     kernel_ms += ms;
@@ -1007,12 +1041,14 @@ int GicpEngine::run_error(const double T[16], double* err)
     double* d_res = d_part + size_t(nblk) * kGicpStride;
     hipLaunchKernelGGL(gicp_error_kernel, dim3(nblk), dim3(256), 0, st, d_src_, n, d_tgt_, make_pose(T, prm_.variant), d_corr_.as<int32_t>(), d_mahal_.as<double>(), d_part,
                        prm_.variant == 2 ? d_vox_.as<const double>() : static_cast<const double*>(nullptr));
-    hipLaunchKernelGGL(gicp_reduce_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, d_res);
+    (void)d_res;
+    MRGFE_TRY(h_rec_.ensure(sizeof(double) * (kGicpStride + 1)));
+    const double tag = static_cast<double>(++rec_tag_);
+    h_rec_.as<double>()[kGicpStride] = 0.0;  // (nothing is in flight: the previous record was waited for)
+    hipLaunchKernelGGL(gicp_reduce_host_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, h_rec_.as<double>(), tag);
     MRGFE_HIP_CHECK(hipGetLastError());
-    double r[kGicpStride];
-    MRGFE_HIP_CHECK(hipMemcpyAsync(r, d_res, sizeof(r), hipMemcpyDeviceToHost, st));
-    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
-    *err = r[0];
+    MRGFE_TRY(gicp_wait_record(st, h_rec_.as<double>(), tag));
+    *err = h_rec_.as<double>()[0];
     return MRGFE_OK;
 }
 

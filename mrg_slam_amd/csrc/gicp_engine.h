@@ -105,6 +105,8 @@ class GicpEngine {
     int pcl_evaluate(const float T_rowmajor[16], const float guess_rowmajor[16], const float4* d_pts, bool search, const double x[6], double* f, double g[6], int* n_corr);
     const float4* source_points() const { return d_src_; }
    private:
+    PinBuf   h_rec_;        // the reduced record of a linearisation / error evaluation, written by the device (gicp_reduce_host_kernel)
+    uint64_t rec_tag_ = 0;  // ... and the tag of the last one asked for
     DevBuf d_cur_;  // ICP: the source as transformed so far
     NnGrid cur_grid_;  // ICP with reciprocal correspondences: exact-NN grid over d_cur_
     float  final_[16];
