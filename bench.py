@@ -787,6 +787,39 @@ def main():
             del f_dev
         # (4) BASELINE config[2]: GICP scan-to-keyframe (the k-NN correspondence path), keyframe = scan 0, frames = scans 1..6
         extras["config2_gicp"] = run_config2(ctx, scans, dev, poses, lib, args)
+        # (5) the per-scan path every robot of config[4] runs: raw scan in host memory -> mrgfe_prefilter_device (distance 0.1-35 m, VoxelGrid 0.1 m,
+        # RadiusOutlierRemoval 0.5 m / 2) -> setInputSourceDevice + scan-to-keyframe align, with the chain's counts on the device (one host wait) and, for
+        # comparison, every stage reporting to the host (round 3)
+        if raw is not None:
+            from mrg_slam_amd import prefilter_to_device
+
+            dbuf = torch.empty((max(len(r) for r in raw[:8]) + 16, 4), dtype=torch.float32, device=gdev)
+            kf = prefilter(raw[0], ctx=ctx)
+            odo = NdtHip(resolution=1.0, transformation_epsilon=args.eps, maximum_iterations=64, ctx=ctx)
+            odo.setInputTarget(kf)
+            per_scan = {}
+            for mode, name in ((1, "device_driven"), (0, "host_driven")):
+                lib().mrgfe_dbg_set_prefilter_device_driven(mode)
+                t_pf, t_fr = [], []
+                for rep in range(3):
+                    for k in range(1, 7):
+                        g = synth.warm_guess(synth.rel_pose(poses[0], poses[k]), 9000 + k)
+                        ctx.synchronize()
+                        t0 = time.perf_counter()
+                        m = prefilter_to_device(raw[k], dbuf.data_ptr(), dbuf.shape[0], ctx=ctx)
+                        t1 = time.perf_counter()
+                        odo.setInputSourceDevice(dbuf.data_ptr(), m)
+                        odo.align(g)
+                        t2 = time.perf_counter()
+                        if rep:
+                            t_pf.append(1e3 * (t1 - t0))
+                            t_fr.append(1e3 * (t2 - t0))
+                per_scan[name] = {"prefilter_ms": float(np.median(t_pf)), "prefilter_plus_ndt_frame_ms": float(np.median(t_fr))}
+            lib().mrgfe_dbg_set_prefilter_device_driven(1)
+            per_scan["raw_points"] = int(np.mean([len(r) for r in raw[1:7]]))
+            per_scan["filtered_points"] = int(m)
+            per_scan["note"] = "median of 12 frames, raw scans handed over as host pointers (the 2 MB upload is inside), result left in HBM for the scan matcher"
+            extras["per_scan_path"] = per_scan
 
     shard = None
     if args.shard_steps > 0:
@@ -991,6 +1024,7 @@ def main():
         "gpu_split_ms_per_step": extras.get("gpu_split_ms_per_step"),
         "pipeline_shape": extras.get("pipeline_shape"),
         "config2_gicp": extras.get("config2_gicp"),
+        "per_scan_path": extras.get("per_scan_path"),
         "config3_shard": shard,
     }
     print(json.dumps(out))

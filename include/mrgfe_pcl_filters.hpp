@@ -2,6 +2,8 @@
 // odometry components hold:
 //   voxelgrid_filter_                    /root/reference/apps/prefiltering_component.cpp:37 (used :168-171);
 //                                        apps/scan_matching_odometry_component.cpp:176-179 (pcl::VoxelGrid built in place)
+//   approx_voxelgrid_filter_             prefiltering_component.cpp:38 (used :173-175); approx_voxel_grid_filter_
+//                                        scan_matching_odometry_component.cpp:39 (used :181-183)
 //   statistical_outlier_removal_filter_  prefiltering_component.cpp:54  (used :189-192)
 //   radius_outlier_removal_filter_       prefiltering_component.cpp:55  (used :195-198)
 // The reference configures them through PCL's own setters (setLeafSize, setMinimumPointsNumberPerVoxel, setRadiusSearch,
@@ -17,6 +19,7 @@
 #pragma once
 #if __has_include(<pcl/filters/voxel_grid.h>)
 
+#include <pcl/filters/approximate_voxel_grid.h>
 #include <pcl/filters/radius_outlier_removal.h>
 #include <pcl/filters/statistical_outlier_removal.h>
 #include <pcl/filters/voxel_grid.h>
@@ -111,6 +114,45 @@ class HipVoxelGrid : public pcl::VoxelGrid<PointT> {
         }
         detail::unpack(buf_, m, output);
         output.is_dense = true;  // we filter out invalid points (pcl::VoxelGrid::applyFilter)
+    }
+
+   private:
+    mrgfe_ctx*         ctx_;
+    std::vector<float> buf_;
+    std::size_t        gpu_calls_ = 0;
+};
+
+// pcl::ApproximateVoxelGrid<PointT> whose applyFilter runs mrgfe_approx_voxelgrid (downsample_method APPROX_VOXELGRID): the 512-entry
+// history of cells flushed in arrival order — the same points in the same order as PCL's sequential loop, from 512 independent sequences on the
+// GPU (csrc/filters.hip).  A history of another size (a PCL built with another histsize_), unequal leaf sizes or downsample_all_data = false
+// stay PCL's.
+template <typename PointT = pcl::PointXYZI>
+class HipApproximateVoxelGrid : public pcl::ApproximateVoxelGrid<PointT> {
+   public:
+    using Base = pcl::ApproximateVoxelGrid<PointT>;
+    using PointCloud = typename Base::PointCloud;
+    explicit HipApproximateVoxelGrid(int device = 0) : ctx_(shared_context(device)) {}
+    std::size_t gpu_calls() const { return gpu_calls_; }
+
+   protected:
+    void applyFilter(PointCloud& output) override
+    {
+        const bool cubic = this->leaf_size_[0] == this->leaf_size_[1] && this->leaf_size_[0] == this->leaf_size_[2];
+        if (!cubic || !this->downsample_all_data_ || this->histsize_ != 512) { Base::applyFilter(output); return; }  // not offered: PCL's own code
+        const auto& in = *this->input_;
+        if (in.empty()) { output.points.clear(); output.width = 0; output.height = 1; output.is_dense = false; return; }
+        buf_.resize(in.size() * 4);
+        std::size_t m = 0;
+        if (mrgfe_approx_voxelgrid(ctx_, &in.points[0].x, in.size(), point_layout<PointT>(), this->leaf_size_[0], buf_.data(), &m) != MRGFE_OK) {
+            PCL_ERROR("[mrgfe_pcl::HipApproximateVoxelGrid::applyFilter] %s\n", mrgfe_last_error());
+            output.points.clear();
+            output.width = 0;
+            output.height = 1;
+            return;
+        }
+        ++gpu_calls_;
+        detail::unpack(buf_, m, output);
+        output.is_dense = false;  // "we filter out invalid points" is NOT what pcl::ApproximateVoxelGrid::applyFilter says: it sets is_dense = false
     }
 
    private:

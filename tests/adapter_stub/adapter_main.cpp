@@ -192,6 +192,18 @@ int main(int argc, char** argv)
         base->setInputCloud(inplace);
         base->filter(*inplace);
         check(same_as(*inplace, packed(*filtered), filtered->size()), "pcl::Filter base pointer, in place: same voxel grid output");
+        // downsample(), APPROX_VOXELGRID :173-175
+        {
+            std::shared_ptr<pcl::ApproximateVoxelGrid<PointT>> approx_voxelgrid_filter_ = std::make_shared<mrgfe_pcl::HipApproximateVoxelGrid<PointT>>();  // :38
+            Cloud::Ptr approx(new Cloud());
+            approx_voxelgrid_filter_->setLeafSize(downsample_resolution, downsample_resolution, downsample_resolution);
+            approx_voxelgrid_filter_->setInputCloud(cloud);
+            approx_voxelgrid_filter_->filter(*approx);
+            std::size_t ma = 0;
+            mrgfe_approx_voxelgrid(ctx, in.data(), cloud->size(), 16, 0.25f, exp.data(), &ma);
+            check(ma > 0 && ma < cloud->size() && same_as(*approx, exp, ma), "pcl::ApproximateVoxelGrid::filter through HipApproximateVoxelGrid == mrgfe_approx_voxelgrid on the packed cloud");
+            check(!approx->is_dense && Filter::cpu_calls() == cpu0, "approximate voxel grid output: is_dense = false, PCL's CPU loop did not run");
+        }
         // what the GPU path does not offer stays PCL's: unequal leaf sizes
         voxelgrid_filter_->setLeafSize(0.25f, 0.5f, 0.25f);
         voxelgrid_filter_->setInputCloud(cloud);
