@@ -304,6 +304,31 @@ def run_config2(ctx, scans, dev, poses, lib, args):
                                        "frames_over_bar": int(sum(a > 1e-4 or b > 1e-4 for a, b in zip(dts, drs))), "frames_bit_identical": int(sum(a == 0.0 and b == 0.0 for a, b in zip(dts, drs))),
                                        "far_frames_with_other_iterations_or_convergence": mism, "far_frames_oracle_outer_iterations": its_o, "bar": "1e-4 m / 1e-4 rad"}
         out[name] = rec
+    # the same method over a loop-closure-sized batch: 32 candidates (scans 1..4 in turn, warm guesses) against keyframe 0, k-NN covariances of every
+    # candidate recomputed in the call (no keyframe store) - where the chip is full; the kernels behind it are priced in profiles/ (gicp_profile.py batch)
+    from mrg_slam_amd import BatchMatcher
+    from mrg_slam_amd._lib import SMALL_GICP_HIP
+    from mrg_slam_amd.registration import default_params
+
+    gp = default_params(SMALL_GICP_HIP)
+    gp.transformation_epsilon = args.eps
+    gb = BatchMatcher(gp, ctx)
+    n_c = min(4, len(scans) - 1)
+    cand = [1 + b % n_c for b in range(32)]
+    g_args = ([dev[0].data_ptr()], [len(scans[0])], np.zeros(32, dtype=np.int32), [dev[k].data_ptr() for k in cand], [len(scans[k]) for k in cand],
+              np.stack([synth.warm_guess(rels[k] if k in rels else synth.rel_pose(poses[0], poses[k]), 7000 + b) for b, k in enumerate(cand)]))
+    t_b = []
+    for rep in range(4):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        gb.clear()
+        gb.add_device(*g_args)
+        rb = gb.align(-1.0)
+        ctx.synchronize()
+        t_b.append(1e3 * (time.perf_counter() - t0))
+    out["SMALL_GICP_HIP"]["batch_32_candidates"] = {"ms_per_call": float(np.median(t_b[1:])), "ms_per_alignment": float(np.median(t_b[1:])) / 32.0, "converged": int(rb["converged"].sum()),
+                                                    "points_per_cloud": int(np.mean([len(scans[k]) for k in cand])),
+                                                    "note": "clear + add + align of 32 candidates against one keyframe, clouds resident, every candidate's k = 20 covariances recomputed in the call"}
     return out
 
 
