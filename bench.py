@@ -948,10 +948,12 @@ def main():
                 "ndt_bit_identical_to_reference_order_oracle": f"{a['ndt_exact_ref']}/{a['ndt']}", "ndt_bit_identical_to_gpu_order_replay": f"{a['ndt_exact_gpu_order']}/{a['ndt']}",
                 "ndt_worst_settled_m_or_rad": a["ndt_worst_settled"], "ndt_worst_m_or_rad": a["ndt_worst"],
                 "icp_gicp_vgicp_small_gicp": f"{a['other_over_bar']}/{a['other']}", "icp_gicp_vgicp_small_gicp_bit_identical": f"{a['other_exact']}/{a['other']}",
-                "pcl_gicp": f"{b['gicp_over_bar']}/{b['gicp']}", "pcl_gicp_over_bar_equal_to_gpu_order_replay": f"{b['gicp_over_bar_equal_to_gpu_order_replay']}/{b['gicp_over_bar']}",
-                "pcl_gicp_bit_identical_to_gpu_order_replay": f"{b['gicp_exact_gpu_order']}/{b['gicp']}", "pcl_gicp_bit_identical_to_reference_order_oracle": f"{b['gicp_exact_ref']}/{b['gicp']}",
-                "pcl_gicp_worst_m_or_rad": b["gicp_worst"], "icp_reciprocal": f"{b['icp_over_bar']}/{b['icp']}",
-                "worst_m": max(a["ndt_worst"], a["other_worst"], b["gicp_worst"], b["icp_worst"]),
+                "pcl_gicp_serial": f"{b['gicp_serial_over_bar']}/{b['gicp_serial']}", "pcl_gicp_serial_bit_identical_to_reference_order_oracle": f"{b['gicp_serial_exact_ref']}/{b['gicp_serial']}",
+                "pcl_gicp_serial_worst_m_or_rad": b["gicp_serial_worst"],
+                "pcl_gicp_omp": f"{b['gicp_omp_over_bar']}/{b['gicp_omp']}", "pcl_gicp_omp_over_bar_equal_to_gpu_order_replay": f"{b['gicp_omp_over_bar_equal_to_gpu_order_replay']}/{b['gicp_omp_over_bar']}",
+                "pcl_gicp_omp_bit_identical_to_gpu_order_replay": f"{b['gicp_omp_exact_gpu_order']}/{b['gicp_omp']}", "pcl_gicp_omp_bit_identical_to_reference_order_oracle": f"{b['gicp_omp_exact_ref']}/{b['gicp_omp']}",
+                "pcl_gicp_omp_worst_m_or_rad": b["gicp_omp_worst"], "icp_reciprocal": f"{b['icp_over_bar']}/{b['icp']}",
+                "worst_m": max(a["ndt_worst"], a["other_worst"], b["gicp_serial_worst"], b["gicp_omp_worst"], b["icp_worst"]),
                 "flag_or_iteration_mismatches": a["ndt_flag_or_iteration_mismatch"] + a["other_flag_mismatch"] + b["gicp_flag_or_iteration_mismatch"] + b["icp_flag_or_iteration_mismatch"],
                 "over_bar_cases": a["over_bar"] + b["over_bar"], "seconds": time.perf_counter() - ts,
                 "what": f"{args.soak_cases} + {max(1, args.soak_cases // 3)} random 1.5k-9k-point scenes (oracle/replay.py, seeds 20260411 / 20260412: every method, resolution 0.5-2 m, four NDT "

@@ -416,6 +416,11 @@ int mrgfe_dbg_set_fit_sweep(int mode);
  * call waits once at its end, 0 every stage reports its count to the host (round 3; also what an unusual scan falls back to); other values
  * query.  Same outputs either way. */
 int mrgfe_dbg_set_prefilter_device_driven(int mode);
+/* PCL_GICP_HIP (serial pcl::GeneralizedIterativeClosestPoint, registrations.cpp:93-103): 1 (default) the thirteen sums of every cost / gradient
+ * evaluation are added in the reference's order, point after point (bit-identical BFGS trajectories; ~4 ns per point and evaluation), 0 in a tree
+ * (round 3: faster, and outside the 1e-4 bar on one random scene in fourteen); other values query.  PCL_GICP_OMP_HIP always uses the tree:
+ * pclomp's own sums have no fixed order. */
+int mrgfe_dbg_set_pclgicp_reference_order(int mode);
 /* Counters of the seed + sweep pass (mrgfe_ctx_fitness_stats out[6..9], mrgfe_batch_fitness_stats) during the following calls of this process:
  * 0 = off (default; MRGFE_FIT_STATS sets the initial value), 1 = counted, 2 = also the kernel's phase clocks and a line on stderr (slows
  * the kernel: a clock read waits for the memory operations in flight).  Any other value only asks.  Returns the setting in effect. */

@@ -184,6 +184,7 @@ SIGNATURES = {
     "mrgfe_dbg_set_fused_launch": (C.c_int, [C.c_int]),
     "mrgfe_dbg_set_fit_sweep": (C.c_int, [C.c_int]),
     "mrgfe_dbg_set_prefilter_device_driven": (C.c_int, [C.c_int]),
+    "mrgfe_dbg_set_pclgicp_reference_order": (C.c_int, [C.c_int]),
     "mrgfe_dbg_set_fit_stats": (C.c_int, [C.c_int]),
     "mrgfe_batch_rounds": (C.c_int, [_vp]),
     "mrgfe_dbg_sincosf": (None, [_fp, C.c_size_t, _fp, _fp]),

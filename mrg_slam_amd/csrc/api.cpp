@@ -52,6 +52,7 @@ GicpParams gicp_params_from(const mrgfe_reg_params& p)
     g.variant = p.method == MRGFE_SMALL_GICP_HIP ? 1 : p.method == MRGFE_VGICP_HIP ? 2 : p.method == MRGFE_ICP_HIP ? 3 : (p.method == MRGFE_PCL_GICP_HIP || p.method == MRGFE_PCL_GICP_OMP_HIP) ? 4 : 0;
     g.max_inner_iterations = p.max_optimizer_iterations;
     g.pcl_whole_gradient_norm = p.method == MRGFE_PCL_GICP_OMP_HIP;
+    g.pcl_reference_order_sums = p.method == MRGFE_PCL_GICP_HIP;
     g.use_reciprocal = p.method == MRGFE_ICP_HIP && p.use_reciprocal_correspondences != 0;
     g.voxel_resolution = p.resolution;
     return g;
@@ -1372,6 +1373,7 @@ int mrgfe_batch_kernel_stats(const mrgfe_batch* b, int mode, double* ms, int64_t
 }
 
 int mrgfe_dbg_set_prefilter_device_driven(int mode) { return prefilter_set_device_driven(mode); }
+int mrgfe_dbg_set_pclgicp_reference_order(int mode) { return gicp_set_pcl_reference_order(mode); }
 
 int mrgfe_batch_largest_launch(const mrgfe_batch* b, double out[4])
 {

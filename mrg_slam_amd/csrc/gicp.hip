@@ -349,8 +349,11 @@ __global__ __launch_bounds__(256) void pclgicp_corr_kernel(NnGrid2Dev g, const f
 
 // OptimizationFunctorWithIndices::fdf over the correspondences: d = T(x) p_src - p_tgt (float), Md = M d, f += d^T Md, g_t += Md,
 // dCost_dR_T += p_base_src Md^T (base_transformation_ is the identity in computeTransformation: p_base_src = p_src)
+// kTerms: the 13 terms + the correspondence flag of every point go to `terms` ([14][n_pad], a column per sum) instead of into the block tree — the
+// serial reference adds them one after the other in point order, and pclgicp_seqsum_kernel does exactly that
+template <bool kTerms>
 __global__ __launch_bounds__(256) void pclgicp_fdf_kernel(const float4* __restrict__ src, uint32_t n, const float4* __restrict__ tgt, const int32_t* __restrict__ corr,
-                                                           const double* __restrict__ mahal, PclGicpIter it, double* __restrict__ partials)
+                                                           const double* __restrict__ mahal, PclGicpIter it, double* __restrict__ partials, double* __restrict__ terms, uint32_t n_pad)
 {
 #pragma clang fp contract(off)
     double vals[29];
@@ -383,7 +386,62 @@ __global__ __launch_bounds__(256) void pclgicp_fdf_kernel(const float4* __restri
             vals[28] = 1.0;
         }
     }
+    if (kTerms) {
+        if (i < n) {
+#pragma unroll
+            for (int k = 0; k < 13; ++k) terms[size_t(k) * n_pad + i] = vals[k];
+            terms[size_t(13) * n_pad + i] = vals[28];
+        }
+        return;
+    }
     gicp_block_reduce(vals, partials + size_t(blockIdx.x) * kGicpStride, 13);
+}
+
+// The reference's order of additions for serial pcl::GICP (registration_method "GICP"): OptimizationFunctorWithIndices adds the terms of the
+// correspondences one after the other, in source-index order, into f, g.head<3>() and the 3x3 dCost_dR_T — thirteen chains of dependent f64
+// additions.  A point without a correspondence contributes +0.0, which leaves a sum that started at +0.0 unchanged, so the chains run over ALL
+// source points.  Lane c (c < 14; the fourteenth chain counts the correspondences) walks its column: 32 terms in flight, then 32 dependent adds.
+// Not parallel and meant not to be: ~4 ns per point and evaluation, which is what bit-identity with a deterministic reference costs
+// (the tree of pclgicp_fdf_kernel<false> leaves the bar on one random scene in fourteen).
+__global__ __launch_bounds__(256) void pclgicp_seqsum_kernel(const double* __restrict__ terms, uint32_t n, uint32_t n_pad, double* __restrict__ out)
+{
+    // The chains are bound by the latency of a dependent f64 addition (~8 cycles) only if the terms are THERE: a lane streaming its column from
+    // global memory waited a round trip per 32 terms (2.1 ms per 130k-point evaluation).  So the whole workgroup streams the next tile of 256 points
+    // x 14 columns into LDS (coalesced, a column at a time) while lanes 0..13 of wavefront 0 add the current one out of LDS.
+    constexpr int kT = 256;
+    __shared__ double buf[2][14][kT];
+    const int      tid = threadIdx.x;
+    const uint32_t ntile = (n + kT - 1) / kT;
+    double v[14];
+    auto fetch = [&](uint32_t t) {
+        const uint32_t i = t * kT + tid;
+#pragma unroll
+        for (int c = 0; c < 14; ++c) v[c] = i < n ? terms[size_t(c) * n_pad + i] : 0.0;  // (+0.0 past the end: exact to add)
+    };
+    auto stash = [&](int b) {
+#pragma unroll
+        for (int c = 0; c < 14; ++c) buf[b][c][tid] = v[c];
+    };
+    if (ntile) { fetch(0); stash(0); }
+    __syncthreads();
+    double acc = 0.0;
+    for (uint32_t t = 0; t < ntile; ++t) {
+        const int b = static_cast<int>(t & 1u);
+        if (t + 1 < ntile) fetch(t + 1);  // in flight during the additions below
+        if (tid < 14) {
+            const double* __restrict__ col = buf[b][tid];
+#pragma unroll 4
+            for (int u = 0; u < kT; u += 8) {
+                const double2 a0 = *reinterpret_cast<const double2*>(col + u), a1 = *reinterpret_cast<const double2*>(col + u + 2), a2 = *reinterpret_cast<const double2*>(col + u + 4),
+                              a3 = *reinterpret_cast<const double2*>(col + u + 6);
+                acc += a0.x; acc += a0.y; acc += a1.x; acc += a1.y; acc += a2.x; acc += a2.y; acc += a3.x; acc += a3.y;
+            }
+        }
+        if (t + 1 < ntile) stash(b ^ 1);
+        __syncthreads();
+    }
+    if (tid < 14) out[tid < 13 ? tid : 28] = acc;
+    else if (tid < kGicpStride + 1 && tid - 1 != 28 && tid - 1 >= 13) out[tid - 1] = 0.0;
 }
 
 // linearize over the correspondences of gicp_corr_kernel
@@ -753,6 +811,7 @@ GicpEngine::~GicpEngine()
     d_tgt_cov_.release(); d_src_cov_.release(); d_corr_.release(); d_mahal_.release(); d_partial_.release(); d_T_.release();
     d_vox_.release(); d_vox_runs_.release(); d_cur_.release();
     h_rec_.release();
+    d_terms_.release();
 }
 
 int GicpEngine::set_target(const void* d, size_t n)
@@ -1280,6 +1339,21 @@ void pclgicp_r_derivative(const double x[6], const double dC[9], double g[6])
 }
 }  // namespace
 
+// serial pcl::GICP adds its cost terms in point order: 1 (default) so does PCL_GICP_HIP (pclgicp_seqsum_kernel), 0 the tree sums of round 3
+// (MRGFE_PCLGICP_TREE_SUMS=1; mrgfe_dbg_set_pclgicp_reference_order).  PCL_GICP_OMP_HIP always sums in a tree: pclomp's own per-thread sums have no fixed order.
+static std::atomic<int> g_pclgicp_ref_order{-1};
+static int pclgicp_reference_order_mode()
+{
+    int v = g_pclgicp_ref_order.load(std::memory_order_relaxed);
+    if (v < 0) { v = std::getenv("MRGFE_PCLGICP_TREE_SUMS") ? 0 : 1; g_pclgicp_ref_order.store(v, std::memory_order_relaxed); }
+    return v;
+}
+int gicp_set_pcl_reference_order(int mode)
+{
+    if (mode == 0 || mode == 1) g_pclgicp_ref_order.store(mode, std::memory_order_relaxed);
+    return pclgicp_reference_order_mode();
+}
+
 int GicpEngine::pcl_evaluate(const float T_rowmajor[16], const float guess_rowmajor[16], const float4* d_pts, bool search, const double x[6], double* f, double g[6], int* n_corr)
 {
     hipStream_t    st = ctx_->stream;
@@ -1313,9 +1387,17 @@ int GicpEngine::pcl_evaluate(const float T_rowmajor[16], const float guess_rowma
     double* d_part = d_partial_.as<double>();
     double* d_res = d_part + size_t(nblk) * kGicpStride;
     MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev0, st));
-    hipLaunchKernelGGL(pclgicp_fdf_kernel, dim3(nblk), dim3(256), 0, st, d_pts, n, d_tgt_, d_corr_.as<int32_t>(), d_mahal_.as<double>(), it, d_part);
-    MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev1, st));
-    hipLaunchKernelGGL(gicp_reduce_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, d_res);
+    if (prm_.pcl_reference_order_sums && pclgicp_reference_order_mode()) {
+        const uint32_t n_pad = (n + 1u) & ~1u;
+        MRGFE_TRY(d_terms_.ensure(sizeof(double) * 14 * size_t(n_pad)));
+        hipLaunchKernelGGL(pclgicp_fdf_kernel<true>, dim3(nblk), dim3(256), 0, st, d_pts, n, d_tgt_, d_corr_.as<int32_t>(), d_mahal_.as<double>(), it, d_part, d_terms_.as<double>(), n_pad);
+        hipLaunchKernelGGL(pclgicp_seqsum_kernel, dim3(1), dim3(256), 0, st, d_terms_.as<double>(), n, n_pad, d_res);
+        MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev1, st));
+    } else {
+        hipLaunchKernelGGL(pclgicp_fdf_kernel<false>, dim3(nblk), dim3(256), 0, st, d_pts, n, d_tgt_, d_corr_.as<int32_t>(), d_mahal_.as<double>(), it, d_part, static_cast<double*>(nullptr), 0u);
+        MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev1, st));
+        hipLaunchKernelGGL(gicp_reduce_kernel, dim3(1), dim3(256), 0, st, d_part, nblk, d_res);
+    }
     MRGFE_HIP_CHECK(hipGetLastError());
     double r[kGicpStride];
     MRGFE_HIP_CHECK(hipMemcpyAsync(r, d_res, sizeof(r), hipMemcpyDeviceToHost, st));

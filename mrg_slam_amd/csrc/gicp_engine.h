@@ -39,6 +39,9 @@ struct GicpParams {
     // converged iff max entry change / (rot_eps | trans_eps) < 1 or the iteration limit is reached
     int    max_inner_iterations = 20;
     bool   pcl_whole_gradient_norm = false;
+    // serial pcl::GICP (registration_method "GICP") is deterministic: its cost and gradient sums are added in point order, and so are ours
+    // (pclgicp_seqsum_kernel) unless this is false (pclomp::GICP: per-thread sums without a fixed order -> the block tree)
+    bool   pcl_reference_order_sums = false;
     double sg_init_lambda = 1e-3, sg_lambda_factor = 10.0;
     int    sg_max_inner_iterations = 10;
 };
@@ -105,6 +108,7 @@ class GicpEngine {
     int pcl_evaluate(const float T_rowmajor[16], const float guess_rowmajor[16], const float4* d_pts, bool search, const double x[6], double* f, double g[6], int* n_corr);
     const float4* source_points() const { return d_src_; }
    private:
+    DevBuf   d_terms_;      // PCL_GICP_HIP: the per-point terms of one cost / gradient evaluation, a column per sum
     PinBuf   h_rec_;        // the reduced record of a linearisation / error evaluation, written by the device (gicp_reduce_host_kernel)
     uint64_t rec_tag_ = 0;  // ... and the tag of the last one asked for
     DevBuf d_cur_;  // ICP: the source as transformed so far
@@ -180,6 +184,8 @@ class GicpBatch {
     hipEvent_t done_ = nullptr;
 };
 
+// PCL_GICP_HIP: 1 the cost / gradient sums in the reference's (point) order, 0 in a tree; other values query
+int gicp_set_pcl_reference_order(int mode);
 // correspondence search of GICP_HIP / SMALL_GICP_HIP: 1 the passes of nn_nearest_batch for large batches (default), 0 one lane group per query always, 2 the passes always
 int gicp_set_corr_passes(int mode);
 

@@ -258,8 +258,10 @@ def main():
                            "ndt_over_bar_equal_to_gpu_order_replay": f"{a['ndt_over_bar_equal_to_gpu_order_replay']}/{a['ndt_over_bar']}",
                            "ndt_bit_identical_to_reference_order_oracle": f"{a['ndt_exact_ref']}/{a['ndt']}", "ndt_bit_identical_to_gpu_order_replay": f"{a['ndt_exact_gpu_order']}/{a['ndt']}",
                            "ndt_worst_settled": a["ndt_worst_settled"], "other_methods_over_bar": f"{a['other_over_bar']}/{a['other']}", "other_methods_bit_identical": f"{a['other_exact']}/{a['other']}",
-                           "pcl_gicp_over_bar": f"{b['gicp_over_bar']}/{b['gicp']}", "pcl_gicp_over_bar_equal_to_gpu_order_replay": f"{b['gicp_over_bar_equal_to_gpu_order_replay']}/{b['gicp_over_bar']}",
-                           "pcl_gicp_bit_identical_to_gpu_order_replay": f"{b['gicp_exact_gpu_order']}/{b['gicp']}", "pcl_gicp_worst": b["gicp_worst"],
+                           "pcl_gicp_serial_over_bar": f"{b['gicp_serial_over_bar']}/{b['gicp_serial']}", "pcl_gicp_serial_bit_identical_to_reference_order_oracle": f"{b['gicp_serial_exact_ref']}/{b['gicp_serial']}",
+                           "pcl_gicp_omp_over_bar": f"{b['gicp_omp_over_bar']}/{b['gicp_omp']}", "pcl_gicp_omp_over_bar_equal_to_gpu_order_replay": f"{b['gicp_omp_over_bar_equal_to_gpu_order_replay']}/{b['gicp_omp_over_bar']}",
+                           "pcl_gicp_omp_bit_identical_to_gpu_order_replay": f"{b['gicp_omp_exact_gpu_order']}/{b['gicp_omp']}", "pcl_gicp_omp_worst": b["gicp_omp_worst"],
+                           "pcl_gicp_flag_or_iteration_mismatch": b["gicp_flag_or_iteration_mismatch"],
                            "icp_reciprocal_over_bar": f"{b['icp_over_bar']}/{b['icp']}", "seconds": sj["seconds"]}
         lines += ["", f"## parity soak (`python3 profiles/soak.py 2000 600`, profiles/{tag}_soak.json)", "", "```json", json.dumps(summary["soak"], indent=1), "```"]
     for part in ("trace", "pmc"):
