@@ -90,8 +90,7 @@ class NnGrid {
     NnGrid2Dev h_;
     DevBuf     d_cell_start_[kNnMaxLevels], d_sorted_[kNnMaxLevels];
     int build_levels_together(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, const float* cell, int n_levels, double* crowding);
-    int build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, float cell, const SliceTable& tab, NnGridDev& lv, DevBuf& d_cells, DevBuf& d_sorted,
-                    bool counts_only, double* crowding);
+    int count_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, float cell, DevBuf& d_cells, double* crowding);
 };
 
 // Grids over several clouds built TOGETHER: every step of the build (bounding boxes, binning, the radix sort, the scan of the cell

@@ -72,17 +72,6 @@ __global__ __launch_bounds__(256) void nn_cellkey_kernel(const float4* __restric
     nn_cellkey_body(pts, n, g, n_cells, keys, vals, counts, crowd);
 }
 
-// occupancy words of the bricks (after cell_start is final): one thread per cell, an atomic only for occupied cells
-__device__ __forceinline__ void nn_occupancy_body(const NnGridDev& g, uint32_t n_cells, unsigned long long* __restrict__ occ)
-{
-    const uint32_t at = blockIdx.x * 256u + threadIdx.x;
-    if (at >= n_cells || g.cell_start[at + 1] == g.cell_start[at]) return;
-    const uint32_t x = at % g.dim[0], y = (at / g.dim[0]) % g.dim[1], z = at / (static_cast<uint32_t>(g.dim[0]) * g.dim[1]);
-    const uint32_t brick = ((z >> 2) * g.bdim[1] + (y >> 2)) * g.bdim[0] + (x >> 2);
-    atomicOr(&occ[brick], 1ull << ((x & 3u) | ((y & 3u) << 2) | ((z & 3u) << 4)));
-}
-__global__ __launch_bounds__(256) void nn_occupancy_kernel(NnGridDev g, uint32_t n_cells, unsigned long long* __restrict__ occ) { nn_occupancy_body(g, n_cells, occ); }
-
 // next pyramid level: bit of a child node set iff its word is non-zero (dims = child grid, pdim = parent grid)
 __device__ __forceinline__ void nn_occupancy_up_body(const unsigned long long* __restrict__ child, int dx, int dy, int dz, int px, int py, unsigned long long* __restrict__ parent)
 {
@@ -94,16 +83,6 @@ __device__ __forceinline__ void nn_occupancy_up_body(const unsigned long long* _
 __global__ __launch_bounds__(256) void nn_occupancy_up_kernel(const unsigned long long* __restrict__ child, int dx, int dy, int dz, int px, int py, unsigned long long* __restrict__ parent)
 {
     nn_occupancy_up_body(child, dx, dy, dz, px, py, parent);
-}
-
-__global__ __launch_bounds__(256) void nn_gather_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ sorted_vals, uint32_t n_valid, float4* __restrict__ sorted)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n_valid) return;
-    const uint32_t v = sorted_vals[i];
-    float4 p = pts[v];
-    p.w = __int_as_float(static_cast<int>(v));
-    sorted[i] = p;
 }
 
 // The cell table straight from the sorted keys (round 4).  After the stable sort, cell_start[c] is the position of the first sorted point
@@ -206,12 +185,6 @@ __device__ __forceinline__ void nn_fill_body(const uint32_t* __restrict__ keys, 
     }
 }
 
-__global__ __launch_bounds__(256) void nn_fill_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const float4* __restrict__ pts, uint32_t n, NnGridDev g,
-                                                       uint32_t n_cells, uint32_t* __restrict__ cell_start, unsigned long long* __restrict__ occ, float4* __restrict__ sorted,
-                                                       unsigned long long* __restrict__ crowd, NnGapQueue* __restrict__ gapq)
-{
-    nn_fill_body(keys, vals, pts, n, g, n_cells, cell_start, occ, sorted, crowd, gapq);
-}
 __device__ __forceinline__ void nn_fill_long_body(const NnGapQueue* __restrict__ q, uint32_t* __restrict__ cell_start)
 {
     const uint32_t cnt = min(q->count, kGapCap);
@@ -220,7 +193,6 @@ __device__ __forceinline__ void nn_fill_long_body(const NnGapQueue* __restrict__
         for (uint32_t c = r.x + threadIdx.x; c < r.y; c += 256u) cell_start[c] = r.z;
     }
 }
-__global__ __launch_bounds__(256) void nn_fill_long_kernel(const NnGapQueue* __restrict__ q, uint32_t* __restrict__ cell_start) { nn_fill_long_body(q, cell_start); }
 constexpr uint32_t kFillLongBlocks = 1024;
 
 // ---- the same steps for the members of an NnGridSet: blockIdx.y = member --------------------------------------
@@ -257,35 +229,21 @@ __global__ __launch_bounds__(256) void nn_fill_long_many_kernel(const NnBuildDev
     if (!b.active || b.gapq == nullptr) return;
     nn_fill_long_body(b.gapq, b.counts);
 }
-__global__ __launch_bounds__(256) void nn_occupancy_many_kernel(const NnBuildDev* __restrict__ d)
-{
-    const NnBuildDev& b = d[blockIdx.y];
-    if (!b.active || blockIdx.x * 256u >= b.n_cells) return;
-    nn_occupancy_body(b.lv, b.n_cells, b.occ[0]);
-}
 __global__ __launch_bounds__(256) void nn_occupancy_up_many_kernel(const NnBuildDev* __restrict__ d, int from)
 {
     const NnBuildDev& b = d[blockIdx.y];
     if (!b.active) return;
     nn_occupancy_up_body(b.occ[from], b.pd[from][0], b.pd[from][1], b.pd[from][2], b.pd[from + 1][0], b.pd[from + 1][1], b.occ[from + 1]);
 }
-__global__ __launch_bounds__(256) void nn_gather_many_kernel(const NnBuildDev* __restrict__ d, const uint32_t* __restrict__ sorted_vals)
-{
-    const NnBuildDev& b = d[blockIdx.y];
-    const uint32_t    i = blockIdx.x * 256u + threadIdx.x;
-    if (!b.active || i >= b.lv.n) return;
-    const uint32_t v = sorted_vals[b.off + i];
-    float4 p = b.pts[v];
-    p.w = __int_as_float(static_cast<int>(v));
-    b.sorted[i] = p;
-}
 
-// bins, sorts and gathers one level; `counts_only` stops after the binning kernel (adaptive cell search)
-int NnGrid::build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, float cell, const SliceTable& tab, NnGridDev& lv, DevBuf& d_cells, DevBuf& d_sorted,
-                        bool counts_only, double* crowding)
+// one COUNTING pass of the adaptive cell search: bins the points at edge `cell` with one atomic per distinct cell of a wavefront and reads back
+// the crowding figure (population of the cell an average point sits in).  Full builds are build_levels_together's.
+int NnGrid::count_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, float cell, DevBuf& d_cells, double* crowding)
 {
     hipStream_t st = ctx->stream;
-    DevBuf &ds = ctx->scratch[0], &dk = ctx->scratch[2], &dv = ctx->scratch[3], &dkt = ctx->scratch[4], &dvt = ctx->scratch[5], &dh = ctx->scratch[6], &dblk = ctx->scratch[8];
+    DevBuf &dk = ctx->scratch[2], &dv = ctx->scratch[3];
+    NnGridDev lv;
+    std::memset(&lv, 0, sizeof(lv));
     float extent = 0.0f;
     for (int a = 0; a < 3; ++a) { lv.origin[a] = bb.mn[a]; extent = std::max(extent, bb.mx[a] - bb.mn[a]); }
     lv.cell = cell;
@@ -293,74 +251,20 @@ int NnGrid::build_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const 
     lv.n = bb.n_finite;
     for (int a = 0; a < 3; ++a) lv.dim[a] = static_cast<int>(std::floor((bb.mx[a] - bb.mn[a]) / cell)) + 1;
     const uint32_t n_cells = static_cast<uint32_t>(lv.dim[0]) * lv.dim[1] * lv.dim[2];
-    int    pd[3][3];  // node grids of the occupancy pyramid: bricks, super-bricks, blocks
-    size_t pn[3] = {1, 1, 1};
-    for (int a = 0; a < 3; ++a) {
-        lv.bdim[a] = pd[0][a] = (lv.dim[a] + 3) / 4;
-        pd[1][a] = (pd[0][a] + 3) / 4;
-        pd[2][a] = (pd[1][a] + 3) / 4;
-        for (int k = 0; k < 3; ++k) pn[k] *= static_cast<size_t>(pd[k][a]);
-    }
-    // [counts / cell_start: n_cells + 1][crowd counters][occupancy words of the three pyramid levels], zeroed together
-    const size_t head_words = size_t(n_cells) + 4 + 2 * kCrowdSlots, occ_at = (head_words + 1) & ~size_t(1);
-    const bool   long_gaps = !counts_only && n_cells >= 64u * kLongGap;  // tables in which long gaps are worth a second launch
-    const size_t gapq_at = (occ_at + 2 * (pn[0] + pn[1] + pn[2]) + 3) & ~size_t(3);  // 16-byte aligned
-    const size_t all_words = gapq_at + (long_gaps ? sizeof(NnGapQueue) / 4 : 0);
-    MRGFE_TRY(d_cells.ensure(sizeof(uint32_t) * all_words));
-    // counting passes zero the count table; a full build writes every entry of the cell table itself (nn_fill_kernel) and only needs the
-    // crowd counters and the pyramid words behind it cleared
+    // [counts: n_cells + 1][crowd counters], zeroed together
     const size_t crowd_word = (size_t(n_cells) + 2) & ~size_t(1);
-    if (counts_only) MRGFE_HIP_CHECK(hipMemsetAsync(d_cells.p, 0, sizeof(uint32_t) * all_words, st));
-    else             MRGFE_HIP_CHECK(hipMemsetAsync(d_cells.as<uint32_t>() + crowd_word, 0, sizeof(uint32_t) * (all_words - crowd_word), st));
-    lv.cell_start = d_cells.as<uint32_t>();
-    lv.occ = reinterpret_cast<const unsigned long long*>(d_cells.as<uint32_t>() + occ_at);
-    lv.occ1 = lv.occ + pn[0];
-    lv.occ2 = lv.occ1 + pn[1];
-    // the crowd counters live behind the (n_cells + 1)-entry count table, 8-byte aligned
-    unsigned long long* d_crowd = reinterpret_cast<unsigned long long*>(d_cells.as<uint32_t>() + ((size_t(n_cells) + 2) & ~size_t(1)));
-    hipLaunchKernelGGL(nn_cellkey_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, d_pts, nn, lv, n_cells, dk.as<uint32_t>(), dv.as<uint32_t>(), counts_only ? d_cells.as<uint32_t>() : nullptr,
-                       (crowding && counts_only) ? d_crowd : nullptr);
+    const size_t all_words = crowd_word + 2 * kCrowdSlots;
+    MRGFE_TRY(d_cells.ensure(sizeof(uint32_t) * all_words));
+    MRGFE_HIP_CHECK(hipMemsetAsync(d_cells.p, 0, sizeof(uint32_t) * all_words, st));
+    unsigned long long* d_crowd = reinterpret_cast<unsigned long long*>(d_cells.as<uint32_t>() + crowd_word);
+    hipLaunchKernelGGL(nn_cellkey_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, d_pts, nn, lv, n_cells, dk.as<uint32_t>(), dv.as<uint32_t>(), d_cells.as<uint32_t>(), d_crowd);
     MRGFE_HIP_CHECK(hipGetLastError());
     unsigned long long slots[kCrowdSlots];
-    auto crowding_from_slots = [&]() {
-        unsigned long long crowd = 0;
-        for (unsigned long long v : slots) crowd += v;
-        // population of the cell an average POINT sits in (queries are distributed like the points, not like the cells)
-        *crowding = 1.0 + 2.0 * double(crowd) / double(bb.n_finite);
-    };
-    if (crowding && counts_only) {
-        MRGFE_HIP_CHECK(hipMemcpyAsync(slots, d_crowd, sizeof(slots), hipMemcpyDeviceToHost, st));
-        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
-        crowding_from_slots();
-    }
-    if (counts_only) return MRGFE_OK;
-    int key_bits = 1;
-    while (key_bits < 32 && (uint64_t(1) << key_bits) <= n_cells) ++key_bits;
-    uint32_t *sk, *sv;
-    MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), ds.as<Slice>(), tab, key_bits, dh.as<uint32_t>(), &sk, &sv, true));
-    // cell table, brick words, sorted points and the crowding figure from the sorted (key, index) pairs in one launch
-    (void)dblk;
-    MRGFE_TRY(d_sorted.ensure(sizeof(float4) * std::max<size_t>(nn, 1)));
-    lv.sorted = d_sorted.as<float4>();
-    const bool pyramid = &lv == &h_.level[0];  // only the finest level is searched through the pyramid (the coarser ones serve the k-NN climb)
-    NnGapQueue* d_gapq = long_gaps ? reinterpret_cast<NnGapQueue*>(d_cells.as<uint32_t>() + gapq_at) : nullptr;
-    hipLaunchKernelGGL(nn_fill_kernel, dim3(nn / 256 + 1), dim3(256), 0, st, sk, sv, d_pts, nn, lv, n_cells, d_cells.as<uint32_t>(), pyramid ? const_cast<unsigned long long*>(lv.occ) : nullptr,
-                       d_sorted.as<float4>(), crowding ? d_crowd : nullptr, d_gapq);
-    if (long_gaps) hipLaunchKernelGGL(nn_fill_long_kernel, dim3(kFillLongBlocks), dim3(256), 0, st, d_gapq, d_cells.as<uint32_t>());
-    if (pyramid) {
-        hipLaunchKernelGGL(nn_occupancy_up_kernel, dim3(static_cast<uint32_t>((pn[0] + 255) / 256)), dim3(256), 0, st, lv.occ, pd[0][0], pd[0][1], pd[0][2], pd[1][0], pd[1][1],
-                           const_cast<unsigned long long*>(lv.occ1));
-        hipLaunchKernelGGL(nn_occupancy_up_kernel, dim3(static_cast<uint32_t>((pn[1] + 255) / 256)), dim3(256), 0, st, lv.occ1, pd[1][0], pd[1][1], pd[1][2], pd[2][0], pd[2][1],
-                           const_cast<unsigned long long*>(lv.occ2));
-    }
-    MRGFE_HIP_CHECK(hipGetLastError());
-    // a full build that also measures: the counters ride on one synchronisation; a build that does not measure returns without waiting
-    // (nothing on the host was the source of an asynchronous copy here: the stream orders the searches behind the build)
-    if (crowding) {
-        MRGFE_HIP_CHECK(hipMemcpyAsync(slots, d_crowd, sizeof(slots), hipMemcpyDeviceToHost, st));
-        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
-        crowding_from_slots();
-    }
+    MRGFE_HIP_CHECK(hipMemcpyAsync(slots, d_crowd, sizeof(slots), hipMemcpyDeviceToHost, st));
+    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    unsigned long long crowd = 0;
+    for (unsigned long long v : slots) crowd += v;
+    *crowding = 1.0 + 2.0 * double(crowd) / double(bb.n_finite);  // queries are distributed like the points, not like the cells
     return MRGFE_OK;
 }
 
@@ -556,7 +460,7 @@ int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size
         int halvings = 0;
         for (int pass = 0; pass < 3 && halvings < 4 && cells_at(cell * 0.5f) <= double(1u << 24); ++pass) {
             double crowding = 0;
-            MRGFE_TRY(build_level(ctx, d_pts, nn, bb, cell, tab, h_.level[0], d_cell_start_[0], d_sorted_[0], true, &crowding));
+            MRGFE_TRY(count_level(ctx, d_pts, nn, bb, cell, d_cell_start_[0], &crowding));
             if (crowding <= crowding_target) break;
             int step = std::max(1, static_cast<int>(std::ceil(std::log(crowding / crowding_target) / std::log(4.0))));
             step = std::min(step, 4 - halvings);

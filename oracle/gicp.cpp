@@ -148,6 +148,21 @@ double FastGicp::linearize(const double T[16], double H[36], double b[6], int* n
             auto it = voxel_index_.find(voxel_coord(tA));
             if (it == voxel_index_.end()) continue;
             j = it->second;
+        } else if (variant == 1 && double_search) {
+            double qd[3];
+            for (int r = 0; r < 3; ++r) { double s = T[r * 4 + 0] * static_cast<double>(a[0]); s = s + T[r * 4 + 1] * static_cast<double>(a[1]); s = s + T[r * 4 + 2] * static_cast<double>(a[2]); qd[r] = s + T[r * 4 + 3]; }
+            int   cid[8];
+            float csq[8];
+            const int got = target_grid_.knn(static_cast<float>(qd[0]), static_cast<float>(qd[1]), static_cast<float>(qd[2]), 8, cid, csq);
+            double best = 0;
+            j = -1;
+            for (int c = 0; c < got; ++c) {
+                const float* t = &target[4 * static_cast<size_t>(cid[c])];
+                const double dx = static_cast<double>(t[0]) - qd[0], dy = static_cast<double>(t[1]) - qd[1], dz = static_cast<double>(t[2]) - qd[2];
+                const double d = (dx * dx + dy * dy) + dz * dz;
+                if (j < 0 || d < best || (d == best && cid[c] < j)) { best = d; j = cid[c]; }
+            }
+            if (j < 0 || best > thr2) continue;  // DistanceRejector: sq_dist > max_dist_sq
         } else {
             float sqd;
             j = target_grid_.nearest(q[0], q[1], q[2], sqd);

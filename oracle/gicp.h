@@ -48,6 +48,10 @@ struct FastGicp {
     int    num_threads       = 1;
     int    lm_max_iterations = 10;
     double lm_init_lambda_factor = 1e-9;
+    // variant 1 only, diagnostic: small_gicp's OWN correspondence search — the source point transformed in double (Isometry3d * Vector4d), the nearest
+    // target point by double-precision distance, rejected iff that exceeds max_dist_sq — instead of fast_gicp's float transform and float distances that
+    // the restatement (and the HIP path) keeps for both formulations ("deviations").  The candidates are the 8 float-nearest target points.
+    bool   double_search = false;
     int    variant = 0;                 // 0: fast_gicp::FastGICP, 1: small_gicp::RegistrationPCL (GICP), 2: fast_gicp::FastVGICP, 3: pcl::IterativeClosestPoint
     double voxel_resolution = 1.0;      // variant 2: setResolution(reg_resolution)
     bool   use_reciprocal = false;      // variant 3: setUseReciprocalCorrespondences (registrations.cpp:91): CorrespondenceEstimation::determineReciprocalCorrespondences

@@ -96,6 +96,7 @@ def lib():
             "orc_gicp_destroy": (None, [vp]),
             "orc_gicp_set_params": (None, [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]),
             "orc_gicp_set_variant": (None, [vp, C.c_int]),
+            "orc_gicp_set_double_search": (None, [vp, C.c_int]),
             "orc_gicp_set_reciprocal": (None, [vp, C.c_int]),
             "orc_gicp_set_resolution": (None, [vp, C.c_double]),
             "orc_gicp_num_voxels": (C.c_int, [vp]),
@@ -456,6 +457,12 @@ class SmallGicp(FastGicp):
     """small_gicp::RegistrationPCL (GICP) restated: the reference's YAML default "SMALL_GICP" (oracle/gicp.h, variant 1)."""
 
     VARIANT = 1
+
+    def __init__(self, *args, double_search=False, **kwargs):
+        """``double_search`` (diagnostic): small_gicp's own correspondence search — double-precision transform and distances — instead of the
+        float search the restatement shares with fast_gicp (oracle/gicp.h); tests/test_oracle_gicp.py measures what the difference amounts to."""
+        super().__init__(*args, **kwargs)
+        lib().orc_gicp_set_double_search(self._h, int(bool(double_search)))
 
 
 class FastVgicp(FastGicp):

@@ -173,6 +173,7 @@ void  orc_gicp_set_params(void* h, int k_correspondences, double max_corr_dist, 
     g->max_iterations = max_iterations; g->num_threads = num_threads > 0 ? num_threads : 1;
 }
 void orc_gicp_set_reciprocal(void* h, int on) { static_cast<FastGicp*>(h)->use_reciprocal = on != 0; }
+void orc_gicp_set_double_search(void* h, int on) { static_cast<FastGicp*>(h)->double_search = on != 0; }
 void orc_gicp_set_variant(void* h, int variant) { static_cast<FastGicp*>(h)->variant = variant; }  // 1: small_gicp formulation, 2: fast_gicp::FastVGICP
 void orc_gicp_set_resolution(void* h, double resolution) { static_cast<FastGicp*>(h)->voxel_resolution = resolution; }
 int  orc_gicp_num_voxels(void* h) { FastGicp* g = static_cast<FastGicp*>(h); double H[36], b[6], I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; g->linearize(I, H, b, nullptr); return g->num_voxels(); }
