@@ -157,6 +157,7 @@ def test_small_gicp_double_precision_search_changes_nothing_measurable():
     path) shares fast_gicp's float transform + float distances for both formulations (deviations).  The two searches can only differ
     where two target points are equidistant to float rounding or a correspondence sits on the rejection radius: SmallGicp(double_search=True) ends
     at the same float transform, with the same iteration count, on random scenes (60 / 60 and a 130k-point VLP-64 pair when this was written)."""
+    from oracle import oracle as orc
     from oracle.replay import soak_scene
 
     rng = np.random.default_rng(123)
