@@ -44,8 +44,8 @@ NdtEngine::~NdtEngine()
     cloud_arena_.release();
     grid_arena_.release();
     for (auto& e : ev_pool_) if (e) (void)hipEventDestroy(e);
-    d_grids_.release(); d_pairs_.release(); d_evals_.release(); d_partials_.release(); d_T12_.release(); d_aligned_.release(); d_states_.release(); d_plan_.release();
-    h_evals_.release(); h_results_.release(); h_states_.release(); h_info_.release(); h_plan_.release();
+    d_grids_.release(); d_pairs_.release(); d_evals_.release(); d_partials_.release(); d_T12_.release(); d_aligned_.release(); d_states_.release();
+    h_evals_.release(); h_results_.release(); h_states_.release(); h_info_.release();
 }
 
 void NdtEngine::clear()
@@ -342,12 +342,14 @@ int NdtEngine::upload_pairs()
     }
     const size_t P1 = static_cast<size_t>(std::max(P, 1));
     MRGFE_TRY(d_pairs_.ensure(sizeof(NdtPairDev) * P1));
-    MRGFE_TRY(d_evals_.ensure(sizeof(NdtEvalDev) * P1));
+    // the requests and the round's plan share one device buffer and one pinned staging buffer: the host-stepped path sends both with ONE copy per round
+    evals_bytes_ = (sizeof(NdtEvalDev) * P1 + 255) & ~size_t(255);
+    const size_t plan_bytes = sizeof(uint32_t) * ndt_plan_words(static_cast<uint32_t>(P1));
+    MRGFE_TRY(d_evals_.ensure(evals_bytes_ + plan_bytes));
     MRGFE_TRY(d_states_.ensure(sizeof(NdtCtlState) * P1));
-    MRGFE_TRY(d_plan_.ensure(sizeof(uint32_t) * ndt_plan_words(static_cast<uint32_t>(P1))));
     total_part_blocks_ = part;
     MRGFE_TRY(d_partials_.ensure(sizeof(double) * kNdtPartialStride * std::max<uint32_t>(part, 1)));  // one record per tile: enough for any tiles-per-item
-    MRGFE_TRY(h_evals_.ensure(sizeof(NdtEvalDev) * P1));
+    MRGFE_TRY(h_evals_.ensure(evals_bytes_ + plan_bytes));
     MRGFE_TRY(h_states_.ensure(sizeof(NdtCtlState) * P1));
     MRGFE_TRY(h_results_.ensure(sizeof(double) * kNdtPartialStride * P1));
     // (pageable source: staged by the runtime before the call returns — no wait, the rounds are enqueued behind the build and this copy)
@@ -450,15 +452,15 @@ int NdtEngine::enqueue_round(uint32_t round, bool device_control, const bool wan
     static const uint32_t per_cu = static_cast<uint32_t>(std::max(1, env_int("MRGFE_WG_PER_CU", 4)));
     static const uint32_t max_ppt = static_cast<uint32_t>(std::max(1, env_int("MRGFE_MAX_PPT", 8)));
     if (device_control) {
-        MRGFE_TRY(ndt_launch_plan(ctx_, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), P, d_plan_.as<uint32_t>(), static_cast<uint32_t>(ctx_->cu_count) * per_cu, max_ppt,
+        MRGFE_TRY(ndt_launch_plan(ctx_, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), P, d_plan(), static_cast<uint32_t>(ctx_->cu_count) * per_cu, max_ppt,
                                   static_cast<uint32_t>(forced_ppt_), round, h_info));
     } else {
-        // host-stepped: requests and plan go up together (pinned staging, two small copies), no plan launch
+        // host-stepped: the requests (filled by the caller in h_evals_) and the plan go up in ONE copy out of the pinned buffer, no plan launch
+        // (round 3 sent them as two copies: a copy command per round less on the single registration's critical path)
         const size_t words = ndt_plan_words(P);
-        MRGFE_TRY(h_plan_.ensure(words * 4));
         host_plan(plan_scratch_, static_cast<uint32_t>(ctx_->cu_count) * per_cu, max_ppt);
-        std::memcpy(h_plan_.p, plan_scratch_.data(), words * 4);
-        MRGFE_HIP_CHECK(hipMemcpyAsync(d_plan_.p, h_plan_.p, words * 4, hipMemcpyHostToDevice, st));
+        std::memcpy(h_evals_.as<char>() + evals_bytes_, plan_scratch_.data(), words * 4);
+        MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, h_evals_.p, evals_bytes_ + words * 4, hipMemcpyHostToDevice, st));
     }
     if (fused_launch()) {
         // every variant's items in one launch (ndt_derivatives_all_kernel); its events sit in the slots of variant 0
@@ -470,7 +472,7 @@ int NdtEngine::enqueue_round(uint32_t round, bool device_control, const bool wan
                 const NdtPlanHead* h = reinterpret_cast<const NdtPlanHead*>(plan_scratch_.data());
                 grid = std::min(grid, h->n_items[0] + h->n_items[1] + h->n_items[2]);  // the host knows the item count
             }
-            MRGFE_TRY(ndt_launch_derivatives_all(ctx_, prm_.search, grid, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_plan_.as<uint32_t>(), P,
+            MRGFE_TRY(ndt_launch_derivatives_all(ctx_, prm_.search, grid, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_plan(), P,
                                                  d_partials_.as<double>()));
             if (timed) MRGFE_HIP_CHECK(hipEventRecord(ev_pool_[size_t(round) * 6 + 1], st));
         }
@@ -482,11 +484,11 @@ int NdtEngine::enqueue_round(uint32_t round, bool device_control, const bool wan
         uint32_t grid = derivative_grid(m);
         if (!device_control) grid = std::min(grid, reinterpret_cast<const NdtPlanHead*>(plan_scratch_.data())->n_items[m]);  // the host knows the item count
         MRGFE_TRY(ndt_launch_derivatives(ctx_, m, prm_.search, grid, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(),
-                                         d_plan_.as<uint32_t>(), P, d_partials_.as<double>()));
+                                         d_plan(), P, d_partials_.as<double>()));
         if (timed) MRGFE_HIP_CHECK(hipEventRecord(ev_pool_[size_t(round) * 6 + m * 2 + 1], st));
     }
     // host control: the 384-byte result records go straight into pinned host memory (no device-to-host copy command)
-    MRGFE_TRY(ndt_launch_reduce(ctx_, P, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_partials_.as<double>(), d_plan_.as<uint32_t>(), h_results_.as<double>(),
+    MRGFE_TRY(ndt_launch_reduce(ctx_, P, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_partials_.as<double>(), d_plan(), h_results_.as<double>(),
                                 device_control ? d_states_.as<NdtCtlState>() : nullptr));
     return MRGFE_OK;
 }
@@ -569,7 +571,7 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
     const int    hc = host_control_mode();
     const bool   device_control = hc == 0 || (hc < 0 && P > 1);
     hipStream_t  st = ctx_->stream;
-    MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));
+    if (device_control) MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));  // (host control: enqueue_round sends requests + plan together)
     static const bool trace = std::getenv("MRGFE_TRACE") != nullptr;  // per-round host timings on stderr
     std::vector<NdtRoundInfo> info;
 
@@ -652,7 +654,6 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
         info.push_back(ri);
         const auto t0 = std::chrono::steady_clock::now();
         MRGFE_TRY(ensure_events(round + 1));
-        if (round) MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));
         MRGFE_TRY(enqueue_round(static_cast<uint32_t>(round), false, want, nullptr));
         MRGFE_HIP_CHECK(hipStreamSynchronize(st));
         const auto t1 = std::chrono::steady_clock::now();
@@ -693,7 +694,6 @@ int NdtEngine::evaluate(int pair, const float T[16], const double p[6], int mode
     for (int i = 0; i < P; ++i) he[i].active = 0;
     ctl::fill_eval(s, he[pair]);
     hipStream_t st = ctx_->stream;
-    MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));
     MRGFE_TRY(ensure_events(1));
     bool want[3] = {mode == 0, mode == 1, mode == 2};
     // the host-built plan lists the pairs whose controller has a request pending: lend this pair's controller the request

@@ -122,8 +122,10 @@ class NdtEngine {
     std::vector<LeafArrays> leaf_arrays_;
 
     // rounds (see align_all)
-    DevBuf d_states_, d_plan_;            // NdtCtlState[P] (device control), the round's plan
-    PinBuf h_states_, h_info_, h_plan_;   // staging of the states, NdtRoundInfo per round (written by the plan kernel), host-built plan
+    DevBuf d_states_;                     // NdtCtlState[P] (device control)
+    PinBuf h_states_, h_info_;            // staging of the states, NdtRoundInfo per round (written by the plan kernel)
+    size_t evals_bytes_ = 0;              // the round's plan lives behind the requests in d_evals_ / h_evals_ (one copy per host-stepped round)
+    uint32_t* d_plan() const { return reinterpret_cast<uint32_t*>(d_evals_.as<char>() + evals_bytes_); }
     std::vector<uint32_t> plan_scratch_;
     void host_plan(std::vector<uint32_t>& plan, uint32_t wg_target, uint32_t max_ppt) const;
     std::vector<hipEvent_t> ev_pool_;     // [round][variant][begin, end]
