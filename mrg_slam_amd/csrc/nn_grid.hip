@@ -523,12 +523,11 @@ int NnGridSet::build(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32
     if (total > 0x7fffffffu) { set_error("NnGridSet: %llu points in one set", static_cast<unsigned long long>(total)); return MRGFE_ERR_INVALID; }
     SliceTable tab;
     tab.build(n, count);
-    // descriptors: [point slices][cell slices][cloud pointers][NnBuildDev]
+    // descriptors: [point slices][cloud pointers][NnBuildDev]
     DevBuf& ds = ctx->scratch[0];
-    const size_t at_cs = sizeof(Slice) * M, at_ptr = 2 * sizeof(Slice) * M, at_dev = (at_ptr + sizeof(void*) * M + 15) & ~size_t(15);
+    const size_t at_ptr = sizeof(Slice) * M, at_dev = (at_ptr + sizeof(void*) * M + 15) & ~size_t(15);
     MRGFE_TRY(ds.ensure(at_dev + sizeof(NnBuildDev) * M));
     const Slice*      d_slices = ds.as<Slice>();
-    const Slice*      d_cslices = reinterpret_cast<const Slice*>(ds.as<char>() + at_cs);
     const NnBuildDev* d_dev = reinterpret_cast<const NnBuildDev*>(ds.as<char>() + at_dev);
     MRGFE_HIP_CHECK(hipMemcpyAsync(ds.p, tab.h.data(), sizeof(Slice) * M, hipMemcpyHostToDevice, st));
     MRGFE_HIP_CHECK(hipMemcpyAsync(ds.as<char>() + at_ptr, d_clouds, sizeof(void*) * M, hipMemcpyHostToDevice, st));
@@ -540,7 +539,7 @@ int NnGridSet::build(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32
     std::vector<BBox> bb(M);
     MRGFE_HIP_CHECK(hipMemcpyAsync(bb.data(), d_out, sizeof(BBox) * M, hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
-    DevBuf &dk = ctx->scratch[2], &dv = ctx->scratch[3], &dkt = ctx->scratch[4], &dvt = ctx->scratch[5], &dh = ctx->scratch[6], &dblk = ctx->scratch[8];
+    DevBuf &dk = ctx->scratch[2], &dv = ctx->scratch[3], &dkt = ctx->scratch[4], &dvt = ctx->scratch[5], &dh = ctx->scratch[6];
     const size_t ne = std::max<size_t>(tab.total_elems, 4);
     MRGFE_TRY(dk.ensure(ne * 4)); MRGFE_TRY(dv.ensure(ne * 4)); MRGFE_TRY(dkt.ensure(ne * 4)); MRGFE_TRY(dvt.ensure(ne * 4));
     MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + M)));
@@ -660,7 +659,7 @@ int NnGridSet::build(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32
         uint32_t *sk = nullptr, *sv = nullptr;
         if (tab.max_blks) MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), d_slices, tab, key_bits, dh.as<uint32_t>(), &sk, &sv, true));
         // cell tables, brick words, sorted points and crowding figures of all members from their sorted (key, index) pairs in one launch
-        (void)d_cslices; (void)dblk; (void)max_cells;
+        (void)max_cells;
         if (tab.max_blks) hipLaunchKernelGGL(nn_fill_many_kernel, dim3(tab.max_blks * (kTile / 256) + 1, count), dim3(256), 0, st, d_dev, sk, sv, level == 0 ? 1 : 0);
         if (tab.max_blks && any_long) hipLaunchKernelGGL(nn_fill_long_many_kernel, dim3(kFillLongBlocks / 4, count), dim3(256), 0, st, d_dev);
         if (level == 0) {  // only the finest level is searched through the pyramid
