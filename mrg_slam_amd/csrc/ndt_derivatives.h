@@ -21,7 +21,7 @@ int ndt_launch_derivatives_all(mrgfe_ctx* ctx, int search, uint32_t grid, const 
 // fixed-order sum of the item partials of every pending evaluation.  d_states != NULL: followed by the controller step on the
 // device (next request written to d_evals).  d_states == NULL: results[pair][48] = {score, g[6], H[36] row-major, neighbours, pad}
 int ndt_launch_reduce(mrgfe_ctx* ctx, uint32_t P, const NdtPairDev* d_pairs, NdtEvalDev* d_evals, const double* d_partials, const uint32_t* d_plan, double* d_results,
-                      NdtCtlState* d_states);
+                      NdtCtlState* d_states, double tag = 0.0);  // tag != 0 and P == 1: stored at d_results[48] once the record is visible to the host
 // diagnostic: ctl::pose_to_matrix / angle_tables / svd_solve6 for n cases of 48 doubles (p[6], A[36], b[6]) on the device
 int ndt_ctl_math_device(mrgfe_ctx* ctx, const double* d_in, int n, float* d_M, double* d_tables, double* d_x);
 // diagnostic: n_vals (44, 37 or 1) doubles per lane and wavefront, summed by wave_sum_fold and by wave_sum (dev_utils.h)

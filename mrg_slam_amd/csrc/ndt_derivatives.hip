@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256) void ndt_plan_kernel(const NdtPairDev* __restr
 //   CONTROL = false: the sums go to `results` (pinned host memory) for the host-stepped controller.
 template <bool CONTROL>
 __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __restrict__ pairs, NdtEvalDev* __restrict__ evals, const double* __restrict__ partials,
-                                                          const uint32_t* __restrict__ plan, double* __restrict__ results, NdtCtlState* __restrict__ states)
+                                                          const uint32_t* __restrict__ plan, double* __restrict__ results, NdtCtlState* __restrict__ states, double tag)
 {
     const NdtPairDev pr = pairs[blockIdx.x];
     const NdtEvalDev& ev = evals[blockIdx.x];
@@ -686,7 +686,18 @@ __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __res
         if (CONTROL) s_r[threadIdx.x] = r;
         else         results[(size_t)blockIdx.x * kNdtPartialStride + threadIdx.x] = r;
     }
-    if (!CONTROL) return;
+    if (!CONTROL) {
+        // a single registration polls for its record instead of waiting for the stream: the slot behind the records gets `tag` once they are visible
+        // (one workgroup per pair: only a launch of ONE pair may be asked for a tag)
+        if (tag != 0.0) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __threadfence_system();
+                __hip_atomic_store(&results[(size_t)gridDim.x * kNdtPartialStride], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
     // stage the state in LDS (coalesced), step it on one lane, write it and the next request back
     constexpr int kWords = sizeof(NdtCtlState) / 8;
     static_assert(sizeof(NdtCtlState) % 8 == 0, "state is copied as 8-byte words");
@@ -902,11 +913,11 @@ int ndt_launch_derivatives(mrgfe_ctx* ctx, int mode, int search, uint32_t grid, 
 }
 
 int ndt_launch_reduce(mrgfe_ctx* ctx, uint32_t P, const NdtPairDev* d_pairs, NdtEvalDev* d_evals, const double* d_partials, const uint32_t* d_plan, double* d_results,
-                      NdtCtlState* d_states)
+                      NdtCtlState* d_states, double tag)
 {
     if (P == 0) return MRGFE_OK;
-    if (d_states) hipLaunchKernelGGL((ndt_reduce_kernel<true>), dim3(P), dim3(256), 0, ctx->stream, d_pairs, d_evals, d_partials, d_plan, d_results, d_states);
-    else          hipLaunchKernelGGL((ndt_reduce_kernel<false>), dim3(P), dim3(256), 0, ctx->stream, d_pairs, d_evals, d_partials, d_plan, d_results, d_states);
+    if (d_states) hipLaunchKernelGGL((ndt_reduce_kernel<true>), dim3(P), dim3(256), 0, ctx->stream, d_pairs, d_evals, d_partials, d_plan, d_results, d_states, 0.0);
+    else          hipLaunchKernelGGL((ndt_reduce_kernel<false>), dim3(P), dim3(256), 0, ctx->stream, d_pairs, d_evals, d_partials, d_plan, d_results, d_states, P == 1 ? tag : 0.0);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }

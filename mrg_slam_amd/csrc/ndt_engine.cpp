@@ -351,7 +351,7 @@ int NdtEngine::upload_pairs()
     MRGFE_TRY(d_partials_.ensure(sizeof(double) * kNdtPartialStride * std::max<uint32_t>(part, 1)));  // one record per tile: enough for any tiles-per-item
     MRGFE_TRY(h_evals_.ensure(evals_bytes_ + plan_bytes));
     MRGFE_TRY(h_states_.ensure(sizeof(NdtCtlState) * P1));
-    MRGFE_TRY(h_results_.ensure(sizeof(double) * kNdtPartialStride * P1));
+    MRGFE_TRY(h_results_.ensure(sizeof(double) * (kNdtPartialStride * P1 + 1)));  // (+1: the tag a single registration polls for)
     // (pageable source: staged by the runtime before the call returns — no wait, the rounds are enqueued behind the build and this copy)
     if (P) MRGFE_HIP_CHECK(hipMemcpyAsync(d_pairs_.p, h_pairs_.data(), sizeof(NdtPairDev) * P, hipMemcpyHostToDevice, ctx_->stream));
     pairs_dirty_ = false;
@@ -445,7 +445,7 @@ void NdtEngine::host_plan(std::vector<uint32_t>& plan, uint32_t wg_target, uint3
     std::memcpy(plan.data(), &h, sizeof(h));
 }
 
-int NdtEngine::enqueue_round(uint32_t round, bool device_control, const bool want_mode[3], NdtRoundInfo* h_info)
+int NdtEngine::enqueue_round(uint32_t round, bool device_control, const bool want_mode[3], NdtRoundInfo* h_info, double result_tag)
 {
     hipStream_t st = ctx_->stream;
     const uint32_t P = static_cast<uint32_t>(n_pairs());
@@ -489,8 +489,28 @@ int NdtEngine::enqueue_round(uint32_t round, bool device_control, const bool wan
     }
     // host control: the 384-byte result records go straight into pinned host memory (no device-to-host copy command)
     MRGFE_TRY(ndt_launch_reduce(ctx_, P, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_partials_.as<double>(), d_plan(), h_results_.as<double>(),
-                                device_control ? d_states_.as<NdtCtlState>() : nullptr));
+                                device_control ? d_states_.as<NdtCtlState>() : nullptr, result_tag));
     return MRGFE_OK;
+}
+
+// the reduction's tag store is the last thing a host-stepped round of ONE registration does: seeing it = the record is complete
+static int wait_result_tag(hipStream_t st, const volatile double* h_tag, double tag)
+{
+    uint64_t want;
+    std::memcpy(&want, &tag, sizeof(want));
+    const volatile uint64_t* p = reinterpret_cast<const volatile uint64_t*>(h_tag);
+    for (uint32_t spin = 0;; ++spin) {
+        if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == want) return MRGFE_OK;
+        if ((spin & 0x3ff) == 0x3ff) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) {  // everything queued has run: the record is there, or never will be
+                if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == want) return MRGFE_OK;
+                set_error("NDT: the reduction did not report");
+                return MRGFE_ERR_HIP;
+            }
+            if (q != hipErrorNotReady) { set_error("NDT: %s", hipGetErrorString(q)); return MRGFE_ERR_HIP; }
+        }
+    }
 }
 
 void NdtEngine::account(const std::vector<NdtRoundInfo>& info, size_t rounds)
@@ -654,8 +674,17 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
         info.push_back(ri);
         const auto t0 = std::chrono::steady_clock::now();
         MRGFE_TRY(ensure_events(round + 1));
-        MRGFE_TRY(enqueue_round(static_cast<uint32_t>(round), false, want, nullptr));
-        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+        if (P == 1) {
+            // a single registration: the reduction writes `tag` behind its record in pinned memory and the host polls for it (a stream wait
+            // costs ~10 us more per round than seeing the store)
+            const double tag = static_cast<double>(++result_tag_);
+            const_cast<double*>(hr)[kNdtPartialStride] = 0.0;
+            MRGFE_TRY(enqueue_round(static_cast<uint32_t>(round), false, want, nullptr, tag));
+            MRGFE_TRY(wait_result_tag(st, hr + kNdtPartialStride, tag));
+        } else {
+            MRGFE_TRY(enqueue_round(static_cast<uint32_t>(round), false, want, nullptr));
+            MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+        }
         const auto t1 = std::chrono::steady_clock::now();
         // controller steps are independent per pair: spread them over the host worker threads for large batches
         host_parallel_for(P, kHostParallelMinPairs, [&](int b, int e) {

@@ -130,11 +130,12 @@ class NdtEngine {
     void host_plan(std::vector<uint32_t>& plan, uint32_t wg_target, uint32_t max_ppt) const;
     std::vector<hipEvent_t> ev_pool_;     // [round][variant][begin, end]
     int    rounds_ = 0;
+    uint64_t result_tag_ = 0;  // host-stepped single registration: the value its next reduction stores behind the record
     std::vector<NdtRoundInfo> round_info_;  // busy pairs per kind of every round of the last align_all
     int upload_pairs();
     int ensure_events(size_t rounds);
     uint32_t derivative_grid(int mode) const;
-    int enqueue_round(uint32_t round, bool device_control, const bool want_mode[3], NdtRoundInfo* h_info);
+    int enqueue_round(uint32_t round, bool device_control, const bool want_mode[3], NdtRoundInfo* h_info, double result_tag = 0.0);
     void account(const std::vector<NdtRoundInfo>& info, size_t rounds);
 };
 
