@@ -1737,7 +1737,8 @@ int nn_nearest_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     if (max_n == 0) return MRGFE_OK;
     // One or a few clouds do not fill the chip with a lane per query (130k queries: 507 workgroups in the block pass, two wavefronts per SIMD
     // working through dependent loads): eight lanes per query then (161 -> 85 us).  (The sweep stays as it is: 64-query tiles made it slower,
-    // 244 -> 312 us per 130k-query cloud — a launch lasts as long as its widest tile either way.)
+    // 244 -> 312 us per 130k-query cloud — a launch lasts as long as its widest tile either way; round 4, a rank's shard of 32 pairs: 2.28 ms of
+    // fitness passes with tiles of 256, 2.46 with 128, 2.56 with 64.)
     const bool     small = total < kFitSmallTotal;
     const uint32_t per_blk = small ? 256u / 8u : 256u / kBlockGroup;
     const uint32_t want = static_cast<uint32_t>(std::max<size_t>(1, (size_t(ctx->cu_count) * 128 + count - 1) / count));
