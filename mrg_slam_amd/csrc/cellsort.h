@@ -39,6 +39,9 @@ struct BBox {  // result of bounding_boxes, one per problem (32 bytes)
 // d_partial needs total_blks BBox entries; d_out nprob entries.
 int bounding_boxes(mrgfe_ctx* ctx, const float4* const* d_clouds, const Slice* d_slices, const SliceTable& t, BBox* d_partial, BBox* d_out);
 
+// the first half of bounding_boxes only: one box per 2048-point tile in d_partial (a consumer that merges them itself: bbox_device.h)
+int bounding_box_partials(mrgfe_ctx* ctx, const float4* const* d_clouds, const Slice* d_slices, const SliceTable& t, BBox* d_partial);
+
 // stable LSD radix sort by the low `key_bits` bits. Buffers ping-pong; *out_keys/*out_vals point at the sorted data
 // (either the input or the tmp buffers). d_hist needs (total_blks + nprob) * 256 words.
 // `iota_vals`: the values are the element indices 0 .. n-1 of each problem and d_vals need not be filled (the first pass makes them up);
@@ -49,6 +52,11 @@ int radix_sort_pairs(mrgfe_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, uint32_
 
 // exclusive prefix sum of uint32 per problem; d_totals[p] = sum. d_blk needs total_blks words. in == out allowed.
 int exclusive_scan(mrgfe_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, const Slice* d_slices, const SliceTable& t, uint32_t* d_blk, uint32_t* d_totals);
+
+// the first step of exclusive_scan only: d_blk[tile] = sum of the tile's 2048 elements (a consumer that adds up the tiles before its own itself)
+int tile_sums(mrgfe_ctx* ctx, const uint32_t* d_in, const Slice* d_slices, const SliceTable& t, uint32_t* d_blk);
+// the first step of exclusive_scan_run_heads only: d_blk[tile] = run heads in the tile
+int run_head_tile_counts(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, const Slice* d_slices, const SliceTable& t, const uint32_t* d_n_valid, uint32_t* d_blk);
 
 // run heads of a sorted key array: element i starts a run of equal keys among the first d_n_valid[p] elements of problem p (the invalid
 // keys sort behind them).  d_out[i] = number of run heads before element i (the ordinal of i's run when i is a head), d_totals[p] = runs.

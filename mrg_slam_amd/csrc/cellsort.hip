@@ -105,6 +105,14 @@ __global__ __launch_bounds__(256) void bbox_final_kernel(const Slice* __restrict
     }
 }
 
+int bounding_box_partials(mrgfe_ctx* ctx, const float4* const* d_clouds, const Slice* d_slices, const SliceTable& t, BBox* d_partial)
+{
+    if (t.nprob() == 0 || t.max_blks == 0) return MRGFE_OK;
+    hipLaunchKernelGGL(bbox_partial_kernel, dim3(t.max_blks, t.nprob()), dim3(256), 0, ctx->stream, d_clouds, d_slices, d_partial);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
 int bounding_boxes(mrgfe_ctx* ctx, const float4* const* d_clouds, const Slice* d_slices, const SliceTable& t, BBox* d_partial, BBox* d_out)
 {
     if (t.nprob() == 0) return MRGFE_OK;
@@ -178,10 +186,14 @@ __global__ __launch_bounds__(256) void rs_scan_kernel(const Slice* __restrict__ 
     digit_base[(size_t)blockIdx.x * 256 + threadIdx.x] = base;
 }
 
+constexpr uint32_t kOwnScanBlks = 512;  // tiles of a sort (all its problems) up to which the scatter kernel does the scan of the histograms as well
 // pass 3: stable scatter. The tile is consumed in 8 rounds of 256 keys; inside a round the rank of a key among equal
 // digits is (keys of earlier rounds) + (keys of earlier waves) + (lower lanes of its own wave, by ballot matching).
 // kIota: the values are the element indices 0 .. n-1 of the problem (first pass of a sort of (key, index) pairs: nobody has to write or read them)
-template <bool kIota>
+// kOwnScan (a sort of a few tiles, bound by its launches): `hist` holds the tiles' COUNTS as rs_hist_kernel left them and every workgroup adds up
+// column d over the tiles before its own and over all of them itself — rs_scan_kernel's work, 64 KB of L2 reads per workgroup of a 130k-key
+// sort instead of a launch per pass.
+template <bool kIota, bool kOwnScan>
 __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t* __restrict__ keys_out,
                                                           uint32_t* __restrict__ vals_out, const Slice* __restrict__ slices, const uint32_t* __restrict__ hist,
                                                           const uint32_t* __restrict__ digit_base, int shift)
@@ -191,7 +203,27 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint32_t* __restr
     __shared__ uint32_t goff[256];        // global offset of this tile's first key of each digit
     __shared__ uint32_t seen[256];        // keys of each digit consumed in earlier rounds
     __shared__ uint32_t wcount[4][256];   // per-wave digit counts of the current round
-    goff[threadIdx.x] = digit_base[(size_t)blockIdx.y * 256 + threadIdx.x] + hist[(size_t)(s.blk_off + blockIdx.x) * 256 + threadIdx.x];
+    if (kOwnScan) {
+        __shared__ uint32_t lds[8];
+        const uint32_t* col = hist + (size_t)s.blk_off * 256 + threadIdx.x;
+        uint32_t before = 0, total = 0, b = 0;
+        for (; b + 16 <= s.nblk; b += 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = col[(size_t)(b + u) * 256];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { total += v[u]; before += b + u < blockIdx.x ? v[u] : 0u; }
+        }
+        for (; b < s.nblk; ++b) {
+            const uint32_t v = col[(size_t)b * 256];
+            total += v;
+            before += b < blockIdx.x ? v : 0u;
+        }
+        uint32_t all;
+        goff[threadIdx.x] = block_exclusive_scan<256>(total, lds, &all) + before;
+    } else {
+        goff[threadIdx.x] = digit_base[(size_t)blockIdx.y * 256 + threadIdx.x] + hist[(size_t)(s.blk_off + blockIdx.x) * 256 + threadIdx.x];
+    }
     seen[threadIdx.x] = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) wcount[w][threadIdx.x] = 0;
@@ -238,12 +270,20 @@ int radix_sort_pairs(mrgfe_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, uint32_
     uint32_t* digit_base = d_hist + (size_t)t.total_blks * 256;
     uint32_t *ki = d_keys, *vi = d_vals, *ko = d_keys_tmp, *vo = d_vals_tmp;
     dim3 grid(t.max_blks, t.nprob());
+    // a sort of a few hundred tiles lasts as long as its launches: the scatter kernel scans the tile histograms itself (see rs_scatter_kernel)
+    static const uint32_t own_scan_blks = [] { const char* e = std::getenv("MRGFE_SORT_OWN_SCAN_BLKS"); return e ? static_cast<uint32_t>(std::atoi(e)) : kOwnScanBlks; }();
+    const bool own_scan = t.total_blks <= own_scan_blks && t.max_blks <= 1024;
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
         if (!(p == 0 && first_hist_ready)) hipLaunchKernelGGL(rs_hist_kernel, grid, dim3(256), 0, ctx->stream, ki, d_slices, d_hist, shift);
-        hipLaunchKernelGGL(rs_scan_kernel, dim3(t.nprob()), dim3(256), 0, ctx->stream, d_slices, d_hist, digit_base);
-        if (p == 0 && iota_vals) hipLaunchKernelGGL(rs_scatter_kernel<true>, grid, dim3(256), 0, ctx->stream, ki, vi, ko, vo, d_slices, d_hist, digit_base, shift);
-        else                     hipLaunchKernelGGL(rs_scatter_kernel<false>, grid, dim3(256), 0, ctx->stream, ki, vi, ko, vo, d_slices, d_hist, digit_base, shift);
+        if (own_scan) {
+            if (p == 0 && iota_vals) hipLaunchKernelGGL((rs_scatter_kernel<true, true>), grid, dim3(256), 0, ctx->stream, ki, vi, ko, vo, d_slices, d_hist, digit_base, shift);
+            else                     hipLaunchKernelGGL((rs_scatter_kernel<false, true>), grid, dim3(256), 0, ctx->stream, ki, vi, ko, vo, d_slices, d_hist, digit_base, shift);
+        } else {
+            hipLaunchKernelGGL(rs_scan_kernel, dim3(t.nprob()), dim3(256), 0, ctx->stream, d_slices, d_hist, digit_base);
+            if (p == 0 && iota_vals) hipLaunchKernelGGL((rs_scatter_kernel<true, false>), grid, dim3(256), 0, ctx->stream, ki, vi, ko, vo, d_slices, d_hist, digit_base, shift);
+            else                     hipLaunchKernelGGL((rs_scatter_kernel<false, false>), grid, dim3(256), 0, ctx->stream, ki, vi, ko, vo, d_slices, d_hist, digit_base, shift);
+        }
         uint32_t* tk = ki; ki = ko; ko = tk;
         uint32_t* tv = vi; vi = vo; vo = tv;
     }
@@ -373,6 +413,22 @@ __global__ __launch_bounds__(256) void scan_heads_apply_kernel(const uint32_t* _
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         if (first + k < s.n) out[s.off + first + k] = v[k] + pre;
+}
+
+int run_head_tile_counts(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, const Slice* d_slices, const SliceTable& t, const uint32_t* d_n_valid, uint32_t* d_blk)
+{
+    if (t.nprob() == 0 || t.max_blks == 0) return MRGFE_OK;
+    hipLaunchKernelGGL(scan_heads_tile_sum_kernel, dim3(t.max_blks, t.nprob()), dim3(256), 0, ctx->stream, d_sorted_keys, d_slices, d_n_valid, d_blk);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
+int tile_sums(mrgfe_ctx* ctx, const uint32_t* d_in, const Slice* d_slices, const SliceTable& t, uint32_t* d_blk)
+{
+    if (t.nprob() == 0 || t.max_blks == 0) return MRGFE_OK;
+    hipLaunchKernelGGL(scan_tile_sum_kernel, dim3(t.max_blks, t.nprob()), dim3(256), 0, ctx->stream, d_in, d_slices, d_blk);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
 }
 
 int exclusive_scan_run_heads(mrgfe_ctx* ctx, const uint32_t* d_sorted_keys, uint32_t* d_out, const Slice* d_slices, const SliceTable& t, const uint32_t* d_n_valid, uint32_t* d_blk,

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include "bbox_device.h"
 #include "cellsort.h"
 #include "dev_float.h"
 #include "dev_utils.h"
@@ -453,6 +454,7 @@ struct PfState {
     uint32_t    counts[6];  // after the distance filter, finite among them, voxels, after the voxel grid, after the radius filter
     uint32_t    anomaly;
     uint32_t    pad1;
+    uint32_t    bb_n[2];    // partial bounding boxes (one per tile of the producer's INPUT) of the cloud the voxel grid / the radius filter reads
 };
 constexpr uint32_t kPfAnomalyEmpty = 1u, kPfAnomalyOverflow = 2u, kPfAnomalyNoVoxel = 4u;
 
@@ -462,39 +464,133 @@ __device__ __forceinline__ Slice pf_slice(uint32_t n)
     s.n = n; s.off = 0; s.blk_off = 0; s.nblk = (n + kTile - 1) / kTile;
     return s;
 }
-__global__ void pf_init_kernel(PfState* __restrict__ st, const float4* cp0, const float4* cp1, uint32_t n_in)
+__device__ __forceinline__ void pf_state_init(PfState* __restrict__ st, const float4* cp0, const float4* cp1, uint32_t n_in)
 {
-    if (threadIdx.x || blockIdx.x) return;
     PfState s;
     memset(&s, 0, sizeof(s));
     s.cp[0] = cp0;
     s.cp[1] = cp1;
     s.sl_in = pf_slice(n_in);
     s.counts[0] = n_in;
+    s.bb_n[0] = s.sl_in.nblk;
     *st = s;
 }
-// which 0: the distance filter's kept count -> sl_in; which 1: the voxel grid's kept count -> sl_rad; which 2: the radius filter's -> counts[4] and the
-// host's status words
-__global__ void pf_count_kernel(PfState* __restrict__ st, const uint32_t* __restrict__ count, int which, uint32_t* __restrict__ h_status)
+__global__ void pf_init_kernel(PfState* __restrict__ st, const float4* cp0, const float4* cp1, uint32_t n_in)
 {
     if (threadIdx.x || blockIdx.x) return;
-    const uint32_t c = *count;
-    if (which == 0) { st->sl_in = pf_slice(c); st->counts[0] = c; }
-    else if (which == 1) { st->sl_rad = pf_slice(c); st->counts[3] = c; }
-    else {
-        st->counts[4] = c;
-        for (int k = 0; k < 5; ++k) h_status[k] = st->counts[k];
-        h_status[5] = st->anomaly;
-        __threadfence_system();
-        h_status[6] = 0x600df00du;  // written last: the record is complete
+    pf_state_init(st, cp0, cp1, n_in);
+}
+// The distance filter of the chain: flags of a tile of 2048 points and the tile's count of kept points (what scan_tile_sum_kernel would
+// count in a launch of its own); workgroup 0 starts the chain's state first.
+__global__ __launch_bounds__(256) void pf_distance_tiles_kernel(const float4* __restrict__ in, uint32_t n, double near_t, double far_t, uint32_t* __restrict__ flags,
+                                                                 uint32_t* __restrict__ blk, PfState* __restrict__ st, const float4* cp0, const float4* cp1)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) pf_state_init(st, cp0, cp1, n);
+    const uint32_t base = blockIdx.x * kTile;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kTile / 256; ++k) {
+        const uint32_t i = base + k * 256 + threadIdx.x;
+        if (i < n) {
+            const float4 p = in[i];
+            // (distance_flags_kernel's test)
+            const float  s = dot3f(p.x, p.x, p.y, p.y, p.z, p.z);
+            const double d = static_cast<double>(sqrtf(s));
+            const uint32_t f = (d > near_t && d < far_t) ? 1u : 0u;
+            flags[i] = f;
+            cnt += f;
+        }
+    }
+    __shared__ uint32_t sw[4];
+    cnt = wave_sum(cnt);
+    if (lane_id() == 0) sw[wave_id()] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
+}
+// Order-preserving compaction of the chain in ONE launch behind the tile counts: a workgroup adds up the counts of the tiles before its own
+// (and of all tiles) itself, ranks its tile's kept elements by ballots and moves them; workgroup 0 records the kept count in the chain's state, and (kWhich 0 and 1) every workgroup leaves the bounding box of what it kept for the stage that reads the output — the
+// exclusive scan (three launches), the compaction, the count and the bounding-box pass were six launches.
+//   kWhich 0: the distance filter (n known to the host)      -> sl_in,  counts[0], boxes for the voxel grid
+//   kWhich 1: the voxel grid's centroids (n = sl_vox.n)       -> sl_rad, counts[3], boxes for the radius filter's grid
+//   kWhich 2: the radius filter (n = sl_rad.n)               -> counts[4] and the host's status words
+template <int kWhich>
+__global__ __launch_bounds__(256) void pf_compact_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ blk, uint32_t n_host,
+                                                          float4* __restrict__ out, PfState* st, uint32_t* __restrict__ h_status, BBox* __restrict__ partial)
+{
+    const uint32_t n = kWhich == 0 ? n_host : (kWhich == 1 ? st->sl_vox.n : st->sl_rad.n);
+    const uint32_t nblk = (n + kTile - 1) / kTile;
+    if (blockIdx.x >= nblk && blockIdx.x != 0) return;  // (workgroup 0 reports the count of an empty input too)
+    __shared__ uint32_t s_red[2][4];
+    __shared__ uint32_t s_cnt[kTile / 256][4], s_off[kTile / 256][4];
+    uint32_t before = 0, total = 0;
+    for (uint32_t b = threadIdx.x; b < nblk; b += 256) {
+        const uint32_t v = blk[b];
+        total += v;
+        before += b < blockIdx.x ? v : 0u;
+    }
+    before = wave_sum(before);
+    total = wave_sum(total);
+    const int lane = lane_id(), w = wave_id();
+    if (lane == 0) { s_red[0][w] = before; s_red[1][w] = total; }
+    __syncthreads();
+    before = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    total = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (kWhich == 0) { st->sl_in = pf_slice(total); st->counts[0] = total; st->bb_n[0] = nblk; }
+        else if (kWhich == 1) { st->sl_rad = pf_slice(total); st->counts[3] = total; st->bb_n[1] = nblk; }
+        else {
+            st->counts[4] = total;
+            for (int k = 0; k < 5; ++k) h_status[k] = st->counts[k];
+            h_status[5] = st->anomaly;
+            __threadfence_system();
+            h_status[6] = 0x600df00du;  // written last: the record is complete (the host reads it behind its one wait for the stream)
+        }
+    }
+    if (blockIdx.x >= nblk) return;
+    // rank of a kept element = kept elements of earlier rounds and wavefronts of the tile + kept lanes below its own
+    const uint32_t base = blockIdx.x * kTile;
+    uint32_t f[kTile / 256], lr[kTile / 256];
+#pragma unroll
+    for (int k = 0; k < kTile / 256; ++k) {
+        const uint32_t i = base + k * 256 + threadIdx.x;
+        f[k] = i < n ? flags[i] : 0u;
+        const uint64_t m = __ballot(f[k] != 0u);
+        lr[k] = static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+        if (lane == 0) s_cnt[k][w] = static_cast<uint32_t>(__popcll(m));
+    }
+    __syncthreads();
+    if (threadIdx.x < (kTile / 256) * 4) {  // 32 lanes of wavefront 0: exclusive prefix in (round, wavefront) order
+        const uint32_t v = s_cnt[threadIdx.x / 4][threadIdx.x % 4];
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < (kTile / 256) * 4; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, kWave);
+            if (lane >= off) incl += t;
+        }
+        s_off[threadIdx.x / 4][threadIdx.x % 4] = incl - v;
+    }
+    __syncthreads();
+    BoxAcc acc;
+    acc.init();
+#pragma unroll
+    for (int k = 0; k < kTile / 256; ++k) {
+        if (f[k]) {
+            const float4 p = in[base + k * 256 + threadIdx.x];
+            out[before + s_off[k][w] + lr[k]] = p;
+            if (kWhich != 2) acc.add(p);
+        }
+    }
+    if (kWhich != 2) {
+        const BBox b = block_merge_box(acc);
+        if (threadIdx.x == 0) partial[blockIdx.x] = b;
     }
 }
 // voxel_params_from_bbox (ndt_engine.cpp) on the device, float for float
-__global__ void pf_voxel_params_kernel(PfState* __restrict__ st, const BBox* __restrict__ bbox, float leaf)
+__global__ __launch_bounds__(256) void pf_voxel_params_kernel(PfState* __restrict__ st, const BBox* __restrict__ partial, float leaf)
 {
 #pragma clang fp contract(off)
-    if (threadIdx.x || blockIdx.x) return;
-    const BBox bb = *bbox;
+    const BBox bb = block_merge_partials(partial, st->bb_n[0]);  // (the boxes the producer of the cloud left, one per tile of its input)
+    if (threadIdx.x) return;
     st->counts[1] = bb.n_finite;
     VoxelParams vp;
     memset(&vp, 0, sizeof(vp));
@@ -522,10 +618,22 @@ __global__ void pf_voxel_params_kernel(PfState* __restrict__ st, const BBox* __r
     st->vp = vp;
     st->nv = bb.n_finite;
 }
-__global__ void pf_leaves_kernel(PfState* __restrict__ st, const uint32_t* __restrict__ n_runs)
+// blk: the tiles' run-head counts (run_head_tile_counts) -> their exclusive prefix, in place (scan_tiles_kernel's work), and the run count into the state
+__global__ __launch_bounds__(256) void pf_leaves_kernel(PfState* __restrict__ st, uint32_t* __restrict__ blk)
 {
-    if (threadIdx.x || blockIdx.x) return;
-    const uint32_t V = st->anomaly ? 0u : *n_runs;
+    __shared__ uint32_t lds[8];
+    const uint32_t nblk = st->sl_in.nblk;
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += 256) {
+        const uint32_t b = b0 + threadIdx.x;
+        const uint32_t v = b < nblk ? blk[b] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan<256>(v, lds, &total);
+        if (b < nblk) blk[b] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x) return;
+    const uint32_t V = st->anomaly ? 0u : carry;
     LeafSlice ls;
     memset(&ls, 0, sizeof(ls));
     ls.n_leaves = V;
@@ -551,13 +659,6 @@ __global__ __launch_bounds__(256) void voxel_centroid_dd_kernel(const float4* __
     centroids[s] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
     keep[s] = (e - b) >= static_cast<uint32_t>(min_pts) ? 1u : 0u;
 }
-__global__ __launch_bounds__(256) void compact_dd_kernel(const float4* __restrict__ in, const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos, const Slice* __restrict__ sl,
-                                                          float4* __restrict__ out)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < sl->n && flags[i]) out[pos[i]] = in[i];
-}
-
 // 1 (default): the usual chain keeps its counts on the device; 0: always the host-driven chain of round 3 (MRGFE_PREFILTER_HOST_DRIVEN=1, tests)
 static std::atomic<int> g_pf_device_driven{-1};
 static int prefilter_device_driven_mode()
@@ -592,7 +693,7 @@ static int filter_chain_device_driven(mrgfe_ctx* ctx, const PrefilterChain& ch, 
     uint32_t* h_status = ctx->pf_status.as<uint32_t>();
     h_status[6] = 0;
     DevBuf &dbb = ctx->scratch[1], &dk = ctx->scratch[2], &dv = ctx->scratch[3], &dkt = ctx->scratch[4], &dvt = ctx->scratch[5], &dh = ctx->scratch[6], &dfl = ctx->scratch[7],
-           &dblk = ctx->scratch[8], &dseg = ctx->scratch[9], &dcent = ctx->scratch[10], &dkeep = ctx->scratch[11], &dpos = ctx->scratch[12];
+           &dblk = ctx->scratch[8], &dseg = ctx->scratch[9], &dcent = ctx->scratch[10], &dkeep = ctx->scratch[11];
     MRGFE_TRY(dbb.ensure(sizeof(BBox) * (tab.total_blks + 2)));
     MRGFE_TRY(dk.ensure(size_t(n) * 4)); MRGFE_TRY(dv.ensure(size_t(n) * 4)); MRGFE_TRY(dkt.ensure(size_t(n) * 4)); MRGFE_TRY(dvt.ensure(size_t(n) * 4));
     MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + 1)));
@@ -601,46 +702,41 @@ static int filter_chain_device_driven(mrgfe_ctx* ctx, const PrefilterChain& ch, 
     MRGFE_TRY(dseg.ensure(sizeof(uint32_t) * (size_t(n) + 4) + sizeof(int32_t) * size_t(n)));
     MRGFE_TRY(dcent.ensure(sizeof(float4) * size_t(n)));
     MRGFE_TRY(dkeep.ensure(sizeof(uint32_t) * size_t(n)));
-    MRGFE_TRY(dpos.ensure(sizeof(uint32_t) * size_t(n)));
     const dim3 g256((n + 255) / 256), b256(256);
-    uint32_t*  d_tot = dblk.as<uint32_t>() + tab.total_blks;
-    BBox*      d_part = dbb.as<BBox>();
-    BBox*      d_bbo = d_part + tab.total_blks;
-    // ---- distance filter: flags, scan, compaction into the work buffer; the count stays in d_tot
+    BBox*      d_part = dbb.as<BBox>();  // one box per tile of the stage that made the cloud
+    // ---- distance filter: flags + tile counts (and the state's first values), compaction into the work buffer with the count and the kept points' boxes
     const float4* vox_in = ch.distance ? d_work : d_in;
-    hipLaunchKernelGGL(pf_init_kernel, dim3(1), dim3(1), 0, st, d_st, vox_in, d_final, n);
+    const dim3    gtiles(std::max<uint32_t>(1, tab.total_blks));
+    uint32_t*     d_blk = dblk.as<uint32_t>();
     if (ch.distance) {
-        hipLaunchKernelGGL(distance_flags_kernel, g256, b256, 0, st, d_in, n, ch.near_t, ch.far_t, dfl.as<uint32_t>());
-        MRGFE_TRY(exclusive_scan(ctx, dfl.as<uint32_t>(), dpos.as<uint32_t>(), &d_st->sl_in, tab, dblk.as<uint32_t>(), d_tot));
-        hipLaunchKernelGGL(compact_kernel, g256, b256, 0, st, d_in, dfl.as<uint32_t>(), dpos.as<uint32_t>(), n, d_work);
-        hipLaunchKernelGGL(pf_count_kernel, dim3(1), dim3(1), 0, st, d_st, d_tot, 0, h_status);
+        hipLaunchKernelGGL(pf_distance_tiles_kernel, gtiles, b256, 0, st, d_in, n, ch.near_t, ch.far_t, dfl.as<uint32_t>(), d_blk, d_st, vox_in, d_final);
+        hipLaunchKernelGGL(pf_compact_kernel<0>, gtiles, b256, 0, st, d_in, dfl.as<uint32_t>(), d_blk, n, d_work, d_st, h_status, d_part);
+    } else {
+        hipLaunchKernelGGL(pf_init_kernel, dim3(1), dim3(1), 0, st, d_st, vox_in, d_final, n);
+        MRGFE_TRY(bounding_box_partials(ctx, &d_st->cp[0], &d_st->sl_in, tab, d_part));
     }
-    // ---- VoxelGrid: bounding box, voxel parameters (device), keys, stable sort (32 key bits: the host does not know the cell count), runs, centroids
-    MRGFE_TRY(bounding_boxes(ctx, &d_st->cp[0], &d_st->sl_in, tab, d_part, d_bbo));
-    hipLaunchKernelGGL(pf_voxel_params_kernel, dim3(1), dim3(1), 0, st, d_st, d_bbo, ch.leaf);
+    // ---- VoxelGrid: voxel parameters from the boxes (device), keys, stable sort (32 key bits: the host does not know the cell count), runs, centroids
+    hipLaunchKernelGGL(pf_voxel_params_kernel, dim3(1), b256, 0, st, d_st, d_part, ch.leaf);
     MRGFE_TRY(ndt_launch_cellkeys(ctx, &d_st->cp[0], &d_st->sl_in, tab, &d_st->vp, dk.as<uint32_t>(), dh.as<uint32_t>()));
     uint32_t *sk, *sv;
     MRGFE_TRY(radix_sort_pairs(ctx, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), &d_st->sl_in, tab, 32, dh.as<uint32_t>(), &sk, &sv, true, true));
-    MRGFE_TRY(exclusive_scan_run_heads(ctx, sk, nullptr, &d_st->sl_in, tab, &d_st->nv, dblk.as<uint32_t>(), d_tot));
-    hipLaunchKernelGGL(pf_leaves_kernel, dim3(1), dim3(1), 0, st, d_st, d_tot);
+    MRGFE_TRY(run_head_tile_counts(ctx, sk, &d_st->sl_in, tab, &d_st->nv, d_blk));
+    hipLaunchKernelGGL(pf_leaves_kernel, dim3(1), b256, 0, st, d_st, d_blk);
     uint32_t* d_seg = dseg.as<uint32_t>();
     int32_t*  d_segkey = reinterpret_cast<int32_t*>(d_seg + size_t(n) + 4);
-    MRGFE_TRY(ndt_launch_segments(ctx, sk, &d_st->sl_in, tab, &d_st->nv, dblk.as<uint32_t>(), &d_st->ls, d_seg, d_segkey));
+    MRGFE_TRY(ndt_launch_segments(ctx, sk, &d_st->sl_in, tab, &d_st->nv, d_blk, &d_st->ls, d_seg, d_segkey));
     hipLaunchKernelGGL(voxel_centroid_dd_kernel, g256, b256, 0, st, vox_in, sv, d_seg, &d_st->sl_vox, ch.min_pts, dcent.as<float4>(), dkeep.as<uint32_t>());
-    MRGFE_TRY(exclusive_scan(ctx, dkeep.as<uint32_t>(), dpos.as<uint32_t>(), &d_st->sl_vox, tab, dblk.as<uint32_t>(), d_tot));
+    MRGFE_TRY(tile_sums(ctx, dkeep.as<uint32_t>(), &d_st->sl_vox, tab, d_blk));
     // (the voxel grid's output goes to d_final for now: the radius filter reads it there and compacts into the work buffer ...)
-    hipLaunchKernelGGL(compact_dd_kernel, g256, b256, 0, st, dcent.as<float4>(), dkeep.as<uint32_t>(), dpos.as<uint32_t>(), &d_st->sl_vox, d_final);
-    hipLaunchKernelGGL(pf_count_kernel, dim3(1), dim3(1), 0, st, d_st, d_tot, 1, h_status);
-    // ---- RadiusOutlierRemoval: a grid that sizes itself, neighbour counts, compaction
-    MRGFE_TRY(bounding_boxes(ctx, &d_st->cp[1], &d_st->sl_rad, tab, d_part, d_bbo + 1));
+    hipLaunchKernelGGL(pf_compact_kernel<1>, gtiles, b256, 0, st, dcent.as<float4>(), dkeep.as<uint32_t>(), d_blk, 0u, d_final, d_st, h_status, d_part);
+    // ---- RadiusOutlierRemoval: a grid that sizes itself (from the boxes of the centroids kept), neighbour counts, compaction
     NnDeviceDrivenGrid& grid = pf_grid(ctx);
     const float cell = static_cast<float>(ch.radius);
-    MRGFE_TRY(nn_build_device_driven(ctx, &d_st->cp[1], &d_st->sl_rad, n, d_bbo + 1, cell, 1u << 22, grid, &d_st->anomaly));
+    MRGFE_TRY(nn_build_device_driven(ctx, &d_st->cp[1], &d_st->sl_rad, n, d_part, &d_st->bb_n[1], cell, 1u << 22, grid, &d_st->anomaly));
     // inlier iff #{q: (double)sqdist <= radius*radius} >= min_neighbors + 1 (the point itself counts)
     MRGFE_TRY(nn_radius_flags_device_driven(ctx, grid, d_final, &d_st->sl_rad, n, ch.radius * ch.radius, ch.radius_min_neighbors + 1, cell, dfl.as<uint32_t>()));
-    MRGFE_TRY(exclusive_scan(ctx, dfl.as<uint32_t>(), dpos.as<uint32_t>(), &d_st->sl_rad, tab, dblk.as<uint32_t>(), d_tot));
-    hipLaunchKernelGGL(compact_dd_kernel, g256, b256, 0, st, d_final, dfl.as<uint32_t>(), dpos.as<uint32_t>(), &d_st->sl_rad, d_work);
-    hipLaunchKernelGGL(pf_count_kernel, dim3(1), dim3(1), 0, st, d_st, d_tot, 2, h_status);
+    MRGFE_TRY(tile_sums(ctx, dfl.as<uint32_t>(), &d_st->sl_rad, tab, d_blk));
+    hipLaunchKernelGGL(pf_compact_kernel<2>, gtiles, b256, 0, st, d_final, dfl.as<uint32_t>(), d_blk, 0u, d_work, d_st, h_status, d_part);
     MRGFE_HIP_CHECK(hipGetLastError());
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));  // the chain's one wait
     if (h_status[6] != 0x600df00du) { set_error("prefilter: the device-driven chain did not report"); return MRGFE_ERR_HIP; }

@@ -121,8 +121,9 @@ constexpr uint32_t kNnAnomalyCells = 1u << 8;
 struct NnDeviceDrivenGrid {
     DevBuf cells, sorted, desc;  // cell table (cells_cap + 8 words), cell-major points (n_cap), the NnBuildDev record
 };
-int nn_build_device_driven(mrgfe_ctx* ctx, const float4* const* d_cloud_ptr, const Slice* d_slice, uint32_t n_cap, const BBox* d_bbox, float cell, uint32_t cells_cap,
-                           NnDeviceDrivenGrid& g, uint32_t* d_anomaly);
+// d_n_boxes == NULL: d_bbox is the cloud's bounding box; else d_bbox is a list of *d_n_boxes partial boxes that the geometry kernel merges itself
+int nn_build_device_driven(mrgfe_ctx* ctx, const float4* const* d_cloud_ptr, const Slice* d_slice, uint32_t n_cap, const BBox* d_bbox, const uint32_t* d_n_boxes, float cell,
+                           uint32_t cells_cap, NnDeviceDrivenGrid& g, uint32_t* d_anomaly);
 // flags[i] = 1 iff #{j : sqdist(q_i, p_j) <= r2} >= need for the first d_slice->n points of d_q (the grid's own cloud): nn_radius_flags_kernel with
 // the grid and the count read from device memory
 int nn_radius_flags_device_driven(mrgfe_ctx* ctx, const NnDeviceDrivenGrid& g, const float4* d_q, const Slice* d_slice, uint32_t n_cap, double r2, int need, float cell, uint32_t* d_flags);

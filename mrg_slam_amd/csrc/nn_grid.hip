@@ -14,6 +14,8 @@
 #include "dev_utils.h"
 #include "nn_device.h"
 #include "nn_grid.h"
+#include "bbox_device.h"
+#include "bbox_device.h"
 
 namespace mrgfe {
 
@@ -837,12 +839,16 @@ int NnGridSet::build(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32
 }
 
 // ---- a grid the device sizes itself (nn_grid.h: NnDeviceDrivenGrid) ---------------------------------------------------
-__global__ void nn_geometry_kernel(const float4* const* __restrict__ cloud_ptr, const Slice* __restrict__ slice, const BBox* __restrict__ bbox, float cell, uint32_t cells_cap,
-                                   uint32_t* cell_table, float4* sorted, NnBuildDev* __restrict__ out, uint32_t* __restrict__ anomaly)
+// n_boxes != nullptr: `bbox` is a list of *n_boxes partial boxes (the producer of the cloud left one per tile), merged here by the 256 threads
+__global__ __launch_bounds__(256) void nn_geometry_kernel(const float4* const* __restrict__ cloud_ptr, const Slice* __restrict__ slice, const BBox* __restrict__ bbox,
+                                                           const uint32_t* __restrict__ n_boxes, float cell, uint32_t cells_cap, uint32_t* cell_table, float4* sorted,
+                                                           NnBuildDev* __restrict__ out, uint32_t* __restrict__ anomaly)
 {
 #pragma clang fp contract(off)
-    if (threadIdx.x || blockIdx.x) return;
-    const BBox bb = *bbox;
+    BBox bb;
+    if (n_boxes) bb = block_merge_partials(bbox, *n_boxes);  // (uniform)
+    else         bb = *bbox;
+    if (threadIdx.x) return;
     NnBuildDev b;
     memset(&b, 0, sizeof(b));
     NnGridDev& lv = b.lv;
@@ -902,8 +908,8 @@ __global__ __launch_bounds__(256) void nn_radius_flags_dd_kernel(const NnBuildDe
     flags[i] = count >= need ? 1u : 0u;
 }
 
-int nn_build_device_driven(mrgfe_ctx* ctx, const float4* const* d_cloud_ptr, const Slice* d_slice, uint32_t n_cap, const BBox* d_bbox, float cell, uint32_t cells_cap,
-                           NnDeviceDrivenGrid& g, uint32_t* d_anomaly)
+int nn_build_device_driven(mrgfe_ctx* ctx, const float4* const* d_cloud_ptr, const Slice* d_slice, uint32_t n_cap, const BBox* d_bbox, const uint32_t* d_n_boxes, float cell,
+                           uint32_t cells_cap, NnDeviceDrivenGrid& g, uint32_t* d_anomaly)
 {
     hipStream_t st = ctx->stream;
     SliceTable  tab;
@@ -916,7 +922,8 @@ int nn_build_device_driven(mrgfe_ctx* ctx, const float4* const* d_cloud_ptr, con
     MRGFE_TRY(dk.ensure(ne * 4)); MRGFE_TRY(dv.ensure(ne * 4)); MRGFE_TRY(dkt.ensure(ne * 4)); MRGFE_TRY(dvt.ensure(ne * 4));
     MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + 1)));
     NnBuildDev* d_dev = g.desc.as<NnBuildDev>();
-    hipLaunchKernelGGL(nn_geometry_kernel, dim3(1), dim3(1), 0, st, d_cloud_ptr, d_slice, d_bbox, cell, cells_cap, g.cells.as<uint32_t>(), g.sorted.as<float4>(), d_dev, d_anomaly);
+    hipLaunchKernelGGL(nn_geometry_kernel, dim3(1), dim3(256), 0, st, d_cloud_ptr, d_slice, d_bbox, d_n_boxes, cell, cells_cap, g.cells.as<uint32_t>(), g.sorted.as<float4>(), d_dev,
+                       d_anomaly);
     if (tab.max_blks == 0) { MRGFE_HIP_CHECK(hipGetLastError()); return MRGFE_OK; }
     hipLaunchKernelGGL(nn_cellkey_many_kernel, dim3(tab.max_blks * (kTile / 256), 1), dim3(256), 0, st, d_dev, dk.as<uint32_t>(), dv.as<uint32_t>(), 0);
     int key_bits = 1;
