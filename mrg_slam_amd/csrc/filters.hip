@@ -94,9 +94,17 @@ __global__ __launch_bounds__(256) void voxel_centroid_kernel(const float4* __res
     if (s >= n_seg) return;
     const uint32_t b = seg_start[s], e = seg_start[s + 1];
     float sx = 0, sy = 0, sz = 0, si = 0;
-    for (uint32_t k = b; k < e; ++k) {
-        const float4 p = pts[sorted_vals[k]];
-        sx += p.x; sy += p.y; sz += p.z; si += p.w;
+    // four indices, then their four points, in flight at a time (two dependent loads per point otherwise); the additions stay in point order
+    for (uint32_t k = b; k < e; k += 4) {
+        uint32_t id[4];
+        float4   p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) id[u] = sorted_vals[min(k + u, e - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = pts[id[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k + u < e) { sx += p[u].x; sy += p[u].y; sz += p[u].z; si += p[u].w; }
     }
     const float cnt = static_cast<float>(e - b);
     centroids[s] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
@@ -651,9 +659,17 @@ __global__ __launch_bounds__(256) void voxel_centroid_dd_kernel(const float4* __
     if (s >= runs->n) return;
     const uint32_t b = seg_start[s], e = seg_start[s + 1];
     float sx = 0, sy = 0, sz = 0, si = 0;
-    for (uint32_t k = b; k < e; ++k) {
-        const float4 p = pts[sorted_vals[k]];
-        sx += p.x; sy += p.y; sz += p.z; si += p.w;
+    // four indices, then their four points, in flight at a time (two dependent loads per point otherwise); the additions stay in point order
+    for (uint32_t k = b; k < e; k += 4) {
+        uint32_t id[4];
+        float4   p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) id[u] = sorted_vals[min(k + u, e - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = pts[id[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k + u < e) { sx += p[u].x; sy += p[u].y; sz += p[u].z; si += p[u].w; }
     }
     const float cnt = static_cast<float>(e - b);
     centroids[s] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);

@@ -883,29 +883,63 @@ __global__ __launch_bounds__(256) void nn_geometry_kernel(const float4* const* _
     *out = b;
 }
 
+// Eight lanes per query: a scan's radius filter is 33k queries of a ring walk each — one lane per query left the chip waiting on 25 dependent row
+// probes per outlier (65 us per scan).  The lanes of a group take the x-rows of a ring in turn and meet in a sum after every ring; the flag only
+// asks whether the count within the radius reaches `need`, which no order of counting changes.
+constexpr int kRadiusGroup = 8;
 __global__ __launch_bounds__(256) void nn_radius_flags_dd_kernel(const NnBuildDev* __restrict__ d, const float4* __restrict__ q, const Slice* __restrict__ slice, double r2, int need, int rings,
                                                                   uint32_t* __restrict__ flags)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (blockIdx.x * 256u >= slice->n) return;  // uniform
+    constexpr uint32_t per_blk = 256u / kRadiusGroup;
+    const uint32_t i = blockIdx.x * per_blk + threadIdx.x / kRadiusGroup;
+    const int      sub = static_cast<int>(threadIdx.x % kRadiusGroup);
+    if (blockIdx.x * per_blk >= slice->n) return;  // uniform
     __shared__ NnGridDev s_g;
     static_assert(sizeof(NnGridDev) % 4 == 0 && sizeof(NnGridDev) / 4 <= 256, "one word per thread");
     if (threadIdx.x < sizeof(NnGridDev) / 4) reinterpret_cast<uint32_t*>(&s_g)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&d->lv)[threadIdx.x];
     __syncthreads();
-    if (i >= slice->n) return;
+    if (i >= slice->n) return;  // (whole groups)
     const NnGridDev& g = s_g;
     const float4 p = q[i];
     int          c[3];
-    int          count = 0;
+    int          count = 0;  // the group's count so far (the same in its eight lanes)
     if (g.n > 0 && nn_cell_of(g, p.x, p.y, p.z, c)) {
-        nn_walk(
-            g, c, 0.0, rings,
-            [&](const float4& t) {
-                if (static_cast<double>(sqdist3f(t.x, t.y, t.z, p.x, p.y, p.z)) <= r2) ++count;
-            },
-            [&](double) { return count >= need; });
+        int rmax = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) rmax = max(rmax, max(c[a], g.dim[a] - 1 - c[a]));
+        rmax = min(rmax, rings);
+        for (int r = 0; r <= rmax && count < need; ++r) {  // (nn_walk_ranges' rings: rows of cells along x are runs of the sorted points)
+            int       mine = 0, k = 0;
+            auto range = [&](uint32_t b, uint32_t e) {
+                for (uint32_t kk = b; kk < e && mine < need; ++kk) {  // (a lane that has counted `need` by itself has settled the flag)
+                    const float4 t = load_point(g.sorted + kk);
+                    if (static_cast<double>(sqdist3f(t.x, t.y, t.z, p.x, p.y, p.z)) <= r2) ++mine;
+                }
+            };
+            const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.dim[2] - 1);
+            const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.dim[1] - 1);
+            for (int z = z0; z <= z1; ++z) {
+                const bool zface = (z - c[2] == r) || (c[2] - z == r);
+                for (int y = y0; y <= y1; ++y, ++k) {
+                    if (k % kRadiusGroup != sub) continue;
+                    const bool     face = zface || (y - c[1] == r) || (c[1] - y == r);
+                    const uint32_t row = (static_cast<uint32_t>(z) * g.dim[1] + y) * g.dim[0];
+                    if (face) {
+                        const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.dim[0] - 1);
+                        range(as_global(g.cell_start)[row + x0], as_global(g.cell_start)[row + x1 + 1]);
+                    } else {
+                        const int xa = c[0] - r, xb = c[0] + r;
+                        if (xa >= 0) range(as_global(g.cell_start)[row + xa], as_global(g.cell_start)[row + xa + 1]);
+                        if (xb < g.dim[0]) range(as_global(g.cell_start)[row + xb], as_global(g.cell_start)[row + xb + 1]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 1; m < kRadiusGroup; m <<= 1) mine += __shfl_xor(mine, m);
+            count += mine;
+        }
     }
-    flags[i] = count >= need ? 1u : 0u;
+    if (sub == 0) flags[i] = count >= need ? 1u : 0u;
 }
 
 int nn_build_device_driven(mrgfe_ctx* ctx, const float4* const* d_cloud_ptr, const Slice* d_slice, uint32_t n_cap, const BBox* d_bbox, const uint32_t* d_n_boxes, float cell,
@@ -939,7 +973,7 @@ int nn_radius_flags_device_driven(mrgfe_ctx* ctx, const NnDeviceDrivenGrid& g, c
 {
     if (n_cap == 0) return MRGFE_OK;
     const int rings = static_cast<int>(std::ceil(std::sqrt(r2) / cell)) + 1;  // (NnGrid::radius_count_flags)
-    hipLaunchKernelGGL(nn_radius_flags_dd_kernel, dim3((n_cap + 255) / 256), dim3(256), 0, ctx->stream, g.desc.as<NnBuildDev>(), d_q, d_slice, r2, need, rings, d_flags);
+    hipLaunchKernelGGL(nn_radius_flags_dd_kernel, dim3((n_cap + 256 / kRadiusGroup - 1) / (256 / kRadiusGroup)), dim3(256), 0, ctx->stream, g.desc.as<NnBuildDev>(), d_q, d_slice, r2, need, rings, d_flags);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }
