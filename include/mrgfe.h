@@ -98,6 +98,10 @@ int  mrgfe_ctx_create(int device_id, mrgfe_ctx** out);
  * dispatched ahead of those of normal contexts as slots free up — for the latency-critical odometry registration of a process that
  * also runs loop-closure batches (scan_matching_odometry_component next to mrg_slam_component's LoopDetector) */
 int  mrgfe_ctx_create_priority(int device_id, int high_priority, mrgfe_ctx** out);
+/* a context whose kernels never occupy `reserve_cus` of the device's compute units (HIP stream with a CU mask; its helper streams too): for the
+ * throughput work of a process — loop-closure batches (mrg_slam_component's LoopDetector) — so that the small per-scan launches of the odometry
+ * contexts beside it always find free compute units instead of waiting for a batch's workgroups to drain.  reserve_cus = 0: mrgfe_ctx_create. */
+int  mrgfe_ctx_create_reserving(int device_id, int reserve_cus, mrgfe_ctx** out);
 void mrgfe_ctx_destroy(mrgfe_ctx* ctx);
 int  mrgfe_ctx_synchronize(mrgfe_ctx* ctx);
 /* HIP stream of the context as an opaque pointer (hipStream_t), for callers that order their own work after it */

@@ -95,6 +95,7 @@ SIGNATURES = {
     "mrgfe_version": (C.c_char_p, []),
     "mrgfe_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "mrgfe_ctx_create_priority": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
+    "mrgfe_ctx_create_reserving": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
     "mrgfe_ctx_destroy": (None, [_vp]),
     "mrgfe_ctx_synchronize": (C.c_int, [_vp]),
     "mrgfe_ctx_stream": (_vp, [_vp]),
@@ -249,10 +250,15 @@ def check(status: int) -> int:
 class Context:
     """mrgfe_ctx: one per (process, GPU)."""
 
-    def __init__(self, device: int = 0, high_priority: bool = False):
-        """``high_priority``: the context's stream gets the device's highest stream priority (odometry next to loop-closure batches)."""
+    def __init__(self, device: int = 0, high_priority: bool = False, reserve_cus: int = 0):
+        """``high_priority``: the context's stream gets the device's highest stream priority (odometry next to loop-closure batches).
+        ``reserve_cus`` > 0: the kernels of this context never occupy that many of the device's compute units (``mrgfe_ctx_create_reserving``:
+        the loop-closure batches' context, so that the odometry contexts' small launches always find free compute units)."""
         self._h = _vp()
-        check(lib().mrgfe_ctx_create_priority(device, int(bool(high_priority)), C.byref(self._h)))
+        if reserve_cus:
+            check(lib().mrgfe_ctx_create_reserving(device, int(reserve_cus), C.byref(self._h)))
+        else:
+            check(lib().mrgfe_ctx_create_priority(device, int(bool(high_priority)), C.byref(self._h)))
         self.device = device
 
     def synchronize(self):

@@ -1214,7 +1214,7 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
             while (b->fit_sets.size() < n_chunks) b->fit_sets.emplace_back(new NnGridSet());
             while (b->fit_ctxs.size() < n_builders + (early_on ? 1 : 0)) {  // with early passes on, one more context for them (the last)
                 mrgfe_ctx* fc = nullptr;
-                if (mrgfe_ctx_create(b->ctx->device, &fc) != MRGFE_OK) return MRGFE_ERR_HIP;
+                if (ctx_create_like(b->ctx, &fc) != MRGFE_OK) return MRGFE_ERR_HIP;  // (same compute-unit mask as the batch's own context)
                 b->fit_ctxs.push_back(fc);
             }
             // the target clouds reach the device by asynchronous copies (and gathers) on the batch's stream: the helper streams

@@ -283,7 +283,30 @@ static hipError_t create_stream(hipStream_t* st, bool high_priority)
     return hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest);
 }
 
-int mrgfe_ctx_create_priority(int device_id, int high_priority, mrgfe_ctx** out)
+}  // extern "C"
+
+int mrgfe_ctx::make_stream(hipStream_t* st) const
+{
+    const hipError_t e = cu_mask.empty() ? hipStreamCreateWithFlags(st, hipStreamNonBlocking)
+                                         : hipExtStreamCreateWithCUMask(st, static_cast<uint32_t>(cu_mask.size()), cu_mask.data());
+    if (e != hipSuccess) { mrgfe::set_error("stream creation failed: %s", hipGetErrorString(e)); return MRGFE_ERR_HIP; }
+    return MRGFE_OK;
+}
+
+extern "C" {
+
+static int ctx_create(int device_id, int high_priority, int reserve_cus, const mrgfe_ctx* like, mrgfe_ctx** out);
+
+int mrgfe_ctx_create_priority(int device_id, int high_priority, mrgfe_ctx** out) { return ctx_create(device_id, high_priority, 0, nullptr, out); }
+
+int mrgfe_ctx_create_reserving(int device_id, int reserve_cus, mrgfe_ctx** out)
+{
+    if (reserve_cus < 0) { mrgfe::set_error("mrgfe_ctx_create_reserving: reserve_cus must not be negative"); return MRGFE_ERR_INVALID; }
+    return ctx_create(device_id, 0, reserve_cus, nullptr, out);
+}
+
+
+static int ctx_create(int device_id, int high_priority, int reserve_cus, const mrgfe_ctx* like, mrgfe_ctx** out)
 {
     if (!out) { mrgfe::set_error("mrgfe_ctx_create: out is NULL"); return MRGFE_ERR_INVALID; }
     *out = nullptr;
@@ -299,7 +322,21 @@ int mrgfe_ctx_create_priority(int device_id, int high_priority, mrgfe_ctx** out)
     if (c->bind() != MRGFE_OK) { delete c; return MRGFE_ERR_HIP; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->cu_count = prop.multiProcessorCount;
-    if (create_stream(&c->stream, high_priority != 0) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    if (like) {
+        c->cu_mask = like->cu_mask;
+        c->cu_count = like->cu_count;
+    } else if (reserve_cus > 0) {
+        // the LAST reserve_cus bits of the mask stay clear: the kernels of this context never occupy those compute units, so the small launches of
+        // other contexts (a robot's per-scan path beside a loop-closure batch) always find them free
+        const int total = c->cu_count;
+        if (reserve_cus >= total) { mrgfe::set_error("mrgfe_ctx_create_reserving: %d of %d compute units reserved leaves none", reserve_cus, total); delete c; return MRGFE_ERR_INVALID; }
+        c->cu_mask.assign((total + 31) / 32, 0u);
+        for (int k = 0; k < total - reserve_cus; ++k) c->cu_mask[k / 32] |= 1u << (k % 32);
+        // (cu_count stays the device's: it enters the tiles-per-item of the derivative launches, i.e. the grouping of their partial sums — a context's
+        // mask must not change a bit of any result)
+    }
+    const bool stream_ok = c->cu_mask.empty() ? create_stream(&c->stream, high_priority != 0) == hipSuccess : c->make_stream(&c->stream) == MRGFE_OK;
+    if (!stream_ok || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         mrgfe::set_error("failed to create HIP stream / events");
         delete c;
         return MRGFE_ERR_HIP;
@@ -384,3 +421,11 @@ int mrgfe_ctx_fitness_stats(mrgfe_ctx* ctx, double out[11])
 }
 
 }  // extern "C"
+
+namespace mrgfe {
+int ctx_create_like(const mrgfe_ctx* parent, mrgfe_ctx** out)
+{
+    if (!parent) { set_error("ctx_create_like: parent is NULL"); return MRGFE_ERR_INVALID; }
+    return ctx_create(parent->device, 0, 0, parent, out);
+}
+}  // namespace mrgfe

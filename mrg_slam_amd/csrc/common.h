@@ -117,6 +117,8 @@ struct mrgfe_ctx {
     bool         up_busy[2] = {false, false};
     int          up_next = 0;
     hipEvent_t   ev_fit[4] = {nullptr, nullptr, nullptr, nullptr};  // around the passes of nn_fitness_batch
+    std::vector<uint32_t> cu_mask;              // non-empty: every stream of this context is confined to these compute units (mrgfe_ctx_create_reserving)
+    int          make_stream(hipStream_t* st) const;  // a further stream of this context: same compute-unit mask
     hipStream_t  side = nullptr;                // second stream of nn_fitness_batch: the pyramid walk of the unseeded queries beside the sweep
     hipEvent_t   ev_side[4] = {nullptr, nullptr, nullptr, nullptr};  // fork, start and end of the side work, join
     mrgfe::FitStats fit_stats;                  // of the last nn_fitness_batch on this context
@@ -143,4 +145,7 @@ namespace mrgfe {
 // ABI (16, or MRGFE_LAYOUT(stride, xyz offset, intensity offset): such records are gathered on the device)
 int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t layout, void* d_dst, int pin_slot = 0);
 int decode_layout(size_t layout, uint32_t* stride, uint32_t* xyz_off, int32_t* intensity_off);
+// a helper context of `parent` (builder threads of a batch, GICP lanes): same device, same compute-unit mask
+int ctx_create_like(const mrgfe_ctx* parent, mrgfe_ctx** out);
+
 }  // namespace mrgfe

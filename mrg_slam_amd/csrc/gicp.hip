@@ -1707,7 +1707,7 @@ int GicpBatch::align_all(std::vector<GicpEngine*>& engines, std::vector<GicpBatc
         const int n_lanes = std::max(1, std::min(std::min(want, 8), P));
         while (static_cast<int>(lanes_.size()) < n_lanes) {
             Lane* l = new Lane();
-            if (mrgfe_ctx_create(ctx_->device, &l->ctx) != MRGFE_OK) { delete l; return MRGFE_ERR_HIP; }
+            if (ctx_create_like(ctx_, &l->ctx) != MRGFE_OK) { delete l; return MRGFE_ERR_HIP; }
             lanes_.push_back(l);
         }
         std::vector<int> status(n_lanes, MRGFE_OK);

@@ -1806,7 +1806,7 @@ int nn_nearest_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
     else       hipLaunchKernelGGL((nn_fit_block_kernel<true, kBlockGroup>), grid, dim3(256), 0, st, d_jobs, d_off, max_sq, dq.as<float>(), d_pend[0], d_cnts[0]);
     hipLaunchKernelGGL(nn_fit_seed_kernel<true>, grid, dim3(256), 0, st, d_jobs, d_off, max_sq, d_pend[0], d_cnts[0], dq.as<float>(), d_pend[1], d_cnts[1], static_cast<unsigned long long*>(nullptr));
     // the unseeded queries' pyramid walk beside the sweep, as in nn_fitness_batch
-    if (!ctx->side) MRGFE_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    if (!ctx->side) MRGFE_TRY(ctx->make_stream(&ctx->side));
     for (int e = 0; e < 4; ++e)
         if (!ctx->ev_side[e]) MRGFE_HIP_CHECK((e == 1 || e == 2) ? hipEventCreate(&ctx->ev_side[e]) : hipEventCreateWithFlags(&ctx->ev_side[e], hipEventDisableTiming));
     MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[0], st));
@@ -1877,7 +1877,7 @@ int nn_fitness_batch(mrgfe_ctx* ctx, const NnFitnessJob* jobs, size_t count, dou
         // The unseeded queries (a few hundred of millions: nothing within three blocks) walk the pyramid, a handful of long dependent walks
         // that occupy a few wavefronts for ~0.25 ms: on a second stream beside the sweep, which leaves them alone (their queue entries are
         // flagged), instead of behind it.
-        if (!ctx->side) MRGFE_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        if (!ctx->side) MRGFE_TRY(ctx->make_stream(&ctx->side));
         for (int e = 0; e < 4; ++e)
             if (!ctx->ev_side[e]) MRGFE_HIP_CHECK((e == 1 || e == 2) ? hipEventCreate(&ctx->ev_side[e]) : hipEventCreateWithFlags(&ctx->ev_side[e], hipEventDisableTiming));
         MRGFE_HIP_CHECK(hipEventRecord(ctx->ev_side[0], st));

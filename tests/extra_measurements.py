@@ -263,8 +263,8 @@ def main():
             lb.align(-1.0)
             count.append(1)
 
-    def concurrent(high_priority):
-        cA, cB, cC = Context(0, high_priority), Context(0, high_priority), Context(0)
+    def concurrent(high_priority, reserve_cus=0):
+        cA, cB, cC = Context(0, high_priority), Context(0, high_priority), Context(0, reserve_cus=reserve_cus)
         alone = []
         odo_stream(cA, 24, alone)
         latA, latB, calls, stop = [], [], [], threading.Event()
@@ -284,6 +284,10 @@ def main():
 
     out["two_odometry_streams_plus_loop_closure_stream"] = concurrent(False)
     out["two_high_priority_odometry_streams_plus_loop_closure_stream"] = concurrent(True)
+    # the loop-closure context confined to 224 / 192 of the 256 compute units (mrgfe_ctx_create_reserving): the odometry launches find the rest free
+    out["two_high_priority_odometry_streams_plus_loop_closure_stream_reserving_32_cus"] = concurrent(True, 32)
+    out["two_high_priority_odometry_streams_plus_loop_closure_stream_reserving_64_cus"] = concurrent(True, 64)
+    out["two_odometry_streams_plus_loop_closure_stream_reserving_32_cus"] = concurrent(False, 32)
 
     # ---- map cloud of 200 prefiltered keyframes (6.5 M points): host clouds every call vs the HBM map store -------------
     from mrg_slam_amd import KeyFrameSnapshot, MapCloudGenerator, MapCloudStore

@@ -150,6 +150,44 @@ def test_two_contexts_from_two_threads_give_the_sequential_results():
             assert par[w][k]["fitness"] == seq[w][k]["fitness"] and par[w][k]["iterations"] == seq[w][k]["iterations"]
 
 
+def test_context_confined_to_a_part_of_the_chip_gives_the_same_records():
+    """mrgfe_ctx_create_reserving: the loop-closure context's streams (its own, the fitness side stream, the grid builders') carry a compute-unit
+    mask; which compute units run a kernel enters no result (fixed-order sums everywhere), and a mask that leaves nothing is refused."""
+    from mrg_slam_amd import BatchMatcher, Context, NdtHip, synth
+    from mrg_slam_amd._lib import MrgfeError
+    from mrg_slam_amd.registration import result_matrix
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(77)
+    tgt = small_cloud(9000, 410)
+    pairs = []
+    for k in range(7):
+        rel = synth.make_pose(rng.normal(0, 0.2, 3), synth.rot_xyz(*rng.normal(0, 0.02, 3)))
+        pairs.append((orc.transform_points(np.linalg.inv(rel), tgt[: 4000 + 500 * k]), synth.perturb_pose(np.eye(4), rng)))
+
+    def run(ctx):
+        bm = BatchMatcher(ctx=ctx, transformation_epsilon=0.01)
+        t = bm.add_target(tgt)
+        for src, guess in pairs:
+            bm.add_pair(t, src, guess)
+        res = bm.align(fitness_max_range=float("inf"))
+        reg = NdtHip(transformation_epsilon=0.01, ctx=ctx)
+        reg.setInputTarget(tgt)
+        reg.setInputSource(pairs[0][0])
+        reg.align(pairs[0][1])
+        return res, reg.getFinalTransformation().copy()
+
+    full, full_single = run(Context(0))
+    for reserve in (32, 200):
+        part, part_single = run(Context(0, reserve_cus=reserve))
+        for a, b in zip(full, part):
+            np.testing.assert_array_equal(result_matrix(a), result_matrix(b))
+            assert a["fitness"] == b["fitness"] and a["iterations"] == b["iterations"]
+        np.testing.assert_array_equal(full_single, part_single)
+    with pytest.raises(MrgfeError):
+        Context(0, reserve_cus=100000)
+
+
 @pytest.mark.parametrize("method", ["NDT_HIP", "GICP_HIP", "SMALL_GICP_HIP"])
 def test_keyframe_store_gives_the_unkeyed_results(method):
     """Candidates added by keyframe id stay resident (cloud, GICP covariances) across clear(); a later batch that names
