@@ -369,6 +369,42 @@ def test_device_driven_prefilter_chain_equals_the_host_driven_one_and_the_oracle
         lib().mrgfe_dbg_set_prefilter_device_driven(1)
 
 
+def test_device_driven_prefilter_chain_at_tile_boundaries_and_random_parameters():
+    """The chain's compaction kernels add up tile counts, rank by ballots and merge per-tile boundary boxes (csrc/filters.hip: pf_compact_kernel):
+    sizes around the 2048-point tiles and the 256-point rounds, survivors in the last tile only / the first tile only / none, random leaves, radii and
+    neighbour counts — always the host-driven stages' and the oracle's output, bit for bit."""
+    from mrg_slam_amd import prefilter
+    from mrg_slam_amd._lib import lib
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(20261004)
+    sizes = [1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4095, 4096, 4097, 6143, 6145, 10000]
+    try:
+        for trial, n in enumerate(sizes + [int(v) for v in rng.integers(300, 30000, 14)]):
+            cloud = small_cloud(n, 1000 + trial, extent=(rng.uniform(3, 40), rng.uniform(3, 40), rng.uniform(0.5, 6)))
+            kind = trial % 5
+            if kind == 1:    # only the last points survive the distance filter
+                cloud[: max(0, n - 7), :3] *= np.float32(1e-4)
+            elif kind == 2:  # only the first points do
+                cloud[min(n, 5):, :3] = np.float32(900.0)
+            elif kind == 3 and n > 10:
+                cloud[rng.choice(n, max(1, n // 50), replace=False), rng.integers(0, 3)] = np.nan
+            p = {"distance_near_thresh": 0.1, "distance_far_thresh": float(rng.choice([8.0, 35.0, 1e4])), "downsample_resolution": float(rng.choice([0.05, 0.1, 0.3, 1.0])),
+                 "downsample_min_points_per_voxel": int(rng.choice([1, 1, 2])), "radius_radius": float(rng.choice([0.3, 0.5, 1.2])), "radius_min_neighbors": int(rng.choice([1, 2, 5]))}
+            assert lib().mrgfe_dbg_set_prefilter_device_driven(1) == 1
+            fast = prefilter(cloud, p)
+            assert lib().mrgfe_dbg_set_prefilter_device_driven(0) == 0
+            slow = prefilter(cloud, p)
+            name = f"trial {trial}: n={n} kind={kind} {p}"
+            np.testing.assert_array_equal(fast, slow, err_msg=name)
+            c = orc.distance_filter(cloud, p["distance_near_thresh"], p["distance_far_thresh"])
+            c, _ = orc.voxelgrid(c, p["downsample_resolution"], p["downsample_min_points_per_voxel"])
+            c, _ = orc.radius_outlier(c, p["radius_radius"], p["radius_min_neighbors"])
+            np.testing.assert_array_equal(fast, c, err_msg=name)
+    finally:
+        lib().mrgfe_dbg_set_prefilter_device_driven(1)
+
+
 @pytest.mark.parametrize("leaf", [0.05, 0.1, 0.5, 5.0, 80.0])
 def test_approx_voxelgrid_exact(street_pair_vlp16, leaf):
     """pcl::ApproximateVoxelGrid (downsample_method APPROX_VOXELGRID) — a sequential loop over a 512-entry history in the reference, 512 independent
