@@ -104,6 +104,11 @@ int  mrgfe_ctx_create_priority(int device_id, int high_priority, mrgfe_ctx** out
 int  mrgfe_ctx_create_reserving(int device_id, int reserve_cus, mrgfe_ctx** out);
 void mrgfe_ctx_destroy(mrgfe_ctx* ctx);
 int  mrgfe_ctx_synchronize(mrgfe_ctx* ctx);
+/* page-lock a host buffer the caller keeps between calls (hipHostRegister): downloads into it and uploads out of it are direct DMA at PCIe rate
+ * instead of staged through the runtime's bounce buffers — worth it for the 60 MB map cloud of mrgfe_map_store_generate / mrgfe_map_cloud_generate
+ * (map_cloud_generator.cpp:14-86 returns a fresh pcl cloud per call; a caller of this library reuses one buffer).  Unpin before freeing it. */
+int  mrgfe_pin_host_buffer(mrgfe_ctx* ctx, void* p, size_t bytes);
+int  mrgfe_unpin_host_buffer(mrgfe_ctx* ctx, void* p);
 /* HIP stream of the context as an opaque pointer (hipStream_t), for callers that order their own work after it */
 void* mrgfe_ctx_stream(mrgfe_ctx* ctx);
 /* Measurement hook ("1-NN fitness on hash grid: N (16 + 27*8 + m*16)"): what the last getFitnessScore pass on this context

@@ -98,6 +98,8 @@ SIGNATURES = {
     "mrgfe_ctx_create_reserving": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
     "mrgfe_ctx_destroy": (None, [_vp]),
     "mrgfe_ctx_synchronize": (C.c_int, [_vp]),
+    "mrgfe_pin_host_buffer": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "mrgfe_unpin_host_buffer": (C.c_int, [_vp, _vp]),
     "mrgfe_ctx_stream": (_vp, [_vp]),
     "mrgfe_ctx_fitness_stats": (C.c_int, [_vp, _dp]),
     "mrgfe_ctx_knn_stats": (C.c_int, [_vp, _dp]),

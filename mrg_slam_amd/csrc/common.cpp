@@ -379,6 +379,22 @@ void mrgfe_ctx_destroy(mrgfe_ctx* ctx)
     delete ctx;
 }
 
+int mrgfe_pin_host_buffer(mrgfe_ctx* ctx, void* p, size_t bytes)
+{
+    if (!ctx || !p || bytes == 0) { mrgfe::set_error("mrgfe_pin_host_buffer: NULL context / pointer or empty range"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(ctx->bind());
+    MRGFE_HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return MRGFE_OK;
+}
+
+int mrgfe_unpin_host_buffer(mrgfe_ctx* ctx, void* p)
+{
+    if (!ctx || !p) { mrgfe::set_error("mrgfe_unpin_host_buffer: NULL context / pointer"); return MRGFE_ERR_INVALID; }
+    MRGFE_TRY(ctx->bind());
+    MRGFE_HIP_CHECK(hipHostUnregister(p));
+    return MRGFE_OK;
+}
+
 int mrgfe_ctx_synchronize(mrgfe_ctx* ctx)
 {
     if (!ctx) { mrgfe::set_error("NULL context"); return MRGFE_ERR_INVALID; }

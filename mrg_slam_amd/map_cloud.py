@@ -38,8 +38,14 @@ class MapCloudStore:
         self._h = C.c_void_p()
         check(lib().mrgfe_map_store_create(self._ctx._h, C.byref(self._h)))
 
+    def _release_out(self):
+        if getattr(self, "_out", None) is not None and getattr(self, "_out_pinned", False):
+            lib().mrgfe_unpin_host_buffer(self._ctx._h, self._out.ctypes.data_as(C.c_void_p))
+        self._out, self._out_pinned = None, False
+
     def __del__(self):
         try:
+            self._release_out()
             if getattr(self, "_h", None):
                 lib().mrgfe_map_store_destroy(self._h)
                 self._h = None
@@ -65,14 +71,25 @@ class MapCloudStore:
         return out.value
 
     def generate(self, keys, poses, first_keyframe=None, resolution: float = 0.1, min_points_per_voxel: int = 1, distance_far_thresh: float = 10000.0,
-                 skip_first_cloud: bool = False):
-        """MapCloudGenerator.generate over the stored keyframes ``keys`` with their current ``poses`` (4 x 4 each)."""
+                 skip_first_cloud: bool = False, copy: bool = True):
+        """MapCloudGenerator.generate over the stored keyframes ``keys`` with their current ``poses`` (4 x 4 each).
+        The download lands in a buffer the store keeps between calls (a fresh 100 MB array per call costs more in page faults than the
+        kernels and the copy together); ``copy=False`` returns a view of it that the next call overwrites."""
         K = len(keys)
         ks = np.ascontiguousarray(np.asarray(keys, dtype=np.uint64))
         P = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.float64).T.reshape(16) for p in poses])) if K else np.zeros((0, 16))
         first = np.ascontiguousarray(np.asarray(first_keyframe if first_keyframe is not None else np.zeros(K), dtype=np.uint8))
         cap = max(sum(self.has(int(k)) or 0 for k in keys), 1)
-        out = np.empty((cap, 4), dtype=np.float32)
+        if getattr(self, "_out", None) is None or len(self._out) < cap:
+            self._release_out()
+            self._out = np.empty((cap + cap // 4, 4), dtype=np.float32)
+            self._out[:] = 0  # (touch the pages once, here)
+            try:  # page-locked: the download is direct DMA
+                check(lib().mrgfe_pin_host_buffer(self._ctx._h, self._out.ctypes.data_as(C.c_void_p), self._out.nbytes))
+                self._out_pinned = True
+            except MrgfeError:
+                self._out_pinned = False
+        out = self._out
         m = C.c_size_t(0)
         try:
             check(lib().mrgfe_map_store_generate(self._h, K, ks.ctypes.data_as(C.POINTER(C.c_uint64)), P.ctypes.data_as(C.POINTER(C.c_double)),
@@ -82,7 +99,7 @@ class MapCloudStore:
             if e.status == ERR_EMPTY:
                 return None
             raise
-        return out[: m.value].copy()
+        return out[: m.value].copy() if copy else out[: m.value]
 
 
 class MapCloudGenerator:

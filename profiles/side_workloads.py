@@ -41,6 +41,18 @@ def main():
             g.setInputSource(b)
             g.align(rel @ synth.make_pose([0.3, -0.2, 0.05], synth.rot_z(0.03)))
         print("gicp iterations", g.getFinalNumIteration())
+    if which == "mapcloud":  # map cloud of 200 prefiltered keyframes out of the HBM map store (map_cloud_generator.cpp:14-86), three times
+        from mrg_slam_amd import MapCloudStore
+
+        kf = [prefilter(raw[k % 3], ctx=ctx) for k in range(3)]
+        K = 200
+        kposes = [synth.make_pose([1.0 * k, 0.3 * k, 0.0], synth.rot_z(0.01 * k)) for k in range(K)]
+        ms = MapCloudStore(ctx)
+        for k in range(K):
+            ms.add(k + 1, kf[k % 3])
+        for _ in range(3):
+            out = ms.generate(list(range(1, K + 1)), kposes, None, 0.1)
+        print("map points", len(out))
     if which == "lc":  # loop-closure batch: one 130k-point keyframe against 64 candidates, getFitnessScore(inf) of each
         from mrg_slam_amd import BatchMatcher, distance_filter
 

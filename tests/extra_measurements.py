@@ -300,7 +300,8 @@ def main():
         mstore.add(k + 1, kf_clouds[k % 5])
     snaps = [KeyFrameSnapshot(kposes[k], kf_clouds[k % 5], k == 0) for k in range(K)]
     tm = {}
-    for name, fn in (("host_clouds_ms", lambda: gen.generate(snaps, 0.1)), ("map_store_ms", lambda: mstore.generate(list(range(1, K + 1)), kposes, None, 0.1))):
+    for name, fn in (("host_clouds_ms", lambda: gen.generate(snaps, 0.1)), ("map_store_ms", lambda: mstore.generate(list(range(1, K + 1)), kposes, None, 0.1)),
+                     ("map_store_view_ms", lambda: mstore.generate(list(range(1, K + 1)), kposes, None, 0.1, copy=False))):
         fn()
         ts = []
         for _ in range(3):
