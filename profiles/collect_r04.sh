@@ -33,6 +33,7 @@ if [ "$part" = trace ]; then
     for w in prefilter lc gicp_lc; do
         rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_side_$w -o s -- python3 profiles/side_workloads.py $w > gpurun_out/side_$w.log 2>&1 || exit 1
     done
+    python3 profiles/overlap_steps.py 12 2>/dev/null | tail -1 > gpurun_out/overlap_$tag.json
     python3 tests/extra_measurements.py > gpurun_out/extra_$tag.json 2> gpurun_out/extra_$tag.err
     echo "extra measurements done"
     python3 profiles/soak.py 2000 600 > gpurun_out/soak_$tag.json 2> gpurun_out/soak_$tag.err

@@ -114,7 +114,12 @@ def main():
                           f"rocprofv3 average = {float(dom['AverageNs']) / 1e3:.2f} us over {dom['Calls']} launches (warm-up included)."]
     extra = os.path.join(OUT, f"extra_{tag}.json")
     if os.path.exists(extra):
-        json.dump(json.load(open(extra)), open(os.path.join(ROOT, "profiles", f"{tag}_extra_measurements.json"), "w"), indent=1)
+        ex = json.load(open(extra))
+        overlap = os.path.join(OUT, f"overlap_{tag}.json")  # profiles/overlap_steps.py: several config[1] steps in flight
+        if os.path.exists(overlap) and open(overlap).read().strip().startswith("{"):
+            ex["config1_steps_in_flight"] = json.loads(open(overlap).read().strip())
+            summary["config1_steps_in_flight"] = ex["config1_steps_in_flight"]
+        json.dump(ex, open(os.path.join(ROOT, "profiles", f"{tag}_extra_measurements.json"), "w"), indent=1)
     # kernel stats of the non-headline paths (profiles/side_workloads.py): GICP (33k / 130k points), prefilter chain,
     # calc_fitness_score, loop-closure batch with getFitnessScore
     shard = os.path.join(OUT, f"prof_shard_{tag}", "s_kernel_stats.csv")
