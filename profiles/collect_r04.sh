@@ -38,6 +38,7 @@ if [ "$part" = trace ]; then
     echo "extra measurements done"
     python3 profiles/soak.py 2000 600 > gpurun_out/soak_$tag.json 2> gpurun_out/soak_$tag.err
     python3 profiles/soak_filters.py 3000 2> gpurun_out/soak_filters_$tag.err | tail -1 > gpurun_out/soak_filters_$tag.json
+    python3 profiles/soak_misc.py 3000 2> gpurun_out/soak_misc_$tag.err | tail -1 > gpurun_out/soak_misc_$tag.json
     echo "soak done"
     $C3 2>/dev/null | tail -1 > gpurun_out/bench_shard_$tag.json
     $C38 2>/dev/null | tail -1 > gpurun_out/bench_shard8_$tag.json
