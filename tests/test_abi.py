@@ -57,3 +57,21 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src and '#include "../../oracle' not in src, f
+
+
+def test_every_entry_point_is_placed_in_the_integration_table():
+    """INTEGRATION.md §1 says for every entry point of include/mrgfe.h which reference call it stands for (or that it has none): by name, by a
+    `prefix_*` row, or in a `name_a/b/c` row."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "mrgfe.h")).read()
+    names = sorted(set(re.findall(r"\b(mrgfe_[a-z0-9_]+)\s*\(", header)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    wild = re.findall(r"`(mrgfe_[a-z0-9_]*)\*`", doc)
+    slashed = set()
+    for m in re.finditer(r"`(mrgfe_[a-z0-9_]+)((?:/[a-z0-9_]+)+)`", doc):  # `mrgfe_map_store_create/add/has`: the parts replace the first name's last word
+        prefix = m.group(1)[: m.group(1).rindex("_") + 1]
+        slashed.update(prefix + part for part in m.group(2).strip("/").split("/"))
+    missing = [n for n in names if n not in doc and n not in slashed and not any(n.startswith(w) for w in wild)]
+    assert not missing, missing
