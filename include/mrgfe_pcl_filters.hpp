@@ -30,6 +30,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "mrgfe.h"
@@ -38,17 +39,27 @@ namespace mrgfe_pcl {
 
 #ifndef MRGFE_PCL_SHARED_CONTEXT
 #define MRGFE_PCL_SHARED_CONTEXT
-// One context per process and GPU (stream + workspaces), shared by every adapter object on that GPU.
-inline mrgfe_ctx* shared_context(int device = 0)
+// One context (HIP stream + workspaces) per process, GPU and ROLE, shared by the adapter objects of that role: calls on one context are
+// serialised, so the odometry registration (scan_matching_odometry_component, every scan) must not share one with the loop-closure
+// registration (mrg_slam_component's LoopDetector, batches of candidates) when both components live in one container process.
+//   General     : mrgfe_ctx_create
+//   Odometry    : mrgfe_ctx_create_priority — its small launches are dispatched ahead of a batch's as slots free up
+//   LoopClosure : mrgfe_ctx_create_reserving(kReservedCus) — its kernels leave a quarter of the chip to the odometry contexts
+enum class ContextRole { General = 0, Odometry = 1, LoopClosure = 2 };
+constexpr int kReservedCus = 64;
+inline mrgfe_ctx* shared_context(int device = 0, ContextRole role = ContextRole::General)
 {
-    static std::mutex               mu;
-    static std::map<int, mrgfe_ctx*> ctxs;
+    static std::mutex                              mu;
+    static std::map<std::pair<int, int>, mrgfe_ctx*> ctxs;
     std::lock_guard<std::mutex> lock(mu);
-    auto it = ctxs.find(device);
+    const std::pair<int, int> key(device, static_cast<int>(role));
+    auto it = ctxs.find(key);
     if (it != ctxs.end()) return it->second;
     mrgfe_ctx* ctx = nullptr;
-    if (mrgfe_ctx_create(device, &ctx) != MRGFE_OK) throw std::runtime_error(std::string("mrgfe: ") + mrgfe_last_error());
-    ctxs[device] = ctx;
+    const int  st = role == ContextRole::Odometry ? mrgfe_ctx_create_priority(device, 1, &ctx)
+                  : role == ContextRole::LoopClosure ? mrgfe_ctx_create_reserving(device, kReservedCus, &ctx) : mrgfe_ctx_create(device, &ctx);
+    if (st != MRGFE_OK) throw std::runtime_error(std::string("mrgfe: ") + mrgfe_last_error());
+    ctxs[key] = ctx;
     return ctx;
 }
 // stride_bytes descriptor of a PCL point type with x, y, z and intensity members (pcl::PointXYZI: 32 bytes, intensity at 16);

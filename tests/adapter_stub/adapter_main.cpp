@@ -86,6 +86,26 @@ int main(int argc, char** argv)
     // intensity of the 32-byte records reached the device: the aligned cloud carries it
     check((*aligned)[n / 2].intensity == (*source)[n / 2].intensity, "aligned cloud keeps the source intensities");
 
+    // the two components' registrations on their own contexts (the odometry one at the highest stream priority, the loop detector's
+    // confined to a part of the chip): distinct HIP streams, the same transformation bit for bit
+    {
+        pcl::Registration<PointT, PointT>::Ptr odo(new mrgfe_pcl::HipRegistration<PointT, PointT>(prm, 0, mrgfe_pcl::ContextRole::Odometry));
+        pcl::Registration<PointT, PointT>::Ptr lc(new mrgfe_pcl::HipRegistration<PointT, PointT>(prm, 0, mrgfe_pcl::ContextRole::LoopClosure));
+        check(mrgfe_pcl::shared_context(0, mrgfe_pcl::ContextRole::Odometry) != mrgfe_pcl::shared_context(0, mrgfe_pcl::ContextRole::LoopClosure) &&
+                  mrgfe_pcl::shared_context(0, mrgfe_pcl::ContextRole::Odometry) != mrgfe_pcl::shared_context(),
+              "one context per role");
+        bool same_T = true;
+        for (auto& r : {odo, lc}) {
+            Cloud::Ptr out(new Cloud);
+            r->setInputTarget(target);
+            r->setInputSource(source);
+            r->align(*out, Eigen::Matrix4f::Identity());
+            const Eigen::Matrix4f Tr = r->getFinalTransformation(), T0 = registration->getFinalTransformation();
+            for (int i = 0; i < 16; ++i) same_T = same_T && Tr.data()[i] == T0.data()[i];
+        }
+        check(same_T, "odometry-role and loop-closure-role registrations return the general one's transformation");
+    }
+
     // scan_matching_odometry_component.cpp:405-417: inlier fraction through getSearchMethodTarget()
     const std::size_t before = hip->gpuSearch().batched_answers();
     int                num_inliers = 0;
