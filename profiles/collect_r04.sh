@@ -36,7 +36,7 @@ if [ "$part" = trace ]; then
     python3 profiles/overlap_steps.py 12 2>/dev/null | tail -1 > gpurun_out/overlap_$tag.json
     python3 tests/extra_measurements.py > gpurun_out/extra_$tag.json 2> gpurun_out/extra_$tag.err
     echo "extra measurements done"
-    python3 profiles/soak.py 2000 600 > gpurun_out/soak_$tag.json 2> gpurun_out/soak_$tag.err
+    python3 profiles/soak.py 10000 3000 > gpurun_out/soak_$tag.json 2> gpurun_out/soak_$tag.err
     python3 profiles/soak_filters.py 3000 2> gpurun_out/soak_filters_$tag.err | tail -1 > gpurun_out/soak_filters_$tag.json
     python3 profiles/soak_misc.py 3000 2> gpurun_out/soak_misc_$tag.err | tail -1 > gpurun_out/soak_misc_$tag.json
     echo "soak done"
