@@ -39,6 +39,7 @@ if [ "$part" = trace ]; then
     python3 profiles/soak.py 10000 3000 > gpurun_out/soak_$tag.json 2> gpurun_out/soak_$tag.err
     python3 profiles/soak_filters.py 3000 2> gpurun_out/soak_filters_$tag.err | tail -1 > gpurun_out/soak_filters_$tag.json
     python3 profiles/soak_misc.py 3000 2> gpurun_out/soak_misc_$tag.err | tail -1 > gpurun_out/soak_misc_$tag.json
+    python3 profiles/loop_parity_seeds.py 4243,4244,4245,4246,4247,4248,4249,4250 2>/dev/null | tail -1 > gpurun_out/loop_parity_seeds_$tag.json
     echo "soak done"
     $C3 2>/dev/null | tail -1 > gpurun_out/bench_shard_$tag.json
     $C38 2>/dev/null | tail -1 > gpurun_out/bench_shard8_$tag.json

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""BASELINE config[3] at its stated size against the reference's sequential loop (oracle/replay.py: loop_parity) for SEVERAL draws of the 256
+(new keyframe, candidate) pairs and their graph-estimate guesses — bench.py's line carries the draw of seed 4242 only:
+    python3 profiles/loop_parity_seeds.py [seeds=4243,4244,4245,4246] > gpurun_out/loop_parity_seeds.json
+Per seed: pairs within the 1e-4 m / 1e-4 rad bar, bit-identical transformations, iteration / convergence / best-candidate agreement, fitness(inf)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from mrg_slam_amd import BatchMatcher, Context, NdtHip, distance_filter  # noqa: E402
+from mrg_slam_amd._lib import NDT_HIP, SEARCH  # noqa: E402
+from mrg_slam_amd.registration import default_params  # noqa: E402
+from oracle.replay import loop_parity  # noqa: E402
+
+seeds = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "4243,4244,4245,4246").split(",")]
+ctx = Context(0)
+prm = default_params(NDT_HIP)
+prm.transformation_epsilon = 0.1
+prm.maximum_iterations = 64
+prm.resolution = 1.0
+prm.nn_search_method = SEARCH["DIRECT7"]
+out = {"workload": "BASELINE config[3]: 64 keyframes on a 40 m ring, 256 pairs within 15 m, guesses = truth perturbed by N(0, 0.5 m / 2 deg), NDT res 1.0 eps 0.1, getFitnessScore(inf)", "seeds": {}}
+host = dev = None
+for seed in seeds:
+    t0 = time.time()
+    raw, pairs = bench.make_loop_workload(seed=seed)
+    if host is None:  # (the keyframe scans do not depend on the seed)
+        host = [distance_filter(s, 0.1, 35.0, ctx=ctx) for s in raw]
+        dev = [torch.from_numpy(s).to("cuda:0") for s in host]
+    targets = sorted({p[0] for p in pairs})
+    tpos = {a: k for k, a in enumerate(targets)}
+    bm = BatchMatcher(prm, ctx)
+    bm.add_device([dev[a].data_ptr() for a in targets], [len(host[a]) for a in targets], np.array([tpos[p[0]] for p in pairs], dtype=np.int32),
+                  [dev[p[1]].data_ptr() for p in pairs], [len(host[p[1]]) for p in pairs], np.stack([p[2] for p in pairs]))
+    rec = bm.align(float("inf"))
+
+    def single(i):
+        reg = NdtHip(resolution=1.0, transformation_epsilon=0.1, maximum_iterations=64, ctx=ctx)
+        a, b = pairs[i][0], pairs[i][1]
+        reg.setInputTargetDevice(dev[a].data_ptr(), len(host[a]))
+        reg.setInputSourceDevice(dev[b].data_ptr(), len(host[b]))
+        reg.align(pairs[i][2])
+        return reg.getFinalTransformation(), reg.hasConverged(), reg.getFinalNumIteration()
+
+    par = loop_parity(host, pairs, rec, 0.1, single_runner=single)
+    par["seconds"] = time.time() - t0
+    out["seeds"][str(seed)] = par
+    print(f"[loop_parity_seeds] seed {seed}: {time.time() - t0:.0f} s", file=sys.stderr)
+print(json.dumps(out))
