@@ -1,7 +1,8 @@
 #!/bin/bash
-# Round-4 profile collection (run on the GPU box through gpurun from the repo root, two calls: each stays under gpurun's 1200 s):
+# Round-4 profile collection (run on the GPU box through gpurun from the repo root, three calls: each stays under gpurun's 1200 s):
 #   gpurun --timeout 1150 -- "bash profiles/collect_r04.sh trace r04 $(git rev-parse --short HEAD)"
 #   gpurun --timeout 1150 -- "bash profiles/collect_r04.sh pmc r04 $(git rev-parse --short HEAD)"
+#   gpurun --timeout 1150 -- "bash profiles/collect_r04.sh soak r04 $(git rev-parse --short HEAD)"
 # then, back in the container:  python profiles/summarize.py r04
 # Every traced command launches the dominant kernel of its workload ONLY in steps of that workload (no CPU legs, no side measurements, no
 # config[3] leg inside the config[1] run), so the per-kernel average of `--kernel-trace --stats` is over the launch population bench.py's own
@@ -36,14 +37,18 @@ if [ "$part" = trace ]; then
     python3 profiles/overlap_steps.py 12 2>/dev/null | tail -1 > gpurun_out/overlap_$tag.json
     python3 tests/extra_measurements.py > gpurun_out/extra_$tag.json 2> gpurun_out/extra_$tag.err
     echo "extra measurements done"
-    python3 profiles/soak.py 10000 3000 > gpurun_out/soak_$tag.json 2> gpurun_out/soak_$tag.err
-    python3 profiles/soak_filters.py 3000 2> gpurun_out/soak_filters_$tag.err | tail -1 > gpurun_out/soak_filters_$tag.json
-    python3 profiles/soak_misc.py 3000 2> gpurun_out/soak_misc_$tag.err | tail -1 > gpurun_out/soak_misc_$tag.json
-    python3 profiles/loop_parity_seeds.py 4243,4244,4245,4246,4247,4248,4249,4250 2>/dev/null | tail -1 > gpurun_out/loop_parity_seeds_$tag.json
-    echo "soak done"
     $C3 2>/dev/null | tail -1 > gpurun_out/bench_shard_$tag.json
     $C38 2>/dev/null | tail -1 > gpurun_out/bench_shard8_$tag.json
     for b in 32 64 128; do python3 bench.py --no-cpu --no-extras --shard-steps 0 --batch $b --steps 10 2>/dev/null | tail -1 > gpurun_out/bench_${tag}_b$b.json; done
+elif [ "$part" = soak ]; then
+    # the randomised parity runs (about 13 minutes): registration methods, prefilter rows, the rows around the alignment, config[3] for 24 more draws
+    python3 profiles/soak.py 10000 3000 > gpurun_out/soak_$tag.json 2> gpurun_out/soak_$tag.err
+    echo "registration soak done"
+    python3 profiles/soak_filters.py 3000 2> gpurun_out/soak_filters_$tag.err | tail -1 > gpurun_out/soak_filters_$tag.json
+    python3 profiles/soak_misc.py 3000 2> gpurun_out/soak_misc_$tag.err | tail -1 > gpurun_out/soak_misc_$tag.json
+    echo "filter / misc soaks done"
+    python3 profiles/loop_parity_seeds.py $(python3 -c "print(','.join(str(4243 + i) for i in range(24)))") 2> gpurun_out/loop_parity_seeds_$tag.err | tail -1 > gpurun_out/loop_parity_seeds_$tag.json
+    echo "soak done"
 else
     P1="$C1 --steps 1 --warmup 0"
     P3="python3 bench.py --mode shard --no-cpu --no-extras --steps 1 --warmup 1"

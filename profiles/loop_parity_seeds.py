@@ -54,4 +54,11 @@ for seed in seeds:
     par["seconds"] = time.time() - t0
     out["seeds"][str(seed)] = par
     print(f"[loop_parity_seeds] seed {seed}: {time.time() - t0:.0f} s", file=sys.stderr)
+tot = {"pairs": 0, "pairs_bit_identical": 0, "pairs_over_bar": 0, "pairs_with_other_iterations_or_convergence": 0, "best_candidate_mismatches": 0, "max_dt_m": 0.0, "fitness_max_rel_diff": 0.0}
+for p in out["seeds"].values():
+    for k in ("pairs", "pairs_bit_identical", "pairs_over_bar", "pairs_with_other_iterations_or_convergence", "best_candidate_mismatches"):
+        tot[k] += p[k]
+    tot["max_dt_m"] = max(tot["max_dt_m"], p["max_dt_m"])
+    tot["fitness_max_rel_diff"] = max(tot["fitness_max_rel_diff"], p["fitness_max_rel_diff_pairs_within_bar"])
+out["total"] = tot
 print(json.dumps(out))
