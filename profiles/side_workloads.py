@@ -41,6 +41,19 @@ def main():
             g.setInputSource(b)
             g.align(rel @ synth.make_pose([0.3, -0.2, 0.05], synth.rot_z(0.03)))
         print("gicp iterations", g.getFinalNumIteration())
+    if which == "odo_ndt":  # odometry frames: raw scan -> prefilter (result left in HBM) -> scan-to-keyframe NDT_HIP align, six frames
+        import torch
+
+        from mrg_slam_amd import NdtHip, prefilter_to_device
+
+        o = NdtHip(resolution=1.0, transformation_epsilon=0.1, maximum_iterations=64, ctx=ctx)
+        o.setInputTarget(ft)
+        buf = torch.empty((len(raw[1]) + 16, 4), dtype=torch.float32, device="cuda:0")
+        for k in range(6):
+            m = prefilter_to_device(raw[1 + k % 2], buf.data_ptr(), buf.shape[0], ctx=ctx)
+            o.setInputSourceDevice(buf.data_ptr(), m)
+            o.align(synth.warm_guess(np.linalg.inv(poses[0]) @ poses[1 + k % 2], k))
+        print("iterations", o.getFinalNumIteration())
     if which == "mapcloud":  # map cloud of 200 prefiltered keyframes out of the HBM map store (map_cloud_generator.cpp:14-86), three times
         from mrg_slam_amd import MapCloudStore
 
