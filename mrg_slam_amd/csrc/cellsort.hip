@@ -186,6 +186,66 @@ __global__ __launch_bounds__(256) void rs_scan_kernel(const Slice* __restrict__ 
     digit_base[(size_t)blockIdx.x * 256 + threadIdx.x] = base;
 }
 
+// A problem of thousands of tiles (the map cloud: 6.5 M points, 3200 tiles) kept ONE workgroup busy for 110 us per pass walking its 3200 x 256
+// counts.  Two launches instead: the digit counts of every chunk of 64 tiles, then one workgroup per chunk that adds up the chunks before its own
+// (a few dozen rows) and scans its own 64 tiles; the workgroup of chunk 0 also leaves the digit bases.
+constexpr uint32_t kScanChunk = 64;      // tiles per chunk
+constexpr uint32_t kBigScanBlks = 512;   // a sort with a problem of more tiles than this takes the chunked scan
+__global__ __launch_bounds__(256) void rs_chunk_sums_kernel(const Slice* __restrict__ slices, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ chunk_off,
+                                                             uint32_t* __restrict__ chunk_sums)
+{
+    const Slice s = slices[blockIdx.y];
+    const uint32_t b0 = blockIdx.x * kScanChunk;
+    if (b0 >= s.nblk) return;
+    const uint32_t b1 = min(b0 + kScanChunk, s.nblk);
+    const uint32_t* col = hist + (size_t)s.blk_off * 256 + threadIdx.x;
+    uint32_t sum = 0, b = b0;
+    for (; b + 16 <= b1; b += 16) {
+        uint32_t v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = col[(size_t)(b + u) * 256];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sum += v[u];
+    }
+    for (; b < b1; ++b) sum += col[(size_t)b * 256];
+    chunk_sums[(size_t)(chunk_off[blockIdx.y] + blockIdx.x) * 256 + threadIdx.x] = sum;
+}
+__global__ __launch_bounds__(256) void rs_scan_chunks_kernel(const Slice* __restrict__ slices, uint32_t* __restrict__ hist, const uint32_t* __restrict__ chunk_off,
+                                                              const uint32_t* __restrict__ chunk_sums, uint32_t* __restrict__ digit_base)
+{
+    const Slice s = slices[blockIdx.y];
+    const uint32_t nchunk = (s.nblk + kScanChunk - 1) / kScanChunk;
+    if (blockIdx.x >= nchunk && blockIdx.x != 0) return;  // (chunk 0 of an empty problem still writes its digit bases: all zero)
+    __shared__ uint32_t lds[8];
+    const uint32_t* cs = chunk_sums + (size_t)chunk_off[blockIdx.y] * 256 + threadIdx.x;
+    uint32_t before = 0, total = 0;
+    for (uint32_t c = 0; c < nchunk; ++c) {
+        const uint32_t v = cs[(size_t)c * 256];
+        total += v;
+        before += c < blockIdx.x ? v : 0u;
+    }
+    if (blockIdx.x == 0) {
+        uint32_t all;
+        digit_base[(size_t)blockIdx.y * 256 + threadIdx.x] = block_exclusive_scan<256>(total, lds, &all);
+    }
+    if (blockIdx.x >= nchunk) return;
+    const uint32_t b0 = blockIdx.x * kScanChunk, b1 = min(b0 + kScanChunk, s.nblk);
+    uint32_t* col = hist + (size_t)s.blk_off * 256 + threadIdx.x;
+    uint32_t  run = before, b = b0;
+    for (; b + 16 <= b1; b += 16) {
+        uint32_t v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = col[(size_t)(b + u) * 256];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { col[(size_t)(b + u) * 256] = run; run += v[u]; }
+    }
+    for (; b < b1; ++b) {
+        const uint32_t v = col[(size_t)b * 256];
+        col[(size_t)b * 256] = run;
+        run += v;
+    }
+}
+
 constexpr uint32_t kOwnScanBlks = 512;  // tiles of a sort (all its problems) up to which the scatter kernel does the scan of the histograms as well
 // pass 3: stable scatter. The tile is consumed in 8 rounds of 256 keys; inside a round the rank of a key among equal
 // digits is (keys of earlier rounds) + (keys of earlier waves) + (lower lanes of its own wave, by ballot matching).
@@ -273,6 +333,24 @@ int radix_sort_pairs(mrgfe_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, uint32_
     // a sort of a few hundred tiles lasts as long as its launches: the scatter kernel scans the tile histograms itself (see rs_scatter_kernel)
     static const uint32_t own_scan_blks = [] { const char* e = std::getenv("MRGFE_SORT_OWN_SCAN_BLKS"); return e ? static_cast<uint32_t>(std::atoi(e)) : kOwnScanBlks; }();
     const bool own_scan = t.total_blks <= own_scan_blks && t.max_blks <= 1024;
+    // the chunked scan for problems of many tiles: chunk offsets per problem (host-known sizes) staged up once per sort
+    const bool      big_scan = !own_scan && t.max_blks > kBigScanBlks;
+    uint32_t        max_chunks = 0;
+    const uint32_t* d_chunk_off = nullptr;
+    uint32_t*       d_chunk_sums = nullptr;
+    if (big_scan) {
+        std::vector<uint32_t> off(t.nprob() + 1, 0);
+        for (int p = 0; p < t.nprob(); ++p) {
+            const uint32_t nc = (t.h[p].nblk + kScanChunk - 1) / kScanChunk;
+            off[p + 1] = off[p] + nc;
+            max_chunks = std::max(max_chunks, nc);
+        }
+        const size_t off_bytes = (sizeof(uint32_t) * off.size() + 255) & ~size_t(255);
+        MRGFE_TRY(ctx->sort_chunks.ensure(off_bytes + sizeof(uint32_t) * 256 * std::max<uint32_t>(off.back(), 1)));
+        MRGFE_TRY(ctx->stage_h2d(ctx->sort_chunks.p, off.data(), sizeof(uint32_t) * off.size(), ctx->stream));
+        d_chunk_off = ctx->sort_chunks.as<uint32_t>();
+        d_chunk_sums = reinterpret_cast<uint32_t*>(ctx->sort_chunks.as<char>() + off_bytes);
+    }
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
         if (!(p == 0 && first_hist_ready)) hipLaunchKernelGGL(rs_hist_kernel, grid, dim3(256), 0, ctx->stream, ki, d_slices, d_hist, shift);
@@ -280,7 +358,12 @@ int radix_sort_pairs(mrgfe_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, uint32_
             if (p == 0 && iota_vals) hipLaunchKernelGGL((rs_scatter_kernel<true, true>), grid, dim3(256), 0, ctx->stream, ki, vi, ko, vo, d_slices, d_hist, digit_base, shift);
             else                     hipLaunchKernelGGL((rs_scatter_kernel<false, true>), grid, dim3(256), 0, ctx->stream, ki, vi, ko, vo, d_slices, d_hist, digit_base, shift);
         } else {
-            hipLaunchKernelGGL(rs_scan_kernel, dim3(t.nprob()), dim3(256), 0, ctx->stream, d_slices, d_hist, digit_base);
+            if (big_scan) {
+                hipLaunchKernelGGL(rs_chunk_sums_kernel, dim3(max_chunks, t.nprob()), dim3(256), 0, ctx->stream, d_slices, d_hist, d_chunk_off, d_chunk_sums);
+                hipLaunchKernelGGL(rs_scan_chunks_kernel, dim3(max_chunks, t.nprob()), dim3(256), 0, ctx->stream, d_slices, d_hist, d_chunk_off, d_chunk_sums, digit_base);
+            } else {
+                hipLaunchKernelGGL(rs_scan_kernel, dim3(t.nprob()), dim3(256), 0, ctx->stream, d_slices, d_hist, digit_base);
+            }
             if (p == 0 && iota_vals) hipLaunchKernelGGL((rs_scatter_kernel<true, false>), grid, dim3(256), 0, ctx->stream, ki, vi, ko, vo, d_slices, d_hist, digit_base, shift);
             else                     hipLaunchKernelGGL((rs_scatter_kernel<false, false>), grid, dim3(256), 0, ctx->stream, ki, vi, ko, vo, d_slices, d_hist, digit_base, shift);
         }

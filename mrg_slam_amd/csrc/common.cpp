@@ -360,6 +360,7 @@ void mrgfe_ctx_destroy(mrgfe_ctx* ctx)
     ctx->pf_state.release();
     ctx->pf_status.release();
     for (auto& b : ctx->scratch) b.release();
+    ctx->sort_chunks.release();
     for (auto& b : ctx->pin) b.release();
     for (auto& b : ctx->up_pin) b.release();
     ctx->up_raw.release();

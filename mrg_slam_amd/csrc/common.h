@@ -110,6 +110,7 @@ struct mrgfe_ctx {
     hipEvent_t   ev0 = nullptr, ev1 = nullptr;  // timing of the dominant kernel on `stream`
     hipEvent_t   ev_mode[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // per NDT kernel variant
     mrgfe::DevBuf scratch[14];                  // named by the algorithms that use them
+    mrgfe::DevBuf sort_chunks;                  // radix_sort_pairs: digit counts per chunk of 64 tiles (sorts of thousands of tiles: the map cloud)
     mrgfe::PinBuf pin[4];
     mrgfe::PinBuf up_pin[2];                    // upload_cloud staging ring: the host packs cloud k + 1 while cloud k is on the wire
     mrgfe::DevBuf up_raw, up_out;               // raw strided records waiting for the device gather / packed result of mrgfe_ingest_pointcloud2

@@ -35,6 +35,23 @@ def test_radix_sort_is_a_stable_sort(ctx, n, bits):
     np.testing.assert_array_equal(ov, order.astype(np.uint32))
 
 
+@pytest.mark.parametrize("n,bits", [(1048577, 20), (1150000, 9), (2500003, 31), (6600000, 26)])
+def test_radix_sort_of_thousands_of_tiles(ctx, n, bits):
+    """More than 512 tiles in one problem (the map cloud's 6.5 M points): the digit counts are scanned chunk by chunk (rs_chunk_sums_kernel,
+    rs_scan_chunks_kernel) instead of by one workgroup per problem; sizes just past the switch, with ragged last chunks and a ragged last tile."""
+    from mrg_slam_amd._lib import check, lib
+
+    rng = np.random.default_rng(n + bits)
+    keys = rng.integers(0, min(1 << bits, 1 << 31), n, dtype=np.uint32)
+    keys[n // 2: n // 2 + n // 5] = keys[7]
+    vals = np.arange(n, dtype=np.uint32)
+    ok, ov = np.empty_like(keys), np.empty_like(vals)
+    check(lib().mrgfe_dbg_sort_pairs(ctx._h, keys.ctypes.data_as(_u32p), vals.ctypes.data_as(_u32p), n, bits, ok.ctypes.data_as(_u32p), ov.ctypes.data_as(_u32p)))
+    order = np.argsort(keys, kind="stable")
+    np.testing.assert_array_equal(ok, keys[order])
+    np.testing.assert_array_equal(ov, order.astype(np.uint32))
+
+
 @pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 2047, 2048, 2049, 100000, 600001])
 def test_exclusive_scan(ctx, n):
     from mrg_slam_amd._lib import check, lib
