@@ -272,14 +272,14 @@ def main():
         tl.start()
         time.sleep(0.05)
         t_begin = time.perf_counter()
-        ta, tb = threading.Thread(target=odo_stream, args=(cA, 60, latA)), threading.Thread(target=odo_stream, args=(cB, 60, latB))
+        ta, tb = threading.Thread(target=odo_stream, args=(cA, 240, latA)), threading.Thread(target=odo_stream, args=(cB, 240, latB))
         ta.start(); tb.start(); ta.join(); tb.join()
         span = time.perf_counter() - t_begin
         stop.set()
         tl.join()
         both = np.array(latA[4:] + latB[4:])
         return {"odometry_frame_alone_ms": 1e3 * float(np.median(alone[4:])), "odometry_frame_median_ms": 1e3 * float(np.median(both)),
-                "odometry_frame_p95_ms": 1e3 * float(np.percentile(both, 95)), "odometry_frames_per_s_both_robots": 120 / span,
+                "odometry_frame_p95_ms": 1e3 * float(np.percentile(both, 95)), "odometry_frames_per_s_both_robots": 480 / span,
                 "loop_closure_calls_per_s_64_candidates": len(calls) / span}
 
     out["two_odometry_streams_plus_loop_closure_stream"] = concurrent(False)
