@@ -316,9 +316,12 @@ class Ndt:
         self._n_src = 0
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_ndt_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().orc_ndt_destroy(self._h)
+                self._h = None
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
     def setInputTarget(self, cloud):
         c = _cloud(cloud)
@@ -401,9 +404,12 @@ class FastGicp:
         self._n_src = self._n_tgt = 0
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_gicp_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().orc_gicp_destroy(self._h)
+                self._h = None
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
     def setInputTarget(self, cloud):
         c = _cloud(cloud)
