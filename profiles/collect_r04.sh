@@ -48,6 +48,7 @@ elif [ "$part" = soak ]; then
     python3 profiles/soak_misc.py 3000 2> gpurun_out/soak_misc_$tag.err | tail -1 > gpurun_out/soak_misc_$tag.json
     echo "filter / misc soaks done"
     python3 profiles/loop_parity_seeds.py $(python3 -c "print(','.join(str(4243 + i) for i in range(24)))") 2> gpurun_out/loop_parity_seeds_$tag.err | tail -1 > gpurun_out/loop_parity_seeds_$tag.json
+    python3 profiles/config1_parity_ranks.py 1,2,3,4,5,6,7 2> gpurun_out/config1_parity_ranks_$tag.err | tail -1 > gpurun_out/config1_parity_ranks_$tag.json
     python3 profiles/config2_parity.py 96 2> gpurun_out/config2_parity_$tag.err | tail -1 > gpurun_out/config2_parity_$tag.json
     echo "soak done"
 else
