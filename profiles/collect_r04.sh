@@ -1,8 +1,9 @@
 #!/bin/bash
-# Round-4 profile collection (run on the GPU box through gpurun from the repo root, three calls: each stays under gpurun's 1200 s):
+# Round-4 profile collection (run on the GPU box through gpurun from the repo root, four calls: each stays under gpurun's 1200 s):
 #   gpurun --timeout 1150 -- "bash profiles/collect_r04.sh trace r04 $(git rev-parse --short HEAD)"
 #   gpurun --timeout 1150 -- "bash profiles/collect_r04.sh pmc r04 $(git rev-parse --short HEAD)"
 #   gpurun --timeout 1150 -- "bash profiles/collect_r04.sh soak r04 $(git rev-parse --short HEAD)"
+#   gpurun --timeout 1150 -- "bash profiles/collect_r04.sh parity r04 $(git rev-parse --short HEAD)"
 # then, back in the container:  python profiles/summarize.py r04
 # Every traced command launches the dominant kernel of its workload ONLY in steps of that workload (no CPU legs, no side measurements, no
 # config[3] leg inside the config[1] run), so the per-kernel average of `--kernel-trace --stats` is over the launch population bench.py's own
@@ -48,9 +49,13 @@ elif [ "$part" = soak ]; then
     python3 profiles/soak_misc.py 3000 2> gpurun_out/soak_misc_$tag.err | tail -1 > gpurun_out/soak_misc_$tag.json
     echo "filter / misc soaks done"
     python3 profiles/loop_parity_seeds.py $(python3 -c "print(','.join(str(4243 + i) for i in range(24)))") 2> gpurun_out/loop_parity_seeds_$tag.err | tail -1 > gpurun_out/loop_parity_seeds_$tag.json
-    python3 profiles/config1_parity_ranks.py 1,2,3,4,5,6,7 2> gpurun_out/config1_parity_ranks_$tag.err | tail -1 > gpurun_out/config1_parity_ranks_$tag.json
-    python3 profiles/config2_parity.py 96 2> gpurun_out/config2_parity_$tag.err | tail -1 > gpurun_out/config2_parity_$tag.json
     echo "soak done"
+elif [ "$part" = parity ]; then
+    # the stated-size parity sweeps beyond what bench.py's line holds (about 8 minutes, most of it ray-casting the other ranks' streets)
+    python3 profiles/config1_parity_ranks.py 1,2,3,4,5,6,7 2> gpurun_out/config1_parity_ranks_$tag.err | tail -1 > gpurun_out/config1_parity_ranks_$tag.json
+    echo "config[1] ranks done"
+    python3 profiles/config2_parity.py 96 2> gpurun_out/config2_parity_$tag.err | tail -1 > gpurun_out/config2_parity_$tag.json
+    echo "parity done"
 else
     P1="$C1 --steps 1 --warmup 0"
     P3="python3 bench.py --mode shard --no-cpu --no-extras --steps 1 --warmup 1"
