@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstdlib>
+#include <cstring>
 #include <atomic>
 #include <thread>
 
@@ -21,6 +22,10 @@ void set_error(const char* fmt, ...)
 }
 const char* get_error() { return g_err; }
 
+// MRGFE_POISON=1 (tests): every fresh device / pinned allocation is filled with 0xCD — fresh memory from the driver is usually zero, which hides a kernel
+// that reads what nobody wrote
+static bool poison_allocations() { static const bool v = std::getenv("MRGFE_POISON") != nullptr; return v; }
+
 int DevBuf::ensure(size_t bytes)
 {
     if (bytes <= cap) return MRGFE_OK;
@@ -30,6 +35,7 @@ int DevBuf::ensure(size_t bytes)
     if (p) { MRGFE_HIP_CHECK(hipFree(p)); p = nullptr; cap = 0; }
     MRGFE_HIP_CHECK(hipMalloc(&p, want));
     cap = want;
+    if (poison_allocations()) { MRGFE_HIP_CHECK(hipMemset(p, 0xCD, want)); MRGFE_HIP_CHECK(hipDeviceSynchronize()); }
     return MRGFE_OK;
 }
 void DevBuf::release()
@@ -46,6 +52,7 @@ int PinBuf::ensure(size_t bytes)
     if (p) { MRGFE_HIP_CHECK(hipHostFree(p)); p = nullptr; cap = 0; }
     MRGFE_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
     cap = want;
+    if (poison_allocations()) std::memset(p, 0xCD, want);
     return MRGFE_OK;
 }
 void PinBuf::release()
@@ -70,6 +77,7 @@ int Arena::alloc(size_t bytes, void** out)
     c.used = 0;
     c.p = nullptr;
     MRGFE_HIP_CHECK(hipMalloc(&c.p, c.cap));
+    if (poison_allocations()) { MRGFE_HIP_CHECK(hipMemset(c.p, 0xCD, c.cap)); MRGFE_HIP_CHECK(hipDeviceSynchronize()); }
     *out = c.p;
     c.used = bytes;
     chunks.push_back(c);
