@@ -54,6 +54,7 @@ elif [ "$part" = parity ]; then
     # the stated-size parity sweeps beyond what bench.py's line holds (about 8 minutes, most of it ray-casting the other ranks' streets)
     python3 profiles/config1_parity_ranks.py 1,2,3,4,5,6,7 2> gpurun_out/config1_parity_ranks_$tag.err | tail -1 > gpurun_out/config1_parity_ranks_$tag.json
     echo "config[1] ranks done"
+    python3 profiles/ndt_fullsize_sweep.py 64 2> gpurun_out/ndt_fullsize_sweep_$tag.err | tail -1 > gpurun_out/ndt_fullsize_sweep_$tag.json
     python3 profiles/config2_parity.py 96 2> gpurun_out/config2_parity_$tag.err | tail -1 > gpurun_out/config2_parity_$tag.json
     echo "parity done"
 else

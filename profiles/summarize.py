@@ -112,7 +112,7 @@ def main():
             ev = b["roofline"]["avg_launch_ms"]
             lines += ["", f"Agreement check: HIP-event average of `{DOMINANT}` inside bench.py = {ev * 1e3:.2f} us over {b['roofline']['launches']} timed launches; "
                           f"rocprofv3 average = {float(dom['AverageNs']) / 1e3:.2f} us over {dom['Calls']} launches (warm-up included)."]
-    for kind in ("soak_filters", "soak_misc", "loop_parity_seeds", "config2_parity", "config1_parity_ranks"):  # profiles/soak_filters.py, soak_misc.py: the rows around the alignment against the oracle
+    for kind in ("soak_filters", "soak_misc", "loop_parity_seeds", "config2_parity", "config1_parity_ranks", "ndt_fullsize_sweep"):  # profiles/soak_filters.py, soak_misc.py: the rows around the alignment against the oracle
         sf = os.path.join(OUT, f"{kind}_{tag}.json")
         if os.path.exists(sf) and open(sf).read().strip().startswith("{"):
             json.dump(json.loads(open(sf).read().strip()), open(os.path.join(ROOT, "profiles", f"{tag}_{kind}.json"), "w"), indent=1)
