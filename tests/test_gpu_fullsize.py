@@ -158,3 +158,43 @@ def test_small_gicp_batch_full_size_takes_the_correspondence_passes_and_equals_s
     Tg = result_matrix(res[2])
     assert np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3]) <= 1e-4 and synth.rotation_angle(Tg, To) <= 1e-4
     assert res[2]["iterations"] == o.getFinalNumIteration()
+
+
+def test_registration_far_above_the_stated_size():
+    """Fifteen times BASELINE's scan size: a 2-million-point NDT registration (31k tiles of source points, a radix sort of ~1000 tiles per pass, an exact-NN grid
+    for getFitnessScore over 2 M targets) and a 600k-point SMALL_GICP one (k-NN covariances of both clouds) — the indices, tile tables and byte offsets of the path at
+    a size where a 32-bit slip would show; both against the oracle, bit for bit."""
+    import os
+
+    from conftest import small_cloud
+    from mrg_slam_amd import NdtHip, SmallGicpHip, synth
+    from oracle import oracle as orc
+
+    threads = max(2, min(32, os.cpu_count() or 2))
+    n = 2_000_000
+    tgt = small_cloud(n, 31, extent=(120.0, 90.0, 12.0))
+    rel = synth.make_pose([0.4, -0.2, 0.05], synth.rot_xyz(0.004, -0.003, 0.02))
+    src = orc.transform_points(np.linalg.inv(rel), tgt[: n - 12345])
+    src[:, :3] += np.random.default_rng(3).normal(0, 0.01, (len(src), 3)).astype(np.float32)
+    r = NdtHip(resolution=1.0, transformation_epsilon=0.01)
+    r.setInputTarget(tgt)
+    r.setInputSource(src)
+    r.align(np.eye(4))
+    o = orc.Ndt(resolution=1.0, transformation_epsilon=0.01, num_threads=threads)
+    o.setInputTarget(tgt)
+    o.setInputSource(src)
+    o.align(np.eye(4))
+    assert r.getFinalNumIteration() == o.getFinalNumIteration() and bool(r.hasConverged()) == bool(o.hasConverged())
+    np.testing.assert_array_equal(r.getFinalTransformation(), o.getFinalTransformation())
+    assert r.getFitnessScore(float("inf")) == pytest.approx(o.getFitnessScore(float("inf")), rel=1e-12)
+    m = 600_000
+    g = SmallGicpHip(transformation_epsilon=0.01)
+    g.setInputTarget(tgt[:m])
+    g.setInputSource(src[:m])
+    g.align(np.eye(4))
+    og = orc.SmallGicp(transformation_epsilon=0.01, num_threads=threads)
+    og.setInputTarget(tgt[:m])
+    og.setInputSource(src[:m])
+    og.align(np.eye(4))
+    assert g.getFinalNumIteration() == og.getFinalNumIteration()
+    np.testing.assert_array_equal(g.getFinalTransformation(), og.getFinalTransformation())
