@@ -34,6 +34,17 @@ int ndt_launch_leaves(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint3
                       const VoxelParams* d_vp, uint32_t max_leaves, const uint32_t* d_seg_start, uint32_t* d_big_cnt, uint32_t* d_big_list, const int32_t* d_seg_key, double* d_sums, NdtLeafRec* d_leaves,
                       double* d_icov64, float4* d_centroid, int32_t* d_nr_points, void* d_lookup_base);
 
+// A single target's voxel parameters made on the device (NdtEngine::build_targets with one host wait): the tile boxes merged, voxel_params_from_bbox's
+// arithmetic float for float, the parameters and the finite-point count written where the key / run-head kernels read them, and a copy of everything the
+// host wants to see behind its one wait.  A cloud without a finite point or with PCL's index overflow gets zeroed parameters and n_valid = 0.
+struct DdTargetOut {
+    BBox        bb;
+    VoxelParams vp;
+    uint32_t    n_valid;
+    uint32_t    n_runs;  // written later by the run-head scan (exclusive_scan_run_heads' d_totals points here)
+};
+int ndt_launch_dd_voxel_params(mrgfe_ctx* ctx, const BBox* d_partial, uint32_t n_partial, float leaf, VoxelParams* d_vp, uint32_t* d_n_valid, DdTargetOut* d_out);
+
 // host: PCL's bounding-box -> (min_b, max_b, div_b, divb_mul) arithmetic. Returns MRGFE_ERR_OVERFLOW when
 // dx*dy*dz > INT32_MAX ("Leaf size is too small for the input dataset").
 int voxel_params_from_bbox(const BBox& bb, float leaf, VoxelParams* vp, int32_t max_b[3], int32_t div_b[3]);

@@ -12,6 +12,7 @@
 #include "dev_linalg.h"
 #include "dev_utils.h"
 #include "ndt_build.h"
+#include "bbox_device.h"
 
 namespace mrgfe {
 
@@ -385,6 +386,53 @@ __global__ __launch_bounds__(256) void ndt_leaf_finalize_kernel(const LeafSlice*
         }
     }
     (void)g;
+}
+
+__global__ __launch_bounds__(256) void ndt_dd_voxel_params_kernel(const BBox* __restrict__ partial, uint32_t n_partial, float leaf, VoxelParams* __restrict__ vp_out,
+                                                                   uint32_t* __restrict__ nv_out, DdTargetOut* __restrict__ out)
+{
+#pragma clang fp contract(off)
+    const BBox bb = block_merge_partials(partial, n_partial);
+    if (threadIdx.x) return;
+    VoxelParams vp;
+    memset(&vp, 0, sizeof(vp));
+    uint32_t nv = 0;
+    if (bb.n_finite != 0) {
+        // (voxel_params_from_bbox, ndt_engine.cpp: the same float operations in the same order)
+        const float   inv_leaf = 1.0f / leaf;
+        const int64_t dx = static_cast<int64_t>((bb.mx[0] - bb.mn[0]) * inv_leaf) + 1;
+        const int64_t dy = static_cast<int64_t>((bb.mx[1] - bb.mn[1]) * inv_leaf) + 1;
+        const int64_t dz = static_cast<int64_t>((bb.mx[2] - bb.mn[2]) * inv_leaf) + 1;
+        bool over = dx * dy * dz > static_cast<int64_t>(INT32_MAX);
+        if (!over) {
+            int32_t div_b[3];
+            for (int a = 0; a < 3; ++a) {
+                vp.min_b[a] = static_cast<int32_t>(floorf(bb.mn[a] * inv_leaf));
+                div_b[a] = static_cast<int32_t>(floorf(bb.mx[a] * inv_leaf)) - vp.min_b[a] + 1;
+            }
+            vp.divb_mul[0] = 1;
+            vp.divb_mul[1] = div_b[0];
+            vp.divb_mul[2] = div_b[0] * div_b[1];
+            vp.inv_leaf = inv_leaf;
+            const int64_t cells = static_cast<int64_t>(div_b[0]) * div_b[1] * div_b[2];
+            over = cells > static_cast<int64_t>(INT32_MAX);
+            vp.n_cells = static_cast<uint32_t>(cells);
+        }
+        if (over) memset(&vp, 0, sizeof(vp));
+        else      nv = bb.n_finite;
+    }
+    *vp_out = vp;
+    *nv_out = nv;
+    out->bb = bb;
+    out->vp = vp;
+    out->n_valid = nv;
+}
+
+int ndt_launch_dd_voxel_params(mrgfe_ctx* ctx, const BBox* d_partial, uint32_t n_partial, float leaf, VoxelParams* d_vp, uint32_t* d_n_valid, DdTargetOut* d_out)
+{
+    hipLaunchKernelGGL(ndt_dd_voxel_params_kernel, dim3(1), dim3(256), 0, ctx->stream, d_partial, n_partial, leaf, d_vp, d_n_valid, d_out);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
 }
 
 int ndt_launch_cellkeys(mrgfe_ctx* ctx, const float4* const* d_clouds, const Slice* d_slices, const SliceTable& t, const VoxelParams* d_vp, uint32_t* d_keys, uint32_t* d_hist)

@@ -38,6 +38,8 @@ int voxel_params_from_bbox(const BBox& bb, float leaf, VoxelParams* vp, int32_t 
     return MRGFE_OK;
 }
 
+static bool one_wait_build_allowed();
+
 NdtEngine::~NdtEngine()
 {
     if (ctx_) (void)hipSetDevice(ctx_->device);
@@ -143,7 +145,7 @@ int NdtEngine::build_targets(bool wait)
     const size_t o_ls = (o_vp + sizeof(VoxelParams) * P + 15) & ~size_t(15);
     const size_t desc_bytes = o_ls + sizeof(LeafSlice) * P;
     PinBuf& hdesc = ctx_->pin[1];
-    MRGFE_TRY(hdesc.ensure(desc_bytes + sizeof(BBox) * P + sizeof(uint32_t) * P));
+    MRGFE_TRY(hdesc.ensure(desc_bytes + sizeof(BBox) * P + sizeof(uint32_t) * P + 16 + sizeof(DdTargetOut)));
     char* hd = hdesc.as<char>();
     Slice*         h_sl = reinterpret_cast<Slice*>(hd + o_sl);
     const float4** h_cp = reinterpret_cast<const float4**>(hd + o_cp);
@@ -167,11 +169,57 @@ int NdtEngine::build_targets(bool wait)
     std::memset(h_ls, 0, sizeof(LeafSlice) * P);
     MRGFE_HIP_CHECK(hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, st));
 
-    // 1. bounding boxes
     DevBuf& dbb = ctx_->scratch[1];
-    MRGFE_TRY(dbb.ensure(sizeof(BBox) * (tab.total_blks + P)));
+    MRGFE_TRY(dbb.ensure(sizeof(BBox) * (tab.total_blks + P) + sizeof(DdTargetOut)));
     BBox* d_bb_part = dbb.as<BBox>();
     BBox* d_bb_out = d_bb_part + tab.total_blks;
+    DevBuf &dk = ctx_->scratch[2], &dv = ctx_->scratch[3], &dkt = ctx_->scratch[4], &dvt = ctx_->scratch[5], &dh = ctx_->scratch[6], &dblk = ctx_->scratch[8];
+    uint32_t *sk = nullptr, *sv = nullptr;
+    uint32_t* d_tot = nullptr;
+    int       key_bits = 1;
+    // ONE target whose key width the previous build of this engine suggests (consecutive keyframes of one sensor): the voxel parameters are made on
+    // the device and the build waits ONCE, behind the run-head count, for the bounding box, the parameters and the count together — the host
+    // recomputes the parameters from the box as always and falls back to the two-wait path below if anything is off (no finite point, PCL's index
+    // overflow, more cells than the guessed key width holds, parameters that differ).
+    bool one_wait = P == 1 && key_bits_hint_ > 0 && one_wait_build_allowed();
+    if (one_wait) {
+        DdTargetOut* d_out = reinterpret_cast<DdTargetOut*>(d_bb_out + P);
+        MRGFE_TRY(bounding_box_partials(ctx_, d_cp, d_sl, tab, d_bb_part));
+        MRGFE_TRY(ndt_launch_dd_voxel_params(ctx_, d_bb_part, tab.total_blks, prm_.resolution, const_cast<VoxelParams*>(d_vp), const_cast<uint32_t*>(d_nv), d_out));
+        key_bits = key_bits_hint_;
+        const size_t ne = std::max<size_t>(tab.total_elems, 4);
+        MRGFE_TRY(dk.ensure(ne * 4)); MRGFE_TRY(dv.ensure(ne * 4)); MRGFE_TRY(dkt.ensure(ne * 4)); MRGFE_TRY(dvt.ensure(ne * 4));
+        MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + P)));
+        MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (tab.total_blks + P + 4)));
+        MRGFE_TRY(ndt_launch_cellkeys(ctx_, d_cp, d_sl, tab, d_vp, dk.as<uint32_t>(), dh.as<uint32_t>()));
+        MRGFE_TRY(radix_sort_pairs(ctx_, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), d_sl, tab, key_bits, dh.as<uint32_t>(), &sk, &sv, true, true));
+        d_tot = &d_out->n_runs;
+        MRGFE_TRY(exclusive_scan_run_heads(ctx_, sk, nullptr, d_sl, tab, d_nv, dblk.as<uint32_t>(), d_tot));
+        DdTargetOut& h_out = *reinterpret_cast<DdTargetOut*>(hd + ((desc_bytes + sizeof(BBox) * P + sizeof(uint32_t) * P + 15) & ~size_t(15)));  // (pinned)
+        MRGFE_HIP_CHECK(hipMemcpyAsync(&h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost, st));
+        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+        NdtTargetInfo& T = targets_[todo[0]];
+        VoxelParams    vp_host;
+        std::memset(&vp_host, 0, sizeof(vp_host));
+        const bool ok = h_out.bb.n_finite != 0 && voxel_params_from_bbox(h_out.bb, prm_.resolution, &vp_host, T.max_b, T.div_b) == MRGFE_OK &&
+                        std::memcmp(&vp_host, &h_out.vp, sizeof(vp_host)) == 0 && h_out.n_valid == h_out.bb.n_finite && (uint64_t(1) << key_bits) > vp_host.n_cells;
+        if (ok) {
+            T.built = true;
+            T.status = MRGFE_OK;
+            for (int a = 0; a < 3; ++a) T.min_b[a] = vp_host.min_b[a];
+            h_bb[0] = h_out.bb;
+            h_vp[0] = vp_host;
+            h_nv[0] = h_out.n_valid;
+            h_tot[0] = h_out.n_runs;
+            int kb = 1;
+            while (kb < 32 && (uint64_t(1) << kb) <= vp_host.n_cells) ++kb;
+            key_bits_hint_ = std::min(32, kb + 1);
+        } else {
+            one_wait = false;  // the ordinary path decides what the reference does with this cloud
+        }
+    }
+    if (!one_wait) {
+    // 1. bounding boxes
     MRGFE_TRY(bounding_boxes(ctx_, d_cp, d_sl, tab, d_bb_part, d_bb_out));
     MRGFE_HIP_CHECK(hipMemcpyAsync(h_bb, d_bb_out, sizeof(BBox) * P, hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
@@ -194,23 +242,23 @@ int NdtEngine::build_targets(bool wait)
     tab.build(sizes.data(), P);
     for (int k = 0; k < P; ++k) h_sl[k] = tab.h[k];
     MRGFE_HIP_CHECK(hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, st));
-    int key_bits = 1;
+    key_bits = 1;
     while (key_bits < 32 && (uint64_t(1) << key_bits) <= max_cells) ++key_bits;  // key == n_cells marks non-finite points
+    if (P == 1 && targets_[todo[0]].status == MRGFE_OK) key_bits_hint_ = std::min(32, key_bits + 1);  // (a bit of room for the next keyframe's extent)
 
     // 3. keys, stable sort, run heads, ordinals
     const size_t ne = std::max<size_t>(tab.total_elems, 4);
-    DevBuf &dk = ctx_->scratch[2], &dv = ctx_->scratch[3], &dkt = ctx_->scratch[4], &dvt = ctx_->scratch[5], &dh = ctx_->scratch[6], &dblk = ctx_->scratch[8];
     MRGFE_TRY(dk.ensure(ne * 4)); MRGFE_TRY(dv.ensure(ne * 4)); MRGFE_TRY(dkt.ensure(ne * 4)); MRGFE_TRY(dvt.ensure(ne * 4));
     MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + P)));
     MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (tab.total_blks + P + 4)));
     MRGFE_TRY(ndt_launch_cellkeys(ctx_, d_cp, d_sl, tab, d_vp, dk.as<uint32_t>(), dh.as<uint32_t>()));
-    uint32_t *sk = nullptr, *sv = nullptr;
     MRGFE_TRY(radix_sort_pairs(ctx_, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), d_sl, tab, key_bits, dh.as<uint32_t>(), &sk, &sv, true, true));
     // run heads of the sorted keys: their number per target and the tiles' prefixes (a head's ordinal = its voxel's leaf index, made up by the segments kernel)
-    uint32_t* d_tot = dblk.as<uint32_t>() + tab.total_blks;
+    d_tot = dblk.as<uint32_t>() + tab.total_blks;
     MRGFE_TRY(exclusive_scan_run_heads(ctx_, sk, nullptr, d_sl, tab, d_nv, dblk.as<uint32_t>(), d_tot));
     MRGFE_HIP_CHECK(hipMemcpyAsync(h_tot, d_tot, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    }
 
     // 4. leaf storage
     uint32_t total_leaves = 0, max_leaves = 0;
@@ -377,6 +425,8 @@ static bool fused_launch()
     if (v < 0) { const char* e = std::getenv("MRGFE_FUSED"); v = e ? (std::atoi(e) != 0 ? 1 : 0) : 1; g_fused.store(v, std::memory_order_relaxed); }
     return v != 0;
 }
+// MRGFE_NDT_BUILD_TWO_WAITS=1: a single target's build always waits for its bounding box before it sorts (the path before round 4's second half)
+static bool one_wait_build_allowed() { static const bool v = std::getenv("MRGFE_NDT_BUILD_TWO_WAITS") == nullptr; return v; }
 int ndt_set_fused_launch(int mode)
 {
     if (mode == 0 || mode == 1) g_fused.store(mode, std::memory_order_relaxed);

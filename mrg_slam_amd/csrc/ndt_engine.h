@@ -130,6 +130,7 @@ class NdtEngine {
     void host_plan(std::vector<uint32_t>& plan, uint32_t wg_target, uint32_t max_ppt) const;
     std::vector<hipEvent_t> ev_pool_;     // [round][variant][begin, end]
     int    rounds_ = 0;
+    int      key_bits_hint_ = 0;   // key width of this engine's last single-target build + 1 (0: none yet): lets the next one sort before the host has seen its box
     uint64_t result_tag_ = 0;  // host-stepped single registration: the value its next reduction stores behind the record
     std::vector<NdtRoundInfo> round_info_;  // busy pairs per kind of every round of the last align_all
     int upload_pairs();

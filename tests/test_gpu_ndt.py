@@ -65,6 +65,62 @@ def test_target_grid_matches_oracle(force_hash, monkeypatch):
     assert (gi[~valid] == 0).all()
 
 
+def test_a_registration_object_rebuilds_its_target_with_one_host_wait():
+    """The second and later setInputTarget calls of one object (a new keyframe of the same sensor) make the voxel parameters on the device and wait once
+    (NdtEngine::build_targets: key width guessed from the previous build).  Same leaves as the first build's path and the oracle's, bit for bit — also when
+    the guess does not hold (a cloud of a hundred times the extent: back to the two-wait path), for a cloud without a finite point (the registration is left
+    without a target, as PCL's) and for the next good cloud after it."""
+    import numpy as np
+
+    from mrg_slam_amd import NdtHip
+    from mrg_slam_amd._lib import MrgfeError
+    from oracle import oracle as orc
+
+    def same_leaves(g, cloud):
+        o = orc.Ndt(num_threads=4)
+        o.setInputTarget(cloud)
+        gk, gn, gm, gi = g.leaves()
+        ok, on, om, oc, oi = o.leaves()
+        np.testing.assert_array_equal(gk, ok)
+        np.testing.assert_array_equal(gn, on)
+        np.testing.assert_array_equal(gm, om)
+        valid = on >= 6
+        np.testing.assert_array_equal(gi[valid], oi[valid])
+        for a, b in zip(g.grid(), o.grid()):
+            np.testing.assert_array_equal(a, b)
+
+    a, src, _ = _pair(6000)
+    b = small_cloud(9000, 77, extent=(24.0, 15.0, 3.5))
+    b[17, 1] = np.nan
+    wide = small_cloud(5000, 78, extent=(2500.0, 1800.0, 40.0))
+    g = NdtHip(resolution=1.0, transformation_epsilon=0.01)
+    for cloud in (a, b, a, wide, b):  # first build; one wait; one wait; the guess fails; one wait again with the wider guess
+        assert g.setInputTarget(cloud) == 0
+        same_leaves(g, cloud)
+    g.setInputSource(src)
+    g.setInputTarget(a)
+    g.align(np.eye(4))
+    o = orc.Ndt(transformation_epsilon=0.01, num_threads=4)
+    o.setInputTarget(a)
+    o.setInputSource(src)
+    o.align(np.eye(4))
+    np.testing.assert_array_equal(g.getFinalTransformation(), o.getFinalTransformation())
+    # no finite point: the same outcome as on a fresh object, and the object recovers with the next cloud
+    nothing = np.full((300, 4), np.nan, dtype=np.float32)
+    fresh = NdtHip(resolution=1.0)
+    try:
+        exp = fresh.setInputTarget(nothing)
+    except MrgfeError as e:
+        exp = e.status
+    try:
+        got = g.setInputTarget(nothing)
+    except MrgfeError as e:
+        got = e.status
+    assert got == exp
+    assert g.setInputTarget(b) == 0
+    same_leaves(g, b)
+
+
 def test_voxel_sums_at_every_population_boundary():
     """ndt_leaf_sums_kernel takes voxels of up to 512 points four at a time per wavefront, 64 points a round, spans of 16 voxels per
     wavefront, and gives bigger voxels a wavefront of their own with four 64-point steps in flight: voxels of 1 ... 3000 points,
