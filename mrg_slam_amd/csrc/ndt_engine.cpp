@@ -170,7 +170,7 @@ int NdtEngine::build_targets(bool wait)
     MRGFE_HIP_CHECK(hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, st));
 
     DevBuf& dbb = ctx_->scratch[1];
-    MRGFE_TRY(dbb.ensure(sizeof(BBox) * (tab.total_blks + P) + sizeof(DdTargetOut)));
+    MRGFE_TRY(dbb.ensure(sizeof(BBox) * (tab.total_blks + P)));
     BBox* d_bb_part = dbb.as<BBox>();
     BBox* d_bb_out = d_bb_part + tab.total_blks;
     DevBuf &dk = ctx_->scratch[2], &dv = ctx_->scratch[3], &dkt = ctx_->scratch[4], &dvt = ctx_->scratch[5], &dh = ctx_->scratch[6], &dblk = ctx_->scratch[8];
@@ -183,7 +183,11 @@ int NdtEngine::build_targets(bool wait)
     // overflow, more cells than the guessed key width holds, parameters that differ).
     bool one_wait = P == 1 && key_bits_hint_ > 0 && one_wait_build_allowed();
     if (one_wait) {
-        DdTargetOut* d_out = reinterpret_cast<DdTargetOut*>(d_bb_out + P);
+        // (the record lives in pinned host memory: the kernels write it over PCIe and the host polls its last word — no copy command, no stream wait)
+        DdTargetOut& h_out = *reinterpret_cast<DdTargetOut*>(hd + ((desc_bytes + sizeof(BBox) * P + sizeof(uint32_t) * P + 15) & ~size_t(15)));
+        DdTargetOut* d_out = &h_out;
+        constexpr uint32_t kNotYet = 0xFFFFFFFFu;  // (a run count is at most the point count, < 2^31)
+        h_out.n_runs = kNotYet;
         MRGFE_TRY(bounding_box_partials(ctx_, d_cp, d_sl, tab, d_bb_part));
         MRGFE_TRY(ndt_launch_dd_voxel_params(ctx_, d_bb_part, tab.total_blks, prm_.resolution, const_cast<VoxelParams*>(d_vp), const_cast<uint32_t*>(d_nv), d_out));
         key_bits = key_bits_hint_;
@@ -195,9 +199,18 @@ int NdtEngine::build_targets(bool wait)
         MRGFE_TRY(radix_sort_pairs(ctx_, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), d_sl, tab, key_bits, dh.as<uint32_t>(), &sk, &sv, true, true));
         d_tot = &d_out->n_runs;
         MRGFE_TRY(exclusive_scan_run_heads(ctx_, sk, nullptr, d_sl, tab, d_nv, dblk.as<uint32_t>(), d_tot));
-        DdTargetOut& h_out = *reinterpret_cast<DdTargetOut*>(hd + ((desc_bytes + sizeof(BBox) * P + sizeof(uint32_t) * P + 15) & ~size_t(15)));  // (pinned)
-        MRGFE_HIP_CHECK(hipMemcpyAsync(&h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost, st));
-        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+        {
+            const volatile uint32_t* flag = &h_out.n_runs;
+            for (uint32_t spin = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) == kNotYet; ++spin) {
+                if ((spin & 0x3ff) != 0x3ff) continue;
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) {  // everything queued has run: the count is there, or never will be
+                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == kNotYet) { set_error("NDT target build: the run-head count did not arrive"); return MRGFE_ERR_HIP; }
+                    break;
+                }
+                if (q != hipErrorNotReady) { set_error("NDT target build: %s", hipGetErrorString(q)); return MRGFE_ERR_HIP; }
+            }
+        }
         NdtTargetInfo& T = targets_[todo[0]];
         VoxelParams    vp_host;
         std::memset(&vp_host, 0, sizeof(vp_host));
