@@ -232,45 +232,45 @@ int NdtEngine::build_targets(bool wait)
         }
     }
     if (!one_wait) {
-    // 1. bounding boxes
-    MRGFE_TRY(bounding_boxes(ctx_, d_cp, d_sl, tab, d_bb_part, d_bb_out));
-    MRGFE_HIP_CHECK(hipMemcpyAsync(h_bb, d_bb_out, sizeof(BBox) * P, hipMemcpyDeviceToHost, st));
-    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+        // 1. bounding boxes
+        MRGFE_TRY(bounding_boxes(ctx_, d_cp, d_sl, tab, d_bb_part, d_bb_out));
+        MRGFE_HIP_CHECK(hipMemcpyAsync(h_bb, d_bb_out, sizeof(BBox) * P, hipMemcpyDeviceToHost, st));
+        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
 
-    // 2. voxel parameters (host, PCL arithmetic); failed targets become empty problems
-    uint32_t max_cells = 1;
-    for (int k = 0; k < P; ++k) {
-        NdtTargetInfo& T = targets_[todo[k]];
-        T.built = true;
-        if (h_bb[k].n_finite == 0) { T.status = MRGFE_ERR_EMPTY; h_sl[k].n = 0; h_sl[k].nblk = 0; continue; }
-        int st_vp = voxel_params_from_bbox(h_bb[k], prm_.resolution, &h_vp[k], T.max_b, T.div_b);
-        if (st_vp != MRGFE_OK) { T.status = st_vp; h_sl[k].n = 0; h_sl[k].nblk = 0; std::memset(&h_vp[k], 0, sizeof(VoxelParams)); continue; }
-        for (int a = 0; a < 3; ++a) T.min_b[a] = h_vp[k].min_b[a];
-        T.status = MRGFE_OK;
-        h_nv[k] = h_bb[k].n_finite;
-        max_cells = std::max(max_cells, h_vp[k].n_cells);
-    }
-    // rebuild the tile bookkeeping for the (possibly emptied) problems
-    for (int k = 0; k < P; ++k) sizes[k] = h_sl[k].n;
-    tab.build(sizes.data(), P);
-    for (int k = 0; k < P; ++k) h_sl[k] = tab.h[k];
-    MRGFE_HIP_CHECK(hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, st));
-    key_bits = 1;
-    while (key_bits < 32 && (uint64_t(1) << key_bits) <= max_cells) ++key_bits;  // key == n_cells marks non-finite points
-    if (P == 1 && targets_[todo[0]].status == MRGFE_OK) key_bits_hint_ = std::min(32, key_bits + 1);  // (a bit of room for the next keyframe's extent)
+        // 2. voxel parameters (host, PCL arithmetic); failed targets become empty problems
+        uint32_t max_cells = 1;
+        for (int k = 0; k < P; ++k) {
+            NdtTargetInfo& T = targets_[todo[k]];
+            T.built = true;
+            if (h_bb[k].n_finite == 0) { T.status = MRGFE_ERR_EMPTY; h_sl[k].n = 0; h_sl[k].nblk = 0; continue; }
+            int st_vp = voxel_params_from_bbox(h_bb[k], prm_.resolution, &h_vp[k], T.max_b, T.div_b);
+            if (st_vp != MRGFE_OK) { T.status = st_vp; h_sl[k].n = 0; h_sl[k].nblk = 0; std::memset(&h_vp[k], 0, sizeof(VoxelParams)); continue; }
+            for (int a = 0; a < 3; ++a) T.min_b[a] = h_vp[k].min_b[a];
+            T.status = MRGFE_OK;
+            h_nv[k] = h_bb[k].n_finite;
+            max_cells = std::max(max_cells, h_vp[k].n_cells);
+        }
+        // rebuild the tile bookkeeping for the (possibly emptied) problems
+        for (int k = 0; k < P; ++k) sizes[k] = h_sl[k].n;
+        tab.build(sizes.data(), P);
+        for (int k = 0; k < P; ++k) h_sl[k] = tab.h[k];
+        MRGFE_HIP_CHECK(hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, st));
+        key_bits = 1;
+        while (key_bits < 32 && (uint64_t(1) << key_bits) <= max_cells) ++key_bits;  // key == n_cells marks non-finite points
+        if (P == 1 && targets_[todo[0]].status == MRGFE_OK) key_bits_hint_ = std::min(32, key_bits + 1);  // (a bit of room for the next keyframe's extent)
 
-    // 3. keys, stable sort, run heads, ordinals
-    const size_t ne = std::max<size_t>(tab.total_elems, 4);
-    MRGFE_TRY(dk.ensure(ne * 4)); MRGFE_TRY(dv.ensure(ne * 4)); MRGFE_TRY(dkt.ensure(ne * 4)); MRGFE_TRY(dvt.ensure(ne * 4));
-    MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + P)));
-    MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (tab.total_blks + P + 4)));
-    MRGFE_TRY(ndt_launch_cellkeys(ctx_, d_cp, d_sl, tab, d_vp, dk.as<uint32_t>(), dh.as<uint32_t>()));
-    MRGFE_TRY(radix_sort_pairs(ctx_, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), d_sl, tab, key_bits, dh.as<uint32_t>(), &sk, &sv, true, true));
-    // run heads of the sorted keys: their number per target and the tiles' prefixes (a head's ordinal = its voxel's leaf index, made up by the segments kernel)
-    d_tot = dblk.as<uint32_t>() + tab.total_blks;
-    MRGFE_TRY(exclusive_scan_run_heads(ctx_, sk, nullptr, d_sl, tab, d_nv, dblk.as<uint32_t>(), d_tot));
-    MRGFE_HIP_CHECK(hipMemcpyAsync(h_tot, d_tot, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, st));
-    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+        // 3. keys, stable sort, run heads, ordinals
+        const size_t ne = std::max<size_t>(tab.total_elems, 4);
+        MRGFE_TRY(dk.ensure(ne * 4)); MRGFE_TRY(dv.ensure(ne * 4)); MRGFE_TRY(dkt.ensure(ne * 4)); MRGFE_TRY(dvt.ensure(ne * 4));
+        MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + P)));
+        MRGFE_TRY(dblk.ensure(sizeof(uint32_t) * (tab.total_blks + P + 4)));
+        MRGFE_TRY(ndt_launch_cellkeys(ctx_, d_cp, d_sl, tab, d_vp, dk.as<uint32_t>(), dh.as<uint32_t>()));
+        MRGFE_TRY(radix_sort_pairs(ctx_, dk.as<uint32_t>(), dv.as<uint32_t>(), dkt.as<uint32_t>(), dvt.as<uint32_t>(), d_sl, tab, key_bits, dh.as<uint32_t>(), &sk, &sv, true, true));
+        // run heads of the sorted keys: their number per target and the tiles' prefixes (a head's ordinal = its voxel's leaf index, made up by the segments kernel)
+        d_tot = dblk.as<uint32_t>() + tab.total_blks;
+        MRGFE_TRY(exclusive_scan_run_heads(ctx_, sk, nullptr, d_sl, tab, d_nv, dblk.as<uint32_t>(), d_tot));
+        MRGFE_HIP_CHECK(hipMemcpyAsync(h_tot, d_tot, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, st));
+        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
     }
 
     // 4. leaf storage
