@@ -66,8 +66,11 @@ enum mrgfe_method {
                           single registrations only (not in mrgfe_batch_*) */
     MRGFE_PCL_GICP_HIP = 5, /* replaces "GICP": pcl::GeneralizedIterativeClosestPoint (registrations.cpp:93-103): PCL's covariances, nearest-point
                                correspondences, inner BFGS with max_optimizer_iterations steps; single registrations only */
-    MRGFE_PCL_GICP_OMP_HIP = 6 /* replaces "GICP_OMP": pclomp::GeneralizedIterativeClosestPoint (registrations.cpp:104-114): the same algorithm with
-                                  the older stopping rule of the inner BFGS (norm of the whole gradient < 1e-2) */
+    MRGFE_PCL_GICP_OMP_HIP = 6, /* replaces "GICP_OMP": pclomp::GeneralizedIterativeClosestPoint (registrations.cpp:104-114): the same algorithm with
+                                   the older stopping rule of the inner BFGS (norm of the whole gradient < 1e-2) */
+    MRGFE_PCL_NDT_HIP = 7 /* replaces "NDT" and every name the factory does not know: pcl::NormalDistributionsTransform (registrations.cpp:115-129;
+                             PCL 1.12): f64 pair terms, the radius search over the voxel centroids (nn_search_method is ignored), PCL's own
+                             iteration test (squared translation of the last step <= transformation_epsilon); also in mrgfe_batch_* */
 };
 /* reg_nn_search_method (registrations.cpp:140-146) */
 enum mrgfe_ndt_search { MRGFE_KDTREE = 0, MRGFE_DIRECT26 = 1, MRGFE_DIRECT7 = 2, MRGFE_DIRECT1 = 3 };
@@ -170,7 +173,7 @@ int    mrgfe_reg_hessian(const mrgfe_reg* reg, double out[36]);
 
 /* ---- NDT internals exposed for kernel-level parity tests and the roofline accounting --------------------------- */
 /* one derivative evaluation at pose vector p (tx,ty,tz,rx,ry,rz) with the source transformed by T:
- * mode 0 = score+gradient+Hessian, 1 = score+gradient, 2 = Hessian only in double (pclomp computeHessian). */
+ * mode 0 = score+gradient+Hessian, 1 = score+gradient, 2 = Hessian only in double (pclomp computeHessian).  PCL_NDT_HIP: all three in f64. */
 int mrgfe_ndt_evaluate(mrgfe_reg* reg, const float T[16], const double p[6], int mode, double* score, double grad[6], double hess[36]);
 /* target grid: number of voxels with >= 1 point; per-voxel key (ascending), point count (-1: rejected by the
  * eigenvalue / inf checks), mean[3], inverse covariance[9] (row-major). Arrays sized by mrgfe_ndt_num_leaves. */

@@ -239,8 +239,8 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
 
     explicit HipRegistration(const mrgfe_reg_params& params, int device = 0, ContextRole role = ContextRole::General)
     {
-        static const char* const names[] = {"NDT_HIP", "GICP_HIP", "SMALL_GICP_HIP", "VGICP_HIP", "ICP_HIP", "PCL_GICP_HIP", "PCL_GICP_OMP_HIP"};
-        this->reg_name_ = (params.method >= 0 && params.method <= MRGFE_PCL_GICP_OMP_HIP) ? names[params.method] : "MRGFE";
+        static const char* const names[] = {"NDT_HIP", "GICP_HIP", "SMALL_GICP_HIP", "VGICP_HIP", "ICP_HIP", "PCL_GICP_HIP", "PCL_GICP_OMP_HIP", "PCL_NDT_HIP"};
+        this->reg_name_ = (params.method >= 0 && params.method <= MRGFE_PCL_NDT_HIP) ? names[params.method] : "MRGFE";
         if (mrgfe_reg_create(shared_context(device, role), &params, &reg_) != MRGFE_OK) throw std::runtime_error(std::string("mrgfe: ") + mrgfe_last_error());
         this->max_iterations_ = params.maximum_iterations;
         this->transformation_epsilon_ = params.transformation_epsilon;

@@ -16,7 +16,7 @@ _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.environ.get("MRGFE_LIB") or os.path.join(_PKG, "libmrgfe.so")  # MRGFE_LIB: kernel-variant experiments only
 
 MRGFE_OK, ERR_INVALID, ERR_HIP, ERR_OVERFLOW, ERR_EMPTY, ERR_STATE = 0, -1, -2, -3, -4, -5
-NDT_HIP, GICP_HIP, SMALL_GICP_HIP, VGICP_HIP, ICP_HIP, PCL_GICP_HIP, PCL_GICP_OMP_HIP = 0, 1, 2, 3, 4, 5, 6
+NDT_HIP, GICP_HIP, SMALL_GICP_HIP, VGICP_HIP, ICP_HIP, PCL_GICP_HIP, PCL_GICP_OMP_HIP, PCL_NDT_HIP = 0, 1, 2, 3, 4, 5, 6, 7
 SEARCH = {"KDTREE": 0, "DIRECT26": 1, "DIRECT7": 2, "DIRECT1": 3}
 
 

@@ -30,6 +30,8 @@ namespace {
 void col2row(const float in[16], float out[16]) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[r * 4 + c] = in[c * 4 + r]; }
 void row2col(const float in[16], float out[16]) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[c * 4 + r] = in[r * 4 + c]; }
 
+bool is_ndt(int method) { return method == MRGFE_NDT_HIP || method == MRGFE_PCL_NDT_HIP; }
+
 NdtParams ndt_params_from(const mrgfe_reg_params& p)
 {
     NdtParams n;
@@ -39,6 +41,10 @@ NdtParams ndt_params_from(const mrgfe_reg_params& p)
     n.trans_eps = p.transformation_epsilon;
     n.max_iterations = p.maximum_iterations;
     n.search = p.nn_search_method;
+    if (p.method == MRGFE_PCL_NDT_HIP) {  // pcl::NormalDistributionsTransform has one neighbourhood: target_cells_.radiusSearch(point, resolution_)
+        n.formulation = 1;
+        n.search = MRGFE_KDTREE;
+    }
     return n;
 }
 GicpParams gicp_params_from(const mrgfe_reg_params& p)
@@ -61,11 +67,11 @@ GicpParams gicp_params_from(const mrgfe_reg_params& p)
 int check_params(const mrgfe_reg_params* p)
 {
     if (!p) { set_error("NULL params"); return MRGFE_ERR_INVALID; }
-    if (p->method < MRGFE_NDT_HIP || p->method > MRGFE_PCL_GICP_OMP_HIP) { set_error("unknown registration method %d", p->method); return MRGFE_ERR_INVALID; }
+    if (p->method < MRGFE_NDT_HIP || p->method > MRGFE_PCL_NDT_HIP) { set_error("unknown registration method %d", p->method); return MRGFE_ERR_INVALID; }
     if ((p->method == MRGFE_PCL_GICP_HIP || p->method == MRGFE_PCL_GICP_OMP_HIP) && p->max_optimizer_iterations < 1) { set_error("max_optimizer_iterations must be >= 1"); return MRGFE_ERR_INVALID; }
-    if (p->method == MRGFE_NDT_HIP) {
+    if (is_ndt(p->method)) {
         if (!(p->resolution > 0)) { set_error("resolution must be > 0"); return MRGFE_ERR_INVALID; }
-        if (p->nn_search_method < 0 || p->nn_search_method > 3) { set_error("unknown nn_search_method %d", p->nn_search_method); return MRGFE_ERR_INVALID; }
+        if (p->method == MRGFE_NDT_HIP && (p->nn_search_method < 0 || p->nn_search_method > 3)) { set_error("unknown nn_search_method %d", p->nn_search_method); return MRGFE_ERR_INVALID; }
     } else {
         if (p->method != MRGFE_ICP_HIP && (p->correspondence_randomness < 4 || p->correspondence_randomness > 64)) { set_error("correspondence_randomness must be in [4, 64]"); return MRGFE_ERR_INVALID; }
         if (p->method == MRGFE_VGICP_HIP && !(p->resolution > 0)) { set_error("resolution must be > 0"); return MRGFE_ERR_INVALID; }
@@ -175,7 +181,7 @@ int mrgfe_reg_create(mrgfe_ctx* ctx, const mrgfe_reg_params* params, mrgfe_reg**
     if (!r) { set_error("out of host memory"); return MRGFE_ERR_INVALID; }
     r->ctx = ctx;
     r->params = *params;
-    if (params->method == MRGFE_NDT_HIP) {
+    if (is_ndt(params->method)) {
         r->ndt = new NdtEngine(ctx, ndt_params_from(*params));
         if (const char* e = std::getenv("MRGFE_FORCE_HASH")) r->ndt->set_force_hash(e[0] == '1');
     } else {
@@ -1045,7 +1051,7 @@ int mrgfe_batch_add_pair_keyed(mrgfe_batch* b, int target, uint64_t key, const f
             delete it->second;
             b->store.erase(it);
         }
-        store_make_room(b, n * 16 + (b->params.method != MRGFE_NDT_HIP ? n * 48 : 0));
+        store_make_room(b, n * 16 + (!is_ndt(b->params.method) ? n * 48 : 0));
         kf = new (std::nothrow) mrgfe_batch::Keyframe();
         if (!kf) { set_error("out of host memory"); return MRGFE_ERR_INVALID; }
         int rc = kf->cloud.ensure(std::max<size_t>(n, 1) * 16);
@@ -1109,7 +1115,7 @@ int mrgfe_batch_build_targets(mrgfe_batch* b)
 {
     if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(b->ctx);
-    if (b->params.method != MRGFE_NDT_HIP) return MRGFE_OK;  // GICP variants: target covariances and grids are built by the first align
+    if (!is_ndt(b->params.method)) return MRGFE_OK;  // GICP variants: target covariances and grids are built by the first align
     return b->ndt->build_targets();
 }
 int mrgfe_batch_num_pairs(const mrgfe_batch* b) { return b ? b->ndt->n_pairs() : 0; }
@@ -1120,7 +1126,7 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
     MRGFE_LOCK(b->ctx);
     NdtEngine& e = *b->ndt;
     const int P = e.n_pairs();
-    const bool gicp = b->params.method != MRGFE_NDT_HIP;
+    const bool gicp = !is_ndt(b->params.method);
     std::vector<char> fit_built;   // targets whose fitness grid is built in this call
     std::vector<char> early_skip;  // pairs whose fitness score was computed beside the alignment rounds
     if (gicp) {
@@ -1536,7 +1542,7 @@ int mrgfe_batch_rounds(const mrgfe_batch* b) { return b && b->ndt ? b->ndt->roun
 int mrgfe_dbg_ctl_create(const mrgfe_reg_params* params, const float guess[16], uint32_t n_src, mrgfe_dbg_ctl** out)
 {
     if (!params || !guess || !out) { set_error("mrgfe_dbg_ctl_create: NULL argument"); return MRGFE_ERR_INVALID; }
-    if (params->method != MRGFE_NDT_HIP) { set_error("mrgfe_dbg_ctl_create: NDT_HIP only"); return MRGFE_ERR_INVALID; }
+    if (!is_ndt(params->method)) { set_error("mrgfe_dbg_ctl_create: NDT_HIP / PCL_NDT_HIP only"); return MRGFE_ERR_INVALID; }
     MRGFE_TRY(check_params(params));
     mrgfe_dbg_ctl* h = new mrgfe_dbg_ctl();
     float g[16];

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void ndt_leaf_finalize_kernel(const LeafSlice*
     rec.icov[3] = static_cast<float>(icov[4]); rec.icov[4] = static_cast<float>(icov[5]); rec.icov[5] = static_cast<float>(icov[8]);
     leaves[gl] = rec;
     nr_points[gl] = npts;
-    if (npts >= kNdtMinPointsPerVoxel) {
+    if (npts >= kNdtMinPointsPerVoxel || (ls.keep_rejected && n >= kNdtMinPointsPerVoxel)) {
         const uint32_t key = static_cast<uint32_t>(seg_key[gl]);
         if (ls.dense) {
             reinterpret_cast<int32_t*>(static_cast<char*>(lookup_base) + ls.lookup_byte_off)[key] = static_cast<int32_t>(leaf);

@@ -40,7 +40,8 @@ void NdtController::start(const NdtParams& prm, const float guess[16], uint32_t 
     s_.max_iterations = prm.max_iterations;
     s_.search = prm.search;
     s_.reuse = reuse_enabled() ? 1 : 0;
-    s_.split_first = split_first ? 1 : 0;
+    s_.split_first = (split_first && prm.formulation == 0) ? 1 : 0;
+    s_.formulation = prm.formulation;
     s_.n_src = n_src;
     // pcl::Registration::align
     ctl::identity16(s_.final_); ctl::identity16(s_.transformation_); ctl::identity16(s_.previous_);

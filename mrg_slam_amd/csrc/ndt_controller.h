@@ -18,6 +18,8 @@ struct NdtParams {
     double trans_eps = 0.1;
     int    max_iterations = 35;
     int    search = 2;  // MRGFE_DIRECT7
+    int    formulation = 0;  // 0: pclomp (NDT_HIP); 1: pcl::NormalDistributionsTransform, PCL 1.12 (PCL_NDT_HIP): f64 terms, radius search (search is
+                             // MRGFE_KDTREE then), PCL's iteration test
 };
 
 class NdtController {

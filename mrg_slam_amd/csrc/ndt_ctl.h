@@ -33,6 +33,8 @@ struct NdtCtlState {
     uint32_t n_src;
     int32_t  converged, nr_iterations, n_evals, n_reused, cache_valid;
     int32_t  split_first;  // 1: the first trial of a line search is evaluated without its Hessian, which is fetched afterwards if used (below)
+    int32_t  formulation;  // 0: pclomp::NormalDistributionsTransform (NDT_OMP); 1: pcl::NormalDistributionsTransform of PCL 1.12 ("NDT",
+                           // registrations.cpp:115-129): f64 pair terms (the kernels), PCL's iteration test and zero-step rule (below)
     float    final_[16], transformation_[16], previous_[16];  // row-major
     double   cache_p[6], cache_nb;
     double   trans_probability, nb_sum;
@@ -551,8 +553,20 @@ MRGFE_HD int ls_flow(NdtCtlState& s, CtlNext next, double a_fin)
                 for (int k = 0; k < 6; ++k) delta_p[k] = s.dir[k] * a_fin;
                 pose_to_matrix(delta_p, s.transformation_);
                 for (int k = 0; k < 6; ++k) s.p[k] = s.p[k] + delta_p[k];
-                if (s.nr_iterations > s.max_iterations || (s.nr_iterations && (fabs(a_fin) < s.trans_eps))) s.converged = 1;
-                s.nr_iterations++;
+                if (s.formulation == 1) {
+                    // PCL >= 1.11.1 (ndt.hpp computeTransformation): nr_iterations_++ first; then the step's float matrix against the epsilons —
+                    // the SQUARED translation against the un-squared transformation_epsilon_ (squaredNorm of a 3-vector: Eigen adds e0 + (e1 + e2));
+                    // transformation_rotation_epsilon_ stays 0 in the reference (registrations.cpp:125-127), which leaves
+                    //   nr_iterations_ >= max_iterations_ || (transformation_epsilon_ > 0 && translation_sqr <= transformation_epsilon_)
+                    const float tx = s.transformation_[3], ty = s.transformation_[7], tz = s.transformation_[11];
+                    const float yz = ty * ty + tz * tz;
+                    const double translation_sqr = static_cast<double>(tx * tx + yz);
+                    s.nr_iterations++;
+                    if (s.nr_iterations >= s.max_iterations || (s.trans_eps > 0 && translation_sqr <= s.trans_eps)) s.converged = 1;
+                } else {
+                    if (s.nr_iterations > s.max_iterations || (s.nr_iterations && (fabs(a_fin) < s.trans_eps))) s.converged = 1;
+                    s.nr_iterations++;
+                }
                 if (s.converged) {
                     s.trans_probability = s.score / static_cast<double>(s.n_src);
                     s.phase = NDT_DONE;
@@ -585,7 +599,7 @@ MRGFE_HD int after_solve(NdtCtlState& s, const double delta[6])
     const double norm = sqrt(n2);
     if (norm == 0 || norm != norm) {
         s.trans_probability = s.score / static_cast<double>(s.n_src);
-        s.converged = (norm == norm) ? 1 : 0;
+        s.converged = s.formulation == 1 ? (norm == 0 ? 1 : 0) : ((norm == norm) ? 1 : 0);  // PCL >= 1.11.1: converged_ = delta_norm == 0
         s.phase = NDT_DONE;
         return CTL_RETURN;
     }

@@ -14,10 +14,10 @@ int ndt_launch_plan(mrgfe_ctx* ctx, const NdtPairDev* d_pairs, const NdtEvalDev*
 int ndt_launch_snapshot(mrgfe_ctx* ctx, const NdtCtlState* d_states, uint32_t P, uint32_t tag, NdtSnapshotHead* h_head, NdtSnapshotRec* h_recs);
 // one derivative evaluation for the pairs the plan lists under `mode`: `grid` workgroups walk the plan's items
 int ndt_launch_derivatives(mrgfe_ctx* ctx, int mode, int search, uint32_t grid, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals,
-                           const uint32_t* d_plan, uint32_t P, double* d_partials);
+                           const uint32_t* d_plan, uint32_t P, double* d_partials, int formulation = 0);
 // the same for all three variants in ONE launch (items interleaved in proportion to their counts)
 int ndt_launch_derivatives_all(mrgfe_ctx* ctx, int search, uint32_t grid, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const uint32_t* d_plan,
-                               uint32_t P, double* d_partials);
+                               uint32_t P, double* d_partials, int formulation = 0);  // formulation 1: the f64 items of PCL_NDT_HIP (radius search, 27 probes)
 // fixed-order sum of the item partials of every pending evaluation.  d_states != NULL: followed by the controller step on the
 // device (next request written to d_evals).  d_states == NULL: results[pair][48] = {score, g[6], H[36] row-major, neighbours, pad}
 int ndt_launch_reduce(mrgfe_ctx* ctx, uint32_t P, const NdtPairDev* d_pairs, NdtEvalDev* d_evals, const double* d_partials, const uint32_t* d_plan, double* d_results,

@@ -488,6 +488,195 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
     }
 }
 
+// ---- PCL_NDT_HIP: pcl::NormalDistributionsTransform (PCL 1.12), the f64 formulation ---------------------------------------------------
+// What registration_method "NDT" (and every unknown name) runs in the reference (/root/reference/src/mrg_slam/registrations.cpp:115-129):
+// computeDerivatives / updateDerivatives / computeHessian / updateHessian with Eigen::Vector3d / Matrix3d throughout, over
+// target_cells_.radiusSearch(x_trans_pt, resolution_) — the voxels whose float centroid lies within one resolution of the point (27 cells
+// to probe).  One lane per POINT for all three kinds of evaluation.  J and the second-derivative vectors belong to the point, so with
+// v = C q and e the pair's weight the reference's per-pair sums
+//     score += -d1 exp(..);   g_i += e (q.C J_i);   H_ij += e ( -d2 (q.C J_i)(q.C J_j) + q.C PH_ij + J_j.C J_i )
+// factor over the point's voxels into
+//     g_i = (sum e v) . J_i;   H_ij = J_i^T [ sum e C - d2 sum e v v^T ] J_j + (sum e v) . PH_ij
+// — ~45 fused multiply-adds per voxel and ~110 per point instead of ~300 per pair.  Everything is f64: the different association moves
+// a sum by ~1e-16 relative, like the order of the additions (the reference adds point after point on one thread); oracle/pcl_ndt.cpp restates
+// both the reference's order and, as a diagnostic, this one.  The inverse covariance is read as its upper triangle (the cofactor inverse of
+// a clamped covariance is symmetric to ~1e-14 relative).
+// The lane first collects its hits — occupied cell, centroid inside the radius — in its own column of the LDS queue, then walks them: a
+// wavefront runs max(hits) rounds instead of 27 mostly empty ones.
+template <int MODE>
+__device__ __forceinline__ void ndt_derivatives_f64_item(NdtDerivShared<27>& sh, const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
+                                                         const NdtEvalDev* __restrict__ evals, uint32_t pi, uint32_t item_in_pair, uint32_t ppt, double* __restrict__ partials)
+{
+    constexpr int NNB = 27;
+    float (&s_T)[12] = sh.T;
+    uint32_t (&s_hits)[kTilePts * NNB] = sh.queue;  // [hit][lane]
+    double (&s_red)[4][kNdtPartialStride] = sh.red;
+    const NdtPairDev pr = pairs[pi];
+    const NdtEvalDev& ev = evals[pi];
+    const uint32_t part_off = pr.part_off;
+    const NdtGridDev g = grids[pr.grid];
+    __syncthreads();  // the previous item's epilogue has read s_red / the staged transform
+    if (threadIdx.x < 12) s_T[threadIdx.x] = ev.T[threadIdx.x];
+    __syncthreads();
+    const double gauss_d1 = ev.gauss_d1, gauss_d2 = ev.gauss_d2;
+    const float  leaf = g.leaf_size;
+    const float  r2 = leaf * leaf;  // float(radius * radius): the product of two floats is exact in double, so one rounding either way
+
+    Accum acc;
+    acc.score = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc.g[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc.H[k] = 0;
+    uint32_t nb_mine = 0;
+
+    const uint32_t base = item_in_pair * static_cast<uint32_t>(kTilePts) * ppt;
+    const uint32_t last = min(pr.n_src, base + static_cast<uint32_t>(kTilePts) * ppt);
+    for (uint32_t tile0 = base; tile0 < last; tile0 += kTilePts) {
+        const uint32_t i = tile0 + threadIdx.x;
+        if (i >= last) continue;
+        const float4 p = load_point(pr.src + i);
+        float xt[3];
+        transform_point(s_T, p.x, p.y, p.z, xt[0], xt[1], xt[2]);
+        int ijk[3];
+        if (leaf == 1.0f) { ijk[0] = static_cast<int>(floorf(xt[0])); ijk[1] = static_cast<int>(floorf(xt[1])); ijk[2] = static_cast<int>(floorf(xt[2])); }
+        else              { ijk[0] = static_cast<int>(floorf(xt[0] / leaf)); ijk[1] = static_cast<int>(floorf(xt[1] / leaf)); ijk[2] = static_cast<int>(floorf(xt[2] / leaf)); }
+        bool in_box[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int o = -1; o <= 1; ++o) in_box[a][o + 1] = ijk[a] + o >= g.min_b[a] && ijk[a] + o <= g.max_b[a];
+        const uint32_t mul[3] = {static_cast<uint32_t>(g.divb_mul[0]), static_cast<uint32_t>(g.divb_mul[1]), static_cast<uint32_t>(g.divb_mul[2])};
+        const uint32_t key0 = (static_cast<uint32_t>(ijk[0]) - static_cast<uint32_t>(g.min_b[0])) * mul[0] + (static_cast<uint32_t>(ijk[1]) - static_cast<uint32_t>(g.min_b[1])) * mul[1] +
+                              (static_cast<uint32_t>(ijk[2]) - static_cast<uint32_t>(g.min_b[2])) * mul[2];
+        // ---- the point's hits: nine probes (one x slab) in flight at a time, then their centroids --------------------------------------
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int slab = 0; slab < 3; ++slab) {
+            int32_t ids[9];
+#pragma unroll
+            for (int m = 0; m < 9; ++m) {
+                const int o0 = slab - 1, o1 = m / 3 - 1, o2 = m % 3 - 1;
+                const bool     ok = in_box[0][o0 + 1] && in_box[1][o1 + 1] && in_box[2][o2 + 1];
+                const uint32_t key = key0 + static_cast<uint32_t>(o0) * mul[0] + static_cast<uint32_t>(o1) * mul[1] + static_cast<uint32_t>(o2) * mul[2];
+                if (g.dense) { const int32_t v = as_global(static_cast<const int32_t*>(g.lookup))[ok ? key : 0u]; ids[m] = ok ? v : -1; }
+                else         ids[m] = ok ? ndt_lookup(g, key) : -1;
+            }
+            float4 c[9];
+#pragma unroll
+            for (int m = 0; m < 9; ++m) c[m] = load_point(g.centroid + (ids[m] >= 0 && static_cast<uint32_t>(ids[m]) < g.n_leaves ? ids[m] : 0));
+#pragma unroll
+            for (int m = 0; m < 9; ++m) {
+                if (ids[m] < 0 || static_cast<uint32_t>(ids[m]) >= g.n_leaves) continue;
+                const float dx = c[m].x - xt[0], dy = c[m].y - xt[1], dz = c[m].z - xt[2];
+                const float d = dot3f(dx, dx, dy, dy, dz, dz);
+                if (d < r2) { s_hits[cnt * kTilePts + threadIdx.x] = static_cast<uint32_t>(ids[m]); ++cnt; }  // FLANN keeps dist^2 < r^2
+            }
+        }
+        nb_mine += cnt;
+        if (!cnt) continue;
+        // ---- the point's voxels ---------------------------------------------------------------------------------------------------------
+        double M1[6] = {0, 0, 0, 0, 0, 0}, M2[6] = {0, 0, 0, 0, 0, 0}, w[3] = {0, 0, 0}, sc = 0;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const uint32_t lid = s_hits[k * kTilePts + threadIdx.x];
+            const MRGFE_GLOBAL double* __restrict__ C = as_global(g.icov64 + (size_t)lid * 9);
+            const MRGFE_GLOBAL double* __restrict__ mean = as_global(g.leaves[lid].mean);
+            const double c00 = C[0], c01 = C[1], c02 = C[2], c11 = C[4], c12 = C[5], c22 = C[8];
+            const double q[3] = {static_cast<double>(xt[0]) - mean[0], static_cast<double>(xt[1]) - mean[1], static_cast<double>(xt[2]) - mean[2]};
+            double v[3];
+            v[0] = fdot3d(c00, q[0], c01, q[1], c02, q[2]);
+            v[1] = fdot3d(c01, q[0], c11, q[1], c12, q[2]);
+            v[2] = fdot3d(c02, q[0], c12, q[1], c22, q[2]);
+            const double e_raw = exp(-gauss_d2 * fdot3d(q[0], v[0], q[1], v[1], q[2], v[2]) / 2);
+            double e = gauss_d2 * e_raw;
+            if (e > 1 || e < 0 || e != e) continue;  // updateDerivatives returns 0: the pair adds nothing, not even its score
+            e *= gauss_d1;
+            sc += -gauss_d1 * e_raw;
+            const double ev3[3] = {e * v[0], e * v[1], e * v[2]};
+            w[0] += ev3[0]; w[1] += ev3[1]; w[2] += ev3[2];
+            if (MODE != 1) {
+                M1[0] = __builtin_fma(e, c00, M1[0]); M1[1] = __builtin_fma(e, c01, M1[1]); M1[2] = __builtin_fma(e, c02, M1[2]);
+                M1[3] = __builtin_fma(e, c11, M1[3]); M1[4] = __builtin_fma(e, c12, M1[4]); M1[5] = __builtin_fma(e, c22, M1[5]);
+                M2[0] = __builtin_fma(ev3[0], v[0], M2[0]); M2[1] = __builtin_fma(ev3[0], v[1], M2[1]); M2[2] = __builtin_fma(ev3[0], v[2], M2[2]);
+                M2[3] = __builtin_fma(ev3[1], v[1], M2[3]); M2[4] = __builtin_fma(ev3[1], v[2], M2[4]); M2[5] = __builtin_fma(ev3[2], v[2], M2[5]);
+            }
+        }
+        // ---- the point's share: computePointDerivatives (f64) applied once to the voxel sums ---------------------------------------------
+        const double x[3] = {p.x, p.y, p.z};
+        double xj[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xj[r] = fdot3d(x[0], ev.j_ang_d[r][0], x[1], ev.j_ang_d[r][1], x[2], ev.j_ang_d[r][2]);
+        const double Jr[3][3] = {{0.0, xj[2], xj[5]}, {xj[0], xj[3], xj[6]}, {xj[1], xj[4], xj[7]}};  // Jr[row][c]: columns 3, 4, 5 of J
+        if (MODE != 2) {
+            acc.score += sc;
+            acc.g[0] += w[0]; acc.g[1] += w[1]; acc.g[2] += w[2];
+            acc.g[3] += fdot3d_z(w[1], Jr[1][0], w[2], Jr[2][0]);
+            acc.g[4] += fdot3d(w[0], Jr[0][1], w[1], Jr[1][1], w[2], Jr[2][1]);
+            acc.g[5] += fdot3d(w[0], Jr[0][2], w[1], Jr[1][2], w[2], Jr[2][2]);
+        }
+        if (MODE != 1) {
+            double xh[15];
+#pragma unroll
+            for (int r = 0; r < 15; ++r) xh[r] = fdot3d(x[0], ev.h_ang_d[r][0], x[1], ev.h_ang_d[r][1], x[2], ev.h_ang_d[r][2]);
+            double A[3][3];
+            {
+                double a[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) a[k] = __builtin_fma(-gauss_d2, M2[k], M1[k]);
+                A[0][0] = a[0]; A[0][1] = A[1][0] = a[1]; A[0][2] = A[2][0] = a[2]; A[1][1] = a[3]; A[1][2] = A[2][1] = a[4]; A[2][2] = a[5];
+            }
+            double AJ[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                AJ[r][0] = fdot3d_z(A[r][1], Jr[1][0], A[r][2], Jr[2][0]);
+                AJ[r][1] = fdot3d(A[r][0], Jr[0][1], A[r][1], Jr[1][1], A[r][2], Jr[2][1]);
+                AJ[r][2] = fdot3d(A[r][0], Jr[0][2], A[r][1], Jr[1][2], A[r][2], Jr[2][2]);
+            }
+            acc.H[0 * 6 + 0] += A[0][0]; acc.H[0 * 6 + 1] += A[0][1]; acc.H[0 * 6 + 2] += A[0][2]; acc.H[1 * 6 + 1] += A[1][1]; acc.H[1 * 6 + 2] += A[1][2]; acc.H[2 * 6 + 2] += A[2][2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc.H[i * 6 + 3 + c] += AJ[i][c];
+            const double PH[6][3] = {{0, xh[0], xh[1]}, {0, xh[2], xh[3]}, {0, xh[4], xh[5]}, {xh[6], xh[7], xh[8]}, {xh[9], xh[10], xh[11]}, {xh[12], xh[13], xh[14]}};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = i; j < 3; ++j) {
+                    const int ph = (i == 0) ? j : (i == 1 ? j + 2 : 5);
+                    const double jaj = (i == 0) ? fdot3d_z(Jr[1][0], AJ[1][j], Jr[2][0], AJ[2][j]) : fdot3d(Jr[0][i], AJ[0][j], Jr[1][i], AJ[1][j], Jr[2][i], AJ[2][j]);
+                    const double wph = (ph < 3) ? fdot3d_z(w[1], PH[ph][1], w[2], PH[ph][2]) : fdot3d(w[0], PH[ph][0], w[1], PH[ph][1], w[2], PH[ph][2]);
+                    acc.H[(3 + i) * 6 + 3 + j] += jaj + wph;
+                }
+        }
+    }
+
+    // ---- workgroup reduction: the float variants' tree (the Hessian's upper triangle is mirrored on the way) ----------------------------
+    constexpr int kVals = MODE == 0 ? kNdtAccum : (MODE == 1 ? 8 : 37);
+    double vals[kVals];
+    int    keys[kVals];
+#pragma unroll
+    for (int n = 0; n < kVals; ++n) {
+        const int k = (MODE == 1 && n == 7) ? kNdtNbIndex : (MODE == 2 ? 7 + n : n);
+        keys[n] = k;
+        if (k == 0)                vals[n] = acc.score;
+        else if (k < 7)            vals[n] = acc.g[k - 1];
+        else if (k < kNdtNbIndex)  vals[n] = ((k - 7) / 6 > (k - 7) % 6) ? acc.H[((k - 7) % 6) * 6 + (k - 7) / 6] : acc.H[k - 7];
+        else                       vals[n] = static_cast<double>(nb_mine);
+    }
+    double total_v;
+    int    total_k;
+    wave_sum_fold<kVals, 32>(vals, keys, total_v, total_k);
+    s_red[wave_id()][total_k] = total_v;
+    __syncthreads();
+    if (threadIdx.x < kNdtPartialStride) {
+        const int  k = threadIdx.x;
+        const bool skip = k >= kNdtAccum || (MODE == 1 && k >= 7 && k < kNdtNbIndex) || (MODE == 2 && k < 7);
+        double     r = 0.0;
+        if (!skip) r = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
+        partials[(size_t)(part_off + item_in_pair) * kNdtPartialStride + k] = r;
+    }
+}
+
 // pair and position within the pair of item `item` of variant `mode`: the last busy pair whose first item is <= item
 // (uniform over the workgroup: scalar loads)
 __device__ __forceinline__ void ndt_plan_find(const uint32_t* __restrict__ plan, uint32_t n_all_pairs, int mode, uint32_t n_busy, uint32_t item, uint32_t& pi, uint32_t& item_in_pair)
@@ -560,6 +749,50 @@ __global__ __launch_bounds__(256, NNB <= 7 ? NDT_MODE0_WAVES : 2) void ndt_deriv
     if (at < n2) at += (n2 - at + g - 1) / g * g;
     at -= n2;
     ndt_derivatives_walk<1, NNB>(sh, at, grids, pairs, evals, plan, n_all_pairs, partials);
+}
+
+// PCL_NDT_HIP launches: the same plan, the f64 items
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void ndt_derivatives_f64_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs, const NdtEvalDev* __restrict__ evals,
+                                                                      const uint32_t* __restrict__ plan, uint32_t n_all_pairs, double* __restrict__ partials)
+{
+    const NdtPlanHead& head = *reinterpret_cast<const NdtPlanHead*>(plan);
+    const uint32_t n_items = head.n_items[MODE];
+    if (blockIdx.x >= n_items) return;
+    const uint32_t ppt = head.ppt[MODE], n_busy = head.n_pairs[MODE];
+    __shared__ NdtDerivShared<27> sh;
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        uint32_t pi, item_in_pair;
+        ndt_plan_find(plan, n_all_pairs, MODE, n_busy, item, pi, item_in_pair);
+        ndt_derivatives_f64_item<MODE>(sh, grids, pairs, evals, pi, item_in_pair, ppt, partials);
+    }
+}
+template <int MODE>
+__device__ __forceinline__ void ndt_derivatives_f64_walk(NdtDerivShared<27>& sh, uint32_t first, const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
+                                                         const NdtEvalDev* __restrict__ evals, const uint32_t* __restrict__ plan, uint32_t n_all_pairs, double* __restrict__ partials)
+{
+    const NdtPlanHead& head = *reinterpret_cast<const NdtPlanHead*>(plan);
+    const uint32_t n_items = head.n_items[MODE], ppt = head.ppt[MODE], n_busy = head.n_pairs[MODE];
+    for (uint32_t item = first; item < n_items; item += gridDim.x) {
+        uint32_t pi, item_in_pair;
+        ndt_plan_find(plan, n_all_pairs, MODE, n_busy, item, pi, item_in_pair);
+        ndt_derivatives_f64_item<MODE>(sh, grids, pairs, evals, pi, item_in_pair, ppt, partials);
+    }
+}
+__global__ __launch_bounds__(256, 2) void ndt_derivatives_f64_all_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs, const NdtEvalDev* __restrict__ evals,
+                                                                          const uint32_t* __restrict__ plan, uint32_t n_all_pairs, double* __restrict__ partials)
+{
+    __shared__ NdtDerivShared<27> sh;
+    const NdtPlanHead& head = *reinterpret_cast<const NdtPlanHead*>(plan);
+    const uint32_t n0 = head.n_items[0], n2 = head.n_items[2], g = gridDim.x;
+    uint32_t at = blockIdx.x;
+    ndt_derivatives_f64_walk<0>(sh, at, grids, pairs, evals, plan, n_all_pairs, partials);
+    if (at < n0) at += (n0 - at + g - 1) / g * g;
+    at -= n0;
+    ndt_derivatives_f64_walk<2>(sh, at, grids, pairs, evals, plan, n_all_pairs, partials);
+    if (at < n2) at += (n2 - at + g - 1) / g * g;
+    at -= n2;
+    ndt_derivatives_f64_walk<1>(sh, at, grids, pairs, evals, plan, n_all_pairs, partials);
 }
 
 // ---- the round's plan -------------------------------------------------------------------------------------------------
@@ -839,10 +1072,11 @@ static void launch_mode(mrgfe_ctx* ctx, int nnb, uint32_t grid, const NdtGridDev
 }
 
 int ndt_launch_derivatives_all(mrgfe_ctx* ctx, int search, uint32_t grid, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const uint32_t* d_plan,
-                               uint32_t P, double* d_partials)
+                               uint32_t P, double* d_partials, int formulation)
 {
     if (grid == 0 || P == 0) return MRGFE_OK;
-    if (search == MRGFE_DIRECT7)      hipLaunchKernelGGL((ndt_derivatives_all_kernel<7>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
+    if (formulation == 1)             hipLaunchKernelGGL(ndt_derivatives_f64_all_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
+    else if (search == MRGFE_DIRECT7)      hipLaunchKernelGGL((ndt_derivatives_all_kernel<7>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
     else if (search == MRGFE_DIRECT1) hipLaunchKernelGGL((ndt_derivatives_all_kernel<1>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
     else                              hipLaunchKernelGGL((ndt_derivatives_all_kernel<27>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
     MRGFE_HIP_CHECK(hipGetLastError());
@@ -901,9 +1135,16 @@ int ndt_launch_plan(mrgfe_ctx* ctx, const NdtPairDev* d_pairs, const NdtEvalDev*
 }
 
 int ndt_launch_derivatives(mrgfe_ctx* ctx, int mode, int search, uint32_t grid, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals,
-                           const uint32_t* d_plan, uint32_t P, double* d_partials)
+                           const uint32_t* d_plan, uint32_t P, double* d_partials, int formulation)
 {
     if (grid == 0 || P == 0) return MRGFE_OK;
+    if (formulation == 1) {
+        if (mode == 0)      hipLaunchKernelGGL((ndt_derivatives_f64_kernel<0>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
+        else if (mode == 1) hipLaunchKernelGGL((ndt_derivatives_f64_kernel<1>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
+        else                hipLaunchKernelGGL((ndt_derivatives_f64_kernel<2>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
+        MRGFE_HIP_CHECK(hipGetLastError());
+        return MRGFE_OK;
+    }
     const int nnb = (search == MRGFE_DIRECT7) ? 7 : (search == MRGFE_DIRECT1 ? 1 : 27);
     if (mode == 0)      launch_mode<0>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
     else if (mode == 1) launch_mode<1>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_plan, P, d_partials);

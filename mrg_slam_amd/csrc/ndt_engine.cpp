@@ -290,6 +290,7 @@ int NdtEngine::build_targets(bool wait)
         ls.leaf_off = total_leaves;
         ls.seg_off = total_leaves + k;
         ls.n_valid = h_nv[k];
+        ls.keep_rejected = prm_.search == MRGFE_KDTREE ? 1u : 0u;  // radiusSearch has no nr_points test (ndt_build.h)
         ls.lookup_byte_off = lookup_bytes;
         if (T.status == MRGFE_OK) {
             if (h_vp[k].n_cells <= kDenseLookupMaxCells && !force_hash_) {
@@ -463,7 +464,7 @@ static int env_int(const char* name, int dflt) { const char* e = std::getenv(nam
 uint32_t NdtEngine::derivative_grid(int mode) const
 {
     static const int per_slot = std::max(1, env_int("MRGFE_GRID_PER_SLOT", 8));
-    const bool narrow = prm_.search != MRGFE_KDTREE && prm_.search != MRGFE_DIRECT26;
+    const bool narrow = prm_.search != MRGFE_KDTREE && prm_.search != MRGFE_DIRECT26 && prm_.formulation == 0;
     const int slots_per_cu = fused_launch() ? (narrow ? 3 : 2) : ((mode != 1 && narrow) ? 3 : 2);  // __launch_bounds__ of the kernels
     return static_cast<uint32_t>(ctx_->cu_count * slots_per_cu * per_slot);
 }
@@ -536,7 +537,7 @@ int NdtEngine::enqueue_round(uint32_t round, bool device_control, const bool wan
                 grid = std::min(grid, h->n_items[0] + h->n_items[1] + h->n_items[2]);  // the host knows the item count
             }
             MRGFE_TRY(ndt_launch_derivatives_all(ctx_, prm_.search, grid, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_plan(), P,
-                                                 d_partials_.as<double>()));
+                                                 d_partials_.as<double>(), prm_.formulation));
             if (timed) MRGFE_HIP_CHECK(hipEventRecord(ev_pool_[size_t(round) * 6 + 1], st));
         }
     } else
@@ -547,7 +548,7 @@ int NdtEngine::enqueue_round(uint32_t round, bool device_control, const bool wan
         uint32_t grid = derivative_grid(m);
         if (!device_control) grid = std::min(grid, reinterpret_cast<const NdtPlanHead*>(plan_scratch_.data())->n_items[m]);  // the host knows the item count
         MRGFE_TRY(ndt_launch_derivatives(ctx_, m, prm_.search, grid, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(),
-                                         d_plan(), P, d_partials_.as<double>()));
+                                         d_plan(), P, d_partials_.as<double>(), prm_.formulation));
         if (timed) MRGFE_HIP_CHECK(hipEventRecord(ev_pool_[size_t(round) * 6 + m * 2 + 1], st));
     }
     // host control: the 384-byte result records go straight into pinned host memory (no device-to-host copy command)
@@ -609,8 +610,9 @@ void NdtEngine::account(const std::vector<NdtRoundInfo>& info, size_t rounds)
     for (const auto& p : pairs_) {
         const NdtCtlState& s = p.ctl.state();
         for (int m = 0; m < 3; ++m) {
-            // SURVEY.md §8(d) byte model: point (16) + probes (8 each) + 48 per valid neighbour voxel
-            mode_alg_bytes[m] += s.acct_points[m] * (16.0 + 8.0 * probes) + s.acct_nb[m] * 48.0;
+            // SURVEY.md §8(d) byte model: point (16) + probes (8 each) + 48 per valid neighbour voxel; the f64 formulation reads 96 per
+            // neighbour (mean 3 x f64 + inverse covariance 9 x f64) and a 16-byte centroid per hit
+            mode_alg_bytes[m] += s.acct_points[m] * (16.0 + 8.0 * probes) + s.acct_nb[m] * (prm_.formulation == 1 ? 112.0 : 48.0);
             mode_points[m] += s.acct_points[m];
             mode_neighbours[m] += s.acct_nb[m];
         }

@@ -17,7 +17,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import GICP_HIP, ICP_HIP, NDT_HIP, PCL_GICP_HIP, PCL_GICP_OMP_HIP, SEARCH, SMALL_GICP_HIP, VGICP_HIP, Context, PairResult, RegParams, check, default_context, lib
+from ._lib import GICP_HIP, ICP_HIP, NDT_HIP, PCL_GICP_HIP, PCL_GICP_OMP_HIP, PCL_NDT_HIP, SEARCH, SMALL_GICP_HIP, VGICP_HIP, Context, PairResult, RegParams, check, default_context, lib
 
 _fp = C.POINTER(C.c_float)
 _dp = C.POINTER(C.c_double)
@@ -179,6 +179,26 @@ class NdtHip(HipRegistration):
         return a, b, c
 
 
+class PclNdtHip(NdtHip):
+    """registration_method "PCL_NDT_HIP": drop-in for the branch every name without "OMP" in it ends in — "NDT" and any unknown string
+    (registrations.cpp:115-129): pcl::NormalDistributionsTransform of PCL 1.12.  Pair terms in f64, the radius search over the voxel
+    centroids (its only neighbourhood), PCL's iteration test: the squared translation of the last step against the un-squared
+    transformation_epsilon — with step_size 0.1 and any epsilon >= 0.01 that is ONE Newton iteration (oracle/quirks.h)."""
+
+    METHOD = PCL_NDT_HIP
+
+    def __init__(self, resolution=1.0, transformation_epsilon=0.1, maximum_iterations=35, step_size=0.1, outlier_ratio=0.55, ctx: Context | None = None):
+        p = default_params(PCL_NDT_HIP)
+        p.resolution = resolution
+        p.transformation_epsilon = transformation_epsilon
+        p.maximum_iterations = maximum_iterations
+        p.step_size = step_size
+        p.outlier_ratio = outlier_ratio
+        HipRegistration.__init__(self, p, ctx)
+
+    getTransformationLikelihood = NdtHip.getTransformationProbability  # PCL 1.12's name for score / N
+
+
 class GicpHip(HipRegistration):
     """registration_method "GICP_HIP": drop-in for the FAST_GICP branch (registrations.cpp:55-63)."""
 
@@ -304,8 +324,8 @@ def select_registration_method(params: dict, ctx: Context | None = None) -> HipR
     reg_resolution, reg_nn_search_method).  "NDT_HIP" (and, to stay drop-in, "NDT_OMP"/"NDT") select :class:`NdtHip`;
     "GICP_HIP" / "FAST_GICP" select :class:`GicpHip`, "SMALL_GICP_HIP" / "SMALL_GICP" :class:`SmallGicpHip`, "VGICP_HIP" /
     "FAST_VGICP" / "FAST_VGICP_CUDA" :class:`VgicpHip`.  Like the reference, an unknown name falls through to NDT: names
-    without "OMP" in them ("NDT", or any unknown string) reach pcl's single-threaded class there (:115-129) and get the KDTREE
-    neighbourhood, its only one, on the pclomp float formulation; "ICP" / "ICP_HIP"
+    without "OMP" in them ("NDT", "PCL_NDT_HIP", or any unknown string) reach pcl::NormalDistributionsTransform there (:115-129) and
+    select :class:`PclNdtHip`, its f64 formulation; "ICP" / "ICP_HIP"
     select :class:`IcpHip`; "GICP" / "GICP_OMP" (:93-114) select :class:`PclGicpHip` (pcl::GeneralizedIterativeClosestPoint / pclomp::GICP with
     the BFGS inner optimiser).
     """
@@ -333,9 +353,9 @@ def select_registration_method(params: dict, ctx: Context | None = None) -> HipR
     if search not in ("KDTREE", "DIRECT1"):
         search = "DIRECT7"  # registrations.cpp:140-146: anything else means DIRECT7
     if "OMP" not in method and method != "NDT_HIP":
-        # :115-129: every name without "OMP" in it — "NDT" and any unknown string alike — ends in pcl::NormalDistributionsTransform,
-        # whose only neighbourhood is the radius search over the voxel centroids
-        search = "KDTREE"
+        # :115-129: every name without "OMP" in it — "NDT" and any unknown string alike — ends in pcl::NormalDistributionsTransform with
+        # setTransformationEpsilon / setMaximumIterations / setResolution (:125-127); reg_nn_search_method and reg_num_threads are not read
+        return PclNdtHip(float(params.get("reg_resolution", 1.0)), eps, iters, ctx=ctx)
     return NdtHip(float(params.get("reg_resolution", 1.0)), eps, iters, search, num_threads=threads, ctx=ctx)
 
 

@@ -100,6 +100,7 @@ int VoxelGridCovariance::build(const float* xyzi, int n, float leaf)
         double pt_sum[3] = {a.mean[0], a.mean[1], a.mean[2]};
         for (int r = 0; r < 3; ++r) L.mean[r] = a.mean[r] / a.n;
         if (a.n < quirks::kNdtMinPointsPerVoxel) continue;
+        L.in_search = 1;  // voxel_centroids_.push_back / voxel_centroids_leaf_indices_.push_back come before the checks below
         // single pass covariance, then PCL's (n-1)/n normalisation
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 3; ++c) L.cov[r * 3 + c] = (a.cov[r * 3 + c] - 2 * (pt_sum[r] * L.mean[c])) / a.n + L.mean[r] * L.mean[c];
@@ -157,18 +158,30 @@ int VoxelGridCovariance::neighbours(float x, float y, float z, NdtSearch method,
         }
         return cnt;
     }
-    // KDTREE: radiusSearch(point, resolution) over the centroids of valid leaves (sorted by distance).
-    // A centroid within one leaf size of the point lies in one of the 27 surrounding cells.
+    // KDTREE: radiusSearch(point, resolution) over the centroids the kd-tree holds (sorted by distance)
+    return radius_neighbours(x, y, z, out);
+}
+
+int VoxelGridCovariance::radius_neighbours(float x, float y, float z, int out[27]) const
+{
+    // kdtree_.radiusSearch(point, radius) over voxel_centroids_ (float centroids of the leaves with >= 6 points, ascending key), FLANN L2_Simple in
+    // float, dist^2 < float(radius * radius), sorted by (distance, index); then leaves_.find(voxel_centroids_leaf_indices_[k]) — no nr_points test.
+    // A centroid within one leaf size of the point lies in one of the 27 cells around the point's cell.
+    const int ijk[3] = {static_cast<int>(std::floor(x / leaf_size)), static_cast<int>(std::floor(y / leaf_size)), static_cast<int>(std::floor(z / leaf_size))};
     std::pair<float, int> found[27];
-    int ijk_m[3] = {static_cast<int>(std::floor(x * inv_leaf)), static_cast<int>(std::floor(y * inv_leaf)), static_cast<int>(std::floor(z * inv_leaf))};
-    (void)ijk_m;
-    float r2 = leaf_size * leaf_size;
+    int cnt = 0;
+    const float r2 = leaf_size * leaf_size;
     for (int ox = -1; ox <= 1; ++ox) for (int oy = -1; oy <= 1; ++oy) for (int oz = -1; oz <= 1; ++oz) {
-        int l = probe(ox, oy, oz);
-        if (l < 0) continue;
-        const float* c = leaves[l].centroid;
-        float d = sqdist_f(c[0], c[1], c[2], x, y, z);
-        if (d < r2) found[cnt++] = std::make_pair(d, l);  // FLANN RadiusResultSet: dist < radius^2
+        const int c[3] = {ijk[0] + ox, ijk[1] + oy, ijk[2] + oz};
+        bool inside = true;
+        for (int a = 0; a < 3; ++a) inside = inside && c[a] >= min_b[a] && c[a] <= max_b[a];
+        if (!inside) continue;
+        const int key = (c[0] - min_b[0]) * divb_mul[0] + (c[1] - min_b[1]) * divb_mul[1] + (c[2] - min_b[2]) * divb_mul[2];
+        auto it = index.find(key);
+        if (it == index.end() || !leaves[it->second].in_search) continue;
+        const float* ce = leaves[it->second].centroid;
+        const float d = sqdist_f(ce[0], ce[1], ce[2], x, y, z);
+        if (d < r2) found[cnt++] = std::make_pair(d, it->second);
     }
     std::sort(found, found + cnt);
     for (int k = 0; k < cnt; ++k) out[k] = found[k].second;
@@ -522,8 +535,7 @@ void Ndt::compute_hessian_impl(double hess[36], const double p[6])
 // evaluation in four interleaved slices, combined the same way.  The f64 Hessian pass is the kernel's per-point factorisation (one lane
 // per point).  With the same per-pair float terms this reproduces the GPU's sums bit for bit (float path; the f64 pass differs where
 // the two C libraries' exp differ in the last bit), so a test can tell summation-order noise from an arithmetic difference.
-namespace {
-inline void gpu_tree_reduce(std::vector<double>& acc /* [256][48] */, double out[48])
+void gpu_tree_reduce(std::vector<double>& acc /* [256][48] */, double out[48])
 {
     double waves[4][48];
     for (int w = 0; w < 4; ++w)
@@ -536,7 +548,7 @@ inline void gpu_tree_reduce(std::vector<double>& acc /* [256][48] */, double out
         }
     for (int k = 0; k < 48; ++k) out[k] = ((waves[0][k] + waves[1][k]) + waves[2][k]) + waves[3][k];
 }
-inline void gpu_slice_reduce(const std::vector<double>& partials /* [nblk][48] */, size_t nblk, double out[48])
+void gpu_slice_reduce(const std::vector<double>& partials /* [nblk][48] */, size_t nblk, double out[48])
 {
     for (int k = 0; k < 48; ++k) {
         double s[4] = {0, 0, 0, 0};
@@ -545,25 +557,28 @@ inline void gpu_slice_reduce(const std::vector<double>& partials /* [nblk][48] *
         out[k] = ((s[0] + s[1]) + s[2]) + s[3];
     }
 }
-}  // namespace
 
 int Ndt::neighbours_probe_order(float x, float y, float z, int out[27]) const
 {
     if (search != NDT_KDTREE) return cells.neighbours(x, y, z, search, out);
     // the kernel keeps the 27 probes in probe order and drops the centroids outside the radius; the reference sorts by distance
-    int all[27];
-    const int m = cells.neighbours(x, y, z, NDT_DIRECT26, all);
-    int cnt = 0;
-    const float r2 = cells.leaf_size * cells.leaf_size;
+    int found[27];
+    const int m = cells.radius_neighbours(x, y, z, found);
+    // probe order of the kernel = ascending (ox, oy, oz) = ascending key offset order used by radius_neighbours' loops: re-sort by leaf key offset
+    std::pair<int, int> byprobe[27];
+    const int ijk[3] = {static_cast<int>(std::floor(x / cells.leaf_size)), static_cast<int>(std::floor(y / cells.leaf_size)), static_cast<int>(std::floor(z / cells.leaf_size))};
     for (int k = 0; k < m; ++k) {
-        const float* c = cells.leaves[all[k]].centroid;
-        const float dx = c[0] - x, dy = c[1] - y, dz = c[2] - z;
-        float d = dx * dx;
-        d += dy * dy;
-        d += dz * dz;
-        if (d < r2) out[cnt++] = all[k];
+        // recover the cell of the leaf from its key
+        int key = cells.leaves[found[k]].key;
+        const int cz = key / cells.divb_mul[2]; key -= cz * cells.divb_mul[2];
+        const int cy = key / cells.divb_mul[1]; key -= cy * cells.divb_mul[1];
+        const int cx = key;
+        const int ox = cx + cells.min_b[0] - ijk[0] + 1, oy = cy + cells.min_b[1] - ijk[1] + 1, oz = cz + cells.min_b[2] - ijk[2] + 1;
+        byprobe[k] = std::make_pair(ox * 9 + oy * 3 + oz, found[k]);
     }
-    return cnt;
+    std::sort(byprobe, byprobe + m);
+    for (int k = 0; k < m; ++k) out[k] = byprobe[k].second;
+    return m;
 }
 
 double Ndt::compute_derivatives_gpu_order(double grad[6], double hess[36], const double p[6], bool compute_hessian)
@@ -717,7 +732,7 @@ double Ndt::evaluate(const float T[16], const double p[6], int mode, double grad
 static inline double psi_mt(double a, double f_a, double f_0, double g_0, double mu) { return f_a - f_0 - mu * g_0 * a; }
 static inline double dpsi_mt(double g_a, double g_0, double mu) { return g_a - mu * g_0; }
 
-static bool update_interval_mt(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t, double g_t)
+bool mt_update_interval(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t, double g_t)
 {
     if (f_t > f_l) { a_u = a_t; f_u = f_t; g_u = g_t; return false; }
     else if (g_t * (a_l - a_t) > 0) { a_l = a_t; f_l = f_t; g_l = g_t; return false; }
@@ -725,7 +740,7 @@ static bool update_interval_mt(double& a_l, double& f_l, double& g_l, double& a_
     return true;
 }
 
-static double trial_value_selection_mt(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t)
+double mt_trial_value_selection(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t)
 {
     if (f_t > f_l) {  // case 1
         double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
@@ -792,8 +807,8 @@ double Ndt::step_length_mt(const double x[6], double step_dir[6], double step_in
     double psi_t = psi_mt(a_t, phi_t, phi_0, d_phi_0, mu);
     double d_psi_t = dpsi_mt(d_phi_t, d_phi_0, mu);
     while (!interval_converged && step_iterations < max_step_iterations && !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
-        if (open_interval) a_t = trial_value_selection_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t);
-        else               a_t = trial_value_selection_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
+        if (open_interval) a_t = mt_trial_value_selection(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t);
+        else               a_t = mt_trial_value_selection(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
         a_t = std::min(a_t, step_max);
         a_t = std::max(a_t, step_min);
         for (int k = 0; k < 6; ++k) x_t[k] = x[k] + step_dir[k] * a_t;
@@ -813,8 +828,8 @@ double Ndt::step_length_mt(const double x[6], double step_dir[6], double step_in
             f_u = f_u + phi_0 - mu * d_phi_0 * a_u;
             g_u = g_u + mu * d_phi_0;
         }
-        if (open_interval) interval_converged = update_interval_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t);
-        else               interval_converged = update_interval_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
+        if (open_interval) interval_converged = mt_update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t);
+        else               interval_converged = mt_update_interval(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
         step_iterations++;
     }
     if (step_iterations) compute_hessian(hess, x_t);

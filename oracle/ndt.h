@@ -7,6 +7,7 @@
 // src/mrg_slam/loop_detector.cpp:104,127,134-144).  PARITY UNPINNED (see quirks.h): follows SURVEY.md
 // Appendix A.2-A.5.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <unordered_map>
 #include <vector>
@@ -22,6 +23,9 @@ struct NdtLeaf {
     double cov[9];
     double icov[9];
     float  centroid[4];  // float accumulation of x,y,z,intensity (KDTREE search uses xyz)
+    int    in_search;    // 1: the leaf had >= 6 points in the second pass, so its centroid went into voxel_centroids_ (and the kd-tree) BEFORE the
+                         // eigenvalue / inf checks could set nr_points = -1: radiusSearch still returns it (no nr_points test there), with the
+                         // zero inverse covariance of the Leaf constructor (eigenvalue check) or the non-finite one (inf check)
 };
 
 // pclomp::VoxelGridCovariance<PointXYZI>::applyFilter + getNeighborhoodAtPoint{,7,1}
@@ -36,7 +40,18 @@ struct VoxelGridCovariance {
     int build(const float* xyzi, int n, float leaf);
     // neighbours (leaf positions) of an already transformed point; returns count (<= 27)
     int neighbours(float x, float y, float z, NdtSearch method, int out[27]) const;
+    // VoxelGridCovariance::radiusSearch(point, leaf size) as upstream has it: every leaf whose centroid went into the kd-tree (in_search),
+    // sorted by (distance, leaf position); leaves the later checks rejected are among them
+    int radius_neighbours(float x, float y, float z, int out[27]) const;
 };
+
+// computeStepLengthMT's helpers (identical text in PCL's ndt.hpp and in ndt_omp): shared by ndt.cpp and pcl_ndt.cpp
+bool   mt_update_interval(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t, double g_t);
+double mt_trial_value_selection(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t);
+// the HIP derivative kernels' reduction tree (diagnostic "GPU order" modes of ndt.cpp and pcl_ndt.cpp): 256 lanes x 48 slots -> one item record
+// (64-lane shuffle tree, offsets 32..1; the four waves as ((w0 + w1) + w2) + w3), and the item records of an evaluation in four interleaved slices
+void gpu_tree_reduce(std::vector<double>& acc /* [256][48] */, double out[48]);
+void gpu_slice_reduce(const std::vector<double>& partials /* [nblk][48] */, size_t nblk, double out[48]);
 
 struct Ndt {
     // parameters (defaults = ndt_omp ctor; mrg_slam overrides through registrations.cpp:134-146)

@@ -77,6 +77,23 @@ def lib():
             "orc_ndt_num_leaves": (C.c_int, [vp]),
             "orc_ndt_grid": (None, [vp, ip, ip, ip]),
             "orc_ndt_leaves": (None, [vp, ip, ip, dp, dp, dp]),
+            "orc_pclndt_create": (vp, []),
+            "orc_pclndt_destroy": (None, [vp]),
+            "orc_pclndt_set_params": (None, [vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]),
+            "orc_pclndt_set_target": (C.c_int, [vp, fp, C.c_int]),
+            "orc_pclndt_set_source": (None, [vp, fp, C.c_int]),
+            "orc_pclndt_align": (None, [vp, fp, fp]),
+            "orc_pclndt_converged": (C.c_int, [vp]),
+            "orc_pclndt_iterations": (C.c_int, [vp]),
+            "orc_pclndt_evals": (C.c_int, [vp]),
+            "orc_pclndt_mean_neighbours": (C.c_double, [vp]),
+            "orc_pclndt_trans_likelihood": (C.c_double, [vp]),
+            "orc_pclndt_final": (None, [vp, fp]),
+            "orc_pclndt_hessian": (None, [vp, dp]),
+            "orc_pclndt_fitness": (C.c_double, [vp, C.c_double]),
+            "orc_pclndt_evaluate": (C.c_double, [vp, fp, dp, C.c_int, dp, dp]),
+            "orc_pclndt_num_leaves": (C.c_int, [vp]),
+            "orc_pclndt_leaves": (None, [vp, ip, ip, ip, dp, dp, fp]),
             "orc_pclgicp_create": (vp, []),
             "orc_pclgicp_destroy": (None, [vp]),
             "orc_pclgicp_set_params": (None, [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -390,6 +407,86 @@ class Ndt:
 
 
 # ---- GICP --------------------------------------------------------------------------------------------------
+
+class PclNdt:
+    """pcl::NormalDistributionsTransform (PCL 1.12) restated (oracle/pcl_ndt.cpp) behind the pcl::Registration call surface: what the
+    reference's factory returns for registration_method "NDT" and every unknown name (registrations.cpp:115-129)."""
+
+    def __init__(self, resolution=1.0, step_size=0.1, outlier_ratio=0.55, transformation_epsilon=0.1, maximum_iterations=35, gpu_order=0, num_threads=1):
+        """gpu_order > 0 (diagnostic): the per-point factorised sums of the HIP kernel, added in its tree (items of that many 256-point tiles)."""
+        self._h = lib().orc_pclndt_create()
+        lib().orc_pclndt_set_params(self._h, resolution, step_size, outlier_ratio, transformation_epsilon, maximum_iterations, int(gpu_order), int(num_threads))
+        self._n_src = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().orc_pclndt_destroy(self._h)
+                self._h = None
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def setInputTarget(self, cloud):
+        c = _cloud(cloud)
+        return lib().orc_pclndt_set_target(self._h, _pf(c), len(c))
+
+    def setInputSource(self, cloud):
+        c = _cloud(cloud)
+        self._n_src = len(c)
+        lib().orc_pclndt_set_source(self._h, _pf(c), len(c))
+
+    def align(self, guess=None, want_aligned=False):
+        g = _colmajor(np.eye(4) if guess is None else guess)
+        out = np.empty((self._n_src, 4), dtype=np.float32) if want_aligned else None
+        lib().orc_pclndt_align(self._h, _pf(g), _pf(out) if want_aligned else None)
+        return out
+
+    def hasConverged(self):
+        return bool(lib().orc_pclndt_converged(self._h))
+
+    def getFinalTransformation(self):
+        Tc = np.empty((4, 4), dtype=np.float32)
+        lib().orc_pclndt_final(self._h, _pf(Tc))
+        return Tc.T.copy()
+
+    def getFitnessScore(self, max_range=float("inf")):
+        return lib().orc_pclndt_fitness(self._h, max_range)
+
+    def getFinalNumIteration(self):
+        return lib().orc_pclndt_iterations(self._h)
+
+    def getTransformationLikelihood(self):
+        return lib().orc_pclndt_trans_likelihood(self._h)
+
+    getTransformationProbability = getTransformationLikelihood  # the name PCL < 1.12 (and pclomp) uses
+
+    def getHessian(self):
+        H = np.empty((6, 6))
+        lib().orc_pclndt_hessian(self._h, _pd(H))
+        return H
+
+    @property
+    def evals(self):
+        return lib().orc_pclndt_evals(self._h)
+
+    @property
+    def mean_neighbours(self):
+        return lib().orc_pclndt_mean_neighbours(self._h)
+
+    def evaluate(self, T, p, mode=0):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        g, H = np.zeros(6), np.zeros((6, 6))
+        s = lib().orc_pclndt_evaluate(self._h, _pf(_colmajor(T)), _pd(p), mode, _pd(g), _pd(H))
+        return s, g, H
+
+    def leaves(self):
+        n = lib().orc_pclndt_num_leaves(self._h)
+        keys, npts, ins = (np.empty(n, dtype=np.int32) for _ in range(3))
+        mean, icov, cent = np.empty((n, 3)), np.empty((n, 3, 3)), np.empty((n, 4), dtype=np.float32)
+        if n:
+            lib().orc_pclndt_leaves(self._h, _pi(keys), _pi(npts), _pi(ins), _pd(mean), _pd(icov), _pf(cent))
+        return keys, npts, ins, mean, icov, cent
+
 class FastGicp:
     """fast_gicp::FastGICP restated (oracle/gicp.cpp)."""
 

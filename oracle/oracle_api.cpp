@@ -12,6 +12,7 @@
 #include "linalg.h"
 #include "mapcloud.h"
 #include "ndt.h"
+#include "pcl_ndt.h"
 #include "nn.h"
 
 using namespace orc;
@@ -149,6 +150,45 @@ double orc_ndt_evaluate(void* h, const float T_colmajor[16], const double p[6], 
 {
     float T[16]; colmajor_to_rowmajor4(T_colmajor, T);
     return static_cast<Ndt*>(h)->evaluate(T, p, mode, grad, hess_rowmajor);
+}
+// ---- pcl::NormalDistributionsTransform (registration_method "NDT", registrations.cpp:115-129) ------------------------------
+void* orc_pclndt_create() { return new PclNdt(); }
+void  orc_pclndt_destroy(void* h) { delete static_cast<PclNdt*>(h); }
+void  orc_pclndt_set_params(void* h, double resolution, double step_size, double outlier_ratio, double trans_eps, int max_iterations, int gpu_order, int num_threads)
+{
+    PclNdt* n = static_cast<PclNdt*>(h);
+    n->resolution = static_cast<float>(resolution); n->step_size = step_size; n->outlier_ratio = outlier_ratio; n->trans_eps = trans_eps;
+    n->max_iterations = max_iterations; n->gpu_order = gpu_order; n->num_threads = num_threads > 0 ? num_threads : 1;
+}
+int  orc_pclndt_set_target(void* h, const float* xyzi, int n) { return static_cast<PclNdt*>(h)->set_target(xyzi, n); }
+void orc_pclndt_set_source(void* h, const float* xyzi, int n) { static_cast<PclNdt*>(h)->set_source(xyzi, n); }
+void orc_pclndt_align(void* h, const float guess_colmajor[16], float* aligned_or_null)
+{
+    float g[16]; colmajor_to_rowmajor4(guess_colmajor, g);
+    static_cast<PclNdt*>(h)->align(g, aligned_or_null);
+}
+int    orc_pclndt_converged(void* h) { return static_cast<PclNdt*>(h)->converged ? 1 : 0; }
+int    orc_pclndt_iterations(void* h) { return static_cast<PclNdt*>(h)->nr_iterations; }
+int    orc_pclndt_evals(void* h) { return static_cast<PclNdt*>(h)->n_evals; }
+double orc_pclndt_mean_neighbours(void* h) { PclNdt* n = static_cast<PclNdt*>(h); return n->n_evals ? n->neighbours_sum / n->n_evals : 0.0; }
+double orc_pclndt_trans_likelihood(void* h) { return static_cast<PclNdt*>(h)->trans_likelihood; }
+void   orc_pclndt_final(void* h, float out_colmajor[16]) { rowmajor_to_colmajor4(static_cast<PclNdt*>(h)->final_, out_colmajor); }
+void   orc_pclndt_hessian(void* h, double out_rowmajor[36]) { std::memcpy(out_rowmajor, static_cast<PclNdt*>(h)->hessian, sizeof(double) * 36); }
+double orc_pclndt_fitness(void* h, double max_range) { return static_cast<PclNdt*>(h)->fitness(max_range); }
+double orc_pclndt_evaluate(void* h, const float T_colmajor[16], const double p[6], int mode, double grad[6], double hess_rowmajor[36])
+{
+    float T[16]; colmajor_to_rowmajor4(T_colmajor, T);
+    return static_cast<PclNdt*>(h)->evaluate(T, p, mode, grad, hess_rowmajor);
+}
+int  orc_pclndt_num_leaves(void* h) { return static_cast<int>(static_cast<PclNdt*>(h)->cells.leaves.size()); }
+void orc_pclndt_leaves(void* h, int* keys, int* nr_points, int* in_search, double* mean3, double* icov9, float* centroid4)
+{
+    PclNdt* n = static_cast<PclNdt*>(h);
+    for (size_t i = 0; i < n->cells.leaves.size(); ++i) {
+        const NdtLeaf& L = n->cells.leaves[i];
+        keys[i] = L.key; nr_points[i] = L.nr_points; in_search[i] = L.in_search;
+        std::memcpy(mean3 + 3 * i, L.mean, 24); std::memcpy(icov9 + 9 * i, L.icov, 72); std::memcpy(centroid4 + 4 * i, L.centroid, 16);
+    }
 }
 // target grid inspection: leaves in ascending key order
 int  orc_ndt_num_leaves(void* h) { return static_cast<int>(static_cast<Ndt*>(h)->cells.leaves.size()); }

@@ -41,6 +41,20 @@ constexpr int    kMtMaxStepIterations    = 10;
 constexpr double kMtMu                   = 1.e-4;
 constexpr double kMtNu                   = 0.9;
 
+// ---- pcl::NormalDistributionsTransform (PCL 1.12 registration/impl/ndt.hpp; oracle/pcl_ndt.cpp) — what differs from the pclomp fork ----------
+// Same class defaults (resolution 1.0, step_size 0.1, outlier_ratio 0.55, transformation_epsilon 0.1, max_iterations 35), same gauss constants,
+// same small-angle rule and the same +sy in angular_hessian_ row d1, same More-Thuente constants; min_points_per_voxel_ 6 and
+// min_covar_eigvalue_mult_ 0.01 in pcl::VoxelGridCovariance.  All per-pair arithmetic is f64.
+// kPclNdtIterationRule 1 (PCL >= 1.11.1, the assumed 1.12.1): after each Newton step  nr_iterations_++  and then converged_ when
+//   nr_iterations_ >= max_iterations_  or  |t_step|^2 <= transformation_epsilon_ (the SQUARED translation of the step's float matrix against the
+//   un-squared epsilon; the rotation test cos_angle >= transformation_rotation_epsilon_ joins only when that epsilon is > 0, and the reference
+//   never sets it: registrations.cpp:125-127).  With step_size 0.1 every step is at most 0.1 long, so for any epsilon >= 0.01 — mrg_slam's YAML has
+//   0.1 — the first step already satisfies the test: "NDT" in the reference runs ONE Newton iteration.  0: PCL <= 1.11.0, the rule pclomp kept.
+constexpr int    kPclNdtIterationRule    = 1;
+// a vanishing or NaN Newton step ends computeTransformation with converged_ = (delta_norm == 0) in PCL >= 1.11.1 (true); before: = !isnan (false)
+constexpr bool   kPclNdtZeroStepConverges = true;
+// three-term f64 products are written left to right here; Eigen's unrolled reduction adds e0 + (e1 + e2): 1e-16 relative, not part of the contract
+
 // ---- mrg_slam overrides (config/mrg_slam.yaml:100-109, registrations.cpp:130-148) -------------------
 constexpr double kMrgTransformationEps   = 0.1;
 constexpr int    kMrgMaxIterations       = 64;

@@ -66,14 +66,16 @@ def neighbours(xt, search, leaf, min_b, max_b, div_b, key_to_leaf):
     return out
 
 
-def evaluate(source_xyz, p, search, resolution, grid, leaves, outlier_ratio=0.55, transformed=None, upstream_d1_sign=False):
+def evaluate(source_xyz, p, search, resolution, grid, leaves, outlier_ratio=0.55, transformed=None, upstream_d1_sign=False, nb_lists=None):
     """score, gradient[6], Hessian[6, 6] at pose vector p = (tx, ty, tz, rx, ry, rz).  `transformed` (N x 3 float32): where the
     reference puts the points — it transforms the cloud with its float matrix in float arithmetic and stores float points, and a
     thin (planar) voxel has inverse-covariance eigenvalues above 1000 / m^2, so the last bit of those floats (2e-6 m) already moves
     the Hessian by 1e-4 relative; the model is evaluated AT those points.  The derivatives of the point with respect to the pose
     use p and the untransformed point.
     upstream_d1_sign: PCL / ndt_omp's table of second derivatives has +sin(ry) where d^2 R / d ry^2 has -sin(ry) (row x, column z:
-    oracle/quirks.h kNdtHAngD1ZSign); True reproduces that one sign, so that everything ELSE is held against first principles."""
+    oracle/quirks.h kNdtHAngD1ZSign); True reproduces that one sign, so that everything ELSE is held against first principles.
+    nb_lists: per point the leaves to use instead of the voxel neighbourhood `search` (pcl::NormalDistributionsTransform's radius search: the caller
+    finds them by brute force over the centroids, tests/test_oracle_pclndt.py)."""
     min_b, max_b, div_b = (np.asarray(a, dtype=np.int64) for a in grid)
     keys, npts, mean, icov = leaves
     key_to_leaf = {int(k): i for i, k in enumerate(keys) if npts[i] >= 6}
@@ -86,7 +88,7 @@ def evaluate(source_xyz, p, search, resolution, grid, leaves, outlier_ratio=0.55
     s, g, H = 0.0, np.zeros(6), np.zeros((6, 6))
     for n, x in enumerate(np.asarray(source_xyz, dtype=np.float64)):
         xt = R @ x + p[:3] if transformed is None else np.asarray(transformed[n], dtype=np.float64)
-        nb = neighbours(xt.astype(np.float32).astype(np.float64), search, resolution, min_b, max_b, div_b, key_to_leaf)
+        nb = nb_lists[n] if nb_lists is not None else neighbours(xt.astype(np.float32).astype(np.float64), search, resolution, min_b, max_b, div_b, key_to_leaf)
         if not nb:
             continue
         dq = np.zeros((6, 3))

@@ -217,19 +217,20 @@ def test_config5_two_robots_concurrent_streams_and_inter_robot_batch(street_scan
 
 def test_factory_mirror_dispatch():
     """select_registration_method: the reference's names and the HIP ones (registrations.cpp:45-151)."""
-    from mrg_slam_amd import GicpHip, NdtHip, SmallGicpHip, VgicpHip, select_registration_method
-    from mrg_slam_amd._lib import SEARCH
+    from mrg_slam_amd import GicpHip, NdtHip, PclNdtHip, SmallGicpHip, VgicpHip, select_registration_method
+    from mrg_slam_amd._lib import PCL_NDT_HIP, SEARCH
 
-    expect = {"NDT_OMP": NdtHip, "NDT_HIP": NdtHip, "NDT": NdtHip, "no such method": NdtHip, "FAST_GICP": GicpHip, "GICP_HIP": GicpHip, "SMALL_GICP": SmallGicpHip,
+    expect = {"NDT_OMP": NdtHip, "NDT_HIP": NdtHip, "NDT": PclNdtHip, "PCL_NDT_HIP": PclNdtHip, "no such method": PclNdtHip, "FAST_GICP": GicpHip, "GICP_HIP": GicpHip, "SMALL_GICP": SmallGicpHip,
               "SMALL_GICP_HIP": SmallGicpHip, "FAST_VGICP": VgicpHip, "FAST_VGICP_CUDA": VgicpHip, "VGICP_HIP": VgicpHip}
     for name, cls in expect.items():
         assert type(select_registration_method({"registration_method": name})) is cls, name
     assert select_registration_method({"registration_method": "NDT_OMP", "reg_nn_search_method": "whatever"})._params.nn_search_method == SEARCH["DIRECT7"]
     assert select_registration_method({"registration_method": "NDT_OMP", "reg_nn_search_method": "DIRECT1"})._params.nn_search_method == SEARCH["DIRECT1"]
-    assert select_registration_method({"registration_method": "NDT"})._params.nn_search_method == SEARCH["KDTREE"]
-    # registrations.cpp:115-129: an unknown name without "OMP" in it ends in pcl::NormalDistributionsTransform (KDTREE only),
-    # one with "OMP" in the pclomp branch with the requested neighbourhood
-    assert select_registration_method({"registration_method": "FOO", "reg_nn_search_method": "DIRECT1"})._params.nn_search_method == SEARCH["KDTREE"]
+    # registrations.cpp:115-129: "NDT" and an unknown name without "OMP" in it end in pcl::NormalDistributionsTransform — PCL's f64 class, with
+    # the three setters of :125-127 and nothing else —, one with "OMP" in the pclomp branch with the requested neighbourhood
+    r = select_registration_method({"registration_method": "NDT", "reg_transformation_epsilon": 0.05, "reg_maximum_iterations": 17, "reg_resolution": 0.5})
+    assert r._params.method == PCL_NDT_HIP and r._params.transformation_epsilon == 0.05 and r._params.maximum_iterations == 17 and r._params.resolution == 0.5
+    assert select_registration_method({"registration_method": "FOO", "reg_nn_search_method": "DIRECT1"})._params.method == PCL_NDT_HIP
     assert select_registration_method({"registration_method": "FOO_OMP", "reg_nn_search_method": "DIRECT1"})._params.nn_search_method == SEARCH["DIRECT1"]
     assert select_registration_method({"registration_method": "FAST_VGICP", "reg_resolution": 0.5})._params.resolution == 0.5
     from mrg_slam_amd import IcpHip
