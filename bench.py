@@ -332,6 +332,69 @@ def run_config2(ctx, scans, dev, poses, lib, args):
     return out
 
 
+def run_pcl_ndt(ctx, scans, dev, pairs, lib, args):
+    """registration_method "NDT" = pcl::NormalDistributionsTransform (registrations.cpp:115-129) on BASELINE config[1]'s pairs: PCL_NDT_HIP, all pair terms
+    in f64, radius search over the voxel centroids (27 probes per point).  Two epsilons: the run's own (mrg_slam's 0.1: PCL's iteration rule stops after
+    ONE Newton step) and 1e-5 (tens of iterations).  Device time of the f64 derivative launches from the library's HIP events; byte model
+    N * (16 + 27*8) + neighbours * 112 (f64 mean 24 + f64 inverse covariance 72 + float centroid 16)."""
+    from mrg_slam_amd import BatchMatcher
+    from mrg_slam_amd._lib import PCL_NDT_HIP
+    from mrg_slam_amd.registration import default_params, result_matrix
+    from oracle import oracle as orc
+
+    out = {"workload": f"{len(pairs)} distinct config[1] pairs, one setInputTarget per alignment, clouds resident in HBM, resolution 1.0, max_iterations 64"}
+    add_args = ([dev[p[0]].data_ptr() for p in pairs], [len(scans[p[0]]) for p in pairs], np.arange(len(pairs), dtype=np.int32),
+                [dev[p[1]].data_ptr() for p in pairs], [len(scans[p[1]]) for p in pairs], np.stack([p[2] for p in pairs]))
+    for eps in (args.eps, 1e-5):
+        prm = default_params(PCL_NDT_HIP)
+        prm.transformation_epsilon, prm.maximum_iterations, prm.resolution = eps, 64, 1.0
+        bm = BatchMatcher(prm, ctx)
+        t, k = [], np.zeros(3)
+        pts = nb = 0.0
+        res = None
+        for rep in range(4):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            bm.clear()
+            bm.add_device(*add_args)
+            res = bm.align()
+            ctx.synchronize()
+            if rep:
+                t.append(1e3 * (time.perf_counter() - t0))
+                k += np.array(bm.kernel_stats())
+                a, b = bm.pair_counts()
+                pts, nb = pts + a, nb + b
+        gbps = (k[2] / 1e9) / (k[0] / 1e3) if k[0] > 0 else 0.0
+        rec = {"ms_per_step": float(np.median(t)), "alignments_per_s": len(pairs) / (np.median(t) / 1e3), "iterations_per_alignment": float(res["iterations"].mean()),
+               "evaluations_per_alignment": float(res["evaluations"].mean()), "converged": int(res["converged"].sum()), "mean_neighbours_per_point": nb / pts if pts else 0.0,
+               "median_translation_error_vs_truth_m": float(np.median([np.linalg.norm(result_matrix(res[b])[:3, 3] - pairs[b][3][:3, 3]) for b in range(len(pairs))])),
+               "roofline": {"bound": "valu (f64)", "byte_model_bound": "hbm", "kernel": "ndt_derivatives_f64_all_kernel", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": gbps / HBM_PEAK_GBPS, "traffic": None, "launches": int(k[1]), "avg_launch_ms": k[0] / k[1] if k[1] else None,
+                            "byte_model": "N * (16 + 27*8) + neighbours * 112 per evaluation"}}
+        if not args.no_cpu:
+            n_par = min(8, len(pairs))
+            dts, drs, mism = [], [], 0
+            tc = 0.0
+            o = orc.PclNdt(resolution=1.0, transformation_epsilon=eps, maximum_iterations=64)
+            for b in range(n_par):
+                ti, si, guess = pairs[b][0], pairs[b][1], pairs[b][2]
+                t0 = time.perf_counter()
+                o.setInputTarget(scans[ti])
+                o.setInputSource(scans[si])
+                o.align(guess)
+                tc += time.perf_counter() - t0
+                Tg, To = result_matrix(res[b]), o.getFinalTransformation()
+                dts.append(float(np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3])))
+                drs.append(rot_angle(Tg[:3, :3], To[:3, :3]))
+                mism += int(bool(res[b]["converged"]) != bool(o.hasConverged()) or int(res[b]["iterations"]) != int(o.getFinalNumIteration()) or int(res[b]["evaluations"]) != int(o.evals))
+            rec["cpu_oracle"] = {"alignments_per_s": n_par / tc, "threads": 1, "kind": "port", "sample": f"{n_par} pairs incl. setInputTarget (pcl::NormalDistributionsTransform is single-threaded)"}
+            rec["parity_vs_oracle"] = {"pairs": n_par, "max_dt_m": max(dts), "max_dr_rad": max(drs), "pairs_over_bar": int(sum(a > 1e-4 or b > 1e-4 for a, b in zip(dts, drs))),
+                                       "pairs_with_other_iterations_evaluations_or_convergence": mism, "bar": "1e-4 m / 1e-4 rad"}
+        out[f"eps_{eps:g}"] = rec
+        del bm
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -812,6 +875,8 @@ def main():
             del f_dev
         # (4) BASELINE config[2]: GICP scan-to-keyframe (the k-NN correspondence path), keyframe = scan 0, frames = scans 1..6
         extras["config2_gicp"] = run_config2(ctx, scans, dev, poses, lib, args)
+        # (4b) registration_method "NDT": pcl::NormalDistributionsTransform, the f64 formulation, on the headline's pairs
+        extras["pcl_ndt"] = run_pcl_ndt(ctx, scans, dev, pairs, lib, args)
         # (5) the per-scan path every robot of config[4] runs: raw scan in host memory -> mrgfe_prefilter_device (distance 0.1-35 m, VoxelGrid 0.1 m,
         # RadiusOutlierRemoval 0.5 m / 2) -> setInputSourceDevice + scan-to-keyframe align, with the chain's counts on the device (one host wait) and, for
         # comparison, every stage reporting to the host (round 3)
@@ -938,11 +1003,12 @@ def main():
     # ---- every tolerated over-the-bar case as a number: the randomised soak of the GPU suite, a bounded sample of it per run
     soak = None
     if not args.no_cpu and args.soak_cases > 0 and rank == 0 and world == 1:
-        from oracle.replay import ndt_soak, round3_soak
+        from oracle.replay import ndt_soak, pclndt_soak, round3_soak
 
         ts = time.perf_counter()
         a = ndt_soak(args.soak_cases, 20260411)
         b = round3_soak(max(1, args.soak_cases // 3), 20260412)
+        c = pclndt_soak(max(1, args.soak_cases // 2), 20260413)
         soak = {"ndt": f"{a['ndt_over_bar']}/{a['ndt']}", "ndt_settled": f"{a['ndt_settled_over_bar']}/{a['ndt_settled']}",
                 "ndt_over_bar_equal_to_gpu_order_replay": f"{a['ndt_over_bar_equal_to_gpu_order_replay']}/{a['ndt_over_bar']}",
                 "ndt_bit_identical_to_reference_order_oracle": f"{a['ndt_exact_ref']}/{a['ndt']}", "ndt_bit_identical_to_gpu_order_replay": f"{a['ndt_exact_gpu_order']}/{a['ndt']}",
@@ -953,9 +1019,12 @@ def main():
                 "pcl_gicp_omp": f"{b['gicp_omp_over_bar']}/{b['gicp_omp']}", "pcl_gicp_omp_over_bar_equal_to_gpu_order_replay": f"{b['gicp_omp_over_bar_equal_to_gpu_order_replay']}/{b['gicp_omp_over_bar']}",
                 "pcl_gicp_omp_bit_identical_to_gpu_order_replay": f"{b['gicp_omp_exact_gpu_order']}/{b['gicp_omp']}", "pcl_gicp_omp_bit_identical_to_reference_order_oracle": f"{b['gicp_omp_exact_ref']}/{b['gicp_omp']}",
                 "pcl_gicp_omp_worst_m_or_rad": b["gicp_omp_worst"], "icp_reciprocal": f"{b['icp_over_bar']}/{b['icp']}",
-                "worst_m": max(a["ndt_worst"], a["other_worst"], b["gicp_serial_worst"], b["gicp_omp_worst"], b["icp_worst"]),
-                "flag_or_iteration_mismatches": a["ndt_flag_or_iteration_mismatch"] + a["other_flag_mismatch"] + b["gicp_flag_or_iteration_mismatch"] + b["icp_flag_or_iteration_mismatch"],
-                "over_bar_cases": a["over_bar"] + b["over_bar"], "seconds": time.perf_counter() - ts,
+                "pcl_ndt": f"{c['over_bar']}/{c['cases']}", "pcl_ndt_bit_identical_to_reference_order_oracle": f"{c['exact']}/{c['cases']}", "pcl_ndt_worst_m_or_rad": c["worst"],
+                "pcl_ndt_scenes_that_stop_after_one_iteration": f"{c['one_iteration']}/{c['cases']}",
+                "worst_m": max(a["ndt_worst"], a["other_worst"], b["gicp_serial_worst"], b["gicp_omp_worst"], b["icp_worst"], c["worst"]),
+                "flag_or_iteration_mismatches": a["ndt_flag_or_iteration_mismatch"] + a["other_flag_mismatch"] + b["gicp_flag_or_iteration_mismatch"] + b["icp_flag_or_iteration_mismatch"]
+                                                + c["flag_or_iteration_mismatch"],
+                "over_bar_cases": a["over_bar"] + b["over_bar"] + c["over_bar_cases"], "seconds": time.perf_counter() - ts,
                 "what": f"{args.soak_cases} + {max(1, args.soak_cases // 3)} random 1.5k-9k-point scenes (oracle/replay.py, seeds 20260411 / 20260412: every method, resolution 0.5-2 m, four NDT "
                         "neighbourhoods, eps 0.1-0.001, warm and identity guesses), k/N = scenes over the 1e-4 m / 1e-4 rad bar against the reference-order oracle; "
                         "'settled' = converged within 30 iterations on both sides; a larger run of the same soak is kept under profiles/"}
@@ -1051,6 +1120,7 @@ def main():
         "gpu_split_ms_per_step": extras.get("gpu_split_ms_per_step"),
         "pipeline_shape": extras.get("pipeline_shape"),
         "config2_gicp": extras.get("config2_gicp"),
+        "pcl_ndt": extras.get("pcl_ndt"),
         "per_scan_path": extras.get("per_scan_path"),
         "config3_shard": shard,
     }

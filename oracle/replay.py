@@ -5,7 +5,7 @@ never imports this; this module drives the product through its C ABI to hold it 
   oracle object supplying every derivative evaluation it asks for.  With ``orc.Ndt(gpu_order_ppt=k)`` as the evaluator this is the
   *GPU-order replay*: same per-pair float terms as the HIP kernels, added in the kernels' order => the same doubles, so a HIP
   trajectory must repeat bit for bit.
-* :func:`soak_scene`, :func:`ndt_soak`, :func:`round3_soak` — the randomised parity soak (small scenes, every method, resolutions,
+* :func:`soak_scene`, :func:`ndt_soak`, :func:`round3_soak`, :func:`pclndt_soak` — the randomised parity soak (small scenes, every method, resolutions,
   neighbourhoods, epsilons, guesses).  The GPU suite asserts on the returned counts; bench.py prints them (``soak_over_bar``), so a
   tolerated over-the-bar case is a NUMBER in the driver-run line and not an allowance inside a test.
 * :func:`loop_parity` — BASELINE config[3] held against the reference's sequential loop (loop_detector.cpp:104,126-145) pair by pair.
@@ -160,6 +160,44 @@ def ndt_soak(cases: int, seed: int, ndt_share: float = 0.75):
                                    "settled": settled, "equal_to_gpu_order_replay": same})
         if not exact and not same:
             st["unexplained"].append({"case": tag, "dt_m": dt, "dt_vs_replay_m": _diff(Tg, Tr)[0], "iterations_hip": int(g.getFinalNumIteration()), "iterations_replay": int(it_r)})
+    return st
+
+
+def pclndt_soak(cases: int, seed: int):
+    """pcl::NormalDistributionsTransform (registration_method "NDT" and every unknown name, registrations.cpp:115-129): PCL_NDT_HIP against the
+    reference-order oracle (oracle/pcl_ndt.cpp) on random scenes — resolutions 0.5-2 m, epsilons from mrg_slam's 0.1 (PCL's rule: one Newton
+    iteration) down to 1e-7 (tens of iterations), warm and identity guesses.  Every pair term is f64 on both sides; only the association of the sums
+    and their order differ, and a line search amplifies that now and then: counted here, asserted on by the GPU suite, printed by bench.py."""
+    from mrg_slam_amd import PclNdtHip
+
+    from . import oracle as orc
+
+    rng = np.random.default_rng(seed)
+    st = {"cases": cases, "seed": seed, "exact": 0, "over_bar": 0, "worst": 0.0, "flag_or_iteration_mismatch": 0, "evaluation_count_mismatch": 0, "one_iteration": 0,
+          "iterations_total": 0, "over_bar_cases": []}
+    for c in range(cases):
+        tgt, src, guess, _ = soak_scene(rng)
+        eps = float(rng.choice([0.1, 0.01, 1e-3, 1e-5, 1e-7]))
+        res = float(rng.choice([0.5, 1.0, 1.5, 2.0]))
+        iters = int(rng.choice([35, 64]))
+        g = PclNdtHip(resolution=res, transformation_epsilon=eps, maximum_iterations=iters)
+        o = orc.PclNdt(resolution=res, transformation_epsilon=eps, maximum_iterations=iters)
+        for r in (g, o):
+            r.setInputTarget(tgt)
+            r.setInputSource(src)
+            r.align(guess)
+        Tg, To = g.getFinalTransformation(), o.getFinalTransformation()
+        dt, dr = _diff(Tg, To)
+        st["exact"] += bool(np.array_equal(Tg, To))
+        st["worst"] = max(st["worst"], dt, dr)
+        st["flag_or_iteration_mismatch"] += int(bool(g.hasConverged()) != bool(o.hasConverged()) or g.getFinalNumIteration() != o.getFinalNumIteration())
+        st["evaluation_count_mismatch"] += int(g.evals != o.evals)
+        st["one_iteration"] += int(o.getFinalNumIteration() == 1)
+        st["iterations_total"] += int(o.getFinalNumIteration())
+        if dt > BAR or dr > BAR:
+            st["over_bar"] += 1
+            st["over_bar_cases"].append({"case": f"case {c}: PCL NDT res={res} eps={eps}", "dt_m": dt, "dr_rad": dr, "iterations_hip": int(g.getFinalNumIteration()),
+                                         "iterations_oracle": int(o.getFinalNumIteration())})
     return st
 
 

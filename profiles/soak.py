@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The randomised parity soak at a size the GPU suite and bench.py do not run every time:
-    python3 profiles/soak.py [ndt_cases=2000] [round3_cases=600] > gpurun_out/soak.json
+    python3 profiles/soak.py [ndt_cases=2000] [round3_cases=600] [pcl_ndt_cases=500] > gpurun_out/soak.json
 Counts per method of scenes over the 1e-4 m / 1e-4 rad bar against the reference-order oracle, of bit-identical results, and of over-the-bar scenes
 that equal the GPU-order replay (oracle/replay.py).  The summary is kept as profiles/<tag>_soak.json."""
 import json
@@ -12,14 +12,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402,F401  (before libmrgfe)
 
-from oracle.replay import ndt_soak, round3_soak  # noqa: E402
+from oracle.replay import ndt_soak, pclndt_soak, round3_soak  # noqa: E402
 
 a_n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 b_n = int(sys.argv[2]) if len(sys.argv) > 2 else 600
+c_n = int(sys.argv[3]) if len(sys.argv) > 3 else 500
 t0 = time.time()
 a = ndt_soak(a_n, 77)
 t1 = time.time()
 print(f"[soak] {a_n} scenes in {t1 - t0:.0f} s", file=sys.stderr)
 b = round3_soak(b_n, 78)
 print(f"[soak] {b_n} scenes in {time.time() - t1:.0f} s", file=sys.stderr)
-print(json.dumps({"all_methods": a, "pcl_gicp_and_reciprocal_icp": b, "seconds": time.time() - t0}))
+t2 = time.time()
+c = pclndt_soak(c_n, 79)
+print(f"[soak] {c_n} scenes in {time.time() - t2:.0f} s", file=sys.stderr)
+print(json.dumps({"all_methods": a, "pcl_gicp_and_reciprocal_icp": b, "pcl_ndt": c, "seconds": time.time() - t0}))

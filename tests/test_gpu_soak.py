@@ -61,6 +61,19 @@ def test_soak_round3_methods():
     assert st["gicp_omp_worst"] <= 2e-2  # regression guard only (the numbers are in the bench line)
 
 
+def test_soak_pcl_ndt():
+    """PCL_NDT_HIP (registration_method "NDT"): 120 random scenes against the reference-order oracle.  All pair terms are f64 on both sides, so the
+    bar is unconditional here: no scene over 1e-4 m / 1e-4 rad, the same flags, iteration and evaluation counts."""
+    from oracle.replay import pclndt_soak
+
+    st = pclndt_soak(120, 31)
+    print({k: v for k, v in st.items() if k != "over_bar_cases"})
+    assert st["over_bar"] == 0, st["over_bar_cases"]
+    assert st["flag_or_iteration_mismatch"] == 0 and st["evaluation_count_mismatch"] == 0
+    assert st["worst"] <= 1e-6 and st["exact"] >= 0.95 * st["cases"]
+    assert 10 <= st["one_iteration"] < st["cases"] and st["iterations_total"] > 4 * st["cases"]  # both regimes are in the sample
+
+
 def test_pcl_gicp_tree_sums_still_equal_the_gpu_order_oracle():
     """The round-3 evaluation (block tree) stays behind mrgfe_dbg_set_pclgicp_reference_order(0): bit-identical to the oracle in the kernels' order."""
     from mrg_slam_amd import PclGicpHip
