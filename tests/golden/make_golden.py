@@ -10,6 +10,7 @@ the HIP path against them on the GPU box.  Re-run only when the oracle is delibe
     python tests/golden/make_golden.py --vgicp-only         # tests/golden/vgicp.npz only
     python tests/golden/make_golden.py --icp-only           # tests/golden/icp.npz only
     python tests/golden/make_golden.py --round3-only        # tests/golden/round3.npz only (pcl::GICP, pclomp::GICP, reciprocal ICP)
+    python tests/golden/make_golden.py --pcl-ndt-only       # tests/golden/pcl_ndt.npz only (pcl::NormalDistributionsTransform, registration_method "NDT")
 """
 import os
 import sys
@@ -179,8 +180,32 @@ def round3():
     print(path, os.path.getsize(path), "bytes")
 
 
+def pcl_ndt():
+    """tests/golden/pcl_ndt.npz: the restated pcl::NormalDistributionsTransform (oracle/pcl_ndt.cpp; registration_method "NDT", registrations.cpp:115-129)
+    on the inputs of frontend_small.npz: mrg_slam's epsilon (one Newton iteration under PCL's rule) and a tight one, plus one evaluation of each kind."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "frontend_small.npz"))
+    out = {}
+    for eps, tag in ((0.1, "eps0p1"), (1e-6, "eps1em6")):
+        g = orc.PclNdt(resolution=1.0, transformation_epsilon=eps, maximum_iterations=64)
+        assert g.setInputTarget(G["tgt"]) == 0
+        g.setInputSource(G["src"])
+        g.align(G["guess"])
+        out[f"{tag}_T"] = g.getFinalTransformation()
+        out[f"{tag}_H"] = g.getHessian()
+        out[f"{tag}_meta"] = np.array([g.hasConverged(), g.getFinalNumIteration(), g.evals], dtype=np.int64)
+        out[f"{tag}_fitness"] = np.array([g.getFitnessScore(), g.getTransformationLikelihood()])
+    for mode in (0, 1, 2):
+        s, gr, H = g.evaluate(G["eval_T"], G["eval_p"], mode)
+        out[f"eval{mode}_score"], out[f"eval{mode}_g"], out[f"eval{mode}_H"] = np.array([s]), gr, H
+    path = os.path.join(ROOT, "tests", "golden", "pcl_ndt.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    if "--round3-only" in sys.argv:
+    if "--pcl-ndt-only" in sys.argv:
+        pcl_ndt()
+    elif "--round3-only" in sys.argv:
         round3()
     elif "--icp-only" in sys.argv:
         icp()
@@ -194,3 +219,4 @@ if __name__ == "__main__":
         vgicp()
         icp()
         round3()
+        pcl_ndt()

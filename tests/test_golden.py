@@ -131,6 +131,53 @@ def test_oracle_round3_methods_reproduce_golden():
     assert np.linalg.norm(R["gicp_T"][:3, 3] - G["rel"][:3, 3]) < 2e-3
 
 
+def test_oracle_pcl_ndt_reproduces_golden():
+    """pcl::NormalDistributionsTransform (tests/golden/pcl_ndt.npz)."""
+    from oracle import oracle as orc
+
+    P = np.load(os.path.join(os.path.dirname(__file__), "golden", "pcl_ndt.npz"))
+    for eps, tag in ((0.1, "eps0p1"), (1e-6, "eps1em6")):
+        g = orc.PclNdt(resolution=1.0, transformation_epsilon=eps, maximum_iterations=64)
+        assert g.setInputTarget(G["tgt"]) == 0
+        g.setInputSource(G["src"])
+        g.align(G["guess"])
+        np.testing.assert_array_equal(g.getFinalTransformation(), P[f"{tag}_T"])
+        np.testing.assert_array_equal(g.getHessian(), P[f"{tag}_H"])
+        assert [int(g.hasConverged()), g.getFinalNumIteration(), g.evals] == P[f"{tag}_meta"].tolist()
+        assert [g.getFitnessScore(), g.getTransformationLikelihood()] == P[f"{tag}_fitness"].tolist()
+    assert P["eps0p1_meta"][1] == 1 and P["eps1em6_meta"][1] > 3  # PCL's iteration rule: mrg_slam's epsilon stops after one Newton step
+    assert np.linalg.norm(P["eps1em6_T"][:3, 3] - G["rel"][:3, 3]) < 0.02
+    for mode in (0, 1, 2):
+        s, gr, H = g.evaluate(G["eval_T"], G["eval_p"], mode)
+        assert s == P[f"eval{mode}_score"][0]
+        np.testing.assert_array_equal(gr, P[f"eval{mode}_g"])
+        np.testing.assert_array_equal(H, P[f"eval{mode}_H"])
+
+
+@pytest.mark.gpu
+def test_hip_pcl_ndt_matches_golden():
+    from mrg_slam_amd import PclNdtHip, synth
+
+    P = np.load(os.path.join(os.path.dirname(__file__), "golden", "pcl_ndt.npz"))
+    for eps, tag in ((0.1, "eps0p1"), (1e-6, "eps1em6")):
+        g = PclNdtHip(resolution=1.0, transformation_epsilon=eps, maximum_iterations=64)
+        assert g.setInputTarget(G["tgt"]) == 0
+        g.setInputSource(G["src"])
+        g.align(G["guess"])
+        T = g.getFinalTransformation()
+        assert np.linalg.norm(T[:3, 3].astype(np.float64) - P[f"{tag}_T"][:3, 3]) <= 1e-4 and synth.rotation_angle(T, P[f"{tag}_T"]) <= 1e-4
+        assert [int(g.hasConverged()), g.getFinalNumIteration(), g.evals] == P[f"{tag}_meta"].tolist()
+        np.testing.assert_allclose(g.getHessian(), P[f"{tag}_H"], rtol=0, atol=1e-8 * np.abs(P[f"{tag}_H"]).max())
+        assert g.getFitnessScore() == pytest.approx(P[f"{tag}_fitness"][0], rel=1e-6)
+    for mode in (0, 1, 2):
+        s, gr, H = g.evaluate(G["eval_T"], G["eval_p"], mode)
+        if mode != 2:
+            assert s == pytest.approx(P[f"eval{mode}_score"][0], rel=1e-12)
+            np.testing.assert_allclose(gr, P[f"eval{mode}_g"], rtol=0, atol=1e-10 * np.abs(P[f"eval{mode}_g"]).max())
+        if mode != 1:
+            np.testing.assert_allclose(H, P[f"eval{mode}_H"], rtol=0, atol=1e-10 * np.abs(P[f"eval{mode}_H"]).max())
+
+
 def test_oracle_perpoint_passes_reproduce_golden():
     from oracle import oracle as orc
 
