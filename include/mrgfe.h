@@ -386,6 +386,46 @@ int  mrgfe_batch_largest_launch(const mrgfe_batch* b, double out[4]);
  * scored in waves beside the remaining alignment rounds, the rest afterwards): the layout of mrgfe_ctx_fitness_stats, out[10] = launches. */
 int  mrgfe_batch_fitness_stats(const mrgfe_batch* b, double out[11]);
 
+/* ---- the same batch over the GPUs of one node ---------------------------------------------------------------------------
+ * LoopDetector::matching runs in ONE host process per robot (src/mrg_slam/loop_detector.cpp:104,126-145 under mrg_slam_component's main
+ * thread mutex): a node object lets that process reach every GPU of the machine through this header.  It owns one MEMBER per entry of
+ * device_ids — a context, a batch and a host thread each; the same ordinal may appear several times (members sharing a card).
+ * mrgfe_node_align cuts the declared pair list into n_members contiguous blocks whose sizes differ by at most one (the list is in the
+ * reference's order — new keyframe after new keyframe, candidates in candidate order — so a block touches few distinct targets), every
+ * member builds the targets and aligns the pairs of its block on its GPU (no data-path collective), and the 384-byte records are gathered
+ * into `results` in pair order: with one ncclAllGather over the members' streams (RCCL over xGMI; librccl is loaded with dlopen) when there
+ * are two or more members on distinct devices, through host memory otherwise (MRGFE_NODE_GATHER=host / rccl forces either).  The records —
+ * and so the best candidates — are those of ONE batch holding the whole list, bit for bit, whatever n_members is.
+ * Unlike mrgfe_batch_add_*, the clouds are only REFERENCED by the add calls (which member a pair goes to is known once the list is complete):
+ * the host buffers must stay valid until mrgfe_node_align returns.  Keys (non-zero keyframe ids) keep a cloud resident on the member that
+ * used it — candidates in the member's batch store (mrgfe_batch_add_pair_keyed), targets in the node's own per-member store —, and a later
+ * call that names a resident key with the same point count may pass NULL.  A member that fails (out of memory, a bad cloud) makes
+ * mrgfe_node_align return its error code with the member named in mrgfe_last_error(); the node stays usable. */
+typedef struct mrgfe_node mrgfe_node;
+int    mrgfe_node_create(int n_members, const int* device_ids, const mrgfe_reg_params* params, mrgfe_node** out);
+void   mrgfe_node_destroy(mrgfe_node* node);
+int    mrgfe_node_num_members(const mrgfe_node* node);
+int    mrgfe_node_clear(mrgfe_node* node);
+/* registration_->setInputTarget(new_keyframe->cloud), loop_detector.cpp:104: returns the target index (>= 0) or an error (< 0) */
+int    mrgfe_node_add_target(mrgfe_node* node, const float* xyzi, size_t n, size_t stride_bytes);
+int    mrgfe_node_add_target_keyed(mrgfe_node* node, uint64_t cloud_key, const float* xyzi, size_t n, size_t stride_bytes);
+/* one candidate: setInputSource(candidate->cloud) + align(guess), loop_detector.cpp:127-134: returns the pair index (>= 0) or an error (< 0) */
+int    mrgfe_node_add_pair(mrgfe_node* node, int target_index, const float* src_xyzi, size_t n, size_t stride_bytes, const float guess[16]);
+int    mrgfe_node_add_pair_keyed(mrgfe_node* node, int target_index, uint64_t cloud_key, const float* src_xyzi, size_t n, size_t stride_bytes, const float guess[16]);
+int    mrgfe_node_num_pairs(const mrgfe_node* node);
+int    mrgfe_node_align(mrgfe_node* node, double fitness_max_range, mrgfe_pair_result* results /* n_pairs, pair_id = index in the list */);
+/* block of member `member` in the last mrgfe_node_align; how its records were gathered (0 host memory, 1 RCCL all-gather) */
+int    mrgfe_node_shard(const mrgfe_node* node, int member, int* first_pair, int* n_pairs);
+int    mrgfe_node_last_gather(const mrgfe_node* node);
+int    mrgfe_node_forget(mrgfe_node* node, uint64_t cloud_key); /* drops a key from every member's stores (0: all) */
+size_t mrgfe_node_store_bytes(const mrgfe_node* node);
+/* the reference's sequential rule on gathered records (loop_detector.cpp:126-145: "if( !hasConverged() || score > best_score ) continue;"): group g
+ * = records group_first[g] .. group_first[g + 1] - 1 (the candidates of one new keyframe, in candidate order); best[g] = position within the
+ * group or -1, best_score[g] = its fitness or DBL_MAX.  Among equal scores the LAST candidate wins, as there. */
+int    mrgfe_node_select_best(const mrgfe_pair_result* results, int n_groups, const int32_t* group_first, int32_t* best, double* best_score);
+/* test hook: the next mrgfe_node_align fails on that member (the error path without an out-of-memory condition) */
+int    mrgfe_dbg_node_fail_member(mrgfe_node* node, int member);
+
 /* ---- diagnostic entry points for the primitive tests (tests/test_gpu_primitives.py) --------------------------- */
 /* correspondence search of GICP_HIP / SMALL_GICP_HIP (fast_gicp / small_gicp update_correspondences): the batched passes of getFitnessScore
  * carrying the index of the nearest point (csrc nn_nearest_batch) or one lane group per query until its answer is final.  1 = the passes for

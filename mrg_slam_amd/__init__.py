@@ -4,7 +4,7 @@ pcl::Registration / pcl::Filter call surface.  See DESIGN.md."""
 from ._lib import Context, MrgfeError, build, default_context  # noqa: F401
 from .filters import ApproximateVoxelGrid, InformationMatrixCalculator, RadiusOutlierRemoval, StatisticalOutlierRemoval, VoxelGrid, calc_fitness_score, distance_filter, knn, prefilter, prefilter_to_device  # noqa: F401
 from .map_cloud import KeyFrameSnapshot, MapCloudGenerator, MapCloudStore, deskew, remove_points_near, transform_cloud  # noqa: F401
-from .registration import BatchMatcher, GicpHip, IcpHip, NdtHip, PclGicpHip, PclNdtHip, SmallGicpHip, VgicpHip, select_registration_method  # noqa: F401
+from .registration import BatchMatcher, GicpHip, IcpHip, NdtHip, NodeMatcher, PclGicpHip, PclNdtHip, SmallGicpHip, VgicpHip, select_registration_method  # noqa: F401
 from .loop_detector import KeyFrame, LoopDetector  # noqa: F401,E402
 from .odometry import ScanMatchingOdometry  # noqa: F401,E402
 from .prefiltering import PrefilteringComponent  # noqa: F401,E402

@@ -177,6 +177,22 @@ SIGNATURES = {
     "mrgfe_reg_kernel_stats": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_int64), _dp]),
     "mrgfe_batch_pair_counts": (C.c_int, [_vp, C.c_int, _dp, _dp]),
     "mrgfe_batch_largest_launch": (C.c_int, [_vp, _dp]),
+    "mrgfe_node_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(RegParams), C.POINTER(_vp)]),
+    "mrgfe_node_destroy": (None, [_vp]),
+    "mrgfe_node_num_members": (C.c_int, [_vp]),
+    "mrgfe_node_clear": (C.c_int, [_vp]),
+    "mrgfe_node_add_target": (C.c_int, [_vp, _fp, C.c_size_t, C.c_size_t]),
+    "mrgfe_node_add_target_keyed": (C.c_int, [_vp, C.c_uint64, _fp, C.c_size_t, C.c_size_t]),
+    "mrgfe_node_add_pair": (C.c_int, [_vp, C.c_int, _fp, C.c_size_t, C.c_size_t, _fp]),
+    "mrgfe_node_add_pair_keyed": (C.c_int, [_vp, C.c_int, C.c_uint64, _fp, C.c_size_t, C.c_size_t, _fp]),
+    "mrgfe_node_num_pairs": (C.c_int, [_vp]),
+    "mrgfe_node_align": (C.c_int, [_vp, C.c_double, C.POINTER(PairResult)]),
+    "mrgfe_node_shard": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mrgfe_node_last_gather": (C.c_int, [_vp]),
+    "mrgfe_node_forget": (C.c_int, [_vp, C.c_uint64]),
+    "mrgfe_node_store_bytes": (C.c_size_t, [_vp]),
+    "mrgfe_node_select_best": (C.c_int, [C.POINTER(PairResult), C.c_int, _ip, _ip, _dp]),
+    "mrgfe_dbg_node_fail_member": (C.c_int, [_vp, C.c_int]),
     "mrgfe_dbg_set_gicp_corr_passes": (C.c_int, [C.c_int]),
     "mrgfe_dbg_grid_set_query": (C.c_int, [_vp, C.POINTER(_fp), C.POINTER(C.c_size_t), C.c_int, _fp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int32), _fp]),
     "mrgfe_dbg_sort_pairs": (C.c_int, [_vp, _u32p, _u32p, C.c_size_t, C.c_int, _u32p, _u32p]),

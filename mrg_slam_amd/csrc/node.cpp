@@ -1,0 +1,523 @@
+// csrc/node.cpp — mrgfe_node_*: the multi-GPU form of the loop-closure candidate batch behind the C ABI.
+//
+// The reference's host is ONE C++ process per robot whose LoopDetector::matching walks the candidates of a new keyframe one
+// after the other on one registration object (/root/reference/src/mrg_slam/loop_detector.cpp:104,126-145).  The alignments are
+// independent, so a node object owns one MEMBER per GPU — a context, a batch (mrgfe_batch_*) and a host thread each — and
+//   * cuts the declared pair list into contiguous blocks, one per member, sizes differing by at most one (the list is ordered by
+//     new keyframe, so a block touches few distinct targets: the partitioning of mrg_slam_amd/loop_closure.py shard_indices);
+//   * every member uploads / finds resident the clouds of ITS block, builds ITS targets and aligns ITS pairs on its GPU: no
+//     data-path collective;
+//   * the fixed-size 384-byte result records (pose, 6x6 Hessian, fitness, flags) are gathered into the caller's array — through
+//     host memory, or with ONE ncclAllGather over the members' streams (RCCL over xGMI) when the members sit on distinct
+//     devices and librccl can be loaded (dlopen: no link-time dependency);
+//   * the caller replays the reference's sequential best-candidate rule on the gathered records (mrgfe_node_select_best), so the
+//     answer does not depend on the number of GPUs.
+// Members on the SAME device are allowed (several batches sharing one card): that is what a one-GPU box can test, bit for bit
+// against a single batch, and RCCL — which refuses duplicate devices — is then not used.
+// Never re-execs, never forks: threads only (a process that has initialised the GPU must not exec on this pool).
+#include <dlfcn.h>
+
+#include <atomic>
+#include <cfloat>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+using namespace mrgfe;
+
+namespace {
+
+// ---- RCCL through dlopen: only the five entry points the record gather needs (signatures of rccl.h) -------------------------------
+typedef struct ncclComm* nccl_comm_t;
+struct Rccl {
+    void* lib = nullptr;
+    int (*CommInitAll)(nccl_comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(nccl_comm_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int /* ncclDataType_t */, nccl_comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok() const { return lib && CommInitAll && CommDestroy && AllGather && GroupStart && GroupEnd; }
+};
+constexpr int kNcclChar = 0;  // ncclInt8 / ncclChar
+
+Rccl& rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return;
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.lib, "ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.lib, "ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.lib, "ncclGroupEnd"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    });
+    return r;
+}
+
+struct TargetDecl {
+    uint64_t     key;
+    const float* xyzi;
+    size_t       n, stride;
+};
+struct PairDecl {
+    int          target;
+    uint64_t     key;
+    const float* xyzi;
+    size_t       n, stride;
+    float        guess[16];
+};
+struct ResidentCloud {
+    DevBuf buf;
+    size_t n = 0;
+};
+
+enum Job { JOB_NONE = 0, JOB_ALIGN = 1, JOB_QUIT = 2 };
+
+}  // namespace
+
+struct mrgfe_node {
+    struct Member {
+        int          index = 0, device = 0;
+        mrgfe_ctx*   ctx = nullptr;
+        mrgfe_batch* batch = nullptr;
+        std::thread  th;
+        std::mutex   mu;
+        std::condition_variable cv;
+        Job          job = JOB_NONE;
+        bool         done = true;
+        int          status = MRGFE_OK;
+        std::string  error;
+        int          first = 0, count = 0;  // this member's block of the pair list
+        std::vector<mrgfe_pair_result> local;
+        std::unordered_map<uint64_t, ResidentCloud*> targets;  // keyed target clouds resident on this member's device
+        DevBuf       d_send, d_recv;                            // RCCL gather
+        int          fail_next = 0;                             // test hook
+    };
+    mrgfe_reg_params         params;
+    std::vector<Member*>     members;
+    std::vector<TargetDecl>  targets;
+    std::vector<PairDecl>    pairs;
+    double                   fitness_max_range = -1.0;
+    std::vector<nccl_comm_t> comms;     // one per member when the RCCL gather is in use
+    bool                     rccl_tried = false;
+    int                      last_gather = 0;  // 0 host, 1 RCCL
+    std::mutex               api_mu;    // one align at a time
+};
+
+namespace {
+
+using Member = mrgfe_node::Member;
+
+int member_fail(Member& m, int status)
+{
+    m.status = status;
+    m.error = mrgfe_last_error();
+    return status;
+}
+
+// the member's block: targets in order of first use, pairs in list order; then the batch's own align
+int member_align(mrgfe_node* node, Member& m)
+{
+    m.status = MRGFE_OK;
+    m.error.clear();
+    m.local.assign(static_cast<size_t>(m.count), mrgfe_pair_result{});
+    if (m.fail_next) {
+        m.fail_next = 0;
+        set_error("member %d: failure injected by mrgfe_dbg_node_fail_member", m.index);
+        return member_fail(m, MRGFE_ERR_STATE);
+    }
+    if (m.count == 0) return MRGFE_OK;
+    int st = mrgfe_batch_clear(m.batch);
+    if (st != MRGFE_OK) return member_fail(m, st);
+    std::unordered_map<int, int> local_target;
+    for (int i = m.first; i < m.first + m.count; ++i) {
+        const PairDecl& p = node->pairs[static_cast<size_t>(i)];
+        auto it = local_target.find(p.target);
+        if (it == local_target.end()) {
+            const TargetDecl& t = node->targets[static_cast<size_t>(p.target)];
+            int ti;
+            if (t.key) {
+                // a keyed target stays resident on this member's device: uploaded once, found again by the next batches that name it
+                ResidentCloud*& rc = m.targets[t.key];
+                if (!rc) rc = new (std::nothrow) ResidentCloud();
+                if (!rc) { set_error("out of host memory"); return member_fail(m, MRGFE_ERR_INVALID); }
+                if (rc->n != t.n || !rc->buf.p) {
+                    if (!t.xyzi && t.n) { set_error("member %d: target key %llu is not resident and no cloud was given", m.index, static_cast<unsigned long long>(t.key)); return member_fail(m, MRGFE_ERR_INVALID); }
+                    MRGFE_LOCK(m.ctx);
+                    if ((st = m.ctx->bind()) != MRGFE_OK) return member_fail(m, st);
+                    if ((st = rc->buf.ensure(std::max<size_t>(t.n, 1) * 16)) != MRGFE_OK) return member_fail(m, st);
+                    if ((st = upload_cloud(m.ctx, t.xyzi, t.n, t.stride, rc->buf.p)) != MRGFE_OK) return member_fail(m, st);
+                    rc->n = t.n;
+                }
+                ti = mrgfe_batch_add_target_device(m.batch, rc->buf.p, rc->n);
+            } else {
+                ti = mrgfe_batch_add_target(m.batch, t.xyzi, t.n, t.stride);
+            }
+            if (ti < 0) return member_fail(m, ti);
+            it = local_target.emplace(p.target, ti).first;
+        }
+        const int pi = p.key ? mrgfe_batch_add_pair_keyed(m.batch, it->second, p.key, p.xyzi, p.n, p.stride, p.guess)
+                             : mrgfe_batch_add_pair(m.batch, it->second, p.xyzi, p.n, p.stride, p.guess);
+        if (pi < 0) return member_fail(m, pi);
+    }
+    st = mrgfe_batch_align(m.batch, node->fitness_max_range, m.local.data());
+    if (st != MRGFE_OK) return member_fail(m, st);
+    for (int k = 0; k < m.count; ++k) m.local[static_cast<size_t>(k)].pair_id = m.first + k;  // the GLOBAL pair index
+    return MRGFE_OK;
+}
+
+void member_main(mrgfe_node* node, Member* m)
+{
+    for (;;) {
+        Job job;
+        {
+            std::unique_lock<std::mutex> lk(m->mu);
+            m->cv.wait(lk, [&] { return m->job != JOB_NONE; });
+            job = m->job;
+        }
+        if (job == JOB_QUIT) return;
+        int st;
+        try {
+            st = member_align(node, *m);
+        } catch (const std::exception& e) {  // (std::bad_alloc of a host container: an error code, never std::terminate)
+            m->status = st = MRGFE_ERR_INVALID;
+            m->error = std::string("member ") + std::to_string(m->index) + ": " + e.what();
+        } catch (...) {
+            m->status = st = MRGFE_ERR_INVALID;
+            m->error = "member " + std::to_string(m->index) + ": unknown exception";
+        }
+        (void)st;
+        {
+            std::lock_guard<std::mutex> lk(m->mu);
+            m->job = JOB_NONE;
+            m->done = true;
+        }
+        m->cv.notify_all();
+    }
+}
+
+void post(Member* m, Job job)
+{
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        m->job = job;
+        m->done = false;
+    }
+    m->cv.notify_all();
+}
+void wait_done(Member* m)
+{
+    std::unique_lock<std::mutex> lk(m->mu);
+    m->cv.wait(lk, [&] { return m->done; });
+}
+
+bool distinct_devices(const mrgfe_node* node)
+{
+    for (size_t a = 0; a < node->members.size(); ++a)
+        for (size_t b = a + 1; b < node->members.size(); ++b)
+            if (node->members[a]->device == node->members[b]->device) return false;
+    return true;
+}
+
+// MRGFE_NODE_GATHER: "host" never uses RCCL, "rccl" uses it whenever the devices are distinct (also for ONE member: the code path a
+// one-GPU box can exercise), unset: RCCL for two or more members on distinct devices
+bool want_rccl(const mrgfe_node* node)
+{
+    const char* e = std::getenv("MRGFE_NODE_GATHER");
+    if (e && std::strcmp(e, "host") == 0) return false;
+    if (!distinct_devices(node)) return false;
+    if (e && std::strcmp(e, "rccl") == 0) return true;
+    return node->members.size() >= 2;
+}
+
+int rccl_setup(mrgfe_node* node)
+{
+    if (!node->comms.empty()) return MRGFE_OK;
+    if (node->rccl_tried) return MRGFE_ERR_STATE;
+    node->rccl_tried = true;
+    Rccl& r = rccl();
+    if (!r.ok()) { set_error("librccl could not be loaded"); return MRGFE_ERR_STATE; }
+    std::vector<int> devs;
+    for (Member* m : node->members) devs.push_back(m->device);
+    node->comms.assign(devs.size(), nullptr);
+    const int rc = r.CommInitAll(node->comms.data(), static_cast<int>(devs.size()), devs.data());
+    if (rc != 0) {
+        set_error("ncclCommInitAll failed: %s", r.GetErrorString ? r.GetErrorString(rc) : "?");
+        node->comms.clear();
+        return MRGFE_ERR_HIP;
+    }
+    return MRGFE_OK;
+}
+
+// one ncclAllGather of `per` records per member over the members' streams; member 0's receive buffer comes back to the host
+int rccl_gather(mrgfe_node* node, int per, mrgfe_pair_result* results, int n_pairs)
+{
+    Rccl& r = rccl();
+    const size_t G = node->members.size();
+    const size_t rec = sizeof(mrgfe_pair_result), bytes = rec * static_cast<size_t>(per);
+    std::vector<mrgfe_pair_result> pad(static_cast<size_t>(per));
+    for (Member* m : node->members) {
+        MRGFE_LOCK(m->ctx);
+        MRGFE_TRY(m->ctx->bind());
+        MRGFE_TRY(m->d_send.ensure(bytes));
+        MRGFE_TRY(m->d_recv.ensure(bytes * G));
+        for (int k = 0; k < per; ++k) {
+            if (k < m->count) pad[static_cast<size_t>(k)] = m->local[static_cast<size_t>(k)];
+            else { std::memset(&pad[static_cast<size_t>(k)], 0, rec); pad[static_cast<size_t>(k)].pair_id = -1; }
+        }
+        MRGFE_TRY(m->ctx->stage_h2d(m->d_send.p, pad.data(), bytes, m->ctx->stream));
+    }
+    int rc = r.GroupStart();
+    for (size_t g = 0; g < G && rc == 0; ++g) {
+        Member* m = node->members[g];
+        (void)hipSetDevice(m->device);
+        rc = r.AllGather(m->d_send.p, m->d_recv.p, bytes, kNcclChar, node->comms[g], m->ctx->stream);
+    }
+    const int rc_end = r.GroupEnd();
+    if (rc == 0) rc = rc_end;
+    if (rc != 0) { set_error("ncclAllGather failed: %s", r.GetErrorString ? r.GetErrorString(rc) : "?"); return MRGFE_ERR_HIP; }
+    std::vector<mrgfe_pair_result> all(static_cast<size_t>(per) * G);
+    {
+        Member* m0 = node->members[0];
+        MRGFE_LOCK(m0->ctx);
+        MRGFE_TRY(m0->ctx->bind());
+        MRGFE_HIP_CHECK(hipMemcpyAsync(all.data(), m0->d_recv.p, bytes * G, hipMemcpyDeviceToHost, m0->ctx->stream));
+        MRGFE_HIP_CHECK(hipStreamSynchronize(m0->ctx->stream));
+    }
+    for (size_t g = 1; g < G; ++g) {  // every member's collective has to have finished before its buffers are reused
+        Member* m = node->members[g];
+        MRGFE_LOCK(m->ctx);
+        MRGFE_TRY(m->ctx->bind());
+        MRGFE_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    }
+    int seen = 0;
+    for (const mrgfe_pair_result& x : all) {
+        if (x.pair_id < 0) continue;
+        if (x.pair_id >= n_pairs) { set_error("gathered record names pair %d of %d", x.pair_id, n_pairs); return MRGFE_ERR_STATE; }
+        results[x.pair_id] = x;
+        ++seen;
+    }
+    if (seen != n_pairs) { set_error("gathered %d records for %d pairs", seen, n_pairs); return MRGFE_ERR_STATE; }
+    return MRGFE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrgfe_node_create(int n_members, const int* device_ids, const mrgfe_reg_params* params, mrgfe_node** out)
+{
+    if (!out || !params || n_members < 1 || n_members > 64 || !device_ids) { set_error("mrgfe_node_create: bad argument"); return MRGFE_ERR_INVALID; }
+    *out = nullptr;
+    mrgfe_node* node = new (std::nothrow) mrgfe_node();
+    if (!node) { set_error("out of host memory"); return MRGFE_ERR_INVALID; }
+    node->params = *params;
+    int st = MRGFE_OK;
+    for (int i = 0; i < n_members && st == MRGFE_OK; ++i) {
+        Member* m = new (std::nothrow) Member();
+        if (!m) { set_error("out of host memory"); st = MRGFE_ERR_INVALID; break; }
+        m->index = i;
+        m->device = device_ids[i];
+        node->members.push_back(m);
+        st = mrgfe_ctx_create(m->device, &m->ctx);
+        if (st == MRGFE_OK) st = mrgfe_batch_create(m->ctx, params, &m->batch);
+    }
+    if (st != MRGFE_OK) {
+        const std::string msg = mrgfe_last_error();
+        mrgfe_node_destroy(node);
+        set_error("%s", msg.c_str());
+        return st;
+    }
+    for (Member* m : node->members) m->th = std::thread(member_main, node, m);
+    *out = node;
+    return MRGFE_OK;
+}
+
+void mrgfe_node_destroy(mrgfe_node* node)
+{
+    if (!node) return;
+    for (Member* m : node->members) {
+        if (m->th.joinable()) {
+            wait_done(m);
+            post(m, JOB_QUIT);
+            m->th.join();
+        }
+    }
+    if (!node->comms.empty() && rccl().ok())
+        for (nccl_comm_t c : node->comms) if (c) (void)rccl().CommDestroy(c);
+    for (Member* m : node->members) {
+        if (m->batch) mrgfe_batch_destroy(m->batch);
+        if (m->ctx) {
+            (void)hipSetDevice(m->device);
+            for (auto& kv : m->targets) { kv.second->buf.release(); delete kv.second; }
+            m->d_send.release();
+            m->d_recv.release();
+            mrgfe_ctx_destroy(m->ctx);
+        }
+        delete m;
+    }
+    delete node;
+}
+
+int mrgfe_node_num_members(const mrgfe_node* node) { return node ? static_cast<int>(node->members.size()) : MRGFE_ERR_INVALID; }
+int mrgfe_node_num_pairs(const mrgfe_node* node) { return node ? static_cast<int>(node->pairs.size()) : MRGFE_ERR_INVALID; }
+
+int mrgfe_node_clear(mrgfe_node* node)
+{
+    if (!node) { set_error("mrgfe_node_clear: NULL node"); return MRGFE_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(node->api_mu);
+    node->targets.clear();
+    node->pairs.clear();
+    return MRGFE_OK;
+}
+
+int mrgfe_node_add_target_keyed(mrgfe_node* node, uint64_t cloud_key, const float* xyzi, size_t n, size_t stride_bytes)
+{
+    if (!node || (n && !xyzi && !cloud_key)) { set_error("mrgfe_node_add_target: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (n > 0x7fffffffu) { set_error("mrgfe_node_add_target: cloud too large"); return MRGFE_ERR_INVALID; }
+    uint32_t s; uint32_t xo; int32_t io;
+    if (decode_layout(stride_bytes, &s, &xo, &io) != MRGFE_OK) return MRGFE_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(node->api_mu);
+    try {
+        node->targets.push_back(TargetDecl{cloud_key, xyzi, n, stride_bytes});
+    } catch (const std::bad_alloc&) { set_error("out of host memory"); return MRGFE_ERR_INVALID; }
+    return static_cast<int>(node->targets.size()) - 1;
+}
+int mrgfe_node_add_target(mrgfe_node* node, const float* xyzi, size_t n, size_t stride_bytes) { return mrgfe_node_add_target_keyed(node, 0, xyzi, n, stride_bytes); }
+
+int mrgfe_node_add_pair_keyed(mrgfe_node* node, int target_index, uint64_t cloud_key, const float* src_xyzi, size_t n, size_t stride_bytes, const float guess[16])
+{
+    if (!node || !guess || (n && !src_xyzi && !cloud_key)) { set_error("mrgfe_node_add_pair: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (n > 0x7fffffffu) { set_error("mrgfe_node_add_pair: cloud too large"); return MRGFE_ERR_INVALID; }
+    uint32_t s; uint32_t xo; int32_t io;
+    if (decode_layout(stride_bytes, &s, &xo, &io) != MRGFE_OK) return MRGFE_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(node->api_mu);
+    if (target_index < 0 || target_index >= static_cast<int>(node->targets.size())) { set_error("mrgfe_node_add_pair: target index %d out of range", target_index); return MRGFE_ERR_INVALID; }
+    PairDecl p;
+    p.target = target_index; p.key = cloud_key; p.xyzi = src_xyzi; p.n = n; p.stride = stride_bytes;
+    std::memcpy(p.guess, guess, sizeof(p.guess));
+    try {
+        node->pairs.push_back(p);
+    } catch (const std::bad_alloc&) { set_error("out of host memory"); return MRGFE_ERR_INVALID; }
+    return static_cast<int>(node->pairs.size()) - 1;
+}
+int mrgfe_node_add_pair(mrgfe_node* node, int target_index, const float* src_xyzi, size_t n, size_t stride_bytes, const float guess[16])
+{
+    return mrgfe_node_add_pair_keyed(node, target_index, 0, src_xyzi, n, stride_bytes, guess);
+}
+
+int mrgfe_node_align(mrgfe_node* node, double fitness_max_range, mrgfe_pair_result* results)
+{
+    if (!node) { set_error("mrgfe_node_align: NULL node"); return MRGFE_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(node->api_mu);
+    const int n = static_cast<int>(node->pairs.size()), G = static_cast<int>(node->members.size());
+    if (n && !results) { set_error("mrgfe_node_align: NULL results"); return MRGFE_ERR_INVALID; }
+    node->fitness_max_range = fitness_max_range;
+    // contiguous blocks, sizes differing by at most one, the first n mod G blocks the longer ones
+    const int base = n / G, extra = n % G;
+    for (int g = 0; g < G; ++g) {
+        Member* m = node->members[static_cast<size_t>(g)];
+        m->first = g * base + std::min(g, extra);
+        m->count = base + (g < extra ? 1 : 0);
+    }
+    for (Member* m : node->members) post(m, JOB_ALIGN);
+    for (Member* m : node->members) wait_done(m);
+    for (Member* m : node->members)
+        if (m->status != MRGFE_OK) {  // the first member that failed names the error; the others have finished their blocks and are idle again
+            set_error("mrgfe_node_align: member %d (device %d): %s", m->index, m->device, m->error.c_str());
+            return m->status;
+        }
+    if (n == 0) return MRGFE_OK;
+    node->last_gather = 0;
+    if (want_rccl(node) && rccl_setup(node) == MRGFE_OK) {
+        const int per = (n + G - 1) / G;
+        const int st = rccl_gather(node, per, results, n);
+        if (st == MRGFE_OK) { node->last_gather = 1; return MRGFE_OK; }
+        if (const char* e = std::getenv("MRGFE_NODE_GATHER")) if (std::strcmp(e, "rccl") == 0) return st;  // asked for: do not hide the failure
+    }
+    for (Member* m : node->members)
+        if (m->count) std::memcpy(results + m->first, m->local.data(), sizeof(mrgfe_pair_result) * static_cast<size_t>(m->count));
+    return MRGFE_OK;
+}
+
+int mrgfe_node_shard(const mrgfe_node* node, int member, int* first_pair, int* n_pairs)
+{
+    if (!node || member < 0 || member >= static_cast<int>(node->members.size())) { set_error("mrgfe_node_shard: bad argument"); return MRGFE_ERR_INVALID; }
+    if (first_pair) *first_pair = node->members[static_cast<size_t>(member)]->first;
+    if (n_pairs) *n_pairs = node->members[static_cast<size_t>(member)]->count;
+    return MRGFE_OK;
+}
+
+int mrgfe_node_last_gather(const mrgfe_node* node) { return node ? node->last_gather : MRGFE_ERR_INVALID; }
+
+int mrgfe_node_forget(mrgfe_node* node, uint64_t cloud_key)
+{
+    if (!node) { set_error("mrgfe_node_forget: NULL node"); return MRGFE_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(node->api_mu);
+    for (Member* m : node->members) {
+        {
+            MRGFE_LOCK(m->ctx);
+            (void)m->ctx->bind();
+            for (auto it = m->targets.begin(); it != m->targets.end();) {
+                if (cloud_key == 0 || it->first == cloud_key) { it->second->buf.release(); delete it->second; it = m->targets.erase(it); }
+                else ++it;
+            }
+        }
+        MRGFE_TRY(mrgfe_batch_forget(m->batch, cloud_key));
+    }
+    return MRGFE_OK;
+}
+
+size_t mrgfe_node_store_bytes(const mrgfe_node* node)
+{
+    if (!node) return 0;
+    size_t total = 0;
+    for (Member* m : node->members) {
+        total += mrgfe_batch_store_bytes(m->batch);
+        for (auto& kv : m->targets) total += kv.second->buf.cap;
+    }
+    return total;
+}
+
+int mrgfe_node_select_best(const mrgfe_pair_result* results, int n_groups, const int32_t* group_first, int32_t* best, double* best_score)
+{
+    if ((n_groups > 0 && (!results || !group_first)) || n_groups < 0) { set_error("mrgfe_node_select_best: bad argument"); return MRGFE_ERR_INVALID; }
+    for (int g = 0; g < n_groups; ++g) {
+        // loop_detector.cpp:126-145:  if( !hasConverged() || score > best_score ) continue;  best_score = score;  best_matched = candidate;
+        double bs = DBL_MAX;
+        int    b = -1;
+        for (int i = group_first[g]; i < group_first[g + 1]; ++i) {
+            const double score = results[i].fitness;
+            if (!results[i].converged || score > bs) continue;
+            bs = score;
+            b = i - group_first[g];
+        }
+        if (best) best[g] = b;
+        if (best_score) best_score[g] = bs;
+    }
+    return MRGFE_OK;
+}
+
+int mrgfe_dbg_node_fail_member(mrgfe_node* node, int member)
+{
+    if (!node || member < 0 || member >= static_cast<int>(node->members.size())) { set_error("mrgfe_dbg_node_fail_member: bad argument"); return MRGFE_ERR_INVALID; }
+    node->members[static_cast<size_t>(member)]->fail_next = 1;
+    return MRGFE_OK;
+}
+
+}  // extern "C"

@@ -483,6 +483,95 @@ class BatchMatcher:
         return ms.value, n.value, b.value
 
 
+class NodeMatcher:
+    """``mrgfe_node_*``: the candidate batch of LoopDetector::matching (loop_detector.cpp:104,126-145) over several GPUs of one machine from ONE
+    process — a member (context + batch + host thread) per entry of ``devices``; the same ordinal may appear more than once.  The pair list is cut
+    into contiguous blocks, the 384-byte records come back in pair order (RCCL all-gather between distinct devices, host memory otherwise); they equal
+    the records of one :class:`BatchMatcher` holding the whole list bit for bit."""
+
+    def __init__(self, devices, params: RegParams | None = None, **ndt_kwargs):
+        if params is None:
+            params = default_params(NDT_HIP)
+            params.transformation_epsilon = ndt_kwargs.get("transformation_epsilon", 0.01)
+            params.maximum_iterations = ndt_kwargs.get("maximum_iterations", 64)
+            params.resolution = ndt_kwargs.get("resolution", 1.0)
+            params.nn_search_method = SEARCH[ndt_kwargs.get("search", "DIRECT7")]
+        dev = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._h = C.c_void_p()
+        check(lib().mrgfe_node_create(len(devices), dev, C.byref(params), C.byref(self._h)))
+        self._keep = []  # the add calls only REFERENCE the clouds: keep them alive until align() returns
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().mrgfe_node_destroy(self._h)
+                self._h = None
+        except Exception:  # noqa: BLE001
+            pass
+
+    close = __del__
+
+    @property
+    def n_members(self) -> int:
+        return lib().mrgfe_node_num_members(self._h)
+
+    def clear(self):
+        check(lib().mrgfe_node_clear(self._h))
+        self._keep = []
+
+    def add_target(self, cloud, key: int = 0, n_points: int | None = None) -> int:
+        """``cloud=None``: a keyed target that is resident on the member that will need it (same key and point count as before)."""
+        if cloud is None:
+            return check(lib().mrgfe_node_add_target_keyed(self._h, key, None, int(n_points or 0), 16))
+        c = _cloud(cloud)
+        self._keep.append(c)
+        return check(lib().mrgfe_node_add_target_keyed(self._h, key, c.ctypes.data_as(_fp), len(c), 16))
+
+    def add_pair(self, target: int, source, guess=None, key: int = 0, n_points: int | None = None) -> int:
+        g = _colmajor(np.eye(4) if guess is None else guess)
+        if source is None:
+            return check(lib().mrgfe_node_add_pair_keyed(self._h, target, key, None, int(n_points or 0), 16, g.ctypes.data_as(_fp)))
+        c = _cloud(source)
+        self._keep.append(c)
+        return check(lib().mrgfe_node_add_pair_keyed(self._h, target, key, c.ctypes.data_as(_fp), len(c), 16, g.ctypes.data_as(_fp)))
+
+    def align(self, fitness_max_range: float = -1.0):
+        n = lib().mrgfe_node_num_pairs(self._h)
+        res = (PairResult * max(n, 1))()
+        try:
+            check(lib().mrgfe_node_align(self._h, fitness_max_range, res))
+        finally:
+            self._keep = []
+        return results_to_numpy(res, n)
+
+    def shard(self, member: int):
+        a, b = C.c_int(0), C.c_int(0)
+        check(lib().mrgfe_node_shard(self._h, member, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def last_gather(self) -> str:
+        return "rccl" if lib().mrgfe_node_last_gather(self._h) == 1 else "host"
+
+    def forget(self, key: int = 0):
+        check(lib().mrgfe_node_forget(self._h, key))
+
+    def store_bytes(self) -> int:
+        return int(lib().mrgfe_node_store_bytes(self._h))
+
+    def fail_member_once(self, member: int):
+        check(lib().mrgfe_dbg_node_fail_member(self._h, member))
+
+    @staticmethod
+    def select_best(records: np.ndarray, group_first):
+        """``mrgfe_node_select_best``: [(position within the group or None, score)] for the groups ``group_first[g] .. group_first[g + 1]``."""
+        gf = np.ascontiguousarray(group_first, dtype=np.int32)
+        ng = len(gf) - 1
+        rec = np.ascontiguousarray(records)
+        best, score = np.empty(max(ng, 1), dtype=np.int32), np.empty(max(ng, 1))
+        check(lib().mrgfe_node_select_best(C.cast(rec.ctypes.data, C.POINTER(PairResult)), ng, gf.ctypes.data_as(_ip), best.ctypes.data_as(_ip), score.ctypes.data_as(_dp)))
+        return [(int(best[g]) if best[g] >= 0 else None, float(score[g])) for g in range(ng)]
+
+
 RESULT_DTYPE = np.dtype([("T", np.float32, (16,)), ("H", np.float64, (36,)), ("fitness", np.float64), ("trans_probability", np.float64),
                          ("converged", np.int32), ("iterations", np.int32), ("evaluations", np.int32), ("pair_id", np.int32)])
 assert RESULT_DTYPE.itemsize == 384

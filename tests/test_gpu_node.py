@@ -1,0 +1,171 @@
+"""GPU: mrgfe_node_* — the loop-closure candidate batch over several members (one per GPU on a real node; here N members on the one card of the
+box, which is what the header allows for exactly this purpose): the gathered records must equal those of ONE batch holding the whole pair list bit
+for bit, for uneven blocks, keyed and unkeyed clouds, every method the batch API serves; a failing member returns an error code and leaves the
+node usable; the RCCL gather is exercised with one member (RCCL refuses duplicate devices)."""
+import numpy as np
+import pytest
+
+from conftest import small_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def _workload(n_targets=3, n_pairs=11, seed=5, sizes=(5000, 3800, 4400)):
+    from mrg_slam_amd import synth
+    from oracle import oracle as orc
+
+    targets = [small_cloud(sizes[k % len(sizes)], 300 + k) for k in range(n_targets)]
+    rng = np.random.default_rng(seed)
+    pairs = []
+    for k in range(n_pairs):
+        ti = min(n_targets - 1, k * n_targets // n_pairs)  # ordered by target, like the reference's list (new keyframe after new keyframe)
+        rel = synth.make_pose(rng.normal(0, 0.2, 3), synth.rot_xyz(*rng.normal(0, 0.02, 3)))
+        src = orc.transform_points(np.linalg.inv(rel), targets[ti][: 2400 + 170 * k])
+        pairs.append((ti, src, synth.perturb_pose(np.eye(4), rng)))
+    return targets, pairs
+
+
+def _one_batch(params, targets, pairs, fit=float("inf")):
+    from mrg_slam_amd import BatchMatcher
+
+    bm = BatchMatcher(params)
+    tids = [bm.add_target(t) for t in targets]
+    for ti, src, guess in pairs:
+        bm.add_pair(tids[ti], src, guess)
+    res = bm.align(fit)
+    res["pair_id"] = np.arange(len(pairs))
+    return res
+
+
+def _params(method, eps=0.01):
+    from mrg_slam_amd.registration import default_params
+
+    p = default_params(method)
+    p.transformation_epsilon, p.maximum_iterations = eps, 64
+    return p
+
+
+@pytest.mark.parametrize("members", [1, 2, 3, 4])
+def test_node_records_equal_one_batch(members):
+    from mrg_slam_amd import NodeMatcher
+    from mrg_slam_amd._lib import NDT_HIP
+
+    targets, pairs = _workload()
+    want = _one_batch(_params(NDT_HIP), targets, pairs)
+    node = NodeMatcher([0] * members, _params(NDT_HIP))
+    assert node.n_members == members
+    for rep in range(2):  # the second call reuses the members' workspaces
+        node.clear()
+        tids = [node.add_target(t) for t in targets]
+        for ti, src, guess in pairs:
+            node.add_pair(tids[ti], src, guess)
+        got = node.align(float("inf"))
+        assert got.tobytes() == want.tobytes()
+    blocks = [node.shard(m) for m in range(members)]
+    assert blocks[0][0] == 0 and sum(b[1] for b in blocks) == len(pairs) and max(b[1] for b in blocks) - min(b[1] for b in blocks) <= 1
+    assert all(blocks[m][0] + blocks[m][1] == blocks[m + 1][0] for m in range(members - 1))
+    assert node.last_gather() == "host"  # members share a card: RCCL refuses duplicate devices
+
+
+@pytest.mark.parametrize("method", ["GICP_HIP", "SMALL_GICP_HIP", "VGICP_HIP", "PCL_NDT_HIP"])
+def test_node_serves_every_batch_method(method):
+    from mrg_slam_amd import NodeMatcher, _lib
+
+    targets, pairs = _workload(n_targets=2, n_pairs=5, seed=8)
+    prm = _params(getattr(_lib, method), eps=1e-4 if method == "PCL_NDT_HIP" else 0.01)
+    want = _one_batch(prm, targets, pairs)
+    node = NodeMatcher([0, 0], prm)
+    tids = [node.add_target(t) for t in targets]
+    for ti, src, guess in pairs:
+        node.add_pair(tids[ti], src, guess)
+    assert node.align(float("inf")).tobytes() == want.tobytes()
+
+
+def test_keyed_clouds_stay_resident_and_may_be_named_without_data():
+    from mrg_slam_amd import NodeMatcher
+    from mrg_slam_amd._lib import NDT_HIP
+
+    targets, pairs = _workload(n_targets=2, n_pairs=7, seed=3)
+    want = _one_batch(_params(NDT_HIP), targets, pairs)
+    node = NodeMatcher([0, 0, 0], _params(NDT_HIP))
+    for rep in range(3):
+        node.clear()
+        tids = [node.add_target(t if rep < 2 else None, key=1000 + k, n_points=len(t)) for k, t in enumerate(targets)]
+        for k, (ti, src, guess) in enumerate(pairs):
+            # first call: clouds handed over; later calls: the same list names them by key only (same blocks -> same members hold them)
+            node.add_pair(tids[ti], src if rep == 0 else None, guess, key=50 + k, n_points=len(src))
+        got = node.align(float("inf"))
+        assert got.tobytes() == want.tobytes(), rep
+    assert node.store_bytes() >= sum(len(p[1]) for p in pairs) * 16
+    node.forget(0)
+    assert node.store_bytes() == 0
+    node.clear()
+    t = node.add_target(None, key=1000, n_points=len(targets[0]))  # forgotten: naming it without data is now an error of the member that needs it
+    node.add_pair(t, pairs[0][1], pairs[0][2])
+    from mrg_slam_amd import MrgfeError
+
+    with pytest.raises(MrgfeError, match="member 0"):
+        node.align()
+
+
+def test_a_failing_member_returns_an_error_and_the_node_stays_usable():
+    from mrg_slam_amd import MrgfeError, NodeMatcher
+    from mrg_slam_amd._lib import NDT_HIP
+
+    targets, pairs = _workload(n_targets=2, n_pairs=6, seed=4)
+    want = _one_batch(_params(NDT_HIP), targets, pairs)
+    node = NodeMatcher([0, 0, 0], _params(NDT_HIP))
+
+    def declare():
+        node.clear()
+        tids = [node.add_target(t) for t in targets]
+        for ti, src, guess in pairs:
+            node.add_pair(tids[ti], src, guess)
+
+    declare()
+    node.fail_member_once(1)
+    with pytest.raises(MrgfeError, match=r"member 1 \(device 0\)"):
+        node.align(float("inf"))
+    declare()
+    assert node.align(float("inf")).tobytes() == want.tobytes()
+    # bad arguments are error codes, not crashes
+    with pytest.raises(MrgfeError):
+        node.add_pair(99, pairs[0][1], pairs[0][2])
+    with pytest.raises(MrgfeError):
+        NodeMatcher([], _params(NDT_HIP))
+    with pytest.raises(MrgfeError):
+        NodeMatcher([12345], _params(NDT_HIP))  # no such device
+    # an empty list aligns to nothing
+    node.clear()
+    assert len(node.align()) == 0
+
+
+def test_select_best_is_the_references_sequential_rule():
+    from mrg_slam_amd import NodeMatcher, loop_closure
+    from mrg_slam_amd.registration import RESULT_DTYPE
+
+    rng = np.random.default_rng(0)
+    rec = np.zeros(40, dtype=RESULT_DTYPE)
+    rec["fitness"] = rng.choice([0.1, 0.2, 0.2, 0.5, np.finfo(np.float64).max, np.inf, np.nan], 40)
+    rec["converged"] = rng.random(40) < 0.7
+    group_first = [0, 7, 7, 19, 40]  # an empty group among them
+    got = NodeMatcher.select_best(rec, group_first)
+    for g in range(4):
+        assert got[g] == loop_closure.select_best(rec[group_first[g]:group_first[g + 1]]) or (got[g][0] is None and loop_closure.select_best(rec[group_first[g]:group_first[g + 1]])[0] is None)
+
+
+def test_rccl_gather_with_one_member(monkeypatch):
+    """the RCCL path (dlopen, ncclCommInitAll, grouped ncclAllGather, unpacking by pair id) on the one device of the box"""
+    from mrg_slam_amd import NodeMatcher
+    from mrg_slam_amd._lib import NDT_HIP
+
+    monkeypatch.setenv("MRGFE_NODE_GATHER", "rccl")
+    targets, pairs = _workload(n_targets=2, n_pairs=5, seed=6)
+    want = _one_batch(_params(NDT_HIP), targets, pairs)
+    node = NodeMatcher([0], _params(NDT_HIP))
+    tids = [node.add_target(t) for t in targets]
+    for ti, src, guess in pairs:
+        node.add_pair(tids[ti], src, guess)
+    got = node.align(float("inf"))
+    assert node.last_gather() == "rccl"
+    assert got.tobytes() == want.tobytes()
