@@ -478,6 +478,7 @@ int mrgfe_node_forget(mrgfe_node* node, uint64_t cloud_key)
                 else ++it;
             }
         }
+        MRGFE_TRY(mrgfe_batch_clear(m->batch));  // the member's last block still references its clouds; the node's own list is re-declared per call anyway
         MRGFE_TRY(mrgfe_batch_forget(m->batch, cloud_key));
     }
     return MRGFE_OK;
