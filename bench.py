@@ -395,6 +395,70 @@ def run_pcl_ndt(ctx, scans, dev, pairs, lib, args):
     return out
 
 
+def run_inproc(args, loop_raw, loop_pairs):
+    """`--mode shard --inproc --gpus N`: BASELINE config[3] through mrgfe_node_* (csrc/node.cpp) — ONE process, one member (context + batch + host
+    thread) per GPU, contiguous blocks of the keyframe-ordered pair list, the 384-byte records gathered by one ncclAllGather between distinct devices
+    (host memory when members share a card: a one-GPU box rehearses N members on device 0), the best-candidate rule replayed on the gathered records
+    (mrgfe_node_select_best).  What the reference's single host process per robot can call.  Prints the same record digest as the
+    one-rank `--mode shard` run."""
+    import hashlib
+
+    import torch  # noqa: F401  (before libmrgfe)
+
+    from mrg_slam_amd import NodeMatcher, distance_filter
+    from mrg_slam_amd._lib import NDT_HIP, SEARCH
+    from mrg_slam_amd.registration import default_params
+
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    devices = [g % ndev for g in range(args.gpus)]
+    prm = default_params(NDT_HIP)
+    prm.transformation_epsilon, prm.maximum_iterations, prm.resolution, prm.nn_search_method, prm.num_threads = args.eps, 64, 1.0, SEARCH["DIRECT7"], 8
+    l_host = [distance_filter(s, 0.1, 35.0) for s in loop_raw]
+    node = NodeMatcher(devices, prm)
+    group_first = [0] + [i for i in range(1, len(loop_pairs)) if loop_pairs[i][0] != loop_pairs[i - 1][0]] + [len(loop_pairs)]
+
+    def step(first=False):
+        node.clear()
+        tid = {}
+        for a, b, guess, _ in loop_pairs:
+            if a not in tid:  # registration_->setInputTarget(new_keyframe->cloud), once per new keyframe (loop_detector.cpp:104)
+                tid[a] = node.add_target(l_host[a] if first else None, key=100000 + a, n_points=len(l_host[a]))
+            node.add_pair(tid[a], l_host[b] if first else None, guess, key=1 + b, n_points=len(l_host[b]))
+        res = node.align(float("inf"))
+        return res, NodeMatcher.select_best(res, group_first)
+
+    step(first=True)  # the clouds go up once and stay resident on the members that use them (keys): inputs in HBM when the timed region starts
+    for _ in range(args.warmup):
+        step()
+    t0 = time.perf_counter()
+    step_ms = []
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        res, best = step()
+        step_ms.append(1e3 * (time.perf_counter() - ts))
+    elapsed = time.perf_counter() - t0
+    digest = hashlib.sha256(res["T"].tobytes() + res["fitness"].tobytes() + res["converged"].tobytes()).hexdigest()[:16]
+    in_digest = hashlib.sha256(b"".join(np.ascontiguousarray(c).tobytes() for c in l_host)).hexdigest()[:16]
+    err = [float(np.linalg.norm(np.asarray(res[i]["T"]).reshape(4, 4).T[:3, 3] - loop_pairs[i][3][:3, 3])) for i in range(len(loop_pairs))]
+    print(f"[bench inproc] per-step ms: " + " ".join(f"{v:.2f}" for v in step_ms), file=sys.stderr)
+    print(json.dumps({
+        "metric": "scan-pair alignments/sec (NDT, ~120k pts, 1.0 m voxel) at 1/2/4/8 MI355X; HBM GB/s achieved", "value": len(loop_pairs) * args.steps / elapsed,
+        "unit": "alignments/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32 per-pair terms, f64 accumulation", "data": "synthetic",
+        "config": {"workload": f"BASELINE config[3] through mrgfe_node_* in ONE process: {len(loop_pairs)} loop-closure candidate pairs over {len(l_host)} keyframes, "
+                               f"{args.gpus} members on devices {devices}, contiguous blocks, NDT_HIP DIRECT7 res 1.0 eps {args.eps}, getFitnessScore(inf), "
+                               "keyed clouds resident in HBM, record gather + best-candidate replay inside the step",
+                   "pairs_per_step": len(loop_pairs), "members": args.gpus, "devices": devices, "record_gather": node.last_gather(),
+                   "blocks": [node.shard(m) for m in range(args.gpus)]},
+        "records_sha256_16": digest, "inputs_sha256_16": in_digest, "converged": int(res["converged"].sum()),
+        "loops_found": int(sum(b is not None for b, _ in best)), "median_translation_error_vs_truth_m": float(np.median(err)),
+        "mean_points_per_scan": float(np.mean([len(c) for c in l_host])),
+        "roofline": None, "cpu_baseline": None,
+        "note": "side mode (never the driver's line): the node path behind the C ABI; compare records_sha256_16 with `--mode shard` on one rank"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -411,6 +475,8 @@ def main():
     ap.add_argument("--shard-steps", type=int, default=3, help="steps of the config[3] side measurement of a --mode weak run (0 disables)")
     ap.add_argument("--shard-of", type=int, default=0, help="--mode shard on ONE GPU: run only rank 0's shard of an N-rank job (no process group): what each GPU of an "
                                                            "N-GPU node would do per step, for projecting the strong scaling where N GPUs are not at hand")
+    ap.add_argument("--inproc", action="store_true", help="--mode shard through mrgfe_node_* (csrc/node.cpp): ONE process, --gpus members (on distinct devices where the box has "
+                                                          "them, sharing device 0 otherwise), no process group; prints the record digest of the one-rank run")
     ap.add_argument("--prepare-only", action="store_true", help="generate (and cache) the synthetic scans, then exit without touching the GPU")
     ap.add_argument("--parity-pairs", type=int, default=0, help="pairs of the step checked against the CPU oracle (0: all of them; the CPU TIMING uses --cpu-pairs)")
     ap.add_argument("--no-shard-parity", action="store_true", help="skip the 256-pair oracle loop of the config[3] leg (parity_vs_oracle of config3_shard)")
@@ -422,6 +488,11 @@ def main():
     if args.distinct <= 0:
         args.distinct = args.batch
 
+    if args.inproc:
+        if args.mode != "shard":
+            raise SystemExit("--inproc drives config[3]: use it with --mode shard")
+        loop_raw, loop_pairs = make_loop_workload()
+        return run_inproc(args, loop_raw, loop_pairs)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 

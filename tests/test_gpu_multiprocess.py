@@ -113,3 +113,11 @@ def test_bench_shard_mode_two_gloo_ranks_print_the_one_rank_digest(tmp_path):
     assert s1["inputs_sha256_16"] == s2["inputs_sha256_16"] and s1["raw_inputs_as_in_the_build_container"] is True
     assert s1["records_sha256_16"] == s2["records_sha256_16"]
     assert [p["rank"] for p in s2["per_rank_phases_ms"]] == [0, 1] and all(p["alignment_rounds"] > 0 for p in s2["per_rank_phases_ms"])
+    # the same 256 pairs through mrgfe_node_* (csrc/node.cpp): ONE process, three members sharing the card (blocks of 86 / 85 / 85), records gathered
+    # behind the C ABI, best candidates from mrgfe_node_select_best — the one-rank digest again
+    three = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "shard", "--inproc", "--gpus", "3", "--steps", "2", "--warmup", "1"], env=env,
+                           capture_output=True, text=True, timeout=900)
+    assert three.returncode == 0, three.stderr[-3000:]
+    l3 = json.loads([ln for ln in three.stdout.splitlines() if ln.startswith("{")][-1])
+    assert l3["n_gpus"] == 3 and l3["config"]["blocks"] == [[0, 86], [86, 85], [171, 85]] and l3["config"]["record_gather"] == "host"
+    assert l3["inputs_sha256_16"] == s1["inputs_sha256_16"] and l3["records_sha256_16"] == s1["records_sha256_16"]
