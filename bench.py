@@ -477,6 +477,7 @@ def main():
                                                            "N-GPU node would do per step, for projecting the strong scaling where N GPUs are not at hand")
     ap.add_argument("--inproc", action="store_true", help="--mode shard through mrgfe_node_* (csrc/node.cpp): ONE process, --gpus members (on distinct devices where the box has "
                                                           "them, sharing device 0 otherwise), no process group; prints the record digest of the one-rank run")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight in the timed region (mrgfe_batch_align_async / _wait on as many contexts); 1: one step at a time")
     ap.add_argument("--prepare-only", action="store_true", help="generate (and cache) the synthetic scans, then exit without touching the GPU")
     ap.add_argument("--parity-pairs", type=int, default=0, help="pairs of the step checked against the CPU oracle (0: all of them; the CPU TIMING uses --cpu-pairs)")
     ap.add_argument("--no-shard-parity", action="store_true", help="skip the 256-pair oracle loop of the config[3] leg (parity_vs_oracle of config3_shard)")
@@ -579,9 +580,13 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def timed(step_fn, steps, warmup):
+    def timed(step_fn, steps, warmup, drain_fn=None):
+        """drain_fn: steps that are submitted and collected later (--in-flight > 1) — whatever is still in flight is collected INSIDE the timed
+        region, before the closing synchronisation: K steps are submitted and K steps complete between the two clock reads"""
         for _ in range(warmup):
             step_fn()
+        if drain_fn and warmup:
+            drain_fn()
         sync()
         # a full (generation 2) collection walks every object `import torch` created: ~40 ms, once, at an arbitrary step.
         # Collect now and move the survivors to the permanent generation so the timed steps are not interrupted by it.
@@ -591,8 +596,12 @@ def main():
         step_ms, last = [], None
         for _ in range(steps):
             ts = time.perf_counter()
-            last = step_fn()
+            r = step_fn()
+            last = r if r is not None else last
             step_ms.append(1e3 * (time.perf_counter() - ts))
+        if drain_fn:
+            r = drain_fn()
+            last = r if r is not None else last
         sync()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -835,30 +844,82 @@ def main():
     add_args = ([dev[p[0]].data_ptr() for p in pairs], [len(scans[p[0]]) for p in pairs], np.arange(args.batch, dtype=np.int32),
                 [dev[p[1]].data_ptr() for p in pairs], [len(scans[p[1]]) for p in pairs], np.stack([p[2] for p in pairs]))
 
-    def step():
-        bm.clear()
-        bm.add_device(*add_args)
-        res = bm.align()
+    def account(b, res):
         if world > 1:  # pose / Hessian record gather over RCCL
             res["pair_id"] = np.arange(args.batch, dtype=np.int32)
             all_gather_records(res, args.batch)
         if counters["on"]:
             for m in range(3):
-                per_mode[m] += bm.kernel_stats(m)
-            launched[:] += np.array(bm.pair_counts())
+                per_mode[m] += b.kernel_stats(m)
+            launched[:] += np.array(b.pair_counts())
             for m in range(3):
-                points_by_kind[m] += bm.pair_counts(m)[0]
-            lm, lp = bm.largest_launch()
+                points_by_kind[m] += b.pair_counts(m)[0]
+            lm, lp = b.largest_launch()
             if lm > largest["ms"]:
                 largest["ms"], largest["pairs"] = lm, lp
             counters["evals"] += int(res["evaluations"].sum())
             counters["iters"] += int(res["iterations"].sum())
         return res
 
+    def step():  # one step at a time: queue the batch, align it, take its records
+        bm.clear()
+        bm.add_device(*add_args)
+        return account(bm, bm.align())
+
+    # --in-flight N > 1 (default 2): N batches on N contexts, mrgfe_batch_align_async / mrgfe_batch_wait (a worker thread per batch behind the C
+    # ABI).  A step then SUBMITS its batch and collects the records of the batch submitted N steps earlier: the target build and the straggler
+    # rounds of one batch are filled by the derivative launches of the other.  Same pairs, same records.
+    n_fl = max(1, args.in_flight)
+    bms = [bm] + [BatchMatcher(prm, Context(local_rank)) for _ in range(n_fl - 1)]
+    pending = [False] * n_fl
+    slot = {"k": 0}
+
+    def step_pipelined():
+        k = slot["k"] % n_fl
+        slot["k"] += 1
+        b, res = bms[k], None
+        if pending[k]:
+            res = account(b, b.wait())
+            pending[k] = False
+        b.clear()
+        b.add_device(*add_args)
+        b.align_async()
+        pending[k] = True
+        return res
+
+    def drain():
+        last = None
+        for j in range(n_fl):  # in submission order
+            k = (slot["k"] + j) % n_fl
+            if pending[k]:
+                last = account(bms[k], bms[k].wait())
+                pending[k] = False
+        return last
+
     for _ in range(args.warmup):
         step()
+    seq = None
+    if n_fl > 1:
+        # the same K steps one at a time first (untimed for `value`; reported beside it): elapsed time, and the derivative kernel's HIP-event
+        # time WITHOUT another batch's kernels on the chip — in the pipelined region every launch shares the chip with the other batch's
+        counters["on"] = True
+        e1, sm1, _ = timed(step, args.steps, 0)
+        counters["on"] = False
+        seq = {"value": world * args.batch * args.steps / e1, "unit": "alignments/s", "ms_per_step": 1e3 * e1 / args.steps, "steps": args.steps,
+               "derivative_kernel_ms": float(per_mode[0][0]), "derivative_launches": int(per_mode[0][1]), "alg_bytes": float(per_mode[:, 2].sum()),
+               "avg_launch_ms": float(per_mode[0][0] / per_mode[0][1]) if per_mode[0][1] else None,
+               "frac": float((per_mode[:, 2].sum() / 1e9) / (per_mode[0][0] / 1e3) / HBM_PEAK_GBPS) if per_mode[0][0] > 0 else None,
+               "note": "one step at a time on one context (the timed region of rounds 1-4): queue, align, records, then the next step"}
+        per_mode[:] = 0
+        launched[:] = 0
+        points_by_kind[:] = 0
+        largest["ms"], largest["pairs"] = 0.0, [0, 0, 0]
+        counters["evals"] = counters["iters"] = 0
+        for _ in range(2):
+            step_pipelined()
+        drain()
     counters["on"] = True
-    elapsed, step_ms, res = timed(step, args.steps, 0)
+    elapsed, step_ms, res = timed(step_pipelined if n_fl > 1 else step, args.steps, 0, drain if n_fl > 1 else None)
     counters["on"] = False
     evals, iters = counters["evals"], counters["iters"]
     print(f"[bench rank {rank}] per-step ms: " + " ".join(f"{v:.2f}" for v in step_ms), file=sys.stderr)
@@ -1154,7 +1215,10 @@ def main():
                         f"{args.batch} pairs per GPU per step = {min(args.distinct, args.batch)} distinct scan pairs ({hbm_input_bytes / 1e6:.0f} MB of clouds per step), "
                         f"{len(warm_ix)} warm + {len(cold_ix)} cold (identity) guesses, mean {n_pts:.0f} pts/scan "
                         f"({'distance filter 0.1-35 m' if args.prefilter == 'distance' else 'distance + 0.1 m voxel + radius outlier prefilter'}), "
-                        f"setInputTarget + setInputSource + align per pair, inputs resident in HBM",
+                        f"setInputTarget + setInputSource + align per pair, inputs resident in HBM"
+                        + (f"; {n_fl} steps in flight per GPU (mrgfe_batch_align_async on {n_fl} contexts: a step submits its batch and collects the one submitted "
+                           f"{n_fl} steps earlier; every submitted step completes inside the timed region)" if n_fl > 1 else ""),
+            "steps_in_flight": n_fl,
             "pairs_per_gpu_per_step": args.batch,
             "distinct_pairs": min(args.distinct, args.batch),
             "points_per_scan": n_pts,
@@ -1187,6 +1251,8 @@ def main():
         "single_pair_latency_ms": single_ms,
         "median_translation_error_vs_truth_m": float(np.median(true_err)),
         "input_generation_s": t_gen,
+        "steps_in_flight": n_fl,
+        "value_one_step_at_a_time": seq,
         "value_host_pointers": extras.get("value_host_pointers"),
         "gpu_split_ms_per_step": extras.get("gpu_split_ms_per_step"),
         "pipeline_shape": extras.get("pipeline_shape"),

@@ -365,6 +365,14 @@ int  mrgfe_batch_set_guess(mrgfe_batch* b, int pair_index, const float guess[16]
 /* build every target grid (setInputTarget), then align every pair; fitness_max_range < 0 skips getFitnessScore */
 int  mrgfe_batch_build_targets(mrgfe_batch* b);
 int  mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_result* results /* n_pairs */);
+/* The same align on a worker thread of the batch's own: returns as soon as the worker holds the batch's context, mrgfe_batch_wait returns the align's
+ * status (and sets mrgfe_last_error() in the waiting thread).  `results` must stay valid until then; every other call on this batch waits for the
+ * align to finish.  A caller that keeps TWO batches on two contexts in flight — queue batch k + 1 while batch k aligns — fills one batch's target
+ * build and straggler rounds with the other's derivative launches: config[1], 256 pairs per batch, 10.2 -> 9.3 ms per batch on one MI355X, same
+ * records (a pair's record does not depend on what else runs on the chip).  One align in flight per batch: a second _async before _wait is
+ * MRGFE_ERR_STATE. */
+int  mrgfe_batch_align_async(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_result* results /* n_pairs */);
+int  mrgfe_batch_wait(mrgfe_batch* b);
 int  mrgfe_batch_num_pairs(const mrgfe_batch* b);
 /* Accounting of the NDT derivative kernel in the last mrgfe_batch_align / mrgfe_reg_align, per kind of evaluation
  * `mode` (0: score+gradient+Hessian, 1: score+gradient, 2: f64 Hessian; -1: all): device time in ms from HIP events recorded

@@ -171,6 +171,8 @@ SIGNATURES = {
     "mrgfe_batch_set_guess": (C.c_int, [_vp, C.c_int, _fp]),
     "mrgfe_batch_build_targets": (C.c_int, [_vp]),
     "mrgfe_batch_align": (C.c_int, [_vp, C.c_double, C.POINTER(PairResult)]),
+    "mrgfe_batch_align_async": (C.c_int, [_vp, C.c_double, C.POINTER(PairResult)]),
+    "mrgfe_batch_wait": (C.c_int, [_vp]),
     "mrgfe_batch_num_pairs": (C.c_int, [_vp]),
     "mrgfe_batch_fitness_stats": (C.c_int, [_vp, _dp]),
     "mrgfe_batch_kernel_stats": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_int64), _dp]),

@@ -2,6 +2,7 @@
 // conversion, and dispatch into the engines.  Never throws; failures set the thread-local message.
 #include <atomic>
 #include <cfloat>
+#include <condition_variable>
 #include <chrono>
 #include <memory>
 #include <cmath>
@@ -112,6 +113,7 @@ struct mrgfe_batch {
     std::vector<GicpBatchPair> gicp_pairs;  // per-pair device buffers, kept between align calls
     std::vector<NnGrid> fit_grids;  // getFitnessScore grids, one per target; device buffers kept between align calls
     std::vector<std::unique_ptr<NnGridSet>> fit_sets;  // ... which are views into these when the grids were built a chunk of targets at a time
+    mrgfe_ctx* early_ctx = nullptr;         // lowest-priority context of the early fitness pass (mrgfe_batch_align)
     std::vector<mrgfe_ctx*> fit_ctxs;       // helper contexts (own stream and workspaces each): the grids are built on them by extra host
                                             // thread while the alignment rounds run on the batch's context
     // keyframe store (mrgfe_batch_add_pair_keyed): packed clouds and GICP covariances by caller-chosen key, resident across clears
@@ -130,6 +132,20 @@ struct mrgfe_batch {
     hipEvent_t uploads_done = nullptr;  // recorded on ctx->stream before helper streams read the batch's clouds (upload_cloud is stream-ordered only)
     uint64_t epoch = 1, tick = 0;
     size_t   store_cap = size_t(16384) << 20;
+    // mrgfe_batch_align_async / mrgfe_batch_wait: a worker thread of the batch's own runs mrgfe_batch_align while the caller queues the next batch
+    // on another object.  It takes the context lock BEFORE the async call returns, so every other call on this batch simply waits for the align.
+    struct Async {
+        std::thread th;
+        std::mutex  mu;
+        std::condition_variable cv;
+        int    state = 0;  // 0 idle, 1 posted, 2 running (context lock held), 3 finished and not yet waited for
+        bool   quit = false;
+        double fitness_max_range = -1.0;
+        mrgfe_pair_result* results = nullptr;
+        int    status = MRGFE_OK;
+        std::string error;
+    };
+    std::unique_ptr<Async> async;
 };
 
 // drop least recently used keyframes that the current batch does not reference until `need` more bytes fit
@@ -950,15 +966,103 @@ int mrgfe_batch_create(mrgfe_ctx* ctx, const mrgfe_reg_params* params, mrgfe_bat
     *out = b;
     return MRGFE_OK;
 }
+static void batch_async_main(mrgfe_batch* b)
+{
+    mrgfe_batch::Async& a = *b->async;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(a.mu);
+            a.cv.wait(lk, [&] { return a.state == 1 || a.quit; });
+            if (a.quit) return;
+        }
+        int st;
+        std::string err;
+        {
+            MRGFE_LOCK(b->ctx);
+            {
+                std::lock_guard<std::mutex> lk(a.mu);
+                a.state = 2;
+            }
+            a.cv.notify_all();
+            try {
+                st = mrgfe_batch_align(b, a.fitness_max_range, a.results);
+                if (st != MRGFE_OK) err = mrgfe_last_error();
+            } catch (const std::exception& e) {  // (a host container's bad_alloc: an error code for the waiter, never std::terminate)
+                st = MRGFE_ERR_INVALID;
+                err = std::string("mrgfe_batch_align_async: ") + e.what();
+            } catch (...) {
+                st = MRGFE_ERR_INVALID;
+                err = "mrgfe_batch_align_async: unknown exception";
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(a.mu);
+            a.status = st;
+            a.error = err;
+            a.state = 3;
+        }
+        a.cv.notify_all();
+    }
+}
+
+int mrgfe_batch_align_async(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_result* results)
+{
+    if (!b || !results) { set_error("mrgfe_batch_align_async: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (!b->async) {
+        b->async.reset(new (std::nothrow) mrgfe_batch::Async());
+        if (!b->async) { set_error("out of host memory"); return MRGFE_ERR_INVALID; }
+        try {
+            b->async->th = std::thread(batch_async_main, b);
+        } catch (const std::exception& e) {
+            b->async.reset();
+            set_error("mrgfe_batch_align_async: %s", e.what());
+            return MRGFE_ERR_INVALID;
+        }
+    }
+    mrgfe_batch::Async& a = *b->async;
+    std::unique_lock<std::mutex> lk(a.mu);
+    if (a.state != 0) { set_error("mrgfe_batch_align_async: an align of this batch is %s: call mrgfe_batch_wait first", a.state == 3 ? "finished and not yet waited for" : "in flight"); return MRGFE_ERR_STATE; }
+    a.fitness_max_range = fitness_max_range;
+    a.results = results;
+    a.state = 1;
+    a.cv.notify_all();
+    a.cv.wait(lk, [&] { return a.state >= 2; });  // the worker holds the context lock now: later calls on this batch queue up behind the align
+    return MRGFE_OK;
+}
+
+int mrgfe_batch_wait(mrgfe_batch* b)
+{
+    if (!b) { set_error("mrgfe_batch_wait: NULL batch"); return MRGFE_ERR_INVALID; }
+    if (!b->async) { set_error("mrgfe_batch_wait: no asynchronous align was started"); return MRGFE_ERR_STATE; }
+    mrgfe_batch::Async& a = *b->async;
+    std::unique_lock<std::mutex> lk(a.mu);
+    if (a.state == 0) { set_error("mrgfe_batch_wait: no asynchronous align was started"); return MRGFE_ERR_STATE; }
+    a.cv.wait(lk, [&] { return a.state == 3; });
+    a.state = 0;
+    if (a.status != MRGFE_OK) set_error("%s", a.error.c_str());
+    return a.status;
+}
+
 void mrgfe_batch_destroy(mrgfe_batch* b)
 {
     if (!b) return;
+    if (b->async) {  // before the context lock below: a running align holds it
+        mrgfe_batch::Async& a = *b->async;
+        {
+            std::unique_lock<std::mutex> lk(a.mu);
+            a.cv.wait(lk, [&] { return a.state == 0 || a.state == 3; });
+            a.quit = true;
+        }
+        a.cv.notify_all();
+        if (a.th.joinable()) a.th.join();
+    }
     {
         MRGFE_LOCK(b->ctx);
         (void)b->ctx->bind();
         for (auto& g : b->fit_grids) g.release();
         for (auto& gs : b->fit_sets) gs->release();
         for (mrgfe_ctx* fc : b->fit_ctxs) mrgfe_ctx_destroy(fc);
+        if (b->early_ctx) mrgfe_ctx_destroy(b->early_ctx);
         if (b->uploads_done) (void)hipEventDestroy(b->uploads_done);
         if (b->port) b->port->buf.release();
         for (auto& gp : b->gicp_pairs) { gp.cov.release(); gp.corr.release(); gp.mahal.release(); }
@@ -1190,12 +1294,16 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
         auto fail = [&](int st, const std::string& why) { std::lock_guard<std::mutex> g(build_mu); if (build_status == MRGFE_OK) { build_status = st; build_error = why; } };
         // Everything that can fail with an early return happens BEFORE the first helper thread exists: a joinable std::thread
         // destroyed by a return would end the process (the SLAM node) instead of reporting the error.
-        // (early fitness waves, measured on config[3] while the grids were built one by one and outlasted the rounds: 256 pairs 30.8 -> 29.7 ms
-        // per step, 128 pairs no change, 64 and 32 pairs slower.  With the grids built a chunk at a time (NnGridSet) they are complete a few ms
-        // into the rounds, a step is the sum of its kernel times, and the waves only add their fixed costs: 27.8 ms without them, 28.7 ms with.
-        // Off unless MRGFE_EARLY_FIT_MIN_PAIRS asks for them.)
-        int early_min_pairs = 1 << 30;
-        if (const char* env = std::getenv("MRGFE_EARLY_FIT_MIN_PAIRS")) early_min_pairs = std::max(8, std::atoi(env));
+        // Early fitness pass.  Round 4 ran a wave whenever a sixth of the pairs had finished: the chip is still full of derivative work then, and
+        // the waves only added their fixed costs (config[3], 256 pairs: 27.8 ms without them, 28.7 ms with).  What IS idle is the tail: a few
+        // stragglers line-searching through tens of small rounds (one pair: ~12 us of derivative work on a chip that holds twenty times that).
+        // So ONE pass, started when the pairs still running drop to an eighth of the batch (MRGFE_EARLY_FIT_ACTIVE_DIV), scores every finished
+        // pair on a helper context beside the stragglers' rounds; the stragglers are scored behind the last round as before.  The count comes
+        // from the round plans the device already publishes (no extra kernel until the one snapshot that carries the final transformations).
+        int early_min_pairs = 8;
+        if (const char* env = std::getenv("MRGFE_EARLY_FIT_MIN_PAIRS")) early_min_pairs = std::max(2, std::atoi(env));
+        int early_div = 8;
+        if (const char* env = std::getenv("MRGFE_EARLY_FIT_ACTIVE_DIV")) early_div = std::max(1, std::atoi(env));
         const bool early_on = overlap && P >= early_min_pairs && std::getenv("MRGFE_NO_EARLY_FIT") == nullptr;
         if (!b->port) b->port.reset(new NdtSnapshotPort());
         NdtSnapshotPort& port = *b->port;  // (its pinned buffer is kept between calls)
@@ -1218,11 +1326,15 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
             const size_t n_chunks = (todo.size() + chunk - 1) / chunk;
             n_builders = std::min(n_builders, n_chunks);
             while (b->fit_sets.size() < n_chunks) b->fit_sets.emplace_back(new NnGridSet());
-            while (b->fit_ctxs.size() < n_builders + (early_on ? 1 : 0)) {  // with early passes on, one more context for them (the last)
+            while (b->fit_ctxs.size() < n_builders) {
                 mrgfe_ctx* fc = nullptr;
                 if (ctx_create_like(b->ctx, &fc) != MRGFE_OK) return MRGFE_ERR_HIP;  // (same compute-unit mask as the batch's own context)
                 b->fit_ctxs.push_back(fc);
             }
+            // the early fitness pass runs on a context of its own whose streams have the device's LOWEST priority: the stragglers' small launches
+            // on the batch's stream are dispatched ahead of the pass's workgroups as slots free up (at equal priority the tail's rounds took twice as
+            // long beside the pass: what the overlap gained, the rounds lost)
+            if (early_on && !b->early_ctx && ctx_create_like(b->ctx, &b->early_ctx, -1) != MRGFE_OK) return MRGFE_ERR_HIP;
             // the target clouds reach the device by asynchronous copies (and gathers) on the batch's stream: the helper streams
             // must not read them before those have finished
             MRGFE_TRY(b->ctx->bind());
@@ -1266,51 +1378,42 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
         b->fit_total = FitStats();
         if (early_on) {
             port.head()->tag = 0;
-            early = std::thread([&, P] {
-                mrgfe_ctx* fc = b->fit_ctxs.back();
+            port.n_active.store(static_cast<uint32_t>(P), std::memory_order_release);
+            early = std::thread([&, P, early_div] {
+                mrgfe_ctx* fc = b->early_ctx;
                 std::lock_guard<std::recursive_mutex> lock(fc->mu);
                 if (fc->bind() != MRGFE_OK) { fail(MRGFE_ERR_HIP, mrgfe_last_error()); return; }
-                const int min_wave = std::max(4, P / 6);
+                const uint32_t threshold = static_cast<uint32_t>(std::max(1, P / early_div));
+                // wait for the tail (or the end of the alignment)
+                while (!port.finished.load(std::memory_order_acquire) && port.n_active.load(std::memory_order_acquire) > threshold) std::this_thread::sleep_for(std::chrono::microseconds(20));
+                if (port.finished.load(std::memory_order_acquire)) return;
+                port.want.store(1, std::memory_order_release);
+                while (port.issued.load(std::memory_order_acquire) == 0 && !port.finished.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(5));
+                const uint32_t tag = port.issued.load(std::memory_order_acquire);
+                if (tag == 0) return;  // finished without a snapshot
+                volatile NdtSnapshotHead* hd = port.head();
+                while (__atomic_load_n(&hd->tag, __ATOMIC_ACQUIRE) != tag) {
+                    if (port.finished.load(std::memory_order_acquire) && __atomic_load_n(&hd->tag, __ATOMIC_ACQUIRE) != tag) return;  // align_all failed before the kernel ran
+                    std::this_thread::sleep_for(std::chrono::microseconds(5));
+                }
                 std::vector<NnFitnessJob> jobs;
                 std::vector<int>          job_pair;
-                std::vector<double>       fit;
-                uint32_t seen_tag = 0;
-                while (!port.finished.load(std::memory_order_acquire)) {
-                    port.want.store(1, std::memory_order_release);
-                    // wait for the snapshot (or the end of the alignment)
-                    while (port.issued.load(std::memory_order_acquire) == seen_tag && !port.finished.load(std::memory_order_acquire)) std::this_thread::yield();
-                    const uint32_t tag = port.issued.load(std::memory_order_acquire);
-                    if (tag == seen_tag) break;  // finished without another snapshot
-                    volatile NdtSnapshotHead* hd = port.head();
-                    bool alive = true;
-                    while (__atomic_load_n(&hd->tag, __ATOMIC_ACQUIRE) != tag) {
-                        if (port.finished.load(std::memory_order_acquire) && __atomic_load_n(&hd->tag, __ATOMIC_ACQUIRE) != tag) { alive = false; break; }  // align_all failed before the kernel ran
-                        std::this_thread::yield();
-                    }
-                    if (!alive) break;
-                    seen_tag = tag;
-                    jobs.clear();
-                    job_pair.clear();
-                    const NdtSnapshotRec* recs = port.recs();
-                    for (int i = 0; i < P; ++i) {
-                        if (early_done[i] || !recs[i].done) continue;
-                        const NdtPairInfo& p = e.pair(i);
-                        if (e.target(p.target).n == 0 || p.n == 0 || !grid_ready[p.target].load(std::memory_order_acquire)) continue;
-                        float T[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
-                        std::memcpy(T, recs[i].T12, sizeof(recs[i].T12));
-                        jobs.push_back(b->fit_grids[p.target].make_fitness_job(p.d_src, p.n, T));
-                        job_pair.push_back(i);
-                    }
-                    if (static_cast<int>(jobs.size()) < min_wave) {  // not worth a launch yet
-                        std::this_thread::sleep_for(std::chrono::microseconds(150));
-                        continue;
-                    }
-                    fit.assign(jobs.size(), 0.0);
-                    const int st = nn_fitness_batch(fc, jobs.data(), jobs.size(), fitness_max_range, fit.data());
-                    if (st != MRGFE_OK) { fail(st, mrgfe_last_error()); return; }
-                    b->fit_total.add(fc->fit_stats);
-                    for (size_t j = 0; j < jobs.size(); ++j) { results[job_pair[j]].fitness = fit[j]; early_done[job_pair[j]] = 1; }
+                const NdtSnapshotRec* recs = port.recs();
+                for (int i = 0; i < P; ++i) {
+                    if (!recs[i].done) continue;
+                    const NdtPairInfo& p = e.pair(i);
+                    if (e.target(p.target).n == 0 || p.n == 0 || !grid_ready[p.target].load(std::memory_order_acquire)) continue;
+                    float T[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
+                    std::memcpy(T, recs[i].T12, sizeof(recs[i].T12));
+                    jobs.push_back(b->fit_grids[p.target].make_fitness_job(p.d_src, p.n, T));
+                    job_pair.push_back(i);
                 }
+                if (jobs.empty()) return;
+                std::vector<double> fit(jobs.size(), 0.0);
+                const int st = nn_fitness_batch(fc, jobs.data(), jobs.size(), fitness_max_range, fit.data());
+                if (st != MRGFE_OK) { fail(st, mrgfe_last_error()); return; }
+                b->fit_total.add(fc->fit_stats);
+                for (size_t j = 0; j < jobs.size(); ++j) { results[job_pair[j]].fitness = fit[j]; early_done[job_pair[j]] = 1; }
             });
         }
         const int align_status = e.align_all(early_on ? &port : nullptr);

@@ -283,19 +283,19 @@ extern "C" {
 const char* mrgfe_last_error(void) { return mrgfe::get_error(); }
 const char* mrgfe_version(void) { return "mrgfe 0.1 (gfx950)"; }
 
-static hipError_t create_stream(hipStream_t* st, bool high_priority)
+static hipError_t create_stream(hipStream_t* st, int priority)  // > 0: the device's highest stream priority, < 0: its lowest, 0: the default
 {
-    if (!high_priority) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    if (priority == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     int least = 0, greatest = 0;  // numerically lower = higher priority
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest);
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, priority > 0 ? greatest : least);
 }
 
 }  // extern "C"
 
 int mrgfe_ctx::make_stream(hipStream_t* st) const
 {
-    const hipError_t e = cu_mask.empty() ? hipStreamCreateWithFlags(st, hipStreamNonBlocking)
+    const hipError_t e = cu_mask.empty() ? create_stream(st, priority)
                                          : hipExtStreamCreateWithCUMask(st, static_cast<uint32_t>(cu_mask.size()), cu_mask.data());
     if (e != hipSuccess) { mrgfe::set_error("stream creation failed: %s", hipGetErrorString(e)); return MRGFE_ERR_HIP; }
     return MRGFE_OK;
@@ -343,7 +343,8 @@ static int ctx_create(int device_id, int high_priority, int reserve_cus, const m
         // (cu_count stays the device's: it enters the tiles-per-item of the derivative launches, i.e. the grouping of their partial sums — a context's
         // mask must not change a bit of any result)
     }
-    const bool stream_ok = c->cu_mask.empty() ? create_stream(&c->stream, high_priority != 0) == hipSuccess : c->make_stream(&c->stream) == MRGFE_OK;
+    c->priority = high_priority;
+    const bool stream_ok = c->make_stream(&c->stream) == MRGFE_OK;
     if (!stream_ok || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         mrgfe::set_error("failed to create HIP stream / events");
         delete c;
@@ -448,9 +449,9 @@ int mrgfe_ctx_fitness_stats(mrgfe_ctx* ctx, double out[11])
 }  // extern "C"
 
 namespace mrgfe {
-int ctx_create_like(const mrgfe_ctx* parent, mrgfe_ctx** out)
+int ctx_create_like(const mrgfe_ctx* parent, mrgfe_ctx** out, int priority)
 {
     if (!parent) { set_error("ctx_create_like: parent is NULL"); return MRGFE_ERR_INVALID; }
-    return ctx_create(parent->device, 0, 0, parent, out);
+    return ctx_create(parent->device, priority, 0, parent, out);
 }
 }  // namespace mrgfe

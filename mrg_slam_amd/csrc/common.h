@@ -118,6 +118,7 @@ struct mrgfe_ctx {
     bool         up_busy[2] = {false, false};
     int          up_next = 0;
     hipEvent_t   ev_fit[4] = {nullptr, nullptr, nullptr, nullptr};  // around the passes of nn_fitness_batch
+    int          priority = 0;                  // > 0: streams at the device's highest priority, < 0: at its lowest (throughput work beside latency-critical rounds)
     std::vector<uint32_t> cu_mask;              // non-empty: every stream of this context is confined to these compute units (mrgfe_ctx_create_reserving)
     int          make_stream(hipStream_t* st) const;  // a further stream of this context: same compute-unit mask
     hipStream_t  side = nullptr;                // second stream of nn_fitness_batch: the pyramid walk of the unseeded queries beside the sweep
@@ -147,6 +148,6 @@ namespace mrgfe {
 int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t layout, void* d_dst, int pin_slot = 0);
 int decode_layout(size_t layout, uint32_t* stride, uint32_t* xyz_off, int32_t* intensity_off);
 // a helper context of `parent` (builder threads of a batch, GICP lanes): same device, same compute-unit mask
-int ctx_create_like(const mrgfe_ctx* parent, mrgfe_ctx** out);
+int ctx_create_like(const mrgfe_ctx* parent, mrgfe_ctx** out, int priority = 0);  // priority: see mrgfe_ctx::priority
 
 }  // namespace mrgfe

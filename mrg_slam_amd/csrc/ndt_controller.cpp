@@ -16,6 +16,12 @@ static bool reuse_enabled()
     return on;
 }
 
+static bool newton_svd_only()
+{
+    static const bool on = [] { const char* e = std::getenv("MRGFE_NEWTON_SVD"); return e && e[0] == '1'; }();
+    return on;
+}
+
 void NdtController::euler_xyz(const float M[16], float out[3])
 {
     // Eigen 3.4 Matrix3f::eulerAngles(0, 1, 2)
@@ -42,6 +48,7 @@ void NdtController::start(const NdtParams& prm, const float guess[16], uint32_t 
     s_.reuse = reuse_enabled() ? 1 : 0;
     s_.split_first = (split_first && prm.formulation == 0) ? 1 : 0;
     s_.formulation = prm.formulation;
+    s_.svd_only = newton_svd_only() ? 1 : 0;
     s_.n_src = n_src;
     // pcl::Registration::align
     ctl::identity16(s_.final_); ctl::identity16(s_.transformation_); ctl::identity16(s_.previous_);

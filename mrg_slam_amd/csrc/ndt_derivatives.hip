@@ -32,6 +32,7 @@ namespace mrgfe {
 // (end of the point phase), pair phase — and in the item's epilogue, summed over all workgroups; MRGFE_PHASE=1 prints them after an alignment
 #ifdef NDT_PHASE_CLOCK
 __device__ unsigned long long g_phase[8];
+__device__ unsigned long long g_rphase[10];  // ndt_reduce_kernel<true>: sums | state in | resume | solves | trig + request | state out, solve count, workgroups
 #define NDT_CLOCK(var) long long var = 0; if (MODE == 0 && threadIdx.x == 0) var = wall_clock64()
 #define NDT_CLOCK_WAIT(var) if (MODE == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); NDT_CLOCK(var)
 #define NDT_CLOCK_ADD(slot, ticks) if (MODE == 0 && threadIdx.x == 0) atomicAdd(&g_phase[slot], static_cast<unsigned long long>(ticks))
@@ -883,6 +884,10 @@ __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __res
     const NdtPairDev pr = pairs[blockIdx.x];
     const NdtEvalDev& ev = evals[blockIdx.x];
     if (!ev.active) return;
+#ifdef NDT_PHASE_CLOCK
+    long long rc0 = 0, rc1 = 0, rc2 = 0, rc3 = 0, rc4 = 0, rc5 = 0, rc6 = 0, rsolves = 0;
+    if (CONTROL && threadIdx.x == 0) rc0 = wall_clock64();
+#endif
     const NdtPlanHead& head = *reinterpret_cast<const NdtPlanHead*>(plan);
     // items (= partial records) the derivative launch of this pair's kernel variant used
     const uint32_t per_item = 256u * head.ppt[ev.mode];
@@ -938,22 +943,42 @@ __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __res
     __shared__ NdtEvalDev s_eval;
     __shared__ ctl::SvdWaveScratch s_svd;
     __shared__ double s_negg[6], s_delta[6];
+#ifdef NDT_PHASE_CLOCK
+    if (threadIdx.x == 0) rc1 = wall_clock64();
+#endif
     const double* gs = reinterpret_cast<const double*>(states + blockIdx.x);
     for (int w = threadIdx.x; w < kWords; w += 256) s_state[w] = gs[w];
     __syncthreads();
+#ifdef NDT_PHASE_CLOCK
+    if (threadIdx.x == 0) rc2 = wall_clock64();
+#endif
     if (wave_id() == 0) {
         // lane 0 runs the state machine; the 6x6 SVD solves of its Newton steps run on the whole wavefront
         NdtCtlState& st = *reinterpret_cast<NdtCtlState*>(s_state);
         int next = 0;
         if (threadIdx.x == 0) next = ctl::resume(st, s_r);
         next = __shfl(next, 0, kWave);
+#ifdef NDT_PHASE_CLOCK
+        if (threadIdx.x == 0) rc3 = wall_clock64();
+#endif
         while (next == ctl::CTL_NEED_SOLVE) {
+#ifdef NDT_PHASE_CLOCK
+            ++rsolves;
+#endif
             if (threadIdx.x < 6) s_negg[threadIdx.x] = -st.g[threadIdx.x];
             ctl::svd_wave_sync();
-            ctl::svd_solve6_wave(st.H, s_negg, s_delta, s_svd);
+            // the LU fast path on lane 0 (ndt_ctl.h newton_solve6); a matrix it declines goes through the wavefront SVD
+            int solved = 0;
+            if (threadIdx.x == 0 && !st.svd_only) solved = ctl::lu_solve6(st.H, s_negg, s_delta) ? 1 : 0;
+            solved = __shfl(solved, 0, kWave);
+            if (!solved) ctl::svd_solve6_wave(st.H, s_negg, s_delta, s_svd);
+            else         ctl::svd_wave_sync();
             if (threadIdx.x == 0) next = ctl::after_solve(st, s_delta);
             next = __shfl(next, 0, kWave);
         }
+#ifdef NDT_PHASE_CLOCK
+        if (threadIdx.x == 0) rc4 = wall_clock64();
+#endif
         // the six double-precision sines / cosines of the next request's angle tables: one lane each instead of six in a row
         __shared__ double s_cs[6];
         if (threadIdx.x < 6 && !ctl::done(st)) s_cs[threadIdx.x] = ctl::angle_trig(st.req_p, threadIdx.x);
@@ -963,6 +988,9 @@ __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __res
             ctl::fill_eval_from(st, s_cs, s_eval);
         }
     }
+#ifdef NDT_PHASE_CLOCK
+    if (threadIdx.x == 0) rc5 = wall_clock64();
+#endif
     __syncthreads();
     double* gd = reinterpret_cast<double*>(states + blockIdx.x);
     for (int w = threadIdx.x; w < kWords; w += 256) gd[w] = s_state[w];
@@ -972,6 +1000,14 @@ __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __res
     double*       ge = reinterpret_cast<double*>(evals + blockIdx.x);
     if (s_eval.active) { for (int w = threadIdx.x; w < kEvalWords; w += 256) ge[w] = se[w]; }
     else if (threadIdx.x == 0) evals[blockIdx.x].active = 0;
+#ifdef NDT_PHASE_CLOCK
+    if (threadIdx.x == 0) {
+        rc6 = wall_clock64();
+        atomicAdd(&g_rphase[0], (unsigned long long)(rc1 - rc0)); atomicAdd(&g_rphase[1], (unsigned long long)(rc2 - rc1)); atomicAdd(&g_rphase[2], (unsigned long long)(rc3 - rc2));
+        atomicAdd(&g_rphase[3], (unsigned long long)(rc4 - rc3)); atomicAdd(&g_rphase[4], (unsigned long long)(rc5 - rc4)); atomicAdd(&g_rphase[5], (unsigned long long)(rc6 - rc5));
+        atomicAdd(&g_rphase[6], (unsigned long long)rsolves); atomicAdd(&g_rphase[7], 1ull);
+    }
+#endif
 }
 
 // ---- diagnostic: the controller's scalar routines on the device (tests/test_gpu_control.py holds them against the host build
@@ -1091,6 +1127,11 @@ void ndt_phase_dump()
     const double t = 100.0 * (h[5] ? h[5] : 1);
     std::fprintf(stderr, "[mrgfe phase clocks] %llu tiles, us per tile: point loaded %.2f, probes back %.2f, terms staged %.2f, queue built %.2f | pair phase %.2f; %llu items: epilogue %.2f us per item\n",
                  h[5], h[0] / t, h[1] / t, h[2] / t, h[3] / t, h[4] / t, h[7], h[6] / 100.0 / (h[7] ? h[7] : 1));
+    unsigned long long r[10];
+    if (hipMemcpyFromSymbol(r, HIP_SYMBOL(g_rphase), sizeof(r)) != hipSuccess) return;
+    const double n = 100.0 * (r[7] ? r[7] : 1);
+    std::fprintf(stderr, "[mrgfe reduce clocks] %llu controller workgroups, us each: partial sums %.2f, state in %.2f, resume %.2f, solves %.2f (%.2f solves per workgroup, %.2f us per solve), "
+                         "trig + request %.2f, state out %.2f\n", r[7], r[0] / n, r[1] / n, r[2] / n, r[3] / n, double(r[6]) / (r[7] ? r[7] : 1), r[6] ? r[3] / 100.0 / r[6] : 0.0, r[4] / n, r[5] / n);
 #endif
 }
 

@@ -687,6 +687,7 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
                         if (hi[seen].tag != static_cast<uint32_t>(seen + 1)) { set_error("NDT round %zu never reported", seen); return MRGFE_ERR_HIP; }
                     }
                 }
+                if (port) port->n_active.store(hi[seen].n_active, std::memory_order_release);
                 if (hi[seen].n_active == 0) finished = true;
                 ++seen;
                 if (seen >= round_cap && !finished) break;

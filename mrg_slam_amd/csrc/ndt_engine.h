@@ -44,6 +44,7 @@ struct NdtSnapshotPort {
     std::atomic<int>      want{0};
     std::atomic<uint32_t> issued{0};
     std::atomic<int>      finished{0};
+    std::atomic<uint32_t> n_active{0xFFFFFFFFu};  // pairs still running as of the last round plan the aligning thread has seen (published for the other thread)
     PinBuf                buf;  // NdtSnapshotHead, then NdtSnapshotRec[P]
     NdtSnapshotHead*      head() const { return buf.as<NdtSnapshotHead>(); }
     NdtSnapshotRec*       recs() const { return reinterpret_cast<NdtSnapshotRec*>(buf.as<char>() + sizeof(NdtSnapshotHead)); }

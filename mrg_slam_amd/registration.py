@@ -457,6 +457,21 @@ class BatchMatcher:
         check(lib().mrgfe_batch_align(self._h, fitness_max_range, res))
         return results_to_numpy(res, n)
 
+    def align_async(self, fitness_max_range: float = -1.0):
+        """``mrgfe_batch_align_async``: the align runs on the batch's worker thread; :meth:`wait` returns its records.  Keep two BatchMatchers on two
+        contexts in flight to overlap one batch's build and straggler rounds with the other's derivative launches."""
+        n = lib().mrgfe_batch_num_pairs(self._h)
+        self._async = ((PairResult * max(n, 1))(), n)
+        check(lib().mrgfe_batch_align_async(self._h, fitness_max_range, self._async[0]))
+
+    def wait(self):
+        res, n = self._async
+        try:
+            check(lib().mrgfe_batch_wait(self._h))
+        finally:
+            self._async = None
+        return results_to_numpy(res, n)
+
     def pair_counts(self, mode: int = -1):
         """(source points, valid point-voxel pairs) of the derivative evaluations the last align launched."""
         p, n = C.c_double(0), C.c_double(0)
