@@ -477,6 +477,8 @@ def main():
                                                            "N-GPU node would do per step, for projecting the strong scaling where N GPUs are not at hand")
     ap.add_argument("--inproc", action="store_true", help="--mode shard through mrgfe_node_* (csrc/node.cpp): ONE process, --gpus members (on distinct devices where the box has "
                                                           "them, sharing device 0 otherwise), no process group; prints the record digest of the one-rank run")
+    ap.add_argument("--no-seq", action="store_true", help="skip the one-step-at-a-time pass in front of a pipelined timed region (profiling runs: every derivative launch of the "
+                                                         "command then belongs to the pipelined steps)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight in the timed region (mrgfe_batch_align_async / _wait on as many contexts); 1: one step at a time")
     ap.add_argument("--prepare-only", action="store_true", help="generate (and cache) the synthetic scans, then exit without touching the GPU")
     ap.add_argument("--parity-pairs", type=int, default=0, help="pairs of the step checked against the CPU oracle (0: all of them; the CPU TIMING uses --cpu-pairs)")
@@ -899,7 +901,7 @@ def main():
     for _ in range(args.warmup):
         step()
     seq = None
-    if n_fl > 1:
+    if n_fl > 1 and not args.no_seq:
         # the same K steps one at a time first (untimed for `value`; reported beside it): elapsed time, and the derivative kernel's HIP-event
         # time WITHOUT another batch's kernels on the chip — in the pipelined region every launch shares the chip with the other batch's
         counters["on"] = True
@@ -915,6 +917,7 @@ def main():
         points_by_kind[:] = 0
         largest["ms"], largest["pairs"] = 0.0, [0, 0, 0]
         counters["evals"] = counters["iters"] = 0
+    if n_fl > 1:
         for _ in range(2):
             step_pipelined()
         drain()
@@ -1233,6 +1236,16 @@ def main():
                                    "asks; `bound` is what the PMC counters say limits the kernel (most of these bytes are served by L2 / Infinity Cache: `traffic`)",
                      "alg_bytes_by_evaluation_kind": {"score+gradient+hessian": per_mode[0][2] / max(k_launch, 1), "score+gradient": per_mode[1][2] / max(k_launch, 1),
                                                       "f64_hessian": per_mode[2][2] / max(k_launch, 1)},
+                     "launches_overlap": n_fl > 1,
+                     "aggregate_GBps_over_the_timed_region": (k_bytes / 1e9) / elapsed if elapsed > 0 else None,
+                     "aggregate_frac_over_the_timed_region": (k_bytes / 1e9) / elapsed / HBM_PEAK_GBPS if elapsed > 0 else None,
+                     "one_step_at_a_time": ({"avg_launch_ms": seq["avg_launch_ms"], "launches": seq["derivative_launches"], "frac": seq["frac"],
+                                             "achieved": seq["frac"] * HBM_PEAK_GBPS if seq["frac"] else None} if seq else None),
+                     "overlap_note": (f"{n_fl} batches are in flight in the timed region: a derivative launch shares the chip with the other batch's launches, so its HIP-event "
+                                      "duration (and `frac`, which prices ONE launch's algorithmic bytes against it) is about that of two launches side by side, and the sum of "
+                                      "the launch durations exceeds the wall time of the region; `aggregate_*` = algorithmic bytes of ALL derivative launches of the region over "
+                                      "its wall time (which also holds the target builds and the controller kernels); `one_step_at_a_time` = the same kernel in the K steps "
+                                      "run before the timed region on one context with nothing beside it (rounds 1-4's region)") if n_fl > 1 else None,
                      "largest_launch": largest_rec,
                      "score_gradient_hessian_variant_alone": alone,
                      "variants": variants},

@@ -461,8 +461,9 @@ class BatchMatcher:
         """``mrgfe_batch_align_async``: the align runs on the batch's worker thread; :meth:`wait` returns its records.  Keep two BatchMatchers on two
         contexts in flight to overlap one batch's build and straggler rounds with the other's derivative launches."""
         n = lib().mrgfe_batch_num_pairs(self._h)
-        self._async = ((PairResult * max(n, 1))(), n)
-        check(lib().mrgfe_batch_align_async(self._h, fitness_max_range, self._async[0]))
+        buf = (PairResult * max(n, 1))()
+        check(lib().mrgfe_batch_align_async(self._h, fitness_max_range, buf))  # (a refused call must not replace the buffer a running align writes into)
+        self._async = (buf, n)
 
     def wait(self):
         res, n = self._async
