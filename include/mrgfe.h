@@ -103,8 +103,13 @@ int  mrgfe_ctx_create(int device_id, mrgfe_ctx** out);
 int  mrgfe_ctx_create_priority(int device_id, int high_priority, mrgfe_ctx** out);
 /* a context whose kernels never occupy `reserve_cus` of the device's compute units (HIP stream with a CU mask; its helper streams too): for the
  * throughput work of a process — loop-closure batches (mrg_slam_component's LoopDetector) — so that the small per-scan launches of the odometry
- * contexts beside it always find free compute units instead of waiting for a batch's workgroups to drain.  reserve_cus = 0: mrgfe_ctx_create. */
+ * contexts beside it always find free compute units instead of waiting for a batch's workgroups to drain.  reserve_cus = 0: mrgfe_ctx_create;
+ * MRGFE_RESERVE_AUTO: sized from the device; reserve_cus >= the device's compute units: MRGFE_ERR_INVALID. */
+#define MRGFE_RESERVE_AUTO (-1) /* reserve_cus: a quarter of the device's compute units, at most 64 (MI355X: 64 of 256; a 32-CU partition: 8) */
 int  mrgfe_ctx_create_reserving(int device_id, int reserve_cus, mrgfe_ctx** out);
+/* (HIP creates compute-unit-masked streams with default flags: unlike every other stream of this library they synchronise with the legacy NULL stream.  A
+ * process that also enqueues work on the NULL stream — torch's default stream, a synchronous hipMemcpy — serialises a reserving context's kernels
+ * against it; keep NULL-stream work out of such a process or use per-thread default streams.  Results never depend on it.) */
 void mrgfe_ctx_destroy(mrgfe_ctx* ctx);
 int  mrgfe_ctx_synchronize(mrgfe_ctx* ctx);
 /* page-lock a host buffer the caller keeps between calls (hipHostRegister): downloads into it and uploads out of it are direct DMA at PCIe rate

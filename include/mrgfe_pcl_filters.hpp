@@ -44,9 +44,9 @@ namespace mrgfe_pcl {
 // registration (mrg_slam_component's LoopDetector, batches of candidates) when both components live in one container process.
 //   General     : mrgfe_ctx_create
 //   Odometry    : mrgfe_ctx_create_priority — its small launches are dispatched ahead of a batch's as slots free up
-//   LoopClosure : mrgfe_ctx_create_reserving(kReservedCus) — its kernels leave a quarter of the chip to the odometry contexts
+//   LoopClosure : mrgfe_ctx_create_reserving(MRGFE_RESERVE_AUTO) — its kernels leave a quarter of the chip (at most 64 compute units) to the
+//                 odometry contexts; on a device too small to split (or if the masked stream cannot be made) a plain context: the node keeps running
 enum class ContextRole { General = 0, Odometry = 1, LoopClosure = 2 };
-constexpr int kReservedCus = 64;
 inline mrgfe_ctx* shared_context(int device = 0, ContextRole role = ContextRole::General)
 {
     static std::mutex                              mu;
@@ -56,8 +56,9 @@ inline mrgfe_ctx* shared_context(int device = 0, ContextRole role = ContextRole:
     auto it = ctxs.find(key);
     if (it != ctxs.end()) return it->second;
     mrgfe_ctx* ctx = nullptr;
-    const int  st = role == ContextRole::Odometry ? mrgfe_ctx_create_priority(device, 1, &ctx)
-                  : role == ContextRole::LoopClosure ? mrgfe_ctx_create_reserving(device, kReservedCus, &ctx) : mrgfe_ctx_create(device, &ctx);
+    int st = role == ContextRole::Odometry ? mrgfe_ctx_create_priority(device, 1, &ctx)
+             : role == ContextRole::LoopClosure ? mrgfe_ctx_create_reserving(device, MRGFE_RESERVE_AUTO, &ctx) : mrgfe_ctx_create(device, &ctx);
+    if (st != MRGFE_OK && role == ContextRole::LoopClosure) st = mrgfe_ctx_create(device, &ctx);  // degrade to an unmasked context rather than stop the node
     if (st != MRGFE_OK) throw std::runtime_error(std::string("mrgfe: ") + mrgfe_last_error());
     ctxs[key] = ctx;
     return ctx;

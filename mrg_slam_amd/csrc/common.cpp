@@ -22,6 +22,12 @@ void set_error(const char* fmt, ...)
 }
 const char* get_error() { return g_err; }
 
+bool poll_disabled()
+{
+    static const bool off = [] { const char* e = std::getenv("MRGFE_NO_POLL"); return e && e[0] == '1'; }();
+    return off;
+}
+
 // MRGFE_POISON=1 (tests): every fresh device / pinned allocation is filled with 0xCD — fresh memory from the driver is usually zero, which hides a kernel
 // that reads what nobody wrote
 static bool poison_allocations() { static const bool v = std::getenv("MRGFE_POISON") != nullptr; return v; }
@@ -309,7 +315,7 @@ int mrgfe_ctx_create_priority(int device_id, int high_priority, mrgfe_ctx** out)
 
 int mrgfe_ctx_create_reserving(int device_id, int reserve_cus, mrgfe_ctx** out)
 {
-    if (reserve_cus < 0) { mrgfe::set_error("mrgfe_ctx_create_reserving: reserve_cus must not be negative"); return MRGFE_ERR_INVALID; }
+    if (reserve_cus < 0 && reserve_cus != MRGFE_RESERVE_AUTO) { mrgfe::set_error("mrgfe_ctx_create_reserving: reserve_cus must not be negative"); return MRGFE_ERR_INVALID; }
     return ctx_create(device_id, 0, reserve_cus, nullptr, out);
 }
 
@@ -333,7 +339,10 @@ static int ctx_create(int device_id, int high_priority, int reserve_cus, const m
     if (like) {
         c->cu_mask = like->cu_mask;
         c->cu_count = like->cu_count;
-    } else if (reserve_cus > 0) {
+    } else if (reserve_cus == MRGFE_RESERVE_AUTO && c->cu_count < 8) {
+        // nothing sensible to split off: a plain context
+    } else if (reserve_cus > 0 || reserve_cus == MRGFE_RESERVE_AUTO) {
+        if (reserve_cus == MRGFE_RESERVE_AUTO) reserve_cus = std::min(64, c->cu_count / 4);
         // the LAST reserve_cus bits of the mask stay clear: the kernels of this context never occupy those compute units, so the small launches of
         // other contexts (a robot's per-scan path beside a loop-closure batch) always find them free
         const int total = c->cu_count;

@@ -51,6 +51,43 @@ struct PinBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// Wait for a record a kernel writes into pinned host memory (system-scope release store of its last word): `done()` reads it.  A bounded spin with
+// a pause instruction between the loads (the poll saves ~10 us per round over a stream wait, which is what a single registration's latency is made
+// of) that asks the stream now and then, so that a failed launch cannot hang the caller; past the budget (~0.3 ms: a core shared with the other nodes
+// of a robot is not held for a long kernel) it falls back to hipStreamSynchronize.  MRGFE_NO_POLL=1: no spinning at all, every wait is a stream wait.
+bool poll_disabled();
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#endif
+}
+template <class Done>
+inline int poll_host_record(hipStream_t st, Done done, const char* what)
+{
+    if (!poll_disabled()) {
+        for (uint32_t spin = 0; spin < (1u << 16); ++spin) {  // ~65k paused loads: a few hundred microseconds
+            if (done()) return MRGFE_OK;
+            cpu_relax();
+            if ((spin & 0x3ff) != 0x3ff) continue;
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) {  // everything queued has run: the record is there, or never will be
+                if (done()) return MRGFE_OK;
+                set_error("%s: the kernel did not report", what);
+                return MRGFE_ERR_HIP;
+            }
+            if (q != hipErrorNotReady) { set_error("%s: %s", what, hipGetErrorString(q)); return MRGFE_ERR_HIP; }
+        }
+    }
+    const hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_error("%s: %s", what, hipGetErrorString(e)); return MRGFE_ERR_HIP; }
+    if (done()) return MRGFE_OK;
+    set_error("%s: the kernel did not report", what);
+    return MRGFE_ERR_HIP;
+}
+
 // persistent host worker threads for the per-pair controller steps of large batches (a 6x6 SVD solve and the line-search
 // bookkeeping per pair and round: ~3 us each, which adds up to the kernel time of a round once a batch has >100 pairs)
 void host_parallel_for(int n, int min_serial, const std::function<void(int, int)>& body);

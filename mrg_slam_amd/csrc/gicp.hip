@@ -1014,18 +1014,10 @@ int GicpEngine::covariances(int which, double* out9)
 // wait for gicp_reduce_host_kernel's record: poll the tag in pinned memory; the stream is asked now and then so that a failed launch cannot hang the caller
 static int gicp_wait_record(hipStream_t st, const volatile double* h_rec, double tag)
 {
-    for (uint32_t spin = 0;; ++spin) {
-        if (__atomic_load_n(reinterpret_cast<const volatile uint64_t*>(&h_rec[kGicpStride]), __ATOMIC_ACQUIRE) == *reinterpret_cast<const uint64_t*>(&tag)) return MRGFE_OK;
-        if ((spin & 0x3ff) == 0x3ff) {
-            const hipError_t q = hipStreamQuery(st);
-            if (q == hipSuccess) {  // everything queued has run: the record is there, or never will be
-                if (__atomic_load_n(reinterpret_cast<const volatile uint64_t*>(&h_rec[kGicpStride]), __ATOMIC_ACQUIRE) == *reinterpret_cast<const uint64_t*>(&tag)) return MRGFE_OK;
-                set_error("GICP: the reduction did not report");
-                return MRGFE_ERR_HIP;
-            }
-            if (q != hipErrorNotReady) { set_error("GICP: %s", hipGetErrorString(q)); return MRGFE_ERR_HIP; }
-        }
-    }
+    uint64_t want;
+    memcpy(&want, &tag, sizeof(want));
+    const volatile uint64_t* p = reinterpret_cast<const volatile uint64_t*>(&h_rec[kGicpStride]);
+    return poll_host_record(st, [&] { return __atomic_load_n(p, __ATOMIC_ACQUIRE) == want; }, "GICP reduction");
 }
 
 int GicpEngine::run_linearize(const double T[16], bool, double H[36], double b[6], double* err, int* n_corr)

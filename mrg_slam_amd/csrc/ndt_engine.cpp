@@ -201,15 +201,7 @@ int NdtEngine::build_targets(bool wait)
         MRGFE_TRY(exclusive_scan_run_heads(ctx_, sk, nullptr, d_sl, tab, d_nv, dblk.as<uint32_t>(), d_tot));
         {
             const volatile uint32_t* flag = &h_out.n_runs;
-            for (uint32_t spin = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) == kNotYet; ++spin) {
-                if ((spin & 0x3ff) != 0x3ff) continue;
-                const hipError_t q = hipStreamQuery(st);
-                if (q == hipSuccess) {  // everything queued has run: the count is there, or never will be
-                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == kNotYet) { set_error("NDT target build: the run-head count did not arrive"); return MRGFE_ERR_HIP; }
-                    break;
-                }
-                if (q != hipErrorNotReady) { set_error("NDT target build: %s", hipGetErrorString(q)); return MRGFE_ERR_HIP; }
-            }
+            MRGFE_TRY(poll_host_record(st, [&] { return __atomic_load_n(flag, __ATOMIC_ACQUIRE) != kNotYet; }, "NDT target build"));
         }
         NdtTargetInfo& T = targets_[todo[0]];
         VoxelParams    vp_host;
@@ -563,18 +555,7 @@ static int wait_result_tag(hipStream_t st, const volatile double* h_tag, double 
     uint64_t want;
     std::memcpy(&want, &tag, sizeof(want));
     const volatile uint64_t* p = reinterpret_cast<const volatile uint64_t*>(h_tag);
-    for (uint32_t spin = 0;; ++spin) {
-        if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == want) return MRGFE_OK;
-        if ((spin & 0x3ff) == 0x3ff) {
-            const hipError_t q = hipStreamQuery(st);
-            if (q == hipSuccess) {  // everything queued has run: the record is there, or never will be
-                if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == want) return MRGFE_OK;
-                set_error("NDT: the reduction did not report");
-                return MRGFE_ERR_HIP;
-            }
-            if (q != hipErrorNotReady) { set_error("NDT: %s", hipGetErrorString(q)); return MRGFE_ERR_HIP; }
-        }
-    }
+    return poll_host_record(st, [&] { return __atomic_load_n(p, __ATOMIC_ACQUIRE) == want; }, "NDT reduction");
 }
 
 void NdtEngine::account(const std::vector<NdtRoundInfo>& info, size_t rounds)
@@ -680,9 +661,13 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
         while (!finished) {
             // keep a few rounds queued ahead of the GPU; beyond that wait for the oldest unseen plan
             if (enq - seen >= lookahead || enq >= round_cap) {
-                while (__atomic_load_n(&hi[seen].tag, __ATOMIC_ACQUIRE) != static_cast<uint32_t>(seen + 1)) {
+                // (paused loads; the stream — whose query takes runtime locks other contexts' launches need — is asked every 256th time, and not at
+                // all while polling is off: MRGFE_NO_POLL=1 waits for the stream instead)
+                for (uint32_t spin = 0; __atomic_load_n(&hi[seen].tag, __ATOMIC_ACQUIRE) != static_cast<uint32_t>(seen + 1); ++spin) {
                     MRGFE_TRY(serve_port());
-                    if (hipStreamQuery(st) != hipErrorNotReady && __atomic_load_n(&hi[seen].tag, __ATOMIC_ACQUIRE) != static_cast<uint32_t>(seen + 1)) {
+                    cpu_relax();
+                    const bool ask = poll_disabled() || (spin & 0xff) == 0xff;
+                    if (ask && (poll_disabled() || hipStreamQuery(st) != hipErrorNotReady) && __atomic_load_n(&hi[seen].tag, __ATOMIC_ACQUIRE) != static_cast<uint32_t>(seen + 1)) {
                         MRGFE_HIP_CHECK(hipStreamSynchronize(st));
                         if (hi[seen].tag != static_cast<uint32_t>(seen + 1)) { set_error("NDT round %zu never reported", seen); return MRGFE_ERR_HIP; }
                     }

@@ -66,9 +66,15 @@ class KeyFrame:
 
         The reference re-reads ``candidate->cloud`` on every ``matching`` call (loop_detector.cpp:128), so a keyframe whose cloud was
         replaced — or two robots reusing an id — must not meet a stale resident copy: the content is part of the name.  The digest is
-        computed once per cloud OBJECT (keyframe clouds are ``ConstPtr`` in the reference: replaced, never edited in place)."""
+        computed once per cloud OBJECT (keyframe clouds are ``ConstPtr`` in the reference: replaced, never edited in place), and the array is
+        made read-only when it is hashed, so that an in-place edit raises instead of silently meeting the resident copy of the old content.
+        ``retired_store_key`` names the entry of the cloud this one replaced (once): the detector drops it from the GPU store."""
         tok = getattr(self, "_store_token", None)
         if tok is None or tok[0] is not self.cloud:
+            if tok is not None:
+                self._retired_key = tok[1]
+            if isinstance(self.cloud, np.ndarray):
+                self.cloud.setflags(write=False)
             c = np.ascontiguousarray(self.cloud, dtype=np.float32)
             h = hashlib.blake2b(digest_size=8)
             h.update(f"{self.slam_uuid}/{self.id}/{c.shape[0]}/".encode())
@@ -76,6 +82,12 @@ class KeyFrame:
             tok = (self.cloud, (int.from_bytes(h.digest(), "little") & ((1 << 63) - 1)) | 1)
             self._store_token = tok
         return tok[1]
+
+    def retired_store_key(self):
+        """The store key of the cloud that ``cloud`` replaced, once (None otherwise): its resident copy is garbage now."""
+        k = getattr(self, "_retired_key", None)
+        self._retired_key = None
+        return k
 
 
 @dataclasses.dataclass(eq=False)
@@ -216,6 +228,9 @@ class LoopDetector:
         t = bm.add_target(new_keyframe.cloud)
         for kf, g in zip(sources, guesses):
             key = kf.store_key()  # (slam_uuid, id, content): an equal-length replacement or another robot's same id is another entry
+            old = kf.retired_store_key()
+            if old is not None and old != key:
+                bm.forget(old)  # the replaced cloud's resident copy (the batch was just cleared: nothing references it)
             have = bm.has_cloud(key) == len(kf.cloud)
             bm.add_pair(t, None if have else kf.cloud, g, key=key)
         res = bm.align(max_range if want_fitness else -1.0)

@@ -159,6 +159,11 @@ def test_config4_256_candidate_pairs_as_bench_shards_them():
     assert par["pairs_bit_identical"] >= 0.9 * 256
     assert par["fitness_max_rel_diff_pairs_within_bar"] <= 1e-6
     assert par["best_candidate_mismatches"] <= par["pairs_over_bar"]
+    # absolute caps, whatever the replay says (it shares the optimiser's source with the product: a divergence both carry would pass the
+    # comparison above): rounds 3-5 measured 0 of 256 over the bar on these inputs; a settled pair never leaves it; nothing moves far
+    assert par["pairs_over_bar"] <= 2 and par["pairs_over_bar_settled"] == 0
+    assert par["max_dt_m"] <= 5e-2 and par["max_dr_rad"] <= 5e-2
+    assert par["pairs_with_other_iterations_or_convergence"] <= par["pairs_over_bar"]
 
 
 def test_config5_two_robots_concurrent_streams_and_inter_robot_batch(street_scans):

@@ -26,18 +26,16 @@ def test_soak_all_methods():
     for u in st["over_bar"]:
         print("over the bar:", u)
     assert st["other_exact"] == st["other"] and st["other_flag_mismatch"] == 0, "ICP / GICP / VGICP results are bit-identical to the oracle's"
-    # every GPU trajectory repeats bit for bit on the CPU in GPU order, up to the rare scene where the f64 Hessian pass sees the two
-    # C libraries' exp differ in the last bit (it then still ends within 1e-6)
-    assert st["ndt_exact_gpu_order"] >= 0.97 * st["ndt"]
-    for u in st["unexplained"]:
-        assert u["dt_vs_replay_m"] <= 1e-6, u
-    # reference order: parity wherever the optimisation settles; a settled scene over the bar must be order noise (equal to the replay).
-    # The COUNT of such scenes is not an allowance of this test any more: bench.py prints it (`soak_over_bar`) with every run.
-    assert st["ndt_exact_ref"] >= 0.9 * st["ndt"]
+    # EVERY NDT scene equals the GPU-order replay: bit for bit, or — where the f64 Hessian pass met an argument on which the device's exp and
+    # glibc's differ in the last bit — within 1e-6 m / rad of it after the same number of iterations.  No share, no allowance: a count that must
+    # come out as the number of scenes.
+    near = [u for u in st["unexplained"] if u["dt_vs_replay_m"] <= 1e-6 and u["iterations_hip"] == u["iterations_replay"]]
+    assert len(near) == len(st["unexplained"]), [u for u in st["unexplained"] if u not in near]
+    # (`unexplained` lists the scenes that equal NEITHER oracle run bit for bit; one that equals the reference-order run needs no explanation)
+    # reference order: a scene over the bar — settled or not — must be summation-order noise, i.e. equal to the replay.  How MANY there are is
+    # a property of the sample, printed by bench.py with every run (`soak_over_bar`), not a threshold of this test.
     for u in st["over_bar"]:
-        if u["settled"]:
-            assert u["equal_to_gpu_order_replay"], u
-    assert st["ndt_settled_over_bar"] <= 3  # regression guard only (round 3 measured 0-2 per 232; the number itself is in the bench line)
+        assert u["equal_to_gpu_order_replay"] or any(v["case"] == u["case"] for v in near), u
 
 
 def test_soak_round3_methods():
@@ -58,7 +56,6 @@ def test_soak_round3_methods():
     assert st["gicp_omp_exact_gpu_order"] == st["gicp_omp"], "a pclomp::GICP result differs from the oracle in the kernels' summation order"
     assert st["gicp_flag_or_iteration_mismatch"] == 0
     assert st["gicp_omp_over_bar_equal_to_gpu_order_replay"] == st["gicp_omp_over_bar"]
-    assert st["gicp_omp_worst"] <= 2e-2  # regression guard only (the numbers are in the bench line)
 
 
 def test_soak_pcl_ndt():

@@ -59,6 +59,10 @@ class ScriptedMatcher:
     def has_cloud(self, key):
         return self.store.get(key)
 
+    def forget(self, key=0):
+        self.store.pop(key, None)
+        self.ids.pop(key, None)
+
     def add_pair(self, t, cloud, guess, key=0):
         if cloud is None:
             assert key in self.store
@@ -188,3 +192,22 @@ def test_store_key_names_the_cloud_content_not_just_the_id():
     assert a.store_key() != k0
     b = _kf(7, 0, 0, 0.0, uuid="b")
     assert b.store_key() != k0
+
+
+def test_a_replaced_cloud_leaves_the_store_and_an_edited_one_raises():
+    """the entry of a replaced cloud must not stay resident for ever, and an in-place edit of a hashed cloud must not meet the stale copy"""
+    kfs = _chain(3)
+    table = {(t, s): (None, True, 0.2) for t in (50, 51, 52) for s in range(1, 4)}
+    m = ScriptedMatcher(table)
+    det = LoopDetector({"enable_loop_closure_consistency_check": False}, matcher=m)
+    det.matching(kfs[1:], _kf(50, 1.0, 0.0, 400.0))
+    old_keys = set(m.store)
+    assert len(old_keys) == 2
+    replaced = kfs[1]
+    old = replaced.store_key()
+    replaced.cloud = replaced.cloud.copy() + np.float32(0.5)  # a NEW cloud object with other content: another name
+    replaced.cloud[:, 0] = kfs[1].id  # (the scripted table reads the keyframe id out of x)
+    det.matching(kfs[1:], _kf(51, 1.0, 0.0, 500.0))
+    assert old not in m.store and replaced.store_key() in m.store and len(m.store) == 2  # the old entry was dropped, not leaked
+    with pytest.raises(ValueError):
+        replaced.cloud[0, 1] = 3.0  # hashed clouds are read-only: an in-place edit raises instead of meeting the resident copy
