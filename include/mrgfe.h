@@ -436,6 +436,10 @@ size_t mrgfe_node_store_bytes(const mrgfe_node* node);
  * = records group_first[g] .. group_first[g + 1] - 1 (the candidates of one new keyframe, in candidate order); best[g] = position within the
  * group or -1, best_score[g] = its fitness or DBL_MAX.  Among equal scores the LAST candidate wins, as there. */
 int    mrgfe_node_select_best(const mrgfe_pair_result* results, int n_groups, const int32_t* group_first, int32_t* best, double* best_score);
+/* hardening hook: the k-th device / pinned allocation of this process from now on (0 = the next one) fails as if the device were out of memory, every
+ * later one works again; k < 0 switches the injector off (MRGFE_FAIL_ALLOC_AFTER sets the initial value).  Returns the number of allocations made
+ * since the previous call: a test sweeps k over a whole entry point and wants an error code from every k, then a correct answer. */
+long   mrgfe_dbg_fail_alloc_after(long k);
 /* test hook: the next mrgfe_node_align fails on that member (the error path without an out-of-memory condition) */
 int    mrgfe_dbg_node_fail_member(mrgfe_node* node, int member);
 

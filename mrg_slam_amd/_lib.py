@@ -195,6 +195,7 @@ SIGNATURES = {
     "mrgfe_node_store_bytes": (C.c_size_t, [_vp]),
     "mrgfe_node_select_best": (C.c_int, [C.POINTER(PairResult), C.c_int, _ip, _ip, _dp]),
     "mrgfe_dbg_node_fail_member": (C.c_int, [_vp, C.c_int]),
+    "mrgfe_dbg_fail_alloc_after": (C.c_long, [C.c_long]),
     "mrgfe_dbg_set_gicp_corr_passes": (C.c_int, [C.c_int]),
     "mrgfe_dbg_grid_set_query": (C.c_int, [_vp, C.POINTER(_fp), C.POINTER(C.c_size_t), C.c_int, _fp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int32), _fp]),
     "mrgfe_dbg_sort_pairs": (C.c_int, [_vp, _u32p, _u32p, C.c_size_t, C.c_int, _u32p, _u32p]),

@@ -1639,6 +1639,8 @@ int mrgfe_dbg_ctl_math(mrgfe_ctx* ctx, const double* cases48, int n, int on_devi
     MRGFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return MRGFE_OK;
 }
+long mrgfe_dbg_fail_alloc_after(long k) { return fail_alloc_after(k); }
+
 int mrgfe_batch_rounds(const mrgfe_batch* b) { return b && b->ndt ? b->ndt->rounds() : 0; }
 
 

@@ -32,6 +32,31 @@ bool poll_disabled()
 // that reads what nobody wrote
 static bool poison_allocations() { static const bool v = std::getenv("MRGFE_POISON") != nullptr; return v; }
 
+// ---- allocation-failure injector (hardening tests) -------------------------------------------------------------------------------
+// mrgfe_dbg_fail_alloc_after(k) / MRGFE_FAIL_ALLOC_AFTER=k: the k-th device / pinned allocation from now (0 = the next one) reports an
+// out-of-memory error instead of calling HIP; every later one works again.  tests/test_gpu_hardening.py sweeps k over whole calls —
+// mrgfe_batch_align, mrgfe_prefilter, mrgfe_map_store_generate — and wants an error code from each, no leak, no std::terminate, and a
+// correct answer from the next call.
+static std::atomic<long> g_fail_alloc_in{[] { const char* e = std::getenv("MRGFE_FAIL_ALLOC_AFTER"); return e ? std::atol(e) : -1L; }()};
+static std::atomic<long> g_allocs{0};
+static bool inject_alloc_failure()
+{
+    g_allocs.fetch_add(1, std::memory_order_relaxed);
+    long v = g_fail_alloc_in.load(std::memory_order_relaxed);
+    while (v >= 0) {
+        if (g_fail_alloc_in.compare_exchange_weak(v, v - 1, std::memory_order_relaxed)) {
+            if (v == 0) { set_error("out of memory (injected: MRGFE_FAIL_ALLOC_AFTER / mrgfe_dbg_fail_alloc_after)"); return true; }
+            return false;
+        }
+    }
+    return false;
+}
+long fail_alloc_after(long k)
+{
+    g_fail_alloc_in.store(k, std::memory_order_relaxed);
+    return g_allocs.exchange(0, std::memory_order_relaxed);
+}
+
 int DevBuf::ensure(size_t bytes)
 {
     if (bytes <= cap) return MRGFE_OK;
@@ -39,6 +64,7 @@ int DevBuf::ensure(size_t bytes)
     while (want < bytes) want += want / 2 + 4096;
     want = (want + 255) & ~size_t(255);
     if (p) { MRGFE_HIP_CHECK(hipFree(p)); p = nullptr; cap = 0; }
+    if (inject_alloc_failure()) return MRGFE_ERR_HIP;
     MRGFE_HIP_CHECK(hipMalloc(&p, want));
     cap = want;
     if (poison_allocations()) { MRGFE_HIP_CHECK(hipMemset(p, 0xCD, want)); MRGFE_HIP_CHECK(hipDeviceSynchronize()); }
@@ -56,6 +82,7 @@ int PinBuf::ensure(size_t bytes)
     size_t want = cap ? cap : 4096;
     while (want < bytes) want += want / 2 + 4096;
     if (p) { MRGFE_HIP_CHECK(hipHostFree(p)); p = nullptr; cap = 0; }
+    if (inject_alloc_failure()) return MRGFE_ERR_HIP;
     MRGFE_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
     cap = want;
     if (poison_allocations()) std::memset(p, 0xCD, want);
@@ -82,6 +109,7 @@ int Arena::alloc(size_t bytes, void** out)
     c.cap = bytes > chunk_bytes ? bytes : chunk_bytes;
     c.used = 0;
     c.p = nullptr;
+    if (inject_alloc_failure()) return MRGFE_ERR_HIP;
     MRGFE_HIP_CHECK(hipMalloc(&c.p, c.cap));
     if (poison_allocations()) { MRGFE_HIP_CHECK(hipMemset(c.p, 0xCD, c.cap)); MRGFE_HIP_CHECK(hipDeviceSynchronize()); }
     *out = c.p;

@@ -17,6 +17,7 @@
 namespace mrgfe {
 
 void set_error(const char* fmt, ...);
+long fail_alloc_after(long k);  // allocation-failure injector (common.cpp): the k-th allocation from now fails (k < 0: off); returns the allocations counted since the last call
 
 #define MRGFE_HIP_CHECK(expr)                                                                                   \
     do {                                                                                                        \
