@@ -31,6 +31,14 @@ namespace {
 void col2row(const float in[16], float out[16]) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[r * 4 + c] = in[c * 4 + r]; }
 void row2col(const float in[16], float out[16]) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[c * 4 + r] = in[r * 4 + c]; }
 
+// point counts the library accepts: the kernels index points with 32-bit words (and a count beyond 2^31 is a caller's bug, not a cloud)
+constexpr size_t kMaxPoints = 0x7fffffffu;
+int check_count(size_t n, const char* fn)
+{
+    if (n > kMaxPoints) { set_error("%s: %zu points: more than 2^31 - 1", fn, n); return MRGFE_ERR_INVALID; }
+    return MRGFE_OK;
+}
+
 bool is_ndt(int method) { return method == MRGFE_NDT_HIP || method == MRGFE_PCL_NDT_HIP; }
 
 NdtParams ndt_params_from(const mrgfe_reg_params& p)
@@ -243,6 +251,7 @@ static int reg_target_changed(mrgfe_reg* reg)
 
 int mrgfe_reg_set_target(mrgfe_reg* reg, const float* xyzi, size_t n, size_t stride_bytes)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_reg_set_target"));
     if (!reg || (n && !xyzi)) { set_error("mrgfe_reg_set_target: NULL argument"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(reg->ctx);
     MRGFE_TRY(reg->ctx->bind());
@@ -255,6 +264,7 @@ int mrgfe_reg_set_target(mrgfe_reg* reg, const float* xyzi, size_t n, size_t str
 
 int mrgfe_reg_set_target_device(mrgfe_reg* reg, const void* d_xyzi, size_t n)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_reg_set_target_device"));
     if (!reg || (n && !d_xyzi)) { set_error("mrgfe_reg_set_target_device: NULL argument"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(reg->ctx);
     MRGFE_TRY(reg->ctx->bind());
@@ -265,6 +275,7 @@ int mrgfe_reg_set_target_device(mrgfe_reg* reg, const void* d_xyzi, size_t n)
 
 int mrgfe_reg_set_source(mrgfe_reg* reg, const float* xyzi, size_t n, size_t stride_bytes)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_reg_set_source"));
     if (!reg || (n && !xyzi)) { set_error("mrgfe_reg_set_source: NULL argument"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(reg->ctx);
     MRGFE_TRY(reg->ctx->bind());
@@ -279,6 +290,7 @@ int mrgfe_reg_set_source(mrgfe_reg* reg, const float* xyzi, size_t n, size_t str
 
 int mrgfe_reg_set_source_device(mrgfe_reg* reg, const void* d_xyzi, size_t n)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_reg_set_source_device"));
     if (!reg || (n && !d_xyzi)) { set_error("mrgfe_reg_set_source_device: NULL argument"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(reg->ctx);
     MRGFE_TRY(reg->ctx->bind());
@@ -359,6 +371,7 @@ int mrgfe_reg_fitness(mrgfe_reg* reg, double max_range, double* out)
 
 int mrgfe_reg_nn1_target(mrgfe_reg* reg, const float* q, size_t n, size_t stride_bytes, int32_t* idx, float* sqd)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_reg_nn1_target"));
     if (!reg || (n && (!q || !idx || !sqd))) { set_error("mrgfe_reg_nn1_target: NULL argument"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(reg->ctx);
     MRGFE_TRY(reg->ctx->bind());
@@ -395,6 +408,8 @@ int mrgfe_ndt_evaluate(mrgfe_reg* reg, const float T[16], const double p[6], int
 
 int mrgfe_knn(mrgfe_ctx* ctx, const float* cloud, size_t n, const float* query, size_t nq, size_t stride, int k, int32_t* idx, float* sqd)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_knn"));
+    MRGFE_TRY(check_count(nq, "mrgfe_knn"));
     if (!ctx || (n && !cloud) || (nq && (!query || !idx || !sqd))) { set_error("mrgfe_knn: NULL argument"); return MRGFE_ERR_INVALID; }
     if (k < 1 || k > 64) { set_error("mrgfe_knn: k must be in [1, 64]"); return MRGFE_ERR_INVALID; }
     if (nq == 0) return MRGFE_OK;
@@ -536,6 +551,7 @@ int mrgfe_reg_kernel_stats(const mrgfe_reg* reg, int mode, double* ms, int64_t* 
 // ---- prefilters -----------------------------------------------------------------------------------------------
 int mrgfe_distance_filter(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double near_thresh, double far_thresh, float* out, size_t* out_n)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_distance_filter"));
     if (!ctx || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_distance_filter: NULL argument"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(ctx);
     MRGFE_TRY(ctx->bind());
@@ -543,6 +559,7 @@ int mrgfe_distance_filter(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t st
 }
 int mrgfe_approx_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, float leaf, float* out, size_t* out_n)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_approx_voxelgrid"));
     if (!ctx || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_approx_voxelgrid: NULL argument"); return MRGFE_ERR_INVALID; }
     if (!(leaf > 0)) { set_error("mrgfe_approx_voxelgrid: leaf size must be > 0"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(ctx);
@@ -551,6 +568,7 @@ int mrgfe_approx_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t s
 }
 int mrgfe_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, float leaf, int min_pts, float* out, size_t* out_n, int* overflow)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_voxelgrid"));
     if (!ctx || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_voxelgrid: NULL argument"); return MRGFE_ERR_INVALID; }
     if (!(leaf > 0)) { set_error("mrgfe_voxelgrid: leaf size must be > 0"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(ctx);
@@ -559,6 +577,7 @@ int mrgfe_voxelgrid(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, 
 }
 int mrgfe_radius_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, double radius, int min_neighbors, float* out, size_t* out_n)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_radius_outlier"));
     if (!ctx || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_radius_outlier: NULL argument"); return MRGFE_ERR_INVALID; }
     if (!(radius > 0)) { set_error("mrgfe_radius_outlier: radius must be > 0"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(ctx);
@@ -567,6 +586,7 @@ int mrgfe_radius_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t str
 }
 int mrgfe_statistical_outlier(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, int mean_k, double stddev_mul, float* out, size_t* out_n)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_statistical_outlier"));
     if (!ctx || !out_n || (n && (!xyzi || !out))) { set_error("mrgfe_statistical_outlier: NULL argument"); return MRGFE_ERR_INVALID; }
     if (mean_k < 1 || mean_k > 63) { set_error("mrgfe_statistical_outlier: mean_k must be in [1, 63]"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(ctx);
@@ -592,10 +612,12 @@ void mrgfe_prefilter_default_params(mrgfe_prefilter_params* p)
 static int prefilter_impl(mrgfe_ctx* ctx, const mrgfe_prefilter_params* p, const float* xyzi, size_t n, size_t stride, void* out, size_t* out_n, bool on_device);
 int mrgfe_prefilter(mrgfe_ctx* ctx, const mrgfe_prefilter_params* p, const float* xyzi, size_t n, size_t stride, float* out, size_t* out_n)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_prefilter"));
     return prefilter_impl(ctx, p, xyzi, n, stride, out, out_n, false);
 }
 int mrgfe_prefilter_device(mrgfe_ctx* ctx, const mrgfe_prefilter_params* p, const float* xyzi, size_t n, size_t stride, void* d_out, size_t* out_n)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_prefilter_device"));
     return prefilter_impl(ctx, p, xyzi, n, stride, d_out, out_n, true);
 }
 static int prefilter_impl(mrgfe_ctx* ctx, const mrgfe_prefilter_params* p, const float* xyzi, size_t n, size_t stride, void* out, size_t* out_n, bool on_device)
@@ -622,6 +644,8 @@ static int prefilter_impl(mrgfe_ctx* ctx, const mrgfe_prefilter_params* p, const
 }
 int mrgfe_calc_fitness_score(mrgfe_ctx* ctx, const float* cloud1, size_t n1, const float* cloud2, size_t n2, size_t stride, const double relpose[16], double max_range, double* out)
 {
+    MRGFE_TRY(check_count(n1, "mrgfe_calc_fitness_score"));
+    MRGFE_TRY(check_count(n2, "mrgfe_calc_fitness_score"));
     if (!ctx || !out || !relpose || (n1 && !cloud1) || (n2 && !cloud2)) { set_error("mrgfe_calc_fitness_score: NULL argument"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(ctx);
     MRGFE_TRY(ctx->bind());
@@ -680,6 +704,8 @@ int mrgfe_inf_matrix_from_fitness(const mrgfe_inf_params* p, double fitness_scor
 int mrgfe_calc_information_matrix(mrgfe_ctx* ctx, const mrgfe_inf_params* p, const float* cloud1, size_t n1, const float* cloud2, size_t n2, size_t stride,
                                   const double relpose[16], double inf[36], double* fitness_out)
 {
+    MRGFE_TRY(check_count(n1, "mrgfe_calc_information_matrix"));
+    MRGFE_TRY(check_count(n2, "mrgfe_calc_information_matrix"));
     if (!p || !inf) { set_error("mrgfe_calc_information_matrix: NULL argument"); return MRGFE_ERR_INVALID; }
     double fit = 0.0;
     if (!p->use_const_inf_matrix) MRGFE_TRY(mrgfe_calc_fitness_score(ctx, cloud1, n1, cloud2, n2, stride, relpose, DBL_MAX, &fit));  // the header's default max_range
@@ -788,6 +814,7 @@ void mrgfe_map_store_destroy(mrgfe_map_store* s)
 }
 int mrgfe_map_store_add(mrgfe_map_store* s, uint64_t key, const float* xyzi, size_t n, size_t stride)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_map_store_add"));
     if (!s || key == 0 || (n && !xyzi)) { set_error("mrgfe_map_store_add: NULL store / cloud or key 0"); return MRGFE_ERR_INVALID; }
     if (n > 0x7fffffffu) { set_error("cloud too large"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(s->ctx);
@@ -885,6 +912,7 @@ int mrgfe_map_store_information_matrix(mrgfe_map_store* s, const mrgfe_inf_param
 int mrgfe_remove_points_near(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, const float* centres, int n_centres, float radius_sqr, float* kept, size_t* n_kept,
                              float* removed, size_t* n_removed)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_remove_points_near"));
     if (!ctx || !n_kept || (n && (!xyzi || !kept)) || (n_centres > 0 && !centres) || n_centres < 0) { set_error("mrgfe_remove_points_near: bad argument"); return MRGFE_ERR_INVALID; }
     *n_kept = 0;
     if (n_removed) *n_removed = 0;
@@ -909,6 +937,7 @@ int mrgfe_remove_points_near(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t
 
 int mrgfe_deskew(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, const float ang_v[3], double scan_period, float* out)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_deskew"));
     if (!ctx || !ang_v || (n && (!xyzi || !out))) { set_error("mrgfe_deskew: NULL argument"); return MRGFE_ERR_INVALID; }
     if (n == 0) return MRGFE_OK;
     MRGFE_LOCK(ctx);
@@ -928,6 +957,7 @@ int mrgfe_deskew(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, con
 
 int mrgfe_transform_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride, const float T[16], float* out)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_transform_cloud"));
     if (!ctx || !T || (n && (!xyzi || !out))) { set_error("mrgfe_transform_cloud: NULL argument"); return MRGFE_ERR_INVALID; }
     if (n == 0) return MRGFE_OK;
     MRGFE_LOCK(ctx);
@@ -1086,18 +1116,21 @@ int mrgfe_batch_clear(mrgfe_batch* b)
 }
 int mrgfe_batch_add_target(mrgfe_batch* b, const float* xyzi, size_t n, size_t stride)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_batch_add_target"));
     if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(b->ctx);
     return b->ndt->add_target_host(xyzi, n, stride);
 }
 int mrgfe_batch_add_target_device(mrgfe_batch* b, const void* d, size_t n)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_batch_add_target_device"));
     if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(b->ctx);
     return b->ndt->add_target_device(d, n);
 }
 int mrgfe_batch_add_pair(mrgfe_batch* b, int target, const float* xyzi, size_t n, size_t stride, const float guess[16])
 {
+    MRGFE_TRY(check_count(n, "mrgfe_batch_add_pair"));
     if (!b || !guess) { set_error("NULL argument"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(b->ctx);
     float g[16];
@@ -1106,6 +1139,7 @@ int mrgfe_batch_add_pair(mrgfe_batch* b, int target, const float* xyzi, size_t n
 }
 int mrgfe_batch_add_pair_device(mrgfe_batch* b, int target, const void* d, size_t n, const float guess[16])
 {
+    MRGFE_TRY(check_count(n, "mrgfe_batch_add_pair_device"));
     if (!b || !guess) { set_error("NULL argument"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(b->ctx);
     float g[16];
@@ -1137,6 +1171,7 @@ int mrgfe_batch_add_device(mrgfe_batch* b, int n_targets, const void* const* d_t
 }
 int mrgfe_batch_add_pair_keyed(mrgfe_batch* b, int target, uint64_t key, const float* xyzi, size_t n, size_t stride, const float guess[16])
 {
+    MRGFE_TRY(check_count(n, "mrgfe_batch_add_pair_keyed"));
     if (!b || !guess) { set_error("NULL argument"); return MRGFE_ERR_INVALID; }
     if (key == 0) return mrgfe_batch_add_pair(b, target, xyzi, n, stride, guess);
     MRGFE_LOCK(b->ctx);
@@ -1506,6 +1541,7 @@ int mrgfe_batch_pair_counts(const mrgfe_batch* b, int mode, double* points, doub
 // ---- diagnostics ----------------------------------------------------------------------------------------------
 int mrgfe_dbg_sort_pairs(mrgfe_ctx* ctx, const uint32_t* keys, const uint32_t* vals, size_t n, int key_bits, uint32_t* out_keys, uint32_t* out_vals)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_dbg_sort_pairs"));
     if (!ctx || (n && (!keys || !vals || !out_keys || !out_vals))) { set_error("mrgfe_dbg_sort_pairs: NULL argument"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(ctx);
     MRGFE_TRY(ctx->bind());
@@ -1546,6 +1582,7 @@ int mrgfe_dbg_wave_sums(mrgfe_ctx* ctx, int n_vals, const double* in, int cases,
 
 int mrgfe_dbg_exclusive_scan(mrgfe_ctx* ctx, const uint32_t* in, size_t n, uint32_t* out, uint32_t* total)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_dbg_exclusive_scan"));
     if (!ctx || !total || (n && (!in || !out))) { set_error("mrgfe_dbg_exclusive_scan: NULL argument"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(ctx);
     MRGFE_TRY(ctx->bind());
@@ -1568,6 +1605,7 @@ int mrgfe_dbg_exclusive_scan(mrgfe_ctx* ctx, const uint32_t* in, size_t n, uint3
 
 int mrgfe_dbg_minmax(mrgfe_ctx* ctx, const float* xyzi, size_t n, float min3[3], float max3[3], uint32_t* n_finite)
 {
+    MRGFE_TRY(check_count(n, "mrgfe_dbg_minmax"));
     if (!ctx || !min3 || !max3 || !n_finite || (n && !xyzi)) { set_error("mrgfe_dbg_minmax: NULL argument"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(ctx);
     MRGFE_TRY(ctx->bind());
