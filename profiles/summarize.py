@@ -94,8 +94,8 @@ def main():
     bench = os.path.join(OUT, f"bench_{tag}.json")
     if os.path.exists(bench):
         b = json.load(open(bench))
-        summary["bench"] = {k: b.get(k) for k in ("value", "unit", "ms_per_step", "roofline", "cpu_baseline", "parity_vs_oracle", "evaluations_per_alignment", "mean_valid_neighbours",
-                                                   "single_pair_latency_ms", "config3_shard")}
+        summary["bench"] = {k: b.get(k) for k in ("value", "unit", "ms_per_step", "steps_in_flight", "value_one_step_at_a_time", "roofline", "cpu_baseline", "parity_vs_oracle",
+                                                   "evaluations_per_alignment", "mean_valid_neighbours", "single_pair_latency_ms", "config3_shard", "pcl_ndt")}
         small = {}
         for bsz in (32, 64, 128):
             f = os.path.join(OUT, f"bench_{tag}_b{bsz}.json")
@@ -229,6 +229,7 @@ def main():
 
     rft = {}
     for name, log, stats_csv in (("config1", os.path.join(OUT, f"prof_{tag}.log"), os.path.join(OUT, f"prof_{tag}", f"{tag}_kernel_stats.csv")),
+                                 ("config1_two_steps_in_flight", os.path.join(OUT, f"prof_pipe_{tag}.log"), os.path.join(OUT, f"prof_pipe_{tag}", "s_kernel_stats.csv")),
                                  ("config3", os.path.join(OUT, f"prof_shard_{tag}.log"), os.path.join(OUT, f"prof_shard_{tag}", "s_kernel_stats.csv")),
                                  ("config3_shard_of_8", os.path.join(OUT, f"prof_shard8_{tag}.log"), os.path.join(OUT, f"prof_shard8_{tag}", "s_kernel_stats.csv"))):
         j, row = last_json(log), trace_row(stats_csv, DOMINANT)
@@ -240,7 +241,8 @@ def main():
         rec = {"kernel": DOMINANT, "trace_calls": int(row["Calls"]), "trace_avg_launch_ms": avg_ms, "trace_max_launch_ms": max_ms, "alg_bytes_per_launch": alg,
                "frac_from_trace": (alg / 1e9) / (avg_ms / 1e3) / 8000.0 if alg else None, "frac_in_bench_line": roof.get("frac"), "hip_event_avg_launch_ms": roof.get("avg_launch_ms"),
                "hip_event_launches": roof.get("launches"), "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py " +
-               {"config1": "--no-cpu --no-extras --shard-steps 0", "config3": "--mode shard --no-cpu --no-extras --steps 6 --warmup 2",
+               {"config1": "--no-cpu --no-extras --shard-steps 0" + (" --in-flight 1" if os.path.exists(os.path.join(OUT, f"prof_pipe_{tag}.log")) else ""),
+                "config1_two_steps_in_flight": "--no-cpu --no-extras --shard-steps 0 --in-flight 2 --no-seq --steps 10", "config3": "--mode shard --no-cpu --no-extras --steps 6 --warmup 2",
                 "config3_shard_of_8": "--mode shard --no-cpu --no-extras --shard-of 8 --steps 12 --warmup 3"}[name]}
         if rec["frac_from_trace"] and rec["frac_in_bench_line"]:
             rec["agreement"] = rec["frac_from_trace"] / rec["frac_in_bench_line"]
@@ -258,6 +260,38 @@ def main():
             ll = r.get("largest_launch")
             lines.append(f"| {name} | {r['trace_calls']} | {r['trace_avg_launch_ms']:.4f} | {r['hip_event_avg_launch_ms']:.4f} | {r['alg_bytes_per_launch'] / 1e9:.3f} | {r['frac_from_trace']:.3f} | "
                          f"{r['frac_in_bench_line']:.3f} | {r.get('agreement', float('nan')):.3f} | " + (f"{r['trace_max_launch_ms']:.3f} / {ll['alg_bytes'] / 1e9:.2f} / {ll['frac_from_trace_max']:.2f}" if ll else "—") + " |")
+    # ---- round 5: PCL_NDT_HIP (registration_method "NDT": pcl::NormalDistributionsTransform, f64 pair terms) — trace, the workload's own line, counters
+    pj = last_json(os.path.join(OUT, f"prof_pclndt_{tag}.log"))
+    prow = trace_row(os.path.join(OUT, f"prof_pclndt_{tag}", "s_kernel_stats.csv"), "ndt_derivatives_f64_all_kernel")
+    if pj and prow:
+        avg_ms = float(prow["AverageNs"]) / 1e6
+        rec = {"workload": pj, "trace_calls": int(prow["Calls"]), "trace_avg_launch_ms": avg_ms, "trace_max_launch_ms": float(prow["MaxNs"]) / 1e6,
+               "frac_from_trace": (pj["alg_bytes_per_launch"] / 1e9) / (avg_ms / 1e3) / 8000.0 if pj.get("alg_bytes_per_launch") else None,
+               "command": "rocprofv3 --kernel-trace --stats -- python3 profiles/pclndt_profile.py 64 1e-5 3"}
+        lines += ["", "## PCL_NDT_HIP (`rocprofv3 --kernel-trace --stats -- python3 profiles/pclndt_profile.py 64 1e-5 3`: 64 config[1] pairs, eps 1e-5), top kernels", "",
+                  "| kernel | calls | total ms | avg us | % |", "|---|---:|---:|---:|---:|"]
+        for r in list(csv.DictReader(open(os.path.join(OUT, f"prof_pclndt_{tag}", "s_kernel_stats.csv"))))[:8]:
+            lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |")
+        lines += ["", f"`ndt_derivatives_f64_all_kernel`: trace average {avg_ms * 1e3:.1f} us over {prow['Calls']} launches (warm-up step included), HIP-event average {pj['avg_launch_ms'] * 1e3:.1f} us over "
+                      f"{pj['launches']}; algorithmic bytes per launch {pj['alg_bytes_per_launch'] / 1e9:.3f} GB (N (16 + 27*8) + neighbours * 112) -> frac {rec['frac_from_trace']:.3f} from the trace, "
+                      f"{pj['frac']:.3f} in the workload's own line; {pj['ms_per_step']:.2f} ms per 64-pair step, {pj['iterations_per_alignment']:.1f} iterations / {pj['evaluations_per_alignment']:.1f} evaluations per alignment."]
+        pn = pmc_table("## PCL_NDT_HIP, counter passes (`rocprofv3 --pmc ... -- python3 profiles/pclndt_profile.py 64 1e-5 1`: two 64-pair steps per run)", "pclndt", ("ndt_derivatives_f64", "ndt_reduce", "ndt_plan"), 1, "run")
+        if pn:
+            rec["pmc"] = pn
+            k = pn.get("ndt_derivatives_f64_all_kernel")
+            if k and k["launches"]:
+                rec["traffic_bytes_per_launch"] = k["hbm_bytes"] / k["launches"]
+                rec["traffic_over_algorithmic"] = rec["traffic_bytes_per_launch"] / pj["alg_bytes_per_launch"] if pj.get("alg_bytes_per_launch") else None
+        summary["pcl_ndt"] = rec
+    inproc = os.path.join(OUT, f"inproc_{tag}.jsonl")
+    if os.path.exists(inproc):
+        rows = [json.loads(ln) for ln in open(inproc).read().splitlines() if ln.startswith("{")]
+        if rows:
+            summary["node_inproc"] = [{"members": r["n_gpus"], "devices": r["config"]["devices"], "ms_per_step": r["ms_per_step"], "records_sha256_16": r["records_sha256_16"],
+                                       "record_gather": r["config"]["record_gather"], "blocks": r["config"]["blocks"]} for r in rows]
+            lines += ["", "## mrgfe_node_* on ONE card (`python3 bench.py --mode shard --inproc --gpus N`: N members sharing device 0 — the digest is the point, not the time)", "",
+                      "| members | ms per step | records digest | gather |", "|---:|---:|---|---|"]
+            lines += [f"| {r['n_gpus']} | {r['ms_per_step']:.2f} | {r['records_sha256_16']} | {r['config']['record_gather']} |" for r in rows]
     soak = os.path.join(OUT, f"soak_{tag}.json")
     if os.path.exists(soak) and os.path.getsize(soak):
         sj = json.load(open(soak))
@@ -272,6 +306,11 @@ def main():
                            "pcl_gicp_omp_bit_identical_to_gpu_order_replay": f"{b['gicp_omp_exact_gpu_order']}/{b['gicp_omp']}", "pcl_gicp_omp_worst": b["gicp_omp_worst"],
                            "pcl_gicp_flag_or_iteration_mismatch": b["gicp_flag_or_iteration_mismatch"],
                            "icp_reciprocal_over_bar": f"{b['icp_over_bar']}/{b['icp']}", "seconds": sj["seconds"]}
+        if "pcl_ndt" in sj:
+            c = sj["pcl_ndt"]
+            summary["soak"].update({"pcl_ndt_over_bar": f"{c['over_bar']}/{c['cases']}", "pcl_ndt_bit_identical_to_reference_order_oracle": f"{c['exact']}/{c['cases']}", "pcl_ndt_worst": c["worst"],
+                                    "pcl_ndt_flag_iteration_or_evaluation_mismatch": c["flag_or_iteration_mismatch"] + c["evaluation_count_mismatch"],
+                                    "pcl_ndt_scenes_that_stop_after_one_iteration": f"{c['one_iteration']}/{c['cases']}"})
         lines += ["", f"## parity soak (`python3 profiles/soak.py 2000 600`, profiles/{tag}_soak.json)", "", "```json", json.dumps(summary["soak"], indent=1), "```"]
     for part in ("trace", "pmc"):
         f = os.path.join(OUT, f"collected_rev_{part}.txt")
