@@ -67,7 +67,9 @@ enum mrgfe_method {
     MRGFE_PCL_GICP_HIP = 5, /* replaces "GICP": pcl::GeneralizedIterativeClosestPoint (registrations.cpp:93-103): PCL's covariances, nearest-point
                                correspondences, inner BFGS with max_optimizer_iterations steps; single registrations only */
     MRGFE_PCL_GICP_OMP_HIP = 6, /* replaces "GICP_OMP": pclomp::GeneralizedIterativeClosestPoint (registrations.cpp:104-114): the same algorithm with
-                                   the older stopping rule of the inner BFGS (norm of the whole gradient < 1e-2) */
+                                   the older stopping rule of the inner BFGS (norm of the whole gradient < 1e-2) and pclomp's accumulation: per-thread
+                                   partial sums over static chunks of the correspondences, added in thread order — for num_threads threads (0: 8; at
+                                   most 16).  Upstream the count is omp_get_max_threads() of the host: the reference's result depends on it */
     MRGFE_PCL_NDT_HIP = 7 /* replaces "NDT" and every name the factory does not know: pcl::NormalDistributionsTransform (registrations.cpp:115-129;
                              PCL 1.12): f64 pair terms, the radius search over the voxel centroids (nn_search_method is ignored), PCL's own
                              iteration test (squared translation of the last step <= transformation_epsilon); also in mrgfe_batch_* */
@@ -79,7 +81,8 @@ enum mrgfe_ndt_search { MRGFE_KDTREE = 0, MRGFE_DIRECT26 = 1, MRGFE_DIRECT7 = 2,
  * library defaults those classes carry (ndt_omp: step_size 0.1, outlier_ratio 0.55; fast_gicp: rotation_epsilon 2e-3). */
 typedef struct mrgfe_reg_params {
     int    method;                          /* enum mrgfe_method                        "registration_method"               */
-    int    num_threads;                     /* accepted for parity, unused on the GPU   "reg_num_threads"                   */
+    int    num_threads;                     /* unused on the GPU, except PCL_GICP_OMP_HIP: "reg_num_threads"
+                                               the OpenMP thread count whose order of additions is reproduced               */
     double transformation_epsilon;          /*                                          "reg_transformation_epsilon"        */
     int    maximum_iterations;              /*                                          "reg_maximum_iterations"            */
     double max_correspondence_distance;     /* GICP                                     "reg_max_correspondence_distance"   */
@@ -487,8 +490,8 @@ int mrgfe_dbg_set_fit_sweep(int mode);
 int mrgfe_dbg_set_prefilter_device_driven(int mode);
 /* PCL_GICP_HIP (serial pcl::GeneralizedIterativeClosestPoint, registrations.cpp:93-103): 1 (default) the thirteen sums of every cost / gradient
  * evaluation are added in the reference's order, point after point (bit-identical BFGS trajectories; ~4 ns per point and evaluation), 0 in a tree
- * (round 3: faster, and outside the 1e-4 bar on one random scene in fourteen); other values query.  PCL_GICP_OMP_HIP always uses the tree:
- * pclomp's own sums have no fixed order. */
+ * (round 3: faster, and outside the 1e-4 bar on one random scene in fourteen); other values query.  PCL_GICP_OMP_HIP: 1 = pclomp's per-thread chunk
+ * sums for its stated thread count (n / T dependent additions per evaluation), 0 = the tree. */
 int mrgfe_dbg_set_pclgicp_reference_order(int mode);
 /* Counters of the seed + sweep pass (mrgfe_ctx_fitness_stats out[6..9], mrgfe_batch_fitness_stats) during the following calls of this process:
  * 0 = off (default; MRGFE_FIT_STATS sets the initial value), 1 = counted, 2 = also the kernel's phase clocks and a line on stderr (slows

@@ -68,6 +68,9 @@ GicpParams gicp_params_from(const mrgfe_reg_params& p)
     g.max_inner_iterations = p.max_optimizer_iterations;
     g.pcl_whole_gradient_norm = p.method == MRGFE_PCL_GICP_OMP_HIP;
     g.pcl_reference_order_sums = p.method == MRGFE_PCL_GICP_HIP;
+    // pclomp::GICP never sees reg_num_threads (registrations.cpp:104-114 does not call setNumThreads): its sums are those of omp_get_max_threads() threads
+    // of the reference's host.  Here: num_threads of the params when given, 8 (the YAML's reg_num_threads) otherwise; at most 16 chains
+    g.pcl_omp_sum_threads = p.method == MRGFE_PCL_GICP_OMP_HIP ? std::min(16, p.num_threads > 0 ? p.num_threads : 8) : 0;
     g.use_reciprocal = p.method == MRGFE_ICP_HIP && p.use_reciprocal_correspondences != 0;
     g.voxel_resolution = p.resolution;
     return g;

@@ -448,6 +448,91 @@ __global__ __launch_bounds__(256) void pclgicp_seqsum_kernel(const double* __res
     else if (tid < kGicpStride + 1 && tid - 1 != 28 && tid - 1 >= 13) out[tid - 1] = 0.0;
 }
 
+// pclomp::GICP (registration_method "GICP_OMP") accumulates into f_array / g_array / R_array[omp_get_thread_num()] inside `#pragma omp parallel for`
+// and adds the per-thread partials afterwards: T chains over the static chunks of the CORRESPONDENCE list (libgomp: thread t takes the
+// iterations [q t + min(t, r), ...), q = m / T, r = m mod T), then ((0 + p_0) + p_1) + ... in thread order.  The result depends on T =
+// omp_get_max_threads() of the host the reference runs on; PCL_GICP_OMP_HIP reproduces it for a stated T (reg_num_threads, 8 when that is 0).
+// pclgicp_chunk_bounds_kernel: the chunk boundaries in SOURCE-POINT space (a point without a correspondence adds +0.0 wherever it falls): bounds[t] =
+// index of the point that holds correspondence number start_t, bounds[T] = n.  Once per outer iteration: the correspondences stay while the BFGS runs.
+constexpr int kChunkMaxThreads = 16;
+__global__ __launch_bounds__(256) void pclgicp_chunk_bounds_kernel(const int32_t* __restrict__ corr, uint32_t n, int T, uint32_t* __restrict__ bounds)
+{
+    __shared__ uint32_t lds[8];
+    __shared__ uint32_t s_start[kChunkMaxThreads + 1];
+    const uint32_t seg = (n + 255u) / 256u, lo = min(n, threadIdx.x * seg), hi = min(n, lo + seg);
+    uint32_t mine = 0;
+    for (uint32_t i = lo; i < hi; ++i) mine += corr[i] >= 0 ? 1u : 0u;
+    uint32_t m;
+    uint32_t rank = block_exclusive_scan<256>(mine, lds, &m);
+    if (threadIdx.x <= static_cast<uint32_t>(T)) {
+        const uint32_t t = threadIdx.x, q = m / static_cast<uint32_t>(T), r = m % static_cast<uint32_t>(T);
+        s_start[t] = t == static_cast<uint32_t>(T) ? m : q * t + min(t, r);
+        bounds[t] = n;  // chunks that start behind the last correspondence are empty
+    }
+    __syncthreads();
+    int next = 0;
+    while (next < T && s_start[next] < rank) ++next;
+    for (uint32_t i = lo; i < hi; ++i) {
+        if (corr[i] < 0) continue;
+        while (next < T && s_start[next] == rank) { bounds[next] = i; ++next; }  // (several empty chunks may start at the same rank when m < T)
+        ++rank;
+    }
+}
+// The chains.  Thread (column c, chunk t) adds its chunk's terms of column c in point order; the workgroup streams tiles of kChunkTile / T points per
+// chunk and all 14 columns into LDS (coalesced along the points) while the chains add the previous tile.  n / T dependent additions per evaluation
+// instead of n: 130k points, T = 8: ~55 us (the single chain of serial pcl::GICP: ~430 us; the tree, which matches no reference: ~10 us).
+constexpr int kChunkTile = 512;  // points per column and tile, over all chunks
+__global__ __launch_bounds__(256) void pclgicp_chunksum_kernel(const double* __restrict__ terms, uint32_t n, uint32_t n_pad, const uint32_t* __restrict__ bounds, int T, double* __restrict__ out)
+{
+    __shared__ double   buf[2][14][kChunkTile];  // [column][chunk * L + j]
+    __shared__ uint32_t s_b[kChunkMaxThreads + 1];
+    __shared__ double   s_part[14][kChunkMaxThreads];
+    const int tid = threadIdx.x, L = (kChunkTile / T) & ~3;  // points per chunk and tile: a multiple of four (the chains read double2 pairs); T L <= kChunkTile
+    if (tid <= T) s_b[tid] = bounds[tid];
+    __syncthreads();
+    uint32_t longest = 0;
+    for (int t = 0; t < T; ++t) longest = max(longest, s_b[t + 1] - s_b[t]);
+    const uint32_t ntile = (longest + static_cast<uint32_t>(L) - 1u) / static_cast<uint32_t>(L);
+    constexpr int kPer = 14 * kChunkTile / 256;  // elements of a tile per thread: 28
+    double v[kPer];
+    auto fetch = [&](uint32_t tile) {
+#pragma unroll
+        for (int e = 0; e < kPer; ++e) {
+            const int      flat = e * 256 + tid, c = flat / kChunkTile, w = flat % kChunkTile, t = w / L, j = w % L;
+            const uint32_t i = t < T ? s_b[t] + tile * static_cast<uint32_t>(L) + static_cast<uint32_t>(j) : 0xFFFFFFFFu;  // (slots behind T L stay unused)
+            v[e] = (t < T && i < s_b[t + 1]) ? terms[size_t(c) * n_pad + i] : 0.0;  // (+0.0 past the chunk's end: exact to add)
+        }
+    };
+    auto stash = [&](int b) {
+#pragma unroll
+        for (int e = 0; e < kPer; ++e) { const int flat = e * 256 + tid; buf[b][flat / kChunkTile][flat % kChunkTile] = v[e]; }
+    };
+    if (ntile) { fetch(0); stash(0); }
+    __syncthreads();
+    const int c = tid / T, t = tid % T;  // chain (c, t) for tid < 14 T
+    double    acc = 0.0;
+    for (uint32_t tile = 0; tile < ntile; ++tile) {
+        const int b = static_cast<int>(tile & 1u);
+        if (tile + 1 < ntile) fetch(tile + 1);
+        if (tid < 14 * T) {
+            const double* __restrict__ col = &buf[b][c][t * L];
+            for (int u = 0; u < L; u += 4) {
+                const double2 a0 = *reinterpret_cast<const double2*>(col + u), a1 = *reinterpret_cast<const double2*>(col + u + 2);
+                acc += a0.x; acc += a0.y; acc += a1.x; acc += a1.y;
+            }
+        }
+        if (tile + 1 < ntile) stash(b ^ 1);
+        __syncthreads();
+    }
+    if (tid < 14 * T) s_part[c][t] = acc;
+    __syncthreads();
+    if (tid < 14) {
+        double s = 0.0;
+        for (int k = 0; k < T; ++k) s += s_part[tid][k];  // f = std::accumulate(f_array.begin(), f_array.end(), 0.0): thread order
+        out[tid < 13 ? tid : 28] = s;
+    } else if (tid < kGicpStride + 1 && tid - 1 != 28 && tid - 1 >= 13) out[tid - 1] = 0.0;
+}
+
 // linearize over the correspondences of gicp_corr_kernel
 __device__ __forceinline__ void gicp_linearize_block(const float4* __restrict__ src, uint32_t n, const float4* __restrict__ tgt, const double* __restrict__ cov_src,
                                                      const double* __restrict__ cov_tgt, const GicpPose& pose, const int32_t* __restrict__ corr, double* __restrict__ mahal,
@@ -816,6 +901,7 @@ GicpEngine::~GicpEngine()
     d_vox_.release(); d_vox_runs_.release(); d_cur_.release();
     h_rec_.release();
     d_terms_.release();
+    d_chunk_bounds_.release();
 }
 
 int GicpEngine::set_target(const void* d, size_t n)
@@ -1375,6 +1461,11 @@ int GicpEngine::pcl_evaluate(const float T_rowmajor[16], const float guess_rowma
         hipLaunchKernelGGL(pclgicp_corr_kernel, dim3((n + per_blk - 1) / per_blk), dim3(256), 0, st, tgt_grid_.dev2(), d_pts, n, it, d_src_cov_.as<double>(), d_tgt_cov_.as<double>(),
                            d_corr_.as<int32_t>(), d_mahal_.as<double>());
         MRGFE_HIP_CHECK(hipGetLastError());
+        if (prm_.pcl_omp_sum_threads > 1) {  // the chunk boundaries of pclomp's per-thread sums belong to these correspondences
+            MRGFE_TRY(d_chunk_bounds_.ensure(sizeof(uint32_t) * (kChunkMaxThreads + 1)));
+            hipLaunchKernelGGL(pclgicp_chunk_bounds_kernel, dim3(1), dim3(256), 0, st, d_corr_.as<int32_t>(), n, prm_.pcl_omp_sum_threads, d_chunk_bounds_.as<uint32_t>());
+            MRGFE_HIP_CHECK(hipGetLastError());
+        }
         if (!x) return MRGFE_OK;
     }
     float Tx[16];
@@ -1391,6 +1482,16 @@ int GicpEngine::pcl_evaluate(const float T_rowmajor[16], const float guess_rowma
         MRGFE_TRY(d_terms_.ensure(sizeof(double) * 14 * size_t(n_pad)));
         hipLaunchKernelGGL(pclgicp_fdf_kernel<true>, dim3(nblk), dim3(256), 0, st, d_pts, n, d_tgt_, d_corr_.as<int32_t>(), d_mahal_.as<double>(), it, d_part, d_terms_.as<double>(), n_pad);
         hipLaunchKernelGGL(pclgicp_seqsum_kernel, dim3(1), dim3(256), 0, st, d_terms_.as<double>(), n, n_pad, d_res);
+        MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev1, st));
+    } else if (prm_.pcl_omp_sum_threads > 1 && pclgicp_reference_order_mode()) {
+        // pclomp::GICP for T = pcl_omp_sum_threads OpenMP threads: T chains over the static chunks of the correspondence list, partials in thread order
+        const uint32_t n_pad = (n + 1u) & ~1u;
+        const int      T = prm_.pcl_omp_sum_threads;
+        MRGFE_TRY(d_terms_.ensure(sizeof(double) * 14 * size_t(n_pad)));
+        if (!d_chunk_bounds_.p) { set_error("pclomp sums: no correspondences were searched yet"); return MRGFE_ERR_STATE; }
+        const uint32_t* d_bounds = d_chunk_bounds_.as<uint32_t>();
+        hipLaunchKernelGGL(pclgicp_fdf_kernel<true>, dim3(nblk), dim3(256), 0, st, d_pts, n, d_tgt_, d_corr_.as<int32_t>(), d_mahal_.as<double>(), it, d_part, d_terms_.as<double>(), n_pad);
+        hipLaunchKernelGGL(pclgicp_chunksum_kernel, dim3(1), dim3(256), 0, st, d_terms_.as<double>(), n, n_pad, d_bounds, T, d_res);
         MRGFE_HIP_CHECK(hipEventRecord(ctx_->ev1, st));
     } else {
         hipLaunchKernelGGL(pclgicp_fdf_kernel<false>, dim3(nblk), dim3(256), 0, st, d_pts, n, d_tgt_, d_corr_.as<int32_t>(), d_mahal_.as<double>(), it, d_part, static_cast<double*>(nullptr), 0u);

@@ -42,6 +42,9 @@ struct GicpParams {
     // serial pcl::GICP (registration_method "GICP") is deterministic: its cost and gradient sums are added in point order, and so are ours
     // (pclgicp_seqsum_kernel) unless this is false (pclomp::GICP: per-thread sums without a fixed order -> the block tree)
     bool   pcl_reference_order_sums = false;
+    // pclomp::GICP (PCL_GICP_OMP_HIP): T > 1 = the sums as T OpenMP threads form them — T chains over the static chunks of the correspondence list, the
+    // partials added in thread order (gicp.hip pclgicp_chunksum_kernel); 0 / 1: the block tree (matches no reference, 5 x faster per evaluation)
+    int    pcl_omp_sum_threads = 0;
     double sg_init_lambda = 1e-3, sg_lambda_factor = 10.0;
     int    sg_max_inner_iterations = 10;
 };
@@ -108,6 +111,7 @@ class GicpEngine {
     int pcl_evaluate(const float T_rowmajor[16], const float guess_rowmajor[16], const float4* d_pts, bool search, const double x[6], double* f, double g[6], int* n_corr);
     const float4* source_points() const { return d_src_; }
    private:
+    DevBuf   d_chunk_bounds_;  // PCL_GICP_OMP_HIP: the chunk boundaries (source-point indices) of pclomp's per-thread sums for the current correspondences
     DevBuf   d_terms_;      // PCL_GICP_HIP: the per-point terms of one cost / gradient evaluation, a column per sum
     PinBuf   h_rec_;        // the reduced record of a linearisation / error evaluation, written by the device (gicp_reduce_host_kernel)
     uint64_t rec_tag_ = 0;  // ... and the tag of the last one asked for

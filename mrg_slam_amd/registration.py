@@ -289,8 +289,11 @@ class PclGicpHip(HipRegistration):
     METHOD = PCL_GICP_HIP
 
     def __init__(self, correspondence_randomness=20, max_correspondence_distance=2.0, transformation_epsilon=0.01, rotation_epsilon=2e-3, maximum_iterations=64,
-                 max_optimizer_iterations=20, use_reciprocal_correspondences=False, omp=False, ctx: Context | None = None):
+                 max_optimizer_iterations=20, use_reciprocal_correspondences=False, omp=False, num_threads=0, ctx: Context | None = None):
+        """``num_threads`` (``omp=True`` only): the number of OpenMP threads whose accumulation is reproduced — pclomp adds per-thread partial sums over
+        static chunks of the correspondences, so its result depends on omp_get_max_threads() of the reference's host; 0 = 8 (the YAML's reg_num_threads)."""
         p = default_params(PCL_GICP_OMP_HIP if omp else PCL_GICP_HIP)
+        p.num_threads = num_threads
         p.correspondence_randomness = correspondence_randomness
         p.max_correspondence_distance = max_correspondence_distance
         p.transformation_epsilon = transformation_epsilon
@@ -348,7 +351,8 @@ def select_registration_method(params: dict, ctx: Context | None = None) -> HipR
         # registrations.cpp:93-114: any other name with "GICP" in it is pcl::GeneralizedIterativeClosestPoint, with "OMP" in it as well pclomp's
         return PclGicpHip(int(params.get("reg_correspondence_randomness", 20)), float(params.get("reg_max_correspondence_distance", 2.0)), eps, maximum_iterations=iters,
                           max_optimizer_iterations=int(params.get("reg_max_optimizer_iterations", 20)),
-                          use_reciprocal_correspondences=bool(params.get("reg_use_reciprocal_correspondences", False)), omp="OMP" in method, ctx=ctx)
+                          use_reciprocal_correspondences=bool(params.get("reg_use_reciprocal_correspondences", False)), omp="OMP" in method,
+                          num_threads=threads, ctx=ctx)  # (pclomp::GICP never sees reg_num_threads upstream: it sums over omp_get_max_threads() threads; that number is stated here)
     search = str(params.get("reg_nn_search_method", "DIRECT7"))
     if search not in ("KDTREE", "DIRECT1"):
         search = "DIRECT7"  # registrations.cpp:140-146: anything else means DIRECT7

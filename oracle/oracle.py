@@ -98,6 +98,7 @@ def lib():
             "orc_pclgicp_destroy": (None, [vp]),
             "orc_pclgicp_set_params": (None, [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]),
             "orc_pclgicp_set_gpu_order": (None, [vp, C.c_int]),
+            "orc_pclgicp_set_sum_threads": (None, [vp, C.c_int]),
             "orc_pclgicp_set_target": (None, [vp, fp, C.c_int]),
             "orc_pclgicp_set_source": (None, [vp, fp, C.c_int]),
             "orc_pclgicp_align": (None, [vp, fp, fp]),
@@ -596,10 +597,13 @@ class PclGicp:
     whole-gradient-norm stopping rule of the inner BFGS) restated (oracle/pcl_gicp.h), registrations.cpp:93-114."""
 
     def __init__(self, correspondence_randomness=20, max_correspondence_distance=2.0, transformation_epsilon=0.01, rotation_epsilon=2e-3, maximum_iterations=64,
-                 max_optimizer_iterations=20, omp=False, num_threads=1, gpu_order=False):
-        """``gpu_order``: diagnostic — the cost sums of every BFGS evaluation added in the order the HIP kernels add them."""
+                 max_optimizer_iterations=20, omp=False, num_threads=1, gpu_order=False, sum_threads=1):
+        """``gpu_order``: diagnostic — the cost sums of every BFGS evaluation added in the order the HIP kernels add them.
+        ``sum_threads`` T > 1: pclomp's accumulation for T OpenMP threads — per-thread partial sums over the static chunks of the correspondence
+        list, added in thread order (what pclomp::GICP computes on a host with omp_get_max_threads() == T); 1: one chain (serial pcl::GICP)."""
         self._h = lib().orc_pclgicp_create()
         lib().orc_pclgicp_set_gpu_order(self._h, int(bool(gpu_order)))
+        lib().orc_pclgicp_set_sum_threads(self._h, int(sum_threads))
         lib().orc_pclgicp_set_params(self._h, correspondence_randomness, max_correspondence_distance, transformation_epsilon, rotation_epsilon, maximum_iterations,
                                      max_optimizer_iterations, int(bool(omp)), num_threads)
         self._n_src = self._n_tgt = 0

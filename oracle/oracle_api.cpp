@@ -248,6 +248,7 @@ void  orc_pclgicp_set_params(void* h, int k, double max_corr_dist, double trans_
     g->max_inner_iterations = max_inner_iterations; g->whole_gradient_norm = whole_gradient_norm; g->num_threads = num_threads;
 }
 void orc_pclgicp_set_gpu_order(void* h, int on) { static_cast<orc::PclGicp*>(h)->gpu_order = on; }
+void orc_pclgicp_set_sum_threads(void* h, int t) { static_cast<orc::PclGicp*>(h)->sum_threads = t > 0 ? t : 1; }
 void orc_pclgicp_set_target(void* h, const float* xyzi, int n) { static_cast<orc::PclGicp*>(h)->set_target(xyzi, n); }
 void orc_pclgicp_set_source(void* h, const float* xyzi, int n) { static_cast<orc::PclGicp*>(h)->set_source(xyzi, n); }
 void orc_pclgicp_align(void* h, const float guess_colmajor[16], float* aligned_or_null)

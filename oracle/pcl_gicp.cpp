@@ -57,6 +57,7 @@ struct Functor {  // OptimizationFunctorWithIndices
     const std::vector<double>* mahal;  // 9 per source point
     float base[16];                    // base_transformation_ (identity in computeTransformation)
     int   gpu_order = 0;               // diagnostic: add the per-point terms in the order the HIP kernels do (see terms_gpu_order)
+    int   sum_threads = 1;             // pclomp: per-thread partial sums over static chunks, added in thread order (see terms)
 
     // The same per-point terms as terms(), added in the order of mrg_slam_amd/csrc/gicp.hip (pclgicp_fdf_kernel + gicp_reduce_record): one
     // lane per SOURCE point (points without a correspondence contribute exact zeros), workgroups of 256 points, per wavefront of 64 a
@@ -122,9 +123,18 @@ struct Functor {  // OptimizationFunctorWithIndices
         std::memcpy(T, base, sizeof(T));
         apply_state(T, x);
         const int m = static_cast<int>(idx_src->size());
+        // pclomp (gicp_omp_impl.hpp OptimizationFunctorWithIndices): `#pragma omp parallel for` over the correspondences with f_array / g_array / R_array
+        // indexed by omp_get_thread_num(), summed over the threads afterwards.  schedule(static) without a chunk size: thread t of T takes iterations
+        // [q t + min(t, r), ...) with q = m / T, r = m mod T, the first r threads one more (libgomp).  T = sum_threads; 1 = serial pcl::GICP: one chunk.
+        const int NT = std::max(1, sum_threads);
         double f = 0;
         if (g_t) { g_t[0] = g_t[1] = g_t[2] = 0; for (int k = 0; k < 9; ++k) dC[k] = 0; }
-        for (int i = 0; i < m; ++i) {
+        const int q_len = m / NT, r_len = m % NT;
+        for (int th = 0; th < NT; ++th) {
+          const int i0 = q_len * th + std::min(th, r_len);
+          const int i1 = i0 + q_len + (th < r_len ? 1 : 0);
+          double f_th = 0, g_th[3] = {0, 0, 0}, dC_th[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+          for (int i = i0; i < i1; ++i) {
             const int    is = (*idx_src)[i], it = (*idx_tgt)[i];
             const float* ps = &(*src)[4 * static_cast<size_t>(is)];
             const float* pt = &(*tgt)[4 * static_cast<size_t>(it)];
@@ -133,13 +143,17 @@ struct Functor {  // OptimizationFunctorWithIndices
             const double d[3] = {static_cast<double>(q[0] - pt[0]), static_cast<double>(q[1] - pt[1]), static_cast<double>(q[2] - pt[2])};
             const double* M = &(*mahal)[9 * static_cast<size_t>(is)];
             const double Md[3] = {M[0] * d[0] + M[1] * d[1] + M[2] * d[2], M[3] * d[0] + M[4] * d[1] + M[5] * d[2], M[6] * d[0] + M[7] * d[1] + M[8] * d[2]};
-            f += d[0] * Md[0] + d[1] * Md[1] + d[2] * Md[2];
+            f_th += d[0] * Md[0] + d[1] * Md[1] + d[2] * Md[2];
             if (g_t) {
-                for (int k = 0; k < 3; ++k) g_t[k] += Md[k];
+                for (int k = 0; k < 3; ++k) g_th[k] += Md[k];
                 float pb[3];
                 mat4f_point(base, ps, pb);  // p_base_src = base_transformation_ * p_src
-                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) dC[r * 3 + c] += static_cast<double>(pb[r]) * Md[c];  // p_base_src * Md^T
+                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) dC_th[r * 3 + c] += static_cast<double>(pb[r]) * Md[c];  // p_base_src * Md^T
             }
+          }
+          // the partials in thread order (a sum that starts at +0.0 takes its first term exactly: T = 1 is the serial chain)
+          f += f_th;
+          if (g_t) { for (int k = 0; k < 3; ++k) g_t[k] += g_th[k]; for (int k = 0; k < 9; ++k) dC[k] += dC_th[k]; }
         }
         *fsum = f;
     }
@@ -311,7 +325,7 @@ double PclGicp::evaluate(const float T[16], const double x[6], double g[6], int*
     std::vector<double> mahal;
     correspondences(*this, target_grid_, source, T, eye, is, it, mahal);
     if (n_corr) *n_corr = static_cast<int>(is.size());
-    Functor fn{&source, &target, &is, &it, &mahal, {}, gpu_order};
+    Functor fn{&source, &target, &is, &it, &mahal, {}, gpu_order, sum_threads};
     mat4f_identity(fn.base);
     double f = 0;
     if (is.empty()) { for (int k = 0; k < 6; ++k) g[k] = 0; return 0.0; }
@@ -350,7 +364,7 @@ void PclGicp::align(const float guess[16], float* aligned)
         // the unqualified C function, i.e. in double
         double x[6] = {transformation[3], transformation[7], transformation[11], static_cast<double>(std::atan2(transformation[9], transformation[10])),
                        std::asin(static_cast<double>(-transformation[8])), static_cast<double>(std::atan2(transformation[4], transformation[0]))};
-        Functor fn{&output, &target, &idx_src, &idx_tgt, &mahal, {}, gpu_order};
+        Functor fn{&output, &target, &idx_src, &idx_tgt, &mahal, {}, gpu_order, sum_threads};
         mat4f_identity(fn.base);
         Bfgs<Functor> bfgs(fn);
         int inner = 0;

@@ -35,6 +35,9 @@ struct PclGicp {
     double translation_gradient_tolerance = 1e-2, rotation_gradient_tolerance = 1e-2;  // PCL >= 1.11
     int    whole_gradient_norm = 0;      // 1: pclomp / PCL <= 1.10: |g| < 1e-2 over all six components
     int    num_threads = 1;
+    int    sum_threads = 1;              // > 1: pclomp's accumulation for that many OpenMP threads — f_array / g_array / R_array[omp_get_thread_num()] over the static
+                                         // chunks of the correspondence list (libgomp: the first m mod T threads take one more), the per-thread partials
+                                         // then added in thread order (pcl_gicp.cpp Functor::terms).  1: one chain over all correspondences (serial pcl::GICP)
     int    gpu_order = 0;                // diagnostic: the cost sums in the HIP kernels' order of additions (pcl_gicp.cpp Functor::terms_gpu_order)
 
     std::vector<float>  target, source;  // xyzi

@@ -50,7 +50,7 @@ def test_pcl_gicp_align_matches_oracle(omp, eps, guess_seed):
     guess = np.eye(4) if guess_seed is None else synth.perturb_pose(rel, np.random.default_rng(guess_seed))
     g = select_registration_method({"registration_method": "GICP_OMP" if omp else "GICP", "reg_transformation_epsilon": eps, "reg_use_reciprocal_correspondences": True})
     assert type(g) is PclGicpHip
-    o = orc.PclGicp(transformation_epsilon=eps, omp=omp, num_threads=4)
+    o = orc.PclGicp(transformation_epsilon=eps, omp=omp, num_threads=4, sum_threads=8 if omp else 1)  # GICP_OMP: the sums of 8 OpenMP threads (the product's default)
     for r in (g, o):
         r.setInputTarget(tgt)
         r.setInputSource(src)
@@ -58,11 +58,51 @@ def test_pcl_gicp_align_matches_oracle(omp, eps, guess_seed):
     o.align(guess)
     Tg, To = g.getFinalTransformation(), o.getFinalTransformation()
     assert g.hasConverged() == o.hasConverged() and g.getFinalNumIteration() == o.getFinalNumIteration()
-    assert np.linalg.norm(Tg[:3, 3].astype(np.float64) - To[:3, 3]) <= 1e-4
-    assert synth.rotation_angle(Tg.astype(np.float64), To.astype(np.float64)) <= 1e-4
+    np.testing.assert_array_equal(Tg, To)  # both formulations add their cost terms in the reference's order: the same BFGS trajectory, bit for bit
     assert np.linalg.norm(Tg[:3, 3].astype(np.float64) - rel[:3, 3]) < 5e-3  # and it is the motion
     np.testing.assert_array_equal(aligned, orc.transform_points(Tg, src))
     assert g.getFitnessScore() == pytest.approx(o.getFitnessScore(), rel=1e-3, abs=1e-9)
+
+
+@pytest.mark.parametrize("threads", [2, 5, 8, 16])
+def test_pclomp_sums_follow_the_stated_thread_count(threads):
+    """pclomp::GICP adds per-thread partial sums over static chunks of the correspondence list (libgomp: the first m mod T threads take one more) and
+    the partials in thread order: PCL_GICP_OMP_HIP with num_threads = T equals the oracle's T-thread accumulation bit for bit — cost, gradient, and
+    whole alignments; another T gives other last bits"""
+    from mrg_slam_amd import PclGicpHip, synth
+    from oracle import oracle as orc
+
+    tgt, src, rel = _pair(6000, 21, 5003)  # (a correspondence count that no thread count divides)
+    g, o = PclGicpHip(omp=True, num_threads=threads, transformation_epsilon=1e-4), orc.PclGicp(omp=True, num_threads=4, sum_threads=threads, transformation_epsilon=1e-4)
+    other = orc.PclGicp(omp=True, num_threads=4, sum_threads=1, transformation_epsilon=1e-4)
+    for r in (g, o, other):
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+    differs = False
+    for T, x in ((np.eye(4), np.zeros(6)), (rel, np.array([0.05, -0.02, 0.01, 0.004, -0.003, 0.01])), (np.eye(4), np.array([0.2, -0.1, 0.05, 0.01, -0.01, 0.03]))):
+        fg, gg, ng = g.evaluate(T, x)
+        fo, go, no = o.evaluate(T, x)
+        f1, g1, _ = other.evaluate(T, x)
+        # the same additions in the same order (a term itself differs in its last bit now and then — the Mahalanobis matrices come from the device's
+        # and the host's own 3 x 3 inverses —: one ulp of a sum in a few hundred evaluations, so "equal" here is 1e-14 relative, not bitwise)
+        assert ng == no and fg == pytest.approx(fo, rel=1e-14)
+        np.testing.assert_allclose(gg, go, rtol=0, atol=1e-14 * np.abs(go).max())
+        differs = differs or fg != f1 or (gg != g1).any()
+    assert differs  # (the serial chain rounds differently somewhere in three evaluations of 5000 terms)
+    for guess in (np.eye(4), synth.perturb_pose(rel, np.random.default_rng(3))):
+        g.align(guess)
+        o.align(guess)
+        np.testing.assert_array_equal(g.getFinalTransformation(), o.getFinalTransformation())
+        assert (g.hasConverged(), g.getFinalNumIteration()) == (o.hasConverged(), o.getFinalNumIteration())
+    # fewer correspondences than threads: empty chunks
+    tiny_t, tiny_s = tgt[:40], src[:9]
+    g2, o2 = PclGicpHip(omp=True, num_threads=threads), orc.PclGicp(omp=True, sum_threads=threads)
+    for r in (g2, o2):
+        r.setInputTarget(tiny_t)
+        r.setInputSource(tiny_s)
+    fg, gg, ng = g2.evaluate(np.eye(4), np.zeros(6))
+    fo, go, no = o2.evaluate(np.eye(4), np.zeros(6))
+    assert ng == no and fg == pytest.approx(fo, rel=1e-14) and np.allclose(gg, go, rtol=0, atol=1e-14 * max(1e-300, np.abs(go).max()))
 
 
 def test_pcl_gicp_limits_and_degenerate_inputs():
