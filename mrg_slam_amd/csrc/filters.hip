@@ -443,7 +443,7 @@ static int host_wrap(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t stride,
 
 // ---- the chain with its counts on the device (round 4) --------------------------------------------------------------------------------
 // distance filter -> VoxelGrid -> RadiusOutlierRemoval used to hand every intermediate point COUNT to the host, which sized the next stage's
-// tables: 8 host waits and ~18 small copies per scan for 0.45 ms of kernel time (1.0 - 1.16 ms per 132k-point scan).  Here
+// tables: 8 host waits and ~18 small copies per scan for 0.45 ms of kernel time (CHANGELOG.md (rounds 1 - 4 notes, §10.6): 1.0 - 1.16 ms per 132k-point scan).  Here
 // the counts stay where they are produced: the slices, voxel parameters and leaf slices the batched primitives read are members of ONE state
 // record in device memory (PfState), rewritten between the stages by single-thread kernels that repeat the host's arithmetic float for float;
 // every launch is sized for the input size and skips what lies beyond the device-side count; the radius filter's grid sizes itself
