@@ -118,6 +118,10 @@ int  mrgfe_ctx_synchronize(mrgfe_ctx* ctx);
 /* page-lock a host buffer the caller keeps between calls (hipHostRegister): downloads into it and uploads out of it are direct DMA at PCIe rate
  * instead of staged through the runtime's bounce buffers — worth it for the 60 MB map cloud of mrgfe_map_store_generate / mrgfe_map_cloud_generate
  * (map_cloud_generator.cpp:14-86 returns a fresh pcl cloud per call; a caller of this library reuses one buffer).  Unpin before freeing it. */
+/* Uploads, too (round 5): a packed cloud handed to mrgfe_*_set_* / mrgfe_batch_add_* / mrgfe_node_add_* out of page-locked memory is read by DMA straight
+ * from the caller's buffer instead of through the staging ring (a single-thread copy at about half the link's rate).  That copy is stream-ordered:
+ * keep such a buffer unchanged until the call that consumes the cloud (…_align, mrgfe_ctx_synchronize) has returned.  Pageable buffers keep the old
+ * contract: free or reuse them as soon as the add / set call returns. */
 int  mrgfe_pin_host_buffer(mrgfe_ctx* ctx, void* p, size_t bytes);
 int  mrgfe_unpin_host_buffer(mrgfe_ctx* ctx, void* p);
 /* HIP stream of the context as an opaque pointer (hipStream_t), for callers that order their own work after it */

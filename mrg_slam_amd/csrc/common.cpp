@@ -274,6 +274,19 @@ int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t layout, voi
     (void)pin_slot;
     if (!(stride == 16 && xo == 0 && io == 12))  // strided records: raw bytes up in one copy, x/y/z/intensity gathered on the device (ingest.hip)
         return upload_gathered(ctx, xyzi, n * size_t(stride), n, static_cast<uint32_t>(n), static_cast<uint32_t>(n) * stride, stride, xo, xo + 4, xo + 8, io, d_dst);
+    // A cloud that sits in page-locked host memory (mrgfe_pin_host_buffer, hipHostMalloc, hipHostRegister) goes up by DMA straight out of the caller's
+    // buffer: the staging copy below is a single-thread memcpy (~25 GB/s) and halves what the link gives.  The copy is stream-ordered like every
+    // upload, so such a buffer must stay unchanged until the call that consumes the cloud has returned (mrgfe.h: mrgfe_pin_host_buffer) — the
+    // reference's keyframe clouds are immutable ConstPtr clouds.  MRGFE_NO_DIRECT_UPLOAD=1: always stage.
+    static const bool direct_ok = std::getenv("MRGFE_NO_DIRECT_UPLOAD") == nullptr;
+    if (direct_ok && n * 16 >= (size_t(64) << 10)) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, xyzi) == hipSuccess && attr.type == hipMemoryTypeHost) {
+            MRGFE_HIP_CHECK(hipMemcpyAsync(d_dst, xyzi, n * 16, hipMemcpyHostToDevice, ctx->stream));
+            return MRGFE_OK;
+        }
+        (void)hipGetLastError();  // (an unregistered pointer is an error to the query, not to us)
+    }
     const int slot = ctx->up_next;
     ctx->up_next ^= 1;
     if (!ctx->up_ev[slot]) MRGFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->up_ev[slot], hipEventDisableTiming));

@@ -169,3 +169,43 @@ def test_allocation_failures_in_node_align_name_the_member():
     want = run(NodeMatcher([0, 0], prm))
     n = _sweep(lambda: NodeMatcher([0, 0], prm), run, lambda r: r.tobytes() == want.tobytes() or (_ for _ in ()).throw(AssertionError("records differ")))
     assert n >= 10
+
+
+def test_page_locked_host_clouds_upload_by_dma_with_the_same_results():
+    """mrgfe.h (mrgfe_pin_host_buffer): a cloud in page-locked memory is read by DMA straight from the caller's buffer, a pageable one goes through the
+    staging ring.  Same bytes in HBM either way: the batch records must be byte-identical, also for clouds that start in the MIDDLE of a pinned range
+    and for one below the direct-upload floor (64 KB)."""
+    from mrg_slam_amd import BatchMatcher, Context
+    from mrg_slam_amd._lib import lib
+
+    rng = np.random.default_rng(3)
+    ctx = Context()
+    pairs = []
+    for k, n in enumerate((9000, 30000, 2000)):
+        t = small_cloud(n, seed=40 + k)
+        g = np.eye(4)
+        g[:3, 3] = rng.uniform(-0.3, 0.3, 3)
+        pairs.append((t, small_cloud(n, seed=40 + k)[: n - 50].copy(), g))
+    # one pinned slab holding every cloud back to back (so all but the first start inside the registered range, not at its base)
+    total = sum(len(t) + len(s) for t, s, _ in pairs)
+    slab = np.empty((total, 4), np.float32)
+    assert lib().mrgfe_pin_host_buffer(ctx._h, slab.ctypes.data_as(C.c_void_p), slab.nbytes) == 0
+    try:
+        o, views = 0, []
+        for t, s, g in pairs:
+            tv = slab[o:o + len(t)]
+            o += len(t)
+            sv = slab[o:o + len(s)]
+            o += len(s)
+            tv[:], sv[:] = t, s
+            views.append((tv, sv, g))
+        out = []
+        for clouds in (pairs, views):
+            bm = BatchMatcher(ctx=ctx)
+            for t, s, g in clouds:
+                bm.add_pair(bm.add_target(t), s, g)
+            out.append(bm.align().copy())
+        assert out[0].tobytes() == out[1].tobytes()
+        assert out[0]["converged"].all()
+    finally:
+        assert lib().mrgfe_unpin_host_buffer(ctx._h, slab.ctypes.data_as(C.c_void_p)) == 0
