@@ -129,33 +129,37 @@ int bounding_boxes(mrgfe_ctx* ctx, const float4* const* d_clouds, const Slice* d
 // radix sort (8-bit digits, stable)
 // ------------------------------------------------------------------------------------------------------
 // pass 1: per-tile digit histogram, LDS atomics.  hist layout: [tile][256] so the scan kernel reads coalesced.
+constexpr int kHistTiles = 2;  // tiles per workgroup of rs_hist_kernel: both tiles' loads go out before the first count (the kernel waited for one 8 KB tile per workgroup)
 __global__ __launch_bounds__(256) void rs_hist_kernel(const uint32_t* __restrict__ keys, const Slice* __restrict__ slices, uint32_t* __restrict__ hist, int shift)
 {
     const Slice s = slices[blockIdx.y];
-    if (blockIdx.x >= s.nblk) return;
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+    const uint32_t tile0 = blockIdx.x * kHistTiles;
+    if (tile0 >= s.nblk) return;
+    __shared__ uint32_t h[kHistTiles][256];
+#pragma unroll
+    for (int t = 0; t < kHistTiles; ++t) h[t][threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * kTile;
     // neighbours in a scan fall into the same voxel: a wavefront's keys share a handful of digits, and 64 LDS atomics on one
-    // counter are served one after the other.  The lanes of a wavefront that hold the same digit are matched by ballots (as in the
-    // scatter kernel) and the first of them adds their number: one atomic per distinct digit.  All eight loads of the tile first.
-    uint32_t key[kTile / 256];
+    // counter are served one after the other: wave_hist_add (dev_utils.h) lets the lanes that share a digit add together.
+    // (a count does not mind the order: every lane takes eight CONSECUTIVE keys of each tile, two 16-byte loads instead of eight strided words)
+    static_assert(kTile / 256 == 8, "eight keys per lane");
+    uint32_t key[kHistTiles][8];
 #pragma unroll
-    for (int k = 0; k < kTile / 256; ++k) {
-        const uint32_t i = base + k * 256 + threadIdx.x;
-        key[k] = i < s.n ? keys[s.off + i] : 0u;
-    }
-    const int lane = lane_id();
+    for (int t = 0; t < kHistTiles; ++t) load8_u32(keys + s.off, (tile0 + t) * kTile + threadIdx.x * 8u, s.n, 0u, key[t]);  // (a tile past the end: n <= its first key, all fill)
 #pragma unroll
-    for (int k = 0; k < kTile / 256; ++k) {
-        const bool     valid = base + k * 256 + threadIdx.x < s.n;
-        const uint32_t d = (key[k] >> shift) & 255u;
-        const uint64_t m = wave_match_digit8(d, __ballot(valid));
-        if (valid && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&h[d], static_cast<uint32_t>(__popcll(m)));
+    for (int t = 0; t < kHistTiles; ++t) {
+        const uint32_t first = (tile0 + t) * kTile + threadIdx.x * 8u;
+#pragma unroll
+        for (int k = 0; k < kTile / 256; ++k) {
+            const bool     valid = first + k < s.n;
+            const uint32_t d = (key[t][k] >> shift) & 255u;
+            wave_hist_add(h[t], d, valid);
+        }
     }
     __syncthreads();
-    hist[(size_t)(s.blk_off + blockIdx.x) * 256 + threadIdx.x] = h[threadIdx.x];
+#pragma unroll
+    for (int t = 0; t < kHistTiles; ++t)
+        if (tile0 + t < s.nblk) hist[(size_t)(s.blk_off + tile0 + t) * 256 + threadIdx.x] = h[t][threadIdx.x];
 }
 
 // pass 2: one workgroup per problem. Thread d turns column d of hist into an exclusive prefix over tiles, then the
@@ -353,7 +357,7 @@ int radix_sort_pairs(mrgfe_ctx* ctx, uint32_t* d_keys, uint32_t* d_vals, uint32_
     }
     for (int p = 0; p < passes; ++p) {
         const int shift = 8 * p;
-        if (!(p == 0 && first_hist_ready)) hipLaunchKernelGGL(rs_hist_kernel, grid, dim3(256), 0, ctx->stream, ki, d_slices, d_hist, shift);
+        if (!(p == 0 && first_hist_ready)) hipLaunchKernelGGL(rs_hist_kernel, dim3((t.max_blks + kHistTiles - 1) / kHistTiles, t.nprob()), dim3(256), 0, ctx->stream, ki, d_slices, d_hist, shift);
         if (own_scan) {
             if (p == 0 && iota_vals) hipLaunchKernelGGL((rs_scatter_kernel<true, true>), grid, dim3(256), 0, ctx->stream, ki, vi, ko, vo, d_slices, d_hist, digit_base, shift);
             else                     hipLaunchKernelGGL((rs_scatter_kernel<false, true>), grid, dim3(256), 0, ctx->stream, ki, vi, ko, vo, d_slices, d_hist, digit_base, shift);
@@ -451,7 +455,6 @@ int exclusive_scan(mrgfe_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, const 
 // Exclusive scan of the run-head flags of a sorted key array (flag i = 1 iff i starts a run of equal keys among the first n_valid elements; the
 // invalid keys sort behind them) without a flag array: both scan kernels read the keys and compare neighbours.  (Round 2 marked the heads
 // in a kernel of their own and scanned the flags: one launch and 4 bytes per element more.)
-__device__ __forceinline__ uint32_t run_head(const uint32_t* __restrict__ keys, uint32_t i, uint32_t nv) { return i < nv && (i == 0 || keys[i - 1] != keys[i]) ? 1u : 0u; }
 
 __global__ __launch_bounds__(256) void scan_heads_tile_sum_kernel(const uint32_t* __restrict__ keys, const Slice* __restrict__ slices, const uint32_t* __restrict__ n_valid, uint32_t* __restrict__ blk)
 {
@@ -459,12 +462,14 @@ __global__ __launch_bounds__(256) void scan_heads_tile_sum_kernel(const uint32_t
     if (blockIdx.x >= s.nblk) return;
     const uint32_t base = blockIdx.x * kTile, nv = n_valid[blockIdx.y];
     const uint32_t* __restrict__ k0 = keys + s.off;
+    // eight consecutive keys per lane (two 16-byte loads) and the one before them
+    const uint32_t first = base + threadIdx.x * 8u;
+    uint32_t kk[9];
+    kk[0] = (first > 0 && first - 1 < s.n) ? k0[first - 1] : 0u;
+    load8_u32(k0, first, s.n, 0u, kk + 1);
     uint32_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < kTile / 256; ++k) {
-        const uint32_t i = base + k * 256 + threadIdx.x;
-        if (i < s.n) acc += run_head(k0, i, nv);
-    }
+    for (int k = 0; k < 8; ++k) acc += (first + k < nv && (first + k == 0 || kk[k] != kk[k + 1])) ? 1u : 0u;
     __shared__ uint32_t sw[4];
     acc = wave_sum(acc);
     if (lane_id() == 0) sw[wave_id()] = acc;

@@ -117,7 +117,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
 }
 
 // lanes of the wave (among `active`) that hold the same 8-bit digit as this lane
-__device__ __forceinline__ uint64_t wave_match_digit8(uint32_t d, uint64_t active)
+__device__ __forceinline__ uint64_t wave_match_digit8_bits(uint32_t d, uint64_t active)
 {
     uint64_t m = active;
 #pragma unroll
@@ -127,6 +127,65 @@ __device__ __forceinline__ uint64_t wave_match_digit8(uint32_t d, uint64_t activ
         m &= bit ? bal : ~bal;
     }
     return m;
+}
+// The same set, found by peeling: the digit of the first lane not yet matched is broadcast, one ballot names its lanes, and so on.  The keys of a
+// wavefront are neighbours in a scan — a handful of distinct digits, often one — so this is a few ballots instead of eight (the bit-by-bit form
+// is ~60 VALU instructions per key and was what bound the histogram and scatter kernels of the radix sort: 800 - 1100 per wavefront of eight
+// keys).  After kPeel digits whatever is left takes the bit-by-bit form: a wavefront of unrelated keys pays a little more than before, not 64 ballots.
+__device__ __forceinline__ uint64_t wave_match_digit8(uint32_t d, uint64_t active)
+{
+    constexpr int kPeel = 4;
+    const bool    mine = (active >> lane_id()) & 1ull;
+    uint64_t      left = active, m = 0ull;
+#pragma unroll
+    for (int it = 0; it < kPeel; ++it) {
+        if (left == 0ull) break;  // uniform
+        const int      leader = __ffsll(static_cast<unsigned long long>(left)) - 1;
+        const uint32_t dv = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(d), leader));
+        const uint64_t hit = __ballot(mine && d == dv);
+        if (mine && d == dv) m = hit;
+        left &= ~hit;
+    }
+    if (left != 0ull) {  // uniform
+        const uint64_t full = wave_match_digit8_bits(d, active);
+        if ((left >> lane_id()) & 1ull) m = full;
+    }
+    return m;
+}
+
+// eight consecutive words p[first .. first + 8) of an array of n (first a multiple of 4, p 16-byte aligned: the slices of cellsort.h): two 16-byte
+// loads when all eight exist, else word by word with `fill` past the end
+// h[d] += 1 for every `valid` lane (h: the workgroup's LDS histogram): the lanes that share one of the first few distinct digits of the wavefront
+// add together (one atomic per digit: 64 atomics on one counter are served one after the other), whoever is left adds for itself — a count needs
+// no ranks, so unrelated digits (the upper digits of a sort's later passes) cost a ballot or two and one atomic per lane instead of the full match
+__device__ __forceinline__ void wave_hist_add(uint32_t* h, uint32_t d, bool valid)
+{
+    constexpr int kPeel = 3;
+    uint64_t left = __ballot(valid);
+    bool     mine = valid;
+#pragma unroll
+    for (int it = 0; it < kPeel; ++it) {
+        if (left == 0ull) break;  // uniform
+        const int      leader = __ffsll(static_cast<unsigned long long>(left)) - 1;
+        const uint32_t dv = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(d), leader));
+        const bool     same = mine && d == dv;
+        const uint64_t hit = __ballot(same);
+        if (lane_id() == leader) atomicAdd(&h[dv], static_cast<uint32_t>(__popcll(hit)));
+        mine = mine && !same;
+        left &= ~hit;
+    }
+    if (mine) atomicAdd(&h[d], 1u);
+}
+
+__device__ __forceinline__ void load8_u32(const uint32_t* __restrict__ p, uint32_t first, uint32_t n, uint32_t fill, uint32_t out[8])
+{
+    if (first + 8u <= n) {
+        const uint4 a = *reinterpret_cast<const uint4*>(p + first), b = *reinterpret_cast<const uint4*>(p + first + 4);
+        out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = first + k < n ? p[first + k] : fill;
+    }
 }
 
 __device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }

@@ -47,14 +47,8 @@ __global__ __launch_bounds__(256) void ndt_cellkey_kernel(const float4* const* _
             keys[s.off + i] = key[k];
         }
     }
-    const int lane = lane_id();
 #pragma unroll
-    for (int k = 0; k < kTile / 256; ++k) {
-        const bool     valid = base + k * 256 + threadIdx.x < s.n;
-        const uint32_t d = key[k] & 255u;
-        const uint64_t m = wave_match_digit8(d, __ballot(valid));
-        if (valid && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&h[d], static_cast<uint32_t>(__popcll(m)));
-    }
+    for (int k = 0; k < kTile / 256; ++k) wave_hist_add(h, key[k] & 255u, base + k * 256 + threadIdx.x < s.n);
     __syncthreads();
     hist[(size_t)(s.blk_off + blockIdx.x) * 256 + threadIdx.x] = h[threadIdx.x];
 }
@@ -76,8 +70,7 @@ __global__ __launch_bounds__(256) void ndt_segments_kernel(const uint32_t* __res
     const uint32_t first = blockIdx.x * kTile + threadIdx.x * 8;
     uint32_t kk[9];  // the thread's eight keys and the one before them
     kk[0] = (first > 0 && first - 1 < s.n) ? k0[first - 1] : 0u;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) kk[k + 1] = (first + k < s.n) ? k0[first + k] : 0u;
+    load8_u32(k0, first, s.n, 0u, kk + 1);
     uint32_t head[8], tsum = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { head[k] = (first + k < nv && (first + k == 0 || kk[k] != kk[k + 1])) ? 1u : 0u; tsum += head[k]; }
