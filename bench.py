@@ -995,6 +995,8 @@ def main():
         # (2b) the same with the host clouds page-locked (mrgfe_pin_host_buffer: a caller that keeps its keyframe clouds pinned): DMA straight out of them
         pinned = []
         try:
+            for b in bms:
+                b._ctx.set_zero_copy_uploads(True)
             for sc in scans:
                 if lib().mrgfe_pin_host_buffer(ctx._h, sc.ctypes.data_as(C.c_void_p), sc.nbytes) == 0:
                     pinned.append(sc)
@@ -1040,6 +1042,8 @@ def main():
                                                                        "GBps_over_pcie": hbm_input_bytes / 1e9 / (tp / n_host), "same_results_as_device_pointers": bool(np.array_equal(pin_res["T"], res["T"])),
                                                                        "note": "the caller's clouds page-locked once (mrgfe_pin_host_buffer): uploads are DMA out of the caller's buffers, no staging copy"}
         finally:
+            for b in bms:
+                b._ctx.set_zero_copy_uploads(False)
             for sc in pinned:
                 lib().mrgfe_unpin_host_buffer(ctx._h, sc.ctypes.data_as(C.c_void_p))
         # (3) pipeline shape: what prefiltering_component -> scan_matching_odometry really feeds NDT (distance + 0.1 m voxel + radius outlier filter)

@@ -118,12 +118,16 @@ int  mrgfe_ctx_synchronize(mrgfe_ctx* ctx);
 /* page-lock a host buffer the caller keeps between calls (hipHostRegister): downloads into it and uploads out of it are direct DMA at PCIe rate
  * instead of staged through the runtime's bounce buffers — worth it for the 60 MB map cloud of mrgfe_map_store_generate / mrgfe_map_cloud_generate
  * (map_cloud_generator.cpp:14-86 returns a fresh pcl cloud per call; a caller of this library reuses one buffer).  Unpin before freeing it. */
-/* Uploads, too (round 5): a packed cloud handed to mrgfe_*_set_* / mrgfe_batch_add_* / mrgfe_node_add_* out of page-locked memory is read by DMA straight
- * from the caller's buffer instead of through the staging ring (a single-thread copy at about half the link's rate).  That copy is stream-ordered:
- * keep such a buffer unchanged until the call that consumes the cloud (…_align, mrgfe_ctx_synchronize) has returned.  Pageable buffers keep the old
- * contract: free or reuse them as soon as the add / set call returns. */
 int  mrgfe_pin_host_buffer(mrgfe_ctx* ctx, void* p, size_t bytes);
 int  mrgfe_unpin_host_buffer(mrgfe_ctx* ctx, void* p);
+/* Zero-copy uploads (round 5; off by default).  on = 1: a packed cloud (stride 16) of 64 KB or more that is handed to mrgfe_*_set_* / mrgfe_batch_add_* /
+ * mrgfe_node_add_* on this context out of page-locked host memory is read by DMA straight from the caller's buffer instead of through the context's
+ * staging ring (a single-thread copy at about half the link's rate: 256 config[1] pairs from host clouds 44 -> 34.5 ms per step, 28.4 ms with two
+ * batches in flight = 37 GB/s over the link).  The DMA is stream-ordered, so the CONTRACT CHANGES for such buffers: keep them unchanged until the call
+ * that consumes the cloud (…_align / …_wait, mrgfe_ctx_synchronize) has returned — the reference's keyframe clouds are immutable ConstPtr clouds.
+ * Pageable buffers, and everything while the switch is off, keep the default contract: free or reuse the memory as soon as the add / set call returns.
+ * (mrgfe_node_* declares its clouds by pointer and uploads them inside mrgfe_node_align: its members always run with the switch on.) */
+int  mrgfe_ctx_set_zero_copy_uploads(mrgfe_ctx* ctx, int on);
 /* HIP stream of the context as an opaque pointer (hipStream_t), for callers that order their own work after it */
 void* mrgfe_ctx_stream(mrgfe_ctx* ctx);
 /* Measurement hook ("1-NN fitness on hash grid: N (16 + 27*8 + m*16)"): what the last getFitnessScore pass on this context

@@ -100,6 +100,7 @@ SIGNATURES = {
     "mrgfe_ctx_synchronize": (C.c_int, [_vp]),
     "mrgfe_pin_host_buffer": (C.c_int, [_vp, _vp, C.c_size_t]),
     "mrgfe_unpin_host_buffer": (C.c_int, [_vp, _vp]),
+    "mrgfe_ctx_set_zero_copy_uploads": (C.c_int, [_vp, C.c_int]),
     "mrgfe_ctx_stream": (_vp, [_vp]),
     "mrgfe_ctx_fitness_stats": (C.c_int, [_vp, _dp]),
     "mrgfe_ctx_knn_stats": (C.c_int, [_vp, _dp]),
@@ -284,6 +285,11 @@ class Context:
 
     def synchronize(self):
         check(lib().mrgfe_ctx_synchronize(self._h))
+
+    def set_zero_copy_uploads(self, on: bool = True):
+        """``mrgfe_ctx_set_zero_copy_uploads``: clouds in page-locked host memory go up by DMA from the caller's buffer — which must then stay
+        unchanged until the consuming call (align / wait / synchronize) has returned."""
+        check(lib().mrgfe_ctx_set_zero_copy_uploads(self._h, int(bool(on))))
 
     def fitness_stats(self) -> dict:
         """What the last getFitnessScore pass on this context did (``mrgfe_ctx_fitness_stats``)."""

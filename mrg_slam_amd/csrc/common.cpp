@@ -274,12 +274,12 @@ int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t layout, voi
     (void)pin_slot;
     if (!(stride == 16 && xo == 0 && io == 12))  // strided records: raw bytes up in one copy, x/y/z/intensity gathered on the device (ingest.hip)
         return upload_gathered(ctx, xyzi, n * size_t(stride), n, static_cast<uint32_t>(n), static_cast<uint32_t>(n) * stride, stride, xo, xo + 4, xo + 8, io, d_dst);
-    // A cloud that sits in page-locked host memory (mrgfe_pin_host_buffer, hipHostMalloc, hipHostRegister) goes up by DMA straight out of the caller's
-    // buffer: the staging copy below is a single-thread memcpy (~25 GB/s) and halves what the link gives.  The copy is stream-ordered like every
-    // upload, so such a buffer must stay unchanged until the call that consumes the cloud has returned (mrgfe.h: mrgfe_pin_host_buffer) — the
-    // reference's keyframe clouds are immutable ConstPtr clouds.  MRGFE_NO_DIRECT_UPLOAD=1: always stage.
-    static const bool direct_ok = std::getenv("MRGFE_NO_DIRECT_UPLOAD") == nullptr;
-    if (direct_ok && n * 16 >= (size_t(64) << 10)) {
+    // mrgfe_ctx_set_zero_copy_uploads(ctx, 1): a cloud that sits in page-locked host memory (mrgfe_pin_host_buffer, hipHostMalloc, hipHostRegister)
+    // goes up by DMA straight out of the caller's buffer: the staging copy below is a single-thread memcpy (~25 GB/s) and halves what the link gives.
+    // The copy is stream-ordered like every upload, so under that switch such a buffer must stay unchanged until the call that consumes the cloud
+    // has returned (mrgfe.h) — the reference's keyframe clouds are immutable ConstPtr clouds.  Off by default: the add / set call is done with the
+    // caller's memory when it returns.
+    if (ctx->zero_copy_uploads && n * 16 >= (size_t(64) << 10)) {
         hipPointerAttribute_t attr;
         if (hipPointerGetAttributes(&attr, xyzi) == hipSuccess && attr.type == hipMemoryTypeHost) {
             MRGFE_HIP_CHECK(hipMemcpyAsync(d_dst, xyzi, n * 16, hipMemcpyHostToDevice, ctx->stream));
@@ -380,6 +380,7 @@ static int ctx_create(int device_id, int high_priority, int reserve_cus, const m
     if (like) {
         c->cu_mask = like->cu_mask;
         c->cu_count = like->cu_count;
+        c->zero_copy_uploads = like->zero_copy_uploads;
     } else if (reserve_cus == MRGFE_RESERVE_AUTO && c->cu_count < 8) {
         // nothing sensible to split off: a plain context
     } else if (reserve_cus > 0 || reserve_cus == MRGFE_RESERVE_AUTO) {
@@ -444,6 +445,13 @@ int mrgfe_pin_host_buffer(mrgfe_ctx* ctx, void* p, size_t bytes)
     if (!ctx || !p || bytes == 0) { mrgfe::set_error("mrgfe_pin_host_buffer: NULL context / pointer or empty range"); return MRGFE_ERR_INVALID; }
     MRGFE_TRY(ctx->bind());
     MRGFE_HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return MRGFE_OK;
+}
+
+int mrgfe_ctx_set_zero_copy_uploads(mrgfe_ctx* ctx, int on)
+{
+    if (!ctx) { mrgfe::set_error("mrgfe_ctx_set_zero_copy_uploads: NULL context"); return MRGFE_ERR_INVALID; }
+    ctx->zero_copy_uploads = on != 0;
     return MRGFE_OK;
 }
 

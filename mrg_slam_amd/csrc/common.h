@@ -155,6 +155,7 @@ struct mrgfe_ctx {
     hipEvent_t   up_ev[2] = {nullptr, nullptr};
     bool         up_busy[2] = {false, false};
     int          up_next = 0;
+    bool         zero_copy_uploads = false;   // mrgfe_ctx_set_zero_copy_uploads: clouds in page-locked host memory go up by DMA from the caller's buffer
     hipEvent_t   ev_fit[4] = {nullptr, nullptr, nullptr, nullptr};  // around the passes of nn_fitness_batch
     int          priority = 0;                  // > 0: streams at the device's highest priority, < 0: at its lowest (throughput work beside latency-critical rounds)
     std::vector<uint32_t> cu_mask;              // non-empty: every stream of this context is confined to these compute units (mrgfe_ctx_create_reserving)

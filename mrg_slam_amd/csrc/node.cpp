@@ -335,6 +335,9 @@ int mrgfe_node_create(int n_members, const int* device_ids, const mrgfe_reg_para
         m->device = device_ids[i];
         node->members.push_back(m);
         st = mrgfe_ctx_create(m->device, &m->ctx);
+        // (the node's clouds are declared by pointer and uploaded inside mrgfe_node_align, which returns after the members have finished: page-locked
+        // ones can always go up by DMA from where they lie)
+        if (st == MRGFE_OK) st = mrgfe_ctx_set_zero_copy_uploads(m->ctx, 1);
         if (st == MRGFE_OK) st = mrgfe_batch_create(m->ctx, params, &m->batch);
     }
     if (st != MRGFE_OK) {

@@ -172,14 +172,15 @@ def test_allocation_failures_in_node_align_name_the_member():
 
 
 def test_page_locked_host_clouds_upload_by_dma_with_the_same_results():
-    """mrgfe.h (mrgfe_pin_host_buffer): a cloud in page-locked memory is read by DMA straight from the caller's buffer, a pageable one goes through the
-    staging ring.  Same bytes in HBM either way: the batch records must be byte-identical, also for clouds that start in the MIDDLE of a pinned range
+    """mrgfe.h (mrgfe_ctx_set_zero_copy_uploads): with the switch on a cloud in page-locked memory is read by DMA straight from the caller's buffer, a
+    pageable one goes through the staging ring.  Same bytes in HBM either way: the batch records must be byte-identical, also for clouds that start in the MIDDLE of a pinned range
     and for one below the direct-upload floor (64 KB)."""
     from mrg_slam_amd import BatchMatcher, Context
     from mrg_slam_amd._lib import lib
 
     rng = np.random.default_rng(3)
     ctx = Context()
+    ctx.set_zero_copy_uploads(True)
     pairs = []
     for k, n in enumerate((9000, 30000, 2000)):
         t = small_cloud(n, seed=40 + k)
