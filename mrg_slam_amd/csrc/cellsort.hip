@@ -251,8 +251,8 @@ __global__ __launch_bounds__(256) void rs_scan_chunks_kernel(const Slice* __rest
 }
 
 constexpr uint32_t kOwnScanBlks = 512;  // tiles of a sort (all its problems) up to which the scatter kernel does the scan of the histograms as well
-// pass 3: stable scatter. The tile is consumed in 8 rounds of 256 keys; inside a round the rank of a key among equal
-// digits is (keys of earlier rounds) + (keys of earlier waves) + (lower lanes of its own wave, by ballot matching).
+// pass 3: stable scatter. The tile is 8 rounds of 256 keys; the rank of a key among equal digits is (keys of earlier rounds and of
+// earlier waves of its round: a scan over the 32 (round, wave) counts of the digit) + (lower lanes of its own wave, by ballot matching).
 // kIota: the values are the element indices 0 .. n-1 of the problem (first pass of a sort of (key, index) pairs: nobody has to write or read them)
 // kOwnScan (a sort of a few tiles, bound by its launches): `hist` holds the tiles' COUNTS as rs_hist_kernel left them and every workgroup adds up
 // column d over the tiles before its own and over all of them itself — rs_scan_kernel's work, 64 KB of L2 reads per workgroup of a 130k-key
@@ -264,9 +264,8 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint32_t* __restr
 {
     const Slice s = slices[blockIdx.y];
     if (blockIdx.x >= s.nblk) return;
-    __shared__ uint32_t goff[256];        // global offset of this tile's first key of each digit
-    __shared__ uint32_t seen[256];        // keys of each digit consumed in earlier rounds
-    __shared__ uint32_t wcount[4][256];   // per-wave digit counts of the current round
+    __shared__ uint32_t goff[256];             // global offset of this tile's first key of each digit
+    __shared__ uint16_t cnt[kTile / 256][4][256];  // keys of each digit per (round, wavefront); after the scan: the tile's keys of the digit BEFORE that (round, wavefront)
     if (kOwnScan) {
         __shared__ uint32_t lds[8];
         const uint32_t* col = hist + (size_t)s.blk_off * 256 + threadIdx.x;
@@ -288,37 +287,61 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint32_t* __restr
     } else {
         goff[threadIdx.x] = digit_base[(size_t)blockIdx.y * 256 + threadIdx.x] + hist[(size_t)(s.blk_off + blockIdx.x) * 256 + threadIdx.x];
     }
-    seen[threadIdx.x] = 0;
+    {
+        uint32_t* z = reinterpret_cast<uint32_t*>(&cnt[0][0][0]);
 #pragma unroll
-    for (int w = 0; w < 4; ++w) wcount[w][threadIdx.x] = 0;
+        for (int u = 0; u < (kTile / 256) * 4 * 256 / 2 / 256; ++u) z[u * 256 + threadIdx.x] = 0u;
+    }
     __syncthreads();
     const uint32_t base = blockIdx.x * kTile;
     const int      lane = lane_id(), w = wave_id();
+    // The tile is eight rounds of 256 keys (round k: keys base + 256 k + thread: the order of the input).  All keys and values first, then every round's
+    // match; ONE barrier; thread d turns column d of the 32 (round, wavefront) counts into exclusive prefixes; one more barrier; every key knows
+    // its place.  (Round 4 ran the rounds one after the other with three barriers each and a load at the top of each: 24 barriers and eight memory
+    // round trips per tile, the wavefronts parked 80 % of their cycles.)
+    uint32_t key8[kTile / 256], val8[kTile / 256], rank8[kTile / 256];
+#pragma unroll
     for (int k = 0; k < kTile / 256; ++k) {
         const uint32_t i = base + k * 256 + threadIdx.x;
-        const bool     valid = i < s.n;
-        uint32_t key = 0, val = 0;
-        if (valid) { key = keys[s.off + i]; val = kIota ? i : vals[s.off + i]; }
-        const uint32_t d = (key >> shift) & 255u;
-        const uint64_t active = __ballot(valid);
-        const uint64_t m = wave_match_digit8(d, active);
-        const uint32_t lane_rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (valid && lane_rank == 0) wcount[w][d] = __popcll(m);
-        __syncthreads();
-        if (valid) {
-            uint32_t pre = seen[d];
-            for (int ww = 0; ww < w; ++ww) pre += wcount[ww][d];
-            const uint32_t pos = s.off + goff[d] + pre + lane_rank;
-            keys_out[pos] = key;
-            vals_out[pos] = val;
+        key8[k] = i < s.n ? keys[s.off + i] : 0u;
+    }
+    if (!kIota) {
+#pragma unroll
+        for (int k = 0; k < kTile / 256; ++k) {
+            const uint32_t i = base + k * 256 + threadIdx.x;
+            val8[k] = i < s.n ? vals[s.off + i] : 0u;
         }
-        __syncthreads();
-        {
-            const uint32_t t = threadIdx.x;
-            seen[t] += wcount[0][t] + wcount[1][t] + wcount[2][t] + wcount[3][t];
-            wcount[0][t] = 0; wcount[1][t] = 0; wcount[2][t] = 0; wcount[3][t] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kTile / 256; ++k) {
+        const bool     valid = base + k * 256 + threadIdx.x < s.n;
+        const uint32_t d = (key8[k] >> shift) & 255u;
+        const uint64_t m = wave_match_digit8(d, __ballot(valid));
+        rank8[k] = __popcll(m & ((1ull << lane) - 1ull));
+        if (valid && rank8[k] == 0) cnt[k][w][d] = static_cast<uint16_t>(__popcll(m));
+    }
+    __syncthreads();
+    {
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < kTile / 256; ++k)
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                const uint32_t c = cnt[k][ww][threadIdx.x];
+                cnt[k][ww][threadIdx.x] = static_cast<uint16_t>(run);
+                run += c;
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kTile / 256; ++k) {
+        const uint32_t i = base + k * 256 + threadIdx.x;
+        if (i < s.n) {
+            const uint32_t d = (key8[k] >> shift) & 255u;
+            const uint32_t pos = s.off + goff[d] + cnt[k][w][d] + rank8[k];
+            keys_out[pos] = key8[k];
+            vals_out[pos] = kIota ? i : val8[k];
         }
-        __syncthreads();
     }
 }
 
