@@ -12,6 +12,6 @@ for d in ("pmc_build1","pmc_build2"):
         k=r["Kernel_Name"].split("(")[0].replace("mrgfe::","").replace("void ","")
         agg[k][r["Counter_Name"]]+=float(r["Counter_Value"])
         if (k,r["Dispatch_Id"]) not in seen: seen.add((k,r["Dispatch_Id"])); cnt[k]+=1
-    for k in ("ndt_leaf_sums_kernel","rs_scatter_kernel<false, false>","rs_scatter_kernel<true, false>","ndt_cellkey_kernel","rs_hist_kernel"):
+    for k in ("ndt_leaf_sums_kernel","ndt_leaf_sums4_kernel","rs_scatter_kernel<false, false>","rs_scatter_kernel<true, false>","ndt_cellkey_kernel","rs_hist_kernel"):
         if k in agg: print(d,k,cnt[k],{c:round(v/cnt[k]) for c,v in agg[k].items()})
 PY
