@@ -35,6 +35,28 @@ def test_radix_sort_is_a_stable_sort(ctx, n, bits):
     np.testing.assert_array_equal(ov, order.astype(np.uint32))
 
 
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 6, 17, 64, 200, 256])
+def test_radix_sort_with_m_distinct_digits_per_wavefront(ctx, m):
+    """The kernels match the lanes of a wavefront that hold the same digit by peeling the first few distinct digits and fall back to the bit-by-bit
+    match for what is left (dev_utils.h wave_match_digit8, wave_hist_add): m distinct digits interleaved lane by lane — below, at and above the peel
+    depth — in BOTH passes of a 16-bit sort, plus runs of 70 equal keys that cross wavefront and round boundaries."""
+    from mrg_slam_amd._lib import check, lib
+
+    n = 50001
+    i = np.arange(n, dtype=np.uint64)
+    lo = (i * 3) % m
+    hi = ((i // 7) * 5) % m
+    keys = (lo | (hi << 8)).astype(np.uint32)
+    keys[20000:20070] = keys[20000]
+    keys[30000:33000] = np.repeat(keys[30000:30000 + 43], 70)[:3000]
+    vals = np.arange(n, dtype=np.uint32)
+    ok, ov = np.empty_like(keys), np.empty_like(vals)
+    check(lib().mrgfe_dbg_sort_pairs(ctx._h, keys.ctypes.data_as(_u32p), vals.ctypes.data_as(_u32p), n, 16, ok.ctypes.data_as(_u32p), ov.ctypes.data_as(_u32p)))
+    order = np.argsort(keys, kind="stable")
+    np.testing.assert_array_equal(ok, keys[order])
+    np.testing.assert_array_equal(ov, order.astype(np.uint32))
+
+
 @pytest.mark.parametrize("n,bits", [(1048577, 20), (1150000, 9), (2500003, 31), (6600000, 26)])
 def test_radix_sort_of_thousands_of_tiles(ctx, n, bits):
     """More than 512 tiles in one problem (the map cloud's 6.5 M points): the digit counts are scanned chunk by chunk (rs_chunk_sums_kernel,
