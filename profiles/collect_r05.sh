@@ -3,6 +3,8 @@
 #   gpurun --timeout 1150 -- "bash profiles/collect_r05.sh trace r05 $(git rev-parse --short HEAD)"
 #   gpurun --timeout 1150 -- "bash profiles/collect_r05.sh pmc r05 $(git rev-parse --short HEAD)"
 #   gpurun --timeout 1150 -- "bash profiles/collect_r05.sh soak r05 $(git rev-parse --short HEAD)"
+#   gpurun --timeout 1150 -- "bash profiles/collect_r05.sh soak2 r05 $(git rev-parse --short HEAD)"
+#   gpurun --timeout 1150 -- "bash profiles/collect_r05.sh parity r05 $(git rev-parse --short HEAD)"
 # then, back in the container:  python profiles/summarize.py r05
 # As in round 4 every traced command launches the dominant kernel of its workload only in steps of that workload.  New in round 5: the headline's
 # timed region keeps TWO batches in flight (bench.py --in-flight 2, mrgfe_batch_align_async), so config[1] is traced twice — one step at a time
@@ -43,6 +45,21 @@ if [ "$part" = trace ]; then
     : > gpurun_out/inproc_$tag.jsonl
     for g in 1 2 4 8; do python3 bench.py --mode shard --inproc --gpus $g --steps 6 --warmup 2 2>/dev/null | tail -1 >> gpurun_out/inproc_$tag.jsonl; done
     for b in 32 64 128; do python3 bench.py --no-cpu --no-extras --shard-steps 0 --batch $b --steps 10 2>/dev/null | tail -1 > gpurun_out/bench_${tag}_b$b.json; done
+elif [ "$part" = parity ]; then
+    # the stated-size parity sweeps beyond what bench.py's line holds, with the round-5 library (new sort kernels under every grid; PCL_NDT_HIP in the sweep)
+    python3 profiles/config1_parity_ranks.py 1,2,3,4,5,6,7 2> gpurun_out/config1_parity_ranks_$tag.err | tail -1 > gpurun_out/config1_parity_ranks_$tag.json
+    echo "config[1] ranks done"
+    python3 profiles/ndt_fullsize_sweep.py 64 2> gpurun_out/ndt_fullsize_sweep_$tag.err | tail -1 > gpurun_out/ndt_fullsize_sweep_$tag.json
+    echo "full-size sweep done"
+    python3 profiles/config2_parity.py 96 2> gpurun_out/config2_parity_$tag.err | tail -1 > gpurun_out/config2_parity_$tag.json
+    echo "parity done"
+elif [ "$part" = soak2 ]; then
+    # the prefilter rows and the rows around the alignment, randomised (the radix sort under their grids changed in round 5)
+    python3 profiles/soak_filters.py 3000 2> gpurun_out/soak_filters_$tag.err | tail -1 > gpurun_out/soak_filters_$tag.json
+    python3 profiles/soak_misc.py 3000 2> gpurun_out/soak_misc_$tag.err | tail -1 > gpurun_out/soak_misc_$tag.json
+    echo "filter / misc soaks done"
+    python3 profiles/loop_parity_seeds.py $(python3 -c "print(','.join(str(4251 + i) for i in range(16)))") 2> gpurun_out/loop_parity_seeds2_$tag.err | tail -1 > gpurun_out/loop_parity_seeds2_$tag.json
+    echo "soak2 done"
 elif [ "$part" = soak ]; then
     python3 profiles/soak.py 4000 1200 500 > gpurun_out/soak_$tag.json 2> gpurun_out/soak_$tag.err
     echo "registration soak done"

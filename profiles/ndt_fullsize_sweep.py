@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-from mrg_slam_amd import Context, NdtHip, distance_filter, synth  # noqa: E402
+from mrg_slam_amd import Context, NdtHip, PclNdtHip, distance_filter, synth  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 12
@@ -31,13 +31,20 @@ for (search, res, eps) in itertools.product(("DIRECT1", "DIRECT7", "DIRECT26", "
     for j, k in enumerate(idx):
         rel = synth.rel_pose(poses[k], poses[k + 1])
         cases.append((search, res, eps, k, np.eye(4) if j % 4 == 3 else synth.warm_guess(rel, 8000 + k)))
+# round 5: registration_method "NDT" = pcl::NormalDistributionsTransform (PCL_NDT_HIP): its one neighbourhood (radius search over the voxel centroids),
+# the same resolutions, eps 0.1 (mrg_slam's value: ONE Newton iteration by PCL's rule) / 0.001 / 1e-5 (runs to the zero-step or iteration limit)
+for (res, eps) in itertools.product((0.5, 1.0, 2.0), (0.1, 1e-3, 1e-5)):
+    for j, k in enumerate(idx[:: max(1, len(idx) // 16)]):
+        rel = synth.rel_pose(poses[k], poses[k + 1])
+        cases.append(("PCL_NDT", res, eps, k, np.eye(4) if j % 4 == 3 else synth.warm_guess(rel, 8000 + k)))
 t0 = time.time()
 hip = []
 regs = {}
 for (search, res, eps, k, guess) in cases:
     key = (search, res, eps)
     if key not in regs:
-        regs[key] = NdtHip(resolution=res, transformation_epsilon=eps, maximum_iterations=64, search=search, ctx=ctx)
+        regs[key] = (PclNdtHip(resolution=res, transformation_epsilon=eps, maximum_iterations=64, ctx=ctx) if search == "PCL_NDT" else
+                     NdtHip(resolution=res, transformation_epsilon=eps, maximum_iterations=64, search=search, ctx=ctx))
     r = regs[key]
     r.setInputTargetDevice(dev[k].data_ptr(), len(host[k]))
     r.setInputSourceDevice(dev[k + 1].data_ptr(), len(host[k + 1]))
@@ -48,7 +55,8 @@ t_hip = time.time() - t0
 
 def oracle_case(c):
     search, res, eps, k, guess = c
-    o = orc.Ndt(resolution=res, transformation_epsilon=eps, maximum_iterations=64, num_threads=2, search=search)
+    o = (orc.PclNdt(resolution=res, transformation_epsilon=eps, maximum_iterations=64, num_threads=2) if search == "PCL_NDT" else
+         orc.Ndt(resolution=res, transformation_epsilon=eps, maximum_iterations=64, num_threads=2, search=search))
     o.setInputTarget(host[k])
     o.setInputSource(host[k + 1])
     o.align(guess)
@@ -57,7 +65,7 @@ def oracle_case(c):
 
 with ThreadPoolExecutor(max(1, min(16, (os.cpu_count() or 2) // 2))) as ex:
     ora = list(ex.map(oracle_case, cases))
-out = {"workload": f"{n_pairs} pairs of ~129k points x 4 neighbourhoods x 3 resolutions x 2 eps = {len(cases)} single registrations, every fourth from the identity", "by_search": {},
+out = {"workload": f"{n_pairs} pairs of ~129k points x 4 neighbourhoods x 3 resolutions x 2 eps, plus up to 16 pairs x 3 resolutions x 3 eps through PCL_NDT_HIP = {len(cases)} single registrations, every fourth from the identity", "by_search": {},
        "hip_seconds": t_hip, "seconds": None}
 over = []
 for (c, h, o) in zip(cases, hip, ora):
