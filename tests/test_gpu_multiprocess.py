@@ -121,3 +121,26 @@ def test_bench_shard_mode_two_gloo_ranks_print_the_one_rank_digest(tmp_path):
     l3 = json.loads([ln for ln in three.stdout.splitlines() if ln.startswith("{")][-1])
     assert l3["n_gpus"] == 3 and l3["config"]["blocks"] == [[0, 86], [86, 85], [171, 85]] and l3["config"]["record_gather"] == "host"
     assert l3["inputs_sha256_16"] == s1["inputs_sha256_16"] and l3["records_sha256_16"] == s1["records_sha256_16"]
+
+
+def test_bench_default_mode_under_torchrun_two_gloo_ranks(tmp_path):
+    """The driver's SCALE launch line — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N … bench.py --gpus N --steps K --warmup W`, the
+    default (weak) mode with two batches in flight per rank and the record all-gather of every collected batch — with N = 2 gloo ranks on the one card
+    (BENCH_DIST_BACKEND=gloo) and a small batch: ONE JSON line from rank 0, n_gpus 2, twice the pairs of a rank per step in `value`."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BENCH_CACHE=str(tmp_path / "cache"), OMP_NUM_THREADS="8", BENCH_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "16", "--no-cpu", "--no-extras", "--shard-steps", "0"]
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["steps_in_flight"] == 2 and line["value"] > 0
+    assert abs(line["value"] - 2 * 16 * 4 / (line["ms_per_step"] * 4e-3)) < 1e-6 * line["value"]
+    assert line["parity_vs_oracle"] is None or line["parity_vs_oracle"].get("pairs_over_bar", 0) == 0
