@@ -22,8 +22,14 @@ N > 1     = `python bench.py --gpus N` starts the N ranks itself (child processe
             with max_range = inf, RCCL all-gather of the records, replay of the reference's best-candidate rule
             (loop_detector.cpp:126-145) per new keyframe.  Strong scaling.  The default run also measures a few steps of it
             and reports them under "config3_shard" (never as `value`).
+Timed     = K steps with TWO batches in flight (--in-flight 2, round 5: mrgfe_batch_align_async / _wait on two contexts; a step submits its batch
+region      and collects the one submitted two steps earlier; everything still in flight is collected before the closing synchronisation).  The
+            same K steps one at a time are measured beside it (`value_one_step_at_a_time`; --in-flight 1 makes that the timed region).
 Output    = ONE JSON line (rank 0) with `roofline` (derivative kernel: algorithmic bytes / HIP-event time on the launch
-            stream) and `cpu_baseline` (the CPU oracle, kind "port", timed on a bounded sample of the same pairs).
+            stream; under pipelining two launches share the chip: `aggregate_*` and `one_step_at_a_time` beside the per-launch figure) and
+            `cpu_baseline` (the CPU oracle, kind "port", timed on a bounded sample of the same pairs).  Side measurements, never `value`:
+            `value_host_pointers` (both clouds of every pair over PCIe inside the step: pageable, page-locked, page-locked + two batches in
+            flight), `gpu_split_ms_per_step`, `pipeline_shape`, `config2_gicp`, `pcl_ndt`, `config3_shard` (+ `two_batches_in_flight`), `soak_over_bar`.
 """
 from __future__ import annotations
 
