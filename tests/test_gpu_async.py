@@ -76,3 +76,51 @@ def test_misuse_returns_error_codes():
     _queue(bm, tgt, pairs)
     bm.align_async()
     del bm
+
+
+def test_zero_copy_uploads_with_two_batches_in_flight():
+    """mrgfe_ctx_set_zero_copy_uploads + mrgfe_batch_align_async: page-locked clouds are read by DMA while the OTHER batch aligns; the clouds stay
+    unchanged until the wait, as the switch's contract asks.  Records equal the synchronous ones from pageable copies."""
+    import ctypes as C
+
+    from mrg_slam_amd import BatchMatcher, Context
+    from mrg_slam_amd._lib import lib
+
+    rng = np.random.default_rng(11)
+    clouds = [small_cloud(20000 + 500 * k, 900 + k) for k in range(4)]
+    guesses = []
+    for _ in range(3):
+        g = np.eye(4)
+        g[:3, 3] = rng.uniform(-0.2, 0.2, 3)
+        guesses.append(g)
+
+    def fill(bm, cs):
+        bm.clear()
+        for k in range(3):
+            bm.add_pair(bm.add_target(cs[k]), cs[k + 1][: len(cs[k + 1]) - 100], guesses[k])
+
+    ref = BatchMatcher(ctx=Context())
+    fill(ref, clouds)
+    want = ref.align(float("inf"))
+    ctxs = [Context(), Context()]
+    slab = np.empty((sum(len(c) for c in clouds), 4), np.float32)
+    assert lib().mrgfe_pin_host_buffer(ctxs[0]._h, slab.ctypes.data_as(C.c_void_p), slab.nbytes) == 0
+    try:
+        o, pinned = 0, []
+        for c in clouds:
+            v = slab[o:o + len(c)]
+            v[:] = c
+            o += len(c)
+            pinned.append(v)
+        bms = []
+        for c in ctxs:
+            c.set_zero_copy_uploads(True)
+            bms.append(BatchMatcher(ctx=c))
+        for rep in range(3):
+            for bm in bms:
+                fill(bm, pinned)
+                bm.align_async(float("inf"))
+            for bm in bms:
+                assert bm.wait().tobytes() == want.tobytes()
+    finally:
+        assert lib().mrgfe_unpin_host_buffer(ctxs[0]._h, slab.ctypes.data_as(C.c_void_p)) == 0

@@ -169,3 +169,42 @@ def test_rccl_gather_with_one_member(monkeypatch):
     got = node.align(float("inf"))
     assert node.last_gather() == "rccl"
     assert got.tobytes() == want.tobytes()
+
+
+def test_node_reads_page_locked_clouds_by_dma_with_the_same_records():
+    """The members of a node run with zero-copy uploads on (mrgfe.h: the node's clouds are declared by pointer and uploaded inside mrgfe_node_align):
+    clouds of 64 KB and more in page-locked memory go up by DMA from the caller's slab, smaller and pageable ones through the staging ring — keyed
+    (resident) targets included.  Same records as one batch fed pageable copies."""
+    import ctypes as C
+
+    from mrg_slam_amd import Context, NodeMatcher
+    from mrg_slam_amd._lib import NDT_HIP, lib
+
+    targets, pairs = _workload(n_targets=3, n_pairs=9, sizes=(9000, 5200, 4400))
+    want = _one_batch(_params(NDT_HIP), targets, pairs)
+    ctx = Context()
+    total = sum(len(t) for t in targets) + sum(len(p[1]) for p in pairs)
+    slab = np.empty((total, 4), np.float32)
+    assert lib().mrgfe_pin_host_buffer(ctx._h, slab.ctypes.data_as(C.c_void_p), slab.nbytes) == 0
+    try:
+        o = 0
+
+        def put(a):
+            nonlocal o
+            v = slab[o:o + len(a)]
+            v[:] = a
+            o += len(a)
+            return v
+
+        p_targets = [put(t) for t in targets]
+        p_pairs = [(ti, put(src), g) for ti, src, g in pairs]
+        node = NodeMatcher([0, 0], _params(NDT_HIP))
+        for rep in range(2):  # (the second call finds the keyed target resident)
+            node.clear()
+            tids = [node.add_target(t, key=(7 if k == 0 else 0)) for k, t in enumerate(p_targets)]
+            for ti, src, guess in p_pairs:
+                node.add_pair(tids[ti], src, guess)
+            got = node.align(float("inf"))
+            assert got.tobytes() == want.tobytes()
+    finally:
+        assert lib().mrgfe_unpin_host_buffer(ctx._h, slab.ctypes.data_as(C.c_void_p)) == 0
