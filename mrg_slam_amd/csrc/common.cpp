@@ -451,6 +451,7 @@ int mrgfe_pin_host_buffer(mrgfe_ctx* ctx, void* p, size_t bytes)
 int mrgfe_ctx_set_zero_copy_uploads(mrgfe_ctx* ctx, int on)
 {
     if (!ctx) { mrgfe::set_error("mrgfe_ctx_set_zero_copy_uploads: NULL context"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(ctx);  // (an asynchronous align of a batch on this context holds the lock: the switch takes effect behind it)
     ctx->zero_copy_uploads = on != 0;
     return MRGFE_OK;
 }
