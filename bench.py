@@ -208,6 +208,146 @@ def sha16(arrays) -> str:
     return h.hexdigest()[:16]
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# the driver's line
+# ------------------------------------------------------------------------------------------------------------------------
+LINE_BUDGET = 4096  # bytes; round 5's 20 KB line was not parsed by the driver (BENCH_r05.json: parsed null)
+EXTRAS_FILE = "bench_extras.json"
+
+
+def _sig(x, n=5):
+    """floats to n significant digits (the line is a summary; the full-precision record is the extras file)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}") if np.isfinite(x) else None
+    if isinstance(x, (np.floating, np.integer)):
+        return _sig(x.item(), n)
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+def _pick(d, *keys):
+    return {k: d.get(k) for k in keys} if isinstance(d, dict) else None
+
+
+def compact_line(full: dict) -> dict:
+    """The ONE stdout line of a run: the contract's keys + `roofline` + `cpu_baseline` + the parity counts, under LINE_BUDGET bytes.  Everything else
+    `full` holds (config[2] GICP, PCL NDT, the config[3] leg's phase times, notes) is written to EXTRAS_FILE and to stderr.
+    `roofline` describes the dominant kernel ALONE on the chip: when the timed region keeps two batches in flight its launches overlap the other
+    batch's and their HIP-event durations are those of two launches side by side — so the figure comes from the same K steps run one at a time
+    just before the timed region (the shape profiles/*_rocprof_summary.md traces: `--in-flight 1`), and the timed region's own per-launch and
+    aggregate figures ride beside it as `in_timed_region`."""
+    g = full.get
+    out = {k: g(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = g("config") or {}
+    out["config"] = {"workload": str(cfg.get("workload_short") or cfg.get("workload", ""))[:320]}
+    for k in ("steps_in_flight", "pairs_per_gpu_per_step", "points_per_scan", "parallelism", "record_gather"):
+        if cfg.get(k) is not None:
+            out["config"][k] = cfg[k]
+    roof = g("roofline")
+    if roof:
+        iso = roof.get("one_step_at_a_time") or None
+        r = {"kernel": roof.get("kernel"), "bound": "hbm", "limited_by": roof.get("bound"), "peak": roof.get("peak"), "unit": roof.get("unit")}
+        src = iso if iso else roof
+        r.update({"achieved": src.get("achieved"), "frac": src.get("frac"), "avg_launch_ms": src.get("avg_launch_ms"), "launches": src.get("launches"),
+                  "alg_bytes_per_launch": roof.get("alg_bytes_per_launch"), "traffic": roof.get("traffic"), "valu_busy": roof.get("valu_busy"),
+                  "pmc_profile": roof.get("pmc_profile"),
+                  "measured": "HIP events, the K steps one at a time before the timed region (kernel alone on the chip)" if iso else "HIP events over the timed region"})
+        if iso:
+            r["in_timed_region"] = {"avg_launch_ms": roof.get("avg_launch_ms"), "frac_per_overlapped_launch": roof.get("frac"),
+                                    "aggregate_frac": roof.get("aggregate_frac_over_the_timed_region")}
+        out["roofline"] = r
+    else:
+        out["roofline"] = None
+    cpu = g("cpu_baseline")
+    out["cpu_baseline"] = dict(_pick(cpu, "value", "unit", "cores", "kind"), sample=cpu.get("sample_short") or str(cpu.get("sample", ""))[:160]) if cpu else None
+    par = g("parity_vs_oracle")
+    out["parity_vs_oracle"] = _pick(par, "pairs", "pairs_over_bar", "max_dt_m", "max_dr_rad", "pairs_with_other_iterations_or_convergence") if par else None
+    soak = g("soak_over_bar")
+    if soak:
+        def kn(keys):
+            k = n = 0
+            for key in keys:
+                a, b = str(soak.get(key, "0/0")).split("/")
+                k, n = k + int(a), n + int(b)
+            return f"{k}/{n}"
+        out["soak_over_bar"] = {"ndt": soak.get("ndt"), "ndt_reference_order": soak.get("ndt_reference_order"), "pcl_ndt": soak.get("pcl_ndt"),
+                                "other": kn(("icp_gicp_vgicp_small_gicp", "pcl_gicp_serial", "pcl_gicp_omp", "icp_reciprocal")), "worst_m": soak.get("worst_m")}
+    seq = g("value_one_step_at_a_time")
+    if seq:
+        out["value_one_step_at_a_time"] = seq.get("value")
+    hp = g("value_host_pointers")
+    if hp:
+        pin = hp.get("pinned_host_clouds") or {}
+        out["value_host_pointers"] = {"pageable": hp.get("value"), "page_locked": pin.get("value"),
+                                      "page_locked_two_in_flight": (pin.get("two_batches_in_flight") or {}).get("value")}
+    for k in ("single_pair_latency_ms", "evaluations_launched_per_alignment", "iterations_per_alignment", "mean_valid_neighbours", "converged"):
+        if g(k) is not None:
+            out[k] = g(k)
+    sp = g("gpu_split_ms_per_step")
+    if sp:
+        out["set_target_ms_per_step"] = sp.get("set_target_ms")
+    c3 = g("config3_shard")
+    if c3:
+        ph = (c3.get("per_rank_phases_ms") or [{}])[0]
+        p3 = c3.get("parity_vs_oracle") or {}
+        out["config3"] = {"pairs": c3.get("pairs_total"), "ms_per_step": c3.get("ms_per_step"), "alignments_per_s": c3.get("alignments_per_s"),
+                          "rounds_ms": ph.get("alignment_rounds"), "fitness_ms": ph.get("fitness_passes"), "build_ms": ph.get("build_targets"),
+                          "two_in_flight_ms": (c3.get("two_batches_in_flight") or {}).get("ms_per_step"),
+                          "fitness_frac": (c3.get("roofline_fitness") or {}).get("frac"), "derivative_frac": (c3.get("roofline") or {}).get("frac"),
+                          "pairs_over_bar": p3.get("pairs_over_bar"), "best_candidate_mismatches": p3.get("best_candidate_mismatches"),
+                          "records_sha256_16": c3.get("records_sha256_16")}
+        for k in ("detect_batched", "shard_of_8_ms"):
+            if c3.get(k) is not None:
+                out["config3"][k] = c3[k]
+    c2 = g("config2_gicp")
+    if c2:
+        out["config2_gicp"] = {}
+        for m in ("GICP_HIP", "SMALL_GICP_HIP"):
+            if isinstance(c2.get(m), dict):
+                e = c2[m]
+                out["config2_gicp"][m] = {"frame_ms": e.get("frame_ms"), "batch32_ms": (e.get("batch_32_candidates") or {}).get("ms_per_call"),
+                                          "frames_over_bar": (e.get("parity_vs_oracle") or {}).get("frames_over_bar"),
+                                          "knn_frac": (e.get("roofline_knn") or {}).get("frac"), "linearize_frac": (e.get("roofline_linearize") or {}).get("frac")}
+    for k in ("records_sha256_16", "raw_inputs_as_in_the_build_container"):
+        if g(k) is not None:
+            out[k] = g(k)
+    out["extras"] = EXTRAS_FILE
+    out = _sig(out)
+    # the budget is a promise to the driver: shed the optional blocks, largest first, rather than print a line it cannot parse
+    for k in ("config2_gicp", "config3", "soak_over_bar", "value_host_pointers"):
+        if len(json.dumps(out)) < LINE_BUDGET:
+            break
+        out.pop(k, None)
+    return out
+
+
+def emit(full: dict, full_line: bool = False) -> None:
+    """rank 0's output: the full record to stderr and to EXTRAS_FILE (gpurun_out/ when it exists, so that it travels back from the GPU box), then the
+    compact line as the ONLY stdout line (`--full-line`: the full record on stdout instead, for the tools under profiles/ that read its side blocks)."""
+    text = json.dumps(full)
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, EXTRAS_FILE), "w") as f:
+                    f.write(text + "\n")
+                break
+            except OSError:
+                pass
+    if full_line:
+        print(text)
+    else:
+        print("[bench extras] " + text, file=sys.stderr)
+        line = json.dumps(compact_line(full))
+        assert len(line) < LINE_BUDGET, len(line)
+        print(line)
+    sys.stdout.flush()
+
+
 # digests of the RAW synthetic scans of the default workloads as generated in the build container (mrg_slam_amd/synth.py is built from IEEE
 # + - * / sqrt alone, tests/test_synth_reproducible.py): the same value must come out on every host
 EXPECTED_RAW_INPUTS = {"config1_rank0_257_scans": "656edc98f6ac7ec3", "config3_64_keyframes": "dc76f90d0d1b35a7"}
@@ -450,7 +590,7 @@ def run_inproc(args, loop_raw, loop_pairs):
     in_digest = hashlib.sha256(b"".join(np.ascontiguousarray(c).tobytes() for c in l_host)).hexdigest()[:16]
     err = [float(np.linalg.norm(np.asarray(res[i]["T"]).reshape(4, 4).T[:3, 3] - loop_pairs[i][3][:3, 3])) for i in range(len(loop_pairs))]
     print(f"[bench inproc] per-step ms: " + " ".join(f"{v:.2f}" for v in step_ms), file=sys.stderr)
-    print(json.dumps({
+    emit({
         "metric": "scan-pair alignments/sec (NDT, ~120k pts, 1.0 m voxel) at 1/2/4/8 MI355X; HBM GB/s achieved", "value": len(loop_pairs) * args.steps / elapsed,
         "unit": "alignments/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32 per-pair terms, f64 accumulation", "data": "synthetic",
@@ -463,7 +603,7 @@ def run_inproc(args, loop_raw, loop_pairs):
         "loops_found": int(sum(b is not None for b, _ in best)), "median_translation_error_vs_truth_m": float(np.median(err)),
         "mean_points_per_scan": float(np.mean([len(c) for c in l_host])),
         "roofline": None, "cpu_baseline": None,
-        "note": "side mode (never the driver's line): the node path behind the C ABI; compare records_sha256_16 with `--mode shard` on one rank"}))
+        "note": "side mode (never the driver's line): the node path behind the C ABI; compare records_sha256_16 with `--mode shard` on one rank"}, args.full_line)
 
 
 def main():
@@ -492,8 +632,10 @@ def main():
     ap.add_argument("--no-shard-parity", action="store_true", help="skip the 256-pair oracle loop of the config[3] leg (parity_vs_oracle of config3_shard)")
     ap.add_argument("--soak-cases", type=int, default=120, help="random small scenes of the parity soak printed as soak_over_bar (0 disables; pcl::GICP / reciprocal ICP get a third as many)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs behind the main line (setInputTarget / align split, host-pointer rate, pipeline shape, config[2] GICP)")
-    ap.add_argument("--latency", action="store_true", help="also time single-pair setInputTarget+align latency (extra, differently sized launches of the "
-                                                            "same kernels: off by default so rocprof averages of the default run describe the timed workload)")
+    ap.add_argument("--full-line", action="store_true", help="print the FULL record as the stdout line (tools under profiles/ and tests that read its side blocks); default: "
+                                                              "the compact line (< 4 KB) on stdout, the full record on stderr and in bench_extras.json")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-pair setInputTarget + align latency behind the timed region (profiling runs: it adds differently "
+                                                               "sized launches of the same kernels, so the trace averages would no longer describe the timed workload)")
     args = ap.parse_args()
     if args.distinct <= 0:
         args.distinct = args.batch
@@ -549,7 +691,10 @@ def main():
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()  # test hook only: gloo ranks may share a GPU (one rank per GPU otherwise)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # a launcher (torchrun / bench.py's own) sets WORLD_SIZE: then the process group exists and the records are gathered even when the job has ONE rank
+    # (`torchrun --nproc-per-node 1`: RCCL initialisation and all_gather_into_tensor on device tensors run on a one-GPU box, tests/test_gpu_multiprocess.py)
+    use_pg = world > 1 or ("WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ)
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL over xGMI; BENCH_DIST_BACKEND=gloo lets two ranks share one GPU to exercise this path on a 1-GPU box (RCCL
         # refuses duplicate devices)
@@ -596,7 +741,7 @@ def main():
     def sync():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             dist.barrier()
 
     def timed(step_fn, steps, warmup, drain_fn=None):
@@ -623,7 +768,7 @@ def main():
             last = r if r is not None else last
         sync()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if use_pg:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=gdev if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
@@ -658,7 +803,7 @@ def main():
             local = bm.align(float("inf"))  # getFitnessScore(fitness_score_max_range = .inf), config/mrg_slam.yaml:172
             t2 = time.perf_counter()
             local["pair_id"] = mine.astype(np.int32)
-            rec = all_gather_records(local, per) if world > 1 else local
+            rec = all_gather_records(local, per) if use_pg else local
             full = np.zeros(n_pairs, dtype=RESULT_DTYPE)
             full["pair_id"] = -1
             full[rec["pair_id"]] = rec
@@ -732,7 +877,7 @@ def main():
             local = bm.align(float("inf"))
             t5 = time.perf_counter()
             local["pair_id"] = mine.astype(np.int32)
-            rec = all_gather_records(local, per) if world > 1 else local
+            rec = all_gather_records(local, per) if use_pg else local
             t6 = time.perf_counter()
             fl = np.zeros(n_pairs, dtype=RESULT_DTYPE)
             fl["pair_id"] = -1
@@ -741,7 +886,7 @@ def main():
             t7 = time.perf_counter()
             ph[rep] = [t1 - t0, t2 - t1, t3 - t2, (t5 - t4) - (t3 - t1), t6 - t5, t7 - t6, t5 - t4]
         ph_med = 1e3 * np.median(ph, axis=0)
-        if world > 1:
+        if use_pg:
             tt = torch.from_numpy(ph_med.copy())
             tt = tt.to(gdev) if backend == "nccl" else tt
             allp = torch.empty(world * NPH, dtype=torch.float64, device=tt.device)
@@ -865,10 +1010,10 @@ def main():
                    "config": {"workload": f"BASELINE config[3]: {r['pairs_total']} loop-closure candidate pairs ({r['new_keyframes']} new keyframes on a 40 m ring, VLP-64, "
                                           f"mean {r['mean_points_per_scan']:.0f} pts/scan), NDT_HIP DIRECT7 res 1.0 eps {args.eps}, contiguous blocks of the keyframe-ordered pair list per rank, one target grid per "
                                           f"new keyframe and rank, getFitnessScore(inf), record all-gather, best-candidate replay; inputs resident in HBM",
-                              "parallelism": f"{world} x 1 GPU" if world > 1 else "1 GPU"},
+                              "parallelism": f"{world} x 1 GPU" if world > 1 else "1 GPU", "record_gather": backend if use_pg else None},
                    "roofline": r["roofline"], "roofline_fitness": r["roofline_fitness"], "cpu_baseline": None, "config3_shard": r}
-            print(json.dumps(out))
-        if world > 1:
+            emit(out, args.full_line)
+        if use_pg:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -899,7 +1044,7 @@ def main():
                 [dev[p[1]].data_ptr() for p in pairs], [len(scans[p[1]]) for p in pairs], np.stack([p[2] for p in pairs]))
 
     def account(b, res):
-        if world > 1:  # pose / Hessian record gather over RCCL
+        if use_pg:  # pose / Hessian record gather over RCCL
             res["pair_id"] = np.arange(args.batch, dtype=np.int32)
             all_gather_records(res, args.batch)
         if counters["on"]:
@@ -1157,14 +1302,14 @@ def main():
         shard = run_shard(args.shard_steps, 1)
 
     if rank != 0:
-        if world > 1:
+        if use_pg:
             dist.barrier()
             dist.destroy_process_group()
         return
 
     # ---- single-pair latency (one pcl::Registration-style object), opt-in ------------------------------------------------------
     single_ms = None
-    if args.latency:
+    if not args.no_latency:
         reg = NdtHip(resolution=1.0, transformation_epsilon=args.eps, maximum_iterations=64, ctx=ctx)
         ti, si, guess, truth, _ = pairs[0]
         lat = []
@@ -1215,6 +1360,7 @@ def main():
         cores = min(sweep, key=lambda nt: probe_r[nt][0])
         tc, tc_set, tc_align, o_res = run_cpu(cores, pairs[:ncpu])
         cpu = {"value": ncpu / tc, "unit": "alignments/s", "cores": cores, "kind": "port",
+               "sample_short": f"{ncpu} of the step's {args.batch} pairs (setInputTarget + align each), restated pclomp NDT_OMP, {cores} OpenMP threads (fastest of {sweep}), {tc:.1f} s",
                "sample": f"{ncpu} of the {args.batch} pairs of one step (setInputTarget+align each, same warm/cold guesses), CPU oracle = restated pclomp NDT_OMP "
                          f"(not the upstream library: parity unpinned, DESIGN.md §2), -O3 -fopenmp, fastest of OpenMP thread counts {sweep} on a {host_cores}-thread "
                          f"host = {cores} threads, {tc:.2f} s",
@@ -1327,11 +1473,14 @@ def main():
                         f"setInputTarget + setInputSource + align per pair, inputs resident in HBM"
                         + (f"; {n_fl} steps in flight per GPU (mrgfe_batch_align_async on {n_fl} contexts: a step submits its batch and collects the one submitted "
                            f"{n_fl} steps earlier; every submitted step completes inside the timed region)" if n_fl > 1 else ""),
+            "workload_short": f"BASELINE config[1]: {args.batch} distinct synthetic VLP-64 scan pairs per GPU per step, NDT_HIP DIRECT7 res 1.0 eps {args.eps} max_iter 64, "
+                              f"setInputTarget + setInputSource + align per pair, clouds resident in HBM, {n_fl} step(s) in flight",
             "steps_in_flight": n_fl,
             "pairs_per_gpu_per_step": args.batch,
             "distinct_pairs": min(args.distinct, args.batch),
             "points_per_scan": n_pts,
             "parallelism": f"{world} x 1 GPU, own pairs per rank, RCCL all-gather of 384-byte result records" if world > 1 else "1 GPU",
+            "record_gather": backend if use_pg else None,
         },
         "roofline": {"bound": limiter, "byte_model_bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": traffic, "traffic_over_algorithmic": ratio, "valu_busy": valu_busy, "pmc_profile": prof_name,
@@ -1380,8 +1529,8 @@ def main():
         "per_scan_path": extras.get("per_scan_path"),
         "config3_shard": shard,
     }
-    print(json.dumps(out))
-    if world > 1:
+    emit(out, args.full_line)
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

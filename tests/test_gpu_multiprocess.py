@@ -94,13 +94,50 @@ def test_four_gloo_ranks_uneven_shards_equal_one_rank(tmp_path):
     assert one[0][1].strip().splitlines()[-1].split() == four[0][1].strip().splitlines()[-1].split()
 
 
+def test_rccl_process_group_of_one_rank_gathers_the_same_records(tmp_path):
+    """The `backend="nccl"` (= RCCL) branch of loop_closure.gather_records — process-group init on the device, all_gather_into_tensor on DEVICE tensors,
+    teardown — on the one-GPU box: a ONE-rank RCCL job through match_candidates returns the records of the job without a process group (that
+    code had never run on hardware; reference for the independence being sharded: loop_detector.cpp:126-145)."""
+    n = 11
+    worker = os.path.join(ROOT, "tests", "workers", "gloo_matcher_worker.py")
+    plain = _run_all([[sys.executable, worker, "0", "1", "0", str(n), str(tmp_path / "plain.npy")]], timeout=600)
+    assert plain[0][0] == 0, plain[0][2][-3000:]
+    rccl = _run_all([[sys.executable, worker, "0", "1", str(_free_port()), str(n), str(tmp_path / "rccl.npy"), "nccl"]], timeout=600)
+    assert rccl[0][0] == 0, rccl[0][2][-3000:]
+    assert "backend nccl world 1" in rccl[0][1]
+    a, b = np.load(tmp_path / "plain.npy"), np.load(tmp_path / "rccl.npy")
+    assert len(a) == len(b) == n and a.tobytes() == b.tobytes()
+    assert plain[0][1].strip().splitlines()[-1].split() == rccl[0][1].strip().splitlines()[-1].split()
+
+
+def test_bench_under_torchrun_one_rccl_rank(tmp_path):
+    """The driver's SCALE launch line with N = 1 and the REAL backend: `python -m torch.distributed.run --nproc-per-node 1 … bench.py --gpus 1` — the launcher
+    starts before anything touches the GPU; bench.py then initialises the RCCL process group, every collected batch's records go through
+    all_gather_into_tensor on device tensors, the elapsed time through the MAX all-reduce, and rank 0 alone prints the compact line (< 4 KB).  Both
+    modes: weak (config[1] shape, small batch) and shard (config[3], one step)."""
+    env = dict(os.environ, BENCH_CACHE=str(tmp_path / "cache"), OMP_NUM_THREADS="8")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_DIST_BACKEND"):
+        env.pop(k, None)
+    for extra, scaling in ((["--steps", "3", "--warmup", "1", "--batch", "16", "--shard-steps", "0"], "weak"), (["--mode", "shard", "--steps", "1", "--warmup", "1"], "strong")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+               os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu", "--no-extras", "--no-latency"] + extra
+        run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert run.returncode == 0, run.stderr[-3000:]
+        lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and len(lines[0]) < 4096, lines
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 1 and line["scaling"] == scaling and line["value"] > 0 and line["config"]["record_gather"] == "nccl", line
+        if scaling == "strong":
+            assert line["config3"]["records_sha256_16"] and line["config3"]["pairs"] == 256
+
+
 def test_bench_shard_mode_two_gloo_ranks_print_the_one_rank_digest(tmp_path):
     """`bench.py --mode shard` (BASELINE config[3], 256 pairs) as the driver's launcher would run it on two GPUs — here two gloo ranks on the one
     card (BENCH_DIST_BACKEND=gloo), started by bench.py's own launcher as child processes: the printed line says n_gpus 2, carries both ranks'
     phase times and the SAME record digest as the one-rank line."""
     env = dict(os.environ, BENCH_CACHE=str(tmp_path / "cache"), OMP_NUM_THREADS="8")
     env.pop("WORLD_SIZE", None)
-    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "shard", "--no-cpu", "--no-extras", "--steps", "1", "--warmup", "1"]
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "shard", "--no-cpu", "--no-extras", "--steps", "1", "--warmup", "1", "--full-line"]
     one = subprocess.run(base, env=env, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-3000:]
     two = subprocess.run(base + ["--gpus", "2"], env=dict(env, BENCH_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
@@ -115,7 +152,7 @@ def test_bench_shard_mode_two_gloo_ranks_print_the_one_rank_digest(tmp_path):
     assert [p["rank"] for p in s2["per_rank_phases_ms"]] == [0, 1] and all(p["alignment_rounds"] > 0 for p in s2["per_rank_phases_ms"])
     # the same 256 pairs through mrgfe_node_* (csrc/node.cpp): ONE process, three members sharing the card (blocks of 86 / 85 / 85), records gathered
     # behind the C ABI, best candidates from mrgfe_node_select_best — the one-rank digest again
-    three = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "shard", "--inproc", "--gpus", "3", "--steps", "2", "--warmup", "1"], env=env,
+    three = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "shard", "--inproc", "--gpus", "3", "--steps", "2", "--warmup", "1", "--full-line"], env=env,
                            capture_output=True, text=True, timeout=900)
     assert three.returncode == 0, three.stderr[-3000:]
     l3 = json.loads([ln for ln in three.stdout.splitlines() if ln.startswith("{")][-1])
@@ -141,6 +178,6 @@ def test_bench_default_mode_under_torchrun_two_gloo_ranks(tmp_path):
     assert len(lines) == 1, lines
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1 and line["scaling"] == "weak"
-    assert line["steps_in_flight"] == 2 and line["value"] > 0
+    assert len(lines[0]) < 4096 and line["config"]["steps_in_flight"] == 2 and line["value"] > 0 and line["roofline"]["frac"] > 0 and line["cpu_baseline"] is None
     assert abs(line["value"] - 2 * 16 * 4 / (line["ms_per_step"] * 4e-3)) < 1e-6 * line["value"]
     assert line["parity_vs_oracle"] is None or line["parity_vs_oracle"].get("pairs_over_bar", 0) == 0

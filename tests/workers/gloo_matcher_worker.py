@@ -2,7 +2,10 @@
 all-gathered over gloo (RCCL refuses two ranks on one device; the gather code is the same), the best-candidate replay on every rank
 (mrg_slam_amd/loop_closure.py, /root/reference/src/mrg_slam/loop_detector.cpp:104,126-145).
 
-    python tests/workers/gloo_matcher_worker.py <rank> <world> <port> <n_candidates> <out.npy>
+    python tests/workers/gloo_matcher_worker.py <rank> <world> <port> <n_candidates> <out.npy> [backend]
+
+backend "nccl" with world 1: the RCCL process group of a ONE-rank job — init, all_gather_into_tensor on device tensors (loop_closure.py
+gather_records' `use_cuda` branch) and teardown run on the one-GPU box (a port other than 0 asks for the process group).
 """
 import os
 import sys
@@ -32,22 +35,30 @@ def workload(n):
 
 def main():
     rank, world, port, n, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    backend = sys.argv[6] if len(sys.argv) > 6 else "gloo"
+    use_pg = world > 1 or port != 0
     import torch  # noqa: F401  (before libmrgfe)
     import torch.distributed as dist
 
     from mrg_slam_amd import BatchMatcher
     from mrg_slam_amd import loop_closure as lc
 
-    if world > 1:
+    if use_pg:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     tgt, cands, guesses = workload(n)
     rec, best, score = lc.match_candidates(lambda: BatchMatcher(transformation_epsilon=0.01, maximum_iterations=64), tgt, cands, guesses)
     if rank == 0:
         np.save(out, rec)
+        if use_pg:
+            print("backend", dist.get_backend(), "world", dist.get_world_size())
         print(best, score)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 
