@@ -1262,9 +1262,27 @@ int mrgfe_batch_build_targets(mrgfe_batch* b)
 }
 int mrgfe_batch_num_pairs(const mrgfe_batch* b) { return b ? b->ndt->n_pairs() : 0; }
 
+static int batch_align_impl(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_result* results);
+
 int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_result* results)
 {
     if (!b || !results) { set_error("mrgfe_batch_align: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(b->ctx);
+    const int st = batch_align_impl(b, fitness_max_range, results);
+    // zero-copy uploads (mrgfe_ctx_set_zero_copy_uploads): the caller's page-locked clouds are its own again when this call returns — also when it fails
+    // with their DMA still queued.  The error text of the failure is kept.
+    if (st != MRGFE_OK && b->ctx->dma_from_caller) {
+        const std::string msg = mrgfe_last_error();
+        drain_caller_dma(b->ctx);
+        set_error("%s", msg.c_str());
+    } else {
+        b->ctx->dma_from_caller = false;  // a successful align has waited for its stream
+    }
+    return st;
+}
+
+static int batch_align_impl(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_result* results)
+{
     MRGFE_LOCK(b->ctx);
     NdtEngine& e = *b->ndt;
     const int P = e.n_pairs();

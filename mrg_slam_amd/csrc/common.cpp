@@ -280,9 +280,15 @@ int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t layout, voi
     // has returned (mrgfe.h) — the reference's keyframe clouds are immutable ConstPtr clouds.  Off by default: the add / set call is done with the
     // caller's memory when it returns.
     if (ctx->zero_copy_uploads && n * 16 >= (size_t(64) << 10)) {
-        hipPointerAttribute_t attr;
-        if (hipPointerGetAttributes(&attr, xyzi) == hipSuccess && attr.type == hipMemoryTypeHost) {
+        // BOTH ends of the cloud must lie in page-locked memory (a cloud whose tail leaves the registered range would be DMA'd out of a
+        // partly pageable buffer); a registration covers whole pages, so two page-locked ends with a pageable hole between them would take two
+        // registrations inside one cloud — not something a caller that pins its clouds produces
+        hipPointerAttribute_t a0, a1;
+        const char* last = reinterpret_cast<const char*>(xyzi) + n * 16 - 1;
+        if (hipPointerGetAttributes(&a0, xyzi) == hipSuccess && a0.type == hipMemoryTypeHost &&
+            hipPointerGetAttributes(&a1, last) == hipSuccess && a1.type == hipMemoryTypeHost) {
             MRGFE_HIP_CHECK(hipMemcpyAsync(d_dst, xyzi, n * 16, hipMemcpyHostToDevice, ctx->stream));
+            ctx->dma_from_caller = true;  // a failing consuming call waits for the stream before it hands the caller's buffers back (drain_caller_dma)
             return MRGFE_OK;
         }
         (void)hipGetLastError();  // (an unregistered pointer is an error to the query, not to us)
@@ -300,6 +306,16 @@ int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t layout, voi
     MRGFE_HIP_CHECK(hipEventRecord(ctx->up_ev[slot], ctx->stream));
     ctx->up_busy[slot] = true;
     return MRGFE_OK;  // stream-ordered: later work on ctx->stream sees the cloud; the caller's buffer is already free
+}
+
+void drain_caller_dma(mrgfe_ctx* ctx)
+{
+    // error paths only: a zero-copy upload may still be reading the caller's page-locked buffer when a consuming call gives up — the header promises
+    // the buffer is the caller's again once that call has returned, so the stream is waited for first
+    if (!ctx || !ctx->dma_from_caller) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->dma_from_caller = false;
 }
 
 }  // namespace mrgfe

@@ -155,6 +155,7 @@ struct mrgfe_ctx {
     hipEvent_t   up_ev[2] = {nullptr, nullptr};
     bool         up_busy[2] = {false, false};
     int          up_next = 0;
+    bool         dma_from_caller = false;     // a zero-copy upload was queued since the last wait for the stream (drain_caller_dma on error paths)
     bool         zero_copy_uploads = false;   // mrgfe_ctx_set_zero_copy_uploads: clouds in page-locked host memory go up by DMA from the caller's buffer
     hipEvent_t   ev_fit[4] = {nullptr, nullptr, nullptr, nullptr};  // around the passes of nn_fitness_batch
     int          priority = 0;                  // > 0: streams at the device's highest priority, < 0: at its lowest (throughput work beside latency-critical rounds)
@@ -185,6 +186,7 @@ namespace mrgfe {
 // copy a host cloud into packed float4 device memory via the pinned staging ring; `layout` is the stride_bytes argument of the C
 // ABI (16, or MRGFE_LAYOUT(stride, xyz offset, intensity offset): such records are gathered on the device)
 int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t layout, void* d_dst, int pin_slot = 0);
+void drain_caller_dma(mrgfe_ctx* ctx);  // error paths: wait for zero-copy uploads still reading the caller's page-locked buffers
 int decode_layout(size_t layout, uint32_t* stride, uint32_t* xyz_off, int32_t* intensity_off);
 // a helper context of `parent` (builder threads of a batch, GICP lanes): same device, same compute-unit mask
 int ctx_create_like(const mrgfe_ctx* parent, mrgfe_ctx** out, int priority = 0);  // priority: see mrgfe_ctx::priority

@@ -82,8 +82,9 @@ struct PairDecl {
     float        guess[16];
 };
 struct ResidentCloud {
-    DevBuf buf;
-    size_t n = 0;
+    DevBuf   buf;
+    size_t   n = 0;
+    uint64_t last_use = 0;  // serial of the member's align call that named it last
 };
 
 enum Job { JOB_NONE = 0, JOB_ALIGN = 1, JOB_QUIT = 2 };
@@ -105,6 +106,8 @@ struct mrgfe_node {
         int          first = 0, count = 0;  // this member's block of the pair list
         std::vector<mrgfe_pair_result> local;
         std::unordered_map<uint64_t, ResidentCloud*> targets;  // keyed target clouds resident on this member's device
+        uint64_t     align_serial = 0;
+        size_t       target_cap = size_t(16) << 30;             // bytes of keyed targets kept resident (MRGFE_KEYFRAME_STORE_MB, the batch store's cap), LRU beyond it
         DevBuf       d_send, d_recv;                            // RCCL gather
         int          fail_next = 0;                             // test hook
     };
@@ -142,6 +145,7 @@ int member_align(mrgfe_node* node, Member& m)
         return member_fail(m, MRGFE_ERR_STATE);
     }
     if (m.count == 0) return MRGFE_OK;
+    ++m.align_serial;
     int st = mrgfe_batch_clear(m.batch);
     if (st != MRGFE_OK) return member_fail(m, st);
     std::unordered_map<int, int> local_target;
@@ -156,10 +160,26 @@ int member_align(mrgfe_node* node, Member& m)
                 ResidentCloud*& rc = m.targets[t.key];
                 if (!rc) rc = new (std::nothrow) ResidentCloud();
                 if (!rc) { set_error("out of host memory"); return member_fail(m, MRGFE_ERR_INVALID); }
+                rc->last_use = m.align_serial;
                 if (rc->n != t.n || !rc->buf.p) {
                     if (!t.xyzi && t.n) { set_error("member %d: target key %llu is not resident and no cloud was given", m.index, static_cast<unsigned long long>(t.key)); return member_fail(m, MRGFE_ERR_INVALID); }
                     MRGFE_LOCK(m.ctx);
                     if ((st = m.ctx->bind()) != MRGFE_OK) return member_fail(m, st);
+                    // the store is bounded (in the LoopDetector flow every keyframe is a target once, so an unbounded store grows by a cloud per
+                    // keyframe for the life of the process): least recently named keys go first, never one this call has named
+                    size_t held = 0;
+                    for (auto& kv : m.targets) held += kv.second->buf.cap;
+                    const size_t need = std::max<size_t>(t.n, 1) * 16;
+                    while (held + need > m.target_cap) {
+                        auto victim = m.targets.end();
+                        for (auto jt = m.targets.begin(); jt != m.targets.end(); ++jt)
+                            if (jt->second->last_use < m.align_serial && jt->second->buf.p && (victim == m.targets.end() || jt->second->last_use < victim->second->last_use)) victim = jt;
+                        if (victim == m.targets.end()) break;  // everything left is named by this call: the block's own working set may exceed the cap
+                        held -= victim->second->buf.cap;
+                        victim->second->buf.release();
+                        delete victim->second;
+                        m.targets.erase(victim);
+                    }
                     if ((st = rc->buf.ensure(std::max<size_t>(t.n, 1) * 16)) != MRGFE_OK) return member_fail(m, st);
                     if ((st = upload_cloud(m.ctx, t.xyzi, t.n, t.stride, rc->buf.p)) != MRGFE_OK) return member_fail(m, st);
                     rc->n = t.n;
@@ -201,7 +221,12 @@ void member_main(mrgfe_node* node, Member* m)
             m->status = st = MRGFE_ERR_INVALID;
             m->error = "member " + std::to_string(m->index) + ": unknown exception";
         }
-        (void)st;
+        if (st != MRGFE_OK) {
+            // the member's clouds go up by DMA out of the caller's page-locked buffers (zero-copy uploads are always on for members) and a failing
+            // block may have queued copies it never waited for: mrgfe_node_align hands the buffers back only after they have drained
+            MRGFE_LOCK(m->ctx);
+            drain_caller_dma(m->ctx);
+        }
         {
             std::lock_guard<std::mutex> lk(m->mu);
             m->job = JOB_NONE;
@@ -333,6 +358,7 @@ int mrgfe_node_create(int n_members, const int* device_ids, const mrgfe_reg_para
         if (!m) { set_error("out of host memory"); st = MRGFE_ERR_INVALID; break; }
         m->index = i;
         m->device = device_ids[i];
+        if (const char* e = std::getenv("MRGFE_KEYFRAME_STORE_MB")) m->target_cap = static_cast<size_t>(std::max(0.0, std::atof(e))) << 20;
         node->members.push_back(m);
         st = mrgfe_ctx_create(m->device, &m->ctx);
         // (the node's clouds are declared by pointer and uploaded inside mrgfe_node_align, which returns after the members have finished: page-locked
@@ -346,7 +372,14 @@ int mrgfe_node_create(int n_members, const int* device_ids, const mrgfe_reg_para
         set_error("%s", msg.c_str());
         return st;
     }
-    for (Member* m : node->members) m->th = std::thread(member_main, node, m);
+    try {
+        for (Member* m : node->members) m->th = std::thread(member_main, node, m);
+    } catch (const std::exception& e) {  // std::system_error (thread limit): an error code, never an exception across the C boundary
+        const std::string msg = e.what();
+        mrgfe_node_destroy(node);  // joins the members that did start
+        set_error("mrgfe_node_create: could not start a member thread: %s", msg.c_str());
+        return MRGFE_ERR_STATE;
+    }
     *out = node;
     return MRGFE_OK;
 }

@@ -210,3 +210,51 @@ def test_page_locked_host_clouds_upload_by_dma_with_the_same_results():
         assert out[0]["converged"].all()
     finally:
         assert lib().mrgfe_unpin_host_buffer(ctx._h, slab.ctypes.data_as(C.c_void_p)) == 0
+
+
+def test_cloud_whose_tail_leaves_the_page_locked_range_is_staged_not_dma():
+    """the zero-copy upload looked at the cloud's FIRST byte only.  A cloud that starts inside a registered range and ends in pageable memory
+    must take the staging ring (both ends are checked now); same records as the pageable cloud.  And a failing align that has queued zero-copy uploads
+    waits for them before it returns (mrgfe.h: the buffers are the caller's again when the consuming call returns) — seen here as: the failure is an
+    error code, the buffer can be unpinned and freed right away, and the next align gives the right records."""
+    from mrg_slam_amd import BatchMatcher, Context, MrgfeError
+    from mrg_slam_amd._lib import lib
+
+    ctx = Context()
+    ctx.set_zero_copy_uploads(True)
+    t = small_cloud(30000, seed=77)
+    s = t[:29000].copy()
+    want = None
+    slab = np.empty((2 * len(t), 4), np.float32)
+    slab[: len(t)] = t
+    half = (len(t) // 2) * 16  # page-lock only the first half of the target cloud (whole pages)
+    half -= half % 4096
+    assert lib().mrgfe_pin_host_buffer(ctx._h, slab.ctypes.data_as(C.c_void_p), half) == 0
+    try:
+        for cloud in (t, slab[: len(t)]):
+            bm = BatchMatcher(ctx=ctx)
+            bm.add_pair(bm.add_target(cloud), s, np.eye(4))
+            got = bm.align().copy()
+            want = got if want is None else want
+            assert got.tobytes() == want.tobytes()
+    finally:
+        assert lib().mrgfe_unpin_host_buffer(ctx._h, slab.ctypes.data_as(C.c_void_p)) == 0
+    # failing align with zero-copy uploads queued: injected allocation failure, then the pinned cloud is released at once
+    pinned = t.copy()
+    ctx = Context()  # (fresh: grow-only workspaces of the context above would leave the align nothing to allocate)
+    ctx.set_zero_copy_uploads(True)
+    assert lib().mrgfe_pin_host_buffer(ctx._h, pinned.ctypes.data_as(C.c_void_p), pinned.nbytes) == 0
+    bm = BatchMatcher(ctx=ctx)
+    bm.add_pair(bm.add_target(pinned), s, np.eye(4))
+    lib().mrgfe_dbg_fail_alloc_after(2)
+    try:
+        with pytest.raises(MrgfeError):
+            bm.align()
+    finally:
+        lib().mrgfe_dbg_fail_alloc_after(-1)
+        assert lib().mrgfe_unpin_host_buffer(ctx._h, pinned.ctypes.data_as(C.c_void_p)) == 0
+    pinned[:] = 0.0
+    del pinned
+    bm.clear()
+    bm.add_pair(bm.add_target(t), s, np.eye(4))
+    assert bm.align().tobytes() == want.tobytes()

@@ -108,6 +108,43 @@ def test_keyed_clouds_stay_resident_and_may_be_named_without_data():
         node.align()
 
 
+def test_member_target_store_is_bounded_lru(monkeypatch):
+    """in the LoopDetector flow every keyframe is a target exactly once (loop_detector.cpp:104), so the members' keyed TARGET store must not
+    grow by a cloud per keyframe for the life of the process.  With a small cap (MRGFE_KEYFRAME_STORE_MB, the batch store's knob) the least recently
+    named targets are dropped — never one the running call names — and naming a dropped key without data is the usual error."""
+    from mrg_slam_amd import MrgfeError, NodeMatcher
+    from mrg_slam_amd._lib import NDT_HIP
+
+    monkeypatch.setenv("MRGFE_KEYFRAME_STORE_MB", "1")  # 1 MiB: three ~20k-point targets (0.3 MB each) fit, the fourth evicts the oldest
+    node = NodeMatcher([0], _params(NDT_HIP))
+    monkeypatch.delenv("MRGFE_KEYFRAME_STORE_MB")
+    targets = [small_cloud(20000, 900 + k) for k in range(6)]
+    src = targets[0][:3000].copy()
+    held = []
+    for k, t in enumerate(targets):  # one new keyframe per call, like matching()
+        node.clear()
+        node.add_pair(node.add_target(t, key=7000 + k, n_points=len(t)), src, np.eye(4))
+        node.align()
+        held.append(node.store_bytes())
+    assert max(held) <= (1 << 20) + 20000 * 16 and held[-1] <= (1 << 20)
+    # the most recent keys are still resident and can be named without data; the oldest is gone
+    node.clear()
+    node.add_pair(node.add_target(None, key=7005, n_points=len(targets[5])), src, np.eye(4))
+    node.add_pair(node.add_target(None, key=7004, n_points=len(targets[4])), src, np.eye(4))
+    assert len(node.align()) == 2
+    node.clear()
+    node.add_pair(node.add_target(None, key=7000, n_points=len(targets[0])), src, np.eye(4))
+    with pytest.raises(MrgfeError, match="not resident"):
+        node.align()
+    # a call whose OWN targets exceed the cap keeps all of them (nothing it names is evicted) and gives the records of an unbounded node
+    big = NodeMatcher([0], _params(NDT_HIP))
+    for nd in (node, big):
+        nd.clear()
+        for k, t in enumerate(targets):
+            nd.add_pair(nd.add_target(t, key=8000 + k, n_points=len(t)), targets[k][:2500 + 100 * k].copy(), np.eye(4))
+    assert node.align(float("inf")).tobytes() == big.align(float("inf")).tobytes()
+
+
 def test_a_failing_member_returns_an_error_and_the_node_stays_usable():
     from mrg_slam_amd import MrgfeError, NodeMatcher
     from mrg_slam_amd._lib import NDT_HIP
