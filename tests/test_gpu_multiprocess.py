@@ -179,5 +179,5 @@ def test_bench_default_mode_under_torchrun_two_gloo_ranks(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1 and line["scaling"] == "weak"
     assert len(lines[0]) < 4096 and line["config"]["steps_in_flight"] == 2 and line["value"] > 0 and line["roofline"]["frac"] > 0 and line["cpu_baseline"] is None
-    assert abs(line["value"] - 2 * 16 * 4 / (line["ms_per_step"] * 4e-3)) < 1e-6 * line["value"]
+    assert abs(line["value"] - 2 * 16 * 4 / (line["ms_per_step"] * 4e-3)) < 1e-4 * line["value"]  # (the line carries five significant digits)
     assert line["parity_vs_oracle"] is None or line["parity_vs_oracle"].get("pairs_over_bar", 0) == 0
