@@ -301,9 +301,12 @@ def compact_line(full: dict) -> dict:
                           "fitness_frac": (c3.get("roofline_fitness") or {}).get("frac"), "derivative_frac": (c3.get("roofline") or {}).get("frac"),
                           "pairs_over_bar": p3.get("pairs_over_bar"), "best_candidate_mismatches": p3.get("best_candidate_mismatches"),
                           "records_sha256_16": c3.get("records_sha256_16")}
-        for k in ("detect_batched", "shard_of_8_ms"):
-            if c3.get(k) is not None:
-                out["config3"][k] = c3[k]
+        db = c3.get("detect_batched")
+        if db:
+            out["config3"]["detect_8_new_keyframes"] = {g: _pick(db[g], "detect_ms", "detect_batched_ms", "alignments_sequential", "alignments_batched", "same_loops")
+                                                        for g in ("no_gating", "default_gates") if g in db}
+        if c3.get("shard_of_8_ms") is not None:
+            out["config3"]["shard_of_8_ms"] = c3["shard_of_8_ms"]
     c2 = g("config2_gicp")
     if c2:
         out["config2_gicp"] = {}
@@ -539,6 +542,64 @@ def run_pcl_ndt(ctx, scans, dev, pairs, lib, args):
                                        "pairs_with_other_iterations_evaluations_or_convergence": mism, "bar": "1e-4 m / 1e-4 rad"}
         out[f"eps_{eps:g}"] = rec
         del bm
+    return out
+
+
+def run_detect_leg(ctx, prm, loop_raw, radius=40.0, laps=4, n_new=8, reps=3):
+    """LoopDetector::detect() (loop_detector.cpp:15-38) with SEVERAL new keyframes per call — the call shape the reference really has: 1-30 candidates per
+    new keyframe, one matching() after the other.  `laps` earlier laps of the 64-keyframe ring are the graph (4 x 64 keyframes, robot "a"), `n_new`
+    consecutive keyframes of the next lap arrive in one detect() call: ~30 candidates within 15 m each.  Timed: detect() — matching() per new keyframe,
+    each a candidate batch + a consistency batch (the round-3 mirror) — against detect_batched() — ONE superset batch + one consistency batch + host
+    replay.  Two gate settings: `no_gating` (accum_distance_thresh_same_robot 0: the sequential loop aligns every candidate, the two do the same
+    alignments) and `default_gates` (15 m: a loop found for keyframe k prunes the same-robot candidates of the next three, so the sequential loop
+    aligns fewer pairs than the superset).  Same Loop lists (asserted).  Untimed for `value`."""
+    from mrg_slam_amd import BatchMatcher, distance_filter, synth
+    from mrg_slam_amd.loop_detector import Edge, KeyFrame, LoopDetector, LoopManager
+
+    clouds = [distance_filter(s, 0.1, 35.0, ctx=ctx) for s in loop_raw]
+    n_ring = len(clouds)
+    poses = synth.loop_trajectory(n_ring, radius)
+    circ = 2.0 * np.pi * radius
+    rng = np.random.default_rng(4243)
+    kfs = []
+    for lap in range(laps + 1):
+        for k in range(n_ring):
+            est = synth.perturb_pose(poses[k], rng, sigma_t=(0.3, 0.3, 0.05), sigma_r_deg=(0.3, 0.3, 1.0))
+            kf = KeyFrame(id=len(kfs) + 1, cloud=clouds[k], estimate=est, accum_distance=lap * circ + circ * k / n_ring, slam_uuid="a", first_keyframe=(len(kfs) == 0))
+            if kfs:
+                prev = kfs[-1]
+                rel = np.linalg.inv(kf.estimate) @ prev.estimate
+                kf.prev_edge = Edge(kf, prev, rel)
+                prev.next_edge = Edge(kf, prev, rel)
+                kf.connected.add(prev.id)
+                prev.connected.add(kf.id)
+            kfs.append(kf)
+    known, new = kfs[: laps * n_ring], kfs[laps * n_ring + 10: laps * n_ring + 10 + n_new]
+    out = {}
+    for name, thresh in (("no_gating", 0.0), ("default_gates", 15.0)):
+        det = LoopDetector({"accum_distance_thresh_same_robot": thresh}, matcher=BatchMatcher(prm, ctx))
+        t_seq, t_bat, loops = [], [], {}
+        for rep in range(reps + 1):  # the first repetition uploads the candidates' clouds into the keyframe store (keys): untimed
+            for mode in ("sequential", "batched"):
+                det.loop_manager = LoopManager()
+                a0 = det.alignments
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                found = det.detect_batched(known, new) if mode == "batched" else det.detect(known, new)
+                dt = 1e3 * (time.perf_counter() - t0)
+                loops[mode] = [(lp.key1.id, lp.key2.id, lp.relative_pose.tobytes()) for lp in found]
+                if rep:
+                    (t_bat if mode == "batched" else t_seq).append(dt)
+                if mode == "batched":
+                    info = dict(det.last_batched)
+                else:
+                    seq_aligned = det.alignments - a0
+        out[name] = {"detect_ms": float(np.median(t_seq)), "detect_batched_ms": float(np.median(t_bat)), "speedup": float(np.median(t_seq) / np.median(t_bat)),
+                     "new_keyframes": n_new, "alignments_sequential": int(seq_aligned), "alignments_batched": int(info["superset_pairs"] + info["consistency_pairs"]),
+                     "superset_pairs": info["superset_pairs"], "loops": len(loops["batched"]), "same_loops": loops["batched"] == loops["sequential"]}
+        del det
+    out["what"] = (f"{n_new} new keyframes per detect() call against {laps} x {n_ring} ring keyframes of one robot (~{out['no_gating']['superset_pairs'] // n_new} candidates within 15 m each, "
+                   f"{int(np.mean([len(c) for c in clouds]))} points per cloud, candidates resident in the HBM keyframe store), NDT_HIP DIRECT7 res 1.0, median of {reps} calls")
     return out
 
 
@@ -1300,6 +1361,8 @@ def main():
     shard = None
     if args.shard_steps > 0:
         shard = run_shard(args.shard_steps, 1)
+        if not args.no_extras and rank == 0 and world == 1:
+            shard["detect_batched"] = run_detect_leg(ctx, prm, loop_raw)
 
     if rank != 0:
         if use_pg:

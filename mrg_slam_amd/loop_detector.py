@@ -12,12 +12,19 @@ Two ways to run ``matching`` on the same decisions:
   next keyframe against the same target — supplies the consistency check; the next keyframe's result is used only where the reference
   would have computed it (the previous one failed).  The alignments are independent, so the Loop list is the reference's.
 
+``detect_batched`` goes one level up: ``detect`` (:15-38) calls ``matching`` once per NEW keyframe, 1-30 candidates each — launch-latency-sized
+batches.  The LoopManager gates of ``find_candidates`` (:77-90) only REMOVE candidates, so the candidates of all new keyframes with the gates
+ignored are a superset of what the sequential loop will ever align: ONE batch aligns and scores them all (one target grid per new keyframe), a
+second batch supplies the consistency alignments of every best match any gate state can produce, and the gates, the best-score rule, the
+thresholds and ``add_loop`` are replayed keyframe after keyframe on the host from the records.  Same Loop list as ``detect``.
+
 Poses are ``numpy`` 4 x 4 matrices: keyframe estimates in double (``Eigen::Isometry3d``), registration results in float
 (``Eigen::Matrix4f``), products and inverses in the type the reference forms them in."""
 from __future__ import annotations
 
 import dataclasses
 import hashlib
+import time
 
 import numpy as np
 
@@ -169,19 +176,148 @@ class LoopDetector:
         self.registration, self.matcher = registration, matcher
         self.loop_manager = LoopManager()
         self.alignments = 0  # registrations run so far (candidates + consistency checks)
+        # the reference's only performance counters (loop_detector.cpp:22-34, written out as average_time_per_candidate_us by
+        # apps/mrg_slam_component.cpp:1032-1037): candidates and microseconds per new keyframe that had candidates
+        self.loop_candidates_sizes: list = []
+        self.loop_detection_times: list = []
 
     # ---- detect (:14-38)
     def detect(self, keyframes, new_keyframes):
         detected = []
         for new_keyframe in new_keyframes:
+            start = time.perf_counter()
             candidates = self.find_candidates(new_keyframe, keyframes)
             loop = self.matching(candidates, new_keyframe)
             if loop is not None:
                 detected.append(loop)
+            if candidates:  # :29-33
+                self.loop_candidates_sizes.append(len(candidates))
+                self.loop_detection_times.append(int(1e6 * (time.perf_counter() - start)))
+        return detected
+
+    def average_time_per_candidate_us(self) -> float | None:
+        """apps/mrg_slam_component.cpp:1032-1037: total loop detection time over total candidates."""
+        total = sum(self.loop_candidates_sizes)
+        return float(sum(self.loop_detection_times)) / total if total else None
+
+    # ---- detect, all new keyframes in one batch
+    def detect_batched(self, keyframes, new_keyframes):
+        """``detect`` with the alignments of ALL new keyframes in two batches (module docstring).  Needs ``matcher=``.  Returns the Loop list
+        ``detect(keyframes, new_keyframes)`` returns, loop for loop (same keyframes, same relative poses)."""
+        if self.matcher is None:
+            raise ValueError("detect_batched needs a BatchMatcher (matcher=)")
+        from .registration import result_matrix
+
+        start = time.perf_counter()
+        p, bm = self.p, self.matcher
+        new_keyframes = list(new_keyframes)
+        new_est = [normalize_estimate(k.estimate) for k in new_keyframes]
+        supersets = [self.find_candidates(k, keyframes, ignore_loop_manager=True) for k in new_keyframes]
+        n_super = sum(len(s) for s in supersets)
+        if n_super == 0:
+            return []
+
+        def queue(pairs):  # pairs: (index of the new keyframe, source keyframe); one target grid per new keyframe that has pairs
+            bm.clear()
+            tid = {}
+            for k, kf in pairs:
+                if k not in tid:
+                    tid[k] = bm.add_target(new_keyframes[k].cloud)  # registration_->setInputTarget(new_keyframe->cloud), :104
+                key = kf.store_key()
+                old = kf.retired_store_key()
+                if old is not None and old != key:
+                    bm.forget(old)
+                have = bm.has_cloud(key) == len(kf.cloud)
+                bm.add_pair(tid[k], None if have else kf.cloud, self._guess(new_est[k], kf), key=key)
+            self.alignments += len(pairs)
+
+        # ---- batch 1: every (new keyframe, superset candidate) pair, aligned and scored
+        pairs1 = [(k, c) for k, cands in enumerate(supersets) for c in cands]
+        queue(pairs1)
+        rec1 = bm.align(p["fitness_score_max_range"])
+        first = np.cumsum([0] + [len(s) for s in supersets])
+        results = [[(result_matrix(r), bool(r["converged"]), float(r["fitness"])) for r in rec1[first[k]:first[k + 1]]] for k in range(len(new_keyframes))]
+
+        def best_of(k, keep):  # the rule of :137-144 over the candidates `keep` leaves, in candidate order
+            best_score, best_matched, rel_pose = np.finfo(np.float64).max, None, None
+            for candidate, (T, converged, score), use in zip(supersets[k], results[k], keep):
+                if not use or not converged or score > best_score:
+                    continue
+                best_score, best_matched, rel_pose = score, candidate, T
+            return best_score, best_matched, rel_pose
+
+        def needs_alignments(best_matched, best_score):  # _consistency_check reaches the registration
+            return (best_matched is not None and not (best_matched.first_keyframe or best_matched.static_keyframe) and p["enable_loop_closure_consistency_check"]
+                    and not best_score > p["fitness_score_thresh"])
+
+        # ---- batch 2: the gates drop ALL candidates of a SLAM instance or none (their conditions name the candidate's instance only), so the candidate
+        # lists the replay can meet are the supersets minus any set of instances: the best match of each is known now, and its previous / next keyframe
+        # are aligned against the new keyframe for all of them at once
+        pairs2, seen2 = [], set()
+        for k, cands in enumerate(supersets):
+            robots = sorted({c.slam_uuid for c in cands})
+            for mask in range(1 << len(robots)):
+                gated = {r for b, r in enumerate(robots) if mask >> b & 1}
+                best_score, best_matched, _ = best_of(k, [c.slam_uuid not in gated for c in cands])
+                if not needs_alignments(best_matched, best_score):
+                    continue
+                for kf in (best_matched.prev_edge.to_keyframe if best_matched.prev_edge is not None else None,
+                           best_matched.next_edge.from_keyframe if best_matched.next_edge is not None else None):
+                    if kf is not None and (k, id(kf)) not in seen2:
+                        seen2.add((k, id(kf)))
+                        pairs2.append((k, kf))
+        T2 = {}
+        if pairs2:
+            queue(pairs2)
+            rec2 = bm.align(-1.0)
+            T2 = {(k, id(kf)): result_matrix(r) for (k, kf), r in zip(pairs2, rec2)}
+
+        # ---- the reference's loop, keyframe after keyframe, on the records
+        detected, kept_sizes = [], []
+        for k, new_keyframe in enumerate(new_keyframes):
+            keep = [not self._loop_manager_gate(new_keyframe, c) for c in supersets[k]]
+            n_cand = sum(keep)
+            if n_cand == 0:
+                continue
+            kept_sizes.append(n_cand)
+            best_score, best_matched, rel_pose = best_of(k, keep)
+            consistent = False
+            if best_matched is not None and (best_matched.first_keyframe or best_matched.static_keyframe):
+                consistent = True
+            elif needs_alignments(best_matched, best_score):
+                prev_kf = best_matched.prev_edge.to_keyframe if best_matched.prev_edge is not None else None
+                next_kf = best_matched.next_edge.from_keyframe if best_matched.next_edge is not None else None
+                consistent = bool((prev_kf is not None and self._consistent_prev(best_matched, rel_pose, T2[(k, id(prev_kf))]))
+                                  or (next_kf is not None and self._consistent_next(best_matched, rel_pose, T2[(k, id(next_kf))])))
+            if best_score > p["fitness_score_thresh"]:
+                continue
+            if p["enable_loop_closure_consistency_check"] and best_matched is not None and not best_matched.first_keyframe and not consistent:
+                continue
+            loop = Loop(new_keyframe, best_matched, rel_pose)
+            self.loop_manager.add_loop(loop)
+            detected.append(loop)
+        # the reference's counters: the candidates the sequential loop would have aligned; the call's time shared out by candidate count
+        elapsed_us = 1e6 * (time.perf_counter() - start)
+        total = sum(kept_sizes)
+        for n in kept_sizes:
+            self.loop_candidates_sizes.append(n)
+            self.loop_detection_times.append(int(elapsed_us * n / total))
+        self.last_batched = {"superset_pairs": n_super, "sequential_pairs": total, "consistency_pairs": len(pairs2), "new_keyframes": len(new_keyframes)}
         return detected
 
     # ---- find_candidates (:41-95)
-    def find_candidates(self, new_keyframe: KeyFrame, keyframes):
+    def _loop_manager_gate(self, new_keyframe: KeyFrame, candidate: KeyFrame) -> bool:
+        """:77-90, True = the candidate is skipped: a loop was closed too recently (in accumulated distance) between the two SLAM instances.
+        Depends on the candidate through its ``slam_uuid`` only."""
+        p = self.p
+        last_loop = self.loop_manager.get_loop(new_keyframe.slam_uuid, candidate.slam_uuid)
+        if last_loop and new_keyframe.slam_uuid == candidate.slam_uuid and new_keyframe.accum_distance - last_loop.key1.accum_distance < p["accum_distance_thresh_same_robot"]:
+            return True
+        if last_loop and new_keyframe.slam_uuid != candidate.slam_uuid and new_keyframe.accum_distance - last_loop.key1.accum_distance < p["accum_distance_thresh_other_robot"]:
+            return True
+        return False
+
+    def find_candidates(self, new_keyframe: KeyFrame, keyframes, ignore_loop_manager: bool = False):
         p = self.p
         max_sq = p["candidate_max_xy_distance"] * p["candidate_max_xy_distance"]
         out = []
@@ -195,10 +331,7 @@ class LoopDetector:
                 continue
             if new_keyframe.slam_uuid == candidate.slam_uuid and new_keyframe.accum_distance - candidate.accum_distance < p["accum_distance_thresh_same_robot"]:
                 continue
-            last_loop = self.loop_manager.get_loop(new_keyframe.slam_uuid, candidate.slam_uuid)
-            if last_loop and new_keyframe.slam_uuid == candidate.slam_uuid and new_keyframe.accum_distance - last_loop.key1.accum_distance < p["accum_distance_thresh_same_robot"]:
-                continue
-            if last_loop and new_keyframe.slam_uuid != candidate.slam_uuid and new_keyframe.accum_distance - last_loop.key1.accum_distance < p["accum_distance_thresh_other_robot"]:
+            if not ignore_loop_manager and self._loop_manager_gate(new_keyframe, candidate):
                 continue
             out.append(candidate)
         return out

@@ -50,15 +50,16 @@ def make_ring_session(n_keyframes=64, model="VLP16", laps=1.25, radius=40.0, pre
     return kfs, order
 
 
-def run_session(detector, kfs, order):
-    """Feeds the keyframes one at a time; every detected loop becomes a graph edge (as mrg_slam_component does), so later keyframes see it."""
+def run_session(detector, kfs, order, group=1, batched=False):
+    """Feeds the keyframes `group` at a time (the reference's detect() receives every keyframe added since the last optimisation, loop_detector.cpp:18-21);
+    every detected loop becomes a graph edge (as mrg_slam_component does), so later calls see it.  batched: detect_batched instead of detect."""
     known, loops = [], []
-    for i in order:
-        new = kfs[i]
-        found = detector.detect(known, [new])
+    for g0 in range(0, len(order), group):
+        new = [kfs[i] for i in order[g0:g0 + group]]
+        found = detector.detect_batched(known, new) if batched else detector.detect(known, new)
         for lp in found:
             lp.key1.connected.add(lp.key2.id)
             lp.key2.connected.add(lp.key1.id)
         loops += found
-        known.append(new)
+        known += new
     return loops

@@ -50,11 +50,11 @@ class ScriptedMatcher:
         self.table, self.store, self.ids, self.calls = table, {}, {}, []
 
     def clear(self):
-        self.pairs = []
+        self.pairs, self.targets = [], []
 
     def add_target(self, cloud):
-        self.t = int(cloud[0, 0])
-        return 0
+        self.targets.append(int(cloud[0, 0]))
+        return len(self.targets) - 1
 
     def has_cloud(self, key):
         return self.store.get(key)
@@ -69,15 +69,15 @@ class ScriptedMatcher:
         else:
             self.store[key] = len(cloud)
             self.ids[key] = int(cloud[0, 0])  # the store key names (slam_uuid, id, content); the table is keyed by keyframe id
-        self.pairs.append((self.ids[key], np.asarray(guess)))
+        self.pairs.append((self.targets[t], self.ids[key], np.asarray(guess)))
 
     def align(self, fitness_max_range):
         from mrg_slam_amd.registration import RESULT_DTYPE
 
         out = np.zeros(len(self.pairs), dtype=RESULT_DTYPE)
-        for i, (key, guess) in enumerate(self.pairs):
-            T, conv, score = self.table[(self.t, key)]
-            self.calls.append((self.t, key))
+        for i, (t, key, guess) in enumerate(self.pairs):
+            T, conv, score = self.table[(t, key)]
+            self.calls.append((t, key))
             out[i]["T"] = (guess if T is None else T).astype(np.float32).T.reshape(-1)
             out[i]["converged"] = conv
             out[i]["fitness"] = score if fitness_max_range >= 0 else np.finfo(np.float64).max
@@ -211,3 +211,76 @@ def test_a_replaced_cloud_leaves_the_store_and_an_edited_one_raises():
     assert old not in m.store and replaced.store_key() in m.store and len(m.store) == 2  # the old entry was dropped, not leaked
     with pytest.raises(ValueError):
         replaced.cloud[0, 1] = 3.0  # hashed clouds are read-only: an in-place edit raises instead of meeting the resident copy
+
+
+def _random_session(rng, n_known=40, n_new=24):
+    """Two robots on two parallel tracks; graph edges along each track; `n_new` further keyframes of robot a arrive in groups."""
+    kfs, per_robot = [], {"a": [], "b": []}
+    for i in range(n_known):
+        uuid = "a" if i % 3 else "b"
+        lst = per_robot[uuid]
+        kf = _kf(i + 1, 1.5 * len(lst), 0.0 if uuid == "a" else 2.0, 4.0 * len(lst), uuid=uuid, first=(len(lst) == 0))
+        if rng.random() < 0.05:
+            kf.static_keyframe = True
+        if lst:
+            prev = lst[-1]
+            rel = np.linalg.inv(kf.estimate) @ prev.estimate
+            kf.prev_edge = Edge(kf, prev, rel)
+            prev.next_edge = Edge(kf, prev, rel)
+        lst.append(kf)
+        kfs.append(kf)
+    news = [_kf(1000 + j, 1.5 * (j % 20) + rng.normal(0, 0.3), 1.0, 400.0 + 3.0 * j, uuid="a") for j in range(n_new)]
+    table = {}
+    for new in news:
+        ne = normalize_estimate(new.estimate)
+        for kf in kfs:
+            # mostly near the true relative pose (consistent with the graph edges), now and then off by metres; scores around the 1.25 threshold
+            dx = 0.0 if rng.random() < 0.7 else rng.normal(0, 1.5)
+            T = (np.linalg.inv(ne) @ kf.estimate @ synth.make_pose([dx, 0, 0], synth.rot_z(0.0 if rng.random() < 0.8 else rng.normal(0, 0.1)))).astype(np.float32)
+            score = float(rng.choice([0.2, 0.4, 0.4, 0.9, 1.3, 2.0])) if rng.random() < 0.6 else float(rng.uniform(0.1, 2.0))
+            table[(new.id, kf.id)] = (T, bool(rng.random() < 0.85), score)
+    return kfs, news, table
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_detect_batched_returns_the_sequential_loop_list(seed):
+    """detect_batched (superset batch + consistency batch + host replay) against detect() — the reference's loop with its LoopManager gates
+    (loop_detector.cpp:15-38,77-90) — on random two-robot sessions whose new keyframes arrive several per call: a loop found for one new keyframe
+    prunes the candidates of the following ones (same-robot 15 m, other-robot 5 m of accumulated distance), ties, non-converged and over-threshold
+    candidates, first / static keyframes, failed and rescued consistency checks all occur.  Same loops, same poses, and never an alignment outside
+    the superset; the reference's counters (candidates per keyframe) come out the same."""
+    rng = np.random.default_rng(1000 + seed)
+    kfs, news, table = _random_session(rng)
+    prm = {"accum_distance_thresh_same_robot": 15.0, "accum_distance_thresh_other_robot": 5.0, "candidate_max_xy_distance": 6.0}
+    seq = LoopDetector(prm, registration=ScriptedRegistration(table))
+    bat = LoopDetector(prm, matcher=ScriptedMatcher(table))
+    group = [1, 2, 5, 8][seed % 4]
+    loops_s, loops_b, pruned = [], [], 0
+    for g0 in range(0, len(news), group):
+        batch = news[g0:g0 + group]
+        ls, lb = seq.detect(kfs, batch), bat.detect_batched(kfs, batch)
+        assert [(lp.key1.id, lp.key2.id) for lp in ls] == [(lp.key1.id, lp.key2.id) for lp in lb]
+        for a, b in zip(ls, lb):
+            np.testing.assert_array_equal(a.relative_pose, b.relative_pose)
+        loops_s += ls
+        loops_b += lb
+        pruned += bat.last_batched["superset_pairs"] - bat.last_batched["sequential_pairs"]
+        assert bat.last_batched["superset_pairs"] >= bat.last_batched["sequential_pairs"]
+    assert len(loops_s) >= 2
+    assert seq.loop_candidates_sizes == bat.loop_candidates_sizes and len(bat.loop_detection_times) == len(bat.loop_candidates_sizes)
+    assert seq.average_time_per_candidate_us() is not None and bat.average_time_per_candidate_us() is not None
+    if group > 1:
+        assert pruned > 0, "the session never exercised the LoopManager gates inside a call"
+    # every alignment the sequential loop ran is in the batches (the batches may hold more: gated candidates, both consistency neighbours)
+    assert set(seq.registration.calls) <= set(bat.matcher.calls)
+    for name in ("a", "b"):
+        la, lb_ = seq.loop_manager.get_loop("a", name), bat.loop_manager.get_loop("a", name)
+        assert (la is None) == (lb_ is None) and (la is None or (la.key1.id, la.key2.id) == (lb_.key1.id, lb_.key2.id))
+
+
+def test_detect_batched_edge_cases():
+    kfs, news, table = _random_session(np.random.default_rng(5), n_known=12, n_new=3)
+    bat = LoopDetector(matcher=ScriptedMatcher(table))
+    assert bat.detect_batched(kfs, []) == [] and bat.detect_batched([], news) == []
+    with pytest.raises(ValueError):
+        LoopDetector(registration=ScriptedRegistration(table)).detect_batched(kfs, news)
