@@ -299,6 +299,7 @@ def compact_line(full: dict) -> dict:
                           "rounds_ms": ph.get("alignment_rounds"), "fitness_ms": ph.get("fitness_passes"), "build_ms": ph.get("build_targets"),
                           "two_in_flight_ms": (c3.get("two_batches_in_flight") or {}).get("ms_per_step"),
                           "fitness_frac": (c3.get("roofline_fitness") or {}).get("frac"), "derivative_frac": (c3.get("roofline") or {}).get("frac"),
+                          "average_time_per_candidate_us": c3.get("average_time_per_candidate_us"),
                           "pairs_over_bar": p3.get("pairs_over_bar"), "best_candidate_mismatches": p3.get("best_candidate_mismatches"),
                           "records_sha256_16": c3.get("records_sha256_16")}
         db = c3.get("detect_batched")
@@ -895,7 +896,9 @@ def main():
                     fit_acc[k] += fs[k]
             return out
 
+        bm.timing(reset=True)
         elapsed, step_ms, (full, best) = timed(step, steps, warmup)
+        us_per_candidate = bm.timing()["average_time_per_candidate_us"]  # the reference's own statistic (apps/mrg_slam_component.cpp:1032-1037) over the timed steps + warm-up
         if phases:
             print("[bench] step phases, median ms: queue the batch %.3f, align %.3f, records + best candidate %.3f" % tuple(1e3 * np.median(np.array(phases[-steps:]), axis=0)), file=sys.stderr)
         # kernel times for the roofline records: two more, untimed, steps WITHOUT the early fitness waves (beside the alignment rounds the
@@ -1056,6 +1059,7 @@ def main():
                 "raw_inputs_as_in_the_build_container": (raw_digest == EXPECTED_RAW_INPUTS["config3_64_keyframes"]) if EXPECTED_RAW_INPUTS["config3_64_keyframes"] else None,
                 "pmc_reference": pmc_reference(pmc_name, pmc),
                 "steps": steps, "ms_per_step": 1e3 * elapsed / steps, "alignments_per_s": n_pairs * steps / elapsed, "scaling": "strong",
+                "average_time_per_candidate_us": us_per_candidate,
                 "projected_for_gpus": fake_world or None,
                 "fitness_max_range": "inf", "converged": int(full["converged"].sum()), "matched_keyframes": int(sum(b[0] is not None for b in best.values())),
                 "median_translation_error_vs_truth_m": float(np.median(err)), "mean_iterations": float(full["iterations"][have].mean()),

@@ -195,8 +195,13 @@ SIGNATURES = {
     "mrgfe_node_forget": (C.c_int, [_vp, C.c_uint64]),
     "mrgfe_node_store_bytes": (C.c_size_t, [_vp]),
     "mrgfe_node_select_best": (C.c_int, [C.POINTER(PairResult), C.c_int, _ip, _ip, _dp]),
-    "mrgfe_dbg_node_fail_member": (C.c_int, [_vp, C.c_int]),
-    "mrgfe_dbg_fail_alloc_after": (C.c_long, [C.c_long]),
+    "mrgfe_batch_rounds": (C.c_int, [_vp]),
+    "mrgfe_batch_timing": (C.c_int, [_vp, _dp]),
+    "mrgfe_batch_timing_reset": (C.c_int, [_vp]),
+}
+
+# include/mrgfe_debug.h: diagnostic entry points (exported by the shipped library) ...
+DEBUG_SIGNATURES = {
     "mrgfe_dbg_set_gicp_corr_passes": (C.c_int, [C.c_int]),
     "mrgfe_dbg_grid_set_query": (C.c_int, [_vp, C.POINTER(_fp), C.POINTER(C.c_size_t), C.c_int, _fp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int32), _fp]),
     "mrgfe_dbg_sort_pairs": (C.c_int, [_vp, _u32p, _u32p, C.c_size_t, C.c_int, _u32p, _u32p]),
@@ -209,7 +214,6 @@ SIGNATURES = {
     "mrgfe_dbg_set_prefilter_device_driven": (C.c_int, [C.c_int]),
     "mrgfe_dbg_set_pclgicp_reference_order": (C.c_int, [C.c_int]),
     "mrgfe_dbg_set_fit_stats": (C.c_int, [C.c_int]),
-    "mrgfe_batch_rounds": (C.c_int, [_vp]),
     "mrgfe_dbg_sincosf": (None, [_fp, C.c_size_t, _fp, _fp]),
     "mrgfe_dbg_ctl_math": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _fp, _dp, _dp]),
     "mrgfe_dbg_ctl_create": (C.c_int, [C.POINTER(RegParams), _fp, C.c_uint32, C.POINTER(_vp)]),
@@ -218,13 +222,22 @@ SIGNATURES = {
     "mrgfe_dbg_ctl_result": (C.c_int, [_vp, C.c_double, _dp, _dp, C.c_double]),
     "mrgfe_dbg_ctl_final": (C.c_int, [_vp, _fp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
+# ... and its two fault injectors, which exist only in the -DMRGFE_TESTING build (libmrgfe_testing.so: tests/faultinject/ runs under MRGFE_LIB=that file)
+TESTING_SIGNATURES = {
+    "mrgfe_dbg_node_fail_member": (C.c_int, [_vp, C.c_int]),
+    "mrgfe_dbg_fail_alloc_after": (C.c_long, [C.c_long]),
+}
+TESTING_LIB_PATH = os.path.join(_PKG, "libmrgfe_testing.so")
 
 
 def build(force: bool = False) -> str:
     """Compile libmrgfe.so for gfx950 with hipcc (csrc/Makefile). No-op when it is newer than its sources."""
     srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".cpp", ".h")) or f == "Makefile"]
     srcs.append(os.path.join(os.path.dirname(_PKG), "include", "mrgfe.h"))
-    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    srcs.append(os.path.join(os.path.dirname(_PKG), "include", "mrgfe_debug.h"))
+    default_lib = os.path.join(_PKG, "libmrgfe.so")
+    outs = [default_lib, TESTING_LIB_PATH]  # (make builds both: the shipped library and the -DMRGFE_TESTING variant)
+    stale = force or any(not os.path.exists(o) or any(os.path.getmtime(s) > os.path.getmtime(o) for s in srcs) for o in outs)
     if stale:
         subprocess.run(["make", "-C", _CSRC, "-j8", "-s"] + (["-B"] if force else []), check=True)
     return LIB_PATH
@@ -250,11 +263,15 @@ def lib() -> C.CDLL:
             except Exception:  # noqa: BLE001
                 pass
         L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL if "torch" in sys.modules else C.DEFAULT_MODE)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in {**SIGNATURES, **DEBUG_SIGNATURES}.items():
             if os.environ.get("MRGFE_LIB") and os.environ.get("MRGFE_LIB_ALLOW_MISSING") and not hasattr(L, name):
                 continue  # an OLDER library file in an A/B measurement (MRGFE_LIB): symbols added since are simply not there
             f = getattr(L, name)  # AttributeError here == the library does not export a declared symbol
             f.restype, f.argtypes = res, args
+        for name, (res, args) in TESTING_SIGNATURES.items():  # only the testing variant has them
+            if hasattr(L, name):
+                f = getattr(L, name)
+                f.restype, f.argtypes = res, args
         _lib = L
     return _lib
 

@@ -143,6 +143,11 @@ struct mrgfe_batch {
     hipEvent_t uploads_done = nullptr;  // recorded on ctx->stream before helper streams read the batch's clouds (upload_cloud is stream-ordered only)
     uint64_t epoch = 1, tick = 0;
     size_t   store_cap = size_t(16384) << 20;
+    // mrgfe_batch_timing: the reference's per-candidate time (loop_detector.cpp:22-34): from the clear that starts queueing a batch to its records
+    std::chrono::steady_clock::time_point t_queue;
+    bool     t_queue_set = false;
+    double   last_us = 0.0, total_us = 0.0;
+    int64_t  last_pairs = 0, total_pairs = 0;
     // mrgfe_batch_align_async / mrgfe_batch_wait: a worker thread of the batch's own runs mrgfe_batch_align while the caller queues the next batch
     // on another object.  It takes the context lock BEFORE the async call returns, so every other call on this batch simply waits for the align.
     struct Async {
@@ -262,6 +267,7 @@ int mrgfe_reg_set_target(mrgfe_reg* reg, const float* xyzi, size_t n, size_t str
     MRGFE_TRY(upload_cloud(reg->ctx, xyzi, n, stride_bytes, reg->tgt.p));
     reg->d_tgt = reg->tgt.p;
     reg->n_tgt = n;
+    TraceRange tr("mrgfe_reg_set_target");
     return reg_target_changed(reg);
 }
 
@@ -310,6 +316,7 @@ int mrgfe_reg_align(mrgfe_reg* reg, const float guess[16], float* aligned_xyzi)
     if (!reg->has_target || !reg->has_source) { set_error("align: setInputTarget / setInputSource first"); return MRGFE_ERR_STATE; }
     MRGFE_LOCK(reg->ctx);
     MRGFE_TRY(reg->ctx->bind());
+    TraceRange tr("mrgfe_reg_align");
     float g[16];
     col2row(guess, g);
     if (reg->ndt) {
@@ -363,6 +370,7 @@ static int reg_ensure_nn(mrgfe_reg* reg)
 
 int mrgfe_reg_fitness(mrgfe_reg* reg, double max_range, double* out)
 {
+    TraceRange tr("mrgfe_reg_fitness");
     if (!reg || !out) { set_error("mrgfe_reg_fitness: NULL argument"); return MRGFE_ERR_INVALID; }
     if (!reg->has_target || !reg->has_source) { set_error("getFitnessScore: target / source not set"); return MRGFE_ERR_STATE; }
     MRGFE_LOCK(reg->ctx);
@@ -1115,6 +1123,8 @@ int mrgfe_batch_clear(mrgfe_batch* b)
     b->gicp.clear();
     b->pair_key.clear();
     ++b->epoch;  // stored keyframes stay; none is referenced by the (now empty) batch
+    b->t_queue = std::chrono::steady_clock::now();  // mrgfe_batch_timing: the next align's time starts where its queueing starts
+    b->t_queue_set = true;
     return MRGFE_OK;
 }
 int mrgfe_batch_add_target(mrgfe_batch* b, const float* xyzi, size_t n, size_t stride)
@@ -1258,6 +1268,7 @@ int mrgfe_batch_build_targets(mrgfe_batch* b)
     if (!b) { set_error("NULL batch"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(b->ctx);
     if (!is_ndt(b->params.method)) return MRGFE_OK;  // GICP variants: target covariances and grids are built by the first align
+    TraceRange tr("mrgfe set_target (batch)");
     return b->ndt->build_targets();
 }
 int mrgfe_batch_num_pairs(const mrgfe_batch* b) { return b ? b->ndt->n_pairs() : 0; }
@@ -1268,7 +1279,19 @@ int mrgfe_batch_align(mrgfe_batch* b, double fitness_max_range, mrgfe_pair_resul
 {
     if (!b || !results) { set_error("mrgfe_batch_align: NULL argument"); return MRGFE_ERR_INVALID; }
     MRGFE_LOCK(b->ctx);
-    const int st = batch_align_impl(b, fitness_max_range, results);
+    const auto t_start = b->t_queue_set ? b->t_queue : std::chrono::steady_clock::now();
+    int st;
+    {
+        TraceRange tr("mrgfe_batch_align");
+        st = batch_align_impl(b, fitness_max_range, results);
+    }
+    if (st == MRGFE_OK) {
+        b->last_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count();
+        b->last_pairs = b->ndt->n_pairs();
+        b->total_us += b->last_us;
+        b->total_pairs += b->last_pairs;
+    }
+    b->t_queue_set = false;
     // zero-copy uploads (mrgfe_ctx_set_zero_copy_uploads): the caller's page-locked clouds are its own again when this call returns — also when it fails
     // with their DMA still queued.  The error text of the failure is kept.
     if (st != MRGFE_OK && b->ctx->dma_from_caller) {
@@ -1466,13 +1489,18 @@ static int batch_align_impl(mrgfe_batch* b, double fitness_max_range, mrgfe_pair
                 }
                 if (jobs.empty()) return;
                 std::vector<double> fit(jobs.size(), 0.0);
+                TraceRange tr("mrgfe early fitness pass");
                 const int st = nn_fitness_batch(fc, jobs.data(), jobs.size(), fitness_max_range, fit.data());
                 if (st != MRGFE_OK) { fail(st, mrgfe_last_error()); return; }
                 b->fit_total.add(fc->fit_stats);
                 for (size_t j = 0; j < jobs.size(); ++j) { results[job_pair[j]].fitness = fit[j]; early_done[job_pair[j]] = 1; }
             });
         }
-        const int align_status = e.align_all(early_on ? &port : nullptr);
+        int align_status;
+        {
+            TraceRange tr("mrgfe rounds (set_target + align_all)");
+            align_status = e.align_all(early_on ? &port : nullptr);
+        }
         if (early.joinable()) early.join();
         for (std::thread& t : builders) t.join();
         MRGFE_TRY(align_status);
@@ -1492,6 +1520,7 @@ static int batch_align_impl(mrgfe_batch* b, double fitness_max_range, mrgfe_pair
         early_skip.swap(early_done);
     }
     if (fitness_max_range >= 0) {
+        TraceRange tr("mrgfe fitness passes");
         // getFitnessScore of every pair in one launch: one exact-NN grid per distinct target
         std::vector<NnGrid>& grids = b->fit_grids;
         if (grids.size() < static_cast<size_t>(e.n_targets())) grids.resize(e.n_targets());
@@ -1527,6 +1556,25 @@ int mrgfe_batch_fitness_stats(const mrgfe_batch* b, double out[11])
     const FitStats& f = b->fit_total;
     const double v[11] = {f.ms_block, f.ms_sweep, f.ms_far, double(f.queries), double(f.queued), double(f.queued_far), double(f.words), double(f.tested), double(f.cells), double(f.points), double(f.calls)};
     std::memcpy(out, v, sizeof(v));
+    return MRGFE_OK;
+}
+
+int mrgfe_batch_timing(const mrgfe_batch* b, double out[4])
+{
+    if (!b || !out) { set_error("mrgfe_batch_timing: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(b->ctx);
+    out[0] = b->total_pairs > 0 ? b->total_us / double(b->total_pairs) : 0.0;  // average_time_per_candidate_us (apps/mrg_slam_component.cpp:1032-1037)
+    out[1] = b->last_us;
+    out[2] = double(b->last_pairs);
+    out[3] = double(b->total_pairs);
+    return MRGFE_OK;
+}
+int mrgfe_batch_timing_reset(mrgfe_batch* b)
+{
+    if (!b) { set_error("mrgfe_batch_timing_reset: NULL batch"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(b->ctx);
+    b->last_us = b->total_us = 0.0;
+    b->last_pairs = b->total_pairs = 0;
     return MRGFE_OK;
 }
 
@@ -1698,7 +1746,9 @@ int mrgfe_dbg_ctl_math(mrgfe_ctx* ctx, const double* cases48, int n, int on_devi
     MRGFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return MRGFE_OK;
 }
+#ifdef MRGFE_TESTING
 long mrgfe_dbg_fail_alloc_after(long k) { return fail_alloc_after(k); }
+#endif
 
 int mrgfe_batch_rounds(const mrgfe_batch* b) { return b && b->ndt ? b->ndt->rounds() : 0; }
 

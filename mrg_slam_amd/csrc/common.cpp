@@ -1,4 +1,6 @@
 // csrc/common.cpp — error reporting, device / pinned workspaces, context lifetime.
+#include <dlfcn.h>
+
 #include "common.h"
 #include "ingest.h"
 
@@ -32,11 +34,12 @@ bool poll_disabled()
 // that reads what nobody wrote
 static bool poison_allocations() { static const bool v = std::getenv("MRGFE_POISON") != nullptr; return v; }
 
-// ---- allocation-failure injector (hardening tests) -------------------------------------------------------------------------------
+// ---- allocation-failure injector (hardening tests; -DMRGFE_TESTING builds only: libmrgfe_testing.so) ---------------------------------
 // mrgfe_dbg_fail_alloc_after(k) / MRGFE_FAIL_ALLOC_AFTER=k: the k-th device / pinned allocation from now (0 = the next one) reports an
-// out-of-memory error instead of calling HIP; every later one works again.  tests/test_gpu_hardening.py sweeps k over whole calls —
+// out-of-memory error instead of calling HIP; every later one works again.  tests/faultinject/ sweeps k over whole calls —
 // mrgfe_batch_align, mrgfe_prefilter, mrgfe_map_store_generate — and wants an error code from each, no leak, no std::terminate, and a
-// correct answer from the next call.
+// correct answer from the next call.  The shipped library compiles the check away.
+#ifdef MRGFE_TESTING
 static std::atomic<long> g_fail_alloc_in{[] { const char* e = std::getenv("MRGFE_FAIL_ALLOC_AFTER"); return e ? std::atol(e) : -1L; }()};
 static std::atomic<long> g_allocs{0};
 static bool inject_alloc_failure()
@@ -56,6 +59,32 @@ long fail_alloc_after(long k)
     g_fail_alloc_in.store(k, std::memory_order_relaxed);
     return g_allocs.exchange(0, std::memory_order_relaxed);
 }
+#else
+static inline bool inject_alloc_failure() { return false; }
+#endif
+
+// ---- roctx ranges -------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        if (std::getenv("MRGFE_NO_ROCTX")) return;
+        for (const char* name : {"libroctx64.so.4", "libroctx64.so", "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so"}) {
+            if (void* lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+TraceRange::TraceRange(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+TraceRange::~TraceRange() { if (on) roctx().pop(); }
 
 int DevBuf::ensure(size_t bytes)
 {

@@ -13,11 +13,14 @@
 #include <vector>
 
 #include "../../include/mrgfe.h"
+#include "../../include/mrgfe_debug.h"
 
 namespace mrgfe {
 
 void set_error(const char* fmt, ...);
+#ifdef MRGFE_TESTING
 long fail_alloc_after(long k);  // allocation-failure injector (common.cpp): the k-th allocation from now fails (k < 0: off); returns the allocations counted since the last call
+#endif
 
 #define MRGFE_HIP_CHECK(expr)                                                                                   \
     do {                                                                                                        \
@@ -186,7 +189,16 @@ namespace mrgfe {
 // copy a host cloud into packed float4 device memory via the pinned staging ring; `layout` is the stride_bytes argument of the C
 // ABI (16, or MRGFE_LAYOUT(stride, xyz offset, intensity offset): such records are gathered on the device)
 int upload_cloud(mrgfe_ctx* ctx, const float* xyzi, size_t n, size_t layout, void* d_dst, int pin_slot = 0);
-void drain_caller_dma(mrgfe_ctx* ctx);  // error paths: wait for zero-copy uploads still reading the caller's page-locked buffers
+void drain_caller_dma(mrgfe_ctx* ctx);
+// roctx ranges around the phases of a call (set_target / rounds / fitness / gather): visible to rocprofv3 --marker-trace and to any roctx consumer; libroctx64 is
+// found through dlopen, and the range is a no-op when it is not there
+struct TraceRange {
+    explicit TraceRange(const char* name);
+    ~TraceRange();
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+    bool on;
+};  // error paths: wait for zero-copy uploads still reading the caller's page-locked buffers
 int decode_layout(size_t layout, uint32_t* stride, uint32_t* xyz_off, int32_t* intensity_off);
 // a helper context of `parent` (builder threads of a batch, GICP lanes): same device, same compute-unit mask
 int ctx_create_like(const mrgfe_ctx* parent, mrgfe_ctx** out, int priority = 0);  // priority: see mrgfe_ctx::priority

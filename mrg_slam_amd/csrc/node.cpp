@@ -139,11 +139,13 @@ int member_align(mrgfe_node* node, Member& m)
     m.status = MRGFE_OK;
     m.error.clear();
     m.local.assign(static_cast<size_t>(m.count), mrgfe_pair_result{});
+#ifdef MRGFE_TESTING
     if (m.fail_next) {
         m.fail_next = 0;
         set_error("member %d: failure injected by mrgfe_dbg_node_fail_member", m.index);
         return member_fail(m, MRGFE_ERR_STATE);
     }
+#endif
     if (m.count == 0) return MRGFE_OK;
     ++m.align_serial;
     int st = mrgfe_batch_clear(m.batch);
@@ -471,8 +473,11 @@ int mrgfe_node_align(mrgfe_node* node, double fitness_max_range, mrgfe_pair_resu
         m->first = g * base + std::min(g, extra);
         m->count = base + (g < extra ? 1 : 0);
     }
-    for (Member* m : node->members) post(m, JOB_ALIGN);
-    for (Member* m : node->members) wait_done(m);
+    {
+        TraceRange tr("mrgfe_node_align members");
+        for (Member* m : node->members) post(m, JOB_ALIGN);
+        for (Member* m : node->members) wait_done(m);
+    }
     for (Member* m : node->members)
         if (m->status != MRGFE_OK) {  // the first member that failed names the error; the others have finished their blocks and are idle again
             set_error("mrgfe_node_align: member %d (device %d): %s", m->index, m->device, m->error.c_str());
@@ -482,6 +487,7 @@ int mrgfe_node_align(mrgfe_node* node, double fitness_max_range, mrgfe_pair_resu
     node->last_gather = 0;
     if (want_rccl(node) && rccl_setup(node) == MRGFE_OK) {
         const int per = (n + G - 1) / G;
+        TraceRange tr("mrgfe_node_align record gather (RCCL)");
         const int st = rccl_gather(node, per, results, n);
         if (st == MRGFE_OK) { node->last_gather = 1; return MRGFE_OK; }
         if (const char* e = std::getenv("MRGFE_NODE_GATHER")) if (std::strcmp(e, "rccl") == 0) return st;  // asked for: do not hide the failure
@@ -550,11 +556,13 @@ int mrgfe_node_select_best(const mrgfe_pair_result* results, int n_groups, const
     return MRGFE_OK;
 }
 
+#ifdef MRGFE_TESTING
 int mrgfe_dbg_node_fail_member(mrgfe_node* node, int member)
 {
     if (!node || member < 0 || member >= static_cast<int>(node->members.size())) { set_error("mrgfe_dbg_node_fail_member: bad argument"); return MRGFE_ERR_INVALID; }
     node->members[static_cast<size_t>(member)]->fail_next = 1;
     return MRGFE_OK;
 }
+#endif
 
 }  // extern "C"

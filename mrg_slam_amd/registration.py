@@ -425,6 +425,14 @@ class BatchMatcher:
     def store_bytes(self) -> int:
         return int(lib().mrgfe_batch_store_bytes(self._h))
 
+    def timing(self, reset: bool = False) -> dict:
+        """``mrgfe_batch_timing``: the reference's ``average_time_per_candidate_us`` (apps/mrg_slam_component.cpp:1032-1037) for this batch object."""
+        v = (C.c_double * 4)()
+        check(lib().mrgfe_batch_timing(self._h, v))
+        if reset:
+            check(lib().mrgfe_batch_timing_reset(self._h))
+        return {"average_time_per_candidate_us": float(v[0]), "last_align_us": float(v[1]), "last_align_pairs": int(v[2]), "total_pairs": int(v[3])}
+
     def forget(self, key: int = 0) -> None:
         check(lib().mrgfe_batch_forget(self._h, key))
 
@@ -579,6 +587,8 @@ class NodeMatcher:
         return int(lib().mrgfe_node_store_bytes(self._h))
 
     def fail_member_once(self, member: int):
+        if not hasattr(lib(), "mrgfe_dbg_node_fail_member"):
+            raise RuntimeError("mrgfe_dbg_node_fail_member exists only in the -DMRGFE_TESTING build (MRGFE_LIB=mrg_slam_amd/libmrgfe_testing.so)")
         check(lib().mrgfe_dbg_node_fail_member(self._h, member))
 
     @staticmethod

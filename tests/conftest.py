@@ -14,6 +14,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# tests/faultinject/ needs the -DMRGFE_TESTING build of the library: collected only in the child process tests/test_gpu_hardening.py starts for it
+collect_ignore = [] if os.environ.get("MRGFE_FAULTINJECT") else ["faultinject"]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with `pytest -m gpu`)")
 

@@ -9,9 +9,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "mrgfe.h")).read()
+def _declared_symbols(header="mrgfe.h", testing=None):
+    """Function names a header declares; testing=None: all of them, True / False: only those inside / outside `#ifdef MRGFE_TESTING`."""
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    m = re.search(r"#ifdef MRGFE_TESTING(.*?)#endif", txt, flags=re.S)
+    inside = m.group(1) if m else ""
+    if testing is True:
+        txt = inside
+    elif testing is False and m:
+        txt = txt[: m.start()] + txt[m.end():]
     return sorted(set(re.findall(r"\b(mrgfe_[a-z0-9_]+)\s*\(", txt)))
 
 
@@ -26,6 +33,28 @@ def test_library_exports_every_declared_symbol():
     # and the Python binding table covers the header exactly
     assert sorted(_lib.SIGNATURES) == declared
     assert b"gfx950" in L.mrgfe_version()
+    # the integrator's header carries no diagnostic entry point (21 mrgfe_dbg_* declarations sat in it)
+    assert not [s for s in declared if s.startswith("mrgfe_dbg_")]
+
+
+def test_debug_header_and_the_testing_variant():
+    """include/mrgfe_debug.h: the diagnostic entry points (exported by the shipped library, bound by the ctypes table) and, under MRGFE_TESTING, the two
+    fault injectors — which the shipped libmrgfe.so must NOT export and mrg_slam_amd/libmrgfe_testing.so must."""
+    from mrg_slam_amd import _lib
+
+    _lib.build()
+    diag, inject = _declared_symbols("mrgfe_debug.h", testing=False), _declared_symbols("mrgfe_debug.h", testing=True)
+    assert sorted(_lib.DEBUG_SIGNATURES) == diag and all(s.startswith("mrgfe_dbg_") for s in diag) and len(diag) >= 15
+    assert sorted(_lib.TESTING_SIGNATURES) == inject == ["mrgfe_dbg_fail_alloc_after", "mrgfe_dbg_node_fail_member"]
+    shipped = C.CDLL(os.path.join(ROOT, "mrg_slam_amd", "libmrgfe.so"))
+    testing = C.CDLL(_lib.TESTING_LIB_PATH)
+    for s in diag:
+        assert hasattr(shipped, s) and hasattr(testing, s), s
+    for s in inject:
+        assert not hasattr(shipped, s), f"the shipped library exports the fault injector {s}"
+        assert hasattr(testing, s), s
+    for s in _declared_symbols():
+        assert hasattr(testing, s), s
 
 
 def test_struct_layouts_match_the_header():

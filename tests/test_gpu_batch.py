@@ -323,3 +323,30 @@ def test_fitness_grids_wait_for_the_target_upload(monkeypatch):
         for a, b in zip(*got):
             assert a["fitness"] == b["fitness"] and np.isfinite(a["fitness"])
             np.testing.assert_array_equal(a["T"], b["T"])
+
+
+def test_batch_timing_is_the_references_per_candidate_statistic():
+    """mrgfe_batch_timing: average_time_per_candidate_us as apps/mrg_slam_component.cpp:1032-1037 writes it (total loop-detection wall time over total
+    candidates, loop_detector.cpp:22-34) for a batch object: queueing (from the clear) to records, over the pairs aligned; totals add up over calls."""
+    import time
+
+    from mrg_slam_amd import BatchMatcher
+
+    tgt = small_cloud(6000, 3)
+    bm = BatchMatcher(transformation_epsilon=0.01, maximum_iterations=64)
+    assert bm.timing() == {"average_time_per_candidate_us": 0.0, "last_align_us": 0.0, "last_align_pairs": 0, "total_pairs": 0}
+    walls = []
+    for n in (3, 5):
+        t0 = time.perf_counter()
+        bm.clear()
+        t = bm.add_target(tgt)
+        for k in range(n):
+            bm.add_pair(t, tgt[: 4000 + 100 * k].copy(), np.eye(4))
+        bm.align(float("inf"))
+        walls.append(1e6 * (time.perf_counter() - t0))
+        tm = bm.timing()
+        assert tm["last_align_pairs"] == n and 0 < tm["last_align_us"] <= walls[-1]
+        assert tm["last_align_us"] > 0.5 * walls[-1]  # the statistic covers the call sequence, not just a kernel
+    tm = bm.timing(reset=True)
+    assert tm["total_pairs"] == 8 and abs(tm["average_time_per_candidate_us"] * 8 - sum(walls)) < 0.5 * sum(walls)
+    assert bm.timing()["total_pairs"] == 0

@@ -1,7 +1,7 @@
 """GPU hardening: bad arguments into the C ABI come back as error codes (huge sizes, NaN / negative parameters, layout misuse, wrong indices), and
-an allocation-failure injector (mrgfe_dbg_fail_alloc_after) swept over whole entry points — mrgfe_batch_align (NDT and GICP), mrgfe_prefilter,
-mrgfe_map_store_generate, mrgfe_node_align — shows every path unwinding with an error code: no crash, no std::terminate from a joinable helper
-thread, and the next call (injector off) gives the right answer."""
+the fault-injection suite (tests/faultinject/: an allocation-failure injector swept over whole entry points — mrgfe_batch_align (NDT and GICP),
+mrgfe_prefilter, mrgfe_map_store_generate, mrgfe_node_align — every path unwinding with an error code) runs in a child process bound to the
+-DMRGFE_TESTING build of the library; the shipped libmrgfe.so has no injector."""
 import ctypes as C
 
 import numpy as np
@@ -65,112 +65,6 @@ def test_bad_arguments_are_error_codes():
     assert L.mrgfe_distance_filter(ctx._h, p, 500, 16, 0.1, 35.0, out.ctypes.data_as(_fp), C.byref(m)) == 0 and 0 < m.value <= 500
 
 
-def _sweep(make, run, check_ok, max_k=400):
-    """fresh objects per k (grow-only workspaces would hide later allocations); every k must fail cleanly until one passes"""
-    from mrg_slam_amd import MrgfeError
-    from mrg_slam_amd._lib import lib
-
-    failures = 0
-    for k in range(max_k):
-        obj = make()
-        lib().mrgfe_dbg_fail_alloc_after(k)
-        try:
-            res = run(obj)
-        except MrgfeError as e:
-            assert "injected" in str(e) or "out of memory" in str(e).lower() or "member" in str(e), str(e)
-            failures += 1
-            continue
-        finally:
-            lib().mrgfe_dbg_fail_alloc_after(-1)
-        check_ok(res)  # the injection point lay beyond the call's last allocation: the call ran to the end
-        # a failed object must be reusable... the LAST failing one is gone; run once more on this one for the steady state
-        check_ok(run(obj))
-        return failures
-    raise AssertionError(f"still failing after {max_k} injected allocation failures")
-
-
-@pytest.mark.parametrize("method", ["NDT_HIP", "SMALL_GICP_HIP", "PCL_NDT_HIP"])
-def test_allocation_failures_in_batch_align_unwind(method):
-    from mrg_slam_amd import BatchMatcher, Context, _lib, synth
-    from mrg_slam_amd.registration import default_params
-    from oracle import oracle as orc
-
-    tgt = small_cloud(3000, 5)
-    rng = np.random.default_rng(1)
-    pairs = []
-    for k in range(5):
-        rel = synth.make_pose(rng.normal(0, 0.2, 3), synth.rot_xyz(*rng.normal(0, 0.02, 3)))
-        pairs.append((orc.transform_points(np.linalg.inv(rel), tgt[: 1800 + 100 * k]), synth.perturb_pose(np.eye(4), rng)))
-    prm = default_params(getattr(_lib, method))
-
-    def run(bm):
-        bm.clear()
-        t = bm.add_target(tgt)
-        for src, g in pairs:
-            bm.add_pair(t, src, g)
-        return bm.align(float("inf"))
-
-    want = run(BatchMatcher(prm, Context(0)))
-
-    def ok(res):
-        assert res.tobytes() == want.tobytes()
-
-    n = _sweep(lambda: BatchMatcher(prm, Context(0)), run, ok)
-    assert n >= 10  # the sweep really walked through the call's allocations
-
-
-def test_allocation_failures_in_prefilter_and_map_store_unwind():
-    from mrg_slam_amd import Context, MapCloudStore, prefilter, synth
-
-    raw = small_cloud(6000, 9, extent=(40, 30, 4))
-    want = prefilter(raw)
-    n = _sweep(lambda: Context(0), lambda ctx: prefilter(raw, ctx=ctx), lambda r: np.testing.assert_array_equal(r, want))
-    assert n >= 5
-    for mode in ({"outlier_removal_method": "STATISTICAL"}, {"downsample_method": "APPROX_VOXELGRID"}):
-        w2 = prefilter(raw, mode)
-        _sweep(lambda: Context(0), lambda ctx, mode=mode: prefilter(raw, mode, ctx=ctx), lambda r, w2=w2: np.testing.assert_array_equal(r, w2))
-    clouds = [small_cloud(2000, 20 + k) for k in range(4)]
-    poses = [synth.make_pose([2.0 * k, -1.0 * k, 0.0], synth.rot_xyz(0, 0, 0.2 * k)) for k in range(4)]
-    ref_store = MapCloudStore(Context(0))
-    for k, c in enumerate(clouds):
-        ref_store.add(10 + k, c)
-    want_map = ref_store.generate([10, 11, 12, 13], poses, resolution=0.25)
-
-    def run(store):
-        for k, c in enumerate(clouds):
-            store.add(10 + k, c)  # (adding a key again with the same point count is a no-op)
-        return store.generate([10, 11, 12, 13], poses, resolution=0.25)
-
-    n = _sweep(lambda: MapCloudStore(Context(0)), run, lambda r: np.testing.assert_array_equal(r, want_map))
-    assert n >= 5
-
-
-def test_allocation_failures_in_node_align_name_the_member():
-    from mrg_slam_amd import NodeMatcher, synth
-    from mrg_slam_amd._lib import NDT_HIP
-    from mrg_slam_amd.registration import default_params
-    from oracle import oracle as orc
-
-    tgt = small_cloud(3000, 6)
-    rng = np.random.default_rng(2)
-    pairs = []
-    for k in range(6):
-        rel = synth.make_pose(rng.normal(0, 0.2, 3), synth.rot_xyz(*rng.normal(0, 0.02, 3)))
-        pairs.append((orc.transform_points(np.linalg.inv(rel), tgt[: 1800 + 100 * k]), synth.perturb_pose(np.eye(4), rng)))
-    prm = default_params(NDT_HIP)
-
-    def run(node):
-        node.clear()
-        t = node.add_target(tgt)
-        for src, g in pairs:
-            node.add_pair(t, src, g)
-        return node.align(float("inf"))
-
-    want = run(NodeMatcher([0, 0], prm))
-    n = _sweep(lambda: NodeMatcher([0, 0], prm), run, lambda r: r.tobytes() == want.tobytes() or (_ for _ in ()).throw(AssertionError("records differ")))
-    assert n >= 10
-
-
 def test_page_locked_host_clouds_upload_by_dma_with_the_same_results():
     """mrgfe.h (mrgfe_ctx_set_zero_copy_uploads): with the switch on a cloud in page-locked memory is read by DMA straight from the caller's buffer, a
     pageable one goes through the staging ring.  Same bytes in HBM either way: the batch records must be byte-identical, also for clouds that start in the MIDDLE of a pinned range
@@ -214,10 +108,9 @@ def test_page_locked_host_clouds_upload_by_dma_with_the_same_results():
 
 def test_cloud_whose_tail_leaves_the_page_locked_range_is_staged_not_dma():
     """the zero-copy upload looked at the cloud's FIRST byte only.  A cloud that starts inside a registered range and ends in pageable memory
-    must take the staging ring (both ends are checked now); same records as the pageable cloud.  And a failing align that has queued zero-copy uploads
-    waits for them before it returns (mrgfe.h: the buffers are the caller's again when the consuming call returns) — seen here as: the failure is an
-    error code, the buffer can be unpinned and freed right away, and the next align gives the right records."""
-    from mrg_slam_amd import BatchMatcher, Context, MrgfeError
+    must take the staging ring (both ends are checked now); same records as the pageable cloud.  (The failing-align half of that finding — queued
+    zero-copy uploads are waited for before an error returns — needs the allocation-failure injector: tests/faultinject/.)"""
+    from mrg_slam_amd import BatchMatcher, Context
     from mrg_slam_amd._lib import lib
 
     ctx = Context()
@@ -239,22 +132,24 @@ def test_cloud_whose_tail_leaves_the_page_locked_range_is_staged_not_dma():
             assert got.tobytes() == want.tobytes()
     finally:
         assert lib().mrgfe_unpin_host_buffer(ctx._h, slab.ctypes.data_as(C.c_void_p)) == 0
-    # failing align with zero-copy uploads queued: injected allocation failure, then the pinned cloud is released at once
-    pinned = t.copy()
-    ctx = Context()  # (fresh: grow-only workspaces of the context above would leave the align nothing to allocate)
-    ctx.set_zero_copy_uploads(True)
-    assert lib().mrgfe_pin_host_buffer(ctx._h, pinned.ctypes.data_as(C.c_void_p), pinned.nbytes) == 0
-    bm = BatchMatcher(ctx=ctx)
-    bm.add_pair(bm.add_target(pinned), s, np.eye(4))
-    lib().mrgfe_dbg_fail_alloc_after(2)
-    try:
-        with pytest.raises(MrgfeError):
-            bm.align()
-    finally:
-        lib().mrgfe_dbg_fail_alloc_after(-1)
-        assert lib().mrgfe_unpin_host_buffer(ctx._h, pinned.ctypes.data_as(C.c_void_p)) == 0
-    pinned[:] = 0.0
-    del pinned
-    bm.clear()
-    bm.add_pair(bm.add_target(t), s, np.eye(4))
-    assert bm.align().tobytes() == want.tobytes()
+
+
+def test_fault_injection_suite_under_the_testing_library():
+    """The fault injectors (mrgfe_dbg_fail_alloc_after, mrgfe_dbg_node_fail_member: include/mrgfe_debug.h under MRGFE_TESTING) are NOT in the shipped
+    libmrgfe.so; they exist in mrg_slam_amd/libmrgfe_testing.so (same kernel objects, three host translation units compiled with -DMRGFE_TESTING).  The
+    tests that sweep allocation failures over whole entry points live in tests/faultinject/ and run here in ONE child process bound to that library
+    (MRGFE_LIB) — never an exec of this process, which has initialised the GPU."""
+    import os
+    import subprocess
+    import sys
+
+    from mrg_slam_amd import _lib
+
+    assert not hasattr(_lib.lib(), "mrgfe_dbg_fail_alloc_after") or os.environ.get("MRGFE_LIB"), "the shipped library carries a fault injector"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MRGFE_LIB=_lib.TESTING_LIB_PATH, MRGFE_FAULTINJECT="1", OMP_NUM_THREADS="8")
+    run = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "faultinject"), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"], env=env, capture_output=True,
+                         text=True, timeout=1500)
+    print(run.stdout[-3000:])
+    assert run.returncode == 0, run.stdout[-4000:] + run.stderr[-2000:]
+    assert " passed" in run.stdout and "failed" not in run.stdout.splitlines()[-1]

@@ -1,7 +1,6 @@
 """GPU: mrgfe_node_* — the loop-closure candidate batch over several members (one per GPU on a real node; here N members on the one card of the
 box, which is what the header allows for exactly this purpose): the gathered records must equal those of ONE batch holding the whole pair list bit
-for bit, for uneven blocks, keyed and unkeyed clouds, every method the batch API serves; a failing member returns an error code and leaves the
-node usable; the RCCL gather is exercised with one member (RCCL refuses duplicate devices)."""
+for bit, for uneven blocks, keyed and unkeyed clouds, every method the batch API serves (a failing member: tests/faultinject/); the RCCL gather is exercised with one member (RCCL refuses duplicate devices)."""
 import numpy as np
 import pytest
 
@@ -145,27 +144,12 @@ def test_member_target_store_is_bounded_lru(monkeypatch):
     assert node.align(float("inf")).tobytes() == big.align(float("inf")).tobytes()
 
 
-def test_a_failing_member_returns_an_error_and_the_node_stays_usable():
+def test_node_bad_arguments_are_error_codes():
     from mrg_slam_amd import MrgfeError, NodeMatcher
     from mrg_slam_amd._lib import NDT_HIP
 
     targets, pairs = _workload(n_targets=2, n_pairs=6, seed=4)
-    want = _one_batch(_params(NDT_HIP), targets, pairs)
     node = NodeMatcher([0, 0, 0], _params(NDT_HIP))
-
-    def declare():
-        node.clear()
-        tids = [node.add_target(t) for t in targets]
-        for ti, src, guess in pairs:
-            node.add_pair(tids[ti], src, guess)
-
-    declare()
-    node.fail_member_once(1)
-    with pytest.raises(MrgfeError, match=r"member 1 \(device 0\)"):
-        node.align(float("inf"))
-    declare()
-    assert node.align(float("inf")).tobytes() == want.tobytes()
-    # bad arguments are error codes, not crashes
     with pytest.raises(MrgfeError):
         node.add_pair(99, pairs[0][1], pairs[0][2])
     with pytest.raises(MrgfeError):

@@ -12,7 +12,7 @@ from mrg_slam_amd import _lib  # noqa: E402
 L = _lib.lib()
 skip = {"mrgfe_last_error", "mrgfe_version"}
 bad = []
-for name, (res, args) in sorted(_lib.SIGNATURES.items()):
+for name, (res, args) in sorted({**_lib.SIGNATURES, **_lib.DEBUG_SIGNATURES}.items()):
     if name in skip:
         continue
     print("calling", name, flush=True)
@@ -24,8 +24,6 @@ for name, (res, args) in sorted(_lib.SIGNATURES.items()):
             vals.append(a(0.0))
         else:
             vals.append(None)  # every pointer NULL
-    if name == "mrgfe_dbg_fail_alloc_after":
-        vals = [C.c_long(-1)]
     r = getattr(L, name)(*vals)
     if res is C.c_int and name.startswith(("mrgfe_reg_", "mrgfe_batch_", "mrgfe_node_", "mrgfe_map_store_", "mrgfe_ctx_")) and not name.endswith(("_has_converged", "_iterations", "_evaluations", "_num_pairs", "_num_members", "_has_cloud", "_has", "_rounds", "_last_gather", "_select_best")):
         if r >= 0:
