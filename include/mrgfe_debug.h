@@ -48,6 +48,12 @@ int mrgfe_dbg_set_host_control(int mode);
  * 0 = one launch per variant.  Any other value only asks.  Returns the setting in effect.  Same sums either way: an item's partial
  * record does not depend on the launch it is computed in (tests/test_gpu_control.py). */
 int mrgfe_dbg_set_fused_launch(int mode);
+/* NDT_HIP's f64 sums during the following alignments of this process: 1 = in the REFERENCE's order — ndt_omp adds a point's voxel terms from zero, then the
+ * per-point sums point after point ("invariant against the summing up order"), and computeHessian pair after pair on one thread — reproduced by a record
+ * kernel + one dependent-add chain per accumulator (csrc/ndt_derivatives.hip ndt_ref_*): bit-identical to the reference-order oracle, results inside the
+ * 1e-4 bar unconditionally, several times slower (a 130k-step chain per evaluation whatever the batch size; host-stepped rounds); 0 = the tree (default; the
+ * environment variable MRGFE_NDT_REFERENCE_ORDER sets the initial value).  Any other value only asks.  Returns the setting in effect. */
+int mrgfe_dbg_set_ndt_reference_order(int mode);
 /* How getFitnessScore's far pass runs during the following calls of this process: 1 = seed + sweep (nn_fit_sweep_kernel: a near occupied
  * cell found through the occupancy words gives a radius, the occupied cells inside it are enumerated top-down with bit masks; default,
  * MRGFE_FIT_SWEEP sets the initial value), 0 = round 2's pyramid walk for every queued query.  Any other value only asks.  Returns the

@@ -210,6 +210,7 @@ DEBUG_SIGNATURES = {
     "mrgfe_dbg_minmax": (C.c_int, [_vp, _fp, C.c_size_t, _fp, _fp, _u32p]),
     "mrgfe_dbg_set_host_control": (C.c_int, [C.c_int]),
     "mrgfe_dbg_set_fused_launch": (C.c_int, [C.c_int]),
+    "mrgfe_dbg_set_ndt_reference_order": (C.c_int, [C.c_int]),
     "mrgfe_dbg_set_fit_sweep": (C.c_int, [C.c_int]),
     "mrgfe_dbg_set_prefilter_device_driven": (C.c_int, [C.c_int]),
     "mrgfe_dbg_set_pclgicp_reference_order": (C.c_int, [C.c_int]),

@@ -1710,6 +1710,7 @@ int mrgfe_dbg_set_host_control(int mode)
     return MRGFE_OK;
 }
 int mrgfe_dbg_set_fused_launch(int mode) { return ndt_set_fused_launch(mode); }
+int mrgfe_dbg_set_ndt_reference_order(int mode) { return ndt_set_reference_order(mode); }
 int mrgfe_dbg_set_fit_sweep(int mode) { return nn_set_fit_sweep(mode); }
 int mrgfe_dbg_set_fit_stats(int mode) { return nn_set_fit_stats(mode); }
 void mrgfe_dbg_sincosf(const float* x, size_t n, float* sin_out, float* cos_out)

@@ -678,6 +678,287 @@ __device__ __forceinline__ void ndt_derivatives_f64_item(NdtDerivShared<27>& sh,
     }
 }
 
+// ---- NDT_OMP in the REFERENCE's summation order (opt-in: MRGFE_NDT_REFERENCE_ORDER=1 / mrgfe_dbg_set_ndt_reference_order) ------------------
+// The default kernels above add the per-pair terms in a tree: every sum differs from the reference's by rounding (1e-16 relative), which an
+// optimisation that does not settle can amplify past the 1e-4 bar.  ndt_omp's own order is
+//   computeDerivatives:  per POINT the terms of its voxels are added from zero in neighbourhood order (scores[i], score_gradients[i],
+//                        hessians[i]), then those per-point sums are added point after point ("invariant against the summing up order");
+//   computeHessian:      one thread, hess(i, j) += e * (...) pair after pair, in PCL's f64 association.
+// Both are chains of dependent f64 additions over the whole cloud: they cannot be split without changing the roundings.  So the work is
+// cut in two kernels: ndt_ref_records_kernel computes, fully parallel, what each step of the chain adds — 44 doubles per point, or 37 per
+// (point, voxel) pair for the f64 Hessian — and ndt_ref_chain_kernel walks them in order, one lane per accumulator (a wavefront per
+// evaluation).  ~8 cycles per dependent f64 add: 0.45 ms per 130k-point evaluation, 1.9 ms per f64 Hessian pass (570k pairs), whatever the
+// batch size; the records are 46 MB / 270 MB per evaluation.  Same per-pair float terms as everywhere else (pair_float), hence results
+// bit-identical to the reference-order oracle (oracle/ndt.cpp compute_derivatives_impl<true> / compute_hessian_impl<true>).
+template <int NNB>
+__device__ __forceinline__ uint32_t ndt_point_neighbours(const NdtGridDev& g, bool kdtree, const float xt[3], int32_t (&ids)[NNB])
+{
+    const float leaf = g.leaf_size;
+    int ijk[3];
+    if (leaf == 1.0f) { ijk[0] = static_cast<int>(floorf(xt[0])); ijk[1] = static_cast<int>(floorf(xt[1])); ijk[2] = static_cast<int>(floorf(xt[2])); }
+    else              { ijk[0] = static_cast<int>(floorf(xt[0] / leaf)); ijk[1] = static_cast<int>(floorf(xt[1] / leaf)); ijk[2] = static_cast<int>(floorf(xt[2] / leaf)); }
+    bool in_box[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int o = -1; o <= 1; ++o) in_box[a][o + 1] = ijk[a] + o >= g.min_b[a] && ijk[a] + o <= g.max_b[a];
+    const uint32_t mul[3] = {static_cast<uint32_t>(g.divb_mul[0]), static_cast<uint32_t>(g.divb_mul[1]), static_cast<uint32_t>(g.divb_mul[2])};
+    const uint32_t key0 = (static_cast<uint32_t>(ijk[0]) - static_cast<uint32_t>(g.min_b[0])) * mul[0] + (static_cast<uint32_t>(ijk[1]) - static_cast<uint32_t>(g.min_b[1])) * mul[1] +
+                          (static_cast<uint32_t>(ijk[2]) - static_cast<uint32_t>(g.min_b[2])) * mul[2];
+    uint32_t cnt = 0;
+    float    dist[NNB == 27 ? 27 : 1];
+#pragma unroll
+    for (int n = 0; n < NNB; ++n) {
+        int o0, o1, o2;
+        if (NNB == 27) { o0 = n / 9 - 1; o1 = (n / 3) % 3 - 1; o2 = n % 3 - 1; }
+        else if (NNB == 7) { o0 = (n == 1) - (n == 2); o1 = (n == 3) - (n == 4); o2 = (n == 5) - (n == 6); }
+        else           { o0 = o1 = o2 = 0; }
+        const bool     ok = in_box[0][o0 + 1] && in_box[1][o1 + 1] && in_box[2][o2 + 1];
+        const uint32_t key = key0 + static_cast<uint32_t>(o0) * mul[0] + static_cast<uint32_t>(o1) * mul[1] + static_cast<uint32_t>(o2) * mul[2];
+        int32_t id = -1;
+        if (ok) id = g.dense ? as_global(static_cast<const int32_t*>(g.lookup))[key] : ndt_lookup(g, key);
+        if (id >= 0 && static_cast<uint32_t>(id) >= g.n_leaves) id = -1;  // cannot happen; keeps a corrupted table entry from faulting the GPU
+        if (kdtree && id >= 0) {  // radiusSearch(point, resolution) over voxel centroids: FLANN keeps dist^2 < r^2
+            const float4 c = load_point(g.centroid + id);
+            const float  dx = c.x - xt[0], dy = c.y - xt[1], dz = c.z - xt[2];
+            const float  d = dot3f(dx, dx, dy, dy, dz, dz);
+            if (!(d < leaf * leaf)) id = -1;
+            else if (NNB == 27) dist[n] = d;
+        }
+        ids[n] = id;
+        cnt += id >= 0 ? 1u : 0u;
+    }
+    if (NNB == 27 && kdtree && cnt > 1) {
+        // the kd-tree hands its hits over sorted by (distance, index): that is the order the reference adds a point's voxels in.  Compact, then an
+        // insertion sort over the few hits (private arrays with runtime indices: scratch memory — this path is the opt-in reference-order mode only)
+        uint32_t m = 0;
+        for (int n = 0; n < NNB; ++n)
+            if (ids[n] >= 0) { ids[m] = ids[n]; dist[m] = dist[n]; ++m; }
+        for (uint32_t n = m; n < NNB; ++n) ids[n] = -1;
+        for (uint32_t a = 1; a < m; ++a) {
+            const float   da = dist[a];
+            const int32_t ia = ids[a];
+            uint32_t b = a;
+            while (b > 0 && (dist[b - 1] > da || (dist[b - 1] == da && ids[b - 1] > ia))) { dist[b] = dist[b - 1]; ids[b] = ids[b - 1]; --b; }
+            dist[b] = da;
+            ids[b] = ia;
+        }
+    }
+    return cnt;
+}
+
+// rec layout of one job (doubles, column-major so that the chain's lane k streams column k):
+//   mode 0 / 1:  rec[k * n_src + i], k = 0 score, 1..6 gradient, 7..42 Hessian (mode 0 only), 43 the point's neighbour count
+//   mode 2:      rec[k * (n_src * NNB) + i * NNB + j], k = 0 the pair's weight e, 1..36 the bracket of hess(i, j) — the j-th CONTRIBUTING pair of
+//                point i; cnt8[i] = how many there are; column 37's first n_src entries hold the neighbour counts (as doubles)
+template <int NNB>
+__global__ __launch_bounds__(256, 2) void ndt_ref_records_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs, const NdtEvalDev* __restrict__ evals,
+                                                                  const NdtRefJob* __restrict__ jobs, double* __restrict__ rec_base, uint8_t* __restrict__ cnt_base)
+{
+    const NdtRefJob job = jobs[blockIdx.y];
+    const NdtPairDev pr = pairs[job.pair];
+    if (blockIdx.x * 256u >= pr.n_src) return;  // (uniform: the grid is as wide as the job with the most tiles)
+    const NdtEvalDev& ev = evals[job.pair];
+    const NdtGridDev  g = grids[pr.grid];
+    __shared__ float s_T[12];
+    if (threadIdx.x < 12) s_T[threadIdx.x] = ev.T[threadIdx.x];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= pr.n_src) return;
+    const size_t n = pr.n_src;
+    double* __restrict__ rec = rec_base + job.rec_off;
+    const float4 p = load_point(pr.src + i);
+    float xt[3];
+    transform_point(s_T, p.x, p.y, p.z, xt[0], xt[1], xt[2]);
+    int32_t ids[NNB];
+    const uint32_t cnt = ndt_point_neighbours<NNB>(g, (NNB == 27) && (ev.search == MRGFE_KDTREE), xt, ids);
+    const float  gauss_d2f = static_cast<float>(ev.gauss_d2);
+    const double gauss_d1 = ev.gauss_d1, gauss_d2 = ev.gauss_d2;
+    if (job.mode != 2) {
+        Accum pt;  // the point's own sums, from zero, in neighbourhood order (scores[i], score_gradients[i], hessians[i])
+        pt.score = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pt.g[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 36; ++k) pt.H[k] = 0;
+        if (cnt) {
+            float xj[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) xj[r] = fdot3f(ev.j_ang[r][0], p.x, ev.j_ang[r][1], p.y, ev.j_ang[r][2], p.z);
+            const float J3[3] = {0.0f, xj[0], xj[1]}, J4[3] = {xj[2], xj[3], xj[4]}, J5[3] = {xj[5], xj[6], xj[7]};
+            float PH[6][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            if (job.mode == 0) {
+                float xh[15];
+#pragma unroll
+                for (int r = 0; r < 15; ++r) xh[r] = fdot3f(ev.h_ang[r][0], p.x, ev.h_ang[r][1], p.y, ev.h_ang[r][2], p.z);
+                PH[0][1] = xh[0];  PH[0][2] = xh[1];
+                PH[1][1] = xh[2];  PH[1][2] = xh[3];
+                PH[2][1] = xh[4];  PH[2][2] = xh[5];
+                PH[3][0] = xh[6];  PH[3][1] = xh[7];  PH[3][2] = xh[8];
+                PH[4][0] = xh[9];  PH[4][1] = xh[10]; PH[4][2] = xh[11];
+                PH[5][0] = xh[12]; PH[5][1] = xh[13]; PH[5][2] = xh[14];
+            }
+#pragma unroll
+            for (int nb = 0; nb < NNB; ++nb) {
+                if (ids[nb] < 0) continue;
+                const NdtLeafRec leaf_rec = load_leaf(g.leaves + ids[nb]);
+                if (job.mode == 0) pair_float<true>(pt, leaf_rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
+                else               pair_float<false>(pt, leaf_rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
+            }
+        }
+        rec[i] = pt.score;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) rec[(size_t)(1 + k) * n + i] = pt.g[k];
+        if (job.mode == 0) {
+#pragma unroll
+            for (int k = 0; k < 36; ++k) rec[(size_t)(7 + k) * n + i] = pt.H[k];
+        }
+        rec[(size_t)kNdtNbIndex * n + i] = static_cast<double>(cnt);
+        return;
+    }
+    // ---- computeHessian (f64, PCL's 3x6 / 18x6 point derivative forms), per pair the bracket the reference multiplies by e_x_cov_x ------------
+    const size_t slots = n * NNB;
+    uint32_t used = 0;
+    if (cnt) {
+        const double x[3] = {p.x, p.y, p.z};
+        double xjd[8], xhd[15];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xjd[r] = fdot3d(x[0], ev.j_ang_d[r][0], x[1], ev.j_ang_d[r][1], x[2], ev.j_ang_d[r][2]);
+#pragma unroll
+        for (int r = 0; r < 15; ++r) xhd[r] = fdot3d(x[0], ev.h_ang_d[r][0], x[1], ev.h_ang_d[r][1], x[2], ev.h_ang_d[r][2]);
+        // J: 3 x 6, identity | columns 3..5;  PH(i, j), i, j >= 3: a b c / b d e / c e f
+        const double J[3][6] = {{1, 0, 0, 0, xjd[2], xjd[5]}, {0, 1, 0, xjd[0], xjd[3], xjd[6]}, {0, 0, 1, xjd[1], xjd[4], xjd[7]}};
+        const double PHd[6][3] = {{0, xhd[0], xhd[1]}, {0, xhd[2], xhd[3]}, {0, xhd[4], xhd[5]}, {xhd[6], xhd[7], xhd[8]}, {xhd[9], xhd[10], xhd[11]}, {xhd[12], xhd[13], xhd[14]}};
+#pragma unroll 1
+        for (int nb = 0; nb < NNB; ++nb) {
+            if (ids[nb] < 0) continue;
+            const uint32_t lid = static_cast<uint32_t>(ids[nb]);
+            const MRGFE_GLOBAL double* __restrict__ Cg = as_global(g.icov64 + (size_t)lid * 9);
+            const MRGFE_GLOBAL double* __restrict__ mean = as_global(g.leaves[lid].mean);
+            double C[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) C[t] = Cg[t];
+            const double q[3] = {static_cast<double>(xt[0]) - mean[0], static_cast<double>(xt[1]) - mean[1], static_cast<double>(xt[2]) - mean[2]};
+            double Cq[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) Cq[r] = fdot3d(C[r * 3 + 0], q[0], C[r * 3 + 1], q[1], C[r * 3 + 2], q[2]);
+            double e = gauss_d2 * exp(-gauss_d2 * fdot3d(q[0], Cq[0], q[1], Cq[1], q[2], Cq[2]) / 2);
+            if (e > 1 || e < 0 || e != e) continue;
+            e *= gauss_d1;
+            const size_t slot = (size_t)i * NNB + used;
+            rec[slot] = e;
+            double CJ[6][3];  // C * J(:, c)
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) CJ[c][r] = fdot3d(C[r * 3 + 0], J[0][c], C[r * 3 + 1], J[1][c], C[r * 3 + 2], J[2][c]);
+            double qCJ[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) qCJ[c] = fdot3d(q[0], CJ[c][0], q[1], CJ[c][1], q[2], CJ[c][2]);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const double t0 = -gauss_d2 * qCJ[a];
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    double qCH = 0.0;  // q . (C * 0) = +0
+                    if (a >= 3 && b >= 3) {
+                        const int lo = a < b ? a : b, hi = a < b ? b : a;
+                        const int ph = (lo == 3) ? (hi - 3) : (lo == 4 ? (hi - 4 + 3) : 5);
+                        double CH[3];
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) CH[r] = fdot3d(C[r * 3 + 0], PHd[ph][0], C[r * 3 + 1], PHd[ph][1], C[r * 3 + 2], PHd[ph][2]);
+                        qCH = fdot3d(q[0], CH[0], q[1], CH[1], q[2], CH[2]);
+                    }
+                    const double jtcj = fdot3d(J[0][b], CJ[a][0], J[1][b], CJ[a][1], J[2][b], CJ[a][2]);
+                    rec[(size_t)(1 + a * 6 + b) * slots + slot] = __builtin_fma(t0, qCJ[b], qCH) + jtcj;
+                }
+            }
+            ++used;
+        }
+    }
+    cnt_base[job.cnt_off + i] = static_cast<uint8_t>(used);
+    rec[(size_t)37 * slots + i] = static_cast<double>(cnt);
+}
+
+// one wavefront per job: lane k owns accumulator k and adds its column in order.  Loads run 16 steps ahead of the additions.
+template <int NNB>
+__global__ __launch_bounds__(64) void ndt_ref_chain_kernel(const NdtPairDev* __restrict__ pairs, const NdtRefJob* __restrict__ jobs, const double* __restrict__ rec_base,
+                                                            const uint8_t* __restrict__ cnt_base, double* __restrict__ results)
+{
+    const NdtRefJob job = jobs[blockIdx.x];
+    const NdtPairDev pr = pairs[job.pair];
+    const size_t n = pr.n_src;
+    const double* __restrict__ rec = rec_base + job.rec_off;
+    const int k = threadIdx.x;
+    double acc = 0.0;
+    bool   mine;
+    if (job.mode != 2) {
+        mine = k < 7 || k == kNdtNbIndex || (job.mode == 0 && k < kNdtNbIndex);
+        if (mine) {
+            const MRGFE_GLOBAL double* __restrict__ col = as_global(rec + (size_t)k * n);
+            size_t i = 0;
+            for (; i + 16 <= n; i += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = col[i + u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += v[u];
+            }
+            for (; i < n; ++i) acc += col[i];
+        }
+    } else {
+        // hess(a, b) = fma(e, bracket, hess(a, b)) over the contributing pairs, point after point; lanes 0..35 = entry a * 6 + b
+        const size_t slots = n * NNB;
+        mine = k < 36 || k == kNdtNbIndex;
+        if (k < 36) {
+            const MRGFE_GLOBAL double* __restrict__ ecol = as_global(rec);
+            const MRGFE_GLOBAL double* __restrict__ col = as_global(rec + (size_t)(1 + k) * slots);
+            const MRGFE_GLOBAL uint8_t* __restrict__ cnt = as_global(cnt_base + job.cnt_off);
+            for (size_t i0 = 0; i0 < n; i0 += 8) {
+                // eight points' counts, then their slots (every lane walks the same counts: uniform control flow)
+                uint32_t c[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) c[u] = (i0 + u < n) ? cnt[i0 + u] : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const size_t base = (i0 + u) * NNB;
+                    for (uint32_t j = 0; j < c[u]; ++j) acc = __builtin_fma(ecol[base + j], col[base + j], acc);
+                }
+            }
+        } else if (k == kNdtNbIndex) {
+            const MRGFE_GLOBAL double* __restrict__ col = as_global(rec + (size_t)37 * slots);
+            for (size_t i = 0; i < n; ++i) acc += col[i];
+        }
+    }
+    // the record of ndt_reduce_kernel<false>: score, gradient, Hessian (row-major), neighbour count
+    if (k < kNdtPartialStride) {
+        double out = 0.0;
+        if (job.mode != 2) out = mine ? acc : 0.0;
+        else if (k == kNdtNbIndex) out = acc;
+        results[(size_t)job.pair * kNdtPartialStride + k] = out;
+    }
+    if (job.mode == 2 && k < 36) results[(size_t)job.pair * kNdtPartialStride + 7 + k] = acc;
+}
+
+int ndt_launch_ref_round(mrgfe_ctx* ctx, int search, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const NdtRefJob* d_jobs, uint32_t n_jobs,
+                         uint32_t max_tiles, double* d_rec, uint8_t* d_cnt, double* results)
+{
+    if (n_jobs == 0 || max_tiles == 0) return MRGFE_OK;
+    const dim3 grid(max_tiles, n_jobs);
+    if (search == MRGFE_DIRECT7) {
+        hipLaunchKernelGGL((ndt_ref_records_kernel<7>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_jobs, d_rec, d_cnt);
+        hipLaunchKernelGGL((ndt_ref_chain_kernel<7>), dim3(n_jobs), dim3(64), 0, ctx->stream, d_pairs, d_jobs, d_rec, d_cnt, results);
+    } else if (search == MRGFE_DIRECT1) {
+        hipLaunchKernelGGL((ndt_ref_records_kernel<1>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_jobs, d_rec, d_cnt);
+        hipLaunchKernelGGL((ndt_ref_chain_kernel<1>), dim3(n_jobs), dim3(64), 0, ctx->stream, d_pairs, d_jobs, d_rec, d_cnt, results);
+    } else {
+        hipLaunchKernelGGL((ndt_ref_records_kernel<27>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_jobs, d_rec, d_cnt);
+        hipLaunchKernelGGL((ndt_ref_chain_kernel<27>), dim3(n_jobs), dim3(64), 0, ctx->stream, d_pairs, d_jobs, d_rec, d_cnt, results);
+    }
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
 // pair and position within the pair of item `item` of variant `mode`: the last busy pair whose first item is <= item
 // (uniform over the workgroup: scalar loads)
 __device__ __forceinline__ void ndt_plan_find(const uint32_t* __restrict__ plan, uint32_t n_all_pairs, int mode, uint32_t n_busy, uint32_t item, uint32_t& pi, uint32_t& item_in_pair)

@@ -47,6 +47,7 @@ NdtEngine::~NdtEngine()
     grid_arena_.release();
     for (auto& e : ev_pool_) if (e) (void)hipEventDestroy(e);
     d_grids_.release(); d_pairs_.release(); d_evals_.release(); d_partials_.release(); d_T12_.release(); d_aligned_.release(); d_states_.release();
+    d_ref_rec_.release(); d_ref_cnt_.release(); d_ref_jobs_.release();
     h_evals_.release(); h_results_.release(); h_states_.release(); h_info_.release();
 }
 
@@ -439,6 +440,22 @@ int ndt_set_fused_launch(int mode)
     return fused_launch() ? 1 : 0;
 }
 
+// MRGFE_NDT_REFERENCE_ORDER=1 / mrgfe_dbg_set_ndt_reference_order(1): NDT_OMP's sums in the reference's own order (ndt_ref_records_kernel + ndt_ref_chain_kernel,
+// ndt_derivatives.hip) — per-point sums, then a point-order chain; computeHessian pair after pair.  Host-stepped (the host cuts a round's evaluations into
+// chunks that fit the record workspace).  Several times slower than the default tree; bit-identical to the reference-order oracle.
+static std::atomic<int> g_ref_order{-1};  // -1: not read yet
+static bool reference_order()
+{
+    int v = g_ref_order.load(std::memory_order_relaxed);
+    if (v < 0) { const char* e = std::getenv("MRGFE_NDT_REFERENCE_ORDER"); v = (e && std::atoi(e) != 0) ? 1 : 0; g_ref_order.store(v, std::memory_order_relaxed); }
+    return v != 0;
+}
+int ndt_set_reference_order(int mode)
+{
+    if (mode == 0 || mode == 1) g_ref_order.store(mode, std::memory_order_relaxed);
+    return reference_order() ? 1 : 0;
+}
+
 constexpr int kHostParallelMinPairs = 48;  // below this the controller steps of a round run on the calling thread
 
 // -1: automatic (single registrations are stepped by the host, batches on the device); 0 / 1 force device / host control
@@ -499,6 +516,47 @@ void NdtEngine::host_plan(std::vector<uint32_t>& plan, uint32_t wg_target, uint3
     }
     for (int m = 0; m < 3; ++m) plan[ndt_plan_start_off(P, m) + h.n_pairs[m]] = h.n_items[m];
     std::memcpy(plan.data(), &h, sizeof(h));
+}
+
+// One round of the host-stepped path in the reference's summation order: every pending request (filled into h_evals_ by the caller) becomes a job — its
+// records, then its chain — and the 384-byte result records land in pinned host memory like those of ndt_reduce_kernel<false>.  The record workspace is
+// bounded (MRGFE_REF_WORKSPACE_MB, default 16 GiB of the 288): a round whose jobs need more runs in several launches, one after the other on the stream.
+int NdtEngine::reference_round()
+{
+    hipStream_t st = ctx_->stream;
+    const uint32_t P = static_cast<uint32_t>(n_pairs());
+    const size_t ws_cap = static_cast<size_t>(std::max(1, env_int("MRGFE_REF_WORKSPACE_MB", 16384))) << 20;  // (read per round: tests shrink it to force several launches)
+    const size_t nnb = prm_.search == MRGFE_DIRECT7 ? 7 : (prm_.search == MRGFE_DIRECT1 ? 1 : 27);
+    MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, h_evals_.p, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));
+    std::vector<NdtRefJob> jobs;
+    size_t   rec_doubles = 0, cnt_bytes = 0;
+    uint32_t max_tiles = 0;
+    auto flush = [&]() -> int {
+        if (jobs.empty()) return MRGFE_OK;
+        MRGFE_TRY(d_ref_rec_.ensure(rec_doubles * sizeof(double)));
+        MRGFE_TRY(d_ref_cnt_.ensure(std::max<size_t>(cnt_bytes, 1)));
+        MRGFE_TRY(d_ref_jobs_.ensure(sizeof(NdtRefJob) * jobs.size()));
+        MRGFE_TRY(ctx_->stage_h2d(d_ref_jobs_.p, jobs.data(), sizeof(NdtRefJob) * jobs.size(), st));
+        MRGFE_TRY(ndt_launch_ref_round(ctx_, prm_.search, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_ref_jobs_.as<NdtRefJob>(),
+                                       static_cast<uint32_t>(jobs.size()), max_tiles, d_ref_rec_.as<double>(), d_ref_cnt_.as<uint8_t>(), h_results_.as<double>()));
+        jobs.clear();
+        rec_doubles = cnt_bytes = 0;
+        max_tiles = 0;
+        return MRGFE_OK;
+    };
+    for (uint32_t i = 0; i < P; ++i) {
+        const NdtController& c = pairs_[i].ctl;
+        if (c.done()) continue;
+        const uint32_t mode = static_cast<uint32_t>(c.request_mode());
+        const size_t   n = pairs_[i].n;
+        const size_t   need = mode == 2 ? 38 * n * nnb : size_t(kNdtAccum) * n;  // doubles
+        if (!jobs.empty() && (rec_doubles + need) * sizeof(double) > ws_cap) MRGFE_TRY(flush());
+        jobs.push_back(NdtRefJob{i, mode, rec_doubles, cnt_bytes});
+        rec_doubles += need;
+        if (mode == 2) cnt_bytes += (n + 15) & ~size_t(15);
+        max_tiles = std::max(max_tiles, static_cast<uint32_t>((n + 255) / 256));
+    }
+    return flush();
 }
 
 int NdtEngine::enqueue_round(uint32_t round, bool device_control, const bool want_mode[3], NdtRoundInfo* h_info, double result_tag)
@@ -635,7 +693,8 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
     // every controller needs at most (max_iterations + 2) * (max line-search trials + 2) evaluations
     const size_t round_cap = size_t(prm_.max_iterations + 3) * 13 + 8;
     const int    hc = host_control_mode();
-    const bool   device_control = hc == 0 || (hc < 0 && P > 1);
+    const bool   ref_order = reference_order() && prm_.formulation == 0;
+    const bool   device_control = !ref_order && (hc == 0 || (hc < 0 && P > 1));
     hipStream_t  st = ctx_->stream;
     if (device_control) MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));  // (host control: enqueue_round sends requests + plan together)
     static const bool trace = std::getenv("MRGFE_TRACE") != nullptr;  // per-round host timings on stderr
@@ -725,7 +784,10 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
         info.push_back(ri);
         const auto t0 = std::chrono::steady_clock::now();
         MRGFE_TRY(ensure_events(round + 1));
-        if (P == 1) {
+        if (ref_order) {
+            MRGFE_TRY(reference_round());
+            MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+        } else if (P == 1) {
             // a single registration: the reduction writes `tag` behind its record in pinned memory and the host polls for it (a stream wait
             // costs ~10 us more per round than seeing the store)
             const double tag = static_cast<double>(++result_tag_);
@@ -782,7 +844,7 @@ int NdtEngine::evaluate(int pair, const float T[16], const double p[6], int mode
     pairs_[pair].ctl.adopt(s);
     const int keep = forced_ppt_;
     forced_ppt_ = 1;
-    const int rc = enqueue_round(0, false, want, nullptr);
+    const int rc = (reference_order() && prm_.formulation == 0) ? reference_round() : enqueue_round(0, false, want, nullptr);
     forced_ppt_ = keep;
     for (int i = 0; i < P; ++i) pairs_[i].ctl.adopt(saved[i]);
     MRGFE_TRY(rc);

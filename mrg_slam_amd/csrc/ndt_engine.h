@@ -36,6 +36,9 @@ void ndt_set_host_control(int mode);
 // derivative launches of the following alignments: 1 = one launch per round for all kernel variants (default; MRGFE_FUSED
 // overrides), 0 = one launch per variant; any other value only asks.  Returns the setting in effect.
 int ndt_set_fused_launch(int mode);
+// NDT_OMP sums of the following alignments: 1 = the reference's own order (per-point sums, then point-order chains: ndt_ref_*_kernel; host-stepped, several
+// times slower), 0 = the tree (default; MRGFE_NDT_REFERENCE_ORDER sets the initial value); any other value only asks.  Returns the setting in effect.
+int ndt_set_reference_order(int mode);
 
 // A second host thread may ask a running device-controlled align_all() for snapshots (which pairs have finished, their final
 // transformations): it raises `want`; the aligning thread enqueues ndt_snapshot_kernel between two rounds and counts `issued` up; the
@@ -138,6 +141,8 @@ class NdtEngine {
     int ensure_events(size_t rounds);
     uint32_t derivative_grid(int mode) const;
     int enqueue_round(uint32_t round, bool device_control, const bool want_mode[3], NdtRoundInfo* h_info, double result_tag = 0.0);
+    int reference_round();                // the same round in the reference's summation order (ndt_set_reference_order)
+    DevBuf d_ref_rec_, d_ref_cnt_, d_ref_jobs_;
     void account(const std::vector<NdtRoundInfo>& info, size_t rounds);
 };
 

@@ -125,6 +125,14 @@ struct NdtSnapshotHead {
     uint32_t pad[2];
 };
 
+// one evaluation in the reference's summation order (ndt_ref_records_kernel / ndt_ref_chain_kernel): which pair, which kind, where its records start
+struct NdtRefJob {
+    uint32_t pair;
+    uint32_t mode;
+    uint64_t rec_off;  // doubles into the record workspace
+    uint64_t cnt_off;  // bytes into the per-point pair-count workspace (mode 2)
+};
+
 // block partial / final result of one evaluation: score, gradient(6), full 6x6 Hessian(36, row-major), neighbour count.
 // All 36 Hessian entries are kept: the reference fills H(i,j) and H(j,i) with differently rounded float terms, and an
 // ill-conditioned Newton solve amplifies that 1e-7 asymmetry far above the 1e-4 parity bar if it is mirrored away.

@@ -163,6 +163,42 @@ def ndt_soak(cases: int, seed: int, ndt_share: float = 0.75):
     return st
 
 
+def ndt_reference_order_soak(cases: int, seed: int):
+    """NDT_HIP with mrgfe_dbg_set_ndt_reference_order(1) (the caller switches it on) against the reference-order oracle on the scenes of ndt_soak: counts of
+    bit-identical results, scenes over the bar, flag / iteration / evaluation mismatches; `unsettled` = optimisations of more than 30 iterations or without
+    convergence (where the default tree order's noise is amplified)."""
+    from mrg_slam_amd import NdtHip
+
+    from . import oracle as orc
+
+    rng = np.random.default_rng(seed)
+    st = {"cases": cases, "seed": seed, "exact": 0, "over_bar": 0, "worst": 0.0, "flag_or_iteration_mismatch": 0, "iterations_total": 0, "unsettled": 0, "not_identical": []}
+    for c in range(cases):
+        tgt, src, guess, eps = soak_scene(rng)
+        res = float(rng.choice([0.5, 1.0, 1.5, 2.0]))
+        search = str(rng.choice(["DIRECT7", "DIRECT1", "DIRECT26", "KDTREE"]))
+        g = NdtHip(resolution=res, transformation_epsilon=eps, maximum_iterations=64, search=search)
+        o = orc.Ndt(resolution=res, transformation_epsilon=eps, maximum_iterations=64, num_threads=8, search=search)
+        for r in (g, o):
+            r.setInputTarget(tgt)
+            r.setInputSource(src)
+            r.align(guess)
+        Tg, To = g.getFinalTransformation(), o.getFinalTransformation()
+        dt, dr = _diff(Tg, To)
+        same = bool(np.array_equal(Tg, To))
+        mism = bool(g.hasConverged()) != bool(o.hasConverged()) or g.getFinalNumIteration() != o.getFinalNumIteration() or g.evals != o.evals
+        st["exact"] += int(same and not mism)
+        st["over_bar"] += int(dt > BAR or dr > BAR)
+        st["worst"] = max(st["worst"], dt, dr)
+        st["flag_or_iteration_mismatch"] += int(mism)
+        st["iterations_total"] += int(o.getFinalNumIteration())
+        st["unsettled"] += int(not o.hasConverged() or o.getFinalNumIteration() > 30)
+        if not same or mism:
+            st["not_identical"].append({"case": f"case {c}: NDT res={res} {search} eps={eps}", "dt_m": dt, "dr_rad": dr, "iterations_hip": int(g.getFinalNumIteration()),
+                                        "iterations_oracle": int(o.getFinalNumIteration())})
+    return st
+
+
 def pclndt_soak(cases: int, seed: int):
     """pcl::NormalDistributionsTransform (registration_method "NDT" and every unknown name, registrations.cpp:115-129): PCL_NDT_HIP against the
     reference-order oracle (oracle/pcl_ndt.cpp) on random scenes — resolutions 0.5-2 m, epsilons from mrg_slam's 0.1 (PCL's rule: one Newton
