@@ -79,6 +79,10 @@ int mrgfe_dbg_set_fit_stats(int mode);
 /* the float sine / cosine the optimiser builds its pose matrices with (host build of csrc/ndt_ctl.h: glibc's sinf / cosf algorithm
  * restated, because the reference's Eigen::AngleAxisf calls exactly those and they are not correctly rounded) */
 void mrgfe_dbg_sincosf(const float* x, size_t n, float* sin_out, float* cos_out);
+/* glibc's double exp() as the kernels compute it (csrc/glibc_exp.h: the reference evaluates its per-pair weights with the host's libm, and exp is not
+ * correctly rounded — the device library's differs in the last bit on one argument in ten): on the host (on_device = 0, ctx may be NULL) or on the device.
+ * tests/test_glibc_exp.py holds the host build against the C library and regenerates the table; tests/test_gpu_primitives.py holds the device against the host. */
+int mrgfe_dbg_exp(mrgfe_ctx* ctx, const double* x, size_t n, int on_device, double* out);
 int mrgfe_dbg_ctl_math(mrgfe_ctx* ctx, const double* cases48, int n, int on_device, float* M16, double* tables69, double* x6);
 typedef struct mrgfe_dbg_ctl mrgfe_dbg_ctl;
 int  mrgfe_dbg_ctl_create(const mrgfe_reg_params* params, const float guess[16], uint32_t n_src, mrgfe_dbg_ctl** out);

@@ -216,6 +216,7 @@ DEBUG_SIGNATURES = {
     "mrgfe_dbg_set_pclgicp_reference_order": (C.c_int, [C.c_int]),
     "mrgfe_dbg_set_fit_stats": (C.c_int, [C.c_int]),
     "mrgfe_dbg_sincosf": (None, [_fp, C.c_size_t, _fp, _fp]),
+    "mrgfe_dbg_exp": (C.c_int, [_vp, _dp, C.c_size_t, C.c_int, _dp]),
     "mrgfe_dbg_ctl_math": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _fp, _dp, _dp]),
     "mrgfe_dbg_ctl_create": (C.c_int, [C.POINTER(RegParams), _fp, C.c_uint32, C.POINTER(_vp)]),
     "mrgfe_dbg_ctl_destroy": (None, [_vp]),

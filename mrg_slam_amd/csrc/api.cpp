@@ -17,6 +17,7 @@
 
 #include "cellsort.h"
 #include "common.h"
+#include "glibc_exp.h"
 #include "filters.h"
 #include "mapcloud.h"
 #include "gicp_engine.h"
@@ -1717,6 +1718,30 @@ void mrgfe_dbg_sincosf(const float* x, size_t n, float* sin_out, float* cos_out)
 {
     for (size_t i = 0; i < n; ++i) { sin_out[i] = ctl::sin_f(x[i]); cos_out[i] = ctl::cos_f(x[i]); }
 }
+int mrgfe_dbg_exp(mrgfe_ctx* ctx, const double* x, size_t n, int on_device, double* out)
+{
+    if ((n && (!x || !out)) || (on_device && !ctx)) { set_error("mrgfe_dbg_exp: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (!on_device) {
+        for (size_t i = 0; i < n; ++i) out[i] = glibc_exp(x[i]);
+        return MRGFE_OK;
+    }
+    MRGFE_LOCK(ctx);
+    MRGFE_TRY(ctx->bind());
+    DevBuf dx, dout;
+    MRGFE_TRY(dx.ensure(std::max<size_t>(n, 1) * 8));
+    int st = dout.ensure(std::max<size_t>(n, 1) * 8);
+    if (st == MRGFE_OK && n) {
+        if (hipMemcpyAsync(dx.p, x, n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = MRGFE_ERR_HIP;
+        if (st == MRGFE_OK) st = glibc_exp_device(ctx, dx.as<double>(), n, dout.as<double>());
+        if (st == MRGFE_OK && hipMemcpyAsync(out, dout.p, n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = MRGFE_ERR_HIP;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == MRGFE_OK) st = MRGFE_ERR_HIP;
+        if (st == MRGFE_ERR_HIP) set_error("mrgfe_dbg_exp: a HIP call failed");
+    }
+    dx.release();
+    dout.release();
+    return st;
+}
+
 int mrgfe_dbg_ctl_math(mrgfe_ctx* ctx, const double* cases48, int n, int on_device, float* M16, double* tables69, double* x6)
 {
     if (!cases48 || !M16 || !tables69 || !x6 || n < 0) { set_error("mrgfe_dbg_ctl_math: bad argument"); return MRGFE_ERR_INVALID; }

@@ -31,6 +31,7 @@ int ndt_ctl_math_device(mrgfe_ctx* ctx, const double* d_in, int n, float* d_M, d
 // diagnostic: n_vals (44, 37 or 1) doubles per lane and wavefront, summed by wave_sum_fold and by wave_sum (dev_utils.h)
 int wave_fold_check_device(mrgfe_ctx* ctx, int n_vals, const double* d_in, int cases, double* d_fold, double* d_plain);
 int ndt_ctl_svd_wave_device(mrgfe_ctx* ctx, const double* d_in, int n, double* d_x);  // the wavefront form of the solve, one case per workgroup
+int glibc_exp_device(mrgfe_ctx* ctx, const double* d_x, size_t n, double* d_out);  // diagnostic: glibc_exp (glibc_exp.h) on n doubles
 // diagnostic builds (-DNDT_PHASE_CLOCK): prints the phase clocks of the derivative kernel to stderr; a no-op otherwise
 void ndt_phase_dump();
 // dst = T * src (row-major 3x4 float T in device memory)

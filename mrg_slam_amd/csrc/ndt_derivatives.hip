@@ -22,6 +22,7 @@
 
 #include "dev_float.h"
 #include "dev_utils.h"
+#include "glibc_exp.h"
 #include "ndt_ctl.h"
 #include "ndt_derivatives.h"
 
@@ -45,6 +46,13 @@ __device__ unsigned long long g_rphase[10];  // ndt_reduce_kernel<true>: sums | 
 // DIRECT7 probes: the voxel of the point, then +x, -x, +y, -y, +z, -z (pclomp getNeighborhoodAtPoint7)
 
 constexpr int kTilePts = 256;  // points per tile == threads per workgroup
+
+// exp of the per-pair weight: the reference's (glibc's, restated in glibc_exp.h) — the device library's differs from it in the last bit of the double on
+// one argument in ten (invisible after the cast to float except once in 2^29 pairs, decisive for the f64 passes).  -DNDT_PAIR_EXP=exp selects the device
+// library's for the float path (A/B measurements).
+#ifndef NDT_PAIR_EXP
+#define NDT_PAIR_EXP glibc_exp
+#endif
 
 struct Accum {
     double score;
@@ -78,7 +86,7 @@ __device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, co
     const float qCq = fdot3f(q[0], qC[0], q[1], qC[1], q[2], qC[2]);
     const float arg0 = -gauss_d2f * qCq;
     const float arg = arg0 * 0.5f;
-    float e = static_cast<float>(exp(static_cast<double>(arg)));
+    float e = static_cast<float>(NDT_PAIR_EXP(static_cast<double>(arg)));
     const float score_inc = static_cast<float>(-gauss_d1 * static_cast<double>(e));
     e = gauss_d2f * e;
     if (e > 1.0f || e < 0.0f || e != e) return;
@@ -296,7 +304,7 @@ __device__ __forceinline__ void ndt_derivatives_item(NdtDerivShared<NNB>& sh, co
                         double v[3];
 #pragma unroll
                         for (int r = 0; r < 3; ++r) v[r] = fdot3d(C[r * 3 + 0], q[0], C[r * 3 + 1], q[1], C[r * 3 + 2], q[2]);
-                        double e = gauss_d2 * exp(-gauss_d2 * fdot3d(q[0], v[0], q[1], v[1], q[2], v[2]) / 2);
+                        double e = gauss_d2 * glibc_exp(-gauss_d2 * fdot3d(q[0], v[0], q[1], v[1], q[2], v[2]) / 2);
                         if (e > 1 || e < 0 || e != e) continue;
                         e *= gauss_d1;
                         const double ev3[3] = {e * v[0], e * v[1], e * v[2]};
@@ -588,7 +596,7 @@ __device__ __forceinline__ void ndt_derivatives_f64_item(NdtDerivShared<27>& sh,
             v[0] = fdot3d(c00, q[0], c01, q[1], c02, q[2]);
             v[1] = fdot3d(c01, q[0], c11, q[1], c12, q[2]);
             v[2] = fdot3d(c02, q[0], c12, q[1], c22, q[2]);
-            const double e_raw = exp(-gauss_d2 * fdot3d(q[0], v[0], q[1], v[1], q[2], v[2]) / 2);
+            const double e_raw = glibc_exp(-gauss_d2 * fdot3d(q[0], v[0], q[1], v[1], q[2], v[2]) / 2);
             double e = gauss_d2 * e_raw;
             if (e > 1 || e < 0 || e != e) continue;  // updateDerivatives returns 0: the pair adds nothing, not even its score
             e *= gauss_d1;
@@ -842,7 +850,7 @@ __global__ __launch_bounds__(256, 2) void ndt_ref_records_kernel(const NdtGridDe
             double Cq[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) Cq[r] = fdot3d(C[r * 3 + 0], q[0], C[r * 3 + 1], q[1], C[r * 3 + 2], q[2]);
-            double e = gauss_d2 * exp(-gauss_d2 * fdot3d(q[0], Cq[0], q[1], Cq[1], q[2], Cq[2]) / 2);
+            double e = gauss_d2 * glibc_exp(-gauss_d2 * fdot3d(q[0], Cq[0], q[1], Cq[1], q[2], Cq[2]) / 2);
             if (e > 1 || e < 0 || e != e) continue;
             e *= gauss_d1;
             const size_t slot = (size_t)i * NNB + used;
@@ -1316,6 +1324,20 @@ __global__ __launch_bounds__(64) void ndt_ctl_svd_wave_kernel(const double* __re
     ctl::svd_wave_sync();
     ctl::svd_solve6_wave(s_A, s_b, s_x, s_svd);
     if (threadIdx.x < 6) x[size_t(blockIdx.x) * 6 + threadIdx.x] = s_x[threadIdx.x];
+}
+
+// ---- diagnostic: glibc's exp restated (glibc_exp.h) on the device; tests hold it against the host build of the same header and against the host's libm
+__global__ __launch_bounds__(256) void glibc_exp_kernel(const double* __restrict__ x, size_t n, double* __restrict__ out)
+{
+    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) out[i] = glibc_exp(x[i]);
+}
+int glibc_exp_device(mrgfe_ctx* ctx, const double* d_x, size_t n, double* d_out)
+{
+    if (n == 0) return MRGFE_OK;
+    hipLaunchKernelGGL(glibc_exp_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ctx->stream, d_x, n, d_out);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
 }
 
 // ---- diagnostic: the folded wave reduction against the plain one (tests/test_gpu_primitives.py) -----------------------------------

@@ -210,3 +210,23 @@ def test_grid_set_degenerate_sets(ctx, k):
             np.testing.assert_array_equal(idx[m], bi)
             ok = bi >= 0
             np.testing.assert_array_equal(sqd[m][ok], bd[ok])
+
+
+
+def test_glibc_exp_on_the_device_equals_the_host_build():
+    """csrc/glibc_exp.h compiled for gfx950 against its host build (which tests/test_glibc_exp.py holds against the C library): bit for bit on a million
+    arguments over every branch — the f64 passes of the NDT kernels then weigh every (point, voxel) pair with the double the reference's host computes."""
+    import ctypes as C
+
+    from mrg_slam_amd import Context
+    from mrg_slam_amd._lib import lib
+    from test_glibc_exp import _args
+
+    ctx = Context()
+    x = _args(1_000_000, 11)
+    dev, host = np.empty_like(x), np.empty_like(x)
+    dp = C.POINTER(C.c_double)
+    assert lib().mrgfe_dbg_exp(ctx._h, x.ctypes.data_as(dp), len(x), 1, dev.ctypes.data_as(dp)) == 0
+    assert lib().mrgfe_dbg_exp(None, x.ctypes.data_as(dp), len(x), 0, host.ctypes.data_as(dp)) == 0
+    same = (dev == host) | (np.isnan(dev) & np.isnan(host))
+    assert same.all(), [(float(a).hex(), float(b).hex(), float(c).hex()) for a, b, c in zip(x[~same][:5], dev[~same][:5], host[~same][:5])]
