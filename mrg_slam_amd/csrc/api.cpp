@@ -1788,6 +1788,7 @@ int mrgfe_dbg_ctl_create(const mrgfe_reg_params* params, const float guess[16], 
     float g[16];
     col2row(guess, g);
     h->c.start(ndt_params_from(*params), g, n_src, std::getenv("MRGFE_DBG_CTL_SPLIT") != nullptr);
+    if (ndt_set_reference_order(-1) && params->method == MRGFE_NDT_HIP) h->c.force_reference_solve();  // (as NdtEngine::align_all does in that mode)
     *out = h;
     return MRGFE_OK;
 }

@@ -47,6 +47,7 @@ class NdtController {
     int    reused_evaluations() const { return s_.n_reused; }  // of those, served from the previous identical trial
     double trans_probability() const { return s_.trans_probability; }
     const double* hessian() const { return s_.H; }  // 6x6 row-major
+    void force_reference_solve() { s_.svd_only = 2; }  // every Newton solve through Eigen's two-sided JacobiSVD, operation for operation (reference-order mode)
     double neighbours_sum() const { return s_.nb_sum; }
     double gauss_d1() const { return s_.gauss_d1; }
     double gauss_d2() const { return s_.gauss_d2; }

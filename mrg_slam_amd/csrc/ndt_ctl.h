@@ -33,7 +33,7 @@ struct NdtCtlState {
     uint32_t n_src;
     int32_t  converged, nr_iterations, n_evals, n_reused, cache_valid;
     int32_t  split_first;  // 1: the first trial of a line search is evaluated without its Hessian, which is fetched afterwards if used (below)
-    int32_t  svd_only;     // 1: every Newton solve through the Jacobi SVD (MRGFE_NEWTON_SVD=1: round 4's solve, kept to hold the LU fast path against)
+    int32_t  svd_only;     // 2: every Newton solve through Eigen's two-sided JacobiSVD restated (reference-order mode, host-stepped); 1: every Newton solve through the Jacobi SVD (MRGFE_NEWTON_SVD=1: round 4's solve, kept to hold the LU fast path against)
     int32_t  formulation;  // 0: pclomp::NormalDistributionsTransform (NDT_OMP); 1: pcl::NormalDistributionsTransform of PCL 1.12 ("NDT",
                            // registrations.cpp:115-129): f64 pair terms (the kernels), PCL's iteration test and zero-step rule (below)
     float    final_[16], transformation_[16], previous_[16];  // row-major
@@ -204,6 +204,109 @@ MRGFE_HD void svd_solve6(const double A[36], const double b[6], double x[6])
     }
 }
 
+// ---- the REFERENCE's solve, operation for operation (reference-order mode only) --------------------------------------------------------------
+// Eigen::JacobiSVD<Matrix6d>(H, ComputeFullU | ComputeFullV).solve(-g) as Eigen 3.4 runs it for a square real matrix (no QR preconditioner): scale by
+// the largest |entry|; sweeps over the pairs p = 1..5, q = 0..p-1; for a pair whose off-diagonal entries exceed max(DBL_MIN, 2 eps maxDiagEntry) the
+// 2 x 2 block is diagonalised by real_2x2_jacobi_svd (a rotation that symmetrises it, then makeJacobi) and the rotations are applied to the working
+// matrix, U and V; singular values |diag|, signs moved into U, sorted descending; solve = V diag(1 / s_i, i < rank) U^T b with rank from
+// s_i > max(6 eps s_0, DBL_MIN).  The one-sided Hestenes SVD above gives the same solution to ~1e-16 — but the optimiser's pose vector then differs
+// from the reference's in its last bits, and an optimisation that runs to the iteration limit without settling amplifies that like it amplifies
+// summation order (2 of 160 random scenes left the bar with every SUM already in the reference's order).  With this solve the whole double trajectory
+// is the reference-order oracle's.  ~4 us on the host; never used on the device.
+MRGFE_HD void jacobi2_rot_rows(double M[36], int p, int q, double c, double s)  // applyOnTheLeft(p, q, j): row_p' = c row_p + s row_q, row_q' = -s row_p + c row_q
+{
+    for (int k = 0; k < 6; ++k) {
+        const double xp = M[p * 6 + k], xq = M[q * 6 + k];
+        M[p * 6 + k] = c * xp + s * xq;
+        M[q * 6 + k] = -s * xp + c * xq;
+    }
+}
+MRGFE_HD void jacobi2_rot_cols(double M[36], int p, int q, double c, double s)  // applyOnTheRight(p, q, j): col_p' = c col_p - s col_q, col_q' = s col_p + c col_q
+{
+    for (int k = 0; k < 6; ++k) {
+        const double xp = M[k * 6 + p], xq = M[k * 6 + q];
+        M[k * 6 + p] = c * xp - s * xq;
+        M[k * 6 + q] = s * xp + c * xq;
+    }
+}
+MRGFE_HD void jacobi2_solve6(const double A[36], const double b[6], double x[6])
+{
+    const double kNaN = __builtin_nan(""), kMin = 2.2250738585072014e-308, kEps = 2.2204460492503131e-16;
+    double scale = 0;
+    bool   fin = true;
+    for (int i = 0; i < 36; ++i) { scale = dmax(scale, fabs(A[i])); fin = fin && finite_d(A[i]); }
+    if (!fin) { for (int k = 0; k < 6; ++k) x[k] = kNaN; return; }  // Eigen: m_info = InvalidInput
+    if (scale == 0) scale = 1;
+    double W[36], U[36], V[36], S[6];
+    for (int i = 0; i < 36; ++i) { W[i] = A[i] / scale; U[i] = V[i] = (i % 7 == 0) ? 1.0 : 0.0; }
+    const double precision = 2.0 * kEps;
+    double max_diag = 0;
+    for (int i = 0; i < 6; ++i) max_diag = dmax(max_diag, fabs(W[i * 7]));
+    bool finished = false;
+    for (int guard = 0; !finished && guard < 200; ++guard) {
+        finished = true;
+        for (int p = 1; p < 6; ++p)
+            for (int q = 0; q < p; ++q) {
+                const double thr = dmax(kMin, precision * max_diag);
+                if (!(fabs(W[p * 6 + q]) > thr || fabs(W[q * 6 + p]) > thr)) continue;
+                finished = false;
+                // real_2x2_jacobi_svd of [[W(p,p) W(p,q)], [W(q,p) W(q,q)]]
+                const double m00 = W[p * 6 + p], m01 = W[p * 6 + q], m10 = W[q * 6 + p], m11 = W[q * 6 + q];
+                const double t = m00 + m11, d = m10 - m01;
+                double c1 = 1, s1 = 0;
+                if (!(fabs(d) < kMin)) { const double u = t / d, h = sqrt(1.0 + u * u); s1 = 1.0 / h; c1 = u / h; }
+                const double n00 = c1 * m00 + s1 * m10, n01 = c1 * m01 + s1 * m11, n11 = -s1 * m01 + c1 * m11;  // the block after the symmetrising rotation
+                double cr = 1, sr = 0;  // makeJacobi(n00, n01, n11)
+                const double deno = 2.0 * fabs(n01);
+                if (!(deno < kMin)) {
+                    const double tau = (n00 - n11) / deno, w = sqrt(tau * tau + 1.0);
+                    const double tt = (tau > 0) ? 1.0 / (tau + w) : 1.0 / (tau - w);
+                    const double sign_t = tt > 0 ? 1.0 : -1.0, nn = 1.0 / sqrt(tt * tt + 1.0);
+                    sr = -sign_t * (n01 / fabs(n01)) * fabs(tt) * nn;
+                    cr = nn;
+                }
+                const double cl = c1 * cr + s1 * sr, sl = s1 * cr - c1 * sr;  // j_left = rot1 * j_right^T
+                jacobi2_rot_rows(W, p, q, cl, sl);
+                jacobi2_rot_cols(U, p, q, cl, -sl);
+                jacobi2_rot_cols(W, p, q, cr, sr);
+                jacobi2_rot_cols(V, p, q, cr, sr);
+                max_diag = dmax(max_diag, dmax(fabs(W[p * 7]), fabs(W[q * 7])));
+            }
+    }
+    for (int i = 0; i < 6; ++i) {
+        const double a = W[i * 7];
+        S[i] = fabs(a);
+        if (a < 0) for (int k = 0; k < 6; ++k) U[k * 6 + i] = -U[k * 6 + i];
+    }
+    for (int i = 0; i < 6; ++i) {  // descending; columns of U and V follow
+        int best = i;
+        for (int k = i + 1; k < 6; ++k) if (S[k] > S[best]) best = k;
+        if (S[best] == 0) break;
+        if (best != i) {
+            const double ts = S[i]; S[i] = S[best]; S[best] = ts;
+            for (int k = 0; k < 6; ++k) {
+                const double tu = U[k * 6 + i]; U[k * 6 + i] = U[k * 6 + best]; U[k * 6 + best] = tu;
+                const double tv = V[k * 6 + i]; V[k * 6 + i] = V[k * 6 + best]; V[k * 6 + best] = tv;
+            }
+        }
+    }
+    for (int i = 0; i < 6; ++i) S[i] *= scale;
+    const double rthr = dmax(S[0] * 6.0 * kEps, kMin);
+    int rank = 0;
+    for (int i = 0; i < 6; ++i) if (S[i] > rthr) ++rank;
+    double tmp[6];
+    for (int i = 0; i < 6; ++i) {
+        double acc = 0;
+        for (int k = 0; k < 6; ++k) acc += U[k * 6 + i] * b[k];
+        tmp[i] = (i < rank) ? acc / S[i] : 0.0;
+    }
+    for (int r = 0; r < 6; ++r) {
+        double acc = 0;
+        for (int i = 0; i < rank; ++i) acc += V[r * 6 + i] * tmp[i];
+        x[r] = acc;
+    }
+}
+
 // ---- the fast path of the Newton solve ------------------------------------------------------------------------------------------
 // JacobiSVD(H).solve(-g) is the minimum-norm solution over the singular values above 6 eps s_max.  For a matrix that is far from
 // rank-deficient that IS H^-1 (-g), and an LU factorisation with partial pivoting delivers it with the same forward error (cond * eps)
@@ -269,8 +372,9 @@ MRGFE_HD bool lu_solve6(const double A[36], const double b[6], double x[6])
     return true;
 }
 // MRGFE_NEWTON_SVD=1 (host: environment; device: the flag rides in the state): always the SVD, the solve of round 4
-MRGFE_HD void newton_solve6(const double A[36], const double b[6], double x[6], bool svd_only)
+MRGFE_HD void newton_solve6(const double A[36], const double b[6], double x[6], int svd_only)
 {
+    if (svd_only == 2) { jacobi2_solve6(A, b, x); return; }  // reference-order mode: Eigen's two-sided JacobiSVD, operation for operation
     if (!svd_only && lu_solve6(A, b, x)) return;
     svd_solve6(A, b, x);
 }
@@ -712,7 +816,7 @@ MRGFE_HD void on_result(NdtCtlState& s, const double r[44])
     while (next == CTL_NEED_SOLVE) {
         double neg_g[6], delta[6];
         for (int k = 0; k < 6; ++k) neg_g[k] = -s.g[k];
-        newton_solve6(s.H, neg_g, delta, s.svd_only != 0);
+        newton_solve6(s.H, neg_g, delta, s.svd_only);
         next = after_solve(s, delta);
     }
 }

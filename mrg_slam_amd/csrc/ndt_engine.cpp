@@ -627,7 +627,7 @@ void NdtEngine::account(const std::vector<NdtRoundInfo>& info, size_t rounds)
         for (size_t r = 0; r < rounds && timing_level() > 0; ++r) {
             if (!info.empty() && (r >= info.size() || info[r].n_active == 0)) continue;
             float ms = 0;
-            if (hipEventElapsedTime(&ms, ev_pool_[r * 6], ev_pool_[r * 6 + 1]) != hipSuccess) continue;
+            if (hipEventElapsedTime(&ms, ev_pool_[r * 6], ev_pool_[r * 6 + 1]) != hipSuccess) { (void)hipGetLastError(); continue; }  // (never recorded, e.g. reference-order rounds: not a sticky error for the next call)
             mode_ms[0] += ms;
             mode_launches[0] += 1;
             if (ms > largest_ms && r < round_info_.size()) {
@@ -641,7 +641,7 @@ void NdtEngine::account(const std::vector<NdtRoundInfo>& info, size_t rounds)
             if (timing_level() <= (m == 0 ? 0 : 1)) continue;
             if (!info.empty() && (r >= info.size() || info[r].n_pairs[m] == 0)) continue;
             float ms = 0;
-            if (hipEventElapsedTime(&ms, ev_pool_[r * 6 + m * 2], ev_pool_[r * 6 + m * 2 + 1]) != hipSuccess) continue;
+            if (hipEventElapsedTime(&ms, ev_pool_[r * 6 + m * 2], ev_pool_[r * 6 + m * 2 + 1]) != hipSuccess) { (void)hipGetLastError(); continue; }
             mode_ms[m] += ms;
             mode_launches[m] += 1;
         }
@@ -681,9 +681,13 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
     // (13.6 vs 13.0 ms per 256-pair step): the fetches add rounds, and in lock-step rounds every extra launch pays its own tail.
     static const bool split_first = env_int("MRGFE_SPLIT_FIRST", 0) != 0;
     int running = 0;
+    const bool ref_order = reference_order() && prm_.formulation == 0;
     for (int i = 0; i < P; ++i) {
         NdtPairInfo& p = pairs_[i];
-        p.ctl.start(prm_, p.guess, p.n, split_first);
+        p.ctl.start(prm_, p.guess, p.n, split_first && !ref_order);
+        // the reference's order is the reference's solve too: Eigen's two-sided JacobiSVD for every Newton step (the LU fast path and the one-sided SVD give
+        // the same step to ~1e-16 — which a run to the iteration limit amplifies like it amplifies summation order)
+        if (ref_order) p.ctl.force_reference_solve();
         if (targets_[p.target].status != MRGFE_OK && !p.ctl.done()) p.ctl.abort_no_target();
         he[i].active = 0;
         p.ctl.fill_eval(he[i]);
@@ -693,7 +697,6 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
     // every controller needs at most (max_iterations + 2) * (max line-search trials + 2) evaluations
     const size_t round_cap = size_t(prm_.max_iterations + 3) * 13 + 8;
     const int    hc = host_control_mode();
-    const bool   ref_order = reference_order() && prm_.formulation == 0;
     const bool   device_control = !ref_order && (hc == 0 || (hc < 0 && P > 1));
     hipStream_t  st = ctx_->stream;
     if (device_control) MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));  // (host control: enqueue_round sends requests + plan together)

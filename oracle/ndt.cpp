@@ -364,12 +364,14 @@ inline bool pair_terms_f(const PointTermsF& P, const NdtLeaf& cell, float gauss_
 
 double Ndt::compute_derivatives(double grad[6], double hess[36], const double p[6], bool compute_hessian)
 {
+    for (int k = 0; k < 6; ++k) last_p[k] = p[k];
     if (gpu_order_ppt > 0) return compute_derivatives_gpu_order(grad, hess, p, compute_hessian);
     return fused ? compute_derivatives_impl<true>(grad, hess, p, compute_hessian) : compute_derivatives_impl<false>(grad, hess, p, compute_hessian);
 }
 
 void Ndt::compute_hessian(double hess[36], const double p[6])
 {
+    for (int k = 0; k < 6; ++k) last_p[k] = p[k];
     if (gpu_order_ppt > 0) { compute_hessian_gpu_order(hess, p); return; }
     if (fused) compute_hessian_impl<true>(hess, p);
     else       compute_hessian_impl<false>(hess, p);

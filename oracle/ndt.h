@@ -79,6 +79,7 @@ struct Ndt {
     double trans_probability = 0;
     double hessian[36];
     int    n_evals = 0;          // derivative evaluations executed (all modes)
+    double last_p[6] = {0, 0, 0, 0, 0, 0};  // pose vector of the last derivative evaluation (diagnostic: the optimiser's trajectory in double)
     double neighbours_sum = 0;   // sum over evals of mean valid neighbour voxels per point (k-bar numerator)
 
     int  set_target(const float* xyzi, int n);

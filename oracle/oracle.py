@@ -68,6 +68,7 @@ def lib():
             "orc_ndt_converged": (C.c_int, [vp]),
             "orc_ndt_iterations": (C.c_int, [vp]),
             "orc_ndt_evals": (C.c_int, [vp]),
+            "orc_ndt_last_pose": (None, [vp, C.POINTER(C.c_double)]),
             "orc_ndt_mean_neighbours": (C.c_double, [vp]),
             "orc_ndt_trans_probability": (C.c_double, [vp]),
             "orc_ndt_final": (None, [vp, fp]),
@@ -381,6 +382,12 @@ class Ndt:
     @property
     def evals(self):
         return lib().orc_ndt_evals(self._h)
+
+    def last_pose(self):
+        """pose vector (double) of the last derivative evaluation: where the optimiser stood, before the cast to the float transformation"""
+        p = np.empty(6)
+        lib().orc_ndt_last_pose(self._h, _pd(p))
+        return p
 
     @property
     def mean_neighbours(self):

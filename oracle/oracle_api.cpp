@@ -141,6 +141,7 @@ void orc_ndt_align(void* h, const float guess_colmajor[16], float* aligned_or_nu
 int    orc_ndt_converged(void* h) { return static_cast<Ndt*>(h)->converged ? 1 : 0; }
 int    orc_ndt_iterations(void* h) { return static_cast<Ndt*>(h)->nr_iterations; }
 int    orc_ndt_evals(void* h) { return static_cast<Ndt*>(h)->n_evals; }
+void   orc_ndt_last_pose(void* h, double out[6]) { std::memcpy(out, static_cast<Ndt*>(h)->last_p, sizeof(double) * 6); }
 double orc_ndt_mean_neighbours(void* h) { Ndt* n = static_cast<Ndt*>(h); return n->n_evals ? n->neighbours_sum / n->n_evals : 0.0; }
 double orc_ndt_trans_probability(void* h) { return static_cast<Ndt*>(h)->trans_probability; }
 void   orc_ndt_final(void* h, float out_colmajor[16]) { rowmajor_to_colmajor4(static_cast<Ndt*>(h)->final_, out_colmajor); }

@@ -113,3 +113,38 @@ def test_float_sine_cosine_are_the_c_librarys():
     sb, cb = np.empty_like(big), np.empty_like(big)
     lib().mrgfe_dbg_sincosf(big.ctypes.data_as(_fp), 4, sb.ctypes.data_as(_fp), cb.ctypes.data_as(_fp))
     assert abs(sb[0] - np.sin(120.0)) < 1e-7 and abs(cb[1] - np.cos(1e6)) < 1e-7 and np.isnan(sb[2:]).all() and np.isnan(cb[2:]).all()
+
+
+def test_reference_order_mode_reproduces_the_oracles_double_trajectory():
+    """mrgfe_dbg_set_ndt_reference_order(1): the optimiser's Newton solve becomes Eigen's two-sided JacobiSVD restated operation for operation (csrc/ndt_ctl.h
+    jacobi2_solve6) instead of the LU fast path / the one-sided SVD — those give the same step to ~1e-16, which a run to the iteration limit amplifies.  Fed
+    with the reference-order oracle's evaluations (what the reference-order kernels deliver bit for bit, tests/test_gpu_ndt_reforder.py), the state machine
+    must then reproduce the oracle's whole alignment in DOUBLE: the last pose vector, not only the float transformation."""
+    from mrg_slam_amd._lib import NDT_HIP, SEARCH, lib
+    from mrg_slam_amd.registration import default_params
+    from oracle import oracle as orc
+    from oracle.replay import soak_scene
+
+    assert lib().mrgfe_dbg_set_ndt_reference_order(1) == 1
+    try:
+        rng = np.random.default_rng(20261004)
+        iterations = 0
+        for c in range(24):
+            tgt, src, guess, eps = soak_scene(rng)
+            res, search = float(rng.choice([0.5, 1.0, 1.5, 2.0])), str(rng.choice(["DIRECT7", "DIRECT1", "DIRECT26", "KDTREE"]))
+            kw = dict(resolution=res, num_threads=8, transformation_epsilon=eps, maximum_iterations=64, search=search)
+            o, d = orc.Ndt(**kw), orc.Ndt(**kw)
+            for x in (o, d):
+                x.setInputTarget(tgt)
+                x.setInputSource(src)
+            o.align(guess)
+            prm = default_params(NDT_HIP)
+            prm.transformation_epsilon, prm.maximum_iterations, prm.resolution, prm.nn_search_method = eps, 64, res, SEARCH[search]
+            T, conv, it, ev, _ = _drive(d, prm, guess, len(src))
+            np.testing.assert_array_equal(T, o.getFinalTransformation())
+            assert (conv, it, ev) == (o.hasConverged(), o.getFinalNumIteration(), o.evals)
+            np.testing.assert_array_equal(d.last_pose(), o.last_pose())
+            iterations += it
+        assert iterations > 150
+    finally:
+        assert lib().mrgfe_dbg_set_ndt_reference_order(0) == 0
