@@ -288,6 +288,9 @@ def compact_line(full: dict) -> dict:
     for k in ("single_pair_latency_ms", "evaluations_launched_per_alignment", "iterations_per_alignment", "mean_valid_neighbours", "converged"):
         if g(k) is not None:
             out[k] = g(k)
+    ro = g("ndt_reference_order")
+    if ro:
+        out["ndt_reference_order_ms_per_step"] = ro.get("ms_per_step")
     sp = g("gpu_split_ms_per_step")
     if sp:
         out["set_target_ms_per_step"] = sp.get("set_target_ms")
@@ -1324,6 +1327,23 @@ def main():
                                         "note": "the same pairs after mrgfe_prefilter (distance 0.1-35 m, VoxelGrid 0.1 m, RadiusOutlierRemoval 0.5 m / 2): the synthetic street saturates "
                                                 "that voxel grid at a quarter of the points"}
             del f_dev
+        # (3b) what the reference's own summation order costs (opt-in, mrgfe_dbg_set_ndt_reference_order): the same 256 pairs, host-stepped, record + chain kernels
+        lib().mrgfe_dbg_set_ndt_reference_order(1)
+        try:
+            ro = step()
+            ctx.synchronize()
+            tr = time.perf_counter()
+            for _ in range(2):
+                ro = step()
+            ctx.synchronize()
+            tr = time.perf_counter() - tr
+            extras["ndt_reference_order"] = {"ms_per_step": 1e3 * tr / 2, "alignments_per_s": args.batch * 2 / tr, "steps": 2,
+                                             "pairs_with_the_default_orders_transformation": int((ro["T"] == res["T"]).all(axis=1).sum()), "pairs": args.batch,
+                                             "same_iterations_and_convergence_as_default": bool(np.array_equal(ro["iterations"], res["iterations"]) and np.array_equal(ro["converged"], res["converged"])),
+                                             "note": "MRGFE_NDT_REFERENCE_ORDER=1: per-point sums + point-order chains (computeDerivatives), pair-order chain (computeHessian), Eigen's "
+                                                     "JacobiSVD solve; bit-identical to the reference-order oracle (tests/test_gpu_ndt_reforder.py, soak_over_bar.ndt_reference_order)"}
+        finally:
+            lib().mrgfe_dbg_set_ndt_reference_order(0)
         # (4) BASELINE config[2]: GICP scan-to-keyframe (the k-NN correspondence path), keyframe = scan 0, frames = scans 1..6
         extras["config2_gicp"] = run_config2(ctx, scans, dev, poses, lib, args)
         # (4b) registration_method "NDT": pcl::NormalDistributionsTransform, the f64 formulation, on the headline's pairs
@@ -1463,6 +1483,16 @@ def main():
         a = ndt_soak(args.soak_cases, 20260411)
         b = round3_soak(max(1, args.soak_cases // 3), 20260412)
         c = pclndt_soak(max(1, args.soak_cases // 2), 20260413)
+        # ... and NDT_HIP with its sums and Newton solve in the reference's order (opt-in mode, mrgfe_dbg_set_ndt_reference_order): bit identity is the bar there
+        from oracle.replay import ndt_reference_order_soak
+
+        lib().mrgfe_dbg_set_ndt_reference_order(1)
+        try:
+            tr = time.perf_counter()
+            d = ndt_reference_order_soak(max(1, args.soak_cases // 2), 20260414)
+            d["seconds"] = time.perf_counter() - tr
+        finally:
+            lib().mrgfe_dbg_set_ndt_reference_order(0)
         soak = {"ndt": f"{a['ndt_over_bar']}/{a['ndt']}", "ndt_settled": f"{a['ndt_settled_over_bar']}/{a['ndt_settled']}",
                 "ndt_over_bar_equal_to_gpu_order_replay": f"{a['ndt_over_bar_equal_to_gpu_order_replay']}/{a['ndt_over_bar']}",
                 "ndt_bit_identical_to_reference_order_oracle": f"{a['ndt_exact_ref']}/{a['ndt']}", "ndt_bit_identical_to_gpu_order_replay": f"{a['ndt_exact_gpu_order']}/{a['ndt']}",
@@ -1473,6 +1503,8 @@ def main():
                 "pcl_gicp_omp": f"{b['gicp_omp_over_bar']}/{b['gicp_omp']}", "pcl_gicp_omp_over_bar_equal_to_gpu_order_replay": f"{b['gicp_omp_over_bar_equal_to_gpu_order_replay']}/{b['gicp_omp_over_bar']}",
                 "pcl_gicp_omp_bit_identical_to_gpu_order_replay": f"{b['gicp_omp_exact_gpu_order']}/{b['gicp_omp']}", "pcl_gicp_omp_bit_identical_to_reference_order_oracle": f"{b['gicp_omp_exact_ref']}/{b['gicp_omp']}",
                 "pcl_gicp_omp_worst_m_or_rad": b["gicp_omp_worst"], "icp_reciprocal": f"{b['icp_over_bar']}/{b['icp']}",
+                "ndt_reference_order": f"{d['over_bar']}/{d['cases']}", "ndt_reference_order_bit_identical": f"{d['exact']}/{d['cases']}",
+                "ndt_reference_order_unsettled_scenes": d["unsettled"], "ndt_reference_order_seconds": d["seconds"],
                 "pcl_ndt": f"{c['over_bar']}/{c['cases']}", "pcl_ndt_bit_identical_to_reference_order_oracle": f"{c['exact']}/{c['cases']}", "pcl_ndt_worst_m_or_rad": c["worst"],
                 "pcl_ndt_scenes_that_stop_after_one_iteration": f"{c['one_iteration']}/{c['cases']}",
                 "worst_m": max(a["ndt_worst"], a["other_worst"], b["gicp_serial_worst"], b["gicp_omp_worst"], b["icp_worst"], c["worst"]),
@@ -1591,6 +1623,7 @@ def main():
         "value_host_pointers": extras.get("value_host_pointers"),
         "gpu_split_ms_per_step": extras.get("gpu_split_ms_per_step"),
         "pipeline_shape": extras.get("pipeline_shape"),
+        "ndt_reference_order": extras.get("ndt_reference_order"),
         "config2_gicp": extras.get("config2_gicp"),
         "pcl_ndt": extras.get("pcl_ndt"),
         "per_scan_path": extras.get("per_scan_path"),

@@ -32,10 +32,46 @@ def test_soak_all_methods():
     near = [u for u in st["unexplained"] if u["dt_vs_replay_m"] <= 1e-6 and u["iterations_hip"] == u["iterations_replay"]]
     assert len(near) == len(st["unexplained"]), [u for u in st["unexplained"] if u not in near]
     # (`unexplained` lists the scenes that equal NEITHER oracle run bit for bit; one that equals the reference-order run needs no explanation)
-    # reference order: a scene over the bar — settled or not — must be summation-order noise, i.e. equal to the replay.  How MANY there are is
-    # a property of the sample, printed by bench.py with every run (`soak_over_bar`), not a threshold of this test.
+    # reference order: a scene over the bar — settled or not — must be summation-order noise, i.e. equal to the replay ...
     for u in st["over_bar"]:
         assert u["equal_to_gpu_order_replay"] or any(v["case"] == u["case"] for v in near), u
+    # ... AND the counts are capped in absolute terms against the reference-order oracle, which does not go through the product's own optimiser (ADVICE r5:
+    # the replay steps csrc/ndt_ctl.h too, so a defect in its LU fast path would be shared).  Measured on 7,505 scenes (profiles/r05_soak.json): 0.6 % over
+    # the bar, 2 of them settled, worst settled 2.4 cm; on this draw of 240 NDT scenes: at most 5 over the bar, at most 1 settled, and at least 90 % bit-identical.
+    assert st["ndt"] >= 200
+    assert st["ndt_over_bar"] <= 5 and st["ndt_settled_over_bar"] <= 1, st["over_bar"]
+    assert st["ndt_worst_settled"] <= 0.05, st["over_bar"]
+    assert st["ndt_exact_ref"] >= 0.9 * st["ndt"]
+    assert st["ndt_flag_or_iteration_mismatch"] <= st["ndt_over_bar"]
+
+
+def test_soak_lu_fast_path_against_the_svd_solve():
+    """the LU fast path of the Newton solve (ndt_ctl.h lu_solve6) replaced round 4's one-sided Jacobi SVD, and the GPU-order replay shares it.
+    The same 120 scenes in two child processes — default, and MRGFE_NEWTON_SVD=1 (read once per process) — each held against the reference-order oracle,
+    which knows neither: flags, iteration counts and the counts of scenes over the bar must agree between the two solves."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import json, sys; sys.path.insert(0, %r); import torch; from oracle.replay import ndt_soak; st = ndt_soak(120, 13); "
+            "print(json.dumps({k: v for k, v in st.items() if k not in ('over_bar', 'unexplained')}))" % root)
+    out = {}
+    for name in ("lu", "svd"):
+        env = dict(os.environ, OMP_NUM_THREADS="8")
+        env.pop("MRGFE_NEWTON_SVD", None)
+        if name == "svd":
+            env["MRGFE_NEWTON_SVD"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    lu, svd = out["lu"], out["svd"]
+    print(lu, svd)
+    for k in ("ndt", "ndt_flag_or_iteration_mismatch", "other_over_bar", "other_exact"):
+        assert lu[k] == svd[k], k
+    assert abs(lu["ndt_over_bar"] - svd["ndt_over_bar"]) <= 1 and abs(lu["ndt_exact_ref"] - svd["ndt_exact_ref"]) <= 2
+    assert lu["ndt_settled_over_bar"] == svd["ndt_settled_over_bar"] == 0
 
 
 def test_soak_round3_methods():
