@@ -47,12 +47,10 @@ __device__ unsigned long long g_rphase[10];  // ndt_reduce_kernel<true>: sums | 
 
 constexpr int kTilePts = 256;  // points per tile == threads per workgroup
 
-// exp of the per-pair weight: the reference's (glibc's, restated in glibc_exp.h) — the device library's differs from it in the last bit of the double on
-// one argument in ten (invisible after the cast to float except once in 2^29 pairs, decisive for the f64 passes).  -DNDT_PAIR_EXP=exp selects the device
-// library's for the float path (A/B measurements).
-#ifndef NDT_PAIR_EXP
-#define NDT_PAIR_EXP glibc_exp
-#endif
+// exp of the per-pair weight.  The f64 passes (computeHessian, PCL NDT) and everything in reference-order mode call glibc's exp restated (glibc_exp.h): the
+// double the reference's host computes.  The float path of the DEFAULT kernels keeps the device library's: its result differs from glibc's in the last bit of
+// the double on one argument in ten, which survives the cast to float once in ~2^29 pairs (far below the default tree order's own noise), and glibc_exp costs
+// the dominant kernel 5 % (0.585 -> 0.615 ms per launch of a 256-pair step, profiles/ab_libs.sh).  GLIBC = true: the reference-order record kernel.
 
 struct Accum {
     double score;
@@ -70,7 +68,7 @@ __device__ __forceinline__ NdtLeafRec load_leaf(const NdtLeafRec* p)
 }
 
 // float path: updateDerivatives for one (point, voxel) pair
-template <bool HESS>
+template <bool HESS, bool GLIBC = false>
 __device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, const float xt[3], const float J3[3], const float J4[3], const float J5[3],
                                            const float (&PH)[6][3], float gauss_d2f, double gauss_d1)
 {
@@ -86,7 +84,7 @@ __device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, co
     const float qCq = fdot3f(q[0], qC[0], q[1], qC[1], q[2], qC[2]);
     const float arg0 = -gauss_d2f * qCq;
     const float arg = arg0 * 0.5f;
-    float e = static_cast<float>(NDT_PAIR_EXP(static_cast<double>(arg)));
+    float e = static_cast<float>(GLIBC ? glibc_exp(static_cast<double>(arg)) : exp(static_cast<double>(arg)));
     const float score_inc = static_cast<float>(-gauss_d1 * static_cast<double>(e));
     e = gauss_d2f * e;
     if (e > 1.0f || e < 0.0f || e != e) return;
@@ -810,8 +808,8 @@ __global__ __launch_bounds__(256, 2) void ndt_ref_records_kernel(const NdtGridDe
             for (int nb = 0; nb < NNB; ++nb) {
                 if (ids[nb] < 0) continue;
                 const NdtLeafRec leaf_rec = load_leaf(g.leaves + ids[nb]);
-                if (job.mode == 0) pair_float<true>(pt, leaf_rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
-                else               pair_float<false>(pt, leaf_rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
+                if (job.mode == 0) pair_float<true, true>(pt, leaf_rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
+                else               pair_float<false, true>(pt, leaf_rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
             }
         }
         rec[i] = pt.score;
