@@ -24,8 +24,9 @@ int ndt_launch_reduce(mrgfe_ctx* ctx, uint32_t P, const NdtPairDev* d_pairs, Ndt
                       NdtCtlState* d_states, double tag = 0.0);  // tag != 0 and P == 1: stored at d_results[48] once the record is visible to the host
 // NDT_OMP in the reference's summation order (opt-in): per job the records kernel (what every step of the chain adds) and the chain kernel (one lane per
 // accumulator, in order); results[pair][48] like ndt_launch_reduce without states.  max_tiles = ceil(max n_src of the jobs / 256).
+size_t ndt_ref_record_doubles(int mode, size_t n_src, int nnb);  // workspace of one job (tile-major record layout, ndt_derivatives.hip)
 int ndt_launch_ref_round(mrgfe_ctx* ctx, int search, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const NdtRefJob* d_jobs, uint32_t n_jobs,
-                         uint32_t max_tiles, double* d_rec, uint8_t* d_cnt, double* results);
+                         uint32_t max_tiles, double* d_rec, uint8_t* d_cnt, double* results, bool any_mode01, bool any_mode2);
 // diagnostic: ctl::pose_to_matrix / angle_tables / svd_solve6 for n cases of 48 doubles (p[6], A[36], b[6]) on the device
 int ndt_ctl_math_device(mrgfe_ctx* ctx, const double* d_in, int n, float* d_M, double* d_tables, double* d_x);
 // diagnostic: n_vals (44, 37 or 1) doubles per lane and wavefront, summed by wave_sum_fold and by wave_sum (dev_utils.h)

@@ -753,10 +753,21 @@ __device__ __forceinline__ uint32_t ndt_point_neighbours(const NdtGridDev& g, bo
     return cnt;
 }
 
-// rec layout of one job (doubles, column-major so that the chain's lane k streams column k):
-//   mode 0 / 1:  rec[k * n_src + i], k = 0 score, 1..6 gradient, 7..42 Hessian (mode 0 only), 43 the point's neighbour count
-//   mode 2:      rec[k * (n_src * NNB) + i * NNB + j], k = 0 the pair's weight e, 1..36 the bracket of hess(i, j) — the j-th CONTRIBUTING pair of
-//                point i; cnt8[i] = how many there are; column 37's first n_src entries hold the neighbour counts (as doubles)
+// rec layout of one job (doubles), TILE-major so that the chain kernel streams it front to back (column-major over the whole cloud put 44 rows a megabyte
+// apart into every tile: a TLB miss per row and tile):
+//   mode 0 / 1:  tiles of kChainTile points;  rec[(tile * 44 + k) * kChainTile + i % kChainTile], k = 0 score, 1..6 gradient, 7..42 Hessian (mode 0 only),
+//                43 the point's neighbour count
+//   mode 2:      tiles of P = kChainSlots / NNB points = S = P * NNB slots;  rec[(tile * 38 + k) * S + (i % P) * NNB + j], k = 0 the pair's weight e, 1..36 the
+//                bracket of hess(a, b) — the j-th CONTRIBUTING pair of point i; cnt8[i] = how many there are; row 37 holds the neighbour count of point i at
+//                (i % P)
+constexpr int kChainTile = 64;    // points per tile (modes 0 / 1)
+constexpr int kChainSlots = 126;  // record slots per tile (mode 2): 18 points x 7 / 4 x 27 / 126 x 1
+size_t ndt_ref_record_doubles(int mode, size_t n, int nnb)
+{
+    if (mode != 2) return (n + kChainTile - 1) / kChainTile * size_t(kChainTile) * kNdtAccum;
+    const size_t P = static_cast<size_t>(kChainSlots / nnb);
+    return (n + P - 1) / P * (P * nnb) * 38;
+}
 template <int NNB>
 __global__ __launch_bounds__(256, 2) void ndt_ref_records_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs, const NdtEvalDev* __restrict__ evals,
                                                                   const NdtRefJob* __restrict__ jobs, double* __restrict__ rec_base, uint8_t* __restrict__ cnt_base)
@@ -771,7 +782,6 @@ __global__ __launch_bounds__(256, 2) void ndt_ref_records_kernel(const NdtGridDe
     __syncthreads();
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= pr.n_src) return;
-    const size_t n = pr.n_src;
     double* __restrict__ rec = rec_base + job.rec_off;
     const float4 p = load_point(pr.src + i);
     float xt[3];
@@ -812,18 +822,20 @@ __global__ __launch_bounds__(256, 2) void ndt_ref_records_kernel(const NdtGridDe
                 else               pair_float<false, true>(pt, leaf_rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
             }
         }
-        rec[i] = pt.score;
+        double* __restrict__ tile_rec = rec + (size_t)(i / kChainTile) * (kNdtAccum * kChainTile) + i % kChainTile;
+        tile_rec[0] = pt.score;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) rec[(size_t)(1 + k) * n + i] = pt.g[k];
+        for (int k = 0; k < 6; ++k) tile_rec[(1 + k) * kChainTile] = pt.g[k];
         if (job.mode == 0) {
 #pragma unroll
-            for (int k = 0; k < 36; ++k) rec[(size_t)(7 + k) * n + i] = pt.H[k];
+            for (int k = 0; k < 36; ++k) tile_rec[(7 + k) * kChainTile] = pt.H[k];
         }
-        rec[(size_t)kNdtNbIndex * n + i] = static_cast<double>(cnt);
+        tile_rec[kNdtNbIndex * kChainTile] = static_cast<double>(cnt);
         return;
     }
     // ---- computeHessian (f64, PCL's 3x6 / 18x6 point derivative forms), per pair the bracket the reference multiplies by e_x_cov_x ------------
-    const size_t slots = n * NNB;
+    constexpr int kP = kChainSlots / NNB, kS = kP * NNB;
+    double* __restrict__ tile_rec = rec + (size_t)(i / kP) * (38 * kS) + (i % kP) * NNB;
     uint32_t used = 0;
     if (cnt) {
         const double x[3] = {p.x, p.y, p.z};
@@ -851,8 +863,7 @@ __global__ __launch_bounds__(256, 2) void ndt_ref_records_kernel(const NdtGridDe
             double e = gauss_d2 * glibc_exp(-gauss_d2 * fdot3d(q[0], Cq[0], q[1], Cq[1], q[2], Cq[2]) / 2);
             if (e > 1 || e < 0 || e != e) continue;
             e *= gauss_d1;
-            const size_t slot = (size_t)i * NNB + used;
-            rec[slot] = e;
+            tile_rec[used] = e;
             double CJ[6][3];  // C * J(:, c)
 #pragma unroll
             for (int c = 0; c < 6; ++c)
@@ -876,90 +887,187 @@ __global__ __launch_bounds__(256, 2) void ndt_ref_records_kernel(const NdtGridDe
                         qCH = fdot3d(q[0], CH[0], q[1], CH[1], q[2], CH[2]);
                     }
                     const double jtcj = fdot3d(J[0][b], CJ[a][0], J[1][b], CJ[a][1], J[2][b], CJ[a][2]);
-                    rec[(size_t)(1 + a * 6 + b) * slots + slot] = __builtin_fma(t0, qCJ[b], qCH) + jtcj;
+                    tile_rec[(1 + a * 6 + b) * kS + used] = __builtin_fma(t0, qCJ[b], qCH) + jtcj;
                 }
             }
             ++used;
         }
     }
     cnt_base[job.cnt_off + i] = static_cast<uint8_t>(used);
-    rec[(size_t)37 * slots + i] = static_cast<double>(cnt);
+    rec[(size_t)(i / kP) * (38 * kS) + 37 * kS + (i % kP)] = static_cast<double>(cnt);
 }
 
-// one wavefront per job: lane k owns accumulator k and adds its column in order.  Loads run 16 steps ahead of the additions.
-template <int NNB>
-__global__ __launch_bounds__(64) void ndt_ref_chain_kernel(const NdtPairDev* __restrict__ pairs, const NdtRefJob* __restrict__ jobs, const double* __restrict__ rec_base,
-                                                            const uint8_t* __restrict__ cnt_base, double* __restrict__ results)
+// One workgroup per job.  The additions of an accumulator are a chain, so ONE wavefront adds — lane k owns accumulator k — and what it must never do is wait
+// for memory on the chain (a load per step was 0.5 s per evaluation; a 16-deep register prefetch of the lane's own column, 44 cache lines per load
+// instruction, 14 ms).  So all four wavefronts fetch the next tile of records with coalesced loads (the records are tile-major: a tile is one contiguous
+// block) while wavefront 0 adds the current one out of LDS, where lane k walks row k (odd row length in 8-byte words: conflict-free), eight values into
+// registers ahead of their additions.  The f64 Hessian's records come per (point, slot) with 0..NNB used slots per point: the staging step compacts them
+// (a prefix over the tile's counts), so its chain is the same streaming loop with a fused multiply-add in place of the add.
+template <bool WEIGHTED>
+__device__ __forceinline__ double ref_chain_row(double acc, const double* __restrict__ row, const double* __restrict__ wrow, int count)
 {
+    // `count` values of row (and their weights) in order; read in groups of eight (the rows are long enough for the last group to run over)
+#pragma unroll 1
+    for (int h = 0; h < count; h += 8) {
+        double v[8], w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = row[h + j]; if (WEIGHTED) w[j] = wrow[h + j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (h + j < count) acc = WEIGHTED ? __builtin_fma(w[j], v[j], acc) : acc + v[j];
+        }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void ndt_ref_chain01_kernel(const NdtPairDev* __restrict__ pairs, const NdtRefJob* __restrict__ jobs, const double* __restrict__ rec_base,
+                                                               double* __restrict__ results)
+{
+    constexpr int T = kChainTile, kRow = T + 1;
+    constexpr int kPer = (kNdtAccum * T + 255) / 256;  // 11 elements of a tile per thread
+    __shared__ double s_v[2][kNdtAccum * kRow];
     const NdtRefJob job = jobs[blockIdx.x];
-    const NdtPairDev pr = pairs[job.pair];
-    const size_t n = pr.n_src;
-    const double* __restrict__ rec = rec_base + job.rec_off;
-    const int k = threadIdx.x;
+    if (job.mode == 2) return;  // (the f64 Hessian jobs of the round: ndt_ref_chain2_kernel)
+    const uint32_t n = pairs[job.pair].n_src;
+    const MRGFE_GLOBAL double* __restrict__ rec = as_global(rec_base + job.rec_off);
+    const int tid = threadIdx.x;  // (a lane of wavefront 0 owns accumulator tid)
+    // columns this kind delivers: mode 0 all 44 (score, gradient, Hessian, count), mode 1 score + gradient + count (its rows 0..7 = columns 0..6, 43)
+    const int      n_cols = job.mode == 0 ? kNdtAccum : 8;
+    const uint32_t n_tiles = (n + T - 1) / T;
+    // element e of a tile = (row c, position j); what a thread fetches is fixed over the tiles
+    int  lds_at[kPer];
+    uint32_t g_at[kPer];
+    bool mine[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int e = tid + u * 256, c = e / T, j = e % T;
+        mine[u] = c < n_cols;
+        lds_at[u] = c * kRow + j;
+        g_at[u] = static_cast<uint32_t>(((job.mode == 0) ? c : (c < 7 ? c : kNdtNbIndex)) * T + j);
+    }
+    double pre[kPer];
     double acc = 0.0;
-    bool   mine;
-    if (job.mode != 2) {
-        mine = k < 7 || k == kNdtNbIndex || (job.mode == 0 && k < kNdtNbIndex);
-        if (mine) {
-            const MRGFE_GLOBAL double* __restrict__ col = as_global(rec + (size_t)k * n);
-            size_t i = 0;
-            for (; i + 16 <= n; i += 16) {
-                double v[16];
+    // (a tile past the end of the cloud is padding the record kernel never wrote: its last tile is cut to the points that exist — a padded position reads
+    // +0, which is exact to add: the sums start at +0 and are never -0)
+    auto fetch = [&](uint32_t tile) {
+        const MRGFE_GLOBAL double* __restrict__ t0 = rec + (size_t)tile * (kNdtAccum * T);
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = col[i + u];
+        for (int u = 0; u < kPer; ++u) pre[u] = (mine[u] && tile * T + (g_at[u] % T) < n) ? t0[g_at[u]] : 0.0;
+    };
+    auto stage = [&](int buf) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) acc += v[u];
-            }
-            for (; i < n; ++i) acc += col[i];
-        }
-    } else {
-        // hess(a, b) = fma(e, bracket, hess(a, b)) over the contributing pairs, point after point; lanes 0..35 = entry a * 6 + b
-        const size_t slots = n * NNB;
-        mine = k < 36 || k == kNdtNbIndex;
-        if (k < 36) {
-            const MRGFE_GLOBAL double* __restrict__ ecol = as_global(rec);
-            const MRGFE_GLOBAL double* __restrict__ col = as_global(rec + (size_t)(1 + k) * slots);
-            const MRGFE_GLOBAL uint8_t* __restrict__ cnt = as_global(cnt_base + job.cnt_off);
-            for (size_t i0 = 0; i0 < n; i0 += 8) {
-                // eight points' counts, then their slots (every lane walks the same counts: uniform control flow)
-                uint32_t c[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) c[u] = (i0 + u < n) ? cnt[i0 + u] : 0u;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const size_t base = (i0 + u) * NNB;
-                    for (uint32_t j = 0; j < c[u]; ++j) acc = __builtin_fma(ecol[base + j], col[base + j], acc);
-                }
-            }
-        } else if (k == kNdtNbIndex) {
-            const MRGFE_GLOBAL double* __restrict__ col = as_global(rec + (size_t)37 * slots);
-            for (size_t i = 0; i < n; ++i) acc += col[i];
-        }
+        for (int u = 0; u < kPer; ++u)
+            if (mine[u]) s_v[buf][lds_at[u]] = pre[u];
+    };
+    if (n_tiles) { fetch(0); stage(0); }
+    __syncthreads();
+    for (uint32_t tile = 0; tile < n_tiles; ++tile) {
+        const int buf = static_cast<int>(tile & 1u);
+        if (tile + 1 < n_tiles) fetch(tile + 1);  // in flight while wavefront 0 adds
+        if (tid < n_cols) acc = ref_chain_row<false>(acc, &s_v[buf][tid * kRow], nullptr, T);
+        if (tile + 1 < n_tiles) stage(buf ^ 1);
+        __syncthreads();
     }
-    // the record of ndt_reduce_kernel<false>: score, gradient, Hessian (row-major), neighbour count
-    if (k < kNdtPartialStride) {
-        double out = 0.0;
-        if (job.mode != 2) out = mine ? acc : 0.0;
-        else if (k == kNdtNbIndex) out = acc;
-        results[(size_t)job.pair * kNdtPartialStride + k] = out;
+    // the record of ndt_reduce_kernel<false>: score, gradient, Hessian (row-major), neighbour count at slot 43 (mode 1 carries it in its eighth row)
+    if (tid < kNdtPartialStride) {
+        double o = 0.0;
+        if (job.mode == 0) o = tid < kNdtAccum ? acc : 0.0;
+        else if (tid < 7)  o = acc;
+        results[(size_t)job.pair * kNdtPartialStride + tid] = o;
     }
-    if (job.mode == 2 && k < 36) results[(size_t)job.pair * kNdtPartialStride + 7 + k] = acc;
+    if (job.mode == 1) {
+        __syncthreads();
+        if (tid == 7) results[(size_t)job.pair * kNdtPartialStride + kNdtNbIndex] = acc;
+    }
+}
+
+// hess(a, b) = fma(e, bracket, hess(a, b)) over the contributing pairs, point after point; lanes 0..35 = entry a * 6 + b, lane 36 the neighbour count
+template <int NNB>
+__global__ __launch_bounds__(256) void ndt_ref_chain2_kernel(const NdtPairDev* __restrict__ pairs, const NdtRefJob* __restrict__ jobs, const double* __restrict__ rec_base,
+                                                              const uint8_t* __restrict__ cnt_base, double* __restrict__ results)
+{
+    constexpr int P = kChainSlots / NNB, S = P * NNB, kRow = 137;  // (rows are read in whole groups of eight: up to index 127 + 8)
+    constexpr int kPer = (38 * S + 255) / 256;
+    static_assert(P >= 1 && P <= 128 && S <= 128, "tile");
+    __shared__ double   s_v[2][38 * kRow];
+    __shared__ uint32_t s_cnt[2][128], s_off[2][128], s_tot[2];
+    const NdtRefJob job = jobs[blockIdx.x];
+    if (job.mode != 2) return;
+    const uint32_t n = pairs[job.pair].n_src;
+    const MRGFE_GLOBAL double* __restrict__ rec = as_global(rec_base + job.rec_off);
+    const MRGFE_GLOBAL uint8_t* __restrict__ cnt = as_global(cnt_base + job.cnt_off);
+    const int tid = threadIdx.x;
+    const uint32_t n_tiles = (n + P - 1) / P;
+    int row_of[kPer], pt_of[kPer], jj_of[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int e = tid + u * 256, c = e / S, j = e % S;
+        row_of[u] = c < 38 ? c : -1;
+        pt_of[u] = c == 37 ? j : j / NNB;  // row 37: the neighbour count of point j of the tile (j < P)
+        jj_of[u] = j % NNB;
+        if (c == 37 && j >= P) row_of[u] = -1;
+    }
+    double   pre[kPer];
+    uint32_t pre_c = 0;
+    double   acc = 0.0;
+    auto fetch = [&](uint32_t tile) {
+        const MRGFE_GLOBAL double* __restrict__ t0 = rec + (size_t)tile * (38 * S);
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            // rows 0..36: the tile's slots (unused ones hold whatever the workspace held: dropped at staging); row 37: per point, +0 past the end of the cloud
+            const int e = tid + u * 256;
+            const bool want = row_of[u] >= 0 && (row_of[u] < 37 || tile * P + pt_of[u] < n);
+            pre[u] = want ? t0[e] : 0.0;
+        }
+        pre_c = (tid < P && tile * P + tid < n) ? cnt[tile * P + tid] : 0u;
+    };
+    auto stage = [&](int buf) {  // all threads; compacts the used slots of the tile's points
+        if (tid < P) s_cnt[buf][tid] = pre_c;
+        __syncthreads();
+        if (tid < P) {
+            uint32_t o = 0;
+            for (int v = 0; v < tid; ++v) o += s_cnt[buf][v];
+            s_off[buf][tid] = o;
+            if (tid == P - 1) s_tot[buf] = o + pre_c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            if (row_of[u] < 0) continue;
+            if (row_of[u] == 37) s_v[buf][37 * kRow + pt_of[u]] = pre[u];
+            else if (static_cast<uint32_t>(jj_of[u]) < s_cnt[buf][pt_of[u]]) s_v[buf][row_of[u] * kRow + s_off[buf][pt_of[u]] + jj_of[u]] = pre[u];
+        }
+    };
+    if (n_tiles) { fetch(0); stage(0); }
+    __syncthreads();
+    for (uint32_t tile = 0; tile < n_tiles; ++tile) {
+        const int buf = static_cast<int>(tile & 1u);
+        if (tile + 1 < n_tiles) fetch(tile + 1);
+        if (tid < 36)       acc = ref_chain_row<true>(acc, &s_v[buf][(1 + tid) * kRow], &s_v[buf][0], static_cast<int>(s_tot[buf]));
+        else if (tid == 36) acc = ref_chain_row<false>(acc, &s_v[buf][37 * kRow], nullptr, P);  // neighbour counts (integers: exact)
+        if (tile + 1 < n_tiles) stage(buf ^ 1);  // (uniform condition: the barriers inside are reached by all or none)
+        __syncthreads();
+    }
+    if (tid < kNdtPartialStride) results[(size_t)job.pair * kNdtPartialStride + tid] = 0.0;  // (score / gradient slots: this kind delivers none)
+    __syncthreads();
+    if (tid < 36) results[(size_t)job.pair * kNdtPartialStride + 7 + tid] = acc;
+    if (tid == 36) results[(size_t)job.pair * kNdtPartialStride + kNdtNbIndex] = acc;
 }
 
 int ndt_launch_ref_round(mrgfe_ctx* ctx, int search, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const NdtRefJob* d_jobs, uint32_t n_jobs,
-                         uint32_t max_tiles, double* d_rec, uint8_t* d_cnt, double* results)
+                         uint32_t max_tiles, double* d_rec, uint8_t* d_cnt, double* results, bool any_mode01, bool any_mode2)
 {
     if (n_jobs == 0 || max_tiles == 0) return MRGFE_OK;
     const dim3 grid(max_tiles, n_jobs);
-    if (search == MRGFE_DIRECT7) {
-        hipLaunchKernelGGL((ndt_ref_records_kernel<7>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_jobs, d_rec, d_cnt);
-        hipLaunchKernelGGL((ndt_ref_chain_kernel<7>), dim3(n_jobs), dim3(64), 0, ctx->stream, d_pairs, d_jobs, d_rec, d_cnt, results);
-    } else if (search == MRGFE_DIRECT1) {
-        hipLaunchKernelGGL((ndt_ref_records_kernel<1>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_jobs, d_rec, d_cnt);
-        hipLaunchKernelGGL((ndt_ref_chain_kernel<1>), dim3(n_jobs), dim3(64), 0, ctx->stream, d_pairs, d_jobs, d_rec, d_cnt, results);
-    } else {
-        hipLaunchKernelGGL((ndt_ref_records_kernel<27>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_jobs, d_rec, d_cnt);
-        hipLaunchKernelGGL((ndt_ref_chain_kernel<27>), dim3(n_jobs), dim3(64), 0, ctx->stream, d_pairs, d_jobs, d_rec, d_cnt, results);
+    if (search == MRGFE_DIRECT7)      hipLaunchKernelGGL((ndt_ref_records_kernel<7>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_jobs, d_rec, d_cnt);
+    else if (search == MRGFE_DIRECT1) hipLaunchKernelGGL((ndt_ref_records_kernel<1>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_jobs, d_rec, d_cnt);
+    else                              hipLaunchKernelGGL((ndt_ref_records_kernel<27>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_jobs, d_rec, d_cnt);
+    // a workgroup per job in both chain kernels; a job of the other kind returns at once
+    if (any_mode01) hipLaunchKernelGGL(ndt_ref_chain01_kernel, dim3(n_jobs), dim3(256), 0, ctx->stream, d_pairs, d_jobs, d_rec, results);
+    if (any_mode2) {
+        if (search == MRGFE_DIRECT7)      hipLaunchKernelGGL((ndt_ref_chain2_kernel<7>), dim3(n_jobs), dim3(256), 0, ctx->stream, d_pairs, d_jobs, d_rec, d_cnt, results);
+        else if (search == MRGFE_DIRECT1) hipLaunchKernelGGL((ndt_ref_chain2_kernel<1>), dim3(n_jobs), dim3(256), 0, ctx->stream, d_pairs, d_jobs, d_rec, d_cnt, results);
+        else                              hipLaunchKernelGGL((ndt_ref_chain2_kernel<27>), dim3(n_jobs), dim3(256), 0, ctx->stream, d_pairs, d_jobs, d_rec, d_cnt, results);
     }
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;

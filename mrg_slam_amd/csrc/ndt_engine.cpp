@@ -531,6 +531,7 @@ int NdtEngine::reference_round()
     std::vector<NdtRefJob> jobs;
     size_t   rec_doubles = 0, cnt_bytes = 0;
     uint32_t max_tiles = 0;
+    bool     any01 = false, any2 = false;
     auto flush = [&]() -> int {
         if (jobs.empty()) return MRGFE_OK;
         MRGFE_TRY(d_ref_rec_.ensure(rec_doubles * sizeof(double)));
@@ -538,10 +539,11 @@ int NdtEngine::reference_round()
         MRGFE_TRY(d_ref_jobs_.ensure(sizeof(NdtRefJob) * jobs.size()));
         MRGFE_TRY(ctx_->stage_h2d(d_ref_jobs_.p, jobs.data(), sizeof(NdtRefJob) * jobs.size(), st));
         MRGFE_TRY(ndt_launch_ref_round(ctx_, prm_.search, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_ref_jobs_.as<NdtRefJob>(),
-                                       static_cast<uint32_t>(jobs.size()), max_tiles, d_ref_rec_.as<double>(), d_ref_cnt_.as<uint8_t>(), h_results_.as<double>()));
+                                       static_cast<uint32_t>(jobs.size()), max_tiles, d_ref_rec_.as<double>(), d_ref_cnt_.as<uint8_t>(), h_results_.as<double>(), any01, any2));
         jobs.clear();
         rec_doubles = cnt_bytes = 0;
         max_tiles = 0;
+        any01 = any2 = false;
         return MRGFE_OK;
     };
     for (uint32_t i = 0; i < P; ++i) {
@@ -549,9 +551,10 @@ int NdtEngine::reference_round()
         if (c.done()) continue;
         const uint32_t mode = static_cast<uint32_t>(c.request_mode());
         const size_t   n = pairs_[i].n;
-        const size_t   need = mode == 2 ? 38 * n * nnb : size_t(kNdtAccum) * n;  // doubles
+        const size_t   need = ndt_ref_record_doubles(static_cast<int>(mode), n, static_cast<int>(nnb));  // doubles
         if (!jobs.empty() && (rec_doubles + need) * sizeof(double) > ws_cap) MRGFE_TRY(flush());
         jobs.push_back(NdtRefJob{i, mode, rec_doubles, cnt_bytes});
+        (mode == 2 ? any2 : any01) = true;
         rec_doubles += need;
         if (mode == 2) cnt_bytes += (n + 15) & ~size_t(15);
         max_tiles = std::max(max_tiles, static_cast<uint32_t>((n + 255) / 256));
