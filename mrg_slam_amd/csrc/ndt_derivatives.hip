@@ -760,7 +760,7 @@ __device__ __forceinline__ uint32_t ndt_point_neighbours(const NdtGridDev& g, bo
 //   mode 2:      tiles of P = kChainSlots / NNB points = S = P * NNB slots;  rec[(tile * 38 + k) * S + (i % P) * NNB + j], k = 0 the pair's weight e, 1..36 the
 //                bracket of hess(a, b) — the j-th CONTRIBUTING pair of point i; cnt8[i] = how many there are; row 37 holds the neighbour count of point i at
 //                (i % P)
-constexpr int kChainTile = 64;    // points per tile (modes 0 / 1)
+constexpr int kChainTile = 128;   // points per tile (modes 0 / 1): two LDS buffers of 44 rows = 91 KB
 constexpr int kChainSlots = 126;  // record slots per tile (mode 2): 18 points x 7 / 4 x 27 / 126 x 1
 size_t ndt_ref_record_doubles(int mode, size_t n, int nnb)
 {
@@ -904,18 +904,17 @@ __global__ __launch_bounds__(256, 2) void ndt_ref_records_kernel(const NdtGridDe
 // registers ahead of their additions.  The f64 Hessian's records come per (point, slot) with 0..NNB used slots per point: the staging step compacts them
 // (a prefix over the tile's counts), so its chain is the same streaming loop with a fused multiply-add in place of the add.
 template <bool WEIGHTED>
-__device__ __forceinline__ double ref_chain_row(double acc, const double* __restrict__ row, const double* __restrict__ wrow, int count)
+__device__ __forceinline__ double ref_chain_row(double acc, const double* __restrict__ row, const double* __restrict__ wrow, int count8)
 {
-    // `count` values of row (and their weights) in order; read in groups of eight (the rows are long enough for the last group to run over)
-#pragma unroll 1
-    for (int h = 0; h < count; h += 8) {
+    // `count8` (a multiple of eight) values of row (and their weights) in order, eight LDS reads ahead of their eight dependent operations.  No predicate on the
+    // chain: what lies past the real count is zero (+0 terms, or 0 * 0 under the fused multiply-add: both leave a sum that is never -0 unchanged).
+#pragma unroll 2
+    for (int h = 0; h < count8; h += 8) {
         double v[8], w[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { v[j] = row[h + j]; if (WEIGHTED) w[j] = wrow[h + j]; }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (h + j < count) acc = WEIGHTED ? __builtin_fma(w[j], v[j], acc) : acc + v[j];
-        }
+        for (int j = 0; j < 8; ++j) acc = WEIGHTED ? __builtin_fma(w[j], v[j], acc) : acc + v[j];
     }
     return acc;
 }
@@ -924,7 +923,7 @@ __global__ __launch_bounds__(256) void ndt_ref_chain01_kernel(const NdtPairDev* 
                                                                double* __restrict__ results)
 {
     constexpr int T = kChainTile, kRow = T + 1;
-    constexpr int kPer = (kNdtAccum * T + 255) / 256;  // 11 elements of a tile per thread
+    constexpr int kPer = (kNdtAccum * T + 255) / 256;  // 22 elements of a tile per thread
     __shared__ double s_v[2][kNdtAccum * kRow];
     const NdtRefJob job = jobs[blockIdx.x];
     if (job.mode == 2) return;  // (the f64 Hessian jobs of the round: ndt_ref_chain2_kernel)
@@ -986,7 +985,7 @@ template <int NNB>
 __global__ __launch_bounds__(256) void ndt_ref_chain2_kernel(const NdtPairDev* __restrict__ pairs, const NdtRefJob* __restrict__ jobs, const double* __restrict__ rec_base,
                                                               const uint8_t* __restrict__ cnt_base, double* __restrict__ results)
 {
-    constexpr int P = kChainSlots / NNB, S = P * NNB, kRow = 137;  // (rows are read in whole groups of eight: up to index 127 + 8)
+    constexpr int P = kChainSlots / NNB, S = P * NNB, kRow = 137;  // (rows are read in whole groups of eight: S <= 128 entries + 8 of padding, odd length)
     constexpr int kPer = (38 * S + 255) / 256;
     static_assert(P >= 1 && P <= 128 && S <= 128, "tile");
     __shared__ double   s_v[2][38 * kRow];
@@ -1037,14 +1036,17 @@ __global__ __launch_bounds__(256) void ndt_ref_chain2_kernel(const NdtPairDev* _
             if (row_of[u] == 37) s_v[buf][37 * kRow + pt_of[u]] = pre[u];
             else if (static_cast<uint32_t>(jj_of[u]) < s_cnt[buf][pt_of[u]]) s_v[buf][row_of[u] * kRow + s_off[buf][pt_of[u]] + jj_of[u]] = pre[u];
         }
+        // zeros behind the compacted entries up to the next multiple of eight (the chain reads whole groups), and behind the P neighbour counts of row 37
+        if (tid < 37 * 8) s_v[buf][(tid / 8) * kRow + s_tot[buf] + tid % 8] = 0.0;
+        else if (tid < 38 * 8) s_v[buf][37 * kRow + P + tid % 8] = 0.0;
     };
     if (n_tiles) { fetch(0); stage(0); }
     __syncthreads();
     for (uint32_t tile = 0; tile < n_tiles; ++tile) {
         const int buf = static_cast<int>(tile & 1u);
         if (tile + 1 < n_tiles) fetch(tile + 1);
-        if (tid < 36)       acc = ref_chain_row<true>(acc, &s_v[buf][(1 + tid) * kRow], &s_v[buf][0], static_cast<int>(s_tot[buf]));
-        else if (tid == 36) acc = ref_chain_row<false>(acc, &s_v[buf][37 * kRow], nullptr, P);  // neighbour counts (integers: exact)
+        if (tid < 36)       acc = ref_chain_row<true>(acc, &s_v[buf][(1 + tid) * kRow], &s_v[buf][0], (static_cast<int>(s_tot[buf]) + 7) & ~7);
+        else if (tid == 36) acc = ref_chain_row<false>(acc, &s_v[buf][37 * kRow], nullptr, (P + 7) & ~7);  // neighbour counts (integers: exact)
         if (tile + 1 < n_tiles) stage(buf ^ 1);  // (uniform condition: the barriers inside are reached by all or none)
         __syncthreads();
     }
