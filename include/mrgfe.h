@@ -82,7 +82,8 @@ enum mrgfe_ndt_search { MRGFE_KDTREE = 0, MRGFE_DIRECT26 = 1, MRGFE_DIRECT7 = 2,
 typedef struct mrgfe_reg_params {
     int    method;                          /* enum mrgfe_method                        "registration_method"               */
     int    num_threads;                     /* unused on the GPU, except PCL_GICP_OMP_HIP: "reg_num_threads"
-                                               the OpenMP thread count whose order of additions is reproduced               */
+                                               the OpenMP thread count whose order of additions is reproduced: 1..16
+                                               (0 = 8, the YAML's value; 1 = one chain; more than 16 is refused)            */
     double transformation_epsilon;          /*                                          "reg_transformation_epsilon"        */
     int    maximum_iterations;              /*                                          "reg_maximum_iterations"            */
     double max_correspondence_distance;     /* GICP                                     "reg_max_correspondence_distance"   */

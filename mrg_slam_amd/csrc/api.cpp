@@ -68,10 +68,12 @@ GicpParams gicp_params_from(const mrgfe_reg_params& p)
     g.variant = p.method == MRGFE_SMALL_GICP_HIP ? 1 : p.method == MRGFE_VGICP_HIP ? 2 : p.method == MRGFE_ICP_HIP ? 3 : (p.method == MRGFE_PCL_GICP_HIP || p.method == MRGFE_PCL_GICP_OMP_HIP) ? 4 : 0;
     g.max_inner_iterations = p.max_optimizer_iterations;
     g.pcl_whole_gradient_norm = p.method == MRGFE_PCL_GICP_OMP_HIP;
-    g.pcl_reference_order_sums = p.method == MRGFE_PCL_GICP_HIP;
     // pclomp::GICP never sees reg_num_threads (registrations.cpp:104-114 does not call setNumThreads): its sums are those of omp_get_max_threads() threads
-    // of the reference's host.  Here: num_threads of the params when given, 8 (the YAML's reg_num_threads) otherwise; at most 16 chains
-    g.pcl_omp_sum_threads = p.method == MRGFE_PCL_GICP_OMP_HIP ? std::min(16, p.num_threads > 0 ? p.num_threads : 8) : 0;
+    // of the reference's host.  Here: num_threads of the params when given, 8 (the YAML's reg_num_threads) otherwise; 2..16 chains (check_params refuses more).
+    // ONE thread is the serial chain over the correspondences (one partial, 0 + p_0 = p_0): pcl::GICP's order (it used to fall through to the tree)
+    const int omp_threads = p.method == MRGFE_PCL_GICP_OMP_HIP ? (p.num_threads > 0 ? p.num_threads : 8) : 0;
+    g.pcl_reference_order_sums = p.method == MRGFE_PCL_GICP_HIP || omp_threads == 1;
+    g.pcl_omp_sum_threads = omp_threads > 1 ? std::min(16, omp_threads) : 0;
     g.use_reciprocal = p.method == MRGFE_ICP_HIP && p.use_reciprocal_correspondences != 0;
     g.voxel_resolution = p.resolution;
     return g;
@@ -80,6 +82,10 @@ GicpParams gicp_params_from(const mrgfe_reg_params& p)
 int check_params(const mrgfe_reg_params* p)
 {
     if (!p) { set_error("NULL params"); return MRGFE_ERR_INVALID; }
+    if (p->method == MRGFE_PCL_GICP_OMP_HIP && p->num_threads > 16) {
+        set_error("PCL_GICP_OMP_HIP adds its cost terms as num_threads OpenMP threads would (static chunks, partials in thread order): 1..16 threads are supported, got %d", p->num_threads);
+        return MRGFE_ERR_INVALID;
+    }
     if (p->method < MRGFE_NDT_HIP || p->method > MRGFE_PCL_NDT_HIP) { set_error("unknown registration method %d", p->method); return MRGFE_ERR_INVALID; }
     if ((p->method == MRGFE_PCL_GICP_HIP || p->method == MRGFE_PCL_GICP_OMP_HIP) && p->max_optimizer_iterations < 1) { set_error("max_optimizer_iterations must be >= 1"); return MRGFE_ERR_INVALID; }
     if (is_ndt(p->method)) {

@@ -131,3 +131,34 @@ def test_pcl_gicp_limits_and_degenerate_inputs():
     np.testing.assert_array_equal(far.getFinalTransformation(), np.eye(4, dtype=np.float32))
     with pytest.raises(MrgfeError):
         BatchMatcher(default_params(PCL_GICP_HIP))
+
+
+def test_pclomp_with_one_thread_is_the_serial_chain_and_more_than_sixteen_is_refused():
+    """`reg_num_threads: 1` with GICP_OMP used to fall through to the block tree, which matches no reference.  One OpenMP thread adds ALL terms into its
+    one partial in correspondence order (then 0 + p_0 = p_0): the serial chain.  So PCL_GICP_OMP_HIP with num_threads = 1 must equal the oracle's one-thread
+    accumulation; thread counts beyond the sixteen chains the kernel has are an error, not a silent clamp."""
+    from mrg_slam_amd import MrgfeError, PclGicpHip, synth
+    from oracle import oracle as orc
+
+    tgt, src, rel = _pair(6000, 22, 5003)
+    g, o = PclGicpHip(omp=True, num_threads=1, transformation_epsilon=1e-4), orc.PclGicp(omp=True, num_threads=4, sum_threads=1, transformation_epsilon=1e-4)
+    eight = orc.PclGicp(omp=True, num_threads=4, sum_threads=8, transformation_epsilon=1e-4)
+    for r in (g, o, eight):
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+    differs = False
+    for T, x in ((np.eye(4), np.zeros(6)), (rel, np.array([0.05, -0.02, 0.01, 0.004, -0.003, 0.01])), (np.eye(4), np.array([0.2, -0.1, 0.05, 0.01, -0.01, 0.03]))):
+        fg, gg, ng = g.evaluate(T, x)
+        fo, go, no = o.evaluate(T, x)
+        f8, g8, _ = eight.evaluate(T, x)
+        assert ng == no and fg == pytest.approx(fo, rel=1e-14)
+        np.testing.assert_allclose(gg, go, rtol=0, atol=1e-14 * np.abs(go).max())
+        differs = differs or fg != f8 or (gg != g8).any()
+    assert differs  # (eight partials round differently somewhere)
+    for guess in (np.eye(4), synth.perturb_pose(rel, np.random.default_rng(4))):
+        g.align(guess)
+        o.align(guess)
+        np.testing.assert_array_equal(g.getFinalTransformation(), o.getFinalTransformation())
+        assert (g.hasConverged(), g.getFinalNumIteration()) == (o.hasConverged(), o.getFinalNumIteration())
+    with pytest.raises(MrgfeError, match="1..16 threads"):
+        PclGicpHip(omp=True, num_threads=17)
