@@ -23,6 +23,8 @@ struct LeafSlice {
     uint32_t hash_shift, hash_mask;
     uint32_t keep_rejected;  // 1: voxels with >= 6 points that the eigenvalue / inf checks rejected (nr_points -1) stay in the lookup — upstream's
                              // radiusSearch returns them (their centroid entered the kd-tree before the checks); the DIRECT searches test nr_points
+    uint32_t pcl_eigen_rule;   // 1: pcl::VoxelGridCovariance's validity test (eigenvalues below -1e-12 invalidate), 0: pclomp's (below 0)
+    uint32_t pad_;
     uint64_t lookup_byte_off;  // byte offset of this target's lookup table in the lookup arena
 };
 

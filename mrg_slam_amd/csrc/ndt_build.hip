@@ -340,7 +340,8 @@ __global__ __launch_bounds__(256) void ndt_leaf_finalize_kernel(const LeafSlice*
         for (int k = 0; k < 9; ++k) cov[k] *= f;
         double w[3], V[9];
         dl_sym_eig3(cov, w, V);
-        if (w[0] < 0 || w[1] < 0 || w[2] <= 0) {
+        const double neg_tol = ls.pcl_eigen_rule ? kPclVgcNegativeEigenTolerance : 0.0;
+        if (w[0] < -neg_tol || w[1] < -neg_tol || w[2] <= 0) {
             npts = -1;
         } else {
             const double min_ev = kNdtMinCovarEigMult * w[2];

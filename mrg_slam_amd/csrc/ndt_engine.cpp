@@ -284,6 +284,8 @@ int NdtEngine::build_targets(bool wait)
         ls.seg_off = total_leaves + k;
         ls.n_valid = h_nv[k];
         ls.keep_rejected = prm_.search == MRGFE_KDTREE ? 1u : 0u;  // radiusSearch has no nr_points test (ndt_build.h)
+        ls.pcl_eigen_rule = prm_.formulation == 1 ? 1u : 0u;       // PCL_NDT_HIP: pcl::VoxelGridCovariance, not ndt_omp's fork of it
+        ls.pad_ = 0;
         ls.lookup_byte_off = lookup_bytes;
         if (T.status == MRGFE_OK) {
             if (h_vp[k].n_cells <= kDenseLookupMaxCells && !force_hash_) {

@@ -16,6 +16,9 @@ namespace mrgfe {
 
 constexpr int      kNdtMinPointsPerVoxel = 6;      // pclomp::VoxelGridCovariance::min_points_per_voxel_
 constexpr double   kNdtMinCovarEigMult   = 0.01;   // min_covar_eigvalue_mult_
+// a leaf is invalid when one of its two smaller covariance eigenvalues is below minus this: 0 in ndt_omp's filter (forked from PCL 1.8), dummy_precision() = 1e-12
+// in pcl::VoxelGridCovariance of PCL >= 1.11, which PCL_NDT_HIP's targets follow: an exactly planar voxel (eigenvalue ~ -1e-18) is inflated and kept there
+constexpr double   kPclVgcNegativeEigenTolerance = 1e-12;
 constexpr uint32_t kHashEmpty            = 0xFFFFFFFFu;
 constexpr uint32_t kDenseLookupMaxCells  = 1u << 22;
 

@@ -108,7 +108,7 @@ int VoxelGridCovariance::build(const float* xyzi, int n, float leaf)
         for (int k = 0; k < 9; ++k) L.cov[k] *= f;
         double ev[3], evec[9];
         sym_eig3(L.cov, ev, evec);
-        if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) { L.nr_points = -1; continue; }
+        if (ev[0] < -negative_eigen_tolerance || ev[1] < -negative_eigen_tolerance || ev[2] <= 0) { L.nr_points = -1; continue; }
         double min_ev = quirks::kNdtMinCovarEigvalMult * ev[2];
         if (ev[0] < min_ev) {
             ev[0] = min_ev;

@@ -35,6 +35,7 @@ struct VoxelGridCovariance {
     std::vector<NdtLeaf>         leaves;  // ascending key (std::map iteration order)
     std::unordered_map<int, int> index;   // key -> leaves[] position (all leaves, also < 6 points)
     int n_valid = 0;
+    double negative_eigen_tolerance = 0.0;  // quirks.h: 0 for pclomp's filter, 1e-12 for PCL 1.12's (set by PclNdt)
 
     // returns 0 ok, -1 index overflow ("Leaf size is too small"), -2 empty input
     int build(const float* xyzi, int n, float leaf);

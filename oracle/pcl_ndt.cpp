@@ -34,6 +34,7 @@ int PclNdt::set_target(const float* xyzi, int n)
 {
     // setInputTarget -> init(): target_cells_.setLeafSize(resolution_ x3); setInputCloud(target_); filter(true)
     target.assign(xyzi, xyzi + static_cast<size_t>(n) * 4);
+    cells.negative_eigen_tolerance = quirks::kPclVgcNegativeEigenTolerance;  // pcl::VoxelGridCovariance of PCL 1.12, not ndt_omp's fork of it
     target_status = cells.build(target.data(), n, resolution);
     return target_status;
 }

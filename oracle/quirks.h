@@ -15,6 +15,12 @@ namespace quirks {
 // ---- pclomp::VoxelGridCovariance (ndt_omp voxel_grid_covariance_omp.h) ------------------------------
 constexpr int    kNdtMinPointsPerVoxel   = 6;     // min_points_per_voxel_
 constexpr double kNdtMinCovarEigvalMult  = 0.01;  // min_covar_eigvalue_mult_
+// A leaf is invalid when an eigenvalue of its covariance is negative.  ndt_omp's copy of the filter (forked from PCL 1.8) tests `< 0`; pcl::VoxelGridCovariance of
+// PCL >= 1.11 — what pcl::NormalDistributionsTransform (registration_method "NDT") builds its target with — tests `< -Eigen::NumTraits<double>::dummy_precision()`
+// (= -1e-12) for the two smaller ones, so that an exactly planar voxel (smallest eigenvalue ~ -1e-18 by rounding) is inflated and kept instead of dropped.
+// [UPSTREAM-RECALL, ADVICE r5: PCL is not in the image] — one edit here and in csrc/ndt_types.h (kPclVgcNegativeEigenTolerance) to correct.
+constexpr double kNdtNegativeEigenTolerance    = 0.0;    // pclomp::VoxelGridCovariance
+constexpr double kPclVgcNegativeEigenTolerance = 1e-12;  // pcl::VoxelGridCovariance (PCL 1.12)
 
 // ---- pclomp::NormalDistributionsTransform defaults (ndt_omp_impl.hpp ctor) ---------------------------
 constexpr float  kNdtResolution          = 1.0f;

@@ -177,6 +177,39 @@ def test_rejected_leaf_answers_the_radius_search():
         assert (npts == -1).sum() >= 1  # the read-out still says "rejected"
 
 
+def test_exactly_planar_voxels_follow_pcl_112s_eigenvalue_tolerance():
+    """ADVICE r5: pcl::VoxelGridCovariance of PCL >= 1.11 invalidates a leaf only when one of its two smaller eigenvalues is below -dummy_precision() (1e-12);
+    ndt_omp's fork tests `< 0`.  A voxel of exactly coplanar points has a smallest eigenvalue of ~ -1e-18 .. +1e-18 by rounding: PCL's NDT inflates and keeps every
+    such voxel, pclomp's drops the negative half.  A cloud of exactly planar patches at many offsets: PCL_NDT_HIP's leaves equal the oracle's PclNdt leaves (counts incl.
+    the -1 marks, inverse covariances), no planar voxel is marked invalid there, and NDT_HIP on the same cloud — the pclomp rule, equal to ITS oracle — marks some."""
+    from mrg_slam_amd import NdtHip, PclNdtHip
+    from oracle import oracle as orc
+
+    rng = np.random.default_rng(12)
+    pts = []
+    for k in range(400):  # patches of 12 points, each exactly in a plane z = const, x = const or y = const of its own voxel
+        c = np.floor(rng.uniform(-20, 20, 3)) + 0.5
+        p = c + rng.uniform(-0.45, 0.45, (12, 3))
+        p[:, k % 3] = np.float32(c[k % 3] + rng.uniform(-0.3, 0.3))
+        pts.append(p)
+    tgt = np.concatenate(pts).astype(np.float32)
+    tgt = np.concatenate([tgt, np.zeros((len(tgt), 1), np.float32)], axis=1)
+    g, o = PclNdtHip(), orc.PclNdt()
+    assert g.setInputTarget(tgt) == 0 and o.setInputTarget(tgt) == 0
+    kg, ng, mg, ig = g.leaves()
+    ko, no, _, mo, io, _ = o.leaves()
+    np.testing.assert_array_equal(kg, ko)
+    np.testing.assert_array_equal(ng, no)
+    np.testing.assert_array_equal(mg, mo)
+    np.testing.assert_array_equal(ig, io)
+    assert (ng >= 6).sum() >= 300 and (ng == -1).sum() == 0  # every planar voxel is kept (inflated to 1 % of its largest eigenvalue)
+    g2, o2 = NdtHip(), orc.Ndt()
+    assert g2.setInputTarget(tgt) == 0 and o2.setInputTarget(tgt) == 0
+    n2, no2 = g2.leaves()[1], o2.leaves()[1]
+    np.testing.assert_array_equal(n2, no2)
+    assert (n2 == -1).sum() >= 10  # pclomp's `< 0`: the patches whose smallest eigenvalue rounded to the negative side are dropped
+
+
 def test_degenerate_inputs_behave_like_the_reference():
     from mrg_slam_amd import PclNdtHip, _lib, synth
 
