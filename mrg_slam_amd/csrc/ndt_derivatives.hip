@@ -68,16 +68,17 @@ __device__ __forceinline__ NdtLeafRec load_leaf(const NdtLeafRec* p)
 }
 
 // float path: updateDerivatives for one (point, voxel) pair
-template <bool HESS, bool GLIBC = false>
-__device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, const float xt[3], const float J3[3], const float J4[3], const float J5[3],
-                                           const float (&PH)[6][3], float gauss_d2f, double gauss_d1)
+// `mean` + the inverse covariance as the 3 x 3 float matrix the reference casts it to.  The default kernels read the 48-byte leaf record, which keeps the
+// UPPER TRIANGLE (pair_float below: C symmetric); the inverse of a clamped covariance is asymmetric at ~1e-14 relative in f64, so on roughly one target in
+// twenty some leaf has a float(icov(r, c)) one ulp away from float(icov(c, r)) — a 1e-8 relative difference in the sums of the points that meet that leaf, a
+// documented deviation of the default mode.  The reference-order record kernel casts all nine f64 entries like the reference does.
+template <bool HESS, bool GLIBC>
+__device__ __forceinline__ void pair_float_c(Accum& acc, const double (&mean)[3], const float (&C)[3][3], const float xt[3], const float J3[3], const float J4[3], const float J5[3],
+                                             const float (&PH)[6][3], float gauss_d2f, double gauss_d1)
 {
 #pragma clang fp contract(off)
-    const float q[3] = {static_cast<float>(static_cast<double>(xt[0]) - rec.mean[0]), static_cast<float>(static_cast<double>(xt[1]) - rec.mean[1]),
-                        static_cast<float>(static_cast<double>(xt[2]) - rec.mean[2])};
-    // symmetric inverse covariance
-    const float c00 = rec.icov[0], c01 = rec.icov[1], c02 = rec.icov[2], c11 = rec.icov[3], c12 = rec.icov[4], c22 = rec.icov[5];
-    const float C[3][3] = {{c00, c01, c02}, {c01, c11, c12}, {c02, c12, c22}};
+    const float q[3] = {static_cast<float>(static_cast<double>(xt[0]) - mean[0]), static_cast<float>(static_cast<double>(xt[1]) - mean[1]),
+                        static_cast<float>(static_cast<double>(xt[2]) - mean[2])};
     float qC[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) qC[c] = fdot3f(q[0], C[0][c], q[1], C[1][c], q[2], C[2][c]);
@@ -136,6 +137,17 @@ __device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, co
             acc.H[i * 6 + j] += static_cast<double>(t4);
         }
     }
+}
+
+template <bool HESS, bool GLIBC = false>
+__device__ __forceinline__ void pair_float(Accum& acc, const NdtLeafRec& rec, const float xt[3], const float J3[3], const float J4[3], const float J5[3],
+                                           const float (&PH)[6][3], float gauss_d2f, double gauss_d1)
+{
+    // symmetric inverse covariance out of the record's upper triangle
+    const float c00 = rec.icov[0], c01 = rec.icov[1], c02 = rec.icov[2], c11 = rec.icov[3], c12 = rec.icov[4], c22 = rec.icov[5];
+    const float  C[3][3] = {{c00, c01, c02}, {c01, c11, c12}, {c02, c12, c22}};
+    const double mean[3] = {rec.mean[0], rec.mean[1], rec.mean[2]};
+    pair_float_c<HESS, GLIBC>(acc, mean, C, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
 }
 
 // MODE 0: score+gradient+Hessian, 1: score+gradient, 2: Hessian only (double).  NNB: probed voxels (7, 1 or 27).
@@ -817,9 +829,15 @@ __global__ __launch_bounds__(256, 2) void ndt_ref_records_kernel(const NdtGridDe
 #pragma unroll
             for (int nb = 0; nb < NNB; ++nb) {
                 if (ids[nb] < 0) continue;
-                const NdtLeafRec leaf_rec = load_leaf(g.leaves + ids[nb]);
-                if (job.mode == 0) pair_float<true, true>(pt, leaf_rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
-                else               pair_float<false, true>(pt, leaf_rec, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
+                // the reference's operands: the leaf's f64 mean and ALL NINE entries of its f64 inverse covariance cast to float
+                const MRGFE_GLOBAL double* __restrict__ Cg = as_global(g.icov64 + (size_t)ids[nb] * 9);
+                const MRGFE_GLOBAL double* __restrict__ mg = as_global(g.leaves[ids[nb]].mean);
+                const float  C[3][3] = {{static_cast<float>(Cg[0]), static_cast<float>(Cg[1]), static_cast<float>(Cg[2])},
+                                        {static_cast<float>(Cg[3]), static_cast<float>(Cg[4]), static_cast<float>(Cg[5])},
+                                        {static_cast<float>(Cg[6]), static_cast<float>(Cg[7]), static_cast<float>(Cg[8])}};
+                const double mean[3] = {mg[0], mg[1], mg[2]};
+                if (job.mode == 0) pair_float_c<true, true>(pt, mean, C, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
+                else               pair_float_c<false, true>(pt, mean, C, xt, J3, J4, J5, PH, gauss_d2f, gauss_d1);
             }
         }
         double* __restrict__ tile_rec = rec + (size_t)(i / kChainTile) * (kNdtAccum * kChainTile) + i % kChainTile;
@@ -1037,8 +1055,10 @@ __global__ __launch_bounds__(256) void ndt_ref_chain2_kernel(const NdtPairDev* _
             else if (static_cast<uint32_t>(jj_of[u]) < s_cnt[buf][pt_of[u]]) s_v[buf][row_of[u] * kRow + s_off[buf][pt_of[u]] + jj_of[u]] = pre[u];
         }
         // zeros behind the compacted entries up to the next multiple of eight (the chain reads whole groups), and behind the P neighbour counts of row 37
-        if (tid < 37 * 8) s_v[buf][(tid / 8) * kRow + s_tot[buf] + tid % 8] = 0.0;
-        else if (tid < 38 * 8) s_v[buf][37 * kRow + P + tid % 8] = 0.0;
+        for (int t = tid; t < 38 * 8; t += 256) {  // (304 entries, 256 threads)
+            if (t < 37 * 8) s_v[buf][(t / 8) * kRow + s_tot[buf] + t % 8] = 0.0;
+            else            s_v[buf][37 * kRow + P + t % 8] = 0.0;
+        }
     };
     if (n_tiles) { fetch(0); stage(0); }
     __syncthreads();
