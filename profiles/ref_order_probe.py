@@ -1,4 +1,4 @@
-"""Diagnostic: the product's NDT optimiser stepped by hand (mrgfe_dbg_ctl_*) on saved scenes (profiles/cases/*.npz); every request is evaluated by the GPU in
+"""Diagnostic: the product's NDT optimiser stepped by hand (mrgfe_dbg_ctl_*) on saved scenes (tests/golden/reforder_case_*.npz); every request is evaluated by the GPU in
 reference order AND by the reference-order oracle, compared bit for bit; the oracle's answer is fed back."""
 import sys, os, glob
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
@@ -11,7 +11,7 @@ from mrg_slam_amd.registration import default_params
 from oracle import oracle as orc
 _fp, _dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
 lib().mrgfe_dbg_set_ndt_reference_order(1)
-for f in sorted(glob.glob("profiles/cases/case_*.npz")):
+for f in sorted(glob.glob("tests/golden/reforder_case_*.npz")):
     z = np.load(f)
     tgt, src, guess, eps, res, search = z["tgt"], z["src"], z["guess"], float(z["eps"]), float(z["res"]), str(z["search"])
     g = NdtHip(resolution=res, transformation_epsilon=eps, maximum_iterations=64, search=search); o = orc.Ndt(resolution=res, num_threads=8, transformation_epsilon=eps, maximum_iterations=64, search=search)
