@@ -572,6 +572,11 @@ class NodeMatcher:
             self._keep = []
         return results_to_numpy(res, n)
 
+    def has_cloud(self, key: int):
+        """The BatchMatcher call surface (LoopDetector's matcher): a node cannot say which member will need a key before the pair list is complete, so the
+        caller always hands the cloud over — the member that gets the pair uploads it only when the key is not resident there with the same point count."""
+        return None
+
     def shard(self, member: int):
         a, b = C.c_int(0), C.c_int(0)
         check(lib().mrgfe_node_shard(self._h, member, C.byref(a), C.byref(b)))

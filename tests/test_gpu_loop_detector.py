@@ -71,3 +71,26 @@ def test_detect_batched_on_the_ring_session_equals_the_sequential_oracle():
     assert det_b.alignments > det_o.alignments
     assert det_b.loop_candidates_sizes == det_o.loop_candidates_sizes
     assert det_b.average_time_per_candidate_us() < det_o.average_time_per_candidate_us()
+
+
+def test_detect_batched_over_node_members_equals_one_batch():
+    """The same detect_batched with a NodeMatcher as the matcher (mrgfe_node_*: the pair list of the call cut into contiguous blocks over the members — one per
+    GPU on a real node, three sharing the card here): the superset batch and the consistency batch are sharded, the records gathered, and the Loop list with its
+    relative poses is bit for bit the one-batch detector's."""
+    from loop_session import make_ring_session, run_session
+    from mrg_slam_amd import BatchMatcher, NodeMatcher, prefilter
+    from mrg_slam_amd.loop_detector import LoopDetector
+
+    reg_kw = dict(resolution=1.0, transformation_epsilon=0.01, maximum_iterations=64)
+    pf = lambda c: prefilter(c, {"downsample_resolution": 0.2})  # noqa: E731
+    out = {}
+    for name in ("batch", "node"):
+        kfs, order = make_ring_session(64, "VLP64", prefilter=pf)
+        matcher = BatchMatcher(**reg_kw) if name == "batch" else NodeMatcher([0, 0, 0], **reg_kw)
+        det = LoopDetector(matcher=matcher)
+        out[name] = (run_session(det, kfs, order, group=6, batched=True), det)
+    a, b = out["batch"][0], out["node"][0]
+    assert len(a) >= 3 and [(lp.key1.id, lp.key2.id) for lp in a] == [(lp.key1.id, lp.key2.id) for lp in b]
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x.relative_pose, y.relative_pose)
+    assert out["batch"][1].alignments == out["node"][1].alignments
