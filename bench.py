@@ -1356,7 +1356,7 @@ def main():
                                                                                             np.array_equal(ro_t[1][1]["converged"], ro_t[0][1]["converged"])),
                                          "note": "MRGFE_NDT_REFERENCE_ORDER=1: per-point sums + point-order chains (computeDerivatives), pair-order chain (computeHessian), Eigen's "
                                                  "JacobiSVD solve; bit-identical to the reference-order oracle (tests/test_gpu_ndt_reforder.py, soak_over_bar.ndt_reference_order); the "
-                                                 "chains are one wavefront per evaluation whatever the batch size (~2 ms per 130k-point evaluation, ~35 ms per f64 Hessian pass)"}
+                                                 "chains are one wavefront per evaluation whatever the batch size (~1 ms per 130k-point evaluation, ~9 ms per f64 Hessian pass)"}
         # (4) BASELINE config[2]: GICP scan-to-keyframe (the k-NN correspondence path), keyframe = scan 0, frames = scans 1..6
         extras["config2_gicp"] = run_config2(ctx, scans, dev, poses, lib, args)
         # (4b) registration_method "NDT": pcl::NormalDistributionsTransform, the f64 formulation, on the headline's pairs

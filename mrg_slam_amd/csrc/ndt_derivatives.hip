@@ -769,17 +769,19 @@ __device__ __forceinline__ uint32_t ndt_point_neighbours(const NdtGridDev& g, bo
 // apart into every tile: a TLB miss per row and tile):
 //   mode 0 / 1:  tiles of kChainTile points;  rec[(tile * 44 + k) * kChainTile + i % kChainTile], k = 0 score, 1..6 gradient, 7..42 Hessian (mode 0 only),
 //                43 the point's neighbour count
-//   mode 2:      tiles of P = kChainSlots / NNB points = S = P * NNB slots;  rec[(tile * 38 + k) * S + (i % P) * NNB + j], k = 0 the pair's weight e, 1..36 the
-//                bracket of hess(a, b) — the j-th CONTRIBUTING pair of point i; cnt8[i] = how many there are; row 37 holds the neighbour count of point i at
-//                (i % P)
+//   mode 2:      tiles of P = ref_tile_points(NNB) points, S = P * NNB slots per row;  rec[(tile * 38 + k) * S + s], k = 0 the pair's weight e, 1..36 the bracket of
+//                hess(a, b); s = 0 .. tot - 1: the tile's CONTRIBUTING (point, voxel) pairs in (point, neighbourhood) order — the record kernel compacts them
+//                (a prefix over the P lanes of the tile), tot goes to the tile's header word (cnt workspace, one uint32 per tile); row 37 holds the neighbour
+//                count of point i at i % P
 constexpr int kChainTile = 128;   // points per tile (modes 0 / 1): two LDS buffers of 44 rows = 91 KB
-constexpr int kChainSlots = 126;  // record slots per tile (mode 2): 18 points x 7 / 4 x 27 / 126 x 1
+__host__ __device__ constexpr int ref_tile_points(int nnb) { return nnb == 7 ? 16 : (nnb == 1 ? 64 : 4); }  // 112 / 64 / 108 slots per row
 size_t ndt_ref_record_doubles(int mode, size_t n, int nnb)
 {
     if (mode != 2) return (n + kChainTile - 1) / kChainTile * size_t(kChainTile) * kNdtAccum;
-    const size_t P = static_cast<size_t>(kChainSlots / nnb);
+    const size_t P = static_cast<size_t>(ref_tile_points(nnb));
     return (n + P - 1) / P * (P * nnb) * 38;
 }
+
 template <int NNB>
 __global__ __launch_bounds__(256, 2) void ndt_ref_records_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs, const NdtEvalDev* __restrict__ evals,
                                                                   const NdtRefJob* __restrict__ jobs, double* __restrict__ rec_base, uint8_t* __restrict__ cnt_base)
@@ -793,13 +795,16 @@ __global__ __launch_bounds__(256, 2) void ndt_ref_records_kernel(const NdtGridDe
     if (threadIdx.x < 12) s_T[threadIdx.x] = ev.T[threadIdx.x];
     __syncthreads();
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= pr.n_src) return;
+    const bool     live = i < pr.n_src;
+    if (!live && job.mode != 2) return;  // (a lane past the end of a mode-2 job stays: its tile's lanes compact their pairs together)
     double* __restrict__ rec = rec_base + job.rec_off;
-    const float4 p = load_point(pr.src + i);
+    const float4 p = live ? load_point(pr.src + i) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float xt[3];
     transform_point(s_T, p.x, p.y, p.z, xt[0], xt[1], xt[2]);
     int32_t ids[NNB];
-    const uint32_t cnt = ndt_point_neighbours<NNB>(g, (NNB == 27) && (ev.search == MRGFE_KDTREE), xt, ids);
+#pragma unroll
+    for (int nb = 0; nb < NNB; ++nb) ids[nb] = -1;
+    const uint32_t cnt = live ? ndt_point_neighbours<NNB>(g, (NNB == 27) && (ev.search == MRGFE_KDTREE), xt, ids) : 0u;
     const float  gauss_d2f = static_cast<float>(ev.gauss_d2);
     const double gauss_d1 = ev.gauss_d1, gauss_d2 = ev.gauss_d2;
     if (job.mode != 2) {
@@ -852,10 +857,43 @@ __global__ __launch_bounds__(256, 2) void ndt_ref_records_kernel(const NdtGridDe
         return;
     }
     // ---- computeHessian (f64, PCL's 3x6 / 18x6 point derivative forms), per pair the bracket the reference multiplies by e_x_cov_x ------------
-    constexpr int kP = kChainSlots / NNB, kS = kP * NNB;
-    double* __restrict__ tile_rec = rec + (size_t)(i / kP) * (38 * kS) + (i % kP) * NNB;
+    constexpr int kP = ref_tile_points(NNB), kS = kP * NNB;
+    // the pair's weight, or false when the reference's range check drops the pair
+    auto weight = [&](uint32_t lid, double (&C)[9], double (&q)[3], double& e) -> bool {
+        const MRGFE_GLOBAL double* __restrict__ Cg = as_global(g.icov64 + (size_t)lid * 9);
+        const MRGFE_GLOBAL double* __restrict__ mean = as_global(g.leaves[lid].mean);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) C[t] = Cg[t];
+        q[0] = static_cast<double>(xt[0]) - mean[0]; q[1] = static_cast<double>(xt[1]) - mean[1]; q[2] = static_cast<double>(xt[2]) - mean[2];
+        double Cq[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Cq[r] = fdot3d(C[r * 3 + 0], q[0], C[r * 3 + 1], q[1], C[r * 3 + 2], q[2]);
+        e = gauss_d2 * glibc_exp(-gauss_d2 * fdot3d(q[0], Cq[0], q[1], Cq[1], q[2], Cq[2]) / 2);
+        if (e > 1 || e < 0 || e != e) return false;
+        e *= gauss_d1;
+        return true;
+    };
+    // pass 1: how many of the point's pairs contribute; then the tile's P lanes agree on where each point's pairs go (inclusive scan over the lane group)
     uint32_t used = 0;
-    if (cnt) {
+#pragma unroll 1
+    for (int nb = 0; nb < NNB; ++nb) {
+        if (ids[nb] < 0) continue;
+        double C[9], q[3], e;
+        used += weight(static_cast<uint32_t>(ids[nb]), C, q, e) ? 1u : 0u;
+    }
+    uint32_t incl = used;
+#pragma unroll
+    for (int d = 1; d < kP; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, kP);
+        if ((threadIdx.x & (kP - 1)) >= static_cast<uint32_t>(d)) incl += up;
+    }
+    const uint32_t off = incl - used, tot = __shfl(incl, kP - 1, kP);
+    double* __restrict__ tile_rec = rec + (size_t)(i / kP) * (38 * kS);
+    // (a tile whose first point lies past the end of the cloud does not exist: nothing of it is written; dead lanes of the last tile write nothing either)
+    if ((threadIdx.x & (kP - 1)) == 0 && live) reinterpret_cast<uint32_t*>(cnt_base + job.cnt_off)[i / kP] = tot;
+    if (live) tile_rec[37 * kS + (i % kP)] = static_cast<double>(cnt);
+    if (used) {
+        // pass 2: the brackets, written behind the pairs of the tile's earlier points
         const double x[3] = {p.x, p.y, p.z};
         double xjd[8], xhd[15];
 #pragma unroll
@@ -865,23 +903,13 @@ __global__ __launch_bounds__(256, 2) void ndt_ref_records_kernel(const NdtGridDe
         // J: 3 x 6, identity | columns 3..5;  PH(i, j), i, j >= 3: a b c / b d e / c e f
         const double J[3][6] = {{1, 0, 0, 0, xjd[2], xjd[5]}, {0, 1, 0, xjd[0], xjd[3], xjd[6]}, {0, 0, 1, xjd[1], xjd[4], xjd[7]}};
         const double PHd[6][3] = {{0, xhd[0], xhd[1]}, {0, xhd[2], xhd[3]}, {0, xhd[4], xhd[5]}, {xhd[6], xhd[7], xhd[8]}, {xhd[9], xhd[10], xhd[11]}, {xhd[12], xhd[13], xhd[14]}};
+        uint32_t slot = off;
 #pragma unroll 1
         for (int nb = 0; nb < NNB; ++nb) {
             if (ids[nb] < 0) continue;
-            const uint32_t lid = static_cast<uint32_t>(ids[nb]);
-            const MRGFE_GLOBAL double* __restrict__ Cg = as_global(g.icov64 + (size_t)lid * 9);
-            const MRGFE_GLOBAL double* __restrict__ mean = as_global(g.leaves[lid].mean);
-            double C[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) C[t] = Cg[t];
-            const double q[3] = {static_cast<double>(xt[0]) - mean[0], static_cast<double>(xt[1]) - mean[1], static_cast<double>(xt[2]) - mean[2]};
-            double Cq[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) Cq[r] = fdot3d(C[r * 3 + 0], q[0], C[r * 3 + 1], q[1], C[r * 3 + 2], q[2]);
-            double e = gauss_d2 * glibc_exp(-gauss_d2 * fdot3d(q[0], Cq[0], q[1], Cq[1], q[2], Cq[2]) / 2);
-            if (e > 1 || e < 0 || e != e) continue;
-            e *= gauss_d1;
-            tile_rec[used] = e;
+            double C[9], q[3], e;
+            if (!weight(static_cast<uint32_t>(ids[nb]), C, q, e)) continue;
+            tile_rec[slot] = e;
             double CJ[6][3];  // C * J(:, c)
 #pragma unroll
             for (int c = 0; c < 6; ++c)
@@ -905,85 +933,98 @@ __global__ __launch_bounds__(256, 2) void ndt_ref_records_kernel(const NdtGridDe
                         qCH = fdot3d(q[0], CH[0], q[1], CH[1], q[2], CH[2]);
                     }
                     const double jtcj = fdot3d(J[0][b], CJ[a][0], J[1][b], CJ[a][1], J[2][b], CJ[a][2]);
-                    tile_rec[(1 + a * 6 + b) * kS + used] = __builtin_fma(t0, qCJ[b], qCH) + jtcj;
+                    tile_rec[(1 + a * 6 + b) * kS + slot] = __builtin_fma(t0, qCJ[b], qCH) + jtcj;
                 }
             }
-            ++used;
+            ++slot;
         }
     }
-    cnt_base[job.cnt_off + i] = static_cast<uint8_t>(used);
-    rec[(size_t)(i / kP) * (38 * kS) + 37 * kS + (i % kP)] = static_cast<double>(cnt);
 }
 
-// One workgroup per job.  The additions of an accumulator are a chain, so ONE wavefront adds — lane k owns accumulator k — and what it must never do is wait
-// for memory on the chain (a load per step was 0.5 s per evaluation; a 16-deep register prefetch of the lane's own column, 44 cache lines per load
-// instruction, 14 ms).  So all four wavefronts fetch the next tile of records with coalesced loads (the records are tile-major: a tile is one contiguous
-// block) while wavefront 0 adds the current one out of LDS, where lane k walks row k (odd row length in 8-byte words: conflict-free), eight values into
-// registers ahead of their additions.  The f64 Hessian's records come per (point, slot) with 0..NNB used slots per point: the staging step compacts them
-// (a prefix over the tile's counts), so its chain is the same streaming loop with a fused multiply-add in place of the add.
+// One workgroup of eight wavefronts per job.  The additions of an accumulator are a chain, so ONE wavefront adds — wavefront 0, lane k owns accumulator k —
+// and it does nothing else: what it must never do is wait for memory or spend issue slots on address arithmetic (a load per step on the chain was 0.5 s per
+// evaluation; a 16-deep register prefetch of the lane's own column, 44 cache lines per load instruction, 14 ms; four wavefronts that all fetched, staged AND —
+// the first of them — added, 1.7 ms per 130k points: the adding wavefront spent two thirds of a tile on its share of the copying).  The other seven wavefronts
+// feed it: coalesced loads of the tile-major records TWO tiles ahead (two register sets, offsets computed once), staged into the LDS buffer the adder is not
+// reading.  Lane k walks row k of the buffer (odd row length in 8-byte words: conflict-free), eight values into registers ahead of their additions.
+constexpr int kChainThreads = 512, kFeeders = kChainThreads - 64;
 template <bool WEIGHTED>
 __device__ __forceinline__ double ref_chain_row(double acc, const double* __restrict__ row, const double* __restrict__ wrow, int count8)
 {
-    // `count8` (a multiple of eight) values of row (and their weights) in order, eight LDS reads ahead of their eight dependent operations.  No predicate on the
-    // chain: what lies past the real count is zero (+0 terms, or 0 * 0 under the fused multiply-add: both leave a sum that is never -0 unchanged).
+    // `count8` (a multiple of eight) values of row (and their weights) in order: eight LDS reads, then the eight dependent operations.  No predicate on the
+    // chain: what lies past the real count is zero (+0 terms, or 0 * 0 under the fused multiply-add: both leave a sum that is never -0 unchanged).  Sixteen-byte
+    // reads with the next group in flight behind the additions (two or four register sets) were measured: 18 ms per alignment against 14 ms for this.
 #pragma unroll 2
     for (int h = 0; h < count8; h += 8) {
         double v[8], w[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { v[j] = row[h + j]; if (WEIGHTED) w[j] = wrow[h + j]; }
+        for (int j = 0; j < 8; ++j) {
+            v[j] = row[h + j];
+            if (WEIGHTED) w[j] = wrow[h + j];
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc = WEIGHTED ? __builtin_fma(w[j], v[j], acc) : acc + v[j];
     }
     return acc;
 }
 
-__global__ __launch_bounds__(256) void ndt_ref_chain01_kernel(const NdtPairDev* __restrict__ pairs, const NdtRefJob* __restrict__ jobs, const double* __restrict__ rec_base,
-                                                               double* __restrict__ results)
+__global__ __launch_bounds__(kChainThreads) void ndt_ref_chain01_kernel(const NdtPairDev* __restrict__ pairs, const NdtRefJob* __restrict__ jobs, const double* __restrict__ rec_base,
+                                                                         double* __restrict__ results)
 {
-    constexpr int T = kChainTile, kRow = T + 1;
-    constexpr int kPer = (kNdtAccum * T + 255) / 256;  // 22 elements of a tile per thread
+    constexpr int T = kChainTile, kRow = T + 1;  // (odd row length in 8-byte words: the lanes' rows start in different banks)
+    static_assert(T % 8 == 0, "tile");
+    constexpr int kPer = (kNdtAccum * T + kFeeders - 1) / kFeeders;  // 13 elements of a tile per feeder thread
     __shared__ double s_v[2][kNdtAccum * kRow];
     const NdtRefJob job = jobs[blockIdx.x];
     if (job.mode == 2) return;  // (the f64 Hessian jobs of the round: ndt_ref_chain2_kernel)
     const uint32_t n = pairs[job.pair].n_src;
     const MRGFE_GLOBAL double* __restrict__ rec = as_global(rec_base + job.rec_off);
-    const int tid = threadIdx.x;  // (a lane of wavefront 0 owns accumulator tid)
+    const int  tid = threadIdx.x, f = tid - 64;  // f >= 0: a feeder
+    const bool adder = tid < 64;
     // columns this kind delivers: mode 0 all 44 (score, gradient, Hessian, count), mode 1 score + gradient + count (its rows 0..7 = columns 0..6, 43)
     const int      n_cols = job.mode == 0 ? kNdtAccum : 8;
     const uint32_t n_tiles = (n + T - 1) / T;
-    // element e of a tile = (row c, position j); what a thread fetches is fixed over the tiles
-    int  lds_at[kPer];
-    uint32_t g_at[kPer];
-    bool mine[kPer];
+    // what a feeder fetches is the same in every tile: element e = (row c, position j) -> offset in the tile's block / in the LDS buffer
+    int  goff[kPer], loff[kPer], jpos[kPer];
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
-        const int e = tid + u * 256, c = e / T, j = e % T;
-        mine[u] = c < n_cols;
-        lds_at[u] = c * kRow + j;
-        g_at[u] = static_cast<uint32_t>(((job.mode == 0) ? c : (c < 7 ? c : kNdtNbIndex)) * T + j);
+        const int e = f + u * kFeeders, c = e / T, j = e % T;
+        const bool mine = !adder && c < n_cols;
+        goff[u] = mine ? ((job.mode == 0) ? c : (c < 7 ? c : kNdtNbIndex)) * T + j : -1;
+        loff[u] = c * kRow + j;
+        jpos[u] = j;
     }
-    double pre[kPer];
+    double pa[kPer], pb[kPer];
     double acc = 0.0;
-    // (a tile past the end of the cloud is padding the record kernel never wrote: its last tile is cut to the points that exist — a padded position reads
-    // +0, which is exact to add: the sums start at +0 and are never -0)
-    auto fetch = [&](uint32_t tile) {
+    // A position past the end of the cloud is padding the record kernel never wrote: it reads +0, which is exact to add (the sums start at +0, never -0)
+    auto fetch = [&](uint32_t tile, double (&pre)[kPer]) {
+        if (tile >= n_tiles) return;
         const MRGFE_GLOBAL double* __restrict__ t0 = rec + (size_t)tile * (kNdtAccum * T);
+        const uint32_t left = n - tile * T;  // points of this tile that exist (>= T except in the last one)
 #pragma unroll
-        for (int u = 0; u < kPer; ++u) pre[u] = (mine[u] && tile * T + (g_at[u] % T) < n) ? t0[g_at[u]] : 0.0;
+        for (int u = 0; u < kPer; ++u) pre[u] = (goff[u] >= 0 && static_cast<uint32_t>(jpos[u]) < left) ? t0[goff[u]] : 0.0;
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int buf, const double (&pre)[kPer]) {
 #pragma unroll
         for (int u = 0; u < kPer; ++u)
-            if (mine[u]) s_v[buf][lds_at[u]] = pre[u];
+            if (goff[u] >= 0) s_v[buf][loff[u]] = pre[u];
     };
-    if (n_tiles) { fetch(0); stage(0); }
-    __syncthreads();
-    for (uint32_t tile = 0; tile < n_tiles; ++tile) {
+    // LDS holds `tile`; `next` holds tile + 1 (fetched a whole step ago); `after` receives tile + 2
+    auto step = [&](uint32_t tile, const double (&next)[kPer], double (&after)[kPer]) {
         const int buf = static_cast<int>(tile & 1u);
-        if (tile + 1 < n_tiles) fetch(tile + 1);  // in flight while wavefront 0 adds
-        if (tid < n_cols) acc = ref_chain_row<false>(acc, &s_v[buf][tid * kRow], nullptr, T);
-        if (tile + 1 < n_tiles) stage(buf ^ 1);
+        if (adder) {
+            if (tid < n_cols) acc = ref_chain_row<false>(acc, &s_v[buf][tid * kRow], nullptr, T);
+        } else {
+            fetch(tile + 2, after);
+            if (tile + 1 < n_tiles) stage(buf ^ 1, next);
+        }
         __syncthreads();
+    };
+    if (!adder) { fetch(0, pa); stage(0, pa); fetch(1, pa); }
+    __syncthreads();
+    for (uint32_t tile = 0; tile < n_tiles; tile += 2) {
+        step(tile, pa, pb);
+        if (tile + 1 < n_tiles) step(tile + 1, pb, pa);
     }
     // the record of ndt_reduce_kernel<false>: score, gradient, Hessian (row-major), neighbour count at slot 43 (mode 1 carries it in its eighth row)
     if (tid < kNdtPartialStride) {
@@ -1000,75 +1041,77 @@ __global__ __launch_bounds__(256) void ndt_ref_chain01_kernel(const NdtPairDev* 
 
 // hess(a, b) = fma(e, bracket, hess(a, b)) over the contributing pairs, point after point; lanes 0..35 = entry a * 6 + b, lane 36 the neighbour count
 template <int NNB>
-__global__ __launch_bounds__(256) void ndt_ref_chain2_kernel(const NdtPairDev* __restrict__ pairs, const NdtRefJob* __restrict__ jobs, const double* __restrict__ rec_base,
-                                                              const uint8_t* __restrict__ cnt_base, double* __restrict__ results)
+__global__ __launch_bounds__(kChainThreads) void ndt_ref_chain2_kernel(const NdtPairDev* __restrict__ pairs, const NdtRefJob* __restrict__ jobs, const double* __restrict__ rec_base,
+                                                                        const uint8_t* __restrict__ cnt_base, double* __restrict__ results)
 {
-    constexpr int P = kChainSlots / NNB, S = P * NNB, kRow = 137;  // (rows are read in whole groups of eight: S <= 128 entries + 8 of padding, odd length)
-    constexpr int kPer = (38 * S + 255) / 256;
-    static_assert(P >= 1 && P <= 128 && S <= 128, "tile");
+    constexpr int P = ref_tile_points(NNB), S = P * NNB, kRow = (S + 8) | 1;  // rows are read in whole groups of eight; odd length
+    constexpr int kPer = (38 * S + kFeeders - 1) / kFeeders;
     __shared__ double   s_v[2][38 * kRow];
-    __shared__ uint32_t s_cnt[2][128], s_off[2][128], s_tot[2];
+    __shared__ uint32_t s_tot[2];
     const NdtRefJob job = jobs[blockIdx.x];
     if (job.mode != 2) return;
     const uint32_t n = pairs[job.pair].n_src;
     const MRGFE_GLOBAL double* __restrict__ rec = as_global(rec_base + job.rec_off);
-    const MRGFE_GLOBAL uint8_t* __restrict__ cnt = as_global(cnt_base + job.cnt_off);
-    const int tid = threadIdx.x;
+    const MRGFE_GLOBAL uint32_t* __restrict__ tile_tot = as_global(reinterpret_cast<const uint32_t*>(cnt_base + job.cnt_off));
+    const int  tid = threadIdx.x, f = tid - 64;
+    const bool adder = tid < 64;
     const uint32_t n_tiles = (n + P - 1) / P;
-    int row_of[kPer], pt_of[kPer], jj_of[kPer];
+    // element e of a tile's block = (row c, slot j); rows 0..36: the tile's compacted pairs (what lies behind them was never written: zeros are staged
+    // there up to the next multiple of eight); row 37: one neighbour count per point
+    int goff[kPer], loff[kPer], jpos[kPer], rowk[kPer];
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
-        const int e = tid + u * 256, c = e / S, j = e % S;
-        row_of[u] = c < 38 ? c : -1;
-        pt_of[u] = c == 37 ? j : j / NNB;  // row 37: the neighbour count of point j of the tile (j < P)
-        jj_of[u] = j % NNB;
-        if (c == 37 && j >= P) row_of[u] = -1;
+        const int e = f + u * kFeeders, c = e / S, j = e % S;
+        goff[u] = (!adder && c < 38) ? e : -1;
+        loff[u] = c * kRow + j;
+        jpos[u] = j;
+        rowk[u] = c;
     }
-    double   pre[kPer];
-    uint32_t pre_c = 0;
+    double   pa[kPer], pb[kPer];
+    uint32_t ta = 0, tb = 0;
     double   acc = 0.0;
-    auto fetch = [&](uint32_t tile) {
+    auto fetch = [&](uint32_t tile, double (&pre)[kPer], uint32_t& tot) {
+        tot = 0;
+        if (tile >= n_tiles) return;
         const MRGFE_GLOBAL double* __restrict__ t0 = rec + (size_t)tile * (38 * S);
+        tot = tile_tot[tile];  // (every feeder reads the same word: it bounds what it fetches)
+        const uint32_t left = n - tile * P;
+        // predicated loads: most of a tile's S slots per row lie behind its pairs and were never written (loading all of them and selecting afterwards
+        // was measured: 17.6 ms per alignment against 14.2 ms)
 #pragma unroll
         for (int u = 0; u < kPer; ++u) {
-            // rows 0..36: the tile's slots (unused ones hold whatever the workspace held: dropped at staging); row 37: per point, +0 past the end of the cloud
-            const int e = tid + u * 256;
-            const bool want = row_of[u] >= 0 && (row_of[u] < 37 || tile * P + pt_of[u] < n);
-            pre[u] = want ? t0[e] : 0.0;
+            const bool want = goff[u] >= 0 && (rowk[u] < 37 ? static_cast<uint32_t>(jpos[u]) < tot : (jpos[u] < P && static_cast<uint32_t>(jpos[u]) < left));
+            pre[u] = want ? t0[goff[u]] : 0.0;
         }
-        pre_c = (tid < P && tile * P + tid < n) ? cnt[tile * P + tid] : 0u;
     };
-    auto stage = [&](int buf) {  // all threads; compacts the used slots of the tile's points
-        if (tid < P) s_cnt[buf][tid] = pre_c;
-        __syncthreads();
-        if (tid < P) {
-            uint32_t o = 0;
-            for (int v = 0; v < tid; ++v) o += s_cnt[buf][v];
-            s_off[buf][tid] = o;
-            if (tid == P - 1) s_tot[buf] = o + pre_c;
-        }
-        __syncthreads();
+    auto stage = [&](int buf, const double (&pre)[kPer], uint32_t tot) {
+        const uint32_t tot8 = (tot + 7u) & ~7u;
 #pragma unroll
         for (int u = 0; u < kPer; ++u) {
-            if (row_of[u] < 0) continue;
-            if (row_of[u] == 37) s_v[buf][37 * kRow + pt_of[u]] = pre[u];
-            else if (static_cast<uint32_t>(jj_of[u]) < s_cnt[buf][pt_of[u]]) s_v[buf][row_of[u] * kRow + s_off[buf][pt_of[u]] + jj_of[u]] = pre[u];
+            // everything up to the next multiple of eight behind the pairs is written (the zeros fetch left there): the adder reads whole groups
+            if (goff[u] >= 0 && (rowk[u] < 37 ? static_cast<uint32_t>(jpos[u]) < tot8 : jpos[u] < ((P + 7) & ~7))) s_v[buf][loff[u]] = pre[u];
         }
-        // zeros behind the compacted entries up to the next multiple of eight (the chain reads whole groups), and behind the P neighbour counts of row 37
-        for (int t = tid; t < 38 * 8; t += 256) {  // (304 entries, 256 threads)
-            if (t < 37 * 8) s_v[buf][(t / 8) * kRow + s_tot[buf] + t % 8] = 0.0;
-            else            s_v[buf][37 * kRow + P + t % 8] = 0.0;
+        if (S % 8 != 0) {  // a row length that is no multiple of eight: the last group runs past the S fetched entries
+            for (int t = f; t < 38 * 8; t += kFeeders) s_v[buf][(t / 8) * kRow + S + t % 8] = 0.0;
         }
+        if (f == 0) s_tot[buf] = tot;
     };
-    if (n_tiles) { fetch(0); stage(0); }
-    __syncthreads();
-    for (uint32_t tile = 0; tile < n_tiles; ++tile) {
+    auto step = [&](uint32_t tile, const double (&next)[kPer], uint32_t next_tot, double (&after)[kPer], uint32_t& after_tot) {
         const int buf = static_cast<int>(tile & 1u);
-        if (tile + 1 < n_tiles) fetch(tile + 1);
-        if (tid < 36)       acc = ref_chain_row<true>(acc, &s_v[buf][(1 + tid) * kRow], &s_v[buf][0], (static_cast<int>(s_tot[buf]) + 7) & ~7);
-        else if (tid == 36) acc = ref_chain_row<false>(acc, &s_v[buf][37 * kRow], nullptr, (P + 7) & ~7);  // neighbour counts (integers: exact)
-        if (tile + 1 < n_tiles) stage(buf ^ 1);  // (uniform condition: the barriers inside are reached by all or none)
+        if (adder) {
+            if (tid < 36)       acc = ref_chain_row<true>(acc, &s_v[buf][(1 + tid) * kRow], &s_v[buf][0], static_cast<int>((s_tot[buf] + 7u) & ~7u));
+            else if (tid == 36) acc = ref_chain_row<false>(acc, &s_v[buf][37 * kRow], nullptr, (P + 7) & ~7);  // neighbour counts (integers: exact)
+        } else {
+            fetch(tile + 2, after, after_tot);
+            if (tile + 1 < n_tiles) stage(buf ^ 1, next, next_tot);
+        }
         __syncthreads();
+    };
+    if (!adder) { fetch(0, pa, ta); stage(0, pa, ta); fetch(1, pa, ta); }
+    __syncthreads();
+    for (uint32_t tile = 0; tile < n_tiles; tile += 2) {
+        step(tile, pa, ta, pb, tb);
+        if (tile + 1 < n_tiles) step(tile + 1, pb, tb, pa, ta);
     }
     if (tid < kNdtPartialStride) results[(size_t)job.pair * kNdtPartialStride + tid] = 0.0;  // (score / gradient slots: this kind delivers none)
     __syncthreads();
@@ -1085,11 +1128,11 @@ int ndt_launch_ref_round(mrgfe_ctx* ctx, int search, const NdtGridDev* d_grids, 
     else if (search == MRGFE_DIRECT1) hipLaunchKernelGGL((ndt_ref_records_kernel<1>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_jobs, d_rec, d_cnt);
     else                              hipLaunchKernelGGL((ndt_ref_records_kernel<27>), grid, dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_jobs, d_rec, d_cnt);
     // a workgroup per job in both chain kernels; a job of the other kind returns at once
-    if (any_mode01) hipLaunchKernelGGL(ndt_ref_chain01_kernel, dim3(n_jobs), dim3(256), 0, ctx->stream, d_pairs, d_jobs, d_rec, results);
+    if (any_mode01) hipLaunchKernelGGL(ndt_ref_chain01_kernel, dim3(n_jobs), dim3(kChainThreads), 0, ctx->stream, d_pairs, d_jobs, d_rec, results);
     if (any_mode2) {
-        if (search == MRGFE_DIRECT7)      hipLaunchKernelGGL((ndt_ref_chain2_kernel<7>), dim3(n_jobs), dim3(256), 0, ctx->stream, d_pairs, d_jobs, d_rec, d_cnt, results);
-        else if (search == MRGFE_DIRECT1) hipLaunchKernelGGL((ndt_ref_chain2_kernel<1>), dim3(n_jobs), dim3(256), 0, ctx->stream, d_pairs, d_jobs, d_rec, d_cnt, results);
-        else                              hipLaunchKernelGGL((ndt_ref_chain2_kernel<27>), dim3(n_jobs), dim3(256), 0, ctx->stream, d_pairs, d_jobs, d_rec, d_cnt, results);
+        if (search == MRGFE_DIRECT7)      hipLaunchKernelGGL((ndt_ref_chain2_kernel<7>), dim3(n_jobs), dim3(kChainThreads), 0, ctx->stream, d_pairs, d_jobs, d_rec, d_cnt, results);
+        else if (search == MRGFE_DIRECT1) hipLaunchKernelGGL((ndt_ref_chain2_kernel<1>), dim3(n_jobs), dim3(kChainThreads), 0, ctx->stream, d_pairs, d_jobs, d_rec, d_cnt, results);
+        else                              hipLaunchKernelGGL((ndt_ref_chain2_kernel<27>), dim3(n_jobs), dim3(kChainThreads), 0, ctx->stream, d_pairs, d_jobs, d_rec, d_cnt, results);
     }
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
