@@ -311,7 +311,12 @@ def main():
             summary["soak"].update({"pcl_ndt_over_bar": f"{c['over_bar']}/{c['cases']}", "pcl_ndt_bit_identical_to_reference_order_oracle": f"{c['exact']}/{c['cases']}", "pcl_ndt_worst": c["worst"],
                                     "pcl_ndt_flag_iteration_or_evaluation_mismatch": c["flag_or_iteration_mismatch"] + c["evaluation_count_mismatch"],
                                     "pcl_ndt_scenes_that_stop_after_one_iteration": f"{c['one_iteration']}/{c['cases']}"})
-        lines += ["", f"## parity soak (`python3 profiles/soak.py 2000 600`, profiles/{tag}_soak.json)", "", "```json", json.dumps(summary["soak"], indent=1), "```"]
+        if "ndt_reference_order" in sj:  # NDT_HIP with MRGFE_NDT_REFERENCE_ORDER=1 against the reference-order oracle (round 6)
+            c = sj["ndt_reference_order"]
+            summary["soak"].update({"ndt_reference_order_over_bar": f"{c['over_bar']}/{c['cases']}", "ndt_reference_order_bit_identical_to_reference_order_oracle": f"{c['exact']}/{c['cases']}",
+                                    "ndt_reference_order_worst": c["worst"], "ndt_reference_order_flag_or_iteration_mismatch": c["flag_or_iteration_mismatch"],
+                                    "ndt_reference_order_scenes_that_do_not_settle": f"{c['unsettled']}/{c['cases']}"})
+        lines += ["", f"## parity soak (`python3 profiles/soak.py 3000 900 500 2000`, profiles/{tag}_soak.json)", "", "```json", json.dumps(summary["soak"], indent=1), "```"]
     for part in ("trace", "pmc"):
         f = os.path.join(OUT, f"collected_rev_{part}.txt")
         if os.path.exists(f):
