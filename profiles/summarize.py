@@ -109,9 +109,13 @@ def main():
             lines.append(f"| 256 | {b['value']:.0f} | {b['ms_per_step']:.3f} |")
         lines += ["", "## bench.py line of the same build (`python bench.py`)", "", "```json", json.dumps(b, indent=1), "```"]
         if dom:
-            ev = b["roofline"]["avg_launch_ms"]
-            lines += ["", f"Agreement check: HIP-event average of `{DOMINANT}` inside bench.py = {ev * 1e3:.2f} us over {b['roofline']['launches']} timed launches; "
-                          f"rocprofv3 average = {float(dom['AverageNs']) / 1e3:.2f} us over {dom['Calls']} launches (warm-up included)."]
+            # the trace is of steps run one at a time (--in-flight 1): it is held against the HIP events of the line's own one-step-at-a-time leg, not against the
+            # timed region's (two batches in flight: a launch shares the chip and its event pair spans both)
+            one = b["roofline"].get("one_step_at_a_time") or b["roofline"]
+            ev = one["avg_launch_ms"]
+            lines += ["", f"Agreement check: HIP-event average of `{DOMINANT}` inside bench.py, steps one at a time = {ev * 1e3:.2f} us over {one.get('launches', b['roofline']['launches'])} launches; "
+                          f"rocprofv3 average of the traced run (same shape) = {float(dom['AverageNs']) / 1e3:.2f} us over {dom['Calls']} launches (warm-up included); in the timed region "
+                          f"(two batches in flight) the event pairs average {b['roofline']['avg_launch_ms'] * 1e3:.2f} us."]
     for kind in ("soak_filters", "soak_misc", "loop_parity_seeds", "config2_parity", "config1_parity_ranks", "ndt_fullsize_sweep"):  # profiles/soak_filters.py, soak_misc.py: the rows around the alignment against the oracle
         sf = os.path.join(OUT, f"{kind}_{tag}.json")
         if os.path.exists(sf) and open(sf).read().strip().startswith("{"):
