@@ -2125,6 +2125,23 @@ __device__ __forceinline__ uint32_t nn_knn_query(const NnGrid2Dev& g, const floa
                     if (cnt == k) { kth_d = wave_read(td, k - 1); kth_i = wave_read(ti, k - 1); }
                 }
             };
+            // the candidates of up to 64 ranges of lv.sorted, lane j holding range [qb, qb + ql): consumed as ONE list, 64 candidates a step whatever the
+            // range lengths (a ring's ranges hold a handful of points each where a query has to look that far: a step per range measured ~30 extra
+            // candidates per query for a third of the kernel's time).  Candidate v of the list lies in the LAST range j whose exclusive prefix is
+            // <= v: six cross-lane probes.
+            auto consume_ranges = [&](uint32_t qb, uint32_t ql) {
+                const uint32_t incl = wave_inclusive_scan(ql), excl = incl - ql;
+                const uint32_t total = wave_read(incl, kWave - 1);
+                for (uint32_t base = 0; base < total; base += 64u) {
+                    const uint32_t v = base + lane;
+                    int            j = 0;
+#pragma unroll
+                    for (int s = 32; s > 0; s >>= 1)
+                        if (__shfl(excl, j + s) <= v) j += s;
+                    const uint32_t at = __shfl(qb, j) + (v - __shfl(excl, j));
+                    step(v < total, v < total ? lv.sorted[at] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                }
+            };
             const double margin = nn_face_margin(lv, c, p.x, p.y, p.z);
             int          first_ring = 0;
             if (last_ring >= 1) {
@@ -2192,11 +2209,7 @@ __device__ __forceinline__ uint32_t nn_knn_query(const NnGrid2Dev& g, const floa
                             ql = lv.cell_start[row + x1 + 1] - qb;
                         }
                     }
-                    for (int r = 0; r < 34; ++r) {
-                        const uint32_t rb2 = wave_read(qb, r), rl2 = wave_read(ql, r);
-                        for (uint32_t base = 0; base < rl2; base += 64u)
-                            step(base + lane < rl2, base + lane < rl2 ? lv.sorted[rb2 + base + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-                    }
+                    consume_ranges(qb, ql);
                     first_ring = 3;
                 }
             }
@@ -2233,13 +2246,7 @@ __device__ __forceinline__ uint32_t nn_knn_query(const NnGrid2Dev& g, const floa
                             }
                         }
                     }
-                    uint64_t some = __ballot(qe > qb);
-                    while (some) {
-                        const int src = __ffsll(static_cast<unsigned long long>(some)) - 1;
-                        some &= some - 1;
-                        const uint32_t b = wave_read(qb, src), e = wave_read(qe, src);
-                        for (uint32_t base = b; base < e; base += 64u) step(base + lane < e, base + lane < e ? lv.sorted[base + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-                    }
+                    if (__ballot(qe > qb)) consume_ranges(qb, qe - qb);
                 }
             }
             // conclusive iff everything beyond the walked rings is farther than the k-th entry (or the level is exhausted)
