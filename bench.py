@@ -317,7 +317,9 @@ def compact_line(full: dict) -> dict:
         for m in ("GICP_HIP", "SMALL_GICP_HIP"):
             if isinstance(c2.get(m), dict):
                 e = c2[m]
-                out["config2_gicp"][m] = {"frame_ms": e.get("frame_ms"), "batch32_ms": (e.get("batch_32_candidates") or {}).get("ms_per_call"),
+                out["config2_gicp"][m] = {"frame_ms": e.get("frame_ms"), "frame_ms_1m_from_keyframe": (e.get("frame_ms_by_displacement_m") or {}).get("1"),
+                                          "keyframe_every_metre_ms": (e.get("keyframe_every_metre") or {}).get("frame_ms"),
+                                          "batch32_ms": (e.get("batch_32_candidates") or {}).get("ms_per_call"),
                                           "frames_over_bar": (e.get("parity_vs_oracle") or {}).get("frames_over_bar"),
                                           "knn_frac": (e.get("roofline_knn") or {}).get("frac"), "linearize_frac": (e.get("roofline_linearize") or {}).get("frac")}
     for k in ("records_sha256_16", "raw_inputs_as_in_the_build_container"):
@@ -366,7 +368,7 @@ def run_config2(ctx, scans, dev, poses, lib, args):
     from mrg_slam_amd import GicpHip, SmallGicpHip, synth
     from oracle import oracle as orc
 
-    out = {"workload": f"keyframe = scan 0 ({len(scans[0])} points), frames = scans 1..6, guess = perturbed true motion (seed 777+k), max_correspondence_distance 2.0, "
+    out = {"workload": f"keyframe = scan 0 ({len(scans[0])} points), frames = scans 1..6 (1 .. 6 m from the keyframe), guess = perturbed true motion (seed 5000+k), max_correspondence_distance 2.0, "
                        f"k = 20, eps {args.eps}, clouds resident in HBM"}
     frames = list(range(1, min(7, len(scans))))
     rels = {k: synth.rel_pose(poses[0], poses[k]) for k in frames}
@@ -419,6 +421,34 @@ def run_config2(ctx, scans, dev, poses, lib, args):
                                       "achieved": lin_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": lin_gbps / HBM_PEAK_GBPS, "traffic": None, "launches": int(lin[1]),
                                       "avg_launch_ms": lin[0] / lin[1] if lin[1] else None,
                                       "byte_model": "N_src * (16 + 48 + 27*8) + correspondences * (16 + 48) per linearisation (SURVEY.md §8d)"}}
+        # frame time against the displacement from the keyframe (the correspondence search of a frame a few metres from its keyframe walks the occupancy pyramid
+        # for the ground rings that fall between the keyframe's: profiles/gicp_corr_modes.py), and SURVEY.md §8(d)'s own shape of this config — a keyframe every
+        # metre on the 1 m / scan trajectory: frame k against keyframe k - 1, the keyframe's setInputTarget (grid + k = 20 covariances) inside the time
+        by_k = {k: [] for k in frames}
+        for rep in range(3):
+            for k in frames:
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                reg.setInputSourceDevice(dev[k].data_ptr(), len(scans[k]))
+                reg.align(guesses[k])
+                by_k[k].append(1e3 * (time.perf_counter() - t0))
+        rec["frame_ms_by_displacement_m"] = {str(k): float(np.median(v[1:])) for k, v in by_k.items()}
+        t_kf = []
+        for rep in range(3):
+            for k in frames:
+                g_k = synth.warm_guess(synth.rel_pose(poses[k - 1], poses[k]), 6000 + k)
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                reg.setInputTargetDevice(dev[k - 1].data_ptr(), len(scans[k - 1]))
+                reg.setInputSourceDevice(dev[k].data_ptr(), len(scans[k]))
+                reg.align(g_k)
+                if rep:
+                    t_kf.append(1e3 * (time.perf_counter() - t0))
+        rec["keyframe_every_metre"] = {"frame_ms": float(np.median(t_kf)), "frames_timed": len(t_kf),
+                                       "note": "SURVEY.md §8(d) C3: frame k against keyframe k - 1 (1 m apart), setInputTarget of the keyframe + setInputSource + align per frame"}
+        reg.setInputTargetDevice(dev[0].data_ptr(), len(scans[0]))  # back to keyframe 0 for the legs below
+        reg.setInputSourceDevice(dev[frames[0]].data_ptr(), len(scans[frames[0]]))
+        reg.align(guesses[frames[0]])
         # the same frames from loop-closure-sized guesses: several outer iterations per alignment (the warm frames above converge in one)
         far = {}
         t_far = []
