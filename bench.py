@@ -433,19 +433,30 @@ def run_config2(ctx, scans, dev, poses, lib, args):
                 reg.align(guesses[k])
                 by_k[k].append(1e3 * (time.perf_counter() - t0))
         rec["frame_ms_by_displacement_m"] = {str(k): float(np.median(v[1:])) for k, v in by_k.items()}
-        t_kf = []
-        for rep in range(3):
-            for k in frames:
-                g_k = synth.warm_guess(synth.rel_pose(poses[k - 1], poses[k]), 6000 + k)
-                ctx.synchronize()
-                t0 = time.perf_counter()
-                reg.setInputTargetDevice(dev[k - 1].data_ptr(), len(scans[k - 1]))
-                reg.setInputSourceDevice(dev[k].data_ptr(), len(scans[k]))
-                reg.align(g_k)
-                if rep:
-                    t_kf.append(1e3 * (time.perf_counter() - t0))
-        rec["keyframe_every_metre"] = {"frame_ms": float(np.median(t_kf)), "frames_timed": len(t_kf),
-                                       "note": "SURVEY.md §8(d) C3: frame k against keyframe k - 1 (1 m apart), setInputTarget of the keyframe + setInputSource + align per frame"}
+        kf = {}
+        for mode in ("set_input_target", "source_becomes_target"):  # the keyframe handed over again / taken over from the source (mrgfe_reg_source_becomes_target: what the PCL adapter does)
+            reg.setInputTargetDevice(dev[0].data_ptr(), len(scans[0]))
+            t_kf, fin = [], []
+            for rep in range(3):
+                for k in frames:
+                    g_k = synth.warm_guess(synth.rel_pose(poses[k - 1], poses[k]), 6000 + k)
+                    ctx.synchronize()
+                    t0 = time.perf_counter()
+                    reg.setInputSourceDevice(dev[k].data_ptr(), len(scans[k]))
+                    reg.align(g_k)
+                    if mode == "set_input_target":
+                        reg.setInputTargetDevice(dev[k].data_ptr(), len(scans[k]))  # (prepared by the next align: the steady loop's median holds it)
+                    else:
+                        reg.sourceBecomesTarget()
+                    if rep:
+                        t_kf.append(1e3 * (time.perf_counter() - t0))
+                    fin.append(reg.getFinalTransformation().copy())
+                reg.setInputTargetDevice(dev[0].data_ptr(), len(scans[0]))
+            kf[mode] = (float(np.median(t_kf)), np.stack(fin))
+        rec["keyframe_every_metre"] = {"frame_ms": kf["source_becomes_target"][0], "frame_ms_keyframe_handed_over_again": kf["set_input_target"][0], "frames_timed": len(t_kf),
+                                       "same_transformations": bool(np.array_equal(kf["set_input_target"][1], kf["source_becomes_target"][1])),
+                                       "note": "SURVEY.md §8(d) C3: frame k against keyframe k - 1 (1 m apart): setInputSource + align, then the frame becomes the keyframe "
+                                               "(scan_matching_odometry_component.cpp:326-339) — taken over from the source with its covariances and grid, or handed over again"}
         reg.setInputTargetDevice(dev[0].data_ptr(), len(scans[0]))  # back to keyframe 0 for the legs below
         reg.setInputSourceDevice(dev[frames[0]].data_ptr(), len(scans[frames[0]]))
         reg.align(guesses[frames[0]])

@@ -171,6 +171,10 @@ int  mrgfe_reg_set_source(mrgfe_reg* reg, const float* xyzi, size_t n, size_t st
 /* same, from packed float4 clouds already resident in device memory (zero-copy ingest; bench.py's timed region) */
 int  mrgfe_reg_set_target_device(mrgfe_reg* reg, const void* d_xyzi, size_t n);
 int  mrgfe_reg_set_source_device(mrgfe_reg* reg, const void* d_xyzi, size_t n);
+/* replaces registration_->setInputTarget(keyframe) where the keyframe IS the cloud last given to set_source (the odometry's keyframe update,
+ * scan_matching_odometry_component.cpp:326-339 -> :333): same result as set_target of that cloud, without uploading it again and, for the GICP
+ * family, without recomputing its k-NN covariances and search grid (they were made when it was the source).  The source stays set. */
+int  mrgfe_reg_source_becomes_target(mrgfe_reg* reg);
 /* replaces registration_->align(*aligned, guess): scan_matching_odometry_component.cpp:265-266; loop_detector.cpp:134,236,279.
  * `aligned_xyzi` (n_source packed float4, may be NULL) receives final_transformation * source. */
 int  mrgfe_reg_align(mrgfe_reg* reg, const float guess[16], float* aligned_xyzi);

@@ -259,6 +259,12 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
         Base::setInputTarget(cloud);
         search_->setInputCloud(cloud);
         search_->expect_queries(nullptr, 0);
+        // the odometry's keyframe update hands over the scan it has just aligned (scan_matching_odometry_component.cpp:333: the same cloud object as the
+        // source): the library takes it over with what it computed for it as a source, and does not upload it again
+        if (source_set_ && static_cast<const void*>(cloud.get()) == static_cast<const void*>(this->input_.get())) {
+            mrgfe_reg_source_becomes_target(reg_);
+            return;
+        }
         // overflow -> no target, like PCL's "Leaf size is too small" warning
         mrgfe_reg_set_target(reg_, cloud->empty() ? nullptr : &cloud->points[0].x, cloud->size(), point_layout<PointTarget>());
     }
@@ -266,8 +272,8 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
     {
         Base::setInputSource(cloud);
         search_->expect_queries(nullptr, 0);
-        if (mrgfe_reg_set_source(reg_, cloud->empty() ? nullptr : &cloud->points[0].x, cloud->size(), point_layout<PointSource>()) != MRGFE_OK)
-            PCL_ERROR("[%s::setInputSource] %s\n", this->reg_name_.c_str(), mrgfe_last_error());
+        source_set_ = mrgfe_reg_set_source(reg_, cloud->empty() ? nullptr : &cloud->points[0].x, cloud->size(), point_layout<PointSource>()) == MRGFE_OK;
+        if (!source_set_) PCL_ERROR("[%s::setInputSource] %s\n", this->reg_name_.c_str(), mrgfe_last_error());
     }
 
     // Fast path for holders of the DERIVED pointer (this hides the non-virtual base method): one GPU call, no per-point host
@@ -315,6 +321,7 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
     mrgfe_reg*                 reg_ = nullptr;
     pcl::shared_ptr<Search>    search_;
     std::vector<float>         aligned_;
+    bool                       source_set_ = false;
 };
 
 }  // namespace mrgfe_pcl

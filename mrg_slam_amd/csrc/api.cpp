@@ -317,6 +317,27 @@ int mrgfe_reg_set_source_device(mrgfe_reg* reg, const void* d_xyzi, size_t n)
     return MRGFE_OK;
 }
 
+int mrgfe_reg_source_becomes_target(mrgfe_reg* reg)
+{
+    if (!reg) { set_error("mrgfe_reg_source_becomes_target: NULL argument"); return MRGFE_ERR_INVALID; }
+    if (!reg->has_source) { set_error("mrgfe_reg_source_becomes_target: setInputSource first"); return MRGFE_ERR_STATE; }
+    MRGFE_LOCK(reg->ctx);
+    MRGFE_TRY(reg->ctx->bind());
+    TraceRange tr("mrgfe_reg_source_becomes_target");
+    // a cloud the library uploaded lives in reg->src: that buffer becomes the target's, the old target's takes the next source
+    if (reg->d_src == reg->src.p && reg->src.p != nullptr) std::swap(reg->src, reg->tgt);
+    reg->d_tgt = reg->d_src;
+    reg->n_tgt = reg->n_src;
+    if (reg->gicp) {
+        reg->has_target = true;
+        reg->nn_valid = false;
+        MRGFE_TRY(reg->gicp->source_becomes_target());
+        reg->target_status = MRGFE_OK;
+        return MRGFE_OK;
+    }
+    return reg_target_changed(reg);  // NDT: the voxel grid of the new target (a source has nothing to hand over)
+}
+
 int mrgfe_reg_align(mrgfe_reg* reg, const float guess[16], float* aligned_xyzi)
 {
     if (!reg || !guess) { set_error("mrgfe_reg_align: NULL argument"); return MRGFE_ERR_INVALID; }

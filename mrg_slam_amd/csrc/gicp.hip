@@ -918,6 +918,18 @@ int GicpEngine::set_source(const void* d, size_t n)
     src_cov_valid_ = false;
     return MRGFE_OK;
 }
+int GicpEngine::source_becomes_target()
+{
+    if (!src_cov_valid_ || n_src_ == 0) return set_target(d_src_, n_src_);  // nothing computed yet (an empty source has no grid): an ordinary target, prepared by the next align
+    std::swap(tgt_grid_, cov_grid_);  // (plain structs of device pointers: the buffers travel with them, the old target's are reused for the next source)
+    std::swap(d_tgt_cov_, d_src_cov_);
+    d_tgt_ = d_src_;
+    n_tgt_ = n_src_;
+    tgt_grid_valid_ = tgt_cov_valid_ = true;
+    vox_valid_ = false;
+    src_cov_valid_ = false;
+    return MRGFE_OK;
+}
 
 // k-NN covariances of one cloud on ctx's stream, through the caller's grid and neighbour buffers
 // Correspondence search of GICP_HIP / SMALL_GICP_HIP: one lane group per query that walks until its answer is final (gicp_corr_kernel), or the

@@ -55,6 +55,10 @@ class GicpEngine {
     ~GicpEngine();
     int set_target(const void* d_xyzi, size_t n);
     int set_source(const void* d_xyzi, size_t n);
+    // the keyframe update of the odometry (scan_matching_odometry_component.cpp:326-339: keyframe = the scan just aligned): the source cloud becomes the
+    // target WITH what was computed for it as a source — its k-NN covariances and the grid they were found through, which is the grid the correspondence
+    // search runs on (prepare_target builds exactly these for a new target): no k-NN search, no grid build.  The source stays set, without covariances.
+    int source_becomes_target();
     int align(const float guess_rowmajor[16]);
     int aligned_cloud(float* out_xyzi_host);
     // update_correspondences + linearize at T (row-major double 4x4): tests

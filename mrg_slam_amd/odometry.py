@@ -56,6 +56,7 @@ class ScanMatchingOdometry:
         self.p = dict(DEFAULTS)
         self.p.update(params or {})
         self._downsample = downsample or (lambda c: c)
+        self._promote = set_target is None and set_source is None and hasattr(registration, "sourceBecomesTarget") and self.p.get("promote_source_to_keyframe", True)
         self._set_target = set_target or (lambda c: registration.setInputTarget(c))
         self._set_source = set_source or (lambda c: registration.setInputSource(c))
         self.keyframe_cloud = None
@@ -111,8 +112,12 @@ class ScanMatchingOdometry:
         return odom
 
     def _new_keyframe(self, filtered, odom, stamp):
+        # (`filtered` is the cloud that has just been aligned as the source, :208 -> :333: a HIP registration takes it over with what it computed for it)
         self.keyframe_cloud = filtered
-        self._set_target(filtered)
+        if self._promote:
+            self.reg.sourceBecomesTarget()
+        else:
+            self._set_target(filtered)
         self.keyframe_pose = odom
         self.keyframe_stamp = stamp
         self.prev_time = stamp

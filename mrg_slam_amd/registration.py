@@ -88,6 +88,15 @@ class HipRegistration:
         self._n_src = n
         check(lib().mrgfe_reg_set_source_device(self._h, C.c_void_p(dev_ptr), n))
 
+    def sourceBecomesTarget(self) -> int:
+        """``registration_->setInputTarget(keyframe)`` where the keyframe is the cloud last given to ``setInputSource`` (the odometry's keyframe update,
+        scan_matching_odometry_component.cpp:326-339): the GICP family keeps the covariances and the search grid it computed for the cloud as a source."""
+        self._n_tgt = self._n_src
+        st = lib().mrgfe_reg_source_becomes_target(self._h)
+        if st < 0 and st not in (_lib.ERR_OVERFLOW, _lib.ERR_EMPTY):
+            check(st)
+        return st
+
     def align(self, guess=None, want_aligned: bool = False):
         """registration_->align(*aligned, guess); returns the aligned cloud when ``want_aligned``."""
         g = _colmajor(np.eye(4) if guess is None else guess)

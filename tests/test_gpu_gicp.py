@@ -457,3 +457,58 @@ def test_batch_correspondence_passes_with_empty_clouds():
         lib().mrgfe_dbg_set_gicp_corr_passes(1)
     for f in ("T", "H", "converged", "iterations"):
         np.testing.assert_array_equal(out[0][f], out[1][f], err_msg=f)
+
+
+@pytest.mark.parametrize("cls_name", ["GicpHip", "SmallGicpHip", "VgicpHip", "PclGicpHip", "NdtHip"])
+@pytest.mark.parametrize("resident", [False, True])
+def test_source_becomes_target_equals_set_input_target(street_pair_vlp16, cls_name, resident):
+    """The odometry's keyframe update (scan_matching_odometry_component.cpp:326-339 -> :333: keyframe = the scan just aligned) through
+    mrgfe_reg_source_becomes_target: the registration that took its source over as the target — with the covariances and the grid it made for it as a source —
+    aligns the next frame bit for bit like one that was handed the same cloud through setInputTarget; also when no align came in between (nothing to take
+    over), and with clouds it uploaded itself as well as with clouds resident in HBM."""
+    import torch
+
+    import mrg_slam_amd as M
+    from mrg_slam_amd import synth
+
+    cls = getattr(M, cls_name)
+    a, b = street_pair_vlp16[0], street_pair_vlp16[1]
+    c = (b + np.float32(0.01) * np.random.default_rng(3).normal(size=b.shape).astype(np.float32))[: len(b) - 17]
+    guess = synth.make_pose([0.3, 0.1, 0.0], synth.rot_xyz(0.0, 0.0, 0.01))
+    dev = [torch.from_numpy(x).to("cuda:0") for x in (a, b, c)] if resident else None
+
+    def tgt(r, k, x):
+        return r.setInputTargetDevice(dev[k].data_ptr(), len(x)) if resident else r.setInputTarget(x)
+
+    def src(r, k, x):
+        return r.setInputSourceDevice(dev[k].data_ptr(), len(x)) if resident else r.setInputSource(x)
+
+    for align_first in (True, False):
+        plain, promo = cls(transformation_epsilon=0.01), cls(transformation_epsilon=0.01)
+        for r in (plain, promo):
+            tgt(r, 0, a)
+            src(r, 1, b)
+            if align_first:
+                r.align(guess)
+        assert tgt(plain, 1, b) == 0
+        assert promo.sourceBecomesTarget() == 0
+        for r in (plain, promo):
+            src(r, 2, c)
+            r.align(guess)
+        np.testing.assert_array_equal(promo.getFinalTransformation(), plain.getFinalTransformation())
+        assert promo.hasConverged() == plain.hasConverged() and promo.getFinalNumIteration() == plain.getFinalNumIteration()
+        assert promo.getFitnessScore() == plain.getFitnessScore()
+        # and the promoted registration goes on like any other: a third keyframe the ordinary way
+        for r in (plain, promo):
+            tgt(r, 0, a)
+            src(r, 1, b)
+            r.align(guess)
+        np.testing.assert_array_equal(promo.getFinalTransformation(), plain.getFinalTransformation())
+
+
+def test_source_becomes_target_needs_a_source():
+    from mrg_slam_amd import SmallGicpHip
+    from mrg_slam_amd._lib import MrgfeError
+
+    with pytest.raises(MrgfeError):
+        SmallGicpHip().sourceBecomesTarget()
