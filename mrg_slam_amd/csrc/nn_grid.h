@@ -89,7 +89,13 @@ class NnGrid {
     double    hint_target_ = 0;
     NnGrid2Dev h_;
     DevBuf     d_cell_start_[kNnMaxLevels], d_sorted_[kNnMaxLevels];
-    int build_levels_together(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, const float* cell, int n_levels, double* crowding);
+    // the crowding of a build on the hinted edge is read back WITHOUT a wait and looked at by the next build of this object (below its own first wait):
+    // search results do not depend on the edge, only the time does, so a cloud that has outgrown the hint costs one slower search, not a stream wait per build
+    PinBuf      crowd_box_;
+    bool        crowd_pending_ = false;
+    hipStream_t crowd_stream_ = nullptr;
+    uint32_t    crowd_n_finite_ = 0;
+    int build_levels_together(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, const float* cell, int n_levels, double* crowding, unsigned long long* h_slots_async = nullptr);
     int count_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, float cell, DevBuf& d_cells, double* crowding);
 };
 

@@ -274,7 +274,7 @@ int NnGrid::count_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const 
 // built one after the other — bin, sort, fill: a dozen launches each — and a 130k-point GICP frame spent 0.38 ms in them for 0.2 ms of kernels.
 // Here every level is a member of the batched kernels (blockIdx.y = level: its own geometry, cell table and sorted copy, the same points), so
 // the three levels cost the launches of one; only level 0 carries the pyramid and the crowding counters.
-int NnGrid::build_levels_together(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, const float* cell, int L, double* crowding)
+int NnGrid::build_levels_together(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, const float* cell, int L, double* crowding, unsigned long long* h_slots_async)
 {
     hipStream_t st = ctx->stream;
     std::vector<uint32_t> sizes(L, nn);
@@ -361,7 +361,9 @@ int NnGrid::build_levels_together(mrgfe_ctx* ctx, const float4* d_pts, uint32_t 
     hipLaunchKernelGGL(nn_occupancy_up_many_kernel, dim3((max_bricks + 255) / 256, 1), dim3(256), 0, st, d_dev, 0);  // (member 0 = the finest level)
     hipLaunchKernelGGL(nn_occupancy_up_many_kernel, dim3((max_super + 255) / 256, 1), dim3(256), 0, st, d_dev, 1);
     MRGFE_HIP_CHECK(hipGetLastError());
-    if (crowding) {
+    if (crowding && h_slots_async) {  // (pinned destination: the copy is a command on the stream, nobody waits for it here)
+        MRGFE_HIP_CHECK(hipMemcpyAsync(h_slots_async, d_crowd, sizeof(unsigned long long) * kCrowdSlots, hipMemcpyDeviceToHost, st));
+    } else if (crowding) {
         unsigned long long slots[kCrowdSlots];
         MRGFE_HIP_CHECK(hipMemcpyAsync(slots, d_crowd, sizeof(slots), hipMemcpyDeviceToHost, st));
         MRGFE_HIP_CHECK(hipStreamSynchronize(st));
@@ -399,6 +401,25 @@ int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size
     BBox bb;
     MRGFE_HIP_CHECK(hipMemcpyAsync(&bb, d_out, sizeof(BBox), hipMemcpyDeviceToHost, st));
     MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    auto cells_of = [&](float c) {
+        double prod = 1;
+        for (int a = 0; a < 3; ++a) prod *= std::floor((bb.mx[a] - bb.mn[a]) / c) + 1;
+        return prod;
+    };
+    if (crowd_pending_) {
+        // what the previous build on the hinted edge measured (its copy is behind the wait above when it went over this stream): a hint that has become
+        // too crowded or too fine is dropped, the adaptive passes below choose a new one
+        if (crowd_stream_ != st) MRGFE_HIP_CHECK(hipStreamSynchronize(crowd_stream_));
+        crowd_pending_ = false;
+        unsigned long long crowd = 0;
+        for (int k = 0; k < kCrowdSlots; ++k) crowd += crowd_box_.as<unsigned long long>()[k];
+        const double crowding = 1.0 + 2.0 * double(crowd) / double(std::max(crowd_n_finite_, 1u));
+        if (hint_cell_ > 0 && hint_target_ > 0) {
+            const bool too_crowded = crowding > 1.5 * hint_target_ && cells_of(hint_cell_ * 0.5f) <= double(1u << 24) && hint_cell_ * 16.0f > hint_cell_size_ * 0.999f;
+            const bool too_fine = crowding * 6.0 < hint_target_ && hint_cell_ < hint_cell_size_;
+            if (too_crowded || too_fine) hint_cell_ = 0;
+        }
+    }
     if (bb.n_finite == 0) {  // empty grid: one cell, no points
         MRGFE_TRY(d_cell_start_[0].ensure(32));
         MRGFE_HIP_CHECK(hipMemsetAsync(d_cell_start_[0].p, 0, 32, st));
@@ -445,6 +466,16 @@ int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size
     if (crowding_target > 0 && hint_cell_ > 0 && hint_target_ == crowding_target && hint_cell_size_ == cell_size && hint_cell_ <= cell && cells_at(hint_cell_) <= double(1u << 24)) {
         double crowding = 0;
         const int L = level_edges(hint_cell_, edges);
+        static const bool defer = [] { const char* e = std::getenv("MRGFE_NN_DEFER_CROWDING"); return e == nullptr || std::atoi(e) != 0; }();
+        if (defer) {
+            MRGFE_TRY(crowd_box_.ensure(sizeof(unsigned long long) * kCrowdSlots));
+            MRGFE_TRY(build_levels_together(ctx, d_pts, nn, bb, edges, L, &crowding, crowd_box_.as<unsigned long long>()));
+            crowd_pending_ = true;
+            crowd_stream_ = st;
+            crowd_n_finite_ = bb.n_finite;
+            built_ = true;
+            return MRGFE_OK;
+        }
         MRGFE_TRY(build_levels_together(ctx, d_pts, nn, bb, edges, L, &crowding));
         const bool too_crowded = crowding > 1.5 * crowding_target && cells_at(hint_cell_ * 0.5f) <= double(1u << 24) && hint_cell_ * 16.0f > cell_size * 0.999f;
         const bool too_fine = crowding * 6.0 < crowding_target && hint_cell_ < cell;
@@ -501,6 +532,8 @@ void ctx_tmp_grid_free(mrgfe_ctx* ctx)
 
 void NnGrid::release()
 {
+    if (crowd_pending_) { (void)hipStreamSynchronize(crowd_stream_); crowd_pending_ = false; }  // the copy into crowd_box_ must have landed before the box goes
+    crowd_box_.release();
     for (auto& b : d_cell_start_) b.release();
     for (auto& b : d_sorted_) b.release();
     built_ = false;
