@@ -1431,9 +1431,33 @@ def main():
                             t_fr.append(1e3 * (t2 - t0))
                 per_scan[name] = {"prefilter_ms": float(np.median(t_pf)), "prefilter_plus_ndt_frame_ms": float(np.median(t_fr))}
             lib().mrgfe_dbg_set_prefilter_device_driven(1)
+            # the same path with the reference's YAML default, registration_method "SMALL_GICP" (config/mrg_slam.yaml:100), as the odometry runs it on this
+            # 1 m / scan trajectory: every frame is aligned against the frame before it and then becomes the keyframe (keyframe_delta_translation 1.0, :80;
+            # scan_matching_odometry_component.cpp:326-339) — taken over from the source (mrgfe_reg_source_becomes_target)
+            from mrg_slam_amd import SmallGicpHip
+
+            gic = SmallGicpHip(transformation_epsilon=args.eps, ctx=ctx)
+            bufs = [torch.empty_like(dbuf), torch.empty_like(dbuf)]
+            t_g = []
+            for rep in range(3):
+                m0 = prefilter_to_device(raw[0], bufs[0].data_ptr(), bufs[0].shape[0], ctx=ctx)
+                gic.setInputTargetDevice(bufs[0].data_ptr(), m0)
+                for k in range(1, 7):
+                    g = synth.warm_guess(synth.rel_pose(poses[k - 1], poses[k]), 9500 + k)
+                    ctx.synchronize()
+                    t0 = time.perf_counter()
+                    b = bufs[k % 2]
+                    mk = prefilter_to_device(raw[k], b.data_ptr(), b.shape[0], ctx=ctx)
+                    gic.setInputSourceFromPrefilter(b.data_ptr(), mk)
+                    gic.align(g)
+                    gic.sourceBecomesTarget()
+                    if rep:
+                        t_g.append(1e3 * (time.perf_counter() - t0))
+            per_scan["device_driven"]["prefilter_plus_small_gicp_frame_ms"] = float(np.median(t_g))
             per_scan["raw_points"] = int(np.mean([len(r) for r in raw[1:7]]))
             per_scan["filtered_points"] = int(m)
-            per_scan["note"] = "median of 12 frames, raw scans handed over as host pointers (the 2 MB upload is inside), result left in HBM for the scan matcher"
+            per_scan["note"] = ("median of 12 frames, raw scans handed over as host pointers (the 2 MB upload is inside), result left in HBM for the scan matcher; NDT_HIP frames "
+                                "against one keyframe, SMALL_GICP_HIP frames each against the frame before it, which it then takes over as its keyframe")
             extras["per_scan_path"] = per_scan
 
     shard = None

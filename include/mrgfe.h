@@ -171,6 +171,10 @@ int  mrgfe_reg_set_source(mrgfe_reg* reg, const float* xyzi, size_t n, size_t st
 /* same, from packed float4 clouds already resident in device memory (zero-copy ingest; bench.py's timed region) */
 int  mrgfe_reg_set_target_device(mrgfe_reg* reg, const void* d_xyzi, size_t n);
 int  mrgfe_reg_set_source_device(mrgfe_reg* reg, const void* d_xyzi, size_t n);
+/* mrgfe_reg_set_source_device for the cloud the last mrgfe_prefilter_device call on this registration's context left in `d_xyzi` (n = the count it
+ * returned), UNTOUCHED since: the prefilter chain knows a box that encloses its output, so the GICP family builds the source's search grid without its own
+ * bounding-box pass and stream wait.  Anything else (another pointer or count, a cloud that went to the host, NDT) is mrgfe_reg_set_source_device. */
+int  mrgfe_reg_set_source_from_prefilter(mrgfe_reg* reg, const void* d_xyzi, size_t n);
 /* replaces registration_->setInputTarget(keyframe) where the keyframe IS the cloud last given to set_source (the odometry's keyframe update,
  * scan_matching_odometry_component.cpp:326-339 -> :333): same result as set_target of that cloud, without uploading it again and, for the GICP
  * family, without recomputing its k-NN covariances and search grid (they were made when it was the source).  The source stays set. */

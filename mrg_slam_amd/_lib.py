@@ -113,6 +113,7 @@ SIGNATURES = {
     "mrgfe_reg_set_target_device": (C.c_int, [_vp, _vp, C.c_size_t]),
     "mrgfe_reg_set_source_device": (C.c_int, [_vp, _vp, C.c_size_t]),
     "mrgfe_reg_source_becomes_target": (C.c_int, [_vp]),
+    "mrgfe_reg_set_source_from_prefilter": (C.c_int, [_vp, _vp, C.c_size_t]),
     "mrgfe_reg_align": (C.c_int, [_vp, _fp, _fp]),
     "mrgfe_reg_has_converged": (C.c_int, [_vp]),
     "mrgfe_reg_final_transformation": (C.c_int, [_vp, _fp]),

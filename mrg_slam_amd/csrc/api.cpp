@@ -317,6 +317,21 @@ int mrgfe_reg_set_source_device(mrgfe_reg* reg, const void* d_xyzi, size_t n)
     return MRGFE_OK;
 }
 
+int mrgfe_reg_set_source_from_prefilter(mrgfe_reg* reg, const void* d_xyzi, size_t n)
+{
+    MRGFE_TRY(check_count(n, "mrgfe_reg_set_source_from_prefilter"));
+    if (!reg || (n && !d_xyzi)) { set_error("mrgfe_reg_set_source_from_prefilter: NULL argument"); return MRGFE_ERR_INVALID; }
+    MRGFE_LOCK(reg->ctx);
+    MRGFE_TRY(reg->ctx->bind());
+    reg->d_src = d_xyzi;
+    reg->n_src = n;
+    reg->has_source = true;
+    const mrgfe_ctx* c = reg->ctx;
+    const bool boxed = c->pf_out_valid && c->pf_out_ptr == d_xyzi && c->pf_out_n == n && n > 0;
+    if (reg->gicp) MRGFE_TRY(reg->gicp->set_source(reg->d_src, reg->n_src, boxed ? c->pf_out_box : nullptr));
+    return MRGFE_OK;
+}
+
 int mrgfe_reg_source_becomes_target(mrgfe_reg* reg)
 {
     if (!reg) { set_error("mrgfe_reg_source_becomes_target: NULL argument"); return MRGFE_ERR_INVALID; }

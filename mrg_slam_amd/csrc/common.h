@@ -179,6 +179,12 @@ struct mrgfe_ctx {
     mrgfe::DevBuf pf_buf[2], pf_state;          // prefilter chain: ping-pong clouds and the device-resident state record (filters.hip)
     mrgfe::PinBuf pf_status;                    // ... and the few words the host reads at the chain's single wait
     void*        pf_grid = nullptr;             // NnDeviceDrivenGrid of the radius filter (nn_grid.h), created on first use
+    // what the last mrgfe_prefilter_device of the device-driven chain left in the caller's buffer: the cloud, its size and a box that ENCLOSES it (the box of the
+    // voxel centroids before the outlier filter, read with the chain's status words) — mrgfe_reg_set_source_from_prefilter builds the source's search grid on it
+    const void*  pf_out_ptr = nullptr;
+    size_t       pf_out_n = 0;
+    float        pf_out_box[6] = {0, 0, 0, 0, 0, 0};  // min xyz, max xyz
+    bool         pf_out_valid = false;
     int          cu_count = 256;
     mrgfe::NnGrid* tmp_grid = nullptr;          // reusable exact-NN grid of the stateless filter / fitness calls (nn_grid.hip)
     std::recursive_mutex mu;                    // serialises API calls that share this context's stream / workspaces

@@ -748,7 +748,8 @@ static int filter_chain_device_driven(mrgfe_ctx* ctx, const PrefilterChain& ch, 
     // ---- RadiusOutlierRemoval: a grid that sizes itself (from the boxes of the centroids kept), neighbour counts, compaction
     NnDeviceDrivenGrid& grid = pf_grid(ctx);
     const float cell = static_cast<float>(ch.radius);
-    MRGFE_TRY(nn_build_device_driven(ctx, &d_st->cp[1], &d_st->sl_rad, n, d_part, &d_st->bb_n[1], cell, 1u << 22, grid, &d_st->anomaly));
+    BBox* h_box = reinterpret_cast<BBox*>(h_status + 8);  // the box of the voxel centroids: it encloses what the outlier filter keeps of them
+    MRGFE_TRY(nn_build_device_driven(ctx, &d_st->cp[1], &d_st->sl_rad, n, d_part, &d_st->bb_n[1], cell, 1u << 22, grid, &d_st->anomaly, h_box));
     // inlier iff #{q: (double)sqdist <= radius*radius} >= min_neighbors + 1 (the point itself counts)
     MRGFE_TRY(nn_radius_flags_device_driven(ctx, grid, d_final, &d_st->sl_rad, n, ch.radius * ch.radius, ch.radius_min_neighbors + 1, cell, dfl.as<uint32_t>()));
     MRGFE_TRY(tile_sums(ctx, dfl.as<uint32_t>(), &d_st->sl_rad, tab, d_blk));
@@ -759,12 +760,19 @@ static int filter_chain_device_driven(mrgfe_ctx* ctx, const PrefilterChain& ch, 
     if (h_status[5] != 0) return MRGFE_OK;  // something unusual: the host-driven chain decides what the reference does with it
     *out_n = h_status[4];
     *used = true;
+    if (h_box->n_finite > 0 && *out_n > 0) {  // (remembered for mrgfe_reg_set_source_from_prefilter; filter_chain says whether d_work is the caller's buffer)
+        for (int a = 0; a < 3; ++a) { ctx->pf_out_box[a] = h_box->mn[a]; ctx->pf_out_box[3 + a] = h_box->mx[a]; }
+        ctx->pf_out_ptr = d_work;
+        ctx->pf_out_n = *out_n;
+        ctx->pf_out_valid = true;
+    }
     return MRGFE_OK;  // the result is in d_work
 }
 
 int filter_chain(mrgfe_ctx* ctx, const PrefilterChain& ch, const float* xyzi, size_t n, size_t stride, void* out, size_t* out_n, bool out_on_device)
 {
     *out_n = 0;
+    ctx->pf_out_valid = false;
     if (n == 0) return MRGFE_OK;
     if (n > 0x7fffffffu) { set_error("prefilter: cloud too large"); return MRGFE_ERR_INVALID; }
     DevBuf &a = ctx->pf_buf[0], &b = ctx->pf_buf[1];  // ping-pong, kept between calls (grow-only: a hipMalloc / hipFree pair per scan is a device-wide wait)
@@ -782,6 +790,7 @@ int filter_chain(mrgfe_ctx* ctx, const PrefilterChain& ch, const float* xyzi, si
         if (rc == MRGFE_OK) rc = filter_chain_device_driven(ctx, ch, a.as<float4>(), static_cast<uint32_t>(n), work, final_buf, &m, &used);
         if (rc != MRGFE_OK) return rc;
         if (used) {
+            if (!out_on_device) ctx->pf_out_valid = false;  // (the cloud went to the host: nothing of the caller's stays on the device)
             if (!out_on_device) rc = download(ctx, work, m, static_cast<float*>(out));
             if (rc == MRGFE_OK) *out_n = m;
             return rc;

@@ -911,11 +911,13 @@ int GicpEngine::set_target(const void* d, size_t n)
     tgt_grid_valid_ = tgt_cov_valid_ = false;
     return MRGFE_OK;
 }
-int GicpEngine::set_source(const void* d, size_t n)
+int GicpEngine::set_source(const void* d, size_t n, const float* enclosing_box)
 {
     d_src_ = static_cast<const float4*>(d);
     n_src_ = n;
     src_cov_valid_ = false;
+    src_box_valid_ = enclosing_box != nullptr;
+    if (enclosing_box) std::memcpy(src_box_, enclosing_box, sizeof(src_box_));
     return MRGFE_OK;
 }
 int GicpEngine::source_becomes_target()
@@ -958,11 +960,11 @@ int gicp_set_corr_passes(int mode)
 }
 
 int gicp_covariances_on_grid(mrgfe_ctx* ctx, int k, const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid, DevBuf& knn_i, DevBuf& knn_d, bool pcl_moments);
-int gicp_compute_covariances(mrgfe_ctx* ctx, int k, const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid, DevBuf& knn_i, DevBuf& knn_d, bool pcl_moments)
+int gicp_compute_covariances(mrgfe_ctx* ctx, int k, const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid, DevBuf& knn_i, DevBuf& knn_d, bool pcl_moments, const float* known_box)
 {
     MRGFE_TRY(out.ensure(std::max<size_t>(n, 1) * 48));
     if (n == 0) return MRGFE_OK;
-    MRGFE_TRY(grid.build(ctx, d_pts, n, 1.0f, NnGrid::kCrowdingKnn));
+    MRGFE_TRY(grid.build(ctx, d_pts, n, 1.0f, NnGrid::kCrowdingKnn, kNnMaxLevels, known_box));
     return gicp_covariances_on_grid(ctx, k, d_pts, n, out, grid, knn_i, knn_d, pcl_moments);
 }
 
@@ -983,7 +985,9 @@ int gicp_covariances_on_grid(mrgfe_ctx* ctx, int k, const float4* d_pts, size_t 
 
 int GicpEngine::compute_covariances(const float4* d_pts, size_t n, DevBuf& out, NnGrid& grid)
 {
-    return gicp_compute_covariances(ctx_, prm_.k_correspondences, d_pts, n, out, grid, d_knn_i_, d_knn_d_, prm_.variant == 4);
+    // (the source's enclosing box, when its producer handed one over: set_source)
+    const float* box = (d_pts == d_src_ && n == n_src_ && src_box_valid_) ? src_box_ : nullptr;
+    return gicp_compute_covariances(ctx_, prm_.k_correspondences, d_pts, n, out, grid, d_knn_i_, d_knn_d_, prm_.variant == 4, box);
 }
 
 void GicpEngine::voxel_grid(double* res, int32_t cmin[3], int32_t dim[3], uint32_t* n_cells) const

@@ -54,7 +54,7 @@ class GicpEngine {
     GicpEngine(mrgfe_ctx* ctx, const GicpParams& prm) : ctx_(ctx), prm_(prm) {}
     ~GicpEngine();
     int set_target(const void* d_xyzi, size_t n);
-    int set_source(const void* d_xyzi, size_t n);
+    int set_source(const void* d_xyzi, size_t n, const float* enclosing_box = nullptr);  // enclosing_box (min xyz, max xyz; all points finite): NnGrid::build's known_box
     // the keyframe update of the odometry (scan_matching_odometry_component.cpp:326-339: keyframe = the scan just aligned): the source cloud becomes the
     // target WITH what was computed for it as a source — its k-NN covariances and the grid they were found through, which is the grid the correspondence
     // search runs on (prepare_target builds exactly these for a new target): no k-NN search, no grid build.  The source stays set, without covariances.
@@ -100,6 +100,8 @@ class GicpEngine {
     NnGrid cov_grid_;        // k-NN grid of the source cloud (covariances only; buffers reused)
     DevBuf d_knn_i_, d_knn_d_;
     bool   tgt_grid_valid_ = false, tgt_cov_valid_ = false, src_cov_valid_ = false;
+    bool   src_box_valid_ = false;
+    float  src_box_[6] = {0, 0, 0, 0, 0, 0};
     DevBuf d_tgt_cov_, d_src_cov_, d_corr_, d_mahal_, d_partial_, d_T_;
     DevBuf d_vox_, d_vox_runs_;  // VGICP voxel records; first / last run positions (build scratch)
     bool     vox_valid_ = false;

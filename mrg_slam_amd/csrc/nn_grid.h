@@ -61,7 +61,9 @@ class NnGrid {
     static constexpr double kCrowding1nn = 12.0;  // lane-group 1-NN / radius walks: short cell runs
     static constexpr double kCrowdingKnn = 32.0;  // wave-per-query k-NN: cell rows of about one wavefront
     static constexpr float  kLevelRatio = 4.0f;
-    int build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size, double crowding_target = kCrowding1nn, int max_levels = kNnMaxLevels);
+    // known_box (min xyz, max xyz): a box the caller KNOWS to enclose the cloud, all of whose points are finite — the bounding-box pass and its stream wait are
+    // skipped (search results do not depend on the box, only on its enclosing the points)
+    int build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size, double crowding_target = kCrowding1nn, int max_levels = kNnMaxLevels, const float* known_box = nullptr);
     void release();
     bool valid() const { return built_; }
     const NnGridDev&  dev() const { return h_.level[0]; }  // radius queries walk the finest level only
@@ -93,7 +95,7 @@ class NnGrid {
     // search results do not depend on the edge, only the time does, so a cloud that has outgrown the hint costs one slower search, not a stream wait per build
     PinBuf      crowd_box_;
     bool        crowd_pending_ = false;
-    hipStream_t crowd_stream_ = nullptr;
+    hipEvent_t  crowd_event_ = nullptr;
     uint32_t    crowd_n_finite_ = 0;
     int build_levels_together(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, const float* cell, int n_levels, double* crowding, unsigned long long* h_slots_async = nullptr);
     int count_level(mrgfe_ctx* ctx, const float4* d_pts, uint32_t nn, const BBox& bb, float cell, DevBuf& d_cells, double* crowding);
@@ -129,7 +131,7 @@ struct NnDeviceDrivenGrid {
 };
 // d_n_boxes == NULL: d_bbox is the cloud's bounding box; else d_bbox is a list of *d_n_boxes partial boxes that the geometry kernel merges itself
 int nn_build_device_driven(mrgfe_ctx* ctx, const float4* const* d_cloud_ptr, const Slice* d_slice, uint32_t n_cap, const BBox* d_bbox, const uint32_t* d_n_boxes, float cell,
-                           uint32_t cells_cap, NnDeviceDrivenGrid& g, uint32_t* d_anomaly);
+                           uint32_t cells_cap, NnDeviceDrivenGrid& g, uint32_t* d_anomaly, BBox* h_box_out = nullptr);  // h_box_out: pinned; receives the (merged) box
 // flags[i] = 1 iff #{j : sqdist(q_i, p_j) <= r2} >= need for the first d_slice->n points of d_q (the grid's own cloud): nn_radius_flags_kernel with
 // the grid and the count read from device memory
 int nn_radius_flags_device_driven(mrgfe_ctx* ctx, const NnDeviceDrivenGrid& g, const float4* d_q, const Slice* d_slice, uint32_t n_cap, double r2, int need, float cell, uint32_t* d_flags);

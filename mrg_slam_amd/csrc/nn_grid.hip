@@ -374,7 +374,7 @@ int NnGrid::build_levels_together(mrgfe_ctx* ctx, const float4* d_pts, uint32_t 
     return MRGFE_OK;
 }
 
-int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size, double crowding_target, int max_levels)
+int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size, double crowding_target, int max_levels, const float* known_box)
 {
     built_ = false;
     n_ = n;
@@ -387,29 +387,35 @@ int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size
     uint32_t    nn = static_cast<uint32_t>(n);
     SliceTable  tab;
     tab.build(&nn, 1);
-    // descriptor: slice + cloud pointer
-    DevBuf& ds = ctx->scratch[0];
-    MRGFE_TRY(ds.ensure(sizeof(Slice) * 2 + sizeof(void*)));
-    const void* cp = d_pts;
-    MRGFE_HIP_CHECK(hipMemcpyAsync(ds.p, tab.h.data(), sizeof(Slice), hipMemcpyHostToDevice, st));
-    MRGFE_HIP_CHECK(hipMemcpyAsync(ds.as<char>() + 2 * sizeof(Slice), &cp, sizeof(void*), hipMemcpyHostToDevice, st));
-    DevBuf& dbb = ctx->scratch[1];
-    MRGFE_TRY(dbb.ensure(sizeof(BBox) * (tab.total_blks + 1)));
-    BBox* d_part = dbb.as<BBox>();
-    BBox* d_out = d_part + tab.total_blks;
-    MRGFE_TRY(bounding_boxes(ctx, reinterpret_cast<const float4* const*>(ds.as<char>() + 2 * sizeof(Slice)), ds.as<Slice>(), tab, d_part, d_out));
     BBox bb;
-    MRGFE_HIP_CHECK(hipMemcpyAsync(&bb, d_out, sizeof(BBox), hipMemcpyDeviceToHost, st));
-    MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    if (known_box && n > 0) {
+        for (int a = 0; a < 3; ++a) { bb.mn[a] = known_box[a]; bb.mx[a] = known_box[3 + a]; }
+        bb.n_finite = nn;
+        bb.pad = 0;
+    } else {
+        // descriptor: slice + cloud pointer
+        DevBuf& ds = ctx->scratch[0];
+        MRGFE_TRY(ds.ensure(sizeof(Slice) * 2 + sizeof(void*)));
+        const void* cp = d_pts;
+        MRGFE_HIP_CHECK(hipMemcpyAsync(ds.p, tab.h.data(), sizeof(Slice), hipMemcpyHostToDevice, st));
+        MRGFE_HIP_CHECK(hipMemcpyAsync(ds.as<char>() + 2 * sizeof(Slice), &cp, sizeof(void*), hipMemcpyHostToDevice, st));
+        DevBuf& dbb = ctx->scratch[1];
+        MRGFE_TRY(dbb.ensure(sizeof(BBox) * (tab.total_blks + 1)));
+        BBox* d_part = dbb.as<BBox>();
+        BBox* d_out = d_part + tab.total_blks;
+        MRGFE_TRY(bounding_boxes(ctx, reinterpret_cast<const float4* const*>(ds.as<char>() + 2 * sizeof(Slice)), ds.as<Slice>(), tab, d_part, d_out));
+        MRGFE_HIP_CHECK(hipMemcpyAsync(&bb, d_out, sizeof(BBox), hipMemcpyDeviceToHost, st));
+        MRGFE_HIP_CHECK(hipStreamSynchronize(st));
+    }
     auto cells_of = [&](float c) {
         double prod = 1;
         for (int a = 0; a < 3; ++a) prod *= std::floor((bb.mx[a] - bb.mn[a]) / c) + 1;
         return prod;
     };
     if (crowd_pending_) {
-        // what the previous build on the hinted edge measured (its copy is behind the wait above when it went over this stream): a hint that has become
+        // what the previous build on the hinted edge measured (the event behind its copy has normally passed long ago): a hint that has become
         // too crowded or too fine is dropped, the adaptive passes below choose a new one
-        if (crowd_stream_ != st) MRGFE_HIP_CHECK(hipStreamSynchronize(crowd_stream_));
+        MRGFE_HIP_CHECK(hipEventSynchronize(crowd_event_));
         crowd_pending_ = false;
         unsigned long long crowd = 0;
         for (int k = 0; k < kCrowdSlots; ++k) crowd += crowd_box_.as<unsigned long long>()[k];
@@ -470,8 +476,9 @@ int NnGrid::build(mrgfe_ctx* ctx, const float4* d_pts, size_t n, float cell_size
         if (defer) {
             MRGFE_TRY(crowd_box_.ensure(sizeof(unsigned long long) * kCrowdSlots));
             MRGFE_TRY(build_levels_together(ctx, d_pts, nn, bb, edges, L, &crowding, crowd_box_.as<unsigned long long>()));
+            if (!crowd_event_) MRGFE_HIP_CHECK(hipEventCreateWithFlags(&crowd_event_, hipEventDisableTiming));
+            MRGFE_HIP_CHECK(hipEventRecord(crowd_event_, st));
             crowd_pending_ = true;
-            crowd_stream_ = st;
             crowd_n_finite_ = bb.n_finite;
             built_ = true;
             return MRGFE_OK;
@@ -532,7 +539,8 @@ void ctx_tmp_grid_free(mrgfe_ctx* ctx)
 
 void NnGrid::release()
 {
-    if (crowd_pending_) { (void)hipStreamSynchronize(crowd_stream_); crowd_pending_ = false; }  // the copy into crowd_box_ must have landed before the box goes
+    if (crowd_pending_) { (void)hipEventSynchronize(crowd_event_); crowd_pending_ = false; }  // the copy into crowd_box_ must have landed before the box goes
+    if (crowd_event_) { (void)hipEventDestroy(crowd_event_); crowd_event_ = nullptr; }
     crowd_box_.release();
     for (auto& b : d_cell_start_) b.release();
     for (auto& b : d_sorted_) b.release();
@@ -875,13 +883,14 @@ int NnGridSet::build(mrgfe_ctx* ctx, const float4* const* d_clouds, const uint32
 // n_boxes != nullptr: `bbox` is a list of *n_boxes partial boxes (the producer of the cloud left one per tile), merged here by the 256 threads
 __global__ __launch_bounds__(256) void nn_geometry_kernel(const float4* const* __restrict__ cloud_ptr, const Slice* __restrict__ slice, const BBox* __restrict__ bbox,
                                                            const uint32_t* __restrict__ n_boxes, float cell, uint32_t cells_cap, uint32_t* cell_table, float4* sorted,
-                                                           NnBuildDev* __restrict__ out, uint32_t* __restrict__ anomaly)
+                                                           NnBuildDev* __restrict__ out, uint32_t* __restrict__ anomaly, BBox* __restrict__ h_box)
 {
 #pragma clang fp contract(off)
     BBox bb;
     if (n_boxes) bb = block_merge_partials(bbox, *n_boxes);  // (uniform)
     else         bb = *bbox;
     if (threadIdx.x) return;
+    if (h_box) *h_box = bb;  // (pinned host memory: read behind the caller's stream wait)
     NnBuildDev b;
     memset(&b, 0, sizeof(b));
     NnGridDev& lv = b.lv;
@@ -976,7 +985,7 @@ __global__ __launch_bounds__(256) void nn_radius_flags_dd_kernel(const NnBuildDe
 }
 
 int nn_build_device_driven(mrgfe_ctx* ctx, const float4* const* d_cloud_ptr, const Slice* d_slice, uint32_t n_cap, const BBox* d_bbox, const uint32_t* d_n_boxes, float cell,
-                           uint32_t cells_cap, NnDeviceDrivenGrid& g, uint32_t* d_anomaly)
+                           uint32_t cells_cap, NnDeviceDrivenGrid& g, uint32_t* d_anomaly, BBox* h_box_out)
 {
     hipStream_t st = ctx->stream;
     SliceTable  tab;
@@ -990,7 +999,7 @@ int nn_build_device_driven(mrgfe_ctx* ctx, const float4* const* d_cloud_ptr, con
     MRGFE_TRY(dh.ensure(sizeof(uint32_t) * 256 * (tab.total_blks + 1)));
     NnBuildDev* d_dev = g.desc.as<NnBuildDev>();
     hipLaunchKernelGGL(nn_geometry_kernel, dim3(1), dim3(256), 0, st, d_cloud_ptr, d_slice, d_bbox, d_n_boxes, cell, cells_cap, g.cells.as<uint32_t>(), g.sorted.as<float4>(), d_dev,
-                       d_anomaly);
+                       d_anomaly, h_box_out);
     if (tab.max_blks == 0) { MRGFE_HIP_CHECK(hipGetLastError()); return MRGFE_OK; }
     hipLaunchKernelGGL(nn_cellkey_many_kernel, dim3(tab.max_blks * (kTile / 256), 1), dim3(256), 0, st, d_dev, dk.as<uint32_t>(), dv.as<uint32_t>(), 0);
     int key_bits = 1;

@@ -88,6 +88,12 @@ class HipRegistration:
         self._n_src = n
         check(lib().mrgfe_reg_set_source_device(self._h, C.c_void_p(dev_ptr), n))
 
+    def setInputSourceFromPrefilter(self, dev_ptr: int, n: int) -> None:
+        """``setInputSourceDevice`` for the cloud ``prefilter_to_device`` has just left at ``dev_ptr`` on this registration's context (untouched since): the GICP
+        family builds the source's search grid inside the box the prefilter chain already knows, without a bounding-box pass and stream wait of its own."""
+        self._n_src = n
+        check(lib().mrgfe_reg_set_source_from_prefilter(self._h, C.c_void_p(dev_ptr), n))
+
     def sourceBecomesTarget(self) -> int:
         """``registration_->setInputTarget(keyframe)`` where the keyframe is the cloud last given to ``setInputSource`` (the odometry's keyframe update,
         scan_matching_odometry_component.cpp:326-339): the GICP family keeps the covariances and the search grid it computed for the cloud as a source."""

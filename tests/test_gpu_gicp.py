@@ -512,3 +512,55 @@ def test_source_becomes_target_needs_a_source():
 
     with pytest.raises(MrgfeError):
         SmallGicpHip().sourceBecomesTarget()
+
+
+@pytest.mark.parametrize("cls_name", ["SmallGicpHip", "GicpHip", "NdtHip"])
+def test_source_from_prefilter_equals_set_input_source_device(cls_name):
+    """mrgfe_reg_set_source_from_prefilter: the source's search grid built inside the box the prefilter chain knows to enclose its output (no bounding-box pass of
+    its own) answers like the grid over the tight box — same transformation, iterations and fitness as setInputSourceDevice of the same buffer; a pointer or
+    count the prefilter did not produce, and a prefilter that ran on another context, fall back to the ordinary path."""
+    import torch
+
+    import mrg_slam_amd as M
+    from mrg_slam_amd import Context, prefilter, prefilter_to_device, synth
+
+    ctx = Context()
+    cls = getattr(M, cls_name)
+    scene = synth.street_scene()
+    poses = synth.arc_trajectory(3)
+    raw = [synth.synth_lidar(scene, poses[k], "VLP16", synth.BASE_SEED + k) for k in range(3)]
+    kf = prefilter(raw[0], ctx=ctx)
+    guess = synth.warm_guess(synth.rel_pose(poses[0], poses[1]), 3)
+    buf = torch.empty((max(len(r) for r in raw) + 16, 4), dtype=torch.float32, device="cuda:0")
+    other = torch.empty_like(buf)
+    res = {}
+    for how in ("plain", "from_prefilter", "stale_pointer", "other_context"):
+        reg = cls(transformation_epsilon=0.01, ctx=ctx)
+        reg.setInputTarget(kf)
+        pf_ctx = Context() if how == "other_context" else ctx
+        m = prefilter_to_device(raw[1], buf.data_ptr(), buf.shape[0], ctx=pf_ctx)
+        pf_ctx.synchronize()
+        if how == "plain":
+            reg.setInputSourceDevice(buf.data_ptr(), m)
+        elif how == "stale_pointer":  # the same points somewhere else: not what the prefilter left
+            other[:m] = buf[:m]
+            torch.cuda.synchronize()
+            reg.setInputSourceFromPrefilter(other.data_ptr(), m)
+        else:
+            reg.setInputSourceFromPrefilter(buf.data_ptr(), m)
+        reg.align(guess)
+        res[how] = (reg.getFinalTransformation().copy(), reg.hasConverged(), reg.getFinalNumIteration(), reg.getFitnessScore())
+        if how == "from_prefilter" and cls_name != "NdtHip":  # ... and the keyframe update takes the boxed grid over
+            assert reg.sourceBecomesTarget() == 0
+            m2 = prefilter_to_device(raw[2], other.data_ptr(), other.shape[0], ctx=ctx)
+            reg.setInputSourceFromPrefilter(other.data_ptr(), m2)
+            reg.align(synth.warm_guess(synth.rel_pose(poses[1], poses[2]), 4))
+            chained = reg.getFinalTransformation().copy()
+            ref = cls(transformation_epsilon=0.01, ctx=ctx)
+            ref.setInputTargetDevice(buf.data_ptr(), m)
+            ref.setInputSourceDevice(other.data_ptr(), m2)
+            ref.align(synth.warm_guess(synth.rel_pose(poses[1], poses[2]), 4))
+            np.testing.assert_array_equal(chained, ref.getFinalTransformation())
+    for how in ("from_prefilter", "stale_pointer", "other_context"):
+        np.testing.assert_array_equal(res[how][0], res["plain"][0], err_msg=how)
+        assert res[how][1:] == res["plain"][1:], how
