@@ -16,20 +16,24 @@ sys.path.insert(0, ROOT)
 def main():
     import torch
 
-    from mrg_slam_amd import Context, SmallGicpHip, distance_filter, synth
+    from mrg_slam_amd import Context, SmallGicpHip, distance_filter, prefilter, synth
 
     ctx = Context(0)
     scene = synth.street_scene()
     K = 7
     poses = synth.arc_trajectory(K)
     raw = [synth.synth_lidar(scene, poses[k], "VLP64", synth.BASE_SEED + k) for k in range(K)]
-    scans = [distance_filter(s, 0.1, 35.0, ctx=ctx) for s in raw]
+    pre = len(sys.argv) > 1 and sys.argv[1] == "prefiltered"  # the ~33k-point clouds of the odometry / loop-closure path instead of the ~130k-point ones
+    scans = [prefilter(s, ctx=ctx) if pre else distance_filter(s, 0.1, 35.0, ctx=ctx) for s in raw]
     dev = [torch.from_numpy(s).to("cuda:0") for s in scans]
     odo = SmallGicpHip(transformation_epsilon=0.1, ctx=ctx)
     odo.setInputTarget(scans[0])
-    out = {"mode": os.environ.get("MRGFE_GICP_CORR_PASSES", "default")}
+    out = {"mode": os.environ.get("MRGFE_GICP_CORR_PASSES", "default"), "points": len(scans[1])}
+    far = len(sys.argv) > 2 and sys.argv[2] == "far"  # loop-closure-sized guesses (0.5 m / 2 deg): several outer iterations
     for k in range(1, K):
         guess = synth.warm_guess(np.linalg.inv(poses[0]) @ poses[k], k)
+        if far:
+            guess = synth.perturb_pose(np.linalg.inv(poses[0]) @ poses[k], np.random.default_rng(4242 + k), sigma_t=(0.5, 0.5, 0.1), sigma_r_deg=(0.5, 0.5, 2.0))
         tf, fin = [], None
         for rep in range(6):
             ctx.synchronize()
