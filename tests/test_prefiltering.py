@@ -153,3 +153,50 @@ def test_prefiltering_into_odometry_hip_chain_equals_oracle_chain(method):
     assert gk == ok and len(set(gk)) >= 2  # the keyframe was switched at least once, at the same frames
     for a, b in zip(go, oo):
         assert np.linalg.norm(a[:3, 3] - b[:3, 3]) <= 1e-4 and synth.rotation_angle(a, b) <= 1e-4
+
+
+def test_odometry_keyframe_update_takes_the_source_over_when_the_registration_can():
+    """ScanMatchingOdometry._new_keyframe (scan_matching_odometry_component.cpp:326-339): a registration with ``sourceBecomesTarget`` is told to keep what
+    it made for the scan it has just aligned; one without it (the CPU oracle), or a caller that routes the clouds itself, gets ``setInputTarget`` as before."""
+    import numpy as np
+
+    from mrg_slam_amd.odometry import ScanMatchingOdometry
+
+    class Reg:
+        def __init__(self, can_promote):
+            self.calls = []
+            if can_promote:
+                self.sourceBecomesTarget = lambda: self.calls.append("promote") or 0
+
+        def setInputTarget(self, c):
+            self.calls.append("target")
+
+        def setInputSource(self, c):
+            self.calls.append("source")
+
+        def align(self, guess=None, want_aligned=False):
+            self.calls.append("align")
+
+        def hasConverged(self):
+            return True
+
+        def getFinalTransformation(self):
+            T = np.eye(4, dtype=np.float32)
+            T[0, 3] = 1.5  # farther than keyframe_delta_translation: every frame becomes a keyframe
+            return T
+
+    cloud = np.zeros((10, 4), dtype=np.float32)
+    for can, routed, want in ((True, False, "promote"), (False, False, "target"), (True, True, "routed")):
+        reg = Reg(can)
+        routed_calls = []
+        kw = {"set_target": lambda c: routed_calls.append("routed"), "set_source": lambda c: None} if routed else {}
+        odo = ScanMatchingOdometry(reg, **kw)
+        odo.matching(0.0, cloud)
+        odo.matching(0.1, cloud)
+        odo.matching(0.2, cloud)
+        assert odo.keyframes == 3
+        updates = (routed_calls if routed else reg.calls)
+        # (the first keyframe is always handed over: there is no source yet)
+        assert updates.count(want) == (2 if want == "promote" else 3), (can, routed, reg.calls, routed_calls)
+        if want == "promote":
+            assert reg.calls.count("target") == 1
