@@ -20,6 +20,10 @@ int ndt_launch_derivatives_all(mrgfe_ctx* ctx, int search, uint32_t grid, const 
                                uint32_t P, double* d_partials, int formulation = 0);  // formulation 1: the f64 items of PCL_NDT_HIP (radius search, 27 probes)
 // fixed-order sum of the item partials of every pending evaluation.  d_states != NULL: followed by the controller step on the
 // device (next request written to d_evals).  d_states == NULL: results[pair][48] = {score, g[6], H[36] row-major, neighbours, pad}
+// ONE host-stepped registration's round in one launch: the items of its pending evaluation, then — in the workgroup that finishes last — the sum of the item
+// records into h_results (pinned) and the tag behind them (ndt_launch_reduce without states, P == 1).  *d_ticket must be 0 before the first launch; the kernel leaves it 0.
+int ndt_launch_single_round(mrgfe_ctx* ctx, int search, uint32_t grid, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const uint32_t* d_plan,
+                            double* d_partials, uint32_t* d_ticket, double* h_results, double tag);
 int ndt_launch_reduce(mrgfe_ctx* ctx, uint32_t P, const NdtPairDev* d_pairs, NdtEvalDev* d_evals, const double* d_partials, const uint32_t* d_plan, double* d_results,
                       NdtCtlState* d_states, double tag = 0.0);  // tag != 0 and P == 1: stored at d_results[48] once the record is visible to the host
 // NDT_OMP in the reference's summation order (opt-in): per job the records kernel (what every step of the chain adds) and the chain kernel (one lane per

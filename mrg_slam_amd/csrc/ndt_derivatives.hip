@@ -1172,6 +1172,47 @@ __global__ __launch_bounds__(256, ((MODE == 0 && NNB <= 7) ? NDT_MODE0_WAVES : (
     }
 }
 
+// The fixed-order sum of a pair's item records into its result record (ndt_reduce_kernel below; ndt_derivatives_single_kernel): 256 threads, four interleaved
+// slices per slot, ((s0 + s1) + s2) + s3.  `s`: 4 x kNdtPartialStride doubles of LDS.  CONTROL keeps the sums in s_r instead of `results`.
+template <bool CONTROL = false>
+__device__ __forceinline__ void ndt_sum_records(const NdtPairDev& pr, uint32_t mode, const NdtPlanHead& head, const double* __restrict__ partials, double (&s)[4][kNdtPartialStride],
+                                                double* __restrict__ results, uint32_t pair_index, double* __restrict__ s_r = nullptr)
+{
+    // items (= partial records) the derivative launch of this pair's kernel variant used
+    const uint32_t per_item = 256u * head.ppt[mode];
+    const uint32_t nblk = (pr.n_src + per_item - 1) / per_item;
+    const int k = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    if (k < kNdtPartialStride) {
+        // the additions stay in order; 32 (then eight) loads are in flight ahead of them (a straggler round has one pair with 500
+        // records, and a load-add-load-add chain over them took longer than the derivative kernel it follows)
+        const double* col = partials + (size_t)pr.part_off * kNdtPartialStride + k;
+        double   acc = 0.0;
+        uint32_t b = slice;
+        for (; b + 124 < nblk; b += 128) {
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = col[(size_t)(b + 4 * u) * kNdtPartialStride];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc += v[u];
+        }
+        for (; b + 28 < nblk; b += 32) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(b + 4 * u) * kNdtPartialStride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; b < nblk; b += 4) acc += col[(size_t)b * kNdtPartialStride];
+        s[slice][k] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNdtPartialStride) {
+        const double r = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
+        if (CONTROL) s_r[threadIdx.x] = r;
+        else         results[(size_t)pair_index * kNdtPartialStride + threadIdx.x] = r;
+    }
+}
+
 // All three variants in ONE launch per round.  The items of the variants are interleaved in proportion to their counts
 // (two nested Bresenham splits: variant 0 against the rest, then 2 against 1), so that the f64 Hessian items — latency-bound,
 // VALU busy 0.41 on their own — and the cheap score+gradient items share the CUs with the VALU-bound items of variant 0
@@ -1210,6 +1251,44 @@ __global__ __launch_bounds__(256, NNB <= 7 ? NDT_MODE0_WAVES : 2) void ndt_deriv
     if (at < n2) at += (n2 - at + g - 1) / g * g;
     at -= n2;
     ndt_derivatives_walk<1, NNB>(sh, at, grids, pairs, evals, plan, n_all_pairs, partials);
+}
+
+// The round of ONE host-stepped registration in one launch: the same items, and the workgroup that finishes LAST sums the item records (ndt_reduce_kernel<false>'s
+// order, its code below: ndt_sum_records) and writes record + tag into pinned host memory — a 33k-point frame's round is ~41 us of which the reduction's own
+// launch and the gap in front of it were ~6.  Every workgroup's record stores are released (agent scope) by the lanes that made them before the workgroup
+// takes its ticket; the last one acquires before it reads them.  No workgroup waits for another: the grid cannot hang.  (A twin of the kernel above and
+// not a flag in it: the batch launches keep their registers.)
+template <int NNB>
+__global__ __launch_bounds__(256, NNB <= 7 ? NDT_MODE0_WAVES : 2) void ndt_derivatives_single_kernel(const NdtGridDev* __restrict__ grids, const NdtPairDev* __restrict__ pairs,
+                                                                  const NdtEvalDev* __restrict__ evals, const uint32_t* __restrict__ plan, double* __restrict__ partials,
+                                                                  uint32_t* __restrict__ ticket, double* __restrict__ results, double tag)
+{
+    __shared__ NdtDerivShared<NNB> sh;
+    __shared__ uint32_t s_last;
+    const NdtPlanHead& head = *reinterpret_cast<const NdtPlanHead*>(plan);
+    const uint32_t n0 = head.n_items[0], n2 = head.n_items[2], g = gridDim.x;
+    uint32_t at = blockIdx.x;
+    ndt_derivatives_walk<0, NNB>(sh, at, grids, pairs, evals, plan, 1u, partials);
+    if (at < n0) at += (n0 - at + g - 1) / g * g;
+    at -= n0;
+    ndt_derivatives_walk<2, NNB>(sh, at, grids, pairs, evals, plan, 1u, partials);
+    if (at < n2) at += (n2 - at + g - 1) / g * g;
+    at -= n2;
+    ndt_derivatives_walk<1, NNB>(sh, at, grids, pairs, evals, plan, 1u, partials);
+    if (threadIdx.x < kNdtPartialStride) __threadfence();  // (the lanes that stored the records)
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) atomicExch(ticket, 0u);  // for the next round's launch (behind this one on the stream)
+    if (!evals[0].active) return;
+    ndt_sum_records(pairs[0], evals[0].mode, head, partials, sh.red, results, 0u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(&results[kNdtPartialStride], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // PCL_NDT_HIP launches: the same plan, the f64 items
@@ -1349,41 +1428,9 @@ __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __res
     if (CONTROL && threadIdx.x == 0) rc0 = wall_clock64();
 #endif
     const NdtPlanHead& head = *reinterpret_cast<const NdtPlanHead*>(plan);
-    // items (= partial records) the derivative launch of this pair's kernel variant used
-    const uint32_t per_item = 256u * head.ppt[ev.mode];
-    const uint32_t nblk = (pr.n_src + per_item - 1) / per_item;
     __shared__ double s[4][kNdtPartialStride];
     __shared__ double s_r[kNdtPartialStride];
-    const int k = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    if (k < kNdtPartialStride) {
-        // the additions stay in order; 32 (then eight) loads are in flight ahead of them (a straggler round has one pair with 500
-        // records, and a load-add-load-add chain over them took longer than the derivative kernel it follows)
-        const double* col = partials + (size_t)pr.part_off * kNdtPartialStride + k;
-        double   acc = 0.0;
-        uint32_t b = slice;
-        for (; b + 124 < nblk; b += 128) {
-            double v[32];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) v[u] = col[(size_t)(b + 4 * u) * kNdtPartialStride];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) acc += v[u];
-        }
-        for (; b + 28 < nblk; b += 32) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(b + 4 * u) * kNdtPartialStride];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u];
-        }
-        for (; b < nblk; b += 4) acc += col[(size_t)b * kNdtPartialStride];
-        s[slice][k] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x < kNdtPartialStride) {
-        const double r = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
-        if (CONTROL) s_r[threadIdx.x] = r;
-        else         results[(size_t)blockIdx.x * kNdtPartialStride + threadIdx.x] = r;
-    }
+    ndt_sum_records<CONTROL>(pr, ev.mode, head, partials, s, results, blockIdx.x, s_r);
     if (!CONTROL) {
         // a single registration polls for its record instead of waiting for the stream: the slot behind the records gets `tag` once they are visible
         // (one workgroup per pair: only a launch of ONE pair may be asked for a tag)
@@ -1664,6 +1711,17 @@ int ndt_launch_derivatives(mrgfe_ctx* ctx, int mode, int search, uint32_t grid, 
     if (mode == 0)      launch_mode<0>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
     else if (mode == 1) launch_mode<1>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
     else                launch_mode<2>(ctx, nnb, grid, d_grids, d_pairs, d_evals, d_plan, P, d_partials);
+    MRGFE_HIP_CHECK(hipGetLastError());
+    return MRGFE_OK;
+}
+
+int ndt_launch_single_round(mrgfe_ctx* ctx, int search, uint32_t grid, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const uint32_t* d_plan,
+                            double* d_partials, uint32_t* d_ticket, double* h_results, double tag)
+{
+    if (grid == 0) return MRGFE_OK;
+    if (search == MRGFE_DIRECT7)      hipLaunchKernelGGL((ndt_derivatives_single_kernel<7>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, d_partials, d_ticket, h_results, tag);
+    else if (search == MRGFE_DIRECT1) hipLaunchKernelGGL((ndt_derivatives_single_kernel<1>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, d_partials, d_ticket, h_results, tag);
+    else                              hipLaunchKernelGGL((ndt_derivatives_single_kernel<27>), dim3(grid), dim3(256), 0, ctx->stream, d_grids, d_pairs, d_evals, d_plan, d_partials, d_ticket, h_results, tag);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }

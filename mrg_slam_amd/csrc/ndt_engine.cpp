@@ -46,7 +46,7 @@ NdtEngine::~NdtEngine()
     cloud_arena_.release();
     grid_arena_.release();
     for (auto& e : ev_pool_) if (e) (void)hipEventDestroy(e);
-    d_grids_.release(); d_pairs_.release(); d_evals_.release(); d_partials_.release(); d_T12_.release(); d_aligned_.release(); d_states_.release();
+    d_grids_.release(); d_pairs_.release(); d_evals_.release(); d_partials_.release(); d_T12_.release(); d_aligned_.release(); d_states_.release(); d_ticket_.release();
     d_ref_rec_.release(); d_ref_cnt_.release(); d_ref_jobs_.release();
     h_evals_.release(); h_results_.release(); h_states_.release(); h_info_.release();
 }
@@ -581,6 +581,25 @@ int NdtEngine::enqueue_round(uint32_t round, bool device_control, const bool wan
         std::memcpy(h_evals_.as<char>() + evals_bytes_, plan_scratch_.data(), words * 4);
         MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, h_evals_.p, evals_bytes_ + words * 4, hipMemcpyHostToDevice, st));
     }
+    // ONE host-stepped NDT_HIP registration: items and the sum of their records in one launch (ndt_derivatives_single_kernel); MRGFE_SINGLE_ROUND=0: two launches
+    static const bool single_round = env_int("MRGFE_SINGLE_ROUND", 1) != 0;
+    if (fused_launch() && !device_control && P == 1 && prm_.formulation == 0 && result_tag != 0.0 && single_round) {
+        const NdtPlanHead* h = reinterpret_cast<const NdtPlanHead*>(plan_scratch_.data());
+        const uint32_t grid = std::min(derivative_grid(0), h->n_items[0] + h->n_items[1] + h->n_items[2]);
+        if (grid > 0) {
+            if (!d_ticket_.p || ticket_dirty_) {  // first use, or a round that never reported (a failed launch): start from zero
+                MRGFE_TRY(d_ticket_.ensure(256));
+                MRGFE_HIP_CHECK(hipMemsetAsync(d_ticket_.p, 0, 256, st));
+            }
+            ticket_dirty_ = true;
+            const bool timed = timing_level() > 0;
+            if (timed) MRGFE_HIP_CHECK(hipEventRecord(ev_pool_[size_t(round) * 6], st));
+            MRGFE_TRY(ndt_launch_single_round(ctx_, prm_.search, grid, d_grids_.as<NdtGridDev>(), d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_plan(), d_partials_.as<double>(),
+                                              d_ticket_.as<uint32_t>(), h_results_.as<double>(), result_tag));
+            if (timed) MRGFE_HIP_CHECK(hipEventRecord(ev_pool_[size_t(round) * 6 + 1], st));
+            return MRGFE_OK;
+        }
+    }
     if (fused_launch()) {
         // every variant's items in one launch (ndt_derivatives_all_kernel); its events sit in the slots of variant 0
         if (want_mode[0] || want_mode[1] || want_mode[2]) {
@@ -802,6 +821,7 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
             const_cast<double*>(hr)[kNdtPartialStride] = 0.0;
             MRGFE_TRY(enqueue_round(static_cast<uint32_t>(round), false, want, nullptr, tag));
             MRGFE_TRY(wait_result_tag(st, hr + kNdtPartialStride, tag));
+            ticket_dirty_ = false;  // (the record is there: the last workgroup has cleared the counter)
         } else {
             MRGFE_TRY(enqueue_round(static_cast<uint32_t>(round), false, want, nullptr));
             MRGFE_HIP_CHECK(hipStreamSynchronize(st));

@@ -114,6 +114,8 @@ class NdtEngine {
     // packed per-leaf arrays of the built targets (grid_arena_)
     std::vector<NdtGridDev> h_grids_;
     DevBuf d_grids_, d_pairs_, d_evals_, d_partials_, d_T12_, d_aligned_;
+    DevBuf d_ticket_;              // ndt_derivatives_single_kernel's workgroup counter: 0 between launches (the last workgroup clears it)
+    bool   ticket_dirty_ = false;  // a round was enqueued whose record has not been seen: the counter is cleared before the next one
     PinBuf h_evals_, h_results_;
     bool   pairs_dirty_ = true;
     bool   force_hash_ = false;
