@@ -100,3 +100,19 @@ def test_emit_prints_one_stdout_line_and_keeps_the_full_record(bench, full, tmp_
     with redirect_stdout(out):
         bench.emit(full, full_line=True)
     assert json.loads(out.getvalue()) == full
+
+
+def test_compact_line_of_this_rounds_record_fits_with_its_newer_blocks(bench):
+    """The full record of round 6's driver-shaped run (profiles/r06_bench_extras.json: with the config[2] keyframe figures and the detect() leg the line has
+    grown to 3.3 KB) through the line builder: under the budget with every optional block still in it."""
+    path = os.path.join(ROOT, "profiles", "r06_bench_extras.json")
+    if not os.path.exists(path):
+        pytest.skip("profiles/r06_bench_extras.json is not in this tree")
+    full = json.load(open(path))
+    line = json.dumps(bench.compact_line(full))
+    assert len(line) < bench.LINE_BUDGET
+    d = strict_loads(line)
+    for k in REQUIRED + ("parity_vs_oracle", "soak_over_bar", "value_host_pointers", "single_pair_latency_ms", "config3", "config2_gicp"):
+        assert k in d, k
+    g = d["config2_gicp"]["SMALL_GICP_HIP"]
+    assert g["frame_ms_1m_from_keyframe"] < g["frame_ms"] and g["keyframe_every_metre_ms"] > 0
