@@ -2,6 +2,11 @@
 #include <dlfcn.h>
 
 #include "common.h"
+#ifdef MRGFE_TESTING
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+#endif
 #include "ingest.h"
 
 #include <algorithm>
@@ -59,6 +64,29 @@ long fail_alloc_after(long k)
     g_fail_alloc_in.store(k, std::memory_order_relaxed);
     return g_allocs.exchange(0, std::memory_order_relaxed);
 }
+// A process that ends in abort() under the injector (std::terminate of a helper thread, the runtime's own abort) says where: the native stack of the aborting
+// thread on stderr, then whatever handler was there before (pytest's faulthandler prints the Python side).  TESTING library only.
+static struct sigaction g_prev_abrt;
+static void abrt_backtrace(int sig, siginfo_t* info, void* uc)
+{
+    static const char head[] = "\n[mrgfe testing] SIGABRT; native stack of the aborting thread:\n";
+    (void)!write(2, head, sizeof(head) - 1);
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    if (g_prev_abrt.sa_flags & SA_SIGINFO) { if (g_prev_abrt.sa_sigaction) g_prev_abrt.sa_sigaction(sig, info, uc); }
+    else if (g_prev_abrt.sa_handler != SIG_DFL && g_prev_abrt.sa_handler != SIG_IGN && g_prev_abrt.sa_handler) g_prev_abrt.sa_handler(sig);
+    signal(SIGABRT, SIG_DFL);
+    raise(SIGABRT);
+}
+static const bool g_abrt_installed = [] {
+    struct sigaction sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.sa_sigaction = abrt_backtrace;
+    sa.sa_flags = SA_SIGINFO;
+    sigemptyset(&sa.sa_mask);
+    return sigaction(SIGABRT, &sa, &g_prev_abrt) == 0;
+}();
 #else
 static inline bool inject_alloc_failure() { return false; }
 #endif
