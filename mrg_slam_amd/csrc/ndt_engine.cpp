@@ -728,7 +728,11 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
     std::vector<NdtRoundInfo> info;
 
     if (device_control) {
-        static const size_t lookahead = static_cast<size_t>(std::max(1, env_int("MRGFE_LOOKAHEAD", 2)));
+        // rounds enqueued beyond the last plan the host has seen.  A round's plan is published when its plan kernel runs, i.e. before its derivative launch:
+        // with ONE round ahead the host enqueues round r + 1 while round r computes, and no launch is queued for a round that finds nothing left to do
+        // (two ahead, the default until round 6: 256 config[1] pairs 8.98 -> 8.85 ms per step with two steps in flight, 10.13 -> 10.05 one at a time;
+        // 32 pairs of 33k points 1.24 -> 1.21 ms; config[3] and its shard of 8 unchanged; same records)
+        static const size_t lookahead = static_cast<size_t>(std::max(1, env_int("MRGFE_LOOKAHEAD", 1)));
         for (int i = 0; i < P; ++i) hs[i] = pairs_[i].ctl.state();
         MRGFE_HIP_CHECK(hipMemcpyAsync(d_states_.p, hs, sizeof(NdtCtlState) * P, hipMemcpyHostToDevice, st));
         MRGFE_TRY(h_info_.ensure(sizeof(NdtRoundInfo) * (round_cap + lookahead + 2)));
