@@ -722,12 +722,12 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
     const size_t round_cap = size_t(prm_.max_iterations + 3) * 13 + 8;
     const int    hc = host_control_mode();
     // Who steps the optimisers (MRGFE_HOST_CONTROL: 1 the host, 0 the device; unset: by the size of the batch).  The device-stepped rounds (plan, derivatives,
-    // reduce + controller, the host only enqueueing) win where the chip is full: from 128 pairs on, and from 13 on when the early fitness pass wants its
+    // reduce + controller, the host only enqueueing) win where the chip is full: from 128 pairs on, and from 16 on when the early fitness pass wants its
     // snapshots (`port`).  Below that the host-stepped round — one copy, derivatives, a reduction, a stream wait — is shorter than the three launches of a
     // device-stepped one and its plan (round 6, records identical either way: 2 / 8 / 32 / 64 pairs of 33k points 0.69 -> 0.56, 0.91 -> 0.74, 1.22 -> 1.06,
-    // 1.57 -> 1.43 ms; of 129k points 0.64 -> 0.55, 0.98 -> 0.88, 1.95 -> 1.83, 2.96 -> 2.91; with getFitnessScore 4 / 8 pairs 3.15 -> 3.02, 4.18 -> 3.97 ms
+    // 1.57 -> 1.43 ms; of 129k points 0.64 -> 0.55, 0.98 -> 0.88, 1.95 -> 1.83, 2.96 -> 2.91; with getFitnessScore 4 / 8 / 13 pairs 3.15 -> 3.02, 4.18 -> 3.97, 4.45 -> 4.15 ms
     // but 16 / 32 / 64 pairs 4.4 / 6.1 / 8.5 against 4.7 / 6.3 / 8.7 host-stepped; 128 and 256 pairs: the device by 2 - 4 %).
-    const bool   device_control = !ref_order && (hc == 0 || (hc < 0 && (P > 64 || (port != nullptr && P >= 13))));
+    const bool   device_control = !ref_order && (hc == 0 || (hc < 0 && (P > 64 || (port != nullptr && P >= 16))));
     hipStream_t  st = ctx_->stream;
     if (device_control) MRGFE_HIP_CHECK(hipMemcpyAsync(d_evals_.p, he, sizeof(NdtEvalDev) * P, hipMemcpyHostToDevice, st));  // (host control: enqueue_round sends requests + plan together)
     static const bool trace = std::getenv("MRGFE_TRACE") != nullptr;  // per-round host timings on stderr
