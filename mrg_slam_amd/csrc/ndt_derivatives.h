@@ -25,7 +25,7 @@ int ndt_launch_derivatives_all(mrgfe_ctx* ctx, int search, uint32_t grid, const 
 int ndt_launch_single_round(mrgfe_ctx* ctx, int search, uint32_t grid, const NdtGridDev* d_grids, const NdtPairDev* d_pairs, const NdtEvalDev* d_evals, const uint32_t* d_plan,
                             double* d_partials, uint32_t* d_ticket, double* h_results, double tag);
 int ndt_launch_reduce(mrgfe_ctx* ctx, uint32_t P, const NdtPairDev* d_pairs, NdtEvalDev* d_evals, const double* d_partials, const uint32_t* d_plan, double* d_results,
-                      NdtCtlState* d_states, double tag = 0.0);  // tag != 0 and P == 1: stored at d_results[48] once the record is visible to the host
+                      NdtCtlState* d_states, double tag = 0.0, uint32_t* d_ticket = nullptr);  // d_ticket (a zeroed word the kernel leaves zero): P > 1 records + ONE tag  // tag != 0 and P == 1: stored at d_results[48] once the record is visible to the host
 // NDT_OMP in the reference's summation order (opt-in): per job the records kernel (what every step of the chain adds) and the chain kernel (one lane per
 // accumulator, in order); results[pair][48] like ndt_launch_reduce without states.  max_tiles = ceil(max n_src of the jobs / 256).
 size_t ndt_ref_record_doubles(int mode, size_t n_src, int nnb);  // workspace of one job (tile-major record layout, ndt_derivatives.hip)

@@ -1418,11 +1418,27 @@ __global__ __launch_bounds__(256) void ndt_plan_kernel(const NdtPairDev* __restr
 //   CONTROL = false: the sums go to `results` (pinned host memory) for the host-stepped controller.
 template <bool CONTROL>
 __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __restrict__ pairs, NdtEvalDev* __restrict__ evals, const double* __restrict__ partials,
-                                                          const uint32_t* __restrict__ plan, double* __restrict__ results, NdtCtlState* __restrict__ states, double tag)
+                                                          const uint32_t* __restrict__ plan, double* __restrict__ results, NdtCtlState* __restrict__ states, double tag,
+                                                          uint32_t* __restrict__ ticket)
 {
     const NdtPairDev pr = pairs[blockIdx.x];
     const NdtEvalDev& ev = evals[blockIdx.x];
-    if (!ev.active) return;
+    // host-stepped batches poll for `tag` (below): the workgroup that is done LAST writes it, so every workgroup takes a ticket — also the ones of pairs
+    // without a request this round
+    auto done_for_host = [&]() {
+        if (CONTROL || tag == 0.0) return;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();  // this workgroup's record is in host memory before its ticket counts
+            const bool last = gridDim.x == 1u || atomicAdd(ticket, 1u) == gridDim.x - 1u;
+            if (last) {
+                if (gridDim.x > 1u) atomicExch(ticket, 0u);  // for the next round's launch
+                __threadfence_system();
+                __hip_atomic_store(&results[(size_t)gridDim.x * kNdtPartialStride], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
+    if (!ev.active) { done_for_host(); return; }
 #ifdef NDT_PHASE_CLOCK
     long long rc0 = 0, rc1 = 0, rc2 = 0, rc3 = 0, rc4 = 0, rc5 = 0, rc6 = 0, rsolves = 0;
     if (CONTROL && threadIdx.x == 0) rc0 = wall_clock64();
@@ -1432,15 +1448,9 @@ __global__ __launch_bounds__(256) void ndt_reduce_kernel(const NdtPairDev* __res
     __shared__ double s_r[kNdtPartialStride];
     ndt_sum_records<CONTROL>(pr, ev.mode, head, partials, s, results, blockIdx.x, s_r);
     if (!CONTROL) {
-        // a single registration polls for its record instead of waiting for the stream: the slot behind the records gets `tag` once they are visible
-        // (one workgroup per pair: only a launch of ONE pair may be asked for a tag)
-        if (tag != 0.0) {
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __threadfence_system();
-                __hip_atomic_store(&results[(size_t)gridDim.x * kNdtPartialStride], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
+        // a host-stepped alignment polls for its records instead of waiting for the stream: the slot behind the records gets `tag` once they are ALL visible
+        // (one workgroup per pair; the last one to finish writes it)
+        done_for_host();
         return;
     }
     // stage the state in LDS (coalesced), step it on one lane, write it and the next request back
@@ -1727,11 +1737,12 @@ int ndt_launch_single_round(mrgfe_ctx* ctx, int search, uint32_t grid, const Ndt
 }
 
 int ndt_launch_reduce(mrgfe_ctx* ctx, uint32_t P, const NdtPairDev* d_pairs, NdtEvalDev* d_evals, const double* d_partials, const uint32_t* d_plan, double* d_results,
-                      NdtCtlState* d_states, double tag)
+                      NdtCtlState* d_states, double tag, uint32_t* d_ticket)
 {
     if (P == 0) return MRGFE_OK;
-    if (d_states) hipLaunchKernelGGL((ndt_reduce_kernel<true>), dim3(P), dim3(256), 0, ctx->stream, d_pairs, d_evals, d_partials, d_plan, d_results, d_states, 0.0);
-    else          hipLaunchKernelGGL((ndt_reduce_kernel<false>), dim3(P), dim3(256), 0, ctx->stream, d_pairs, d_evals, d_partials, d_plan, d_results, d_states, P == 1 ? tag : 0.0);
+    if (d_states) hipLaunchKernelGGL((ndt_reduce_kernel<true>), dim3(P), dim3(256), 0, ctx->stream, d_pairs, d_evals, d_partials, d_plan, d_results, d_states, 0.0, static_cast<uint32_t*>(nullptr));
+    else          hipLaunchKernelGGL((ndt_reduce_kernel<false>), dim3(P), dim3(256), 0, ctx->stream, d_pairs, d_evals, d_partials, d_plan, d_results, d_states,
+                                     (P == 1 || d_ticket != nullptr) ? tag : 0.0, d_ticket);
     MRGFE_HIP_CHECK(hipGetLastError());
     return MRGFE_OK;
 }

@@ -625,9 +625,19 @@ int NdtEngine::enqueue_round(uint32_t round, bool device_control, const bool wan
                                          d_plan(), P, d_partials_.as<double>(), prm_.formulation));
         if (timed) MRGFE_HIP_CHECK(hipEventRecord(ev_pool_[size_t(round) * 6 + m * 2 + 1], st));
     }
-    // host control: the 384-byte result records go straight into pinned host memory (no device-to-host copy command)
+    // host control: the 384-byte result records go straight into pinned host memory (no device-to-host copy command); a host-stepped batch that polls for
+    // its records (result_tag != 0, P > 1) hands the reduction the counter its last workgroup is told by
+    uint32_t* d_reduce_ticket = nullptr;
+    if (!device_control && P > 1 && result_tag != 0.0) {
+        if (!d_ticket_.p || ticket_dirty_) {
+            MRGFE_TRY(d_ticket_.ensure(256));
+            MRGFE_HIP_CHECK(hipMemsetAsync(d_ticket_.p, 0, 256, st));
+        }
+        ticket_dirty_ = true;
+        d_reduce_ticket = d_ticket_.as<uint32_t>() + 1;  // (word 0 is ndt_derivatives_single_kernel's)
+    }
     MRGFE_TRY(ndt_launch_reduce(ctx_, P, d_pairs_.as<NdtPairDev>(), d_evals_.as<NdtEvalDev>(), d_partials_.as<double>(), d_plan(), h_results_.as<double>(),
-                                device_control ? d_states_.as<NdtCtlState>() : nullptr, result_tag));
+                                device_control ? d_states_.as<NdtCtlState>() : nullptr, result_tag, d_reduce_ticket));
     return MRGFE_OK;
 }
 
@@ -802,6 +812,9 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
         ~HotGuard() { if (on) host_parallel_hot(false); }
     } hot_guard(P >= kHostParallelMinPairs);  // large batches: keep the host workers spinning between rounds (see host_parallel_for)
     const double* hr = h_results_.as<double>();
+    // MRGFE_BATCH_POLL=0: host-stepped batches wait for the stream after every round, as before round 6
+    static const bool batch_poll = env_int("MRGFE_BATCH_POLL", 1) != 0;
+    const bool poll_records = P == 1 || (batch_poll && P <= 64);
     for (size_t round = 0; round < round_cap; ++round) {
         bool want[3] = {false, false, false};
         NdtRoundInfo ri{};
@@ -824,14 +837,14 @@ int NdtEngine::align_all(NdtSnapshotPort* port)
         if (ref_order) {
             MRGFE_TRY(reference_round());
             MRGFE_HIP_CHECK(hipStreamSynchronize(st));
-        } else if (P == 1) {
-            // a single registration: the reduction writes `tag` behind its record in pinned memory and the host polls for it (a stream wait
-            // costs ~10 us more per round than seeing the store)
+        } else if (poll_records) {
+            // a single registration, or a host-stepped batch: the reduction writes `tag` behind the records in pinned memory — its last workgroup, when
+            // there are several — and the host polls for it (a stream wait costs ~10 us more per round than seeing the store)
             const double tag = static_cast<double>(++result_tag_);
-            const_cast<double*>(hr)[kNdtPartialStride] = 0.0;
+            const_cast<double*>(hr)[size_t(kNdtPartialStride) * P] = 0.0;
             MRGFE_TRY(enqueue_round(static_cast<uint32_t>(round), false, want, nullptr, tag));
-            MRGFE_TRY(wait_result_tag(st, hr + kNdtPartialStride, tag));
-            ticket_dirty_ = false;  // (the record is there: the last workgroup has cleared the counter)
+            MRGFE_TRY(wait_result_tag(st, hr + size_t(kNdtPartialStride) * P, tag));
+            ticket_dirty_ = false;  // (the records are there: the last workgroup has cleared the counter)
         } else {
             MRGFE_TRY(enqueue_round(static_cast<uint32_t>(round), false, want, nullptr));
             MRGFE_HIP_CHECK(hipStreamSynchronize(st));
